@@ -1,0 +1,147 @@
+/*
+ * rg_step1.h -- C ABI of librg_step1_hip.so: regenie's Step-1 stacked ridge regression
+ * hot path on MI355X (gfx950).  Plain C, plain pointers and sizes, no torch / C++ types.
+ *
+ * regenie has no plugin/FFI layer; the seam this library replaces is the function seam
+ * inside Data::run_step1 (reference src/Data.cpp:95-133):
+ *
+ *   get_G -> residualize_genotypes -> calc_cv_matrices -> ridge_level_0      (per SNP block)
+ *   ridge_level_1 -> output/make_predictions -> write_predictions (LOCO)      (per phenotype)
+ *
+ * Each entry point below cites the reference function(s) it stands in for.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; rg_last_error(ctx) gives a message whose
+ *     text mirrors the reference's `throw` strings (the C++ host re-throws them, Regenie.cpp:72-91)
+ *   - matrices passed from the host are column-major doubles exactly as the reference's Eigen
+ *     MatrixXd members are laid out (phenodt::phenotypes N x P, new_cov N x C, masked_indivs N x P)
+ *   - "N" is params.n_samples (samples kept after --keep/--remove), "N_file" the .fam size
+ *   - one rg_ctx per process/GPU; calls on one ctx are serialised by the caller
+ */
+#ifndef RG_STEP1_H
+#define RG_STEP1_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rg_ctx rg_ctx;
+
+#define RG_OK 0
+#define RG_ERR_ARG (-1)
+#define RG_ERR_HIP (-2)
+#define RG_ERR_LOW_VARIANCE (-3) /* Data.cpp:207-209 "has low variance" */
+#define RG_ERR_NOT_SPD (-4)
+#define RG_ERR_STATE (-5)
+
+#define RG_MEM_HOST 0
+#define RG_MEM_DEVICE 1
+
+/* The per-run inputs of the level-0/level-1 math: struct param / phenodt / filter subset that
+ * Data::level_0_calculations (Data.cpp:594-727) and ridge_level_1 (Step1_Models.cpp:772-872) read. */
+typedef struct rg_problem {
+  int64_t n_samples;       /* N: params.n_samples */
+  int64_t n_file;          /* N_file: rows of .fam (bed rows hold ceil(N_file/4) bytes per SNP) */
+  int32_t n_pheno;         /* P */
+  int32_t n_cov;           /* C = params.ncov (columns of the orthonormal basis, incl. intercept) */
+  int32_t cv_folds;        /* K (>=2); LOOCV is not part of this ABI revision */
+  int32_t n_ridge_l0;      /* R0 */
+  int32_t ref_first;       /* --ref-first (Geno.cpp:1746) */
+  int32_t reserved0;
+  int64_t n_analyzed;      /* params.n_analyzed */
+  const int32_t* cv_sizes; /* K entries, params.cv_sizes (Data.cpp:401-426), sum = N */
+  const double* lambda;    /* R0 entries, ALREADY scaled: M*(1-h)/h (Data.cpp:607) */
+  const double* X;         /* N x C  col-major: phenodt::new_cov after getBasis, masked rows zero */
+  const double* Y;         /* N x P  col-major: phenodt::phenotypes (residualised, scaled) */
+  const uint8_t* mask;     /* N x P  col-major: phenodt::masked_indivs */
+  const uint8_t* ind_in_analysis; /* N: filter::ind_in_analysis */
+  const uint8_t* ind_ignore;      /* N_file or NULL: filter::ind_ignore */
+  const double* neff;      /* P: phenodt::Neff */
+  int32_t n_blocks_total;  /* B: total level-0 blocks of the whole run (columns of W = B*R0) */
+  int32_t max_block_size;  /* params.block_size */
+} rg_problem;
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+/* stream: a hipStream_t to enqueue on (e.g. torch's current stream) or NULL for a private one. */
+int rg_create(rg_ctx** out, int device_id, void* hip_stream);
+void rg_destroy(rg_ctx* ctx);
+const char* rg_last_error(const rg_ctx* ctx);
+/* replaces setmem/set_folds state (Data.cpp:401-577): uploads X, Y, masks; builds the fold-aligned
+ * sample layout used by every kernel. */
+int rg_set_problem(rg_ctx* ctx, const rg_problem* p);
+
+/* Optional: caller-owned storage for the level-0 predictors W (e.g. a torch tensor that RCCL
+ * all-gathers in place).  Layout: [B*R0][P][Np] doubles, Np = rg_w_rows(ctx).  If never called the
+ * library allocates it on first use. */
+int64_t rg_w_rows(const rg_ctx* ctx);  /* Np: fold-aligned padded sample count */
+int64_t rg_w_bytes(const rg_ctx* ctx); /* bytes of the whole W buffer */
+int rg_set_w_buffer(rg_ctx* ctx, void* dev_ptr, int64_t bytes);
+void* rg_w_device_ptr(rg_ctx* ctx);
+
+/* ---- level 0 -------------------------------------------------------------------------------
+ * Replaces, for nblk SNP blocks at once: get_G/readChunkFromBedFileToG decode+impute
+ * (Geno.cpp:1702-1769), residualize_genotypes (Data.cpp:190-224), calc_cv_matrices K-fold branch
+ * (Data.cpp:741-751) and ridge_level_0 (Step1_Models.cpp:458-613).
+ *   block_ids[b] : global block index (W columns block*R0 .. block*R0+R0-1, Step1_Models.cpp:511)
+ *   bs[b]        : SNPs in the block
+ *   bed_rows[b]  : pointer to bs[b] packed .bed rows (2 bits/sample, N_file samples), row b*stride
+ *   row_stride   : bytes between consecutive SNP rows (>= ceil(N_file/4))
+ *   mem_kind     : RG_MEM_HOST or RG_MEM_DEVICE (where bed_rows[b] live)
+ * Work is asynchronous on the ctx stream; rg_sync() (or any readback) waits for it. */
+int rg_l0_blocks(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int32_t* bs,
+                 const uint8_t* const* bed_rows, int64_t row_stride, int mem_kind);
+int rg_sync(rg_ctx* ctx); /* waits and reports deferred device-side errors (low variance, not SPD) */
+
+/* Readback in the reference's own layout (= the `--lowmem` file of write_l0_file,
+ * Step1_Models.cpp:728-734): out is N x R0 col-major for (block, pheno). */
+int rg_l0_get_w(rg_ctx* ctx, int32_t block_id, int32_t pheno, double* out_host);
+/* Injects externally produced level-0 predictors (read_l0 analogue, Step1_Models.cpp:1921-1953). */
+int rg_l0_set_w(rg_ctx* ctx, int32_t block_id, int32_t pheno, const double* in_host);
+
+/* ---- level 1, quantitative traits, K-fold ---------------------------------------------------
+ * Replaces ridge_level_1 (Step1_Models.cpp:772-872), the tau selection of Data::output
+ * (Data.cpp:1025-1037), make_predictions (Data.cpp:1196-1266) and the LOCO assembly of
+ * write_predictions (Data.cpp:1846-1858).
+ *   tau          : R1 x P col-major, ALREADY scaled (check_l0, Step1_Models.cpp:2115-2117)
+ *   cols_per_chr : nchr entries: number of W columns (blocks*R0) of each chromosome that has blocks,
+ *                  in file order (Data.cpp:1246)
+ *   cumsum_out   : 5 x R1 x P (Sx,Sy,Sx2,Sy2,Sxy; ridgel1::cumsum_values)
+ *   best_out     : P  (argmin MSE, first minimum)
+ *   pred_out     : N x nchr x P  col-major per phenotype (Data::predictions[0]); host memory */
+int rg_l1_qt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, int32_t nchr,
+             const int32_t* cols_per_chr, double* cumsum_out, int32_t* best_out, double* pred_out);
+
+/* ---- introspection used by bench.py (timing of the dominant kernels with HIP events) --------- */
+typedef struct rg_timing {
+  double ms_prep, ms_xy, ms_gram, ms_assemble, ms_chol, ms_solve, ms_pred, ms_l1_gram, ms_l1_chol,
+      ms_l1_pred;
+  int64_t n_gram_launches, n_chol_launches;
+} rg_timing;
+int rg_enable_timing(rg_ctx* ctx, int on); /* wraps kernel groups in hipEvents on the ctx stream */
+int rg_get_timing(rg_ctx* ctx, rg_timing* out);
+
+/* ---- single-kernel entry points (device pointers) used by the parity tests -------------------
+ * These expose the individual HIP kernels so tests/ can check each against the oracle. */
+/* C[m][n] (int32, ldc) = sum_k dec(A[m][k]) * dec(B[n][k]) over packed 2-bit rows (cleaned layout:
+ * code 00->2, 10->1, 11->0, 01->missing->0 [a_miss/b_miss=0] or indicator [=1]); K4 = bytes per row
+ * to contract (multiple of 16). */
+int rg_k_gram_i8(void* stream, const uint8_t* A, int64_t lda, int a_miss, const uint8_t* B,
+                 int64_t ldb, int b_miss, int32_t m, int32_t n, int64_t k_bytes, int32_t* C,
+                 int64_t ldc);
+/* batched in-place Cholesky with appended RHS rows: mats[b] is (n_pad + rhs_pad) x n_pad row-major
+ * (ld = n_pad), lower triangle referenced; on exit rows < n_pad hold L, RHS rows hold solutions x
+ * (A x = rhs).  n_pad and rhs_pad multiples of 64. */
+int rg_k_chol_solve(void* stream, double* mats, int64_t mat_stride, int32_t batch, int32_t n_pad,
+                    int32_t rhs_pad, int32_t nrhs /* valid RHS rows <= rhs_pad */,
+                    double* dinv_ws /* batch*(n_pad/64)*4096 doubles */,
+                    int32_t* info /* device int, set !=0 if not SPD */);
+/* C[m][n] = sum_k A[m][k]*B[n][k] (fp64 MFMA, row-major, K multiple of 64, m,n multiples of 64) */
+int rg_k_dgemm_nt(void* stream, const double* A, int64_t lda, const double* B, int64_t ldb,
+                  int32_t m, int32_t n, int64_t k, double* C, int64_t ldc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RG_STEP1_H */

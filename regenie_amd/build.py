@@ -1,0 +1,72 @@
+"""Builds librg_step1_hip.so (gfx950) in-tree with hipcc.  No JIT cache: the .so travels with the repo
+snapshot to the GPU box (it is git-ignored, not gpurun-ignored)."""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "librg_step1_hip.so")
+SOURCES = ["rg_api.hip", "bed_prep.hip", "gram_i8.hip", "assemble.hip", "chol.hip", "pred.hip", "l1.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _digest(paths) -> str:
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        with open(p, "rb") as fh:
+            h.update(p.encode())
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "rg_internal.h"),
+                                                      os.path.join(HERE, "..", "include", "rg_step1.h")]
+    stamp = os.path.join(LIBDIR, "build.stamp")
+    dig = _digest(deps)
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+
+    def compile_one(src):
+        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return src, obj, r
+
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        for src, obj, r in ex.map(compile_one, SOURCES):
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+            if verbose and r.stderr.strip():
+                sys.stderr.write(r.stderr)
+            objs.append(obj)
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs,
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    with open(stamp, "w") as fh:
+        fh.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,274 @@
+// Level-1 cross-validated ridge for quantitative traits (K-fold) on the level-0 predictors W.
+//
+// Reference: src/Step1_Models.cpp:772-872 ridge_level_1 (fold Grams X_folds[i] = W_i^T W_i,
+// XtY[i] = W_i^T y_i, per fold solve for all tau, out-of-fold p1 = W_i beta, five running sums),
+// src/Data.cpp:1025-1037 (argmin MSE) and :1242-1258 make_predictions (per-chromosome W_i beta_i).
+//
+// W lives in HBM as [L][P][Np] (fold-aligned position space; padding / ignored samples are exact
+// zeros so they drop out of every contraction).  The fold Grams run on the fp64 MFMA straight from
+// HBM rows (K-contiguous on both sides, see chol.hip); y rides along as one extra row so
+// W_f^T y_f and the fold systems' right-hand sides come out of the same launch.  The K*R1 systems
+// (sum_f S_f - S_i + tau_j I) are then factored by the same batched Cholesky as level 0.
+#include <algorithm>
+#include <cmath>
+#include "rg_internal.h"
+
+#define CT 64
+
+// ---- fold Gram: out[f][tr*64..][tc*64..] = sum_{pos in fold f} row_tr(pos) * row_tc(pos) ------------
+// rows < L : W column (i*P + p);  L <= row < n64 : zero row;  row == n64 : y_p;  other: zero row.
+struct L1Rows {
+  const double* W; const double* y; const double* zero;
+  int64_t Np; int L, P, p, n64;
+};
+__device__ __forceinline__ const double* l1_row(const L1Rows& R, int row) {
+  if (row < R.L) return R.W + ((int64_t)row * R.P + R.p) * R.Np;
+  if (row == R.n64) return R.y;
+  return R.zero;
+}
+
+__global__ __launch_bounds__(256) void k_l1_gram(L1Rows R, SegLayout seg, int ntile_mat, int rtot,
+                                                 double* out) {
+  const int f = blockIdx.y;
+  const int tri = ntile_mat * (ntile_mat + 1) / 2;
+  int idx = blockIdx.x, tr, tc;
+  if (idx < tri) {
+    int rr = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+    while ((rr + 1) * (rr + 2) / 2 <= idx) ++rr;
+    while (rr * (rr + 1) / 2 > idx) --rr;
+    tr = rr;
+    tc = idx - rr * (rr + 1) / 2;
+  } else {
+    tr = ntile_mat;  // the RHS row tile (y)
+    tc = idx - tri;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, q = lane >> 4;
+  const int64_t p0 = seg.pos_start[f] + 16 * q;
+  const double* ar[2] = {l1_row(R, tr * CT + wr * 32 + i) + p0, l1_row(R, tr * CT + wr * 32 + 16 + i) + p0};
+  const double* br[2] = {l1_row(R, tc * CT + wc * 32 + i) + p0, l1_row(R, tc * CT + wc * 32 + 16 + i) + p0};
+  v4d acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
+  const int64_t plen = seg.plen[f];
+  for (int64_t k = 0; k < plen; k += 64) {
+    double av[2][16], bv[2][16];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const double4* pa = reinterpret_cast<const double4*>(ar[m] + k);
+      const double4* pb = reinterpret_cast<const double4*>(br[m] + k);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const double4 x = pa[v], y = pb[v];
+        av[m][4 * v] = x.x; av[m][4 * v + 1] = x.y; av[m][4 * v + 2] = x.z; av[m][4 * v + 3] = x.w;
+        bv[m][4 * v] = y.x; bv[m][4 * v + 1] = y.y; bv[m][4 * v + 2] = y.z; bv[m][4 * v + 3] = y.w;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m][s], bv[n][s], acc[m][n], 0, 0, 0);
+  }
+  double* O = out + (int64_t)f * rtot * R.n64 + (int64_t)tr * CT * R.n64 + tc * CT;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        O[(int64_t)(wr * 32 + m * 16 + q + 4 * r) * R.n64 + wc * 32 + n * 16 + i] = acc[m][n][r];
+}
+
+__global__ void k_sum_folds(const double* fold, int64_t msz, int nfold, double* sum) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= msz) return;
+  double t = 0.0;
+  for (int f = 0; f < nfold; ++f) t += fold[(int64_t)f * msz + e];
+  sum[e] = t;
+}
+
+// ---- out-of-fold predictions for every tau + the five running sums -----------------------------------
+// alpha: [(f*R1 + j)] systems, solution = RHS row 0 (row n64) of each factored system.
+// grid (nchunk), 256 threads, thread = one position.  part: [chunk][R1][3] + ysum [chunk][2]
+#define R1MAX 8
+#define L1_CT 256
+__global__ __launch_bounds__(256) void k_l1_cv(L1Rows R, const double* wk, int64_t msz, int R1,
+                                               const int32_t* chunk_seg, const int64_t* chunk_pos,
+                                               const int64_t* chunk_len, double* part) {
+  __shared__ double sA[L1_CT][R1MAX];
+  __shared__ double sred[4][R1MAX * 3 + 2];
+  const int ch = blockIdx.x;
+  const int f = chunk_seg[ch];
+  const int64_t p0 = chunk_pos[ch], plen = chunk_len[ch];
+  double tot[R1MAX * 3 + 2];
+#pragma unroll
+  for (int t = 0; t < R1MAX * 3 + 2; ++t) tot[t] = 0.0;
+  for (int64_t sub = 0; sub < plen; sub += 256) {
+    const int64_t pos = p0 + sub + threadIdx.x;
+    const bool live = sub + threadIdx.x < plen;
+    double acc[R1MAX];
+#pragma unroll
+    for (int j = 0; j < R1MAX; ++j) acc[j] = 0.0;
+    for (int c0 = 0; c0 < R.L; c0 += L1_CT) {
+      __syncthreads();
+      for (int j = 0; j < R1MAX; ++j) {
+        const int col = c0 + threadIdx.x;
+        sA[threadIdx.x][j] = (j < R1 && col < R.L)
+            ? wk[((int64_t)f * R1 + j) * msz + (int64_t)R.n64 * R.n64 + col] : 0.0;
+      }
+      __syncthreads();
+      if (live) {
+        const int cn = min(L1_CT, R.L - c0);
+        const double* w = R.W + ((int64_t)c0 * R.P + R.p) * R.Np + pos;
+        for (int c = 0; c < cn; ++c) {
+          const double x = w[(int64_t)c * R.P * R.Np];
+#pragma unroll
+          for (int j = 0; j < R1MAX; ++j) acc[j] = fma(x, sA[c][j], acc[j]);
+        }
+      }
+    }
+    if (live) {
+      const double y = R.y[pos];
+#pragma unroll
+      for (int j = 0; j < R1MAX; ++j) {
+        tot[3 * j] += acc[j];
+        tot[3 * j + 1] = fma(acc[j], acc[j], tot[3 * j + 1]);
+        tot[3 * j + 2] = fma(acc[j], y, tot[3 * j + 2]);
+      }
+      tot[R1MAX * 3] += y;
+      tot[R1MAX * 3 + 1] = fma(y, y, tot[R1MAX * 3 + 1]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < R1MAX * 3 + 2; ++t) {
+    double x = tot[t];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6][t] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < R1MAX * 3 + 2)
+    part[(int64_t)ch * (R1MAX * 3 + 2) + threadIdx.x] =
+        (sred[0][threadIdx.x] + sred[1][threadIdx.x]) + (sred[2][threadIdx.x] + sred[3][threadIdx.x]);
+}
+
+// ---- final per-chromosome predictions with the selected tau ------------------------------------------------
+// pred: [nchr][N] (compact sample order); thread = one position
+__global__ __launch_bounds__(256) void k_l1_pred(L1Rows R, const double* wk, int64_t msz, int R1,
+                                                 int best, const int32_t* chunk_seg,
+                                                 const int64_t* chunk_pos, const int64_t* chunk_len,
+                                                 const int32_t* chr_col0 /*[nchr+1]*/, int nchr,
+                                                 const int32_t* cidx, int64_t N, double* pred) {
+  extern __shared__ double sAl[];  // [L]
+  const int ch = blockIdx.x;
+  const int f = chunk_seg[ch];
+  const int64_t p0 = chunk_pos[ch], plen = chunk_len[ch];
+  const double* al = wk + ((int64_t)f * R1 + best) * msz + (int64_t)R.n64 * R.n64;
+  for (int c = threadIdx.x; c < R.L; c += 256) sAl[c] = al[c];
+  __syncthreads();
+  for (int64_t sub = 0; sub < plen; sub += 256) {
+    const int64_t pos = p0 + sub + threadIdx.x;
+    if (sub + threadIdx.x >= plen) continue;
+    const int32_t n = cidx[pos];
+    if (n < 0) continue;
+    for (int c = 0; c < nchr; ++c) {
+      double acc = 0.0;
+      const double* w = R.W + ((int64_t)chr_col0[c] * R.P + R.p) * R.Np + pos;
+      const int nn = chr_col0[c + 1] - chr_col0[c];
+      for (int t = 0; t < nn; ++t) acc = fma(w[(int64_t)t * R.P * R.Np], sAl[chr_col0[c] + t], acc);
+      pred[(int64_t)c * N + n] = acc;
+    }
+  }
+}
+
+int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_t* cols_per_chr,
+                  double* cumsum_out, int32_t* best_out, double* pred_out) {
+  if (!ctx->have_problem || !ctx->d_W) { ctx->err = "rg_l1_qt: no level-0 predictors"; return RG_ERR_STATE; }
+  if (R1 < 1 || R1 > R1MAX) { ctx->err = "rg_l1_qt: n_ridge_l1 must be in [1,8]"; return RG_ERR_ARG; }
+  hipStream_t st = ctx->stream;
+  const int L = ctx->B_total * ctx->R0, P = ctx->P, K = ctx->K;
+  int ltot = 0;
+  std::vector<int32_t> col0(nchr + 1, 0);
+  for (int c = 0; c < nchr; ++c) { col0[c + 1] = col0[c] + cols_per_chr[c]; }
+  ltot = col0[nchr];
+  if (ltot != L) { ctx->err = "rg_l1_qt: cols_per_chr does not sum to n_blocks*R0"; return RG_ERR_ARG; }
+  const int n64 = (int)rg_round_up(L, CT), rtot = n64 + CT, T = n64 / CT;
+  const int64_t msz = (int64_t)rtot * n64;
+  const int nsys = K * R1;
+  const int nch = ctx->xy_nchunk;
+  const int NPART = R1MAX * 3 + 2;
+
+  double *d_fold = nullptr, *d_sum = nullptr, *d_wk = nullptr, *d_dinv = nullptr, *d_tau = nullptr,
+         *d_part = nullptr, *d_pred = nullptr;
+  int32_t* d_col0 = nullptr;
+  RG_HIP(hipMalloc(&d_fold, sizeof(double) * msz * K));
+  RG_HIP(hipMalloc(&d_sum, sizeof(double) * msz));
+  RG_HIP(hipMalloc(&d_wk, sizeof(double) * msz * nsys));
+  RG_HIP(hipMalloc(&d_dinv, sizeof(double) * (size_t)nsys * T * CT * CT));
+  RG_HIP(hipMalloc(&d_tau, sizeof(double) * R1));
+  RG_HIP(hipMalloc(&d_part, sizeof(double) * (size_t)nch * NPART));
+  RG_HIP(hipMalloc(&d_pred, sizeof(double) * (size_t)nchr * ctx->N));
+  RG_HIP(hipMalloc(&d_col0, sizeof(int32_t) * (nchr + 1)));
+  RG_HIP(hipMemcpyAsync(d_col0, col0.data(), sizeof(int32_t) * (nchr + 1), hipMemcpyHostToDevice, st));
+  std::vector<double> hpart((size_t)nch * NPART);
+  int rc = RG_OK;
+
+  for (int p = 0; p < P && rc == RG_OK; ++p) {
+    L1Rows R{ctx->d_W, ctx->d_V + (int64_t)(ctx->C + p) * ctx->Np, ctx->d_zero, ctx->Np, L, P, p, n64};
+    hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
+    if (ctx->timing) hipEventRecord(e0, st);
+    hipMemsetAsync(d_fold, 0, sizeof(double) * msz * K, st);
+    hipLaunchKernelGGL(k_l1_gram, dim3(T * (T + 1) / 2 + T, K), dim3(256), 0, st, R, ctx->seg, T, rtot, d_fold);
+    hipLaunchKernelGGL(k_sum_folds, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, st, d_fold, msz, K, d_sum);
+    if (ctx->timing) { hipEventRecord(e1, st); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ctx->tm.ms_l1_gram += ms; hipEventRecord(e0, st); }
+    hipMemcpyAsync(d_tau, tau + (int64_t)p * R1, sizeof(double) * R1, hipMemcpyHostToDevice, st);
+    rg_launch_form(st, d_sum, 0, d_fold, msz, K, d_tau, R1, nullptr, L, 1, n64, rtot, d_wk);
+    rg_launch_chol_solve(st, d_wk, msz, nsys, n64, CT, 1, d_dinv, ctx->d_info + 1, &ctx->tm.n_chol_launches);
+    if (ctx->timing) { hipEventRecord(e1, st); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ctx->tm.ms_l1_chol += ms; hipEventRecord(e0, st); }
+    hipLaunchKernelGGL(k_l1_cv, dim3(nch), dim3(256), 0, st, R, d_wk, msz, R1, ctx->d_chunk_seg,
+                       ctx->d_chunk_pos, ctx->d_chunk_len, d_part);
+    RG_HIP(hipMemcpyAsync(hpart.data(), d_part, sizeof(double) * hpart.size(), hipMemcpyDeviceToHost, st));
+    RG_HIP(hipStreamSynchronize(st));
+    // cumsum_values (Step1_Models.cpp:854-858): fixed-order host reduction of the chunk partials
+    double* cs = cumsum_out + (int64_t)p * 5 * R1;  // [5][R1] row-major per phenotype
+    for (int t = 0; t < 5 * R1; ++t) cs[t] = 0.0;
+    double sy = 0.0, sy2 = 0.0;
+    for (int ch = 0; ch < nch; ++ch) {
+      const double* q = hpart.data() + (size_t)ch * NPART;
+      for (int j = 0; j < R1; ++j) {
+        cs[0 * R1 + j] += q[3 * j];
+        cs[2 * R1 + j] += q[3 * j + 1];
+        cs[4 * R1 + j] += q[3 * j + 2];
+      }
+      sy += q[R1MAX * 3];
+      sy2 += q[R1MAX * 3 + 1];
+    }
+    for (int j = 0; j < R1; ++j) { cs[1 * R1 + j] = sy; cs[3 * R1 + j] = sy2; }
+    // Data.cpp:1025-1037: first minimum of (Sx2 + Sy2 - 2 Sxy) / Neff
+    int best = 0; double minv = 1e10;
+    for (int j = 0; j < R1; ++j) {
+      const double perf = (cs[2 * R1 + j] + cs[3 * R1 + j] - 2 * cs[4 * R1 + j]) / ctx->neff[p];
+      if (perf < minv) { best = j; minv = perf; }
+    }
+    best_out[p] = best;
+    hipMemsetAsync(d_pred, 0, sizeof(double) * (size_t)nchr * ctx->N, st);
+    hipLaunchKernelGGL(k_l1_pred, dim3(nch), dim3(256), sizeof(double) * L, st, R, d_wk, msz, R1, best,
+                       ctx->d_chunk_seg, ctx->d_chunk_pos, ctx->d_chunk_len, d_col0, nchr,
+                       ctx->d_cidx, ctx->N, d_pred);
+    RG_HIP(hipMemcpyAsync(pred_out + (int64_t)p * nchr * ctx->N, d_pred,
+                          sizeof(double) * (size_t)nchr * ctx->N, hipMemcpyDeviceToHost, st));
+    RG_HIP(hipStreamSynchronize(st));
+    if (ctx->timing) { hipEventRecord(e1, st); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ctx->tm.ms_l1_pred += ms; }
+    int32_t info[2] = {0, 0};
+    RG_HIP(hipMemcpy(info, ctx->d_info, sizeof(info), hipMemcpyDeviceToHost));
+    if (info[1]) { ctx->err = "level 1 ridge system is not positive definite"; rc = RG_ERR_NOT_SPD; }
+  }
+  hipFree(d_fold); hipFree(d_sum); hipFree(d_wk); hipFree(d_dinv); hipFree(d_tau); hipFree(d_part);
+  hipFree(d_pred); hipFree(d_col0);
+  return rc;
+}

@@ -1,0 +1,200 @@
+// Level-0 out-of-fold predictions, their column standardisation, and W gather/scatter helpers.
+//
+// Reference: src/Step1_Models.cpp:496-511 (pred = beta^T G_fold masked, running sums) and :539-571
+// (centre/scale with mean = p_sum/Neff, invsd = sqrt((Neff-1)/(p_sum2 - Neff mean^2)), applied to
+// ALL rows of the fold blocks, masked rows included).
+// beta^T G is evaluated on the raw dosages:  beta^T G = (D_s^-1 beta)^T G~ - ((D_s^-1 beta)^T B) X^T
+// with G~ = G0 + D_mu M decoded on the fly from the cleaned 2-bit rows, so the standardised
+// genotype matrix is never materialised (the reference allocates bs x N doubles per block).
+#include "rg_internal.h"
+
+// ---- beta~ = x / scale_G and cb = beta~^T B --------------------------------------------------------
+// grid (nseg*R0, nblk); the solutions x sit in the RHS rows of the factored systems.
+__global__ __launch_bounds__(256) void k_beta_post(PredArgs a) {
+  __shared__ double red[4];
+  const int blk = blockIdx.y, m = blockIdx.x;
+  const int bs = a.bs[blk];
+  const int nm = a.nseg * a.R0;
+  const int64_t msz = (int64_t)a.rtot * a.n64;
+  const double* M = a.wk + ((int64_t)blk * nm + m) * msz;
+  const double* sc = a.sc + (int64_t)blk * a.n128;
+  const double* Bm = a.Bm + (int64_t)blk * a.n128 * a.C;
+  for (int p = 0; p < a.P; ++p) {
+    double* beta = a.beta + (((int64_t)blk * nm + m) * a.P + p) * a.n64;
+    const double* x = M + (int64_t)(a.n64 + p) * a.n64;
+    for (int j = threadIdx.x; j < a.n64; j += 256) beta[j] = (j < bs) ? x[j] / sc[j] : 0.0;
+    for (int c = 0; c < a.C; ++c) {
+      double t = 0.0;
+      for (int j = threadIdx.x; j < bs; j += 256) t = fma(x[j] / sc[j], Bm[(int64_t)j * a.C + c], t);
+      for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+      __syncthreads();
+      if (threadIdx.x == 0)
+        a.cb[(((int64_t)blk * nm + m) * a.P + p) * a.C + c] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+  }
+}
+
+// ---- predictions -----------------------------------------------------------------------------------------------
+// grid (nchunk, P, nblk); 256 threads, thread = 4 consecutive positions (one packed byte column).
+#define RMAX 8
+#define JT 256
+struct ChunkTab { const int32_t* seg; const int64_t* pos; const int64_t* len; int n; };
+
+__global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
+  __shared__ double sB[JT][RMAX];
+  __shared__ double smu[JT];
+  __shared__ double sred[4][RMAX][2];
+  const int blk = blockIdx.z, p = blockIdx.y, ch = blockIdx.x;
+  const int bs = a.bs[blk];
+  const int s = ct.seg[ch];
+  const int64_t p0 = ct.pos[ch], plen = ct.len[ch];
+  const int R0 = a.R0;
+  const int nm = a.nseg * R0;
+  const uint8_t* pk = a.pk + (int64_t)blk * a.pk_blk_stride;
+  const double* mu = a.mu + (int64_t)blk * a.n128;
+  const int col0 = a.blockid[blk] * R0;
+  double tsum[RMAX], tsq[RMAX];
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) tsum[r] = tsq[r] = 0.0;
+
+  for (int64_t sub = 0; sub < plen; sub += 1024) {
+    const int64_t pos = p0 + sub + 4 * (int64_t)threadIdx.x;
+    const bool live = (sub + 4 * (int64_t)threadIdx.x) < plen;
+    double acc[4][RMAX];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) acc[i][r] = 0.0;
+    for (int jt = 0; jt < bs; jt += JT) {
+      __syncthreads();
+      {
+        const int j = jt + threadIdx.x;
+        for (int r = 0; r < RMAX; ++r)
+          sB[threadIdx.x][r] = (r < R0 && j < bs)
+              ? a.beta[(((int64_t)blk * nm + s * R0 + r) * a.P + p) * a.n64 + j] : 0.0;
+        smu[threadIdx.x] = (j < bs) ? mu[j] : 0.0;
+      }
+      __syncthreads();
+      if (live) {
+        const int jn = min(JT, bs - jt);
+        const uint8_t* col = pk + (int64_t)jt * a.pk_ld + pos / 4;
+        for (int t = 0; t < jn; ++t) {
+          const unsigned b = col[(int64_t)t * a.pk_ld];
+          if (b == 0xFFu) continue;
+          double g[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const unsigned code = (b >> (2 * i)) & 3u;
+            g[i] = (code == 0u) ? 2.0 : ((code == 2u) ? 1.0 : ((code == 1u) ? smu[t] : 0.0));
+          }
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) {
+            const double bt = sB[t][r];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][r] = fma(g[i], bt, acc[i][r]);
+          }
+        }
+      }
+    }
+    if (live) {
+      // covariate term and mask
+#pragma unroll
+      for (int r = 0; r < RMAX; ++r) {
+        if (r >= R0) break;
+        const double* cb = a.cb + (((int64_t)blk * nm + s * R0 + r) * a.P + p) * a.C;
+        double corr[4] = {0, 0, 0, 0};
+        for (int c = 0; c < a.C; ++c) {
+          const double cc = cb[c];
+          const double* x = a.V + (int64_t)c * a.Np + pos;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) corr[i] = fma(cc, x[i], corr[i]);
+        }
+        double* w = a.W + ((int64_t)(col0 + r) * a.P + p) * a.Np + pos;
+        const double* mk = a.maskp + (int64_t)p * a.Np + pos;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const double v = (acc[i][r] - corr[i]) * mk[i];
+          w[i] = v;
+          tsum[r] += v;
+          tsq[r] = fma(v, v, tsq[r]);
+        }
+      }
+    }
+  }
+  // block reduction of the running sums -> per-chunk partials
+#pragma unroll
+  for (int r = 0; r < RMAX; ++r) {
+    double x = tsum[r], y = tsq[r];
+    for (int o = 32; o > 0; o >>= 1) {
+      x += __shfl_down(x, o);
+      y += __shfl_down(y, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      sred[threadIdx.x >> 6][r][0] = x;
+      sred[threadIdx.x >> 6][r][1] = y;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < R0 * 2) {
+    const int r = threadIdx.x >> 1, q = threadIdx.x & 1;
+    a.psum[((((int64_t)blk * ct.n + ch) * a.P + p) * RMAX + r) * 2 + q] =
+        (sred[0][r][q] + sred[1][r][q]) + (sred[2][r][q] + sred[3][r][q]);
+  }
+}
+
+// ---- centre / scale (all kept rows; padding and ignored samples stay 0) -----------------------------
+// grid (ceil(Np/1024), R0*P, nblk)
+__global__ __launch_bounds__(256) void k_l0_scale(PredArgs a, int nchunk) {
+  const int blk = blockIdx.z, r = blockIdx.y % a.R0, p = blockIdx.y / a.R0;
+  double sx = 0.0, sq = 0.0;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const double* q = a.psum + ((((int64_t)blk * nchunk + ch) * a.P + p) * RMAX + r) * 2;
+    sx += q[0];
+    sq += q[1];
+  }
+  const double neff = a.neff[p];
+  const double mean = sx / neff;
+  const double invsd = sqrt((neff - 1.0) / (sq - neff * mean * mean));
+  double* w = a.W + ((int64_t)(a.blockid[blk] * a.R0 + r) * a.P + p) * a.Np;
+  const int64_t pos = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (pos >= a.Np) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[pos + i] = a.keptp[pos + i] ? (w[pos + i] - mean) * invsd : 0.0;
+}
+
+void rg_launch_l0_pred_impl(hipStream_t st, const PredArgs& a, const int32_t* chunk_seg,
+                            const int64_t* chunk_pos, const int64_t* chunk_len, int nchunk) {
+  hipLaunchKernelGGL(k_beta_post, dim3(a.nseg * a.R0, a.nblk), dim3(256), 0, st, a);
+  ChunkTab ct{chunk_seg, chunk_pos, chunk_len, nchunk};
+  hipLaunchKernelGGL(k_l0_pred, dim3(nchunk, a.P, a.nblk), dim3(256), 0, st, a, ct);
+  hipLaunchKernelGGL(k_l0_scale, dim3((unsigned)((a.Np / 4 + 255) / 256), a.R0 * a.P, a.nblk),
+                     dim3(256), 0, st, a, nchunk);
+}
+
+// ---- W gather / scatter between position space and the reference's N x R0 column-major slab ---------
+__global__ void k_w_gather(const double* W, int64_t Np, int P, int p, int col0, int R0,
+                           const int64_t* posc, int64_t N, double* out) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (n >= N) return;
+  out[(int64_t)r * N + n] = W[((int64_t)(col0 + r) * P + p) * Np + posc[n]];
+}
+__global__ void k_w_scatter(double* W, int64_t Np, int P, int p, int col0, int R0,
+                            const int64_t* posc, int64_t N, const double* in) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (n >= N) return;
+  W[((int64_t)(col0 + r) * P + p) * Np + posc[n]] = in[(int64_t)r * N + n];
+}
+void rg_launch_w_gather(hipStream_t st, const double* W, int64_t Np, int P, int p, int col0, int R0,
+                        const int64_t* posc, int64_t N, double* out) {
+  hipLaunchKernelGGL(k_w_gather, dim3((unsigned)((N + 255) / 256), R0), dim3(256), 0, st, W, Np, P, p,
+                     col0, R0, posc, N, out);
+}
+void rg_launch_w_scatter(hipStream_t st, double* W, int64_t Np, int P, int p, int col0, int R0,
+                         const int64_t* posc, int64_t N, const double* in) {
+  hipLaunchKernelGGL(k_w_scatter, dim3((unsigned)((N + 255) / 256), R0), dim3(256), 0, st, W, Np, P,
+                     p, col0, R0, posc, N, in);
+}

@@ -1,0 +1,443 @@
+// C-ABI entry points of librg_step1_hip.so (see include/rg_step1.h) and the host-side
+// orchestration of the level-0 block pipeline.  No CPU compute fallback exists: every numerical
+// step is a HIP kernel launch; if no GPU is present rg_create fails.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include "rg_internal.h"
+
+namespace {
+
+template <class T>
+int dev_alloc(rg_ctx* ctx, T** p, size_t n) {
+  if (*p) { hipFree(*p); *p = nullptr; }
+  if (n == 0) n = 1;
+  RG_HIP(hipMalloc((void**)p, n * sizeof(T)));
+  return RG_OK;
+}
+template <class T>
+int dev_upload(rg_ctx* ctx, T** p, const std::vector<T>& v) {
+  int rc = dev_alloc(ctx, p, v.size());
+  if (rc) return rc;
+  if (!v.empty()) RG_HIP(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return RG_OK;
+}
+
+void free_all(rg_ctx* c) {
+  void* ptrs[] = {c->d_cidx, c->d_act, c->d_V, c->d_maskp, c->d_Q, c->d_XtY, c->d_lambda, c->d_neff,
+                  c->d_keptp, c->d_posc, c->d_zero, c->d_raw, c->d_pk, c->d_mu, c->d_nmiss,
+                  c->d_xypart, c->d_chunk_seg, c->d_chunk_pos, c->d_chunk_len, c->d_S, c->d_F, c->d_Bm,
+                  c->d_BQ, c->d_GYt, c->d_sc, c->d_fold, c->d_sum, c->d_wk, c->d_dinv, c->d_beta,
+                  c->d_cb, c->d_psum, c->d_info, c->d_bs, c->d_blockid};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  if (c->own_W && c->d_W) hipFree(c->d_W);
+}
+
+struct StageTimer {
+  rg_ctx* c; double* slot;
+  StageTimer(rg_ctx* ctx, double* s) : c(ctx), slot(s) { if (c->timing) hipEventRecord(c->ev0, c->stream); }
+  ~StageTimer() {
+    if (!c->timing) return;
+    hipEventRecord(c->ev1, c->stream);
+    hipEventSynchronize(c->ev1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    *slot += ms;
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+int rg_create(rg_ctx** out, int device_id, void* hip_stream) {
+  if (!out) return RG_ERR_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id >= ndev) return RG_ERR_HIP;
+  if (hipSetDevice(device_id) != hipSuccess) return RG_ERR_HIP;
+  rg_ctx* c = new rg_ctx();
+  c->device = device_id;
+  if (hip_stream) c->stream = (hipStream_t)hip_stream;
+  else {
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return RG_ERR_HIP; }
+    c->own_stream = true;
+  }
+  hipEventCreate(&c->ev0);
+  hipEventCreate(&c->ev1);
+  *out = c;
+  return RG_OK;
+}
+
+void rg_destroy(rg_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  free_all(c);
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  if (c->own_stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* rg_last_error(const rg_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
+  if (!ctx || !p) return RG_ERR_ARG;
+  hipSetDevice(ctx->device);
+  if (p->cv_folds < 2 || p->cv_folds > RG_MAX_SEG) { ctx->err = "cv_folds must be in [2,32]"; return RG_ERR_ARG; }
+  if (p->n_ridge_l0 < 1 || p->n_ridge_l0 > 8) { ctx->err = "n_ridge_l0 must be in [1,8]"; return RG_ERR_ARG; }
+  if (p->n_pheno < 1 || p->n_pheno > 64 || p->n_cov < 1 || p->n_cov > 64) { ctx->err = "n_pheno / n_cov must be in [1,64]"; return RG_ERR_ARG; }
+  if (p->n_samples < 1 || p->n_file < p->n_samples || p->max_block_size < 1 || p->n_blocks_total < 1) { ctx->err = "bad sizes"; return RG_ERR_ARG; }
+  ctx->N = p->n_samples; ctx->Nfile = p->n_file; ctx->P = p->n_pheno; ctx->C = p->n_cov;
+  ctx->K = p->cv_folds; ctx->R0 = p->n_ridge_l0; ctx->ref_first = p->ref_first;
+  ctx->n_analyzed = p->n_analyzed; ctx->B_total = p->n_blocks_total; ctx->bs_max = p->max_block_size;
+  const int64_t N = ctx->N, Nf = ctx->Nfile;
+  const int P = ctx->P, C = ctx->C, K = ctx->K;
+  ctx->lambda.assign(p->lambda, p->lambda + ctx->R0);
+  ctx->neff.assign(p->neff, p->neff + P);
+
+  // compact -> file index
+  std::vector<int64_t> file_of_c(N);
+  {
+    int64_t n = 0;
+    for (int64_t i = 0; i < Nf; ++i) {
+      if (p->ind_ignore && p->ind_ignore[i]) continue;
+      if (n >= N) { ctx->err = "ind_ignore keeps more than n_samples samples"; return RG_ERR_ARG; }
+      file_of_c[n++] = i;
+    }
+    if (n != N) { ctx->err = "ind_ignore does not keep n_samples samples"; return RG_ERR_ARG; }
+  }
+  ctx->fold_cstart.assign(K + 1, 0);
+  for (int f = 0; f < K; ++f) {
+    if (p->cv_sizes[f] < 1) { ctx->err = "empty CV fold"; return RG_ERR_ARG; }
+    ctx->fold_cstart[f + 1] = ctx->fold_cstart[f] + p->cv_sizes[f];
+  }
+  if (ctx->fold_cstart[K] != N) { ctx->err = "cv_sizes do not sum to n_samples"; return RG_ERR_ARG; }
+
+  SegLayout& sg = ctx->seg;
+  memset(&sg, 0, sizeof(sg));
+  sg.nseg = K;
+  int64_t pos = 0;
+  for (int f = 0; f < K; ++f) {
+    const int64_t fs = (f == 0) ? 0 : file_of_c[ctx->fold_cstart[f]];
+    const int64_t fe = (f == K - 1) ? Nf : file_of_c[ctx->fold_cstart[f + 1]];
+    sg.file_start[f] = fs;
+    sg.len[f] = fe - fs;
+    sg.plen[f] = rg_round_up(fe - fs, 64);
+    sg.pos_start[f] = pos;
+    pos += sg.plen[f];
+  }
+  ctx->Np = pos;
+  const int64_t Np = ctx->Np;
+
+  std::vector<int32_t> cidx(Np, -1);
+  std::vector<uint8_t> act(Np / 4, 0), keptp(Np, 0);
+  std::vector<int64_t> posc(N);
+  const int Cv = C + P;
+  std::vector<double> V((size_t)Cv * Np, 0.0), maskp((size_t)P * Np, 0.0);
+  std::vector<double> Q((size_t)K * C * C, 0.0), XtY((size_t)K * C * P, 0.0);
+  int n_active = 0;
+  {
+    int64_t n = 0;
+    for (int f = 0; f < K; ++f)
+      for (int64_t i = sg.file_start[f]; i < sg.file_start[f] + sg.len[f]; ++i) {
+        if (p->ind_ignore && p->ind_ignore[i]) continue;
+        const int64_t ps = sg.pos_start[f] + (i - sg.file_start[f]);
+        cidx[ps] = (int32_t)n;
+        posc[n] = ps;
+        keptp[ps] = 1;
+        if (p->ind_in_analysis[n]) { act[ps >> 2] |= (uint8_t)(3u << (2 * (ps & 3))); ++n_active; }
+        for (int c = 0; c < C; ++c) V[(size_t)c * Np + ps] = p->X[(size_t)c * N + n];
+        for (int q = 0; q < P; ++q) {
+          V[(size_t)(C + q) * Np + ps] = p->Y[(size_t)q * N + n];
+          maskp[(size_t)q * Np + ps] = p->mask[(size_t)q * N + n] ? 1.0 : 0.0;
+        }
+        // the fold of a compact sample is defined by cv_sizes, which the segments reproduce
+        for (int c = 0; c < C; ++c) {
+          const double xc = p->X[(size_t)c * N + n];
+          for (int c2 = 0; c2 < C; ++c2) Q[((size_t)f * C + c) * C + c2] += xc * p->X[(size_t)c2 * N + n];
+          for (int q = 0; q < P; ++q) XtY[((size_t)f * C + c) * P + q] += xc * p->Y[(size_t)q * N + n];
+        }
+        ++n;
+      }
+    if (n != N) { ctx->err = "internal: fold layout does not cover all samples"; return RG_ERR_STATE; }
+  }
+  ctx->n_active = n_active;
+
+  // position chunks (<= 4096 positions, inside one fold)
+  ctx->h_chunk_seg.clear(); ctx->h_chunk_pos.clear(); ctx->h_chunk_len.clear();
+  for (int f = 0; f < K; ++f)
+    for (int64_t o = 0; o < sg.plen[f]; o += 4096) {
+      ctx->h_chunk_seg.push_back(f);
+      ctx->h_chunk_pos.push_back(sg.pos_start[f] + o);
+      ctx->h_chunk_len.push_back(std::min<int64_t>(4096, sg.plen[f] - o));
+    }
+  ctx->xy_nchunk = (int)ctx->h_chunk_seg.size();
+
+  int rc;
+  if ((rc = dev_upload(ctx, &ctx->d_cidx, cidx))) return rc;
+  if ((rc = dev_upload(ctx, &ctx->d_act, act))) return rc;
+  if ((rc = dev_upload(ctx, &ctx->d_keptp, keptp))) return rc;
+  if ((rc = dev_upload(ctx, &ctx->d_posc, posc))) return rc;
+  if ((rc = dev_upload(ctx, &ctx->d_V, V))) return rc;
+  if ((rc = dev_upload(ctx, &ctx->d_maskp, maskp))) return rc;
+  if ((rc = dev_upload(ctx, &ctx->d_Q, Q))) return rc;
+  if ((rc = dev_upload(ctx, &ctx->d_XtY, XtY))) return rc;
+  if ((rc = dev_upload(ctx, &ctx->d_lambda, ctx->lambda))) return rc;
+  if ((rc = dev_upload(ctx, &ctx->d_neff, ctx->neff))) return rc;
+  if ((rc = dev_upload(ctx, &ctx->d_chunk_seg, ctx->h_chunk_seg))) return rc;
+  if ((rc = dev_upload(ctx, &ctx->d_chunk_pos, ctx->h_chunk_pos))) return rc;
+  if ((rc = dev_upload(ctx, &ctx->d_chunk_len, ctx->h_chunk_len))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_zero, (size_t)Np))) return rc;
+  RG_HIP(hipMemset(ctx->d_zero, 0, sizeof(double) * Np));
+  if ((rc = dev_alloc(ctx, &ctx->d_info, 4))) return rc;
+  RG_HIP(hipMemset(ctx->d_info, 0, sizeof(int32_t) * 4));
+
+  // level-0 workspaces
+  const int bsm = ctx->bs_max;
+  ctx->n128 = (int)rg_round_up(bsm, 128);
+  ctx->n64 = (int)rg_round_up(bsm, 64);
+  ctx->rtot = ctx->n64 + (int)rg_round_up(P, 64);
+  int nb = 8;
+  if (const char* e = getenv("RG_NBLK")) nb = std::max(1, atoi(e));
+  nb = std::min(nb, ctx->B_total);
+  ctx->nblk_cap = nb;
+  const int nseg = K, R0 = ctx->R0, n128 = ctx->n128, n64 = ctx->n64, rtot = ctx->rtot;
+  ctx->raw_ld = rg_round_up((Nf + 3) / 4, 16);
+  ctx->pk_ld = Np / 4;
+  const size_t msz = (size_t)rtot * n64;
+  if ((rc = dev_alloc(ctx, &ctx->d_raw, (size_t)nb * bsm * ctx->raw_ld + 16))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_pk, (size_t)nb * n128 * ctx->pk_ld + 16))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_mu, (size_t)nb * n128 * 2))) return rc;  // mu + int scratch
+  if ((rc = dev_alloc(ctx, &ctx->d_nmiss, (size_t)nb))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_xypart, (size_t)nb * ctx->xy_nchunk * n128 * 2 * Cv))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_S, (size_t)nb * nseg * 4 * n128 * n128))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_F, (size_t)nb * nseg * n128 * C))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_Bm, (size_t)nb * n128 * C))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_BQ, (size_t)nb * nseg * n128 * C))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_GYt, (size_t)nb * nseg * n128 * P))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_sc, (size_t)nb * n128))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_fold, (size_t)nb * nseg * msz))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_sum, (size_t)nb * msz))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_wk, (size_t)nb * nseg * R0 * msz))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_dinv, (size_t)nb * nseg * R0 * (n64 / 64) * 4096))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_beta, (size_t)nb * nseg * R0 * P * n64))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_cb, (size_t)nb * nseg * R0 * P * C))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_psum, (size_t)nb * ctx->xy_nchunk * P * 8 * 2))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_bs, (size_t)nb))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_blockid, (size_t)nb))) return rc;
+  ctx->W_bytes = (int64_t)sizeof(double) * ctx->B_total * R0 * P * Np;
+  if (ctx->own_W && ctx->d_W) { hipFree(ctx->d_W); }
+  ctx->d_W = nullptr; ctx->own_W = false;
+  ctx->block_done.assign(ctx->B_total, 0);
+  ctx->have_problem = true;
+  memset(&ctx->tm, 0, sizeof(ctx->tm));
+  return RG_OK;
+}
+
+int64_t rg_w_rows(const rg_ctx* c) { return c ? c->Np : 0; }
+int64_t rg_w_bytes(const rg_ctx* c) { return c ? c->W_bytes : 0; }
+void* rg_w_device_ptr(rg_ctx* c) { return c ? c->d_W : nullptr; }
+
+int rg_set_w_buffer(rg_ctx* ctx, void* dev_ptr, int64_t bytes) {
+  if (!ctx || !ctx->have_problem) return RG_ERR_STATE;
+  if (bytes < ctx->W_bytes) { ctx->err = "W buffer too small"; return RG_ERR_ARG; }
+  if (ctx->own_W && ctx->d_W) hipFree(ctx->d_W);
+  ctx->d_W = (double*)dev_ptr;
+  ctx->own_W = false;
+  return RG_OK;
+}
+
+static int ensure_W(rg_ctx* ctx) {
+  if (ctx->d_W) return RG_OK;
+  RG_HIP(hipMalloc((void**)&ctx->d_W, (size_t)ctx->W_bytes));
+  RG_HIP(hipMemsetAsync(ctx->d_W, 0, (size_t)ctx->W_bytes, ctx->stream));
+  ctx->own_W = true;
+  return RG_OK;
+}
+
+static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32_t* bs,
+                    const uint8_t* const* bed_rows, int64_t row_stride, int mem_kind) {
+  hipStream_t st = ctx->stream;
+  const int nseg = ctx->K, R0 = ctx->R0, P = ctx->P, C = ctx->C, Cv = C + P;
+  const int n128 = ctx->n128, n64 = ctx->n64, rtot = ctx->rtot;
+  const int64_t bytes_row = (ctx->Nfile + 3) / 4;
+  const int64_t raw_blk = (int64_t)ctx->bs_max * ctx->raw_ld, pk_blk = (int64_t)n128 * ctx->pk_ld;
+  const int64_t msz = (int64_t)rtot * n64;
+  RG_HIP(hipMemcpyAsync(ctx->d_bs, bs, sizeof(int32_t) * nblk, hipMemcpyHostToDevice, st));
+  RG_HIP(hipMemcpyAsync(ctx->d_blockid, block_ids, sizeof(int32_t) * nblk, hipMemcpyHostToDevice, st));
+  {
+    StageTimer t(ctx, &ctx->tm.ms_prep);
+    for (int b = 0; b < nblk; ++b)
+      RG_HIP(hipMemcpy2DAsync(ctx->d_raw + (int64_t)b * raw_blk, ctx->raw_ld, bed_rows[b], row_stride,
+                              bytes_row, bs[b],
+                              mem_kind == RG_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    rg_launch_bed_prep(st, ctx->d_raw, ctx->raw_ld, raw_blk, ctx->d_pk, ctx->pk_ld, pk_blk, ctx->d_bs,
+                       nblk, n128, ctx->d_act, ctx->seg, ctx->Np, ctx->ref_first, ctx->n_active,
+                       ctx->d_mu, ctx->d_nmiss);
+  }
+  {
+    StageTimer t(ctx, &ctx->tm.ms_xy);
+    rg_launch_geno_xy(st, ctx->d_pk, ctx->pk_ld, pk_blk, ctx->d_bs, nblk, n128, ctx->d_V, ctx->Np, Cv,
+                      ctx->d_chunk_pos, ctx->d_chunk_len, ctx->xy_nchunk, ctx->d_xypart);
+  }
+  {
+    StageTimer t(ctx, &ctx->tm.ms_gram);
+    rg_launch_gram_blocks(st, ctx->d_pk, ctx->pk_ld, pk_blk, nblk, n128, ctx->seg, ctx->d_nmiss, ctx->d_S);
+    ctx->tm.n_gram_launches += 1;
+  }
+  {
+    StageTimer t(ctx, &ctx->tm.ms_assemble);
+    AsmArgs a;
+    a.nblk = nblk; a.nseg = nseg; a.n128 = n128; a.n64 = n64; a.rtot = rtot; a.C = C; a.P = P; a.Cv = Cv;
+    a.nchunk = ctx->xy_nchunk; a.n_analyzed = ctx->n_analyzed; a.bs = ctx->d_bs;
+    a.chunk_seg = ctx->d_chunk_seg; a.part = ctx->d_xypart; a.mu = ctx->d_mu; a.S = ctx->d_S;
+    a.nmiss = ctx->d_nmiss; a.Q = ctx->d_Q; a.XtY = ctx->d_XtY; a.F = ctx->d_F; a.Bm = ctx->d_Bm;
+    a.BQ = ctx->d_BQ; a.GYt = ctx->d_GYt; a.sc = ctx->d_sc; a.fold = ctx->d_fold; a.sum = ctx->d_sum;
+    a.info = ctx->d_info;
+    rg_launch_rowstats(st, a);
+    rg_launch_assemble(st, a);
+    rg_launch_form(st, ctx->d_sum, msz, ctx->d_fold, msz, nseg, ctx->d_lambda, R0, ctx->d_bs, 0, nblk,
+                   n64, rtot, ctx->d_wk);
+  }
+  {
+    StageTimer t(ctx, &ctx->tm.ms_chol);
+    rg_launch_chol_solve(st, ctx->d_wk, msz, nblk * nseg * R0, n64, rtot - n64, P, ctx->d_dinv,
+                         ctx->d_info + 1, &ctx->tm.n_chol_launches);
+  }
+  {
+    StageTimer t(ctx, &ctx->tm.ms_pred);
+    PredArgs pa;
+    pa.nblk = nblk; pa.nseg = nseg; pa.R0 = R0; pa.P = P; pa.C = C; pa.n128 = n128; pa.n64 = n64;
+    pa.rtot = rtot; pa.B_total = ctx->B_total; pa.Np = ctx->Np; pa.pk_ld = ctx->pk_ld;
+    pa.pk_blk_stride = pk_blk; pa.seg = ctx->seg; pa.pk = ctx->d_pk; pa.mu = ctx->d_mu; pa.sc = ctx->d_sc;
+    pa.Bm = ctx->d_Bm; pa.wk = ctx->d_wk; pa.V = ctx->d_V; pa.maskp = ctx->d_maskp;
+    pa.keptp = ctx->d_keptp; pa.bs = ctx->d_bs; pa.blockid = ctx->d_blockid; pa.neff = ctx->d_neff;
+    pa.beta = ctx->d_beta; pa.cb = ctx->d_cb; pa.psum = ctx->d_psum; pa.W = ctx->d_W;
+    rg_launch_l0_pred_impl(st, pa, ctx->d_chunk_seg, ctx->d_chunk_pos, ctx->d_chunk_len, ctx->xy_nchunk);
+  }
+  for (int b = 0; b < nblk; ++b) ctx->block_done[block_ids[b]] = 1;
+  return RG_OK;
+}
+
+int rg_l0_blocks(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int32_t* bs,
+                 const uint8_t* const* bed_rows, int64_t row_stride, int mem_kind) {
+  if (!ctx || !ctx->have_problem) return RG_ERR_STATE;
+  hipSetDevice(ctx->device);
+  if (nblk < 1 || !block_ids || !bs || !bed_rows) { ctx->err = "rg_l0_blocks: bad arguments"; return RG_ERR_ARG; }
+  if (row_stride < (ctx->Nfile + 3) / 4) { ctx->err = "rg_l0_blocks: row_stride < ceil(N_file/4)"; return RG_ERR_ARG; }
+  for (int b = 0; b < nblk; ++b) {
+    if (bs[b] < 1 || bs[b] > ctx->bs_max) { ctx->err = "rg_l0_blocks: block size out of range"; return RG_ERR_ARG; }
+    if (block_ids[b] < 0 || block_ids[b] >= ctx->B_total) { ctx->err = "rg_l0_blocks: block id out of range"; return RG_ERR_ARG; }
+  }
+  int rc = ensure_W(ctx);
+  if (rc) return rc;
+  for (int b0 = 0; b0 < nblk; b0 += ctx->nblk_cap) {
+    const int nb = std::min(ctx->nblk_cap, nblk - b0);
+    // the small H2D descriptor copies of the next batch must not overtake the kernels of this one:
+    // everything is ordered on the single ctx stream.
+    rc = l0_batch(ctx, nb, block_ids + b0, bs + b0, bed_rows + b0, row_stride, mem_kind);
+    if (rc) return rc;
+  }
+  return RG_OK;
+}
+
+int rg_sync(rg_ctx* ctx) {
+  if (!ctx) return RG_ERR_ARG;
+  hipSetDevice(ctx->device);
+  RG_HIP(hipStreamSynchronize(ctx->stream));
+  if (!ctx->d_info) return RG_OK;
+  int32_t info[4] = {0, 0, 0, 0};
+  RG_HIP(hipMemcpy(info, ctx->d_info, sizeof(info), hipMemcpyDeviceToHost));
+  if (info[0]) {
+    const int j = (info[0] & 0xFFFFF) - 1, blk = info[0] >> 20;
+    ctx->err = "!! Uh-oh, SNP #" + std::to_string(j) + " of batch block " + std::to_string(blk) + " has low variance.";
+    hipMemset(ctx->d_info, 0, sizeof(info));
+    return RG_ERR_LOW_VARIANCE;
+  }
+  if (info[1]) {
+    ctx->err = "ridge system is not positive definite";
+    hipMemset(ctx->d_info, 0, sizeof(info));
+    return RG_ERR_NOT_SPD;
+  }
+  return RG_OK;
+}
+
+int rg_l0_get_w(rg_ctx* ctx, int32_t block_id, int32_t pheno, double* out_host) {
+  if (!ctx || !ctx->have_problem || !ctx->d_W) return RG_ERR_STATE;
+  if (block_id < 0 || block_id >= ctx->B_total || pheno < 0 || pheno >= ctx->P || !out_host) return RG_ERR_ARG;
+  hipSetDevice(ctx->device);
+  double* tmp = nullptr;
+  RG_HIP(hipMalloc((void**)&tmp, sizeof(double) * ctx->N * ctx->R0));
+  rg_launch_w_gather(ctx->stream, ctx->d_W, ctx->Np, ctx->P, pheno, block_id * ctx->R0, ctx->R0, ctx->d_posc, ctx->N, tmp);
+  hipError_t e = hipMemcpyAsync(out_host, tmp, sizeof(double) * ctx->N * ctx->R0, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(tmp);
+  if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return RG_ERR_HIP; }
+  return RG_OK;
+}
+
+int rg_l0_set_w(rg_ctx* ctx, int32_t block_id, int32_t pheno, const double* in_host) {
+  if (!ctx || !ctx->have_problem) return RG_ERR_STATE;
+  if (block_id < 0 || block_id >= ctx->B_total || pheno < 0 || pheno >= ctx->P || !in_host) return RG_ERR_ARG;
+  hipSetDevice(ctx->device);
+  int rc = ensure_W(ctx);
+  if (rc) return rc;
+  double* tmp = nullptr;
+  RG_HIP(hipMalloc((void**)&tmp, sizeof(double) * ctx->N * ctx->R0));
+  hipError_t e = hipMemcpyAsync(tmp, in_host, sizeof(double) * ctx->N * ctx->R0, hipMemcpyHostToDevice, ctx->stream);
+  rg_launch_w_scatter(ctx->stream, ctx->d_W, ctx->Np, ctx->P, pheno, block_id * ctx->R0, ctx->R0, ctx->d_posc, ctx->N, tmp);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipFree(tmp);
+  if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return RG_ERR_HIP; }
+  ctx->block_done[block_id] = 1;
+  return RG_OK;
+}
+
+int rg_l1_qt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, int32_t nchr,
+             const int32_t* cols_per_chr, double* cumsum_out, int32_t* best_out, double* pred_out) {
+  if (!ctx) return RG_ERR_ARG;
+  hipSetDevice(ctx->device);
+  if (!tau || nchr < 1 || !cols_per_chr || !cumsum_out || !best_out || !pred_out) { ctx->err = "rg_l1_qt: bad arguments"; return RG_ERR_ARG; }
+  int rc = rg_sync(ctx);
+  if (rc) return rc;
+  return rg_l1_qt_impl(ctx, n_ridge_l1, tau, nchr, cols_per_chr, cumsum_out, best_out, pred_out);
+}
+
+int rg_enable_timing(rg_ctx* ctx, int on) {
+  if (!ctx) return RG_ERR_ARG;
+  ctx->timing = on != 0;
+  memset(&ctx->tm, 0, sizeof(ctx->tm));
+  return RG_OK;
+}
+int rg_get_timing(rg_ctx* ctx, rg_timing* out) {
+  if (!ctx || !out) return RG_ERR_ARG;
+  *out = ctx->tm;
+  return RG_OK;
+}
+
+// ---- single-kernel entry points ------------------------------------------------------------------------------
+int rg_k_gram_i8(void* stream, const uint8_t* A, int64_t lda, int a_miss, const uint8_t* B,
+                 int64_t ldb, int b_miss, int32_t m, int32_t n, int64_t k_bytes, int32_t* C, int64_t ldc) {
+  if (!A || !B || !C || m < 1 || n < 1 || k_bytes < 16 || (k_bytes & 15) || (lda & 15) || (ldb & 15)) return RG_ERR_ARG;
+  rg_launch_gram_generic((hipStream_t)stream, A, lda, a_miss, B, ldb, b_miss, m, n, k_bytes, C, ldc);
+  return hipGetLastError() == hipSuccess ? RG_OK : RG_ERR_HIP;
+}
+
+int rg_k_chol_solve(void* stream, double* mats, int64_t mat_stride, int32_t batch, int32_t n_pad,
+                    int32_t rhs_pad, int32_t nrhs, double* dinv_ws, int32_t* info) {
+  if (!mats || !dinv_ws || !info || batch < 1 || n_pad < 64 || (n_pad & 63) || (rhs_pad & 63) || nrhs > rhs_pad) return RG_ERR_ARG;
+  rg_launch_chol_solve((hipStream_t)stream, mats, mat_stride, batch, n_pad, rhs_pad, nrhs, dinv_ws, info, nullptr);
+  return hipGetLastError() == hipSuccess ? RG_OK : RG_ERR_HIP;
+}
+
+int rg_k_dgemm_nt(void* stream, const double* A, int64_t lda, const double* B, int64_t ldb, int32_t m,
+                  int32_t n, int64_t k, double* C, int64_t ldc) {
+  if (!A || !B || !C || (m & 63) || (n & 63) || (k & 63) || m < 64 || n < 64 || k < 64) return RG_ERR_ARG;
+  rg_launch_dgemm_nt((hipStream_t)stream, A, lda, B, ldb, m, n, k, C, ldc);
+  return hipGetLastError() == hipSuccess ? RG_OK : RG_ERR_HIP;
+}
+
+}  // extern "C"

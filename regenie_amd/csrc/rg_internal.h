@@ -1,0 +1,165 @@
+// Internal declarations shared by the HIP translation units of librg_step1_hip.so.
+// Product code: nothing here may reference oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/rg_step1.h"
+
+#define RG_MAX_SEG 32      // max CV folds handled by the fold-aligned layout
+#define RG_TILE_G 128      // i8 Gram output tile
+#define RG_TILE_C 64       // fp64 Cholesky / Gram tile
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+static inline int64_t rg_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// Fold-aligned sample layout ("position space"): fold f occupies positions
+// [pos_start[f], pos_start[f]+len[f]) which map to .fam indices [file_start[f], +len[f]);
+// every fold starts at a multiple of 64 positions, so a fold boundary never cuts a packed
+// 16-byte K-step of the i8 Gram kernel nor a 64-sample chunk of the fp64 kernels.
+struct SegLayout {
+  int32_t nseg;
+  int32_t pad_;
+  int64_t pos_start[RG_MAX_SEG];
+  int64_t file_start[RG_MAX_SEG];
+  int64_t len[RG_MAX_SEG];      // in file samples
+  int64_t plen[RG_MAX_SEG];     // padded length (multiple of 64)
+};
+
+struct rg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string err;
+  bool have_problem = false;
+
+  // problem
+  int64_t N = 0, Nfile = 0, Np = 0, n_analyzed = 0;
+  int P = 0, C = 0, K = 0, R0 = 0, ref_first = 0, B_total = 0, bs_max = 0;
+  int n_active = 0;
+  std::vector<int64_t> fold_cstart;  // compact start of each fold (K+1)
+  std::vector<double> lambda, neff;
+  SegLayout seg;
+
+  // device: per-position side arrays
+  int32_t* d_cidx = nullptr;     // [Np] compact index or -1
+  uint8_t* d_act = nullptr;      // [Np/4] 2-bit 11 for samples in the analysis
+  double* d_V = nullptr;         // [(C+P)][Np]  X then Y in position space
+  double* d_maskp = nullptr;     // [P][Np] 0/1 masked_indivs in position space
+  double* d_Q = nullptr;         // [nseg][C][C]   X_f^T X_f
+  double* d_XtY = nullptr;       // [nseg][C][P]   X_f^T Y_f
+  double* d_lambda = nullptr;    // [R0]
+  double* d_neff = nullptr;      // [P]
+  uint8_t* d_keptp = nullptr;    // [Np] 1 if the position is one of the N kept samples
+  int64_t* d_posc = nullptr;     // [N] position of each compact sample
+  double* d_zero = nullptr;      // [Np] zeros (padding rows of the level-1 Gram)
+
+  // W
+  double* d_W = nullptr;         // [B*R0][P][Np]
+  bool own_W = false;
+  int64_t W_bytes = 0;
+
+  // level-0 workspaces (sized for NBLK blocks)
+  int nblk_cap = 0;
+  int n128 = 0, n64 = 0, rtot = 0;  // paddings for bs_max
+  uint8_t* d_raw = nullptr;  int64_t raw_ld = 0;    // staged raw rows [nblk][bs_max][raw_ld]
+  uint8_t* d_pk = nullptr;   int64_t pk_ld = 0;     // cleaned packed   [nblk][n128][pk_ld]
+  double* d_mu = nullptr;        // [nblk][n128]
+  int32_t* d_nmiss = nullptr;    // [nblk]
+  double* d_xypart = nullptr;    // [nblk][nchunk][n128][2][Cv]
+  int32_t xy_nchunk = 0;
+  std::vector<int32_t> h_chunk_seg; std::vector<int64_t> h_chunk_pos, h_chunk_len;
+  int32_t* d_chunk_seg = nullptr; int64_t* d_chunk_pos = nullptr; int64_t* d_chunk_len = nullptr;
+  int32_t* d_S = nullptr;        // [nblk][nseg][2*n128][2*n128] int32 stacked Gram
+  double* d_F = nullptr;         // [nblk][nseg][n128][C]
+  double* d_Bm = nullptr;        // [nblk][n128][C]
+  double* d_BQ = nullptr;        // [nblk][nseg][n128][C]
+  double* d_GYt = nullptr;       // [nblk][nseg][n128][P]
+  double* d_sc = nullptr;        // [nblk][n128]  scale_G
+  double* d_fold = nullptr;      // [nblk][nseg][rtot][n64]
+  double* d_sum = nullptr;       // [nblk][rtot][n64]
+  double* d_wk = nullptr;        // [nblk][nseg*R0][rtot][n64]
+  double* d_dinv = nullptr;      // [nblk*nseg*R0][n64/64][64*64]
+  double* d_beta = nullptr;      // [nblk][nseg*R0][P][n64]  beta / scale_G
+  double* d_cb = nullptr;        // [nblk][nseg*R0][P][C]
+  double* d_psum = nullptr;      // [nblk][npchunk][R0*P][2]
+  int32_t* d_info = nullptr;     // [4] deferred error flags: [0]=low variance, [1]=not SPD
+  int32_t* d_bs = nullptr;       // [nblk]
+  int32_t* d_blockid = nullptr;  // [nblk]
+  std::vector<int> block_done;
+
+  // timing
+  bool timing = false;
+  rg_timing tm{};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+#define RG_HIP(call)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+      return RG_ERR_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+// ---- launchers implemented in the .hip files ------------------------------------------------
+// bed_prep.hip
+void rg_launch_bed_prep(hipStream_t st, const uint8_t* raw, int64_t raw_ld, int64_t raw_blk_stride,
+                        uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs,
+                        int nblk, int n128, const uint8_t* act, SegLayout seg, int64_t Np,
+                        int ref_first, int n_active, double* mu, int32_t* nmiss);
+void rg_launch_geno_xy(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride,
+                       const int32_t* d_bs, int nblk, int n128, const double* V, int64_t Np, int Cv,
+                       const int64_t* chunk_pos, const int64_t* chunk_len, int nchunk, double* part);
+// gram_i8.hip
+void rg_launch_gram_blocks(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride,
+                           int nblk, int n128, SegLayout seg, const int32_t* nmiss, int32_t* S);
+void rg_launch_gram_generic(hipStream_t st, const uint8_t* A, int64_t lda, int a_miss,
+                            const uint8_t* B, int64_t ldb, int b_miss, int m, int n, int64_t kbytes,
+                            int32_t* C, int64_t ldc);
+// assemble.hip
+struct AsmArgs {
+  int nblk, nseg, n128, n64, rtot, C, P, Cv, nchunk;
+  int64_t n_analyzed;
+  const int32_t* bs; const int32_t* chunk_seg;
+  const double* part; const double* mu; const int32_t* S; const int32_t* nmiss;
+  const double* Q; const double* XtY;
+  double *F, *Bm, *BQ, *GYt, *sc, *fold, *sum;
+  int32_t* info;
+};
+void rg_launch_rowstats(hipStream_t st, const AsmArgs& a);
+void rg_launch_assemble(hipStream_t st, const AsmArgs& a);
+// chol.hip
+void rg_launch_form(hipStream_t st, const double* sum, int64_t sum_stride, const double* fold,
+                    int64_t fold_stride, int nfold, const double* shift, int nshift, const int32_t* d_n,
+                    int n_fixed, int nouter, int n64, int rtot, double* wk);
+void rg_launch_chol_solve(hipStream_t st, double* mats, int64_t mat_stride, int batch, int n64,
+                          int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch);
+void rg_launch_dgemm_nt(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
+                        int m, int n, int64_t k, double* C, int64_t ldc);
+// pred.hip
+struct PredArgs {
+  int nblk, nseg, R0, P, C, n128, n64, rtot, B_total;
+  int64_t Np, pk_ld, pk_blk_stride;
+  SegLayout seg;
+  const uint8_t* pk; const double* mu; const double* sc; const double* Bm; const double* wk;
+  const double* V; const double* maskp; const uint8_t* keptp; const int32_t* bs;
+  const int32_t* blockid; const double* neff;
+  double *beta, *cb, *psum, *W;
+};
+void rg_launch_l0_pred_impl(hipStream_t st, const PredArgs& a, const int32_t* chunk_seg,
+                            const int64_t* chunk_pos, const int64_t* chunk_len, int nchunk);
+void rg_launch_w_gather(hipStream_t st, const double* W, int64_t Np, int P, int p, int col0, int R0,
+                        const int64_t* posc, int64_t N, double* out);
+void rg_launch_w_scatter(hipStream_t st, double* W, int64_t Np, int P, int p, int col0, int R0,
+                         const int64_t* posc, int64_t N, const double* in);
+// l1.hip
+struct L1Args;
+int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_t* cols_per_chr,
+                  double* cumsum_out, int32_t* best_out, double* pred_out);

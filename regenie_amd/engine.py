@@ -1,0 +1,226 @@
+"""ctypes binding of librg_step1_hip.so -- the product path.
+
+This is the thin host-side mirror of the seam inside regenie's Data::run_step1
+(reference src/Data.cpp:95-133): `set_problem` stands where setmem/set_folds do, `l0_blocks` where
+the get_G -> residualize_genotypes -> calc_cv_matrices -> ridge_level_0 block loop does
+(Data.cpp:636-678), `l1_qt` where ridge_level_1 + output/make_predictions do.
+
+There is NO CPU fallback: if the HIP library cannot be loaded or no GPU is present every call fails
+loudly.  Nothing here imports oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_LIB = None
+RG_MEM_HOST, RG_MEM_DEVICE = 0, 1
+
+
+class RgProblem(C.Structure):
+    _fields_ = [
+        ("n_samples", C.c_int64), ("n_file", C.c_int64), ("n_pheno", C.c_int32), ("n_cov", C.c_int32),
+        ("cv_folds", C.c_int32), ("n_ridge_l0", C.c_int32), ("ref_first", C.c_int32),
+        ("reserved0", C.c_int32), ("n_analyzed", C.c_int64), ("cv_sizes", C.c_void_p),
+        ("lambda_", C.c_void_p), ("X", C.c_void_p), ("Y", C.c_void_p), ("mask", C.c_void_p),
+        ("ind_in_analysis", C.c_void_p), ("ind_ignore", C.c_void_p), ("neff", C.c_void_p),
+        ("n_blocks_total", C.c_int32), ("max_block_size", C.c_int32),
+    ]
+
+
+class RgTiming(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("ms_prep", "ms_xy", "ms_gram", "ms_assemble", "ms_chol",
+                                          "ms_solve", "ms_pred", "ms_l1_gram", "ms_l1_chol",
+                                          "ms_l1_pred")] + \
+               [("n_gram_launches", C.c_int64), ("n_chol_launches", C.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_w_rows", "rg_w_bytes",
+           "rg_set_w_buffer", "rg_w_device_ptr", "rg_l0_blocks", "rg_sync", "rg_l0_get_w",
+           "rg_l0_set_w", "rg_l1_qt", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8",
+           "rg_k_chol_solve", "rg_k_dgemm_nt"]
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librg_step1_hip.so")
+
+
+def load_library() -> C.CDLL:
+    """Loads the in-tree HIP library; raises if it is missing (no silent fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError("librg_step1_hip.so is not built (%s): run `python -m regenie_amd.build` "
+                           "or __graft_entry__.build()" % path)
+    lib = C.CDLL(path)
+    lib.rg_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p]
+    lib.rg_destroy.argtypes = [C.c_void_p]
+    lib.rg_destroy.restype = None
+    lib.rg_last_error.argtypes = [C.c_void_p]
+    lib.rg_last_error.restype = C.c_char_p
+    lib.rg_set_problem.argtypes = [C.c_void_p, C.POINTER(RgProblem)]
+    lib.rg_w_rows.argtypes = [C.c_void_p]
+    lib.rg_w_rows.restype = C.c_int64
+    lib.rg_w_bytes.argtypes = [C.c_void_p]
+    lib.rg_w_bytes.restype = C.c_int64
+    lib.rg_set_w_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    lib.rg_w_device_ptr.argtypes = [C.c_void_p]
+    lib.rg_w_device_ptr.restype = C.c_void_p
+    lib.rg_l0_blocks.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+    lib.rg_sync.argtypes = [C.c_void_p]
+    lib.rg_l0_get_w.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.rg_l0_set_w.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.rg_l1_qt.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                             C.c_void_p, C.c_void_p]
+    lib.rg_enable_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.rg_get_timing.argtypes = [C.c_void_p, C.POINTER(RgTiming)]
+    lib.rg_k_gram_i8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
+                                 C.c_int, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int64]
+    lib.rg_k_chol_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rg_k_dgemm_nt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                  C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int64]
+    _LIB = lib
+    return lib
+
+
+class RgError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("rg error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Step1Engine:
+    """One context per process / GPU."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.rg_create(C.byref(h), device, C.c_void_p(stream) if stream else None)
+        if rc != 0 or not h:
+            raise RgError(rc, "rg_create failed (no MI355X / HIP device visible?)")
+        self.h = h
+        self._keep = []
+        self.N = self.P = self.R0 = self.B = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise RgError(rc, self.lib.rg_last_error(self.h).decode())
+
+    def set_problem(self, *, X, Y, mask, ind_in_analysis, cv_sizes, lam, neff, n_file,
+                    n_blocks_total, max_block_size, ind_ignore=None, ref_first=False):
+        X = np.asfortranarray(X, dtype=np.float64)
+        Y = np.asfortranarray(Y, dtype=np.float64)
+        mask = np.asfortranarray(mask, dtype=np.uint8)
+        ain = np.ascontiguousarray(ind_in_analysis, dtype=np.uint8)
+        cvs = np.ascontiguousarray(cv_sizes, dtype=np.int32)
+        lam = np.ascontiguousarray(lam, dtype=np.float64)
+        neff = np.ascontiguousarray(neff, dtype=np.float64)
+        ign = None if ind_ignore is None else np.ascontiguousarray(ind_ignore, dtype=np.uint8)
+        N, P = Y.shape
+        p = RgProblem()
+        p.n_samples, p.n_file, p.n_pheno, p.n_cov = N, int(n_file), P, X.shape[1]
+        p.cv_folds, p.n_ridge_l0, p.ref_first = cvs.size, lam.size, int(bool(ref_first))
+        p.n_analyzed = int(ain.sum())
+        p.cv_sizes, p.lambda_ = cvs.ctypes.data, lam.ctypes.data
+        p.X, p.Y, p.mask = X.ctypes.data, Y.ctypes.data, mask.ctypes.data
+        p.ind_in_analysis = ain.ctypes.data
+        p.ind_ignore = ign.ctypes.data if ign is not None else None
+        p.neff = neff.ctypes.data
+        p.n_blocks_total, p.max_block_size = int(n_blocks_total), int(max_block_size)
+        self._check(self.lib.rg_set_problem(self.h, C.byref(p)))
+        self.N, self.P, self.R0, self.B = N, P, lam.size, int(n_blocks_total)
+        self.n_file = int(n_file)
+
+    @property
+    def w_rows(self) -> int:
+        return self.lib.rg_w_rows(self.h)
+
+    @property
+    def w_bytes(self) -> int:
+        return self.lib.rg_w_bytes(self.h)
+
+    def set_w_buffer(self, dev_ptr: int, nbytes: int):
+        self._check(self.lib.rg_set_w_buffer(self.h, C.c_void_p(dev_ptr), nbytes))
+
+    def l0_blocks_host(self, block_ids: Sequence[int], rows: List[np.ndarray]):
+        """rows[b]: (bs_b, ceil(N_file/4)) uint8 C-contiguous packed .bed rows (host memory)."""
+        nb = len(block_ids)
+        ids = np.ascontiguousarray(block_ids, dtype=np.int32)
+        bs = np.ascontiguousarray([r.shape[0] for r in rows], dtype=np.int32)
+        rows = [np.ascontiguousarray(r, dtype=np.uint8) for r in rows]
+        stride = rows[0].shape[1]
+        assert all(r.shape[1] == stride for r in rows)
+        ptrs = (C.c_void_p * nb)(*[r.ctypes.data for r in rows])
+        self._check(self.lib.rg_l0_blocks(self.h, nb, ids.ctypes.data, bs.ctypes.data, ptrs, stride, RG_MEM_HOST))
+
+    def l0_blocks_device(self, block_ids: Sequence[int], bs: Sequence[int], dev_ptrs: Sequence[int], row_stride: int):
+        nb = len(block_ids)
+        ids = np.ascontiguousarray(block_ids, dtype=np.int32)
+        bsa = np.ascontiguousarray(bs, dtype=np.int32)
+        ptrs = (C.c_void_p * nb)(*[int(p) for p in dev_ptrs])
+        self._check(self.lib.rg_l0_blocks(self.h, nb, ids.ctypes.data, bsa.ctypes.data, ptrs, int(row_stride), RG_MEM_DEVICE))
+
+    def sync(self):
+        self._check(self.lib.rg_sync(self.h))
+
+    def get_w(self, block_id: int, pheno: int) -> np.ndarray:
+        out = np.empty((self.N, self.R0), dtype=np.float64, order="F")
+        self._check(self.lib.rg_l0_get_w(self.h, block_id, pheno, out.ctypes.data))
+        return out
+
+    def set_w(self, block_id: int, pheno: int, w: np.ndarray):
+        w = np.asfortranarray(w, dtype=np.float64)
+        assert w.shape == (self.N, self.R0)
+        self._check(self.lib.rg_l0_set_w(self.h, block_id, pheno, w.ctypes.data))
+
+    def l1_qt(self, tau: np.ndarray, cols_per_chr: Sequence[int]):
+        """tau: (P, R1) scaled ridge values.  Returns (cumsum [P,5,R1], best [P], pred [P][N,nchr])."""
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        P, R1 = tau.shape
+        assert P == self.P
+        cpc = np.ascontiguousarray(cols_per_chr, dtype=np.int32)
+        nchr = cpc.size
+        cs = np.zeros((P, 5, R1))
+        best = np.zeros(P, dtype=np.int32)
+        pred = np.zeros((P, nchr, self.N))
+        self._check(self.lib.rg_l1_qt(self.h, R1, tau.ctypes.data, nchr, cpc.ctypes.data, cs.ctypes.data,
+                                      best.ctypes.data, pred.ctypes.data))
+        return cs, best, [pred[p].T.copy() for p in range(P)]
+
+    def enable_timing(self, on: bool = True):
+        self._check(self.lib.rg_enable_timing(self.h, int(on)))
+
+    def timing(self) -> dict:
+        t = RgTiming()
+        self._check(self.lib.rg_get_timing(self.h, C.byref(t)))
+        return t.as_dict()
+
+
+def loco_from_predictions(pred: np.ndarray, chroms: Sequence[int], nchrom: int = 23) -> np.ndarray:
+    """write_predictions' LOCO assembly (reference src/Data.cpp:1846-1858): LOCO[:,c] = rowsum - pred[:,c];
+    chromosomes without blocks get the full sum."""
+    tot = pred.sum(axis=1)
+    out = np.repeat(tot[:, None], nchrom, axis=1)
+    for ci, c in enumerate(chroms):
+        out[:, c - 1] -= pred[:, ci]
+    return out

@@ -1,0 +1,126 @@
+"""Shared helpers of the parity tests.  The oracle is used here as the CHECKER only: it prepares the
+inputs both sides consume (phenotype/covariate prep is host-side prerequisite work, SURVEY.md 8a row
+a23) and produces the expected outputs; everything under test goes through the C ABI."""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import regenie_step1 as orc
+from regenie_amd.engine import Step1Engine, loco_from_predictions
+
+
+def gpu_step1(opt: orc.Step1Options, nblk_env=None):
+    """Runs level 0 + level 1 (QT, K-fold) through librg_step1_hip.so on the inputs the oracle prepared.
+    Returns dict(W=[P][N,L], cumsum, best, pred, loco, prep, blocks, ...)."""
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    bed, bpr = orc.open_bed(opt.bed + ".bed", prep.n_file)
+    blocks = orc.chrom_blocks(chrom, bim.chr_read, opt.bsize)
+    B = len(blocks)
+    h0 = orc.set_ridge_params(opt.n_ridge_l0)
+    h1 = orc.set_ridge_params(opt.n_ridge_l1)
+    M = chrom.size
+    lam = M * (1 - h0) / h0
+    cv_sizes = orc.set_folds(prep.ind_in_analysis, opt.cv_folds)
+    eng = Step1Engine(0)
+    eng.set_problem(X=prep.X, Y=prep.Y, mask=prep.mask, ind_in_analysis=prep.ind_in_analysis,
+                    cv_sizes=cv_sizes, lam=lam, neff=prep.Neff, n_file=prep.n_file, n_blocks_total=B,
+                    max_block_size=opt.bsize, ind_ignore=prep.ind_ignore if prep.ind_ignore.any() else None,
+                    ref_first=opt.ref_first)
+    rows = [np.ascontiguousarray(bed[offs[s:s + bs]]) for (_, s, bs) in blocks]
+    eng.l0_blocks_host(list(range(B)), rows)
+    eng.sync()
+    N, P = prep.Y.shape
+    R0 = lam.size
+    W = [np.zeros((N, B * R0)) for _ in range(P)]
+    for b in range(B):
+        for ph in range(P):
+            W[ph][:, b * R0:(b + 1) * R0] = eng.get_w(b, ph)
+    L = B * R0
+    tau = np.stack([orc.tau_from_h(h1, L, False) for _ in range(P)])
+    chrcols = orc.chr_columns(blocks, bim.chr_read, R0)
+    cs, best, pred = eng.l1_qt(tau, [nn for (_, _, nn) in chrcols])
+    loco = [loco_from_predictions(pred[ph], [c for (c, _, _) in chrcols], opt.nchrom) for ph in range(P)]
+    eng.close()
+    return dict(W=W, cumsum=cs, best=best, pred=pred, loco=loco, prep=prep, blocks=blocks, lam=lam,
+                cv_sizes=cv_sizes, tau=tau, chrcols=chrcols, rows=rows)
+
+
+def rel_err(a, b):
+    """BASELINE.json's accuracy metric: max|a-b| / max|b|."""
+    return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+
+# ---- deterministic synthetic PLINK data (SplitMix64 counter hash) ----------------
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    return z ^ (z >> np.uint64(31))
+
+
+def u01(seed, j, i):
+    with np.errstate(over="ignore"):
+        x = (np.uint64(seed) * np.uint64(0x100000001B3)) ^ (np.asarray(j, np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        x = _splitmix64(x) ^ np.asarray(i, np.uint64)
+        return (_splitmix64(x) >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+
+
+def synth_dosages(M, N, miss_rate=0.0, seed=7):
+    """HWE genotypes, MAF ~ U(0.05, 0.5); returns int8 (M,N) with -3 for missing."""
+    j = np.arange(M)[:, None]
+    i = np.arange(N)[None, :]
+    maf = 0.05 + 0.45 * u01(101 + seed, np.arange(M), 0)
+    g = (u01(102 + seed, j, i) < maf[:, None]).astype(np.int8) + (u01(103 + seed, j, i) < maf[:, None]).astype(np.int8)
+    if miss_rate > 0:
+        g = np.where(u01(104 + seed, j, i) < miss_rate, np.int8(-3), g)
+    return g
+
+
+def pack_bed(g):
+    """int8 dosage (count of the first allele; -3 missing) -> packed .bed rows (Geno.cpp:2838-2843)."""
+    M, N = g.shape
+    code = np.full(g.shape, 3, np.uint8)      # dosage 0 -> 11
+    code[g == 2] = 0
+    code[g == 1] = 2
+    code[g == -3] = 1
+    pad = (-N) % 4
+    if pad:
+        code = np.concatenate([code, np.zeros((M, pad), np.uint8)], axis=1)
+    c = code.reshape(M, -1, 4)
+    return (c[:, :, 0] | (c[:, :, 1] << 2) | (c[:, :, 2] << 4) | (c[:, :, 3] << 6)).astype(np.uint8)
+
+
+def write_plink(prefix, g, chroms, P=2, ncov=2, seed=3, h2=0.2, missing_pheno=0.0):
+    """Writes prefix.bed/.bim/.fam + prefix.pheno + prefix.covar; returns nothing."""
+    M, N = g.shape
+    with open(prefix + ".bed", "wb") as fh:
+        fh.write(b"\x6c\x1b\x01")
+        fh.write(pack_bed(g).tobytes())
+    with open(prefix + ".bim", "w") as fh:
+        for j in range(M):
+            fh.write("%d\ts%d\t0\t%d\tA\tG\n" % (chroms[j], j, j + 1))
+    with open(prefix + ".fam", "w") as fh:
+        for i in range(N):
+            fh.write("%d %d 0 0 0 -9\n" % (i + 1, i + 1))
+    rng = np.random.default_rng(seed)
+    gs = np.where(g < 0, 0, g).astype(np.float64)
+    gs = (gs - gs.mean(axis=1, keepdims=True)) / (gs.std(axis=1, keepdims=True) + 1e-12)
+    cov = rng.standard_normal((N, ncov))
+    with open(prefix + ".covar", "w") as fh:
+        fh.write("FID IID " + " ".join("C%d" % (c + 1) for c in range(ncov)) + "\n")
+        for i in range(N):
+            fh.write("%d %d " % (i + 1, i + 1) + " ".join("%.15g" % v for v in cov[i]) + "\n")
+    ys = []
+    for p in range(P):
+        ncausal = min(M, 50)
+        idx = rng.choice(M, ncausal, replace=False)
+        beta = rng.standard_normal(ncausal) * np.sqrt(h2 / ncausal)
+        y = gs[idx].T @ beta + rng.standard_normal(N) * np.sqrt(1 - h2) + 0.3 * cov[:, 0]
+        ys.append(y)
+    Y = np.stack(ys, axis=1)
+    miss = rng.random((N, P)) < missing_pheno
+    with open(prefix + ".pheno", "w") as fh:
+        fh.write("FID IID " + " ".join("Y%d" % (p + 1) for p in range(P)) + "\n")
+        for i in range(N):
+            fh.write("%d %d " % (i + 1, i + 1) + " ".join(("NA" if miss[i, p] else "%.15g" % Y[i, p]) for p in range(P)) + "\n")
