@@ -183,7 +183,7 @@ def main():
         step()
         tm = eng.timing()
         eng.enable_timing(False)
-        n_batches = -(-nb // int(os.environ.get("RG_NBLK", "8")))
+        n_batches = -(-nb // int(os.environ.get("RG_NBLK", "32")))
         bs_eff = float(np.mean(bss))
         flops = {
             "gram_i8": 2.0 * N * sum(x * x for x in bss),                        # F_gram = 2 N bs^2 per block

@@ -141,6 +141,10 @@ int rg_k_chol_solve(void* stream, double* mats, int64_t mat_stride, int32_t batc
 int rg_k_dgemm_nt(void* stream, const double* A, int64_t lda, const double* B, int64_t ldb,
                   int32_t m, int32_t n, int64_t k, double* C, int64_t ldc);
 
+/* register-only MFMA issue-rate micro-benchmark: kind 0 = v_mfma_f64_16x16x4_f64 (TFLOP/s),
+ * kind 1 = v_mfma_i32_32x32x32_i8 (TOP/s); the measured ceilings bench.py quotes next to the peaks. */
+int rg_k_mfma_peak(int kind, int iters, double* tera_ops_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -115,7 +115,13 @@ __global__ __launch_bounds__(256) void k_assemble(AsmArgs a) {
     sum[e] = tot;
     return;
   }
-  if (k > i) return;  // upper triangle never referenced
+  if (k > i) {  // upper triangle: never referenced, except inside diagonal 64-tiles (kept finite)
+    if ((k >> 6) == (i >> 6)) {
+      for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = 0.0;
+      sum[e] = 0.0;
+    }
+    return;
+  }
   if (i >= bs) {      // padding (k <= i)
     for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = 0.0;
     sum[e] = 0.0;

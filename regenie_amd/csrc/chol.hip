@@ -22,6 +22,7 @@
 // contraction is invariant under any K permutation applied to both operands alike, so lane (i, q)
 // takes the 16 CONSECUTIVE k = 16q .. 16q+15 of a 64-chunk (one 128-byte piece of its row): four
 // 32-byte global loads per row, no LDS staging.
+#include <algorithm>
 #include "rg_internal.h"
 
 #define CT 64
@@ -128,54 +129,143 @@ void rg_launch_form(hipStream_t st, const double* sum, int64_t sum_stride, const
                      fold, fold_stride, nfold, shift, nshift, d_n, n_fixed, n64, rtot, wk);
 }
 
-// ---- diagonal tile: potf2 + triangular inverse in LDS ---------------------------------------------
+// ---- lazy "form": value of element (i,j) of system b = sum[o] - fold[o][f] + shift[r] on the diagonal ----
+// Every tile of a system is first touched exactly once during the first column group of the
+// factorization, so the systems are never materialised by a separate pass: the first-touch kernels
+// read (sum, fold) instead of the workspace.
+struct FormSrc {
+  const double* sum; int64_t sum_stride;
+  const double* fold; int64_t fold_stride;
+  const double* shift; const int32_t* d_n;
+  int nfold, nshift, n_fixed, enabled;
+};
+struct FormIdx { const double* S; const double* F; double sh; int n; };
+__device__ __forceinline__ FormIdx form_idx(const FormSrc& f, int b) {
+  const int per = f.nfold * f.nshift;
+  const int o = b / per, rem = b % per, fo = rem / f.nshift, r = rem % f.nshift;
+  FormIdx x;
+  x.S = f.sum + (int64_t)o * f.sum_stride;
+  x.F = f.fold + ((int64_t)o * f.nfold + fo) * f.fold_stride;
+  x.sh = f.shift[r];
+  x.n = f.d_n ? f.d_n[o] : f.n_fixed;
+  return x;
+}
+__device__ __forceinline__ double form_val(const FormIdx& x, int i, int j, int64_t e) {
+  double v = x.S[e] - x.F[e];
+  if (i == j) v = (i < x.n) ? v + x.sh : 1.0;
+  return v;
+}
+
+// ---- diagonal tile: blocked (16) potf2 + blocked triangular inverse, all in LDS -------------------
 __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_stride, int n64, int k,
-                                                   double* dinv, int32_t* info) {
+                                                   double* dinv, int32_t* info, FormSrc fs) {
   __shared__ double s[CT][CT + 1];
   __shared__ double si[CT][CT + 1];
+  __shared__ double tmp[16][17];
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   double* D = mats + (int64_t)b * mat_stride + (int64_t)k * CT * n64 + k * CT;
-  for (int e = tid; e < CT * CT; e += 256) {
-    const int r = e >> 6, c = e & 63;
-    s[r][c] = (c <= r) ? D[(int64_t)r * n64 + c] : 0.0;
-    si[r][c] = 0.0;
+  if (fs.enabled) {
+    const FormIdx fx = form_idx(fs, b);
+    for (int e = tid; e < CT * CT; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      const int gi = k * CT + r, gj = k * CT + c;
+      s[r][c] = (c <= r) ? form_val(fx, gi, gj, (int64_t)gi * n64 + gj) : 0.0;
+      si[r][c] = 0.0;
+    }
+  } else {
+    for (int e = tid; e < CT * CT; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      s[r][c] = (c <= r) ? D[(int64_t)r * n64 + c] : 0.0;
+      si[r][c] = 0.0;
+    }
   }
   __syncthreads();
-  // left-looking column Cholesky: 4 threads per row split the dot product
-  const int r = tid >> 2, part = tid & 3;
-  for (int c = 0; c < CT; ++c) {
-    double p = 0.0;
-    for (int j = part; j < c; j += 4) p = fma(s[r][j], s[c][j], p);
-    p += __shfl_xor(p, 1);
-    p += __shfl_xor(p, 2);
-    __syncthreads();
-    if (part == 0 && r >= c) s[r][c] -= p;
-    __syncthreads();
-    const double piv = s[c][c];
-    double d = sqrt(piv);
-    if (!(piv > 0.0)) {
-      d = 1.0;
-      if (tid == 0) atomicMax(info, 1);
+  bool bad = false;
+  for (int sb = 0; sb < 4; ++sb) {
+    const int o = sb * 16;
+    // (i) 16x16 diagonal block: lanes 0..15 of wave 0 hold one row each in registers
+    if (tid < 16) {
+      double a[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = s[o + tid][o + c];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double piv = __shfl(a[c], c, 16);
+        double d = sqrt(piv);
+        if (!(piv > 0.0)) { d = 1.0; bad = true; }
+        if (tid > c) a[c] /= d;
+        else if (tid == c) a[c] = d;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; ++c2) {
+          const double l = __shfl(a[c], c2, 16);  // L[c2][c]
+          if (tid >= c2) a[c2] = fma(-a[c], l, a[c2]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c <= tid) s[o + tid][o + c] = a[c];
     }
     __syncthreads();
-    if (part == 0) {
-      if (r > c) s[r][c] /= d;
-      else if (r == c) s[r][c] = d;
+    // (ii) rows below: X L11^T = A, one thread per row
+    const int nbelow = CT - o - 16;
+    if (tid < nbelow) {
+      const int r = o + 16 + tid;
+      double x[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        double v = s[r][o + c];
+#pragma unroll
+        for (int c2 = 0; c2 < c; ++c2) v = fma(-x[c2], s[o + c][o + c2], v);
+        x[c] = v / s[o + c][o + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) s[r][o + c] = x[c];
+    }
+    __syncthreads();
+    // (iii) trailing update inside the tile: A22 -= X X^T (lower part)
+    for (int e = tid; e < nbelow * nbelow; e += 256) {
+      const int r = e / nbelow, c = e % nbelow;
+      if (c > r) continue;
+      double v = 0.0;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) v = fma(s[o + 16 + r][o + m], s[o + 16 + c][o + m], v);
+      s[o + 16 + r][o + 16 + c] -= v;
     }
     __syncthreads();
   }
-  // inverse of the lower-triangular factor: thread (c = tid>>2, part) builds column c
-  {
-    const int c = tid >> 2;
-    for (int rr = 0; rr < CT; ++rr) {
-      double p = 0.0;
-      for (int j = part; j < rr; j += 4) p = fma(s[rr][j], si[j][c], p);
-      p += __shfl_xor(p, 1);
-      p += __shfl_xor(p, 2);
-      if (part == 0) si[rr][c] = (((rr == c) ? 1.0 : 0.0) - p) / s[rr][rr];
-      __syncthreads();
+  if (bad) atomicMax(info, 1);
+  // inverse of L by 16-blocks.  diagonal blocks: thread (block q, column c) forward-substitutes.
+  if (tid < 64) {
+    const int q = tid >> 4, c = tid & 15, o = q * 16;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double v = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j < r; ++j) v = fma(-s[o + r][o + j], x[j], v);
+      x[r] = v / s[o + r][o + r];
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) si[o + r][o + c] = (r >= c) ? x[r] : 0.0;
+  }
+  __syncthreads();
+  // off-diagonal blocks (i > j), by sub-diagonal distance: Li[i][j] = -Li[i][i] * sum_{k=j}^{i-1} L[i][k] Li[k][j]
+  {
+    const int a = tid >> 4, bb = tid & 15;
+    for (int dist = 1; dist < 4; ++dist)
+      for (int j = 0; j + dist < 4; ++j) {
+        const int i = j + dist;
+        double v = 0.0;
+        for (int kk = j * 16; kk < i * 16; ++kk) v = fma(s[i * 16 + a][kk], si[kk][j * 16 + bb], v);
+        tmp[a][bb] = v;
+        __syncthreads();
+        double w = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) w = fma(si[i * 16 + a][i * 16 + m], tmp[m][bb], w);
+        si[i * 16 + a][j * 16 + bb] = -w;
+        __syncthreads();
+      }
   }
   double* I = dinv + ((int64_t)b * (n64 / CT) + k) * CT * CT;
   for (int e = tid; e < CT * CT; e += 256) {
@@ -187,18 +277,37 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_str
 
 // ---- panel: L[t][k] = A[t][k] * Linv^T ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chol_panel(double* mats, int64_t mat_stride, int n64, int k,
-                                                    const double* dinv) {
+                                                    const double* dinv, FormSrc fs) {
   const int b = blockIdx.y, t = k + 1 + blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int i = lane & 15, q = lane >> 4;
   double* T = mats + (int64_t)b * mat_stride + (int64_t)t * CT * n64 + k * CT;
   const double* I = dinv + ((int64_t)b * (n64 / CT) + k) * CT * CT;
-  const double* ar[2] = {T + (int64_t)(wr * 32 + i) * n64 + 16 * q,
-                         T + (int64_t)(wr * 32 + 16 + i) * n64 + 16 * q};
-  const double* br[2] = {I + (wc * 32 + i) * CT + 16 * q, I + (wc * 32 + 16 + i) * CT + 16 * q};
   double av[2][16], bv[2][16];
-  dmma_load<2, 2>(ar, br, av, bv);
+  if (fs.enabled) {
+    const FormIdx fx = form_idx(fs, b);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int gi = t * CT + wr * 32 + m * 16 + i;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int gj = k * CT + 16 * q + v;
+        av[m][v] = form_val(fx, gi, gj, (int64_t)gi * n64 + gj);
+      }
+      const double4* p = reinterpret_cast<const double4*>(I + (wc * 32 + m * 16 + i) * CT + 16 * q);
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const double4 x = p[v];
+        bv[m][4 * v] = x.x; bv[m][4 * v + 1] = x.y; bv[m][4 * v + 2] = x.z; bv[m][4 * v + 3] = x.w;
+      }
+    }
+  } else {
+    const double* ar[2] = {T + (int64_t)(wr * 32 + i) * n64 + 16 * q,
+                           T + (int64_t)(wr * 32 + 16 + i) * n64 + 16 * q};
+    const double* br[2] = {I + (wc * 32 + i) * CT + 16 * q, I + (wc * 32 + 16 + i) * CT + 16 * q};
+    dmma_load<2, 2>(ar, br, av, bv);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // every wave holds its operands before any wave overwrites the tile
   v4d acc[2][2];
@@ -216,111 +325,168 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* mats, int64_t mat_st
         T[(int64_t)(wr * 32 + m * 16 + q + 4 * r) * n64 + wc * 32 + n * 16 + i] = acc[m][n][r];
 }
 
-// ---- trailing update: A[r][c] -= L[r][k] L[c][k]^T -----------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_update(double* mats, int64_t mat_stride, int n64,
-                                                     int ntile_mat, int k) {
+// ---- update: A[r][c] -= sum_{q in [kc0, kc0+nkc)} L[r][q] L[c][q]^T for tile columns c in [c_lo, c_hi),
+//      rows r in [c, Ttot) (matrix tiles below/on the diagonal plus the RHS row tiles) ---------------------
+// One WAVE per 64x64 tile (4 x 4 MFMA sub-tiles, 64 accumulator doubles per lane): per 16-deep K chunk a
+// wave loads 2 x 4 row pieces of 32 bytes per lane and issues 64 MFMAs (~4K cycles), i.e. ~4 B/clk of
+// operands per wave -- half of a 32x32-per-wave tiling; the four waves of a workgroup take consecutive
+// tiles of one tile column, so they share the B operand in L1.
+__global__ __launch_bounds__(256, 2) void k_chol_update(double* mats, int64_t mat_stride, int n64,
+                                                        int Ttot, int c_lo, int c_hi, int ntile,
+                                                        int kc0, int nkc, FormSrc fs) {
   const int b = blockIdx.y;
-  const int nrem = ntile_mat - 1 - k;
-  const int tri = nrem * (nrem + 1) / 2;
-  int idx = blockIdx.x, tr, tc;
-  if (idx < tri) {
-    int rr = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
-    while ((rr + 1) * (rr + 2) / 2 <= idx) ++rr;
-    while (rr * (rr + 1) / 2 > idx) --rr;
-    tr = k + 1 + rr;
-    tc = k + 1 + (idx - rr * (rr + 1) / 2);
-  } else {
-    idx -= tri;
-    tr = ntile_mat + idx / nrem;
-    tc = k + 1 + idx % nrem;
-  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  int idx = blockIdx.x * 4 + wave, tc = c_lo;
+  if (idx >= ntile) return;
+  while (tc < c_hi && idx >= Ttot - tc) { idx -= Ttot - tc; ++tc; }
+  const int tr = tc + idx;
   const int i = lane & 15, q = lane >> 4;
   double* M = mats + (int64_t)b * mat_stride;
-  const double* A = M + (int64_t)tr * CT * n64 + k * CT;
-  const double* B = M + (int64_t)tc * CT * n64 + k * CT;
+  const double* A = M + ((int64_t)tr * CT + i) * n64 + kc0 * CT + 4 * q;
+  const double* B = M + ((int64_t)tc * CT + i) * n64 + kc0 * CT + 4 * q;
   double* C = M + (int64_t)tr * CT * n64 + tc * CT;
-  const double* ar[2] = {A + (int64_t)(wr * 32 + i) * n64 + 16 * q,
-                         A + (int64_t)(wr * 32 + 16 + i) * n64 + 16 * q};
-  const double* br[2] = {B + (int64_t)(wc * 32 + i) * n64 + 16 * q,
-                         B + (int64_t)(wc * 32 + 16 + i) * n64 + 16 * q};
-  double av[2][16], bv[2][16];
-  dmma_load<2, 2>(ar, br, av, bv);
-  v4d acc[2][2];
+  v4d acc[4][4];
+  if (fs.enabled) {
+    const FormIdx fx = form_idx(fs, b);
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int gi = tr * CT + m * 16 + q + 4 * r, gj = tc * CT + n * 16 + i;
+          acc[m][n][r] = -form_val(fx, gi, gj, (int64_t)gi * n64 + gj);
+        }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[m][n][r] = -C[(int64_t)(m * 16 + q + 4 * r) * n64 + n * 16 + i];
+  }
+  const int nk16 = nkc * 4;
+  for (int kc = 0; kc < nk16; ++kc) {
+    double4 av[4], bv[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      av[m] = *reinterpret_cast<const double4*>(A + (int64_t)m * 16 * n64 + kc * 16);
+      bv[m] = *reinterpret_cast<const double4*>(B + (int64_t)m * 16 * n64 + kc * 16);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].x, bv[n].x, acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].y, bv[n].y, acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].z, bv[n].z, acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].w, bv[n].w, acc[m][n], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        acc[m][n][r] = -C[(int64_t)(wr * 32 + m * 16 + q + 4 * r) * n64 + wc * 32 + n * 16 + i];
-  dmma_fma<2, 2>(av, bv, acc);
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        C[(int64_t)(wr * 32 + m * 16 + q + 4 * r) * n64 + wc * 32 + n * 16 + i] = -acc[m][n][r];
+        C[(int64_t)(m * 16 + q + 4 * r) * n64 + n * 16 + i] = -acc[m][n][r];
 }
 
 // ---- back substitution L^T x = y for the RHS rows (in place), one workgroup per system -------------
-#define BS_PG 4  // RHS rows per pass: 4 x 64 outputs = 256 threads
+// The four waves split either the RHS rows (pg = 4 or 2 per pass) or, for few RHS, the 64-row
+// contraction of each tile (parts = 4 / pg), so a single right-hand side still keeps 4 waves of
+// loads in flight.
 __global__ __launch_bounds__(256) void k_chol_backsolve(double* mats, int64_t mat_stride, int n64,
                                                         int nrhs, const double* dinv) {
-  __shared__ double xk[BS_PG][CT];
-  __shared__ double yk[BS_PG][CT];
+  __shared__ double xk[4][CT];
+  __shared__ double yk[4][CT];
+  __shared__ double red[4][CT];
   const int b = blockIdx.x;
   const int T = n64 / CT;
-  const int p = threadIdx.x >> 6, c = threadIdx.x & 63;
+  const int w = threadIdx.x >> 6, c = threadIdx.x & 63;
+  const int pg = nrhs >= 4 ? 4 : (nrhs >= 2 ? 2 : 1);
+  const int parts = 4 / pg;
+  const int p = w % pg, part = w / pg;
+  const int rlen = CT / parts, r0 = part * rlen;
   double* M = mats + (int64_t)b * mat_stride;
-  for (int p0 = 0; p0 < nrhs; p0 += BS_PG) {
+  for (int p0 = 0; p0 < nrhs; p0 += pg) {
     const bool act = (p0 + p) < nrhs;
-    double* Y = M + (int64_t)(n64 + p0 + p) * n64;  // this thread's RHS row
+    double* Y = M + (int64_t)(n64 + p0 + p) * n64;
     for (int k = T - 1; k >= 0; --k) {
       __syncthreads();
-      yk[p][c] = act ? Y[k * CT + c] : 0.0;
+      if (part == 0) yk[p][c] = act ? Y[k * CT + c] : 0.0;
       __syncthreads();
-      // x_k[c] = sum_r y_k[r] * Linv[r][c]   (Linv lower: r >= c)
       const double* I = dinv + ((int64_t)b * T + k) * CT * CT;
       double x = 0.0;
-      for (int r = c; r < CT; ++r) x = fma(yk[p][r], I[r * CT + c], x);
-      xk[p][c] = x;
-      if (act) Y[k * CT + c] = x;
+      for (int r = r0; r < r0 + rlen; ++r) x = fma(yk[p][r], I[r * CT + c], x);  // Linv is lower: zeros above
+      red[w][c] = x;
       __syncthreads();
-      // y_j[c] -= sum_r x_k[r] * L[k*64 + r][j*64 + c]   for j < k
+      if (part == 0) {
+        double t = 0.0;
+        for (int s2 = 0; s2 < parts; ++s2) t += red[p + s2 * pg][c];
+        xk[p][c] = t;
+        if (act) Y[k * CT + c] = t;
+      }
+      __syncthreads();
       for (int j = 0; j < k; ++j) {
-        const double* Lt = M + (int64_t)k * CT * n64 + j * CT + c;
+        const double* Lt = M + (int64_t)(k * CT + r0) * n64 + j * CT + c;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        for (int r = 0; r < CT; r += 4) {
-          a0 = fma(xk[p][r], Lt[(int64_t)r * n64], a0);
-          a1 = fma(xk[p][r + 1], Lt[(int64_t)(r + 1) * n64], a1);
-          a2 = fma(xk[p][r + 2], Lt[(int64_t)(r + 2) * n64], a2);
-          a3 = fma(xk[p][r + 3], Lt[(int64_t)(r + 3) * n64], a3);
+        for (int r = 0; r < rlen; r += 4) {
+          a0 = fma(xk[p][r0 + r], Lt[(int64_t)r * n64], a0);
+          a1 = fma(xk[p][r0 + r + 1], Lt[(int64_t)(r + 1) * n64], a1);
+          a2 = fma(xk[p][r0 + r + 2], Lt[(int64_t)(r + 2) * n64], a2);
+          a3 = fma(xk[p][r0 + r + 3], Lt[(int64_t)(r + 3) * n64], a3);
         }
-        if (act) Y[j * CT + c] -= (a0 + a1) + (a2 + a3);
+        const double v = (a0 + a1) + (a2 + a3);
+        if (parts == 1) {
+          if (act) Y[j * CT + c] -= v;
+        } else {
+          __syncthreads();
+          red[w][c] = v;
+          __syncthreads();
+          if (part == 0 && act) {
+            double t = 0.0;
+            for (int s2 = 0; s2 < parts; ++s2) t += red[p + s2 * pg][c];
+            Y[j * CT + c] -= t;
+          }
+        }
       }
     }
   }
 }
 
-void rg_launch_chol_solve(hipStream_t st, double* mats, int64_t mat_stride, int batch, int n64,
-                          int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch) {
-  const int T = n64 / CT, Tr = rhs_pad / CT;
+void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, int batch, int n64,
+                              int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch,
+                              const FormSrc* src) {
+  const int T = n64 / CT, Tr = rhs_pad / CT, Ttot = T + Tr;
+  const int G = 4;  // tile columns per group: trailing updates contract K = 64*G at once
+  FormSrc off{};
+  off.enabled = 0;
   int64_t nl = 0;
-  for (int k = 0; k < T; ++k) {
-    hipLaunchKernelGGL(k_chol_diag, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, k, dinv, info);
-    ++nl;
-    const int below = T - 1 - k + Tr;
-    if (below > 0) {
-      hipLaunchKernelGGL(k_chol_panel, dim3(below, batch), dim3(256), 0, st, mats, mat_stride, n64, k, dinv);
+  for (int k0 = 0; k0 < T; k0 += G) {
+    const int k1 = std::min(T, k0 + G);
+    const FormSrc& first = (src && k0 == 0) ? *src : off;
+    for (int j = k0; j < k1; ++j) {
+      if (j > k0) {  // narrow update of tile column j with the group's earlier columns
+        hipLaunchKernelGGL(k_chol_update, dim3((Ttot - j + 3) / 4, batch), dim3(256), 0, st, mats, mat_stride,
+                           n64, Ttot, j, j + 1, Ttot - j, k0, j - k0, first);
+        ++nl;
+      }
+      hipLaunchKernelGGL(k_chol_diag, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, j, dinv, info,
+                         (j == 0 && src) ? *src : off);
       ++nl;
+      if (Ttot - 1 - j > 0) {
+        hipLaunchKernelGGL(k_chol_panel, dim3(Ttot - 1 - j, batch), dim3(256), 0, st, mats, mat_stride, n64,
+                           j, dinv, (j == 0 && src) ? *src : off);
+        ++nl;
+      }
     }
-    const int nrem = T - 1 - k;
-    const int ntile = nrem * (nrem + 1) / 2 + Tr * nrem;
-    if (ntile > 0) {
-      hipLaunchKernelGGL(k_chol_update, dim3(ntile, batch), dim3(256), 0, st, mats, mat_stride, n64, T, k);
+    if (k1 < T) {  // wide trailing update with the whole group (K = 64 * (k1 - k0))
+      int ntile = 0;
+      for (int c = k1; c < T; ++c) ntile += Ttot - c;
+      hipLaunchKernelGGL(k_chol_update, dim3((ntile + 3) / 4, batch), dim3(256), 0, st, mats, mat_stride, n64,
+                         Ttot, k1, T, ntile, k0, k1 - k0, first);
       ++nl;
     }
   }
@@ -329,4 +495,22 @@ void rg_launch_chol_solve(hipStream_t st, double* mats, int64_t mat_stride, int 
     ++nl;
   }
   if (n_launch) *n_launch += nl;
+}
+
+void rg_launch_chol_solve(hipStream_t st, double* mats, int64_t mat_stride, int batch, int n64,
+                          int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch) {
+  rg_launch_chol_solve_src(st, mats, mat_stride, batch, n64, rhs_pad, nrhs, dinv, info, n_launch, nullptr);
+}
+
+// Factor + solve the systems (sum[o] - fold[o][f] + shift[r] I) without materialising them first.
+void rg_launch_chol_solve_formed(hipStream_t st, const double* sum, int64_t sum_stride, const double* fold,
+                                 int64_t fold_stride, int nfold, const double* shift, int nshift,
+                                 const int32_t* d_n, int n_fixed, int nouter, double* mats,
+                                 int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
+                                 int32_t* info, int64_t* n_launch) {
+  FormSrc f;
+  f.sum = sum; f.sum_stride = sum_stride; f.fold = fold; f.fold_stride = fold_stride; f.shift = shift;
+  f.d_n = d_n; f.nfold = nfold; f.nshift = nshift; f.n_fixed = n_fixed; f.enabled = 1;
+  rg_launch_chol_solve_src(st, mats, mat_stride, nouter * nfold * nshift, n64, rhs_pad, nrhs, dinv, info,
+                           n_launch, &f);
 }

@@ -227,8 +227,8 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
     hipLaunchKernelGGL(k_sum_folds, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, st, d_fold, msz, K, d_sum);
     if (ctx->timing) { hipEventRecord(e1, st); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ctx->tm.ms_l1_gram += ms; hipEventRecord(e0, st); }
     hipMemcpyAsync(d_tau, tau + (int64_t)p * R1, sizeof(double) * R1, hipMemcpyHostToDevice, st);
-    rg_launch_form(st, d_sum, 0, d_fold, msz, K, d_tau, R1, nullptr, L, 1, n64, rtot, d_wk);
-    rg_launch_chol_solve(st, d_wk, msz, nsys, n64, CT, 1, d_dinv, ctx->d_info + 1, &ctx->tm.n_chol_launches);
+    rg_launch_chol_solve_formed(st, d_sum, 0, d_fold, msz, K, d_tau, R1, nullptr, L, 1, d_wk, msz, n64, CT, 1,
+                                d_dinv, ctx->d_info + 1, &ctx->tm.n_chol_launches);
     if (ctx->timing) { hipEventRecord(e1, st); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ctx->tm.ms_l1_chol += ms; hipEventRecord(e0, st); }
     hipLaunchKernelGGL(k_l1_cv, dim3(nch), dim3(256), 0, st, R, d_wk, msz, R1, ctx->d_chunk_seg,
                        ctx->d_chunk_pos, ctx->d_chunk_len, d_part);

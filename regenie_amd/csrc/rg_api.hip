@@ -200,7 +200,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   ctx->n128 = (int)rg_round_up(bsm, 128);
   ctx->n64 = (int)rg_round_up(bsm, 64);
   ctx->rtot = ctx->n64 + (int)rg_round_up(P, 64);
-  int nb = 8;
+  int nb = 32;  // blocks per batch: more systems per launch hide the Cholesky dependency chain
   if (const char* e = getenv("RG_NBLK")) nb = std::max(1, atoi(e));
   nb = std::min(nb, ctx->B_total);
   ctx->nblk_cap = nb;
@@ -299,13 +299,12 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     a.info = ctx->d_info;
     rg_launch_rowstats(st, a);
     rg_launch_assemble(st, a);
-    rg_launch_form(st, ctx->d_sum, msz, ctx->d_fold, msz, nseg, ctx->d_lambda, R0, ctx->d_bs, 0, nblk,
-                   n64, rtot, ctx->d_wk);
   }
   {
     StageTimer t(ctx, &ctx->tm.ms_chol);
-    rg_launch_chol_solve(st, ctx->d_wk, msz, nblk * nseg * R0, n64, rtot - n64, P, ctx->d_dinv,
-                         ctx->d_info + 1, &ctx->tm.n_chol_launches);
+    rg_launch_chol_solve_formed(st, ctx->d_sum, msz, ctx->d_fold, msz, nseg, ctx->d_lambda, R0, ctx->d_bs, 0,
+                                nblk, ctx->d_wk, msz, n64, rtot - n64, P, ctx->d_dinv, ctx->d_info + 1,
+                                &ctx->tm.n_chol_launches);
   }
   {
     StageTimer t(ctx, &ctx->tm.ms_pred);

@@ -141,6 +141,11 @@ void rg_launch_form(hipStream_t st, const double* sum, int64_t sum_stride, const
                     int n_fixed, int nouter, int n64, int rtot, double* wk);
 void rg_launch_chol_solve(hipStream_t st, double* mats, int64_t mat_stride, int batch, int n64,
                           int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch);
+void rg_launch_chol_solve_formed(hipStream_t st, const double* sum, int64_t sum_stride, const double* fold,
+                                 int64_t fold_stride, int nfold, const double* shift, int nshift,
+                                 const int32_t* d_n, int n_fixed, int nouter, double* mats,
+                                 int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
+                                 int32_t* info, int64_t* n_launch);
 void rg_launch_dgemm_nt(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                         int m, int n, int64_t k, double* C, int64_t ldc);
 // pred.hip

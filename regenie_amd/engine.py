@@ -44,7 +44,7 @@ class RgTiming(C.Structure):
 EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_w_rows", "rg_w_bytes",
            "rg_set_w_buffer", "rg_w_device_ptr", "rg_l0_blocks", "rg_sync", "rg_l0_get_w",
            "rg_l0_set_w", "rg_l1_qt", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8",
-           "rg_k_chol_solve", "rg_k_dgemm_nt"]
+           "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak"]
 
 
 def lib_path() -> str:
@@ -88,8 +88,18 @@ def load_library() -> C.CDLL:
                                     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rg_k_dgemm_nt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                   C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int64]
+    lib.rg_k_mfma_peak.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
     _LIB = lib
     return lib
+
+
+def mfma_peak(kind: int, iters: int = 2000) -> float:
+    """Measured register-only MFMA rate (kind 0: fp64 TFLOP/s, kind 1: i8 TOP/s)."""
+    out = C.c_double(0.0)
+    rc = load_library().rg_k_mfma_peak(kind, iters, C.byref(out))
+    if rc != 0:
+        raise RgError(rc, "rg_k_mfma_peak failed")
+    return out.value
 
 
 class RgError(RuntimeError):

@@ -1,6 +1,5 @@
 """Host-side prerequisites of the Step-1 hot path (tiny N x C / N x P fp64 work that stays on the CPU,
-SURVEY.md 8a row a23), for Python hosts of the C ABI (bench.py, examples).  Product code: does not
-import oracle/.  Mirrors, with file:line citations into the reference:
+SURVEY.md 8a row a23), for Python hosts of the C ABI (bench.py, examples).  Product code: never touches the oracle package.  Mirrors, with file:line citations into the reference:
   set_ridge_params   src/Regenie.cpp:1497-1508
   get_basis          src/Pheno.cpp:1660-1681 (getBasis)
   residualize_pheno  src/Pheno.cpp:1799-1834 (residualize_phenotypes)
