@@ -112,39 +112,51 @@ void rg_launch_bed_prep(hipStream_t st, const uint8_t* raw, int64_t raw_ld, int6
 
 // ---------------------------------------------------------------------------------------------
 // k_geno_xy: thread = one SNP row; workgroup = 256 rows x one chunk of positions (<= 4096, inside
-// one fold).  V columns are processed in groups of CG to keep the accumulators in registers.
+// one fold).  Per 256-position sub-chunk the packed tile (256 rows x 64 bytes) and the V tile
+// (CG columns x 256 positions) are staged through LDS with coalesced loads; V columns are processed
+// in groups of CG to keep the accumulators in registers.
 // part layout: [blk][chunk][row][2][Cv]   (0: sum g0*V, 1: sum miss*V)
-#define CG 8
+#define CG 4
+#define XP 80  // LDS row pitch of the packed tile: 64 data bytes + 16 (conflict-free 16-byte row reads)
 __global__ __launch_bounds__(256) void k_geno_xy(const uint8_t* pk, int64_t pk_ld,
                                                  int64_t pk_blk_stride, const int32_t* d_bs, int n128,
                                                  const double* V, int64_t Np, int Cv,
                                                  const int64_t* chunk_pos, const int64_t* chunk_len,
                                                  int nchunk, double* part) {
-  __shared__ double sV[CG][64];
+  __shared__ double sV[CG][256];
+  __shared__ __attribute__((aligned(16))) uint8_t sP[256 * XP];
   const int blk = blockIdx.z, ch = blockIdx.y;
-  const int row = blockIdx.x * 256 + threadIdx.x;
+  const int row0 = blockIdx.x * 256;
+  const int row = row0 + threadIdx.x;
   const int bs = d_bs[blk];
   const int64_t p0 = chunk_pos[ch], plen = chunk_len[ch];
-  const uint8_t* r = pk + (int64_t)blk * pk_blk_stride + (int64_t)row * pk_ld + p0 / 4;
+  const uint8_t* base = pk + (int64_t)blk * pk_blk_stride + p0 / 4;
   double* outp = part + ((((int64_t)blk * nchunk + ch) * n128 + row) * 2) * Cv;
   const bool live = row < bs;
   for (int c0 = 0; c0 < Cv; c0 += CG) {
     double a0[CG], am[CG];
 #pragma unroll
     for (int c = 0; c < CG; ++c) a0[c] = am[c] = 0.0;
-    for (int64_t q = 0; q < plen; q += 64) {
+    for (int64_t q = 0; q < plen; q += 256) {
+      const int npos = (int)min((int64_t)256, plen - q);  // multiple of 64
       __syncthreads();
-      for (int t = threadIdx.x; t < CG * 64; t += 256) {
-        const int c = t >> 6, i = t & 63;
-        sV[c][i] = (c0 + c < Cv) ? V[(int64_t)(c0 + c) * Np + p0 + q + i] : 0.0;
+      for (int t = threadIdx.x; t < CG * 256; t += 256) {
+        const int c = t >> 8, i = t & 255;
+        sV[c][i] = (c0 + c < Cv && i < npos) ? V[(int64_t)(c0 + c) * Np + p0 + q + i] : 0.0;
+      }
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 64 + (threadIdx.x >> 2), piece = (threadIdx.x & 3) * 16;
+        uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (row0 + r < bs && piece * 4 < npos)
+          v = *reinterpret_cast<const uint4*>(base + (int64_t)(row0 + r) * pk_ld + q / 4 + piece);
+        *reinterpret_cast<uint4*>(sP + r * XP + piece) = v;
       }
       __syncthreads();
       if (live) {
-        const uint4 w4 = *reinterpret_cast<const uint4*>(r + q / 4);
-        const unsigned ws[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const unsigned w = ws[d];
+#pragma unroll 1
+        for (int d = 0; d < 16; ++d) {
+          const unsigned w = *reinterpret_cast<const unsigned*>(sP + threadIdx.x * XP + d * 4);
           if (w == 0xFFFFFFFFu) continue;  // 16 samples with dosage 0
 #pragma unroll
           for (int i = 0; i < 16; ++i) {

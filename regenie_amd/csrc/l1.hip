@@ -200,7 +200,7 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
   const int n64 = (int)rg_round_up(L, CT), rtot = n64 + CT, T = n64 / CT;
   const int64_t msz = (int64_t)rtot * n64;
   const int nsys = K * R1;
-  const int nch = ctx->xy_nchunk;
+  const int nch = ctx->n_c256;
   const int NPART = R1MAX * 3 + 2;
 
   double *d_fold = nullptr, *d_sum = nullptr, *d_wk = nullptr, *d_dinv = nullptr, *d_tau = nullptr,
@@ -230,8 +230,8 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
     rg_launch_chol_solve_formed(st, d_sum, 0, d_fold, msz, K, d_tau, R1, nullptr, L, 1, d_wk, msz, n64, CT, 1,
                                 d_dinv, ctx->d_info + 1, &ctx->tm.n_chol_launches);
     if (ctx->timing) { hipEventRecord(e1, st); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ctx->tm.ms_l1_chol += ms; hipEventRecord(e0, st); }
-    hipLaunchKernelGGL(k_l1_cv, dim3(nch), dim3(256), 0, st, R, d_wk, msz, R1, ctx->d_chunk_seg,
-                       ctx->d_chunk_pos, ctx->d_chunk_len, d_part);
+    hipLaunchKernelGGL(k_l1_cv, dim3(nch), dim3(256), 0, st, R, d_wk, msz, R1, ctx->d_c256_seg,
+                       ctx->d_c256_pos, ctx->d_c256_len, d_part);
     RG_HIP(hipMemcpyAsync(hpart.data(), d_part, sizeof(double) * hpart.size(), hipMemcpyDeviceToHost, st));
     RG_HIP(hipStreamSynchronize(st));
     // cumsum_values (Step1_Models.cpp:854-858): fixed-order host reduction of the chunk partials
@@ -258,7 +258,7 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
     best_out[p] = best;
     hipMemsetAsync(d_pred, 0, sizeof(double) * (size_t)nchr * ctx->N, st);
     hipLaunchKernelGGL(k_l1_pred, dim3(nch), dim3(256), sizeof(double) * L, st, R, d_wk, msz, R1, best,
-                       ctx->d_chunk_seg, ctx->d_chunk_pos, ctx->d_chunk_len, d_col0, nchr,
+                       ctx->d_c256_seg, ctx->d_c256_pos, ctx->d_c256_len, d_col0, nchr,
                        ctx->d_cidx, ctx->N, d_pred);
     RG_HIP(hipMemcpyAsync(pred_out + (int64_t)p * nchr * ctx->N, d_pred,
                           sizeof(double) * (size_t)nchr * ctx->N, hipMemcpyDeviceToHost, st));

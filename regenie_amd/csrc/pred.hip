@@ -39,11 +39,16 @@ __global__ __launch_bounds__(256) void k_beta_post(PredArgs a) {
 // ---- predictions -----------------------------------------------------------------------------------------------
 // grid (nchunk, P, nblk); 256 threads, thread = 4 consecutive positions (one packed byte column).
 #define RMAX 8
-#define JT 256
+#define JT 128
 struct ChunkTab { const int32_t* seg; const int64_t* pos; const int64_t* len; int n; };
 
+// NR = number of ridge values carried in registers (5 for the default grid, 8 max).
+// The packed genotype tile (JT SNP rows x 1024 positions = 256 bytes per row) is staged through LDS
+// with coalesced 16-byte loads so the inner loop never waits on HBM.
+template <int NR>
 __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
-  __shared__ double sB[JT][RMAX];
+  __shared__ __attribute__((aligned(16))) uint8_t sP[JT][256 + 16];
+  __shared__ double sB[JT][NR];
   __shared__ double smu[JT];
   __shared__ double sred[4][RMAX][2];
   const int blk = blockIdx.z, p = blockIdx.y, ch = blockIdx.x;
@@ -55,34 +60,45 @@ __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
   const uint8_t* pk = a.pk + (int64_t)blk * a.pk_blk_stride;
   const double* mu = a.mu + (int64_t)blk * a.n128;
   const int col0 = a.blockid[blk] * R0;
-  double tsum[RMAX], tsq[RMAX];
+  double tsum[NR], tsq[NR];
 #pragma unroll
-  for (int r = 0; r < RMAX; ++r) tsum[r] = tsq[r] = 0.0;
+  for (int r = 0; r < NR; ++r) tsum[r] = tsq[r] = 0.0;
 
   for (int64_t sub = 0; sub < plen; sub += 1024) {
     const int64_t pos = p0 + sub + 4 * (int64_t)threadIdx.x;
     const bool live = (sub + 4 * (int64_t)threadIdx.x) < plen;
-    double acc[4][RMAX];
+    const int64_t nbytes = min((int64_t)256, (plen - sub) / 4);  // valid packed bytes per row in this tile
+    double acc[4][NR];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) acc[i][r] = 0.0;
+      for (int r = 0; r < NR; ++r) acc[i][r] = 0.0;
     for (int jt = 0; jt < bs; jt += JT) {
       __syncthreads();
-      {
+      if (threadIdx.x < JT) {
         const int j = jt + threadIdx.x;
-        for (int r = 0; r < RMAX; ++r)
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
           sB[threadIdx.x][r] = (r < R0 && j < bs)
               ? a.beta[(((int64_t)blk * nm + s * R0 + r) * a.P + p) * a.n64 + j] : 0.0;
         smu[threadIdx.x] = (j < bs) ? mu[j] : 0.0;
       }
+      {
+        const int c16 = (threadIdx.x & 15) * 16;
+#pragma unroll
+        for (int it = 0; it < JT / 16; ++it) {
+          const int row = it * 16 + (threadIdx.x >> 4);
+          uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+          if (jt + row < bs && c16 < nbytes)
+            v = *reinterpret_cast<const uint4*>(pk + (int64_t)(jt + row) * a.pk_ld + (p0 + sub) / 4 + c16);
+          *reinterpret_cast<uint4*>(&sP[row][c16]) = v;
+        }
+      }
       __syncthreads();
       if (live) {
         const int jn = min(JT, bs - jt);
-        const uint8_t* col = pk + (int64_t)jt * a.pk_ld + pos / 4;
         for (int t = 0; t < jn; ++t) {
-          const unsigned b = col[(int64_t)t * a.pk_ld];
-          if (b == 0xFFu) continue;
+          const unsigned b = sP[t][threadIdx.x];
           double g[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -90,7 +106,7 @@ __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
             g[i] = (code == 0u) ? 2.0 : ((code == 2u) ? 1.0 : ((code == 1u) ? smu[t] : 0.0));
           }
 #pragma unroll
-          for (int r = 0; r < RMAX; ++r) {
+          for (int r = 0; r < NR; ++r) {
             const double bt = sB[t][r];
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i][r] = fma(g[i], bt, acc[i][r]);
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
     if (live) {
       // covariate term and mask
 #pragma unroll
-      for (int r = 0; r < RMAX; ++r) {
+      for (int r = 0; r < NR; ++r) {
         if (r >= R0) break;
         const double* cb = a.cb + (((int64_t)blk * nm + s * R0 + r) * a.P + p) * a.C;
         double corr[4] = {0, 0, 0, 0};
@@ -125,7 +141,7 @@ __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
   }
   // block reduction of the running sums -> per-chunk partials
 #pragma unroll
-  for (int r = 0; r < RMAX; ++r) {
+  for (int r = 0; r < NR; ++r) {
     double x = tsum[r], y = tsq[r];
     for (int o = 32; o > 0; o >>= 1) {
       x += __shfl_down(x, o);
@@ -168,7 +184,8 @@ void rg_launch_l0_pred_impl(hipStream_t st, const PredArgs& a, const int32_t* ch
                             const int64_t* chunk_pos, const int64_t* chunk_len, int nchunk) {
   hipLaunchKernelGGL(k_beta_post, dim3(a.nseg * a.R0, a.nblk), dim3(256), 0, st, a);
   ChunkTab ct{chunk_seg, chunk_pos, chunk_len, nchunk};
-  hipLaunchKernelGGL(k_l0_pred, dim3(nchunk, a.P, a.nblk), dim3(256), 0, st, a, ct);
+  if (a.R0 <= 5) hipLaunchKernelGGL(k_l0_pred<5>, dim3(nchunk, a.P, a.nblk), dim3(256), 0, st, a, ct);
+  else hipLaunchKernelGGL(k_l0_pred<8>, dim3(nchunk, a.P, a.nblk), dim3(256), 0, st, a, ct);
   hipLaunchKernelGGL(k_l0_scale, dim3((unsigned)((a.Np / 4 + 255) / 256), a.R0 * a.P, a.nblk),
                      dim3(256), 0, st, a, nchunk);
 }

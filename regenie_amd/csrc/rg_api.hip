@@ -28,7 +28,8 @@ void free_all(rg_ctx* c) {
                   c->d_keptp, c->d_posc, c->d_zero, c->d_raw, c->d_pk, c->d_mu, c->d_nmiss,
                   c->d_xypart, c->d_chunk_seg, c->d_chunk_pos, c->d_chunk_len, c->d_S, c->d_F, c->d_Bm,
                   c->d_BQ, c->d_GYt, c->d_sc, c->d_fold, c->d_sum, c->d_wk, c->d_dinv, c->d_beta,
-                  c->d_cb, c->d_psum, c->d_info, c->d_bs, c->d_blockid};
+                  c->d_cb, c->d_psum, c->d_info, c->d_bs, c->d_blockid, c->d_c1k_seg, c->d_c1k_pos,
+                  c->d_c1k_len, c->d_c256_seg, c->d_c256_pos, c->d_c256_len};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->own_W && c->d_W) hipFree(c->d_W);
@@ -175,6 +176,24 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
       ctx->h_chunk_len.push_back(std::min<int64_t>(4096, sg.plen[f] - o));
     }
   ctx->xy_nchunk = (int)ctx->h_chunk_seg.size();
+  for (int pass = 0; pass < 2; ++pass) {
+    const int64_t step = pass == 0 ? 1024 : 256;
+    std::vector<int32_t> cs; std::vector<int64_t> cp, cl;
+    for (int f = 0; f < K; ++f)
+      for (int64_t o = 0; o < sg.plen[f]; o += step) {
+        cs.push_back(f); cp.push_back(sg.pos_start[f] + o); cl.push_back(std::min<int64_t>(step, sg.plen[f] - o));
+      }
+    int rc2;
+    if (pass == 0) {
+      ctx->n_c1k = (int)cs.size();
+      if ((rc2 = dev_upload(ctx, &ctx->d_c1k_seg, cs)) || (rc2 = dev_upload(ctx, &ctx->d_c1k_pos, cp)) ||
+          (rc2 = dev_upload(ctx, &ctx->d_c1k_len, cl))) return rc2;
+    } else {
+      ctx->n_c256 = (int)cs.size();
+      if ((rc2 = dev_upload(ctx, &ctx->d_c256_seg, cs)) || (rc2 = dev_upload(ctx, &ctx->d_c256_pos, cp)) ||
+          (rc2 = dev_upload(ctx, &ctx->d_c256_len, cl))) return rc2;
+    }
+  }
 
   int rc;
   if ((rc = dev_upload(ctx, &ctx->d_cidx, cidx))) return rc;
@@ -225,7 +244,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if ((rc = dev_alloc(ctx, &ctx->d_dinv, (size_t)nb * nseg * R0 * (n64 / 64) * 4096))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_beta, (size_t)nb * nseg * R0 * P * n64))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_cb, (size_t)nb * nseg * R0 * P * C))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->d_psum, (size_t)nb * ctx->xy_nchunk * P * 8 * 2))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_psum, (size_t)nb * ctx->n_c1k * P * 8 * 2))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_bs, (size_t)nb))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_blockid, (size_t)nb))) return rc;
   ctx->W_bytes = (int64_t)sizeof(double) * ctx->B_total * R0 * P * Np;
@@ -315,7 +334,7 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     pa.Bm = ctx->d_Bm; pa.wk = ctx->d_wk; pa.V = ctx->d_V; pa.maskp = ctx->d_maskp;
     pa.keptp = ctx->d_keptp; pa.bs = ctx->d_bs; pa.blockid = ctx->d_blockid; pa.neff = ctx->d_neff;
     pa.beta = ctx->d_beta; pa.cb = ctx->d_cb; pa.psum = ctx->d_psum; pa.W = ctx->d_W;
-    rg_launch_l0_pred_impl(st, pa, ctx->d_chunk_seg, ctx->d_chunk_pos, ctx->d_chunk_len, ctx->xy_nchunk);
+    rg_launch_l0_pred_impl(st, pa, ctx->d_c1k_seg, ctx->d_c1k_pos, ctx->d_c1k_len, ctx->n_c1k);
   }
   for (int b = 0; b < nblk; ++b) ctx->block_done[block_ids[b]] = 1;
   return RG_OK;

@@ -75,6 +75,10 @@ struct rg_ctx {
   int32_t xy_nchunk = 0;
   std::vector<int32_t> h_chunk_seg; std::vector<int64_t> h_chunk_pos, h_chunk_len;
   int32_t* d_chunk_seg = nullptr; int64_t* d_chunk_pos = nullptr; int64_t* d_chunk_len = nullptr;
+  // finer position chunk tables: 1024 positions (level-0 predictions), 256 (level-1 CV / predictions)
+  int32_t n_c1k = 0, n_c256 = 0;
+  int32_t* d_c1k_seg = nullptr; int64_t* d_c1k_pos = nullptr; int64_t* d_c1k_len = nullptr;
+  int32_t* d_c256_seg = nullptr; int64_t* d_c256_pos = nullptr; int64_t* d_c256_len = nullptr;
   int32_t* d_S = nullptr;        // [nblk][nseg][2*n128][2*n128] int32 stacked Gram
   double* d_F = nullptr;         // [nblk][nseg][n128][C]
   double* d_Bm = nullptr;        // [nblk][n128][C]
