@@ -129,6 +129,19 @@ void rg_launch_form(hipStream_t st, const double* sum, int64_t sum_stride, const
                      fold, fold_stride, nfold, shift, nshift, d_n, n_fixed, n64, rtot, wk);
 }
 
+// ---- XCD-affine work order -----------------------------------------------------------------------
+// MI355X dispatches workgroup id w to XCD (w % 8), each XCD with its own 4 MiB L2.  All `ngrp` work items
+// of one system share that system's panel rows, so system b is pinned to XCD (b % 8) and its items run
+// back to back there: id w -> xcd = w % 8, s = w / 8, system = (s / ngrp) * 8 + xcd, item = s % ngrp.
+// Only speed depends on the placement; the mapping is a bijection onto (system, item) for any dispatch.
+__device__ __forceinline__ bool xcd_affine(int w, int ngrp, int batch, int& b, int& g) {
+  const int xcd = w & 7, s = w >> 3;
+  b = (s / ngrp) * 8 + xcd;
+  g = s % ngrp;
+  return b < batch;
+}
+static inline unsigned xcd_affine_grid(int ngrp, int batch) { return (unsigned)(((batch + 7) / 8) * 8 * ngrp); }
+
 // ---- lazy "form": value of element (i,j) of system b = sum[o] - fold[o][f] + shift[r] on the diagonal ----
 // Every tile of a system is first touched exactly once during the first column group of the
 // factorization, so the systems are never materialised by a separate pass: the first-touch kernels
@@ -277,8 +290,10 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_str
 
 // ---- panel: L[t][k] = A[t][k] * Linv^T ---------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_chol_panel(double* mats, int64_t mat_stride, int n64, int k,
-                                                    const double* dinv, FormSrc fs) {
-  const int b = blockIdx.y, t = k + 1 + blockIdx.x;
+                                                    const double* dinv, int ngrp, int batch, FormSrc fs) {
+  int b, g;
+  if (!xcd_affine(blockIdx.x, ngrp, batch, b, g)) return;
+  const int t = k + 1 + g;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int i = lane & 15, q = lane >> 4;
@@ -333,10 +348,11 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* mats, int64_t mat_st
 // tiles of one tile column, so they share the B operand in L1.
 __global__ __launch_bounds__(256, 2) void k_chol_update(double* mats, int64_t mat_stride, int n64,
                                                         int Ttot, int c_lo, int c_hi, int ntile,
-                                                        int kc0, int nkc, FormSrc fs) {
-  const int b = blockIdx.y;
+                                                        int kc0, int nkc, int batch, FormSrc fs) {
+  int b, g;
+  if (!xcd_affine(blockIdx.x, (ntile + 3) / 4, batch, b, g)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int idx = blockIdx.x * 4 + wave, tc = c_lo;
+  int idx = g * 4 + wave, tc = c_lo;
   if (idx >= ntile) return;
   while (tc < c_hi && idx >= Ttot - tc) { idx -= Ttot - tc; ++tc; }
   const int tr = tc + idx;
@@ -366,23 +382,39 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(double* mats, int64_t ma
         for (int r = 0; r < 4; ++r)
           acc[m][n][r] = -C[(int64_t)(m * 16 + q + 4 * r) * n64 + n * 16 + i];
   }
+  // K loop in 16-deep chunks: 8 x 32-byte loads then 64 MFMAs (~4K cycles) per chunk.
   const int nk16 = nkc * 4;
-  for (int kc = 0; kc < nk16; ++kc) {
-    double4 av[4], bv[4];
+  auto load16 = [&](double4 (&av)[4], double4 (&bv)[4], int kc) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       av[m] = *reinterpret_cast<const double4*>(A + (int64_t)m * 16 * n64 + kc * 16);
       bv[m] = *reinterpret_cast<const double4*>(B + (int64_t)m * 16 * n64 + kc * 16);
     }
+  };
+  auto mma16 = [&](const double4 (&av)[4], const double4 (&bv)[4]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].x, bv[n].x, acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].y, bv[n].y, acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].z, bv[n].z, acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].w, bv[n].w, acc[m][n], 0, 0, 0);
-      }
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].x, bv[n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].y, bv[n].y, acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].z, bv[n].z, acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].w, bv[n].w, acc[m][n], 0, 0, 0);
+  };
+  // Measured: two waves per SIMD with plain per-chunk loads (45.3 ms/step) beat one wave per SIMD with the
+  // next chunk prefetched into a second register set (48.4 ms/step), so the simple form is kept.
+  for (int kc = 0; kc < nk16; ++kc) {
+    double4 a0[4], b0[4];
+    load16(a0, b0, kc);
+    mma16(a0, b0);
   }
 #pragma unroll
   for (int m = 0; m < 4; ++m)
@@ -469,24 +501,24 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
     const FormSrc& first = (src && k0 == 0) ? *src : off;
     for (int j = k0; j < k1; ++j) {
       if (j > k0) {  // narrow update of tile column j with the group's earlier columns
-        hipLaunchKernelGGL(k_chol_update, dim3((Ttot - j + 3) / 4, batch), dim3(256), 0, st, mats, mat_stride,
-                           n64, Ttot, j, j + 1, Ttot - j, k0, j - k0, first);
+        hipLaunchKernelGGL(k_chol_update, dim3(xcd_affine_grid((Ttot - j + 3) / 4, batch)), dim3(256), 0, st, mats,
+                           mat_stride, n64, Ttot, j, j + 1, Ttot - j, k0, j - k0, batch, first);
         ++nl;
       }
       hipLaunchKernelGGL(k_chol_diag, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, j, dinv, info,
                          (j == 0 && src) ? *src : off);
       ++nl;
       if (Ttot - 1 - j > 0) {
-        hipLaunchKernelGGL(k_chol_panel, dim3(Ttot - 1 - j, batch), dim3(256), 0, st, mats, mat_stride, n64,
-                           j, dinv, (j == 0 && src) ? *src : off);
+        hipLaunchKernelGGL(k_chol_panel, dim3(xcd_affine_grid(Ttot - 1 - j, batch)), dim3(256), 0, st, mats,
+                           mat_stride, n64, j, dinv, Ttot - 1 - j, batch, (j == 0 && src) ? *src : off);
         ++nl;
       }
     }
     if (k1 < T) {  // wide trailing update with the whole group (K = 64 * (k1 - k0))
       int ntile = 0;
       for (int c = k1; c < T; ++c) ntile += Ttot - c;
-      hipLaunchKernelGGL(k_chol_update, dim3((ntile + 3) / 4, batch), dim3(256), 0, st, mats, mat_stride, n64,
-                         Ttot, k1, T, ntile, k0, k1 - k0, first);
+      hipLaunchKernelGGL(k_chol_update, dim3(xcd_affine_grid((ntile + 3) / 4, batch)), dim3(256), 0, st, mats,
+                         mat_stride, n64, Ttot, k1, T, ntile, k0, k1 - k0, batch, first);
       ++nl;
     }
   }

@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Aggregates a rocprofv3 `--pmc X --kernel-trace --output-format csv` run: per kernel (name cut at '('),
+number of dispatches and the mean / total of each counter.  FETCH_SIZE / WRITE_SIZE are reported by
+rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced streams
+(MI355X_MICROARCH.md, HBM section), so the corrected read bytes are 2x -- both figures are printed."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+
+def main(d, out=None):
+    files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+    if not files:
+        print("no counter_collection.csv under", d)
+        return
+    agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
+            if not name.startswith("k_"):
+                continue
+            a = agg[name][r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    lines = ["| kernel | counter | dispatches | mean per dispatch | total |", "|---|---|---:|---:|---:|"]
+    for name in sorted(agg):
+        for c, (n, tot) in sorted(agg[name].items()):
+            lines.append("| %s | %s | %d | %.4g | %.4g |" % (name, c, n, tot / n, tot))
+    txt = "\n".join(lines)
+    print(txt)
+    if out:
+        open(out, "w").write(txt + "\n")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
