@@ -37,7 +37,8 @@ def _digest(paths) -> str:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "rg_internal.h"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "host", "rg_step1_main.cpp"),
+                                                      os.path.join(CSRC, "rg_internal.h"),
                                                       os.path.join(HERE, "..", "include", "rg_step1.h")]
     stamp = os.path.join(LIBDIR, "build.stamp")
     dig = _digest(deps)
@@ -63,6 +64,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    # C++ host driver (the reference's host language): `regenie-amd --step 1 ...`
+    bindir = os.path.join(HERE, "bin")
+    os.makedirs(bindir, exist_ok=True)
+    r = subprocess.run([hipcc, "-O2", "-std=c++17", os.path.join(HERE, "host", "rg_step1_main.cpp"), "-o",
+                        os.path.join(bindir, "regenie-amd"), "-L" + LIBDIR, "-lrg_step1_hip",
+                        "-Wl,-rpath,$ORIGIN/../lib"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("host driver build failed:\n%s\n%s" % (r.stdout, r.stderr))
     with open(stamp, "w") as fh:
         fh.write(dig)
     return LIB

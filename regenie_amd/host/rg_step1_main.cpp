@@ -1,0 +1,737 @@
+// regenie-amd: C++ host driver for `--step 1` on MI355X.
+//
+// Keeps the reference's command-line surface for Step 1 (src/Regenie.cpp:146-371 option table, subset
+// listed in SURVEY.md section 2 row 1) and its outputs (<out>.log, <out>_pred.list, <out>_<k>.loco,
+// optional <out>_<k>.prs / <out>_prs.list; src/Data.cpp:956-1129, :1795-1975) and calls the HIP library
+// through the C ABI of include/rg_step1.h for everything Data::level_0_calculations, ridge_level_1 and
+// make_predictions do.  Host-side prerequisites (text parsing, masks, covariate basis, phenotype
+// residualisation, fold / block bookkeeping, LOCO assembly, writers) follow the reference functions
+// cited next to each routine.  There is no CPU compute fallback for the hot path.
+//
+// Not yet served by the GPU library in this revision (explicit errors, never silent): --bt, --loocv,
+// --pgen/--bgen input, --gz, --split-l0/--run-l0/--run-l1.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <climits>
+#include <unistd.h>
+
+#include "../../include/rg_step1.h"
+
+namespace {
+
+const double MISSING = -999.0;  // Regenie.hpp:215
+
+struct Params {
+  int step = 0;
+  std::string bed, pheno_file, covar_file, out = "regenie_out";
+  std::vector<std::string> keep, remove, extract, exclude, pheno_cols, covar_cols;
+  int bsize = 0, cv_folds = 5, n_ridge_l0 = 5, n_ridge_l1 = 5, nchrom = 23, threads = 0;
+  bool bt = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
+       print_prs = false, force_step1 = false, lowmem = false, force_qt = false;
+  std::vector<double> setl0, setl1;
+  int device = 0;
+};
+
+struct Log {  // mstream (Regenie.hpp:120-142): tee to stdout and <out>.log
+  std::ofstream f;
+  template <class T>
+  Log& operator<<(const T& v) { std::cout << v; if (f.is_open()) f << v; return *this; }
+  Log& operator<<(std::ostream& (*m)(std::ostream&)) { std::cout << m; if (f.is_open()) f << m; return *this; }
+};
+Log sout;
+
+std::vector<std::string> split_ws(const std::string& s) {
+  std::vector<std::string> out;
+  std::istringstream is(s);
+  std::string t;
+  while (is >> t) out.push_back(t);
+  return out;
+}
+std::vector<std::string> split_char(const std::string& s, char c) {
+  std::vector<std::string> out;
+  std::string t;
+  std::istringstream is(s);
+  while (std::getline(is, t, c)) if (!t.empty()) out.push_back(t);
+  return out;
+}
+
+int chr_str_to_int(std::string s, int nchrom) {  // Regenie.cpp:1583-1594
+  if (s.compare(0, 3, "chr") == 0) s = s.substr(3);
+  if (!s.empty() && isdigit((unsigned char)s[0])) {
+    int c = atoi(s.c_str());
+    if (c >= 1 && c <= nchrom) return c;
+  } else if (s == "X" || s == "XY" || s == "Y" || s == "PAR1" || s == "PAR2") return nchrom;
+  return -1;
+}
+
+double convert_double(const std::string& v) {  // Regenie.cpp:1663-1675
+  if (v == "NA" || v == "nan" || v == "inf") return MISSING;
+  char* end = nullptr;
+  double d = strtod(v.c_str(), &end);
+  if (end == v.c_str()) throw std::runtime_error("could not convert value to double: '" + v + "'");
+  return d;
+}
+
+std::string cpp_double(double v) {  // default ostream formatting (precision 6)
+  std::ostringstream o;
+  o << v;
+  return o.str();
+}
+
+std::set<std::string> read_id_files(const std::vector<std::string>& files) {  // Geno.cpp:1382-1441
+  std::set<std::string> ids;
+  for (auto& fn : files) {
+    std::ifstream f(fn);
+    if (!f) throw std::runtime_error("cannot open file : " + fn);
+    std::string line;
+    while (std::getline(f, line)) {
+      auto t = split_ws(line);
+      if (t.size() < 2) throw std::runtime_error("incorrectly formatted file: " + fn);
+      ids.insert(t[0] + "_" + t[1]);
+    }
+  }
+  return ids;
+}
+std::set<std::string> read_snp_files(const std::vector<std::string>& files) {
+  std::set<std::string> ids;
+  for (auto& fn : files) {
+    std::ifstream f(fn);
+    if (!f) throw std::runtime_error("cannot open file : " + fn);
+    std::string line;
+    while (std::getline(f, line)) {
+      auto t = split_ws(line);
+      if (!t.empty()) ids.insert(t[0]);
+    }
+  }
+  return ids;
+}
+
+// symmetric eigen-decomposition (cyclic Jacobi), ascending eigenvalues; n is the covariate count
+void jacobi_eigh(std::vector<double> A, int n, std::vector<double>& d, std::vector<double>& V) {
+  V.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) off += A[(size_t)p * n + q] * A[(size_t)p * n + q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[(size_t)p * n + q];
+        if (std::fabs(apq) < 1e-300) continue;
+        const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+          A[(size_t)k * n + p] = c * akp - s * akq;
+          A[(size_t)k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+          A[(size_t)p * n + k] = c * apk - s * aqk;
+          A[(size_t)q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+          V[(size_t)k * n + p] = c * vkp - s * vkq;
+          V[(size_t)k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  d.resize(n);
+  for (int i = 0; i < n; ++i) d[i] = A[(size_t)i * n + i];
+  std::vector<int> idx(n);
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  std::sort(idx.begin(), idx.end(), [&](int a, int b) { return d[a] < d[b]; });
+  std::vector<double> d2(n), V2((size_t)n * n);
+  for (int j = 0; j < n; ++j) {
+    d2[j] = d[idx[j]];
+    for (int k = 0; k < n; ++k) V2[(size_t)k * n + j] = V[(size_t)k * n + idx[j]];
+  }
+  d.swap(d2);
+  V.swap(V2);
+}
+
+[[noreturn]] void usage_error(const std::string& m) { throw std::runtime_error(m); }
+
+Params parse_args(int argc, char** argv) {
+  Params p;
+  auto need = [&](int& i) -> std::string {
+    if (i + 1 >= argc) usage_error(std::string("option '") + argv[i] + "' needs a value");
+    return argv[++i];
+  };
+  auto list = [&](std::vector<std::string>& dst, const std::string& v) {
+    for (auto& s : split_char(v, ',')) dst.push_back(s);
+  };
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a == "--step") p.step = atoi(need(i).c_str());
+    else if (a == "--bed") p.bed = need(i);
+    else if (a == "--phenoFile" || a == "--p") p.pheno_file = need(i);
+    else if (a == "--covarFile" || a == "--c") p.covar_file = need(i);
+    else if (a == "--phenoCol" || a == "--phenoColList") list(p.pheno_cols, need(i));
+    else if (a == "--covarCol" || a == "--covarColList") list(p.covar_cols, need(i));
+    else if (a == "--keep") list(p.keep, need(i));
+    else if (a == "--remove") list(p.remove, need(i));
+    else if (a == "--extract") list(p.extract, need(i));
+    else if (a == "--exclude") list(p.exclude, need(i));
+    else if (a == "--bsize" || a == "--b") p.bsize = atoi(need(i).c_str());
+    else if (a == "--cv") p.cv_folds = atoi(need(i).c_str());
+    else if (a == "--l0") p.n_ridge_l0 = atoi(need(i).c_str());
+    else if (a == "--l1") p.n_ridge_l1 = atoi(need(i).c_str());
+    else if (a == "--setl0") { for (auto& s : split_char(need(i), ',')) p.setl0.push_back(atof(s.c_str())); }
+    else if (a == "--setl1") { for (auto& s : split_char(need(i), ',')) p.setl1.push_back(atof(s.c_str())); }
+    else if (a == "--out" || a == "--o") p.out = need(i);
+    else if (a == "--threads") p.threads = atoi(need(i).c_str());
+    else if (a == "--nauto") p.nchrom = atoi(need(i).c_str()) + 1;
+    else if (a == "--device") p.device = atoi(need(i).c_str());
+    else if (a == "--lowmem-prefix") { need(i); p.lowmem = true; }
+    else if (a == "--qt") p.bt = false;
+    else if (a == "--bt") p.bt = true;
+    else if (a == "--loocv") p.loocv = true;
+    else if (a == "--strict") p.strict = true;
+    else if (a == "--ref-first") p.ref_first = true;
+    else if (a == "--use-relative-path") p.use_rel_path = true;
+    else if (a == "--print-prs") p.print_prs = true;
+    else if (a == "--force-step1") p.force_step1 = true;
+    else if (a == "--force-qt") p.force_qt = true;
+    else if (a == "--lowmem") p.lowmem = true;
+    else if (a == "--gz") usage_error("--gz is not available in this build (as in reference builds without Boost Iostreams)");
+    else if (a == "--pgen" || a == "--bgen") usage_error(a + " input is not served by the GPU path yet; use --bed");
+    else if (a == "--split-l0" || a == "--run-l0" || a == "--run-l1")
+      usage_error(a + ": file-based level-0 splitting is replaced by multi-GPU block sharding in this build");
+    else usage_error("unrecognised option '" + a + "'");
+  }
+  if (p.step != 1) usage_error("specify which mode regenie should be running using option --step (only --step 1 is served).");
+  if (p.bed.empty()) usage_error("must specify --bed");
+  if (p.pheno_file.empty()) usage_error("option '--phenoFile' is required.");
+  if (p.bsize < 1) usage_error("must specify the block size using '--bsize'.");
+  if (p.bt) usage_error("--bt (logistic level 1) is not served by the GPU path in this revision");
+  if (p.loocv) usage_error("--loocv is not served by the GPU path in this revision");
+  if (p.cv_folds < 2) usage_error("number of CV folds must be at least 2");
+  return p;
+}
+
+struct Run {
+  Params p;
+  // genotype meta
+  std::vector<std::string> fam_ids;      // FID_IID, file order
+  std::vector<int> snp_chrom;            // kept variants
+  std::vector<int64_t> snp_offset;
+  std::vector<int> chr_read;             // chromosomes in file order
+  int64_t n_file = 0, bpr = 0;
+  // samples
+  std::vector<uint8_t> ind_ignore, ain;  // N_file, N
+  std::vector<std::string> ids;          // kept, file order
+  int64_t N = 0, n_analyzed = 0;
+  // phenotypes / covariates
+  std::vector<std::string> pheno_names;
+  int P = 0, C = 0;
+  std::vector<double> Y, X, neff, scale_Y;  // col-major N x P, N x C
+  std::vector<uint8_t> mask;                // col-major N x P
+};
+
+void read_bim_fam(Run& r) {  // Geno.cpp:518-610, :643-690, :1128-1220
+  const Params& p = r.p;
+  {
+    std::string fn = p.bed + ".fam";
+    std::ifstream f(fn);
+    if (!f) throw std::runtime_error("cannot open file : " + fn);
+    sout << std::left << std::setw(20) << " * fam" << ": [" << fn << "] ";
+    std::string line;
+    std::set<std::string> seen;
+    while (std::getline(f, line)) {
+      auto t = split_ws(line);
+      if (t.size() < 6) throw std::runtime_error("incorrectly formatted fam file at line " + std::to_string(r.fam_ids.size() + 1));
+      std::string id = t[0] + "_" + t[1];
+      if (!seen.insert(id).second) throw std::runtime_error("duplicate individual in fam file : FID_IID=" + id);
+      if (t[4] != "0" && t[4] != "1" && t[4] != "2") throw std::runtime_error("unrecognized sex code in file : '" + t[4] + "'");
+      r.fam_ids.push_back(id);
+    }
+    r.n_file = (int64_t)r.fam_ids.size();
+    sout << "n_samples = " << r.n_file << "\n";
+  }
+  std::set<std::string> ext, exc;
+  if (!p.extract.empty()) ext = read_snp_files(p.extract);
+  if (!p.exclude.empty()) exc = read_snp_files(p.exclude);
+  {
+    std::string fn = p.bed + ".bim";
+    std::ifstream f(fn);
+    if (!f) throw std::runtime_error("cannot open file : " + fn);
+    sout << std::left << std::setw(20) << " * bim" << ": [" << fn << "] ";
+    std::string line;
+    int64_t lineno = 0;
+    int minchr = 0;
+    while (std::getline(f, line)) {
+      auto t = split_ws(line);
+      if (t.size() < 6) throw std::runtime_error("incorrectly formatted bim file at line " + std::to_string(lineno + 1));
+      int c = chr_str_to_int(t[0], p.nchrom);
+      if (c == -1) throw std::runtime_error("unknown chromosome code in bim file at line " + std::to_string(lineno + 1));
+      if (r.chr_read.empty() || c != r.chr_read.back()) {
+        r.chr_read.push_back(c);
+        if (c <= minchr) throw std::runtime_error("chromosomes in bim file are not in ascending order.");
+        minchr = c;
+      }
+      bool keep = true;
+      if (!p.extract.empty() && !ext.count(t[1])) keep = false;
+      if (!p.exclude.empty() && exc.count(t[1])) keep = false;
+      if (keep) { r.snp_chrom.push_back(c); r.snp_offset.push_back(lineno); }
+      ++lineno;
+    }
+    sout << "n_snps = " << lineno << "\n";
+    if (!p.extract.empty()) sout << "   -keeping variants specified by --extract\n";
+    if (!p.exclude.empty()) sout << "   -removing variants specified by --exclude\n";
+    if (r.snp_chrom.empty()) throw std::runtime_error("no variant left to include in analysis.");
+    if (!p.extract.empty() || !p.exclude.empty())
+      sout << "   -number of variants remaining in the analysis = " << r.snp_chrom.size() << "\n";
+  }
+  if (r.snp_chrom.size() > 1000000 && !p.force_step1)  // Data.cpp:173-175
+    throw std::runtime_error("it is not recommened to use more than 1M variants in step 1 (use --force-step1 to override)");
+  {
+    std::string fn = p.bed + ".bed";
+    std::ifstream f(fn, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open file : " + fn);
+    unsigned char magic[3];
+    f.read((char*)magic, 3);
+    if (magic[0] != 0x6c || magic[1] != 0x1b || magic[2] != 0x01) throw std::runtime_error("invalid bed file format.");
+    sout << std::left << std::setw(20) << " * bed" << ": [" << fn << "]\n";
+    r.bpr = (r.n_file + 3) / 4;
+  }
+  // --keep / --remove (Geno.cpp:1263-1341)
+  r.ind_ignore.assign(r.n_file, 0);
+  if (!p.remove.empty()) {
+    auto s = read_id_files(p.remove);
+    sout << "   -removing individuals specified by --remove\n";
+    for (int64_t i = 0; i < r.n_file; ++i) r.ind_ignore[i] = s.count(r.fam_ids[i]) ? 1 : 0;
+  } else if (!p.keep.empty()) {
+    auto s = read_id_files(p.keep);
+    sout << "   -keeping only individuals specified by --keep\n";
+    for (int64_t i = 0; i < r.n_file; ++i) r.ind_ignore[i] = s.count(r.fam_ids[i]) ? 0 : 1;
+  }
+  for (int64_t i = 0; i < r.n_file; ++i)
+    if (!r.ind_ignore[i]) r.ids.push_back(r.fam_ids[i]);
+  r.N = (int64_t)r.ids.size();
+  if (r.N == 0) throw std::runtime_error("no samples remaining in the analysis.");
+  if (r.N != r.n_file) sout << "   -number of genotyped individuals remaining in the analysis = " << r.N << "\n";
+}
+
+void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841, :1903-1935
+  const Params& p = r.p;
+  const int64_t N = r.N;
+  std::map<std::string, int64_t> idx;
+  for (int64_t i = 0; i < N; ++i) idx[r.ids[i]] = i;
+  std::vector<uint8_t> in_pheno(N, 0), in_cov(N, p.covar_file.empty() ? 1 : 0);
+  {
+    std::ifstream f(p.pheno_file);
+    if (!f) throw std::runtime_error("cannot open file : " + p.pheno_file);
+    sout << std::left << std::setw(20) << " * phenotypes" << ": [" << p.pheno_file << "] ";
+    std::string line;
+    std::getline(f, line);
+    auto hdr = split_ws(line);
+    if (hdr.size() < 2) throw std::runtime_error("header of phenotype file has too few columns.");
+    if (hdr[0] != "FID" || hdr[1] != "IID") throw std::runtime_error("header of phenotype file must start with: FID IID.");
+    std::set<std::string> want(p.pheno_cols.begin(), p.pheno_cols.end());
+    std::vector<int> keep_cols;
+    for (size_t j = 2; j < hdr.size(); ++j)
+      if (want.empty() || want.count(hdr[j])) { keep_cols.push_back((int)j); r.pheno_names.push_back(hdr[j]); }
+    r.P = (int)keep_cols.size();
+    if (r.P < 1) throw std::runtime_error("need at least one phenotype.");
+    sout << "n_pheno = " << r.P << "\n";
+    const bool strict = p.strict || r.P == 1;  // Pheno.cpp:198
+    if (strict) sout << "   -dropping observations with missing values at any of the phenotypes\n";
+    else sout << "   -keeping and mean-imputing missing observations (done for each trait)\n";
+    r.Y.assign((size_t)N * r.P, 0.0);
+    r.mask.assign((size_t)N * r.P, 1);
+    while (std::getline(f, line)) {
+      auto t = split_ws(line);
+      if (t.empty()) continue;
+      if (t.size() != hdr.size()) throw std::runtime_error("incorrectly formatted phenotype file.");
+      auto it = idx.find(t[0] + "_" + t[1]);
+      if (it == idx.end()) continue;
+      const int64_t i = it->second;
+      if (in_pheno[i]) throw std::runtime_error("individual appears more than once in phenotype file: FID=" + t[0] + " IID=" + t[1]);
+      in_pheno[i] = 1;
+      bool all_miss = true;
+      for (int q = 0; q < r.P; ++q) {
+        const double v = convert_double(t[keep_cols[q]]);
+        r.Y[(size_t)q * N + i] = v;
+        if (v != MISSING) all_miss = false;
+        else if (strict) {
+          for (int q2 = 0; q2 < r.P; ++q2) r.mask[(size_t)q2 * N + i] = 0;
+          all_miss = true;
+          break;
+        }
+      }
+      if (all_miss) in_pheno[i] = 0;
+    }
+    for (int q = 0; q < r.P; ++q) {
+      int64_t n = 0;
+      for (int64_t i = 0; i < N; ++i) { r.mask[(size_t)q * N + i] &= in_pheno[i]; n += r.mask[(size_t)q * N + i]; }
+      if (n == 0) throw std::runtime_error("all individuals have missing/invalid values for phenotype '" + r.pheno_names[q] + "'.");
+    }
+    int64_t np = 0;
+    for (int64_t i = 0; i < N; ++i) np += in_pheno[i];
+    sout << "   -number of phenotyped individuals " << (strict ? "with no missing data" : "") << " = " << np << "\n";
+  }
+  int ncols = 1;
+  std::vector<double> Xraw;  // col-major N x ncols
+  if (!p.covar_file.empty()) {
+    std::ifstream f(p.covar_file);
+    if (!f) throw std::runtime_error("cannot open file : " + p.covar_file);
+    sout << std::left << std::setw(20) << " * covariates" << ": [" << p.covar_file << "] ";
+    std::string line;
+    std::getline(f, line);
+    auto hdr = split_ws(line);
+    if (hdr.size() < 2 || hdr[0] != "FID" || hdr[1] != "IID") throw std::runtime_error("header of covariate file must start with: FID IID.");
+    std::set<std::string> want(p.covar_cols.begin(), p.covar_cols.end());
+    std::vector<int> kc;
+    for (size_t j = 2; j < hdr.size(); ++j)
+      if (want.empty() || want.count(hdr[j])) kc.push_back((int)j);
+    ncols = 1 + (int)kc.size();
+    sout << "n_cov = " << kc.size() << "\n";
+    Xraw.assign((size_t)N * ncols, 0.0);
+    for (int64_t i = 0; i < N; ++i) Xraw[i] = 1.0;
+    while (std::getline(f, line)) {
+      auto t = split_ws(line);
+      if (t.empty()) continue;
+      auto it = idx.find(t[0] + "_" + t[1]);
+      if (it == idx.end()) continue;
+      const int64_t i = it->second;
+      if (in_cov[i]) throw std::runtime_error("individual appears more than once in covariate file: FID=" + t[0] + " IID=" + t[1]);
+      in_cov[i] = 1;
+      for (size_t c = 0; c < kc.size(); ++c) {
+        const double v = convert_double(t[kc[c]]);
+        Xraw[(size_t)(1 + c) * N + i] = v;
+        if (v == MISSING) { in_cov[i] = 0; break; }
+      }
+    }
+    int64_t nc = 0;
+    for (int64_t i = 0; i < N; ++i) nc += in_cov[i];
+    if (nc == 0) throw std::runtime_error("none of the individuals have covariate data (check sample IDs across files)");
+    sout << "   -number of individuals with covariate data = " << nc << "\n";
+  } else {
+    Xraw.assign((size_t)N, 1.0);
+  }
+  // masks (Pheno.cpp:101, :810-841)
+  const bool strict = p.strict || r.P == 1;
+  r.ain.assign(N, 0);
+  r.n_analyzed = 0;
+  for (int64_t i = 0; i < N; ++i) {
+    bool any = false, all = true;
+    for (int q = 0; q < r.P; ++q) { any |= r.mask[(size_t)q * N + i] != 0; all &= r.mask[(size_t)q * N + i] != 0; }
+    r.ain[i] = (in_pheno[i] && in_cov[i] && (strict ? all : any)) ? 1 : 0;
+    r.n_analyzed += r.ain[i];
+  }
+  if (r.n_analyzed < 1) throw std::runtime_error("sample size cannot be < 1.");
+  sout << " * number of individuals used in analysis = " << r.n_analyzed << "\n";
+  if (ncols >= N) throw std::runtime_error("Number of covariates is greater than sample size!");
+  r.neff.assign(r.P, 0.0);
+  for (int q = 0; q < r.P; ++q)
+    for (int64_t i = 0; i < N; ++i) {
+      r.mask[(size_t)q * N + i] &= r.ain[i];
+      r.Y[(size_t)q * N + i] *= r.ain[i];
+      r.neff[q] += r.mask[(size_t)q * N + i];
+    }
+  for (int c = 0; c < ncols; ++c)
+    for (int64_t i = 0; i < N; ++i) Xraw[(size_t)c * N + i] *= (r.ain[i] && in_cov[i]) ? 1.0 : 0.0;
+  // pheno_impute_miss (QT): missing -> mean over analysed non-missing, then mask
+  for (int q = 0; q < r.P; ++q) {
+    double total = 0.0, ns = 0.0;
+    std::set<double> distinct;
+    for (int64_t i = 0; i < N; ++i) {
+      const double v = r.Y[(size_t)q * N + i];
+      if (v != MISSING) { total += v; if (r.ain[i]) { ns += 1.0; if (distinct.size() < 3) distinct.insert(v); } }
+    }
+    if (distinct.size() <= 2 && !p.force_qt)  // Pheno.cpp:907-925
+      throw std::runtime_error("phenotype '" + r.pheno_names[q] + "' has very few unique values (=" + std::to_string(distinct.size()) + "). If you really want to analyze it as a QT, use --force-qt.");
+    for (int64_t i = 0; i < N; ++i) {
+      double& v = r.Y[(size_t)q * N + i];
+      if (v == MISSING) v = total / ns;
+      v *= r.mask[(size_t)q * N + i];
+    }
+  }
+  // getBasis (Pheno.cpp:1660-1681)
+  std::vector<double> xtx((size_t)ncols * ncols, 0.0), d, V;
+  for (int a = 0; a < ncols; ++a)
+    for (int b = a; b < ncols; ++b) {
+      double s = 0.0;
+      for (int64_t i = 0; i < N; ++i) s += Xraw[(size_t)a * N + i] * Xraw[(size_t)b * N + i];
+      xtx[(size_t)a * ncols + b] = xtx[(size_t)b * ncols + a] = s;
+    }
+  jacobi_eigh(xtx, ncols, d, V);
+  int nz = 0;
+  for (int j = 0; j < ncols; ++j) nz += d[j] > d[ncols - 1] * 1e-15;
+  r.C = nz;
+  r.X.assign((size_t)N * nz, 0.0);
+  for (int j = 0; j < nz; ++j) {
+    const int src = ncols - nz + j;
+    const double inv = 1.0 / std::sqrt(d[src]);
+    for (int c = 0; c < ncols; ++c) {
+      const double v = V[(size_t)c * ncols + src] * inv;
+      for (int64_t i = 0; i < N; ++i) r.X[(size_t)j * N + i] += Xraw[(size_t)c * N + i] * v;
+    }
+  }
+  // residualize_phenotypes (Pheno.cpp:1799-1834)
+  sout << "   -residualizing and scaling phenotypes...";
+  r.scale_Y.assign(r.P, 1.0);
+  for (int q = 0; q < r.P; ++q) {
+    std::vector<double> beta(nz, 0.0);
+    for (int j = 0; j < nz; ++j)
+      for (int64_t i = 0; i < N; ++i) beta[j] += r.Y[(size_t)q * N + i] * r.X[(size_t)j * N + i];
+    double ss = 0.0;
+    for (int64_t i = 0; i < N; ++i) {
+      double fit = 0.0;
+      for (int j = 0; j < nz; ++j) fit += r.X[(size_t)j * N + i] * beta[j];
+      double& y = r.Y[(size_t)q * N + i];
+      y -= fit * r.mask[(size_t)q * N + i];
+      ss += y * y;
+    }
+    r.scale_Y[q] = std::sqrt(ss) / std::sqrt(r.neff[q] - nz);
+    if (r.scale_Y[q] < 1e-6) throw std::runtime_error("phenotype '" + r.pheno_names[q] + "' has sd=0.");
+    for (int64_t i = 0; i < N; ++i) r.Y[(size_t)q * N + i] /= r.scale_Y[q];
+  }
+  sout << "done\n";
+}
+
+std::string get_fullpath(const std::string& f) {  // Data.cpp:1150-1194
+  char buf[PATH_MAX];
+  if (realpath(f.c_str(), buf)) return buf;
+  if (!f.empty() && f[0] == '/') return f;
+  if (getcwd(buf, sizeof(buf))) return std::string(buf) + "/" + f;
+  return f;
+}
+
+void check(rg_ctx* ctx, int rc) {
+  if (rc != 0) throw std::runtime_error(rg_last_error(ctx));
+}
+
+int run(int argc, char** argv) {
+  Run r;
+  r.p = parse_args(argc, argv);
+  const Params& p = r.p;
+  sout.f.open(p.out + ".log");
+  auto t_start = std::chrono::steady_clock::now();
+  sout << "              |=============================|\n              |   REGENIE-AMD (step 1, HIP)  |\n              |=============================|\n\n";
+  sout << "Log of output saved in file : " << p.out << ".log\n\nOptions in effect:\n";
+  for (int i = 1; i < argc; ++i) sout << (argv[i][0] == '-' && argv[i][1] == '-' ? "  " : " ") << argv[i] << (i + 1 < argc && argv[i + 1][0] == '-' ? " \\\n" : "");
+  sout << "\n\nFitting null model\n";
+  read_bim_fam(r);
+  read_pheno_cov(r);
+  const int64_t N = r.N;
+  const int P = r.P;
+
+  // set_blocks (Data.cpp:311-398)
+  std::map<int, int> chr_nsnp;
+  for (int c : r.snp_chrom) chr_nsnp[c]++;
+  struct Blk { int chrom; int64_t start; int bs; };
+  std::vector<Blk> blocks;
+  {
+    int64_t pos = 0;
+    for (int c : r.chr_read) {
+      const int n = chr_nsnp.count(c) ? chr_nsnp[c] : 0;
+      const int nb = (n + p.bsize - 1) / p.bsize;
+      for (int bb = 0; bb < nb; ++bb) blocks.push_back({c, pos + (int64_t)bb * p.bsize, std::min(p.bsize, n - bb * p.bsize)});
+      pos += n;
+    }
+  }
+  const int B = (int)blocks.size();
+  if (B == 0) throw std::runtime_error("total number of blocks must be > 0.");
+  const int64_t M = (int64_t)r.snp_chrom.size();
+  std::vector<double> h0 = p.setl0, h1 = p.setl1;
+  auto grid = [](int n) {  // set_ridge_params (Regenie.cpp:1497-1508)
+    if (n < 2) throw std::runtime_error("number of ridge parameters must be at least 2 (=" + std::to_string(n) + ")");
+    std::vector<double> v(n);
+    for (int i = 0; i < n; ++i) v[i] = (double)i / (n - 1);
+    v[0] = 0.01; v[n - 1] = 0.99;
+    return v;
+  };
+  if (h0.empty()) h0 = grid(p.n_ridge_l0);
+  if (h1.empty()) h1 = grid(p.n_ridge_l1);
+  const int R0 = (int)h0.size(), R1 = (int)h1.size();
+  std::vector<double> lambda(R0);
+  for (int i = 0; i < R0; ++i) lambda[i] = (double)M * (1 - h0[i]) / h0[i];  // Data.cpp:607
+  sout << std::left << std::setw(20) << " * block size" << ": [" << p.bsize << "]\n";
+  sout << std::left << std::setw(20) << " * # blocks" << ": [" << B << "] for " << M << " variants\n";
+  sout << std::left << std::setw(20) << " * # CV folds" << ": [" << p.cv_folds << "]\n";
+  sout << std::left << std::setw(20) << " * ridge data_l0" << ": [ " << R0 << " : ";
+  for (double h : h0) sout << h << " ";
+  sout << "]\n" << std::left << std::setw(20) << " * ridge data_l1" << ": [ " << R1 << " : ";
+  for (double h : h1) sout << h << " ";
+  sout << "]\n";
+
+  // set_folds (Data.cpp:401-426)
+  std::vector<int32_t> cv_sizes(p.cv_folds, 1);
+  {
+    const int64_t target = r.n_analyzed / p.cv_folds;
+    if (target < 1) throw std::runtime_error("not enough samples are present for " + std::to_string(p.cv_folds) + "-fold CV.");
+    int64_t cnt = 0, cum = 0;
+    int cur = 0;
+    for (int64_t i = 0; i < N; ++i) {
+      if (r.ain[i]) cnt++;
+      if (cnt == target) { cv_sizes[cur] = (int32_t)(i - cum + 1); cum += cv_sizes[cur]; cnt = 0; cur++; }
+      else if (cur == p.cv_folds - 1) { cv_sizes[cur] = (int32_t)(N - i); break; }
+    }
+  }
+
+  rg_ctx* ctx = nullptr;
+  if (rg_create(&ctx, p.device, nullptr) != 0 || !ctx) throw std::runtime_error("no MI355X / HIP device available (rg_create failed)");
+  rg_problem pr;
+  memset(&pr, 0, sizeof(pr));
+  pr.n_samples = N; pr.n_file = r.n_file; pr.n_pheno = P; pr.n_cov = r.C; pr.cv_folds = p.cv_folds;
+  pr.n_ridge_l0 = R0; pr.ref_first = p.ref_first; pr.n_analyzed = r.n_analyzed; pr.cv_sizes = cv_sizes.data();
+  pr.lambda = lambda.data(); pr.X = r.X.data(); pr.Y = r.Y.data(); pr.mask = r.mask.data();
+  pr.ind_in_analysis = r.ain.data(); pr.ind_ignore = (r.N != r.n_file) ? r.ind_ignore.data() : nullptr;
+  pr.neff = r.neff.data(); pr.n_blocks_total = B; pr.max_block_size = p.bsize;
+  check(ctx, rg_set_problem(ctx, &pr));
+
+  // level 0: stream blocks from the bed file (get_G, Geno.cpp:1498-1517) in batches
+  {
+    std::ifstream bed(p.bed + ".bed", std::ios::binary);
+    const int NB = 32;
+    std::vector<std::vector<uint8_t>> bufs(NB);
+    int cur_chr = -1;
+    for (int b0 = 0; b0 < B; b0 += NB) {
+      const int nb = std::min(NB, B - b0);
+      std::vector<int32_t> ids(nb), bss(nb);
+      std::vector<const uint8_t*> ptrs(nb);
+      auto t0 = std::chrono::steady_clock::now();
+      for (int b = 0; b < nb; ++b) {
+        const Blk& bl = blocks[b0 + b];
+        if (bl.chrom != cur_chr) { cur_chr = bl.chrom; sout << "Chromosome " << cur_chr << "\n"; }
+        bufs[b].resize((size_t)bl.bs * r.bpr);
+        for (int j = 0; j < bl.bs; ++j) {  // jumpto_bed (Geno.cpp:2828-2830)
+          bed.seekg(3 + r.snp_offset[bl.start + j] * r.bpr, std::ios::beg);
+          bed.read((char*)bufs[b].data() + (size_t)j * r.bpr, r.bpr);
+          if (!bed) throw std::runtime_error("cannot read bed file");
+        }
+        ids[b] = b0 + b; bss[b] = bl.bs; ptrs[b] = bufs[b].data();
+      }
+      auto t1 = std::chrono::steady_clock::now();
+      check(ctx, rg_l0_blocks(ctx, nb, ids.data(), bss.data(), ptrs.data(), r.bpr, RG_MEM_HOST));
+      check(ctx, rg_sync(ctx));
+      auto t2 = std::chrono::steady_clock::now();
+      int64_t nsnp = 0;
+      for (int v : bss) nsnp += v;
+      sout << " blocks [" << b0 + 1 << ".." << b0 + nb << "] : " << nsnp << " snps  (read "
+           << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << "ms, level 0 ridge on GPU "
+           << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms)\n";
+    }
+  }
+
+  // level 1 (ridge_level_1 + output)
+  sout << "\n Level 1 ridge...\n";
+  const int L = B * R0;
+  std::vector<double> tau((size_t)P * R1);
+  for (int q = 0; q < P; ++q)
+    for (int j = 0; j < R1; ++j) tau[(size_t)q * R1 + j] = (double)L * (1 - h1[j]) / h1[j];  // Step1_Models.cpp:2115
+  std::vector<int32_t> cols_per_chr;
+  std::vector<int> chroms;
+  for (int c : r.chr_read) {
+    int nb = 0;
+    for (auto& bl : blocks) nb += bl.chrom == c;
+    if (nb > 0) { cols_per_chr.push_back(nb * R0); chroms.push_back(c); }
+  }
+  const int nchr = (int)chroms.size();
+  std::vector<double> cumsum((size_t)P * 5 * R1), pred((size_t)P * nchr * N);
+  std::vector<int32_t> best(P);
+  auto tl0 = std::chrono::steady_clock::now();
+  check(ctx, rg_l1_qt(ctx, R1, tau.data(), nchr, cols_per_chr.data(), cumsum.data(), best.data(), pred.data()));
+  sout << "   -level 1 for " << P << " phenotype(s) done ("
+       << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tl0).count() << "ms)\n\n";
+
+  // output (Data.cpp:956-1129, :1795-1975)
+  sout << "Output\n------\n";
+  std::ofstream plist(p.out + "_pred.list"), prslist;
+  if (p.print_prs) prslist.open(p.out + "_prs.list");
+  std::vector<int64_t> order(N);  // std::map<string,...> iteration order (Data.cpp:1934)
+  for (int64_t i = 0; i < N; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return r.ids[a] < r.ids[b]; });
+  std::string header = "FID_IID ";
+  for (int64_t i : order) if (r.ain[i]) header += r.ids[i] + " ";
+  header += "\n";
+  for (int q = 0; q < P; ++q) {
+    sout << "phenotype " << q + 1 << " (" << r.pheno_names[q] << ") : \n";
+    const double* cs = cumsum.data() + (size_t)q * 5 * R1;
+    for (int j = 0; j < R1; ++j) {
+      const double neff = r.neff[q];
+      double num = cs[4 * R1 + j] - cs[0 * R1 + j] * cs[1 * R1 + j] / neff;
+      const double rsq = num * num / ((cs[2 * R1 + j] - cs[0 * R1 + j] * cs[0 * R1 + j] / neff) * (cs[3 * R1 + j] - cs[1 * R1 + j] * cs[1 * R1 + j] / neff));
+      const double sse = cs[2 * R1 + j] + cs[3 * R1 + j] - 2 * cs[4 * R1 + j];
+      sout << "  " << std::right << std::setw(5) << (double)L / (L + tau[(size_t)q * R1 + j]) << " : Rsq = " << rsq << ", MSE = " << sse / neff;
+      if (j == best[q]) sout << "<- min value";
+      sout << "\n";
+    }
+    sout << "  * making predictions...writing LOCO predictions...";
+    const std::string loco_fn = p.out + "_" + std::to_string(q + 1) + ".loco";
+    const double* pq = pred.data() + (size_t)q * nchr * N;  // [nchr][N]
+    std::vector<double> tot(N, 0.0);
+    for (int c = 0; c < nchr; ++c)
+      for (int64_t i = 0; i < N; ++i) tot[i] += pq[(size_t)c * N + i];
+    {
+      std::ofstream lf(loco_fn);
+      lf << header;
+      std::map<int, int> cidx;
+      for (int c = 0; c < nchr; ++c) cidx[chroms[c]] = c;
+      for (int chr = 1; chr <= p.nchrom; ++chr) {
+        std::ostringstream row;
+        row << chr << " ";
+        const double* sub = cidx.count(chr) ? pq + (size_t)cidx[chr] * N : nullptr;
+        for (int64_t i : order) {
+          if (!r.ain[i]) continue;
+          if (r.mask[(size_t)q * N + i]) row << (tot[i] - (sub ? sub[i] : 0.0)) << " ";
+          else row << "NA ";
+        }
+        row << "\n";
+        lf << row.str();
+      }
+    }
+    plist << r.pheno_names[q] << " " << (p.use_rel_path ? loco_fn : get_fullpath(loco_fn)) << "\n";
+    if (p.print_prs) {
+      const std::string prs_fn = p.out + "_" + std::to_string(q + 1) + ".prs";
+      std::ofstream pf(prs_fn);
+      pf << header;
+      std::ostringstream row;
+      row << 0 << " ";
+      for (int64_t i : order) {
+        if (!r.ain[i]) continue;
+        if (r.mask[(size_t)q * N + i]) row << tot[i] << " ";
+        else row << "NA ";
+      }
+      row << "\n";
+      pf << row.str();
+      prslist << r.pheno_names[q] << " " << (p.use_rel_path ? prs_fn : get_fullpath(prs_fn)) << "\n";
+    }
+    sout << "done\n\n";
+  }
+  sout << "List of blup files written to: [" << p.out << "_pred.list]\n";
+  if (p.print_prs) sout << "List of files with whole genome PRS written to: [" << p.out << "_prs.list]\n";
+  rg_destroy(ctx);
+  sout << "\nElapsed time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << "s\nEnd of run\n";
+  return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  try {
+    return run(argc, argv);
+  } catch (const std::exception& e) {  // Regenie.cpp:72-91
+    sout << "\nERROR: " << e.what() << "\nFor more information, use option '--help' or visit the website: https://rgcgithub.github.io/regenie/\n";
+    return EXIT_FAILURE;
+  }
+}

@@ -1,0 +1,91 @@
+"""Drop-in check of the C++ host driver (GPU): `regenie-amd --step 1 ...` must produce the reference's
+output files (<out>_pred.list, <out>_<k>.loco, <out>.log) in the reference's format (src/Data.cpp:1926-1975)
+with values equal to the oracle's to the 6 significant digits the format carries."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+pytest.importorskip("torch")
+
+from oracle import regenie_step1 as orc  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "regenie_amd", "bin", "regenie-amd")
+
+
+def _parse_loco(path):
+    lines = open(path).read().split("\n")
+    assert lines[-1] == ""
+    hdr = lines[0].split(" ")
+    assert hdr[0] == "FID_IID" and hdr[-1] == ""
+    rows = []
+    for ln in lines[1:-1]:
+        t = ln.split(" ")
+        assert t[-1] == ""
+        rows.append([np.nan if v == "NA" else float(v) for v in t[1:-1]])
+    return hdr[1:-1], [ln.split(" ")[0] for ln in lines[1:-1]], np.array(rows), lines
+
+
+def _run(args, cwd):
+    r = subprocess.run([BIN] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    return r
+
+
+def test_cli_matches_oracle_files(example_dir, tmp_path):
+    E = example_dir
+    args = ["--step", "1", "--bed", os.path.join(E, "example_3chr"), "--phenoFile", os.path.join(E, "phenotype.txt"),
+            "--covarFile", os.path.join(E, "covariates.txt"), "--bsize", "100", "--lowmem", "--lowmem-prefix", "tmp_rg",
+            "--out", str(tmp_path / "gpu")]
+    r = _run(args, str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    opt = orc.Step1Options(bed=os.path.join(E, "example_3chr"), pheno_file=os.path.join(E, "phenotype.txt"),
+                           covar_file=os.path.join(E, "covariates.txt"), bsize=100, out=str(tmp_path / "ref"))
+    ref = orc.run_step1(opt, write_files=True)
+    for k in (1, 2):
+        ids_g, chr_g, val_g, lines_g = _parse_loco(str(tmp_path / ("gpu_%d.loco" % k)))
+        ids_r, chr_r, val_r, lines_r = _parse_loco(str(tmp_path / ("ref_%d.loco" % k)))
+        assert ids_g == ids_r and chr_g == chr_r == [str(c) for c in range(1, 24)]
+        assert val_g.shape == val_r.shape == (23, 500)
+        assert np.nanmax(np.abs(val_g - val_r)) <= 2e-6 * np.nanmax(np.abs(val_r))   # 6 printed digits
+        same = sum(a == b for a, b in zip(lines_g, lines_r))
+        assert same >= 20, "text of most chromosome rows should be byte-identical (%d/25)" % same
+    pl = open(str(tmp_path / "gpu_pred.list")).read().split("\n")
+    assert pl[0] == "Y1 " + str(tmp_path / "gpu_1.loco") and pl[1] == "Y2 " + str(tmp_path / "gpu_2.loco")
+    log = open(str(tmp_path / "gpu.log")).read()
+    assert log.count("<- min value") == 2
+    for ph in range(2):
+        j = ref.best[ph]
+        cs = ref.cumsum[ph]
+        mse = (cs[2, j] + cs[3, j] - 2 * cs[4, j]) / ref.prep.Neff[ph]
+        assert ("MSE = %s<- min value" % orc.cpp_double(mse)) in log
+
+
+def test_cli_remove_exclude_prs(example_dir, tmp_path):
+    E = example_dir
+    args = ["--step", "1", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype.txt"),
+            "--remove", os.path.join(E, "fid_iid_to_remove.txt"), "--exclude", os.path.join(E, "snplist_rm.txt"),
+            "--bsize", "100", "--print-prs", "--use-relative-path", "--phenoCol", "Y2", "--out", "o"]
+    r = _run(args, str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    opt = orc.Step1Options(bed=os.path.join(E, "example"), pheno_file=os.path.join(E, "phenotype.txt"),
+                           remove=[os.path.join(E, "fid_iid_to_remove.txt")], exclude=[os.path.join(E, "snplist_rm.txt")],
+                           bsize=100, pheno_cols=["Y2"])
+    ref = orc.run_step1(opt)
+    ids, chrs, val, _ = _parse_loco(str(tmp_path / "o_1.loco"))
+    assert len(ids) == 494
+    order = sorted(range(494), key=lambda i: ref.prep.ids[i])
+    exp = ref.loco[0][order].T
+    assert np.max(np.abs(val - exp)) <= 2e-6 * np.max(np.abs(exp))
+    assert open(str(tmp_path / "o_pred.list")).read() == "Y2 o_1.loco\n"
+    assert os.path.exists(str(tmp_path / "o_1.prs")) and open(str(tmp_path / "o_prs.list")).read() == "Y2 o_1.prs\n"
+
+
+def test_cli_errors_like_reference(example_dir, tmp_path):
+    E = example_dir
+    r = _run(["--step", "1", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype.txt")], str(tmp_path))
+    assert r.returncode != 0 and "ERROR: must specify the block size using '--bsize'." in r.stdout
+    r = _run(["--step", "1", "--bed", os.path.join(E, "nope"), "--phenoFile", os.path.join(E, "phenotype.txt"), "--bsize", "10"], str(tmp_path))
+    assert r.returncode != 0 and "ERROR:" in r.stdout
