@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--bsize", type=int, default=1000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-blocks", type=int, default=4)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for the "
+                    "single-box smoke of the N>1 code path")
+    ap.add_argument("--single-device", action="store_true", help="test mode: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -85,11 +88,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
+    if args.single_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     N, P, bsize = args.samples, args.phenos, args.bsize
     assert N % 4 == 0
@@ -143,11 +151,11 @@ def main():
     ptrs = [packed[b].data_ptr() for b in my_blocks]
     bss = [blocks[b][2] for b in my_blocks]
 
-    def step():
+    def step(exchange=True):
         eng.l0_blocks_device(my_blocks, bss, ptrs, N // 4)
         eng.sync()
-        if world > 1:
-            allgather_w(Wv, shards, R0)
+        if world > 1 and exchange:
+            allgather_w(Wv, shards, R0, force_broadcast=(args.backend != "nccl"))
             torch.cuda.synchronize()
         out = None
         if rank == 0:                                       # level 1 is phenotype-level work (P small here)
@@ -180,7 +188,7 @@ def main():
     roof, kernels = None, None
     if rank == 0:
         eng.enable_timing(True)
-        step()
+        step(exchange=False)      # rank-0-only pass: no collective may be issued here (W is already gathered)
         tm = eng.timing()
         eng.enable_timing(False)
         n_batches = -(-nb // int(os.environ.get("RG_NBLK", "32")))
@@ -229,6 +237,7 @@ def main():
                        % (N, M, args.snps, P, bsize), "samples": N, "snps": M, "phenos": P, "bsize": bsize, "blocks": B,
                        "parallelism": "blocks sharded x%d, all-gather of W" % world},
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+            "loco_checksum": float(sum(np.abs(l).sum() for l in res[0])), "selected_tau_index": [int(b) for b in res[2]],
             "setup_s": {"generate": t_gen},
         }
         print(json.dumps(line))

@@ -21,7 +21,7 @@ def shard_blocks(n_blocks: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def allgather_w(W, shards: List[Tuple[int, int]], r0: int, group=None):
+def allgather_w(W, shards: List[Tuple[int, int]], r0: int, group=None, force_broadcast: bool = False):
     """In-place all-gather of the level-0 predictors.
 
     W: torch tensor [B*R0, P, Np] (float64), on every rank the columns of its own blocks are filled.
@@ -35,7 +35,7 @@ def allgather_w(W, shards: List[Tuple[int, int]], r0: int, group=None):
         return W
     rank = dist.get_rank(group)
     sizes = {nb for (_, nb) in shards}
-    if len(sizes) == 1 and shards[0][1] > 0:
+    if len(sizes) == 1 and shards[0][1] > 0 and not force_broadcast:
         nb = shards[0][1]
         mine = W[shards[rank][0] * r0:(shards[rank][0] + nb) * r0]
         dist.all_gather_into_tensor(W[: world * nb * r0], mine.clone(), group=group)
