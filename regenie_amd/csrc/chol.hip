@@ -146,25 +146,36 @@ static inline unsigned xcd_affine_grid(int ngrp, int batch) { return (unsigned)(
 // Every tile of a system is first touched exactly once during the first column group of the
 // factorization, so the systems are never materialised by a separate pass: the first-touch kernels
 // read (sum, fold) instead of the workspace.
+// `extra`: rows >= extra_row0 of every system come from a shared matrix (per outer index) instead of
+// sum/fold -- the LOOCV paths append the sample-major predictor rows there so that the factorization
+// forward-substitutes them (z_i = L^-1 x_i gives the LOO leverages ||z_i||^2 without any inverse).
+// `subtract` = 0: the system is sum + shift (no held-out fold), used by LOOCV.
 struct FormSrc {
   const double* sum; int64_t sum_stride;
   const double* fold; int64_t fold_stride;
   const double* shift; const int32_t* d_n;
-  int nfold, nshift, n_fixed, enabled;
+  const double* extra; int64_t extra_stride;
+  int nfold, nshift, n_fixed, enabled, subtract, extra_row0, n64;
 };
-struct FormIdx { const double* S; const double* F; double sh; int n; };
+struct FormIdx { const double* S; const double* F; const double* X; double sh; int64_t xoff; int n, x0; };
 __device__ __forceinline__ FormIdx form_idx(const FormSrc& f, int b) {
   const int per = f.nfold * f.nshift;
   const int o = b / per, rem = b % per, fo = rem / f.nshift, r = rem % f.nshift;
   FormIdx x;
   x.S = f.sum + (int64_t)o * f.sum_stride;
-  x.F = f.fold + ((int64_t)o * f.nfold + fo) * f.fold_stride;
+  x.F = f.subtract ? f.fold + ((int64_t)o * f.nfold + fo) * f.fold_stride : nullptr;
+  x.X = f.extra ? f.extra + (int64_t)o * f.extra_stride : nullptr;
+  x.x0 = f.extra ? f.extra_row0 : 0x7fffffff;
+  x.xoff = (int64_t)f.extra_row0 * f.n64;
   x.sh = f.shift[r];
   x.n = f.d_n ? f.d_n[o] : f.n_fixed;
   return x;
 }
+// e = i * n64 + j
 __device__ __forceinline__ double form_val(const FormIdx& x, int i, int j, int64_t e) {
-  double v = x.S[e] - x.F[e];
+  if (i >= x.x0) return x.X[e - x.xoff];   // (i - extra_row0) * n64 + j
+  double v = x.S[e];
+  if (x.F) v -= x.F[e];
   if (i == j) v = (i < x.n) ? v + x.sh : 1.0;
   return v;
 }
@@ -494,7 +505,7 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
   const int T = n64 / CT, Tr = rhs_pad / CT, Ttot = T + Tr;
   const int G = 4;  // tile columns per group: trailing updates contract K = 64*G at once
   FormSrc off{};
-  off.enabled = 0;
+  off.enabled = 0; off.extra = nullptr;
   int64_t nl = 0;
   for (int k0 = 0; k0 < T; k0 += G) {
     const int k1 = std::min(T, k0 + G);
@@ -540,9 +551,22 @@ void rg_launch_chol_solve_formed(hipStream_t st, const double* sum, int64_t sum_
                                  const int32_t* d_n, int n_fixed, int nouter, double* mats,
                                  int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
                                  int32_t* info, int64_t* n_launch) {
+  rg_launch_chol_solve_formed_x(st, sum, sum_stride, fold, fold_stride, nfold, shift, nshift, d_n, n_fixed, nouter,
+                                mats, mat_stride, n64, rhs_pad, nrhs, dinv, info, n_launch, 1, nullptr, 0, 0);
+}
+
+// General form: subtract = 0 drops the held-out-fold term (LOOCV); rows >= extra_row0 of every system are
+// read from extra[outer] (shared by the nfold*nshift systems of one outer index).
+void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t sum_stride, const double* fold,
+                                   int64_t fold_stride, int nfold, const double* shift, int nshift,
+                                   const int32_t* d_n, int n_fixed, int nouter, double* mats,
+                                   int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
+                                   int32_t* info, int64_t* n_launch, int subtract, const double* extra,
+                                   int64_t extra_stride, int extra_row0) {
   FormSrc f;
   f.sum = sum; f.sum_stride = sum_stride; f.fold = fold; f.fold_stride = fold_stride; f.shift = shift;
   f.d_n = d_n; f.nfold = nfold; f.nshift = nshift; f.n_fixed = n_fixed; f.enabled = 1;
+  f.subtract = subtract; f.extra = extra; f.extra_stride = extra_stride; f.extra_row0 = extra_row0; f.n64 = n64;
   rg_launch_chol_solve_src(st, mats, mat_stride, nouter * nfold * nshift, n64, rhs_pad, nrhs, dinv, info,
                            n_launch, &f);
 }

@@ -29,7 +29,7 @@ void free_all(rg_ctx* c) {
                   c->d_xypart, c->d_chunk_seg, c->d_chunk_pos, c->d_chunk_len, c->d_S, c->d_F, c->d_Bm,
                   c->d_BQ, c->d_GYt, c->d_sc, c->d_fold, c->d_sum, c->d_wk, c->d_dinv, c->d_beta,
                   c->d_cb, c->d_psum, c->d_info, c->d_bs, c->d_blockid, c->d_c1k_seg, c->d_c1k_pos,
-                  c->d_c1k_len, c->d_c256_seg, c->d_c256_pos, c->d_c256_len};
+                  c->d_c1k_len, c->d_c256_seg, c->d_c256_pos, c->d_c256_len, c->d_gt, c->d_lpart};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->own_W && c->d_W) hipFree(c->d_W);
@@ -87,12 +87,15 @@ const char* rg_last_error(const rg_ctx* c) { return c ? c->err.c_str() : "null c
 int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if (!ctx || !p) return RG_ERR_ARG;
   hipSetDevice(ctx->device);
-  if (p->cv_folds < 2 || p->cv_folds > RG_MAX_SEG) { ctx->err = "cv_folds must be in [2,32]"; return RG_ERR_ARG; }
+  // cv_folds == 0 selects leave-one-out CV (params.use_loocv: cv_folds := n_samples, Data.cpp:363)
+  if (p->cv_folds != 0 && (p->cv_folds < 2 || p->cv_folds > RG_MAX_SEG)) { ctx->err = "cv_folds must be 0 (LOOCV) or in [2,32]"; return RG_ERR_ARG; }
+  ctx->loocv = (p->cv_folds == 0);
   if (p->n_ridge_l0 < 1 || p->n_ridge_l0 > 8) { ctx->err = "n_ridge_l0 must be in [1,8]"; return RG_ERR_ARG; }
   if (p->n_pheno < 1 || p->n_pheno > 64 || p->n_cov < 1 || p->n_cov > 64) { ctx->err = "n_pheno / n_cov must be in [1,64]"; return RG_ERR_ARG; }
   if (p->n_samples < 1 || p->n_file < p->n_samples || p->max_block_size < 1 || p->n_blocks_total < 1) { ctx->err = "bad sizes"; return RG_ERR_ARG; }
   ctx->N = p->n_samples; ctx->Nfile = p->n_file; ctx->P = p->n_pheno; ctx->C = p->n_cov;
-  ctx->K = p->cv_folds; ctx->R0 = p->n_ridge_l0; ctx->ref_first = p->ref_first;
+  ctx->K = ctx->loocv ? 1 : p->cv_folds;  // LOOCV: one segment holding every sample
+  ctx->R0 = p->n_ridge_l0; ctx->ref_first = p->ref_first;
   ctx->n_analyzed = p->n_analyzed; ctx->B_total = p->n_blocks_total; ctx->bs_max = p->max_block_size;
   const int64_t N = ctx->N, Nf = ctx->Nfile;
   const int P = ctx->P, C = ctx->C, K = ctx->K;
@@ -112,8 +115,9 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   }
   ctx->fold_cstart.assign(K + 1, 0);
   for (int f = 0; f < K; ++f) {
-    if (p->cv_sizes[f] < 1) { ctx->err = "empty CV fold"; return RG_ERR_ARG; }
-    ctx->fold_cstart[f + 1] = ctx->fold_cstart[f] + p->cv_sizes[f];
+    const int64_t sz = ctx->loocv ? N : (int64_t)p->cv_sizes[f];
+    if (sz < 1) { ctx->err = "empty CV fold"; return RG_ERR_ARG; }
+    ctx->fold_cstart[f + 1] = ctx->fold_cstart[f] + sz;
   }
   if (ctx->fold_cstart[K] != N) { ctx->err = "cv_sizes do not sum to n_samples"; return RG_ERR_ARG; }
 
@@ -219,9 +223,16 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   ctx->n128 = (int)rg_round_up(bsm, 128);
   ctx->n64 = (int)rg_round_up(bsm, 64);
   ctx->rtot = ctx->n64 + (int)rg_round_up(P, 64);
+  // LOOCV: every (block, lambda) system carries the Np sample rows as extra right-hand sides
+  ctx->rtot_wk = ctx->loocv ? ctx->rtot + Np : (int64_t)ctx->rtot;
+  ctx->nsys = ctx->loocv ? ctx->R0 : K * ctx->R0;
   int nb = 32;  // blocks per batch: more systems per launch hide the Cholesky dependency chain
   if (const char* e = getenv("RG_NBLK")) nb = std::max(1, atoi(e));
   nb = std::min(nb, ctx->B_total);
+  if (ctx->loocv) {  // bound the forward-substituted row storage (~24 GB)
+    const double per_blk = 8.0 * ctx->n64 * ((double)ctx->R0 * ctx->rtot_wk + (double)Np);
+    nb = (int)std::max(1.0, std::min((double)nb, 24e9 / per_blk));
+  }
   ctx->nblk_cap = nb;
   const int nseg = K, R0 = ctx->R0, n128 = ctx->n128, n64 = ctx->n64, rtot = ctx->rtot;
   ctx->raw_ld = rg_round_up((Nf + 3) / 4, 16);
@@ -240,8 +251,12 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if ((rc = dev_alloc(ctx, &ctx->d_sc, (size_t)nb * n128))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_fold, (size_t)nb * nseg * msz))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_sum, (size_t)nb * msz))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->d_wk, (size_t)nb * nseg * R0 * msz))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->d_dinv, (size_t)nb * nseg * R0 * (n64 / 64) * 4096))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_wk, (size_t)nb * ctx->nsys * ctx->rtot_wk * n64))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_dinv, (size_t)nb * ctx->nsys * (n64 / 64) * 4096))) return rc;
+  if (ctx->loocv) {
+    if ((rc = dev_alloc(ctx, &ctx->d_gt, (size_t)nb * Np * n64))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_lpart, (size_t)2 * nb * R0 * P * 64))) return rc;
+  }
   if ((rc = dev_alloc(ctx, &ctx->d_beta, (size_t)nb * nseg * R0 * P * n64))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_cb, (size_t)nb * nseg * R0 * P * C))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_psum, (size_t)nb * ctx->n_c1k * P * 8 * 2))) return rc;
@@ -319,6 +334,26 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     rg_launch_rowstats(st, a);
     rg_launch_assemble(st, a);
   }
+  if (ctx->loocv) {
+    LoocvArgs la;
+    la.nblk = nblk; la.R0 = R0; la.P = P; la.C = C; la.n128 = n128; la.n64 = n64; la.rtot = (int)ctx->rtot_wk;
+    la.row_g0 = rtot; la.Np = ctx->Np; la.pk_ld = ctx->pk_ld; la.pk_blk_stride = pk_blk; la.pk = ctx->d_pk;
+    la.mu = ctx->d_mu; la.sc = ctx->d_sc; la.Bm = ctx->d_Bm; la.V = ctx->d_V; la.maskp = ctx->d_maskp;
+    la.neff = ctx->d_neff; la.bs = ctx->d_bs; la.blockid = ctx->d_blockid; la.wk = ctx->d_wk; la.gt = ctx->d_gt;
+    la.W = ctx->d_W;
+    {
+      StageTimer t(ctx, &ctx->tm.ms_chol);
+      rg_launch_decode_gt(st, la);
+      rg_launch_chol_solve_formed_x(st, ctx->d_sum, msz, ctx->d_fold, msz, 1, ctx->d_lambda, R0, ctx->d_bs, 0, nblk,
+                                    ctx->d_wk, ctx->rtot_wk * n64, n64, (int)(ctx->rtot_wk - n64), 0, ctx->d_dinv,
+                                    ctx->d_info + 1, &ctx->tm.n_chol_launches, 0, ctx->d_gt,
+                                    (int64_t)ctx->Np * n64, rtot);
+    }
+    {
+      StageTimer t(ctx, &ctx->tm.ms_pred);
+      rg_launch_l0_loocv(st, la, ctx->d_lpart, ctx->d_lpart + (size_t)nblk * R0 * P * 64, 64);
+    }
+  } else {
   {
     StageTimer t(ctx, &ctx->tm.ms_chol);
     rg_launch_chol_solve_formed(st, ctx->d_sum, msz, ctx->d_fold, msz, nseg, ctx->d_lambda, R0, ctx->d_bs, 0,
@@ -335,6 +370,7 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     pa.keptp = ctx->d_keptp; pa.bs = ctx->d_bs; pa.blockid = ctx->d_blockid; pa.neff = ctx->d_neff;
     pa.beta = ctx->d_beta; pa.cb = ctx->d_cb; pa.psum = ctx->d_psum; pa.W = ctx->d_W;
     rg_launch_l0_pred_impl(st, pa, ctx->d_c1k_seg, ctx->d_c1k_pos, ctx->d_c1k_len, ctx->n_c1k);
+  }
   }
   for (int b = 0; b < nblk; ++b) ctx->block_done[block_ids[b]] = 1;
   return RG_OK;

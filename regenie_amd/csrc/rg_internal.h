@@ -37,6 +37,11 @@ struct rg_ctx {
   bool own_stream = false;
   std::string err;
   bool have_problem = false;
+  bool loocv = false;            // cv_folds == 0: leave-one-out CV, one sample segment
+  int64_t rtot_wk = 0;           // rows of one ridge system workspace (LOOCV: + Np appended sample rows)
+  int nsys = 0;                  // systems per block: K*R0 (K-fold) or R0 (LOOCV)
+  double* d_gt = nullptr;        // [nblk][Np][n64] standardised genotypes, sample-major (LOOCV)
+  double* d_lpart = nullptr;     // LOOCV standardisation partial sums
 
   // problem
   int64_t N = 0, Nfile = 0, Np = 0, n_analyzed = 0;
@@ -150,6 +155,12 @@ void rg_launch_chol_solve_formed(hipStream_t st, const double* sum, int64_t sum_
                                  const int32_t* d_n, int n_fixed, int nouter, double* mats,
                                  int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
                                  int32_t* info, int64_t* n_launch);
+void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t sum_stride, const double* fold,
+                                   int64_t fold_stride, int nfold, const double* shift, int nshift,
+                                   const int32_t* d_n, int n_fixed, int nouter, double* mats,
+                                   int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
+                                   int32_t* info, int64_t* n_launch, int subtract, const double* extra,
+                                   int64_t extra_stride, int extra_row0);
 void rg_launch_dgemm_nt(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                         int m, int n, int64_t k, double* C, int64_t ldc);
 // pred.hip
@@ -168,6 +179,16 @@ void rg_launch_w_gather(hipStream_t st, const double* W, int64_t Np, int P, int 
                         const int64_t* posc, int64_t N, double* out);
 void rg_launch_w_scatter(hipStream_t st, double* W, int64_t Np, int P, int p, int col0, int R0,
                          const int64_t* posc, int64_t N, const double* in);
+// loocv.hip
+struct LoocvArgs {
+  int nblk, R0, P, C, n128, n64, rtot, row_g0;
+  int64_t Np, pk_ld, pk_blk_stride;
+  const uint8_t* pk; const double* mu; const double* sc; const double* Bm; const double* V;
+  const double* maskp; const double* neff; const int32_t* bs; const int32_t* blockid;
+  const double* wk; double* gt; double* W;
+};
+void rg_launch_decode_gt(hipStream_t st, const LoocvArgs& a);
+void rg_launch_l0_loocv(hipStream_t st, const LoocvArgs& a, double* part0, double* part1, int nchunk);
 // l1.hip
 struct L1Args;
 int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_t* cols_per_chr,

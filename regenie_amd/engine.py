@@ -142,7 +142,8 @@ class Step1Engine:
         Y = np.asfortranarray(Y, dtype=np.float64)
         mask = np.asfortranarray(mask, dtype=np.uint8)
         ain = np.ascontiguousarray(ind_in_analysis, dtype=np.uint8)
-        cvs = np.ascontiguousarray(cv_sizes, dtype=np.int32)
+        # cv_sizes=None selects leave-one-out CV (cv_folds = 0 in the ABI)
+        cvs = np.ascontiguousarray(cv_sizes if cv_sizes is not None else [], dtype=np.int32)
         lam = np.ascontiguousarray(lam, dtype=np.float64)
         neff = np.ascontiguousarray(neff, dtype=np.float64)
         ign = None if ind_ignore is None else np.ascontiguousarray(ind_ignore, dtype=np.uint8)
@@ -151,7 +152,7 @@ class Step1Engine:
         p.n_samples, p.n_file, p.n_pheno, p.n_cov = N, int(n_file), P, X.shape[1]
         p.cv_folds, p.n_ridge_l0, p.ref_first = cvs.size, lam.size, int(bool(ref_first))
         p.n_analyzed = int(ain.sum())
-        p.cv_sizes, p.lambda_ = cvs.ctypes.data, lam.ctypes.data
+        p.cv_sizes, p.lambda_ = (cvs.ctypes.data if cvs.size else None), lam.ctypes.data
         p.X, p.Y, p.mask = X.ctypes.data, Y.ctypes.data, mask.ctypes.data
         p.ind_in_analysis = ain.ctypes.data
         p.ind_ignore = ign.ctypes.data if ign is not None else None

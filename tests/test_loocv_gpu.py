@@ -1,0 +1,61 @@
+"""LOOCV and binary-trait paths on the GPU against the oracle (through the C ABI).
+
+The BT case is the reference's own Step-1 test command (test/test_bash.sh:62-80): N = 494 < 5000 forces
+LOOCV (Data.cpp:353-356), and its log must carry `0.4504` on the `min value` line."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+pytest.importorskip("torch")
+
+from oracle import regenie_step1 as orc  # noqa: E402
+from regenie_amd.engine import Step1Engine  # noqa: E402
+from tests.util import rel_err, synth_dosages, write_plink  # noqa: E402
+
+
+def _level0_loocv(opt):
+    """Level-0 LOOCV predictors of every block through the C ABI; returns (ref Step1Result, W_gpu list)."""
+    ref = orc.run_step1(opt)
+    assert ref.use_loocv
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    bed, _ = orc.open_bed(opt.bed + ".bed", prep.n_file)
+    B = len(ref.blocks)
+    eng = Step1Engine(0)
+    eng.set_problem(X=prep.X, Y=prep.Y, mask=prep.mask, ind_in_analysis=prep.ind_in_analysis, cv_sizes=None,
+                    lam=ref.lam, neff=prep.Neff, n_file=prep.n_file, n_blocks_total=B, max_block_size=opt.bsize,
+                    ind_ignore=prep.ind_ignore if prep.ind_ignore.any() else None, ref_first=opt.ref_first)
+    rows = [np.ascontiguousarray(bed[offs[s:s + bs]]) for (_, s, bs) in ref.blocks]
+    eng.l0_blocks_host(list(range(B)), rows)
+    eng.sync()
+    N, P = prep.Y.shape
+    R0 = ref.lam.size
+    W = [np.zeros((N, B * R0)) for _ in range(P)]
+    for b in range(B):
+        for ph in range(P):
+            W[ph][:, b * R0:(b + 1) * R0] = eng.get_w(b, ph)
+    return ref, W, eng
+
+
+def test_level0_loocv_reference_bt_command(example_dir):
+    E = example_dir
+    opt = orc.Step1Options(bed=os.path.join(E, "example"), pheno_file=os.path.join(E, "phenotype_bin.txt"),
+                           covar_file=os.path.join(E, "covariates.txt"), remove=[os.path.join(E, "fid_iid_to_remove.txt")],
+                           exclude=[os.path.join(E, "snplist_rm.txt")], bsize=100, bt=True)
+    ref, W, eng = _level0_loocv(opt)
+    eng.close()
+    for ph in range(2):
+        assert rel_err(W[ph], ref.W[ph]) < 1e-8
+
+
+def test_level0_loocv_qt_missing(tmp_path):
+    N, M = 700, 300
+    g = synth_dosages(M, N, miss_rate=0.02, seed=33)
+    pre = str(tmp_path / "lo")
+    write_plink(pre, g, np.repeat([1, 3], [150, 150]), P=2, ncov=2, seed=6)
+    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=70, loocv=True)
+    ref, W, eng = _level0_loocv(opt)
+    eng.close()
+    for ph in range(2):
+        assert rel_err(W[ph], ref.W[ph]) < 1e-8
