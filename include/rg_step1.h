@@ -46,7 +46,7 @@ typedef struct rg_problem {
   int64_t n_file;          /* N_file: rows of .fam (bed rows hold ceil(N_file/4) bytes per SNP) */
   int32_t n_pheno;         /* P */
   int32_t n_cov;           /* C = params.ncov (columns of the orthonormal basis, incl. intercept) */
-  int32_t cv_folds;        /* K (>=2); LOOCV is not part of this ABI revision */
+  int32_t cv_folds;        /* K in [2,32], or 0 = leave-one-out CV (params.use_loocv) */
   int32_t n_ridge_l0;      /* R0 */
   int32_t ref_first;       /* --ref-first (Geno.cpp:1746) */
   int32_t reserved0;
@@ -112,6 +112,35 @@ int rg_l0_set_w(rg_ctx* ctx, int32_t block_id, int32_t pheno, const double* in_h
  *   pred_out     : N x nchr x P  col-major per phenotype (Data::predictions[0]); host memory */
 int rg_l1_qt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, int32_t nchr,
              const int32_t* cols_per_chr, double* cumsum_out, int32_t* best_out, double* pred_out);
+
+/* ---- level 1, quantitative traits, leave-one-out CV ------------------------------------------
+ * Replaces ridge_level_1_loocv (Step1_Models.cpp:875-962), the tau selection of Data::output and
+ * make_predictions_loocv (Data.cpp:1269-1342).  Requires a problem set up with cv_folds = 0.
+ * Arguments as rg_l1_qt; cumsum_out rows Sy / Sy2 hold the reference's presets 0 and Neff - ncov. */
+int rg_l1_qt_loocv(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, int32_t nchr,
+                   const int32_t* cols_per_chr, double* cumsum_out, int32_t* best_out,
+                   double* pred_out);
+
+/* ---- level 1, binary traits: logistic ridge, K-fold or LOOCV (by the problem's cv_folds) ------
+ * Replaces ridge_logistic_level_1 (Step1_Models.cpp:966-1156) / ridge_logistic_level_1_loocv +
+ * run_log_ridge_loocv (Step1_Models.cpp:1159-1374), the -logLik tau selection (Data.cpp:1030) and
+ * make_predictions_binary / make_predictions_binary_loocv (Data.cpp:1346-1427, :1484-1571).
+ *   yraw, offset  : N x P col-major: phenodt::phenotypes_raw (0/1) and ests::offset_nullreg
+ *   opt           : iteration limits / tolerances (NULL = the reference defaults below)
+ *   cumsum_out    : 6 x R1 x P (Sx,Sy,Sx2,Sy2,Sxy,-logLik)
+ *   converged_out : P; 0 marks pheno_l1_not_converged (its predictions are skipped, Data.cpp:1016) */
+typedef struct rg_bt_options {
+  int32_t niter_max_ridge;             /* 100   params.niter_max_ridge */
+  int32_t niter_max_line_search_ridge; /* 100   params.niter_max_line_search_ridge */
+  int32_t niter_max_line_search;       /* 25    params.niter_max_line_search (LOOCV Newton) */
+  int32_t reserved0;
+  double l1_ridge_tol;                 /* 1e-4  params.l1_ridge_tol */
+  double tol;                          /* 1e-8  params.tol */
+} rg_bt_options;
+int rg_l1_bt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, const double* yraw,
+             const double* offset, const rg_bt_options* opt, int32_t nchr,
+             const int32_t* cols_per_chr, double* cumsum_out, int32_t* converged_out,
+             int32_t* best_out, double* pred_out);
 
 /* ---- introspection used by bench.py (timing of the dominant kernels with HIP events) --------- */
 typedef struct rg_timing {

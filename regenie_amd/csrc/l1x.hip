@@ -1,0 +1,850 @@
+// Level-1 models beyond the QT K-fold path of l1.hip:
+//   * QT leave-one-out CV          ridge_level_1_loocv          src/Step1_Models.cpp:875-962
+//                                  make_predictions_loocv       src/Data.cpp:1269-1342
+//   * BT logistic ridge, K-fold    ridge_logistic_level_1       src/Step1_Models.cpp:966-1156
+//                                  make_predictions_binary      src/Data.cpp:1346-1427
+//   * BT logistic ridge, LOOCV     ridge_logistic_level_1_loocv src/Step1_Models.cpp:1159-1286
+//                                  run_log_ridge_loocv          src/Step1_Models.cpp:1288-1374
+//                                  make_predictions_binary_loocv src/Data.cpp:1484-1571
+//
+// Building blocks (all fp64):
+//   k_wgram        weighted Gram  sum_pos w(pos) W_r(pos) W_c(pos)  on v_mfma_f64_16x16x4_f64 straight from the
+//                  [L][P][Np] predictor rows, one "chain" (= CV fold model, or the single LOOCV model) per
+//                  grid.y, a per-chain extra row (working response) so the IRLS right-hand side X^T W z comes
+//                  out of the same launch, the chain's held-out fold skipped, tau added on the diagonal.
+//   batched Cholesky of chol.hip for the solves; for the leave-one-out leverages the identity is appended as
+//                  right-hand-side rows, which the factorization turns into Y = L^-T, then H = Y Y^T = A^-1 and
+//                  U^T = H W^T are two MFMA GEMMs; h_i = w_i . u_i is a streaming dot product.
+// The reference gets the same quantities from a symmetric eigendecomposition (QT) or LLT + explicit
+// solves against X^T (BT); the closed forms are identical, the factorization differs (agreement ~1e-11).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include "rg_internal.h"
+
+#define CT 64
+#define NCH 8  // chains handled per pass of the streaming kernels
+
+// ---------------------------------------------------------------------------------------------------------
+struct WgArgs {
+  const double* W; const double* zero; int64_t Np; int L, P, p, n64;
+  const double* wv;        // [nchain][Np] weights (0 on masked / held-out / padding) or nullptr = 1
+  const double* zv;        // [nchain][Np] extra row n64 (working response / y) or nullptr = zero row
+  const double* dshift;    // [nchain] added to diagonal entries < L (entries >= L get 1.0); nullptr = none
+  const int32_t* chainmap; // [gridDim.y] chain id of each output slot (nullptr = identity)
+  int excl_own;            // chain c skips fold segment c (its held-out fold)
+  double* out; int64_t out_stride;  // slot s -> out + s*out_stride, (n64+64) x n64 row-major
+};
+__device__ __forceinline__ const double* wg_row(const WgArgs& a, int chain, int row) {
+  if (row < a.L) return a.W + ((int64_t)row * a.P + a.p) * a.Np;
+  if (row == a.n64 && a.zv) return a.zv + (int64_t)chain * a.Np;
+  return a.zero;
+}
+
+__global__ __launch_bounds__(256) void k_wgram(WgArgs a, SegLayout seg, int T) {
+  const int slot = blockIdx.y;
+  const int chain = a.chainmap ? a.chainmap[slot] : slot;
+  const int tri = T * (T + 1) / 2;
+  int idx = blockIdx.x, tr, tc;
+  if (idx < tri) {
+    int rr = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
+    while ((rr + 1) * (rr + 2) / 2 <= idx) ++rr;
+    while (rr * (rr + 1) / 2 > idx) --rr;
+    tr = rr;
+    tc = idx - rr * (rr + 1) / 2;
+  } else {
+    tr = T;
+    tc = idx - tri;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, q = lane >> 4;
+  const double* ar[2] = {wg_row(a, chain, tr * CT + wr * 32 + i), wg_row(a, chain, tr * CT + wr * 32 + 16 + i)};
+  const double* br[2] = {wg_row(a, chain, tc * CT + wc * 32 + i), wg_row(a, chain, tc * CT + wc * 32 + 16 + i)};
+  const double* wrow = a.wv ? a.wv + (int64_t)chain * a.Np : nullptr;
+  v4d acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
+  for (int f = 0; f < seg.nseg; ++f) {
+    if (a.excl_own && f == chain) continue;
+    const int64_t p0 = seg.pos_start[f] + 16 * q, plen = seg.plen[f];
+    for (int64_t k = 0; k < plen; k += 64) {
+      double av[2][16], bv[2][16];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const double4* pa = reinterpret_cast<const double4*>(ar[m] + p0 + k);
+        const double4* pb = reinterpret_cast<const double4*>(br[m] + p0 + k);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const double4 x = pa[v], y = pb[v];
+          av[m][4 * v] = x.x; av[m][4 * v + 1] = x.y; av[m][4 * v + 2] = x.z; av[m][4 * v + 3] = x.w;
+          bv[m][4 * v] = y.x; bv[m][4 * v + 1] = y.y; bv[m][4 * v + 2] = y.z; bv[m][4 * v + 3] = y.w;
+        }
+      }
+      if (wrow) {
+        const double4* pw = reinterpret_cast<const double4*>(wrow + p0 + k);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const double4 w = pw[v];
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            av[m][4 * v] *= w.x; av[m][4 * v + 1] *= w.y; av[m][4 * v + 2] *= w.z; av[m][4 * v + 3] *= w.w;
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m][s], bv[n][s], acc[m][n], 0, 0, 0);
+    }
+  }
+  const double sh = a.dshift ? a.dshift[chain] : 0.0;
+  double* O = a.out + (int64_t)slot * a.out_stride + (int64_t)tr * CT * a.n64 + tc * CT;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int lr = wr * 32 + m * 16 + q + 4 * r, lc = wc * 32 + n * 16 + i;
+        double v = acc[m][n][r];
+        if (a.dshift && tr == tc && lr == lc) v = (tr * CT + lr < a.L) ? v + sh : 1.0;
+        O[(int64_t)lr * a.n64 + lc] = v;
+      }
+}
+
+// ---- Wt[pos][c] = W[c][p][pos] (c < L; 0 for L <= c < n64): sample-major copy, the K-contiguous operand of
+//      U^T = H W^T.  grid (Np/64, n64/64) --------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose_w(const double* W, int64_t Np, int L, int P, int p, int n64,
+                                                     double* Wt) {
+  __shared__ double s[64][65];
+  const int64_t pos0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  {
+    const int cl = threadIdx.x >> 2, qd = threadIdx.x & 3;
+    const int c = c0 + cl;
+    if (c < L) {
+      const double* src = W + ((int64_t)c * P + p) * Np + pos0 + qd * 16;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[cl][qd * 16 + i] = src[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[cl][qd * 16 + i] = 0.0;
+    }
+  }
+  __syncthreads();
+  {
+    const int pl = threadIdx.x >> 2, jq = threadIdx.x & 3;
+    double* dst = Wt + (pos0 + pl) * n64 + c0 + jq * 16;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dst[i] = s[jq * 16 + i][pl];
+  }
+}
+
+__global__ void k_eye(double* E, int n) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (int64_t)n * n) return;
+  E[e] = (e / n == e % n) ? 1.0 : 0.0;
+}
+
+// b[r] = sum_k H[r][k] v[k]; one wave per row
+__global__ __launch_bounds__(256) void k_symv(const double* H, const double* v, int n, double* b) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= n) return;
+  double acc = 0.0;
+  for (int k = lane; k < n; k += 64) acc = fma(H[(int64_t)r * n + k], v[k], acc);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if (lane == 0) b[r] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Leave-one-out closed forms, thread = one position.  Ut[c][pos] = (H w_pos)[c], bv = H W^T y (QT) or beta (BT).
+//   QT  (Step1_Models.cpp:934-952):  pred = (w.b - h y) / (1 - h)
+//   BT  (Step1_Models.cpp:1221-1262): pred = w.beta - h (y - p) / (1 - h wgt) + offset -> p1 = clamp(sigmoid)
+struct LooArgs {
+  const double* W; const double* Ut; const double* bv; int64_t Np; int L, P, p;
+  const double* y;      // QT: residualised y;  BT: raw 0/1 y            [Np]
+  const double* rv;     // BT: y - p (0 on masked)                         [Np]
+  const double* wv;     // BT: p(1-p) (0 on masked)                        [Np]
+  const double* off;    // BT: offset                                      [Np]
+  const double* maskp;  // BT: 0/1                                         [Np]
+  int bt;
+};
+#define LOO_NPART 6
+__device__ __forceinline__ double block_sum_256(double x, double* sred /*[4]*/) {
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+// part: [gridDim.x][6] = Sx, Sy, Sx2, Sy2, Sxy, -LL  (QT fills Sx, Sx2, Sxy only)
+__global__ __launch_bounds__(256) void k_loo_cv(LooArgs a, double* part) {
+  __shared__ double sred[4];
+  const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double t[LOO_NPART] = {0, 0, 0, 0, 0, 0};
+  if (pos < a.Np) {
+    double h = 0.0, xb = 0.0;
+    const double* w = a.W + (int64_t)a.p * a.Np + pos;
+    const double* u = a.Ut + pos;
+    for (int c = 0; c < a.L; ++c) {
+      const double x = w[(int64_t)c * a.P * a.Np];
+      h = fma(x, u[(int64_t)c * a.Np], h);
+      xb = fma(x, a.bv[c], xb);
+    }
+    if (!a.bt) {
+      const double y = a.y[pos];
+      const double pred = (xb - h * y) / (1.0 - h);
+      t[0] = pred; t[2] = pred * pred; t[4] = pred * y;
+    } else if (a.maskp[pos] != 0.0) {
+      const double y = a.y[pos];
+      const double eta = xb - h * a.rv[pos] / (1.0 - h * a.wv[pos]) + a.off[pos];
+      double p1 = 1.0 - 1.0 / (exp(eta) + 1.0);
+      p1 = fmin(fmax(p1, 1e-5), 1.0 - 1e-5);   // l1_ridge_eps, Step1_Models.cpp:1256-1257
+      t[0] = p1; t[1] = y; t[2] = p1 * p1; t[3] = y * y; t[4] = p1 * y;
+      t[5] = -((y == 0.0) ? log(1.0 - p1) : log(p1));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < LOO_NPART; ++k) {
+    const double s = block_sum_256(t[k], sred);
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.x * LOO_NPART + k] = s;
+  }
+}
+
+// pred[c][n] (compact sample order) = sum_{col in chr c} w_col (b_col - u_col g),
+//   QT: g = (y - w.b) / (1 - h)     (Data.cpp:1311-1326)      BT: g = (y - p) / (1 - h wgt)  (Data.cpp:1530-1548)
+__global__ __launch_bounds__(256) void k_loo_pred(LooArgs a, const int32_t* chr_col0, int nchr,
+                                                  const int32_t* cidx, int64_t N, double* pred) {
+  const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pos >= a.Np) return;
+  const int32_t n = cidx[pos];
+  if (n < 0) return;
+  const double* w = a.W + (int64_t)a.p * a.Np + pos;
+  const double* u = a.Ut + pos;
+  double h = 0.0, xb = 0.0;
+  for (int c = 0; c < a.L; ++c) {
+    const double x = w[(int64_t)c * a.P * a.Np];
+    h = fma(x, u[(int64_t)c * a.Np], h);
+    xb = fma(x, a.bv[c], xb);
+  }
+  const double g = a.bt ? a.rv[pos] / (1.0 - h * a.wv[pos]) : (a.y[pos] - xb) / (1.0 - h);
+  for (int c = 0; c < nchr; ++c) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int col = chr_col0[c]; col < chr_col0[c + 1]; ++col) {
+      const double x = w[(int64_t)col * a.P * a.Np];
+      s1 = fma(x, a.bv[col], s1);
+      s2 = fma(x, u[(int64_t)col * a.Np], s2);
+    }
+    pred[(int64_t)c * N + n] = s1 - s2 * g;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Logistic state at beta for up to NCH chains at once (one read of W), thread = one position.
+//   training position of chain ch (mask, not in ch's held-out fold):  eta = off + w.beta, p = get_pvec(eta)
+//   (Step1_Models.cpp:1799-1806), wgt = p(1-p), z = w.beta + (y-p)/wgt, r = y - p, deviance partial;
+//   held-out position (K-fold only): test p1 = sigmoid(off + w.beta) clamped, the six running sums
+//   (Step1_Models.cpp:1113-1134).
+struct BtArgs {
+  const double* W; int64_t Np; int L, P, p, n64;
+  const double* yraw; const double* off; const double* maskp;
+  const double* beta;   // [nchain][n64]
+  int nchain, kfold;
+  double *wv, *zv, *rv; // [nchain][Np]
+};
+#define BT_NPART 8      // Sx, Sy, Sx2, Sy2, Sxy, -LL (held-out), deviance (training), #(wgt == 0)
+__device__ __forceinline__ double rg_pvec(double eta) {
+  const double eps = 10.0 * 2.220446049250313e-16;   // numtol_eps, Regenie.hpp:225
+  double p = 1.0 - 1.0 / (exp(eta) + 1.0);
+  if (eta < -30.0) p = eps / (1.0 + eps);           // ETAMINTHR / ETAMAXTHR, Step1_Models.hpp:30-31
+  if (eta > 30.0) p = 1.0 / (1.0 + eps);
+  return p;
+}
+
+__global__ __launch_bounds__(256) void k_bt_eval(BtArgs a, int ch0, const int32_t* chunk_seg,
+                                                 const int64_t* chunk_pos, const int64_t* chunk_len,
+                                                 double* part /*[nchunk][nchain][BT_NPART]*/) {
+  __shared__ double sB[256][NCH];
+  __shared__ double sred[4];
+  const int chunk = blockIdx.x;
+  const int f = chunk_seg[chunk];
+  const int64_t p0 = chunk_pos[chunk], plen = chunk_len[chunk];
+  const int nc = min(NCH, a.nchain - ch0);
+  const bool live = threadIdx.x < plen;   // chunks are <= 256 positions
+  const int64_t pos = p0 + threadIdx.x;
+  double acc[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) acc[j] = 0.0;
+  for (int c0 = 0; c0 < a.L; c0 += 256) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int col = c0 + threadIdx.x;
+      sB[threadIdx.x][j] = (j < nc && col < a.L) ? a.beta[(int64_t)(ch0 + j) * a.n64 + col] : 0.0;
+    }
+    __syncthreads();
+    if (live) {
+      const int cn = min(256, a.L - c0);
+      const double* w = a.W + ((int64_t)c0 * a.P + a.p) * a.Np + pos;
+      for (int c = 0; c < cn; ++c) {
+        const double x = w[(int64_t)c * a.P * a.Np];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) acc[j] = fma(x, sB[c][j], acc[j]);
+      }
+    }
+  }
+  const double m = live ? a.maskp[pos] : 0.0;
+  const double y = live ? a.yraw[pos] : 0.0;
+  const double off = live ? a.off[pos] : 0.0;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    if (j >= nc) break;
+    const int ch = ch0 + j;
+    const bool test = a.kfold && (f == ch);
+    double t[BT_NPART] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double wgt = 0.0, z = 0.0, r = 0.0;
+    if (m != 0.0) {
+      if (!test) {
+        const double p = rg_pvec(off + acc[j]);
+        wgt = p * (1.0 - p);
+        r = y - p;
+        if (wgt == 0.0) t[7] = 1.0;
+        else z = acc[j] + r / wgt;
+        t[6] = -2.0 * ((y == 0.0) ? log(1.0 - p) : log(p));
+      } else {
+        double p1 = 1.0 - 1.0 / (exp(off + acc[j]) + 1.0);
+        p1 = fmin(fmax(p1, 1e-5), 1.0 - 1e-5);
+        t[0] = p1; t[1] = y; t[2] = p1 * p1; t[3] = y * y; t[4] = p1 * y;
+        t[5] = -((y == 0.0) ? log(1.0 - p1) : log(p1));
+      }
+    }
+    if (live) {
+      a.wv[(int64_t)ch * a.Np + pos] = wgt;
+      a.zv[(int64_t)ch * a.Np + pos] = z;
+      a.rv[(int64_t)ch * a.Np + pos] = r;
+    }
+#pragma unroll
+    for (int k = 0; k < BT_NPART; ++k) {
+      const double s = block_sum_256(t[k], sred);
+      if (threadIdx.x == 0) part[((int64_t)chunk * a.nchain + ch) * BT_NPART + k] = s;
+    }
+  }
+}
+
+// score[ch][c] = sum_pos W[c][pos] r_ch(pos) - tau_ch beta_ch[c]   (Step1_Models.cpp:1088-1092 / :1361)
+__global__ __launch_bounds__(256) void k_bt_score(BtArgs a, int ch0, const double* tauc, double* score) {
+  __shared__ double sred[4];
+  const int c = blockIdx.x;
+  const int nc = min(NCH, a.nchain - ch0);
+  const double* w = a.W + ((int64_t)c * a.P + a.p) * a.Np;
+  double acc[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) acc[j] = 0.0;
+  for (int64_t pos = threadIdx.x; pos < a.Np; pos += 256) {
+    const double x = w[pos];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+      if (j < nc) acc[j] = fma(x, a.rv[(int64_t)(ch0 + j) * a.Np + pos], acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    if (j >= nc) break;
+    const double s = block_sum_256(acc[j], sred);
+    if (threadIdx.x == 0)
+      score[(int64_t)(ch0 + j) * a.n64 + c] = s - tauc[ch0 + j] * a.beta[(int64_t)(ch0 + j) * a.n64 + c];
+  }
+}
+
+// per-chromosome linear predictors with fold-specific coefficient vectors (make_predictions /
+// make_predictions_binary, Data.cpp:1242-1258, :1398-1414): alpha of fold f = alpha0 + f * alpha_stride
+__global__ __launch_bounds__(256) void k_fold_pred(const double* W, int64_t Np, int L, int P, int p,
+                                                   const double* alpha0, int64_t alpha_stride,
+                                                   const int32_t* chunk_seg, const int64_t* chunk_pos,
+                                                   const int64_t* chunk_len, const int32_t* chr_col0, int nchr,
+                                                   const int32_t* cidx, int64_t N, double* pred) {
+  extern __shared__ double sAl[];
+  const int ch = blockIdx.x;
+  const int f = chunk_seg[ch];
+  const int64_t p0 = chunk_pos[ch], plen = chunk_len[ch];
+  const double* al = alpha0 + (int64_t)f * alpha_stride;
+  for (int c = threadIdx.x; c < L; c += 256) sAl[c] = al[c];
+  __syncthreads();
+  if (threadIdx.x >= plen) return;
+  const int64_t pos = p0 + threadIdx.x;
+  const int32_t n = cidx[pos];
+  if (n < 0) return;
+  for (int c = 0; c < nchr; ++c) {
+    double acc = 0.0;
+    const double* w = W + ((int64_t)chr_col0[c] * P + p) * Np + pos;
+    const int nn = chr_col0[c + 1] - chr_col0[c];
+    for (int t = 0; t < nn; ++t) acc = fma(w[(int64_t)t * P * Np], sAl[chr_col0[c] + t], acc);
+    pred[(int64_t)c * N + n] = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct DevBufs {
+  std::vector<void*> ptrs;
+  ~DevBufs() { for (void* p : ptrs) if (p) hipFree(p); }
+  template <class T> hipError_t alloc(T** p, size_t n) {
+    *p = nullptr;
+    hipError_t e = hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e == hipSuccess) ptrs.push_back(*p);
+    return e;
+  }
+};
+
+#define L1X_HIP(call)                                                                  \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) {                                                            \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                    \
+      return RG_ERR_HIP;                                                               \
+    }                                                                                  \
+  } while (0)
+
+struct L1Common {
+  rg_ctx* ctx; hipStream_t st;
+  int L, P, n64, rtot, T, nchr;
+  int64_t msz, Np, N;
+  std::vector<int32_t> col0;
+  int32_t* d_col0 = nullptr;
+  double* d_pred = nullptr;
+  DevBufs bufs;
+};
+
+int l1_common_init(rg_ctx* ctx, L1Common& c, int nchr, const int32_t* cols_per_chr, const char* who) {
+  if (!ctx->have_problem || !ctx->d_W) { ctx->err = std::string(who) + ": no level-0 predictors"; return RG_ERR_STATE; }
+  c.ctx = ctx; c.st = ctx->stream;
+  c.L = ctx->B_total * ctx->R0; c.P = ctx->P; c.Np = ctx->Np; c.N = ctx->N; c.nchr = nchr;
+  c.col0.assign(nchr + 1, 0);
+  for (int i = 0; i < nchr; ++i) c.col0[i + 1] = c.col0[i] + cols_per_chr[i];
+  if (c.col0[nchr] != c.L) { ctx->err = std::string(who) + ": cols_per_chr does not sum to n_blocks*R0"; return RG_ERR_ARG; }
+  c.n64 = (int)rg_round_up(c.L, CT); c.rtot = c.n64 + CT; c.T = c.n64 / CT;
+  c.msz = (int64_t)c.rtot * c.n64;
+  L1X_HIP(c.bufs.alloc(&c.d_col0, nchr + 1));
+  L1X_HIP(c.bufs.alloc(&c.d_pred, (size_t)nchr * c.N));
+  L1X_HIP(hipMemcpyAsync(c.d_col0, c.col0.data(), sizeof(int32_t) * (nchr + 1), hipMemcpyHostToDevice, c.st));
+  return RG_OK;
+}
+
+// compact (N) host vector -> position space (Np), zeros elsewhere
+void to_pos(const rg_ctx* ctx, const double* src, std::vector<double>& dst) {
+  dst.assign((size_t)ctx->Np, 0.0);
+  for (int64_t n = 0; n < ctx->N; ++n) dst[(size_t)ctx->h_posc[n]] = src[n];
+}
+
+int check_spd(rg_ctx* ctx, bool* bad) {
+  int32_t info[2] = {0, 0};
+  L1X_HIP(hipMemcpy(info, ctx->d_info, sizeof(info), hipMemcpyDeviceToHost));
+  *bad = info[1] != 0;
+  if (*bad) L1X_HIP(hipMemset(ctx->d_info + 1, 0, sizeof(int32_t)));
+  return RG_OK;
+}
+
+// H = (G + tau I)^-1 for `nsh` shifts at once.  G: (n64+64) x n64 (lower triangle used).
+//   sysI: [nsh][2*n64][n64] workspace; on exit rows n64.. of system s hold Y_s = L_s^-T;  Hs[s] = Y_s Y_s^T.
+int invert_shifted(rg_ctx* ctx, const L1Common& c, const double* d_G, const double* d_shift, int nsh,
+                   const double* d_eye, double* d_sysI, double* d_dinv, double* d_H /*[nsh][n64][n64]*/) {
+  const int n64 = c.n64;
+  const int64_t ssz = (int64_t)2 * n64 * n64;
+  rg_launch_chol_solve_formed_x(c.st, d_G, 0, nullptr, 0, 1, d_shift, nsh, nullptr, c.L, 1, d_sysI, ssz, n64,
+                                n64, 0, d_dinv, ctx->d_info + 1, &ctx->tm.n_chol_launches, 0, d_eye, 0, n64);
+  for (int s = 0; s < nsh; ++s) {
+    const double* Y = d_sysI + s * ssz + (int64_t)n64 * n64;
+    rg_launch_dgemm_nt(c.st, Y, n64, Y, n64, n64, n64, n64, d_H + (int64_t)s * n64 * n64, n64);
+  }
+  return RG_OK;
+}
+
+}  // namespace
+
+// =========================================================================================================
+// QT, leave-one-out
+// =========================================================================================================
+int rg_l1_qt_loocv_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_t* cols_per_chr,
+                        double* cumsum_out, int32_t* best_out, double* pred_out) {
+  if (R1 < 1 || R1 > 16) { ctx->err = "rg_l1_qt_loocv: n_ridge_l1 must be in [1,16]"; return RG_ERR_ARG; }
+  if (!ctx->loocv) { ctx->err = "rg_l1_qt_loocv: the problem was set up for K-fold CV"; return RG_ERR_STATE; }
+  L1Common c;
+  int rc = l1_common_init(ctx, c, nchr, cols_per_chr, "rg_l1_qt_loocv");
+  if (rc) return rc;
+  hipStream_t st = c.st;
+  const int L = c.L, P = c.P, n64 = c.n64, T = c.T;
+  const int64_t Np = c.Np, N = c.N;
+  const unsigned gpos = (unsigned)((Np + 255) / 256);
+  double *d_G, *d_eye, *d_sysI, *d_dinv, *d_H, *d_tau, *d_Wt, *d_Ut, *d_b, *d_part;
+  L1X_HIP(c.bufs.alloc(&d_G, (size_t)c.msz));
+  L1X_HIP(c.bufs.alloc(&d_eye, (size_t)n64 * n64));
+  L1X_HIP(c.bufs.alloc(&d_sysI, (size_t)R1 * 2 * n64 * n64));
+  L1X_HIP(c.bufs.alloc(&d_dinv, (size_t)R1 * T * CT * CT));
+  L1X_HIP(c.bufs.alloc(&d_H, (size_t)R1 * n64 * n64));
+  L1X_HIP(c.bufs.alloc(&d_tau, (size_t)R1));
+  L1X_HIP(c.bufs.alloc(&d_Wt, (size_t)Np * n64));
+  L1X_HIP(c.bufs.alloc(&d_Ut, (size_t)Np * n64));
+  L1X_HIP(c.bufs.alloc(&d_b, (size_t)n64));
+  L1X_HIP(c.bufs.alloc(&d_part, (size_t)gpos * LOO_NPART));
+  hipLaunchKernelGGL(k_eye, dim3((unsigned)(((int64_t)n64 * n64 + 255) / 256)), dim3(256), 0, st, d_eye, n64);
+  std::vector<double> hpart((size_t)gpos * LOO_NPART);
+
+  for (int p = 0; p < P; ++p) {
+    const double* d_y = ctx->d_V + (int64_t)(ctx->C + p) * Np;
+    // G = W^T W with W^T y as row n64 (xtx, zvec of Step1_Models.cpp:893-907)
+    WgArgs g{ctx->d_W, ctx->d_zero, Np, L, P, p, n64, nullptr, d_y, nullptr, nullptr, 0, d_G, c.msz};
+    hipLaunchKernelGGL(k_wgram, dim3(T * (T + 1) / 2 + T, 1), dim3(256), 0, st, g, ctx->seg, T);
+    hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, ctx->d_W, Np, L, P, p,
+                       n64, d_Wt);
+    L1X_HIP(hipMemcpyAsync(d_tau, tau + (int64_t)p * R1, sizeof(double) * R1, hipMemcpyHostToDevice, st));
+    rc = invert_shifted(ctx, c, d_G, d_tau, R1, d_eye, d_sysI, d_dinv, d_H);
+    if (rc) return rc;
+    const double* d_z = d_G + (int64_t)n64 * n64;  // W^T y (padded with zeros to n64)
+    double* cs = cumsum_out + (int64_t)p * 5 * R1;
+    for (int t = 0; t < 5 * R1; ++t) cs[t] = 0.0;
+    LooArgs la{ctx->d_W, d_Ut, d_b, Np, L, P, p, d_y, nullptr, nullptr, nullptr, nullptr, 0};
+    auto prepare = [&](int j) {
+      const double* H = d_H + (int64_t)j * n64 * n64;
+      hipLaunchKernelGGL(k_symv, dim3((n64 + 3) / 4), dim3(256), 0, st, H, d_z, n64, d_b);
+      rg_launch_dgemm_nt(st, H, n64, d_Wt, n64, n64, (int)Np, n64, d_Ut, Np);
+    };
+    for (int j = 0; j < R1; ++j) {
+      prepare(j);
+      hipLaunchKernelGGL(k_loo_cv, dim3(gpos), dim3(256), 0, st, la, d_part);
+      L1X_HIP(hipMemcpyAsync(hpart.data(), d_part, sizeof(double) * hpart.size(), hipMemcpyDeviceToHost, st));
+      L1X_HIP(hipStreamSynchronize(st));
+      double sx = 0, sx2 = 0, sxy = 0;
+      for (unsigned b = 0; b < gpos; ++b) {
+        sx += hpart[(size_t)b * LOO_NPART]; sx2 += hpart[(size_t)b * LOO_NPART + 2]; sxy += hpart[(size_t)b * LOO_NPART + 4];
+      }
+      cs[0 * R1 + j] = sx; cs[2 * R1 + j] = sx2; cs[4 * R1 + j] = sxy;
+      cs[1 * R1 + j] = 0.0;                                  // Sy preset (Step1_Models.cpp:890)
+      cs[3 * R1 + j] = ctx->neff[p] - ctx->C;                // Sy2 = Neff - ncov (:891)
+    }
+    bool bad = false;
+    if ((rc = check_spd(ctx, &bad))) return rc;
+    if (bad) { ctx->err = "level 1 ridge system is not positive definite"; return RG_ERR_NOT_SPD; }
+    int best = 0; double minv = 1e10;
+    for (int j = 0; j < R1; ++j) {
+      const double perf = (cs[2 * R1 + j] + cs[3 * R1 + j] - 2 * cs[4 * R1 + j]) / ctx->neff[p];
+      if (perf < minv) { best = j; minv = perf; }
+    }
+    best_out[p] = best;
+    if (best != R1 - 1) prepare(best);
+    L1X_HIP(hipMemsetAsync(c.d_pred, 0, sizeof(double) * (size_t)nchr * N, st));
+    hipLaunchKernelGGL(k_loo_pred, dim3(gpos), dim3(256), 0, st, la, c.d_col0, nchr, ctx->d_cidx, N, c.d_pred);
+    L1X_HIP(hipMemcpyAsync(pred_out + (int64_t)p * nchr * N, c.d_pred, sizeof(double) * (size_t)nchr * N,
+                           hipMemcpyDeviceToHost, st));
+    L1X_HIP(hipStreamSynchronize(st));
+  }
+  return RG_OK;
+}
+
+// =========================================================================================================
+// BT logistic ridge
+// =========================================================================================================
+namespace {
+
+struct BtState {
+  rg_ctx* ctx; L1Common* c; int p, nchain, nchunk;
+  BtArgs a;
+  double *d_beta, *d_score, *d_tauc, *d_part, *d_sys, *d_dinv;
+  int32_t* d_map;
+  std::vector<double> h_part, h_score, h_sol;
+};
+
+// state (wgt, z, r, sums) of every chain at the coefficients in hbeta [nchain][n64]
+int bt_eval(BtState& s, const std::vector<double>& hbeta, std::vector<double>& sums /*[nchain][BT_NPART]*/) {
+  rg_ctx* ctx = s.ctx;
+  hipStream_t st = s.c->st;
+  L1X_HIP(hipMemcpyAsync(s.d_beta, hbeta.data(), sizeof(double) * hbeta.size(), hipMemcpyHostToDevice, st));
+  for (int ch0 = 0; ch0 < s.nchain; ch0 += NCH)
+    hipLaunchKernelGGL(k_bt_eval, dim3(s.nchunk), dim3(256), 0, st, s.a, ch0, ctx->d_c256_seg, ctx->d_c256_pos,
+                       ctx->d_c256_len, s.d_part);
+  L1X_HIP(hipMemcpyAsync(s.h_part.data(), s.d_part, sizeof(double) * s.h_part.size(), hipMemcpyDeviceToHost, st));
+  L1X_HIP(hipStreamSynchronize(st));
+  sums.assign((size_t)s.nchain * BT_NPART, 0.0);
+  for (int chk = 0; chk < s.nchunk; ++chk)
+    for (int t = 0; t < s.nchain * BT_NPART; ++t) sums[t] += s.h_part[(size_t)chk * s.nchain * BT_NPART + t];
+  return RG_OK;
+}
+
+// score of every chain at the state of the last bt_eval; returns max |score| per chain
+int bt_score(BtState& s, const std::vector<double>& tauc, std::vector<double>& maxabs) {
+  rg_ctx* ctx = s.ctx;
+  hipStream_t st = s.c->st;
+  L1X_HIP(hipMemcpyAsync(s.d_tauc, tauc.data(), sizeof(double) * s.nchain, hipMemcpyHostToDevice, st));
+  for (int ch0 = 0; ch0 < s.nchain; ch0 += NCH)
+    hipLaunchKernelGGL(k_bt_score, dim3(s.c->L), dim3(256), 0, st, s.a, ch0, s.d_tauc, s.d_score);
+  L1X_HIP(hipMemcpyAsync(s.h_score.data(), s.d_score, sizeof(double) * s.h_score.size(), hipMemcpyDeviceToHost, st));
+  L1X_HIP(hipStreamSynchronize(st));
+  maxabs.assign(s.nchain, 0.0);
+  for (int ch = 0; ch < s.nchain; ++ch)
+    for (int k = 0; k < s.c->L; ++k) maxabs[ch] = std::max(maxabs[ch], std::fabs(s.h_score[(size_t)ch * s.c->n64 + k]));
+  return RG_OK;
+}
+
+// (X^T W X + tau I) x = rhs for the chains in `act` (rhs = X^T W z from the extra row, or the score);
+// solutions land in h_sol [nchain][n64].  *bad is set when a system is not positive definite.
+int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<double>& tauc, bool rhs_is_score,
+             bool* bad) {
+  rg_ctx* ctx = s.ctx;
+  L1Common& c = *s.c;
+  hipStream_t st = c.st;
+  const int na = (int)act.size();
+  L1X_HIP(hipMemcpyAsync(s.d_map, act.data(), sizeof(int32_t) * na, hipMemcpyHostToDevice, st));
+  L1X_HIP(hipMemcpyAsync(s.d_tauc, tauc.data(), sizeof(double) * s.nchain, hipMemcpyHostToDevice, st));
+  WgArgs g{ctx->d_W, ctx->d_zero, c.Np, c.L, c.P, s.p, c.n64, s.a.wv, rhs_is_score ? nullptr : s.a.zv, s.d_tauc,
+           s.d_map, s.a.kfold, s.d_sys, c.msz};
+  hipLaunchKernelGGL(k_wgram, dim3(c.T * (c.T + 1) / 2 + c.T, na), dim3(256), 0, st, g, ctx->seg, c.T);
+  if (rhs_is_score)
+    for (int i = 0; i < na; ++i)
+      L1X_HIP(hipMemcpyAsync(s.d_sys + (int64_t)i * c.msz + (int64_t)c.n64 * c.n64, s.d_score + (int64_t)act[i] * c.n64,
+                             sizeof(double) * c.L, hipMemcpyDeviceToDevice, st));
+  rg_launch_chol_solve(st, s.d_sys, c.msz, na, c.n64, CT, 1, s.d_dinv, ctx->d_info + 1, &ctx->tm.n_chol_launches);
+  for (int i = 0; i < na; ++i)
+    L1X_HIP(hipMemcpyAsync(s.h_sol.data() + (size_t)act[i] * c.n64, s.d_sys + (int64_t)i * c.msz + (int64_t)c.n64 * c.n64,
+                           sizeof(double) * c.n64, hipMemcpyDeviceToHost, st));
+  L1X_HIP(hipStreamSynchronize(st));
+  return check_spd(ctx, bad);
+}
+
+// run_log_ridge_loocv (Step1_Models.cpp:1288-1374) for the single all-sample chain; beta in/out (n64 padded).
+// On success the device state (wgt, r) is the state at the returned beta.
+int bt_newton_loocv(BtState& s, double lam, std::vector<double>& beta, const rg_bt_options& o, bool* ok) {
+  const int L = s.c->L;
+  *ok = false;
+  std::vector<double> sums, maxabs, betanew = beta, step(beta.size(), 0.0);
+  std::vector<double> tauc(1, lam);
+  std::vector<int32_t> act(1, 0);
+  auto pen = [&](const std::vector<double>& b) { double t = 0; for (int k = 0; k < L; ++k) t += b[k] * b[k]; return lam * t; };
+  int rc = bt_eval(s, beta, sums);
+  if (rc) return rc;
+  double fn_start = sums[6] + pen(beta), fn_end = fn_start;
+  if (sums[7] != 0.0) return RG_OK;
+  if ((rc = bt_score(s, tauc, maxabs))) return rc;
+  int niter = 0;
+  bool dev_conv = false;
+  while (true) {
+    if (++niter > o.niter_max_ridge) break;
+    bool bad = false;
+    if ((rc = bt_solve(s, act, tauc, true, &bad))) return rc;
+    if (bad) return RG_OK;
+    for (int k = 0; k < L; ++k) step[k] = s.h_sol[k];
+    for (int ls = 0; ls < o.niter_max_line_search; ++ls) {
+      for (int k = 0; k < L; ++k) betanew[k] = beta[k] + step[k];
+      if ((rc = bt_eval(s, betanew, sums))) return rc;
+      fn_end = sums[6] + pen(betanew);
+      if (sums[7] != 0.0) return RG_OK;
+      if (fn_end < fn_start + 1e-6) break;   // numtol
+      for (int k = 0; k < L; ++k) step[k] *= 0.5;
+    }
+    if ((rc = bt_score(s, tauc, maxabs))) return rc;
+    dev_conv = std::fabs(fn_end - fn_start) / (0.01 + std::fabs(fn_end)) < o.tol;
+    if (maxabs[0] < o.l1_ridge_tol) break;
+    beta = betanew;
+    fn_start = fn_end;
+  }
+  if (!dev_conv && niter > o.niter_max_ridge) return RG_OK;
+  beta = betanew;
+  *ok = true;
+  return RG_OK;
+}
+
+}  // namespace
+
+int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, const double* offset,
+                  const rg_bt_options* opt, int nchr, const int32_t* cols_per_chr, double* cumsum_out,
+                  int32_t* converged_out, int32_t* best_out, double* pred_out) {
+  if (R1 < 1 || R1 > 16) { ctx->err = "rg_l1_bt: n_ridge_l1 must be in [1,16]"; return RG_ERR_ARG; }
+  rg_bt_options o;
+  o.niter_max_ridge = 100; o.niter_max_line_search_ridge = 100; o.niter_max_line_search = 25;
+  o.l1_ridge_tol = 1e-4; o.tol = 1e-8;
+  if (opt) o = *opt;
+  L1Common c;
+  int rc = l1_common_init(ctx, c, nchr, cols_per_chr, "rg_l1_bt");
+  if (rc) return rc;
+  hipStream_t st = c.st;
+  const int L = c.L, P = c.P, n64 = c.n64, T = c.T;
+  const int64_t Np = c.Np, N = c.N;
+  const bool loocv = ctx->loocv;
+  const int K = ctx->K;
+  const int nchain = loocv ? 1 : K;
+  const unsigned gpos = (unsigned)((Np + 255) / 256);
+
+  BtState s;
+  s.ctx = ctx; s.c = &c; s.nchain = nchain; s.nchunk = ctx->n_c256;
+  double *d_yraw, *d_off, *d_wv, *d_zv, *d_rv, *d_betas = nullptr;
+  L1X_HIP(c.bufs.alloc(&d_yraw, (size_t)Np));
+  L1X_HIP(c.bufs.alloc(&d_off, (size_t)Np));
+  L1X_HIP(c.bufs.alloc(&d_wv, (size_t)nchain * Np));
+  L1X_HIP(c.bufs.alloc(&d_zv, (size_t)nchain * Np));
+  L1X_HIP(c.bufs.alloc(&d_rv, (size_t)nchain * Np));
+  L1X_HIP(c.bufs.alloc(&s.d_beta, (size_t)nchain * n64));
+  L1X_HIP(c.bufs.alloc(&s.d_score, (size_t)nchain * n64));
+  L1X_HIP(c.bufs.alloc(&s.d_tauc, (size_t)nchain));
+  L1X_HIP(c.bufs.alloc(&s.d_part, (size_t)s.nchunk * nchain * BT_NPART));
+  L1X_HIP(c.bufs.alloc(&s.d_sys, (size_t)nchain * c.msz));
+  L1X_HIP(c.bufs.alloc(&s.d_dinv, (size_t)nchain * T * CT * CT));
+  L1X_HIP(c.bufs.alloc(&s.d_map, (size_t)nchain));
+  L1X_HIP(hipMemsetAsync(s.d_score, 0, sizeof(double) * (size_t)nchain * n64, st));
+  s.h_part.resize((size_t)s.nchunk * nchain * BT_NPART);
+  s.h_score.resize((size_t)nchain * n64);
+  s.h_sol.assign((size_t)nchain * n64, 0.0);
+  // LOOCV extras: identity rows, inverse, sample-major W and U^T = H W^T
+  double *d_eye = nullptr, *d_sysI = nullptr, *d_H = nullptr, *d_Wt = nullptr, *d_Ut = nullptr, *d_G = nullptr,
+         *d_lpart = nullptr, *d_tau1 = nullptr, *d_dinvI = nullptr;
+  if (loocv) {
+    L1X_HIP(c.bufs.alloc(&d_eye, (size_t)n64 * n64));
+    L1X_HIP(c.bufs.alloc(&d_sysI, (size_t)2 * n64 * n64));
+    L1X_HIP(c.bufs.alloc(&d_dinvI, (size_t)T * CT * CT));
+    L1X_HIP(c.bufs.alloc(&d_H, (size_t)n64 * n64));
+    L1X_HIP(c.bufs.alloc(&d_G, (size_t)c.msz));
+    L1X_HIP(c.bufs.alloc(&d_Wt, (size_t)Np * n64));
+    L1X_HIP(c.bufs.alloc(&d_Ut, (size_t)Np * n64));
+    L1X_HIP(c.bufs.alloc(&d_lpart, (size_t)gpos * LOO_NPART));
+    L1X_HIP(c.bufs.alloc(&d_tau1, 1));
+    hipLaunchKernelGGL(k_eye, dim3((unsigned)(((int64_t)n64 * n64 + 255) / 256)), dim3(256), 0, st, d_eye, n64);
+  } else {
+    L1X_HIP(c.bufs.alloc(&d_betas, (size_t)K * R1 * n64));
+  }
+  std::vector<double> hpos, hl((size_t)gpos * LOO_NPART);
+
+  for (int p = 0; p < P; ++p) {
+    double* cs = cumsum_out + (int64_t)p * 6 * R1;
+    for (int t = 0; t < 6 * R1; ++t) cs[t] = 0.0;
+    converged_out[p] = 0;
+    best_out[p] = 0;
+    const double* taup = tau + (int64_t)p * R1;
+    to_pos(ctx, yraw + (int64_t)p * N, hpos);
+    L1X_HIP(hipMemcpyAsync(d_yraw, hpos.data(), sizeof(double) * Np, hipMemcpyHostToDevice, st));
+    L1X_HIP(hipStreamSynchronize(st));
+    to_pos(ctx, offset + (int64_t)p * N, hpos);
+    L1X_HIP(hipMemcpyAsync(d_off, hpos.data(), sizeof(double) * Np, hipMemcpyHostToDevice, st));
+    L1X_HIP(hipStreamSynchronize(st));
+    s.p = p;
+    s.a = BtArgs{ctx->d_W, Np, L, P, p, n64, d_yraw, d_off, ctx->d_maskp + (int64_t)p * Np, s.d_beta, nchain,
+                 loocv ? 0 : 1, d_wv, d_zv, d_rv};
+    bool ok = true;
+
+    if (!loocv) {
+      // ---- K-fold: the K fold models advance in lockstep launches, each with its own (tau index, iteration) ----
+      std::vector<double> beta((size_t)K * n64, 0.0), betaold = beta, sums, maxabs, tauc(K), hbetas((size_t)K * R1 * n64, 0.0);
+      std::vector<int> jj(K, 0), niter(K, 0), solved(K, 0), halv(K, 0);
+      int ndone = 0;
+      std::vector<char> done(K, 0);
+      while (ok && ndone < K) {
+        if ((rc = bt_eval(s, beta, sums))) return rc;
+        for (int ch = 0; ch < K; ++ch) tauc[ch] = taup[std::min(jj[ch], R1 - 1)];
+        bool any_solved = false;
+        for (int ch = 0; ch < K; ++ch) any_solved |= (!done[ch] && solved[ch]);
+        if (any_solved && (rc = bt_score(s, tauc, maxabs))) return rc;
+        std::vector<int32_t> act;
+        for (int ch = 0; ch < K && ok; ++ch) {
+          if (done[ch]) continue;
+          const double* sm = sums.data() + (size_t)ch * BT_NPART;
+          if (solved[ch]) {
+            if (sm[7] != 0.0) {  // zero weights: halve towards the previous iterate (Step1_Models.cpp:1066-1079)
+              if (++halv[ch] > o.niter_max_line_search_ridge) { ok = false; break; }
+              for (int k = 0; k < L; ++k)
+                beta[(size_t)ch * n64 + k] = 0.5 * (betaold[(size_t)ch * n64 + k] + beta[(size_t)ch * n64 + k]);
+              continue;  // re-evaluate, no new solve
+            }
+            halv[ch] = 0;
+            if (maxabs[ch] < o.l1_ridge_tol) {  // converged at tau_j: record beta + held-out sums
+              const int j = jj[ch];
+              std::memcpy(hbetas.data() + ((size_t)ch * R1 + j) * n64, beta.data() + (size_t)ch * n64, sizeof(double) * n64);
+              for (int t = 0; t < 6; ++t) cs[t * R1 + j] += sm[t];
+              if (++jj[ch] == R1) { done[ch] = 1; ++ndone; continue; }
+              niter[ch] = 0;
+            }
+          } else if (sm[7] != 0.0) { ok = false; break; }
+          if (++niter[ch] > o.niter_max_ridge) { ok = false; break; }
+          std::memcpy(betaold.data() + (size_t)ch * n64, beta.data() + (size_t)ch * n64, sizeof(double) * n64);
+          act.push_back(ch);
+        }
+        if (!ok) break;
+        if (act.empty()) continue;
+        for (int ch = 0; ch < K; ++ch) tauc[ch] = taup[std::min(jj[ch], R1 - 1)];
+        bool bad = false;
+        if ((rc = bt_solve(s, act, tauc, false, &bad))) return rc;
+        if (bad) { ok = false; break; }
+        for (int ch : act) {
+          std::memcpy(beta.data() + (size_t)ch * n64, s.h_sol.data() + (size_t)ch * n64, sizeof(double) * L);
+          solved[ch] = 1;
+        }
+      }
+      if (!ok) continue;  // pheno_l1_not_converged: LOCO predictions are skipped (Data.cpp:1016-1021)
+      converged_out[p] = 1;
+      int best = 0; double minv = 1e10;
+      for (int j = 0; j < R1; ++j) {
+        const double perf = cs[5 * R1 + j] / ctx->neff[p];   // -logLik / Neff (Data.cpp:1030)
+        if (perf < minv) { best = j; minv = perf; }
+      }
+      best_out[p] = best;
+      L1X_HIP(hipMemcpyAsync(d_betas, hbetas.data(), sizeof(double) * hbetas.size(), hipMemcpyHostToDevice, st));
+      L1X_HIP(hipMemsetAsync(c.d_pred, 0, sizeof(double) * (size_t)nchr * N, st));
+      hipLaunchKernelGGL(k_fold_pred, dim3(ctx->n_c256), dim3(256), sizeof(double) * L, st, ctx->d_W, Np, L, P, p,
+                         d_betas + (int64_t)best * n64, (int64_t)R1 * n64, ctx->d_c256_seg, ctx->d_c256_pos,
+                         ctx->d_c256_len, c.d_col0, nchr, ctx->d_cidx, N, c.d_pred);
+    } else {
+      // ---- LOOCV: warm-started Newton per tau, then the leave-one-out shortcut -----------------------------
+      hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, ctx->d_W, Np, L, P, p,
+                         n64, d_Wt);
+      std::vector<double> beta((size_t)n64, 0.0);
+      LooArgs la{ctx->d_W, d_Ut, s.d_beta, Np, L, P, p, d_yraw, d_rv, d_wv, d_off, ctx->d_maskp + (int64_t)p * Np, 1};
+      auto loo_setup = [&](double lam) -> int {   // H = (X^T W X + lam I)^-1 at the current weights, U^T = H W^T
+        WgArgs g{ctx->d_W, ctx->d_zero, Np, L, P, p, n64, d_wv, nullptr, nullptr, nullptr, 0, d_G, c.msz};
+        hipLaunchKernelGGL(k_wgram, dim3(T * (T + 1) / 2 + T, 1), dim3(256), 0, st, g, ctx->seg, T);
+        L1X_HIP(hipMemcpyAsync(d_tau1, &lam, sizeof(double), hipMemcpyHostToDevice, st));
+        L1X_HIP(hipStreamSynchronize(st));
+        int r2 = invert_shifted(ctx, c, d_G, d_tau1, 1, d_eye, d_sysI, d_dinvI, d_H);
+        if (r2) return r2;
+        rg_launch_dgemm_nt(st, d_H, n64, d_Wt, n64, n64, (int)Np, n64, d_Ut, Np);
+        return RG_OK;
+      };
+      for (int j = 0; j < R1 && ok; ++j) {
+        bool conv = false;
+        if ((rc = bt_newton_loocv(s, taup[j], beta, o, &conv))) return rc;
+        if (!conv) { ok = false; break; }
+        if ((rc = loo_setup(taup[j]))) return rc;
+        hipLaunchKernelGGL(k_loo_cv, dim3(gpos), dim3(256), 0, st, la, d_lpart);
+        L1X_HIP(hipMemcpyAsync(hl.data(), d_lpart, sizeof(double) * hl.size(), hipMemcpyDeviceToHost, st));
+        L1X_HIP(hipStreamSynchronize(st));
+        for (unsigned b = 0; b < gpos; ++b)
+          for (int t = 0; t < 6; ++t) cs[t * R1 + j] += hl[(size_t)b * LOO_NPART + t];
+        bool bad = false;
+        if ((rc = check_spd(ctx, &bad))) return rc;
+        if (bad) ok = false;
+      }
+      if (!ok) continue;
+      converged_out[p] = 1;
+      int best = 0; double minv = 1e10;
+      for (int j = 0; j < R1; ++j) {
+        const double perf = cs[5 * R1 + j] / ctx->neff[p];
+        if (perf < minv) { best = j; minv = perf; }
+      }
+      best_out[p] = best;
+      // make_predictions_binary_loocv refits at tau* from beta = 0 (Data.cpp:1499-1503)
+      std::fill(beta.begin(), beta.end(), 0.0);
+      bool conv = false;
+      if ((rc = bt_newton_loocv(s, taup[best], beta, o, &conv))) return rc;
+      if (!conv) { converged_out[p] = 0; continue; }
+      if ((rc = loo_setup(taup[best]))) return rc;
+      L1X_HIP(hipMemsetAsync(c.d_pred, 0, sizeof(double) * (size_t)nchr * N, st));
+      hipLaunchKernelGGL(k_loo_pred, dim3(gpos), dim3(256), 0, st, la, c.d_col0, nchr, ctx->d_cidx, N, c.d_pred);
+    }
+    L1X_HIP(hipMemcpyAsync(pred_out + (int64_t)p * nchr * N, c.d_pred, sizeof(double) * (size_t)nchr * N,
+                           hipMemcpyDeviceToHost, st));
+    L1X_HIP(hipStreamSynchronize(st));
+  }
+  return RG_OK;
+}

@@ -204,6 +204,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if ((rc = dev_upload(ctx, &ctx->d_act, act))) return rc;
   if ((rc = dev_upload(ctx, &ctx->d_keptp, keptp))) return rc;
   if ((rc = dev_upload(ctx, &ctx->d_posc, posc))) return rc;
+  ctx->h_posc = posc;
   if ((rc = dev_upload(ctx, &ctx->d_V, V))) return rc;
   if ((rc = dev_upload(ctx, &ctx->d_maskp, maskp))) return rc;
   if ((rc = dev_upload(ctx, &ctx->d_Q, Q))) return rc;
@@ -458,6 +459,30 @@ int rg_l1_qt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, int32_t nchr,
   int rc = rg_sync(ctx);
   if (rc) return rc;
   return rg_l1_qt_impl(ctx, n_ridge_l1, tau, nchr, cols_per_chr, cumsum_out, best_out, pred_out);
+}
+
+int rg_l1_qt_loocv(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, int32_t nchr,
+                   const int32_t* cols_per_chr, double* cumsum_out, int32_t* best_out, double* pred_out) {
+  if (!ctx) return RG_ERR_ARG;
+  hipSetDevice(ctx->device);
+  if (!tau || nchr < 1 || !cols_per_chr || !cumsum_out || !best_out || !pred_out) { ctx->err = "rg_l1_qt_loocv: bad arguments"; return RG_ERR_ARG; }
+  int rc = rg_sync(ctx);
+  if (rc) return rc;
+  return rg_l1_qt_loocv_impl(ctx, n_ridge_l1, tau, nchr, cols_per_chr, cumsum_out, best_out, pred_out);
+}
+
+int rg_l1_bt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, const double* yraw, const double* offset,
+             const rg_bt_options* opt, int32_t nchr, const int32_t* cols_per_chr, double* cumsum_out,
+             int32_t* converged_out, int32_t* best_out, double* pred_out) {
+  if (!ctx) return RG_ERR_ARG;
+  hipSetDevice(ctx->device);
+  if (!tau || !yraw || !offset || nchr < 1 || !cols_per_chr || !cumsum_out || !converged_out || !best_out || !pred_out) {
+    ctx->err = "rg_l1_bt: bad arguments"; return RG_ERR_ARG;
+  }
+  int rc = rg_sync(ctx);
+  if (rc) return rc;
+  return rg_l1_bt_impl(ctx, n_ridge_l1, tau, yraw, offset, opt, nchr, cols_per_chr, cumsum_out, converged_out,
+                       best_out, pred_out);
 }
 
 int rg_enable_timing(rg_ctx* ctx, int on) {

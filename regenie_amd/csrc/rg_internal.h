@@ -48,6 +48,7 @@ struct rg_ctx {
   int P = 0, C = 0, K = 0, R0 = 0, ref_first = 0, B_total = 0, bs_max = 0;
   int n_active = 0;
   std::vector<int64_t> fold_cstart;  // compact start of each fold (K+1)
+  std::vector<int64_t> h_posc;       // position of each compact sample (host copy)
   std::vector<double> lambda, neff;
   SegLayout seg;
 
@@ -193,3 +194,9 @@ void rg_launch_l0_loocv(hipStream_t st, const LoocvArgs& a, double* part0, doubl
 struct L1Args;
 int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_t* cols_per_chr,
                   double* cumsum_out, int32_t* best_out, double* pred_out);
+// l1x.hip
+int rg_l1_qt_loocv_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_t* cols_per_chr,
+                        double* cumsum_out, int32_t* best_out, double* pred_out);
+int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, const double* offset,
+                  const rg_bt_options* opt, int nchr, const int32_t* cols_per_chr, double* cumsum_out,
+                  int32_t* converged_out, int32_t* best_out, double* pred_out);

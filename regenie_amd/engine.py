@@ -31,6 +31,12 @@ class RgProblem(C.Structure):
     ]
 
 
+class RgBtOptions(C.Structure):
+    _fields_ = [("niter_max_ridge", C.c_int32), ("niter_max_line_search_ridge", C.c_int32),
+                ("niter_max_line_search", C.c_int32), ("reserved0", C.c_int32),
+                ("l1_ridge_tol", C.c_double), ("tol", C.c_double)]
+
+
 class RgTiming(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("ms_prep", "ms_xy", "ms_gram", "ms_assemble", "ms_chol",
                                           "ms_solve", "ms_pred", "ms_l1_gram", "ms_l1_chol",
@@ -43,7 +49,7 @@ class RgTiming(C.Structure):
 
 EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_w_rows", "rg_w_bytes",
            "rg_set_w_buffer", "rg_w_device_ptr", "rg_l0_blocks", "rg_sync", "rg_l0_get_w",
-           "rg_l0_set_w", "rg_l1_qt", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8",
+           "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8",
            "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak"]
 
 
@@ -80,6 +86,9 @@ def load_library() -> C.CDLL:
     lib.rg_l0_set_w.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.rg_l1_qt.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_void_p]
+    lib.rg_l1_qt_loocv.argtypes = lib.rg_l1_qt.argtypes
+    lib.rg_l1_bt.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rg_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.rg_get_timing.argtypes = [C.c_void_p, C.POINTER(RgTiming)]
     lib.rg_k_gram_i8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
@@ -217,6 +226,43 @@ class Step1Engine:
         self._check(self.lib.rg_l1_qt(self.h, R1, tau.ctypes.data, nchr, cpc.ctypes.data, cs.ctypes.data,
                                       best.ctypes.data, pred.ctypes.data))
         return cs, best, [pred[p].T.copy() for p in range(P)]
+
+    def l1_qt_loocv(self, tau: np.ndarray, cols_per_chr: Sequence[int]):
+        """Leave-one-out level 1 (problem set up with cv_sizes=None).  Same returns as l1_qt."""
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        P, R1 = tau.shape
+        assert P == self.P
+        cpc = np.ascontiguousarray(cols_per_chr, dtype=np.int32)
+        nchr = cpc.size
+        cs = np.zeros((P, 5, R1))
+        best = np.zeros(P, dtype=np.int32)
+        pred = np.zeros((P, nchr, self.N))
+        self._check(self.lib.rg_l1_qt_loocv(self.h, R1, tau.ctypes.data, nchr, cpc.ctypes.data, cs.ctypes.data,
+                                            best.ctypes.data, pred.ctypes.data))
+        return cs, best, [pred[p].T.copy() for p in range(P)]
+
+    def l1_bt(self, tau: np.ndarray, yraw: np.ndarray, offset: np.ndarray, cols_per_chr: Sequence[int],
+              niter_max_ridge: int = 100, niter_max_line_search_ridge: int = 100,
+              niter_max_line_search: int = 25, l1_ridge_tol: float = 1e-4, tol: float = 1e-8):
+        """Logistic ridge level 1 (K-fold or LOOCV as the problem was set up).
+        Returns (cumsum [P,6,R1], converged [P] bool, best [P], pred [P][N,nchr])."""
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        P, R1 = tau.shape
+        assert P == self.P
+        yraw = np.asfortranarray(yraw, dtype=np.float64)
+        offset = np.asfortranarray(offset, dtype=np.float64)
+        assert yraw.shape == (self.N, P) and offset.shape == (self.N, P)
+        cpc = np.ascontiguousarray(cols_per_chr, dtype=np.int32)
+        nchr = cpc.size
+        o = RgBtOptions(niter_max_ridge, niter_max_line_search_ridge, niter_max_line_search, 0, l1_ridge_tol, tol)
+        cs = np.zeros((P, 6, R1))
+        conv = np.zeros(P, dtype=np.int32)
+        best = np.zeros(P, dtype=np.int32)
+        pred = np.zeros((P, nchr, self.N))
+        self._check(self.lib.rg_l1_bt(self.h, R1, tau.ctypes.data, yraw.ctypes.data, offset.ctypes.data,
+                                      C.byref(o), nchr, cpc.ctypes.data, cs.ctypes.data, conv.ctypes.data,
+                                      best.ctypes.data, pred.ctypes.data))
+        return cs, conv.astype(bool), best, [pred[p].T.copy() for p in range(P)]
 
     def enable_timing(self, on: bool = True):
         self._check(self.lib.rg_enable_timing(self.h, int(on)))

@@ -124,3 +124,80 @@ def write_plink(prefix, g, chroms, P=2, ncov=2, seed=3, h2=0.2, missing_pheno=0.
         fh.write("FID IID " + " ".join("Y%d" % (p + 1) for p in range(P)) + "\n")
         for i in range(N):
             fh.write("%d %d " % (i + 1, i + 1) + " ".join(("NA" if miss[i, p] else "%.15g" % Y[i, p]) for p in range(P)) + "\n")
+
+
+# ---- any trait mode / CV scheme through the C ABI, and the matching oracle run ---------------------
+def _use_loocv(opt, prep, force_kfold):
+    return bool(opt.loocv or (opt.bt and prep.n_analyzed < 5000 and not force_kfold))   # Data.cpp:353-356
+
+
+def oracle_step1_any(opt: orc.Step1Options, force_kfold: bool = False):
+    """orc.run_step1 with the option of keeping K-fold CV for a small binary-trait data set (the
+    reference switches BT runs below 5,000 samples to LOOCV, which would leave the BT K-fold model
+    untestable at oracle-friendly sizes).  Same calls, same order as orc.run_step1."""
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    bed, _ = orc.open_bed(opt.bed + ".bed", prep.n_file)
+    N, P = prep.Y.shape
+    blocks = orc.chrom_blocks(chrom, bim.chr_read, opt.bsize)
+    use_loocv = _use_loocv(opt, prep, force_kfold)
+    h0 = orc.set_ridge_params(opt.n_ridge_l0)
+    h1 = orc.set_ridge_params(opt.n_ridge_l1)
+    R0 = h0.size
+    lam = chrom.size * (1 - h0) / h0
+    cv_sizes = None if use_loocv else orc.set_folds(prep.ind_in_analysis, opt.cv_folds)
+    W = [np.zeros((N, len(blocks) * R0)) for _ in range(P)]
+    for b, (c, start, bs) in enumerate(blocks):
+        rows = np.asarray(bed[offs[start:start + bs]])
+        G = orc.read_chunk_from_bed(rows, prep.n_file, prep.ind_ignore, prep.ind_in_analysis, opt.ref_first)
+        G, _ = orc.residualize_genotypes(G, prep)
+        Wb = orc.ridge_level_0_loocv(G, prep, lam) if use_loocv else orc.ridge_level_0(G, prep, cv_sizes, lam)
+        for ph in range(P):
+            W[ph][:, b * R0:(b + 1) * R0] = Wb[ph]
+    return orc.finish_level_1(opt, prep, blocks, bim.chr_read, cv_sizes, lam, h1, W, use_loocv, [])
+
+
+def gpu_step1_any(opt: orc.Step1Options, force_kfold: bool = False, inject_W=None):
+    """Level 0 + level 1 through librg_step1_hip.so for QT/BT x K-fold/LOOCV.
+    inject_W: optional per-phenotype N x L predictors to load instead of running level 0."""
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    bed, _ = orc.open_bed(opt.bed + ".bed", prep.n_file)
+    blocks = orc.chrom_blocks(chrom, bim.chr_read, opt.bsize)
+    B = len(blocks)
+    use_loocv = _use_loocv(opt, prep, force_kfold)
+    h0 = orc.set_ridge_params(opt.n_ridge_l0)
+    h1 = orc.set_ridge_params(opt.n_ridge_l1)
+    lam = chrom.size * (1 - h0) / h0
+    cv_sizes = None if use_loocv else orc.set_folds(prep.ind_in_analysis, opt.cv_folds)
+    eng = Step1Engine(0)
+    eng.set_problem(X=prep.X, Y=prep.Y, mask=prep.mask, ind_in_analysis=prep.ind_in_analysis,
+                    cv_sizes=cv_sizes, lam=lam, neff=prep.Neff, n_file=prep.n_file, n_blocks_total=B,
+                    max_block_size=opt.bsize, ind_ignore=prep.ind_ignore if prep.ind_ignore.any() else None,
+                    ref_first=opt.ref_first)
+    N, P = prep.Y.shape
+    R0 = lam.size
+    if inject_W is None:
+        rows = [np.ascontiguousarray(bed[offs[s:s + bs]]) for (_, s, bs) in blocks]
+        eng.l0_blocks_host(list(range(B)), rows)
+        eng.sync()
+    else:
+        for b in range(B):
+            for ph in range(P):
+                eng.set_w(b, ph, inject_W[ph][:, b * R0:(b + 1) * R0])
+    L = B * R0
+    tau = np.stack([orc.tau_from_h(h1, L, opt.bt) for _ in range(P)])
+    chrcols = orc.chr_columns(blocks, bim.chr_read, R0)
+    cols = [nn for (_, _, nn) in chrcols]
+    conv = np.ones(P, bool)
+    if opt.bt:
+        cs, conv, best, pred = eng.l1_bt(tau, prep.Y_raw, prep.offset, cols,
+                                         niter_max_ridge=opt.niter_max_ridge,
+                                         niter_max_line_search_ridge=opt.niter_max_line_search_ridge,
+                                         niter_max_line_search=opt.niter_max_line_search)
+    elif use_loocv:
+        cs, best, pred = eng.l1_qt_loocv(tau, cols)
+    else:
+        cs, best, pred = eng.l1_qt(tau, cols)
+    loco = [loco_from_predictions(pred[ph], [c for (c, _, _) in chrcols], opt.nchrom) for ph in range(P)]
+    eng.close()
+    return dict(cumsum=cs, best=best, pred=pred, loco=loco, converged=conv, prep=prep, tau=tau, L=L,
+                use_loocv=use_loocv)
