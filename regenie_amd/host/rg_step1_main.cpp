@@ -8,8 +8,9 @@
 // residualisation, fold / block bookkeeping, LOCO assembly, writers) follow the reference functions
 // cited next to each routine.  There is no CPU compute fallback for the hot path.
 //
-// Not yet served by the GPU library in this revision (explicit errors, never silent): --bt, --loocv,
-// --pgen/--bgen input, --gz, --split-l0/--run-l0/--run-l1.
+// Served: --qt / --bt, K-fold CV / --loocv (and the reference's automatic LOOCV for --bt below 5,000 samples).
+// Not served in this revision (explicit errors, never silent): --pgen/--bgen input, --gz,
+// --split-l0/--run-l0/--run-l1.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -41,7 +42,8 @@ struct Params {
   std::vector<std::string> keep, remove, extract, exclude, pheno_cols, covar_cols;
   int bsize = 0, cv_folds = 5, n_ridge_l0 = 5, n_ridge_l1 = 5, nchrom = 23, threads = 0;
   bool bt = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
-       print_prs = false, force_step1 = false, lowmem = false, force_qt = false;
+       print_prs = false, force_step1 = false, lowmem = false, force_qt = false, cc12 = false;
+  int min_case_count = 10, niter_max = 50, niter_max_line_search = 25;
   std::vector<double> setl0, setl1;
   int device = 0;
 };
@@ -211,6 +213,9 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--force-step1") p.force_step1 = true;
     else if (a == "--force-qt") p.force_qt = true;
     else if (a == "--lowmem") p.lowmem = true;
+    else if (a == "--1" || a == "--cc12") p.cc12 = true;
+    else if (a == "--minCaseCount") p.min_case_count = atoi(need(i).c_str());
+    else if (a == "--niter") p.niter_max = atoi(need(i).c_str());
     else if (a == "--gz") usage_error("--gz is not available in this build (as in reference builds without Boost Iostreams)");
     else if (a == "--pgen" || a == "--bgen") usage_error(a + " input is not served by the GPU path yet; use --bed");
     else if (a == "--split-l0" || a == "--run-l0" || a == "--run-l1")
@@ -221,8 +226,6 @@ Params parse_args(int argc, char** argv) {
   if (p.bed.empty()) usage_error("must specify --bed");
   if (p.pheno_file.empty()) usage_error("option '--phenoFile' is required.");
   if (p.bsize < 1) usage_error("must specify the block size using '--bsize'.");
-  if (p.bt) usage_error("--bt (logistic level 1) is not served by the GPU path in this revision");
-  if (p.loocv) usage_error("--loocv is not served by the GPU path in this revision");
   if (p.cv_folds < 2) usage_error("number of CV folds must be at least 2");
   return p;
 }
@@ -244,7 +247,99 @@ struct Run {
   int P = 0, C = 0;
   std::vector<double> Y, X, neff, scale_Y;  // col-major N x P, N x C
   std::vector<uint8_t> mask;                // col-major N x P
+  std::vector<double> Yraw, offset;         // BT: phenotypes_raw (0/1) and offset_nullreg, col-major N x P
+  std::vector<uint8_t> pheno_pass;          // BT: null logistic model converged
 };
+
+// ---- binary traits: covariate-only logistic regression (Step1_Models.cpp:54-222) ---------------------------
+const double NUMTOL = 1e-6;                                   // Regenie.hpp numtol
+const double NUMTOL_EPS = 10 * 2.220446049250313e-16;         // Regenie.hpp:225
+double get_pvec1(double eta) {                                // Step1_Models.cpp:1799-1806
+  double pr = 1.0 - 1.0 / (std::exp(eta) + 1.0);
+  if (eta < -30.0) pr = NUMTOL_EPS / (1.0 + NUMTOL_EPS);
+  if (eta > 30.0) pr = 1.0 / (1.0 + NUMTOL_EPS);
+  return pr;
+}
+// dense solve by Gaussian elimination with partial pivoting (order = number of covariates)
+bool solve_dense(std::vector<double> A, std::vector<double> b, int n, std::vector<double>& x) {
+  for (int k = 0; k < n; ++k) {
+    int piv = k;
+    for (int i = k + 1; i < n; ++i) if (std::fabs(A[(size_t)i * n + k]) > std::fabs(A[(size_t)piv * n + k])) piv = i;
+    if (A[(size_t)piv * n + k] == 0.0) return false;
+    if (piv != k) { for (int j = 0; j < n; ++j) std::swap(A[(size_t)k * n + j], A[(size_t)piv * n + j]); std::swap(b[k], b[piv]); }
+    for (int i = k + 1; i < n; ++i) {
+      const double f = A[(size_t)i * n + k] / A[(size_t)k * n + k];
+      for (int j = k; j < n; ++j) A[(size_t)i * n + j] -= f * A[(size_t)k * n + j];
+      b[i] -= f * b[k];
+    }
+  }
+  x.assign(n, 0.0);
+  for (int i = n - 1; i >= 0; --i) {
+    double v = b[i];
+    for (int j = i + 1; j < n; ++j) v -= A[(size_t)i * n + j] * x[j];
+    x[i] = v / A[(size_t)i * n + i];
+  }
+  return true;
+}
+// fit_logistic (Step1_Models.cpp:156-222) for one phenotype, zero offset; eta_out = X beta on success
+bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t N, int C, const Params& prm,
+                  bool check_hs_dev, std::vector<double>& eta) {
+  std::vector<double> beta(C, 0.0), betanew(C, 0.0), pv(N), w(N);
+  auto dev = [&](const std::vector<double>& pp) {
+    double t = 0.0;
+    for (int64_t i = 0; i < N; ++i) if (mask[i]) t -= (y[i] == 0.0) ? std::log(1.0 - pp[i]) : std::log(pp[i]);
+    return 2.0 * t;
+  };
+  eta.assign(N, 0.0);
+  for (int64_t i = 0; i < N; ++i) pv[i] = get_pvec1(0.0);
+  double dev_old = dev(pv), dev_new = dev_old, diff_dev = 0.0;
+  int niter = 0;
+  bool small_score = false;
+  while (true) {
+    if (++niter > prm.niter_max) break;
+    for (int64_t i = 0; i < N; ++i) { w[i] = mask[i] ? pv[i] * (1.0 - pv[i]) : 1.0; if (w[i] == 0.0) return false; }
+    std::vector<double> A((size_t)C * C, 0.0), b(C, 0.0);
+    for (int64_t i = 0; i < N; ++i) {
+      if (!mask[i]) continue;
+      const double z = eta[i] + (y[i] - pv[i]) / w[i];
+      for (int a = 0; a < C; ++a) {
+        const double xa = X[(size_t)a * N + i] * w[i];
+        b[a] += xa * z;
+        for (int c = 0; c < C; ++c) A[(size_t)a * C + c] += xa * X[(size_t)c * N + i];
+      }
+    }
+    if (!solve_dense(A, b, C, betanew)) return false;
+    bool ok_search = false;
+    for (int ls = 0; ls < prm.niter_max_line_search; ++ls) {
+      bool inside = true;
+      for (int64_t i = 0; i < N; ++i) {
+        double e = 0.0;
+        for (int a = 0; a < C; ++a) e += X[(size_t)a * N + i] * betanew[a];
+        eta[i] = e;
+        pv[i] = get_pvec1(e);
+        if (mask[i] && !(pv[i] > 0.0 && pv[i] < 1.0)) inside = false;
+      }
+      dev_new = dev(pv);
+      if (inside && (!check_hs_dev || dev_new < dev_old)) { ok_search = true; break; }
+      for (int a = 0; a < C; ++a) betanew[a] = (beta[a] + betanew[a]) / 2;
+    }
+    if (!ok_search) return false;
+    double smax = 0.0;
+    for (int a = 0; a < C; ++a) {
+      double sc = 0.0;
+      for (int64_t i = 0; i < N; ++i) if (mask[i]) sc += X[(size_t)a * N + i] * (y[i] - pv[i]);
+      smax = std::max(smax, std::fabs(sc));
+    }
+    if (smax < NUMTOL) break;
+    if (!small_score && niter < 20 && smax < 1) small_score = true;
+    if (small_score && niter > 20 && smax > 5) return false;
+    diff_dev = std::fabs(dev_new - dev_old) / (0.1 + std::fabs(dev_new));
+    beta = betanew;
+    dev_old = dev_new;
+  }
+  if ((diff_dev == 0 || diff_dev >= NUMTOL) && niter > prm.niter_max) return false;
+  return true;
+}
 
 void read_bim_fam(Run& r) {  // Geno.cpp:518-610, :643-690, :1128-1220
   const Params& p = r.p;
@@ -357,6 +452,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     else sout << "   -keeping and mean-imputing missing observations (done for each trait)\n";
     r.Y.assign((size_t)N * r.P, 0.0);
     r.mask.assign((size_t)N * r.P, 1);
+    if (p.bt) r.Yraw.assign((size_t)N * r.P, 0.0);
     while (std::getline(f, line)) {
       auto t = split_ws(line);
       if (t.empty()) continue;
@@ -368,7 +464,15 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
       in_pheno[i] = 1;
       bool all_miss = true;
       for (int q = 0; q < r.P; ++q) {
-        const double v = convert_double(t[keep_cols[q]]);
+        double v = convert_double(t[keep_cols[q]]);
+        if (p.bt) {  // Pheno.cpp:260-283
+          if (p.cc12 && v != MISSING) v -= 1;
+          r.Yraw[(size_t)q * N + i] = v;
+          if (v != 0 && v != 1) {
+            if (v != MISSING) throw std::runtime_error("a phenotype value is not 0/1/NA for individual: FID=" + t[0] + " IID=" + t[1] + " Y=" + t[keep_cols[q]]);
+            r.mask[(size_t)q * N + i] = 0;
+          }
+        }
         r.Y[(size_t)q * N + i] = v;
         if (v != MISSING) all_miss = false;
         else if (strict) {
@@ -383,6 +487,33 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
       int64_t n = 0;
       for (int64_t i = 0; i < N; ++i) { r.mask[(size_t)q * N + i] &= in_pheno[i]; n += r.mask[(size_t)q * N + i]; }
       if (n == 0) throw std::runtime_error("all individuals have missing/invalid values for phenotype '" + r.pheno_names[q] + "'.");
+    }
+    if (p.bt) {  // rm_phenoCols (Pheno.cpp:528-570): drop traits with too few cases
+      std::vector<int> keepq;
+      for (int q = 0; q < r.P; ++q) {
+        int64_t ncases = 0;
+        for (int64_t i = 0; i < N; ++i) ncases += (r.Yraw[(size_t)q * N + i] == 1 && r.mask[(size_t)q * N + i]);
+        if (ncases >= p.min_case_count) keepq.push_back(q);
+        else sout << "   -WARNING: phenotype '" << r.pheno_names[q] << "' has fewer than " << p.min_case_count << " cases and is dropped\n";
+      }
+      if (keepq.empty()) throw std::runtime_error("all phenotypes have less than " + std::to_string(p.min_case_count) + " cases.");
+      if ((int)keepq.size() != r.P) {
+        std::vector<double> Y2, R2; std::vector<uint8_t> M2; std::vector<std::string> n2;
+        for (int q : keepq) {
+          Y2.insert(Y2.end(), r.Y.begin() + (size_t)q * N, r.Y.begin() + (size_t)(q + 1) * N);
+          R2.insert(R2.end(), r.Yraw.begin() + (size_t)q * N, r.Yraw.begin() + (size_t)(q + 1) * N);
+          M2.insert(M2.end(), r.mask.begin() + (size_t)q * N, r.mask.begin() + (size_t)(q + 1) * N);
+          n2.push_back(r.pheno_names[q]);
+        }
+        r.Y.swap(Y2); r.Yraw.swap(R2); r.mask.swap(M2); r.pheno_names.swap(n2);
+        r.P = (int)keepq.size();
+        if (!strict)
+          for (int64_t i = 0; i < N; ++i) {
+            bool any = false;
+            for (int q = 0; q < r.P; ++q) any |= r.mask[(size_t)q * N + i] != 0;
+            in_pheno[i] &= any;
+          }
+      }
     }
     int64_t np = 0;
     for (int64_t i = 0; i < N; ++i) np += in_pheno[i];
@@ -445,12 +576,22 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     for (int64_t i = 0; i < N; ++i) {
       r.mask[(size_t)q * N + i] &= r.ain[i];
       r.Y[(size_t)q * N + i] *= r.ain[i];
+      if (p.bt) r.Yraw[(size_t)q * N + i] *= r.ain[i];
       r.neff[q] += r.mask[(size_t)q * N + i];
     }
   for (int c = 0; c < ncols; ++c)
     for (int64_t i = 0; i < N; ++i) Xraw[(size_t)c * N + i] *= (r.ain[i] && in_cov[i]) ? 1.0 : 0.0;
   // pheno_impute_miss (QT): missing -> mean over analysed non-missing, then mask
-  for (int q = 0; q < r.P; ++q) {
+  for (int q = 0; q < r.P && p.bt; ++q) {  // BT: mean over the unmasked entries (Pheno.cpp:1921-1930)
+    double total = 0.0, ns = 0.0;
+    for (int64_t i = 0; i < N; ++i) if (r.mask[(size_t)q * N + i]) { total += r.Y[(size_t)q * N + i]; ns += 1.0; }
+    for (int64_t i = 0; i < N; ++i) {
+      double& v = r.Y[(size_t)q * N + i];
+      if (!r.mask[(size_t)q * N + i]) v = total / ns;
+      v *= r.mask[(size_t)q * N + i];
+    }
+  }
+  for (int q = 0; q < r.P && !p.bt; ++q) {
     double total = 0.0, ns = 0.0;
     std::set<double> distinct;
     for (int64_t i = 0; i < N; ++i) {
@@ -486,6 +627,20 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
       for (int64_t i = 0; i < N; ++i) r.X[(size_t)j * N + i] += Xraw[(size_t)c * N + i] * v;
     }
   }
+  // fit_null_logistic (Step1_Models.cpp:54-154): offsets of the covariate-only logistic model
+  r.pheno_pass.assign(r.P, 1);
+  if (p.bt) {
+    sout << "   -fitting null logistic regression on binary phenotypes...";
+    r.offset.assign((size_t)N * r.P, 0.0);
+    for (int q = 0; q < r.P; ++q) {
+      std::vector<double> eta;
+      bool ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, true, eta);
+      if (!ok) ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, false, eta);
+      if (!ok) { r.pheno_pass[q] = 0; continue; }
+      for (int64_t i = 0; i < N; ++i) r.offset[(size_t)q * N + i] = eta[i];
+    }
+    sout << "done\n";
+  }
   // residualize_phenotypes (Pheno.cpp:1799-1834)
   sout << "   -residualizing and scaling phenotypes...";
   r.scale_Y.assign(r.P, 1.0);
@@ -502,6 +657,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
       ss += y * y;
     }
     r.scale_Y[q] = std::sqrt(ss) / std::sqrt(r.neff[q] - nz);
+    if (!r.pheno_pass[q]) r.scale_Y[q] = 1.0;
     if (r.scale_Y[q] < 1e-6) throw std::runtime_error("phenotype '" + r.pheno_names[q] + "' has sd=0.");
     for (int64_t i = 0; i < N; ++i) r.Y[(size_t)q * N + i] /= r.scale_Y[q];
   }
@@ -568,15 +724,21 @@ int run(int argc, char** argv) {
   sout << std::left << std::setw(20) << " * block size" << ": [" << p.bsize << "]\n";
   sout << std::left << std::setw(20) << " * # blocks" << ": [" << B << "] for " << M << " variants\n";
   sout << std::left << std::setw(20) << " * # CV folds" << ": [" << p.cv_folds << "]\n";
+  if (p.loocv) sout << std::left << std::setw(20) << " * LOOCV" << ": [enabled]\n";
   sout << std::left << std::setw(20) << " * ridge data_l0" << ": [ " << R0 << " : ";
   for (double h : h0) sout << h << " ";
   sout << "]\n" << std::left << std::setw(20) << " * ridge data_l1" << ": [ " << R1 << " : ";
   for (double h : h1) sout << h << " ";
   sout << "]\n";
 
+  bool use_loocv = p.loocv;
+  if (p.bt && !use_loocv && r.n_analyzed < 5000) {  // Data.cpp:353-356
+    sout << "   -WARNING: Sample size is less than 5,000 so using LOOCV instead of " << p.cv_folds << "-fold CV.\n";
+    use_loocv = true;
+  }
   // set_folds (Data.cpp:401-426)
   std::vector<int32_t> cv_sizes(p.cv_folds, 1);
-  {
+  if (!use_loocv) {
     const int64_t target = r.n_analyzed / p.cv_folds;
     if (target < 1) throw std::runtime_error("not enough samples are present for " + std::to_string(p.cv_folds) + "-fold CV.");
     int64_t cnt = 0, cum = 0;
@@ -592,7 +754,7 @@ int run(int argc, char** argv) {
   if (rg_create(&ctx, p.device, nullptr) != 0 || !ctx) throw std::runtime_error("no MI355X / HIP device available (rg_create failed)");
   rg_problem pr;
   memset(&pr, 0, sizeof(pr));
-  pr.n_samples = N; pr.n_file = r.n_file; pr.n_pheno = P; pr.n_cov = r.C; pr.cv_folds = p.cv_folds;
+  pr.n_samples = N; pr.n_file = r.n_file; pr.n_pheno = P; pr.n_cov = r.C; pr.cv_folds = use_loocv ? 0 : p.cv_folds;
   pr.n_ridge_l0 = R0; pr.ref_first = p.ref_first; pr.n_analyzed = r.n_analyzed; pr.cv_sizes = cv_sizes.data();
   pr.lambda = lambda.data(); pr.X = r.X.data(); pr.Y = r.Y.data(); pr.mask = r.mask.data();
   pr.ind_in_analysis = r.ain.data(); pr.ind_ignore = (r.N != r.n_file) ? r.ind_ignore.data() : nullptr;
@@ -638,7 +800,8 @@ int run(int argc, char** argv) {
   const int L = B * R0;
   std::vector<double> tau((size_t)P * R1);
   for (int q = 0; q < P; ++q)
-    for (int j = 0; j < R1; ++j) tau[(size_t)q * R1 + j] = (double)L * (1 - h1[j]) / h1[j];  // Step1_Models.cpp:2115
+    for (int j = 0; j < R1; ++j)   // check_l0, Step1_Models.cpp:2115-2117
+      tau[(size_t)q * R1 + j] = (double)L * (1 - h1[j]) / h1[j] * (p.bt ? 3.0 / (M_PI * M_PI) : 1.0);
   std::vector<int32_t> cols_per_chr;
   std::vector<int> chroms;
   for (int c : r.chr_read) {
@@ -647,10 +810,18 @@ int run(int argc, char** argv) {
     if (nb > 0) { cols_per_chr.push_back(nb * R0); chroms.push_back(c); }
   }
   const int nchr = (int)chroms.size();
-  std::vector<double> cumsum((size_t)P * 5 * R1), pred((size_t)P * nchr * N);
-  std::vector<int32_t> best(P);
+  const int NCS = p.bt ? 6 : 5;
+  std::vector<double> cumsum((size_t)P * NCS * R1), pred((size_t)P * nchr * N);
+  std::vector<int32_t> best(P), converged(P, 1);
   auto tl0 = std::chrono::steady_clock::now();
-  check(ctx, rg_l1_qt(ctx, R1, tau.data(), nchr, cols_per_chr.data(), cumsum.data(), best.data(), pred.data()));
+  if (p.bt) {
+    check(ctx, rg_l1_bt(ctx, R1, tau.data(), r.Yraw.data(), r.offset.data(), nullptr, nchr, cols_per_chr.data(),
+                        cumsum.data(), converged.data(), best.data(), pred.data()));
+    for (int q = 0; q < P; ++q) if (!r.pheno_pass[q]) converged[q] = 0;
+  } else if (use_loocv)
+    check(ctx, rg_l1_qt_loocv(ctx, R1, tau.data(), nchr, cols_per_chr.data(), cumsum.data(), best.data(), pred.data()));
+  else
+    check(ctx, rg_l1_qt(ctx, R1, tau.data(), nchr, cols_per_chr.data(), cumsum.data(), best.data(), pred.data()));
   sout << "   -level 1 for " << P << " phenotype(s) done ("
        << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tl0).count() << "ms)\n\n";
 
@@ -666,13 +837,19 @@ int run(int argc, char** argv) {
   header += "\n";
   for (int q = 0; q < P; ++q) {
     sout << "phenotype " << q + 1 << " (" << r.pheno_names[q] << ") : \n";
-    const double* cs = cumsum.data() + (size_t)q * 5 * R1;
+    if (!converged[q]) {  // Data.cpp:1016-1021
+      sout << "Level 1 model did not converge. LOCO predictions calculations are skipped.\n\n";
+      continue;
+    }
+    const double* cs = cumsum.data() + (size_t)q * NCS * R1;
     for (int j = 0; j < R1; ++j) {
       const double neff = r.neff[q];
       double num = cs[4 * R1 + j] - cs[0 * R1 + j] * cs[1 * R1 + j] / neff;
       const double rsq = num * num / ((cs[2 * R1 + j] - cs[0 * R1 + j] * cs[0 * R1 + j] / neff) * (cs[3 * R1 + j] - cs[1 * R1 + j] * cs[1 * R1 + j] / neff));
       const double sse = cs[2 * R1 + j] + cs[3 * R1 + j] - 2 * cs[4 * R1 + j];
-      sout << "  " << std::right << std::setw(5) << (double)L / (L + tau[(size_t)q * R1 + j]) << " : Rsq = " << rsq << ", MSE = " << sse / neff;
+      sout << "  " << std::right << std::setw(5) << (double)L / (L + (p.bt ? M_PI * M_PI / 3.0 : 1.0) * tau[(size_t)q * R1 + j])
+           << " : Rsq = " << rsq << ", MSE = " << sse / neff;
+      if (p.bt) sout << ", -logLik/N = " << cs[5 * R1 + j] / neff;
       if (j == best[q]) sout << "<- min value";
       sout << "\n";
     }

@@ -89,3 +89,49 @@ def test_cli_errors_like_reference(example_dir, tmp_path):
     assert r.returncode != 0 and "ERROR: must specify the block size using '--bsize'." in r.stdout
     r = _run(["--step", "1", "--bed", os.path.join(E, "nope"), "--phenoFile", os.path.join(E, "phenotype.txt"), "--bsize", "10"], str(tmp_path))
     assert r.returncode != 0 and "ERROR:" in r.stdout
+
+
+def test_cli_bt_reference_command(example_dir, tmp_path):
+    """The reference's own Step-1 test (test/test_bash.sh:62-89): --bt on 494 samples (automatic LOOCV),
+    --lowmem; its log must show 0.4504 on the `min value` line of Y2."""
+    E = example_dir
+    args = ["--step", "1", "--bed", os.path.join(E, "example"), "--exclude", os.path.join(E, "snplist_rm.txt"),
+            "--covarFile", os.path.join(E, "covariates.txt"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"),
+            "--remove", os.path.join(E, "fid_iid_to_remove.txt"), "--bsize", "100", "--bt", "--lowmem",
+            "--lowmem-prefix", "tmp_rg", "--out", str(tmp_path / "gpu")]
+    r = _run(args, str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    log = open(str(tmp_path / "gpu.log")).read()
+    assert any(("0.4504" in ln and "min value" in ln) for ln in log.split("\n")), log
+    assert "using LOOCV instead of 5-fold CV" in log
+    opt = orc.Step1Options(bed=os.path.join(E, "example"), pheno_file=os.path.join(E, "phenotype_bin.txt"),
+                           covar_file=os.path.join(E, "covariates.txt"), remove=[os.path.join(E, "fid_iid_to_remove.txt")],
+                           exclude=[os.path.join(E, "snplist_rm.txt")], bsize=100, bt=True, out=str(tmp_path / "ref"))
+    ref = orc.run_step1(opt, write_files=True)
+    for ln in ref.log:   # every per-tau line of the oracle's log appears verbatim in the driver's log
+        if "Rsq" in ln:
+            assert ln in log, ln
+    for k in (1, 2):
+        ids_g, chr_g, val_g, lines_g = _parse_loco(str(tmp_path / ("gpu_%d.loco" % k)))
+        ids_r, chr_r, val_r, lines_r = _parse_loco(str(tmp_path / ("ref_%d.loco" % k)))
+        assert ids_g == ids_r and chr_g == chr_r
+        assert np.nanmax(np.abs(val_g - val_r)) <= 2e-6 * np.nanmax(np.abs(val_r))
+
+
+def test_cli_qt_loocv(example_dir, tmp_path):
+    E = example_dir
+    args = ["--step", "1", "--bed", os.path.join(E, "example_3chr"), "--phenoFile", os.path.join(E, "phenotype.txt"),
+            "--covarFile", os.path.join(E, "covariates.txt"), "--bsize", "100", "--loocv", "--out", str(tmp_path / "gpu")]
+    r = _run(args, str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    opt = orc.Step1Options(bed=os.path.join(E, "example_3chr"), pheno_file=os.path.join(E, "phenotype.txt"),
+                           covar_file=os.path.join(E, "covariates.txt"), bsize=100, loocv=True, out=str(tmp_path / "ref"))
+    ref = orc.run_step1(opt, write_files=True)
+    log = open(str(tmp_path / "gpu.log")).read()
+    for ln in ref.log:
+        if "Rsq" in ln:
+            assert ln in log, ln
+    for k in (1, 2):
+        _, _, val_g, _ = _parse_loco(str(tmp_path / ("gpu_%d.loco" % k)))
+        _, _, val_r, _ = _parse_loco(str(tmp_path / ("ref_%d.loco" % k)))
+        assert np.nanmax(np.abs(val_g - val_r)) <= 2e-6 * np.nanmax(np.abs(val_r))
