@@ -159,6 +159,11 @@ int rg_get_timing(rg_ctx* ctx, rg_timing* out);
 int rg_k_gram_i8(void* stream, const uint8_t* A, int64_t lda, int a_miss, const uint8_t* B,
                  int64_t ldb, int b_miss, int32_t m, int32_t n, int64_t k_bytes, int32_t* C,
                  int64_t ldc);
+/* C[m][n] (int32, ldc) = sum_k A4[m][k] * B4[n][k] over FP4-E2M1 rows (two samples per byte, values
+ * 0000 = 0, 0010 = 1, 0100 = 2) on v_mfma_scale_f32_32x32x64_f8f6f4 with exact flushing to int32;
+ * k_bytes = bytes per row to contract (multiple of 128 = one LDS stage), lda/ldb multiples of 16. */
+int rg_k_gram_fp4(void* stream, const uint8_t* A4, int64_t lda, const uint8_t* B4, int64_t ldb,
+                  int32_t m, int32_t n, int64_t k_bytes, int32_t* C, int64_t ldc);
 /* batched in-place Cholesky with appended RHS rows: mats[b] is (n_pad + rhs_pad) x n_pad row-major
  * (ld = n_pad), lower triangle referenced; on exit rows < n_pad hold L, RHS rows hold solutions x
  * (A x = rhs).  n_pad and rhs_pad multiples of 64. */

@@ -12,6 +12,15 @@
 //               Data.cpp:199 and Data.cpp:746) once combined with the SNP mean.
 #include "rg_internal.h"
 
+// flags at bit positions 0,2,..,14 (8 samples) -> bit 0 of nibbles 0..7
+__device__ __forceinline__ unsigned spread8(unsigned y) {
+  y &= 0x5555u;
+  y = (y | (y << 8)) & 0x00FF00FFu;
+  y = (y | (y << 4)) & 0x0F0F0F0Fu;
+  y = (y | (y << 2)) & 0x11111111u;
+  return y;
+}
+
 __device__ __forceinline__ unsigned load_u8(const uint8_t* p, int64_t i, int64_t n) {
   return (i >= 0 && i < n) ? (unsigned)p[i] : 0xFFu;
 }
@@ -23,7 +32,8 @@ __global__ __launch_bounds__(256) void k_bed_prep_rows(const uint8_t* raw, int64
                                                        const int32_t* d_bs, const uint8_t* act,
                                                        SegLayout seg, int64_t Np, int ref_first,
                                                        int64_t nfile_bytes,
-                                                       int32_t* cnt_part /*[nblk][n128][2]*/) {
+                                                       int32_t* cnt_part /*[nblk][n128][2]*/,
+                                                       uint8_t* pk4, int64_t pk4_ld, int64_t pk4_blk_stride) {
   const int blk = blockIdx.z, row = blockIdx.y;
   const int bs = d_bs[blk];
   const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;  // output dword index
@@ -65,6 +75,16 @@ __global__ __launch_bounds__(256) void k_bed_prep_rows(const uint8_t* raw, int64
     }
   }
   if (w < nw) *reinterpret_cast<unsigned*>(pk + (int64_t)blk * pk_blk_stride + (int64_t)row * pk_ld + w * 4) = out;
+  if (pk4 && w < nw) {
+    // FP4 E2M1 plane for the matrix cores (gram_fp4.hip): dosage 2 (code 00) -> 0100, 1 (code 10) -> 0010,
+    // 0 / missing -> 0000; sample i of this dword -> nibble i of the 8 output bytes
+    const unsigned lo = out & 0x55555555u, hi = (out >> 1) & 0x55555555u;
+    const unsigned two = ~lo & ~hi & 0x55555555u, one = ~lo & hi;
+    uint2 o;
+    o.x = (spread8(two) << 2) | (spread8(one) << 1);
+    o.y = (spread8(two >> 16) << 2) | (spread8(one >> 16) << 1);
+    *reinterpret_cast<uint2*>(pk4 + (int64_t)blk * pk4_blk_stride + (int64_t)row * pk4_ld + w * 8) = o;
+  }
   // block reduction of (nmiss, gsum) -> integer atomics (exact, order independent)
   for (int o = 32; o > 0; o >>= 1) {
     nmiss += __shfl_down(nmiss, o);
@@ -96,7 +116,8 @@ __global__ void k_bed_mu(const int32_t* cnt_part, const int32_t* d_bs, int n128,
 void rg_launch_bed_prep(hipStream_t st, const uint8_t* raw, int64_t raw_ld, int64_t raw_blk_stride,
                         uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs,
                         int nblk, int n128, const uint8_t* act, SegLayout seg, int64_t Np,
-                        int ref_first, int n_active, double* mu, int32_t* nmiss) {
+                        int ref_first, int n_active, double* mu, int32_t* nmiss, uint8_t* pk4,
+                        int64_t pk4_ld, int64_t pk4_blk_stride) {
   // mu buffer is followed by an int32 scratch [nblk][n128][2] owned by the caller (see rg_ctx: the
   // scratch lives right behind d_mu); here we only receive pointers.
   int32_t* cnt = reinterpret_cast<int32_t*>(mu + (int64_t)nblk * n128);
@@ -105,7 +126,7 @@ void rg_launch_bed_prep(hipStream_t st, const uint8_t* raw, int64_t raw_ld, int6
   const int64_t nw = Np / 16;
   dim3 grid((unsigned)((nw + 255) / 256), n128, nblk);
   hipLaunchKernelGGL(k_bed_prep_rows, grid, dim3(256), 0, st, raw, raw_ld, raw_blk_stride, pk, pk_ld,
-                     pk_blk_stride, d_bs, act, seg, Np, ref_first, raw_ld, cnt);
+                     pk_blk_stride, d_bs, act, seg, Np, ref_first, raw_ld, cnt, pk4, pk4_ld, pk4_blk_stride);
   hipLaunchKernelGGL(k_bed_mu, dim3((n128 + 127) / 128, nblk), dim3(128), 0, st, cnt, d_bs, n128,
                      n_active, mu, nmiss);
 }

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_gram_generic(const uint8_t* A, int64_t 
 // indicator exit at once when the block has no missing call (nmiss[blk] == 0).
 __global__ __launch_bounds__(256) void k_gram_blocks(const uint8_t* pk, int64_t pk_ld,
                                                      int64_t pk_blk_stride, int n128, SegLayout seg,
-                                                     const int32_t* nmiss, int32_t* S) {
+                                                     const int32_t* nmiss, int32_t* S, int miss_only) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[2 * GT * LDS_PITCH];
   const int nt = n128 / GT;
   // XCD-aware remap: consecutive tile ids share operand panels; keep them on one XCD's L2.
@@ -143,6 +143,7 @@ __global__ __launch_bounds__(256) void k_gram_blocks(const uint8_t* pk, int64_t 
   const int blk = blockIdx.z, f = blockIdx.y;
   const bool a_miss = tr >= nt, b_miss = tc >= nt;
   if ((a_miss || b_miss) && nmiss[blk] == 0) return;
+  if (miss_only && !(a_miss || b_miss)) return;   // dosage x dosage tiles come from gram_fp4.hip
   const int ar = (a_miss ? tr - nt : tr), br = (b_miss ? tc - nt : tc);
   const uint8_t* base = pk + (int64_t)blk * pk_blk_stride + seg.pos_start[f] / 4;
   const int64_t ldS = 2 * (int64_t)n128;
@@ -154,11 +155,11 @@ __global__ __launch_bounds__(256) void k_gram_blocks(const uint8_t* pk, int64_t 
 }
 
 void rg_launch_gram_blocks(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride,
-                           int nblk, int n128, SegLayout seg, const int32_t* nmiss, int32_t* S) {
+                           int nblk, int n128, SegLayout seg, const int32_t* nmiss, int32_t* S, int miss_only) {
   const int nt2 = 2 * (n128 / GT);
   dim3 grid(nt2 * (nt2 + 1) / 2, seg.nseg, nblk);
   hipLaunchKernelGGL(k_gram_blocks, grid, dim3(256), 0, st, pk, pk_ld, pk_blk_stride, n128, seg,
-                     nmiss, S);
+                     nmiss, S, miss_only);
 }
 
 void rg_launch_gram_generic(hipStream_t st, const uint8_t* A, int64_t lda, int a_miss,

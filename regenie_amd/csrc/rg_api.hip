@@ -25,7 +25,7 @@ int dev_upload(rg_ctx* ctx, T** p, const std::vector<T>& v) {
 
 void free_all(rg_ctx* c) {
   void* ptrs[] = {c->d_cidx, c->d_act, c->d_V, c->d_maskp, c->d_Q, c->d_XtY, c->d_lambda, c->d_neff,
-                  c->d_keptp, c->d_posc, c->d_zero, c->d_raw, c->d_pk, c->d_mu, c->d_nmiss,
+                  c->d_keptp, c->d_posc, c->d_zero, c->d_raw, c->d_pk, c->d_pk4, c->d_mu, c->d_nmiss,
                   c->d_xypart, c->d_chunk_seg, c->d_chunk_pos, c->d_chunk_len, c->d_S, c->d_F, c->d_Bm,
                   c->d_BQ, c->d_GYt, c->d_sc, c->d_fold, c->d_sum, c->d_wk, c->d_dinv, c->d_beta,
                   c->d_cb, c->d_psum, c->d_info, c->d_bs, c->d_blockid, c->d_c1k_seg, c->d_c1k_pos,
@@ -130,7 +130,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
     const int64_t fe = (f == K - 1) ? Nf : file_of_c[ctx->fold_cstart[f + 1]];
     sg.file_start[f] = fs;
     sg.len[f] = fe - fs;
-    sg.plen[f] = rg_round_up(fe - fs, 64);
+    sg.plen[f] = rg_round_up(fe - fs, 256);  // one LDS stage of the FP4 Gram kernel (gram_fp4.hip)
     sg.pos_start[f] = pos;
     pos += sg.plen[f];
   }
@@ -241,6 +241,12 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   const size_t msz = (size_t)rtot * n64;
   if ((rc = dev_alloc(ctx, &ctx->d_raw, (size_t)nb * bsm * ctx->raw_ld + 16))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_pk, (size_t)nb * n128 * ctx->pk_ld + 16))) return rc;
+  ctx->gram_fp4 = true;
+  if (const char* e = getenv("RG_GRAM")) ctx->gram_fp4 = std::string(e) != "i8";
+  ctx->pk4_ld = Np / 2;
+  if (ctx->gram_fp4) {
+    if ((rc = dev_alloc(ctx, &ctx->d_pk4, (size_t)nb * n128 * ctx->pk4_ld + 16))) return rc;
+  } else if (ctx->d_pk4) { hipFree(ctx->d_pk4); ctx->d_pk4 = nullptr; }
   if ((rc = dev_alloc(ctx, &ctx->d_mu, (size_t)nb * n128 * 2))) return rc;  // mu + int scratch
   if ((rc = dev_alloc(ctx, &ctx->d_nmiss, (size_t)nb))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_xypart, (size_t)nb * ctx->xy_nchunk * n128 * 2 * Cv))) return rc;
@@ -311,7 +317,8 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
                               mem_kind == RG_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     rg_launch_bed_prep(st, ctx->d_raw, ctx->raw_ld, raw_blk, ctx->d_pk, ctx->pk_ld, pk_blk, ctx->d_bs,
                        nblk, n128, ctx->d_act, ctx->seg, ctx->Np, ctx->ref_first, ctx->n_active,
-                       ctx->d_mu, ctx->d_nmiss);
+                       ctx->d_mu, ctx->d_nmiss, ctx->gram_fp4 ? ctx->d_pk4 : nullptr, ctx->pk4_ld,
+                       (int64_t)n128 * ctx->pk4_ld);
   }
   {
     StageTimer t(ctx, &ctx->tm.ms_xy);
@@ -320,7 +327,10 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
   }
   {
     StageTimer t(ctx, &ctx->tm.ms_gram);
-    rg_launch_gram_blocks(st, ctx->d_pk, ctx->pk_ld, pk_blk, nblk, n128, ctx->seg, ctx->d_nmiss, ctx->d_S);
+    if (ctx->gram_fp4)
+      rg_launch_gram_fp4_blocks(st, ctx->d_pk4, ctx->pk4_ld, (int64_t)n128 * ctx->pk4_ld, nblk, n128, ctx->seg, ctx->d_S);
+    rg_launch_gram_blocks(st, ctx->d_pk, ctx->pk_ld, pk_blk, nblk, n128, ctx->seg, ctx->d_nmiss, ctx->d_S,
+                          ctx->gram_fp4 ? 1 : 0);
     ctx->tm.n_gram_launches += 1;
   }
   {
@@ -502,6 +512,13 @@ int rg_k_gram_i8(void* stream, const uint8_t* A, int64_t lda, int a_miss, const 
                  int64_t ldb, int b_miss, int32_t m, int32_t n, int64_t k_bytes, int32_t* C, int64_t ldc) {
   if (!A || !B || !C || m < 1 || n < 1 || k_bytes < 16 || (k_bytes & 15) || (lda & 15) || (ldb & 15)) return RG_ERR_ARG;
   rg_launch_gram_generic((hipStream_t)stream, A, lda, a_miss, B, ldb, b_miss, m, n, k_bytes, C, ldc);
+  return hipGetLastError() == hipSuccess ? RG_OK : RG_ERR_HIP;
+}
+
+int rg_k_gram_fp4(void* stream, const uint8_t* A, int64_t lda, const uint8_t* B, int64_t ldb, int32_t m,
+                  int32_t n, int64_t k_bytes, int32_t* C, int64_t ldc) {
+  if (!A || !B || !C || m < 1 || n < 1 || k_bytes < 128 || (k_bytes & 127) || (lda & 15) || (ldb & 15)) return RG_ERR_ARG;
+  rg_launch_gram_fp4_generic((hipStream_t)stream, A, lda, B, ldb, m, n, k_bytes, C, ldc);
   return hipGetLastError() == hipSuccess ? RG_OK : RG_ERR_HIP;
 }
 

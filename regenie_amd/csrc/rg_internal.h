@@ -20,15 +20,16 @@ static inline int64_t rg_round_up(int64_t x, int64_t m) { return (x + m - 1) / m
 
 // Fold-aligned sample layout ("position space"): fold f occupies positions
 // [pos_start[f], pos_start[f]+len[f]) which map to .fam indices [file_start[f], +len[f]);
-// every fold starts at a multiple of 64 positions, so a fold boundary never cuts a packed
-// 16-byte K-step of the i8 Gram kernel nor a 64-sample chunk of the fp64 kernels.
+// every fold starts at a multiple of 256 positions, so a fold boundary never cuts a 128-byte LDS stage
+// of the FP4 Gram kernel, a packed 16-byte K-step of the i8 Gram kernel nor a 64-sample chunk of the
+// fp64 kernels.
 struct SegLayout {
   int32_t nseg;
   int32_t pad_;
   int64_t pos_start[RG_MAX_SEG];
   int64_t file_start[RG_MAX_SEG];
   int64_t len[RG_MAX_SEG];      // in file samples
-  int64_t plen[RG_MAX_SEG];     // padded length (multiple of 64)
+  int64_t plen[RG_MAX_SEG];     // padded length (multiple of 256)
 };
 
 struct rg_ctx {
@@ -75,6 +76,8 @@ struct rg_ctx {
   int n128 = 0, n64 = 0, rtot = 0;  // paddings for bs_max
   uint8_t* d_raw = nullptr;  int64_t raw_ld = 0;    // staged raw rows [nblk][bs_max][raw_ld]
   uint8_t* d_pk = nullptr;   int64_t pk_ld = 0;     // cleaned packed   [nblk][n128][pk_ld]
+  uint8_t* d_pk4 = nullptr;  int64_t pk4_ld = 0;    // FP4 dosage plane [nblk][n128][pk4_ld] (gram_fp4.hip)
+  bool gram_fp4 = true;          // dosage x dosage Gram on the FP4 matrix cores (RG_GRAM=i8 selects the i8 kernel)
   double* d_mu = nullptr;        // [nblk][n128]
   int32_t* d_nmiss = nullptr;    // [nblk]
   double* d_xypart = nullptr;    // [nblk][nchunk][n128][2][Cv]
@@ -123,13 +126,19 @@ struct rg_ctx {
 void rg_launch_bed_prep(hipStream_t st, const uint8_t* raw, int64_t raw_ld, int64_t raw_blk_stride,
                         uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs,
                         int nblk, int n128, const uint8_t* act, SegLayout seg, int64_t Np,
-                        int ref_first, int n_active, double* mu, int32_t* nmiss);
+                        int ref_first, int n_active, double* mu, int32_t* nmiss, uint8_t* pk4,
+                        int64_t pk4_ld, int64_t pk4_blk_stride);
 void rg_launch_geno_xy(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride,
                        const int32_t* d_bs, int nblk, int n128, const double* V, int64_t Np, int Cv,
                        const int64_t* chunk_pos, const int64_t* chunk_len, int nchunk, double* part);
 // gram_i8.hip
 void rg_launch_gram_blocks(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride,
-                           int nblk, int n128, SegLayout seg, const int32_t* nmiss, int32_t* S);
+                           int nblk, int n128, SegLayout seg, const int32_t* nmiss, int32_t* S, int miss_only);
+// gram_fp4.hip
+void rg_launch_gram_fp4_blocks(hipStream_t st, const uint8_t* pk4, int64_t pk4_ld, int64_t pk4_blk_stride, int nblk,
+                               int n128, SegLayout seg, int32_t* S);
+void rg_launch_gram_fp4_generic(hipStream_t st, const uint8_t* A, int64_t lda, const uint8_t* B, int64_t ldb, int m,
+                                int n, int64_t kbytes, int32_t* C, int64_t ldc);
 void rg_launch_gram_generic(hipStream_t st, const uint8_t* A, int64_t lda, int a_miss,
                             const uint8_t* B, int64_t ldb, int b_miss, int m, int n, int64_t kbytes,
                             int32_t* C, int64_t ldc);

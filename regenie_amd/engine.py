@@ -49,7 +49,7 @@ class RgTiming(C.Structure):
 
 EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_w_rows", "rg_w_bytes",
            "rg_set_w_buffer", "rg_w_device_ptr", "rg_l0_blocks", "rg_sync", "rg_l0_get_w",
-           "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8",
+           "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
            "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak"]
 
 
@@ -93,6 +93,8 @@ def load_library() -> C.CDLL:
     lib.rg_get_timing.argtypes = [C.c_void_p, C.POINTER(RgTiming)]
     lib.rg_k_gram_i8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
                                  C.c_int, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int64]
+    lib.rg_k_gram_fp4.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                  C.c_int64, C.c_void_p, C.c_int64]
     lib.rg_k_chol_solve.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rg_k_dgemm_nt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
