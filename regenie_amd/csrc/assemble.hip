@@ -103,6 +103,15 @@ __global__ __launch_bounds__(256) void k_assemble(AsmArgs a) {
   double* sum = a.sum + (int64_t)blk * msz;
   const int64_t e = (int64_t)i * n64 + k;
   const double* sc = a.sc + (int64_t)blk * n128;
+  // diff_mode: fold[f] := (sum over folds) - (fold f) = the training-fold system of CV fold f, so the
+  // Cholesky's first touch reads ONE matrix; otherwise fold[f] and their sum are both written (LOOCV path).
+  auto finish = [&](double tot) {
+    if (a.diff_mode) {
+      for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = tot - fold[(int64_t)s * msz + e];
+    } else {
+      sum[e] = tot;
+    }
+  };
   if (i >= n64) {  // RHS rows: b_f^T
     const int p = i - n64;
     double tot = 0.0;
@@ -112,19 +121,19 @@ __global__ __launch_bounds__(256) void k_assemble(AsmArgs a) {
       fold[(int64_t)s * msz + e] = v;
       tot += v;
     }
-    sum[e] = tot;
+    finish(tot);
     return;
   }
   if (k > i) {  // upper triangle: never referenced, except inside diagonal 64-tiles (kept finite)
     if ((k >> 6) == (i >> 6)) {
       for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = 0.0;
-      sum[e] = 0.0;
+      if (!a.diff_mode) sum[e] = 0.0;
     }
     return;
   }
   if (i >= bs) {      // padding (k <= i)
     for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = 0.0;
-    sum[e] = 0.0;
+    if (!a.diff_mode) sum[e] = 0.0;
     return;
   }
   const bool has_miss = a.nmiss[blk] > 0;
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(256) void k_assemble(AsmArgs a) {
     fold[(int64_t)s * msz + e] = v;
     tot += v;
   }
-  sum[e] = tot;
+  finish(tot);
 }
 
 void rg_launch_rowstats(hipStream_t st, const AsmArgs& a) {

@@ -131,16 +131,23 @@ void rg_launch_form(hipStream_t st, const double* sum, int64_t sum_stride, const
 
 // ---- XCD-affine work order -----------------------------------------------------------------------
 // MI355X dispatches workgroup id w to XCD (w % 8), each XCD with its own 4 MiB L2.  All `ngrp` work items
-// of one system share that system's panel rows, so system b is pinned to XCD (b % 8) and its items run
-// back to back there: id w -> xcd = w % 8, s = w / 8, system = (s / ngrp) * 8 + xcd, item = s % ngrp.
+// of one system share that system's panel rows, so system b is pinned to one XCD and its items run back to
+// back there.  R consecutive systems (the ridge shifts of one fold matrix) are pinned to the SAME XCD and
+// advance item by item together, so that a first-touch tile of the shared matrix is fetched from HBM once
+// and served to the other R-1 systems by that XCD's L2:
+//   id w -> xcd = w % 8, s = w / 8, r = s % R, item = (s / R) % ngrp, group = s / (R * ngrp),
+//   system = (group * 8 + xcd) * R + r.
 // Only speed depends on the placement; the mapping is a bijection onto (system, item) for any dispatch.
-__device__ __forceinline__ bool xcd_affine(int w, int ngrp, int batch, int& b, int& g) {
+__device__ __forceinline__ bool xcd_affine(int w, int ngrp, int batch, int R, int& b, int& g) {
   const int xcd = w & 7, s = w >> 3;
-  b = (s / ngrp) * 8 + xcd;
-  g = s % ngrp;
+  const int r = s % R, t = s / R;
+  g = t % ngrp;
+  b = ((t / ngrp) * 8 + xcd) * R + r;
   return b < batch;
 }
-static inline unsigned xcd_affine_grid(int ngrp, int batch) { return (unsigned)(((batch + 7) / 8) * 8 * ngrp); }
+static inline unsigned xcd_affine_grid(int ngrp, int batch, int R) {
+  return (unsigned)(((batch + 8 * R - 1) / (8 * R)) * 8 * R * ngrp);
+}
 
 // ---- lazy "form": value of element (i,j) of system b = sum[o] - fold[o][f] + shift[r] on the diagonal ----
 // Every tile of a system is first touched exactly once during the first column group of the
@@ -155,7 +162,7 @@ struct FormSrc {
   const double* fold; int64_t fold_stride;
   const double* shift; const int32_t* d_n;
   const double* extra; int64_t extra_stride;
-  int nfold, nshift, n_fixed, enabled, subtract, extra_row0, n64;
+  int nfold, nshift, n_fixed, enabled, subtract, extra_row0, n64, n_div;
 };
 struct FormIdx { const double* S; const double* F; const double* X; double sh; int64_t xoff; int n, x0; };
 __device__ __forceinline__ FormIdx form_idx(const FormSrc& f, int b) {
@@ -168,7 +175,7 @@ __device__ __forceinline__ FormIdx form_idx(const FormSrc& f, int b) {
   x.x0 = f.extra ? f.extra_row0 : 0x7fffffff;
   x.xoff = (int64_t)f.extra_row0 * f.n64;
   x.sh = f.shift[r];
-  x.n = f.d_n ? f.d_n[o] : f.n_fixed;
+  x.n = f.d_n ? f.d_n[o / f.n_div] : f.n_fixed;
   return x;
 }
 // e = i * n64 + j
@@ -181,8 +188,10 @@ __device__ __forceinline__ double form_val(const FormIdx& x, int i, int j, int64
 }
 
 // ---- diagonal tile: blocked (16) potf2 + blocked triangular inverse, all in LDS -------------------
-__global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_stride, int n64, int k,
-                                                   double* dinv, int32_t* info, FormSrc fs) {
+// Left-looking inside a column group: before factoring, the tile is updated with the group's earlier tile
+// columns [kc0, kc0 + nkc):  A[k][k] -= sum_q L[k][q] L[k][q]^T  (fp64 MFMA, operands straight from HBM/L2).
+__global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_stride, int n64, int k, int kc0,
+                                                   int nkc, double* dinv, int32_t* info, FormSrc fs) {
   __shared__ double s[CT][CT + 1];
   __shared__ double si[CT][CT + 1];
   __shared__ double tmp[16][17];
@@ -205,6 +214,36 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_str
     }
   }
   __syncthreads();
+  if (nkc > 0) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i = lane & 15, q = lane >> 4;
+    const double* Mrow = mats + (int64_t)b * mat_stride + (int64_t)k * CT * n64 + (int64_t)kc0 * CT + 16 * q;
+    v4d acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
+    if (wc <= wr) {   // the strictly upper 32x32 block is never referenced
+      for (int kk = 0; kk < nkc; ++kk) {
+        const double* ar[2] = {Mrow + (int64_t)(wr * 32 + i) * n64 + kk * CT, Mrow + (int64_t)(wr * 32 + 16 + i) * n64 + kk * CT};
+        const double* br[2] = {Mrow + (int64_t)(wc * 32 + i) * n64 + kk * CT, Mrow + (int64_t)(wc * 32 + 16 + i) * n64 + kk * CT};
+        double av[2][16], bv[2][16];
+        dmma_load<2, 2>(ar, br, av, bv);
+        dmma_fma<2, 2>(av, bv, acc);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rr = wr * 32 + m * 16 + q + 4 * r, cc = wc * 32 + n * 16 + i;
+            if (cc <= rr) s[rr][cc] -= acc[m][n][r];
+          }
+    }
+    __syncthreads();
+  }
   bool bad = false;
   for (int sb = 0; sb < 4; ++sb) {
     const int o = sb * 16;
@@ -299,44 +338,80 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_str
   }
 }
 
-// ---- panel: L[t][k] = A[t][k] * Linv^T ---------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_chol_panel(double* mats, int64_t mat_stride, int n64, int k,
-                                                    const double* dinv, int ngrp, int batch, FormSrc fs) {
+// ---- panel: L[t][k] = (A[t][k] - sum_q L[t][q] L[k][q]^T) * Linv^T, q over the group's earlier tile columns ----
+// (left-looking inside the column group: the tile is read once and written once).  The updated tile goes
+// through LDS so that every wave sees all 64 columns of its rows for the triangular multiply.
+#define PU_PITCH 66
+__global__ __launch_bounds__(256) void k_chol_panel(double* mats, int64_t mat_stride, int n64, int k, int kc0,
+                                                    int nkc, const double* dinv, int ngrp, int batch, int R,
+                                                    FormSrc fs) {
+  __shared__ double sU[CT * PU_PITCH];
   int b, g;
-  if (!xcd_affine(blockIdx.x, ngrp, batch, b, g)) return;
+  if (!xcd_affine(blockIdx.x, ngrp, batch, R, b, g)) return;
   const int t = k + 1 + g;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int i = lane & 15, q = lane >> 4;
-  double* T = mats + (int64_t)b * mat_stride + (int64_t)t * CT * n64 + k * CT;
+  double* M = mats + (int64_t)b * mat_stride;
+  double* T = M + (int64_t)t * CT * n64 + k * CT;
   const double* I = dinv + ((int64_t)b * (n64 / CT) + k) * CT * CT;
-  double av[2][16], bv[2][16];
+  v4d acc[2][2];
+  // acc = -(tile value) at (row = wr*32 + m*16 + q + 4r, col = wc*32 + n*16 + i)
   if (fs.enabled) {
     const FormIdx fx = form_idx(fs, b);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const int gi = t * CT + wr * 32 + m * 16 + i;
+    for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        const int gj = k * CT + 16 * q + v;
-        av[m][v] = form_val(fx, gi, gj, (int64_t)gi * n64 + gj);
-      }
-      const double4* p = reinterpret_cast<const double4*>(I + (wc * 32 + m * 16 + i) * CT + 16 * q);
+      for (int n = 0; n < 2; ++n)
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const double4 x = p[v];
-        bv[m][4 * v] = x.x; bv[m][4 * v + 1] = x.y; bv[m][4 * v + 2] = x.z; bv[m][4 * v + 3] = x.w;
-      }
-    }
+        for (int r = 0; r < 4; ++r) {
+          const int gi = t * CT + wr * 32 + m * 16 + q + 4 * r, gj = k * CT + wc * 32 + n * 16 + i;
+          acc[m][n][r] = -form_val(fx, gi, gj, (int64_t)gi * n64 + gj);
+        }
   } else {
-    const double* ar[2] = {T + (int64_t)(wr * 32 + i) * n64 + 16 * q,
-                           T + (int64_t)(wr * 32 + 16 + i) * n64 + 16 * q};
-    const double* br[2] = {I + (wc * 32 + i) * CT + 16 * q, I + (wc * 32 + 16 + i) * CT + 16 * q};
-    dmma_load<2, 2>(ar, br, av, bv);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          acc[m][n][r] = -T[(int64_t)(wr * 32 + m * 16 + q + 4 * r) * n64 + wc * 32 + n * 16 + i];
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // every wave holds its operands before any wave overwrites the tile
-  v4d acc[2][2];
+  {
+    const double* Arow = M + (int64_t)t * CT * n64 + (int64_t)kc0 * CT + 16 * q;
+    const double* Brow = M + (int64_t)k * CT * n64 + (int64_t)kc0 * CT + 16 * q;
+    for (int kk = 0; kk < nkc; ++kk) {
+      const double* ar[2] = {Arow + (int64_t)(wr * 32 + i) * n64 + kk * CT, Arow + (int64_t)(wr * 32 + 16 + i) * n64 + kk * CT};
+      const double* br[2] = {Brow + (int64_t)(wc * 32 + i) * n64 + kk * CT, Brow + (int64_t)(wc * 32 + 16 + i) * n64 + kk * CT};
+      double av[2][16], bv[2][16];
+      dmma_load<2, 2>(ar, br, av, bv);
+      dmma_fma<2, 2>(av, bv, acc);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sU[(wr * 32 + m * 16 + q + 4 * r) * PU_PITCH + wc * 32 + n * 16 + i] = -acc[m][n][r];
+  __syncthreads();
+  double av[2][16], bv[2][16];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const double2* pu = reinterpret_cast<const double2*>(sU + (wr * 32 + m * 16 + i) * PU_PITCH + 16 * q);
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+      const double2 x = pu[v];
+      av[m][2 * v] = x.x; av[m][2 * v + 1] = x.y;
+    }
+    const double4* p = reinterpret_cast<const double4*>(I + (wc * 32 + m * 16 + i) * CT + 16 * q);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const double4 x = p[v];
+      bv[m][4 * v] = x.x; bv[m][4 * v + 1] = x.y; bv[m][4 * v + 2] = x.z; bv[m][4 * v + 3] = x.w;
+    }
+  }
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -359,9 +434,9 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* mats, int64_t mat_st
 // tiles of one tile column, so they share the B operand in L1.
 __global__ __launch_bounds__(256, 2) void k_chol_update(double* mats, int64_t mat_stride, int n64,
                                                         int Ttot, int c_lo, int c_hi, int ntile,
-                                                        int kc0, int nkc, int batch, FormSrc fs) {
+                                                        int kc0, int nkc, int batch, int R, FormSrc fs) {
   int b, g;
-  if (!xcd_affine(blockIdx.x, (ntile + 3) / 4, batch, b, g)) return;
+  if (!xcd_affine(blockIdx.x, (ntile + 3) / 4, batch, R, b, g)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int idx = g * 4 + wave, tc = c_lo;
   if (idx >= ntile) return;
@@ -505,31 +580,29 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
   const int T = n64 / CT, Tr = rhs_pad / CT, Ttot = T + Tr;
   const int G = 4;  // tile columns per group: trailing updates contract K = 64*G at once
   FormSrc off{};
-  off.enabled = 0; off.extra = nullptr;
+  off.enabled = 0; off.extra = nullptr; off.n_div = 1;
   int64_t nl = 0;
   for (int k0 = 0; k0 < T; k0 += G) {
     const int k1 = std::min(T, k0 + G);
+    // first touch of every tile happens in the first group: tile columns < G by diag/panel, the rest by the
+    // wide update; systems that share a source matrix (the shifts) are co-located on one XCD for those launches
     const FormSrc& first = (src && k0 == 0) ? *src : off;
+    const int R = (src && k0 == 0) ? std::max(1, src->nshift) : 1;
     for (int j = k0; j < k1; ++j) {
-      if (j > k0) {  // narrow update of tile column j with the group's earlier columns
-        hipLaunchKernelGGL(k_chol_update, dim3(xcd_affine_grid((Ttot - j + 3) / 4, batch)), dim3(256), 0, st, mats,
-                           mat_stride, n64, Ttot, j, j + 1, Ttot - j, k0, j - k0, batch, first);
-        ++nl;
-      }
-      hipLaunchKernelGGL(k_chol_diag, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, j, dinv, info,
-                         (j == 0 && src) ? *src : off);
+      hipLaunchKernelGGL(k_chol_diag, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, j, k0, j - k0, dinv,
+                         info, first);
       ++nl;
       if (Ttot - 1 - j > 0) {
-        hipLaunchKernelGGL(k_chol_panel, dim3(xcd_affine_grid(Ttot - 1 - j, batch)), dim3(256), 0, st, mats,
-                           mat_stride, n64, j, dinv, Ttot - 1 - j, batch, (j == 0 && src) ? *src : off);
+        hipLaunchKernelGGL(k_chol_panel, dim3(xcd_affine_grid(Ttot - 1 - j, batch, R)), dim3(256), 0, st, mats,
+                           mat_stride, n64, j, k0, j - k0, dinv, Ttot - 1 - j, batch, R, first);
         ++nl;
       }
     }
     if (k1 < T) {  // wide trailing update with the whole group (K = 64 * (k1 - k0))
       int ntile = 0;
       for (int c = k1; c < T; ++c) ntile += Ttot - c;
-      hipLaunchKernelGGL(k_chol_update, dim3(xcd_affine_grid((ntile + 3) / 4, batch)), dim3(256), 0, st, mats,
-                         mat_stride, n64, Ttot, k1, T, ntile, k0, k1 - k0, batch, first);
+      hipLaunchKernelGGL(k_chol_update, dim3(xcd_affine_grid((ntile + 3) / 4, batch, R)), dim3(256), 0, st, mats,
+                         mat_stride, n64, Ttot, k1, T, ntile, k0, k1 - k0, batch, R, first);
       ++nl;
     }
   }
@@ -552,7 +625,7 @@ void rg_launch_chol_solve_formed(hipStream_t st, const double* sum, int64_t sum_
                                  int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
                                  int32_t* info, int64_t* n_launch) {
   rg_launch_chol_solve_formed_x(st, sum, sum_stride, fold, fold_stride, nfold, shift, nshift, d_n, n_fixed, nouter,
-                                mats, mat_stride, n64, rhs_pad, nrhs, dinv, info, n_launch, 1, nullptr, 0, 0);
+                                mats, mat_stride, n64, rhs_pad, nrhs, dinv, info, n_launch, 1, nullptr, 0, 0, 1);
 }
 
 // General form: subtract = 0 drops the held-out-fold term (LOOCV); rows >= extra_row0 of every system are
@@ -562,11 +635,12 @@ void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t su
                                    const int32_t* d_n, int n_fixed, int nouter, double* mats,
                                    int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
                                    int32_t* info, int64_t* n_launch, int subtract, const double* extra,
-                                   int64_t extra_stride, int extra_row0) {
+                                   int64_t extra_stride, int extra_row0, int n_div) {
   FormSrc f;
   f.sum = sum; f.sum_stride = sum_stride; f.fold = fold; f.fold_stride = fold_stride; f.shift = shift;
   f.d_n = d_n; f.nfold = nfold; f.nshift = nshift; f.n_fixed = n_fixed; f.enabled = 1;
   f.subtract = subtract; f.extra = extra; f.extra_stride = extra_stride; f.extra_row0 = extra_row0; f.n64 = n64;
+  f.n_div = n_div;
   rg_launch_chol_solve_src(st, mats, mat_stride, nouter * nfold * nshift, n64, rhs_pad, nrhs, dinv, info,
                            n_launch, &f);
 }

@@ -342,6 +342,7 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     a.nmiss = ctx->d_nmiss; a.Q = ctx->d_Q; a.XtY = ctx->d_XtY; a.F = ctx->d_F; a.Bm = ctx->d_Bm;
     a.BQ = ctx->d_BQ; a.GYt = ctx->d_GYt; a.sc = ctx->d_sc; a.fold = ctx->d_fold; a.sum = ctx->d_sum;
     a.info = ctx->d_info;
+    a.diff_mode = ctx->loocv ? 0 : 1;
     rg_launch_rowstats(st, a);
     rg_launch_assemble(st, a);
   }
@@ -367,9 +368,11 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
   } else {
   {
     StageTimer t(ctx, &ctx->tm.ms_chol);
-    rg_launch_chol_solve_formed(st, ctx->d_sum, msz, ctx->d_fold, msz, nseg, ctx->d_lambda, R0, ctx->d_bs, 0,
-                                nblk, ctx->d_wk, msz, n64, rtot - n64, P, ctx->d_dinv, ctx->d_info + 1,
-                                &ctx->tm.n_chol_launches);
+    // d_fold[(blk, f)] holds the training-fold system of fold f (assemble.hip diff_mode): one source matrix per
+    // (block, fold), shared by the R0 shifted systems that are co-located on one XCD for their first touch
+    rg_launch_chol_solve_formed_x(st, ctx->d_fold, msz, nullptr, 0, 1, ctx->d_lambda, R0, ctx->d_bs, 0, nblk * nseg,
+                                  ctx->d_wk, msz, n64, rtot - n64, P, ctx->d_dinv, ctx->d_info + 1,
+                                  &ctx->tm.n_chol_launches, 0, nullptr, 0, 0, nseg);
   }
   {
     StageTimer t(ctx, &ctx->tm.ms_pred);

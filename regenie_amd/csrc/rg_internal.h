@@ -151,6 +151,7 @@ struct AsmArgs {
   const double* Q; const double* XtY;
   double *F, *Bm, *BQ, *GYt, *sc, *fold, *sum;
   int32_t* info;
+  int diff_mode;   // 1: fold[f] holds (sum over folds) - (fold f), i.e. the training-fold matrix; sum is not written
 };
 void rg_launch_rowstats(hipStream_t st, const AsmArgs& a);
 void rg_launch_assemble(hipStream_t st, const AsmArgs& a);
@@ -170,7 +171,7 @@ void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t su
                                    const int32_t* d_n, int n_fixed, int nouter, double* mats,
                                    int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
                                    int32_t* info, int64_t* n_launch, int subtract, const double* extra,
-                                   int64_t extra_stride, int extra_row0);
+                                   int64_t extra_stride, int extra_row0, int n_div = 1);
 void rg_launch_dgemm_nt(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                         int m, int n, int64_t k, double* C, int64_t ldc);
 // pred.hip
