@@ -2,10 +2,11 @@
 """Step-1 benchmark (BASELINE.json metric: Step-1 SNPs x samples x phenos / sec).
 
 A "step" is one complete pass of the Step-1 hot path over the synthetic workload with the packed
-genotypes already resident in HBM: level 0 over every SNP block (decode/impute, i8-MFMA fold Gram,
-fp64 multi-lambda ridge solves, out-of-fold predictions, standardisation), [N>1: all-gather of the
-level-0 predictors], level 1 (fold Grams, K*R1 ridge solves, CV statistics, tau selection,
-per-chromosome predictions) and the LOCO assembly on the host.
+genotypes already resident in HBM: level 0 over every SNP block (decode/impute, FP4 matrix-core fold
+Gram, fp64 multi-lambda ridge solves, out-of-fold predictions, standardisation), [N>1: all-gather of
+the level-0 predictors], level 1 (fold Grams, K*R1 ridge solves, CV statistics, tau selection,
+per-chromosome predictions; N>1: Gram tiles and ridge systems shared among the ranks, two all-reduces)
+and the LOCO assembly on the host.
 
 N=1 workload = BASELINE.json configs[1]: synthetic PLINK bed, 50K samples x 100K SNPs, 1 QT phenotype,
 bsize 1000, 22 chromosomes.  N>1: weak scaling, every rank processes its own 100K SNPs (M = 100K * N).
@@ -28,7 +29,8 @@ sys.path.insert(0, ROOT)
 # hg38 autosome lengths (Mb), used only to spread SNPs over 22 chromosomes
 CHR_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51]
 
-PEAK = {"i8_mfma_TOPS": 5000.0,      # 2x the bf16 dense peak (MI355X_MICROARCH.md: I8 ~2x bf16 rate; ubench 4404)
+PEAK = {"fp4_mfma_TOPS": 10000.0,    # MX FP4 dense (MI355X_MICROARCH.md: ~10 PF dense, ubench 9099 TF at 32x32x64)
+        "i8_mfma_TOPS": 5000.0,      # 2x the bf16 dense peak (MI355X_MICROARCH.md: I8 ~2x bf16 rate; ubench 4404)
         "f64_mfma_TFLOPS": 78.6,     # AMD datasheet FP64 matrix (not listed in the guide)
         "hbm_GBs": 8000.0}
 
@@ -51,6 +53,7 @@ def gen_block(torch, dev, block_id, bs, N, seed, ncausal):
     code = torch.where(d == 2, torch.zeros_like(d), torch.where(d == 1, torch.full_like(d, 2), torch.full_like(d, 3)))
     c = code.view(bs, N // 4, 4)
     packed = (c[:, :, 0] | (c[:, :, 1] << 2) | (c[:, :, 2] << 4) | (c[:, :, 3] << 6)).contiguous()
+    ncausal = min(ncausal, bs)
     idx = torch.randperm(bs, generator=g, device=dev)[:ncausal]
     beta = torch.randn(ncausal, generator=g, device=dev, dtype=torch.float64)
     p = maf[idx, 0].double()
@@ -151,14 +154,33 @@ def main():
     ptrs = [packed[b].data_ptr() for b in my_blocks]
     bss = [blocks[b][2] for b in my_blocks]
 
-    def step(exchange=True):
+    class _DevBuf:                                          # raw device pointer -> torch tensor view
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
+
+    def _allreduce(ptr, n):                                 # completes the level-1 Gram / solution buffers
+        t = torch.as_tensor(_DevBuf(ptr, n), device=dev)
+        if args.backend == "nccl":
+            dist.all_reduce(t)
+        else:                                               # gloo (CPU test mode): stage through host memory
+            h = t.cpu()
+            dist.all_reduce(h)
+            t.copy_(h)
+        torch.cuda.synchronize()
+
+    if world > 1:
+        eng.set_collective(world, rank, _allreduce)
+
+    def step(exchange=True, solo=False):
         eng.l0_blocks_device(my_blocks, bss, ptrs, N // 4)
         eng.sync()
         if world > 1 and exchange:
             allgather_w(Wv, shards, R0, force_broadcast=(args.backend != "nccl"))
             torch.cuda.synchronize()
         out = None
-        if rank == 0:                                       # level 1 is phenotype-level work (P small here)
+        if solo:                                            # rank-0-only timing pass: no collective may be issued
+            eng.set_collective(1, 0, None)
+        if rank == 0 or (world > 1 and not solo):           # N>1: level 1 is shared among the ranks
             cs, best, pred = eng.l1_qt(tau, cols_per_chr)
             out = [loco_from_predictions(pred[p], chroms) for p in range(P)], cs, best
         return out
@@ -188,19 +210,19 @@ def main():
     roof, kernels = None, None
     if rank == 0:
         eng.enable_timing(True)
-        step(exchange=False)      # rank-0-only pass: no collective may be issued here (W is already gathered)
+        step(exchange=False, solo=True)   # rank-0-only pass: no collective may be issued here (W is already gathered)
         tm = eng.timing()
         eng.enable_timing(False)
         n_batches = -(-nb // int(os.environ.get("RG_NBLK", "32")))
         bs_eff = float(np.mean(bss))
         flops = {
-            "gram_i8": 2.0 * N * sum(x * x for x in bss),                        # F_gram = 2 N bs^2 per block
+            "gram_fp4": 2.0 * N * sum(x * x for x in bss),                       # F_gram = 2 N bs^2 per block
             "chol_f64": sum((x ** 3 / 3.0 + 2.0 * x * x * P) * 5 * R0 for x in bss),  # K*R0 systems per block
             "l1_gram_f64": 2.0 * N * L * L * P,
             "l1_chol_f64": P * 5 * R1 * (L ** 3 / 3.0 + 2.0 * L * L),
         }
         kernels = {
-            "gram_i8": {"ms": tm["ms_gram"], "achieved_TOPS": flops["gram_i8"] / (tm["ms_gram"] * 1e-3) / 1e12 if tm["ms_gram"] else None,
+            "gram_fp4": {"ms": tm["ms_gram"], "achieved_TOPS": flops["gram_fp4"] / (tm["ms_gram"] * 1e-3) / 1e12 if tm["ms_gram"] else None,
                         "launches": tm["n_gram_launches"]},
             "chol_f64": {"ms": tm["ms_chol"], "achieved_TFLOPS": flops["chol_f64"] / (tm["ms_chol"] * 1e-3) / 1e12 if tm["ms_chol"] else None},
             "prep": {"ms": tm["ms_prep"]}, "geno_xy": {"ms": tm["ms_xy"]}, "assemble_form": {"ms": tm["ms_assemble"]},
@@ -208,12 +230,13 @@ def main():
             "l1_gram_f64": {"ms": tm["ms_l1_gram"], "achieved_TFLOPS": flops["l1_gram_f64"] / (tm["ms_l1_gram"] * 1e-3) / 1e12 if tm["ms_l1_gram"] else None},
             "l1_chol_f64": {"ms": tm["ms_l1_chol"]}, "l1_cv_pred": {"ms": tm["ms_l1_pred"]},
         }
-        dom = max(("gram_i8", "chol_f64", "l1_gram_f64"), key=lambda k: kernels[k]["ms"])
-        if dom == "gram_i8":
+        dom = max(("gram_fp4", "chol_f64", "l1_gram_f64"), key=lambda k: kernels[k]["ms"])
+        kernels["gram_fp4"]["frac_of_fp4_peak"] = kernels["gram_fp4"]["achieved_TOPS"] / PEAK["fp4_mfma_TOPS"]
+        if dom == "gram_fp4":
             a = kernels[dom]["achieved_TOPS"]
-            roof = {"kernel": "k_gram_blocks (i8 MFMA fold Gram)", "bound": "mfma", "achieved": a, "peak": PEAK["i8_mfma_TOPS"],
-                    "unit": "TOP/s", "frac": a / PEAK["i8_mfma_TOPS"], "traffic": None,
-                    "algorithmic_ops_per_launch": flops["gram_i8"] / max(1, n_batches), "avg_launch_ms": tm["ms_gram"] / max(1, n_batches)}
+            roof = {"kernel": "k_gram_fp4_blocks (FP4 matrix-core fold Gram)", "bound": "mfma", "achieved": a, "peak": PEAK["fp4_mfma_TOPS"],
+                    "unit": "TOP/s", "frac": a / PEAK["fp4_mfma_TOPS"], "traffic": None,
+                    "algorithmic_ops_per_launch": flops["gram_fp4"] / max(1, n_batches), "avg_launch_ms": tm["ms_gram"] / max(1, n_batches)}
         else:
             a = kernels[dom]["achieved_TFLOPS"]
             roof = {"kernel": {"chol_f64": "k_chol_update/panel/diag (fp64 MFMA batched Cholesky, per batch of systems)",
@@ -231,11 +254,11 @@ def main():
         line = {
             "metric": "Step-1 SNPs x samples x phenos / sec", "value": value, "unit": "SNP*sample*pheno/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "i8 (Gram) + f64 (solves, level 1)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp4 (exact integer Gram) + f64 (solves, level 1)",
             "data": "synthetic",
             "config": {"workload": "synthetic PLINK bed %d samples x %d SNPs (%d per GPU), %d QT pheno, bsize %d, 22 chromosomes, 5-fold CV, 5x5 ridge grid"
                        % (N, M, args.snps, P, bsize), "samples": N, "snps": M, "phenos": P, "bsize": bsize, "blocks": B,
-                       "parallelism": "blocks sharded x%d, all-gather of W" % world},
+                       "parallelism": "blocks sharded x%d, all-gather of W, level-1 Gram tiles / ridge systems shared x%d" % (world, world)},
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
             "loco_checksum": float(sum(np.abs(l).sum() for l in res[0])), "selected_tau_index": [int(b) for b in res[2]],
             "setup_s": {"generate": t_gen},

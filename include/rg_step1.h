@@ -113,6 +113,17 @@ int rg_l0_set_w(rg_ctx* ctx, int32_t block_id, int32_t pheno, const double* in_h
 int rg_l1_qt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, int32_t nchr,
              const int32_t* cols_per_chr, double* cumsum_out, int32_t* best_out, double* pred_out);
 
+/* ---- multi-GPU level 1 (optional) ----------------------------------------------------------------
+ * After the level-0 predictors have been all-gathered (every rank holds the full W), rg_l1_qt can
+ * share its two heavy steps among `world` ranks: the fold-Gram tiles are computed tile-cyclically and
+ * the K*R1 ridge systems in contiguous ranges; each step is completed by ONE in-place sum all-reduce
+ * of a device buffer, performed by the caller's callback (RCCL through torch.distributed, ncclAllReduce
+ * in a C++ host, ...) between the library's kernels.  Every rank must then call rg_l1_qt with the same
+ * arguments and receives identical results.  The reference has no counterpart (level 1 is single-node,
+ * Step1_Models.cpp:772-872); the decomposition follows SURVEY.md section 8(e). */
+typedef int (*rg_allreduce_fn)(void* user, void* dev_ptr, int64_t n_doubles);
+int rg_set_collective(rg_ctx* ctx, int32_t world, int32_t rank, rg_allreduce_fn fn, void* user);
+
 /* ---- level 1, quantitative traits, leave-one-out CV ------------------------------------------
  * Replaces ridge_level_1_loocv (Step1_Models.cpp:875-962), the tau selection of Data::output and
  * make_predictions_loocv (Data.cpp:1269-1342).  Requires a problem set up with cv_folds = 0.

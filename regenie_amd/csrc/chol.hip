@@ -162,10 +162,11 @@ struct FormSrc {
   const double* fold; int64_t fold_stride;
   const double* shift; const int32_t* d_n;
   const double* extra; int64_t extra_stride;
-  int nfold, nshift, n_fixed, enabled, subtract, extra_row0, n64, n_div;
+  int nfold, nshift, n_fixed, enabled, subtract, extra_row0, n64, n_div, b_offset;
 };
 struct FormIdx { const double* S; const double* F; const double* X; double sh; int64_t xoff; int n, x0; };
-__device__ __forceinline__ FormIdx form_idx(const FormSrc& f, int b) {
+__device__ __forceinline__ FormIdx form_idx(const FormSrc& f, int b_local) {
+  const int b = b_local + f.b_offset;   // a rank / caller may own a contiguous sub-range of the systems
   const int per = f.nfold * f.nshift;
   const int o = b / per, rem = b % per, fo = rem / f.nshift, r = rem % f.nshift;
   FormIdx x;
@@ -580,7 +581,7 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
   const int T = n64 / CT, Tr = rhs_pad / CT, Ttot = T + Tr;
   const int G = 4;  // tile columns per group: trailing updates contract K = 64*G at once
   FormSrc off{};
-  off.enabled = 0; off.extra = nullptr; off.n_div = 1;
+  off.enabled = 0; off.extra = nullptr; off.n_div = 1; off.b_offset = 0;
   int64_t nl = 0;
   for (int k0 = 0; k0 < T; k0 += G) {
     const int k1 = std::min(T, k0 + G);
@@ -625,7 +626,7 @@ void rg_launch_chol_solve_formed(hipStream_t st, const double* sum, int64_t sum_
                                  int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
                                  int32_t* info, int64_t* n_launch) {
   rg_launch_chol_solve_formed_x(st, sum, sum_stride, fold, fold_stride, nfold, shift, nshift, d_n, n_fixed, nouter,
-                                mats, mat_stride, n64, rhs_pad, nrhs, dinv, info, n_launch, 1, nullptr, 0, 0, 1);
+                                mats, mat_stride, n64, rhs_pad, nrhs, dinv, info, n_launch, 1, nullptr, 0, 0, 1, 0, -1);
 }
 
 // General form: subtract = 0 drops the held-out-fold term (LOOCV); rows >= extra_row0 of every system are
@@ -635,12 +636,12 @@ void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t su
                                    const int32_t* d_n, int n_fixed, int nouter, double* mats,
                                    int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
                                    int32_t* info, int64_t* n_launch, int subtract, const double* extra,
-                                   int64_t extra_stride, int extra_row0, int n_div) {
+                                   int64_t extra_stride, int extra_row0, int n_div, int b_offset, int b_count) {
   FormSrc f;
   f.sum = sum; f.sum_stride = sum_stride; f.fold = fold; f.fold_stride = fold_stride; f.shift = shift;
   f.d_n = d_n; f.nfold = nfold; f.nshift = nshift; f.n_fixed = n_fixed; f.enabled = 1;
   f.subtract = subtract; f.extra = extra; f.extra_stride = extra_stride; f.extra_row0 = extra_row0; f.n64 = n64;
-  f.n_div = n_div;
-  rg_launch_chol_solve_src(st, mats, mat_stride, nouter * nfold * nshift, n64, rhs_pad, nrhs, dinv, info,
-                           n_launch, &f);
+  f.n_div = n_div; f.b_offset = b_offset;
+  rg_launch_chol_solve_src(st, mats, mat_stride, b_count >= 0 ? b_count : nouter * nfold * nshift, n64, rhs_pad, nrhs,
+                           dinv, info, n_launch, &f);
 }

@@ -10,7 +10,9 @@
 // W_f^T y_f and the fold systems' right-hand sides come out of the same launch.  The K*R1 systems
 // (sum_f S_f - S_i + tau_j I) are then factored by the same batched Cholesky as level 0.
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include "rg_internal.h"
 
 #define CT 64
@@ -27,62 +29,81 @@ __device__ __forceinline__ const double* l1_row(const L1Rows& R, int row) {
   return R.zero;
 }
 
-__global__ __launch_bounds__(256) void k_l1_gram(L1Rows R, SegLayout seg, int ntile_mat, int rtot,
-                                                 double* out) {
-  const int f = blockIdx.y;
-  const int tri = ntile_mat * (ntile_mat + 1) / 2;
-  int idx = blockIdx.x, tr, tc;
-  if (idx < tri) {
-    int rr = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
-    while ((rr + 1) * (rr + 2) / 2 <= idx) ++rr;
-    while (rr * (rr + 1) / 2 > idx) --rr;
-    tr = rr;
-    tc = idx - rr * (rr + 1) / 2;
-  } else {
-    tr = ntile_mat;  // the RHS row tile (y)
-    tc = idx - tri;
-  }
+// ---- fold Gram, one WAVE per 64x64 tile (4 x 4 MFMA 16x16x4 sub-tiles, as k_chol_update): 4 B/clk of operand
+//      traffic per wave instead of 8 with 32x32 per wave.  Work item = (K slice, tile); tiles are enumerated
+//      column by column so the four waves of a workgroup share their B rows in L1; the K range of a fold is cut
+//      into `nslice` slices when there are too few tiles to fill the chip (small L), each slice writing its own
+//      partial matrix (summed in fixed order by k_reduce_slices: deterministic).  Multi-GPU: rank r computes the
+//      tiles with index = r (mod world); the others stay zero and an all-reduce completes the matrices.
+struct L1G64 {
+  L1Rows R; int T, rtot, nslice, ntile, world, rank;
+  double* out; int64_t slice_stride;
+};
+__global__ __launch_bounds__(256, 2) void k_l1_gram64(L1G64 g, SegLayout seg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int f = blockIdx.y;
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= g.ntile * g.nslice) return;
+  const int sl = item / g.ntile, idx = item % g.ntile;
+  if (idx % g.world != g.rank) return;
+  int tc = 0, rem = idx;
+  while (rem >= g.T + 1 - tc) { rem -= g.T + 1 - tc; ++tc; }
+  const int tr = tc + rem;                       // tr == T: the right-hand-side row tile (y)
   const int i = lane & 15, q = lane >> 4;
-  const int64_t p0 = seg.pos_start[f] + 16 * q;
-  const double* ar[2] = {l1_row(R, tr * CT + wr * 32 + i) + p0, l1_row(R, tr * CT + wr * 32 + 16 + i) + p0};
-  const double* br[2] = {l1_row(R, tc * CT + wc * 32 + i) + p0, l1_row(R, tc * CT + wc * 32 + 16 + i) + p0};
-  v4d acc[2][2];
+  const int64_t nch = seg.plen[f] / 64;
+  const int64_t c0 = nch * sl / g.nslice, c1 = nch * (sl + 1) / g.nslice;
+  const int64_t p0 = seg.pos_start[f] + 4 * q;
+  const double* A[4];
+  const double* B[4];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < 4; ++m) {
+    A[m] = l1_row(g.R, tr * CT + m * 16 + i) + p0;
+    B[m] = l1_row(g.R, tc * CT + m * 16 + i) + p0;
+  }
+  v4d acc[4][4];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
-  const int64_t plen = seg.plen[f];
-  for (int64_t k = 0; k < plen; k += 64) {
-    double av[2][16], bv[2][16];
+  for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      const double4* pa = reinterpret_cast<const double4*>(ar[m] + k);
-      const double4* pb = reinterpret_cast<const double4*>(br[m] + k);
+    for (int n = 0; n < 4; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
+  for (int64_t kc = c0 * 4; kc < c1 * 4; ++kc) {
+    double4 av[4], bv[4];
 #pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        const double4 x = pa[v], y = pb[v];
-        av[m][4 * v] = x.x; av[m][4 * v + 1] = x.y; av[m][4 * v + 2] = x.z; av[m][4 * v + 3] = x.w;
-        bv[m][4 * v] = y.x; bv[m][4 * v + 1] = y.y; bv[m][4 * v + 2] = y.z; bv[m][4 * v + 3] = y.w;
-      }
+    for (int m = 0; m < 4; ++m) {
+      av[m] = *reinterpret_cast<const double4*>(A[m] + kc * 16);
+      bv[m] = *reinterpret_cast<const double4*>(B[m] + kc * 16);
     }
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].x, bv[n].x, acc[m][n], 0, 0, 0);
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
-          acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m][s], bv[n][s], acc[m][n], 0, 0, 0);
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].y, bv[n].y, acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].z, bv[n].z, acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].w, bv[n].w, acc[m][n], 0, 0, 0);
   }
-  double* O = out + (int64_t)f * rtot * R.n64 + (int64_t)tr * CT * R.n64 + tc * CT;
+  double* O = g.out + (int64_t)sl * g.slice_stride + (int64_t)f * g.rtot * g.R.n64 + (int64_t)tr * CT * g.R.n64 + tc * CT;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < 4; ++n)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        O[(int64_t)(wr * 32 + m * 16 + q + 4 * r) * R.n64 + wc * 32 + n * 16 + i] = acc[m][n][r];
+      for (int r = 0; r < 4; ++r) O[(int64_t)(m * 16 + q + 4 * r) * g.R.n64 + n * 16 + i] = acc[m][n][r];
+}
+
+__global__ void k_reduce_slices(const double* part, int64_t slice_stride, int nslice, int64_t n, double* out) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  double t = 0.0;
+  for (int s = 0; s < nslice; ++s) t += part[(int64_t)s * slice_stride + e];
+  out[e] = t;
 }
 
 __global__ void k_sum_folds(const double* fold, int64_t msz, int nfold, double* sum) {
@@ -98,7 +119,7 @@ __global__ void k_sum_folds(const double* fold, int64_t msz, int nfold, double* 
 // grid (nchunk), 256 threads, thread = one position.  part: [chunk][R1][3] + ysum [chunk][2]
 #define R1MAX 8
 #define L1_CT 256
-__global__ __launch_bounds__(256) void k_l1_cv(L1Rows R, const double* wk, int64_t msz, int R1,
+__global__ __launch_bounds__(256) void k_l1_cv(L1Rows R, const double* alpha /*[K*R1][n64]*/, int R1,
                                                const int32_t* chunk_seg, const int64_t* chunk_pos,
                                                const int64_t* chunk_len, double* part) {
   __shared__ double sA[L1_CT][R1MAX];
@@ -120,7 +141,7 @@ __global__ __launch_bounds__(256) void k_l1_cv(L1Rows R, const double* wk, int64
       for (int j = 0; j < R1MAX; ++j) {
         const int col = c0 + threadIdx.x;
         sA[threadIdx.x][j] = (j < R1 && col < R.L)
-            ? wk[((int64_t)f * R1 + j) * msz + (int64_t)R.n64 * R.n64 + col] : 0.0;
+            ? alpha[((int64_t)f * R1 + j) * R.n64 + col] : 0.0;
       }
       __syncthreads();
       if (live) {
@@ -159,7 +180,7 @@ __global__ __launch_bounds__(256) void k_l1_cv(L1Rows R, const double* wk, int64
 
 // ---- final per-chromosome predictions with the selected tau ------------------------------------------------
 // pred: [nchr][N] (compact sample order); thread = one position
-__global__ __launch_bounds__(256) void k_l1_pred(L1Rows R, const double* wk, int64_t msz, int R1,
+__global__ __launch_bounds__(256) void k_l1_pred(L1Rows R, const double* alpha /*[K*R1][n64]*/, int R1,
                                                  int best, const int32_t* chunk_seg,
                                                  const int64_t* chunk_pos, const int64_t* chunk_len,
                                                  const int32_t* chr_col0 /*[nchr+1]*/, int nchr,
@@ -168,7 +189,7 @@ __global__ __launch_bounds__(256) void k_l1_pred(L1Rows R, const double* wk, int
   const int ch = blockIdx.x;
   const int f = chunk_seg[ch];
   const int64_t p0 = chunk_pos[ch], plen = chunk_len[ch];
-  const double* al = wk + ((int64_t)f * R1 + best) * msz + (int64_t)R.n64 * R.n64;
+  const double* al = alpha + ((int64_t)f * R1 + best) * R.n64;
   for (int c = threadIdx.x; c < R.L; c += 256) sAl[c] = al[c];
   __syncthreads();
   for (int64_t sub = 0; sub < plen; sub += 256) {
@@ -190,6 +211,7 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
                   double* cumsum_out, int32_t* best_out, double* pred_out) {
   if (!ctx->have_problem || !ctx->d_W) { ctx->err = "rg_l1_qt: no level-0 predictors"; return RG_ERR_STATE; }
   if (R1 < 1 || R1 > R1MAX) { ctx->err = "rg_l1_qt: n_ridge_l1 must be in [1,8]"; return RG_ERR_ARG; }
+  if (ctx->loocv) { ctx->err = "rg_l1_qt: the problem was set up for LOOCV (use rg_l1_qt_loocv)"; return RG_ERR_STATE; }
   hipStream_t st = ctx->stream;
   const int L = ctx->B_total * ctx->R0, P = ctx->P, K = ctx->K;
   int ltot = 0;
@@ -202,37 +224,82 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
   const int nsys = K * R1;
   const int nch = ctx->n_c256;
   const int NPART = R1MAX * 3 + 2;
+  const int world = ctx->coll_world, rank = ctx->coll_rank;
+  const bool multi = world > 1 && ctx->coll_allreduce != nullptr;
+  // systems (fold f, tau j) -> b = f*R1 + j; rank r factors the contiguous range [b0, b1)
+  const int b0 = multi ? (int)((int64_t)nsys * rank / world) : 0;
+  const int b1 = multi ? (int)((int64_t)nsys * (rank + 1) / world) : nsys;
+  const int nloc = b1 - b0;
+  // Gram work items: tiles (lower triangle + the y row tile) x K slices
+  const int ntile = T * (T + 1) / 2 + T;
+  int64_t min_nch = INT64_MAX;
+  for (int f = 0; f < K; ++f) min_nch = std::min(min_nch, ctx->seg.plen[f] / 64);
+  int nslice = (int)std::min<int64_t>(16, std::max<int64_t>(1, (4096 + (int64_t)ntile * K - 1) / ((int64_t)ntile * K)));
+  nslice = (int)std::max<int64_t>(1, std::min<int64_t>(nslice, min_nch / 4));
 
-  double *d_fold = nullptr, *d_sum = nullptr, *d_wk = nullptr, *d_dinv = nullptr, *d_tau = nullptr,
-         *d_part = nullptr, *d_pred = nullptr;
+  double *d_fold = nullptr, *d_part = nullptr, *d_sum = nullptr, *d_wk = nullptr, *d_dinv = nullptr, *d_tau = nullptr,
+         *d_cvp = nullptr, *d_pred = nullptr, *d_alpha = nullptr;
   int32_t* d_col0 = nullptr;
-  RG_HIP(hipMalloc(&d_fold, sizeof(double) * msz * K));
-  RG_HIP(hipMalloc(&d_sum, sizeof(double) * msz));
-  RG_HIP(hipMalloc(&d_wk, sizeof(double) * msz * nsys));
-  RG_HIP(hipMalloc(&d_dinv, sizeof(double) * (size_t)nsys * T * CT * CT));
-  RG_HIP(hipMalloc(&d_tau, sizeof(double) * R1));
-  RG_HIP(hipMalloc(&d_part, sizeof(double) * (size_t)nch * NPART));
-  RG_HIP(hipMalloc(&d_pred, sizeof(double) * (size_t)nchr * ctx->N));
-  RG_HIP(hipMalloc(&d_col0, sizeof(int32_t) * (nchr + 1)));
+#define L1_WS(var, slot, type, count)                                                   \
+  var = (type*)rg_ws(ctx, slot, sizeof(type) * (size_t)(count));                        \
+  if (!var) { ctx->err = "rg_l1_qt: out of device memory"; return RG_ERR_HIP; }
+  L1_WS(d_fold, 0, double, msz * K)
+  if (nslice > 1) { L1_WS(d_part, 1, double, msz * K * nslice) }
+  L1_WS(d_sum, 2, double, msz)
+  L1_WS(d_wk, 3, double, msz * std::max(1, nloc))
+  L1_WS(d_dinv, 4, double, (size_t)std::max(1, nloc) * T * CT * CT)
+  L1_WS(d_tau, 5, double, R1)
+  L1_WS(d_cvp, 6, double, (size_t)nch * NPART)
+  L1_WS(d_pred, 7, double, (size_t)nchr * ctx->N)
+  L1_WS(d_alpha, 8, double, (size_t)nsys * n64)
+  L1_WS(d_col0, 9, int32_t, nchr + 1)
+#undef L1_WS
   RG_HIP(hipMemcpyAsync(d_col0, col0.data(), sizeof(int32_t) * (nchr + 1), hipMemcpyHostToDevice, st));
   std::vector<double> hpart((size_t)nch * NPART);
   int rc = RG_OK;
+  auto lap = [&](double* slot, hipEvent_t e0, hipEvent_t e1) {
+    if (!ctx->timing) return;
+    hipEventRecord(e1, st); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); *slot += ms;
+    hipEventRecord(e0, st);
+  };
 
   for (int p = 0; p < P && rc == RG_OK; ++p) {
     L1Rows R{ctx->d_W, ctx->d_V + (int64_t)(ctx->C + p) * ctx->Np, ctx->d_zero, ctx->Np, L, P, p, n64};
     hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
     if (ctx->timing) hipEventRecord(e0, st);
-    hipMemsetAsync(d_fold, 0, sizeof(double) * msz * K, st);
-    hipLaunchKernelGGL(k_l1_gram, dim3(T * (T + 1) / 2 + T, K), dim3(256), 0, st, R, ctx->seg, T, rtot, d_fold);
+    // ---- fold Grams X_f = W_f^T W_f with W_f^T y_f as an extra row ------------------------------------------
+    double* gout = nslice > 1 ? d_part : d_fold;
+    hipMemsetAsync(gout, 0, sizeof(double) * msz * K * nslice, st);
+    L1G64 g{R, T, rtot, nslice, ntile, multi ? world : 1, multi ? rank : 0, gout, msz * K};
+    hipLaunchKernelGGL(k_l1_gram64, dim3((ntile * nslice + 3) / 4, K), dim3(256), 0, st, g, ctx->seg);
+    if (nslice > 1)
+      hipLaunchKernelGGL(k_reduce_slices, dim3((unsigned)((msz * K + 255) / 256)), dim3(256), 0, st, d_part, msz * K,
+                         nslice, msz * K, d_fold);
+    if (multi) {  // every rank needs every fold matrix: sum of disjoint tile sets
+      RG_HIP(hipStreamSynchronize(st));
+      if (ctx->coll_allreduce(ctx->coll_user, d_fold, msz * K) != 0) { ctx->err = "rg_l1_qt: all-reduce callback failed"; rc = RG_ERR_STATE; break; }
+    }
     hipLaunchKernelGGL(k_sum_folds, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, st, d_fold, msz, K, d_sum);
-    if (ctx->timing) { hipEventRecord(e1, st); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ctx->tm.ms_l1_gram += ms; hipEventRecord(e0, st); }
+    lap(&ctx->tm.ms_l1_gram, e0, e1);
+    // ---- the K*R1 systems (sum - X_f + tau_j I) alpha = (sum - X_f^T y_f) -----------------------------------
     hipMemcpyAsync(d_tau, tau + (int64_t)p * R1, sizeof(double) * R1, hipMemcpyHostToDevice, st);
-    rg_launch_chol_solve_formed(st, d_sum, 0, d_fold, msz, K, d_tau, R1, nullptr, L, 1, d_wk, msz, n64, CT, 1,
-                                d_dinv, ctx->d_info + 1, &ctx->tm.n_chol_launches);
-    if (ctx->timing) { hipEventRecord(e1, st); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ctx->tm.ms_l1_chol += ms; hipEventRecord(e0, st); }
-    hipLaunchKernelGGL(k_l1_cv, dim3(nch), dim3(256), 0, st, R, d_wk, msz, R1, ctx->d_c256_seg,
-                       ctx->d_c256_pos, ctx->d_c256_len, d_part);
-    RG_HIP(hipMemcpyAsync(hpart.data(), d_part, sizeof(double) * hpart.size(), hipMemcpyDeviceToHost, st));
+    hipMemsetAsync(d_alpha, 0, sizeof(double) * (size_t)nsys * n64, st);
+    if (nloc > 0) {
+      rg_launch_chol_solve_formed_x(st, d_sum, 0, d_fold, msz, K, d_tau, R1, nullptr, L, 1, d_wk, msz, n64, CT, 1,
+                                    d_dinv, ctx->d_info + 1, &ctx->tm.n_chol_launches, 1, nullptr, 0, 0, 1, b0, nloc);
+      RG_HIP(hipMemcpy2DAsync(d_alpha + (int64_t)b0 * n64, sizeof(double) * n64, d_wk + (int64_t)n64 * n64,
+                              sizeof(double) * msz, sizeof(double) * n64, nloc, hipMemcpyDeviceToDevice, st));
+    }
+    if (multi) {
+      RG_HIP(hipStreamSynchronize(st));
+      if (ctx->coll_allreduce(ctx->coll_user, d_alpha, (int64_t)nsys * n64) != 0) { ctx->err = "rg_l1_qt: all-reduce callback failed"; rc = RG_ERR_STATE; break; }
+    }
+    lap(&ctx->tm.ms_l1_chol, e0, e1);
+    // ---- out-of-fold predictions for every tau, the five sums (every rank: identical, deterministic) -------------
+    hipLaunchKernelGGL(k_l1_cv, dim3(nch), dim3(256), 0, st, R, d_alpha, R1, ctx->d_c256_seg,
+                       ctx->d_c256_pos, ctx->d_c256_len, d_cvp);
+    RG_HIP(hipMemcpyAsync(hpart.data(), d_cvp, sizeof(double) * hpart.size(), hipMemcpyDeviceToHost, st));
     RG_HIP(hipStreamSynchronize(st));
     // cumsum_values (Step1_Models.cpp:854-858): fixed-order host reduction of the chunk partials
     double* cs = cumsum_out + (int64_t)p * 5 * R1;  // [5][R1] row-major per phenotype
@@ -257,7 +324,7 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
     }
     best_out[p] = best;
     hipMemsetAsync(d_pred, 0, sizeof(double) * (size_t)nchr * ctx->N, st);
-    hipLaunchKernelGGL(k_l1_pred, dim3(nch), dim3(256), sizeof(double) * L, st, R, d_wk, msz, R1, best,
+    hipLaunchKernelGGL(k_l1_pred, dim3(nch), dim3(256), sizeof(double) * L, st, R, d_alpha, R1, best,
                        ctx->d_c256_seg, ctx->d_c256_pos, ctx->d_c256_len, d_col0, nchr,
                        ctx->d_cidx, ctx->N, d_pred);
     RG_HIP(hipMemcpyAsync(pred_out + (int64_t)p * nchr * ctx->N, d_pred,
@@ -268,7 +335,5 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
     RG_HIP(hipMemcpy(info, ctx->d_info, sizeof(info), hipMemcpyDeviceToHost));
     if (info[1]) { ctx->err = "level 1 ridge system is not positive definite"; rc = RG_ERR_NOT_SPD; }
   }
-  hipFree(d_fold); hipFree(d_sum); hipFree(d_wk); hipFree(d_dinv); hipFree(d_tau); hipFree(d_part);
-  hipFree(d_pred); hipFree(d_col0);
   return rc;
 }

@@ -33,6 +33,8 @@ void free_all(rg_ctx* c) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->own_W && c->d_W) hipFree(c->d_W);
+  for (int i = 0; i < 12; ++i)
+    if (c->ws_ptr[i]) { hipFree(c->ws_ptr[i]); c->ws_ptr[i] = nullptr; c->ws_bytes[i] = 0; }
 }
 
 struct StageTimer {
@@ -496,6 +498,13 @@ int rg_l1_bt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, const double* y
   if (rc) return rc;
   return rg_l1_bt_impl(ctx, n_ridge_l1, tau, yraw, offset, opt, nchr, cols_per_chr, cumsum_out, converged_out,
                        best_out, pred_out);
+}
+
+int rg_set_collective(rg_ctx* ctx, int32_t world, int32_t rank, rg_allreduce_fn fn, void* user) {
+  if (!ctx) return RG_ERR_ARG;
+  if (world < 1 || rank < 0 || rank >= world || (world > 1 && !fn)) { ctx->err = "rg_set_collective: bad arguments"; return RG_ERR_ARG; }
+  ctx->coll_world = world; ctx->coll_rank = rank; ctx->coll_allreduce = fn; ctx->coll_user = user;
+  return RG_OK;
 }
 
 int rg_enable_timing(rg_ctx* ctx, int on) {

@@ -106,11 +106,32 @@ struct rg_ctx {
   int32_t* d_blockid = nullptr;  // [nblk]
   std::vector<int> block_done;
 
+  // multi-GPU level 1: tile-sharded Gram and system-sharded solves, completed by caller-provided all-reduces
+  int coll_world = 1, coll_rank = 0;
+  rg_allreduce_fn coll_allreduce = nullptr;
+  void* coll_user = nullptr;
+
+  // level-1 workspaces, kept across calls (hipMalloc/hipFree per call costs milliseconds)
+  void* ws_ptr[12] = {};
+  size_t ws_bytes[12] = {};
+
   // timing
   bool timing = false;
   rg_timing tm{};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
+
+// grows-only device workspace slot; returns nullptr on allocation failure
+static inline void* rg_ws(rg_ctx* ctx, int slot, size_t bytes) {
+  if (bytes == 0) bytes = 8;
+  if (ctx->ws_bytes[slot] < bytes) {
+    if (ctx->ws_ptr[slot]) hipFree(ctx->ws_ptr[slot]);
+    ctx->ws_ptr[slot] = nullptr; ctx->ws_bytes[slot] = 0;
+    if (hipMalloc(&ctx->ws_ptr[slot], bytes) != hipSuccess) return nullptr;
+    ctx->ws_bytes[slot] = bytes;
+  }
+  return ctx->ws_ptr[slot];
+}
 
 #define RG_HIP(call)                                                                   \
   do {                                                                                 \
@@ -171,7 +192,8 @@ void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t su
                                    const int32_t* d_n, int n_fixed, int nouter, double* mats,
                                    int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
                                    int32_t* info, int64_t* n_launch, int subtract, const double* extra,
-                                   int64_t extra_stride, int extra_row0, int n_div = 1);
+                                   int64_t extra_stride, int extra_row0, int n_div = 1, int b_offset = 0,
+                                   int b_count = -1);
 void rg_launch_dgemm_nt(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                         int m, int n, int64_t k, double* C, int64_t ldc);
 // pred.hip

@@ -49,7 +49,7 @@ class RgTiming(C.Structure):
 
 EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_w_rows", "rg_w_bytes",
            "rg_set_w_buffer", "rg_w_device_ptr", "rg_l0_blocks", "rg_sync", "rg_l0_get_w",
-           "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
+           "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_set_collective", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
            "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak"]
 
 
@@ -89,6 +89,7 @@ def load_library() -> C.CDLL:
     lib.rg_l1_qt_loocv.argtypes = lib.rg_l1_qt.argtypes
     lib.rg_l1_bt.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rg_set_collective.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rg_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.rg_get_timing.argtypes = [C.c_void_p, C.POINTER(RgTiming)]
     lib.rg_k_gram_i8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
@@ -265,6 +266,23 @@ class Step1Engine:
                                       C.byref(o), nchr, cpc.ctypes.data, cs.ctypes.data, conv.ctypes.data,
                                       best.ctypes.data, pred.ctypes.data))
         return cs, conv.astype(bool), best, [pred[p].T.copy() for p in range(P)]
+
+    def set_collective(self, world: int, rank: int, allreduce=None):
+        """Shares level 1 among `world` ranks.  allreduce(dev_ptr: int, n_doubles: int) must sum the device
+        buffer in place over all ranks (e.g. torch.distributed.all_reduce on a tensor view of it)."""
+        cb_t = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+
+        def _cb(_user, ptr, n):
+            try:
+                allreduce(int(ptr), int(n))
+                return 0
+            except Exception as e:  # noqa: BLE001 - reported through the C return code
+                import sys
+                print("all-reduce callback failed:", e, file=sys.stderr)
+                return 1
+        self._coll_cb = cb_t(_cb) if allreduce is not None else None
+        self._check(self.lib.rg_set_collective(self.h, world, rank,
+                                               C.cast(self._coll_cb, C.c_void_p) if self._coll_cb else None, None))
 
     def enable_timing(self, on: bool = True):
         self._check(self.lib.rg_enable_timing(self.h, int(on)))
