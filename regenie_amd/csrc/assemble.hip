@@ -90,7 +90,10 @@ __global__ __launch_bounds__(64) void k_rowstats(AsmArgs a) {
   a.sc[(int64_t)blk * a.n128 + j] = sc;
 }
 
-// grid (n64/32, rtot/8, nblk), block (32, 8): element (row i = by*8+ty, col k = bx*32+tx)
+// grid (n64/32, rtot/8, nblk), block (32, 8): element (row i = by*8+ty, col k = bx*32+tx).
+// The per-fold values of one element live in registers (up to AF folds) so that in diff_mode the training-fold
+// matrices (total - fold f) are written in a single pass; more folds fall back to a second pass through memory.
+#define AF 8
 __global__ __launch_bounds__(256) void k_assemble(AsmArgs a) {
   const int blk = blockIdx.z;
   const int k = blockIdx.x * 32 + threadIdx.x;
@@ -99,68 +102,76 @@ __global__ __launch_bounds__(256) void k_assemble(AsmArgs a) {
   const int C = a.C, P = a.P, ns = a.nseg, n128 = a.n128, n64 = a.n64;
   if (i >= a.rtot || k >= n64) return;
   const int64_t msz = (int64_t)a.rtot * n64;
-  double* fold = a.fold + (int64_t)blk * ns * msz;
-  double* sum = a.sum + (int64_t)blk * msz;
+  double* __restrict__ fold = a.fold + (int64_t)blk * ns * msz;
+  double* __restrict__ sum = a.sum + (int64_t)blk * msz;
   const int64_t e = (int64_t)i * n64 + k;
-  const double* sc = a.sc + (int64_t)blk * n128;
-  // diff_mode: fold[f] := (sum over folds) - (fold f) = the training-fold system of CV fold f, so the
-  // Cholesky's first touch reads ONE matrix; otherwise fold[f] and their sum are both written (LOOCV path).
-  auto finish = [&](double tot) {
-    if (a.diff_mode) {
-      for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = tot - fold[(int64_t)s * msz + e];
-    } else {
-      sum[e] = tot;
-    }
-  };
+  const double* __restrict__ sc = a.sc + (int64_t)blk * n128;
+  const bool inreg = ns <= AF;
+  double vf[AF];
+#pragma unroll
+  for (int s = 0; s < AF; ++s) vf[s] = 0.0;
+  double tot = 0.0;
+  bool write_zero = false, skip = false;
   if (i >= n64) {  // RHS rows: b_f^T
     const int p = i - n64;
-    double tot = 0.0;
     for (int s = 0; s < ns; ++s) {
       double v = 0.0;
       if (p < P && k < bs) v = a.GYt[(((int64_t)blk * ns + s) * n128 + k) * P + p] / sc[k];
-      fold[(int64_t)s * msz + e] = v;
+      if (inreg) {
+#pragma unroll
+        for (int t = 0; t < AF; ++t) if (t == s) vf[t] = v;
+      } else fold[(int64_t)s * msz + e] = v;
       tot += v;
     }
-    finish(tot);
-    return;
-  }
-  if (k > i) {  // upper triangle: never referenced, except inside diagonal 64-tiles (kept finite)
-    if ((k >> 6) == (i >> 6)) {
-      for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = 0.0;
-      if (!a.diff_mode) sum[e] = 0.0;
+  } else if (k > i) {  // upper triangle: never referenced, except inside diagonal 64-tiles (kept finite)
+    if ((k >> 6) == (i >> 6)) write_zero = true;
+    else skip = true;
+  } else if (i >= bs) {  // padding (k <= i)
+    write_zero = true;
+  } else {
+    const bool has_miss = a.nmiss[blk] > 0;
+    const double mui = a.mu[(int64_t)blk * n128 + i], muk = a.mu[(int64_t)blk * n128 + k];
+    const double inv = 1.0 / (sc[i] * sc[k]);
+    const double* __restrict__ Bi = a.Bm + ((int64_t)blk * n128 + i) * C;
+    const double* __restrict__ Bk = a.Bm + ((int64_t)blk * n128 + k) * C;
+    const int64_t ldS = 2 * (int64_t)n128;
+    for (int s = 0; s < ns; ++s) {
+      const int32_t* __restrict__ S = a.S + ((int64_t)blk * ns + s) * ldS * ldS;
+      double at = (double)S[(int64_t)i * ldS + k];
+      if (has_miss) {
+        at += mui * (double)S[(int64_t)(n128 + i) * ldS + k];
+        at += muk * (double)S[(int64_t)(n128 + k) * ldS + i];
+        at += mui * muk * (double)S[(int64_t)(n128 + i) * ldS + n128 + k];
+      }
+      const double* __restrict__ Fi = a.F + (((int64_t)blk * ns + s) * n128 + i) * C;
+      const double* __restrict__ Fk = a.F + (((int64_t)blk * ns + s) * n128 + k) * C;
+      const double* __restrict__ BQi = a.BQ + (((int64_t)blk * ns + s) * n128 + i) * C;
+      double corr = 0.0;
+      for (int c = 0; c < C; ++c) corr += BQi[c] * Bk[c] - Fi[c] * Bk[c] - Bi[c] * Fk[c];
+      const double v = (at + corr) * inv;
+      if (inreg) {
+#pragma unroll
+        for (int t = 0; t < AF; ++t) if (t == s) vf[t] = v;
+      } else fold[(int64_t)s * msz + e] = v;
+      tot += v;
     }
-    return;
   }
-  if (i >= bs) {      // padding (k <= i)
+  if (skip) return;
+  if (write_zero) {
     for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = 0.0;
     if (!a.diff_mode) sum[e] = 0.0;
     return;
   }
-  const bool has_miss = a.nmiss[blk] > 0;
-  const double mui = a.mu[(int64_t)blk * n128 + i], muk = a.mu[(int64_t)blk * n128 + k];
-  const double inv = 1.0 / (sc[i] * sc[k]);
-  const double* Bi = a.Bm + ((int64_t)blk * n128 + i) * C;
-  const double* Bk = a.Bm + ((int64_t)blk * n128 + k) * C;
-  const int64_t ldS = 2 * (int64_t)n128;
-  double tot = 0.0;
-  for (int s = 0; s < ns; ++s) {
-    const int32_t* S = a.S + ((int64_t)blk * ns + s) * ldS * ldS;
-    double at = (double)S[(int64_t)i * ldS + k];
-    if (has_miss) {
-      at += mui * (double)S[(int64_t)(n128 + i) * ldS + k];
-      at += muk * (double)S[(int64_t)(n128 + k) * ldS + i];
-      at += mui * muk * (double)S[(int64_t)(n128 + i) * ldS + n128 + k];
-    }
-    const double* Fi = a.F + (((int64_t)blk * ns + s) * n128 + i) * C;
-    const double* Fk = a.F + (((int64_t)blk * ns + s) * n128 + k) * C;
-    const double* BQi = a.BQ + (((int64_t)blk * ns + s) * n128 + i) * C;
-    double corr = 0.0;
-    for (int c = 0; c < C; ++c) corr += BQi[c] * Bk[c] - Fi[c] * Bk[c] - Bi[c] * Fk[c];
-    const double v = (at + corr) * inv;
-    fold[(int64_t)s * msz + e] = v;
-    tot += v;
+  // diff_mode: fold[f] := (sum over folds) - (fold f) = the training-fold system of CV fold f, so the
+  // Cholesky's first touch reads ONE matrix; otherwise fold[f] and their sum are both written (LOOCV path).
+  if (inreg) {
+#pragma unroll
+    for (int t = 0; t < AF; ++t)
+      if (t < ns) fold[(int64_t)t * msz + e] = a.diff_mode ? tot - vf[t] : vf[t];
+  } else if (a.diff_mode) {
+    for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = tot - fold[(int64_t)s * msz + e];
   }
-  finish(tot);
+  if (!a.diff_mode) sum[e] = tot;
 }
 
 void rg_launch_rowstats(hipStream_t st, const AsmArgs& a) {

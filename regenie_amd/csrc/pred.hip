@@ -44,12 +44,11 @@ struct ChunkTab { const int32_t* seg; const int64_t* pos; const int64_t* len; in
 
 // NR = number of ridge values carried in registers (5 for the default grid, 8 max).
 // The packed genotype tile (JT SNP rows x 1024 positions = 256 bytes per row) is staged through LDS
-// with coalesced 16-byte loads so the inner loop never waits on HBM.
+// with coalesced 16-byte loads so the inner loop never waits on HBM; the inner loop per SNP row is
+// decode (2 ops per sample) + NR FMAs per sample with the coefficients as scalar (SGPR) operands.
 template <int NR>
 __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
   __shared__ __attribute__((aligned(16))) uint8_t sP[JT][256 + 16];
-  __shared__ double sB[JT][NR];
-  __shared__ double smu[JT];
   __shared__ double sred[4][RMAX][2];
   const int blk = blockIdx.z, p = blockIdx.y, ch = blockIdx.x;
   const int bs = a.bs[blk];
@@ -57,8 +56,13 @@ __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
   const int64_t p0 = ct.pos[ch], plen = ct.len[ch];
   const int R0 = a.R0;
   const int nm = a.nseg * R0;
-  const uint8_t* pk = a.pk + (int64_t)blk * a.pk_blk_stride;
-  const double* mu = a.mu + (int64_t)blk * a.n128;
+  const uint8_t* __restrict__ pk = a.pk + (int64_t)blk * a.pk_blk_stride;
+  const double* __restrict__ mu = a.mu + (int64_t)blk * a.n128;
+  const bool has_miss = a.nmiss[blk] > 0;
+  const double* __restrict__ bp[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+    bp[r] = a.beta + (((int64_t)blk * nm + s * R0 + (r < R0 ? r : 0)) * a.P + p) * a.n64;
   const int col0 = a.blockid[blk] * R0;
   double tsum[NR], tsq[NR];
 #pragma unroll
@@ -75,14 +79,6 @@ __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
       for (int r = 0; r < NR; ++r) acc[i][r] = 0.0;
     for (int jt = 0; jt < bs; jt += JT) {
       __syncthreads();
-      if (threadIdx.x < JT) {
-        const int j = jt + threadIdx.x;
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-          sB[threadIdx.x][r] = (r < R0 && j < bs)
-              ? a.beta[(((int64_t)blk * nm + s * R0 + r) * a.P + p) * a.n64 + j] : 0.0;
-        smu[threadIdx.x] = (j < bs) ? mu[j] : 0.0;
-      }
       {
         const int c16 = (threadIdx.x & 15) * 16;
 #pragma unroll
@@ -96,20 +92,32 @@ __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
       }
       __syncthreads();
       if (live) {
-        const int jn = min(JT, bs - jt);
-        for (int t = 0; t < jn; ++t) {
-          const unsigned b = sP[t][threadIdx.x];
-          double g[4];
+        // beta_r[j] and mu[j] are the same for every position, i.e. uniform across the wave: they come through the
+        // scalar cache and enter the FMAs as SGPR operands (beta is zero-padded beyond bs, rows beyond bs decode to 0)
+        const int jn = (min(JT, bs - jt) + 3) & ~3;
+#pragma unroll 1
+        for (int t0 = 0; t0 < jn; t0 += 4) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const unsigned code = (b >> (2 * i)) & 3u;
-            g[i] = (code == 0u) ? 2.0 : ((code == 2u) ? 1.0 : ((code == 1u) ? smu[t] : 0.0));
-          }
+          for (int tt = 0; tt < 4; ++tt) {
+            const int t = t0 + tt;
+            const unsigned b = sP[t][threadIdx.x];
+            const unsigned lo = b & 0x55u, hi = (b >> 1) & 0x55u;
+            const unsigned dd = (hi & ~lo) | ((~(hi | lo) & 0x55u) << 1);   // 2-bit dosage fields
+            double g[4];
 #pragma unroll
-          for (int r = 0; r < NR; ++r) {
-            const double bt = sB[t][r];
+            for (int i = 0; i < 4; ++i) g[i] = (double)((dd >> (2 * i)) & 3u);
+            if (has_miss) {
+              const unsigned ms = lo & ~hi;
+              const double m = mu[jt + t];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][r] = fma(g[i], bt, acc[i][r]);
+              for (int i = 0; i < 4; ++i) g[i] = fma((double)((ms >> (2 * i)) & 1u), m, g[i]);
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+              const double bt = bp[r < R0 ? r : 0][jt + t];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[i][r] = fma(g[i], bt, acc[i][r]);
+            }
           }
         }
       }

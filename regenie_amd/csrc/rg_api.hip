@@ -324,7 +324,7 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
   }
   {
     StageTimer t(ctx, &ctx->tm.ms_xy);
-    rg_launch_geno_xy(st, ctx->d_pk, ctx->pk_ld, pk_blk, ctx->d_bs, nblk, n128, ctx->d_V, ctx->Np, Cv,
+    rg_launch_geno_xy(st, ctx->d_pk, ctx->pk_ld, pk_blk, ctx->d_bs, ctx->d_nmiss, nblk, n128, ctx->d_V, ctx->Np, Cv,
                       ctx->d_chunk_pos, ctx->d_chunk_len, ctx->xy_nchunk, ctx->d_xypart);
   }
   {
@@ -383,7 +383,7 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     pa.rtot = rtot; pa.B_total = ctx->B_total; pa.Np = ctx->Np; pa.pk_ld = ctx->pk_ld;
     pa.pk_blk_stride = pk_blk; pa.seg = ctx->seg; pa.pk = ctx->d_pk; pa.mu = ctx->d_mu; pa.sc = ctx->d_sc;
     pa.Bm = ctx->d_Bm; pa.wk = ctx->d_wk; pa.V = ctx->d_V; pa.maskp = ctx->d_maskp;
-    pa.keptp = ctx->d_keptp; pa.bs = ctx->d_bs; pa.blockid = ctx->d_blockid; pa.neff = ctx->d_neff;
+    pa.keptp = ctx->d_keptp; pa.bs = ctx->d_bs; pa.blockid = ctx->d_blockid; pa.neff = ctx->d_neff; pa.nmiss = ctx->d_nmiss;
     pa.beta = ctx->d_beta; pa.cb = ctx->d_cb; pa.psum = ctx->d_psum; pa.W = ctx->d_W;
     rg_launch_l0_pred_impl(st, pa, ctx->d_c1k_seg, ctx->d_c1k_pos, ctx->d_c1k_len, ctx->n_c1k);
   }

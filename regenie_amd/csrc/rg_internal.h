@@ -150,8 +150,8 @@ void rg_launch_bed_prep(hipStream_t st, const uint8_t* raw, int64_t raw_ld, int6
                         int ref_first, int n_active, double* mu, int32_t* nmiss, uint8_t* pk4,
                         int64_t pk4_ld, int64_t pk4_blk_stride);
 void rg_launch_geno_xy(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride,
-                       const int32_t* d_bs, int nblk, int n128, const double* V, int64_t Np, int Cv,
-                       const int64_t* chunk_pos, const int64_t* chunk_len, int nchunk, double* part);
+                       const int32_t* d_bs, const int32_t* nmiss, int nblk, int n128, const double* V, int64_t Np,
+                       int Cv, const int64_t* chunk_pos, const int64_t* chunk_len, int nchunk, double* part);
 // gram_i8.hip
 void rg_launch_gram_blocks(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride,
                            int nblk, int n128, SegLayout seg, const int32_t* nmiss, int32_t* S, int miss_only);
@@ -203,7 +203,7 @@ struct PredArgs {
   SegLayout seg;
   const uint8_t* pk; const double* mu; const double* sc; const double* Bm; const double* wk;
   const double* V; const double* maskp; const uint8_t* keptp; const int32_t* bs;
-  const int32_t* blockid; const double* neff;
+  const int32_t* blockid; const double* neff; const int32_t* nmiss;
   double *beta, *cb, *psum, *W;
 };
 void rg_launch_l0_pred_impl(hipStream_t st, const PredArgs& a, const int32_t* chunk_seg,
