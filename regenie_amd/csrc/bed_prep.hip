@@ -25,8 +25,8 @@ __device__ __forceinline__ unsigned spread8(unsigned y) {
 // The 16-sample window of a dword starts at an arbitrary 2-bit offset of the raw row (folds are re-aligned to 256
 // positions): it is cut out of two ALIGNED raw dwords.  Row totals (missing calls, dosage sum) are reduced inside the
 // workgroup -- integer, hence exact and order independent -- and the SNP mean is written by the same launch.
-__global__ __launch_bounds__(256) void k_bed_prep_rows(const uint8_t* __restrict__ raw, int64_t raw_ld,
-                                                       int64_t raw_blk_stride, uint8_t* __restrict__ pk,
+__global__ __launch_bounds__(256) void k_bed_prep_rows(const uint8_t* const* __restrict__ rawptr, int64_t raw_ld,
+                                                       uint8_t* __restrict__ pk,
                                                        int64_t pk_ld, int64_t pk_blk_stride,
                                                        const int32_t* __restrict__ d_bs,
                                                        const uint8_t* __restrict__ act, SegLayout seg, int64_t Np,
@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void k_bed_prep_rows(const uint8_t* __restrict
   const int n128 = gridDim.x;
   const int bs = d_bs[blk];
   const int64_t nw = Np / 16;
-  const uint32_t* r32 = reinterpret_cast<const uint32_t*>(raw + (int64_t)blk * raw_blk_stride + (int64_t)row * raw_ld);
+  // raw rows may sit in the caller's own device buffer at any byte alignment: the window is cut out of the
+  // aligned dwords around it (a dword that holds at least one valid byte never crosses into an unmapped page)
+  const uint8_t* rowp = rawptr[blk] + (int64_t)row * raw_ld;
   uint32_t* po = reinterpret_cast<uint32_t*>(pk + (int64_t)blk * pk_blk_stride + (int64_t)row * pk_ld);
   uint2* p4 = pk4 ? reinterpret_cast<uint2*>(pk4 + (int64_t)blk * pk4_blk_stride + (int64_t)row * pk4_ld) : nullptr;
   const uint32_t* a32 = reinterpret_cast<const uint32_t*>(act);
@@ -56,10 +58,11 @@ __global__ __launch_bounds__(256) void k_bed_prep_rows(const uint8_t* __restrict
       if (nvalid > 16) nvalid = 16;
       if (nvalid > 0) {
         const int64_t i0 = seg.file_start[s] + off;       // first file sample of this dword
-        const int64_t d0 = i0 >> 4;                       // aligned raw dword holding it
-        const int sh = (int)(i0 & 15) * 2;
-        const unsigned lo32 = r32[d0];
-        const unsigned hi32 = (sh != 0) ? r32[d0 + 1] : 0u;   // stays inside the padded row (raw_ld is 16-byte rounded)
+        const uintptr_t ab = reinterpret_cast<uintptr_t>(rowp) + (uintptr_t)(i0 >> 2);   // byte holding sample i0
+        const uint32_t* ap = reinterpret_cast<const uint32_t*>(ab & ~(uintptr_t)3);
+        const int sh = (int)(ab & 3) * 8 + (int)(i0 & 3) * 2;                            // <= 30
+        const unsigned lo32 = ap[0];
+        const unsigned hi32 = (sh + 2 * (int)nvalid > 32) ? ap[1] : 0u;
         unsigned x = (unsigned)((((unsigned long long)hi32 << 32) | lo32) >> sh);
         if (ref_first) {  // swap 00 <-> 11, keep 01 (missing) and 10 (het)
           const unsigned lo = x & 0x55555555u, hi = (x >> 1) & 0x55555555u;
@@ -106,13 +109,13 @@ __global__ __launch_bounds__(256) void k_bed_prep_rows(const uint8_t* __restrict
   }
 }
 
-void rg_launch_bed_prep(hipStream_t st, const uint8_t* raw, int64_t raw_ld, int64_t raw_blk_stride,
+void rg_launch_bed_prep(hipStream_t st, const uint8_t* const* rawptr, int64_t raw_ld,
                         uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs,
                         int nblk, int n128, const uint8_t* act, SegLayout seg, int64_t Np,
                         int ref_first, int n_active, double* mu, int32_t* nmiss, uint8_t* pk4,
                         int64_t pk4_ld, int64_t pk4_blk_stride) {
   hipMemsetAsync(nmiss, 0, sizeof(int32_t) * nblk, st);
-  hipLaunchKernelGGL(k_bed_prep_rows, dim3(n128, nblk), dim3(256), 0, st, raw, raw_ld, raw_blk_stride, pk, pk_ld,
+  hipLaunchKernelGGL(k_bed_prep_rows, dim3(n128, nblk), dim3(256), 0, st, rawptr, raw_ld, pk, pk_ld,
                      pk_blk_stride, d_bs, act, seg, Np, ref_first, n_active, mu, nmiss, pk4, pk4_ld, pk4_blk_stride);
 }
 

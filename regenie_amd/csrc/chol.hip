@@ -23,6 +23,7 @@
 // takes the 16 CONSECUTIVE k = 16q .. 16q+15 of a 64-chunk (one 128-byte piece of its row): four
 // 32-byte global loads per row, no LDS staging.
 #include <algorithm>
+#include <cstdlib>
 #include "rg_internal.h"
 
 #define CT 64
@@ -189,13 +190,22 @@ __device__ __forceinline__ double form_val(const FormIdx& x, int i, int j, int64
 }
 
 // ---- diagonal tile: blocked (16) potf2 + blocked triangular inverse, all in LDS -------------------
+// value of `x` in lane `l` (compile-time constant), broadcast through SGPRs
+__device__ __forceinline__ double bcast_lane(double x, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+
 // Left-looking inside a column group: before factoring, the tile is updated with the group's earlier tile
 // columns [kc0, kc0 + nkc):  A[k][k] -= sum_q L[k][q] L[k][q]^T  (fp64 MFMA, operands straight from HBM/L2).
 __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_stride, int n64, int k, int kc0,
                                                    int nkc, double* dinv, int32_t* info, FormSrc fs) {
-  __shared__ double s[CT][CT + 1];
-  __shared__ double si[CT][CT + 1];
-  __shared__ double tmp[16][17];
+  // ONE 64 x 66 LDS array holds both results (34 KB -> 4 workgroups per CU, a whole 800-system batch resident):
+  //   lower triangle + diagonal : L            strict upper triangle : Linv^T  (Linv[r][c] at s[c][r], r > c)
+  //   dv[r] = Linv[r][r] = 1 / L[r][r]
+  __shared__ double s[CT][CT + 2];
+  __shared__ double dv[CT];
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   double* D = mats + (int64_t)b * mat_stride + (int64_t)k * CT * n64 + k * CT;
@@ -205,20 +215,19 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_str
       const int r = e >> 6, c = e & 63;
       const int gi = k * CT + r, gj = k * CT + c;
       s[r][c] = (c <= r) ? form_val(fx, gi, gj, (int64_t)gi * n64 + gj) : 0.0;
-      si[r][c] = 0.0;
     }
   } else {
     for (int e = tid; e < CT * CT; e += 256) {
       const int r = e >> 6, c = e & 63;
       s[r][c] = (c <= r) ? D[(int64_t)r * n64 + c] : 0.0;
-      si[r][c] = 0.0;
     }
   }
   __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
   if (nkc > 0) {
-    const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int i = lane & 15, q = lane >> 4;
+    const int i = li, q = lq;
     const double* Mrow = mats + (int64_t)b * mat_stride + (int64_t)k * CT * n64 + (int64_t)kc0 * CT + 16 * q;
     v4d acc[2][2];
 #pragma unroll
@@ -245,97 +254,125 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_str
     }
     __syncthreads();
   }
+  // ---- blocked (16) factorization + inverse, the 16x16x16 block products on the fp64 MFMA ---------------
+  // MFMA 16x16x4: lane (i = lane&15, q = lane>>4) supplies A[i][kk], B[kk][i] and owns D[q + 4r][i], r = 0..3;
+  // a K = 16 block product is 4 instructions with kk(q, s) chosen per product (any permutation of K is fine
+  // as long as A and B use the same one).
+  // element (r, c) of the inverse of a DIAGONAL 16-block at offset o (0 above the diagonal)
+  auto inv_diag = [&](int o, int r, int c) -> double {
+    return (c < r) ? s[o + c][o + r] : ((c == r) ? dv[o + r] : 0.0);
+  };
   bool bad = false;
   for (int sb = 0; sb < 4; ++sb) {
     const int o = sb * 16;
-    // (i) 16x16 diagonal block: lanes 0..15 of wave 0 hold one row each in registers
+    const int nb = 3 - sb;   // 16-row blocks below the diagonal block
+    // (i) diagonal block: lanes 0..15 of wave 0 hold one row each in registers; then its inverse, one column each
     if (tid < 16) {
-      double a[16];
+      // cross-lane values are broadcast with v_readlane (compile-time lane index, no LDS round trip); square root
+      // and reciprocal come from one v_rsq_f64 + two Newton steps (~1 ulp), far shorter than sqrt() followed by a division
+      double a[16], rdv[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = s[o + tid][o + c];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        const double piv = __shfl(a[c], c, 16);
-        double d = sqrt(piv);
-        if (!(piv > 0.0)) { d = 1.0; bad = true; }
-        if (tid > c) a[c] /= d;
+        const double piv = bcast_lane(a[c], c);
+        double d, rd;
+        if (piv > 0.0) {
+          double r0 = __builtin_amdgcn_rsq(piv);
+          r0 = r0 * fma(-0.5 * piv * r0, r0, 1.5);
+          r0 = r0 * fma(-0.5 * piv * r0, r0, 1.5);
+          d = piv * r0;
+          d = fma(0.5 * r0, fma(-d, d, piv), d);     // sqrt(piv)
+          rd = fma(r0, fma(-d, r0, 1.0), r0);        // 1 / sqrt(piv)
+        } else { d = 1.0; rd = 1.0; bad = true; }
+        rdv[c] = rd;
+        if (tid > c) a[c] *= rd;
         else if (tid == c) a[c] = d;
 #pragma unroll
         for (int c2 = c + 1; c2 < 16; ++c2) {
-          const double l = __shfl(a[c], c2, 16);  // L[c2][c]
+          const double l = bcast_lane(a[c], c2);  // L[c2][c]
           if (tid >= c2) a[c2] = fma(-a[c], l, a[c2]);
         }
       }
 #pragma unroll
       for (int c = 0; c < 16; ++c)
         if (c <= tid) s[o + tid][o + c] = a[c];
-    }
-    __syncthreads();
-    // (ii) rows below: X L11^T = A, one thread per row
-    const int nbelow = CT - o - 16;
-    if (tid < nbelow) {
-      const int r = o + 16 + tid;
+      // inverse of the 16x16 triangle: lane = column, forward substitution; L[r][j] comes from lane r's registers
       double x[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        double v = s[r][o + c];
+      for (int r = 0; r < 16; ++r) {
+        double v = (r == tid) ? 1.0 : 0.0;
 #pragma unroll
-        for (int c2 = 0; c2 < c; ++c2) v = fma(-x[c2], s[o + c][o + c2], v);
-        x[c] = v / s[o + c][o + c];
+        for (int j = 0; j < r; ++j) v = fma(-bcast_lane(a[j], r), x[j], v);
+        x[r] = v * rdv[r];
       }
+      dv[o + tid] = x[tid];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) s[r][o + c] = x[c];
+      for (int r = 0; r < 16; ++r)
+        if (r > tid) s[o + tid][o + r] = x[r];   // Linv[r][tid], transposed into the upper triangle
     }
     __syncthreads();
-    // (iii) trailing update inside the tile: A22 -= X X^T (lower part)
-    for (int e = tid; e < nbelow * nbelow; e += 256) {
-      const int r = e / nbelow, c = e % nbelow;
-      if (c > r) continue;
-      double v = 0.0;
+    // (ii) rows below: L21 = A21 * Linv11^T, one 16-row block per wave
+    if (wave < nb) {
+      const int rb = o + 16 + 16 * wave;
+      v4d acc = (v4d){0, 0, 0, 0};
 #pragma unroll
-      for (int m = 0; m < 16; ++m) v = fma(s[o + 16 + r][o + m], s[o + 16 + c][o + m], v);
-      s[o + 16 + r][o + 16 + c] -= v;
+      for (int st = 0; st < 4; ++st)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s[rb + li][o + 4 * lq + st], inv_diag(o, li, 4 * lq + st), acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[rb + lq + 4 * r][o + li] = acc[r];
+    }
+    __syncthreads();
+    // (iii) trailing update inside the tile: A22 -= L21 L21^T (lower blocks; only the lower triangle of the
+    //       diagonal blocks is written -- their upper triangle will hold the inverse), blocks dealt to the waves
+    {
+      const int nblk2 = nb * (nb + 1) / 2;
+      for (int idx = wave; idx < nblk2; idx += 4) {
+        int bi = 0, rem = idx;
+        while (rem > bi) { rem -= bi + 1; ++bi; }
+        const int bj = rem;
+        const int ri = o + 16 + 16 * bi, rj = o + 16 + 16 * bj;
+        v4d acc = (v4d){0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s[ri + li][o + 4 * lq + st], s[rj + li][o + 4 * lq + st], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (bi != bj || li <= lq + 4 * r) s[ri + lq + 4 * r][rj + li] -= acc[r];
+      }
     }
     __syncthreads();
   }
   if (bad) atomicMax(info, 1);
-  // inverse of L by 16-blocks.  diagonal blocks: thread (block q, column c) forward-substitutes.
-  if (tid < 64) {
-    const int q = tid >> 4, c = tid & 15, o = q * 16;
-    double x[16];
+  // off-diagonal blocks of the inverse (i > j), by sub-diagonal distance:
+  //   Linv[i][j] = -Linv[i][i] * sum_{kb=j}^{i-1} L[i][kb] Linv[kb][j]      (Linv[kb][j] at s[16j + .][16kb + .]^T)
+  for (int dist = 1; dist < 4; ++dist) {
+    const int j = wave, ib = wave + dist;
+    if (ib < 4) {
+      v4d m1 = (v4d){0, 0, 0, 0};
+      for (int kb = j; kb < ib; ++kb) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      double v = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-      for (int j = 0; j < r; ++j) v = fma(-s[o + r][o + j], x[j], v);
-      x[r] = v / s[o + r][o + r];
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) si[o + r][o + c] = (r >= c) ? x[r] : 0.0;
-  }
-  __syncthreads();
-  // off-diagonal blocks (i > j), by sub-diagonal distance: Li[i][j] = -Li[i][i] * sum_{k=j}^{i-1} L[i][k] Li[k][j]
-  {
-    const int a = tid >> 4, bb = tid & 15;
-    for (int dist = 1; dist < 4; ++dist)
-      for (int j = 0; j + dist < 4; ++j) {
-        const int i = j + dist;
-        double v = 0.0;
-        for (int kk = j * 16; kk < i * 16; ++kk) v = fma(s[i * 16 + a][kk], si[kk][j * 16 + bb], v);
-        tmp[a][bb] = v;
-        __syncthreads();
-        double w = 0.0;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) w = fma(si[i * 16 + a][i * 16 + m], tmp[m][bb], w);
-        si[i * 16 + a][j * 16 + bb] = -w;
-        __syncthreads();
+        for (int st = 0; st < 4; ++st) {
+          const int kk = 4 * lq + st;
+          const double bval = (kb == j) ? inv_diag(16 * j, kk, li) : s[16 * j + li][16 * kb + kk];
+          m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(s[16 * ib + li][16 * kb + kk], bval, m1, 0, 0, 0);
+        }
       }
+      // second product with kk(q, st) = q + 4 st: the B operand M1[kk][li] is exactly register st of m1
+      v4d acc = (v4d){0, 0, 0, 0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(inv_diag(16 * ib, li, lq + 4 * st), m1[st], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[16 * j + li][16 * ib + lq + 4 * r] = -acc[r];
+    }
+    __syncthreads();
   }
   double* I = dinv + ((int64_t)b * (n64 / CT) + k) * CT * CT;
   for (int e = tid; e < CT * CT; e += 256) {
     const int rr = e >> 6, c = e & 63;
     if (c <= rr) D[(int64_t)rr * n64 + c] = s[rr][c];
-    I[e] = (c <= rr) ? si[rr][c] : 0.0;
+    I[e] = (c < rr) ? s[c][rr] : ((c == rr) ? dv[rr] : 0.0);
   }
 }
 

@@ -28,7 +28,7 @@ void free_all(rg_ctx* c) {
                   c->d_keptp, c->d_posc, c->d_zero, c->d_raw, c->d_pk, c->d_pk4, c->d_mu, c->d_nmiss,
                   c->d_xypart, c->d_chunk_seg, c->d_chunk_pos, c->d_chunk_len, c->d_S, c->d_F, c->d_Bm,
                   c->d_BQ, c->d_GYt, c->d_sc, c->d_fold, c->d_sum, c->d_wk, c->d_dinv, c->d_beta,
-                  c->d_cb, c->d_psum, c->d_info, c->d_bs, c->d_blockid, c->d_c1k_seg, c->d_c1k_pos,
+                  c->d_cb, c->d_psum, c->d_info, c->d_bs, c->d_blockid, (void*)c->d_rawptr, c->d_c1k_seg, c->d_c1k_pos,
                   c->d_c1k_len, c->d_c256_seg, c->d_c256_pos, c->d_c256_len, c->d_gt, c->d_lpart};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -271,6 +271,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if ((rc = dev_alloc(ctx, &ctx->d_psum, (size_t)nb * ctx->n_c1k * P * 8 * 2))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_bs, (size_t)nb))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_blockid, (size_t)nb))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_rawptr, (size_t)nb))) return rc;
   ctx->W_bytes = (int64_t)sizeof(double) * ctx->B_total * R0 * P * Np;
   if (ctx->own_W && ctx->d_W) { hipFree(ctx->d_W); }
   ctx->d_W = nullptr; ctx->own_W = false;
@@ -313,11 +314,22 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
   RG_HIP(hipMemcpyAsync(ctx->d_blockid, block_ids, sizeof(int32_t) * nblk, hipMemcpyHostToDevice, st));
   {
     StageTimer t(ctx, &ctx->tm.ms_prep);
-    for (int b = 0; b < nblk; ++b)
-      RG_HIP(hipMemcpy2DAsync(ctx->d_raw + (int64_t)b * raw_blk, ctx->raw_ld, bed_rows[b], row_stride,
-                              bytes_row, bs[b],
-                              mem_kind == RG_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    rg_launch_bed_prep(st, ctx->d_raw, ctx->raw_ld, raw_blk, ctx->d_pk, ctx->pk_ld, pk_blk, ctx->d_bs,
+    // host rows are staged into d_raw; rows that already live in device memory are read in place
+    std::vector<const uint8_t*>& hp = ctx->h_rawptr;
+    hp.resize(nblk);
+    int64_t ld = row_stride;
+    if (mem_kind == RG_MEM_DEVICE) {
+      for (int b = 0; b < nblk; ++b) hp[b] = bed_rows[b];
+    } else {
+      ld = ctx->raw_ld;
+      for (int b = 0; b < nblk; ++b) {
+        RG_HIP(hipMemcpy2DAsync(ctx->d_raw + (int64_t)b * raw_blk, ctx->raw_ld, bed_rows[b], row_stride, bytes_row,
+                                bs[b], hipMemcpyHostToDevice, st));
+        hp[b] = ctx->d_raw + (int64_t)b * raw_blk;
+      }
+    }
+    RG_HIP(hipMemcpyAsync(ctx->d_rawptr, hp.data(), sizeof(uint8_t*) * nblk, hipMemcpyHostToDevice, st));
+    rg_launch_bed_prep(st, ctx->d_rawptr, ld, ctx->d_pk, ctx->pk_ld, pk_blk, ctx->d_bs,
                        nblk, n128, ctx->d_act, ctx->seg, ctx->Np, ctx->ref_first, ctx->n_active,
                        ctx->d_mu, ctx->d_nmiss, ctx->gram_fp4 ? ctx->d_pk4 : nullptr, ctx->pk4_ld,
                        (int64_t)n128 * ctx->pk4_ld);

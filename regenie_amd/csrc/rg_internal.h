@@ -104,6 +104,8 @@ struct rg_ctx {
   int32_t* d_info = nullptr;     // [4] deferred error flags: [0]=low variance, [1]=not SPD
   int32_t* d_bs = nullptr;       // [nblk]
   int32_t* d_blockid = nullptr;  // [nblk]
+  const uint8_t** d_rawptr = nullptr;  // [nblk] device pointers to the raw .bed rows of each block
+  std::vector<const uint8_t*> h_rawptr;
   std::vector<int> block_done;
 
   // multi-GPU level 1: tile-sharded Gram and system-sharded solves, completed by caller-provided all-reduces
@@ -144,7 +146,7 @@ static inline void* rg_ws(rg_ctx* ctx, int slot, size_t bytes) {
 
 // ---- launchers implemented in the .hip files ------------------------------------------------
 // bed_prep.hip
-void rg_launch_bed_prep(hipStream_t st, const uint8_t* raw, int64_t raw_ld, int64_t raw_blk_stride,
+void rg_launch_bed_prep(hipStream_t st, const uint8_t* const* rawptr, int64_t raw_ld,
                         uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs,
                         int nblk, int n128, const uint8_t* act, SegLayout seg, int64_t Np,
                         int ref_first, int n_active, double* mu, int32_t* nmiss, uint8_t* pk4,
