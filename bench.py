@@ -213,7 +213,7 @@ def main():
         step(exchange=False, solo=True)   # rank-0-only pass: no collective may be issued here (W is already gathered)
         tm = eng.timing()
         eng.enable_timing(False)
-        n_batches = -(-nb // int(os.environ.get("RG_NBLK", "32")))
+        n_batches = max(1, int(tm["n_gram_launches"]))      # one Gram launch per level-0 batch
         bs_eff = float(np.mean(bss))
         flops = {
             "gram_fp4": 2.0 * N * sum(x * x for x in bss),                       # F_gram = 2 N bs^2 per block

@@ -616,7 +616,8 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
                               int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch,
                               const FormSrc* src) {
   const int T = n64 / CT, Tr = rhs_pad / CT, Ttot = T + Tr;
-  const int G = 4;  // tile columns per group: trailing updates contract K = 64*G at once
+  static const int Genv = getenv("RG_CHOL_G") ? atoi(getenv("RG_CHOL_G")) : 4;
+  const int G = Genv;  // tile columns per group: trailing updates contract K = 64*G at once
   FormSrc off{};
   off.enabled = 0; off.extra = nullptr; off.n_div = 1; off.b_offset = 0;
   int64_t nl = 0;

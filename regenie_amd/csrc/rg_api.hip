@@ -229,7 +229,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   // LOOCV: every (block, lambda) system carries the Np sample rows as extra right-hand sides
   ctx->rtot_wk = ctx->loocv ? ctx->rtot + Np : (int64_t)ctx->rtot;
   ctx->nsys = ctx->loocv ? ctx->R0 : K * ctx->R0;
-  int nb = 32;  // blocks per batch: more systems per launch hide the Cholesky dependency chain
+  int nb = 64;  // blocks per batch: more systems per launch hide the Cholesky dependency chain
   if (const char* e = getenv("RG_NBLK")) nb = std::max(1, atoi(e));
   nb = std::min(nb, ctx->B_total);
   if (ctx->loocv) {  // bound the forward-substituted row storage (~24 GB)
@@ -416,8 +416,11 @@ int rg_l0_blocks(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int3
   }
   int rc = ensure_W(ctx);
   if (rc) return rc;
-  for (int b0 = 0; b0 < nblk; b0 += ctx->nblk_cap) {
-    const int nb = std::min(ctx->nblk_cap, nblk - b0);
+  // balanced batches: ceil(nblk / cap) batches of (almost) equal size
+  const int nbatch = (nblk + ctx->nblk_cap - 1) / ctx->nblk_cap;
+  const int per = (nblk + nbatch - 1) / nbatch;
+  for (int b0 = 0; b0 < nblk; b0 += per) {
+    const int nb = std::min(per, nblk - b0);
     // the small H2D descriptor copies of the next batch must not overtake the kernels of this one:
     // everything is ordered on the single ctx stream.
     rc = l0_batch(ctx, nb, block_ids + b0, bs + b0, bed_rows + b0, row_stride, mem_kind);

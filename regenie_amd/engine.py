@@ -228,7 +228,7 @@ class Step1Engine:
         pred = np.zeros((P, nchr, self.N))
         self._check(self.lib.rg_l1_qt(self.h, R1, tau.ctypes.data, nchr, cpc.ctypes.data, cs.ctypes.data,
                                       best.ctypes.data, pred.ctypes.data))
-        return cs, best, [pred[p].T.copy() for p in range(P)]
+        return cs, best, [pred[p].T for p in range(P)]
 
     def l1_qt_loocv(self, tau: np.ndarray, cols_per_chr: Sequence[int]):
         """Leave-one-out level 1 (problem set up with cv_sizes=None).  Same returns as l1_qt."""
@@ -295,9 +295,12 @@ class Step1Engine:
 
 def loco_from_predictions(pred: np.ndarray, chroms: Sequence[int], nchrom: int = 23) -> np.ndarray:
     """write_predictions' LOCO assembly (reference src/Data.cpp:1846-1858): LOCO[:,c] = rowsum - pred[:,c];
-    chromosomes without blocks get the full sum."""
-    tot = pred.sum(axis=1)
-    out = np.repeat(tot[:, None], nchrom, axis=1)
+    chromosomes without blocks get the full sum.  pred: (N, nchr); works on chromosome-major rows so that a
+    transposed view of the library's [nchr][N] output is processed without strided passes."""
+    pt = pred.T                                     # (nchr, N); contiguous when pred is a transposed view
+    tot = pt.sum(axis=0)
+    out = np.empty((nchrom, pred.shape[0]))
+    out[:] = tot
     for ci, c in enumerate(chroms):
-        out[:, c - 1] -= pred[:, ci]
-    return out
+        out[c - 1] -= pt[ci]
+    return out.T

@@ -5,8 +5,11 @@ rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide co
 (MI355X_MICROARCH.md, HBM section), so the corrected read bytes are 2x -- both figures are printed."""
 import csv
 import glob
+import os
 import sys
 from collections import defaultdict
+
+BY_GRID = os.environ.get("PMC_BY_GRID", "0") == "1"
 
 
 def main(d, out=None):
@@ -20,6 +23,8 @@ def main(d, out=None):
             name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
             if not name.startswith("k_"):
                 continue
+            if BY_GRID:   # one row per launch shape: distinguishes e.g. the wide trailing updates from the narrow ones
+                name += "@%d" % (int(r["Grid_Size"]) // max(1, int(r["Workgroup_Size"])))
             a = agg[name][r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
