@@ -239,9 +239,17 @@ def main():
                     "algorithmic_ops_per_launch": flops["gram_fp4"] / max(1, n_batches), "avg_launch_ms": tm["ms_gram"] / max(1, n_batches)}
         else:
             a = kernels[dom]["achieved_TFLOPS"]
-            roof = {"kernel": {"chol_f64": "k_chol_update/panel/diag (fp64 MFMA batched Cholesky, per batch of systems)",
+            traffic = None
+            if dom == "chol_f64":   # HBM bytes per batch from the separate rocprofv3 PMC passes of this same command
+                try:                # (profiles/r1_traffic.json, tools/pmc_traffic.py: FETCH_SIZE x 2 + WRITE_SIZE)
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+                    traffic = tj["hbm_bytes_per_batch"] * (len(my_blocks) / n_batches) / (109 / 2.0)
+                except Exception:   # noqa: BLE001 - the field is optional
+                    traffic = None
+            roof = {"kernel": {"chol_f64": "k_chol_update/panel/diag/backsolve (fp64 MFMA batched Cholesky, per level-0 batch of systems)",
                                "l1_gram_f64": "k_l1_gram (fp64 MFMA fold Gram)"}[dom], "bound": "mfma", "achieved": a,
-                    "peak": PEAK["f64_mfma_TFLOPS"], "unit": "TFLOP/s", "frac": a / PEAK["f64_mfma_TFLOPS"], "traffic": None,
+                    "peak": PEAK["f64_mfma_TFLOPS"], "unit": "TFLOP/s", "frac": a / PEAK["f64_mfma_TFLOPS"], "traffic": traffic,
+                    "traffic_note": "HBM bytes per launch group from separate rocprofv3 --pmc passes (profiles/r1_traffic.json), scaled by blocks per batch",
                     "algorithmic_flops_per_launch": flops[dom] / max(1, n_batches if dom == "chol_f64" else P),
                     "avg_launch_ms": kernels[dom]["ms"] / max(1, n_batches if dom == "chol_f64" else P)}
 
