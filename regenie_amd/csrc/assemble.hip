@@ -11,6 +11,7 @@
 //   s_j^2     = sum_f R_f[j][j] / (n_analyzed - C)                 (Data.cpp:203)
 //   A_f       = D_s^-1 R_f D_s^-1 ,   b_f = D_s^-1 (G~_f Y_f - B X_f^T Y_f)
 // which is the same arithmetic re-associated; it agrees with the reference order to ~1e-15.
+#include <type_traits>
 #include "rg_internal.h"
 
 // thread = one SNP row of one block
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(64) void k_rowstats(AsmArgs a) {
 // The per-fold values of one element live in registers (up to AF folds) so that in diff_mode the training-fold
 // matrices (total - fold f) are written in a single pass; more folds fall back to a second pass through memory.
 #define AF 8
-__global__ __launch_bounds__(256) void k_assemble(AsmArgs a) {
+__global__ __launch_bounds__(256) void k_assemble_generic(AsmArgs a) {
   const int blk = blockIdx.z;
   const int k = blockIdx.x * 32 + threadIdx.x;
   const int i = blockIdx.y * 8 + threadIdx.y;
@@ -174,10 +175,171 @@ __global__ __launch_bounds__(256) void k_assemble(AsmArgs a) {
   if (!a.diff_mode) sum[e] = tot;
 }
 
+// ---- tiled assemble (the default: up to AF folds) --------------------------------------------------------------
+// grid (n64/32, ceil(rtot/32), nblk), block (32, 8): a 32 x 32 tile per workgroup, thread (tx, ty) owns column
+// k = k0 + tx of rows i0 + ty + {0, 8, 16, 24}.  The small per-row / per-column covariate terms
+//   E_s[i] = B Q_s [i] - F_s[i],   F_s[k],   B[i],   B[k]            (C numbers each)
+// are staged once per tile in LDS (chunks of ACC covariates); correction_s(i,k) = sum_c E_s[i][c] B[k][c] - B[i][c] F_s[k][c].
+// Every global load is UNCONDITIONAL with a clamped address and the value is selected afterwards: hipcc turns a load
+// under a data-dependent `if` into branch + load + s_waitcnt vmcnt(0), i.e. one full memory round trip per load,
+// whereas unconditional loads of an unrolled loop are all in flight together.
+#define ACC 8
+__global__ __launch_bounds__(256) void k_assemble_tiled(AsmArgs a) {
+  __shared__ double sE[AF][32][ACC + 1];
+  __shared__ double sF[AF][32][ACC + 1];
+  __shared__ double sBi[32][ACC + 1];
+  __shared__ double sBk[32][ACC + 1];
+  const int blk = blockIdx.z;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 32 + tx;
+  const int k0 = blockIdx.x * 32, i0 = blockIdx.y * 32;
+  const int bs = a.bs[blk];
+  const int C = a.C, P = a.P, ns = a.nseg, n128 = a.n128, n64 = a.n64;
+  const int64_t msz = (int64_t)a.rtot * n64;
+  double* __restrict__ fold = a.fold + (int64_t)blk * ns * msz;
+  double* __restrict__ sum = a.sum + (int64_t)blk * msz;
+  const double* __restrict__ sc = a.sc + (int64_t)blk * n128;
+  const int k = k0 + tx;                       // < n64 (grid.x = n64 / 32)
+  const int kc = min(k, n128 - 1);
+  if (i0 >= n64) {  // RHS rows: b_f^T
+    const double isck = 1.0 / sc[kc];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int i = i0 + ty + 8 * rr;
+      const int p = i - n64;
+      const bool live = (i < a.rtot) && (p < P) && (k < bs);
+      const int pc = live ? p : 0;
+      double vf[AF], tot = 0.0;
+#pragma unroll
+      for (int s = 0; s < AF; ++s) {
+        const int ss = min(s, ns - 1);
+        const double g = a.GYt[(((int64_t)blk * ns + ss) * n128 + kc) * P + pc];
+        vf[s] = (live && s < ns) ? g * isck : 0.0;
+        tot += vf[s];
+      }
+      if (i < a.rtot) {
+        const int64_t e = (int64_t)i * n64 + k;
+#pragma unroll
+        for (int s = 0; s < AF; ++s)
+          if (s < ns) fold[(int64_t)s * msz + e] = a.diff_mode ? tot - vf[s] : vf[s];
+        if (!a.diff_mode) sum[e] = tot;
+      }
+    }
+    return;
+  }
+  if (k0 > i0 + 31) {  // tile strictly above the diagonal: only the part inside a diagonal 64-tile is kept finite
+    if ((k0 >> 6) == (i0 >> 6)) {
+      for (int rr = 0; rr < 4; ++rr) {
+        const int64_t e = (int64_t)(i0 + ty + 8 * rr) * n64 + k;
+        for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = 0.0;
+        if (!a.diff_mode) sum[e] = 0.0;
+      }
+    }
+    return;
+  }
+  const bool has_miss = a.nmiss[blk] > 0;      // uniform per block
+  const int64_t ldS = 2 * (int64_t)n128;
+  // integer Gram values of this thread's 4 elements, all folds: independent unconditional loads
+  double at[4][AF];
+  const double muk = a.mu[(int64_t)blk * n128 + kc];
+  // the missing-call terms are a per-block (uniform) property: the branch is taken ONCE, around the whole unrolled
+  // loop, so that each variant is straight-line code with all its loads in flight together
+  auto gram_vals = [&](auto hm) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int i = i0 + ty + 8 * rr;            // < n64 <= n128
+      const bool live = (k <= i) && (i < bs);
+      const int il = live ? i : 0, kl = live ? k : 0;
+      const double mui = a.mu[(int64_t)blk * n128 + i];
+#pragma unroll
+      for (int s = 0; s < AF; ++s) {
+        const int ss = min(s, ns - 1);
+        const int32_t* __restrict__ S = a.S + ((int64_t)blk * ns + ss) * ldS * ldS;
+        double v = (double)S[(int64_t)il * ldS + kl];
+        if (decltype(hm)::value) {
+          v += mui * (double)S[(int64_t)(n128 + il) * ldS + kl];
+          v += muk * (double)S[(int64_t)(n128 + kl) * ldS + il];
+          v += mui * muk * (double)S[(int64_t)(n128 + il) * ldS + n128 + kl];
+        }
+        // multiply by a 0/1 mask instead of selecting: a select lets the optimizer sink the load back under the
+        // condition (and serialise it); v is an exact integer-valued double, so v * 0.0 is exactly 0
+        at[rr][s] = v * ((live && s < ns) ? 1.0 : 0.0);
+      }
+    }
+  };
+  if (has_miss) gram_vals(std::true_type{});
+  else gram_vals(std::false_type{});
+  double corr[4][AF];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+    for (int s = 0; s < AF; ++s) corr[rr][s] = 0.0;
+  for (int c0 = 0; c0 < C; c0 += ACC) {
+    const int cn = min(ACC, C - c0);
+    __syncthreads();
+    // stage (32 rows x ACC) B[i], B[k] and (ns x 32 x ACC) E_s[i], F_s[k]; rows of this tile are all < n128
+    for (int t = tid; t < 32 * ACC; t += 256) {
+      const int r = t / ACC, c = t % ACC;
+      const int cc = c0 + min(c, cn - 1);
+      const double bi = a.Bm[((int64_t)blk * n128 + i0 + r) * C + cc];
+      const double bk = a.Bm[((int64_t)blk * n128 + k0 + r) * C + cc];
+      sBi[r][c] = (c < cn) ? bi : 0.0;
+      sBk[r][c] = (c < cn) ? bk : 0.0;
+    }
+    for (int t = tid; t < ns * 32 * ACC; t += 256) {
+      const int s = t / (32 * ACC), r = (t / ACC) % 32, c = t % ACC;
+      const int cc = c0 + min(c, cn - 1);
+      const int64_t oi = (((int64_t)blk * ns + s) * n128 + i0 + r) * C + cc;
+      const int64_t ok = (((int64_t)blk * ns + s) * n128 + k0 + r) * C + cc;
+      const double e = a.BQ[oi] - a.F[oi], f = a.F[ok];
+      sE[s][r][c] = (c < cn) ? e : 0.0;
+      sF[s][r][c] = (c < cn) ? f : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < ACC; ++c) {
+      const double bk = sBk[tx][c];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const double bi = sBi[ty + 8 * rr][c];
+#pragma unroll
+        for (int s = 0; s < AF; ++s)
+          if (s < ns) corr[rr][s] = fma(sE[s][ty + 8 * rr][c], bk, fma(-bi, sF[s][tx][c], corr[rr][s]));
+      }
+    }
+  }
+  const double sck = sc[kc];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int i = i0 + ty + 8 * rr;
+    const int64_t e = (int64_t)i * n64 + k;
+    const double inv = 1.0 / (sc[i] * sck);
+    if (k > i) {  // upper triangle inside a diagonal tile
+      if ((k >> 6) == (i >> 6)) {
+        for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = 0.0;
+        if (!a.diff_mode) sum[e] = 0.0;
+      }
+      continue;
+    }
+    // rows >= bs (padding): at and the covariate terms are zero -> zeros are written
+    double vf[AF], tot = 0.0;
+#pragma unroll
+    for (int s = 0; s < AF; ++s) {
+      vf[s] = (s < ns && i < bs) ? (at[rr][s] + corr[rr][s]) * inv : 0.0;
+      tot += vf[s];
+    }
+#pragma unroll
+    for (int s = 0; s < AF; ++s)
+      if (s < ns) fold[(int64_t)s * msz + e] = a.diff_mode ? tot - vf[s] : vf[s];
+    if (!a.diff_mode) sum[e] = tot;
+  }
+}
+
 void rg_launch_rowstats(hipStream_t st, const AsmArgs& a) {
   hipLaunchKernelGGL(k_rowstats, dim3((a.n128 + 63) / 64, a.nblk), dim3(64), 0, st, a);
 }
 void rg_launch_assemble(hipStream_t st, const AsmArgs& a) {
-  hipLaunchKernelGGL(k_assemble, dim3((a.n64 + 31) / 32, (a.rtot + 7) / 8, a.nblk), dim3(32, 8), 0,
-                     st, a);
+  if (a.nseg <= AF)
+    hipLaunchKernelGGL(k_assemble_tiled, dim3((a.n64 + 31) / 32, (a.rtot + 31) / 32, a.nblk), dim3(32, 8), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_assemble_generic, dim3((a.n64 + 31) / 32, (a.rtot + 7) / 8, a.nblk), dim3(32, 8), 0, st, a);
 }

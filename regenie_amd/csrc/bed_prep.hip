@@ -40,55 +40,72 @@ __global__ __launch_bounds__(256) void k_bed_prep_rows(const uint8_t* const* __r
   const int64_t nw = Np / 16;
   // raw rows may sit in the caller's own device buffer at any byte alignment: the window is cut out of the
   // aligned dwords around it (a dword that holds at least one valid byte never crosses into an unmapped page)
-  const uint8_t* rowp = rawptr[blk] + (int64_t)row * raw_ld;
+  const uint8_t* rowp = rawptr[blk] + (int64_t)min(row, bs - 1) * raw_ld;   // padding rows (>= bs) read nothing new
   uint32_t* po = reinterpret_cast<uint32_t*>(pk + (int64_t)blk * pk_blk_stride + (int64_t)row * pk_ld);
   uint2* p4 = pk4 ? reinterpret_cast<uint2*>(pk4 + (int64_t)blk * pk4_blk_stride + (int64_t)row * pk4_ld) : nullptr;
   const uint32_t* a32 = reinterpret_cast<const uint32_t*>(act);
   int nmiss = 0, gsum = 0;
-  // fold segment walk: w advances by 256 per iteration, segments are >= 256 positions = 16 dwords
-  for (int64_t w = threadIdx.x; w < nw; w += 256) {
-    unsigned out = 0xFFFFFFFFu;
-    if (row < bs) {
-      const int64_t pos = w * 16;
-      int s = 0;
+  // 4 output dwords per thread and iteration: all raw / activity loads of an iteration are issued (unconditionally,
+  // at clamped addresses) before any of them is consumed, so four memory round trips overlap instead of queueing
+  const bool row_live = row < bs;
+  for (int64_t w0 = threadIdx.x; w0 < nw; w0 += 1024) {
+    unsigned lo32[4], hi32[4], av[4];
+    int shv[4], nv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t w = w0 + 256 * u;
+      const int64_t wc = w < nw ? w : 0;
+      const int64_t pos = wc * 16;
+      int sgm = 0;
       for (int t = 1; t < seg.nseg; ++t)
-        if (pos >= seg.pos_start[t]) s = t;
-      const int64_t off = pos - seg.pos_start[s];
-      int64_t nvalid = seg.len[s] - off;
+        if (pos >= seg.pos_start[t]) sgm = t;
+      const int64_t off = pos - seg.pos_start[sgm];
+      int64_t nvalid = seg.len[sgm] - off;
       if (nvalid > 16) nvalid = 16;
-      if (nvalid > 0) {
-        const int64_t i0 = seg.file_start[s] + off;       // first file sample of this dword
-        const uintptr_t ab = reinterpret_cast<uintptr_t>(rowp) + (uintptr_t)(i0 >> 2);   // byte holding sample i0
-        const uint32_t* ap = reinterpret_cast<const uint32_t*>(ab & ~(uintptr_t)3);
-        const int sh = (int)(ab & 3) * 8 + (int)(i0 & 3) * 2;                            // <= 30
-        const unsigned lo32 = ap[0];
-        const unsigned hi32 = (sh + 2 * (int)nvalid > 32) ? ap[1] : 0u;
-        unsigned x = (unsigned)((((unsigned long long)hi32 << 32) | lo32) >> sh);
+      if (nvalid < 0 || w >= nw || !row_live) nvalid = 0;
+      const int64_t i0 = nvalid > 0 ? seg.file_start[sgm] + off : 0;   // first file sample of this dword
+      const uintptr_t ab = reinterpret_cast<uintptr_t>(rowp) + (uintptr_t)(i0 >> 2);   // byte holding sample i0
+      const uint32_t* ap = reinterpret_cast<const uint32_t*>(ab & ~(uintptr_t)3);
+      const int sh = (int)(ab & 3) * 8 + (int)(i0 & 3) * 2;                            // <= 30
+      // the second dword is fetched only when the window needs it (it may lie beyond the row otherwise)
+      const bool need2 = sh + 2 * (int)nvalid > 32;
+      lo32[u] = ap[0];
+      hi32[u] = ap[need2 ? 1 : 0];
+      av[u] = a32[wc];                                     // 11 per analysed sample
+      shv[u] = sh;
+      nv[u] = (int)nvalid;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t w = w0 + 256 * u;
+      if (w >= nw) continue;
+      unsigned out = 0xFFFFFFFFu;
+      if (nv[u] > 0) {
+        unsigned x = (unsigned)((((unsigned long long)hi32[u] << 32) | lo32[u]) >> shv[u]);
         if (ref_first) {  // swap 00 <-> 11, keep 01 (missing) and 10 (het)
           const unsigned lo = x & 0x55555555u, hi = (x >> 1) & 0x55555555u;
           const unsigned eq = ~(lo ^ hi) & 0x55555555u;
           x ^= eq | (eq << 1);
         }
-        const unsigned a = a32[w];                        // 11 per analysed sample
-        const unsigned vm = (nvalid >= 16) ? 0xFFFFFFFFu : ((1u << (2 * nvalid)) - 1u);
-        const unsigned keep = a & vm;
+        const unsigned vm = (nv[u] >= 16) ? 0xFFFFFFFFu : ((1u << (2 * nv[u])) - 1u);
+        const unsigned keep = av[u] & vm;
         out = (x & keep) | ~keep;
         const unsigned lo = out & 0x55555555u, hi = (out >> 1) & 0x55555555u;
         const unsigned nlo = ~lo & 0x55555555u;
         nmiss += __popc(lo & ~hi & 0x55555555u);
         gsum += 2 * __popc(nlo & ~hi) + __popc(nlo & hi);
       }
-    }
-    po[w] = out;
-    if (p4) {
-      // FP4 E2M1 plane for the matrix cores (gram_fp4.hip): dosage 2 (code 00) -> 0100, 1 (code 10) -> 0010,
-      // 0 / missing -> 0000; sample i of this dword -> nibble i of the 8 output bytes
-      const unsigned lo = out & 0x55555555u, hi = (out >> 1) & 0x55555555u;
-      const unsigned two = ~lo & ~hi & 0x55555555u, one = ~lo & hi;
-      uint2 o;
-      o.x = (spread8(two) << 2) | (spread8(one) << 1);
-      o.y = (spread8(two >> 16) << 2) | (spread8(one >> 16) << 1);
-      p4[w] = o;
+      po[w] = out;
+      if (p4) {
+        // FP4 E2M1 plane for the matrix cores (gram_fp4.hip): dosage 2 (code 00) -> 0100, 1 (code 10) -> 0010,
+        // 0 / missing -> 0000; sample i of this dword -> nibble i of the 8 output bytes
+        const unsigned lo = out & 0x55555555u, hi = (out >> 1) & 0x55555555u;
+        const unsigned two = ~lo & ~hi & 0x55555555u, one = ~lo & hi;
+        uint2 o;
+        o.x = (spread8(two) << 2) | (spread8(one) << 1);
+        o.y = (spread8(two >> 16) << 2) | (spread8(one >> 16) << 1);
+        p4[w] = o;
+      }
     }
   }
   for (int o = 32; o > 0; o >>= 1) {
@@ -160,9 +177,11 @@ __global__ __launch_bounds__(256) void k_geno_xy(const uint8_t* __restrict__ pk,
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int r = it * 64 + (threadIdx.x >> 2), piece = (threadIdx.x & 3) * 16;
-        uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (row0 + r < bs && piece * 4 < npos)
-          v = *reinterpret_cast<const uint4*>(base + (int64_t)(row0 + r) * pk_ld + q / 4 + piece);
+        // unconditional load at a clamped address + select (a load under `if` costs a full round trip each)
+        const bool ok = (row0 + r < bs) && (piece * 4 < npos);
+        uint4 v = *reinterpret_cast<const uint4*>(base + (int64_t)min(row0 + r, bs - 1) * pk_ld + q / 4 +
+                                                  (piece * 4 < npos ? piece : 0));
+        if (!ok) v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         *reinterpret_cast<uint4*>(sP + r * XP + piece) = v;
       }
       __syncthreads();

@@ -24,6 +24,7 @@
 // 32-byte global loads per row, no LDS staging.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "rg_internal.h"
 
 #define CT 64
@@ -180,14 +181,25 @@ __device__ __forceinline__ FormIdx form_idx(const FormSrc& f, int b_local) {
   x.n = f.d_n ? f.d_n[o / f.n_div] : f.n_fixed;
   return x;
 }
-// e = i * n64 + j
+// e = i * n64 + j.  MODE is resolved OUTSIDE the unrolled element loops: hipcc turns every load under an `if` into
+// branch + load + s_waitcnt vmcnt(0) -- one full memory round trip per element -- whereas straight-line loads of an
+// unrolled loop are all in flight together.  MODE 0: S only (one source matrix); 1: S - F; 2: general (extra rows).
+template <int MODE>
 __device__ __forceinline__ double form_val(const FormIdx& x, int i, int j, int64_t e) {
-  if (i >= x.x0) return x.X[e - x.xoff];   // (i - extra_row0) * n64 + j
-  double v = x.S[e];
-  if (x.F) v -= x.F[e];
+  double v;
+  if (MODE == 2) {
+    if (i >= x.x0) return x.X[e - x.xoff];   // (i - extra_row0) * n64 + j
+    v = x.S[e];
+    if (x.F) v -= x.F[e];
+  } else if (MODE == 1) {
+    v = x.S[e] - x.F[e];
+  } else {
+    v = x.S[e];
+  }
   if (i == j) v = (i < x.n) ? v + x.sh : 1.0;
   return v;
 }
+__device__ __forceinline__ int form_mode(const FormIdx& x) { return x.X ? 2 : (x.F ? 1 : 0); }
 
 // ---- diagonal tile: blocked (16) potf2 + blocked triangular inverse, all in LDS -------------------
 // value of `x` in lane `l` (compile-time constant), broadcast through SGPRs
@@ -211,15 +223,23 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_str
   double* D = mats + (int64_t)b * mat_stride + (int64_t)k * CT * n64 + k * CT;
   if (fs.enabled) {
     const FormIdx fx = form_idx(fs, b);
-    for (int e = tid; e < CT * CT; e += 256) {
+    const int md = form_mode(fx);
+#pragma unroll
+    for (int u = 0; u < CT * CT / 256; ++u) {   // unconditional loads (the upper triangle of the source exists), then select
+      const int e = tid + 256 * u;
       const int r = e >> 6, c = e & 63;
       const int gi = k * CT + r, gj = k * CT + c;
-      s[r][c] = (c <= r) ? form_val(fx, gi, gj, (int64_t)gi * n64 + gj) : 0.0;
+      const int64_t ge = (int64_t)gi * n64 + gj;
+      const double v = md == 0 ? form_val<0>(fx, gi, gj, ge) : (md == 1 ? form_val<1>(fx, gi, gj, ge) : form_val<2>(fx, gi, gj, ge));
+      s[r][c] = (c <= r) ? v : 0.0;
     }
   } else {
-    for (int e = tid; e < CT * CT; e += 256) {
+#pragma unroll
+    for (int u = 0; u < CT * CT / 256; ++u) {
+      const int e = tid + 256 * u;
       const int r = e >> 6, c = e & 63;
-      s[r][c] = (c <= r) ? D[(int64_t)r * n64 + c] : 0.0;
+      const double v = D[(int64_t)r * n64 + c];
+      s[r][c] = (c <= r) ? v : 0.0;
     }
   }
   __syncthreads();
@@ -397,15 +417,21 @@ __global__ __launch_bounds__(256) void k_chol_panel(double* mats, int64_t mat_st
   // acc = -(tile value) at (row = wr*32 + m*16 + q + 4r, col = wc*32 + n*16 + i)
   if (fs.enabled) {
     const FormIdx fx = form_idx(fs, b);
+    auto init = [&](auto mode) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int gi = t * CT + wr * 32 + m * 16 + q + 4 * r, gj = k * CT + wc * 32 + n * 16 + i;
-          acc[m][n][r] = -form_val(fx, gi, gj, (int64_t)gi * n64 + gj);
-        }
+          for (int r = 0; r < 4; ++r) {
+            const int gi = t * CT + wr * 32 + m * 16 + q + 4 * r, gj = k * CT + wc * 32 + n * 16 + i;
+            acc[m][n][r] = -form_val<decltype(mode)::value>(fx, gi, gj, (int64_t)gi * n64 + gj);
+          }
+    };
+    const int md = form_mode(fx);
+    if (md == 0) init(std::integral_constant<int, 0>{});
+    else if (md == 1) init(std::integral_constant<int, 1>{});
+    else init(std::integral_constant<int, 2>{});
   } else {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -482,21 +508,27 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(double* mats, int64_t ma
   const int tr = tc + idx;
   const int i = lane & 15, q = lane >> 4;
   double* M = mats + (int64_t)b * mat_stride;
-  const double* A = M + ((int64_t)tr * CT + i) * n64 + kc0 * CT + 4 * q;
-  const double* B = M + ((int64_t)tc * CT + i) * n64 + kc0 * CT + 4 * q;
+  const double* A = M + ((int64_t)tr * CT + i) * n64 + kc0 * CT + 2 * q;
+  const double* B = M + ((int64_t)tc * CT + i) * n64 + kc0 * CT + 2 * q;
   double* C = M + (int64_t)tr * CT * n64 + tc * CT;
   v4d acc[4][4];
   if (fs.enabled) {
     const FormIdx fx = form_idx(fs, b);
+    auto init = [&](auto mode) {
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int gi = tr * CT + m * 16 + q + 4 * r, gj = tc * CT + n * 16 + i;
-          acc[m][n][r] = -form_val(fx, gi, gj, (int64_t)gi * n64 + gj);
-        }
+          for (int r = 0; r < 4; ++r) {
+            const int gi = tr * CT + m * 16 + q + 4 * r, gj = tc * CT + n * 16 + i;
+            acc[m][n][r] = -form_val<decltype(mode)::value>(fx, gi, gj, (int64_t)gi * n64 + gj);
+          }
+    };
+    const int md = form_mode(fx);
+    if (md == 0) init(std::integral_constant<int, 0>{});
+    else if (md == 1) init(std::integral_constant<int, 1>{});
+    else init(std::integral_constant<int, 2>{});
   } else {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -506,16 +538,19 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(double* mats, int64_t ma
         for (int r = 0; r < 4; ++r)
           acc[m][n][r] = -C[(int64_t)(m * 16 + q + 4 * r) * n64 + n * 16 + i];
   }
-  // K loop in 16-deep chunks: 8 x 32-byte loads then 64 MFMAs (~4K cycles) per chunk.
-  const int nk16 = nkc * 4;
-  auto load16 = [&](double4 (&av)[4], double4 (&bv)[4], int kc) {
+  // K loop in 8-deep chunks, software pipelined over two register sets: the 8 x 16-byte loads of chunk c+1 are in
+  // flight while the 32 MFMAs (~2K cycles) of chunk c issue, so a wave no longer stalls for the full load latency in
+  // front of every MFMA burst (with only two waves per SIMD that stall was ~1/3 of the time).  Lane (i, q) supplies
+  // k = 2q + s of a chunk to MFMA step s.
+  const int nk8 = nkc * 8;
+  auto load8 = [&](double2 (&av)[4], double2 (&bv)[4], int kc) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      av[m] = *reinterpret_cast<const double4*>(A + (int64_t)m * 16 * n64 + kc * 16);
-      bv[m] = *reinterpret_cast<const double4*>(B + (int64_t)m * 16 * n64 + kc * 16);
+      av[m] = *reinterpret_cast<const double2*>(A + (int64_t)m * 16 * n64 + kc * 8);
+      bv[m] = *reinterpret_cast<const double2*>(B + (int64_t)m * 16 * n64 + kc * 8);
     }
   };
-  auto mma16 = [&](const double4 (&av)[4], const double4 (&bv)[4]) {
+  auto mma8 = [&](const double2 (&av)[4], const double2 (&bv)[4]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -524,21 +559,16 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(double* mats, int64_t ma
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].y, bv[n].y, acc[m][n], 0, 0, 0);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].z, bv[n].z, acc[m][n], 0, 0, 0);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].w, bv[n].w, acc[m][n], 0, 0, 0);
   };
-  // Measured: two waves per SIMD with plain per-chunk loads (45.3 ms/step) beat one wave per SIMD with the
-  // next chunk prefetched into a second register set (48.4 ms/step), so the simple form is kept.
-  for (int kc = 0; kc < nk16; ++kc) {
-    double4 a0[4], b0[4];
-    load16(a0, b0, kc);
-    mma16(a0, b0);
+  {
+    double2 a0[4], b0[4], a1[4], b1[4];
+    load8(a0, b0, 0);
+    for (int kc = 0; kc < nk8; kc += 2) {   // nk8 is a multiple of 8
+      load8(a1, b1, kc + 1);
+      mma8(a0, b0);
+      if (kc + 2 < nk8) load8(a0, b0, kc + 2);
+      mma8(a1, b1);
+    }
   }
 #pragma unroll
   for (int m = 0; m < 4; ++m)

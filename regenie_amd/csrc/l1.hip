@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void k_l1_gram64(L1G64 g, SegLayout seg) {
   const int i = lane & 15, q = lane >> 4;
   const int64_t nch = seg.plen[f] / 64;
   const int64_t c0 = nch * sl / g.nslice, c1 = nch * (sl + 1) / g.nslice;
-  const int64_t p0 = seg.pos_start[f] + 4 * q;
+  const int64_t p0 = seg.pos_start[f] + 2 * q;
   const double* A[4];
   const double* B[4];
 #pragma unroll
@@ -65,13 +65,16 @@ __global__ __launch_bounds__(256, 2) void k_l1_gram64(L1G64 g, SegLayout seg) {
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
-  for (int64_t kc = c0 * 4; kc < c1 * 4; ++kc) {
-    double4 av[4], bv[4];
+  // 8-deep K chunks, two register sets: the loads of chunk c+1 fly while the 32 MFMAs of chunk c issue (see
+  // k_chol_update).  Lane (i, q) supplies k = 2q + s of a chunk to MFMA step s.
+  auto load8 = [&](double2 (&av)[4], double2 (&bv)[4], int64_t kc) {
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
-      av[m] = *reinterpret_cast<const double4*>(A[m] + kc * 16);
-      bv[m] = *reinterpret_cast<const double4*>(B[m] + kc * 16);
+      av[m] = *reinterpret_cast<const double2*>(A[m] + kc * 8);
+      bv[m] = *reinterpret_cast<const double2*>(B[m] + kc * 8);
     }
+  };
+  auto mma8 = [&](const double2 (&av)[4], const double2 (&bv)[4]) {
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -80,14 +83,19 @@ __global__ __launch_bounds__(256, 2) void k_l1_gram64(L1G64 g, SegLayout seg) {
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].y, bv[n].y, acc[m][n], 0, 0, 0);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].z, bv[n].z, acc[m][n], 0, 0, 0);
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].w, bv[n].w, acc[m][n], 0, 0, 0);
+  };
+  {
+    const int64_t k0 = c0 * 8, k1 = c1 * 8;   // 64-chunks -> 8-chunks; (k1 - k0) is a multiple of 8
+    if (k1 > k0) {
+      double2 a0[4], b0[4], a1[4], b1[4];
+      load8(a0, b0, k0);
+      for (int64_t kc = k0; kc < k1; kc += 2) {
+        load8(a1, b1, kc + 1);
+        mma8(a0, b0);
+        if (kc + 2 < k1) load8(a0, b0, kc + 2);
+        mma8(a1, b1);
+      }
+    }
   }
   double* O = g.out + (int64_t)sl * g.slice_stride + (int64_t)f * g.rtot * g.R.n64 + (int64_t)tr * CT * g.R.n64 + tc * CT;
 #pragma unroll

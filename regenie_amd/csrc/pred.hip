@@ -84,9 +84,11 @@ __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
 #pragma unroll
         for (int it = 0; it < JT / 16; ++it) {
           const int row = it * 16 + (threadIdx.x >> 4);
-          uint4 v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-          if (jt + row < bs && c16 < nbytes)
-            v = *reinterpret_cast<const uint4*>(pk + (int64_t)(jt + row) * a.pk_ld + (p0 + sub) / 4 + c16);
+          // unconditional load at a clamped address + select (a load under `if` costs a full round trip each)
+          const bool ok = (jt + row < bs) && (c16 < nbytes);
+          uint4 v = *reinterpret_cast<const uint4*>(pk + (int64_t)min(jt + row, bs - 1) * a.pk_ld + (p0 + sub) / 4 +
+                                                    (c16 < nbytes ? c16 : 0));
+          if (!ok) v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
           *reinterpret_cast<uint4*>(&sP[row][c16]) = v;
         }
       }
@@ -123,23 +125,43 @@ __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
       }
     }
     if (live) {
-      // covariate term and mask
+      // covariate term: sum_c cb_r[c] X_c(pos).  The X values are loaded once per covariate chunk (unconditional,
+      // clamped) and reused by every ridge value; cb_r[c] is wave-uniform (scalar loads)
+      double corr[NR][4];
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) corr[r][i] = 0.0;
+      for (int c0 = 0; c0 < a.C; c0 += 4) {
+        double xv[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double* x = a.V + (int64_t)min(c0 + u, a.C - 1) * a.Np + pos;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) xv[u][i] = x[i];
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          const double* cb = a.cb + (((int64_t)blk * nm + s * R0 + (r < R0 ? r : 0)) * a.P + p) * a.C;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const double cc = cb[min(c0 + u, a.C - 1)] * ((c0 + u < a.C) ? 1.0 : 0.0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) corr[r][i] = fma(cc, xv[u][i], corr[r][i]);
+          }
+        }
+      }
+      const double* mk = a.maskp + (int64_t)p * a.Np + pos;
+      double mkv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) mkv[i] = mk[i];
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         if (r >= R0) break;
-        const double* cb = a.cb + (((int64_t)blk * nm + s * R0 + r) * a.P + p) * a.C;
-        double corr[4] = {0, 0, 0, 0};
-        for (int c = 0; c < a.C; ++c) {
-          const double cc = cb[c];
-          const double* x = a.V + (int64_t)c * a.Np + pos;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) corr[i] = fma(cc, x[i], corr[i]);
-        }
         double* w = a.W + ((int64_t)(col0 + r) * a.P + p) * a.Np + pos;
-        const double* mk = a.maskp + (int64_t)p * a.Np + pos;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const double v = (acc[i][r] - corr[i]) * mk[i];
+          const double v = (acc[i][r] - corr[r][i]) * mkv[i];
           w[i] = v;
           tsum[r] += v;
           tsq[r] = fma(v, v, tsq[r]);
