@@ -397,97 +397,119 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_str
 }
 
 // ---- panel: L[t][k] = (A[t][k] - sum_q L[t][q] L[k][q]^T) * Linv^T, q over the group's earlier tile columns ----
-// (left-looking inside the column group: the tile is read once and written once).  The updated tile goes
-// through LDS so that every wave sees all 64 columns of its rows for the triangular multiply.
-#define PU_PITCH 66
-__global__ __launch_bounds__(256) void k_chol_panel(double* mats, int64_t mat_stride, int n64, int k, int kc0,
-                                                    int nkc, const double* dinv, int ngrp, int batch, int R,
-                                                    FormSrc fs) {
-  __shared__ double sU[CT * PU_PITCH];
+// (left-looking inside the column group: the tile is read once and written once).  One WAVE per 64x64 tile, four
+// tiles of the same tile column per workgroup (they share L[k][q] and Linv, the latter staged once in LDS).
+// The in-group update is accumulated TRANSPOSED -- acc[n][m] += L[k]-rows(n) x L[t]-rows(m)^T -- so that lane
+// (i, q) ends up holding U[row 16m + i][cols 16n + q + 4r] of the updated tile U: one row, 16 column values per
+// 16-column block, which is exactly an MFMA A-operand layout for the triangular multiply T = U * Linv^T with the K
+// assignment kk(q, step = (n, r)) = 16n + q + 4r.  No LDS round trip, no barrier between update and multiply; the
+// K steps with n > (column block of the output) are skipped because Linv is lower triangular.
+#define PL_PITCH 66
+__global__ __launch_bounds__(256, 2) void k_chol_panel(double* mats, int64_t mat_stride, int n64, int k, int kc0,
+                                                       int nkc, const double* dinv, int ngrp4, int batch, int R,
+                                                       int ntile, FormSrc fs) {
+  __shared__ double sLi[CT * PL_PITCH];
   int b, g;
-  if (!xcd_affine(blockIdx.x, ngrp, batch, R, b, g)) return;
-  const int t = k + 1 + g;
+  if (!xcd_affine(blockIdx.x, ngrp4, batch, R, b, g)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
   const int i = lane & 15, q = lane >> 4;
   double* M = mats + (int64_t)b * mat_stride;
+  {  // stage Linv (64 x 64 doubles) with coalesced 32-byte loads
+    const double* I = dinv + ((int64_t)b * (n64 / CT) + k) * CT * CT;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e4 = threadIdx.x + 256 * u;          // index of a double4
+      const int r = e4 >> 4, c4 = (e4 & 15) * 4;
+      const double4 v = *reinterpret_cast<const double4*>(I + r * CT + c4);
+      double* d = sLi + r * PL_PITCH + c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
+  __syncthreads();
+  const int idx = g * 4 + wave;
+  if (idx >= ntile) return;
+  const int t = k + 1 + idx;
   double* T = M + (int64_t)t * CT * n64 + k * CT;
-  const double* I = dinv + ((int64_t)b * (n64 / CT) + k) * CT * CT;
-  v4d acc[2][2];
-  // acc = -(tile value) at (row = wr*32 + m*16 + q + 4r, col = wc*32 + n*16 + i)
-  if (fs.enabled) {
-    const FormIdx fx = form_idx(fs, b);
+  // accT[n][m][r] = -(U[row 16m + i][col 16n + q + 4r])
+  v4d acc[4][4];
+  {
     auto init = [&](auto mode) {
+      FormIdx fx{};
+      if (decltype(mode)::value >= 0) fx = form_idx(fs, b);
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int n = 0; n < 4; ++n)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int gi = t * CT + wr * 32 + m * 16 + q + 4 * r, gj = k * CT + wc * 32 + n * 16 + i;
-            acc[m][n][r] = -form_val<decltype(mode)::value>(fx, gi, gj, (int64_t)gi * n64 + gj);
+            const int lr = m * 16 + i, lc = n * 16 + q + 4 * r;
+            if (decltype(mode)::value < 0) acc[n][m][r] = -T[(int64_t)lr * n64 + lc];
+            else {
+              const int gi = t * CT + lr, gj = k * CT + lc;
+              acc[n][m][r] = -form_val<(decltype(mode)::value < 0 ? 0 : decltype(mode)::value)>(fx, gi, gj, (int64_t)gi * n64 + gj);
+            }
           }
     };
-    const int md = form_mode(fx);
-    if (md == 0) init(std::integral_constant<int, 0>{});
-    else if (md == 1) init(std::integral_constant<int, 1>{});
-    else init(std::integral_constant<int, 2>{});
-  } else {
+    if (!fs.enabled) init(std::integral_constant<int, -1>{});
+    else {
+      const FormIdx f0 = form_idx(fs, b);
+      const int md = form_mode(f0);
+      if (md == 0) init(std::integral_constant<int, 0>{});
+      else if (md == 1) init(std::integral_constant<int, 1>{});
+      else init(std::integral_constant<int, 2>{});
+    }
+  }
+  if (nkc > 0) {
+    const double* A = M + ((int64_t)t * CT + i) * n64 + kc0 * CT + 2 * q;   // rows of the tile's own tile row
+    const double* B = M + ((int64_t)k * CT + i) * n64 + kc0 * CT + 2 * q;   // rows of tile row k (the column's L[k][q])
+    const int nk8 = nkc * 8;
+    auto load8 = [&](double2 (&av)[4], double2 (&bv)[4], int kc) {
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 4; ++m) {
+        av[m] = *reinterpret_cast<const double2*>(A + (int64_t)m * 16 * n64 + kc * 8);
+        bv[m] = *reinterpret_cast<const double2*>(B + (int64_t)m * 16 * n64 + kc * 8);
+      }
+    };
+    auto mma8 = [&](const double2 (&av)[4], const double2 (&bv)[4]) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[n].x, av[m].x, acc[n][m], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[n].y, av[m].y, acc[n][m], 0, 0, 0);
+    };
+    double2 a0[4], b0[4], a1[4], b1[4];
+    load8(a0, b0, 0);
+    for (int kc = 0; kc < nk8; kc += 2) {
+      load8(a1, b1, kc + 1);
+      mma8(a0, b0);
+      if (kc + 2 < nk8) load8(a0, b0, kc + 2);
+      mma8(a1, b1);
+    }
+  }
+  // triangular multiply, one 16-row block at a time: out[cb] = sum_{n <= cb, r} (-acc[n][m][r]) x Linv[16cb + i][16n + q + 4r]
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    v4d out[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      out[cb] = (v4d){0, 0, 0, 0};
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (n > cb) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          acc[m][n][r] = -T[(int64_t)(wr * 32 + m * 16 + q + 4 * r) * n64 + wc * 32 + n * 16 + i];
-  }
-  {
-    const double* Arow = M + (int64_t)t * CT * n64 + (int64_t)kc0 * CT + 16 * q;
-    const double* Brow = M + (int64_t)k * CT * n64 + (int64_t)kc0 * CT + 16 * q;
-    for (int kk = 0; kk < nkc; ++kk) {
-      const double* ar[2] = {Arow + (int64_t)(wr * 32 + i) * n64 + kk * CT, Arow + (int64_t)(wr * 32 + 16 + i) * n64 + kk * CT};
-      const double* br[2] = {Brow + (int64_t)(wc * 32 + i) * n64 + kk * CT, Brow + (int64_t)(wc * 32 + 16 + i) * n64 + kk * CT};
-      double av[2][16], bv[2][16];
-      dmma_load<2, 2>(ar, br, av, bv);
-      dmma_fma<2, 2>(av, bv, acc);
+          out[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[n][m][r], sLi[(cb * 16 + i) * PL_PITCH + n * 16 + q + 4 * r],
+                                                         out[cb], 0, 0, 0);
+      }
     }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(int64_t)(m * 16 + q + 4 * r) * n64 + cb * 16 + i] = out[cb][r];
   }
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        sU[(wr * 32 + m * 16 + q + 4 * r) * PU_PITCH + wc * 32 + n * 16 + i] = -acc[m][n][r];
-  __syncthreads();
-  double av[2][16], bv[2][16];
-#pragma unroll
-  for (int m = 0; m < 2; ++m) {
-    const double2* pu = reinterpret_cast<const double2*>(sU + (wr * 32 + m * 16 + i) * PU_PITCH + 16 * q);
-#pragma unroll
-    for (int v = 0; v < 8; ++v) {
-      const double2 x = pu[v];
-      av[m][2 * v] = x.x; av[m][2 * v + 1] = x.y;
-    }
-    const double4* p = reinterpret_cast<const double4*>(I + (wc * 32 + m * 16 + i) * CT + 16 * q);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const double4 x = p[v];
-      bv[m][4 * v] = x.x; bv[m][4 * v + 1] = x.y; bv[m][4 * v + 2] = x.z; bv[m][4 * v + 3] = x.w;
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
-  dmma_fma<2, 2>(av, bv, acc);
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        T[(int64_t)(wr * 32 + m * 16 + q + 4 * r) * n64 + wc * 32 + n * 16 + i] = acc[m][n][r];
 }
 
 // ---- update: A[r][c] -= sum_{q in [kc0, kc0+nkc)} L[r][q] L[c][q]^T for tile columns c in [c_lo, c_hi),
@@ -662,8 +684,9 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
                          info, first);
       ++nl;
       if (Ttot - 1 - j > 0) {
-        hipLaunchKernelGGL(k_chol_panel, dim3(xcd_affine_grid(Ttot - 1 - j, batch, R)), dim3(256), 0, st, mats,
-                           mat_stride, n64, j, k0, j - k0, dinv, Ttot - 1 - j, batch, R, first);
+        const int npt = Ttot - 1 - j;   // panel tiles of this column, four per workgroup
+        hipLaunchKernelGGL(k_chol_panel, dim3(xcd_affine_grid((npt + 3) / 4, batch, R)), dim3(256), 0, st, mats,
+                           mat_stride, n64, j, k0, j - k0, dinv, (npt + 3) / 4, batch, R, npt, first);
         ++nl;
       }
     }
