@@ -8,9 +8,10 @@
 // residualisation, fold / block bookkeeping, LOCO assembly, writers) follow the reference functions
 // cited next to each routine.  There is no CPU compute fallback for the hot path.
 //
-// Served: --qt / --bt, K-fold CV / --loocv (and the reference's automatic LOOCV for --bt below 5,000 samples).
-// Not served in this revision (explicit errors, never silent): --pgen/--bgen input, --gz,
-// --split-l0/--run-l0/--run-l1.
+// Served: --qt / --bt, K-fold CV / --loocv (and the reference's automatic LOOCV for --bt below 5,000 samples), and the
+// file protocol of the level-0 job split: --split-l0 PFX,N / --run-l0 PFX.master,k / --run-l1 PFX.master [--keep-l0]
+// (src/Data.cpp:232-309, :818-908; raw double N x (blocks*R0) files of Step1_Models.cpp:728-734).
+// Not served in this revision (explicit errors, never silent): --pgen/--bgen input, --gz.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -44,6 +45,10 @@ struct Params {
   bool bt = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
        print_prs = false, force_step1 = false, lowmem = false, force_qt = false, cc12 = false;
   int min_case_count = 10, niter_max = 50, niter_max_line_search = 25;
+  // level-0 job split (Data.cpp:232-309, :818-908)
+  std::string split_file;              // --split-l0 prefix / --run-l0, --run-l1 master file
+  int njobs = 0, job_num = 0;
+  bool split_l0 = false, run_l0 = false, run_l1 = false, keep_l0 = false;
   std::vector<double> setl0, setl1;
   int device = 0;
 };
@@ -218,8 +223,17 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--niter") p.niter_max = atoi(need(i).c_str());
     else if (a == "--gz") usage_error("--gz is not available in this build (as in reference builds without Boost Iostreams)");
     else if (a == "--pgen" || a == "--bgen") usage_error(a + " input is not served by the GPU path yet; use --bed");
-    else if (a == "--split-l0" || a == "--run-l0" || a == "--run-l1")
-      usage_error(a + ": file-based level-0 splitting is replaced by multi-GPU block sharding in this build");
+    else if (a == "--split-l0") {
+      auto t = split_char(need(i), ',');
+      if (t.size() != 2) usage_error("must specify number of jobs for --split-l0 (i.e. prefix,njobs).");
+      p.split_l0 = true; p.split_file = t[0]; p.njobs = atoi(t[1].c_str());
+    } else if (a == "--run-l0") {
+      auto t = split_char(need(i), ',');
+      if (t.size() != 2) usage_error("must specify job number for --run-l0 (i.e. master_file,job_number).");
+      p.run_l0 = true; p.split_file = t[0]; p.job_num = atoi(t[1].c_str());
+      if (p.job_num < 1) usage_error("invalid job number for --run-l0 (must be >=1).");
+    } else if (a == "--run-l1") { p.run_l1 = true; p.split_file = need(i); }
+    else if (a == "--keep-l0") p.keep_l0 = true;
     else usage_error("unrecognised option '" + a + "'");
   }
   if (p.step != 1) usage_error("specify which mode regenie should be running using option --step (only --step 1 is served).");
@@ -237,6 +251,12 @@ struct Run {
   std::vector<int> snp_chrom;            // kept variants
   std::vector<int64_t> snp_offset;
   std::vector<int> chr_read;             // chromosomes in file order
+  std::vector<std::string> snp_ids;      // kept variants
+  // --run-l0 / --run-l1 (prep_parallel_l0 / prep_parallel_l1)
+  int64_t parallel_nGeno = 0;            // global number of variants (lambda uses it, Data.cpp:607)
+  int parallel_nBlocks = 0, parallel_nSnps = 0;
+  std::string job_prefix;
+  std::vector<std::string> mprefix; std::vector<int> bstart, btot;
   int64_t n_file = 0, bpr = 0;
   // samples
   std::vector<uint8_t> ind_ignore, ain;  // N_file, N
@@ -362,8 +382,13 @@ void read_bim_fam(Run& r) {  // Geno.cpp:518-610, :643-690, :1128-1220
     sout << "n_samples = " << r.n_file << "\n";
   }
   std::set<std::string> ext, exc;
-  if (!p.extract.empty()) ext = read_snp_files(p.extract);
-  if (!p.exclude.empty()) exc = read_snp_files(p.exclude);
+  std::vector<std::string> extract_files = p.extract, exclude_files = p.exclude;
+  if (p.run_l0) {  // the job's snplist replaces --extract; --exclude is ignored (Data.cpp:852-854, Regenie.cpp:668)
+    extract_files.assign(1, r.job_prefix + ".snplist");
+    exclude_files.clear();
+  }
+  if (!extract_files.empty()) ext = read_snp_files(extract_files);
+  if (!exclude_files.empty()) exc = read_snp_files(exclude_files);
   {
     std::string fn = p.bed + ".bim";
     std::ifstream f(fn);
@@ -383,16 +408,16 @@ void read_bim_fam(Run& r) {  // Geno.cpp:518-610, :643-690, :1128-1220
         minchr = c;
       }
       bool keep = true;
-      if (!p.extract.empty() && !ext.count(t[1])) keep = false;
-      if (!p.exclude.empty() && exc.count(t[1])) keep = false;
-      if (keep) { r.snp_chrom.push_back(c); r.snp_offset.push_back(lineno); }
+      if (!extract_files.empty() && !ext.count(t[1])) keep = false;
+      if (!exclude_files.empty() && exc.count(t[1])) keep = false;
+      if (keep) { r.snp_chrom.push_back(c); r.snp_offset.push_back(lineno); r.snp_ids.push_back(t[1]); }
       ++lineno;
     }
     sout << "n_snps = " << lineno << "\n";
-    if (!p.extract.empty()) sout << "   -keeping variants specified by --extract\n";
-    if (!p.exclude.empty()) sout << "   -removing variants specified by --exclude\n";
+    if (!extract_files.empty()) sout << "   -keeping variants specified by --extract\n";
+    if (!exclude_files.empty()) sout << "   -removing variants specified by --exclude\n";
     if (r.snp_chrom.empty()) throw std::runtime_error("no variant left to include in analysis.");
-    if (!p.extract.empty() || !p.exclude.empty())
+    if (!extract_files.empty() || !exclude_files.empty())
       sout << "   -number of variants remaining in the analysis = " << r.snp_chrom.size() << "\n";
   }
   if (r.snp_chrom.size() > 1000000 && !p.force_step1)  // Data.cpp:173-175
@@ -672,6 +697,50 @@ std::string get_fullpath(const std::string& f) {  // Data.cpp:1150-1194
   return f;
 }
 
+// prep_parallel_l0 (Data.cpp:818-859): header + line `job_num` of the master file
+void prep_parallel_l0(Run& r) {
+  const Params& p = r.p;
+  sout << " * running jobs in parallel (job #" << p.job_num << ")\n";
+  std::ifstream f(p.split_file);
+  if (!f) throw std::runtime_error("cannot open file : " + p.split_file);
+  std::string line;
+  if (!std::getline(f, line)) throw std::runtime_error("cannot read header line in master file.");
+  long long ng = 0; int bsz = 0;
+  if (sscanf(line.c_str(), "%lld %d", &ng, &bsz) != 2 || bsz != p.bsize) throw std::runtime_error("invalid header line in master file.");
+  r.parallel_nGeno = ng;
+  for (int k = 1; k <= p.job_num; ++k)
+    if (!std::getline(f, line)) throw std::runtime_error("could not read line " + std::to_string(p.job_num + 1) + " (check number of lines in file).");
+  char pref[4096];
+  if (sscanf(line.c_str(), "%4095s %d %d", pref, &r.parallel_nBlocks, &r.parallel_nSnps) != 3)
+    throw std::runtime_error("could not read line " + std::to_string(p.job_num + 1) + " (check number of lines and format in file).");
+  r.job_prefix = pref;
+}
+
+// prep_parallel_l1 (Data.cpp:862-908)
+void prep_parallel_l1(Run& r, int total_n_block, int64_t n_variants) {
+  const Params& p = r.p;
+  std::ifstream f(p.split_file);
+  if (!f) throw std::runtime_error("cannot open file : " + p.split_file);
+  std::string line;
+  if (!std::getline(f, line)) throw std::runtime_error("cannot read header line in master file.");
+  long long ng = 0; int bsz = 0;
+  if (sscanf(line.c_str(), "%lld %d", &ng, &bsz) != 2 || bsz != p.bsize) throw std::runtime_error("invalid header line in master file.");
+  r.parallel_nGeno = ng;
+  int nblocks = 0, lineread = 0;
+  int64_t nsnps = 0;
+  while (std::getline(f, line)) {
+    char pref[4096]; int nb = 0, ns = 0;
+    if (sscanf(line.c_str(), "%4095s %d %d", pref, &nb, &ns) != 3)
+      throw std::runtime_error("could not read line " + std::to_string(lineread + 2) + " (check number of lines and format in file).");
+    r.bstart.push_back(nblocks); r.btot.push_back(nb); r.mprefix.push_back(pref);
+    if (nblocks > total_n_block || nb < 0) throw std::runtime_error("invalid block information in master file at line " + std::to_string(lineread + 2) + ".");
+    nblocks += nb; nsnps += ns; ++lineread;
+  }
+  if (nblocks != total_n_block || nsnps != n_variants)
+    throw std::runtime_error("number of blocks/variants in master file '" + p.split_file + "' doesn't match that in the analysis.");
+  sout << " * using results from running " << lineread << " parallel jobs at level 0\n";
+}
+
 void check(rg_ctx* ctx, int rc) {
   if (rc != 0) throw std::runtime_error(rg_last_error(ctx));
 }
@@ -686,7 +755,43 @@ int run(int argc, char** argv) {
   sout << "Log of output saved in file : " << p.out << ".log\n\nOptions in effect:\n";
   for (int i = 1; i < argc; ++i) sout << (argv[i][0] == '-' && argv[i][1] == '-' ? "  " : " ") << argv[i] << (i + 1 < argc && argv[i + 1][0] == '-' ? " \\\n" : "");
   sout << "\n\nFitting null model\n";
+  if (p.run_l0) prep_parallel_l0(r);
   read_bim_fam(r);
+  if (p.split_l0) {  // set_parallel_l0 / write_l0_master (Data.cpp:232-309): master + per-job variant lists, then exit
+    std::map<int, int> cn;
+    for (int c : r.snp_chrom) cn[c]++;
+    std::vector<int> bsizes;     // block sizes in traversal order
+    for (int c : r.chr_read) {
+      const int n = cn.count(c) ? cn[c] : 0;
+      const int nbc = (n + p.bsize - 1) / p.bsize;
+      for (int bb = 0; bb < nbc; ++bb) bsizes.push_back(std::min(p.bsize, n - bb * p.bsize));
+    }
+    const int total = (int)bsizes.size();
+    int njobs = p.njobs;
+    sout << " * running level 0 in parallel across " << total << " genotype blocks\n";
+    if (njobs <= 1) throw std::runtime_error("number of jobs must be >1.");
+    if (njobs > total) { sout << "   -WARNING: Number of jobs cannot be greater than number of blocks.\n"; njobs = total; }
+    sout << "   -using " << njobs << " jobs\n   -master file written to [" << p.split_file << ".master]\n";
+    sout << "   -variant list files written to [" << p.split_file << "_job*.snplist]\n";
+    std::ofstream mf(p.split_file + ".master");
+    if (!mf) throw std::runtime_error("cannot write file : " + p.split_file + ".master");
+    mf << r.snp_chrom.size() << " " << p.bsize << std::endl;
+    const int nall = total / njobs, rem = total - nall * njobs;
+    int b = 0; size_t scount = 0;
+    for (int j = 0; j < njobs; ++j) {
+      const int bt = nall + (j < rem ? 1 : 0);
+      int ns = 0;
+      for (int t = 0; t < bt; ++t) ns += bsizes[b++];
+      const std::string fname = p.split_file + "_job" + std::to_string(j + 1);
+      mf << fname << " " << bt << " " << ns << std::endl;
+      std::ofstream sf(fname + ".snplist");
+      if (!sf) throw std::runtime_error("cannot write file : " + fname + ".snplist");
+      for (int t = 0; t < ns; ++t) sf << r.snp_ids[scount + t] << "\n";
+      scount += ns;
+    }
+    sout << "\nEnd of run\n";
+    return 0;
+  }
   read_pheno_cov(r);
   const int64_t N = r.N;
   const int P = r.P;
@@ -707,7 +812,10 @@ int run(int argc, char** argv) {
   }
   const int B = (int)blocks.size();
   if (B == 0) throw std::runtime_error("total number of blocks must be > 0.");
-  const int64_t M = (int64_t)r.snp_chrom.size();
+  const int64_t M = p.run_l0 ? r.parallel_nGeno : (int64_t)r.snp_chrom.size();   // --run-l0: global count (Data.cpp:607)
+  if (p.run_l0 && (B != r.parallel_nBlocks || (int)r.snp_chrom.size() != r.parallel_nSnps))
+    throw std::runtime_error("number of blocks/variants in the job's snplist doesn't match the master file.");
+  if (p.run_l1) prep_parallel_l1(r, B, (int64_t)r.snp_chrom.size());
   std::vector<double> h0 = p.setl0, h1 = p.setl1;
   auto grid = [](int n) {  // set_ridge_params (Regenie.cpp:1497-1508)
     if (n < 2) throw std::runtime_error("number of ridge parameters must be at least 2 (=" + std::to_string(n) + ")");
@@ -761,8 +869,27 @@ int run(int argc, char** argv) {
   pr.neff = r.neff.data(); pr.n_blocks_total = B; pr.max_block_size = p.bsize;
   check(ctx, rg_set_problem(ctx, &pr));
 
-  // level 0: stream blocks from the bed file (get_G, Geno.cpp:1498-1517) in batches
-  {
+  if (p.run_l1) {
+    // read_l0 (Step1_Models.cpp:1921-1987): every job file holds N x (blocks_k * R0) raw doubles, column-major,
+    // block-major then ridge index; its columns go to W at block offset bstart_k
+    std::vector<double> slab((size_t)N * R0);
+    for (size_t k = 0; k < r.mprefix.size(); ++k)
+      for (int q = 0; q < P; ++q) {
+        const std::string fn = r.mprefix[k] + "_l0_Y" + std::to_string(q + 1);
+        std::ifstream lf(fn, std::ios::binary | std::ios::ate);
+        if (!lf) throw std::runtime_error("cannot read file : " + fn);
+        const int64_t want = (int64_t)sizeof(double) * N * r.btot[k] * R0;
+        if ((int64_t)lf.tellg() != want) throw std::runtime_error("file " + fn + " is not the right size.");   // Step1_Models.cpp:1962
+        lf.seekg(0);
+        for (int bb = 0; bb < r.btot[k]; ++bb) {
+          lf.read((char*)slab.data(), sizeof(double) * slab.size());
+          if (!lf) throw std::runtime_error("cannot read file : " + fn);
+          check(ctx, rg_l0_set_w(ctx, r.bstart[k] + bb, q, slab.data()));
+        }
+      }
+    sout << "   -level 0 predictors read from the job files\n";
+  } else {
+    // level 0: stream blocks from the bed file (get_G, Geno.cpp:1498-1517) in batches
     std::ifstream bed(p.bed + ".bed", std::ios::binary);
     const int NB = 32;
     std::vector<std::vector<uint8_t>> bufs(NB);
@@ -793,6 +920,22 @@ int run(int argc, char** argv) {
            << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << "ms, level 0 ridge on GPU "
            << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms)\n";
     }
+  }
+  if (p.run_l0) {  // write_l0_file (Step1_Models.cpp:728-734): PFX_job<k>_l0_Y<ph>, then stop (Data.cpp:113-117)
+    std::vector<double> slab((size_t)N * R0);
+    for (int q = 0; q < P; ++q) {
+      const std::string fn = r.job_prefix + "_l0_Y" + std::to_string(q + 1);
+      std::ofstream lf(fn, std::ios::binary);
+      if (!lf) throw std::runtime_error("cannot write file : " + fn);
+      for (int bb = 0; bb < B; ++bb) {
+        check(ctx, rg_l0_get_w(ctx, bb, q, slab.data()));
+        lf.write((const char*)slab.data(), sizeof(double) * slab.size());
+      }
+    }
+    sout << "   -level 0 predictions written to [" << r.job_prefix << "_l0_Y*]\n";
+    rg_destroy(ctx);
+    sout << "\nElapsed time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << "s\nEnd of run\n";
+    return 0;
   }
 
   // level 1 (ridge_level_1 + output)
@@ -895,6 +1038,9 @@ int run(int argc, char** argv) {
     }
     sout << "done\n\n";
   }
+  if (p.run_l1 && !p.keep_l0)   // rm_l0_files (Data.cpp:1131-1147)
+    for (auto& pre : r.mprefix)
+      for (int q = 0; q < P; ++q) std::remove((pre + "_l0_Y" + std::to_string(q + 1)).c_str());
   sout << "List of blup files written to: [" << p.out << "_pred.list]\n";
   if (p.print_prs) sout << "List of files with whole genome PRS written to: [" << p.out << "_prs.list]\n";
   rg_destroy(ctx);

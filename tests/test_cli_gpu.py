@@ -135,3 +135,35 @@ def test_cli_qt_loocv(example_dir, tmp_path):
         _, _, val_g, _ = _parse_loco(str(tmp_path / ("gpu_%d.loco" % k)))
         _, _, val_r, _ = _parse_loco(str(tmp_path / ("ref_%d.loco" % k)))
         assert np.nanmax(np.abs(val_g - val_r)) <= 2e-6 * np.nanmax(np.abs(val_r))
+
+
+def test_cli_split_l0_equals_single_run(example_dir, tmp_path):
+    """The reference's self-consistency test (test/test_bash.sh:91-138) on the C++ driver: --split-l0 into 4 jobs,
+    4 x --run-l0 (raw double level-0 files, global M for lambda), --run-l1; both .loco files must be byte-identical
+    to the single-process run of the same (BT, automatic LOOCV) command."""
+    E = example_dir
+    base = ["--step", "1", "--bed", os.path.join(E, "example"), "--exclude", os.path.join(E, "snplist_rm.txt"),
+            "--covarFile", os.path.join(E, "covariates.txt"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"),
+            "--remove", os.path.join(E, "fid_iid_to_remove.txt"), "--bsize", "100", "--bt", "--lowmem",
+            "--lowmem-prefix", "tmp_rg"]
+    r = _run(base + ["--out", str(tmp_path / "fit_bin_out")], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    pre = str(tmp_path / "fit_bin_parallel")
+    r = _run(base + ["--split-l0", pre + ",4", "--out", str(tmp_path / "fit_bin_l0")], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    master = open(pre + ".master").read().split("\n")
+    assert master[0] == "994 100"                                 # <n_variants> <bsize> (1000 - 6 excluded)
+    assert [ln.split(" ")[1:] for ln in master[1:5]] == [["3", "300"], ["3", "300"], ["2", "200"], ["2", "194"]]
+    assert len(open(pre + "_job4.snplist").read().split()) == 194
+    for job in range(1, 5):
+        r = _run(base + ["--run-l0", "%s.master,%d" % (pre, job), "--out", str(tmp_path / "fit_bin_l0")], str(tmp_path))
+        assert r.returncode == 0, r.stdout + r.stderr
+        nb = int(master[job].split(" ")[1])
+        assert os.path.getsize("%s_job%d_l0_Y1" % (pre, job)) == 8 * 494 * nb * 5   # raw double N x (blocks*R0)
+    r = _run(base + ["--run-l1", pre + ".master", "--out", str(tmp_path / "fit_bin_l1")], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    for k in (1, 2):
+        a = open(str(tmp_path / ("fit_bin_out_%d.loco" % k)), "rb").read()
+        b = open(str(tmp_path / ("fit_bin_l1_%d.loco" % k)), "rb").read()
+        assert a == b, "split-l0 run differs from the single run for phenotype %d" % k
+    assert not os.path.exists(pre + "_job1_l0_Y1")                # removed after --run-l1 (no --keep-l0)
