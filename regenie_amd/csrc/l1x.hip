@@ -42,77 +42,74 @@ __device__ __forceinline__ const double* wg_row(const WgArgs& a, int chain, int 
   return a.zero;
 }
 
-__global__ __launch_bounds__(256) void k_wgram(WgArgs a, SegLayout seg, int T) {
+// One WAVE per 64x64 tile (4 x 4 MFMA 16x16x4 sub-tiles), four tiles of one tile column per workgroup, K loop in
+// 8-deep chunks software-pipelined over two register sets (as k_chol_update / k_l1_gram64); the weights scale the
+// A operand on the fly.  Tiles are enumerated column by column: column tc holds rows tc..T (T = the extra-row tile).
+__global__ __launch_bounds__(256, 2) void k_wgram(WgArgs a, SegLayout seg, int T) {
   const int slot = blockIdx.y;
   const int chain = a.chainmap ? a.chainmap[slot] : slot;
-  const int tri = T * (T + 1) / 2;
-  int idx = blockIdx.x, tr, tc;
-  if (idx < tri) {
-    int rr = (int)((sqrtf(8.0f * idx + 1.0f) - 1.0f) * 0.5f);
-    while ((rr + 1) * (rr + 2) / 2 <= idx) ++rr;
-    while (rr * (rr + 1) / 2 > idx) --rr;
-    tr = rr;
-    tc = idx - rr * (rr + 1) / 2;
-  } else {
-    tr = T;
-    tc = idx - tri;
-  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int ntile = T * (T + 1) / 2 + T;
+  const int idx = blockIdx.x * 4 + wave;
+  if (idx >= ntile) return;
+  int tc = 0, rem = idx;
+  while (rem >= T + 1 - tc) { rem -= T + 1 - tc; ++tc; }
+  const int tr = tc + rem;
   const int i = lane & 15, q = lane >> 4;
-  const double* ar[2] = {wg_row(a, chain, tr * CT + wr * 32 + i), wg_row(a, chain, tr * CT + wr * 32 + 16 + i)};
-  const double* br[2] = {wg_row(a, chain, tc * CT + wc * 32 + i), wg_row(a, chain, tc * CT + wc * 32 + 16 + i)};
-  const double* wrow = a.wv ? a.wv + (int64_t)chain * a.Np : nullptr;
-  v4d acc[2][2];
+  const double* A[4];
+  const double* B[4];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < 4; ++m) {
+    A[m] = wg_row(a, chain, tr * CT + m * 16 + i) + 2 * q;
+    B[m] = wg_row(a, chain, tc * CT + m * 16 + i) + 2 * q;
+  }
+  const double* wrow = a.wv ? a.wv + (int64_t)chain * a.Np + 2 * q : nullptr;
+  v4d acc[4][4];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
+  auto load8 = [&](double2 (&av)[4], double2 (&bv)[4], int64_t p8) {   // p8: position / 8
+    double2 w = make_double2(1.0, 1.0);
+    if (wrow) w = *reinterpret_cast<const double2*>(wrow + p8 * 8);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const double2 x = *reinterpret_cast<const double2*>(A[m] + p8 * 8);
+      av[m] = make_double2(x.x * w.x, x.y * w.y);
+      bv[m] = *reinterpret_cast<const double2*>(B[m] + p8 * 8);
+    }
+  };
+  auto mma8 = [&](const double2 (&av)[4], const double2 (&bv)[4]) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].x, bv[n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].y, bv[n].y, acc[m][n], 0, 0, 0);
+  };
   for (int f = 0; f < seg.nseg; ++f) {
     if (a.excl_own && f == chain) continue;
-    const int64_t p0 = seg.pos_start[f] + 16 * q, plen = seg.plen[f];
-    for (int64_t k = 0; k < plen; k += 64) {
-      double av[2][16], bv[2][16];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const double4* pa = reinterpret_cast<const double4*>(ar[m] + p0 + k);
-        const double4* pb = reinterpret_cast<const double4*>(br[m] + p0 + k);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const double4 x = pa[v], y = pb[v];
-          av[m][4 * v] = x.x; av[m][4 * v + 1] = x.y; av[m][4 * v + 2] = x.z; av[m][4 * v + 3] = x.w;
-          bv[m][4 * v] = y.x; bv[m][4 * v + 1] = y.y; bv[m][4 * v + 2] = y.z; bv[m][4 * v + 3] = y.w;
-        }
-      }
-      if (wrow) {
-        const double4* pw = reinterpret_cast<const double4*>(wrow + p0 + k);
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          const double4 w = pw[v];
-#pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            av[m][4 * v] *= w.x; av[m][4 * v + 1] *= w.y; av[m][4 * v + 2] *= w.z; av[m][4 * v + 3] *= w.w;
-          }
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < 16; ++s)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int n = 0; n < 2; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m][s], bv[n][s], acc[m][n], 0, 0, 0);
+    const int64_t k0 = seg.pos_start[f] / 8, k1 = k0 + seg.plen[f] / 8;   // (k1 - k0) is a multiple of 32
+    double2 a0[4], b0[4], a1[4], b1[4];
+    load8(a0, b0, k0);
+    for (int64_t kc = k0; kc < k1; kc += 2) {
+      load8(a1, b1, kc + 1);
+      mma8(a0, b0);
+      if (kc + 2 < k1) load8(a0, b0, kc + 2);
+      mma8(a1, b1);
     }
   }
   const double sh = a.dshift ? a.dshift[chain] : 0.0;
   double* O = a.out + (int64_t)slot * a.out_stride + (int64_t)tr * CT * a.n64 + tc * CT;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int lr = wr * 32 + m * 16 + q + 4 * r, lc = wc * 32 + n * 16 + i;
+        const int lr = m * 16 + q + 4 * r, lc = n * 16 + i;
         double v = acc[m][n][r];
         if (a.dshift && tr == tc && lr == lc) v = (tr * CT + lr < a.L) ? v + sh : 1.0;
         O[(int64_t)lr * a.n64 + lc] = v;
@@ -501,7 +498,7 @@ int rg_l1_qt_loocv_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const 
     const double* d_y = ctx->d_V + (int64_t)(ctx->C + p) * Np;
     // G = W^T W with W^T y as row n64 (xtx, zvec of Step1_Models.cpp:893-907)
     WgArgs g{ctx->d_W, ctx->d_zero, Np, L, P, p, n64, nullptr, d_y, nullptr, nullptr, 0, d_G, c.msz};
-    hipLaunchKernelGGL(k_wgram, dim3(T * (T + 1) / 2 + T, 1), dim3(256), 0, st, g, ctx->seg, T);
+    hipLaunchKernelGGL(k_wgram, dim3((T * (T + 1) / 2 + T + 3) / 4, 1), dim3(256), 0, st, g, ctx->seg, T);
     hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, ctx->d_W, Np, L, P, p,
                        n64, d_Wt);
     L1X_HIP(hipMemcpyAsync(d_tau, tau + (int64_t)p * R1, sizeof(double) * R1, hipMemcpyHostToDevice, st));
@@ -604,7 +601,7 @@ int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<doub
   L1X_HIP(hipMemcpyAsync(s.d_tauc, tauc.data(), sizeof(double) * s.nchain, hipMemcpyHostToDevice, st));
   WgArgs g{ctx->d_W, ctx->d_zero, c.Np, c.L, c.P, s.p, c.n64, s.a.wv, rhs_is_score ? nullptr : s.a.zv, s.d_tauc,
            s.d_map, s.a.kfold, s.d_sys, c.msz};
-  hipLaunchKernelGGL(k_wgram, dim3(c.T * (c.T + 1) / 2 + c.T, na), dim3(256), 0, st, g, ctx->seg, c.T);
+  hipLaunchKernelGGL(k_wgram, dim3((c.T * (c.T + 1) / 2 + c.T + 3) / 4, na), dim3(256), 0, st, g, ctx->seg, c.T);
   if (rhs_is_score)
     for (int i = 0; i < na; ++i)
       L1X_HIP(hipMemcpyAsync(s.d_sys + (int64_t)i * c.msz + (int64_t)c.n64 * c.n64, s.d_score + (int64_t)act[i] * c.n64,
@@ -803,7 +800,7 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
       LooArgs la{ctx->d_W, d_Ut, s.d_beta, Np, L, P, p, d_yraw, d_rv, d_wv, d_off, ctx->d_maskp + (int64_t)p * Np, 1};
       auto loo_setup = [&](double lam) -> int {   // H = (X^T W X + lam I)^-1 at the current weights, U^T = H W^T
         WgArgs g{ctx->d_W, ctx->d_zero, Np, L, P, p, n64, d_wv, nullptr, nullptr, nullptr, 0, d_G, c.msz};
-        hipLaunchKernelGGL(k_wgram, dim3(T * (T + 1) / 2 + T, 1), dim3(256), 0, st, g, ctx->seg, T);
+        hipLaunchKernelGGL(k_wgram, dim3((T * (T + 1) / 2 + T + 3) / 4, 1), dim3(256), 0, st, g, ctx->seg, T);
         L1X_HIP(hipMemcpyAsync(d_tau1, &lam, sizeof(double), hipMemcpyHostToDevice, st));
         L1X_HIP(hipStreamSynchronize(st));
         int r2 = invert_shifted(ctx, c, d_G, d_tau1, 1, d_eye, d_sysI, d_dinvI, d_H);
