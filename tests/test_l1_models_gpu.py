@@ -79,3 +79,18 @@ def test_bt_kfold_missing_pheno(example_dir):
     ref = oracle_step1_any(opt, force_kfold=True)
     got = gpu_step1_any(opt, force_kfold=True)
     _compare(ref, got, 2, TOL_BT, 6)
+
+
+def test_bt_kfold_native_above_5000(tmp_path):
+    """--bt with more than 5,000 samples keeps K-fold CV by the reference's own rule (Data.cpp:353): the logistic
+    ridge IRLS with all K fold models in lock-step launches, on synthetic 0/1 traits with missing values."""
+    N, M = 5300, 600
+    g = synth_dosages(M, N, miss_rate=0.01, seed=77)
+    pre = str(tmp_path / "btk")
+    write_plink(pre, g, np.repeat([1, 2, 7], [250, 200, 150]), P=2, ncov=2, seed=12, missing_pheno=0.03, binary=True)
+    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=100, bt=True)
+    ref = orc.run_step1(opt)
+    assert not ref.use_loocv
+    got = gpu_step1_any(opt)
+    assert not got["use_loocv"]
+    _compare(ref, got, 2, TOL_BT, 6)
