@@ -64,8 +64,8 @@ def gen_block(torch, dev, block_id, bs, N, seed, ncausal):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--samples", type=int, default=50000)
     ap.add_argument("--snps", type=int, default=100000, help="SNPs per GPU")
     ap.add_argument("--phenos", type=int, default=1)
