@@ -76,6 +76,9 @@ int rg_create(rg_ctx** out, int device_id, void* hip_stream) {
 void rg_destroy(rg_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
+  if (c->twin) { rg_destroy(c->twin); c->twin = nullptr; }
+  if (c->ev_tw_fork) hipEventDestroy(c->ev_tw_fork);
+  if (c->ev_tw_join) hipEventDestroy(c->ev_tw_join);
   hipStreamSynchronize(c->stream);
   free_all(c);
   if (c->ev0) hipEventDestroy(c->ev0);
@@ -278,6 +281,23 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   ctx->block_done.assign(ctx->B_total, 0);
   ctx->have_problem = true;
   memset(&ctx->tm, 0, sizeof(ctx->tm));
+  // second pipeline (see rg_ctx::twin); RG_PIPELINES=1 keeps a single one
+  if (ctx->twin) { rg_destroy(ctx->twin); ctx->twin = nullptr; }
+  int npipe = 2;
+  if (const char* e = getenv("RG_PIPELINES")) npipe = atoi(e);
+  if (!ctx->is_child && npipe >= 2 && !ctx->loocv && ctx->B_total > 1) {
+    rg_ctx* ch = nullptr;
+    if (rg_create(&ch, ctx->device, nullptr) == RG_OK && ch) {
+      ch->is_child = true;
+      if (rg_set_problem(ch, p) == RG_OK) {
+        ctx->twin = ch;
+        if (!ctx->ev_tw_fork) hipEventCreateWithFlags(&ctx->ev_tw_fork, hipEventDisableTiming);
+        if (!ctx->ev_tw_join) hipEventCreateWithFlags(&ctx->ev_tw_join, hipEventDisableTiming);
+      } else {
+        rg_destroy(ch);   // e.g. not enough memory for a second workspace set: single pipeline
+      }
+    }
+  }
   return RG_OK;
 }
 
@@ -291,6 +311,7 @@ int rg_set_w_buffer(rg_ctx* ctx, void* dev_ptr, int64_t bytes) {
   if (ctx->own_W && ctx->d_W) hipFree(ctx->d_W);
   ctx->d_W = (double*)dev_ptr;
   ctx->own_W = false;
+  if (ctx->twin) { ctx->twin->d_W = ctx->d_W; ctx->twin->own_W = false; }
   return RG_OK;
 }
 
@@ -299,6 +320,7 @@ static int ensure_W(rg_ctx* ctx) {
   RG_HIP(hipMalloc((void**)&ctx->d_W, (size_t)ctx->W_bytes));
   RG_HIP(hipMemsetAsync(ctx->d_W, 0, (size_t)ctx->W_bytes, ctx->stream));
   ctx->own_W = true;
+  if (ctx->twin) { ctx->twin->d_W = ctx->d_W; ctx->twin->own_W = false; }
   return RG_OK;
 }
 
@@ -419,12 +441,28 @@ int rg_l0_blocks(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int3
   // balanced batches: ceil(nblk / cap) batches of (almost) equal size
   const int nbatch = (nblk + ctx->nblk_cap - 1) / ctx->nblk_cap;
   const int per = (nblk + nbatch - 1) / nbatch;
-  for (int b0 = 0; b0 < nblk; b0 += per) {
+  // two pipelines: odd batches run in the child context on its own stream, ordered after everything already queued
+  // on ctx->stream, and joined back before this call returns (the caller sees one stream).  The per-stage timing mode
+  // keeps a single pipeline so that its HIP-event brackets stay meaningful.
+  rg_ctx* tw = (ctx->twin && !ctx->timing && nbatch > 1) ? ctx->twin : nullptr;
+  if (tw) {
+    tw->d_W = ctx->d_W; tw->own_W = false;
+    RG_HIP(hipEventRecord(ctx->ev_tw_fork, ctx->stream));
+    RG_HIP(hipStreamWaitEvent(tw->stream, ctx->ev_tw_fork, 0));
+  }
+  int ib = 0;
+  for (int b0 = 0; b0 < nblk; b0 += per, ++ib) {
     const int nb = std::min(per, nblk - b0);
-    // the small H2D descriptor copies of the next batch must not overtake the kernels of this one:
-    // everything is ordered on the single ctx stream.
-    rc = l0_batch(ctx, nb, block_ids + b0, bs + b0, bed_rows + b0, row_stride, mem_kind);
-    if (rc) return rc;
+    // within a context the small H2D descriptor copies of the next batch must not overtake the kernels of the
+    // previous one: everything of a pipeline is ordered on its stream.
+    rg_ctx* c = (tw && (ib & 1)) ? tw : ctx;
+    rc = l0_batch(c, nb, block_ids + b0, bs + b0, bed_rows + b0, row_stride, mem_kind);
+    if (rc) { if (c != ctx) ctx->err = c->err; return rc; }
+    if (c != ctx) for (int b = 0; b < nb; ++b) ctx->block_done[block_ids[b0 + b]] = 1;
+  }
+  if (tw) {
+    RG_HIP(hipEventRecord(ctx->ev_tw_join, tw->stream));
+    RG_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tw_join, 0));
   }
   return RG_OK;
 }
@@ -433,6 +471,10 @@ int rg_sync(rg_ctx* ctx) {
   if (!ctx) return RG_ERR_ARG;
   hipSetDevice(ctx->device);
   RG_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->twin) {   // deferred device-side errors of the second pipeline
+    int rc2 = rg_sync(ctx->twin);
+    if (rc2) { ctx->err = ctx->twin->err; return rc2; }
+  }
   if (!ctx->d_info) return RG_OK;
   int32_t info[4] = {0, 0, 0, 0};
   RG_HIP(hipMemcpy(info, ctx->d_info, sizeof(info), hipMemcpyDeviceToHost));

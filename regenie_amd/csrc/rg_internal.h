@@ -113,6 +113,13 @@ struct rg_ctx {
   rg_allreduce_fn coll_allreduce = nullptr;
   void* coll_user = nullptr;
 
+  // second level-0 pipeline: a child context with its own workspaces and HIP stream that shares W.  Alternate
+  // batches go to it, so the streaming phases (ingest, covariate products, FP4 Gram, assemble, predictions) of
+  // one batch overlap the latency/HBM-bound Cholesky of the other.  Joined back onto `stream` with events.
+  rg_ctx* twin = nullptr;
+  bool is_child = false;
+  hipEvent_t ev_tw_fork = nullptr, ev_tw_join = nullptr;
+
   // level-1 workspaces, kept across calls (hipMalloc/hipFree per call costs milliseconds)
   void* ws_ptr[12] = {};
   size_t ws_bytes[12] = {};
