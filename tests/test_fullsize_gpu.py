@@ -1,5 +1,5 @@
-"""Size-independent properties at BASELINE.json's config-2 sample count (50,000 samples, bsize 1000), where the
-oracle would take minutes: exact-Gram checksum of checksums, symmetry and diagonal; level-0 predictors invariant
+"""Size-independent properties at BASELINE.json's config-2 and config-3 sample counts (50,000 and 500,000 samples,
+bsize 1000), where the oracle would take minutes to hours: exact-Gram checksum of checksums, symmetry and diagonal; level-0 predictors invariant
 under a rescaling of the phenotype (the column standardisation makes W scale-free) and under the batch composition;
 level 1 reproduces the phenotype sign flip (LOCO(-y) = -LOCO(y))."""
 import ctypes as C
@@ -13,10 +13,11 @@ torch = pytest.importorskip("torch")
 from regenie_amd import hostprep as hp  # noqa: E402
 from regenie_amd.engine import Step1Engine, load_library, loco_from_predictions  # noqa: E402
 
-N, BS = 50000, 1000
+BS = 1000
+N = 50000          # module default; the level-0 / level-1 property tests also run at 500,000
 
 
-def _gen(seed, bs=BS, n=N):
+def _gen(seed, bs=BS, n=50000):
     g = torch.Generator(device="cuda")
     g.manual_seed(seed)
     maf = 0.05 + 0.45 * torch.rand(bs, 1, generator=g, device="cuda")
@@ -35,7 +36,7 @@ def test_fp4_gram_checksums_full_size():
     lib = load_library()
     n = 50176                                       # 50,000 rounded up to a multiple of 256 (one LDS stage)
     d = torch.zeros(BS, n, dtype=torch.uint8, device="cuda")
-    d[:, :N] = _gen(1)
+    d[:, :N] = _gen(1, n=N)
     nib = torch.where(d == 1, torch.full_like(d, 2), torch.where(d == 2, torch.full_like(d, 4), torch.zeros_like(d)))
     p4 = (nib[:, 0::2] | (nib[:, 1::2] << 4)).contiguous()
     S = torch.full((BS, BS), -1, dtype=torch.int32, device="cuda")
@@ -52,6 +53,7 @@ def test_fp4_gram_checksums_full_size():
 
 
 def _problem(Yraw, nblk):
+    N = Yraw.shape[0]
     rng = np.random.default_rng(5)
     cov = rng.standard_normal((N, 2))
     X = hp.get_basis(np.concatenate([np.ones((N, 1)), cov], axis=1))
@@ -69,9 +71,10 @@ def _problem(Yraw, nblk):
     return eng
 
 
-def test_level0_scale_and_batch_invariance_full_size():
+@pytest.mark.parametrize("N", [50000, 500000])
+def test_level0_scale_and_batch_invariance_full_size(N):
     nblk = 3
-    packed = [_pack_bed(_gen(10 + b)) for b in range(nblk)]
+    packed = [_pack_bed(_gen(10 + b, n=N)) for b in range(nblk)]
     rng = np.random.default_rng(1)
     y = rng.standard_normal((N, 1))
     outs = []
@@ -91,9 +94,10 @@ def test_level0_scale_and_batch_invariance_full_size():
     assert np.max(np.abs(W1 + W2)) < 1e-9 * np.max(np.abs(W1))
 
 
-def test_level1_sign_flip_full_size():
+@pytest.mark.parametrize("N", [50000, 500000])
+def test_level1_sign_flip_full_size(N):
     nblk = 2
-    packed = [_pack_bed(_gen(20 + b)) for b in range(nblk)]
+    packed = [_pack_bed(_gen(20 + b, n=N)) for b in range(nblk)]
     rng = np.random.default_rng(2)
     y = rng.standard_normal((N, 1))
     locos = []
