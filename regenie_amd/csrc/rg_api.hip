@@ -28,7 +28,7 @@ void free_all(rg_ctx* c) {
                   c->d_keptp, c->d_posc, c->d_zero, c->d_raw, c->d_pk, c->d_pk4, c->d_mu, c->d_nmiss,
                   c->d_xypart, c->d_chunk_seg, c->d_chunk_pos, c->d_chunk_len, c->d_S, c->d_F, c->d_Bm,
                   c->d_BQ, c->d_GYt, c->d_sc, c->d_fold, c->d_sum, c->d_wk, c->d_dinv, c->d_beta,
-                  c->d_cb, c->d_psum, c->d_info, c->d_bs, c->d_blockid, (void*)c->d_rawptr, c->d_c1k_seg, c->d_c1k_pos,
+                  c->d_cb, c->d_psum, c->d_pstat, c->d_info, c->d_bs, c->d_blockid, (void*)c->d_rawptr, c->d_c1k_seg, c->d_c1k_pos,
                   c->d_c1k_len, c->d_c256_seg, c->d_c256_pos, c->d_c256_len, c->d_gt, c->d_lpart};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -271,7 +271,8 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   }
   if ((rc = dev_alloc(ctx, &ctx->d_beta, (size_t)nb * nseg * R0 * P * n64))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_cb, (size_t)nb * nseg * R0 * P * C))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->d_psum, (size_t)nb * ctx->n_c1k * P * 8 * 2))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_psum, (size_t)nb * ctx->n_c256 * P * 8 * 2))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_pstat, (size_t)nb * P * 8 * 2))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_bs, (size_t)nb))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_blockid, (size_t)nb))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_rawptr, (size_t)nb))) return rc;
@@ -419,7 +420,8 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     pa.Bm = ctx->d_Bm; pa.wk = ctx->d_wk; pa.V = ctx->d_V; pa.maskp = ctx->d_maskp;
     pa.keptp = ctx->d_keptp; pa.bs = ctx->d_bs; pa.blockid = ctx->d_blockid; pa.neff = ctx->d_neff; pa.nmiss = ctx->d_nmiss;
     pa.beta = ctx->d_beta; pa.cb = ctx->d_cb; pa.psum = ctx->d_psum; pa.W = ctx->d_W;
-    rg_launch_l0_pred_impl(st, pa, ctx->d_c1k_seg, ctx->d_c1k_pos, ctx->d_c1k_len, ctx->n_c1k);
+    rg_launch_l0_pred_impl(st, pa, ChunkTab{ctx->d_c1k_seg, ctx->d_c1k_pos, ctx->d_c1k_len, ctx->n_c1k},
+                           ChunkTab{ctx->d_c256_seg, ctx->d_c256_pos, ctx->d_c256_len, ctx->n_c256}, ctx->d_pstat);
   }
   }
   for (int b = 0; b < nblk; ++b) ctx->block_done[block_ids[b]] = 1;

@@ -100,7 +100,8 @@ struct rg_ctx {
   double* d_dinv = nullptr;      // [nblk*nseg*R0][n64/64][64*64]
   double* d_beta = nullptr;      // [nblk][nseg*R0][P][n64]  beta / scale_G
   double* d_cb = nullptr;        // [nblk][nseg*R0][P][C]
-  double* d_psum = nullptr;      // [nblk][npchunk][R0*P][2]
+  double* d_psum = nullptr;      // [nblk][n_c256][P][8][2]
+  double* d_pstat = nullptr;     // [nblk][P][8][2] column mean and 1/sd
   int32_t* d_info = nullptr;     // [4] deferred error flags: [0]=low variance, [1]=not SPD
   int32_t* d_bs = nullptr;       // [nblk]
   int32_t* d_blockid = nullptr;  // [nblk]
@@ -215,8 +216,8 @@ struct PredArgs {
   const int32_t* blockid; const double* neff; const int32_t* nmiss;
   double *beta, *cb, *psum, *W;
 };
-void rg_launch_l0_pred_impl(hipStream_t st, const PredArgs& a, const int32_t* chunk_seg,
-                            const int64_t* chunk_pos, const int64_t* chunk_len, int nchunk);
+struct ChunkTab { const int32_t* seg; const int64_t* pos; const int64_t* len; int n; };
+void rg_launch_l0_pred_impl(hipStream_t st, const PredArgs& a, const ChunkTab& c1k, const ChunkTab& c256, double* stats);
 void rg_launch_w_gather(hipStream_t st, const double* W, int64_t Np, int P, int p, int col0, int R0,
                         const int64_t* posc, int64_t N, double* out);
 void rg_launch_w_scatter(hipStream_t st, double* W, int64_t Np, int P, int p, int col0, int R0,
