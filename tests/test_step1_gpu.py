@@ -68,6 +68,17 @@ def test_missing_genotypes_and_phenotypes(tmp_path):
     _compare(orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=130))
 
 
+@pytest.mark.parametrize("P", [4, 7, 14])
+def test_many_phenotypes_matrix_core_predictions(tmp_path, P):
+    """R0*P > 16 prediction rows select the fp64-MFMA level-0 prediction kernel (2, 3 and 4 row blocks, and two
+    phenotype groups for P = 14): missing genotypes, missing phenotypes, ragged blocks, --remove-free file order."""
+    N, M = 1100, 420
+    g = synth_dosages(M, N, miss_rate=0.02, seed=31 + P)
+    pre = str(tmp_path / "mp")
+    write_plink(pre, g, np.repeat([1, 4, 9], [150, 150, 120]), P=P, ncov=2, seed=14, missing_pheno=0.04)
+    _compare(orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=110))
+
+
 def test_ref_first_and_three_folds(tmp_path):
     N, M = 640, 256
     g = synth_dosages(M, N, miss_rate=0.01, seed=5)
