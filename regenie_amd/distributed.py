@@ -24,24 +24,39 @@ def shard_blocks(n_blocks: int, world: int) -> List[Tuple[int, int]]:
 def allgather_w(W, shards: List[Tuple[int, int]], r0: int, group=None, force_broadcast: bool = False):
     """In-place all-gather of the level-0 predictors.
 
-    W: torch tensor [B*R0, P, Np] (float64), on every rank the columns of its own blocks are filled.
-    Each rank broadcasts its contiguous column slab; with uneven slabs this is a sequence of
-    broadcasts (RCCL schedules each as a direct xGMI transfer to the 7 peers), equal slabs use one
-    all_gather_into_tensor.
+    W: torch tensor [B*R0 (+ slack rows), P, Np] (float64); on every rank the columns of its own blocks are filled.
+    Equal slabs: one all_gather_into_tensor straight into W.  Uneven slabs (B not divisible by the world size:
+    the block counts differ by one): ONE all-gather of equal-size, zero-padded slabs into a staging tensor followed by
+    device-side copies of the valid rows -- RCCL drives all xGMI links at once, where a sequence of per-rank
+    broadcasts would serialise `world` transfers.  force_broadcast keeps the broadcast sequence (debug / comparison).
     """
+    import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if world == 1:
         return W
     rank = dist.get_rank(group)
     sizes = {nb for (_, nb) in shards}
-    if len(sizes) == 1 and shards[0][1] > 0 and not force_broadcast:
+    nmax = max(nb for (_, nb) in shards)
+    row_bytes = W[0].numel() * W.element_size()
+    stage_too_big = world * nmax * r0 * row_bytes > (16 << 30)   # a second copy of W must fit beside W (config 3: it does not)
+    if force_broadcast or (len(sizes) > 1 and stage_too_big):
+        for src, (b0, nb) in enumerate(shards):
+            if nb == 0:
+                continue
+            dist.broadcast(W[b0 * r0:(b0 + nb) * r0], src=src, group=group)
+        return W
+    if len(sizes) == 1 and shards[0][1] > 0:
         nb = shards[0][1]
         mine = W[shards[rank][0] * r0:(shards[rank][0] + nb) * r0]
         dist.all_gather_into_tensor(W[: world * nb * r0], mine.clone(), group=group)
         return W
-    for src, (b0, nb) in enumerate(shards):
-        if nb == 0:
-            continue
-        dist.broadcast(W[b0 * r0:(b0 + nb) * r0], src=src, group=group)
+    b0, nb = shards[rank]
+    mine = torch.zeros((nmax * r0,) + tuple(W.shape[1:]), dtype=W.dtype, device=W.device)
+    mine[: nb * r0] = W[b0 * r0:(b0 + nb) * r0]
+    stage = torch.empty((world * nmax * r0,) + tuple(W.shape[1:]), dtype=W.dtype, device=W.device)
+    dist.all_gather_into_tensor(stage, mine, group=group)
+    for src, (s0, sn) in enumerate(shards):
+        if sn > 0 and src != rank:
+            W[s0 * r0:(s0 + sn) * r0] = stage[src * nmax * r0: src * nmax * r0 + sn * r0]
     return W
