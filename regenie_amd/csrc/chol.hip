@@ -11,17 +11,25 @@
 // substitution happens for free as part of the panel/update steps (the RHS rows are just one more
 // row tile).  Padded diagonal entries are 1.
 //
-// Right-looking tile algorithm, tile 64: per step k
-//   k_chol_diag   : factor the 64x64 diagonal tile in LDS, also emit its inverse
-//   k_chol_panel  : L[t][k] = A[t][k] * inv(L[k][k])^T               (fp64 MFMA, NT form)
-//   k_chol_update : A[r][c] -= L[r][k] * L[c][k]^T  for k < c <= r    (fp64 MFMA, NT form)
-// then k_chol_backsolve (one workgroup per system) solves L^T x = y for the RHS rows.
+// Tile algorithm, tile 64, tile columns in groups of 4 (left-looking inside a group, right-looking between groups):
+//   k_chol_diag   : [in-group update of the tile,] factor the 64x64 diagonal tile in LDS (16x16x16 MFMA block
+//                   products), also emit its inverse
+//   k_chol_panel  : L[t][k] = (A[t][k] - sum_q L[t][q] L[k][q]^T) inv(L[k][k])^T, q over the group's earlier
+//                   columns; one wave per tile, the update accumulated transposed so that its result registers are
+//                   the A operand of the triangular multiply
+//   k_chol_update : A[r][c] -= sum_{q in group} L[r][q] L[c][q]^T  for the columns c beyond the group, K = 256
+// then k_chol_backsolve (one workgroup per system) solves L^T x = y for the RHS rows (HBM-bound: reads L once).
+// The systems are never materialised by a separate pass: the first kernel that touches a tile reads it from the
+// source matrices (FormSrc).
 //
 // fp64 MFMA (v_mfma_f64_16x16x4_f64): lane l supplies A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15]
 // and owns D[row = (l>>4) + 4*reg][col = l&15].  Both operands are K-contiguous rows here, and a
-// contraction is invariant under any K permutation applied to both operands alike, so lane (i, q)
-// takes the 16 CONSECUTIVE k = 16q .. 16q+15 of a 64-chunk (one 128-byte piece of its row): four
-// 32-byte global loads per row, no LDS staging.
+// contraction is invariant under any K permutation applied to both operands alike, so a lane takes a few
+// CONSECUTIVE k of a chunk (one 16- or 32-byte piece of its row) straight from HBM/L2, no LDS staging; the K loops
+// are software-pipelined over two register sets.
+// Every global load sits in straight-line code: hipcc turns a load under a data-dependent `if` into branch + load +
+// s_waitcnt vmcnt(0) (one full memory round trip each); conditions are applied to addresses (clamping) and values
+// (0/1 masks) instead.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -95,40 +103,6 @@ __global__ __launch_bounds__(256) void k_dgemm_nt(const double* A, int64_t lda, 
 void rg_launch_dgemm_nt(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                         int m, int n, int64_t k, double* C, int64_t ldc) {
   hipLaunchKernelGGL(k_dgemm_nt, dim3(n / CT, m / CT), dim3(256), 0, st, A, lda, B, ldb, k, C, ldc);
-}
-
-// ---- form: wk[(o, f, r)] = sum[o] - fold[o][f] + shift[r] on the diagonal ----------------------
-__global__ __launch_bounds__(256) void k_form(const double* sum, int64_t sum_stride,
-                                              const double* fold, int64_t fold_stride, int nfold,
-                                              const double* shift, int nshift, const int32_t* d_n,
-                                              int n_fixed, int n64, int rtot, double* wk) {
-  const int o = blockIdx.z;
-  const int f = blockIdx.y / nshift, r = blockIdx.y % nshift;
-  const int n = d_n ? d_n[o] : n_fixed;
-  const int64_t msz = (int64_t)rtot * n64;
-  const double* S = sum + (int64_t)o * sum_stride;
-  const double* F = fold + ((int64_t)o * nfold + f) * fold_stride;
-  double* W = wk + (((int64_t)o * nfold + f) * nshift + r) * msz;
-  const double sh = shift[r];
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < msz; e += (int64_t)gridDim.x * 256) {
-    const int i = (int)(e / n64), j = (int)(e % n64);
-    double v = 0.0;
-    if (i >= n64 || j <= i) {
-      v = S[e] - F[e];
-      if (i == j) v = (i < n) ? v + sh : 1.0;
-    }
-    W[e] = v;
-  }
-}
-
-void rg_launch_form(hipStream_t st, const double* sum, int64_t sum_stride, const double* fold,
-                    int64_t fold_stride, int nfold, const double* shift, int nshift,
-                    const int32_t* d_n, int n_fixed, int nouter, int n64, int rtot, double* wk) {
-  const int64_t msz = (int64_t)rtot * n64;
-  int gx = (int)((msz + 256 * 8 - 1) / (256 * 8));
-  if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(k_form, dim3(gx, nfold * nshift, nouter), dim3(256), 0, st, sum, sum_stride,
-                     fold, fold_stride, nfold, shift, nshift, d_n, n_fixed, n64, rtot, wk);
 }
 
 // ---- XCD-affine work order -----------------------------------------------------------------------
@@ -708,16 +682,6 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
 void rg_launch_chol_solve(hipStream_t st, double* mats, int64_t mat_stride, int batch, int n64,
                           int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch) {
   rg_launch_chol_solve_src(st, mats, mat_stride, batch, n64, rhs_pad, nrhs, dinv, info, n_launch, nullptr);
-}
-
-// Factor + solve the systems (sum[o] - fold[o][f] + shift[r] I) without materialising them first.
-void rg_launch_chol_solve_formed(hipStream_t st, const double* sum, int64_t sum_stride, const double* fold,
-                                 int64_t fold_stride, int nfold, const double* shift, int nshift,
-                                 const int32_t* d_n, int n_fixed, int nouter, double* mats,
-                                 int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
-                                 int32_t* info, int64_t* n_launch) {
-  rg_launch_chol_solve_formed_x(st, sum, sum_stride, fold, fold_stride, nfold, shift, nshift, d_n, n_fixed, nouter,
-                                mats, mat_stride, n64, rhs_pad, nrhs, dinv, info, n_launch, 1, nullptr, 0, 0, 1, 0, -1);
 }
 
 // General form: subtract = 0 drops the held-out-fold term (LOOCV); rows >= extra_row0 of every system are

@@ -187,16 +187,8 @@ struct AsmArgs {
 void rg_launch_rowstats(hipStream_t st, const AsmArgs& a);
 void rg_launch_assemble(hipStream_t st, const AsmArgs& a);
 // chol.hip
-void rg_launch_form(hipStream_t st, const double* sum, int64_t sum_stride, const double* fold,
-                    int64_t fold_stride, int nfold, const double* shift, int nshift, const int32_t* d_n,
-                    int n_fixed, int nouter, int n64, int rtot, double* wk);
 void rg_launch_chol_solve(hipStream_t st, double* mats, int64_t mat_stride, int batch, int n64,
                           int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch);
-void rg_launch_chol_solve_formed(hipStream_t st, const double* sum, int64_t sum_stride, const double* fold,
-                                 int64_t fold_stride, int nfold, const double* shift, int nshift,
-                                 const int32_t* d_n, int n_fixed, int nouter, double* mats,
-                                 int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
-                                 int32_t* info, int64_t* n_launch);
 void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t sum_stride, const double* fold,
                                    int64_t fold_stride, int nfold, const double* shift, int nshift,
                                    const int32_t* d_n, int n_fixed, int nouter, double* mats,
