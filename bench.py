@@ -80,7 +80,7 @@ def main():
     import torch
     import torch.distributed as dist
     from regenie_amd import hostprep as hp
-    from regenie_amd.distributed import allgather_w, shard_blocks
+    from regenie_amd.distributed import allgather_w, exchange_w_by_phenotype, shard_blocks, shard_phenotypes
     from regenie_amd.engine import Step1Engine, loco_from_predictions
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -168,18 +168,36 @@ def main():
             t.copy_(h)
         torch.cuda.synchronize()
 
-    if world > 1:
+    # N>1 hand-off of the level-0 predictors: with at least one phenotype per rank the ranks exchange predictor slabs
+    # BY PHENOTYPE (all-to-all, 1/world of the all-gather volume) and each runs level 1 for its own phenotypes; with
+    # fewer phenotypes than ranks W is all-gathered and level 1 is shared tile-wise (two all-reduces).
+    pheno_sharded = world > 1 and P >= world
+    pshards = shard_phenotypes(P, world) if pheno_sharded else None
+    if world > 1 and not pheno_sharded:
         eng.set_collective(world, rank, _allreduce)
 
     def step(exchange=True, solo=False):
         eng.l0_blocks_device(my_blocks, bss, ptrs, N // 4)
         eng.sync()
-        if world > 1 and exchange:
+        if pheno_sharded and not solo:
+            Wg = exchange_w_by_phenotype(Wv, shards, pshards, R0, via_host=(args.backend != "nccl"))
+            torch.cuda.synchronize()
+            q0, qn = pshards[rank]
+            eng.set_l1_view(Wg.data_ptr(), q0, qn)
+            cs, best, pred = eng.l1_qt(tau[q0:q0 + qn], cols_per_chr)
+            eng.set_l1_view(None, 0, P)
+            mine = ([loco_from_predictions(pred[p], chroms) for p in range(qn)], cs, [int(b) for b in best])
+            gathered = [None] * world                        # small per-phenotype summaries; predictions stay on their rank
+            dist.all_gather_object(gathered, (float(sum(np.abs(l).sum() for l in mine[0])), mine[2]))
+            return (mine[0], cs, [b for g in gathered for b in g[1]], sum(g[0] for g in gathered))
+        if world > 1 and exchange and not pheno_sharded:
             allgather_w(Wv, shards, R0, force_broadcast=(args.backend != "nccl"))
             torch.cuda.synchronize()
         out = None
         if solo:                                            # rank-0-only timing pass: no collective may be issued
             eng.set_collective(1, 0, None)
+            if pheno_sharded:
+                return None                                 # W is not gathered in this mode: level 0 only
         if rank == 0 or (world > 1 and not solo):           # N>1: level 1 is shared among the ranks
             cs, best, pred = eng.l1_qt(tau, cols_per_chr)
             out = [loco_from_predictions(pred[p], chroms) for p in range(P)], cs, best
@@ -266,9 +284,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": "synthetic PLINK bed %d samples x %d SNPs (%d per GPU), %d QT pheno, bsize %d, 22 chromosomes, 5-fold CV, 5x5 ridge grid"
                        % (N, M, args.snps, P, bsize), "samples": N, "snps": M, "phenos": P, "bsize": bsize, "blocks": B,
-                       "parallelism": "blocks sharded x%d, all-gather of W, level-1 Gram tiles / ridge systems shared x%d" % (world, world)},
+                       "parallelism": ("blocks sharded x%d, all-to-all of W by phenotype, level 1 phenotype-sharded x%d" if pheno_sharded else
+                                       "blocks sharded x%d, all-gather of W, level-1 Gram tiles / ridge systems shared x%d") % (world, world)},
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
-            "loco_checksum": float(sum(np.abs(l).sum() for l in res[0])), "selected_tau_index": [int(b) for b in res[2]],
+            "loco_checksum": float(res[3]) if len(res) > 3 else float(sum(np.abs(l).sum() for l in res[0])),
+            "selected_tau_index": [int(b) for b in res[2]],
             "setup_s": {"generate": t_gen},
         }
         print(json.dumps(line))

@@ -124,6 +124,15 @@ int rg_l1_qt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, int32_t nchr,
 typedef int (*rg_allreduce_fn)(void* user, void* dev_ptr, int64_t n_doubles);
 int rg_set_collective(rg_ctx* ctx, int32_t world, int32_t rank, rg_allreduce_fn fn, void* user);
 
+/* ---- phenotype-sharded level 1 (optional) ------------------------------------------------------------
+ * With P >= world phenotypes the ranks can exchange predictor slabs by phenotype instead of all-gathering W:
+ * rank g receives, from every rank, the columns of that rank's blocks for ITS phenotypes only (an all-to-all
+ * of 1/world of the all-gather volume) into a buffer laid out [L][count][Np] (Np = rg_w_rows), and then runs
+ * the level-1 entry points on that phenotype range.  tau / yraw / offset inputs and every output of the
+ * rg_l1_* calls are then arrays for `pheno_count` phenotypes.  w_dev = NULL with the full range restores the
+ * default view (the context's own W, all phenotypes). */
+int rg_set_l1_view(rg_ctx* ctx, const void* w_dev, int32_t pheno_begin, int32_t pheno_count);
+
 /* ---- level 1, quantitative traits, leave-one-out CV ------------------------------------------
  * Replaces ridge_level_1_loocv (Step1_Models.cpp:875-962), the tau selection of Data::output and
  * make_predictions_loocv (Data.cpp:1269-1342).  Requires a problem set up with cv_folds = 0.

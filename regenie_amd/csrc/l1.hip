@@ -217,11 +217,15 @@ __global__ __launch_bounds__(256) void k_l1_pred(L1Rows R, const double* alpha /
 
 int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_t* cols_per_chr,
                   double* cumsum_out, int32_t* best_out, double* pred_out) {
-  if (!ctx->have_problem || !ctx->d_W) { ctx->err = "rg_l1_qt: no level-0 predictors"; return RG_ERR_STATE; }
+  if (!ctx->have_problem || !(ctx->d_W || ctx->v_W)) { ctx->err = "rg_l1_qt: no level-0 predictors"; return RG_ERR_STATE; }
   if (R1 < 1 || R1 > R1MAX) { ctx->err = "rg_l1_qt: n_ridge_l1 must be in [1,8]"; return RG_ERR_ARG; }
   if (ctx->loocv) { ctx->err = "rg_l1_qt: the problem was set up for LOOCV (use rg_l1_qt_loocv)"; return RG_ERR_STATE; }
   hipStream_t st = ctx->stream;
-  const int L = ctx->B_total * ctx->R0, P = ctx->P, K = ctx->K;
+  const int L = ctx->B_total * ctx->R0, K = ctx->K;
+  // phenotype view (rg_set_l1_view): local phenotype p <-> global pg = v_p0 + p; predictors read from v_W laid out
+  // [L][v_np][Np] when a view buffer is set, else from the context's W [L][P][Np]
+  const double* Wv = ctx->v_W ? ctx->v_W : ctx->d_W;
+  const int Pv = ctx->v_W ? ctx->v_np : ctx->P, P = ctx->v_np, p0v = ctx->v_p0;
   int ltot = 0;
   std::vector<int32_t> col0(nchr + 1, 0);
   for (int c = 0; c < nchr; ++c) { col0[c + 1] = col0[c] + cols_per_chr[c]; }
@@ -273,7 +277,8 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
   };
 
   for (int p = 0; p < P && rc == RG_OK; ++p) {
-    L1Rows R{ctx->d_W, ctx->d_V + (int64_t)(ctx->C + p) * ctx->Np, ctx->d_zero, ctx->Np, L, P, p, n64};
+    const int pg = p0v + p, pw = ctx->v_W ? p : pg;
+    L1Rows R{Wv, ctx->d_V + (int64_t)(ctx->C + pg) * ctx->Np, ctx->d_zero, ctx->Np, L, Pv, pw, n64};
     hipEvent_t e0 = ctx->ev0, e1 = ctx->ev1;
     if (ctx->timing) hipEventRecord(e0, st);
     // ---- fold Grams X_f = W_f^T W_f with W_f^T y_f as an extra row ------------------------------------------
@@ -327,7 +332,7 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
     // Data.cpp:1025-1037: first minimum of (Sx2 + Sy2 - 2 Sxy) / Neff
     int best = 0; double minv = 1e10;
     for (int j = 0; j < R1; ++j) {
-      const double perf = (cs[2 * R1 + j] + cs[3 * R1 + j] - 2 * cs[4 * R1 + j]) / ctx->neff[p];
+      const double perf = (cs[2 * R1 + j] + cs[3 * R1 + j] - 2 * cs[4 * R1 + j]) / ctx->neff[pg];
       if (perf < minv) { best = j; minv = perf; }
     }
     best_out[p] = best;

@@ -412,7 +412,8 @@ struct DevBufs {
 
 struct L1Common {
   rg_ctx* ctx; hipStream_t st;
-  int L, P, n64, rtot, T, nchr;
+  int L, P, n64, rtot, T, nchr;   // P: phenotypes of the current view
+  const double* Wv; int Pv, p0v; bool view;   // predictor buffer / its phenotype stride / first global phenotype
   int64_t msz, Np, N;
   std::vector<int32_t> col0;
   int32_t* d_col0 = nullptr;
@@ -421,9 +422,10 @@ struct L1Common {
 };
 
 int l1_common_init(rg_ctx* ctx, L1Common& c, int nchr, const int32_t* cols_per_chr, const char* who) {
-  if (!ctx->have_problem || !ctx->d_W) { ctx->err = std::string(who) + ": no level-0 predictors"; return RG_ERR_STATE; }
+  if (!ctx->have_problem || !(ctx->d_W || ctx->v_W)) { ctx->err = std::string(who) + ": no level-0 predictors"; return RG_ERR_STATE; }
   c.ctx = ctx; c.st = ctx->stream;
-  c.L = ctx->B_total * ctx->R0; c.P = ctx->P; c.Np = ctx->Np; c.N = ctx->N; c.nchr = nchr;
+  c.L = ctx->B_total * ctx->R0; c.P = ctx->v_np; c.Np = ctx->Np; c.N = ctx->N; c.nchr = nchr;
+  c.view = ctx->v_W != nullptr; c.Wv = c.view ? ctx->v_W : ctx->d_W; c.Pv = c.view ? ctx->v_np : ctx->P; c.p0v = ctx->v_p0;
   c.col0.assign(nchr + 1, 0);
   for (int i = 0; i < nchr; ++i) c.col0[i + 1] = c.col0[i] + cols_per_chr[i];
   if (c.col0[nchr] != c.L) { ctx->err = std::string(who) + ": cols_per_chr does not sum to n_blocks*R0"; return RG_ERR_ARG; }
@@ -495,11 +497,12 @@ int rg_l1_qt_loocv_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const 
   std::vector<double> hpart((size_t)gpos * LOO_NPART);
 
   for (int p = 0; p < P; ++p) {
-    const double* d_y = ctx->d_V + (int64_t)(ctx->C + p) * Np;
+    const int pg = c.p0v + p, pw = c.view ? p : pg;   // global phenotype / index inside the predictor buffer
+    const double* d_y = ctx->d_V + (int64_t)(ctx->C + pg) * Np;
     // G = W^T W with W^T y as row n64 (xtx, zvec of Step1_Models.cpp:893-907)
-    WgArgs g{ctx->d_W, ctx->d_zero, Np, L, P, p, n64, nullptr, d_y, nullptr, nullptr, 0, d_G, c.msz};
+    WgArgs g{c.Wv, ctx->d_zero, Np, L, c.Pv, pw, n64, nullptr, d_y, nullptr, nullptr, 0, d_G, c.msz};
     hipLaunchKernelGGL(k_wgram, dim3((T * (T + 1) / 2 + T + 3) / 4, 1), dim3(256), 0, st, g, ctx->seg, T);
-    hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, ctx->d_W, Np, L, P, p,
+    hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, c.Wv, Np, L, c.Pv, pw,
                        n64, d_Wt);
     L1X_HIP(hipMemcpyAsync(d_tau, tau + (int64_t)p * R1, sizeof(double) * R1, hipMemcpyHostToDevice, st));
     rc = invert_shifted(ctx, c, d_G, d_tau, R1, d_eye, d_sysI, d_dinv, d_H);
@@ -507,7 +510,7 @@ int rg_l1_qt_loocv_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const 
     const double* d_z = d_G + (int64_t)n64 * n64;  // W^T y (padded with zeros to n64)
     double* cs = cumsum_out + (int64_t)p * 5 * R1;
     for (int t = 0; t < 5 * R1; ++t) cs[t] = 0.0;
-    LooArgs la{ctx->d_W, d_Ut, d_b, Np, L, P, p, d_y, nullptr, nullptr, nullptr, nullptr, 0};
+    LooArgs la{c.Wv, d_Ut, d_b, Np, L, c.Pv, pw, d_y, nullptr, nullptr, nullptr, nullptr, 0};
     auto prepare = [&](int j) {
       const double* H = d_H + (int64_t)j * n64 * n64;
       hipLaunchKernelGGL(k_symv, dim3((n64 + 3) / 4), dim3(256), 0, st, H, d_z, n64, d_b);
@@ -524,14 +527,14 @@ int rg_l1_qt_loocv_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const 
       }
       cs[0 * R1 + j] = sx; cs[2 * R1 + j] = sx2; cs[4 * R1 + j] = sxy;
       cs[1 * R1 + j] = 0.0;                                  // Sy preset (Step1_Models.cpp:890)
-      cs[3 * R1 + j] = ctx->neff[p] - ctx->C;                // Sy2 = Neff - ncov (:891)
+      cs[3 * R1 + j] = ctx->neff[pg] - ctx->C;               // Sy2 = Neff - ncov (:891)
     }
     bool bad = false;
     if ((rc = check_spd(ctx, &bad))) return rc;
     if (bad) { ctx->err = "level 1 ridge system is not positive definite"; return RG_ERR_NOT_SPD; }
     int best = 0; double minv = 1e10;
     for (int j = 0; j < R1; ++j) {
-      const double perf = (cs[2 * R1 + j] + cs[3 * R1 + j] - 2 * cs[4 * R1 + j]) / ctx->neff[p];
+      const double perf = (cs[2 * R1 + j] + cs[3 * R1 + j] - 2 * cs[4 * R1 + j]) / ctx->neff[pg];
       if (perf < minv) { best = j; minv = perf; }
     }
     best_out[p] = best;
@@ -599,7 +602,7 @@ int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<doub
   const int na = (int)act.size();
   L1X_HIP(hipMemcpyAsync(s.d_map, act.data(), sizeof(int32_t) * na, hipMemcpyHostToDevice, st));
   L1X_HIP(hipMemcpyAsync(s.d_tauc, tauc.data(), sizeof(double) * s.nchain, hipMemcpyHostToDevice, st));
-  WgArgs g{ctx->d_W, ctx->d_zero, c.Np, c.L, c.P, s.p, c.n64, s.a.wv, rhs_is_score ? nullptr : s.a.zv, s.d_tauc,
+  WgArgs g{c.Wv, ctx->d_zero, c.Np, c.L, c.Pv, s.p, c.n64, s.a.wv, rhs_is_score ? nullptr : s.a.zv, s.d_tauc,
            s.d_map, s.a.kfold, s.d_sys, c.msz};
   hipLaunchKernelGGL(k_wgram, dim3((c.T * (c.T + 1) / 2 + c.T + 3) / 4, na), dim3(256), 0, st, g, ctx->seg, c.T);
   if (rhs_is_score)
@@ -727,8 +730,9 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
     to_pos(ctx, offset + (int64_t)p * N, hpos);
     L1X_HIP(hipMemcpyAsync(d_off, hpos.data(), sizeof(double) * Np, hipMemcpyHostToDevice, st));
     L1X_HIP(hipStreamSynchronize(st));
-    s.p = p;
-    s.a = BtArgs{ctx->d_W, Np, L, P, p, n64, d_yraw, d_off, ctx->d_maskp + (int64_t)p * Np, s.d_beta, nchain,
+    const int pg = c.p0v + p, pw = c.view ? p : pg;   // global phenotype / index inside the predictor buffer
+    s.p = pw;
+    s.a = BtArgs{c.Wv, Np, L, c.Pv, pw, n64, d_yraw, d_off, ctx->d_maskp + (int64_t)pg * Np, s.d_beta, nchain,
                  loocv ? 0 : 1, d_wv, d_zv, d_rv};
     bool ok = true;
 
@@ -783,23 +787,23 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
       converged_out[p] = 1;
       int best = 0; double minv = 1e10;
       for (int j = 0; j < R1; ++j) {
-        const double perf = cs[5 * R1 + j] / ctx->neff[p];   // -logLik / Neff (Data.cpp:1030)
+        const double perf = cs[5 * R1 + j] / ctx->neff[pg];  // -logLik / Neff (Data.cpp:1030)
         if (perf < minv) { best = j; minv = perf; }
       }
       best_out[p] = best;
       L1X_HIP(hipMemcpyAsync(d_betas, hbetas.data(), sizeof(double) * hbetas.size(), hipMemcpyHostToDevice, st));
       L1X_HIP(hipMemsetAsync(c.d_pred, 0, sizeof(double) * (size_t)nchr * N, st));
-      hipLaunchKernelGGL(k_fold_pred, dim3(ctx->n_c256), dim3(256), sizeof(double) * L, st, ctx->d_W, Np, L, P, p,
+      hipLaunchKernelGGL(k_fold_pred, dim3(ctx->n_c256), dim3(256), sizeof(double) * L, st, c.Wv, Np, L, c.Pv, pw,
                          d_betas + (int64_t)best * n64, (int64_t)R1 * n64, ctx->d_c256_seg, ctx->d_c256_pos,
                          ctx->d_c256_len, c.d_col0, nchr, ctx->d_cidx, N, c.d_pred);
     } else {
       // ---- LOOCV: warm-started Newton per tau, then the leave-one-out shortcut -----------------------------
-      hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, ctx->d_W, Np, L, P, p,
+      hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, c.Wv, Np, L, c.Pv, pw,
                          n64, d_Wt);
       std::vector<double> beta((size_t)n64, 0.0);
-      LooArgs la{ctx->d_W, d_Ut, s.d_beta, Np, L, P, p, d_yraw, d_rv, d_wv, d_off, ctx->d_maskp + (int64_t)p * Np, 1};
+      LooArgs la{c.Wv, d_Ut, s.d_beta, Np, L, c.Pv, pw, d_yraw, d_rv, d_wv, d_off, ctx->d_maskp + (int64_t)pg * Np, 1};
       auto loo_setup = [&](double lam) -> int {   // H = (X^T W X + lam I)^-1 at the current weights, U^T = H W^T
-        WgArgs g{ctx->d_W, ctx->d_zero, Np, L, P, p, n64, d_wv, nullptr, nullptr, nullptr, 0, d_G, c.msz};
+        WgArgs g{c.Wv, ctx->d_zero, Np, L, c.Pv, pw, n64, d_wv, nullptr, nullptr, nullptr, 0, d_G, c.msz};
         hipLaunchKernelGGL(k_wgram, dim3((T * (T + 1) / 2 + T + 3) / 4, 1), dim3(256), 0, st, g, ctx->seg, T);
         L1X_HIP(hipMemcpyAsync(d_tau1, &lam, sizeof(double), hipMemcpyHostToDevice, st));
         L1X_HIP(hipStreamSynchronize(st));
@@ -826,7 +830,7 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
       converged_out[p] = 1;
       int best = 0; double minv = 1e10;
       for (int j = 0; j < R1; ++j) {
-        const double perf = cs[5 * R1 + j] / ctx->neff[p];
+        const double perf = cs[5 * R1 + j] / ctx->neff[pg];
         if (perf < minv) { best = j; minv = perf; }
       }
       best_out[p] = best;

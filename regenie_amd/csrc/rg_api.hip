@@ -280,6 +280,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if (ctx->own_W && ctx->d_W) { hipFree(ctx->d_W); }
   ctx->d_W = nullptr; ctx->own_W = false;
   ctx->block_done.assign(ctx->B_total, 0);
+  ctx->v_W = nullptr; ctx->v_p0 = 0; ctx->v_np = P;
   ctx->have_problem = true;
   memset(&ctx->tm, 0, sizeof(ctx->tm));
   // second pipeline (see rg_ctx::twin); RG_PIPELINES=1 keeps a single one
@@ -557,6 +558,14 @@ int rg_l1_bt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, const double* y
   if (rc) return rc;
   return rg_l1_bt_impl(ctx, n_ridge_l1, tau, yraw, offset, opt, nchr, cols_per_chr, cumsum_out, converged_out,
                        best_out, pred_out);
+}
+
+int rg_set_l1_view(rg_ctx* ctx, const void* w_dev, int32_t pheno_begin, int32_t pheno_count) {
+  if (!ctx || !ctx->have_problem) return RG_ERR_STATE;
+  if (pheno_begin < 0 || pheno_count < 1 || pheno_begin + pheno_count > ctx->P) { ctx->err = "rg_set_l1_view: phenotype range out of bounds"; return RG_ERR_ARG; }
+  if (!w_dev && (pheno_begin != 0 || pheno_count != ctx->P)) { ctx->err = "rg_set_l1_view: a phenotype subset needs its own predictor buffer"; return RG_ERR_ARG; }
+  ctx->v_W = (const double*)w_dev; ctx->v_p0 = pheno_begin; ctx->v_np = pheno_count;
+  return RG_OK;
 }
 
 int rg_set_collective(rg_ctx* ctx, int32_t world, int32_t rank, rg_allreduce_fn fn, void* user) {

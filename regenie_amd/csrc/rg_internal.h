@@ -109,6 +109,11 @@ struct rg_ctx {
   std::vector<const uint8_t*> h_rawptr;
   std::vector<int> block_done;
 
+  // level-1 phenotype view (rg_set_l1_view): phenotypes [v_p0, v_p0 + v_np) with predictors in v_W [L][v_np][Np]
+  // (v_W == nullptr: the context's own W with all P phenotypes)
+  const double* v_W = nullptr;
+  int v_p0 = 0, v_np = 0;
+
   // multi-GPU level 1: tile-sharded Gram and system-sharded solves, completed by caller-provided all-reduces
   int coll_world = 1, coll_rank = 0;
   rg_allreduce_fn coll_allreduce = nullptr;

@@ -60,3 +60,40 @@ def allgather_w(W, shards: List[Tuple[int, int]], r0: int, group=None, force_bro
         if sn > 0 and src != rank:
             W[s0 * r0:(s0 + sn) * r0] = stage[src * nmax * r0: src * nmax * r0 + sn * r0]
     return W
+
+
+def shard_phenotypes(n_pheno: int, world: int) -> List[Tuple[int, int]]:
+    """[(first_phenotype, count)] per rank, contiguous and balanced (same rule as shard_blocks)."""
+    return shard_blocks(n_pheno, world)
+
+
+def exchange_w_by_phenotype(W, shards: List[Tuple[int, int]], pshards: List[Tuple[int, int]], r0: int, group=None,
+                            via_host: bool = False):
+    """Phenotype-sharded hand-off of the level-0 predictors: ONE all-to-all in which rank r sends to rank g
+    the predictor rows of r's blocks for g's phenotypes only -- 1/world of the all-gather volume -- and every rank ends
+    up with W_g [L, count_g, Np], the layout the library's level-1 view expects (rg_set_l1_view).
+
+    W: [B*R0, P, Np] with this rank's block columns filled.  Returns the received tensor (None if this rank owns no
+    phenotype).  via_host stages the exchange through host memory (gloo test mode)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    b0, nb = shards[rank]
+    P, Np = W.shape[1], W.shape[2]
+    mine = W[b0 * r0:(b0 + nb) * r0]                                     # [nb*R0, P, Np]
+    send = torch.cat([mine[:, q0:q0 + qn, :].reshape(-1) for (q0, qn) in pshards]) if nb > 0 else W.new_empty(0)
+    in_split = [nb * r0 * qn * Np for (_, qn) in pshards]
+    q0, qn = pshards[rank]
+    out_split = [sn * r0 * qn * Np for (_, sn) in shards]
+    recv = torch.empty(sum(out_split), dtype=W.dtype, device=W.device)
+    if via_host:
+        hs, hr = send.cpu(), torch.empty(sum(out_split), dtype=W.dtype)
+        dist.all_to_all_single(hr, hs, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+        recv.copy_(hr)
+    else:
+        dist.all_to_all_single(recv, send, output_split_sizes=out_split, input_split_sizes=in_split, group=group)
+    if qn == 0:
+        return None
+    L = sum(sn for (_, sn) in shards) * r0
+    return recv.view(L, qn, Np)

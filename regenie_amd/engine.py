@@ -49,7 +49,7 @@ class RgTiming(C.Structure):
 
 EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_w_rows", "rg_w_bytes",
            "rg_set_w_buffer", "rg_w_device_ptr", "rg_l0_blocks", "rg_sync", "rg_l0_get_w",
-           "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_set_collective", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
+           "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_set_collective", "rg_set_l1_view", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
            "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak"]
 
 
@@ -90,6 +90,7 @@ def load_library() -> C.CDLL:
     lib.rg_l1_bt.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rg_set_collective.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rg_set_l1_view.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.rg_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.rg_get_timing.argtypes = [C.c_void_p, C.POINTER(RgTiming)]
     lib.rg_k_gram_i8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
@@ -172,6 +173,7 @@ class Step1Engine:
         p.n_blocks_total, p.max_block_size = int(n_blocks_total), int(max_block_size)
         self._check(self.lib.rg_set_problem(self.h, C.byref(p)))
         self.N, self.P, self.R0, self.B = N, P, lam.size, int(n_blocks_total)
+        self.Pv = P                       # phenotypes of the current level-1 view
         self.n_file = int(n_file)
 
     @property
@@ -220,7 +222,7 @@ class Step1Engine:
         """tau: (P, R1) scaled ridge values.  Returns (cumsum [P,5,R1], best [P], pred [P][N,nchr])."""
         tau = np.ascontiguousarray(tau, dtype=np.float64)
         P, R1 = tau.shape
-        assert P == self.P
+        assert P == self.Pv
         cpc = np.ascontiguousarray(cols_per_chr, dtype=np.int32)
         nchr = cpc.size
         cs = np.zeros((P, 5, R1))
@@ -234,7 +236,7 @@ class Step1Engine:
         """Leave-one-out level 1 (problem set up with cv_sizes=None).  Same returns as l1_qt."""
         tau = np.ascontiguousarray(tau, dtype=np.float64)
         P, R1 = tau.shape
-        assert P == self.P
+        assert P == self.Pv
         cpc = np.ascontiguousarray(cols_per_chr, dtype=np.int32)
         nchr = cpc.size
         cs = np.zeros((P, 5, R1))
@@ -251,7 +253,7 @@ class Step1Engine:
         Returns (cumsum [P,6,R1], converged [P] bool, best [P], pred [P][N,nchr])."""
         tau = np.ascontiguousarray(tau, dtype=np.float64)
         P, R1 = tau.shape
-        assert P == self.P
+        assert P == self.Pv
         yraw = np.asfortranarray(yraw, dtype=np.float64)
         offset = np.asfortranarray(offset, dtype=np.float64)
         assert yraw.shape == (self.N, P) and offset.shape == (self.N, P)
@@ -266,6 +268,12 @@ class Step1Engine:
                                       C.byref(o), nchr, cpc.ctypes.data, cs.ctypes.data, conv.ctypes.data,
                                       best.ctypes.data, pred.ctypes.data))
         return cs, conv.astype(bool), best, [pred[p].T.copy() for p in range(P)]
+
+    def set_l1_view(self, w_dev_ptr, pheno_begin: int, pheno_count: int):
+        """Phenotype-sharded level 1: the following l1_* calls work on phenotypes [begin, begin+count) and read the
+        predictors from the device buffer w_dev_ptr laid out [L][count][w_rows]; (None, 0, P) restores the default."""
+        self._check(self.lib.rg_set_l1_view(self.h, C.c_void_p(w_dev_ptr) if w_dev_ptr else None, pheno_begin, pheno_count))
+        self.Pv = pheno_count
 
     def set_collective(self, world: int, rank: int, allreduce=None):
         """Shares level 1 among `world` ranks.  allreduce(dev_ptr: int, n_doubles: int) must sum the device

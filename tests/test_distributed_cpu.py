@@ -57,3 +57,34 @@ def test_allgather_w_gloo_world2(B):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True), (1, True)]
+
+
+def _worker_a2a(rank, world, port, B, R0, P, Np, q):
+    from regenie_amd.distributed import exchange_w_by_phenotype, shard_phenotypes
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shards = shard_blocks(B, world)
+    pshards = shard_phenotypes(P, world)
+    full = torch.arange(B * R0 * P * Np, dtype=torch.float64).view(B * R0, P, Np)
+    W = torch.zeros_like(full)
+    b0, nb = shards[rank]
+    W[b0 * R0:(b0 + nb) * R0] = full[b0 * R0:(b0 + nb) * R0]             # each rank fills only its own block columns
+    Wg = exchange_w_by_phenotype(W, shards, pshards, R0)
+    q0, qn = pshards[rank]
+    q.put((rank, bool(torch.equal(Wg, full[:, q0:q0 + qn, :])) and tuple(Wg.shape) == (B * R0, qn, Np)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,P", [(6, 4), (7, 3)])                       # even / uneven block and phenotype shards
+def test_exchange_w_by_phenotype_gloo_world2(B, P):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_a2a, args=(r, 2, port, B, 5, P, 64, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(0, True), (1, True)]

@@ -31,8 +31,11 @@ def _line(out):
     raise AssertionError(out)
 
 
-def test_two_ranks_equal_one_rank():
-    common = ["--samples", "2048", "--bsize", "200", "--steps", "1", "--warmup", "0", "--no-cpu"]
+@pytest.mark.parametrize("phenos", [1, 4])
+def test_two_ranks_equal_one_rank(phenos):
+    """phenos = 1: W all-gathered, level 1 shared tile-wise (all-reduce callback).  phenos = 4 (>= world): predictor
+    slabs exchanged by phenotype (all-to-all), each rank runs level 1 for its own two phenotypes (rg_set_l1_view)."""
+    common = ["--samples", "2048", "--bsize", "200", "--steps", "1", "--warmup", "0", "--no-cpu", "--phenos", str(phenos)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--snps", "3000"] + common,
                         capture_output=True, text=True, timeout=600, env=env)
