@@ -189,7 +189,7 @@ int rg_k_gram_fp4(void* stream, const uint8_t* A4, int64_t lda, const uint8_t* B
  * (A x = rhs).  n_pad and rhs_pad multiples of 64. */
 int rg_k_chol_solve(void* stream, double* mats, int64_t mat_stride, int32_t batch, int32_t n_pad,
                     int32_t rhs_pad, int32_t nrhs /* valid RHS rows <= rhs_pad */,
-                    double* dinv_ws /* batch*(n_pad/64)*4096 doubles */,
+                    double* dinv_ws /* batch*(T + 10*ceil(T/4))*4096 doubles, T = n_pad/64 */,
                     int32_t* info /* device int, set !=0 if not SPD */);
 /* C[m][n] = sum_k A[m][k]*B[n][k] (fp64 MFMA, row-major, K multiple of 64, m,n multiples of 64) */
 int rg_k_dgemm_nt(void* stream, const double* A, int64_t lda, const double* B, int64_t ldb,

@@ -183,71 +183,13 @@ __device__ __forceinline__ double bcast_lane(double x, int l) {
   return __hiloint2double(hi, lo);
 }
 
-// Left-looking inside a column group: before factoring, the tile is updated with the group's earlier tile
-// columns [kc0, kc0 + nkc):  A[k][k] -= sum_q L[k][q] L[k][q]^T  (fp64 MFMA, operands straight from HBM/L2).
-__global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_stride, int n64, int k, int kc0,
-                                                   int nkc, double* dinv, int32_t* info, FormSrc fs) {
-  // ONE 64 x 66 LDS array holds both results (34 KB -> 4 workgroups per CU, a whole 800-system batch resident):
-  //   lower triangle + diagonal : L            strict upper triangle : Linv^T  (Linv[r][c] at s[c][r], r > c)
-  //   dv[r] = Linv[r][r] = 1 / L[r][r]
-  __shared__ double s[CT][CT + 2];
-  __shared__ double dv[CT];
-  const int b = blockIdx.x;
+// ---- blocked (16) factorization + inverse of the 64x64 tile held in LDS (lower triangle of s), 256 threads -------
+// On return: lower triangle + diagonal of s = L, strict upper triangle = Linv^T, dv[r] = Linv[r][r].
+// Returns true (in some thread) when a pivot was not positive.
+__device__ __forceinline__ bool diag_factor_lds(double (&s)[CT][CT + 2], double (&dv)[CT]) {
   const int tid = threadIdx.x;
-  double* D = mats + (int64_t)b * mat_stride + (int64_t)k * CT * n64 + k * CT;
-  if (fs.enabled) {
-    const FormIdx fx = form_idx(fs, b);
-    const int md = form_mode(fx);
-#pragma unroll
-    for (int u = 0; u < CT * CT / 256; ++u) {   // unconditional loads (the upper triangle of the source exists), then select
-      const int e = tid + 256 * u;
-      const int r = e >> 6, c = e & 63;
-      const int gi = k * CT + r, gj = k * CT + c;
-      const int64_t ge = (int64_t)gi * n64 + gj;
-      const double v = md == 0 ? form_val<0>(fx, gi, gj, ge) : (md == 1 ? form_val<1>(fx, gi, gj, ge) : form_val<2>(fx, gi, gj, ge));
-      s[r][c] = (c <= r) ? v : 0.0;
-    }
-  } else {
-#pragma unroll
-    for (int u = 0; u < CT * CT / 256; ++u) {
-      const int e = tid + 256 * u;
-      const int r = e >> 6, c = e & 63;
-      const double v = D[(int64_t)r * n64 + c];
-      s[r][c] = (c <= r) ? v : 0.0;
-    }
-  }
-  __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lq = lane >> 4;
-  if (nkc > 0) {
-    const int wr = wave >> 1, wc = wave & 1;
-    const int i = li, q = lq;
-    const double* Mrow = mats + (int64_t)b * mat_stride + (int64_t)k * CT * n64 + (int64_t)kc0 * CT + 16 * q;
-    v4d acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int n = 0; n < 2; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
-    if (wc <= wr) {   // the strictly upper 32x32 block is never referenced
-      for (int kk = 0; kk < nkc; ++kk) {
-        const double* ar[2] = {Mrow + (int64_t)(wr * 32 + i) * n64 + kk * CT, Mrow + (int64_t)(wr * 32 + 16 + i) * n64 + kk * CT};
-        const double* br[2] = {Mrow + (int64_t)(wc * 32 + i) * n64 + kk * CT, Mrow + (int64_t)(wc * 32 + 16 + i) * n64 + kk * CT};
-        double av[2][16], bv[2][16];
-        dmma_load<2, 2>(ar, br, av, bv);
-        dmma_fma<2, 2>(av, bv, acc);
-      }
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int rr = wr * 32 + m * 16 + q + 4 * r, cc = wc * 32 + n * 16 + i;
-            if (cc <= rr) s[rr][cc] -= acc[m][n][r];
-          }
-    }
-    __syncthreads();
-  }
   // ---- blocked (16) factorization + inverse, the 16x16x16 block products on the fp64 MFMA ---------------
   // MFMA 16x16x4: lane (i = lane&15, q = lane>>4) supplies A[i][kk], B[kk][i] and owns D[q + 4r][i], r = 0..3;
   // a K = 16 block product is 4 instructions with kk(q, s) chosen per product (any permutation of K is fine
@@ -337,7 +279,6 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_str
     }
     __syncthreads();
   }
-  if (bad) atomicMax(info, 1);
   // off-diagonal blocks of the inverse (i > j), by sub-diagonal distance:
   //   Linv[i][j] = -Linv[i][i] * sum_{kb=j}^{i-1} L[i][kb] Linv[kb][j]      (Linv[kb][j] at s[16j + .][16kb + .]^T)
   for (int dist = 1; dist < 4; ++dist) {
@@ -362,6 +303,75 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_str
     }
     __syncthreads();
   }
+  return bad;
+}
+
+// Left-looking inside a column group: before factoring, the tile is updated with the group's earlier tile
+// columns [kc0, kc0 + nkc):  A[k][k] -= sum_q L[k][q] L[k][q]^T  (fp64 MFMA, operands straight from HBM/L2).
+__global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_stride, int n64, int k, int kc0,
+                                                   int nkc, double* dinv, int32_t* info, FormSrc fs) {
+  // ONE 64 x 66 LDS array holds both results (34 KB -> 4 workgroups per CU, a whole 800-system batch resident):
+  //   lower triangle + diagonal : L            strict upper triangle : Linv^T  (Linv[r][c] at s[c][r], r > c)
+  //   dv[r] = Linv[r][r] = 1 / L[r][r]
+  __shared__ double s[CT][CT + 2];
+  __shared__ double dv[CT];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  double* D = mats + (int64_t)b * mat_stride + (int64_t)k * CT * n64 + k * CT;
+  if (fs.enabled) {
+    const FormIdx fx = form_idx(fs, b);
+    const int md = form_mode(fx);
+#pragma unroll
+    for (int u = 0; u < CT * CT / 256; ++u) {   // unconditional loads (the upper triangle of the source exists), then select
+      const int e = tid + 256 * u;
+      const int r = e >> 6, c = e & 63;
+      const int gi = k * CT + r, gj = k * CT + c;
+      const int64_t ge = (int64_t)gi * n64 + gj;
+      const double v = md == 0 ? form_val<0>(fx, gi, gj, ge) : (md == 1 ? form_val<1>(fx, gi, gj, ge) : form_val<2>(fx, gi, gj, ge));
+      s[r][c] = (c <= r) ? v : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < CT * CT / 256; ++u) {
+      const int e = tid + 256 * u;
+      const int r = e >> 6, c = e & 63;
+      const double v = D[(int64_t)r * n64 + c];
+      s[r][c] = (c <= r) ? v : 0.0;
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  if (nkc > 0) {
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i = li, q = lq;
+    const double* Mrow = mats + (int64_t)b * mat_stride + (int64_t)k * CT * n64 + (int64_t)kc0 * CT + 16 * q;
+    v4d acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
+    if (wc <= wr) {   // the strictly upper 32x32 block is never referenced
+      for (int kk = 0; kk < nkc; ++kk) {
+        const double* ar[2] = {Mrow + (int64_t)(wr * 32 + i) * n64 + kk * CT, Mrow + (int64_t)(wr * 32 + 16 + i) * n64 + kk * CT};
+        const double* br[2] = {Mrow + (int64_t)(wc * 32 + i) * n64 + kk * CT, Mrow + (int64_t)(wc * 32 + 16 + i) * n64 + kk * CT};
+        double av[2][16], bv[2][16];
+        dmma_load<2, 2>(ar, br, av, bv);
+        dmma_fma<2, 2>(av, bv, acc);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rr = wr * 32 + m * 16 + q + 4 * r, cc = wc * 32 + n * 16 + i;
+            if (cc <= rr) s[rr][cc] -= acc[m][n][r];
+          }
+    }
+    __syncthreads();
+  }
+  if (diag_factor_lds(s, dv)) atomicMax(info, 1);
   double* I = dinv + ((int64_t)b * (n64 / CT) + k) * CT * CT;
   for (int e = tid; e < CT * CT; e += 256) {
     const int rr = e >> 6, c = e & 63;
@@ -575,6 +585,542 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(double* mats, int64_t ma
         C[(int64_t)(m * 16 + q + 4 * r) * n64 + n * 16 + i] = -acc[m][n][r];
 }
 
+
+// =====================================================================================================================
+// Group-wise (left-looking) factorization: per group of 4 tile columns [k0, k0+nc)
+//   k_chol_update (reused) : the group's DIAGONAL block (<= 10 tiles) -= L[.][q < k0] L[.][q < k0]^T
+//   k_chol_gfact           : one workgroup per system factors that block (<= 256 x 256) tile column by tile column
+//                            (diagonal tile in LDS, the <= 3 tiles below it by 16-row slabs) and emits the tile inverses
+//   k_chol_gstrip          : every tile row below the block, one workgroup each: C = A - L[t][q < k0] L[g][q < k0]^T
+//                            (K = 64*k0 contracted through LDS stages) and then T = C * Lgg^-T by forward substitution
+//                            over the group's tile columns, all in registers: each wave owns 16 rows x 256 columns
+// Every tile below the diagonal blocks is read (or formed from the sources) ONCE and written ONCE, the L panels are
+// read through LDS stages shared by the four waves of a workgroup, and a group takes 3 launches.
+// =====================================================================================================================
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+// ---- operand images of a group's diagonal block ------------------------------------------------------------------------
+// gfact leaves, per system and group, the 64x64 tiles that k_chol_gstrip's substitution consumes, in consumption order
+// (for c: L[c][0..c-1], then the inverse of L[c][c]) and in the exact byte image the consumer wants in LDS, so that staging
+// is a straight copy: element (row, col = 16n + q + 4r) sits at row*64 + 2*((8n + 2q + (r >> 1)) ^ (row & 15)) + (r & 1),
+// i.e. the four k = 16n + q + 4r, r = 0..3 a lane needs are two aligned 16-byte slots, XOR-swizzled by the row so that
+// every ds_read_b128 lane group falls on 16 distinct bank groups.
+#define GT_TILE (CT * CT)
+#define GT_NIMG 10
+__device__ __forceinline__ int img_pos(int row, int col) {
+  const int n = col >> 4, qq = col & 3, r = (col >> 2) & 3;
+  return row * CT + ((((8 * n + 2 * qq + (r >> 1)) ^ (row & 15)) << 1) | (r & 1));
+}
+static inline size_t chol_ws_img_offset(size_t batch, int n64) { return batch * (size_t)(n64 / CT) * GT_TILE; }
+
+// ---- wave-level 64x64 factorization + inverse in LDS (same algorithm as diag_factor_lds, one wave, no barriers) -----------
+__device__ __forceinline__ bool diag_factor_wave(double (*s)[CT + 2], double* dv) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lq = lane >> 4;
+  // unconditional LDS reads combined with 0/1 factors: a load under a data-dependent condition becomes a branch + wait
+  auto inv_diag = [&](int o, int r, int c) -> double {
+    return s[o + c][o + r] * (c < r ? 1.0 : 0.0) + dv[o + r] * (c == r ? 1.0 : 0.0);
+  };
+  bool bad = false;
+#pragma unroll 1
+  for (int sb = 0; sb < 4; ++sb) {
+    const int o = sb * 16;
+    const int nb = 3 - sb;
+    if (lane < 16) {
+      double a[16], rdv[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = s[o + lane][o + c];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double piv = bcast_lane(a[c], c);
+        double d, rd;
+        if (piv > 0.0) {
+          double r0 = __builtin_amdgcn_rsq(piv);
+          r0 = r0 * fma(-0.5 * piv * r0, r0, 1.5);
+          r0 = r0 * fma(-0.5 * piv * r0, r0, 1.5);
+          d = piv * r0;
+          d = fma(0.5 * r0, fma(-d, d, piv), d);
+          rd = fma(r0, fma(-d, r0, 1.0), r0);
+        } else { d = 1.0; rd = 1.0; bad = true; }
+        rdv[c] = rd;
+        if (lane > c) a[c] *= rd;
+        else if (lane == c) a[c] = d;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; ++c2) {
+          const double l = bcast_lane(a[c], c2);
+          if (lane >= c2) a[c2] = fma(-a[c], l, a[c2]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c <= lane) s[o + lane][o + c] = a[c];
+      double x[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        double v = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < r; ++j) v = fma(-bcast_lane(a[j], r), x[j], v);
+        x[r] = v * rdv[r];
+      }
+      dv[o + lane] = x[lane];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (r > lane) s[o + lane][o + r] = x[r];
+    }
+    // rows below: L21 = A21 * Linv11^T
+#pragma unroll 1
+    for (int wv = 0; wv < nb; ++wv) {
+      const int rb = o + 16 + 16 * wv;
+      v4d acc = (v4d){0, 0, 0, 0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s[rb + li][o + 4 * lq + st], inv_diag(o, li, 4 * lq + st), acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[rb + lq + 4 * r][o + li] = acc[r];
+    }
+    // trailing update inside the tile
+#pragma unroll 1
+    for (int bi = 0; bi < nb; ++bi)
+#pragma unroll 1
+      for (int bj = 0; bj <= bi; ++bj) {
+        const int ri = o + 16 + 16 * bi, rj = o + 16 + 16 * bj;
+        v4d acc = (v4d){0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s[ri + li][o + 4 * lq + st], s[rj + li][o + 4 * lq + st], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[ri + lq + 4 * r][rj + li] -= acc[r];   // upper triangles of later diagonal blocks: scratch until factored
+      }
+  }
+  // off-diagonal blocks of the inverse, by sub-diagonal distance
+#pragma unroll 1
+  for (int dist = 1; dist < 4; ++dist)
+#pragma unroll 1
+    for (int j = 0; j + dist < 4; ++j) {
+      const int ib = j + dist;
+      v4d m1 = (v4d){0, 0, 0, 0};
+#pragma unroll 1
+      for (int kb = j; kb < ib; ++kb) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const int kk = 4 * lq + st;
+          const double bval = (kb == j) ? inv_diag(16 * j, kk, li) : s[16 * j + li][16 * kb + kk];
+          m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(s[16 * ib + li][16 * kb + kk], bval, m1, 0, 0, 0);
+        }
+      }
+      v4d acc = (v4d){0, 0, 0, 0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(inv_diag(16 * ib, li, lq + 4 * st), m1[st], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[16 * j + li][16 * ib + lq + 4 * r] = -acc[r];
+    }
+  return bad;
+}
+
+// ---- diagonal block of a group: <= 4 tile columns, ONE WAVE per system (four systems per workgroup) ---------------------
+// A 64x64 factorization is a chain of 64 dependent pivots; with one system per wave nothing waits at a barrier, the
+// four SIMDs of a CU run four independent chains, and the tile never leaves the wave's LDS slice.  Per tile column k:
+//   tile (k,k) -= sum_q L[k][q] L[k][q]^T over the group's earlier columns (accumulated in registers), factored and
+//   inverted in LDS; then the tiles below it inside the block: L[t][k] = (A[t][k] - sum_q L[t][q] L[k][q]^T) Linv^T,
+//   accumulated transposed like k_chol_panel.  Tiles written in one step are re-read by the same wave in the next.
+// value of element (gi, gj) of the system: from the workspace (md < 0) or formed from the sources; the mode is resolved
+// around whole unrolled load loops (dispatch_md) so that every loop body is straight-line loads
+template <int MD>
+__device__ __forceinline__ double sys_val(const FormIdx& fx, const double* M, int n64, int gi, int gj) {
+  const int64_t e = (int64_t)gi * n64 + gj;
+  if (MD < 0) return M[e];
+  return form_val<(MD < 0 ? 0 : MD)>(fx, gi, gj, e);
+}
+template <typename F>
+__device__ __forceinline__ void dispatch_md(int md, F&& f) {
+  if (md < 0) f(std::integral_constant<int, -1>{});
+  else if (md == 0) f(std::integral_constant<int, 0>{});
+  else if (md == 1) f(std::integral_constant<int, 1>{});
+  else f(std::integral_constant<int, 2>{});
+}
+
+__device__ __forceinline__ void gfact_wave(int md, double (*s)[CT + 2], double* dv, double* M, int b, int n64, int k0, int nc,
+                                           double* dinvb, double* img, int32_t* info, const FormSrc& fs) {
+  const int lane = threadIdx.x & 63;
+  const int i = lane & 15, q = lane >> 4;
+  FormIdx fx{};
+  if (md >= 0) fx = form_idx(fs, b);
+  bool bad = false;
+#pragma unroll 1
+  for (int c = 0; c < nc; ++c) {
+    const int k = k0 + c;
+    double* D = M + (int64_t)k * CT * n64 + k * CT;
+    {
+      // acc[m][n][r] = -(tile[16m + q + 4r][16n + i]), lower blocks only
+      v4d acc[4][4];
+      dispatch_md(md, [&](auto mode) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            if (n > m) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc[m][n][r] = -sys_val<decltype(mode)::value>(fx, M, n64, k * CT + 16 * m + q + 4 * r, k * CT + 16 * n + i);
+          }
+      });
+      if (c > 0) {
+        const double* Rk = M + ((int64_t)k * CT + i) * n64 + k0 * CT + 2 * q;
+        // 8-deep chunks, software pipelined over two register sets (a single wave has nobody to hide a load behind)
+        auto ld = [&](double2 (&av)[4], int kc) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) av[m] = *reinterpret_cast<const double2*>(Rk + (int64_t)m * 16 * n64 + kc * 8);
+        };
+        auto mm = [&](const double2 (&av)[4]) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+              if (n > m) continue;
+              acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].x, av[n].x, acc[m][n], 0, 0, 0);
+            }
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+              if (n > m) continue;
+              acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[m].y, av[n].y, acc[m][n], 0, 0, 0);
+            }
+        };
+        double2 u0[4], u1[4];
+        const int nk8 = c * 8;
+        ld(u0, 0);
+#pragma unroll 1
+        for (int kc = 0; kc < nk8; kc += 2) {
+          ld(u1, kc + 1);
+          mm(u0);
+          ld(u0, kc + 2 < nk8 ? kc + 2 : kc);
+          mm(u1);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int lr = 16 * m + q + 4 * r, lc = 16 * n + i;
+            s[lr][lc] = (n < m || (n == m && lc <= lr)) ? -acc[n <= m ? m : 0][n <= m ? n : 0][r] : 0.0;
+          }
+    }
+    bad |= diag_factor_wave(s, dv);
+    {
+      double* I = dinvb + (int64_t)k * GT_TILE;
+      double* G = img + (int64_t)(c * (c + 1) / 2 + c) * GT_TILE;
+#pragma unroll 4
+      for (int rr = 0; rr < CT; ++rr) {
+        const int cc = lane;
+        if (cc <= rr) D[(int64_t)rr * n64 + cc] = s[rr][cc];
+        const double lin = s[cc][rr] * (cc < rr ? 1.0 : 0.0) + dv[rr] * (cc == rr ? 1.0 : 0.0);
+        I[rr * CT + cc] = lin;
+        G[img_pos(rr, cc)] = lin;
+      }
+    }
+    // tiles (t, k) below the diagonal tile inside the block, one at a time
+#pragma unroll 1
+    for (int t = k + 1; t < k0 + nc; ++t) {
+      double* T = M + (int64_t)t * CT * n64 + k * CT;
+      v4d acc[4][4];   // accT[n][m][r] = -(U[row 16m + i][col 16n + q + 4r])
+      dispatch_md(md, [&](auto mode) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc[n][m][r] = -sys_val<decltype(mode)::value>(fx, M, n64, t * CT + m * 16 + i, k * CT + n * 16 + q + 4 * r);
+      });
+      if (c > 0) {
+        const double* A = M + ((int64_t)t * CT + i) * n64 + k0 * CT + 2 * q;
+        const double* B = M + ((int64_t)k * CT + i) * n64 + k0 * CT + 2 * q;
+        auto ld = [&](double2 (&av)[4], double2 (&bv)[4], int kc) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            av[m] = *reinterpret_cast<const double2*>(A + (int64_t)m * 16 * n64 + kc * 8);
+            bv[m] = *reinterpret_cast<const double2*>(B + (int64_t)m * 16 * n64 + kc * 8);
+          }
+        };
+        auto mm = [&](const double2 (&av)[4], const double2 (&bv)[4]) {
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[n].x, av[m].x, acc[n][m], 0, 0, 0);
+#pragma unroll
+          for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[n].y, av[m].y, acc[n][m], 0, 0, 0);
+        };
+        double2 a0[4], b0[4], a1[4], b1[4];
+        const int nk8 = c * 8;
+        ld(a0, b0, 0);
+#pragma unroll 1
+        for (int kc = 0; kc < nk8; kc += 2) {
+          ld(a1, b1, kc + 1);
+          mm(a0, b0);
+          ld(a0, b0, kc + 2 < nk8 ? kc + 2 : kc);
+          mm(a1, b1);
+        }
+      }
+      const int ct = t - k0;
+      double* G = img + (int64_t)(ct * (ct + 1) / 2 + c) * GT_TILE;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        v4d out[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          out[cb] = (v4d){0, 0, 0, 0};
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            if (n > cb) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int lr = 16 * cb + i, lc = 16 * n + q + 4 * r;
+              const double li = (n < cb) ? s[lc][lr] : s[lc][lr] * (lc < lr ? 1.0 : 0.0) + dv[lr] * (lc == lr ? 1.0 : 0.0);
+              out[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[n][m][r], li, out[cb], 0, 0, 0);
+            }
+          }
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int lr = m * 16 + q + 4 * r, lc = cb * 16 + i;
+            T[(int64_t)lr * n64 + lc] = out[cb][r];
+            G[img_pos(lr, lc)] = out[cb][r];
+          }
+      }
+    }
+    __threadfence_block();
+  }
+  if (bad) atomicMax(info, 1);
+}
+
+__global__ __launch_bounds__(256) void k_chol_gfact(double* mats, int64_t mat_stride, int n64, int k0, int nc, int batch,
+                                                    double* dinv, double* dimg, int ngrp, int32_t* info, FormSrc fs) {
+  __shared__ double S[4][CT][CT + 2];
+  __shared__ double DV[4][CT];
+  const int wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= batch) return;     // no workgroup barriers below: the waves are independent
+  double* M = mats + (int64_t)b * mat_stride;
+  double* dinvb = dinv + (int64_t)b * (n64 / CT) * GT_TILE;
+  double* img = dimg + ((int64_t)b * ngrp + k0 / 4) * GT_NIMG * GT_TILE;
+  const int md = fs.enabled ? form_mode(form_idx(fs, b)) : -1;
+  gfact_wave(md, S[wave], DV[wave], M, b, n64, k0, nc, dinvb, img, info, fs);
+}
+
+// ---- tile rows below the diagonal block -----------------------------------------------------------------------------
+// 256 threads = 4 waves x 16 rows = one tile row.  Lane (i, q) of a wave holds xn[n][r] = -X[row i][col 16n + q + 4r],
+// n = 0..15 over the group's 256 columns: the transposed-accumulation layout (acc = mfma(L-rows, strip-rows)), which is
+// also the B-operand layout (k = 16n + q + 4r) of the substitution products.
+// Phase 1, K loop over the tile columns left of the group: stages of 16 k (128 B per row) of the group's 256 rows, direct
+//   global -> LDS, double buffered (2 x 32 KB: two workgroups per CU); 16-byte slots XOR-swizzled by ((row >> 1) & 7); lane
+//   (i, q) takes the logical slots q and q + 4 (k = 2q, 2q+1, 8+2q, 9+2q), which keeps every ds_read_b128 lane group
+//   ({0-3,12-15,20-27}, ...) on 16 distinct 16-byte bank groups.  The strip's own rows (one per lane, the same k) come
+//   straight from global memory, one stage ahead.
+// Phase 2, substitution: the tiles of the diagonal block (L[c][c'] and the tile inverses) are staged one at a time through
+//   the same two buffers (slots XOR-swizzled by (row & 15), read by ds_read_b64):
+//     for c:  Xn_c += sum_{c' < c} L[c][c'] (x) T_c'      (64x64x64 products)
+//             T_c = -(Linv_cc (x) Xn_c)                     (lower-triangular product), stored
+#define GS_KC 16
+#define GS_ROWS 256
+#define GS_BUF (GS_ROWS * GS_KC)       // doubles per buffer (32 KB = one 64 x 64 tile image)
+// byte offsets (within the system) of the eight 16-byte pieces a lane copies per stage: piece g = 8*wave + u covers LDS rows
+// 8g .. 8g+7 (rows of the group), 16-byte slots XOR-swizzled by ((row >> 1) & 7)
+__device__ __forceinline__ void gs_offsets(int64_t n64, int rowB0, int maxrow, uint32_t (&off)[8]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int row = (wave * 8 + u) * 8 + (lane >> 3);
+    int grow = rowB0 + row;
+    grow = grow < maxrow ? grow : maxrow;
+    const int slot = (lane & 7) ^ ((row >> 1) & 7);
+    off[u] = (uint32_t)(((int64_t)grow * n64 + slot * 2) * 8);
+  }
+}
+__device__ __forceinline__ void gs_stage(const double* Mk /* system base + k offset of the stage */, const uint32_t (&off)[8],
+                                         double* buf) {
+  const int wave = threadIdx.x >> 6;
+  const char* base = reinterpret_cast<const char*>(Mk);
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(base + off[u]), (lds_void_t*)(buf + (wave * 8 + u) * 128), 16, 0, 0);
+}
+__device__ __forceinline__ void gt_stage(const double* src, double* buf) {   // straight 32 KB copy of a tile image
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int g = wave * 8 + u;
+    __builtin_amdgcn_global_load_lds((glb_void_t*)(src + g * 128 + lane * 2), (lds_void_t*)(buf + g * 128), 16, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void k_chol_gstrip(double* mats, int64_t mat_stride, int n64, int Ttot, int k0, int nc,
+                                                        const double* dimg, int ngrp, int nitem, int batch, int R, int row_end, int dbg, FormSrc fs) {
+  __shared__ __attribute__((aligned(16))) double smem[2 * GS_BUF];
+  int b, g;
+  if (!xcd_affine(blockIdx.x, nitem, batch, R, b, g)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int k1 = k0 + nc;
+  const int tr = k1 + g;
+  double* M = mats + (int64_t)b * mat_stride;
+  const double* img = dimg + ((int64_t)b * ngrp + k0 / 4) * GT_NIMG * GT_TILE;
+  const int nstage = k0 * (CT / GS_KC);
+  const int ntrsm = nc * (nc + 1) / 2;
+  const int rowB0 = k0 * CT, maxrow = Ttot * CT - 1;
+  // unified step list: K stages, then the tile images of the substitution (for c: L[c][0..c-1], inverse of L[c][c])
+  uint32_t goff[8];
+  gs_offsets(n64, rowB0, maxrow, goff);
+  auto stage_step = [&](int step, double* buf) {
+    if (step < nstage) gs_stage(M + step * GS_KC, goff, buf);
+    else gt_stage(img + (int64_t)(step - nstage) * GT_TILE, buf);
+  };
+  if (!(dbg & 2)) stage_step(0, smem);
+  const bool act = tr * CT + 16 * wave < row_end;   // wave-uniform: slabs of padding rows only take part in the staging
+  const int64_t row = (int64_t)tr * CT + 16 * wave + i;
+  double* Xr = M + row * n64 + k0 * CT;
+  v4d xn[16];
+  {
+    auto init = [&](auto mode) {
+      FormIdx fx{};
+      if (decltype(mode)::value >= 0) fx = form_idx(fs, b);
+#pragma unroll
+      for (int n = 0; n < 16; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lc = 16 * n + q + 4 * r;
+          const int lcc = (n >> 2) < nc ? lc : 0;     // tile columns beyond the group are never used: clamp the address
+          if (decltype(mode)::value < 0) xn[n][r] = -Xr[lcc];
+          else {
+            const int gi = (int)row, gj = k0 * CT + lcc;
+            xn[n][r] = -form_val<(decltype(mode)::value < 0 ? 0 : decltype(mode)::value)>(fx, gi, gj, (int64_t)gi * n64 + gj);
+          }
+        }
+    };
+    if ((dbg & 4) || !act) {
+#pragma unroll
+      for (int n = 0; n < 16; ++n) xn[n] = (v4d){1.0, 2.0, 3.0, 4.0};
+    } else if (!fs.enabled) init(std::integral_constant<int, -1>{});
+    else {
+      const FormIdx f0 = form_idx(fs, b);
+      const int md = form_mode(f0);
+      if (md == 0) init(std::integral_constant<int, 0>{});
+      else if (md == 1) init(std::integral_constant<int, 1>{});
+      else init(std::integral_constant<int, 2>{});
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const int nstep = nstage + ntrsm;
+  // ---- phase 1 ----
+  {
+    const int xs = (i >> 1) & 7;
+    const int ob = i * GS_KC;
+    const int s0 = (q ^ xs) * 2, s1 = ((q + 4) ^ xs) * 2;
+    const double* Ap = M + row * n64 + 2 * q;        // this lane's strip row: k = 2q, 2q+1 and 8+2q, 9+2q of every stage
+    double2 a0 = {0, 0}, a1 = {0, 0};
+    if (nstage > 0) {
+      a0 = *reinterpret_cast<const double2*>(Ap);
+      a1 = *reinterpret_cast<const double2*>(Ap + 8);
+    }
+    for (int s = 0; s < nstage; ++s) {
+      const double* cur = smem + (s & 1) * GS_BUF;
+      double* nxt = smem + ((s & 1) ^ 1) * GS_BUF;
+      if (s + 1 < nstep && !(dbg & 2)) stage_step(s + 1, nxt);
+      const int sn = s + 1 < nstage ? s + 1 : s;
+      const double2 an0 = *reinterpret_cast<const double2*>(Ap + sn * GS_KC);
+      const double2 an1 = *reinterpret_cast<const double2*>(Ap + sn * GS_KC + 8);
+      if (act) {
+#pragma unroll
+      for (int n4 = 0; n4 < 4; ++n4) {
+        double2 b0[4], b1[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          b0[n] = *reinterpret_cast<const double2*>(cur + ob + (n4 * 4 + n) * 16 * GS_KC + s0);
+          b1[n] = *reinterpret_cast<const double2*>(cur + ob + (n4 * 4 + n) * 16 * GS_KC + s1);
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) xn[n4 * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[n].x, a0.x, xn[n4 * 4 + n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) xn[n4 * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[n].y, a0.y, xn[n4 * 4 + n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) xn[n4 * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[n].x, a1.x, xn[n4 * 4 + n], 0, 0, 0);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) xn[n4 * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[n].y, a1.y, xn[n4 * 4 + n], 0, 0, 0);
+      }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      a0 = an0; a1 = an1;
+      __syncthreads();
+    }
+  }
+  // ---- phase 2 ----
+  int step = nstage;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (c >= nc) break;
+#pragma unroll
+    for (int cp = 0; cp <= c; ++cp, ++step) {
+      const double* cur = smem + (step & 1) * GS_BUF;
+      double* nxt = smem + ((step & 1) ^ 1) * GS_BUF;
+      if (step + 1 < nstep && !(dbg & 2)) stage_step(step + 1, nxt);
+      // a operand of block (nb, n): image row 16nb + i, the two 16-byte slots (8n + 2q + h) ^ i
+      auto a4 = [&](int nb, int n, double (&a)[4]) {
+        const double* rowp = cur + (16 * nb + i) * CT;
+        const double2 lo = *reinterpret_cast<const double2*>(rowp + (((8 * n + 2 * q) ^ i) << 1));
+        const double2 hi = *reinterpret_cast<const double2*>(rowp + (((8 * n + 2 * q + 1) ^ i) << 1));
+        a[0] = lo.x; a[1] = lo.y; a[2] = hi.x; a[3] = hi.y;
+      };
+      if ((dbg & 1) || !act) {
+      } else if (cp < c) {            // Xn_c += L[c][cp] (x) T_cp
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            double a[4];
+            a4(nb, n, a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              xn[4 * c + nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], xn[4 * cp + n][r], xn[4 * c + nb], 0, 0, 0);
+          }
+      } else {                 // T_c = -(Linv_cc (x) Xn_c), lower triangular: blocks n <= nb
+        v4d out[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) out[nb] = (v4d){0, 0, 0, 0};
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            if (n > nb) continue;
+            double a[4];
+            a4(nb, n, a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              out[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], xn[4 * c + n][r], out[nb], 0, 0, 0);
+          }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) xn[4 * c + nb] = -out[nb];
+        if (!(dbg & 8)) {
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Xr[c * CT + 16 * nb + q + 4 * r] = xn[4 * c + nb][r];
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  }
+}
+
 // ---- back substitution L^T x = y for the RHS rows (in place), one workgroup per system -------------
 // The four waves split either the RHS rows (pg = 4 or 2 per pass) or, for few RHS, the 64-row
 // contraction of each tile (parts = 4 / pg), so a single right-hand side still keeps 4 waves of
@@ -643,10 +1189,47 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
                               const FormSrc* src) {
   const int T = n64 / CT, Tr = rhs_pad / CT, Ttot = T + Tr;
   static const int Genv = getenv("RG_CHOL_G") ? atoi(getenv("RG_CHOL_G")) : 4;
-  const int G = Genv;  // tile columns per group: trailing updates contract K = 64*G at once
+  static const int Venv = getenv("RG_CHOL_V") ? atoi(getenv("RG_CHOL_V")) : 3;
   FormSrc off{};
   off.enabled = 0; off.extra = nullptr; off.n_div = 1; off.b_offset = 0;
   int64_t nl = 0;
+  if (Venv >= 3) {
+    // group-wise left-looking factorization.  First touch of a tile (read from the source matrices instead of the
+    // workspace): group 0 by gfact/gstrip, later groups by the diagonal-block update and gstrip.  Systems that share a
+    // source matrix (the shifts) are co-located on one XCD.
+    const int R = src ? std::max(1, src->nshift) : 1;
+    const int ngrp = (T + 3) / 4;
+    // right-hand-side rows beyond the ones that are solved for are padding: their 16-row slabs are skipped.  (nrhs == 0:
+    // forward substitution only, every appended row is real -- the LOOCV / inverse callers.)
+    const int row_end = n64 + (nrhs > 0 ? nrhs : rhs_pad);
+    double* dimg = dinv + chol_ws_img_offset((size_t)batch, n64);   // the workspace holds the tile inverses, then the images
+    for (int k0 = 0; k0 < T; k0 += 4) {
+      const int nc = std::min(4, T - k0), k1 = k0 + nc;
+      const FormSrc& first = src ? *src : off;
+      if (k0 > 0) {   // diagonal block: tiles (r, c), k0 <= c <= r < k1, K = 64 * k0
+        const int ntile = nc * (nc + 1) / 2;
+        hipLaunchKernelGGL(k_chol_update, dim3(xcd_affine_grid((ntile + 3) / 4, batch, R)), dim3(256), 0, st, mats,
+                           mat_stride, n64, k1, k0, k1, ntile, 0, k0, batch, R, first);
+        ++nl;
+      }
+      hipLaunchKernelGGL(k_chol_gfact, dim3((batch + 3) / 4), dim3(256), 0, st, mats, mat_stride, n64, k0, nc, batch, dinv,
+                         dimg, ngrp, info, k0 == 0 ? first : off);
+      ++nl;
+      if (Ttot > k1) {
+        const int nitem = Ttot - k1;
+        hipLaunchKernelGGL(k_chol_gstrip, dim3(xcd_affine_grid(nitem, batch, R)), dim3(256), 0, st, mats, mat_stride, n64,
+                           Ttot, k0, nc, dimg, ngrp, nitem, batch, R, row_end, getenv("RG_CHOL_DBG") ? atoi(getenv("RG_CHOL_DBG")) : 0, first);
+        ++nl;
+      }
+    }
+    if (nrhs > 0) {
+      hipLaunchKernelGGL(k_chol_backsolve, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, nrhs, dinv);
+      ++nl;
+    }
+    if (n_launch) *n_launch += nl;
+    return;
+  }
+  const int G = Genv;  // tile columns per group: trailing updates contract K = 64*G at once
   for (int k0 = 0; k0 < T; k0 += G) {
     const int k1 = std::min(T, k0 + G);
     // first touch of every tile happens in the first group: tile columns < G by diag/panel, the rest by the

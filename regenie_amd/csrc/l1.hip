@@ -259,7 +259,7 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
   if (nslice > 1) { L1_WS(d_part, 1, double, msz * K * nslice) }
   L1_WS(d_sum, 2, double, msz)
   L1_WS(d_wk, 3, double, msz * std::max(1, nloc))
-  L1_WS(d_dinv, 4, double, (size_t)std::max(1, nloc) * T * CT * CT)
+  L1_WS(d_dinv, 4, double, rg_chol_ws_doubles((size_t)std::max(1, nloc), n64))
   L1_WS(d_tau, 5, double, R1)
   L1_WS(d_cvp, 6, double, (size_t)nch * NPART)
   L1_WS(d_pred, 7, double, (size_t)nchr * ctx->N)

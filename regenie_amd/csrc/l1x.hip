@@ -486,7 +486,7 @@ int rg_l1_qt_loocv_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const 
   L1X_HIP(c.bufs.alloc(&d_G, (size_t)c.msz));
   L1X_HIP(c.bufs.alloc(&d_eye, (size_t)n64 * n64));
   L1X_HIP(c.bufs.alloc(&d_sysI, (size_t)R1 * 2 * n64 * n64));
-  L1X_HIP(c.bufs.alloc(&d_dinv, (size_t)R1 * T * CT * CT));
+  L1X_HIP(c.bufs.alloc(&d_dinv, rg_chol_ws_doubles((size_t)R1, c.n64)));
   L1X_HIP(c.bufs.alloc(&d_H, (size_t)R1 * n64 * n64));
   L1X_HIP(c.bufs.alloc(&d_tau, (size_t)R1));
   L1X_HIP(c.bufs.alloc(&d_Wt, (size_t)Np * n64));
@@ -693,7 +693,7 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
   L1X_HIP(c.bufs.alloc(&s.d_tauc, (size_t)nchain));
   L1X_HIP(c.bufs.alloc(&s.d_part, (size_t)s.nchunk * nchain * BT_NPART));
   L1X_HIP(c.bufs.alloc(&s.d_sys, (size_t)nchain * c.msz));
-  L1X_HIP(c.bufs.alloc(&s.d_dinv, (size_t)nchain * T * CT * CT));
+  L1X_HIP(c.bufs.alloc(&s.d_dinv, rg_chol_ws_doubles((size_t)nchain, c.n64)));
   L1X_HIP(c.bufs.alloc(&s.d_map, (size_t)nchain));
   L1X_HIP(hipMemsetAsync(s.d_score, 0, sizeof(double) * (size_t)nchain * n64, st));
   s.h_part.resize((size_t)s.nchunk * nchain * BT_NPART);
@@ -705,7 +705,7 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
   if (loocv) {
     L1X_HIP(c.bufs.alloc(&d_eye, (size_t)n64 * n64));
     L1X_HIP(c.bufs.alloc(&d_sysI, (size_t)2 * n64 * n64));
-    L1X_HIP(c.bufs.alloc(&d_dinvI, (size_t)T * CT * CT));
+    L1X_HIP(c.bufs.alloc(&d_dinvI, rg_chol_ws_doubles(1, c.n64)));
     L1X_HIP(c.bufs.alloc(&d_H, (size_t)n64 * n64));
     L1X_HIP(c.bufs.alloc(&d_G, (size_t)c.msz));
     L1X_HIP(c.bufs.alloc(&d_Wt, (size_t)Np * n64));

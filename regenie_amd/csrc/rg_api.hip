@@ -264,7 +264,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if ((rc = dev_alloc(ctx, &ctx->d_fold, (size_t)nb * nseg * msz))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_sum, (size_t)nb * msz))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_wk, (size_t)nb * ctx->nsys * ctx->rtot_wk * n64))) return rc;
-  if ((rc = dev_alloc(ctx, &ctx->d_dinv, (size_t)nb * ctx->nsys * (n64 / 64) * 4096))) return rc;
+  if ((rc = dev_alloc(ctx, &ctx->d_dinv, rg_chol_ws_doubles((size_t)nb * ctx->nsys, n64)))) return rc;
   if (ctx->loocv) {
     if ((rc = dev_alloc(ctx, &ctx->d_gt, (size_t)nb * Np * n64))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_lpart, (size_t)2 * nb * R0 * P * 64))) return rc;

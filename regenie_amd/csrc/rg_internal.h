@@ -17,6 +17,12 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 static inline int64_t rg_round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+// doubles of workspace (`dinv`) one batched Cholesky call needs: the 64x64 tile inverses (T per system) followed by the
+// operand images of the diagonal blocks (10 tiles per group of 4 tile columns), see chol.hip
+static inline size_t rg_chol_ws_doubles(size_t batch, int n64) {
+  const size_t T = (size_t)n64 / 64;
+  return batch * (T + (T + 3) / 4 * 10) * 4096;
+}
 
 // Fold-aligned sample layout ("position space"): fold f occupies positions
 // [pos_start[f], pos_start[f]+len[f]) which map to .fam indices [file_start[f], +len[f]);

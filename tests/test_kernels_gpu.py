@@ -71,12 +71,15 @@ def test_dgemm_nt(m, n, k):
     assert np.max(np.abs(Cd.cpu().numpy() - ref)) <= 1e-11 * np.max(np.abs(ref))
 
 
-@pytest.mark.parametrize("n,nrhs,batch", [(64, 1, 3), (100, 2, 2), (200, 5, 4), (1000, 3, 2)])
-def test_chol_solve(n, nrhs, batch):
+@pytest.mark.parametrize("n,nrhs,batch,rhs_pad", [(64, 1, 3, 64), (100, 2, 2, 64), (200, 5, 4, 64), (1000, 3, 2, 64),
+                                                  (300, 2, 3, 64), (545, 70, 2, 128), (256, 130, 9, 192),
+                                                  (130, 300, 2, 320)])
+def test_chol_solve(n, nrhs, batch, rhs_pad):
+    """tile counts 1..16 (partial last column group: 5, 9 tiles), several right-hand-side row tiles (odd totals)"""
     lib = load_library()
     rng = np.random.default_rng(11)
     n64 = (n + 63) // 64 * 64
-    rtot = n64 + 64
+    rtot = n64 + rhs_pad
     mats = np.zeros((batch, rtot, n64))
     sols = []
     for b in range(batch):
@@ -88,9 +91,10 @@ def test_chol_solve(n, nrhs, batch):
         mats[b, n64:n64 + nrhs, :n] = rhs
         sols.append(np.linalg.solve(A, rhs.T).T)
     Md = _dev(mats)
-    dinv = torch.zeros(batch * (n64 // 64) * 4096, dtype=torch.float64, device="cuda")
+    T = n64 // 64
+    dinv = torch.zeros(batch * (T + 10 * ((T + 3) // 4)) * 4096, dtype=torch.float64, device="cuda")
     info = torch.zeros(4, dtype=torch.int32, device="cuda")
-    rc = lib.rg_k_chol_solve(_stream(), Md.data_ptr(), rtot * n64, batch, n64, 64, nrhs, dinv.data_ptr(), info.data_ptr())
+    rc = lib.rg_k_chol_solve(_stream(), Md.data_ptr(), rtot * n64, batch, n64, rhs_pad, nrhs, dinv.data_ptr(), info.data_ptr())
     assert rc == 0
     torch.cuda.synchronize()
     out = Md.cpu().numpy()
@@ -109,7 +113,7 @@ def test_chol_flags_non_spd():
     mats = np.zeros((1, rtot, n64))
     mats[0, :64, :64] = -np.eye(64)
     Md = _dev(mats)
-    dinv = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    dinv = torch.zeros(11 * 4096, dtype=torch.float64, device="cuda")
     info = torch.zeros(4, dtype=torch.int32, device="cuda")
     assert lib.rg_k_chol_solve(_stream(), Md.data_ptr(), rtot * n64, 1, n64, 64, 1, dinv.data_ptr(), info.data_ptr()) == 0
     torch.cuda.synchronize()
