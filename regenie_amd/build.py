@@ -15,7 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librg_step1_hip.so")
 SOURCES = ["rg_api.hip", "bed_prep.hip", "gram_i8.hip", "gram_fp4.hip", "assemble.hip", "chol.hip", "pred.hip", "l1.hip", "ubench.hip", "loocv.hip", "l1x.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result"]
+         "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result", "-Wno-inline-asm"]
 
 
 def _hipcc() -> str:

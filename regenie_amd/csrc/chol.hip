@@ -603,14 +603,15 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 // ---- operand images of a group's diagonal block ------------------------------------------------------------------------
 // gfact leaves, per system and group, the 64x64 tiles that k_chol_gstrip's substitution consumes, in consumption order
 // (for c: L[c][0..c-1], then the inverse of L[c][c]) and in the exact byte image the consumer wants in LDS, so that staging
-// is a straight copy: element (row, col = 16n + q + 4r) sits at row*64 + 2*((8n + 2q + (r >> 1)) ^ (row & 15)) + (r & 1),
-// i.e. the four k = 16n + q + 4r, r = 0..3 a lane needs are two aligned 16-byte slots, XOR-swizzled by the row so that
-// every ds_read_b128 lane group falls on 16 distinct bank groups.
+// is a straight copy.  A tile is two 16 KB halves (columns 0-31 | 32-63), each [64 rows][32 columns]; inside a half, element
+// (row, col = 16n + q + 4r) sits at row*32 + 2*(((8(n&1) + 2q + (r >> 1)) ^ (row & 15))) + (r & 1): the four k = 16n + q + 4r,
+// r = 0..3 a lane needs are two aligned 16-byte slots, XOR-swizzled by the row so that every ds_read_b128 lane group
+// falls on 16 distinct bank groups.
 #define GT_TILE (CT * CT)
 #define GT_NIMG 10
 __device__ __forceinline__ int img_pos(int row, int col) {
   const int n = col >> 4, qq = col & 3, r = (col >> 2) & 3;
-  return row * CT + ((((8 * n + 2 * qq + (r >> 1)) ^ (row & 15)) << 1) | (r & 1));
+  return (n >> 1) * (GT_TILE / 2) + row * 32 + ((((8 * (n & 1) + 2 * qq + (r >> 1)) ^ (row & 15)) << 1) | (r & 1));
 }
 static inline size_t chol_ws_img_offset(size_t batch, int n64) { return batch * (size_t)(n64 / CT) * GT_TILE; }
 
@@ -917,206 +918,335 @@ __global__ __launch_bounds__(256) void k_chol_gfact(double* mats, int64_t mat_st
 }
 
 // ---- tile rows below the diagonal block -----------------------------------------------------------------------------
-// 256 threads = 4 waves x 16 rows = one tile row.  Lane (i, q) of a wave holds xn[n][r] = -X[row i][col 16n + q + 4r],
-// n = 0..15 over the group's 256 columns: the transposed-accumulation layout (acc = mfma(L-rows, strip-rows)), which is
-// also the B-operand layout (k = 16n + q + 4r) of the substitution products.
-// Phase 1, K loop over the tile columns left of the group: stages of 16 k (128 B per row) of the group's 256 rows, direct
-//   global -> LDS, double buffered (2 x 32 KB: two workgroups per CU); 16-byte slots XOR-swizzled by ((row >> 1) & 7); lane
-//   (i, q) takes the logical slots q and q + 4 (k = 2q, 2q+1, 8+2q, 9+2q), which keeps every ds_read_b128 lane group
-//   ({0-3,12-15,20-27}, ...) on 16 distinct 16-byte bank groups.  The strip's own rows (one per lane, the same k) come
-//   straight from global memory, one stage ahead.
-// Phase 2, substitution: the tiles of the diagonal block (L[c][c'] and the tile inverses) are staged one at a time through
-//   the same two buffers (slots XOR-swizzled by (row & 15), read by ds_read_b64):
-//     for c:  Xn_c += sum_{c' < c} L[c][c'] (x) T_c'      (64x64x64 products)
-//             T_c = -(Linv_cc (x) Xn_c)                     (lower-triangular product), stored
-#define GS_KC 16
-#define GS_ROWS 256
-#define GS_BUF (GS_ROWS * GS_KC)       // doubles per buffer (32 KB = one 64 x 64 tile image)
-// byte offsets (within the system) of the eight 16-byte pieces a lane copies per stage: piece g = 8*wave + u covers LDS rows
-// 8g .. 8g+7 (rows of the group), 16-byte slots XOR-swizzled by ((row >> 1) & 7)
-__device__ __forceinline__ void gs_offsets(int64_t n64, int rowB0, int maxrow, uint32_t (&off)[8]) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int row = (wave * 8 + u) * 8 + (lane >> 3);
-    int grow = rowB0 + row;
-    grow = grow < maxrow ? grow : maxrow;
-    const int slot = (lane & 7) ^ ((row >> 1) & 7);
-    off[u] = (uint32_t)(((int64_t)grow * n64 + slot * 2) * 8);
-  }
-}
-__device__ __forceinline__ void gs_stage(const double* Mk /* system base + k offset of the stage */, const uint32_t (&off)[8],
-                                         double* buf) {
-  const int wave = threadIdx.x >> 6;
-  const char* base = reinterpret_cast<const char*>(Mk);
-#pragma unroll
-  for (int u = 0; u < 8; ++u)
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(base + off[u]), (lds_void_t*)(buf + (wave * 8 + u) * 128), 16, 0, 0);
-}
-__device__ __forceinline__ void gt_stage(const double* src, double* buf) {   // straight 32 KB copy of a tile image
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const int g = wave * 8 + u;
-    __builtin_amdgcn_global_load_lds((glb_void_t*)(src + g * 128 + lane * 2), (lds_void_t*)(buf + g * 128), 16, 0, 0);
-  }
+// 256 threads = 4 waves; a wave owns NS slabs of 16 rows, the workgroup 64*NS rows.  Lane (i, q) holds, per slab,
+// xn[n][r] = -X[row i][col 16n + q + 4r], n = 0..15 over the group's 256 columns: the transposed-accumulation layout
+// (acc = mfma(L-rows, strip-rows)), which is also the B-operand layout (k = 16n + q + 4r) of the substitution products.
+// EVERYTHING the workgroup reads streams through one ring of 16 KB LDS units filled by direct global -> LDS copies issued
+// NBUF-1 units ahead; a step never waits for more than "the unit after this one has landed" (counted vmcnt, raw s_barrier):
+//   A units    : 64 strip rows x 32 k (two 16-k stages), copied to registers when their turn comes
+//   B units    : 16 k x 128 rows of the group (two units per stage), 16-byte slots XOR-swizzled by ((row >> 1) & 7);
+//                lane (i, q) takes the logical slots q and q + 4 (k = 2q, 2q+1, 8+2q, 9+2q)     -> 32 MFMAs per wave and slab
+//   X units    : 64 strip rows x 32 columns of the tile being solved, from the workspace or from the source matrices
+//                (first touch: S, and F to subtract), slots swizzled by (row & 15), read back in the xn layout
+//   image units: half tiles of the diagonal block (L[c][c'] and the tile inverses) exactly as gfact left them
+//     for c:  Xn_c = sum over the K units - X_c;  Xn_c += sum_{c' < c} L[c][c'] (x) T_c';  T_c = -(Linv_cc (x) Xn_c), stored
+// What bounds this kernel is the L2 -> LDS traffic per flop (the images and the group's rows are re-read by every
+// workgroup of a system); NS = 2 halves it.
+#define GU_UNIT 2048            // doubles per ring unit (16 KB)
+
+// direct global -> LDS copy of 16 bytes per lane (1 KB per wave) issued through inline assembly: hipcc orders every LDS
+// read behind ALL pending global_load_lds it knows of (an s_waitcnt vmcnt(0) in front of the first ds_read of each unit),
+// which would drain the prefetch ring; the copies are ordered by the counted waits of unit_end() instead, and the loops
+// contain no other loads the compiler would count.
+// sbase: wave-uniform base, voff: per-lane byte offset, lds_addr: wave-uniform LDS byte address of the 1 KB destination.
+__device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+  const uint64_t a = reinterpret_cast<uint64_t>(sbase);   // uniform by construction; pin it to scalar registers
+  const uint64_t sa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sa),
+               "s"(__builtin_amdgcn_readfirstlane((int)lds_addr))
+               : "memory", "m0");
 }
 
-__global__ __launch_bounds__(256, 2) void k_chol_gstrip(double* mats, int64_t mat_stride, int n64, int Ttot, int k0, int nc,
-                                                        const double* dimg, int ngrp, int nitem, int batch, int R, int row_end, int dbg, FormSrc fs) {
-  __shared__ __attribute__((aligned(16))) double smem[2 * GS_BUF];
+template <int N>
+__device__ __forceinline__ void gu_wait_upto(int n) {   // s_waitcnt vmcnt(4 * min(n, N)), immediate operands only
+  if (N > 0 && n >= N) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * N) : "memory"); return; }
+  if (N > 0) gu_wait_upto<(N > 0 ? N - 1 : 0)>(n);
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int NS>
+__global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void k_chol_gstrip(double* mats, int64_t mat_stride, int n64, int Ttot,
+                                                                      int k0, int nc, const double* dimg, int ngrp,
+                                                                      int nitem, int batch, int R, int row_end,
+                                                                      FormSrc fs) {
+  constexpr int NBUF = NS == 1 ? 5 : 9;     // ring units: 80 KB (two workgroups per CU) or 144 KB
+  constexpr int DIST = NBUF - 1;            // prefetch distance in units
+  constexpr int PAIR = NS + 4;              // K units per pair of stages: NS A units, 2 x 2 B units
+  __shared__ __attribute__((aligned(16))) double ring[NBUF * GU_UNIT];
   int b, g;
   if (!xcd_affine(blockIdx.x, nitem, batch, R, b, g)) return;
+  b = __builtin_amdgcn_readfirstlane(b);   // uniform, but the integer divisions leave them in vector registers;
+  g = __builtin_amdgcn_readfirstlane(g);   // the copy bases must be scalar
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int k1 = k0 + nc;
-  const int tr = k1 + g;
+  const int tr0 = k1 + NS * g;              // first tile row of the workgroup; slab t of wave w: rows 64(tr0+t) + 16w + i
   double* M = mats + (int64_t)b * mat_stride;
   const double* img = dimg + ((int64_t)b * ngrp + k0 / 4) * GT_NIMG * GT_TILE;
-  const int nstage = k0 * (CT / GS_KC);
-  const int ntrsm = nc * (nc + 1) / 2;
-  const int rowB0 = k0 * CT, maxrow = Ttot * CT - 1;
-  // unified step list: K stages, then the tile images of the substitution (for c: L[c][0..c-1], inverse of L[c][c])
-  uint32_t goff[8];
-  gs_offsets(n64, rowB0, maxrow, goff);
-  auto stage_step = [&](int step, double* buf) {
-    if (step < nstage) gs_stage(M + step * GS_KC, goff, buf);
-    else gt_stage(img + (int64_t)(step - nstage) * GT_TILE, buf);
+  bool act[NS];                             // wave-uniform: slabs of padding rows only take part in the staging
+  double* Xr[NS];
+  int trc[NS];                              // a slab row block past the end re-reads the last one (results unused)
+#pragma unroll
+  for (int t = 0; t < NS; ++t) {
+    act[t] = (tr0 + t) * CT + 16 * wave < row_end;
+    trc[t] = tr0 + t < Ttot ? tr0 + t : Ttot - 1;
+    Xr[t] = M + ((int64_t)trc[t] * CT + 16 * wave + i) * n64 + k0 * CT;
+  }
+  const int nact = act[NS - 1] ? NS : (act[0] ? 1 : 0);     // slabs are in row order: slab 1 active implies slab 0 active
+  // compute bodies are instantiated per active-slab count so that the MFMA streams stay branch-free
+  auto with_nact = [&](auto&& f) {
+    if (nact == NS) f(std::integral_constant<int, NS>{});
+    else if (NS > 1 && nact == 1) f(std::integral_constant<int, 1>{});
   };
-  if (!(dbg & 2)) stage_step(0, smem);
-  const bool act = tr * CT + 16 * wave < row_end;   // wave-uniform: slabs of padding rows only take part in the staging
-  const int64_t row = (int64_t)tr * CT + 16 * wave + i;
-  double* Xr = M + row * n64 + k0 * CT;
-  v4d xn[16];
+  // sources of the strip's own tiles: X = srcA - srcB (srcB optional); strip rows are never on the diagonal
+  const double* srcA = M;
+  const double* srcB = nullptr;
+  if (fs.enabled) {
+    const FormIdx fx = form_idx(fs, b);
+    if (fx.X && tr0 * CT >= fx.x0) srcA = fx.X - fx.xoff;
+    else { srcA = fx.S; srcB = fx.F; }
+  }
+  const int nsrc = srcB ? 2 : 1;
+  const int npair = k0 * 2;                                     // pairs of 16-k stages left of the group (k0 * 64 / 32)
+  const int nK = npair * PAIR;
+  auto cnt = [&](int c) { return 2 * (NS * nsrc + c + 1); };    // units of tile column c: X (per slab row block), L[c][0..c-1], inverse
+  int total = nK;
+  for (int c = 0; c < nc; ++c) total += cnt(c);
+  // per-lane byte offsets of the pieces this lane copies: B units (2 halves x 4 pieces), A / X units (4 pieces), images
+  uint32_t koff[2][4], xoff[4], ioff[4];
   {
-    auto init = [&](auto mode) {
-      FormIdx fx{};
-      if (decltype(mode)::value >= 0) fx = form_idx(fs, b);
+    const int maxrow = Ttot * CT - 1;
 #pragma unroll
-      for (int n = 0; n < 16; ++n)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int lc = 16 * n + q + 4 * r;
-          const int lcc = (n >> 2) < nc ? lc : 0;     // tile columns beyond the group are never used: clamp the address
-          if (decltype(mode)::value < 0) xn[n][r] = -Xr[lcc];
-          else {
-            const int gi = (int)row, gj = k0 * CT + lcc;
-            xn[n][r] = -form_val<(decltype(mode)::value < 0 ? 0 : decltype(mode)::value)>(fx, gi, gj, (int64_t)gi * n64 + gj);
-          }
-        }
-    };
-    if ((dbg & 4) || !act) {
+      for (int j = 0; j < 4; ++j) {
+        const int lr = (wave * 4 + j) * 8 + (lane >> 3);
+        int grow = k0 * CT + h * 128 + lr;
+        grow = grow < maxrow ? grow : maxrow;
+        const int slot = (lane & 7) ^ ((lr >> 1) & 7);
+        koff[h][j] = (uint32_t)(((int64_t)grow * n64 + slot * 2) * 8);
+      }
 #pragma unroll
-      for (int n = 0; n < 16; ++n) xn[n] = (v4d){1.0, 2.0, 3.0, 4.0};
-    } else if (!fs.enabled) init(std::integral_constant<int, -1>{});
-    else {
-      const FormIdx f0 = form_idx(fs, b);
-      const int md = form_mode(f0);
-      if (md == 0) init(std::integral_constant<int, 0>{});
-      else if (md == 1) init(std::integral_constant<int, 1>{});
-      else init(std::integral_constant<int, 2>{});
+    for (int j = 0; j < 4; ++j) {
+      const int lr = (wave * 4 + j) * 4 + (lane >> 4);
+      const int slot = (lane & 15) ^ (lr & 15);
+      xoff[j] = (uint32_t)(((int64_t)lr * n64 + slot * 2) * 8);
+      ioff[j] = (uint32_t)((wave * 512 + j * 128 + lane * 2) * 8);
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  const int nstep = nstage + ntrsm;
-  // ---- phase 1 ----
+  const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) double*)ring;
+  const uint32_t wave_lds = __builtin_amdgcn_readfirstlane(ring_lds + wave * 4096);     // this wave's 4 KB of every unit
+  // prefetch cursor: units are staged strictly in order
+  int pf_u = 0, pf_slot = 0, pf_pp = 0, pf_r = 0, pf_c = 0, pf_v = 0;
+  auto stage_next = [&]() {
+    const uint32_t dst = wave_lds + pf_slot * (GU_UNIT * 8);
+    if (pf_u < nK) {
+      if (pf_r < NS) {                      // A unit of slab row block pf_r: 64 rows x 32 k
+        const double* base = M + (int64_t)trc[pf_r < NS ? pf_r : 0] * CT * n64 + pf_pp * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(base, xoff[j], dst + j * 1024);
+      } else {                              // B unit: stage 2 pp + (r' >> 1), half r' & 1
+        const int rr = pf_r - NS;
+        const double* base = M + (2 * pf_pp + (rr >> 1)) * 16;
+        if (rr & 1) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) glds16(base, koff[1][j], dst + j * 1024);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) glds16(base, koff[0][j], dst + j * 1024);
+        }
+      }
+    } else {
+      if (pf_v < 2 * NS * nsrc) {           // X unit: (slab row block t, source, column half)
+        const int xsh = nsrc == 2 ? 2 : 1;                      // 2 * nsrc is 2 or 4: no integer division in scalar code
+        const int t = pf_v >> xsh, rem = pf_v & (2 * nsrc - 1);
+        const double* src = (rem >> 1) ? srcB : srcA;
+        const double* base = src + (int64_t)trc[t < NS ? t : 0] * CT * n64 + (k0 + pf_c) * CT + (rem & 1) * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(base, xoff[j], dst + j * 1024);
+      } else {
+        const int w = pf_v - 2 * NS * nsrc;
+        const double* base = img + (int64_t)(pf_c * (pf_c + 1) / 2 + (w >> 1)) * GT_TILE + (w & 1) * (GT_TILE / 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(base, ioff[j], dst + j * 1024);
+      }
+    }
+    {  // advance the cursor with plain value selects (conditional ++ of either pair ends up as an indexed stack slot)
+      const bool ink = pf_u < nK;
+      const int nr = pf_r + 1, nv = pf_v + 1;
+      const bool wk = nr == PAIR, wc = nv == cnt(pf_c);
+      pf_r = ink ? (wk ? 0 : nr) : pf_r;
+      pf_pp = ink ? pf_pp + (wk ? 1 : 0) : pf_pp;
+      pf_v = ink ? pf_v : (wc ? 0 : nv);
+      pf_c = ink ? pf_c : pf_c + (wc ? 1 : 0);
+    }
+    ++pf_u;
+    pf_slot = pf_slot + 1 == NBUF ? 0 : pf_slot + 1;
+  };
+  // ring bookkeeping: unit u lives in slot u % NBUF; units 0 .. DIST-1 are issued up front, unit u + DIST at the start of unit u
+  int u = 0, cur_slot = 0;
+  for (int p = 0; p < DIST && p < total; ++p) stage_next();
+  auto unit_begin = [&]() -> const double* {
+    if (pf_u < total) stage_next();
+    return ring + cur_slot * GU_UNIT;
+  };
+  auto unit_end = [&]() {            // the next unit must have landed: at most 4 pieces per later unit may be in flight
+    gu_wait_upto<DIST - 1>(total - 2 - u);
+    // raw barrier: __syncthreads() would fence with vmcnt(0) and drain the copies still in flight for later units
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    ++u;
+    cur_slot = cur_slot + 1 == NBUF ? 0 : cur_slot + 1;
+  };
+  v4d xn[NS][16];
+#pragma unroll
+  for (int t = 0; t < NS; ++t)
+#pragma unroll
+    for (int n = 0; n < 16; ++n) xn[t][n] = (v4d){0, 0, 0, 0};
+  gu_wait_upto<DIST - 1>(total - 1);   // unit 0
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // ---- phase 1: K units ----
   {
     const int xs = (i >> 1) & 7;
-    const int ob = i * GS_KC;
-    const int s0 = (q ^ xs) * 2, s1 = ((q + 4) ^ xs) * 2;
-    const double* Ap = M + row * n64 + 2 * q;        // this lane's strip row: k = 2q, 2q+1 and 8+2q, 9+2q of every stage
-    double2 a0 = {0, 0}, a1 = {0, 0};
-    if (nstage > 0) {
-      a0 = *reinterpret_cast<const double2*>(Ap);
-      a1 = *reinterpret_cast<const double2*>(Ap + 8);
-    }
-    for (int s = 0; s < nstage; ++s) {
-      const double* cur = smem + (s & 1) * GS_BUF;
-      double* nxt = smem + ((s & 1) ^ 1) * GS_BUF;
-      if (s + 1 < nstep && !(dbg & 2)) stage_step(s + 1, nxt);
-      const int sn = s + 1 < nstage ? s + 1 : s;
-      const double2 an0 = *reinterpret_cast<const double2*>(Ap + sn * GS_KC);
-      const double2 an1 = *reinterpret_cast<const double2*>(Ap + sn * GS_KC + 8);
-      if (act) {
+    const int s0 = ((q ^ xs) << 1), s1 = (((q + 4) ^ xs) << 1);
+    const int ob = i * 16;
+    for (int pp = 0; pp < npair; ++pp) {
+      double2 av[NS][2][2];              // [slab][stage of the pair][k pair]: this lane's strip row, k = 2q, 2q+1 | 8+2q, 9+2q
 #pragma unroll
-      for (int n4 = 0; n4 < 4; ++n4) {
-        double2 b0[4], b1[4];
+      for (int t = 0; t < NS; ++t) {
+        const double* cur = unit_begin();
+        const double* rp = cur + (16 * wave + i) * 32;
 #pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          b0[n] = *reinterpret_cast<const double2*>(cur + ob + (n4 * 4 + n) * 16 * GS_KC + s0);
-          b1[n] = *reinterpret_cast<const double2*>(cur + ob + (n4 * 4 + n) * 16 * GS_KC + s1);
+        for (int sp = 0; sp < 2; ++sp) {
+          av[t][sp][0] = *reinterpret_cast<const double2*>(rp + (((8 * sp + q) ^ i) << 1));
+          av[t][sp][1] = *reinterpret_cast<const double2*>(rp + (((8 * sp + 4 + q) ^ i) << 1));
         }
-#pragma unroll
-        for (int n = 0; n < 4; ++n) xn[n4 * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[n].x, a0.x, xn[n4 * 4 + n], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) xn[n4 * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[n].y, a0.y, xn[n4 * 4 + n], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) xn[n4 * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[n].x, a1.x, xn[n4 * 4 + n], 0, 0, 0);
-#pragma unroll
-        for (int n = 0; n < 4; ++n) xn[n4 * 4 + n] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[n].y, a1.y, xn[n4 * 4 + n], 0, 0, 0);
+        unit_end();
       }
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      a0 = an0; a1 = an1;
-      __syncthreads();
+#pragma unroll
+      for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const double* cur = unit_begin();
+          with_nact([&](auto na) {
+            constexpr int NA = decltype(na)::value;
+            double2 b0[2][2], b1[2][2];
+            auto rd = [&](int j, int set) {
+#pragma unroll
+              for (int t2 = 0; t2 < 2; ++t2) {
+                b0[set][t2] = *reinterpret_cast<const double2*>(cur + ob + (2 * j + t2) * 256 + s0);
+                b1[set][t2] = *reinterpret_cast<const double2*>(cur + ob + (2 * j + t2) * 256 + s1);
+              }
+            };
+            rd(0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              if (j < 3) rd(j + 1, (j + 1) & 1);
+              const int st = j & 1, n0 = 8 * h + 2 * j;
+#pragma unroll
+              for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                  for (int t = 0; t < NA; ++t) {
+                    const double bb = kk == 0 ? b0[st][t2].x : (kk == 1 ? b0[st][t2].y : (kk == 2 ? b1[st][t2].x : b1[st][t2].y));
+                    const double aa = kk == 0 ? av[t][sp][0].x : (kk == 1 ? av[t][sp][0].y : (kk == 2 ? av[t][sp][1].x : av[t][sp][1].y));
+                    xn[t][n0 + t2] = __builtin_amdgcn_mfma_f64_16x16x4f64(bb, aa, xn[t][n0 + t2], 0, 0, 0);
+                  }
+            }
+          });
+          unit_end();
+        }
     }
   }
-  // ---- phase 2 ----
-  int step = nstage;
+  // ---- phase 2: per tile column X units, L tiles, inverse ----
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     if (c >= nc) break;
 #pragma unroll
-    for (int cp = 0; cp <= c; ++cp, ++step) {
-      const double* cur = smem + (step & 1) * GS_BUF;
-      double* nxt = smem + ((step & 1) ^ 1) * GS_BUF;
-      if (step + 1 < nstep && !(dbg & 2)) stage_step(step + 1, nxt);
-      // a operand of block (nb, n): image row 16nb + i, the two 16-byte slots (8n + 2q + h) ^ i
-      auto a4 = [&](int nb, int n, double (&a)[4]) {
-        const double* rowp = cur + (16 * nb + i) * CT;
-        const double2 lo = *reinterpret_cast<const double2*>(rowp + (((8 * n + 2 * q) ^ i) << 1));
-        const double2 hi = *reinterpret_cast<const double2*>(rowp + (((8 * n + 2 * q + 1) ^ i) << 1));
-        a[0] = lo.x; a[1] = lo.y; a[2] = hi.x; a[3] = hi.y;
-      };
-      if ((dbg & 1) || !act) {
-      } else if (cp < c) {            // Xn_c += L[c][cp] (x) T_cp
+    for (int t = 0; t < NS; ++t)
+      for (int src = 0; src < nsrc; ++src) {
+        const double sgn = src ? 1.0 : -1.0;          // xn = -X + ..., X = A - B
 #pragma unroll
-        for (int n = 0; n < 4; ++n)
+        for (int h = 0; h < 2; ++h) {
+          const double* cur = unit_begin();
+          if (act[t]) {
+            const double* rp = cur + (16 * wave + i) * 32 + (q & 1);
 #pragma unroll
-          for (int nb = 0; nb < 4; ++nb) {
-            double a[4];
-            a4(nb, n, a);
+            for (int nbl = 0; nbl < 2; ++nbl)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              xn[4 * c + nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], xn[4 * cp + n][r], xn[4 * c + nb], 0, 0, 0);
+              for (int r = 0; r < 4; ++r) {
+                const int slot = (8 * nbl + 2 * r + (q >> 1)) ^ i;
+                xn[t][4 * c + 2 * h + nbl][r] = fma(sgn, rp[slot << 1], xn[t][4 * c + 2 * h + nbl][r]);
+              }
           }
-      } else {                 // T_c = -(Linv_cc (x) Xn_c), lower triangular: blocks n <= nb
-        v4d out[4];
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) out[nb] = (v4d){0, 0, 0, 0};
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-          for (int nb = 0; nb < 4; ++nb) {
-            if (n > nb) continue;
-            double a[4];
-            a4(nb, n, a);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              out[nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], xn[4 * c + n][r], out[nb], 0, 0, 0);
-          }
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb) xn[4 * c + nb] = -out[nb];
-        if (!(dbg & 8)) {
-#pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Xr[c * CT + 16 * nb + q + 4 * r] = xn[4 * c + nb][r];
+          unit_end();
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+    // a operand of block (nb, n) in a half-tile image: row 16nb + i, the two 16-byte slots (8(n&1) + 2q + hh) ^ i
+    auto a4 = [&](const double* cur, int nb, int nl, double (&a)[4]) {
+      const double* rowp = cur + (16 * nb + i) * 32;
+      const double2 lo = *reinterpret_cast<const double2*>(rowp + (((8 * nl + 2 * q) ^ i) << 1));
+      const double2 hi = *reinterpret_cast<const double2*>(rowp + (((8 * nl + 2 * q + 1) ^ i) << 1));
+      a[0] = lo.x; a[1] = lo.y; a[2] = hi.x; a[3] = hi.y;
+    };
+#pragma unroll
+    for (int cp = 0; cp < c; ++cp) {          // Xn_c += L[c][cp] (x) T_cp
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double* cur = unit_begin();
+        with_nact([&](auto na) {
+          constexpr int NA = decltype(na)::value;
+#pragma unroll
+          for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+            for (int nbp = 0; nbp < 2; ++nbp) {
+              double a[2][4];
+              a4(cur, 2 * nbp, nl, a[0]);
+              a4(cur, 2 * nbp + 1, nl, a[1]);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+                  for (int t = 0; t < NA; ++t)
+                    xn[t][4 * c + 2 * nbp + t2] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                        a[t2][r], xn[t][4 * cp + 2 * h + nl][r], xn[t][4 * c + 2 * nbp + t2], 0, 0, 0);
+            }
+        });
+        unit_end();
+      }
+    }
+    {                                         // T_c = -(Linv_cc (x) Xn_c), lower triangular: blocks n <= nb
+      v4d out[NS][4];
+#pragma unroll
+      for (int t = 0; t < NS; ++t)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) out[t][nb] = (v4d){0, 0, 0, 0};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const double* cur = unit_begin();
+        with_nact([&](auto na) {
+          constexpr int NA = decltype(na)::value;
+#pragma unroll
+          for (int nl = 0; nl < 2; ++nl)
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) {
+              const int n = 2 * h + nl;
+              if (n > nb) continue;
+              double a[4];
+              a4(cur, nb, nl, a);
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < NA; ++t)
+                  out[t][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], xn[t][4 * c + n][r], out[t][nb], 0, 0, 0);
+            }
+        });
+        if (h == 1) {
+#pragma unroll
+          for (int t = 0; t < NS; ++t) {
+            if (!act[t]) continue;
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb) xn[t][4 * c + nb] = -out[t][nb];
+#pragma unroll
+            for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) Xr[t][c * CT + 16 * nb + q + 4 * r] = xn[t][4 * c + nb][r];
+          }
+        }
+        unit_end();
+      }
     }
   }
 }
@@ -1216,9 +1346,16 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
                          dimg, ngrp, info, k0 == 0 ? first : off);
       ++nl;
       if (Ttot > k1) {
-        const int nitem = Ttot - k1;
-        hipLaunchKernelGGL(k_chol_gstrip, dim3(xcd_affine_grid(nitem, batch, R)), dim3(256), 0, st, mats, mat_stride, n64,
-                           Ttot, k0, nc, dimg, ngrp, nitem, batch, R, row_end, getenv("RG_CHOL_DBG") ? atoi(getenv("RG_CHOL_DBG")) : 0, first);
+        static const int NSenv = getenv("RG_CHOL_NS") ? atoi(getenv("RG_CHOL_NS")) : 1;
+        if (NSenv == 1) {
+          const int nitem = Ttot - k1;
+          hipLaunchKernelGGL(k_chol_gstrip<1>, dim3(xcd_affine_grid(nitem, batch, R)), dim3(256), 0, st, mats, mat_stride,
+                             n64, Ttot, k0, nc, dimg, ngrp, nitem, batch, R, row_end, first);
+        } else {
+          const int nitem = (Ttot - k1 + 1) / 2;
+          hipLaunchKernelGGL(k_chol_gstrip<2>, dim3(xcd_affine_grid(nitem, batch, R)), dim3(256), 0, st, mats, mat_stride,
+                             n64, Ttot, k0, nc, dimg, ngrp, nitem, batch, R, row_end, first);
+        }
         ++nl;
       }
     }
