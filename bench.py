@@ -264,7 +264,7 @@ def main():
                     traffic = tj["hbm_bytes_per_batch"] * (len(my_blocks) / n_batches) / (109 / 2.0)
                 except Exception:   # noqa: BLE001 - the field is optional
                     traffic = None
-            roof = {"kernel": {"chol_f64": "k_chol_update/panel/diag/backsolve (fp64 MFMA batched Cholesky, per level-0 batch of systems)",
+            roof = {"kernel": {"chol_f64": "k_chol_update/gfact/gstrip/backsolve (fp64 MFMA batched Cholesky, per level-0 batch of systems)",
                                "l1_gram_f64": "k_l1_gram (fp64 MFMA fold Gram)"}[dom], "bound": "mfma", "achieved": a,
                     "peak": PEAK["f64_mfma_TFLOPS"], "unit": "TFLOP/s", "frac": a / PEAK["f64_mfma_TFLOPS"], "traffic": traffic,
                     "traffic_note": "HBM bytes per launch group from separate rocprofv3 --pmc passes (profiles/r1_traffic.json), scaled by blocks per batch",

@@ -283,22 +283,24 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   ctx->v_W = nullptr; ctx->v_p0 = 0; ctx->v_np = P;
   ctx->have_problem = true;
   memset(&ctx->tm, 0, sizeof(ctx->tm));
-  // second pipeline (see rg_ctx::twin); RG_PIPELINES=1 keeps a single one
+  // further pipelines (see rg_ctx::twin): a chain of child contexts; RG_PIPELINES=1 keeps a single one
   if (ctx->twin) { rg_destroy(ctx->twin); ctx->twin = nullptr; }
   int npipe = 2;
   if (const char* e = getenv("RG_PIPELINES")) npipe = atoi(e);
+  ctx->n_pipe = 1;
   if (!ctx->is_child && npipe >= 2 && !ctx->loocv && ctx->B_total > 1) {
-    rg_ctx* ch = nullptr;
-    if (rg_create(&ch, ctx->device, nullptr) == RG_OK && ch) {
+    rg_ctx* tail = ctx;
+    for (int k = 1; k < npipe && k < ctx->B_total; ++k) {
+      rg_ctx* ch = nullptr;
+      if (rg_create(&ch, ctx->device, nullptr) != RG_OK || !ch) break;
       ch->is_child = true;
-      if (rg_set_problem(ch, p) == RG_OK) {
-        ctx->twin = ch;
-        if (!ctx->ev_tw_fork) hipEventCreateWithFlags(&ctx->ev_tw_fork, hipEventDisableTiming);
-        if (!ctx->ev_tw_join) hipEventCreateWithFlags(&ctx->ev_tw_join, hipEventDisableTiming);
-      } else {
-        rg_destroy(ch);   // e.g. not enough memory for a second workspace set: single pipeline
-      }
+      if (rg_set_problem(ch, p) != RG_OK) { rg_destroy(ch); break; }   // e.g. not enough memory for another workspace set
+      if (!ch->ev_tw_join) hipEventCreateWithFlags(&ch->ev_tw_join, hipEventDisableTiming);
+      tail->twin = ch;
+      tail = ch;
+      ++ctx->n_pipe;
     }
+    if (ctx->n_pipe > 1 && !ctx->ev_tw_fork) hipEventCreateWithFlags(&ctx->ev_tw_fork, hipEventDisableTiming);
   }
   return RG_OK;
 }
@@ -313,7 +315,7 @@ int rg_set_w_buffer(rg_ctx* ctx, void* dev_ptr, int64_t bytes) {
   if (ctx->own_W && ctx->d_W) hipFree(ctx->d_W);
   ctx->d_W = (double*)dev_ptr;
   ctx->own_W = false;
-  if (ctx->twin) { ctx->twin->d_W = ctx->d_W; ctx->twin->own_W = false; }
+  for (rg_ctx* t = ctx->twin; t; t = t->twin) { t->d_W = ctx->d_W; t->own_W = false; }
   return RG_OK;
 }
 
@@ -322,7 +324,7 @@ static int ensure_W(rg_ctx* ctx) {
   RG_HIP(hipMalloc((void**)&ctx->d_W, (size_t)ctx->W_bytes));
   RG_HIP(hipMemsetAsync(ctx->d_W, 0, (size_t)ctx->W_bytes, ctx->stream));
   ctx->own_W = true;
-  if (ctx->twin) { ctx->twin->d_W = ctx->d_W; ctx->twin->own_W = false; }
+  for (rg_ctx* t = ctx->twin; t; t = t->twin) { t->d_W = ctx->d_W; t->own_W = false; }
   return RG_OK;
 }
 
@@ -441,31 +443,38 @@ int rg_l0_blocks(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int3
   }
   int rc = ensure_W(ctx);
   if (rc) return rc;
-  // balanced batches: ceil(nblk / cap) batches of (almost) equal size
-  const int nbatch = (nblk + ctx->nblk_cap - 1) / ctx->nblk_cap;
+  // balanced batches: ceil(nblk / cap) batches of (almost) equal size, at least one per pipeline
+  // Several pipelines: batch ib runs in context (ib mod n_pipe) of the chain, each on its own stream, ordered after
+  // everything already queued on ctx->stream and joined back before this call returns (the caller sees one stream).  The
+  // per-stage timing mode keeps a single pipeline so that its HIP-event brackets stay meaningful.
+  const int npipe = (ctx->twin && !ctx->timing) ? ctx->n_pipe : 1;
+  int nbatch = (nblk + ctx->nblk_cap - 1) / ctx->nblk_cap;
+  if (npipe > 1 && nblk >= 2 * npipe) nbatch = (nbatch + npipe - 1) / npipe * npipe;
   const int per = (nblk + nbatch - 1) / nbatch;
-  // two pipelines: odd batches run in the child context on its own stream, ordered after everything already queued
-  // on ctx->stream, and joined back before this call returns (the caller sees one stream).  The per-stage timing mode
-  // keeps a single pipeline so that its HIP-event brackets stay meaningful.
-  rg_ctx* tw = (ctx->twin && !ctx->timing && nbatch > 1) ? ctx->twin : nullptr;
-  if (tw) {
-    tw->d_W = ctx->d_W; tw->own_W = false;
+  const bool multi = npipe > 1 && nbatch > 1;
+  if (multi) {
     RG_HIP(hipEventRecord(ctx->ev_tw_fork, ctx->stream));
-    RG_HIP(hipStreamWaitEvent(tw->stream, ctx->ev_tw_fork, 0));
+    for (rg_ctx* t = ctx->twin; t; t = t->twin) {
+      t->d_W = ctx->d_W; t->own_W = false;
+      RG_HIP(hipStreamWaitEvent(t->stream, ctx->ev_tw_fork, 0));
+    }
   }
   int ib = 0;
   for (int b0 = 0; b0 < nblk; b0 += per, ++ib) {
     const int nb = std::min(per, nblk - b0);
     // within a context the small H2D descriptor copies of the next batch must not overtake the kernels of the
     // previous one: everything of a pipeline is ordered on its stream.
-    rg_ctx* c = (tw && (ib & 1)) ? tw : ctx;
+    rg_ctx* c = ctx;
+    if (multi) for (int k = ib % npipe; k > 0 && c->twin; --k) c = c->twin;
     rc = l0_batch(c, nb, block_ids + b0, bs + b0, bed_rows + b0, row_stride, mem_kind);
     if (rc) { if (c != ctx) ctx->err = c->err; return rc; }
     if (c != ctx) for (int b = 0; b < nb; ++b) ctx->block_done[block_ids[b0 + b]] = 1;
   }
-  if (tw) {
-    RG_HIP(hipEventRecord(ctx->ev_tw_join, tw->stream));
-    RG_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_tw_join, 0));
+  if (multi) {
+    for (rg_ctx* t = ctx->twin; t; t = t->twin) {
+      RG_HIP(hipEventRecord(t->ev_tw_join, t->stream));
+      RG_HIP(hipStreamWaitEvent(ctx->stream, t->ev_tw_join, 0));
+    }
   }
   return RG_OK;
 }
@@ -474,7 +483,7 @@ int rg_sync(rg_ctx* ctx) {
   if (!ctx) return RG_ERR_ARG;
   hipSetDevice(ctx->device);
   RG_HIP(hipStreamSynchronize(ctx->stream));
-  if (ctx->twin) {   // deferred device-side errors of the second pipeline
+  if (ctx->twin) {   // deferred device-side errors of the other pipelines (each child syncs the rest of the chain)
     int rc2 = rg_sync(ctx->twin);
     if (rc2) { ctx->err = ctx->twin->err; return rc2; }
   }

@@ -125,10 +125,11 @@ struct rg_ctx {
   rg_allreduce_fn coll_allreduce = nullptr;
   void* coll_user = nullptr;
 
-  // second level-0 pipeline: a child context with its own workspaces and HIP stream that shares W.  Alternate
-  // batches go to it, so the streaming phases (ingest, covariate products, FP4 Gram, assemble, predictions) of
+  // further level-0 pipelines: a chain of child contexts, each with its own workspaces and HIP stream, sharing W.
+  // Batches are dealt round-robin, so the streaming phases (ingest, covariate products, FP4 Gram, assemble, predictions) of
   // one batch overlap the latency/HBM-bound Cholesky of the other.  Joined back onto `stream` with events.
-  rg_ctx* twin = nullptr;
+  rg_ctx* twin = nullptr;       // next context of the pipeline chain
+  int n_pipe = 1;               // contexts in the chain (set on the parent)
   bool is_child = false;
   hipEvent_t ev_tw_fork = nullptr, ev_tw_join = nullptr;
 

@@ -9,7 +9,7 @@ import glob
 import json
 import sys
 
-GROUP = ("k_chol_update", "k_chol_panel", "k_chol_diag", "k_chol_backsolve")
+GROUP = ("k_chol_update", "k_chol_gfact", "k_chol_gstrip", "k_chol_backsolve")
 
 
 def total(d, counter, level0_only=True):
