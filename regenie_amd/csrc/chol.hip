@@ -187,6 +187,324 @@ __device__ __forceinline__ double bcast_lane(double x, int l) {
   return __hiloint2double(hi, lo);
 }
 
+// ---- blocked (16) factorization + inverse of the 64x64 tile held in LDS (lower triangle of s), 256 threads -------
+// On return: lower triangle + diagonal of s = L, strict upper triangle = Linv^T, dv[r] = Linv[r][r].
+// Returns true (in some thread) when a pivot was not positive.
+__device__ __forceinline__ bool diag_factor_lds(double (&s)[CT][CT + 2], double (&dv)[CT]) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  // ---- blocked (16) factorization + inverse, the 16x16x16 block products on the fp64 MFMA ---------------
+  // MFMA 16x16x4: lane (i = lane&15, q = lane>>4) supplies A[i][kk], B[kk][i] and owns D[q + 4r][i], r = 0..3;
+  // a K = 16 block product is 4 instructions with kk(q, s) chosen per product (any permutation of K is fine
+  // as long as A and B use the same one).
+  // element (r, c) of the inverse of a DIAGONAL 16-block at offset o (0 above the diagonal)
+  auto inv_diag = [&](int o, int r, int c) -> double {
+    return (c < r) ? s[o + c][o + r] : ((c == r) ? dv[o + r] : 0.0);
+  };
+  bool bad = false;
+  for (int sb = 0; sb < 4; ++sb) {
+    const int o = sb * 16;
+    const int nb = 3 - sb;   // 16-row blocks below the diagonal block
+    // (i) diagonal block: lanes 0..15 of wave 0 hold one row each in registers; then its inverse, one column each
+    if (tid < 16) {
+      // cross-lane values are broadcast with v_readlane (compile-time lane index, no LDS round trip); square root
+      // and reciprocal come from one v_rsq_f64 + two Newton steps (~1 ulp), far shorter than sqrt() followed by a division
+      double a[16], rdv[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = s[o + tid][o + c];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double piv = bcast_lane(a[c], c);
+        double d, rd;
+        if (piv > 0.0) {
+          double r0 = __builtin_amdgcn_rsq(piv);
+          r0 = r0 * fma(-0.5 * piv * r0, r0, 1.5);
+          r0 = r0 * fma(-0.5 * piv * r0, r0, 1.5);
+          d = piv * r0;
+          d = fma(0.5 * r0, fma(-d, d, piv), d);     // sqrt(piv)
+          rd = fma(r0, fma(-d, r0, 1.0), r0);        // 1 / sqrt(piv)
+        } else { d = 1.0; rd = 1.0; bad = true; }
+        rdv[c] = rd;
+        if (tid > c) a[c] *= rd;
+        else if (tid == c) a[c] = d;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; ++c2) {
+          const double l = bcast_lane(a[c], c2);  // L[c2][c]
+          if (tid >= c2) a[c2] = fma(-a[c], l, a[c2]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c <= tid) s[o + tid][o + c] = a[c];
+      // inverse of the 16x16 triangle: lane = column, forward substitution; L[r][j] comes from lane r's registers
+      double x[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        double v = (r == tid) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < r; ++j) v = fma(-bcast_lane(a[j], r), x[j], v);
+        x[r] = v * rdv[r];
+      }
+      dv[o + tid] = x[tid];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (r > tid) s[o + tid][o + r] = x[r];   // Linv[r][tid], transposed into the upper triangle
+    }
+    __syncthreads();
+    // (ii) rows below: L21 = A21 * Linv11^T, one 16-row block per wave
+    if (wave < nb) {
+      const int rb = o + 16 + 16 * wave;
+      v4d acc = (v4d){0, 0, 0, 0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s[rb + li][o + 4 * lq + st], inv_diag(o, li, 4 * lq + st), acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[rb + lq + 4 * r][o + li] = acc[r];
+    }
+    __syncthreads();
+    // (iii) trailing update inside the tile: A22 -= L21 L21^T (lower blocks; only the lower triangle of the
+    //       diagonal blocks is written -- their upper triangle will hold the inverse), blocks dealt to the waves
+    {
+      const int nblk2 = nb * (nb + 1) / 2;
+      for (int idx = wave; idx < nblk2; idx += 4) {
+        int bi = 0, rem = idx;
+        while (rem > bi) { rem -= bi + 1; ++bi; }
+        const int bj = rem;
+        const int ri = o + 16 + 16 * bi, rj = o + 16 + 16 * bj;
+        v4d acc = (v4d){0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s[ri + li][o + 4 * lq + st], s[rj + li][o + 4 * lq + st], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (bi != bj || li <= lq + 4 * r) s[ri + lq + 4 * r][rj + li] -= acc[r];
+      }
+    }
+    __syncthreads();
+  }
+  // off-diagonal blocks of the inverse (i > j), by sub-diagonal distance:
+  //   Linv[i][j] = -Linv[i][i] * sum_{kb=j}^{i-1} L[i][kb] Linv[kb][j]      (Linv[kb][j] at s[16j + .][16kb + .]^T)
+  for (int dist = 1; dist < 4; ++dist) {
+    const int j = wave, ib = wave + dist;
+    if (ib < 4) {
+      v4d m1 = (v4d){0, 0, 0, 0};
+      for (int kb = j; kb < ib; ++kb) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const int kk = 4 * lq + st;
+          const double bval = (kb == j) ? inv_diag(16 * j, kk, li) : s[16 * j + li][16 * kb + kk];
+          m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(s[16 * ib + li][16 * kb + kk], bval, m1, 0, 0, 0);
+        }
+      }
+      // second product with kk(q, st) = q + 4 st: the B operand M1[kk][li] is exactly register st of m1
+      v4d acc = (v4d){0, 0, 0, 0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(inv_diag(16 * ib, li, lq + 4 * st), m1[st], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[16 * j + li][16 * ib + lq + 4 * r] = -acc[r];
+    }
+    __syncthreads();
+  }
+  return bad;
+}
+
+// ==== small-batch path (a few dozen systems: level 1, the logistic IRLS steps) ========================================
+// With fewer systems than SIMDs the wave-per-system block factorization is a long serial chain per system; here every
+// tile column is two launches that spread one system over many waves: k_chol_diag (one workgroup per system: in-group
+// update, factorization and inverse of the diagonal tile) and k_chol_panel (one wave per tile below it), followed per
+// group by the wide trailing update.
+// Left-looking inside a column group: before factoring, the tile is updated with the group's earlier tile
+// columns [kc0, kc0 + nkc):  A[k][k] -= sum_q L[k][q] L[k][q]^T  (fp64 MFMA, operands straight from HBM/L2).
+__global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_stride, int n64, int k, int kc0,
+                                                   int nkc, double* dinv, int32_t* info, FormSrc fs) {
+  // ONE 64 x 66 LDS array holds both results (34 KB -> 4 workgroups per CU, a whole 800-system batch resident):
+  //   lower triangle + diagonal : L            strict upper triangle : Linv^T  (Linv[r][c] at s[c][r], r > c)
+  //   dv[r] = Linv[r][r] = 1 / L[r][r]
+  __shared__ double s[CT][CT + 2];
+  __shared__ double dv[CT];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  double* D = mats + (int64_t)b * mat_stride + (int64_t)k * CT * n64 + k * CT;
+  if (fs.enabled) {
+    const FormIdx fx = form_idx(fs, b);
+    const int md = form_mode(fx);
+#pragma unroll
+    for (int u = 0; u < CT * CT / 256; ++u) {   // unconditional loads (the upper triangle of the source exists), then select
+      const int e = tid + 256 * u;
+      const int r = e >> 6, c = e & 63;
+      const int gi = k * CT + r, gj = k * CT + c;
+      const int64_t ge = (int64_t)gi * n64 + gj;
+      const double v = md == 0 ? form_val<0>(fx, gi, gj, ge) : (md == 1 ? form_val<1>(fx, gi, gj, ge) : form_val<2>(fx, gi, gj, ge));
+      s[r][c] = (c <= r) ? v : 0.0;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < CT * CT / 256; ++u) {
+      const int e = tid + 256 * u;
+      const int r = e >> 6, c = e & 63;
+      const double v = D[(int64_t)r * n64 + c];
+      s[r][c] = (c <= r) ? v : 0.0;
+    }
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  if (nkc > 0) {
+    const int wr = wave >> 1, wc = wave & 1;
+    const int i = li, q = lq;
+    const double* Mrow = mats + (int64_t)b * mat_stride + (int64_t)k * CT * n64 + (int64_t)kc0 * CT + 16 * q;
+    v4d acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
+    if (wc <= wr) {   // the strictly upper 32x32 block is never referenced
+      for (int kk = 0; kk < nkc; ++kk) {
+        const double* ar[2] = {Mrow + (int64_t)(wr * 32 + i) * n64 + kk * CT, Mrow + (int64_t)(wr * 32 + 16 + i) * n64 + kk * CT};
+        const double* br[2] = {Mrow + (int64_t)(wc * 32 + i) * n64 + kk * CT, Mrow + (int64_t)(wc * 32 + 16 + i) * n64 + kk * CT};
+        double av[2][16], bv[2][16];
+        dmma_load<2, 2>(ar, br, av, bv);
+        dmma_fma<2, 2>(av, bv, acc);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rr = wr * 32 + m * 16 + q + 4 * r, cc = wc * 32 + n * 16 + i;
+            if (cc <= rr) s[rr][cc] -= acc[m][n][r];
+          }
+    }
+    __syncthreads();
+  }
+  if (diag_factor_lds(s, dv)) atomicMax(info, 1);
+  double* I = dinv + ((int64_t)b * (n64 / CT) + k) * CT * CT;
+  for (int e = tid; e < CT * CT; e += 256) {
+    const int rr = e >> 6, c = e & 63;
+    if (c <= rr) D[(int64_t)rr * n64 + c] = s[rr][c];
+    I[e] = (c < rr) ? s[c][rr] : ((c == rr) ? dv[rr] : 0.0);
+  }
+}
+
+// ---- panel: L[t][k] = (A[t][k] - sum_q L[t][q] L[k][q]^T) * Linv^T, q over the group's earlier tile columns ----
+// (left-looking inside the column group: the tile is read once and written once).  One WAVE per 64x64 tile, four
+// tiles of the same tile column per workgroup (they share L[k][q] and Linv, the latter staged once in LDS).
+// The in-group update is accumulated TRANSPOSED -- acc[n][m] += L[k]-rows(n) x L[t]-rows(m)^T -- so that lane
+// (i, q) ends up holding U[row 16m + i][cols 16n + q + 4r] of the updated tile U: one row, 16 column values per
+// 16-column block, which is exactly an MFMA A-operand layout for the triangular multiply T = U * Linv^T with the K
+// assignment kk(q, step = (n, r)) = 16n + q + 4r.  No LDS round trip, no barrier between update and multiply; the
+// K steps with n > (column block of the output) are skipped because Linv is lower triangular.
+#define PL_PITCH 66
+__global__ __launch_bounds__(256, 2) void k_chol_panel(double* mats, int64_t mat_stride, int n64, int k, int kc0,
+                                                       int nkc, const double* dinv, int ngrp4, int batch, int R,
+                                                       int ntile, FormSrc fs) {
+  __shared__ double sLi[CT * PL_PITCH];
+  int b, g;
+  if (!xcd_affine(blockIdx.x, ngrp4, batch, R, b, g)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  double* M = mats + (int64_t)b * mat_stride;
+  {  // stage Linv (64 x 64 doubles) with coalesced 32-byte loads
+    const double* I = dinv + ((int64_t)b * (n64 / CT) + k) * CT * CT;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e4 = threadIdx.x + 256 * u;          // index of a double4
+      const int r = e4 >> 4, c4 = (e4 & 15) * 4;
+      const double4 v = *reinterpret_cast<const double4*>(I + r * CT + c4);
+      double* d = sLi + r * PL_PITCH + c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  }
+  __syncthreads();
+  const int idx = g * 4 + wave;
+  if (idx >= ntile) return;
+  const int t = k + 1 + idx;
+  double* T = M + (int64_t)t * CT * n64 + k * CT;
+  // accT[n][m][r] = -(U[row 16m + i][col 16n + q + 4r])
+  v4d acc[4][4];
+  {
+    auto init = [&](auto mode) {
+      FormIdx fx{};
+      if (decltype(mode)::value >= 0) fx = form_idx(fs, b);
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int lr = m * 16 + i, lc = n * 16 + q + 4 * r;
+            if (decltype(mode)::value < 0) acc[n][m][r] = -T[(int64_t)lr * n64 + lc];
+            else {
+              const int gi = t * CT + lr, gj = k * CT + lc;
+              acc[n][m][r] = -form_val<(decltype(mode)::value < 0 ? 0 : decltype(mode)::value)>(fx, gi, gj, (int64_t)gi * n64 + gj);
+            }
+          }
+    };
+    if (!fs.enabled) init(std::integral_constant<int, -1>{});
+    else {
+      const FormIdx f0 = form_idx(fs, b);
+      const int md = form_mode(f0);
+      if (md == 0) init(std::integral_constant<int, 0>{});
+      else if (md == 1) init(std::integral_constant<int, 1>{});
+      else init(std::integral_constant<int, 2>{});
+    }
+  }
+  if (nkc > 0) {
+    const double* A = M + ((int64_t)t * CT + i) * n64 + kc0 * CT + 2 * q;   // rows of the tile's own tile row
+    const double* B = M + ((int64_t)k * CT + i) * n64 + kc0 * CT + 2 * q;   // rows of tile row k (the column's L[k][q])
+    const int nk8 = nkc * 8;
+    auto load8 = [&](double2 (&av)[4], double2 (&bv)[4], int kc) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        av[m] = *reinterpret_cast<const double2*>(A + (int64_t)m * 16 * n64 + kc * 8);
+        bv[m] = *reinterpret_cast<const double2*>(B + (int64_t)m * 16 * n64 + kc * 8);
+      }
+    };
+    auto mma8 = [&](const double2 (&av)[4], const double2 (&bv)[4]) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[n].x, av[m].x, acc[n][m], 0, 0, 0);
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[n][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv[n].y, av[m].y, acc[n][m], 0, 0, 0);
+    };
+    double2 a0[4], b0[4], a1[4], b1[4];
+    load8(a0, b0, 0);
+    for (int kc = 0; kc < nk8; kc += 2) {
+      load8(a1, b1, kc + 1);
+      mma8(a0, b0);
+      if (kc + 2 < nk8) load8(a0, b0, kc + 2);
+      mma8(a1, b1);
+    }
+  }
+  // triangular multiply, one 16-row block at a time: out[cb] = sum_{n <= cb, r} (-acc[n][m][r]) x Linv[16cb + i][16n + q + 4r]
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    v4d out[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      out[cb] = (v4d){0, 0, 0, 0};
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (n > cb) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          out[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[n][m][r], sLi[(cb * 16 + i) * PL_PITCH + n * 16 + q + 4 * r],
+                                                         out[cb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) T[(int64_t)(m * 16 + q + 4 * r) * n64 + cb * 16 + i] = out[cb][r];
+  }
+}
+
 // ---- update: A[r][c] -= sum_{q in [kc0, kc0+nkc)} L[r][q] L[c][q]^T for tile columns c in [c_lo, c_hi),
 //      rows r in [c, Ttot) (matrix tiles below/on the diagonal plus the RHS row tiles) ---------------------
 // One WAVE per 64x64 tile (4 x 4 MFMA sub-tiles, 64 accumulator doubles per lane): per 16-deep K chunk a
@@ -1017,6 +1335,43 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
   FormSrc off{};
   off.enabled = 0; off.extra = nullptr; off.n_div = 1; off.b_offset = 0;
   int64_t nl = 0;
+  const char* se = getenv("RG_CHOL_SMALL");   // read per call: the tests switch paths
+  const int small_max = se ? atoi(se) : 64;
+  if (batch <= small_max) {   // small-batch path: per-column diag / panel launches, wide updates per group
+    const int G = 4;
+  for (int k0 = 0; k0 < T; k0 += G) {
+    const int k1 = std::min(T, k0 + G);
+    // first touch of every tile happens in the first group: tile columns < G by diag/panel, the rest by the
+    // wide update; systems that share a source matrix (the shifts) are co-located on one XCD for those launches
+    const FormSrc& first = (src && k0 == 0) ? *src : off;
+    const int R = (src && k0 == 0) ? std::max(1, src->nshift) : 1;
+    for (int j = k0; j < k1; ++j) {
+      hipLaunchKernelGGL(k_chol_diag, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, j, k0, j - k0, dinv,
+                         info, first);
+      ++nl;
+      if (Ttot - 1 - j > 0) {
+        const int npt = Ttot - 1 - j;   // panel tiles of this column, four per workgroup
+        hipLaunchKernelGGL(k_chol_panel, dim3(xcd_affine_grid((npt + 3) / 4, batch, R)), dim3(256), 0, st, mats,
+                           mat_stride, n64, j, k0, j - k0, dinv, (npt + 3) / 4, batch, R, npt, first);
+        ++nl;
+      }
+    }
+    if (k1 < T) {  // wide trailing update with the whole group (K = 64 * (k1 - k0))
+      int ntile = 0;
+      for (int c = k1; c < T; ++c) ntile += Ttot - c;
+      hipLaunchKernelGGL(k_chol_update, dim3(xcd_affine_grid((ntile + 3) / 4, batch, R)), dim3(256), 0, st, mats,
+                         mat_stride, n64, Ttot, k1, T, ntile, k0, k1 - k0, batch, R, first);
+      ++nl;
+    }
+  }
+  if (nrhs > 0) {
+    hipLaunchKernelGGL(k_chol_backsolve, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, nrhs, dinv);
+    ++nl;
+  }
+  if (n_launch) *n_launch += nl;
+    return;
+  }
+
   // First touch of a tile (read from the source matrices instead of the workspace): group 0 by gfact/gstrip, later groups
   // by the diagonal-block update and gstrip.  Systems that share a source matrix (the shifts) are co-located on one XCD.
   const int R = src ? std::max(1, src->nshift) : 1;

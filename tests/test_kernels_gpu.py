@@ -74,8 +74,11 @@ def test_dgemm_nt(m, n, k):
 @pytest.mark.parametrize("n,nrhs,batch,rhs_pad", [(64, 1, 3, 64), (100, 2, 2, 64), (200, 5, 4, 64), (1000, 3, 2, 64),
                                                   (300, 2, 3, 64), (545, 70, 2, 128), (256, 130, 9, 192),
                                                   (130, 300, 2, 320)])
-def test_chol_solve(n, nrhs, batch, rhs_pad):
-    """tile counts 1..16 (partial last column group: 5, 9 tiles), several right-hand-side row tiles (odd totals)"""
+@pytest.mark.parametrize("path", ["group", "column"])
+def test_chol_solve(n, nrhs, batch, rhs_pad, path, monkeypatch):
+    """tile counts 1..16 (partial last column group: 5, 9 tiles), several right-hand-side row tiles (odd totals); both
+    factorization paths: group-wise (large batches) and per-column (small batches)"""
+    monkeypatch.setenv("RG_CHOL_SMALL", "0" if path == "group" else "1000000")
     lib = load_library()
     rng = np.random.default_rng(11)
     n64 = (n + 63) // 64 * 64
