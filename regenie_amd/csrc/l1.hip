@@ -122,6 +122,25 @@ __global__ void k_sum_folds(const double* fold, int64_t msz, int nfold, double* 
   sum[e] = t;
 }
 
+// ---- multi-rank exchange of the fold Grams: only the computed tiles travel ------------------------------------------
+// The fold matrices live as full rows (ld = n64) but only the lower-triangle tiles and the y-row tiles are ever non-zero;
+// packing them tile by tile ([fold][tile][64][64], tile (tr, tc) -> tr(tr+1)/2 + tc) halves the all-reduce volume.
+__global__ __launch_bounds__(256) void k_tiles_pack(double* fold, int64_t msz, int T, int n64, double* packed, int unpack) {
+  const int t = blockIdx.x, f = blockIdx.y;
+  int tr = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+  while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+  while (tr * (tr + 1) / 2 > t) --tr;
+  int tc = t - tr * (tr + 1) / 2;
+  if (tr >= T) { tc = t - T * (T + 1) / 2; tr = T; }      // the y row tiles follow the triangle
+  double* src = fold + (int64_t)f * msz + (int64_t)tr * CT * n64 + tc * CT;
+  double* pk = packed + ((int64_t)f * gridDim.x + t) * (CT * CT);
+  for (int e = threadIdx.x; e < CT * CT; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    if (unpack) src[(int64_t)r * n64 + c] = pk[e];
+    else pk[e] = src[(int64_t)r * n64 + c];
+  }
+}
+
 // ---- out-of-fold predictions for every tau + the five running sums -----------------------------------
 // alpha: [(f*R1 + j)] systems, solution = RHS row 0 (row n64) of each factored system.
 // grid (nchunk), 256 threads, thread = one position.  part: [chunk][R1][3] + ysum [chunk][2]
@@ -250,7 +269,7 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
   nslice = (int)std::max<int64_t>(1, std::min<int64_t>(nslice, min_nch / 4));
 
   double *d_fold = nullptr, *d_part = nullptr, *d_sum = nullptr, *d_wk = nullptr, *d_dinv = nullptr, *d_tau = nullptr,
-         *d_cvp = nullptr, *d_pred = nullptr, *d_alpha = nullptr;
+         *d_cvp = nullptr, *d_pred = nullptr, *d_alpha = nullptr, *d_pack = nullptr;
   int32_t* d_col0 = nullptr;
 #define L1_WS(var, slot, type, count)                                                   \
   var = (type*)rg_ws(ctx, slot, sizeof(type) * (size_t)(count));                        \
@@ -265,6 +284,7 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
   L1_WS(d_pred, 7, double, (size_t)nchr * ctx->N)
   L1_WS(d_alpha, 8, double, (size_t)nsys * n64)
   L1_WS(d_col0, 9, int32_t, nchr + 1)
+  if (multi) { L1_WS(d_pack, 10, double, (size_t)ntile * K * CT * CT) }
 #undef L1_WS
   RG_HIP(hipMemcpyAsync(d_col0, col0.data(), sizeof(int32_t) * (nchr + 1), hipMemcpyHostToDevice, st));
   std::vector<double> hpart((size_t)nch * NPART);
@@ -289,9 +309,11 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
     if (nslice > 1)
       hipLaunchKernelGGL(k_reduce_slices, dim3((unsigned)((msz * K + 255) / 256)), dim3(256), 0, st, d_part, msz * K,
                          nslice, msz * K, d_fold);
-    if (multi) {  // every rank needs every fold matrix: sum of disjoint tile sets
+    if (multi) {  // every rank needs every fold matrix: sum of disjoint tile sets, exchanged tile-packed
+      hipLaunchKernelGGL(k_tiles_pack, dim3(ntile, K), dim3(256), 0, st, d_fold, msz, T, n64, d_pack, 0);
       RG_HIP(hipStreamSynchronize(st));
-      if (ctx->coll_allreduce(ctx->coll_user, d_fold, msz * K) != 0) { ctx->err = "rg_l1_qt: all-reduce callback failed"; rc = RG_ERR_STATE; break; }
+      if (ctx->coll_allreduce(ctx->coll_user, d_pack, (int64_t)ntile * K * CT * CT) != 0) { ctx->err = "rg_l1_qt: all-reduce callback failed"; rc = RG_ERR_STATE; break; }
+      hipLaunchKernelGGL(k_tiles_pack, dim3(ntile, K), dim3(256), 0, st, d_fold, msz, T, n64, d_pack, 1);
     }
     hipLaunchKernelGGL(k_sum_folds, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, st, d_fold, msz, K, d_sum);
     lap(&ctx->tm.ms_l1_gram, e0, e1);
