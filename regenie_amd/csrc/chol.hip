@@ -1330,13 +1330,19 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(double* mats, int64_t ma
 
 void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, int batch, int n64,
                               int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch,
-                              const FormSrc* src) {
+                              const FormSrc* src, int path) {
   const int T = n64 / CT, Tr = rhs_pad / CT, Ttot = T + Tr;
   FormSrc off{};
   off.enabled = 0; off.extra = nullptr; off.n_div = 1; off.b_offset = 0;
   int64_t nl = 0;
-  const char* se = getenv("RG_CHOL_SMALL");   // read per call: the tests switch paths
-  const int small_max = se ? atoi(se) : 64;
+  // path: 0 = group-wise (throughput: level 0, whatever the batch size, so that results do not depend on how the blocks
+  // are batched), 1 = per-column (latency: level 1 and the logistic steps, a few dozen systems), -1 = by batch size
+  // (test entry; RG_CHOL_SMALL moves the threshold)
+  int small_max = path == 1 ? 0x7fffffff : -1;
+  if (path < 0) {
+    const char* se = getenv("RG_CHOL_SMALL");
+    small_max = se ? atoi(se) : 64;
+  }
   if (batch <= small_max) {   // small-batch path: per-column diag / panel launches, wide updates per group
     const int G = 4;
   for (int k0 = 0; k0 < T; k0 += G) {
@@ -1407,8 +1413,8 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
 }
 
 void rg_launch_chol_solve(hipStream_t st, double* mats, int64_t mat_stride, int batch, int n64,
-                          int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch) {
-  rg_launch_chol_solve_src(st, mats, mat_stride, batch, n64, rhs_pad, nrhs, dinv, info, n_launch, nullptr);
+                          int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch, int path) {
+  rg_launch_chol_solve_src(st, mats, mat_stride, batch, n64, rhs_pad, nrhs, dinv, info, n_launch, nullptr, path);
 }
 
 // General form: subtract = 0 drops the held-out-fold term (LOOCV); rows >= extra_row0 of every system are
@@ -1418,12 +1424,12 @@ void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t su
                                    const int32_t* d_n, int n_fixed, int nouter, double* mats,
                                    int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
                                    int32_t* info, int64_t* n_launch, int subtract, const double* extra,
-                                   int64_t extra_stride, int extra_row0, int n_div, int b_offset, int b_count) {
+                                   int64_t extra_stride, int extra_row0, int n_div, int b_offset, int b_count, int path) {
   FormSrc f;
   f.sum = sum; f.sum_stride = sum_stride; f.fold = fold; f.fold_stride = fold_stride; f.shift = shift;
   f.d_n = d_n; f.nfold = nfold; f.nshift = nshift; f.n_fixed = n_fixed; f.enabled = 1;
   f.subtract = subtract; f.extra = extra; f.extra_stride = extra_stride; f.extra_row0 = extra_row0; f.n64 = n64;
   f.n_div = n_div; f.b_offset = b_offset;
   rg_launch_chol_solve_src(st, mats, mat_stride, b_count >= 0 ? b_count : nouter * nfold * nshift, n64, rhs_pad, nrhs,
-                           dinv, info, n_launch, &f);
+                           dinv, info, n_launch, &f, path);
 }

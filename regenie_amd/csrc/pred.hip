@@ -7,6 +7,7 @@
 // with G~ = G0 + D_mu M decoded on the fly from the cleaned 2-bit rows, so the standardised
 // genotype matrix is never materialised (the reference allocates bs x N doubles per block).
 #include <algorithm>
+#include <type_traits>
 #include "rg_internal.h"
 
 // ---- beta~ = x / scale_G and cb = beta~^T B --------------------------------------------------------
@@ -45,10 +46,12 @@ __global__ __launch_bounds__(256) void k_beta_post(PredArgs a) {
 // NR = number of ridge values carried in registers (5 for the default grid, 8 max).
 // The packed genotype tile (JT SNP rows x 1024 positions = 256 bytes per row) is staged through LDS
 // with coalesced 16-byte loads so the inner loop never waits on HBM; the inner loop per SNP row is
-// decode (2 ops per sample) + NR FMAs per sample with the coefficients as scalar (SGPR) operands.
+// decode (2 ops per sample) + NR FMAs per sample; the coefficients of the tile are staged in LDS next to it and read
+// back as broadcasts.
 template <int NR>
 __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
   __shared__ __attribute__((aligned(16))) uint8_t sP[JT][256 + 16];
+  __shared__ __attribute__((aligned(16))) double sB[JT][NR + 1];   // coefficients of the tile's SNPs, then their means
   __shared__ double sred[4][RMAX][2];
   const int blk = blockIdx.z, p = blockIdx.y, ch = blockIdx.x;
   const int bs = a.bs[blk];
@@ -91,37 +94,50 @@ __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
           if (!ok) v = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
           *reinterpret_cast<uint4*>(&sP[row][c16]) = v;
         }
+        // the tile's coefficients (and means): uniform across the wave, so every lane reads the same LDS word
+        // (broadcast).  Left to itself hipcc fetched them with per-SNP vector loads followed by vmcnt(0).
+        for (int e = threadIdx.x; e < JT * (NR + 1); e += 256) {
+          const int r = e / JT, t = e - r * JT;     // beta is zero-padded beyond bs (n64 entries), mu has n128
+          const int j = min(jt + t, a.n64 - 1);     // clamped: rows beyond bs decode to 0 and are never multiplied
+          const double v = r < NR ? bp[r < R0 ? r : 0][j] : mu[j];
+          sB[t][r] = jt + t < bs ? v : 0.0;
+        }
       }
       __syncthreads();
       if (live) {
-        // beta_r[j] and mu[j] are the same for every position, i.e. uniform across the wave: they come through the
-        // scalar cache and enter the FMAs as SGPR operands (beta is zero-padded beyond bs, rows beyond bs decode to 0)
         const int jn = (min(JT, bs - jt) + 3) & ~3;
+        auto run = [&](auto miss) {
 #pragma unroll 1
-        for (int t0 = 0; t0 < jn; t0 += 4) {
+          for (int t0 = 0; t0 < jn; t0 += 4) {
+            unsigned bb[4];
 #pragma unroll
-          for (int tt = 0; tt < 4; ++tt) {
-            const int t = t0 + tt;
-            const unsigned b = sP[t][threadIdx.x];
-            const unsigned lo = b & 0x55u, hi = (b >> 1) & 0x55u;
-            const unsigned dd = (hi & ~lo) | ((~(hi | lo) & 0x55u) << 1);   // 2-bit dosage fields
-            double g[4];
+            for (int tt = 0; tt < 4; ++tt) bb[tt] = sP[t0 + tt][threadIdx.x];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g[i] = (double)((dd >> (2 * i)) & 3u);
-            if (has_miss) {
-              const unsigned ms = lo & ~hi;
-              const double m = mu[jt + t];
+            for (int tt = 0; tt < 4; ++tt) {
+              const int t = t0 + tt;
+              const unsigned b = bb[tt];
+              const unsigned lo = b & 0x55u, hi = (b >> 1) & 0x55u;
+              const unsigned dd = (hi & ~lo) | ((~(hi | lo) & 0x55u) << 1);   // 2-bit dosage fields
+              double g[4];
 #pragma unroll
-              for (int i = 0; i < 4; ++i) g[i] = fma((double)((ms >> (2 * i)) & 1u), m, g[i]);
-            }
+              for (int i = 0; i < 4; ++i) g[i] = (double)((dd >> (2 * i)) & 3u);
+              if (decltype(miss)::value) {
+                const unsigned ms = lo & ~hi;
+                const double m = sB[t][NR];
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-              const double bt = bp[r < R0 ? r : 0][jt + t];
+                for (int i = 0; i < 4; ++i) g[i] = fma((double)((ms >> (2 * i)) & 1u), m, g[i]);
+              }
 #pragma unroll
-              for (int i = 0; i < 4; ++i) acc[i][r] = fma(g[i], bt, acc[i][r]);
+              for (int r = 0; r < NR; ++r) {
+                const double bt = sB[t][r];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i][r] = fma(g[i], bt, acc[i][r]);
+              }
             }
           }
-        }
+        };
+        if (has_miss) run(std::true_type{});
+        else run(std::false_type{});
       }
     }
     if (live) {

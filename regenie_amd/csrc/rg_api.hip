@@ -399,7 +399,7 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
       rg_launch_chol_solve_formed_x(st, ctx->d_sum, msz, ctx->d_fold, msz, 1, ctx->d_lambda, R0, ctx->d_bs, 0, nblk,
                                     ctx->d_wk, ctx->rtot_wk * n64, n64, (int)(ctx->rtot_wk - n64), 0, ctx->d_dinv,
                                     ctx->d_info + 1, &ctx->tm.n_chol_launches, 0, ctx->d_gt,
-                                    (int64_t)ctx->Np * n64, rtot);
+                                    (int64_t)ctx->Np * n64, rtot, 1, 0, -1, 0);
     }
     {
       StageTimer t(ctx, &ctx->tm.ms_pred);
@@ -412,7 +412,7 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     // (block, fold), shared by the R0 shifted systems that are co-located on one XCD for their first touch
     rg_launch_chol_solve_formed_x(st, ctx->d_fold, msz, nullptr, 0, 1, ctx->d_lambda, R0, ctx->d_bs, 0, nblk * nseg,
                                   ctx->d_wk, msz, n64, rtot - n64, P, ctx->d_dinv, ctx->d_info + 1,
-                                  &ctx->tm.n_chol_launches, 0, nullptr, 0, 0, nseg);
+                                  &ctx->tm.n_chol_launches, 0, nullptr, 0, 0, nseg, 0, -1, 0);
   }
   {
     StageTimer t(ctx, &ctx->tm.ms_pred);
@@ -614,7 +614,7 @@ int rg_k_gram_fp4(void* stream, const uint8_t* A, int64_t lda, const uint8_t* B,
 int rg_k_chol_solve(void* stream, double* mats, int64_t mat_stride, int32_t batch, int32_t n_pad,
                     int32_t rhs_pad, int32_t nrhs, double* dinv_ws, int32_t* info) {
   if (!mats || !dinv_ws || !info || batch < 1 || n_pad < 64 || (n_pad & 63) || (rhs_pad & 63) || nrhs > rhs_pad) return RG_ERR_ARG;
-  rg_launch_chol_solve((hipStream_t)stream, mats, mat_stride, batch, n_pad, rhs_pad, nrhs, dinv_ws, info, nullptr);
+  rg_launch_chol_solve((hipStream_t)stream, mats, mat_stride, batch, n_pad, rhs_pad, nrhs, dinv_ws, info, nullptr, -1);
   return hipGetLastError() == hipSuccess ? RG_OK : RG_ERR_HIP;
 }
 

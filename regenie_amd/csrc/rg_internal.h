@@ -198,16 +198,16 @@ struct AsmArgs {
 };
 void rg_launch_rowstats(hipStream_t st, const AsmArgs& a);
 void rg_launch_assemble(hipStream_t st, const AsmArgs& a);
-// chol.hip
+// chol.hip  (path: 0 = group-wise / throughput, 1 = per-column / latency, -1 = by batch size)
 void rg_launch_chol_solve(hipStream_t st, double* mats, int64_t mat_stride, int batch, int n64,
-                          int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch);
+                          int rhs_pad, int nrhs, double* dinv, int32_t* info, int64_t* n_launch, int path = 1);
 void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t sum_stride, const double* fold,
                                    int64_t fold_stride, int nfold, const double* shift, int nshift,
                                    const int32_t* d_n, int n_fixed, int nouter, double* mats,
                                    int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
                                    int32_t* info, int64_t* n_launch, int subtract, const double* extra,
                                    int64_t extra_stride, int extra_row0, int n_div = 1, int b_offset = 0,
-                                   int b_count = -1);
+                                   int b_count = -1, int path = 1);
 void rg_launch_dgemm_nt(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                         int m, int n, int64_t k, double* C, int64_t ldc);
 // pred.hip
