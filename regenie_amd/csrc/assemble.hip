@@ -184,9 +184,12 @@ __global__ __launch_bounds__(256) void k_assemble_generic(AsmArgs a) {
 // under a data-dependent `if` into branch + load + s_waitcnt vmcnt(0), i.e. one full memory round trip per load,
 // whereas unconditional loads of an unrolled loop are all in flight together.
 #define ACC 8
-__global__ __launch_bounds__(256) void k_assemble_tiled(AsmArgs a) {
-  __shared__ double sE[AF][32][ACC + 1];
-  __shared__ double sF[AF][32][ACC + 1];
+// NF = number of folds carried in registers / LDS (5: the default K; 8: the maximum of this kernel) -- sizing the per-fold
+// arrays for 8 when K = 5 cost a third of the registers and left ONE workgroup resident per CU.
+template <int NF>
+__global__ __launch_bounds__(256, (NF <= 5 ? 2 : 1)) void k_assemble_tiled(AsmArgs a) {
+  __shared__ double sE[NF][32][ACC + 1];
+  __shared__ double sF[NF][32][ACC + 1];
   __shared__ double sBi[32][ACC + 1];
   __shared__ double sBk[32][ACC + 1];
   const int blk = blockIdx.z;
@@ -208,9 +211,9 @@ __global__ __launch_bounds__(256) void k_assemble_tiled(AsmArgs a) {
       const int p = i - n64;
       const bool live = (i < a.rtot) && (p < P) && (k < bs);
       const int pc = live ? p : 0;
-      double vf[AF], tot = 0.0;
+      double vf[NF], tot = 0.0;
 #pragma unroll
-      for (int s = 0; s < AF; ++s) {
+      for (int s = 0; s < NF; ++s) {
         const int ss = min(s, ns - 1);
         const double g = a.GYt[(((int64_t)blk * ns + ss) * n128 + kc) * P + pc];
         vf[s] = (live && s < ns) ? g * isck : 0.0;
@@ -219,7 +222,7 @@ __global__ __launch_bounds__(256) void k_assemble_tiled(AsmArgs a) {
       if (i < a.rtot) {
         const int64_t e = (int64_t)i * n64 + k;
 #pragma unroll
-        for (int s = 0; s < AF; ++s)
+        for (int s = 0; s < NF; ++s)
           if (s < ns) fold[(int64_t)s * msz + e] = a.diff_mode ? tot - vf[s] : vf[s];
         if (!a.diff_mode) sum[e] = tot;
       }
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) void k_assemble_tiled(AsmArgs a) {
   const bool has_miss = a.nmiss[blk] > 0;      // uniform per block
   const int64_t ldS = 2 * (int64_t)n128;
   // integer Gram values of this thread's 4 elements, all folds: independent unconditional loads
-  double at[4][AF];
+  double at[4][NF];
   const double muk = a.mu[(int64_t)blk * n128 + kc];
   // the missing-call terms are a per-block (uniform) property: the branch is taken ONCE, around the whole unrolled
   // loop, so that each variant is straight-line code with all its loads in flight together
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(256) void k_assemble_tiled(AsmArgs a) {
       const int il = live ? i : 0, kl = live ? k : 0;
       const double mui = a.mu[(int64_t)blk * n128 + i];
 #pragma unroll
-      for (int s = 0; s < AF; ++s) {
+      for (int s = 0; s < NF; ++s) {
         const int ss = min(s, ns - 1);
         const int32_t* __restrict__ S = a.S + ((int64_t)blk * ns + ss) * ldS * ldS;
         double v = (double)S[(int64_t)il * ldS + kl];
@@ -268,11 +271,11 @@ __global__ __launch_bounds__(256) void k_assemble_tiled(AsmArgs a) {
   };
   if (has_miss) gram_vals(std::true_type{});
   else gram_vals(std::false_type{});
-  double corr[4][AF];
+  double corr[4][NF];
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
-    for (int s = 0; s < AF; ++s) corr[rr][s] = 0.0;
+    for (int s = 0; s < NF; ++s) corr[rr][s] = 0.0;
   for (int c0 = 0; c0 < C; c0 += ACC) {
     const int cn = min(ACC, C - c0);
     __syncthreads();
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void k_assemble_tiled(AsmArgs a) {
       for (int rr = 0; rr < 4; ++rr) {
         const double bi = sBi[ty + 8 * rr][c];
 #pragma unroll
-        for (int s = 0; s < AF; ++s)
+        for (int s = 0; s < NF; ++s)
           if (s < ns) corr[rr][s] = fma(sE[s][ty + 8 * rr][c], bk, fma(-bi, sF[s][tx][c], corr[rr][s]));
       }
     }
@@ -321,14 +324,14 @@ __global__ __launch_bounds__(256) void k_assemble_tiled(AsmArgs a) {
       continue;
     }
     // rows >= bs (padding): at and the covariate terms are zero -> zeros are written
-    double vf[AF], tot = 0.0;
+    double vf[NF], tot = 0.0;
 #pragma unroll
-    for (int s = 0; s < AF; ++s) {
+    for (int s = 0; s < NF; ++s) {
       vf[s] = (s < ns && i < bs) ? (at[rr][s] + corr[rr][s]) * inv : 0.0;
       tot += vf[s];
     }
 #pragma unroll
-    for (int s = 0; s < AF; ++s)
+    for (int s = 0; s < NF; ++s)
       if (s < ns) fold[(int64_t)s * msz + e] = a.diff_mode ? tot - vf[s] : vf[s];
     if (!a.diff_mode) sum[e] = tot;
   }
@@ -339,7 +342,10 @@ void rg_launch_rowstats(hipStream_t st, const AsmArgs& a) {
 }
 void rg_launch_assemble(hipStream_t st, const AsmArgs& a) {
   if (a.nseg <= AF)
-    hipLaunchKernelGGL(k_assemble_tiled, dim3((a.n64 + 31) / 32, (a.rtot + 31) / 32, a.nblk), dim3(32, 8), 0, st, a);
+    if (a.nseg <= 5)
+      hipLaunchKernelGGL(k_assemble_tiled<5>, dim3((a.n64 + 31) / 32, (a.rtot + 31) / 32, a.nblk), dim3(32, 8), 0, st, a);
+    else
+      hipLaunchKernelGGL(k_assemble_tiled<AF>, dim3((a.n64 + 31) / 32, (a.rtot + 31) / 32, a.nblk), dim3(32, 8), 0, st, a);
   else
     hipLaunchKernelGGL(k_assemble_generic, dim3((a.n64 + 31) / 32, (a.rtot + 7) / 8, a.nblk), dim3(32, 8), 0, st, a);
 }
