@@ -21,9 +21,9 @@ __device__ __forceinline__ unsigned spread8(unsigned y) {
   return y;
 }
 
-// grid: (n128, nblk); one workgroup per SNP row, thread -> output dwords (16 positions each) w = tid, tid+256, ...
-// The 16-sample window of a dword starts at an arbitrary 2-bit offset of the raw row (folds are re-aligned to 256
-// positions): it is cut out of two ALIGNED raw dwords.  Row totals (missing calls, dosage sum) are reduced inside the
+// grid: (n128, nblk); one workgroup per SNP row, thread -> groups of 64 positions (4 output dwords) g = tid, tid+256, ...
+// The window of a group starts at an arbitrary 2-bit offset of the raw row (folds are re-aligned to 256 positions): it is
+// cut out of up to five ALIGNED raw dwords.  Row totals (missing calls, dosage sum) are reduced inside the
 // workgroup -- integer, hence exact and order independent -- and the SNP mean is written by the same launch.
 __global__ __launch_bounds__(256) void k_bed_prep_rows(const uint8_t* const* __restrict__ rawptr, int64_t raw_ld,
                                                        uint8_t* __restrict__ pk,
@@ -43,68 +43,86 @@ __global__ __launch_bounds__(256) void k_bed_prep_rows(const uint8_t* const* __r
   const uint8_t* rowp = rawptr[blk] + (int64_t)min(row, bs - 1) * raw_ld;   // padding rows (>= bs) read nothing new
   uint32_t* po = reinterpret_cast<uint32_t*>(pk + (int64_t)blk * pk_blk_stride + (int64_t)row * pk_ld);
   uint2* p4 = pk4 ? reinterpret_cast<uint2*>(pk4 + (int64_t)blk * pk4_blk_stride + (int64_t)row * pk4_ld) : nullptr;
-  const uint32_t* a32 = reinterpret_cast<const uint32_t*>(act);
+  const uint4* a128 = reinterpret_cast<const uint4*>(act);
   int nmiss = 0, gsum = 0;
-  // 4 output dwords per thread and iteration: all raw / activity loads of an iteration are issued (unconditionally,
-  // at clamped addresses) before any of them is consumed, so four memory round trips overlap instead of queueing
+  // A thread handles GROUPS of 64 positions (4 output dwords: one 16-byte store, two for the FP4 plane, one 16-byte load
+  // of the activity bits) -- a quarter of the memory instructions of a dword-per-thread loop.  Fold segments start at
+  // multiples of 256 positions, so a group never straddles one.  The 128 raw bits of a group start at an arbitrary 2-bit
+  // offset of the row and are cut out of up to five ALIGNED raw dwords; dword j is fetched only if the window reaches it
+  // (re-reading dword 0 otherwise), so no load ever leaves the row.  All loads of GI groups are issued (unconditionally,
+  // at clamped addresses) before any is consumed.
   const bool row_live = row < bs;
-  for (int64_t w0 = threadIdx.x; w0 < nw; w0 += 1024) {
-    unsigned lo32[4], hi32[4], av[4];
-    int shv[4], nv[4];
+  const int64_t ng = Np / 64;
+  constexpr int GI = 2;
+  for (int64_t g0 = threadIdx.x; g0 < ng; g0 += 256 * GI) {
+    unsigned rw[GI][5];
+    uint4 av[GI];
+    int shv[GI], nv[GI];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t w = w0 + 256 * u;
-      const int64_t wc = w < nw ? w : 0;
-      const int64_t pos = wc * 16;
+    for (int u = 0; u < GI; ++u) {
+      const int64_t gq = g0 + 256 * u;
+      const int64_t gc = gq < ng ? gq : 0;
+      const int64_t pos = gc * 64;
       int sgm = 0;
       for (int t = 1; t < seg.nseg; ++t)
         if (pos >= seg.pos_start[t]) sgm = t;
       const int64_t off = pos - seg.pos_start[sgm];
       int64_t nvalid = seg.len[sgm] - off;
-      if (nvalid > 16) nvalid = 16;
-      if (nvalid < 0 || w >= nw || !row_live) nvalid = 0;
-      const int64_t i0 = nvalid > 0 ? seg.file_start[sgm] + off : 0;   // first file sample of this dword
+      if (nvalid > 64) nvalid = 64;
+      if (nvalid < 0 || gq >= ng || !row_live) nvalid = 0;
+      const int64_t i0 = nvalid > 0 ? seg.file_start[sgm] + off : 0;   // first file sample of this group
       const uintptr_t ab = reinterpret_cast<uintptr_t>(rowp) + (uintptr_t)(i0 >> 2);   // byte holding sample i0
       const uint32_t* ap = reinterpret_cast<const uint32_t*>(ab & ~(uintptr_t)3);
       const int sh = (int)(ab & 3) * 8 + (int)(i0 & 3) * 2;                            // <= 30
-      // the second dword is fetched only when the window needs it (it may lie beyond the row otherwise)
-      const bool need2 = sh + 2 * (int)nvalid > 32;
-      lo32[u] = ap[0];
-      hi32[u] = ap[need2 ? 1 : 0];
-      av[u] = a32[wc];                                     // 11 per analysed sample
+      const int nbits = sh + 2 * (int)nvalid;                                          // window end, in bits from ap[0]
+#pragma unroll
+      for (int j = 0; j < 5; ++j) rw[u][j] = ap[(j == 0 || nbits > 32 * j) ? j : 0];
+      av[u] = a128[gc];                                    // 11 per analysed sample
       shv[u] = sh;
       nv[u] = (int)nvalid;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t w = w0 + 256 * u;
-      if (w >= nw) continue;
-      unsigned out = 0xFFFFFFFFu;
-      if (nv[u] > 0) {
-        unsigned x = (unsigned)((((unsigned long long)hi32[u] << 32) | lo32[u]) >> shv[u]);
-        if (ref_first) {  // swap 00 <-> 11, keep 01 (missing) and 10 (het)
-          const unsigned lo = x & 0x55555555u, hi = (x >> 1) & 0x55555555u;
-          const unsigned eq = ~(lo ^ hi) & 0x55555555u;
-          x ^= eq | (eq << 1);
+    for (int u = 0; u < GI; ++u) {
+      const int64_t gq = g0 + 256 * u;
+      if (gq >= ng) continue;
+      unsigned outw[4];
+      const unsigned avw[4] = {av[u].x, av[u].y, av[u].z, av[u].w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        unsigned out = 0xFFFFFFFFu;
+        const int nvd = nv[u] - 16 * d;                    // valid samples of this dword
+        if (nvd > 0) {
+          unsigned x = (unsigned)((((unsigned long long)rw[u][d + 1] << 32) | rw[u][d]) >> shv[u]);
+          if (ref_first) {  // swap 00 <-> 11, keep 01 (missing) and 10 (het)
+            const unsigned lo = x & 0x55555555u, hi = (x >> 1) & 0x55555555u;
+            const unsigned eq = ~(lo ^ hi) & 0x55555555u;
+            x ^= eq | (eq << 1);
+          }
+          const unsigned vm = (nvd >= 16) ? 0xFFFFFFFFu : ((1u << (2 * nvd)) - 1u);
+          const unsigned keep = avw[d] & vm;
+          out = (x & keep) | ~keep;
+          const unsigned lo = out & 0x55555555u, hi = (out >> 1) & 0x55555555u;
+          const unsigned nlo = ~lo & 0x55555555u;
+          nmiss += __popc(lo & ~hi & 0x55555555u);
+          gsum += 2 * __popc(nlo & ~hi) + __popc(nlo & hi);
         }
-        const unsigned vm = (nv[u] >= 16) ? 0xFFFFFFFFu : ((1u << (2 * nv[u])) - 1u);
-        const unsigned keep = av[u] & vm;
-        out = (x & keep) | ~keep;
-        const unsigned lo = out & 0x55555555u, hi = (out >> 1) & 0x55555555u;
-        const unsigned nlo = ~lo & 0x55555555u;
-        nmiss += __popc(lo & ~hi & 0x55555555u);
-        gsum += 2 * __popc(nlo & ~hi) + __popc(nlo & hi);
+        outw[d] = out;
       }
-      po[w] = out;
+      reinterpret_cast<uint4*>(po)[gq] = make_uint4(outw[0], outw[1], outw[2], outw[3]);
       if (p4) {
         // FP4 E2M1 plane for the matrix cores (gram_fp4.hip): dosage 2 (code 00) -> 0100, 1 (code 10) -> 0010,
-        // 0 / missing -> 0000; sample i of this dword -> nibble i of the 8 output bytes
-        const unsigned lo = out & 0x55555555u, hi = (out >> 1) & 0x55555555u;
-        const unsigned two = ~lo & ~hi & 0x55555555u, one = ~lo & hi;
-        uint2 o;
-        o.x = (spread8(two) << 2) | (spread8(one) << 1);
-        o.y = (spread8(two >> 16) << 2) | (spread8(one >> 16) << 1);
-        p4[w] = o;
+        // 0 / missing -> 0000; sample i of a dword -> nibble i of its 8 output bytes
+        unsigned o8[8];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const unsigned lo = outw[d] & 0x55555555u, hi = (outw[d] >> 1) & 0x55555555u;
+          const unsigned two = ~lo & ~hi & 0x55555555u, one = ~lo & hi;
+          o8[2 * d] = (spread8(two) << 2) | (spread8(one) << 1);
+          o8[2 * d + 1] = (spread8(two >> 16) << 2) | (spread8(one >> 16) << 1);
+        }
+        uint4* q4 = reinterpret_cast<uint4*>(p4) + 2 * gq;
+        q4[0] = make_uint4(o8[0], o8[1], o8[2], o8[3]);
+        q4[1] = make_uint4(o8[4], o8[5], o8[6], o8[7]);
       }
     }
   }
