@@ -948,20 +948,6 @@ __global__ __launch_bounds__(256) void k_chol_gfact(double* mats, int64_t mat_st
 // keep the MFMA pipe fed across the per-unit barriers.
 #define GU_UNIT 2048            // doubles per ring unit (16 KB)
 
-// direct global -> LDS copy of 16 bytes per lane (1 KB per wave) issued through inline assembly: hipcc orders every LDS
-// read behind ALL pending global_load_lds it knows of (an s_waitcnt vmcnt(0) in front of the first ds_read of each unit),
-// which would drain the prefetch ring; the copies are ordered by the counted waits of unit_end() instead, and the loops
-// contain no other loads the compiler would count.
-// sbase: wave-uniform base, voff: per-lane byte offset, lds_addr: wave-uniform LDS byte address of the 1 KB destination.
-__device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
-  const uint64_t a = reinterpret_cast<uint64_t>(sbase);   // uniform by construction; pin it to scalar registers
-  const uint64_t sa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
-                      (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sa),
-               "s"(__builtin_amdgcn_readfirstlane((int)lds_addr))
-               : "memory", "m0");
-}
-
 template <int N>
 __device__ __forceinline__ void gu_wait_upto(int n) {   // s_waitcnt vmcnt(4 * min(n, N)), immediate operands only
   if (N > 0 && n >= N) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * N) : "memory"); return; }

@@ -155,6 +155,23 @@ static inline void* rg_ws(rg_ctx* ctx, int slot, size_t bytes) {
   return ctx->ws_ptr[slot];
 }
 
+#if defined(__HIPCC__)
+// direct global -> LDS copy of 16 bytes per lane (1 KB per wave) issued through inline assembly: hipcc orders every LDS
+// read behind ALL pending global_load_lds it knows of (an s_waitcnt vmcnt(0) in front of the first ds_read of each unit),
+// which drains a prefetch ring, and it bunches builtin copies up instead of leaving them between MFMAs; issued this way
+// the copies are ordered by the caller's own counted waits (chol.hip) or sit where they are put (gram_fp4.hip).
+// sbase: wave-uniform base, voff: per-lane byte offset, lds_addr: wave-uniform LDS byte address of the 1 KB destination.
+__device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_t lds_addr) {
+  const uint64_t a = reinterpret_cast<uint64_t>(sbase);   // uniform by construction; pin it to scalar registers
+  const uint64_t sa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                      (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sa),
+               "s"(__builtin_amdgcn_readfirstlane((int)lds_addr))
+               : "memory", "m0");
+}
+
+#endif
+
 #define RG_HIP(call)                                                                   \
   do {                                                                                 \
     hipError_t e_ = (call);                                                            \
