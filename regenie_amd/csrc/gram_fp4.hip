@@ -12,15 +12,17 @@
 // Tiles that involve the missing-call indicator stay on the i8 kernel (gram_i8.hip); they exist only
 // for blocks that have missing genotypes.
 //
-// Tile: 256 x 256 outputs per 256-thread workgroup, one wave per SIMD, 128 x 128 per wave
-// (4 x 4 MFMA 32x32x64, 256 fp32 accumulators per lane).  K stage = 256 samples = 128 B per row,
-// 512 rows (A and B operands), double-buffered in LDS and filled by direct global -> LDS copies
-// (global_load_lds_dwordx4: no staging registers).  Those copies land at wave-base + lane*16, so the
-// LDS rows are unpadded (128 B pitch) and bank conflicts are avoided by an XOR swizzle of the 16-byte
-// slot index applied to the per-lane GLOBAL address: slot' = slot ^ ((row >> 1) & 7), which makes the
-// 16 rows of every ds_read_b128 lane group hit 16 distinct 4-bank groups.  Per 64-sample MFMA step a
-// wave reads 8 x 16 B fragments for 16 MFMAs: 16 B/clk of LDS traffic per wave and 32 B/clk/CU of
-// L2 traffic -- both well inside budget, which 128 x 128 workgroup tiles are not at this matrix rate.
+// Tile: 256 x 256 outputs per 1024-thread workgroup: 16 waves (8 x 2), 32 x 128 per wave (1 x 4 MFMA 32x32x64, 64 fp32
+// accumulators per lane), four waves per SIMD.  K stage = 256 samples = 128 B per row, 512 rows (A and B operands),
+// double-buffered in LDS and filled by direct global -> LDS copies (global_load_lds_dwordx4: no staging registers).
+// Those copies land at wave-base + lane*16, so the LDS rows are unpadded (128 B pitch) and bank conflicts are avoided by
+// an XOR swizzle of the 16-byte slot index applied to the per-lane GLOBAL address: slot' = slot ^ ((row >> 1) & 7), which
+// makes the 16 rows of every ds_read_b128 lane group hit 16 distinct 4-bank groups.
+// Why so many waves: a stage is 64 KB = 64 copy instructions per workgroup, and each costs its wave ~150 cycles of issue
+// during which that wave issues no MFMA.  With one 128 x 128 wave per SIMD (16 copies, 64 MFMAs of 32 cycles per stage)
+// the copies took longer than the MFMAs (46 % of the FP4 peak); with four waves per SIMD the copy-issue and LDS-read
+// phases of one wave run under the MFMAs of the others (53 %).  Spreading the copies between the MFMAs of a single wave
+// instead was slower.
 // Every fold segment of the position space is a multiple of 256 samples (SegLayout), so a stage
 // never straddles a fold boundary and there is no K tail.
 #include <algorithm>
@@ -41,7 +43,7 @@ struct G4Operand { const uint8_t* base; int64_t ld; int rows; };
 template <bool SAME>
 __device__ __forceinline__ void g4_stage(const G4Operand& A, const G4Operand& B, int64_t kb0, uint8_t* buf) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int NPER = SAME ? 4 : 8;    // 8 waves
+  constexpr int NPER = SAME ? 2 : 4;    // 16 waves
 #pragma unroll
   for (int i = 0; i < NPER; ++i) {
     const int g = wave * NPER + i;
@@ -64,9 +66,9 @@ __device__ __forceinline__ void gram4_tile(G4Operand A, G4Operand B, int nstage,
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;       // 8 waves: 4 x 2, each 64 x 128 (two waves per SIMD cover each other's
   const int l31 = lane & 31, h = lane >> 5;      // copy-issue and LDS-read phases)
-  v16f acc[2][4];
+  v16f acc[1][4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 1; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -78,7 +80,7 @@ __device__ __forceinline__ void gram4_tile(G4Operand A, G4Operand B, int nstage,
   __syncthreads();
   // fragment addresses: row R -> slot (2*ks + h) ^ ((R >> 1) & 7); the rows of one lane differ by multiples of 32,
   // so the swizzle term is the same for all four fragments of an operand
-  const int ra = wr * 64 + l31, rb = (SAME ? 0 : FT) + wc * 128 + l31;
+  const int ra = wr * 32 + l31, rb = (SAME ? 0 : FT) + wc * 128 + l31;
   const int xa = (ra >> 1) & 7, xb = (rb >> 1) & 7;
   for (int s = 0; s < nstage; ++s) {
     uint8_t* cur = (s & 1) ? buf1 : buf0;
@@ -88,15 +90,15 @@ __device__ __forceinline__ void gram4_tile(G4Operand A, G4Operand B, int nstage,
     const uint8_t* sb = cur + rb * FROWB;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      v4i af[2], bf[4];
+      v4i af[1], bf[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 1; ++i)
         af[i] = *reinterpret_cast<const v4i*>(sa + i * 32 * FROWB + (((2 * ks + h) ^ xa) << 4));
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         bf[j] = *reinterpret_cast<const v4i*>(sb + j * 32 * FROWB + (((2 * ks + h) ^ xb) << 4));
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < 1; ++i) {
         const v8i a8 = __builtin_shufflevector(af[i], af[i], 0, 1, 2, 3, -1, -1, -1, -1);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -111,12 +113,12 @@ __device__ __forceinline__ void gram4_tile(G4Operand A, G4Operand B, int nstage,
   }
   // the fp32 sums are exact integers
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 1; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int row = wr * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int col = wc * 128 + j * 32 + l31;
         if (row < c_rows && col < c_cols) {
           int32_t* p = C + (int64_t)row * ldc + col;
@@ -128,7 +130,7 @@ __device__ __forceinline__ void gram4_tile(G4Operand A, G4Operand B, int nstage,
 }
 
 // ---- test / generic entry: C[m][n] = A4 * B4^T; grid.z splits K into super-chunks of FP4_FLUSH_STAGES stages ----
-__global__ __launch_bounds__(512) void k_gram_fp4_generic(const uint8_t* A, int64_t lda, const uint8_t* B,
+__global__ __launch_bounds__(1024) void k_gram_fp4_generic(const uint8_t* A, int64_t lda, const uint8_t* B,
                                                           int64_t ldb, int m, int n, int64_t kbytes,
                                                           int32_t* C, int64_t ldc) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[4 * FT * FROWB];
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(512) void k_gram_fp4_generic(const uint8_t* A, int6
 
 // ---- production: grid.x = lower-triangular 256-tile index over the n128 rows of the block (x K super-chunks),
 //      grid.y = fold, grid.z = block; output into the dosage x dosage quadrant of S (ld = 2*n128) --------
-__global__ __launch_bounds__(512) void k_gram_fp4_blocks(const uint8_t* pk4, int64_t pk4_ld, int64_t pk4_blk_stride,
+__global__ __launch_bounds__(1024) void k_gram_fp4_blocks(const uint8_t* pk4, int64_t pk4_ld, int64_t pk4_blk_stride,
                                                          int n128, SegLayout seg, int ntile, int nsuper, int32_t* S) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[4 * FT * FROWB];
   int tidx = blockIdx.x % ntile;
@@ -184,7 +186,7 @@ void rg_launch_gram_fp4_blocks(hipStream_t st, const uint8_t* pk4, int64_t pk4_l
     hipMemsetAsync(S, 0, sizeof(int32_t) * (size_t)nblk * seg.nseg * ldS * ldS, st);
   }
   dim3 grid(ntile * nsuper, seg.nseg, nblk);
-  hipLaunchKernelGGL(k_gram_fp4_blocks, grid, dim3(512), 0, st, pk4, pk4_ld, pk4_blk_stride, n128, seg, ntile, nsuper, S);
+  hipLaunchKernelGGL(k_gram_fp4_blocks, grid, dim3(1024), 0, st, pk4, pk4_ld, pk4_blk_stride, n128, seg, ntile, nsuper, S);
 }
 
 void rg_launch_gram_fp4_generic(hipStream_t st, const uint8_t* A, int64_t lda, const uint8_t* B, int64_t ldb, int m,
@@ -194,5 +196,5 @@ void rg_launch_gram_fp4_generic(hipStream_t st, const uint8_t* A, int64_t lda, c
   if (nsuper > 1)
     for (int r = 0; r < m; ++r) hipMemsetAsync(C + (int64_t)r * ldc, 0, sizeof(int32_t) * n, st);
   dim3 grid((n + FT - 1) / FT, (m + FT - 1) / FT, nsuper);
-  hipLaunchKernelGGL(k_gram_fp4_generic, grid, dim3(512), 0, st, A, lda, B, ldb, m, n, kbytes, C, ldc);
+  hipLaunchKernelGGL(k_gram_fp4_generic, grid, dim3(1024), 0, st, A, lda, B, ldb, m, n, kbytes, C, ldc);
 }
