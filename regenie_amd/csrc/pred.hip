@@ -218,7 +218,9 @@ __global__ __launch_bounds__(256) void k_l0_pred(PredArgs a, ChunkTab ct) {
 #define PG_MAX 64
 template <int MB>
 __global__ __launch_bounds__(256, 2) void k_l0_pred_mfma(PredArgs a, ChunkTab ct, int pg /*phenotypes per group*/) {
+  constexpr int PJ = 64;                              // SNPs per LDS tile of coefficients
   __shared__ double sred[4][MB * 16][2];
+  __shared__ __attribute__((aligned(16))) double sBe[MB * 16][PJ + 2];
   const int blk = blockIdx.z, ch = blockIdx.x, p0 = blockIdx.y * pg;
   const int npg = min(pg, a.P - p0);
   const int nrow = npg * a.R0;                       // live rows of this group, m = pl * R0 + r
@@ -234,17 +236,9 @@ __global__ __launch_bounds__(256, 2) void k_l0_pred_mfma(PredArgs a, ChunkTab ct
   const bool has_miss = a.nmiss[blk] > 0;
   const uint8_t* __restrict__ pk = a.pk + (int64_t)blk * a.pk_blk_stride + pos0 / 4;
   const double* __restrict__ mu = a.mu + (int64_t)blk * a.n128;
-  // A-operand rows: beta of row m = mb*16 + i (clamped + masked beyond nrow)
-  const double* brow[MB];
-  double bmask[MB];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb) {
-    const int m = mb * 16 + i;
-    const int mc = min(m, nrow - 1);
-    const int pl = mc / R0, r = mc % R0;
-    brow[mb] = a.beta + (((int64_t)blk * nm + s * R0 + r) * a.P + p0 + pl) * a.n64 + 4 * q;
-    bmask[mb] = m < nrow ? 1.0 : 0.0;
-  }
+  // A operand: the coefficient rows m = pl*R0 + r of the group, staged per tile of PJ SNPs in LDS (shared by the four
+  // waves, which differ only in their positions; rows beyond nrow are zero).  Register double-buffering of the
+  // coefficients next to the 128 accumulator registers spilled, and every wave fetched the same rows from L2.
   const int sh = 8 * (i >> 2) + 2 * (i & 3);         // bit offset of this lane's sample inside each dword of a 16-byte row piece
   v4d acc[MB][4];
 #pragma unroll
@@ -252,16 +246,17 @@ __global__ __launch_bounds__(256, 2) void k_l0_pred_mfma(PredArgs a, ChunkTab ct
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (v4d){0, 0, 0, 0};
   const int nsup = (bs + 15) / 16;                    // rows >= bs decode to 0 and have beta = 0 (n64 >= 16*nsup)
-  struct Stage { double4 be[MB]; uint4 g[4]; double4 mu4; };
+  struct Stage { uint4 g[4]; double4 mu4; };
   auto load = [&](Stage& t, int su) {
     const int j = su * 16 + 4 * q;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) t.be[mb] = *reinterpret_cast<const double4*>(brow[mb] + su * 16);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) t.g[ks] = *reinterpret_cast<const uint4*>(pk + (int64_t)min(j + ks, a.n128 - 1) * a.pk_ld);
     t.mu4 = *reinterpret_cast<const double4*>(mu + min(j, a.n128 - 4));
   };
-  auto compute = [&](const Stage& t) {
+  auto compute = [&](const Stage& t, int sl /* super-step inside the LDS tile */) {
+    double4 be[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) be[mb] = *reinterpret_cast<const double4*>(&sBe[mb * 16 + i][sl * 16 + 4 * q]);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const unsigned wv[4] = {t.g[ks].x, t.g[ks].y, t.g[ks].z, t.g[ks].w};
@@ -278,20 +273,39 @@ __global__ __launch_bounds__(256, 2) void k_l0_pred_mfma(PredArgs a, ChunkTab ct
       }
 #pragma unroll
       for (int mb = 0; mb < MB; ++mb) {
-        const double av = (ks == 0 ? t.be[mb].x : (ks == 1 ? t.be[mb].y : (ks == 2 ? t.be[mb].z : t.be[mb].w))) * bmask[mb];
+        const double av = ks == 0 ? be[mb].x : (ks == 1 ? be[mb].y : (ks == 2 ? be[mb].z : be[mb].w));
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[nb], acc[mb][nb], 0, 0, 0);
       }
     }
   };
-  if (wlive) {
+  {
     Stage t0, t1;
-    load(t0, 0);
-    for (int su = 0; su < nsup; su += 2) {
-      if (su + 1 < nsup) load(t1, su + 1);
-      compute(t0);
-      if (su + 2 < nsup) load(t0, su + 2);
-      if (su + 1 < nsup) compute(t1);
+    if (wlive) load(t0, 0);
+    for (int jt = 0; jt < bs; jt += PJ) {
+      __syncthreads();
+      // stage the tile: MB*16 rows x PJ coefficients, coalesced along the SNP index (n64 >= jt + PJ: both multiples of 64)
+      for (int e = threadIdx.x; e < MB * 16 * (PJ / 2); e += 256) {
+        const int m = e / (PJ / 2), c2 = (e - m * (PJ / 2)) * 2;
+        const int mc = min(m, nrow - 1);
+        const int pl = mc / R0, r = mc - pl * R0;
+        const double2 v = *reinterpret_cast<const double2*>(
+            a.beta + (((int64_t)blk * nm + s * R0 + r) * a.P + p0 + pl) * a.n64 + jt + c2);
+        const double mk = m < nrow ? 1.0 : 0.0;
+        sBe[m][c2] = v.x * mk;
+        sBe[m][c2 + 1] = v.y * mk;
+      }
+      __syncthreads();
+      if (wlive) {
+        const int su0 = jt / 16, sun = min(PJ / 16, nsup - su0);   // super-steps of this tile
+        for (int sl = 0; sl < sun; sl += 2) {
+          const int su = su0 + sl;
+          if (su + 1 < nsup) load(t1, su + 1);
+          compute(t0, sl);
+          if (su + 2 < nsup) load(t0, su + 2);
+          if (sl + 1 < sun) compute(t1, sl + 1);
+        }
+      }
     }
   }
   // ---- epilogue: covariate term, mask, store, per-row sums --------------------------------------------------------
