@@ -162,8 +162,10 @@ void rg_launch_bed_prep(hipStream_t st, const uint8_t* const* rawptr, int64_t ra
 // operands, so the inner loop is decode (bit-field extract + convert, 2 ops) + CG FMAs per sample.
 // The missing-indicator sums are only formed for blocks that have missing calls.
 // part layout: [blk][chunk][row][2][Cv]   (0: sum g0*V, 1: sum miss*V)
-#define CG 4
 #define XP 80  // LDS row pitch of the packed tile: 64 data bytes + 16 (conflict-free 16-byte row reads)
+// CG = columns of V per pass over the packed rows (every pass re-stages and re-decodes them), SB = samples per batch of
+// scalar loads (CG * SB doubles = 2 * CG * SB SGPRs): 4 x 8 for up to four columns, 8 x 4 beyond.
+template <int CG, int SB>
 __global__ __launch_bounds__(256) void k_geno_xy(const uint8_t* __restrict__ pk, int64_t pk_ld,
                                                  int64_t pk_blk_stride, const int32_t* __restrict__ d_bs,
                                                  const int32_t* __restrict__ nmiss_blk, int n128,
@@ -210,21 +212,21 @@ __global__ __launch_bounds__(256) void k_geno_xy(const uint8_t* __restrict__ pk,
         const unsigned lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
         const unsigned dd = (hi & ~lo) | ((~(hi | lo) & 0x55555555u) << 1);   // 2-bit dosage fields
         const unsigned ms = lo & ~hi;
-        // 8 samples at a time: 8 x CG doubles of V = 64 SGPRs per scalar-load batch
+        // SB samples at a time: SB x CG doubles of V = 64 SGPRs per scalar-load batch
 #pragma unroll 1
-        for (int hf = 0; hf < 2; ++hf) {
-          const int64_t vo = q + d * 16 + hf * 8;
-          const unsigned dh = dd >> (16 * hf);
+        for (int hf = 0; hf < 16 / SB; ++hf) {
+          const int64_t vo = q + d * 16 + hf * SB;
+          const unsigned dh = dd >> (2 * SB * hf);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < SB; ++i) {
             const double g = (double)((dh >> (2 * i)) & 3u);
 #pragma unroll
             for (int c = 0; c < CG; ++c) a0[c] = fma(g, Vc[c][vo + i], a0[c]);
           }
           if (has_miss) {
-            const unsigned mh = ms >> (16 * hf);
+            const unsigned mh = ms >> (2 * SB * hf);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < SB; ++i) {
               const double m = (double)((mh >> (2 * i)) & 1u);
 #pragma unroll
               for (int c = 0; c < CG; ++c) am[c] = fma(m, Vc[c][vo + i], am[c]);
@@ -248,6 +250,10 @@ void rg_launch_geno_xy(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t
                        const int32_t* d_bs, const int32_t* nmiss, int nblk, int n128, const double* V, int64_t Np,
                        int Cv, const int64_t* chunk_pos, const int64_t* chunk_len, int nchunk, double* part) {
   dim3 grid((n128 + 255) / 256, nchunk, nblk);
-  hipLaunchKernelGGL(k_geno_xy, grid, dim3(256), 0, st, pk, pk_ld, pk_blk_stride, d_bs, nmiss, n128, V, Np,
-                     Cv, chunk_pos, chunk_len, nchunk, part);
+  if (Cv <= 4)
+    hipLaunchKernelGGL((k_geno_xy<4, 8>), grid, dim3(256), 0, st, pk, pk_ld, pk_blk_stride, d_bs, nmiss, n128, V, Np, Cv,
+                       chunk_pos, chunk_len, nchunk, part);
+  else
+    hipLaunchKernelGGL((k_geno_xy<8, 4>), grid, dim3(256), 0, st, pk, pk_ld, pk_blk_stride, d_bs, nmiss, n128, V, Np, Cv,
+                       chunk_pos, chunk_len, nchunk, part);
 }
