@@ -104,7 +104,8 @@ def test_low_variance_snp_is_reported(tmp_path):
 
 
 def test_block_batching_is_invariant(example_dir, monkeypatch):
-    """Processing blocks 1-at-a-time or 8-at-a-time must give bit-identical W (deterministic kernels)."""
+    """Processing blocks 1-at-a-time or 8-at-a-time, on one, two or three pipelines, must give bit-identical W
+    (deterministic kernels; level 0 always takes the group-wise Cholesky path)."""
     E = example_dir
     opt = orc.Step1Options(bed=os.path.join(E, "example_3chr"), pheno_file=os.path.join(E, "phenotype.txt"),
                            covar_file=os.path.join(E, "covariates.txt"), bsize=100)
@@ -112,9 +113,16 @@ def test_block_batching_is_invariant(example_dir, monkeypatch):
     a = gpu_step1(opt)
     monkeypatch.setenv("RG_NBLK", "8")
     b = gpu_step1(opt)
+    # one pipeline, and three pipelines with two blocks per batch (batches dealt round-robin over three HIP streams)
+    monkeypatch.setenv("RG_PIPELINES", "1")
+    c = gpu_step1(opt)
+    monkeypatch.setenv("RG_PIPELINES", "3")
+    monkeypatch.setenv("RG_NBLK", "2")
+    d = gpu_step1(opt)
     for ph in range(2):
-        assert np.array_equal(a["W"][ph], b["W"][ph])
-        assert np.array_equal(a["loco"][ph], b["loco"][ph])
+        for other in (b, c, d):
+            assert np.array_equal(a["W"][ph], other["W"][ph])
+            assert np.array_equal(a["loco"][ph], other["loco"][ph])
 
 
 def test_level1_on_injected_predictors(example_dir):
