@@ -153,6 +153,7 @@ def main():
     Wv = Wt.view(L, P, eng.w_rows)
     ptrs = [packed[b].data_ptr() for b in my_blocks]
     bss = [blocks[b][2] for b in my_blocks]
+    eng.set_loco_output(chroms)                             # level 1 returns the 23 LOCO rows (write_predictions' assembly)
 
     class _DevBuf:                                          # raw device pointer -> torch tensor view
         def __init__(self, ptr, n):
@@ -186,7 +187,7 @@ def main():
             eng.set_l1_view(Wg.data_ptr(), q0, qn)
             cs, best, pred = eng.l1_qt(tau[q0:q0 + qn], cols_per_chr)
             eng.set_l1_view(None, 0, P)
-            mine = ([loco_from_predictions(pred[p], chroms) for p in range(qn)], cs, [int(b) for b in best])
+            mine = ([pred[p] for p in range(qn)], cs, [int(b) for b in best])          # LOCO rows, assembled on the device
             gathered = [None] * world                        # small per-phenotype summaries; predictions stay on their rank
             dist.all_gather_object(gathered, (float(sum(np.abs(l).sum() for l in mine[0])), mine[2]))
             return (mine[0], cs, [b for g in gathered for b in g[1]], sum(g[0] for g in gathered))
@@ -200,7 +201,7 @@ def main():
                 return None                                 # W is not gathered in this mode: level 0 only
         if rank == 0 or (world > 1 and not solo):           # N>1: level 1 is shared among the ranks
             cs, best, pred = eng.l1_qt(tau, cols_per_chr)
-            out = [loco_from_predictions(pred[p], chroms) for p in range(P)], cs, best
+            out = [pred[p] for p in range(P)], cs, best                                    # LOCO rows, assembled on the device
         return out
 
     def fence():

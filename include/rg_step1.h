@@ -133,6 +133,15 @@ int rg_set_collective(rg_ctx* ctx, int32_t world, int32_t rank, rg_allreduce_fn 
  * default view (the context's own W, all phenotypes). */
 int rg_set_l1_view(rg_ctx* ctx, const void* w_dev, int32_t pheno_begin, int32_t pheno_count);
 
+/* ---- LOCO output of the level-1 entry points (optional) ---------------------------------------------------
+ * Replaces the assembly loop of write_predictions (Data.cpp:1846-1858): pred_loco[:, c] = rowsum(predictions) -
+ * predictions[:, idx(c)] for each of `nchrom` chromosomes (chromosomes without blocks get the full sum).
+ * After rg_set_loco_output(ctx, nchrom, chrom_ids) the rg_l1_* calls write, per phenotype, nchrom x N doubles
+ * (row c-1 = LOCO predictions leaving chromosome c out) into pred_out instead of the nchr x N per-chromosome
+ * predictions; chrom_ids[k] (1-based, <= nchrom) is the chromosome of the k-th entry of cols_per_chr.
+ * nchrom = 0 restores the per-chromosome output. */
+int rg_set_loco_output(rg_ctx* ctx, int32_t nchrom, const int32_t* chrom_ids, int32_t n_ids);
+
 /* ---- level 1, quantitative traits, leave-one-out CV ------------------------------------------
  * Replaces ridge_level_1_loocv (Step1_Models.cpp:875-962), the tau selection of Data::output and
  * make_predictions_loocv (Data.cpp:1269-1342).  Requires a problem set up with cv_folds = 0.

@@ -122,6 +122,34 @@ __global__ void k_sum_folds(const double* fold, int64_t msz, int nfold, double* 
   sum[e] = t;
 }
 
+// ---- LOCO assembly (write_predictions, Data.cpp:1846-1858): out[c][n] = sum_k pred[k][n] - pred[idx(c)][n] ------------
+__global__ __launch_bounds__(256) void k_loco(const double* pred, int nchr, int64_t N, const int32_t* chrom, int nchrom,
+                                              double* out) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  double tot = 0.0;
+  for (int k = 0; k < nchr; ++k) tot += pred[(int64_t)k * N + n];      // fixed order: the reference's rowwise().sum()
+  for (int c = 0; c < nchrom; ++c) out[(int64_t)c * N + n] = tot;
+  for (int k = 0; k < nchr; ++k) out[(int64_t)(chrom[k] - 1) * N + n] = tot - pred[(int64_t)k * N + n];
+}
+
+int rg_emit_pred(rg_ctx* ctx, hipStream_t st, const double* d_pred, int nchr, int p, double* pred_out) {
+  const int64_t N = ctx->N;
+  if (ctx->loco_nchrom <= 0) {
+    RG_HIP(hipMemcpyAsync(pred_out + (int64_t)p * nchr * N, d_pred, sizeof(double) * (size_t)nchr * N, hipMemcpyDeviceToHost, st));
+    return RG_OK;
+  }
+  if ((int)ctx->loco_chrom.size() != nchr) { ctx->err = "LOCO output: rg_set_loco_output was given a different number of chromosomes"; return RG_ERR_ARG; }
+  const int nchrom = ctx->loco_nchrom;
+  double* d_out = (double*)rg_ws(ctx, 11, sizeof(double) * (size_t)nchrom * N + sizeof(int32_t) * (size_t)nchr + 64);
+  if (!d_out) { ctx->err = "LOCO output: out of device memory"; return RG_ERR_HIP; }
+  int32_t* d_chr = reinterpret_cast<int32_t*>(d_out + (size_t)nchrom * N);
+  RG_HIP(hipMemcpyAsync(d_chr, ctx->loco_chrom.data(), sizeof(int32_t) * nchr, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_loco, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_pred, nchr, N, d_chr, nchrom, d_out);
+  RG_HIP(hipMemcpyAsync(pred_out + (int64_t)p * nchrom * N, d_out, sizeof(double) * (size_t)nchrom * N, hipMemcpyDeviceToHost, st));
+  return RG_OK;
+}
+
 // ---- multi-rank exchange of the fold Grams: only the computed tiles travel ------------------------------------------
 // The fold matrices live as full rows (ld = n64) but only the lower-triangle tiles and the y-row tiles are ever non-zero;
 // packing them tile by tile ([fold][tile][64][64], tile (tr, tc) -> tr(tr+1)/2 + tc) halves the all-reduce volume.
@@ -362,8 +390,7 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
     hipLaunchKernelGGL(k_l1_pred, dim3(nch), dim3(256), sizeof(double) * L, st, R, d_alpha, R1, best,
                        ctx->d_c256_seg, ctx->d_c256_pos, ctx->d_c256_len, d_col0, nchr,
                        ctx->d_cidx, ctx->N, d_pred);
-    RG_HIP(hipMemcpyAsync(pred_out + (int64_t)p * nchr * ctx->N, d_pred,
-                          sizeof(double) * (size_t)nchr * ctx->N, hipMemcpyDeviceToHost, st));
+    if ((rc = rg_emit_pred(ctx, st, d_pred, nchr, p, pred_out))) break;
     RG_HIP(hipStreamSynchronize(st));
     if (ctx->timing) { hipEventRecord(e1, st); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ctx->tm.ms_l1_pred += ms; }
     int32_t info[2] = {0, 0};

@@ -541,8 +541,7 @@ int rg_l1_qt_loocv_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const 
     if (best != R1 - 1) prepare(best);
     L1X_HIP(hipMemsetAsync(c.d_pred, 0, sizeof(double) * (size_t)nchr * N, st));
     hipLaunchKernelGGL(k_loo_pred, dim3(gpos), dim3(256), 0, st, la, c.d_col0, nchr, ctx->d_cidx, N, c.d_pred);
-    L1X_HIP(hipMemcpyAsync(pred_out + (int64_t)p * nchr * N, c.d_pred, sizeof(double) * (size_t)nchr * N,
-                           hipMemcpyDeviceToHost, st));
+    { const int rce = rg_emit_pred(ctx, st, c.d_pred, nchr, p, pred_out); if (rce) return rce; }
     L1X_HIP(hipStreamSynchronize(st));
   }
   return RG_OK;
@@ -843,8 +842,7 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
       L1X_HIP(hipMemsetAsync(c.d_pred, 0, sizeof(double) * (size_t)nchr * N, st));
       hipLaunchKernelGGL(k_loo_pred, dim3(gpos), dim3(256), 0, st, la, c.d_col0, nchr, ctx->d_cidx, N, c.d_pred);
     }
-    L1X_HIP(hipMemcpyAsync(pred_out + (int64_t)p * nchr * N, c.d_pred, sizeof(double) * (size_t)nchr * N,
-                           hipMemcpyDeviceToHost, st));
+    { const int rce = rg_emit_pred(ctx, st, c.d_pred, nchr, p, pred_out); if (rce) return rce; }
     L1X_HIP(hipStreamSynchronize(st));
   }
   return RG_OK;

@@ -569,6 +569,17 @@ int rg_l1_bt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, const double* y
                        best_out, pred_out);
 }
 
+int rg_set_loco_output(rg_ctx* ctx, int32_t nchrom, const int32_t* chrom_ids, int32_t n_ids) {
+  if (!ctx) return RG_ERR_ARG;
+  if (nchrom <= 0) { ctx->loco_nchrom = 0; ctx->loco_chrom.clear(); return RG_OK; }
+  if (!chrom_ids || n_ids < 1) { ctx->err = "rg_set_loco_output: chromosome ids missing"; return RG_ERR_ARG; }
+  for (int k = 0; k < n_ids; ++k)
+    if (chrom_ids[k] < 1 || chrom_ids[k] > nchrom) { ctx->err = "rg_set_loco_output: chromosome id out of range"; return RG_ERR_ARG; }
+  ctx->loco_nchrom = nchrom;
+  ctx->loco_chrom.assign(chrom_ids, chrom_ids + n_ids);
+  return RG_OK;
+}
+
 int rg_set_l1_view(rg_ctx* ctx, const void* w_dev, int32_t pheno_begin, int32_t pheno_count) {
   if (!ctx || !ctx->have_problem) return RG_ERR_STATE;
   if (pheno_begin < 0 || pheno_count < 1 || pheno_begin + pheno_count > ctx->P) { ctx->err = "rg_set_l1_view: phenotype range out of bounds"; return RG_ERR_ARG; }

@@ -120,6 +120,10 @@ struct rg_ctx {
   const double* v_W = nullptr;
   int v_p0 = 0, v_np = 0;
 
+  // LOCO output mode of the level-1 entry points (rg_set_loco_output): nchrom rows per phenotype instead of nchr
+  int loco_nchrom = 0;
+  std::vector<int32_t> loco_chrom;   // chromosome (1-based) of each cols_per_chr entry
+
   // multi-GPU level 1: tile-sharded Gram and system-sharded solves, completed by caller-provided all-reduces
   int coll_world = 1, coll_rank = 0;
   rg_allreduce_fn coll_allreduce = nullptr;
@@ -254,6 +258,9 @@ struct LoocvArgs {
 void rg_launch_decode_gt(hipStream_t st, const LoocvArgs& a);
 void rg_launch_l0_loocv(hipStream_t st, const LoocvArgs& a, double* part0, double* part1, int nchunk);
 // l1.hip
+// copies the per-chromosome predictions of one phenotype (device, [nchr][N]) to the caller: as they are, or assembled
+// into LOCO rows [nchrom][N] first (rg_set_loco_output).  Returns an RG_* code.
+int rg_emit_pred(rg_ctx* ctx, hipStream_t st, const double* d_pred, int nchr, int p, double* pred_out);
 struct L1Args;
 int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_t* cols_per_chr,
                   double* cumsum_out, int32_t* best_out, double* pred_out);

@@ -49,7 +49,7 @@ class RgTiming(C.Structure):
 
 EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_w_rows", "rg_w_bytes",
            "rg_set_w_buffer", "rg_w_device_ptr", "rg_l0_blocks", "rg_sync", "rg_l0_get_w",
-           "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_set_collective", "rg_set_l1_view", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
+           "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_set_collective", "rg_set_l1_view", "rg_set_loco_output", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
            "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak"]
 
 
@@ -91,6 +91,7 @@ def load_library() -> C.CDLL:
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rg_set_collective.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rg_set_l1_view.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+    lib.rg_set_loco_output.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
     lib.rg_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.rg_get_timing.argtypes = [C.c_void_p, C.POINTER(RgTiming)]
     lib.rg_k_gram_i8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
@@ -227,7 +228,7 @@ class Step1Engine:
         nchr = cpc.size
         cs = np.zeros((P, 5, R1))
         best = np.zeros(P, dtype=np.int32)
-        pred = self._host_out((P, nchr, self.N))
+        pred = self._host_out((P, self._pred_rows(nchr), self.N))
         self._check(self.lib.rg_l1_qt(self.h, R1, tau.ctypes.data, nchr, cpc.ctypes.data, cs.ctypes.data,
                                       best.ctypes.data, pred.ctypes.data))
         return cs, best, [pred[p].T for p in range(P)]
@@ -258,7 +259,7 @@ class Step1Engine:
         nchr = cpc.size
         cs = np.zeros((P, 5, R1))
         best = np.zeros(P, dtype=np.int32)
-        pred = np.zeros((P, nchr, self.N))
+        pred = np.zeros((P, self._pred_rows(nchr), self.N))
         self._check(self.lib.rg_l1_qt_loocv(self.h, R1, tau.ctypes.data, nchr, cpc.ctypes.data, cs.ctypes.data,
                                             best.ctypes.data, pred.ctypes.data))
         return cs, best, [pred[p].T.copy() for p in range(P)]
@@ -280,11 +281,26 @@ class Step1Engine:
         cs = np.zeros((P, 6, R1))
         conv = np.zeros(P, dtype=np.int32)
         best = np.zeros(P, dtype=np.int32)
-        pred = np.zeros((P, nchr, self.N))
+        pred = np.zeros((P, self._pred_rows(nchr), self.N))
         self._check(self.lib.rg_l1_bt(self.h, R1, tau.ctypes.data, yraw.ctypes.data, offset.ctypes.data,
                                       C.byref(o), nchr, cpc.ctypes.data, cs.ctypes.data, conv.ctypes.data,
                                       best.ctypes.data, pred.ctypes.data))
         return cs, conv.astype(bool), best, [pred[p].T.copy() for p in range(P)]
+
+    def set_loco_output(self, chroms: Optional[Sequence[int]], nchrom: int = 23):
+        """LOCO output mode: the l1_* calls then return, per phenotype, the (N, nchrom) LOCO predictions (column c-1 leaves
+        chromosome c out) assembled on the device instead of the (N, nchr) per-chromosome predictions.  chroms[k] is the
+        chromosome (1-based) of the k-th entry of cols_per_chr; None switches back."""
+        if chroms is None:
+            self._check(self.lib.rg_set_loco_output(self.h, 0, None, 0))
+            self._loco_rows = 0
+            return
+        ids = np.ascontiguousarray(chroms, dtype=np.int32)
+        self._check(self.lib.rg_set_loco_output(self.h, int(nchrom), ids.ctypes.data, ids.size))
+        self._loco_rows = int(nchrom)
+
+    def _pred_rows(self, nchr: int) -> int:
+        return getattr(self, "_loco_rows", 0) or nchr
 
     def set_l1_view(self, w_dev_ptr, pheno_begin: int, pheno_count: int):
         """Phenotype-sharded level 1: the following l1_* calls work on phenotypes [begin, begin+count) and read the

@@ -94,3 +94,19 @@ def test_bt_kfold_native_above_5000(tmp_path):
     got = gpu_step1_any(opt)
     assert not got["use_loocv"]
     _compare(ref, got, 2, TOL_BT, 6)
+
+
+@pytest.mark.parametrize("kind", ["qt_kfold", "qt_loocv", "bt_loocv"])
+def test_loco_output_mode_matches_host_assembly(example_dir, kind):
+    """rg_set_loco_output: the device-side LOCO assembly (write_predictions, Data.cpp:1846-1858) is bit-identical to the
+    host-side assembly of the per-chromosome predictions, for every level-1 entry point."""
+    E = example_dir
+    opt = orc.Step1Options(bed=os.path.join(E, "example" if kind == "bt_loocv" else "example_3chr"),
+                           pheno_file=os.path.join(E, "phenotype_bin.txt" if kind == "bt_loocv" else "phenotype.txt"),
+                           covar_file=os.path.join(E, "covariates.txt"), bsize=100, bt=(kind == "bt_loocv"),
+                           loocv=(kind == "qt_loocv"))
+    ref = gpu_step1_any(opt)
+    got = gpu_step1_any(opt, loco_on_device=True)
+    for ph in range(len(ref["loco"])):
+        assert got["loco"][ph].shape == ref["loco"][ph].shape
+        assert np.array_equal(ref["loco"][ph], got["loco"][ph])

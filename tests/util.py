@@ -158,9 +158,10 @@ def oracle_step1_any(opt: orc.Step1Options, force_kfold: bool = False):
     return orc.finish_level_1(opt, prep, blocks, bim.chr_read, cv_sizes, lam, h1, W, use_loocv, [])
 
 
-def gpu_step1_any(opt: orc.Step1Options, force_kfold: bool = False, inject_W=None):
+def gpu_step1_any(opt: orc.Step1Options, force_kfold: bool = False, inject_W=None, loco_on_device: bool = False):
     """Level 0 + level 1 through librg_step1_hip.so for QT/BT x K-fold/LOOCV.
-    inject_W: optional per-phenotype N x L predictors to load instead of running level 0."""
+    inject_W: optional per-phenotype N x L predictors to load instead of running level 0.
+    loco_on_device: let the library assemble the LOCO rows (rg_set_loco_output) instead of the host."""
     bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
     bed, _ = orc.open_bed(opt.bed + ".bed", prep.n_file)
     blocks = orc.chrom_blocks(chrom, bim.chr_read, opt.bsize)
@@ -190,6 +191,8 @@ def gpu_step1_any(opt: orc.Step1Options, force_kfold: bool = False, inject_W=Non
     chrcols = orc.chr_columns(blocks, bim.chr_read, R0)
     cols = [nn for (_, _, nn) in chrcols]
     conv = np.ones(P, bool)
+    if loco_on_device:
+        eng.set_loco_output([c for (c, _, _) in chrcols], opt.nchrom)
     if opt.bt:
         cs, conv, best, pred = eng.l1_bt(tau, prep.Y_raw, prep.offset, cols,
                                          niter_max_ridge=opt.niter_max_ridge,
@@ -199,7 +202,10 @@ def gpu_step1_any(opt: orc.Step1Options, force_kfold: bool = False, inject_W=Non
         cs, best, pred = eng.l1_qt_loocv(tau, cols)
     else:
         cs, best, pred = eng.l1_qt(tau, cols)
-    loco = [loco_from_predictions(pred[ph], [c for (c, _, _) in chrcols], opt.nchrom) for ph in range(P)]
+    if loco_on_device:
+        loco = [np.array(pred[ph]) for ph in range(P)]
+    else:
+        loco = [loco_from_predictions(pred[ph], [c for (c, _, _) in chrcols], opt.nchrom) for ph in range(P)]
     eng.close()
     return dict(cumsum=cs, best=best, pred=pred, loco=loco, converged=conv, prep=prep, tau=tau, L=L,
                 use_loocv=use_loocv)
