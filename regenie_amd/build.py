@@ -13,7 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librg_step1_hip.so")
-SOURCES = ["rg_api.hip", "bed_prep.hip", "gram_i8.hip", "gram_fp4.hip", "assemble.hip", "chol.hip", "pred.hip", "l1.hip", "ubench.hip", "loocv.hip", "l1x.hip"]
+SOURCES = ["rg_api.hip", "bed_prep.hip", "gram_i8.hip", "gram_fp4.hip", "assemble.hip", "chol.hip", "pred.hip", "l1.hip", "ubench.hip", "loocv.hip", "l1x.hip",
+           "pgen_api.cpp"]  # pgen_api.cpp: host-only (.pgen hardcall input, include/rg_pgen.h)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result", "-Wno-inline-asm"]
 
@@ -39,6 +40,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "host", "rg_step1_main.cpp"),
                                                       os.path.join(CSRC, "rg_internal.h"),
+                                                      os.path.join(CSRC, "pgen_reader.h"),
+                                                      os.path.join(HERE, "..", "include", "rg_pgen.h"),
                                                       os.path.join(HERE, "..", "include", "rg_step1.h")]
     stamp = os.path.join(LIBDIR, "build.stamp")
     dig = _digest(deps)
@@ -48,8 +51,9 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objs = []
 
     def compile_one(src):
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
+        flags = FLAGS if src.endswith(".hip") else [f for f in FLAGS if not f.startswith("--offload-arch")]
+        cmd = [hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return src, obj, r
 

@@ -1,0 +1,93 @@
+// C ABI over rgpgen::Reader (include/rg_pgen.h).  Host-only.
+#include <new>
+#include <string>
+
+#include "../../include/rg_pgen.h"
+#include "pgen_reader.h"
+
+struct rg_pgen {
+  rgpgen::Reader rd;
+  std::string err;
+  bool ok = false;
+};
+
+namespace {
+int fail(rg_pgen* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+}  // namespace
+
+extern "C" {
+
+int rg_pgen_open(rg_pgen** out, const char* path) {
+  if (!out) return RG_PGEN_ERR_ARG;
+  *out = nullptr;
+  rg_pgen* h = new (std::nothrow) rg_pgen();
+  if (!h) return RG_PGEN_ERR_ARG;
+  *out = h;
+  if (!path) return fail(h, RG_PGEN_ERR_ARG, "rg_pgen_open: null path");
+  try {
+    h->rd.open(path);
+  } catch (const std::exception& e) {
+    h->rd.close();
+    const bool unsupported = h->rd.dosage_present() || h->rd.max_alleles() != 2;
+    return fail(h, unsupported ? RG_PGEN_ERR_UNSUPPORTED : RG_PGEN_ERR_FORMAT, e.what());
+  }
+  if (h->rd.max_alleles() != 2) {  // prep_pgen, Geno.cpp:1098-1099
+    h->rd.close();
+    return fail(h, RG_PGEN_ERR_UNSUPPORTED, "only bi-allelic variants are accepted.");
+  }
+  if (h->rd.dosage_present()) {  // regenie would read dosages (Geno.cpp:1101, :1795); not a 2-bit input
+    h->rd.close();
+    return fail(h, RG_PGEN_ERR_UNSUPPORTED,
+                std::string("pgen file has dosages; the GPU path reads hardcall (2-bit) genotypes only : ") + path);
+  }
+  h->ok = true;
+  return RG_PGEN_OK;
+}
+
+void rg_pgen_close(rg_pgen* h) { delete h; }
+
+const char* rg_pgen_last_error(const rg_pgen* h) { return h ? h->err.c_str() : "null pgen handle"; }
+
+int rg_pgen_info(const rg_pgen* h, int64_t* n_samples, int64_t* n_variants, int32_t* max_alleles, int32_t* phase_present) {
+  if (!h || !h->ok) return RG_PGEN_ERR_ARG;
+  if (n_samples) *n_samples = h->rd.n_samples();
+  if (n_variants) *n_variants = h->rd.n_variants();
+  if (max_alleles) *max_alleles = h->rd.max_alleles();
+  if (phase_present) *phase_present = h->rd.phase_present() ? 1 : 0;
+  return RG_PGEN_OK;
+}
+
+int rg_pgen_read_bed_rows(rg_pgen* h, int64_t n, const int64_t* variant_idx, uint8_t* rows, int64_t row_stride) {
+  if (!h) return RG_PGEN_ERR_ARG;
+  if (!h->ok) return fail(h, RG_PGEN_ERR_ARG, "pgen file is not open");
+  if (n < 0 || (n > 0 && (!variant_idx || !rows)) || row_stride < h->rd.bytes_per_row())
+    return fail(h, RG_PGEN_ERR_ARG, "rg_pgen_read_bed_rows: bad argument");
+  try {
+    for (int64_t k = 0; k < n; ++k) {
+      if (variant_idx[k] < 0 || variant_idx[k] >= (int64_t)h->rd.n_variants())
+        return fail(h, RG_PGEN_ERR_ARG, "variant index " + std::to_string(variant_idx[k] + 1) + " is out of range (1.." +
+                                            std::to_string(h->rd.n_variants()) + ")");
+      h->rd.read_bed_row((uint32_t)variant_idx[k], rows + k * row_stride);
+    }
+  } catch (const std::exception& e) {
+    return fail(h, RG_PGEN_ERR_FORMAT, e.what());
+  }
+  return RG_PGEN_OK;
+}
+
+int rg_pgen_read_hardcalls(rg_pgen* h, int64_t variant_idx, double* out) {
+  if (!h) return RG_PGEN_ERR_ARG;
+  if (!h->ok) return fail(h, RG_PGEN_ERR_ARG, "pgen file is not open");
+  if (!out || variant_idx < 0 || variant_idx >= (int64_t)h->rd.n_variants())
+    return fail(h, RG_PGEN_ERR_ARG, "rg_pgen_read_hardcalls: bad argument");
+  try {
+    h->rd.read_hardcalls((uint32_t)variant_idx, out);
+  } catch (const std::exception& e) {
+    return fail(h, RG_PGEN_ERR_FORMAT, e.what());
+  }
+  return RG_PGEN_OK;
+}
+}

@@ -50,7 +50,10 @@ class RgTiming(C.Structure):
 EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_w_rows", "rg_w_bytes",
            "rg_set_w_buffer", "rg_w_device_ptr", "rg_l0_blocks", "rg_sync", "rg_l0_get_w",
            "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_set_collective", "rg_set_l1_view", "rg_set_loco_output", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
-           "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak"]
+           "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak",
+           # include/rg_pgen.h (host-side .pgen hardcall input; wrapped by regenie_amd/pgen.py)
+           "rg_pgen_open", "rg_pgen_close", "rg_pgen_last_error", "rg_pgen_info", "rg_pgen_read_bed_rows",
+           "rg_pgen_read_hardcalls"]
 
 
 def lib_path() -> str:
@@ -103,6 +106,15 @@ def load_library() -> C.CDLL:
     lib.rg_k_dgemm_nt.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                   C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_int64]
     lib.rg_k_mfma_peak.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double)]
+    lib.rg_pgen_open.argtypes = [C.POINTER(C.c_void_p), C.c_char_p]
+    lib.rg_pgen_close.argtypes = [C.c_void_p]
+    lib.rg_pgen_close.restype = None
+    lib.rg_pgen_last_error.argtypes = [C.c_void_p]
+    lib.rg_pgen_last_error.restype = C.c_char_p
+    lib.rg_pgen_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                 C.POINTER(C.c_int32)]
+    lib.rg_pgen_read_bed_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.rg_pgen_read_hardcalls.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     _LIB = lib
     return lib
 

@@ -11,7 +11,8 @@
 // Served: --qt / --bt, K-fold CV / --loocv (and the reference's automatic LOOCV for --bt below 5,000 samples), and the
 // file protocol of the level-0 job split: --split-l0 PFX,N / --run-l0 PFX.master,k / --run-l1 PFX.master [--keep-l0]
 // (src/Data.cpp:232-309, :818-908; raw double N x (blocks*R0) files of Step1_Models.cpp:728-734).
-// Not served in this revision (explicit errors, never silent): --pgen/--bgen input, --gz.
+// Genotype input: --bed PFX (bed/bim/fam) or --pgen PFX (pgen/pvar/psam hardcalls, decoded to the same 2-bit rows by
+// include/rg_pgen.h).  Not served in this revision (explicit errors, never silent): --bgen input, pgen dosages, --gz.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -31,6 +32,7 @@
 #include <climits>
 #include <unistd.h>
 
+#include "../../include/rg_pgen.h"
 #include "../../include/rg_step1.h"
 
 namespace {
@@ -39,7 +41,7 @@ const double MISSING = -999.0;  // Regenie.hpp:215
 
 struct Params {
   int step = 0;
-  std::string bed, pheno_file, covar_file, out = "regenie_out";
+  std::string bed, pgen, pheno_file, covar_file, out = "regenie_out";
   std::vector<std::string> keep, remove, extract, exclude, pheno_cols, covar_cols;
   int bsize = 0, cv_folds = 5, n_ridge_l0 = 5, n_ridge_l1 = 5, nchrom = 23, threads = 0;
   bool bt = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
@@ -222,7 +224,8 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--minCaseCount") p.min_case_count = atoi(need(i).c_str());
     else if (a == "--niter") p.niter_max = atoi(need(i).c_str());
     else if (a == "--gz") usage_error("--gz is not available in this build (as in reference builds without Boost Iostreams)");
-    else if (a == "--pgen" || a == "--bgen") usage_error(a + " input is not served by the GPU path yet; use --bed");
+    else if (a == "--pgen") p.pgen = need(i);
+    else if (a == "--bgen") usage_error(a + " input is not served by the GPU path yet; use --bed or --pgen");
     else if (a == "--split-l0") {
       auto t = split_char(need(i), ',');
       if (t.size() != 2) usage_error("must specify number of jobs for --split-l0 (i.e. prefix,njobs).");
@@ -237,7 +240,7 @@ Params parse_args(int argc, char** argv) {
     else usage_error("unrecognised option '" + a + "'");
   }
   if (p.step != 1) usage_error("specify which mode regenie should be running using option --step (only --step 1 is served).");
-  if (p.bed.empty()) usage_error("must specify --bed");
+  if (p.bed.empty() == p.pgen.empty()) usage_error("must use either --bed,--bgen or --pgen.");  // Regenie.cpp:419-420
   if (p.pheno_file.empty()) usage_error("option '--phenoFile' is required.");
   if (p.bsize < 1) usage_error("must specify the block size using '--bsize'.");
   if (p.cv_folds < 2) usage_error("number of CV folds must be at least 2");
@@ -258,6 +261,10 @@ struct Run {
   std::string job_prefix;
   std::vector<std::string> mprefix; std::vector<int> bstart, btot;
   int64_t n_file = 0, bpr = 0;
+  rg_pgen* pgen = nullptr;               // --pgen: open reader (bed rows come from rg_pgen_read_bed_rows)
+  Run() = default;
+  Run(const Run&) = delete;
+  ~Run() { if (pgen) rg_pgen_close(pgen); }
   // samples
   std::vector<uint8_t> ind_ignore, ain;  // N_file, N
   std::vector<std::string> ids;          // kept, file order
@@ -361,9 +368,10 @@ bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t
   return true;
 }
 
-void read_bim_fam(Run& r) {  // Geno.cpp:518-610, :643-690, :1128-1220
+void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pgen: read_pvar / read_psam, Geno.cpp:771-1004
   const Params& p = r.p;
-  {
+  const bool pg = !p.pgen.empty();
+  if (!pg) {
     std::string fn = p.bed + ".fam";
     std::ifstream f(fn);
     if (!f) throw std::runtime_error("cannot open file : " + fn);
@@ -380,6 +388,38 @@ void read_bim_fam(Run& r) {  // Geno.cpp:518-610, :643-690, :1128-1220
     }
     r.n_file = (int64_t)r.fam_ids.size();
     sout << "n_samples = " << r.n_file << "\n";
+  } else {  // read_psam (Geno.cpp:941-1004): header line "#FID IID [SEX ...]", any "##" lines before it are skipped
+    std::string fn = p.pgen + ".psam";
+    std::ifstream f(fn);
+    if (!f) throw std::runtime_error("cannot open file : " + fn);
+    sout << std::left << std::setw(20) << " * psam" << ": [" << fn << "] ";
+    std::string line;
+    std::vector<std::string> t;
+    while (std::getline(f, line)) {
+      t = split_ws(line);
+      if (t.empty()) throw std::runtime_error("no blank lines should be before the header line in psam file.");
+      if (t[0] == "#IID") throw std::runtime_error("invalid header (must start with #FID [not #IID]).");
+      if (t[0] == "#FID") break;
+    }
+    if (t.size() < 2 || t[1] != "IID") throw std::runtime_error("header does not have the correct format.");
+    const auto sc = std::find(t.begin(), t.end(), "SEX");
+    const bool has_sex = sc != t.end();
+    const size_t sex_col = has_sex ? (size_t)(sc - t.begin()) : 0;
+    std::set<std::string> seen;
+    while (std::getline(f, line)) {
+      t = split_ws(line);
+      if (t.size() < 3) throw std::runtime_error("incorrectly formatted psam file at line " + std::to_string(r.fam_ids.size() + 1));
+      std::string id = t[0] + "_" + t[1];
+      if (!seen.insert(id).second) throw std::runtime_error("duplicate individual in fam file : FID_IID=" + id);
+      if (has_sex) {
+        if (sex_col >= t.size()) throw std::runtime_error("incorrectly formatted psam file at line " + std::to_string(r.fam_ids.size() + 1));
+        const std::string& sx = t[sex_col];
+        if (sx != "0" && sx != "NA" && sx != "1" && sx != "2") throw std::runtime_error("unrecognized sex code in file : '" + sx + "'");
+      }
+      r.fam_ids.push_back(id);
+    }
+    r.n_file = (int64_t)r.fam_ids.size();
+    sout << "n_samples = " << r.n_file << "\n";
   }
   std::set<std::string> ext, exc;
   std::vector<std::string> extract_files = p.extract, exclude_files = p.exclude;
@@ -389,30 +429,50 @@ void read_bim_fam(Run& r) {  // Geno.cpp:518-610, :643-690, :1128-1220
   }
   if (!extract_files.empty()) ext = read_snp_files(extract_files);
   if (!exclude_files.empty()) exc = read_snp_files(exclude_files);
+  int64_t n_variants_file = 0;
   {
-    std::string fn = p.bed + ".bim";
+    const std::string kind = pg ? "pvar" : "bim";
+    std::string fn = pg ? p.pgen + ".pvar" : p.bed + ".bim";
     std::ifstream f(fn);
     if (!f) throw std::runtime_error("cannot open file : " + fn);
-    sout << std::left << std::setw(20) << " * bim" << ": [" << fn << "] ";
+    sout << std::left << std::setw(20) << (" * " + kind) << ": [" << fn << "] ";
     std::string line;
     int64_t lineno = 0;
     int minchr = 0;
+    size_t min_cols = 6, id_col = 1;
+    if (pg) {  // read_pvar (Geno.cpp:787-815): skip to the "#CHROM" header and locate the POS / ID / REF / ALT columns
+      std::vector<std::string> t;
+      while (std::getline(f, line)) {
+        t = split_ws(line);
+        if (t.empty()) throw std::runtime_error("no blank lines should be before the header line in pvar file.");
+        if (t[0] == "#CHROM") break;
+      }
+      if (t.size() < 5) throw std::runtime_error("header of pvar file does not have correct format.");
+      const auto idc = std::find(t.begin(), t.end(), "ID");
+      for (const char* col : {"POS", "ID", "REF", "ALT"})
+        if (std::find(t.begin(), t.end(), col) == t.end()) throw std::runtime_error("header of pvar file does not have correct format.");
+      min_cols = 5;
+      id_col = (size_t)(idc - t.begin());
+    }
     while (std::getline(f, line)) {
       auto t = split_ws(line);
-      if (t.size() < 6) throw std::runtime_error("incorrectly formatted bim file at line " + std::to_string(lineno + 1));
+      if (t.size() < min_cols || id_col >= t.size())
+        throw std::runtime_error("incorrectly formatted " + kind + " file at line " + std::to_string(lineno + 1));
       int c = chr_str_to_int(t[0], p.nchrom);
-      if (c == -1) throw std::runtime_error("unknown chromosome code in bim file at line " + std::to_string(lineno + 1));
+      if (c == -1) throw std::runtime_error("unknown chromosome code in " + kind + " file at line " + std::to_string(lineno + 1));
       if (r.chr_read.empty() || c != r.chr_read.back()) {
         r.chr_read.push_back(c);
-        if (c <= minchr) throw std::runtime_error("chromosomes in bim file are not in ascending order.");
+        if (c <= minchr) throw std::runtime_error("chromosomes in " + kind + " file are not in ascending order.");
         minchr = c;
       }
+      const std::string& vid = t[id_col];
       bool keep = true;
-      if (!extract_files.empty() && !ext.count(t[1])) keep = false;
-      if (!exclude_files.empty() && exc.count(t[1])) keep = false;
-      if (keep) { r.snp_chrom.push_back(c); r.snp_offset.push_back(lineno); r.snp_ids.push_back(t[1]); }
+      if (!extract_files.empty() && !ext.count(vid)) keep = false;
+      if (!exclude_files.empty() && exc.count(vid)) keep = false;
+      if (keep) { r.snp_chrom.push_back(c); r.snp_offset.push_back(lineno); r.snp_ids.push_back(vid); }
       ++lineno;
     }
+    n_variants_file = lineno;
     sout << "n_snps = " << lineno << "\n";
     if (!extract_files.empty()) sout << "   -keeping variants specified by --extract\n";
     if (!exclude_files.empty()) sout << "   -removing variants specified by --exclude\n";
@@ -422,7 +482,7 @@ void read_bim_fam(Run& r) {  // Geno.cpp:518-610, :643-690, :1128-1220
   }
   if (r.snp_chrom.size() > 1000000 && !p.force_step1)  // Data.cpp:173-175
     throw std::runtime_error("it is not recommened to use more than 1M variants in step 1 (use --force-step1 to override)");
-  {
+  if (!pg) {
     std::string fn = p.bed + ".bed";
     std::ifstream f(fn, std::ios::binary);
     if (!f) throw std::runtime_error("cannot open file : " + fn);
@@ -430,6 +490,20 @@ void read_bim_fam(Run& r) {  // Geno.cpp:518-610, :643-690, :1128-1220
     f.read((char*)magic, 3);
     if (magic[0] != 0x6c || magic[1] != 0x1b || magic[2] != 0x01) throw std::runtime_error("invalid bed file format.");
     sout << std::left << std::setw(20) << " * bed" << ": [" << fn << "]\n";
+    r.bpr = (r.n_file + 3) / 4;
+  } else {  // prep_pgen (Geno.cpp:1071-1103)
+    std::string fn = p.pgen + ".pgen";
+    sout << std::left << std::setw(20) << " * pgen" << ": [" << fn << "] \n";
+    if (rg_pgen_open(&r.pgen, fn.c_str()) != RG_PGEN_OK) {
+      const std::string msg = rg_pgen_last_error(r.pgen);
+      rg_pgen_close(r.pgen);
+      r.pgen = nullptr;
+      throw std::runtime_error(msg);
+    }
+    int64_t ns = 0, nv = 0;
+    rg_pgen_info(r.pgen, &ns, &nv, nullptr, nullptr);
+    if (ns != r.n_file) throw std::runtime_error("number of samples in pgen file and psam file don't match.");
+    if (nv != n_variants_file) throw std::runtime_error("number of variants in pgen file and pvar file don't match.");
     r.bpr = (r.n_file + 3) / 4;
   }
   // --keep / --remove (Geno.cpp:1263-1341)
@@ -889,8 +963,9 @@ int run(int argc, char** argv) {
       }
     sout << "   -level 0 predictors read from the job files\n";
   } else {
-    // level 0: stream blocks from the bed file (get_G, Geno.cpp:1498-1517) in batches
-    std::ifstream bed(p.bed + ".bed", std::ios::binary);
+    // level 0: stream blocks from the bed / pgen file (get_G, Geno.cpp:1498-1517) in batches
+    std::ifstream bed;
+    if (!r.pgen) bed.open(p.bed + ".bed", std::ios::binary);
     const int NB = 32;
     std::vector<std::vector<uint8_t>> bufs(NB);
     int cur_chr = -1;
@@ -903,10 +978,15 @@ int run(int argc, char** argv) {
         const Blk& bl = blocks[b0 + b];
         if (bl.chrom != cur_chr) { cur_chr = bl.chrom; sout << "Chromosome " << cur_chr << "\n"; }
         bufs[b].resize((size_t)bl.bs * r.bpr);
-        for (int j = 0; j < bl.bs; ++j) {  // jumpto_bed (Geno.cpp:2828-2830)
-          bed.seekg(3 + r.snp_offset[bl.start + j] * r.bpr, std::ios::beg);
-          bed.read((char*)bufs[b].data() + (size_t)j * r.bpr, r.bpr);
-          if (!bed) throw std::runtime_error("cannot read bed file");
+        if (r.pgen) {  // ReadHardcalls per kept variant (Geno.cpp:1781-1798), as .bed-coded rows
+          if (rg_pgen_read_bed_rows(r.pgen, bl.bs, &r.snp_offset[bl.start], bufs[b].data(), r.bpr) != RG_PGEN_OK)
+            throw std::runtime_error(rg_pgen_last_error(r.pgen));
+        } else {
+          for (int j = 0; j < bl.bs; ++j) {  // jumpto_bed (Geno.cpp:2828-2830)
+            bed.seekg(3 + r.snp_offset[bl.start + j] * r.bpr, std::ios::beg);
+            bed.read((char*)bufs[b].data() + (size_t)j * r.bpr, r.bpr);
+            if (!bed) throw std::runtime_error("cannot read bed file");
+          }
         }
         ids[b] = b0 + b; bss[b] = bl.bs; ptrs[b] = bufs[b].data();
       }

@@ -167,3 +167,72 @@ def test_cli_split_l0_equals_single_run(example_dir, tmp_path):
         b = open(str(tmp_path / ("fit_bin_l1_%d.loco" % k)), "rb").read()
         assert a == b, "split-l0 run differs from the single run for phenotype %d" % k
     assert not os.path.exists(pre + "_job1_l0_Y1")                # removed after --run-l1 (no --keep-l0)
+
+
+def test_cli_pgen_equals_bed(example_dir, tmp_path):
+    """`--pgen example` and `--bed example` are the same genotypes (the reference's own test test/test_bash.sh:411-433
+    relies on that pair): every output file of the two runs must be byte-identical, with sample and variant filters."""
+    E = example_dir
+    common = ["--step", "1", "--exclude", os.path.join(E, "snplist_rm.txt"), "--covarFile", os.path.join(E, "covariates.txt"),
+              "--phenoFile", os.path.join(E, "phenotype.txt"), "--remove", os.path.join(E, "fid_iid_to_remove.txt"),
+              "--bsize", "100"]
+    r = _run(common + ["--bed", os.path.join(E, "example"), "--out", str(tmp_path / "b")], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = _run(common + ["--pgen", os.path.join(E, "example"), "--out", str(tmp_path / "p")], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " * pgen" in r.stdout and "n_snps = 1000" in r.stdout
+    for k in (1, 2):
+        a = open(str(tmp_path / ("b_%d.loco" % k)), "rb").read()
+        b = open(str(tmp_path / ("p_%d.loco" % k)), "rb").read()
+        assert len(a) > 1000 and a == b
+
+
+def test_cli_pgen_compressed_records(tmp_path):
+    """A .pgen that uses every record type (LD-compressed, one-bit, difflists ...) against the same genotypes as .bed."""
+    from oracle import pgen as opg
+    from tests.test_pgen import synth
+    m, n = 400, 600
+    g, vts = synth(m, n, seed=77)
+    rng = np.random.default_rng(4)
+    # keep the variants polymorphic enough for the level-0 blocks: replace monomorphic rows by common 2-bit ones
+    for j in range(m):
+        gj = g[j][g[j] != 3]
+        if gj.size < n // 2 or gj.std() < 0.2:
+            g[j] = (rng.random(n) < 0.3).astype(np.uint8) + (rng.random(n) < 0.3).astype(np.uint8)
+            vts[j] = 0
+    # re-derive LD-compressed records after the edits (their base may have changed)
+    prev = None
+    for j in range(m):
+        if (vts[j] & 6) == 2:
+            d = (g[j] if vts[j] == 2 else opg._invert(g[j])) != prev
+            if prev is None or d.sum() > n // 8:
+                vts[j] = 0
+        if (vts[j] & 6) != 2:
+            prev = g[j]
+    assert {1, 2, 3} <= set(vts)
+    pfx = str(tmp_path / "syn")
+    opg.write_pgen(pfx + ".pgen", g, vts)
+    chroms = [1 + (j * 4) // m for j in range(m)]
+    opg.write_pvar_psam(pfx, chroms, n)
+    with open(pfx + ".bed", "wb") as fh:
+        fh.write(b"\x6c\x1b\x01")
+        for j in range(m):
+            fh.write(opg._pack2(opg.PGEN_TO_BED[g[j]]))
+    with open(pfx + ".bim", "w") as fh:
+        for j in range(m):
+            fh.write("%d\tv%d\t0\t%d\tC\tA\n" % (chroms[j], j + 1, j + 1))
+    with open(pfx + ".fam", "w") as fh:
+        for i in range(n):
+            fh.write("%d %d 0 0 0 -9\n" % (i + 1, i + 1))
+    with open(pfx + ".pheno", "w") as fh:
+        fh.write("FID IID Y1 Y2\n")
+        y = rng.standard_normal((n, 2)) + 0.3 * (g[:40] % 3).sum(0)[:, None]
+        for i in range(n):
+            fh.write("%d %d %.6f %.6f\n" % (i + 1, i + 1, y[i, 0], y[i, 1]))
+    common = ["--step", "1", "--phenoFile", pfx + ".pheno", "--bsize", "50"]
+    r = _run(common + ["--bed", pfx, "--out", str(tmp_path / "b")], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = _run(common + ["--pgen", pfx, "--out", str(tmp_path / "p")], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    for k in (1, 2):
+        assert open(str(tmp_path / ("b_%d.loco" % k)), "rb").read() == open(str(tmp_path / ("p_%d.loco" % k)), "rb").read()
