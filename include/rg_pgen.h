@@ -15,7 +15,8 @@
  *
  * Conventions as in rg_step1.h: 0 on success, <0 on error, rg_pgen_last_error(h) gives the message.
  * rg_pgen_open always stores a handle in *out (also on failure, so the message can be read); free it
- * with rg_pgen_close.  A handle is not thread-safe; open one per reading thread.
+ * with rg_pgen_close.  Calls on one handle must not overlap (rg_pgen_read_bed_rows spreads its own work over the
+ * threads set with rg_pgen_set_threads).
  */
 #ifndef RG_PGEN_H
 #define RG_PGEN_H
@@ -41,6 +42,10 @@ const char* rg_pgen_last_error(const rg_pgen* h);
 /* Any pointer may be NULL.  phase_present: hardcall phase tracks exist (they are ignored, as by ReadHardcalls). */
 int rg_pgen_info(const rg_pgen* h, int64_t* n_samples, int64_t* n_variants, int32_t* max_alleles,
                  int32_t* phase_present);
+
+/* Worker threads used by rg_pgen_read_bed_rows (default 1): the counterpart of the OpenMP loop over the block's
+ * variants in the reference's reader (Geno.cpp:1777-1781, PgenReader::Load(.., nthr)). */
+int rg_pgen_set_threads(rg_pgen* h, int32_t n_threads);
 
 /* Decodes n variants (0-based file indices, any order; ascending order keeps the LD-base cache warm)
  * into rows[k * row_stride .. + ceil(n_samples/4)). */

@@ -31,27 +31,29 @@ constexpr uint32_t kVblock = 65536;      // variants per header block
 constexpr uint32_t kDifflistGroup = 64;  // entries per difflist group
 constexpr uint32_t kMaxDifflistDiv = 8;  // a difflist holds at most N/8 entries
 
+// pgen code -> PLINK1 bed code in every 2-bit slot of a word: 0->11, 1->10, 2->00, 3->01, i.e.
+// (hi, lo) -> (~hi, ~(hi ^ lo)).
+inline uint64_t pgen_to_bed_word(uint64_t w) {
+  const uint64_t m = 0x5555555555555555ull;
+  const uint64_t hi = (w >> 1) & m, lo = w & m;
+  return ((~hi & m) << 1) | (~(hi ^ lo) & m);
+}
+
+// 0 <-> 2 in every 2-bit slot (1 and 3 stay): (hi, lo) -> (hi ^ ~lo, lo).
+inline uint64_t invert_word(uint64_t w) {
+  const uint64_t m = 0x5555555555555555ull;
+  const uint64_t hi = (w >> 1) & m, lo = w & m;
+  return (((hi ^ ~lo) & m) << 1) | lo;
+}
+
 struct Tables {
-  uint8_t bed[256];     // 4 pgen codes -> 4 bed codes: 0->11, 1->10, 2->00, 3->01
-  uint8_t inv[256];     // 0<->2 in each 2-bit slot
-  uint8_t spread[16];   // bit k of a nibble -> bit 2k of a byte
+  uint16_t spread[256];  // bit k of a byte -> bit 2k of a 16-bit word
   Tables() {
-    static const uint8_t b[4] = {3, 2, 0, 1}, v[4] = {2, 1, 0, 3};
     for (int x = 0; x < 256; ++x) {
-      uint8_t o = 0, w = 0;
-      for (int k = 0; k < 4; ++k) {
-        const int c = (x >> (2 * k)) & 3;
-        o |= (uint8_t)(b[c] << (2 * k));
-        w |= (uint8_t)(v[c] << (2 * k));
-      }
-      bed[x] = o;
-      inv[x] = w;
-    }
-    for (int x = 0; x < 16; ++x) {
-      uint8_t s = 0;
-      for (int k = 0; k < 4; ++k)
-        if (x & (1 << k)) s |= (uint8_t)(1 << (2 * k));
-      spread[x] = s;
+      uint16_t v = 0;
+      for (int k = 0; k < 8; ++k)
+        if (x & (1 << k)) v |= (uint16_t)(1u << (2 * k));
+      spread[x] = v;
     }
   }
 };
@@ -60,6 +62,12 @@ inline const Tables& tables() {
   static const Tables t;
   return t;
 }
+
+// Per-thread decode state: record bytes, the current variant and the cached LD base as packed pgen codes.
+struct Scratch {
+  std::vector<uint8_t> rec, cur, ld;
+  int64_t ld_vidx = -1;
+};
 
 class Reader {
  public:
@@ -160,23 +168,44 @@ class Reader {
         if ((t & 0x08) && max_alleles_ < 3) max_alleles_ = 3;
       }
     }
-    cur_.assign((size_t)bpr_ + 2, 0);
-    ld_.assign((size_t)bpr_ + 2, 0);
-    ld_vidx_ = -1;
+    own_ = make_scratch();
   }
 
-  // One variant as a PLINK1 bed row (ceil(N/4) bytes; padding bits zero).
-  void read_bed_row(uint32_t vidx, uint8_t* out) {
-    const uint8_t* g = decode(vidx);
-    const Tables& t = tables();
-    for (int64_t i = 0; i < bpr_; ++i) out[i] = t.bed[g[i]];
+  // Buffers are padded to whole 64-bit words so the row transforms can run word-wise.
+  Scratch make_scratch() const {
+    Scratch s;
+    const size_t padded = ((size_t)bpr_ + 7) / 8 * 8 + 8;
+    s.cur.assign(padded, 0);
+    s.ld.assign(padded, 0);
+    return s;
+  }
+
+  // One variant as a PLINK1 bed row (ceil(N/4) bytes; padding bits zero).  The const overloads take the
+  // caller's Scratch, so several threads can decode from one open file (pread carries its own offset).
+  void read_bed_row(uint32_t vidx, uint8_t* out) { read_bed_row(vidx, out, own_); }
+  void read_bed_row(uint32_t vidx, uint8_t* out, Scratch& s) const {
+    const uint8_t* g = decode(vidx, s);
+    const int64_t words = bpr_ / 8;
+    for (int64_t i = 0; i < words; ++i) {
+      uint64_t w;
+      std::memcpy(&w, g + 8 * i, 8);
+      w = pgen_to_bed_word(w);
+      std::memcpy(out + 8 * i, &w, 8);
+    }
+    if (bpr_ & 7) {
+      uint64_t w;
+      std::memcpy(&w, g + 8 * words, 8);  // the buffers are padded past the row
+      w = pgen_to_bed_word(w);
+      std::memcpy(out + 8 * words, &w, (size_t)(bpr_ & 7));
+    }
     if (n_ & 3) out[bpr_ - 1] &= (uint8_t)((1u << (2 * (n_ & 3))) - 1);
   }
 
   // One variant as ALT-allele counts 0/1/2 and -3 for missing: ReadHardcalls(.., allele_idx = 1).
-  void read_hardcalls(uint32_t vidx, double* out) {
+  void read_hardcalls(uint32_t vidx, double* out) { read_hardcalls(vidx, out, own_); }
+  void read_hardcalls(uint32_t vidx, double* out, Scratch& s) const {
     static const double val[4] = {0.0, 1.0, 2.0, -3.0};
-    const uint8_t* g = decode(vidx);
+    const uint8_t* g = decode(vidx, s);
     for (uint32_t i = 0; i < n_; ++i) out[i] = val[(g[i >> 2] >> (2 * (i & 3))) & 3];
   }
 
@@ -190,8 +219,7 @@ class Reader {
   bool dosage_ = false, phase_ = false;
   std::vector<uint8_t> vrtypes_;
   std::vector<uint64_t> fpos_;
-  std::vector<uint8_t> rec_, cur_, ld_;  // record bytes; genotypes as packed pgen codes; cached LD base
-  int64_t ld_vidx_ = -1;
+  Scratch own_;  // state of the single-threaded entry points
 
   bool pread_all(void* dst, uint64_t len, uint64_t off) const {
     uint8_t* d = (uint8_t*)dst;
@@ -250,8 +278,8 @@ class Reader {
     }
   }
 
-  // Main genotype track of variant vidx as packed pgen codes (valid until the next call).
-  const uint8_t* decode(uint32_t vidx) {
+  // Main genotype track of variant vidx as packed pgen codes (valid until the next call on the same Scratch).
+  const uint8_t* decode(uint32_t vidx, Scratch& s) const {
     if (fd_ < 0) throw std::runtime_error("pgen file is closed");
     if (vidx >= m_) throw std::runtime_error("variant index " + std::to_string((uint64_t)vidx + 1) + " is out of range (1.." + std::to_string(m_) + ")");
     const uint32_t vt = vrtypes_[vidx] & 7;
@@ -259,55 +287,61 @@ class Reader {
       int64_t base = (int64_t)vidx - 1;
       while (base >= 0 && (vrtypes_[base] & 6) == 2) --base;
       if (base < 0) bad(vidx, "LD-compressed variant without a base variant");
-      if (ld_vidx_ != base) {
-        decode_plain((uint32_t)base, ld_.data());
-        ld_vidx_ = base;
+      if (s.ld_vidx != base) {
+        s.ld_vidx = -1;
+        decode_plain((uint32_t)base, s.ld.data(), s);
+        s.ld_vidx = base;
       }
-      std::memcpy(cur_.data(), ld_.data(), (size_t)bpr_);
+      std::memcpy(s.cur.data(), s.ld.data(), (size_t)bpr_);
       const uint8_t *p, *end;
-      load_record(vidx, p, end);
-      apply_difflist(p, end, cur_.data(), vidx);
+      load_record(vidx, p, end, s);
+      apply_difflist(p, end, s.cur.data(), vidx);
       if (vt == 3) {
-        const Tables& t = tables();
-        for (int64_t i = 0; i < bpr_; ++i) cur_[i] = t.inv[cur_[i]];
+        const int64_t words = (bpr_ + 7) / 8;
+        for (int64_t i = 0; i < words; ++i) {
+          uint64_t w;
+          std::memcpy(&w, s.cur.data() + 8 * i, 8);
+          w = invert_word(w);
+          std::memcpy(s.cur.data() + 8 * i, &w, 8);
+        }
       }
-      return cur_.data();
+      return s.cur.data();
     }
     if ((vrtypes_[vidx + 1] & 6) == 2) {  // the next variant will want this one as its base
-      decode_plain(vidx, ld_.data());
-      ld_vidx_ = vidx;
-      return ld_.data();
+      s.ld_vidx = -1;
+      decode_plain(vidx, s.ld.data(), s);
+      s.ld_vidx = vidx;
+      return s.ld.data();
     }
-    decode_plain(vidx, cur_.data());
-    return cur_.data();
+    decode_plain(vidx, s.cur.data(), s);
+    return s.cur.data();
   }
 
-  void load_record(uint32_t vidx, const uint8_t*& p, const uint8_t*& end) {
+  void load_record(uint32_t vidx, const uint8_t*& p, const uint8_t*& end, Scratch& s) const {
     const uint64_t len = fpos_[vidx + 1] - fpos_[vidx];
-    rec_.resize(len + 1);
-    if (len && !pread_all(rec_.data(), len, fpos_[vidx])) throw std::runtime_error("cannot read pgen file");
-    p = rec_.data();
+    if (s.rec.size() < len + 1) s.rec.resize(len + 1);
+    if (len && !pread_all(s.rec.data(), len, fpos_[vidx])) throw std::runtime_error("cannot read pgen file");
+    p = s.rec.data();
     end = p + len;
   }
 
-  void decode_plain(uint32_t vidx, uint8_t* g) {  // record types 0, 1, 4..7
+  void decode_plain(uint32_t vidx, uint8_t* g, Scratch& s) const {  // record types 0, 1, 4..7
     const uint32_t vt = vrtypes_[vidx] & 7;
     const uint8_t *p, *end;
-    load_record(vidx, p, end);
+    load_record(vidx, p, end, s);
     if (!(vt & 4)) {
       if (vt & 3) {  // one bit per sample picks one of two codes; exceptions follow as a difflist
         const int64_t nb = ((int64_t)n_ + 7) / 8;
         if (end - p < 1 + nb) bad(vidx, "one-bit track runs past the record");
         const uint8_t c2 = *p++;
-        const uint8_t lo = (uint8_t)((c2 >> 2) * 0x55), dlt = c2 & 3;
+        const uint16_t lo = (uint16_t)((c2 >> 2) * 0x5555u), dlt = c2 & 3;
         const Tables& t = tables();
         const int64_t full = bpr_ / 2;  // whole bit-bytes that map to two whole output bytes
         for (int64_t i = 0; i < full; ++i) {
-          const uint8_t b = p[i];
-          g[2 * i] = (uint8_t)(lo + t.spread[b & 15] * dlt);
-          g[2 * i + 1] = (uint8_t)(lo + t.spread[b >> 4] * dlt);
+          const uint16_t v = (uint16_t)(lo + t.spread[p[i]] * dlt);
+          std::memcpy(g + 2 * i, &v, 2);
         }
-        if (bpr_ & 1) g[bpr_ - 1] = (uint8_t)(lo + t.spread[p[full] & 15] * dlt);
+        if (bpr_ & 1) g[bpr_ - 1] = (uint8_t)(lo + t.spread[p[full]] * dlt);
         p += nb;
         apply_difflist(p, end, g, vidx);
       } else {

@@ -28,6 +28,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 #include <climits>
 #include <unistd.h>
@@ -499,6 +500,11 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
       rg_pgen_close(r.pgen);
       r.pgen = nullptr;
       throw std::runtime_error(msg);
+    }
+    {  // --threads, default = hardware threads - 1 (Regenie.cpp:1104-1106); the decode of a block's variants is spread over them
+      int nt = p.threads;
+      if (nt < 1) nt = std::max(1, (int)std::thread::hardware_concurrency() - 1);
+      rg_pgen_set_threads(r.pgen, std::min(nt, 64));
     }
     int64_t ns = 0, nv = 0;
     rg_pgen_info(r.pgen, &ns, &nv, nullptr, nullptr);

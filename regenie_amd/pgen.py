@@ -16,7 +16,7 @@ from .engine import RgError, load_library
 
 
 class PgenFile:
-    def __init__(self, path: str):
+    def __init__(self, path: str, threads: int = 1):
         self.lib = load_library()
         self.h = C.c_void_p()
         rc = self.lib.rg_pgen_open(C.byref(self.h), path.encode())
@@ -29,6 +29,12 @@ class PgenFile:
         self.n_samples, self.n_variants = ns.value, nv.value
         self.max_alleles, self.phase_present = ac.value, bool(ph.value)
         self.bytes_per_row = (self.n_samples + 3) // 4
+        if threads != 1:
+            self.set_threads(threads)
+
+    def set_threads(self, n: int) -> None:
+        """Worker threads for read_bed_rows (the reference decodes a block's variants under OpenMP)."""
+        self._check(self.lib.rg_pgen_set_threads(self.h, int(n)))
 
     def close(self) -> None:
         if getattr(self, "h", None):

@@ -153,6 +153,10 @@ def test_every_record_type(tmp_path, m, n, rl, wide, phase, nonref, mode):
         perm = np.random.default_rng(5).permutation(m)[:300]
         assert (f.read_bed_rows(perm) == rows[perm]).all()
         assert (f.read_hardcalls(int(perm[0])) == truth[perm[0]]).all()
+        # worker threads (the reference decodes a block's variants under OpenMP): same rows, each worker with its own LD cache
+        f.set_threads(5)
+        assert (f.read_bed_rows(np.arange(m)) == rows).all()
+        assert (f.read_bed_rows(perm) == rows[perm]).all()
     if os.path.exists(REF_LIB):  # the writer is format-conformant: regenie's own reader gets the genotypes back
         assert _ref_counts(path, n) == [n, m, 2, 0]
         assert (_ref_hardcalls(path, n, m) == truth).all()
@@ -231,6 +235,12 @@ def test_malformed_files_are_errors_not_crashes(tmp_path):
             f.read_bed_rows([j])
         assert e.value.code == -2 and "variant %d" % (j + 1) in str(e.value)
         assert (f.read_hardcalls(0) == opg.HARDCALL[g[0]]).all()  # the handle survives the error
+        f.set_threads(3)
+        with pytest.raises(RgError) as e:
+            f.read_bed_rows(np.arange(40))
+        assert "variant %d" % (j + 1) in str(e.value)
+        with pytest.raises(RgError):
+            f.set_threads(0)
     with pytest.raises(opg.PgenError):
         opg.PgenOracle(b).codes(j)
     # a difflist longer than N/8
