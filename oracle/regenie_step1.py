@@ -18,6 +18,7 @@ Appendix E.2 vs this file).
 """
 from __future__ import annotations
 
+import gzip
 import math
 import os
 from dataclasses import dataclass, field
@@ -105,6 +106,15 @@ def chr_str_to_int(s: str, nchrom: int) -> int:
     return -1
 
 
+def _open_text(path: str):
+    """Files::openForRead (Files.cpp:38-64, :139-160): gzip only when the name ends in .gz AND the magic bytes match."""
+    if path.endswith(".gz"):
+        with open(path, "rb") as fh:
+            if fh.read(2) == b"\x1f\x8b":
+                return gzip.open(path, "rt")
+    return open(path)
+
+
 @dataclass
 class Bim:
     chrom: np.ndarray       # int per variant kept
@@ -158,7 +168,7 @@ def read_id_files(paths: Sequence[str]) -> set:
     """--keep/--remove files: >=2 whitespace columns FID IID, no header (Geno.cpp:1382-1441)."""
     out = set()
     for p in paths:
-        with open(p) as fh:
+        with _open_text(p) as fh:
             for line in fh:
                 t = line.split()
                 if len(t) < 2:
@@ -170,7 +180,7 @@ def read_id_files(paths: Sequence[str]) -> set:
 def read_snp_files(paths: Sequence[str]) -> set:
     out = set()
     for p in paths:
-        with open(p) as fh:
+        with _open_text(p) as fh:
             for line in fh:
                 t = line.split()
                 if t:
@@ -278,7 +288,7 @@ def read_pheno_and_cov(opt: Step1Options, fam_ids: List[str]) -> Prepared:
     trait_mode = 1 if opt.bt else 0
 
     # ---- pheno_read
-    with open(opt.pheno_file) as fh:
+    with _open_text(opt.pheno_file) as fh:
         lines = fh.read().splitlines()
     hdr = lines[0].rstrip("\r").split()
     if len(hdr) < 2:
@@ -354,7 +364,7 @@ def read_pheno_and_cov(opt: Step1Options, fam_ids: List[str]) -> Prepared:
     X = np.ones((N, 1))
     in_cov = np.ones(N, bool) if not opt.covar_file else np.zeros(N, bool)
     if opt.covar_file:
-        with open(opt.covar_file) as fh:
+        with _open_text(opt.covar_file) as fh:
             lines = fh.read().splitlines()
         hdr = lines[0].rstrip("\r").split()
         if hdr[0] != "FID" or hdr[1] != "IID":

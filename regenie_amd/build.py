@@ -73,7 +73,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(bindir, exist_ok=True)
     r = subprocess.run([hipcc, "-O2", "-std=c++17", os.path.join(HERE, "host", "rg_step1_main.cpp"), "-o",
                         os.path.join(bindir, "regenie-amd"), "-L" + LIBDIR, "-lrg_step1_hip",
-                        "-Wl,-rpath,$ORIGIN/../lib"], capture_output=True, text=True)
+                        "-Wl,-rpath,$ORIGIN/../lib", "-lz"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("host driver build failed:\n%s\n%s" % (r.stdout, r.stderr))
     with open(stamp, "w") as fh:

@@ -24,6 +24,7 @@
 #include <iomanip>
 #include <iostream>
 #include <map>
+#include <memory>
 #include <set>
 #include <sstream>
 #include <stdexcept>
@@ -32,6 +33,7 @@
 #include <vector>
 #include <climits>
 #include <unistd.h>
+#include <zlib.h>
 
 #include "../../include/rg_pgen.h"
 #include "../../include/rg_step1.h"
@@ -46,7 +48,7 @@ struct Params {
   std::vector<std::string> keep, remove, extract, exclude, pheno_cols, covar_cols;
   int bsize = 0, cv_folds = 5, n_ridge_l0 = 5, n_ridge_l1 = 5, nchrom = 23, threads = 0;
   bool bt = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
-       print_prs = false, force_step1 = false, lowmem = false, force_qt = false, cc12 = false;
+       print_prs = false, force_step1 = false, lowmem = false, force_qt = false, cc12 = false, gz = false;
   int min_case_count = 10, niter_max = 50, niter_max_line_search = 25;
   // level-0 job split (Data.cpp:232-309, :818-908)
   std::string split_file;              // --split-l0 prefix / --run-l0, --run-l1 master file
@@ -63,6 +65,85 @@ struct Log {  // mstream (Regenie.hpp:120-142): tee to stdout and <out>.log
   Log& operator<<(std::ostream& (*m)(std::ostream&)) { std::cout << m; if (f.is_open()) f << m; return *this; }
 };
 Log sout;
+
+// Files (Files.cpp:38-160): a file whose name ends in ".gz" and starts with the gzip magic is read through zlib, anything
+// else as plain text; `--gz` writes the .loco / .prs outputs through zlib.  (The reference needs Boost Iostreams for this.)
+bool ends_with_gz(const std::string& fn) { return fn.size() > 3 && fn.compare(fn.size() - 3, 3, ".gz") == 0; }
+bool file_exists(const std::string& fn) { return access(fn.c_str(), F_OK) == 0; }
+
+class GzInBuf : public std::streambuf {
+ public:
+  explicit GzInBuf(const std::string& fn) : f_(gzopen(fn.c_str(), "rb")), buf_(1 << 16) {}
+  ~GzInBuf() override { if (f_) gzclose(f_); }
+  bool ok() const { return f_ != nullptr; }
+ protected:
+  int_type underflow() override {
+    if (gptr() < egptr()) return traits_type::to_int_type(*gptr());
+    const int n = f_ ? gzread(f_, buf_.data(), (unsigned)buf_.size()) : 0;
+    if (n <= 0) return traits_type::eof();
+    setg(buf_.data(), buf_.data(), buf_.data() + n);
+    return traits_type::to_int_type(*gptr());
+  }
+ private:
+  gzFile f_;
+  std::vector<char> buf_;
+};
+
+class TextIn : public std::istream {  // Files::openForRead
+ public:
+  explicit TextIn(const std::string& fn) : std::istream(nullptr) {
+    bool gz = false;
+    if (ends_with_gz(fn)) {  // isGzipped(filename, true): extension first, then the two magic bytes
+      std::ifstream t(fn, std::ios::binary);
+      unsigned char h[2] = {0, 0};
+      t.read((char*)h, 2);
+      gz = t && h[0] == 0x1f && h[1] == 0x8b;
+    }
+    if (gz) {
+      gz_.reset(new GzInBuf(fn));
+      if (gz_->ok()) rdbuf(gz_.get()); else setstate(std::ios::failbit);
+    } else {
+      if (plain_.open(fn, std::ios::in)) rdbuf(&plain_); else setstate(std::ios::failbit);
+    }
+  }
+ private:
+  std::filebuf plain_;
+  std::unique_ptr<GzInBuf> gz_;
+};
+
+class GzOutBuf : public std::streambuf {
+ public:
+  explicit GzOutBuf(const std::string& fn) : f_(gzopen(fn.c_str(), "wb")) {}
+  ~GzOutBuf() override { if (f_) gzclose(f_); }
+  bool ok() const { return f_ != nullptr; }
+ protected:
+  int_type overflow(int_type c) override {
+    if (c == traits_type::eof()) return traits_type::not_eof(c);
+    const char ch = traits_type::to_char_type(c);
+    return (f_ && gzwrite(f_, &ch, 1) == 1) ? c : traits_type::eof();
+  }
+  std::streamsize xsputn(const char* p, std::streamsize n) override {
+    if (!f_ || n <= 0) return 0;
+    return gzwrite(f_, p, (unsigned)n) > 0 ? n : 0;
+  }
+ private:
+  gzFile f_;
+};
+
+class TextOut : public std::ostream {  // Files::openForWrite
+ public:
+  TextOut(const std::string& fn, bool gz) : std::ostream(nullptr) {
+    if (gz) {
+      gz_.reset(new GzOutBuf(fn));
+      if (gz_->ok()) rdbuf(gz_.get()); else setstate(std::ios::failbit);
+    } else {
+      if (plain_.open(fn, std::ios::out)) rdbuf(&plain_); else setstate(std::ios::failbit);
+    }
+  }
+ private:
+  std::filebuf plain_;
+  std::unique_ptr<GzOutBuf> gz_;
+};
 
 std::vector<std::string> split_ws(const std::string& s) {
   std::vector<std::string> out;
@@ -105,7 +186,7 @@ std::string cpp_double(double v) {  // default ostream formatting (precision 6)
 std::set<std::string> read_id_files(const std::vector<std::string>& files) {  // Geno.cpp:1382-1441
   std::set<std::string> ids;
   for (auto& fn : files) {
-    std::ifstream f(fn);
+    TextIn f(fn);
     if (!f) throw std::runtime_error("cannot open file : " + fn);
     std::string line;
     while (std::getline(f, line)) {
@@ -119,7 +200,7 @@ std::set<std::string> read_id_files(const std::vector<std::string>& files) {  //
 std::set<std::string> read_snp_files(const std::vector<std::string>& files) {
   std::set<std::string> ids;
   for (auto& fn : files) {
-    std::ifstream f(fn);
+    TextIn f(fn);
     if (!f) throw std::runtime_error("cannot open file : " + fn);
     std::string line;
     while (std::getline(f, line)) {
@@ -224,7 +305,7 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--1" || a == "--cc12") p.cc12 = true;
     else if (a == "--minCaseCount") p.min_case_count = atoi(need(i).c_str());
     else if (a == "--niter") p.niter_max = atoi(need(i).c_str());
-    else if (a == "--gz") usage_error("--gz is not available in this build (as in reference builds without Boost Iostreams)");
+    else if (a == "--gz") p.gz = true;
     else if (a == "--pgen") p.pgen = need(i);
     else if (a == "--bgen") usage_error(a + " input is not served by the GPU path yet; use --bed or --pgen");
     else if (a == "--split-l0") {
@@ -391,7 +472,8 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
     sout << "n_samples = " << r.n_file << "\n";
   } else {  // read_psam (Geno.cpp:941-1004): header line "#FID IID [SEX ...]", any "##" lines before it are skipped
     std::string fn = p.pgen + ".psam";
-    std::ifstream f(fn);
+    if (!file_exists(fn)) fn += ".gz";  // Geno.cpp:952
+    TextIn f(fn);
     if (!f) throw std::runtime_error("cannot open file : " + fn);
     sout << std::left << std::setw(20) << " * psam" << ": [" << fn << "] ";
     std::string line;
@@ -434,7 +516,8 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
   {
     const std::string kind = pg ? "pvar" : "bim";
     std::string fn = pg ? p.pgen + ".pvar" : p.bed + ".bim";
-    std::ifstream f(fn);
+    if (pg && !file_exists(fn)) fn += ".gz";  // Geno.cpp:783
+    TextIn f(fn);
     if (!f) throw std::runtime_error("cannot open file : " + fn);
     sout << std::left << std::setw(20) << (" * " + kind) << ": [" << fn << "] ";
     std::string line;
@@ -537,7 +620,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
   for (int64_t i = 0; i < N; ++i) idx[r.ids[i]] = i;
   std::vector<uint8_t> in_pheno(N, 0), in_cov(N, p.covar_file.empty() ? 1 : 0);
   {
-    std::ifstream f(p.pheno_file);
+    TextIn f(p.pheno_file);
     if (!f) throw std::runtime_error("cannot open file : " + p.pheno_file);
     sout << std::left << std::setw(20) << " * phenotypes" << ": [" << p.pheno_file << "] ";
     std::string line;
@@ -627,7 +710,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
   int ncols = 1;
   std::vector<double> Xraw;  // col-major N x ncols
   if (!p.covar_file.empty()) {
-    std::ifstream f(p.covar_file);
+    TextIn f(p.covar_file);
     if (!f) throw std::runtime_error("cannot open file : " + p.covar_file);
     sout << std::left << std::setw(20) << " * covariates" << ": [" << p.covar_file << "] ";
     std::string line;
@@ -1083,13 +1166,14 @@ int run(int argc, char** argv) {
       sout << "\n";
     }
     sout << "  * making predictions...writing LOCO predictions...";
-    const std::string loco_fn = p.out + "_" + std::to_string(q + 1) + ".loco";
+    const std::string loco_fn = p.out + "_" + std::to_string(q + 1) + ".loco" + (p.gz ? ".gz" : "");  // Data.cpp:987
     const double* pq = pred.data() + (size_t)q * nchr * N;  // [nchr][N]
     std::vector<double> tot(N, 0.0);
     for (int c = 0; c < nchr; ++c)
       for (int64_t i = 0; i < N; ++i) tot[i] += pq[(size_t)c * N + i];
     {
-      std::ofstream lf(loco_fn);
+      TextOut lf(loco_fn, p.gz);
+      if (!lf) throw std::runtime_error("cannot write file : " + loco_fn);
       lf << header;
       std::map<int, int> cidx;
       for (int c = 0; c < nchr; ++c) cidx[chroms[c]] = c;
@@ -1108,8 +1192,8 @@ int run(int argc, char** argv) {
     }
     plist << r.pheno_names[q] << " " << (p.use_rel_path ? loco_fn : get_fullpath(loco_fn)) << "\n";
     if (p.print_prs) {
-      const std::string prs_fn = p.out + "_" + std::to_string(q + 1) + ".prs";
-      std::ofstream pf(prs_fn);
+      const std::string prs_fn = p.out + "_" + std::to_string(q + 1) + ".prs" + (p.gz ? ".gz" : "");
+      TextOut pf(prs_fn, p.gz);
       pf << header;
       std::ostringstream row;
       row << 0 << " ";

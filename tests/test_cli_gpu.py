@@ -236,3 +236,33 @@ def test_cli_pgen_compressed_records(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     for k in (1, 2):
         assert open(str(tmp_path / ("b_%d.loco" % k)), "rb").read() == open(str(tmp_path / ("p_%d.loco" % k)), "rb").read()
+
+
+def test_cli_gz_mode_of_the_reference_test(example_dir, tmp_path):
+    """test/test_bash.sh run with Boost Iostreams (`fsuf=.gz`, `arg_gz=--gz`, :45-53, :64-76): the covariate and phenotype files
+    are read gzipped and the .loco files are written gzipped.  Decompressed they must be the plain run's bytes, and
+    _pred.list must point at the .gz files."""
+    import gzip
+    E = example_dir
+    base = ["--step", "1", "--bed", os.path.join(E, "example"), "--exclude", os.path.join(E, "snplist_rm.txt"),
+            "--remove", os.path.join(E, "fid_iid_to_remove.txt"), "--bsize", "100", "--bt", "--lowmem", "--lowmem-prefix", "tmp_rg"]
+    plain = base + ["--covarFile", os.path.join(E, "covariates.txt"), "--phenoFile", os.path.join(E, "phenotype_bin.txt")]
+    gz = base + ["--covarFile", os.path.join(E, "covariates.txt.gz"), "--phenoFile", os.path.join(E, "phenotype_bin.txt.gz"), "--gz"]
+    r = _run(plain + ["--out", str(tmp_path / "a")], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = _run(gz + ["--out", str(tmp_path / "z")], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    for k in (1, 2):
+        assert not os.path.exists(str(tmp_path / ("z_%d.loco" % k)))
+        a = open(str(tmp_path / ("a_%d.loco" % k)), "rb").read()
+        z = gzip.open(str(tmp_path / ("z_%d.loco.gz" % k)), "rb").read()
+        assert len(a) > 1000 and a == z
+    lines = open(str(tmp_path / "z_pred.list")).read().split("\n")
+    assert lines[0] == "Y1 " + str(tmp_path / "z_1.loco.gz") and lines[1] == "Y2 " + str(tmp_path / "z_2.loco.gz")
+    # a file named .gz that is not gzip data is read as plain text (Files::isGzipped checks the magic bytes)
+    import shutil
+    shutil.copy(os.path.join(E, "phenotype_bin.txt"), str(tmp_path / "fake.txt.gz"))
+    r = _run(base + ["--covarFile", os.path.join(E, "covariates.txt"), "--phenoFile", str(tmp_path / "fake.txt.gz"),
+                     "--out", str(tmp_path / "f")], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert open(str(tmp_path / "f_1.loco"), "rb").read() == open(str(tmp_path / "a_1.loco"), "rb").read()
