@@ -12,7 +12,8 @@
 // file protocol of the level-0 job split: --split-l0 PFX,N / --run-l0 PFX.master,k / --run-l1 PFX.master [--keep-l0]
 // (src/Data.cpp:232-309, :818-908; raw double N x (blocks*R0) files of Step1_Models.cpp:728-734).
 // Genotype input: --bed PFX (bed/bim/fam) or --pgen PFX (pgen/pvar/psam hardcalls, decoded to the same 2-bit rows by
-// include/rg_pgen.h).  Not served in this revision (explicit errors, never silent): --bgen input, pgen dosages, --gz.
+// include/rg_pgen.h); gzipped text inputs and --gz outputs through zlib (Files.cpp:38-160).  Not served in this revision
+// (explicit errors, never silent): --bgen input, pgen dosages.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
