@@ -49,7 +49,8 @@ typedef struct rg_problem {
   int32_t cv_folds;        /* K in [2,32], or 0 = leave-one-out CV (params.use_loocv) */
   int32_t n_ridge_l0;      /* R0 */
   int32_t ref_first;       /* --ref-first (Geno.cpp:1746) */
-  int32_t reserved0;
+  int32_t family;                      /* 0 = logistic (--bt); 1 = Poisson (--ct: ridge_poisson_level_1[_loocv],
+                                          Step1_Models.cpp:1429-1758; yraw = counts, offset = null Poisson eta) */
   int64_t n_analyzed;      /* params.n_analyzed */
   const int32_t* cv_sizes; /* K entries, params.cv_sizes (Data.cpp:401-426), sum = N */
   const double* lambda;    /* R0 entries, ALREADY scaled: M*(1-h)/h (Data.cpp:607) */
@@ -162,7 +163,8 @@ typedef struct rg_bt_options {
   int32_t niter_max_ridge;             /* 100   params.niter_max_ridge */
   int32_t niter_max_line_search_ridge; /* 100   params.niter_max_line_search_ridge */
   int32_t niter_max_line_search;       /* 25    params.niter_max_line_search (LOOCV Newton) */
-  int32_t reserved0;
+  int32_t family;                      /* 0 = logistic (--bt); 1 = Poisson (--ct: ridge_poisson_level_1[_loocv],
+                                          Step1_Models.cpp:1429-1758; yraw = counts, offset = null Poisson eta) */
   double l1_ridge_tol;                 /* 1e-4  params.l1_ridge_tol */
   double tol;                          /* 1e-8  params.tol */
 } rg_bt_options;

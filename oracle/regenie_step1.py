@@ -46,6 +46,7 @@ class Step1Options:
     out: str = "regenie_out"
     bsize: int = 1000
     bt: bool = False                 # --bt (trait_mode 1); default --qt
+    ct: bool = False                 # --ct (trait_mode 2): count phenotypes, Poisson level 1
     cv_folds: int = 5                # --cv
     loocv: bool = False              # --loocv
     n_ridge_l0: int = 5              # --l0
@@ -285,7 +286,7 @@ def read_pheno_and_cov(opt: Step1Options, fam_ids: List[str]) -> Prepared:
     ids = [k for k, m in zip(fam_ids, keep_mask) if m]
     idx = {k: i for i, k in enumerate(ids)}
     N = len(ids)
-    trait_mode = 1 if opt.bt else 0
+    trait_mode = 1 if opt.bt else (2 if opt.ct else 0)
 
     # ---- pheno_read
     with _open_text(opt.pheno_file) as fh:
@@ -333,6 +334,12 @@ def read_pheno_and_cov(opt: Step1Options, fam_ids: List[str]) -> Prepared:
                 if v != 0 and v != 1:
                     if v != MISSING:
                         raise ValueError("a phenotype value is not 0/1/NA for individual: FID=%s IID=%s Y=%s" % (t[0], t[1], t[2 + j]))
+                    mask[i, ip] = False
+            elif trait_mode == 2:                      # Pheno.cpp:298, :313-320: counts must be non-negative
+                Yraw[i, ip] = v
+                if v < 0:
+                    if v != MISSING:
+                        raise ValueError("a phenotype value is <0 for individual: FID=%s IID=%s Y=%s" % (t[0], t[1], t[2 + j]))
                     mask[i, ip] = False
             Y[i, ip] = v
             if v != MISSING:
@@ -534,12 +541,79 @@ def fit_null_logistic(prep: Prepared, opt: Step1Options) -> None:
         prep.offset[:, ph] = eta
 
 
+def poisson_dev(y: np.ndarray, p: np.ndarray, mask: np.ndarray) -> float:
+    """get_poisson_dev / compute_log_lik_poisson (Step1_Models.cpp:1830-1849): 2 * sum -(y log p - p)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ll = -(y * np.log(p) - p)
+    return 2.0 * float(ll[mask].sum())
+
+
+def fit_poisson(y, X, offset, mask, p, eta, beta, opt: Step1Options):
+    """Step1_Models.cpp:290-345.  Returns (ok, beta, p, eta)."""
+    dev_old = poisson_dev(y, p, mask)
+    niter = 0
+    dev_conv = False
+    betanew = beta
+    while True:
+        niter += 1
+        if niter > opt.niter_max:
+            break
+        if (p[mask] == 0).any():
+            return False, beta, p, eta
+        wm = np.where(mask, p, 0.0)
+        XtW = X.T * wm[None, :]
+        XtWX = XtW @ X
+        with np.errstate(divide="ignore", invalid="ignore"):
+            z = np.where(mask, eta - offset + (y - p) / p, 0.0)
+        betanew = np.linalg.lstsq(XtWX, XtW @ z, rcond=None)[0]        # colPivHouseholderQr().solve
+        dev_new = dev_old
+        for _ in range(opt.niter_max_line_search):
+            eta = offset + X @ betanew
+            with np.errstate(over="ignore"):
+                p = np.exp(eta)
+            dev_new = poisson_dev(y, p, mask)
+            if not (p[mask] == 0).any():
+                break
+            betanew = (beta + betanew) / 2
+        score = X.T @ np.where(mask, y - p, 0.0)
+        dev_conv = abs(dev_new - dev_old) / (0.1 + abs(dev_new)) < 1e-8        # params->tol
+        if np.abs(score).max() < 1e-8:
+            break
+        beta = betanew
+        dev_old = dev_new
+    if (not dev_conv) and niter > opt.niter_max:
+        return False, beta, p, eta
+    return True, betanew, p, eta
+
+
+def fit_null_poisson(prep: Prepared, opt: Step1Options) -> None:
+    """Step1_Models.cpp:225-288 (step-1 branch): covariate-only Poisson regression -> offset_nullreg = eta."""
+    N, P = prep.Y.shape
+    prep.offset = np.zeros((N, P))
+    for ph in range(P):
+        y = prep.Y_raw[:, ph]
+        mask = prep.mask[:, ph]
+        off = np.zeros(N)
+        p = y + 1e-1
+        with np.errstate(divide="ignore", invalid="ignore"):
+            eta = np.where(mask, np.log(p), 0.0)
+        beta0 = np.zeros(prep.X.shape[1])
+        beta0[0] = eta.mean() - off.mean()
+        ok, beta, p, eta = fit_poisson(y, prep.X, off, mask, p, eta, beta0, opt)
+        if not ok:
+            prep.pheno_pass[ph] = False
+            continue
+        prep.offset[:, ph] = eta
+
+
 def prep_run(prep: Prepared, opt: Step1Options) -> None:
     """Pheno.cpp:1060-1202 prep_run (step-1 subset): getBasis, null models, residualize_phenotypes
     (:1799-1834)."""
     prep.X, prep.ncov = get_basis(prep.X)
     if opt.bt:
         fit_null_logistic(prep, opt)
+    elif opt.ct:
+        fit_null_poisson(prep, opt)
     beta = prep.Y.T @ prep.X                              # P x C
     prep.Y = prep.Y - (prep.X @ beta.T) * prep.mask
     prep.scale_Y = np.linalg.norm(prep.Y, axis=0) / np.sqrt(prep.Neff - prep.ncov)
@@ -886,6 +960,154 @@ def ridge_logistic_level_1(W, yraw, offset, mask, cv_sizes, tau, opt: Step1Optio
     return cs, betas, True
 
 
+def _poisson_sums(cs, j, p1, y):
+    """The six running sums of Step1_Models.cpp:1557-1570 / :1672-1684 (p1 clamped below at l1_ridge_eps)."""
+    p1 = np.maximum(p1, L1_RIDGE_EPS)
+    cs[0, j] += p1.sum()
+    cs[1, j] += y.sum()
+    cs[2, j] += (p1 * p1).sum()
+    cs[3, j] += (y * y).sum()
+    cs[4, j] += (p1 * y).sum()
+    cs[5, j] += (-(y * np.log(p1) - p1)).sum()
+
+
+def ridge_poisson_level_1(W, yraw, offset, mask, cv_sizes, tau, opt: Step1Options):
+    """Step1_Models.cpp:1429-1583 for ONE phenotype.  Returns (cumsum[6,R1], betas[K] each L x R1, converged)."""
+    N, L = W.shape
+    K = cv_sizes.size
+    R1 = tau.size
+    starts = np.concatenate([[0], np.cumsum(cv_sizes)])
+    cs = np.zeros((6, R1))
+    betas = [np.zeros((L, R1)) for _ in range(K)]
+
+    def pvec(b, X, o):
+        with np.errstate(over="ignore"):
+            e = o + X @ b
+            return e, np.exp(e)
+
+    for i in range(K):
+        tr = np.ones(N, bool)
+        tr[starts[i]:starts[i + 1]] = False
+        Xt, yt, ot, mt = W[tr], yraw[tr], offset[tr], mask[tr]
+        betanew = np.zeros(L)
+        for j in range(R1):
+            betaold = betanew
+            niter = 0
+            while True:
+                niter += 1
+                if niter > opt.niter_max_ridge:
+                    break
+                eta, p = pvec(betaold, Xt, ot)
+                if (p[mt] == 0).any():
+                    return cs, betas, False
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    z = np.where(mt, (eta - ot) + (yt - p) / p, 0.0)
+                wm = np.where(mt, p, 0.0)
+                XtW = Xt.T * wm[None, :]
+                XtWX = XtW @ Xt
+                XtWX[np.diag_indices_from(XtWX)] += tau[j]
+                cho = np.linalg.cholesky(XtWX)
+                betanew = np.linalg.solve(cho.T, np.linalg.solve(cho, XtW @ z))
+                for _ in range(opt.niter_max_line_search_ridge):
+                    _, p = pvec(betanew, Xt, ot)
+                    if not (p[mt] == 0).any():
+                        break
+                    betanew = (betaold + betanew) / 2
+                _, p = pvec(betanew, Xt, ot)
+                if (p[mt] == 0).any():
+                    return cs, betas, False
+                score = Xt.T @ np.where(mt, yt - p, 0.0) - tau[j] * betanew
+                if np.abs(score).max() < L1_RIDGE_TOL:
+                    break
+                betaold = betanew
+            if niter > opt.niter_max_ridge:
+                return cs, betas, False
+            sl = slice(starts[i], starts[i + 1])
+            _, p1 = pvec(betanew, W[sl], offset[sl])
+            betas[i][:, j] = betanew
+            m = mask[sl]
+            _poisson_sums(cs, j, p1[m], yraw[sl][m])
+    return cs, betas, True
+
+
+def run_ct_ridge_loocv(lam: float, beta: np.ndarray, y, X, offset, mask, opt: Step1Options):
+    """Step1_Models.cpp:1694-1758: plain Newton (no line search).  Returns (ok, beta, p)."""
+    betaold = beta
+    betanew = beta
+    niter = 0
+    p = None
+    while True:
+        niter += 1
+        if niter > opt.niter_max_ridge:
+            break
+        with np.errstate(over="ignore"):
+            eta = offset + X @ betaold
+            p = np.exp(eta)
+        if (p[mask] == 0).any():
+            return False, betaold, p
+        with np.errstate(divide="ignore", invalid="ignore"):
+            z = np.where(mask, (eta - offset) + (y - p) / p, 0.0)
+        wm = np.where(mask, p, 0.0)
+        XtW = X.T * wm[None, :]
+        XtWX = XtW @ X
+        XtWX[np.diag_indices_from(XtWX)] += lam
+        cho = np.linalg.cholesky(XtWX)
+        betanew = np.linalg.solve(cho.T, np.linalg.solve(cho, XtW @ z))
+        with np.errstate(over="ignore"):
+            p = np.exp(offset + X @ betanew)
+        if (p[mask] == 0).any():
+            return False, betaold, p
+        score = X.T @ np.where(mask, y - p, 0.0) - lam * betanew
+        if np.abs(score).max() < L1_RIDGE_TOL:
+            break
+        betaold = betanew
+    if niter > opt.niter_max_ridge:
+        return False, betaold, p
+    return True, betanew, p
+
+
+def ridge_poisson_level_1_loocv(W, yraw, offset, mask, tau, opt: Step1Options):
+    """Step1_Models.cpp:1585-1692 for ONE phenotype.  Returns (cumsum[6,R1], converged)."""
+    N, L = W.shape
+    R1 = tau.size
+    cs = np.zeros((6, R1))
+    beta = np.zeros(L)
+    for j in range(R1):
+        ok, beta, p = run_ct_ridge_loocv(tau[j], beta, yraw, W, offset, mask, opt)
+        if not ok:
+            return cs, False
+        b_loo = _loo_betas(W, yraw, p, p, mask, beta, tau[j])            # weights of a Poisson model are its means
+        with np.errstate(over="ignore"):
+            p1 = np.exp((W * b_loo.T).sum(axis=1) + offset)
+        _poisson_sums(cs, j, p1[mask], yraw[mask])
+    return cs, True
+
+
+def make_predictions_count_loocv(W, yraw, offset, mask, tau_best, chrcols, opt: Step1Options):
+    """Data.cpp:1625-1712: refit at tau* from beta = 0.  Its Hessian sums the weights of ALL rows (no mask); the rows
+    of masked samples in the LOOCV level-0 predictors are zero (Step1_Models.cpp:693-704), so that is the same matrix."""
+    N, L = W.shape
+    ok, beta, p = run_ct_ridge_loocv(tau_best, np.zeros(L), yraw, W, offset, mask, opt)
+    XtWX = (W.T * p[None, :]) @ W
+    XtWX[np.diag_indices_from(XtWX)] += tau_best
+    cho = np.linalg.cholesky(XtWX)
+    V1 = np.linalg.solve(cho.T, np.linalg.solve(cho, W.T))
+    v2 = (W * V1.T).sum(axis=1) * p
+    b_loo = beta[:, None] - V1 * ((yraw - p) / (1 - v2))[None, :]
+    pred = np.zeros((N, len(chrcols)))
+    for ci, (_, ctr, nn) in enumerate(chrcols):
+        pred[:, ci] = (W[:, ctr:ctr + nn] * b_loo[ctr:ctr + nn].T).sum(axis=1)
+    return pred
+
+
+def tau_count(h: np.ndarray, L: int, yraw_col: np.ndarray, Neff: float) -> np.ndarray:
+    """check_l0, Step1_Models.cpp:2101-2104: tau_j = L / log(1 + h_j / (rate (1 - h_j))), rate = sum(raw) / Neff.
+    (The reference sums the raw column as it is: a sample kept in the analysis but missing for this phenotype
+    contributes its missing-value code; restated as is.)"""
+    rate = yraw_col.sum() / Neff
+    return L / np.log(1 + h / (rate * (1 - h)))
+
+
 # --------------------------------------------------------------------------
 # output stage (Data.cpp:956-1129 output, :1196-1342, :1346-1427, :1484-1571, :1795-1975)
 # --------------------------------------------------------------------------
@@ -902,16 +1124,22 @@ def select_tau(cs: np.ndarray, Neff: float, bt: bool) -> int:
     return best
 
 
-def cv_table(cs: np.ndarray, Neff: float, L: int, tau: np.ndarray, bt: bool, best: int) -> List[str]:
-    """The per-tau log lines of Data.cpp:1042-1077."""
+def cv_table(cs: np.ndarray, Neff: float, L: int, tau: np.ndarray, bt: bool, best: int, ct_rate: Optional[float] = None) -> List[str]:
+    """The per-tau log lines of Data.cpp:1042-1077 (ct_rate: count traits, :1039-1054 -- no MSE column)."""
     out = []
     for j in range(tau.size):
-        h = L / (L + ((math.pi ** 2 / 3) if bt else 1.0) * tau[j])
+        if ct_rate is not None:
+            zv = math.exp(L / tau[j]) - 1
+            h = ct_rate * zv / (1 + ct_rate * zv)
+        else:
+            h = L / (L + ((math.pi ** 2 / 3) if bt else 1.0) * tau[j])
         num = cs[4, j] - cs[0, j] * cs[1, j] / Neff
         rsq = num * num / ((cs[2, j] - cs[0, j] ** 2 / Neff) * (cs[3, j] - cs[1, j] ** 2 / Neff))
         sse = cs[2, j] + cs[3, j] - 2 * cs[4, j]
-        s = "  %-5s : Rsq = %s, MSE = %s" % (cpp_double(h).rjust(5), cpp_double(rsq), cpp_double(sse / Neff))
-        if bt:
+        s = "  %-5s : Rsq = %s" % (cpp_double(h).rjust(5), cpp_double(rsq))
+        if ct_rate is None:
+            s += ", MSE = %s" % cpp_double(sse / Neff)
+        if bt or ct_rate is not None:
             s += ", -logLik/N = %s" % cpp_double(cs[5, j] / Neff)
         if j == best:
             s += "<- min value"
@@ -1065,6 +1293,14 @@ def run_step1(opt: Step1Options, write_files: bool = False, keep_W: bool = True)
     M = opt.parallel_nGeno if opt.parallel_nGeno is not None else chrom.size
     lam = M * (1 - h0) / h0                                       # Data.cpp:607
     cv_sizes = None if use_loocv else set_folds(prep.ind_in_analysis, opt.cv_folds)
+    if opt.ct and not use_loocv:                                  # Data.cpp:436-466: a fold without any count
+        st = np.concatenate([[0], np.cumsum(cv_sizes)])
+        for i in range(cv_sizes.size):
+            ssum = (prep.Y_raw[st[i]:st[i + 1]] * prep.mask[st[i]:st[i + 1]]).sum(axis=0)
+            ssum = np.where(prep.pheno_pass, ssum, 10.0)
+            if ssum.min() == 0:
+                raise ValueError("one of the folds has only zero counts for phenotype '%s'. Either use smaller #folds (option --cv) "
+                                 "or use LOOCV (option --loocv)." % prep.pheno_names[int(np.argmin(ssum))])
     L = B * R0
     W = [np.zeros((N, L)) for _ in range(P)]
     for b, (c, start, bs) in enumerate(blocks):
@@ -1085,6 +1321,7 @@ def run_step1(opt: Step1Options, write_files: bool = False, keep_W: bool = True)
 def finish_level_1(opt, prep, blocks, chr_read, cv_sizes, lam, h1, W, use_loocv, log, write_files=False) -> Step1Result:
     """prep_l1_models + level-1 dispatch + output (Data.cpp:113-131)."""
     bt = opt.bt
+    ct = opt.ct
     P = prep.Y.shape[1]
     R0 = lam.size
     L = len(blocks) * R0
@@ -1092,7 +1329,7 @@ def finish_level_1(opt, prep, blocks, chr_read, cv_sizes, lam, h1, W, use_loocv,
     taus, css, bests, preds, locos, conv = [], [], [], [], [], []
     pred_list = []
     for ph in range(P):
-        tau = tau_from_h(h1, L, bt)
+        tau = tau_count(h1, L, prep.Y_raw[:, ph], prep.Neff[ph]) if ct else tau_from_h(h1, L, bt)
         taus.append(tau)
         y = prep.Y[:, ph]
         betas = None
@@ -1100,7 +1337,12 @@ def finish_level_1(opt, prep, blocks, chr_read, cv_sizes, lam, h1, W, use_loocv,
         if not prep.pheno_pass[ph]:
             css.append(np.zeros((6, h1.size))); bests.append(0); preds.append(None); locos.append(None); conv.append(False)
             continue
-        if not bt:
+        if ct:
+            if use_loocv:
+                cs, ok = ridge_poisson_level_1_loocv(W[ph], prep.Y_raw[:, ph], prep.offset[:, ph], prep.mask[:, ph], tau, opt)
+            else:
+                cs, betas, ok = ridge_poisson_level_1(W[ph], prep.Y_raw[:, ph], prep.offset[:, ph], prep.mask[:, ph], cv_sizes, tau, opt)
+        elif not bt:
             if use_loocv:
                 cs = ridge_level_1_loocv(W[ph], y, tau, prep.Neff[ph], prep.ncov)
             else:
@@ -1117,10 +1359,13 @@ def finish_level_1(opt, prep, blocks, chr_read, cv_sizes, lam, h1, W, use_loocv,
             log.append("Level 1 model did not converge. LOCO predictions calculations are skipped.")
             bests.append(0); preds.append(None); locos.append(None)
             continue
-        best = select_tau(cs, prep.Neff[ph], bt)
+        best = select_tau(cs, prep.Neff[ph], bt or ct)
         bests.append(best)
-        log.extend(cv_table(cs, prep.Neff[ph], L, tau, bt, best))
-        if not bt:
+        log.extend(cv_table(cs, prep.Neff[ph], L, tau, bt, best, ct_rate=(prep.Y_raw[:, ph].sum() / prep.Neff[ph]) if ct else None))
+        if ct:
+            pred = make_predictions_count_loocv(W[ph], prep.Y_raw[:, ph], prep.offset[:, ph], prep.mask[:, ph], tau[best], chrcols, opt) \
+                if use_loocv else make_predictions(W[ph], betas, best, cv_sizes, chrcols)    # make_predictions_count, Data.cpp:1575-1622
+        elif not bt:
             pred = make_predictions_loocv(W[ph], y, tau[best], chrcols) if use_loocv else \
                 make_predictions(W[ph], betas, best, cv_sizes, chrcols)
         else:

@@ -171,7 +171,7 @@ struct LooArgs {
   const double* wv;     // BT: p(1-p) (0 on masked)                        [Np]
   const double* off;    // BT: offset                                      [Np]
   const double* maskp;  // BT: 0/1                                         [Np]
-  int bt;
+  int bt;               // 0 = QT, 1 = binary (logistic), 2 = count (Poisson: wv = mean, p1 = exp(eta))
 };
 #define LOO_NPART 6
 __device__ __forceinline__ double block_sum_256(double x, double* sred /*[4]*/) {
@@ -203,10 +203,16 @@ __global__ __launch_bounds__(256) void k_loo_cv(LooArgs a, double* part) {
     } else if (a.maskp[pos] != 0.0) {
       const double y = a.y[pos];
       const double eta = xb - h * a.rv[pos] / (1.0 - h * a.wv[pos]) + a.off[pos];
-      double p1 = 1.0 - 1.0 / (exp(eta) + 1.0);
-      p1 = fmin(fmax(p1, 1e-5), 1.0 - 1e-5);   // l1_ridge_eps, Step1_Models.cpp:1256-1257
+      double p1;
+      if (a.bt == 2) {                         // count trait: mean exp(eta), floored (Step1_Models.cpp:1669-1684)
+        p1 = fmax(exp(eta), 1e-5);
+        t[5] = -(y * log(p1) - p1);
+      } else {
+        p1 = 1.0 - 1.0 / (exp(eta) + 1.0);
+        p1 = fmin(fmax(p1, 1e-5), 1.0 - 1e-5);   // l1_ridge_eps, Step1_Models.cpp:1256-1257
+        t[5] = -((y == 0.0) ? log(1.0 - p1) : log(p1));
+      }
       t[0] = p1; t[1] = y; t[2] = p1 * p1; t[3] = y * y; t[4] = p1 * y;
-      t[5] = -((y == 0.0) ? log(1.0 - p1) : log(p1));
     }
   }
 #pragma unroll
@@ -256,6 +262,7 @@ struct BtArgs {
   const double* beta;   // [nchain][n64]
   int nchain, kfold;
   double *wv, *zv, *rv; // [nchain][Np]
+  int family;           // 0 = logistic, 1 = Poisson (p = exp(eta), wgt = p; Step1_Models.cpp:1813-1818, :1483-1493)
 };
 #define BT_NPART 8      // Sx, Sy, Sx2, Sy2, Sxy, -LL (held-out), deviance (training), #(wgt == 0)
 __device__ __forceinline__ double rg_pvec(double eta) {
@@ -310,17 +317,30 @@ __global__ __launch_bounds__(256) void k_bt_eval(BtArgs a, int ch0, const int32_
     double wgt = 0.0, z = 0.0, r = 0.0;
     if (m != 0.0) {
       if (!test) {
-        const double p = rg_pvec(off + acc[j]);
-        wgt = p * (1.0 - p);
+        double p;
+        if (a.family == 1) {
+          p = exp(off + acc[j]);
+          wgt = p;
+          t[6] = -2.0 * (y * log(p) - p);
+        } else {
+          p = rg_pvec(off + acc[j]);
+          wgt = p * (1.0 - p);
+          t[6] = -2.0 * ((y == 0.0) ? log(1.0 - p) : log(p));
+        }
         r = y - p;
         if (wgt == 0.0) t[7] = 1.0;
         else z = acc[j] + r / wgt;
-        t[6] = -2.0 * ((y == 0.0) ? log(1.0 - p) : log(p));
       } else {
-        double p1 = 1.0 - 1.0 / (exp(off + acc[j]) + 1.0);
-        p1 = fmin(fmax(p1, 1e-5), 1.0 - 1e-5);
+        double p1;
+        if (a.family == 1) {
+          p1 = fmax(exp(off + acc[j]), 1e-5);     // l1_ridge_eps floor, Step1_Models.cpp:1560-1561
+          t[5] = -(y * log(p1) - p1);
+        } else {
+          p1 = 1.0 - 1.0 / (exp(off + acc[j]) + 1.0);
+          p1 = fmin(fmax(p1, 1e-5), 1.0 - 1e-5);
+          t[5] = -((y == 0.0) ? log(1.0 - p1) : log(p1));
+        }
         t[0] = p1; t[1] = y; t[2] = p1 * p1; t[3] = y * y; t[4] = p1 * y;
-        t[5] = -((y == 0.0) ? log(1.0 - p1) : log(p1));
       }
     }
     if (live) {
@@ -658,6 +678,35 @@ int bt_newton_loocv(BtState& s, double lam, std::vector<double>& beta, const rg_
   return RG_OK;
 }
 
+// run_ct_ridge_loocv (Step1_Models.cpp:1694-1758): plain Newton on the penalised Poisson likelihood, no line search;
+// beta in/out.  On success the device state (wgt = mean, r) is the state at the returned beta.
+int ct_newton_loocv(BtState& s, double lam, std::vector<double>& beta, const rg_bt_options& o, bool* ok) {
+  const int L = s.c->L;
+  *ok = false;
+  std::vector<double> sums, maxabs, betaold = beta, betanew = beta;
+  std::vector<double> tauc(1, lam);
+  std::vector<int32_t> act(1, 0);
+  int rc, niter = 0;
+  while (true) {
+    if (++niter > o.niter_max_ridge) break;
+    if ((rc = bt_eval(s, betaold, sums))) return rc;
+    if (sums[7] != 0.0) return RG_OK;            // a zero mean among the analysed samples
+    bool bad = false;
+    if ((rc = bt_solve(s, act, tauc, false, &bad))) return rc;
+    if (bad) return RG_OK;
+    for (int k = 0; k < L; ++k) betanew[k] = s.h_sol[k];
+    if ((rc = bt_eval(s, betanew, sums))) return rc;
+    if (sums[7] != 0.0) return RG_OK;
+    if ((rc = bt_score(s, tauc, maxabs))) return rc;
+    if (maxabs[0] < o.l1_ridge_tol) break;
+    betaold = betanew;
+  }
+  if (niter > o.niter_max_ridge) return RG_OK;
+  beta = betanew;
+  *ok = true;
+  return RG_OK;
+}
+
 }  // namespace
 
 int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, const double* offset,
@@ -666,8 +715,10 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
   if (R1 < 1 || R1 > 16) { ctx->err = "rg_l1_bt: n_ridge_l1 must be in [1,16]"; return RG_ERR_ARG; }
   rg_bt_options o;
   o.niter_max_ridge = 100; o.niter_max_line_search_ridge = 100; o.niter_max_line_search = 25;
-  o.l1_ridge_tol = 1e-4; o.tol = 1e-8;
+  o.l1_ridge_tol = 1e-4; o.tol = 1e-8; o.family = 0;
   if (opt) o = *opt;
+  if (o.family != 0 && o.family != 1) { ctx->err = "rg_l1_bt: family must be 0 (logistic) or 1 (Poisson)"; return RG_ERR_ARG; }
+  const bool poisson = o.family == 1;
   L1Common c;
   int rc = l1_common_init(ctx, c, nchr, cols_per_chr, "rg_l1_bt");
   if (rc) return rc;
@@ -732,7 +783,7 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
     const int pg = c.p0v + p, pw = c.view ? p : pg;   // global phenotype / index inside the predictor buffer
     s.p = pw;
     s.a = BtArgs{c.Wv, Np, L, c.Pv, pw, n64, d_yraw, d_off, ctx->d_maskp + (int64_t)pg * Np, s.d_beta, nchain,
-                 loocv ? 0 : 1, d_wv, d_zv, d_rv};
+                 loocv ? 0 : 1, d_wv, d_zv, d_rv, o.family};
     bool ok = true;
 
     if (!loocv) {
@@ -800,7 +851,8 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
       hipLaunchKernelGGL(k_transpose_w, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, c.Wv, Np, L, c.Pv, pw,
                          n64, d_Wt);
       std::vector<double> beta((size_t)n64, 0.0);
-      LooArgs la{c.Wv, d_Ut, s.d_beta, Np, L, c.Pv, pw, d_yraw, d_rv, d_wv, d_off, ctx->d_maskp + (int64_t)pg * Np, 1};
+      LooArgs la{c.Wv, d_Ut, s.d_beta, Np, L, c.Pv, pw, d_yraw, d_rv, d_wv, d_off, ctx->d_maskp + (int64_t)pg * Np, poisson ? 2 : 1};
+      auto newton = [&](double lam, std::vector<double>& b, bool* cv) { return poisson ? ct_newton_loocv(s, lam, b, o, cv) : bt_newton_loocv(s, lam, b, o, cv); };
       auto loo_setup = [&](double lam) -> int {   // H = (X^T W X + lam I)^-1 at the current weights, U^T = H W^T
         WgArgs g{c.Wv, ctx->d_zero, Np, L, c.Pv, pw, n64, d_wv, nullptr, nullptr, nullptr, 0, d_G, c.msz};
         hipLaunchKernelGGL(k_wgram, dim3((T * (T + 1) / 2 + T + 3) / 4, 1), dim3(256), 0, st, g, ctx->seg, T);
@@ -813,7 +865,7 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
       };
       for (int j = 0; j < R1 && ok; ++j) {
         bool conv = false;
-        if ((rc = bt_newton_loocv(s, taup[j], beta, o, &conv))) return rc;
+        if ((rc = newton(taup[j], beta, &conv))) return rc;
         if (!conv) { ok = false; break; }
         if ((rc = loo_setup(taup[j]))) return rc;
         hipLaunchKernelGGL(k_loo_cv, dim3(gpos), dim3(256), 0, st, la, d_lpart);
@@ -836,7 +888,7 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
       // make_predictions_binary_loocv refits at tau* from beta = 0 (Data.cpp:1499-1503)
       std::fill(beta.begin(), beta.end(), 0.0);
       bool conv = false;
-      if ((rc = bt_newton_loocv(s, taup[best], beta, o, &conv))) return rc;
+      if ((rc = newton(taup[best], beta, &conv))) return rc;
       if (!conv) { converged_out[p] = 0; continue; }
       if ((rc = loo_setup(taup[best]))) return rc;
       L1X_HIP(hipMemsetAsync(c.d_pred, 0, sizeof(double) * (size_t)nchr * N, st));

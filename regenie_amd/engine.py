@@ -33,7 +33,7 @@ class RgProblem(C.Structure):
 
 class RgBtOptions(C.Structure):
     _fields_ = [("niter_max_ridge", C.c_int32), ("niter_max_line_search_ridge", C.c_int32),
-                ("niter_max_line_search", C.c_int32), ("reserved0", C.c_int32),
+                ("niter_max_line_search", C.c_int32), ("family", C.c_int32),
                 ("l1_ridge_tol", C.c_double), ("tol", C.c_double)]
 
 
@@ -279,8 +279,8 @@ class Step1Engine:
 
     def l1_bt(self, tau: np.ndarray, yraw: np.ndarray, offset: np.ndarray, cols_per_chr: Sequence[int],
               niter_max_ridge: int = 100, niter_max_line_search_ridge: int = 100,
-              niter_max_line_search: int = 25, l1_ridge_tol: float = 1e-4, tol: float = 1e-8):
-        """Logistic ridge level 1 (K-fold or LOOCV as the problem was set up).
+              niter_max_line_search: int = 25, l1_ridge_tol: float = 1e-4, tol: float = 1e-8, family: int = 0):
+        """Logistic (family 0, --bt) or Poisson (family 1, --ct) ridge level 1, K-fold or LOOCV as the problem was set up.
         Returns (cumsum [P,6,R1], converged [P] bool, best [P], pred [P][N,nchr])."""
         tau = np.ascontiguousarray(tau, dtype=np.float64)
         P, R1 = tau.shape
@@ -290,7 +290,7 @@ class Step1Engine:
         assert yraw.shape == (self.N, P) and offset.shape == (self.N, P)
         cpc = np.ascontiguousarray(cols_per_chr, dtype=np.int32)
         nchr = cpc.size
-        o = RgBtOptions(niter_max_ridge, niter_max_line_search_ridge, niter_max_line_search, 0, l1_ridge_tol, tol)
+        o = RgBtOptions(niter_max_ridge, niter_max_line_search_ridge, niter_max_line_search, family, l1_ridge_tol, tol)
         cs = np.zeros((P, 6, R1))
         conv = np.zeros(P, dtype=np.int32)
         best = np.zeros(P, dtype=np.int32)

@@ -110,3 +110,62 @@ def test_loco_output_mode_matches_host_assembly(example_dir, kind):
     for ph in range(len(ref["loco"])):
         assert got["loco"][ph].shape == ref["loco"][ph].shape
         assert np.array_equal(ref["loco"][ph], got["loco"][ph])
+
+
+# ---- count traits (--ct): Poisson ridge level 1, Step1_Models.cpp:1429-1758 ----------------------------------------------
+def _count_pheno_file(example_dir, path, with_na_rows=True, seed=5):
+    """Two count phenotypes on the example's samples: one driven by the example's first QT, one pure noise.  A row is
+    either complete or missing both (a partially missing row would hit the reference's rate-with-missing-code quirk,
+    oracle.tau_count)."""
+    rng = np.random.default_rng(seed)
+    lines = open(os.path.join(example_dir, "phenotype.txt")).read().split("\n")
+    with open(path, "w") as fh:
+        fh.write("FID IID C1 C2\n")
+        for i, ln in enumerate(lines[1:]):
+            t = ln.split()
+            if not t:
+                continue
+            c1 = rng.poisson(np.exp(0.5 + 0.4 * float(t[2])))
+            c2 = rng.poisson(2.0)
+            if with_na_rows and i % 50 == 7:
+                fh.write("%s %s NA NA\n" % (t[0], t[1]))
+            else:
+                fh.write("%s %s %d %d\n" % (t[0], t[1], c1, c2))
+
+
+@pytest.mark.parametrize("loocv", [False, True])
+def test_ct_poisson_example(example_dir, tmp_path, loocv):
+    E = example_dir
+    ph = str(tmp_path / "ct.txt")
+    _count_pheno_file(E, ph)
+    opt = orc.Step1Options(bed=os.path.join(E, "example"), pheno_file=ph, covar_file=os.path.join(E, "covariates.txt"),
+                           remove=[os.path.join(E, "fid_iid_to_remove.txt")], bsize=100, ct=True, loocv=loocv)
+    ref = orc.run_step1(opt)
+    got = gpu_step1_any(opt)
+    assert got["use_loocv"] == loocv and ref.use_loocv == loocv
+    assert all(ref.converged)
+    _compare(ref, got, 2, TOL_BT, 6)
+    # the log label of a count trait inverts the tau map back to the h grid (Data.cpp:1039-1054)
+    rate = got["prep"].Y_raw[:, 0].sum() / got["prep"].Neff[0]
+    lines = orc.cv_table(np.asarray(got["cumsum"][0]), got["prep"].Neff[0], got["L"], got["tau"][0], False, int(got["best"][0]), ct_rate=rate)
+    assert [ln.split(":")[0].strip() for ln in lines] == ["0.01", "0.25", "0.5", "0.75", "0.99"]
+    assert all("MSE" not in ln and "-logLik/N" in ln for ln in lines)
+
+
+def test_ct_poisson_loco_on_device_and_ragged(tmp_path):
+    N, M = 640, 300
+    g = synth_dosages(M, N, miss_rate=0.01, seed=13)
+    pre = str(tmp_path / "ct")
+    write_plink(pre, g, np.repeat([1, 3, 4], [110, 100, 90]), P=2, ncov=2, seed=4)
+    rng = np.random.default_rng(2)
+    rows = open(pre + ".pheno").read().split("\n")
+    with open(pre + ".ct", "w") as fh:
+        fh.write("FID IID K1\n")
+        for ln in rows[1:]:
+            t = ln.split()
+            if t:
+                fh.write("%s %s %d\n" % (t[0], t[1], rng.poisson(np.exp(0.2 + 0.5 * float(t[2]))) if t[2] != "NA" else 0))
+    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".ct", covar_file=pre + ".covar", bsize=70, ct=True)
+    ref = orc.run_step1(opt)
+    got = gpu_step1_any(opt, loco_on_device=True)
+    _compare(ref, got, 1, TOL_BT, 6)

@@ -187,17 +187,17 @@ def gpu_step1_any(opt: orc.Step1Options, force_kfold: bool = False, inject_W=Non
             for ph in range(P):
                 eng.set_w(b, ph, inject_W[ph][:, b * R0:(b + 1) * R0])
     L = B * R0
-    tau = np.stack([orc.tau_from_h(h1, L, opt.bt) for _ in range(P)])
+    tau = np.stack([orc.tau_count(h1, L, prep.Y_raw[:, ph], prep.Neff[ph]) if opt.ct else orc.tau_from_h(h1, L, opt.bt) for ph in range(P)])
     chrcols = orc.chr_columns(blocks, bim.chr_read, R0)
     cols = [nn for (_, _, nn) in chrcols]
     conv = np.ones(P, bool)
     if loco_on_device:
         eng.set_loco_output([c for (c, _, _) in chrcols], opt.nchrom)
-    if opt.bt:
+    if opt.bt or opt.ct:
         cs, conv, best, pred = eng.l1_bt(tau, prep.Y_raw, prep.offset, cols,
                                          niter_max_ridge=opt.niter_max_ridge,
                                          niter_max_line_search_ridge=opt.niter_max_line_search_ridge,
-                                         niter_max_line_search=opt.niter_max_line_search)
+                                         niter_max_line_search=opt.niter_max_line_search, family=1 if opt.ct else 0)
     elif use_loocv:
         cs, best, pred = eng.l1_qt_loocv(tau, cols)
     else:
