@@ -48,9 +48,9 @@ struct Params {
   std::string bed, pgen, pheno_file, covar_file, out = "regenie_out";
   std::vector<std::string> keep, remove, extract, exclude, pheno_cols, covar_cols;
   int bsize = 0, cv_folds = 5, n_ridge_l0 = 5, n_ridge_l1 = 5, nchrom = 23, threads = 0;
-  bool bt = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
+  bool bt = false, ct = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
        print_prs = false, force_step1 = false, lowmem = false, force_qt = false, cc12 = false, gz = false;
-  int min_case_count = 10, niter_max = 50, niter_max_line_search = 25;
+  int min_case_count = 10, niter_max = 50, niter_max_line_search = 25, niter_max_ridge = 100;
   // level-0 job split (Data.cpp:232-309, :818-908)
   std::string split_file;              // --split-l0 prefix / --run-l0, --run-l1 master file
   int njobs = 0, job_num = 0;
@@ -293,8 +293,9 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--nauto") p.nchrom = atoi(need(i).c_str()) + 1;
     else if (a == "--device") p.device = atoi(need(i).c_str());
     else if (a == "--lowmem-prefix") { need(i); p.lowmem = true; }
-    else if (a == "--qt") p.bt = false;
-    else if (a == "--bt") p.bt = true;
+    else if (a == "--qt") { p.bt = false; p.ct = false; }
+    else if (a == "--bt") { p.bt = true; p.ct = false; }
+    else if (a == "--ct") { p.ct = true; p.bt = false; }
     else if (a == "--loocv") p.loocv = true;
     else if (a == "--strict") p.strict = true;
     else if (a == "--ref-first") p.ref_first = true;
@@ -305,7 +306,7 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--lowmem") p.lowmem = true;
     else if (a == "--1" || a == "--cc12") p.cc12 = true;
     else if (a == "--minCaseCount") p.min_case_count = atoi(need(i).c_str());
-    else if (a == "--niter") p.niter_max = atoi(need(i).c_str());
+    else if (a == "--niter") { p.niter_max = atoi(need(i).c_str()); p.niter_max_ridge = p.niter_max; }  // Regenie.cpp:483
     else if (a == "--gz") p.gz = true;
     else if (a == "--pgen") p.pgen = need(i);
     else if (a == "--bgen") usage_error(a + " input is not served by the GPU path yet; use --bed or --pgen");
@@ -448,6 +449,66 @@ bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t
     dev_old = dev_new;
   }
   if ((diff_dev == 0 || diff_dev >= NUMTOL) && niter > prm.niter_max) return false;
+  return true;
+}
+
+// fit_null_poisson + fit_poisson (Step1_Models.cpp:225-345) for one phenotype, zero offset; eta_out = X beta on success
+bool fit_poisson(const double* y, const double* X, const uint8_t* mask, int64_t N, int C, const Params& prm, std::vector<double>& eta) {
+  std::vector<double> beta(C, 0.0), betanew(C, 0.0), pv(N);
+  auto dev = [&](const std::vector<double>& pp) {
+    double t = 0.0;
+    for (int64_t i = 0; i < N; ++i) if (mask[i]) t -= y[i] * std::log(pp[i]) - pp[i];
+    return 2.0 * t;
+  };
+  auto any_zero = [&]() { for (int64_t i = 0; i < N; ++i) if (mask[i] && pv[i] == 0.0) return true; return false; };
+  eta.assign(N, 0.0);
+  double esum = 0.0;
+  for (int64_t i = 0; i < N; ++i) {  // starting values: p = y + 0.1, eta = log p on the analysed samples, intercept = mean(eta)
+    pv[i] = y[i] + 1e-1;
+    eta[i] = mask[i] ? std::log(pv[i]) : 0.0;
+    esum += eta[i];
+  }
+  beta[0] = esum / (double)N;
+  double dev_old = dev(pv), dev_new = dev_old;
+  int niter = 0;
+  bool dev_conv = false;
+  while (true) {
+    if (++niter > prm.niter_max) break;
+    if (any_zero()) return false;
+    std::vector<double> A((size_t)C * C, 0.0), b(C, 0.0);
+    for (int64_t i = 0; i < N; ++i) {
+      if (!mask[i]) continue;
+      const double z = eta[i] + (y[i] - pv[i]) / pv[i];
+      for (int a = 0; a < C; ++a) {
+        const double xa = X[(size_t)a * N + i] * pv[i];
+        b[a] += xa * z;
+        for (int c = 0; c < C; ++c) A[(size_t)a * C + c] += xa * X[(size_t)c * N + i];
+      }
+    }
+    if (!solve_dense(A, b, C, betanew)) return false;
+    for (int ls = 0; ls < prm.niter_max_line_search; ++ls) {
+      for (int64_t i = 0; i < N; ++i) {
+        double e = 0.0;
+        for (int a = 0; a < C; ++a) e += X[(size_t)a * N + i] * betanew[a];
+        eta[i] = e;
+        pv[i] = std::exp(e);
+      }
+      dev_new = dev(pv);
+      if (!any_zero()) break;
+      for (int a = 0; a < C; ++a) betanew[a] = (beta[a] + betanew[a]) / 2;
+    }
+    double smax = 0.0;
+    for (int a = 0; a < C; ++a) {
+      double sc = 0.0;
+      for (int64_t i = 0; i < N; ++i) if (mask[i]) sc += X[(size_t)a * N + i] * (y[i] - pv[i]);
+      smax = std::max(smax, std::fabs(sc));
+    }
+    dev_conv = std::fabs(dev_new - dev_old) / (0.1 + std::fabs(dev_new)) < 1e-8;  // params->tol
+    if (smax < 1e-8) break;
+    beta = betanew;
+    dev_old = dev_new;
+  }
+  if (!dev_conv && niter > prm.niter_max) return false;
   return true;
 }
 
@@ -641,7 +702,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     else sout << "   -keeping and mean-imputing missing observations (done for each trait)\n";
     r.Y.assign((size_t)N * r.P, 0.0);
     r.mask.assign((size_t)N * r.P, 1);
-    if (p.bt) r.Yraw.assign((size_t)N * r.P, 0.0);
+    if (p.bt || p.ct) r.Yraw.assign((size_t)N * r.P, 0.0);
     while (std::getline(f, line)) {
       auto t = split_ws(line);
       if (t.empty()) continue;
@@ -659,6 +720,12 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
           r.Yraw[(size_t)q * N + i] = v;
           if (v != 0 && v != 1) {
             if (v != MISSING) throw std::runtime_error("a phenotype value is not 0/1/NA for individual: FID=" + t[0] + " IID=" + t[1] + " Y=" + t[keep_cols[q]]);
+            r.mask[(size_t)q * N + i] = 0;
+          }
+        } else if (p.ct) {  // Pheno.cpp:298, :313-320: counts must be non-negative
+          r.Yraw[(size_t)q * N + i] = v;
+          if (v < 0) {
+            if (v != MISSING) throw std::runtime_error("a phenotype value is <0 for individual: FID=" + t[0] + " IID=" + t[1] + " Y=" + t[keep_cols[q]]);
             r.mask[(size_t)q * N + i] = 0;
           }
         }
@@ -765,13 +832,13 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     for (int64_t i = 0; i < N; ++i) {
       r.mask[(size_t)q * N + i] &= r.ain[i];
       r.Y[(size_t)q * N + i] *= r.ain[i];
-      if (p.bt) r.Yraw[(size_t)q * N + i] *= r.ain[i];
+      if (p.bt || p.ct) r.Yraw[(size_t)q * N + i] *= r.ain[i];
       r.neff[q] += r.mask[(size_t)q * N + i];
     }
   for (int c = 0; c < ncols; ++c)
     for (int64_t i = 0; i < N; ++i) Xraw[(size_t)c * N + i] *= (r.ain[i] && in_cov[i]) ? 1.0 : 0.0;
   // pheno_impute_miss (QT): missing -> mean over analysed non-missing, then mask
-  for (int q = 0; q < r.P && p.bt; ++q) {  // BT: mean over the unmasked entries (Pheno.cpp:1921-1930)
+  for (int q = 0; q < r.P && (p.bt || p.ct); ++q) {  // non-QT: mean over the unmasked entries (Pheno.cpp:1921-1930)
     double total = 0.0, ns = 0.0;
     for (int64_t i = 0; i < N; ++i) if (r.mask[(size_t)q * N + i]) { total += r.Y[(size_t)q * N + i]; ns += 1.0; }
     for (int64_t i = 0; i < N; ++i) {
@@ -780,7 +847,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
       v *= r.mask[(size_t)q * N + i];
     }
   }
-  for (int q = 0; q < r.P && !p.bt; ++q) {
+  for (int q = 0; q < r.P && !(p.bt || p.ct); ++q) {
     double total = 0.0, ns = 0.0;
     std::set<double> distinct;
     for (int64_t i = 0; i < N; ++i) {
@@ -826,6 +893,19 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
       bool ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, true, eta);
       if (!ok) ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, false, eta);
       if (!ok) { r.pheno_pass[q] = 0; continue; }
+      for (int64_t i = 0; i < N; ++i) r.offset[(size_t)q * N + i] = eta[i];
+    }
+    sout << "done\n";
+  } else if (p.ct) {
+    sout << "   -fitting null poisson regression...";
+    r.offset.assign((size_t)N * r.P, 0.0);
+    for (int q = 0; q < r.P; ++q) {
+      std::vector<double> eta;
+      if (!fit_poisson(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, eta)) {
+        r.pheno_pass[q] = 0;
+        sout << "\n     WARNING: poisson regression did not converge for phenotype '" << r.pheno_names[q] << "'.";
+        continue;
+      }
       for (int64_t i = 0; i < N; ++i) r.offset[(size_t)q * N + i] = eta[i];
     }
     sout << "done\n";
@@ -1022,6 +1102,25 @@ int run(int argc, char** argv) {
     }
   }
 
+  if (!use_loocv && (p.bt || p.ct)) {  // Data.cpp:436-466: every fold needs both classes / at least one count
+    int64_t start = 0;
+    for (int f = 0; f < p.cv_folds; ++f) {
+      for (int q = 0; q < r.P; ++q) {
+        if (!r.pheno_pass[q]) continue;
+        double sum = 0.0, n = 0.0;
+        for (int64_t i = start; i < start + cv_sizes[f]; ++i)
+          if (r.mask[(size_t)q * N + i]) { sum += r.Yraw[(size_t)q * N + i]; n += 1.0; }
+        if (p.bt && (sum / n) * (1 - sum / n) < NUMTOL)
+          throw std::runtime_error("one of the folds has only cases/controls for phenotype '" + r.pheno_names[q] +
+                                   "'. Either use smaller #folds (option --cv) or use LOOCV (option --loocv).");
+        if (p.ct && sum == 0)
+          throw std::runtime_error("one of the folds has only zero counts for phenotype '" + r.pheno_names[q] +
+                                   "'. Either use smaller #folds (option --cv) or use LOOCV (option --loocv).");
+      }
+      start += cv_sizes[f];
+    }
+  }
+
   rg_ctx* ctx = nullptr;
   if (rg_create(&ctx, p.device, nullptr) != 0 || !ctx) throw std::runtime_error("no MI355X / HIP device available (rg_create failed)");
   rg_problem pr;
@@ -1115,6 +1214,14 @@ int run(int argc, char** argv) {
   for (int q = 0; q < P; ++q)
     for (int j = 0; j < R1; ++j)   // check_l0, Step1_Models.cpp:2115-2117
       tau[(size_t)q * R1 + j] = (double)L * (1 - h1[j]) / h1[j] * (p.bt ? 3.0 / (M_PI * M_PI) : 1.0);
+  std::vector<double> ct_rate(P, 0.0);
+  if (p.ct)  // Step1_Models.cpp:2101-2104: tau_j = L / log(1 + h_j / (rate (1 - h_j))); rate sums the raw column as it is
+    for (int q = 0; q < P; ++q) {
+      double sum = 0.0;
+      for (int64_t i = 0; i < N; ++i) sum += r.Yraw[(size_t)q * N + i];
+      ct_rate[q] = sum / r.neff[q];
+      for (int j = 0; j < R1; ++j) tau[(size_t)q * R1 + j] = (double)L / std::log(1.0 + h1[j] / (ct_rate[q] * (1 - h1[j])));
+    }
   std::vector<int32_t> cols_per_chr;
   std::vector<int> chroms;
   for (int c : r.chr_read) {
@@ -1123,12 +1230,16 @@ int run(int argc, char** argv) {
     if (nb > 0) { cols_per_chr.push_back(nb * R0); chroms.push_back(c); }
   }
   const int nchr = (int)chroms.size();
-  const int NCS = p.bt ? 6 : 5;
+  const int NCS = (p.bt || p.ct) ? 6 : 5;
   std::vector<double> cumsum((size_t)P * NCS * R1), pred((size_t)P * nchr * N);
   std::vector<int32_t> best(P), converged(P, 1);
   auto tl0 = std::chrono::steady_clock::now();
-  if (p.bt) {
-    check(ctx, rg_l1_bt(ctx, R1, tau.data(), r.Yraw.data(), r.offset.data(), nullptr, nchr, cols_per_chr.data(),
+  if (p.bt || p.ct) {
+    rg_bt_options bo;  // Regenie.hpp:287-290 defaults; family picks ridge_logistic_level_1* or ridge_poisson_level_1*
+    bo.niter_max_ridge = p.niter_max_ridge; bo.niter_max_line_search_ridge = 100; bo.niter_max_line_search = p.niter_max_line_search;
+    bo.family = p.ct ? 1 : 0; bo.l1_ridge_tol = 1e-4; bo.tol = 1e-8;
+    if (p.ct) sout << " Level 1 ridge with poisson regression...\n";
+    check(ctx, rg_l1_bt(ctx, R1, tau.data(), r.Yraw.data(), r.offset.data(), &bo, nchr, cols_per_chr.data(),
                         cumsum.data(), converged.data(), best.data(), pred.data()));
     for (int q = 0; q < P; ++q) if (!r.pheno_pass[q]) converged[q] = 0;
   } else if (use_loocv)
@@ -1160,9 +1271,14 @@ int run(int argc, char** argv) {
       double num = cs[4 * R1 + j] - cs[0 * R1 + j] * cs[1 * R1 + j] / neff;
       const double rsq = num * num / ((cs[2 * R1 + j] - cs[0 * R1 + j] * cs[0 * R1 + j] / neff) * (cs[3 * R1 + j] - cs[1 * R1 + j] * cs[1 * R1 + j] / neff));
       const double sse = cs[2 * R1 + j] + cs[3 * R1 + j] - 2 * cs[4 * R1 + j];
-      sout << "  " << std::right << std::setw(5) << (double)L / (L + (p.bt ? M_PI * M_PI / 3.0 : 1.0) * tau[(size_t)q * R1 + j])
-           << " : Rsq = " << rsq << ", MSE = " << sse / neff;
-      if (p.bt) sout << ", -logLik/N = " << cs[5 * R1 + j] / neff;
+      double label = (double)L / (L + (p.bt ? M_PI * M_PI / 3.0 : 1.0) * tau[(size_t)q * R1 + j]);
+      if (p.ct) {  // Data.cpp:1039-1054
+        const double zv = std::exp((double)L / tau[(size_t)q * R1 + j]) - 1;
+        label = ct_rate[q] * zv / (1 + ct_rate[q] * zv);
+      }
+      sout << "  " << std::right << std::setw(5) << label << " : Rsq = " << rsq;
+      if (!p.ct) sout << ", MSE = " << sse / neff;
+      if (p.bt || p.ct) sout << ", -logLik/N = " << cs[5 * R1 + j] / neff;
       if (j == best[q]) sout << "<- min value";
       sout << "\n";
     }

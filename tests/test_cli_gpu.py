@@ -266,3 +266,39 @@ def test_cli_gz_mode_of_the_reference_test(example_dir, tmp_path):
                      "--out", str(tmp_path / "f")], str(tmp_path))
     assert r.returncode == 0, r.stdout + r.stderr
     assert open(str(tmp_path / "f_1.loco"), "rb").read() == open(str(tmp_path / "a_1.loco"), "rb").read()
+
+
+@pytest.mark.parametrize("loocv", [False, True])
+def test_cli_ct_count_traits(example_dir, tmp_path, loocv):
+    """`--ct`: count phenotypes, null Poisson offsets, Poisson ridge level 1 (Step1_Models.cpp:225-345, :1429-1758) -- the
+    driver's files against the oracle's."""
+    from tests.test_l1_models_gpu import _count_pheno_file
+    E = example_dir
+    ph = str(tmp_path / "ct.txt")
+    _count_pheno_file(E, ph)
+    args = ["--step", "1", "--bed", os.path.join(E, "example"), "--phenoFile", ph, "--covarFile", os.path.join(E, "covariates.txt"),
+            "--bsize", "100", "--ct", "--out", str(tmp_path / "c")] + (["--loocv"] if loocv else [])
+    r = _run(args, str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    opt = orc.Step1Options(bed=os.path.join(E, "example"), pheno_file=ph, covar_file=os.path.join(E, "covariates.txt"), bsize=100,
+                           ct=True, loocv=loocv, out=str(tmp_path / "o"))
+    ref = orc.run_step1(opt, write_files=True)
+    assert "fitting null poisson regression" in r.stdout and "Level 1 ridge with poisson regression" in r.stdout
+    for k in (1, 2):
+        h1, ids1, v1, _ = _parse_loco(str(tmp_path / ("c_%d.loco" % k)))
+        h2, ids2, v2, _ = _parse_loco(str(tmp_path / ("o_%d.loco" % k)))
+        assert h1 == h2 and ids1 == ids2
+        assert np.allclose(v1, v2, rtol=2e-5, atol=1e-7, equal_nan=True)
+    # the per-tau table (label column inverts tau back to the h grid; no MSE column for counts)
+    tab = [ln for ln in r.stdout.split("\n") if " : Rsq = " in ln]
+    want = [ln for ln in ref.log if " : Rsq = " in ln]
+    assert len(tab) == 10 and all("MSE" not in ln for ln in tab)
+    for a, b in zip(tab, want):
+        assert a.split(":")[0].strip() == b.split(":")[0].strip() and ("min value" in a) == ("min value" in b)
+    # negative counts are refused with the reference's message (Pheno.cpp:317-318)
+    bad = open(ph).read().replace("\n", "\n", 1).split("\n")
+    t = bad[3].split()
+    bad[3] = "%s %s -2 1" % (t[0], t[1])
+    open(str(tmp_path / "bad.txt"), "w").write("\n".join(bad))
+    r = _run(args[:5] + [str(tmp_path / "bad.txt")] + args[6:], str(tmp_path))
+    assert r.returncode != 0 and "a phenotype value is <0 for individual: FID=%s IID=%s Y=-2" % (t[0], t[1]) in r.stdout
