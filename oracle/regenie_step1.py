@@ -59,6 +59,9 @@ class Step1Options:
     exclude: Sequence[str] = ()
     pheno_cols: Sequence[str] = ()   # --phenoCol / --phenoColList
     covar_cols: Sequence[str] = ()
+    cat_covar: Sequence[str] = ()    # --catCovarList: categorical covariates -> K-1 dummy columns
+    max_cat_levels: int = 10         # --maxCatLevels
+    apply_rint: bool = False         # --apply-rint (ignored with --bt, Regenie.cpp:432)
     strict: bool = False
     ref_first: bool = False
     nchrom: int = 23                 # --nauto + 1
@@ -376,10 +379,26 @@ def read_pheno_and_cov(opt: Step1Options, fam_ids: List[str]) -> Prepared:
         hdr = lines[0].rstrip("\r").split()
         if hdr[0] != "FID" or hdr[1] != "IID":
             raise ValueError("header of covariate file must start with: FID IID.")
-        kc = [True] * (len(hdr) - 2)
-        if opt.covar_cols:
-            kc = [h in set(opt.covar_cols) for h in hdr[2:]]
+        # cov_colKeep_names (Regenie.cpp:591-619): name -> quantitative?; --catCovarList names are kept as well
+        colmap = {h: True for h in opt.covar_cols}
+        colmap.update({h: False for h in opt.cat_covar})
+        kc = []
+        for h in hdr[2:]:                                   # Pheno.cpp:599-617
+            if not opt.covar_cols and h not in colmap:
+                colmap[h] = True
+                keep = True
+            else:
+                keep = h in colmap
+            if keep and h in names:                         # a covariate that is an analysed phenotype is ignored
+                keep = False
+                del colmap[h]
+            kc.append(keep)
         nc = sum(kc)
+        if len(colmap) != nc:
+            raise ValueError("not all covariates specified are found in the covariate file.")
+        is_cat = [not colmap[h] for h, k in zip(hdr[2:], kc) if k]
+        cat_names = [h for h, k in zip(hdr[2:], kc) if k]
+        levels = [dict() for _ in is_cat]                   # convertNumLevel (Regenie.cpp:1720-1735): order of appearance
         X = np.zeros((N, 1 + nc))
         X[:, 0] = 1.0
         for line in lines[1:]:
@@ -397,7 +416,14 @@ def read_pheno_and_cov(opt: Step1Options, fam_ids: List[str]) -> Prepared:
             for j, kk in enumerate(kc):
                 if not kk:
                     continue
-                v = convert_double(t[2 + j])
+                if is_cat[ic]:
+                    tok = t[2 + j]
+                    if tok in ("NA", "nan", "inf"):
+                        v = MISSING
+                    else:
+                        v = float(levels[ic].setdefault(tok, len(levels[ic])))
+                else:
+                    v = convert_double(t[2 + j])
                 X[i, 1 + ic] = v
                 if v == MISSING:
                     in_cov[i] = False
@@ -406,6 +432,19 @@ def read_pheno_and_cov(opt: Step1Options, fam_ids: List[str]) -> Prepared:
         if not in_cov.any():
             raise ValueError("none of the individuals have covariate data (check sample IDs across files)")
         X *= in_cov[:, None]
+        if any(is_cat):                                     # dummies (Pheno.cpp:716-783, check_categories :985-1011, get_dummies)
+            cols = [X[:, 0]]
+            for ic in range(nc):
+                col = X[:, 1 + ic]
+                if not is_cat[ic]:
+                    cols.append(col)
+                    continue
+                if len(levels[ic]) > opt.max_cat_levels:
+                    raise ValueError("too many categories for covariate: %s (=%d). Either use '--maxCatLevels' or combine categories."
+                                     % (cat_names[ic], len(levels[ic])))
+                for lvl in range(1, int(col.max()) + 1):    # level 0 goes to the intercept
+                    cols.append((col == lvl).astype(np.float64))
+            X = np.stack(cols, axis=1)
 
     # ---- Pheno.cpp:101 + setMasks :810-841
     ain = in_pheno & in_cov
@@ -421,6 +460,24 @@ def read_pheno_and_cov(opt: Step1Options, fam_ids: List[str]) -> Prepared:
     Neff = mask.sum(axis=0).astype(np.float64)
     if X.shape[1] >= N:
         raise ValueError("Number of covariates is greater than sample size!")
+
+    # ---- apply_rint / rint_pheno (Pheno.cpp:111-115, :1937-2010): ranks with ties averaged -> normal quantiles
+    if opt.apply_rint and not opt.bt:
+        from scipy.special import ndtri
+        for j in range(P):
+            sel = np.flatnonzero((Y[:, j] != MISSING) & mask[:, j])
+            vals = Y[sel, j]
+            order = np.argsort(vals, kind="stable")
+            ranks = np.empty(sel.size)
+            sv = vals[order]
+            a = 0
+            while a < sel.size:
+                b = a + 1
+                while b < sel.size and sv[b] == sv[a]:
+                    b += 1
+                ranks[order[a:b]] = (a + 1) + (b - a - 1) / 2.0
+                a = b
+            Y[sel, j] = ndtri((ranks - 3 / 8.0) / (sel.size - 2 * (3 / 8.0) + 1))
 
     # ---- pheno_impute_miss (Pheno.cpp:1903-1935)
     for j in range(P):

@@ -46,7 +46,9 @@ const double MISSING = -999.0;  // Regenie.hpp:215
 struct Params {
   int step = 0;
   std::string bed, pgen, pheno_file, covar_file, out = "regenie_out";
-  std::vector<std::string> keep, remove, extract, exclude, pheno_cols, covar_cols;
+  std::vector<std::string> keep, remove, extract, exclude, pheno_cols, covar_cols, cat_covar;
+  int max_cat_levels = 10;
+  bool rint = false;
   int bsize = 0, cv_folds = 5, n_ridge_l0 = 5, n_ridge_l1 = 5, nchrom = 23, threads = 0;
   bool bt = false, ct = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
        print_prs = false, force_step1 = false, lowmem = false, force_qt = false, cc12 = false, gz = false;
@@ -278,6 +280,9 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--covarFile" || a == "--c") p.covar_file = need(i);
     else if (a == "--phenoCol" || a == "--phenoColList") list(p.pheno_cols, need(i));
     else if (a == "--covarCol" || a == "--covarColList") list(p.covar_cols, need(i));
+    else if (a == "--catCovarList") list(p.cat_covar, need(i));
+    else if (a == "--maxCatLevels") p.max_cat_levels = atoi(need(i).c_str());
+    else if (a == "--apply-rint") p.rint = true;
     else if (a == "--keep") list(p.keep, need(i));
     else if (a == "--remove") list(p.remove, need(i));
     else if (a == "--extract") list(p.extract, need(i));
@@ -323,6 +328,7 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--keep-l0") p.keep_l0 = true;
     else usage_error("unrecognised option '" + a + "'");
   }
+  if (p.bt) p.rint = false;  // Regenie.cpp:432
   if (p.step != 1) usage_error("specify which mode regenie should be running using option --step (only --step 1 is served).");
   if (p.bed.empty() == p.pgen.empty()) usage_error("must use either --bed,--bgen or --pgen.");  // Regenie.cpp:419-420
   if (p.pheno_file.empty()) usage_error("option '--phenoFile' is required.");
@@ -450,6 +456,39 @@ bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t
   }
   if ((diff_dev == 0 || diff_dev >= NUMTOL) && niter > prm.niter_max) return false;
   return true;
+}
+
+// Standard normal quantile (what boost::math::quantile(normal(0,1), p) returns in rint_pheno, Pheno.cpp:2002-2008):
+// Wichura's algorithm AS 241 (PPND16), relative accuracy about 1e-16.
+double norm_quantile(double p) {
+  const double q = p - 0.5;
+  if (std::fabs(q) <= 0.425) {
+    const double r = 0.180625 - q * q;
+    const double num = (((((((2.5090809287301226727e3 * r + 3.3430575583588128105e4) * r + 6.7265770927008700853e4) * r + 4.5921953931549871457e4) * r +
+                           1.3731693765509461125e4) * r + 1.9715909503065514427e3) * r + 1.3314166789178437745e2) * r + 3.3871328727963666080e0);
+    const double den = (((((((5.2264952788528545610e3 * r + 2.8729085735721942674e4) * r + 3.9307895800092710610e4) * r + 2.1213794301586595867e4) * r +
+                           5.3941960214247511077e3) * r + 6.8718700749205790830e2) * r + 4.2313330701600911252e1) * r + 1.0);
+    return q * num / den;
+  }
+  double r = q < 0 ? p : 1.0 - p;
+  r = std::sqrt(-std::log(r));
+  double v;
+  if (r <= 5.0) {
+    r -= 1.6;
+    const double num = (((((((7.74545014278341407640e-4 * r + 2.27238449892691845833e-2) * r + 2.41780725177450611770e-1) * r + 1.27045825245236838258e0) * r +
+                           3.64784832476320460504e0) * r + 5.76949722146069140550e0) * r + 4.63033784615654529590e0) * r + 1.42343711074968357734e0);
+    const double den = (((((((1.05075007164441684324e-9 * r + 5.47593808499534494600e-4) * r + 1.51986665636164571966e-2) * r + 1.48103976427480074590e-1) * r +
+                           6.89767334985100004550e-1) * r + 1.67638483018380384940e0) * r + 2.05319162663775882187e0) * r + 1.0);
+    v = num / den;
+  } else {
+    r -= 5.0;
+    const double num = (((((((2.01033439929228813265e-7 * r + 2.71155556874348757815e-5) * r + 1.24266094738807843860e-3) * r + 2.65321895265761230930e-2) * r +
+                           2.96560571828504891230e-1) * r + 1.78482653991729133580e0) * r + 5.46378491116411436990e0) * r + 6.65790464350110377720e0);
+    const double den = (((((((2.04426310338993978564e-15 * r + 1.42151175831644588870e-7) * r + 1.84631831751005468180e-5) * r + 7.86869131145613259100e-4) * r +
+                           1.48753612908506148525e-2) * r + 1.36929880922735805310e-1) * r + 5.99832206555887937690e-1) * r + 1.0);
+    v = num / den;
+  }
+  return q < 0 ? -v : v;
 }
 
 // fit_null_poisson + fit_poisson (Step1_Models.cpp:225-345) for one phenotype, zero offset; eta_out = X beta on success
@@ -785,10 +824,25 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     std::getline(f, line);
     auto hdr = split_ws(line);
     if (hdr.size() < 2 || hdr[0] != "FID" || hdr[1] != "IID") throw std::runtime_error("header of covariate file must start with: FID IID.");
-    std::set<std::string> want(p.covar_cols.begin(), p.covar_cols.end());
+    // cov_colKeep_names (Regenie.cpp:591-619, Pheno.cpp:599-632): name -> quantitative?  --catCovarList names are kept too
+    std::map<std::string, bool> colmap;
+    for (auto& h : p.covar_cols) colmap[h] = true;
+    for (auto& h : p.cat_covar) colmap[h] = false;
     std::vector<int> kc;
-    for (size_t j = 2; j < hdr.size(); ++j)
-      if (want.empty() || want.count(hdr[j])) kc.push_back((int)j);
+    std::vector<uint8_t> is_cat;
+    std::vector<std::string> cov_names;
+    for (size_t j = 2; j < hdr.size(); ++j) {
+      bool keep;
+      if (p.covar_cols.empty() && !colmap.count(hdr[j])) { colmap[hdr[j]] = true; keep = true; }
+      else keep = colmap.count(hdr[j]) != 0;
+      if (keep && std::find(r.pheno_names.begin(), r.pheno_names.end(), hdr[j]) != r.pheno_names.end()) {
+        keep = false;  // a covariate that is one of the analysed phenotypes is ignored
+        colmap.erase(hdr[j]);
+      }
+      if (keep) { kc.push_back((int)j); is_cat.push_back(colmap[hdr[j]] ? 0 : 1); cov_names.push_back(hdr[j]); }
+    }
+    if (colmap.size() != kc.size()) throw std::runtime_error("not all covariates specified are found in the covariate file.");
+    std::vector<std::map<std::string, int>> levels(kc.size());  // convertNumLevel (Regenie.cpp:1720-1735): order of appearance
     ncols = 1 + (int)kc.size();
     sout << "n_cov = " << kc.size() << "\n";
     Xraw.assign((size_t)N * ncols, 0.0);
@@ -796,16 +850,48 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     while (std::getline(f, line)) {
       auto t = split_ws(line);
       if (t.empty()) continue;
+      if (t.size() != hdr.size()) throw std::runtime_error("incorrectly formatted covariate file.");
       auto it = idx.find(t[0] + "_" + t[1]);
       if (it == idx.end()) continue;
       const int64_t i = it->second;
       if (in_cov[i]) throw std::runtime_error("individual appears more than once in covariate file: FID=" + t[0] + " IID=" + t[1]);
       in_cov[i] = 1;
       for (size_t c = 0; c < kc.size(); ++c) {
-        const double v = convert_double(t[kc[c]]);
+        double v;
+        if (is_cat[c]) {
+          const std::string& tok = t[kc[c]];
+          if (tok == "NA" || tok == "nan" || tok == "inf") v = MISSING;
+          else {
+            auto lv = levels[c].find(tok);
+            if (lv == levels[c].end()) lv = levels[c].emplace(tok, (int)levels[c].size()).first;
+            v = lv->second;
+          }
+        } else v = convert_double(t[kc[c]]);
         Xraw[(size_t)(1 + c) * N + i] = v;
         if (v == MISSING) { in_cov[i] = 0; break; }
       }
+    }
+    if (std::find(is_cat.begin(), is_cat.end(), (uint8_t)1) != is_cat.end()) {
+      // dummy variables (Pheno.cpp:716-783, check_categories :985-1011, get_dummies): level 0 goes to the intercept
+      std::vector<double> full(Xraw.begin(), Xraw.begin() + N);
+      int nfull = 1;
+      for (size_t c = 0; c < kc.size(); ++c) {
+        double* col = Xraw.data() + (size_t)(1 + c) * N;
+        for (int64_t i = 0; i < N; ++i) col[i] *= in_cov[i];
+        if (!is_cat[c]) { full.insert(full.end(), col, col + N); ++nfull; continue; }
+        const int nlev = (int)levels[c].size();
+        if (nlev > p.max_cat_levels)
+          throw std::runtime_error("too many categories for covariate: " + cov_names[c] + " (=" + std::to_string(nlev) + "). Either use '--maxCatLevels' or combine categories.");
+        if (nlev == 1) sout << "WARNING: covariate ' " << cov_names[c] << "' only has a single category so it will be ignored\n";
+        int top = 0;
+        for (int64_t i = 0; i < N; ++i) top = std::max(top, (int)col[i]);
+        for (int lvl = 1; lvl <= top; ++lvl) {
+          for (int64_t i = 0; i < N; ++i) full.push_back(col[i] == lvl ? 1.0 : 0.0);
+          ++nfull;
+        }
+      }
+      Xraw.swap(full);
+      ncols = nfull;
     }
     int64_t nc = 0;
     for (int64_t i = 0; i < N; ++i) nc += in_cov[i];
@@ -837,6 +923,24 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     }
   for (int c = 0; c < ncols; ++c)
     for (int64_t i = 0; i < N; ++i) Xraw[(size_t)c * N + i] *= (r.ain[i] && in_cov[i]) ? 1.0 : 0.0;
+  if (p.rint) {  // apply_rint / rint_pheno (Pheno.cpp:111-115, :1937-2010): ranks with ties averaged -> normal quantiles
+    sout << "   -applying RINT to all phenotypes\n";
+    for (int q = 0; q < r.P; ++q) {
+      std::vector<std::pair<double, int64_t>> yv;
+      for (int64_t i = 0; i < N; ++i)
+        if (r.Y[(size_t)q * N + i] != MISSING && r.mask[(size_t)q * N + i]) yv.emplace_back(r.Y[(size_t)q * N + i], i);
+      std::stable_sort(yv.begin(), yv.end(), [](const std::pair<double, int64_t>& a, const std::pair<double, int64_t>& b) { return a.first < b.first; });
+      const size_t nv = yv.size();
+      for (size_t a = 0; a < nv;) {
+        size_t b = a + 1;
+        while (b < nv && yv[b].first == yv[a].first) ++b;
+        const double rank = (double)(a + 1) + (double)(b - a - 1) / 2.0;
+        for (size_t k = a; k < b; ++k)
+          r.Y[(size_t)q * N + yv[k].second] = norm_quantile((rank - 3.0 / 8.0) / ((double)nv - 2.0 * (3.0 / 8.0) + 1.0));
+        a = b;
+      }
+    }
+  }
   // pheno_impute_miss (QT): missing -> mean over analysed non-missing, then mask
   for (int q = 0; q < r.P && (p.bt || p.ct); ++q) {  // non-QT: mean over the unmasked entries (Pheno.cpp:1921-1930)
     double total = 0.0, ns = 0.0;
