@@ -196,6 +196,10 @@ class PgenOracle:
 
     def codes(self, vidx: int) -> np.ndarray:
         """ReadGenovecSubsetUnsafe (:2837-2900) without subsetting: pgen 2-bit codes of one variant."""
+        return self._codes_pos(vidx)[0]
+
+    def _codes_pos(self, vidx: int):
+        """(codes, offset of the first byte after the main genotype track inside the record)."""
         if not (0 <= vidx < self.m):
             raise IndexError("variant index out of range")
         vt = int(self.vrtypes[vidx]) & 7
@@ -207,11 +211,12 @@ class PgenOracle:
                 self._ld_geno = self.codes(base)
                 self._ld_vidx = base
             g = self._ld_geno.copy()
-            ids, cd, _ = self._difflist(rec, 0)
+            ids, cd, pos = self._difflist(rec, 0)
             g[ids] = cd
             if vt == 3:  # GenovecInvertUnsafe: 0<->2
                 g = np.where(g == 0, 2, np.where(g == 2, 0, g)).astype(np.uint8)
-            return g
+            return g, pos
+        pos = 0
         if not (vt & 4):
             if vt & 3:  # ParseOnebitUnsafe (:2597-2680)
                 nb = (n + 7) // 8
@@ -221,19 +226,89 @@ class PgenOracle:
                 lo, dlt = c2 >> 2, c2 & 3
                 bits = np.unpackbits(np.frombuffer(rec, dtype=np.uint8, count=nb, offset=1), bitorder="little")[:n]
                 g = (lo + dlt * bits).astype(np.uint8)
-                ids, cd, _ = self._difflist(rec, 1 + nb)
+                ids, cd, pos = self._difflist(rec, 1 + nb)
                 g[ids] = cd
             else:
                 if len(rec) < self.bpr:
                     raise PgenError("malformed .pgen record (2-bit track runs past the record)")
                 g = _unpack2(rec[:self.bpr], n)
+                pos = self.bpr
         elif (vt & 3) == 1:  # all hom-REF, empty record (:2727-2729)
             g = np.zeros(n, dtype=np.uint8)
         else:
             g = np.full(n, vt & 3, dtype=np.uint8)
-            ids, cd, _ = self._difflist(rec, 0)
+            ids, cd, pos = self._difflist(rec, 0)
             g[ids] = cd
-        return g
+        return g, pos
+
+    def dosages(self, vidx: int) -> np.ndarray:
+        """What PgenReader::Read(.., allele_idx=1) returns (pgenlibr.cpp:323-349 -> PgrGet1D, pgenlib_read.cc:7459-7497,
+        ParseDosage16 :7185-7330, Dosage16ToDoubles): ALT dosage = value / 16384 where the variant stores one for the
+        sample, the hardcall (0/1/2, -3 missing) elsewhere.  Biallelic files only."""
+        g, pos = self._codes_pos(vidx)
+        out = HARDCALL[g].copy()
+        vt = int(self.vrtypes[vidx])
+        if not (vt & 0x60):
+            return out
+        if vt & 0x08:
+            raise PgenError("multiallelic variant")
+        rec = self.data[self.fpos[vidx]:self.fpos[vidx + 1]]
+        n = self.n
+        if vt & 0x10:  # SkipAux2 (:6819-6840): hardcall-phase track, sized by the number of heterozygous calls
+            het = int((g == 1).sum())
+            first = 1 + het // 8
+            if het == 0 or pos + first > len(rec):       # ParseAux2Subset (:6743-6760): no het, no phase track
+                raise PgenError("malformed .pgen record (phase track)")
+            if rec[pos] & 1:
+                present = int(np.unpackbits(np.frombuffer(rec, np.uint8, first, pos)).sum()) - 1
+                if present == 0:
+                    raise PgenError("malformed .pgen record (phase track without a phased call)")
+                first += (present + 7) // 8
+            pos += first
+        kind = vt & 0x60
+        if kind == 0x20:      # list of sample ids (a difflist without replacement codes), then one value per entry
+            ids, pos = self._deltalist(rec, pos)
+        elif kind == 0x40:    # one value per sample; 65535 = none
+            ids = np.arange(n)
+        else:                 # one bit per sample, then one value per set bit
+            nb = (n + 7) // 8
+            if pos + nb > len(rec):
+                raise PgenError("malformed .pgen record (dosage bit array runs past the record)")
+            ids = np.flatnonzero(np.unpackbits(np.frombuffer(rec, np.uint8, nb, pos), bitorder="little")[:n])
+            pos += nb
+        if pos + 2 * ids.size > len(rec):
+            raise PgenError("malformed .pgen record (dosage values run past the record)")
+        vals = np.frombuffer(rec, dtype="<u2", count=ids.size, offset=pos)
+        keep = vals != 65535 if kind == 0x40 else np.ones(ids.size, bool)
+        out[ids[keep]] = vals[keep].astype(np.float64) / 16384.0
+        return out
+
+    def _deltalist(self, rec: bytes, pos: int):
+        """ParseAndSaveDeltalistAsBitarr: the difflist header and id stream without the 2-bit codes."""
+        n = self.n
+        ln, pos = _vint(rec, pos)
+        if ln == 0:
+            return np.zeros(0, np.int64), pos
+        if ln > n // MAX_DIFFLIST_DIV:
+            raise PgenError("malformed .pgen record (dosage list too long)")
+        groups = (ln + DIFFLIST_GROUP - 1) // DIFFLIST_GROUP
+        sib = _sample_id_bytes(n)
+        first = [int.from_bytes(rec[pos + g * sib: pos + (g + 1) * sib], "little") for g in range(groups)]
+        pos += groups * (sib + 1) - 1
+        ids = np.empty(ln, dtype=np.int64)
+        k = 0
+        for g in range(groups):
+            cur = first[g]
+            ids[k] = cur
+            k += 1
+            for _ in range(min(DIFFLIST_GROUP, ln - g * DIFFLIST_GROUP) - 1):
+                dlt, pos = _vint(rec, pos)
+                cur += dlt
+                ids[k] = cur
+                k += 1
+            if cur >= n:
+                raise PgenError("malformed .pgen record (dosage list sample index out of range)")
+        return ids, pos
 
     def hardcalls(self, vidx: int) -> np.ndarray:
         """What PgenReader::ReadHardcalls(.., allele_idx=1) returns (pgenlibr.cpp:296-321)."""
@@ -320,14 +395,14 @@ def encode_record(g: np.ndarray, vt: int, ldbase: np.ndarray | None) -> bytes:
 
 def write_pgen(path: str, geno: np.ndarray, vrtypes, *, reclen_bytes: int = 2, wide_vrtypes: bool = False,
                phase: bool = False, nonref: int = 0, dosage_variant: int | None = None, allele_counts=None,
-               mode: int = 0x10, seed: int = 0) -> None:
+               mode: int = 0x10, seed: int = 0, dosage: dict | None = None) -> None:
     """Writes a mode-0x10 .pgen.  geno: M x N pgen codes; vrtypes: M record types (0..7).
-    phase=True (needs wide_vrtypes) appends a hardcall-phase track to every variant that has hets, so a
+    phase=True / "explicit" (needs wide_vrtypes) appends a hardcall-phase track to every variant that has hets, so a
     hardcall reader must step over it; dosage_variant marks one variant as carrying a dosage track;
     allele_counts (M values) adds the per-variant allele-count bytes of a file that may be multiallelic."""
     rng = np.random.default_rng(seed)
     m, n = geno.shape
-    if (phase or dosage_variant is not None) and not wide_vrtypes:
+    if (phase or dosage_variant is not None or dosage) and not wide_vrtypes:
         raise ValueError("phase/dosage tracks need 8-bit vrtypes")
     recs, vts = [], []
     ldbase = None
@@ -341,12 +416,44 @@ def write_pgen(path: str, geno: np.ndarray, vrtypes, *, reclen_bytes: int = 2, w
         if phase:
             het = int((g == 1).sum())
             if het:
-                full |= 0x10  # first bit 0 = every het phased, then one phase bit per het
-                bits = np.concatenate([[0], rng.integers(0, 2, het)]).astype(np.uint8)
-                rec += np.packbits(bits, bitorder="little").tobytes()
+                full |= 0x10
+                if phase == "explicit" and j % 2:
+                    # first bit 1, then one "is this het phased" bit per het; the phase bits of the phased ones follow
+                    pp = rng.integers(0, 2, het).astype(np.uint8)
+                    pp[int(rng.integers(0, het))] = 1           # a track without any phased het is malformed (ParseAux2Subset)
+                    first = np.zeros((1 + het // 8) * 8, dtype=np.uint8)
+                    first[0] = 1
+                    first[1:1 + het] = pp
+                    rec += np.packbits(first, bitorder="little").tobytes()
+                    rec += np.packbits(rng.integers(0, 2, int(pp.sum())).astype(np.uint8), bitorder="little").tobytes()
+                else:  # first bit 0 = every het phased, then one phase bit per het
+                    bits = np.concatenate([[0], rng.integers(0, 2, het)]).astype(np.uint8)
+                    rec += np.packbits(bits, bitorder="little").tobytes()
         if dosage_variant == j:
             full |= 0x40  # unconditional dosage: a 16-bit value per sample
             rec += rng.integers(0, 32768, n).astype("<u2").tobytes()
+        if dosage is not None and j in dosage:
+            kind, ids, vals = dosage[j]          # kind 0x20 list / 0x40 all samples / 0x60 bit array; vals: uint16 per id
+            ids = np.asarray(ids, dtype=np.int64)
+            vals = np.asarray(vals, dtype=np.uint16)
+            full |= kind
+            if kind == 0x20:
+                dl = _enc_difflist(ids, np.zeros(ids.size, np.uint8), n)
+                # a deltalist is a difflist without the 2-bit codes: cut them out again
+                hdr_len = len(_enc_vint(ids.size))
+                if ids.size:
+                    groups = (ids.size + DIFFLIST_GROUP - 1) // DIFFLIST_GROUP
+                    cut = hdr_len + groups * (_sample_id_bytes(n) + 1) - 1
+                    dl = dl[:cut] + dl[cut + (ids.size + 3) // 4:]
+                rec += dl + vals.astype("<u2").tobytes()
+            elif kind == 0x40:
+                full_vals = np.full(n, 65535, dtype=np.uint16)
+                full_vals[ids] = vals
+                rec += full_vals.astype("<u2").tobytes()
+            else:
+                bits = np.zeros(n, dtype=np.uint8)
+                bits[ids] = 1
+                rec += np.packbits(bits, bitorder="little").tobytes() + vals.astype("<u2").tobytes()
         recs.append(rec)
         vts.append(full)
     nblk = (m + VBLOCK - 1) // VBLOCK

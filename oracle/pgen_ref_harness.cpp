@@ -39,3 +39,13 @@ int pgen_ref_hardcalls(const char* path, uint32_t n_samples, const int32_t* keep
   return 0;
 }
 }
+
+// PgenReader::Read(buf, n, thr, idx, 1) -- what regenie calls in dosage_mode (Geno.cpp:1795-1796): ALT dosages where the
+// file stores them, hardcalls elsewhere, -3 for missing.
+extern "C" int pgen_ref_dosages(const char* path, uint32_t n_samples, const int64_t* idx, int64_t n_idx, double* out) {
+  PgenReader pgr;
+  pgr.Load(path, n_samples, std::vector<int>(), 1);
+  for (int64_t j = 0; j < n_idx; ++j) pgr.Read(out + (size_t)j * n_samples, n_samples, 0, (int)idx[j], 1);
+  pgr.Close();
+  return 0;
+}

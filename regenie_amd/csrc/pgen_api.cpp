@@ -43,12 +43,7 @@ int rg_pgen_open(rg_pgen** out, const char* path) {
     h->rd.close();
     return fail(h, RG_PGEN_ERR_UNSUPPORTED, "only bi-allelic variants are accepted.");
   }
-  if (h->rd.dosage_present()) {  // regenie would read dosages (Geno.cpp:1101, :1795); not a 2-bit input
-    h->rd.close();
-    return fail(h, RG_PGEN_ERR_UNSUPPORTED,
-                std::string("pgen file has dosages; the GPU path reads hardcall (2-bit) genotypes only : ") + path);
-  }
-  h->ok = true;
+  h->ok = true;  // a file with dosage tracks opens: rg_pgen_info reports it and rg_pgen_read_bed_rows refuses it
   return RG_PGEN_OK;
 }
 
@@ -56,8 +51,10 @@ void rg_pgen_close(rg_pgen* h) { delete h; }
 
 const char* rg_pgen_last_error(const rg_pgen* h) { return h ? h->err.c_str() : "null pgen handle"; }
 
-int rg_pgen_info(const rg_pgen* h, int64_t* n_samples, int64_t* n_variants, int32_t* max_alleles, int32_t* phase_present) {
+int rg_pgen_info(const rg_pgen* h, int64_t* n_samples, int64_t* n_variants, int32_t* max_alleles, int32_t* phase_present,
+                 int32_t* dosage_present) {
   if (!h || !h->ok) return RG_PGEN_ERR_ARG;
+  if (dosage_present) *dosage_present = h->rd.dosage_present() ? 1 : 0;
   if (n_samples) *n_samples = h->rd.n_samples();
   if (n_variants) *n_variants = h->rd.n_variants();
   if (max_alleles) *max_alleles = h->rd.max_alleles();
@@ -77,6 +74,8 @@ int rg_pgen_read_bed_rows(rg_pgen* h, int64_t n, const int64_t* variant_idx, uin
   if (!h->ok) return fail(h, RG_PGEN_ERR_ARG, "pgen file is not open");
   if (n < 0 || (n > 0 && (!variant_idx || !rows)) || row_stride < h->rd.bytes_per_row())
     return fail(h, RG_PGEN_ERR_ARG, "rg_pgen_read_bed_rows: bad argument");
+  if (h->rd.dosage_present())  // regenie reads such a file as dosages (Geno.cpp:1101, :1795-1796): 2-bit rows would be other numbers
+    return fail(h, RG_PGEN_ERR_UNSUPPORTED, "pgen file has dosages; the GPU path reads hardcall (2-bit) genotypes only");
   for (int64_t k = 0; k < n; ++k)
     if (variant_idx[k] < 0 || variant_idx[k] >= (int64_t)h->rd.n_variants())
       return fail(h, RG_PGEN_ERR_ARG, "variant index " + std::to_string(variant_idx[k] + 1) + " is out of range (1.." +
@@ -106,6 +105,19 @@ int rg_pgen_read_bed_rows(rg_pgen* h, int64_t n, const int64_t* variant_idx, uin
   }
   for (const auto& e : errs)
     if (!e.empty()) return fail(h, RG_PGEN_ERR_FORMAT, e);
+  return RG_PGEN_OK;
+}
+
+int rg_pgen_read_dosages(rg_pgen* h, int64_t variant_idx, double* out) {
+  if (!h) return RG_PGEN_ERR_ARG;
+  if (!h->ok) return fail(h, RG_PGEN_ERR_ARG, "pgen file is not open");
+  if (!out || variant_idx < 0 || variant_idx >= (int64_t)h->rd.n_variants())
+    return fail(h, RG_PGEN_ERR_ARG, "rg_pgen_read_dosages: bad argument");
+  try {
+    h->rd.read_dosages((uint32_t)variant_idx, out);
+  } catch (const std::exception& e) {
+    return fail(h, RG_PGEN_ERR_FORMAT, e.what());
+  }
   return RG_PGEN_OK;
 }
 

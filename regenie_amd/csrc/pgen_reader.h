@@ -67,6 +67,7 @@ inline const Tables& tables() {
 struct Scratch {
   std::vector<uint8_t> rec, cur, ld;
   int64_t ld_vidx = -1;
+  size_t main_end = 0;  // offset in rec of the first byte after the main genotype track of the last decoded variant
 };
 
 class Reader {
@@ -209,6 +210,90 @@ class Reader {
     for (uint32_t i = 0; i < n_; ++i) out[i] = val[(g[i >> 2] >> (2 * (i & 3))) & 3];
   }
 
+  // One variant as PgenReader::Read(.., allele_idx = 1) gives it (pgenlibr.cpp:323-349; PgrGet1D / ParseDosage16,
+  // pgenlib_read.cc:7185-7330, :7459-7497): the ALT dosage value / 16384 where the record stores one for the sample, the
+  // hardcall (0/1/2, -3 missing) elsewhere.  The dosage track follows the main track and, when present, the
+  // hardcall-phase track (stepped over: its length follows from the number of heterozygous calls, SkipAux2 :6819-6840).
+  // Three layouts (vrtype & 0x60): 0x20 = list of sample ids + one value each, 0x40 = one value per sample (65535 = none),
+  // 0x60 = one bit per sample + one value per set bit.
+  void read_dosages(uint32_t vidx, double* out) { read_dosages(vidx, out, own_); }
+  void read_dosages(uint32_t vidx, double* out, Scratch& s) const {
+    read_hardcalls(vidx, out, s);
+    const uint8_t vt = vrtypes_[vidx];
+    if (!(vt & 0x60)) return;
+    if (vt & 0x08) bad(vidx, "multiallelic variant");
+    const uint8_t* g = ((vt & 6) == 2 || (vrtypes_[vidx + 1] & 6) != 2) ? s.cur.data() : s.ld.data();
+    const uint8_t* p = s.rec.data() + s.main_end;
+    const uint8_t* end = s.rec.data() + (fpos_[vidx + 1] - fpos_[vidx]);
+    if (vt & 0x10) {
+      uint64_t het = 0;  // heterozygous = code 1 = (lo & ~hi) in each 2-bit slot; padding slots of the last byte are masked
+      for (int64_t i = 0; i < bpr_; ++i) {
+        uint8_t b = g[i];
+        if (i == bpr_ - 1 && (n_ & 3)) b &= (uint8_t)((1u << (2 * (n_ & 3))) - 1);
+        het += (uint64_t)__builtin_popcount((unsigned)(b & ~(b >> 1) & 0x55));
+      }
+      uint64_t first = 1 + het / 8;
+      if (het == 0) bad(vidx, "phase track on a variant without heterozygous calls");  // as ParseAux2Subset (:6743-6760)
+      if ((uint64_t)(end - p) < first) bad(vidx, "phase track runs past the record");
+      if (p[0] & 1) {
+        uint64_t present = 0;
+        for (uint64_t i = 0; i < first; ++i) present += (uint64_t)__builtin_popcount(p[i]);
+        if (present < 2) bad(vidx, "phase track without a phased call");
+        first += (present - 1 + 7) / 8;
+        if ((uint64_t)(end - p) < first) bad(vidx, "phase track runs past the record");
+      }
+      p += first;
+    }
+    const uint8_t kind = vt & 0x60;
+    const double scale = 1.0 / 16384.0;
+    auto value = [&](const uint8_t* q) { return (uint16_t)(q[0] | (q[1] << 8)); };
+    if (kind == 0x40) {
+      if ((uint64_t)(end - p) < 2ull * n_) bad(vidx, "dosage values run past the record");
+      for (uint32_t i = 0; i < n_; ++i) {
+        const uint16_t v = value(p + 2 * (size_t)i);
+        if (v != 65535) out[i] = v * scale;
+      }
+    } else if (kind == 0x60) {
+      const int64_t nb = ((int64_t)n_ + 7) / 8;
+      if (end - p < nb) bad(vidx, "dosage bit array runs past the record");
+      const uint8_t* bits = p;
+      p += nb;
+      uint64_t cnt = 0;
+      for (int64_t i = 0; i < nb; ++i) {
+        uint8_t b = bits[i];
+        if (i == nb - 1 && (n_ & 7)) b &= (uint8_t)((1u << (n_ & 7)) - 1);
+        cnt += (uint64_t)__builtin_popcount(b);
+      }
+      if ((uint64_t)(end - p) < 2 * cnt) bad(vidx, "dosage values run past the record");
+      for (uint32_t i = 0; i < n_; ++i)
+        if (bits[i >> 3] & (1u << (i & 7))) { out[i] = value(p) * scale; p += 2; }
+    } else {  // list: the id stream of a difflist (no replacement codes), then the values
+      const uint32_t len = vint(p, end, vidx);
+      if (!len) return;
+      if (len > n_ / kMaxDifflistDiv) bad(vidx, "dosage list too long");
+      const uint32_t groups = (len + kDifflistGroup - 1) / kDifflistGroup;
+      const uint64_t index_bytes = (uint64_t)groups * (sample_id_bytes_ + 1) - 1;
+      if ((uint64_t)(end - p) < index_bytes) bad(vidx, "dosage list runs past the record");
+      const uint8_t* first = p;
+      p += index_bytes;
+      std::vector<uint32_t> ids(len);
+      uint32_t k = 0;
+      for (uint32_t gi = 0; gi < groups; ++gi) {
+        uint64_t id = 0;
+        for (uint32_t b = 0; b < sample_id_bytes_; ++b) id |= (uint64_t)first[(size_t)gi * sample_id_bytes_ + b] << (8 * b);
+        const uint32_t stop = (len - k < kDifflistGroup) ? len : k + kDifflistGroup;
+        for (;;) {
+          if (id >= n_) bad(vidx, "dosage list sample index out of range");
+          ids[k] = (uint32_t)id;
+          if (++k == stop) break;
+          id += vint(p, end, vidx);
+        }
+      }
+      if ((uint64_t)(end - p) < 2ull * len) bad(vidx, "dosage values run past the record");
+      for (uint32_t j = 0; j < len; ++j) out[ids[j]] = value(p + 2 * (size_t)j) * scale;
+    }
+  }
+
  private:
   int fd_ = -1;
   uint64_t fsize_ = 0;
@@ -296,6 +381,7 @@ class Reader {
       const uint8_t *p, *end;
       load_record(vidx, p, end, s);
       apply_difflist(p, end, s.cur.data(), vidx);
+      s.main_end = (size_t)(p - s.rec.data());
       if (vt == 3) {
         const int64_t words = (bpr_ + 7) / 8;
         for (int64_t i = 0; i < words; ++i) {
@@ -347,6 +433,7 @@ class Reader {
       } else {
         if (end - p < bpr_) bad(vidx, "2-bit track runs past the record");
         std::memcpy(g, p, (size_t)bpr_);
+        p += bpr_;
       }
     } else if ((vt & 3) == 1) {
       std::memset(g, 0, (size_t)bpr_);  // every sample hom-REF; the record is empty
@@ -354,6 +441,7 @@ class Reader {
       std::memset(g, (int)((vt & 3) * 0x55), (size_t)bpr_);
       apply_difflist(p, end, g, vidx);
     }
+    s.main_end = (size_t)(p - s.rec.data());
   }
 };
 

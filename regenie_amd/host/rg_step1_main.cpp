@@ -691,7 +691,10 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
       rg_pgen_set_threads(r.pgen, std::min(nt, 64));
     }
     int64_t ns = 0, nv = 0;
-    rg_pgen_info(r.pgen, &ns, &nv, nullptr, nullptr);
+    int32_t has_dosage = 0;
+    rg_pgen_info(r.pgen, &ns, &nv, nullptr, nullptr, &has_dosage);
+    if (has_dosage)  // regenie would set dosage_mode and read non-integer genotypes (Geno.cpp:1101, :1795-1796)
+      throw std::runtime_error("pgen file has dosages; the GPU level 0 reads hardcall (2-bit) genotypes only : " + fn);
     if (ns != r.n_file) throw std::runtime_error("number of samples in pgen file and psam file don't match.");
     if (nv != n_variants_file) throw std::runtime_error("number of variants in pgen file and pvar file don't match.");
     r.bpr = (r.n_file + 3) / 4;

@@ -24,10 +24,10 @@ class PgenFile:
             msg = self.lib.rg_pgen_last_error(self.h).decode() if self.h else "rg_pgen_open failed"
             self.close()
             raise RgError(rc, msg)
-        ns, nv, ac, ph = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32()
-        self.lib.rg_pgen_info(self.h, C.byref(ns), C.byref(nv), C.byref(ac), C.byref(ph))
+        ns, nv, ac, ph, ds = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+        self.lib.rg_pgen_info(self.h, C.byref(ns), C.byref(nv), C.byref(ac), C.byref(ph), C.byref(ds))
         self.n_samples, self.n_variants = ns.value, nv.value
-        self.max_alleles, self.phase_present = ac.value, bool(ph.value)
+        self.max_alleles, self.phase_present, self.dosage_present = ac.value, bool(ph.value), bool(ds.value)
         self.bytes_per_row = (self.n_samples + 3) // 4
         if threads != 1:
             self.set_threads(threads)
@@ -62,6 +62,14 @@ class PgenFile:
         rows = np.empty((idx.size, self.bytes_per_row), dtype=np.uint8)
         self._check(self.lib.rg_pgen_read_bed_rows(self.h, idx.size, idx.ctypes.data, rows.ctypes.data, self.bytes_per_row))
         return rows
+
+    def read_dosages(self, variant_idx: int) -> np.ndarray:
+        """ALT dosages where the file stores them, hardcalls elsewhere, -3 for missing: PgenReader::Read(.., allele_idx=1)."""
+        if not self.h:
+            raise RgError(-1, "pgen file is closed")
+        out = np.empty(self.n_samples, dtype=np.float64)
+        self._check(self.lib.rg_pgen_read_dosages(self.h, int(variant_idx), out.ctypes.data))
+        return out
 
     def read_hardcalls(self, variant_idx: int) -> np.ndarray:
         """ALT-allele counts 0/1/2 and -3 for missing, as PgenReader::ReadHardcalls(.., allele_idx=1) gives."""

@@ -162,6 +162,75 @@ def test_every_record_type(tmp_path, m, n, rl, wide, phase, nonref, mode):
         assert (_ref_hardcalls(path, n, m) == truth).all()
 
 
+def _ref_dosages(path, n, m):
+    lib = ctypes.CDLL(REF_LIB)
+    idx = np.arange(m, dtype=np.int64)
+    out = np.zeros((m, n))
+    lib.pgen_ref_dosages(path.encode(), ctypes.c_uint32(n), idx.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(m),
+                         out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+@pytest.mark.parametrize("m,n,phase", [(120, 500, False), (121, 1003, True), (122, 261, "explicit"), (40, 70001, "explicit")])
+def test_dosage_tracks_read_like_the_reference(tmp_path, m, n, phase):
+    """PgenReader::Read -- what regenie calls once a file has dosages (Geno.cpp:1101, :1795-1796): the three dosage layouts,
+    behind every main-track record type and behind both forms of the phase track."""
+    g, vts = synth(m, n, seed=m + n)
+    rng = np.random.default_rng(m)
+    dos = {}
+    truth = opg.HARDCALL[g].copy()
+    for j in range(m):
+        kind = [None, 0x20, 0x40, 0x60][j % 4]
+        if kind is None:
+            continue
+        k = int(rng.integers(0, (n // 8 if kind == 0x20 else n) + 1))
+        if j in (1, 2, 3):
+            k = 0                                               # empty list / all-65535 / all-zero bit array
+        ids = np.sort(rng.choice(n, size=k, replace=False))
+        vals = rng.integers(0, 32769, ids.size).astype(np.uint16)
+        dos[j] = (kind, ids, vals)
+        truth[j, ids] = vals / 16384.0
+    path = str(tmp_path / "d.pgen")
+    opg.write_pgen(path, g, vts, wide_vrtypes=True, phase=phase, dosage=dos, reclen_bytes=3, seed=m)
+    o = opg.PgenOracle(path)
+    assert o.dosage_present and o.phase_present == bool(phase)
+    with PgenFile(path) as f:
+        assert f.dosage_present and f.n_variants == m
+        order = list(range(m)) + [int(x) for x in rng.permutation(m)[:50]]   # in sequence, then out of order (LD bases)
+        for j in order:
+            assert (f.read_dosages(j) == truth[j]).all(), (j, vts[j], dos.get(j, (0,))[0])
+        for j in range(0, m, 3):
+            assert (o.dosages(j) == truth[j]).all()
+            assert (f.read_hardcalls(j) == opg.HARDCALL[g[j]]).all()        # ReadHardcalls still ignores the dosages
+        with pytest.raises(RgError) as e:                                   # 2-bit rows are not what regenie would use here
+            f.read_bed_rows([0])
+        assert e.value.code == -3 and "dosages" in str(e.value)
+    if os.path.exists(REF_LIB):
+        assert _ref_counts(path, n) == [n, m, 2, 1]
+        assert (_ref_dosages(path, n, m) == truth).all()
+    # a record cut short inside its dosage values is an error that names the variant
+    j = max(k for k in dos if dos[k][0] == 0x60 and dos[k][1].size)
+    raw = bytearray(open(path, "rb").read())
+    end = int(o.fpos[j + 1])
+    lens_at = 12 + 8 + m                                         # 8-bit vrtypes, then 3-byte record lengths
+    ln = int.from_bytes(raw[lens_at + 3 * j: lens_at + 3 * j + 3], "little")
+    raw[lens_at + 3 * j: lens_at + 3 * j + 3] = (ln - 2).to_bytes(3, "little")
+    del raw[end - 2:end]
+    bad = str(tmp_path / "cut.pgen")
+    open(bad, "wb").write(raw)
+    with PgenFile(bad) as f:
+        with pytest.raises(RgError) as e:
+            f.read_dosages(j)
+        assert e.value.code == -2 and "variant %d" % (j + 1) in str(e.value)
+
+
+def test_dosages_of_a_hardcall_file_are_its_hardcalls(example_dir):
+    with PgenFile(os.path.join(example_dir, "example.pgen")) as f:
+        assert not f.dosage_present
+        for j in (0, 1, 500, 999):
+            assert (f.read_dosages(j) == f.read_hardcalls(j)).all()
+
+
 def test_fixed_width_mode(tmp_path):
     g, _ = synth(50, 333, seed=9)
     path = str(tmp_path / "f.pgen")
@@ -186,8 +255,11 @@ def test_refusals(tmp_path, example_dir):
     # dosage track: regenie would switch to dosages (Geno.cpp:1101), so a 2-bit reader must not accept the file
     p = str(tmp_path / "d.pgen")
     opg.write_pgen(p, g, vts, wide_vrtypes=True, dosage_variant=17)
-    err = _open_error(p)
-    assert err.code == -3 and "dosages" in str(err)
+    with PgenFile(p) as f:
+        assert f.dosage_present
+        with pytest.raises(RgError) as e:
+            f.read_bed_rows([0])
+        assert e.value.code == -3 and "dosages" in str(e.value)
     assert opg.PgenOracle(p).dosage_present
     if os.path.exists(REF_LIB):
         assert _ref_counts(p, 200)[3] == 1
@@ -208,7 +280,7 @@ def test_refusals(tmp_path, example_dir):
     assert "--bed" in str(_open_error(os.path.join(example_dir, "example.bed")))
     p = str(tmp_path / "m3.pgen")
     open(p, "wb").write(b"\x6c\x1b\x03" + b"\x00" * 20)
-    assert _open_error(p).code == -3
+    assert _open_error(p).code == -3                                    # fixed-width dosage storage modes are not read
     assert "cannot open" in str(_open_error(str(tmp_path / "nope.pgen")))
 
 
@@ -302,6 +374,15 @@ def test_cli_pgen_input_errors_like_reference(example_dir, tmp_path):
     assert "ERROR: unrecognized sex code in file : 'F'" in run_with(psam_lines=psam[:1] + ["1\t1\tF\t0.1"] + psam[2:])
     # leading "##" meta lines are skipped, a blank one is an error
     assert "ERROR: no blank lines should be before the header line in pvar file." in run_with(pvar_lines=["##fileformat=x", ""] + pvar)
+    # a file with dosage tracks: regenie would run it in dosage mode (Geno.cpp:1101); the 2-bit level 0 must not take it
+    g, vts = synth(30, 500, seed=3)
+    dpfx = str(tmp_path / "dos")
+    opg.write_pgen(dpfx + ".pgen", g, vts, wide_vrtypes=True, dosage={4: (0x40, np.arange(500), np.full(500, 8192, np.uint16))})
+    opg.write_pvar_psam(dpfx, [1] * 30, 500)
+    import subprocess as sp
+    r = sp.run([BIN, "--step", "1", "--pgen", dpfx, "--phenoFile", os.path.join(example_dir, "phenotype.txt"), "--bsize", "10"],
+               cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode != 0 and "ERROR: pgen file has dosages" in r.stdout
     # both inputs at once
     import subprocess
     r = subprocess.run([BIN, "--step", "1", "--pgen", pfx, "--bed", os.path.join(example_dir, "example"), "--phenoFile",
