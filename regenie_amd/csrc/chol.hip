@@ -165,6 +165,7 @@ __device__ __forceinline__ FormIdx form_idx(const FormSrc& f, int b_local) {
 template <int MODE>
 __device__ __forceinline__ double form_val(const FormIdx& x, int i, int j, int64_t e) {
   double v;
+  if (MODE == 3) return x.X[e - x.xoff];       // a tile that lies entirely in the extra rows (never on the diagonal)
   if (MODE == 2) {
     if (i >= x.x0) return x.X[e - x.xoff];   // (i - extra_row0) * n64 + j
     v = x.S[e];
@@ -178,6 +179,13 @@ __device__ __forceinline__ double form_val(const FormIdx& x, int i, int j, int64
   return v;
 }
 __device__ __forceinline__ int form_mode(const FormIdx& x) { return x.X ? 2 : (x.F ? 1 : 0); }
+// Mode of a tile whose rows are [row_lo, row_hi): the extra rows start at a tile boundary in every caller, so a tile is
+// either all matrix / right-hand-side rows (modes 0, 1: straight-line loads) or all extra rows (mode 3); the per-element
+// branch of mode 2 -- one serialized memory round trip per element -- is only a fallback for a straddling tile.
+__device__ __forceinline__ int form_mode_rows(const FormIdx& x, int row_lo, int row_hi) {
+  if (!x.X || row_hi <= x.x0) return x.F ? 1 : 0;
+  return row_lo >= x.x0 ? 3 : 2;
+}
 
 // ---- diagonal tile: blocked (16) potf2 + blocked triangular inverse, all in LDS -------------------
 // value of `x` in lane `l` (compile-time constant), broadcast through SGPRs
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(256) void k_chol_diag(double* mats, int64_t mat_str
   double* D = mats + (int64_t)b * mat_stride + (int64_t)k * CT * n64 + k * CT;
   if (fs.enabled) {
     const FormIdx fx = form_idx(fs, b);
-    const int md = form_mode(fx);
+    const int md = form_mode_rows(fx, k * CT, (k + 1) * CT);   // a diagonal tile never lies in the extra rows: 0 or 1
 #pragma unroll
     for (int u = 0; u < CT * CT / 256; ++u) {   // unconditional loads (the upper triangle of the source exists), then select
       const int e = tid + 256 * u;
@@ -446,9 +454,10 @@ __global__ __launch_bounds__(256, 2) void k_chol_panel(double* mats, int64_t mat
     if (!fs.enabled) init(std::integral_constant<int, -1>{});
     else {
       const FormIdx f0 = form_idx(fs, b);
-      const int md = form_mode(f0);
+      const int md = form_mode_rows(f0, t * CT, (t + 1) * CT);
       if (md == 0) init(std::integral_constant<int, 0>{});
       else if (md == 1) init(std::integral_constant<int, 1>{});
+      else if (md == 3) init(std::integral_constant<int, 3>{});
       else init(std::integral_constant<int, 2>{});
     }
   }
@@ -540,9 +549,10 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(double* mats, int64_t ma
             acc[m][n][r] = -form_val<decltype(mode)::value>(fx, gi, gj, (int64_t)gi * n64 + gj);
           }
     };
-    const int md = form_mode(fx);
+    const int md = form_mode_rows(fx, tr * CT, (tr + 1) * CT);
     if (md == 0) init(std::integral_constant<int, 0>{});
     else if (md == 1) init(std::integral_constant<int, 1>{});
+    else if (md == 3) init(std::integral_constant<int, 3>{});
     else init(std::integral_constant<int, 2>{});
   } else {
 #pragma unroll
@@ -747,12 +757,12 @@ __device__ __forceinline__ double sys_val(const FormIdx& fx, const double* M, in
   if (MD < 0) return M[e];
   return form_val<(MD < 0 ? 0 : MD)>(fx, gi, gj, e);
 }
+// the diagonal block of a group consists of matrix rows only (extra rows start past the right-hand sides): -1, 0 or 1
 template <typename F>
 __device__ __forceinline__ void dispatch_md(int md, F&& f) {
   if (md < 0) f(std::integral_constant<int, -1>{});
   else if (md == 0) f(std::integral_constant<int, 0>{});
-  else if (md == 1) f(std::integral_constant<int, 1>{});
-  else f(std::integral_constant<int, 2>{});
+  else f(std::integral_constant<int, 1>{});
 }
 
 __device__ __forceinline__ void gfact_wave(int md, double (*s)[CT + 2], double* dv, double* M, int b, int n64, int k0, int nc,
@@ -926,7 +936,11 @@ __global__ __launch_bounds__(256) void k_chol_gfact(double* mats, int64_t mat_st
   double* M = mats + (int64_t)b * mat_stride;
   double* dinvb = dinv + (int64_t)b * (n64 / CT) * GT_TILE;
   double* img = dimg + ((int64_t)b * ngrp + k0 / 4) * GT_NIMG * GT_TILE;
-  const int md = fs.enabled ? form_mode(form_idx(fs, b)) : -1;
+  int md = -1;
+  if (fs.enabled) {
+    const FormIdx f0 = form_idx(fs, b);
+    md = f0.F ? 1 : 0;   // form_mode_rows for rows < n64 <= extra_row0
+  }
   gfact_wave(md, S[wave], DV[wave], M, b, n64, k0, nc, dinvb, img, info, fs);
 }
 
