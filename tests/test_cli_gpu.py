@@ -302,3 +302,40 @@ def test_cli_ct_count_traits(example_dir, tmp_path, loocv):
     open(str(tmp_path / "bad.txt"), "w").write("\n".join(bad))
     r = _run(args[:5] + [str(tmp_path / "bad.txt")] + args[6:], str(tmp_path))
     assert r.returncode != 0 and "a phenotype value is <0 for individual: FID=%s IID=%s Y=-2" % (t[0], t[1]) in r.stdout
+
+
+def test_cli_option_mix(example_dir, tmp_path):
+    """Less-travelled Step-1 options together: --keep / --extract (files made here), --phenoColList, --covarColList, --strict,
+    --setl0 / --setl1 grids, --cv 3, --use-relative-path -- the driver's files against the oracle's."""
+    E = example_dir
+    fam = [ln.split() for ln in open(os.path.join(E, "example.fam")).read().split("\n") if ln]
+    bim = [ln.split() for ln in open(os.path.join(E, "example.bim")).read().split("\n") if ln]
+    keep = str(tmp_path / "keep.txt")
+    with open(keep, "w") as fh:
+        for t in fam[:420]:
+            fh.write("%s %s\n" % (t[0], t[1]))
+    ext = str(tmp_path / "extract.txt")
+    with open(ext, "w") as fh:
+        for j, t in enumerate(bim):
+            if j % 5 != 3:
+                fh.write(t[1] + "\n")
+    args = ["--step", "1", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype_bin_wNA.txt"),
+            "--covarFile", os.path.join(E, "covariates.txt"), "--keep", keep, "--extract", ext, "--phenoColList", "Y1,Y2",
+            "--covarColList", "V1,V3", "--strict", "--force-qt", "--setl0", "0.1,0.5,0.9", "--setl1", "0.2,0.8", "--cv", "3", "--bsize", "75",
+            "--use-relative-path", "--out", "mix"]
+    r = _run(args, str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    opt = orc.Step1Options(bed=os.path.join(E, "example"), pheno_file=os.path.join(E, "phenotype_bin_wNA.txt"),
+                           covar_file=os.path.join(E, "covariates.txt"), keep=[keep], extract=[ext], pheno_cols=["Y1", "Y2"],
+                           covar_cols=["V1", "V3"], strict=True, setl0=[0.1, 0.5, 0.9], setl1=[0.2, 0.8], cv_folds=3, bsize=75,
+                           use_rel_path=True, out=str(tmp_path / "omix"))
+    ref = orc.run_step1(opt, write_files=True)
+    assert open(str(tmp_path / "mix_pred.list")).read() == "Y1 mix_1.loco\nY2 mix_2.loco\n"
+    for k in (1, 2):
+        h1, ids1, v1, _ = _parse_loco(str(tmp_path / ("mix_%d.loco" % k)))
+        h2, ids2, v2, _ = _parse_loco(str(tmp_path / ("omix_%d.loco" % k)))
+        assert h1 == h2 and ids1 == ids2 and len(h1) < 420
+        assert np.allclose(v1, v2, rtol=2e-5, atol=1e-7, equal_nan=True)
+    tab = [ln for ln in r.stdout.split("\n") if " : Rsq = " in ln]
+    want = [ln for ln in ref.log if " : Rsq = " in ln]
+    assert len(tab) == 4 and [a.split(":")[0].strip() for a in tab] == [b.split(":")[0].strip() for b in want]
