@@ -93,6 +93,16 @@ void* rg_w_device_ptr(rg_ctx* ctx);
  * Work is asynchronous on the ctx stream; rg_sync() (or any readback) waits for it. */
 int rg_l0_blocks(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int32_t* bs,
                  const uint8_t* const* bed_rows, int64_t row_stride, int mem_kind);
+/* Level 0 on NON-INTEGER genotypes (dosages): what level_0_calculations does after readChunkFromPGENFileToG in dosage_mode
+ * (Geno.cpp:1773-1822: PgenReader::Read, mean imputation over the analysed non-missing samples, zero for the others) or
+ * after a BGEN read.  rows[b] holds bs[b] variants x n_file doubles (row j at rows[b] + j * row_stride doubles, file sample
+ * order, ALT dosage in [0, 2], -3 = missing: exactly what rg_pgen_read_dosages / PgenReader::Read return).  Same results
+ * contract as rg_l0_blocks (the predictors of the blocks land in W); the arithmetic is fp64 throughout -- standardised
+ * genotypes materialised per block, fold Grams and G~ Y as fp64 MFMA GEMMs, the same batched Cholesky -- where the 2-bit path
+ * uses exact integer Grams.  K-fold CV only in this revision (RG_ERR_STATE with cv_folds == 0).  A value outside [0, 2]
+ * other than -3 is reported by the next rg_sync ("... has a value not in [0,2] or missing", Geno.cpp:1819-1820). */
+int rg_l0_blocks_f64(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int32_t* bs,
+                     const double* const* rows, int64_t row_stride, int mem_kind);
 int rg_sync(rg_ctx* ctx); /* waits and reports deferred device-side errors (low variance, not SPD) */
 
 /* Readback in the reference's own layout (= the `--lowmem` file of write_l0_file,

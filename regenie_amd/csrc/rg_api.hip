@@ -35,6 +35,8 @@ void free_all(rg_ctx* c) {
   if (c->own_W && c->d_W) hipFree(c->d_W);
   for (int i = 0; i < 12; ++i)
     if (c->ws_ptr[i]) { hipFree(c->ws_ptr[i]); c->ws_ptr[i] = nullptr; c->ws_bytes[i] = 0; }
+  for (int i = 0; i < 10; ++i)
+    if (c->f64_ptr[i]) { hipFree(c->f64_ptr[i]); c->f64_ptr[i] = nullptr; c->f64_bytes[i] = 0; }
 }
 
 struct StageTimer {
@@ -479,6 +481,21 @@ int rg_l0_blocks(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int3
   return RG_OK;
 }
 
+int rg_l0_blocks_f64(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int32_t* bs, const double* const* rows,
+                     int64_t row_stride, int mem_kind) {
+  if (!ctx || !ctx->have_problem) return RG_ERR_STATE;
+  hipSetDevice(ctx->device);
+  if (nblk < 1 || !block_ids || !bs || !rows) { ctx->err = "rg_l0_blocks_f64: bad arguments"; return RG_ERR_ARG; }
+  if (row_stride < ctx->Nfile) { ctx->err = "rg_l0_blocks_f64: row_stride < N_file"; return RG_ERR_ARG; }
+  for (int b = 0; b < nblk; ++b) {
+    if (block_ids[b] < 0 || block_ids[b] >= ctx->B_total) { ctx->err = "rg_l0_blocks_f64: block id out of range"; return RG_ERR_ARG; }
+    if (bs[b] < 1 || bs[b] > ctx->bs_max) { ctx->err = "rg_l0_blocks_f64: block size out of range"; return RG_ERR_ARG; }
+    if (!rows[b]) { ctx->err = "rg_l0_blocks_f64: null row pointer"; return RG_ERR_ARG; }
+  }
+  { const int rcw = ensure_W(ctx); if (rcw) return rcw; }
+  return rg_l0_blocks_f64_impl(ctx, nblk, block_ids, bs, rows, row_stride, mem_kind);
+}
+
 int rg_sync(rg_ctx* ctx) {
   if (!ctx) return RG_ERR_ARG;
   hipSetDevice(ctx->device);
@@ -495,6 +512,11 @@ int rg_sync(rg_ctx* ctx) {
     ctx->err = "!! Uh-oh, SNP #" + std::to_string(j) + " of batch block " + std::to_string(blk) + " has low variance.";
     hipMemset(ctx->d_info, 0, sizeof(info));
     return RG_ERR_LOW_VARIANCE;
+  }
+  if (info[2]) {  // Geno.cpp:1799-1800, :1819-1820
+    ctx->err = "there is a variant in the block that has a value not in [0,2] or missing";
+    hipMemset(ctx->d_info, 0, sizeof(info));
+    return RG_ERR_ARG;
   }
   if (info[1]) {
     ctx->err = "ridge system is not positive definite";

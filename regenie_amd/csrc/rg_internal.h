@@ -141,6 +141,10 @@ struct rg_ctx {
   void* ws_ptr[12] = {};
   size_t ws_bytes[12] = {};
 
+  // fp64 genotype input (l0_f64.hip): grows-only device buffers of the dosage path
+  void* f64_ptr[10] = {};
+  size_t f64_bytes[10] = {};
+
   // timing
   bool timing = false;
   rg_timing tm{};
@@ -257,6 +261,9 @@ struct LoocvArgs {
 };
 void rg_launch_decode_gt(hipStream_t st, const LoocvArgs& a);
 void rg_launch_l0_loocv(hipStream_t st, const LoocvArgs& a, double* part0, double* part1, int nchunk);
+// l0_f64.hip: level 0 on non-integer genotypes (dosages)
+int rg_l0_blocks_f64_impl(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32_t* bs, const double* const* rows,
+                          int64_t row_stride, int mem_kind);
 // l1.hip
 // copies the per-chromosome predictions of one phenotype (device, [nchr][N]) to the caller: as they are, or assembled
 // into LOCO rows [nchrom][N] first (rg_set_loco_output).  Returns an RG_* code.

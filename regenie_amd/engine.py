@@ -48,7 +48,7 @@ class RgTiming(C.Structure):
 
 
 EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_w_rows", "rg_w_bytes",
-           "rg_set_w_buffer", "rg_w_device_ptr", "rg_l0_blocks", "rg_sync", "rg_l0_get_w",
+           "rg_set_w_buffer", "rg_w_device_ptr", "rg_l0_blocks", "rg_l0_blocks_f64", "rg_sync", "rg_l0_get_w",
            "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_set_collective", "rg_set_l1_view", "rg_set_loco_output", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
            "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak",
            # include/rg_pgen.h (host-side .pgen hardcall input; wrapped by regenie_amd/pgen.py)
@@ -84,6 +84,7 @@ def load_library() -> C.CDLL:
     lib.rg_w_device_ptr.argtypes = [C.c_void_p]
     lib.rg_w_device_ptr.restype = C.c_void_p
     lib.rg_l0_blocks.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+    lib.rg_l0_blocks_f64.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
     lib.rg_sync.argtypes = [C.c_void_p]
     lib.rg_l0_get_w.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
     lib.rg_l0_set_w.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
@@ -212,6 +213,18 @@ class Step1Engine:
         assert all(r.shape[1] == stride for r in rows)
         ptrs = (C.c_void_p * nb)(*[r.ctypes.data for r in rows])
         self._check(self.lib.rg_l0_blocks(self.h, nb, ids.ctypes.data, bs.ctypes.data, ptrs, stride, RG_MEM_HOST))
+
+    def l0_blocks_f64_host(self, block_ids: Sequence[int], rows: List[np.ndarray]):
+        """Level 0 on non-integer genotypes: rows[b] is (bs_b, N_file) float64, C-contiguous, file sample order, ALT dosages
+        in [0, 2] with -3 for missing (what PgenFile.read_dosages returns).  K-fold CV only."""
+        nb = len(block_ids)
+        ids = np.ascontiguousarray(block_ids, dtype=np.int32)
+        bs = np.ascontiguousarray([r.shape[0] for r in rows], dtype=np.int32)
+        rows = [np.ascontiguousarray(r, dtype=np.float64) for r in rows]
+        stride = rows[0].shape[1]
+        assert all(r.shape[1] == stride for r in rows)
+        ptrs = (C.c_void_p * nb)(*[r.ctypes.data for r in rows])
+        self._check(self.lib.rg_l0_blocks_f64(self.h, nb, ids.ctypes.data, bs.ctypes.data, ptrs, stride, RG_MEM_HOST))
 
     def l0_blocks_device(self, block_ids: Sequence[int], bs: Sequence[int], dev_ptrs: Sequence[int], row_stride: int):
         nb = len(block_ids)
