@@ -77,6 +77,9 @@ class Step1Options:
     force_step1: bool = False
     # --split-l0 / --run-l0 analogue: global M used for lambda (Data.cpp:607)
     parallel_nGeno: Optional[int] = None
+    # dosage input (pgen dosage_mode): callable(file_offsets) -> (len, N_file) float64, ALT dosages in [0, 2], -3 = missing
+    # (what PgenReader::Read returns); the .bed of `bed` is then only used for its .bim / .fam
+    dosage_provider: Optional[object] = None
 
 
 def set_ridge_params(n: int) -> np.ndarray:
@@ -238,6 +241,22 @@ def read_chunk_from_bed(rows: np.ndarray, n_file: int, ind_ignore: np.ndarray,
     g = np.where(miss, mu[:, None], g)         # mean_impute_g (Geno.cpp:3183-3188)
     g = np.where(ind_in_analysis[None, :], g, 0.0)
     return g
+
+
+def read_chunk_from_dosages(g: np.ndarray, ind_ignore: np.ndarray, ind_in_analysis: np.ndarray) -> np.ndarray:
+    """Geno.cpp:1773-1822 readChunkFromPGENFileToG in dosage_mode: Read() rows (the reader already dropped the ignored
+    samples), a value outside [-3, 2] is an error, total = mean over analysed non-missing, mean_impute_g."""
+    g = np.asarray(g, dtype=np.float64)
+    if ind_ignore is not None and ind_ignore.any():
+        g = g[:, ~ind_ignore]
+    if ((g < -3) | (g > 2)).any():
+        raise ValueError("there is a variant in the block that has a value not in [0,2] or missing")
+    miss = g == -3
+    ok = (~miss) & ind_in_analysis[None, :]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        mu = np.where(ok, g, 0.0).sum(axis=1) / ok.sum(axis=1)
+    g = np.where(miss, mu[:, None], g)
+    return np.where(ind_in_analysis[None, :], g, 0.0)
 
 
 # --------------------------------------------------------------------------
@@ -1361,8 +1380,11 @@ def run_step1(opt: Step1Options, write_files: bool = False, keep_W: bool = True)
     L = B * R0
     W = [np.zeros((N, L)) for _ in range(P)]
     for b, (c, start, bs) in enumerate(blocks):
-        rows = np.asarray(bed[offs[start:start + bs]])
-        G = read_chunk_from_bed(rows, prep.n_file, prep.ind_ignore, prep.ind_in_analysis, opt.ref_first)
+        if opt.dosage_provider is not None:
+            G = read_chunk_from_dosages(opt.dosage_provider(offs[start:start + bs]), prep.ind_ignore, prep.ind_in_analysis)
+        else:
+            rows = np.asarray(bed[offs[start:start + bs]])
+            G = read_chunk_from_bed(rows, prep.n_file, prep.ind_ignore, prep.ind_in_analysis, opt.ref_first)
         G, _ = residualize_genotypes(G, prep)
         Wb = ridge_level_0_loocv(G, prep, lam) if use_loocv else ridge_level_0(G, prep, cv_sizes, lam)
         for ph in range(P):

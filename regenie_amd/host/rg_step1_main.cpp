@@ -352,6 +352,7 @@ struct Run {
   std::vector<std::string> mprefix; std::vector<int> bstart, btot;
   int64_t n_file = 0, bpr = 0;
   rg_pgen* pgen = nullptr;               // --pgen: open reader (bed rows come from rg_pgen_read_bed_rows)
+  bool dosage_mode = false;              // --pgen with dosage tracks: rows come from rg_pgen_read_dosages, level 0 from rg_l0_blocks_f64
   Run() = default;
   Run(const Run&) = delete;
   ~Run() { if (pgen) rg_pgen_close(pgen); }
@@ -693,8 +694,8 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
     int64_t ns = 0, nv = 0;
     int32_t has_dosage = 0;
     rg_pgen_info(r.pgen, &ns, &nv, nullptr, nullptr, &has_dosage);
-    if (has_dosage)  // regenie would set dosage_mode and read non-integer genotypes (Geno.cpp:1101, :1795-1796)
-      throw std::runtime_error("pgen file has dosages; the GPU level 0 reads hardcall (2-bit) genotypes only : " + fn);
+    r.dosage_mode = has_dosage != 0;  // params->dosage_mode (Geno.cpp:1101): every variant is then read with Read(), not ReadHardcalls()
+    if (r.dosage_mode) sout << "   -dosages present: level 0 runs on the fp64 genotype path\n";
     if (ns != r.n_file) throw std::runtime_error("number of samples in pgen file and psam file don't match.");
     if (nv != n_variants_file) throw std::runtime_error("number of variants in pgen file and pvar file don't match.");
     r.bpr = (r.n_file + 3) / 4;
@@ -1262,8 +1263,9 @@ int run(int argc, char** argv) {
     // level 0: stream blocks from the bed / pgen file (get_G, Geno.cpp:1498-1517) in batches
     std::ifstream bed;
     if (!r.pgen) bed.open(p.bed + ".bed", std::ios::binary);
-    const int NB = 32;
+    const int NB = r.dosage_mode ? 1 : 32;   // a block of dosages is bs x N_file doubles on the host: one at a time
     std::vector<std::vector<uint8_t>> bufs(NB);
+    std::vector<double> dbuf;
     int cur_chr = -1;
     for (int b0 = 0; b0 < B; b0 += NB) {
       const int nb = std::min(NB, B - b0);
@@ -1273,6 +1275,14 @@ int run(int argc, char** argv) {
       for (int b = 0; b < nb; ++b) {
         const Blk& bl = blocks[b0 + b];
         if (bl.chrom != cur_chr) { cur_chr = bl.chrom; sout << "Chromosome " << cur_chr << "\n"; }
+        if (r.dosage_mode) {  // Read() per kept variant (Geno.cpp:1795-1796): ALT dosages, -3 = missing
+          dbuf.resize((size_t)bl.bs * r.n_file);
+          for (int j = 0; j < bl.bs; ++j)
+            if (rg_pgen_read_dosages(r.pgen, r.snp_offset[bl.start + j], dbuf.data() + (size_t)j * r.n_file) != RG_PGEN_OK)
+              throw std::runtime_error(rg_pgen_last_error(r.pgen));
+          ids[b] = b0 + b; bss[b] = bl.bs;
+          continue;
+        }
         bufs[b].resize((size_t)bl.bs * r.bpr);
         if (r.pgen) {  // ReadHardcalls per kept variant (Geno.cpp:1781-1798), as .bed-coded rows
           if (rg_pgen_read_bed_rows(r.pgen, bl.bs, &r.snp_offset[bl.start], bufs[b].data(), r.bpr) != RG_PGEN_OK)
@@ -1287,7 +1297,11 @@ int run(int argc, char** argv) {
         ids[b] = b0 + b; bss[b] = bl.bs; ptrs[b] = bufs[b].data();
       }
       auto t1 = std::chrono::steady_clock::now();
-      check(ctx, rg_l0_blocks(ctx, nb, ids.data(), bss.data(), ptrs.data(), r.bpr, RG_MEM_HOST));
+      if (r.dosage_mode) {
+        const double* dp = dbuf.data();
+        check(ctx, rg_l0_blocks_f64(ctx, nb, ids.data(), bss.data(), &dp, r.n_file, RG_MEM_HOST));
+      } else
+        check(ctx, rg_l0_blocks(ctx, nb, ids.data(), bss.data(), ptrs.data(), r.bpr, RG_MEM_HOST));
       check(ctx, rg_sync(ctx));
       auto t2 = std::chrono::steady_clock::now();
       int64_t nsnp = 0;

@@ -339,3 +339,60 @@ def test_cli_option_mix(example_dir, tmp_path):
     tab = [ln for ln in r.stdout.split("\n") if " : Rsq = " in ln]
     want = [ln for ln in ref.log if " : Rsq = " in ln]
     assert len(tab) == 4 and [a.split(":")[0].strip() for a in tab] == [b.split(":")[0].strip() for b in want]
+
+
+def test_cli_pgen_dosages(tmp_path):
+    """A .pgen with dosage tracks: regenie switches to PgenReader::Read and analyses non-integer genotypes (Geno.cpp:1101,
+    :1795-1822).  The driver decodes them (rg_pgen_read_dosages) and runs level 0 on the fp64 path (rg_l0_blocks_f64); its
+    files against the oracle working on the same dosages."""
+    from oracle import pgen as opg
+    from tests.util import synth_dosages, write_plink
+    N, M = 800, 300
+    g = synth_dosages(M, N, miss_rate=0.01, seed=21)              # hardcalls 0/1/2, -9 style missing handled by write_plink
+    pre = str(tmp_path / "h")
+    chroms = np.repeat([1, 2, 3], [100, 100, 100])
+    write_plink(pre, g, chroms, P=2, ncov=2, seed=9, missing_pheno=0.02)
+    bim = [ln.split() for ln in open(pre + ".bim").read().split("\n") if ln]
+    fam = [ln.split() for ln in open(pre + ".fam").read().split("\n") if ln]
+    # pgen codes from the bed (so that hardcalls and the companion .bed agree), dosages on most variants in all three layouts
+    bedrows = np.fromfile(pre + ".bed", dtype=np.uint8)[3:].reshape(M, (N + 3) // 4)
+    codes = np.array([2, 3, 1, 0], dtype=np.uint8)[((bedrows[:, :, None] >> np.array([0, 2, 4, 6])) & 3).reshape(M, -1)[:, :N]]
+    rng = np.random.default_rng(3)
+    dos = {}
+    for j in range(M):
+        kind = [None, 0x20, 0x40, 0x60][j % 4]
+        if kind is None:
+            continue
+        k = int(rng.integers(1, (N // 8 if kind == 0x20 else N) + 1))
+        ids = np.sort(rng.choice(N, size=k, replace=False))
+        hc = np.where(codes[j, ids] == 3, 1.0, codes[j, ids].astype(np.float64))
+        vals = np.clip(np.round((hc + rng.normal(0, 0.2, k)) * 16384), 0, 32768).astype(np.uint16)
+        dos[j] = (kind, ids, vals)
+    pfx = str(tmp_path / "d")
+    opg.write_pgen(pfx + ".pgen", codes, [0] * M, wide_vrtypes=True, dosage=dos, reclen_bytes=3)
+    with open(pfx + ".pvar", "w") as fh:
+        fh.write("#CHROM\tPOS\tID\tREF\tALT\n")
+        for t in bim:
+            fh.write("%s\t%s\t%s\t%s\t%s\n" % (t[0], t[3], t[1], t[5], t[4]))
+    with open(pfx + ".psam", "w") as fh:
+        fh.write("#FID\tIID\tSEX\n")
+        for t in fam:
+            fh.write("%s\t%s\tNA\n" % (t[0], t[1]))
+    args = ["--step", "1", "--pgen", pfx, "--phenoFile", pre + ".pheno", "--covarFile", pre + ".covar", "--bsize", "60", "--out", str(tmp_path / "c")]
+    r = _run(args, str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "-dosages present: level 0 runs on the fp64 genotype path" in r.stdout
+    o = opg.PgenOracle(pfx + ".pgen")
+    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=60, out=str(tmp_path / "o"),
+                           dosage_provider=lambda offs: np.stack([o.dosages(int(j)) for j in offs]))
+    ref = orc.run_step1(opt, write_files=True)
+    hard = orc.run_step1(orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=60))
+    for k in (1, 2):
+        h1, ids1, v1, _ = _parse_loco(str(tmp_path / ("c_%d.loco" % k)))
+        h2, ids2, v2, _ = _parse_loco(str(tmp_path / ("o_%d.loco" % k)))
+        assert h1 == h2 and ids1 == ids2
+        assert np.allclose(v1, v2, rtol=2e-5, atol=1e-7, equal_nan=True)
+        assert not np.allclose(ref.loco[k - 1], hard.loco[k - 1], rtol=1e-3)      # the dosages matter: hardcalls give other numbers
+    # leave-one-out level 0 on dosages is not served: an error, not a silent hardcall run
+    r = _run(args + ["--loocv"], str(tmp_path))
+    assert r.returncode != 0 and "leave-one-out level 0 on dosages is not served yet" in r.stdout

@@ -374,7 +374,8 @@ def test_cli_pgen_input_errors_like_reference(example_dir, tmp_path):
     assert "ERROR: unrecognized sex code in file : 'F'" in run_with(psam_lines=psam[:1] + ["1\t1\tF\t0.1"] + psam[2:])
     # leading "##" meta lines are skipped, a blank one is an error
     assert "ERROR: no blank lines should be before the header line in pvar file." in run_with(pvar_lines=["##fileformat=x", ""] + pvar)
-    # a file with dosage tracks: regenie would run it in dosage mode (Geno.cpp:1101); the 2-bit level 0 must not take it
+    # a file with dosage tracks is run in dosage mode (Geno.cpp:1101): the driver announces the fp64 level-0 path
+    # (end to end on a GPU: tests/test_cli_gpu.py::test_cli_pgen_dosages)
     g, vts = synth(30, 500, seed=3)
     dpfx = str(tmp_path / "dos")
     opg.write_pgen(dpfx + ".pgen", g, vts, wide_vrtypes=True, dosage={4: (0x40, np.arange(500), np.full(500, 8192, np.uint16))})
@@ -382,7 +383,7 @@ def test_cli_pgen_input_errors_like_reference(example_dir, tmp_path):
     import subprocess as sp
     r = sp.run([BIN, "--step", "1", "--pgen", dpfx, "--phenoFile", os.path.join(example_dir, "phenotype.txt"), "--bsize", "10"],
                cwd=str(tmp_path), capture_output=True, text=True)
-    assert r.returncode != 0 and "ERROR: pgen file has dosages" in r.stdout
+    assert "-dosages present: level 0 runs on the fp64 genotype path" in r.stdout
     # both inputs at once
     import subprocess
     r = subprocess.run([BIN, "--step", "1", "--pgen", pfx, "--bed", os.path.join(example_dir, "example"), "--phenoFile",
