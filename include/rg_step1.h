@@ -99,7 +99,7 @@ int rg_l0_blocks(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int3
  * order, ALT dosage in [0, 2], -3 = missing: exactly what rg_pgen_read_dosages / PgenReader::Read return).  Same results
  * contract as rg_l0_blocks (the predictors of the blocks land in W); the arithmetic is fp64 throughout -- standardised
  * genotypes materialised per block, fold Grams and G~ Y as fp64 MFMA GEMMs, the same batched Cholesky -- where the 2-bit path
- * uses exact integer Grams.  K-fold CV only in this revision (RG_ERR_STATE with cv_folds == 0).  A value outside [0, 2]
+ * uses exact integer Grams.  K-fold and leave-one-out CV as set in rg_problem.  A value outside [0, 2]
  * other than -3 is reported by the next rg_sync ("... has a value not in [0,2] or missing", Geno.cpp:1819-1820). */
 int rg_l0_blocks_f64(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int32_t* bs,
                      const double* const* rows, int64_t row_stride, int mem_kind);

@@ -192,6 +192,23 @@ __global__ __launch_bounds__(256) void k_f64_wscale(double* W, int64_t Np, int R
   if (pos < Np) w[pos] = keptp[pos] ? (w[pos] - mean) * invsd : 0.0;
 }
 
+// gt[pos][j] = G[j][pos]: the sample-major standardised genotypes the leave-one-out path appends to its systems as extra
+// right-hand-side rows (loocv.hip); grid (Np / 64, n64 / 64), a 64 x 64 tile through LDS
+__global__ __launch_bounds__(256) void k_f64_transpose(const double* G, int64_t Np, int n64, double* gt) {
+  __shared__ double t[64][65];
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  const int j0 = blockIdx.y * 64;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int jl = e >> 6, pl = e & 63;
+    t[jl][pl] = G[(int64_t)(j0 + jl) * Np + p0 + pl];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int pl = e >> 6, jl = e & 63;
+    gt[(p0 + pl) * n64 + j0 + jl] = t[jl][pl];
+  }
+}
+
 template <class T>
 T* f64_buf(rg_ctx* ctx, int slot, size_t count) {
   const size_t bytes = std::max<size_t>(8, count * sizeof(T));
@@ -209,7 +226,6 @@ T* f64_buf(rg_ctx* ctx, int slot, size_t count) {
 
 int rg_l0_blocks_f64_impl(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32_t* bs, const double* const* rows,
                           int64_t row_stride, int mem_kind) {
-  if (ctx->loocv) { ctx->err = "rg_l0_blocks_f64: leave-one-out level 0 on dosages is not served yet (use K-fold CV)"; return RG_ERR_STATE; }
   if (ctx->C > 64) { ctx->err = "rg_l0_blocks_f64: more than 64 covariate basis columns"; return RG_ERR_ARG; }
   if (ctx->R0 > F64_RMAX) { ctx->err = "rg_l0_blocks_f64: more than 8 level-0 ridge values"; return RG_ERR_ARG; }
   hipStream_t st = ctx->stream;
@@ -264,6 +280,28 @@ int rg_l0_blocks_f64_impl(rg_ctx* ctx, int nblk, const int32_t* block_ids, const
     hipLaunchKernelGGL(k_f64_resid, dim3(gpos, nb), dim3(256), 0, st, G, Np, gx, Xp, C, part);
     hipLaunchKernelGGL(k_f64_scale1, dim3((nb + 63) / 64), dim3(64), 0, st, part, (int)gpos, nb, denom, b, sc, ctx->d_info);
     hipLaunchKernelGGL(k_f64_scale2, dim3(gpos, nb), dim3(256), 0, st, G, Np, sc);
+    if (ctx->loocv) {
+      // calc_cv_matrices, LOOCV branch (Data.cpp:755-767): the full Gram and G~ Y; the standardised genotypes, sample-major,
+      // ride along as extra right-hand-side rows of the (A + lambda_r I) systems (loocv.hip) -- the same launches as the
+      // 2-bit path from here on, for one block
+      F64_HIP(hipMemcpyAsync(ctx->d_blockid, &block_ids[b], sizeof(int32_t), hipMemcpyHostToDevice, st));
+      rg_launch_dgemm_nt(st, G, Np, G, Np, n64, n64, Np, ctx->d_sum, n64);
+      rg_launch_dgemm_nt(st, Yp, Np, G, Np, rhs_pad, n64, Np, ctx->d_sum + (int64_t)n64 * n64, n64);
+      hipLaunchKernelGGL(k_f64_transpose, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, G, Np, n64, ctx->d_gt);
+      rg_launch_chol_solve_formed_x(st, ctx->d_sum, msz, ctx->d_fold, msz, 1, ctx->d_lambda, R0, ctx->d_bs, 0, 1, ctx->d_wk,
+                                    ctx->rtot_wk * n64, n64, (int)(ctx->rtot_wk - n64), 0, ctx->d_dinv, ctx->d_info + 1,
+                                    &ctx->tm.n_chol_launches, 0, ctx->d_gt, (int64_t)Np * n64, rtot, 1, 0, -1, 0);
+      LoocvArgs la;
+      la.nblk = 1; la.R0 = R0; la.P = P; la.C = C; la.n128 = ctx->n128; la.n64 = n64; la.rtot = (int)ctx->rtot_wk;
+      la.row_g0 = rtot; la.Np = Np; la.pk_ld = ctx->pk_ld; la.pk_blk_stride = 0; la.pk = nullptr;
+      la.mu = nullptr; la.sc = nullptr; la.Bm = nullptr; la.V = ctx->d_V; la.maskp = ctx->d_maskp;
+      la.neff = ctx->d_neff; la.bs = ctx->d_bs; la.blockid = ctx->d_blockid; la.wk = ctx->d_wk; la.gt = ctx->d_gt;
+      la.W = ctx->d_W;
+      rg_launch_l0_loocv(st, la, ctx->d_lpart, ctx->d_lpart + (size_t)R0 * P * 64, 64);
+      if (mem_kind != RG_MEM_DEVICE) F64_HIP(hipStreamSynchronize(st));
+      ctx->block_done[block_ids[b]] = 1;
+      continue;
+    }
     // calc_cv_matrices: per-fold Gram and right-hand sides into the workspace layout [rtot][n64] of block slot 0
     for (int f = 0; f < K; ++f) {
       double* Ff = ctx->d_fold + (int64_t)f * msz;

@@ -216,7 +216,7 @@ class Step1Engine:
 
     def l0_blocks_f64_host(self, block_ids: Sequence[int], rows: List[np.ndarray]):
         """Level 0 on non-integer genotypes: rows[b] is (bs_b, N_file) float64, C-contiguous, file sample order, ALT dosages
-        in [0, 2] with -3 for missing (what PgenFile.read_dosages returns).  K-fold CV only."""
+        in [0, 2] with -3 for missing (what PgenFile.read_dosages returns).  K-fold or leave-one-out CV as the problem was set up."""
         nb = len(block_ids)
         ids = np.ascontiguousarray(block_ids, dtype=np.int32)
         bs = np.ascontiguousarray([r.shape[0] for r in rows], dtype=np.int32)

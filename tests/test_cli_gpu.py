@@ -393,6 +393,12 @@ def test_cli_pgen_dosages(tmp_path):
         assert h1 == h2 and ids1 == ids2
         assert np.allclose(v1, v2, rtol=2e-5, atol=1e-7, equal_nan=True)
         assert not np.allclose(ref.loco[k - 1], hard.loco[k - 1], rtol=1e-3)      # the dosages matter: hardcalls give other numbers
-    # leave-one-out level 0 on dosages is not served: an error, not a silent hardcall run
-    r = _run(args + ["--loocv"], str(tmp_path))
-    assert r.returncode != 0 and "leave-one-out level 0 on dosages is not served yet" in r.stdout
+    # leave-one-out CV on the same dosages
+    r = _run(args[:-1] + [str(tmp_path / "cl"), "--loocv"], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    opt.loocv, opt.out = True, str(tmp_path / "ol")
+    orc.run_step1(opt, write_files=True)
+    for k in (1, 2):
+        _, _, v1, _ = _parse_loco(str(tmp_path / ("cl_%d.loco" % k)))
+        _, _, v2, _ = _parse_loco(str(tmp_path / ("ol_%d.loco" % k)))
+        assert np.allclose(v1, v2, rtol=2e-5, atol=1e-7, equal_nan=True)

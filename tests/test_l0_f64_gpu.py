@@ -21,7 +21,7 @@ def _setup(opt):
     blocks = orc.chrom_blocks(chrom, bim.chr_read, opt.bsize)
     h0 = orc.set_ridge_params(opt.n_ridge_l0)
     lam = chrom.size * (1 - h0) / h0
-    cv_sizes = orc.set_folds(prep.ind_in_analysis, opt.cv_folds)
+    cv_sizes = None if opt.loocv else orc.set_folds(prep.ind_in_analysis, opt.cv_folds)
     return prep, bed, offs, blocks, lam, cv_sizes
 
 
@@ -33,10 +33,12 @@ def _engine(prep, blocks, lam, cv_sizes, bsize):
     return eng
 
 
-def test_f64_path_reproduces_the_2bit_path(example_dir):
+@pytest.mark.parametrize("loocv", [False, True])
+def test_f64_path_reproduces_the_2bit_path(example_dir, loocv):
     E = example_dir
     opt = orc.Step1Options(bed=os.path.join(E, "example"), pheno_file=os.path.join(E, "phenotype_bin_wNA.txt"),
-                           covar_file=os.path.join(E, "covariates.txt"), remove=[os.path.join(E, "fid_iid_to_remove.txt")], bsize=100)
+                           covar_file=os.path.join(E, "covariates.txt"), remove=[os.path.join(E, "fid_iid_to_remove.txt")], bsize=100,
+                           loocv=loocv)
     prep, bed, offs, blocks, lam, cv_sizes = _setup(opt)
     B, P = len(blocks), prep.Y.shape[1]
     rows = [np.ascontiguousarray(bed[offs[s:s + bs]]) for (_, s, bs) in blocks]
@@ -58,13 +60,14 @@ def test_f64_path_reproduces_the_2bit_path(example_dir):
     b.close()
 
 
-def test_f64_path_matches_oracle_on_dosages(tmp_path):
+@pytest.mark.parametrize("loocv", [False, True])
+def test_f64_path_matches_oracle_on_dosages(tmp_path, loocv):
     from tests.util import synth_dosages, write_plink
     N, M = 900, 260
     g = synth_dosages(M, N, miss_rate=0.01, seed=5)
     pre = str(tmp_path / "d")
     write_plink(pre, g, np.repeat([1, 2], [140, 120]), P=2, ncov=2, seed=6, missing_pheno=0.03)
-    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=64)
+    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=64, loocv=loocv)
     prep, bed, offs, blocks, lam, cv_sizes = _setup(opt)
     B, P = len(blocks), prep.Y.shape[1]
     rng = np.random.default_rng(8)
@@ -83,10 +86,10 @@ def test_f64_path_matches_oracle_on_dosages(tmp_path):
         mu = np.where(ok, G, 0).sum(1) / ok.sum(1)
         G = np.where(miss, mu[:, None], G) * prep.ind_in_analysis[None, :]               # Geno.cpp:1805-1812
         Gr, _ = orc.residualize_genotypes(G, prep)
-        Wb = orc.ridge_level_0(Gr, prep, cv_sizes, lam)
+        Wb = orc.ridge_level_0_loocv(Gr, prep, lam) if loocv else orc.ridge_level_0(Gr, prep, cv_sizes, lam)
         for ph in range(P):
             assert rel_err(eng.get_w(blk, ph), Wb[ph]) < 1e-8, (blk, ph)
-    # leave-one-out level 0 is refused, a value outside [0, 2] is reported
+    # a value outside [0, 2] is reported
     eng.close()
     bad = [d.copy() for d in dos]
     bad[1][3, 7] = 2.5
