@@ -1,0 +1,51 @@
+/* rg_bgen.h -- C ABI of the BGEN v1.2 input of the Step-1 path (`regenie --step 1 --bgen FILE`).
+ *
+ * It replaces, for the files regenie reads through its own fast path (layout 2, 8-bit probabilities, unphased, biallelic,
+ * diploid; zlib / zstd / no compression -- check_bgen, Geno.cpp:1826-1958):
+ *   rg_bgen_open            the variant scan of prep_bgen (BgenParser::read_variant loop)   Geno.cpp:38-175
+ *   rg_bgen_sample_id       BgenParser::get_sample_ids (embedded identifiers = FID_IID)     Geno.cpp:146-152
+ *   rg_bgen_variant         snpinfo[] fields: chromosome, position, rsid, alleles, offset   Geno.cpp:73-128
+ *   rg_bgen_read_dosages    readChunkFromBGEN + readChunkFromBGENFileToG_fast               Geno.cpp:2122-2171, :1574-1699
+ * The rows are ALT-count style dosages in [0, 2] (G = prob1 + 2 prob0, or prob1 + 2 prob2 with ref_first), -3 = missing:
+ * the input of rg_l0_blocks_f64 (rg_step1.h), which applies the reference's mean imputation.  Host-only code.
+ * Conventions as in rg_pgen.h: 0 on success, <0 on error, rg_bgen_last_error(h); rg_bgen_open always stores a handle.
+ */
+#ifndef RG_BGEN_H
+#define RG_BGEN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rg_bgen rg_bgen;
+
+#define RG_BGEN_OK 0
+#define RG_BGEN_ERR_ARG (-1)
+#define RG_BGEN_ERR_FORMAT (-2)      /* not a bgen file, malformed or truncated, inflate failure */
+#define RG_BGEN_ERR_UNSUPPORTED (-3) /* layout 1, phased / non-8-bit / multiallelic / non-diploid data */
+
+int rg_bgen_open(rg_bgen** out, const char* path); /* parses the header and scans the variant identifying data */
+void rg_bgen_close(rg_bgen* h);
+const char* rg_bgen_last_error(const rg_bgen* h);
+
+/* compression: 0 none, 1 zlib, 2 zstd.  Any pointer may be NULL. */
+int rg_bgen_info(const rg_bgen* h, int64_t* n_samples, int64_t* n_variants, int32_t* compression,
+                 int32_t* has_sample_ids);
+/* Embedded sample identifier i (regenie uses it as FID_IID as it is); the pointer stays valid until rg_bgen_close. */
+int rg_bgen_sample_id(const rg_bgen* h, int64_t i, const char** id);
+/* Identifying data of variant j (file order).  Strings stay valid until rg_bgen_close; file_offset is the position of the
+ * record (regenie's snpinfo[].offset). */
+int rg_bgen_variant(const rg_bgen* h, int64_t j, const char** chrom, uint32_t* position, const char** rsid,
+                    const char** allele0, const char** allele1, int64_t* file_offset);
+/* Worker threads of rg_bgen_read_dosages (default 1; the reference inflates a block's variants under OpenMP). */
+int rg_bgen_set_threads(rg_bgen* h, int32_t n_threads);
+/* Dosage rows of n variants: rows[k * row_stride .. + n_samples) doubles. */
+int rg_bgen_read_dosages(rg_bgen* h, int64_t n, const int64_t* variant_idx, int32_t ref_first, double* rows,
+                         int64_t row_stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

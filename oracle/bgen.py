@@ -1,0 +1,136 @@
+"""TEST INFRASTRUCTURE -- CPU restatement of the BGEN v1.2 reading regenie does for Step-1 `--bgen` input, plus a small BGEN
+WRITER for fixtures.  Only tests/ may import this module; the product reader is regenie_amd/csrc/bgen_reader.h.
+
+The reference reads the variant list through the external BGEN library (not vendored under /root/reference: "BGEN v1.1.7",
+Makefile:135-141) and the genotype blocks of "layout 2, 8-bit" files through its own fast path (Geno.cpp:2122-2171,
+:1574-1699).  The header / sample block / variant identifying data follow the published BGEN v1.2 layout; the dosage
+arithmetic follows the reference's fast path line by line.  PINNED by the reference's fixture pairs: example.bgen against
+example.bed, example_3chr.bgen and example_3chr_zstd.bgen against example_3chr.bed (the reference's tests compare bgen and
+bed runs, test/test_bash.sh:143-216) -- every dosage must equal the .bed genotype."""
+from __future__ import annotations
+
+import ctypes
+import struct
+import zlib
+
+import numpy as np
+
+
+class BgenError(ValueError):
+    pass
+
+
+def _zstd_decompress(src: bytes, dlen: int) -> bytes:
+    lib = ctypes.CDLL("libzstd.so.1")
+    lib.ZSTD_decompress.restype = ctypes.c_size_t
+    lib.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    dst = ctypes.create_string_buffer(dlen)
+    n = lib.ZSTD_decompress(dst, dlen, src, len(src))
+    if n != dlen:
+        raise BgenError("failed to decompress genotype data block")
+    return dst.raw
+
+
+class BgenOracle:
+    def __init__(self, path: str):
+        d = open(path, "rb").read()
+        self.data = d
+        if len(d) < 24:
+            raise BgenError("invalid bgen file")
+        offset, lh, self.m, self.n = struct.unpack_from("<IIII", d, 0)
+        if d[16:20] not in (b"bgen", b"\0\0\0\0"):
+            raise BgenError("invalid bgen file (magic number mismatch)")
+        (flags,) = struct.unpack_from("<I", d, 4 + lh - 4)
+        self.compression = flags & 3
+        self.layout = (flags >> 2) & 15
+        if self.layout != 2:
+            raise BgenError("bgen layout %d is not supported" % self.layout)
+        pos = 4 + lh
+        self.sample_ids = []
+        if flags >> 31:
+            lsi, ns = struct.unpack_from("<II", d, pos)
+            p = pos + 8
+            for _ in range(ns):
+                (l,) = struct.unpack_from("<H", d, p)
+                self.sample_ids.append(d[p + 2:p + 2 + l].decode())
+                p += 2 + l
+        pos = 4 + offset
+        self.variants = []
+        for _ in range(self.m):
+            start = pos
+            fields = []
+            for _k in range(3):
+                (l,) = struct.unpack_from("<H", d, pos)
+                fields.append(d[pos + 2:pos + 2 + l].decode())
+                pos += 2 + l
+            bp, k = struct.unpack_from("<IH", d, pos)
+            pos += 6
+            if k != 2:
+                raise BgenError("only bi-allelic variants are accepted")
+            al = []
+            for _a in range(2):
+                (l,) = struct.unpack_from("<I", d, pos)
+                al.append(d[pos + 4:pos + 4 + l].decode())
+                pos += 4 + l
+            (c,) = struct.unpack_from("<I", d, pos)
+            self.variants.append(dict(offset=start, data=pos, id=fields[0], rsid=fields[1], chrom=fields[2], pos=bp, a0=al[0], a1=al[1]))
+            pos += 4 + c
+
+    def dosages(self, j: int, ref_first: bool = False) -> np.ndarray:
+        """readChunkFromBGENFileToG_fast (Geno.cpp:1600-1690): G = prob1 + 2 prob0 (prob1 + 2 prob2 with --ref-first)."""
+        d, v = self.data, self.variants[j]
+        (c,) = struct.unpack_from("<I", d, v["data"])
+        if self.compression == 0:
+            blk = d[v["data"] + 4:v["data"] + 4 + c]
+        else:
+            (dl,) = struct.unpack_from("<I", d, v["data"] + 4)
+            raw = d[v["data"] + 8:v["data"] + 4 + c]
+            blk = zlib.decompress(raw) if self.compression == 1 else _zstd_decompress(raw, dl)
+            if len(blk) != dl:
+                raise BgenError("failed to decompress genotype data block for variant: " + v["rsid"])
+        n, k, pmin, pmax = struct.unpack_from("<IHBB", blk, 0)
+        if n != self.n or k != 2 or pmin != 2 or pmax != 2:
+            raise BgenError("unsupported genotype data block")
+        ploidy = np.frombuffer(blk, np.uint8, n, 8)
+        phased, bits = blk[8 + n], blk[9 + n]
+        if phased or bits != 8:
+            raise BgenError("only unphased 8-bit bgen data is supported")
+        pr = np.frombuffer(blk, np.uint8, 2 * n, 10 + n).reshape(n, 2) / 255.0
+        p0, p1 = pr[:, 0], pr[:, 1]
+        p2 = np.maximum(1 - p0 - p1, 0.0)
+        g = p1 + 2 * p2 if ref_first else p1 + 2 * p0
+        return np.where(ploidy & 0x80, -3.0, g)
+
+
+def write_bgen(path: str, probs: np.ndarray, missing: np.ndarray, variants, sample_ids=None, compression: int = 1) -> None:
+    """probs: M x N x 2 uint8 (P(hom first allele), P(het)); missing: M x N bool; variants: list of
+    (chrom, pos, rsid, allele0, allele1).  compression 0 / 1 (zlib)."""
+    m, n, _ = probs.shape
+    body = bytearray()
+    for j in range(m):
+        ch, bp, rs, a0, a1 = variants[j]
+        rec = bytearray()
+        for s in ("", rs, str(ch)):
+            b = s.encode()
+            rec += struct.pack("<H", len(b)) + b
+        rec += struct.pack("<IH", bp, 2)
+        for a in (a0, a1):
+            b = a.encode()
+            rec += struct.pack("<I", len(b)) + b
+        blk = struct.pack("<IHBB", n, 2, 2, 2) + np.where(missing[j], 0x82, 0x02).astype(np.uint8).tobytes() + bytes([0, 8])
+        blk += np.where(missing[j][:, None], 0, probs[j]).astype(np.uint8).tobytes()
+        if compression == 1:
+            z = zlib.compress(blk)
+            rec += struct.pack("<II", len(z) + 4, len(blk)) + z
+        else:
+            rec += struct.pack("<I", len(blk)) + blk
+        body += rec
+    flags = compression | (2 << 2) | ((1 << 31) if sample_ids is not None else 0)
+    header = struct.pack("<III", 20, m, n) + b"bgen" + struct.pack("<I", flags)
+    sblock = b""
+    if sample_ids is not None:
+        ids = b"".join(struct.pack("<H", len(s.encode())) + s.encode() for s in sample_ids)
+        sblock = struct.pack("<II", 8 + len(ids), n) + ids
+    offset = len(header) + len(sblock)
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<I", offset) + header + sblock + bytes(body))

@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librg_step1_hip.so")
 SOURCES = ["rg_api.hip", "bed_prep.hip", "gram_i8.hip", "gram_fp4.hip", "assemble.hip", "chol.hip", "pred.hip", "l1.hip", "ubench.hip", "loocv.hip", "l1x.hip", "l0_f64.hip",
-           "pgen_api.cpp"]  # pgen_api.cpp: host-only (.pgen hardcall input, include/rg_pgen.h)
+           "pgen_api.cpp", "bgen_api.cpp"]  # host-only: .pgen input (include/rg_pgen.h), BGEN v1.2 input (include/rg_bgen.h)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result", "-Wno-inline-asm"]
 
@@ -41,6 +41,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "host", "rg_step1_main.cpp"),
                                                       os.path.join(CSRC, "rg_internal.h"),
                                                       os.path.join(CSRC, "pgen_reader.h"),
+                                                      os.path.join(CSRC, "bgen_reader.h"),
+                                                      os.path.join(HERE, "..", "include", "rg_bgen.h"),
                                                       os.path.join(HERE, "..", "include", "rg_pgen.h"),
                                                       os.path.join(HERE, "..", "include", "rg_step1.h")]
     stamp = os.path.join(LIBDIR, "build.stamp")
@@ -64,7 +66,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
             if verbose and r.stderr.strip():
                 sys.stderr.write(r.stderr)
             objs.append(obj)
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs,
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lz", "-ldl"],
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))

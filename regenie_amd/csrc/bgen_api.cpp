@@ -1,0 +1,118 @@
+// C ABI over rgbgen::Reader (include/rg_bgen.h).  Host-only.
+#include <algorithm>
+#include <new>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rg_bgen.h"
+#include "bgen_reader.h"
+
+struct rg_bgen {
+  rgbgen::Reader rd;
+  std::string err;
+  bool ok = false;
+  int threads = 1;
+};
+
+namespace {
+int fail(rg_bgen* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  return code;
+}
+int classify(const std::string& m) {
+  for (const char* k : {"not supported", "only bi-allelic", "only unphased", "only diploid"})
+    if (m.find(k) != std::string::npos) return RG_BGEN_ERR_UNSUPPORTED;
+  return RG_BGEN_ERR_FORMAT;
+}
+}  // namespace
+
+extern "C" {
+
+int rg_bgen_open(rg_bgen** out, const char* path) {
+  if (!out) return RG_BGEN_ERR_ARG;
+  *out = nullptr;
+  rg_bgen* h = new (std::nothrow) rg_bgen();
+  if (!h) return RG_BGEN_ERR_ARG;
+  *out = h;
+  if (!path) return fail(h, RG_BGEN_ERR_ARG, "rg_bgen_open: null path");
+  try {
+    h->rd.open(path);
+  } catch (const std::exception& e) {
+    h->rd.close();
+    return fail(h, classify(e.what()), e.what());
+  }
+  h->ok = true;
+  return RG_BGEN_OK;
+}
+
+void rg_bgen_close(rg_bgen* h) { delete h; }
+const char* rg_bgen_last_error(const rg_bgen* h) { return h ? h->err.c_str() : "null bgen handle"; }
+
+int rg_bgen_info(const rg_bgen* h, int64_t* n_samples, int64_t* n_variants, int32_t* compression, int32_t* has_sample_ids) {
+  if (!h || !h->ok) return RG_BGEN_ERR_ARG;
+  if (n_samples) *n_samples = h->rd.n_samples();
+  if (n_variants) *n_variants = h->rd.n_variants();
+  if (compression) *compression = h->rd.compression();
+  if (has_sample_ids) *has_sample_ids = h->rd.has_sample_ids() ? 1 : 0;
+  return RG_BGEN_OK;
+}
+
+int rg_bgen_sample_id(const rg_bgen* h, int64_t i, const char** id) {
+  if (!h || !h->ok || !id || i < 0 || i >= (int64_t)h->rd.sample_ids().size()) return RG_BGEN_ERR_ARG;
+  *id = h->rd.sample_ids()[(size_t)i].c_str();
+  return RG_BGEN_OK;
+}
+
+int rg_bgen_variant(const rg_bgen* h, int64_t j, const char** chrom, uint32_t* position, const char** rsid, const char** allele0,
+                    const char** allele1, int64_t* file_offset) {
+  if (!h || !h->ok || j < 0 || j >= (int64_t)h->rd.n_variants()) return RG_BGEN_ERR_ARG;
+  const rgbgen::Variant& v = h->rd.variants()[(size_t)j];
+  if (chrom) *chrom = v.chrom.c_str();
+  if (position) *position = v.position;
+  if (rsid) *rsid = v.rsid.c_str();
+  if (allele0) *allele0 = v.a0.c_str();
+  if (allele1) *allele1 = v.a1.c_str();
+  if (file_offset) *file_offset = (int64_t)v.offset;
+  return RG_BGEN_OK;
+}
+
+int rg_bgen_set_threads(rg_bgen* h, int32_t n_threads) {
+  if (!h) return RG_BGEN_ERR_ARG;
+  if (n_threads < 1) return fail(h, RG_BGEN_ERR_ARG, "rg_bgen_set_threads: thread count must be at least 1");
+  h->threads = std::min<int32_t>(n_threads, 256);
+  return RG_BGEN_OK;
+}
+
+int rg_bgen_read_dosages(rg_bgen* h, int64_t n, const int64_t* variant_idx, int32_t ref_first, double* rows, int64_t row_stride) {
+  if (!h) return RG_BGEN_ERR_ARG;
+  if (!h->ok) return fail(h, RG_BGEN_ERR_ARG, "bgen file is not open");
+  if (n < 0 || (n > 0 && (!variant_idx || !rows)) || row_stride < (int64_t)h->rd.n_samples())
+    return fail(h, RG_BGEN_ERR_ARG, "rg_bgen_read_dosages: bad argument");
+  for (int64_t k = 0; k < n; ++k)
+    if (variant_idx[k] < 0 || variant_idx[k] >= (int64_t)h->rd.n_variants())
+      return fail(h, RG_BGEN_ERR_ARG, "variant index " + std::to_string(variant_idx[k] + 1) + " is out of range");
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(h->threads, n / 4));
+  std::vector<std::string> errs((size_t)nt);
+  auto work = [&](int t) {
+    std::vector<uint8_t> cbuf, ubuf;
+    const int64_t k0 = n * t / nt, k1 = n * (t + 1) / nt;
+    try {
+      for (int64_t k = k0; k < k1; ++k) h->rd.read_dosages((uint32_t)variant_idx[k], ref_first != 0, rows + k * row_stride, cbuf, ubuf);
+    } catch (const std::exception& e) {
+      errs[(size_t)t] = e.what();
+      if (errs[(size_t)t].empty()) errs[(size_t)t] = "bgen read failed";
+    }
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+  }
+  for (const auto& e : errs)
+    if (!e.empty()) return fail(h, classify(e), e);
+  return RG_BGEN_OK;
+}
+}

@@ -1,0 +1,231 @@
+// BGEN v1.2 reader for regenie's Step-1 `--bgen` input: the host-side counterpart of prep_bgen's variant scan
+// (Geno.cpp:38-175) and of the self-contained fast path readChunkFromBGEN / readChunkFromBGENFileToG_fast
+// (Geno.cpp:2122-2171, :1574-1699) that regenie uses for "layout 2, 8 bits per probability" files (the UK Biobank format):
+// per variant, inflate the genotype block and turn the two stored probabilities of every sample into a dosage,
+//     prob2 = max(1 - prob0 - prob1, 0),   G = prob1 + 2 prob0   (or prob1 + 2 prob2 with --ref-first),   missing -> -3.
+// The rows go to the fp64 level 0 (rg_l0_blocks_f64), which does the reference's mean imputation.  Written from the
+// published BGEN v1.2 layout (the reference links the external BGEN library for everything but that fast path; none of it is
+// used here).  Scope = what the fast path accepts: layout 2, unphased, biallelic, diploid, 8-bit probabilities, zlib or zstd
+// (zstd through libzstd.so.1 at run time) or no compression.  Anything else is an error, never a silent fallback.
+#pragma once
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace rgbgen {
+
+struct Variant {
+  uint64_t offset;   // file offset of the variant identifying data (what regenie keeps in snpinfo[].offset)
+  uint64_t data;     // file offset of the genotype data block (its 4-byte length field)
+  uint32_t position;
+  std::string id, rsid, chrom, a0, a1;
+};
+
+class Reader {
+ public:
+  Reader() = default;
+  Reader(const Reader&) = delete;
+  Reader& operator=(const Reader&) = delete;
+  ~Reader() { close(); }
+  void close() {
+    if (fd_ >= 0) ::close(fd_);
+    fd_ = -1;
+  }
+
+  uint32_t n_samples() const { return n_; }
+  uint32_t n_variants() const { return m_; }
+  int compression() const { return comp_; }
+  int layout() const { return layout_; }
+  bool has_sample_ids() const { return !ids_.empty(); }
+  const std::vector<std::string>& sample_ids() const { return ids_; }
+  const std::vector<Variant>& variants() const { return vars_; }
+
+  void open(const std::string& path) {
+    close();
+    fd_ = ::open(path.c_str(), O_RDONLY);
+    if (fd_ < 0) throw std::runtime_error("cannot open file : " + path);
+    struct stat st;
+    if (fstat(fd_, &st) != 0) throw std::runtime_error("cannot stat file : " + path);
+    fsize_ = (uint64_t)st.st_size;
+    uint8_t h[24];
+    if (fsize_ < 24 || !pread_all(h, 24, 0)) throw std::runtime_error("invalid bgen file (too short) : " + path);
+    uint32_t offset, lh;
+    std::memcpy(&offset, h, 4);
+    std::memcpy(&lh, h + 4, 4);
+    std::memcpy(&m_, h + 8, 4);
+    std::memcpy(&n_, h + 12, 4);
+    if (std::memcmp(h + 16, "bgen", 4) != 0 && std::memcmp(h + 16, "\0\0\0\0", 4) != 0)
+      throw std::runtime_error("invalid bgen file (magic number mismatch) : " + path);
+    if (lh < 20 || 4ull + lh > fsize_) throw std::runtime_error("invalid bgen header : " + path);
+    uint32_t flags;
+    if (!pread_all(&flags, 4, 4ull + lh - 4)) throw std::runtime_error("cannot read bgen header : " + path);
+    comp_ = (int)(flags & 3);
+    layout_ = (int)((flags >> 2) & 15);
+    if (layout_ != 2) throw std::runtime_error("bgen layout " + std::to_string(layout_) + " is not supported (layout 2, i.e. BGEN v1.2, is) : " + path);
+    if (comp_ > 2) throw std::runtime_error("unknown bgen compression flag : " + path);
+    if (n_ == 0 || m_ == 0) throw std::runtime_error("empty bgen file : " + path);
+    uint64_t pos = 4ull + lh;
+    if (flags >> 31) {  // sample identifier block
+      uint8_t b[8];
+      if (!pread_all(b, 8, pos)) throw std::runtime_error("cannot read bgen sample block : " + path);
+      uint32_t lsi, ns;
+      std::memcpy(&lsi, b, 4);
+      std::memcpy(&ns, b + 4, 4);
+      if (ns != n_) throw std::runtime_error("bgen sample block does not match the header's sample count : " + path);
+      std::vector<uint8_t> blk(lsi > 8 ? lsi - 8 : 0);
+      if (!blk.empty() && !pread_all(blk.data(), blk.size(), pos + 8)) throw std::runtime_error("cannot read bgen sample block : " + path);
+      size_t p = 0;
+      for (uint32_t i = 0; i < ns; ++i) {
+        if (p + 2 > blk.size()) throw std::runtime_error("malformed bgen sample block : " + path);
+        uint16_t l;
+        std::memcpy(&l, blk.data() + p, 2);
+        p += 2;
+        if (p + l > blk.size()) throw std::runtime_error("malformed bgen sample block : " + path);
+        ids_.emplace_back((const char*)blk.data() + p, l);
+        p += l;
+      }
+    }
+    // variant scan: identifying data, then skip the genotype block
+    pos = 4ull + offset;
+    vars_.reserve(m_);
+    std::vector<uint8_t> buf(1 << 16);
+    for (uint32_t j = 0; j < m_; ++j) {
+      Variant v;
+      v.offset = pos;
+      auto str16 = [&](std::string& s) {
+        uint16_t l;
+        need(pos, 2, path);
+        pread_all(&l, 2, pos);
+        pos += 2;
+        need(pos, l, path);
+        s.resize(l);
+        if (l) pread_all(&s[0], l, pos);
+        pos += l;
+      };
+      str16(v.id);
+      str16(v.rsid);
+      str16(v.chrom);
+      need(pos, 6, path);
+      uint16_t k;
+      pread_all(&v.position, 4, pos);
+      pread_all(&k, 2, pos + 4);
+      pos += 6;
+      if (k != 2) throw std::runtime_error("only bi-allelic variants are accepted (variant '" + v.rsid + "' has " + std::to_string(k) + " alleles).");
+      for (int a = 0; a < 2; ++a) {
+        uint32_t l;
+        need(pos, 4, path);
+        pread_all(&l, 4, pos);
+        pos += 4;
+        need(pos, l, path);
+        std::string& s = a ? v.a1 : v.a0;
+        s.resize(l);
+        if (l) pread_all(&s[0], l, pos);
+        pos += l;
+      }
+      v.data = pos;
+      uint32_t c;
+      need(pos, 4, path);
+      pread_all(&c, 4, pos);
+      pos += 4ull + c;
+      if (pos > fsize_) throw std::runtime_error("bgen file ends inside the data of variant '" + v.rsid + "' : " + path);
+      vars_.push_back(std::move(v));
+    }
+  }
+
+  // Dosage row of variant j: n_samples doubles, -3 = missing.
+  void read_dosages(uint32_t j, bool ref_first, double* out, std::vector<uint8_t>& cbuf, std::vector<uint8_t>& ubuf) const {
+    if (fd_ < 0) throw std::runtime_error("bgen file is closed");
+    if (j >= m_) throw std::runtime_error("variant index out of range");
+    const Variant& v = vars_[j];
+    uint32_t c = 0, d = 0;
+    if (!pread_all(&c, 4, v.data)) throw std::runtime_error("cannot read bgen file");
+    const uint8_t* blk;
+    size_t blen;
+    if (comp_ == 0) {
+      ubuf.resize(c);
+      if (c && !pread_all(ubuf.data(), c, v.data + 4)) throw std::runtime_error("cannot read bgen file");
+      blk = ubuf.data();
+      blen = c;
+    } else {
+      if (c < 4 || !pread_all(&d, 4, v.data + 4)) throw std::runtime_error("failed to decompress genotype data block for variant: " + v.rsid);
+      cbuf.resize(c - 4);
+      if (c > 4 && !pread_all(cbuf.data(), c - 4, v.data + 8)) throw std::runtime_error("cannot read bgen file");
+      ubuf.resize(d);
+      bool fail;
+      if (comp_ == 1) {
+        uLongf dl = d;
+        fail = uncompress(ubuf.data(), &dl, cbuf.data(), c - 4) != Z_OK || dl != d;
+      } else {
+        fail = zstd()(ubuf.data(), d, cbuf.data(), c - 4) != d;
+      }
+      if (fail) throw std::runtime_error("failed to decompress genotype data block for variant: " + v.rsid);  // Geno.cpp:1616-1617
+      blk = ubuf.data();
+      blen = d;
+    }
+    // probability block (layout 2): N, K, min / max ploidy, N ploidy-and-missingness bytes, phased flag, bits, probabilities
+    if (blen < 10ull + n_) throw std::runtime_error("malformed genotype data block for variant: " + v.rsid);
+    uint32_t nind;
+    uint16_t k;
+    std::memcpy(&nind, blk, 4);
+    std::memcpy(&k, blk + 4, 2);
+    const uint8_t pmin = blk[6], pmax = blk[7];
+    if (nind != n_) throw std::runtime_error("sample count of variant '" + v.rsid + "' does not match the bgen header");
+    if (k != 2) throw std::runtime_error("only bi-allelic variants are accepted (variant '" + v.rsid + "').");
+    if (pmin != 2 || pmax != 2) throw std::runtime_error("only diploid genotypes are supported (variant '" + v.rsid + "').");
+    const uint8_t* ploidy = blk + 8;
+    const uint8_t phased = blk[8 + n_], bits = blk[9 + n_];
+    if (phased) throw std::runtime_error("only unphased bgen are supported.");  // Geno.cpp:66-67
+    if (bits != 8) throw std::runtime_error("bgen probabilities with " + std::to_string((int)bits) + " bits are not supported (8-bit encoding is) : variant " + v.rsid);
+    if (blen < 10ull + n_ + 2ull * n_) throw std::runtime_error("malformed genotype data block for variant: " + v.rsid);
+    const uint8_t* pr = blk + 10 + n_;
+    for (uint32_t i = 0; i < n_; ++i) {
+      if (ploidy[i] & 0x80) { out[i] = -3.0; continue; }
+      const double p0 = pr[2 * i] / 255.0, p1 = pr[2 * i + 1] / 255.0;
+      const double p2 = std::max(1.0 - p0 - p1, 0.0);
+      out[i] = ref_first ? p1 + 2.0 * p2 : p1 + 2.0 * p0;   // Geno.cpp:1672-1679
+    }
+  }
+
+ private:
+  int fd_ = -1;
+  uint64_t fsize_ = 0;
+  uint32_t m_ = 0, n_ = 0;
+  int comp_ = 0, layout_ = 0;
+  std::vector<std::string> ids_;
+  std::vector<Variant> vars_;
+
+  bool pread_all(void* dst, uint64_t len, uint64_t off) const {
+    uint8_t* d = (uint8_t*)dst;
+    while (len) {
+      const ssize_t r = ::pread(fd_, d, len, (off_t)off);
+      if (r <= 0) return false;
+      d += r;
+      off += (uint64_t)r;
+      len -= (uint64_t)r;
+    }
+    return true;
+  }
+  void need(uint64_t pos, uint64_t len, const std::string& path) const {
+    if (pos + len > fsize_) throw std::runtime_error("bgen file ends inside a variant record : " + path);
+  }
+  typedef size_t (*zstd_fn)(void*, size_t, const void*, size_t);
+  static zstd_fn zstd() {
+    static zstd_fn fn = []() -> zstd_fn {
+      void* h = dlopen("libzstd.so.1", RTLD_NOW);
+      if (!h) h = dlopen("libzstd.so", RTLD_NOW);
+      return h ? (zstd_fn)dlsym(h, "ZSTD_decompress") : nullptr;
+    }();
+    if (!fn) throw std::runtime_error("bgen file is zstd-compressed and libzstd.so.1 is not available on this machine");
+    return fn;
+  }
+};
+
+}  // namespace rgbgen

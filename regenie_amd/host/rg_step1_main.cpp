@@ -11,9 +11,10 @@
 // Served: --qt / --bt, K-fold CV / --loocv (and the reference's automatic LOOCV for --bt below 5,000 samples), and the
 // file protocol of the level-0 job split: --split-l0 PFX,N / --run-l0 PFX.master,k / --run-l1 PFX.master [--keep-l0]
 // (src/Data.cpp:232-309, :818-908; raw double N x (blocks*R0) files of Step1_Models.cpp:728-734).
-// Genotype input: --bed PFX (bed/bim/fam) or --pgen PFX (pgen/pvar/psam hardcalls, decoded to the same 2-bit rows by
-// include/rg_pgen.h); gzipped text inputs and --gz outputs through zlib (Files.cpp:38-160).  Not served in this revision
-// (explicit errors, never silent): --bgen input, pgen dosages.
+// Genotype input: --bed PFX (bed/bim/fam), --pgen PFX (pgen/pvar/psam: hardcalls decoded to the same 2-bit rows, dosage files
+// to doubles for the fp64 level 0; include/rg_pgen.h) or --bgen FILE [--sample FILE] (BGEN v1.2, 8-bit; include/rg_bgen.h);
+// gzipped text inputs and --gz outputs through zlib (Files.cpp:38-160).  Not served (explicit errors, never silent): BGEN files
+// other than layout 2 with 8-bit probabilities.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -36,6 +37,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include "../../include/rg_bgen.h"
 #include "../../include/rg_pgen.h"
 #include "../../include/rg_step1.h"
 
@@ -45,7 +47,7 @@ const double MISSING = -999.0;  // Regenie.hpp:215
 
 struct Params {
   int step = 0;
-  std::string bed, pgen, pheno_file, covar_file, out = "regenie_out";
+  std::string bed, pgen, bgen, sample_file, pheno_file, covar_file, out = "regenie_out";
   std::vector<std::string> keep, remove, extract, exclude, pheno_cols, covar_cols, cat_covar;
   int max_cat_levels = 10;
   bool rint = false;
@@ -314,7 +316,8 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--niter") { p.niter_max = atoi(need(i).c_str()); p.niter_max_ridge = p.niter_max; }  // Regenie.cpp:483
     else if (a == "--gz") p.gz = true;
     else if (a == "--pgen") p.pgen = need(i);
-    else if (a == "--bgen") usage_error(a + " input is not served by the GPU path yet; use --bed or --pgen");
+    else if (a == "--bgen") p.bgen = need(i);
+    else if (a == "--sample") p.sample_file = need(i);
     else if (a == "--split-l0") {
       auto t = split_char(need(i), ',');
       if (t.size() != 2) usage_error("must specify number of jobs for --split-l0 (i.e. prefix,njobs).");
@@ -330,7 +333,7 @@ Params parse_args(int argc, char** argv) {
   }
   if (p.bt) p.rint = false;  // Regenie.cpp:432
   if (p.step != 1) usage_error("specify which mode regenie should be running using option --step (only --step 1 is served).");
-  if (p.bed.empty() == p.pgen.empty()) usage_error("must use either --bed,--bgen or --pgen.");  // Regenie.cpp:419-420
+  if ((int)!p.bed.empty() + (int)!p.pgen.empty() + (int)!p.bgen.empty() != 1) usage_error("must use either --bed,--bgen or --pgen.");  // Regenie.cpp:419-420
   if (p.pheno_file.empty()) usage_error("option '--phenoFile' is required.");
   if (p.bsize < 1) usage_error("must specify the block size using '--bsize'.");
   if (p.cv_folds < 2) usage_error("number of CV folds must be at least 2");
@@ -352,10 +355,11 @@ struct Run {
   std::vector<std::string> mprefix; std::vector<int> bstart, btot;
   int64_t n_file = 0, bpr = 0;
   rg_pgen* pgen = nullptr;               // --pgen: open reader (bed rows come from rg_pgen_read_bed_rows)
-  bool dosage_mode = false;              // --pgen with dosage tracks: rows come from rg_pgen_read_dosages, level 0 from rg_l0_blocks_f64
+  bool dosage_mode = false;              // --pgen with dosage tracks / --bgen: rows of doubles, level 0 from rg_l0_blocks_f64
+  rg_bgen* bgenh = nullptr;              // --bgen: open reader
   Run() = default;
   Run(const Run&) = delete;
-  ~Run() { if (pgen) rg_pgen_close(pgen); }
+  ~Run() { if (pgen) rg_pgen_close(pgen); if (bgenh) rg_bgen_close(bgenh); }
   // samples
   std::vector<uint8_t> ind_ignore, ain;  // N_file, N
   std::vector<std::string> ids;          // kept, file order
@@ -552,8 +556,94 @@ bool fit_poisson(const double* y, const double* X, const uint8_t* mask, int64_t 
   return true;
 }
 
+void apply_sample_and_variant_filters(Run& r);
+
+// prep_bgen (Geno.cpp:38-175): variant list from the file itself, sample identifiers embedded or from --sample
+void read_bgen_meta(Run& r) {
+  const Params& p = r.p;
+  sout << std::left << std::setw(20) << " * bgen" << ": [" << p.bgen << "]\n";
+  if (rg_bgen_open(&r.bgenh, p.bgen.c_str()) != RG_BGEN_OK) {
+    const std::string msg = rg_bgen_last_error(r.bgenh);
+    rg_bgen_close(r.bgenh);
+    r.bgenh = nullptr;
+    throw std::runtime_error(msg);
+  }
+  int64_t ns = 0, nv = 0;
+  int32_t comp = 0, has_ids = 0;
+  rg_bgen_info(r.bgenh, &ns, &nv, &comp, &has_ids);
+  sout << "   -summary : bgen file (v1.2 layout, " << (comp == 1 ? "zlib " : comp == 2 ? "zstd " : "un") << "compressed) with " << ns << " "
+       << (has_ids ? "named" : "anonymous") << " samples and " << nv << " variants with 8-bit encoding.\n";
+  {
+    int nt = p.threads;
+    if (nt < 1) nt = std::max(1, (int)std::thread::hardware_concurrency() - 1);
+    rg_bgen_set_threads(r.bgenh, std::min(nt, 64));
+  }
+  std::set<std::string> ext, exc;
+  std::vector<std::string> extract_files = p.extract, exclude_files = p.exclude;
+  if (p.run_l0) { extract_files.assign(1, r.job_prefix + ".snplist"); exclude_files.clear(); }
+  if (!extract_files.empty()) ext = read_snp_files(extract_files);
+  if (!exclude_files.empty()) exc = read_snp_files(exclude_files);
+  for (int64_t j = 0; j < nv; ++j) {
+    const char *chrom, *rsid;
+    rg_bgen_variant(r.bgenh, j, &chrom, nullptr, &rsid, nullptr, nullptr, nullptr);
+    const int c = chr_str_to_int(chrom, p.nchrom);
+    if (c == -1) throw std::runtime_error("unknown chromosome code in bgen file.");
+    if (r.chr_read.empty() || c != r.chr_read.back()) r.chr_read.push_back(c);
+    bool keep = true;
+    if (!extract_files.empty() && !ext.count(rsid)) keep = false;
+    if (!exclude_files.empty() && exc.count(rsid)) keep = false;
+    if (keep) { r.snp_chrom.push_back(c); r.snp_offset.push_back(j); r.snp_ids.push_back(rsid); }
+  }
+  sout << "   -n_snps = " << nv << "\n";
+  if (!extract_files.empty()) sout << "   -keeping variants specified by --extract\n";
+  if (!exclude_files.empty()) sout << "   -removing variants specified by --exclude\n";
+  if (r.snp_chrom.empty()) throw std::runtime_error("no variant left to include in analysis.");
+  if (r.snp_chrom.size() > 1000000 && !p.force_step1)
+    throw std::runtime_error("it is not recommened to use more than 1M variants in step 1 (use --force-step1 to override)");
+  // samples
+  if (!p.sample_file.empty()) {  // read_bgen_sample (Geno.cpp:395-456)
+    std::string fn = p.sample_file;
+    if (!file_exists(fn)) fn += ".gz";
+    sout << "   -sample file: " << fn << "\n";
+    TextIn f(fn);
+    if (!f) throw std::runtime_error("cannot open file : " + fn);
+    std::string line;
+    int nline = 0;
+    while (std::getline(f, line)) {
+      auto t = split_ws(line);
+      if (t.size() < 2) throw std::runtime_error("incorrectly formatted sample file at line" + std::to_string(r.fam_ids.size() + 1));
+      if (nline == 0) { if (t[0] != "ID_1" || t[1] != "ID_2") throw std::runtime_error("header of the sample file must start with: ID_1 ID_2"); }
+      else if (nline == 1) { if (t[0] != "0" || t[1] != "0") throw std::runtime_error("second line of sample file must start with: 0 0."); }
+      else {
+        r.fam_ids.push_back(t[0] + "_" + t[1]);
+        if (t.size() >= 4 && t[3] != "0" && t[3] != "NA" && t[3] != "1" && t[3] != "2") throw std::runtime_error("unrecognized sex code in file : '" + t[3] + "'");
+      }
+      ++nline;
+    }
+    if ((int64_t)r.fam_ids.size() != ns) throw std::runtime_error("number of samples in BGEN file does not match that in the sample file.");
+  } else {
+    if (!has_ids) throw std::runtime_error("bgen file has no sample identifiers; specify a sample file with --sample");
+    for (int64_t i = 0; i < ns; ++i) {
+      const char* id;
+      rg_bgen_sample_id(r.bgenh, i, &id);
+      r.fam_ids.push_back(id);
+    }
+  }
+  {
+    std::set<std::string> seen;
+    for (auto& id : r.fam_ids)
+      if (!seen.insert(id).second) throw std::runtime_error("duplicate individual in bgen file : FID_IID =" + id);
+  }
+  r.n_file = ns;
+  sout << "   -n_samples = " << ns << "\n";
+  r.bpr = (r.n_file + 3) / 4;
+  r.dosage_mode = true;
+  apply_sample_and_variant_filters(r);
+}
+
 void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pgen: read_pvar / read_psam, Geno.cpp:771-1004
   const Params& p = r.p;
+  if (!p.bgen.empty()) { read_bgen_meta(r); return; }
   const bool pg = !p.pgen.empty();
   if (!pg) {
     std::string fn = p.bed + ".fam";
@@ -700,6 +790,11 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
     if (nv != n_variants_file) throw std::runtime_error("number of variants in pgen file and pvar file don't match.");
     r.bpr = (r.n_file + 3) / 4;
   }
+  apply_sample_and_variant_filters(r);
+}
+
+void apply_sample_and_variant_filters(Run& r) {
+  const Params& p = r.p;
   // --keep / --remove (Geno.cpp:1263-1341)
   r.ind_ignore.assign(r.n_file, 0);
   if (!p.remove.empty()) {
@@ -1275,6 +1370,13 @@ int run(int argc, char** argv) {
       for (int b = 0; b < nb; ++b) {
         const Blk& bl = blocks[b0 + b];
         if (bl.chrom != cur_chr) { cur_chr = bl.chrom; sout << "Chromosome " << cur_chr << "\n"; }
+        if (r.bgenh) {  // readChunkFromBGENFileToG_fast (Geno.cpp:1574-1699): inflate + probabilities -> dosages
+          dbuf.resize((size_t)bl.bs * r.n_file);
+          if (rg_bgen_read_dosages(r.bgenh, bl.bs, &r.snp_offset[bl.start], p.ref_first ? 1 : 0, dbuf.data(), r.n_file) != RG_BGEN_OK)
+            throw std::runtime_error(rg_bgen_last_error(r.bgenh));
+          ids[b] = b0 + b; bss[b] = bl.bs;
+          continue;
+        }
         if (r.dosage_mode) {  // Read() per kept variant (Geno.cpp:1795-1796): ALT dosages, -3 = missing
           dbuf.resize((size_t)bl.bs * r.n_file);
           for (int j = 0; j < bl.bs; ++j)

@@ -1,0 +1,99 @@
+"""BGEN v1.2 input (layout 2, 8-bit probabilities: the files regenie reads through its own fast path, Geno.cpp:1574-1699):
+oracle and product reader against the reference's fixture pairs and against synthetic files.  Host-only, no GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import bgen as obg
+from regenie_amd.bgen import BgenFile
+from regenie_amd.engine import RgError
+
+
+def _bed_genotypes(prefix, m, n):
+    raw = np.fromfile(prefix + ".bed", dtype=np.uint8)[3:].reshape(m, (n + 3) // 4)
+    codes = ((raw[:, :, None] >> np.array([0, 2, 4, 6])) & 3).reshape(m, -1)[:, :n]
+    return np.array([2.0, -3.0, 1.0, 0.0])[codes]
+
+
+@pytest.mark.parametrize("bgen,bed,m", [("example.bgen", "example", 1000), ("example_3chr.bgen", "example_3chr", 500),
+                                        ("example_3chr_zstd.bgen", "example_3chr", 500)])
+def test_reference_fixture_pairs(example_dir, bgen, bed, m):
+    """The reference ships the same genotypes as .bed and .bgen (zlib and zstd); its tests compare runs on both
+    (test/test_bash.sh:143-216).  Every dosage must be the .bed genotype, for the oracle and for the product reader."""
+    want = _bed_genotypes(os.path.join(example_dir, bed), m, 500)
+    o = obg.BgenOracle(os.path.join(example_dir, bgen))
+    assert (o.m, o.n, o.layout) == (m, 500, 2)
+    got = np.stack([o.dosages(j) for j in range(m)])
+    assert (got == want).all()
+    with BgenFile(os.path.join(example_dir, bgen), threads=3) as f:
+        assert (f.n_variants, f.n_samples) == (m, 500) and f.compression == o.compression
+        rows = f.read_dosages(np.arange(m))
+        assert (rows == want).all()
+        assert (f.read_dosages([m - 1, 0, 7]) == want[[m - 1, 0, 7]]).all()
+        assert (f.read_dosages([3], ref_first=True) == np.where(want[3] == -3, -3, 2 - want[3])).all()
+        ids = f.sample_ids()
+        assert ids == o.sample_ids and (not ids or ids[:2] == ["1_1", "2_2"])
+        bim = [ln.split() for ln in open(os.path.join(example_dir, bed + ".bim")).read().split("\n") if ln]
+        for j in (0, 1, m // 2, m - 1):
+            v = f.variant(j)
+            assert v["rsid"] == bim[j][1] and v["chrom"] == bim[j][0] and v["pos"] == int(bim[j][3])
+            assert v["offset"] == o.variants[j]["offset"]
+
+
+def test_synthetic_probabilities_and_missing(tmp_path):
+    rng = np.random.default_rng(2)
+    m, n = 70, 333
+    p0 = rng.integers(0, 256, (m, n))
+    p1 = np.minimum(rng.integers(0, 256, (m, n)), 255 - p0)
+    probs = np.stack([p0, p1], axis=-1).astype(np.uint8)
+    miss = rng.random((m, n)) < 0.03
+    variants = [(1 + j // 40, 100 + j, "rs%d" % j, "A", "G") for j in range(m)]
+    a, b, d = p0 / 255.0, p1 / 255.0, None
+    c = np.maximum(1 - a - b, 0)
+    want = np.where(miss, -3.0, b + 2 * a)
+    want_rf = np.where(miss, -3.0, b + 2 * c)
+    for comp, ids in ((1, ["%d_%d" % (i, i) for i in range(n)]), (0, None)):
+        path = str(tmp_path / ("s%d.bgen" % comp))
+        obg.write_bgen(path, probs, miss, variants, sample_ids=ids, compression=comp)
+        o = obg.BgenOracle(path)
+        assert all((o.dosages(j) == want[j]).all() for j in range(m))
+        with BgenFile(path, threads=4) as f:
+            assert f.has_sample_ids == (ids is not None) and f.compression == comp
+            assert (f.read_dosages(np.arange(m)) == want).all()
+            assert (f.read_dosages(np.arange(m), ref_first=True) == want_rf).all()
+            assert f.variant(41) == dict(chrom="2", pos=141, rsid="rs41", a0="A", a1="G", offset=o.variants[41]["offset"])
+
+
+def test_refusals_and_damage(tmp_path, example_dir):
+    def err(path):
+        with pytest.raises(RgError) as e:
+            BgenFile(path)
+        return e.value
+    assert "magic" in str(err(os.path.join(example_dir, "example.bed"))) or err(os.path.join(example_dir, "example.bed")).code == -2
+    assert "cannot open" in str(err(str(tmp_path / "nope.bgen")))
+    raw = bytearray(open(os.path.join(example_dir, "example_3chr.bgen"), "rb").read())
+    # layout 1 flag
+    lay1 = bytearray(raw)
+    lay1[20] = (lay1[20] & ~0x3C) | (1 << 2)
+    p = str(tmp_path / "l1.bgen")
+    open(p, "wb").write(lay1)
+    e = err(p)
+    assert e.code == -3 and "layout 1 is not supported" in str(e)
+    # truncated file
+    p = str(tmp_path / "t.bgen")
+    open(p, "wb").write(raw[:len(raw) - 100])
+    assert err(p).code == -2
+    # a damaged compressed block: the reference's message (Geno.cpp:1616-1617)
+    o = obg.BgenOracle(os.path.join(example_dir, "example_3chr.bgen"))
+    bad = bytearray(raw)
+    at = o.variants[5]["data"] + 8
+    bad[at + 2: at + 12] = bytes(10)
+    p = str(tmp_path / "z.bgen")
+    open(p, "wb").write(bad)
+    with BgenFile(p) as f:
+        with pytest.raises(RgError, match="failed to decompress genotype data block for variant: " + o.variants[5]["rsid"]):
+            f.read_dosages([5])
+        assert f.read_dosages([4]).shape == (1, 500)
+        with pytest.raises(RgError):
+            f.read_dosages([500])

@@ -402,3 +402,32 @@ def test_cli_pgen_dosages(tmp_path):
         _, _, v1, _ = _parse_loco(str(tmp_path / ("cl_%d.loco" % k)))
         _, _, v2, _ = _parse_loco(str(tmp_path / ("ol_%d.loco" % k)))
         assert np.allclose(v1, v2, rtol=2e-5, atol=1e-7, equal_nan=True)
+
+
+def test_cli_bgen_equals_bed(example_dir, tmp_path):
+    """`--bgen example.bgen` (zlib) / example_3chr_zstd.bgen (zstd, + --sample) hold the genotypes of the .bed files: level 0
+    runs on the fp64 dosage path there and on the 2-bit path here, and both must give the oracle's LOCO predictions -- two
+    independent device routes (the reference's tests likewise compare its bgen and bed runs, test/test_bash.sh:143-216)."""
+    E = example_dir
+    common = ["--step", "1", "--covarFile", os.path.join(E, "covariates.txt"), "--phenoFile", os.path.join(E, "phenotype.txt"),
+              "--remove", os.path.join(E, "fid_iid_to_remove.txt"), "--exclude", os.path.join(E, "snplist_rm.txt"), "--bsize", "100"]
+    for bed, bgen, extra in (("example", "example.bgen", []),
+                             ("example_3chr", "example_3chr_zstd.bgen", ["--sample", os.path.join(E, "example_3chr.sample")])):
+        r = _run(common + ["--bed", os.path.join(E, bed), "--out", str(tmp_path / "b")], str(tmp_path))
+        assert r.returncode == 0, r.stdout + r.stderr
+        r = _run(common + ["--bgen", os.path.join(E, bgen), "--out", str(tmp_path / "g")] + extra, str(tmp_path))
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert " * bgen" in r.stdout and "8-bit encoding" in r.stdout
+        for k in (1, 2):
+            h1, ids1, v1, _ = _parse_loco(str(tmp_path / ("b_%d.loco" % k)))
+            h2, ids2, v2, _ = _parse_loco(str(tmp_path / ("g_%d.loco" % k)))
+            assert h1 == h2 and ids1 == ids2
+            assert np.allclose(v1, v2, rtol=1e-5, atol=1e-7, equal_nan=True)
+    # --ref-first flips the counted allele in both readers alike
+    r = _run(common + ["--bed", os.path.join(E, "example"), "--ref-first", "--out", str(tmp_path / "br")], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    r = _run(common + ["--bgen", os.path.join(E, "example.bgen"), "--ref-first", "--out", str(tmp_path / "gr")], str(tmp_path))
+    assert r.returncode == 0, r.stdout + r.stderr
+    _, _, v1, _ = _parse_loco(str(tmp_path / "br_1.loco"))
+    _, _, v2, _ = _parse_loco(str(tmp_path / "gr_1.loco"))
+    assert np.allclose(v1, v2, rtol=1e-5, atol=1e-7, equal_nan=True)
