@@ -10,8 +10,8 @@
 //   fold Grams F_f = G_f G_f^T and right-hand sides Y_f G_f^T (fp64 MFMA GEMMs over the fold's position range), then the
 //   training-fold systems sum - F_f in the workspace layout of the 2-bit path, the SAME batched Cholesky with the lambda
 //   shifts formed on the fly, predictions beta^T G_f masked per phenotype, and the same column statistics / scaling kernels.
-// One block at a time (G is 8 n64 Np bytes: 0.4 GB at 50,000 samples, 4 GB at 500,000).  Throughput was not the object of
-// this first version -- the GEMM is the plain register-fed kernel of chol.hip -- parity with the reference's arithmetic was.
+// Blocks go in mini-batches whose G stay resident (8 n64 Np bytes each: 0.4 GB at 50,000 samples, 4 GB at 500,000; <= 24 GB in
+// all) so that one batched Cholesky serves all their systems.
 #include <algorithm>
 #include <vector>
 
@@ -72,6 +72,44 @@ __global__ __launch_bounds__(256) void k_f64_fill(const double* rows, int64_t ld
     }
   }
   G[(int64_t)j * Np + pos] = v;
+}
+
+// grid (Np / 256, bs): partial products of a variant with the C covariate basis columns over one 256-position chunk
+__global__ __launch_bounds__(256) void k_f64_gxpart(const double* G, int64_t Np, const double* X /*[64][Np]*/, int C,
+                                                    double* part /*[bs][nchunk][C]*/) {
+  __shared__ double sred[4];
+  const int j = blockIdx.y;
+  const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const double g = pos < Np ? G[(int64_t)j * Np + pos] : 0.0;
+  for (int c = 0; c < C; ++c) {
+    const double s = block_sum256(pos < Np ? g * X[(int64_t)c * Np + pos] : 0.0, sred);
+    if (threadIdx.x == 0) part[((int64_t)j * gridDim.x + blockIdx.x) * C + c] = s;
+  }
+}
+// gx[j][c] = fixed-order sum of the chunk partials
+__global__ void k_f64_gxsum(const double* part, int nchunk, int C, int bs, double* gx /*[n64][64]*/) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bs * C) return;
+  const int j = t / C, c = t % C;
+  double s = 0.0;
+  for (int ch = 0; ch < nchunk; ++ch) s += part[((int64_t)j * nchunk + ch) * C + c];
+  gx[(int64_t)j * 64 + c] = s;
+}
+
+// right-hand sides: rhs_f[p][j] = sum over the positions of fold f of Y[p][pos] G~[j][pos], written into the system layout
+// (rows n64 + p of fold f's [rtot][n64] block; the padding rows up to rtot are zeroed).  thread = (fold, row p, variant j)
+__global__ void k_f64_gysum(const double* part /*[bs][nchunk][P]*/, int nchunk, int P, int bs, int n64, int rhs_pad, SegLayout seg,
+                            double* F0, int64_t msz) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t per = (int64_t)rhs_pad * n64;
+  if (t >= per * seg.nseg) return;
+  const int f = (int)(t / per), p = (int)((t % per) / n64), j = (int)(t % n64);
+  double s = 0.0;
+  if (p < P && j < bs) {
+    const int c0 = (int)(seg.pos_start[f] / 256), c1 = (int)((seg.pos_start[f] + seg.plen[f]) / 256);
+    for (int ch = c0; ch < c1; ++ch) s += part[((int64_t)j * nchunk + ch) * P + p];
+  }
+  F0[(int64_t)f * msz + (int64_t)(n64 + p) * n64 + j] = s;
 }
 
 // grid (Np / 256, bs): G <- G - (G X^T) X, and the partial sums of squares of the residual rows
@@ -234,19 +272,26 @@ int rg_l0_blocks_f64_impl(rg_ctx* ctx, int nblk, const int32_t* block_ids, const
   const int64_t msz = (int64_t)rtot * n64;
   const int rhs_pad = rtot - n64;
   const unsigned gpos = (unsigned)((Np + 255) / 256);
-  // buffers: 0 G, 1 Xpad [64][Np], 2 Ypad [rhs_pad][Np], 3 pos2file, 4 staged host rows, 5 GX [n64][64], 6 mu, 7 partials, 8 scale
+  // blocks per mini-batch: their standardised genotypes stay resident so that ONE batched Cholesky serves all of them
+  int nbb = 1;
+  if (!ctx->loocv) {
+    const double per = 8.0 * (double)n64 * (double)Np;
+    nbb = (int)std::max(1.0, std::min((double)std::min(nblk, ctx->nblk_cap), 24e9 / per));
+  }
+  // buffers: 0 G [nbb][n64][Np], 1 Xpad [64][Np], 2 Ypad [rhs_pad][Np], 3 pos2file, 4 staged host rows, 5 GX [n64][64], 6 mu,
+  //          7 partials [n64][nchunk][max(C,P,1)], 8 scale
   const bool first = ctx->f64_ptr[1] == nullptr;
-  double* G = f64_buf<double>(ctx, 0, (size_t)n64 * Np);
+  double* Gall = f64_buf<double>(ctx, 0, (size_t)nbb * n64 * Np);
   double* Xp = f64_buf<double>(ctx, 1, (size_t)64 * Np);
   double* Yp = f64_buf<double>(ctx, 2, (size_t)rhs_pad * Np);
   int64_t* p2f = f64_buf<int64_t>(ctx, 3, (size_t)Np);
   double* gx = f64_buf<double>(ctx, 5, (size_t)n64 * 64);
   double* mu = f64_buf<double>(ctx, 6, (size_t)n64);
-  double* part = f64_buf<double>(ctx, 7, (size_t)n64 * gpos);
+  double* part = f64_buf<double>(ctx, 7, (size_t)n64 * gpos * std::max(std::max(C, P), 1));
   double* sc = f64_buf<double>(ctx, 8, (size_t)n64);
   double* stage = nullptr;
   if (mem_kind != RG_MEM_DEVICE) stage = f64_buf<double>(ctx, 4, (size_t)ctx->bs_max * Nfile);
-  if (!G || !Xp || !Yp || !p2f || !gx || !mu || !part || !sc || (mem_kind != RG_MEM_DEVICE && !stage)) {
+  if (!Gall || !Xp || !Yp || !p2f || !gx || !mu || !part || !sc || (mem_kind != RG_MEM_DEVICE && !stage)) {
     ctx->err = "rg_l0_blocks_f64: out of device memory";
     return RG_ERR_HIP;
   }
@@ -262,66 +307,77 @@ int rg_l0_blocks_f64_impl(rg_ctx* ctx, int nblk, const int32_t* block_ids, const
     F64_HIP(hipStreamSynchronize(st));
   }
   const double denom = sqrt((double)(ctx->n_analyzed - C));
-  for (int b = 0; b < nblk; ++b) {
-    const int nb = bs[b];
-    const double* src = rows[b];
-    int64_t ld = row_stride;
-    if (mem_kind != RG_MEM_DEVICE) {
-      F64_HIP(hipMemcpy2DAsync(stage, sizeof(double) * Nfile, rows[b], sizeof(double) * row_stride, sizeof(double) * Nfile, nb,
-                               hipMemcpyHostToDevice, st));
-      src = stage;
-      ld = Nfile;
+  for (int b0 = 0; b0 < nblk; b0 += nbb) {
+    const int nb_ = std::min(nbb, nblk - b0);
+    F64_HIP(hipMemcpyAsync(ctx->d_bs, bs + b0, sizeof(int32_t) * nb_, hipMemcpyHostToDevice, st));
+    F64_HIP(hipMemcpyAsync(ctx->d_blockid, block_ids + b0, sizeof(int32_t) * nb_, hipMemcpyHostToDevice, st));
+    // ---- per block: ingest, residualise, fold Grams --------------------------------------------------------------------
+    for (int i = 0; i < nb_; ++i) {
+      const int b = b0 + i, nb = bs[b];
+      double* G = Gall + (size_t)i * n64 * Np;
+      const double* src = rows[b];
+      int64_t ld = row_stride;
+      if (mem_kind != RG_MEM_DEVICE) {   // stream order protects the staging buffer: the copy queues behind its last readers
+        F64_HIP(hipMemcpy2DAsync(stage, sizeof(double) * Nfile, rows[b], sizeof(double) * row_stride, sizeof(double) * Nfile, nb,
+                                 hipMemcpyHostToDevice, st));
+        src = stage;
+        ld = Nfile;
+      }
+      hipLaunchKernelGGL(k_f64_rowstat, dim3(nb), dim3(256), 0, st, src, ld, p2f, ctx->d_act, Np, mu, ctx->d_info);
+      hipLaunchKernelGGL(k_f64_fill, dim3(gpos, n64), dim3(256), 0, st, src, ld, p2f, ctx->d_act, Np, mu, nb, G);
+      // residualize_genotypes
+      hipLaunchKernelGGL(k_f64_gxpart, dim3(gpos, nb), dim3(256), 0, st, G, Np, Xp, C, part);
+      hipLaunchKernelGGL(k_f64_gxsum, dim3((nb * C + 255) / 256), dim3(256), 0, st, part, (int)gpos, C, nb, gx);
+      hipLaunchKernelGGL(k_f64_resid, dim3(gpos, nb), dim3(256), 0, st, G, Np, gx, Xp, C, part);
+      hipLaunchKernelGGL(k_f64_scale1, dim3((nb + 63) / 64), dim3(64), 0, st, part, (int)gpos, nb, denom, i, sc, ctx->d_info);
+      hipLaunchKernelGGL(k_f64_scale2, dim3(gpos, nb), dim3(256), 0, st, G, Np, sc);
+      if (ctx->loocv) {
+        // calc_cv_matrices, LOOCV branch (Data.cpp:755-767): the full Gram and G~ Y; the standardised genotypes, sample-major,
+        // ride along as extra right-hand-side rows of the (A + lambda_r I) systems (loocv.hip) -- the same launches as the
+        // 2-bit path from here on, one block at a time (nbb == 1)
+        rg_launch_dsyrk_folds(st, G, Np, n64, ctx->seg, ctx->d_sum, 0, n64);
+        rg_launch_dgemm_nt(st, Yp, Np, G, Np, rhs_pad, n64, Np, ctx->d_sum + (int64_t)n64 * n64, n64);
+        hipLaunchKernelGGL(k_f64_transpose, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, G, Np, n64, ctx->d_gt);
+        rg_launch_chol_solve_formed_x(st, ctx->d_sum, msz, ctx->d_fold, msz, 1, ctx->d_lambda, R0, ctx->d_bs, 0, 1, ctx->d_wk,
+                                      ctx->rtot_wk * n64, n64, (int)(ctx->rtot_wk - n64), 0, ctx->d_dinv, ctx->d_info + 1,
+                                      &ctx->tm.n_chol_launches, 0, ctx->d_gt, (int64_t)Np * n64, rtot, 1, 0, -1, 0);
+        LoocvArgs la;
+        la.nblk = 1; la.R0 = R0; la.P = P; la.C = C; la.n128 = ctx->n128; la.n64 = n64; la.rtot = (int)ctx->rtot_wk;
+        la.row_g0 = rtot; la.Np = Np; la.pk_ld = ctx->pk_ld; la.pk_blk_stride = 0; la.pk = nullptr;
+        la.mu = nullptr; la.sc = nullptr; la.Bm = nullptr; la.V = ctx->d_V; la.maskp = ctx->d_maskp;
+        la.neff = ctx->d_neff; la.bs = ctx->d_bs; la.blockid = ctx->d_blockid; la.wk = ctx->d_wk; la.gt = ctx->d_gt;
+        la.W = ctx->d_W;
+        rg_launch_l0_loocv(st, la, ctx->d_lpart, ctx->d_lpart + (size_t)R0 * P * 64, 64);
+        continue;
+      }
+      // calc_cv_matrices: per-fold Gram (lower tiles, all folds in one launch) and right-hand sides, straight into the
+      // [rtot][n64] system layout of block slot i; then fold f <- sum - fold f
+      double* F0 = ctx->d_fold + (int64_t)i * K * msz;
+      rg_launch_dsyrk_folds(st, G, Np, n64, ctx->seg, F0, msz, n64);
+      hipLaunchKernelGGL(k_f64_gxpart, dim3(gpos, nb), dim3(256), 0, st, G, Np, Yp, P, part);   // chunk partials of Y G~^T
+      hipLaunchKernelGGL(k_f64_gysum, dim3((unsigned)(((int64_t)rhs_pad * n64 * K + 255) / 256)), dim3(256), 0, st, part, (int)gpos, P, nb,
+                         n64, rhs_pad, ctx->seg, F0, msz);
+      hipLaunchKernelGGL(k_f64_train, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, st, F0, K, msz);
     }
-    F64_HIP(hipMemcpyAsync(ctx->d_bs, &bs[b], sizeof(int32_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_f64_rowstat, dim3(nb), dim3(256), 0, st, src, ld, p2f, ctx->d_act, Np, mu, ctx->d_info);
-    hipLaunchKernelGGL(k_f64_fill, dim3(gpos, n64), dim3(256), 0, st, src, ld, p2f, ctx->d_act, Np, mu, nb, G);
-    // residualize_genotypes
-    rg_launch_dgemm_nt(st, G, Np, Xp, Np, n64, 64, Np, gx, 64);
-    hipLaunchKernelGGL(k_f64_resid, dim3(gpos, nb), dim3(256), 0, st, G, Np, gx, Xp, C, part);
-    hipLaunchKernelGGL(k_f64_scale1, dim3((nb + 63) / 64), dim3(64), 0, st, part, (int)gpos, nb, denom, b, sc, ctx->d_info);
-    hipLaunchKernelGGL(k_f64_scale2, dim3(gpos, nb), dim3(256), 0, st, G, Np, sc);
-    if (ctx->loocv) {
-      // calc_cv_matrices, LOOCV branch (Data.cpp:755-767): the full Gram and G~ Y; the standardised genotypes, sample-major,
-      // ride along as extra right-hand-side rows of the (A + lambda_r I) systems (loocv.hip) -- the same launches as the
-      // 2-bit path from here on, for one block
-      F64_HIP(hipMemcpyAsync(ctx->d_blockid, &block_ids[b], sizeof(int32_t), hipMemcpyHostToDevice, st));
-      rg_launch_dgemm_nt(st, G, Np, G, Np, n64, n64, Np, ctx->d_sum, n64);
-      rg_launch_dgemm_nt(st, Yp, Np, G, Np, rhs_pad, n64, Np, ctx->d_sum + (int64_t)n64 * n64, n64);
-      hipLaunchKernelGGL(k_f64_transpose, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, G, Np, n64, ctx->d_gt);
-      rg_launch_chol_solve_formed_x(st, ctx->d_sum, msz, ctx->d_fold, msz, 1, ctx->d_lambda, R0, ctx->d_bs, 0, 1, ctx->d_wk,
-                                    ctx->rtot_wk * n64, n64, (int)(ctx->rtot_wk - n64), 0, ctx->d_dinv, ctx->d_info + 1,
-                                    &ctx->tm.n_chol_launches, 0, ctx->d_gt, (int64_t)Np * n64, rtot, 1, 0, -1, 0);
-      LoocvArgs la;
-      la.nblk = 1; la.R0 = R0; la.P = P; la.C = C; la.n128 = ctx->n128; la.n64 = n64; la.rtot = (int)ctx->rtot_wk;
-      la.row_g0 = rtot; la.Np = Np; la.pk_ld = ctx->pk_ld; la.pk_blk_stride = 0; la.pk = nullptr;
-      la.mu = nullptr; la.sc = nullptr; la.Bm = nullptr; la.V = ctx->d_V; la.maskp = ctx->d_maskp;
-      la.neff = ctx->d_neff; la.bs = ctx->d_bs; la.blockid = ctx->d_blockid; la.wk = ctx->d_wk; la.gt = ctx->d_gt;
-      la.W = ctx->d_W;
-      rg_launch_l0_loocv(st, la, ctx->d_lpart, ctx->d_lpart + (size_t)R0 * P * 64, 64);
-      if (mem_kind != RG_MEM_DEVICE) F64_HIP(hipStreamSynchronize(st));
-      ctx->block_done[block_ids[b]] = 1;
-      continue;
+    if (!ctx->loocv) {
+      // ---- ridge_level_0: the K * R0 shifted systems of every block of the mini-batch in one batched Cholesky --------------
+      rg_launch_chol_solve_formed_x(st, ctx->d_fold, msz, nullptr, 0, 1, ctx->d_lambda, R0, ctx->d_bs, 0, nb_ * K, ctx->d_wk, msz,
+                                    n64, rhs_pad, P, ctx->d_dinv, ctx->d_info + 1, &ctx->tm.n_chol_launches, 0, nullptr, 0, 0, K,
+                                    0, -1, 0);
+      // ---- predictions and their standardisation ----------------------------------------------------------------------
+      for (int i = 0; i < nb_; ++i) {
+        const int b = b0 + i;
+        const double* G = Gall + (size_t)i * n64 * Np;
+        hipLaunchKernelGGL(k_f64_pred, dim3(ctx->n_c256, P), dim3(256), 0, st, G, Np, bs[b], n64, rtot, R0, P,
+                           ctx->d_wk + (int64_t)i * K * R0 * msz, ctx->d_maskp, ctx->d_c256_seg, ctx->d_c256_pos, ctx->d_c256_len,
+                           ctx->n_c256, block_ids[b], ctx->d_W, ctx->d_psum);
+        hipLaunchKernelGGL(k_f64_stats, dim3((P * R0 + 63) / 64), dim3(64), 0, st, ctx->d_psum, ctx->n_c256, P, R0, ctx->d_neff,
+                           ctx->d_pstat);
+        hipLaunchKernelGGL(k_f64_wscale, dim3(gpos, R0 * P), dim3(256), 0, st, ctx->d_W, Np, R0, P, block_ids[b], ctx->d_keptp,
+                           ctx->d_pstat);
+      }
     }
-    // calc_cv_matrices: per-fold Gram and right-hand sides into the workspace layout [rtot][n64] of block slot 0
-    for (int f = 0; f < K; ++f) {
-      double* Ff = ctx->d_fold + (int64_t)f * msz;
-      const int64_t p0 = ctx->seg.pos_start[f], pl = ctx->seg.plen[f];
-      rg_launch_dgemm_nt(st, G + p0, Np, G + p0, Np, n64, n64, pl, Ff, n64);
-      rg_launch_dgemm_nt(st, Yp + p0, Np, G + p0, Np, rhs_pad, n64, pl, Ff + (int64_t)n64 * n64, n64);
-    }
-    hipLaunchKernelGGL(k_f64_train, dim3((unsigned)((msz + 255) / 256)), dim3(256), 0, st, ctx->d_fold, K, msz);
-    // ridge_level_0: the K * R0 shifted systems of this block, formed from the training-fold matrices on the fly
-    rg_launch_chol_solve_formed_x(st, ctx->d_fold, msz, nullptr, 0, 1, ctx->d_lambda, R0, ctx->d_bs, 0, K, ctx->d_wk, msz,
-                                  n64, rhs_pad, P, ctx->d_dinv, ctx->d_info + 1, &ctx->tm.n_chol_launches, 0, nullptr, 0, 0, K,
-                                  0, -1, 0);
-    hipLaunchKernelGGL(k_f64_pred, dim3(ctx->n_c256, P), dim3(256), 0, st, G, Np, nb, n64, rtot, R0, P, ctx->d_wk, ctx->d_maskp,
-                       ctx->d_c256_seg, ctx->d_c256_pos, ctx->d_c256_len, ctx->n_c256, block_ids[b], ctx->d_W, ctx->d_psum);
-    hipLaunchKernelGGL(k_f64_stats, dim3((P * R0 + 63) / 64), dim3(64), 0, st, ctx->d_psum, ctx->n_c256, P, R0, ctx->d_neff,
-                       ctx->d_pstat);
-    hipLaunchKernelGGL(k_f64_wscale, dim3(gpos, R0 * P), dim3(256), 0, st, ctx->d_W, Np, R0, P, block_ids[b], ctx->d_keptp,
-                       ctx->d_pstat);
-    if (mem_kind != RG_MEM_DEVICE) F64_HIP(hipStreamSynchronize(st));   // the staging buffer is reused by the next block
-    ctx->block_done[block_ids[b]] = 1;
+    for (int i = 0; i < nb_; ++i) ctx->block_done[block_ids[b0 + i]] = 1;
   }
   return RG_OK;
 }

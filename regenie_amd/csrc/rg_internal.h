@@ -235,6 +235,9 @@ void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t su
                                    int b_count = -1, int path = 1);
 void rg_launch_dgemm_nt(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                         int m, int n, int64_t k, double* C, int64_t ldc);
+// C_f = G[:, fold f] G[:, fold f]^T for every fold of the layout, lower 64x64 tiles only (G row-major [n64][ld])
+void rg_launch_dsyrk_folds(hipStream_t st, const double* G, int64_t ld, int n64, const SegLayout& seg, double* C, int64_t fold_stride,
+                           int64_t ldc);
 // pred.hip
 struct PredArgs {
   int nblk, nseg, R0, P, C, n128, n64, rtot, B_total;
