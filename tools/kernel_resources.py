@@ -14,7 +14,7 @@ from regenie_amd import build as b  # noqa: E402
 
 def demangle(names):
     out = subprocess.run(["c++filt"] + names, capture_output=True, text=True).stdout.split("\n")
-    return [re.sub(r"\(.*", "", o).replace("void ", "") for o in out]
+    return [re.sub(r"\(.*", "", o.replace("(anonymous namespace)::", "")).replace("void ", "") for o in out]
 
 
 def main():
