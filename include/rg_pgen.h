@@ -58,6 +58,9 @@ int rg_pgen_read_bed_rows(rg_pgen* h, int64_t n, const int64_t* variant_idx, uin
  * 16384, in [0, 2]) where the record stores one for the sample, the hardcall 0/1/2 elsewhere, -3 = missing; n_samples
  * doubles.  All three dosage layouts (list, per-sample, bit array); phase tracks in front of them are stepped over. */
 int rg_pgen_read_dosages(rg_pgen* h, int64_t variant_idx, double* out);
+/* The same for n variants at once, spread over the worker threads of rg_pgen_set_threads: rows[k * row_stride .. + n_samples)
+ * doubles -- a block for rg_l0_blocks_f64. */
+int rg_pgen_read_dosage_rows(rg_pgen* h, int64_t n, const int64_t* variant_idx, double* rows, int64_t row_stride);
 
 /* One variant as ALT-allele counts 0/1/2, -3 = missing (n_samples doubles): the parity hook against
  * PgenReader::ReadHardcalls. */

@@ -108,6 +108,41 @@ int rg_pgen_read_bed_rows(rg_pgen* h, int64_t n, const int64_t* variant_idx, uin
   return RG_PGEN_OK;
 }
 
+int rg_pgen_read_dosage_rows(rg_pgen* h, int64_t n, const int64_t* variant_idx, double* rows, int64_t row_stride) {
+  if (!h) return RG_PGEN_ERR_ARG;
+  if (!h->ok) return fail(h, RG_PGEN_ERR_ARG, "pgen file is not open");
+  if (n < 0 || (n > 0 && (!variant_idx || !rows)) || row_stride < (int64_t)h->rd.n_samples())
+    return fail(h, RG_PGEN_ERR_ARG, "rg_pgen_read_dosage_rows: bad argument");
+  for (int64_t k = 0; k < n; ++k)
+    if (variant_idx[k] < 0 || variant_idx[k] >= (int64_t)h->rd.n_variants())
+      return fail(h, RG_PGEN_ERR_ARG, "variant index " + std::to_string(variant_idx[k] + 1) + " is out of range (1.." +
+                                          std::to_string(h->rd.n_variants()) + ")");
+  const int64_t min_chunk = 8;
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(h->threads, n / min_chunk));
+  while ((int)h->scratch.size() < nt) h->scratch.push_back(h->rd.make_scratch());
+  std::vector<std::string> errs((size_t)nt);
+  auto work = [&](int t) {
+    const int64_t k0 = n * t / nt, k1 = n * (t + 1) / nt;
+    try {
+      for (int64_t k = k0; k < k1; ++k) h->rd.read_dosages((uint32_t)variant_idx[k], rows + k * row_stride, h->scratch[(size_t)t]);
+    } catch (const std::exception& e) {
+      errs[(size_t)t] = e.what();
+      if (errs[(size_t)t].empty()) errs[(size_t)t] = "pgen read failed";
+    }
+  };
+  if (nt == 1) {
+    work(0);
+  } else {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+  }
+  for (const auto& e : errs)
+    if (!e.empty()) return fail(h, RG_PGEN_ERR_FORMAT, e);
+  return RG_PGEN_OK;
+}
+
 int rg_pgen_read_dosages(rg_pgen* h, int64_t variant_idx, double* out) {
   if (!h) return RG_PGEN_ERR_ARG;
   if (!h->ok) return fail(h, RG_PGEN_ERR_ARG, "pgen file is not open");

@@ -53,7 +53,7 @@ EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_w_r
            "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak",
            # include/rg_pgen.h (host-side .pgen hardcall input; wrapped by regenie_amd/pgen.py)
            "rg_pgen_open", "rg_pgen_close", "rg_pgen_last_error", "rg_pgen_info", "rg_pgen_read_bed_rows",
-           "rg_pgen_read_hardcalls", "rg_pgen_set_threads", "rg_pgen_read_dosages",
+           "rg_pgen_read_hardcalls", "rg_pgen_set_threads", "rg_pgen_read_dosages", "rg_pgen_read_dosage_rows",
            # include/rg_bgen.h (host-side BGEN v1.2 input; wrapped by regenie_amd/bgen.py)
            "rg_bgen_open", "rg_bgen_close", "rg_bgen_last_error", "rg_bgen_info", "rg_bgen_sample_id", "rg_bgen_variant",
            "rg_bgen_set_threads", "rg_bgen_read_dosages"]
@@ -118,6 +118,7 @@ def load_library() -> C.CDLL:
     lib.rg_pgen_info.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
                                  C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.rg_pgen_read_dosages.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    lib.rg_pgen_read_dosage_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
     lib.rg_bgen_open.argtypes = [C.POINTER(C.c_void_p), C.c_char_p]
     lib.rg_bgen_close.argtypes = [C.c_void_p]
     lib.rg_bgen_close.restype = None

@@ -1379,9 +1379,8 @@ int run(int argc, char** argv) {
         }
         if (r.dosage_mode) {  // Read() per kept variant (Geno.cpp:1795-1796): ALT dosages, -3 = missing
           dbuf.resize((size_t)bl.bs * r.n_file);
-          for (int j = 0; j < bl.bs; ++j)
-            if (rg_pgen_read_dosages(r.pgen, r.snp_offset[bl.start + j], dbuf.data() + (size_t)j * r.n_file) != RG_PGEN_OK)
-              throw std::runtime_error(rg_pgen_last_error(r.pgen));
+          if (rg_pgen_read_dosage_rows(r.pgen, bl.bs, &r.snp_offset[bl.start], dbuf.data(), r.n_file) != RG_PGEN_OK)
+            throw std::runtime_error(rg_pgen_last_error(r.pgen));
           ids[b] = b0 + b; bss[b] = bl.bs;
           continue;
         }

@@ -71,6 +71,15 @@ class PgenFile:
         self._check(self.lib.rg_pgen_read_dosages(self.h, int(variant_idx), out.ctypes.data))
         return out
 
+    def read_dosage_rows(self, variant_idx) -> np.ndarray:
+        """float64 [len(idx), n_samples]: read_dosages for a block of variants, spread over the worker threads."""
+        if not self.h:
+            raise RgError(-1, "pgen file is closed")
+        idx = np.ascontiguousarray(variant_idx, dtype=np.int64)
+        rows = np.empty((idx.size, self.n_samples), dtype=np.float64)
+        self._check(self.lib.rg_pgen_read_dosage_rows(self.h, idx.size, idx.ctypes.data, rows.ctypes.data, self.n_samples))
+        return rows
+
     def read_hardcalls(self, variant_idx: int) -> np.ndarray:
         """ALT-allele counts 0/1/2 and -3 for missing, as PgenReader::ReadHardcalls(.., allele_idx=1) gives."""
         if not self.h:

@@ -199,6 +199,10 @@ def test_dosage_tracks_read_like_the_reference(tmp_path, m, n, phase):
         order = list(range(m)) + [int(x) for x in rng.permutation(m)[:50]]   # in sequence, then out of order (LD bases)
         for j in order:
             assert (f.read_dosages(j) == truth[j]).all(), (j, vts[j], dos.get(j, (0,))[0])
+        f.set_threads(4)
+        assert (f.read_dosage_rows(np.arange(m)) == truth).all()                # a block at once, over worker threads
+        pick = rng.permutation(m)[:40]
+        assert (f.read_dosage_rows(pick) == truth[pick]).all()
         for j in range(0, m, 3):
             assert (o.dosages(j) == truth[j]).all()
             assert (f.read_hardcalls(j) == opg.HARDCALL[g[j]]).all()        # ReadHardcalls still ignores the dosages
