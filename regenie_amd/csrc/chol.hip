@@ -104,49 +104,6 @@ __global__ __launch_bounds__(256) void k_dgemm_nt(const double* A, int64_t lda, 
         C[(r0 + m * 16 + q + 4 * r) * ldc + c0 + n * 16 + i] = acc[m][n][r];
 }
 
-// ---- per-fold Gram of a row-major matrix: C_f = G[:, fold f] G[:, fold f]^T, lower 64x64 tiles only, every fold in one launch
-// (the fp64 genotype path of l0_f64.hip).  grid (T (T + 1) / 2, nfold); the contraction runs over the fold's position range.
-__global__ __launch_bounds__(256) void k_dsyrk_folds(const double* G, int64_t ld, SegLayout seg, double* C, int64_t fold_stride,
-                                                     int64_t ldc) {
-  int tr = (int)((sqrt(8.0 * blockIdx.x + 1.0) - 1.0) * 0.5);
-  while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
-  while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
-  const int tc = (int)blockIdx.x - tr * (tr + 1) / 2;
-  const int f = blockIdx.y;
-  const double* A = G + seg.pos_start[f];
-  const int64_t K = seg.plen[f];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int i = lane & 15, q = lane >> 4;
-  const int64_t r0 = (int64_t)tr * CT + wr * 32, c0 = (int64_t)tc * CT + wc * 32;
-  v4d acc[2][2];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
-  for (int64_t k = 0; k < K; k += 64) {
-    const double* ar[2] = {A + (r0 + i) * ld + k + 16 * q, A + (r0 + 16 + i) * ld + k + 16 * q};
-    const double* br[2] = {A + (c0 + i) * ld + k + 16 * q, A + (c0 + 16 + i) * ld + k + 16 * q};
-    double av[2][16], bv[2][16];
-    dmma_load<2, 2>(ar, br, av, bv);
-    dmma_fma<2, 2>(av, bv, acc);
-  }
-  double* Cf = C + (int64_t)f * fold_stride;
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        Cf[(r0 + m * 16 + q + 4 * r) * ldc + c0 + n * 16 + i] = acc[m][n][r];
-}
-
-void rg_launch_dsyrk_folds(hipStream_t st, const double* G, int64_t ld, int n64, const SegLayout& seg, double* C, int64_t fold_stride,
-                           int64_t ldc) {
-  const int T = n64 / CT;
-  hipLaunchKernelGGL(k_dsyrk_folds, dim3(T * (T + 1) / 2, seg.nseg), dim3(256), 0, st, G, ld, seg, C, fold_stride, ldc);
-}
-
 void rg_launch_dgemm_nt(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                         int m, int n, int64_t k, double* C, int64_t ldc) {
   hipLaunchKernelGGL(k_dgemm_nt, dim3(n / CT, m / CT), dim3(256), 0, st, A, lda, B, ldb, k, C, ldc);

@@ -106,6 +106,17 @@ __global__ __launch_bounds__(256, 2) void k_l1_gram64(L1G64 g, SegLayout seg) {
       for (int r = 0; r < 4; ++r) O[(int64_t)(m * 16 + q + 4 * r) * g.R.n64 + n * 16 + i] = acc[m][n][r];
 }
 
+// The same fold Gram for any row-major matrix G [n64][ld] (rows >= L read as zero): the fp64 genotype path of l0_f64.hip.
+// out: [nfold][rtot][n64], lower 64x64 tiles; the right-hand-side row tiles are written as zeros (the caller fills them).
+void rg_launch_fold_gram_rows(hipStream_t st, const double* G, int64_t ld, int L, int n64, int rtot, const double* zero,
+                              const SegLayout& seg, double* out) {
+  L1G64 g;
+  g.R = L1Rows{G, zero, zero, ld, L, 1, 0, n64};
+  g.T = n64 / CT; g.rtot = rtot; g.nslice = 1; g.ntile = g.T * (g.T + 1) / 2 + g.T; g.world = 1; g.rank = 0;
+  g.out = out; g.slice_stride = 0;
+  hipLaunchKernelGGL(k_l1_gram64, dim3((g.ntile + 3) / 4, seg.nseg), dim3(256), 0, st, g, seg);
+}
+
 __global__ void k_reduce_slices(const double* part, int64_t slice_stride, int nslice, int64_t n, double* out) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;

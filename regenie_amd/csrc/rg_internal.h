@@ -235,9 +235,6 @@ void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t su
                                    int b_count = -1, int path = 1);
 void rg_launch_dgemm_nt(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                         int m, int n, int64_t k, double* C, int64_t ldc);
-// C_f = G[:, fold f] G[:, fold f]^T for every fold of the layout, lower 64x64 tiles only (G row-major [n64][ld])
-void rg_launch_dsyrk_folds(hipStream_t st, const double* G, int64_t ld, int n64, const SegLayout& seg, double* C, int64_t fold_stride,
-                           int64_t ldc);
 // pred.hip
 struct PredArgs {
   int nblk, nseg, R0, P, C, n128, n64, rtot, B_total;
@@ -264,6 +261,9 @@ struct LoocvArgs {
 };
 void rg_launch_decode_gt(hipStream_t st, const LoocvArgs& a);
 void rg_launch_l0_loocv(hipStream_t st, const LoocvArgs& a, double* part0, double* part1, int nchunk);
+// l1.hip: fold Grams of a row-major matrix with the level-1 Gram kernel (64x64 tile per wave)
+void rg_launch_fold_gram_rows(hipStream_t st, const double* G, int64_t ld, int L, int n64, int rtot, const double* zero,
+                              const SegLayout& seg, double* out);
 // l0_f64.hip: level 0 on non-integer genotypes (dosages)
 int rg_l0_blocks_f64_impl(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32_t* bs, const double* const* rows,
                           int64_t row_stride, int mem_kind);
