@@ -336,7 +336,9 @@ int rg_l0_blocks_f64_impl(rg_ctx* ctx, int nblk, const int32_t* block_ids, const
         // ride along as extra right-hand-side rows of the (A + lambda_r I) systems (loocv.hip) -- the same launches as the
         // 2-bit path from here on, one block at a time (nbb == 1)
         rg_launch_fold_gram_rows(st, G, Np, nb, n64, rtot, ctx->d_zero, ctx->seg, ctx->d_sum);
-        rg_launch_dgemm_nt(st, Yp, Np, G, Np, rhs_pad, n64, Np, ctx->d_sum + (int64_t)n64 * n64, n64);
+        hipLaunchKernelGGL(k_f64_gxpart, dim3(gpos, nb), dim3(256), 0, st, G, Np, Yp, P, part);
+        hipLaunchKernelGGL(k_f64_gysum, dim3((unsigned)(((int64_t)rhs_pad * n64 + 255) / 256)), dim3(256), 0, st, part, (int)gpos, P, nb, n64,
+                           rhs_pad, ctx->seg, ctx->d_sum, msz);
         hipLaunchKernelGGL(k_f64_transpose, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, G, Np, n64, ctx->d_gt);
         rg_launch_chol_solve_formed_x(st, ctx->d_sum, msz, ctx->d_fold, msz, 1, ctx->d_lambda, R0, ctx->d_bs, 0, 1, ctx->d_wk,
                                       ctx->rtot_wk * n64, n64, (int)(ctx->rtot_wk - n64), 0, ctx->d_dinv, ctx->d_info + 1,
