@@ -14,6 +14,7 @@
 #include <unistd.h>
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -96,44 +97,51 @@ class Reader {
     // variant scan: identifying data, then skip the genotype block
     pos = 4ull + offset;
     vars_.reserve(m_);
-    std::vector<uint8_t> buf(1 << 16);
+    // the identifying data of a variant is a few dozen bytes in front of a genotype block that is skipped: one small read
+    // per variant (a window that is refilled when a field runs past it) instead of one system call per field
+    std::vector<uint8_t> win;
+    uint64_t woff = 0;
+    auto fetch = [&](uint64_t at, uint64_t len) -> const uint8_t* {
+      need(at, len, path);
+      if (at < woff || at + len > woff + win.size()) {
+        const uint64_t want = std::min<uint64_t>(std::max<uint64_t>(len, 512), fsize_ - at);
+        win.resize(want);
+        if (!pread_all(win.data(), want, at)) throw std::runtime_error("cannot read bgen file : " + path);
+        woff = at;
+      }
+      return win.data() + (at - woff);
+    };
     for (uint32_t j = 0; j < m_; ++j) {
       Variant v;
       v.offset = pos;
       auto str16 = [&](std::string& s) {
         uint16_t l;
-        need(pos, 2, path);
-        pread_all(&l, 2, pos);
+        std::memcpy(&l, fetch(pos, 2), 2);
         pos += 2;
-        need(pos, l, path);
-        s.resize(l);
-        if (l) pread_all(&s[0], l, pos);
+        s.assign((const char*)fetch(pos, l), l);
         pos += l;
       };
       str16(v.id);
       str16(v.rsid);
       str16(v.chrom);
-      need(pos, 6, path);
       uint16_t k;
-      pread_all(&v.position, 4, pos);
-      pread_all(&k, 2, pos + 4);
+      {
+        const uint8_t* q = fetch(pos, 6);
+        std::memcpy(&v.position, q, 4);
+        std::memcpy(&k, q + 4, 2);
+      }
       pos += 6;
       if (k != 2) throw std::runtime_error("only bi-allelic variants are accepted (variant '" + v.rsid + "' has " + std::to_string(k) + " alleles).");
       for (int a = 0; a < 2; ++a) {
         uint32_t l;
-        need(pos, 4, path);
-        pread_all(&l, 4, pos);
+        std::memcpy(&l, fetch(pos, 4), 4);
         pos += 4;
-        need(pos, l, path);
-        std::string& s = a ? v.a1 : v.a0;
-        s.resize(l);
-        if (l) pread_all(&s[0], l, pos);
+        (a ? v.a1 : v.a0).assign((const char*)fetch(pos, l), l);
         pos += l;
       }
       v.data = pos;
       uint32_t c;
-      need(pos, 4, path);
-      pread_all(&c, 4, pos);
+      std::memcpy(&c, fetch(pos, 4), 4);
       pos += 4ull + c;
       if (pos > fsize_) throw std::runtime_error("bgen file ends inside the data of variant '" + v.rsid + "' : " + path);
       vars_.push_back(std::move(v));
