@@ -407,3 +407,64 @@ def test_cli_pgen_reads_files_then_needs_a_gpu(example_dir, tmp_path):
     r = _cli(pfx, example_dir, str(tmp_path))
     assert "n_snps = 1000" in r.stdout and "n_samples = 500" in r.stdout and " * pgen" in r.stdout
     assert r.returncode != 0 and "no MI355X / HIP device available" in r.stdout
+
+
+# ---- property test: any genotype matrix, any admissible record type per variant, any header layout -------------------------
+try:
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    HAVE_HYP = True
+except Exception:  # pragma: no cover
+    HAVE_HYP = False
+
+
+@pytest.mark.skipif(not HAVE_HYP, reason="hypothesis not installed")
+def test_reader_matches_oracle_on_random_files(tmp_path_factory):
+    d = tmp_path_factory.mktemp("hyp")
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+    @given(st.integers(1, 40), st.integers(1, 300), st.integers(0, 2 ** 31 - 1), st.sampled_from([1, 2, 3, 4]), st.booleans(),
+           st.sampled_from([0, 1, 2, 3]))
+    def run(m, n, seed, rl, wide, nonref):
+        rng = np.random.default_rng(seed)
+        lim = n // opg.MAX_DIFFLIST_DIV
+        g = np.zeros((m, n), dtype=np.uint8)
+        vts = []
+        prev = None
+        for j in range(m):
+            base = rng.integers(0, 4, n).astype(np.uint8) if rng.random() < 0.3 else np.full(n, rng.integers(0, 4), np.uint8)
+            k = int(rng.integers(0, lim + 1)) if lim else 0
+            if prev is not None and rng.random() < 0.4:
+                base = prev.copy() if rng.random() < 0.5 else opg._invert(prev)
+            pos = rng.choice(n, size=k, replace=False)
+            base[pos] = rng.integers(0, 4, k)
+            g[j] = base
+            cand = [0]
+            cnt = np.bincount(base, minlength=4)
+            if n - np.sort(cnt)[-2:].sum() <= lim:
+                cand.append(1)
+            for b, t in ((0, 4), (2, 6), (3, 7)):
+                if (base != b).sum() <= lim:
+                    cand.append(t)
+            if not base.any():
+                cand.append(5)
+            if prev is not None:
+                if (base != prev).sum() <= lim:
+                    cand.append(2)
+                if (opg._invert(base) != prev).sum() <= lim:
+                    cand.append(3)
+            t = int(rng.choice(cand))
+            vts.append(t)
+            if (t & 6) != 2:
+                prev = base
+        path = str(d / ("h%d.pgen" % seed))
+        opg.write_pgen(path, g, vts, reclen_bytes=rl, wide_vrtypes=wide, phase=wide and bool(seed & 1), nonref=nonref, seed=seed)
+        o = opg.PgenOracle(path)
+        with PgenFile(path) as f:
+            order = rng.permutation(m)
+            rows = f.read_bed_rows(order)
+            for a, j in enumerate(order):
+                assert (rows[a] == o.bed_row(int(j))).all(), (j, vts[j])
+                assert (o.codes(int(j)) == g[j]).all()
+        os.remove(path)
+
+    run()
