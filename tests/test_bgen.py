@@ -97,3 +97,56 @@ def test_refusals_and_damage(tmp_path, example_dir):
         assert f.read_dosages([4]).shape == (1, 500)
         with pytest.raises(RgError):
             f.read_dosages([500])
+
+
+# ---- the host driver's --bgen / --sample handling (runs before any device is touched) ---------------------------------------
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "regenie_amd", "bin", "regenie-amd")
+
+
+def _cli(args, cwd):
+    import subprocess
+    from regenie_amd import build
+    build.build()
+    return subprocess.run([BIN, "--step", "1", "--bsize", "100", "--out", os.path.join(cwd, "o")] + args, cwd=cwd, capture_output=True,
+                          text=True, timeout=120)
+
+
+def test_cli_bgen_input_messages(example_dir, tmp_path):
+    """Messages of prep_bgen / read_bgen_sample (Geno.cpp:38-175, :395-456)."""
+    E = example_dir
+    ph = ["--phenoFile", os.path.join(E, "phenotype.txt")]
+    cwd = str(tmp_path)
+    r = _cli(["--bgen", os.path.join(E, "example.bgen")] + ph, cwd)
+    assert " * bgen" in r.stdout and "with 500 named samples and 1000 variants with 8-bit encoding" in r.stdout
+    assert "-n_snps = 1000" in r.stdout and "-n_samples = 500" in r.stdout
+    sample = open(os.path.join(E, "example_3chr.sample")).read().split("\n")
+
+    def with_sample(lines):
+        p = str(tmp_path / "s.sample")
+        open(p, "w").write("\n".join(lines))
+        r = _cli(["--bgen", os.path.join(E, "example_3chr.bgen"), "--sample", p] + ph, cwd)
+        assert r.returncode != 0
+        return r.stdout
+
+    assert "ERROR: number of samples in BGEN file does not match that in the sample file." in with_sample(sample[:-3] + [""])
+    assert "ERROR: header of the sample file must start with: ID_1 ID_2" in with_sample(["FID IID missing"] + sample[1:])
+    assert "ERROR: second line of sample file must start with: 0 0." in with_sample(sample[:1] + ["1 1 0 D P"] + sample[2:])
+    assert "ERROR: duplicate individual in bgen file : FID_IID =1_1" in with_sample(sample[:3] + [sample[2]] + sample[4:])
+    # a file without embedded identifiers needs --sample; an unknown chromosome code is refused
+    rng = np.random.default_rng(0)
+    probs = np.zeros((5, 8, 2), np.uint8)
+    probs[:, :, 0] = 255
+    variants = [("1", 10 + j, "v%d" % j, "A", "C") for j in range(5)]
+    p = str(tmp_path / "noids.bgen")
+    obg.write_bgen(p, probs, np.zeros((5, 8), bool), variants, sample_ids=None)
+    r = _cli(["--bgen", p] + ph, cwd)
+    assert r.returncode != 0 and "ERROR: bgen file has no sample identifiers; specify a sample file with --sample" in r.stdout
+    variants[2] = ("chrUn", 12, "v2", "A", "C")
+    p = str(tmp_path / "badchr.bgen")
+    obg.write_bgen(p, probs, np.zeros((5, 8), bool), variants, sample_ids=["%d_%d" % (i, i) for i in range(8)])
+    r = _cli(["--bgen", p] + ph, cwd)
+    assert r.returncode != 0 and "ERROR: unknown chromosome code in bgen file." in r.stdout
+    # more than one genotype input
+    r = _cli(["--bgen", os.path.join(E, "example.bgen"), "--bed", os.path.join(E, "example")] + ph, cwd)
+    assert r.returncode != 0 and "ERROR: must use either --bed,--bgen or --pgen." in r.stdout
