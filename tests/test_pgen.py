@@ -421,7 +421,7 @@ except Exception:  # pragma: no cover
 def test_reader_matches_oracle_on_random_files(tmp_path_factory):
     d = tmp_path_factory.mktemp("hyp")
 
-    @settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+    @settings(max_examples=60, deadline=None, derandomize=True, database=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
     @given(st.integers(1, 40), st.integers(1, 300), st.integers(0, 2 ** 31 - 1), st.sampled_from([1, 2, 3, 4]), st.booleans(),
            st.sampled_from([0, 1, 2, 3]))
     def run(m, n, seed, rl, wide, nonref):
