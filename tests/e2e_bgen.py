@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """End-to-end wall time of the C++ driver on a synthetic BGEN v1.2 file (8-bit, zlib): inflate + dosage decode on the host
-threads, fp64 level 0 on the GPU.  Usage (GPU box): python tools/bgen_e2e.py [N=20000] [M=4000]"""
+threads, fp64 level 0 on the GPU.  Usage (GPU box): python tests/e2e_bgen.py [N=20000] [M=4000]"""
 import os
 import subprocess
 import sys
@@ -9,7 +9,7 @@ import time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 
-from oracle import bgen as obg   # fixture writer only (this is a measurement tool, not the product path)
+from oracle import bgen as obg   # fixture writer only: this measurement script lives under tests/ for that reason
 
 
 def main(N=20000, M=4000, bs=1000):
