@@ -1,0 +1,65 @@
+/* rg_step2.h -- C ABI of the Step-2 quantitative-trait score test (first slice).
+ *
+ * What it replaces in the reference (`regenie --step 2 --qt`, dense genotypes, the default non-strict mode):
+ *   rg_s2_set_null    the per-chromosome constants the tests read: new_cov (orthonormal covariate basis), the scaled
+ *                     LOCO residuals `res`, masked_indivs and scf_sv = scale_Y * p_sd_yres      Data.cpp:2386-2400 (compute_res)
+ *   rg_s2_qt_block    for one block of variants: mean imputation of the missing entries            Geno.cpp:3183-3188
+ *                     G <- G - X (X^T G), scale_fac = |G| / sqrt(n - C), "ignored" below numtol    Geno.cpp:3242-3260 (residualize_geno)
+ *                     num = res^T G * gsc, denum = gsc^2 * mask^T G^2, stats = num / sqrt(denum),
+ *                     bhat = stats * scf_sv / sqrt(denum), se = bhat / stats, chisq = stats^2      Step2_Models.cpp:343-468 (compute_score_qt)
+ *                     called per variant from compute_tests_mt                                      Data.cpp:2476-2555
+ * Not in this slice (the host keeps doing them): reading the LOCO file (blup_read_chr), the MAC / INFO filters, the sparse
+ * genotype shortcut (same statistic, different summation), --strict, mse_full, MCC, the p-value and the output lines.
+ *
+ * Layout: every matrix is row-major with the SAMPLE index fastest -- G is [bs][ldg], X is [C][n], yres and mask are [P][n];
+ * n = samples in the analysis, in the caller's order.  A missing genotype is NaN or any value < 0 (regenie's -3).
+ * Conventions: 0 on success, <0 on error with rg_s2_last_error(ctx); the library never falls back to the CPU.
+ */
+#ifndef RG_STEP2_H
+#define RG_STEP2_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rg_s2_ctx rg_s2_ctx;
+
+#define RG_S2_OK 0
+#define RG_S2_ERR_ARG (-1)
+#define RG_S2_ERR_HIP (-2)
+
+#define RG_S2_MAX_COV 64
+#define RG_S2_MAX_PHENO 64
+
+/* n samples in the analysis, C covariate basis columns (intercept included, as in new_cov), P phenotypes. */
+int rg_s2_create(rg_s2_ctx** out, int device, int64_t n, int32_t n_cov, int32_t n_pheno);
+void rg_s2_destroy(rg_s2_ctx* ctx);
+const char* rg_s2_last_error(const rg_s2_ctx* ctx);
+
+/* Per chromosome (the LOCO residuals change with it): X [C][n] orthonormal, yres [P][n] already masked and scaled,
+ * mask [P][n] bytes (0 / 1), scf_sv [P].  Host pointers; copied to the device. */
+int rg_s2_set_null(rg_s2_ctx* ctx, const double* X, const double* yres, const uint8_t* mask, const double* scf_sv);
+
+typedef struct rg_s2_qt_out {
+  double* stats;     /* [bs][P]  num / sqrt(denum)  (NaN for an ignored variant)       */
+  double* bhat;      /* [bs][P]  effect size on the raw genotype scale                   */
+  double* scale_fac; /* [bs]     block_info->scale_fac                                   */
+  double* mean;      /* [bs]     mean over the non-missing samples (= 2 * allele freq.)  */
+  int32_t* n_obs;    /* [bs]     non-missing samples                                     */
+  int32_t* ignored;  /* [bs]     1 when scale_fac < numtol (or nothing observed)         */
+} rg_s2_qt_out;      /* every pointer is a HOST pointer and may be NULL                  */
+
+/* One block of bs variants.  G is a host pointer, or a device pointer when g_on_device != 0 (then it is read in place).
+ * se = bhat / stats and chisq = stats^2 are left to the caller. */
+int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int32_t g_on_device, double numtol,
+                   const rg_s2_qt_out* out);
+
+/* Device time of the kernels of the last rg_s2_qt_block call (hipEvents on the library's stream), in ms. */
+double rg_s2_last_kernel_ms(const rg_s2_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

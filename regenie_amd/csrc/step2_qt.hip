@@ -1,0 +1,399 @@
+// Step-2 quantitative-trait score test for one block of variants (include/rg_step2.h; SURVEY.md 8(f) row 1, first slice).
+//
+// Reference path: compute_tests_mt (Data.cpp:2476-2555) -> residualize_geno (Geno.cpp:3242-3260) -> compute_score_qt
+// (Step2_Models.cpp:343-468), dense genotypes, non-strict mode.  With r = g~ - X (X^T g~) (g~ = mean-imputed genotypes) the
+// reference's num = res^T (r / sf) * sf and denum = sf^2 * mask^T (r / sf)^2 are res^T r and mask^T r^2, so the scaled
+// genotypes are never materialised: two streaming passes over the block, both HBM-bound (8 B per genotype each).
+//
+//   pass 1  k_s2_proj   per variant: sum and count of the observed entries, A_c = sum g0 x_c and M_c = sum miss x_c
+//                       (g0 = g with 0 at the missing entries)  ->  mu = sum / count, beta_c = A_c + mu M_c
+//   pass 2  k_s2_score  r = g~ - sum_c beta_c x_c;  |r|^2, and per phenotype res_p . r and mask_p . r^2
+//
+// A workgroup owns VPB = 4 variants x 2048 samples so that every X / res / mask element it loads is used for four variants;
+// each thread keeps its 8 samples of the 4 variants in registers.  The 8 partial sums a thread carries per covariate (or per
+// phenotype) are reduced across the wave with one butterfly that halves the value count at each of the first three exchange
+// steps (10 exchanges instead of 48).  Partials per (variant, 2048-sample chunk) are summed in chunk order: deterministic.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/rg_step2.h"
+
+namespace {
+
+constexpr int VPB = 4;          // variants per workgroup
+constexpr int EPT = 8;          // samples per thread
+constexpr int CH = 256 * EPT;   // samples per workgroup
+
+__device__ __forceinline__ bool is_missing(double g) { return !(g >= 0.0); }   // NaN, or regenie's -3
+
+// v[0..7] are eight independent per-lane partial sums.  On return v[0] of every lane holds the wave total of value
+// (lane >> 3); the summation tree is fixed.
+__device__ __forceinline__ void wave_reduce8(double (&v)[8]) {
+  const int lane = threadIdx.x & 63;
+  {
+    const bool hi = lane & 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double keep = hi ? v[4 + i] : v[i], send = hi ? v[i] : v[4 + i];
+      v[i] = keep + __shfl_xor(send, 32);
+    }
+  }
+  {
+    const bool hi = lane & 16;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const double keep = hi ? v[2 + i] : v[i], send = hi ? v[i] : v[2 + i];
+      v[i] = keep + __shfl_xor(send, 16);
+    }
+  }
+  {
+    const bool hi = lane & 8;
+    const double keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
+    v[0] = keep + __shfl_xor(send, 8);
+  }
+  v[0] += __shfl_xor(v[0], 4);
+  v[0] += __shfl_xor(v[0], 2);
+  v[0] += __shfl_xor(v[0], 1);
+}
+
+// grid (ceil(bs / VPB), nchunk).  part1[(j * nchunk + chunk) * Q1 + q], Q1 = 2 + 2C: sum, count, A_c (C), M_c (C)
+__global__ __launch_bounds__(256) void k_s2_proj(const double* __restrict__ G, int64_t ldg, int bs, int64_t n,
+                                                 const double* __restrict__ X, int C, double* __restrict__ part1) {
+  __shared__ double red[4][VPB][2 + 2 * RG_S2_MAX_COV];
+  const int j0 = blockIdx.x * VPB, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.y * CH + threadIdx.x;
+  double g[VPB][EPT];
+  uint32_t miss[VPB];
+  double v8[8];
+#pragma unroll
+  for (int v = 0; v < VPB; ++v) {
+    miss[v] = 0;
+    double s = 0.0, cnt = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int64_t pos = base + (int64_t)k * 256;
+      double x = 0.0;
+      if (pos < n && j0 + v < bs) {
+        x = G[(int64_t)(j0 + v) * ldg + pos];
+        if (is_missing(x)) { x = 0.0; miss[v] |= 1u << k; } else cnt += 1.0;
+      }
+      g[v][k] = x;
+      s += x;
+    }
+    v8[v] = s;
+    v8[VPB + v] = cnt;
+  }
+  wave_reduce8(v8);
+  if ((lane & 7) == 0) { const int q = lane >> 3; red[w][q & 3][q >> 2] = v8[0]; }
+  for (int c = 0; c < C; ++c) {
+    double xk[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int64_t pos = base + (int64_t)k * 256;
+      xk[k] = pos < n ? X[(int64_t)c * n + pos] : 0.0;
+    }
+#pragma unroll
+    for (int v = 0; v < VPB; ++v) {
+      double a = 0.0, m = 0.0;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        a += g[v][k] * xk[k];
+        m += ((miss[v] >> k) & 1u) ? xk[k] : 0.0;
+      }
+      v8[v] = a;
+      v8[VPB + v] = m;
+    }
+    wave_reduce8(v8);
+    if ((lane & 7) == 0) { const int q = lane >> 3; red[w][q & 3][2 + (q >> 2) * C + c] = v8[0]; }
+  }
+  __syncthreads();
+  const int Q1 = 2 + 2 * C;
+  for (int idx = threadIdx.x; idx < VPB * Q1; idx += 256) {
+    const int v = idx / Q1, q = idx % Q1;
+    if (j0 + v < bs)
+      part1[((int64_t)(j0 + v) * gridDim.y + blockIdx.y) * Q1 + q] = (red[0][v][q] + red[1][v][q]) + (red[2][v][q] + red[3][v][q]);
+  }
+}
+
+// thread = (variant j, covariate c): fixed-order sums over the chunks, mu = sum / count, beta_c = A_c + mu M_c
+__global__ void k_s2_beta(const double* __restrict__ part1, int nchunk, int C, int bs, double* __restrict__ beta /*[bs][64]*/,
+                          double* __restrict__ mu, int32_t* __restrict__ nobs) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bs * C) return;
+  const int j = t / C, c = t % C, Q1 = 2 + 2 * C;
+  double s = 0.0, cnt = 0.0, a = 0.0, m = 0.0;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const double* p = part1 + ((int64_t)j * nchunk + ch) * Q1;
+    s += p[0]; cnt += p[1]; a += p[2 + c]; m += p[2 + C + c];
+  }
+  const double mean = s / cnt;   // NaN when nothing is observed: the variant comes out as ignored
+  beta[(int64_t)j * RG_S2_MAX_COV + c] = a + mean * m;
+  if (c == 0) { mu[j] = mean; nobs[j] = (int32_t)cnt; }
+}
+
+// grid (ceil(bs / VPB), nchunk).  part2[(j * nchunk + chunk) * Q2 + q], Q2 = 1 + 2P: |r|^2, res_p . r (P), mask_p . r^2 (P)
+__global__ __launch_bounds__(256) void k_s2_score(const double* __restrict__ G, int64_t ldg, int bs, int64_t n,
+                                                  const double* __restrict__ X, int C, const double* __restrict__ Y,
+                                                  const uint8_t* __restrict__ M, int P, const double* __restrict__ beta,
+                                                  const double* __restrict__ mu, double* __restrict__ part2) {
+  __shared__ double sb[VPB][RG_S2_MAX_COV];
+  __shared__ double smu[VPB];
+  __shared__ double red[4][VPB][1 + 2 * RG_S2_MAX_PHENO];
+  const int j0 = blockIdx.x * VPB, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.y * CH + threadIdx.x;
+  for (int idx = threadIdx.x; idx < VPB * C; idx += 256) {
+    const int v = idx / C, c = idx % C;
+    sb[v][c] = j0 + v < bs ? beta[(int64_t)(j0 + v) * RG_S2_MAX_COV + c] : 0.0;
+  }
+  if (threadIdx.x < VPB) smu[threadIdx.x] = j0 + threadIdx.x < bs ? mu[j0 + threadIdx.x] : 0.0;
+  __syncthreads();
+  double r[VPB][EPT];
+#pragma unroll
+  for (int v = 0; v < VPB; ++v)
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int64_t pos = base + (int64_t)k * 256;
+      double x = 0.0;
+      if (pos < n && j0 + v < bs) {
+        x = G[(int64_t)(j0 + v) * ldg + pos];
+        if (is_missing(x)) x = smu[v];
+      }
+      r[v][k] = x;
+    }
+  for (int c = 0; c < C; ++c) {
+    double xk[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int64_t pos = base + (int64_t)k * 256;
+      xk[k] = pos < n ? X[(int64_t)c * n + pos] : 0.0;
+    }
+#pragma unroll
+    for (int v = 0; v < VPB; ++v) {
+      const double b = sb[v][c];
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) r[v][k] -= b * xk[k];
+    }
+  }
+  double v8[8];
+#pragma unroll
+  for (int v = 0; v < VPB; ++v) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) s += r[v][k] * r[v][k];
+    v8[v] = s;
+    v8[VPB + v] = 0.0;
+  }
+  wave_reduce8(v8);
+  if ((lane & 7) == 0 && (lane >> 3) < VPB) red[w][lane >> 3][0] = v8[0];
+  for (int p = 0; p < P; ++p) {
+    double yk[EPT], mk[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const int64_t pos = base + (int64_t)k * 256;
+      yk[k] = pos < n ? Y[(int64_t)p * n + pos] : 0.0;
+      mk[k] = (pos < n && M[(int64_t)p * n + pos]) ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int v = 0; v < VPB; ++v) {
+      double num = 0.0, den = 0.0;
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) {
+        num += yk[k] * r[v][k];
+        den += mk[k] * (r[v][k] * r[v][k]);
+      }
+      v8[v] = num;
+      v8[VPB + v] = den;
+    }
+    wave_reduce8(v8);
+    if ((lane & 7) == 0) { const int q = lane >> 3; red[w][q & 3][1 + (q >> 2) * P + p] = v8[0]; }
+  }
+  __syncthreads();
+  const int Q2 = 1 + 2 * P;
+  for (int idx = threadIdx.x; idx < VPB * Q2; idx += 256) {
+    const int v = idx / Q2, q = idx % Q2;
+    if (j0 + v < bs)
+      part2[((int64_t)(j0 + v) * gridDim.y + blockIdx.y) * Q2 + q] = (red[0][v][q] + red[1][v][q]) + (red[2][v][q] + red[3][v][q]);
+  }
+}
+
+// thread = (variant j, phenotype p): the statistic and the effect size (Step2_Models.cpp:415-431)
+__global__ void k_s2_final(const double* __restrict__ part2, int nchunk, int P, int bs, double df /* n - C */, double numtol,
+                           const double* __restrict__ scf_sv, const int32_t* __restrict__ nobs, double* __restrict__ stats,
+                           double* __restrict__ bhat, double* __restrict__ scale_fac, int32_t* __restrict__ ignored) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bs * P) return;
+  const int j = t / P, p = t % P, Q2 = 1 + 2 * P;
+  double ss = 0.0, num = 0.0, den = 0.0;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const double* q = part2 + ((int64_t)j * nchunk + ch) * Q2;
+    ss += q[0]; num += q[1 + p]; den += q[1 + P + p];
+  }
+  const double sf = sqrt(ss) / sqrt(df);                 // residualize_geno: norm / sqrt(n_analyzed - X.cols())
+  const bool ign = !(sf >= numtol) || nobs[j] == 0;      // also catches NaN
+  const double sd = sqrt(den);
+  const double z = num / sd;
+  stats[(int64_t)j * P + p] = ign ? NAN : z;
+  bhat[(int64_t)j * P + p] = ign ? NAN : z * scf_sv[p] / sd;
+  if (p == 0) { scale_fac[j] = sf; ignored[j] = ign ? 1 : 0; }
+}
+
+}  // namespace
+
+struct rg_s2_ctx {
+  int dev = 0;
+  int64_t n = 0;
+  int C = 0, P = 0;
+  bool have_null = false;
+  hipStream_t st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  double *dX = nullptr, *dY = nullptr, *dscf = nullptr;
+  uint8_t* dM = nullptr;
+  void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double last_ms = 0.0;
+  std::string err;
+};
+
+namespace {
+int fail(rg_s2_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+#define S2_HIP(call)                                                                                         \
+  do {                                                                                                       \
+    hipError_t e_ = (call);                                                                                  \
+    if (e_ != hipSuccess) return fail(ctx, RG_S2_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+int ensure(rg_s2_ctx* ctx, int slot, size_t bytes) {
+  if (ctx->cap[slot] >= bytes) return RG_S2_OK;
+  if (ctx->buf[slot]) S2_HIP(hipFree(ctx->buf[slot]));
+  ctx->buf[slot] = nullptr;
+  ctx->cap[slot] = 0;
+  S2_HIP(hipMalloc(&ctx->buf[slot], bytes));
+  ctx->cap[slot] = bytes;
+  return RG_S2_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int rg_s2_create(rg_s2_ctx** out, int device, int64_t n, int32_t n_cov, int32_t n_pheno) {
+  if (!out) return RG_S2_ERR_ARG;
+  rg_s2_ctx* ctx = new rg_s2_ctx();
+  *out = ctx;
+  if (n <= 0 || n_cov < 1 || n_cov > RG_S2_MAX_COV || n_pheno < 1 || n_pheno > RG_S2_MAX_PHENO || n <= n_cov)
+    return fail(ctx, RG_S2_ERR_ARG, "rg_s2_create: need n > n_cov, 1 <= n_cov <= 64, 1 <= n_pheno <= 64");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(ctx, RG_S2_ERR_HIP, "rg_s2_create: no HIP device (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_create: device index out of range");
+  ctx->dev = device; ctx->n = n; ctx->C = n_cov; ctx->P = n_pheno;
+  S2_HIP(hipSetDevice(device));
+  S2_HIP(hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking));
+  S2_HIP(hipEventCreate(&ctx->e0));
+  S2_HIP(hipEventCreate(&ctx->e1));
+  S2_HIP(hipMalloc((void**)&ctx->dX, sizeof(double) * n * n_cov));
+  S2_HIP(hipMalloc((void**)&ctx->dY, sizeof(double) * n * n_pheno));
+  S2_HIP(hipMalloc((void**)&ctx->dM, (size_t)n * n_pheno));
+  S2_HIP(hipMalloc((void**)&ctx->dscf, sizeof(double) * n_pheno));
+  return RG_S2_OK;
+}
+
+void rg_s2_destroy(rg_s2_ctx* ctx) {
+  if (!ctx) return;
+  if (ctx->st) {
+    (void)hipSetDevice(ctx->dev);
+    (void)hipStreamSynchronize(ctx->st);
+    for (void* p : ctx->buf) if (p) (void)hipFree(p);
+    if (ctx->dX) (void)hipFree(ctx->dX);
+    if (ctx->dY) (void)hipFree(ctx->dY);
+    if (ctx->dM) (void)hipFree(ctx->dM);
+    if (ctx->dscf) (void)hipFree(ctx->dscf);
+    if (ctx->e0) (void)hipEventDestroy(ctx->e0);
+    if (ctx->e1) (void)hipEventDestroy(ctx->e1);
+    (void)hipStreamDestroy(ctx->st);
+  }
+  delete ctx;
+}
+
+const char* rg_s2_last_error(const rg_s2_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rg_s2_set_null(rg_s2_ctx* ctx, const double* X, const double* yres, const uint8_t* mask, const double* scf_sv) {
+  if (!ctx || !ctx->st) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_set_null: context was not created");
+  if (!X || !yres || !mask || !scf_sv) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_set_null: null argument");
+  S2_HIP(hipSetDevice(ctx->dev));
+  S2_HIP(hipMemcpyAsync(ctx->dX, X, sizeof(double) * ctx->n * ctx->C, hipMemcpyHostToDevice, ctx->st));
+  S2_HIP(hipMemcpyAsync(ctx->dY, yres, sizeof(double) * ctx->n * ctx->P, hipMemcpyHostToDevice, ctx->st));
+  S2_HIP(hipMemcpyAsync(ctx->dM, mask, (size_t)ctx->n * ctx->P, hipMemcpyHostToDevice, ctx->st));
+  S2_HIP(hipMemcpyAsync(ctx->dscf, scf_sv, sizeof(double) * ctx->P, hipMemcpyHostToDevice, ctx->st));
+  S2_HIP(hipStreamSynchronize(ctx->st));
+  ctx->have_null = true;
+  return RG_S2_OK;
+}
+
+int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int32_t g_on_device, double numtol,
+                   const rg_s2_qt_out* out) {
+  if (!ctx || !ctx->st) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block: context was not created");
+  if (!ctx->have_null) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block: rg_s2_set_null has not been called");
+  if (!G || !out || bs < 1 || ldg < ctx->n) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block: bad arguments (need bs >= 1, ldg >= n)");
+  const int64_t n = ctx->n;
+  const int C = ctx->C, P = ctx->P, Q1 = 2 + 2 * C, Q2 = 1 + 2 * P;
+  const int nchunk = (int)((n + CH - 1) / CH);
+  const unsigned gv = (unsigned)((bs + VPB - 1) / VPB);
+  S2_HIP(hipSetDevice(ctx->dev));
+  enum { B_G, B_PART, B_BETA, B_VAR, B_NOBS, B_STAT };
+  const size_t part_elems = (size_t)bs * nchunk * (size_t)(Q1 > Q2 ? Q1 : Q2);
+  int rc;
+  if ((rc = ensure(ctx, B_PART, part_elems * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, B_BETA, (size_t)bs * RG_S2_MAX_COV * sizeof(double)))) return rc;
+  if ((rc = ensure(ctx, B_VAR, (size_t)bs * 2 * sizeof(double)))) return rc;       // mu | scale_fac
+  if ((rc = ensure(ctx, B_NOBS, (size_t)bs * 2 * sizeof(int32_t)))) return rc;     // nobs | ignored
+  if ((rc = ensure(ctx, B_STAT, (size_t)bs * P * 2 * sizeof(double)))) return rc;  // stats | bhat
+  const double* dG = G;
+  int64_t ld = ldg;
+  if (!g_on_device) {
+    if ((rc = ensure(ctx, B_G, (size_t)bs * n * sizeof(double)))) return rc;
+    S2_HIP(hipMemcpy2DAsync(ctx->buf[B_G], n * sizeof(double), G, ldg * sizeof(double), n * sizeof(double), bs,
+                            hipMemcpyHostToDevice, ctx->st));
+    dG = (const double*)ctx->buf[B_G];
+    ld = n;
+  }
+  double* part = (double*)ctx->buf[B_PART];
+  double* beta = (double*)ctx->buf[B_BETA];
+  double* mu = (double*)ctx->buf[B_VAR];
+  double* sf = mu + bs;
+  int32_t* nobs = (int32_t*)ctx->buf[B_NOBS];
+  int32_t* ign = nobs + bs;
+  double* stats = (double*)ctx->buf[B_STAT];
+  double* bhat = stats + (size_t)bs * P;
+  S2_HIP(hipEventRecord(ctx->e0, ctx->st));
+  hipLaunchKernelGGL(k_s2_proj, dim3(gv, nchunk), dim3(256), 0, ctx->st, dG, ld, bs, n, ctx->dX, C, part);
+  hipLaunchKernelGGL(k_s2_beta, dim3((bs * C + 255) / 256), dim3(256), 0, ctx->st, part, nchunk, C, bs, beta, mu, nobs);
+  hipLaunchKernelGGL(k_s2_score, dim3(gv, nchunk), dim3(256), 0, ctx->st, dG, ld, bs, n, ctx->dX, C, ctx->dY, ctx->dM, P, beta, mu,
+                     part);
+  hipLaunchKernelGGL(k_s2_final, dim3((bs * P + 255) / 256), dim3(256), 0, ctx->st, part, nchunk, P, bs, (double)(n - C), numtol,
+                     ctx->dscf, nobs, stats, bhat, sf, ign);
+  S2_HIP(hipEventRecord(ctx->e1, ctx->st));
+  S2_HIP(hipGetLastError());
+  if (out->stats) S2_HIP(hipMemcpyAsync(out->stats, stats, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));
+  if (out->bhat) S2_HIP(hipMemcpyAsync(out->bhat, bhat, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));
+  if (out->scale_fac) S2_HIP(hipMemcpyAsync(out->scale_fac, sf, sizeof(double) * bs, hipMemcpyDeviceToHost, ctx->st));
+  if (out->mean) S2_HIP(hipMemcpyAsync(out->mean, mu, sizeof(double) * bs, hipMemcpyDeviceToHost, ctx->st));
+  if (out->n_obs) S2_HIP(hipMemcpyAsync(out->n_obs, nobs, sizeof(int32_t) * bs, hipMemcpyDeviceToHost, ctx->st));
+  if (out->ignored) S2_HIP(hipMemcpyAsync(out->ignored, ign, sizeof(int32_t) * bs, hipMemcpyDeviceToHost, ctx->st));
+  S2_HIP(hipStreamSynchronize(ctx->st));
+  float ms = 0.f;
+  S2_HIP(hipEventElapsedTime(&ms, ctx->e0, ctx->e1));
+  ctx->last_ms = ms;
+  return RG_S2_OK;
+}
+
+double rg_s2_last_kernel_ms(const rg_s2_ctx* ctx) { return ctx ? ctx->last_ms : 0.0; }
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+"""Step-2 quantitative-trait score test (`regenie --step 2 --qt`, dense genotypes): ctypes wrapper over include/rg_step2.h
+(regenie_amd/csrc/step2_qt.hip).  Mirrors the reference's per-chromosome / per-block split: `set_null` is what
+Data::compute_res leaves behind (Data.cpp:2386-2400), `score_block` is compute_tests_mt over one block
+(Data.cpp:2476-2555 -> Geno.cpp:3242-3260 -> Step2_Models.cpp:343-468).  No CPU path: without the HIP library or a
+GPU the constructor raises."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from .engine import RgError, load_library
+
+
+class _QtOut(C.Structure):
+    _fields_ = [("stats", C.c_void_p), ("bhat", C.c_void_p), ("scale_fac", C.c_void_p), ("mean", C.c_void_p),
+                ("n_obs", C.c_void_p), ("ignored", C.c_void_p)]
+
+
+class Step2QT:
+    NUMTOL = 1e-6     # params.numtol, Regenie.hpp:220
+
+    def __init__(self, n: int, n_cov: int, n_pheno: int, device: int = 0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        self.n, self.C, self.P = int(n), int(n_cov), int(n_pheno)
+        rc = self.lib.rg_s2_create(C.byref(self.h), int(device), self.n, self.C, self.P)
+        if rc != 0:
+            msg = self.lib.rg_s2_last_error(self.h).decode() if self.h else "rg_s2_create failed"
+            self.close()
+            raise RgError(rc, msg)
+
+    def close(self) -> None:
+        if getattr(self, "h", None):
+            self.lib.rg_s2_destroy(self.h)
+        self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise RgError(rc, self.lib.rg_s2_last_error(self.h).decode())
+
+    def set_null(self, X: np.ndarray, yres: np.ndarray, mask: np.ndarray, scf_sv: np.ndarray) -> None:
+        """X [C][n] orthonormal covariate basis (new_cov^T), yres [P][n] masked + scaled LOCO residuals (res^T),
+        mask [P][n] (masked_indivs^T), scf_sv [P] = scale_Y * p_sd_yres."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        yres = np.ascontiguousarray(yres, dtype=np.float64)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        scf_sv = np.ascontiguousarray(scf_sv, dtype=np.float64)
+        if X.shape != (self.C, self.n) or yres.shape != (self.P, self.n) or mask.shape != (self.P, self.n) \
+                or scf_sv.shape != (self.P,):
+            raise ValueError("set_null: expected X %s, yres/mask %s, scf_sv (%d,)" % ((self.C, self.n), (self.P, self.n), self.P))
+        self._check(self.lib.rg_s2_set_null(self.h, X.ctypes.data, yres.ctypes.data, mask.ctypes.data, scf_sv.ctypes.data))
+
+    def score_block(self, G, numtol: float = NUMTOL) -> dict:
+        """G: numpy [bs][n] float64 (host), or a CUDA torch tensor [bs][n] float64 (read in place).  Missing = NaN or < 0."""
+        on_device = 0
+        if isinstance(G, np.ndarray):
+            G = np.ascontiguousarray(G, dtype=np.float64)
+            bs, ld, ptr = G.shape[0], G.shape[1], G.ctypes.data
+            if G.shape[1] != self.n:
+                raise ValueError("score_block: G must be [bs][n]")
+        else:   # torch tensor on the device
+            if not (G.is_cuda and G.dtype.is_floating_point and G.element_size() == 8 and G.dim() == 2 and G.stride(1) == 1):
+                raise ValueError("score_block: device G must be a 2-d float64 CUDA tensor with unit sample stride")
+            bs, ld, ptr, on_device = G.shape[0], G.stride(0), G.data_ptr(), 1
+            if G.shape[1] != self.n:
+                raise ValueError("score_block: G must be [bs][n]")
+            import torch
+            torch.cuda.current_stream(G.device).synchronize()   # the library runs on its own stream
+        res = {"stats": np.empty((bs, self.P)), "bhat": np.empty((bs, self.P)), "scale_fac": np.empty(bs),
+               "mean": np.empty(bs), "n_obs": np.empty(bs, np.int32), "ignored": np.empty(bs, np.int32)}
+        out = _QtOut(*[res[k].ctypes.data for k in ("stats", "bhat", "scale_fac", "mean", "n_obs", "ignored")])
+        self._check(self.lib.rg_s2_qt_block(self.h, ptr, ld, bs, on_device, float(numtol), C.byref(out)))
+        res["kernel_ms"] = self.lib.rg_s2_last_kernel_ms(self.h)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            res["se"] = res["bhat"] / res["stats"]          # Step2_Models.cpp:440
+            res["chisq"] = res["stats"] ** 2                # Step2_Models.cpp:443
+        return res

@@ -1,0 +1,110 @@
+"""Step-2 QT score test on the GPU (include/rg_step2.h through regenie_amd.step2.Step2QT) against the CPU restatement of
+the reference (oracle/regenie_step2_qt.py).  fp64 throughout; tolerance 1e-9 relative (the kernel sums 2048-sample chunk
+partials in chunk order, the reference sums along Eigen's vectorised order)."""
+import numpy as np
+import pytest
+
+from oracle import regenie_step2_qt as s2o
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def _problem(seed, n, C, P, bs, miss_y=0.05):
+    rng = np.random.default_rng(seed)
+    cov = np.column_stack([np.ones(n), rng.normal(size=(n, C - 1))]) if C > 1 else np.ones((n, 1))
+    X = np.linalg.qr(cov)[0]
+    Y = rng.normal(size=(n, P)) + 0.3 * rng.normal(size=(n, 1))
+    mask = np.ones((n, P))
+    if miss_y:
+        mask[rng.random((n, P)) < miss_y] = 0
+    Y = (Y - X @ (X.T @ Y)) * mask
+    neff = mask.sum(axis=0)
+    scale_Y = np.sqrt((Y ** 2).sum(axis=0) / (neff - C))
+    Y = Y / scale_Y
+    blup = 0.1 * rng.normal(size=(n, P)) * mask
+    res, _, scf = s2o.compute_res(Y, blup, mask, neff, C, scale_Y)
+    G = rng.binomial(2, rng.uniform(0.02, 0.5, size=bs)[:, None], size=(bs, n)).astype(np.float64)
+    return X, res, mask, scf, G
+
+
+def _run(X, res, mask, scf, G, **kw):
+    from regenie_amd.step2 import Step2QT
+    n, C = X.shape
+    with Step2QT(n, C, res.shape[1]) as s2:
+        s2.set_null(X.T, res.T, mask.T, scf)
+        return s2.score_block(G, **kw)
+
+
+def _compare(got, ref):
+    assert np.array_equal(got["ignored"], ref["ignored"])
+    assert np.array_equal(got["n_obs"], ref["n_obs"])
+    ok = ref["ignored"] == 0
+    assert np.isnan(got["stats"][~ok]).all() and np.isnan(got["bhat"][~ok]).all()
+    for k in ("stats", "bhat", "se", "chisq"):
+        scale = np.abs(ref[k][ok]).max()
+        assert np.allclose(got[k][ok], ref[k][ok], rtol=RTOL, atol=RTOL * scale), k
+    obs = ref["n_obs"] > 0
+    assert np.allclose(got["mean"][obs], ref["mean"][obs], rtol=1e-13)
+    assert np.allclose(got["scale_fac"][ok], ref["scale_fac"][ok], rtol=1e-11)
+
+
+@pytest.mark.parametrize("n,C,P,bs", [(5003, 5, 3, 37), (300, 1, 1, 1), (2048, 3, 2, 4), (4097, 12, 7, 9)])
+def test_parity_with_oracle(n, C, P, bs):
+    X, res, mask, scf, G = _problem(n + bs, n, C, P, bs)
+    rng = np.random.default_rng(7)
+    if bs >= 4:
+        G[0, rng.random(n) < 0.1] = np.nan            # missing as NaN
+        G[1, rng.random(n) < 0.02] = -3.0             # missing as regenie's code
+        G[2, :] = 2.0                                 # monomorphic -> scale_fac < numtol -> ignored
+        G[3, :] = np.nan                              # nothing observed -> ignored
+    G = G + (rng.random(G.shape) < 0.3) * rng.uniform(0, 0.01, size=G.shape) * (G < 1.5)   # dosages, not just hardcalls
+    if bs >= 4:
+        G[2, :] = 2.0
+    _compare(_run(X, res, mask, scf, G), s2o.score_qt_block(G, X, res, mask, scf))
+
+
+def test_device_pointer_input_and_determinism():
+    import torch
+    X, res, mask, scf, G = _problem(11, 9000, 6, 4, 50)
+    G[5, ::11] = np.nan
+    a = _run(X, res, mask, scf, G)
+    big = torch.full((50, 9216), float("nan"), dtype=torch.float64, device="cuda")   # padded leading dimension
+    big[:, :9000] = torch.from_numpy(G).cuda()
+    b = _run(X, res, mask, scf, big[:, :9000])
+    c = _run(X, res, mask, scf, G)
+    for k in ("stats", "bhat", "scale_fac", "mean"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+        assert np.array_equal(a[k], c[k], equal_nan=True), k
+
+
+def test_invariances_at_scale():
+    """Sizes the oracle does not loop over: the statistic ignores covariate-space shifts and the genotype scale, bhat
+    scales inversely, and a sub-block equals the same rows of the full block bit for bit."""
+    n, C, P, bs = 120_000, 10, 10, 256
+    X, res, mask, scf, G = _problem(3, n, C, P, bs, miss_y=0.1)
+    rng = np.random.default_rng(5)
+    base = _run(X, res, mask, scf, G)
+    assert not base["ignored"].any() and np.isfinite(base["stats"]).all()
+    shifted = _run(X, res, mask, scf, 0.5 * G + 3.0 + (X[:, 1:] @ rng.normal(size=(C - 1, bs))).T * 5.0 + 40.0)
+    assert np.allclose(shifted["stats"], base["stats"], rtol=1e-7, atol=1e-9)
+    assert np.allclose(shifted["bhat"], 2.0 * base["bhat"], rtol=1e-7, atol=1e-12)
+    sub = _run(X, res, mask, scf, G[64:131])
+    assert np.array_equal(sub["stats"], base["stats"][64:131]) and np.array_equal(sub["bhat"], base["bhat"][64:131])
+    # spot check against the oracle on a few rows
+    ref = s2o.score_qt_block(G[:6], X, res, mask, scf)
+    assert np.allclose(base["stats"][:6], ref["stats"], rtol=RTOL, atol=1e-10)
+    assert np.allclose(base["bhat"][:6], ref["bhat"], rtol=RTOL, atol=1e-13)
+
+
+def test_argument_errors():
+    from regenie_amd.engine import RgError
+    from regenie_amd.step2 import Step2QT
+    with pytest.raises(RgError):
+        Step2QT(100, 65, 1)
+    with pytest.raises(RgError):
+        Step2QT(10, 10, 1)
+    with Step2QT(100, 2, 1) as s2:
+        with pytest.raises(RgError, match="set_null"):
+            s2.score_block(np.zeros((3, 100)))
