@@ -9,15 +9,17 @@
 //                       (g0 = g with 0 at the missing entries)  ->  mu = sum / count, beta_c = A_c + mu M_c
 //   pass 2  k_s2_score  r = g~ - sum_c beta_c x_c;  |r|^2, and per phenotype res_p . r and mask_p . r^2
 //
-// A workgroup owns VPB = 4 variants x 2048 samples so that every X / res / mask element it loads is used for four variants;
-// each thread keeps its 8 samples of the 4 variants in registers.  The 8 partial sums a thread carries per covariate (or per
-// phenotype) are reduced across the wave with one butterfly that halves the value count at each of the first three exchange
-// steps (10 exchanges instead of 48).  Partials per (variant, 2048-sample chunk) are summed in chunk order: deterministic.
+// A workgroup owns VPB variants x 256 * EPT samples so that every X / res / mask element it loads is used for VPB variants;
+// each thread keeps its EPT samples of the VPB variants in registers.  The partial sums a thread carries per covariate (or
+// per phenotype) are reduced across the wave eight at a time with a butterfly that halves the value count at each of the
+// first three exchange steps (10 exchanges instead of 48).  Partials per (variant, sample chunk) are summed in chunk order:
+// deterministic.  The tile (VPB x EPT) is a tuning knob: RG_S2_TILE=4x8|8x4|8x8|16x4 (read at rg_s2_create).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -25,9 +27,7 @@
 
 namespace {
 
-constexpr int VPB = 4;          // variants per workgroup
-constexpr int EPT = 8;          // samples per thread
-constexpr int CH = 256 * EPT;   // samples per workgroup
+constexpr int DEFAULT_VPB = 4, DEFAULT_EPT = 8;   // variants per workgroup, samples per thread
 
 __device__ __forceinline__ bool is_missing(double g) { return !(g >= 0.0); }   // NaN, or regenie's -3
 
@@ -61,15 +61,41 @@ __device__ __forceinline__ void wave_reduce8(double (&v)[8]) {
   v[0] += __shfl_xor(v[0], 1);
 }
 
-// grid (ceil(bs / VPB), nchunk).  part1[(j * nchunk + chunk) * Q1 + q], Q1 = 2 + 2C: sum, count, A_c (C), M_c (C)
+// Wave totals of a[v] and b[v] (v < VPB) into row[v * stride + off_a] and row[v * stride + off_b], eight values per butterfly.
+template <int VPB>
+__device__ __forceinline__ void reduce_pairs(const double (&a)[VPB], const double (&b)[VPB], double* row, int stride, int off_a,
+                                             int off_b) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int grp = 0; grp < 2 * VPB / 8; ++grp) {
+    double v8[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = grp * 8 + i;
+      v8[i] = t < VPB ? a[t < VPB ? t : 0] : b[t < VPB ? 0 : t - VPB];
+    }
+    wave_reduce8(v8);
+    if ((lane & 7) == 0) {
+      const int t = grp * 8 + (lane >> 3);
+      row[(t % VPB) * stride + (t < VPB ? off_a : off_b)] = v8[0];
+    }
+  }
+}
+
+// A workgroup owns VPB variants x (256 * EPT) samples.  grid (ceil(bs / VPB), nchunk), dynamic LDS 4 * VPB * Q1 doubles.
+// part1[(j * nchunk + chunk) * Q1 + q], Q1 = 2 + 2C: sum, count, A_c (C), M_c (C)
+template <int VPB, int EPT>
 __global__ __launch_bounds__(256) void k_s2_proj(const double* __restrict__ G, int64_t ldg, int bs, int64_t n,
                                                  const double* __restrict__ X, int C, double* __restrict__ part1) {
-  __shared__ double red[4][VPB][2 + 2 * RG_S2_MAX_COV];
-  const int j0 = blockIdx.x * VPB, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t base = (int64_t)blockIdx.y * CH + threadIdx.x;
+  extern __shared__ double dyn_lds[];
+  const int Q1 = 2 + 2 * C;
+  double* red = dyn_lds;                                   // [4][VPB][Q1]
+  const int j0 = blockIdx.x * VPB, w = threadIdx.x >> 6;
+  double* row = red + (size_t)w * VPB * Q1;
+  const int64_t base = (int64_t)blockIdx.y * (256 * EPT) + threadIdx.x;
   double g[VPB][EPT];
   uint32_t miss[VPB];
-  double v8[8];
+  double qa[VPB], qb[VPB];
 #pragma unroll
   for (int v = 0; v < VPB; ++v) {
     miss[v] = 0;
@@ -85,11 +111,10 @@ __global__ __launch_bounds__(256) void k_s2_proj(const double* __restrict__ G, i
       g[v][k] = x;
       s += x;
     }
-    v8[v] = s;
-    v8[VPB + v] = cnt;
+    qa[v] = s;
+    qb[v] = cnt;
   }
-  wave_reduce8(v8);
-  if ((lane & 7) == 0) { const int q = lane >> 3; red[w][q & 3][q >> 2] = v8[0]; }
+  reduce_pairs<VPB>(qa, qb, row, Q1, 0, 1);
   for (int c = 0; c < C; ++c) {
     double xk[EPT];
 #pragma unroll
@@ -105,18 +130,17 @@ __global__ __launch_bounds__(256) void k_s2_proj(const double* __restrict__ G, i
         a += g[v][k] * xk[k];
         m += ((miss[v] >> k) & 1u) ? xk[k] : 0.0;
       }
-      v8[v] = a;
-      v8[VPB + v] = m;
+      qa[v] = a;
+      qb[v] = m;
     }
-    wave_reduce8(v8);
-    if ((lane & 7) == 0) { const int q = lane >> 3; red[w][q & 3][2 + (q >> 2) * C + c] = v8[0]; }
+    reduce_pairs<VPB>(qa, qb, row, Q1, 2 + c, 2 + C + c);
   }
   __syncthreads();
-  const int Q1 = 2 + 2 * C;
   for (int idx = threadIdx.x; idx < VPB * Q1; idx += 256) {
-    const int v = idx / Q1, q = idx % Q1;
+    const int v = idx / Q1;
     if (j0 + v < bs)
-      part1[((int64_t)(j0 + v) * gridDim.y + blockIdx.y) * Q1 + q] = (red[0][v][q] + red[1][v][q]) + (red[2][v][q] + red[3][v][q]);
+      part1[((int64_t)(j0 + v) * gridDim.y + blockIdx.y) * Q1 + idx % Q1] =
+          (red[idx] + red[VPB * Q1 + idx]) + (red[2 * VPB * Q1 + idx] + red[3 * VPB * Q1 + idx]);
   }
 }
 
@@ -136,19 +160,24 @@ __global__ void k_s2_beta(const double* __restrict__ part1, int nchunk, int C, i
   if (c == 0) { mu[j] = mean; nobs[j] = (int32_t)cnt; }
 }
 
-// grid (ceil(bs / VPB), nchunk).  part2[(j * nchunk + chunk) * Q2 + q], Q2 = 1 + 2P: |r|^2, res_p . r (P), mask_p . r^2 (P)
+// grid (ceil(bs / VPB), nchunk), dynamic LDS VPB * C + VPB + 4 * VPB * (Q2 + 1) doubles.
+// part2[(j * nchunk + chunk) * Q2 + q], Q2 = 1 + 2P: |r|^2, res_p . r (P), mask_p . r^2 (P)
+template <int VPB, int EPT>
 __global__ __launch_bounds__(256) void k_s2_score(const double* __restrict__ G, int64_t ldg, int bs, int64_t n,
                                                   const double* __restrict__ X, int C, const double* __restrict__ Y,
                                                   const uint8_t* __restrict__ M, int P, const double* __restrict__ beta,
                                                   const double* __restrict__ mu, double* __restrict__ part2) {
-  __shared__ double sb[VPB][RG_S2_MAX_COV];
-  __shared__ double smu[VPB];
-  __shared__ double red[4][VPB][1 + 2 * RG_S2_MAX_PHENO];
-  const int j0 = blockIdx.x * VPB, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t base = (int64_t)blockIdx.y * CH + threadIdx.x;
+  extern __shared__ double dyn_lds[];
+  const int Q2 = 1 + 2 * P, QS = Q2 + 1;                   // one spare column takes the unused half of the |r|^2 butterfly
+  double* sb = dyn_lds;                                    // [VPB][C]
+  double* smu = sb + VPB * C;                              // [VPB]
+  double* red = smu + VPB;                                 // [4][VPB][QS]
+  const int j0 = blockIdx.x * VPB, w = threadIdx.x >> 6;
+  double* row = red + (size_t)w * VPB * QS;
+  const int64_t base = (int64_t)blockIdx.y * (256 * EPT) + threadIdx.x;
   for (int idx = threadIdx.x; idx < VPB * C; idx += 256) {
     const int v = idx / C, c = idx % C;
-    sb[v][c] = j0 + v < bs ? beta[(int64_t)(j0 + v) * RG_S2_MAX_COV + c] : 0.0;
+    sb[idx] = j0 + v < bs ? beta[(int64_t)(j0 + v) * RG_S2_MAX_COV + c] : 0.0;
   }
   if (threadIdx.x < VPB) smu[threadIdx.x] = j0 + threadIdx.x < bs ? mu[j0 + threadIdx.x] : 0.0;
   __syncthreads();
@@ -174,22 +203,23 @@ __global__ __launch_bounds__(256) void k_s2_score(const double* __restrict__ G, 
     }
 #pragma unroll
     for (int v = 0; v < VPB; ++v) {
-      const double b = sb[v][c];
+      const double b = sb[v * C + c];
 #pragma unroll
       for (int k = 0; k < EPT; ++k) r[v][k] -= b * xk[k];
     }
   }
-  double v8[8];
+  double qa[VPB], qb[VPB];
 #pragma unroll
   for (int v = 0; v < VPB; ++v) {
     double s = 0.0;
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) s += r[v][k] * r[v][k];
-    v8[v] = s;
-    v8[VPB + v] = 0.0;
+    for (int k = 0; k < EPT; ++k) {
+      s += r[v][k] * r[v][k];
+    }
+    qa[v] = s;
+    qb[v] = 0.0;
   }
-  wave_reduce8(v8);
-  if ((lane & 7) == 0 && (lane >> 3) < VPB) red[w][lane >> 3][0] = v8[0];
+  reduce_pairs<VPB>(qa, qb, row, QS, 0, Q2);
   for (int p = 0; p < P; ++p) {
     double yk[EPT], mk[EPT];
 #pragma unroll
@@ -206,18 +236,17 @@ __global__ __launch_bounds__(256) void k_s2_score(const double* __restrict__ G, 
         num += yk[k] * r[v][k];
         den += mk[k] * (r[v][k] * r[v][k]);
       }
-      v8[v] = num;
-      v8[VPB + v] = den;
+      qa[v] = num;
+      qb[v] = den;
     }
-    wave_reduce8(v8);
-    if ((lane & 7) == 0) { const int q = lane >> 3; red[w][q & 3][1 + (q >> 2) * P + p] = v8[0]; }
+    reduce_pairs<VPB>(qa, qb, row, QS, 1 + p, 1 + P + p);
   }
   __syncthreads();
-  const int Q2 = 1 + 2 * P;
   for (int idx = threadIdx.x; idx < VPB * Q2; idx += 256) {
-    const int v = idx / Q2, q = idx % Q2;
+    const int v = idx / Q2, q = idx % Q2, o = v * QS + q;
     if (j0 + v < bs)
-      part2[((int64_t)(j0 + v) * gridDim.y + blockIdx.y) * Q2 + q] = (red[0][v][q] + red[1][v][q]) + (red[2][v][q] + red[3][v][q]);
+      part2[((int64_t)(j0 + v) * gridDim.y + blockIdx.y) * Q2 + q] =
+          (red[o] + red[VPB * QS + o]) + (red[2 * VPB * QS + o] + red[3 * VPB * QS + o]);
   }
 }
 
@@ -255,6 +284,7 @@ struct rg_s2_ctx {
   uint8_t* dM = nullptr;
   void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int vpb = 4, ept = 8;   // tile of the two streaming kernels
   double last_ms = 0.0;
   std::string err;
 };
@@ -294,6 +324,13 @@ int rg_s2_create(rg_s2_ctx** out, int device, int64_t n, int32_t n_cov, int32_t 
     return fail(ctx, RG_S2_ERR_HIP, "rg_s2_create: no HIP device (this library has no CPU path)");
   if (device < 0 || device >= ndev) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_create: device index out of range");
   ctx->dev = device; ctx->n = n; ctx->C = n_cov; ctx->P = n_pheno;
+  ctx->vpb = DEFAULT_VPB; ctx->ept = DEFAULT_EPT;
+  if (const char* t = getenv("RG_S2_TILE")) {
+    int a = 0, b = 0;
+    if (sscanf(t, "%dx%d", &a, &b) != 2 || !((a == 4 && b == 8) || (a == 8 && b == 4) || (a == 8 && b == 8) || (a == 16 && b == 4)))
+      return fail(ctx, RG_S2_ERR_ARG, "RG_S2_TILE must be one of 4x8, 8x4, 8x8, 16x4");
+    ctx->vpb = a; ctx->ept = b;
+  }
   S2_HIP(hipSetDevice(device));
   S2_HIP(hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking));
   S2_HIP(hipEventCreate(&ctx->e0));
@@ -344,8 +381,14 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
   if (!G || !out || bs < 1 || ldg < ctx->n) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block: bad arguments (need bs >= 1, ldg >= n)");
   const int64_t n = ctx->n;
   const int C = ctx->C, P = ctx->P, Q1 = 2 + 2 * C, Q2 = 1 + 2 * P;
-  const int nchunk = (int)((n + CH - 1) / CH);
-  const unsigned gv = (unsigned)((bs + VPB - 1) / VPB);
+  int vpb = ctx->vpb, ept = ctx->ept;
+  size_t lds1 = sizeof(double) * 4 * vpb * Q1, lds2 = sizeof(double) * ((size_t)vpb * C + vpb + 4 * (size_t)vpb * (Q2 + 1));
+  if (lds1 > 60 * 1024 || lds2 > 60 * 1024) {   // many covariates / phenotypes: the narrow tile always fits (<= 17 KB)
+    vpb = 4; ept = 8;
+    lds1 = sizeof(double) * 4 * vpb * Q1; lds2 = sizeof(double) * ((size_t)vpb * C + vpb + 4 * (size_t)vpb * (Q2 + 1));
+  }
+  const int nchunk = (int)((n + 256 * ept - 1) / (256 * ept));
+  const unsigned gv = (unsigned)((bs + vpb - 1) / vpb);
   S2_HIP(hipSetDevice(ctx->dev));
   enum { B_G, B_PART, B_BETA, B_VAR, B_NOBS, B_STAT };
   const size_t part_elems = (size_t)bs * nchunk * (size_t)(Q1 > Q2 ? Q1 : Q2);
@@ -373,10 +416,17 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
   double* stats = (double*)ctx->buf[B_STAT];
   double* bhat = stats + (size_t)bs * P;
   S2_HIP(hipEventRecord(ctx->e0, ctx->st));
-  hipLaunchKernelGGL(k_s2_proj, dim3(gv, nchunk), dim3(256), 0, ctx->st, dG, ld, bs, n, ctx->dX, C, part);
+#define S2_TILE(V, E, KERNEL_CALL) if (vpb == V && ept == E) { constexpr int TV = V, TE = E; KERNEL_CALL; }
+#define S2_PROJ hipLaunchKernelGGL((k_s2_proj<TV, TE>), dim3(gv, nchunk), dim3(256), lds1, ctx->st, dG, ld, bs, n, ctx->dX, C, part)
+#define S2_SCORE                                                                                                              \
+  hipLaunchKernelGGL((k_s2_score<TV, TE>), dim3(gv, nchunk), dim3(256), lds2, ctx->st, dG, ld, bs, n, ctx->dX, C, ctx->dY, ctx->dM, \
+                     P, beta, mu, part)
+  S2_TILE(4, 8, S2_PROJ) S2_TILE(8, 4, S2_PROJ) S2_TILE(8, 8, S2_PROJ) S2_TILE(16, 4, S2_PROJ)
   hipLaunchKernelGGL(k_s2_beta, dim3((bs * C + 255) / 256), dim3(256), 0, ctx->st, part, nchunk, C, bs, beta, mu, nobs);
-  hipLaunchKernelGGL(k_s2_score, dim3(gv, nchunk), dim3(256), 0, ctx->st, dG, ld, bs, n, ctx->dX, C, ctx->dY, ctx->dM, P, beta, mu,
-                     part);
+  S2_TILE(4, 8, S2_SCORE) S2_TILE(8, 4, S2_SCORE) S2_TILE(8, 8, S2_SCORE) S2_TILE(16, 4, S2_SCORE)
+#undef S2_TILE
+#undef S2_PROJ
+#undef S2_SCORE
   hipLaunchKernelGGL(k_s2_final, dim3((bs * P + 255) / 256), dim3(256), 0, ctx->st, part, nchunk, P, bs, (double)(n - C), numtol,
                      ctx->dscf, nobs, stats, bhat, sf, ign);
   S2_HIP(hipEventRecord(ctx->e1, ctx->st));

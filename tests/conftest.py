@@ -18,3 +18,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def example_dir():
     return EXAMPLE
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_hip_first():
+    """On the GPU box torch must bring up its HIP runtime before librg_step1_hip.so does: initialised the other way round,
+    torch.cuda reports "No HIP GPUs are available" for the rest of the process (bench.py imports torch first as well)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except ImportError:
+        pass
+    yield

@@ -65,6 +65,20 @@ def test_parity_with_oracle(n, C, P, bs):
     _compare(_run(X, res, mask, scf, G), s2o.score_qt_block(G, X, res, mask, scf))
 
 
+@pytest.mark.parametrize("tile", ["4x8", "8x4", "8x8", "16x4"])
+def test_tiles_agree_with_oracle(tile, monkeypatch):
+    """RG_S2_TILE picks the workgroup tile of the two streaming kernels; every tile must pass the same parity bar."""
+    monkeypatch.setenv("RG_S2_TILE", tile)
+    X, res, mask, scf, G = _problem(21, 10_007, 6, 5, 43)
+    G[0, ::9] = np.nan
+    G[7, :] = 0.0
+    _compare(_run(X, res, mask, scf, G), s2o.score_qt_block(G, X, res, mask, scf))
+    monkeypatch.setenv("RG_S2_TILE", "3x3")
+    from regenie_amd.engine import RgError
+    with pytest.raises(RgError, match="RG_S2_TILE"):
+        _run(X, res, mask, scf, G)
+
+
 def test_device_pointer_input_and_determinism():
     import torch
     X, res, mask, scf, G = _problem(11, 9000, 6, 4, 50)

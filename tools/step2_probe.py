@@ -2,6 +2,7 @@
 Prints one JSON line per configuration: ms per block, variants/s, and the achieved rate against the algorithmic bytes
 (one 8-byte read of every genotype; the current two-pass kernels read the block twice)."""
 import json
+import os
 import sys
 
 import numpy as np
@@ -25,7 +26,7 @@ def run(n, C, P, bs, reps=5):
             ms.append(s2.score_block(G)["kernel_ms"])
     best, med = min(ms), sorted(ms)[len(ms) // 2]
     alg = bs * n * 8.0
-    print(json.dumps({"n": n, "C": C, "P": P, "bs": bs, "ms_median": round(med, 4), "ms_best": round(best, 4),
+    print(json.dumps({"tile": os.environ.get("RG_S2_TILE", "default"), "n": n, "C": C, "P": P, "bs": bs, "ms_median": round(med, 4), "ms_best": round(best, 4),
                       "variants_per_s": round(bs / med * 1e3), "algorithmic_GBps": round(alg / med / 1e6, 1),
                       "frac_of_8TBps": round(alg / med / 1e6 / 8000, 4)}), flush=True)
 
@@ -34,5 +35,9 @@ if __name__ == "__main__":
     cfgs = [(100_000, 10, 10, 512), (200_000, 10, 10, 512), (500_000, 10, 10, 256), (500_000, 20, 50, 256)]
     if len(sys.argv) > 1:
         cfgs = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]]
-    for c in cfgs:
-        run(*c)
+    tiles = os.environ.get("RG_S2_TILES", "").split(",") if os.environ.get("RG_S2_TILES") else [None]
+    for tile in tiles:
+        if tile:
+            os.environ["RG_S2_TILE"] = tile
+        for c in cfgs:
+            run(*c)
