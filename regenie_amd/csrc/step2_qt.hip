@@ -13,7 +13,7 @@
 // each thread keeps its EPT samples of the VPB variants in registers.  The partial sums a thread carries per covariate (or
 // per phenotype) are reduced across the wave eight at a time with a butterfly that halves the value count at each of the
 // first three exchange steps (10 exchanges instead of 48).  Partials per (variant, sample chunk) are summed in chunk order:
-// deterministic.  The tile (VPB x EPT) is a tuning knob: RG_S2_TILE=4x8|8x4|8x8|16x4 (read at rg_s2_create).
+// deterministic.  The tile (VPB x EPT) is a tuning knob: RG_S2_TILE=4x4|4x8|8x4|8x8|16x4 (read at rg_s2_create).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -27,7 +27,8 @@
 
 namespace {
 
-constexpr int DEFAULT_VPB = 4, DEFAULT_EPT = 8;   // variants per workgroup, samples per thread
+constexpr int DEFAULT_VPB = 4, DEFAULT_EPT = 4;   // variants per workgroup, samples per thread (best of the sweep in
+                                                 // profiles/r1_step2_qt.md)
 
 __device__ __forceinline__ bool is_missing(double g) { return !(g >= 0.0); }   // NaN, or regenie's -3
 
@@ -82,6 +83,27 @@ __device__ __forceinline__ void reduce_pairs(const double (&a)[VPB], const doubl
   }
 }
 
+// The per-covariate / per-phenotype loops are latency-bound when each iteration waits for its own loads (measured: 2.5 us per
+// workgroup-iteration at 3 waves per SIMD), so the next row is fetched into registers before the current one is consumed.
+template <int EPT>
+__device__ __forceinline__ void load_row(const double* __restrict__ src, int64_t row, int64_t n, int64_t base, double (&dst)[EPT]) {
+  const double* p = src + row * n;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int64_t pos = base + (int64_t)k * 256;
+    dst[k] = pos < n ? p[pos] : 0.0;
+  }
+}
+template <int EPT>
+__device__ __forceinline__ void load_mask_row(const uint8_t* __restrict__ src, int64_t row, int64_t n, int64_t base, uint32_t (&dst)[EPT]) {
+  const uint8_t* p = src + row * n;
+#pragma unroll
+  for (int k = 0; k < EPT; ++k) {
+    const int64_t pos = base + (int64_t)k * 256;
+    dst[k] = pos < n ? p[pos] : 0u;
+  }
+}
+
 // A workgroup owns VPB variants x (256 * EPT) samples.  grid (ceil(bs / VPB), nchunk), dynamic LDS 4 * VPB * Q1 doubles.
 // part1[(j * nchunk + chunk) * Q1 + q], Q1 = 2 + 2C: sum, count, A_c (C), M_c (C)
 template <int VPB, int EPT>
@@ -115,13 +137,13 @@ __global__ __launch_bounds__(256) void k_s2_proj(const double* __restrict__ G, i
     qb[v] = cnt;
   }
   reduce_pairs<VPB>(qa, qb, row, Q1, 0, 1);
+  double xn[EPT];
+  load_row<EPT>(X, 0, n, base, xn);
   for (int c = 0; c < C; ++c) {
     double xk[EPT];
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int64_t pos = base + (int64_t)k * 256;
-      xk[k] = pos < n ? X[(int64_t)c * n + pos] : 0.0;
-    }
+    for (int k = 0; k < EPT; ++k) xk[k] = xn[k];
+    if (c + 1 < C) load_row<EPT>(X, c + 1, n, base, xn);
 #pragma unroll
     for (int v = 0; v < VPB; ++v) {
       double a = 0.0, m = 0.0;
@@ -194,13 +216,15 @@ __global__ __launch_bounds__(256) void k_s2_score(const double* __restrict__ G, 
       }
       r[v][k] = x;
     }
+  double xn[EPT], yn[EPT];
+  uint32_t mn[EPT];
+  load_row<EPT>(X, 0, n, base, xn);
   for (int c = 0; c < C; ++c) {
     double xk[EPT];
 #pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-      const int64_t pos = base + (int64_t)k * 256;
-      xk[k] = pos < n ? X[(int64_t)c * n + pos] : 0.0;
-    }
+    for (int k = 0; k < EPT; ++k) xk[k] = xn[k];
+    if (c + 1 < C) load_row<EPT>(X, c + 1, n, base, xn);
+    else { load_row<EPT>(Y, 0, n, base, yn); load_mask_row<EPT>(M, 0, n, base, mn); }
 #pragma unroll
     for (int v = 0; v < VPB; ++v) {
       const double b = sb[v * C + c];
@@ -224,10 +248,10 @@ __global__ __launch_bounds__(256) void k_s2_score(const double* __restrict__ G, 
     double yk[EPT], mk[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-      const int64_t pos = base + (int64_t)k * 256;
-      yk[k] = pos < n ? Y[(int64_t)p * n + pos] : 0.0;
-      mk[k] = (pos < n && M[(int64_t)p * n + pos]) ? 1.0 : 0.0;
+      yk[k] = yn[k];
+      mk[k] = mn[k] ? 1.0 : 0.0;
     }
+    if (p + 1 < P) { load_row<EPT>(Y, p + 1, n, base, yn); load_mask_row<EPT>(M, p + 1, n, base, mn); }
 #pragma unroll
     for (int v = 0; v < VPB; ++v) {
       double num = 0.0, den = 0.0;
@@ -327,8 +351,8 @@ int rg_s2_create(rg_s2_ctx** out, int device, int64_t n, int32_t n_cov, int32_t 
   ctx->vpb = DEFAULT_VPB; ctx->ept = DEFAULT_EPT;
   if (const char* t = getenv("RG_S2_TILE")) {
     int a = 0, b = 0;
-    if (sscanf(t, "%dx%d", &a, &b) != 2 || !((a == 4 && b == 8) || (a == 8 && b == 4) || (a == 8 && b == 8) || (a == 16 && b == 4)))
-      return fail(ctx, RG_S2_ERR_ARG, "RG_S2_TILE must be one of 4x8, 8x4, 8x8, 16x4");
+    if (sscanf(t, "%dx%d", &a, &b) != 2 || !((a == 4 && b == 4) || (a == 4 && b == 8) || (a == 8 && b == 4) || (a == 8 && b == 8) || (a == 16 && b == 4)))
+      return fail(ctx, RG_S2_ERR_ARG, "RG_S2_TILE must be one of 4x4, 4x8, 8x4, 8x8, 16x4");
     ctx->vpb = a; ctx->ept = b;
   }
   S2_HIP(hipSetDevice(device));
@@ -421,9 +445,9 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
 #define S2_SCORE                                                                                                              \
   hipLaunchKernelGGL((k_s2_score<TV, TE>), dim3(gv, nchunk), dim3(256), lds2, ctx->st, dG, ld, bs, n, ctx->dX, C, ctx->dY, ctx->dM, \
                      P, beta, mu, part)
-  S2_TILE(4, 8, S2_PROJ) S2_TILE(8, 4, S2_PROJ) S2_TILE(8, 8, S2_PROJ) S2_TILE(16, 4, S2_PROJ)
+  S2_TILE(4, 4, S2_PROJ) S2_TILE(4, 8, S2_PROJ) S2_TILE(8, 4, S2_PROJ) S2_TILE(8, 8, S2_PROJ) S2_TILE(16, 4, S2_PROJ)
   hipLaunchKernelGGL(k_s2_beta, dim3((bs * C + 255) / 256), dim3(256), 0, ctx->st, part, nchunk, C, bs, beta, mu, nobs);
-  S2_TILE(4, 8, S2_SCORE) S2_TILE(8, 4, S2_SCORE) S2_TILE(8, 8, S2_SCORE) S2_TILE(16, 4, S2_SCORE)
+  S2_TILE(4, 4, S2_SCORE) S2_TILE(4, 8, S2_SCORE) S2_TILE(8, 4, S2_SCORE) S2_TILE(8, 8, S2_SCORE) S2_TILE(16, 4, S2_SCORE)
 #undef S2_TILE
 #undef S2_PROJ
 #undef S2_SCORE

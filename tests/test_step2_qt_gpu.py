@@ -65,7 +65,7 @@ def test_parity_with_oracle(n, C, P, bs):
     _compare(_run(X, res, mask, scf, G), s2o.score_qt_block(G, X, res, mask, scf))
 
 
-@pytest.mark.parametrize("tile", ["4x8", "8x4", "8x8", "16x4"])
+@pytest.mark.parametrize("tile", ["4x4", "4x8", "8x4", "8x8", "16x4"])
 def test_tiles_agree_with_oracle(tile, monkeypatch):
     """RG_S2_TILE picks the workgroup tile of the two streaming kernels; every tile must pass the same parity bar."""
     monkeypatch.setenv("RG_S2_TILE", tile)
