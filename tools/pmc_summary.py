@@ -20,7 +20,7 @@ def main(d, out=None):
     agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
     for f in files:
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].replace("void ", "").strip()
             if not name.startswith("k_"):
                 continue
             if BY_GRID:   # one row per launch shape: distinguishes e.g. the wide trailing updates from the narrow ones
