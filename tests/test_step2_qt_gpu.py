@@ -122,3 +122,41 @@ def test_argument_errors():
     with Step2QT(100, 2, 1) as s2:
         with pytest.raises(RgError, match="set_null"):
             s2.score_block(np.zeros((3, 100)))
+
+
+def test_step1_loco_feeds_step2(example_dir, tmp_path):
+    """The reference's two-step flow on its own example: `--step 1` (the C++ driver of this repo) writes the LOCO files, the
+    chromosome-2 row becomes the `blup` of compute_res (Data.cpp:2386-2400), and the chromosome-2 variants of the .bed go
+    through the score test -- GPU against the oracle on identical inputs."""
+    import os
+    import subprocess
+    from oracle import regenie_step1 as orc
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    E = example_dir
+    common = dict(bed=os.path.join(E, "example_3chr"), pheno_file=os.path.join(E, "phenotype.txt"),
+                  covar_file=os.path.join(E, "covariates.txt"), bsize=100)
+    r = subprocess.run([os.path.join(root, "regenie_amd", "bin", "regenie-amd"), "--step", "1", "--bed", common["bed"],
+                        "--phenoFile", common["pheno_file"], "--covarFile", common["covar_file"], "--bsize", "100",
+                        "--out", str(tmp_path / "s1")], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(orc.Step1Options(out=str(tmp_path / "unused"), **common))
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    n, P = int(ia.sum()), prep.Y.shape[1]
+    blup = np.zeros((n, P))
+    for k in range(P):
+        lines = open(str(tmp_path / ("s1_%d.loco" % (k + 1)))).read().split("\n")
+        hdr = lines[0].split(" ")[1:-1]             # the writer's own sample order (Data.cpp:1934); Step 2 matches by name
+        assert sorted(hdr) == sorted(ids)
+        row = [ln for ln in lines[1:-1] if ln.split(" ")[0] == "2"][0]
+        val = dict(zip(hdr, (float(v) for v in row.split(" ")[1:-1])))
+        blup[:, k] = [val[i] for i in ids]
+    X, Y, mask = prep.X[ia], prep.Y[ia], prep.mask[ia].astype(np.float64)
+    res, _, scf = s2o.compute_res(Y, blup * mask, mask, prep.Neff, X.shape[1], prep.scale_Y)
+    rows, _ = orc.open_bed(common["bed"] + ".bed", prep.n_file)
+    sel = np.flatnonzero(chrom == 2)
+    G = orc.decode_bed_rows(np.asarray(rows[sel]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
+    assert G.shape == (len(sel), n) and len(sel) > 50
+    ref = s2o.score_qt_block(G, X, res, mask, scf)
+    assert (ref["ignored"] == 0).sum() > 50 and np.nanmax(np.abs(ref["stats"])) > 1.0
+    _compare(_run(X, res, mask, scf, G), ref)
