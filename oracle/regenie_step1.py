@@ -9,12 +9,15 @@ release binaries route Eigen to (Makefile:87-113).
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
 import this module, and there only as the checker / the timed CPU baseline.
 
-Parity pin: `tests/test_oracle_golden.py` checks this file against
-the reference's only Step-1 known answer (`0.4504 ... min value`,
-test/test_bash.sh:87) and the split-l0 == single-run identity
-(test/test_bash.sh:91-138).  QT / K-fold paths are unpinned by the reference's own
-tests; they are anchored by two independent restatements agreeing (SURVEY.md
-Appendix E.2 vs this file).
+Parity pin: PINNED against regenie itself.  oracle/Makefile compiles the
+reference's own sources into oracle/_ref/regenie (which reproduces the reference-held
+example/test_bin_out_firth_Y1.regenie); tests/test_reference_pin.py requires this file to
+reproduce that binary's outputs (fixtures: tests/golden/ref_outputs/, generator
+tests/golden/make_ref_outputs.py) on every Step-1 route -- QT K-fold, QT LOOCV, BT LOOCV,
+BT K-fold, missing data, sample / variant filters -- to the 6 printed digits of the .loco
+files and CV tables, and the level-0 predictors to 1e-11 through the --run-l0 job files.
+`tests/test_oracle_golden.py` keeps the reference's own test answers (`0.4504 ... min value`,
+test/test_bash.sh:87; split-l0 == single run, test/test_bash.sh:91-138).
 """
 from __future__ import annotations
 

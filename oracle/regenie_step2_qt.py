@@ -3,10 +3,9 @@
 TEST INFRASTRUCTURE ONLY: imported by tests/ (and nothing in the product path).  numpy, fp64, the reference's own
 operation order and orientation (samples down the rows).
 
-PARITY UNPINNED: the reference ships no Step-2 golden output for a quantitative trait (its only Step-2 golden file,
-example/test_bin_out_firth_Y1.regenie, is a binary-trait Firth run) and regenie itself is not buildable here, so this
-restatement is anchored on the source lines cited below and on closed-form identities (tests/test_step2_oracle.py:
-Frisch-Waugh OLS coefficient, partial correlation), not on reference outputs.
+PINNED against regenie itself: tests/test_reference_pin.py::test_step2_qt_oracle_against_reference compares BETA / SE /
+CHISQ / LOG10P with the Step-2 output of oracle/_ref/regenie (the reference's sources compiled by oracle/Makefile) on
+example_3chr.bed, fixtures under tests/golden/ref_outputs/step2/; closed-form identities in tests/test_step2_oracle.py.
 """
 from __future__ import annotations
 

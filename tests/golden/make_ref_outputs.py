@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""TEST INFRASTRUCTURE.  Generates tests/golden/ref_outputs/: outputs of regenie v4.1.2 ITSELF, i.e. of
+oracle/_ref/regenie = the reference's own sources compiled where they lie under /root/reference by
+oracle/Makefile (reference flags -O3 -ffast-math -fopenmp; the Boost / BGEN-container / sqlite names the image
+lacks come from oracle/ref_shim/).  The build reproduces the reference-held golden file
+example/test_bin_out_firth_Y1.regenie (all non-Firth rows byte-identical, see tests/test_reference_pin.py).
+
+Every case below is a regenie command on the reference's own example data (tests/golden/example/ holds verbatim
+copies) or on the deterministic synthetic data of tests/util.py (cases that need more than 5,000 samples).
+Stored per case: the .loco files (gzipped text), the CV table lines of the log, _pred.list phenotype names,
+and for the split-l0 case the raw level-0 predictor files (full fp64).
+
+  python tests/golden/make_ref_outputs.py            # needs oracle/_ref/regenie (make -C oracle)
+"""
+from __future__ import annotations
+
+import gzip
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+EX = os.path.join(HERE, "example")
+OUT = os.path.join(HERE, "ref_outputs")
+REGENIE = os.path.join(ROOT, "oracle", "_ref", "regenie")
+
+# name -> (argument list with {E} = example dir, {S} = synthetic prefix, synthetic spec or None)
+CASES = {
+    # BASELINE configs[0]: example.bed, 2 QT phenotypes, --bsize 100 (K-fold)
+    "qt_kfold_config1": (["--step", "1", "--bed", "{E}/example", "--covarFile", "{E}/covariates.txt",
+                          "--phenoFile", "{E}/phenotype.txt", "--bsize", "100", "--qt"], None),
+    "qt_kfold_3chr": (["--step", "1", "--bed", "{E}/example_3chr", "--covarFile", "{E}/covariates.txt",
+                       "--phenoFile", "{E}/phenotype.txt", "--bsize", "100", "--qt"], None),
+    "qt_kfold_3chr_opts": (["--step", "1", "--bed", "{E}/example_3chr", "--covarFile", "{E}/covariates.txt",
+                            "--phenoFile", "{E}/phenotype.txt", "--remove", "{E}/fid_iid_to_remove.txt",
+                            "--bsize", "70", "--cv", "3", "--ref-first", "--qt", "--print-prs"], None),
+    "qt_loocv_3chr": (["--step", "1", "--bed", "{E}/example_3chr", "--covarFile", "{E}/covariates.txt",
+                       "--phenoFile", "{E}/phenotype.txt", "--bsize", "100", "--qt", "--loocv"], None),
+    # the reference's own Step-1 test command (test/test_bash.sh:62-89, docs/docs/options.md:20-33)
+    "bt_loocv_refcmd": (["--step", "1", "--bed", "{E}/example", "--exclude", "{E}/snplist_rm.txt",
+                         "--covarFile", "{E}/covariates.txt", "--phenoFile", "{E}/phenotype_bin.txt",
+                         "--remove", "{E}/fid_iid_to_remove.txt", "--bsize", "100", "--bt", "--lowmem",
+                         "--lowmem-prefix", "tmp_rg"], None),
+    "bt_loocv_wNA": (["--step", "1", "--bed", "{E}/example_3chr", "--covarFile", "{E}/covariates.txt",
+                      "--phenoFile", "{E}/phenotype_bin_wNA.txt", "--bsize", "100", "--bt"], None),
+    # binary traits keep K-fold CV only from 5,000 analysed samples on (Data.cpp:353): synthetic data
+    "bt_kfold_synth": (["--step", "1", "--bed", "{S}", "--covarFile", "{S}.covar", "--phenoFile", "{S}.pheno",
+                        "--bsize", "100", "--bt"],
+                       dict(M=400, N=5200, chroms=[1] * 150 + [2] * 130 + [5] * 120, P=3, seed=11, binary=True,
+                            missing_pheno=0.02)),
+    "qt_kfold_synth_missing": (["--step", "1", "--bed", "{S}", "--covarFile", "{S}.covar", "--phenoFile", "{S}.pheno",
+                                "--bsize", "128", "--qt"],
+                               dict(M=500, N=3001, chroms=[1] * 200 + [3] * 170 + [22] * 130, P=4, seed=5, binary=False,
+                                    missing_pheno=0.05, miss_rate=0.01)),
+}
+
+
+def synth(prefix, spec):
+    from tests.util import synth_dosages, write_plink
+    g = synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"])
+    write_plink(prefix, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"],
+                missing_pheno=spec["missing_pheno"])
+
+
+def table_lines(log_text):
+    """The per-phenotype CV table of Data::output (Data.cpp:1042-1077)."""
+    keep, on = [], False
+    for ln in log_text.splitlines():
+        if ln.startswith("phenotype ") and ln.rstrip().endswith(":"):
+            on = True
+        if on and (ln.startswith("phenotype ") or ": Rsq = " in ln):
+            keep.append(ln.rstrip())
+    return keep
+
+
+def run_case(name, args, spec, workdir):
+    d = os.path.join(workdir, name)
+    os.makedirs(d)
+    S = os.path.join(d, "synth")
+    if spec:
+        synth(S, spec)
+    cmd = [REGENIE] + [a.format(E=EX, S=S) for a in args] + ["--out", "out"]
+    r = subprocess.run(cmd, cwd=d, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("%s failed:\n%s\n%s" % (name, r.stdout[-3000:], r.stderr[-3000:]))
+    od = os.path.join(OUT, name)
+    os.makedirs(od, exist_ok=True)
+    log = open(os.path.join(d, "out.log")).read()
+    meta = {"args": args, "synthetic": spec, "table": table_lines(log),
+            "pred_list": [ln.split()[0] for ln in open(os.path.join(d, "out_pred.list"))]}
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith(".loco") or fn.endswith(".prs"):
+            with open(os.path.join(d, fn), "rb") as fi, gzip.GzipFile(os.path.join(od, fn + ".gz"), "wb", mtime=0) as fo:
+                shutil.copyfileobj(fi, fo)
+    json.dump(meta, open(os.path.join(od, "meta.json"), "w"), indent=1)
+    return d
+
+
+def split_l0_case(workdir):
+    """--split-l0 / --run-l0 with --keep-l0 (test/test_bash.sh:91-138): the job files PFX_job<k>_l0_Y<ph> are the
+    reference's level-0 predictors as raw doubles (Step1_Models.cpp:728-734) -- full-precision pins of ridge_level_0."""
+    name = "qt_split_l0_3chr"
+    d = os.path.join(workdir, name)
+    os.makedirs(d)
+    base = ["--bed", EX + "/example_3chr", "--covarFile", EX + "/covariates.txt", "--phenoFile", EX + "/phenotype.txt",
+            "--bsize", "100", "--qt"]
+
+    def rg(extra):
+        r = subprocess.run([REGENIE, "--step", "1"] + base + extra, cwd=d, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("%s failed:\n%s\n%s" % (name, r.stdout[-3000:], r.stderr[-3000:]))
+    rg(["--split-l0", "par,2", "--out", "split"])
+    for j in (1, 2):
+        rg(["--run-l0", "par.master,%d" % j, "--out", "split_l0_%d" % j])
+    rg(["--run-l1", "par.master", "--keep-l0", "--out", "out"])
+    od = os.path.join(OUT, name)
+    os.makedirs(od, exist_ok=True)
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith(".loco") or "_l0_Y" in fn or fn.endswith(".snplist") or fn.endswith(".master"):
+            with open(os.path.join(d, fn), "rb") as fi, gzip.GzipFile(os.path.join(od, fn + ".gz"), "wb", mtime=0) as fo:
+                shutil.copyfileobj(fi, fo)
+    log = open(os.path.join(d, "out.log")).read()
+    json.dump({"args": base, "table": table_lines(log)}, open(os.path.join(od, "meta.json"), "w"), indent=1)
+
+
+def step2_cases(workdir, step1_dirs):
+    """Step 2 single-variant tests fed by the reference's own Step-1 output: QT on the .bed (pins the Step-2 QT oracle)
+    and the documented BT Firth command on example.bgen (the reference holds its output: example/test_bin_out_firth_Y1.regenie)."""
+    od = os.path.join(OUT, "step2")
+    os.makedirs(od, exist_ok=True)
+    d = os.path.join(workdir, "step2")
+    os.makedirs(d)
+    os.symlink(os.path.join(EX, "example.bgen"), os.path.join(d, "ex.bgen"))     # no .bgi next to it (sqlite3 is a stand-in)
+    runs = {
+        "qt_bed_3chr": (step1_dirs["qt_kfold_3chr"], ["--step", "2", "--bed", EX + "/example_3chr", "--covarFile", EX + "/covariates.txt",
+                                                      "--phenoFile", EX + "/phenotype.txt", "--bsize", "200", "--qt"]),
+        "bt_firth_bgen": (step1_dirs["bt_loocv_refcmd"], ["--step", "2", "--bgen", "ex.bgen", "--covarFile", EX + "/covariates.txt",
+                                                         "--phenoFile", EX + "/phenotype_bin.txt", "--remove", EX + "/fid_iid_to_remove.txt",
+                                                         "--bsize", "200", "--bt", "--firth", "--approx", "--pThresh", "0.01"]),
+        "bt_score_bed": (step1_dirs["bt_loocv_refcmd"], ["--step", "2", "--bed", EX + "/example", "--covarFile", EX + "/covariates.txt",
+                                                        "--phenoFile", EX + "/phenotype_bin.txt", "--remove", EX + "/fid_iid_to_remove.txt",
+                                                        "--bsize", "200", "--bt"]),
+    }
+    for name, (s1, args) in runs.items():
+        r = subprocess.run([REGENIE] + args + ["--pred", os.path.join(s1, "out_pred.list"), "--out", name], cwd=d,
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("%s failed:\n%s\n%s" % (name, r.stdout[-3000:], r.stderr[-3000:]))
+        for fn in sorted(os.listdir(d)):
+            if fn.startswith(name) and fn.endswith(".regenie"):
+                with open(os.path.join(d, fn), "rb") as fi, gzip.GzipFile(os.path.join(od, fn + ".gz"), "wb", mtime=0) as fo:
+                    shutil.copyfileobj(fi, fo)
+
+
+def main():
+    if not os.path.exists(REGENIE):
+        raise SystemExit("build the reference first: make -C oracle")
+    if os.path.isdir(OUT):
+        shutil.rmtree(OUT)
+    os.makedirs(OUT)
+    with tempfile.TemporaryDirectory() as wd:
+        dirs = {}
+        for name, (args, spec) in CASES.items():
+            dirs[name] = run_case(name, args, spec, wd)
+            print("ok", name)
+        split_l0_case(wd)
+        print("ok split-l0")
+        step2_cases(wd, dirs)
+        print("ok step2")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,262 @@
+"""Pins the oracle to regenie ITSELF (CPU, no GPU).
+
+tests/golden/ref_outputs/ holds outputs of regenie v4.1.2 compiled from /root/reference by oracle/Makefile
+(oracle/_ref/regenie; generating script tests/golden/make_ref_outputs.py).  Here the numpy restatement
+(oracle/regenie_step1.py, oracle/regenie_step2_qt.py) must reproduce them:
+
+ * every Step-1 route -- QT K-fold (BASELINE configs[0]), QT LOOCV, BT LOOCV (the reference's own test command),
+   BT K-fold (needs >= 5,000 samples: synthetic), missing genotypes / phenotypes, --remove / --cv 3 / --ref-first /
+   --print-prs -- on the .loco text (6 significant digits => 1e-5 of the largest value is the bar of BASELINE.json,
+   the comparison here is per value at the text's own resolution), the CV tables of the log and the selected ridge value;
+ * the level-0 predictors at full fp64 precision through the reference's --split-l0/--run-l0/--keep-l0 job files;
+ * the build itself: when oracle/_ref/regenie is present it must reproduce the reference-HELD golden file
+   example/test_bin_out_firth_Y1.regenie (docs/docs/options.md:20-53) and the committed fixtures byte for byte.
+"""
+import gzip
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import regenie_step1 as orc
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF_OUT = os.path.join(HERE, "golden", "ref_outputs")
+EX = os.path.join(HERE, "golden", "example")
+REGENIE = os.path.join(ROOT, "oracle", "_ref", "regenie")
+
+
+def read_loco_gz(path):
+    """-> (ids, values [nchrom][n] with NaN for NA)"""
+    with gzip.open(path, "rt") as fh:
+        lines = fh.read().splitlines()
+    ids = lines[0].split()[1:]
+    rows = []
+    for ln in lines[1:]:
+        tok = ln.split()
+        rows.append([np.nan if t == "NA" else float(t) for t in tok[1:]])
+    return ids, np.array(rows)
+
+
+def oracle_loco_rows(res, ph):
+    """The oracle's LOCO matrix in the file's layout: std::map id order over analysed samples, NaN where masked."""
+    prep = res.prep
+    order = [i for i in sorted(range(len(prep.ids)), key=lambda i: prep.ids[i]) if prep.ind_in_analysis[i]]
+    v = res.loco[ph][order, :].T.copy()
+    v[:, ~prep.mask[order, ph]] = np.nan
+    return [prep.ids[i] for i in order], v
+
+
+def assert_text_equal(got, ref, what):
+    """`ref` was printed with 6 significant digits: got must round to it (half an ulp of the text + fp64 slack)."""
+    assert got.shape == ref.shape, what
+    assert np.array_equal(np.isnan(got), np.isnan(ref)), what + ": NA pattern"
+    ok = ~np.isnan(ref)
+    mag = np.maximum(np.abs(ref[ok]), 1e-300)
+    ulp = 10.0 ** (np.floor(np.log10(mag)) - 5)
+    err = np.abs(got[ok] - ref[ok])
+    worst = float(np.max(err / ulp)) if err.size else 0.0
+    assert worst <= 0.5 + 1e-3, "%s: %.3f text ulps" % (what, worst)
+    # BASELINE.json's metric as well
+    assert float(np.max(err)) / float(np.max(np.abs(ref[ok]))) < 1e-5, what
+
+
+TABLE_RE = re.compile(r"^\s*(\S+)\s*: Rsq = ([^,]+), MSE = ([^,<]+)(?:, -logLik/N = ([^<]+))?(<- min value)?")
+
+
+def parse_table(lines):
+    """-> list per phenotype of [(h, rsq, mse, ll or None, is_min)]"""
+    out = []
+    for ln in lines:
+        if ln.startswith("phenotype "):
+            out.append([])
+            continue
+        m = TABLE_RE.match(ln)
+        assert m, ln
+        out[-1].append((float(m.group(1)), float(m.group(2)), float(m.group(3)),
+                        float(m.group(4)) if m.group(4) else None, bool(m.group(5))))
+    return out
+
+
+def check_case(name, opt, synth=None, tmp_path=None):
+    meta = json.load(open(os.path.join(REF_OUT, name, "meta.json")))
+    if synth is not None:
+        from tests.util import synth_dosages, write_plink
+        spec = meta["synthetic"]
+        pre = str(tmp_path / "synth")
+        g = synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"])
+        write_plink(pre, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"],
+                    missing_pheno=spec["missing_pheno"])
+        opt.bed, opt.pheno_file, opt.covar_file = pre, pre + ".pheno", pre + ".covar"
+    res = orc.run_step1(opt)
+    ref_tab = parse_table(meta["table"])
+    got_tab = parse_table([l for l in res.log if l.startswith("phenotype ") or ": Rsq = " in l])
+    assert len(ref_tab) == len(got_tab) == len(meta["pred_list"])
+    for ph, (rt, gt) in enumerate(zip(ref_tab, got_tab)):
+        assert len(rt) == len(gt)
+        for (h, rsq, mse, ll, mn), (h2, rsq2, mse2, ll2, mn2) in zip(rt, gt):
+            assert h == h2 and mn == mn2, (name, ph, h)
+            assert rsq2 == pytest.approx(rsq, rel=2e-5) and mse2 == pytest.approx(mse, rel=2e-5), (name, ph, h)
+            if ll is not None:
+                assert ll2 == pytest.approx(ll, rel=2e-5), (name, ph, h)
+        ids, ref = read_loco_gz(os.path.join(REF_OUT, name, "out_%d.loco.gz" % (ph + 1)))
+        gids, got = oracle_loco_rows(res, ph)
+        assert ids == gids, name
+        assert_text_equal(got, ref, "%s pheno %d" % (name, ph + 1))
+    return res
+
+
+def E(*p):
+    return os.path.join(EX, *p)
+
+
+def test_qt_kfold_config1():
+    check_case("qt_kfold_config1", orc.Step1Options(bed=E("example"), pheno_file=E("phenotype.txt"),
+                                                    covar_file=E("covariates.txt"), bsize=100))
+
+
+def test_qt_kfold_3chr():
+    check_case("qt_kfold_3chr", orc.Step1Options(bed=E("example_3chr"), pheno_file=E("phenotype.txt"),
+                                                 covar_file=E("covariates.txt"), bsize=100))
+
+
+def test_qt_kfold_options():
+    check_case("qt_kfold_3chr_opts", orc.Step1Options(bed=E("example_3chr"), pheno_file=E("phenotype.txt"),
+                                                      covar_file=E("covariates.txt"), remove=[E("fid_iid_to_remove.txt")],
+                                                      bsize=70, cv_folds=3, ref_first=True))
+
+
+def test_qt_loocv():
+    check_case("qt_loocv_3chr", orc.Step1Options(bed=E("example_3chr"), pheno_file=E("phenotype.txt"),
+                                                 covar_file=E("covariates.txt"), bsize=100, loocv=True))
+
+
+def test_bt_loocv_reference_command():
+    res = check_case("bt_loocv_refcmd", orc.Step1Options(bed=E("example"), pheno_file=E("phenotype_bin.txt"),
+                                                         covar_file=E("covariates.txt"), remove=[E("fid_iid_to_remove.txt")],
+                                                         exclude=[E("snplist_rm.txt")], bsize=100, bt=True))
+    assert res.use_loocv
+
+
+def test_bt_loocv_missing_phenotypes():
+    check_case("bt_loocv_wNA", orc.Step1Options(bed=E("example_3chr"), pheno_file=E("phenotype_bin_wNA.txt"),
+                                                covar_file=E("covariates.txt"), bsize=100, bt=True))
+
+
+def test_bt_kfold_synthetic(tmp_path):
+    res = check_case("bt_kfold_synth", orc.Step1Options(bsize=100, bt=True), synth=True, tmp_path=tmp_path)
+    assert not res.use_loocv
+
+
+def test_qt_kfold_synthetic_missing(tmp_path):
+    check_case("qt_kfold_synth_missing", orc.Step1Options(bsize=128), synth=True, tmp_path=tmp_path)
+
+
+def test_level0_predictors_full_precision():
+    """The reference's --run-l0 job files are its level-0 predictors as raw doubles, column-major N x (blocks*R0) per
+    phenotype (Step1_Models.cpp:728-734): ridge_level_0 of the oracle against them at fp64 resolution."""
+    res = orc.run_step1(orc.Step1Options(bed=E("example_3chr"), pheno_file=E("phenotype.txt"),
+                                         covar_file=E("covariates.txt"), bsize=100))
+    N = res.prep.Y.shape[0]
+    for ph in (0, 1):
+        cols = []
+        for job in (1, 2):
+            raw = np.frombuffer(gzip.open(os.path.join(REF_OUT, "qt_split_l0_3chr", "par_job%d_l0_Y%d.gz" % (job, ph + 1)), "rb").read(),
+                                dtype="<f8")
+            assert raw.size % N == 0
+            cols.append(raw.reshape(-1, N).T)
+        Wref = np.concatenate(cols, axis=1)
+        assert Wref.shape == res.W[ph].shape
+        err = np.max(np.abs(res.W[ph] - Wref)) / np.max(np.abs(Wref))
+        assert err < 1e-11, err
+    # and the reference's own identity: the split run's .loco equal the single run's, byte for byte (test_bash.sh:126-138)
+    for ph in (1, 2):
+        a = gzip.open(os.path.join(REF_OUT, "qt_split_l0_3chr", "out_%d.loco.gz" % ph), "rb").read()
+        b = gzip.open(os.path.join(REF_OUT, "qt_kfold_3chr", "out_%d.loco.gz" % ph), "rb").read()
+        assert a == b
+
+
+def _read_regenie(path_or_bytes):
+    txt = gzip.open(path_or_bytes, "rt").read() if isinstance(path_or_bytes, str) and path_or_bytes.endswith(".gz") \
+        else open(path_or_bytes).read()
+    lines = txt.splitlines()
+    hdr = lines[0].split()
+    return hdr, [ln.split() for ln in lines[1:]]
+
+
+def test_step2_qt_oracle_against_reference():
+    """compute_res / residualize_geno / compute_score_qt / get_logp of the oracle (oracle/regenie_step2_qt.py) against the
+    reference's Step-2 output on the .bed, fed by the reference's own Step-1 LOCO files (printed with 6 digits)."""
+    from oracle import regenie_step2_qt as s2
+    opt = orc.Step1Options(bed=E("example_3chr"), pheno_file=E("phenotype.txt"), covar_file=E("covariates.txt"), bsize=100)
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    bed, _ = orc.open_bed(opt.bed + ".bed", prep.n_file)
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    n, P = int(ia.sum()), prep.Y.shape[1]
+    loco = []
+    for ph in range(P):
+        hdr, v = read_loco_gz(os.path.join(REF_OUT, "qt_kfold_3chr", "out_%d.loco.gz" % (ph + 1)))
+        pos = {s: k for k, s in enumerate(hdr)}
+        loco.append(v[:, [pos[i] for i in ids]])                  # [nchrom][n] in the analysis order
+    refs = [_read_regenie(os.path.join(REF_OUT, "step2", "qt_bed_3chr_Y%d.regenie.gz" % (ph + 1))) for ph in range(P)]
+    col = {nm: i for i, nm in enumerate(refs[0][0])}
+    X, Y, mask = prep.X[ia], prep.Y[ia], prep.mask[ia].astype(np.float64)
+    row = 0
+    for c in sorted(set(chrom.tolist())):
+        blup = np.stack([loco[ph][c - 1] for ph in range(P)], axis=1)
+        res, _, scf = s2.compute_res(Y, blup * mask, mask, prep.Neff, X.shape[1], prep.scale_Y)
+        sel = np.flatnonzero(chrom == c)
+        G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
+        out = s2.score_qt_block(G, X, res, mask, scf)
+        for k in range(sel.size):
+            for ph in range(P):
+                r = refs[ph][1][row + k]
+                assert r[col["ID"]] == snp_ids[sel[k]]
+                beta, se, chisq, logp = (float(r[col[nm]]) for nm in ("BETA", "SE", "CHISQ", "LOG10P"))
+                # the LOCO input was rounded to 6 digits by the writer: the statistics agree to ~1e-5
+                assert out["bhat"][k, ph] == pytest.approx(beta, rel=5e-5, abs=2e-6)
+                assert out["se"][k, ph] == pytest.approx(se, rel=5e-5)
+                assert out["chisq"][k, ph] == pytest.approx(chisq, rel=1e-4, abs=2e-6)
+                assert s2.get_logp(out["chisq"][k, ph]) == pytest.approx(logp, rel=1e-4, abs=2e-6)
+        row += sel.size
+    assert row == len(refs[0][1])
+
+
+needs_ref_binary = pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")
+
+
+@needs_ref_binary
+def test_reference_build_reproduces_the_reference_held_golden(tmp_path):
+    """docs/docs/options.md:20-53: the two documented commands; example/test_bin_out_firth_Y1.regenie is the reference's
+    own copy of the output.  Rows without the Firth correction (closed-form score test) must match byte for byte; the
+    Firth rows (iterative fit, tolerance-stopped) to 1e-4."""
+    d = str(tmp_path)
+    os.symlink(E("example.bgen"), os.path.join(d, "ex.bgen"))
+    base = ["--covarFile", E("covariates.txt"), "--phenoFile", E("phenotype_bin.txt"), "--remove", E("fid_iid_to_remove.txt"), "--bt"]
+    r = subprocess.run([REGENIE, "--step", "1", "--bed", E("example"), "--exclude", E("snplist_rm.txt"), "--bsize", "100",
+                        "--lowmem", "--lowmem-prefix", "tmp_rg", "--out", "fit_bin_out"] + base, cwd=d, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert any("0.4504" in ln and "min value" in ln for ln in r.stdout.splitlines())     # test/test_bash.sh:87
+    r = subprocess.run([REGENIE, "--step", "2", "--bgen", "ex.bgen", "--bsize", "200", "--firth", "--approx", "--pThresh", "0.01",
+                        "--pred", "fit_bin_out_pred.list", "--out", "test_bin_out_firth"] + base, cwd=d, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    got = open(os.path.join(d, "test_bin_out_firth_Y1.regenie")).read().splitlines()
+    ref = open(E("test_bin_out_firth_Y1.regenie")).read().splitlines()
+    assert len(got) == len(ref) == 1001 and got[0] == ref[0]
+    same = sum(1 for a, b in zip(got, ref) if a == b)
+    assert same >= 975, same
+    for a, b in zip(got, ref):
+        if a != b:
+            ta, tb = a.split(), b.split()
+            assert ta[:9] == tb[:9]
+            for x, y in zip(ta[9:13], tb[9:13]):
+                assert float(x) == pytest.approx(float(y), rel=1e-4)
+    # the committed Step-1 fixture of the same command is what this binary writes
+    for ph in (1, 2):
+        assert open(os.path.join(d, "fit_bin_out_%d.loco" % ph), "rb").read() == \
+            gzip.open(os.path.join(REF_OUT, "bt_loocv_refcmd", "out_%d.loco.gz" % ph), "rb").read()
