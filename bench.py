@@ -275,7 +275,8 @@ def main():
     # ---- CPU baseline: the oracle (numpy/OpenBLAS restatement of the reference) on a bounded sample ----
     cpu = None
     if rank == 0 and not args.no_cpu and world == 1:
-        cpu = cpu_baseline(args, eng, packed, blocks, my_blocks, X, Y, mask, ain, neff, cv_sizes, lam, tau, M, N, P, B, R0)
+        cpu = cpu_baseline(args, eng, torch, dev, packed, blocks, my_blocks, X, Y, Yraw, cov, mask, ain, neff, cv_sizes, tau, M, N, P, B, R0,
+                           (res[0], res[1], res[2]))
 
     if rank == 0:
         line = {
@@ -288,6 +289,7 @@ def main():
                        "parallelism": ("blocks sharded x%d, all-to-all of W by phenotype, level 1 phenotype-sharded x%d" if pheno_sharded else
                                        "blocks sharded x%d, all-gather of W, level-1 Gram tiles / ridge systems shared x%d") % (world, world)},
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+            "loco_max_rel_err": cpu.get("loco_max_rel_err") if cpu else None,
             "loco_checksum": float(res[3]) if len(res) > 3 else float(sum(np.abs(l).sum() for l in res[0])),
             "selected_tau_index": [int(b) for b in res[2]],
             "setup_s": {"generate": t_gen},
@@ -302,17 +304,127 @@ def math_sqrt(x):
     return float(np.sqrt(x))
 
 
-def cpu_baseline(args, eng, packed, blocks, my_blocks, X, Y, mask, ain, neff, cv_sizes, lam, tau, M, N, P, B, R0):
-    """Times the oracle on the GPU box's host cores: level 0 on `cpu_blocks` full blocks (level 0 is exactly
-    linear in the number of blocks) + level 1 for one phenotype on the full W, extrapolated to the run."""
+def _parse_loco(path):
+    lines = open(path).read().splitlines()
+    ids = lines[0].split()[1:]
+    vals = np.array([[float(t) for t in ln.split()[1:]] for ln in lines[1:]])
+    return ids, vals
+
+
+def cpu_baseline(args, eng, torch, dev, packed, blocks, my_blocks, X, Y, Yraw, cov, mask, ain, neff, cv_sizes, tau, M, N, P, B, R0,
+                 gpu_full):
+    """CPU leg (rank 0, N=1 only), two parts.
+
+    (1) `kind: "reference"` -- regenie v4.1.2 ITSELF (oracle/_ref/regenie: the reference's sources compiled by
+        oracle/Makefile with its own flags) timed on this box's host cores on a BOUNDED sample of the same workload:
+        every SNP block of the last two chromosomes (4 blocks, two of them ragged chromosome ends) written to a .bed on
+        the local disk with the full sample count and all phenotypes, run as a complete `regenie --step 1` (file parsing,
+        level 0, level 1, .loco writing).  The GPU then solves that same sub-problem through the C ABI and the LOCO
+        predictors are compared with the reference's files: `loco_max_rel_err` is BASELINE.json's accuracy metric,
+        measured against the real reference (its .loco text carries 6 significant digits).
+    (2) the numpy oracle (pinned to the reference by tests/test_reference_pin.py) checks the FULL configuration: level-0
+        predictors of a sample of blocks, and level 1 of phenotype 0 on the full W -- CV sums, selected ridge value,
+        LOCO predictors (`full_config_vs_oracle`)."""
+    import shutil
+    import subprocess
+    import tempfile
     from oracle import regenie_step1 as orc          # timed CPU baseline / checker only
+    from regenie_amd import hostprep as hp
+    from regenie_amd.engine import Step1Engine
+    out = {}
+    regenie = os.path.join(ROOT, "oracle", "_ref", "regenie")
+    chr_ids = sorted({blocks[b][0] for b in my_blocks})
+    sel_chr = chr_ids[-2:]
+    sel = [b for b in my_blocks if blocks[b][0] in sel_chr]
+    if len(sel) > args.cpu_blocks:
+        sel = sel[:max(1, args.cpu_blocks // 2)] + sel[-(args.cpu_blocks - max(1, args.cpu_blocks // 2)):]
+    Ms = sum(blocks[b][2] for b in sel)
+    if os.path.exists(regenie):
+        d = tempfile.mkdtemp(prefix="rg_cpu_baseline_")
+        try:
+            pre = os.path.join(d, "s")
+            with open(pre + ".bed", "wb") as fh:
+                fh.write(b"\x6c\x1b\x01")
+                for b in sel:
+                    fh.write(packed[b].cpu().numpy().tobytes())
+            with open(pre + ".bim", "w") as fh:
+                j = 0
+                for b in sel:
+                    for _ in range(blocks[b][2]):
+                        fh.write("%d\ts%d\t0\t%d\tA\tG\n" % (blocks[b][0] + 1, j, j + 1))
+                        j += 1
+            with open(pre + ".fam", "w") as fh:
+                fh.write("".join("%d %d 0 0 0 -9\n" % (i + 1, i + 1) for i in range(N)))
+            with open(pre + ".pheno", "w") as fh:
+                fh.write("FID IID " + " ".join("Y%d" % (p + 1) for p in range(P)) + "\n")
+                for i in range(N):
+                    fh.write("%d %d " % (i + 1, i + 1) + " ".join("%.17g" % v for v in Yraw[i]) + "\n")
+            with open(pre + ".covar", "w") as fh:
+                fh.write("FID IID C1 C2\n")
+                for i in range(N):
+                    fh.write("%d %d %.17g %.17g\n" % (i + 1, i + 1, cov[i, 0], cov[i, 1]))
+            ncore = os.cpu_count() or 1
+            thr = max(1, ncore - 1)                     # the reference's own default (Regenie.cpp:1104-1106)
+            t0 = time.perf_counter()
+            r = subprocess.run([regenie, "--step", "1", "--bed", pre, "--phenoFile", pre + ".pheno", "--covarFile", pre + ".covar",
+                                "--bsize", str(args.bsize), "--qt", "--threads", str(thr), "--out", os.path.join(d, "ref")],
+                               capture_output=True, text=True, cwd=d)
+            t_ref = time.perf_counter() - t0
+            if r.returncode != 0:
+                raise RuntimeError("reference run failed: " + r.stdout[-2000:] + r.stderr[-2000:])
+            phases = {"geno_resid_ms": 0.0, "working_matrices_ms": 0.0, "level0_ridge_ms": 0.0}
+            for ln in r.stdout.splitlines():
+                for key, tag in (("geno_resid_ms", "-residualizing and scaling genotypes...done ("),
+                                 ("working_matrices_ms", "-calc working matrices...done ("),
+                                 ("level0_ridge_ms", "-calc level 0 ridge...done (")):
+                    if tag in ln:
+                        phases[key] += float(ln.split(tag)[1].split("ms")[0])
+            # the same sub-problem through the C ABI
+            sblocks = [(blocks[b][0], None, blocks[b][2]) for b in sel]
+            Bs = len(sel)
+            h0 = hp.set_ridge_params(R0)
+            lam_s = Ms * (1 - h0) / h0
+            h1 = hp.set_ridge_params(tau.shape[1])
+            Ls = Bs * R0
+            tau_s = np.tile(Ls * (1 - h1) / h1, (P, 1))
+            e2 = Step1Engine(dev.index or 0, torch.cuda.current_stream().cuda_stream)
+            e2.set_problem(X=X, Y=Y, mask=mask, ind_in_analysis=ain, cv_sizes=cv_sizes, lam=lam_s, neff=neff, n_file=N,
+                           n_blocks_total=Bs, max_block_size=args.bsize)
+            e2.l0_blocks_device(list(range(Bs)), [blocks[b][2] for b in sel], [packed[b].data_ptr() for b in sel], N // 4)
+            e2.sync()
+            cols = [sum(R0 for b in sel if blocks[b][0] == c) for c in sel_chr]
+            e2.set_loco_output([c + 1 for c in sel_chr])
+            cs2, best2, pred2 = e2.l1_qt(tau_s, cols)
+            err, tab_ok = 0.0, True
+            order = sorted(range(N), key=lambda i: "%d_%d" % (i + 1, i + 1))      # the writer's std::map order (Data.cpp:1934)
+            for p in range(P):
+                ids, ref = _parse_loco(os.path.join(d, "ref_%d.loco" % (p + 1)))
+                got = np.asarray(pred2[p])[order, :].T
+                err = max(err, float(np.max(np.abs(got - ref)) / np.max(np.abs(ref))))
+            mins = [ln for ln in r.stdout.splitlines() if "<- min value" in ln]
+            h1s = ["%g" % v for v in h1]
+            ref_best = [h1s.index(ln.split(":")[0].strip()) if ln.split(":")[0].strip() in h1s else -1 for ln in mins]
+            e2.close()
+            out.update({"value": Ms * N * P / t_ref, "unit": "SNP*sample*pheno/s", "cores": thr, "kind": "reference",
+                        "sample": "regenie v4.1.2 (oracle/_ref/regenie, -O3 -ffast-math -fopenmp, Eigen 3.4.0, --threads %d of %d host "
+                                  "cores): complete --step 1 from files on %d of the run's %d SNP blocks (all blocks of chromosomes %s: "
+                                  "%d SNPs x %d samples x %d phenotypes), %.1f s wall" % (thr, ncore, Bs, B, [c + 1 for c in sel_chr], Ms, N, P, t_ref),
+                        "sample_wall_s": t_ref, "reference_phase_ms": phases,
+                        "extrapolated_total_s": (phases["geno_resid_ms"] + phases["working_matrices_ms"] + phases["level0_ridge_ms"]) * 1e-3 / Ms * M,
+                        "extrapolation_note": "level-0 phases of the reference's own log scaled linearly in SNPs to the full run (level 1 and I/O not included)",
+                        "loco_max_rel_err": err, "selected_tau_index_reference": ref_best,
+                        "selected_tau_index_gpu": [int(b) for b in best2]})
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    # ---- the numpy oracle on the full configuration ----
     prep = orc.Prepared(ids=[], n_file=N, ind_ignore=np.zeros(N, bool), ind_in_analysis=ain, pheno_names=[],
                         Y=Y, Y_raw=None, mask=mask, X=X, Neff=neff, scale_Y=np.ones(P), ncov=X.shape[1],
                         n_analyzed=N)
-    nsel = min(args.cpu_blocks, len(my_blocks))
-    sel = [my_blocks[int(i)] for i in np.linspace(0, len(my_blocks) - 1, nsel)]
-    t_l0, err = 0.0, 0.0
-    for b in sel:
+    lam = M * (1 - hp.set_ridge_params(R0)) / hp.set_ridge_params(R0)
+    nsel = min(2, len(my_blocks))
+    osel = [my_blocks[int(i)] for i in np.linspace(0, len(my_blocks) - 1, nsel)]
+    t_l0, werr = 0.0, 0.0
+    for b in osel:
         rows = packed[b].cpu().numpy()
         t0 = time.perf_counter()
         G = orc.read_chunk_from_bed(rows, N, None, ain)
@@ -320,16 +432,29 @@ def cpu_baseline(args, eng, packed, blocks, my_blocks, X, Y, mask, ain, neff, cv
         Wb = orc.ridge_level_0(G, prep, cv_sizes, lam)
         t_l0 += time.perf_counter() - t0
         for p in range(P):
-            err = max(err, float(np.max(np.abs(eng.get_w(b, p) - Wb[p])) / np.max(np.abs(Wb[p]))))
+            werr = max(werr, float(np.max(np.abs(eng.get_w(b, p) - Wb[p])) / np.max(np.abs(Wb[p]))))
     W0 = np.concatenate([eng.get_w(b, 0) for b in range(B)], axis=1)
     t0 = time.perf_counter()
     cs, betas = orc.ridge_level_1(W0, Y[:, 0], cv_sizes, tau[0])
+    best = orc.select_tau(cs, neff[0], False)
+    chrcols = orc.chr_columns([(c + 1, s0, n) for (c, s0, n) in blocks], sorted({bl[0] + 1 for bl in blocks}), R0)
+    pred = orc.make_predictions(W0, betas, best, cv_sizes, chrcols)
+    loco = orc.loco_from_predictions(pred, chrcols, 23)
     t_l1 = time.perf_counter() - t0
-    total = t_l0 / nsel * B + t_l1 * P
-    return {"value": M * N * P / total, "unit": "SNP*sample*pheno/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "oracle (numpy+OpenBLAS fp64, all host threads): level 0 on %d of %d blocks (%.1f s) extrapolated linearly in "
-                      "blocks + level 1 of one phenotype on the full W (%.1f s) x P" % (nsel, B, t_l0, t_l1),
-            "extrapolated_total_s": total, "gpu_vs_oracle_W_max_rel_err_on_sample": err}
+    g_loco, g_cs, g_best = gpu_full
+    full = {"W_max_rel_err_on_%d_blocks" % nsel: werr,
+            "l1_cumsum_max_rel_err": float(np.max(np.abs(np.asarray(g_cs)[0][:5] - cs[:5]) / np.maximum(np.abs(cs[:5]), 1e-300))),
+            "selected_tau_index_oracle": int(best), "selected_tau_index_gpu": int(g_best[0]),
+            "loco_max_rel_err_pheno0": float(np.max(np.abs(np.asarray(g_loco[0]) - loco)) / np.max(np.abs(loco))),
+            "oracle_s": {"level0_%d_blocks" % nsel: t_l0, "level1_pheno0": t_l1}}
+    out["full_config_vs_oracle"] = full
+    if "value" not in out:       # no reference binary on this box: the numpy restatement is the baseline
+        total = t_l0 / nsel * B + t_l1 * P
+        out.update({"value": M * N * P / total, "unit": "SNP*sample*pheno/s", "cores": os.cpu_count(), "kind": "port",
+                    "sample": "oracle (numpy+OpenBLAS fp64): level 0 on %d of %d blocks (%.1f s) extrapolated linearly + level 1 of one "
+                              "phenotype on the full W (%.1f s) x P" % (nsel, B, t_l0, t_l1), "extrapolated_total_s": total,
+                    "loco_max_rel_err": full["loco_max_rel_err_pheno0"]})
+    return out
 
 
 if __name__ == "__main__":

@@ -143,7 +143,18 @@ struct FormSrc {
   const double* shift; const int32_t* d_n;
   const double* extra; int64_t extra_stride;
   int nfold, nshift, n_fixed, enabled, subtract, extra_row0, n64, n_div, b_offset;
+  int skip_pad;   // group-wise path: tile rows / columns past a system's own order (identity padding) are not computed
 };
+// Tile columns of system b that hold data: ceil(n_b / 64) when the caller gave per-system orders (level 0: the SNP count of
+// the block, so that a chromosome-end block of 300 SNPs is factored at order 320 instead of the batch's 1024), else T.
+// Tile rows [T_b, T) and tile columns >= T_b of such a system are identity padding: never read, never written.
+__device__ __forceinline__ int sys_tiles(const FormSrc& f, int b_local, int T) {
+  if (!f.skip_pad || !f.d_n) return T;
+  const int b = b_local + f.b_offset;
+  const int o = b / (f.nfold * f.nshift);
+  const int tb = (f.d_n[o / f.n_div] + CT - 1) / CT;
+  return tb < T ? tb : T;
+}
 struct FormIdx { const double* S; const double* F; const double* X; double sh; int64_t xoff; int n, x0; };
 __device__ __forceinline__ FormIdx form_idx(const FormSrc& f, int b_local) {
   const int b = b_local + f.b_offset;   // a rank / caller may own a contiguous sub-range of the systems
@@ -530,6 +541,10 @@ __global__ __launch_bounds__(256, 2) void k_chol_update(double* mats, int64_t ma
   if (idx >= ntile) return;
   while (tc < c_hi && idx >= Ttot - tc) { idx -= Ttot - tc; ++tc; }
   const int tr = tc + idx;
+  {
+    const int T = n64 / CT;
+    if (tr < T && tr >= sys_tiles(fs, b, T)) return;   // identity padding of a system smaller than the batch's order
+  }
   const int i = lane & 15, q = lane >> 4;
   double* M = mats + (int64_t)b * mat_stride;
   const double* A = M + ((int64_t)tr * CT + i) * n64 + kc0 * CT + 2 * q;
@@ -941,6 +956,9 @@ __global__ __launch_bounds__(256) void k_chol_gfact(double* mats, int64_t mat_st
     const FormIdx f0 = form_idx(fs, b);
     md = f0.F ? 1 : 0;   // form_mode_rows for rows < n64 <= extra_row0
   }
+  const int tb = sys_tiles(fs, b, n64 / CT);
+  if (k0 >= tb) return;                 // the whole group is identity padding for this system
+  if (k0 + nc > tb) nc = tb - k0;
   gfact_wave(md, S[wave], DV[wave], M, b, n64, k0, nc, dinvb, img, info, fs);
 }
 
@@ -986,6 +1004,12 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void k_chol_gstrip(double* 
   const int i = lane & 15, q = lane >> 4;
   const int k1 = k0 + nc;
   const int tr0 = k1 + NS * g;              // first tile row of the workgroup; slab t of wave w: rows 64(tr0+t) + 16w + i
+  {
+    const int T = n64 / CT;
+    const int tb = __builtin_amdgcn_readfirstlane(sys_tiles(fs, b, T));
+    if (k0 >= tb || (tr0 < T && tr0 >= tb)) return;   // group or tile row in the identity padding of a smaller system
+    if (k1 > tb) nc = tb - k0;                        // only the tile columns that hold data are solved for
+  }
   double* M = mats + (int64_t)b * mat_stride;
   const double* img = dimg + ((int64_t)b * ngrp + k0 / 4) * GT_NIMG * GT_TILE;
   bool act[NS];                             // wave-uniform: slabs of padding rows only take part in the staging
@@ -1270,12 +1294,13 @@ __global__ __launch_bounds__(256, (NS == 1 ? 2 : 1)) void k_chol_gstrip(double* 
 // contraction of each tile (parts = 4 / pg), so a single right-hand side still keeps 4 waves of
 // loads in flight.
 __global__ __launch_bounds__(256) void k_chol_backsolve(double* mats, int64_t mat_stride, int n64,
-                                                        int nrhs, const double* dinv) {
+                                                        int nrhs, const double* dinv, FormSrc fs) {
   __shared__ double xk[4][CT];
   __shared__ double yk[4][CT];
   __shared__ double red[4][CT];
   const int b = blockIdx.x;
-  const int T = n64 / CT;
+  const int Tfull = n64 / CT;
+  const int T = sys_tiles(fs, b, Tfull);    // solution entries past the system's own order are not produced (nor read)
   const int w = threadIdx.x >> 6, c = threadIdx.x & 63;
   const int pg = nrhs >= 4 ? 4 : (nrhs >= 2 ? 2 : 1);
   const int parts = 4 / pg;
@@ -1289,7 +1314,7 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(double* mats, int64_t ma
       __syncthreads();
       if (part == 0) yk[p][c] = act ? Y[k * CT + c] : 0.0;
       __syncthreads();
-      const double* I = dinv + ((int64_t)b * T + k) * CT * CT;
+      const double* I = dinv + ((int64_t)b * Tfull + k) * CT * CT;
       double x = 0.0;
       for (int r = r0; r < r0 + rlen; ++r) x = fma(yk[p][r], I[r * CT + c], x);  // Linv is lower: zeros above
       red[w][c] = x;
@@ -1400,7 +1425,7 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
                               const FormSrc* src, int path) {
   const int T = n64 / CT, Tr = rhs_pad / CT, Ttot = T + Tr;
   FormSrc off{};
-  off.enabled = 0; off.extra = nullptr; off.n_div = 1; off.b_offset = 0;
+  off.enabled = 0; off.extra = nullptr; off.n_div = 1; off.b_offset = 0; off.skip_pad = 0; off.d_n = nullptr; off.nfold = off.nshift = 1;
   int64_t nl = 0;
   // path: 0 = group-wise (throughput: level 0, whatever the batch size, so that results do not depend on how the blocks
   // are batched), 1 = per-column (latency: level 1 and the logistic steps, a few dozen systems), -1 = by batch size
@@ -1441,7 +1466,7 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
     // few, large systems: row-parallel back substitution; many small ones: one workgroup per system
     if ((int64_t)batch * 4 <= 256 && T >= 8) launch_backsolve_rows(st, mats, mat_stride, batch, n64, nrhs, dinv, nl);
     else {
-      hipLaunchKernelGGL(k_chol_backsolve, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, nrhs, dinv);
+      hipLaunchKernelGGL(k_chol_backsolve, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, nrhs, dinv, off);
       ++nl;
     }
   }
@@ -1457,7 +1482,10 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
   // forward substitution only, every appended row is real -- the LOOCV / inverse callers.)
   const int row_end = n64 + (nrhs > 0 ? nrhs : rhs_pad);
   double* dimg = dinv + chol_ws_img_offset((size_t)batch, n64);   // the workspace holds the tile inverses, then the images
-  const FormSrc& first = src ? *src : off;
+  FormSrc first = src ? *src : off;
+  first.skip_pad = (src && src->d_n && !getenv("RG_CHOL_FULLPAD")) ? 1 : 0;
+  FormSrc later = first;          // launches past a tile's first touch: workspace values, but still the per-system orders
+  later.enabled = 0;
   for (int k0 = 0; k0 < T; k0 += 4) {
     const int nc = std::min(4, T - k0), k1 = k0 + nc;
     if (k0 > 0) {   // diagonal block: tiles (r, c), k0 <= c <= r < k1, K = 64 * k0
@@ -1467,7 +1495,7 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
       ++nl;
     }
     hipLaunchKernelGGL(k_chol_gfact, dim3((batch + 3) / 4), dim3(256), 0, st, mats, mat_stride, n64, k0, nc, batch, dinv,
-                       dimg, ngrp, info, k0 == 0 ? first : off);
+                       dimg, ngrp, info, k0 == 0 ? first : later);
     ++nl;
     if (Ttot > k1) {
       const int nitem = Ttot - k1;
@@ -1477,7 +1505,7 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
     }
   }
   if (nrhs > 0) {
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, nrhs, dinv);
+    hipLaunchKernelGGL(k_chol_backsolve, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, nrhs, dinv, later);
     ++nl;
   }
   if (n_launch) *n_launch += nl;
@@ -1500,7 +1528,7 @@ void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t su
   f.sum = sum; f.sum_stride = sum_stride; f.fold = fold; f.fold_stride = fold_stride; f.shift = shift;
   f.d_n = d_n; f.nfold = nfold; f.nshift = nshift; f.n_fixed = n_fixed; f.enabled = 1;
   f.subtract = subtract; f.extra = extra; f.extra_stride = extra_stride; f.extra_row0 = extra_row0; f.n64 = n64;
-  f.n_div = n_div; f.b_offset = b_offset;
+  f.n_div = n_div; f.b_offset = b_offset; f.skip_pad = 0;
   rg_launch_chol_solve_src(st, mats, mat_stride, b_count >= 0 ? b_count : nouter * nfold * nshift, n64, rhs_pad, nrhs,
                            dinv, info, n_launch, &f, path);
 }

@@ -143,22 +143,28 @@ __global__ __launch_bounds__(1024) void k_gram_fp4_generic(const uint8_t* A, int
                     smem);
 }
 
-// ---- production: grid.x = lower-triangular 256-tile index over the n128 rows of the block (x K super-chunks),
-//      grid.y = fold, grid.z = block; output into the dosage x dosage quadrant of S (ld = 2*n128) --------
+// ---- production: one workgroup per (lower-triangular 256-tile, K super-chunk, fold, block); output into the
+//      dosage x dosage quadrant of S (ld = 2*n128) --------
+// Placement: the hardware deals workgroups to the 8 XCDs round-robin by LINEAR workgroup id, and each XCD has its own L2.
+// The ntile tiles of one (block, fold) read the same nt operand panels (each panel by up to nt tiles: 4x re-reads at
+// nt = 4 when the tiles land on different XCDs), so the grid is one-dimensional and work item w = xcd * ceil(total / 8) +
+// slot (xcd = id & 7, slot = id >> 3) is decoded tile-fastest: every XCD walks its own contiguous range of (block, fold)
+// groups and the tiles of a group are co-resident on it, streaming the same K window through one L2.
 __global__ __launch_bounds__(1024) void k_gram_fp4_blocks(const uint8_t* pk4, int64_t pk4_ld, int64_t pk4_blk_stride,
-                                                         int n128, SegLayout seg, int ntile, int nsuper, int32_t* S) {
+                                                         int n128, SegLayout seg, int ntile, int nsuper, int total,
+                                                         int32_t* S) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[4 * FT * FROWB];
-  int tidx = blockIdx.x % ntile;
-  const int sup = blockIdx.x / ntile;
-  {  // XCD-aware remap: consecutive tile ids share operand panels; keep them on one XCD's L2
-    const int q = ntile / 8, r = ntile % 8, xcd = tidx % 8, k = tidx / 8;
-    tidx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-  }
+  const int per_xcd = (total + 7) >> 3;
+  const int w = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if ((int)(blockIdx.x >> 3) >= per_xcd || w >= total) return;
+  const int per_group = ntile * nsuper;
+  const int t = w % per_group, grp = w / per_group;
+  const int tidx = t % ntile, sup = t / ntile;
+  const int f = grp % seg.nseg, blk = grp / seg.nseg;
   int tr = (int)((sqrtf(8.0f * tidx + 1.0f) - 1.0f) * 0.5f);
   while ((tr + 1) * (tr + 2) / 2 <= tidx) ++tr;
   while (tr * (tr + 1) / 2 > tidx) --tr;
   const int tc = tidx - tr * (tr + 1) / 2;
-  const int blk = blockIdx.z, f = blockIdx.y;
   const int64_t kbytes = seg.plen[f] / 2;
   const int64_t k0 = (int64_t)sup * FP4_FLUSH_STAGES * FROWB;
   if (k0 >= kbytes) return;
@@ -185,8 +191,9 @@ void rg_launch_gram_fp4_blocks(hipStream_t st, const uint8_t* pk4, int64_t pk4_l
     const int64_t ldS = 2 * (int64_t)n128;
     hipMemsetAsync(S, 0, sizeof(int32_t) * (size_t)nblk * seg.nseg * ldS * ldS, st);
   }
-  dim3 grid(ntile * nsuper, seg.nseg, nblk);
-  hipLaunchKernelGGL(k_gram_fp4_blocks, grid, dim3(1024), 0, st, pk4, pk4_ld, pk4_blk_stride, n128, seg, ntile, nsuper, S);
+  const int total = ntile * nsuper * seg.nseg * nblk;
+  dim3 grid((unsigned)(((total + 7) / 8) * 8));
+  hipLaunchKernelGGL(k_gram_fp4_blocks, grid, dim3(1024), 0, st, pk4, pk4_ld, pk4_blk_stride, n128, seg, ntile, nsuper, total, S);
 }
 
 void rg_launch_gram_fp4_generic(hipStream_t st, const uint8_t* A, int64_t lda, const uint8_t* B, int64_t ldb, int m,

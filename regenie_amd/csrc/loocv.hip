@@ -76,7 +76,9 @@ __global__ __launch_bounds__(256) void k_l0_loocv_pred(LoocvArgs a) {
       double h = 0.0, num[LP_MAX];
 #pragma unroll
       for (int p = 0; p < LP_MAX; ++p) num[p] = 0.0;
-      for (int k = lane * 2; k < a.n64; k += 128) {
+      // columns past the block's own tile count are identity padding the factorization does not produce (chol.hip: sys_tiles)
+      const int kend = min(a.n64, (a.bs[blk] + 63) & ~63);
+      for (int k = lane * 2; k < kend; k += 128) {
         const double2 zz = *reinterpret_cast<const double2*>(z + k);
         h = fma(zz.x, zz.x, h);
         h = fma(zz.y, zz.y, h);

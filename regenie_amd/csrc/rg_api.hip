@@ -234,7 +234,9 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   // LOOCV: every (block, lambda) system carries the Np sample rows as extra right-hand sides
   ctx->rtot_wk = ctx->loocv ? ctx->rtot + Np : (int64_t)ctx->rtot;
   ctx->nsys = ctx->loocv ? ctx->R0 : K * ctx->R0;
-  int nb = 64;  // blocks per batch: more systems per launch hide the Cholesky dependency chain
+  // blocks per batch: more systems per launch hide the Cholesky dependency chain, but the block factorization of a column
+  // group runs one wave per system, 4 waves per CU (LDS): up to 1024 systems are one round of it, 1025 are two
+  int nb = std::max(8, 1024 / std::max(1, ctx->nsys));
   if (const char* e = getenv("RG_NBLK")) nb = std::max(1, atoi(e));
   nb = std::min(nb, ctx->B_total);
   if (ctx->loocv) {  // bound the forward-substituted row storage (~24 GB)
@@ -451,7 +453,11 @@ int rg_l0_blocks(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int3
   // per-stage timing mode keeps a single pipeline so that its HIP-event brackets stay meaningful.
   const int npipe = (ctx->twin && !ctx->timing) ? ctx->n_pipe : 1;
   int nbatch = (nblk + ctx->nblk_cap - 1) / ctx->nblk_cap;
-  if (npipe > 1 && nblk >= 2 * npipe) nbatch = (nbatch + npipe - 1) / npipe * npipe;
+  {
+    // batches are dealt round-robin to the pipelines; RG_BATCH_ROUND=1 rounds their number up to a multiple of the pipelines
+    static const bool round_up = getenv("RG_BATCH_ROUND") && atoi(getenv("RG_BATCH_ROUND")) != 0;
+    if (npipe > 1 && nblk >= 2 * npipe && (round_up || nbatch < npipe)) nbatch = (nbatch + npipe - 1) / npipe * npipe;
+  }
   const int per = (nblk + nbatch - 1) / nbatch;
   const bool multi = npipe > 1 && nbatch > 1;
   if (multi) {

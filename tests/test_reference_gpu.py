@@ -1,0 +1,153 @@
+"""The C++ driver on the GPU against regenie ITSELF: `regenie-amd --step 1 <args>` must write what regenie v4.1.2 wrote for
+the same command (tests/golden/ref_outputs/, produced by oracle/_ref/regenie = the reference's sources compiled by
+oracle/Makefile; generator tests/golden/make_ref_outputs.py).  Compared: every .loco / .prs value at the resolution of
+the reference's 6-digit text (and under BASELINE.json's max-relative-error metric, bar 1e-5), the NA pattern, sample and
+chromosome order, the CV table of the log with the selected ridge parameter, the phenotype names of _pred.list.
+With the reference binary present (it ships to the GPU box prebuilt) two full-sample-size cases run it live next to the
+driver: N = 500,000 with 10 QT phenotypes (BASELINE configs[2] shape) and N = 500,000 binary traits, K-fold (configs[3])."""
+import gzip
+import json
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+pytest.importorskip("torch")
+
+from tests.test_reference_pin import (EX, REF_OUT, REGENIE, assert_text_equal, parse_table, read_loco_gz)  # noqa: E402
+from tests.golden.make_ref_outputs import CASES, table_lines  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "regenie_amd", "bin", "regenie-amd")
+
+
+def _loco_file(path):
+    lines = open(path).read().splitlines()
+    ids = lines[0].split()[1:]
+    return ids, np.array([[np.nan if t == "NA" else float(t) for t in ln.split()[1:]] for ln in lines[1:]]), \
+        [ln.split()[0] for ln in lines[1:]]
+
+
+def _compare_tables(got_lines, ref_lines, what, rel=2e-5):
+    gt, rt = parse_table(got_lines), parse_table(ref_lines)
+    assert len(gt) == len(rt), what
+    for ph, (g, r) in enumerate(zip(gt, rt)):
+        assert len(g) == len(r), what
+        for (h, rsq, mse, ll, mn), (h2, rsq2, mse2, ll2, mn2) in zip(r, g):
+            assert h == h2 and mn == mn2, (what, ph, h)
+            assert rsq2 == pytest.approx(rsq, rel=rel) and mse2 == pytest.approx(mse, rel=rel), (what, ph, h)
+            if ll is not None:
+                assert ll2 == pytest.approx(ll, rel=rel), (what, ph, h)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_driver_reproduces_reference_outputs(name, tmp_path):
+    args, spec = CASES[name]
+    d = str(tmp_path)
+    S = os.path.join(d, "synth")
+    if spec:
+        from tests.util import synth_dosages, write_plink
+        g = synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"])
+        write_plink(S, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    r = subprocess.run([BIN] + [a.format(E=EX, S=S) for a in args] + ["--out", "out"], cwd=d, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    meta = json.load(open(os.path.join(REF_OUT, name, "meta.json")))
+    assert [ln.split()[0] for ln in open(os.path.join(d, "out_pred.list"))] == meta["pred_list"]
+    _compare_tables(table_lines(open(os.path.join(d, "out.log")).read()), meta["table"], name)
+    n = 0
+    for fn in sorted(os.listdir(os.path.join(REF_OUT, name))):
+        if not (fn.endswith(".loco.gz") or fn.endswith(".prs.gz")):
+            continue
+        ids_r, ref = read_loco_gz(os.path.join(REF_OUT, name, fn))
+        ids_g, got, first = _loco_file(os.path.join(d, fn[:-3]))
+        assert ids_g == ids_r, fn
+        if fn.endswith(".loco.gz"):
+            assert first == [str(c) for c in range(1, 24)]
+        assert_text_equal(got, ref, "%s %s" % (name, fn))
+        n += 1
+    assert n >= len(meta["pred_list"])
+
+
+def _write_big(prefix, N, M, chroms, P, binary, seed, missing_pheno):
+    """N x M .bed with HWE genotypes (MAF U(0.05, 0.5), 0.2 % missing calls), P phenotypes with a polygenic signal."""
+    rng = np.random.default_rng(seed)
+    maf = 0.05 + 0.45 * rng.random(M)
+    score = np.zeros((P, N))
+    with open(prefix + ".bed", "wb") as fh:
+        fh.write(b"\x6c\x1b\x01")
+        for j in range(M):
+            g = (rng.random(N) < maf[j]).astype(np.int8) + (rng.random(N) < maf[j]).astype(np.int8)
+            gs = (g - 2 * maf[j]) / np.sqrt(2 * maf[j] * (1 - maf[j]))
+            for p in range(P):
+                if (j + p) % 7 == 0:
+                    score[p] += gs * (0.05 if (j // 7) % 2 else -0.04)
+            code = np.where(g == 2, 0, np.where(g == 1, 2, 3)).astype(np.uint8)
+            code[rng.random(N) < 0.002] = 1
+            c = code.reshape(-1, 4)
+            fh.write((c[:, 0] | (c[:, 1] << 2) | (c[:, 2] << 4) | (c[:, 3] << 6)).astype(np.uint8).tobytes())
+    with open(prefix + ".bim", "w") as fh:
+        for j in range(M):
+            fh.write("%d\ts%d\t0\t%d\tA\tG\n" % (chroms[j], j, j + 1))
+    with open(prefix + ".fam", "w") as fh:
+        fh.write("".join("%d %d 0 0 0 -9\n" % (i + 1, i + 1) for i in range(N)))
+    cov = rng.standard_normal((N, 2))
+    with open(prefix + ".covar", "w") as fh:
+        fh.write("FID IID C1 C2\n")
+        fh.write("".join("%d %d %.10g %.10g\n" % (i + 1, i + 1, cov[i, 0], cov[i, 1]) for i in range(N)))
+    Y = score.T / score.std(axis=1) * 0.5 + rng.standard_normal((N, P)) + 0.3 * cov[:, :1]
+    if binary:
+        Y = (Y > np.quantile(Y, 0.8, axis=0, keepdims=True)).astype(np.float64)
+    miss = rng.random((N, P)) < missing_pheno
+    with open(prefix + ".pheno", "w") as fh:
+        fh.write("FID IID " + " ".join("Y%d" % (p + 1) for p in range(P)) + "\n")
+        for i in range(N):
+            fh.write("%d %d " % (i + 1, i + 1) + " ".join("NA" if miss[i, p] else "%.10g" % Y[i, p] for p in range(P)) + "\n")
+
+
+needs_ref_binary = pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")
+
+
+@needs_ref_binary
+@pytest.mark.parametrize("kind", ["qt_config3_shape", "bt_kfold_config4_shape"])
+def test_driver_vs_live_reference_at_500k_samples(kind, tmp_path):
+    """BASELINE configs[2] / [3] at their real sample count, phenotype count (10 QT with missing values / 6 BT, K-fold) and
+    block size 1000, on a slice of SNP blocks both programs finish in about a minute: regenie itself and the driver read
+    the same files; LOCO predictors must agree to the printed digits (bar 1e-5, BASELINE.json)."""
+    d = str(tmp_path)
+    N = 500_000
+    if kind == "qt_config3_shape":
+        M, chroms, P, binary = 2600, [1] * 1000 + [2] * 1000 + [7] * 600, 10, False
+    else:
+        M, chroms, P, binary = 1600, [3] * 1000 + [9] * 600, 6, True
+    pre = os.path.join(d, "big")
+    _write_big(pre, N, M, chroms, P, binary, seed=2026, missing_pheno=0.01)
+    common = ["--step", "1", "--bed", pre, "--covarFile", pre + ".covar", "--phenoFile", pre + ".pheno", "--bsize", "1000",
+              "--bt" if binary else "--qt"]
+    t0 = time.time()
+    r = subprocess.run([REGENIE] + common + ["--out", "ref"], cwd=d, capture_output=True, text=True, timeout=3000)
+    t_ref = time.time() - t0
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    t0 = time.time()
+    g = subprocess.run([BIN] + common + ["--out", "gpu"], cwd=d, capture_output=True, text=True, timeout=1200)
+    t_gpu = time.time() - t0
+    assert g.returncode == 0, g.stdout[-3000:] + g.stderr[-3000:]
+    print("%s: reference %.1f s, driver %.1f s (wall, from files)" % (kind, t_ref, t_gpu))
+    _compare_tables(table_lines(open(os.path.join(d, "gpu.log")).read()), table_lines(open(os.path.join(d, "ref.log")).read()), kind)
+    worst = 0.0
+    for ph in range(1, P + 1):
+        ids_r, ref, _ = _loco_file(os.path.join(d, "ref_%d.loco" % ph))
+        ids_g, got, _ = _loco_file(os.path.join(d, "gpu_%d.loco" % ph))
+        assert ids_r == ids_g and ref.shape == (23, N - 0) or ref.shape[0] == 23
+        assert np.array_equal(np.isnan(ref), np.isnan(got))
+        ok = ~np.isnan(ref)
+        # both files carry 6 significant digits: one unit of the last printed digit + the metric of BASELINE.json
+        mag = np.maximum(np.abs(ref[ok]), 1e-300)
+        ulp = 10.0 ** (np.floor(np.log10(mag)) - 5)
+        assert float(np.max(np.abs(got[ok] - ref[ok]) / ulp)) <= 1.0 + 1e-6, (kind, ph)
+        e = float(np.max(np.abs(got[ok] - ref[ok])) / np.max(np.abs(ref[ok])))
+        worst = max(worst, e)
+    assert worst < 1e-5, worst
+    print("%s: LOCO max-rel-err vs regenie %.2e" % (kind, worst))
