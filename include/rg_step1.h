@@ -79,6 +79,11 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p);
 int64_t rg_w_rows(const rg_ctx* ctx);  /* Np: fold-aligned padded sample count */
 int64_t rg_w_bytes(const rg_ctx* ctx); /* bytes of the whole W buffer */
 int rg_set_w_buffer(rg_ctx* ctx, void* dev_ptr, int64_t bytes);
+/* A rank that only ever produces the predictors of blocks [first_block, first_block + n_blocks) -- a GPU of a sharded
+ * run that hands them on by phenotype (rg_l0_finish / an all-to-all by the caller) -- can keep W for that range alone:
+ * rg_w_bytes then reports n_blocks*R0*P*Np doubles, rg_w_device_ptr / rg_set_w_buffer refer to a buffer that STARTS at
+ * block first_block, and level 1 runs on the exchanged view (rg_set_l1_view).  Call after rg_set_problem, before level 0. */
+int rg_set_block_range(rg_ctx* ctx, int32_t first_block, int32_t n_blocks);
 void* rg_w_device_ptr(rg_ctx* ctx);
 
 /* ---- level 0 -------------------------------------------------------------------------------
@@ -134,6 +139,38 @@ int rg_l1_qt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, int32_t nchr,
  * Step1_Models.cpp:772-872); the decomposition follows SURVEY.md section 8(e). */
 typedef int (*rg_allreduce_fn)(void* user, void* dev_ptr, int64_t n_doubles);
 int rg_set_collective(rg_ctx* ctx, int32_t world, int32_t rank, rg_allreduce_fn fn, void* user);
+
+/* ---- one node, several GPUs: the level-0 hand-off (optional) --------------------------------------------------
+ * The reference splits level 0 over jobs through files: write_l0_master deals contiguous block ranges (Data.cpp:270-302),
+ * every job writes PFX_job<k>_l0_Y<ph> (write_l0_file, Step1_Models.cpp:728-734) and the --run-l1 job reads them back
+ * (prep_parallel_l1, Data.cpp:862-908; read_l0, Step1_Models.cpp:1921-1987).  Here the jobs are the GPUs of a node: one
+ * context per GPU, one host thread per context, and ONE exchange of the predictors over xGMI instead of the files.
+ *   rg_group_create : binds n contexts (same rg_problem on each) to a transport: RG_TRANSPORT_RCCL (one RCCL communicator
+ *                     per context, librccl resolved at run time) or RG_TRANSPORT_PEER (direct device-to-device copies;
+ *                     also valid for contexts sharing one device, which is how world-size-2 runs are tested on one GPU).
+ *   rg_l0_finish    : called by EVERY rank from its own thread after its rg_l0_blocks calls.  block_begin[n+1] = the
+ *                     contiguous block range of each rank.  pheno_begin[n+1] != NULL (needs P >= n): all-to-all by
+ *                     phenotype -- the rank receives the rows of every rank's blocks for its phenotypes only and its
+ *                     level-1 view is set to that range (rg_set_l1_view); NULL: all-gather of the block slabs, after
+ *                     which rg_l1_qt shares its Gram tiles / ridge systems among the ranks (rg_set_collective with the
+ *                     group's RCCL all-reduce).  Returns after the exchange has completed on this rank. */
+#define RG_TRANSPORT_RCCL 0
+#define RG_TRANSPORT_PEER 1
+typedef struct rg_group rg_group;
+int rg_group_create(rg_group** out, int32_t n, rg_ctx* const* ctxs, int transport);
+void rg_group_destroy(rg_group* g);
+int rg_l0_finish(rg_group* g, int32_t rank, const int32_t* block_begin, const int32_t* pheno_begin);
+
+/* ---- pinned host memory for streamed ingest (optional) ------------------------------------------------------------
+ * Rows handed to rg_l0_blocks with RG_MEM_HOST cross PCIe by asynchronous copies only if they live in page-locked
+ * memory; a reader thread can then fill the next buffer while the GPU works on the previous ones (the block loop of
+ * Data.cpp:636-678 with the file read taken off the critical path).  rg_ingest_fence blocks the calling host thread
+ * until every host-to-device copy issued so far by rg_l0_blocks / rg_l0_blocks_f64 has completed, i.e. until the buffers
+ * passed to those calls may be overwritten. */
+int32_t rg_l0_batch_blocks(const rg_ctx* ctx); /* SNP blocks the library works on as one batch: the natural size of one rg_l0_blocks call */
+void* rg_host_alloc(int64_t bytes);
+void rg_host_free(void* p);
+int rg_ingest_fence(rg_ctx* ctx);
 
 /* ---- phenotype-sharded level 1 (optional) ------------------------------------------------------------
  * With P >= world phenotypes the ranks can exchange predictor slabs by phenotype instead of all-gathering W:

@@ -348,7 +348,7 @@ int rg_l0_blocks_f64_impl(rg_ctx* ctx, int nblk, const int32_t* block_ids, const
         la.row_g0 = rtot; la.Np = Np; la.pk_ld = ctx->pk_ld; la.pk_blk_stride = 0; la.pk = nullptr;
         la.mu = nullptr; la.sc = nullptr; la.Bm = nullptr; la.V = ctx->d_V; la.maskp = ctx->d_maskp;
         la.neff = ctx->d_neff; la.bs = ctx->d_bs; la.blockid = ctx->d_blockid; la.wk = ctx->d_wk; la.gt = ctx->d_gt;
-        la.W = ctx->d_W;
+        la.W = rg_w_base(ctx);
         rg_launch_l0_loocv(st, la, ctx->d_lpart, ctx->d_lpart + (size_t)R0 * P * 64, 64);
         continue;
       }
@@ -372,10 +372,10 @@ int rg_l0_blocks_f64_impl(rg_ctx* ctx, int nblk, const int32_t* block_ids, const
         const double* G = Gall + (size_t)i * n64 * Np;
         hipLaunchKernelGGL(k_f64_pred, dim3(ctx->n_c256, P), dim3(256), 0, st, G, Np, bs[b], n64, rtot, R0, P,
                            ctx->d_wk + (int64_t)i * K * R0 * msz, ctx->d_maskp, ctx->d_c256_seg, ctx->d_c256_pos, ctx->d_c256_len,
-                           ctx->n_c256, block_ids[b], ctx->d_W, ctx->d_psum);
+                           ctx->n_c256, block_ids[b], rg_w_base(ctx), ctx->d_psum);
         hipLaunchKernelGGL(k_f64_stats, dim3((P * R0 + 63) / 64), dim3(64), 0, st, ctx->d_psum, ctx->n_c256, P, R0, ctx->d_neff,
                            ctx->d_pstat);
-        hipLaunchKernelGGL(k_f64_wscale, dim3(gpos, R0 * P), dim3(256), 0, st, ctx->d_W, Np, R0, P, block_ids[b], ctx->d_keptp,
+        hipLaunchKernelGGL(k_f64_wscale, dim3(gpos, R0 * P), dim3(256), 0, st, rg_w_base(ctx), Np, R0, P, block_ids[b], ctx->d_keptp,
                            ctx->d_pstat);
       }
     }

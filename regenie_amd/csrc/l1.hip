@@ -282,6 +282,7 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
   const int L = ctx->B_total * ctx->R0, K = ctx->K;
   // phenotype view (rg_set_l1_view): local phenotype p <-> global pg = v_p0 + p; predictors read from v_W laid out
   // [L][v_np][Np] when a view buffer is set, else from the context's W [L][P][Np]
+  if (!ctx->v_W && ctx->w_nb != ctx->B_total) { ctx->err = "rg_l1_qt: W holds a block range only (rg_set_block_range): level 1 needs the exchanged view"; return RG_ERR_STATE; }
   const double* Wv = ctx->v_W ? ctx->v_W : ctx->d_W;
   const int Pv = ctx->v_W ? ctx->v_np : ctx->P, P = ctx->v_np, p0v = ctx->v_p0;
   int ltot = 0;
@@ -295,7 +296,8 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
   const int nch = ctx->n_c256;
   const int NPART = R1MAX * 3 + 2;
   const int world = ctx->coll_world, rank = ctx->coll_rank;
-  const bool multi = world > 1 && ctx->coll_allreduce != nullptr;
+  // a callback with world == 1 is legal: the shared form then runs with a single rank (its all-reduces are identities)
+  const bool multi = ctx->coll_allreduce != nullptr;
   // systems (fold f, tau j) -> b = f*R1 + j; rank r factors the contiguous range [b0, b1)
   const int b0 = multi ? (int)((int64_t)nsys * rank / world) : 0;
   const int b1 = multi ? (int)((int64_t)nsys * (rank + 1) / world) : nsys;

@@ -445,6 +445,7 @@ int l1_common_init(rg_ctx* ctx, L1Common& c, int nchr, const int32_t* cols_per_c
   if (!ctx->have_problem || !(ctx->d_W || ctx->v_W)) { ctx->err = std::string(who) + ": no level-0 predictors"; return RG_ERR_STATE; }
   c.ctx = ctx; c.st = ctx->stream;
   c.L = ctx->B_total * ctx->R0; c.P = ctx->v_np; c.Np = ctx->Np; c.N = ctx->N; c.nchr = nchr;
+  if (!ctx->v_W && ctx->w_nb != ctx->B_total) { ctx->err = std::string(who) + ": W holds a block range only (rg_set_block_range): level 1 needs the exchanged view"; return RG_ERR_STATE; }
   c.view = ctx->v_W != nullptr; c.Wv = c.view ? ctx->v_W : ctx->d_W; c.Pv = c.view ? ctx->v_np : ctx->P; c.p0v = ctx->v_p0;
   c.col0.assign(nchr + 1, 0);
   for (int i = 0; i < nchr; ++i) c.col0[i + 1] = c.col0[i] + cols_per_chr[i];

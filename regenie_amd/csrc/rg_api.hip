@@ -79,6 +79,7 @@ void rg_destroy(rg_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->twin) { rg_destroy(c->twin); c->twin = nullptr; }
+  if (c->ev_ingest) hipEventDestroy(c->ev_ingest);
   if (c->ev_tw_fork) hipEventDestroy(c->ev_tw_fork);
   if (c->ev_tw_join) hipEventDestroy(c->ev_tw_join);
   hipStreamSynchronize(c->stream);
@@ -234,9 +235,10 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   // LOOCV: every (block, lambda) system carries the Np sample rows as extra right-hand sides
   ctx->rtot_wk = ctx->loocv ? ctx->rtot + Np : (int64_t)ctx->rtot;
   ctx->nsys = ctx->loocv ? ctx->R0 : K * ctx->R0;
-  // blocks per batch: more systems per launch hide the Cholesky dependency chain, but the block factorization of a column
-  // group runs one wave per system, 4 waves per CU (LDS): up to 1024 systems are one round of it, 1025 are two
-  int nb = std::max(8, 1024 / std::max(1, ctx->nsys));
+  // blocks per batch: more systems per launch hide the Cholesky dependency chain.  (Sizing batches to one round of the
+  // block factorization -- one wave per system, 4 per CU: 1024 systems -- was measured: 37.9 ms per step with 3 batches of 37
+  // blocks against 36.1 ms with 2 of 55 at BASELINE configs[1]; what the extra batch costs elsewhere outweighs the saved round.)
+  int nb = 64;
   if (const char* e = getenv("RG_NBLK")) nb = std::max(1, atoi(e));
   nb = std::min(nb, ctx->B_total);
   if (ctx->loocv) {  // bound the forward-substituted row storage (~24 GB)
@@ -248,7 +250,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   ctx->raw_ld = rg_round_up((Nf + 3) / 4, 16);
   ctx->pk_ld = Np / 4;
   const size_t msz = (size_t)rtot * n64;
-  if ((rc = dev_alloc(ctx, &ctx->d_raw, (size_t)nb * bsm * ctx->raw_ld + 16))) return rc;
+  if (ctx->d_raw) { hipFree(ctx->d_raw); ctx->d_raw = nullptr; }   // staging of host rows: allocated by the first RG_MEM_HOST batch
   if ((rc = dev_alloc(ctx, &ctx->d_pk, (size_t)nb * n128 * ctx->pk_ld + 16))) return rc;
   ctx->gram_fp4 = true;
   if (const char* e = getenv("RG_GRAM")) ctx->gram_fp4 = std::string(e) != "i8";
@@ -280,12 +282,14 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if ((rc = dev_alloc(ctx, &ctx->d_bs, (size_t)nb))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_blockid, (size_t)nb))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_rawptr, (size_t)nb))) return rc;
+  ctx->w_b0 = 0; ctx->w_nb = ctx->B_total;
   ctx->W_bytes = (int64_t)sizeof(double) * ctx->B_total * R0 * P * Np;
   if (ctx->own_W && ctx->d_W) { hipFree(ctx->d_W); }
   ctx->d_W = nullptr; ctx->own_W = false;
   ctx->block_done.assign(ctx->B_total, 0);
   ctx->v_W = nullptr; ctx->v_p0 = 0; ctx->v_np = P;
   ctx->have_problem = true;
+  ctx->join_pending = false; ctx->pipe_rr = 0; ctx->ingest_pending = false;
   memset(&ctx->tm, 0, sizeof(ctx->tm));
   // further pipelines (see rg_ctx::twin): a chain of child contexts; RG_PIPELINES=1 keeps a single one
   if (ctx->twin) { rg_destroy(ctx->twin); ctx->twin = nullptr; }
@@ -310,8 +314,20 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
 }
 
 int64_t rg_w_rows(const rg_ctx* c) { return c ? c->Np : 0; }
+int32_t rg_l0_batch_blocks(const rg_ctx* c) { return c ? c->nblk_cap : 0; }
 int64_t rg_w_bytes(const rg_ctx* c) { return c ? c->W_bytes : 0; }
 void* rg_w_device_ptr(rg_ctx* c) { return c ? c->d_W : nullptr; }
+
+int rg_set_block_range(rg_ctx* ctx, int32_t first_block, int32_t n_blocks) {
+  if (!ctx || !ctx->have_problem) return RG_ERR_STATE;
+  if (first_block < 0 || n_blocks < 0 || first_block + n_blocks > ctx->B_total) { ctx->err = "rg_set_block_range: range out of bounds"; return RG_ERR_ARG; }
+  if (ctx->own_W && ctx->d_W) hipFree(ctx->d_W);
+  ctx->d_W = nullptr; ctx->own_W = false;
+  ctx->w_b0 = first_block; ctx->w_nb = n_blocks;
+  ctx->W_bytes = (int64_t)sizeof(double) * std::max(1, n_blocks) * ctx->R0 * ctx->P * ctx->Np;
+  for (rg_ctx* t = ctx->twin; t; t = t->twin) { t->d_W = nullptr; t->own_W = false; t->w_b0 = first_block; t->w_nb = n_blocks; t->W_bytes = ctx->W_bytes; }
+  return RG_OK;
+}
 
 int rg_set_w_buffer(rg_ctx* ctx, void* dev_ptr, int64_t bytes) {
   if (!ctx || !ctx->have_problem) return RG_ERR_STATE;
@@ -352,11 +368,20 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
       for (int b = 0; b < nblk; ++b) hp[b] = bed_rows[b];
     } else {
       ld = ctx->raw_ld;
+      if (!ctx->d_raw) {
+        const int rca = dev_alloc(ctx, &ctx->d_raw, (size_t)ctx->nblk_cap * ctx->bs_max * ctx->raw_ld + 16);
+        if (rca) return rca;
+      }
       for (int b = 0; b < nblk; ++b) {
         RG_HIP(hipMemcpy2DAsync(ctx->d_raw + (int64_t)b * raw_blk, ctx->raw_ld, bed_rows[b], row_stride, bytes_row,
                                 bs[b], hipMemcpyHostToDevice, st));
         hp[b] = ctx->d_raw + (int64_t)b * raw_blk;
       }
+    }
+    if (mem_kind != RG_MEM_DEVICE) {   // the caller's host buffers are free again once this event has passed (rg_ingest_fence)
+      if (!ctx->ev_ingest) RG_HIP(hipEventCreateWithFlags(&ctx->ev_ingest, hipEventDisableTiming));
+      RG_HIP(hipEventRecord(ctx->ev_ingest, st));
+      ctx->ingest_pending = true;
     }
     RG_HIP(hipMemcpyAsync(ctx->d_rawptr, hp.data(), sizeof(uint8_t*) * nblk, hipMemcpyHostToDevice, st));
     rg_launch_bed_prep(st, ctx->d_rawptr, ld, ctx->d_pk, ctx->pk_ld, pk_blk, ctx->d_bs,
@@ -396,7 +421,7 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     la.row_g0 = rtot; la.Np = ctx->Np; la.pk_ld = ctx->pk_ld; la.pk_blk_stride = pk_blk; la.pk = ctx->d_pk;
     la.mu = ctx->d_mu; la.sc = ctx->d_sc; la.Bm = ctx->d_Bm; la.V = ctx->d_V; la.maskp = ctx->d_maskp;
     la.neff = ctx->d_neff; la.bs = ctx->d_bs; la.blockid = ctx->d_blockid; la.wk = ctx->d_wk; la.gt = ctx->d_gt;
-    la.W = ctx->d_W;
+    la.W = rg_w_base(ctx);
     {
       StageTimer t(ctx, &ctx->tm.ms_chol);
       rg_launch_decode_gt(st, la);
@@ -426,7 +451,7 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     pa.pk_blk_stride = pk_blk; pa.seg = ctx->seg; pa.pk = ctx->d_pk; pa.mu = ctx->d_mu; pa.sc = ctx->d_sc;
     pa.Bm = ctx->d_Bm; pa.wk = ctx->d_wk; pa.V = ctx->d_V; pa.maskp = ctx->d_maskp;
     pa.keptp = ctx->d_keptp; pa.bs = ctx->d_bs; pa.blockid = ctx->d_blockid; pa.neff = ctx->d_neff; pa.nmiss = ctx->d_nmiss;
-    pa.beta = ctx->d_beta; pa.cb = ctx->d_cb; pa.psum = ctx->d_psum; pa.W = ctx->d_W;
+    pa.beta = ctx->d_beta; pa.cb = ctx->d_cb; pa.psum = ctx->d_psum; pa.W = rg_w_base(ctx);
     rg_launch_l0_pred_impl(st, pa, ChunkTab{ctx->d_c1k_seg, ctx->d_c1k_pos, ctx->d_c1k_len, ctx->n_c1k},
                            ChunkTab{ctx->d_c256_seg, ctx->d_c256_pos, ctx->d_c256_len, ctx->n_c256}, ctx->d_pstat);
   }
@@ -443,47 +468,58 @@ int rg_l0_blocks(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int3
   if (row_stride < (ctx->Nfile + 3) / 4) { ctx->err = "rg_l0_blocks: row_stride < ceil(N_file/4)"; return RG_ERR_ARG; }
   for (int b = 0; b < nblk; ++b) {
     if (bs[b] < 1 || bs[b] > ctx->bs_max) { ctx->err = "rg_l0_blocks: block size out of range"; return RG_ERR_ARG; }
-    if (block_ids[b] < 0 || block_ids[b] >= ctx->B_total) { ctx->err = "rg_l0_blocks: block id out of range"; return RG_ERR_ARG; }
+    if (block_ids[b] < ctx->w_b0 || block_ids[b] >= ctx->w_b0 + ctx->w_nb) { ctx->err = "rg_l0_blocks: block id out of range"; return RG_ERR_ARG; }
   }
   int rc = ensure_W(ctx);
   if (rc) return rc;
-  // balanced batches: ceil(nblk / cap) batches of (almost) equal size, at least one per pipeline
-  // Several pipelines: batch ib runs in context (ib mod n_pipe) of the chain, each on its own stream, ordered after
-  // everything already queued on ctx->stream and joined back before this call returns (the caller sees one stream).  The
-  // per-stage timing mode keeps a single pipeline so that its HIP-event brackets stay meaningful.
+  // balanced batches: ceil(nblk / cap) batches of (almost) equal size.
+  // Several pipelines: batch number (pipe_rr + ib) runs in context ((pipe_rr + ib) mod n_pipe) of the chain, each on its own
+  // stream.  The children are ordered after everything queued on ctx->stream before the FIRST level-0 call of a sequence
+  // (fork event) and joined back lazily -- by rg_sync and every entry point that reads W -- so that consecutive calls (a
+  // driver streaming one batch per call from a reader thread) keep alternating pipelines and overlap, exactly like the
+  // batches of one big call.  The per-stage timing mode keeps a single pipeline so that its HIP-event brackets stay meaningful.
   const int npipe = (ctx->twin && !ctx->timing) ? ctx->n_pipe : 1;
   int nbatch = (nblk + ctx->nblk_cap - 1) / ctx->nblk_cap;
   {
-    // batches are dealt round-robin to the pipelines; RG_BATCH_ROUND=1 rounds their number up to a multiple of the pipelines
+    // RG_BATCH_ROUND=1 rounds the number of batches of a call up to a multiple of the pipelines
     static const bool round_up = getenv("RG_BATCH_ROUND") && atoi(getenv("RG_BATCH_ROUND")) != 0;
-    if (npipe > 1 && nblk >= 2 * npipe && (round_up || nbatch < npipe)) nbatch = (nbatch + npipe - 1) / npipe * npipe;
+    if (npipe > 1 && nblk >= 2 * npipe && round_up) nbatch = (nbatch + npipe - 1) / npipe * npipe;
   }
   const int per = (nblk + nbatch - 1) / nbatch;
-  const bool multi = npipe > 1 && nbatch > 1;
-  if (multi) {
+  const bool multi = npipe > 1;
+  if (multi && !ctx->join_pending) {
     RG_HIP(hipEventRecord(ctx->ev_tw_fork, ctx->stream));
     for (rg_ctx* t = ctx->twin; t; t = t->twin) {
       t->d_W = ctx->d_W; t->own_W = false;
       RG_HIP(hipStreamWaitEvent(t->stream, ctx->ev_tw_fork, 0));
     }
+    ctx->join_pending = true;
   }
-  int ib = 0;
-  for (int b0 = 0; b0 < nblk; b0 += per, ++ib) {
+  for (int b0 = 0; b0 < nblk; b0 += per) {
     const int nb = std::min(per, nblk - b0);
     // within a context the small H2D descriptor copies of the next batch must not overtake the kernels of the
     // previous one: everything of a pipeline is ordered on its stream.
     rg_ctx* c = ctx;
-    if (multi) for (int k = ib % npipe; k > 0 && c->twin; --k) c = c->twin;
+    if (multi) {
+      for (int k = ctx->pipe_rr % npipe; k > 0 && c->twin; --k) c = c->twin;
+      ++ctx->pipe_rr;
+    }
     rc = l0_batch(c, nb, block_ids + b0, bs + b0, bed_rows + b0, row_stride, mem_kind);
     if (rc) { if (c != ctx) ctx->err = c->err; return rc; }
     if (c != ctx) for (int b = 0; b < nb; ++b) ctx->block_done[block_ids[b0 + b]] = 1;
   }
-  if (multi) {
-    for (rg_ctx* t = ctx->twin; t; t = t->twin) {
-      RG_HIP(hipEventRecord(t->ev_tw_join, t->stream));
-      RG_HIP(hipStreamWaitEvent(ctx->stream, t->ev_tw_join, 0));
-    }
+  return RG_OK;
+}
+
+// joins the level-0 pipelines back onto ctx->stream (see rg_l0_blocks)
+static int join_pipes(rg_ctx* ctx) {
+  if (!ctx->join_pending) return RG_OK;
+  for (rg_ctx* t = ctx->twin; t; t = t->twin) {
+    RG_HIP(hipEventRecord(t->ev_tw_join, t->stream));
+    RG_HIP(hipStreamWaitEvent(ctx->stream, t->ev_tw_join, 0));
   }
+  ctx->join_pending = false;
+  ctx->pipe_rr = 0;
   return RG_OK;
 }
 
@@ -494,17 +530,43 @@ int rg_l0_blocks_f64(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const 
   if (nblk < 1 || !block_ids || !bs || !rows) { ctx->err = "rg_l0_blocks_f64: bad arguments"; return RG_ERR_ARG; }
   if (row_stride < ctx->Nfile) { ctx->err = "rg_l0_blocks_f64: row_stride < N_file"; return RG_ERR_ARG; }
   for (int b = 0; b < nblk; ++b) {
-    if (block_ids[b] < 0 || block_ids[b] >= ctx->B_total) { ctx->err = "rg_l0_blocks_f64: block id out of range"; return RG_ERR_ARG; }
+    if (block_ids[b] < ctx->w_b0 || block_ids[b] >= ctx->w_b0 + ctx->w_nb) { ctx->err = "rg_l0_blocks_f64: block id out of range"; return RG_ERR_ARG; }
     if (bs[b] < 1 || bs[b] > ctx->bs_max) { ctx->err = "rg_l0_blocks_f64: block size out of range"; return RG_ERR_ARG; }
     if (!rows[b]) { ctx->err = "rg_l0_blocks_f64: null row pointer"; return RG_ERR_ARG; }
   }
   { const int rcw = ensure_W(ctx); if (rcw) return rcw; }
-  return rg_l0_blocks_f64_impl(ctx, nblk, block_ids, bs, rows, row_stride, mem_kind);
+  { const int rcj = join_pipes(ctx); if (rcj) return rcj; }
+  const int rc = rg_l0_blocks_f64_impl(ctx, nblk, block_ids, bs, rows, row_stride, mem_kind);
+  if (rc == RG_OK && mem_kind != RG_MEM_DEVICE) {   // coarse: the rows are free once the whole call has run
+    if (!ctx->ev_ingest) RG_HIP(hipEventCreateWithFlags(&ctx->ev_ingest, hipEventDisableTiming));
+    RG_HIP(hipEventRecord(ctx->ev_ingest, ctx->stream));
+    ctx->ingest_pending = true;
+  }
+  return rc;
+}
+
+void* rg_host_alloc(int64_t bytes) {
+  void* p = nullptr;
+  if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void rg_host_free(void* p) { if (p) hipHostFree(p); }
+
+int rg_ingest_fence(rg_ctx* ctx) {
+  if (!ctx) return RG_ERR_ARG;
+  hipSetDevice(ctx->device);
+  for (rg_ctx* c = ctx; c; c = c->twin)
+    if (c->ingest_pending) {
+      if (hipEventSynchronize(c->ev_ingest) != hipSuccess) { ctx->err = "rg_ingest_fence: event wait failed"; return RG_ERR_HIP; }
+      c->ingest_pending = false;
+    }
+  return RG_OK;
 }
 
 int rg_sync(rg_ctx* ctx) {
   if (!ctx) return RG_ERR_ARG;
   hipSetDevice(ctx->device);
+  { const int rcj = join_pipes(ctx); if (rcj) return rcj; }
   RG_HIP(hipStreamSynchronize(ctx->stream));
   if (ctx->twin) {   // deferred device-side errors of the other pipelines (each child syncs the rest of the chain)
     int rc2 = rg_sync(ctx->twin);
@@ -534,11 +596,12 @@ int rg_sync(rg_ctx* ctx) {
 
 int rg_l0_get_w(rg_ctx* ctx, int32_t block_id, int32_t pheno, double* out_host) {
   if (!ctx || !ctx->have_problem || !ctx->d_W) return RG_ERR_STATE;
-  if (block_id < 0 || block_id >= ctx->B_total || pheno < 0 || pheno >= ctx->P || !out_host) return RG_ERR_ARG;
+  if (block_id < ctx->w_b0 || block_id >= ctx->w_b0 + ctx->w_nb || pheno < 0 || pheno >= ctx->P || !out_host) return RG_ERR_ARG;
   hipSetDevice(ctx->device);
+  { const int rcj = join_pipes(ctx); if (rcj) return rcj; }
   double* tmp = nullptr;
   RG_HIP(hipMalloc((void**)&tmp, sizeof(double) * ctx->N * ctx->R0));
-  rg_launch_w_gather(ctx->stream, ctx->d_W, ctx->Np, ctx->P, pheno, block_id * ctx->R0, ctx->R0, ctx->d_posc, ctx->N, tmp);
+  rg_launch_w_gather(ctx->stream, rg_w_base(ctx), ctx->Np, ctx->P, pheno, block_id * ctx->R0, ctx->R0, ctx->d_posc, ctx->N, tmp);
   hipError_t e = hipMemcpyAsync(out_host, tmp, sizeof(double) * ctx->N * ctx->R0, hipMemcpyDeviceToHost, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   hipFree(tmp);
@@ -548,14 +611,15 @@ int rg_l0_get_w(rg_ctx* ctx, int32_t block_id, int32_t pheno, double* out_host) 
 
 int rg_l0_set_w(rg_ctx* ctx, int32_t block_id, int32_t pheno, const double* in_host) {
   if (!ctx || !ctx->have_problem) return RG_ERR_STATE;
-  if (block_id < 0 || block_id >= ctx->B_total || pheno < 0 || pheno >= ctx->P || !in_host) return RG_ERR_ARG;
+  if (block_id < ctx->w_b0 || block_id >= ctx->w_b0 + ctx->w_nb || pheno < 0 || pheno >= ctx->P || !in_host) return RG_ERR_ARG;
   hipSetDevice(ctx->device);
   int rc = ensure_W(ctx);
   if (rc) return rc;
+  if ((rc = join_pipes(ctx))) return rc;
   double* tmp = nullptr;
   RG_HIP(hipMalloc((void**)&tmp, sizeof(double) * ctx->N * ctx->R0));
   hipError_t e = hipMemcpyAsync(tmp, in_host, sizeof(double) * ctx->N * ctx->R0, hipMemcpyHostToDevice, ctx->stream);
-  rg_launch_w_scatter(ctx->stream, ctx->d_W, ctx->Np, ctx->P, pheno, block_id * ctx->R0, ctx->R0, ctx->d_posc, ctx->N, tmp);
+  rg_launch_w_scatter(ctx->stream, rg_w_base(ctx), ctx->Np, ctx->P, pheno, block_id * ctx->R0, ctx->R0, ctx->d_posc, ctx->N, tmp);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   hipFree(tmp);
   if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return RG_ERR_HIP; }

@@ -76,6 +76,7 @@ struct rg_ctx {
   double* d_W = nullptr;         // [B*R0][P][Np]
   bool own_W = false;
   int64_t W_bytes = 0;
+  int w_b0 = 0, w_nb = 0;        // W holds the predictor rows of blocks [w_b0, w_b0 + w_nb) only (rg_set_block_range; default: all)
 
   // level-0 workspaces (sized for NBLK blocks)
   int nblk_cap = 0;
@@ -136,6 +137,12 @@ struct rg_ctx {
   int n_pipe = 1;               // contexts in the chain (set on the parent)
   bool is_child = false;
   hipEvent_t ev_tw_fork = nullptr, ev_tw_join = nullptr;
+  bool join_pending = false;    // children hold level-0 work not yet joined onto `stream` (lazy join, rg_api.hip)
+  int pipe_rr = 0;              // round-robin cursor over the pipelines, persistent across rg_l0_blocks calls
+
+  // streamed ingest: recorded on this context's stream right after the host-to-device copies of a level-0 batch
+  hipEvent_t ev_ingest = nullptr;
+  bool ingest_pending = false;
 
   // level-1 workspaces, kept across calls (hipMalloc/hipFree per call costs milliseconds)
   void* ws_ptr[12] = {};
@@ -150,6 +157,9 @@ struct rg_ctx {
   rg_timing tm{};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
+
+// address of row 0 of block 0 in W's [B*R0][P][Np] indexing (d_W itself starts at block w_b0)
+static inline double* rg_w_base(const rg_ctx* c) { return c->d_W ? c->d_W - (int64_t)c->w_b0 * c->R0 * c->P * c->Np : nullptr; }
 
 // grows-only device workspace slot; returns nullptr on allocation failure
 static inline void* rg_ws(rg_ctx* ctx, int slot, size_t bytes) {

@@ -68,25 +68,37 @@ def shard_phenotypes(n_pheno: int, world: int) -> List[Tuple[int, int]]:
 
 
 def exchange_w_by_phenotype(W, shards: List[Tuple[int, int]], pshards: List[Tuple[int, int]], r0: int, group=None,
-                            via_host: bool = False):
+                            via_host: bool = False, buffers: dict = None, own_rows_only: bool = False):
     """Phenotype-sharded hand-off of the level-0 predictors: ONE all-to-all in which rank r sends to rank g
     the predictor rows of r's blocks for g's phenotypes only -- 1/world of the all-gather volume -- and every rank ends
     up with W_g [L, count_g, Np], the layout the library's level-1 view expects (rg_set_l1_view).
 
-    W: [B*R0, P, Np] with this rank's block columns filled.  Returns the received tensor (None if this rank owns no
-    phenotype).  via_host stages the exchange through host memory (gloo test mode)."""
+    W: [B*R0, P, Np] with this rank's block columns filled, or (own_rows_only, rg_set_block_range) just the rows of this
+    rank's blocks [nb*R0, P, Np].  Returns the received tensor (None if this rank owns no phenotype).  `buffers`: a dict
+    the send / receive tensors are kept in across calls (one strided copy per destination into a preallocated buffer
+    instead of fresh temporaries: at BASELINE configs[2] the send side alone is tens of GB).  via_host stages the exchange
+    through host memory (gloo test mode)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     b0, nb = shards[rank]
     P, Np = W.shape[1], W.shape[2]
-    mine = W[b0 * r0:(b0 + nb) * r0]                                     # [nb*R0, P, Np]
-    send = torch.cat([mine[:, q0:q0 + qn, :].reshape(-1) for (q0, qn) in pshards]) if nb > 0 else W.new_empty(0)
+    mine = W[: nb * r0] if own_rows_only else W[b0 * r0:(b0 + nb) * r0]   # [nb*R0, P, Np]
     in_split = [nb * r0 * qn * Np for (_, qn) in pshards]
     q0, qn = pshards[rank]
     out_split = [sn * r0 * qn * Np for (_, sn) in shards]
-    recv = torch.empty(sum(out_split), dtype=W.dtype, device=W.device)
+    if buffers is None:
+        buffers = {}
+    if buffers.get("send") is None or buffers["send"].numel() != sum(in_split):
+        buffers["send"] = torch.empty(sum(in_split), dtype=W.dtype, device=W.device)
+        buffers["recv"] = torch.empty(sum(out_split), dtype=W.dtype, device=W.device)
+    send, recv = buffers["send"], buffers["recv"]
+    off = 0
+    for (p0, pn), cnt in zip(pshards, in_split):
+        if cnt:
+            send[off:off + cnt].view(nb * r0, pn, Np).copy_(mine[:, p0:p0 + pn, :])
+        off += cnt
     if via_host:
         hs, hr = send.cpu(), torch.empty(sum(out_split), dtype=W.dtype)
         dist.all_to_all_single(hr, hs, output_split_sizes=out_split, input_split_sizes=in_split, group=group)

@@ -48,9 +48,12 @@ class RgTiming(C.Structure):
 
 
 EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_w_rows", "rg_w_bytes",
-           "rg_set_w_buffer", "rg_w_device_ptr", "rg_l0_blocks", "rg_l0_blocks_f64", "rg_sync", "rg_l0_get_w",
+           "rg_set_w_buffer", "rg_set_block_range", "rg_w_device_ptr", "rg_l0_blocks", "rg_l0_blocks_f64", "rg_sync", "rg_l0_get_w",
            "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_set_collective", "rg_set_l1_view", "rg_set_loco_output", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
            "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak",
+           # one node, several GPUs: level-0 hand-off over RCCL / peer copies; streamed ingest helpers (used by the C++ driver)
+           "rg_group_create", "rg_group_destroy", "rg_l0_finish", "rg_l0_batch_blocks", "rg_host_alloc", "rg_host_free",
+           "rg_ingest_fence",
            # include/rg_pgen.h (host-side .pgen hardcall input; wrapped by regenie_amd/pgen.py)
            "rg_pgen_open", "rg_pgen_close", "rg_pgen_last_error", "rg_pgen_info", "rg_pgen_read_bed_rows",
            "rg_pgen_read_hardcalls", "rg_pgen_set_threads", "rg_pgen_read_dosages", "rg_pgen_read_dosage_rows",
@@ -101,6 +104,18 @@ def load_library() -> C.CDLL:
     lib.rg_set_collective.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rg_set_l1_view.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.rg_set_loco_output.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+    lib.rg_set_block_range.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    lib.rg_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p), C.c_int]
+    lib.rg_group_destroy.argtypes = [C.c_void_p]
+    lib.rg_group_destroy.restype = None
+    lib.rg_l0_finish.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.rg_l0_batch_blocks.argtypes = [C.c_void_p]
+    lib.rg_l0_batch_blocks.restype = C.c_int32
+    lib.rg_host_alloc.argtypes = [C.c_int64]
+    lib.rg_host_alloc.restype = C.c_void_p
+    lib.rg_host_free.argtypes = [C.c_void_p]
+    lib.rg_host_free.restype = None
+    lib.rg_ingest_fence.argtypes = [C.c_void_p]
     lib.rg_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.rg_get_timing.argtypes = [C.c_void_p, C.POINTER(RgTiming)]
     lib.rg_k_gram_i8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,
@@ -228,6 +243,10 @@ class Step1Engine:
 
     def set_w_buffer(self, dev_ptr: int, nbytes: int):
         self._check(self.lib.rg_set_w_buffer(self.h, C.c_void_p(dev_ptr), nbytes))
+
+    def set_block_range(self, first_block: int, n_blocks: int):
+        """W then holds the predictor rows of blocks [first_block, first_block + n_blocks) only (rg_set_block_range)."""
+        self._check(self.lib.rg_set_block_range(self.h, int(first_block), int(n_blocks)))
 
     def l0_blocks_host(self, block_ids: Sequence[int], rows: List[np.ndarray]):
         """rows[b]: (bs_b, ceil(N_file/4)) uint8 C-contiguous packed .bed rows (host memory)."""

@@ -27,6 +27,10 @@
 #include <iostream>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <fcntl.h>
 #include <set>
 #include <sstream>
 #include <stdexcept>
@@ -61,6 +65,14 @@ struct Params {
   bool split_l0 = false, run_l0 = false, run_l1 = false, keep_l0 = false;
   std::vector<double> setl0, setl1;
   int device = 0;
+  // one node, several GPUs (no counterpart option in the reference, whose job split goes through files): --gpus N deals the
+  // SNP blocks to N GPUs like write_l0_master (Data.cpp:270-302), one host thread per GPU, and replaces the job files by one
+  // exchange of the level-0 predictors (rg_l0_finish).  --transport rccl (default) | peer; --single-device puts every rank on
+  // --device (test mode, needs --transport peer); --force-collectives runs the exchange code with a single GPU as well.
+  int gpus = 1;
+  int transport = RG_TRANSPORT_RCCL;
+  bool single_device = false, force_collectives = false;
+  bool l1_shared = false;   // --l1-shared: all-gather + shared level 1 even when every GPU could own a phenotype
 };
 
 struct Log {  // mstream (Regenie.hpp:120-142): tee to stdout and <out>.log
@@ -329,6 +341,16 @@ Params parse_args(int argc, char** argv) {
       if (p.job_num < 1) usage_error("invalid job number for --run-l0 (must be >=1).");
     } else if (a == "--run-l1") { p.run_l1 = true; p.split_file = need(i); }
     else if (a == "--keep-l0") p.keep_l0 = true;
+    else if (a == "--gpus") p.gpus = atoi(need(i).c_str());
+    else if (a == "--transport") {
+      const std::string t = need(i);
+      if (t == "rccl") p.transport = RG_TRANSPORT_RCCL;
+      else if (t == "peer") p.transport = RG_TRANSPORT_PEER;
+      else usage_error("--transport must be rccl or peer");
+    }
+    else if (a == "--single-device") p.single_device = true;
+    else if (a == "--force-collectives") p.force_collectives = true;
+    else if (a == "--l1-shared") p.l1_shared = true;
     else usage_error("unrecognised option '" + a + "'");
   }
   if (p.bt) p.rint = false;  // Regenie.cpp:432
@@ -337,6 +359,9 @@ Params parse_args(int argc, char** argv) {
   if (p.pheno_file.empty()) usage_error("option '--phenoFile' is required.");
   if (p.bsize < 1) usage_error("must specify the block size using '--bsize'.");
   if (p.cv_folds < 2) usage_error("number of CV folds must be at least 2");
+  if (p.gpus < 1) usage_error("--gpus must be at least 1");
+  if (p.single_device && p.gpus > 1 && p.transport != RG_TRANSPORT_PEER) usage_error("--single-device needs --transport peer (RCCL refuses two ranks on one device)");
+  if ((p.gpus > 1 || p.force_collectives) && (p.run_l0 || p.run_l1 || p.split_l0)) usage_error("--gpus / --force-collectives cannot be combined with the --split-l0 / --run-l0 / --run-l1 file protocol");
   return p;
 }
 
@@ -1324,8 +1349,10 @@ int run(int argc, char** argv) {
     }
   }
 
-  rg_ctx* ctx = nullptr;
-  if (rg_create(&ctx, p.device, nullptr) != 0 || !ctx) throw std::runtime_error("no MI355X / HIP device available (rg_create failed)");
+  // ---- devices: one context per GPU, one host thread per context ------------------------------------------------------
+  const int G = p.gpus;
+  const bool use_group = G > 1 || p.force_collectives;
+  std::vector<rg_ctx*> ctxs(G, nullptr);
   rg_problem pr;
   memset(&pr, 0, sizeof(pr));
   pr.n_samples = N; pr.n_file = r.n_file; pr.n_pheno = P; pr.n_cov = r.C; pr.cv_folds = use_loocv ? 0 : p.cv_folds;
@@ -1333,7 +1360,184 @@ int run(int argc, char** argv) {
   pr.lambda = lambda.data(); pr.X = r.X.data(); pr.Y = r.Y.data(); pr.mask = r.mask.data();
   pr.ind_in_analysis = r.ain.data(); pr.ind_ignore = (r.N != r.n_file) ? r.ind_ignore.data() : nullptr;
   pr.neff = r.neff.data(); pr.n_blocks_total = B; pr.max_block_size = p.bsize;
-  check(ctx, rg_set_problem(ctx, &pr));
+  for (int g = 0; g < G; ++g) {
+    if (rg_create(&ctxs[g], p.single_device ? p.device : p.device + g, nullptr) != 0 || !ctxs[g])
+      throw std::runtime_error("no MI355X / HIP device available (rg_create failed for device " + std::to_string(p.single_device ? p.device : p.device + g) + ")");
+    check(ctxs[g], rg_set_problem(ctxs[g], &pr));
+  }
+  rg_ctx* ctx = ctxs[0];
+  rg_group* grp = nullptr;
+  if (use_group) {
+    if (rg_group_create(&grp, G, ctxs.data(), p.transport) != 0 || !grp) throw std::runtime_error(std::string("cannot set up the GPU group: ") + rg_last_error(ctxs[0]));
+    sout << std::left << std::setw(20) << " * # GPUs" << ": [" << G << "] (" << (p.transport == RG_TRANSPORT_RCCL ? "RCCL" : "peer copies") << ")\n";
+  }
+  // block ranges of the ranks: floor(B/G) blocks each, the first B mod G one more (write_l0_master, Data.cpp:270-302)
+  std::vector<int32_t> bbeg(G + 1, 0), pbeg(G + 1, 0);
+  for (int g = 0; g < G; ++g) bbeg[g + 1] = bbeg[g] + B / G + (g < B % G ? 1 : 0);
+  const bool pheno_sharded = use_group && P >= G && !p.l1_shared;      // all-to-all by phenotype; else all-gather + shared level 1
+  for (int g = 0; g < G; ++g) pbeg[g + 1] = pheno_sharded ? pbeg[g] + P / G + (g < P % G ? 1 : 0) : P;
+  if (!pheno_sharded) pbeg[0] = 0;
+
+  std::mutex io_mu;      // the .pgen / .bgen readers keep per-handle state: one block read at a time
+  // ---- level 0 of blocks [b_lo, b_hi) on one context -------------------------------------------------------------------
+  // get_G + the block loop of level_0_calculations (Data.cpp:636-678) with the file read taken off the critical path: a
+  // reader thread fills page-locked buffers (one pread per block when its variants are contiguous in the file, Geno.cpp:
+  // 1702-1769 reads them one by one), the calling thread hands each buffer to rg_l0_blocks -- asynchronous copies, kernels
+  // queued behind the previous batch on the other pipeline -- and recycles it once its copy has completed (rg_ingest_fence).
+  auto level0_range = [&](rg_ctx* cx, int b_lo, int b_hi, std::ostringstream& lg) {
+    if (b_lo >= b_hi) return;
+    if (r.dosage_mode) {   // a block of dosages is bs x N_file doubles on the host: one block at a time, synchronous
+      std::vector<double> dbuf;
+      for (int b = b_lo; b < b_hi; ++b) {
+        const Blk& bl = blocks[b];
+        auto t0 = std::chrono::steady_clock::now();
+        dbuf.resize((size_t)bl.bs * r.n_file);
+        {
+          std::lock_guard<std::mutex> lk(io_mu);
+          if (r.bgenh) {  // readChunkFromBGENFileToG_fast (Geno.cpp:1574-1699): inflate + probabilities -> dosages
+            if (rg_bgen_read_dosages(r.bgenh, bl.bs, &r.snp_offset[bl.start], p.ref_first ? 1 : 0, dbuf.data(), r.n_file) != RG_BGEN_OK)
+              throw std::runtime_error(rg_bgen_last_error(r.bgenh));
+          } else {        // Read() per kept variant (Geno.cpp:1795-1796): ALT dosages, -3 = missing
+            if (rg_pgen_read_dosage_rows(r.pgen, bl.bs, &r.snp_offset[bl.start], dbuf.data(), r.n_file) != RG_PGEN_OK)
+              throw std::runtime_error(rg_pgen_last_error(r.pgen));
+          }
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        const int32_t id = b, bsv = bl.bs;
+        const double* dp = dbuf.data();
+        check(cx, rg_l0_blocks_f64(cx, 1, &id, &bsv, &dp, r.n_file, RG_MEM_HOST));
+        check(cx, rg_sync(cx));
+        auto t2 = std::chrono::steady_clock::now();
+        lg << " block [" << b + 1 << "] (chromosome " << bl.chrom << ") : " << bl.bs << " snps  (read "
+           << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << "ms, level 0 ridge on GPU "
+           << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms)\n";
+      }
+      return;
+    }
+    const int64_t blk_bytes = (int64_t)p.bsize * r.bpr;
+    int64_t budget_mb = 2048;
+    if (const char* e = getenv("RG_INGEST_MB")) budget_mb = std::max(1, atoi(e));
+    const int per = (int)std::max<int64_t>(1, std::min<int64_t>(rg_l0_batch_blocks(cx), budget_mb * 1048576 / std::max<int64_t>(1, blk_bytes)));
+    const int NBUF = 3;
+    struct Slot { uint8_t* mem = nullptr; int b0 = 0, nb = 0; double read_ms = 0; };
+    std::vector<Slot> slots(NBUF);
+    for (auto& sl : slots) {
+      sl.mem = (uint8_t*)rg_host_alloc((int64_t)per * blk_bytes);
+      if (!sl.mem) throw std::runtime_error("cannot allocate page-locked memory for the genotype buffers");
+    }
+    std::mutex mu; std::condition_variable cv;
+    std::deque<int> free_q, ready_q;
+    for (int i = 0; i < NBUF; ++i) free_q.push_back(i);
+    std::exception_ptr rd_err = nullptr;
+    bool rd_done = false;
+    std::thread reader([&]() {
+      int fd = -1;
+      try {
+        if (!r.pgen) {
+          fd = open((p.bed + ".bed").c_str(), O_RDONLY);
+          if (fd < 0) throw std::runtime_error("cannot read bed file");
+        }
+        for (int b0 = b_lo; b0 < b_hi; b0 += per) {
+          int si;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !free_q.empty(); });
+            si = free_q.front(); free_q.pop_front();
+          }
+          Slot& sl = slots[si];
+          sl.b0 = b0; sl.nb = std::min(per, b_hi - b0);
+          auto t0 = std::chrono::steady_clock::now();
+          for (int b = 0; b < sl.nb; ++b) {
+            const Blk& bl = blocks[b0 + b];
+            uint8_t* dst = sl.mem + (int64_t)b * blk_bytes;
+            if (r.pgen) {  // ReadHardcalls per kept variant (Geno.cpp:1781-1798), as .bed-coded rows
+              std::lock_guard<std::mutex> lk(io_mu);
+              if (rg_pgen_read_bed_rows(r.pgen, bl.bs, &r.snp_offset[bl.start], dst, r.bpr) != RG_PGEN_OK)
+                throw std::runtime_error(rg_pgen_last_error(r.pgen));
+              continue;
+            }
+            int j = 0;
+            while (j < bl.bs) {   // runs of variants that are consecutive in the file: one pread each (jumpto_bed, Geno.cpp:2828-2830)
+              int e = j + 1;
+              while (e < bl.bs && r.snp_offset[bl.start + e] == r.snp_offset[bl.start + e - 1] + 1) ++e;
+              int64_t want = (int64_t)(e - j) * r.bpr, got = 0;
+              const int64_t off = 3 + r.snp_offset[bl.start + j] * r.bpr;
+              while (got < want) {
+                const ssize_t k = pread(fd, dst + (int64_t)j * r.bpr + got, (size_t)(want - got), off + got);
+                if (k <= 0) throw std::runtime_error("cannot read bed file");
+                got += k;
+              }
+              j = e;
+            }
+          }
+          sl.read_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            ready_q.push_back(si);
+          }
+          cv.notify_all();
+        }
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(mu);
+        rd_err = std::current_exception();
+      }
+      if (fd >= 0) close(fd);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        rd_done = true;
+      }
+      cv.notify_all();
+    });
+    std::exception_ptr main_err = nullptr;
+    try {
+      for (;;) {
+        int si = -1;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return !ready_q.empty() || rd_done; });
+          if (!ready_q.empty()) { si = ready_q.front(); ready_q.pop_front(); }
+          else if (rd_err) std::rethrow_exception(rd_err);
+          else break;
+        }
+        Slot& sl = slots[si];
+        std::vector<int32_t> ids(sl.nb), bss(sl.nb);
+        std::vector<const uint8_t*> ptrs(sl.nb);
+        int64_t nsnp = 0;
+        for (int b = 0; b < sl.nb; ++b) {
+          ids[b] = sl.b0 + b; bss[b] = blocks[sl.b0 + b].bs; ptrs[b] = sl.mem + (int64_t)b * blk_bytes;
+          nsnp += bss[b];
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        check(cx, rg_l0_blocks(cx, sl.nb, ids.data(), bss.data(), ptrs.data(), r.bpr, RG_MEM_HOST));
+        check(cx, rg_ingest_fence(cx));     // the rows have crossed PCIe: the buffer goes back to the reader
+        auto t2 = std::chrono::steady_clock::now();
+        lg << " blocks [" << sl.b0 + 1 << ".." << sl.b0 + sl.nb << "] (chromosomes " << blocks[sl.b0].chrom << ".." << blocks[sl.b0 + sl.nb - 1].chrom
+           << ") : " << nsnp << " snps  (read " << (int64_t)sl.read_ms << "ms in the reader thread, queued on the GPU after "
+           << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms)\n";
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          free_q.push_back(si);
+        }
+        cv.notify_all();
+      }
+    } catch (...) {
+      main_err = std::current_exception();
+      {   // let the reader run to its end: hand every buffer back
+        std::lock_guard<std::mutex> lk(mu);
+        for (int i = 0; i < NBUF; ++i) free_q.push_back(i);
+      }
+      cv.notify_all();
+    }
+    reader.join();
+    if (!main_err) {
+      auto t1 = std::chrono::steady_clock::now();
+      try { check(cx, rg_sync(cx)); } catch (...) { main_err = std::current_exception(); }
+      lg << "   -level 0 ridge of blocks [" << b_lo + 1 << ".." << b_hi << "] complete (" <<
+          std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() << "ms after the last batch was queued)\n";
+    }
+    for (auto& sl : slots) rg_host_free(sl.mem);
+    if (main_err) std::rethrow_exception(main_err);
+  };
 
   if (p.run_l1) {
     // read_l0 (Step1_Models.cpp:1921-1987): every job file holds N x (blocks_k * R0) raw doubles, column-major,
@@ -1354,65 +1558,11 @@ int run(int argc, char** argv) {
         }
       }
     sout << "   -level 0 predictors read from the job files\n";
-  } else {
-    // level 0: stream blocks from the bed / pgen file (get_G, Geno.cpp:1498-1517) in batches
-    std::ifstream bed;
-    if (!r.pgen) bed.open(p.bed + ".bed", std::ios::binary);
-    const int NB = r.dosage_mode ? 1 : 32;   // a block of dosages is bs x N_file doubles on the host: one at a time
-    std::vector<std::vector<uint8_t>> bufs(NB);
-    std::vector<double> dbuf;
-    int cur_chr = -1;
-    for (int b0 = 0; b0 < B; b0 += NB) {
-      const int nb = std::min(NB, B - b0);
-      std::vector<int32_t> ids(nb), bss(nb);
-      std::vector<const uint8_t*> ptrs(nb);
-      auto t0 = std::chrono::steady_clock::now();
-      for (int b = 0; b < nb; ++b) {
-        const Blk& bl = blocks[b0 + b];
-        if (bl.chrom != cur_chr) { cur_chr = bl.chrom; sout << "Chromosome " << cur_chr << "\n"; }
-        if (r.bgenh) {  // readChunkFromBGENFileToG_fast (Geno.cpp:1574-1699): inflate + probabilities -> dosages
-          dbuf.resize((size_t)bl.bs * r.n_file);
-          if (rg_bgen_read_dosages(r.bgenh, bl.bs, &r.snp_offset[bl.start], p.ref_first ? 1 : 0, dbuf.data(), r.n_file) != RG_BGEN_OK)
-            throw std::runtime_error(rg_bgen_last_error(r.bgenh));
-          ids[b] = b0 + b; bss[b] = bl.bs;
-          continue;
-        }
-        if (r.dosage_mode) {  // Read() per kept variant (Geno.cpp:1795-1796): ALT dosages, -3 = missing
-          dbuf.resize((size_t)bl.bs * r.n_file);
-          if (rg_pgen_read_dosage_rows(r.pgen, bl.bs, &r.snp_offset[bl.start], dbuf.data(), r.n_file) != RG_PGEN_OK)
-            throw std::runtime_error(rg_pgen_last_error(r.pgen));
-          ids[b] = b0 + b; bss[b] = bl.bs;
-          continue;
-        }
-        bufs[b].resize((size_t)bl.bs * r.bpr);
-        if (r.pgen) {  // ReadHardcalls per kept variant (Geno.cpp:1781-1798), as .bed-coded rows
-          if (rg_pgen_read_bed_rows(r.pgen, bl.bs, &r.snp_offset[bl.start], bufs[b].data(), r.bpr) != RG_PGEN_OK)
-            throw std::runtime_error(rg_pgen_last_error(r.pgen));
-        } else {
-          for (int j = 0; j < bl.bs; ++j) {  // jumpto_bed (Geno.cpp:2828-2830)
-            bed.seekg(3 + r.snp_offset[bl.start + j] * r.bpr, std::ios::beg);
-            bed.read((char*)bufs[b].data() + (size_t)j * r.bpr, r.bpr);
-            if (!bed) throw std::runtime_error("cannot read bed file");
-          }
-        }
-        ids[b] = b0 + b; bss[b] = bl.bs; ptrs[b] = bufs[b].data();
-      }
-      auto t1 = std::chrono::steady_clock::now();
-      if (r.dosage_mode) {
-        const double* dp = dbuf.data();
-        check(ctx, rg_l0_blocks_f64(ctx, nb, ids.data(), bss.data(), &dp, r.n_file, RG_MEM_HOST));
-      } else
-        check(ctx, rg_l0_blocks(ctx, nb, ids.data(), bss.data(), ptrs.data(), r.bpr, RG_MEM_HOST));
-      check(ctx, rg_sync(ctx));
-      auto t2 = std::chrono::steady_clock::now();
-      int64_t nsnp = 0;
-      for (int v : bss) nsnp += v;
-      sout << " blocks [" << b0 + 1 << ".." << b0 + nb << "] : " << nsnp << " snps  (read "
-           << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << "ms, level 0 ridge on GPU "
-           << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms)\n";
-    }
   }
-  if (p.run_l0) {  // write_l0_file (Step1_Models.cpp:728-734): PFX_job<k>_l0_Y<ph>, then stop (Data.cpp:113-117)
+  if (p.run_l0) {  // level 0 of this job, then write_l0_file (Step1_Models.cpp:728-734): PFX_job<k>_l0_Y<ph>, and stop (Data.cpp:113-117)
+    std::ostringstream lg;
+    level0_range(ctx, 0, B, lg);
+    sout << lg.str();
     std::vector<double> slab((size_t)N * R0);
     for (int q = 0; q < P; ++q) {
       const std::string fn = r.job_prefix + "_l0_Y" + std::to_string(q + 1);
@@ -1429,8 +1579,7 @@ int run(int argc, char** argv) {
     return 0;
   }
 
-  // level 1 (ridge_level_1 + output)
-  sout << "\n Level 1 ridge...\n";
+  // level-1 inputs shared by the ranks
   const int L = B * R0;
   std::vector<double> tau((size_t)P * R1);
   for (int q = 0; q < P; ++q)
@@ -1453,41 +1602,25 @@ int run(int argc, char** argv) {
   }
   const int nchr = (int)chroms.size();
   const int NCS = (p.bt || p.ct) ? 6 : 5;
-  std::vector<double> cumsum((size_t)P * NCS * R1), pred((size_t)P * nchr * N);
-  std::vector<int32_t> best(P), converged(P, 1);
-  auto tl0 = std::chrono::steady_clock::now();
-  if (p.bt || p.ct) {
-    rg_bt_options bo;  // Regenie.hpp:287-290 defaults; family picks ridge_logistic_level_1* or ridge_poisson_level_1*
-    bo.niter_max_ridge = p.niter_max_ridge; bo.niter_max_line_search_ridge = 100; bo.niter_max_line_search = p.niter_max_line_search;
-    bo.family = p.ct ? 1 : 0; bo.l1_ridge_tol = 1e-4; bo.tol = 1e-8;
-    if (p.ct) sout << " Level 1 ridge with poisson regression...\n";
-    check(ctx, rg_l1_bt(ctx, R1, tau.data(), r.Yraw.data(), r.offset.data(), &bo, nchr, cols_per_chr.data(),
-                        cumsum.data(), converged.data(), best.data(), pred.data()));
-    for (int q = 0; q < P; ++q) if (!r.pheno_pass[q]) converged[q] = 0;
-  } else if (use_loocv)
-    check(ctx, rg_l1_qt_loocv(ctx, R1, tau.data(), nchr, cols_per_chr.data(), cumsum.data(), best.data(), pred.data()));
-  else
-    check(ctx, rg_l1_qt(ctx, R1, tau.data(), nchr, cols_per_chr.data(), cumsum.data(), best.data(), pred.data()));
-  sout << "   -level 1 for " << P << " phenotype(s) done ("
-       << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tl0).count() << "ms)\n\n";
-
-  // output (Data.cpp:956-1129, :1795-1975)
-  sout << "Output\n------\n";
-  std::ofstream plist(p.out + "_pred.list"), prslist;
-  if (p.print_prs) prslist.open(p.out + "_prs.list");
   std::vector<int64_t> order(N);  // std::map<string,...> iteration order (Data.cpp:1934)
   for (int64_t i = 0; i < N; ++i) order[i] = i;
   std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return r.ids[a] < r.ids[b]; });
   std::string header = "FID_IID ";
   for (int64_t i : order) if (r.ain[i]) header += r.ids[i] + " ";
   header += "\n";
-  for (int q = 0; q < P; ++q) {
-    sout << "phenotype " << q + 1 << " (" << r.pheno_names[q] << ") : \n";
-    if (!converged[q]) {  // Data.cpp:1016-1021
-      sout << "Level 1 model did not converge. LOCO predictions calculations are skipped.\n\n";
-      continue;
+
+  // per-phenotype results, filled by whichever rank owns the phenotype
+  std::vector<std::string> ph_log(P), ph_plist(P), ph_prslist(P);
+
+  // output of one phenotype (Data::output + write_predictions, Data.cpp:956-1129, :1795-1975)
+  auto emit_pheno = [&](int q, const double* cs, int bestq, int conv, const double* pq /* [nchr][N] */) {
+    std::ostringstream lo;
+    lo << "phenotype " << q + 1 << " (" << r.pheno_names[q] << ") : \n";
+    if (!conv) {  // Data.cpp:1016-1021
+      lo << "Level 1 model did not converge. LOCO predictions calculations are skipped.\n\n";
+      ph_log[q] = lo.str();
+      return;
     }
-    const double* cs = cumsum.data() + (size_t)q * NCS * R1;
     for (int j = 0; j < R1; ++j) {
       const double neff = r.neff[q];
       double num = cs[4 * R1 + j] - cs[0 * R1 + j] * cs[1 * R1 + j] / neff;
@@ -1498,15 +1631,14 @@ int run(int argc, char** argv) {
         const double zv = std::exp((double)L / tau[(size_t)q * R1 + j]) - 1;
         label = ct_rate[q] * zv / (1 + ct_rate[q] * zv);
       }
-      sout << "  " << std::right << std::setw(5) << label << " : Rsq = " << rsq;
-      if (!p.ct) sout << ", MSE = " << sse / neff;
-      if (p.bt || p.ct) sout << ", -logLik/N = " << cs[5 * R1 + j] / neff;
-      if (j == best[q]) sout << "<- min value";
-      sout << "\n";
+      lo << "  " << std::right << std::setw(5) << label << " : Rsq = " << rsq;
+      if (!p.ct) lo << ", MSE = " << sse / neff;
+      if (p.bt || p.ct) lo << ", -logLik/N = " << cs[5 * R1 + j] / neff;
+      if (j == bestq) lo << "<- min value";
+      lo << "\n";
     }
-    sout << "  * making predictions...writing LOCO predictions...";
+    lo << "  * making predictions...writing LOCO predictions...";
     const std::string loco_fn = p.out + "_" + std::to_string(q + 1) + ".loco" + (p.gz ? ".gz" : "");  // Data.cpp:987
-    const double* pq = pred.data() + (size_t)q * nchr * N;  // [nchr][N]
     std::vector<double> tot(N, 0.0);
     for (int c = 0; c < nchr; ++c)
       for (int64_t i = 0; i < N; ++i) tot[i] += pq[(size_t)c * N + i];
@@ -1529,7 +1661,7 @@ int run(int argc, char** argv) {
         lf << row.str();
       }
     }
-    plist << r.pheno_names[q] << " " << (p.use_rel_path ? loco_fn : get_fullpath(loco_fn)) << "\n";
+    ph_plist[q] = r.pheno_names[q] + " " + (p.use_rel_path ? loco_fn : get_fullpath(loco_fn)) + "\n";
     if (p.print_prs) {
       const std::string prs_fn = p.out + "_" + std::to_string(q + 1) + ".prs" + (p.gz ? ".gz" : "");
       TextOut pf(prs_fn, p.gz);
@@ -1543,16 +1675,97 @@ int run(int argc, char** argv) {
       }
       row << "\n";
       pf << row.str();
-      prslist << r.pheno_names[q] << " " << (p.use_rel_path ? prs_fn : get_fullpath(prs_fn)) << "\n";
+      ph_prslist[q] = r.pheno_names[q] + " " + (p.use_rel_path ? prs_fn : get_fullpath(prs_fn)) + "\n";
     }
-    sout << "done\n\n";
+    lo << "done\n\n";
+    ph_log[q] = lo.str();
+  };
+
+  // level 1 of phenotypes [q0, q0 + nq) on one context (its view already set for a phenotype-sharded run)
+  auto level1_range = [&](rg_ctx* cx, int q0, int nq, bool write_out) {
+    std::vector<double> cumsum((size_t)nq * NCS * R1), pred((size_t)nq * nchr * N);
+    std::vector<int32_t> best(nq), converged(nq, 1);
+    const double* tq = tau.data() + (size_t)q0 * R1;
+    if (p.bt || p.ct) {
+      rg_bt_options bo;  // Regenie.hpp:287-290 defaults; family picks ridge_logistic_level_1* or ridge_poisson_level_1*
+      bo.niter_max_ridge = p.niter_max_ridge; bo.niter_max_line_search_ridge = 100; bo.niter_max_line_search = p.niter_max_line_search;
+      bo.family = p.ct ? 1 : 0; bo.l1_ridge_tol = 1e-4; bo.tol = 1e-8;
+      check(cx, rg_l1_bt(cx, R1, tq, r.Yraw.data() + (size_t)q0 * N, r.offset.data() + (size_t)q0 * N, &bo, nchr, cols_per_chr.data(),
+                         cumsum.data(), converged.data(), best.data(), pred.data()));
+      for (int q = 0; q < nq; ++q) if (!r.pheno_pass[q0 + q]) converged[q] = 0;
+    } else if (use_loocv)
+      check(cx, rg_l1_qt_loocv(cx, R1, tq, nchr, cols_per_chr.data(), cumsum.data(), best.data(), pred.data()));
+    else
+      check(cx, rg_l1_qt(cx, R1, tq, nchr, cols_per_chr.data(), cumsum.data(), best.data(), pred.data()));
+    if (!write_out) return;
+    for (int q = 0; q < nq; ++q)
+      emit_pheno(q0 + q, cumsum.data() + (size_t)q * NCS * R1, best[q], converged[q], pred.data() + (size_t)q * nchr * N);
+  };
+
+  auto tl0 = std::chrono::steady_clock::now();
+  if (!use_group) {
+    if (!p.run_l1) {
+      std::ostringstream lg;
+      level0_range(ctx, 0, B, lg);
+      sout << lg.str();
+    }
+    sout << "\n Level 1 ridge...\n";
+    if (p.ct) sout << " Level 1 ridge with poisson regression...\n";
+    tl0 = std::chrono::steady_clock::now();
+    level1_range(ctx, 0, P, true);
+  } else {
+    // one host thread per GPU: level 0 of the rank's blocks, the exchange, level 1 of the rank's phenotypes (phenotype-
+    // sharded) or of all phenotypes with the heavy steps shared (all-gather form; level-1 models other than the K-fold
+    // ridge run on rank 0 alone there)
+    std::vector<std::string> rank_log(G);
+    std::vector<std::exception_ptr> errs(G, nullptr);
+    const bool shared_l1 = !pheno_sharded && !(p.bt || p.ct) && !use_loocv;
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g)
+      th.emplace_back([&, g]() {
+        bool finished = false;
+        try {
+          std::ostringstream lg;
+          level0_range(ctxs[g], bbeg[g], bbeg[g + 1], lg);
+          rank_log[g] = lg.str();
+          finished = true;
+          check(ctxs[g], rg_l0_finish(grp, g, bbeg.data(), pheno_sharded ? pbeg.data() : nullptr));
+          if (pheno_sharded) level1_range(ctxs[g], pbeg[g], pbeg[g + 1] - pbeg[g], true);
+          else if (shared_l1 || g == 0) level1_range(ctxs[g], 0, P, g == 0);
+        } catch (...) {
+          errs[g] = std::current_exception();
+          if (!finished) {   // the other ranks wait in the exchange: join them so that they can fail too
+            try { rg_l0_finish(grp, g, bbeg.data(), pheno_sharded ? pbeg.data() : nullptr); } catch (...) {}
+          }
+        }
+      });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < G; ++g) {
+      sout << " GPU " << g << " : blocks [" << bbeg[g] + 1 << ".." << bbeg[g + 1] << "]"
+           << (pheno_sharded ? ", level 1 of phenotypes [" + std::to_string(pbeg[g] + 1) + ".." + std::to_string(pbeg[g + 1]) + "]" : std::string()) << "\n" << rank_log[g];
+    }
+    for (int g = 0; g < G; ++g) if (errs[g]) std::rethrow_exception(errs[g]);
+    sout << "\n Level 1 ridge...\n";
+  }
+  sout << "   -level 1 for " << P << " phenotype(s) done ("
+       << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tl0).count() << "ms)\n\n";
+
+  // output (Data.cpp:956-1129): the per-phenotype tables and file lists in phenotype order
+  sout << "Output\n------\n";
+  std::ofstream plist(p.out + "_pred.list"), prslist;
+  if (p.print_prs) prslist.open(p.out + "_prs.list");
+  for (int q = 0; q < P; ++q) {
+    sout << ph_log[q];
+    plist << ph_plist[q];
+    if (p.print_prs) prslist << ph_prslist[q];
   }
   if (p.run_l1 && !p.keep_l0)   // rm_l0_files (Data.cpp:1131-1147)
     for (auto& pre : r.mprefix)
       for (int q = 0; q < P; ++q) std::remove((pre + "_l0_Y" + std::to_string(q + 1)).c_str());
   sout << "List of blup files written to: [" << p.out << "_pred.list]\n";
   if (p.print_prs) sout << "List of files with whole genome PRS written to: [" << p.out << "_prs.list]\n";
-  rg_destroy(ctx);
+  if (grp) rg_group_destroy(grp);
+  for (rg_ctx* cx : ctxs) rg_destroy(cx);
   sout << "\nElapsed time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << "s\nEnd of run\n";
   return 0;
 }

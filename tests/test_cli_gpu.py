@@ -431,3 +431,54 @@ def test_cli_bgen_equals_bed(example_dir, tmp_path):
     _, _, v1, _ = _parse_loco(str(tmp_path / "br_1.loco"))
     _, _, v2, _ = _parse_loco(str(tmp_path / "gr_1.loco"))
     assert np.allclose(v1, v2, rtol=1e-5, atol=1e-7, equal_nan=True)
+
+
+# ---- one node, several GPUs: the C++ driver's rank threads, the level-0 hand-off and the sharded / shared level 1 ----------
+def _run_pair(E, tmp_path, extra_common, variants):
+    """runs the plain single-GPU command and each variant; returns {name: {file: bytes}}"""
+    out = {}
+    for name, extra in [("plain", [])] + variants:
+        d = tmp_path / name
+        d.mkdir()
+        r = _run(extra_common + extra + ["--out", "o"], str(d))
+        assert r.returncode == 0, name + "\n" + r.stdout[-3000:] + r.stderr[-3000:]
+        out[name] = {fn: open(str(d / fn), "rb").read() for fn in sorted(os.listdir(str(d))) if fn.endswith(".loco")}
+        out[name]["_log"] = r.stdout
+    return out
+
+
+def test_cli_multi_gpu_qt(example_dir, tmp_path):
+    """--gpus 2 on ONE device (peer-copy transport): block ranges as write_l0_master, all-to-all by phenotype + level 1 per
+    rank, and the all-gather form with the shared level 1 (--l1-shared) -- .loco files byte-identical to the single-GPU run;
+    --gpus 1 --force-collectives runs the same code over RCCL with a world of one (send/recv to self, broadcast, all-reduce)."""
+    E = example_dir
+    common = ["--step", "1", "--bed", os.path.join(E, "example_3chr"), "--phenoFile", os.path.join(E, "phenotype.txt"),
+              "--covarFile", os.path.join(E, "covariates.txt"), "--bsize", "100"]
+    res = _run_pair(E, tmp_path, common, [
+        ("peer2", ["--gpus", "2", "--single-device", "--transport", "peer"]),
+        ("peer2_shared", ["--gpus", "2", "--single-device", "--transport", "peer", "--l1-shared"]),
+        ("peer3", ["--gpus", "3", "--single-device", "--transport", "peer"]),
+        ("rccl1", ["--gpus", "1", "--force-collectives"]),
+        ("rccl1_shared", ["--gpus", "1", "--force-collectives", "--l1-shared"]),
+    ])
+    for name in ("peer2", "peer2_shared", "peer3", "rccl1", "rccl1_shared"):
+        assert sorted(k for k in res[name] if k != "_log") == ["o_1.loco", "o_2.loco"]
+        for fn in ("o_1.loco", "o_2.loco"):
+            assert res[name][fn] == res["plain"][fn], (name, fn)
+    assert "GPU 1 : blocks [4..6]" in res["peer2"]["_log"] and "RCCL" in res["rccl1"]["_log"]
+
+
+def test_cli_multi_gpu_bt_and_loocv(example_dir, tmp_path):
+    E = example_dir
+    common = ["--step", "1", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"),
+              "--covarFile", os.path.join(E, "covariates.txt"), "--remove", os.path.join(E, "fid_iid_to_remove.txt"),
+              "--exclude", os.path.join(E, "snplist_rm.txt"), "--bsize", "100", "--bt"]
+    res = _run_pair(E, tmp_path, common, [
+        ("peer2", ["--gpus", "2", "--single-device", "--transport", "peer"]),
+        ("peer2_gather", ["--gpus", "2", "--single-device", "--transport", "peer", "--l1-shared"]),   # BT: level 1 on rank 0 after the all-gather
+        ("rccl1", ["--gpus", "1", "--force-collectives"]),
+    ])
+    for name in ("peer2", "peer2_gather", "rccl1"):
+        for fn in ("o_1.loco", "o_2.loco"):
+            assert res[name][fn] == res["plain"][fn], (name, fn)
+        assert "0.4504" in [ln for ln in res[name]["_log"].splitlines() if "min value" in ln][1]

@@ -72,7 +72,14 @@ def _worker_a2a(rank, world, port, B, R0, P, Np, q):
     W[b0 * R0:(b0 + nb) * R0] = full[b0 * R0:(b0 + nb) * R0]             # each rank fills only its own block columns
     Wg = exchange_w_by_phenotype(W, shards, pshards, R0)
     q0, qn = pshards[rank]
-    q.put((rank, bool(torch.equal(Wg, full[:, q0:q0 + qn, :])) and tuple(Wg.shape) == (B * R0, qn, Np)))
+    ok = bool(torch.equal(Wg, full[:, q0:q0 + qn, :])) and tuple(Wg.shape) == (B * R0, qn, Np)
+    # a rank that keeps the rows of its own blocks only (rg_set_block_range), buffers reused across calls
+    bufs = {}
+    own = full[b0 * R0:(b0 + nb) * R0].clone()
+    for _ in range(2):
+        Wg2 = exchange_w_by_phenotype(own, shards, pshards, R0, buffers=bufs, own_rows_only=True)
+        ok = ok and bool(torch.equal(Wg2, full[:, q0:q0 + qn, :]))
+    q.put((rank, ok))
     dist.destroy_process_group()
 
 

@@ -3,8 +3,9 @@ the same command (tests/golden/ref_outputs/, produced by oracle/_ref/regenie = t
 oracle/Makefile; generator tests/golden/make_ref_outputs.py).  Compared: every .loco / .prs value at the resolution of
 the reference's 6-digit text (and under BASELINE.json's max-relative-error metric, bar 1e-5), the NA pattern, sample and
 chromosome order, the CV table of the log with the selected ridge parameter, the phenotype names of _pred.list.
-With the reference binary present (it ships to the GPU box prebuilt) two full-sample-size cases run it live next to the
-driver: N = 500,000 with 10 QT phenotypes (BASELINE configs[2] shape) and N = 500,000 binary traits, K-fold (configs[3])."""
+Two cases at the full sample count of BASELINE configs[2] / [3] (500,000 samples, 10 QT / 6 BT phenotypes, bsize 1000) run the
+driver against the numpy oracle (pinned to regenie by tests/test_reference_pin.py); with RG_LIVE_REFERENCE_500K=1 the
+reference binary itself runs next to the driver (minutes per case; last run recorded in profiles/r2_reference_500k.md)."""
 import gzip
 import json
 import os
@@ -29,6 +30,18 @@ def _loco_file(path):
     ids = lines[0].split()[1:]
     return ids, np.array([[np.nan if t == "NA" else float(t) for t in ln.split()[1:]] for ln in lines[1:]]), \
         [ln.split()[0] for ln in lines[1:]]
+
+
+def _loco_file_fast(path):
+    """as _loco_file for files with millions of values: one C-level parse per row"""
+    with open(path) as fh:
+        ids = fh.readline().split()[1:]
+        rows, first = [], []
+        for ln in fh:
+            sp = ln.index(" ")
+            first.append(ln[:sp])
+            rows.append(np.fromstring(ln[sp + 1:].replace("NA", "nan"), sep=" "))
+    return ids, np.array(rows), first
 
 
 def _compare_tables(got_lines, ref_lines, what, rel=2e-5):
@@ -107,25 +120,86 @@ def _write_big(prefix, N, M, chroms, P, binary, seed, missing_pheno):
             fh.write("%d %d " % (i + 1, i + 1) + " ".join("NA" if miss[i, p] else "%.10g" % Y[i, p] for p in range(P)) + "\n")
 
 
-needs_ref_binary = pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")
-
-
-@needs_ref_binary
-@pytest.mark.parametrize("kind", ["qt_config3_shape", "bt_kfold_config4_shape"])
-def test_driver_vs_live_reference_at_500k_samples(kind, tmp_path):
-    """BASELINE configs[2] / [3] at their real sample count, phenotype count (10 QT with missing values / 6 BT, K-fold) and
-    block size 1000, on a slice of SNP blocks both programs finish in about a minute: regenie itself and the driver read
-    the same files; LOCO predictors must agree to the printed digits (bar 1e-5, BASELINE.json)."""
-    d = str(tmp_path)
+def _big_case(kind, d):
     N = 500_000
     if kind == "qt_config3_shape":
-        M, chroms, P, binary = 2600, [1] * 1000 + [2] * 1000 + [7] * 600, 10, False
+        M, chroms, P, binary = 1400, [1] * 1000 + [2] * 400, 10, False
     else:
-        M, chroms, P, binary = 1600, [3] * 1000 + [9] * 600, 6, True
+        M, chroms, P, binary = 1300, [3] * 1000 + [9] * 300, 6, True
     pre = os.path.join(d, "big")
     _write_big(pre, N, M, chroms, P, binary, seed=2026, missing_pheno=0.01)
     common = ["--step", "1", "--bed", pre, "--covarFile", pre + ".covar", "--phenoFile", pre + ".pheno", "--bsize", "1000",
               "--bt" if binary else "--qt"]
+    return N, P, binary, pre, common
+
+
+def _check_vals(got, ref, what):
+    assert ref.shape[0] == 23 and got.shape == ref.shape
+    assert np.array_equal(np.isnan(ref), np.isnan(got)), what
+    ok = ~np.isnan(ref)
+    return float(np.max(np.abs(got[ok] - ref[ok])) / np.max(np.abs(ref[ok]))), ok
+
+
+def _compare_loco_files(d, P, kind, ref_prefix):
+    worst = 0.0
+    for ph in range(1, P + 1):
+        ids_r, ref, _ = _loco_file_fast(os.path.join(d, "%s_%d.loco" % (ref_prefix, ph)))
+        ids_g, got, _ = _loco_file_fast(os.path.join(d, "gpu_%d.loco" % ph))
+        assert ids_r == ids_g
+        e, ok = _check_vals(got, ref, (kind, ph))
+        # both files carry 6 significant digits: one unit of the last printed digit + the metric of BASELINE.json
+        mag = np.maximum(np.abs(ref[ok]), 1e-300)
+        ulp = 10.0 ** (np.floor(np.log10(mag)) - 5)
+        assert float(np.max(np.abs(got[ok] - ref[ok]) / ulp)) <= 1.0 + 1e-6, (kind, ph)
+        worst = max(worst, e)
+    assert worst < 1e-5, worst
+    return worst
+
+
+@pytest.mark.parametrize("kind", ["qt_config3_shape", "bt_kfold_config4_shape"])
+def test_driver_vs_oracle_at_500k_samples(kind, tmp_path):
+    """BASELINE configs[2] / [3] at their real sample count (500,000), phenotype count (10 QT with missing values / 6 BT,
+    K-fold) and block size 1000, on two SNP blocks (one full, one chromosome end): the C++ driver against the numpy oracle
+    -- which tests/test_reference_pin.py pins to regenie itself -- reading the same files.  LOCO predictors at the
+    resolution of the driver's 6-digit text (bar 1e-5, BASELINE.json), CV tables, selected ridge parameters."""
+    from oracle import regenie_step1 as orc
+    from tests.test_reference_pin import oracle_loco_rows
+    d = str(tmp_path)
+    N, P, binary, pre, common = _big_case(kind, d)
+    g = subprocess.run([BIN] + common + ["--out", "gpu"], cwd=d, capture_output=True, text=True, timeout=1200)
+    assert g.returncode == 0, g.stdout[-3000:] + g.stderr[-3000:]
+    t0 = time.time()
+    res = orc.run_step1(orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=1000, bt=binary), keep_W=False)
+    assert not res.use_loocv
+    print("%s: oracle %.1f s" % (kind, time.time() - t0))
+    _compare_tables(table_lines(open(os.path.join(d, "gpu.log")).read()),
+                    [l for l in res.log if l.startswith("phenotype ") or ": Rsq = " in l], kind)
+    worst = 0.0
+    for ph in range(P):
+        ids_g, got, first = _loco_file_fast(os.path.join(d, "gpu_%d.loco" % (ph + 1)))
+        ids_o, ref = oracle_loco_rows(res, ph)
+        assert ids_g == ids_o and first == [str(c) for c in range(1, 24)]
+        e, ok = _check_vals(got, ref, (kind, ph))
+        mag = np.maximum(np.abs(ref[ok]), 1e-300)
+        ulp = 10.0 ** (np.floor(np.log10(mag)) - 5)
+        assert float(np.max(np.abs(got[ok] - ref[ok]) / ulp)) <= 0.5 + 1e-3, (kind, ph)     # the text rounds the oracle's value
+        worst = max(worst, e)
+    assert worst < 1e-5, worst
+    print("%s: LOCO max-rel-err vs the oracle (6-digit text) %.2e" % (kind, worst))
+
+
+needs_ref_binary = pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")
+
+
+@needs_ref_binary
+@pytest.mark.skipif(os.environ.get("RG_LIVE_REFERENCE_500K") != "1",
+                    reason="regenie itself at 500,000 samples takes 5-10 minutes per case on the GPU box's host (its Eigen GEMM on 255 "
+                           "threads); set RG_LIVE_REFERENCE_500K=1.  Last run: profiles/r2_reference_500k.md")
+@pytest.mark.parametrize("kind", ["qt_config3_shape", "bt_kfold_config4_shape"])
+def test_driver_vs_live_reference_at_500k_samples(kind, tmp_path):
+    """The same two cases with regenie ITSELF (oracle/_ref/regenie) run next to the driver on the same files."""
+    d = str(tmp_path)
+    N, P, binary, pre, common = _big_case(kind, d)
     t0 = time.time()
     r = subprocess.run([REGENIE] + common + ["--out", "ref"], cwd=d, capture_output=True, text=True, timeout=3000)
     t_ref = time.time() - t0
@@ -136,18 +210,4 @@ def test_driver_vs_live_reference_at_500k_samples(kind, tmp_path):
     assert g.returncode == 0, g.stdout[-3000:] + g.stderr[-3000:]
     print("%s: reference %.1f s, driver %.1f s (wall, from files)" % (kind, t_ref, t_gpu))
     _compare_tables(table_lines(open(os.path.join(d, "gpu.log")).read()), table_lines(open(os.path.join(d, "ref.log")).read()), kind)
-    worst = 0.0
-    for ph in range(1, P + 1):
-        ids_r, ref, _ = _loco_file(os.path.join(d, "ref_%d.loco" % ph))
-        ids_g, got, _ = _loco_file(os.path.join(d, "gpu_%d.loco" % ph))
-        assert ids_r == ids_g and ref.shape == (23, N - 0) or ref.shape[0] == 23
-        assert np.array_equal(np.isnan(ref), np.isnan(got))
-        ok = ~np.isnan(ref)
-        # both files carry 6 significant digits: one unit of the last printed digit + the metric of BASELINE.json
-        mag = np.maximum(np.abs(ref[ok]), 1e-300)
-        ulp = 10.0 ** (np.floor(np.log10(mag)) - 5)
-        assert float(np.max(np.abs(got[ok] - ref[ok]) / ulp)) <= 1.0 + 1e-6, (kind, ph)
-        e = float(np.max(np.abs(got[ok] - ref[ok])) / np.max(np.abs(ref[ok])))
-        worst = max(worst, e)
-    assert worst < 1e-5, worst
-    print("%s: LOCO max-rel-err vs regenie %.2e" % (kind, worst))
+    print("%s: LOCO max-rel-err vs regenie %.2e" % (kind, _compare_loco_files(d, P, kind, "ref")))
