@@ -279,15 +279,15 @@ def main():
             a = kernels[dom]["achieved_TFLOPS"]
             traffic = None
             if dom == "chol_f64":   # HBM bytes per batch from the separate rocprofv3 PMC passes of this same command
-                try:                # (profiles/r1_traffic.json, tools/pmc_traffic.py: FETCH_SIZE x 2 + WRITE_SIZE)
-                    tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+                try:                # (profiles/r2_traffic.json, tools/pmc_traffic.py: FETCH_SIZE x 2 + WRITE_SIZE)
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
                     traffic = tj["hbm_bytes_per_batch"] * (len(my_blocks) / n_batches) / (109 / 2.0)
                 except Exception:   # noqa: BLE001 - the field is optional
                     traffic = None
             roof = {"kernel": {"chol_f64": "k_chol_update/gfact/gstrip/backsolve (fp64 MFMA batched Cholesky, per level-0 batch of systems)",
                                "l1_gram_f64": "k_l1_gram (fp64 MFMA fold Gram)"}[dom], "bound": "mfma", "achieved": a,
                     "peak": PEAK["f64_mfma_TFLOPS"], "unit": "TFLOP/s", "frac": a / PEAK["f64_mfma_TFLOPS"], "traffic": traffic,
-                    "traffic_note": "HBM bytes per launch group from separate rocprofv3 --pmc passes (profiles/r1_traffic.json), scaled by blocks per batch",
+                    "traffic_note": "HBM bytes per launch group from separate rocprofv3 --pmc passes of this command at this commit's kernels (profiles/r2_traffic.json, tools/collect_profiles.sh), scaled by blocks per batch; not re-measured inside this run",
                     "algorithmic_flops_per_launch": flops[dom] / max(1, n_batches if dom == "chol_f64" else P),
                     "avg_launch_ms": kernels[dom]["ms"] / max(1, n_batches if dom == "chol_f64" else P)}
 
@@ -384,7 +384,8 @@ def from_disk_leg(args, torch, packed, blocks, my_blocks, Yraw, cov, M, N, P, gp
         order = sorted(range(N), key=lambda i: "%d_%d" % (i + 1, i + 1))
         got = np.asarray(gpu_loco[0])[order, :].T
         err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
-        stages = [ln.strip() for ln in r.stdout.splitlines() if "level 0 ridge of blocks" in ln or "-level 1 for" in ln or "Elapsed time" in ln]
+        stages = [ln.strip() for ln in r.stdout.splitlines() if "level 0 ridge of blocks" in ln or "-level 1 for" in ln or "Elapsed time" in ln
+                  or "since start" in ln]
         return {"value": M * N * P / wall, "unit": "SNP*sample*pheno/s", "wall_s": wall, "walls_s": walls, "bed_bytes": nbytes,
                 "bed_GBps": nbytes / wall / 1e9, "driver_log": stages, "setup_write_s": t_write,
                 "loco_text_vs_resident_run_max_rel_err": err,
@@ -453,7 +454,10 @@ def cpu_baseline(args, eng, torch, dev, packed, blocks, my_blocks, X, Y, Yraw, c
                 for i in range(N):
                     fh.write("%d %d %.17g %.17g\n" % (i + 1, i + 1, cov[i, 0], cov[i, 1]))
             ncore = os.cpu_count() or 1
-            thr = max(1, ncore - 1)                     # the reference's own default (Regenie.cpp:1104-1106)
+            # the reference's own default is all cores - 1 (Regenie.cpp:1104-1106), but its Eigen GEMM does not scale to hundreds
+            # of threads: on the 256-thread GPU box two 50,000 x 1,000 blocks take 7.6 s with 16 threads, 9.0 s with 32, 15 s
+            # with 64 and > 80 s with 255 (tools/ref_threads_probe.py, profiles/r2_reference_threads.md) -- it gets 16
+            thr = max(1, min(ncore - 1, int(os.environ.get("RG_REF_THREADS", "16"))))
             t0 = time.perf_counter()
             r = subprocess.run([regenie, "--step", "1", "--bed", pre, "--phenoFile", pre + ".pheno", "--covarFile", pre + ".covar",
                                 "--bsize", str(args.bsize), "--qt", "--threads", str(thr), "--out", os.path.join(d, "ref")],

@@ -44,6 +44,7 @@
 #include "../../include/rg_bgen.h"
 #include "../../include/rg_pgen.h"
 #include "../../include/rg_step1.h"
+#include "../../include/rg_step2.h"
 
 namespace {
 
@@ -73,6 +74,9 @@ struct Params {
   int transport = RG_TRANSPORT_RCCL;
   bool single_device = false, force_collectives = false;
   bool l1_shared = false;   // --l1-shared: all-gather + shared level 1 even when every GPU could own a phenotype
+  // --step 2 (single-variant association test, quantitative traits: Data::test_snps_fast, Data.cpp:2230-2360)
+  std::string pred_list;    // --pred: the _pred.list of step 1
+  double min_mac = 5;       // --minMAC (Regenie.hpp:311)
 };
 
 struct Log {  // mstream (Regenie.hpp:120-142): tee to stdout and <out>.log
@@ -351,10 +355,19 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--single-device") p.single_device = true;
     else if (a == "--force-collectives") p.force_collectives = true;
     else if (a == "--l1-shared") p.l1_shared = true;
+    else if (a == "--pred") p.pred_list = need(i);
+    else if (a == "--minMAC") p.min_mac = atof(need(i).c_str());
     else usage_error("unrecognised option '" + a + "'");
   }
   if (p.bt) p.rint = false;  // Regenie.cpp:432
-  if (p.step != 1) usage_error("specify which mode regenie should be running using option --step (only --step 1 is served).");
+  if (p.step != 1 && p.step != 2) usage_error("specify which mode regenie should be running using option --step.");
+  if (p.step == 2) {
+    if (p.bt || p.ct) usage_error("--step 2 serves quantitative traits only (--qt): the binary / count trait tests (Firth, SPA) are not built.");
+    if (p.bed.empty()) usage_error("--step 2 reads hard calls from --bed (the .pgen / .bgen readers feed --step 1 only).");
+    if (p.pred_list.empty()) usage_error("option '--pred' is required (use the _pred.list file written by step 1).");
+    if (p.min_mac < 0.5) usage_error("minimum MAC must be at least 0.5.");   // Regenie.cpp:1054
+    if (p.gpus > 1 || p.force_collectives) usage_error("--step 2 runs on one GPU.");
+  }
   if ((int)!p.bed.empty() + (int)!p.pgen.empty() + (int)!p.bgen.empty() != 1) usage_error("must use either --bed,--bgen or --pgen.");  // Regenie.cpp:419-420
   if (p.pheno_file.empty()) usage_error("option '--phenoFile' is required.");
   if (p.bsize < 1) usage_error("must specify the block size using '--bsize'.");
@@ -373,6 +386,11 @@ struct Run {
   std::vector<int64_t> snp_offset;
   std::vector<int> chr_read;             // chromosomes in file order
   std::vector<std::string> snp_ids;      // kept variants
+  std::vector<int64_t> snp_pos;          // kept variants: physpos, and the two alleles in output order (Geno.cpp:546-553)
+  std::vector<std::string> snp_a0, snp_a1;
+  // --step 2: the LOCO files of step 1 (blup_read, Pheno.cpp:1241-1391)
+  struct Blup { std::string file; std::vector<int64_t> col_sample; std::vector<int64_t> line_off; };
+  std::vector<Blup> blups;               // per phenotype
   // --run-l0 / --run-l1 (prep_parallel_l0 / prep_parallel_l1)
   int64_t parallel_nGeno = 0;            // global number of variants (lambda uses it, Data.cpp:607)
   int parallel_nBlocks = 0, parallel_nSnps = 0;
@@ -582,6 +600,7 @@ bool fit_poisson(const double* y, const double* X, const uint8_t* mask, int64_t 
 }
 
 void apply_sample_and_variant_filters(Run& r);
+void blup_read(struct Run& r, const std::map<std::string, int64_t>& idx);
 
 // prep_bgen (Geno.cpp:38-175): variant list from the file itself, sample identifiers embedded or from --sample
 void read_bgen_meta(Run& r) {
@@ -770,7 +789,14 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
       bool keep = true;
       if (!extract_files.empty() && !ext.count(vid)) keep = false;
       if (!exclude_files.empty() && exc.count(vid)) keep = false;
-      if (keep) { r.snp_chrom.push_back(c); r.snp_offset.push_back(lineno); r.snp_ids.push_back(vid); }
+      if (keep) {
+        r.snp_chrom.push_back(c); r.snp_offset.push_back(lineno); r.snp_ids.push_back(vid);
+        if (!pg && p.step == 2) {   // read_bim (Geno.cpp:546-553): the reference allele is the LAST one unless --ref-first
+          r.snp_pos.push_back((int64_t)std::strtoul(t[3].c_str(), nullptr, 0));
+          r.snp_a0.push_back(p.ref_first ? t[4] : t[5]);
+          r.snp_a1.push_back(p.ref_first ? t[5] : t[4]);
+        }
+      }
       ++lineno;
     }
     n_variants_file = lineno;
@@ -781,7 +807,7 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
     if (!extract_files.empty() || !exclude_files.empty())
       sout << "   -number of variants remaining in the analysis = " << r.snp_chrom.size() << "\n";
   }
-  if (r.snp_chrom.size() > 1000000 && !p.force_step1)  // Data.cpp:173-175
+  if (p.step == 1 && r.snp_chrom.size() > 1000000 && !p.force_step1)  // Data.cpp:173-175
     throw std::runtime_error("it is not recommened to use more than 1M variants in step 1 (use --force-step1 to override)");
   if (!pg) {
     std::string fn = p.bed + ".bed";
@@ -836,6 +862,62 @@ void apply_sample_and_variant_filters(Run& r) {
   r.N = (int64_t)r.ids.size();
   if (r.N == 0) throw std::runtime_error("no samples remaining in the analysis.");
   if (r.N != r.n_file) sout << "   -number of genotyped individuals remaining in the analysis = " << r.N << "\n";
+}
+
+// --pred list + first pass over every LOCO file (check_blup / blup_read, Pheno.cpp:1204-1391): header ids -> samples,
+// line 2 tells which samples have NA predictions (masked for the trait), byte offsets of the chromosome lines for later
+void blup_read(Run& r, const std::map<std::string, int64_t>& idx) {
+  const Params& p = r.p;
+  const int64_t N = r.N;
+  std::map<std::string, std::string> files;
+  {
+    TextIn f(p.pred_list);
+    if (!f) throw std::runtime_error("cannot open file : " + p.pred_list);
+    std::string line;
+    while (std::getline(f, line)) {
+      auto t = split_ws(line);
+      if (t.empty()) continue;
+      if (t.size() != 2) throw std::runtime_error("step 1 list file is not in the right format : " + p.pred_list);
+      if (files.count(t[0])) throw std::runtime_error("phenotype '" + t[0] + "' appears more than once in step 1 list file.");
+      files[t[0]] = t[1];
+    }
+  }
+  sout << " * LOCO predictions : [" << p.pred_list << "]\n";
+  r.blups.resize(r.P);
+  for (int q = 0; q < r.P; ++q) {
+    if (!files.count(r.pheno_names[q])) throw std::runtime_error("No step 1 file provided for phenotype '" + r.pheno_names[q] + "'.");
+    Run::Blup& bl = r.blups[q];
+    bl.file = files[r.pheno_names[q]];
+    sout << "   -file [" << bl.file << "] for phenotype '" << r.pheno_names[q] << "'\n";
+    if (ends_with_gz(bl.file)) throw std::runtime_error("gzipped LOCO files are not read by --step 2 here (write them without --gz): " + bl.file);
+    std::ifstream f(bl.file, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open file : " + bl.file);
+    std::string line;
+    std::getline(f, line);
+    auto hdr = split_ws(line);
+    if (hdr.empty() || hdr[0] != "FID_IID") throw std::runtime_error("header of blup file must start with FID_IID (=" + (hdr.empty() ? std::string() : hdr[0]) + ")");
+    bl.col_sample.assign(hdr.size(), -1);
+    for (size_t c = 1; c < hdr.size(); ++c) {
+      auto it = idx.find(hdr[c]);
+      if (it != idx.end()) bl.col_sample[c] = it->second;
+    }
+    bl.line_off.push_back((int64_t)f.tellg());
+    std::getline(f, line);
+    auto l2 = split_ws(line);
+    if (l2.size() != hdr.size()) throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' has different number of entries on line 2 compared to the header.");
+    std::vector<uint8_t> have(N, 0);
+    for (size_t c = 1; c < hdr.size(); ++c)
+      if (bl.col_sample[c] >= 0 && convert_double(l2[c]) != MISSING) have[bl.col_sample[c]] = 1;
+    int64_t before = 0, after = 0;
+    for (int64_t i = 0; i < N; ++i) { before += r.mask[(size_t)q * N + i]; r.mask[(size_t)q * N + i] &= have[i]; after += r.mask[(size_t)q * N + i]; }
+    if (after < 1) throw std::runtime_error("all individuals are missing LOCO predictions for phenotype '" + r.pheno_names[q] + "'.");
+    if (after < before) sout << "    + " << before - after << " individuals with missing LOCO predictions will be ignored for the trait\n";
+    for (;;) {   // offsets of the following lines (one per chromosome)
+      const int64_t off = (int64_t)f.tellg();
+      if (!std::getline(f, line) || line.empty()) break;
+      bl.line_off.push_back(off);
+    }
+  }
 }
 
 void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841, :1903-1935
@@ -894,6 +976,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
         }
         r.Y[(size_t)q * N + i] = v;
         if (v != MISSING) all_miss = false;
+        else if (p.step == 2 && !strict && !p.bt && !p.ct) r.mask[(size_t)q * N + i] = 0;   // rm_missing_qt (Pheno.cpp:328, Regenie.cpp:1086)
         else if (strict) {
           for (int q2 = 0; q2 < r.P; ++q2) r.mask[(size_t)q2 * N + i] = 0;
           all_miss = true;
@@ -938,6 +1021,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     for (int64_t i = 0; i < N; ++i) np += in_pheno[i];
     sout << "   -number of phenotyped individuals " << (strict ? "with no missing data" : "") << " = " << np << "\n";
   }
+  if (p.step == 2) blup_read(r, idx);   // prep_run (Pheno.cpp:1063-1068): samples without LOCO predictions are masked for the trait
   int ncols = 1;
   std::vector<double> Xraw;  // col-major N x ncols
   if (!p.covar_file.empty()) {
@@ -1217,6 +1301,238 @@ void check(rg_ctx* ctx, int rc) {
   if (rc != 0) throw std::runtime_error(rg_last_error(ctx));
 }
 
+// the variant loop of a block spread over host threads (the reference's OpenMP loop in compute_tests_mt, Data.cpp:2484-2486)
+template <class F>
+void parallel_for(int n, int nthreads, F&& fn) {
+  nthreads = std::max(1, std::min(nthreads, n));
+  if (nthreads == 1) { for (int j = 0; j < n; ++j) fn(j); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; ++t)
+    th.emplace_back([&, t]() { for (int j = t; j < n; j += nthreads) fn(j); });
+  for (auto& x : th) x.join();
+}
+
+// -log10 p of a 1-df chi-square statistic (get_logp, Regenie.cpp:1843-1856)
+double get_logp(double t) {
+  if (t < 0 && std::fabs(t) < 1e-6) return 0.0;
+  if (t < 0) return -1.0;
+  const double pv = std::erfc(std::sqrt(t / 2.0));   // cdf(complement(chi_squared(1), t))
+  const double lp = pv == 0 ? std::log10(2.0) - 0.5 * std::log10(2 * M_PI * t) - 0.5 * t * M_LOG10E : std::log10(pv);
+  return -lp;
+}
+
+// ---- `--step 2 --qt`: single-variant score tests on hard calls (Data::test_snps_fast, Data.cpp:2230-2360) -----------------
+// Host side: the LOCO reader (blup_read / blup_read_chr, Pheno.cpp:1241-1391, Step2_Models.cpp:51-140), compute_res
+// (Data.cpp:2386-2400), the per-variant bookkeeping of parseSnpfromBed (Geno.cpp:2414-2536: allele counts, the MAC filter of
+// compute_mac, allele frequencies, per-trait counts for samples with missing phenotypes) and the output lines
+// (print_sum_stats_head / print_sum_stats_single, Step2_Models.cpp:2410-2530).  Device side (include/rg_step2.h): mean
+// imputation, residualize_geno and compute_score_qt for a block of variants.
+// Served: runs in which every analysed sample is observed for every phenotype (complete phenotypes, one phenotype, or
+// --strict).  Refused with an explicit error: phenotypes with different missingness patterns.  There the reference tests a
+// "sparse" variant (at most half of the samples non-zero, check_sparse_G, Geno.cpp:3165-3180: most variants below ~29 % MAF)
+// with an approximate per-trait denominator ("assuming X'X is same for all traits", Step2_Models.cpp:400-409) that differs
+// from the exact dense expression by up to ~10 % on the reference's own example with 14 % missing values; reproducing that
+// approximation needs per-(covariate, trait) accumulators the device kernel does not carry yet.  With complete phenotypes
+// the sparse and dense expressions are the same number, which is what the kernel evaluates.
+int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
+  const Params& p = r.p;
+  const int64_t N = r.N;
+  const int P = r.P, C = r.C;
+  std::vector<int64_t> an;                      // analysed samples (rows handed to the device), file order
+  for (int64_t i = 0; i < N; ++i) if (r.ain[i]) an.push_back(i);
+  const int64_t n = (int64_t)an.size();
+  bool any_missing = false;                     // filters->has_missing: a sample masked for at least one trait
+  std::vector<uint8_t> has_missing(n, 0);
+  for (int64_t k = 0; k < n; ++k)
+    for (int q = 0; q < P; ++q)
+      if (!r.mask[(size_t)q * N + an[k]]) { has_missing[k] = 1; any_missing = true; }
+  if (any_missing)
+    throw std::runtime_error("--step 2 with phenotypes that differ in their missing values is not built (the reference's sparse-genotype "
+                             "approximation of the per-trait denominators, Step2_Models.cpp:400-409): analyse the traits one at a time or use --strict.");
+  // compact, sample-fastest copies for the C ABI
+  std::vector<double> Xc((size_t)C * n), Yc((size_t)P * n), resc((size_t)P * n), scf(P);
+  std::vector<uint8_t> Mc((size_t)P * n);
+  for (int c = 0; c < C; ++c) for (int64_t k = 0; k < n; ++k) Xc[(size_t)c * n + k] = r.X[(size_t)c * N + an[k]];
+  for (int q = 0; q < P; ++q)
+    for (int64_t k = 0; k < n; ++k) { Yc[(size_t)q * n + k] = r.Y[(size_t)q * N + an[k]]; Mc[(size_t)q * n + k] = r.mask[(size_t)q * N + an[k]]; }
+
+  rg_s2_ctx* s2 = nullptr;
+  if (rg_s2_create(&s2, p.device, n, C, P) != RG_S2_OK || !s2) throw std::runtime_error("no MI355X / HIP device available (rg_s2_create failed)");
+  auto s2check = [&](int rc) { if (rc != RG_S2_OK) throw std::runtime_error(rg_s2_last_error(s2)); };
+
+  // blocks per chromosome (set_blocks_for_testing: ceil(n_chr / bsize))
+  std::map<int, std::vector<int64_t>> chr_snps;
+  for (size_t j = 0; j < r.snp_chrom.size(); ++j) chr_snps[r.snp_chrom[j]].push_back((int64_t)j);
+  int total_blocks = 0;
+  for (auto& kv : chr_snps) total_blocks += (int)((kv.second.size() + p.bsize - 1) / p.bsize);
+  sout << std::left << std::setw(20) << " * block size" << ": [" << p.bsize << "]\n";
+  sout << std::left << std::setw(20) << " * # blocks" << ": [" << total_blocks << "]\n";
+  sout << " * approximate memory usage : n/a (genotype blocks are tested on the GPU)\n";
+  sout << " * using minimum MAC of " << p.min_mac << " (variants with lower MAC are ignored)\n";
+
+  // output files, one per phenotype (split_by_pheno is the default; print_header_output_single, Step2_Models.cpp:2386-2398)
+  std::vector<std::unique_ptr<TextOut>> ofs;
+  std::vector<std::string> out_names;
+  for (int q = 0; q < P; ++q) {
+    out_names.push_back(p.out + "_" + r.pheno_names[q] + ".regenie" + (p.gz ? ".gz" : ""));
+    ofs.emplace_back(new TextOut(out_names.back(), p.gz));
+    if (!*ofs.back()) throw std::runtime_error("cannot write file : " + out_names.back());
+    *ofs.back() << "CHROM GENPOS ID ALLELE0 ALLELE1 A1FREQ N TEST BETA SE CHISQ LOG10P EXTRA\n";
+  }
+
+  const int fd = open((p.bed + ".bed").c_str(), O_RDONLY);
+  if (fd < 0) throw std::runtime_error("cannot read bed file");
+  std::vector<int64_t> file_idx(n, 0);          // file index of every analysed sample
+  {
+    int64_t kept = 0, k = 0;
+    for (int64_t i = 0; i < r.n_file && k < n; ++i) {
+      if (r.ind_ignore[i]) continue;
+      if (kept == an[k]) file_idx[k++] = i;
+      ++kept;
+    }
+  }
+  int nthreads = p.threads > 0 ? p.threads : std::max(1, (int)std::thread::hardware_concurrency() - 1);   // Regenie.cpp:1104-1106
+  nthreads = std::min(nthreads, 64);
+  // buildLookupTable (Geno.cpp:2833-2856): 00 -> 2, 01 -> missing (-3), 10 -> 1, 11 -> 0 copies of the first .bim allele
+  static const double lut[4] = {2.0, -3.0, 1.0, 0.0};
+  std::vector<uint8_t> rows;
+  std::vector<double> G, stats, bhat, sfac;
+  std::vector<int32_t> ign;
+  int64_t n_ignored_snps = 0, n_ignored_tests = 0, n_tested = 0;
+  int block = 0;
+  for (int chrom : r.chr_read) {
+    if (!chr_snps.count(chrom)) continue;
+    const std::vector<int64_t>& snps = chr_snps[chrom];
+    const int nb_chr = (int)((snps.size() + p.bsize - 1) / p.bsize);
+    sout << "Chromosome " << chrom << " [" << nb_chr << " blocks in total]\n";
+    // blup_read_chr (Step2_Models.cpp:51-140) + compute_res (Data.cpp:2386-2400)
+    sout << "   -reading loco predictions for the chromosome...";
+    auto tb = std::chrono::steady_clock::now();
+    for (int q = 0; q < P; ++q) {
+      Run::Blup& bl = r.blups[q];
+      if (chrom < 1 || chrom > (int)bl.line_off.size()) throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' has no line for chromosome " + std::to_string(chrom) + ".");
+      std::ifstream f(bl.file, std::ios::binary);
+      f.seekg(bl.line_off[chrom - 1]);
+      std::string line;
+      std::getline(f, line);
+      auto t = split_ws(line);
+      if (t.size() != bl.col_sample.size())
+        throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' has different number of entries on line " + std::to_string(chrom + 1) + " compared to the header (=" + std::to_string(t.size()) + " vs " + std::to_string(bl.col_sample.size()) + ").");
+      if (chr_str_to_int(t[0], p.nchrom) != chrom)
+        throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' starts with `" + t[0] + "`instead of chromosome number=" + std::to_string(chrom) + ".");
+      std::vector<double> blup(N, 0.0);
+      for (size_t c = 1; c < t.size(); ++c) {
+        const int64_t i = bl.col_sample[c];
+        if (i < 0 || !r.ain[i] || !r.mask[(size_t)q * N + i]) continue;
+        const double v = convert_double(t[c]);
+        if (v == MISSING) throw std::runtime_error("individual has missing predictions (chr=" + std::to_string(chrom) + ";phenotype=" + r.pheno_names[q] + ").");
+        blup[i] = v;
+      }
+      double ss = 0.0;
+      for (int64_t k = 0; k < n; ++k) {
+        const double v = (Yc[(size_t)q * n + k] - blup[an[k]]) * Mc[(size_t)q * n + k];
+        resc[(size_t)q * n + k] = v;
+        ss += v * v;
+      }
+      const double sd = std::sqrt(ss) / std::sqrt(r.neff[q] - C);
+      for (int64_t k = 0; k < n; ++k) resc[(size_t)q * n + k] /= sd;
+      scf[q] = r.scale_Y[q] * sd;
+    }
+    s2check(rg_s2_set_null(s2, Xc.data(), resc.data(), Mc.data(), scf.data()));
+    sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tb).count() << "ms) \n";
+
+    for (int bb = 0; bb < nb_chr; ++bb, ++block) {
+      const int64_t j0 = (int64_t)bb * p.bsize;
+      const int bs = (int)std::min<int64_t>(p.bsize, (int64_t)snps.size() - j0);
+      sout << " block [" << block + 1 << "/" << total_blocks << "] : ";
+      auto t1 = std::chrono::steady_clock::now();
+      rows.resize((size_t)bs * r.bpr);
+      for (int j = 0; j < bs;) {   // consecutive variants: one pread
+        int e = j + 1;
+        while (e < bs && r.snp_offset[snps[j0 + e]] == r.snp_offset[snps[j0 + e - 1]] + 1) ++e;
+        int64_t want = (int64_t)(e - j) * r.bpr, got = 0;
+        const int64_t off = 3 + r.snp_offset[snps[j0 + j]] * r.bpr;
+        while (got < want) {
+          const ssize_t k = pread(fd, rows.data() + (size_t)j * r.bpr + got, (size_t)(want - got), off + got);
+          if (k <= 0) throw std::runtime_error("cannot read bed file");
+          got += k;
+        }
+        j = e;
+      }
+      // parseSnpfromBed: decode the analysed samples, allele counts
+      G.assign((size_t)bs * n, 0.0);
+      std::vector<double> total(bs, 0.0);
+      std::vector<int64_t> ns1(bs, 0);
+      std::vector<double> af_t, mac_t;         // per trait (only filled when some sample is masked for some trait)
+      std::vector<int64_t> ns_t;
+      if (any_missing) { af_t.assign((size_t)bs * P, 0.0); mac_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0); }
+      std::vector<uint8_t> variant_ignored(bs, 0);
+      parallel_for(bs, nthreads, [&](int j) {
+        const uint8_t* row = rows.data() + (size_t)j * r.bpr;
+        double* g = G.data() + (size_t)j * n;
+        double tot = 0.0; int64_t ns = 0;
+        for (int64_t k = 0; k < n; ++k) {
+          const int64_t i = file_idx[k];
+          double hc = lut[(row[i >> 2] >> (2 * (i & 3))) & 3];
+          if (p.ref_first && hc != -3.0) hc = 2.0 - hc;
+          g[k] = hc;
+          if (hc != -3.0) {
+            tot += hc; ++ns;
+            if (any_missing && has_missing[k])   // update_trait_counts (Geno.cpp:2948-2959): subtract from the totals of the traits the sample is masked for
+              for (int q = 0; q < P; ++q)
+                if (!Mc[(size_t)q * n + k]) { af_t[(size_t)j * P + q] -= hc; mac_t[(size_t)j * P + q] -= hc; ns_t[(size_t)j * P + q] -= 1; }
+          }
+        }
+        total[j] = tot; ns1[j] = ns;
+        // compute_mac (Geno.cpp:3077-3108), autosomes
+        const double mac = std::min(tot, 2.0 * ns - tot);
+        if (mac < p.min_mac) variant_ignored[j] = 1;
+      });
+      rg_s2_qt_out o;
+      stats.resize((size_t)bs * P); bhat.resize((size_t)bs * P); sfac.resize(bs); ign.resize(bs);
+      o.stats = stats.data(); o.bhat = bhat.data(); o.scale_fac = sfac.data(); o.mean = nullptr; o.n_obs = nullptr; o.ignored = ign.data();
+      s2check(rg_s2_qt_block(s2, G.data(), n, bs, 0, NUMTOL, &o));
+      // the result lines (compute_score_qt after the statistic, Step2_Models.cpp:440-466; print_sum_stats_single)
+      for (int j = 0; j < bs; ++j) {
+        if (variant_ignored[j] || ign[j]) { ++n_ignored_snps; continue; }
+        const int64_t sj = snps[j0 + j];
+        std::ostringstream head;
+        head << r.snp_chrom[sj] << " " << r.snp_pos[sj] << " " << r.snp_ids[sj] << " " << r.snp_a0[sj] << " " << r.snp_a1[sj] << " ";
+        for (int q = 0; q < P; ++q) {
+          double af = total[j] / (2.0 * ns1[j]);
+          int64_t nsq = ns1[j];
+          if (any_missing) {   // compute_mac / compute_aaf_info per trait
+            const double tq = total[j] + af_t[(size_t)j * P + q];
+            nsq = ns1[j] + ns_t[(size_t)j * P + q];
+            const double macq = std::min(tq, 2.0 * nsq - tq);
+            if (macq < p.min_mac) { ++n_ignored_tests; continue; }
+            af = tq / (2.0 * nsq);
+          }
+          const double st = stats[(size_t)j * P + q], bh = bhat[(size_t)j * P + q];
+          const double se = bh / st, chisq = st * st, logp = get_logp(chisq);
+          std::ostringstream ln;
+          ln << head.str() << af << " " << nsq << " ADD ";
+          if (se >= 0 && !std::isnan(se)) ln << bh << ' ' << se;
+          else ln << "NA NA";
+          if (chisq >= 0 && !std::isnan(logp)) ln << ' ' << chisq << ' ' << logp;
+          else ln << " NA NA";
+          ln << " NA\n";
+          *ofs[q] << ln.str();
+          ++n_tested;
+        }
+      }
+      sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() << "ms) \n";
+    }
+  }
+  close(fd);
+  rg_s2_destroy(s2);
+  sout << "\nAssociation results stored separately for each trait in files : \n";
+  for (auto& fn : out_names) sout << "* [" << fn << "]\n";
+  sout << "\nNumber of ignored tests due to low MAC : " << n_ignored_snps * P + n_ignored_tests << "\n";
+  sout << "\nElapsed time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << "s\nEnd of run\n";
+  return 0;
+}
+
 int run(int argc, char** argv) {
   Run r;
   r.p = parse_args(argc, argv);
@@ -1264,7 +1580,11 @@ int run(int argc, char** argv) {
     sout << "\nEnd of run\n";
     return 0;
   }
+  auto since_start = [&]() { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count(); };
+  sout << "   -genotype metadata read (" << since_start() << "ms since start)\n";
   read_pheno_cov(r);
+  sout << "   -phenotypes and covariates ready (" << since_start() << "ms since start)\n";
+  if (p.step == 2) return run_step2(r, t_start);
   const int64_t N = r.N;
   const int P = r.P;
 
@@ -1365,6 +1685,7 @@ int run(int argc, char** argv) {
       throw std::runtime_error("no MI355X / HIP device available (rg_create failed for device " + std::to_string(p.single_device ? p.device : p.device + g) + ")");
     check(ctxs[g], rg_set_problem(ctxs[g], &pr));
   }
+  sout << "   -GPU context" << (G > 1 ? "s" : "") << " ready (" << since_start() << "ms since start)\n";
   rg_ctx* ctx = ctxs[0];
   rg_group* grp = nullptr;
   if (use_group) {
@@ -1421,9 +1742,15 @@ int run(int argc, char** argv) {
     const int NBUF = 3;
     struct Slot { uint8_t* mem = nullptr; int b0 = 0, nb = 0; double read_ms = 0; };
     std::vector<Slot> slots(NBUF);
+    // Page-locking costs ~0.6 s per GB (measured: the 2.4 GB ring of BASELINE configs[1] took the whole run from 0.95 s to
+    // 2.5 s), so the ring is pinned only when the rows to ingest are several times its size; smaller inputs go through
+    // pageable buffers (the runtime stages those copies itself) -- the reader thread overlaps the file reads either way.
+    const int64_t ring_bytes = (int64_t)NBUF * per * blk_bytes, total_bytes = (int64_t)(b_hi - b_lo) * blk_bytes;
+    bool pinned = total_bytes >= 4 * ring_bytes;
+    if (const char* e = getenv("RG_INGEST_PINNED")) pinned = atoi(e) != 0;
     for (auto& sl : slots) {
-      sl.mem = (uint8_t*)rg_host_alloc((int64_t)per * blk_bytes);
-      if (!sl.mem) throw std::runtime_error("cannot allocate page-locked memory for the genotype buffers");
+      sl.mem = pinned ? (uint8_t*)rg_host_alloc((int64_t)per * blk_bytes) : (uint8_t*)aligned_alloc(4096, (size_t)((int64_t)per * blk_bytes + 4095) / 4096 * 4096);
+      if (!sl.mem) throw std::runtime_error("cannot allocate memory for the genotype buffers");
     }
     std::mutex mu; std::condition_variable cv;
     std::deque<int> free_q, ready_q;
@@ -1535,7 +1862,7 @@ int run(int argc, char** argv) {
       lg << "   -level 0 ridge of blocks [" << b_lo + 1 << ".." << b_hi << "] complete (" <<
           std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() << "ms after the last batch was queued)\n";
     }
-    for (auto& sl : slots) rg_host_free(sl.mem);
+    for (auto& sl : slots) { if (pinned) rg_host_free(sl.mem); else free(sl.mem); }
     if (main_err) std::rethrow_exception(main_err);
   };
 
@@ -1750,6 +2077,7 @@ int run(int argc, char** argv) {
   sout << "   -level 1 for " << P << " phenotype(s) done ("
        << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tl0).count() << "ms)\n\n";
 
+  sout << "   -predictions written (" << since_start() << "ms since start)\n";
   // output (Data.cpp:956-1129): the per-phenotype tables and file lists in phenotype order
   sout << "Output\n------\n";
   std::ofstream plist(p.out + "_pred.list"), prslist;

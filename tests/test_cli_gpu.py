@@ -482,3 +482,41 @@ def test_cli_multi_gpu_bt_and_loocv(example_dir, tmp_path):
         for fn in ("o_1.loco", "o_2.loco"):
             assert res[name][fn] == res["plain"][fn], (name, fn)
         assert "0.4504" in [ln for ln in res[name]["_log"].splitlines() if "min value" in ln][1]
+
+
+# ---- --step 2 --qt: the driver's single-variant score test against regenie's own output ------------------------------------
+def test_cli_step2_qt_against_reference_output(example_dir, tmp_path):
+    """`regenie-amd --step 2 --qt --bed ... --pred <LOCO files written by regenie's own step 1>` against the .regenie files
+    regenie v4.1.2 wrote for the same command (tests/golden/ref_outputs/step2/qt_bed_3chr_Y*.regenie.gz, made by
+    oracle/_ref/regenie): identifying columns, A1FREQ and N as text, BETA / SE / CHISQ / LOG10P to the printed digits."""
+    import gzip
+    E = example_dir
+    R = os.path.join(ROOT, "tests", "golden", "ref_outputs")
+    with open(str(tmp_path / "pred.list"), "w") as pl:
+        for k in (1, 2):
+            fn = str(tmp_path / ("ref_%d.loco" % k))
+            open(fn, "wb").write(gzip.open(os.path.join(R, "qt_kfold_3chr", "out_%d.loco.gz" % k), "rb").read())
+            pl.write("Y%d %s\n" % (k, fn))
+    r = _run(["--step", "2", "--bed", os.path.join(E, "example_3chr"), "--phenoFile", os.path.join(E, "phenotype.txt"),
+              "--covarFile", os.path.join(E, "covariates.txt"), "--bsize", "200", "--qt", "--pred", str(tmp_path / "pred.list"),
+              "--out", "s2"], str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for k in (1, 2):
+        got = open(str(tmp_path / ("s2_Y%d.regenie" % k))).read().splitlines()
+        ref = gzip.open(os.path.join(R, "step2", "qt_bed_3chr_Y%d.regenie.gz" % k), "rt").read().splitlines()
+        assert got[0] == ref[0] and len(got) == len(ref) == 501
+        same = 0
+        for a, b in zip(got[1:], ref[1:]):
+            ta, tb = a.split(" "), b.split(" ")
+            assert ta[:8] == tb[:8] and ta[12] == tb[12] == "NA", (a, b)          # CHROM GENPOS ID ALLELE0 ALLELE1 A1FREQ N TEST ... EXTRA
+            for x, y in zip(ta[8:12], tb[8:12]):
+                assert float(x) == pytest.approx(float(y), rel=2e-5, abs=2e-9), (a, b)
+            same += a == b
+        assert same >= 450, same                                                   # most lines byte-identical
+
+
+def test_cli_step2_refuses_what_is_not_built(example_dir, tmp_path):
+    E = example_dir
+    r = _run(["--step", "2", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"), "--bt", "--bsize", "200",
+              "--pred", "x", "--out", "s2"], str(tmp_path))
+    assert r.returncode != 0 and "quantitative traits only" in r.stdout
