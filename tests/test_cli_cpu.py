@@ -22,7 +22,8 @@ def _log_until_device(args, cwd):
     out = r.stdout
     body = out[out.index("Fitting null model"):] if "Fitting null model" in out else out
     cut = body.find("ERROR: no MI355X")
-    return r, (body[:cut] if cut >= 0 else body)
+    body = body[:cut] if cut >= 0 else body
+    return r, "".join(ln for ln in body.splitlines(True) if "ms since start)" not in ln)     # wall-clock marks differ run to run
 
 
 def _no_gpu():
