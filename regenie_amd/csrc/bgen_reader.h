@@ -157,13 +157,20 @@ class Reader {
     if (!pread_all(&c, 4, v.data)) throw std::runtime_error("cannot read bgen file");
     const uint8_t* blk;
     size_t blen;
+    // a size taken from a corrupt record must not drive the allocations below: the encoding served (layout 2, biallelic,
+    // diploid, 8 bits) inflates to 10 + 3 n bytes, and no biallelic diploid block (up to 32 bits) exceeds 10 + 9 n; the
+    // exact layout checks (with their own messages) follow after decompression
+    const uint64_t most = 64 + 16 * (uint64_t)n_;
     if (comp_ == 0) {
+      if (c > most) throw std::runtime_error("genotype data block of variant " + v.rsid + " is larger than any biallelic diploid block of " + std::to_string(n_) + " samples");
       ubuf.resize(c);
       if (c && !pread_all(ubuf.data(), c, v.data + 4)) throw std::runtime_error("cannot read bgen file");
       blk = ubuf.data();
       blen = c;
     } else {
       if (c < 4 || !pread_all(&d, 4, v.data + 4)) throw std::runtime_error("failed to decompress genotype data block for variant: " + v.rsid);
+      if (d > most) throw std::runtime_error("genotype data block of variant " + v.rsid + " is larger than any biallelic diploid block of " + std::to_string(n_) + " samples");
+      if ((uint64_t)c > fsize_) throw std::runtime_error("failed to decompress genotype data block for variant: " + v.rsid);
       cbuf.resize(c - 4);
       if (c > 4 && !pread_all(cbuf.data(), c - 4, v.data + 8)) throw std::runtime_error("cannot read bgen file");
       ubuf.resize(d);

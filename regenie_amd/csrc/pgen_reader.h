@@ -104,7 +104,8 @@ class Reader {
     if (mode == 0x01) throw std::runtime_error("file is a PLINK1 bed file; pass it with --bed : " + path);
     if (mode == 0x03 || mode == 0x04) {
       dosage_ = true;
-      throw std::runtime_error("pgen file has dosages; the GPU path reads hardcall (2-bit) genotypes only : " + path);
+      throw std::runtime_error("pgen storage modes 0x03 / 0x04 (fixed-width unphased / phased dosages) are not decoded; files with per-variant "
+                               "dosage tracks (modes 0x10 / 0x11) are : " + path);
     }
     if (mode != 0x02 && mode != 0x10 && mode != 0x11)
       throw std::runtime_error("pgen storage mode is not supported : " + path);

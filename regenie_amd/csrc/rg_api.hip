@@ -241,6 +241,11 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   int nb = 64;
   if (const char* e = getenv("RG_NBLK")) nb = std::max(1, atoi(e));
   nb = std::min(nb, ctx->B_total);
+  {  // balanced batches: B blocks go in ceil(B / nb) batches of (almost) equal size -- the workspaces are sized for those,
+     // not for the cap (109 blocks: 2 x 55 instead of 64 + 45; allocation and first-touch time of the set-up scale with it)
+    const int nbatch = (ctx->B_total + nb - 1) / nb;
+    nb = (ctx->B_total + nbatch - 1) / nbatch;
+  }
   if (ctx->loocv) {  // bound the forward-substituted row storage (~24 GB)
     const double per_blk = 8.0 * ctx->n64 * ((double)ctx->R0 * ctx->rtot_wk + (double)Np);
     nb = (int)std::max(1.0, std::min((double)nb, 24e9 / per_blk));

@@ -308,7 +308,7 @@ struct rg_s2_ctx {
   uint8_t* dM = nullptr;
   void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int vpb = 4, ept = 8;   // tile of the two streaming kernels
+  int vpb = DEFAULT_VPB, ept = DEFAULT_EPT;   // tile of the two streaming kernels (resolved in rg_s2_create)
   double last_ms = 0.0;
   std::string err;
 };
@@ -407,8 +407,8 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
   const int C = ctx->C, P = ctx->P, Q1 = 2 + 2 * C, Q2 = 1 + 2 * P;
   int vpb = ctx->vpb, ept = ctx->ept;
   size_t lds1 = sizeof(double) * 4 * vpb * Q1, lds2 = sizeof(double) * ((size_t)vpb * C + vpb + 4 * (size_t)vpb * (Q2 + 1));
-  if (lds1 > 60 * 1024 || lds2 > 60 * 1024) {   // many covariates / phenotypes: the narrow tile always fits (<= 17 KB)
-    vpb = 4; ept = 8;
+  if (lds1 > 60 * 1024 || lds2 > 60 * 1024) {   // many covariates / phenotypes: the documented default tile always fits (<= 17 KB)
+    vpb = DEFAULT_VPB; ept = DEFAULT_EPT;
     lds1 = sizeof(double) * 4 * vpb * Q1; lds2 = sizeof(double) * ((size_t)vpb * C + vpb + 4 * (size_t)vpb * (Q2 + 1));
   }
   const int nchunk = (int)((n + 256 * ept - 1) / (256 * ept));

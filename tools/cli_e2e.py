@@ -54,18 +54,19 @@ def main(N=50000, M=100000, bs=1000):
     del dd, code, c, packed
     torch.cuda.empty_cache()
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "regenie_amd", "bin", "regenie-amd")
-    for rep in range(2):
+    variants = [("default", {}), ("default", {}), ("default", {}), ("RG_NBLK=28", {"RG_NBLK": "28"}), ("RG_NBLK=28", {"RG_NBLK": "28"}),
+                ("RG_PIPELINES=1", {"RG_PIPELINES": "1"}), ("RG_PIPELINES=1", {"RG_PIPELINES": "1"}),
+                ("RG_INGEST_PINNED=1", {"RG_INGEST_PINNED": "1"}), ("sleep 3 s first", {})]
+    for name, env in variants:
+        if name.startswith("sleep"):
+            time.sleep(3)
         t0 = time.time()
         r = subprocess.run([exe, "--step", "1", "--bed", d + "/x", "--phenoFile", d + "/x.pheno", "--covarFile", d + "/x.covar", "--bsize", str(bs),
-                            "--out", d + "/out"], capture_output=True, text=True)
+                            "--out", d + "/out"], capture_output=True, text=True, env=dict(os.environ, **env))
         dt = time.time() - t0
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        l0 = [ln for ln in r.stdout.split("\n") if "level 0 ridge on GPU" in ln]
-        gpu_ms = sum(int(ln.split("level 0 ridge on GPU ")[1].split("ms")[0]) for ln in l0)
-        rd_ms = sum(int(ln.split("(read ")[1].split("ms")[0]) for ln in l0)
-        l1 = [ln for ln in r.stdout.split("\n") if "level 1 for" in ln]
-        print("run %d: wall %.2f s  = %.2e SNP*sample*pheno/s end to end;  .bed reads %d ms, level 0 (PCIe + GPU) %d ms, %s" % (
-            rep, dt, M * N / dt, rd_ms, gpu_ms, l1[0].strip() if l1 else ""), flush=True)
+        marks = [ln.strip() for ln in r.stdout.split("\n") if "since start" in ln or "level 1 for" in ln or "complete (" in ln]
+        print("%-22s wall %.2f s = %.2e SNP*sample*pheno/s end to end | %s" % (name, dt, M * N / dt, " | ".join(marks)), flush=True)
 
 
 if __name__ == "__main__":
