@@ -7,6 +7,7 @@
 // with G~ = G0 + D_mu M decoded on the fly from the cleaned 2-bit rows, so the standardised
 // genotype matrix is never materialised (the reference allocates bs x N doubles per block).
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include "rg_internal.h"
 
@@ -405,6 +406,10 @@ void rg_launch_l0_pred_impl(hipStream_t st, const PredArgs& a, const ChunkTab& c
     nchunk = c1k.n;
     if (a.R0 <= 5) hipLaunchKernelGGL(k_l0_pred<5>, dim3(c1k.n, a.P, a.nblk), dim3(256), 0, st, a, c1k);
     else hipLaunchKernelGGL(k_l0_pred<8>, dim3(c1k.n, a.P, a.nblk), dim3(256), 0, st, a, c1k);
+  } else if (mb >= 2 && a.bplanes && a.n128 <= 1024 && !getenv("RG_PRED_F64")) {
+    // many rows: exact fixed-point split of the coefficients on the i8 matrix cores (pred_i8.hip); RG_PRED_F64=1 keeps fp64
+    nchunk = c256.n;
+    rg_launch_l0_pred_i8(st, a, c256, pg, ngrp, a.bplanes, a.bsc, a.pkT);
   } else {
     nchunk = c256.n;
     const dim3 grid(c256.n, ngrp, a.nblk);

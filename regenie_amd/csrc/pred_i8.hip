@@ -1,0 +1,232 @@
+// Level-0 out-of-fold predictions for many (phenotype, ridge value) rows on the i8 matrix cores, exactly.
+//
+// out[m][pos] = sum_j beta~_m[j] * g~_j(pos)  is the (R0*P) x bs x N contraction of ridge_level_0
+// (reference src/Step1_Models.cpp:496-511: pred = beta^T G_fold), 5*10^10 multiply-adds per block at
+// 500,000 samples and 10 phenotypes -- the largest kernel of BASELINE configs[2] on the fp64 matrix cores
+// (k_l0_pred_mfma, pred.hip: 96 of 236 ms per step and GPU).  The genotype operand is an exact small integer
+// (dosage 0/1/2, missing indicator 0/1), so the fp64 operand can be taken apart instead of rounded:
+//
+//   * every coefficient row is written in fixed point against its own largest entry, 2^e > max_j |beta~_m[j]|:
+//     q_j = rint(beta~_m[j] * 2^(54-e)), |q_j| < 2^54, and q_j is split into eight balanced base-128 digits
+//     d_k[j] in [-64, 63] (k_beta_split) -- int8 planes;
+//   * S_k[m][pos] = sum_j d_k[m][j] * g_j(pos) runs on v_mfma_i32_32x32x32_i8 with int32 accumulation, EXACT
+//     (|S_k| <= 64 * 2 * bs < 2^31);
+//   * out = 2^(e-54) * sum_k 128^k S_k in fp64: each term is exact, the eight-term sum rounds at 2^-53.
+//   The only approximation is the truncation of beta~ at 2^-54 of the row's largest coefficient: an absolute error
+//   below bs * 2 * 2^-55 * max|beta~| per prediction, the size of the rounding an fp64 dot product of bs terms
+//   carries anyway.  No tolerance changes anywhere: the parity tests stay at 1e-8.
+//   Missing calls are mean-imputed by the same route: a second plane set holds the digits of beta~_m[j] * mu_j and is
+//   contracted with the missing indicator (only for blocks that have missing calls).
+//
+// Layout: the contraction index is the SNP, so the kernel reads a SNP-contiguous copy of the block's cleaned 2-bit
+// rows (k_pk_transpose: pkT [pos][n128/4 bytes], four SNPs per byte) -- one dword per lane and MFMA, expanded to
+// sixteen int8 with v_perm_b32 as a byte LUT (the idiom of gram_i8.hip).  A wave owns 32 positions and keeps their expanded
+// genotype operand for 512 SNPs at a time (16 x 16 bytes per lane) in registers across the 8 digit planes; the coefficient
+// digits of one (row tile, plane, half) are staged in LDS per workgroup (32 rows x 512 bytes) and shared by its eight waves.  Epilogue as in pred.hip: covariate term, mask, store, per-row sums in a fixed order.
+#include <algorithm>
+#include "rg_internal.h"
+
+#define PI8_NPIECE 8
+#define PI8_ROWS 64                 // rows (phenotype, ridge value) of a group, two MFMA row tiles
+#define PI8_KMAX 1024               // SNPs per block served (n128 <= 1024); larger blocks keep the fp64 kernel
+#define PI8_KHALF 512                // SNPs whose expanded genotype operand a lane holds in registers at a time
+#define PI8_PITCH (PI8_KHALF + 16)  // LDS row pitch of the staged digit plane: 16 consecutive rows on distinct bank groups
+#define LUT_DOSAGE 0x00010002u      // cleaned 2-bit code -> dosage (00 -> 2, 01 -> missing = 0 here, 10 -> 1, 11 -> 0)
+#define LUT_MISS 0x00000100u        //                     -> missing indicator
+
+// ---- SNP-contiguous copy of the cleaned packed rows: pkT[blk][pos][j / 4], two bits per SNP -----------------------------
+// grid (Np / 64, n128 / 64, nblk); a 64 SNP x 64 position tile through LDS
+__global__ __launch_bounds__(256) void k_pk_transpose(const uint8_t* __restrict__ pk, int64_t pk_ld, int64_t pk_blk_stride, int n128,
+                                                      int64_t Np, uint8_t* __restrict__ pkT) {
+  __shared__ uint8_t s[64][16 + 1];
+  const int blk = blockIdx.z, j0 = blockIdx.y * 64;
+  const int64_t pos0 = (int64_t)blockIdx.x * 64;
+  const uint8_t* src = pk + (int64_t)blk * pk_blk_stride + (int64_t)j0 * pk_ld + pos0 / 4;
+  {
+    const int j = threadIdx.x >> 2, b4 = (threadIdx.x & 3) * 4;        // 64 rows x 16 bytes, a dword per thread
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(src + (int64_t)j * pk_ld + b4);
+    s[j][b4] = (uint8_t)w; s[j][b4 + 1] = (uint8_t)(w >> 8); s[j][b4 + 2] = (uint8_t)(w >> 16); s[j][b4 + 3] = (uint8_t)(w >> 24);
+  }
+  __syncthreads();
+  const int pl = threadIdx.x >> 2, dw = threadIdx.x & 3;               // output: 64 positions x 4 dwords (16 SNPs each)
+  const int sh = 2 * (pl & 3), pb = pl >> 2;
+  uint32_t o = 0;
+#pragma unroll
+  for (int v = 0; v < 16; ++v) o |= (uint32_t)((s[16 * dw + v][pb] >> sh) & 3u) << (2 * v);
+  uint8_t* dst = pkT + ((int64_t)blk * Np + pos0 + pl) * (n128 / 4) + j0 / 4 + dw * 4;
+  *reinterpret_cast<uint32_t*>(dst) = o;
+}
+
+// ---- fixed-point digit planes of the coefficient rows ------------------------------------------------------------------
+// grid (PI8_ROWS, nseg * ngrp, nblk), 256 threads: one row m of one (block, fold, phenotype group).
+// planes [blk][s][grp][set][k][m][n128] int8 (set 0: beta~, set 1: beta~ * mu), psc [blk][s][grp][set][m] = 2^(e-54).
+__global__ __launch_bounds__(256) void k_beta_split(PredArgs a, int pg, int ngrp, int8_t* __restrict__ planes, double* __restrict__ psc) {
+  __shared__ double red[2][4];
+  __shared__ double smax[2];
+  const int m = blockIdx.x, s = blockIdx.y / ngrp, grp = blockIdx.y % ngrp, blk = blockIdx.z;
+  const int p0 = grp * pg, npg = min(pg, a.P - p0), nrow = npg * a.R0;
+  const int R0 = a.R0, nm = a.nseg * R0;
+  const int bs = a.bs[blk];
+  const bool live = m < nrow;
+  const int pl = live ? m / R0 : 0, r = live ? m % R0 : 0;
+  const double* be = a.beta + (((int64_t)blk * nm + s * R0 + r) * a.P + p0 + pl) * a.n64;
+  const double* mu = a.mu + (int64_t)blk * a.n128;
+  const bool has_miss = a.nmiss[blk] > 0;
+  double mx0 = 0.0, mx1 = 0.0;
+  for (int j = threadIdx.x; j < a.n128; j += 256) {
+    const double b = (live && j < bs) ? be[j] : 0.0;
+    mx0 = fmax(mx0, fabs(b));
+    mx1 = fmax(mx1, fabs(b * mu[min(j, a.n128 - 1)]));
+  }
+  for (int o = 32; o > 0; o >>= 1) { mx0 = fmax(mx0, __shfl_down(mx0, o)); mx1 = fmax(mx1, __shfl_down(mx1, o)); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = mx0; red[1][threadIdx.x >> 6] = mx1; }
+  __syncthreads();
+  if (threadIdx.x < 2) smax[threadIdx.x] = fmax(fmax(red[threadIdx.x][0], red[threadIdx.x][1]), fmax(red[threadIdx.x][2], red[threadIdx.x][3]));
+  __syncthreads();
+  const int64_t grp_idx = ((int64_t)blk * a.nseg + s) * ngrp + grp;
+  for (int set = 0; set < 2; ++set) {
+    if (set == 1 && !has_miss) break;
+    const double mx = smax[set];
+    int e = 0;
+    if (mx > 0.0) { (void)frexp(mx, &e); }              // mx = f * 2^e, 0.5 <= f < 1  =>  |b| < 2^e
+    const double up = mx > 0.0 ? ldexp(1.0, 54 - e) : 0.0;
+    if (threadIdx.x == 0) psc[(grp_idx * 2 + set) * PI8_ROWS + m] = mx > 0.0 ? ldexp(1.0, e - 54) : 0.0;
+    int8_t* pl0 = planes + ((grp_idx * 2 + set) * PI8_NPIECE) * (int64_t)PI8_ROWS * a.n128 + (int64_t)m * a.n128;
+    for (int j = threadIdx.x; j < a.n128; j += 256) {
+      double b = (live && j < bs) ? be[j] : 0.0;
+      if (set == 1) b *= mu[j];
+      long long q = llrint(b * up);                     // |q| <= 2^54
+#pragma unroll
+      for (int k = 0; k < PI8_NPIECE; ++k) {
+        const int d = (int)(((q & 127) ^ 64) - 64);     // balanced digit in [-64, 63]
+        pl0[(int64_t)k * PI8_ROWS * a.n128 + j] = (int8_t)d;
+        q = (q - d) >> 7;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned pi8_expand4(unsigned b, unsigned lut) {
+  unsigned x = b | (b << 6);
+  x = x | (x << 12);
+  x &= 0x03030303u;
+  return __builtin_amdgcn_perm(lut, lut, x);
+}
+
+// ---- the contraction + epilogue ------------------------------------------------------------------------------------------
+// grid (n_c256, ngrp, nblk), 512 threads = 8 waves x 32 positions (a chunk is 256 positions of one fold)
+__global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int pg, int ngrp, const int8_t* __restrict__ planes,
+                                                    const double* __restrict__ psc, const uint8_t* __restrict__ pkT) {
+  __shared__ __attribute__((aligned(16))) int8_t sA[32 * PI8_PITCH];
+  __shared__ double sred[8][PI8_ROWS][2];
+  const int blk = blockIdx.z, ch = blockIdx.x, grp = blockIdx.y, p0 = grp * pg;
+  const int npg = min(pg, a.P - p0), nrow = npg * a.R0;
+  const int s = ct.seg[ch];
+  const int64_t pos0 = ct.pos[ch];
+  const int R0 = a.R0, nm = a.nseg * R0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 31, kb = lane >> 5;
+  const int64_t pos = pos0 + wave * 32 + c;
+  const bool has_miss = a.nmiss[blk] > 0;
+  const int n128 = a.n128, nstep = n128 / 32;          // MFMA K steps of 32 SNPs
+  const int64_t grp_idx = ((int64_t)blk * a.nseg + s) * ngrp + grp;
+  const uint8_t* brow = pkT + ((int64_t)blk * a.Np + pos) * (n128 / 4);
+
+  const int col0 = a.blockid[blk] * R0;
+#pragma unroll 1
+  for (int tile = 0; tile < 2; ++tile) {
+    if (tile * 32 >= nrow) break;                       // no live row in the second tile
+    double out[16];                                     // rows tile*32 + (reg&3) + 8*(reg>>2) + 4*kb, position pos
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[r] = 0.0;
+#pragma unroll 1
+    for (int set = 0; set < 2; ++set) {
+      if (set == 1 && !has_miss) break;
+      const unsigned lut = set == 0 ? LUT_DOSAGE : LUT_MISS;
+      const double* scrow = psc + (grp_idx * 2 + set) * PI8_ROWS + tile * 32 + 4 * kb;   // the rows' 2^(e-54)
+#pragma unroll 1
+      for (int half = 0; half * PI8_KHALF < n128; ++half) {
+        const int nst = min(PI8_KHALF / 32, nstep - half * (PI8_KHALF / 32));            // K steps of this half
+        // this lane's genotype operand for the half: SNPs 32 t + 16 kb .. + 15 of its position, sixteen int8 per step
+        v4i bf[PI8_KHALF / 32];
+#pragma unroll
+        for (int t = 0; t < PI8_KHALF / 32; ++t) {
+          const int tc = half * (PI8_KHALF / 32) + (t < nst ? t : nst - 1);              // steps past the width are never multiplied
+          const uint32_t w = *reinterpret_cast<const uint32_t*>(brow + 8 * tc + 4 * kb);
+          bf[t] = (v4i){(int)pi8_expand4(w & 0xFFu, lut), (int)pi8_expand4((w >> 8) & 0xFFu, lut),
+                        (int)pi8_expand4((w >> 16) & 0xFFu, lut), (int)pi8_expand4(w >> 24, lut)};
+        }
+        double w128 = 1.0;
+#pragma unroll 1
+        for (int k = 0; k < PI8_NPIECE; ++k) {
+          __syncthreads();
+          {  // stage 32 rows x (this half's) digits of plane k: 16-byte pieces, coalesced along the SNP index
+            const int8_t* src = planes + ((grp_idx * 2 + set) * PI8_NPIECE + k) * (int64_t)PI8_ROWS * n128 + (int64_t)tile * 32 * n128 +
+                                half * PI8_KHALF;
+            const int per_row = nst * 2;
+            for (int e = threadIdx.x; e < 32 * per_row; e += 512) {
+              const int row = e / per_row, pc = e - row * per_row;
+              *reinterpret_cast<uint4*>(sA + row * PI8_PITCH + pc * 16) = *reinterpret_cast<const uint4*>(src + (int64_t)row * n128 + pc * 16);
+            }
+          }
+          __syncthreads();
+          v16i acc;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] = 0;
+          const int8_t* arow = sA + c * PI8_PITCH + 16 * kb;
+#pragma unroll
+          for (int t = 0; t < PI8_KHALF / 32; ++t) {
+            if (t < nst) {
+              const v4i af = *reinterpret_cast<const v4i*>(arow + 32 * t);
+              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[t], acc, 0, 0, 0);
+            }
+          }
+          // S_k * 128^k * 2^(e-54): the two factors are powers of two, their product with the integer sum is exact
+#pragma unroll
+          for (int r = 0; r < 16; ++r) out[r] = fma((double)acc[r], w128 * scrow[(r & 3) + 8 * (r >> 2)], out[r]);
+          w128 *= 128.0;
+        }
+      }
+    }
+    // ---- epilogue of the tile: covariate term, mask, store, per-row sums (as pred.hip) ----------------------------------
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+      const bool live = m < nrow;
+      const int mc = live ? m : 0;
+      const int pl = mc / R0, rr = mc % R0;
+      const double* cb = a.cb + (((int64_t)blk * nm + s * R0 + rr) * a.P + p0 + pl) * a.C;
+      double corr = 0.0;
+      for (int cc = 0; cc < a.C; ++cc) corr = fma(cb[cc], a.V[(int64_t)cc * a.Np + pos], corr);
+      const double mk = a.maskp[(int64_t)(p0 + pl) * a.Np + pos];
+      const double v = live ? (out[r] - corr) * mk : 0.0;
+      if (live) a.W[((int64_t)(col0 + rr) * a.P + p0 + pl) * a.Np + pos] = v;
+      double sx = v, sq = v * v;
+#pragma unroll
+      for (int o = 1; o < 32; o <<= 1) {                 // the 32 positions of this half-wave, fixed butterfly order
+        sx += __shfl_xor(sx, o, 32);
+        sq += __shfl_xor(sq, o, 32);
+      }
+      if (c == 0) { sred[wave][m][0] = sx; sred[wave][m][1] = sq; }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nrow * 2) {
+    const int m = threadIdx.x >> 1, q = threadIdx.x & 1;
+    const int pl = m / R0, rr = m % R0;
+    double tsum = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tsum += sred[w][m][q];
+    a.psum[((((int64_t)blk * ct.n + ch) * a.P + p0 + pl) * 8 + rr) * 2 + q] = tsum;
+  }
+}
+
+// planes: nblk * nseg * ngrp * 2 * 8 * 64 * n128 bytes; psc: nblk * nseg * ngrp * 2 * 64 doubles; pkT: nblk * Np * n128 / 4 bytes
+void rg_launch_l0_pred_i8(hipStream_t st, const PredArgs& a, const ChunkTab& c256, int pg, int ngrp, int8_t* planes, double* psc,
+                          uint8_t* pkT) {
+  hipLaunchKernelGGL(k_pk_transpose, dim3((unsigned)(a.Np / 64), a.n128 / 64, a.nblk), dim3(256), 0, st, a.pk, a.pk_ld, a.pk_blk_stride,
+                     a.n128, a.Np, pkT);
+  hipLaunchKernelGGL(k_beta_split, dim3(PI8_ROWS, a.nseg * ngrp, a.nblk), dim3(256), 0, st, a, pg, ngrp, planes, psc);
+  hipLaunchKernelGGL(k_l0_pred_i8, dim3(c256.n, ngrp, a.nblk), dim3(512), 0, st, a, c256, pg, ngrp, (const int8_t*)planes,
+                     (const double*)psc, (const uint8_t*)pkT);
+}

@@ -29,7 +29,7 @@ void free_all(rg_ctx* c) {
                   c->d_xypart, c->d_chunk_seg, c->d_chunk_pos, c->d_chunk_len, c->d_S, c->d_F, c->d_Bm,
                   c->d_BQ, c->d_GYt, c->d_sc, c->d_fold, c->d_sum, c->d_wk, c->d_dinv, c->d_beta,
                   c->d_cb, c->d_psum, c->d_pstat, c->d_info, c->d_bs, c->d_blockid, (void*)c->d_rawptr, c->d_c1k_seg, c->d_c1k_pos,
-                  c->d_c1k_len, c->d_c256_seg, c->d_c256_pos, c->d_c256_len, c->d_gt, c->d_lpart};
+                  c->d_c1k_len, c->d_c256_seg, c->d_c256_pos, c->d_c256_len, c->d_gt, c->d_lpart, c->d_bplanes, c->d_bsc, c->d_pkT};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->own_W && c->d_W) hipFree(c->d_W);
@@ -283,6 +283,17 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if ((rc = dev_alloc(ctx, &ctx->d_beta, (size_t)nb * nseg * R0 * P * n64))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_cb, (size_t)nb * nseg * R0 * P * C))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_psum, (size_t)nb * ctx->n_c256 * P * 8 * 2))) return rc;
+  // many (phenotype, ridge value) rows: the exact i8 route of the predictions (pred_i8.hip) needs digit planes and a
+  // SNP-contiguous copy of the packed rows; few rows (one phenotype) stay on the fp64 VALU kernel
+  if (ctx->d_bplanes) { hipFree(ctx->d_bplanes); ctx->d_bplanes = nullptr; }
+  if (ctx->d_bsc) { hipFree(ctx->d_bsc); ctx->d_bsc = nullptr; }
+  if (ctx->d_pkT) { hipFree(ctx->d_pkT); ctx->d_pkT = nullptr; }
+  if (!ctx->loocv && P * R0 > 16 && R0 <= 8 && n128 <= 1024) {
+    const int pg = std::max(1, std::min(P, 64 / R0)), ngrp = (P + pg - 1) / pg;
+    if ((rc = dev_alloc(ctx, &ctx->d_bplanes, (size_t)nb * nseg * ngrp * 2 * 8 * 64 * n128))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_bsc, (size_t)nb * nseg * ngrp * 2 * 64))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_pkT, (size_t)nb * Np * (n128 / 4)))) return rc;
+  }
   if ((rc = dev_alloc(ctx, &ctx->d_pstat, (size_t)nb * P * 8 * 2))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_bs, (size_t)nb))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_blockid, (size_t)nb))) return rc;
@@ -457,6 +468,7 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     pa.Bm = ctx->d_Bm; pa.wk = ctx->d_wk; pa.V = ctx->d_V; pa.maskp = ctx->d_maskp;
     pa.keptp = ctx->d_keptp; pa.bs = ctx->d_bs; pa.blockid = ctx->d_blockid; pa.neff = ctx->d_neff; pa.nmiss = ctx->d_nmiss;
     pa.beta = ctx->d_beta; pa.cb = ctx->d_cb; pa.psum = ctx->d_psum; pa.W = rg_w_base(ctx);
+    pa.bplanes = ctx->d_bplanes; pa.bsc = ctx->d_bsc; pa.pkT = ctx->d_pkT;
     rg_launch_l0_pred_impl(st, pa, ChunkTab{ctx->d_c1k_seg, ctx->d_c1k_pos, ctx->d_c1k_len, ctx->n_c1k},
                            ChunkTab{ctx->d_c256_seg, ctx->d_c256_pos, ctx->d_c256_len, ctx->n_c256}, ctx->d_pstat);
   }

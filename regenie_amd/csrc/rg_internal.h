@@ -107,6 +107,9 @@ struct rg_ctx {
   double* d_dinv = nullptr;      // [nblk*nseg*R0][n64/64][64*64]
   double* d_beta = nullptr;      // [nblk][nseg*R0][P][n64]  beta / scale_G
   double* d_cb = nullptr;        // [nblk][nseg*R0][P][C]
+  int8_t* d_bplanes = nullptr;   // pred_i8.hip: digit planes [nblk][nseg][ngrp][2][8][64][n128]
+  double* d_bsc = nullptr;       //              row scales   [nblk][nseg][ngrp][2][64]
+  uint8_t* d_pkT = nullptr;      //              SNP-contiguous packed rows [nblk][Np][n128/4]
   double* d_psum = nullptr;      // [nblk][n_c256][P][8][2]
   double* d_pstat = nullptr;     // [nblk][P][8][2] column mean and 1/sd
   int32_t* d_info = nullptr;     // [4] deferred error flags: [0]=low variance, [1]=not SPD
@@ -254,9 +257,13 @@ struct PredArgs {
   const double* V; const double* maskp; const uint8_t* keptp; const int32_t* bs;
   const int32_t* blockid; const double* neff; const int32_t* nmiss;
   double *beta, *cb, *psum, *W;
+  // exact i8 route of the many-row predictions (pred_i8.hip); null = not available for this problem
+  int8_t* bplanes = nullptr; double* bsc = nullptr; uint8_t* pkT = nullptr;
 };
 struct ChunkTab { const int32_t* seg; const int64_t* pos; const int64_t* len; int n; };
 void rg_launch_l0_pred_impl(hipStream_t st, const PredArgs& a, const ChunkTab& c1k, const ChunkTab& c256, double* stats);
+void rg_launch_l0_pred_i8(hipStream_t st, const PredArgs& a, const ChunkTab& c256, int pg, int ngrp, int8_t* planes, double* psc,
+                          uint8_t* pkT);
 void rg_launch_w_gather(hipStream_t st, const double* W, int64_t Np, int P, int p, int col0, int R0,
                         const int64_t* posc, int64_t N, double* out);
 void rg_launch_w_scatter(hipStream_t st, double* W, int64_t Np, int P, int p, int col0, int R0,

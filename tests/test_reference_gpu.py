@@ -183,8 +183,10 @@ def test_driver_vs_oracle_at_500k_samples(kind, tmp_path):
         mag = np.maximum(np.abs(got[ok]), 1e-300)       # the text's own decade (0.0999996 prints as 0.1)
         ulp = 10.0 ** (np.floor(np.log10(mag)) - 5)
         # the text rounds the driver's value (half a unit) and the driver agrees with the oracle to ~1e-8 (QT) / ~1e-6 (the
-        # iterative logistic fits): within one unit of the last printed digit, and the metric of BASELINE.json below
-        assert float(np.max(np.abs(got[ok] - ref[ok]) / ulp)) <= 1.0, (kind, ph)
+        # iterative logistic fits) OF THE COLUMN'S SCALE: within one unit of the last printed digit, except for entries that are
+        # tiny against the scale (a LOCO value of 1e-8 carries the absolute rounding of sums of order 1); then BASELINE's metric
+        tol = np.maximum(ulp, 1e-9 * np.max(np.abs(ref[ok])))
+        assert float(np.max(np.abs(got[ok] - ref[ok]) / tol)) <= 1.0, (kind, ph)
         worst = max(worst, e)
     assert worst < 1e-5, worst
     print("%s: LOCO max-rel-err vs the oracle (6-digit text) %.2e" % (kind, worst))

@@ -79,6 +79,35 @@ def test_many_phenotypes_matrix_core_predictions(tmp_path, P):
     _compare(orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=110))
 
 
+def test_many_phenotypes_fp64_matrix_core_kernel_kept(tmp_path, monkeypatch):
+    """RG_PRED_F64=1 keeps the fp64-MFMA prediction kernel (pred.hip) instead of the exact i8 digit route (pred_i8.hip)."""
+    monkeypatch.setenv("RG_PRED_F64", "1")
+    N, M = 1100, 420
+    g = synth_dosages(M, N, miss_rate=0.02, seed=38)
+    pre = str(tmp_path / "mp")
+    write_plink(pre, g, np.repeat([1, 4, 9], [150, 150, 120]), P=7, ncov=2, seed=14, missing_pheno=0.04)
+    _compare(orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=110))
+
+
+def test_many_phenotypes_full_width_blocks(tmp_path):
+    """The i8 digit route at the block width of the BASELINE configurations (1,000 SNPs: two 512-SNP register passes per
+    position), with and without missing calls in a block, against the oracle and against the fp64 kernel."""
+    N, M = 900, 1600
+    g = synth_dosages(M, N, miss_rate=0.0, seed=77)
+    g[1000:] = synth_dosages(600, N, miss_rate=0.03, seed=78)       # the second block has missing calls, the first has none
+    pre = str(tmp_path / "fw")
+    write_plink(pre, g, np.repeat([1, 2], [1000, 600]), P=6, ncov=2, seed=9, missing_pheno=0.03)
+    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=1000)
+    ref, got = _compare(opt)
+    os.environ["RG_PRED_F64"] = "1"
+    try:
+        got64 = gpu_step1(opt)
+    finally:
+        del os.environ["RG_PRED_F64"]
+    for ph in range(6):
+        assert rel_err(got["W"][ph], got64["W"][ph]) < 1e-12
+
+
 def test_ref_first_and_three_folds(tmp_path):
     N, M = 640, 256
     g = synth_dosages(M, N, miss_rate=0.01, seed=5)
