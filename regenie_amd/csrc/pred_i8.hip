@@ -35,26 +35,30 @@
 #define LUT_MISS 0x00000100u        //                     -> missing indicator
 
 // ---- SNP-contiguous copy of the cleaned packed rows: pkT[blk][pos][j / 4], two bits per SNP -----------------------------
-// grid (Np / 64, n128 / 64, nblk); a 64 SNP x 64 position tile through LDS
+// grid (Np / 128, n128 / 128, nblk); a 128 SNP x 128 position tile through LDS: 32-byte pieces on both sides
 __global__ __launch_bounds__(256) void k_pk_transpose(const uint8_t* __restrict__ pk, int64_t pk_ld, int64_t pk_blk_stride, int n128,
                                                       int64_t Np, uint8_t* __restrict__ pkT) {
-  __shared__ uint8_t s[64][16 + 1];
-  const int blk = blockIdx.z, j0 = blockIdx.y * 64;
-  const int64_t pos0 = (int64_t)blockIdx.x * 64;
+  __shared__ __attribute__((aligned(16))) uint8_t s[128][32 + 16];
+  const int blk = blockIdx.z, j0 = blockIdx.y * 128;
+  const int64_t pos0 = (int64_t)blockIdx.x * 128;
   const uint8_t* src = pk + (int64_t)blk * pk_blk_stride + (int64_t)j0 * pk_ld + pos0 / 4;
   {
-    const int j = threadIdx.x >> 2, b4 = (threadIdx.x & 3) * 4;        // 64 rows x 16 bytes, a dword per thread
-    const uint32_t w = *reinterpret_cast<const uint32_t*>(src + (int64_t)j * pk_ld + b4);
-    s[j][b4] = (uint8_t)w; s[j][b4 + 1] = (uint8_t)(w >> 8); s[j][b4 + 2] = (uint8_t)(w >> 16); s[j][b4 + 3] = (uint8_t)(w >> 24);
+    const int j = threadIdx.x >> 1, h = threadIdx.x & 1;               // 128 rows x 32 bytes, 16 bytes per thread
+    *reinterpret_cast<uint4*>(&s[j][16 * h]) = *reinterpret_cast<const uint4*>(src + (int64_t)j * pk_ld + 16 * h);
   }
   __syncthreads();
-  const int pl = threadIdx.x >> 2, dw = threadIdx.x & 3;               // output: 64 positions x 4 dwords (16 SNPs each)
+  const int pl = threadIdx.x >> 1, hh = threadIdx.x & 1;               // output: 128 positions x 32 bytes, 16 bytes (64 SNPs) per thread
   const int sh = 2 * (pl & 3), pb = pl >> 2;
-  uint32_t o = 0;
+  uint32_t o[4];
 #pragma unroll
-  for (int v = 0; v < 16; ++v) o |= (uint32_t)((s[16 * dw + v][pb] >> sh) & 3u) << (2 * v);
-  uint8_t* dst = pkT + ((int64_t)blk * Np + pos0 + pl) * (n128 / 4) + j0 / 4 + dw * 4;
-  *reinterpret_cast<uint32_t*>(dst) = o;
+  for (int d = 0; d < 4; ++d) {
+    uint32_t w = 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) w |= (uint32_t)((s[64 * hh + 16 * d + v][pb] >> sh) & 3u) << (2 * v);
+    o[d] = w;
+  }
+  uint8_t* dst = pkT + ((int64_t)blk * Np + pos0 + pl) * (n128 / 4) + j0 / 4 + 16 * hh;
+  *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
 // ---- fixed-point digit planes of the coefficient rows ------------------------------------------------------------------
@@ -114,11 +118,15 @@ __device__ __forceinline__ unsigned pi8_expand4(unsigned b, unsigned lut) {
 }
 
 // ---- the contraction + epilogue ------------------------------------------------------------------------------------------
-// grid (n_c256, ngrp, nblk), 512 threads = 8 waves x 32 positions (a chunk is 256 positions of one fold)
+// grid (n_c256, ngrp, nblk), 512 threads = 8 waves x 32 positions (a chunk is 256 positions of one fold).
+// LDS: the eight digit planes of one (row tile, set, half): 8 x 32 rows x 512 bytes (+ pad) = 132 KB, staged once per round, so a
+// round is one pair of barriers and 8 x 16 back-to-back MFMAs per wave.
+#define PI8_PLANE (32 * PI8_PITCH)
 __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int pg, int ngrp, const int8_t* __restrict__ planes,
                                                     const double* __restrict__ psc, const uint8_t* __restrict__ pkT) {
-  __shared__ __attribute__((aligned(16))) int8_t sA[32 * PI8_PITCH];
-  __shared__ double sred[8][PI8_ROWS][2];
+  extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+  int8_t* sA = smem;                                                       // [8 planes][32 rows][PI8_PITCH]
+  double (*sred)[PI8_ROWS][2] = reinterpret_cast<double (*)[PI8_ROWS][2]>(smem + PI8_NPIECE * PI8_PLANE);   // [8 waves][64][2]
   const int blk = blockIdx.z, ch = blockIdx.x, grp = blockIdx.y, p0 = grp * pg;
   const int npg = min(pg, a.P - p0), nrow = npg * a.R0;
   const int s = ct.seg[ch];
@@ -131,7 +139,6 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
   const int n128 = a.n128, nstep = n128 / 32;          // MFMA K steps of 32 SNPs
   const int64_t grp_idx = ((int64_t)blk * a.nseg + s) * ngrp + grp;
   const uint8_t* brow = pkT + ((int64_t)blk * a.Np + pos) * (n128 / 4);
-
   const int col0 = a.blockid[blk] * R0;
 #pragma unroll 1
   for (int tile = 0; tile < 2; ++tile) {
@@ -143,10 +150,26 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
     for (int set = 0; set < 2; ++set) {
       if (set == 1 && !has_miss) break;
       const unsigned lut = set == 0 ? LUT_DOSAGE : LUT_MISS;
-      const double* scrow = psc + (grp_idx * 2 + set) * PI8_ROWS + tile * 32 + 4 * kb;   // the rows' 2^(e-54)
+      double sc[16];                                    // the rows' 2^(e-54)
+      {
+        const double* scrow = psc + (grp_idx * 2 + set) * PI8_ROWS + tile * 32 + 4 * kb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = scrow[(r & 3) + 8 * (r >> 2)];
+      }
 #pragma unroll 1
       for (int half = 0; half * PI8_KHALF < n128; ++half) {
         const int nst = min(PI8_KHALF / 32, nstep - half * (PI8_KHALF / 32));            // K steps of this half
+        __syncthreads();
+        {  // stage 8 planes x 32 rows x (this half's) digits: 16-byte pieces, coalesced along the SNP index
+          const int8_t* src = planes + ((grp_idx * 2 + set) * PI8_NPIECE) * (int64_t)PI8_ROWS * n128 + (int64_t)tile * 32 * n128 + half * PI8_KHALF;
+          const int per_row = nst * 2, per_plane = 32 * per_row;
+          for (int e = threadIdx.x; e < PI8_NPIECE * per_plane; e += 512) {
+            const int k = e / per_plane, e2 = e - k * per_plane;
+            const int row = e2 / per_row, pc = e2 - row * per_row;
+            *reinterpret_cast<uint4*>(sA + k * PI8_PLANE + row * PI8_PITCH + pc * 16) =
+                *reinterpret_cast<const uint4*>(src + (int64_t)k * PI8_ROWS * n128 + (int64_t)row * n128 + pc * 16);
+          }
+        }
         // this lane's genotype operand for the half: SNPs 32 t + 16 kb .. + 15 of its position, sixteen int8 per step
         v4i bf[PI8_KHALF / 32];
 #pragma unroll
@@ -156,24 +179,14 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
           bf[t] = (v4i){(int)pi8_expand4(w & 0xFFu, lut), (int)pi8_expand4((w >> 8) & 0xFFu, lut),
                         (int)pi8_expand4((w >> 16) & 0xFFu, lut), (int)pi8_expand4(w >> 24, lut)};
         }
+        __syncthreads();
         double w128 = 1.0;
 #pragma unroll 1
         for (int k = 0; k < PI8_NPIECE; ++k) {
-          __syncthreads();
-          {  // stage 32 rows x (this half's) digits of plane k: 16-byte pieces, coalesced along the SNP index
-            const int8_t* src = planes + ((grp_idx * 2 + set) * PI8_NPIECE + k) * (int64_t)PI8_ROWS * n128 + (int64_t)tile * 32 * n128 +
-                                half * PI8_KHALF;
-            const int per_row = nst * 2;
-            for (int e = threadIdx.x; e < 32 * per_row; e += 512) {
-              const int row = e / per_row, pc = e - row * per_row;
-              *reinterpret_cast<uint4*>(sA + row * PI8_PITCH + pc * 16) = *reinterpret_cast<const uint4*>(src + (int64_t)row * n128 + pc * 16);
-            }
-          }
-          __syncthreads();
           v16i acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0;
-          const int8_t* arow = sA + c * PI8_PITCH + 16 * kb;
+          const int8_t* arow = sA + k * PI8_PLANE + c * PI8_PITCH + 16 * kb;
 #pragma unroll
           for (int t = 0; t < PI8_KHALF / 32; ++t) {
             if (t < nst) {
@@ -183,31 +196,46 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
           }
           // S_k * 128^k * 2^(e-54): the two factors are powers of two, their product with the integer sum is exact
 #pragma unroll
-          for (int r = 0; r < 16; ++r) out[r] = fma((double)acc[r], w128 * scrow[(r & 3) + 8 * (r >> 2)], out[r]);
+          for (int r = 0; r < 16; ++r) out[r] = fma((double)acc[r], w128 * sc[r], out[r]);
           w128 *= 128.0;
         }
       }
     }
     // ---- epilogue of the tile: covariate term, mask, store, per-row sums (as pred.hip) ----------------------------------
+    {
+      double corr[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
-      const bool live = m < nrow;
-      const int mc = live ? m : 0;
-      const int pl = mc / R0, rr = mc % R0;
-      const double* cb = a.cb + (((int64_t)blk * nm + s * R0 + rr) * a.P + p0 + pl) * a.C;
-      double corr = 0.0;
-      for (int cc = 0; cc < a.C; ++cc) corr = fma(cb[cc], a.V[(int64_t)cc * a.Np + pos], corr);
-      const double mk = a.maskp[(int64_t)(p0 + pl) * a.Np + pos];
-      const double v = live ? (out[r] - corr) * mk : 0.0;
-      if (live) a.W[((int64_t)(col0 + rr) * a.P + p0 + pl) * a.Np + pos] = v;
-      double sx = v, sq = v * v;
+      for (int r = 0; r < 16; ++r) corr[r] = 0.0;
+      for (int c0 = 0; c0 < a.C; c0 += 4) {             // covariate values of this position, four at a time
+        double xv[4];
 #pragma unroll
-      for (int o = 1; o < 32; o <<= 1) {                 // the 32 positions of this half-wave, fixed butterfly order
-        sx += __shfl_xor(sx, o, 32);
-        sq += __shfl_xor(sq, o, 32);
+        for (int u = 0; u < 4; ++u) xv[u] = a.V[(int64_t)min(c0 + u, a.C - 1) * a.Np + pos] * (c0 + u < a.C ? 1.0 : 0.0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+          const int mc = m < nrow ? m : 0;
+          const double* cb = a.cb + (((int64_t)blk * nm + s * R0 + mc % R0) * a.P + p0 + mc / R0) * a.C;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) corr[r] = fma(cb[min(c0 + u, a.C - 1)], xv[u], corr[r]);
+        }
       }
-      if (c == 0) { sred[wave][m][0] = sx; sred[wave][m][1] = sq; }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+        const bool live = m < nrow;
+        const int mc = live ? m : 0;
+        const int pl = mc / R0, rr = mc % R0;
+        const double mk = a.maskp[(int64_t)(p0 + pl) * a.Np + pos];
+        const double v = live ? (out[r] - corr[r]) * mk : 0.0;
+        if (live) a.W[((int64_t)(col0 + rr) * a.P + p0 + pl) * a.Np + pos] = v;
+        double sx = v, sq = v * v;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {                 // the 32 positions of this half-wave, fixed butterfly order
+          sx += __shfl_xor(sx, o, 32);
+          sq += __shfl_xor(sq, o, 32);
+        }
+        if (c == 0) { sred[wave][m][0] = sx; sred[wave][m][1] = sq; }
+      }
     }
   }
   __syncthreads();
@@ -224,9 +252,12 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
 // planes: nblk * nseg * ngrp * 2 * 8 * 64 * n128 bytes; psc: nblk * nseg * ngrp * 2 * 64 doubles; pkT: nblk * Np * n128 / 4 bytes
 void rg_launch_l0_pred_i8(hipStream_t st, const PredArgs& a, const ChunkTab& c256, int pg, int ngrp, int8_t* planes, double* psc,
                           uint8_t* pkT) {
-  hipLaunchKernelGGL(k_pk_transpose, dim3((unsigned)(a.Np / 64), a.n128 / 64, a.nblk), dim3(256), 0, st, a.pk, a.pk_ld, a.pk_blk_stride,
+  hipLaunchKernelGGL(k_pk_transpose, dim3((unsigned)(a.Np / 128), a.n128 / 128, a.nblk), dim3(256), 0, st, a.pk, a.pk_ld, a.pk_blk_stride,
                      a.n128, a.Np, pkT);
   hipLaunchKernelGGL(k_beta_split, dim3(PI8_ROWS, a.nseg * ngrp, a.nblk), dim3(256), 0, st, a, pg, ngrp, planes, psc);
-  hipLaunchKernelGGL(k_l0_pred_i8, dim3(c256.n, ngrp, a.nblk), dim3(512), 0, st, a, c256, pg, ngrp, (const int8_t*)planes,
+  const size_t lds = (size_t)PI8_NPIECE * PI8_PLANE + sizeof(double) * 8 * PI8_ROWS * 2;     // 135,168 + 8,192 bytes
+  // more than 64 KB of dynamic LDS needs the attribute; set per launch (it is per device, and a process may drive several)
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_l0_pred_i8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_l0_pred_i8, dim3(c256.n, ngrp, a.nblk), dim3(512), lds, st, a, c256, pg, ngrp, (const int8_t*)planes,
                      (const double*)psc, (const uint8_t*)pkT);
 }
