@@ -121,7 +121,11 @@ __device__ __forceinline__ unsigned pi8_expand4(unsigned b, unsigned lut) {
 // grid (n_c256, ngrp, nblk), 512 threads = 8 waves x 32 positions (a chunk is 256 positions of one fold).
 // LDS: the eight digit planes of one (row tile, set, half): 8 x 32 rows x 512 bytes (+ pad) = 132 KB, staged once per round, so a
 // round is one pair of barriers and 8 x 16 back-to-back MFMAs per wave.
+// FULL: every half is 512 SNPs wide (n128 a multiple of 512: the block widths of the BASELINE configurations) -- trip counts
+// are then compile-time constants and the loops carry no predicates (a predicate per MFMA put every MFMA into its own basic
+// block, which kept the scheduler from moving the LDS reads of the next step above it).
 #define PI8_PLANE (32 * PI8_PITCH)
+template <bool FULL>
 __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int pg, int ngrp, const int8_t* __restrict__ planes,
                                                     const double* __restrict__ psc, const uint8_t* __restrict__ pkT) {
   extern __shared__ __attribute__((aligned(16))) int8_t smem[];
@@ -158,23 +162,33 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
       }
 #pragma unroll 1
       for (int half = 0; half * PI8_KHALF < n128; ++half) {
-        const int nst = min(PI8_KHALF / 32, nstep - half * (PI8_KHALF / 32));            // K steps of this half
+        const int nst = FULL ? PI8_KHALF / 32 : min(PI8_KHALF / 32, nstep - half * (PI8_KHALF / 32));   // K steps of this half
         __syncthreads();
-        {  // stage 8 planes x 32 rows x (this half's) digits: 16-byte pieces, coalesced along the SNP index
+        {  // stage 8 planes x 32 rows x (this half's) digits: 16-byte pieces, coalesced along the SNP index.  All loads of a
+           // thread are issued before its first LDS store (a load -> store loop with a run-time trip count is one memory
+           // round trip per iteration: 64 of them per workgroup were ~3/4 of this kernel's time)
           const int8_t* src = planes + ((grp_idx * 2 + set) * PI8_NPIECE) * (int64_t)PI8_ROWS * n128 + (int64_t)tile * 32 * n128 + half * PI8_KHALF;
-          const int per_row = nst * 2, per_plane = 32 * per_row;
-          for (int e = threadIdx.x; e < PI8_NPIECE * per_plane; e += 512) {
-            const int k = e / per_plane, e2 = e - k * per_plane;
-            const int row = e2 / per_row, pc = e2 - row * per_row;
-            *reinterpret_cast<uint4*>(sA + k * PI8_PLANE + row * PI8_PITCH + pc * 16) =
-                *reinterpret_cast<const uint4*>(src + (int64_t)k * PI8_ROWS * n128 + (int64_t)row * n128 + pc * 16);
+          const int per_row = nst * 2;                  // 16-byte pieces per row; a plane has 32 * per_row, all 8 planes 256 * per_row
+          uint4 v[PI8_KHALF / 32];
+          int dst[PI8_KHALF / 32];
+#pragma unroll
+          for (int it = 0; it < PI8_KHALF / 32; ++it) {   // 256 * per_row pieces over 512 threads: per_row / 2 = nst each
+            const int e = threadIdx.x + 512 * it;
+            const int rowk = e / per_row, pc = e - rowk * per_row;       // rowk = k * 32 + row
+            const int k = rowk >> 5, row = rowk & 31;
+            const bool on = FULL || it < nst;
+            v[it] = *reinterpret_cast<const uint4*>(src + (int64_t)(on ? k : 0) * PI8_ROWS * n128 + (int64_t)(on ? row : 0) * n128 + (on ? pc : 0) * 16);
+            dst[it] = on ? k * PI8_PLANE + row * PI8_PITCH + pc * 16 : -1;
           }
+#pragma unroll
+          for (int it = 0; it < PI8_KHALF / 32; ++it)
+            if (FULL || dst[it] >= 0) *reinterpret_cast<uint4*>(sA + dst[it]) = v[it];
         }
         // this lane's genotype operand for the half: SNPs 32 t + 16 kb .. + 15 of its position, sixteen int8 per step
         v4i bf[PI8_KHALF / 32];
 #pragma unroll
         for (int t = 0; t < PI8_KHALF / 32; ++t) {
-          const int tc = half * (PI8_KHALF / 32) + (t < nst ? t : nst - 1);              // steps past the width are never multiplied
+          const int tc = half * (PI8_KHALF / 32) + ((FULL || t < nst) ? t : nst - 1);   // steps past the width are never multiplied
           const uint32_t w = *reinterpret_cast<const uint32_t*>(brow + 8 * tc + 4 * kb);
           bf[t] = (v4i){(int)pi8_expand4(w & 0xFFu, lut), (int)pi8_expand4((w >> 8) & 0xFFu, lut),
                         (int)pi8_expand4((w >> 16) & 0xFFu, lut), (int)pi8_expand4(w >> 24, lut)};
@@ -189,7 +203,7 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
           const int8_t* arow = sA + k * PI8_PLANE + c * PI8_PITCH + 16 * kb;
 #pragma unroll
           for (int t = 0; t < PI8_KHALF / 32; ++t) {
-            if (t < nst) {
+            if (FULL || t < nst) {
               const v4i af = *reinterpret_cast<const v4i*>(arow + 32 * t);
               acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[t], acc, 0, 0, 0);
             }
@@ -257,7 +271,13 @@ void rg_launch_l0_pred_i8(hipStream_t st, const PredArgs& a, const ChunkTab& c25
   hipLaunchKernelGGL(k_beta_split, dim3(PI8_ROWS, a.nseg * ngrp, a.nblk), dim3(256), 0, st, a, pg, ngrp, planes, psc);
   const size_t lds = (size_t)PI8_NPIECE * PI8_PLANE + sizeof(double) * 8 * PI8_ROWS * 2;     // 135,168 + 8,192 bytes
   // more than 64 KB of dynamic LDS needs the attribute; set per launch (it is per device, and a process may drive several)
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k_l0_pred_i8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_l0_pred_i8, dim3(c256.n, ngrp, a.nblk), dim3(512), lds, st, a, c256, pg, ngrp, (const int8_t*)planes,
-                     (const double*)psc, (const uint8_t*)pkT);
+  if (a.n128 % PI8_KHALF == 0) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_l0_pred_i8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_l0_pred_i8<true>, dim3(c256.n, ngrp, a.nblk), dim3(512), lds, st, a, c256, pg, ngrp, (const int8_t*)planes,
+                       (const double*)psc, (const uint8_t*)pkT);
+  } else {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_l0_pred_i8<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_l0_pred_i8<false>, dim3(c256.n, ngrp, a.nblk), dim3(512), lds, st, a, c256, pg, ngrp, (const int8_t*)planes,
+                       (const double*)psc, (const uint8_t*)pkT);
+  }
 }

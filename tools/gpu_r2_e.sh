@@ -1,8 +1,8 @@
 #!/bin/bash
 # round-2 GPU session E: the exact i8 prediction route (pred_i8.hip): parity tests, config-3 per-GPU share, kernel stats
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r2f
-O=gpurun_out/r2f
+mkdir -p gpurun_out/r2g
+O=gpurun_out/r2g
 ( time timeout 900 python -m pytest tests/test_step1_gpu.py tests/test_reference_gpu.py tests/test_distributed_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x 2>&1 | tail -40 ) > $O/pytest.log 2>&1
 timeout 600 python bench.py --samples 500000 --snps 62500 --phenos 10 --no-cpu --steps 3 --warmup 1 > $O/config3_share.json 2> $O/config3_share.err
 RG_PRED_F64=1 timeout 600 python bench.py --samples 500000 --snps 62500 --phenos 10 --no-cpu --steps 3 --warmup 1 > $O/config3_share_f64.json 2>> $O/config3_share.err
