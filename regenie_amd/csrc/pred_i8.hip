@@ -19,7 +19,7 @@
 //   contracted with the missing indicator (only for blocks that have missing calls).
 //
 // Layout: the contraction index is the SNP, so the kernel reads a SNP-contiguous copy of the block's cleaned 2-bit
-// rows (k_pk_transpose: pkT [pos][n128/4 bytes], four SNPs per byte) -- one dword per lane and MFMA, expanded to
+// rows (k_pk_transpose: 16 SNPs per dword, stored in the order the lanes of a wave read them) -- one dword per lane and MFMA, expanded to
 // sixteen int8 with v_perm_b32 as a byte LUT (the idiom of gram_i8.hip).  A wave owns 32 positions and keeps their expanded
 // genotype operand for 512 SNPs at a time (16 x 16 bytes per lane) in registers across the 8 digit planes; the coefficient
 // digits of one (row tile, plane, half) are staged in LDS per workgroup (32 rows x 512 bytes) and shared by its eight waves.  Epilogue as in pred.hip: covariate term, mask, store, per-row sums in a fixed order.
@@ -57,8 +57,16 @@ __global__ __launch_bounds__(256) void k_pk_transpose(const uint8_t* __restrict_
     for (int v = 0; v < 16; ++v) w |= (uint32_t)((s[64 * hh + 16 * d + v][pb] >> sh) & 3u) << (2 * v);
     o[d] = w;
   }
-  uint8_t* dst = pkT + ((int64_t)blk * Np + pos0 + pl) * (n128 / 4) + j0 / 4 + 16 * hh;
-  *reinterpret_cast<uint4*>(dst) = make_uint4(o[0], o[1], o[2], o[3]);
+  // lane-ordered layout for the prediction kernel: dword (pos, SNP group of 16 = (t, kb)) at
+  //   (((blk * Np/32 + pos/32) * (n128/32) + t) * 2 + kb) * 32 + pos%32   -- a wave's operand load for one K step is 256 contiguous bytes
+  uint32_t* out32 = reinterpret_cast<uint32_t*>(pkT);
+  const int64_t pg32 = (pos0 + pl) >> 5;
+  const int cc = (int)((pos0 + pl) & 31);
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const int sg = (j0 + 64 * hh + 16 * d) >> 4;          // SNP group of 16: t = sg >> 1, kb = sg & 1
+    out32[((((int64_t)blk * (Np >> 5) + pg32) * (n128 >> 5) + (sg >> 1)) * 2 + (sg & 1)) * 32 + cc] = o[d];
+  }
 }
 
 // ---- fixed-point digit planes of the coefficient rows ------------------------------------------------------------------
@@ -131,6 +139,8 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
   extern __shared__ __attribute__((aligned(16))) int8_t smem[];
   int8_t* sA = smem;                                                       // [8 planes][32 rows][PI8_PITCH]
   double (*sred)[PI8_ROWS][2] = reinterpret_cast<double (*)[PI8_ROWS][2]>(smem + PI8_NPIECE * PI8_PLANE);   // [8 waves][64][2]
+  __shared__ double scb[PI8_ROWS][16 + 1];             // cb of the group's rows, 16 covariates at a time
+  __shared__ int srow_w[PI8_ROWS], srow_p[PI8_ROWS];   // W row (col0 + r) * P + p and phenotype of every row m (-1: dead)
   const int blk = blockIdx.z, ch = blockIdx.x, grp = blockIdx.y, p0 = grp * pg;
   const int npg = min(pg, a.P - p0), nrow = npg * a.R0;
   const int s = ct.seg[ch];
@@ -142,8 +152,16 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
   const bool has_miss = a.nmiss[blk] > 0;
   const int n128 = a.n128, nstep = n128 / 32;          // MFMA K steps of 32 SNPs
   const int64_t grp_idx = ((int64_t)blk * a.nseg + s) * ngrp + grp;
-  const uint8_t* brow = pkT + ((int64_t)blk * a.Np + pos) * (n128 / 4);
+  // this lane's dword of K step t: ((pos group * nstep + t) * 2 + kb) * 32 + c  (k_pk_transpose)
+  const uint32_t* brow = reinterpret_cast<const uint32_t*>(pkT) + (((int64_t)blk * (a.Np >> 5) + (pos >> 5)) * nstep) * 64 + kb * 32 + c;
   const int col0 = a.blockid[blk] * R0;
+  if (threadIdx.x < PI8_ROWS) {
+    const int m = threadIdx.x;
+    const bool live = m < nrow;
+    const int pl = live ? m / R0 : 0, rr = live ? m % R0 : 0;
+    srow_w[m] = live ? (col0 + rr) * a.P + p0 + pl : -1;
+    srow_p[m] = p0 + pl;
+  }
 #pragma unroll 1
   for (int tile = 0; tile < 2; ++tile) {
     if (tile * 32 >= nrow) break;                       // no live row in the second tile
@@ -189,7 +207,7 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
 #pragma unroll
         for (int t = 0; t < PI8_KHALF / 32; ++t) {
           const int tc = half * (PI8_KHALF / 32) + ((FULL || t < nst) ? t : nst - 1);   // steps past the width are never multiplied
-          const uint32_t w = *reinterpret_cast<const uint32_t*>(brow + 8 * tc + 4 * kb);
+          const uint32_t w = brow[(int64_t)tc * 64];
           bf[t] = (v4i){(int)pi8_expand4(w & 0xFFu, lut), (int)pi8_expand4((w >> 8) & 0xFFu, lut),
                         (int)pi8_expand4((w >> 16) & 0xFFu, lut), (int)pi8_expand4(w >> 24, lut)};
         }
@@ -220,28 +238,30 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
       double corr[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) corr[r] = 0.0;
-      for (int c0 = 0; c0 < a.C; c0 += 4) {             // covariate values of this position, four at a time
-        double xv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xv[u] = a.V[(int64_t)min(c0 + u, a.C - 1) * a.Np + pos] * (c0 + u < a.C ? 1.0 : 0.0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+      for (int c0 = 0; c0 < a.C; c0 += 16) {            // 16 covariates at a time: their products cb[m][c] through LDS
+        __syncthreads();
+        for (int e = threadIdx.x; e < 32 * 16; e += 512) {
+          const int ml = e >> 4, cc = e & 15, m = tile * 32 + ml;
           const int mc = m < nrow ? m : 0;
           const double* cb = a.cb + (((int64_t)blk * nm + s * R0 + mc % R0) * a.P + p0 + mc / R0) * a.C;
+          scb[ml][cc] = (c0 + cc < a.C && m < nrow) ? cb[c0 + cc] : 0.0;
+        }
+        __syncthreads();
+        const int ncc = min(16, a.C - c0);
+        for (int cc = 0; cc < ncc; ++cc) {
+          const double xv = a.V[(int64_t)(c0 + cc) * a.Np + pos];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) corr[r] = fma(cb[min(c0 + u, a.C - 1)], xv[u], corr[r]);
+          for (int r = 0; r < 16; ++r) corr[r] = fma(scb[(r & 3) + 8 * (r >> 2) + 4 * kb][cc], xv, corr[r]);
         }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
-        const bool live = m < nrow;
-        const int mc = live ? m : 0;
-        const int pl = mc / R0, rr = mc % R0;
-        const double mk = a.maskp[(int64_t)(p0 + pl) * a.Np + pos];
+        const int wrow = srow_w[m];
+        const bool live = wrow >= 0;
+        const double mk = a.maskp[(int64_t)srow_p[m] * a.Np + pos];
         const double v = live ? (out[r] - corr[r]) * mk : 0.0;
-        if (live) a.W[((int64_t)(col0 + rr) * a.P + p0 + pl) * a.Np + pos] = v;
+        if (live) a.W[(int64_t)wrow * a.Np + pos] = v;
         double sx = v, sq = v * v;
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) {                 // the 32 positions of this half-wave, fixed butterfly order

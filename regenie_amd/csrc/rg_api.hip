@@ -29,7 +29,7 @@ void free_all(rg_ctx* c) {
                   c->d_xypart, c->d_chunk_seg, c->d_chunk_pos, c->d_chunk_len, c->d_S, c->d_F, c->d_Bm,
                   c->d_BQ, c->d_GYt, c->d_sc, c->d_fold, c->d_sum, c->d_wk, c->d_dinv, c->d_beta,
                   c->d_cb, c->d_psum, c->d_pstat, c->d_info, c->d_bs, c->d_blockid, (void*)c->d_rawptr, c->d_c1k_seg, c->d_c1k_pos,
-                  c->d_c1k_len, c->d_c256_seg, c->d_c256_pos, c->d_c256_len, c->d_gt, c->d_lpart, c->d_bplanes, c->d_bsc, c->d_pkT};
+                  c->d_c1k_len, c->d_c256_seg, c->d_c256_pos, c->d_c256_len, c->d_gt, c->d_lpart, c->d_bplanes, c->d_bsc, c->d_pkT, c->d_vd, c->d_vsc, c->d_xyS, c->d_segid};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->own_W && c->d_W) hipFree(c->d_W);
@@ -283,6 +283,21 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if ((rc = dev_alloc(ctx, &ctx->d_beta, (size_t)nb * nseg * R0 * P * n64))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_cb, (size_t)nb * nseg * R0 * P * C))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_psum, (size_t)nb * ctx->n_c256 * P * 8 * 2))) return rc;
+  // G~X / G~Y on the i8 matrix cores (xy_i8.hip): digit planes of V = [X | Y], once per problem (RG_XY_F64=1 keeps the fp64 kernel)
+  if (ctx->d_vd) { hipFree(ctx->d_vd); ctx->d_vd = nullptr; }
+  if (ctx->d_vsc) { hipFree(ctx->d_vsc); ctx->d_vsc = nullptr; }
+  if (ctx->d_xyS) { hipFree(ctx->d_xyS); ctx->d_xyS = nullptr; }
+  if (ctx->d_segid) { hipFree(ctx->d_segid); ctx->d_segid = nullptr; }
+  if (Cv * 8 <= 128 && !getenv("RG_XY_F64")) {
+    if ((rc = dev_alloc(ctx, &ctx->d_vd, (size_t)Cv * 8 * Np))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_vsc, (size_t)Cv))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_xyS, (size_t)nb * 2 * nseg * n128 * 128))) return rc;
+    std::vector<int32_t> ids(nseg);
+    for (int f = 0; f < nseg; ++f) ids[f] = f;
+    if ((rc = dev_upload(ctx, &ctx->d_segid, ids))) return rc;
+    rg_launch_v_split(ctx->stream, ctx->d_V, Np, Cv, ctx->d_vd, ctx->d_vsc);
+    RG_HIP(hipStreamSynchronize(ctx->stream));
+  }
   // many (phenotype, ridge value) rows: the exact i8 route of the predictions (pred_i8.hip) needs digit planes and a
   // SNP-contiguous copy of the packed rows; few rows (one phenotype) stay on the fp64 VALU kernel
   if (ctx->d_bplanes) { hipFree(ctx->d_bplanes); ctx->d_bplanes = nullptr; }
@@ -407,8 +422,12 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
   }
   {
     StageTimer t(ctx, &ctx->tm.ms_xy);
-    rg_launch_geno_xy(st, ctx->d_pk, ctx->pk_ld, pk_blk, ctx->d_bs, ctx->d_nmiss, nblk, n128, ctx->d_V, ctx->Np, Cv,
-                      ctx->d_chunk_pos, ctx->d_chunk_len, ctx->xy_nchunk, ctx->d_xypart);
+    if (ctx->d_vd)
+      rg_launch_xy_i8(st, ctx->d_pk, ctx->pk_ld, pk_blk, ctx->d_bs, ctx->d_nmiss, nblk, n128, ctx->seg, ctx->d_vd, ctx->d_vsc, ctx->Np, Cv,
+                      ctx->d_xyS, ctx->d_xypart);
+    else
+      rg_launch_geno_xy(st, ctx->d_pk, ctx->pk_ld, pk_blk, ctx->d_bs, ctx->d_nmiss, nblk, n128, ctx->d_V, ctx->Np, Cv,
+                        ctx->d_chunk_pos, ctx->d_chunk_len, ctx->xy_nchunk, ctx->d_xypart);
   }
   {
     StageTimer t(ctx, &ctx->tm.ms_gram);
@@ -422,8 +441,8 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     StageTimer t(ctx, &ctx->tm.ms_assemble);
     AsmArgs a;
     a.nblk = nblk; a.nseg = nseg; a.n128 = n128; a.n64 = n64; a.rtot = rtot; a.C = C; a.P = P; a.Cv = Cv;
-    a.nchunk = ctx->xy_nchunk; a.n_analyzed = ctx->n_analyzed; a.bs = ctx->d_bs;
-    a.chunk_seg = ctx->d_chunk_seg; a.part = ctx->d_xypart; a.mu = ctx->d_mu; a.S = ctx->d_S;
+    a.nchunk = ctx->d_vd ? nseg : ctx->xy_nchunk; a.n_analyzed = ctx->n_analyzed; a.bs = ctx->d_bs;
+    a.chunk_seg = ctx->d_vd ? ctx->d_segid : ctx->d_chunk_seg; a.part = ctx->d_xypart; a.mu = ctx->d_mu; a.S = ctx->d_S;
     a.nmiss = ctx->d_nmiss; a.Q = ctx->d_Q; a.XtY = ctx->d_XtY; a.F = ctx->d_F; a.Bm = ctx->d_Bm;
     a.BQ = ctx->d_BQ; a.GYt = ctx->d_GYt; a.sc = ctx->d_sc; a.fold = ctx->d_fold; a.sum = ctx->d_sum;
     a.info = ctx->d_info;

@@ -107,6 +107,10 @@ struct rg_ctx {
   double* d_dinv = nullptr;      // [nblk*nseg*R0][n64/64][64*64]
   double* d_beta = nullptr;      // [nblk][nseg*R0][P][n64]  beta / scale_G
   double* d_cb = nullptr;        // [nblk][nseg*R0][P][C]
+  int8_t* d_vd = nullptr;        // xy_i8.hip: digit planes of V = [X | Y]  [Cv][8][Np]
+  double* d_vsc = nullptr;       //            column scales [Cv]
+  int32_t* d_xyS = nullptr;      //            integer sums [nblk][2][nseg][n128][128]
+  int32_t* d_segid = nullptr;    //            [nseg] = 0 .. nseg-1 (the per-fold partials are read with chunk == fold)
   int8_t* d_bplanes = nullptr;   // pred_i8.hip: digit planes [nblk][nseg][ngrp][2][8][64][n128]
   double* d_bsc = nullptr;       //              row scales   [nblk][nseg][ngrp][2][64]
   uint8_t* d_pkT = nullptr;      //              SNP-contiguous packed rows [nblk][Np][n128/4]
@@ -262,6 +266,11 @@ struct PredArgs {
 };
 struct ChunkTab { const int32_t* seg; const int64_t* pos; const int64_t* len; int n; };
 void rg_launch_l0_pred_impl(hipStream_t st, const PredArgs& a, const ChunkTab& c1k, const ChunkTab& c256, double* stats);
+// xy_i8.hip
+void rg_launch_v_split(hipStream_t st, const double* V, int64_t Np, int Cv, int8_t* vd, double* vsc);
+void rg_launch_xy_i8(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs, const int32_t* nmiss,
+                     int nblk, int n128, const SegLayout& seg, const int8_t* vd, const double* vsc, int64_t Np, int Cv, int32_t* S32,
+                     double* part);
 void rg_launch_l0_pred_i8(hipStream_t st, const PredArgs& a, const ChunkTab& c256, int pg, int ngrp, int8_t* planes, double* psc,
                           uint8_t* pkT);
 void rg_launch_w_gather(hipStream_t st, const double* W, int64_t Np, int P, int p, int col0, int R0,

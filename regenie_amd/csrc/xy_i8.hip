@@ -1,0 +1,172 @@
+// G~X and G~Y (the two skinny products of residualize_genotypes and calc_cv_matrices, reference src/Data.cpp:199 and :746)
+// on the i8 matrix cores, exactly.
+//
+// out[j][c] = sum_pos g_j(pos) * V_c(pos) over the positions of a fold, V = [X | Y] (C + P fp64 columns): the contraction index
+// is the sample, which is how the packed rows are stored, and the genotype operand is an exact small integer, so -- as in
+// pred_i8.hip -- the fp64 operand is taken apart instead of rounded: every column of V is written in fixed point against its
+// largest entry (2^e > max |V_c|, q = rint(V_c(pos) * 2^(54-e))) and split into eight balanced base-128 digits d_k in
+// [-64, 63] (k_v_split, once per problem: V does not change between blocks); S_k[j][c] = sum_pos g_j(pos) d_k[c](pos) runs on
+// v_mfma_i32_32x32x32_i8 with exact int32 sums (|S_k| <= 64 * 2 * n_fold < 2^31 up to 16 million samples per fold); the value is
+// 2^(e-54) * sum_k 128^k S_k in fp64 (k_xy_combine).  The truncation of V at 2^-54 of the column's largest entry is below the
+// rounding the chunked fp64 sums of k_geno_xy (bed_prep.hip) carry.  Missing calls: the same contraction with the missing
+// indicator, for blocks that have any.
+// Tile: 128 SNP rows x 128 (column, digit) pairs per 256-thread workgroup, K step = 64 positions: the packed row piece is
+// expanded to int8 with v_perm_b32 as a byte LUT and the digit rows are copied, both into 80-byte-pitch LDS images (the tile
+// idiom of gram_i8.hip).  At 500,000 samples and 13 columns this is 1.3*10^11 integer multiply-adds per block against the
+// 29 ms per 32 blocks of the fp64 VALU kernel.
+#include "rg_internal.h"
+
+#define XT 128
+#define X_PITCH 80
+#define X_NPIECE 8
+#define X_LUT_DOSAGE 0x00010002u
+#define X_LUT_MISS 0x00000100u
+
+// ---- digit planes of V: vd [Cv][8][Np] int8, vsc [Cv] = 2^(e-54); grid (Cv), 256 threads -----------------------------------
+__global__ __launch_bounds__(256) void k_v_split(const double* __restrict__ V, int64_t Np, int8_t* __restrict__ vd, double* __restrict__ vsc) {
+  __shared__ double red[4];
+  __shared__ double smax;
+  const int c = blockIdx.x;
+  const double* v = V + (int64_t)c * Np;
+  double mx = 0.0;
+  for (int64_t i = threadIdx.x; i < Np; i += 256) mx = fmax(mx, fabs(v[i]));
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) smax = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  __syncthreads();
+  mx = smax;
+  int e = 0;
+  if (mx > 0.0) (void)frexp(mx, &e);
+  const double up = mx > 0.0 ? ldexp(1.0, 54 - e) : 0.0;
+  if (threadIdx.x == 0) vsc[c] = mx > 0.0 ? ldexp(1.0, e - 54) : 0.0;
+  int8_t* d0 = vd + (int64_t)c * X_NPIECE * Np;
+  for (int64_t i = threadIdx.x; i < Np; i += 256) {
+    long long q = llrint(v[i] * up);
+#pragma unroll
+    for (int k = 0; k < X_NPIECE; ++k) {
+      const int d = (int)(((q & 127) ^ 64) - 64);
+      d0[(int64_t)k * Np + i] = (int8_t)d;
+      q = (q - d) >> 7;
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned x_expand4(unsigned b, unsigned lut) {
+  unsigned x = b | (b << 6);
+  x = x | (x << 12);
+  x &= 0x03030303u;
+  return __builtin_amdgcn_perm(lut, lut, x);
+}
+
+// ---- S[blk][set][fold][row][col] = sum over the fold's positions; grid (n128 / 128, nseg, nblk * 2), set = z & 1 ----------------
+__global__ __launch_bounds__(256) void k_xy_i8(const uint8_t* __restrict__ pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* __restrict__ d_bs,
+                                               const int32_t* __restrict__ nmiss, int n128, SegLayout seg, const int8_t* __restrict__ vd,
+                                               int64_t Np, int ncol /* Cv * 8 <= 128 */, int32_t* __restrict__ S) {
+  __shared__ __attribute__((aligned(16))) uint8_t sA[XT * X_PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t sB[XT * X_PITCH];
+  const int blk = blockIdx.z >> 1, set = blockIdx.z & 1, f = blockIdx.y, tr = blockIdx.x;
+  if (set == 1 && nmiss[blk] == 0) return;
+  const int bs = d_bs[blk];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned lut = set ? X_LUT_MISS : X_LUT_DOSAGE;
+  const int64_t pos0 = seg.pos_start[f], kbytes = seg.plen[f] / 4;
+  v16i acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+  const bool isA = tid < 128;
+  const int srow = isA ? tid : tid - 128;
+  const int arow = tr * XT + srow;
+  const bool validA = arow < bs;
+  const uint8_t* ga = pk + (int64_t)blk * pk_blk_stride + (int64_t)(validA ? arow : 0) * pk_ld + pos0 / 4;
+  const bool validB = srow < ncol;
+  const int8_t* gb = vd + (int64_t)(validB ? srow : 0) * Np + pos0;      // (column, digit) row srow = c * 8 + k of vd [Cv][8][Np]
+  uint8_t* lrow = (isA ? sA : sB) + srow * X_PITCH;
+  for (int64_t kb = 0; kb < kbytes; kb += 16) {      // 64 positions per step
+    if (isA) {
+      uint4 w = *reinterpret_cast<const uint4*>(ga + kb);
+      if (!validA) w = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11 -> 0 under both LUTs
+      const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint4 o;
+        o.x = x_expand4(ws[d] & 0xFFu, lut);
+        o.y = x_expand4((ws[d] >> 8) & 0xFFu, lut);
+        o.z = x_expand4((ws[d] >> 16) & 0xFFu, lut);
+        o.w = x_expand4(ws[d] >> 24, lut);
+        *reinterpret_cast<uint4*>(lrow + d * 16) = o;
+      }
+    } else {
+      const uint4* src = reinterpret_cast<const uint4*>(gb + kb * 4);
+      uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+      if (!validB) v0 = v1 = v2 = v3 = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(lrow) = v0;
+      *reinterpret_cast<uint4*>(lrow + 16) = v1;
+      *reinterpret_cast<uint4*>(lrow + 32) = v2;
+      *reinterpret_cast<uint4*>(lrow + 48) = v3;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      v4i af[2], bf[2];
+      const int koff = ks * 32 + (lane >> 5) * 16;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sA + (wr * 64 + i * 32 + (lane & 31)) * X_PITCH + koff);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sB + (wc * 64 + j * 32 + (lane & 31)) * X_PITCH + koff);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  int32_t* Sf = S + ((((int64_t)blk * 2 + set) * seg.nseg + f) * n128) * (int64_t)XT;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tr * XT + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = wc * 64 + j * 32 + (lane & 31);
+        Sf[(int64_t)row * XT + col] = acc[i][j][r];
+      }
+}
+
+// ---- part[blk][fold][row][set][c] = vsc[c] * sum_k 128^k S[.][c*8+k]; grid (ceil(n128*Cv / 256), nseg, nblk) -------------------
+__global__ void k_xy_combine(const int32_t* __restrict__ S, const double* __restrict__ vsc, const int32_t* __restrict__ nmiss, int n128, int nseg,
+                             int Cv, double* __restrict__ part) {
+  const int blk = blockIdx.z, f = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n128 * Cv) return;
+  const int j = t / Cv, c = t - j * Cv;
+  const int nset = nmiss[blk] > 0 ? 2 : 1;
+  for (int set = 0; set < nset; ++set) {
+    const int32_t* s = S + (((((int64_t)blk * 2 + set) * nseg + f) * n128 + j) * (int64_t)XT) + c * X_NPIECE;
+    double v = 0.0, w = 1.0;
+#pragma unroll
+    for (int k = 0; k < X_NPIECE; ++k) { v = fma((double)s[k], w, v); w *= 128.0; }
+    part[((((int64_t)blk * nseg + f) * n128 + j) * 2 + set) * Cv + c] = v * vsc[c];
+  }
+}
+
+void rg_launch_v_split(hipStream_t st, const double* V, int64_t Np, int Cv, int8_t* vd, double* vsc) {
+  hipLaunchKernelGGL(k_v_split, dim3(Cv), dim3(256), 0, st, V, Np, vd, vsc);
+}
+
+// S32: nblk * 2 * nseg * n128 * 128 int32; part: [nblk][nseg][n128][2][Cv] (rowstats reads it with nchunk = nseg, chunk_seg = identity)
+void rg_launch_xy_i8(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs, const int32_t* nmiss,
+                     int nblk, int n128, const SegLayout& seg, const int8_t* vd, const double* vsc, int64_t Np, int Cv, int32_t* S32,
+                     double* part) {
+  hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, nblk * 2), dim3(256), 0, st, pk, pk_ld, pk_blk_stride, d_bs, nmiss, n128, seg, vd, Np,
+                     Cv * X_NPIECE, S32);
+  hipLaunchKernelGGL(k_xy_combine, dim3((n128 * Cv + 255) / 256, seg.nseg, nblk), dim3(256), 0, st, (const int32_t*)S32, vsc, nmiss, n128, seg.nseg,
+                     Cv, part);
+}
