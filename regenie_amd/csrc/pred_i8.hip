@@ -11,7 +11,8 @@
 //     d_k[j] in [-64, 63] (k_beta_split) -- int8 planes;
 //   * S_k[m][pos] = sum_j d_k[m][j] * g_j(pos) runs on v_mfma_i32_32x32x32_i8 with int32 accumulation, EXACT
 //     (|S_k| <= 64 * 2 * bs < 2^31);
-//   * out = 2^(e-54) * sum_k 128^k S_k in fp64: each term is exact, the eight-term sum rounds at 2^-53.
+//   * out = 2^(e-54) * sum_k 128^k S_k: digit pairs are combined in int32 (128 S_{k+1} + S_k, still exact), the four pairs by
+//     Horner in fp64 (every product with a power of two is exact; the sum rounds at 2^-53 of its value).
 //   The only approximation is the truncation of beta~ at 2^-54 of the row's largest coefficient: an absolute error
 //   below bs * 2 * 2^-55 * max|beta~| per prediction, the size of the rounding an fp64 dot product of bs terms
 //   carries anyway.  No tolerance changes anywhere: the parity tests stay at 1e-8.
@@ -167,17 +168,12 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
     if (tile * 32 >= nrow) break;                       // no live row in the second tile
     double out[16];                                     // rows tile*32 + (reg&3) + 8*(reg>>2) + 4*kb, position pos
 #pragma unroll
-    for (int r = 0; r < 16; ++r) out[r] = 0.0;
-#pragma unroll 1
-    for (int set = 0; set < 2; ++set) {
+    for (int set = 0; set < 2; ++set) {                 // unrolled: `out` is not live while the first set is contracted
       if (set == 1 && !has_miss) break;
       const unsigned lut = set == 0 ? LUT_DOSAGE : LUT_MISS;
-      double sc[16];                                    // the rows' 2^(e-54)
-      {
-        const double* scrow = psc + (grp_idx * 2 + set) * PI8_ROWS + tile * 32 + 4 * kb;
+      double oi[16];                                    // sum_k 128^k S_k over both halves, an integer held in fp64
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sc[r] = scrow[(r & 3) + 8 * (r >> 2)];
-      }
+      for (int r = 0; r < 16; ++r) oi[r] = 0.0;
 #pragma unroll 1
       for (int half = 0; half * PI8_KHALF < n128; ++half) {
         const int nst = FULL ? PI8_KHALF / 32 : min(PI8_KHALF / 32, nstep - half * (PI8_KHALF / 32));   // K steps of this half
@@ -212,25 +208,42 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
                         (int)pi8_expand4((w >> 16) & 0xFFu, lut), (int)pi8_expand4(w >> 24, lut)};
         }
         __syncthreads();
-        double w128 = 1.0;
+        // digit planes from the most significant pair down: a pair is combined in int32 (|S_k| <= 64 * 2 * 512 = 2^16 per half, so
+        // 128 S_{k+1} + S_k < 2^24) -- the second chain simply accumulates onto the shifted sums -- and the pairs by Horner in fp64
+        double hr[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hr[r] = 0.0;
 #pragma unroll 1
-        for (int k = 0; k < PI8_NPIECE; ++k) {
+        for (int kp = PI8_NPIECE / 2 - 1; kp >= 0; --kp) {
           v16i acc;
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[r] = 0;
-          const int8_t* arow = sA + k * PI8_PLANE + c * PI8_PITCH + 16 * kb;
 #pragma unroll
-          for (int t = 0; t < PI8_KHALF / 32; ++t) {
-            if (FULL || t < nst) {
-              const v4i af = *reinterpret_cast<const v4i*>(arow + 32 * t);
-              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[t], acc, 0, 0, 0);
+          for (int hl = 1; hl >= 0; --hl) {
+            const int8_t* arow = sA + (2 * kp + hl) * PI8_PLANE + c * PI8_PITCH + 16 * kb;
+#pragma unroll
+            for (int t = 0; t < PI8_KHALF / 32; ++t) {
+              if (FULL || t < nst) {
+                const v4i af = *reinterpret_cast<const v4i*>(arow + 32 * t);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[t], acc, 0, 0, 0);
+              }
+            }
+            if (hl == 1) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[r] *= 128;
             }
           }
-          // S_k * 128^k * 2^(e-54): the two factors are powers of two, their product with the integer sum is exact
 #pragma unroll
-          for (int r = 0; r < 16; ++r) out[r] = fma((double)acc[r], w128 * sc[r], out[r]);
-          w128 *= 128.0;
+          for (int r = 0; r < 16; ++r) hr[r] = fma(hr[r], 16384.0, (double)acc[r]);
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oi[r] += hr[r];
+      }
+      // the rows' 2^(e-54): a power of two times an integer -- exact up to the one rounding of the sum above
+      {
+        const double* scrow = psc + (grp_idx * 2 + set) * PI8_ROWS + tile * 32 + 4 * kb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[r] = set == 0 ? oi[r] * scrow[(r & 3) + 8 * (r >> 2)] : fma(oi[r], scrow[(r & 3) + 8 * (r >> 2)], out[r]);
       }
     }
     // ---- epilogue of the tile: covariate term, mask, store, per-row sums (as pred.hip) ----------------------------------
