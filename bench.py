@@ -305,7 +305,7 @@ def main():
         line = {
             "metric": "Step-1 SNPs x samples x phenos / sec", "value": value, "unit": "SNP*sample*pheno/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "fp4 (exact integer Gram) + f64 (solves, level 1)",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "fp4 (exact integer Gram) + i8 (exact fixed-point digit planes of the fp64 operands: G~X / G~Y, many-row predictions) + f64 (solves, level 1)",
             "data": "synthetic",
             "config": {"workload": "%ssynthetic PLINK bed %d samples x %d SNPs (%d per GPU), %d QT pheno, bsize %d, 22 chromosomes, 5-fold CV, 5x5 ridge grid"
                        % ("BASELINE configs[2], blocks sharded over the GPUs: " if strong else ("BASELINE configs[1]: " if world == 1 else "weak scaling of BASELINE configs[1]: "),

@@ -241,6 +241,21 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   int nb = 64;
   if (const char* e = getenv("RG_NBLK")) nb = std::max(1, atoi(e));
   nb = std::min(nb, ctx->B_total);
+  {  // memory: the per-block workspaces of all pipelines stay inside a budget (default 64 GB, RG_WS_GB): at 500,000 samples a
+     // block costs ~0.95 GB (packed planes 0.5, the 25 system workspaces 0.22, integer Grams 0.08, ...), so 2 x 64 blocks
+     // would take 120 GB next to W, the exchange buffers and the resident genotypes of a 2-GPU BASELINE configs[2] run
+    double budget = 64e9;
+    if (const char* e = getenv("RG_WS_GB")) budget = std::max(1.0, atof(e)) * 1e9;
+    const double n128d = (double)rg_round_up(ctx->bs_max, 128), n64d = (double)rg_round_up(ctx->bs_max, 64);
+    const double rtotd = n64d + (double)rg_round_up(P, 64);
+    const double per_blk = n128d * (Np / 4.0) * 2.0 /* pk + pkT */ + n128d * (Np / 2.0) /* FP4 plane */ + (double)K * 4.0 * n128d * n128d * 4.0 /* S */ +
+                           ((double)K + 1.0 + (double)K * ctx->R0) * rtotd * n64d * 8.0 /* fold, sum, wk */ +
+                           (double)K * ctx->R0 * (n64d / 64.0 + 10.0 * ((n64d / 64.0 + 3.0) / 4.0)) * 4096.0 * 8.0 /* dinv + images */;
+    int npipe = 2;
+    if (const char* e = getenv("RG_PIPELINES")) npipe = std::max(1, atoi(e));
+    if (!ctx->loocv) nb = (int)std::max(4.0, std::min((double)nb, budget / (npipe * per_blk)));
+    nb = std::min(nb, ctx->B_total);
+  }
   {  // balanced batches: B blocks go in ceil(B / nb) batches of (almost) equal size -- the workspaces are sized for those,
      // not for the cap (109 blocks: 2 x 55 instead of 64 + 45; allocation and first-touch time of the set-up scale with it)
     const int nbatch = (ctx->B_total + nb - 1) / nb;
