@@ -56,7 +56,16 @@ typedef struct rg_s2_qt_out {
 int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int32_t g_on_device, double numtol,
                    const rg_s2_qt_out* out);
 
-/* Device time of the kernels of the last rg_s2_qt_block call (hipEvents on the library's stream), in ms. */
+/* The same statistic for HARD CALLS handed over as they lie in a .bed file: row j holds the 2-bit codes of the n analysed samples in
+ * the caller's order, sample-fastest, 4 per byte, low bits first (00 -> 2 copies of the counted allele, 01 -> missing, 10 -> 1,
+ * 11 -> 0: buildLookupTable, Geno.cpp:2833-2856), rows ld >= ceil(n / 4) bytes apart; flip != 0 counts the other allele
+ * (2 - g, the reference's --ref-first).  Needs mask == 1 everywhere in the last rg_s2_set_null (every analysed sample observed for
+ * every phenotype): RG_S2_ERR_ARG otherwise -- use rg_s2_qt_block then.  The contractions run on the i8 matrix cores with exact
+ * integer sums (csrc/step2_qt.hip); the genotypes are read at 2 bits each.  rows: host pointer, or device when rows_on_device. */
+int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32_t bs, int32_t rows_on_device, int32_t flip,
+                          double numtol, const rg_s2_qt_out* out);
+
+/* Device time of the kernels of the last rg_s2_qt_block / rg_s2_qt_block_packed call (hipEvents on the library's stream), in ms. */
 double rg_s2_last_kernel_ms(const rg_s2_ctx* ctx);
 
 #ifdef __cplusplus

@@ -16,14 +16,28 @@
 // deterministic.  The tile (VPB x EPT) is a tuning knob: RG_S2_TILE=4x4|4x8|8x4|8x8|16x4 (read at rg_s2_create).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/rg_step2.h"
+#include "rg_internal.h"
+
+// Hard calls (rg_s2_qt_block_packed): the same statistic from the 2-bit rows, exactly, on the i8 matrix cores.  When every
+// analysed sample is observed for every phenotype (mask all ones, the only case the reference's dense path and its sparse
+// shortcut agree on) the statistic needs nothing but CONTRACTIONS of the genotype row with fixed fp64 columns plus counts:
+//   A_c = sum g0 x_c, M_c = sum miss x_c, R_p = sum g0 res_p, T_p = sum miss res_p        (g0 in {0,1,2}, miss in {0,1})
+//   mu = (n1 + 2 n2) / (n - nmiss),  beta = A + mu M,  |r|^2 = n1 + 4 n2 + nmiss mu^2 - |beta|^2   (X orthonormal)
+//   num_p = R_p + mu T_p - (res_p^T X) beta,  denum_p = |r|^2
+// and those contractions are what xy_i8.hip evaluates for Step 1: the columns [X | res] are split once per chromosome into
+// eight balanced base-128 digit planes (k_v_split), v_mfma_i32_32x32x32_i8 accumulates exact int32 digit sums per sample
+// segment, the segments are added in int64 and the digits recombined in fp64 (k_s2_combine).  The genotype operand is read
+// at 2 bits per call -- 0.25 B per genotype against 16 B over the two fp64 passes above -- and never leaves integer form.
 
 namespace {
 
@@ -295,6 +309,118 @@ __global__ void k_s2_final(const double* __restrict__ part2, int nchunk, int P, 
   if (p == 0) { scale_fac[j] = sf; ignored[j] = ign ? 1 : 0; }
 }
 
+// ---- hard-call route ---------------------------------------------------------------------------------------------------------
+// One workgroup per staged row [ldp bytes = Np / 4]: positions >= n become code 11 (0 copies, not missing), the counted allele
+// is swapped when flip != 0 (00 <-> 11, the reference's --ref-first), and the calls are counted (.bed coding, Geno.cpp:2833-2856:
+// 00 -> 2 copies, 01 -> missing, 10 -> 1, 11 -> 0).  cnt [bs][4] = n1, n2, nmiss, 0; *total_miss accumulates nmiss.
+__global__ __launch_bounds__(256) void k_s2_rows(uint8_t* __restrict__ pk, int64_t ldp, int64_t n, int flip, int32_t* __restrict__ cnt,
+                                                 int32_t* __restrict__ total_miss) {
+  __shared__ int red[3][4];
+  uint32_t* w = reinterpret_cast<uint32_t*>(pk + (int64_t)blockIdx.x * ldp);
+  const int64_t nwords = ldp / 4;
+  int c1 = 0, c2 = 0, cm = 0;
+  for (int64_t i = threadIdx.x; i < nwords; i += 256) {
+    const uint32_t x0 = w[i];
+    uint32_t x = x0;
+    if (flip) {
+      const uint32_t eq = ~(x ^ (x >> 1)) & 0x55555555u;
+      x ^= eq | (eq << 1);
+    }
+    const int64_t p0 = i * 16;
+    if (p0 + 16 > n) {
+      const int64_t valid = n > p0 ? n - p0 : 0;
+      const uint32_t keep = valid == 0 ? 0u : ((1u << (2 * valid)) - 1u);   // valid < 16 here
+      x |= ~keep;
+    }
+    if (x != x0) w[i] = x;
+    const uint32_t lo = x & 0x55555555u, hi = (x >> 1) & 0x55555555u;
+    c2 += __popc(~lo & ~hi & 0x55555555u);
+    cm += __popc(lo & ~hi);
+    c1 += __popc(hi & ~lo);
+  }
+  for (int o = 32; o > 0; o >>= 1) { c1 += __shfl_down(c1, o); c2 += __shfl_down(c2, o); cm += __shfl_down(cm, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = c1; red[1][threadIdx.x >> 6] = c2; red[2][threadIdx.x >> 6] = cm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int a = red[0][0] + red[0][1] + red[0][2] + red[0][3], b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const int m = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    cnt[blockIdx.x * 4 + 0] = a; cnt[blockIdx.x * 4 + 1] = b; cnt[blockIdx.x * 4 + 2] = m; cnt[blockIdx.x * 4 + 3] = 0;
+    if (m) atomicAdd(total_miss, m);
+  }
+}
+
+// YtX[p][c] = sum_i res_p(i) x_c(i); grid (P * C), 256 threads, fixed summation tree
+__global__ __launch_bounds__(256) void k_s2_ytx(const double* __restrict__ X, const double* __restrict__ Y, int64_t n, int C, double* __restrict__ ytx) {
+  __shared__ double red[4];
+  const int p = blockIdx.x / C, c = blockIdx.x % C;
+  const double* x = X + (int64_t)c * n;
+  const double* y = Y + (int64_t)p * n;
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s = fma(x[i], y[i], s);
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) ytx[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// A[j][set][c] = vsc[c] * sum_k 128^k (sum over segments of S[grp][set][f][j][cl * 8 + k]): the segment sums are exact in int64, so the
+// value does not depend on how the samples were cut into segments.  thread = (j, c); set 1 only when the block has a missing call.
+__global__ void k_s2_combine(const int32_t* __restrict__ S, const double* __restrict__ vsc, const int32_t* __restrict__ total_miss, int bs,
+                             int n128, int nseg, int Cv, double* __restrict__ A) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bs * Cv) return;
+  const int j = t / Cv, c = t - j * Cv, grp = c >> 4, cl = c & 15;
+  const int nset = *total_miss > 0 ? 2 : 1;
+  for (int set = 0; set < 2; ++set) {
+    double v = 0.0;
+    if (set < nset) {
+      long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int f = 0; f < nseg; ++f) {
+        const int32_t* s = S + (((((int64_t)grp * 2 + set) * nseg + f) * n128 + j) * 128) + cl * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tk[k] += s[k];
+      }
+#pragma unroll
+      for (int k = 7; k >= 0; --k) v = fma(v, 128.0, (double)tk[k]);
+      v *= vsc[c];
+    }
+    A[((int64_t)j * 2 + set) * Cv + c] = v;
+  }
+}
+
+// thread = variant: the statistic from the contractions and the counts (formulas at the top of the file)
+__global__ void k_s2_packed_final(const double* __restrict__ A, const int32_t* __restrict__ cnt, const double* __restrict__ ytx, int bs, int C, int P,
+                                  int64_t n, double numtol, const double* __restrict__ scf_sv, double* __restrict__ stats, double* __restrict__ bhat,
+                                  double* __restrict__ scale_fac, double* __restrict__ mean, int32_t* __restrict__ nobs_out, int32_t* __restrict__ ignored) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= bs) return;
+  const int Cv = C + P;
+  const double n1 = cnt[j * 4 + 0], n2 = cnt[j * 4 + 1], nm = cnt[j * 4 + 2];
+  const double nobs = (double)n - nm;
+  const double mu = nobs > 0 ? (n1 + 2.0 * n2) / nobs : 0.0;
+  const double* a0 = A + (int64_t)j * 2 * Cv;
+  const double* a1 = a0 + Cv;
+  double b2 = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const double b = fma(mu, a1[c], a0[c]);
+    b2 = fma(b, b, b2);
+  }
+  const double ss = (n1 + 4.0 * n2 + nm * mu * mu) - b2;
+  const double sf = sqrt(ss) / sqrt((double)(n - C));
+  const bool ign = !(sf >= numtol) || nobs <= 0;
+  const double sd = sqrt(ss);
+  for (int p = 0; p < P; ++p) {
+    double num = fma(mu, a1[C + p], a0[C + p]);
+    double corr = 0.0;
+    for (int c = 0; c < C; ++c) corr = fma(ytx[p * C + c], fma(mu, a1[c], a0[c]), corr);
+    num -= corr;
+    const double z = num / sd;
+    stats[(int64_t)j * P + p] = ign ? NAN : z;
+    bhat[(int64_t)j * P + p] = ign ? NAN : z * scf_sv[p] / sd;
+  }
+  scale_fac[j] = sf; mean[j] = mu; nobs_out[j] = (int32_t)nobs; ignored[j] = ign ? 1 : 0;
+}
+
 }  // namespace
 
 struct rg_s2_ctx {
@@ -310,6 +436,17 @@ struct rg_s2_ctx {
   size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int vpb = DEFAULT_VPB, ept = DEFAULT_EPT;   // tile of the two streaming kernels (resolved in rg_s2_create)
   double last_ms = 0.0;
+  // hard-call route (rg_s2_qt_block_packed): built lazily after rg_s2_set_null
+  bool complete = false;        // every mask byte is 1
+  bool planes_ready = false;
+  int64_t Np = 0;               // samples padded to nseg segments of a multiple of 64
+  SegLayout seg;
+  double* dV = nullptr;         // [C + P][Np]  X then res, zero padded
+  int8_t* dvd = nullptr;        // [C + P][8][Np] digit planes
+  double *dvsc = nullptr, *dYtX = nullptr;   // [C + P] plane scales, [P][C] res_p^T x_c
+  void* pbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t pcap[6] = {0, 0, 0, 0, 0, 0};
+  int32_t hdr[2] = {0, 0};      // staged {total_miss = 0, bs} of the block in flight
   std::string err;
 };
 
@@ -324,15 +461,17 @@ int fail(rg_s2_ctx* ctx, int code, const std::string& msg) {
     if (e_ != hipSuccess) return fail(ctx, RG_S2_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
   } while (0)
 
-int ensure(rg_s2_ctx* ctx, int slot, size_t bytes) {
-  if (ctx->cap[slot] >= bytes) return RG_S2_OK;
-  if (ctx->buf[slot]) S2_HIP(hipFree(ctx->buf[slot]));
-  ctx->buf[slot] = nullptr;
-  ctx->cap[slot] = 0;
-  S2_HIP(hipMalloc(&ctx->buf[slot], bytes));
-  ctx->cap[slot] = bytes;
+int ensure_in(rg_s2_ctx* ctx, void** buf, size_t* cap, int slot, size_t bytes) {
+  if (cap[slot] >= bytes) return RG_S2_OK;
+  if (buf[slot]) S2_HIP(hipFree(buf[slot]));
+  buf[slot] = nullptr;
+  cap[slot] = 0;
+  S2_HIP(hipMalloc(&buf[slot], bytes));
+  cap[slot] = bytes;
   return RG_S2_OK;
 }
+int ensure(rg_s2_ctx* ctx, int slot, size_t bytes) { return ensure_in(ctx, ctx->buf, ctx->cap, slot, bytes); }
+int ensure_p(rg_s2_ctx* ctx, int slot, size_t bytes) { return ensure_in(ctx, ctx->pbuf, ctx->pcap, slot, bytes); }
 }  // namespace
 
 extern "C" {
@@ -372,6 +511,11 @@ void rg_s2_destroy(rg_s2_ctx* ctx) {
     (void)hipSetDevice(ctx->dev);
     (void)hipStreamSynchronize(ctx->st);
     for (void* p : ctx->buf) if (p) (void)hipFree(p);
+    for (void* p : ctx->pbuf) if (p) (void)hipFree(p);
+    if (ctx->dV) (void)hipFree(ctx->dV);
+    if (ctx->dvd) (void)hipFree(ctx->dvd);
+    if (ctx->dvsc) (void)hipFree(ctx->dvsc);
+    if (ctx->dYtX) (void)hipFree(ctx->dYtX);
     if (ctx->dX) (void)hipFree(ctx->dX);
     if (ctx->dY) (void)hipFree(ctx->dY);
     if (ctx->dM) (void)hipFree(ctx->dM);
@@ -395,6 +539,10 @@ int rg_s2_set_null(rg_s2_ctx* ctx, const double* X, const double* yres, const ui
   S2_HIP(hipMemcpyAsync(ctx->dscf, scf_sv, sizeof(double) * ctx->P, hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipStreamSynchronize(ctx->st));
   ctx->have_null = true;
+  ctx->planes_ready = false;
+  ctx->complete = true;
+  for (size_t i = 0, e = (size_t)ctx->n * ctx->P; i < e; ++i)
+    if (!mask[i]) { ctx->complete = false; break; }
   return RG_S2_OK;
 }
 
@@ -453,6 +601,91 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
 #undef S2_SCORE
   hipLaunchKernelGGL(k_s2_final, dim3((bs * P + 255) / 256), dim3(256), 0, ctx->st, part, nchunk, P, bs, (double)(n - C), numtol,
                      ctx->dscf, nobs, stats, bhat, sf, ign);
+  S2_HIP(hipEventRecord(ctx->e1, ctx->st));
+  S2_HIP(hipGetLastError());
+  if (out->stats) S2_HIP(hipMemcpyAsync(out->stats, stats, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));
+  if (out->bhat) S2_HIP(hipMemcpyAsync(out->bhat, bhat, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));
+  if (out->scale_fac) S2_HIP(hipMemcpyAsync(out->scale_fac, sf, sizeof(double) * bs, hipMemcpyDeviceToHost, ctx->st));
+  if (out->mean) S2_HIP(hipMemcpyAsync(out->mean, mu, sizeof(double) * bs, hipMemcpyDeviceToHost, ctx->st));
+  if (out->n_obs) S2_HIP(hipMemcpyAsync(out->n_obs, nobs, sizeof(int32_t) * bs, hipMemcpyDeviceToHost, ctx->st));
+  if (out->ignored) S2_HIP(hipMemcpyAsync(out->ignored, ign, sizeof(int32_t) * bs, hipMemcpyDeviceToHost, ctx->st));
+  S2_HIP(hipStreamSynchronize(ctx->st));
+  float ms = 0.f;
+  S2_HIP(hipEventElapsedTime(&ms, ctx->e0, ctx->e1));
+  ctx->last_ms = ms;
+  return RG_S2_OK;
+}
+
+int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32_t bs, int32_t rows_on_device, int32_t flip, double numtol,
+                          const rg_s2_qt_out* out) {
+  if (!ctx || !ctx->st) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_packed: context was not created");
+  if (!ctx->have_null) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_packed: rg_s2_set_null has not been called");
+  const int64_t n = ctx->n, nbytes = (n + 3) / 4;
+  if (!rows || !out || bs < 1 || ld < nbytes) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_packed: bad arguments (need bs >= 1, ld >= ceil(n / 4))");
+  if (!ctx->complete)
+    return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_packed: a sample is masked for some phenotype; the hard-call route needs mask == 1 "
+                                    "everywhere (use rg_s2_qt_block)");
+  const int C = ctx->C, P = ctx->P, Cv = C + P, ngrp = (Cv + 15) / 16;
+  S2_HIP(hipSetDevice(ctx->dev));
+  int rc;
+  if (!ctx->planes_ready) {   // once per rg_s2_set_null: the digit planes of [X | res] and res^T X
+    if (!ctx->dV) {
+      // the sample axis is cut into 32 pieces of a multiple of 64 samples; a call contracts 32 / m merged pieces per workgroup row
+      ctx->Np = (n + 64 * RG_MAX_SEG - 1) / (64 * RG_MAX_SEG) * (64 * RG_MAX_SEG);
+      S2_HIP(hipMalloc((void**)&ctx->dV, sizeof(double) * Cv * ctx->Np));
+      S2_HIP(hipMalloc((void**)&ctx->dvd, (size_t)ngrp * 16 * 8 * ctx->Np));
+      S2_HIP(hipMalloc((void**)&ctx->dvsc, sizeof(double) * ngrp * 16));
+      S2_HIP(hipMalloc((void**)&ctx->dYtX, sizeof(double) * P * C));
+      S2_HIP(hipMemsetAsync(ctx->dV, 0, sizeof(double) * Cv * ctx->Np, ctx->st));
+    }
+    S2_HIP(hipMemcpy2DAsync(ctx->dV, ctx->Np * sizeof(double), ctx->dX, n * sizeof(double), n * sizeof(double), C, hipMemcpyDeviceToDevice, ctx->st));
+    S2_HIP(hipMemcpy2DAsync(ctx->dV + (int64_t)C * ctx->Np, ctx->Np * sizeof(double), ctx->dY, n * sizeof(double), n * sizeof(double), P,
+                            hipMemcpyDeviceToDevice, ctx->st));
+    rg_launch_v_split(ctx->st, ctx->dV, ctx->Np, Cv, ctx->dvd, ctx->dvsc);
+    hipLaunchKernelGGL(k_s2_ytx, dim3(P * C), dim3(256), 0, ctx->st, ctx->dX, ctx->dY, n, C, ctx->dYtX);
+    S2_HIP(hipGetLastError());
+    ctx->planes_ready = true;
+  }
+  const int64_t Np = ctx->Np, ldp = Np / 4;
+  const int n128 = (int)((bs + 127) / 128 * 128);
+  // enough workgroups to fill the 256 CUs (tiles x segments x column groups >= 768), as few segments as that allows: every segment
+  // costs a 64 KB tile of partial sums per workgroup
+  int nseg = 1;
+  while (nseg < RG_MAX_SEG && (int64_t)(n128 / 128) * nseg * ngrp < 768 && Np / (nseg * 2) >= 1024) nseg *= 2;
+  SegLayout& seg = ctx->seg;
+  memset(&seg, 0, sizeof(seg));
+  seg.nseg = nseg;
+  for (int f = 0; f < nseg; ++f) { seg.pos_start[f] = f * (Np / nseg); seg.file_start[f] = seg.pos_start[f]; seg.len[f] = Np / nseg; seg.plen[f] = Np / nseg; }
+  enum { Q_PK, Q_CNT, Q_S, Q_A, Q_VAR, Q_STAT };
+  if ((rc = ensure_p(ctx, Q_PK, (size_t)bs * ldp))) return rc;
+  if ((rc = ensure_p(ctx, Q_CNT, ((size_t)bs * 4 + 8) * sizeof(int32_t)))) return rc;            // counts | total_miss | bs
+  if ((rc = ensure_p(ctx, Q_S, (size_t)ngrp * 2 * nseg * n128 * 128 * sizeof(int32_t)))) return rc;
+  if ((rc = ensure_p(ctx, Q_A, (size_t)bs * 2 * Cv * sizeof(double)))) return rc;
+  if ((rc = ensure_p(ctx, Q_VAR, (size_t)bs * (2 * sizeof(double) + 2 * sizeof(int32_t))))) return rc;   // scale_fac | mean | nobs | ignored
+  if ((rc = ensure_p(ctx, Q_STAT, (size_t)bs * P * 2 * sizeof(double)))) return rc;                     // stats | bhat
+  uint8_t* pk = (uint8_t*)ctx->pbuf[Q_PK];
+  int32_t* cnt = (int32_t*)ctx->pbuf[Q_CNT];
+  int32_t* total_miss = cnt + (size_t)bs * 4;
+  int32_t* d_bs = total_miss + 1;
+  int32_t* S = (int32_t*)ctx->pbuf[Q_S];
+  double* A = (double*)ctx->pbuf[Q_A];
+  double* sf = (double*)ctx->pbuf[Q_VAR];
+  double* mu = sf + bs;
+  int32_t* nobs = (int32_t*)(mu + bs);
+  int32_t* ign = nobs + bs;
+  double* stats = (double*)ctx->pbuf[Q_STAT];
+  double* bhat = stats + (size_t)bs * P;
+  ctx->hdr[0] = 0; ctx->hdr[1] = bs;
+  S2_HIP(hipMemcpyAsync(total_miss, ctx->hdr, sizeof(ctx->hdr), hipMemcpyHostToDevice, ctx->st));
+  S2_HIP(hipMemcpy2DAsync(pk, ldp, rows, ld, nbytes, bs, rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->st));
+  S2_HIP(hipEventRecord(ctx->e0, ctx->st));
+  hipLaunchKernelGGL(k_s2_rows, dim3(bs), dim3(256), 0, ctx->st, pk, ldp, n, flip ? 1 : 0, cnt, total_miss);
+  for (int g = 0; g < ngrp; ++g)
+    rg_launch_xy_i8_sums(ctx->st, pk, ldp, 0, d_bs, total_miss, 1, n128, ctx->seg, ctx->dvd + (size_t)g * 16 * 8 * Np, Np, std::min(16, Cv - g * 16),
+                         S + (size_t)g * 2 * nseg * n128 * 128);
+  hipLaunchKernelGGL(k_s2_combine, dim3((bs * Cv + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->dvsc, total_miss, bs, n128, nseg, Cv, A);
+  hipLaunchKernelGGL(k_s2_packed_final, dim3((bs + 63) / 64), dim3(64), 0, ctx->st, (const double*)A, (const int32_t*)cnt, ctx->dYtX, bs, C, P, n, numtol,
+                     ctx->dscf, stats, bhat, sf, mu, nobs, ign);
   S2_HIP(hipEventRecord(ctx->e1, ctx->st));
   S2_HIP(hipGetLastError());
   if (out->stats) S2_HIP(hipMemcpyAsync(out->stats, stats, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));

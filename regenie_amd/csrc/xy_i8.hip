@@ -87,10 +87,15 @@ __global__ __launch_bounds__(256) void k_xy_i8(const uint8_t* __restrict__ pk, i
   const bool validB = srow < ncol;
   const int8_t* gb = vd + (int64_t)(validB ? srow : 0) * Np + pos0;      // (column, digit) row srow = c * 8 + k of vd [Cv][8][Np]
   uint8_t* lrow = (isA ? sA : sB) + srow * X_PITCH;
+  // the global loads of step kb + 16 are issued before the MFMAs of step kb (registers), so their latency hides behind the math
+  uint4 w = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11 -> 0 under both LUTs
+  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+  if (kbytes > 0) {
+    if (isA) { if (validA) w = *reinterpret_cast<const uint4*>(ga); }
+    else if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
+  }
   for (int64_t kb = 0; kb < kbytes; kb += 16) {      // 64 positions per step
     if (isA) {
-      uint4 w = *reinterpret_cast<const uint4*>(ga + kb);
-      if (!validA) w = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11 -> 0 under both LUTs
       const unsigned ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
@@ -102,15 +107,16 @@ __global__ __launch_bounds__(256) void k_xy_i8(const uint8_t* __restrict__ pk, i
         *reinterpret_cast<uint4*>(lrow + d * 16) = o;
       }
     } else {
-      const uint4* src = reinterpret_cast<const uint4*>(gb + kb * 4);
-      uint4 v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-      if (!validB) v0 = v1 = v2 = v3 = make_uint4(0, 0, 0, 0);
       *reinterpret_cast<uint4*>(lrow) = v0;
       *reinterpret_cast<uint4*>(lrow + 16) = v1;
       *reinterpret_cast<uint4*>(lrow + 32) = v2;
       *reinterpret_cast<uint4*>(lrow + 48) = v3;
     }
     __syncthreads();
+    if (kb + 16 < kbytes) {
+      if (isA) { if (validA) w = *reinterpret_cast<const uint4*>(ga + kb + 16); }
+      else if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb + (kb + 16) * 4); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       v4i af[2], bf[2];
@@ -159,6 +165,13 @@ __global__ void k_xy_combine(const int32_t* __restrict__ S, const double* __rest
 
 void rg_launch_v_split(hipStream_t st, const double* V, int64_t Np, int Cv, int8_t* vd, double* vsc) {
   hipLaunchKernelGGL(k_v_split, dim3(Cv), dim3(256), 0, st, V, Np, vd, vsc);
+}
+
+// the digit sums alone (step2_qt.hip sums them over the segments itself): S32 [nblk][2][nseg][n128][128]
+void rg_launch_xy_i8_sums(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs, const int32_t* nmiss,
+                          int nblk, int n128, const SegLayout& seg, const int8_t* vd, int64_t Np, int Cv, int32_t* S32) {
+  hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, nblk * 2), dim3(256), 0, st, pk, pk_ld, pk_blk_stride, d_bs, nmiss, n128, seg, vd, Np,
+                     Cv * X_NPIECE, S32);
 }
 
 // S32: nblk * 2 * nseg * n128 * 128 int32; part: [nblk][nseg][n128][2][Cv] (rowstats reads it with nchunk = nseg, chunk_seg = identity)

@@ -1395,9 +1395,12 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   nthreads = std::min(nthreads, 64);
   // buildLookupTable (Geno.cpp:2833-2856): 00 -> 2, 01 -> missing (-3), 10 -> 1, 11 -> 0 copies of the first .bim allele
   static const double lut[4] = {2.0, -3.0, 1.0, 0.0};
-  std::vector<uint8_t> rows;
-  std::vector<double> G, stats, bhat, sfac;
-  std::vector<int32_t> ign;
+  std::vector<uint8_t> rows, packed;
+  std::vector<double> G, stats, bhat, sfac, mean_v;
+  std::vector<int32_t> ign, nobs_v;
+  bool identity = n == r.n_file;                 // every sample of the file is analysed, in file order
+  for (int64_t k = 0; identity && k < n; ++k) identity = file_idx[k] == k;
+  const bool dense_route = getenv("RG_S2_DENSE") != nullptr;     // the fp64 route of the library (rg_s2_qt_block), kept for comparison
   int64_t n_ignored_snps = 0, n_ignored_tests = 0, n_tested = 0;
   int block = 0;
   for (int chrom : r.chr_read) {
@@ -1459,39 +1462,67 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
         }
         j = e;
       }
-      // parseSnpfromBed: decode the analysed samples, allele counts
-      G.assign((size_t)bs * n, 0.0);
       std::vector<double> total(bs, 0.0);
       std::vector<int64_t> ns1(bs, 0);
       std::vector<double> af_t, mac_t;         // per trait (only filled when some sample is masked for some trait)
       std::vector<int64_t> ns_t;
-      if (any_missing) { af_t.assign((size_t)bs * P, 0.0); mac_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0); }
       std::vector<uint8_t> variant_ignored(bs, 0);
-      parallel_for(bs, nthreads, [&](int j) {
-        const uint8_t* row = rows.data() + (size_t)j * r.bpr;
-        double* g = G.data() + (size_t)j * n;
-        double tot = 0.0; int64_t ns = 0;
-        for (int64_t k = 0; k < n; ++k) {
-          const int64_t i = file_idx[k];
-          double hc = lut[(row[i >> 2] >> (2 * (i & 3))) & 3];
-          if (p.ref_first && hc != -3.0) hc = 2.0 - hc;
-          g[k] = hc;
-          if (hc != -3.0) {
-            tot += hc; ++ns;
-            if (any_missing && has_missing[k])   // update_trait_counts (Geno.cpp:2948-2959): subtract from the totals of the traits the sample is masked for
-              for (int q = 0; q < P; ++q)
-                if (!Mc[(size_t)q * n + k]) { af_t[(size_t)j * P + q] -= hc; mac_t[(size_t)j * P + q] -= hc; ns_t[(size_t)j * P + q] -= 1; }
-          }
-        }
-        total[j] = tot; ns1[j] = ns;
-        // compute_mac (Geno.cpp:3077-3108), autosomes
-        const double mac = std::min(tot, 2.0 * ns - tot);
-        if (mac < p.min_mac) variant_ignored[j] = 1;
-      });
       rg_s2_qt_out o;
       stats.resize((size_t)bs * P); bhat.resize((size_t)bs * P); sfac.resize(bs); ign.resize(bs);
       o.stats = stats.data(); o.bhat = bhat.data(); o.scale_fac = sfac.data(); o.mean = nullptr; o.n_obs = nullptr; o.ignored = ign.data();
-      s2check(rg_s2_qt_block(s2, G.data(), n, bs, 0, NUMTOL, &o));
+      if (!dense_route) {
+        // hard calls stay packed: the 2-bit codes of the analysed samples go to the device as they are (the rows of the file itself
+        // when no sample was dropped), the library counts the calls and contracts them on the i8 matrix cores
+        const uint8_t* src = rows.data();
+        int64_t ld = r.bpr;
+        if (!identity) {
+          ld = (n + 3) / 4;
+          packed.assign((size_t)bs * ld, 0);
+          parallel_for(bs, nthreads, [&](int j) {
+            const uint8_t* row = rows.data() + (size_t)j * r.bpr;
+            uint8_t* dst = packed.data() + (size_t)j * ld;
+            for (int64_t k = 0; k < n; ++k) {
+              const int64_t i = file_idx[k];
+              dst[k >> 2] |= (uint8_t)(((row[i >> 2] >> (2 * (i & 3))) & 3) << (2 * (k & 3)));
+            }
+          });
+          src = packed.data();
+        }
+        mean_v.resize(bs); nobs_v.resize(bs);
+        o.mean = mean_v.data(); o.n_obs = nobs_v.data();
+        s2check(rg_s2_qt_block_packed(s2, src, ld, bs, 0, p.ref_first ? 1 : 0, NUMTOL, &o));
+        for (int j = 0; j < bs; ++j) {
+          ns1[j] = nobs_v[j];
+          total[j] = std::nearbyint(mean_v[j] * (double)nobs_v[j]);       // the allele count is an integer: mean = total / n_obs
+          if (std::min(total[j], 2.0 * ns1[j] - total[j]) < p.min_mac) variant_ignored[j] = 1;   // compute_mac (Geno.cpp:3077-3108), autosomes
+        }
+      } else {
+        // parseSnpfromBed: decode the analysed samples, allele counts
+        G.assign((size_t)bs * n, 0.0);
+        if (any_missing) { af_t.assign((size_t)bs * P, 0.0); mac_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0); }
+        parallel_for(bs, nthreads, [&](int j) {
+          const uint8_t* row = rows.data() + (size_t)j * r.bpr;
+          double* g = G.data() + (size_t)j * n;
+          double tot = 0.0; int64_t ns = 0;
+          for (int64_t k = 0; k < n; ++k) {
+            const int64_t i = file_idx[k];
+            double hc = lut[(row[i >> 2] >> (2 * (i & 3))) & 3];
+            if (p.ref_first && hc != -3.0) hc = 2.0 - hc;
+            g[k] = hc;
+            if (hc != -3.0) {
+              tot += hc; ++ns;
+              if (any_missing && has_missing[k])   // update_trait_counts (Geno.cpp:2948-2959): subtract from the totals of the traits the sample is masked for
+                for (int q = 0; q < P; ++q)
+                  if (!Mc[(size_t)q * n + k]) { af_t[(size_t)j * P + q] -= hc; mac_t[(size_t)j * P + q] -= hc; ns_t[(size_t)j * P + q] -= 1; }
+            }
+          }
+          total[j] = tot; ns1[j] = ns;
+          // compute_mac (Geno.cpp:3077-3108), autosomes
+          const double mac = std::min(tot, 2.0 * ns - tot);
+          if (mac < p.min_mac) variant_ignored[j] = 1;
+        });
+        s2check(rg_s2_qt_block(s2, G.data(), n, bs, 0, NUMTOL, &o));
+      }
       // the result lines (compute_score_qt after the statistic, Step2_Models.cpp:440-466; print_sum_stats_single)
       for (int j = 0; j < bs; ++j) {
         if (variant_ignored[j] || ign[j]) { ++n_ignored_snps; continue; }

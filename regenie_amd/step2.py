@@ -80,8 +80,33 @@ class Step2QT:
                "mean": np.empty(bs), "n_obs": np.empty(bs, np.int32), "ignored": np.empty(bs, np.int32)}
         out = _QtOut(*[res[k].ctypes.data for k in ("stats", "bhat", "scale_fac", "mean", "n_obs", "ignored")])
         self._check(self.lib.rg_s2_qt_block(self.h, ptr, ld, bs, on_device, float(numtol), C.byref(out)))
+        return self._finish(res)
+
+    def _finish(self, res: dict) -> dict:
         res["kernel_ms"] = self.lib.rg_s2_last_kernel_ms(self.h)
         with np.errstate(invalid="ignore", divide="ignore"):
             res["se"] = res["bhat"] / res["stats"]          # Step2_Models.cpp:440
             res["chisq"] = res["stats"] ** 2                # Step2_Models.cpp:443
         return res
+
+    def score_block_packed(self, rows, flip: bool = False, numtol: float = NUMTOL) -> dict:
+        """Hard calls as they lie in a .bed file: rows [bs][>= ceil(n/4)] uint8 (numpy, or a CUDA torch tensor read in place),
+        2 bits per analysed sample (00 -> 2, 01 -> missing, 10 -> 1, 11 -> 0 copies of the counted allele); flip = --ref-first.
+        Every analysed sample must be observed for every phenotype (mask all ones in set_null)."""
+        on_device = 0
+        if isinstance(rows, np.ndarray):
+            rows = np.ascontiguousarray(rows, dtype=np.uint8)
+            bs, ld, ptr = rows.shape[0], rows.shape[1], rows.ctypes.data
+        else:
+            if not (rows.is_cuda and rows.element_size() == 1 and rows.dim() == 2 and rows.stride(1) == 1):
+                raise ValueError("score_block_packed: device rows must be a 2-d uint8 CUDA tensor with unit byte stride")
+            bs, ld, ptr, on_device = rows.shape[0], rows.stride(0), rows.data_ptr(), 1
+            import torch
+            torch.cuda.current_stream(rows.device).synchronize()
+        if rows.shape[1] < (self.n + 3) // 4:
+            raise ValueError("score_block_packed: rows must hold ceil(n / 4) bytes")
+        res = {"stats": np.empty((bs, self.P)), "bhat": np.empty((bs, self.P)), "scale_fac": np.empty(bs),
+               "mean": np.empty(bs), "n_obs": np.empty(bs, np.int32), "ignored": np.empty(bs, np.int32)}
+        out = _QtOut(*[res[k].ctypes.data for k in ("stats", "bhat", "scale_fac", "mean", "n_obs", "ignored")])
+        self._check(self.lib.rg_s2_qt_block_packed(self.h, ptr, ld, bs, on_device, 1 if flip else 0, float(numtol), C.byref(out)))
+        return self._finish(res)

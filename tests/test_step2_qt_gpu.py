@@ -160,3 +160,95 @@ def test_step1_loco_feeds_step2(example_dir, tmp_path):
     ref = s2o.score_qt_block(G, X, res, mask, scf)
     assert (ref["ignored"] == 0).sum() > 50 and np.nanmax(np.abs(ref["stats"])) > 1.0
     _compare(_run(X, res, mask, scf, G), ref)
+
+
+# ---- hard calls: rg_s2_qt_block_packed (2-bit rows, exact i8 matrix-core contractions) -------------------------------------------
+def _pack_bed(G):
+    """[bs][n] dosages in {0, 1, 2, nan} -> .bed rows (00 -> 2, 01 -> missing, 10 -> 1, 11 -> 0; low bits first; the unused bits
+    of the last byte are 00, as plink writes them)."""
+    code = np.where(np.isnan(G), 1, np.where(G == 2, 0, np.where(G == 1, 2, 3))).astype(np.uint8)
+    bs, n = code.shape
+    pad = (-n) % 4
+    if pad:
+        code = np.concatenate([code, np.zeros((bs, pad), np.uint8)], axis=1)
+    c = code.reshape(bs, -1, 4)
+    return (c[:, :, 0] | (c[:, :, 1] << 2) | (c[:, :, 2] << 4) | (c[:, :, 3] << 6)).astype(np.uint8)
+
+
+def _run_packed(X, res, mask, scf, rows, **kw):
+    from regenie_amd.step2 import Step2QT
+    n, C = X.shape
+    with Step2QT(n, C, res.shape[1]) as s2:
+        s2.set_null(X.T, res.T, mask.T, scf)
+        return s2.score_block_packed(rows, **kw)
+
+
+@pytest.mark.parametrize("n,C,P,bs", [(5003, 5, 3, 37), (301, 1, 1, 5), (2048, 3, 2, 4), (4097, 12, 7, 9), (70_001, 11, 9, 300), (9_999, 3, 2, 1)])
+def test_packed_parity_with_oracle(n, C, P, bs):
+    """Tail samples (n not a multiple of 4 nor of 64), more than 16 contraction columns (two column groups), several sample
+    segments, more than one 128-row tile, missing calls, a monomorphic and an all-missing variant."""
+    X, res, mask, scf, G = _problem(n + bs, n, C, P, bs, miss_y=0)
+    rng = np.random.default_rng(9)
+    if bs >= 4:
+        G[0, rng.random(n) < 0.1] = np.nan
+        G[1, rng.random(n) < 0.002] = np.nan
+        G[2, :] = 2.0
+        G[3, :] = np.nan
+    ref = s2o.score_qt_block(G, X, res, mask, scf)
+    got = _run_packed(X, res, mask, scf, _pack_bed(G))
+    _compare(got, ref)
+    dense = _run(X, res, mask, scf, G)
+    ok = ref["ignored"] == 0
+    assert np.allclose(got["stats"][ok], dense["stats"][ok], rtol=1e-10, atol=1e-11)
+
+
+def test_packed_no_missing_calls_and_flip():
+    """No missing call in the block (the missing-indicator contraction is skipped), and --ref-first = 2 - g on the observed calls."""
+    X, res, mask, scf, G = _problem(77, 12_345, 4, 3, 200, miss_y=0)
+    ref = s2o.score_qt_block(G, X, res, mask, scf)
+    _compare(_run_packed(X, res, mask, scf, _pack_bed(G)), ref)
+    G[10, ::7] = np.nan
+    G[150, 5] = np.nan
+    ref2 = s2o.score_qt_block(2.0 - G, X, res, mask, scf)
+    _compare(_run_packed(X, res, mask, scf, _pack_bed(G), flip=True), ref2)
+
+
+def test_packed_device_rows_padded_ld_and_determinism():
+    import torch
+    X, res, mask, scf, G = _problem(13, 30_011, 6, 4, 260, miss_y=0)
+    G[5, ::11] = np.nan
+    rows = _pack_bed(G)
+    a = _run_packed(X, res, mask, scf, rows)
+    big = torch.randint(0, 256, (260, rows.shape[1] + 37), dtype=torch.uint8, device="cuda")   # garbage beyond the row
+    big[:, :rows.shape[1]] = torch.from_numpy(rows).cuda()
+    b = _run_packed(X, res, mask, scf, big)
+    c = _run_packed(X, res, mask, scf, rows[100:200])
+    for k in ("stats", "bhat", "scale_fac", "mean", "n_obs"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+        assert np.array_equal(a[k][100:200], c[k], equal_nan=True), k
+
+
+def test_packed_refuses_masked_samples():
+    from regenie_amd.engine import RgError
+    X, res, mask, scf, G = _problem(5, 2000, 3, 2, 8, miss_y=0.05)
+    with pytest.raises(RgError, match="masked"):
+        _run_packed(X, res, mask, scf, _pack_bed(G))
+
+
+def test_packed_at_scale_matches_dense_route():
+    """200,000 samples x 1,024 variants (the sample count of BASELINE configs[4]): the packed route against the fp64 route of the
+    same library, and a spot check against the oracle."""
+    n, C, P, bs = 200_000, 10, 10, 1024
+    X, res, mask, scf, G = _problem(31, n, C, P, bs, miss_y=0)
+    rng = np.random.default_rng(2)
+    G[rng.random(G.shape) < 0.01] = np.nan
+    rows = _pack_bed(G)
+    got = _run_packed(X, res, mask, scf, rows)
+    dense = _run(X, res, mask, scf, G)
+    assert not got["ignored"].any()
+    assert np.array_equal(got["n_obs"], dense["n_obs"])
+    assert np.allclose(got["stats"], dense["stats"], rtol=1e-9, atol=1e-10)
+    assert np.allclose(got["bhat"], dense["bhat"], rtol=1e-9, atol=1e-13)
+    ref = s2o.score_qt_block(G[:4], X, res, mask, scf)
+    assert np.allclose(got["stats"][:4], ref["stats"], rtol=RTOL, atol=1e-10)
+    print("packed kernel %.3f ms, dense kernel %.3f ms for %d variants x %d samples" % (got["kernel_ms"], dense["kernel_ms"], bs, n))

@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Step-2 QT, hard calls: device time of rg_s2_qt_block_packed against rg_s2_qt_block (fp64 rows) at BASELINE configs[4]'s sample
+count (200,000 samples, 10 covariates, 10 phenotypes), for several block sizes.  Usage (GPU box): python tools/step2_packed_probe.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
+
+from regenie_amd.step2 import Step2QT
+
+
+def main(n=200_000, C=10, P=10):
+    rng = np.random.default_rng(1)
+    X = np.linalg.qr(np.column_stack([np.ones(n), rng.normal(size=(n, C - 1))]))[0]
+    res = rng.normal(size=(n, P))
+    res -= X @ (X.T @ res)
+    res /= res.std(axis=0)
+    mask = np.ones((n, P), np.uint8)
+    scf = np.ones(P)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    with Step2QT(n, C, P) as s2:
+        s2.set_null(X.T, res.T, mask.T, scf)
+        for bs in (512, 1024, 4096, 16384):
+            rows = torch.randint(0, 256, (bs, (n + 3) // 4), dtype=torch.uint8, device=dev, generator=g)   # uniform codes: 25% missing
+            rows_nomiss = rows | ((rows & 0x55) & ~((rows >> 1) & 0x55)) << 1                                    # 01 -> 11
+            for name, rr in (("25% missing calls", rows), ("no missing call", rows_nomiss.to(torch.uint8))):
+                ms = []
+                for _ in range(5):
+                    out = s2.score_block_packed(rr)
+                    ms.append(out["kernel_ms"])
+                t = float(np.median(ms[1:]))
+                print("packed  bs %6d  %-18s %8.3f ms  %7.2f M variants/s  %6.1f GB/s of 2-bit rows  %.2e genotype*pheno/s"
+                      % (bs, name, t, bs / t / 1e3, bs * n / 4 / t / 1e6, bs * n * P / t * 1e3), flush=True)
+            if bs <= 4096:
+                G = torch.randint(0, 3, (bs, n), device=dev, generator=g).double()
+                ms = [s2.score_block(G)["kernel_ms"] for _ in range(4)]
+                t = float(np.median(ms[1:]))
+                print("fp64    bs %6d  %-18s %8.3f ms  %7.2f M variants/s  %6.1f GB/s of fp64 rows" % (bs, "", t, bs / t / 1e3, 2 * bs * n * 8 / t / 1e6), flush=True)
+                del G
+
+
+if __name__ == "__main__":
+    main()
