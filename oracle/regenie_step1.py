@@ -66,6 +66,7 @@ class Step1Options:
     max_cat_levels: int = 10         # --maxCatLevels
     apply_rint: bool = False         # --apply-rint (ignored with --bt, Regenie.cpp:432)
     strict: bool = False
+    test_mode: bool = False          # --step 2: rm_missing_qt (Regenie.cpp:1086) keeps a QT's missing values masked (Pheno.cpp:328)
     ref_first: bool = False
     nchrom: int = 23                 # --nauto + 1
     min_case_count: int = 10
@@ -369,10 +370,13 @@ def read_pheno_and_cov(opt: Step1Options, fam_ids: List[str]) -> Prepared:
             Y[i, ip] = v
             if v != MISSING:
                 all_miss = False
-            elif strict:
-                mask[i, :] = False
-                all_miss = True
-                break
+            else:
+                if opt.test_mode and trait_mode == 0:   # Pheno.cpp:328: test_mode && rm_missing_qt
+                    mask[i, ip] = False
+                if strict:
+                    mask[i, :] = False
+                    all_miss = True
+                    break
             ip += 1
         if all_miss:
             in_pheno[i] = False

@@ -5,7 +5,10 @@ operation order and orientation (samples down the rows).
 
 PINNED against regenie itself: tests/test_reference_pin.py::test_step2_qt_oracle_against_reference compares BETA / SE /
 CHISQ / LOG10P with the Step-2 output of oracle/_ref/regenie (the reference's sources compiled by oracle/Makefile) on
-example_3chr.bed, fixtures under tests/golden/ref_outputs/step2/; closed-form identities in tests/test_step2_oracle.py.
+example_3chr.bed, and ::test_step2_qt_oracle_sparse_branch_against_reference pins score_qt_block_ref (the sparse-genotype branch
+the reference takes for variants with at most half of the samples non-zero, which differs from the dense one when phenotypes
+differ in their missing values) on synthetic data with 5 % missing phenotypes; fixtures under tests/golden/ref_outputs/step2/;
+closed-form identities in tests/test_step2_oracle.py.
 """
 from __future__ import annotations
 
@@ -77,6 +80,62 @@ def score_qt_block(G, X, res, masked_indivs, scf_sv, numtol=NUMTOL):
     with np.errstate(invalid="ignore", divide="ignore"):
         out["se"] = out["bhat"] / out["stats"]        # :440
         out["chisq"] = out["stats"] ** 2              # :443
+    return out
+
+
+def check_sparse(g_imputed, n_samples, prop_zero_thr=0.5):
+    """check_sparse_G for .bed input (n_zero == -1), Geno.cpp:3165-3177: after the mean imputation, at most
+    n_samples * (1 - prop_zero_thr) analysed entries are non-zero.  n_samples = params.n_samples (every kept sample of the file,
+    analysed or not)."""
+    return int(np.count_nonzero(g_imputed)) <= n_samples * (1.0 - prop_zero_thr)
+
+
+def score_qt_sparse(g, X, res, masked_indivs, scf_sv, YtX):
+    """compute_score_qt, the sparse non-strict branch, Step2_Models.cpp:402-413, 420-427: the mean-imputed genotype on its raw
+    scale, covariates projected out of the numerator through YtX = res^T X (Data.cpp:2402), and per trait
+    denum = |G m|^2 - 2 (X^T (G m)) . (X^T G) + |X^T G|^2 -- "an approximation assuming X'X is same for all traits (=I)"."""
+    XtG = X.T @ g                                                       # :403
+    num = res.T @ g - YtX @ XtG                                         # :404
+    XtG_ss = float(XtG @ XtG)                                           # :405
+    P = res.shape[1]
+    denum = np.empty(P)
+    for ph in range(P):                                                 # :407-410
+        gm = g * masked_indivs[:, ph]
+        XtGm = X.T @ gm
+        denum[ph] = float(gm @ gm) - 2.0 * float(XtGm @ XtG) + XtG_ss
+    stats = num / np.sqrt(denum)                                        # :420
+    bhat = stats * scf_sv / np.sqrt(denum)                              # :427
+    return stats, bhat
+
+
+def score_qt_block_ref(G, X, res, masked_indivs, scf_sv, n_samples=None, numtol=NUMTOL, prop_zero_thr=0.5):
+    """compute_tests_mt over one block as the reference runs it for hard calls (Data.cpp:2476-2555): check_sparse_G decides per
+    variant between the sparse branch (no residualisation, scale_fac = 1: Data.cpp:2513-2515) and the dense one.  With every
+    mask entry 1 the two branches are the same number; they differ when phenotypes differ in their missing values.
+    Extra output: "sparse" [bs]."""
+    bs, P = G.shape[0], res.shape[1]
+    n_samples = X.shape[0] if n_samples is None else n_samples
+    YtX = res.T @ X                                                    # Data.cpp:2402
+    out = {"stats": np.full((bs, P), np.nan), "bhat": np.full((bs, P), np.nan), "scale_fac": np.zeros(bs),
+           "mean": np.zeros(bs), "n_obs": np.zeros(bs, np.int32), "ignored": np.zeros(bs, np.int32), "sparse": np.zeros(bs, np.int32)}
+    for j in range(bs):
+        g, mean, nobs = mean_impute(G[j])
+        out["mean"][j], out["n_obs"][j] = mean, nobs
+        if nobs == 0:
+            out["ignored"][j], out["scale_fac"][j] = 1, float("nan")
+            continue
+        if check_sparse(g, n_samples, prop_zero_thr):
+            out["sparse"][j], out["scale_fac"][j] = 1, 1.0
+            out["stats"][j], out["bhat"][j] = score_qt_sparse(g, X, res, masked_indivs, scf_sv, YtX)
+            continue
+        gs, sf, ign = residualize_geno(X, g, numtol)
+        out["scale_fac"][j], out["ignored"][j] = sf, int(ign)
+        if ign:
+            continue
+        out["stats"][j], out["bhat"][j] = score_qt(gs, sf, res, masked_indivs, scf_sv)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        out["se"] = out["bhat"] / out["stats"]
+        out["chisq"] = out["stats"] ** 2
     return out
 
 

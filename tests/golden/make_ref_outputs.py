@@ -146,6 +146,11 @@ def step2_cases(workdir, step1_dirs):
                                                         "--phenoFile", EX + "/phenotype_bin.txt", "--remove", EX + "/fid_iid_to_remove.txt",
                                                         "--bsize", "200", "--bt"]),
     }
+    # phenotypes that differ in their missing values (5 %) and genotypes with missing calls (1 %): the sparse-genotype branch of
+    # compute_score_qt (Step2_Models.cpp:402-413, variants with at most half of the samples non-zero) next to the dense one
+    S = os.path.join(step1_dirs["qt_kfold_synth_missing"], "synth")
+    runs["qt_synth_missing"] = (step1_dirs["qt_kfold_synth_missing"], ["--step", "2", "--bed", S, "--covarFile", S + ".covar", "--phenoFile", S + ".pheno",
+                                                                      "--bsize", "200", "--qt"])
     for name, (s1, args) in runs.items():
         r = subprocess.run([REGENIE] + args + ["--pred", os.path.join(s1, "out_pred.list"), "--out", name], cwd=d,
                            capture_output=True, text=True)

@@ -227,6 +227,59 @@ def test_step2_qt_oracle_against_reference():
     assert row == len(refs[0][1])
 
 
+def test_step2_qt_oracle_sparse_branch_against_reference(tmp_path):
+    """Phenotypes that differ in their missing values (5 %), genotypes with missing calls (1 %): the reference takes the sparse
+    branch of compute_score_qt (approximate per-trait denominators, Step2_Models.cpp:402-413) for the variants check_sparse_G
+    flags and the dense branch for the others; oracle s2.score_qt_block_ref against regenie's own output for 500 variants x 4
+    traits on the synthetic data of the qt_kfold_synth_missing case (regenerated here, deterministic)."""
+    import json
+    from oracle import regenie_step2_qt as s2
+    from tests.util import synth_dosages, write_plink
+    meta = json.load(open(os.path.join(REF_OUT, "qt_kfold_synth_missing", "meta.json")))
+    spec = meta["synthetic"]
+    S = str(tmp_path / "synth")
+    write_plink(S, synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"]), spec["chroms"], P=spec["P"],
+                seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=128, test_mode=True)
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    bed, _ = orc.open_bed(opt.bed + ".bed", prep.n_file)
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    P = prep.Y.shape[1]
+    loco = []
+    for ph in range(P):
+        hdr, v = read_loco_gz(os.path.join(REF_OUT, "qt_kfold_synth_missing", "out_%d.loco.gz" % (ph + 1)))
+        pos = {s: k for k, s in enumerate(hdr)}
+        loco.append(v[:, [pos[i] for i in ids]])
+    refs = [_read_regenie(os.path.join(REF_OUT, "step2", "qt_synth_missing_Y%d.regenie.gz" % (ph + 1))) for ph in range(P)]
+    col = {nm: i for i, nm in enumerate(refs[0][0])}
+    X, Y, mask = prep.X[ia], prep.Y[ia], prep.mask[ia].astype(np.float64)
+    assert (mask.min(axis=0) == 0).all()                       # every trait has missing values
+    row, nsparse, ndense, moved = 0, 0, 0, 0
+    for c in sorted(set(chrom.tolist())):
+        blup = np.stack([loco[ph][c - 1] for ph in range(P)], axis=1)             # the .loco has a line for every chromosome 1..23
+        res, _, scf = s2.compute_res(Y, blup * mask, mask, prep.Neff, X.shape[1], prep.scale_Y)
+        sel = np.flatnonzero(chrom == c)
+        G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
+        out = s2.score_qt_block_ref(G, X, res, mask, scf, n_samples=int((~prep.ind_ignore).sum()))
+        dense = s2.score_qt_block(G, X, res, mask, scf)
+        nsparse += int(out["sparse"].sum()); ndense += int((1 - out["sparse"]).sum())
+        moved = max(moved, float(np.nanmax(np.abs(out["chisq"] / dense["chisq"] - 1.0))))
+        for k in range(sel.size):
+            for ph in range(P):
+                r = refs[ph][1][row + k]
+                assert r[col["ID"]] == snp_ids[sel[k]]
+                beta, se, chisq, logp = (float(r[col[nm]]) for nm in ("BETA", "SE", "CHISQ", "LOG10P"))
+                assert out["bhat"][k, ph] == pytest.approx(beta, rel=5e-5, abs=2e-6)
+                assert out["se"][k, ph] == pytest.approx(se, rel=5e-5)
+                assert out["chisq"][k, ph] == pytest.approx(chisq, rel=1e-4, abs=2e-6)
+                assert s2.get_logp(out["chisq"][k, ph]) == pytest.approx(logp, rel=1e-4, abs=2e-6)
+        row += sel.size
+    assert row == len(refs[0][1]) == 500
+    assert nsparse > 100 and ndense > 100                      # both branches exercised
+    assert moved > 1e-3                                        # and the sparse branch is not the dense number
+
+
 needs_ref_binary = pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")
 
 
