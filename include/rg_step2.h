@@ -8,8 +8,11 @@
  *                     num = res^T G * gsc, denum = gsc^2 * mask^T G^2, stats = num / sqrt(denum),
  *                     bhat = stats * scf_sv / sqrt(denum), se = bhat / stats, chisq = stats^2      Step2_Models.cpp:343-468 (compute_score_qt)
  *                     called per variant from compute_tests_mt                                      Data.cpp:2476-2555
- * Not in this slice (the host keeps doing them): reading the LOCO file (blup_read_chr), the MAC / INFO filters, the sparse
- * genotype shortcut (same statistic, different summation), --strict, mse_full, MCC, the p-value and the output lines.
+ *   rg_s2_qt_block_packed  the same for hard calls as they lie in a .bed file, INCLUDING the sparse-genotype branch the
+ *                     reference takes per variant (check_sparse_G, Geno.cpp:3165-3177; Step2_Models.cpp:402-413)
+ * Not in this slice (the host keeps doing them): reading the LOCO file (blup_read_chr), the MAC / INFO filters, --strict,
+ * mse_full, MCC, the p-value and the output lines.  rg_s2_qt_block evaluates the dense branch for every variant: equal to the
+ * reference when every analysed sample is observed for every phenotype, the exact mask_p^T r^2 otherwise.
  *
  * Layout: every matrix is row-major with the SAMPLE index fastest -- G is [bs][ldg], X is [C][n], yres and mask are [P][n];
  * n = samples in the analysis, in the caller's order.  A missing genotype is NaN or any value < 0 (regenie's -3).
@@ -49,6 +52,9 @@ typedef struct rg_s2_qt_out {
   double* mean;      /* [bs]     mean over the non-missing samples (= 2 * allele freq.)  */
   int32_t* n_obs;    /* [bs]     non-missing samples                                     */
   int32_t* ignored;  /* [bs]     1 when scale_fac < numtol (or nothing observed)         */
+  double* total_p;   /* [bs][P]  rg_s2_qt_block_packed only: allele count over the samples observed for the variant and the trait
+                                 (what update_trait_counts leaves in af / mac per trait, Geno.cpp:2948-2959)        */
+  int32_t* n_obs_p;  /* [bs][P]  rg_s2_qt_block_packed only: those samples' number (ns per trait)                   */
 } rg_s2_qt_out;      /* every pointer is a HOST pointer and may be NULL                  */
 
 /* One block of bs variants.  G is a host pointer, or a device pointer when g_on_device != 0 (then it is read in place).
@@ -59,11 +65,19 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
 /* The same statistic for HARD CALLS handed over as they lie in a .bed file: row j holds the 2-bit codes of the n analysed samples in
  * the caller's order, sample-fastest, 4 per byte, low bits first (00 -> 2 copies of the counted allele, 01 -> missing, 10 -> 1,
  * 11 -> 0: buildLookupTable, Geno.cpp:2833-2856), rows ld >= ceil(n / 4) bytes apart; flip != 0 counts the other allele
- * (2 - g, the reference's --ref-first).  Needs mask == 1 everywhere in the last rg_s2_set_null (every analysed sample observed for
- * every phenotype): RG_S2_ERR_ARG otherwise -- use rg_s2_qt_block then.  The contractions run on the i8 matrix cores with exact
- * integer sums (csrc/step2_qt.hip); the genotypes are read at 2 bits each.  rows: host pointer, or device when rows_on_device. */
+ * (2 - g, the reference's --ref-first).  This entry follows compute_tests_mt for hard calls to the letter: check_sparse_G
+ * (Geno.cpp:3165-3177) sends a variant with at most n_samples * (1 - prop_zero_thr) non-zero entries down the sparse branch of
+ * compute_score_qt (Step2_Models.cpp:402-413: no residualisation, scale_fac = 1, per-trait denominators with the reference's
+ * "X'X = I for every trait" approximation) and the others down the dense branch (exact mask_p^T r^2) -- the two are the same
+ * number when mask == 1 everywhere, and differ when phenotypes differ in their missing values (then C * P extra contraction
+ * columns are carried; at most 4096 columns in all).  The contractions run on the i8 matrix cores with exact integer sums
+ * (csrc/step2_qt.hip); the genotypes are read at 2 bits each.  rows: host pointer, or device when rows_on_device. */
 int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32_t bs, int32_t rows_on_device, int32_t flip,
                           double numtol, const rg_s2_qt_out* out);
+
+/* check_sparse_G's constants: n_samples = params.n_samples (every kept sample of the file, >= n; default n) and
+ * prop_zero_thr = --prop-zero-thr (default 0.5). */
+int rg_s2_set_sparse_rule(rg_s2_ctx* ctx, int64_t n_samples, double prop_zero_thr);
 
 /* Device time of the kernels of the last rg_s2_qt_block / rg_s2_qt_block_packed call (hipEvents on the library's stream), in ms. */
 double rg_s2_last_kernel_ms(const rg_s2_ctx* ctx);

@@ -28,16 +28,22 @@
 #include "../../include/rg_step2.h"
 #include "rg_internal.h"
 
-// Hard calls (rg_s2_qt_block_packed): the same statistic from the 2-bit rows, exactly, on the i8 matrix cores.  When every
-// analysed sample is observed for every phenotype (mask all ones, the only case the reference's dense path and its sparse
-// shortcut agree on) the statistic needs nothing but CONTRACTIONS of the genotype row with fixed fp64 columns plus counts:
+// Hard calls (rg_s2_qt_block_packed): the same statistic from the 2-bit rows, exactly, on the i8 matrix cores.  The statistic needs
+// nothing but genotype COUNTS and CONTRACTIONS of the genotype row with columns that are fixed per chromosome:
 //   A_c = sum g0 x_c, M_c = sum miss x_c, R_p = sum g0 res_p, T_p = sum miss res_p        (g0 in {0,1,2}, miss in {0,1})
-//   mu = (n1 + 2 n2) / (n - nmiss),  beta = A + mu M,  |r|^2 = n1 + 4 n2 + nmiss mu^2 - |beta|^2   (X orthonormal)
-//   num_p = R_p + mu T_p - (res_p^T X) beta,  denum_p = |r|^2
-// and those contractions are what xy_i8.hip evaluates for Step 1: the columns [X | res] are split once per chromosome into
-// eight balanced base-128 digit planes (k_v_split), v_mfma_i32_32x32x32_i8 accumulates exact int32 digit sums per sample
-// segment, the segments are added in int64 and the digits recombined in fp64 (k_s2_combine).  The genotype operand is read
-// at 2 bits per call -- 0.25 B per genotype against 16 B over the two fp64 passes above -- and never leaves integer form.
+//   mu = (n1 + 2 n2) / (n - nmiss),  beta = A + mu M = X^T g~,  |r|^2 = n1 + 4 n2 + nmiss mu^2 - |beta|^2   (X orthonormal)
+//   num_p = R_p + mu T_p - (res_p^T X) beta
+// and, when every analysed sample is observed for every phenotype, denum_p = |r|^2.  When phenotypes differ in their missing values
+// the per-trait denominators also need the contractions with x_c * mask_p (C * P columns) and of g0^2 and miss with mask_p:
+//   XtGm_pc = sum g~ mask_p x_c,  g2m_p = sum mask_p g~^2 = sum mask_p g0^2 + mu^2 sum mask_p miss
+//   dense variant :  denum_p = g2m_p - 2 XtGm_p . beta + beta^T Q_p beta,  Q_p = X^T diag(mask_p) X      (= mask_p^T r^2, exact)
+//   sparse variant:  denum_p = g2m_p - 2 XtGm_p . beta + |beta|^2    (the reference's approximation, Step2_Models.cpp:402-413)
+// where "sparse" is check_sparse_G's rule (Geno.cpp:3165-3177: at most n_samples * (1 - prop_zero_thr) non-zero entries after the
+// mean imputation) -- the reference takes that branch without residualising or rescaling the variant (Data.cpp:2513-2515).
+// Those contractions are what xy_i8.hip evaluates for Step 1: the columns are split once into eight balanced base-128 digit
+// planes (k_v_split; only the res columns change with the chromosome), v_mfma_i32_32x32x32_i8 accumulates exact int32 digit sums
+// per sample segment, the segments are added in int64 and the digits recombined in fp64 (k_s2_combine).  The genotype operand is
+// read at 2 bits per call -- 0.25 B per genotype against 16 B over the two fp64 passes above -- and never leaves integer form.
 
 namespace {
 
@@ -363,14 +369,26 @@ __global__ __launch_bounds__(256) void k_s2_ytx(const double* __restrict__ X, co
   if (threadIdx.x == 0) ytx[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// A[j][set][c] = vsc[c] * sum_k 128^k (sum over segments of S[grp][set][f][j][cl * 8 + k]): the segment sums are exact in int64, so the
-// value does not depend on how the samples were cut into segments.  thread = (j, c); set 1 only when the block has a missing call.
+// V[C + P + p * C + c][i] = x_c(i) mask_p(i), V[cm0 + p][i] = mask_p(i); grid (ceil(n / 256), P)
+__global__ void k_s2_mask_cols(const double* __restrict__ X, const uint8_t* __restrict__ M, int64_t n, int64_t Np, int C, int P, int cm0,
+                               double* __restrict__ V) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int p = blockIdx.y;
+  if (i >= n) return;
+  const double m = M[(int64_t)p * n + i] ? 1.0 : 0.0;
+  for (int c = 0; c < C; ++c) V[(int64_t)(C + P + p * C + c) * Np + i] = X[(int64_t)c * n + i] * m;
+  V[(int64_t)(cm0 + p) * Np + i] = m;
+}
+
+// out[j][set][c] = vsc[c] * sum_k 128^k (sum over segments of S[c >> 4][set][f][j][(c & 15) * 8 + k]), c < Cv: the segment sums are exact in
+// int64, so the value does not depend on how the samples were cut into segments.  thread = (j, c); set 1 only when total_miss says the
+// block has a missing call (total_miss == nullptr: set 0 only).
 __global__ void k_s2_combine(const int32_t* __restrict__ S, const double* __restrict__ vsc, const int32_t* __restrict__ total_miss, int bs,
-                             int n128, int nseg, int Cv, double* __restrict__ A) {
+                             int n128, int nseg, int Cv, double* __restrict__ out) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= bs * Cv) return;
   const int j = t / Cv, c = t - j * Cv, grp = c >> 4, cl = c & 15;
-  const int nset = *total_miss > 0 ? 2 : 1;
+  const int nset = (total_miss && *total_miss > 0) ? 2 : 1;
   for (int set = 0; set < 2; ++set) {
     double v = 0.0;
     if (set < nset) {
@@ -384,41 +402,72 @@ __global__ void k_s2_combine(const int32_t* __restrict__ S, const double* __rest
       for (int k = 7; k >= 0; --k) v = fma(v, 128.0, (double)tk[k]);
       v *= vsc[c];
     }
-    A[((int64_t)j * 2 + set) * Cv + c] = v;
+    out[((int64_t)j * 2 + set) * Cv + c] = v;
   }
 }
 
-// thread = variant: the statistic from the contractions and the counts (formulas at the top of the file)
-__global__ void k_s2_packed_final(const double* __restrict__ A, const int32_t* __restrict__ cnt, const double* __restrict__ ytx, int bs, int C, int P,
-                                  int64_t n, double numtol, const double* __restrict__ scf_sv, double* __restrict__ stats, double* __restrict__ bhat,
-                                  double* __restrict__ scale_fac, double* __restrict__ mean, int32_t* __restrict__ nobs_out, int32_t* __restrict__ ignored) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= bs) return;
-  const int Cv = C + P;
-  const double n1 = cnt[j * 4 + 0], n2 = cnt[j * 4 + 1], nm = cnt[j * 4 + 2];
-  const double nobs = (double)n - nm;
+struct PackedFinal {
+  const double* A;      // [bs][2][Cvt]
+  const double* Sq;     // [bs][2][CvB] (masked problems) or null
+  const int32_t* cnt;   // [bs][4]
+  const double *ytx, *Q, *msum, *scf_sv;
+  int bs, C, P, Cvt, cm0, CvB, sqoff, masked;
+  int64_t n;
+  double numtol, nz_max;   // a variant is "sparse" when its non-zero entries number <= nz_max
+  double *stats, *bhat, *scale_fac, *mean, *total_p;
+  int32_t *nobs, *ignored, *nobs_p;
+};
+
+// thread = (variant, phenotype): the statistic from the contractions and the counts (formulas at the top of the file)
+__global__ void k_s2_packed_final(PackedFinal a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.bs * a.P) return;
+  const int j = t / a.P, p = t - j * a.P, C = a.C, P = a.P;
+  const double n1 = a.cnt[j * 4 + 0], n2 = a.cnt[j * 4 + 1], nm = a.cnt[j * 4 + 2];
+  const double nobs = (double)a.n - nm;
   const double mu = nobs > 0 ? (n1 + 2.0 * n2) / nobs : 0.0;
-  const double* a0 = A + (int64_t)j * 2 * Cv;
-  const double* a1 = a0 + Cv;
-  double b2 = 0.0;
+  const double* a0 = a.A + (int64_t)j * 2 * a.Cvt;
+  const double* a1 = a0 + a.Cvt;
+  double b2 = 0.0, corr = 0.0;
   for (int c = 0; c < C; ++c) {
     const double b = fma(mu, a1[c], a0[c]);
     b2 = fma(b, b, b2);
+    corr = fma(a.ytx[p * C + c], b, corr);
   }
-  const double ss = (n1 + 4.0 * n2 + nm * mu * mu) - b2;
-  const double sf = sqrt(ss) / sqrt((double)(n - C));
-  const bool ign = !(sf >= numtol) || nobs <= 0;
-  const double sd = sqrt(ss);
-  for (int p = 0; p < P; ++p) {
-    double num = fma(mu, a1[C + p], a0[C + p]);
-    double corr = 0.0;
-    for (int c = 0; c < C; ++c) corr = fma(ytx[p * C + c], fma(mu, a1[c], a0[c]), corr);
-    num -= corr;
-    const double z = num / sd;
-    stats[(int64_t)j * P + p] = ign ? NAN : z;
-    bhat[(int64_t)j * P + p] = ign ? NAN : z * scf_sv[p] / sd;
+  const double num = fma(mu, a1[C + p], a0[C + p]) - corr;
+  const double ss = (n1 + 4.0 * n2 + nm * mu * mu) - b2;                      // |g~ - X beta|^2 over every analysed sample
+  const bool sparse = (n1 + n2 + (mu != 0.0 ? nm : 0.0)) <= a.nz_max;        // check_sparse_G on the mean-imputed vector
+  const double sf = sparse ? 1.0 : sqrt(ss) / sqrt((double)(a.n - C));       // residualize_geno only runs for dense variants
+  const bool ign = nobs <= 0 || (!sparse && !(sf >= a.numtol));
+  double den = ss, tot = n1 + 2.0 * n2, nobs_p = nobs;
+  if (a.masked) {
+    const double* sq = a.Sq + (int64_t)j * 2 * a.CvB + a.sqoff;
+    const double g2m = sq[p] + mu * mu * a1[a.cm0 + p];
+    const double* x0 = a0 + C + P + p * C;
+    const double* x1 = a1 + C + P + p * C;
+    double cross = 0.0;
+    for (int c = 0; c < C; ++c) cross = fma(fma(mu, x1[c], x0[c]), fma(mu, a1[c], a0[c]), cross);
+    double last = b2;
+    if (!sparse) {
+      last = 0.0;
+      const double* q = a.Q + (int64_t)p * C * C;
+      for (int c = 0; c < C; ++c) {
+        double row = 0.0;
+        for (int d = 0; d < C; ++d) row = fma(q[c * C + d], fma(mu, a1[d], a0[d]), row);
+        last = fma(row, fma(mu, a1[c], a0[c]), last);
+      }
+    }
+    den = g2m - 2.0 * cross + last;
+    tot = a0[a.cm0 + p];
+    nobs_p = a.msum[p] - a1[a.cm0 + p];
   }
-  scale_fac[j] = sf; mean[j] = mu; nobs_out[j] = (int32_t)nobs; ignored[j] = ign ? 1 : 0;
+  const double sd = sqrt(den);
+  const double z = num / sd;
+  a.stats[(int64_t)j * P + p] = ign ? NAN : z;
+  a.bhat[(int64_t)j * P + p] = ign ? NAN : z * a.scf_sv[p] / sd;
+  a.total_p[(int64_t)j * P + p] = tot;
+  a.nobs_p[(int64_t)j * P + p] = (int32_t)nearbyint(nobs_p);
+  if (p == 0) { a.scale_fac[j] = sf; a.mean[j] = mu; a.nobs[j] = (int32_t)nobs; a.ignored[j] = ign ? 1 : 0; }
 }
 
 }  // namespace
@@ -438,15 +487,22 @@ struct rg_s2_ctx {
   double last_ms = 0.0;
   // hard-call route (rg_s2_qt_block_packed): built lazily after rg_s2_set_null
   bool complete = false;        // every mask byte is 1
-  bool planes_ready = false;
-  int64_t Np = 0;               // samples padded to nseg segments of a multiple of 64
+  bool static_ready = false;    // planes of the columns that depend on X and the masks only
+  bool res_ready = false;       // planes of the res columns, res^T X
+  std::vector<double> hX;       // host copies of the last X / mask (the planes are kept while they do not change)
+  std::vector<uint8_t> hM;
+  int64_t Np = 0;               // samples padded to a multiple of 64 * 32
+  int Cvt = 0, cm0 = 0;         // columns in all, first mask column (a multiple of 16); complete problems: Cvt = cm0 = C + P
+  int64_t rule_n = 0;           // check_sparse_G: params.n_samples (0 = the analysed samples)
+  double rule_thr = 0.5;        // params.prop_zero_thr
   SegLayout seg;
-  double* dV = nullptr;         // [C + P][Np]  X then res, zero padded
-  int8_t* dvd = nullptr;        // [C + P][8][Np] digit planes
-  double *dvsc = nullptr, *dYtX = nullptr;   // [C + P] plane scales, [P][C] res_p^T x_c
+  double* dV = nullptr;         // [Cvt (padded to 16)][Np]  X | res | x_c mask_p | 0 | mask_p, zero padded
+  int8_t* dvd = nullptr;        // the digit planes of dV's columns, [col][8][Np]
+  double *dvsc = nullptr, *dYtX = nullptr;   // [col] plane scales, [P][C] res_p^T x_c
+  double *dQ = nullptr, *dMsum = nullptr;    // [P][C][C] X^T diag(mask_p) X, [P] sum of mask_p
   void* pbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t pcap[6] = {0, 0, 0, 0, 0, 0};
-  int32_t hdr[2] = {0, 0};      // staged {total_miss = 0, bs} of the block in flight
+  int32_t hdr[3] = {0, 0, 0};   // staged {total_miss = 0, bs, 0} of the block in flight
   std::string err;
 };
 
@@ -516,6 +572,8 @@ void rg_s2_destroy(rg_s2_ctx* ctx) {
     if (ctx->dvd) (void)hipFree(ctx->dvd);
     if (ctx->dvsc) (void)hipFree(ctx->dvsc);
     if (ctx->dYtX) (void)hipFree(ctx->dYtX);
+    if (ctx->dQ) (void)hipFree(ctx->dQ);
+    if (ctx->dMsum) (void)hipFree(ctx->dMsum);
     if (ctx->dX) (void)hipFree(ctx->dX);
     if (ctx->dY) (void)hipFree(ctx->dY);
     if (ctx->dM) (void)hipFree(ctx->dM);
@@ -539,10 +597,24 @@ int rg_s2_set_null(rg_s2_ctx* ctx, const double* X, const double* yres, const ui
   S2_HIP(hipMemcpyAsync(ctx->dscf, scf_sv, sizeof(double) * ctx->P, hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipStreamSynchronize(ctx->st));
   ctx->have_null = true;
-  ctx->planes_ready = false;
-  ctx->complete = true;
-  for (size_t i = 0, e = (size_t)ctx->n * ctx->P; i < e; ++i)
-    if (!mask[i]) { ctx->complete = false; break; }
+  ctx->res_ready = false;
+  const size_t nx = (size_t)ctx->n * ctx->C, nm = (size_t)ctx->n * ctx->P;
+  if (ctx->hX.size() != nx || ctx->hM.size() != nm || memcmp(ctx->hX.data(), X, nx * sizeof(double)) != 0 || memcmp(ctx->hM.data(), mask, nm) != 0) {
+    ctx->hX.assign(X, X + nx);
+    ctx->hM.assign(mask, mask + nm);
+    ctx->static_ready = false;
+    ctx->complete = true;
+    for (size_t i = 0; i < nm; ++i)
+      if (!mask[i]) { ctx->complete = false; break; }
+  }
+  return RG_S2_OK;
+}
+
+int rg_s2_set_sparse_rule(rg_s2_ctx* ctx, int64_t n_samples, double prop_zero_thr) {
+  if (!ctx || !ctx->st) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_set_sparse_rule: context was not created");
+  if (n_samples < ctx->n || !(prop_zero_thr >= 0.0 && prop_zero_thr <= 1.0))
+    return fail(ctx, RG_S2_ERR_ARG, "rg_s2_set_sparse_rule: need n_samples >= n and 0 <= prop_zero_thr <= 1");
+  ctx->rule_n = n_samples; ctx->rule_thr = prop_zero_thr;
   return RG_S2_OK;
 }
 
@@ -622,32 +694,65 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   if (!ctx->have_null) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_packed: rg_s2_set_null has not been called");
   const int64_t n = ctx->n, nbytes = (n + 3) / 4;
   if (!rows || !out || bs < 1 || ld < nbytes) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_packed: bad arguments (need bs >= 1, ld >= ceil(n / 4))");
-  if (!ctx->complete)
-    return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_packed: a sample is masked for some phenotype; the hard-call route needs mask == 1 "
-                                    "everywhere (use rg_s2_qt_block)");
-  const int C = ctx->C, P = ctx->P, Cv = C + P, ngrp = (Cv + 15) / 16;
+  const int C = ctx->C, P = ctx->P;
   S2_HIP(hipSetDevice(ctx->dev));
   int rc;
-  if (!ctx->planes_ready) {   // once per rg_s2_set_null: the digit planes of [X | res] and res^T X
-    if (!ctx->dV) {
-      // the sample axis is cut into 32 pieces of a multiple of 64 samples; a call contracts 32 / m merged pieces per workgroup row
-      ctx->Np = (n + 64 * RG_MAX_SEG - 1) / (64 * RG_MAX_SEG) * (64 * RG_MAX_SEG);
-      S2_HIP(hipMalloc((void**)&ctx->dV, sizeof(double) * Cv * ctx->Np));
-      S2_HIP(hipMalloc((void**)&ctx->dvd, (size_t)ngrp * 16 * 8 * ctx->Np));
-      S2_HIP(hipMalloc((void**)&ctx->dvsc, sizeof(double) * ngrp * 16));
-      S2_HIP(hipMalloc((void**)&ctx->dYtX, sizeof(double) * P * C));
-      S2_HIP(hipMemsetAsync(ctx->dV, 0, sizeof(double) * Cv * ctx->Np, ctx->st));
-    }
+  if (!ctx->static_ready) {   // X or the masks changed: column layout, the planes of every column but res, Q_p
+    const int cv1 = ctx->complete ? C + P : C + P + C * P;
+    const int cm0 = ctx->complete ? cv1 : (cv1 + 15) / 16 * 16, cvt = ctx->complete ? cv1 : cm0 + P;
+    if (cvt > 4096) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_packed: covariates x phenotypes with differing missing values > 4096 columns");
+    const int ngrp = (cvt + 15) / 16;
+    ctx->Np = (n + 64 * RG_MAX_SEG - 1) / (64 * RG_MAX_SEG) * (64 * RG_MAX_SEG);   // 32 pieces of a multiple of 64 samples
+    for (void** q : {(void**)&ctx->dV, (void**)&ctx->dvd, (void**)&ctx->dvsc, (void**)&ctx->dYtX, (void**)&ctx->dQ, (void**)&ctx->dMsum})
+      if (*q) { S2_HIP(hipFree(*q)); *q = nullptr; }
+    ctx->Cvt = cvt; ctx->cm0 = cm0;
+    S2_HIP(hipMalloc((void**)&ctx->dV, sizeof(double) * ngrp * 16 * ctx->Np));
+    S2_HIP(hipMalloc((void**)&ctx->dvd, (size_t)ngrp * 16 * 8 * ctx->Np));
+    S2_HIP(hipMalloc((void**)&ctx->dvsc, sizeof(double) * ngrp * 16));
+    S2_HIP(hipMalloc((void**)&ctx->dYtX, sizeof(double) * P * C));
+    S2_HIP(hipMalloc((void**)&ctx->dQ, sizeof(double) * P * C * C));
+    S2_HIP(hipMalloc((void**)&ctx->dMsum, sizeof(double) * P));
+    S2_HIP(hipMemsetAsync(ctx->dV, 0, sizeof(double) * ngrp * 16 * ctx->Np, ctx->st));
     S2_HIP(hipMemcpy2DAsync(ctx->dV, ctx->Np * sizeof(double), ctx->dX, n * sizeof(double), n * sizeof(double), C, hipMemcpyDeviceToDevice, ctx->st));
-    S2_HIP(hipMemcpy2DAsync(ctx->dV + (int64_t)C * ctx->Np, ctx->Np * sizeof(double), ctx->dY, n * sizeof(double), n * sizeof(double), P,
-                            hipMemcpyDeviceToDevice, ctx->st));
-    rg_launch_v_split(ctx->st, ctx->dV, ctx->Np, Cv, ctx->dvd, ctx->dvsc);
+    if (!ctx->complete) {
+      hipLaunchKernelGGL(k_s2_mask_cols, dim3((unsigned)((n + 255) / 256), P), dim3(256), 0, ctx->st, ctx->dX, ctx->dM, n, ctx->Np, C, P, cm0, ctx->dV);
+      // Q_p = X^T diag(mask_p) X = I - sum over the samples masked for p of x x^T (X is orthonormal on the analysed samples)
+      std::vector<double> Q((size_t)P * C * C, 0.0), msum(P, 0.0), xi(C);
+      for (int p = 0; p < P; ++p) {
+        double* q = Q.data() + (size_t)p * C * C;
+        for (int c = 0; c < C; ++c) q[c * C + c] = 1.0;
+        const uint8_t* m = ctx->hM.data() + (size_t)p * n;
+        int64_t kept = 0;
+        for (int64_t i = 0; i < n; ++i) {
+          if (m[i]) { ++kept; continue; }
+          for (int c = 0; c < C; ++c) xi[c] = ctx->hX[(size_t)c * n + i];
+          for (int c = 0; c < C; ++c)
+            for (int d = 0; d < C; ++d) q[c * C + d] -= xi[c] * xi[d];
+        }
+        msum[p] = (double)kept;
+      }
+      S2_HIP(hipMemcpyAsync(ctx->dQ, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, ctx->st));
+      S2_HIP(hipMemcpyAsync(ctx->dMsum, msum.data(), sizeof(double) * P, hipMemcpyHostToDevice, ctx->st));
+      S2_HIP(hipStreamSynchronize(ctx->st));      // Q / msum are locals
+    }
+    rg_launch_v_split(ctx->st, ctx->dV, ctx->Np, C, ctx->dvd, ctx->dvsc);
+    if (cvt > C + P)
+      rg_launch_v_split(ctx->st, ctx->dV + (int64_t)(C + P) * ctx->Np, ctx->Np, ngrp * 16 - (C + P), ctx->dvd + (size_t)(C + P) * 8 * ctx->Np, ctx->dvsc + C + P);
+    S2_HIP(hipGetLastError());
+    ctx->static_ready = true;
+    ctx->res_ready = false;
+  }
+  const int Cvt = ctx->Cvt, cm0 = ctx->cm0, ngrp = (Cvt + 15) / 16, masked = ctx->complete ? 0 : 1;
+  const int64_t Np = ctx->Np, ldp = Np / 4;
+  if (!ctx->res_ready) {      // once per rg_s2_set_null: the planes of the res columns and res^T X
+    S2_HIP(hipMemcpy2DAsync(ctx->dV + (int64_t)C * Np, Np * sizeof(double), ctx->dY, n * sizeof(double), n * sizeof(double), P, hipMemcpyDeviceToDevice, ctx->st));
+    rg_launch_v_split(ctx->st, ctx->dV + (int64_t)C * Np, Np, P, ctx->dvd + (size_t)C * 8 * Np, ctx->dvsc + C);
     hipLaunchKernelGGL(k_s2_ytx, dim3(P * C), dim3(256), 0, ctx->st, ctx->dX, ctx->dY, n, C, ctx->dYtX);
     S2_HIP(hipGetLastError());
-    ctx->planes_ready = true;
+    ctx->res_ready = true;
   }
-  const int64_t Np = ctx->Np, ldp = Np / 4;
   const int n128 = (int)((bs + 127) / 128 * 128);
+  const int gm0 = cm0 / 16, ngrpB = masked ? ngrp - gm0 : 0, CvB = ngrpB * 16;      // column groups of the g0^2 contraction (the mask columns)
   // enough workgroups to fill the 256 CUs (tiles x segments x column groups >= 768), as few segments as that allows: every segment
   // costs a 64 KB tile of partial sums per workgroup
   int nseg = 1;
@@ -657,35 +762,52 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   seg.nseg = nseg;
   for (int f = 0; f < nseg; ++f) { seg.pos_start[f] = f * (Np / nseg); seg.file_start[f] = seg.pos_start[f]; seg.len[f] = Np / nseg; seg.plen[f] = Np / nseg; }
   enum { Q_PK, Q_CNT, Q_S, Q_A, Q_VAR, Q_STAT };
+  const size_t s_grp = (size_t)2 * nseg * n128 * 128;
   if ((rc = ensure_p(ctx, Q_PK, (size_t)bs * ldp))) return rc;
-  if ((rc = ensure_p(ctx, Q_CNT, ((size_t)bs * 4 + 8) * sizeof(int32_t)))) return rc;            // counts | total_miss | bs
-  if ((rc = ensure_p(ctx, Q_S, (size_t)ngrp * 2 * nseg * n128 * 128 * sizeof(int32_t)))) return rc;
-  if ((rc = ensure_p(ctx, Q_A, (size_t)bs * 2 * Cv * sizeof(double)))) return rc;
+  if ((rc = ensure_p(ctx, Q_CNT, ((size_t)bs * 4 + 8) * sizeof(int32_t)))) return rc;            // counts | total_miss | bs | 0
+  if ((rc = ensure_p(ctx, Q_S, (size_t)(ngrp + ngrpB) * s_grp * sizeof(int32_t)))) return rc;
+  if ((rc = ensure_p(ctx, Q_A, (size_t)bs * 2 * (Cvt + CvB) * sizeof(double)))) return rc;
   if ((rc = ensure_p(ctx, Q_VAR, (size_t)bs * (2 * sizeof(double) + 2 * sizeof(int32_t))))) return rc;   // scale_fac | mean | nobs | ignored
-  if ((rc = ensure_p(ctx, Q_STAT, (size_t)bs * P * 2 * sizeof(double)))) return rc;                     // stats | bhat
+  if ((rc = ensure_p(ctx, Q_STAT, (size_t)bs * P * (3 * sizeof(double) + sizeof(int32_t))))) return rc;  // stats | bhat | total_p | nobs_p
   uint8_t* pk = (uint8_t*)ctx->pbuf[Q_PK];
   int32_t* cnt = (int32_t*)ctx->pbuf[Q_CNT];
   int32_t* total_miss = cnt + (size_t)bs * 4;
   int32_t* d_bs = total_miss + 1;
+  int32_t* d_zero = total_miss + 2;
   int32_t* S = (int32_t*)ctx->pbuf[Q_S];
   double* A = (double*)ctx->pbuf[Q_A];
+  double* Sq = A + (size_t)bs * 2 * Cvt;
   double* sf = (double*)ctx->pbuf[Q_VAR];
   double* mu = sf + bs;
   int32_t* nobs = (int32_t*)(mu + bs);
   int32_t* ign = nobs + bs;
   double* stats = (double*)ctx->pbuf[Q_STAT];
   double* bhat = stats + (size_t)bs * P;
-  ctx->hdr[0] = 0; ctx->hdr[1] = bs;
+  double* total_p = bhat + (size_t)bs * P;
+  int32_t* nobs_p = (int32_t*)(total_p + (size_t)bs * P);
+  ctx->hdr[0] = 0; ctx->hdr[1] = bs; ctx->hdr[2] = 0;
   S2_HIP(hipMemcpyAsync(total_miss, ctx->hdr, sizeof(ctx->hdr), hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipMemcpy2DAsync(pk, ldp, rows, ld, nbytes, bs, rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipEventRecord(ctx->e0, ctx->st));
   hipLaunchKernelGGL(k_s2_rows, dim3(bs), dim3(256), 0, ctx->st, pk, ldp, n, flip ? 1 : 0, cnt, total_miss);
   for (int g = 0; g < ngrp; ++g)
-    rg_launch_xy_i8_sums(ctx->st, pk, ldp, 0, d_bs, total_miss, 1, n128, ctx->seg, ctx->dvd + (size_t)g * 16 * 8 * Np, Np, std::min(16, Cv - g * 16),
-                         S + (size_t)g * 2 * nseg * n128 * 128);
-  hipLaunchKernelGGL(k_s2_combine, dim3((bs * Cv + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->dvsc, total_miss, bs, n128, nseg, Cv, A);
-  hipLaunchKernelGGL(k_s2_packed_final, dim3((bs + 63) / 64), dim3(64), 0, ctx->st, (const double*)A, (const int32_t*)cnt, ctx->dYtX, bs, C, P, n, numtol,
-                     ctx->dscf, stats, bhat, sf, mu, nobs, ign);
+    rg_launch_xy_i8_sums(ctx->st, pk, ldp, 0, d_bs, total_miss, 1, n128, seg, ctx->dvd + (size_t)g * 16 * 8 * Np, Np, std::min(16, Cvt - g * 16),
+                         RG_XY_LUT_DOSAGE, S + (size_t)g * s_grp);
+  hipLaunchKernelGGL(k_s2_combine, dim3((bs * Cvt + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->dvsc, total_miss, bs, n128, nseg, Cvt, A);
+  if (masked) {   // sum mask_p g0^2: the square LUT against the mask columns only (the missing-indicator set is skipped: d_zero)
+    int32_t* SB = S + (size_t)ngrp * s_grp;
+    for (int g = 0; g < ngrpB; ++g)
+      rg_launch_xy_i8_sums(ctx->st, pk, ldp, 0, d_bs, d_zero, 1, n128, seg, ctx->dvd + (size_t)(gm0 + g) * 16 * 8 * Np, Np,
+                           std::min(16, Cvt - (gm0 + g) * 16), RG_XY_LUT_SQUARE, SB + (size_t)g * s_grp);
+    hipLaunchKernelGGL(k_s2_combine, dim3((bs * CvB + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)SB, ctx->dvsc + gm0 * 16, (const int32_t*)nullptr, bs,
+                       n128, nseg, CvB, Sq);
+  }
+  PackedFinal fa;
+  fa.A = A; fa.Sq = masked ? Sq : nullptr; fa.cnt = cnt; fa.ytx = ctx->dYtX; fa.Q = ctx->dQ; fa.msum = ctx->dMsum; fa.scf_sv = ctx->dscf;
+  fa.bs = bs; fa.C = C; fa.P = P; fa.Cvt = Cvt; fa.cm0 = cm0; fa.CvB = CvB; fa.sqoff = cm0 - gm0 * 16; fa.masked = masked;
+  fa.n = n; fa.numtol = numtol; fa.nz_max = (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * (1.0 - ctx->rule_thr);
+  fa.stats = stats; fa.bhat = bhat; fa.scale_fac = sf; fa.mean = mu; fa.total_p = total_p; fa.nobs = nobs; fa.ignored = ign; fa.nobs_p = nobs_p;
+  hipLaunchKernelGGL(k_s2_packed_final, dim3((bs * P + 255) / 256), dim3(256), 0, ctx->st, fa);
   S2_HIP(hipEventRecord(ctx->e1, ctx->st));
   S2_HIP(hipGetLastError());
   if (out->stats) S2_HIP(hipMemcpyAsync(out->stats, stats, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));
@@ -694,6 +816,8 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   if (out->mean) S2_HIP(hipMemcpyAsync(out->mean, mu, sizeof(double) * bs, hipMemcpyDeviceToHost, ctx->st));
   if (out->n_obs) S2_HIP(hipMemcpyAsync(out->n_obs, nobs, sizeof(int32_t) * bs, hipMemcpyDeviceToHost, ctx->st));
   if (out->ignored) S2_HIP(hipMemcpyAsync(out->ignored, ign, sizeof(int32_t) * bs, hipMemcpyDeviceToHost, ctx->st));
+  if (out->total_p) S2_HIP(hipMemcpyAsync(out->total_p, total_p, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));
+  if (out->n_obs_p) S2_HIP(hipMemcpyAsync(out->n_obs_p, nobs_p, sizeof(int32_t) * bs * P, hipMemcpyDeviceToHost, ctx->st));
   S2_HIP(hipStreamSynchronize(ctx->st));
   float ms = 0.f;
   S2_HIP(hipEventElapsedTime(&ms, ctx->e0, ctx->e1));

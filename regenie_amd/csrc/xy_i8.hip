@@ -19,8 +19,7 @@
 #define XT 128
 #define X_PITCH 80
 #define X_NPIECE 8
-#define X_LUT_DOSAGE 0x00010002u
-#define X_LUT_MISS 0x00000100u
+#define X_LUT_MISS 0x00000100u      // byte k = value of .bed code k: 01 -> 1
 
 // ---- digit planes of V: vd [Cv][8][Np] int8, vsc [Cv] = 2^(e-54); grid (Cv), 256 threads -----------------------------------
 __global__ __launch_bounds__(256) void k_v_split(const double* __restrict__ V, int64_t Np, int8_t* __restrict__ vd, double* __restrict__ vsc) {
@@ -62,7 +61,7 @@ __device__ __forceinline__ unsigned x_expand4(unsigned b, unsigned lut) {
 // ---- S[blk][set][fold][row][col] = sum over the fold's positions; grid (n128 / 128, nseg, nblk * 2), set = z & 1 ----------------
 __global__ __launch_bounds__(256) void k_xy_i8(const uint8_t* __restrict__ pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* __restrict__ d_bs,
                                                const int32_t* __restrict__ nmiss, int n128, SegLayout seg, const int8_t* __restrict__ vd,
-                                               int64_t Np, int ncol /* Cv * 8 <= 128 */, int32_t* __restrict__ S) {
+                                               int64_t Np, int ncol /* Cv * 8 <= 128 */, unsigned lut0 /* set 0: RG_XY_LUT_* */, int32_t* __restrict__ S) {
   __shared__ __attribute__((aligned(16))) uint8_t sA[XT * X_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t sB[XT * X_PITCH];
   const int blk = blockIdx.z >> 1, set = blockIdx.z & 1, f = blockIdx.y, tr = blockIdx.x;
@@ -70,7 +69,7 @@ __global__ __launch_bounds__(256) void k_xy_i8(const uint8_t* __restrict__ pk, i
   const int bs = d_bs[blk];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const unsigned lut = set ? X_LUT_MISS : X_LUT_DOSAGE;
+  const unsigned lut = set ? X_LUT_MISS : lut0;
   const int64_t pos0 = seg.pos_start[f], kbytes = seg.plen[f] / 4;
   v16i acc[2][2];
 #pragma unroll
@@ -167,11 +166,12 @@ void rg_launch_v_split(hipStream_t st, const double* V, int64_t Np, int Cv, int8
   hipLaunchKernelGGL(k_v_split, dim3(Cv), dim3(256), 0, st, V, Np, vd, vsc);
 }
 
-// the digit sums alone (step2_qt.hip sums them over the segments itself): S32 [nblk][2][nseg][n128][128]
+// the digit sums alone (step2_qt.hip sums them over the segments itself): S32 [nblk][2][nseg][n128][128]; lut0 = what set 0 contracts
+// (the allele count, or its square); set 1 is the missing indicator, skipped for blocks with nmiss == 0
 void rg_launch_xy_i8_sums(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs, const int32_t* nmiss,
-                          int nblk, int n128, const SegLayout& seg, const int8_t* vd, int64_t Np, int Cv, int32_t* S32) {
+                          int nblk, int n128, const SegLayout& seg, const int8_t* vd, int64_t Np, int Cv, unsigned lut0, int32_t* S32) {
   hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, nblk * 2), dim3(256), 0, st, pk, pk_ld, pk_blk_stride, d_bs, nmiss, n128, seg, vd, Np,
-                     Cv * X_NPIECE, S32);
+                     Cv * X_NPIECE, lut0, S32);
 }
 
 // S32: nblk * 2 * nseg * n128 * 128 int32; part: [nblk][nseg][n128][2][Cv] (rowstats reads it with nchunk = nseg, chunk_seg = identity)
@@ -179,7 +179,7 @@ void rg_launch_xy_i8(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t p
                      int nblk, int n128, const SegLayout& seg, const int8_t* vd, const double* vsc, int64_t Np, int Cv, int32_t* S32,
                      double* part) {
   hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, nblk * 2), dim3(256), 0, st, pk, pk_ld, pk_blk_stride, d_bs, nmiss, n128, seg, vd, Np,
-                     Cv * X_NPIECE, S32);
+                     Cv * X_NPIECE, RG_XY_LUT_DOSAGE, S32);
   hipLaunchKernelGGL(k_xy_combine, dim3((n128 * Cv + 255) / 256, seg.nseg, nblk), dim3(256), 0, st, (const int32_t*)S32, vsc, nmiss, n128, seg.nseg,
                      Cv, part);
 }

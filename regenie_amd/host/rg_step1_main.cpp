@@ -1346,9 +1346,11 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   for (int64_t k = 0; k < n; ++k)
     for (int q = 0; q < P; ++q)
       if (!r.mask[(size_t)q * N + an[k]]) { has_missing[k] = 1; any_missing = true; }
-  if (any_missing)
-    throw std::runtime_error("--step 2 with phenotypes that differ in their missing values is not built (the reference's sparse-genotype "
-                             "approximation of the per-trait denominators, Step2_Models.cpp:400-409): analyse the traits one at a time or use --strict.");
+  const bool dense_route = getenv("RG_S2_DENSE") != nullptr;     // the fp64 route of the library (rg_s2_qt_block), kept for comparison
+  if (any_missing && dense_route)
+    throw std::runtime_error("RG_S2_DENSE=1 with phenotypes that differ in their missing values: the fp64 route evaluates the dense branch of "
+                             "compute_score_qt for every variant, the reference takes the sparse branch (approximate per-trait denominators, "
+                             "Step2_Models.cpp:402-413) for most; unset RG_S2_DENSE.");
   // compact, sample-fastest copies for the C ABI
   std::vector<double> Xc((size_t)C * n), Yc((size_t)P * n), resc((size_t)P * n), scf(P);
   std::vector<uint8_t> Mc((size_t)P * n);
@@ -1359,6 +1361,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   rg_s2_ctx* s2 = nullptr;
   if (rg_s2_create(&s2, p.device, n, C, P) != RG_S2_OK || !s2) throw std::runtime_error("no MI355X / HIP device available (rg_s2_create failed)");
   auto s2check = [&](int rc) { if (rc != RG_S2_OK) throw std::runtime_error(rg_s2_last_error(s2)); };
+  s2check(rg_s2_set_sparse_rule(s2, N, 0.5));     // check_sparse_G: params.n_samples, params.prop_zero_thr (Regenie.hpp:311)
 
   // blocks per chromosome (set_blocks_for_testing: ceil(n_chr / bsize))
   std::map<int, std::vector<int64_t>> chr_snps;
@@ -1396,11 +1399,10 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   // buildLookupTable (Geno.cpp:2833-2856): 00 -> 2, 01 -> missing (-3), 10 -> 1, 11 -> 0 copies of the first .bim allele
   static const double lut[4] = {2.0, -3.0, 1.0, 0.0};
   std::vector<uint8_t> rows, packed;
-  std::vector<double> G, stats, bhat, sfac, mean_v;
-  std::vector<int32_t> ign, nobs_v;
+  std::vector<double> G, stats, bhat, sfac, mean_v, totp_v;
+  std::vector<int32_t> ign, nobs_v, nobsp_v;
   bool identity = n == r.n_file;                 // every sample of the file is analysed, in file order
   for (int64_t k = 0; identity && k < n; ++k) identity = file_idx[k] == k;
-  const bool dense_route = getenv("RG_S2_DENSE") != nullptr;     // the fp64 route of the library (rg_s2_qt_block), kept for comparison
   int64_t n_ignored_snps = 0, n_ignored_tests = 0, n_tested = 0;
   int block = 0;
   for (int chrom : r.chr_read) {
@@ -1469,7 +1471,8 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       std::vector<uint8_t> variant_ignored(bs, 0);
       rg_s2_qt_out o;
       stats.resize((size_t)bs * P); bhat.resize((size_t)bs * P); sfac.resize(bs); ign.resize(bs);
-      o.stats = stats.data(); o.bhat = bhat.data(); o.scale_fac = sfac.data(); o.mean = nullptr; o.n_obs = nullptr; o.ignored = ign.data();
+      memset(&o, 0, sizeof(o));
+      o.stats = stats.data(); o.bhat = bhat.data(); o.scale_fac = sfac.data(); o.ignored = ign.data();
       if (!dense_route) {
         // hard calls stay packed: the 2-bit codes of the analysed samples go to the device as they are (the rows of the file itself
         // when no sample was dropped), the library counts the calls and contracts them on the i8 matrix cores
@@ -1490,11 +1493,21 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
         }
         mean_v.resize(bs); nobs_v.resize(bs);
         o.mean = mean_v.data(); o.n_obs = nobs_v.data();
+        if (any_missing) {
+          totp_v.resize((size_t)bs * P); nobsp_v.resize((size_t)bs * P);
+          o.total_p = totp_v.data(); o.n_obs_p = nobsp_v.data();
+        }
         s2check(rg_s2_qt_block_packed(s2, src, ld, bs, 0, p.ref_first ? 1 : 0, NUMTOL, &o));
+        if (any_missing) { af_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0); }
         for (int j = 0; j < bs; ++j) {
           ns1[j] = nobs_v[j];
           total[j] = std::nearbyint(mean_v[j] * (double)nobs_v[j]);       // the allele count is an integer: mean = total / n_obs
           if (std::min(total[j], 2.0 * ns1[j] - total[j]) < p.min_mac) variant_ignored[j] = 1;   // compute_mac (Geno.cpp:3077-3108), autosomes
+          if (any_missing)                                                  // update_trait_counts (Geno.cpp:2948-2959) as differences from the totals
+            for (int q = 0; q < P; ++q) {
+              af_t[(size_t)j * P + q] = std::nearbyint(totp_v[(size_t)j * P + q]) - total[j];
+              ns_t[(size_t)j * P + q] = (int64_t)nobsp_v[(size_t)j * P + q] - ns1[j];
+            }
         }
       } else {
         // parseSnpfromBed: decode the analysed samples, allele counts

@@ -14,7 +14,7 @@ from .engine import RgError, load_library
 
 class _QtOut(C.Structure):
     _fields_ = [("stats", C.c_void_p), ("bhat", C.c_void_p), ("scale_fac", C.c_void_p), ("mean", C.c_void_p),
-                ("n_obs", C.c_void_p), ("ignored", C.c_void_p)]
+                ("n_obs", C.c_void_p), ("ignored", C.c_void_p), ("total_p", C.c_void_p), ("n_obs_p", C.c_void_p)]
 
 
 class Step2QT:
@@ -60,6 +60,10 @@ class Step2QT:
             raise ValueError("set_null: expected X %s, yres/mask %s, scf_sv (%d,)" % ((self.C, self.n), (self.P, self.n), self.P))
         self._check(self.lib.rg_s2_set_null(self.h, X.ctypes.data, yres.ctypes.data, mask.ctypes.data, scf_sv.ctypes.data))
 
+    def set_sparse_rule(self, n_samples: int, prop_zero_thr: float = 0.5) -> None:
+        """check_sparse_G's constants (Geno.cpp:3165-3177): params.n_samples (kept samples of the file) and --prop-zero-thr."""
+        self._check(self.lib.rg_s2_set_sparse_rule(self.h, int(n_samples), float(prop_zero_thr)))
+
     def score_block(self, G, numtol: float = NUMTOL) -> dict:
         """G: numpy [bs][n] float64 (host), or a CUDA torch tensor [bs][n] float64 (read in place).  Missing = NaN or < 0."""
         on_device = 0
@@ -92,7 +96,8 @@ class Step2QT:
     def score_block_packed(self, rows, flip: bool = False, numtol: float = NUMTOL) -> dict:
         """Hard calls as they lie in a .bed file: rows [bs][>= ceil(n/4)] uint8 (numpy, or a CUDA torch tensor read in place),
         2 bits per analysed sample (00 -> 2, 01 -> missing, 10 -> 1, 11 -> 0 copies of the counted allele); flip = --ref-first.
-        Every analysed sample must be observed for every phenotype (mask all ones in set_null)."""
+        Follows the reference's per-variant choice between the sparse and the dense branch of compute_score_qt (set_sparse_rule);
+        extra outputs total_p / n_obs_p [bs][P]: allele count and number of the samples observed for the variant and the trait."""
         on_device = 0
         if isinstance(rows, np.ndarray):
             rows = np.ascontiguousarray(rows, dtype=np.uint8)
@@ -106,7 +111,8 @@ class Step2QT:
         if rows.shape[1] < (self.n + 3) // 4:
             raise ValueError("score_block_packed: rows must hold ceil(n / 4) bytes")
         res = {"stats": np.empty((bs, self.P)), "bhat": np.empty((bs, self.P)), "scale_fac": np.empty(bs),
-               "mean": np.empty(bs), "n_obs": np.empty(bs, np.int32), "ignored": np.empty(bs, np.int32)}
-        out = _QtOut(*[res[k].ctypes.data for k in ("stats", "bhat", "scale_fac", "mean", "n_obs", "ignored")])
+               "mean": np.empty(bs), "n_obs": np.empty(bs, np.int32), "ignored": np.empty(bs, np.int32),
+               "total_p": np.empty((bs, self.P)), "n_obs_p": np.empty((bs, self.P), np.int32)}
+        out = _QtOut(*[res[k].ctypes.data for k in ("stats", "bhat", "scale_fac", "mean", "n_obs", "ignored", "total_p", "n_obs_p")])
         self._check(self.lib.rg_s2_qt_block_packed(self.h, ptr, ld, bs, on_device, 1 if flip else 0, float(numtol), C.byref(out)))
         return self._finish(res)

@@ -526,6 +526,46 @@ def test_cli_step2_qt_against_reference_output(example_dir, tmp_path, case, rout
     assert ign and ign[0].split(":")[1].strip() == ("0" if case == "qt_bed_3chr" else "14")
 
 
+def test_cli_step2_qt_masked_phenotypes_against_reference_output(tmp_path):
+    """Phenotypes that differ in their missing values (5 %), genotypes with missing calls (1 %), 3,001 samples x 500 variants x 4
+    traits (the synthetic data of the qt_kfold_synth_missing case, regenerated here): regenie takes the sparse branch of
+    compute_score_qt for most variants (approximate per-trait denominators); the driver's .regenie files against regenie's own
+    (tests/golden/ref_outputs/step2/qt_synth_missing_Y*.regenie.gz), A1FREQ and N per trait as text."""
+    import gzip
+    import json
+    from tests.util import synth_dosages, write_plink
+    R = os.path.join(ROOT, "tests", "golden", "ref_outputs")
+    meta = json.load(open(os.path.join(R, "qt_kfold_synth_missing", "meta.json")))
+    spec = meta["synthetic"]
+    S = str(tmp_path / "synth")
+    write_plink(S, synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"]), spec["chroms"], P=spec["P"],
+                seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    with open(str(tmp_path / "pred.list"), "w") as pl:
+        for k, nm in enumerate(meta["pred_list"]):
+            fn = str(tmp_path / ("ref_%d.loco" % (k + 1)))
+            open(fn, "wb").write(gzip.open(os.path.join(R, "qt_kfold_synth_missing", "out_%d.loco.gz" % (k + 1)), "rb").read())
+            pl.write("%s %s\n" % (nm, fn))
+    env = {k: v for k, v in os.environ.items() if k != "RG_S2_DENSE"}
+    args = [BIN, "--step", "2", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--qt",
+            "--pred", str(tmp_path / "pred.list"), "--out", "s2"]
+    r = subprocess.run(args, cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for k in range(1, spec["P"] + 1):
+        got = open(str(tmp_path / ("s2_Y%d.regenie" % k))).read().splitlines()
+        ref = gzip.open(os.path.join(R, "step2", "qt_synth_missing_Y%d.regenie.gz" % k), "rt").read().splitlines()
+        assert got[0] == ref[0] and len(got) == len(ref) == 501
+        same = 0
+        for a, b in zip(got[1:], ref[1:]):
+            ta, tb = a.split(" "), b.split(" ")
+            assert ta[:8] == tb[:8] and ta[12] == tb[12] == "NA", (a, b)
+            for x, y in zip(ta[8:12], tb[8:12]):
+                assert float(x) == pytest.approx(float(y), rel=2e-5, abs=2e-9), (a, b)
+            same += a == b
+        assert same >= 450, same
+    r2 = subprocess.run(args, cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=dict(env, RG_S2_DENSE="1"))
+    assert r2.returncode != 0 and "RG_S2_DENSE" in r2.stdout
+
+
 def test_cli_step2_refuses_what_is_not_built(example_dir, tmp_path):
     E = example_dir
     r = _run(["--step", "2", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"), "--bt", "--bsize", "200",

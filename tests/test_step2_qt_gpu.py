@@ -194,22 +194,23 @@ def test_packed_parity_with_oracle(n, C, P, bs):
         G[1, rng.random(n) < 0.002] = np.nan
         G[2, :] = 2.0
         G[3, :] = np.nan
-    ref = s2o.score_qt_block(G, X, res, mask, scf)
+    ref = s2o.score_qt_block_ref(G, X, res, mask, scf)
+    assert 0 < ref["sparse"].sum() < bs or bs < 4
     got = _run_packed(X, res, mask, scf, _pack_bed(G))
     _compare(got, ref)
     dense = _run(X, res, mask, scf, G)
     ok = ref["ignored"] == 0
-    assert np.allclose(got["stats"][ok], dense["stats"][ok], rtol=1e-10, atol=1e-11)
+    assert np.allclose(got["stats"][ok], dense["stats"][ok], rtol=1e-10, atol=1e-11)     # mask all ones: both branches are one number
 
 
 def test_packed_no_missing_calls_and_flip():
     """No missing call in the block (the missing-indicator contraction is skipped), and --ref-first = 2 - g on the observed calls."""
     X, res, mask, scf, G = _problem(77, 12_345, 4, 3, 200, miss_y=0)
-    ref = s2o.score_qt_block(G, X, res, mask, scf)
+    ref = s2o.score_qt_block_ref(G, X, res, mask, scf)
     _compare(_run_packed(X, res, mask, scf, _pack_bed(G)), ref)
     G[10, ::7] = np.nan
     G[150, 5] = np.nan
-    ref2 = s2o.score_qt_block(2.0 - G, X, res, mask, scf)
+    ref2 = s2o.score_qt_block_ref(2.0 - G, X, res, mask, scf)
     _compare(_run_packed(X, res, mask, scf, _pack_bed(G), flip=True), ref2)
 
 
@@ -228,11 +229,50 @@ def test_packed_device_rows_padded_ld_and_determinism():
         assert np.array_equal(a[k][100:200], c[k], equal_nan=True), k
 
 
-def test_packed_refuses_masked_samples():
-    from regenie_amd.engine import RgError
-    X, res, mask, scf, G = _problem(5, 2000, 3, 2, 8, miss_y=0.05)
-    with pytest.raises(RgError, match="masked"):
-        _run_packed(X, res, mask, scf, _pack_bed(G))
+@pytest.mark.parametrize("n,C,P,bs,n_samples", [(5003, 5, 3, 64, 5003), (2500, 1, 1, 9, 2500), (4097, 12, 7, 40, 4600), (30_011, 3, 6, 200, 31_000)])
+def test_packed_masked_phenotypes_follow_the_reference_branches(n, C, P, bs, n_samples):
+    """Phenotypes that differ in their missing values: per variant the reference's choice between the sparse branch of
+    compute_score_qt (approximate per-trait denominators) and the dense one (oracle score_qt_block_ref, pinned against regenie's own
+    output in tests/test_reference_pin.py); n_samples > n moves check_sparse_G's threshold.  Also the per-trait allele counts."""
+    X, res, mask, scf, G = _problem(n + bs + 1, n, C, P, bs, miss_y=0.07)
+    rng = np.random.default_rng(4)
+    G[0, rng.random(n) < 0.1] = np.nan
+    G[1, rng.random(n) < 0.002] = np.nan
+    G[2, :] = 2.0
+    G[3, :] = np.nan
+    ref = s2o.score_qt_block_ref(G, X, res, mask, scf, n_samples=n_samples)
+    dense = s2o.score_qt_block(G, X, res, mask, scf)
+    from regenie_amd.step2 import Step2QT
+    with Step2QT(n, C, P) as s2:
+        s2.set_null(X.T, res.T, mask.T, scf)
+        s2.set_sparse_rule(n_samples)
+        got = s2.score_block_packed(_pack_bed(G))
+        again = s2.score_block_packed(_pack_bed(G)[5:9])
+    _compare(got, ref)
+    ok = ref["ignored"] == 0
+    sp = (ref["sparse"] == 1) & ok
+    assert sp.sum() > 0 and (~sp & ok).sum() > 0
+    assert np.abs(ref["chisq"][sp] / dense["chisq"][sp] - 1.0).max() > 1e-4          # the branches are different numbers here
+    obs = ~np.isnan(G)
+    assert np.array_equal(got["n_obs_p"], (obs[:, :, None] & (mask[None] > 0)).sum(axis=1))
+    assert np.array_equal(got["total_p"], np.einsum("jn,np->jp", np.where(obs, G, 0.0), mask))
+    assert np.array_equal(again["stats"], got["stats"][5:9], equal_nan=True)
+
+
+def test_packed_planes_follow_set_null():
+    """A second rg_s2_set_null with other residuals (next chromosome) and then with other masks: the cached digit planes are rebuilt
+    for exactly what changed."""
+    from regenie_amd.step2 import Step2QT
+    n, C, P, bs = 6000, 4, 3, 50
+    X, res, mask, scf, G = _problem(91, n, C, P, bs, miss_y=0.05)
+    _, res2, _, scf2, _ = _problem(92, n, C, P, bs, miss_y=0.05)
+    res2 = res2 * mask
+    mask3 = mask.copy(); mask3[::5, 1] = 0
+    rows = _pack_bed(G)
+    with Step2QT(n, C, P) as s2:
+        for (r_, m_, f_) in ((res, mask, scf), (res2, mask, scf2), (res2 * mask3, mask3, scf2), (res * 0 + res2, np.ones_like(mask), scf)):
+            s2.set_null(X.T, r_.T, m_.T, f_)
+            _compare(s2.score_block_packed(rows), s2o.score_qt_block_ref(G, X, r_, m_, f_))
 
 
 def test_packed_at_scale_matches_dense_route():
