@@ -11,8 +11,7 @@
  *   rg_s2_qt_block_packed  the same for hard calls as they lie in a .bed file, INCLUDING the sparse-genotype branch the
  *                     reference takes per variant (check_sparse_G, Geno.cpp:3165-3177; Step2_Models.cpp:402-413)
  * Not in this slice (the host keeps doing them): reading the LOCO file (blup_read_chr), the MAC / INFO filters, --strict,
- * mse_full, MCC, the p-value and the output lines.  rg_s2_qt_block evaluates the dense branch for every variant: equal to the
- * reference when every analysed sample is observed for every phenotype, the exact mask_p^T r^2 otherwise.
+ * mse_full, MCC, the p-value and the output lines.  Both entries make check_sparse_G's per-variant choice (rg_s2_set_sparse_rule).
  *
  * Layout: every matrix is row-major with the SAMPLE index fastest -- G is [bs][ldg], X is [C][n], yres and mask are [P][n];
  * n = samples in the analysis, in the caller's order.  A missing genotype is NaN or any value < 0 (regenie's -3).

@@ -103,8 +103,9 @@ def score_qt_sparse(g, X, res, masked_indivs, scf_sv, YtX):
         gm = g * masked_indivs[:, ph]
         XtGm = X.T @ gm
         denum[ph] = float(gm @ gm) - 2.0 * float(XtGm @ XtG) + XtG_ss
-    stats = num / np.sqrt(denum)                                        # :420
-    bhat = stats * scf_sv / np.sqrt(denum)                              # :427
+    with np.errstate(invalid="ignore", divide="ignore"):               # an all-zero variant: 0 / 0 (the MAC filter drops it earlier)
+        stats = num / np.sqrt(denum)                                    # :420
+        bhat = stats * scf_sv / np.sqrt(denum)                          # :427
     return stats, bhat
 
 

@@ -47,6 +47,7 @@
 
 namespace {
 
+constexpr double NNZ_UNIT = 67108864.0;   // 2^26: k_s2_proj carries (non-zero count) * 2^26 + (observed count) in one exact fp64 sum (n < 2^26)
 constexpr int DEFAULT_VPB = 4, DEFAULT_EPT = 4;   // variants per workgroup, samples per thread (best of the sweep in
                                                  // profiles/r1_step2_qt.md)
 
@@ -125,7 +126,7 @@ __device__ __forceinline__ void load_mask_row(const uint8_t* __restrict__ src, i
 }
 
 // A workgroup owns VPB variants x (256 * EPT) samples.  grid (ceil(bs / VPB), nchunk), dynamic LDS 4 * VPB * Q1 doubles.
-// part1[(j * nchunk + chunk) * Q1 + q], Q1 = 2 + 2C: sum, count, A_c (C), M_c (C)
+// part1[(j * nchunk + chunk) * Q1 + q], Q1 = 2 + 2C: sum, count (+ 2^26 * non-zero count), A_c (C), M_c (C)
 template <int VPB, int EPT>
 __global__ __launch_bounds__(256) void k_s2_proj(const double* __restrict__ G, int64_t ldg, int bs, int64_t n,
                                                  const double* __restrict__ X, int C, double* __restrict__ part1) {
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void k_s2_proj(const double* __restrict__ G, i
       double x = 0.0;
       if (pos < n && j0 + v < bs) {
         x = G[(int64_t)(j0 + v) * ldg + pos];
-        if (is_missing(x)) { x = 0.0; miss[v] |= 1u << k; } else cnt += 1.0;
+        if (is_missing(x)) { x = 0.0; miss[v] |= 1u << k; } else cnt += x != 0.0 ? 1.0 + NNZ_UNIT : 1.0;   // observed, and non-zero (exact integers)
       }
       g[v][k] = x;
       s += x;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void k_s2_proj(const double* __restrict__ G, i
 
 // thread = (variant j, covariate c): fixed-order sums over the chunks, mu = sum / count, beta_c = A_c + mu M_c
 __global__ void k_s2_beta(const double* __restrict__ part1, int nchunk, int C, int bs, double* __restrict__ beta /*[bs][64]*/,
-                          double* __restrict__ mu, int32_t* __restrict__ nobs) {
+                          double* __restrict__ mu, int32_t* __restrict__ nobs, int32_t* __restrict__ nnz) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= bs * C) return;
   const int j = t / C, c = t % C, Q1 = 2 + 2 * C;
@@ -197,9 +198,11 @@ __global__ void k_s2_beta(const double* __restrict__ part1, int nchunk, int C, i
     const double* p = part1 + ((int64_t)j * nchunk + ch) * Q1;
     s += p[0]; cnt += p[1]; a += p[2 + c]; m += p[2 + C + c];
   }
+  const double nz = floor(cnt / NNZ_UNIT);
+  cnt -= nz * NNZ_UNIT;
   const double mean = s / cnt;   // NaN when nothing is observed: the variant comes out as ignored
   beta[(int64_t)j * RG_S2_MAX_COV + c] = a + mean * m;
-  if (c == 0) { mu[j] = mean; nobs[j] = (int32_t)cnt; }
+  if (c == 0) { mu[j] = mean; nobs[j] = (int32_t)cnt; nnz[j] = (int32_t)nz; }
 }
 
 // grid (ceil(bs / VPB), nchunk), dynamic LDS VPB * C + VPB + 4 * VPB * (Q2 + 1) doubles.
@@ -294,10 +297,51 @@ __global__ __launch_bounds__(256) void k_s2_score(const double* __restrict__ G, 
   }
 }
 
-// thread = (variant j, phenotype p): the statistic and the effect size (Step2_Models.cpp:415-431)
-__global__ void k_s2_final(const double* __restrict__ part2, int nchunk, int P, int bs, double df /* n - C */, double numtol,
-                           const double* __restrict__ scf_sv, const int32_t* __restrict__ nobs, double* __restrict__ stats,
-                           double* __restrict__ bhat, double* __restrict__ scale_fac, int32_t* __restrict__ ignored) {
+// grid (bs, P), 256 threads: sums over the samples masked for phenotype p (mlist[moff[p] .. moff[p + 1])) of the mean-imputed variant j:
+// corr[(j * P + p) * (C + 1) + c] = sum g~_i x_c(i) for c < C, [C] = sum g~_i^2 -- what the per-trait denominators of the sparse branch
+// lack relative to the all-sample sums (X^T (g~ o mask_p) = beta - corr, sum mask_p g~^2 = |g~|^2 - corr_C).
+__global__ __launch_bounds__(256) void k_s2_masked_corr(const double* __restrict__ G, int64_t ldg, int64_t n, const double* __restrict__ X, int C,
+                                                        const int32_t* __restrict__ mlist, const int64_t* __restrict__ moff,
+                                                        const double* __restrict__ mu, int P, double* __restrict__ corr) {
+  __shared__ double red[4][8];
+  const int j = blockIdx.x, p = blockIdx.y;
+  const int64_t e0 = moff[p], e1 = moff[p + 1];
+  const double m = mu[j];
+  const double* g = G + (int64_t)j * ldg;
+  double* out = corr + ((int64_t)j * P + p) * (C + 1);
+  for (int c0 = 0; c0 < C + 1; c0 += 8) {      // eight sums per sweep over the list
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+      const int64_t i = mlist[e];
+      double v = g[i];
+      if (is_missing(v)) v = m;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = c0 + k;
+        if (c < C) acc[k] = fma(v, X[(int64_t)c * n + i], acc[k]);
+        else if (c == C) acc[k] = fma(v, v, acc[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      double v = acc[k];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && c0 + (int)threadIdx.x <= C)
+      out[c0 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    __syncthreads();
+  }
+}
+
+// thread = (variant j, phenotype p): the statistic and the effect size (Step2_Models.cpp:402-431).  check_sparse_G's rule picks the branch:
+// a sparse variant is tested on its raw scale (scale_fac = 1, never "ignored" by residualize_geno) with the reference's approximate
+// per-trait denominator |g~ o m_p|^2 - 2 (X^T (g~ o m_p)) . beta + |beta|^2 = |r|^2 - corr_C + 2 corr . beta; a dense one with mask_p^T r^2.
+__global__ void k_s2_final(const double* __restrict__ part2, int nchunk, int P, int C, int bs, int64_t n, double numtol, double nz_max,
+                           const double* __restrict__ scf_sv, const int32_t* __restrict__ nobs, const int32_t* __restrict__ nnz,
+                           const double* __restrict__ mu, const double* __restrict__ beta, const double* __restrict__ corr /* null: no masked sample */,
+                           double* __restrict__ stats, double* __restrict__ bhat, double* __restrict__ scale_fac, int32_t* __restrict__ ignored) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= bs * P) return;
   const int j = t / P, p = t % P, Q2 = 1 + 2 * P;
@@ -306,8 +350,22 @@ __global__ void k_s2_final(const double* __restrict__ part2, int nchunk, int P, 
     const double* q = part2 + ((int64_t)j * nchunk + ch) * Q2;
     ss += q[0]; num += q[1 + p]; den += q[1 + P + p];
   }
-  const double sf = sqrt(ss) / sqrt(df);                 // residualize_geno: norm / sqrt(n_analyzed - X.cols())
-  const bool ign = !(sf >= numtol) || nobs[j] == 0;      // also catches NaN
+  const double m = mu[j];
+  const bool sparse = (double)nnz[j] + ((m != 0.0) ? (double)(n - nobs[j]) : 0.0) <= nz_max;   // non-zero entries of the mean-imputed vector
+  double sf = 1.0;
+  if (sparse) {
+    den = ss;
+    if (corr) {
+      const double* cr = corr + ((int64_t)j * P + p) * (C + 1);
+      const double* b = beta + (int64_t)j * RG_S2_MAX_COV;
+      double cb = 0.0;
+      for (int c = 0; c < C; ++c) cb = fma(cr[c], b[c], cb);
+      den = ss - cr[C] + 2.0 * cb;
+    }
+  } else {
+    sf = sqrt(ss) / sqrt((double)(n - C));              // residualize_geno: norm / sqrt(n_analyzed - X.cols())
+  }
+  const bool ign = nobs[j] == 0 || (!sparse && !(sf >= numtol));      // also catches NaN
   const double sd = sqrt(den);
   const double z = num / sd;
   stats[(int64_t)j * P + p] = ign ? NAN : z;
@@ -500,6 +558,10 @@ struct rg_s2_ctx {
   int8_t* dvd = nullptr;        // the digit planes of dV's columns, [col][8][Np]
   double *dvsc = nullptr, *dYtX = nullptr;   // [col] plane scales, [P][C] res_p^T x_c
   double *dQ = nullptr, *dMsum = nullptr;    // [P][C][C] X^T diag(mask_p) X, [P] sum of mask_p
+  // dosage route (rg_s2_qt_block), masked problems: per phenotype the samples masked for it
+  bool lists_ready = false;
+  int32_t* d_mlist = nullptr;
+  int64_t* d_moff = nullptr;    // [P + 1]
   void* pbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t pcap[6] = {0, 0, 0, 0, 0, 0};
   int32_t hdr[3] = {0, 0, 0};   // staged {total_miss = 0, bs, 0} of the block in flight
@@ -536,7 +598,7 @@ int rg_s2_create(rg_s2_ctx** out, int device, int64_t n, int32_t n_cov, int32_t 
   if (!out) return RG_S2_ERR_ARG;
   rg_s2_ctx* ctx = new rg_s2_ctx();
   *out = ctx;
-  if (n <= 0 || n_cov < 1 || n_cov > RG_S2_MAX_COV || n_pheno < 1 || n_pheno > RG_S2_MAX_PHENO || n <= n_cov)
+  if (n <= 0 || n >= (1 << 26) || n_cov < 1 || n_cov > RG_S2_MAX_COV || n_pheno < 1 || n_pheno > RG_S2_MAX_PHENO || n <= n_cov)
     return fail(ctx, RG_S2_ERR_ARG, "rg_s2_create: need n > n_cov, 1 <= n_cov <= 64, 1 <= n_pheno <= 64");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -574,6 +636,8 @@ void rg_s2_destroy(rg_s2_ctx* ctx) {
     if (ctx->dYtX) (void)hipFree(ctx->dYtX);
     if (ctx->dQ) (void)hipFree(ctx->dQ);
     if (ctx->dMsum) (void)hipFree(ctx->dMsum);
+    if (ctx->d_mlist) (void)hipFree(ctx->d_mlist);
+    if (ctx->d_moff) (void)hipFree(ctx->d_moff);
     if (ctx->dX) (void)hipFree(ctx->dX);
     if (ctx->dY) (void)hipFree(ctx->dY);
     if (ctx->dM) (void)hipFree(ctx->dM);
@@ -603,6 +667,7 @@ int rg_s2_set_null(rg_s2_ctx* ctx, const double* X, const double* yres, const ui
     ctx->hX.assign(X, X + nx);
     ctx->hM.assign(mask, mask + nm);
     ctx->static_ready = false;
+    ctx->lists_ready = false;
     ctx->complete = true;
     for (size_t i = 0; i < nm; ++i)
       if (!mask[i]) { ctx->complete = false; break; }
@@ -634,13 +699,30 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
   const int nchunk = (int)((n + 256 * ept - 1) / (256 * ept));
   const unsigned gv = (unsigned)((bs + vpb - 1) / vpb);
   S2_HIP(hipSetDevice(ctx->dev));
-  enum { B_G, B_PART, B_BETA, B_VAR, B_NOBS, B_STAT };
+  enum { B_G, B_PART, B_BETA, B_VAR, B_NOBS, B_STAT, B_CORR };
   const size_t part_elems = (size_t)bs * nchunk * (size_t)(Q1 > Q2 ? Q1 : Q2);
   int rc;
   if ((rc = ensure(ctx, B_PART, part_elems * sizeof(double)))) return rc;
   if ((rc = ensure(ctx, B_BETA, (size_t)bs * RG_S2_MAX_COV * sizeof(double)))) return rc;
   if ((rc = ensure(ctx, B_VAR, (size_t)bs * 2 * sizeof(double)))) return rc;       // mu | scale_fac
-  if ((rc = ensure(ctx, B_NOBS, (size_t)bs * 2 * sizeof(int32_t)))) return rc;     // nobs | ignored
+  if ((rc = ensure(ctx, B_NOBS, (size_t)bs * 3 * sizeof(int32_t)))) return rc;     // nobs | ignored | nnz
+  const bool masked = !ctx->complete;
+  if (masked && (rc = ensure(ctx, B_CORR, (size_t)bs * P * (C + 1) * sizeof(double)))) return rc;
+  if (masked && !ctx->lists_ready) {   // per phenotype the analysed samples masked for it (the masks changed since the last build)
+    std::vector<int32_t> lst;
+    std::vector<int64_t> off(P + 1, 0);
+    for (int p = 0; p < P; ++p) {
+      const uint8_t* m = ctx->hM.data() + (size_t)p * n;
+      for (int64_t i = 0; i < n; ++i) if (!m[i]) lst.push_back((int32_t)i);
+      off[p + 1] = (int64_t)lst.size();
+    }
+    if (ctx->d_mlist) { S2_HIP(hipFree(ctx->d_mlist)); ctx->d_mlist = nullptr; }
+    if (!ctx->d_moff) S2_HIP(hipMalloc((void**)&ctx->d_moff, sizeof(int64_t) * (P + 1)));
+    S2_HIP(hipMalloc((void**)&ctx->d_mlist, sizeof(int32_t) * std::max<size_t>(1, lst.size())));
+    S2_HIP(hipMemcpy(ctx->d_mlist, lst.data(), sizeof(int32_t) * lst.size(), hipMemcpyHostToDevice));
+    S2_HIP(hipMemcpy(ctx->d_moff, off.data(), sizeof(int64_t) * (P + 1), hipMemcpyHostToDevice));
+    ctx->lists_ready = true;
+  }
   if ((rc = ensure(ctx, B_STAT, (size_t)bs * P * 2 * sizeof(double)))) return rc;  // stats | bhat
   const double* dG = G;
   int64_t ld = ldg;
@@ -657,8 +739,10 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
   double* sf = mu + bs;
   int32_t* nobs = (int32_t*)ctx->buf[B_NOBS];
   int32_t* ign = nobs + bs;
+  int32_t* nnz = ign + bs;
   double* stats = (double*)ctx->buf[B_STAT];
   double* bhat = stats + (size_t)bs * P;
+  double* corr = masked ? (double*)ctx->buf[B_CORR] : nullptr;
   S2_HIP(hipEventRecord(ctx->e0, ctx->st));
 #define S2_TILE(V, E, KERNEL_CALL) if (vpb == V && ept == E) { constexpr int TV = V, TE = E; KERNEL_CALL; }
 #define S2_PROJ hipLaunchKernelGGL((k_s2_proj<TV, TE>), dim3(gv, nchunk), dim3(256), lds1, ctx->st, dG, ld, bs, n, ctx->dX, C, part)
@@ -666,13 +750,15 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
   hipLaunchKernelGGL((k_s2_score<TV, TE>), dim3(gv, nchunk), dim3(256), lds2, ctx->st, dG, ld, bs, n, ctx->dX, C, ctx->dY, ctx->dM, \
                      P, beta, mu, part)
   S2_TILE(4, 4, S2_PROJ) S2_TILE(4, 8, S2_PROJ) S2_TILE(8, 4, S2_PROJ) S2_TILE(8, 8, S2_PROJ) S2_TILE(16, 4, S2_PROJ)
-  hipLaunchKernelGGL(k_s2_beta, dim3((bs * C + 255) / 256), dim3(256), 0, ctx->st, part, nchunk, C, bs, beta, mu, nobs);
+  hipLaunchKernelGGL(k_s2_beta, dim3((bs * C + 255) / 256), dim3(256), 0, ctx->st, part, nchunk, C, bs, beta, mu, nobs, nnz);
+  if (masked)
+    hipLaunchKernelGGL(k_s2_masked_corr, dim3(bs, P), dim3(256), 0, ctx->st, dG, ld, n, ctx->dX, C, ctx->d_mlist, ctx->d_moff, mu, P, corr);
   S2_TILE(4, 4, S2_SCORE) S2_TILE(4, 8, S2_SCORE) S2_TILE(8, 4, S2_SCORE) S2_TILE(8, 8, S2_SCORE) S2_TILE(16, 4, S2_SCORE)
 #undef S2_TILE
 #undef S2_PROJ
 #undef S2_SCORE
-  hipLaunchKernelGGL(k_s2_final, dim3((bs * P + 255) / 256), dim3(256), 0, ctx->st, part, nchunk, P, bs, (double)(n - C), numtol,
-                     ctx->dscf, nobs, stats, bhat, sf, ign);
+  hipLaunchKernelGGL(k_s2_final, dim3((bs * P + 255) / 256), dim3(256), 0, ctx->st, part, nchunk, P, C, bs, n, numtol,
+                     (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * (1.0 - ctx->rule_thr), ctx->dscf, nobs, nnz, mu, beta, corr, stats, bhat, sf, ign);
   S2_HIP(hipEventRecord(ctx->e1, ctx->st));
   S2_HIP(hipGetLastError());
   if (out->stats) S2_HIP(hipMemcpyAsync(out->stats, stats, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));

@@ -1347,10 +1347,6 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
     for (int q = 0; q < P; ++q)
       if (!r.mask[(size_t)q * N + an[k]]) { has_missing[k] = 1; any_missing = true; }
   const bool dense_route = getenv("RG_S2_DENSE") != nullptr;     // the fp64 route of the library (rg_s2_qt_block), kept for comparison
-  if (any_missing && dense_route)
-    throw std::runtime_error("RG_S2_DENSE=1 with phenotypes that differ in their missing values: the fp64 route evaluates the dense branch of "
-                             "compute_score_qt for every variant, the reference takes the sparse branch (approximate per-trait denominators, "
-                             "Step2_Models.cpp:402-413) for most; unset RG_S2_DENSE.");
   // compact, sample-fastest copies for the C ABI
   std::vector<double> Xc((size_t)C * n), Yc((size_t)P * n), resc((size_t)P * n), scf(P);
   std::vector<uint8_t> Mc((size_t)P * n);

@@ -1,5 +1,6 @@
 """Step-2 QT score test on the GPU (include/rg_step2.h through regenie_amd.step2.Step2QT) against the CPU restatement of
-the reference (oracle/regenie_step2_qt.py).  fp64 throughout; tolerance 1e-9 relative (the kernel sums 2048-sample chunk
+the reference (oracle/regenie_step2_qt.py: score_qt_block_ref makes the reference's per-variant choice between the sparse and the
+dense branch of compute_score_qt).  fp64 throughout; tolerance 1e-9 relative (the kernel sums 2048-sample chunk
 partials in chunk order, the reference sums along Eigen's vectorised order)."""
 import numpy as np
 import pytest
@@ -43,8 +44,8 @@ def _compare(got, ref):
     ok = ref["ignored"] == 0
     assert np.isnan(got["stats"][~ok]).all() and np.isnan(got["bhat"][~ok]).all()
     for k in ("stats", "bhat", "se", "chisq"):
-        scale = np.abs(ref[k][ok]).max()
-        assert np.allclose(got[k][ok], ref[k][ok], rtol=RTOL, atol=RTOL * scale), k
+        scale = np.nanmax(np.abs(ref[k][ok]))
+        assert np.allclose(got[k][ok], ref[k][ok], rtol=RTOL, atol=RTOL * scale, equal_nan=True), k   # NaN: an all-zero variant on the sparse branch (0 / 0)
     obs = ref["n_obs"] > 0
     assert np.allclose(got["mean"][obs], ref["mean"][obs], rtol=1e-13)
     assert np.allclose(got["scale_fac"][ok], ref["scale_fac"][ok], rtol=1e-11)
@@ -62,7 +63,9 @@ def test_parity_with_oracle(n, C, P, bs):
     G = G + (rng.random(G.shape) < 0.3) * rng.uniform(0, 0.01, size=G.shape) * (G < 1.5)   # dosages, not just hardcalls
     if bs >= 4:
         G[2, :] = 2.0
-    _compare(_run(X, res, mask, scf, G), s2o.score_qt_block(G, X, res, mask, scf))
+    ref = s2o.score_qt_block_ref(G, X, res, mask, scf)
+    assert bs <= 4 or 0 < ref["sparse"].sum() < bs           # both branches of compute_score_qt (5 % of the phenotype values are missing)
+    _compare(_run(X, res, mask, scf, G), ref)
 
 
 @pytest.mark.parametrize("tile", ["4x4", "4x8", "8x4", "8x8", "16x4"])
@@ -72,7 +75,7 @@ def test_tiles_agree_with_oracle(tile, monkeypatch):
     X, res, mask, scf, G = _problem(21, 10_007, 6, 5, 43)
     G[0, ::9] = np.nan
     G[7, :] = 0.0
-    _compare(_run(X, res, mask, scf, G), s2o.score_qt_block(G, X, res, mask, scf))
+    _compare(_run(X, res, mask, scf, G), s2o.score_qt_block_ref(G, X, res, mask, scf))
     monkeypatch.setenv("RG_S2_TILE", "3x3")
     from regenie_amd.engine import RgError
     with pytest.raises(RgError, match="RG_S2_TILE"):
@@ -97,7 +100,7 @@ def test_invariances_at_scale():
     """Sizes the oracle does not loop over: the statistic ignores covariate-space shifts and the genotype scale, bhat
     scales inversely, and a sub-block equals the same rows of the full block bit for bit."""
     n, C, P, bs = 120_000, 10, 10, 256
-    X, res, mask, scf, G = _problem(3, n, C, P, bs, miss_y=0.1)
+    X, res, mask, scf, G = _problem(3, n, C, P, bs, miss_y=0)     # complete phenotypes: the sparse and the dense branch are one number
     rng = np.random.default_rng(5)
     base = _run(X, res, mask, scf, G)
     assert not base["ignored"].any() and np.isfinite(base["stats"]).all()
@@ -107,7 +110,7 @@ def test_invariances_at_scale():
     sub = _run(X, res, mask, scf, G[64:131])
     assert np.array_equal(sub["stats"], base["stats"][64:131]) and np.array_equal(sub["bhat"], base["bhat"][64:131])
     # spot check against the oracle on a few rows
-    ref = s2o.score_qt_block(G[:6], X, res, mask, scf)
+    ref = s2o.score_qt_block_ref(G[:6], X, res, mask, scf)
     assert np.allclose(base["stats"][:6], ref["stats"], rtol=RTOL, atol=1e-10)
     assert np.allclose(base["bhat"][:6], ref["bhat"], rtol=RTOL, atol=1e-13)
 
@@ -157,7 +160,7 @@ def test_step1_loco_feeds_step2(example_dir, tmp_path):
     sel = np.flatnonzero(chrom == 2)
     G = orc.decode_bed_rows(np.asarray(rows[sel]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
     assert G.shape == (len(sel), n) and len(sel) > 50
-    ref = s2o.score_qt_block(G, X, res, mask, scf)
+    ref = s2o.score_qt_block_ref(G, X, res, mask, scf)
     assert (ref["ignored"] == 0).sum() > 50 and np.nanmax(np.abs(ref["stats"])) > 1.0
     _compare(_run(X, res, mask, scf, G), ref)
 
@@ -249,6 +252,10 @@ def test_packed_masked_phenotypes_follow_the_reference_branches(n, C, P, bs, n_s
         got = s2.score_block_packed(_pack_bed(G))
         again = s2.score_block_packed(_pack_bed(G)[5:9])
     _compare(got, ref)
+    with Step2QT(n, C, P) as s2:                                   # the fp64 (dosage) route makes the same per-variant choice
+        s2.set_null(X.T, res.T, mask.T, scf)
+        s2.set_sparse_rule(n_samples)
+        _compare(s2.score_block(G), ref)
     ok = ref["ignored"] == 0
     sp = (ref["sparse"] == 1) & ok
     assert sp.sum() > 0 and (~sp & ok).sum() > 0
@@ -289,6 +296,6 @@ def test_packed_at_scale_matches_dense_route():
     assert np.array_equal(got["n_obs"], dense["n_obs"])
     assert np.allclose(got["stats"], dense["stats"], rtol=1e-9, atol=1e-10)
     assert np.allclose(got["bhat"], dense["bhat"], rtol=1e-9, atol=1e-13)
-    ref = s2o.score_qt_block(G[:4], X, res, mask, scf)
+    ref = s2o.score_qt_block_ref(G[:4], X, res, mask, scf)
     assert np.allclose(got["stats"][:4], ref["stats"], rtol=RTOL, atol=1e-10)
     print("packed kernel %.3f ms, dense kernel %.3f ms for %d variants x %d samples" % (got["kernel_ms"], dense["kernel_ms"], bs, n))
