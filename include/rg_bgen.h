@@ -6,6 +6,7 @@
  *   rg_bgen_sample_id       BgenParser::get_sample_ids (embedded identifiers = FID_IID)     Geno.cpp:146-152
  *   rg_bgen_variant         snpinfo[] fields: chromosome, position, rsid, alleles, offset   Geno.cpp:73-128
  *   rg_bgen_read_dosages    readChunkFromBGEN + readChunkFromBGENFileToG_fast               Geno.cpp:2122-2171, :1574-1699
+ *   rg_bgen_read_dosages_info   the Step-2 form: parseSnpfromBGEN's dosages and info-score terms   Geno.cpp:2186-2330
  * The rows are ALT-count style dosages in [0, 2] (G = prob1 + 2 prob0, or prob1 + 2 prob2 with ref_first), -3 = missing:
  * the input of rg_l0_blocks_f64 (rg_step1.h), which applies the reference's mean imputation.  Host-only code.
  * Conventions as in rg_pgen.h: 0 on success, <0 on error, rg_bgen_last_error(h); rg_bgen_open always stores a handle.
@@ -44,6 +45,10 @@ int rg_bgen_set_threads(rg_bgen* h, int32_t n_threads);
 /* Dosage rows of n variants: rows[k * row_stride .. + n_samples) doubles. */
 int rg_bgen_read_dosages(rg_bgen* h, int64_t n, const int64_t* variant_idx, int32_t ref_first, double* rows,
                          int64_t row_stride);
+/* The same, plus each sample's term of the IMPUTE info score the Step-2 reader accumulates (parseSnpfromBGEN, Geno.cpp:2292-2295:
+ * 4 prob0 + prob1 - G^2, or with ref_first 4 prob2 + prob1 - G^2; 0 for a missing sample): info_rows has the layout of rows. */
+int rg_bgen_read_dosages_info(rg_bgen* h, int64_t n, const int64_t* variant_idx, int32_t ref_first, double* rows, double* info_rows,
+                              int64_t row_stride);
 
 #ifdef __cplusplus
 }

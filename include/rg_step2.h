@@ -74,9 +74,11 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
 int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32_t bs, int32_t rows_on_device, int32_t flip,
                           double numtol, const rg_s2_qt_out* out);
 
-/* check_sparse_G's constants: n_samples = params.n_samples (every kept sample of the file, >= n; default n) and
- * prop_zero_thr = --prop-zero-thr (default 0.5). */
-int rg_s2_set_sparse_rule(rg_s2_ctx* ctx, int64_t n_samples, double prop_zero_thr);
+/* check_sparse_G's constants (Geno.cpp:3165-3177): n_samples = params.n_samples (every kept sample of the file, >= n; default n),
+ * prop_zero_thr = --prop-zero-thr (default 0.5).  zero_count_rule = 0: a variant is sparse when the non-zero entries of its
+ * mean-imputed vector number <= n_samples * (1 - prop_zero_thr) (.bed / .bgen input, n_zero == -1); 1: when its observed zero
+ * entries number >= n_samples * prop_zero_thr (.pgen input, which counts n_zero while reading, Geno.cpp:2582-2594). */
+int rg_s2_set_sparse_rule(rg_s2_ctx* ctx, int64_t n_samples, double prop_zero_thr, int32_t zero_count_rule);
 
 /* Device time of the kernels of the last rg_s2_qt_block / rg_s2_qt_block_packed call (hipEvents on the library's stream), in ms. */
 double rg_s2_last_kernel_ms(const rg_s2_ctx* ctx);

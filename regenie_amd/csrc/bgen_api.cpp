@@ -84,7 +84,20 @@ int rg_bgen_set_threads(rg_bgen* h, int32_t n_threads) {
   return RG_BGEN_OK;
 }
 
+static int read_rows(rg_bgen* h, int64_t n, const int64_t* variant_idx, int32_t ref_first, double* rows, double* info_rows, int64_t row_stride);
+
 int rg_bgen_read_dosages(rg_bgen* h, int64_t n, const int64_t* variant_idx, int32_t ref_first, double* rows, int64_t row_stride) {
+  return read_rows(h, n, variant_idx, ref_first, rows, nullptr, row_stride);
+}
+
+int rg_bgen_read_dosages_info(rg_bgen* h, int64_t n, const int64_t* variant_idx, int32_t ref_first, double* rows, double* info_rows,
+                              int64_t row_stride) {
+  if (h && !info_rows) return fail(h, RG_BGEN_ERR_ARG, "rg_bgen_read_dosages_info: bad argument");
+  return read_rows(h, n, variant_idx, ref_first, rows, info_rows, row_stride);
+}
+}  // extern "C"
+
+static int read_rows(rg_bgen* h, int64_t n, const int64_t* variant_idx, int32_t ref_first, double* rows, double* info_rows, int64_t row_stride) {
   if (!h) return RG_BGEN_ERR_ARG;
   if (!h->ok) return fail(h, RG_BGEN_ERR_ARG, "bgen file is not open");
   if (n < 0 || (n > 0 && (!variant_idx || !rows)) || row_stride < (int64_t)h->rd.n_samples())
@@ -98,7 +111,8 @@ int rg_bgen_read_dosages(rg_bgen* h, int64_t n, const int64_t* variant_idx, int3
     std::vector<uint8_t> cbuf, ubuf;
     const int64_t k0 = n * t / nt, k1 = n * (t + 1) / nt;
     try {
-      for (int64_t k = k0; k < k1; ++k) h->rd.read_dosages((uint32_t)variant_idx[k], ref_first != 0, rows + k * row_stride, cbuf, ubuf);
+      for (int64_t k = k0; k < k1; ++k)
+        h->rd.read_dosages((uint32_t)variant_idx[k], ref_first != 0, rows + k * row_stride, cbuf, ubuf, info_rows ? info_rows + k * row_stride : nullptr);
     } catch (const std::exception& e) {
       errs[(size_t)t] = e.what();
       if (errs[(size_t)t].empty()) errs[(size_t)t] = "bgen read failed";
@@ -114,5 +128,4 @@ int rg_bgen_read_dosages(rg_bgen* h, int64_t n, const int64_t* variant_idx, int3
   for (const auto& e : errs)
     if (!e.empty()) return fail(h, classify(e), e);
   return RG_BGEN_OK;
-}
 }

@@ -149,7 +149,7 @@ class Reader {
   }
 
   // Dosage row of variant j: n_samples doubles, -3 = missing.
-  void read_dosages(uint32_t j, bool ref_first, double* out, std::vector<uint8_t>& cbuf, std::vector<uint8_t>& ubuf) const {
+  void read_dosages(uint32_t j, bool ref_first, double* out, std::vector<uint8_t>& cbuf, std::vector<uint8_t>& ubuf, double* info = nullptr) const {
     if (fd_ < 0) throw std::runtime_error("bgen file is closed");
     if (j >= m_) throw std::runtime_error("variant index out of range");
     const Variant& v = vars_[j];
@@ -202,10 +202,11 @@ class Reader {
     if (blen < 10ull + n_ + 2ull * n_) throw std::runtime_error("malformed genotype data block for variant: " + v.rsid);
     const uint8_t* pr = blk + 10 + n_;
     for (uint32_t i = 0; i < n_; ++i) {
-      if (ploidy[i] & 0x80) { out[i] = -3.0; continue; }
+      if (ploidy[i] & 0x80) { out[i] = -3.0; if (info) info[i] = 0.0; continue; }
       const double p0 = pr[2 * i] / 255.0, p1 = pr[2 * i + 1] / 255.0;
       const double p2 = std::max(1.0 - p0 - p1, 0.0);
       out[i] = ref_first ? p1 + 2.0 * p2 : p1 + 2.0 * p0;   // Geno.cpp:1672-1679
+      if (info) info[i] = (ref_first ? 4.0 * p2 + p1 : 4.0 * p0 + p1) - out[i] * out[i];   // the sample's term of the IMPUTE info score (parseSnpfromBGEN, Geno.cpp:2292-2295)
     }
   }
 

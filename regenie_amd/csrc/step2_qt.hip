@@ -339,6 +339,7 @@ __global__ __launch_bounds__(256) void k_s2_masked_corr(const double* __restrict
 // a sparse variant is tested on its raw scale (scale_fac = 1, never "ignored" by residualize_geno) with the reference's approximate
 // per-trait denominator |g~ o m_p|^2 - 2 (X^T (g~ o m_p)) . beta + |beta|^2 = |r|^2 - corr_C + 2 corr . beta; a dense one with mask_p^T r^2.
 __global__ void k_s2_final(const double* __restrict__ part2, int nchunk, int P, int C, int bs, int64_t n, double numtol, double nz_max,
+                           double zeros_min /* < 0: the non-zero form of the rule */,
                            const double* __restrict__ scf_sv, const int32_t* __restrict__ nobs, const int32_t* __restrict__ nnz,
                            const double* __restrict__ mu, const double* __restrict__ beta, const double* __restrict__ corr /* null: no masked sample */,
                            double* __restrict__ stats, double* __restrict__ bhat, double* __restrict__ scale_fac, int32_t* __restrict__ ignored) {
@@ -351,7 +352,8 @@ __global__ void k_s2_final(const double* __restrict__ part2, int nchunk, int P, 
     ss += q[0]; num += q[1 + p]; den += q[1 + P + p];
   }
   const double m = mu[j];
-  const bool sparse = (double)nnz[j] + ((m != 0.0) ? (double)(n - nobs[j]) : 0.0) <= nz_max;   // non-zero entries of the mean-imputed vector
+  const bool sparse = zeros_min >= 0.0 ? (double)(nobs[j] - nnz[j]) >= zeros_min                      // .pgen: observed zeros
+                                       : (double)nnz[j] + ((m != 0.0) ? (double)(n - nobs[j]) : 0.0) <= nz_max;   // non-zero entries of the mean-imputed vector
   double sf = 1.0;
   if (sparse) {
     den = ss;
@@ -471,7 +473,8 @@ struct PackedFinal {
   const double *ytx, *Q, *msum, *scf_sv;
   int bs, C, P, Cvt, cm0, CvB, sqoff, masked;
   int64_t n;
-  double numtol, nz_max;   // a variant is "sparse" when its non-zero entries number <= nz_max
+  double numtol, nz_max;   // a variant is "sparse" when its non-zero entries number <= nz_max ...
+  double zeros_min;        // ... or (>= 0, the .pgen form) when its observed zeros number >= zeros_min
   double *stats, *bhat, *scale_fac, *mean, *total_p;
   int32_t *nobs, *ignored, *nobs_p;
 };
@@ -494,7 +497,8 @@ __global__ void k_s2_packed_final(PackedFinal a) {
   }
   const double num = fma(mu, a1[C + p], a0[C + p]) - corr;
   const double ss = (n1 + 4.0 * n2 + nm * mu * mu) - b2;                      // |g~ - X beta|^2 over every analysed sample
-  const bool sparse = (n1 + n2 + (mu != 0.0 ? nm : 0.0)) <= a.nz_max;        // check_sparse_G on the mean-imputed vector
+  const bool sparse = a.zeros_min >= 0.0 ? (nobs - n1 - n2) >= a.zeros_min
+                                         : (n1 + n2 + (mu != 0.0 ? nm : 0.0)) <= a.nz_max;        // check_sparse_G on the mean-imputed vector
   const double sf = sparse ? 1.0 : sqrt(ss) / sqrt((double)(a.n - C));       // residualize_geno only runs for dense variants
   const bool ign = nobs <= 0 || (!sparse && !(sf >= a.numtol));
   double den = ss, tot = n1 + 2.0 * n2, nobs_p = nobs;
@@ -553,6 +557,7 @@ struct rg_s2_ctx {
   int Cvt = 0, cm0 = 0;         // columns in all, first mask column (a multiple of 16); complete problems: Cvt = cm0 = C + P
   int64_t rule_n = 0;           // check_sparse_G: params.n_samples (0 = the analysed samples)
   double rule_thr = 0.5;        // params.prop_zero_thr
+  int rule_zero_count = 0;      // 1: the .pgen form of the rule (observed zeros >= n_samples * thr)
   SegLayout seg;
   double* dV = nullptr;         // [Cvt (padded to 16)][Np]  X | res | x_c mask_p | 0 | mask_p, zero padded
   int8_t* dvd = nullptr;        // the digit planes of dV's columns, [col][8][Np]
@@ -675,11 +680,11 @@ int rg_s2_set_null(rg_s2_ctx* ctx, const double* X, const double* yres, const ui
   return RG_S2_OK;
 }
 
-int rg_s2_set_sparse_rule(rg_s2_ctx* ctx, int64_t n_samples, double prop_zero_thr) {
+int rg_s2_set_sparse_rule(rg_s2_ctx* ctx, int64_t n_samples, double prop_zero_thr, int32_t zero_count_rule) {
   if (!ctx || !ctx->st) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_set_sparse_rule: context was not created");
   if (n_samples < ctx->n || !(prop_zero_thr >= 0.0 && prop_zero_thr <= 1.0))
     return fail(ctx, RG_S2_ERR_ARG, "rg_s2_set_sparse_rule: need n_samples >= n and 0 <= prop_zero_thr <= 1");
-  ctx->rule_n = n_samples; ctx->rule_thr = prop_zero_thr;
+  ctx->rule_n = n_samples; ctx->rule_thr = prop_zero_thr; ctx->rule_zero_count = zero_count_rule ? 1 : 0;
   return RG_S2_OK;
 }
 
@@ -758,7 +763,9 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
 #undef S2_PROJ
 #undef S2_SCORE
   hipLaunchKernelGGL(k_s2_final, dim3((bs * P + 255) / 256), dim3(256), 0, ctx->st, part, nchunk, P, C, bs, n, numtol,
-                     (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * (1.0 - ctx->rule_thr), ctx->dscf, nobs, nnz, mu, beta, corr, stats, bhat, sf, ign);
+                     (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * (1.0 - ctx->rule_thr),
+                     ctx->rule_zero_count ? (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * ctx->rule_thr : -1.0, ctx->dscf, nobs, nnz, mu, beta, corr, stats,
+                     bhat, sf, ign);
   S2_HIP(hipEventRecord(ctx->e1, ctx->st));
   S2_HIP(hipGetLastError());
   if (out->stats) S2_HIP(hipMemcpyAsync(out->stats, stats, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));
@@ -892,6 +899,7 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   fa.A = A; fa.Sq = masked ? Sq : nullptr; fa.cnt = cnt; fa.ytx = ctx->dYtX; fa.Q = ctx->dQ; fa.msum = ctx->dMsum; fa.scf_sv = ctx->dscf;
   fa.bs = bs; fa.C = C; fa.P = P; fa.Cvt = Cvt; fa.cm0 = cm0; fa.CvB = CvB; fa.sqoff = cm0 - gm0 * 16; fa.masked = masked;
   fa.n = n; fa.numtol = numtol; fa.nz_max = (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * (1.0 - ctx->rule_thr);
+  fa.zeros_min = ctx->rule_zero_count ? (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * ctx->rule_thr : -1.0;
   fa.stats = stats; fa.bhat = bhat; fa.scale_fac = sf; fa.mean = mu; fa.total_p = total_p; fa.nobs = nobs; fa.ignored = ign; fa.nobs_p = nobs_p;
   hipLaunchKernelGGL(k_s2_packed_final, dim3((bs * P + 255) / 256), dim3(256), 0, ctx->st, fa);
   S2_HIP(hipEventRecord(ctx->e1, ctx->st));

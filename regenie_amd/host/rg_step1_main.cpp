@@ -363,7 +363,6 @@ Params parse_args(int argc, char** argv) {
   if (p.step != 1 && p.step != 2) usage_error("specify which mode regenie should be running using option --step.");
   if (p.step == 2) {
     if (p.bt || p.ct) usage_error("--step 2 serves quantitative traits only (--qt): the binary / count trait tests (Firth, SPA) are not built.");
-    if (p.bed.empty()) usage_error("--step 2 reads hard calls from --bed (the .pgen / .bgen readers feed --step 1 only).");
     if (p.pred_list.empty()) usage_error("option '--pred' is required (use the _pred.list file written by step 1).");
     if (p.min_mac < 0.5) usage_error("minimum MAC must be at least 0.5.");   // Regenie.cpp:1054
     if (p.gpus > 1 || p.force_collectives) usage_error("--step 2 runs on one GPU.");
@@ -628,15 +627,23 @@ void read_bgen_meta(Run& r) {
   if (!extract_files.empty()) ext = read_snp_files(extract_files);
   if (!exclude_files.empty()) exc = read_snp_files(exclude_files);
   for (int64_t j = 0; j < nv; ++j) {
-    const char *chrom, *rsid;
-    rg_bgen_variant(r.bgenh, j, &chrom, nullptr, &rsid, nullptr, nullptr, nullptr);
+    const char *chrom, *rsid, *al0, *al1;
+    uint32_t position = 0;
+    rg_bgen_variant(r.bgenh, j, &chrom, &position, &rsid, &al0, &al1, nullptr);
     const int c = chr_str_to_int(chrom, p.nchrom);
     if (c == -1) throw std::runtime_error("unknown chromosome code in bgen file.");
     if (r.chr_read.empty() || c != r.chr_read.back()) r.chr_read.push_back(c);
     bool keep = true;
     if (!extract_files.empty() && !ext.count(rsid)) keep = false;
     if (!exclude_files.empty() && exc.count(rsid)) keep = false;
-    if (keep) { r.snp_chrom.push_back(c); r.snp_offset.push_back(j); r.snp_ids.push_back(rsid); }
+    if (keep) {
+      r.snp_chrom.push_back(c); r.snp_offset.push_back(j); r.snp_ids.push_back(rsid);
+      if (p.step == 2) {   // prep_bgen (Geno.cpp:80-86): allele0 is the file's second allele unless --ref-first ("switch so allele0 is ALT")
+        r.snp_pos.push_back((int64_t)position);
+        r.snp_a0.push_back(p.ref_first ? al0 : al1);
+        r.snp_a1.push_back(p.ref_first ? al1 : al0);
+      }
+    }
   }
   sout << "   -n_snps = " << nv << "\n";
   if (!extract_files.empty()) sout << "   -keeping variants specified by --extract\n";
@@ -759,7 +766,7 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
     std::string line;
     int64_t lineno = 0;
     int minchr = 0;
-    size_t min_cols = 6, id_col = 1;
+    size_t min_cols = 6, id_col = 1, pos_col = 3, ref_col = 0, alt_col = 0;
     if (pg) {  // read_pvar (Geno.cpp:787-815): skip to the "#CHROM" header and locate the POS / ID / REF / ALT columns
       std::vector<std::string> t;
       while (std::getline(f, line)) {
@@ -773,6 +780,9 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
         if (std::find(t.begin(), t.end(), col) == t.end()) throw std::runtime_error("header of pvar file does not have correct format.");
       min_cols = 5;
       id_col = (size_t)(idc - t.begin());
+      pos_col = (size_t)(std::find(t.begin(), t.end(), "POS") - t.begin());
+      ref_col = (size_t)(std::find(t.begin(), t.end(), "REF") - t.begin());
+      alt_col = (size_t)(std::find(t.begin(), t.end(), "ALT") - t.begin());
     }
     while (std::getline(f, line)) {
       auto t = split_ws(line);
@@ -795,6 +805,12 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
           r.snp_pos.push_back((int64_t)std::strtoul(t[3].c_str(), nullptr, 0));
           r.snp_a0.push_back(p.ref_first ? t[4] : t[5]);
           r.snp_a1.push_back(p.ref_first ? t[5] : t[4]);
+        } else if (pg && p.step == 2) {   // read_pvar (Geno.cpp:824-828): allele1 = REF, allele2 = ALT, whatever --ref-first says
+          if (std::max(pos_col, std::max(ref_col, alt_col)) >= t.size())
+            throw std::runtime_error("incorrectly formatted " + kind + " file at line " + std::to_string(lineno + 1));
+          r.snp_pos.push_back((int64_t)std::strtoul(t[pos_col].c_str(), nullptr, 0));
+          r.snp_a0.push_back(t[ref_col]);
+          r.snp_a1.push_back(t[alt_col]);
         }
       }
       ++lineno;
@@ -1357,7 +1373,12 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   rg_s2_ctx* s2 = nullptr;
   if (rg_s2_create(&s2, p.device, n, C, P) != RG_S2_OK || !s2) throw std::runtime_error("no MI355X / HIP device available (rg_s2_create failed)");
   auto s2check = [&](int rc) { if (rc != RG_S2_OK) throw std::runtime_error(rg_s2_last_error(s2)); };
-  s2check(rg_s2_set_sparse_rule(s2, N, 0.5));     // check_sparse_G: params.n_samples, params.prop_zero_thr (Regenie.hpp:311)
+  enum class In { Bed, PgenHard, Dosage };
+  const In in = r.dosage_mode ? In::Dosage : (r.pgen ? In::PgenHard : In::Bed);
+  const bool show_info = r.dosage_mode;                 // params.dosage_mode: the INFO column
+  const int flip = (in == In::Bed && p.ref_first) ? 1 : 0;   // .pgen rows always count ALT (PgenReader::Read / ReadHardcalls)
+  // check_sparse_G: params.n_samples, params.prop_zero_thr (Regenie.hpp:311); the .pgen reader counts the observed zeros itself
+  s2check(rg_s2_set_sparse_rule(s2, N, 0.5, r.pgen ? 1 : 0));
 
   // blocks per chromosome (set_blocks_for_testing: ceil(n_chr / bsize))
   std::map<int, std::vector<int64_t>> chr_snps;
@@ -1376,11 +1397,11 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
     out_names.push_back(p.out + "_" + r.pheno_names[q] + ".regenie" + (p.gz ? ".gz" : ""));
     ofs.emplace_back(new TextOut(out_names.back(), p.gz));
     if (!*ofs.back()) throw std::runtime_error("cannot write file : " + out_names.back());
-    *ofs.back() << "CHROM GENPOS ID ALLELE0 ALLELE1 A1FREQ N TEST BETA SE CHISQ LOG10P EXTRA\n";
+    *ofs.back() << "CHROM GENPOS ID ALLELE0 ALLELE1 A1FREQ " << (show_info ? "INFO " : "") << "N TEST BETA SE CHISQ LOG10P EXTRA\n";
   }
 
-  const int fd = open((p.bed + ".bed").c_str(), O_RDONLY);
-  if (fd < 0) throw std::runtime_error("cannot read bed file");
+  const int fd = in == In::Bed ? open((p.bed + ".bed").c_str(), O_RDONLY) : -1;
+  if (in == In::Bed && fd < 0) throw std::runtime_error("cannot read bed file");
   std::vector<int64_t> file_idx(n, 0);          // file index of every analysed sample
   {
     int64_t kept = 0, k = 0;
@@ -1395,8 +1416,9 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   // buildLookupTable (Geno.cpp:2833-2856): 00 -> 2, 01 -> missing (-3), 10 -> 1, 11 -> 0 copies of the first .bim allele
   static const double lut[4] = {2.0, -3.0, 1.0, 0.0};
   std::vector<uint8_t> rows, packed;
-  std::vector<double> G, stats, bhat, sfac, mean_v, totp_v;
+  std::vector<double> G, stats, bhat, sfac, mean_v, totp_v, dbuf, ibuf;
   std::vector<int32_t> ign, nobs_v, nobsp_v;
+  std::vector<int64_t> vidx;
   bool identity = n == r.n_file;                 // every sample of the file is analysed, in file order
   for (int64_t k = 0; identity && k < n; ++k) identity = file_idx[k] == k;
   int64_t n_ignored_snps = 0, n_ignored_tests = 0, n_tested = 0;
@@ -1447,8 +1469,21 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       const int bs = (int)std::min<int64_t>(p.bsize, (int64_t)snps.size() - j0);
       sout << " block [" << block + 1 << "/" << total_blocks << "] : ";
       auto t1 = std::chrono::steady_clock::now();
-      rows.resize((size_t)bs * r.bpr);
-      for (int j = 0; j < bs;) {   // consecutive variants: one pread
+      vidx.resize(bs);
+      for (int j = 0; j < bs; ++j) vidx[j] = r.snp_offset[snps[j0 + j]];
+      if (in != In::Dosage) rows.resize((size_t)bs * r.bpr);
+      if (in == In::PgenHard) {   // ReadHardcalls per variant (Geno.cpp:2570-2573), as .bed-coded rows (00 = two ALT copies)
+        if (rg_pgen_read_bed_rows(r.pgen, bs, vidx.data(), rows.data(), r.bpr) != RG_PGEN_OK) throw std::runtime_error(rg_pgen_last_error(r.pgen));
+      } else if (in == In::Dosage) {
+        dbuf.resize((size_t)bs * r.n_file);
+        if (r.bgenh) {            // parseSnpfromBGEN (Geno.cpp:2186-2330): dosages and the terms of the IMPUTE info score
+          ibuf.resize((size_t)bs * r.n_file);
+          if (rg_bgen_read_dosages_info(r.bgenh, bs, vidx.data(), p.ref_first ? 1 : 0, dbuf.data(), ibuf.data(), r.n_file) != RG_BGEN_OK)
+            throw std::runtime_error(rg_bgen_last_error(r.bgenh));
+        } else if (rg_pgen_read_dosage_rows(r.pgen, bs, vidx.data(), dbuf.data(), r.n_file) != RG_PGEN_OK)   // Read() (Geno.cpp:2570-2571)
+          throw std::runtime_error(rg_pgen_last_error(r.pgen));
+      }
+      for (int j = 0; in == In::Bed && j < bs;) {   // consecutive variants: one pread
         int e = j + 1;
         while (e < bs && r.snp_offset[snps[j0 + e]] == r.snp_offset[snps[j0 + e - 1]] + 1) ++e;
         int64_t want = (int64_t)(e - j) * r.bpr, got = 0;
@@ -1462,14 +1497,40 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       }
       std::vector<double> total(bs, 0.0);
       std::vector<int64_t> ns1(bs, 0);
-      std::vector<double> af_t, mac_t;         // per trait (only filled when some sample is masked for some trait)
+      std::vector<double> af_t, mac_t, info_num, info_t;   // per trait: only filled when some sample is masked for some trait
       std::vector<int64_t> ns_t;
       std::vector<uint8_t> variant_ignored(bs, 0);
       rg_s2_qt_out o;
       stats.resize((size_t)bs * P); bhat.resize((size_t)bs * P); sfac.resize(bs); ign.resize(bs);
       memset(&o, 0, sizeof(o));
       o.stats = stats.data(); o.bhat = bhat.data(); o.scale_fac = sfac.data(); o.ignored = ign.data();
-      if (!dense_route) {
+      if (in == In::Dosage) {
+        // dosages: the analysed samples' doubles, allele totals, the info-score numerator and the per-trait corrections on the host
+        // (parseSnpfromBGEN / readChunkFromPGENFileToG with update_trait_counts, Geno.cpp:2948-2959), the test on the fp64 route
+        G.assign((size_t)bs * n, 0.0);
+        info_num.assign(bs, 0.0);
+        if (any_missing) { af_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0); info_t.assign((size_t)bs * P, 0.0); }
+        parallel_for(bs, nthreads, [&](int j) {
+          const double* d = dbuf.data() + (size_t)j * r.n_file;
+          const double* iv = r.bgenh ? ibuf.data() + (size_t)j * r.n_file : nullptr;
+          double* g = G.data() + (size_t)j * n;
+          double tot = 0.0, inf = 0.0; int64_t ns = 0;
+          for (int64_t k = 0; k < n; ++k) {
+            const int64_t i = file_idx[k];
+            const double v = d[i];
+            g[k] = v;
+            if (v == -3.0) continue;
+            const double e = iv ? iv[i] : v * v;
+            tot += v; inf += e; ++ns;
+            if (any_missing && has_missing[k])
+              for (int q = 0; q < P; ++q)
+                if (!Mc[(size_t)q * n + k]) { af_t[(size_t)j * P + q] -= v; ns_t[(size_t)j * P + q] -= 1; info_t[(size_t)j * P + q] -= e; }
+          }
+          total[j] = tot; ns1[j] = ns; info_num[j] = inf;
+          if (std::min(tot, 2.0 * ns - tot) < p.min_mac) variant_ignored[j] = 1;      // compute_mac (Geno.cpp:3077-3108), autosomes
+        });
+        s2check(rg_s2_qt_block(s2, G.data(), n, bs, 0, NUMTOL, &o));
+      } else if (!dense_route) {
         // hard calls stay packed: the 2-bit codes of the analysed samples go to the device as they are (the rows of the file itself
         // when no sample was dropped), the library counts the calls and contracts them on the i8 matrix cores
         const uint8_t* src = rows.data();
@@ -1493,7 +1554,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
           totp_v.resize((size_t)bs * P); nobsp_v.resize((size_t)bs * P);
           o.total_p = totp_v.data(); o.n_obs_p = nobsp_v.data();
         }
-        s2check(rg_s2_qt_block_packed(s2, src, ld, bs, 0, p.ref_first ? 1 : 0, NUMTOL, &o));
+        s2check(rg_s2_qt_block_packed(s2, src, ld, bs, 0, flip, NUMTOL, &o));
         if (any_missing) { af_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0); }
         for (int j = 0; j < bs; ++j) {
           ns1[j] = nobs_v[j];
@@ -1516,7 +1577,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
           for (int64_t k = 0; k < n; ++k) {
             const int64_t i = file_idx[k];
             double hc = lut[(row[i >> 2] >> (2 * (i & 3))) & 3];
-            if (p.ref_first && hc != -3.0) hc = 2.0 - hc;
+            if (flip && hc != -3.0) hc = 2.0 - hc;
             g[k] = hc;
             if (hc != -3.0) {
               tot += hc; ++ns;
@@ -1541,17 +1602,24 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
         for (int q = 0; q < P; ++q) {
           double af = total[j] / (2.0 * ns1[j]);
           int64_t nsq = ns1[j];
+          double infq = show_info ? info_num[j] : 0.0;
           if (any_missing) {   // compute_mac / compute_aaf_info per trait
             const double tq = total[j] + af_t[(size_t)j * P + q];
             nsq = ns1[j] + ns_t[(size_t)j * P + q];
             const double macq = std::min(tq, 2.0 * nsq - tq);
             if (macq < p.min_mac) { ++n_ignored_tests; continue; }
             af = tq / (2.0 * nsq);
+            if (show_info) infq += info_t[(size_t)j * P + q];
           }
+          double info = 1.0;     // compute_aaf_info (Geno.cpp:3132-3141): IMPUTE info for .bgen, MaCH r2 for .pgen dosages
+          if (show_info && af != 0.0 && af != 1.0)
+            info = r.bgenh ? 1.0 - infq / (2.0 * nsq * af * (1.0 - af)) : (infq / nsq - 4.0 * af * af) / (2.0 * af * (1.0 - af));
           const double st = stats[(size_t)j * P + q], bh = bhat[(size_t)j * P + q];
           const double se = bh / st, chisq = st * st, logp = get_logp(chisq);
           std::ostringstream ln;
-          ln << head.str() << af << " " << nsq << " ADD ";
+          ln << head.str() << af << " ";
+          if (show_info) ln << info << " ";
+          ln << nsq << " ADD ";
           if (se >= 0 && !std::isnan(se)) ln << bh << ' ' << se;
           else ln << "NA NA";
           if (chisq >= 0 && !std::isnan(logp)) ln << ' ' << chisq << ' ' << logp;
@@ -1564,7 +1632,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() << "ms) \n";
     }
   }
-  close(fd);
+  if (fd >= 0) close(fd);
   rg_s2_destroy(s2);
   sout << "\nAssociation results stored separately for each trait in files : \n";
   for (auto& fn : out_names) sout << "* [" << fn << "]\n";

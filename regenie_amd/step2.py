@@ -60,9 +60,10 @@ class Step2QT:
             raise ValueError("set_null: expected X %s, yres/mask %s, scf_sv (%d,)" % ((self.C, self.n), (self.P, self.n), self.P))
         self._check(self.lib.rg_s2_set_null(self.h, X.ctypes.data, yres.ctypes.data, mask.ctypes.data, scf_sv.ctypes.data))
 
-    def set_sparse_rule(self, n_samples: int, prop_zero_thr: float = 0.5) -> None:
-        """check_sparse_G's constants (Geno.cpp:3165-3177): params.n_samples (kept samples of the file) and --prop-zero-thr."""
-        self._check(self.lib.rg_s2_set_sparse_rule(self.h, int(n_samples), float(prop_zero_thr)))
+    def set_sparse_rule(self, n_samples: int, prop_zero_thr: float = 0.5, zero_count_rule: bool = False) -> None:
+        """check_sparse_G's constants (Geno.cpp:3165-3177): params.n_samples (kept samples of the file) and --prop-zero-thr;
+        zero_count_rule = the .pgen form (observed zeros >= n_samples * thr)."""
+        self._check(self.lib.rg_s2_set_sparse_rule(self.h, int(n_samples), float(prop_zero_thr), 1 if zero_count_rule else 0))
 
     def score_block(self, G, numtol: float = NUMTOL) -> dict:
         """G: numpy [bs][n] float64 (host), or a CUDA torch tensor [bs][n] float64 (read in place).  Missing = NaN or < 0."""

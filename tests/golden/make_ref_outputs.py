@@ -151,13 +151,27 @@ def step2_cases(workdir, step1_dirs):
     S = os.path.join(step1_dirs["qt_kfold_synth_missing"], "synth")
     runs["qt_synth_missing"] = (step1_dirs["qt_kfold_synth_missing"], ["--step", "2", "--bed", S, "--covarFile", S + ".covar", "--phenoFile", S + ".pheno",
                                                                       "--bsize", "200", "--qt"])
+    # the same data as .bgen (8-bit probabilities, 40 % of the calls smeared: INFO < 1; also with --ref-first) and as .pgen with and
+    # without a dosage track (tests/util.py write_synth_bgen / write_synth_pgen)
+    from tests.util import synth_dosages, write_synth_bgen, write_synth_pgen
+    spec = CASES["qt_kfold_synth_missing"][1]
+    g = synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"])
+    write_synth_bgen(S, g, spec["chroms"], seed=spec["seed"])
+    write_synth_pgen(S + "_d", g, spec["chroms"], seed=spec["seed"], soft=0.4)
+    write_synth_pgen(S + "_h", g, spec["chroms"], seed=spec["seed"], soft=0.0)
+    common = ["--covarFile", S + ".covar", "--phenoFile", S + ".pheno", "--bsize", "200", "--qt"]
+    s1m = step1_dirs["qt_kfold_synth_missing"]
+    runs["qt_synth_missing_bgen"] = (s1m, ["--step", "2", "--bgen", S + ".bgen", "--sample", S + ".sample"] + common)
+    runs["qt_synth_missing_bgen_rf"] = (s1m, ["--step", "2", "--bgen", S + ".bgen", "--sample", S + ".sample", "--ref-first"] + common)
+    runs["qt_synth_missing_pgen"] = (s1m, ["--step", "2", "--pgen", S + "_d"] + common)
+    runs["qt_synth_missing_pgenhc"] = (s1m, ["--step", "2", "--pgen", S + "_h"] + common)
     for name, (s1, args) in runs.items():
         r = subprocess.run([REGENIE] + args + ["--pred", os.path.join(s1, "out_pred.list"), "--out", name], cwd=d,
                            capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("%s failed:\n%s\n%s" % (name, r.stdout[-3000:], r.stderr[-3000:]))
         for fn in sorted(os.listdir(d)):
-            if fn.startswith(name) and fn.endswith(".regenie"):
+            if fn.startswith(name + "_Y") and fn.endswith(".regenie"):
                 with open(os.path.join(d, fn), "rb") as fi, gzip.GzipFile(os.path.join(od, fn + ".gz"), "wb", mtime=0) as fo:
                     shutil.copyfileobj(fi, fo)
 

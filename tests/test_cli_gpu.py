@@ -526,42 +526,61 @@ def test_cli_step2_qt_against_reference_output(example_dir, tmp_path, case, rout
     assert ign and ign[0].split(":")[1].strip() == ("0" if case == "qt_bed_3chr" else "14")
 
 
-def test_cli_step2_qt_masked_phenotypes_against_reference_output(tmp_path):
+@pytest.mark.parametrize("fmt", ["bed", "bgen", "bgen_rf", "pgen", "pgenhc"])
+def test_cli_step2_qt_masked_phenotypes_against_reference_output(tmp_path, fmt):
     """Phenotypes that differ in their missing values (5 %), genotypes with missing calls (1 %), 3,001 samples x 500 variants x 4
     traits (the synthetic data of the qt_kfold_synth_missing case, regenerated here): regenie takes the sparse branch of
     compute_score_qt for most variants (approximate per-trait denominators); the driver's .regenie files against regenie's own
-    (tests/golden/ref_outputs/step2/qt_synth_missing_Y*.regenie.gz), A1FREQ and N per trait as text."""
+    (tests/golden/ref_outputs/step2/qt_synth_missing*_Y*.regenie.gz), A1FREQ, INFO and N per trait as text.  Formats: the .bed
+    (hard-call i8 route, and the fp64 route with RG_S2_DENSE=1), the same calls as .bgen with 40 % of them smeared into genuine
+    8-bit probabilities (INFO < 1; also --ref-first), as .pgen with a 16-bit dosage track (MaCH r2 INFO, check_sparse_G's
+    zero-count form) and as a hard-call .pgen."""
     import gzip
     import json
-    from tests.util import synth_dosages, write_plink
+    from tests.util import synth_dosages, write_plink, write_synth_bgen, write_synth_pgen
     R = os.path.join(ROOT, "tests", "golden", "ref_outputs")
     meta = json.load(open(os.path.join(R, "qt_kfold_synth_missing", "meta.json")))
     spec = meta["synthetic"]
     S = str(tmp_path / "synth")
-    write_plink(S, synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"]), spec["chroms"], P=spec["P"],
-                seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    g = synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"])
+    write_plink(S, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    if fmt.startswith("bgen"):
+        write_synth_bgen(S, g, spec["chroms"], seed=spec["seed"])
+        src = ["--bgen", S + ".bgen", "--sample", S + ".sample"] + (["--ref-first"] if fmt == "bgen_rf" else [])
+    elif fmt.startswith("pgen"):
+        write_synth_pgen(S + "_p", g, spec["chroms"], seed=spec["seed"], soft=0.4 if fmt == "pgen" else 0.0)
+        src = ["--pgen", S + "_p"]
+    else:
+        src = ["--bed", S]
+    case = "qt_synth_missing" + ("" if fmt == "bed" else "_" + fmt)
     with open(str(tmp_path / "pred.list"), "w") as pl:
         for k, nm in enumerate(meta["pred_list"]):
             fn = str(tmp_path / ("ref_%d.loco" % (k + 1)))
             open(fn, "wb").write(gzip.open(os.path.join(R, "qt_kfold_synth_missing", "out_%d.loco.gz" % (k + 1)), "rb").read())
             pl.write("%s %s\n" % (nm, fn))
     env = {k: v for k, v in os.environ.items() if k != "RG_S2_DENSE"}
-    args = [BIN, "--step", "2", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--qt",
-            "--pred", str(tmp_path / "pred.list"), "--out", "s2"]
+    args = [BIN, "--step", "2"] + src + ["--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--qt",
+                                         "--pred", str(tmp_path / "pred.list"), "--out", "s2"]
     r = subprocess.run(args, cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ncol = 14 if fmt in ("bgen", "bgen_rf", "pgen") else 13          # with the INFO column
     for k in range(1, spec["P"] + 1):
         got = open(str(tmp_path / ("s2_Y%d.regenie" % k))).read().splitlines()
-        ref = gzip.open(os.path.join(R, "step2", "qt_synth_missing_Y%d.regenie.gz" % k), "rt").read().splitlines()
-        assert got[0] == ref[0] and len(got) == len(ref) == 501
+        ref = gzip.open(os.path.join(R, "step2", "%s_Y%d.regenie.gz" % (case, k)), "rt").read().splitlines()
+        assert got[0] == ref[0] and len(got) == len(ref) == 501 and len(ref[0].split(" ")) == ncol
         same = 0
         for a, b in zip(got[1:], ref[1:]):
             ta, tb = a.split(" "), b.split(" ")
-            assert ta[:8] == tb[:8] and ta[12] == tb[12] == "NA", (a, b)
-            for x, y in zip(ta[8:12], tb[8:12]):
+            t0 = ncol - 5                                                          # first of BETA SE CHISQ LOG10P
+            assert ta[:5] == tb[:5] and ta[t0 - 2:t0] == tb[t0 - 2:t0] and ta[-1] == tb[-1] == "NA", (a, b)   # ids, N TEST, EXTRA
+            for x, y in zip(ta[5:t0 - 2], tb[5:t0 - 2]):                           # A1FREQ (INFO): sums of dosages
+                assert x == y or float(x) == pytest.approx(float(y), rel=2e-6), (a, b)
+            for x, y in zip(ta[t0:t0 + 4], tb[t0:t0 + 4]):
                 assert float(x) == pytest.approx(float(y), rel=2e-5, abs=2e-9), (a, b)
             same += a == b
         assert same >= 450, same
+    if fmt != "bed":
+        return
     # the fp64 route of the library (decoded dosages, the per-trait counts kept on the host) must print the same files
     keep = {k: open(str(tmp_path / ("s2_Y%d.regenie" % k))).read() for k in range(1, spec["P"] + 1)}
     r2 = subprocess.run(args, cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=dict(env, RG_S2_DENSE="1"))

@@ -209,3 +209,61 @@ def gpu_step1_any(opt: orc.Step1Options, force_kfold: bool = False, inject_W=Non
     eng.close()
     return dict(cumsum=cs, best=best, pred=pred, loco=loco, converged=conv, prep=prep, tau=tau, L=L,
                 use_loocv=use_loocv)
+
+
+def write_synth_bgen(prefix, g, chroms, seed=1, soft=0.4):
+    """prefix.bgen (layout 2, 8-bit, zlib, embedded FID_IID identifiers) + prefix.sample for the hard calls g (M,N int8, -3 missing)
+    of synth_dosages, with a fraction `soft` of the calls smeared into genuine genotype probabilities (deterministic hashes), so that
+    dosages are not integers and the IMPUTE info score is below 1.  Variant ids / positions / alleles as write_plink's .bim."""
+    from oracle import bgen as obg
+    M, N = g.shape
+    j = np.arange(M)[:, None]
+    i = np.arange(N)[None, :]
+    p_hom = np.where(g == 2, 255, 0).astype(np.int64)          # P(two copies of the first allele), P(het) in 1/255
+    p_het = np.where(g == 1, 255, 0).astype(np.int64)
+    smear = u01(301 + seed, j, i) < soft
+    a = (u01(302 + seed, j, i) * 90).astype(np.int64)           # mass moved away from the called genotype
+    b = (u01(303 + seed, j, i) * (a + 1)).astype(np.int64)      # part of it that goes to the "next" genotype
+    hom, het = p_hom.copy(), p_het.copy()
+    s2, s1, s0 = smear & (g == 2), smear & (g == 1), smear & (g == 0)
+    hom[s2] -= a[s2]; het[s2] += b[s2]                          # the rest goes to the other homozygote (third probability)
+    het[s1] -= a[s1]; hom[s1] += b[s1]
+    het[s0] += b[s0]; hom[s0] += a[s0] - b[s0]
+    probs = np.stack([hom, het], axis=-1).astype(np.uint8)
+    assert (hom >= 0).all() and (het >= 0).all() and (hom + het <= 255).all()
+    variants = [(int(chroms[k]), k + 1, "s%d" % k, "A", "G") for k in range(M)]
+    obg.write_bgen(prefix + ".bgen", probs, g < 0, variants, sample_ids=["%d_%d" % (k + 1, k + 1) for k in range(N)], compression=1)
+    with open(prefix + ".sample", "w") as fh:
+        fh.write("ID_1 ID_2 missing\n0 0 0\n")
+        for k in range(N):
+            fh.write("%d %d 0\n" % (k + 1, k + 1))
+
+
+def write_synth_pgen(prefix, g, chroms, seed=1, soft=0.4):
+    """prefix.pgen / .pvar / .psam for the hard calls g (M,N int8 = ALT counts, -3 missing) of synth_dosages; soft > 0 adds a dosage
+    track (bit-array layout) to every variant: that fraction of the observed calls gets a 16-bit dosage near its hard call, so the
+    file is read with PgenReader::Read and the MaCH r2 info score is below 1.  Variant ids / positions as write_plink's .bim,
+    REF = G, ALT = A."""
+    from oracle import pgen as opg
+    M, N = g.shape
+    codes = np.where(g < 0, 3, g).astype(np.uint8)
+    dos = None
+    if soft > 0:
+        dos = {}
+        j = np.arange(M)[:, None]
+        i = np.arange(N)[None, :]
+        pick = (u01(401 + seed, j, i) < soft) & (g >= 0)
+        delta = (u01(402 + seed, j, i) * 5000).astype(np.int64)
+        val = np.where(g == 0, delta, np.where(g == 2, 32768 - delta, 16384 + delta - 2500))
+        for k in range(M):
+            ids = np.flatnonzero(pick[k])
+            dos[k] = (0x60, ids, val[k, ids].astype(np.uint16))
+    opg.write_pgen(prefix + ".pgen", codes, np.zeros(M, np.int64), wide_vrtypes=True, dosage=dos, reclen_bytes=3, seed=seed)
+    with open(prefix + ".pvar", "w") as fh:
+        fh.write("#CHROM\tPOS\tID\tREF\tALT\n")
+        for k in range(M):
+            fh.write("%d\t%d\ts%d\tG\tA\n" % (chroms[k], k + 1, k))
+    with open(prefix + ".psam", "w") as fh:
+        fh.write("#FID\tIID\tSEX\n")
+        for k in range(N):
+            fh.write("%d\t%d\tNA\n" % (k + 1, k + 1))
