@@ -74,6 +74,24 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
 int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32_t bs, int32_t rows_on_device, int32_t flip,
                           double numtol, const rg_s2_qt_out* out);
 
+/* The contraction primitive under rg_s2_qt_block_packed, for tests of the same shape (the score tests of binary and count traits are
+ * functions of such sums: Step2_Models.cpp:471-552 compute_score_bt needs sum w g~^2, X^T W g~ and g~ . (y - p^) per trait).
+ * rg_s2_set_columns: n_col fixed fp64 columns [n_col][n] (host, sample-fastest; at most 4096), split once into int8 digit planes.
+ * rg_s2_contract_packed: for every row of 2-bit hard calls (coding and flip as in rg_s2_qt_block_packed)
+ *   sums   [bs][2][n_col]  sum_i g0_i col_c(i) and sum_i miss_i col_c(i)   (g0 = the call with 0 at missing entries, miss = its indicator;
+ *                          the second is left 0 when the block has no missing call)
+ *   sq     [bs][n_sq]      sum_i g0_i^2 col_c(i) for the first n_sq columns
+ *   counts [bs][4]         number of calls equal to 1, equal to 2, missing, 0
+ * exact up to the truncation of a column at 2^-54 of its largest entry; pointers are HOST pointers and may be NULL. */
+typedef struct rg_s2_contract_out {
+  double* sums;
+  double* sq;
+  int32_t* counts;
+} rg_s2_contract_out;
+int rg_s2_set_columns(rg_s2_ctx* ctx, int32_t n_col, const double* cols, int32_t n_sq);
+int rg_s2_contract_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32_t bs, int32_t rows_on_device, int32_t flip,
+                          const rg_s2_contract_out* out);
+
 /* check_sparse_G's constants (Geno.cpp:3165-3177): n_samples = params.n_samples (every kept sample of the file, >= n; default n),
  * prop_zero_thr = --prop-zero-thr (default 0.5).  zero_count_rule = 0: a variant is sparse when the non-zero entries of its
  * mean-imputed vector number <= n_samples * (1 - prop_zero_thr) (.bed / .bgen input, n_zero == -1); 1: when its observed zero

@@ -563,6 +563,11 @@ struct rg_s2_ctx {
   int8_t* dvd = nullptr;        // the digit planes of dV's columns, [col][8][Np]
   double *dvsc = nullptr, *dYtX = nullptr;   // [col] plane scales, [P][C] res_p^T x_c
   double *dQ = nullptr, *dMsum = nullptr;    // [P][C][C] X^T diag(mask_p) X, [P] sum of mask_p
+  // generic contraction (rg_s2_set_columns / rg_s2_contract_packed): caller-defined columns
+  int g_ncol = 0, g_nsq = 0;
+  double* gV = nullptr;         // [ncol padded to 16][Np]
+  int8_t* gvd = nullptr;
+  double* gvsc = nullptr;
   // dosage route (rg_s2_qt_block), masked problems: per phenotype the samples masked for it
   bool lists_ready = false;
   int32_t* d_mlist = nullptr;
@@ -641,6 +646,9 @@ void rg_s2_destroy(rg_s2_ctx* ctx) {
     if (ctx->dYtX) (void)hipFree(ctx->dYtX);
     if (ctx->dQ) (void)hipFree(ctx->dQ);
     if (ctx->dMsum) (void)hipFree(ctx->dMsum);
+    if (ctx->gV) (void)hipFree(ctx->gV);
+    if (ctx->gvd) (void)hipFree(ctx->gvd);
+    if (ctx->gvsc) (void)hipFree(ctx->gvsc);
     if (ctx->d_mlist) (void)hipFree(ctx->d_mlist);
     if (ctx->d_moff) (void)hipFree(ctx->d_moff);
     if (ctx->dX) (void)hipFree(ctx->dX);
@@ -912,6 +920,92 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   if (out->ignored) S2_HIP(hipMemcpyAsync(out->ignored, ign, sizeof(int32_t) * bs, hipMemcpyDeviceToHost, ctx->st));
   if (out->total_p) S2_HIP(hipMemcpyAsync(out->total_p, total_p, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));
   if (out->n_obs_p) S2_HIP(hipMemcpyAsync(out->n_obs_p, nobs_p, sizeof(int32_t) * bs * P, hipMemcpyDeviceToHost, ctx->st));
+  S2_HIP(hipStreamSynchronize(ctx->st));
+  float ms = 0.f;
+  S2_HIP(hipEventElapsedTime(&ms, ctx->e0, ctx->e1));
+  ctx->last_ms = ms;
+  return RG_S2_OK;
+}
+
+int rg_s2_set_columns(rg_s2_ctx* ctx, int32_t n_col, const double* cols, int32_t n_sq) {
+  if (!ctx || !ctx->st) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_set_columns: context was not created");
+  if (!cols || n_col < 1 || n_col > 4096 || n_sq < 0 || n_sq > n_col)
+    return fail(ctx, RG_S2_ERR_ARG, "rg_s2_set_columns: need 1 <= n_col <= 4096 and 0 <= n_sq <= n_col");
+  const int64_t n = ctx->n;
+  S2_HIP(hipSetDevice(ctx->dev));
+  const int ngrp = (n_col + 15) / 16;
+  const int64_t Np = (n + 64 * RG_MAX_SEG - 1) / (64 * RG_MAX_SEG) * (64 * RG_MAX_SEG);
+  if (ctx->g_ncol != n_col || !ctx->gV) {
+    for (void** q : {(void**)&ctx->gV, (void**)&ctx->gvd, (void**)&ctx->gvsc})
+      if (*q) { S2_HIP(hipFree(*q)); *q = nullptr; }
+    ctx->g_ncol = 0;
+    S2_HIP(hipMalloc((void**)&ctx->gV, sizeof(double) * ngrp * 16 * Np));
+    S2_HIP(hipMalloc((void**)&ctx->gvd, (size_t)ngrp * 16 * 8 * Np));
+    S2_HIP(hipMalloc((void**)&ctx->gvsc, sizeof(double) * ngrp * 16));
+    S2_HIP(hipMemsetAsync(ctx->gV, 0, sizeof(double) * ngrp * 16 * Np, ctx->st));
+  }
+  S2_HIP(hipMemcpy2DAsync(ctx->gV, Np * sizeof(double), cols, n * sizeof(double), n * sizeof(double), n_col, hipMemcpyHostToDevice, ctx->st));
+  rg_launch_v_split(ctx->st, ctx->gV, Np, ngrp * 16, ctx->gvd, ctx->gvsc);
+  S2_HIP(hipGetLastError());
+  S2_HIP(hipStreamSynchronize(ctx->st));
+  ctx->g_ncol = n_col; ctx->g_nsq = n_sq;
+  return RG_S2_OK;
+}
+
+int rg_s2_contract_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32_t bs, int32_t rows_on_device, int32_t flip,
+                          const rg_s2_contract_out* out) {
+  if (!ctx || !ctx->st) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_contract_packed: context was not created");
+  if (ctx->g_ncol < 1) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_contract_packed: rg_s2_set_columns has not been called");
+  const int64_t n = ctx->n, nbytes = (n + 3) / 4;
+  if (!rows || !out || bs < 1 || ld < nbytes) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_contract_packed: bad arguments (need bs >= 1, ld >= ceil(n / 4))");
+  S2_HIP(hipSetDevice(ctx->dev));
+  const int ncol = ctx->g_ncol, nsq = ctx->g_nsq, ngrp = (ncol + 15) / 16, ngrpB = (nsq + 15) / 16, CvB = ngrpB * 16;
+  const int64_t Np = (n + 64 * RG_MAX_SEG - 1) / (64 * RG_MAX_SEG) * (64 * RG_MAX_SEG), ldp = Np / 4;
+  const int n128 = (int)((bs + 127) / 128 * 128);
+  int nseg = 1;
+  while (nseg < RG_MAX_SEG && (int64_t)(n128 / 128) * nseg * ngrp < 768 && Np / (nseg * 2) >= 1024) nseg *= 2;
+  SegLayout& seg = ctx->seg;
+  memset(&seg, 0, sizeof(seg));
+  seg.nseg = nseg;
+  for (int f = 0; f < nseg; ++f) { seg.pos_start[f] = f * (Np / nseg); seg.file_start[f] = seg.pos_start[f]; seg.len[f] = Np / nseg; seg.plen[f] = Np / nseg; }
+  enum { Q_PK, Q_CNT, Q_S, Q_A };
+  const size_t s_grp = (size_t)2 * nseg * n128 * 128;
+  int rc;
+  if ((rc = ensure_p(ctx, Q_PK, (size_t)bs * ldp))) return rc;
+  if ((rc = ensure_p(ctx, Q_CNT, ((size_t)bs * 4 + 8) * sizeof(int32_t)))) return rc;
+  if ((rc = ensure_p(ctx, Q_S, (size_t)(ngrp + ngrpB) * s_grp * sizeof(int32_t)))) return rc;
+  if ((rc = ensure_p(ctx, Q_A, (size_t)bs * 2 * (ncol + CvB) * sizeof(double)))) return rc;
+  uint8_t* pk = (uint8_t*)ctx->pbuf[Q_PK];
+  int32_t* cnt = (int32_t*)ctx->pbuf[Q_CNT];
+  int32_t* total_miss = cnt + (size_t)bs * 4;
+  int32_t* d_bs = total_miss + 1;
+  int32_t* d_zero = total_miss + 2;
+  int32_t* S = (int32_t*)ctx->pbuf[Q_S];
+  double* A = (double*)ctx->pbuf[Q_A];
+  double* Sq = A + (size_t)bs * 2 * ncol;
+  ctx->hdr[0] = 0; ctx->hdr[1] = bs; ctx->hdr[2] = 0;
+  S2_HIP(hipMemcpyAsync(total_miss, ctx->hdr, sizeof(ctx->hdr), hipMemcpyHostToDevice, ctx->st));
+  S2_HIP(hipMemcpy2DAsync(pk, ldp, rows, ld, nbytes, bs, rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->st));
+  S2_HIP(hipEventRecord(ctx->e0, ctx->st));
+  hipLaunchKernelGGL(k_s2_rows, dim3(bs), dim3(256), 0, ctx->st, pk, ldp, n, flip ? 1 : 0, cnt, total_miss);
+  for (int g = 0; g < ngrp; ++g)
+    rg_launch_xy_i8_sums(ctx->st, pk, ldp, 0, d_bs, total_miss, 1, n128, seg, ctx->gvd + (size_t)g * 16 * 8 * Np, Np, std::min(16, ncol - g * 16),
+                         RG_XY_LUT_DOSAGE, S + (size_t)g * s_grp);
+  hipLaunchKernelGGL(k_s2_combine, dim3((bs * ncol + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->gvsc, total_miss, bs, n128, nseg, ncol, A);
+  if (nsq > 0) {
+    int32_t* SB = S + (size_t)ngrp * s_grp;
+    for (int g = 0; g < ngrpB; ++g)
+      rg_launch_xy_i8_sums(ctx->st, pk, ldp, 0, d_bs, d_zero, 1, n128, seg, ctx->gvd + (size_t)g * 16 * 8 * Np, Np, std::min(16, ncol - g * 16),
+                           RG_XY_LUT_SQUARE, SB + (size_t)g * s_grp);
+    hipLaunchKernelGGL(k_s2_combine, dim3((bs * CvB + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)SB, ctx->gvsc, (const int32_t*)nullptr, bs, n128, nseg,
+                       CvB, Sq);
+  }
+  S2_HIP(hipEventRecord(ctx->e1, ctx->st));
+  S2_HIP(hipGetLastError());
+  if (out->sums) S2_HIP(hipMemcpyAsync(out->sums, A, sizeof(double) * bs * 2 * ncol, hipMemcpyDeviceToHost, ctx->st));
+  if (out->counts) S2_HIP(hipMemcpyAsync(out->counts, cnt, sizeof(int32_t) * bs * 4, hipMemcpyDeviceToHost, ctx->st));
+  if (out->sq && nsq > 0)     // set 0 of [bs][2][CvB]: the first nsq entries of each row
+    S2_HIP(hipMemcpy2DAsync(out->sq, sizeof(double) * nsq, Sq, sizeof(double) * 2 * CvB, sizeof(double) * nsq, bs, hipMemcpyDeviceToHost, ctx->st));
   S2_HIP(hipStreamSynchronize(ctx->st));
   float ms = 0.f;
   S2_HIP(hipEventElapsedTime(&ms, ctx->e0, ctx->e1));

@@ -357,12 +357,14 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--l1-shared") p.l1_shared = true;
     else if (a == "--pred") p.pred_list = need(i);
     else if (a == "--minMAC") p.min_mac = atof(need(i).c_str());
+    else if (a == "--firth" || a == "--spa" || a == "--approx" || a == "--firth-se")
+      usage_error("'" + a + "': the Firth / SPA corrections of the binary-trait test are not built (the uncorrected score test is: drop the option).");
     else usage_error("unrecognised option '" + a + "'");
   }
   if (p.bt) p.rint = false;  // Regenie.cpp:432
   if (p.step != 1 && p.step != 2) usage_error("specify which mode regenie should be running using option --step.");
   if (p.step == 2) {
-    if (p.bt || p.ct) usage_error("--step 2 serves quantitative traits only (--qt): the binary / count trait tests (Firth, SPA) are not built.");
+    if (p.ct) usage_error("--step 2 serves quantitative and binary traits (--qt / --bt): the count trait test is not built.");
     if (p.pred_list.empty()) usage_error("option '--pred' is required (use the _pred.list file written by step 1).");
     if (p.min_mac < 0.5) usage_error("minimum MAC must be at least 0.5.");   // Regenie.cpp:1054
     if (p.gpus > 1 || p.force_collectives) usage_error("--step 2 runs on one GPU.");
@@ -445,9 +447,10 @@ bool solve_dense(std::vector<double> A, std::vector<double> b, int n, std::vecto
   }
   return true;
 }
-// fit_logistic (Step1_Models.cpp:156-222) for one phenotype, zero offset; eta_out = X beta on success
+// fit_logistic (Step1_Models.cpp:156-222) for one phenotype; offset may be null (zero); eta_out = offset + X beta on success,
+// pv_out (optional) the fitted probabilities
 bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t N, int C, const Params& prm,
-                  bool check_hs_dev, std::vector<double>& eta) {
+                  bool check_hs_dev, std::vector<double>& eta, const double* offset = nullptr, std::vector<double>* pv_out = nullptr) {
   std::vector<double> beta(C, 0.0), betanew(C, 0.0), pv(N), w(N);
   auto dev = [&](const std::vector<double>& pp) {
     double t = 0.0;
@@ -455,7 +458,7 @@ bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t
     return 2.0 * t;
   };
   eta.assign(N, 0.0);
-  for (int64_t i = 0; i < N; ++i) pv[i] = get_pvec1(0.0);
+  for (int64_t i = 0; i < N; ++i) { eta[i] = offset ? offset[i] : 0.0; pv[i] = get_pvec1(eta[i]); }
   double dev_old = dev(pv), dev_new = dev_old, diff_dev = 0.0;
   int niter = 0;
   bool small_score = false;
@@ -465,7 +468,7 @@ bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t
     std::vector<double> A((size_t)C * C, 0.0), b(C, 0.0);
     for (int64_t i = 0; i < N; ++i) {
       if (!mask[i]) continue;
-      const double z = eta[i] + (y[i] - pv[i]) / w[i];
+      const double z = eta[i] - (offset ? offset[i] : 0.0) + (y[i] - pv[i]) / w[i];
       for (int a = 0; a < C; ++a) {
         const double xa = X[(size_t)a * N + i] * w[i];
         b[a] += xa * z;
@@ -477,7 +480,7 @@ bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t
     for (int ls = 0; ls < prm.niter_max_line_search; ++ls) {
       bool inside = true;
       for (int64_t i = 0; i < N; ++i) {
-        double e = 0.0;
+        double e = offset ? offset[i] : 0.0;
         for (int a = 0; a < C; ++a) e += X[(size_t)a * N + i] * betanew[a];
         eta[i] = e;
         pv[i] = get_pvec1(e);
@@ -502,6 +505,7 @@ bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t
     dev_old = dev_new;
   }
   if ((diff_dev == 0 || diff_dev >= NUMTOL) && niter > prm.niter_max) return false;
+  if (pv_out) *pv_out = pv;
   return true;
 }
 
@@ -1368,7 +1372,15 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   std::vector<uint8_t> Mc((size_t)P * n);
   for (int c = 0; c < C; ++c) for (int64_t k = 0; k < n; ++k) Xc[(size_t)c * n + k] = r.X[(size_t)c * N + an[k]];
   for (int q = 0; q < P; ++q)
-    for (int64_t k = 0; k < n; ++k) { Yc[(size_t)q * n + k] = r.Y[(size_t)q * N + an[k]]; Mc[(size_t)q * n + k] = r.mask[(size_t)q * N + an[k]]; }
+    for (int64_t k = 0; k < n; ++k) { Yc[(size_t)q * n + k] = (p.bt ? r.Yraw : r.Y)[(size_t)q * N + an[k]]; Mc[(size_t)q * n + k] = r.mask[(size_t)q * N + an[k]]; }
+  // binary traits (compute_res_bin, Data.cpp:2439-2445; compute_score_bt, Step2_Models.cpp:471-552): per chromosome the null logistic
+  // model with the LOCO offset gives p^, w = p^ (1 - p^); the score test of a variant needs, per trait, sum w g~^2, X^T W g~ and
+  // g~ . (y - p^) -- contractions of the hard-call row with fixed columns, which rg_s2_contract_packed evaluates on the i8 matrix cores
+  const int bt_ncol = P * (C + 3);        // [w_q] (P, also against g^2) | [w_q x_c] (P * C) | [y_q - p^_q] (P) | [mask_q] (P)
+  std::vector<double> bt_cols, bt_xwx_inv, bt_sums, bt_sq;
+  std::vector<int32_t> bt_counts;
+  std::vector<uint8_t> bt_pass(P, 1), test_ignored;
+  if (p.bt) { bt_cols.assign((size_t)bt_ncol * n, 0.0); bt_xwx_inv.assign((size_t)P * C * C, 0.0); }
 
   rg_s2_ctx* s2 = nullptr;
   if (rg_s2_create(&s2, p.device, n, C, P) != RG_S2_OK || !s2) throw std::runtime_error("no MI355X / HIP device available (rg_s2_create failed)");
@@ -1429,7 +1441,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
     const int nb_chr = (int)((snps.size() + p.bsize - 1) / p.bsize);
     sout << "Chromosome " << chrom << " [" << nb_chr << " blocks in total]\n";
     // blup_read_chr (Step2_Models.cpp:51-140) + compute_res (Data.cpp:2386-2400)
-    sout << "   -reading loco predictions for the chromosome...";
+    sout << (p.bt ? "   -reading loco predictions for the chromosome and fitting null logistic regression on binary phenotypes..." : "   -reading loco predictions for the chromosome...");
     auto tb = std::chrono::steady_clock::now();
     for (int q = 0; q < P; ++q) {
       Run::Blup& bl = r.blups[q];
@@ -1451,6 +1463,37 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
         if (v == MISSING) throw std::runtime_error("individual has missing predictions (chr=" + std::to_string(chrom) + ";phenotype=" + r.pheno_names[q] + ").");
         blup[i] = v;
       }
+      if (p.bt) {   // fit_null_logistic, test-mode branch (Step1_Models.cpp:54-140): offset = the LOCO prediction of the analysed, unmasked samples
+        std::vector<double> off(n), eta, pv;
+        for (int64_t k = 0; k < n; ++k) off[k] = blup[an[k]] * Mc[(size_t)q * n + k];
+        const double* yq = Yc.data() + (size_t)q * n;
+        const uint8_t* mq = Mc.data() + (size_t)q * n;
+        bool ok = fit_logistic(yq, Xc.data(), mq, n, C, p, true, eta, off.data(), &pv);
+        if (!ok) ok = fit_logistic(yq, Xc.data(), mq, n, C, p, false, eta, off.data(), &pv);
+        bt_pass[q] = ok ? 1 : 0;
+        if (!ok) { sout << "\n     WARNING: logistic regression did not converge for phenotype '" << r.pheno_names[q] << "'."; continue; }
+        std::vector<double> A((size_t)C * C, 0.0);
+        double* cw = bt_cols.data() + (size_t)q * n;
+        double* cr = bt_cols.data() + (size_t)(P + P * C + q) * n;
+        double* cm = bt_cols.data() + (size_t)(P + P * C + P + q) * n;
+        for (int64_t k = 0; k < n; ++k) {
+          const double m = mq[k] ? 1.0 : 0.0, w = pv[k] * (1.0 - pv[k]) * m;     // get_wvec (Step1_Models.cpp:1808-1815) on the unmasked samples
+          cw[k] = w; cr[k] = (yq[k] - pv[k]) * m; cm[k] = m;
+          for (int a = 0; a < C; ++a) {
+            const double xa = Xc[(size_t)a * n + k] * w;
+            bt_cols[(size_t)(P + q * C + a) * n + k] = xa;
+            for (int c = 0; c < C; ++c) A[(size_t)a * C + c] += xa * Xc[(size_t)c * n + k];
+          }
+        }
+        // (X^T W X)^-1: the projector of getBasis(Gamma X) (Step1_Models.cpp:132-133) written out
+        std::vector<double> e(C), col;
+        for (int c = 0; c < C; ++c) {
+          std::fill(e.begin(), e.end(), 0.0); e[c] = 1.0;
+          if (!solve_dense(A, e, C, col)) throw std::runtime_error("X'WX is singular in the null logistic model of phenotype '" + r.pheno_names[q] + "'.");
+          for (int a = 0; a < C; ++a) bt_xwx_inv[((size_t)q * C + a) * C + c] = col[a];
+        }
+        continue;
+      }
       double ss = 0.0;
       for (int64_t k = 0; k < n; ++k) {
         const double v = (Yc[(size_t)q * n + k] - blup[an[k]]) * Mc[(size_t)q * n + k];
@@ -1461,7 +1504,8 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       for (int64_t k = 0; k < n; ++k) resc[(size_t)q * n + k] /= sd;
       scf[q] = r.scale_Y[q] * sd;
     }
-    s2check(rg_s2_set_null(s2, Xc.data(), resc.data(), Mc.data(), scf.data()));
+    if (p.bt) s2check(rg_s2_set_columns(s2, bt_ncol, bt_cols.data(), P));
+    else s2check(rg_s2_set_null(s2, Xc.data(), resc.data(), Mc.data(), scf.data()));
     sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tb).count() << "ms) \n";
 
     for (int bb = 0; bb < nb_chr; ++bb, ++block) {
@@ -1504,7 +1548,59 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       stats.resize((size_t)bs * P); bhat.resize((size_t)bs * P); sfac.resize(bs); ign.resize(bs);
       memset(&o, 0, sizeof(o));
       o.stats = stats.data(); o.bhat = bhat.data(); o.scale_fac = sfac.data(); o.ignored = ign.data();
-      if (in == In::Dosage) {
+      test_ignored.assign((size_t)bs * P, 0);
+      if (p.bt) {
+        if (in == In::Dosage) throw std::runtime_error("--step 2 --bt reads hard calls (--bed, or a .pgen without dosages): the binary-trait test on dosages is not built.");
+        const uint8_t* src = rows.data();
+        int64_t ld = r.bpr;
+        if (!identity) {
+          ld = (n + 3) / 4;
+          packed.assign((size_t)bs * ld, 0);
+          parallel_for(bs, nthreads, [&](int j) {
+            const uint8_t* row = rows.data() + (size_t)j * r.bpr;
+            uint8_t* dst = packed.data() + (size_t)j * ld;
+            for (int64_t k = 0; k < n; ++k) {
+              const int64_t i = file_idx[k];
+              dst[k >> 2] |= (uint8_t)(((row[i >> 2] >> (2 * (i & 3))) & 3) << (2 * (k & 3)));
+            }
+          });
+          src = packed.data();
+        }
+        bt_sums.resize((size_t)bs * 2 * bt_ncol); bt_sq.resize((size_t)bs * P); bt_counts.resize((size_t)bs * 4);
+        rg_s2_contract_out co;
+        co.sums = bt_sums.data(); co.sq = bt_sq.data(); co.counts = bt_counts.data();
+        s2check(rg_s2_contract_packed(s2, src, ld, bs, 0, flip, &co));
+        af_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0);
+        parallel_for(bs, nthreads, [&](int j) {
+          const double n1 = bt_counts[(size_t)j * 4], n2 = bt_counts[(size_t)j * 4 + 1], nm = bt_counts[(size_t)j * 4 + 2];
+          const double nobs = (double)n - nm, tot = n1 + 2.0 * n2;
+          const double mu = nobs > 0 ? tot / nobs : 0.0;
+          ns1[j] = (int64_t)nobs; total[j] = tot; ign[j] = nobs > 0 ? 0 : 1; sfac[j] = 1.0;
+          if (std::min(tot, 2.0 * nobs - tot) < p.min_mac) variant_ignored[j] = 1;
+          const double* s0 = bt_sums.data() + (size_t)j * 2 * bt_ncol;
+          const double* s1 = s0 + bt_ncol;
+          for (int q = 0; q < P; ++q) {
+            const int cm = P + P * C + P + q, cr = P + P * C + q;
+            af_t[(size_t)j * P + q] = std::nearbyint(s0[cm]) - tot;                                  // per-trait allele and sample counts
+            ns_t[(size_t)j * P + q] = (int64_t)std::nearbyint(r.neff[q] - s1[cm]) - ns1[j];
+            if (!bt_pass[q]) { test_ignored[(size_t)j * P + q] = 1; continue; }
+            const double sw2 = bt_sq[(size_t)j * P + q] + mu * mu * s1[q];                          // sum w g~^2
+            double quad = 0.0;                                                                       // (X^T W g~)^T (X^T W X)^-1 (X^T W g~)
+            const double* inv = bt_xwx_inv.data() + (size_t)q * C * C;
+            for (int a = 0; a < C; ++a) {
+              const double ua = s0[P + q * C + a] + mu * s1[P + q * C + a];
+              double row = 0.0;
+              for (int c = 0; c < C; ++c) row += inv[(size_t)a * C + c] * (s0[P + q * C + c] + mu * s1[P + q * C + c]);
+              quad += ua * row;
+            }
+            const double denum = sw2 - quad, sd = std::sqrt(denum);
+            if (!(sd >= NUMTOL)) { test_ignored[(size_t)j * P + q] = 1; continue; }                 // Step2_Models.cpp:512-517
+            const double st = (s0[cr] + mu * s1[cr]) / sd;
+            stats[(size_t)j * P + q] = st;
+            bhat[(size_t)j * P + q] = st / sd;                                                      // get_sumstats (Step2_Models.cpp:2031-2041)
+          }
+        });
+      } else if (in == In::Dosage) {
         // dosages: the analysed samples' doubles, allele totals, the info-score numerator and the per-trait corrections on the host
         // (parseSnpfromBGEN / readChunkFromPGENFileToG with update_trait_counts, Geno.cpp:2948-2959), the test on the fp64 route
         G.assign((size_t)bs * n, 0.0);
@@ -1603,7 +1699,8 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
           double af = total[j] / (2.0 * ns1[j]);
           int64_t nsq = ns1[j];
           double infq = show_info ? info_num[j] : 0.0;
-          if (any_missing) {   // compute_mac / compute_aaf_info per trait
+          if (test_ignored[(size_t)j * P + q]) continue;
+          if (any_missing || p.bt) {   // compute_mac / compute_aaf_info per trait
             const double tq = total[j] + af_t[(size_t)j * P + q];
             nsq = ns1[j] + ns_t[(size_t)j * P + q];
             const double macq = std::min(tq, 2.0 * nsq - tq);

@@ -17,6 +17,10 @@ class _QtOut(C.Structure):
                 ("n_obs", C.c_void_p), ("ignored", C.c_void_p), ("total_p", C.c_void_p), ("n_obs_p", C.c_void_p)]
 
 
+class _ContractOut(C.Structure):
+    _fields_ = [("sums", C.c_void_p), ("sq", C.c_void_p), ("counts", C.c_void_p)]
+
+
 class Step2QT:
     NUMTOL = 1e-6     # params.numtol, Regenie.hpp:220
 
@@ -117,3 +121,22 @@ class Step2QT:
         out = _QtOut(*[res[k].ctypes.data for k in ("stats", "bhat", "scale_fac", "mean", "n_obs", "ignored", "total_p", "n_obs_p")])
         self._check(self.lib.rg_s2_qt_block_packed(self.h, ptr, ld, bs, on_device, 1 if flip else 0, float(numtol), C.byref(out)))
         return self._finish(res)
+
+    # ---- the contraction primitive (rg_s2_set_columns / rg_s2_contract_packed) ------------------------------------------------
+    def set_columns(self, cols: np.ndarray, n_sq: int = 0) -> None:
+        """cols [n_col][n] float64: the fixed columns the hard-call rows are contracted with; the first n_sq also against g^2."""
+        cols = np.ascontiguousarray(cols, dtype=np.float64)
+        if cols.ndim != 2 or cols.shape[1] != self.n:
+            raise ValueError("set_columns: cols must be [n_col][n]")
+        self._ncol, self._nsq = cols.shape[0], int(n_sq)
+        self._check(self.lib.rg_s2_set_columns(self.h, cols.shape[0], cols.ctypes.data, int(n_sq)))
+
+    def contract_packed(self, rows, flip: bool = False) -> dict:
+        """-> sums [bs][2][n_col] (allele count . column, missing indicator . column), sq [bs][n_sq], counts [bs][4] (ones, twos, missing, 0)."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        bs = rows.shape[0]
+        res = {"sums": np.zeros((bs, 2, self._ncol)), "sq": np.zeros((bs, self._nsq)), "counts": np.zeros((bs, 4), np.int32)}
+        out = _ContractOut(res["sums"].ctypes.data, res["sq"].ctypes.data if self._nsq else None, res["counts"].ctypes.data)
+        self._check(self.lib.rg_s2_contract_packed(self.h, rows.ctypes.data, rows.shape[1], bs, 0, 1 if flip else 0, C.byref(out)))
+        res["kernel_ms"] = self.lib.rg_s2_last_kernel_ms(self.h)
+        return res

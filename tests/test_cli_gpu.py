@@ -595,8 +595,40 @@ def test_cli_step2_qt_masked_phenotypes_against_reference_output(tmp_path, fmt):
                 assert float(x) == pytest.approx(float(y), rel=1e-5, abs=1e-9), (la, lb)
 
 
+def test_cli_step2_bt_score_test_against_reference_output(example_dir, tmp_path):
+    """`regenie-amd --step 2 --bt` (the score test without Firth / SPA: null logistic model with the LOCO offset per chromosome,
+    compute_score_bt, get_sumstats) against regenie's own output for the documented Step-2 command without --firth
+    (tests/golden/ref_outputs/step2/bt_score_bed_Y*.regenie.gz; --remove drops samples, so the rows are re-packed)."""
+    import gzip
+    E = example_dir
+    R = os.path.join(ROOT, "tests", "golden", "ref_outputs")
+    with open(str(tmp_path / "pred.list"), "w") as pl:
+        for k in (1, 2):
+            fn = str(tmp_path / ("ref_%d.loco" % k))
+            open(fn, "wb").write(gzip.open(os.path.join(R, "bt_loocv_refcmd", "out_%d.loco.gz" % k), "rb").read())
+            pl.write("Y%d %s\n" % (k, fn))
+    r = _run(["--step", "2", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"),
+              "--covarFile", os.path.join(E, "covariates.txt"), "--remove", os.path.join(E, "fid_iid_to_remove.txt"), "--bsize", "200", "--bt",
+              "--pred", str(tmp_path / "pred.list"), "--out", "s2"], str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for k in (1, 2):
+        got = open(str(tmp_path / ("s2_Y%d.regenie" % k))).read().splitlines()
+        ref = gzip.open(os.path.join(R, "step2", "bt_score_bed_Y%d.regenie.gz" % k), "rt").read().splitlines()
+        assert got[0] == ref[0] and len(got) == len(ref) > 900
+        same = 0
+        for a, b in zip(got[1:], ref[1:]):
+            ta, tb = a.split(" "), b.split(" ")
+            assert ta[:8] == tb[:8] and ta[12] == tb[12] == "NA", (a, b)
+            for x, y in zip(ta[8:12], tb[8:12]):
+                assert float(x) == pytest.approx(float(y), rel=2e-5, abs=2e-9), (a, b)
+            same += a == b
+        assert same >= 0.9 * (len(ref) - 1), same
+
+
 def test_cli_step2_refuses_what_is_not_built(example_dir, tmp_path):
     E = example_dir
-    r = _run(["--step", "2", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"), "--bt", "--bsize", "200",
-              "--pred", "x", "--out", "s2"], str(tmp_path))
-    assert r.returncode != 0 and "quantitative traits only" in r.stdout
+    base = ["--step", "2", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"), "--bsize", "200", "--pred", "x", "--out", "s2"]
+    r = _run(base + ["--bt", "--firth"], str(tmp_path))
+    assert r.returncode != 0 and "Firth / SPA corrections" in r.stdout
+    r = _run(base + ["--ct"], str(tmp_path))
+    assert r.returncode != 0 and "count trait test is not built" in r.stdout

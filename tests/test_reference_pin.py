@@ -280,6 +280,50 @@ def test_step2_qt_oracle_sparse_branch_against_reference(tmp_path):
     assert moved > 1e-3                                        # and the sparse branch is not the dense number
 
 
+def test_step2_bt_oracle_against_reference():
+    """The binary-trait score test (no Firth / SPA): null logistic model with the LOCO offset per chromosome, compute_score_bt,
+    get_sumstats -- oracle/regenie_step2_bt.py against regenie's own output for the documented Step-2 command without --firth
+    (docs/docs/options.md: --step 2 --bed example --remove fid_iid_to_remove.txt --bt), 1,000 variants x 2 traits."""
+    from oracle import regenie_step2_bt as bt
+    from oracle import regenie_step2_qt as s2
+    opt = orc.Step1Options(bed=E("example"), pheno_file=E("phenotype_bin.txt"), covar_file=E("covariates.txt"), bsize=200, bt=True,
+                           remove=(E("fid_iid_to_remove.txt"),), test_mode=True)
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    bed, _ = orc.open_bed(opt.bed + ".bed", prep.n_file)
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    P = prep.Y.shape[1]
+    loco = []
+    for ph in range(P):
+        hdr, v = read_loco_gz(os.path.join(REF_OUT, "bt_loocv_refcmd", "out_%d.loco.gz" % (ph + 1)))
+        pos = {s: k for k, s in enumerate(hdr)}
+        loco.append(v[:, [pos[i] for i in ids]])
+    refs = [_read_regenie(os.path.join(REF_OUT, "step2", "bt_score_bed_Y%d.regenie.gz" % (ph + 1))) for ph in range(P)]
+    col = {nm: i for i, nm in enumerate(refs[0][0])}
+    X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
+    rows = {ph: {r[col["ID"]]: r for r in refs[ph][1]} for ph in range(P)}
+    seen = 0
+    for c in sorted(set(chrom.tolist())):
+        nulls = [bt.null_logistic(Yraw[:, ph], X, mask[:, ph], loco[ph][c - 1], opt) for ph in range(P)]
+        assert all(nl is not None for nl in nulls)
+        sel = np.flatnonzero(chrom == c)
+        G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
+        for k in range(sel.size):
+            g, mean, nobs = s2.mean_impute(G[k])
+            for ph in range(P):
+                r = rows[ph].get(snp_ids[sel[k]])
+                if r is None:                      # dropped by the MAC filter
+                    continue
+                out = bt.score_bt(g, X, Yraw[:, ph], mask[:, ph].astype(np.float64), nulls[ph])
+                beta, se, chisq, logp = (float(r[col[nm]]) for nm in ("BETA", "SE", "CHISQ", "LOG10P"))
+                assert out["bhat"] == pytest.approx(beta, rel=5e-5, abs=2e-6)
+                assert out["se"] == pytest.approx(se, rel=5e-5)
+                assert out["chisq"] == pytest.approx(chisq, rel=1e-4, abs=2e-6)
+                assert s2.get_logp(out["chisq"]) == pytest.approx(logp, rel=1e-4, abs=2e-6)
+                seen += 1
+    assert seen == sum(len(refs[ph][1]) for ph in range(P)) and seen > 1500
+
+
 needs_ref_binary = pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")
 
 

@@ -299,3 +299,31 @@ def test_packed_at_scale_matches_dense_route():
     ref = s2o.score_qt_block_ref(G[:4], X, res, mask, scf)
     assert np.allclose(got["stats"][:4], ref["stats"], rtol=RTOL, atol=1e-10)
     print("packed kernel %.3f ms, dense kernel %.3f ms for %d variants x %d samples" % (got["kernel_ms"], dense["kernel_ms"], bs, n))
+
+
+def test_contraction_primitive_matches_numpy():
+    """rg_s2_set_columns / rg_s2_contract_packed: hard-call rows against arbitrary fp64 columns (three column groups, wide dynamic
+    range inside a column, an all-zero column), the g^2 contraction of the first columns, the call counts; with and without flip."""
+    from regenie_amd.step2 import Step2QT
+    rng = np.random.default_rng(8)
+    n, ncol, nsq, bs = 20_003, 37, 5, 130
+    cols = rng.normal(size=(ncol, n)) * np.exp(rng.uniform(-12, 12, size=(ncol, 1)))
+    cols[3] *= np.exp(rng.uniform(-20, 0, size=n))           # entries far below the column's largest: truncated at 2^-54 of it
+    cols[7] = 0.0
+    cols[0] = rng.random(n)                                    # a weight column, as the binary-trait test uses
+    G = rng.binomial(2, rng.uniform(0.02, 0.5, size=bs)[:, None], size=(bs, n)).astype(np.float64)
+    G[rng.random(G.shape) < 0.01] = np.nan
+    G[5] = np.where(np.isnan(G[5]), 0.0, G[5])                 # a row without missing calls
+    rows = _pack_bed(G)
+    with Step2QT(n, 2, 1) as s2:
+        s2.set_columns(cols, n_sq=nsq)
+        for flip in (False, True):
+            g = 2.0 - G if flip else G
+            g0, miss = np.where(np.isnan(g), 0.0, g), np.isnan(g).astype(np.float64)
+            got = s2.contract_packed(rows, flip=flip)
+            assert np.array_equal(got["counts"][:, 0], (g0 == 1).sum(axis=1)) and np.array_equal(got["counts"][:, 1], (g0 == 2).sum(axis=1))
+            assert np.array_equal(got["counts"][:, 2], miss.sum(axis=1).astype(np.int32))
+            for name, want, have in (("g0", g0 @ cols.T, got["sums"][:, 0]), ("miss", miss @ cols.T, got["sums"][:, 1]),
+                                     ("sq", (g0 * g0) @ cols[:nsq].T, got["sq"])):
+                bound = (np.abs(g0) + miss) @ np.abs(cols[: want.shape[1]]).T + 1e-300     # sum of the terms' magnitudes
+                assert (np.abs(have - want) <= 4e-15 * bound + 2.0 ** -52 * n * np.abs(cols[: want.shape[1]]).max(axis=1)[None, :]).all(), name
