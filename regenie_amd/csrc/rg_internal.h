@@ -273,8 +273,8 @@ void rg_launch_xy_i8(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t p
                      double* part);
 #define RG_XY_LUT_DOSAGE 0x00010002u   // byte k = value of .bed code k: 00 -> 2, 01 (missing) -> 0, 10 -> 1, 11 -> 0
 #define RG_XY_LUT_SQUARE 0x00010004u   // the square of the allele count
-void rg_launch_xy_i8_sums(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs, const int32_t* nmiss,
-                          int nblk, int n128, const SegLayout& seg, const int8_t* vd, int64_t Np, int Cv, unsigned lut0, int32_t* S32);
+void rg_launch_xy_i8_sums(hipStream_t st, const uint8_t* pk, int64_t pk_ld, const int32_t* d_bs, const int32_t* nmiss, int ncols, int n128,
+                          const SegLayout& seg, const int8_t* vd, int64_t Np, unsigned lut0, int32_t* S32);
 void rg_launch_l0_pred_i8(hipStream_t st, const PredArgs& a, const ChunkTab& c256, int pg, int ngrp, int8_t* planes, double* psc,
                           uint8_t* pkT);
 void rg_launch_w_gather(hipStream_t st, const double* W, int64_t Np, int P, int p, int col0, int R0,

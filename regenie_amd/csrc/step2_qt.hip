@@ -598,6 +598,16 @@ int ensure_in(rg_s2_ctx* ctx, void** buf, size_t* cap, int slot, size_t bytes) {
   cap[slot] = bytes;
   return RG_S2_OK;
 }
+// The sample axis (Np, a multiple of 64 * 32) is cut into nseg equal segments, one workgroup per (row tile, segment, column group, set):
+// enough workgroups to fill the 256 CUs (>= 768), as few segments as that allows -- every segment costs a 64 KB tile of partial sums.
+int pick_segments(int64_t Np, int tiles, int ngrp, SegLayout& seg) {
+  int nseg = 1;
+  while (nseg < RG_MAX_SEG && (int64_t)tiles * nseg * ngrp < 768 && Np / (nseg * 2) >= 1024) nseg *= 2;
+  memset(&seg, 0, sizeof(seg));
+  seg.nseg = nseg;
+  for (int f = 0; f < nseg; ++f) { seg.pos_start[f] = f * (Np / nseg); seg.file_start[f] = seg.pos_start[f]; seg.len[f] = Np / nseg; seg.plen[f] = Np / nseg; }
+  return nseg;
+}
 int ensure(rg_s2_ctx* ctx, int slot, size_t bytes) { return ensure_in(ctx, ctx->buf, ctx->cap, slot, bytes); }
 int ensure_p(rg_s2_ctx* ctx, int slot, size_t bytes) { return ensure_in(ctx, ctx->pbuf, ctx->pcap, slot, bytes); }
 }  // namespace
@@ -856,17 +866,13 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   const int gm0 = cm0 / 16, ngrpB = masked ? ngrp - gm0 : 0, CvB = ngrpB * 16;      // column groups of the g0^2 contraction (the mask columns)
   // enough workgroups to fill the 256 CUs (tiles x segments x column groups >= 768), as few segments as that allows: every segment
   // costs a 64 KB tile of partial sums per workgroup
-  int nseg = 1;
-  while (nseg < RG_MAX_SEG && (int64_t)(n128 / 128) * nseg * ngrp < 768 && Np / (nseg * 2) >= 1024) nseg *= 2;
-  SegLayout& seg = ctx->seg;
-  memset(&seg, 0, sizeof(seg));
-  seg.nseg = nseg;
-  for (int f = 0; f < nseg; ++f) { seg.pos_start[f] = f * (Np / nseg); seg.file_start[f] = seg.pos_start[f]; seg.len[f] = Np / nseg; seg.plen[f] = Np / nseg; }
+  SegLayout seg, segB;
+  const int nseg = pick_segments(Np, n128 / 128, ngrp, seg), nsegB = pick_segments(Np, n128 / 128, std::max(1, ngrpB), segB);
   enum { Q_PK, Q_CNT, Q_S, Q_A, Q_VAR, Q_STAT };
-  const size_t s_grp = (size_t)2 * nseg * n128 * 128;
+  const size_t s_grp = (size_t)2 * nseg * n128 * 128, s_grpB = (size_t)2 * nsegB * n128 * 128;
   if ((rc = ensure_p(ctx, Q_PK, (size_t)bs * ldp))) return rc;
   if ((rc = ensure_p(ctx, Q_CNT, ((size_t)bs * 4 + 8) * sizeof(int32_t)))) return rc;            // counts | total_miss | bs | 0
-  if ((rc = ensure_p(ctx, Q_S, (size_t)(ngrp + ngrpB) * s_grp * sizeof(int32_t)))) return rc;
+  if ((rc = ensure_p(ctx, Q_S, ((size_t)ngrp * s_grp + (size_t)ngrpB * s_grpB) * sizeof(int32_t)))) return rc;
   if ((rc = ensure_p(ctx, Q_A, (size_t)bs * 2 * (Cvt + CvB) * sizeof(double)))) return rc;
   if ((rc = ensure_p(ctx, Q_VAR, (size_t)bs * (2 * sizeof(double) + 2 * sizeof(int32_t))))) return rc;   // scale_fac | mean | nobs | ignored
   if ((rc = ensure_p(ctx, Q_STAT, (size_t)bs * P * (3 * sizeof(double) + sizeof(int32_t))))) return rc;  // stats | bhat | total_p | nobs_p
@@ -891,17 +897,12 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   S2_HIP(hipMemcpy2DAsync(pk, ldp, rows, ld, nbytes, bs, rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipEventRecord(ctx->e0, ctx->st));
   hipLaunchKernelGGL(k_s2_rows, dim3(bs), dim3(256), 0, ctx->st, pk, ldp, n, flip ? 1 : 0, cnt, total_miss);
-  for (int g = 0; g < ngrp; ++g)
-    rg_launch_xy_i8_sums(ctx->st, pk, ldp, 0, d_bs, total_miss, 1, n128, seg, ctx->dvd + (size_t)g * 16 * 8 * Np, Np, std::min(16, Cvt - g * 16),
-                         RG_XY_LUT_DOSAGE, S + (size_t)g * s_grp);
+  rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, total_miss, Cvt, n128, seg, ctx->dvd, Np, RG_XY_LUT_DOSAGE, S);
   hipLaunchKernelGGL(k_s2_combine, dim3((bs * Cvt + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->dvsc, total_miss, bs, n128, nseg, Cvt, A);
   if (masked) {   // sum mask_p g0^2: the square LUT against the mask columns only (the missing-indicator set is skipped: d_zero)
-    int32_t* SB = S + (size_t)ngrp * s_grp;
-    for (int g = 0; g < ngrpB; ++g)
-      rg_launch_xy_i8_sums(ctx->st, pk, ldp, 0, d_bs, d_zero, 1, n128, seg, ctx->dvd + (size_t)(gm0 + g) * 16 * 8 * Np, Np,
-                           std::min(16, Cvt - (gm0 + g) * 16), RG_XY_LUT_SQUARE, SB + (size_t)g * s_grp);
-    hipLaunchKernelGGL(k_s2_combine, dim3((bs * CvB + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)SB, ctx->dvsc + gm0 * 16, (const int32_t*)nullptr, bs,
-                       n128, nseg, CvB, Sq);
+    rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, d_zero, Cvt - gm0 * 16, n128, segB, ctx->dvd + (size_t)gm0 * 16 * 8 * Np, Np, RG_XY_LUT_SQUARE, S + (size_t)ngrp * s_grp);
+    hipLaunchKernelGGL(k_s2_combine, dim3((bs * CvB + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)(S + (size_t)ngrp * s_grp), ctx->dvsc + gm0 * 16,
+                       (const int32_t*)nullptr, bs, n128, nsegB, CvB, Sq);
   }
   PackedFinal fa;
   fa.A = A; fa.Sq = masked ? Sq : nullptr; fa.cnt = cnt; fa.ytx = ctx->dYtX; fa.Q = ctx->dQ; fa.msum = ctx->dMsum; fa.scf_sv = ctx->dscf;
@@ -962,18 +963,14 @@ int rg_s2_contract_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   const int ncol = ctx->g_ncol, nsq = ctx->g_nsq, ngrp = (ncol + 15) / 16, ngrpB = (nsq + 15) / 16, CvB = ngrpB * 16;
   const int64_t Np = (n + 64 * RG_MAX_SEG - 1) / (64 * RG_MAX_SEG) * (64 * RG_MAX_SEG), ldp = Np / 4;
   const int n128 = (int)((bs + 127) / 128 * 128);
-  int nseg = 1;
-  while (nseg < RG_MAX_SEG && (int64_t)(n128 / 128) * nseg * ngrp < 768 && Np / (nseg * 2) >= 1024) nseg *= 2;
-  SegLayout& seg = ctx->seg;
-  memset(&seg, 0, sizeof(seg));
-  seg.nseg = nseg;
-  for (int f = 0; f < nseg; ++f) { seg.pos_start[f] = f * (Np / nseg); seg.file_start[f] = seg.pos_start[f]; seg.len[f] = Np / nseg; seg.plen[f] = Np / nseg; }
+  SegLayout seg, segB;
+  const int nseg = pick_segments(Np, n128 / 128, ngrp, seg), nsegB = pick_segments(Np, n128 / 128, std::max(1, ngrpB), segB);
   enum { Q_PK, Q_CNT, Q_S, Q_A };
-  const size_t s_grp = (size_t)2 * nseg * n128 * 128;
+  const size_t s_grp = (size_t)2 * nseg * n128 * 128, s_grpB = (size_t)2 * nsegB * n128 * 128;
   int rc;
   if ((rc = ensure_p(ctx, Q_PK, (size_t)bs * ldp))) return rc;
   if ((rc = ensure_p(ctx, Q_CNT, ((size_t)bs * 4 + 8) * sizeof(int32_t)))) return rc;
-  if ((rc = ensure_p(ctx, Q_S, (size_t)(ngrp + ngrpB) * s_grp * sizeof(int32_t)))) return rc;
+  if ((rc = ensure_p(ctx, Q_S, ((size_t)ngrp * s_grp + (size_t)ngrpB * s_grpB) * sizeof(int32_t)))) return rc;
   if ((rc = ensure_p(ctx, Q_A, (size_t)bs * 2 * (ncol + CvB) * sizeof(double)))) return rc;
   uint8_t* pk = (uint8_t*)ctx->pbuf[Q_PK];
   int32_t* cnt = (int32_t*)ctx->pbuf[Q_CNT];
@@ -988,17 +985,12 @@ int rg_s2_contract_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   S2_HIP(hipMemcpy2DAsync(pk, ldp, rows, ld, nbytes, bs, rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipEventRecord(ctx->e0, ctx->st));
   hipLaunchKernelGGL(k_s2_rows, dim3(bs), dim3(256), 0, ctx->st, pk, ldp, n, flip ? 1 : 0, cnt, total_miss);
-  for (int g = 0; g < ngrp; ++g)
-    rg_launch_xy_i8_sums(ctx->st, pk, ldp, 0, d_bs, total_miss, 1, n128, seg, ctx->gvd + (size_t)g * 16 * 8 * Np, Np, std::min(16, ncol - g * 16),
-                         RG_XY_LUT_DOSAGE, S + (size_t)g * s_grp);
+  rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, total_miss, ncol, n128, seg, ctx->gvd, Np, RG_XY_LUT_DOSAGE, S);
   hipLaunchKernelGGL(k_s2_combine, dim3((bs * ncol + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->gvsc, total_miss, bs, n128, nseg, ncol, A);
   if (nsq > 0) {
-    int32_t* SB = S + (size_t)ngrp * s_grp;
-    for (int g = 0; g < ngrpB; ++g)
-      rg_launch_xy_i8_sums(ctx->st, pk, ldp, 0, d_bs, d_zero, 1, n128, seg, ctx->gvd + (size_t)g * 16 * 8 * Np, Np, std::min(16, ncol - g * 16),
-                           RG_XY_LUT_SQUARE, SB + (size_t)g * s_grp);
-    hipLaunchKernelGGL(k_s2_combine, dim3((bs * CvB + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)SB, ctx->gvsc, (const int32_t*)nullptr, bs, n128, nseg,
-                       CvB, Sq);
+    rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, d_zero, nsq, n128, segB, ctx->gvd, Np, RG_XY_LUT_SQUARE, S + (size_t)ngrp * s_grp);
+    hipLaunchKernelGGL(k_s2_combine, dim3((bs * CvB + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)(S + (size_t)ngrp * s_grp), ctx->gvsc,
+                       (const int32_t*)nullptr, bs, n128, nsegB, CvB, Sq);
   }
   S2_HIP(hipEventRecord(ctx->e1, ctx->st));
   S2_HIP(hipGetLastError());

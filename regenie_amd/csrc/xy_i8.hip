@@ -61,12 +61,16 @@ __device__ __forceinline__ unsigned x_expand4(unsigned b, unsigned lut) {
 // ---- S[blk][set][fold][row][col] = sum over the fold's positions; grid (n128 / 128, nseg, nblk * 2), set = z & 1 ----------------
 __global__ __launch_bounds__(256) void k_xy_i8(const uint8_t* __restrict__ pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* __restrict__ d_bs,
                                                const int32_t* __restrict__ nmiss, int n128, SegLayout seg, const int8_t* __restrict__ vd,
-                                               int64_t Np, int ncol /* Cv * 8 <= 128 */, unsigned lut0 /* set 0: RG_XY_LUT_* */, int32_t* __restrict__ S) {
+                                               int64_t vd_blk_stride, int meta_bcast /* 1: every blk reads d_bs[0] / nmiss[0] */, int64_t Np,
+                                               int ncol_all /* Cv * 8 <= 128 */, int ncol_last /* >= 0: of the last blk */,
+                                               unsigned lut0 /* set 0: RG_XY_LUT_* */, int32_t* __restrict__ S) {
   __shared__ __attribute__((aligned(16))) uint8_t sA[XT * X_PITCH];
   __shared__ __attribute__((aligned(16))) uint8_t sB[XT * X_PITCH];
   const int blk = blockIdx.z >> 1, set = blockIdx.z & 1, f = blockIdx.y, tr = blockIdx.x;
-  if (set == 1 && nmiss[blk] == 0) return;
-  const int bs = d_bs[blk];
+  const int mb = meta_bcast ? 0 : blk;
+  const int ncol = (ncol_last >= 0 && blk == (int)(gridDim.z >> 1) - 1) ? ncol_last : ncol_all;
+  if (set == 1 && nmiss[mb] == 0) return;
+  const int bs = d_bs[mb];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const unsigned lut = set ? X_LUT_MISS : lut0;
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void k_xy_i8(const uint8_t* __restrict__ pk, i
   const bool validA = arow < bs;
   const uint8_t* ga = pk + (int64_t)blk * pk_blk_stride + (int64_t)(validA ? arow : 0) * pk_ld + pos0 / 4;
   const bool validB = srow < ncol;
-  const int8_t* gb = vd + (int64_t)(validB ? srow : 0) * Np + pos0;      // (column, digit) row srow = c * 8 + k of vd [Cv][8][Np]
+  const int8_t* gb = vd + (int64_t)blk * vd_blk_stride + (int64_t)(validB ? srow : 0) * Np + pos0;   // (column, digit) row srow = c * 8 + k of vd [Cv][8][Np]
   uint8_t* lrow = (isA ? sA : sB) + srow * X_PITCH;
   // the global loads of step kb + 16 are issued before the MFMAs of step kb (registers), so their latency hides behind the math
   uint4 w = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11 -> 0 under both LUTs
@@ -125,9 +129,11 @@ __global__ __launch_bounds__(256) void k_xy_i8(const uint8_t* __restrict__ pk, i
 #pragma unroll
       for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sB + (wc * 64 + j * 32 + (lane & 31)) * X_PITCH + koff);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j) {
+        if (wc * 64 + j * 32 >= ncol) continue;      // a 32-column block past the last (column, digit) pair: nothing but zeros (wave-uniform)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -166,20 +172,23 @@ void rg_launch_v_split(hipStream_t st, const double* V, int64_t Np, int Cv, int8
   hipLaunchKernelGGL(k_v_split, dim3(Cv), dim3(256), 0, st, V, Np, vd, vsc);
 }
 
-// the digit sums alone (step2_qt.hip sums them over the segments itself): S32 [nblk][2][nseg][n128][128]; lut0 = what set 0 contracts
-// (the allele count, or its square); set 1 is the missing indicator, skipped for blocks with nmiss == 0
-void rg_launch_xy_i8_sums(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs, const int32_t* nmiss,
-                          int nblk, int n128, const SegLayout& seg, const int8_t* vd, int64_t Np, int Cv, unsigned lut0, int32_t* S32) {
-  hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, nblk * 2), dim3(256), 0, st, pk, pk_ld, pk_blk_stride, d_bs, nmiss, n128, seg, vd, Np,
-                     Cv * X_NPIECE, lut0, S32);
+// the digit sums alone (step2_qt.hip sums them over the segments itself), ONE block of rows against ncols columns = ngrp groups of 16
+// in one launch (the group takes the kernel's block index: its planes start at vd + grp * 16 * 8 * Np; the last group's missing columns
+// are neither loaded nor multiplied): S32 [ngrp][2][nseg][n128][128]; lut0 = what set 0 contracts (the allele count, or its square); set 1 is the missing
+// indicator, skipped when *nmiss == 0
+void rg_launch_xy_i8_sums(hipStream_t st, const uint8_t* pk, int64_t pk_ld, const int32_t* d_bs, const int32_t* nmiss, int ncols, int n128,
+                          const SegLayout& seg, const int8_t* vd, int64_t Np, unsigned lut0, int32_t* S32) {
+  const int ngrp = (ncols + 15) / 16;
+  hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, ngrp * 2), dim3(256), 0, st, pk, pk_ld, (int64_t)0, d_bs, nmiss, n128, seg, vd,
+                     (int64_t)16 * X_NPIECE * Np, 1, Np, 16 * X_NPIECE, (ncols - (ngrp - 1) * 16) * X_NPIECE, lut0, S32);
 }
 
 // S32: nblk * 2 * nseg * n128 * 128 int32; part: [nblk][nseg][n128][2][Cv] (rowstats reads it with nchunk = nseg, chunk_seg = identity)
 void rg_launch_xy_i8(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs, const int32_t* nmiss,
                      int nblk, int n128, const SegLayout& seg, const int8_t* vd, const double* vsc, int64_t Np, int Cv, int32_t* S32,
                      double* part) {
-  hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, nblk * 2), dim3(256), 0, st, pk, pk_ld, pk_blk_stride, d_bs, nmiss, n128, seg, vd, Np,
-                     Cv * X_NPIECE, RG_XY_LUT_DOSAGE, S32);
+  hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, nblk * 2), dim3(256), 0, st, pk, pk_ld, pk_blk_stride, d_bs, nmiss, n128, seg, vd,
+                     (int64_t)0, 0, Np, Cv * X_NPIECE, -1, RG_XY_LUT_DOSAGE, S32);
   hipLaunchKernelGGL(k_xy_combine, dim3((n128 * Cv + 255) / 256, seg.nseg, nblk), dim3(256), 0, st, (const int32_t*)S32, vsc, nmiss, n128, seg.nseg,
                      Cv, part);
 }

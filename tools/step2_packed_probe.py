@@ -34,12 +34,31 @@ def main(n=200_000, C=10, P=10):
                 t = float(np.median(ms[1:]))
                 print("packed  bs %6d  %-18s %8.3f ms  %7.2f M variants/s  %6.1f GB/s of 2-bit rows  %.2e genotype*pheno/s"
                       % (bs, name, t, bs / t / 1e3, bs * n / 4 / t / 1e6, bs * n * P / t * 1e3), flush=True)
-            if bs <= 4096:
+            if bs <= 4096 and "--no-fp64" not in sys.argv:
                 G = torch.randint(0, 3, (bs, n), device=dev, generator=g).double()
                 ms = [s2.score_block(G)["kernel_ms"] for _ in range(4)]
                 t = float(np.median(ms[1:]))
                 print("fp64    bs %6d  %-18s %8.3f ms  %7.2f M variants/s  %6.1f GB/s of fp64 rows" % (bs, "", t, bs / t / 1e3, 2 * bs * n * 8 / t / 1e6), flush=True)
                 del G
+    # phenotypes that differ in their missing values (5 %): C * P + P more columns (136 instead of 20), the g^2 contraction, both branches
+    mask2 = (rng.random((n, P)) > 0.05).astype(np.uint8)
+    with Step2QT(n, C, P) as s2:
+        s2.set_null(X.T, (res * mask2).T, mask2.T, scf)
+        for bs in (1024, 4096):
+            rows = torch.randint(0, 256, (bs, (n + 3) // 4), dtype=torch.uint8, device=dev, generator=g)
+            rr = (rows | ((rows & 0x55) & ~((rows >> 1) & 0x55)) << 1).to(torch.uint8)
+            ms = [s2.score_block_packed(rr)["kernel_ms"] for _ in range(4)]
+            t = float(np.median(ms[1:]))
+            print("packed, masked phenotypes  bs %6d  %8.3f ms  %7.2f M variants/s  (136 columns)" % (bs, t, bs / t / 1e3), flush=True)
+        # the contraction primitive with the binary-trait test's columns: P * (C + 3) = 130, the first P also against g^2
+        cols = rng.normal(size=(P * (C + 3), n))
+        s2.set_columns(cols, n_sq=P)
+        for bs in (1024, 4096):
+            rows = torch.randint(0, 256, (bs, (n + 3) // 4), dtype=torch.uint8, device=dev, generator=g)
+            rr = (rows | ((rows & 0x55) & ~((rows >> 1) & 0x55)) << 1).to(torch.uint8).cpu().numpy()
+            ms = [s2.contract_packed(rr)["kernel_ms"] for _ in range(4)]
+            t = float(np.median(ms[1:]))
+            print("contraction primitive (bt)  bs %6d  %8.3f ms  %7.2f M variants/s  (130 columns)" % (bs, t, bs / t / 1e3), flush=True)
 
 
 if __name__ == "__main__":
