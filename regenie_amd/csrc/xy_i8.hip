@@ -59,7 +59,7 @@ __device__ __forceinline__ unsigned x_expand4(unsigned b, unsigned lut) {
 }
 
 // ---- S[blk][set][fold][row][col] = sum over the fold's positions; grid (n128 / 128, nseg, nblk * 2), set = z & 1 ----------------
-__global__ __launch_bounds__(256) void k_xy_i8(const uint8_t* __restrict__ pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* __restrict__ d_bs,
+__global__ __launch_bounds__(256, 4) void k_xy_i8(const uint8_t* __restrict__ pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* __restrict__ d_bs,
                                                const int32_t* __restrict__ nmiss, int n128, SegLayout seg, const int8_t* __restrict__ vd,
                                                int64_t vd_blk_stride, int meta_bcast /* 1: every blk reads d_bs[0] / nmiss[0] */, int64_t Np,
                                                int ncol_all /* Cv * 8 <= 128 */, int ncol_last /* >= 0: of the last blk */,
@@ -82,43 +82,42 @@ __global__ __launch_bounds__(256) void k_xy_i8(const uint8_t* __restrict__ pk, i
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-  const bool isA = tid < 128;
-  const int srow = isA ? tid : tid - 128;
+  // staging: every thread expands 32 positions of one packed row (8 bytes -> 32 int8) AND copies 32 bytes of one digit row, so the
+  // byte-LUT work is spread over all four waves (it was the first two waves' alone: two of the four SIMDs carried all of it)
+  const int srow = tid >> 1, half = tid & 1;
   const int arow = tr * XT + srow;
   const bool validA = arow < bs;
-  const uint8_t* ga = pk + (int64_t)blk * pk_blk_stride + (int64_t)(validA ? arow : 0) * pk_ld + pos0 / 4;
+  const uint8_t* ga = pk + (int64_t)blk * pk_blk_stride + (int64_t)(validA ? arow : 0) * pk_ld + pos0 / 4 + half * 8;
   const bool validB = srow < ncol;
-  const int8_t* gb = vd + (int64_t)blk * vd_blk_stride + (int64_t)(validB ? srow : 0) * Np + pos0;   // (column, digit) row srow = c * 8 + k of vd [Cv][8][Np]
-  uint8_t* lrow = (isA ? sA : sB) + srow * X_PITCH;
+  const int8_t* gb = vd + (int64_t)blk * vd_blk_stride + (int64_t)(validB ? srow : 0) * Np + pos0 + half * 32;   // (column, digit) row srow = c * 8 + k of vd [Cv][8][Np]
+  uint8_t* lrowA = sA + srow * X_PITCH + half * 32;
+  uint8_t* lrowB = sB + srow * X_PITCH + half * 32;
   // the global loads of step kb + 16 are issued before the MFMAs of step kb (registers), so their latency hides behind the math
-  uint4 w = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11 -> 0 under both LUTs
-  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
+  uint2 w = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11 -> 0 under both LUTs
+  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
   if (kbytes > 0) {
-    if (isA) { if (validA) w = *reinterpret_cast<const uint4*>(ga); }
-    else if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
+    if (validA) w = *reinterpret_cast<const uint2*>(ga);
+    if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb); v0 = src[0]; v1 = src[1]; }
   }
   for (int64_t kb = 0; kb < kbytes; kb += 16) {      // 64 positions per step
-    if (isA) {
-      const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+    {
+      const unsigned ws[2] = {w.x, w.y};
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
+      for (int d = 0; d < 2; ++d) {
         uint4 o;
         o.x = x_expand4(ws[d] & 0xFFu, lut);
         o.y = x_expand4((ws[d] >> 8) & 0xFFu, lut);
         o.z = x_expand4((ws[d] >> 16) & 0xFFu, lut);
         o.w = x_expand4(ws[d] >> 24, lut);
-        *reinterpret_cast<uint4*>(lrow + d * 16) = o;
+        *reinterpret_cast<uint4*>(lrowA + d * 16) = o;
       }
-    } else {
-      *reinterpret_cast<uint4*>(lrow) = v0;
-      *reinterpret_cast<uint4*>(lrow + 16) = v1;
-      *reinterpret_cast<uint4*>(lrow + 32) = v2;
-      *reinterpret_cast<uint4*>(lrow + 48) = v3;
+      *reinterpret_cast<uint4*>(lrowB) = v0;
+      *reinterpret_cast<uint4*>(lrowB + 16) = v1;
     }
     __syncthreads();
     if (kb + 16 < kbytes) {
-      if (isA) { if (validA) w = *reinterpret_cast<const uint4*>(ga + kb + 16); }
-      else if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb + (kb + 16) * 4); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
+      if (validA) w = *reinterpret_cast<const uint2*>(ga + kb + 16);
+      if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb + (kb + 16) * 4); v0 = src[0]; v1 = src[1]; }
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
