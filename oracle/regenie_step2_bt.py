@@ -1,10 +1,12 @@
-"""CPU restatement of regenie's Step-2 binary-trait score test without the Firth / SPA corrections (`--step 2 --bt`).
+"""CPU restatement of regenie's Step-2 binary-trait score test without the Firth / SPA corrections (`--step 2 --bt`) and of the
+count-trait score test (`--step 2 --ct`).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/ (and nothing in the product path).  numpy, fp64, samples down the rows.
 
 PINNED against regenie itself: tests/test_reference_pin.py::test_step2_bt_oracle_against_reference compares BETA / SE / CHISQ /
 LOG10P / A1FREQ / N with the output of oracle/_ref/regenie for `--step 2 --bt --bed example --remove ...` fed by the reference's own
-Step-1 LOCO files (tests/golden/ref_outputs/step2/bt_score_bed_Y*.regenie.gz).
+Step-1 LOCO files (tests/golden/ref_outputs/step2/bt_score_bed_Y*.regenie.gz); ::test_step2_ct_oracle_against_reference does the same for
+count traits on synthetic data (ct_synth: regenie's own --step 1 --ct and --step 2 --ct outputs).
 """
 from __future__ import annotations
 
@@ -44,6 +46,37 @@ def score_bt(g, X, y_raw, mask, null, numtol=NUMTOL):
     if np.sqrt(denum) < numtol:
         return None
     yres = (y_raw - null["p"]) / null["gamma_sqrt"] * mask
+    stats = float(Gres @ yres) / np.sqrt(denum)
+    se = 1.0 / np.sqrt(denum)
+    return dict(stats=stats, se=se, bhat=stats * se, chisq=stats * stats)
+
+
+def null_poisson(y_raw, X, mask, loco_offset, opt):
+    """fit_null_poisson, test-mode branch (Step1_Models.cpp:225-288), for one count phenotype: Poisson regression on the covariate basis
+    with the LOCO prediction as offset.  None when it does not converge, else dict(p = fitted rates, gamma_sqrt = sqrt(p), w = p)."""
+    off = loco_offset * mask                                            # :240
+    p = y_raw + 1e-1                                                    # :244
+    with np.errstate(invalid="ignore"):
+        eta = np.where(mask, np.log(p), 0.0)                            # :245
+    beta0 = np.zeros(X.shape[1])
+    beta0[0] = eta.mean() - off.mean()                                  # :247
+    ok, beta, p, eta = orc.fit_poisson(y_raw, X, off, mask, p, eta, beta0, opt)
+    if not ok:
+        return None
+    return dict(p=p, w=p, gamma_sqrt=np.sqrt(p), beta=beta)             # :266-268
+
+
+def score_ct(g, X, y_raw, mask, null, numtol=NUMTOL):
+    """compute_score_ct (Step2_Models.cpp:559-622): as compute_score_bt with the Poisson weights; the variant is skipped for the trait
+    when denum itself (not its root) is below numtol (:596)."""
+    gs_mask = null["gamma_sqrt"] * mask
+    XG, _ = orc.get_basis(X * gs_mask[:, None])
+    GW = g * gs_mask
+    Gres = GW - XG @ (XG.T @ GW)
+    denum = float(Gres @ Gres)
+    if denum < numtol:
+        return None
+    yres = (y_raw - null["p"]) / null["gamma_sqrt"] * mask             # compute_res_count, Data.cpp:2457-2465
     stats = float(Gres @ yres) / np.sqrt(denum)
     se = 1.0 / np.sqrt(denum)
     return dict(stats=stats, se=se, bhat=stats * se, chisq=stats * stats)

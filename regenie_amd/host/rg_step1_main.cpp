@@ -364,7 +364,6 @@ Params parse_args(int argc, char** argv) {
   if (p.bt) p.rint = false;  // Regenie.cpp:432
   if (p.step != 1 && p.step != 2) usage_error("specify which mode regenie should be running using option --step.");
   if (p.step == 2) {
-    if (p.ct) usage_error("--step 2 serves quantitative and binary traits (--qt / --bt): the count trait test is not built.");
     if (p.pred_list.empty()) usage_error("option '--pred' is required (use the _pred.list file written by step 1).");
     if (p.min_mac < 0.5) usage_error("minimum MAC must be at least 0.5.");   // Regenie.cpp:1054
     if (p.gpus > 1 || p.force_collectives) usage_error("--step 2 runs on one GPU.");
@@ -400,6 +399,7 @@ struct Run {
   int64_t n_file = 0, bpr = 0;
   rg_pgen* pgen = nullptr;               // --pgen: open reader (bed rows come from rg_pgen_read_bed_rows)
   bool dosage_mode = false;              // --pgen with dosage tracks / --bgen: rows of doubles, level 0 from rg_l0_blocks_f64
+  bool has_male = false;                 // a sample with sex code 1 in the .fam / .psam (Step 2 on chromosome X needs it)
   rg_bgen* bgenh = nullptr;              // --bgen: open reader
   Run() = default;
   Run(const Run&) = delete;
@@ -542,8 +542,10 @@ double norm_quantile(double p) {
   return q < 0 ? -v : v;
 }
 
-// fit_null_poisson + fit_poisson (Step1_Models.cpp:225-345) for one phenotype, zero offset; eta_out = X beta on success
-bool fit_poisson(const double* y, const double* X, const uint8_t* mask, int64_t N, int C, const Params& prm, std::vector<double>& eta) {
+// fit_null_poisson + fit_poisson (Step1_Models.cpp:225-345) for one phenotype; offset may be null (zero); eta_out = offset + X beta on
+// success, pv_out (optional) the fitted rates
+bool fit_poisson(const double* y, const double* X, const uint8_t* mask, int64_t N, int C, const Params& prm, std::vector<double>& eta,
+                 const double* offset = nullptr, std::vector<double>* pv_out = nullptr) {
   std::vector<double> beta(C, 0.0), betanew(C, 0.0), pv(N);
   auto dev = [&](const std::vector<double>& pp) {
     double t = 0.0;
@@ -559,6 +561,7 @@ bool fit_poisson(const double* y, const double* X, const uint8_t* mask, int64_t 
     esum += eta[i];
   }
   beta[0] = esum / (double)N;
+  if (offset) { double osum = 0.0; for (int64_t i = 0; i < N; ++i) osum += offset[i]; beta[0] -= osum / (double)N; }   // Step1_Models.cpp:247
   double dev_old = dev(pv), dev_new = dev_old;
   int niter = 0;
   bool dev_conv = false;
@@ -568,7 +571,7 @@ bool fit_poisson(const double* y, const double* X, const uint8_t* mask, int64_t 
     std::vector<double> A((size_t)C * C, 0.0), b(C, 0.0);
     for (int64_t i = 0; i < N; ++i) {
       if (!mask[i]) continue;
-      const double z = eta[i] + (y[i] - pv[i]) / pv[i];
+      const double z = eta[i] - (offset ? offset[i] : 0.0) + (y[i] - pv[i]) / pv[i];
       for (int a = 0; a < C; ++a) {
         const double xa = X[(size_t)a * N + i] * pv[i];
         b[a] += xa * z;
@@ -578,7 +581,7 @@ bool fit_poisson(const double* y, const double* X, const uint8_t* mask, int64_t 
     if (!solve_dense(A, b, C, betanew)) return false;
     for (int ls = 0; ls < prm.niter_max_line_search; ++ls) {
       for (int64_t i = 0; i < N; ++i) {
-        double e = 0.0;
+        double e = offset ? offset[i] : 0.0;
         for (int a = 0; a < C; ++a) e += X[(size_t)a * N + i] * betanew[a];
         eta[i] = e;
         pv[i] = std::exp(e);
@@ -599,6 +602,7 @@ bool fit_poisson(const double* y, const double* X, const uint8_t* mask, int64_t 
     dev_old = dev_new;
   }
   if (!dev_conv && niter > prm.niter_max) return false;
+  if (pv_out) *pv_out = pv;
   return true;
 }
 
@@ -713,6 +717,7 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
       std::string id = t[0] + "_" + t[1];
       if (!seen.insert(id).second) throw std::runtime_error("duplicate individual in fam file : FID_IID=" + id);
       if (t[4] != "0" && t[4] != "1" && t[4] != "2") throw std::runtime_error("unrecognized sex code in file : '" + t[4] + "'");
+      if (t[4] == "1") r.has_male = true;
       r.fam_ids.push_back(id);
     }
     r.n_file = (int64_t)r.fam_ids.size();
@@ -745,6 +750,7 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
         if (sex_col >= t.size()) throw std::runtime_error("incorrectly formatted psam file at line " + std::to_string(r.fam_ids.size() + 1));
         const std::string& sx = t[sex_col];
         if (sx != "0" && sx != "NA" && sx != "1" && sx != "2") throw std::runtime_error("unrecognized sex code in file : '" + sx + "'");
+        if (sx == "1") r.has_male = true;
       }
       r.fam_ids.push_back(id);
     }
@@ -1367,12 +1373,13 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
     for (int q = 0; q < P; ++q)
       if (!r.mask[(size_t)q * N + an[k]]) { has_missing[k] = 1; any_missing = true; }
   const bool dense_route = getenv("RG_S2_DENSE") != nullptr;     // the fp64 route of the library (rg_s2_qt_block), kept for comparison
+  const bool glm = p.bt || p.ct;                                 // binary / count traits: the score test of a generalised linear null model
   // compact, sample-fastest copies for the C ABI
   std::vector<double> Xc((size_t)C * n), Yc((size_t)P * n), resc((size_t)P * n), scf(P);
   std::vector<uint8_t> Mc((size_t)P * n);
   for (int c = 0; c < C; ++c) for (int64_t k = 0; k < n; ++k) Xc[(size_t)c * n + k] = r.X[(size_t)c * N + an[k]];
   for (int q = 0; q < P; ++q)
-    for (int64_t k = 0; k < n; ++k) { Yc[(size_t)q * n + k] = (p.bt ? r.Yraw : r.Y)[(size_t)q * N + an[k]]; Mc[(size_t)q * n + k] = r.mask[(size_t)q * N + an[k]]; }
+    for (int64_t k = 0; k < n; ++k) { Yc[(size_t)q * n + k] = (glm ? r.Yraw : r.Y)[(size_t)q * N + an[k]]; Mc[(size_t)q * n + k] = r.mask[(size_t)q * N + an[k]]; }
   // binary traits (compute_res_bin, Data.cpp:2439-2445; compute_score_bt, Step2_Models.cpp:471-552): per chromosome the null logistic
   // model with the LOCO offset gives p^, w = p^ (1 - p^); the score test of a variant needs, per trait, sum w g~^2, X^T W g~ and
   // g~ . (y - p^) -- contractions of the hard-call row with fixed columns, which rg_s2_contract_packed evaluates on the i8 matrix cores
@@ -1380,7 +1387,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   std::vector<double> bt_cols, bt_xwx_inv, bt_sums, bt_sq;
   std::vector<int32_t> bt_counts;
   std::vector<uint8_t> bt_pass(P, 1), test_ignored;
-  if (p.bt) { bt_cols.assign((size_t)bt_ncol * n, 0.0); bt_xwx_inv.assign((size_t)P * C * C, 0.0); }
+  if (glm) { bt_cols.assign((size_t)bt_ncol * n, 0.0); bt_xwx_inv.assign((size_t)P * C * C, 0.0); }
 
   rg_s2_ctx* s2 = nullptr;
   if (rg_s2_create(&s2, p.device, n, C, P) != RG_S2_OK || !s2) throw std::runtime_error("no MI355X / HIP device available (rg_s2_create failed)");
@@ -1395,6 +1402,11 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   // blocks per chromosome (set_blocks_for_testing: ceil(n_chr / bsize))
   std::map<int, std::vector<int64_t>> chr_snps;
   for (size_t j = 0; j < r.snp_chrom.size(); ++j) chr_snps[r.snp_chrom[j]].push_back((int64_t)j);
+  // in_non_par (Geno.cpp:2419, :2251): outside the pseudo-autosomal regions of chromosome X the reference halves the males' calls in the
+  // MAC (and, with the default dosage compensation off, nothing else) -- with no male in the sample file that is the autosomal rule
+  if (chr_snps.count(p.nchrom) && r.has_male)
+    throw std::runtime_error("--step 2 on chromosome " + std::to_string(p.nchrom) + " (X) with male samples: the sex-aware allele counts of the non-PAR region "
+                             "are not built; test the autosomes (or supply a sample file without sex codes of 1).");
   int total_blocks = 0;
   for (auto& kv : chr_snps) total_blocks += (int)((kv.second.size() + p.bsize - 1) / p.bsize);
   sout << std::left << std::setw(20) << " * block size" << ": [" << p.bsize << "]\n";
@@ -1441,7 +1453,8 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
     const int nb_chr = (int)((snps.size() + p.bsize - 1) / p.bsize);
     sout << "Chromosome " << chrom << " [" << nb_chr << " blocks in total]\n";
     // blup_read_chr (Step2_Models.cpp:51-140) + compute_res (Data.cpp:2386-2400)
-    sout << (p.bt ? "   -reading loco predictions for the chromosome and fitting null logistic regression on binary phenotypes..." : "   -reading loco predictions for the chromosome...");
+    sout << (p.bt ? "   -reading loco predictions for the chromosome and fitting null logistic regression on binary phenotypes..."
+                  : p.ct ? "   -reading loco predictions for the chromosome and fitting null poisson regression..." : "   -reading loco predictions for the chromosome...");
     auto tb = std::chrono::steady_clock::now();
     for (int q = 0; q < P; ++q) {
       Run::Blup& bl = r.blups[q];
@@ -1463,21 +1476,27 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
         if (v == MISSING) throw std::runtime_error("individual has missing predictions (chr=" + std::to_string(chrom) + ";phenotype=" + r.pheno_names[q] + ").");
         blup[i] = v;
       }
-      if (p.bt) {   // fit_null_logistic, test-mode branch (Step1_Models.cpp:54-140): offset = the LOCO prediction of the analysed, unmasked samples
+      if (glm) {   // fit_null_logistic / fit_null_poisson, test-mode branch (Step1_Models.cpp:54-140, :225-288): offset = the LOCO prediction of
+                   // the analysed, unmasked samples
         std::vector<double> off(n), eta, pv;
         for (int64_t k = 0; k < n; ++k) off[k] = blup[an[k]] * Mc[(size_t)q * n + k];
         const double* yq = Yc.data() + (size_t)q * n;
         const uint8_t* mq = Mc.data() + (size_t)q * n;
-        bool ok = fit_logistic(yq, Xc.data(), mq, n, C, p, true, eta, off.data(), &pv);
-        if (!ok) ok = fit_logistic(yq, Xc.data(), mq, n, C, p, false, eta, off.data(), &pv);
+        bool ok;
+        if (p.ct) ok = fit_poisson(yq, Xc.data(), mq, n, C, p, eta, off.data(), &pv);
+        else {
+          ok = fit_logistic(yq, Xc.data(), mq, n, C, p, true, eta, off.data(), &pv);
+          if (!ok) ok = fit_logistic(yq, Xc.data(), mq, n, C, p, false, eta, off.data(), &pv);
+        }
         bt_pass[q] = ok ? 1 : 0;
-        if (!ok) { sout << "\n     WARNING: logistic regression did not converge for phenotype '" << r.pheno_names[q] << "'."; continue; }
+        if (!ok) { sout << "\n     WARNING: " << (p.ct ? "poisson" : "logistic") << " regression did not converge for phenotype '" << r.pheno_names[q] << "'."; continue; }
         std::vector<double> A((size_t)C * C, 0.0);
         double* cw = bt_cols.data() + (size_t)q * n;
         double* cr = bt_cols.data() + (size_t)(P + P * C + q) * n;
         double* cm = bt_cols.data() + (size_t)(P + P * C + P + q) * n;
         for (int64_t k = 0; k < n; ++k) {
-          const double m = mq[k] ? 1.0 : 0.0, w = pv[k] * (1.0 - pv[k]) * m;     // get_wvec (Step1_Models.cpp:1808-1815) on the unmasked samples
+          const double m = mq[k] ? 1.0 : 0.0;
+          const double w = (p.ct ? pv[k] : pv[k] * (1.0 - pv[k])) * m;          // Gamma_sqrt^2 on the unmasked samples: p (1 - p) (get_wvec) or the Poisson rate
           cw[k] = w; cr[k] = (yq[k] - pv[k]) * m; cm[k] = m;
           for (int a = 0; a < C; ++a) {
             const double xa = Xc[(size_t)a * n + k] * w;
@@ -1504,7 +1523,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       for (int64_t k = 0; k < n; ++k) resc[(size_t)q * n + k] /= sd;
       scf[q] = r.scale_Y[q] * sd;
     }
-    if (p.bt) s2check(rg_s2_set_columns(s2, bt_ncol, bt_cols.data(), P));
+    if (glm) s2check(rg_s2_set_columns(s2, bt_ncol, bt_cols.data(), P));
     else s2check(rg_s2_set_null(s2, Xc.data(), resc.data(), Mc.data(), scf.data()));
     sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tb).count() << "ms) \n";
 
@@ -1549,8 +1568,8 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       memset(&o, 0, sizeof(o));
       o.stats = stats.data(); o.bhat = bhat.data(); o.scale_fac = sfac.data(); o.ignored = ign.data();
       test_ignored.assign((size_t)bs * P, 0);
-      if (p.bt) {
-        if (in == In::Dosage) throw std::runtime_error("--step 2 --bt reads hard calls (--bed, or a .pgen without dosages): the binary-trait test on dosages is not built.");
+      if (glm) {
+        if (in == In::Dosage) throw std::runtime_error("--step 2 --bt / --ct reads hard calls (--bed, or a .pgen without dosages): the binary / count trait test on dosages is not built.");
         const uint8_t* src = rows.data();
         int64_t ld = r.bpr;
         if (!identity) {
@@ -1594,7 +1613,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
               quad += ua * row;
             }
             const double denum = sw2 - quad, sd = std::sqrt(denum);
-            if (!(sd >= NUMTOL)) { test_ignored[(size_t)j * P + q] = 1; continue; }                 // Step2_Models.cpp:512-517
+            if (p.ct ? !(denum >= NUMTOL) : !(sd >= NUMTOL)) { test_ignored[(size_t)j * P + q] = 1; continue; }   // Step2_Models.cpp:512-517, :596
             const double st = (s0[cr] + mu * s1[cr]) / sd;
             stats[(size_t)j * P + q] = st;
             bhat[(size_t)j * P + q] = st / sd;                                                      // get_sumstats (Step2_Models.cpp:2031-2041)
@@ -1700,7 +1719,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
           int64_t nsq = ns1[j];
           double infq = show_info ? info_num[j] : 0.0;
           if (test_ignored[(size_t)j * P + q]) continue;
-          if (any_missing || p.bt) {   // compute_mac / compute_aaf_info per trait
+          if (any_missing || glm) {   // compute_mac / compute_aaf_info per trait
             const double tq = total[j] + af_t[(size_t)j * P + q];
             nsq = ns1[j] + ns_t[(size_t)j * P + q];
             const double macq = std::min(tq, 2.0 * nsq - tq);

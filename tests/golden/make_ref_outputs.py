@@ -57,6 +57,11 @@ CASES = {
                                 "--bsize", "128", "--qt"],
                                dict(M=500, N=3001, chroms=[1] * 200 + [3] * 170 + [22] * 130, P=4, seed=5, binary=False,
                                     missing_pheno=0.05, miss_rate=0.01)),
+    # count phenotypes for the Step-2 count-trait test (no count data in the reference's example directory).  regenie's own --step 1 --ct
+    # does not converge on them ("Penalized poisson regression did not converge", and --loocv crashes), so the LOCO files that feed
+    # --step 2 --ct come from a --qt run on the same file: any LOCO prediction is a valid offset of the null Poisson model
+    "ct_synth": (["--step", "1", "--bed", "{S}", "--covarFile", "{S}.covar", "--phenoFile", "{S}.pheno", "--bsize", "100", "--qt"],
+                 dict(M=300, N=1500, chroms=[1] * 160 + [2] * 140, P=2, seed=23, binary=False, counts=True, missing_pheno=0.03, miss_rate=0.01)),
 }
 
 
@@ -64,7 +69,7 @@ def synth(prefix, spec):
     from tests.util import synth_dosages, write_plink
     g = synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"])
     write_plink(prefix, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"],
-                missing_pheno=spec["missing_pheno"])
+                missing_pheno=spec["missing_pheno"], counts=spec.get("counts", False))
 
 
 def table_lines(log_text):
@@ -165,6 +170,8 @@ def step2_cases(workdir, step1_dirs):
     runs["qt_synth_missing_bgen_rf"] = (s1m, ["--step", "2", "--bgen", S + ".bgen", "--sample", S + ".sample", "--ref-first"] + common)
     runs["qt_synth_missing_pgen"] = (s1m, ["--step", "2", "--pgen", S + "_d"] + common)
     runs["qt_synth_missing_pgenhc"] = (s1m, ["--step", "2", "--pgen", S + "_h"] + common)
+    Sc = os.path.join(step1_dirs["ct_synth"], "synth")
+    runs["ct_synth"] = (step1_dirs["ct_synth"], ["--step", "2", "--bed", Sc, "--covarFile", Sc + ".covar", "--phenoFile", Sc + ".pheno", "--bsize", "100", "--ct"])
     for name, (s1, args) in runs.items():
         r = subprocess.run([REGENIE] + args + ["--pred", os.path.join(s1, "out_pred.list"), "--out", name], cwd=d,
                            capture_output=True, text=True)

@@ -324,6 +324,56 @@ def test_step2_bt_oracle_against_reference():
     assert seen == sum(len(refs[ph][1]) for ph in range(P)) and seen > 1500
 
 
+def test_step2_ct_oracle_against_reference(tmp_path):
+    """The count-trait score test: null Poisson model with the LOCO offset per chromosome, compute_score_ct, get_sumstats --
+    oracle/regenie_step2_bt.py against regenie's own --step 2 --ct output on synthetic counts (300 variants x 2 traits; the LOCO
+    files are regenie's --qt predictions on the same file, see tests/golden/make_ref_outputs.py)."""
+    import json
+    from oracle import regenie_step2_bt as bt
+    from oracle import regenie_step2_qt as s2
+    from tests.util import synth_dosages, write_plink
+    meta = json.load(open(os.path.join(REF_OUT, "ct_synth", "meta.json")))
+    spec = meta["synthetic"]
+    S = str(tmp_path / "synth")
+    write_plink(S, synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"]), spec["chroms"], P=spec["P"],
+                seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"], counts=True)
+    opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=100, ct=True, test_mode=True)
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    bed, _ = orc.open_bed(opt.bed + ".bed", prep.n_file)
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    P = prep.Y.shape[1]
+    loco = []
+    for ph in range(P):
+        hdr, v = read_loco_gz(os.path.join(REF_OUT, "ct_synth", "out_%d.loco.gz" % (ph + 1)))
+        pos = {s: k for k, s in enumerate(hdr)}
+        loco.append(v[:, [pos[i] for i in ids]])
+    refs = [_read_regenie(os.path.join(REF_OUT, "step2", "ct_synth_Y%d.regenie.gz" % (ph + 1))) for ph in range(P)]
+    col = {nm: i for i, nm in enumerate(refs[0][0])}
+    X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
+    rows = {ph: {r[col["ID"]]: r for r in refs[ph][1]} for ph in range(P)}
+    seen = 0
+    for c in sorted(set(chrom.tolist())):
+        nulls = [bt.null_poisson(Yraw[:, ph], X, mask[:, ph], loco[ph][c - 1], opt) for ph in range(P)]
+        assert all(nl is not None for nl in nulls)
+        sel = np.flatnonzero(chrom == c)
+        G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
+        for k in range(sel.size):
+            g, mean, nobs = s2.mean_impute(G[k])
+            for ph in range(P):
+                r = rows[ph].get(snp_ids[sel[k]])
+                if r is None:
+                    continue
+                out = bt.score_ct(g, X, Yraw[:, ph], mask[:, ph].astype(np.float64), nulls[ph])
+                beta, se, chisq, logp = (float(r[col[nm]]) for nm in ("BETA", "SE", "CHISQ", "LOG10P"))
+                assert out["bhat"] == pytest.approx(beta, rel=5e-5, abs=2e-6)
+                assert out["se"] == pytest.approx(se, rel=5e-5)
+                assert out["chisq"] == pytest.approx(chisq, rel=1e-4, abs=2e-6)
+                assert s2.get_logp(out["chisq"]) == pytest.approx(logp, rel=1e-4, abs=2e-6)
+                seen += 1
+    assert seen == sum(len(refs[ph][1]) for ph in range(P)) == 600
+
+
 needs_ref_binary = pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")
 
 

@@ -91,7 +91,7 @@ def pack_bed(g):
     return (c[:, :, 0] | (c[:, :, 1] << 2) | (c[:, :, 2] << 4) | (c[:, :, 3] << 6)).astype(np.uint8)
 
 
-def write_plink(prefix, g, chroms, P=2, ncov=2, seed=3, h2=0.2, missing_pheno=0.0, binary=False):
+def write_plink(prefix, g, chroms, P=2, ncov=2, seed=3, h2=0.2, missing_pheno=0.0, binary=False, counts=False):
     """Writes prefix.bed/.bim/.fam + prefix.pheno + prefix.covar; returns nothing."""
     M, N = g.shape
     with open(prefix + ".bed", "wb") as fh:
@@ -121,6 +121,8 @@ def write_plink(prefix, g, chroms, P=2, ncov=2, seed=3, h2=0.2, missing_pheno=0.
     Y = np.stack(ys, axis=1)
     if binary:      # liability threshold at prevalence 0.3 -> 0/1 phenotypes
         Y = (Y > np.quantile(Y, 0.7, axis=0, keepdims=True)).astype(np.float64)
+    if counts:      # count phenotypes (--ct): Poisson-like integers with the same genetic signal
+        Y = np.floor(np.exp(0.25 * Y + 0.4))
     miss = rng.random((N, P)) < missing_pheno
     with open(prefix + ".pheno", "w") as fh:
         fh.write("FID IID " + " ".join("Y%d" % (p + 1) for p in range(P)) + "\n")
