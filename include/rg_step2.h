@@ -74,6 +74,15 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
 int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32_t bs, int32_t rows_on_device, int32_t flip,
                           double numtol, const rg_s2_qt_out* out);
 
+/* The same statistic for dosages that are INTEGERS in units of 1 / scale -- 8-bit .bgen probabilities (scale 255: G * 255 = p_het + 2 p_hom),
+ * .pgen dosages (scale 16384) -- handed over as uint16 rows [bs][ld >= n], 0xFFFF = missing, values <= 2 * scale (scale <= 16384).
+ * The row is split into two or three balanced base-128 digit planes on the device and contracted on the i8 matrix cores like the hard
+ * calls (exact integer sums; one division by scale at the end), 2 B per genotype over PCIe instead of 8; phenotypes that differ in
+ * their missing values are served through masked-sample lists (no extra contraction columns).  Per-variant choice of branch as
+ * rg_s2_qt_block_packed; total_p / n_obs_p are not filled.  G: host pointer, or device when g_on_device. */
+int rg_s2_qt_block_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs, int32_t g_on_device, int32_t scale, double numtol,
+                       const rg_s2_qt_out* out);
+
 /* The contraction primitive under rg_s2_qt_block_packed, for tests of the same shape (the score tests of binary and count traits are
  * functions of such sums: Step2_Models.cpp:471-552 compute_score_bt needs sum w g~^2, X^T W g~ and g~ . (y - p^) per trait).
  * rg_s2_set_columns: n_col fixed fp64 columns [n_col][n] (host, sample-fastest; at most 4096), split once into int8 digit planes.

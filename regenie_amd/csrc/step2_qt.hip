@@ -380,7 +380,7 @@ __global__ void k_s2_final(const double* __restrict__ part2, int nchunk, int P, 
 // is swapped when flip != 0 (00 <-> 11, the reference's --ref-first), and the calls are counted (.bed coding, Geno.cpp:2833-2856:
 // 00 -> 2 copies, 01 -> missing, 10 -> 1, 11 -> 0).  cnt [bs][4] = n1, n2, nmiss, 0; *total_miss accumulates nmiss.
 __global__ __launch_bounds__(256) void k_s2_rows(uint8_t* __restrict__ pk, int64_t ldp, int64_t n, int flip, int32_t* __restrict__ cnt,
-                                                 int32_t* __restrict__ total_miss) {
+                                                 int32_t* __restrict__ total_miss, double* __restrict__ vstat) {
   __shared__ int red[3][4];
   uint32_t* w = reinterpret_cast<uint32_t*>(pk + (int64_t)blockIdx.x * ldp);
   const int64_t nwords = ldp / 4;
@@ -411,6 +411,10 @@ __global__ __launch_bounds__(256) void k_s2_rows(uint8_t* __restrict__ pk, int64
     const int a = red[0][0] + red[0][1] + red[0][2] + red[0][3], b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     const int m = red[2][0] + red[2][1] + red[2][2] + red[2][3];
     cnt[blockIdx.x * 4 + 0] = a; cnt[blockIdx.x * 4 + 1] = b; cnt[blockIdx.x * 4 + 2] = m; cnt[blockIdx.x * 4 + 3] = 0;
+    if (vstat) {   // sum, sum of squares, observed, observed non-zero (k_s2_packed_final)
+      double* vs = vstat + (int64_t)blockIdx.x * 4;
+      vs[0] = (double)(a + 2 * b); vs[1] = (double)(a + 4 * b); vs[2] = (double)(n - m); vs[3] = (double)(a + b);
+    }
     if (m) atomicAdd(total_miss, m);
   }
 }
@@ -466,13 +470,17 @@ __global__ void k_s2_combine(const int32_t* __restrict__ S, const double* __rest
   }
 }
 
+// vstat [bs][4] (doubles, exact integers): sum of the observed entries, sum of their squares (both in the row's integer units), observed
+// count, observed non-zero count.  Hard calls: k_s2_rows fills it from the call counts; integer dosages: k_s2_int_rows.
 struct PackedFinal {
-  const double* A;      // [bs][2][Cvt]
-  const double* Sq;     // [bs][2][CvB] (masked problems) or null
-  const int32_t* cnt;   // [bs][4]
+  const double* A;      // [bs][2][Cvt]: (row . column) and (missing indicator . column), in genotype units
+  const double* Sq;     // [bs][2][CvB] (hard calls, masked problems) or null
+  const double* vstat;  // [bs][4]
+  const double* corr;   // [bs][P][C + 2] (integer dosages, masked problems: k_s2_masked_int) or null
   const double *ytx, *Q, *msum, *scf_sv;
-  int bs, C, P, Cvt, cm0, CvB, sqoff, masked;
+  int bs, C, P, Cvt, cm0, CvB, sqoff, masked;   // masked: 0 none, 1 = mask columns (hard calls), 2 = masked-sample lists (integer dosages)
   int64_t n;
+  double inv_scale;        // genotype units per integer unit (1 for hard calls, 1 / 255 for 8-bit .bgen probabilities, ...)
   double numtol, nz_max;   // a variant is "sparse" when its non-zero entries number <= nz_max ...
   double zeros_min;        // ... or (>= 0, the .pgen form) when its observed zeros number >= zeros_min
   double *stats, *bhat, *scale_fac, *mean, *total_p;
@@ -484,9 +492,10 @@ __global__ void k_s2_packed_final(PackedFinal a) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.bs * a.P) return;
   const int j = t / a.P, p = t - j * a.P, C = a.C, P = a.P;
-  const double n1 = a.cnt[j * 4 + 0], n2 = a.cnt[j * 4 + 1], nm = a.cnt[j * 4 + 2];
-  const double nobs = (double)a.n - nm;
-  const double mu = nobs > 0 ? (n1 + 2.0 * n2) / nobs : 0.0;
+  const double* vs = a.vstat + (int64_t)j * 4;
+  const double nobs = vs[2], nm = (double)a.n - nobs, nnz = vs[3];
+  const double tot_all = vs[0] * a.inv_scale, sq_all = vs[1] * a.inv_scale * a.inv_scale;
+  const double mu = nobs > 0 ? tot_all / nobs : 0.0;
   const double* a0 = a.A + (int64_t)j * 2 * a.Cvt;
   const double* a1 = a0 + a.Cvt;
   double b2 = 0.0, corr = 0.0;
@@ -496,13 +505,13 @@ __global__ void k_s2_packed_final(PackedFinal a) {
     corr = fma(a.ytx[p * C + c], b, corr);
   }
   const double num = fma(mu, a1[C + p], a0[C + p]) - corr;
-  const double ss = (n1 + 4.0 * n2 + nm * mu * mu) - b2;                      // |g~ - X beta|^2 over every analysed sample
-  const bool sparse = a.zeros_min >= 0.0 ? (nobs - n1 - n2) >= a.zeros_min
-                                         : (n1 + n2 + (mu != 0.0 ? nm : 0.0)) <= a.nz_max;        // check_sparse_G on the mean-imputed vector
+  const double ss = (sq_all + nm * mu * mu) - b2;                             // |g~ - X beta|^2 over every analysed sample
+  const bool sparse = a.zeros_min >= 0.0 ? (nobs - nnz) >= a.zeros_min
+                                         : (nnz + (mu != 0.0 ? nm : 0.0)) <= a.nz_max;            // check_sparse_G on the mean-imputed vector
   const double sf = sparse ? 1.0 : sqrt(ss) / sqrt((double)(a.n - C));       // residualize_geno only runs for dense variants
   const bool ign = nobs <= 0 || (!sparse && !(sf >= a.numtol));
-  double den = ss, tot = n1 + 2.0 * n2, nobs_p = nobs;
-  if (a.masked) {
+  double den = ss, tot = tot_all, nobs_p = nobs;
+  if (a.masked == 1) {
     const double* sq = a.Sq + (int64_t)j * 2 * a.CvB + a.sqoff;
     const double g2m = sq[p] + mu * mu * a1[a.cm0 + p];
     const double* x0 = a0 + C + P + p * C;
@@ -522,6 +531,16 @@ __global__ void k_s2_packed_final(PackedFinal a) {
     den = g2m - 2.0 * cross + last;
     tot = a0[a.cm0 + p];
     nobs_p = a.msum[p] - a1[a.cm0 + p];
+  } else if (a.masked == 2) {
+    // sums over the samples masked for the trait: corr_c = sum g~ x_c, corr2 = sum g~^2, rs2 = sum (g~ - x . beta)^2
+    const double* cr = a.corr + ((int64_t)j * P + p) * (C + 2);
+    if (sparse) {
+      double cb = 0.0;
+      for (int c = 0; c < C; ++c) cb = fma(cr[c], fma(mu, a1[c], a0[c]), cb);
+      den = ss - cr[C] + 2.0 * cb;          // |g~ o m|^2 - 2 (X^T (g~ o m)) . beta + |beta|^2
+    } else {
+      den = ss - cr[C + 1];                 // mask^T r^2
+    }
   }
   const double sd = sqrt(den);
   const double z = num / sd;
@@ -530,6 +549,129 @@ __global__ void k_s2_packed_final(PackedFinal a) {
   a.total_p[(int64_t)j * P + p] = tot;
   a.nobs_p[(int64_t)j * P + p] = (int32_t)nearbyint(nobs_p);
   if (p == 0) { a.scale_fac[j] = sf; a.mean[j] = mu; a.nobs[j] = (int32_t)nobs; a.ignored[j] = ign ? 1 : 0; }
+}
+
+// ---- integer dosages (rg_s2_qt_block_int) -----------------------------------------------------------------------------------------
+// One workgroup per row of uint16 dosages in units of 1 / scale (0xFFFF = missing): balanced base-128 digit planes d_0 .. d_{D-1}
+// (G = sum_k 128^k d_k, d_k in [-64, 63]) and the missing indicator as plane D, zero padded to Np; vstat as for hard calls (exact: the
+// sums stay below 2^53).  planes [D + 1][bs][Np].
+__global__ __launch_bounds__(256) void k_s2_int_rows(const uint16_t* __restrict__ G, int64_t ld, int64_t n, int64_t Np, int D, int8_t* __restrict__ planes,
+                                                     int64_t set_stride, double* __restrict__ vstat, int32_t* __restrict__ total_miss) {
+  __shared__ long long red[4][4];
+  const int j = blockIdx.x;
+  const uint16_t* g = G + (int64_t)j * ld;
+  int8_t* out = planes + (int64_t)j * Np;
+  long long sg = 0, sg2 = 0, no = 0, nz = 0;
+  for (int64_t i = threadIdx.x; i < Np; i += 256) {
+    const unsigned v0 = i < n ? g[i] : 0u;
+    const bool miss = v0 == 0xFFFFu;
+    int v = miss ? 0 : (int)v0;
+    if (i < n && !miss) { sg += v; sg2 += (long long)v * v; ++no; nz += v != 0; }
+    for (int k = 0; k < D; ++k) {
+      const int d = ((v & 127) ^ 64) - 64;
+      out[(int64_t)k * set_stride + i] = (int8_t)d;
+      v = (v - d) >> 7;
+    }
+    out[(int64_t)D * set_stride + i] = miss ? 1 : 0;
+  }
+  long long vals[4] = {sg, sg2, no, nz};
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    long long x = vals[q];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+    if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const long long x = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+    vstat[(int64_t)j * 4 + threadIdx.x] = (double)x;
+    if (threadIdx.x == 2 && x < n) atomicAdd(total_miss, (int)(n - x));
+  }
+}
+
+// out[j][0][c] = vsc[c] / scale * sum_k 128^k (T_k^0 + 128 T_k^1 + 128^2 T_k^2), out[j][1][c] = vsc[c] * sum_k 128^k T_k^D, T_k^s = the sum over
+// the segments of S[c >> 4][s][f][j][(c & 15) * 8 + k] (int64: exact).  thread = (j, c)
+__global__ void k_s2_int_combine(const int32_t* __restrict__ S, const double* __restrict__ vsc, int bs, int n128, int nseg, int nset, int D, double inv_scale,
+                                 int Cv, double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bs * Cv) return;
+  const int j = t / Cv, c = t - j * Cv, grp = c >> 4, cl = c & 15;
+  long long u[8] = {0, 0, 0, 0, 0, 0, 0, 0}, m[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int set = 0; set < nset; ++set) {
+    const long long wgt = set == 0 ? 1 : (set == 1 ? 128 : 16384);
+    for (int f = 0; f < nseg; ++f) {
+      const int32_t* s = S + (((((int64_t)grp * nset + set) * nseg + f) * n128 + j) * 128) + cl * 8;
+      if (set < D) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] += wgt * s[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] += s[k];
+      }
+    }
+  }
+  double v = 0.0, w = 0.0;
+#pragma unroll
+  for (int k = 7; k >= 0; --k) { v = fma(v, 128.0, (double)u[k]); w = fma(w, 128.0, (double)m[k]); }
+  out[((int64_t)j * 2 + 0) * Cv + c] = v * vsc[c] * inv_scale;
+  out[((int64_t)j * 2 + 1) * Cv + c] = w * vsc[c];
+}
+
+// beta[j][c] = A0 + mu A1 (thread = (j, c)), for the masked-sample sums below
+__global__ void k_s2_beta_from_sums(const double* __restrict__ A, const double* __restrict__ vstat, double inv_scale, int bs, int C, int Cv,
+                                    double* __restrict__ beta /*[bs][RG_S2_MAX_COV]*/) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= bs * C) return;
+  const int j = t / C, c = t - j * C;
+  const double nobs = vstat[(int64_t)j * 4 + 2];
+  const double mu = nobs > 0 ? vstat[(int64_t)j * 4] * inv_scale / nobs : 0.0;
+  beta[(int64_t)j * RG_S2_MAX_COV + c] = fma(mu, A[((int64_t)j * 2 + 1) * Cv + c], A[((int64_t)j * 2) * Cv + c]);
+}
+
+// grid (bs, P), 256 threads: over the samples masked for phenotype p (mlist[moff[p] .. moff[p + 1])) of the mean-imputed variant j:
+// corr[(j * P + p) * (C + 2) + c] = sum g~_i x_c(i) (c < C), [C] = sum g~_i^2, [C + 1] = sum (g~_i - x_i . beta_j)^2
+__global__ __launch_bounds__(256) void k_s2_masked_int(const uint16_t* __restrict__ G, int64_t ld, int64_t n, double inv_scale, const double* __restrict__ X,
+                                                       int C, const int32_t* __restrict__ mlist, const int64_t* __restrict__ moff,
+                                                       const double* __restrict__ vstat, const double* __restrict__ beta, int P, double* __restrict__ corr) {
+  __shared__ double red[4][8];
+  __shared__ double sbeta[RG_S2_MAX_COV];
+  const int j = blockIdx.x, p = blockIdx.y;
+  const int64_t e0 = moff[p], e1 = moff[p + 1];
+  const double nobs = vstat[(int64_t)j * 4 + 2];
+  const double mu = nobs > 0 ? vstat[(int64_t)j * 4] * inv_scale / nobs : 0.0;
+  const uint16_t* g = G + (int64_t)j * ld;
+  double* out = corr + ((int64_t)j * P + p) * (C + 2);
+  if (threadIdx.x < C) sbeta[threadIdx.x] = beta[(int64_t)j * RG_S2_MAX_COV + threadIdx.x];
+  __syncthreads();
+  for (int c0 = 0; c0 < C + 2; c0 += 8) {      // eight sums per sweep over the list
+    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+      const int64_t i = mlist[e];
+      const unsigned v0 = g[i];
+      const double v = v0 == 0xFFFFu ? mu : (double)v0 * inv_scale;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = c0 + k;
+        if (c < C) acc[k] = fma(v, X[(int64_t)c * n + i], acc[k]);
+        else if (c == C) acc[k] = fma(v, v, acc[k]);
+        else if (c == C + 1) {
+          double r = v;
+          for (int d = 0; d < C; ++d) r = fma(-X[(int64_t)d * n + i], sbeta[d], r);
+          acc[k] = fma(r, r, acc[k]);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      double v = acc[k];
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && c0 + (int)threadIdx.x < C + 2)
+      out[c0 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    __syncthreads();
+  }
 }
 
 }  // namespace
@@ -550,6 +692,7 @@ struct rg_s2_ctx {
   // hard-call route (rg_s2_qt_block_packed): built lazily after rg_s2_set_null
   bool complete = false;        // every mask byte is 1
   bool static_ready = false;    // planes of the columns that depend on X and the masks only
+  bool planes_mask_cols = false;   // the planes include the x_c mask_p / mask_p columns
   bool res_ready = false;       // planes of the res columns, res^T X
   std::vector<double> hX;       // host copies of the last X / mask (the planes are kept while they do not change)
   std::vector<uint8_t> hM;
@@ -609,6 +752,91 @@ int pick_segments(int64_t Np, int tiles, int ngrp, SegLayout& seg) {
   return nseg;
 }
 int ensure(rg_s2_ctx* ctx, int slot, size_t bytes) { return ensure_in(ctx, ctx->buf, ctx->cap, slot, bytes); }
+// The int8 digit planes of the contraction columns [X | res (| x_c mask_p | mask_p)]: rebuilt when X or the masks changed (everything but
+// res) and after every rg_s2_set_null (the res columns, res^T X).  want_mask_cols: the hard-call route's extra columns for phenotypes that
+// differ in their missing values (the integer-dosage route uses masked-sample lists instead).
+int ensure_planes(rg_s2_ctx* ctx, bool want_mask_cols) {
+  const int64_t n = ctx->n;
+  const int C = ctx->C, P = ctx->P;
+  const bool mask_cols = want_mask_cols && !ctx->complete;
+  if (!ctx->static_ready || ctx->planes_mask_cols != mask_cols) {   // X or the masks changed: column layout, the planes of every column but res, Q_p
+    const int cv1 = !mask_cols ? C + P : C + P + C * P;
+    const int cm0 = !mask_cols ? cv1 : (cv1 + 15) / 16 * 16, cvt = !mask_cols ? cv1 : cm0 + P;
+    if (cvt > 4096) return fail(ctx, RG_S2_ERR_ARG, "covariates x phenotypes with differing missing values > 4096 columns");
+    const int ngrp = (cvt + 15) / 16;
+    ctx->Np = (n + 64 * RG_MAX_SEG - 1) / (64 * RG_MAX_SEG) * (64 * RG_MAX_SEG);   // 32 pieces of a multiple of 64 samples
+    for (void** q : {(void**)&ctx->dV, (void**)&ctx->dvd, (void**)&ctx->dvsc, (void**)&ctx->dYtX, (void**)&ctx->dQ, (void**)&ctx->dMsum})
+      if (*q) { S2_HIP(hipFree(*q)); *q = nullptr; }
+    ctx->Cvt = cvt; ctx->cm0 = cm0;
+    S2_HIP(hipMalloc((void**)&ctx->dV, sizeof(double) * ngrp * 16 * ctx->Np));
+    S2_HIP(hipMalloc((void**)&ctx->dvd, (size_t)ngrp * 16 * 8 * ctx->Np));
+    S2_HIP(hipMalloc((void**)&ctx->dvsc, sizeof(double) * ngrp * 16));
+    S2_HIP(hipMalloc((void**)&ctx->dYtX, sizeof(double) * P * C));
+    S2_HIP(hipMalloc((void**)&ctx->dQ, sizeof(double) * P * C * C));
+    S2_HIP(hipMalloc((void**)&ctx->dMsum, sizeof(double) * P));
+    S2_HIP(hipMemsetAsync(ctx->dV, 0, sizeof(double) * ngrp * 16 * ctx->Np, ctx->st));
+    S2_HIP(hipMemcpy2DAsync(ctx->dV, ctx->Np * sizeof(double), ctx->dX, n * sizeof(double), n * sizeof(double), C, hipMemcpyDeviceToDevice, ctx->st));
+    if (mask_cols) {
+      hipLaunchKernelGGL(k_s2_mask_cols, dim3((unsigned)((n + 255) / 256), P), dim3(256), 0, ctx->st, ctx->dX, ctx->dM, n, ctx->Np, C, P, cm0, ctx->dV);
+      // Q_p = X^T diag(mask_p) X = I - sum over the samples masked for p of x x^T (X is orthonormal on the analysed samples)
+      std::vector<double> Q((size_t)P * C * C, 0.0), msum(P, 0.0), xi(C);
+      for (int p = 0; p < P; ++p) {
+        double* q = Q.data() + (size_t)p * C * C;
+        for (int c = 0; c < C; ++c) q[c * C + c] = 1.0;
+        const uint8_t* m = ctx->hM.data() + (size_t)p * n;
+        int64_t kept = 0;
+        for (int64_t i = 0; i < n; ++i) {
+          if (m[i]) { ++kept; continue; }
+          for (int c = 0; c < C; ++c) xi[c] = ctx->hX[(size_t)c * n + i];
+          for (int c = 0; c < C; ++c)
+            for (int d = 0; d < C; ++d) q[c * C + d] -= xi[c] * xi[d];
+        }
+        msum[p] = (double)kept;
+      }
+      S2_HIP(hipMemcpyAsync(ctx->dQ, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, ctx->st));
+      S2_HIP(hipMemcpyAsync(ctx->dMsum, msum.data(), sizeof(double) * P, hipMemcpyHostToDevice, ctx->st));
+      S2_HIP(hipStreamSynchronize(ctx->st));      // Q / msum are locals
+    }
+    rg_launch_v_split(ctx->st, ctx->dV, ctx->Np, C, ctx->dvd, ctx->dvsc);
+    if (cvt > C + P)
+      rg_launch_v_split(ctx->st, ctx->dV + (int64_t)(C + P) * ctx->Np, ctx->Np, ngrp * 16 - (C + P), ctx->dvd + (size_t)(C + P) * 8 * ctx->Np, ctx->dvsc + C + P);
+    S2_HIP(hipGetLastError());
+    ctx->static_ready = true;
+    ctx->planes_mask_cols = mask_cols;
+    ctx->res_ready = false;
+  }
+  const int64_t Np = ctx->Np;
+  if (!ctx->res_ready) {      // once per rg_s2_set_null: the planes of the res columns and res^T X
+    S2_HIP(hipMemcpy2DAsync(ctx->dV + (int64_t)C * Np, Np * sizeof(double), ctx->dY, n * sizeof(double), n * sizeof(double), P, hipMemcpyDeviceToDevice, ctx->st));
+    rg_launch_v_split(ctx->st, ctx->dV + (int64_t)C * Np, Np, P, ctx->dvd + (size_t)C * 8 * Np, ctx->dvsc + C);
+    hipLaunchKernelGGL(k_s2_ytx, dim3(P * C), dim3(256), 0, ctx->st, ctx->dX, ctx->dY, n, C, ctx->dYtX);
+    S2_HIP(hipGetLastError());
+    ctx->res_ready = true;
+  }
+  return RG_S2_OK;
+}
+
+// Per phenotype the analysed samples masked for it (index lists on the device), rebuilt when the masks changed.
+int ensure_lists(rg_s2_ctx* ctx) {
+  if (ctx->lists_ready) return RG_S2_OK;
+  const int64_t n = ctx->n;
+  const int P = ctx->P;
+  std::vector<int32_t> lst;
+  std::vector<int64_t> off(P + 1, 0);
+  for (int p = 0; p < P; ++p) {
+    const uint8_t* m = ctx->hM.data() + (size_t)p * n;
+    for (int64_t i = 0; i < n; ++i) if (!m[i]) lst.push_back((int32_t)i);
+    off[p + 1] = (int64_t)lst.size();
+  }
+  if (ctx->d_mlist) { S2_HIP(hipFree(ctx->d_mlist)); ctx->d_mlist = nullptr; }
+  if (!ctx->d_moff) S2_HIP(hipMalloc((void**)&ctx->d_moff, sizeof(int64_t) * (P + 1)));
+  S2_HIP(hipMalloc((void**)&ctx->d_mlist, sizeof(int32_t) * std::max<size_t>(1, lst.size())));
+  S2_HIP(hipMemcpy(ctx->d_mlist, lst.data(), sizeof(int32_t) * lst.size(), hipMemcpyHostToDevice));
+  S2_HIP(hipMemcpy(ctx->d_moff, off.data(), sizeof(int64_t) * (P + 1), hipMemcpyHostToDevice));
+  ctx->lists_ready = true;
+  return RG_S2_OK;
+}
+
 int ensure_p(rg_s2_ctx* ctx, int slot, size_t bytes) { return ensure_in(ctx, ctx->pbuf, ctx->pcap, slot, bytes); }
 }  // namespace
 
@@ -731,21 +959,7 @@ int rg_s2_qt_block(rg_s2_ctx* ctx, const double* G, int64_t ldg, int32_t bs, int
   if ((rc = ensure(ctx, B_NOBS, (size_t)bs * 3 * sizeof(int32_t)))) return rc;     // nobs | ignored | nnz
   const bool masked = !ctx->complete;
   if (masked && (rc = ensure(ctx, B_CORR, (size_t)bs * P * (C + 1) * sizeof(double)))) return rc;
-  if (masked && !ctx->lists_ready) {   // per phenotype the analysed samples masked for it (the masks changed since the last build)
-    std::vector<int32_t> lst;
-    std::vector<int64_t> off(P + 1, 0);
-    for (int p = 0; p < P; ++p) {
-      const uint8_t* m = ctx->hM.data() + (size_t)p * n;
-      for (int64_t i = 0; i < n; ++i) if (!m[i]) lst.push_back((int32_t)i);
-      off[p + 1] = (int64_t)lst.size();
-    }
-    if (ctx->d_mlist) { S2_HIP(hipFree(ctx->d_mlist)); ctx->d_mlist = nullptr; }
-    if (!ctx->d_moff) S2_HIP(hipMalloc((void**)&ctx->d_moff, sizeof(int64_t) * (P + 1)));
-    S2_HIP(hipMalloc((void**)&ctx->d_mlist, sizeof(int32_t) * std::max<size_t>(1, lst.size())));
-    S2_HIP(hipMemcpy(ctx->d_mlist, lst.data(), sizeof(int32_t) * lst.size(), hipMemcpyHostToDevice));
-    S2_HIP(hipMemcpy(ctx->d_moff, off.data(), sizeof(int64_t) * (P + 1), hipMemcpyHostToDevice));
-    ctx->lists_ready = true;
-  }
+  if (masked && (rc = ensure_lists(ctx))) return rc;
   if ((rc = ensure(ctx, B_STAT, (size_t)bs * P * 2 * sizeof(double)))) return rc;  // stats | bhat
   const double* dG = G;
   int64_t ld = ldg;
@@ -808,60 +1022,9 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   const int C = ctx->C, P = ctx->P;
   S2_HIP(hipSetDevice(ctx->dev));
   int rc;
-  if (!ctx->static_ready) {   // X or the masks changed: column layout, the planes of every column but res, Q_p
-    const int cv1 = ctx->complete ? C + P : C + P + C * P;
-    const int cm0 = ctx->complete ? cv1 : (cv1 + 15) / 16 * 16, cvt = ctx->complete ? cv1 : cm0 + P;
-    if (cvt > 4096) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_packed: covariates x phenotypes with differing missing values > 4096 columns");
-    const int ngrp = (cvt + 15) / 16;
-    ctx->Np = (n + 64 * RG_MAX_SEG - 1) / (64 * RG_MAX_SEG) * (64 * RG_MAX_SEG);   // 32 pieces of a multiple of 64 samples
-    for (void** q : {(void**)&ctx->dV, (void**)&ctx->dvd, (void**)&ctx->dvsc, (void**)&ctx->dYtX, (void**)&ctx->dQ, (void**)&ctx->dMsum})
-      if (*q) { S2_HIP(hipFree(*q)); *q = nullptr; }
-    ctx->Cvt = cvt; ctx->cm0 = cm0;
-    S2_HIP(hipMalloc((void**)&ctx->dV, sizeof(double) * ngrp * 16 * ctx->Np));
-    S2_HIP(hipMalloc((void**)&ctx->dvd, (size_t)ngrp * 16 * 8 * ctx->Np));
-    S2_HIP(hipMalloc((void**)&ctx->dvsc, sizeof(double) * ngrp * 16));
-    S2_HIP(hipMalloc((void**)&ctx->dYtX, sizeof(double) * P * C));
-    S2_HIP(hipMalloc((void**)&ctx->dQ, sizeof(double) * P * C * C));
-    S2_HIP(hipMalloc((void**)&ctx->dMsum, sizeof(double) * P));
-    S2_HIP(hipMemsetAsync(ctx->dV, 0, sizeof(double) * ngrp * 16 * ctx->Np, ctx->st));
-    S2_HIP(hipMemcpy2DAsync(ctx->dV, ctx->Np * sizeof(double), ctx->dX, n * sizeof(double), n * sizeof(double), C, hipMemcpyDeviceToDevice, ctx->st));
-    if (!ctx->complete) {
-      hipLaunchKernelGGL(k_s2_mask_cols, dim3((unsigned)((n + 255) / 256), P), dim3(256), 0, ctx->st, ctx->dX, ctx->dM, n, ctx->Np, C, P, cm0, ctx->dV);
-      // Q_p = X^T diag(mask_p) X = I - sum over the samples masked for p of x x^T (X is orthonormal on the analysed samples)
-      std::vector<double> Q((size_t)P * C * C, 0.0), msum(P, 0.0), xi(C);
-      for (int p = 0; p < P; ++p) {
-        double* q = Q.data() + (size_t)p * C * C;
-        for (int c = 0; c < C; ++c) q[c * C + c] = 1.0;
-        const uint8_t* m = ctx->hM.data() + (size_t)p * n;
-        int64_t kept = 0;
-        for (int64_t i = 0; i < n; ++i) {
-          if (m[i]) { ++kept; continue; }
-          for (int c = 0; c < C; ++c) xi[c] = ctx->hX[(size_t)c * n + i];
-          for (int c = 0; c < C; ++c)
-            for (int d = 0; d < C; ++d) q[c * C + d] -= xi[c] * xi[d];
-        }
-        msum[p] = (double)kept;
-      }
-      S2_HIP(hipMemcpyAsync(ctx->dQ, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, ctx->st));
-      S2_HIP(hipMemcpyAsync(ctx->dMsum, msum.data(), sizeof(double) * P, hipMemcpyHostToDevice, ctx->st));
-      S2_HIP(hipStreamSynchronize(ctx->st));      // Q / msum are locals
-    }
-    rg_launch_v_split(ctx->st, ctx->dV, ctx->Np, C, ctx->dvd, ctx->dvsc);
-    if (cvt > C + P)
-      rg_launch_v_split(ctx->st, ctx->dV + (int64_t)(C + P) * ctx->Np, ctx->Np, ngrp * 16 - (C + P), ctx->dvd + (size_t)(C + P) * 8 * ctx->Np, ctx->dvsc + C + P);
-    S2_HIP(hipGetLastError());
-    ctx->static_ready = true;
-    ctx->res_ready = false;
-  }
+  if ((rc = ensure_planes(ctx, true))) return rc;
   const int Cvt = ctx->Cvt, cm0 = ctx->cm0, ngrp = (Cvt + 15) / 16, masked = ctx->complete ? 0 : 1;
   const int64_t Np = ctx->Np, ldp = Np / 4;
-  if (!ctx->res_ready) {      // once per rg_s2_set_null: the planes of the res columns and res^T X
-    S2_HIP(hipMemcpy2DAsync(ctx->dV + (int64_t)C * Np, Np * sizeof(double), ctx->dY, n * sizeof(double), n * sizeof(double), P, hipMemcpyDeviceToDevice, ctx->st));
-    rg_launch_v_split(ctx->st, ctx->dV + (int64_t)C * Np, Np, P, ctx->dvd + (size_t)C * 8 * Np, ctx->dvsc + C);
-    hipLaunchKernelGGL(k_s2_ytx, dim3(P * C), dim3(256), 0, ctx->st, ctx->dX, ctx->dY, n, C, ctx->dYtX);
-    S2_HIP(hipGetLastError());
-    ctx->res_ready = true;
-  }
   const int n128 = (int)((bs + 127) / 128 * 128);
   const int gm0 = cm0 / 16, ngrpB = masked ? ngrp - gm0 : 0, CvB = ngrpB * 16;      // column groups of the g0^2 contraction (the mask columns)
   // enough workgroups to fill the 256 CUs (tiles x segments x column groups >= 768), as few segments as that allows: every segment
@@ -874,7 +1037,7 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   if ((rc = ensure_p(ctx, Q_CNT, ((size_t)bs * 4 + 8) * sizeof(int32_t)))) return rc;            // counts | total_miss | bs | 0
   if ((rc = ensure_p(ctx, Q_S, ((size_t)ngrp * s_grp + (size_t)ngrpB * s_grpB) * sizeof(int32_t)))) return rc;
   if ((rc = ensure_p(ctx, Q_A, (size_t)bs * 2 * (Cvt + CvB) * sizeof(double)))) return rc;
-  if ((rc = ensure_p(ctx, Q_VAR, (size_t)bs * (2 * sizeof(double) + 2 * sizeof(int32_t))))) return rc;   // scale_fac | mean | nobs | ignored
+  if ((rc = ensure_p(ctx, Q_VAR, (size_t)bs * (6 * sizeof(double) + 2 * sizeof(int32_t))))) return rc;   // scale_fac | mean | vstat[4] | nobs | ignored
   if ((rc = ensure_p(ctx, Q_STAT, (size_t)bs * P * (3 * sizeof(double) + sizeof(int32_t))))) return rc;  // stats | bhat | total_p | nobs_p
   uint8_t* pk = (uint8_t*)ctx->pbuf[Q_PK];
   int32_t* cnt = (int32_t*)ctx->pbuf[Q_CNT];
@@ -886,7 +1049,8 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   double* Sq = A + (size_t)bs * 2 * Cvt;
   double* sf = (double*)ctx->pbuf[Q_VAR];
   double* mu = sf + bs;
-  int32_t* nobs = (int32_t*)(mu + bs);
+  double* vstat = mu + bs;
+  int32_t* nobs = (int32_t*)(vstat + (size_t)bs * 4);
   int32_t* ign = nobs + bs;
   double* stats = (double*)ctx->pbuf[Q_STAT];
   double* bhat = stats + (size_t)bs * P;
@@ -896,7 +1060,7 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   S2_HIP(hipMemcpyAsync(total_miss, ctx->hdr, sizeof(ctx->hdr), hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipMemcpy2DAsync(pk, ldp, rows, ld, nbytes, bs, rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipEventRecord(ctx->e0, ctx->st));
-  hipLaunchKernelGGL(k_s2_rows, dim3(bs), dim3(256), 0, ctx->st, pk, ldp, n, flip ? 1 : 0, cnt, total_miss);
+  hipLaunchKernelGGL(k_s2_rows, dim3(bs), dim3(256), 0, ctx->st, pk, ldp, n, flip ? 1 : 0, cnt, total_miss, vstat);
   rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, total_miss, Cvt, n128, seg, ctx->dvd, Np, RG_XY_LUT_DOSAGE, S);
   hipLaunchKernelGGL(k_s2_combine, dim3((bs * Cvt + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->dvsc, total_miss, bs, n128, nseg, Cvt, A);
   if (masked) {   // sum mask_p g0^2: the square LUT against the mask columns only (the missing-indicator set is skipped: d_zero)
@@ -905,7 +1069,8 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
                        (const int32_t*)nullptr, bs, n128, nsegB, CvB, Sq);
   }
   PackedFinal fa;
-  fa.A = A; fa.Sq = masked ? Sq : nullptr; fa.cnt = cnt; fa.ytx = ctx->dYtX; fa.Q = ctx->dQ; fa.msum = ctx->dMsum; fa.scf_sv = ctx->dscf;
+  fa.A = A; fa.Sq = masked ? Sq : nullptr; fa.vstat = vstat; fa.corr = nullptr; fa.inv_scale = 1.0;
+  fa.ytx = ctx->dYtX; fa.Q = ctx->dQ; fa.msum = ctx->dMsum; fa.scf_sv = ctx->dscf;
   fa.bs = bs; fa.C = C; fa.P = P; fa.Cvt = Cvt; fa.cm0 = cm0; fa.CvB = CvB; fa.sqoff = cm0 - gm0 * 16; fa.masked = masked;
   fa.n = n; fa.numtol = numtol; fa.nz_max = (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * (1.0 - ctx->rule_thr);
   fa.zeros_min = ctx->rule_zero_count ? (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * ctx->rule_thr : -1.0;
@@ -921,6 +1086,104 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   if (out->ignored) S2_HIP(hipMemcpyAsync(out->ignored, ign, sizeof(int32_t) * bs, hipMemcpyDeviceToHost, ctx->st));
   if (out->total_p) S2_HIP(hipMemcpyAsync(out->total_p, total_p, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));
   if (out->n_obs_p) S2_HIP(hipMemcpyAsync(out->n_obs_p, nobs_p, sizeof(int32_t) * bs * P, hipMemcpyDeviceToHost, ctx->st));
+  S2_HIP(hipStreamSynchronize(ctx->st));
+  float ms = 0.f;
+  S2_HIP(hipEventElapsedTime(&ms, ctx->e0, ctx->e1));
+  ctx->last_ms = ms;
+  return RG_S2_OK;
+}
+
+int rg_s2_qt_block_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs, int32_t g_on_device, int32_t scale, double numtol,
+                       const rg_s2_qt_out* out) {
+  if (!ctx || !ctx->st) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_int: context was not created");
+  if (!ctx->have_null) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_int: rg_s2_set_null has not been called");
+  const int64_t n = ctx->n;
+  if (!G || !out || bs < 1 || ld < n || scale < 1 || scale > 16384)
+    return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_int: bad arguments (need bs >= 1, ld >= n, 1 <= scale <= 16384)");
+  const int C = ctx->C, P = ctx->P, Cv = C + P;
+  S2_HIP(hipSetDevice(ctx->dev));
+  int rc;
+  if ((rc = ensure_planes(ctx, ctx->planes_mask_cols))) return rc;       // [X | res] lead the planes whatever else they hold
+  const int masked = ctx->complete ? 0 : 2;
+  if (masked && (rc = ensure_lists(ctx))) return rc;
+  const int64_t Np = ctx->Np;
+  const int D = 2 * scale <= 8127 ? 2 : 3, nset = D + 1;                 // balanced base-128 digits of a dosage <= 2 * scale (two reach 63 + 128 * 63), then the missing indicator
+  const int n128 = (int)((bs + 127) / 128 * 128), ngrp = (Cv + 15) / 16;
+  SegLayout seg;
+  int nseg = pick_segments(Np, n128 / 128, ngrp * nset, seg);
+  while (Np / nseg > 262144 && nseg < RG_MAX_SEG) { nseg *= 2; }         // |digit x digit| <= 4096: int32 sums hold 2^19 samples per segment
+  if (Np / nseg > 524288) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_qt_block_int: more than 16.7 million samples");
+  memset(&seg, 0, sizeof(seg));
+  seg.nseg = nseg;
+  for (int f = 0; f < nseg; ++f) { seg.pos_start[f] = f * (Np / nseg); seg.file_start[f] = seg.pos_start[f]; seg.len[f] = Np / nseg; seg.plen[f] = Np / nseg; }
+  enum { Q_PK, Q_CNT, Q_S, Q_A, Q_VAR, Q_STAT };
+  enum { B_G, B_PART, B_BETA, B_VAR, B_NOBS, B_STAT, B_CORR, B_PLANES };
+  if ((rc = ensure_p(ctx, Q_CNT, ((size_t)bs * 4 + 8) * sizeof(int32_t)))) return rc;
+  if ((rc = ensure_p(ctx, Q_S, (size_t)ngrp * nset * nseg * n128 * 128 * sizeof(int32_t)))) return rc;
+  if ((rc = ensure_p(ctx, Q_A, (size_t)bs * 2 * ctx->Cvt * sizeof(double)))) return rc;
+  if ((rc = ensure_p(ctx, Q_VAR, (size_t)bs * (6 * sizeof(double) + 2 * sizeof(int32_t))))) return rc;
+  if ((rc = ensure_p(ctx, Q_STAT, (size_t)bs * P * (3 * sizeof(double) + sizeof(int32_t))))) return rc;
+  if ((rc = ensure(ctx, B_PLANES, (size_t)nset * bs * Np))) return rc;
+  if (!g_on_device && (rc = ensure(ctx, B_G, (size_t)bs * n * sizeof(uint16_t)))) return rc;
+  if (masked) {
+    if ((rc = ensure(ctx, B_BETA, (size_t)bs * RG_S2_MAX_COV * sizeof(double)))) return rc;
+    if ((rc = ensure(ctx, B_CORR, (size_t)bs * P * (C + 2) * sizeof(double)))) return rc;
+  }
+  const uint16_t* dG = G;
+  int64_t ldg = ld;
+  if (!g_on_device) {
+    S2_HIP(hipMemcpy2DAsync(ctx->buf[B_G], n * sizeof(uint16_t), G, ld * sizeof(uint16_t), n * sizeof(uint16_t), bs, hipMemcpyHostToDevice, ctx->st));
+    dG = (const uint16_t*)ctx->buf[B_G];
+    ldg = n;
+  }
+  int32_t* cnt = (int32_t*)ctx->pbuf[Q_CNT];
+  int32_t* total_miss = cnt + (size_t)bs * 4;
+  int32_t* d_bs = total_miss + 1;
+  int32_t* S = (int32_t*)ctx->pbuf[Q_S];
+  double* A = (double*)ctx->pbuf[Q_A];
+  double* sf = (double*)ctx->pbuf[Q_VAR];
+  double* mu = sf + bs;
+  double* vstat = mu + bs;
+  int32_t* nobs = (int32_t*)(vstat + (size_t)bs * 4);
+  int32_t* ign = nobs + bs;
+  double* stats = (double*)ctx->pbuf[Q_STAT];
+  double* bhat = stats + (size_t)bs * P;
+  double* total_p = bhat + (size_t)bs * P;
+  int32_t* nobs_p = (int32_t*)(total_p + (size_t)bs * P);
+  int8_t* planes = (int8_t*)ctx->buf[B_PLANES];
+  const double inv_scale = 1.0 / (double)scale;
+  ctx->hdr[0] = 0; ctx->hdr[1] = bs; ctx->hdr[2] = 0;
+  S2_HIP(hipMemcpyAsync(total_miss, ctx->hdr, sizeof(ctx->hdr), hipMemcpyHostToDevice, ctx->st));
+  S2_HIP(hipEventRecord(ctx->e0, ctx->st));
+  hipLaunchKernelGGL(k_s2_int_rows, dim3(bs), dim3(256), 0, ctx->st, dG, ldg, n, Np, D, planes, (int64_t)bs * Np, vstat, total_miss);
+  rg_launch_xy_i8_planes(ctx->st, planes, (int64_t)bs * Np, nset, d_bs, Cv, n128, seg, ctx->dvd, Np, S);
+  // A is laid out with the planes' full column count so that k_s2_packed_final indexes it as for hard calls; only [X | res] are filled
+  hipLaunchKernelGGL(k_s2_int_combine, dim3((bs * Cv + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->dvsc, bs, n128, nseg, nset, D, inv_scale, Cv,
+                     A);
+  double* corr = nullptr;
+  if (masked) {
+    double* beta = (double*)ctx->buf[B_BETA];
+    corr = (double*)ctx->buf[B_CORR];
+    hipLaunchKernelGGL(k_s2_beta_from_sums, dim3((bs * C + 255) / 256), dim3(256), 0, ctx->st, (const double*)A, (const double*)vstat, inv_scale, bs, C, Cv, beta);
+    hipLaunchKernelGGL(k_s2_masked_int, dim3(bs, P), dim3(256), 0, ctx->st, dG, ldg, n, inv_scale, ctx->dX, C, ctx->d_mlist, ctx->d_moff,
+                       (const double*)vstat, (const double*)beta, P, corr);
+  }
+  PackedFinal fa;
+  fa.A = A; fa.Sq = nullptr; fa.vstat = vstat; fa.corr = corr; fa.inv_scale = inv_scale;
+  fa.ytx = ctx->dYtX; fa.Q = ctx->dQ; fa.msum = ctx->dMsum; fa.scf_sv = ctx->dscf;
+  fa.bs = bs; fa.C = C; fa.P = P; fa.Cvt = Cv; fa.cm0 = Cv; fa.CvB = 0; fa.sqoff = 0; fa.masked = masked;
+  fa.n = n; fa.numtol = numtol; fa.nz_max = (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * (1.0 - ctx->rule_thr);
+  fa.zeros_min = ctx->rule_zero_count ? (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * ctx->rule_thr : -1.0;
+  fa.stats = stats; fa.bhat = bhat; fa.scale_fac = sf; fa.mean = mu; fa.total_p = total_p; fa.nobs = nobs; fa.ignored = ign; fa.nobs_p = nobs_p;
+  hipLaunchKernelGGL(k_s2_packed_final, dim3((bs * P + 255) / 256), dim3(256), 0, ctx->st, fa);
+  S2_HIP(hipEventRecord(ctx->e1, ctx->st));
+  S2_HIP(hipGetLastError());
+  if (out->stats) S2_HIP(hipMemcpyAsync(out->stats, stats, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));
+  if (out->bhat) S2_HIP(hipMemcpyAsync(out->bhat, bhat, sizeof(double) * bs * P, hipMemcpyDeviceToHost, ctx->st));
+  if (out->scale_fac) S2_HIP(hipMemcpyAsync(out->scale_fac, sf, sizeof(double) * bs, hipMemcpyDeviceToHost, ctx->st));
+  if (out->mean) S2_HIP(hipMemcpyAsync(out->mean, mu, sizeof(double) * bs, hipMemcpyDeviceToHost, ctx->st));
+  if (out->n_obs) S2_HIP(hipMemcpyAsync(out->n_obs, nobs, sizeof(int32_t) * bs, hipMemcpyDeviceToHost, ctx->st));
+  if (out->ignored) S2_HIP(hipMemcpyAsync(out->ignored, ign, sizeof(int32_t) * bs, hipMemcpyDeviceToHost, ctx->st));
   S2_HIP(hipStreamSynchronize(ctx->st));
   float ms = 0.f;
   S2_HIP(hipEventElapsedTime(&ms, ctx->e0, ctx->e1));
@@ -984,7 +1247,7 @@ int rg_s2_contract_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   S2_HIP(hipMemcpyAsync(total_miss, ctx->hdr, sizeof(ctx->hdr), hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipMemcpy2DAsync(pk, ldp, rows, ld, nbytes, bs, rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipEventRecord(ctx->e0, ctx->st));
-  hipLaunchKernelGGL(k_s2_rows, dim3(bs), dim3(256), 0, ctx->st, pk, ldp, n, flip ? 1 : 0, cnt, total_miss);
+  hipLaunchKernelGGL(k_s2_rows, dim3(bs), dim3(256), 0, ctx->st, pk, ldp, n, flip ? 1 : 0, cnt, total_miss, (double*)nullptr);
   rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, total_miss, ncol, n128, seg, ctx->gvd, Np, RG_XY_LUT_DOSAGE, S);
   hipLaunchKernelGGL(k_s2_combine, dim3((bs * ncol + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->gvsc, total_miss, bs, n128, nseg, ncol, A);
   if (nsq > 0) {

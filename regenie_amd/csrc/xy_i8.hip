@@ -150,6 +150,80 @@ __global__ __launch_bounds__(256, 4) void k_xy_i8(const uint8_t* __restrict__ pk
       }
 }
 
+// ---- the same contraction when the row operand already is int8 (digit planes of integer dosages, step2_qt.hip): A rows are copied like
+// the digit rows.  aplanes [nset][rows][Np]; S[grp][set][seg][row][col]; grid (n128 / 128, nseg, ngrp * nset) --------------------------
+__global__ __launch_bounds__(256, 4) void k_xy_i8_planes(const int8_t* __restrict__ aplanes, int64_t a_set_stride, int nset, const int32_t* __restrict__ d_bs,
+                                                         int n128, SegLayout seg, const int8_t* __restrict__ vd, int64_t Np, int ncol_last,
+                                                         int32_t* __restrict__ S) {
+  __shared__ __attribute__((aligned(16))) uint8_t sA[XT * X_PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t sB[XT * X_PITCH];
+  const int grp = blockIdx.z / nset, set = blockIdx.z - grp * nset, f = blockIdx.y, tr = blockIdx.x;
+  const int ngrp = gridDim.z / nset;
+  const int ncol = grp == ngrp - 1 ? ncol_last : 16 * X_NPIECE;
+  const int bs = d_bs[0];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t pos0 = seg.pos_start[f], klen = seg.plen[f];
+  v16i acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+  const int srow = tid >> 1, half = tid & 1;
+  const int arow = tr * XT + srow;
+  const bool validA = arow < bs, validB = srow < ncol;
+  const int8_t* ga = aplanes + (int64_t)set * a_set_stride + (int64_t)(validA ? arow : 0) * Np + pos0 + half * 32;
+  const int8_t* gb = vd + (int64_t)grp * 16 * X_NPIECE * Np + (int64_t)(validB ? srow : 0) * Np + pos0 + half * 32;
+  uint8_t* lrowA = sA + srow * X_PITCH + half * 32;
+  uint8_t* lrowB = sB + srow * X_PITCH + half * 32;
+  const uint4 z4 = make_uint4(0, 0, 0, 0);
+  uint4 a0 = z4, a1 = z4, v0 = z4, v1 = z4;
+  if (klen > 0) {
+    if (validA) { const uint4* src = reinterpret_cast<const uint4*>(ga); a0 = src[0]; a1 = src[1]; }
+    if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb); v0 = src[0]; v1 = src[1]; }
+  }
+  for (int64_t k = 0; k < klen; k += 64) {      // 64 positions per step
+    *reinterpret_cast<uint4*>(lrowA) = a0;
+    *reinterpret_cast<uint4*>(lrowA + 16) = a1;
+    *reinterpret_cast<uint4*>(lrowB) = v0;
+    *reinterpret_cast<uint4*>(lrowB + 16) = v1;
+    __syncthreads();
+    if (k + 64 < klen) {
+      if (validA) { const uint4* src = reinterpret_cast<const uint4*>(ga + k + 64); a0 = src[0]; a1 = src[1]; }
+      if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb + k + 64); v0 = src[0]; v1 = src[1]; }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      v4i af[2], bf[2];
+      const int koff = ks * 32 + (lane >> 5) * 16;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sA + (wr * 64 + i * 32 + (lane & 31)) * X_PITCH + koff);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sB + (wc * 64 + j * 32 + (lane & 31)) * X_PITCH + koff);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (wc * 64 + j * 32 >= ncol) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  int32_t* Sf = S + ((((int64_t)grp * nset + set) * seg.nseg + f) * n128) * (int64_t)XT;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tr * XT + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = wc * 64 + j * 32 + (lane & 31);
+        Sf[(int64_t)row * XT + col] = acc[i][j][r];
+      }
+}
+
 // ---- part[blk][fold][row][set][c] = vsc[c] * sum_k 128^k S[.][c*8+k]; grid (ceil(n128*Cv / 256), nseg, nblk) -------------------
 __global__ void k_xy_combine(const int32_t* __restrict__ S, const double* __restrict__ vsc, const int32_t* __restrict__ nmiss, int n128, int nseg,
                              int Cv, double* __restrict__ part) {
@@ -180,6 +254,14 @@ void rg_launch_xy_i8_sums(hipStream_t st, const uint8_t* pk, int64_t pk_ld, cons
   const int ngrp = (ncols + 15) / 16;
   hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, ngrp * 2), dim3(256), 0, st, pk, pk_ld, (int64_t)0, d_bs, nmiss, n128, seg, vd,
                      (int64_t)16 * X_NPIECE * Np, 1, Np, 16 * X_NPIECE, (ncols - (ngrp - 1) * 16) * X_NPIECE, lut0, S32);
+}
+
+// int8 row planes against ncols columns: S32 [ngrp][nset][nseg][n128][128]
+void rg_launch_xy_i8_planes(hipStream_t st, const int8_t* aplanes, int64_t a_set_stride, int nset, const int32_t* d_bs, int ncols, int n128,
+                            const SegLayout& seg, const int8_t* vd, int64_t Np, int32_t* S32) {
+  const int ngrp = (ncols + 15) / 16;
+  hipLaunchKernelGGL(k_xy_i8_planes, dim3(n128 / XT, seg.nseg, ngrp * nset), dim3(256), 0, st, aplanes, a_set_stride, nset, d_bs, n128, seg, vd, Np,
+                     (ncols - (ngrp - 1) * 16) * X_NPIECE, S32);
 }
 
 // S32: nblk * 2 * nseg * n128 * 128 int32; part: [nblk][nseg][n128][2][Cv] (rowstats reads it with nchunk = nseg, chunk_seg = identity)

@@ -122,6 +122,18 @@ class Step2QT:
         self._check(self.lib.rg_s2_qt_block_packed(self.h, ptr, ld, bs, on_device, 1 if flip else 0, float(numtol), C.byref(out)))
         return self._finish(res)
 
+    def score_block_int(self, G: np.ndarray, scale: int, numtol: float = NUMTOL) -> dict:
+        """Integer dosages: G [bs][n] uint16 in units of 1 / scale (255 for 8-bit .bgen probabilities, 16384 for .pgen), 0xFFFF = missing."""
+        G = np.ascontiguousarray(G, dtype=np.uint16)
+        if G.ndim != 2 or G.shape[1] != self.n:
+            raise ValueError("score_block_int: G must be [bs][n]")
+        bs = G.shape[0]
+        res = {"stats": np.empty((bs, self.P)), "bhat": np.empty((bs, self.P)), "scale_fac": np.empty(bs),
+               "mean": np.empty(bs), "n_obs": np.empty(bs, np.int32), "ignored": np.empty(bs, np.int32)}
+        out = _QtOut(*[res[k].ctypes.data for k in ("stats", "bhat", "scale_fac", "mean", "n_obs", "ignored")])
+        self._check(self.lib.rg_s2_qt_block_int(self.h, G.ctypes.data, G.shape[1], bs, 0, int(scale), float(numtol), C.byref(out)))
+        return self._finish(res)
+
     # ---- the contraction primitive (rg_s2_set_columns / rg_s2_contract_packed) ------------------------------------------------
     def set_columns(self, cols: np.ndarray, n_sq: int = 0) -> None:
         """cols [n_col][n] float64: the fixed columns the hard-call rows are contracted with; the first n_sq also against g^2."""

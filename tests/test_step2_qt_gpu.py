@@ -327,3 +327,35 @@ def test_contraction_primitive_matches_numpy():
                                      ("sq", (g0 * g0) @ cols[:nsq].T, got["sq"])):
                 bound = (np.abs(g0) + miss) @ np.abs(cols[: want.shape[1]]).T + 1e-300     # sum of the terms' magnitudes
                 assert (np.abs(have - want) <= 4e-15 * bound + 2.0 ** -52 * n * np.abs(cols[: want.shape[1]]).max(axis=1)[None, :]).all(), name
+
+
+@pytest.mark.parametrize("scale,n,C,P,bs,miss_y", [(255, 5003, 5, 3, 64, 0.0), (255, 9001, 12, 7, 130, 0.06), (16384, 4097, 3, 2, 40, 0.05),
+                                                    (1, 3000, 2, 2, 20, 0.04), (4063, 2500, 1, 1, 9, 0.0), (4064, 2500, 1, 1, 9, 0.0)])
+def test_integer_dosage_route_against_oracle(scale, n, C, P, bs, miss_y):
+    """rg_s2_qt_block_int: dosages that are integers in units of 1 / scale (8-bit .bgen probabilities, .pgen's 16-bit dosages, hard
+    calls as scale 1; two digit planes up to scale 4063, three above) against the reference-pinned oracle on the same values as doubles,
+    and against the library's fp64 route; complete phenotypes and phenotypes that differ in their missing values (masked-sample lists)."""
+    from regenie_amd.step2 import Step2QT
+    X, res, mask, scf, _ = _problem(n + bs + scale, n, C, P, bs, miss_y=miss_y)
+    rng = np.random.default_rng(scale + n)
+    af = rng.uniform(0.01, 0.6, size=(bs, 1))
+    hard = rng.binomial(2, af, size=(bs, n))
+    Gi = np.clip(hard * scale + (rng.random((bs, n)) < 0.4) * rng.integers(-scale // 3, scale // 3 + 1, size=(bs, n)), 0, 2 * scale).astype(np.int64)
+    Gi[rng.random((bs, n)) < 0.3] = 0                                # plenty of exact zeros: both branches of check_sparse_G
+    miss = rng.random((bs, n)) < 0.004
+    miss[0] = rng.random(n) < 0.2
+    miss[3] = True                                                   # nothing observed
+    Gi[2] = 2 * scale                                                # monomorphic
+    miss[2] = False
+    Gi[4] = 2 * scale - (np.arange(n) % 3 == 0) * max(1, scale // 8)  # the largest values (third digit at scale >= 4064); not a near-constant row:
+                                                                     # |r|^2 is formed as sum g~^2 - |beta|^2, ill-conditioned only below the MAC filter
+    G = np.where(miss, np.nan, Gi / float(scale))
+    ref = s2o.score_qt_block_ref(G, X, res, mask, scf)
+    assert 0 < ref["sparse"].sum() < bs
+    with Step2QT(n, C, P) as s2:
+        s2.set_null(X.T, res.T, mask.T, scf)
+        got = s2.score_block_int(np.where(miss, 0xFFFF, Gi).astype(np.uint16), scale)
+        dense = s2.score_block(G)
+    _compare(got, ref)
+    ok = ref["ignored"] == 0
+    assert np.allclose(got["stats"][ok], dense["stats"][ok], rtol=1e-9, atol=1e-10, equal_nan=True)
