@@ -1443,6 +1443,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   std::vector<double> G, stats, bhat, sfac, mean_v, totp_v, dbuf, ibuf;
   std::vector<int32_t> ign, nobs_v, nobsp_v;
   std::vector<int64_t> vidx;
+  std::vector<uint16_t> G16;
   bool identity = n == r.n_file;                 // every sample of the file is analysed, in file order
   for (int64_t k = 0; identity && k < n; ++k) identity = file_idx[k] == k;
   int64_t n_ignored_snps = 0, n_ignored_tests = 0, n_tested = 0;
@@ -1644,7 +1645,28 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
           total[j] = tot; ns1[j] = ns; info_num[j] = inf;
           if (std::min(tot, 2.0 * ns - tot) < p.min_mac) variant_ignored[j] = 1;      // compute_mac (Geno.cpp:3077-3108), autosomes
         });
-        s2check(rg_s2_qt_block(s2, G.data(), n, bs, 0, NUMTOL, &o));
+        // 8-bit .bgen probabilities and .pgen dosages are integers in units of 1 / 255 and 1 / 16384: as uint16 rows they take the
+        // integer route of the library (digit planes on the i8 matrix cores, 2 B per genotype over PCIe); anything else, or
+        // RG_S2_DENSE=1, the fp64 route
+        const int scale = r.bgenh ? 255 : 16384;
+        bool integral = !dense_route;
+        if (integral) {
+          G16.resize((size_t)bs * n);
+          std::vector<uint8_t> bad(bs, 0);
+          parallel_for(bs, nthreads, [&](int j) {
+            const double* g = G.data() + (size_t)j * n;
+            uint16_t* q = G16.data() + (size_t)j * n;
+            for (int64_t k = 0; k < n; ++k) {
+              if (g[k] == -3.0) { q[k] = 0xFFFFu; continue; }
+              const double v = g[k] * scale, rv = std::nearbyint(v);
+              if (std::fabs(v - rv) > 1e-6 || rv < 0 || rv > 2.0 * scale) { bad[j] = 1; break; }
+              q[k] = (uint16_t)rv;
+            }
+          });
+          for (int j = 0; j < bs; ++j) if (bad[j]) integral = false;
+        }
+        if (integral) s2check(rg_s2_qt_block_int(s2, G16.data(), n, bs, 0, scale, NUMTOL, &o));
+        else s2check(rg_s2_qt_block(s2, G.data(), n, bs, 0, NUMTOL, &o));
       } else if (!dense_route) {
         // hard calls stay packed: the 2-bit codes of the analysed samples go to the device as they are (the rows of the file itself
         // when no sample was dropped), the library counts the calls and contracts them on the i8 matrix cores
