@@ -555,6 +555,7 @@ __global__ void k_s2_packed_final(PackedFinal a) {
 // One workgroup per row of uint16 dosages in units of 1 / scale (0xFFFF = missing): balanced base-128 digit planes d_0 .. d_{D-1}
 // (G = sum_k 128^k d_k, d_k in [-64, 63]) and the missing indicator as plane D, zero padded to Np; vstat as for hard calls (exact: the
 // sums stay below 2^53).  planes [D + 1][bs][Np].
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_s2_int_rows(const uint16_t* __restrict__ G, int64_t ld, int64_t n, int64_t Np, int D, int8_t* __restrict__ planes,
                                                      int64_t set_stride, double* __restrict__ vstat, int32_t* __restrict__ total_miss) {
   __shared__ long long red[4][4];
@@ -562,17 +563,32 @@ __global__ __launch_bounds__(256) void k_s2_int_rows(const uint16_t* __restrict_
   const uint16_t* g = G + (int64_t)j * ld;
   int8_t* out = planes + (int64_t)j * Np;
   long long sg = 0, sg2 = 0, no = 0, nz = 0;
-  for (int64_t i = threadIdx.x; i < Np; i += 256) {
-    const unsigned v0 = i < n ? g[i] : 0u;
-    const bool miss = v0 == 0xFFFFu;
-    int v = miss ? 0 : (int)v0;
-    if (i < n && !miss) { sg += v; sg2 += (long long)v * v; ++no; nz += v != 0; }
-    for (int k = 0; k < D; ++k) {
-      const int d = ((v & 127) ^ 64) - 64;
-      out[(int64_t)k * set_stride + i] = (int8_t)d;
-      v = (v - d) >> 7;
+  for (int64_t i0 = (int64_t)threadIdx.x * 8; i0 < Np; i0 += 256 * 8) {      // eight entries per thread: one 16-byte load, one 8-byte store per plane
+    unsigned v8[8];
+    if (VEC && i0 + 8 <= n) {
+      const uint4 w = *reinterpret_cast<const uint4*>(g + i0);
+      v8[0] = w.x & 0xFFFFu; v8[1] = w.x >> 16; v8[2] = w.y & 0xFFFFu; v8[3] = w.y >> 16;
+      v8[4] = w.z & 0xFFFFu; v8[5] = w.z >> 16; v8[6] = w.w & 0xFFFFu; v8[7] = w.w >> 16;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v8[e] = i0 + e < n ? g[i0 + e] : 0u;
     }
-    out[(int64_t)D * set_stride + i] = miss ? 1 : 0;
+    unsigned long long dig[3] = {0ull, 0ull, 0ull}, mbits = 0ull;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool miss = v8[e] == 0xFFFFu;
+      int v = miss ? 0 : (int)v8[e];
+      if (i0 + e < n && !miss) { sg += v; sg2 += (long long)v * v; ++no; nz += v != 0; }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int d = ((v & 127) ^ 64) - 64;
+        dig[k] |= (unsigned long long)(uint8_t)(int8_t)d << (8 * e);
+        v = (v - d) >> 7;
+      }
+      mbits |= (unsigned long long)(miss ? 1u : 0u) << (8 * e);
+    }
+    for (int k = 0; k < D; ++k) *reinterpret_cast<unsigned long long*>(out + (int64_t)k * set_stride + i0) = dig[k];
+    *reinterpret_cast<unsigned long long*>(out + (int64_t)D * set_stride + i0) = mbits;
   }
   long long vals[4] = {sg, sg2, no, nz};
 #pragma unroll
@@ -629,11 +645,13 @@ __global__ void k_s2_beta_from_sums(const double* __restrict__ A, const double* 
 }
 
 // grid (bs, P), 256 threads: over the samples masked for phenotype p (mlist[moff[p] .. moff[p + 1])) of the mean-imputed variant j:
-// corr[(j * P + p) * (C + 2) + c] = sum g~_i x_c(i) (c < C), [C] = sum g~_i^2, [C + 1] = sum (g~_i - x_i . beta_j)^2
-__global__ __launch_bounds__(256) void k_s2_masked_int(const uint16_t* __restrict__ G, int64_t ld, int64_t n, double inv_scale, const double* __restrict__ X,
-                                                       int C, const int32_t* __restrict__ mlist, const int64_t* __restrict__ moff,
+// corr[(j * P + p) * (C + 2) + c] = sum g~_i x_c(i) (c < C), [C] = sum g~_i^2, [C + 1] = sum (g~_i - x_i . beta_j)^2.
+// xl [entry][C]: the covariate rows of the listed samples, compact and C-contiguous (ensure_lists) -- one 8 C-byte read per entry instead
+// of C reads n doubles apart.
+__global__ __launch_bounds__(256) void k_s2_masked_int(const uint16_t* __restrict__ G, int64_t ld, double inv_scale, const double* __restrict__ xl, int C,
+                                                       const int32_t* __restrict__ mlist, const int64_t* __restrict__ moff,
                                                        const double* __restrict__ vstat, const double* __restrict__ beta, int P, double* __restrict__ corr) {
-  __shared__ double red[4][8];
+  __shared__ double red[4][18];
   __shared__ double sbeta[RG_S2_MAX_COV];
   const int j = blockIdx.x, p = blockIdx.y;
   const int64_t e0 = moff[p], e1 = moff[p + 1];
@@ -643,33 +661,37 @@ __global__ __launch_bounds__(256) void k_s2_masked_int(const uint16_t* __restric
   double* out = corr + ((int64_t)j * P + p) * (C + 2);
   if (threadIdx.x < C) sbeta[threadIdx.x] = beta[(int64_t)j * RG_S2_MAX_COV + threadIdx.x];
   __syncthreads();
-  for (int c0 = 0; c0 < C + 2; c0 += 8) {      // eight sums per sweep over the list
-    double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
-      const int64_t i = mlist[e];
-      const unsigned v0 = g[i];
-      const double v = v0 == 0xFFFFu ? mu : (double)v0 * inv_scale;
+  for (int c0 = 0; c0 < C; c0 += 16) {         // sixteen covariates per sweep; the first sweep also carries the two quadratic sums
+    const int nc = min(16, C - c0);
+    double acc[18];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int c = c0 + k;
-        if (c < C) acc[k] = fma(v, X[(int64_t)c * n + i], acc[k]);
-        else if (c == C) acc[k] = fma(v, v, acc[k]);
-        else if (c == C + 1) {
-          double r = v;
-          for (int d = 0; d < C; ++d) r = fma(-X[(int64_t)d * n + i], sbeta[d], r);
-          acc[k] = fma(r, r, acc[k]);
-        }
+    for (int k = 0; k < 18; ++k) acc[k] = 0.0;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+      const unsigned v0 = g[mlist[e]];
+      const double v = v0 == 0xFFFFu ? mu : (double)v0 * inv_scale;
+      const double* x = xl + e * C;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (k < nc) acc[k] = fma(v, x[c0 + k], acc[k]);
+      if (c0 == 0) {
+        double r = v;
+        for (int d = 0; d < C; ++d) r = fma(-x[d], sbeta[d], r);
+        acc[16] = fma(v, v, acc[16]);
+        acc[17] = fma(r, r, acc[17]);
       }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 18; ++k) {
       double v = acc[k];
       for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
       if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
     }
     __syncthreads();
-    if (threadIdx.x < 8 && c0 + (int)threadIdx.x < C + 2)
-      out[c0 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (threadIdx.x < 18) {
+      const double v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+      if ((int)threadIdx.x < nc) out[c0 + threadIdx.x] = v;
+      else if (c0 == 0 && threadIdx.x >= 16) out[C + (threadIdx.x - 16)] = v;
+    }
     __syncthreads();
   }
 }
@@ -715,6 +737,7 @@ struct rg_s2_ctx {
   bool lists_ready = false;
   int32_t* d_mlist = nullptr;
   int64_t* d_moff = nullptr;    // [P + 1]
+  double* d_xl = nullptr;       // [list entries][C]: the listed samples' covariate rows
   void* pbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t pcap[6] = {0, 0, 0, 0, 0, 0};
   int32_t hdr[3] = {0, 0, 0};   // staged {total_miss = 0, bs, 0} of the block in flight
@@ -833,6 +856,15 @@ int ensure_lists(rg_s2_ctx* ctx) {
   S2_HIP(hipMalloc((void**)&ctx->d_mlist, sizeof(int32_t) * std::max<size_t>(1, lst.size())));
   S2_HIP(hipMemcpy(ctx->d_mlist, lst.data(), sizeof(int32_t) * lst.size(), hipMemcpyHostToDevice));
   S2_HIP(hipMemcpy(ctx->d_moff, off.data(), sizeof(int64_t) * (P + 1), hipMemcpyHostToDevice));
+  {  // the listed samples' covariate rows, compact and C-contiguous
+    const int C = ctx->C;
+    std::vector<double> xl(std::max<size_t>(1, lst.size() * C));
+    for (size_t e = 0; e < lst.size(); ++e)
+      for (int c = 0; c < C; ++c) xl[e * C + c] = ctx->hX[(size_t)c * n + lst[e]];
+    if (ctx->d_xl) { S2_HIP(hipFree(ctx->d_xl)); ctx->d_xl = nullptr; }
+    S2_HIP(hipMalloc((void**)&ctx->d_xl, sizeof(double) * xl.size()));
+    S2_HIP(hipMemcpy(ctx->d_xl, xl.data(), sizeof(double) * xl.size(), hipMemcpyHostToDevice));
+  }
   ctx->lists_ready = true;
   return RG_S2_OK;
 }
@@ -889,6 +921,7 @@ void rg_s2_destroy(rg_s2_ctx* ctx) {
     if (ctx->gvsc) (void)hipFree(ctx->gvsc);
     if (ctx->d_mlist) (void)hipFree(ctx->d_mlist);
     if (ctx->d_moff) (void)hipFree(ctx->d_moff);
+    if (ctx->d_xl) (void)hipFree(ctx->d_xl);
     if (ctx->dX) (void)hipFree(ctx->dX);
     if (ctx->dY) (void)hipFree(ctx->dY);
     if (ctx->dM) (void)hipFree(ctx->dM);
@@ -1124,7 +1157,8 @@ int rg_s2_qt_block_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs
   if ((rc = ensure_p(ctx, Q_VAR, (size_t)bs * (6 * sizeof(double) + 2 * sizeof(int32_t))))) return rc;
   if ((rc = ensure_p(ctx, Q_STAT, (size_t)bs * P * (3 * sizeof(double) + sizeof(int32_t))))) return rc;
   if ((rc = ensure(ctx, B_PLANES, (size_t)nset * bs * Np))) return rc;
-  if (!g_on_device && (rc = ensure(ctx, B_G, (size_t)bs * n * sizeof(uint16_t)))) return rc;
+  const int64_t ld8 = (n + 7) / 8 * 8;       // staged rows start on 16-byte boundaries
+  if (!g_on_device && (rc = ensure(ctx, B_G, (size_t)bs * ld8 * sizeof(uint16_t)))) return rc;
   if (masked) {
     if ((rc = ensure(ctx, B_BETA, (size_t)bs * RG_S2_MAX_COV * sizeof(double)))) return rc;
     if ((rc = ensure(ctx, B_CORR, (size_t)bs * P * (C + 2) * sizeof(double)))) return rc;
@@ -1132,9 +1166,9 @@ int rg_s2_qt_block_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs
   const uint16_t* dG = G;
   int64_t ldg = ld;
   if (!g_on_device) {
-    S2_HIP(hipMemcpy2DAsync(ctx->buf[B_G], n * sizeof(uint16_t), G, ld * sizeof(uint16_t), n * sizeof(uint16_t), bs, hipMemcpyHostToDevice, ctx->st));
+    S2_HIP(hipMemcpy2DAsync(ctx->buf[B_G], ld8 * sizeof(uint16_t), G, ld * sizeof(uint16_t), n * sizeof(uint16_t), bs, hipMemcpyHostToDevice, ctx->st));
     dG = (const uint16_t*)ctx->buf[B_G];
-    ldg = n;
+    ldg = ld8;
   }
   int32_t* cnt = (int32_t*)ctx->pbuf[Q_CNT];
   int32_t* total_miss = cnt + (size_t)bs * 4;
@@ -1155,7 +1189,10 @@ int rg_s2_qt_block_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs
   ctx->hdr[0] = 0; ctx->hdr[1] = bs; ctx->hdr[2] = 0;
   S2_HIP(hipMemcpyAsync(total_miss, ctx->hdr, sizeof(ctx->hdr), hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipEventRecord(ctx->e0, ctx->st));
-  hipLaunchKernelGGL(k_s2_int_rows, dim3(bs), dim3(256), 0, ctx->st, dG, ldg, n, Np, D, planes, (int64_t)bs * Np, vstat, total_miss);
+  if (ldg % 8 == 0 && ((uintptr_t)dG & 15) == 0)
+    hipLaunchKernelGGL(k_s2_int_rows<true>, dim3(bs), dim3(256), 0, ctx->st, dG, ldg, n, Np, D, planes, (int64_t)bs * Np, vstat, total_miss);
+  else
+    hipLaunchKernelGGL(k_s2_int_rows<false>, dim3(bs), dim3(256), 0, ctx->st, dG, ldg, n, Np, D, planes, (int64_t)bs * Np, vstat, total_miss);
   rg_launch_xy_i8_planes(ctx->st, planes, (int64_t)bs * Np, nset, d_bs, Cv, n128, seg, ctx->dvd, Np, S);
   // A is laid out with the planes' full column count so that k_s2_packed_final indexes it as for hard calls; only [X | res] are filled
   hipLaunchKernelGGL(k_s2_int_combine, dim3((bs * Cv + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->dvsc, bs, n128, nseg, nset, D, inv_scale, Cv,
@@ -1165,7 +1202,7 @@ int rg_s2_qt_block_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs
     double* beta = (double*)ctx->buf[B_BETA];
     corr = (double*)ctx->buf[B_CORR];
     hipLaunchKernelGGL(k_s2_beta_from_sums, dim3((bs * C + 255) / 256), dim3(256), 0, ctx->st, (const double*)A, (const double*)vstat, inv_scale, bs, C, Cv, beta);
-    hipLaunchKernelGGL(k_s2_masked_int, dim3(bs, P), dim3(256), 0, ctx->st, dG, ldg, n, inv_scale, ctx->dX, C, ctx->d_mlist, ctx->d_moff,
+    hipLaunchKernelGGL(k_s2_masked_int, dim3(bs, P), dim3(256), 0, ctx->st, dG, ldg, inv_scale, (const double*)ctx->d_xl, C, ctx->d_mlist, ctx->d_moff,
                        (const double*)vstat, (const double*)beta, P, corr);
   }
   PackedFinal fa;

@@ -59,6 +59,18 @@ def main(n=200_000, C=10, P=10):
             ms = [s2.contract_packed(rr)["kernel_ms"] for _ in range(4)]
             t = float(np.median(ms[1:]))
             print("contraction primitive (bt)  bs %6d  %8.3f ms  %7.2f M variants/s  (130 columns)" % (bs, t, bs / t / 1e3), flush=True)
+    # integer dosages (8-bit .bgen probabilities as uint16 in units of 1 / 255): two digit planes + the missing indicator
+    for msk, name in ((np.ones((n, P), np.uint8), "complete phenotypes"), (mask2, "masked phenotypes (lists)")):
+        with Step2QT(n, C, P) as s2:
+            s2.set_null(X.T, (res * msk).T, msk.T, scf)
+            for bs in (1024, 4096):
+                hard = rng.binomial(2, 0.2, size=(bs, n))
+                Gi = np.clip(hard * 255 + (rng.random((bs, n)) < 0.4) * rng.integers(-80, 81, size=(bs, n)), 0, 510).astype(np.uint16)
+                ms = [s2.score_block_int(Gi, 255)["kernel_ms"] for _ in range(4)]
+                t = float(np.median(ms[1:]))
+                fp = s2.score_block(Gi[:512].astype(np.float64) / 255.0)["kernel_ms"] if bs == 1024 else None
+                print("integer dosages (scale 255), %-26s bs %6d  %8.3f ms  %7.2f M variants/s%s"
+                      % (name, bs, t, bs / t / 1e3, "" if fp is None else "   (fp64 route: %.3f ms per 512)" % fp), flush=True)
 
 
 if __name__ == "__main__":
