@@ -64,7 +64,8 @@ def test_driver_reproduces_reference_outputs(name, tmp_path):
     if spec:
         from tests.util import synth_dosages, write_plink
         g = synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"])
-        write_plink(S, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+        write_plink(S, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"],
+                    counts=spec.get("counts", False))
     r = subprocess.run([BIN] + [a.format(E=EX, S=S) for a in args] + ["--out", "out"], cwd=d, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     meta = json.load(open(os.path.join(REF_OUT, name, "meta.json")))
