@@ -275,6 +275,8 @@ void rg_launch_xy_i8(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t p
 #define RG_XY_LUT_SQUARE 0x00010004u   // the square of the allele count
 void rg_launch_xy_i8_sums(hipStream_t st, const uint8_t* pk, int64_t pk_ld, const int32_t* d_bs, const int32_t* nmiss, int ncols, int n128,
                           const SegLayout& seg, const int8_t* vd, int64_t Np, unsigned lut0, int32_t* S32);
+void rg_launch_xy_i8_both(hipStream_t st, const uint8_t* pk, int64_t pk_ld, const int32_t* d_bs, int ncols, int n128, const SegLayout& seg,
+                          const int8_t* vd, int64_t Np, unsigned lut0, int32_t* S32);
 void rg_launch_xy_i8_planes(hipStream_t st, const int8_t* aplanes, int64_t a_set_stride, int nset, const int32_t* d_bs, int ncols, int n128,
                             const SegLayout& seg, const int8_t* vd, int64_t Np, int32_t* S32);
 void rg_launch_l0_pred_i8(hipStream_t st, const PredArgs& a, const ChunkTab& c256, int pg, int ngrp, int8_t* planes, double* psc,

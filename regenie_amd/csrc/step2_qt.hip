@@ -1094,7 +1094,13 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   S2_HIP(hipMemcpy2DAsync(pk, ldp, rows, ld, nbytes, bs, rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipEventRecord(ctx->e0, ctx->st));
   hipLaunchKernelGGL(k_s2_rows, dim3(bs), dim3(256), 0, ctx->st, pk, ldp, n, flip ? 1 : 0, cnt, total_miss, vstat);
-  rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, total_miss, Cvt, n128, seg, ctx->dvd, Np, RG_XY_LUT_DOSAGE, S);
+  // a block with a missing call contracts both sets (allele count, missing indicator) in one pass over the rows; the count comes back
+  // from k_s2_rows first (4 bytes, one stream synchronisation: tens of microseconds against the milliseconds of the contraction)
+  int32_t h_miss = 0;
+  S2_HIP(hipMemcpyAsync(&h_miss, total_miss, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
+  S2_HIP(hipStreamSynchronize(ctx->st));
+  if (h_miss > 0) rg_launch_xy_i8_both(ctx->st, pk, ldp, d_bs, Cvt, n128, seg, ctx->dvd, Np, RG_XY_LUT_DOSAGE, S);
+  else rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, total_miss, Cvt, n128, seg, ctx->dvd, Np, RG_XY_LUT_DOSAGE, S);
   hipLaunchKernelGGL(k_s2_combine, dim3((bs * Cvt + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->dvsc, total_miss, bs, n128, nseg, Cvt, A);
   if (masked) {   // sum mask_p g0^2: the square LUT against the mask columns only (the missing-indicator set is skipped: d_zero)
     rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, d_zero, Cvt - gm0 * 16, n128, segB, ctx->dvd + (size_t)gm0 * 16 * 8 * Np, Np, RG_XY_LUT_SQUARE, S + (size_t)ngrp * s_grp);
@@ -1285,7 +1291,11 @@ int rg_s2_contract_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   S2_HIP(hipMemcpy2DAsync(pk, ldp, rows, ld, nbytes, bs, rows_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->st));
   S2_HIP(hipEventRecord(ctx->e0, ctx->st));
   hipLaunchKernelGGL(k_s2_rows, dim3(bs), dim3(256), 0, ctx->st, pk, ldp, n, flip ? 1 : 0, cnt, total_miss, (double*)nullptr);
-  rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, total_miss, ncol, n128, seg, ctx->gvd, Np, RG_XY_LUT_DOSAGE, S);
+  int32_t h_miss = 0;      // as in rg_s2_qt_block_packed: both sets in one pass when the block has a missing call
+  S2_HIP(hipMemcpyAsync(&h_miss, total_miss, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
+  S2_HIP(hipStreamSynchronize(ctx->st));
+  if (h_miss > 0) rg_launch_xy_i8_both(ctx->st, pk, ldp, d_bs, ncol, n128, seg, ctx->gvd, Np, RG_XY_LUT_DOSAGE, S);
+  else rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, total_miss, ncol, n128, seg, ctx->gvd, Np, RG_XY_LUT_DOSAGE, S);
   hipLaunchKernelGGL(k_s2_combine, dim3((bs * ncol + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->gvsc, total_miss, bs, n128, nseg, ncol, A);
   if (nsq > 0) {
     rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, d_zero, nsq, n128, segB, ctx->gvd, Np, RG_XY_LUT_SQUARE, S + (size_t)ngrp * s_grp);

@@ -150,6 +150,100 @@ __global__ __launch_bounds__(256, 4) void k_xy_i8(const uint8_t* __restrict__ pk
       }
 }
 
+// ---- both sets (allele count and missing indicator) of ONE block of rows against ngrp column groups in one pass: the packed rows are
+// read and the digit rows staged once for the two contractions (step2_qt.hip, blocks that have a missing call).
+// S[grp][set][seg][row][col]; grid (n128 / 128, nseg, ngrp) ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_xy_i8_both(const uint8_t* __restrict__ pk, int64_t pk_ld, const int32_t* __restrict__ d_bs, int n128, SegLayout seg,
+                                                       const int8_t* __restrict__ vd, int64_t Np, int ncol_last, unsigned lut0, int32_t* __restrict__ S) {
+  __shared__ __attribute__((aligned(16))) uint8_t sA[2][XT * X_PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t sB[XT * X_PITCH];
+  const int grp = blockIdx.z, f = blockIdx.y, tr = blockIdx.x;
+  const int ncol = grp == (int)gridDim.z - 1 ? ncol_last : 16 * X_NPIECE;
+  const int bs = d_bs[0];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t pos0 = seg.pos_start[f], kbytes = seg.plen[f] / 4;
+  v16i acc[2][2][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0;
+  const int srow = tid >> 1, half = tid & 1;
+  const int arow = tr * XT + srow;
+  const bool validA = arow < bs, validB = srow < ncol;
+  const uint8_t* ga = pk + (int64_t)(validA ? arow : 0) * pk_ld + pos0 / 4 + half * 8;
+  const int8_t* gb = vd + (int64_t)grp * 16 * X_NPIECE * Np + (int64_t)(validB ? srow : 0) * Np + pos0 + half * 32;
+  uint8_t* lrowA0 = sA[0] + srow * X_PITCH + half * 32;
+  uint8_t* lrowA1 = sA[1] + srow * X_PITCH + half * 32;
+  uint8_t* lrowB = sB + srow * X_PITCH + half * 32;
+  uint2 w = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11 -> 0 under both LUTs
+  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+  if (kbytes > 0) {
+    if (validA) w = *reinterpret_cast<const uint2*>(ga);
+    if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb); v0 = src[0]; v1 = src[1]; }
+  }
+  for (int64_t kb = 0; kb < kbytes; kb += 16) {      // 64 positions per step
+    {
+      const unsigned ws[2] = {w.x, w.y};
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        uint4 o, m;
+        o.x = x_expand4(ws[d] & 0xFFu, lut0);          m.x = x_expand4(ws[d] & 0xFFu, X_LUT_MISS);
+        o.y = x_expand4((ws[d] >> 8) & 0xFFu, lut0);   m.y = x_expand4((ws[d] >> 8) & 0xFFu, X_LUT_MISS);
+        o.z = x_expand4((ws[d] >> 16) & 0xFFu, lut0);  m.z = x_expand4((ws[d] >> 16) & 0xFFu, X_LUT_MISS);
+        o.w = x_expand4(ws[d] >> 24, lut0);            m.w = x_expand4(ws[d] >> 24, X_LUT_MISS);
+        *reinterpret_cast<uint4*>(lrowA0 + d * 16) = o;
+        *reinterpret_cast<uint4*>(lrowA1 + d * 16) = m;
+      }
+      *reinterpret_cast<uint4*>(lrowB) = v0;
+      *reinterpret_cast<uint4*>(lrowB + 16) = v1;
+    }
+    __syncthreads();
+    if (kb + 16 < kbytes) {
+      if (validA) w = *reinterpret_cast<const uint2*>(ga + kb + 16);
+      if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb + (kb + 16) * 4); v0 = src[0]; v1 = src[1]; }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      v4i bf[2];
+      const int koff = ks * 32 + (lane >> 5) * 16;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sB + (wc * 64 + j * 32 + (lane & 31)) * X_PITCH + koff);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        v4i af[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sA[q] + (wr * 64 + i * 32 + (lane & 31)) * X_PITCH + koff);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (wc * 64 + j * 32 >= ncol) continue;
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[q][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[q][i][j], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int32_t* Sf = S + ((((int64_t)grp * 2 + q) * seg.nseg + f) * n128) * (int64_t)XT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = tr * XT + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int col = wc * 64 + j * 32 + (lane & 31);
+          Sf[(int64_t)row * XT + col] = acc[q][i][j][r];
+        }
+  }
+}
+
 // ---- the same contraction when the row operand already is int8 (digit planes of integer dosages, step2_qt.hip): A rows are copied like
 // the digit rows.  aplanes [nset][rows][Np]; S[grp][set][seg][row][col]; grid (n128 / 128, nseg, ngrp * nset) --------------------------
 __global__ __launch_bounds__(256, 4) void k_xy_i8_planes(const int8_t* __restrict__ aplanes, int64_t a_set_stride, int nset, const int32_t* __restrict__ d_bs,
@@ -254,6 +348,14 @@ void rg_launch_xy_i8_sums(hipStream_t st, const uint8_t* pk, int64_t pk_ld, cons
   const int ngrp = (ncols + 15) / 16;
   hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, ngrp * 2), dim3(256), 0, st, pk, pk_ld, (int64_t)0, d_bs, nmiss, n128, seg, vd,
                      (int64_t)16 * X_NPIECE * Np, 1, Np, 16 * X_NPIECE, (ncols - (ngrp - 1) * 16) * X_NPIECE, lut0, S32);
+}
+
+// both sets in one pass (same S32 layout as rg_launch_xy_i8_sums)
+void rg_launch_xy_i8_both(hipStream_t st, const uint8_t* pk, int64_t pk_ld, const int32_t* d_bs, int ncols, int n128, const SegLayout& seg,
+                          const int8_t* vd, int64_t Np, unsigned lut0, int32_t* S32) {
+  const int ngrp = (ncols + 15) / 16;
+  hipLaunchKernelGGL(k_xy_i8_both, dim3(n128 / XT, seg.nseg, ngrp), dim3(256), 0, st, pk, pk_ld, d_bs, n128, seg, vd, Np,
+                     (ncols - (ngrp - 1) * 16) * X_NPIECE, lut0, S32);
 }
 
 // int8 row planes against ncols columns: S32 [ngrp][nset][nseg][n128][128]
