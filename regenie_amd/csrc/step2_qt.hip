@@ -764,7 +764,7 @@ int ensure_in(rg_s2_ctx* ctx, void** buf, size_t* cap, int slot, size_t bytes) {
   cap[slot] = bytes;
   return RG_S2_OK;
 }
-// The sample axis (Np, a multiple of 64 * 32) is cut into nseg equal segments, one workgroup per (row tile, segment, column group, set):
+// The sample axis (Np, a multiple of 128 * 32) is cut into nseg equal segments, one workgroup per (row tile, segment, column group, set):
 // enough workgroups to fill the 256 CUs (>= 768), as few segments as that allows -- every segment costs a 64 KB tile of partial sums.
 int pick_segments(int64_t Np, int tiles, int ngrp, SegLayout& seg) {
   int nseg = 1;
@@ -787,7 +787,7 @@ int ensure_planes(rg_s2_ctx* ctx, bool want_mask_cols) {
     const int cm0 = !mask_cols ? cv1 : (cv1 + 15) / 16 * 16, cvt = !mask_cols ? cv1 : cm0 + P;
     if (cvt > 4096) return fail(ctx, RG_S2_ERR_ARG, "covariates x phenotypes with differing missing values > 4096 columns");
     const int ngrp = (cvt + 15) / 16;
-    ctx->Np = (n + 64 * RG_MAX_SEG - 1) / (64 * RG_MAX_SEG) * (64 * RG_MAX_SEG);   // 32 pieces of a multiple of 64 samples
+    ctx->Np = (n + 128 * RG_MAX_SEG - 1) / (128 * RG_MAX_SEG) * (128 * RG_MAX_SEG);   // 32 pieces of a multiple of 128 samples
     for (void** q : {(void**)&ctx->dV, (void**)&ctx->dvd, (void**)&ctx->dvsc, (void**)&ctx->dYtX, (void**)&ctx->dQ, (void**)&ctx->dMsum})
       if (*q) { S2_HIP(hipFree(*q)); *q = nullptr; }
     ctx->Cvt = cvt; ctx->cm0 = cm0;
@@ -1241,7 +1241,7 @@ int rg_s2_set_columns(rg_s2_ctx* ctx, int32_t n_col, const double* cols, int32_t
   const int64_t n = ctx->n;
   S2_HIP(hipSetDevice(ctx->dev));
   const int ngrp = (n_col + 15) / 16;
-  const int64_t Np = (n + 64 * RG_MAX_SEG - 1) / (64 * RG_MAX_SEG) * (64 * RG_MAX_SEG);
+  const int64_t Np = (n + 128 * RG_MAX_SEG - 1) / (128 * RG_MAX_SEG) * (128 * RG_MAX_SEG);
   if (ctx->g_ncol != n_col || !ctx->gV) {
     for (void** q : {(void**)&ctx->gV, (void**)&ctx->gvd, (void**)&ctx->gvsc})
       if (*q) { S2_HIP(hipFree(*q)); *q = nullptr; }
@@ -1267,7 +1267,7 @@ int rg_s2_contract_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   if (!rows || !out || bs < 1 || ld < nbytes) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_contract_packed: bad arguments (need bs >= 1, ld >= ceil(n / 4))");
   S2_HIP(hipSetDevice(ctx->dev));
   const int ncol = ctx->g_ncol, nsq = ctx->g_nsq, ngrp = (ncol + 15) / 16, ngrpB = (nsq + 15) / 16, CvB = ngrpB * 16;
-  const int64_t Np = (n + 64 * RG_MAX_SEG - 1) / (64 * RG_MAX_SEG) * (64 * RG_MAX_SEG), ldp = Np / 4;
+  const int64_t Np = (n + 128 * RG_MAX_SEG - 1) / (128 * RG_MAX_SEG) * (128 * RG_MAX_SEG), ldp = Np / 4;
   const int n128 = (int)((bs + 127) / 128 * 128);
   SegLayout seg, segB;
   const int nseg = pick_segments(Np, n128 / 128, ngrp, seg), nsegB = pick_segments(Np, n128 / 128, std::max(1, ngrpB), segB);

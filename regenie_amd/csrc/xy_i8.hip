@@ -64,8 +64,9 @@ __global__ __launch_bounds__(256, 4) void k_xy_i8(const uint8_t* __restrict__ pk
                                                int64_t vd_blk_stride, int meta_bcast /* 1: every blk reads d_bs[0] / nmiss[0] */, int64_t Np,
                                                int ncol_all /* Cv * 8 <= 128 */, int ncol_last /* >= 0: of the last blk */,
                                                unsigned lut0 /* set 0: RG_XY_LUT_* */, int32_t* __restrict__ S) {
-  __shared__ __attribute__((aligned(16))) uint8_t sA[XT * X_PITCH];
-  __shared__ __attribute__((aligned(16))) uint8_t sB[XT * X_PITCH];
+  constexpr int PITCH = 144;      // 128 positions per step + 16: 16-byte reads of 32 consecutive rows spread over the banks
+  __shared__ __attribute__((aligned(16))) uint8_t sA[XT * PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t sB[XT * PITCH];
   const int blk = blockIdx.z >> 1, set = blockIdx.z & 1, f = blockIdx.y, tr = blockIdx.x;
   const int mb = meta_bcast ? 0 : blk;
   const int ncol = (ncol_last >= 0 && blk == (int)(gridDim.z >> 1) - 1) ? ncol_last : ncol_all;
@@ -87,23 +88,23 @@ __global__ __launch_bounds__(256, 4) void k_xy_i8(const uint8_t* __restrict__ pk
   const int srow = tid >> 1, half = tid & 1;
   const int arow = tr * XT + srow;
   const bool validA = arow < bs;
-  const uint8_t* ga = pk + (int64_t)blk * pk_blk_stride + (int64_t)(validA ? arow : 0) * pk_ld + pos0 / 4 + half * 8;
+  const uint8_t* ga = pk + (int64_t)blk * pk_blk_stride + (int64_t)(validA ? arow : 0) * pk_ld + pos0 / 4 + half * 16;
   const bool validB = srow < ncol;
-  const int8_t* gb = vd + (int64_t)blk * vd_blk_stride + (int64_t)(validB ? srow : 0) * Np + pos0 + half * 32;   // (column, digit) row srow = c * 8 + k of vd [Cv][8][Np]
-  uint8_t* lrowA = sA + srow * X_PITCH + half * 32;
-  uint8_t* lrowB = sB + srow * X_PITCH + half * 32;
-  // the global loads of step kb + 16 are issued before the MFMAs of step kb (registers), so their latency hides behind the math
-  uint2 w = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11 -> 0 under both LUTs
-  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+  const int8_t* gb = vd + (int64_t)blk * vd_blk_stride + (int64_t)(validB ? srow : 0) * Np + pos0 + half * 64;   // (column, digit) row srow = c * 8 + k of vd [Cv][8][Np]
+  uint8_t* lrowA = sA + srow * PITCH + half * 64;
+  uint8_t* lrowB = sB + srow * PITCH + half * 64;
+  // the global loads of step kb + 32 are issued before the MFMAs of step kb (registers), so their latency hides behind the math
+  uint4 w = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11 -> 0 under both LUTs
+  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
   if (kbytes > 0) {
-    if (validA) w = *reinterpret_cast<const uint2*>(ga);
-    if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb); v0 = src[0]; v1 = src[1]; }
+    if (validA) w = *reinterpret_cast<const uint4*>(ga);
+    if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
   }
-  for (int64_t kb = 0; kb < kbytes; kb += 16) {      // 64 positions per step
+  for (int64_t kb = 0; kb < kbytes; kb += 32) {      // 128 positions per step (one barrier pair per 128)
     {
-      const unsigned ws[2] = {w.x, w.y};
+      const unsigned ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-      for (int d = 0; d < 2; ++d) {
+      for (int d = 0; d < 4; ++d) {
         uint4 o;
         o.x = x_expand4(ws[d] & 0xFFu, lut);
         o.y = x_expand4((ws[d] >> 8) & 0xFFu, lut);
@@ -113,20 +114,22 @@ __global__ __launch_bounds__(256, 4) void k_xy_i8(const uint8_t* __restrict__ pk
       }
       *reinterpret_cast<uint4*>(lrowB) = v0;
       *reinterpret_cast<uint4*>(lrowB + 16) = v1;
+      *reinterpret_cast<uint4*>(lrowB + 32) = v2;
+      *reinterpret_cast<uint4*>(lrowB + 48) = v3;
     }
     __syncthreads();
-    if (kb + 16 < kbytes) {
-      if (validA) w = *reinterpret_cast<const uint2*>(ga + kb + 16);
-      if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb + (kb + 16) * 4); v0 = src[0]; v1 = src[1]; }
+    if (kb + 32 < kbytes) {
+      if (validA) w = *reinterpret_cast<const uint4*>(ga + kb + 32);
+      if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb + (kb + 32) * 4); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {
       v4i af[2], bf[2];
       const int koff = ks * 32 + (lane >> 5) * 16;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sA + (wr * 64 + i * 32 + (lane & 31)) * X_PITCH + koff);
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sA + (wr * 64 + i * 32 + (lane & 31)) * PITCH + koff);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sB + (wc * 64 + j * 32 + (lane & 31)) * X_PITCH + koff);
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sB + (wc * 64 + j * 32 + (lane & 31)) * PITCH + koff);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         if (wc * 64 + j * 32 >= ncol) continue;      // a 32-column block past the last (column, digit) pair: nothing but zeros (wave-uniform)
@@ -155,8 +158,9 @@ __global__ __launch_bounds__(256, 4) void k_xy_i8(const uint8_t* __restrict__ pk
 // S[grp][set][seg][row][col]; grid (n128 / 128, nseg, ngrp) ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_xy_i8_both(const uint8_t* __restrict__ pk, int64_t pk_ld, const int32_t* __restrict__ d_bs, int n128, SegLayout seg,
                                                        const int8_t* __restrict__ vd, int64_t Np, int ncol_last, unsigned lut0, int32_t* __restrict__ S) {
-  __shared__ __attribute__((aligned(16))) uint8_t sA[2][XT * X_PITCH];
-  __shared__ __attribute__((aligned(16))) uint8_t sB[XT * X_PITCH];
+  constexpr int PITCH = 144;      // 128 positions per step + 16: 16-byte reads of 32 consecutive rows spread over the banks
+  __shared__ __attribute__((aligned(16))) uint8_t sA[2][XT * PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t sB[XT * PITCH];
   const int grp = blockIdx.z, f = blockIdx.y, tr = blockIdx.x;
   const int ncol = grp == (int)gridDim.z - 1 ? ncol_last : 16 * X_NPIECE;
   const int bs = d_bs[0];
@@ -175,22 +179,22 @@ __global__ __launch_bounds__(256, 2) void k_xy_i8_both(const uint8_t* __restrict
   const int srow = tid >> 1, half = tid & 1;
   const int arow = tr * XT + srow;
   const bool validA = arow < bs, validB = srow < ncol;
-  const uint8_t* ga = pk + (int64_t)(validA ? arow : 0) * pk_ld + pos0 / 4 + half * 8;
-  const int8_t* gb = vd + (int64_t)grp * 16 * X_NPIECE * Np + (int64_t)(validB ? srow : 0) * Np + pos0 + half * 32;
-  uint8_t* lrowA0 = sA[0] + srow * X_PITCH + half * 32;
-  uint8_t* lrowA1 = sA[1] + srow * X_PITCH + half * 32;
-  uint8_t* lrowB = sB + srow * X_PITCH + half * 32;
-  uint2 w = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11 -> 0 under both LUTs
-  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0;
+  const uint8_t* ga = pk + (int64_t)(validA ? arow : 0) * pk_ld + pos0 / 4 + half * 16;
+  const int8_t* gb = vd + (int64_t)grp * 16 * X_NPIECE * Np + (int64_t)(validB ? srow : 0) * Np + pos0 + half * 64;
+  uint8_t* lrowA0 = sA[0] + srow * PITCH + half * 64;
+  uint8_t* lrowA1 = sA[1] + srow * PITCH + half * 64;
+  uint8_t* lrowB = sB + srow * PITCH + half * 64;
+  uint4 w = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11 -> 0 under both LUTs
+  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0;
   if (kbytes > 0) {
-    if (validA) w = *reinterpret_cast<const uint2*>(ga);
-    if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb); v0 = src[0]; v1 = src[1]; }
+    if (validA) w = *reinterpret_cast<const uint4*>(ga);
+    if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
   }
-  for (int64_t kb = 0; kb < kbytes; kb += 16) {      // 64 positions per step
+  for (int64_t kb = 0; kb < kbytes; kb += 32) {      // 128 positions per step (one barrier pair per 128)
     {
-      const unsigned ws[2] = {w.x, w.y};
+      const unsigned ws[4] = {w.x, w.y, w.z, w.w};
 #pragma unroll
-      for (int d = 0; d < 2; ++d) {
+      for (int d = 0; d < 4; ++d) {
         uint4 o, m;
         o.x = x_expand4(ws[d] & 0xFFu, lut0);          m.x = x_expand4(ws[d] & 0xFFu, X_LUT_MISS);
         o.y = x_expand4((ws[d] >> 8) & 0xFFu, lut0);   m.y = x_expand4((ws[d] >> 8) & 0xFFu, X_LUT_MISS);
@@ -201,23 +205,25 @@ __global__ __launch_bounds__(256, 2) void k_xy_i8_both(const uint8_t* __restrict
       }
       *reinterpret_cast<uint4*>(lrowB) = v0;
       *reinterpret_cast<uint4*>(lrowB + 16) = v1;
+      *reinterpret_cast<uint4*>(lrowB + 32) = v2;
+      *reinterpret_cast<uint4*>(lrowB + 48) = v3;
     }
     __syncthreads();
-    if (kb + 16 < kbytes) {
-      if (validA) w = *reinterpret_cast<const uint2*>(ga + kb + 16);
-      if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb + (kb + 16) * 4); v0 = src[0]; v1 = src[1]; }
+    if (kb + 32 < kbytes) {
+      if (validA) w = *reinterpret_cast<const uint4*>(ga + kb + 32);
+      if (validB) { const uint4* src = reinterpret_cast<const uint4*>(gb + (kb + 32) * 4); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 4; ++ks) {
       v4i bf[2];
       const int koff = ks * 32 + (lane >> 5) * 16;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sB + (wc * 64 + j * 32 + (lane & 31)) * X_PITCH + koff);
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sB + (wc * 64 + j * 32 + (lane & 31)) * PITCH + koff);
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         v4i af[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sA[q] + (wr * 64 + i * 32 + (lane & 31)) * X_PITCH + koff);
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sA[q] + (wr * 64 + i * 32 + (lane & 31)) * PITCH + koff);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           if (wc * 64 + j * 32 >= ncol) continue;
