@@ -60,3 +60,44 @@ def test_pvar_psam_gz_fallback(example_dir, tmp_path):
     r, log = _log_until_device(["--step", "1", "--pgen", str(tmp_path / "x"), "--phenoFile", os.path.join(example_dir, "phenotype.txt"),
                                 "--bsize", "100", "--out", str(tmp_path / "o")], str(tmp_path))
     assert "x.psam.gz] n_samples = 500" in log and "x.pvar.gz] n_snps = 1000" in log and "ERROR: incorrectly" not in r.stdout
+
+
+def test_step2_usage_errors(example_dir, tmp_path):
+    """--step 2: what is refused at the command line (before any file or device is touched) and how it is said."""
+    E = example_dir
+    base = ["--step", "2", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"), "--bsize", "200", "--out", "x"]
+
+    def err(extra):
+        r = subprocess.run([BIN] + base + extra, cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0
+        return r.stdout + r.stderr
+
+    assert "option '--pred' is required" in err(["--bt"])
+    for opt in ("--firth", "--spa", "--approx"):
+        assert "Firth / SPA corrections of the binary-trait test are not built" in err(["--bt", "--pred", "p.list", opt])
+    assert "minimum MAC must be at least 0.5" in err(["--qt", "--pred", "p.list", "--minMAC", "0.1"])
+    assert "--step 2 runs on one GPU" in err(["--qt", "--pred", "p.list", "--gpus", "2"])
+
+
+def test_step2_reads_inputs_then_needs_a_gpu(example_dir, tmp_path):
+    """Step 2 on the .bgen example up to the device: the LOCO list and files are parsed (check_blup / blup_read), the variant table
+    carries positions and alleles, and without a GPU the run ends with the library's error, not a CPU fallback."""
+    E = example_dir
+    R = os.path.join(ROOT, "tests", "golden", "ref_outputs", "qt_kfold_3chr")
+    with open(str(tmp_path / "pred.list"), "w") as pl:
+        for k in (1, 2):
+            fn = str(tmp_path / ("ref_%d.loco" % k))
+            open(fn, "wb").write(gzip.open(os.path.join(R, "out_%d.loco.gz" % k), "rb").read())
+            pl.write("Y%d %s\n" % (k, fn))
+    os.symlink(os.path.join(E, "example_3chr.bgen"), str(tmp_path / "ex3.bgen"))
+    args = ["--step", "2", "--bgen", str(tmp_path / "ex3.bgen"), "--sample", os.path.join(E, "example_3chr.sample"), "--phenoFile", os.path.join(E, "phenotype.txt"),
+            "--covarFile", os.path.join(E, "covariates.txt"), "--bsize", "200", "--qt", "--pred", str(tmp_path / "pred.list"), "--out", "s2"]
+    r = subprocess.run([BIN] + args, cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert "n_snps" in r.stdout or "variants" in r.stdout
+    if _no_gpu():
+        assert r.returncode != 0 and "no MI355X / HIP device available" in r.stdout
+        assert not os.path.exists(str(tmp_path / "s2_Y1.regenie")) or os.path.getsize(str(tmp_path / "s2_Y1.regenie")) == 0
+    # a LOCO list that names an unknown file is an error before the device is needed
+    open(str(tmp_path / "bad.list"), "w").write("Y1 %s\nY2 %s\n" % (str(tmp_path / "nope.loco"), str(tmp_path / "ref_2.loco")))
+    r = subprocess.run([BIN] + args[:-4] + ["--pred", str(tmp_path / "bad.list"), "--out", "s3"], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "nope.loco" in r.stdout
