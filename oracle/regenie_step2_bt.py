@@ -80,3 +80,121 @@ def score_ct(g, X, y_raw, mask, null, numtol=NUMTOL):
     stats = float(Gres @ yres) / np.sqrt(denum)
     se = 1.0 / np.sqrt(denum)
     return dict(stats=stats, se=se, bhat=stats * se, chisq=stats * stats)
+
+
+# ---- approximate Firth correction (`--firth --approx`) ---------------------------------------------------------------------------------
+# The reference reaches the maximisers below with a chain of solvers and fall-backs (fit_firth_nr, the pseudo-data IRLS of
+# fit_firth_pseudo, step halving, restarts: Step2_Models.cpp:899-984, :1254-1737) that stop at |modified score| < 50 * numtol (null
+# model) or < numtol_firth = 2.5e-4 (per variant).  The penalised likelihood is strictly concave in the range that matters, so its
+# maximiser is unique: this restatement solves the same equations to machine precision with plain Fisher scoring + step halving, and
+# agrees with regenie's printed numbers to its stopping tolerance (~1e-5 relative on BETA, less on CHISQ).
+
+def _pvec(eta):
+    return orc.get_pvec(eta)
+
+
+def firth_null(y_raw, X, mask, offset, beta_start, maxit=2000):
+    """fit_approx_firth_null / fit_firth_nr with every column free (Step2_Models.cpp:899-984, :1267-1385): maximise
+    l(beta) + 0.5 log |X^T W X| over the covariate effects, the LOCO prediction as offset.  Modified score X^T (y - p + h (0.5 - p)),
+    h = diag of the hat matrix of W^(1/2) X.  Returns beta (None if it does not converge)."""
+    m = mask.astype(bool)
+    Xm, ym, om = X[m], y_raw[m], offset[m]
+
+    def pen_dev(b):
+        p = _pvec(om + Xm @ b)
+        w = p * (1 - p)
+        sign, logdet = np.linalg.slogdet(Xm.T @ (Xm * w[:, None]))
+        return -2.0 * float(np.sum(np.where(ym == 0, np.log(1 - p), np.log(p)))) - logdet, p, w
+
+    beta = np.array(beta_start, dtype=np.float64)
+    dev, p, w = pen_dev(beta)
+    for _ in range(maxit):
+        XtWX = Xm.T @ (Xm * w[:, None])
+        U = Xm * np.sqrt(w)[:, None]
+        h = np.einsum("ij,ij->i", U @ np.linalg.inv(XtWX), U)
+        score = Xm.T @ (ym - p + h * (0.5 - p))
+        if np.abs(score).max() < 1e-10:
+            return beta
+        step = np.linalg.solve(XtWX, score)
+        mx = np.abs(step).max() / 25.0                                # maxstep_null
+        if mx > 1:
+            step = step / mx
+        for _ in range(60):
+            dev_new, p_new, w_new = pen_dev(beta + step)
+            if dev_new < dev + 1e-12:
+                break
+            step = step / 2
+        beta, dev, p, w = beta + step, dev_new, p_new, w_new
+    return None
+
+
+def firth_snp(y_raw, gvec, mask, offset, carriers=None, maxit=500):
+    """fit_firth_logistic_snp_fast with its 1-parameter solvers (Step2_Models.cpp:1158-1253, :1548-1737): the variant's effect with
+    the covariate effects of the null Firth model held in the offset; penalty 0.5 log(sum G^2 w), over the carriers only when
+    `carriers` is given (the reference's fast approximation for sparse variants with MAC < 50, where the entries of G off the
+    carriers are dropped from score and information as well).  Returns (beta, se, lrt) or None."""
+    m = mask.astype(bool)
+
+    def dev_all(b):
+        p = _pvec(offset[m] + gvec[m] * b)
+        return -2.0 * float(np.sum(np.where(y_raw[m] == 0, np.log(1 - p), np.log(p))))
+
+    if carriers is not None:
+        idx = np.asarray(carriers)
+        g, y, o = gvec[idx], y_raw[idx], offset[idx]
+        dev_non = dev_all(0.0) - (-2.0 * float(np.sum(np.where(y == 0, np.log(1 - _pvec(o)), np.log(_pvec(o))))))
+    else:
+        g, y, o = np.where(m, gvec, 0.0), y_raw, offset
+        dev_non = 0.0
+    live = m[idx] if carriers is not None else m
+
+    def state(b):
+        p = _pvec(o + g * b)
+        w = np.where(live, p * (1 - p), 0.0) if carriers is None else p * (1 - p)
+        xtwx = float(np.sum(g * g * w))
+        ll = -2.0 * float(np.sum(np.where(live, np.where(y == 0, np.log(1 - p), np.log(p)), 0.0)))
+        return p, w, xtwx, dev_non + ll - np.log(xtwx)
+
+    # dev0: the deviance of the offset-only model with the penalty of the SAME set of samples (:1206-1218)
+    p0, w0, x0, dev0 = state(0.0)
+    beta = 0.0
+    p, w, xtwx, dev = p0, w0, x0, dev0
+    for _ in range(maxit):
+        h = g * g * w / xtwx
+        score = float(np.sum(np.where(live, g * (y + h * (0.5 - p) - p), 0.0)))
+        if abs(score) < 1e-11:
+            break
+        step = score / xtwx
+        if abs(step) > 5:                                             # maxstep
+            step = 5.0 * np.sign(step)
+        for _ in range(60):
+            p_n, w_n, x_n, dev_n = state(beta + step)
+            if dev_n < dev + 1e-12:
+                break
+            step /= 2
+        beta, p, w, xtwx, dev = beta + step, p_n, w_n, x_n, dev_n
+    else:
+        return None
+    lrt = dev0 - dev
+    if lrt < 0:
+        return None
+    return beta, float(np.sqrt(1.0 / xtwx)), lrt
+
+
+def approx_firth(g, X, y_raw, mask, null, cov_blup_offset, sparse=False, mac=None):
+    """The corrected statistic of one (variant, trait) whose score test exceeded the threshold: check_pval_snp -> run_firth_correction_snp
+    -> fit_firth_logistic_snp_fast (Step2_Models.cpp:1987-2010, :2043-2066).  g: mean-imputed genotype; cov_blup_offset = X beta_null +
+    LOCO prediction (fit_null_firth, :1011-1013).  Returns dict(bhat, se, chisq) or None (TEST_FAIL)."""
+    gs_mask = null["gamma_sqrt"] * mask
+    XG, _ = orc.get_basis(X * gs_mask[:, None])
+    GW = g * gs_mask
+    Gres = GW - XG @ (XG.T @ GW)                                        # :528-531 / :503
+    gvec = Gres / null["gamma_sqrt"]                                    # :2061
+    carriers = None
+    if sparse and mac is not None and mac < 50:                        # :1174-1185
+        carriers = np.flatnonzero((mask > 0) & (g > 1e-4))
+    out = firth_snp(y_raw, gvec, mask, cov_blup_offset, carriers)
+    if out is None:
+        return None
+    beta, se, lrt = out
+    return dict(bhat=beta, se=se, chisq=lrt)

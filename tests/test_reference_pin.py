@@ -374,6 +374,66 @@ def test_step2_ct_oracle_against_reference(tmp_path):
     assert seen == sum(len(refs[ph][1]) for ph in range(P)) == 600
 
 
+def test_step2_bt_approx_firth_oracle_against_reference_and_golden():
+    """`--step 2 --bt --firth --approx --pThresh 0.01` on example.bgen, the command behind the ONE golden output the reference holds
+    (example/test_bin_out_firth_Y1.regenie): null logistic + null Firth model per chromosome, score test, and for |z| above the
+    threshold the 1-parameter Firth fit with the covariate effects in the offset (oracle/regenie_step2_bt.py, exact maximisers).
+    Against the output of oracle/_ref/regenie for both traits (1,000 variants each, ~29 corrected rows) and against the golden
+    file itself."""
+    from oracle import bgen as obg
+    from oracle import regenie_step2_bt as bt
+    from oracle import regenie_step2_qt as s2
+    opt = orc.Step1Options(bed=E("example"), pheno_file=E("phenotype_bin.txt"), covar_file=E("covariates.txt"), bsize=200, bt=True,
+                           remove=(E("fid_iid_to_remove.txt"),), test_mode=True)
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    P = prep.Y.shape[1]
+    loco = []
+    for ph in range(P):
+        hdr, v = read_loco_gz(os.path.join(REF_OUT, "bt_loocv_refcmd", "out_%d.loco.gz" % (ph + 1)))
+        pos = {s: k for k, s in enumerate(hdr)}
+        loco.append(v[:, [pos[i] for i in ids]])
+    refs = [_read_regenie(os.path.join(REF_OUT, "step2", "bt_firth_bgen_Y%d.regenie.gz" % (ph + 1))) for ph in range(P)]
+    golden = _read_regenie(E("test_bin_out_firth_Y1.regenie"))
+    col = {nm: i for i, nm in enumerate(refs[0][0])}
+    X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
+    bg = obg.BgenOracle(E("example.bgen"))
+    keep = ~prep.ind_ignore
+    zthr = 2.5758293035489004                                   # sqrt of the 0.99 quantile of chi-square(1): --pThresh 0.01 (Data.cpp:2119-2120)
+    rows = {ph: {r[col["ID"]]: r for r in refs[ph][1]} for ph in range(P)}
+    grow = {r[col["ID"]]: r for r in golden[1]}
+    nfirth = 0
+    for c in sorted(set(chrom.tolist())):
+        nulls, offs_f = [], []
+        for ph in range(P):
+            nl = bt.null_logistic(Yraw[:, ph], X, mask[:, ph], loco[ph][c - 1], opt)
+            bnull = bt.firth_null(Yraw[:, ph], X, mask[:, ph], loco[ph][c - 1], nl["beta"])
+            assert nl is not None and bnull is not None
+            nulls.append(nl)
+            offs_f.append(X @ bnull + loco[ph][c - 1])           # cov_blup_offset (Step2_Models.cpp:1011-1013)
+        for k in np.flatnonzero(chrom == c):
+            g, _, _ = s2.mean_impute(bg.dosages(int(k))[keep][ia])
+            for ph in range(P):
+                r = rows[ph].get(snp_ids[k])
+                if r is None:
+                    continue
+                m = mask[:, ph].astype(np.float64)
+                out = bt.score_bt(g, X, Yraw[:, ph], m, nulls[ph])
+                corrected = abs(out["stats"]) > zthr
+                if corrected:
+                    out = bt.approx_firth(g, X, Yraw[:, ph], m, nulls[ph], offs_f[ph])
+                    assert out is not None
+                    nfirth += 1
+                for rr, tol in ((r, 5e-5),) + (((grow[snp_ids[k]], 2e-4),) if ph == 0 else ()):
+                    beta, se, chisq, logp = (float(rr[col[nm]]) for nm in ("BETA", "SE", "CHISQ", "LOG10P"))
+                    assert out["bhat"] == pytest.approx(beta, rel=tol, abs=2e-6), (snp_ids[k], ph, corrected)
+                    assert out["se"] == pytest.approx(se, rel=tol)
+                    assert out["chisq"] == pytest.approx(chisq, rel=2 * tol, abs=2e-6)
+                    assert s2.get_logp(out["chisq"]) == pytest.approx(logp, rel=2 * tol, abs=2e-6)
+    assert nfirth >= 25
+
+
 needs_ref_binary = pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")
 
 
