@@ -96,10 +96,16 @@ typedef struct rg_s2_contract_out {
   double* sums;
   double* sq;
   int32_t* counts;
+  double* vstat;   /* rg_s2_contract_int only: [bs][4] sum of the observed entries and of their squares (integer units), observed count,
+                      observed non-zero count -- exact integers held in doubles */
 } rg_s2_contract_out;
 int rg_s2_set_columns(rg_s2_ctx* ctx, int32_t n_col, const double* cols, int32_t n_sq);
 int rg_s2_contract_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32_t bs, int32_t rows_on_device, int32_t flip,
                           const rg_s2_contract_out* out);
+/* The same sums for integer dosages (uint16 rows in units of 1 / scale, 0xFFFF = missing; see rg_s2_qt_block_int), in genotype units:
+ * sums and sq as above (sq in fp64 on the vector units), vstat instead of counts. */
+int rg_s2_contract_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs, int32_t g_on_device, int32_t scale,
+                       const rg_s2_contract_out* out);
 
 /* check_sparse_G's constants (Geno.cpp:3165-3177): n_samples = params.n_samples (every kept sample of the file, >= n; default n),
  * prop_zero_thr = --prop-zero-thr (default 0.5).  zero_count_rule = 0: a variant is sparse when the non-zero entries of its

@@ -605,6 +605,33 @@ __global__ __launch_bounds__(256) void k_s2_int_rows(const uint16_t* __restrict_
   }
 }
 
+// sq[j][q] = sum over the observed entries of (G_i / scale)^2 col_q(i), q < nsq (fp64; the binary-trait test's sum w g^2 for dosages).
+// grid (bs, ceil(nsq / 8)), 256 threads
+__global__ __launch_bounds__(256) void k_s2_int_sq(const uint16_t* __restrict__ G, int64_t ld, int64_t n, int64_t Np, double inv_scale,
+                                                   const double* __restrict__ V, int nsq, double* __restrict__ sq) {
+  __shared__ double red[4][8];
+  const int j = blockIdx.x, q0 = blockIdx.y * 8;
+  const uint16_t* g = G + (int64_t)j * ld;
+  double acc[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int64_t i = threadIdx.x; i < n; i += 256) {
+    const unsigned v0 = g[i];
+    if (v0 == 0xFFFFu) continue;
+    const double v = (double)v0 * inv_scale, v2 = v * v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (q0 + k < nsq) acc[k] = fma(v2, V[(int64_t)(q0 + k) * Np + i], acc[k]);
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    double v = acc[k];
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8 && q0 + (int)threadIdx.x < nsq)
+    sq[(int64_t)j * nsq + q0 + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // out[j][0][c] = vsc[c] / scale * sum_k 128^k (T_k^0 + 128 T_k^1 + 128^2 T_k^2), out[j][1][c] = vsc[c] * sum_k 128^k T_k^D, T_k^s = the sum over
 // the segments of S[c >> 4][s][f][j][(c & 15) * 8 + k] (int64: exact).  thread = (j, c)
 __global__ void k_s2_int_combine(const int32_t* __restrict__ S, const double* __restrict__ vsc, int bs, int n128, int nseg, int nset, int D, double inv_scale,
@@ -1308,6 +1335,73 @@ int rg_s2_contract_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   if (out->counts) S2_HIP(hipMemcpyAsync(out->counts, cnt, sizeof(int32_t) * bs * 4, hipMemcpyDeviceToHost, ctx->st));
   if (out->sq && nsq > 0)     // set 0 of [bs][2][CvB]: the first nsq entries of each row
     S2_HIP(hipMemcpy2DAsync(out->sq, sizeof(double) * nsq, Sq, sizeof(double) * 2 * CvB, sizeof(double) * nsq, bs, hipMemcpyDeviceToHost, ctx->st));
+  S2_HIP(hipStreamSynchronize(ctx->st));
+  float ms = 0.f;
+  S2_HIP(hipEventElapsedTime(&ms, ctx->e0, ctx->e1));
+  ctx->last_ms = ms;
+  return RG_S2_OK;
+}
+
+int rg_s2_contract_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs, int32_t g_on_device, int32_t scale, const rg_s2_contract_out* out) {
+  if (!ctx || !ctx->st) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_contract_int: context was not created");
+  if (ctx->g_ncol < 1) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_contract_int: rg_s2_set_columns has not been called");
+  const int64_t n = ctx->n;
+  if (!G || !out || bs < 1 || ld < n || scale < 1 || scale > 16384)
+    return fail(ctx, RG_S2_ERR_ARG, "rg_s2_contract_int: bad arguments (need bs >= 1, ld >= n, 1 <= scale <= 16384)");
+  S2_HIP(hipSetDevice(ctx->dev));
+  const int ncol = ctx->g_ncol, nsq = ctx->g_nsq, ngrp = (ncol + 15) / 16;
+  const int64_t Np = (n + 128 * RG_MAX_SEG - 1) / (128 * RG_MAX_SEG) * (128 * RG_MAX_SEG);
+  const int D = 2 * scale <= 8127 ? 2 : 3, nset = D + 1;
+  const int n128 = (int)((bs + 127) / 128 * 128);
+  SegLayout seg;
+  int nseg = pick_segments(Np, n128 / 128, ngrp * nset, seg);
+  while (Np / nseg > 262144 && nseg < RG_MAX_SEG) nseg *= 2;
+  if (Np / nseg > 524288) return fail(ctx, RG_S2_ERR_ARG, "rg_s2_contract_int: more than 16.7 million samples");
+  memset(&seg, 0, sizeof(seg));
+  seg.nseg = nseg;
+  for (int f = 0; f < nseg; ++f) { seg.pos_start[f] = f * (Np / nseg); seg.file_start[f] = seg.pos_start[f]; seg.len[f] = Np / nseg; seg.plen[f] = Np / nseg; }
+  enum { Q_PK, Q_CNT, Q_S, Q_A, Q_VAR };
+  enum { B_G, B_PART, B_BETA, B_VAR, B_NOBS, B_STAT, B_CORR, B_PLANES };
+  int rc;
+  if ((rc = ensure_p(ctx, Q_CNT, ((size_t)bs * 4 + 8) * sizeof(int32_t)))) return rc;
+  if ((rc = ensure_p(ctx, Q_S, (size_t)ngrp * nset * nseg * n128 * 128 * sizeof(int32_t)))) return rc;
+  if ((rc = ensure_p(ctx, Q_A, ((size_t)bs * 2 * ncol + (size_t)bs * std::max(1, nsq)) * sizeof(double)))) return rc;
+  if ((rc = ensure_p(ctx, Q_VAR, (size_t)bs * (6 * sizeof(double) + 2 * sizeof(int32_t))))) return rc;
+  if ((rc = ensure(ctx, B_PLANES, (size_t)nset * bs * Np))) return rc;
+  const int64_t ld8 = (n + 7) / 8 * 8;
+  if (!g_on_device && (rc = ensure(ctx, B_G, (size_t)bs * ld8 * sizeof(uint16_t)))) return rc;
+  const uint16_t* dG = G;
+  int64_t ldg = ld;
+  if (!g_on_device) {
+    S2_HIP(hipMemcpy2DAsync(ctx->buf[B_G], ld8 * sizeof(uint16_t), G, ld * sizeof(uint16_t), n * sizeof(uint16_t), bs, hipMemcpyHostToDevice, ctx->st));
+    dG = (const uint16_t*)ctx->buf[B_G];
+    ldg = ld8;
+  }
+  int32_t* cnt = (int32_t*)ctx->pbuf[Q_CNT];
+  int32_t* total_miss = cnt + (size_t)bs * 4;
+  int32_t* d_bs = total_miss + 1;
+  int32_t* S = (int32_t*)ctx->pbuf[Q_S];
+  double* A = (double*)ctx->pbuf[Q_A];
+  double* Sq = A + (size_t)bs * 2 * ncol;
+  double* vstat = (double*)ctx->pbuf[Q_VAR] + (size_t)bs * 2;
+  int8_t* planes = (int8_t*)ctx->buf[B_PLANES];
+  const double inv_scale = 1.0 / (double)scale;
+  ctx->hdr[0] = 0; ctx->hdr[1] = bs; ctx->hdr[2] = 0;
+  S2_HIP(hipMemcpyAsync(total_miss, ctx->hdr, sizeof(ctx->hdr), hipMemcpyHostToDevice, ctx->st));
+  S2_HIP(hipEventRecord(ctx->e0, ctx->st));
+  if (ldg % 8 == 0 && ((uintptr_t)dG & 15) == 0)
+    hipLaunchKernelGGL(k_s2_int_rows<true>, dim3(bs), dim3(256), 0, ctx->st, dG, ldg, n, Np, D, planes, (int64_t)bs * Np, vstat, total_miss);
+  else
+    hipLaunchKernelGGL(k_s2_int_rows<false>, dim3(bs), dim3(256), 0, ctx->st, dG, ldg, n, Np, D, planes, (int64_t)bs * Np, vstat, total_miss);
+  rg_launch_xy_i8_planes(ctx->st, planes, (int64_t)bs * Np, nset, d_bs, ncol, n128, seg, ctx->gvd, Np, S);
+  hipLaunchKernelGGL(k_s2_int_combine, dim3((bs * ncol + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->gvsc, bs, n128, nseg, nset, D, inv_scale, ncol, A);
+  if (nsq > 0)
+    hipLaunchKernelGGL(k_s2_int_sq, dim3(bs, (nsq + 7) / 8), dim3(256), 0, ctx->st, dG, ldg, n, Np, inv_scale, (const double*)ctx->gV, nsq, Sq);
+  S2_HIP(hipEventRecord(ctx->e1, ctx->st));
+  S2_HIP(hipGetLastError());
+  if (out->sums) S2_HIP(hipMemcpyAsync(out->sums, A, sizeof(double) * bs * 2 * ncol, hipMemcpyDeviceToHost, ctx->st));
+  if (out->sq && nsq > 0) S2_HIP(hipMemcpyAsync(out->sq, Sq, sizeof(double) * bs * nsq, hipMemcpyDeviceToHost, ctx->st));
+  if (out->vstat) S2_HIP(hipMemcpyAsync(out->vstat, vstat, sizeof(double) * bs * 4, hipMemcpyDeviceToHost, ctx->st));
   S2_HIP(hipStreamSynchronize(ctx->st));
   float ms = 0.f;
   S2_HIP(hipEventElapsedTime(&ms, ctx->e0, ctx->e1));

@@ -57,6 +57,8 @@ struct Params {
   int max_cat_levels = 10;
   bool rint = false;
   int bsize = 0, cv_folds = 5, n_ridge_l0 = 5, n_ridge_l1 = 5, nchrom = 23, threads = 0;
+  bool firth = false, firth_approx = false, firth_se = false;   // --firth --approx [--firth-se] (step 2, binary traits)
+  double pthresh = 0.05;                                        // --pThresh: score tests below it get the correction
   bool bt = false, ct = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
        print_prs = false, force_step1 = false, lowmem = false, force_qt = false, cc12 = false, gz = false;
   int min_case_count = 10, niter_max = 50, niter_max_line_search = 25, niter_max_ridge = 100;
@@ -357,14 +359,20 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--l1-shared") p.l1_shared = true;
     else if (a == "--pred") p.pred_list = need(i);
     else if (a == "--minMAC") p.min_mac = atof(need(i).c_str());
-    else if (a == "--firth" || a == "--spa" || a == "--approx" || a == "--firth-se")
-      usage_error("'" + a + "': the Firth / SPA corrections of the binary-trait test are not built (the uncorrected score test is: drop the option).");
+    else if (a == "--firth") p.firth = true;
+    else if (a == "--approx") p.firth_approx = true;
+    else if (a == "--firth-se") p.firth_se = true;
+    else if (a == "--pThresh") p.pthresh = atof(need(i).c_str());
+    else if (a == "--spa") usage_error("'--spa': the saddlepoint correction of the binary-trait test is not built (--firth --approx is).");
     else usage_error("unrecognised option '" + a + "'");
   }
   if (p.bt) p.rint = false;  // Regenie.cpp:432
   if (p.step != 1 && p.step != 2) usage_error("specify which mode regenie should be running using option --step.");
   if (p.step == 2) {
     if (p.pred_list.empty()) usage_error("option '--pred' is required (use the _pred.list file written by step 1).");
+    if (p.firth && !p.bt) usage_error("option '--firth' applies to binary traits (--bt).");
+    if (p.firth && !p.firth_approx) usage_error("'--firth' without '--approx': the exact Firth test (covariates refitted per variant) is not built; add --approx.");
+    if (p.firth && !(p.pthresh > 0 && p.pthresh < 1)) usage_error("'--pThresh' must be in (0,1).");
     if (p.min_mac < 0.5) usage_error("minimum MAC must be at least 0.5.");   // Regenie.cpp:1054
     if (p.gpus > 1 || p.force_collectives) usage_error("--step 2 runs on one GPU.");
   }
@@ -450,7 +458,8 @@ bool solve_dense(std::vector<double> A, std::vector<double> b, int n, std::vecto
 // fit_logistic (Step1_Models.cpp:156-222) for one phenotype; offset may be null (zero); eta_out = offset + X beta on success,
 // pv_out (optional) the fitted probabilities
 bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t N, int C, const Params& prm,
-                  bool check_hs_dev, std::vector<double>& eta, const double* offset = nullptr, std::vector<double>* pv_out = nullptr) {
+                  bool check_hs_dev, std::vector<double>& eta, const double* offset = nullptr, std::vector<double>* pv_out = nullptr,
+                  std::vector<double>* beta_out = nullptr) {
   std::vector<double> beta(C, 0.0), betanew(C, 0.0), pv(N), w(N);
   auto dev = [&](const std::vector<double>& pp) {
     double t = 0.0;
@@ -506,6 +515,7 @@ bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t
   }
   if ((diff_dev == 0 || diff_dev >= NUMTOL) && niter > prm.niter_max) return false;
   if (pv_out) *pv_out = pv;
+  if (beta_out) *beta_out = betanew;
   return true;
 }
 
@@ -1360,6 +1370,142 @@ double get_logp(double t) {
 // from the exact dense expression by up to ~10 % on the reference's own example with 14 % missing values; reproducing that
 // approximation needs per-(covariate, trait) accumulators the device kernel does not carry yet.  With complete phenotypes
 // the sparse and dense expressions are the same number, which is what the kernel evaluates.
+// ---- approximate Firth correction of the binary-trait test (--firth --approx) ---------------------------------------------------------
+// regenie reaches the maximisers below through a chain of solvers and fall-backs (fit_firth_nr, the pseudo-data IRLS of fit_firth_pseudo,
+// step halving, restarts: Step2_Models.cpp:899-984, :1254-1737) that stop at |modified score| < 50 * numtol (null model) or < 2.5e-4 (per
+// variant).  The penalised likelihood has one maximiser; here it is found to machine precision by Fisher scoring with step halving on
+// the penalised deviance, which agrees with regenie's printed numbers to its stopping tolerance (1e-5 relative on BETA; the reference
+// and its own golden file differ by as much).
+
+// log |A| and A^-1 of a small SPD matrix (Cholesky); false when not positive definite
+bool spd_logdet_inv(const std::vector<double>& A, int n, double& logdet, std::vector<double>* inv) {
+  std::vector<double> L(A);
+  logdet = 0.0;
+  for (int j = 0; j < n; ++j) {
+    double d = L[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) d -= L[(size_t)j * n + k] * L[(size_t)j * n + k];
+    if (!(d > 0.0)) return false;
+    d = std::sqrt(d);
+    L[(size_t)j * n + j] = d;
+    logdet += 2.0 * std::log(d);
+    for (int i = j + 1; i < n; ++i) {
+      double v = L[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) v -= L[(size_t)i * n + k] * L[(size_t)j * n + k];
+      L[(size_t)i * n + j] = v / d;
+    }
+  }
+  if (inv) {
+    inv->assign((size_t)n * n, 0.0);
+    std::vector<double> col(n);
+    for (int c = 0; c < n; ++c) {   // solve L L^T x = e_c
+      for (int i = 0; i < n; ++i) { double v = i == c ? 1.0 : 0.0; for (int k = 0; k < i; ++k) v -= L[(size_t)i * n + k] * col[k]; col[i] = v / L[(size_t)i * n + i]; }
+      for (int i = n - 1; i >= 0; --i) { double v = col[i]; for (int k = i + 1; k < n; ++k) v -= L[(size_t)k * n + i] * col[k]; col[i] = v / L[(size_t)i * n + i]; }
+      for (int i = 0; i < n; ++i) (*inv)[(size_t)i * n + c] = col[i];
+    }
+  }
+  return true;
+}
+
+// fit_approx_firth_null (Step2_Models.cpp:899-984): maximise l(beta) + 0.5 log |X^T W X| over the covariate effects, offset = LOCO prediction.
+// X [C][n] sample-fastest; beta in: start (the null logistic estimate), out: the maximiser.  false when it does not converge.
+bool firth_null_fit(const double* y, const double* X, const uint8_t* mask, const double* offset, int64_t n, int C, std::vector<double>& beta) {
+  std::vector<double> pv(n), w(n), A((size_t)C * C), Ainv, score(C), step(C), bnew(C), hx(C);
+  auto pen_dev = [&](const std::vector<double>& b, double& dev) {
+    double ll = 0.0;
+    std::fill(A.begin(), A.end(), 0.0);
+    for (int64_t i = 0; i < n; ++i) {
+      if (!mask[i]) continue;
+      double e = offset[i];
+      for (int c = 0; c < C; ++c) e += X[(size_t)c * n + i] * b[c];
+      const double pr = get_pvec1(e);
+      pv[i] = pr; w[i] = pr * (1.0 - pr);
+      ll -= (y[i] == 0.0) ? std::log(1.0 - pr) : std::log(pr);
+      for (int a = 0; a < C; ++a) { const double xa = X[(size_t)a * n + i] * w[i]; for (int c = 0; c <= a; ++c) A[(size_t)a * C + c] += xa * X[(size_t)c * n + i]; }
+    }
+    for (int a = 0; a < C; ++a) for (int c = a + 1; c < C; ++c) A[(size_t)a * C + c] = A[(size_t)c * C + a];
+    double logdet;
+    if (!spd_logdet_inv(A, C, logdet, &Ainv)) return false;
+    dev = 2.0 * ll - logdet;
+    return true;
+  };
+  double dev;
+  if (!pen_dev(beta, dev)) return false;
+  for (int it = 0; it < 2000; ++it) {
+    std::fill(score.begin(), score.end(), 0.0);
+    for (int64_t i = 0; i < n; ++i) {
+      if (!mask[i]) continue;
+      double h = 0.0;                                  // h_i = w_i x_i^T (X^T W X)^-1 x_i
+      for (int a = 0; a < C; ++a) { double t = 0.0; for (int c = 0; c < C; ++c) t += Ainv[(size_t)a * C + c] * X[(size_t)c * n + i]; hx[a] = t; }
+      for (int a = 0; a < C; ++a) h += X[(size_t)a * n + i] * hx[a];
+      h *= w[i];
+      const double u = y[i] - pv[i] + h * (0.5 - pv[i]);
+      for (int a = 0; a < C; ++a) score[a] += X[(size_t)a * n + i] * u;
+    }
+    double smax = 0.0, mx = 0.0;
+    for (int a = 0; a < C; ++a) smax = std::max(smax, std::fabs(score[a]));
+    if (smax < 1e-10) return true;
+    for (int a = 0; a < C; ++a) { double t = 0.0; for (int c = 0; c < C; ++c) t += Ainv[(size_t)a * C + c] * score[c]; step[a] = t; mx = std::max(mx, std::fabs(t) / 25.0); }   // maxstep_null
+    if (mx > 1.0) for (int a = 0; a < C; ++a) step[a] /= mx;
+    double dev_new = dev;
+    bool ok = false;
+    const std::vector<double> Akeep = Ainv;
+    for (int hs = 0; hs < 60; ++hs) {
+      for (int a = 0; a < C; ++a) bnew[a] = beta[a] + step[a];
+      if (pen_dev(bnew, dev_new) && dev_new < dev + 1e-12) { ok = true; break; }
+      for (int a = 0; a < C; ++a) step[a] /= 2.0;
+    }
+    if (!ok) return false;
+    beta = bnew; dev = dev_new;
+  }
+  return false;
+}
+
+// fit_firth_logistic_snp_fast with its one-parameter solvers (Step2_Models.cpp:1158-1253, :1548-1737): the variant's effect with the covariate
+// effects of the null Firth model in the offset; penalty 0.5 log(sum G^2 w).  idx / m: the samples that enter score, information and penalty
+// (every unmasked sample, or the carriers alone in the reference's fast form for sparse variants with MAC < 50); dev_rest: the deviance of
+// the samples left out (it does not depend on beta: their G is taken as 0).  false = TEST_FAIL.
+bool firth_snp_fit(const std::vector<double>& g, const std::vector<double>& y, const std::vector<double>& o, double dev_rest, double& beta, double& se, double& lrt) {
+  const size_t m = g.size();
+  std::vector<double> pv(m), w(m);
+  auto state = [&](double b, double& xtwx, double& dev) {
+    double ll = 0.0;
+    xtwx = 0.0;
+    for (size_t i = 0; i < m; ++i) {
+      const double pr = get_pvec1(o[i] + g[i] * b);
+      pv[i] = pr; w[i] = pr * (1.0 - pr);
+      ll -= (y[i] == 0.0) ? std::log(1.0 - pr) : std::log(pr);
+      xtwx += g[i] * g[i] * w[i];
+    }
+    dev = dev_rest + 2.0 * ll - std::log(xtwx);
+  };
+  double xtwx, dev, dev0;
+  state(0.0, xtwx, dev0);
+  dev = dev0;
+  beta = 0.0;
+  bool conv = false;
+  for (int it = 0; it < 500; ++it) {
+    double score = 0.0;
+    for (size_t i = 0; i < m; ++i) score += g[i] * (y[i] - pv[i] + g[i] * g[i] * w[i] / xtwx * (0.5 - pv[i]));
+    if (std::fabs(score) < 1e-11) { conv = true; break; }
+    double step = score / xtwx;
+    if (std::fabs(step) > 5.0) step = step > 0 ? 5.0 : -5.0;      // maxstep
+    double x_n = xtwx, dev_n = dev;
+    bool ok = false;
+    for (int hs = 0; hs < 60; ++hs) {
+      state(beta + step, x_n, dev_n);
+      if (dev_n < dev + 1e-12) { ok = true; break; }
+      step /= 2.0;
+    }
+    if (!ok) { state(beta, xtwx, dev); conv = std::fabs(score) < 1e-8; break; }
+    beta += step; xtwx = x_n; dev = dev_n;
+  }
+  if (!conv) return false;
+  lrt = dev0 - dev;
+  if (lrt < 0) return false;
+  se = std::sqrt(1.0 / xtwx);
+  return true;
+}
+
 int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   const Params& p = r.p;
   const int64_t N = r.N;
@@ -1384,9 +1530,15 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   // model with the LOCO offset gives p^, w = p^ (1 - p^); the score test of a variant needs, per trait, sum w g~^2, X^T W g~ and
   // g~ . (y - p^) -- contractions of the hard-call row with fixed columns, which rg_s2_contract_packed evaluates on the i8 matrix cores
   const int bt_ncol = P * (C + 3);        // [w_q] (P, also against g^2) | [w_q x_c] (P * C) | [y_q - p^_q] (P) | [mask_q] (P)
-  std::vector<double> bt_cols, bt_xwx_inv, bt_sums, bt_sq;
+  std::vector<double> bt_cols, bt_xwx_inv, bt_sums, bt_sq, bt_vstat;
   std::vector<int32_t> bt_counts;
   std::vector<uint8_t> bt_pass(P, 1), test_ignored;
+  const bool firth = p.bt && p.firth;
+  const double z_thr = firth ? norm_quantile(1.0 - 0.5 * p.pthresh) : 0.0;   // sqrt of the chi-square(1) quantile at 1 - pThresh (Data.cpp:2119-2120)
+  std::vector<double> firth_off;                      // [P][n] cov_blup_offset: X beta_nullFirth + LOCO prediction (fit_null_firth, Step2_Models.cpp:1011-1013)
+  if (firth) firth_off.assign((size_t)P * n, 0.0);
+  std::vector<uint8_t> corrected, corr_fail;          // per (variant, trait) of a block
+  std::vector<double> corr_beta, corr_se, corr_chisq;
   if (glm) { bt_cols.assign((size_t)bt_ncol * n, 0.0); bt_xwx_inv.assign((size_t)P * C * C, 0.0); }
 
   rg_s2_ctx* s2 = nullptr;
@@ -1484,13 +1636,23 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
         const double* yq = Yc.data() + (size_t)q * n;
         const uint8_t* mq = Mc.data() + (size_t)q * n;
         bool ok;
+        std::vector<double> bnull;
         if (p.ct) ok = fit_poisson(yq, Xc.data(), mq, n, C, p, eta, off.data(), &pv);
         else {
-          ok = fit_logistic(yq, Xc.data(), mq, n, C, p, true, eta, off.data(), &pv);
-          if (!ok) ok = fit_logistic(yq, Xc.data(), mq, n, C, p, false, eta, off.data(), &pv);
+          ok = fit_logistic(yq, Xc.data(), mq, n, C, p, true, eta, off.data(), &pv, &bnull);
+          if (!ok) ok = fit_logistic(yq, Xc.data(), mq, n, C, p, false, eta, off.data(), &pv, &bnull);
+        }
+        if (ok && firth) {   // fit_null_firth (Step2_Models.cpp:985-1060): penalised fit of the covariates, start = the unpenalised estimate
+          ok = firth_null_fit(yq, Xc.data(), mq, off.data(), n, C, bnull);
+          if (!ok) sout << "\n     WARNING: null Firth failed for phenotype '" << r.pheno_names[q] << "' (it will be skipped).";
+          for (int64_t k = 0; ok && k < n; ++k) {
+            double e = blup[an[k]];
+            for (int c = 0; c < C; ++c) e += Xc[(size_t)c * n + k] * bnull[c];
+            firth_off[(size_t)q * n + k] = e;
+          }
         }
         bt_pass[q] = ok ? 1 : 0;
-        if (!ok) { sout << "\n     WARNING: " << (p.ct ? "poisson" : "logistic") << " regression did not converge for phenotype '" << r.pheno_names[q] << "'."; continue; }
+        if (!ok) { if (!(firth && !bnull.empty())) sout << "\n     WARNING: " << (p.ct ? "poisson" : "logistic") << " regression did not converge for phenotype '" << r.pheno_names[q] << "'."; continue; }
         std::vector<double> A((size_t)C * C, 0.0);
         double* cw = bt_cols.data() + (size_t)q * n;
         double* cr = bt_cols.data() + (size_t)(P + P * C + q) * n;
@@ -1569,40 +1731,112 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       memset(&o, 0, sizeof(o));
       o.stats = stats.data(); o.bhat = bhat.data(); o.scale_fac = sfac.data(); o.ignored = ign.data();
       test_ignored.assign((size_t)bs * P, 0);
-      if (glm) {
-        if (in == In::Dosage) throw std::runtime_error("--step 2 --bt / --ct reads hard calls (--bed, or a .pgen without dosages): the binary / count trait test on dosages is not built.");
-        const uint8_t* src = rows.data();
-        int64_t ld = r.bpr;
-        if (!identity) {
-          ld = (n + 3) / 4;
-          packed.assign((size_t)bs * ld, 0);
+      bool integral = false;
+      const int dscale = r.bgenh ? 255 : 16384;
+      if (in == In::Dosage) {
+        // dosages: the analysed samples' doubles, allele totals, the info-score numerator and the per-trait corrections on the host
+        // (parseSnpfromBGEN / readChunkFromPGENFileToG with update_trait_counts, Geno.cpp:2948-2959), the test on the fp64 route
+        G.assign((size_t)bs * n, 0.0);
+        info_num.assign(bs, 0.0);
+        if (any_missing || glm) { af_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0); info_t.assign((size_t)bs * P, 0.0); }
+        parallel_for(bs, nthreads, [&](int j) {
+          const double* d = dbuf.data() + (size_t)j * r.n_file;
+          const double* iv = r.bgenh ? ibuf.data() + (size_t)j * r.n_file : nullptr;
+          double* g = G.data() + (size_t)j * n;
+          double tot = 0.0, inf = 0.0; int64_t ns = 0;
+          for (int64_t k = 0; k < n; ++k) {
+            const int64_t i = file_idx[k];
+            const double v = d[i];
+            g[k] = v;
+            if (v == -3.0) continue;
+            const double e = iv ? iv[i] : v * v;
+            tot += v; inf += e; ++ns;
+            if ((any_missing || glm) && has_missing[k])
+              for (int q = 0; q < P; ++q)
+                if (!Mc[(size_t)q * n + k]) { af_t[(size_t)j * P + q] -= v; ns_t[(size_t)j * P + q] -= 1; info_t[(size_t)j * P + q] -= e; }
+          }
+          total[j] = tot; ns1[j] = ns; info_num[j] = inf;
+          if (std::min(tot, 2.0 * ns - tot) < p.min_mac) variant_ignored[j] = 1;      // compute_mac (Geno.cpp:3077-3108), autosomes
+        });
+        // 8-bit .bgen probabilities and .pgen dosages are integers in units of 1 / 255 and 1 / 16384: as uint16 rows they take the
+        // integer route of the library (digit planes on the i8 matrix cores, 2 B per genotype over PCIe); anything else, or
+        // RG_S2_DENSE=1, the fp64 route
+        integral = !dense_route || glm;
+        if (integral) {
+          G16.resize((size_t)bs * n);
+          std::vector<uint8_t> bad(bs, 0);
           parallel_for(bs, nthreads, [&](int j) {
-            const uint8_t* row = rows.data() + (size_t)j * r.bpr;
-            uint8_t* dst = packed.data() + (size_t)j * ld;
+            const double* g = G.data() + (size_t)j * n;
+            uint16_t* q = G16.data() + (size_t)j * n;
             for (int64_t k = 0; k < n; ++k) {
-              const int64_t i = file_idx[k];
-              dst[k >> 2] |= (uint8_t)(((row[i >> 2] >> (2 * (i & 3))) & 3) << (2 * (k & 3)));
+              if (g[k] == -3.0) { q[k] = 0xFFFFu; continue; }
+              const double v = g[k] * dscale, rv = std::nearbyint(v);
+              if (std::fabs(v - rv) > 1e-6 || rv < 0 || rv > 2.0 * dscale) { bad[j] = 1; break; }
+              q[k] = (uint16_t)rv;
             }
           });
-          src = packed.data();
+          for (int j = 0; j < bs; ++j) if (bad[j]) integral = false;
         }
-        bt_sums.resize((size_t)bs * 2 * bt_ncol); bt_sq.resize((size_t)bs * P); bt_counts.resize((size_t)bs * 4);
+      }
+      std::vector<double> af_d; std::vector<int64_t> ns_d;
+      if (glm && in == In::Dosage) { af_d = af_t; ns_d = ns_t; }
+      if (glm) {
+        // the contractions of the block: hard calls as packed rows, dosages as integer rows (digit planes on the i8 matrix cores either way)
+        bt_sums.resize((size_t)bs * 2 * bt_ncol); bt_sq.resize((size_t)bs * P); bt_counts.resize((size_t)bs * 4); bt_vstat.resize((size_t)bs * 4);
         rg_s2_contract_out co;
-        co.sums = bt_sums.data(); co.sq = bt_sq.data(); co.counts = bt_counts.data();
-        s2check(rg_s2_contract_packed(s2, src, ld, bs, 0, flip, &co));
+        memset(&co, 0, sizeof(co));
+        co.sums = bt_sums.data(); co.sq = bt_sq.data();
+        const uint8_t* src = rows.data();
+        int64_t ld = r.bpr;
+        if (in == In::Dosage) {
+          if (!integral) throw std::runtime_error("--step 2 --bt / --ct on dosages that are not integer multiples of 1/" + std::to_string(dscale) + " is not built.");
+          co.vstat = bt_vstat.data();
+          s2check(rg_s2_contract_int(s2, G16.data(), n, bs, 0, dscale, &co));
+        } else {
+          if (!identity) {
+            ld = (n + 3) / 4;
+            packed.assign((size_t)bs * ld, 0);
+            parallel_for(bs, nthreads, [&](int j) {
+              const uint8_t* row = rows.data() + (size_t)j * r.bpr;
+              uint8_t* dst = packed.data() + (size_t)j * ld;
+              for (int64_t k = 0; k < n; ++k) {
+                const int64_t i = file_idx[k];
+                dst[k >> 2] |= (uint8_t)(((row[i >> 2] >> (2 * (i & 3))) & 3) << (2 * (k & 3)));
+              }
+            });
+            src = packed.data();
+          }
+          co.counts = bt_counts.data();
+          s2check(rg_s2_contract_packed(s2, src, ld, bs, 0, flip, &co));
+        }
         af_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0);
+        std::vector<double> mu_v(bs, 0.0);
+        std::vector<uint8_t> sparse_v(bs, 0);
         parallel_for(bs, nthreads, [&](int j) {
-          const double n1 = bt_counts[(size_t)j * 4], n2 = bt_counts[(size_t)j * 4 + 1], nm = bt_counts[(size_t)j * 4 + 2];
-          const double nobs = (double)n - nm, tot = n1 + 2.0 * n2;
+          double nobs, tot, nnz;        // observed samples, allele total, observed non-zero entries
+          if (in == In::Dosage) { nobs = bt_vstat[(size_t)j * 4 + 2]; tot = bt_vstat[(size_t)j * 4] / dscale; nnz = bt_vstat[(size_t)j * 4 + 3]; }
+          else {
+            const double n1 = bt_counts[(size_t)j * 4], n2 = bt_counts[(size_t)j * 4 + 1], nm = bt_counts[(size_t)j * 4 + 2];
+            nobs = (double)n - nm; tot = n1 + 2.0 * n2; nnz = n1 + n2;
+          }
           const double mu = nobs > 0 ? tot / nobs : 0.0;
-          ns1[j] = (int64_t)nobs; total[j] = tot; ign[j] = nobs > 0 ? 0 : 1; sfac[j] = 1.0;
-          if (std::min(tot, 2.0 * nobs - tot) < p.min_mac) variant_ignored[j] = 1;
+          mu_v[j] = mu;
+          // check_sparse_G (Geno.cpp:3165-3177): the approximate Firth fit restricts rare sparse variants to their carriers
+          sparse_v[j] = r.pgen ? (nobs - nnz) >= 0.5 * N : (nnz + (mu != 0.0 ? (double)n - nobs : 0.0)) <= 0.5 * N;
+          if (in != In::Dosage) { ns1[j] = (int64_t)nobs; total[j] = tot; }   // (dosages: the host loop above has them, summed as the reference sums)
+          ign[j] = nobs > 0 ? 0 : 1; sfac[j] = 1.0;
+          if (std::min(total[j], 2.0 * ns1[j] - total[j]) < p.min_mac) variant_ignored[j] = 1;
           const double* s0 = bt_sums.data() + (size_t)j * 2 * bt_ncol;
           const double* s1 = s0 + bt_ncol;
           for (int q = 0; q < P; ++q) {
             const int cm = P + P * C + P + q, cr = P + P * C + q;
-            af_t[(size_t)j * P + q] = std::nearbyint(s0[cm]) - tot;                                  // per-trait allele and sample counts
-            ns_t[(size_t)j * P + q] = (int64_t)std::nearbyint(r.neff[q] - s1[cm]) - ns1[j];
+            if (in != In::Dosage) {                                                                  // per-trait allele and sample counts
+              af_t[(size_t)j * P + q] = std::nearbyint(s0[cm]) - tot;
+              ns_t[(size_t)j * P + q] = (int64_t)std::nearbyint(r.neff[q] - s1[cm]) - ns1[j];
+            } else {
+              af_t[(size_t)j * P + q] = af_d[(size_t)j * P + q];
+              ns_t[(size_t)j * P + q] = ns_d[(size_t)j * P + q];
+            }
             if (!bt_pass[q]) { test_ignored[(size_t)j * P + q] = 1; continue; }
             const double sw2 = bt_sq[(size_t)j * P + q] + mu * mu * s1[q];                          // sum w g~^2
             double quad = 0.0;                                                                       // (X^T W g~)^T (X^T W X)^-1 (X^T W g~)
@@ -1620,52 +1854,65 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
             bhat[(size_t)j * P + q] = st / sd;                                                      // get_sumstats (Step2_Models.cpp:2031-2041)
           }
         });
-      } else if (in == In::Dosage) {
-        // dosages: the analysed samples' doubles, allele totals, the info-score numerator and the per-trait corrections on the host
-        // (parseSnpfromBGEN / readChunkFromPGENFileToG with update_trait_counts, Geno.cpp:2948-2959), the test on the fp64 route
-        G.assign((size_t)bs * n, 0.0);
-        info_num.assign(bs, 0.0);
-        if (any_missing) { af_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0); info_t.assign((size_t)bs * P, 0.0); }
-        parallel_for(bs, nthreads, [&](int j) {
-          const double* d = dbuf.data() + (size_t)j * r.n_file;
-          const double* iv = r.bgenh ? ibuf.data() + (size_t)j * r.n_file : nullptr;
-          double* g = G.data() + (size_t)j * n;
-          double tot = 0.0, inf = 0.0; int64_t ns = 0;
-          for (int64_t k = 0; k < n; ++k) {
-            const int64_t i = file_idx[k];
-            const double v = d[i];
-            g[k] = v;
-            if (v == -3.0) continue;
-            const double e = iv ? iv[i] : v * v;
-            tot += v; inf += e; ++ns;
-            if (any_missing && has_missing[k])
-              for (int q = 0; q < P; ++q)
-                if (!Mc[(size_t)q * n + k]) { af_t[(size_t)j * P + q] -= v; ns_t[(size_t)j * P + q] -= 1; info_t[(size_t)j * P + q] -= e; }
-          }
-          total[j] = tot; ns1[j] = ns; info_num[j] = inf;
-          if (std::min(tot, 2.0 * ns - tot) < p.min_mac) variant_ignored[j] = 1;      // compute_mac (Geno.cpp:3077-3108), autosomes
-        });
-        // 8-bit .bgen probabilities and .pgen dosages are integers in units of 1 / 255 and 1 / 16384: as uint16 rows they take the
-        // integer route of the library (digit planes on the i8 matrix cores, 2 B per genotype over PCIe); anything else, or
-        // RG_S2_DENSE=1, the fp64 route
-        const int scale = r.bgenh ? 255 : 16384;
-        bool integral = !dense_route;
-        if (integral) {
-          G16.resize((size_t)bs * n);
-          std::vector<uint8_t> bad(bs, 0);
-          parallel_for(bs, nthreads, [&](int j) {
-            const double* g = G.data() + (size_t)j * n;
-            uint16_t* q = G16.data() + (size_t)j * n;
-            for (int64_t k = 0; k < n; ++k) {
-              if (g[k] == -3.0) { q[k] = 0xFFFFu; continue; }
-              const double v = g[k] * scale, rv = std::nearbyint(v);
-              if (std::fabs(v - rv) > 1e-6 || rv < 0 || rv > 2.0 * scale) { bad[j] = 1; break; }
-              q[k] = (uint16_t)rv;
+        if (firth) {
+          // check_pval_snp (Step2_Models.cpp:1987-2029): |z| above the threshold -> fit_firth_logistic_snp_fast on Gres / Gamma_sqrt with the
+          // null Firth model's covariate effects in the offset.  The few flagged (variant, trait) pairs are fitted on the host threads.
+          corrected.assign((size_t)bs * P, 0); corr_fail.assign((size_t)bs * P, 0);
+          corr_beta.assign((size_t)bs * P, 0.0); corr_se.assign((size_t)bs * P, 0.0); corr_chisq.assign((size_t)bs * P, 0.0);
+          std::vector<int> todo;
+          for (int j = 0; j < bs; ++j)
+            for (int q = 0; q < P; ++q)
+              if (!variant_ignored[j] && !ign[j] && !test_ignored[(size_t)j * P + q] && std::fabs(stats[(size_t)j * P + q]) > z_thr) todo.push_back(j * P + q);
+          parallel_for((int)todo.size(), nthreads, [&](int t) {
+            const int j = todo[t] / P, q = todo[t] % P;
+            const double mu = mu_v[j];
+            std::vector<double> gt(n);                // the mean-imputed genotype of the analysed samples
+            if (in == In::Dosage) { const double* g = G.data() + (size_t)j * n; for (int64_t k = 0; k < n; ++k) gt[k] = g[k] == -3.0 ? mu : g[k]; }
+            else {
+              const uint8_t* row = src + (size_t)j * ld;
+              for (int64_t k = 0; k < n; ++k) {
+                double hc = lut[(row[k >> 2] >> (2 * (k & 3))) & 3];
+                if (flip && hc != -3.0) hc = 2.0 - hc;
+                gt[k] = hc == -3.0 ? mu : hc;
+              }
             }
+            // Gres / Gamma_sqrt = g~ - x^T (X^T W X)^-1 X^T W g~ on the unmasked samples (compute_score_bt :503, :528-531; :2061)
+            const double* s0 = bt_sums.data() + (size_t)j * 2 * bt_ncol;
+            const double* s1 = s0 + bt_ncol;
+            const double* inv = bt_xwx_inv.data() + (size_t)q * C * C;
+            std::vector<double> tc(C, 0.0);
+            for (int a = 0; a < C; ++a)
+              for (int c = 0; c < C; ++c) tc[a] += inv[(size_t)a * C + c] * (s0[P + q * C + c] + mu * s1[P + q * C + c]);
+            const uint8_t* mq = Mc.data() + (size_t)q * n;
+            const double* yq = Yc.data() + (size_t)q * n;
+            const double* oq = firth_off.data() + (size_t)q * n;
+            const double tq = total[j] + af_t[(size_t)j * P + q];
+            const double nsq = (double)(ns1[j] + ns_t[(size_t)j * P + q]);
+            const bool fast = sparse_v[j] && std::min(tq, 2.0 * nsq - tq) < 50.0;        // fit_firth_logistic_snp_fast :1173-1185: carriers only
+            std::vector<double> gv, yv, ov;
+            double dev_rest = 0.0;
+            for (int64_t k = 0; k < n; ++k) {
+              if (!mq[k]) continue;
+              if (fast && !(gt[k] > 1e-4)) {           // a non-carrier: its G is dropped, its deviance is a constant
+                const double pr = get_pvec1(oq[k]);
+                dev_rest -= 2.0 * ((yq[k] == 0.0) ? std::log(1.0 - pr) : std::log(pr));
+                continue;
+              }
+              double v = gt[k];
+              for (int c = 0; c < C; ++c) v -= Xc[(size_t)c * n + k] * tc[c];
+              gv.push_back(v); yv.push_back(yq[k]); ov.push_back(oq[k]);
+            }
+            double b = 0.0, se = 0.0, lrt = 0.0;
+            const bool okf = !gv.empty() && firth_snp_fit(gv, yv, ov, dev_rest, b, se, lrt);
+            corrected[(size_t)j * P + q] = 1;
+            if (!okf) { corr_fail[(size_t)j * P + q] = 1; return; }
+            corr_beta[(size_t)j * P + q] = b;
+            corr_chisq[(size_t)j * P + q] = lrt;
+            corr_se[(size_t)j * P + q] = (p.firth_se && lrt > 0) ? std::fabs(b) / std::sqrt(lrt) : se;     // --firth-se: back_correct_se (:2008-2009)
           });
-          for (int j = 0; j < bs; ++j) if (bad[j]) integral = false;
         }
-        if (integral) s2check(rg_s2_qt_block_int(s2, G16.data(), n, bs, 0, scale, NUMTOL, &o));
+      } else if (in == In::Dosage) {
+        if (integral) s2check(rg_s2_qt_block_int(s2, G16.data(), n, bs, 0, dscale, NUMTOL, &o));
         else s2check(rg_s2_qt_block(s2, G.data(), n, bs, 0, NUMTOL, &o));
       } else if (!dense_route) {
         // hard calls stay packed: the 2-bit codes of the analysed samples go to the device as they are (the rows of the file itself
@@ -1752,17 +1999,23 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
           double info = 1.0;     // compute_aaf_info (Geno.cpp:3132-3141): IMPUTE info for .bgen, MaCH r2 for .pgen dosages
           if (show_info && af != 0.0 && af != 1.0)
             info = r.bgenh ? 1.0 - infq / (2.0 * nsq * af * (1.0 - af)) : (infq / nsq - 4.0 * af * af) / (2.0 * af * (1.0 - af));
-          const double st = stats[(size_t)j * P + q], bh = bhat[(size_t)j * P + q];
-          const double se = bh / st, chisq = st * st, logp = get_logp(chisq);
+          const double st = stats[(size_t)j * P + q];
+          double bh = bhat[(size_t)j * P + q], se = bh / st, chisq = st * st;
+          bool test_fail = false;
+          if (firth && corrected[(size_t)j * P + q]) {
+            if (corr_fail[(size_t)j * P + q]) test_fail = true;                    // get_sumstats(true, ...): the score test's BETA / SE, no p-value
+            else { bh = corr_beta[(size_t)j * P + q]; se = corr_se[(size_t)j * P + q]; chisq = corr_chisq[(size_t)j * P + q]; }
+          }
+          const double logp = get_logp(chisq);
           std::ostringstream ln;
           ln << head.str() << af << " ";
           if (show_info) ln << info << " ";
           ln << nsq << " ADD ";
           if (se >= 0 && !std::isnan(se)) ln << bh << ' ' << se;
           else ln << "NA NA";
-          if (chisq >= 0 && !std::isnan(logp)) ln << ' ' << chisq << ' ' << logp;
+          if (chisq >= 0 && !std::isnan(logp) && !test_fail) ln << ' ' << chisq << ' ' << logp;
           else ln << " NA NA";
-          ln << " NA\n";
+          ln << (test_fail ? " TEST_FAIL\n" : " NA\n");
           *ofs[q] << ln.str();
           ++n_tested;
         }

@@ -18,7 +18,7 @@ class _QtOut(C.Structure):
 
 
 class _ContractOut(C.Structure):
-    _fields_ = [("sums", C.c_void_p), ("sq", C.c_void_p), ("counts", C.c_void_p)]
+    _fields_ = [("sums", C.c_void_p), ("sq", C.c_void_p), ("counts", C.c_void_p), ("vstat", C.c_void_p)]
 
 
 class Step2QT:
@@ -148,7 +148,18 @@ class Step2QT:
         rows = np.ascontiguousarray(rows, dtype=np.uint8)
         bs = rows.shape[0]
         res = {"sums": np.zeros((bs, 2, self._ncol)), "sq": np.zeros((bs, self._nsq)), "counts": np.zeros((bs, 4), np.int32)}
-        out = _ContractOut(res["sums"].ctypes.data, res["sq"].ctypes.data if self._nsq else None, res["counts"].ctypes.data)
+        out = _ContractOut(res["sums"].ctypes.data, res["sq"].ctypes.data if self._nsq else None, res["counts"].ctypes.data, None)
         self._check(self.lib.rg_s2_contract_packed(self.h, rows.ctypes.data, rows.shape[1], bs, 0, 1 if flip else 0, C.byref(out)))
+        res["kernel_ms"] = self.lib.rg_s2_last_kernel_ms(self.h)
+        return res
+
+    def contract_int(self, G: np.ndarray, scale: int) -> dict:
+        """The same sums for integer dosages (uint16, units of 1 / scale, 0xFFFF = missing), in genotype units; vstat [bs][4] = sum,
+        sum of squares (integer units), observed count, observed non-zero count."""
+        G = np.ascontiguousarray(G, dtype=np.uint16)
+        bs = G.shape[0]
+        res = {"sums": np.zeros((bs, 2, self._ncol)), "sq": np.zeros((bs, self._nsq)), "vstat": np.zeros((bs, 4))}
+        out = _ContractOut(res["sums"].ctypes.data, res["sq"].ctypes.data if self._nsq else None, None, res["vstat"].ctypes.data)
+        self._check(self.lib.rg_s2_contract_int(self.h, G.ctypes.data, G.shape[1], bs, 0, int(scale), C.byref(out)))
         res["kernel_ms"] = self.lib.rg_s2_last_kernel_ms(self.h)
         return res

@@ -73,8 +73,9 @@ def test_step2_usage_errors(example_dir, tmp_path):
         return r.stdout + r.stderr
 
     assert "option '--pred' is required" in err(["--bt"])
-    for opt in ("--firth", "--spa", "--approx"):
-        assert "Firth / SPA corrections of the binary-trait test are not built" in err(["--bt", "--pred", "p.list", opt])
+    assert "exact Firth test" in err(["--bt", "--pred", "p.list", "--firth"])
+    assert "saddlepoint correction" in err(["--bt", "--pred", "p.list", "--spa"])
+    assert "applies to binary traits" in err(["--qt", "--pred", "p.list", "--firth", "--approx"])
     assert "minimum MAC must be at least 0.5" in err(["--qt", "--pred", "p.list", "--minMAC", "0.1"])
     assert "--step 2 runs on one GPU" in err(["--qt", "--pred", "p.list", "--gpus", "2"])
 

@@ -627,6 +627,46 @@ def test_cli_step2_bt_score_test_against_reference_output(example_dir, tmp_path)
         assert same >= 0.9 * (len(ref) - 1), same
 
 
+def test_cli_step2_bt_approx_firth_reproduces_the_reference_held_golden(example_dir, tmp_path):
+    """The documented Step-2 command of the reference (docs/docs/options.md:36-53: --step 2 --bgen example.bgen --bt --firth --approx
+    --pThresh 0.01 --remove ...) fed by regenie's own Step-1 LOCO files: Y1 against example/test_bin_out_firth_Y1.regenie, the one
+    golden output the reference holds, Y2 against the output of oracle/_ref/regenie.  Binary-trait score test on 8-bit .bgen dosages
+    (integer route of the contraction primitive) + null Firth model per chromosome + the 1-parameter Firth fit of the ~3 % of tests
+    whose |z| exceeds the threshold.  Rows without the correction to the printed digits; corrected rows to regenie's own stopping
+    tolerance (its build and its golden file differ by 2e-5 there)."""
+    import gzip
+    E = example_dir
+    R = os.path.join(ROOT, "tests", "golden", "ref_outputs")
+    with open(str(tmp_path / "pred.list"), "w") as pl:
+        for k in (1, 2):
+            fn = str(tmp_path / ("ref_%d.loco" % k))
+            open(fn, "wb").write(gzip.open(os.path.join(R, "bt_loocv_refcmd", "out_%d.loco.gz" % k), "rb").read())
+            pl.write("Y%d %s\n" % (k, fn))
+    r = _run(["--step", "2", "--bgen", os.path.join(E, "example.bgen"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"),
+              "--covarFile", os.path.join(E, "covariates.txt"), "--remove", os.path.join(E, "fid_iid_to_remove.txt"), "--bsize", "200", "--bt",
+              "--firth", "--approx", "--pThresh", "0.01", "--pred", str(tmp_path / "pred.list"), "--out", "s2"], str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    refs = {1: open(os.path.join(E, "test_bin_out_firth_Y1.regenie")).read().splitlines(),
+            2: gzip.open(os.path.join(R, "step2", "bt_firth_bgen_Y2.regenie.gz"), "rt").read().splitlines()}
+    plain = {k: gzip.open(os.path.join(R, "step2", "bt_score_bed_Y%d.regenie.gz" % k), "rt").read().splitlines() for k in (1, 2)}
+    ncorr = 0
+    for k in (1, 2):
+        got = open(str(tmp_path / ("s2_Y%d.regenie" % k))).read().splitlines()
+        ref = refs[k]
+        assert got[0] == ref[0] and len(got) == len(ref) == 1001
+        same = 0
+        for a, b in zip(got[1:], ref[1:]):
+            ta, tb = a.split(" "), b.split(" ")
+            assert ta[:9] == tb[:9] and ta[13] == tb[13] == "NA", (a, b)          # CHROM GENPOS ID ALLELE0 ALLELE1 A1FREQ INFO N TEST ... EXTRA
+            corrected = float(tb[11]) > 6.6                                        # CHISQ above the 0.99 quantile: a Firth row
+            ncorr += corrected
+            for x, y in zip(ta[9:13], tb[9:13]):
+                assert float(x) == pytest.approx(float(y), rel=2e-4 if corrected else 2e-5, abs=2e-9), (a, b)
+            same += a == b
+        assert same >= 900, same
+    assert 20 <= ncorr <= 40
+
+
 def test_cli_step2_ct_score_test_against_reference_output(tmp_path):
     """`regenie-amd --step 2 --ct` (null Poisson model with the LOCO offset per chromosome, compute_score_ct) against regenie's own output
     on synthetic counts: 1,500 samples x 300 variants x 2 traits, 3 % missing phenotypes, 1 % missing calls
@@ -666,7 +706,9 @@ def test_cli_step2_refuses_what_is_not_built(example_dir, tmp_path):
     E = example_dir
     base = ["--step", "2", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"), "--bsize", "200", "--pred", "x", "--out", "s2"]
     r = _run(base + ["--bt", "--firth"], str(tmp_path))
-    assert r.returncode != 0 and "Firth / SPA corrections" in r.stdout
+    assert r.returncode != 0 and "exact Firth test" in r.stdout
+    r = _run(base + ["--bt", "--spa"], str(tmp_path))
+    assert r.returncode != 0 and "saddlepoint correction" in r.stdout
     # chromosome X with male samples: the sex-aware allele counts of the non-PAR region are not built -- an error, not different numbers
     import gzip
     import shutil

@@ -359,3 +359,24 @@ def test_integer_dosage_route_against_oracle(scale, n, C, P, bs, miss_y):
     _compare(got, ref)
     ok = ref["ignored"] == 0
     assert np.allclose(got["stats"][ok], dense["stats"][ok], rtol=1e-9, atol=1e-10, equal_nan=True)
+
+
+@pytest.mark.parametrize("scale", [255, 16384])
+def test_contraction_primitive_for_integer_dosages(scale):
+    from regenie_amd.step2 import Step2QT
+    rng = np.random.default_rng(scale)
+    n, ncol, nsq, bs = 12_345, 21, 3, 70
+    cols = rng.normal(size=(ncol, n)) * np.exp(rng.uniform(-8, 8, size=(ncol, 1)))
+    cols[:nsq] = rng.random((nsq, n))
+    Gi = rng.integers(0, 2 * scale + 1, size=(bs, n))
+    Gi[rng.random((bs, n)) < 0.5] = 0
+    miss = rng.random((bs, n)) < 0.01
+    g0 = np.where(miss, 0.0, Gi / float(scale))
+    with Step2QT(n, 2, 1) as s2:
+        s2.set_columns(cols, n_sq=nsq)
+        got = s2.contract_int(np.where(miss, 0xFFFF, Gi).astype(np.uint16), scale)
+    assert np.array_equal(got["vstat"][:, 0], np.where(miss, 0, Gi).sum(axis=1)) and np.array_equal(got["vstat"][:, 1], (np.where(miss, 0, Gi) ** 2).sum(axis=1))
+    assert np.array_equal(got["vstat"][:, 2], (~miss).sum(axis=1)) and np.array_equal(got["vstat"][:, 3], ((Gi != 0) & ~miss).sum(axis=1))
+    for name, want, have in (("g0", g0 @ cols.T, got["sums"][:, 0]), ("miss", miss.astype(float) @ cols.T, got["sums"][:, 1]), ("sq", (g0 * g0) @ cols[:nsq].T, got["sq"])):
+        bound = (np.abs(g0) + miss) @ np.abs(cols[: want.shape[1]]).T * (2.0 if name == "sq" else 1.0) + 1e-300
+        assert (np.abs(have - want) <= 1e-13 * bound).all(), name
