@@ -21,7 +21,7 @@ def null_logistic(y_raw, X, mask, loco_offset, opt):
     """fit_null_logistic, test-mode branch (Step1_Models.cpp:54-140), for one phenotype: logistic regression of the trait on the
     covariate basis with the LOCO prediction as offset.  Returns None when it does not converge (the phenotype is skipped), else
     dict(p = Y_hat_p, gamma_sqrt = sqrt(p (1 - p)) (1 at masked samples), w)."""
-    off = loco_offset * mask                                            # :74
+    off = np.where(mask, loco_offset, 0.0)                              # :74 (the LOCO file holds NA for the samples masked for the trait)
     beta0 = np.zeros(X.shape[1])
     eta = off + X @ beta0
     p = orc.get_pvec(eta)                                               # :80
@@ -54,7 +54,7 @@ def score_bt(g, X, y_raw, mask, null, numtol=NUMTOL):
 def null_poisson(y_raw, X, mask, loco_offset, opt):
     """fit_null_poisson, test-mode branch (Step1_Models.cpp:225-288), for one count phenotype: Poisson regression on the covariate basis
     with the LOCO prediction as offset.  None when it does not converge, else dict(p = fitted rates, gamma_sqrt = sqrt(p), w = p)."""
-    off = loco_offset * mask                                            # :240
+    off = np.where(mask, loco_offset, 0.0)                              # :240
     p = y_raw + 1e-1                                                    # :244
     with np.errstate(invalid="ignore"):
         eta = np.where(mask, np.log(p), 0.0)                            # :245
@@ -98,7 +98,7 @@ def firth_null(y_raw, X, mask, offset, beta_start, maxit=2000):
     l(beta) + 0.5 log |X^T W X| over the covariate effects, the LOCO prediction as offset.  Modified score X^T (y - p + h (0.5 - p)),
     h = diag of the hat matrix of W^(1/2) X.  Returns beta (None if it does not converge)."""
     m = mask.astype(bool)
-    Xm, ym, om = X[m], y_raw[m], offset[m]
+    Xm, ym, om = X[m], y_raw[m], offset[m]          # only the unmasked samples enter (offset may be NA elsewhere)
 
     def pen_dev(b):
         p = _pvec(om + Xm @ b)
@@ -116,12 +116,14 @@ def firth_null(y_raw, X, mask, offset, beta_start, maxit=2000):
         if np.abs(score).max() < 1e-10:
             return beta
         step = np.linalg.solve(XtWX, score)
+        if np.abs(step).max() < 1e-10:
+            return beta
         mx = np.abs(step).max() / 25.0                                # maxstep_null
         if mx > 1:
             step = step / mx
         for _ in range(60):
             dev_new, p_new, w_new = pen_dev(beta + step)
-            if dev_new < dev + 1e-12:
+            if dev_new < dev + 1e-12 or np.abs(step).max() < 1e-6:   # (steps that small change the deviance by less than its rounding)
                 break
             step = step / 2
         beta, dev, p, w = beta + step, dev_new, p_new, w_new
@@ -153,27 +155,34 @@ def firth_snp(y_raw, gvec, mask, offset, carriers=None, maxit=500):
         w = np.where(live, p * (1 - p), 0.0) if carriers is None else p * (1 - p)
         xtwx = float(np.sum(g * g * w))
         ll = -2.0 * float(np.sum(np.where(live, np.where(y == 0, np.log(1 - p), np.log(p)), 0.0)))
-        return p, w, xtwx, dev_non + ll - np.log(xtwx)
+        return p, w, xtwx, ll - np.log(xtwx)        # (the deviance of the samples left out is a constant: it cancels in the LRT)
 
     # dev0: the deviance of the offset-only model with the penalty of the SAME set of samples (:1206-1218)
     p0, w0, x0, dev0 = state(0.0)
     beta = 0.0
     p, w, xtwx, dev = p0, w0, x0, dev0
+    converged = False
     for _ in range(maxit):
         h = g * g * w / xtwx
         score = float(np.sum(np.where(live, g * (y + h * (0.5 - p) - p), 0.0)))
-        if abs(score) < 1e-11:
-            break
         step = score / xtwx
+        if abs(step) < 1e-9:                                         # (below that the deviance comparisons of the step halving are rounding noise)
+            converged = True
+            break
         if abs(step) > 5:                                             # maxstep
             step = 5.0 * np.sign(step)
-        for _ in range(60):
+        ok = False
+        for _ in range(40):
             p_n, w_n, x_n, dev_n = state(beta + step)
-            if dev_n < dev + 1e-12:
+            if dev_n <= dev or abs(step) < 1e-6:                      # (steps that small change the deviance by less than its rounding)
+                ok = True
                 break
             step /= 2
+        if not ok:                                                    # the deviance is flat to rounding: the root is reached
+            converged = abs(score / xtwx) < 1e-6
+            break
         beta, p, w, xtwx, dev = beta + step, p_n, w_n, x_n, dev_n
-    else:
+    if not converged:
         return None
     lrt = dev0 - dev
     if lrt < 0:

@@ -1445,13 +1445,16 @@ bool firth_null_fit(const double* y, const double* X, const uint8_t* mask, const
     for (int a = 0; a < C; ++a) smax = std::max(smax, std::fabs(score[a]));
     if (smax < 1e-10) return true;
     for (int a = 0; a < C; ++a) { double t = 0.0; for (int c = 0; c < C; ++c) t += Ainv[(size_t)a * C + c] * score[c]; step[a] = t; mx = std::max(mx, std::fabs(t) / 25.0); }   // maxstep_null
+    if (mx * 25.0 < 1e-10) return true;
     if (mx > 1.0) for (int a = 0; a < C; ++a) step[a] /= mx;
     double dev_new = dev;
     bool ok = false;
     const std::vector<double> Akeep = Ainv;
     for (int hs = 0; hs < 60; ++hs) {
       for (int a = 0; a < C; ++a) bnew[a] = beta[a] + step[a];
-      if (pen_dev(bnew, dev_new) && dev_new < dev + 1e-12) { ok = true; break; }
+      double smx = 0.0;
+      for (int a = 0; a < C; ++a) smx = std::max(smx, std::fabs(step[a]));
+      if (pen_dev(bnew, dev_new) && (dev_new < dev + 1e-12 || smx < 1e-6)) { ok = true; break; }
       for (int a = 0; a < C; ++a) step[a] /= 2.0;
     }
     if (!ok) return false;
@@ -1476,7 +1479,7 @@ bool firth_snp_fit(const std::vector<double>& g, const std::vector<double>& y, c
       ll -= (y[i] == 0.0) ? std::log(1.0 - pr) : std::log(pr);
       xtwx += g[i] * g[i] * w[i];
     }
-    dev = dev_rest + 2.0 * ll - std::log(xtwx);
+    dev = 2.0 * ll - std::log(xtwx);      // (dev_rest, the deviance of the samples left out, is a constant: it cancels in the LRT)
   };
   double xtwx, dev, dev0;
   state(0.0, xtwx, dev0);
@@ -1486,17 +1489,17 @@ bool firth_snp_fit(const std::vector<double>& g, const std::vector<double>& y, c
   for (int it = 0; it < 500; ++it) {
     double score = 0.0;
     for (size_t i = 0; i < m; ++i) score += g[i] * (y[i] - pv[i] + g[i] * g[i] * w[i] / xtwx * (0.5 - pv[i]));
-    if (std::fabs(score) < 1e-11) { conv = true; break; }
     double step = score / xtwx;
+    if (std::fabs(step) < 1e-9) { conv = true; break; }      // below that the deviance comparisons of the step halving are rounding noise
     if (std::fabs(step) > 5.0) step = step > 0 ? 5.0 : -5.0;      // maxstep
     double x_n = xtwx, dev_n = dev;
     bool ok = false;
     for (int hs = 0; hs < 60; ++hs) {
       state(beta + step, x_n, dev_n);
-      if (dev_n < dev + 1e-12) { ok = true; break; }
+      if (dev_n <= dev || std::fabs(step) < 1e-6) { ok = true; break; }      // steps that small change the deviance by less than its rounding
       step /= 2.0;
     }
-    if (!ok) { state(beta, xtwx, dev); conv = std::fabs(score) < 1e-8; break; }
+    if (!ok) { state(beta, xtwx, dev); conv = std::fabs(score / xtwx) < 1e-6; break; }    // flat to rounding: the root is reached
     beta += step; xtwx = x_n; dev = dev_n;
   }
   if (!conv) return false;

@@ -170,6 +170,14 @@ def step2_cases(workdir, step1_dirs):
     runs["qt_synth_missing_bgen_rf"] = (s1m, ["--step", "2", "--bgen", S + ".bgen", "--sample", S + ".sample", "--ref-first"] + common)
     runs["qt_synth_missing_pgen"] = (s1m, ["--step", "2", "--pgen", S + "_d"] + common)
     runs["qt_synth_missing_pgenhc"] = (s1m, ["--step", "2", "--pgen", S + "_h"] + common)
+    # rare, sparse variants for the carriers-only form of the approximate Firth fit (MAC < 50): a second .bed for the bt_kfold_synth samples
+    from tests.util import synth_rare_dosages, write_bed_bim
+    Sb = os.path.join(step1_dirs["bt_kfold_synth"], "synth")
+    sb = CASES["bt_kfold_synth"][1]
+    write_bed_bim(Sb + "_rare", synth_rare_dosages(300, sb["N"], seed=sb["seed"], miss_rate=0.002), [1] * 100 + [2] * 100 + [5] * 100)
+    shutil.copy(Sb + ".fam", Sb + "_rare.fam")
+    runs["bt_firth_rare"] = (step1_dirs["bt_kfold_synth"], ["--step", "2", "--bed", Sb + "_rare", "--covarFile", Sb + ".covar", "--phenoFile", Sb + ".pheno",
+                                                          "--bsize", "100", "--bt", "--firth", "--approx", "--pThresh", "0.3"])
     Sc = os.path.join(step1_dirs["ct_synth"], "synth")
     runs["ct_synth"] = (step1_dirs["ct_synth"], ["--step", "2", "--bed", Sc, "--covarFile", Sc + ".covar", "--phenoFile", Sc + ".pheno", "--bsize", "100", "--ct"])
     for name, (s1, args) in runs.items():

@@ -667,6 +667,48 @@ def test_cli_step2_bt_approx_firth_reproduces_the_reference_held_golden(example_
     assert 20 <= ncorr <= 40
 
 
+def test_cli_step2_bt_approx_firth_rare_variants_against_reference_output(tmp_path):
+    """Rare, sparse variants (MAF 0.1 - 1 %, 5,200 samples, 3 binary traits with 2 % missing values, --pThresh 0.3): ~270 of the 900 tests get
+    the Firth correction, about half of them in regenie's carriers-only form (MAC < 50).  Driver output against regenie's own
+    (tests/golden/ref_outputs/step2/bt_firth_rare_Y*.regenie.gz).  Corrected rows: regenie stops at |modified score| < 2.5e-4, a few times
+    2.5e-4 * SE^2 from the root, and takes its LRT one iteration before its BETA."""
+    import gzip
+    import json
+    import shutil
+    from tests.util import synth_dosages, synth_rare_dosages, write_bed_bim, write_plink
+    R = os.path.join(ROOT, "tests", "golden", "ref_outputs")
+    meta = json.load(open(os.path.join(R, "bt_kfold_synth", "meta.json")))
+    spec = meta["synthetic"]
+    S = str(tmp_path / "synth")
+    write_plink(S, synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"]), spec["chroms"], P=spec["P"],
+                seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    write_bed_bim(S + "_rare", synth_rare_dosages(300, spec["N"], seed=spec["seed"], miss_rate=0.002), [1] * 100 + [2] * 100 + [5] * 100)
+    shutil.copy(S + ".fam", S + "_rare.fam")
+    with open(str(tmp_path / "pred.list"), "w") as pl:
+        for k, nm in enumerate(meta["pred_list"]):
+            fn = str(tmp_path / ("ref_%d.loco" % (k + 1)))
+            open(fn, "wb").write(gzip.open(os.path.join(R, "bt_kfold_synth", "out_%d.loco.gz" % (k + 1)), "rb").read())
+            pl.write("%s %s\n" % (nm, fn))
+    r = _run(["--step", "2", "--bed", S + "_rare", "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "100", "--bt", "--firth", "--approx",
+              "--pThresh", "0.3", "--pred", str(tmp_path / "pred.list"), "--out", "s2"], str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    ncorr = 0
+    for k in range(1, spec["P"] + 1):
+        got = open(str(tmp_path / ("s2_Y%d.regenie" % k))).read().splitlines()
+        ref = gzip.open(os.path.join(R, "step2", "bt_firth_rare_Y%d.regenie.gz" % k), "rt").read().splitlines()
+        assert got[0] == ref[0] and len(got) == len(ref) == 301
+        for a, b in zip(got[1:], ref[1:]):
+            ta, tb = a.split(" "), b.split(" ")
+            assert ta[:8] == tb[:8] and ta[12] == tb[12] == "NA", (a, b)
+            beta, se, chisq = float(tb[8]), float(tb[9]), float(tb[10])
+            strict = all(float(x) == pytest.approx(float(y), rel=2e-5, abs=2e-9) for x, y in zip(ta[8:12], tb[8:12]))
+            if not strict:          # a corrected row (they cannot be told from the file: the LRT may fall below the threshold the score test exceeded)
+                ncorr += 1
+                assert abs(float(ta[8]) - beta) <= 8e-4 * se * se + 2e-5 * abs(beta) + 5e-6, (a, b)
+                assert float(ta[9]) == pytest.approx(se, rel=2e-4) and float(ta[10]) == pytest.approx(chisq, rel=2e-3, abs=2e-5), (a, b)
+    assert ncorr <= 280          # regenie corrected 271 tests; every other row agrees to the printed digits
+
+
 def test_cli_step2_ct_score_test_against_reference_output(tmp_path):
     """`regenie-amd --step 2 --ct` (null Poisson model with the LOCO offset per chromosome, compute_score_ct) against regenie's own output
     on synthetic counts: 1,500 samples x 300 variants x 2 traits, 3 % missing phenotypes, 1 % missing calls

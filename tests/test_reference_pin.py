@@ -15,6 +15,7 @@ tests/golden/ref_outputs/ holds outputs of regenie v4.1.2 compiled from /root/re
 import gzip
 import json
 import os
+import shutil
 import re
 import subprocess
 
@@ -432,6 +433,75 @@ def test_step2_bt_approx_firth_oracle_against_reference_and_golden():
                     assert out["chisq"] == pytest.approx(chisq, rel=2 * tol, abs=2e-6)
                     assert s2.get_logp(out["chisq"]) == pytest.approx(logp, rel=2 * tol, abs=2e-6)
     assert nfirth >= 25
+
+
+def test_step2_bt_approx_firth_rare_variants_against_reference(tmp_path):
+    """Rare, sparse variants (MAF 0.1 - 1 %, 5,200 samples, 136 of 300 variants with MAC < 50): regenie's approximate Firth fit then keeps the
+    carriers only (fit_firth_logistic_snp_fast, Step2_Models.cpp:1173-1185).  --pThresh 0.3, so ~270 of the 900 tests are corrected.  Oracle
+    against regenie's own output (tests/golden/ref_outputs/step2/bt_firth_rare_Y*.regenie.gz; LOCO files of the bt_kfold_synth case)."""
+    import json
+    from scipy.stats import norm
+    from oracle import regenie_step2_bt as bt
+    from oracle import regenie_step2_qt as s2
+    from tests.util import synth_dosages, synth_rare_dosages, write_bed_bim, write_plink
+    meta = json.load(open(os.path.join(REF_OUT, "bt_kfold_synth", "meta.json")))
+    spec = meta["synthetic"]
+    S = str(tmp_path / "synth")
+    write_plink(S, synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"]), spec["chroms"], P=spec["P"],
+                seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    write_bed_bim(S + "_rare", synth_rare_dosages(300, spec["N"], seed=spec["seed"], miss_rate=0.002), [1] * 100 + [2] * 100 + [5] * 100)
+    shutil.copy(S + ".fam", S + "_rare.fam")
+    opt = orc.Step1Options(bed=S + "_rare", pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=100, bt=True, test_mode=True)
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    bed, _ = orc.open_bed(opt.bed + ".bed", prep.n_file)
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    P = prep.Y.shape[1]
+    loco = []
+    for ph in range(P):
+        hdr, v = read_loco_gz(os.path.join(REF_OUT, "bt_kfold_synth", "out_%d.loco.gz" % (ph + 1)))
+        pos = {s: k for k, s in enumerate(hdr)}
+        loco.append(v[:, [pos[i] for i in ids]])
+    refs = [_read_regenie(os.path.join(REF_OUT, "step2", "bt_firth_rare_Y%d.regenie.gz" % (ph + 1))) for ph in range(P)]
+    col = {nm: i for i, nm in enumerate(refs[0][0])}
+    X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
+    zthr = float(norm.ppf(1 - 0.3 / 2))
+    n_all = int((~prep.ind_ignore).sum())
+    ncorr = nfast = 0
+    for c in sorted(set(chrom.tolist())):
+        nulls, offs_f = [], []
+        for ph in range(P):
+            nl = bt.null_logistic(Yraw[:, ph], X, mask[:, ph], loco[ph][c - 1], opt)
+            bnull = bt.firth_null(Yraw[:, ph], X, mask[:, ph], loco[ph][c - 1], nl["beta"])
+            nulls.append(nl)
+            offs_f.append(X @ bnull + np.nan_to_num(loco[ph][c - 1]))      # NA predictions belong to samples masked for the trait
+        sel = np.flatnonzero(chrom == c)
+        G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
+        rows = {ph: {r[col["ID"]]: r for r in refs[ph][1]} for ph in range(P)}
+        for k in range(sel.size):
+            g, _, _ = s2.mean_impute(G[k])
+            sparse = s2.check_sparse(g, n_all)
+            obs = G[k] >= 0
+            for ph in range(P):
+                r = rows[ph].get(snp_ids[sel[k]])
+                if r is None:
+                    continue
+                m = mask[:, ph].astype(np.float64)
+                out = bt.score_bt(g, X, Yraw[:, ph], m, nulls[ph])
+                if abs(out["stats"]) > zthr:
+                    tq = float(G[k][obs & (m > 0)].sum())
+                    nq = int((obs & (m > 0)).sum())
+                    mac = min(tq, 2 * nq - tq)
+                    out = bt.approx_firth(g, X, Yraw[:, ph], m, nulls[ph], offs_f[ph], sparse=sparse, mac=mac)
+                    assert out is not None
+                    ncorr += 1
+                    nfast += sparse and mac < 50
+                beta, se, chisq = (float(r[col[nm]]) for nm in ("BETA", "SE", "CHISQ"))
+                # regenie stops its 1-parameter fit at |modified score| < 2.5e-4, i.e. within a few times 2.5e-4 * se^2 of the root this oracle finds
+                assert abs(out["bhat"] - beta) <= 8e-4 * se * se + 2e-5 * abs(beta) + 5e-6, (snp_ids[sel[k]], ph)
+                assert out["se"] == pytest.approx(se, rel=2e-4)
+                assert out["chisq"] == pytest.approx(chisq, rel=2e-3, abs=2e-5)      # (its LRT is taken one outer iteration before its BETA)
+    assert ncorr > 200 and nfast > 80
 
 
 needs_ref_binary = pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")

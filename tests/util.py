@@ -269,3 +269,25 @@ def write_synth_pgen(prefix, g, chroms, seed=1, soft=0.4):
         fh.write("#FID\tIID\tSEX\n")
         for k in range(N):
             fh.write("%d\t%d\tNA\n" % (k + 1, k + 1))
+
+
+def synth_rare_dosages(M, N, seed=7, lo=0.001, hi=0.01, miss_rate=0.0):
+    """Hard calls with MAF ~ U(lo, hi): rare, sparse variants (the carriers-only form of regenie's approximate Firth fit needs MAC < 50)."""
+    j = np.arange(M)[:, None]
+    i = np.arange(N)[None, :]
+    maf = lo + (hi - lo) * u01(201 + seed, np.arange(M), 0)
+    g = (u01(202 + seed, j, i) < maf[:, None]).astype(np.int8) + (u01(203 + seed, j, i) < maf[:, None]).astype(np.int8)
+    if miss_rate > 0:
+        g = np.where(u01(204 + seed, j, i) < miss_rate, np.int8(-3), g)
+    return g
+
+
+def write_bed_bim(prefix, g, chroms):
+    """prefix.bed / .bim only (the .fam / phenotype / covariate files of another write_plink call are reused)."""
+    M, N = g.shape
+    with open(prefix + ".bed", "wb") as fh:
+        fh.write(b"\x6c\x1b\x01")
+        fh.write(pack_bed(g).tobytes())
+    with open(prefix + ".bim", "w") as fh:
+        for k in range(M):
+            fh.write("%d\tr%d\t0\t%d\tA\tG\n" % (chroms[k], k, k + 1))
