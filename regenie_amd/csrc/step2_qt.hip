@@ -745,12 +745,11 @@ struct rg_s2_ctx {
   bool res_ready = false;       // planes of the res columns, res^T X
   std::vector<double> hX;       // host copies of the last X / mask (the planes are kept while they do not change)
   std::vector<uint8_t> hM;
-  int64_t Np = 0;               // samples padded to a multiple of 64 * 32
+  int64_t Np = 0;               // samples padded to a multiple of 128 * 32
   int Cvt = 0, cm0 = 0;         // columns in all, first mask column (a multiple of 16); complete problems: Cvt = cm0 = C + P
   int64_t rule_n = 0;           // check_sparse_G: params.n_samples (0 = the analysed samples)
   double rule_thr = 0.5;        // params.prop_zero_thr
   int rule_zero_count = 0;      // 1: the .pgen form of the rule (observed zeros >= n_samples * thr)
-  SegLayout seg;
   double* dV = nullptr;         // [Cvt (padded to 16)][Np]  X | res | x_c mask_p | 0 | mask_p, zero padded
   int8_t* dvd = nullptr;        // the digit planes of dV's columns, [col][8][Np]
   double *dvsc = nullptr, *dYtX = nullptr;   // [col] plane scales, [P][C] res_p^T x_c
