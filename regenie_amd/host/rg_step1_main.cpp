@@ -59,6 +59,7 @@ struct Params {
   int bsize = 0, cv_folds = 5, n_ridge_l0 = 5, n_ridge_l1 = 5, nchrom = 23, threads = 0;
   bool firth = false, firth_approx = false, firth_se = false;   // --firth --approx [--firth-se] (step 2, binary traits)
   double pthresh = 0.05;                                        // --pThresh: score tests below it get the correction
+  double min_info = 0.0; bool set_min_info = false;             // --minINFO (step 2, dosages)
   bool bt = false, ct = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
        print_prs = false, force_step1 = false, lowmem = false, force_qt = false, cc12 = false, gz = false;
   int min_case_count = 10, niter_max = 50, niter_max_line_search = 25, niter_max_ridge = 100;
@@ -359,6 +360,7 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--l1-shared") p.l1_shared = true;
     else if (a == "--pred") p.pred_list = need(i);
     else if (a == "--minMAC") p.min_mac = atof(need(i).c_str());
+    else if (a == "--minINFO") { p.min_info = atof(need(i).c_str()); p.set_min_info = true; }
     else if (a == "--firth") p.firth = true;
     else if (a == "--approx") p.firth_approx = true;
     else if (a == "--firth-se") p.firth_se = true;
@@ -374,6 +376,7 @@ Params parse_args(int argc, char** argv) {
     if (p.firth && !p.firth_approx) usage_error("'--firth' without '--approx': the exact Firth test (covariates refitted per variant) is not built; add --approx.");
     if (p.firth && !(p.pthresh > 0 && p.pthresh < 1)) usage_error("'--pThresh' must be in (0,1).");
     if (p.min_mac < 0.5) usage_error("minimum MAC must be at least 0.5.");   // Regenie.cpp:1054
+    if (p.set_min_info && (p.min_info < 0 || p.min_info > 1)) usage_error("minimum info score must be in [0,1].");
     if (p.gpus > 1 || p.force_collectives) usage_error("--step 2 runs on one GPU.");
   }
   if ((int)!p.bed.empty() + (int)!p.pgen.empty() + (int)!p.bgen.empty() != 1) usage_error("must use either --bed,--bgen or --pgen.");  // Regenie.cpp:419-420
@@ -1357,19 +1360,16 @@ double get_logp(double t) {
   return -lp;
 }
 
-// ---- `--step 2 --qt`: single-variant score tests on hard calls (Data::test_snps_fast, Data.cpp:2230-2360) -----------------
-// Host side: the LOCO reader (blup_read / blup_read_chr, Pheno.cpp:1241-1391, Step2_Models.cpp:51-140), compute_res
-// (Data.cpp:2386-2400), the per-variant bookkeeping of parseSnpfromBed (Geno.cpp:2414-2536: allele counts, the MAC filter of
-// compute_mac, allele frequencies, per-trait counts for samples with missing phenotypes) and the output lines
-// (print_sum_stats_head / print_sum_stats_single, Step2_Models.cpp:2410-2530).  Device side (include/rg_step2.h): mean
-// imputation, residualize_geno and compute_score_qt for a block of variants.
-// Served: runs in which every analysed sample is observed for every phenotype (complete phenotypes, one phenotype, or
-// --strict).  Refused with an explicit error: phenotypes with different missingness patterns.  There the reference tests a
-// "sparse" variant (at most half of the samples non-zero, check_sparse_G, Geno.cpp:3165-3180: most variants below ~29 % MAF)
-// with an approximate per-trait denominator ("assuming X'X is same for all traits", Step2_Models.cpp:400-409) that differs
-// from the exact dense expression by up to ~10 % on the reference's own example with 14 % missing values; reproducing that
-// approximation needs per-(covariate, trait) accumulators the device kernel does not carry yet.  With complete phenotypes
-// the sparse and dense expressions are the same number, which is what the kernel evaluates.
+// ---- `--step 2`: single-variant additive tests (Data::test_snps_fast, Data.cpp:2230-2360) --------------------------------------------
+// Host side: the LOCO reader (blup_read / blup_read_chr, Pheno.cpp:1241-1391, Step2_Models.cpp:51-140), per chromosome compute_res
+// (Data.cpp:2386-2400) or the null logistic / Poisson (/ Firth) model of compute_res_bin / compute_res_count, the per-variant bookkeeping
+// of parseSnpfromBed / parseSnpfromBGEN / readChunkFromPGENFileToG (allele counts, the MAC and INFO filters, allele frequencies, per-trait
+// counts for samples with missing phenotypes) and the output lines (print_sum_stats_head / print_sum_stats_single, Step2_Models.cpp:
+// 2410-2530).  Device side (include/rg_step2.h): every per-variant O(n) contraction -- the QT statistic whole (hard calls: 2-bit rows;
+// dosages: uint16 rows; both on the i8 matrix cores), the sums the binary / count trait score tests are functions of.  Phenotypes may
+// differ in their missing values: the library makes check_sparse_G's per-variant choice between the sparse and the dense branch of
+// compute_score_qt.  The approximate Firth refits of the flagged binary-trait tests run on host threads.
+
 // ---- approximate Firth correction of the binary-trait test (--firth --approx) ---------------------------------------------------------
 // regenie reaches the maximisers below through a chain of solvers and fall-backs (fit_firth_nr, the pseudo-data IRLS of fit_firth_pseudo,
 // step halving, restarts: Step2_Models.cpp:899-984, :1254-1737) that stop at |modified score| < 50 * numtol (null model) or < 2.5e-4 (per
@@ -1982,6 +1982,13 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       }
       // the result lines (compute_score_qt after the statistic, Step2_Models.cpp:440-466; print_sum_stats_single)
       for (int j = 0; j < bs; ++j) {
+        if (!variant_ignored[j] && show_info && p.set_min_info && ns1[j] > 0) {   // the all-sample info score below --minINFO drops the variant (Geno.cpp:2349-2353)
+          const double af1 = total[j] / (2.0 * ns1[j]);
+          double info1 = 1.0;
+          if (af1 != 0.0 && af1 != 1.0)
+            info1 = r.bgenh ? 1.0 - info_num[j] / (2.0 * ns1[j] * af1 * (1.0 - af1)) : (info_num[j] / ns1[j] - 4.0 * af1 * af1) / (2.0 * af1 * (1.0 - af1));
+          if (info1 < p.min_info) variant_ignored[j] = 1;
+        }
         if (variant_ignored[j] || ign[j]) { ++n_ignored_snps; continue; }
         const int64_t sj = snps[j0 + j];
         std::ostringstream head;
@@ -2002,6 +2009,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
           double info = 1.0;     // compute_aaf_info (Geno.cpp:3132-3141): IMPUTE info for .bgen, MaCH r2 for .pgen dosages
           if (show_info && af != 0.0 && af != 1.0)
             info = r.bgenh ? 1.0 - infq / (2.0 * nsq * af * (1.0 - af)) : (infq / nsq - 4.0 * af * af) / (2.0 * af * (1.0 - af));
+          if (show_info && p.set_min_info && info < p.min_info) { ++n_ignored_tests; continue; }     // ignored_trait (Geno.cpp:3143-3144)
           const double st = stats[(size_t)j * P + q];
           double bh = bhat[(size_t)j * P + q], se = bh / st, chisq = st * st;
           bool test_fail = false;
@@ -2030,7 +2038,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   rg_s2_destroy(s2);
   sout << "\nAssociation results stored separately for each trait in files : \n";
   for (auto& fn : out_names) sout << "* [" << fn << "]\n";
-  sout << "\nNumber of ignored tests due to low MAC : " << n_ignored_snps * P + n_ignored_tests << "\n";
+  sout << "\nNumber of ignored tests due to low MAC" << (p.set_min_info ? " or info score" : "") << " : " << n_ignored_snps * P + n_ignored_tests << "\n";
   sout << "\nElapsed time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << "s\nEnd of run\n";
   return 0;
 }

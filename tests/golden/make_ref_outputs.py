@@ -168,6 +168,8 @@ def step2_cases(workdir, step1_dirs):
     s1m = step1_dirs["qt_kfold_synth_missing"]
     runs["qt_synth_missing_bgen"] = (s1m, ["--step", "2", "--bgen", S + ".bgen", "--sample", S + ".sample"] + common)
     runs["qt_synth_missing_bgen_rf"] = (s1m, ["--step", "2", "--bgen", S + ".bgen", "--sample", S + ".sample", "--ref-first"] + common)
+    runs["qt_synth_missing_strict"] = (s1m, ["--step", "2", "--bed", S, "--strict"] + common)
+    runs["qt_synth_missing_bgen_mininfo"] = (s1m, ["--step", "2", "--bgen", S + ".bgen", "--sample", S + ".sample", "--minINFO", "0.75"] + common)
     runs["qt_synth_missing_pgen"] = (s1m, ["--step", "2", "--pgen", S + "_d"] + common)
     runs["qt_synth_missing_pgenhc"] = (s1m, ["--step", "2", "--pgen", S + "_h"] + common)
     # rare, sparse variants for the carriers-only form of the approximate Firth fit (MAC < 50): a second .bed for the bt_kfold_synth samples
