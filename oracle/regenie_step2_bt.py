@@ -207,3 +207,60 @@ def approx_firth(g, X, y_raw, mask, null, cov_blup_offset, sparse=False, mac=Non
         return None
     beta, se, lrt = out
     return dict(bhat=beta, se=se, chisq=lrt)
+
+
+def firth_fit(y_raw, X, mask, offset, beta_start, nfree, maxstep=25.0, maxit=2000):
+    """fit_firth_nr with cols_incl = nfree (Step2_Models.cpp:1267-1385): maximise l(beta) + 0.5 log |X^T W X| over the FIRST nfree
+    coefficients, the others held at their start values; the penalty and the hat diagonal always use every column of X.  Returns
+    (beta, penalised deviance, (X^T W X)^-1) or None."""
+    m = mask.astype(bool)
+    Xm, ym, om = X[m], y_raw[m], offset[m]
+
+    def pen_dev(b):
+        p = _pvec(om + Xm @ b)
+        w = p * (1 - p)
+        sign, logdet = np.linalg.slogdet(Xm.T @ (Xm * w[:, None]))
+        return -2.0 * float(np.sum(np.where(ym == 0, np.log(1 - p), np.log(p)))) - logdet, p, w
+
+    beta = np.array(beta_start, dtype=np.float64)
+    dev, p, w = pen_dev(beta)
+    for _ in range(maxit):
+        XtWX = Xm.T @ (Xm * w[:, None])
+        inv = np.linalg.inv(XtWX)
+        U = Xm * np.sqrt(w)[:, None]
+        h = np.einsum("ij,ij->i", U @ inv, U)
+        score = Xm[:, :nfree].T @ (ym - p + h * (0.5 - p))
+        step = np.zeros_like(beta)
+        step[:nfree] = np.linalg.solve(XtWX[:nfree, :nfree], score)
+        if np.abs(step).max() < 1e-10:
+            return beta, dev, inv
+        mx = np.abs(step).max() / maxstep
+        if mx > 1:
+            step = step / mx
+        for _ in range(60):
+            dev_new, p_new, w_new = pen_dev(beta + step)
+            if dev_new < dev + 1e-12 or np.abs(step).max() < 1e-6:
+                break
+            step = step / 2
+        beta, dev, p, w = beta + step, dev_new, p_new, w_new
+    return None
+
+
+def exact_firth(g, X, y_raw, mask, loco_offset, beta_cov_start):
+    """The exact Firth test of one (variant, trait) (`--firth` without `--approx`): fit_firth_logistic_snp, null fit then full fit
+    (Step2_Models.cpp:1062-1156; run_firth_correction_snp :2045-2051).  Design = [covariates | g] with g the mean-imputed genotype on its raw
+    scale; null = the maximiser with the variant's coefficient held at 0 UNDER THE SAME PENALTY; LRT = difference of the penalised deviances;
+    SE from (X^T W X)^-1 at the full maximiser."""
+    C = X.shape[1]
+    Xf = np.column_stack([X, g])
+    off = np.nan_to_num(loco_offset)
+    nul = firth_fit(y_raw, Xf, mask, off, np.concatenate([beta_cov_start, [0.0]]), C)
+    if nul is None:
+        return None
+    full = firth_fit(y_raw, Xf, mask, off, nul[0], C + 1, maxstep=5.0)
+    if full is None:
+        return None
+    lrt = nul[1] - full[1]
+    if lrt < 0:
+        return None
+    return dict(bhat=float(full[0][C]), se=float(np.sqrt(full[2][C, C])), chisq=lrt)

@@ -373,7 +373,6 @@ Params parse_args(int argc, char** argv) {
   if (p.step == 2) {
     if (p.pred_list.empty()) usage_error("option '--pred' is required (use the _pred.list file written by step 1).");
     if (p.firth && !p.bt) usage_error("option '--firth' applies to binary traits (--bt).");
-    if (p.firth && !p.firth_approx) usage_error("'--firth' without '--approx': the exact Firth test (covariates refitted per variant) is not built; add --approx.");
     if (p.firth && !(p.pthresh > 0 && p.pthresh < 1)) usage_error("'--pThresh' must be in (0,1).");
     if (p.min_mac < 0.5) usage_error("minimum MAC must be at least 0.5.");   // Regenie.cpp:1054
     if (p.set_min_info && (p.min_info < 0 || p.min_info > 1)) usage_error("minimum info score must be in [0,1].");
@@ -1406,25 +1405,28 @@ bool spd_logdet_inv(const std::vector<double>& A, int n, double& logdet, std::ve
   return true;
 }
 
-// fit_approx_firth_null (Step2_Models.cpp:899-984): maximise l(beta) + 0.5 log |X^T W X| over the covariate effects, offset = LOCO prediction.
-// X [C][n] sample-fastest; beta in: start (the null logistic estimate), out: the maximiser.  false when it does not converge.
-bool firth_null_fit(const double* y, const double* X, const uint8_t* mask, const double* offset, int64_t n, int C, std::vector<double>& beta) {
-  std::vector<double> pv(n), w(n), A((size_t)C * C), Ainv, score(C), step(C), bnew(C), hx(C);
+// fit_firth_nr with cols_incl = nfree (Step2_Models.cpp:1267-1385): maximise l(beta) + 0.5 log |X^T W X| over the FIRST nfree coefficients (the
+// others stay where they start); penalty and hat diagonal always use every column.  cols: K column pointers (sample-fastest, n each).
+// beta in: start, out: the maximiser; dev_out: the penalised deviance there; inv_out (optional): (X^T W X)^-1.  false = no convergence.
+bool firth_fit_cols(const double* y, const std::vector<const double*>& cols, const uint8_t* mask, const double* offset, int64_t n, int nfree, double maxstep,
+                    std::vector<double>& beta, double* dev_out = nullptr, std::vector<double>* inv_out = nullptr) {
+  const int K = (int)cols.size();
+  std::vector<double> pv(n), w(n), A((size_t)K * K), Ainv, Afree((size_t)nfree * nfree), Afinv, score(nfree), step(K, 0.0), bnew(K), hx(K);
   auto pen_dev = [&](const std::vector<double>& b, double& dev) {
     double ll = 0.0;
     std::fill(A.begin(), A.end(), 0.0);
     for (int64_t i = 0; i < n; ++i) {
       if (!mask[i]) continue;
       double e = offset[i];
-      for (int c = 0; c < C; ++c) e += X[(size_t)c * n + i] * b[c];
+      for (int c = 0; c < K; ++c) e += cols[c][i] * b[c];
       const double pr = get_pvec1(e);
       pv[i] = pr; w[i] = pr * (1.0 - pr);
       ll -= (y[i] == 0.0) ? std::log(1.0 - pr) : std::log(pr);
-      for (int a = 0; a < C; ++a) { const double xa = X[(size_t)a * n + i] * w[i]; for (int c = 0; c <= a; ++c) A[(size_t)a * C + c] += xa * X[(size_t)c * n + i]; }
+      for (int a = 0; a < K; ++a) { const double xa = cols[a][i] * w[i]; for (int c = 0; c <= a; ++c) A[(size_t)a * K + c] += xa * cols[c][i]; }
     }
-    for (int a = 0; a < C; ++a) for (int c = a + 1; c < C; ++c) A[(size_t)a * C + c] = A[(size_t)c * C + a];
+    for (int a = 0; a < K; ++a) for (int c = a + 1; c < K; ++c) A[(size_t)a * K + c] = A[(size_t)c * K + a];
     double logdet;
-    if (!spd_logdet_inv(A, C, logdet, &Ainv)) return false;
+    if (!spd_logdet_inv(A, K, logdet, &Ainv)) return false;
     dev = 2.0 * ll - logdet;
     return true;
   };
@@ -1435,32 +1437,43 @@ bool firth_null_fit(const double* y, const double* X, const uint8_t* mask, const
     for (int64_t i = 0; i < n; ++i) {
       if (!mask[i]) continue;
       double h = 0.0;                                  // h_i = w_i x_i^T (X^T W X)^-1 x_i
-      for (int a = 0; a < C; ++a) { double t = 0.0; for (int c = 0; c < C; ++c) t += Ainv[(size_t)a * C + c] * X[(size_t)c * n + i]; hx[a] = t; }
-      for (int a = 0; a < C; ++a) h += X[(size_t)a * n + i] * hx[a];
+      for (int a = 0; a < K; ++a) { double t = 0.0; for (int c = 0; c < K; ++c) t += Ainv[(size_t)a * K + c] * cols[c][i]; hx[a] = t; }
+      for (int a = 0; a < K; ++a) h += cols[a][i] * hx[a];
       h *= w[i];
       const double u = y[i] - pv[i] + h * (0.5 - pv[i]);
-      for (int a = 0; a < C; ++a) score[a] += X[(size_t)a * n + i] * u;
+      for (int a = 0; a < nfree; ++a) score[a] += cols[a][i] * u;
     }
-    double smax = 0.0, mx = 0.0;
-    for (int a = 0; a < C; ++a) smax = std::max(smax, std::fabs(score[a]));
-    if (smax < 1e-10) return true;
-    for (int a = 0; a < C; ++a) { double t = 0.0; for (int c = 0; c < C; ++c) t += Ainv[(size_t)a * C + c] * score[c]; step[a] = t; mx = std::max(mx, std::fabs(t) / 25.0); }   // maxstep_null
-    if (mx * 25.0 < 1e-10) return true;
-    if (mx > 1.0) for (int a = 0; a < C; ++a) step[a] /= mx;
+    const std::vector<double>* Finv = &Ainv;
+    if (nfree < K) {                                   // the step solves with the free block of the information alone (:1311-1314)
+      for (int a = 0; a < nfree; ++a) for (int c = 0; c < nfree; ++c) Afree[(size_t)a * nfree + c] = A[(size_t)a * K + c];
+      double ld;
+      if (!spd_logdet_inv(Afree, nfree, ld, &Afinv)) return false;
+      Finv = &Afinv;
+    }
+    const int F = nfree < K ? nfree : K;
+    double mx = 0.0;
+    for (int a = 0; a < nfree; ++a) { double t = 0.0; for (int c = 0; c < nfree; ++c) t += (*Finv)[(size_t)a * F + c] * score[c]; step[a] = t; mx = std::max(mx, std::fabs(t)); }
+    if (mx < 1e-10) { if (dev_out) *dev_out = dev; if (inv_out) *inv_out = Ainv; return true; }
+    if (mx > maxstep) for (int a = 0; a < nfree; ++a) step[a] *= maxstep / mx;
     double dev_new = dev;
     bool ok = false;
-    const std::vector<double> Akeep = Ainv;
     for (int hs = 0; hs < 60; ++hs) {
-      for (int a = 0; a < C; ++a) bnew[a] = beta[a] + step[a];
       double smx = 0.0;
-      for (int a = 0; a < C; ++a) smx = std::max(smx, std::fabs(step[a]));
-      if (pen_dev(bnew, dev_new) && (dev_new < dev + 1e-12 || smx < 1e-6)) { ok = true; break; }
-      for (int a = 0; a < C; ++a) step[a] /= 2.0;
+      for (int a = 0; a < K; ++a) { bnew[a] = beta[a] + (a < nfree ? step[a] : 0.0); if (a < nfree) smx = std::max(smx, std::fabs(step[a])); }
+      if (pen_dev(bnew, dev_new) && (dev_new < dev + 1e-12 || smx < 1e-6)) { ok = true; break; }      // (steps that small change the deviance by less than its rounding)
+      for (int a = 0; a < nfree; ++a) step[a] /= 2.0;
     }
     if (!ok) return false;
     beta = bnew; dev = dev_new;
   }
   return false;
+}
+
+// fit_approx_firth_null (Step2_Models.cpp:899-984): the covariate-only penalised fit, offset = LOCO prediction.  X [C][n] sample-fastest.
+bool firth_null_fit(const double* y, const double* X, const uint8_t* mask, const double* offset, int64_t n, int C, std::vector<double>& beta) {
+  std::vector<const double*> cols(C);
+  for (int c = 0; c < C; ++c) cols[c] = X + (size_t)c * n;
+  return firth_fit_cols(y, cols, mask, offset, n, C, 25.0, beta);      // maxstep_null
 }
 
 // fit_firth_logistic_snp_fast with its one-parameter solvers (Step2_Models.cpp:1158-1253, :1548-1737): the variant's effect with the covariate
@@ -1540,6 +1553,8 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   const double z_thr = firth ? norm_quantile(1.0 - 0.5 * p.pthresh) : 0.0;   // sqrt of the chi-square(1) quantile at 1 - pThresh (Data.cpp:2119-2120)
   std::vector<double> firth_off;                      // [P][n] cov_blup_offset: X beta_nullFirth + LOCO prediction (fit_null_firth, Step2_Models.cpp:1011-1013)
   if (firth) firth_off.assign((size_t)P * n, 0.0);
+  std::vector<double> firth_bnull((size_t)P * C, 0.0), blup_off;      // exact Firth: the covariate-only estimates (start values), the LOCO offsets
+  if (firth && !p.firth_approx) blup_off.assign((size_t)P * n, 0.0);
   std::vector<uint8_t> corrected, corr_fail;          // per (variant, trait) of a block
   std::vector<double> corr_beta, corr_se, corr_chisq;
   if (glm) { bt_cols.assign((size_t)bt_ncol * n, 0.0); bt_xwx_inv.assign((size_t)P * C * C, 0.0); }
@@ -1652,7 +1667,9 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
             double e = blup[an[k]];
             for (int c = 0; c < C; ++c) e += Xc[(size_t)c * n + k] * bnull[c];
             firth_off[(size_t)q * n + k] = e;
+            if (!p.firth_approx) blup_off[(size_t)q * n + k] = blup[an[k]];
           }
+          for (int c = 0; ok && c < C; ++c) firth_bnull[(size_t)q * C + c] = bnull[c];
         }
         bt_pass[q] = ok ? 1 : 0;
         if (!ok) { if (!(firth && !bnull.empty())) sout << "\n     WARNING: " << (p.ct ? "poisson" : "logistic") << " regression did not converge for phenotype '" << r.pheno_names[q] << "'."; continue; }
@@ -1878,6 +1895,26 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
                 if (flip && hc != -3.0) hc = 2.0 - hc;
                 gt[k] = hc == -3.0 ? mu : hc;
               }
+            }
+            if (!p.firth_approx) {
+              // the exact test (fit_firth_logistic_snp, Step2_Models.cpp:1062-1156): design [covariates | g~ on its raw scale], offset = the LOCO
+              // prediction; null fit = the variant's coefficient held at 0 under the same penalty, then every coefficient free
+              const uint8_t* mq = Mc.data() + (size_t)q * n;
+              std::vector<const double*> cols(C + 1);
+              for (int c = 0; c < C; ++c) cols[c] = Xc.data() + (size_t)c * n;
+              cols[C] = gt.data();
+              std::vector<double> bf(C + 1, 0.0), inv;
+              for (int c = 0; c < C; ++c) bf[c] = firth_bnull[(size_t)q * C + c];
+              double dev0 = 0.0, dev1 = 0.0;
+              corrected[(size_t)j * P + q] = 1;
+              const bool okx = firth_fit_cols(Yc.data() + (size_t)q * n, cols, mq, blup_off.data() + (size_t)q * n, n, C, 25.0, bf, &dev0) &&
+                               firth_fit_cols(Yc.data() + (size_t)q * n, cols, mq, blup_off.data() + (size_t)q * n, n, C + 1, 5.0, bf, &dev1, &inv);
+              const double lrt = dev0 - dev1;
+              if (!okx || lrt < 0) { corr_fail[(size_t)j * P + q] = 1; return; }
+              corr_beta[(size_t)j * P + q] = bf[C];
+              corr_chisq[(size_t)j * P + q] = lrt;
+              corr_se[(size_t)j * P + q] = (p.firth_se && lrt > 0) ? std::fabs(bf[C]) / std::sqrt(lrt) : std::sqrt(inv[(size_t)C * (C + 1) + C]);
+              return;
             }
             // Gres / Gamma_sqrt = g~ - x^T (X^T W X)^-1 X^T W g~ on the unmasked samples (compute_score_bt :503, :528-531; :2061)
             const double* s0 = bt_sums.data() + (size_t)j * 2 * bt_ncol;

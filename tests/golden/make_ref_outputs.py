@@ -147,6 +147,9 @@ def step2_cases(workdir, step1_dirs):
         "bt_firth_bgen": (step1_dirs["bt_loocv_refcmd"], ["--step", "2", "--bgen", "ex.bgen", "--covarFile", EX + "/covariates.txt",
                                                          "--phenoFile", EX + "/phenotype_bin.txt", "--remove", EX + "/fid_iid_to_remove.txt",
                                                          "--bsize", "200", "--bt", "--firth", "--approx", "--pThresh", "0.01"]),
+        "bt_firth_exact_bgen": (step1_dirs["bt_loocv_refcmd"], ["--step", "2", "--bgen", "ex.bgen", "--covarFile", EX + "/covariates.txt",
+                                                               "--phenoFile", EX + "/phenotype_bin.txt", "--remove", EX + "/fid_iid_to_remove.txt",
+                                                               "--bsize", "200", "--bt", "--firth", "--pThresh", "0.01"]),
         "bt_score_bed": (step1_dirs["bt_loocv_refcmd"], ["--step", "2", "--bed", EX + "/example", "--covarFile", EX + "/covariates.txt",
                                                         "--phenoFile", EX + "/phenotype_bin.txt", "--remove", EX + "/fid_iid_to_remove.txt",
                                                         "--bsize", "200", "--bt"]),

@@ -670,6 +670,37 @@ def test_cli_step2_bt_approx_firth_reproduces_the_reference_held_golden(example_
     assert 20 <= ncorr <= 40
 
 
+def test_cli_step2_bt_exact_firth_against_reference_output(example_dir, tmp_path):
+    """`--firth` without `--approx` (the covariates refitted with every flagged variant: fit_firth_logistic_snp, null fit under the full
+    penalty, then the full fit) on the documented command: against the output of oracle/_ref/regenie
+    (tests/golden/ref_outputs/step2/bt_firth_exact_bgen_Y*.regenie.gz), 29 corrected tests."""
+    import gzip
+    E = example_dir
+    R = os.path.join(ROOT, "tests", "golden", "ref_outputs")
+    with open(str(tmp_path / "pred.list"), "w") as pl:
+        for k in (1, 2):
+            fn = str(tmp_path / ("ref_%d.loco" % k))
+            open(fn, "wb").write(gzip.open(os.path.join(R, "bt_loocv_refcmd", "out_%d.loco.gz" % k), "rb").read())
+            pl.write("Y%d %s\n" % (k, fn))
+    r = _run(["--step", "2", "--bgen", os.path.join(E, "example.bgen"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"),
+              "--covarFile", os.path.join(E, "covariates.txt"), "--remove", os.path.join(E, "fid_iid_to_remove.txt"), "--bsize", "200", "--bt",
+              "--firth", "--pThresh", "0.01", "--pred", str(tmp_path / "pred.list"), "--out", "s2"], str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    loose = 0
+    for k in (1, 2):
+        got = open(str(tmp_path / ("s2_Y%d.regenie" % k))).read().splitlines()
+        ref = gzip.open(os.path.join(R, "step2", "bt_firth_exact_bgen_Y%d.regenie.gz" % k), "rt").read().splitlines()
+        assert got[0] == ref[0] and len(got) == len(ref) == 1001
+        for a, b in zip(got[1:], ref[1:]):
+            ta, tb = a.split(" "), b.split(" ")
+            assert ta[:9] == tb[:9] and ta[13] == tb[13] == "NA", (a, b)
+            if not all(float(x) == pytest.approx(float(y), rel=2e-5, abs=2e-9) for x, y in zip(ta[9:13], tb[9:13])):
+                loose += 1                                                          # a corrected row: regenie's stopping tolerance
+                for x, y in zip(ta[9:13], tb[9:13]):
+                    assert float(x) == pytest.approx(float(y), rel=3e-4, abs=2e-9), (a, b)
+    assert loose <= 29
+
+
 def test_cli_step2_bt_approx_firth_rare_variants_against_reference_output(tmp_path):
     """Rare, sparse variants (MAF 0.1 - 1 %, 5,200 samples, 3 binary traits with 2 % missing values, --pThresh 0.3): ~270 of the 900 tests get
     the Firth correction, about half of them in regenie's carriers-only form (MAC < 50).  Driver output against regenie's own
@@ -750,8 +781,6 @@ def test_cli_step2_ct_score_test_against_reference_output(tmp_path):
 def test_cli_step2_refuses_what_is_not_built(example_dir, tmp_path):
     E = example_dir
     base = ["--step", "2", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"), "--bsize", "200", "--pred", "x", "--out", "s2"]
-    r = _run(base + ["--bt", "--firth"], str(tmp_path))
-    assert r.returncode != 0 and "exact Firth test" in r.stdout
     r = _run(base + ["--bt", "--spa"], str(tmp_path))
     assert r.returncode != 0 and "saddlepoint correction" in r.stdout
     # chromosome X with male samples: the sex-aware allele counts of the non-PAR region are not built -- an error, not different numbers

@@ -397,6 +397,8 @@ def test_step2_bt_approx_firth_oracle_against_reference_and_golden():
         loco.append(v[:, [pos[i] for i in ids]])
     refs = [_read_regenie(os.path.join(REF_OUT, "step2", "bt_firth_bgen_Y%d.regenie.gz" % (ph + 1))) for ph in range(P)]
     golden = _read_regenie(E("test_bin_out_firth_Y1.regenie"))
+    exact = [_read_regenie(os.path.join(REF_OUT, "step2", "bt_firth_exact_bgen_Y%d.regenie.gz" % (ph + 1))) for ph in range(P)]
+    erow = {ph: {r[2]: r for r in exact[ph][1]} for ph in range(P)}          # by variant ID
     col = {nm: i for i, nm in enumerate(refs[0][0])}
     X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
     bg = obg.BgenOracle(E("example.bgen"))
@@ -406,12 +408,13 @@ def test_step2_bt_approx_firth_oracle_against_reference_and_golden():
     grow = {r[col["ID"]]: r for r in golden[1]}
     nfirth = 0
     for c in sorted(set(chrom.tolist())):
-        nulls, offs_f = [], []
+        nulls, offs_f, bnulls = [], [], []
         for ph in range(P):
             nl = bt.null_logistic(Yraw[:, ph], X, mask[:, ph], loco[ph][c - 1], opt)
             bnull = bt.firth_null(Yraw[:, ph], X, mask[:, ph], loco[ph][c - 1], nl["beta"])
             assert nl is not None and bnull is not None
             nulls.append(nl)
+            bnulls.append(bnull)
             offs_f.append(X @ bnull + loco[ph][c - 1])           # cov_blup_offset (Step2_Models.cpp:1011-1013)
         for k in np.flatnonzero(chrom == c):
             g, _, _ = s2.mean_impute(bg.dosages(int(k))[keep][ia])
@@ -423,6 +426,11 @@ def test_step2_bt_approx_firth_oracle_against_reference_and_golden():
                 out = bt.score_bt(g, X, Yraw[:, ph], m, nulls[ph])
                 corrected = abs(out["stats"]) > zthr
                 if corrected:
+                    ex = bt.exact_firth(g, X, Yraw[:, ph], m, loco[ph][c - 1], bnulls[ph])       # --firth without --approx: same threshold, other fit
+                    re = erow[ph][snp_ids[k]]
+                    assert ex is not None
+                    for nm in ("BETA", "SE", "CHISQ"):
+                        assert ex[{"BETA": "bhat", "SE": "se", "CHISQ": "chisq"}[nm]] == pytest.approx(float(re[col[nm]]), rel=2e-4), (snp_ids[k], ph, nm)
                     out = bt.approx_firth(g, X, Yraw[:, ph], m, nulls[ph], offs_f[ph])
                     assert out is not None
                     nfirth += 1
