@@ -48,7 +48,7 @@ def score_bt(g, X, y_raw, mask, null, numtol=NUMTOL):
     yres = (y_raw - null["p"]) / null["gamma_sqrt"] * mask
     stats = float(Gres @ yres) / np.sqrt(denum)
     se = 1.0 / np.sqrt(denum)
-    return dict(stats=stats, se=se, bhat=stats * se, chisq=stats * stats)
+    return dict(stats=stats, se=se, bhat=stats * se, chisq=stats * stats, denum=denum, Gres=Gres)
 
 
 def null_poisson(y_raw, X, mask, loco_offset, opt):
@@ -264,3 +264,99 @@ def exact_firth(g, X, y_raw, mask, loco_offset, beta_cov_start):
     if lrt < 0:
         return None
     return dict(bhat=float(full[0][C]), se=float(np.sqrt(full[2][C, C])), chisq=lrt)
+
+
+# ---- saddlepoint approximation (`--spa`) -----------------------------------------------------------------------------------------------
+MAX_EXP_LIM = 708.0          # Step2_Models.hpp
+TOL_SPA = np.finfo(np.float64).eps ** 0.25      # params.tol_spa (Regenie.hpp:330): regenie stops Newton at |K'(t) - s| < 1.2e-4, so the
+NITER_SPA = 1000                                 # iteration itself is restated (an exact root would differ in the 4th digit)
+
+
+def spa_test(stats, denum, Gres, null, mask, carriers=None):
+    """run_SPA_test_snp and its helpers (Step2_Models.cpp:2072-2297): the two-sided p-value of the score statistic from the saddlepoint
+    approximation of its null distribution (Lugannani-Rice), cumulant generating function K of sum_i Gmod_i (Y_i - p_i) / c with
+    Gmod = Gres / Gamma_sqrt.  carriers (the non-zero entries of the mean-imputed genotype, unmasked): regenie's fast form for sparse
+    variants -- exact terms for the carriers, a normal approximation for everyone else.  Returns dict(chisq, logp, bhat, se) or None."""
+    from scipy.stats import norm
+    m = mask.astype(bool)
+    phat, gam = null["p"], null["gamma_sqrt"]
+    c = np.sqrt(denum)
+    Gmod = np.where(m, Gres / gam, 0.0)
+    Gmu = Gmod * phat
+    a = float(Gmu[m].sum())
+    fast = carriers is not None
+    if fast:
+        idx = np.asarray([j for j in carriers if m[j]], dtype=np.int64)
+        b = denum - float((Gres[idx] ** 2).sum())
+        d = float(Gmu[idx].sum())
+        gm, ph, gs = Gmod[idx], phat[idx], gam[idx]
+    else:
+        gm, ph, gs = Gmod[m], phat[m], gam[m]
+    score_num = stats * c
+    lo = float(Gmod[m][Gmod[m] < 0].sum()) - a
+    hi = float(Gmod[m][Gmod[m] > 0].sum()) - a
+    if score_num < lo or score_num > hi:
+        return None
+
+    def K(t):
+        v = float(np.log(1 - ph + ph * np.exp(t / c * gm)).sum())
+        return v + (-t * d / c + t * t / 2 / denum * b if fast else -t * a / c)
+
+    def K1(t):
+        v = float(((gm * ph / c) / (ph + (1 - ph) * np.exp(-t / c * gm))).sum())
+        return v + (-d / c + t / denum * b if fast else -a / c)
+
+    def K2(t):
+        vexp = -t / c * gm
+        if (vexp > MAX_EXP_LIM).any():
+            return 0.0
+        v = float(((gm * gm * gs * gs / (c * c) * np.exp(vexp)) / (ph + (1 - ph) * np.exp(vexp)) ** 2).sum())
+        return v + (b / denum if fast else 0.0)
+
+    tval = -abs(stats)
+
+    def solve(lam):                                                    # solve_K1_snp: Newton with a bisection safeguard
+        min_x, max_x = (0.0, np.finfo(np.float64).max) if tval >= 0 else (np.finfo(np.float64).min, 0.0)
+        t_old = 0.0
+        f_old = lam * K1(lam * t_old) - tval
+        t_new = -1.0
+        for _ in range(NITER_SPA):
+            hess = K2(lam * t_old)
+            if hess == 0:
+                return None
+            t_new = t_old - f_old / hess
+            f_new = lam * K1(lam * t_new) - tval
+            if abs(f_new) < TOL_SPA:
+                return t_new
+            if t_new and min_x < t_new < max_x:
+                if f_new > 0:
+                    max_x = t_new
+                else:
+                    min_x = t_new
+            else:
+                t_new = (min_x + max_x) / 2
+                f_new = lam * K1(lam * t_new) - tval
+                if f_new <= 0:
+                    min_x = t_new
+                else:
+                    max_x = t_new
+            t_old, f_old = t_new, f_new
+        return None
+
+    pv = 0.0
+    for lam in (1, -1):
+        root = solve(lam)
+        if root is None:
+            return None
+        kval, k2val = K(lam * root), K2(lam * root)
+        if k2val == 0:
+            return None
+        wval = np.sign(root) * np.sqrt(2 * (root * tval - kval))
+        vval = root * np.sqrt(k2val)
+        pv += 0.5 if vval == 0 else float(norm.cdf(wval + np.log(vval / wval) / wval))
+    if pv > 1:
+        return None
+    pval = max(10.0 * np.finfo(np.float64).tiny, pv)                   # get_logp(pv, ...), Regenie.cpp:1859-1873
+    chisq = float(norm.isf(pval / 2) ** 2)
+    se = 1.0 / np.sqrt(denum)                                          # check_pval_snp :2019-2020
+    return dict(chisq=chisq, logp=-np.log10(pval), se=se, bhat=np.sign(stats) * np.sqrt(chisq) * se)

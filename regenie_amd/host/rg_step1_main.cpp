@@ -58,6 +58,7 @@ struct Params {
   bool rint = false;
   int bsize = 0, cv_folds = 5, n_ridge_l0 = 5, n_ridge_l1 = 5, nchrom = 23, threads = 0;
   bool firth = false, firth_approx = false, firth_se = false;   // --firth --approx [--firth-se] (step 2, binary traits)
+  bool spa = false;                                             // --spa (step 2, binary traits)
   double pthresh = 0.05;                                        // --pThresh: score tests below it get the correction
   double min_info = 0.0; bool set_min_info = false;             // --minINFO (step 2, dosages)
   bool bt = false, ct = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
@@ -365,7 +366,7 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--approx") p.firth_approx = true;
     else if (a == "--firth-se") p.firth_se = true;
     else if (a == "--pThresh") p.pthresh = atof(need(i).c_str());
-    else if (a == "--spa") usage_error("'--spa': the saddlepoint correction of the binary-trait test is not built (--firth --approx is).");
+    else if (a == "--spa") p.spa = true;
     else usage_error("unrecognised option '" + a + "'");
   }
   if (p.bt) p.rint = false;  // Regenie.cpp:432
@@ -373,6 +374,9 @@ Params parse_args(int argc, char** argv) {
   if (p.step == 2) {
     if (p.pred_list.empty()) usage_error("option '--pred' is required (use the _pred.list file written by step 1).");
     if (p.firth && !p.bt) usage_error("option '--firth' applies to binary traits (--bt).");
+    if (p.spa && !p.bt) usage_error("option '--spa' applies to binary traits (--bt).");
+    if (p.spa && p.firth) usage_error("cannot use both '--firth' and '--spa'.");
+    if (p.spa && !(p.pthresh > 0 && p.pthresh < 1)) usage_error("'--pThresh' must be in (0,1).");
     if (p.firth && !(p.pthresh > 0 && p.pthresh < 1)) usage_error("'--pThresh' must be in (0,1).");
     if (p.min_mac < 0.5) usage_error("minimum MAC must be at least 0.5.");   // Regenie.cpp:1054
     if (p.set_min_info && (p.min_info < 0 || p.min_info > 1)) usage_error("minimum info score must be in [0,1].");
@@ -1522,6 +1526,62 @@ bool firth_snp_fit(const std::vector<double>& g, const std::vector<double>& y, c
   return true;
 }
 
+// ---- saddlepoint approximation of the binary-trait test (--spa): run_SPA_test_snp and its helpers (Step2_Models.cpp:2072-2297) -------------
+// The two-sided p-value of the score statistic from the Lugannani-Rice formula, cumulant generating function K of sum_i gm_i (Y_i - p_i) / c.
+// gm / ph / gs: Gmod = Gres / Gamma_sqrt, the fitted probabilities and Gamma_sqrt of the samples that enter the exact terms (every unmasked
+// sample, or the carriers in regenie's fast form, whose other samples enter through the normal approximation b, d); a = sum gm p over every
+// unmasked sample; lo / hi: the range K' can reach.  regenie stops its Newton iteration at |K'(t) - s| < eps^(1/4) = 1.2e-4, so the iteration is
+// restated step for step (an exact root differs in the 4th digit of the p-value).  false = TEST_FAIL.
+bool spa_pvalue(double stats, double denum, const std::vector<double>& gm, const std::vector<double>& ph, const std::vector<double>& gs, double a, bool fast,
+                double b, double d, double lo, double hi, double& pval_out) {
+  const double c = std::sqrt(denum), tol = std::pow(2.220446049250313e-16, 0.25);
+  const size_t m = gm.size();
+  if (stats * c < lo || stats * c > hi) return false;
+  auto K = [&](double t) { double v = 0.0; for (size_t i = 0; i < m; ++i) v += std::log(1.0 - ph[i] + ph[i] * std::exp(t / c * gm[i])); return v + (fast ? -t * d / c + t * t / 2.0 / denum * b : -t * a / c); };
+  auto K1 = [&](double t) { double v = 0.0; for (size_t i = 0; i < m; ++i) v += (gm[i] * ph[i] / c) / (ph[i] + (1.0 - ph[i]) * std::exp(-t / c * gm[i])); return v + (fast ? -d / c + t / denum * b : -a / c); };
+  auto K2 = [&](double t) {
+    double v = 0.0;
+    for (size_t i = 0; i < m; ++i) {
+      const double vexp = -t / c * gm[i];
+      if (vexp > 708.0) return 0.0;                                    // MAX_EXP_LIM
+      const double e = std::exp(vexp), den = ph[i] + (1.0 - ph[i]) * e;
+      v += (gm[i] * gm[i] * gs[i] * gs[i] / (c * c) * e) / (den * den);
+    }
+    return v + (fast ? b / denum : 0.0);
+  };
+  const double tval = stats >= 0 ? -stats : stats;
+  double pv = 0.0;
+  for (int lam = 1; lam >= -1; lam -= 2) {
+    // solve_K1_snp: Newton with a bisection safeguard
+    double min_x = tval >= 0 ? 0.0 : std::numeric_limits<double>::lowest(), max_x = tval >= 0 ? std::numeric_limits<double>::max() : 0.0;
+    double t_old = 0.0, f_old = lam * K1(lam * t_old) - tval, t_new = -1.0, f_new;
+    bool conv = false;
+    for (int it = 0; it < 1000; ++it) {
+      const double hess = K2(lam * t_old);
+      if (hess == 0.0) return false;
+      t_new = t_old - f_old / hess;
+      f_new = lam * K1(lam * t_new) - tval;
+      if (std::fabs(f_new) < tol) { conv = true; break; }
+      if (t_new != 0.0 && t_new > min_x && t_new < max_x) { if (f_new > 0) max_x = t_new; else min_x = t_new; }
+      else {
+        t_new = (min_x + max_x) / 2.0;
+        f_new = lam * K1(lam * t_new) - tval;
+        if (f_new <= 0) min_x = t_new; else max_x = t_new;
+      }
+      t_old = t_new; f_old = f_new;
+    }
+    if (!conv) return false;
+    const double root = t_new, kval = K(lam * root), k2val = K2(lam * root);
+    if (k2val == 0.0) return false;
+    const double wval = (root > 0 ? 1.0 : root < 0 ? -1.0 : 0.0) * std::sqrt(2.0 * (root * tval - kval)), vval = root * std::sqrt(k2val);
+    if (vval == 0.0) pv += 0.5;
+    else { const double rval = wval + std::log(vval / wval) / wval; pv += 0.5 * std::erfc(-rval / std::sqrt(2.0)); }
+  }
+  if (!(pv <= 1.0)) return false;
+  pval_out = pv;
+  return true;
+}
+
 int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   const Params& p = r.p;
   const int64_t N = r.N;
@@ -1549,14 +1609,17 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   std::vector<double> bt_cols, bt_xwx_inv, bt_sums, bt_sq, bt_vstat;
   std::vector<int32_t> bt_counts;
   std::vector<uint8_t> bt_pass(P, 1), test_ignored;
-  const bool firth = p.bt && p.firth;
-  const double z_thr = firth ? norm_quantile(1.0 - 0.5 * p.pthresh) : 0.0;   // sqrt of the chi-square(1) quantile at 1 - pThresh (Data.cpp:2119-2120)
+  const bool firth = p.bt && p.firth, spa = p.bt && p.spa, correct = firth || spa;
+  const double z_thr = correct ? norm_quantile(1.0 - 0.5 * p.pthresh) : 0.0;   // sqrt of the chi-square(1) quantile at 1 - pThresh (Data.cpp:2119-2120)
   std::vector<double> firth_off;                      // [P][n] cov_blup_offset: X beta_nullFirth + LOCO prediction (fit_null_firth, Step2_Models.cpp:1011-1013)
   if (firth) firth_off.assign((size_t)P * n, 0.0);
   std::vector<double> firth_bnull((size_t)P * C, 0.0), blup_off;      // exact Firth: the covariate-only estimates (start values), the LOCO offsets
   if (firth && !p.firth_approx) blup_off.assign((size_t)P * n, 0.0);
+  std::vector<double> bt_phat;                        // [P][n] the null model's fitted probabilities (--spa)
+  if (spa) bt_phat.assign((size_t)P * n, 0.5);
+  std::vector<double> denum_v;                        // per (variant, trait): the score test's denominator
   std::vector<uint8_t> corrected, corr_fail;          // per (variant, trait) of a block
-  std::vector<double> corr_beta, corr_se, corr_chisq;
+  std::vector<double> corr_beta, corr_se, corr_chisq, corr_logp;
   if (glm) { bt_cols.assign((size_t)bt_ncol * n, 0.0); bt_xwx_inv.assign((size_t)P * C * C, 0.0); }
 
   rg_s2_ctx* s2 = nullptr;
@@ -1681,6 +1744,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
           const double m = mq[k] ? 1.0 : 0.0;
           const double w = (p.ct ? pv[k] : pv[k] * (1.0 - pv[k])) * m;          // Gamma_sqrt^2 on the unmasked samples: p (1 - p) (get_wvec) or the Poisson rate
           cw[k] = w; cr[k] = (yq[k] - pv[k]) * m; cm[k] = m;
+          if (spa) bt_phat[(size_t)q * n + k] = pv[k];
           for (int a = 0; a < C; ++a) {
             const double xa = Xc[(size_t)a * n + k] * w;
             bt_cols[(size_t)(P + q * C + a) * n + k] = xa;
@@ -1832,6 +1896,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
         af_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0);
         std::vector<double> mu_v(bs, 0.0);
         std::vector<uint8_t> sparse_v(bs, 0);
+        denum_v.assign((size_t)bs * P, 0.0);
         parallel_for(bs, nthreads, [&](int j) {
           double nobs, tot, nnz;        // observed samples, allele total, observed non-zero entries
           if (in == In::Dosage) { nobs = bt_vstat[(size_t)j * 4 + 2]; tot = bt_vstat[(size_t)j * 4] / dscale; nnz = bt_vstat[(size_t)j * 4 + 3]; }
@@ -1870,15 +1935,16 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
             const double denum = sw2 - quad, sd = std::sqrt(denum);
             if (p.ct ? !(denum >= NUMTOL) : !(sd >= NUMTOL)) { test_ignored[(size_t)j * P + q] = 1; continue; }   // Step2_Models.cpp:512-517, :596
             const double st = (s0[cr] + mu * s1[cr]) / sd;
+            denum_v[(size_t)j * P + q] = denum;
             stats[(size_t)j * P + q] = st;
             bhat[(size_t)j * P + q] = st / sd;                                                      // get_sumstats (Step2_Models.cpp:2031-2041)
           }
         });
-        if (firth) {
-          // check_pval_snp (Step2_Models.cpp:1987-2029): |z| above the threshold -> fit_firth_logistic_snp_fast on Gres / Gamma_sqrt with the
+        if (correct) {
+          // check_pval_snp (Step2_Models.cpp:1987-2029): |z| above the threshold -> run_SPA_test (--spa) or fit_firth_logistic_snp_fast on Gres / Gamma_sqrt with the
           // null Firth model's covariate effects in the offset.  The few flagged (variant, trait) pairs are fitted on the host threads.
           corrected.assign((size_t)bs * P, 0); corr_fail.assign((size_t)bs * P, 0);
-          corr_beta.assign((size_t)bs * P, 0.0); corr_se.assign((size_t)bs * P, 0.0); corr_chisq.assign((size_t)bs * P, 0.0);
+          corr_beta.assign((size_t)bs * P, 0.0); corr_se.assign((size_t)bs * P, 0.0); corr_chisq.assign((size_t)bs * P, 0.0); corr_logp.assign((size_t)bs * P, -1.0);
           std::vector<int> todo;
           for (int j = 0; j < bs; ++j)
             for (int q = 0; q < P; ++q)
@@ -1895,6 +1961,45 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
                 if (flip && hc != -3.0) hc = 2.0 - hc;
                 gt[k] = hc == -3.0 ? mu : hc;
               }
+            }
+            if (spa) {
+              // Gmod = Gres / Gamma_sqrt = g~ - x^T (X^T W X)^-1 X^T W g~ on the unmasked samples; the carriers (non-zero entries of the mean-imputed
+              // genotype) alone enter the exact terms when the variant is sparse (fastSPA, Step2_Models.cpp:2087-2097)
+              const double* s0 = bt_sums.data() + (size_t)j * 2 * bt_ncol;
+              const double* s1 = s0 + bt_ncol;
+              const double* inv = bt_xwx_inv.data() + (size_t)q * C * C;
+              std::vector<double> tc(C, 0.0);
+              for (int a = 0; a < C; ++a)
+                for (int c = 0; c < C; ++c) tc[a] += inv[(size_t)a * C + c] * (s0[P + q * C + c] + mu * s1[P + q * C + c]);
+              const uint8_t* mq = Mc.data() + (size_t)q * n;
+              const double* pq = bt_phat.data() + (size_t)q * n;
+              const bool fast = sparse_v[j] != 0;
+              const double denum = denum_v[(size_t)j * P + q], st = stats[(size_t)j * P + q];
+              std::vector<double> gmv, phv, gsv;
+              double a_all = 0.0, lo = 0.0, hi = 0.0, b = denum, d = 0.0;
+              for (int64_t k = 0; k < n; ++k) {
+                if (!mq[k]) continue;
+                double v = gt[k];
+                for (int c = 0; c < C; ++c) v -= Xc[(size_t)c * n + k] * tc[c];
+                const double ph = pq[k], gs = std::sqrt(ph * (1.0 - ph));
+                a_all += v * ph;
+                if (v < 0) lo += v; else hi += v;
+                if (fast) {
+                  if (gt[k] == 0.0) continue;
+                  b -= v * gs * v * gs; d += v * ph;
+                }
+                gmv.push_back(v); phv.push_back(ph); gsv.push_back(gs);
+              }
+              corrected[(size_t)j * P + q] = 1;
+              double pval = 0.0;
+              if (!spa_pvalue(st, denum, gmv, phv, gsv, a_all, fast, b, d, lo - a_all, hi - a_all, pval)) { corr_fail[(size_t)j * P + q] = 1; return; }
+              pval = std::max(10.0 * std::numeric_limits<double>::min(), pval);          // get_logp(pv, logp, chisq, nl_dbl_dmin), Regenie.cpp:1859-1873
+              const double z = norm_quantile(0.5 * pval), chisq = z * z, se = 1.0 / std::sqrt(denum);
+              corr_chisq[(size_t)j * P + q] = chisq;
+              corr_se[(size_t)j * P + q] = se;                                            // check_pval_snp :2019-2020
+              corr_beta[(size_t)j * P + q] = (st > 0 ? 1.0 : st < 0 ? -1.0 : 0.0) * std::sqrt(chisq) * se;
+              corr_logp[(size_t)j * P + q] = -std::log10(pval);
+              return;
             }
             if (!p.firth_approx) {
               // the exact test (fit_firth_logistic_snp, Step2_Models.cpp:1062-1156): design [covariates | g~ on its raw scale], offset = the LOCO
@@ -2050,11 +2155,12 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
           const double st = stats[(size_t)j * P + q];
           double bh = bhat[(size_t)j * P + q], se = bh / st, chisq = st * st;
           bool test_fail = false;
-          if (firth && corrected[(size_t)j * P + q]) {
+          double logp_spa = -1.0;
+          if (correct && corrected[(size_t)j * P + q]) {
             if (corr_fail[(size_t)j * P + q]) test_fail = true;                    // get_sumstats(true, ...): the score test's BETA / SE, no p-value
-            else { bh = corr_beta[(size_t)j * P + q]; se = corr_se[(size_t)j * P + q]; chisq = corr_chisq[(size_t)j * P + q]; }
+            else { bh = corr_beta[(size_t)j * P + q]; se = corr_se[(size_t)j * P + q]; chisq = corr_chisq[(size_t)j * P + q]; logp_spa = corr_logp[(size_t)j * P + q]; }
           }
-          const double logp = get_logp(chisq);
+          const double logp = logp_spa >= 0 ? logp_spa : get_logp(chisq);       // --spa prints the p-value it computed, the chi-square is derived from it
           std::ostringstream ln;
           ln << head.str() << af << " ";
           if (show_info) ln << info << " ";

@@ -150,6 +150,9 @@ def step2_cases(workdir, step1_dirs):
         "bt_firth_exact_bgen": (step1_dirs["bt_loocv_refcmd"], ["--step", "2", "--bgen", "ex.bgen", "--covarFile", EX + "/covariates.txt",
                                                                "--phenoFile", EX + "/phenotype_bin.txt", "--remove", EX + "/fid_iid_to_remove.txt",
                                                                "--bsize", "200", "--bt", "--firth", "--pThresh", "0.01"]),
+        "bt_spa_bgen": (step1_dirs["bt_loocv_refcmd"], ["--step", "2", "--bgen", "ex.bgen", "--covarFile", EX + "/covariates.txt",
+                                                       "--phenoFile", EX + "/phenotype_bin.txt", "--remove", EX + "/fid_iid_to_remove.txt",
+                                                       "--bsize", "200", "--bt", "--spa", "--pThresh", "0.01"]),
         "bt_score_bed": (step1_dirs["bt_loocv_refcmd"], ["--step", "2", "--bed", EX + "/example", "--covarFile", EX + "/covariates.txt",
                                                         "--phenoFile", EX + "/phenotype_bin.txt", "--remove", EX + "/fid_iid_to_remove.txt",
                                                         "--bsize", "200", "--bt"]),
@@ -183,6 +186,8 @@ def step2_cases(workdir, step1_dirs):
     shutil.copy(Sb + ".fam", Sb + "_rare.fam")
     runs["bt_firth_rare"] = (step1_dirs["bt_kfold_synth"], ["--step", "2", "--bed", Sb + "_rare", "--covarFile", Sb + ".covar", "--phenoFile", Sb + ".pheno",
                                                           "--bsize", "100", "--bt", "--firth", "--approx", "--pThresh", "0.3"])
+    runs["bt_spa_rare"] = (step1_dirs["bt_kfold_synth"], ["--step", "2", "--bed", Sb + "_rare", "--covarFile", Sb + ".covar", "--phenoFile", Sb + ".pheno",
+                                                        "--bsize", "100", "--bt", "--spa", "--pThresh", "0.3"])
     Sc = os.path.join(step1_dirs["ct_synth"], "synth")
     runs["ct_synth"] = (step1_dirs["ct_synth"], ["--step", "2", "--bed", Sc, "--covarFile", Sc + ".covar", "--phenoFile", Sc + ".pheno", "--bsize", "100", "--ct"])
     for name, (s1, args) in runs.items():

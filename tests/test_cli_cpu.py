@@ -73,7 +73,7 @@ def test_step2_usage_errors(example_dir, tmp_path):
         return r.stdout + r.stderr
 
     assert "option '--pred' is required" in err(["--bt"])
-    assert "saddlepoint correction" in err(["--bt", "--pred", "p.list", "--spa"])
+    assert "cannot use both" in err(["--bt", "--pred", "p.list", "--spa", "--firth", "--approx"])
     assert "applies to binary traits" in err(["--qt", "--pred", "p.list", "--firth", "--approx"])
     assert "minimum MAC must be at least 0.5" in err(["--qt", "--pred", "p.list", "--minMAC", "0.1"])
     assert "--step 2 runs on one GPU" in err(["--qt", "--pred", "p.list", "--gpus", "2"])

@@ -701,6 +701,72 @@ def test_cli_step2_bt_exact_firth_against_reference_output(example_dir, tmp_path
     assert loose <= 29
 
 
+def test_cli_step2_bt_spa_against_reference_output(example_dir, tmp_path):
+    """`--spa` on the documented command (.bgen dosages): saddlepoint p-values of the 29 tests above the threshold, run_SPA_test_snp with its
+    Newton iteration restated step for step -- every row to the printed digits (tests/golden/ref_outputs/step2/bt_spa_bgen_Y*.regenie.gz)."""
+    import gzip
+    E = example_dir
+    R = os.path.join(ROOT, "tests", "golden", "ref_outputs")
+    with open(str(tmp_path / "pred.list"), "w") as pl:
+        for k in (1, 2):
+            fn = str(tmp_path / ("ref_%d.loco" % k))
+            open(fn, "wb").write(gzip.open(os.path.join(R, "bt_loocv_refcmd", "out_%d.loco.gz" % k), "rb").read())
+            pl.write("Y%d %s\n" % (k, fn))
+    r = _run(["--step", "2", "--bgen", os.path.join(E, "example.bgen"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"),
+              "--covarFile", os.path.join(E, "covariates.txt"), "--remove", os.path.join(E, "fid_iid_to_remove.txt"), "--bsize", "200", "--bt",
+              "--spa", "--pThresh", "0.01", "--pred", str(tmp_path / "pred.list"), "--out", "s2"], str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    for k in (1, 2):
+        got = open(str(tmp_path / ("s2_Y%d.regenie" % k))).read().splitlines()
+        ref = gzip.open(os.path.join(R, "step2", "bt_spa_bgen_Y%d.regenie.gz" % k), "rt").read().splitlines()
+        assert got[0] == ref[0] and len(got) == len(ref) == 1001
+        same = 0
+        for a, b in zip(got[1:], ref[1:]):
+            ta, tb = a.split(" "), b.split(" ")
+            assert ta[:9] == tb[:9] and ta[13] == tb[13], (a, b)
+            for x, y in zip(ta[9:13], tb[9:13]):
+                assert float(x) == pytest.approx(float(y), rel=3e-5, abs=2e-9), (a, b)
+            same += a == b
+        assert same >= 900, same
+
+
+def test_cli_step2_bt_spa_rare_variants_against_reference_output(tmp_path):
+    """`--spa --pThresh 0.3` on the rare, sparse variants of the Firth test below: 271 corrected tests, the sparse ones in regenie's fast form
+    (exact terms for the carriers, normal approximation for the rest), one of them a TEST_FAIL in regenie's output and here."""
+    import gzip
+    import json
+    import shutil
+    from tests.util import synth_dosages, synth_rare_dosages, write_bed_bim, write_plink
+    R = os.path.join(ROOT, "tests", "golden", "ref_outputs")
+    meta = json.load(open(os.path.join(R, "bt_kfold_synth", "meta.json")))
+    spec = meta["synthetic"]
+    S = str(tmp_path / "synth")
+    write_plink(S, synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"]), spec["chroms"], P=spec["P"],
+                seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    write_bed_bim(S + "_rare", synth_rare_dosages(300, spec["N"], seed=spec["seed"], miss_rate=0.002), [1] * 100 + [2] * 100 + [5] * 100)
+    shutil.copy(S + ".fam", S + "_rare.fam")
+    with open(str(tmp_path / "pred.list"), "w") as pl:
+        for k, nm in enumerate(meta["pred_list"]):
+            fn = str(tmp_path / ("ref_%d.loco" % (k + 1)))
+            open(fn, "wb").write(gzip.open(os.path.join(R, "bt_kfold_synth", "out_%d.loco.gz" % (k + 1)), "rb").read())
+            pl.write("%s %s\n" % (nm, fn))
+    r = _run(["--step", "2", "--bed", S + "_rare", "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "100", "--bt", "--spa",
+              "--pThresh", "0.3", "--pred", str(tmp_path / "pred.list"), "--out", "s2"], str(tmp_path))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    nfail = 0
+    for k in range(1, spec["P"] + 1):
+        got = open(str(tmp_path / ("s2_Y%d.regenie" % k))).read().splitlines()
+        ref = gzip.open(os.path.join(R, "step2", "bt_spa_rare_Y%d.regenie.gz" % k), "rt").read().splitlines()
+        assert got[0] == ref[0] and len(got) == len(ref) == 301
+        for a, b in zip(got[1:], ref[1:]):
+            ta, tb = a.split(" "), b.split(" ")
+            assert ta[:8] == tb[:8] and ta[12] == tb[12], (a, b)                   # EXTRA: NA or TEST_FAIL
+            nfail += tb[12] == "TEST_FAIL"
+            for x, y in zip(ta[8:12], tb[8:12]):
+                assert (x == y == "NA") or float(x) == pytest.approx(float(y), rel=3e-5, abs=2e-9), (a, b)
+    assert nfail == 1
+
+
 def test_cli_step2_bt_approx_firth_rare_variants_against_reference_output(tmp_path):
     """Rare, sparse variants (MAF 0.1 - 1 %, 5,200 samples, 3 binary traits with 2 % missing values, --pThresh 0.3): ~270 of the 900 tests get
     the Firth correction, about half of them in regenie's carriers-only form (MAC < 50).  Driver output against regenie's own
@@ -781,8 +847,8 @@ def test_cli_step2_ct_score_test_against_reference_output(tmp_path):
 def test_cli_step2_refuses_what_is_not_built(example_dir, tmp_path):
     E = example_dir
     base = ["--step", "2", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"), "--bsize", "200", "--pred", "x", "--out", "s2"]
-    r = _run(base + ["--bt", "--spa"], str(tmp_path))
-    assert r.returncode != 0 and "saddlepoint correction" in r.stdout
+    r = _run(base + ["--bt", "--spa", "--firth", "--approx"], str(tmp_path))
+    assert r.returncode != 0 and "cannot use both" in r.stdout
     # chromosome X with male samples: the sex-aware allele counts of the non-PAR region are not built -- an error, not different numbers
     import gzip
     import shutil

@@ -399,6 +399,8 @@ def test_step2_bt_approx_firth_oracle_against_reference_and_golden():
     golden = _read_regenie(E("test_bin_out_firth_Y1.regenie"))
     exact = [_read_regenie(os.path.join(REF_OUT, "step2", "bt_firth_exact_bgen_Y%d.regenie.gz" % (ph + 1))) for ph in range(P)]
     erow = {ph: {r[2]: r for r in exact[ph][1]} for ph in range(P)}          # by variant ID
+    spa = [_read_regenie(os.path.join(REF_OUT, "step2", "bt_spa_bgen_Y%d.regenie.gz" % (ph + 1))) for ph in range(P)]
+    srow = {ph: {r[2]: r for r in spa[ph][1]} for ph in range(P)}
     col = {nm: i for i, nm in enumerate(refs[0][0])}
     X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
     bg = obg.BgenOracle(E("example.bgen"))
@@ -431,6 +433,12 @@ def test_step2_bt_approx_firth_oracle_against_reference_and_golden():
                     assert ex is not None
                     for nm in ("BETA", "SE", "CHISQ"):
                         assert ex[{"BETA": "bhat", "SE": "se", "CHISQ": "chisq"}[nm]] == pytest.approx(float(re[col[nm]]), rel=2e-4), (snp_ids[k], ph, nm)
+                    sparse = s2.check_sparse(g, int(keep.sum()))                                   # fastSPA = the variant is sparse (Data.cpp:2503; Geno.cpp:3179)
+                    sp = bt.spa_test(out["stats"], out["denum"], out["Gres"], nulls[ph], m, carriers=np.flatnonzero(g != 0) if sparse else None)   # --spa
+                    rs = srow[ph][snp_ids[k]]
+                    assert sp is not None
+                    for nm, key in (("BETA", "bhat"), ("SE", "se"), ("CHISQ", "chisq"), ("LOG10P", "logp")):
+                        assert sp[key] == pytest.approx(float(rs[col[nm]]), rel=3e-5), (snp_ids[k], ph, nm)
                     out = bt.approx_firth(g, X, Yraw[:, ph], m, nulls[ph], offs_f[ph])
                     assert out is not None
                     nfirth += 1
@@ -471,9 +479,12 @@ def test_step2_bt_approx_firth_rare_variants_against_reference(tmp_path):
         pos = {s: k for k, s in enumerate(hdr)}
         loco.append(v[:, [pos[i] for i in ids]])
     refs = [_read_regenie(os.path.join(REF_OUT, "step2", "bt_firth_rare_Y%d.regenie.gz" % (ph + 1))) for ph in range(P)]
+    spa = [_read_regenie(os.path.join(REF_OUT, "step2", "bt_spa_rare_Y%d.regenie.gz" % (ph + 1))) for ph in range(P)]
+    srow = {ph: {r[2]: r for r in spa[ph][1]} for ph in range(P)}
     col = {nm: i for i, nm in enumerate(refs[0][0])}
     X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
     zthr = float(norm.ppf(1 - 0.3 / 2))
+    nspa_fail = 0
     n_all = int((~prep.ind_ignore).sum())
     ncorr = nfast = 0
     for c in sorted(set(chrom.tolist())):
@@ -497,6 +508,15 @@ def test_step2_bt_approx_firth_rare_variants_against_reference(tmp_path):
                 m = mask[:, ph].astype(np.float64)
                 out = bt.score_bt(g, X, Yraw[:, ph], m, nulls[ph])
                 if abs(out["stats"]) > zthr:
+                    # --spa on the same data (bt_spa_rare): the fast form for sparse variants, one test regenie reports as TEST_FAIL
+                    sp = bt.spa_test(out["stats"], out["denum"], out["Gres"], nulls[ph], m, carriers=np.flatnonzero(g != 0) if sparse else None)
+                    rs = srow[ph][snp_ids[sel[k]]]
+                    if rs[-1] == "TEST_FAIL":
+                        assert sp is None and out["bhat"] == pytest.approx(float(rs[col["BETA"]]), rel=3e-5)
+                        nspa_fail += 1
+                    else:
+                        for nm, key in (("BETA", "bhat"), ("SE", "se"), ("CHISQ", "chisq"), ("LOG10P", "logp")):
+                            assert sp[key] == pytest.approx(float(rs[col[nm]]), rel=3e-5), (snp_ids[sel[k]], ph, nm)
                     tq = float(G[k][obs & (m > 0)].sum())
                     nq = int((obs & (m > 0)).sum())
                     mac = min(tq, 2 * nq - tq)
@@ -509,7 +529,7 @@ def test_step2_bt_approx_firth_rare_variants_against_reference(tmp_path):
                 assert abs(out["bhat"] - beta) <= 8e-4 * se * se + 2e-5 * abs(beta) + 5e-6, (snp_ids[sel[k]], ph)
                 assert out["se"] == pytest.approx(se, rel=2e-4)
                 assert out["chisq"] == pytest.approx(chisq, rel=2e-3, abs=2e-5)      # (its LRT is taken one outer iteration before its BETA)
-    assert ncorr > 200 and nfast > 80
+    assert ncorr > 200 and nfast > 80 and nspa_fail == 1
 
 
 needs_ref_binary = pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")
