@@ -10,7 +10,7 @@ copies) or on the deterministic synthetic data of tests/util.py (cases that need
 Stored per case: the .loco files (gzipped text), the CV table lines of the log, _pred.list phenotype names,
 and for the split-l0 case the raw level-0 predictor files (full fp64).
 
-  python tests/golden/make_ref_outputs.py            # needs oracle/_ref/regenie (make -C oracle)
+  python tests/golden/make_ref_outputs.py [--out DIR]   # needs oracle/_ref/regenie (make -C oracle)
 """
 from __future__ import annotations
 
@@ -144,6 +144,9 @@ def step2_cases(workdir, step1_dirs):
     runs = {
         "qt_bed_3chr": (step1_dirs["qt_kfold_3chr"], ["--step", "2", "--bed", EX + "/example_3chr", "--covarFile", EX + "/covariates.txt",
                                                       "--phenoFile", EX + "/phenotype.txt", "--bsize", "200", "--qt"]),
+        "qt_bed_3chr_opts": (step1_dirs["qt_kfold_3chr"], ["--step", "2", "--bed", EX + "/example_3chr", "--covarFile", EX + "/covariates.txt",
+                                                           "--phenoFile", EX + "/phenotype.txt", "--remove", EX + "/fid_iid_to_remove.txt",
+                                                           "--ref-first", "--minMAC", "40", "--bsize", "300", "--qt"]),
         "bt_firth_bgen": (step1_dirs["bt_loocv_refcmd"], ["--step", "2", "--bgen", "ex.bgen", "--covarFile", EX + "/covariates.txt",
                                                          "--phenoFile", EX + "/phenotype_bin.txt", "--remove", EX + "/fid_iid_to_remove.txt",
                                                          "--bsize", "200", "--bt", "--firth", "--approx", "--pThresh", "0.01"]),
@@ -202,6 +205,9 @@ def step2_cases(workdir, step1_dirs):
 
 
 def main():
+    global OUT
+    if len(sys.argv) > 2 and sys.argv[1] == "--out":      # write somewhere else (to compare with the committed fixtures)
+        OUT = os.path.abspath(sys.argv[2])
     if not os.path.exists(REGENIE):
         raise SystemExit("build the reference first: make -C oracle")
     if os.path.isdir(OUT):
