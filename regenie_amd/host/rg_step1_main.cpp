@@ -16,6 +16,7 @@
 // gzipped text inputs and --gz outputs through zlib (Files.cpp:38-160).  Not served (explicit errors, never silent): BGEN files
 // other than layout 2 with 8-bit probabilities.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -23,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iomanip>
 #include <iostream>
 #include <map>
@@ -1681,6 +1683,33 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   for (int64_t k = 0; identity && k < n; ++k) identity = file_idx[k] == k;
   int64_t n_ignored_snps = 0, n_ignored_tests = 0, n_tested = 0;
   int block = 0;
+  // .bed rows of a block: runs of consecutive variants are cut into pieces read by several threads (the page-cache copy of one pread is a
+  // single core's memcpy), and the NEXT block of the chromosome is read while the current one is tested
+  std::vector<uint8_t> rows_ahead;
+  std::future<void> ahead;
+  auto read_bed = [&](const std::vector<int64_t>& snps, int64_t j0, int bs, std::vector<uint8_t>& buf) {
+    buf.resize((size_t)bs * r.bpr);
+    struct Piece { int64_t file_off, buf_off, len; };
+    std::vector<Piece> pieces;
+    const int64_t chunk = 16 << 20;
+    for (int j = 0; j < bs;) {
+      int e = j + 1;
+      while (e < bs && r.snp_offset[snps[j0 + e]] == r.snp_offset[snps[j0 + e - 1]] + 1) ++e;
+      const int64_t want = (int64_t)(e - j) * r.bpr, off = 3 + r.snp_offset[snps[j0 + j]] * r.bpr;
+      for (int64_t o = 0; o < want; o += chunk) pieces.push_back({off + o, (int64_t)j * r.bpr + o, std::min(chunk, want - o)});
+      j = e;
+    }
+    std::atomic<int> failed(0);
+    parallel_for((int)pieces.size(), std::min(nthreads, 8), [&](int t) {
+      int64_t got = 0;
+      while (got < pieces[t].len) {
+        const ssize_t k = pread(fd, buf.data() + pieces[t].buf_off + got, (size_t)(pieces[t].len - got), pieces[t].file_off + got);
+        if (k <= 0) { failed = 1; return; }
+        got += k;
+      }
+    });
+    if (failed) throw std::runtime_error("cannot read bed file");
+  };
   for (int chrom : r.chr_read) {
     if (!chr_snps.count(chrom)) continue;
     const std::vector<int64_t>& snps = chr_snps[chrom];
@@ -1793,17 +1822,14 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
         } else if (rg_pgen_read_dosage_rows(r.pgen, bs, vidx.data(), dbuf.data(), r.n_file) != RG_PGEN_OK)   // Read() (Geno.cpp:2570-2571)
           throw std::runtime_error(rg_pgen_last_error(r.pgen));
       }
-      for (int j = 0; in == In::Bed && j < bs;) {   // consecutive variants: one pread
-        int e = j + 1;
-        while (e < bs && r.snp_offset[snps[j0 + e]] == r.snp_offset[snps[j0 + e - 1]] + 1) ++e;
-        int64_t want = (int64_t)(e - j) * r.bpr, got = 0;
-        const int64_t off = 3 + r.snp_offset[snps[j0 + j]] * r.bpr;
-        while (got < want) {
-          const ssize_t k = pread(fd, rows.data() + (size_t)j * r.bpr + got, (size_t)(want - got), off + got);
-          if (k <= 0) throw std::runtime_error("cannot read bed file");
-          got += k;
+      if (in == In::Bed) {   // the block's rows: read ahead by the previous iteration when it could be (same chromosome), else read now
+        if (ahead.valid()) { ahead.get(); rows.swap(rows_ahead); }
+        else read_bed(snps, j0, bs, rows);
+        if (bb + 1 < nb_chr) {
+          const int64_t jn = (int64_t)(bb + 1) * p.bsize;
+          const int bn = (int)std::min<int64_t>(p.bsize, (int64_t)snps.size() - jn);
+          ahead = std::async(std::launch::async, [&, jn, bn]() { read_bed(snps, jn, bn, rows_ahead); });
         }
-        j = e;
       }
       std::vector<double> total(bs, 0.0);
       std::vector<int64_t> ns1(bs, 0);
@@ -2122,57 +2148,67 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
         });
         s2check(rg_s2_qt_block(s2, G.data(), n, bs, 0, NUMTOL, &o));
       }
-      // the result lines (compute_score_qt after the statistic, Step2_Models.cpp:440-466; print_sum_stats_single)
-      for (int j = 0; j < bs; ++j) {
-        if (!variant_ignored[j] && show_info && p.set_min_info && ns1[j] > 0) {   // the all-sample info score below --minINFO drops the variant (Geno.cpp:2349-2353)
-          const double af1 = total[j] / (2.0 * ns1[j]);
-          double info1 = 1.0;
-          if (af1 != 0.0 && af1 != 1.0)
-            info1 = r.bgenh ? 1.0 - info_num[j] / (2.0 * ns1[j] * af1 * (1.0 - af1)) : (info_num[j] / ns1[j] - 4.0 * af1 * af1) / (2.0 * af1 * (1.0 - af1));
-          if (info1 < p.min_info) variant_ignored[j] = 1;
-        }
-        if (variant_ignored[j] || ign[j]) { ++n_ignored_snps; continue; }
-        const int64_t sj = snps[j0 + j];
-        std::ostringstream head;
-        head << r.snp_chrom[sj] << " " << r.snp_pos[sj] << " " << r.snp_ids[sj] << " " << r.snp_a0[sj] << " " << r.snp_a1[sj] << " ";
-        for (int q = 0; q < P; ++q) {
-          double af = total[j] / (2.0 * ns1[j]);
-          int64_t nsq = ns1[j];
-          double infq = show_info ? info_num[j] : 0.0;
-          if (test_ignored[(size_t)j * P + q]) continue;
-          if (any_missing || glm) {   // compute_mac / compute_aaf_info per trait
-            const double tq = total[j] + af_t[(size_t)j * P + q];
-            nsq = ns1[j] + ns_t[(size_t)j * P + q];
-            const double macq = std::min(tq, 2.0 * nsq - tq);
-            if (macq < p.min_mac) { ++n_ignored_tests; continue; }
-            af = tq / (2.0 * nsq);
-            if (show_info) infq += info_t[(size_t)j * P + q];
+      // the result lines (compute_score_qt after the statistic, Step2_Models.cpp:440-466; print_sum_stats_single): formatted by the host threads
+      // in contiguous chunks of variants, appended to the files in order
+      const int nchunk = std::max(1, std::min(nthreads, bs / 64));
+      std::vector<std::string> chunk_out((size_t)nchunk * P);
+      std::vector<int64_t> c_snps(nchunk, 0), c_tests(nchunk, 0), c_tested(nchunk, 0);
+      parallel_for(nchunk, nchunk, [&](int t) {
+        for (int j = (int)((int64_t)bs * t / nchunk), je = (int)((int64_t)bs * (t + 1) / nchunk); j < je; ++j) {
+          if (!variant_ignored[j] && show_info && p.set_min_info && ns1[j] > 0) {   // the all-sample info score below --minINFO drops the variant (Geno.cpp:2349-2353)
+            const double af1 = total[j] / (2.0 * ns1[j]);
+            double info1 = 1.0;
+            if (af1 != 0.0 && af1 != 1.0)
+              info1 = r.bgenh ? 1.0 - info_num[j] / (2.0 * ns1[j] * af1 * (1.0 - af1)) : (info_num[j] / ns1[j] - 4.0 * af1 * af1) / (2.0 * af1 * (1.0 - af1));
+            if (info1 < p.min_info) variant_ignored[j] = 1;
           }
-          double info = 1.0;     // compute_aaf_info (Geno.cpp:3132-3141): IMPUTE info for .bgen, MaCH r2 for .pgen dosages
-          if (show_info && af != 0.0 && af != 1.0)
-            info = r.bgenh ? 1.0 - infq / (2.0 * nsq * af * (1.0 - af)) : (infq / nsq - 4.0 * af * af) / (2.0 * af * (1.0 - af));
-          if (show_info && p.set_min_info && info < p.min_info) { ++n_ignored_tests; continue; }     // ignored_trait (Geno.cpp:3143-3144)
-          const double st = stats[(size_t)j * P + q];
-          double bh = bhat[(size_t)j * P + q], se = bh / st, chisq = st * st;
-          bool test_fail = false;
-          double logp_spa = -1.0;
-          if (correct && corrected[(size_t)j * P + q]) {
-            if (corr_fail[(size_t)j * P + q]) test_fail = true;                    // get_sumstats(true, ...): the score test's BETA / SE, no p-value
-            else { bh = corr_beta[(size_t)j * P + q]; se = corr_se[(size_t)j * P + q]; chisq = corr_chisq[(size_t)j * P + q]; logp_spa = corr_logp[(size_t)j * P + q]; }
+          if (variant_ignored[j] || ign[j]) { ++c_snps[t]; continue; }
+          const int64_t sj = snps[j0 + j];
+          std::ostringstream head;
+          head << r.snp_chrom[sj] << " " << r.snp_pos[sj] << " " << r.snp_ids[sj] << " " << r.snp_a0[sj] << " " << r.snp_a1[sj] << " ";
+          for (int q = 0; q < P; ++q) {
+            double af = total[j] / (2.0 * ns1[j]);
+            int64_t nsq = ns1[j];
+            double infq = show_info ? info_num[j] : 0.0;
+            if (test_ignored[(size_t)j * P + q]) continue;
+            if (any_missing || glm) {   // compute_mac / compute_aaf_info per trait
+              const double tq = total[j] + af_t[(size_t)j * P + q];
+              nsq = ns1[j] + ns_t[(size_t)j * P + q];
+              const double macq = std::min(tq, 2.0 * nsq - tq);
+              if (macq < p.min_mac) { ++c_tests[t]; continue; }
+              af = tq / (2.0 * nsq);
+              if (show_info) infq += info_t[(size_t)j * P + q];
+            }
+            double info = 1.0;     // compute_aaf_info (Geno.cpp:3132-3141): IMPUTE info for .bgen, MaCH r2 for .pgen dosages
+            if (show_info && af != 0.0 && af != 1.0)
+              info = r.bgenh ? 1.0 - infq / (2.0 * nsq * af * (1.0 - af)) : (infq / nsq - 4.0 * af * af) / (2.0 * af * (1.0 - af));
+            if (show_info && p.set_min_info && info < p.min_info) { ++c_tests[t]; continue; }     // ignored_trait (Geno.cpp:3143-3144)
+            const double st = stats[(size_t)j * P + q];
+            double bh = bhat[(size_t)j * P + q], se = bh / st, chisq = st * st;
+            bool test_fail = false;
+            double logp_spa = -1.0;
+            if (correct && corrected[(size_t)j * P + q]) {
+              if (corr_fail[(size_t)j * P + q]) test_fail = true;                    // get_sumstats(true, ...): the score test's BETA / SE, no p-value
+              else { bh = corr_beta[(size_t)j * P + q]; se = corr_se[(size_t)j * P + q]; chisq = corr_chisq[(size_t)j * P + q]; logp_spa = corr_logp[(size_t)j * P + q]; }
+            }
+            const double logp = logp_spa >= 0 ? logp_spa : get_logp(chisq);       // --spa prints the p-value it computed, the chi-square is derived from it
+            std::ostringstream ln;
+            ln << head.str() << af << " ";
+            if (show_info) ln << info << " ";
+            ln << nsq << " ADD ";
+            if (se >= 0 && !std::isnan(se)) ln << bh << ' ' << se;
+            else ln << "NA NA";
+            if (chisq >= 0 && !std::isnan(logp) && !test_fail) ln << ' ' << chisq << ' ' << logp;
+            else ln << " NA NA";
+            ln << (test_fail ? " TEST_FAIL\n" : " NA\n");
+            chunk_out[(size_t)t * P + q] += ln.str();
+            ++c_tested[t];
           }
-          const double logp = logp_spa >= 0 ? logp_spa : get_logp(chisq);       // --spa prints the p-value it computed, the chi-square is derived from it
-          std::ostringstream ln;
-          ln << head.str() << af << " ";
-          if (show_info) ln << info << " ";
-          ln << nsq << " ADD ";
-          if (se >= 0 && !std::isnan(se)) ln << bh << ' ' << se;
-          else ln << "NA NA";
-          if (chisq >= 0 && !std::isnan(logp) && !test_fail) ln << ' ' << chisq << ' ' << logp;
-          else ln << " NA NA";
-          ln << (test_fail ? " TEST_FAIL\n" : " NA\n");
-          *ofs[q] << ln.str();
-          ++n_tested;
         }
+      });
+      for (int t = 0; t < nchunk; ++t) {
+        for (int q = 0; q < P; ++q) *ofs[q] << chunk_out[(size_t)t * P + q];
+        n_ignored_snps += c_snps[t]; n_ignored_tests += c_tests[t]; n_tested += c_tested[t];
       }
       sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() << "ms) \n";
     }
