@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--bsize", type=int, default=1000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-blocks", type=int, default=4)
+    ap.add_argument("--no-ref", action="store_true", help="cpu_baseline: skip the reference binary (oracle/_ref/regenie), time the numpy oracle instead")
+    ap.add_argument("--oracle-check", action="store_true", help="check the full configuration against the numpy oracle even with --no-cpu "
+                    "(level-0 predictors of two blocks, level 1 of phenotype 0 on the full W: CV sums, selected ridge value, LOCO)")
     ap.add_argument("--no-disk", action="store_true", help="skip the end-to-end-from-files leg (the C++ driver on a .bed written to disk)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for the "
                     "single-box smoke of the N>1 code path")
@@ -293,9 +296,9 @@ def main():
 
     # ---- CPU baseline: the oracle (numpy/OpenBLAS restatement of the reference) on a bounded sample ----
     cpu = None
-    if rank == 0 and not args.no_cpu and world == 1:
+    if rank == 0 and world == 1 and (not args.no_cpu or args.oracle_check):
         cpu = cpu_baseline(args, eng, torch, dev, packed, blocks, my_blocks, X, Y, Yraw, cov, mask, ain, neff, cv_sizes, tau, M, N, P, B, R0,
-                           (res[0], res[1], res[2]))
+                           (res[0], res[1], res[2]), with_reference=not (args.no_cpu or args.no_ref))
 
     disk = None
     if rank == 0 and world == 1 and not args.no_cpu and not args.no_disk:
@@ -402,7 +405,7 @@ def _parse_loco(path):
 
 
 def cpu_baseline(args, eng, torch, dev, packed, blocks, my_blocks, X, Y, Yraw, cov, mask, ain, neff, cv_sizes, tau, M, N, P, B, R0,
-                 gpu_full):
+                 gpu_full, with_reference=True):
     """CPU leg (rank 0, N=1 only), two parts.
 
     (1) `kind: "reference"` -- regenie v4.1.2 ITSELF (oracle/_ref/regenie: the reference's sources compiled by
@@ -429,7 +432,7 @@ def cpu_baseline(args, eng, torch, dev, packed, blocks, my_blocks, X, Y, Yraw, c
     if len(sel) > args.cpu_blocks:
         sel = sel[:max(1, args.cpu_blocks // 2)] + sel[-(args.cpu_blocks - max(1, args.cpu_blocks // 2)):]
     Ms = sum(blocks[b][2] for b in sel)
-    if os.path.exists(regenie):
+    if with_reference and os.path.exists(regenie):
         d = tempfile.mkdtemp(prefix="rg_cpu_baseline_")
         try:
             pre = os.path.join(d, "s")

@@ -153,13 +153,21 @@ int rg_set_collective(rg_ctx* ctx, int32_t world, int32_t rank, rg_allreduce_fn 
  *                     phenotype -- the rank receives the rows of every rank's blocks for its phenotypes only and its
  *                     level-1 view is set to that range (rg_set_l1_view); NULL: all-gather of the block slabs, after
  *                     which rg_l1_qt shares its Gram tiles / ridge systems among the ranks (rg_set_collective with the
- *                     group's RCCL all-reduce).  Returns after the exchange has completed on this rank. */
+ *                     group's RCCL all-reduce).  Returns after the exchange has completed on this rank.
+ *   rg_group_prepare: optional, per rank, any time after rg_group_create: allocates that rank's exchange buffers (the
+ *                     phenotype view and, for RCCL, the packed send buffer) so that rg_l0_finish finds them ready.
+ *   rg_group_abort  : a rank whose host side failed for good (file error, exception) calls this INSTEAD of its next group
+ *                     call: the group is broken, every rank waiting in rg_l0_finish or in a shared level-1 all-reduce -- now
+ *                     or later -- returns an error instead of waiting for the failed rank.  rg_l0_finish itself agrees on
+ *                     success among all ranks before any of them enters a collective.  A broken group cannot be reused. */
 #define RG_TRANSPORT_RCCL 0
 #define RG_TRANSPORT_PEER 1
 typedef struct rg_group rg_group;
 int rg_group_create(rg_group** out, int32_t n, rg_ctx* const* ctxs, int transport);
 void rg_group_destroy(rg_group* g);
 int rg_l0_finish(rg_group* g, int32_t rank, const int32_t* block_begin, const int32_t* pheno_begin);
+int rg_group_prepare(rg_group* g, int32_t rank, const int32_t* block_begin, const int32_t* pheno_begin);
+void rg_group_abort(rg_group* g, int32_t rank);
 
 /* ---- pinned host memory for streamed ingest (optional) ------------------------------------------------------------
  * Rows handed to rg_l0_blocks with RG_MEM_HOST cross PCIe by asynchronous copies only if they live in page-locked

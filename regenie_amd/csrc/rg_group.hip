@@ -62,14 +62,24 @@ struct Rccl {
 };
 Rccl g_rccl;
 
-struct Barrier {   // reusable barrier of the rank threads
-  std::mutex m; std::condition_variable cv; int n = 1, count = 0; uint64_t gen = 0;
-  void wait() {
+// Reusable barrier of the rank threads that can be BROKEN: once a rank has failed for good (rg_group_abort, or an error
+// inside a group call) every wait -- pending or future -- returns false at once, so that no rank is ever left waiting for
+// a peer that will not come.  A broken group stays broken: every later group call fails.
+struct Barrier {
+  std::mutex m; std::condition_variable cv; int n = 1, count = 0; uint64_t gen = 0; bool broken = false;
+  bool wait() {
     std::unique_lock<std::mutex> lk(m);
+    if (broken) return false;
     const uint64_t g = gen;
     if (++count == n) { count = 0; ++gen; cv.notify_all(); }
-    else cv.wait(lk, [&] { return gen != g; });
+    else cv.wait(lk, [&] { return gen != g || broken; });
+    return !broken;
   }
+  void abort() {
+    { std::lock_guard<std::mutex> lk(m); broken = true; }
+    cv.notify_all();
+  }
+  bool is_broken() { std::lock_guard<std::mutex> lk(m); return broken; }
 };
 
 }  // namespace
@@ -90,6 +100,15 @@ struct rg_group {
   std::vector<int> failed;
   Barrier bar;
   std::string err;
+  // every rank passes `agree` right before it enters a collective: all ranks alive and willing, or nobody enters
+  bool agree(int rank, bool ok) {
+    failed[rank] = ok ? 0 : 1;
+    if (!bar.wait()) return false;
+    bool all = true;
+    for (int k = 0; k < n; ++k) all = all && failed[k] == 0;
+    if (!bar.wait()) return false;      // everyone has read the flags before anyone rewrites its own
+    return all;
+  }
 };
 
 namespace {
@@ -107,24 +126,55 @@ int group_allreduce(void* user, void* dev_ptr, int64_t n) {
   rg_ctx* c = g->ctx[r];
   hipSetDevice(c->device);
   if (g->transport == RG_TRANSPORT_RCCL) {
+    // all ranks are here and alive (a rank that failed earlier has broken the group): only then is the collective entered.
+    // The all-reduce is ordered on the context's stream like the kernels around it -- no host synchronisation after it.
+    if (!g->agree(r, true)) { c->err = "all-reduce: another GPU of the group has failed"; return 1; }
     ncclResult_t e = g_rccl.AllReduce(dev_ptr, dev_ptr, (size_t)n, kNcclDouble, kNcclSum, g->comm[r], c->stream);
-    if (e != 0) { c->err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(e); return 1; }
-    return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : 1;
+    if (e != 0) { c->err = std::string("ncclAllReduce: ") + g_rccl.GetErrorString(e); g->bar.abort(); return 1; }
+    return 0;
   }
   // peer transport: every rank stages its buffer in host memory, sums all of them in rank order, uploads
   std::vector<double>& h = g->hstage[r];
   h.resize((size_t)n);
-  if (hipMemcpyAsync(h.data(), dev_ptr, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 1;
-  if (hipStreamSynchronize(c->stream) != hipSuccess) return 1;
-  g->bar.wait();
+  bool ok = hipMemcpyAsync(h.data(), dev_ptr, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+            hipStreamSynchronize(c->stream) == hipSuccess;
+  if (!g->agree(r, ok)) { c->err = "all-reduce: another GPU of the group has failed"; return 1; }
   std::vector<double> sum((size_t)n, 0.0);
   for (int k = 0; k < g->n; ++k) {
     const std::vector<double>& o = g->hstage[k];
     for (int64_t i = 0; i < n; ++i) sum[i] += o[i];
   }
-  g->bar.wait();                    // everyone has read every staging buffer
-  if (hipMemcpyAsync(dev_ptr, sum.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return 1;
-  return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : 1;
+  if (!g->bar.wait()) return 1;     // everyone has read every staging buffer
+  if (hipMemcpyAsync(dev_ptr, sum.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) { g->bar.abort(); return 1; }
+  return 0;
+}
+
+// exchange buffers of one rank for the phenotype-sharded form: the view [L][np_r][Np] and (RCCL) the packed send buffer
+int ensure_exchange_buffers(rg_group* g, int rank, const int32_t* block_begin, const int32_t* pheno_begin) {
+  rg_ctx* c = g->ctx[rank];
+  const int R0 = c->R0, P = c->P;
+  const int64_t Np = c->Np;
+  const int nq = pheno_begin[rank + 1] - pheno_begin[rank];
+  if (nq < 1) return rank_error(g, rank, "rg_l0_finish: a rank without phenotypes (use the all-gather form)");
+  const size_t need = sizeof(double) * (size_t)c->B_total * R0 * nq * Np;
+  if (g->wview_bytes[rank] < need) {
+    if (g->wview[rank]) hipFree(g->wview[rank]);
+    g->wview[rank] = nullptr; g->wview_bytes[rank] = 0;
+    if (hipMalloc((void**)&g->wview[rank], need) != hipSuccess) return rank_error(g, rank, "rg_l0_finish: out of device memory for the phenotype view");
+    g->wview_bytes[rank] = need;
+  }
+  if (g->transport == RG_TRANSPORT_RCCL) {
+    const int64_t nlm = (int64_t)(block_begin[rank + 1] - block_begin[rank]) * R0;
+    const size_t sneed = sizeof(double) * (size_t)nlm * P * Np;
+    if (g->sendbuf_bytes[rank] < sneed || !g->sendbuf[rank]) {
+      if (g->sendbuf[rank]) hipFree(g->sendbuf[rank]);
+      g->sendbuf[rank] = nullptr; g->sendbuf_bytes[rank] = 0;
+      if (hipMalloc((void**)&g->sendbuf[rank], sneed ? sneed : 8) != hipSuccess) return rank_error(g, rank, "rg_l0_finish: out of device memory for the send buffer");
+      g->sendbuf_bytes[rank] = sneed;
+    }
+  }
+  return RG_OK;
 }
 
 }  // namespace
@@ -181,39 +231,74 @@ void rg_group_destroy(rg_group* g) {
   delete g;
 }
 
+// Marks the group broken on behalf of `rank` (a host-side failure of that rank: a reader / file error, an exception in its
+// level 1): every rank that waits in a group call -- now or later -- returns with an error instead of waiting for it.
+void rg_group_abort(rg_group* g, int32_t rank) {
+  if (!g) return;
+  if (rank >= 0 && rank < g->n) g->failed[rank] = 1;
+  g->bar.abort();
+}
+
+// Allocates the exchange buffers of `rank` ahead of time (phenotype-sharded form), so that the 13 - 51 GB of the view and the
+// send buffer are not allocated between level 0 and the exchange.  Optional: rg_l0_finish allocates what is missing.
+int rg_group_prepare(rg_group* g, int32_t rank, const int32_t* block_begin, const int32_t* pheno_begin) {
+  if (!g || rank < 0 || rank >= g->n || !block_begin) return RG_ERR_ARG;
+  if (!pheno_begin) return RG_OK;       // all-gather form: the slabs land in W itself
+  hipSetDevice(g->ctx[rank]->device);
+  return ensure_exchange_buffers(g, rank, block_begin, pheno_begin);
+}
+
 // Called by every rank from its own host thread once its level-0 blocks are queued.  block_begin[n+1]: the contiguous
 // block range of every rank (Data.cpp:270-302).  pheno_begin[n+1] != NULL selects the phenotype-sharded form (every rank
 // needs at least one phenotype); NULL the all-gather form.
+// Failure protocol: everything that can fail on the host side of a rank (its level 0, allocations, packing copies) happens
+// BEFORE one agreement of all ranks; the collective is entered by all ranks or by none.  An error after that point (a RCCL or
+// HIP call that fails) breaks the group, so that the peers' later barriers return instead of waiting.
 int rg_l0_finish(rg_group* g, int32_t rank, const int32_t* block_begin, const int32_t* pheno_begin) {
   if (!g || rank < 0 || rank >= g->n || !block_begin) return RG_ERR_ARG;
   rg_ctx* c = g->ctx[rank];
   hipSetDevice(c->device);
   const int n = g->n, R0 = c->R0, P = c->P;
   const int64_t Np = c->Np;
-  int rc = rg_sync(c);                                        // level 0 of this rank is complete (and its deferred errors seen)
-  // the ranks are threads of one process: agree on success before anyone enters the exchange (a rank that failed must not
-  // leave the others waiting in a receive), and -- peer transport -- nobody pulls from a W that is still being written
-  g->failed[rank] = rc != RG_OK ? 1 : 0;
-  g->bar.wait();
-  bool any_failed = false;
-  for (int k = 0; k < g->n; ++k) any_failed |= g->failed[k] != 0;
-  g->bar.wait();
-  if (rc != RG_OK) return rc;
-  if (any_failed) { c->err = "rg_l0_finish: level 0 failed on another GPU"; return RG_ERR_STATE; }
-  if (!c->d_W) return rank_error(g, rank, "rg_l0_finish: no level-0 predictors on this rank");
   hipStream_t st = c->stream;
-  if (pheno_begin) {
-    const int q0 = pheno_begin[rank], nq = pheno_begin[rank + 1] - q0;
-    if (nq < 1) return rank_error(g, rank, "rg_l0_finish: a rank without phenotypes (use the all-gather form)");
-    const size_t L = (size_t)c->B_total * R0;
-    const size_t need = sizeof(double) * L * nq * Np;
-    if (g->wview_bytes[rank] < need) {
-      if (g->wview[rank]) hipFree(g->wview[rank]);
-      g->wview[rank] = nullptr; g->wview_bytes[rank] = 0;
-      if (hipMalloc((void**)&g->wview[rank], need) != hipSuccess) return rank_error(g, rank, "rg_l0_finish: out of device memory for the phenotype view");
-      g->wview_bytes[rank] = need;
+  // ---- phase A (may fail, rank-local): level 0 complete, buffers present, rows packed per destination ----
+  int rc = rg_sync(c);                                        // level 0 of this rank is complete (and its deferred errors seen)
+  if (rc == RG_OK && !c->d_W) rc = rank_error(g, rank, "rg_l0_finish: no level-0 predictors on this rank");
+  if (rc == RG_OK && !pheno_begin && c->w_nb != c->B_total)
+    rc = rank_error(g, rank, "rg_l0_finish: the all-gather form needs the full W on every rank (no rg_set_block_range)");
+  const int q0 = pheno_begin ? pheno_begin[rank] : 0, nq = pheno_begin ? pheno_begin[rank + 1] - q0 : P;
+  const int64_t l0m = (int64_t)block_begin[rank] * R0, nlm = (int64_t)(block_begin[rank + 1] - block_begin[rank]) * R0;
+  std::vector<double*> sptr(n, nullptr);
+  double* Wv = nullptr;
+  if (rc == RG_OK && pheno_begin) {
+    rc = ensure_exchange_buffers(g, rank, block_begin, pheno_begin);
+    Wv = g->wview[rank];
+    if (rc == RG_OK && g->transport == RG_TRANSPORT_RCCL) {
+      // pack my rows per destination (strided device copies); my own share goes straight into the view (a single-rank
+      // group sends it to itself instead, so that the send / receive path of the transport executes on a one-GPU box too)
+      double* sp = g->sendbuf[rank];
+      for (int k = 0; k < n && rc == RG_OK; ++k) {
+        const int qk = pheno_begin[k], nk = pheno_begin[k + 1] - qk;
+        sptr[k] = sp;
+        if (nlm > 0 && nk > 0) {
+          double* dst = (k == rank && n > 1) ? Wv + l0m * nq * Np : sp;
+          if (hipMemcpy2DAsync(dst, sizeof(double) * nk * Np, rg_w_base(c) + (l0m * P + qk) * Np, sizeof(double) * P * Np,
+                               sizeof(double) * nk * Np, (size_t)nlm, hipMemcpyDeviceToDevice, st) != hipSuccess)
+            rc = rank_error(g, rank, "rg_l0_finish: pack failed");
+        }
+        sp += (size_t)nlm * nk * Np;
+      }
     }
-    double* Wv = g->wview[rank];
+  }
+  // ---- agreement: the ranks are threads of one process.  A rank that failed must not leave the others waiting in a
+  //      receive, and -- peer transport -- nobody pulls from a W that is still being written ----
+  if (!g->agree(rank, rc == RG_OK)) {
+    if (rc == RG_OK) { c->err = "rg_l0_finish: level 0 failed on another GPU"; rc = RG_ERR_STATE; }
+    return rc;
+  }
+  // ---- phase B: the exchange.  Errors from here on break the group (the peers are inside the same collective) ----
+  auto broke = [&](const std::string& msg) { g->bar.abort(); return rank_error(g, rank, msg); };
+  if (pheno_begin) {
     if (g->transport == RG_TRANSPORT_PEER) {
       for (int k = 0; k < n; ++k) {   // pull: rows of rank k's blocks, my phenotypes, straight out of k's W
         const int64_t l0 = (int64_t)block_begin[k] * R0, nl = (int64_t)(block_begin[k + 1] - block_begin[k]) * R0;
@@ -221,35 +306,13 @@ int rg_l0_finish(rg_group* g, int32_t rank, const int32_t* block_begin, const in
         const double* src = rg_w_base(g->ctx[k]) + (l0 * P + q0) * Np;
         if (hipMemcpy2DAsync(Wv + l0 * nq * Np, sizeof(double) * nq * Np, src, sizeof(double) * P * Np, sizeof(double) * nq * Np,
                              (size_t)nl, hipMemcpyDeviceToDevice, st) != hipSuccess)
-          return rank_error(g, rank, "rg_l0_finish: peer copy failed");
+          return broke("rg_l0_finish: peer copy failed");
       }
-      if (hipStreamSynchronize(st) != hipSuccess) return rank_error(g, rank, "rg_l0_finish: peer copy failed");
-      g->bar.wait();                  // nobody may overwrite its W (a next run) before every peer has pulled
+      if (hipStreamSynchronize(st) != hipSuccess) return broke("rg_l0_finish: peer copy failed");
+      // nobody may overwrite its W (a next run) before every peer has pulled
+      if (!g->bar.wait()) return rank_error(g, rank, "rg_l0_finish: the exchange failed on another GPU");
     } else {
-      // pack my rows per destination (strided device copies), then one group of send/recv pairs
-      const int64_t l0m = (int64_t)block_begin[rank] * R0, nlm = (int64_t)(block_begin[rank + 1] - block_begin[rank]) * R0;
-      const size_t sneed = sizeof(double) * (size_t)nlm * P * Np;
-      if (g->sendbuf_bytes[rank] < sneed) {
-        if (g->sendbuf[rank]) hipFree(g->sendbuf[rank]);
-        g->sendbuf[rank] = nullptr; g->sendbuf_bytes[rank] = 0;
-        if (hipMalloc((void**)&g->sendbuf[rank], sneed ? sneed : 8) != hipSuccess) return rank_error(g, rank, "rg_l0_finish: out of device memory for the send buffer");
-        g->sendbuf_bytes[rank] = sneed;
-      }
-      std::vector<double*> sptr(n);
-      double* sp = g->sendbuf[rank];
-      for (int k = 0; k < n; ++k) {
-        const int qk = pheno_begin[k], nk = pheno_begin[k + 1] - qk;
-        sptr[k] = sp;
-        if (nlm > 0 && nk > 0) {
-          // my own share goes straight into the view (a single-rank group sends it to itself instead, so that the
-          // send / receive path of the transport executes on a one-GPU box too)
-          double* dst = (k == rank && n > 1) ? Wv + l0m * nq * Np : sp;
-          if (hipMemcpy2DAsync(dst, sizeof(double) * nk * Np, rg_w_base(c) + (l0m * P + qk) * Np, sizeof(double) * P * Np,
-                               sizeof(double) * nk * Np, (size_t)nlm, hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return rank_error(g, rank, "rg_l0_finish: pack failed");
-        }
-        sp += (size_t)nlm * nk * Np;
-      }
+      // one group of send/recv pairs per rank: a direct exchange in which every pair of GPUs uses its own xGMI link
       ncclResult_t e = g_rccl.GroupStart();
       for (int k = 0; k < n && e == 0; ++k) {
         if (k == rank && n > 1) continue;
@@ -259,25 +322,24 @@ int rg_l0_finish(rg_group* g, int32_t rank, const int32_t* block_begin, const in
         if (e == 0 && nlk > 0) e = g_rccl.Recv(Wv + l0k * nq * Np, (size_t)nlk * nq * Np, kNcclDouble, k, g->comm[rank], st);
       }
       ncclResult_t e2 = g_rccl.GroupEnd();
-      if (e != 0 || e2 != 0) return rank_error(g, rank, std::string("RCCL all-to-all: ") + g_rccl.GetErrorString(e ? e : e2));
-      if (hipStreamSynchronize(st) != hipSuccess) return rank_error(g, rank, "rg_l0_finish: exchange failed");
+      if (e != 0 || e2 != 0) return broke(std::string("RCCL all-to-all: ") + g_rccl.GetErrorString(e ? e : e2));
+      if (hipStreamSynchronize(st) != hipSuccess) return broke("rg_l0_finish: exchange failed");
     }
     rc = rg_set_l1_view(c, Wv, q0, nq);
     if (rc) return rc;
     return rg_set_collective(c, 1, 0, nullptr, nullptr);
   }
   // ---- all-gather form: every rank ends with the whole W; level 1 is then shared through all-reduces ----
-  if (c->w_nb != c->B_total) return rank_error(g, rank, "rg_l0_finish: the all-gather form needs the full W on every rank (no rg_set_block_range)");
   if (g->transport == RG_TRANSPORT_PEER) {
     for (int k = 0; k < n; ++k) {
       if (k == rank) continue;
       const int64_t l0 = (int64_t)block_begin[k] * R0, nl = (int64_t)(block_begin[k + 1] - block_begin[k]) * R0;
       if (nl == 0) continue;
       if (hipMemcpyAsync(c->d_W + l0 * P * Np, g->ctx[k]->d_W + l0 * P * Np, sizeof(double) * nl * P * Np, hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return rank_error(g, rank, "rg_l0_finish: peer copy failed");
+        return broke("rg_l0_finish: peer copy failed");
     }
-    if (hipStreamSynchronize(st) != hipSuccess) return rank_error(g, rank, "rg_l0_finish: peer copy failed");
-    g->bar.wait();
+    if (hipStreamSynchronize(st) != hipSuccess) return broke("rg_l0_finish: peer copy failed");
+    if (!g->bar.wait()) return rank_error(g, rank, "rg_l0_finish: the exchange failed on another GPU");
   } else {
     ncclResult_t e = g_rccl.GroupStart();
     for (int k = 0; k < n && e == 0; ++k) {
@@ -287,8 +349,8 @@ int rg_l0_finish(rg_group* g, int32_t rank, const int32_t* block_begin, const in
       e = g_rccl.Broadcast(slab, slab, (size_t)nl * P * Np, kNcclDouble, k, g->comm[rank], st);
     }
     ncclResult_t e2 = g_rccl.GroupEnd();
-    if (e != 0 || e2 != 0) return rank_error(g, rank, std::string("RCCL all-gather: ") + g_rccl.GetErrorString(e ? e : e2));
-    if (hipStreamSynchronize(st) != hipSuccess) return rank_error(g, rank, "rg_l0_finish: all-gather failed");
+    if (e != 0 || e2 != 0) return broke(std::string("RCCL all-gather: ") + g_rccl.GetErrorString(e ? e : e2));
+    if (hipStreamSynchronize(st) != hipSuccess) return broke("rg_l0_finish: all-gather failed");
   }
   for (int b = 0; b < c->B_total; ++b) c->block_done[b] = 1;
   rc = rg_set_l1_view(c, nullptr, 0, P);

@@ -2739,20 +2739,20 @@ int run(int argc, char** argv) {
     std::vector<std::thread> th;
     for (int g = 0; g < G; ++g)
       th.emplace_back([&, g]() {
-        bool finished = false;
         try {
           std::ostringstream lg;
+          // the exchange buffers of this rank (phenotype view, packed send buffer) are allocated before level 0 starts
+          check(ctxs[g], rg_group_prepare(grp, g, bbeg.data(), pheno_sharded ? pbeg.data() : nullptr));
           level0_range(ctxs[g], bbeg[g], bbeg[g + 1], lg);
           rank_log[g] = lg.str();
-          finished = true;
           check(ctxs[g], rg_l0_finish(grp, g, bbeg.data(), pheno_sharded ? pbeg.data() : nullptr));
           if (pheno_sharded) level1_range(ctxs[g], pbeg[g], pbeg[g + 1] - pbeg[g], true);
           else if (shared_l1 || g == 0) level1_range(ctxs[g], 0, P, g == 0);
         } catch (...) {
+          // whatever failed here (reader, file, level 0, level 1): the group is broken, so that the other ranks -- waiting in
+          // the exchange or in a shared level-1 all-reduce, now or later -- fail too instead of waiting for this one
           errs[g] = std::current_exception();
-          if (!finished) {   // the other ranks wait in the exchange: join them so that they can fail too
-            try { rg_l0_finish(grp, g, bbeg.data(), pheno_sharded ? pbeg.data() : nullptr); } catch (...) {}
-          }
+          rg_group_abort(grp, g);
         }
       });
     for (auto& t : th) t.join();
@@ -2760,7 +2760,17 @@ int run(int argc, char** argv) {
       sout << " GPU " << g << " : blocks [" << bbeg[g] + 1 << ".." << bbeg[g + 1] << "]"
            << (pheno_sharded ? ", level 1 of phenotypes [" + std::to_string(pbeg[g] + 1) + ".." + std::to_string(pbeg[g + 1]) + "]" : std::string()) << "\n" << rank_log[g];
     }
-    for (int g = 0; g < G; ++g) if (errs[g]) std::rethrow_exception(errs[g]);
+    {  // report the rank that failed first-hand, not a peer that only noticed it
+      std::exception_ptr any = nullptr;
+      for (int g = 0; g < G; ++g) {
+        if (!errs[g]) continue;
+        if (!any) any = errs[g];
+        try { std::rethrow_exception(errs[g]); }
+        catch (const std::exception& e) { if (!strstr(e.what(), "another GPU")) std::rethrow_exception(errs[g]); }
+        catch (...) { std::rethrow_exception(errs[g]); }
+      }
+      if (any) std::rethrow_exception(any);
+    }
     sout << "\n Level 1 ridge...\n";
   }
   sout << "   -level 1 for " << P << " phenotype(s) done ("
