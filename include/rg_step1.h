@@ -72,6 +72,13 @@ const char* rg_last_error(const rg_ctx* ctx);
 /* replaces setmem/set_folds state (Data.cpp:401-577): uploads X, Y, masks; builds the fold-aligned
  * sample layout used by every kernel. */
 int rg_set_problem(rg_ctx* ctx, const rg_problem* p);
+/* Optional, BEFORE rg_set_problem: sizing of the level-0 workspaces (the reference allocates its block matrices per block,
+ * Data.cpp:652; here a batch of blocks is worked on at once and its workspaces are allocated once).  max_batch_blocks > 0 caps
+ * the SNP blocks of one batch, pipelines > 0 sets the number of level-0 pipelines (default 2), budget_bytes > 0 bounds the
+ * bytes of all pipelines' per-block workspaces (default 64 GB; never more than half of the device memory that is free when
+ * rg_set_problem runs).  0 = library default.  A driver that streams a small input from files asks for small batches: the
+ * set-up cost of a process grows with the bytes it allocates (and the next process waits for them to be reclaimed). */
+int rg_set_l0_workspace(rg_ctx* ctx, int32_t max_batch_blocks, int32_t pipelines, int64_t budget_bytes);
 
 /* Optional: caller-owned storage for the level-0 predictors W (e.g. a torch tensor that RCCL
  * all-gathers in place).  Layout: [B*R0][P][Np] doubles, Np = rg_w_rows(ctx).  If never called the

@@ -13,6 +13,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <vector>
 #include "rg_internal.h"
 
 #define CT 64
@@ -104,6 +105,158 @@ __global__ __launch_bounds__(256, 2) void k_l1_gram64(L1G64 g, SegLayout seg) {
     for (int n = 0; n < 4; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) O[(int64_t)(m * 16 + q + 4 * r) * g.R.n64 + n * 16 + i] = acc[m][n][r];
+}
+
+// ---- fold Gram through LDS: one WORKGROUP per 128 x 128 macro tile (4 waves, 2 x 2 of 64 x 64) --------------------------------
+// The register-fed kernel above pulls 8 flop per byte through the L2 -> CU fabric (~9 TB/s chip-wide), which caps it near
+// 30 TFLOP/s executed; at BASELINE configs[2] (L = 2,560 - 2,610 predictors, 500,000 samples, 10 phenotypes) it was 54 % of the
+// whole Step-1 run.  Here the 256 operand rows of a macro tile are staged 16 positions at a time (32 KB per stage, two stages)
+// by direct global -> LDS copies and shared by the four waves: 16 flop per byte from L2, no staging registers.
+//   LDS stage: [256 rows][16 doubles]; the eight 16-byte slots of a row are XOR-swizzled by ((row >> 1) & 7) and lane (i, q)
+//   reads the logical slots q and q + 4 (k = 2q, 2q+1, 8+2q, 9+2q) of its rows: every ds_read_b128 lane group hits 16
+//   distinct bank quads (the layout of chol.hip's strip kernel).  A contraction is invariant under a permutation of K applied
+//   to both operands alike, so MFMA step s simply takes the lane's s-th value.
+//   One barrier per stage: the copies of stage s+1 are issued (inline assembly, invisible to hipcc's wait-count model) before
+//   the 64 MFMAs of stage s and must have landed -- s_waitcnt vmcnt(0) -- before the barrier that ends it.
+// Work items come from a host-built table: (macro row, macro column, fold, K slice), ordered so that the workgroups an XCD
+// holds at one time belong to one 4 x 4 super tile of one (fold, slice) and stream the same rows through that XCD's L2.
+// The y row (W_f^T y_f) is k_l1_wty's; multi-GPU: rank r computes the macro tiles with index = r (mod world).
+struct L1Item { int16_t mr, mc, fold, slice; };
+struct L1G128 {
+  L1Rows R; int rtot, nslice; const L1Item* items; double* out; int64_t slice_stride;
+};
+#define G128_STAGE 32768   // bytes per LDS stage: 256 rows x 16 positions x 8 B
+__device__ __forceinline__ const double* l1_wrow(const L1Rows& R, int row) {     // predictor row, or the zero row past L
+  return row < R.L ? R.W + ((int64_t)row * R.P + R.p) * R.Np : R.zero;
+}
+__global__ __launch_bounds__(256, 2) void k_l1_gram128(L1G128 g, SegLayout seg) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * G128_STAGE];
+  const L1Item it = g.items[blockIdx.x];
+  if (it.fold < 0) return;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, q = lane >> 4;
+  const int f = it.fold, n64 = g.R.n64;
+  const int64_t nst = seg.plen[f] / 16;
+  const int64_t s0 = nst * it.slice / g.nslice, s1 = nst * (it.slice + 1) / g.nslice;
+  const int ns = (int)(s1 - s0);
+  // the eight 1 KB pieces (8 rows x 128 B) of a stage this wave copies: pieces [8 wave, 8 wave + 8) of 32
+  const double* src[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int rl = 8 * (wave * 8 + j) + (lane >> 3);
+    const int row = rl < 128 ? it.mr * 128 + rl : it.mc * 128 + (rl - 128);
+    const int slot = (lane & 7) ^ ((rl >> 1) & 7);
+    src[j] = l1_wrow(g.R, row) + seg.pos_start[f] + s0 * 16 + 2 * slot;
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+  const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 8192);
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      glds16p(src[j], wdst + buf * G128_STAGE + j * 1024);
+      src[j] += 16;
+    }
+  };
+  // a wave whose 64 x 64 sub-tile lies strictly above the diagonal, or past the padded order, only takes part in the staging
+  const int row0 = it.mr * 128 + wr * 64, col0 = it.mc * 128 + wc * 64;
+  const bool live = row0 >= col0 && row0 < n64 && col0 < n64;
+  v4d acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
+  const int xs = (i >> 1) & 7;
+  const int oa = (wr * 64 + i) * 128 + ((q ^ xs) << 4), ob = 16384 + (wc * 64 + i) * 128 + ((q ^ xs) << 4);
+  const int o4 = (((q + 4) ^ xs) << 4) - ((q ^ xs) << 4);
+  if (ns > 0) issue(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int s = 0; s < ns; ++s) {
+    const uint8_t* cur = smem + (s & 1) * G128_STAGE;
+    if (s + 1 < ns) issue((s + 1) & 1);
+    if (live) {
+      double2 a[4][2], b[4][2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        a[m][0] = *reinterpret_cast<const double2*>(cur + oa + m * 2048);
+        a[m][1] = *reinterpret_cast<const double2*>(cur + oa + m * 2048 + o4);
+        b[m][0] = *reinterpret_cast<const double2*>(cur + ob + m * 2048);
+        b[m][1] = *reinterpret_cast<const double2*>(cur + ob + m * 2048 + o4);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const double av = kk == 0 ? a[m][0].x : (kk == 1 ? a[m][0].y : (kk == 2 ? a[m][1].x : a[m][1].y));
+            const double bv = kk == 0 ? b[n][0].x : (kk == 1 ? b[n][0].y : (kk == 2 ? b[n][1].x : b[n][1].y));
+            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[m][n], 0, 0, 0);
+          }
+    }
+    // the next stage has landed and everybody is done with this one
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  if (!live) return;
+  double* O = g.out + (int64_t)it.slice * g.slice_stride + (int64_t)f * g.rtot * n64 + (int64_t)row0 * n64 + col0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) O[(int64_t)(m * 16 + q + 4 * r) * n64 + n * 16 + i] = acc[m][n][r];
+}
+
+// ---- W_f^T y_f: row n64 of every fold matrix (the right-hand sides), one workgroup per (predictor, fold) -----------------------
+// fixed-order reduction (thread-strided partial sums, wave shuffles, four wave sums): the value does not depend on the launch
+__global__ __launch_bounds__(256) void k_l1_wty(L1Rows R, SegLayout seg, int rtot, int world, int rank, double* out) {
+  __shared__ double red[4];
+  const int l = blockIdx.x, f = blockIdx.y;
+  if (l % world != rank) return;
+  const double* w = R.W + ((int64_t)l * R.P + R.p) * R.Np + seg.pos_start[f];
+  const double* y = R.y + seg.pos_start[f];
+  const int64_t n = seg.plen[f];
+  double t0 = 0.0, t1 = 0.0;
+  for (int64_t e = 2 * (int64_t)threadIdx.x; e < n; e += 512) {
+    const double2 wv = *reinterpret_cast<const double2*>(w + e), yv = *reinterpret_cast<const double2*>(y + e);
+    t0 = fma(wv.x, yv.x, t0);
+    t1 = fma(wv.y, yv.y, t1);
+  }
+  double t = t0 + t1;
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) out[(int64_t)f * rtot * R.n64 + (int64_t)R.n64 * R.n64 + l] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// Work table of k_l1_gram128 for one rank (see the kernel): macro tiles (mr >= mc) of the padded order n64, K folds, nslice K
+// slices.  Groups = the macro tiles of one 4 x 4 super tile of one (fold, slice); the groups are dealt to the eight XCDs and
+// workgroup id 8 j + x is the j-th item of XCD x's list (ids are dispatched to XCD id mod 8).  Lists are padded with fold = -1.
+static std::vector<L1Item> l1_build_items(int n64, int K, int nslice, int world, int rank) {
+  const int T2 = (n64 + 127) / 128, S = 4, TS = (T2 + S - 1) / S;
+  std::vector<std::vector<L1Item>> xl(8);
+  int gi = 0;
+  for (int f = 0; f < K; ++f)
+    for (int sl = 0; sl < nslice; ++sl)
+      for (int Mr = 0; Mr < TS; ++Mr)
+        for (int Mc = 0; Mc <= Mr; ++Mc) {
+          std::vector<L1Item>& dst = xl[gi % 8];
+          bool any = false;
+          for (int mr = Mr * S; mr < std::min(T2, (Mr + 1) * S); ++mr)
+            for (int mc = Mc * S; mc < std::min(T2, (Mc + 1) * S); ++mc) {
+              if (mc > mr) continue;
+              if ((mr * (mr + 1) / 2 + mc) % world != rank) continue;
+              dst.push_back(L1Item{(int16_t)mr, (int16_t)mc, (int16_t)f, (int16_t)sl});
+              any = true;
+            }
+          if (any) ++gi;
+        }
+  size_t mx = 0;
+  for (auto& v : xl) mx = std::max(mx, v.size());
+  std::vector<L1Item> items(mx * 8, L1Item{0, 0, -1, 0});
+  for (int x = 0; x < 8; ++x)
+    for (size_t j = 0; j < xl[x].size(); ++j) items[8 * j + x] = xl[x][j];
+  return items;
 }
 
 // The same fold Gram for any row-major matrix G [n64][ld] (rows >= L read as zero): the fp64 genotype path of l0_f64.hip.
@@ -308,6 +461,15 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
   for (int f = 0; f < K; ++f) min_nch = std::min(min_nch, ctx->seg.plen[f] / 64);
   int nslice = (int)std::min<int64_t>(16, std::max<int64_t>(1, (4096 + (int64_t)ntile * K - 1) / ((int64_t)ntile * K)));
   nslice = (int)std::max<int64_t>(1, std::min<int64_t>(nslice, min_nch / 4));
+  // LDS-staged Gram (k_l1_gram128): 128 x 128 macro tiles; K slices until the table holds several rounds of the chip's 512
+  // workgroup slots (equal-cost items: the tail of the last round is what the slices even out).  RG_L1_GRAM64=1 keeps the
+  // register-fed kernel (one wave per 64 x 64 tile).
+  static const bool gram64 = getenv("RG_L1_GRAM64") && atoi(getenv("RG_L1_GRAM64")) != 0;
+  const int T2 = (n64 + 127) / 128, ntile2 = T2 * (T2 + 1) / 2;
+  if (!gram64) {
+    nslice = (int)std::min<int64_t>(16, std::max<int64_t>(1, (3072 + (int64_t)ntile2 * K - 1) / ((int64_t)ntile2 * K)));
+    nslice = (int)std::max<int64_t>(1, std::min<int64_t>(nslice, min_nch / 2));      // >= 8 stages of 16 positions per slice
+  }
 
   double *d_fold = nullptr, *d_part = nullptr, *d_sum = nullptr, *d_wk = nullptr, *d_dinv = nullptr, *d_tau = nullptr,
          *d_cvp = nullptr, *d_pred = nullptr, *d_alpha = nullptr, *d_pack = nullptr;
@@ -326,6 +488,14 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
   L1_WS(d_alpha, 8, double, (size_t)nsys * n64)
   L1_WS(d_col0, 9, int32_t, nchr + 1)
   if (multi) { L1_WS(d_pack, 10, double, (size_t)ntile * K * CT * CT) }
+  L1Item* d_items = nullptr;
+  std::vector<L1Item> items;
+  if (!gram64) {
+    items = l1_build_items(n64, K, nslice, multi ? world : 1, multi ? rank : 0);
+    L1_WS(d_items, 12, L1Item, items.size())
+    RG_HIP(hipMemcpyAsync(d_items, items.data(), sizeof(L1Item) * items.size(), hipMemcpyHostToDevice, st));
+    RG_HIP(hipStreamSynchronize(st));     // `items` is pageable host memory
+  }
 #undef L1_WS
   RG_HIP(hipMemcpyAsync(d_col0, col0.data(), sizeof(int32_t) * (nchr + 1), hipMemcpyHostToDevice, st));
   std::vector<double> hpart((size_t)nch * NPART);
@@ -345,11 +515,18 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
     // ---- fold Grams X_f = W_f^T W_f with W_f^T y_f as an extra row ------------------------------------------
     double* gout = nslice > 1 ? d_part : d_fold;
     hipMemsetAsync(gout, 0, sizeof(double) * msz * K * nslice, st);
-    L1G64 g{R, T, rtot, nslice, ntile, multi ? world : 1, multi ? rank : 0, gout, msz * K};
-    hipLaunchKernelGGL(k_l1_gram64, dim3((ntile * nslice + 3) / 4, K), dim3(256), 0, st, g, ctx->seg);
+    if (gram64) {
+      L1G64 g{R, T, rtot, nslice, ntile, multi ? world : 1, multi ? rank : 0, gout, msz * K};
+      hipLaunchKernelGGL(k_l1_gram64, dim3((ntile * nslice + 3) / 4, K), dim3(256), 0, st, g, ctx->seg);
+    } else {
+      L1G128 g{R, rtot, nslice, d_items, gout, msz * K};
+      hipLaunchKernelGGL(k_l1_gram128, dim3((unsigned)items.size()), dim3(256), 0, st, g, ctx->seg);
+    }
     if (nslice > 1)
       hipLaunchKernelGGL(k_reduce_slices, dim3((unsigned)((msz * K + 255) / 256)), dim3(256), 0, st, d_part, msz * K,
                          nslice, msz * K, d_fold);
+    if (!gram64)
+      hipLaunchKernelGGL(k_l1_wty, dim3(L, K), dim3(256), 0, st, R, ctx->seg, rtot, multi ? world : 1, multi ? rank : 0, d_fold);
     if (multi) {  // every rank needs every fold matrix: sum of disjoint tile sets, exchanged tile-packed
       hipLaunchKernelGGL(k_tiles_pack, dim3(ntile, K), dim3(256), 0, st, d_fold, msz, T, n64, d_pack, 0);
       RG_HIP(hipStreamSynchronize(st));

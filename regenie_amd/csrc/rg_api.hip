@@ -33,7 +33,7 @@ void free_all(rg_ctx* c) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->own_W && c->d_W) hipFree(c->d_W);
-  for (int i = 0; i < 12; ++i)
+  for (int i = 0; i < 16; ++i)
     if (c->ws_ptr[i]) { hipFree(c->ws_ptr[i]); c->ws_ptr[i] = nullptr; c->ws_bytes[i] = 0; }
   for (int i = 0; i < 10; ++i)
     if (c->f64_ptr[i]) { hipFree(c->f64_ptr[i]); c->f64_ptr[i] = nullptr; c->f64_bytes[i] = 0; }
@@ -238,20 +238,24 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   // blocks per batch: more systems per launch hide the Cholesky dependency chain.  (Sizing batches to one round of the
   // block factorization -- one wave per system, 4 per CU: 1024 systems -- was measured: 37.9 ms per step with 3 batches of 37
   // blocks against 36.1 ms with 2 of 55 at BASELINE configs[1]; what the extra batch costs elsewhere outweighs the saved round.)
-  int nb = 64;
+  int nb = ctx->ws_nblk > 0 ? ctx->ws_nblk : 64;
   if (const char* e = getenv("RG_NBLK")) nb = std::max(1, atoi(e));
   nb = std::min(nb, ctx->B_total);
   {  // memory: the per-block workspaces of all pipelines stay inside a budget (default 64 GB, RG_WS_GB): at 500,000 samples a
      // block costs ~0.95 GB (packed planes 0.5, the 25 system workspaces 0.22, integer Grams 0.08, ...), so 2 x 64 blocks
      // would take 120 GB next to W, the exchange buffers and the resident genotypes of a 2-GPU BASELINE configs[2] run
-    double budget = 64e9;
+    double budget = ctx->ws_budget > 0 ? (double)ctx->ws_budget : 64e9;
     if (const char* e = getenv("RG_WS_GB")) budget = std::max(1.0, atof(e)) * 1e9;
+    {  // never more than half of what the device has free right now (W, the exchange buffers and level 1 come on top)
+      size_t fr = 0, tot = 0;
+      if (!ctx->is_child && hipMemGetInfo(&fr, &tot) == hipSuccess && fr > 0) budget = std::min(budget, 0.5 * (double)fr);
+    }
     const double n128d = (double)rg_round_up(ctx->bs_max, 128), n64d = (double)rg_round_up(ctx->bs_max, 64);
     const double rtotd = n64d + (double)rg_round_up(P, 64);
     const double per_blk = n128d * (Np / 4.0) * 2.0 /* pk + pkT */ + n128d * (Np / 2.0) /* FP4 plane */ + (double)K * 4.0 * n128d * n128d * 4.0 /* S */ +
                            ((double)K + 1.0 + (double)K * ctx->R0) * rtotd * n64d * 8.0 /* fold, sum, wk */ +
                            (double)K * ctx->R0 * (n64d / 64.0 + 10.0 * ((n64d / 64.0 + 3.0) / 4.0)) * 4096.0 * 8.0 /* dinv + images */;
-    int npipe = 2;
+    int npipe = ctx->ws_pipes > 0 ? ctx->ws_pipes : 2;
     if (const char* e = getenv("RG_PIPELINES")) npipe = std::max(1, atoi(e));
     if (!ctx->loocv) nb = (int)std::max(4.0, std::min((double)nb, budget / (npipe * per_blk)));
     nb = std::min(nb, ctx->B_total);
@@ -339,7 +343,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   memset(&ctx->tm, 0, sizeof(ctx->tm));
   // further pipelines (see rg_ctx::twin): a chain of child contexts; RG_PIPELINES=1 keeps a single one
   if (ctx->twin) { rg_destroy(ctx->twin); ctx->twin = nullptr; }
-  int npipe = 2;
+  int npipe = ctx->ws_pipes > 0 ? ctx->ws_pipes : 2;
   if (const char* e = getenv("RG_PIPELINES")) npipe = atoi(e);
   ctx->n_pipe = 1;
   if (!ctx->is_child && npipe >= 2 && !ctx->loocv && ctx->B_total > 1) {
@@ -348,6 +352,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
       rg_ctx* ch = nullptr;
       if (rg_create(&ch, ctx->device, nullptr) != RG_OK || !ch) break;
       ch->is_child = true;
+      ch->ws_nblk = ctx->nblk_cap; ch->ws_pipes = npipe; ch->ws_budget = ctx->ws_budget;   // the same batch size as the parent
       if (rg_set_problem(ch, p) != RG_OK) { rg_destroy(ch); break; }   // e.g. not enough memory for another workspace set
       if (!ch->ev_tw_join) hipEventCreateWithFlags(&ch->ev_tw_join, hipEventDisableTiming);
       tail->twin = ch;
@@ -356,6 +361,13 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
     }
     if (ctx->n_pipe > 1 && !ctx->ev_tw_fork) hipEventCreateWithFlags(&ctx->ev_tw_fork, hipEventDisableTiming);
   }
+  return RG_OK;
+}
+
+int rg_set_l0_workspace(rg_ctx* ctx, int32_t max_batch_blocks, int32_t pipelines, int64_t budget_bytes) {
+  if (!ctx) return RG_ERR_ARG;
+  if (max_batch_blocks < 0 || pipelines < 0 || budget_bytes < 0) { ctx->err = "rg_set_l0_workspace: negative argument"; return RG_ERR_ARG; }
+  ctx->ws_nblk = max_batch_blocks; ctx->ws_pipes = pipelines; ctx->ws_budget = budget_bytes;
   return RG_OK;
 }
 

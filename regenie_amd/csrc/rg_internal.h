@@ -78,7 +78,9 @@ struct rg_ctx {
   int64_t W_bytes = 0;
   int w_b0 = 0, w_nb = 0;        // W holds the predictor rows of blocks [w_b0, w_b0 + w_nb) only (rg_set_block_range; default: all)
 
-  // level-0 workspaces (sized for NBLK blocks)
+  // level-0 workspaces (sized for NBLK blocks); the caller's sizing wishes (rg_set_l0_workspace), 0 = library default
+  int ws_nblk = 0, ws_pipes = 0;
+  int64_t ws_budget = 0;
   int nblk_cap = 0;
   int n128 = 0, n64 = 0, rtot = 0;  // paddings for bs_max
   uint8_t* d_raw = nullptr;  int64_t raw_ld = 0;    // staged raw rows [nblk][bs_max][raw_ld]
@@ -152,8 +154,8 @@ struct rg_ctx {
   bool ingest_pending = false;
 
   // level-1 workspaces, kept across calls (hipMalloc/hipFree per call costs milliseconds)
-  void* ws_ptr[12] = {};
-  size_t ws_bytes[12] = {};
+  void* ws_ptr[16] = {};
+  size_t ws_bytes[16] = {};
 
   // fp64 genotype input (l0_f64.hip): grows-only device buffers of the dosage path
   void* f64_ptr[10] = {};
@@ -191,6 +193,14 @@ __device__ __forceinline__ void glds16(const void* sbase, uint32_t voff, uint32_
   const uint64_t sa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
                       (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sa),
+               "s"(__builtin_amdgcn_readfirstlane((int)lds_addr))
+               : "memory", "m0");
+}
+
+// the same copy with a per-lane 64-bit global address (rows that are not at a fixed stride from one base: the level-1 Gram's
+// predictor / padding rows); lds_addr: wave-uniform LDS byte address of the 1 KB destination (lane l lands at + 16 l)
+__device__ __forceinline__ void glds16p(const void* gptr, uint32_t lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr),
                "s"(__builtin_amdgcn_readfirstlane((int)lds_addr))
                : "memory", "m0");
 }

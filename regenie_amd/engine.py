@@ -47,7 +47,7 @@ class RgTiming(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
-EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_w_rows", "rg_w_bytes",
+EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_set_l0_workspace", "rg_w_rows", "rg_w_bytes",
            "rg_set_w_buffer", "rg_set_block_range", "rg_w_device_ptr", "rg_l0_blocks", "rg_l0_blocks_f64", "rg_sync", "rg_l0_get_w",
            "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_set_collective", "rg_set_l1_view", "rg_set_loco_output", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
            "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak",

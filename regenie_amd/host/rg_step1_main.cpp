@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <future>
 #include <iomanip>
 #include <iostream>
@@ -39,6 +40,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <charconv>
 #include <climits>
 #include <unistd.h>
 #include <zlib.h>
@@ -2222,6 +2224,45 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   return 0;
 }
 
+// Ring of host buffers between the .bed / .pgen reader thread and rg_l0_blocks (the block loop of Data.cpp:636-678 with the file
+// read taken off the critical path).  The buffers are page-locked -- copies to the device are then asynchronous and run at the
+// PCIe rate -- on a thread of their own: page-locking costs ~0.2 s per GB, so a run on one GPU starts it while the phenotype and
+// covariate files are still being parsed and the reader takes each buffer as it becomes ready.
+struct IngestRing {
+  static constexpr int NBUF = 3;
+  int per = 1;                       // SNP blocks per buffer
+  bool pinned = true, failed = false;
+  uint8_t* mem[NBUF] = {nullptr, nullptr, nullptr};
+  std::mutex mu; std::condition_variable cv; std::deque<int> free_q;
+  std::thread th;
+  // total_bytes: the rows this ring will carry; blk_bytes: one block; max_per: most blocks per buffer (the library's batch size) or
+  // <= 0 when not known yet; pin: 1 / 0 forces page-locked / pageable buffers, -1 page-locks only when the input is several rings long
+  void start(int64_t total_bytes, int64_t blk_bytes, int max_per, int pin) {
+    int64_t slot = std::max<int64_t>(16LL << 20, std::min<int64_t>(total_bytes / 8, 4LL << 30));
+    if (const char* e = getenv("RG_INGEST_MB")) slot = (int64_t)std::max(1, atoi(e)) << 20;
+    per = (int)std::max<int64_t>(1, slot / std::max<int64_t>(1, blk_bytes));
+    if (max_per > 0) per = std::min(per, max_per);
+    const int64_t bytes = (int64_t)per * blk_bytes;
+    pinned = pin >= 0 ? pin != 0 : total_bytes >= 4 * NBUF * bytes;
+    if (const char* e = getenv("RG_INGEST_PINNED")) pinned = atoi(e) != 0;
+    th = std::thread([this, bytes]() {
+      for (int i = 0; i < NBUF; ++i) {
+        uint8_t* m = pinned ? (uint8_t*)rg_host_alloc(bytes) : (uint8_t*)aligned_alloc(4096, (size_t)(bytes + 4095) / 4096 * 4096);
+        std::lock_guard<std::mutex> lk(mu);
+        if (!m) { failed = true; cv.notify_all(); return; }
+        mem[i] = m;
+        free_q.push_back(i);
+        cv.notify_all();
+      }
+    });
+  }
+  void release() {
+    if (th.joinable()) th.join();
+    for (auto& m : mem) { if (m) { if (pinned) rg_host_free(m); else free(m); } m = nullptr; }
+  }
+  ~IngestRing() { release(); }
+};
+
 int run(int argc, char** argv) {
   Run r;
   r.p = parse_args(argc, argv);
@@ -2232,6 +2273,16 @@ int run(int argc, char** argv) {
   sout << "Log of output saved in file : " << p.out << ".log\n\nOptions in effect:\n";
   for (int i = 1; i < argc; ++i) sout << (argv[i][0] == '-' && argv[i][1] == '-' ? "  " : " ") << argv[i] << (i + 1 < argc && argv[i + 1][0] == '-' ? " \\\n" : "");
   sout << "\n\nFitting null model\n";
+  // The HIP runtime and the device contexts come up on their own threads while this one parses the text files (bringing the
+  // runtime up costs 150 - 200 ms, as much as the parsing)
+  std::vector<std::future<rg_ctx*>> early_ctx;
+  if (p.step == 1 && !p.split_l0)
+    for (int g = 0; g < p.gpus; ++g)
+      early_ctx.push_back(std::async(std::launch::async, [&p, g]() -> rg_ctx* {
+        rg_ctx* c = nullptr;
+        if (rg_create(&c, p.single_device ? p.device : p.device + g, nullptr) != 0) return nullptr;
+        return c;
+      }));
   if (p.run_l0) prep_parallel_l0(r);
   read_bim_fam(r);
   if (p.split_l0) {  // set_parallel_l0 / write_l0_master (Data.cpp:232-309): master + per-job variant lists, then exit
@@ -2271,6 +2322,13 @@ int run(int argc, char** argv) {
   }
   auto since_start = [&]() { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count(); };
   sout << "   -genotype metadata read (" << since_start() << "ms since start)\n";
+  const int64_t ingest_blk_bytes = (int64_t)p.bsize * r.bpr;
+  IngestRing pre_ring;
+  IngestRing* pre_ring_ptr = nullptr;
+  if (p.step == 1 && p.gpus == 1 && !p.run_l1 && !r.dosage_mode && r.bpr > 0) {   // one GPU: the ring is page-locked under the parsing below
+    pre_ring.start((int64_t)r.snp_chrom.size() * r.bpr, ingest_blk_bytes, -1, 1);
+    pre_ring_ptr = &pre_ring;
+  }
   read_pheno_cov(r);
   sout << "   -phenotypes and covariates ready (" << since_start() << "ms since start)\n";
   if (p.step == 2) return run_step2(r, t_start);
@@ -2369,9 +2427,15 @@ int run(int argc, char** argv) {
   pr.lambda = lambda.data(); pr.X = r.X.data(); pr.Y = r.Y.data(); pr.mask = r.mask.data();
   pr.ind_in_analysis = r.ain.data(); pr.ind_ignore = (r.N != r.n_file) ? r.ind_ignore.data() : nullptr;
   pr.neff = r.neff.data(); pr.n_blocks_total = B; pr.max_block_size = p.bsize;
+  for (int g = 0; g < G; ++g) ctxs[g] = early_ctx[g].get();
   for (int g = 0; g < G; ++g) {
-    if (rg_create(&ctxs[g], p.single_device ? p.device : p.device + g, nullptr) != 0 || !ctxs[g])
+    if (!ctxs[g])
       throw std::runtime_error("no MI355X / HIP device available (rg_create failed for device " + std::to_string(p.single_device ? p.device : p.device + g) + ")");
+    // level-0 workspaces in proportion to what this GPU will ingest: a run over a small file asks for small batches (the
+    // bytes a process allocates are set-up time, for it and for the next process on the device), a large one gets the
+    // library's default of 64 GB
+    const int64_t bed_bytes = (int64_t)(B / G + 1) * ingest_blk_bytes;
+    check(ctxs[g], rg_set_l0_workspace(ctxs[g], 0, 0, std::max<int64_t>(6000000000LL, std::min<int64_t>(64000000000LL, 8 * bed_bytes))));
     check(ctxs[g], rg_set_problem(ctxs[g], &pr));
   }
   sout << "   -GPU context" << (G > 1 ? "s" : "") << " ready (" << since_start() << "ms since start)\n";
@@ -2394,7 +2458,7 @@ int run(int argc, char** argv) {
   // reader thread fills page-locked buffers (one pread per block when its variants are contiguous in the file, Geno.cpp:
   // 1702-1769 reads them one by one), the calling thread hands each buffer to rg_l0_blocks -- asynchronous copies, kernels
   // queued behind the previous batch on the other pipeline -- and recycles it once its copy has completed (rg_ingest_fence).
-  auto level0_range = [&](rg_ctx* cx, int b_lo, int b_hi, std::ostringstream& lg) {
+  auto level0_range = [&](rg_ctx* cx, int b_lo, int b_hi, std::ostringstream& lg, IngestRing* pre_ring) {
     if (b_lo >= b_hi) return;
     if (r.dosage_mode) {   // a block of dosages is bs x N_file doubles on the host: one block at a time, synchronous
       std::vector<double> dbuf;
@@ -2424,28 +2488,23 @@ int run(int argc, char** argv) {
       }
       return;
     }
-    const int64_t blk_bytes = (int64_t)p.bsize * r.bpr;
-    int64_t budget_mb = 2048;
-    if (const char* e = getenv("RG_INGEST_MB")) budget_mb = std::max(1, atoi(e));
-    const int per = (int)std::max<int64_t>(1, std::min<int64_t>(rg_l0_batch_blocks(cx), budget_mb * 1048576 / std::max<int64_t>(1, blk_bytes)));
-    const int NBUF = 3;
-    struct Slot { uint8_t* mem = nullptr; int b0 = 0, nb = 0; double read_ms = 0; };
+    const int64_t blk_bytes = ingest_blk_bytes;
+    // the ring of host buffers: the one whose page-locking was started while the text files were parsed (one GPU), or a
+    // ring of this rank's own
+    IngestRing own;
+    IngestRing& ring = pre_ring ? *pre_ring : own;
+    if (!pre_ring) own.start((int64_t)(b_hi - b_lo) * blk_bytes, blk_bytes, rg_l0_batch_blocks(cx), -1);
+    const int per = ring.per;
+    const int NBUF = IngestRing::NBUF;
+    struct Slot { int b0 = 0, nb = 0; double read_ms = 0; };
     std::vector<Slot> slots(NBUF);
-    // Page-locking costs ~0.6 s per GB (measured: the 2.4 GB ring of BASELINE configs[1] took the whole run from 0.95 s to
-    // 2.5 s), so the ring is pinned only when the rows to ingest are several times its size; smaller inputs go through
-    // pageable buffers (the runtime stages those copies itself) -- the reader thread overlaps the file reads either way.
-    const int64_t ring_bytes = (int64_t)NBUF * per * blk_bytes, total_bytes = (int64_t)(b_hi - b_lo) * blk_bytes;
-    bool pinned = total_bytes >= 4 * ring_bytes;
-    if (const char* e = getenv("RG_INGEST_PINNED")) pinned = atoi(e) != 0;
-    for (auto& sl : slots) {
-      sl.mem = pinned ? (uint8_t*)rg_host_alloc((int64_t)per * blk_bytes) : (uint8_t*)aligned_alloc(4096, (size_t)((int64_t)per * blk_bytes + 4095) / 4096 * 4096);
-      if (!sl.mem) throw std::runtime_error("cannot allocate memory for the genotype buffers");
-    }
-    std::mutex mu; std::condition_variable cv;
-    std::deque<int> free_q, ready_q;
-    for (int i = 0; i < NBUF; ++i) free_q.push_back(i);
+    std::mutex& mu = ring.mu; std::condition_variable& cv = ring.cv;
+    std::deque<int>& free_q = ring.free_q;
+    std::deque<int> ready_q;
     std::exception_ptr rd_err = nullptr;
     bool rd_done = false;
+    int rd_threads = 4;    // preads of one buffer in flight (page-cache copies scale with threads; a disk queue likes depth)
+    if (const char* e = getenv("RG_READ_THREADS")) rd_threads = std::max(1, atoi(e));
     std::thread reader([&]() {
       int fd = -1;
       try {
@@ -2457,15 +2516,19 @@ int run(int argc, char** argv) {
           int si;
           {
             std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return !free_q.empty(); });
+            cv.wait(lk, [&] { return !free_q.empty() || ring.failed; });
+            if (ring.failed) throw std::runtime_error("cannot allocate memory for the genotype buffers");
             si = free_q.front(); free_q.pop_front();
           }
           Slot& sl = slots[si];
+          uint8_t* slmem = ring.mem[si];
           sl.b0 = b0; sl.nb = std::min(per, b_hi - b0);
           auto t0 = std::chrono::steady_clock::now();
+          struct Piece { uint8_t* dst; int64_t off, want; };
+          std::vector<Piece> pieces;
           for (int b = 0; b < sl.nb; ++b) {
             const Blk& bl = blocks[b0 + b];
-            uint8_t* dst = sl.mem + (int64_t)b * blk_bytes;
+            uint8_t* dst = slmem + (int64_t)b * blk_bytes;
             if (r.pgen) {  // ReadHardcalls per kept variant (Geno.cpp:1781-1798), as .bed-coded rows
               std::lock_guard<std::mutex> lk(io_mu);
               if (rg_pgen_read_bed_rows(r.pgen, bl.bs, &r.snp_offset[bl.start], dst, r.bpr) != RG_PGEN_OK)
@@ -2476,15 +2539,23 @@ int run(int argc, char** argv) {
             while (j < bl.bs) {   // runs of variants that are consecutive in the file: one pread each (jumpto_bed, Geno.cpp:2828-2830)
               int e = j + 1;
               while (e < bl.bs && r.snp_offset[bl.start + e] == r.snp_offset[bl.start + e - 1] + 1) ++e;
-              int64_t want = (int64_t)(e - j) * r.bpr, got = 0;
-              const int64_t off = 3 + r.snp_offset[bl.start + j] * r.bpr;
-              while (got < want) {
-                const ssize_t k = pread(fd, dst + (int64_t)j * r.bpr + got, (size_t)(want - got), off + got);
-                if (k <= 0) throw std::runtime_error("cannot read bed file");
-                got += k;
-              }
+              const int64_t want = (int64_t)(e - j) * r.bpr, off = 3 + r.snp_offset[bl.start + j] * r.bpr, chunk = 8 << 20;
+              for (int64_t o = 0; o < want; o += chunk) pieces.push_back({dst + (int64_t)j * r.bpr + o, off + o, std::min(chunk, want - o)});
               j = e;
             }
+          }
+          if (!pieces.empty()) {
+            std::atomic<int> bad{0};
+            parallel_for((int)pieces.size(), rd_threads, [&](int t) {
+              const Piece& pc = pieces[t];
+              int64_t got = 0;
+              while (got < pc.want) {
+                const ssize_t k = pread(fd, pc.dst + got, (size_t)(pc.want - got), pc.off + got);
+                if (k <= 0) { bad = 1; return; }
+                got += k;
+              }
+            });
+            if (bad) throw std::runtime_error("cannot read bed file");
           }
           sl.read_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
           {
@@ -2520,7 +2591,7 @@ int run(int argc, char** argv) {
         std::vector<const uint8_t*> ptrs(sl.nb);
         int64_t nsnp = 0;
         for (int b = 0; b < sl.nb; ++b) {
-          ids[b] = sl.b0 + b; bss[b] = blocks[sl.b0 + b].bs; ptrs[b] = sl.mem + (int64_t)b * blk_bytes;
+          ids[b] = sl.b0 + b; bss[b] = blocks[sl.b0 + b].bs; ptrs[b] = ring.mem[si] + (int64_t)b * blk_bytes;
           nsnp += bss[b];
         }
         auto t1 = std::chrono::steady_clock::now();
@@ -2538,9 +2609,9 @@ int run(int argc, char** argv) {
       }
     } catch (...) {
       main_err = std::current_exception();
-      {   // let the reader run to its end: hand every buffer back
+      {   // let the reader come to its end
         std::lock_guard<std::mutex> lk(mu);
-        for (int i = 0; i < NBUF; ++i) free_q.push_back(i);
+        ring.failed = true;
       }
       cv.notify_all();
     }
@@ -2551,7 +2622,7 @@ int run(int argc, char** argv) {
       lg << "   -level 0 ridge of blocks [" << b_lo + 1 << ".." << b_hi << "] complete (" <<
           std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() << "ms after the last batch was queued)\n";
     }
-    for (auto& sl : slots) { if (pinned) rg_host_free(sl.mem); else free(sl.mem); }
+    ring.release();
     if (main_err) std::rethrow_exception(main_err);
   };
 
@@ -2577,7 +2648,7 @@ int run(int argc, char** argv) {
   }
   if (p.run_l0) {  // level 0 of this job, then write_l0_file (Step1_Models.cpp:728-734): PFX_job<k>_l0_Y<ph>, and stop (Data.cpp:113-117)
     std::ostringstream lg;
-    level0_range(ctx, 0, B, lg);
+    level0_range(ctx, 0, B, lg, pre_ring_ptr);
     sout << lg.str();
     std::vector<double> slab((size_t)N * R0);
     for (int q = 0; q < P; ++q) {
@@ -2622,8 +2693,36 @@ int run(int argc, char** argv) {
   for (int64_t i = 0; i < N; ++i) order[i] = i;
   std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return r.ids[a] < r.ids[b]; });
   std::string header = "FID_IID ";
-  for (int64_t i : order) if (r.ain[i]) header += r.ids[i] + " ";
+  std::vector<int64_t> kept_order;     // the analysed samples in the writer's order
+  for (int64_t i : order) if (r.ain[i]) { header += r.ids[i] + " "; kept_order.push_back(i); }
   header += "\n";
+  const int fmt_threads = std::max(1, std::min(32, p.threads > 0 ? p.threads : (int)std::thread::hardware_concurrency() - 1));
+  // one row of a .loco / .prs file (write_chr_row, Data.cpp:1951-1975): `<chr> v1 v2 ... \n`, NA where the phenotype is missing.
+  // The values are formatted by several threads over chunks of samples; the default stream format of a double (%g, six
+  // significant digits) is what std::to_chars(general, 6) produces.
+  auto format_rows = [&](int nrows, const std::function<double(int, int64_t)>& value, const uint8_t* maskq, std::vector<std::string>& rows) {
+    const int NCK = 16;
+    const int64_t nk = (int64_t)kept_order.size();
+    std::vector<std::string> piece((size_t)nrows * NCK);
+    parallel_for(nrows * NCK, fmt_threads, [&](int t) {
+      const int row = t / NCK, ck = t % NCK;
+      std::string& o = piece[t];
+      const int64_t k0 = nk * ck / NCK, k1 = nk * (ck + 1) / NCK;
+      o.reserve((size_t)(k1 - k0) * 12);
+      char buf[48];
+      for (int64_t k = k0; k < k1; ++k) {
+        const int64_t i = kept_order[k];
+        if (maskq[i]) {
+          const auto res = std::to_chars(buf, buf + sizeof(buf), value(row, i), std::chars_format::general, 6);
+          o.append(buf, res.ptr);
+          o.push_back(' ');
+        } else o += "NA ";
+      }
+    });
+    rows.assign(nrows, std::string());
+    for (int row = 0; row < nrows; ++row)
+      for (int ck = 0; ck < NCK; ++ck) rows[row] += piece[(size_t)row * NCK + ck];
+  };
 
   // per-phenotype results, filled by whichever rank owns the phenotype
   std::vector<std::string> ph_log(P), ph_plist(P), ph_prslist(P);
@@ -2662,35 +2761,20 @@ int run(int argc, char** argv) {
       TextOut lf(loco_fn, p.gz);
       if (!lf) throw std::runtime_error("cannot write file : " + loco_fn);
       lf << header;
-      std::map<int, int> cidx;
-      for (int c = 0; c < nchr; ++c) cidx[chroms[c]] = c;
-      for (int chr = 1; chr <= p.nchrom; ++chr) {
-        std::ostringstream row;
-        row << chr << " ";
-        const double* sub = cidx.count(chr) ? pq + (size_t)cidx[chr] * N : nullptr;
-        for (int64_t i : order) {
-          if (!r.ain[i]) continue;
-          if (r.mask[(size_t)q * N + i]) row << (tot[i] - (sub ? sub[i] : 0.0)) << " ";
-          else row << "NA ";
-        }
-        row << "\n";
-        lf << row.str();
-      }
+      std::vector<const double*> sub(p.nchrom, nullptr);
+      for (int c = 0; c < nchr; ++c) if (chroms[c] >= 1 && chroms[c] <= p.nchrom) sub[chroms[c] - 1] = pq + (size_t)c * N;
+      std::vector<std::string> rows;
+      format_rows(p.nchrom, [&](int row, int64_t i) { return tot[i] - (sub[row] ? sub[row][i] : 0.0); }, r.mask.data() + (size_t)q * N, rows);
+      for (int chr = 1; chr <= p.nchrom; ++chr) lf << std::to_string(chr) << " " << rows[chr - 1] << "\n";
     }
     ph_plist[q] = r.pheno_names[q] + " " + (p.use_rel_path ? loco_fn : get_fullpath(loco_fn)) + "\n";
     if (p.print_prs) {
       const std::string prs_fn = p.out + "_" + std::to_string(q + 1) + ".prs" + (p.gz ? ".gz" : "");
       TextOut pf(prs_fn, p.gz);
       pf << header;
-      std::ostringstream row;
-      row << 0 << " ";
-      for (int64_t i : order) {
-        if (!r.ain[i]) continue;
-        if (r.mask[(size_t)q * N + i]) row << tot[i] << " ";
-        else row << "NA ";
-      }
-      row << "\n";
-      pf << row.str();
+      std::vector<std::string> rows;
+      format_rows(1, [&](int, int64_t i) { return tot[i]; }, r.mask.data() + (size_t)q * N, rows);
+      pf << "0 " << rows[0] << "\n";
       ph_prslist[q] = r.pheno_names[q] + " " + (p.use_rel_path ? prs_fn : get_fullpath(prs_fn)) + "\n";
     }
     lo << "done\n\n";
@@ -2722,7 +2806,7 @@ int run(int argc, char** argv) {
   if (!use_group) {
     if (!p.run_l1) {
       std::ostringstream lg;
-      level0_range(ctx, 0, B, lg);
+      level0_range(ctx, 0, B, lg, pre_ring_ptr);
       sout << lg.str();
     }
     sout << "\n Level 1 ridge...\n";
@@ -2743,7 +2827,7 @@ int run(int argc, char** argv) {
           std::ostringstream lg;
           // the exchange buffers of this rank (phenotype view, packed send buffer) are allocated before level 0 starts
           check(ctxs[g], rg_group_prepare(grp, g, bbeg.data(), pheno_sharded ? pbeg.data() : nullptr));
-          level0_range(ctxs[g], bbeg[g], bbeg[g + 1], lg);
+          level0_range(ctxs[g], bbeg[g], bbeg[g + 1], lg, nullptr);
           rank_log[g] = lg.str();
           check(ctxs[g], rg_l0_finish(grp, g, bbeg.data(), pheno_sharded ? pbeg.data() : nullptr));
           if (pheno_sharded) level1_range(ctxs[g], pbeg[g], pbeg[g + 1] - pbeg[g], true);
