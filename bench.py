@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--oracle-check", action="store_true", help="check the full configuration against the numpy oracle even with --no-cpu "
                     "(level-0 predictors of two blocks, level 1 of phenotype 0 on the full W: CV sums, selected ridge value, LOCO)")
     ap.add_argument("--no-disk", action="store_true", help="skip the end-to-end-from-files leg (the C++ driver on a .bed written to disk)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the sub-records of the default N=1 run: BASELINE configs[2] in full on this one GPU "
+                    "(`config3_single_gpu`) and the Step-2 record at configs[4]'s shape (`step2`)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for the "
                     "single-box smoke of the N>1 code path")
     ap.add_argument("--single-device", action="store_true", help="test mode: every rank uses cuda:0")
@@ -259,38 +261,43 @@ def main():
         flops = {
             "gram_fp4": 2.0 * N * sum(x * x for x in bss),                       # F_gram = 2 N bs^2 per block
             "chol_f64": sum((x ** 3 / 3.0 + 2.0 * x * x * P) * 5 * R0 for x in bss),  # K*R0 systems per block
-            "l1_gram_f64": 2.0 * N * L * L * P,
+            # level-1 fold Grams: the symmetric product, lower triangle with the diagonal (what any algorithm must form); SURVEY 8(d)'s
+            # 2 N L^2 P counts the full product the reference's W_i^T W_i computes -- twice this, reported next to it
+            "l1_gram_f64": 1.0 * N * L * (L + 1) * P,
             "l1_chol_f64": P * 5 * R1 * (L ** 3 / 3.0 + 2.0 * L * L),
+            # many-row predictions on the i8 matrix cores: 8 digit planes x 2 N bs (P R0) integer operations per block
+            "pred_i8": 8 * 2.0 * N * sum(bss) * P * R0 if P * R0 > 16 else 0.0,
         }
         kernels = {
             "gram_fp4": {"ms": tm["ms_gram"], "achieved_TOPS": flops["gram_fp4"] / (tm["ms_gram"] * 1e-3) / 1e12 if tm["ms_gram"] else None,
                         "launches": tm["n_gram_launches"]},
             "chol_f64": {"ms": tm["ms_chol"], "achieved_TFLOPS": flops["chol_f64"] / (tm["ms_chol"] * 1e-3) / 1e12 if tm["ms_chol"] else None},
             "prep": {"ms": tm["ms_prep"]}, "geno_xy": {"ms": tm["ms_xy"]}, "assemble_form": {"ms": tm["ms_assemble"]},
-            "pred": {"ms": tm["ms_pred"]},
-            "l1_gram_f64": {"ms": tm["ms_l1_gram"], "achieved_TFLOPS": flops["l1_gram_f64"] / (tm["ms_l1_gram"] * 1e-3) / 1e12 if tm["ms_l1_gram"] else None},
+            "pred": {"ms": tm["ms_pred"], "achieved_TOPS_i8_digit_planes": flops["pred_i8"] / (tm["ms_pred"] * 1e-3) / 1e12 if (tm["ms_pred"] and flops["pred_i8"]) else None},
+            "l1_gram_f64": {"ms": tm["ms_l1_gram"], "achieved_TFLOPS": flops["l1_gram_f64"] / (tm["ms_l1_gram"] * 1e-3) / 1e12 if tm["ms_l1_gram"] else None,
+                            "full_product_TFLOPS_survey_8d": 2.0 * N * L * L * P / (tm["ms_l1_gram"] * 1e-3) / 1e12 if tm["ms_l1_gram"] else None},
             "l1_chol_f64": {"ms": tm["ms_l1_chol"]}, "l1_cv_pred": {"ms": tm["ms_l1_pred"]},
         }
-        dom = max(("gram_fp4", "chol_f64", "l1_gram_f64"), key=lambda k: kernels[k]["ms"])
+        cand = ["gram_fp4", "chol_f64", "l1_gram_f64"] + (["pred"] if flops["pred_i8"] else [])
+        dom = max(cand, key=lambda k: kernels[k]["ms"])
         kernels["gram_fp4"]["frac_of_fp4_peak"] = kernels["gram_fp4"]["achieved_TOPS"] / PEAK["fp4_mfma_TOPS"]
+        traffic, traffic_note = measured_traffic(dom, len(my_blocks), n_batches, P)
         if dom == "gram_fp4":
             a = kernels[dom]["achieved_TOPS"]
             roof = {"kernel": "k_gram_fp4_blocks (FP4 matrix-core fold Gram)", "bound": "mfma", "achieved": a, "peak": PEAK["fp4_mfma_TOPS"],
-                    "unit": "TOP/s", "frac": a / PEAK["fp4_mfma_TOPS"], "traffic": None,
+                    "unit": "TOP/s", "frac": a / PEAK["fp4_mfma_TOPS"], "traffic": traffic, "traffic_note": traffic_note,
                     "algorithmic_ops_per_launch": flops["gram_fp4"] / max(1, n_batches), "avg_launch_ms": tm["ms_gram"] / max(1, n_batches)}
+        elif dom == "pred":
+            a = kernels[dom]["achieved_TOPS_i8_digit_planes"]
+            roof = {"kernel": "k_l0_pred_i8_ring (level-0 predictions, exact digit planes on the i8 matrix cores)", "bound": "mfma", "achieved": a,
+                    "peak": PEAK["i8_mfma_TOPS"], "unit": "TOP/s", "frac": a / PEAK["i8_mfma_TOPS"], "traffic": traffic, "traffic_note": traffic_note,
+                    "algorithmic_ops_per_launch": flops["pred_i8"] / max(1, n_batches), "avg_launch_ms": tm["ms_pred"] / max(1, n_batches)}
         else:
             a = kernels[dom]["achieved_TFLOPS"]
-            traffic = None
-            if dom == "chol_f64":   # HBM bytes per batch from the separate rocprofv3 PMC passes of this same command
-                try:                # (profiles/r2_traffic.json, tools/pmc_traffic.py: FETCH_SIZE x 2 + WRITE_SIZE)
-                    tj = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
-                    traffic = tj["hbm_bytes_per_batch"] * (len(my_blocks) / n_batches) / (109 / 2.0)
-                except Exception:   # noqa: BLE001 - the field is optional
-                    traffic = None
             roof = {"kernel": {"chol_f64": "k_chol_update/gfact/gstrip/backsolve (fp64 MFMA batched Cholesky, per level-0 batch of systems)",
-                               "l1_gram_f64": "k_l1_gram (fp64 MFMA fold Gram)"}[dom], "bound": "mfma", "achieved": a,
+                               "l1_gram_f64": "k_l1_gram128 (fp64 MFMA level-1 fold Gram, one launch per phenotype)"}[dom], "bound": "mfma", "achieved": a,
                     "peak": PEAK["f64_mfma_TFLOPS"], "unit": "TFLOP/s", "frac": a / PEAK["f64_mfma_TFLOPS"], "traffic": traffic,
-                    "traffic_note": "HBM bytes per launch group from separate rocprofv3 --pmc passes of this command at this commit's kernels (profiles/r2_traffic.json, tools/collect_profiles.sh), scaled by blocks per batch; not re-measured inside this run",
+                    "traffic_note": traffic_note,
                     "algorithmic_flops_per_launch": flops[dom] / max(1, n_batches if dom == "chol_f64" else P),
                     "avg_launch_ms": kernels[dom]["ms"] / max(1, n_batches if dom == "chol_f64" else P)}
 
@@ -304,28 +311,87 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu and not args.no_disk:
         disk = from_disk_leg(args, torch, packed, blocks, my_blocks, Yraw, cov, M, N, P, res[0])
 
+    # ---- sub-records of the default N=1 run (the engine's memory is released first) ----
+    extra = {}
+    default_n1 = rank == 0 and world == 1 and not args.no_cpu and not args.no_extra and (N, M, P) == (50000, 100000, 1)
+    if default_n1:
+        loco_ck = float(sum(np.abs(l).sum() for l in res[0]))
+        eng.close()
+        eng = None
+        del packed, Wt, Wv
+        torch.cuda.empty_cache()
+        import subprocess
+        try:    # BASELINE configs[2] (the north star's target workload) in full on this ONE GPU: 500,000 x 500,000 x 10 QT, resident
+            r3 = subprocess.run([sys.executable, os.path.abspath(__file__), "--samples", "500000", "--snps", "500000", "--phenos", "10", "--steps", "1",
+                                 "--warmup", "1", "--no-cpu"], capture_output=True, text=True, timeout=900)
+            l3 = json.loads([ln for ln in r3.stdout.splitlines() if ln.startswith("{")][-1])
+            extra["config3_single_gpu"] = {k: l3[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernels", "loco_checksum",
+                                                               "selected_tau_index")}
+        except Exception as e:   # noqa: BLE001 - a sub-record must not take the line down
+            extra["config3_single_gpu"] = {"error": repr(e)[:500]}
+        try:
+            from tools.step2_record import step2_record
+            extra["step2"] = step2_record(torch=torch)
+        except Exception as e:   # noqa: BLE001
+            extra["step2"] = {"error": repr(e)[:500]}
     if rank == 0:
         line = {
             "metric": "Step-1 SNPs x samples x phenos / sec", "value": value, "unit": "SNP*sample*pheno/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "fp4 (exact integer Gram) + i8 (exact fixed-point digit planes of the fp64 operands: G~X / G~Y, many-row predictions) + f64 (solves, level 1)",
             "data": "synthetic",
-            "config": {"workload": "%ssynthetic PLINK bed %d samples x %d SNPs (%d per GPU), %d QT pheno, bsize %d, 22 chromosomes, 5-fold CV, 5x5 ridge grid"
-                       % ("BASELINE configs[2], blocks sharded over the GPUs: " if strong else ("BASELINE configs[1]: " if world == 1 else "weak scaling of BASELINE configs[1]: "),
+            "config": {"workload": "%ssynthetic PLINK bed %d samples x %d SNPs (%d per GPU), %d QT pheno, bsize %d, 22 chromosomes, 5-fold CV, 5x5 ridge grid; "
+                       "`value` is the HBM-resident figure (packed genotypes generated on the device, timed region = level 0 + level 1 + LOCO rows); "
+                       "the complete run from files on disk is `end_to_end_from_files`"
+                       % ("BASELINE configs[2], blocks sharded over the GPUs: " if strong else
+                          ("BASELINE configs[1]: " if (world == 1 and (N, M, P) == (50000, 100000, 1)) else
+                           ("BASELINE configs[2] on ONE GPU: " if (world == 1 and (N, M, P) == (500000, 500000, 10)) else
+                            ("" if world == 1 else "weak scaling of BASELINE configs[1]: "))),
                           N, M, args.snps, P, bsize), "samples": N, "snps": M, "phenos": P, "bsize": bsize, "blocks": B,
                        "parallelism": ("blocks sharded x%d, all-to-all of W by phenotype, level 1 phenotype-sharded x%d" if pheno_sharded else
                                        "blocks sharded x%d, all-gather of W, level-1 Gram tiles / ridge systems shared x%d") % (world, world)},
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
             "loco_max_rel_err": cpu.get("loco_max_rel_err") if cpu else None,
             "end_to_end_from_files": disk,
-            "loco_checksum": float(res[3]) if len(res) > 3 else float(sum(np.abs(l).sum() for l in res[0])),
+            "loco_checksum": float(res[3]) if len(res) > 3 else (loco_ck if default_n1 else float(sum(np.abs(l).sum() for l in res[0]))),
             "selected_tau_index": [int(b) for b in res[2]],
             "setup_s": {"generate": t_gen},
         }
+        line.update(extra)
         print(json.dumps(line))
-    eng.close()
+    if eng is not None:
+        eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def measured_traffic(dom, nblocks, n_batches, P):
+    """HBM bytes per launch (group) of the dominant kernel from the rocprofv3 --pmc passes of THIS build: tools/collect_profiles.sh
+    writes profiles/*traffic*.json with the digest of the kernel sources it was measured on (regenie_amd/lib/build.stamp).  A file
+    measured on other sources is refused (traffic = null) rather than rescaled."""
+    import glob
+    try:
+        stamp = open(os.path.join(ROOT, "regenie_amd", "lib", "build.stamp")).read().strip()
+    except OSError:
+        return None, "no build stamp"
+    group = {"chol_f64": "chol", "l1_gram_f64": "l1_gram", "gram_fp4": "gram_fp4", "pred": "pred"}[dom]
+    stale = False
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
+        try:
+            tj = json.load(open(fn))
+        except Exception:   # noqa: BLE001
+            continue
+        if tj.get("build_stamp") != stamp:
+            stale = True
+            continue
+        g = tj.get("groups", {}).get(group)
+        if not g or tj.get("blocks") != nblocks or tj.get("phenos") != P:
+            continue
+        per = g["hbm_bytes"] / max(1, tj["level0_batches"] if group != "l1_gram" else g.get("lead_launches", P))
+        return per, ("FETCH_SIZE x 2 + WRITE_SIZE of the kernel (group) from separate rocprofv3 --pmc passes of this command on this "
+                     "build (%s), per launch" % os.path.basename(fn))
+    return None, ("the committed PMC traffic files were measured on other kernel sources (stale): refused" if stale else
+                  "no PMC traffic file for this build / workload (tools/collect_profiles.sh)")
 
 
 def math_sqrt(x):

@@ -468,6 +468,29 @@ def test_cli_multi_gpu_qt(example_dir, tmp_path):
     assert "GPU 1 : blocks [4..6]" in res["peer2"]["_log"] and "RCCL" in res["rccl1"]["_log"]
 
 
+@pytest.mark.parametrize("form", ["by_phenotype", "all_gather"])
+def test_cli_multi_gpu_rank_failure_does_not_hang(example_dir, tmp_path, form):
+    """A rank whose host side fails (here: the .bed is cut short, so the reader thread of the LAST rank runs out of file) breaks the
+    group (rg_group_abort): the other rank -- waiting in the level-0 exchange -- returns an error too, the process exits with the
+    reference's `ERROR:` line and a failure status, nothing is left waiting in a barrier or a receive, and no .loco file is written."""
+    import shutil
+    E = example_dir
+    d = tmp_path / "cut"
+    d.mkdir()
+    for ext in (".bim", ".fam"):
+        shutil.copy(os.path.join(E, "example_3chr" + ext), str(d / ("g" + ext)))
+    raw = open(os.path.join(E, "example_3chr.bed"), "rb").read()
+    open(str(d / "g.bed"), "wb").write(raw[:len(raw) - 4000])           # the last variants are missing
+    cmd = ["--step", "1", "--bed", str(d / "g"), "--phenoFile", os.path.join(E, "phenotype.txt"), "--covarFile", os.path.join(E, "covariates.txt"),
+           "--bsize", "100", "--gpus", "2", "--single-device", "--transport", "peer", "--out", "o"]
+    if form == "all_gather":
+        cmd.append("--l1-shared")
+    r = subprocess.run([BIN] + cmd, capture_output=True, text=True, cwd=str(d), timeout=120)    # a hang fails the test by timeout
+    assert r.returncode != 0
+    assert "ERROR:" in r.stdout and "cannot read bed file" in r.stdout, r.stdout[-2000:]
+    assert not [fn for fn in os.listdir(str(d)) if fn.endswith(".loco")]
+
+
 def test_cli_multi_gpu_bt_and_loocv(example_dir, tmp_path):
     E = example_dir
     common = ["--step", "1", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype_bin.txt"),

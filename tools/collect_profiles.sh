@@ -19,7 +19,7 @@ python tools/pmc_summary.py $O/fetch $O/${R}_pmc_fetch.md > /dev/null
 python tools/pmc_summary.py $O/write $O/${R}_pmc_write.md > /dev/null
 python tools/pmc_summary.py $O/mfma $O/${R}_pmc_mfma.md > /dev/null
 NB=$(python -c "import csv,glob; f=glob.glob('$O/fetch/**/*counter_collection.csv',recursive=True)[0]; print(sum(1 for r in csv.DictReader(open(f)) if 'k_bed_prep_rows' in r['Kernel_Name'] and r['Counter_Name']=='FETCH_SIZE'))")
-python tools/pmc_traffic.py $O/fetch $O/write $NB $O/${R}_traffic.json
+python tools/pmc_traffic.py $O/fetch $O/write $NB $O/${R}_traffic.json 109 1
 cat $O/${R}_bench_line.json | cut -c1-400
 head -12 $O/${R}_kernel_stats.md
 # keep only the summaries (the raw traces are tens of MB)
