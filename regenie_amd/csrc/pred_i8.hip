@@ -25,7 +25,6 @@
 // genotype operand for 512 SNPs at a time (16 x 16 bytes per lane) in registers across the 8 digit planes; the coefficient
 // digits of one (row tile, plane, half) are staged in LDS per workgroup (32 rows x 512 bytes) and shared by its eight waves.  Epilogue as in pred.hip: covariate term, mask, store, per-row sums in a fixed order.
 #include <algorithm>
-#include <cstdlib>
 #include "rg_internal.h"
 
 #define PI8_NPIECE 8
@@ -323,161 +322,6 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
   }
 }
 
-// ---- the same contraction with the digit planes streamed through an LDS ring (block widths that are multiples of 512 SNPs) --------
-// k_l0_pred_i8 above stages the eight planes of a (row tile, set, half) with register copies between two barriers and computes
-// only afterwards: at BASELINE configs[2] it kept the matrix pipe 25 % busy and was 19 % of the whole Step-1 run.  Here
-//   * a unit = one PAIR of digit planes of one (set, half, row tile): 2 x 32 rows x 512 bytes = 32 KB.  Four units live in LDS;
-//     unit u + 3 is copied in (direct global -> LDS, inline assembly, counted s_waitcnt) while unit u is multiplied, one barrier
-//     per unit -- no staging registers, no LDS stores, no exposed load latency;
-//   * the 16-byte slots of a row are XOR-swizzled by (row & 15): the 32 rows a ds_read_b128 lane group touches fall on 16
-//     distinct bank quads (the padded pitch of the register-staged form is not available to 1 KB copy pieces);
-//   * the lane's packed genotype dwords of all 1,024 SNPs are loaded once (32 registers) and expanded once per (set, half) for
-//     both row tiles (the tile loop is inside), so the byte-LUT expansion is done 2 - 4 times per workgroup instead of 4 - 8;
-//   * every pair sum goes straight into the fp64 accumulator with its exact power-of-two weight 2^(e-54) 16384^kp (a table in
-//     LDS): out += (double) S * w.  The products are exact, the additions round at 2^-53 of the running value, as before.
-#define PI8R_UNIT 32768
-#define PI8R_NSLOT 4
-template <int DUMMY>
-__global__ __launch_bounds__(512) void k_l0_pred_i8_ring(PredArgs a, ChunkTab ct, int pg, int ngrp, const int8_t* __restrict__ planes,
-                                                         const double* __restrict__ psc, const uint8_t* __restrict__ pkT) {
-  extern __shared__ __attribute__((aligned(16))) int8_t smem[];
-  int8_t* ring = smem;                                                      // [4 slots][2 planes][32 rows][512]
-  double (*sred)[PI8_ROWS][2] = reinterpret_cast<double (*)[PI8_ROWS][2]>(smem + PI8R_NSLOT * PI8R_UNIT);   // [8 waves][64][2]
-  double* scl = reinterpret_cast<double*>(smem + PI8R_NSLOT * PI8R_UNIT + sizeof(double) * 8 * PI8_ROWS * 2);   // [2 sets][4 kp][64 rows]
-  __shared__ double scb[PI8_ROWS][16 + 1];
-  __shared__ int srow_w[PI8_ROWS], srow_p[PI8_ROWS];
-  const int blk = blockIdx.z, ch = blockIdx.x, grp = blockIdx.y, p0 = grp * pg;
-  const int npg = min(pg, a.P - p0), nrow = npg * a.R0;
-  const int s = ct.seg[ch];
-  const int64_t pos0 = ct.pos[ch];
-  const int R0 = a.R0, nm = a.nseg * R0;
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int c = lane & 31, kb = lane >> 5;
-  const int64_t pos = pos0 + wave * 32 + c;
-  const bool has_miss = a.nmiss[blk] > 0;
-  const int n128 = a.n128, nstep = n128 / 32, nhalf = n128 / PI8_KHALF;
-  const int64_t grp_idx = ((int64_t)blk * a.nseg + s) * ngrp + grp;
-  const uint32_t* brow = reinterpret_cast<const uint32_t*>(pkT) + (((int64_t)blk * (a.Np >> 5) + (pos >> 5)) * nstep) * 64 + kb * 32 + c;
-  const int col0 = a.blockid[blk] * R0;
-  if (threadIdx.x < PI8_ROWS) {
-    const int m = threadIdx.x;
-    const bool live = m < nrow;
-    const int pl = live ? m / R0 : 0, rr = live ? m % R0 : 0;
-    srow_w[m] = live ? (col0 + rr) * a.P + p0 + pl : -1;
-    srow_p[m] = p0 + pl;
-  }
-  {  // weights of the pair sums: 2^(e-54) of the row (k_beta_split) times 16384^kp
-    const int e = threadIdx.x;   // 512 = 2 sets x 4 kp x 64 rows
-    const int set = e >> 8, kp = (e >> 6) & 3, m = e & 63;
-    const double sc = psc[(grp_idx * 2 + set) * PI8_ROWS + m];
-    scl[e] = (set == 1 && !has_miss) ? 0.0 : sc * (kp == 0 ? 1.0 : (kp == 1 ? 16384.0 : (kp == 2 ? 268435456.0 : 4398046511104.0)));
-  }
-  const int ntile = nrow > 32 ? 2 : 1, nsets = has_miss ? 2 : 1;
-  const int total = __builtin_amdgcn_readfirstlane(nsets * nhalf * ntile * 4);
-  // copies of this wave: plane hl = wave >> 2 of the unit's pair, pieces 4 (wave & 3) .. + 3 of 16 (a piece = 2 rows x 512 bytes)
-  const int hlw = wave >> 2;
-  uint32_t voff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = 2 * (4 * (wave & 3) + j) + (lane >> 5);
-    const int logical = (lane & 31) ^ (row & 15);
-    voff[j] = (uint32_t)(row * n128 + logical * 16);
-  }
-  const uint32_t ring_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int8_t*)ring;
-  const uint32_t wdst = __builtin_amdgcn_readfirstlane(ring_lds + hlw * 16384 + (wave & 3) * 4096);
-  const int8_t* pl_base = planes + (grp_idx * 2) * PI8_NPIECE * (int64_t)PI8_ROWS * n128;
-  auto issue = [&](int u) {      // unit u -> (set, half, tile, kp), consumption order: set, half, tile, kp = 3 .. 0
-    const int kp = 3 - (u & 3);
-    int v = u >> 2;
-    const int tile = ntile == 2 ? (v & 1) : 0;
-    v = ntile == 2 ? (v >> 1) : v;
-    const int half = v % nhalf, set = v / nhalf;
-    const int8_t* base = pl_base + ((int64_t)(set * PI8_NPIECE + 2 * kp + hlw) * PI8_ROWS + tile * 32) * n128 + half * PI8_KHALF;
-    const uint32_t dst = wdst + (u & (PI8R_NSLOT - 1)) * PI8R_UNIT;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) glds16(base, voff[j], dst + j * 1024);
-  };
-  for (int u = 0; u < 3 && u < total; ++u) issue(u);
-  // the lane's packed genotype dwords of every K step (16 SNPs each), once
-  uint32_t raw[PI8_KMAX / 32];
-#pragma unroll
-  for (int t = 0; t < PI8_KMAX / 32; ++t) raw[t] = brow[(int64_t)(t < nstep ? t : nstep - 1) * 64];
-  double out[2][16];
-#pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) out[t2][r] = 0.0;
-  // A fragment of K step t: row c, logical slot 2t + kb -> physical slot ((2t + kb) ^ (c & 15)) (low four bits)
-  int xoff[8];
-#pragma unroll
-  for (int t8 = 0; t8 < 8; ++t8) xoff[t8] = c * 512 + (((2 * t8 + kb) ^ (c & 15)) << 4);
-  int u = 0;
-#pragma unroll 1
-  for (int set = 0; set < nsets; ++set) {
-    const unsigned lut = set == 0 ? LUT_DOSAGE : LUT_MISS;
-#pragma unroll
-    for (int half = 0; half < PI8_KMAX / PI8_KHALF; ++half) {
-      if (half >= nhalf) break;
-      v4i bf[PI8_KHALF / 32];
-#pragma unroll
-      for (int t = 0; t < PI8_KHALF / 32; ++t) {
-        const uint32_t w = raw[half * (PI8_KHALF / 32) + t];
-        bf[t] = (v4i){(int)pi8_expand4(w & 0xFFu, lut), (int)pi8_expand4((w >> 8) & 0xFFu, lut),
-                      (int)pi8_expand4((w >> 16) & 0xFFu, lut), (int)pi8_expand4(w >> 24, lut)};
-      }
-#pragma unroll
-      for (int tile = 0; tile < 2; ++tile) {
-        if (tile >= ntile) break;
-#pragma unroll 1
-        for (int kp = 3; kp >= 0; --kp) {
-          // unit u has landed (at most the copies of units u+1, u+2 may still fly), everybody is done with unit u-1
-          const int rem = total - 1 - u;
-          if (rem >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          else if (rem == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-          if (u + 3 < total) issue(u + 3);
-          const int8_t* ub = ring + (u & (PI8R_NSLOT - 1)) * PI8R_UNIT;
-          v16i acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0;
-#pragma unroll
-          for (int hl = 1; hl >= 0; --hl) {
-#pragma unroll
-            for (int t = 0; t < PI8_KHALF / 32; ++t) {
-              const v4i af = *reinterpret_cast<const v4i*>(ub + hl * 16384 + xoff[t & 7] + (t >> 3) * 256);
-              acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[t], acc, 0, 0, 0);
-            }
-            if (hl == 1) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) acc[r] *= 128;
-            }
-          }
-          const double* wrow = scl + (set * 4 + kp) * PI8_ROWS + tile * 32 + 4 * kb;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) out[tile][r] = fma((double)acc[r], wrow[(r & 3) + 8 * (r >> 2)], out[tile][r]);
-          ++u;
-        }
-      }
-    }
-  }
-  // ---- epilogue per row tile (pi8_epilogue); the ring's LDS carries the per-wave sums once everybody is done with the last unit ----
-#pragma unroll
-  for (int tile = 0; tile < 2; ++tile) {
-    if (tile >= ntile) break;
-    __syncthreads();
-    pi8_epilogue(a, tile, nrow, blk, s, p0, pos, wave, c, kb, out[tile], scb, srow_w, srow_p, reinterpret_cast<double*>(ring), sred);
-  }
-  __syncthreads();
-  if (threadIdx.x < nrow * 2) {
-    const int m = threadIdx.x >> 1, q = threadIdx.x & 1;
-    const int pl = m / R0, rr = m % R0;
-    double tsum = 0.0;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) tsum += sred[w][m][q];
-    a.psum[((((int64_t)blk * ct.n + ch) * a.P + p0 + pl) * 8 + rr) * 2 + q] = tsum;
-  }
-}
-
 // planes: nblk * nseg * ngrp * 2 * 8 * 64 * n128 bytes; psc: nblk * nseg * ngrp * 2 * 64 doubles; pkT: nblk * Np * n128 / 4 bytes
 void rg_launch_l0_pred_i8(hipStream_t st, const PredArgs& a, const ChunkTab& c256, int pg, int ngrp, int8_t* planes, double* psc,
                           uint8_t* pkT) {
@@ -486,13 +330,7 @@ void rg_launch_l0_pred_i8(hipStream_t st, const PredArgs& a, const ChunkTab& c25
   hipLaunchKernelGGL(k_beta_split, dim3(PI8_ROWS, a.nseg * ngrp, a.nblk), dim3(256), 0, st, a, pg, ngrp, planes, psc);
   const size_t lds = (size_t)PI8_NPIECE * PI8_PLANE + sizeof(double) * 8 * PI8_ROWS * 2;     // 135,168 + 8,192 bytes
   // more than 64 KB of dynamic LDS needs the attribute; set per launch (it is per device, and a process may drive several)
-  static const bool staged = getenv("RG_PRED_STAGED") && atoi(getenv("RG_PRED_STAGED")) != 0;   // keeps the register-staged form
-  if (a.n128 % PI8_KHALF == 0 && !staged) {
-    const size_t ldr = (size_t)PI8R_NSLOT * PI8R_UNIT + sizeof(double) * 8 * PI8_ROWS * 2 + sizeof(double) * 2 * 4 * PI8_ROWS;   // 131,072 + 8,192 + 4,096 bytes
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_l0_pred_i8_ring<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldr);
-    hipLaunchKernelGGL(k_l0_pred_i8_ring<0>, dim3(c256.n, ngrp, a.nblk), dim3(512), ldr, st, a, c256, pg, ngrp, (const int8_t*)planes,
-                       (const double*)psc, (const uint8_t*)pkT);
-  } else if (a.n128 % PI8_KHALF == 0) {
+  if (a.n128 % PI8_KHALF == 0) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_l0_pred_i8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_l0_pred_i8<true>, dim3(c256.n, ngrp, a.nblk), dim3(512), lds, st, a, c256, pg, ngrp, (const int8_t*)planes,
                        (const double*)psc, (const uint8_t*)pkT);
