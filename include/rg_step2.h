@@ -113,6 +113,64 @@ int rg_s2_contract_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs
  * entries number >= n_samples * prop_zero_thr (.pgen input, which counts n_zero while reading, Geno.cpp:2582-2594). */
 int rg_s2_set_sparse_rule(rg_s2_ctx* ctx, int64_t n_samples, double prop_zero_thr, int32_t zero_count_rule);
 
+/* ---- binary and count traits: the score test and its corrections ---------------------------------------------------
+ * What it replaces in the reference (`regenie --step 2 --bt [--firth --approx | --spa]`, `--ct`):
+ *   rg_s2_bt_set_null     what compute_res_bin / compute_res_count leave per chromosome (Data.cpp:2439-2455): the fitted mean of the null
+ *                         model with the LOCO prediction as offset (fit_null_logistic / fit_null_poisson, Step1_Models.cpp:54-140, :225-288 --
+ *                         the caller fits it: a C-parameter IRLS), from which the library forms Gamma_sqrt^2 = w, the weighted covariates
+ *                         and (X^T W X)^-1; firth_offset = LOCO prediction + X beta of the null Firth model (fit_null_firth,
+ *                         Step2_Models.cpp:985-1060), needed by the approximate Firth correction only
+ *   rg_s2_bt_score_packed compute_score_bt / compute_score_ct + get_sumstats for a block of hard calls (Step2_Models.cpp:471-622, :2031-2041):
+ *   rg_s2_bt_score_int    z = g~ . (y - p^) / sqrt(denum), denum = sum w g~^2 - (X^T W g~)^T (X^T W X)^-1 (X^T W g~), BETA = z / sqrt(denum);
+ *                         the same for integer dosages.  The contractions run on the i8 matrix cores (rg_s2_contract_*), the C x C
+ *                         algebra per (variant, trait) on the host inside the library.  The block stays on the device for ...
+ *   rg_s2_bt_correct      check_pval_snp's second look at the tests the caller flags (|z| above its threshold, Step2_Models.cpp:1987-2029):
+ *                         RG_S2_BT_FIRTH_APPROX = fit_firth_logistic_snp_fast (:1158-1253), RG_S2_BT_SPA = run_SPA_test_snp (:2072-2297).
+ *                         One workgroup per (variant, trait) pair iterates on the device; fast[t] != 0 selects the reference's carriers-only
+ *                         form (sparse variants: check_sparse_G's verdict is returned by the score call; Firth adds MAC < 50).
+ * Layouts as above: [P][n] / [C][n] sample-fastest host arrays.  The exact Firth test (--firth without --approx) is not behind this ABI. */
+typedef struct rg_s2_bt_null {
+  int32_t family;             /* 0: binary trait (logistic null model), 1: count trait (Poisson; no corrections) */
+  int32_t reserved;
+  const double* X;            /* [C][n] covariates (new_cov) */
+  const double* y;            /* [P][n] raw phenotype */
+  const uint8_t* mask;        /* [P][n] masked_indivs */
+  const double* fitted;       /* [P][n] fitted mean of the null model (probability / rate) */
+  const double* firth_offset; /* [P][n] or NULL */
+  const uint8_t* pass;        /* [P] or NULL: 0 = the null model of the trait failed, its tests come back as ignored */
+} rg_s2_bt_null;
+int rg_s2_bt_set_null(rg_s2_ctx* ctx, const rg_s2_bt_null* null_model);
+
+typedef struct rg_s2_bt_out {   /* HOST pointers, each may be NULL */
+  double* stats;          /* [bs][P] z (0 for an ignored test) */
+  double* bhat;           /* [bs][P] z / sqrt(denum) */
+  double* denum;          /* [bs][P] */
+  uint8_t* test_ignored;  /* [bs][P] 1: failed null model, or denum below numtol (Step2_Models.cpp:512-517, :596) */
+  double* mean;           /* [bs] mean of the observed entries (the imputed value) */
+  int32_t* ignored;       /* [bs] 1: nothing observed */
+  uint8_t* sparse;        /* [bs] check_sparse_G's verdict (rg_s2_set_sparse_rule) */
+  int32_t* counts;        /* [bs][4] hard calls: calls equal to 1, equal to 2, missing, 0 */
+  double* vstat;          /* [bs][4] integer dosages: sum (units of 1 / scale), sum of squares, observed, observed non-zero */
+  double* total_p;        /* [bs][P] hard calls: the trait's allele count minus the variant's (update_trait_counts, Geno.cpp:2948-2959) */
+  int32_t* n_obs_p;       /* [bs][P] hard calls: the trait's observed-sample count minus the variant's */
+} rg_s2_bt_out;
+int rg_s2_bt_score_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32_t bs, int32_t rows_on_device, int32_t flip, double numtol,
+                          const rg_s2_bt_out* out);
+int rg_s2_bt_score_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs, int32_t g_on_device, int32_t scale, double numtol,
+                       const rg_s2_bt_out* out);
+
+#define RG_S2_BT_FIRTH_APPROX 1
+#define RG_S2_BT_SPA 2
+typedef struct rg_s2_bt_corr {
+  double beta, se, chisq;
+  double logp;     /* SPA: -log10 of the saddlepoint p-value; Firth: -1 (the caller takes the p-value of chisq = the likelihood ratio) */
+  int32_t fail;    /* 1: TEST_FAIL (no convergence, statistic outside the range K' can reach, ...) */
+  int32_t reserved;
+} rg_s2_bt_corr;
+/* Corrections of npair tests of the block LAST scored: (variant[t], trait[t]) = (row of the block, trait).  firth_se != 0: --firth-se. */
+int rg_s2_bt_correct(rg_s2_ctx* ctx, int32_t kind, int32_t npair, const int32_t* variant, const int32_t* trait, const uint8_t* fast, int32_t firth_se,
+                     rg_s2_bt_corr* out);
+
 /* Device time of the kernels of the last rg_s2_qt_block / rg_s2_qt_block_packed call (hipEvents on the library's stream), in ms. */
 double rg_s2_last_kernel_ms(const rg_s2_ctx* ctx);
 

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librg_step1_hip.so")
-SOURCES = ["rg_api.hip", "bed_prep.hip", "gram_i8.hip", "gram_fp4.hip", "assemble.hip", "chol.hip", "pred.hip", "l1.hip", "ubench.hip", "loocv.hip", "l1x.hip", "l0_f64.hip", "step2_qt.hip", "rg_group.hip", "pred_i8.hip", "xy_i8.hip",
+SOURCES = ["rg_api.hip", "bed_prep.hip", "gram_i8.hip", "gram_fp4.hip", "assemble.hip", "chol.hip", "pred.hip", "l1.hip", "ubench.hip", "loocv.hip", "l1x.hip", "l0_f64.hip", "step2_qt.hip", "step2_bt.hip", "rg_group.hip", "pred_i8.hip", "xy_i8.hip",
            "pgen_api.cpp", "bgen_api.cpp"]  # host-only: .pgen input (include/rg_pgen.h), BGEN v1.2 input (include/rg_bgen.h)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result", "-Wno-inline-asm"]
@@ -40,6 +40,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "host", "rg_step1_main.cpp"),
                                                       os.path.join(CSRC, "rg_internal.h"),
+                                                      os.path.join(CSRC, "step2_internal.h"),
                                                       os.path.join(CSRC, "pgen_reader.h"),
                                                       os.path.join(CSRC, "bgen_reader.h"),
                                                       os.path.join(HERE, "..", "include", "rg_bgen.h"),

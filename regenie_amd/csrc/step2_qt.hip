@@ -25,8 +25,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/rg_step2.h"
-#include "rg_internal.h"
+#include "step2_internal.h"
 
 // Hard calls (rg_s2_qt_block_packed): the same statistic from the 2-bit rows, exactly, on the i8 matrix cores.  The statistic needs
 // nothing but genotype COUNTS and CONTRACTIONS of the genotype row with columns that are fixed per chromosome:
@@ -725,71 +724,9 @@ __global__ __launch_bounds__(256) void k_s2_masked_int(const uint16_t* __restric
 
 }  // namespace
 
-struct rg_s2_ctx {
-  int dev = 0;
-  int64_t n = 0;
-  int C = 0, P = 0;
-  bool have_null = false;
-  hipStream_t st = nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  double *dX = nullptr, *dY = nullptr, *dscf = nullptr;
-  uint8_t* dM = nullptr;
-  void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int vpb = DEFAULT_VPB, ept = DEFAULT_EPT;   // tile of the two streaming kernels (resolved in rg_s2_create)
-  double last_ms = 0.0;
-  // hard-call route (rg_s2_qt_block_packed): built lazily after rg_s2_set_null
-  bool complete = false;        // every mask byte is 1
-  bool static_ready = false;    // planes of the columns that depend on X and the masks only
-  bool planes_mask_cols = false;   // the planes include the x_c mask_p / mask_p columns
-  bool res_ready = false;       // planes of the res columns, res^T X
-  std::vector<double> hX;       // host copies of the last X / mask (the planes are kept while they do not change)
-  std::vector<uint8_t> hM;
-  int64_t Np = 0;               // samples padded to a multiple of 128 * 32
-  int Cvt = 0, cm0 = 0;         // columns in all, first mask column (a multiple of 16); complete problems: Cvt = cm0 = C + P
-  int64_t rule_n = 0;           // check_sparse_G: params.n_samples (0 = the analysed samples)
-  double rule_thr = 0.5;        // params.prop_zero_thr
-  int rule_zero_count = 0;      // 1: the .pgen form of the rule (observed zeros >= n_samples * thr)
-  double* dV = nullptr;         // [Cvt (padded to 16)][Np]  X | res | x_c mask_p | 0 | mask_p, zero padded
-  int8_t* dvd = nullptr;        // the digit planes of dV's columns, [col][8][Np]
-  double *dvsc = nullptr, *dYtX = nullptr;   // [col] plane scales, [P][C] res_p^T x_c
-  double *dQ = nullptr, *dMsum = nullptr;    // [P][C][C] X^T diag(mask_p) X, [P] sum of mask_p
-  // generic contraction (rg_s2_set_columns / rg_s2_contract_packed): caller-defined columns
-  int g_ncol = 0, g_nsq = 0;
-  double* gV = nullptr;         // [ncol padded to 16][Np]
-  int8_t* gvd = nullptr;
-  double* gvsc = nullptr;
-  // dosage route (rg_s2_qt_block), masked problems: per phenotype the samples masked for it
-  bool lists_ready = false;
-  int32_t* d_mlist = nullptr;
-  int64_t* d_moff = nullptr;    // [P + 1]
-  double* d_xl = nullptr;       // [list entries][C]: the listed samples' covariate rows
-  void* pbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t pcap[6] = {0, 0, 0, 0, 0, 0};
-  int32_t hdr[3] = {0, 0, 0};   // staged {total_miss = 0, bs, 0} of the block in flight
-  std::string err;
-};
-
 namespace {
-int fail(rg_s2_ctx* ctx, int code, const std::string& msg) {
-  if (ctx) ctx->err = msg;
-  return code;
-}
-#define S2_HIP(call)                                                                                         \
-  do {                                                                                                       \
-    hipError_t e_ = (call);                                                                                  \
-    if (e_ != hipSuccess) return fail(ctx, RG_S2_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
-  } while (0)
-
-int ensure_in(rg_s2_ctx* ctx, void** buf, size_t* cap, int slot, size_t bytes) {
-  if (cap[slot] >= bytes) return RG_S2_OK;
-  if (buf[slot]) S2_HIP(hipFree(buf[slot]));
-  buf[slot] = nullptr;
-  cap[slot] = 0;
-  S2_HIP(hipMalloc(&buf[slot], bytes));
-  cap[slot] = bytes;
-  return RG_S2_OK;
-}
+int fail(rg_s2_ctx* ctx, int code, const std::string& msg) { return rg_s2_fail(ctx, code, msg); }
+int ensure_in(rg_s2_ctx* ctx, void** buf, size_t* cap, int slot, size_t bytes) { return rg_s2_ensure_in(ctx, buf, cap, slot, bytes); }
 // The sample axis (Np, a multiple of 128 * 32) is cut into nseg equal segments, one workgroup per (row tile, segment, column group, set):
 // enough workgroups to fill the 256 CUs (>= 768), as few segments as that allows -- every segment costs a 64 KB tile of partial sums.
 int pick_segments(int64_t Np, int tiles, int ngrp, SegLayout& seg) {
@@ -952,6 +889,7 @@ void rg_s2_destroy(rg_s2_ctx* ctx) {
     if (ctx->dY) (void)hipFree(ctx->dY);
     if (ctx->dM) (void)hipFree(ctx->dM);
     if (ctx->dscf) (void)hipFree(ctx->dscf);
+    rg_s2_bt_free(ctx);
     if (ctx->e0) (void)hipEventDestroy(ctx->e0);
     if (ctx->e1) (void)hipEventDestroy(ctx->e1);
     (void)hipStreamDestroy(ctx->st);

@@ -61,7 +61,7 @@ EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_set
            "rg_bgen_open", "rg_bgen_close", "rg_bgen_last_error", "rg_bgen_info", "rg_bgen_sample_id", "rg_bgen_variant",
            "rg_bgen_set_threads", "rg_bgen_read_dosages", "rg_bgen_read_dosages_info",
            # include/rg_step2.h (Step-2 QT score test; wrapped by regenie_amd/step2.py)
-           "rg_s2_create", "rg_s2_destroy", "rg_s2_last_error", "rg_s2_set_null", "rg_s2_qt_block", "rg_s2_qt_block_packed", "rg_s2_qt_block_int", "rg_s2_set_sparse_rule", "rg_s2_set_columns", "rg_s2_contract_packed", "rg_s2_contract_int",
+           "rg_s2_create", "rg_s2_destroy", "rg_s2_last_error", "rg_s2_set_null", "rg_s2_qt_block", "rg_s2_qt_block_packed", "rg_s2_qt_block_int", "rg_s2_set_sparse_rule", "rg_s2_set_columns", "rg_s2_contract_packed", "rg_s2_contract_int", "rg_s2_bt_set_null", "rg_s2_bt_score_packed", "rg_s2_bt_score_int", "rg_s2_bt_correct",
            "rg_s2_last_kernel_ms"]
 
 
@@ -150,6 +150,10 @@ def load_library() -> C.CDLL:
     lib.rg_s2_set_columns.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
     lib.rg_s2_contract_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
     lib.rg_s2_contract_int.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.rg_s2_bt_set_null.argtypes = [C.c_void_p, C.c_void_p]
+    lib.rg_s2_bt_score_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p]
+    lib.rg_s2_bt_score_int.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_void_p]
+    lib.rg_s2_bt_correct.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     lib.rg_s2_last_kernel_ms.argtypes = [C.c_void_p]
     lib.rg_s2_last_kernel_ms.restype = C.c_double
     lib.rg_bgen_open.argtypes = [C.POINTER(C.c_void_p), C.c_char_p]

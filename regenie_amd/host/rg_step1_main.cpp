@@ -1375,7 +1375,8 @@ double get_logp(double t) {
 // 2410-2530).  Device side (include/rg_step2.h): every per-variant O(n) contraction -- the QT statistic whole (hard calls: 2-bit rows;
 // dosages: uint16 rows; both on the i8 matrix cores), the sums the binary / count trait score tests are functions of.  Phenotypes may
 // differ in their missing values: the library makes check_sparse_G's per-variant choice between the sparse and the dense branch of
-// compute_score_qt.  The approximate Firth refits of the flagged binary-trait tests run on host threads.
+// compute_score_qt.  The binary-trait score test and its approximate-Firth / saddlepoint corrections are library calls too (rg_s2_bt_*);
+// the null models (C parameters) and the exact Firth test of flagged variants (C + 1 parameters) are fitted on the host.
 
 // ---- approximate Firth correction of the binary-trait test (--firth --approx) ---------------------------------------------------------
 // regenie reaches the maximisers below through a chain of solvers and fall-backs (fit_firth_nr, the pseudo-data IRLS of fit_firth_pseudo,
@@ -1484,107 +1485,8 @@ bool firth_null_fit(const double* y, const double* X, const uint8_t* mask, const
   return firth_fit_cols(y, cols, mask, offset, n, C, 25.0, beta);      // maxstep_null
 }
 
-// fit_firth_logistic_snp_fast with its one-parameter solvers (Step2_Models.cpp:1158-1253, :1548-1737): the variant's effect with the covariate
-// effects of the null Firth model in the offset; penalty 0.5 log(sum G^2 w).  idx / m: the samples that enter score, information and penalty
-// (every unmasked sample, or the carriers alone in the reference's fast form for sparse variants with MAC < 50); dev_rest: the deviance of
-// the samples left out (it does not depend on beta: their G is taken as 0).  false = TEST_FAIL.
-bool firth_snp_fit(const std::vector<double>& g, const std::vector<double>& y, const std::vector<double>& o, double dev_rest, double& beta, double& se, double& lrt) {
-  const size_t m = g.size();
-  std::vector<double> pv(m), w(m);
-  auto state = [&](double b, double& xtwx, double& dev) {
-    double ll = 0.0;
-    xtwx = 0.0;
-    for (size_t i = 0; i < m; ++i) {
-      const double pr = get_pvec1(o[i] + g[i] * b);
-      pv[i] = pr; w[i] = pr * (1.0 - pr);
-      ll -= (y[i] == 0.0) ? std::log(1.0 - pr) : std::log(pr);
-      xtwx += g[i] * g[i] * w[i];
-    }
-    dev = 2.0 * ll - std::log(xtwx);      // (dev_rest, the deviance of the samples left out, is a constant: it cancels in the LRT)
-  };
-  double xtwx, dev, dev0;
-  state(0.0, xtwx, dev0);
-  dev = dev0;
-  beta = 0.0;
-  bool conv = false;
-  for (int it = 0; it < 500; ++it) {
-    double score = 0.0;
-    for (size_t i = 0; i < m; ++i) score += g[i] * (y[i] - pv[i] + g[i] * g[i] * w[i] / xtwx * (0.5 - pv[i]));
-    double step = score / xtwx;
-    if (std::fabs(step) < 1e-9) { conv = true; break; }      // below that the deviance comparisons of the step halving are rounding noise
-    if (std::fabs(step) > 5.0) step = step > 0 ? 5.0 : -5.0;      // maxstep
-    double x_n = xtwx, dev_n = dev;
-    bool ok = false;
-    for (int hs = 0; hs < 60; ++hs) {
-      state(beta + step, x_n, dev_n);
-      if (dev_n <= dev || std::fabs(step) < 1e-6) { ok = true; break; }      // steps that small change the deviance by less than its rounding
-      step /= 2.0;
-    }
-    if (!ok) { state(beta, xtwx, dev); conv = std::fabs(score / xtwx) < 1e-6; break; }    // flat to rounding: the root is reached
-    beta += step; xtwx = x_n; dev = dev_n;
-  }
-  if (!conv) return false;
-  lrt = dev0 - dev;
-  if (lrt < 0) return false;
-  se = std::sqrt(1.0 / xtwx);
-  return true;
-}
-
-// ---- saddlepoint approximation of the binary-trait test (--spa): run_SPA_test_snp and its helpers (Step2_Models.cpp:2072-2297) -------------
-// The two-sided p-value of the score statistic from the Lugannani-Rice formula, cumulant generating function K of sum_i gm_i (Y_i - p_i) / c.
-// gm / ph / gs: Gmod = Gres / Gamma_sqrt, the fitted probabilities and Gamma_sqrt of the samples that enter the exact terms (every unmasked
-// sample, or the carriers in regenie's fast form, whose other samples enter through the normal approximation b, d); a = sum gm p over every
-// unmasked sample; lo / hi: the range K' can reach.  regenie stops its Newton iteration at |K'(t) - s| < eps^(1/4) = 1.2e-4, so the iteration is
-// restated step for step (an exact root differs in the 4th digit of the p-value).  false = TEST_FAIL.
-bool spa_pvalue(double stats, double denum, const std::vector<double>& gm, const std::vector<double>& ph, const std::vector<double>& gs, double a, bool fast,
-                double b, double d, double lo, double hi, double& pval_out) {
-  const double c = std::sqrt(denum), tol = std::pow(2.220446049250313e-16, 0.25);
-  const size_t m = gm.size();
-  if (stats * c < lo || stats * c > hi) return false;
-  auto K = [&](double t) { double v = 0.0; for (size_t i = 0; i < m; ++i) v += std::log(1.0 - ph[i] + ph[i] * std::exp(t / c * gm[i])); return v + (fast ? -t * d / c + t * t / 2.0 / denum * b : -t * a / c); };
-  auto K1 = [&](double t) { double v = 0.0; for (size_t i = 0; i < m; ++i) v += (gm[i] * ph[i] / c) / (ph[i] + (1.0 - ph[i]) * std::exp(-t / c * gm[i])); return v + (fast ? -d / c + t / denum * b : -a / c); };
-  auto K2 = [&](double t) {
-    double v = 0.0;
-    for (size_t i = 0; i < m; ++i) {
-      const double vexp = -t / c * gm[i];
-      if (vexp > 708.0) return 0.0;                                    // MAX_EXP_LIM
-      const double e = std::exp(vexp), den = ph[i] + (1.0 - ph[i]) * e;
-      v += (gm[i] * gm[i] * gs[i] * gs[i] / (c * c) * e) / (den * den);
-    }
-    return v + (fast ? b / denum : 0.0);
-  };
-  const double tval = stats >= 0 ? -stats : stats;
-  double pv = 0.0;
-  for (int lam = 1; lam >= -1; lam -= 2) {
-    // solve_K1_snp: Newton with a bisection safeguard
-    double min_x = tval >= 0 ? 0.0 : std::numeric_limits<double>::lowest(), max_x = tval >= 0 ? std::numeric_limits<double>::max() : 0.0;
-    double t_old = 0.0, f_old = lam * K1(lam * t_old) - tval, t_new = -1.0, f_new;
-    bool conv = false;
-    for (int it = 0; it < 1000; ++it) {
-      const double hess = K2(lam * t_old);
-      if (hess == 0.0) return false;
-      t_new = t_old - f_old / hess;
-      f_new = lam * K1(lam * t_new) - tval;
-      if (std::fabs(f_new) < tol) { conv = true; break; }
-      if (t_new != 0.0 && t_new > min_x && t_new < max_x) { if (f_new > 0) max_x = t_new; else min_x = t_new; }
-      else {
-        t_new = (min_x + max_x) / 2.0;
-        f_new = lam * K1(lam * t_new) - tval;
-        if (f_new <= 0) min_x = t_new; else max_x = t_new;
-      }
-      t_old = t_new; f_old = f_new;
-    }
-    if (!conv) return false;
-    const double root = t_new, kval = K(lam * root), k2val = K2(lam * root);
-    if (k2val == 0.0) return false;
-    const double wval = (root > 0 ? 1.0 : root < 0 ? -1.0 : 0.0) * std::sqrt(2.0 * (root * tval - kval)), vval = root * std::sqrt(k2val);
-    if (vval == 0.0) pv += 0.5;
-    else { const double rval = wval + std::log(vval / wval) / wval; pv += 0.5 * std::erfc(-rval / std::sqrt(2.0)); }
-  }
-  if (!(pv <= 1.0)) return false;
-  pval_out = pv;
-  return true;
-}
+// The per-variant corrections -- fit_firth_logistic_snp_fast (Step2_Models.cpp:1158-1253) and run_SPA_test_snp (:2072-2297) -- run on the
+// device behind the C ABI (rg_s2_bt_correct, regenie_amd/csrc/step2_bt.hip).
 
 int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   const Params& p = r.p;
@@ -1609,8 +1511,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   // binary traits (compute_res_bin, Data.cpp:2439-2445; compute_score_bt, Step2_Models.cpp:471-552): per chromosome the null logistic
   // model with the LOCO offset gives p^, w = p^ (1 - p^); the score test of a variant needs, per trait, sum w g~^2, X^T W g~ and
   // g~ . (y - p^) -- contractions of the hard-call row with fixed columns, which rg_s2_contract_packed evaluates on the i8 matrix cores
-  const int bt_ncol = P * (C + 3);        // [w_q] (P, also against g^2) | [w_q x_c] (P * C) | [y_q - p^_q] (P) | [mask_q] (P)
-  std::vector<double> bt_cols, bt_xwx_inv, bt_sums, bt_sq, bt_vstat;
+  std::vector<double> bt_fit, bt_vstat;
   std::vector<int32_t> bt_counts;
   std::vector<uint8_t> bt_pass(P, 1), test_ignored;
   const bool firth = p.bt && p.firth, spa = p.bt && p.spa, correct = firth || spa;
@@ -1619,12 +1520,10 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   if (firth) firth_off.assign((size_t)P * n, 0.0);
   std::vector<double> firth_bnull((size_t)P * C, 0.0), blup_off;      // exact Firth: the covariate-only estimates (start values), the LOCO offsets
   if (firth && !p.firth_approx) blup_off.assign((size_t)P * n, 0.0);
-  std::vector<double> bt_phat;                        // [P][n] the null model's fitted probabilities (--spa)
-  if (spa) bt_phat.assign((size_t)P * n, 0.5);
   std::vector<double> denum_v;                        // per (variant, trait): the score test's denominator
   std::vector<uint8_t> corrected, corr_fail;          // per (variant, trait) of a block
   std::vector<double> corr_beta, corr_se, corr_chisq, corr_logp;
-  if (glm) { bt_cols.assign((size_t)bt_ncol * n, 0.0); bt_xwx_inv.assign((size_t)P * C * C, 0.0); }
+  if (glm) bt_fit.assign((size_t)P * n, 0.5);
 
   rg_s2_ctx* s2 = nullptr;
   if (rg_s2_create(&s2, p.device, n, C, P) != RG_S2_OK || !s2) throw std::runtime_error("no MI355X / HIP device available (rg_s2_create failed)");
@@ -1767,28 +1666,8 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
         }
         bt_pass[q] = ok ? 1 : 0;
         if (!ok) { if (!(firth && !bnull.empty())) sout << "\n     WARNING: " << (p.ct ? "poisson" : "logistic") << " regression did not converge for phenotype '" << r.pheno_names[q] << "'."; continue; }
-        std::vector<double> A((size_t)C * C, 0.0);
-        double* cw = bt_cols.data() + (size_t)q * n;
-        double* cr = bt_cols.data() + (size_t)(P + P * C + q) * n;
-        double* cm = bt_cols.data() + (size_t)(P + P * C + P + q) * n;
-        for (int64_t k = 0; k < n; ++k) {
-          const double m = mq[k] ? 1.0 : 0.0;
-          const double w = (p.ct ? pv[k] : pv[k] * (1.0 - pv[k])) * m;          // Gamma_sqrt^2 on the unmasked samples: p (1 - p) (get_wvec) or the Poisson rate
-          cw[k] = w; cr[k] = (yq[k] - pv[k]) * m; cm[k] = m;
-          if (spa) bt_phat[(size_t)q * n + k] = pv[k];
-          for (int a = 0; a < C; ++a) {
-            const double xa = Xc[(size_t)a * n + k] * w;
-            bt_cols[(size_t)(P + q * C + a) * n + k] = xa;
-            for (int c = 0; c < C; ++c) A[(size_t)a * C + c] += xa * Xc[(size_t)c * n + k];
-          }
-        }
-        // (X^T W X)^-1: the projector of getBasis(Gamma X) (Step1_Models.cpp:132-133) written out
-        std::vector<double> e(C), col;
-        for (int c = 0; c < C; ++c) {
-          std::fill(e.begin(), e.end(), 0.0); e[c] = 1.0;
-          if (!solve_dense(A, e, C, col)) throw std::runtime_error("X'WX is singular in the null logistic model of phenotype '" + r.pheno_names[q] + "'.");
-          for (int a = 0; a < C; ++a) bt_xwx_inv[((size_t)q * C + a) * C + c] = col[a];
-        }
+        // the fitted mean of the null model: the library forms Gamma_sqrt^2, the weighted covariates and (X^T W X)^-1 from it (rg_s2_bt_set_null)
+        for (int64_t k = 0; k < n; ++k) bt_fit[(size_t)q * n + k] = pv[k];
         continue;
       }
       double ss = 0.0;
@@ -1801,8 +1680,13 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       for (int64_t k = 0; k < n; ++k) resc[(size_t)q * n + k] /= sd;
       scf[q] = r.scale_Y[q] * sd;
     }
-    if (glm) s2check(rg_s2_set_columns(s2, bt_ncol, bt_cols.data(), P));
-    else s2check(rg_s2_set_null(s2, Xc.data(), resc.data(), Mc.data(), scf.data()));
+    if (glm) {   // compute_res_bin / compute_res_count (Data.cpp:2439-2455): the null models of the chromosome go to the device
+      rg_s2_bt_null nm;
+      memset(&nm, 0, sizeof(nm));
+      nm.family = p.ct ? 1 : 0; nm.X = Xc.data(); nm.y = Yc.data(); nm.mask = Mc.data(); nm.fitted = bt_fit.data();
+      nm.firth_offset = (firth && p.firth_approx) ? firth_off.data() : nullptr; nm.pass = bt_pass.data();
+      s2check(rg_s2_bt_set_null(s2, &nm));
+    } else s2check(rg_s2_set_null(s2, Xc.data(), resc.data(), Mc.data(), scf.data()));
     sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tb).count() << "ms) \n";
 
     for (int bb = 0; bb < nb_chr; ++bb, ++block) {
@@ -1893,17 +1777,23 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       std::vector<double> af_d; std::vector<int64_t> ns_d;
       if (glm && in == In::Dosage) { af_d = af_t; ns_d = ns_t; }
       if (glm) {
-        // the contractions of the block: hard calls as packed rows, dosages as integer rows (digit planes on the i8 matrix cores either way)
-        bt_sums.resize((size_t)bs * 2 * bt_ncol); bt_sq.resize((size_t)bs * P); bt_counts.resize((size_t)bs * 4); bt_vstat.resize((size_t)bs * 4);
-        rg_s2_contract_out co;
-        memset(&co, 0, sizeof(co));
-        co.sums = bt_sums.data(); co.sq = bt_sq.data();
+        // the score test of the block through the C ABI (rg_s2_bt_score_*: contractions on the i8 matrix cores, C x C algebra in the library):
+        // hard calls as packed rows, dosages as integer rows
+        bt_counts.resize((size_t)bs * 4); bt_vstat.resize((size_t)bs * 4);
+        denum_v.assign((size_t)bs * P, 0.0);
+        std::vector<double> mu_v(bs, 0.0), totp((size_t)bs * P, 0.0);
+        std::vector<uint8_t> sparse_v(bs, 0);
+        std::vector<int32_t> nobsp((size_t)bs * P, 0);
+        rg_s2_bt_out bo;
+        memset(&bo, 0, sizeof(bo));
+        bo.stats = stats.data(); bo.bhat = bhat.data(); bo.denum = denum_v.data(); bo.test_ignored = test_ignored.data(); bo.mean = mu_v.data();
+        bo.ignored = ign.data(); bo.sparse = sparse_v.data();
         const uint8_t* src = rows.data();
         int64_t ld = r.bpr;
         if (in == In::Dosage) {
           if (!integral) throw std::runtime_error("--step 2 --bt / --ct on dosages that are not integer multiples of 1/" + std::to_string(dscale) + " is not built.");
-          co.vstat = bt_vstat.data();
-          s2check(rg_s2_contract_int(s2, G16.data(), n, bs, 0, dscale, &co));
+          bo.vstat = bt_vstat.data();
+          s2check(rg_s2_bt_score_int(s2, G16.data(), n, bs, 0, dscale, NUMTOL, &bo));
         } else {
           if (!identity) {
             ld = (n + 3) / 4;
@@ -1918,65 +1808,54 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
             });
             src = packed.data();
           }
-          co.counts = bt_counts.data();
-          s2check(rg_s2_contract_packed(s2, src, ld, bs, 0, flip, &co));
+          bo.counts = bt_counts.data(); bo.total_p = totp.data(); bo.n_obs_p = nobsp.data();
+          s2check(rg_s2_bt_score_packed(s2, src, ld, bs, 0, flip, NUMTOL, &bo));
         }
         af_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0);
-        std::vector<double> mu_v(bs, 0.0);
-        std::vector<uint8_t> sparse_v(bs, 0);
-        denum_v.assign((size_t)bs * P, 0.0);
-        parallel_for(bs, nthreads, [&](int j) {
-          double nobs, tot, nnz;        // observed samples, allele total, observed non-zero entries
-          if (in == In::Dosage) { nobs = bt_vstat[(size_t)j * 4 + 2]; tot = bt_vstat[(size_t)j * 4] / dscale; nnz = bt_vstat[(size_t)j * 4 + 3]; }
-          else {
+        for (int j = 0; j < bs; ++j) {
+          if (in != In::Dosage) {     // (dosages: the host loop above has them, summed as the reference sums)
             const double n1 = bt_counts[(size_t)j * 4], n2 = bt_counts[(size_t)j * 4 + 1], nm = bt_counts[(size_t)j * 4 + 2];
-            nobs = (double)n - nm; tot = n1 + 2.0 * n2; nnz = n1 + n2;
+            ns1[j] = (int64_t)((double)n - nm); total[j] = n1 + 2.0 * n2;
           }
-          const double mu = nobs > 0 ? tot / nobs : 0.0;
-          mu_v[j] = mu;
-          // check_sparse_G (Geno.cpp:3165-3177): the approximate Firth fit restricts rare sparse variants to their carriers
-          sparse_v[j] = r.pgen ? (nobs - nnz) >= 0.5 * N : (nnz + (mu != 0.0 ? (double)n - nobs : 0.0)) <= 0.5 * N;
-          if (in != In::Dosage) { ns1[j] = (int64_t)nobs; total[j] = tot; }   // (dosages: the host loop above has them, summed as the reference sums)
-          ign[j] = nobs > 0 ? 0 : 1; sfac[j] = 1.0;
+          sfac[j] = 1.0;
           if (std::min(total[j], 2.0 * ns1[j] - total[j]) < p.min_mac) variant_ignored[j] = 1;
-          const double* s0 = bt_sums.data() + (size_t)j * 2 * bt_ncol;
-          const double* s1 = s0 + bt_ncol;
           for (int q = 0; q < P; ++q) {
-            const int cm = P + P * C + P + q, cr = P + P * C + q;
-            if (in != In::Dosage) {                                                                  // per-trait allele and sample counts
-              af_t[(size_t)j * P + q] = std::nearbyint(s0[cm]) - tot;
-              ns_t[(size_t)j * P + q] = (int64_t)std::nearbyint(r.neff[q] - s1[cm]) - ns1[j];
-            } else {
-              af_t[(size_t)j * P + q] = af_d[(size_t)j * P + q];
-              ns_t[(size_t)j * P + q] = ns_d[(size_t)j * P + q];
-            }
-            if (!bt_pass[q]) { test_ignored[(size_t)j * P + q] = 1; continue; }
-            const double sw2 = bt_sq[(size_t)j * P + q] + mu * mu * s1[q];                          // sum w g~^2
-            double quad = 0.0;                                                                       // (X^T W g~)^T (X^T W X)^-1 (X^T W g~)
-            const double* inv = bt_xwx_inv.data() + (size_t)q * C * C;
-            for (int a = 0; a < C; ++a) {
-              const double ua = s0[P + q * C + a] + mu * s1[P + q * C + a];
-              double row = 0.0;
-              for (int c = 0; c < C; ++c) row += inv[(size_t)a * C + c] * (s0[P + q * C + c] + mu * s1[P + q * C + c]);
-              quad += ua * row;
-            }
-            const double denum = sw2 - quad, sd = std::sqrt(denum);
-            if (p.ct ? !(denum >= NUMTOL) : !(sd >= NUMTOL)) { test_ignored[(size_t)j * P + q] = 1; continue; }   // Step2_Models.cpp:512-517, :596
-            const double st = (s0[cr] + mu * s1[cr]) / sd;
-            denum_v[(size_t)j * P + q] = denum;
-            stats[(size_t)j * P + q] = st;
-            bhat[(size_t)j * P + q] = st / sd;                                                      // get_sumstats (Step2_Models.cpp:2031-2041)
+            af_t[(size_t)j * P + q] = in != In::Dosage ? totp[(size_t)j * P + q] : af_d[(size_t)j * P + q];      // per-trait allele and sample counts
+            ns_t[(size_t)j * P + q] = in != In::Dosage ? (int64_t)nobsp[(size_t)j * P + q] : ns_d[(size_t)j * P + q];
           }
-        });
+        }
         if (correct) {
-          // check_pval_snp (Step2_Models.cpp:1987-2029): |z| above the threshold -> run_SPA_test (--spa) or fit_firth_logistic_snp_fast on Gres / Gamma_sqrt with the
-          // null Firth model's covariate effects in the offset.  The few flagged (variant, trait) pairs are fitted on the host threads.
+          // check_pval_snp (Step2_Models.cpp:1987-2029): |z| above the threshold -> run_SPA_test (--spa) or fit_firth_logistic_snp_fast on Gres / Gamma_sqrt
+          // with the null Firth model's covariate effects in the offset.  The flagged (variant, trait) pairs are re-tested on the device, one
+          // workgroup per pair (rg_s2_bt_correct); the exact Firth test (--firth without --approx: a C + 1 parameter fit) stays on the host threads.
           corrected.assign((size_t)bs * P, 0); corr_fail.assign((size_t)bs * P, 0);
           corr_beta.assign((size_t)bs * P, 0.0); corr_se.assign((size_t)bs * P, 0.0); corr_chisq.assign((size_t)bs * P, 0.0); corr_logp.assign((size_t)bs * P, -1.0);
           std::vector<int> todo;
           for (int j = 0; j < bs; ++j)
             for (int q = 0; q < P; ++q)
               if (!variant_ignored[j] && !ign[j] && !test_ignored[(size_t)j * P + q] && std::fabs(stats[(size_t)j * P + q]) > z_thr) todo.push_back(j * P + q);
+          if (spa || p.firth_approx) {
+            std::vector<int32_t> pv_(todo.size()), pt_(todo.size());
+            std::vector<uint8_t> pf_(todo.size());
+            for (size_t t = 0; t < todo.size(); ++t) {
+              const int j = todo[t] / P, q = todo[t] % P;
+              pv_[t] = j; pt_[t] = q;
+              if (spa) pf_[t] = sparse_v[j];                                                            // fastSPA (Step2_Models.cpp:2087-2097)
+              else {
+                const double tq = total[j] + af_t[(size_t)j * P + q];
+                const double nsq = (double)(ns1[j] + ns_t[(size_t)j * P + q]);
+                pf_[t] = sparse_v[j] && std::min(tq, 2.0 * nsq - tq) < 50.0;                            // fit_firth_logistic_snp_fast :1173-1185: carriers only
+              }
+            }
+            std::vector<rg_s2_bt_corr> cr(todo.size());
+            s2check(rg_s2_bt_correct(s2, spa ? RG_S2_BT_SPA : RG_S2_BT_FIRTH_APPROX, (int32_t)todo.size(), pv_.data(), pt_.data(), pf_.data(), p.firth_se ? 1 : 0, cr.data()));
+            for (size_t t = 0; t < todo.size(); ++t) {
+              const size_t e = (size_t)todo[t];
+              corrected[e] = 1;
+              if (cr[t].fail) { corr_fail[e] = 1; continue; }
+              corr_beta[e] = cr[t].beta; corr_se[e] = cr[t].se; corr_chisq[e] = cr[t].chisq; corr_logp[e] = cr[t].logp;
+            }
+          } else
           parallel_for((int)todo.size(), nthreads, [&](int t) {
             const int j = todo[t] / P, q = todo[t] % P;
             const double mu = mu_v[j];
@@ -1990,98 +1869,23 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
                 gt[k] = hc == -3.0 ? mu : hc;
               }
             }
-            if (spa) {
-              // Gmod = Gres / Gamma_sqrt = g~ - x^T (X^T W X)^-1 X^T W g~ on the unmasked samples; the carriers (non-zero entries of the mean-imputed
-              // genotype) alone enter the exact terms when the variant is sparse (fastSPA, Step2_Models.cpp:2087-2097)
-              const double* s0 = bt_sums.data() + (size_t)j * 2 * bt_ncol;
-              const double* s1 = s0 + bt_ncol;
-              const double* inv = bt_xwx_inv.data() + (size_t)q * C * C;
-              std::vector<double> tc(C, 0.0);
-              for (int a = 0; a < C; ++a)
-                for (int c = 0; c < C; ++c) tc[a] += inv[(size_t)a * C + c] * (s0[P + q * C + c] + mu * s1[P + q * C + c]);
-              const uint8_t* mq = Mc.data() + (size_t)q * n;
-              const double* pq = bt_phat.data() + (size_t)q * n;
-              const bool fast = sparse_v[j] != 0;
-              const double denum = denum_v[(size_t)j * P + q], st = stats[(size_t)j * P + q];
-              std::vector<double> gmv, phv, gsv;
-              double a_all = 0.0, lo = 0.0, hi = 0.0, b = denum, d = 0.0;
-              for (int64_t k = 0; k < n; ++k) {
-                if (!mq[k]) continue;
-                double v = gt[k];
-                for (int c = 0; c < C; ++c) v -= Xc[(size_t)c * n + k] * tc[c];
-                const double ph = pq[k], gs = std::sqrt(ph * (1.0 - ph));
-                a_all += v * ph;
-                if (v < 0) lo += v; else hi += v;
-                if (fast) {
-                  if (gt[k] == 0.0) continue;
-                  b -= v * gs * v * gs; d += v * ph;
-                }
-                gmv.push_back(v); phv.push_back(ph); gsv.push_back(gs);
-              }
-              corrected[(size_t)j * P + q] = 1;
-              double pval = 0.0;
-              if (!spa_pvalue(st, denum, gmv, phv, gsv, a_all, fast, b, d, lo - a_all, hi - a_all, pval)) { corr_fail[(size_t)j * P + q] = 1; return; }
-              pval = std::max(10.0 * std::numeric_limits<double>::min(), pval);          // get_logp(pv, logp, chisq, nl_dbl_dmin), Regenie.cpp:1859-1873
-              const double z = norm_quantile(0.5 * pval), chisq = z * z, se = 1.0 / std::sqrt(denum);
-              corr_chisq[(size_t)j * P + q] = chisq;
-              corr_se[(size_t)j * P + q] = se;                                            // check_pval_snp :2019-2020
-              corr_beta[(size_t)j * P + q] = (st > 0 ? 1.0 : st < 0 ? -1.0 : 0.0) * std::sqrt(chisq) * se;
-              corr_logp[(size_t)j * P + q] = -std::log10(pval);
-              return;
-            }
-            if (!p.firth_approx) {
-              // the exact test (fit_firth_logistic_snp, Step2_Models.cpp:1062-1156): design [covariates | g~ on its raw scale], offset = the LOCO
-              // prediction; null fit = the variant's coefficient held at 0 under the same penalty, then every coefficient free
-              const uint8_t* mq = Mc.data() + (size_t)q * n;
-              std::vector<const double*> cols(C + 1);
-              for (int c = 0; c < C; ++c) cols[c] = Xc.data() + (size_t)c * n;
-              cols[C] = gt.data();
-              std::vector<double> bf(C + 1, 0.0), inv;
-              for (int c = 0; c < C; ++c) bf[c] = firth_bnull[(size_t)q * C + c];
-              double dev0 = 0.0, dev1 = 0.0;
-              corrected[(size_t)j * P + q] = 1;
-              const bool okx = firth_fit_cols(Yc.data() + (size_t)q * n, cols, mq, blup_off.data() + (size_t)q * n, n, C, 25.0, bf, &dev0) &&
-                               firth_fit_cols(Yc.data() + (size_t)q * n, cols, mq, blup_off.data() + (size_t)q * n, n, C + 1, 5.0, bf, &dev1, &inv);
-              const double lrt = dev0 - dev1;
-              if (!okx || lrt < 0) { corr_fail[(size_t)j * P + q] = 1; return; }
-              corr_beta[(size_t)j * P + q] = bf[C];
-              corr_chisq[(size_t)j * P + q] = lrt;
-              corr_se[(size_t)j * P + q] = (p.firth_se && lrt > 0) ? std::fabs(bf[C]) / std::sqrt(lrt) : std::sqrt(inv[(size_t)C * (C + 1) + C]);
-              return;
-            }
-            // Gres / Gamma_sqrt = g~ - x^T (X^T W X)^-1 X^T W g~ on the unmasked samples (compute_score_bt :503, :528-531; :2061)
-            const double* s0 = bt_sums.data() + (size_t)j * 2 * bt_ncol;
-            const double* s1 = s0 + bt_ncol;
-            const double* inv = bt_xwx_inv.data() + (size_t)q * C * C;
-            std::vector<double> tc(C, 0.0);
-            for (int a = 0; a < C; ++a)
-              for (int c = 0; c < C; ++c) tc[a] += inv[(size_t)a * C + c] * (s0[P + q * C + c] + mu * s1[P + q * C + c]);
+            // the exact test (fit_firth_logistic_snp, Step2_Models.cpp:1062-1156): design [covariates | g~ on its raw scale], offset = the LOCO
+            // prediction; null fit = the variant's coefficient held at 0 under the same penalty, then every coefficient free
             const uint8_t* mq = Mc.data() + (size_t)q * n;
-            const double* yq = Yc.data() + (size_t)q * n;
-            const double* oq = firth_off.data() + (size_t)q * n;
-            const double tq = total[j] + af_t[(size_t)j * P + q];
-            const double nsq = (double)(ns1[j] + ns_t[(size_t)j * P + q]);
-            const bool fast = sparse_v[j] && std::min(tq, 2.0 * nsq - tq) < 50.0;        // fit_firth_logistic_snp_fast :1173-1185: carriers only
-            std::vector<double> gv, yv, ov;
-            double dev_rest = 0.0;
-            for (int64_t k = 0; k < n; ++k) {
-              if (!mq[k]) continue;
-              if (fast && !(gt[k] > 1e-4)) {           // a non-carrier: its G is dropped, its deviance is a constant
-                const double pr = get_pvec1(oq[k]);
-                dev_rest -= 2.0 * ((yq[k] == 0.0) ? std::log(1.0 - pr) : std::log(pr));
-                continue;
-              }
-              double v = gt[k];
-              for (int c = 0; c < C; ++c) v -= Xc[(size_t)c * n + k] * tc[c];
-              gv.push_back(v); yv.push_back(yq[k]); ov.push_back(oq[k]);
-            }
-            double b = 0.0, se = 0.0, lrt = 0.0;
-            const bool okf = !gv.empty() && firth_snp_fit(gv, yv, ov, dev_rest, b, se, lrt);
+            std::vector<const double*> cols(C + 1);
+            for (int c = 0; c < C; ++c) cols[c] = Xc.data() + (size_t)c * n;
+            cols[C] = gt.data();
+            std::vector<double> bf(C + 1, 0.0), inv;
+            for (int c = 0; c < C; ++c) bf[c] = firth_bnull[(size_t)q * C + c];
+            double dev0 = 0.0, dev1 = 0.0;
             corrected[(size_t)j * P + q] = 1;
-            if (!okf) { corr_fail[(size_t)j * P + q] = 1; return; }
-            corr_beta[(size_t)j * P + q] = b;
+            const bool okx = firth_fit_cols(Yc.data() + (size_t)q * n, cols, mq, blup_off.data() + (size_t)q * n, n, C, 25.0, bf, &dev0) &&
+                             firth_fit_cols(Yc.data() + (size_t)q * n, cols, mq, blup_off.data() + (size_t)q * n, n, C + 1, 5.0, bf, &dev1, &inv);
+            const double lrt = dev0 - dev1;
+            if (!okx || lrt < 0) { corr_fail[(size_t)j * P + q] = 1; return; }
+            corr_beta[(size_t)j * P + q] = bf[C];
             corr_chisq[(size_t)j * P + q] = lrt;
-            corr_se[(size_t)j * P + q] = (p.firth_se && lrt > 0) ? std::fabs(b) / std::sqrt(lrt) : se;     // --firth-se: back_correct_se (:2008-2009)
+            corr_se[(size_t)j * P + q] = (p.firth_se && lrt > 0) ? std::fabs(bf[C]) / std::sqrt(lrt) : std::sqrt(inv[(size_t)C * (C + 1) + C]);
           });
         }
       } else if (in == In::Dosage) {

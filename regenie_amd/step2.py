@@ -21,6 +21,24 @@ class _ContractOut(C.Structure):
     _fields_ = [("sums", C.c_void_p), ("sq", C.c_void_p), ("counts", C.c_void_p), ("vstat", C.c_void_p)]
 
 
+class _BtNull(C.Structure):
+    _fields_ = [("family", C.c_int32), ("reserved", C.c_int32), ("X", C.c_void_p), ("y", C.c_void_p), ("mask", C.c_void_p),
+                ("fitted", C.c_void_p), ("firth_offset", C.c_void_p), ("pass_", C.c_void_p)]
+
+
+class _BtOut(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("stats", "bhat", "denum", "test_ignored", "mean", "ignored", "sparse", "counts", "vstat",
+                                           "total_p", "n_obs_p")]
+
+
+class _BtCorr(C.Structure):
+    _fields_ = [("beta", C.c_double), ("se", C.c_double), ("chisq", C.c_double), ("logp", C.c_double), ("fail", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+BT_FIRTH_APPROX, BT_SPA = 1, 2
+
+
 class Step2QT:
     NUMTOL = 1e-6     # params.numtol, Regenie.hpp:220
 
@@ -163,3 +181,56 @@ class Step2QT:
         self._check(self.lib.rg_s2_contract_int(self.h, G.ctypes.data, G.shape[1], bs, 0, int(scale), C.byref(out)))
         res["kernel_ms"] = self.lib.rg_s2_last_kernel_ms(self.h)
         return res
+
+    # ---- binary / count traits behind the ABI (rg_s2_bt_*): score test, approximate Firth and saddlepoint corrections ------------------
+    def bt_set_null(self, X: np.ndarray, y: np.ndarray, mask: np.ndarray, fitted: np.ndarray, firth_offset=None, passed=None,
+                    family: int = 0) -> None:
+        """X [C][n], y / mask / fitted / firth_offset [P][n] (sample-fastest): what compute_res_bin leaves per chromosome."""
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        fitted = np.ascontiguousarray(fitted, dtype=np.float64)
+        fo = None if firth_offset is None else np.ascontiguousarray(firth_offset, dtype=np.float64)
+        ps = None if passed is None else np.ascontiguousarray(passed, dtype=np.uint8)
+        if X.shape != (self.C, self.n) or any(a.shape != (self.P, self.n) for a in (y, mask, fitted)) or (fo is not None and fo.shape != (self.P, self.n)):
+            raise ValueError("bt_set_null: expected X %s and [P][n] arrays %s" % ((self.C, self.n), (self.P, self.n)))
+        nm = _BtNull(int(family), 0, X.ctypes.data, y.ctypes.data, mask.ctypes.data, fitted.ctypes.data,
+                     None if fo is None else fo.ctypes.data, None if ps is None else ps.ctypes.data)
+        self._check(self.lib.rg_s2_bt_set_null(self.h, C.byref(nm)))
+
+    def _bt_out(self, bs: int, packed: bool):
+        res = {"stats": np.zeros((bs, self.P)), "bhat": np.zeros((bs, self.P)), "denum": np.zeros((bs, self.P)),
+               "test_ignored": np.zeros((bs, self.P), np.uint8), "mean": np.zeros(bs), "ignored": np.zeros(bs, np.int32),
+               "sparse": np.zeros(bs, np.uint8), "counts": np.zeros((bs, 4), np.int32), "vstat": np.zeros((bs, 4)),
+               "total_p": np.zeros((bs, self.P)), "n_obs_p": np.zeros((bs, self.P), np.int32)}
+        out = _BtOut(*[res[k].ctypes.data for k in ("stats", "bhat", "denum", "test_ignored", "mean", "ignored", "sparse", "counts", "vstat",
+                                                     "total_p", "n_obs_p")])
+        return res, out
+
+    def bt_score_packed(self, rows: np.ndarray, flip: bool = False, numtol: float = NUMTOL) -> dict:
+        rows = np.ascontiguousarray(rows, dtype=np.uint8)
+        bs = rows.shape[0]
+        res, out = self._bt_out(bs, True)
+        self._check(self.lib.rg_s2_bt_score_packed(self.h, rows.ctypes.data, rows.shape[1], bs, 0, 1 if flip else 0, float(numtol), C.byref(out)))
+        res["kernel_ms"] = self.lib.rg_s2_last_kernel_ms(self.h)
+        return res
+
+    def bt_score_int(self, G: np.ndarray, scale: int, numtol: float = NUMTOL) -> dict:
+        G = np.ascontiguousarray(G, dtype=np.uint16)
+        bs = G.shape[0]
+        res, out = self._bt_out(bs, False)
+        self._check(self.lib.rg_s2_bt_score_int(self.h, G.ctypes.data, G.shape[1], bs, 0, int(scale), float(numtol), C.byref(out)))
+        res["kernel_ms"] = self.lib.rg_s2_last_kernel_ms(self.h)
+        return res
+
+    def bt_correct(self, kind: int, variant, trait, fast, firth_se: bool = False) -> dict:
+        """Corrections of the flagged (variant, trait) pairs of the block last scored; kind = BT_FIRTH_APPROX or BT_SPA."""
+        variant = np.ascontiguousarray(variant, dtype=np.int32)
+        trait = np.ascontiguousarray(trait, dtype=np.int32)
+        fast = np.ascontiguousarray(fast, dtype=np.uint8)
+        k = variant.size
+        arr = (_BtCorr * max(1, k))()
+        self._check(self.lib.rg_s2_bt_correct(self.h, int(kind), k, variant.ctypes.data, trait.ctypes.data, fast.ctypes.data, 1 if firth_se else 0, arr))
+        return {"beta": np.array([arr[i].beta for i in range(k)]), "se": np.array([arr[i].se for i in range(k)]),
+                "chisq": np.array([arr[i].chisq for i in range(k)]), "logp": np.array([arr[i].logp for i in range(k)]),
+                "fail": np.array([arr[i].fail for i in range(k)], np.int32), "kernel_ms": self.lib.rg_s2_last_kernel_ms(self.h)}
