@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--phenos", type=int, default=None)
     ap.add_argument("--weak", action="store_true", help="N>1: weak scaling of the N=1 workload instead of configs[2]")
     ap.add_argument("--bsize", type=int, default=1000)
+    ap.add_argument("--bt", action="store_true", help="binary traits (BASELINE configs[3]'s kind): liability-threshold phenotypes, level 1 = logistic ridge (rg_l1_bt)")
+    ap.add_argument("--l0-only", action="store_true", help="time level 0 alone (a GPU's share of a run whose W does not fit one device: 50 phenotypes at 500,000 samples)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-blocks", type=int, default=4)
     ap.add_argument("--no-ref", action="store_true", help="cpu_baseline: skip the reference binary (oracle/_ref/regenie), time the numpy oracle instead")
@@ -154,13 +156,29 @@ def main():
     X = hp.get_basis(np.concatenate([np.ones((N, 1)), cov], axis=1))
     mask = np.ones((N, P), bool)
     neff = np.full(P, float(N))
+    bt_offset = None
+    if args.bt:     # cases = liability above its (1 - prevalence) quantile, prevalence 5 - 30 %; the null logistic model on the
+        prev = np.linspace(0.05, 0.3, P)          # covariates gives the offset of the level-1 logistic ridge (fit_null_logistic)
+        Yraw = np.column_stack([(Yraw[:, q] > np.quantile(Yraw[:, q], 1 - prev[q])).astype(np.float64) for q in range(P)])
+        bt_offset = np.zeros((N, P))
+        for q in range(P):
+            b = np.zeros(X.shape[1])
+            for _ in range(50):
+                eta = X @ b
+                pr = 1 / (1 + np.exp(-eta))
+                w = pr * (1 - pr)
+                step = np.linalg.solve(X.T @ (X * w[:, None]), X.T @ (Yraw[:, q] - pr))
+                b += step
+                if np.abs(step).max() < 1e-10:
+                    break
+            bt_offset[:, q] = X @ b
     Y, _ = hp.residualize_pheno(Yraw - Yraw.mean(axis=0), X, mask, neff)
     ain = np.ones(N, bool)
     cv_sizes = hp.set_folds(ain, 5)
     lam = M * (1 - hp.set_ridge_params(R0)) / hp.set_ridge_params(R0)
     L = B * R0
     h1 = hp.set_ridge_params(R1)
-    tau = np.tile(L * (1 - h1) / h1, (P, 1))
+    tau = np.tile(L * (1 - h1) / h1 * (3.0 / np.pi ** 2 if args.bt else 1.0), (P, 1))     # check_l0 (Step1_Models.cpp:2115-2117)
     cols_per_chr = [sum(1 for bl in blocks if bl[0] == c) * R0 for c in range(len(spc))]
     chroms = [c + 1 for c, n in enumerate(cols_per_chr) if n > 0]
     cols_per_chr = [n for n in cols_per_chr if n > 0]
@@ -201,6 +219,8 @@ def main():
     if world > 1 and not pheno_sharded:
         eng.set_collective(world, rank, _allreduce)
 
+    extra_t = {}
+
     def step(exchange=True, solo=False):
         eng.l0_blocks_device(my_blocks, bss, ptrs, N // 4)
         eng.sync()
@@ -223,8 +243,16 @@ def main():
             eng.set_collective(1, 0, None)
             if pheno_sharded:
                 return None                                 # W is not gathered in this mode: level 0 only
+        if args.l0_only:
+            return ([np.zeros((N, 1))], None, [0] * P)
         if rank == 0 or (world > 1 and not solo):           # N>1: level 1 is shared among the ranks
-            cs, best, pred = eng.l1_qt(tau, cols_per_chr)
+            t_l1 = time.perf_counter()
+            if args.bt:
+                cs, conv, best, pred = eng.l1_bt(tau, Yraw, bt_offset, cols_per_chr)
+                extra_t["bt_converged"] = [bool(c) for c in conv]
+            else:
+                cs, best, pred = eng.l1_qt(tau, cols_per_chr)
+            extra_t["level1_wall_ms_last_step"] = (time.perf_counter() - t_l1) * 1e3
             out = [pred[p] for p in range(P)], cs, best                                    # LOCO rows, assembled on the device
         return out
 
@@ -340,14 +368,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec_per_step * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "fp4 (exact integer Gram) + i8 (exact fixed-point digit planes of the fp64 operands: G~X / G~Y, many-row predictions) + f64 (solves, level 1)",
             "data": "synthetic",
-            "config": {"workload": "%ssynthetic PLINK bed %d samples x %d SNPs (%d per GPU), %d QT pheno, bsize %d, 22 chromosomes, 5-fold CV, 5x5 ridge grid; "
+            "config": {"workload": "%ssynthetic PLINK bed %d samples x %d SNPs (%d per GPU), %d %s pheno, bsize %d, 22 chromosomes, 5-fold CV, 5x5 ridge grid; "
                        "`value` is the HBM-resident figure (packed genotypes generated on the device, timed region = level 0 + level 1 + LOCO rows); "
                        "the complete run from files on disk is `end_to_end_from_files`"
                        % ("BASELINE configs[2], blocks sharded over the GPUs: " if strong else
                           ("BASELINE configs[1]: " if (world == 1 and (N, M, P) == (50000, 100000, 1)) else
                            ("BASELINE configs[2] on ONE GPU: " if (world == 1 and (N, M, P) == (500000, 500000, 10)) else
                             ("" if world == 1 else "weak scaling of BASELINE configs[1]: "))),
-                          N, M, args.snps, P, bsize), "samples": N, "snps": M, "phenos": P, "bsize": bsize, "blocks": B,
+                          N, M, args.snps, P, "BT" if args.bt else "QT", bsize), "samples": N, "snps": M, "phenos": P, "bsize": bsize, "blocks": B,
                        "parallelism": ("blocks sharded x%d, all-to-all of W by phenotype, level 1 phenotype-sharded x%d" if pheno_sharded else
                                        "blocks sharded x%d, all-gather of W, level-1 Gram tiles / ridge systems shared x%d") % (world, world)},
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
@@ -355,7 +383,7 @@ def main():
             "end_to_end_from_files": disk,
             "loco_checksum": float(res[3]) if len(res) > 3 else (loco_ck if default_n1 else float(sum(np.abs(l).sum() for l in res[0]))),
             "selected_tau_index": [int(b) for b in res[2]],
-            "setup_s": {"generate": t_gen},
+            "setup_s": {"generate": t_gen}, "level1": extra_t,
         }
         line.update(extra)
         print(json.dumps(line))

@@ -19,6 +19,7 @@
 // solves against X^T (BT); the closed forms are identical, the factorization differs (agreement ~1e-11).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "rg_internal.h"
@@ -114,6 +115,205 @@ __global__ __launch_bounds__(256, 2) void k_wgram(WgArgs a, SegLayout seg, int T
         if (a.dshift && tr == tc && lr == lc) v = (tr * CT + lr < a.L) ? v + sh : 1.0;
         O[(int64_t)lr * a.n64 + lc] = v;
       }
+}
+
+// ---- the weighted Gram through LDS (the k_l1_gram128 design of l1.hip): one workgroup per 128 x 128 macro tile ------------------------
+// The logistic ridge of BASELINE configs[3] (50 binary traits at 500,000 samples, L = 2,560) spends its time here: K chains x R1 ridge
+// values x 5 - 8 IRLS steps of 2 * 0.8 N * L^2 flop per phenotype.  The register-fed kernel above runs at ~30 TFLOP/s (L2 -> CU fabric);
+// here the 256 operand rows of a macro tile AND the 16 weights of the stage go through a two-stage direct global -> LDS ring shared by four
+// waves, the weights scale the A fragment as it leaves LDS.  A chain's held-out fold is a gap in its position range (the folds are
+// contiguous in position space): the stage counter of a K slice simply jumps it.  Slices write partial tiles (k_wg_reduce sums them in a
+// fixed order and puts tau on the diagonal); the working-response row X^T W z is k_wg_wz's.
+struct WgItem { int16_t mr, mc, slot, slice; };
+struct Wg128 {
+  WgArgs a; int nslice, nslot; const WgItem* items; double* part;      // part [slice][slot][(n64 + 64) x n64]
+};
+#define WG128_STAGE (32768 + 128)   // 256 rows x 16 positions x 8 B, then the stage's 16 weights
+__global__ __launch_bounds__(256, 2) void k_wgram128(Wg128 g, SegLayout seg) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t wg_smem[];
+  const WgItem it = g.items[blockIdx.x];
+  if (it.slot < 0) return;
+  const WgArgs& a = g.a;
+  const int chain = a.chainmap ? a.chainmap[it.slot] : it.slot;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, q = lane >> 4;
+  const int n64 = a.n64;
+  // virtual stages of the chain: every position but its held-out fold
+  const int64_t all16 = (seg.pos_start[seg.nseg - 1] + seg.plen[seg.nseg - 1]) / 16;
+  const int64_t skip_len = a.excl_own ? seg.plen[chain] / 16 : 0, skip_at = a.excl_own ? seg.pos_start[chain] / 16 : all16 + 1;
+  const int64_t vs = all16 - skip_len;
+  const int64_t v0 = vs * it.slice / g.nslice, v1 = vs * (it.slice + 1) / g.nslice;
+  const int ns = (int)(v1 - v0);
+  const int64_t pos0 = (v0 < skip_at ? v0 : v0 + skip_len) * 16;
+  const double* src[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int rl = 8 * (wave * 8 + j) + (lane >> 3);
+    const int row = rl < 128 ? it.mr * 128 + rl : it.mc * 128 + (rl - 128);
+    const int slot = (lane & 7) ^ ((rl >> 1) & 7);
+    src[j] = (row < a.L ? a.W + ((int64_t)row * a.P + a.p) * a.Np : a.zero) + pos0 + 2 * slot;
+  }
+  const double* wsrc = a.wv + (int64_t)chain * a.Np + pos0 + 2 * (lane & 7);      // the stage's weights: lanes 0..7 of wave 0
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)wg_smem;
+  const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 8192);
+  int64_t vnext = v0;
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) glds16p(src[j], wdst + buf * WG128_STAGE + j * 1024);
+    if (wave == 0 && lane < 8) glds16p(wsrc, lds0 + buf * WG128_STAGE + 32768);
+    const int64_t adv = (vnext + 1 == skip_at) ? (1 + skip_len) * 16 : 16;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) src[j] += adv;
+    wsrc += adv;
+    ++vnext;
+  };
+  const int row0 = it.mr * 128 + wr * 64, col0 = it.mc * 128 + wc * 64;
+  const bool live = row0 >= col0 && row0 < n64 && col0 < n64;
+  v4d acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
+  const int xs = (i >> 1) & 7;
+  const int oa = (wr * 64 + i) * 128 + ((q ^ xs) << 4), ob = 16384 + (wc * 64 + i) * 128 + ((q ^ xs) << 4);
+  const int o4 = (((q + 4) ^ xs) << 4) - ((q ^ xs) << 4);
+  if (ns > 0) issue(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int s = 0; s < ns; ++s) {
+    const uint8_t* cur = wg_smem + (s & 1) * WG128_STAGE;
+    if (s + 1 < ns) issue((s + 1) & 1);
+    if (live) {
+      const double2 w0 = *reinterpret_cast<const double2*>(cur + 32768 + q * 16), w1 = *reinterpret_cast<const double2*>(cur + 32768 + (q + 4) * 16);
+      double2 av[4][2], bv[4][2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const double2 x0 = *reinterpret_cast<const double2*>(cur + oa + m * 2048), x1 = *reinterpret_cast<const double2*>(cur + oa + m * 2048 + o4);
+        av[m][0] = make_double2(x0.x * w0.x, x0.y * w0.y);
+        av[m][1] = make_double2(x1.x * w1.x, x1.y * w1.y);
+        bv[m][0] = *reinterpret_cast<const double2*>(cur + ob + m * 2048);
+        bv[m][1] = *reinterpret_cast<const double2*>(cur + ob + m * 2048 + o4);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const double x = kk == 0 ? av[m][0].x : (kk == 1 ? av[m][0].y : (kk == 2 ? av[m][1].x : av[m][1].y));
+            const double y = kk == 0 ? bv[n][0].x : (kk == 1 ? bv[n][0].y : (kk == 2 ? bv[n][1].x : bv[n][1].y));
+            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, acc[m][n], 0, 0, 0);
+          }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  if (!live) return;
+  double* O = g.part + ((int64_t)it.slice * g.nslot + it.slot) * a.out_stride + (int64_t)row0 * n64 + col0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) O[(int64_t)(m * 16 + q + 4 * r) * n64 + n * 16 + i] = acc[m][n][r];
+}
+
+// out[slot] (lower 64 x 64 tiles) = sum over the K slices in slice order, + tau on the diagonal (1 on the padded diagonal)
+__global__ __launch_bounds__(256) void k_wg_reduce(Wg128 g, int T) {
+  const WgArgs& a = g.a;
+  const int slot = blockIdx.y;
+  const int chain = a.chainmap ? a.chainmap[slot] : slot;
+  int tr = (int)((sqrtf(8.0f * blockIdx.x + 1.0f) - 1.0f) * 0.5f);
+  while ((tr + 1) * (tr + 2) / 2 <= (int)blockIdx.x) ++tr;
+  while (tr * (tr + 1) / 2 > (int)blockIdx.x) --tr;
+  const int tc = blockIdx.x - tr * (tr + 1) / 2;
+  const double sh = a.dshift ? a.dshift[chain] : 0.0;
+  for (int e = threadIdx.x; e < CT * CT; e += 256) {
+    const int lr = e >> 6, lc = e & 63;
+    const int64_t off = (int64_t)(tr * CT + lr) * a.n64 + tc * CT + lc;
+    double v = 0.0;
+    for (int sl = 0; sl < g.nslice; ++sl) v += g.part[((int64_t)sl * g.nslot + slot) * a.out_stride + off];
+    if (a.dshift && tr == tc && lr == lc) v = (tr * CT + lr < a.L) ? v + sh : 1.0;
+    a.out[(int64_t)slot * a.out_stride + off] = v;
+  }
+}
+
+// row n64 of every slot's matrix: X^T W z of the chain (the right-hand side of the IRLS step), one workgroup per (predictor, slot);
+// rows past it in the tile are zeros.  The chain's held-out fold carries zero weights and is skipped.
+__global__ __launch_bounds__(256) void k_wg_wz(WgArgs a, SegLayout seg) {
+  __shared__ double red[4];
+  const int l = blockIdx.x, slot = blockIdx.y;
+  const int chain = a.chainmap ? a.chainmap[slot] : slot;
+  double* orow = a.out + (int64_t)slot * a.out_stride + (int64_t)a.n64 * a.n64;
+  if (l >= a.L) { if (threadIdx.x == 0) orow[l] = 0.0; return; }
+  const double* w = a.W + ((int64_t)l * a.P + a.p) * a.Np;
+  const double* wt = a.wv + (int64_t)chain * a.Np;
+  const double* z = a.zv + (int64_t)chain * a.Np;
+  double t0 = 0.0, t1 = 0.0;
+  for (int f = 0; f < seg.nseg; ++f) {
+    if (a.excl_own && f == chain) continue;
+    const int64_t p0 = seg.pos_start[f], p1 = p0 + seg.plen[f];
+    for (int64_t e = p0 + 2 * (int64_t)threadIdx.x; e < p1; e += 512) {
+      const double2 x = *reinterpret_cast<const double2*>(w + e), ww = *reinterpret_cast<const double2*>(wt + e), zz = *reinterpret_cast<const double2*>(z + e);
+      t0 = fma(x.x * ww.x, zz.x, t0);
+      t1 = fma(x.y * ww.y, zz.y, t1);
+    }
+  }
+  double t = t0 + t1;
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+  __syncthreads();
+  if (threadIdx.x == 0) orow[l] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// the weighted Gram of `nslot` chains: LDS-staged form when weights are given (the logistic / Poisson ridge), else the register-fed kernel
+static int launch_wgram(rg_ctx* ctx, hipStream_t st, const WgArgs& a, int T, int nslot) {
+  static const bool old = getenv("RG_WGRAM64") && atoi(getenv("RG_WGRAM64")) != 0;
+  if (!a.wv || old) {
+    hipLaunchKernelGGL(k_wgram, dim3((T * (T + 1) / 2 + T + 3) / 4, nslot), dim3(256), 0, st, a, ctx->seg, T);
+    return RG_OK;
+  }
+  const int T2 = (a.n64 + 127) / 128, ntile2 = T2 * (T2 + 1) / 2;
+  int64_t all16 = (ctx->seg.pos_start[ctx->seg.nseg - 1] + ctx->seg.plen[ctx->seg.nseg - 1]) / 16, min_vs = all16;
+  if (a.excl_own) for (int f = 0; f < ctx->seg.nseg; ++f) min_vs = std::min(min_vs, all16 - ctx->seg.plen[f] / 16);
+  int nslice = (int)std::min<int64_t>(16, std::max<int64_t>(1, (3072 + (int64_t)ntile2 * nslot - 1) / ((int64_t)ntile2 * nslot)));
+  nslice = (int)std::max<int64_t>(1, std::min<int64_t>(nslice, min_vs / 8));
+  // work table: the macro tiles of one 4 x 4 super tile of one (slot, slice) together, dealt to the eight XCDs (as l1_build_items)
+  std::vector<std::vector<WgItem>> xl(8);
+  int gi = 0;
+  const int S = 4, TS = (T2 + S - 1) / S;
+  for (int sl = 0; sl < nslot; ++sl)
+    for (int ks = 0; ks < nslice; ++ks)
+      for (int Mr = 0; Mr < TS; ++Mr)
+        for (int Mc = 0; Mc <= Mr; ++Mc) {
+          std::vector<WgItem>& dst = xl[gi % 8];
+          bool any = false;
+          for (int mr = Mr * S; mr < std::min(T2, (Mr + 1) * S); ++mr)
+            for (int mc = Mc * S; mc < std::min(T2, (Mc + 1) * S); ++mc) {
+              if (mc > mr) continue;
+              dst.push_back(WgItem{(int16_t)mr, (int16_t)mc, (int16_t)sl, (int16_t)ks});
+              any = true;
+            }
+          if (any) ++gi;
+        }
+  size_t mx = 0;
+  for (auto& v : xl) mx = std::max(mx, v.size());
+  std::vector<WgItem> items(mx * 8, WgItem{0, 0, -1, 0});
+  for (int x = 0; x < 8; ++x)
+    for (size_t j = 0; j < xl[x].size(); ++j) items[8 * j + x] = xl[x][j];
+  WgItem* d_items = (WgItem*)rg_ws(ctx, 13, sizeof(WgItem) * items.size());
+  double* d_part = (double*)rg_ws(ctx, 14, sizeof(double) * (size_t)nslice * nslot * a.out_stride);
+  if (!d_items || !d_part) { ctx->err = "weighted Gram: out of device memory"; return RG_ERR_HIP; }
+  RG_HIP(hipMemcpyAsync(d_items, items.data(), sizeof(WgItem) * items.size(), hipMemcpyHostToDevice, st));
+  RG_HIP(hipStreamSynchronize(st));      // `items` is pageable host memory
+  Wg128 g{a, nslice, nslot, d_items, d_part};
+  const size_t lds = 2 * WG128_STAGE;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_wgram128), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_wgram128, dim3((unsigned)items.size()), dim3(256), lds, st, g, ctx->seg);
+  hipLaunchKernelGGL(k_wg_reduce, dim3(T * (T + 1) / 2, nslot), dim3(256), 0, st, g, T);
+  // the right-hand-side row tile: zeros, then X^T W z in its first row
+  RG_HIP(hipMemset2DAsync(a.out + (int64_t)a.n64 * a.n64, sizeof(double) * a.out_stride, 0, sizeof(double) * CT * a.n64, nslot, st));
+  if (a.zv) hipLaunchKernelGGL(k_wg_wz, dim3(a.n64, nslot), dim3(256), 0, st, a, ctx->seg);
+  return RG_OK;
 }
 
 // ---- Wt[pos][c] = W[c][p][pos] (c < L; 0 for L <= c < n64): sample-major copy, the K-contiguous operand of
@@ -624,7 +824,7 @@ int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<doub
   L1X_HIP(hipMemcpyAsync(s.d_tauc, tauc.data(), sizeof(double) * s.nchain, hipMemcpyHostToDevice, st));
   WgArgs g{c.Wv, ctx->d_zero, c.Np, c.L, c.Pv, s.p, c.n64, s.a.wv, rhs_is_score ? nullptr : s.a.zv, s.d_tauc,
            s.d_map, s.a.kfold, s.d_sys, c.msz};
-  hipLaunchKernelGGL(k_wgram, dim3((c.T * (c.T + 1) / 2 + c.T + 3) / 4, na), dim3(256), 0, st, g, ctx->seg, c.T);
+  { const int rcw = launch_wgram(ctx, st, g, c.T, na); if (rcw) return rcw; }
   if (rhs_is_score)
     for (int i = 0; i < na; ++i)
       L1X_HIP(hipMemcpyAsync(s.d_sys + (int64_t)i * c.msz + (int64_t)c.n64 * c.n64, s.d_score + (int64_t)act[i] * c.n64,
@@ -856,7 +1056,7 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
       auto newton = [&](double lam, std::vector<double>& b, bool* cv) { return poisson ? ct_newton_loocv(s, lam, b, o, cv) : bt_newton_loocv(s, lam, b, o, cv); };
       auto loo_setup = [&](double lam) -> int {   // H = (X^T W X + lam I)^-1 at the current weights, U^T = H W^T
         WgArgs g{c.Wv, ctx->d_zero, Np, L, c.Pv, pw, n64, d_wv, nullptr, nullptr, nullptr, 0, d_G, c.msz};
-        hipLaunchKernelGGL(k_wgram, dim3((T * (T + 1) / 2 + T + 3) / 4, 1), dim3(256), 0, st, g, ctx->seg, T);
+        { const int rcw = launch_wgram(ctx, st, g, T, 1); if (rcw) return rcw; }
         L1X_HIP(hipMemcpyAsync(d_tau1, &lam, sizeof(double), hipMemcpyHostToDevice, st));
         L1X_HIP(hipStreamSynchronize(st));
         int r2 = invert_shifted(ctx, c, d_G, d_tau1, 1, d_eye, d_sysI, d_dinvI, d_H);

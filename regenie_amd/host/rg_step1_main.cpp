@@ -62,6 +62,8 @@ struct Params {
   bool rint = false;
   int bsize = 0, cv_folds = 5, n_ridge_l0 = 5, n_ridge_l1 = 5, nchrom = 23, threads = 0;
   bool firth = false, firth_approx = false, firth_se = false;   // --firth --approx [--firth-se] (step 2, binary traits)
+  bool write_null_firth = false;          // --write-null-firth (step 1 or 2): the null approximate-Firth estimates per chromosome, PFX_<k>.firth + PFX_firth.list
+  std::string use_null_firth;             // --use-null-firth LIST (step 2): start values of the null Firth fits
   bool spa = false;                                             // --spa (step 2, binary traits)
   double pthresh = 0.05;                                        // --pThresh: score tests below it get the correction
   double min_info = 0.0; bool set_min_info = false;             // --minINFO (step 2, dosages)
@@ -369,6 +371,8 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--firth") p.firth = true;
     else if (a == "--approx") p.firth_approx = true;
     else if (a == "--firth-se") p.firth_se = true;
+    else if (a == "--write-null-firth") p.write_null_firth = true;
+    else if (a == "--use-null-firth") p.use_null_firth = need(i);
     else if (a == "--pThresh") p.pthresh = atof(need(i).c_str());
     else if (a == "--spa") p.spa = true;
     else usage_error("unrecognised option '" + a + "'");
@@ -386,6 +390,11 @@ Params parse_args(int argc, char** argv) {
     if (p.set_min_info && (p.min_info < 0 || p.min_info > 1)) usage_error("minimum info score must be in [0,1].");
     if (p.gpus > 1 || p.force_collectives) usage_error("--step 2 runs on one GPU.");
   }
+  if (!p.use_null_firth.empty() && !(p.step == 2 && p.firth && p.firth_approx)) usage_error("option --use-null-firth only wors with approximate Firth test.");   // Regenie.cpp:1216-1217
+  if (p.write_null_firth && ((p.step == 2 && !(p.firth && p.firth_approx)) || (p.step == 1 && !p.bt))) {   // Regenie.cpp:1218-1222
+    std::cout << "WARNING: option --write-null-firth only works for BTs with approximate Firth test.\n";
+    p.write_null_firth = false;
+  }
   if ((int)!p.bed.empty() + (int)!p.pgen.empty() + (int)!p.bgen.empty() != 1) usage_error("must use either --bed,--bgen or --pgen.");  // Regenie.cpp:419-420
   if (p.pheno_file.empty()) usage_error("option '--phenoFile' is required.");
   if (p.bsize < 1) usage_error("must specify the block size using '--bsize'.");
@@ -398,6 +407,7 @@ Params parse_args(int argc, char** argv) {
 
 struct Run {
   Params p;
+  std::vector<double> bhat_start;        // [P][C] null logistic estimates (--write-null-firth in step 1: start of the null Firth fits)
   // genotype meta
   std::vector<std::string> fam_ids;      // FID_IID, file order
   std::vector<int> snp_chrom;            // kept variants
@@ -1248,9 +1258,11 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     r.offset.assign((size_t)N * r.P, 0.0);
     for (int q = 0; q < r.P; ++q) {
       std::vector<double> eta;
-      bool ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, true, eta);
-      if (!ok) ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, false, eta);
+      std::vector<double> b0;
+      bool ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, true, eta, nullptr, nullptr, &b0);
+      if (!ok) ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, false, eta, nullptr, nullptr, &b0);
       if (!ok) { r.pheno_pass[q] = 0; continue; }
+      if (p.write_null_firth) { r.bhat_start.resize((size_t)r.P * nz, 0.0); std::copy(b0.begin(), b0.end(), r.bhat_start.begin() + (size_t)q * nz); }   // Step1_Models.cpp:138
       for (int64_t i = 0; i < N; ++i) r.offset[(size_t)q * N + i] = eta[i];
     }
     sout << "done\n";
@@ -1519,6 +1531,21 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   std::vector<double> firth_off;                      // [P][n] cov_blup_offset: X beta_nullFirth + LOCO prediction (fit_null_firth, Step2_Models.cpp:1011-1013)
   if (firth) firth_off.assign((size_t)P * n, 0.0);
   std::vector<double> firth_bnull((size_t)P * C, 0.0), blup_off;      // exact Firth: the covariate-only estimates (start values), the LOCO offsets
+  std::vector<std::string> null_firth_files, firth_file_body(P);       // --use-null-firth: per-trait files of the list; --write-null-firth: what goes out
+  if (!p.use_null_firth.empty()) {      // check_firth_file / the list reader (Step2_Models.cpp:1871-1934): `<phenotype> <file>` per line
+    sout << " * reading null Firth estimates using file : [" << p.use_null_firth << "]\n";
+    null_firth_files.assign(P, "");
+    TextIn lf(p.use_null_firth);
+    if (!lf) throw std::runtime_error("cannot read file : " + p.use_null_firth);
+    std::string ln;
+    while (std::getline(lf, ln)) {
+      const auto t = split_ws(ln);
+      if (t.empty()) continue;
+      if (t.size() != 2) throw std::runtime_error("incorrectly formatted file specified by --use-null-firth.");
+      for (int q = 0; q < P; ++q) if (r.pheno_names[q] == t[0]) null_firth_files[q] = t[1];
+    }
+  }
+  if (p.write_null_firth) sout << " * writing null Firth estimates to file\n";
   if (firth && !p.firth_approx) blup_off.assign((size_t)P * n, 0.0);
   std::vector<double> denum_v;                        // per (variant, trait): the score test's denominator
   std::vector<uint8_t> corrected, corr_fail;          // per (variant, trait) of a block
@@ -1654,7 +1681,30 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
           if (!ok) ok = fit_logistic(yq, Xc.data(), mq, n, C, p, false, eta, off.data(), &pv, &bnull);
         }
         if (ok && firth) {   // fit_null_firth (Step2_Models.cpp:985-1060): penalised fit of the covariates, start = the unpenalised estimate
+          if (!null_firth_files.empty() && !null_firth_files[q].empty()) {   // --use-null-firth: the stored estimates of this chromosome as start
+            TextIn nf(null_firth_files[q]);                                   // (get_beta_start_firth, Step2_Models.cpp:1936-1981)
+            if (!nf) throw std::runtime_error("cannot read file : " + null_firth_files[q]);
+            std::string ln;
+            while (std::getline(nf, ln)) {
+              const auto t = split_ws(ln);
+              if (t.empty()) throw std::runtime_error("error reading null firth estimates file");
+              if (chr_str_to_int(t[0], p.nchrom) != chrom) continue;
+              if ((int)t.size() - 1 > C) throw std::runtime_error("file has more predictors than included in analysis (=" + std::to_string(t.size()) + " vs " + std::to_string(C) + ")");
+              for (size_t c = 1; c < t.size(); ++c) {
+                const double v = convert_double(t[c]);
+                if (v == MISSING) throw std::runtime_error("no missing values allowed in file");
+                bnull[c - 1] = v;
+              }
+              break;
+            }
+          }
           ok = firth_null_fit(yq, Xc.data(), mq, off.data(), n, C, bnull);
+          if (ok && p.write_null_firth) {     // (*firth_est_files[i]) << chrom << " " << bvec (Step2_Models.cpp:1019-1020)
+            std::ostringstream ln;
+            ln << chrom << " ";
+            for (int c = 0; c < C; ++c) ln << bnull[c] << (c + 1 < C ? " " : "");
+            firth_file_body[q] += ln.str() + "\n";
+          }
           if (!ok) sout << "\n     WARNING: null Firth failed for phenotype '" << r.pheno_names[q] << "' (it will be skipped).";
           for (int64_t k = 0; ok && k < n; ++k) {
             double e = blup[an[k]];
@@ -2021,6 +2071,18 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   }
   if (fd >= 0) close(fd);
   rg_s2_destroy(s2);
+  if (p.write_null_firth) {   // print_null_firth_info (Step2_Models.cpp:1871-1900): PFX_<k>.firth per trait that converged everywhere + PFX_firth.list
+    std::ofstream fl(p.out + "_firth.list");
+    for (int q = 0; q < P; ++q) {
+      if (firth_file_body[q].empty()) continue;
+      const std::string ffn = p.out + "_" + std::to_string(q + 1) + ".firth" + (p.gz ? ".gz" : "");
+      TextOut ff(ffn, p.gz);
+      if (!ff) throw std::runtime_error("cannot write file : " + ffn);
+      ff << firth_file_body[q];
+      fl << r.pheno_names[q] << " " << (p.use_rel_path ? ffn : get_fullpath(ffn)) << "\n";
+    }
+    sout << "List of files with null Firth estimates written to: [" << p.out << "_firth.list]\n";
+  }
   sout << "\nAssociation results stored separately for each trait in files : \n";
   for (auto& fn : out_names) sout << "* [" << fn << "]\n";
   sout << "\nNumber of ignored tests due to low MAC" << (p.set_min_info ? " or info score" : "") << " : " << n_ignored_snps * P + n_ignored_tests << "\n";
@@ -2529,7 +2591,7 @@ int run(int argc, char** argv) {
   };
 
   // per-phenotype results, filled by whichever rank owns the phenotype
-  std::vector<std::string> ph_log(P), ph_plist(P), ph_prslist(P);
+  std::vector<std::string> ph_log(P), ph_plist(P), ph_prslist(P), ph_firthlist(P);
 
   // output of one phenotype (Data::output + write_predictions, Data.cpp:956-1129, :1795-1975)
   auto emit_pheno = [&](int q, const double* cs, int bestq, int conv, const double* pq /* [nchr][N] */) {
@@ -2561,12 +2623,12 @@ int run(int argc, char** argv) {
     std::vector<double> tot(N, 0.0);
     for (int c = 0; c < nchr; ++c)
       for (int64_t i = 0; i < N; ++i) tot[i] += pq[(size_t)c * N + i];
+    std::vector<const double*> sub(p.nchrom, nullptr);
+    for (int c = 0; c < nchr; ++c) if (chroms[c] >= 1 && chroms[c] <= p.nchrom) sub[chroms[c] - 1] = pq + (size_t)c * N;
     {
       TextOut lf(loco_fn, p.gz);
       if (!lf) throw std::runtime_error("cannot write file : " + loco_fn);
       lf << header;
-      std::vector<const double*> sub(p.nchrom, nullptr);
-      for (int c = 0; c < nchr; ++c) if (chroms[c] >= 1 && chroms[c] <= p.nchrom) sub[chroms[c] - 1] = pq + (size_t)c * N;
       std::vector<std::string> rows;
       format_rows(p.nchrom, [&](int row, int64_t i) { return tot[i] - (sub[row] ? sub[row][i] : 0.0); }, r.mask.data() + (size_t)q * N, rows);
       for (int chr = 1; chr <= p.nchrom; ++chr) lf << std::to_string(chr) << " " << rows[chr - 1] << "\n";
@@ -2580,6 +2642,30 @@ int run(int argc, char** argv) {
       format_rows(1, [&](int, int64_t i) { return tot[i]; }, r.mask.data() + (size_t)q * N, rows);
       pf << "0 " << rows[0] << "\n";
       ph_prslist[q] = r.pheno_names[q] + " " + (p.use_rel_path ? prs_fn : get_fullpath(prs_fn)) + "\n";
+    }
+    if (p.write_null_firth) {   // Data.cpp:1873-1902: the null approximate-Firth estimates of every chromosome (offset = its LOCO prediction),
+                                // warm-started along the chromosomes from the null logistic estimates; read back by `--step 2 --use-null-firth`
+      const std::string ffn = p.out + "_" + std::to_string(q + 1) + ".firth" + (p.gz ? ".gz" : "");
+      lo << "writing null approximate Firth estimates...";
+      const int Cn = r.C;
+      std::vector<double> bh(r.bhat_start.begin() + (size_t)q * Cn, r.bhat_start.begin() + (size_t)(q + 1) * Cn), off(N);
+      std::ostringstream body;
+      bool conv = true;
+      for (int chr = 1; chr <= p.nchrom && conv; ++chr) {
+        for (int64_t i = 0; i < N; ++i) off[i] = tot[i] - (sub[chr - 1] ? sub[chr - 1][i] : 0.0);
+        conv = firth_null_fit(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, off.data(), N, Cn, bh);
+        if (!conv) break;
+        body << chr << " ";
+        for (int c = 0; c < Cn; ++c) body << bh[c] << (c + 1 < Cn ? " " : "");
+        body << "\n";
+      }
+      if (!conv) lo << "WARNING: Firth failed to converge";
+      else {
+        TextOut ff(ffn, p.gz);
+        if (!ff) throw std::runtime_error("cannot write file : " + ffn);
+        ff << body.str();
+        ph_firthlist[q] = r.pheno_names[q] + " " + (p.use_rel_path ? ffn : get_fullpath(ffn)) + "\n";
+      }
     }
     lo << "done\n\n";
     ph_log[q] = lo.str();
@@ -2678,6 +2764,11 @@ int run(int argc, char** argv) {
     for (auto& pre : r.mprefix)
       for (int q = 0; q < P; ++q) std::remove((pre + "_l0_Y" + std::to_string(q + 1)).c_str());
   sout << "List of blup files written to: [" << p.out << "_pred.list]\n";
+  if (p.write_null_firth) {   // Data.cpp:1102-1121
+    std::ofstream fl(p.out + "_firth.list");
+    for (int q = 0; q < P; ++q) fl << ph_firthlist[q];
+    sout << "List of files with null Firth estimates written to: [" << p.out << "_firth.list]\n";
+  }
   if (p.print_prs) sout << "List of files with whole genome PRS written to: [" << p.out << "_prs.list]\n";
   if (grp) rg_group_destroy(grp);
   for (rg_ctx* cx : ctxs) rg_destroy(cx);

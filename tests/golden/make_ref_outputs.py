@@ -49,8 +49,9 @@ CASES = {
     "bt_loocv_wNA": (["--step", "1", "--bed", "{E}/example_3chr", "--covarFile", "{E}/covariates.txt",
                       "--phenoFile", "{E}/phenotype_bin_wNA.txt", "--bsize", "100", "--bt"], None),
     # binary traits keep K-fold CV only from 5,000 analysed samples on (Data.cpp:353): synthetic data
+    # (--write-null-firth: the null approximate-Firth estimates per chromosome, out_<k>.firth + out_firth.list, Data.cpp:1873-1902)
     "bt_kfold_synth": (["--step", "1", "--bed", "{S}", "--covarFile", "{S}.covar", "--phenoFile", "{S}.pheno",
-                        "--bsize", "100", "--bt"],
+                        "--bsize", "100", "--bt", "--write-null-firth"],
                        dict(M=400, N=5200, chroms=[1] * 150 + [2] * 130 + [5] * 120, P=3, seed=11, binary=True,
                             missing_pheno=0.02)),
     "qt_kfold_synth_missing": (["--step", "1", "--bed", "{S}", "--covarFile", "{S}.covar", "--phenoFile", "{S}.pheno",
@@ -99,7 +100,7 @@ def run_case(name, args, spec, workdir):
     meta = {"args": args, "synthetic": spec, "table": table_lines(log),
             "pred_list": [ln.split()[0] for ln in open(os.path.join(d, "out_pred.list"))]}
     for fn in sorted(os.listdir(d)):
-        if fn.endswith(".loco") or fn.endswith(".prs"):
+        if fn.endswith(".loco") or fn.endswith(".prs") or fn.endswith(".firth"):
             with open(os.path.join(d, fn), "rb") as fi, gzip.GzipFile(os.path.join(od, fn + ".gz"), "wb", mtime=0) as fo:
                 shutil.copyfileobj(fi, fo)
     json.dump(meta, open(os.path.join(od, "meta.json"), "w"), indent=1)
@@ -191,6 +192,9 @@ def step2_cases(workdir, step1_dirs):
                                                           "--bsize", "100", "--bt", "--firth", "--approx", "--pThresh", "0.3"])
     runs["bt_spa_rare"] = (step1_dirs["bt_kfold_synth"], ["--step", "2", "--bed", Sb + "_rare", "--covarFile", Sb + ".covar", "--phenoFile", Sb + ".pheno",
                                                         "--bsize", "100", "--bt", "--spa", "--pThresh", "0.3"])
+    # the same Firth run started from the estimates Step 1 stored (--use-null-firth), writing its own (--write-null-firth in Step 2)
+    runs["bt_firth_rare_usenull"] = (step1_dirs["bt_kfold_synth"], runs["bt_firth_rare"][1] + ["--use-null-firth", os.path.join(step1_dirs["bt_kfold_synth"], "out_firth.list"),
+                                                                                               "--write-null-firth"])
     Sc = os.path.join(step1_dirs["ct_synth"], "synth")
     runs["ct_synth"] = (step1_dirs["ct_synth"], ["--step", "2", "--bed", Sc, "--covarFile", Sc + ".covar", "--phenoFile", Sc + ".pheno", "--bsize", "100", "--ct"])
     for name, (s1, args) in runs.items():
@@ -199,7 +203,7 @@ def step2_cases(workdir, step1_dirs):
         if r.returncode != 0:
             raise RuntimeError("%s failed:\n%s\n%s" % (name, r.stdout[-3000:], r.stderr[-3000:]))
         for fn in sorted(os.listdir(d)):
-            if fn.startswith(name + "_Y") and fn.endswith(".regenie"):
+            if (fn.startswith(name + "_Y") and fn.endswith(".regenie")) or (fn.startswith(name + "_") and fn.endswith(".firth")):
                 with open(os.path.join(d, fn), "rb") as fi, gzip.GzipFile(os.path.join(od, fn + ".gz"), "wb", mtime=0) as fo:
                     shutil.copyfileobj(fi, fo)
 

@@ -434,6 +434,14 @@ def test_cli_bgen_equals_bed(example_dir, tmp_path):
 
 
 # ---- one node, several GPUs: the C++ driver's rank threads, the level-0 hand-off and the sharded / shared level 1 ----------
+def _world(n, *extra):
+    """--gpus n on ONE device over peer copies (what a single-GPU box can run); RG_TEST_REAL_GPUS=1 (tools/first_multigpu.sh, a multi-GPU
+    node): n real devices over RCCL."""
+    if os.environ.get("RG_TEST_REAL_GPUS") == "1":
+        return ["--gpus", str(n)] + list(extra)
+    return ["--gpus", str(n), "--single-device", "--transport", "peer"] + list(extra)
+
+
 def _run_pair(E, tmp_path, extra_common, variants):
     """runs the plain single-GPU command and each variant; returns {name: {file: bytes}}"""
     out = {}
@@ -455,9 +463,9 @@ def test_cli_multi_gpu_qt(example_dir, tmp_path):
     common = ["--step", "1", "--bed", os.path.join(E, "example_3chr"), "--phenoFile", os.path.join(E, "phenotype.txt"),
               "--covarFile", os.path.join(E, "covariates.txt"), "--bsize", "100"]
     res = _run_pair(E, tmp_path, common, [
-        ("peer2", ["--gpus", "2", "--single-device", "--transport", "peer"]),
-        ("peer2_shared", ["--gpus", "2", "--single-device", "--transport", "peer", "--l1-shared"]),
-        ("peer3", ["--gpus", "3", "--single-device", "--transport", "peer"]),
+        ("peer2", _world(2)),
+        ("peer2_shared", _world(2, "--l1-shared")),
+        ("peer3", _world(3)),
         ("rccl1", ["--gpus", "1", "--force-collectives"]),
         ("rccl1_shared", ["--gpus", "1", "--force-collectives", "--l1-shared"]),
     ])
@@ -482,7 +490,7 @@ def test_cli_multi_gpu_rank_failure_does_not_hang(example_dir, tmp_path, form):
     raw = open(os.path.join(E, "example_3chr.bed"), "rb").read()
     open(str(d / "g.bed"), "wb").write(raw[:len(raw) - 4000])           # the last variants are missing
     cmd = ["--step", "1", "--bed", str(d / "g"), "--phenoFile", os.path.join(E, "phenotype.txt"), "--covarFile", os.path.join(E, "covariates.txt"),
-           "--bsize", "100", "--gpus", "2", "--single-device", "--transport", "peer", "--out", "o"]
+           "--bsize", "100"] + _world(2) + ["--out", "o"]
     if form == "all_gather":
         cmd.append("--l1-shared")
     r = subprocess.run([BIN] + cmd, capture_output=True, text=True, cwd=str(d), timeout=120)    # a hang fails the test by timeout
@@ -497,8 +505,8 @@ def test_cli_multi_gpu_bt_and_loocv(example_dir, tmp_path):
               "--covarFile", os.path.join(E, "covariates.txt"), "--remove", os.path.join(E, "fid_iid_to_remove.txt"),
               "--exclude", os.path.join(E, "snplist_rm.txt"), "--bsize", "100", "--bt"]
     res = _run_pair(E, tmp_path, common, [
-        ("peer2", ["--gpus", "2", "--single-device", "--transport", "peer"]),
-        ("peer2_gather", ["--gpus", "2", "--single-device", "--transport", "peer", "--l1-shared"]),   # BT: level 1 on rank 0 after the all-gather
+        ("peer2", _world(2)),
+        ("peer2_gather", _world(2, "--l1-shared")),   # BT: level 1 on rank 0 after the all-gather
         ("rccl1", ["--gpus", "1", "--force-collectives"]),
     ])
     for name in ("peer2", "peer2_gather", "rccl1"):

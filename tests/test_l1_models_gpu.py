@@ -96,6 +96,22 @@ def test_bt_kfold_native_above_5000(tmp_path):
     _compare(ref, got, 2, TOL_BT, 6)
 
 
+def test_bt_kfold_fifty_phenotypes(tmp_path):
+    """BASELINE configs[3]'s phenotype count: 50 binary traits (prevalence 30 %, 2 % missing values each) through level 0 -- 250 rows
+    of (phenotype, ridge value) per block: five groups of the exact digit-plane prediction kernel -- and the K-fold logistic ridge of every
+    trait, against the oracle: CV sums, selected ridge value, convergence flags and LOCO predictors of all 50."""
+    N, M, P = 5200, 400, 50
+    g = synth_dosages(M, N, miss_rate=0.005, seed=501)
+    pre = str(tmp_path / "bt50")
+    write_plink(pre, g, np.repeat([1, 2], [250, 150]), P=P, ncov=2, seed=21, missing_pheno=0.02, binary=True)
+    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=100, bt=True)
+    ref = orc.run_step1(opt)
+    assert not ref.use_loocv
+    got = gpu_step1_any(opt)
+    assert not got["use_loocv"]
+    _compare(ref, got, P, TOL_BT, 4)
+
+
 @pytest.mark.parametrize("kind", ["qt_kfold", "qt_loocv", "bt_loocv"])
 def test_loco_output_mode_matches_host_assembly(example_dir, kind):
     """rg_set_loco_output: the device-side LOCO assembly (write_predictions, Data.cpp:1846-1858) is bit-identical to the

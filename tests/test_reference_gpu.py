@@ -85,6 +85,67 @@ def test_driver_reproduces_reference_outputs(name, tmp_path):
     assert n >= len(meta["pred_list"])
 
 
+def _read_firth(path):
+    op = gzip.open if path.endswith(".gz") else open
+    return [(ln.split()[0], [float(t) for t in ln.split()[1:]]) for ln in op(path, "rt").read().splitlines()]
+
+
+def test_driver_write_and_use_null_firth(tmp_path):
+    """--write-null-firth in Step 1 (Data.cpp:1873-1902): out_<k>.firth = per chromosome the covariate estimates of the null approximate-Firth
+    model with that chromosome's LOCO prediction as offset, out_firth.list names them -- against the files regenie wrote for the same command
+    (the bt_kfold_synth case; regenie stops its fit at |score| < 5e-5, the driver at the maximiser: 2e-4 relative covers the difference).  Then
+    `--step 2 --firth --approx --use-null-firth LIST --write-null-firth` on the rare variants: the stored estimates are start values only, so every
+    result line equals the run without them, and the estimates Step 2 writes are those of its own null Firth fits."""
+    from tests.util import synth_dosages, synth_rare_dosages, write_bed_bim, write_plink
+    import shutil
+    args, spec = CASES["bt_kfold_synth"]
+    assert "--write-null-firth" in args
+    d = str(tmp_path)
+    S = os.path.join(d, "synth")
+    write_plink(S, synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"]), spec["chroms"], P=spec["P"], seed=spec["seed"],
+                binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    r = subprocess.run([BIN] + [a.format(E=EX, S=S) for a in args] + ["--out", "out"], cwd=d, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "List of files with null Firth estimates written to" in r.stdout
+    lst = [ln.split() for ln in open(os.path.join(d, "out_firth.list"))]
+    assert [t[0] for t in lst] == ["Y1", "Y2", "Y3"] and all(os.path.isabs(t[1]) and t[1].endswith("out_%d.firth" % (k + 1)) for k, t in enumerate(lst))
+    for k in (1, 2, 3):
+        ref = _read_firth(os.path.join(REF_OUT, "bt_kfold_synth", "out_%d.firth.gz" % k))
+        got = _read_firth(os.path.join(d, "out_%d.firth" % k))
+        assert [c for c, _ in got] == [c for c, _ in ref] == [str(c) for c in range(1, 24)]
+        for (_, a), (_, b) in zip(got, ref):
+            assert a == pytest.approx(b, rel=2e-4, abs=2e-6)
+    # step 2 with and without the stored estimates
+    write_bed_bim(S + "_rare", synth_rare_dosages(300, spec["N"], seed=spec["seed"], miss_rate=0.002), [1] * 100 + [2] * 100 + [5] * 100)
+    shutil.copy(S + ".fam", S + "_rare.fam")
+    base = [BIN, "--step", "2", "--bed", S + "_rare", "--covarFile", S + ".covar", "--phenoFile", S + ".pheno", "--bsize", "100", "--bt", "--firth", "--approx",
+            "--pThresh", "0.3", "--pred", os.path.join(d, "out_pred.list")]
+    r0 = subprocess.run(base + ["--out", "plain"], cwd=d, capture_output=True, text=True, timeout=600)
+    r1 = subprocess.run(base + ["--use-null-firth", os.path.join(d, "out_firth.list"), "--write-null-firth", "--out", "warm"], cwd=d, capture_output=True, text=True, timeout=600)
+    assert r0.returncode == 0 and r1.returncode == 0, r0.stdout[-2000:] + r1.stdout[-2000:]
+    assert "reading null Firth estimates using file" in r1.stdout
+    for k in (1, 2, 3):
+        a = open(os.path.join(d, "plain_Y%d.regenie" % k)).read().splitlines()
+        b = open(os.path.join(d, "warm_Y%d.regenie" % k)).read().splitlines()
+        ref = gzip.open(os.path.join(REF_OUT, "step2", "bt_firth_rare_usenull_Y%d.regenie.gz" % k), "rt").read().splitlines()
+        assert len(a) == len(b) == len(ref) and a[0] == b[0] == ref[0]
+        for x, y, z in zip(a[1:], b[1:], ref[1:]):
+            tx, ty, tz = x.split(), y.split(), z.split()
+            assert tx[:8] == ty[:8] == tz[:8] and tx[12] == ty[12] == tz[12]
+            for u, v, w in zip(tx[8:12], ty[8:12], tz[8:12]):
+                if "NA" in (u, v, w):
+                    assert u == v == w
+                    continue
+                assert float(v) == pytest.approx(float(u), rel=1e-6, abs=1e-9)          # the start values do not move the maximisers
+                assert float(v) == pytest.approx(float(w), rel=3e-4, abs=2e-9)          # regenie's own run with --use-null-firth
+        # what Step 2 wrote: the chromosomes it tested, the estimates of its own null Firth fits (= regenie's, to its stopping tolerance)
+        got = _read_firth(os.path.join(d, "warm_%d.firth" % k))
+        ref2 = _read_firth(os.path.join(REF_OUT, "step2", "bt_firth_rare_usenull_%d.firth.gz" % k))
+        assert [c for c, _ in got] == [c for c, _ in ref2] == ["1", "2", "5"]
+        for (_, u), (_, v) in zip(got, ref2):
+            assert u == pytest.approx(v, rel=2e-4, abs=2e-6)
+
+
 def _write_big(prefix, N, M, chroms, P, binary, seed, missing_pheno):
     """N x M .bed with HWE genotypes (MAF U(0.05, 0.5), 0.2 % missing calls), P phenotypes with a polygenic signal."""
     rng = np.random.default_rng(seed)

@@ -283,7 +283,7 @@ def test_packed_planes_follow_set_null():
 
 
 def test_packed_at_scale_matches_dense_route():
-    """200,000 samples x 1,024 variants (the sample count of BASELINE configs[4]): the packed route against the fp64 route of the
+    """200,000 samples x 1,024 variants (BASELINE configs[4] has 500,000 samples: that size is checked against the oracle by bench.py's `step2` record, tools/step2_record.py): the packed route against the fp64 route of the
     same library, and a spot check against the oracle."""
     n, C, P, bs = 200_000, 10, 10, 1024
     X, res, mask, scf, G = _problem(31, n, C, P, bs, miss_y=0)

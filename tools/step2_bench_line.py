@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """One JSON line for the Step-2 QT hard-call route in the shape of bench.py's: rows resident in HBM, 200,000 samples
-(BASELINE configs[4]'s sample count), C = 10 covariate basis columns, P = 10 phenotypes, blocks of 16,384 variants, device time of the
+(round 2's size; BASELINE configs[4] has 500,000 samples -- tools/step2_record.py measures that), C = 10 covariate basis columns, P = 10 phenotypes, blocks of 16,384 variants, device time of the
 library's kernels between its own HIP events.  Roofline: the contraction kernel k_xy_i8 is bound by the i8 MFMA pipe -- algorithmic work
 = 2 x 8 digit planes x (C + P) columns x samples integer operations per variant and contracted set (the missing-indicator set doubles it
 for blocks with missing calls); peak from /opt/skills/guides/MI355X_MICROARCH.md (I8 dense >= 3944 TOPS).  Usage (GPU box):
@@ -48,7 +48,7 @@ def main(n=200_000, C=10, P=10, bs=16384, steps=8, warmup=2):
     line = {"metric": "Step-2 QT variants x samples x phenos / sec (hard calls, rg_s2_qt_block_packed)", "unit": "variant*sample*pheno/s",
             "value": out["missing_calls_1pct"]["value"], "n_gpus": 1, "steps": steps, "warmup": warmup, "dtype": "i8 digit planes (exact integer sums) + f64 recombination",
             "data": "synthetic", "higher_is_better": True,
-            "config": {"workload": "200000 samples (BASELINE configs[4]'s sample count), 10 covariates, 10 phenotypes, blocks of 16384 variants, rows resident in HBM",
+            "config": {"workload": "200000 samples (BASELINE configs[4] itself has 500000: see tools/step2_record.py), 10 covariates, 10 phenotypes, blocks of 16384 variants, rows resident in HBM",
                        "samples": n, "covariates": C, "phenos": P, "block": bs},
             "cases": out,
             "note": "value = the case with 1 % missing calls (every block of real array data has some, which adds the missing-indicator contraction); "

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Step-2 QT, hard calls: device time of rg_s2_qt_block_packed against rg_s2_qt_block (fp64 rows) at BASELINE configs[4]'s sample
+"""Step-2 QT, hard calls: device time of rg_s2_qt_block_packed against rg_s2_qt_block (fp64 rows) at 200,000 samples (BASELINE configs[4] has 500,000; tools/step2_record.py), the round-2 probe's sample
 count (200,000 samples, 10 covariates, 10 phenotypes), for several block sizes.  Usage (GPU box): python tools/step2_packed_probe.py"""
 import os
 import sys
