@@ -89,13 +89,16 @@ struct Params {
   double min_mac = 5;       // --minMAC (Regenie.hpp:311)
 };
 
+// a worker thread of a multi-GPU step-2 run logs into its own buffer (tl_log): the parts' logs are appended in order afterwards
+thread_local std::ostringstream* tl_log = nullptr;
 struct Log {  // mstream (Regenie.hpp:120-142): tee to stdout and <out>.log
   std::ofstream f;
   template <class T>
-  Log& operator<<(const T& v) { std::cout << v; if (f.is_open()) f << v; return *this; }
-  Log& operator<<(std::ostream& (*m)(std::ostream&)) { std::cout << m; if (f.is_open()) f << m; return *this; }
+  Log& operator<<(const T& v) { if (tl_log) { *tl_log << v; return *this; } std::cout << v; if (f.is_open()) f << v; return *this; }
+  Log& operator<<(std::ostream& (*m)(std::ostream&)) { if (tl_log) { *tl_log << m; return *this; } std::cout << m; if (f.is_open()) f << m; return *this; }
 };
 Log sout;
+std::mutex g_reader_mu;      // the .pgen / .bgen readers keep per-handle state: one block read at a time (multi-GPU step 2)
 
 // Files (Files.cpp:38-160): a file whose name ends in ".gz" and starts with the gzip magic is read through zlib, anything
 // else as plain text; `--gz` writes the .loco / .prs outputs through zlib.  (The reference needs Boost Iostreams for this.)
@@ -388,7 +391,7 @@ Params parse_args(int argc, char** argv) {
     if (p.firth && !(p.pthresh > 0 && p.pthresh < 1)) usage_error("'--pThresh' must be in (0,1).");
     if (p.min_mac < 0.5) usage_error("minimum MAC must be at least 0.5.");   // Regenie.cpp:1054
     if (p.set_min_info && (p.min_info < 0 || p.min_info > 1)) usage_error("minimum info score must be in [0,1].");
-    if (p.gpus > 1 || p.force_collectives) usage_error("--step 2 runs on one GPU.");
+    if (p.force_collectives) usage_error("--force-collectives applies to step 1 (step 2 has no collective: its blocks are independent).");
   }
   if (!p.use_null_firth.empty() && !(p.step == 2 && p.firth && p.firth_approx)) usage_error("option --use-null-firth only wors with approximate Firth test.");   // Regenie.cpp:1216-1217
   if (p.write_null_firth && ((p.step == 2 && !(p.firth && p.firth_approx)) || (p.step == 1 && !p.bt))) {   // Regenie.cpp:1218-1222
@@ -400,7 +403,7 @@ Params parse_args(int argc, char** argv) {
   if (p.bsize < 1) usage_error("must specify the block size using '--bsize'.");
   if (p.cv_folds < 2) usage_error("number of CV folds must be at least 2");
   if (p.gpus < 1) usage_error("--gpus must be at least 1");
-  if (p.single_device && p.gpus > 1 && p.transport != RG_TRANSPORT_PEER) usage_error("--single-device needs --transport peer (RCCL refuses two ranks on one device)");
+  if (p.step == 1 && p.single_device && p.gpus > 1 && p.transport != RG_TRANSPORT_PEER) usage_error("--single-device needs --transport peer (RCCL refuses two ranks on one device)");
   if ((p.gpus > 1 || p.force_collectives) && (p.run_l0 || p.run_l1 || p.split_l0)) usage_error("--gpus / --force-collectives cannot be combined with the --split-l0 / --run-l0 / --run-l1 file protocol");
   return p;
 }
@@ -1500,7 +1503,18 @@ bool firth_null_fit(const double* y, const double* X, const uint8_t* mask, const
 // The per-variant corrections -- fit_firth_logistic_snp_fast (Step2_Models.cpp:1158-1253) and run_SPA_test_snp (:2072-2297) -- run on the
 // device behind the C ABI (rg_s2_bt_correct, regenie_amd/csrc/step2_bt.hip).
 
-int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
+// One part of a `--step 2` run: the blocks [blk_lo, blk_hi) of the run's block list (chromosomes in file order, ceil(n_chr / bsize) blocks
+// each) on one device.  A run on G GPUs is G parts on G host threads -- the blocks are independent, there is no exchange -- whose result
+// lines go to part files that are concatenated in block order afterwards (run_step2_all).
+struct S2Part {
+  int part = 0, nparts = 1, device = 0;
+  int blk_lo = 0, blk_hi = INT_MAX;
+  int64_t n_ignored_snps = 0, n_ignored_tests = 0;     // out
+  std::vector<std::string> firth_body;                 // out: --write-null-firth lines per trait
+  std::vector<std::string> files;                      // out: the part's result files, one per trait
+};
+
+int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& part) {
   const Params& p = r.p;
   const int64_t N = r.N;
   const int P = r.P, C = r.C;
@@ -1553,7 +1567,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   if (glm) bt_fit.assign((size_t)P * n, 0.5);
 
   rg_s2_ctx* s2 = nullptr;
-  if (rg_s2_create(&s2, p.device, n, C, P) != RG_S2_OK || !s2) throw std::runtime_error("no MI355X / HIP device available (rg_s2_create failed)");
+  if (rg_s2_create(&s2, part.device, n, C, P) != RG_S2_OK || !s2) throw std::runtime_error("no MI355X / HIP device available (rg_s2_create failed)");
   auto s2check = [&](int rc) { if (rc != RG_S2_OK) throw std::runtime_error(rg_s2_last_error(s2)); };
   enum class In { Bed, PgenHard, Dosage };
   const In in = r.dosage_mode ? In::Dosage : (r.pgen ? In::PgenHard : In::Bed);
@@ -1580,12 +1594,14 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   // output files, one per phenotype (split_by_pheno is the default; print_header_output_single, Step2_Models.cpp:2386-2398)
   std::vector<std::unique_ptr<TextOut>> ofs;
   std::vector<std::string> out_names;
+  const bool multi = part.nparts > 1;        // parts write plain part files; run_step2_all concatenates (and compresses) them
   for (int q = 0; q < P; ++q) {
-    out_names.push_back(p.out + "_" + r.pheno_names[q] + ".regenie" + (p.gz ? ".gz" : ""));
-    ofs.emplace_back(new TextOut(out_names.back(), p.gz));
+    out_names.push_back(p.out + "_" + r.pheno_names[q] + ".regenie" + (multi ? ".part" + std::to_string(part.part) : (p.gz ? ".gz" : "")));
+    ofs.emplace_back(new TextOut(out_names.back(), multi ? false : p.gz));
     if (!*ofs.back()) throw std::runtime_error("cannot write file : " + out_names.back());
-    *ofs.back() << "CHROM GENPOS ID ALLELE0 ALLELE1 A1FREQ " << (show_info ? "INFO " : "") << "N TEST BETA SE CHISQ LOG10P EXTRA\n";
+    if (part.part == 0) *ofs.back() << "CHROM GENPOS ID ALLELE0 ALLELE1 A1FREQ " << (show_info ? "INFO " : "") << "N TEST BETA SE CHISQ LOG10P EXTRA\n";
   }
+  part.files = out_names;
 
   const int fd = in == In::Bed ? open((p.bed + ".bed").c_str(), O_RDONLY) : -1;
   if (in == In::Bed && fd < 0) throw std::runtime_error("cannot read bed file");
@@ -1599,7 +1615,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
     }
   }
   int nthreads = p.threads > 0 ? p.threads : std::max(1, (int)std::thread::hardware_concurrency() - 1);   // Regenie.cpp:1104-1106
-  nthreads = std::min(nthreads, 64);
+  nthreads = std::max(1, std::min(nthreads, 64) / part.nparts);
   // buildLookupTable (Geno.cpp:2833-2856): 00 -> 2, 01 -> missing (-3), 10 -> 1, 11 -> 0 copies of the first .bim allele
   static const double lut[4] = {2.0, -3.0, 1.0, 0.0};
   std::vector<uint8_t> rows, packed;
@@ -1642,6 +1658,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
     if (!chr_snps.count(chrom)) continue;
     const std::vector<int64_t>& snps = chr_snps[chrom];
     const int nb_chr = (int)((snps.size() + p.bsize - 1) / p.bsize);
+    if (block + nb_chr <= part.blk_lo || block >= part.blk_hi) { block += nb_chr; continue; }     // none of the chromosome's blocks is this part's
     sout << "Chromosome " << chrom << " [" << nb_chr << " blocks in total]\n";
     // blup_read_chr (Step2_Models.cpp:51-140) + compute_res (Data.cpp:2386-2400)
     sout << (p.bt ? "   -reading loco predictions for the chromosome and fitting null logistic regression on binary phenotypes..."
@@ -1740,6 +1757,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
     sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tb).count() << "ms) \n";
 
     for (int bb = 0; bb < nb_chr; ++bb, ++block) {
+      if (block < part.blk_lo || block >= part.blk_hi) continue;
       const int64_t j0 = (int64_t)bb * p.bsize;
       const int bs = (int)std::min<int64_t>(p.bsize, (int64_t)snps.size() - j0);
       sout << " block [" << block + 1 << "/" << total_blocks << "] : ";
@@ -1747,6 +1765,8 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
       vidx.resize(bs);
       for (int j = 0; j < bs; ++j) vidx[j] = r.snp_offset[snps[j0 + j]];
       if (in != In::Dosage) rows.resize((size_t)bs * r.bpr);
+      std::unique_lock<std::mutex> rlk(g_reader_mu, std::defer_lock);
+      if (multi && in != In::Bed) rlk.lock();
       if (in == In::PgenHard) {   // ReadHardcalls per variant (Geno.cpp:2570-2573), as .bed-coded rows (00 = two ALT copies)
         if (rg_pgen_read_bed_rows(r.pgen, bs, vidx.data(), rows.data(), r.bpr) != RG_PGEN_OK) throw std::runtime_error(rg_pgen_last_error(r.pgen));
       } else if (in == In::Dosage) {
@@ -1758,10 +1778,11 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
         } else if (rg_pgen_read_dosage_rows(r.pgen, bs, vidx.data(), dbuf.data(), r.n_file) != RG_PGEN_OK)   // Read() (Geno.cpp:2570-2571)
           throw std::runtime_error(rg_pgen_last_error(r.pgen));
       }
+      if (rlk.owns_lock()) rlk.unlock();
       if (in == In::Bed) {   // the block's rows: read ahead by the previous iteration when it could be (same chromosome), else read now
         if (ahead.valid()) { ahead.get(); rows.swap(rows_ahead); }
         else read_bed(snps, j0, bs, rows);
-        if (bb + 1 < nb_chr) {
+        if (bb + 1 < nb_chr && block + 1 < part.blk_hi) {
           const int64_t jn = (int64_t)(bb + 1) * p.bsize;
           const int bn = (int)std::min<int64_t>(p.bsize, (int64_t)snps.size() - jn);
           ahead = std::async(std::launch::async, [&, jn, bn]() { read_bed(snps, jn, bn, rows_ahead); });
@@ -2071,21 +2092,88 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start) {
   }
   if (fd >= 0) close(fd);
   rg_s2_destroy(s2);
-  if (p.write_null_firth) {   // print_null_firth_info (Step2_Models.cpp:1871-1900): PFX_<k>.firth per trait that converged everywhere + PFX_firth.list
+  part.n_ignored_snps = n_ignored_snps; part.n_ignored_tests = n_ignored_tests;
+  part.firth_body = firth_file_body;
+  return 0;
+}
+
+// `--step 2` on G GPUs (G = 1: the calling thread): contiguous block ranges per GPU, floor(B / G) blocks each and the first B mod G one more
+// (the split of write_l0_master, Data.cpp:270-302), one host thread and one library context per GPU, no collective on the data path.
+int run_step2_all(Run& r, std::chrono::steady_clock::time_point t_start) {
+  const Params& p = r.p;
+  const int P = r.P, G = p.gpus;
+  std::map<int, int64_t> cn;
+  for (int c : r.snp_chrom) cn[c]++;
+  int B = 0;
+  for (auto& kv : cn) B += (int)((kv.second + p.bsize - 1) / p.bsize);
+  std::vector<S2Part> parts(G);
+  int b0 = 0;
+  for (int g = 0; g < G; ++g) {
+    parts[g].part = g; parts[g].nparts = G; parts[g].device = p.single_device ? p.device : p.device + g;
+    parts[g].blk_lo = b0; b0 += B / G + (g < B % G ? 1 : 0); parts[g].blk_hi = b0;
+  }
+  if (G == 1) { parts[0].blk_hi = INT_MAX; run_step2(r, t_start, parts[0]); }
+  else {
+    sout << std::left << std::setw(20) << " * # GPUs" << ": [" << G << "] (blocks [1.." << B << "] in contiguous ranges)\n";
+    std::vector<std::ostringstream> logs(G);
+    std::vector<std::exception_ptr> errs(G, nullptr);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g)
+      th.emplace_back([&, g]() {
+        tl_log = &logs[g];
+        try { run_step2(r, t_start, parts[g]); } catch (...) { errs[g] = std::current_exception(); }
+        tl_log = nullptr;
+      });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < G; ++g) {
+      sout << " GPU " << g << " : blocks [" << parts[g].blk_lo + 1 << ".." << parts[g].blk_hi << "]\n";
+      if (g == 0) sout << logs[g].str();
+      else {   // the run-wide header lines were logged by part 0
+        const std::string lg = logs[g].str();
+        const size_t at = lg.find("Chromosome ");
+        if (at != std::string::npos) sout << lg.substr(at);
+      }
+    }
+    for (int g = 0; g < G; ++g) if (errs[g]) std::rethrow_exception(errs[g]);
+    // the parts' result files in block order -> PFX_<trait>.regenie[.gz]
+    for (int q = 0; q < P; ++q) {
+      const std::string fn = p.out + "_" + r.pheno_names[q] + ".regenie" + (p.gz ? ".gz" : "");
+      TextOut of(fn, p.gz);
+      if (!of) throw std::runtime_error("cannot write file : " + fn);
+      std::vector<char> buf(8 << 20);
+      for (int g = 0; g < G; ++g) {
+        std::ifstream in(parts[g].files[q], std::ios::binary);
+        while (in) { in.read(buf.data(), (std::streamsize)buf.size()); of.write(buf.data(), in.gcount()); }
+        in.close();
+        std::remove(parts[g].files[q].c_str());
+      }
+      parts[0].files[q] = fn;
+    }
+  }
+  if (p.write_null_firth) {   // print_null_firth_info (Step2_Models.cpp:1871-1900): PFX_<k>.firth per trait + PFX_firth.list
     std::ofstream fl(p.out + "_firth.list");
     for (int q = 0; q < P; ++q) {
-      if (firth_file_body[q].empty()) continue;
+      std::string body;
+      std::set<std::string> seen;     // a chromosome that spans two parts was fitted by both: one line
+      for (int g = 0; g < G; ++g) {
+        std::istringstream is(parts[g].firth_body.empty() ? std::string() : parts[g].firth_body[q]);
+        std::string ln;
+        while (std::getline(is, ln)) { const std::string chr = ln.substr(0, ln.find(' ')); if (seen.insert(chr).second) body += ln + "\n"; }
+      }
+      if (body.empty()) continue;
       const std::string ffn = p.out + "_" + std::to_string(q + 1) + ".firth" + (p.gz ? ".gz" : "");
       TextOut ff(ffn, p.gz);
       if (!ff) throw std::runtime_error("cannot write file : " + ffn);
-      ff << firth_file_body[q];
+      ff << body;
       fl << r.pheno_names[q] << " " << (p.use_rel_path ? ffn : get_fullpath(ffn)) << "\n";
     }
     sout << "List of files with null Firth estimates written to: [" << p.out << "_firth.list]\n";
   }
+  int64_t n_ignored = 0;
+  for (auto& pt : parts) n_ignored += pt.n_ignored_snps * P + pt.n_ignored_tests;
   sout << "\nAssociation results stored separately for each trait in files : \n";
-  for (auto& fn : out_names) sout << "* [" << fn << "]\n";
-  sout << "\nNumber of ignored tests due to low MAC" << (p.set_min_info ? " or info score" : "") << " : " << n_ignored_snps * P + n_ignored_tests << "\n";
+  for (auto& fn : parts[0].files) sout << "* [" << fn << "]\n";
+  sout << "\nNumber of ignored tests due to low MAC" << (p.set_min_info ? " or info score" : "") << " : " << n_ignored << "\n";
   sout << "\nElapsed time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << "s\nEnd of run\n";
   return 0;
 }
@@ -2197,7 +2285,7 @@ int run(int argc, char** argv) {
   }
   read_pheno_cov(r);
   sout << "   -phenotypes and covariates ready (" << since_start() << "ms since start)\n";
-  if (p.step == 2) return run_step2(r, t_start);
+  if (p.step == 2) return run_step2_all(r, t_start);
   const int64_t N = r.N;
   const int P = r.P;
 

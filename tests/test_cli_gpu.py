@@ -557,6 +557,48 @@ def test_cli_step2_qt_against_reference_output(example_dir, tmp_path, case, rout
     assert ign and ign[0].split(":")[1].strip() == ("0" if case == "qt_bed_3chr" else "14")
 
 
+@pytest.mark.parametrize("mode", ["qt", "bt_firth", "bt_spa_bgen", "gz"])
+def test_cli_step2_multi_gpu(example_dir, tmp_path, mode):
+    """`--step 2 --gpus 3`: the run's blocks in contiguous ranges on three library contexts (one host thread each; --single-device puts them on
+    one GPU, RG_TEST_REAL_GPUS=1 on three), no collective -- every result file byte-identical to the one-GPU run, the count of ignored tests
+    and (binary traits) the null-Firth estimates the parts wrote merged into one file per trait."""
+    import gzip
+    E = example_dir
+    R = os.path.join(ROOT, "tests", "golden", "ref_outputs")
+    bt = mode.startswith("bt")
+    s1 = "bt_loocv_refcmd" if bt else "qt_kfold_3chr"
+    with open(str(tmp_path / "pred.list"), "w") as pl:
+        for k in (1, 2):
+            fn = str(tmp_path / ("ref_%d.loco" % k))
+            open(fn, "wb").write(gzip.open(os.path.join(R, s1, "out_%d.loco.gz" % k), "rb").read())
+            pl.write("Y%d %s\n" % (k, fn))
+    if bt:
+        geno = ["--bgen", os.path.join(E, "example.bgen")] if mode == "bt_spa_bgen" else ["--bed", os.path.join(E, "example")]
+        cmd = ["--step", "2"] + geno + ["--phenoFile", os.path.join(E, "phenotype_bin.txt"), "--covarFile", os.path.join(E, "covariates.txt"),
+               "--remove", os.path.join(E, "fid_iid_to_remove.txt"), "--bsize", "100", "--bt", "--pThresh", "0.05", "--pred", str(tmp_path / "pred.list")]
+        cmd += ["--spa"] if mode == "bt_spa_bgen" else ["--firth", "--approx", "--write-null-firth"]
+    else:
+        cmd = ["--step", "2", "--bed", os.path.join(E, "example_3chr"), "--phenoFile", os.path.join(E, "phenotype.txt"), "--covarFile", os.path.join(E, "covariates.txt"),
+               "--qt", "--bsize", "70", "--pred", str(tmp_path / "pred.list")] + (["--gz"] if mode == "gz" else [])
+    world = ["--gpus", "3"] + ([] if os.environ.get("RG_TEST_REAL_GPUS") == "1" else ["--single-device"])
+    one = subprocess.run([BIN] + cmd + ["--out", "one"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    three = subprocess.run([BIN] + cmd + world + ["--out", "three"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0 and three.returncode == 0, one.stdout[-2000:] + three.stdout[-3000:] + three.stderr[-2000:]
+    suffix = ".regenie.gz" if mode == "gz" else ".regenie"
+    for k in (1, 2):
+        a = open(str(tmp_path / ("one_Y%d%s" % (k, suffix))), "rb").read()
+        b = open(str(tmp_path / ("three_Y%d%s" % (k, suffix))), "rb").read()
+        if mode == "gz":
+            a, b = gzip.decompress(a), gzip.decompress(b)
+        assert a == b and a.count(b"\n") > 400
+    assert not [fn for fn in os.listdir(str(tmp_path)) if ".part" in fn]
+    ign = lambda r: [ln for ln in r.stdout.splitlines() if "ignored tests due to low MAC" in ln][0]      # noqa: E731
+    assert ign(one) == ign(three) and "GPU 2 : blocks" in three.stdout
+    if mode == "bt_firth":
+        for k in (1, 2):
+            assert open(str(tmp_path / ("one_%d.firth" % k))).read() == open(str(tmp_path / ("three_%d.firth" % k))).read()
+
+
 @pytest.mark.parametrize("fmt", ["bed", "bgen", "bgen_rf", "pgen", "pgenhc", "strict", "bgen_mininfo"])
 def test_cli_step2_qt_masked_phenotypes_against_reference_output(tmp_path, fmt):
     """Phenotypes that differ in their missing values (5 %), genotypes with missing calls (1 %), 3,001 samples x 500 variants x 4

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """End-to-end wall time of the C++ driver on a BASELINE configs[1]-sized data set ON DISK (50,000 samples x 100,000 SNPs, 22
 chromosomes, 1 QT, bsize 1000): file parsing, .bed reads, PCIe, level 0, level 1, .loco writing -- everything `bench.py`
-leaves out on purpose.  Usage (GPU box): python tools/cli_e2e.py [N=50000] [M=100000]"""
+leaves out on purpose.  Usage (GPU box): python tools/cli_e2e.py [N=50000] [M=100000] [P=1]
+(N = M = 500000, P = 10 is BASELINE configs[2]: a 62.5 GB .bed; the variants then are the default and more reader threads only)"""
 import os
 import subprocess
 import sys
@@ -12,7 +13,7 @@ import numpy as np
 import torch
 
 
-def main(N=50000, M=100000, bs=1000):
+def main(N=50000, M=100000, P=1, bs=1000):
     d = "/tmp/e2e"
     os.makedirs(d, exist_ok=True)
     dev = torch.device("cuda", 0)
@@ -41,14 +42,14 @@ def main(N=50000, M=100000, bs=1000):
                 j += 1
     rng = np.random.default_rng(1)
     y = ysum.cpu().numpy()
-    y = 0.4 * y / y.std() + rng.standard_normal(N)
+    y = 0.4 * (y / y.std())[:, None] + rng.standard_normal((N, P))
     cov = rng.standard_normal((N, 2))
     with open(d + "/x.fam", "w") as f1, open(d + "/x.pheno", "w") as f2, open(d + "/x.covar", "w") as f3:
-        f2.write("FID IID Y1\n")
+        f2.write("FID IID " + " ".join("Y%d" % (q + 1) for q in range(P)) + "\n")
         f3.write("FID IID C1 C2\n")
         for i in range(N):
             f1.write("%d %d 0 0 0 -9\n" % (i + 1, i + 1))
-            f2.write("%d %d %.8f\n" % (i + 1, i + 1, y[i]))
+            f2.write("%d %d " % (i + 1, i + 1) + " ".join("%.8f" % v for v in y[i]) + "\n")
             f3.write("%d %d %.8f %.8f\n" % (i + 1, i + 1, cov[i, 0], cov[i, 1]))
     print("data set written in %.1f s (%.2f GB .bed)" % (time.time() - t0, os.path.getsize(d + "/x.bed") / 1e9), flush=True)
     del dd, code, c, packed
@@ -57,6 +58,8 @@ def main(N=50000, M=100000, bs=1000):
     variants = [("default", {}), ("default", {}), ("default", {}), ("RG_NBLK=28", {"RG_NBLK": "28"}), ("RG_NBLK=28", {"RG_NBLK": "28"}),
                 ("RG_PIPELINES=1", {"RG_PIPELINES": "1"}), ("RG_PIPELINES=1", {"RG_PIPELINES": "1"}),
                 ("RG_INGEST_PINNED=1", {"RG_INGEST_PINNED": "1"}), ("sleep 3 s first", {})]
+    if N * M > 2e10:      # a large input: the wall is the file read -- the default and more reads in flight
+        variants = [("default (4 reader threads)", {}), ("RG_READ_THREADS=16", {"RG_READ_THREADS": "16"}), ("RG_READ_THREADS=32", {"RG_READ_THREADS": "32"})]
     for name, env in variants:
         if name.startswith("sleep"):
             time.sleep(3)
@@ -66,7 +69,7 @@ def main(N=50000, M=100000, bs=1000):
         dt = time.time() - t0
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         marks = [ln.strip() for ln in r.stdout.split("\n") if "since start" in ln or "level 1 for" in ln or "complete (" in ln]
-        print("%-22s wall %.2f s = %.2e SNP*sample*pheno/s end to end | %s" % (name, dt, M * N / dt, " | ".join(marks)), flush=True)
+        print("%-22s wall %.2f s = %.2e SNP*sample*pheno/s end to end | %s" % (name, dt, M * N * P / dt, " | ".join(marks)), flush=True)
 
 
 if __name__ == "__main__":
