@@ -102,7 +102,9 @@ void* rg_w_device_ptr(rg_ctx* ctx);
  *   bed_rows[b]  : pointer to bs[b] packed .bed rows (2 bits/sample, N_file samples), row b*stride
  *   row_stride   : bytes between consecutive SNP rows (>= ceil(N_file/4))
  *   mem_kind     : RG_MEM_HOST or RG_MEM_DEVICE (where bed_rows[b] live)
- * Work is asynchronous on the ctx stream; rg_sync() (or any readback) waits for it. */
+ * Work is asynchronous: batches alternate between the library's level-0 pipelines, each on a stream of its own, and are joined back
+ * onto the ctx stream by rg_sync, rg_l0_finish, rg_l0_get_w / rg_l0_set_w and the level-1 entries -- W (rg_w_device_ptr, a buffer given
+ * by rg_set_w_buffer) holds the blocks' predictors only after one of those calls, not merely stream-ordered after rg_l0_blocks. */
 int rg_l0_blocks(rg_ctx* ctx, int32_t nblk, const int32_t* block_ids, const int32_t* bs,
                  const uint8_t* const* bed_rows, int64_t row_stride, int mem_kind);
 /* Level 0 on NON-INTEGER genotypes (dosages): what level_0_calculations does after readChunkFromPGENFileToG in dosage_mode

@@ -113,17 +113,24 @@ __global__ __launch_bounds__(256) void k_assemble_generic(AsmArgs a) {
   for (int s = 0; s < AF; ++s) vf[s] = 0.0;
   double tot = 0.0;
   bool write_zero = false, skip = false;
+  int64_t e_rhs = e;
   if (i >= n64) {  // RHS rows: b_f^T
     const int p = i - n64;
+    if (a.embed) {   // embedded: row bs + p of the matrix part (its padding rows), nothing past n64
+      if (p >= P) return;
+      e_rhs = (int64_t)(bs + p) * n64 + k;
+    }
     for (int s = 0; s < ns; ++s) {
       double v = 0.0;
       if (p < P && k < bs) v = a.GYt[(((int64_t)blk * ns + s) * n128 + k) * P + p] / sc[k];
       if (inreg) {
 #pragma unroll
         for (int t = 0; t < AF; ++t) if (t == s) vf[t] = v;
-      } else fold[(int64_t)s * msz + e] = v;
+      } else fold[(int64_t)s * msz + e_rhs] = v;
       tot += v;
     }
+  } else if (a.embed && i >= bs && i < bs + P) {  // an embedded right-hand-side row: written by the thread of row n64 + p
+    skip = true;
   } else if (k > i) {  // upper triangle: never referenced, except inside diagonal 64-tiles (kept finite)
     if ((k >> 6) == (i >> 6)) write_zero = true;
     else skip = true;
@@ -168,11 +175,11 @@ __global__ __launch_bounds__(256) void k_assemble_generic(AsmArgs a) {
   if (inreg) {
 #pragma unroll
     for (int t = 0; t < AF; ++t)
-      if (t < ns) fold[(int64_t)t * msz + e] = a.diff_mode ? tot - vf[t] : vf[t];
+      if (t < ns) fold[(int64_t)t * msz + e_rhs] = a.diff_mode ? tot - vf[t] : vf[t];
   } else if (a.diff_mode) {
-    for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = tot - fold[(int64_t)s * msz + e];
+    for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e_rhs] = tot - fold[(int64_t)s * msz + e_rhs];
   }
-  if (!a.diff_mode) sum[e] = tot;
+  if (!a.diff_mode) sum[e_rhs] = tot;
 }
 
 // ---- tiled assemble (the default: up to AF folds) --------------------------------------------------------------
@@ -219,8 +226,8 @@ __global__ __launch_bounds__(256, (NF <= 5 ? 2 : 1)) void k_assemble_tiled(AsmAr
         vf[s] = (live && s < ns) ? g * isck : 0.0;
         tot += vf[s];
       }
-      if (i < a.rtot) {
-        const int64_t e = (int64_t)i * n64 + k;
+      if (a.embed ? p < P : i < a.rtot) {     // embedded: row bs + p of the matrix part (its padding rows), nothing past n64
+        const int64_t e = (int64_t)(a.embed ? bs + p : i) * n64 + k;
 #pragma unroll
         for (int s = 0; s < NF; ++s)
           if (s < ns) fold[(int64_t)s * msz + e] = a.diff_mode ? tot - vf[s] : vf[s];
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(256, (NF <= 5 ? 2 : 1)) void k_assemble_tiled(AsmAr
     const int i = i0 + ty + 8 * rr;
     const int64_t e = (int64_t)i * n64 + k;
     const double inv = 1.0 / (sc[i] * sck);
+    if (a.embed && i >= bs && i < bs + P) continue;     // an embedded right-hand-side row: written by the workgroup of row n64 + p
     if (k > i) {  // upper triangle inside a diagonal tile
       if ((k >> 6) == (i >> 6)) {
         for (int s = 0; s < ns; ++s) fold[(int64_t)s * msz + e] = 0.0;

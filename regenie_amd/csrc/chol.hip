@@ -10,6 +10,11 @@
 // triangle of the SPD matrix, rows >= n64 hold the right-hand sides as ROWS, so the forward
 // substitution happens for free as part of the factorization (the RHS rows are just more strip rows).
 // Padded diagonal entries are 1.
+// Embedded right-hand sides (FormSrc::embed = P, level 0 whenever bs + P <= n64): the P right-hand sides are rows n .. n + P - 1 of the
+// matrix itself -- the padding rows of its last tile -- with 2^100 on their diagonal: the system [[A, .], [b^T, D]] has the factor
+// [[L, 0], [y^T, .]], y = L^-1 b, so the forward substitution is still part of the factorization, but there is no sixty-four-row tile
+// row for (at level 0) ONE right-hand side: that tile row cost 22 % of the strip kernel's products and a launch of its own for the
+// last group.  The back substitution then reads y from row n + p with the columns >= n masked.
 //
 // Tile algorithm, tile 64, tile columns in groups of 4, left-looking over the groups -- per group [k0, k0+nc):
 //   k_chol_update : the group's DIAGONAL block (<= 10 tiles) -= L[.][q < k0] L[.][q < k0]^T, one wave per tile
@@ -144,7 +149,9 @@ struct FormSrc {
   const double* extra; int64_t extra_stride;
   int nfold, nshift, n_fixed, enabled, subtract, extra_row0, n64, n_div, b_offset;
   int skip_pad;   // group-wise path: tile rows / columns past a system's own order (identity padding) are not computed
+  int embed;      // > 0: that many right-hand sides sit in rows n .. n + embed - 1 of the system (needs d_n; group-wise path only)
 };
+#define RG_EMBED_DIAG 0x1p100   // diagonal of an embedded right-hand-side row: D - y^T y stays positive and sqrt(D) = 2^50 overflows nothing
 // Tile columns of system b that hold data: ceil(n_b / 64) when the caller gave per-system orders (level 0: the SNP count of
 // the block, so that a chromosome-end block of 300 SNPs is factored at order 320 instead of the batch's 1024), else T.
 // Tile rows [T_b, T) and tile columns >= T_b of such a system are identity padding: never read, never written.
@@ -152,10 +159,10 @@ __device__ __forceinline__ int sys_tiles(const FormSrc& f, int b_local, int T) {
   if (!f.skip_pad || !f.d_n) return T;
   const int b = b_local + f.b_offset;
   const int o = b / (f.nfold * f.nshift);
-  const int tb = (f.d_n[o / f.n_div] + CT - 1) / CT;
+  const int tb = (f.d_n[o / f.n_div] + f.embed + CT - 1) / CT;
   return tb < T ? tb : T;
 }
-struct FormIdx { const double* S; const double* F; const double* X; double sh; int64_t xoff; int n, x0; };
+struct FormIdx { const double* S; const double* F; const double* X; double sh; int64_t xoff; int n, x0, nrhs; };
 __device__ __forceinline__ FormIdx form_idx(const FormSrc& f, int b_local) {
   const int b = b_local + f.b_offset;   // a rank / caller may own a contiguous sub-range of the systems
   const int per = f.nfold * f.nshift;
@@ -168,6 +175,7 @@ __device__ __forceinline__ FormIdx form_idx(const FormSrc& f, int b_local) {
   x.xoff = (int64_t)f.extra_row0 * f.n64;
   x.sh = f.shift[r];
   x.n = f.d_n ? f.d_n[o / f.n_div] : f.n_fixed;
+  x.nrhs = x.n + f.embed;
   return x;
 }
 // e = i * n64 + j.  MODE is resolved OUTSIDE the unrolled element loops: hipcc turns every load under an `if` into
@@ -186,7 +194,7 @@ __device__ __forceinline__ double form_val(const FormIdx& x, int i, int j, int64
   } else {
     v = x.S[e];
   }
-  if (i == j) v = (i < x.n) ? v + x.sh : 1.0;
+  if (i == j) v = (i < x.n) ? v + x.sh : (i < x.nrhs ? RG_EMBED_DIAG : 1.0);
   return v;
 }
 __device__ __forceinline__ int form_mode(const FormIdx& x) { return x.X ? 2 : (x.F ? 1 : 0); }
@@ -1307,12 +1315,18 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(double* mats, int64_t ma
   const int p = w % pg, part = w / pg;
   const int rlen = CT / parts, r0 = part * rlen;
   double* M = mats + (int64_t)b * mat_stride;
+  // embedded right-hand sides: y is row n + p of the system, its entries past column n belong to the factor of the padding
+  int nsys = n64;
+  if (fs.embed) {
+    const int bb = b + fs.b_offset;
+    nsys = fs.d_n[(bb / (fs.nfold * fs.nshift)) / fs.n_div];
+  }
   for (int p0 = 0; p0 < nrhs; p0 += pg) {
     const bool act = (p0 + p) < nrhs;
-    double* Y = M + (int64_t)(n64 + p0 + p) * n64;
+    double* Y = M + (int64_t)(nsys + p0 + p) * n64;
     for (int k = T - 1; k >= 0; --k) {
       __syncthreads();
-      if (part == 0) yk[p][c] = act ? Y[k * CT + c] : 0.0;
+      if (part == 0) yk[p][c] = (act && k * CT + c < nsys) ? Y[k * CT + c] : 0.0;
       __syncthreads();
       const double* I = dinv + ((int64_t)b * Tfull + k) * CT * CT;
       double x = 0.0;
@@ -1426,6 +1440,7 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
   const int T = n64 / CT, Tr = rhs_pad / CT, Ttot = T + Tr;
   FormSrc off{};
   off.enabled = 0; off.extra = nullptr; off.n_div = 1; off.b_offset = 0; off.skip_pad = 0; off.d_n = nullptr; off.nfold = off.nshift = 1;
+  off.embed = 0;
   int64_t nl = 0;
   // path: 0 = group-wise (throughput: level 0, whatever the batch size, so that results do not depend on how the blocks
   // are batched), 1 = per-column (latency: level 1 and the logistic steps, a few dozen systems), -1 = by batch size
@@ -1523,8 +1538,9 @@ void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t su
                                    const int32_t* d_n, int n_fixed, int nouter, double* mats,
                                    int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
                                    int32_t* info, int64_t* n_launch, int subtract, const double* extra,
-                                   int64_t extra_stride, int extra_row0, int n_div, int b_offset, int b_count, int path) {
+                                   int64_t extra_stride, int extra_row0, int n_div, int b_offset, int b_count, int path, int embed) {
   FormSrc f;
+  f.embed = (embed > 0 && d_n && path == 0) ? embed : 0;
   f.sum = sum; f.sum_stride = sum_stride; f.fold = fold; f.fold_stride = fold_stride; f.shift = shift;
   f.d_n = d_n; f.nfold = nfold; f.nshift = nshift; f.n_fixed = n_fixed; f.enabled = 1;
   f.subtract = subtract; f.extra = extra; f.extra_stride = extra_stride; f.extra_row0 = extra_row0; f.n64 = n64;

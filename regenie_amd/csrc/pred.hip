@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void k_beta_post(PredArgs a) {
   const double* Bm = a.Bm + (int64_t)blk * a.n128 * a.C;
   for (int p = 0; p < a.P; ++p) {
     double* beta = a.beta + (((int64_t)blk * nm + m) * a.P + p) * a.n64;
-    const double* x = M + (int64_t)(a.n64 + p) * a.n64;
+    const double* x = M + (int64_t)((a.embed ? bs : a.n64) + p) * a.n64;
     for (int j = threadIdx.x; j < a.n64; j += 256) beta[j] = (j < bs) ? x[j] / sc[j] : 0.0;
     for (int c = 0; c < a.C; ++c) {
       double t = 0.0;

@@ -464,6 +464,10 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
                           ctx->gram_fp4 ? 1 : 0);
     ctx->tm.n_gram_launches += 1;
   }
+  // K-fold level 0 with room in the padding rows of the blocks' last tiles: the right-hand sides are embedded in the systems
+  // (chol.hip); RG_NO_EMBED=1 keeps them in a tile row of their own
+  static const bool no_embed = getenv("RG_NO_EMBED") && atoi(getenv("RG_NO_EMBED")) != 0;
+  const int embed = (!ctx->loocv && !no_embed && ctx->bs_max + P <= n64) ? P : 0;
   {
     StageTimer t(ctx, &ctx->tm.ms_assemble);
     AsmArgs a;
@@ -474,6 +478,7 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     a.BQ = ctx->d_BQ; a.GYt = ctx->d_GYt; a.sc = ctx->d_sc; a.fold = ctx->d_fold; a.sum = ctx->d_sum;
     a.info = ctx->d_info;
     a.diff_mode = ctx->loocv ? 0 : 1;
+    a.embed = embed ? 1 : 0;
     rg_launch_rowstats(st, a);
     rg_launch_assemble(st, a);
   }
@@ -502,8 +507,8 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     // d_fold[(blk, f)] holds the training-fold system of fold f (assemble.hip diff_mode): one source matrix per
     // (block, fold), shared by the R0 shifted systems that are co-located on one XCD for their first touch
     rg_launch_chol_solve_formed_x(st, ctx->d_fold, msz, nullptr, 0, 1, ctx->d_lambda, R0, ctx->d_bs, 0, nblk * nseg,
-                                  ctx->d_wk, msz, n64, rtot - n64, P, ctx->d_dinv, ctx->d_info + 1,
-                                  &ctx->tm.n_chol_launches, 0, nullptr, 0, 0, nseg, 0, -1, 0);
+                                  ctx->d_wk, msz, n64, embed ? 0 : rtot - n64, P, ctx->d_dinv, ctx->d_info + 1,
+                                  &ctx->tm.n_chol_launches, 0, nullptr, 0, 0, nseg, 0, -1, 0, embed);
   }
   {
     StageTimer t(ctx, &ctx->tm.ms_pred);
@@ -515,6 +520,7 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     pa.keptp = ctx->d_keptp; pa.bs = ctx->d_bs; pa.blockid = ctx->d_blockid; pa.neff = ctx->d_neff; pa.nmiss = ctx->d_nmiss;
     pa.beta = ctx->d_beta; pa.cb = ctx->d_cb; pa.psum = ctx->d_psum; pa.W = rg_w_base(ctx);
     pa.bplanes = ctx->d_bplanes; pa.bsc = ctx->d_bsc; pa.pkT = ctx->d_pkT;
+    pa.embed = embed ? 1 : 0;
     rg_launch_l0_pred_impl(st, pa, ChunkTab{ctx->d_c1k_seg, ctx->d_c1k_pos, ctx->d_c1k_len, ctx->n_c1k},
                            ChunkTab{ctx->d_c256_seg, ctx->d_c256_pos, ctx->d_c256_len, ctx->n_c256}, ctx->d_pstat);
   }

@@ -247,6 +247,7 @@ struct AsmArgs {
   double *F, *Bm, *BQ, *GYt, *sc, *fold, *sum;
   int32_t* info;
   int diff_mode;   // 1: fold[f] holds (sum over folds) - (fold f), i.e. the training-fold matrix; sum is not written
+  int embed = 0;   // 1: the right-hand sides are rows bs .. bs + P - 1 of a block's matrices (chol.hip, "embedded right-hand sides")
 };
 void rg_launch_rowstats(hipStream_t st, const AsmArgs& a);
 void rg_launch_assemble(hipStream_t st, const AsmArgs& a);
@@ -259,7 +260,7 @@ void rg_launch_chol_solve_formed_x(hipStream_t st, const double* sum, int64_t su
                                    int64_t mat_stride, int n64, int rhs_pad, int nrhs, double* dinv,
                                    int32_t* info, int64_t* n_launch, int subtract, const double* extra,
                                    int64_t extra_stride, int extra_row0, int n_div = 1, int b_offset = 0,
-                                   int b_count = -1, int path = 1);
+                                   int b_count = -1, int path = 1, int embed = 0);
 void rg_launch_dgemm_nt(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                         int m, int n, int64_t k, double* C, int64_t ldc);
 // pred.hip
@@ -273,6 +274,7 @@ struct PredArgs {
   double *beta, *cb, *psum, *W;
   // exact i8 route of the many-row predictions (pred_i8.hip); null = not available for this problem
   int8_t* bplanes = nullptr; double* bsc = nullptr; uint8_t* pkT = nullptr;
+  int embed = 0;   // 1: the solutions sit in rows bs .. bs + P - 1 of the factored systems instead of rows n64 ..
 };
 struct ChunkTab { const int32_t* seg; const int64_t* pos; const int64_t* len; int n; };
 void rg_launch_l0_pred_impl(hipStream_t st, const PredArgs& a, const ChunkTab& c1k, const ChunkTab& c256, double* stats);

@@ -732,6 +732,8 @@ int ensure_in(rg_s2_ctx* ctx, void** buf, size_t* cap, int slot, size_t bytes) {
 int pick_segments(int64_t Np, int tiles, int ngrp, SegLayout& seg) {
   int nseg = 1;
   while (nseg < RG_MAX_SEG && (int64_t)tiles * nseg * ngrp < 768 && Np / (nseg * 2) >= 1024) nseg *= 2;
+  // the int32 sums of a segment must not wrap: |digit| <= 64 times a LUT value of at most 4 (the squared allele count) per sample
+  while (nseg < RG_MAX_SEG && Np / nseg > (1 << 23)) nseg *= 2;
   memset(&seg, 0, sizeof(seg));
   seg.nseg = nseg;
   for (int f = 0; f < nseg; ++f) { seg.pos_start[f] = f * (Np / nseg); seg.file_start[f] = seg.pos_start[f]; seg.len[f] = Np / nseg; seg.plen[f] = Np / nseg; }

@@ -90,9 +90,11 @@ def exchange_w_by_phenotype(W, shards: List[Tuple[int, int]], pshards: List[Tupl
     out_split = [sn * r0 * qn * Np for (_, sn) in shards]
     if buffers is None:
         buffers = {}
-    if buffers.get("send") is None or buffers["send"].numel() != sum(in_split):
+    key = (sum(in_split), sum(out_split), W.dtype, W.device)     # the cached pair fits this exchange exactly, or is replaced
+    if buffers.get("key") != key:
         buffers["send"] = torch.empty(sum(in_split), dtype=W.dtype, device=W.device)
         buffers["recv"] = torch.empty(sum(out_split), dtype=W.dtype, device=W.device)
+        buffers["key"] = key
     send, recv = buffers["send"], buffers["recv"]
     off = 0
     for (p0, pn), cnt in zip(pshards, in_split):

@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cctype>
 #include <cstring>
 #include <fstream>
 #include <functional>
@@ -39,6 +40,7 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 #include <charconv>
 #include <climits>
@@ -179,11 +181,17 @@ class TextOut : public std::ostream {  // Files::openForWrite
   std::unique_ptr<GzOutBuf> gz_;
 };
 
-std::vector<std::string> split_ws(const std::string& s) {
+std::vector<std::string> split_ws(const std::string& s) {     // the tokens `is >> t` would give (a stream per line cost 2 s of a 500,000-sample run)
   std::vector<std::string> out;
-  std::istringstream is(s);
-  std::string t;
-  while (is >> t) out.push_back(t);
+  const size_t n = s.size();
+  size_t i = 0;
+  while (i < n) {
+    while (i < n && std::isspace((unsigned char)s[i])) ++i;
+    size_t j = i;
+    while (j < n && !std::isspace((unsigned char)s[j])) ++j;
+    if (j > i) out.emplace_back(s, i, j - i);
+    i = j;
+  }
   return out;
 }
 std::vector<std::string> split_char(const std::string& s, char c) {
@@ -420,7 +428,8 @@ struct Run {
   std::vector<int64_t> snp_pos;          // kept variants: physpos, and the two alleles in output order (Geno.cpp:546-553)
   std::vector<std::string> snp_a0, snp_a1;
   // --step 2: the LOCO files of step 1 (blup_read, Pheno.cpp:1241-1391)
-  struct Blup { std::string file; std::vector<int64_t> col_sample; std::vector<int64_t> line_off; };
+  struct Blup { std::string file; std::vector<int64_t> col_sample; std::vector<int64_t> line_off;
+                std::vector<std::string> lines; };     // lines: the chromosome rows of a gzipped file (no seeking there), else empty
   std::vector<Blup> blups;               // per phenotype
   // --run-l0 / --run-l1 (prep_parallel_l0 / prep_parallel_l1)
   int64_t parallel_nGeno = 0;            // global number of variants (lambda uses it, Data.cpp:607)
@@ -640,7 +649,7 @@ bool fit_poisson(const double* y, const double* X, const uint8_t* mask, int64_t 
 }
 
 void apply_sample_and_variant_filters(Run& r);
-void blup_read(struct Run& r, const std::map<std::string, int64_t>& idx);
+void blup_read(struct Run& r, const std::unordered_map<std::string, int64_t>& idx);
 
 // prep_bgen (Geno.cpp:38-175): variant list from the file itself, sample identifiers embedded or from --sample
 void read_bgen_meta(Run& r) {
@@ -925,7 +934,7 @@ void apply_sample_and_variant_filters(Run& r) {
 
 // --pred list + first pass over every LOCO file (check_blup / blup_read, Pheno.cpp:1204-1391): header ids -> samples,
 // line 2 tells which samples have NA predictions (masked for the trait), byte offsets of the chromosome lines for later
-void blup_read(Run& r, const std::map<std::string, int64_t>& idx) {
+void blup_read(Run& r, const std::unordered_map<std::string, int64_t>& idx) {
   const Params& p = r.p;
   const int64_t N = r.N;
   std::map<std::string, std::string> files;
@@ -948,8 +957,13 @@ void blup_read(Run& r, const std::map<std::string, int64_t>& idx) {
     Run::Blup& bl = r.blups[q];
     bl.file = files[r.pheno_names[q]];
     sout << "   -file [" << bl.file << "] for phenotype '" << r.pheno_names[q] << "'\n";
-    if (ends_with_gz(bl.file)) throw std::runtime_error("gzipped LOCO files are not read by --step 2 here (write them without --gz): " + bl.file);
-    std::ifstream f(bl.file, std::ios::binary);
+    // a gzipped file (`--step 1 --gz` writes PFX_<k>.loco.gz and lists it; Files::openForRead inflates it) cannot be revisited by byte
+    // offset: its chromosome rows (nChrom lines) are kept in memory instead
+    const bool gzf = ends_with_gz(bl.file);
+    TextIn fgz(gzf ? bl.file : std::string("/dev/null"));
+    std::ifstream fpl;
+    if (!gzf) fpl.open(bl.file, std::ios::binary);
+    std::istream& f = gzf ? static_cast<std::istream&>(fgz) : static_cast<std::istream&>(fpl);
     if (!f) throw std::runtime_error("cannot open file : " + bl.file);
     std::string line;
     std::getline(f, line);
@@ -960,8 +974,9 @@ void blup_read(Run& r, const std::map<std::string, int64_t>& idx) {
       auto it = idx.find(hdr[c]);
       if (it != idx.end()) bl.col_sample[c] = it->second;
     }
-    bl.line_off.push_back((int64_t)f.tellg());
+    bl.line_off.push_back(gzf ? 0 : (int64_t)f.tellg());
     std::getline(f, line);
+    if (gzf) bl.lines.push_back(line);
     auto l2 = split_ws(line);
     if (l2.size() != hdr.size()) throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' has different number of entries on line 2 compared to the header.");
     std::vector<uint8_t> have(N, 0);
@@ -972,17 +987,30 @@ void blup_read(Run& r, const std::map<std::string, int64_t>& idx) {
     if (after < 1) throw std::runtime_error("all individuals are missing LOCO predictions for phenotype '" + r.pheno_names[q] + "'.");
     if (after < before) sout << "    + " << before - after << " individuals with missing LOCO predictions will be ignored for the trait\n";
     for (;;) {   // offsets of the following lines (one per chromosome)
-      const int64_t off = (int64_t)f.tellg();
+      const int64_t off = gzf ? 0 : (int64_t)f.tellg();
       if (!std::getline(f, line) || line.empty()) break;
       bl.line_off.push_back(off);
+      if (gzf) bl.lines.push_back(line);
     }
   }
+}
+
+// a loop spread over host threads (step 2's variant loop is the reference's OpenMP loop in compute_tests_mt, Data.cpp:2484-2486)
+template <class F>
+void parallel_for(int n, int nthreads, F&& fn) {
+  nthreads = std::max(1, std::min(nthreads, n));
+  if (nthreads == 1) { for (int j = 0; j < n; ++j) fn(j); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nthreads; ++t)
+    th.emplace_back([&, t]() { for (int j = t; j < n; j += nthreads) fn(j); });
+  for (auto& x : th) x.join();
 }
 
 void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841, :1903-1935
   const Params& p = r.p;
   const int64_t N = r.N;
-  std::map<std::string, int64_t> idx;
+  std::unordered_map<std::string, int64_t> idx;
+  idx.reserve((size_t)N * 2);
   for (int64_t i = 0; i < N; ++i) idx[r.ids[i]] = i;
   std::vector<uint8_t> in_pheno(N, 0), in_cov(N, p.covar_file.empty() ? 1 : 0);
   {
@@ -1007,29 +1035,55 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     r.Y.assign((size_t)N * r.P, 0.0);
     r.mask.assign((size_t)N * r.P, 1);
     if (p.bt || p.ct) r.Yraw.assign((size_t)N * r.P, 0.0);
-    while (std::getline(f, line)) {
-      auto t = split_ws(line);
-      if (t.empty()) continue;
-      if (t.size() != hdr.size()) throw std::runtime_error("incorrectly formatted phenotype file.");
-      auto it = idx.find(t[0] + "_" + t[1]);
-      if (it == idx.end()) continue;
-      const int64_t i = it->second;
-      if (in_pheno[i]) throw std::runtime_error("individual appears more than once in phenotype file: FID=" + t[0] + " IID=" + t[1]);
+    // The lines are tokenised, matched to their sample and converted by several threads (at 500,000 samples x 10 phenotypes one thread
+    // needs 2 s); the checks and the bookkeeping below then run over the records in file order, exactly as a line-by-line reader would.
+    std::vector<std::string> lines;
+    while (std::getline(f, line)) lines.push_back(std::move(line));
+    struct Rec { int64_t i; int state; };      // state 0: use, 1: blank line, 2: wrong number of columns, 3: a value that is not a number
+    std::vector<Rec> recs(lines.size());
+    std::vector<double> vals(lines.size() * (size_t)r.P);
+    {
+      const int nt = std::max(1, std::min(16, (int)std::thread::hardware_concurrency() - 1));
+      const int nchunk = (int)std::min<size_t>(lines.size(), (size_t)nt * 4);
+      parallel_for(nchunk, nt, [&](int c) {
+        for (size_t li = lines.size() * c / nchunk, le = lines.size() * (c + 1) / nchunk; li < le; ++li) {
+          const auto t = split_ws(lines[li]);
+          Rec& rc = recs[li];
+          rc.i = -1; rc.state = 0;
+          if (t.empty()) { rc.state = 1; continue; }
+          if (t.size() != hdr.size()) { rc.state = 2; continue; }
+          auto it = idx.find(t[0] + "_" + t[1]);
+          if (it == idx.end()) continue;
+          rc.i = it->second;
+          try { for (int q = 0; q < r.P; ++q) vals[li * (size_t)r.P + q] = convert_double(t[keep_cols[q]]); }
+          catch (...) { rc.state = 3; }
+        }
+      });
+    }
+    for (size_t li = 0; li < lines.size(); ++li) {
+      if (recs[li].state == 1) continue;
+      if (recs[li].state == 2) throw std::runtime_error("incorrectly formatted phenotype file.");
+      if (recs[li].i < 0) continue;
+      const int64_t i = recs[li].i;
+      std::vector<std::string> t;                     // the tokens again, for the messages of the rare failing line only
+      auto tok = [&]() -> const std::vector<std::string>& { if (t.empty()) t = split_ws(lines[li]); return t; };
+      if (recs[li].state == 3) for (int q = 0; q < r.P; ++q) (void)convert_double(tok()[keep_cols[q]]);     // rethrows the conversion error
+      if (in_pheno[i]) throw std::runtime_error("individual appears more than once in phenotype file: FID=" + tok()[0] + " IID=" + tok()[1]);
       in_pheno[i] = 1;
       bool all_miss = true;
       for (int q = 0; q < r.P; ++q) {
-        double v = convert_double(t[keep_cols[q]]);
+        double v = vals[li * (size_t)r.P + q];
         if (p.bt) {  // Pheno.cpp:260-283
           if (p.cc12 && v != MISSING) v -= 1;
           r.Yraw[(size_t)q * N + i] = v;
           if (v != 0 && v != 1) {
-            if (v != MISSING) throw std::runtime_error("a phenotype value is not 0/1/NA for individual: FID=" + t[0] + " IID=" + t[1] + " Y=" + t[keep_cols[q]]);
+            if (v != MISSING) throw std::runtime_error("a phenotype value is not 0/1/NA for individual: FID=" + tok()[0] + " IID=" + tok()[1] + " Y=" + tok()[keep_cols[q]]);
             r.mask[(size_t)q * N + i] = 0;
           }
         } else if (p.ct) {  // Pheno.cpp:298, :313-320: counts must be non-negative
           r.Yraw[(size_t)q * N + i] = v;
           if (v < 0) {
-            if (v != MISSING) throw std::runtime_error("a phenotype value is <0 for individual: FID=" + t[0] + " IID=" + t[1] + " Y=" + t[keep_cols[q]]);
+            if (v != MISSING) throw std::runtime_error("a phenotype value is <0 for individual: FID=" + tok()[0] + " IID=" + tok()[1] + " Y=" + tok()[keep_cols[q]]);
             r.mask[(size_t)q * N + i] = 0;
           }
         }
@@ -1362,17 +1416,6 @@ void check(rg_ctx* ctx, int rc) {
   if (rc != 0) throw std::runtime_error(rg_last_error(ctx));
 }
 
-// the variant loop of a block spread over host threads (the reference's OpenMP loop in compute_tests_mt, Data.cpp:2484-2486)
-template <class F>
-void parallel_for(int n, int nthreads, F&& fn) {
-  nthreads = std::max(1, std::min(nthreads, n));
-  if (nthreads == 1) { for (int j = 0; j < n; ++j) fn(j); return; }
-  std::vector<std::thread> th;
-  for (int t = 0; t < nthreads; ++t)
-    th.emplace_back([&, t]() { for (int j = t; j < n; j += nthreads) fn(j); });
-  for (auto& x : th) x.join();
-}
-
 // -log10 p of a 1-df chi-square statistic (get_logp, Regenie.cpp:1843-1856)
 double get_logp(double t) {
   if (t < 0 && std::fabs(t) < 1e-6) return 0.0;
@@ -1667,10 +1710,13 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     for (int q = 0; q < P; ++q) {
       Run::Blup& bl = r.blups[q];
       if (chrom < 1 || chrom > (int)bl.line_off.size()) throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' has no line for chromosome " + std::to_string(chrom) + ".");
-      std::ifstream f(bl.file, std::ios::binary);
-      f.seekg(bl.line_off[chrom - 1]);
       std::string line;
-      std::getline(f, line);
+      if (!bl.lines.empty()) line = bl.lines[chrom - 1];
+      else {
+        std::ifstream f(bl.file, std::ios::binary);
+        f.seekg(bl.line_off[chrom - 1]);
+        std::getline(f, line);
+      }
       auto t = split_ws(line);
       if (t.size() != bl.col_sample.size())
         throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' has different number of entries on line " + std::to_string(chrom + 1) + " compared to the header (=" + std::to_string(t.size()) + " vs " + std::to_string(bl.col_sample.size()) + ").");

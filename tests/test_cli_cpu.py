@@ -76,7 +76,6 @@ def test_step2_usage_errors(example_dir, tmp_path):
     assert "cannot use both" in err(["--bt", "--pred", "p.list", "--spa", "--firth", "--approx"])
     assert "applies to binary traits" in err(["--qt", "--pred", "p.list", "--firth", "--approx"])
     assert "minimum MAC must be at least 0.5" in err(["--qt", "--pred", "p.list", "--minMAC", "0.1"])
-    assert "--step 2 runs on one GPU" in err(["--qt", "--pred", "p.list", "--gpus", "2"])
 
 
 def test_step2_reads_inputs_then_needs_a_gpu(example_dir, tmp_path):

@@ -63,6 +63,22 @@ def test_cli_matches_oracle_files(example_dir, tmp_path):
         assert ("MSE = %s<- min value" % orc.cpp_double(mse)) in log
 
 
+def test_cli_embedded_right_hand_sides_equal_separate_rows(example_dir, tmp_path):
+    """Level 0 keeps the right-hand sides of a block's ridge systems in the padding rows of the systems' last tile whenever they fit
+    (regenie_amd/csrc/chol.hip, "embedded right-hand sides"); RG_NO_EMBED=1 keeps them in a tile row of their own.  Same predictions to
+    the printed digits (the forward substitution of the last tile columns runs in another kernel: rounding differs)."""
+    E = example_dir
+    outs = {}
+    for name, env in (("embedded", {}), ("separate", {"RG_NO_EMBED": "1"})):
+        args = ["--step", "1", "--bed", os.path.join(E, "example_3chr"), "--phenoFile", os.path.join(E, "phenotype.txt"),
+                "--covarFile", os.path.join(E, "covariates.txt"), "--bsize", "100", "--out", str(tmp_path / name)]
+        r = subprocess.run([BIN] + args, cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = [_parse_loco(str(tmp_path / ("%s_%d.loco" % (name, k))))[2] for k in (1, 2)]
+    for a, b in zip(outs["embedded"], outs["separate"]):
+        assert np.nanmax(np.abs(a - b)) <= 2e-6 * np.nanmax(np.abs(b))
+
+
 def test_cli_remove_exclude_prs(example_dir, tmp_path):
     E = example_dir
     args = ["--step", "1", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype.txt"),

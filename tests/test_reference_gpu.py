@@ -96,13 +96,14 @@ def _firth_equal_up_to_basis_signs(got, ref):
     sign = np.sign(np.array(got[0][1]) * np.array(ref[0][1]))
     assert np.all(sign != 0)
     for (_, a), (_, b) in zip(got, ref):
-        assert np.array(a) * sign == pytest.approx(np.array(b), rel=2e-4, abs=2e-6)
+        assert np.array(a) * sign == pytest.approx(np.array(b), rel=3e-3, abs=3e-4)
 
 
 def test_driver_write_and_use_null_firth(tmp_path):
     """--write-null-firth in Step 1 (Data.cpp:1873-1902): out_<k>.firth = per chromosome the covariate estimates of the null approximate-Firth
     model with that chromosome's LOCO prediction as offset, out_firth.list names them -- against the files regenie wrote for the same command
-    (the bt_kfold_synth case; regenie stops its fit at |score| < 5e-5, the driver at the maximiser: 2e-4 relative covers the difference).  Then
+    (the bt_kfold_synth case; regenie stops each warm-started fit at max|score| < 2.5e-4 -- numtol_firth, Regenie.hpp:224 -- the driver at the
+    maximiser, so the estimates differ by about score / information: 1e-3 relative is seen, 3e-3 is allowed).  Then
     `--step 2 --firth --approx --use-null-firth LIST --write-null-firth` on the rare variants: the stored estimates are start values only, so every
     result line equals the run without them, and the estimates Step 2 writes are those of its own null Firth fits."""
     from tests.util import synth_dosages, synth_rare_dosages, write_bed_bim, write_plink
@@ -140,12 +141,17 @@ def test_driver_write_and_use_null_firth(tmp_path):
         for x, y, z in zip(a[1:], b[1:], ref[1:]):
             tx, ty, tz = x.split(), y.split(), z.split()
             assert tx[:8] == ty[:8] == tz[:8] and tx[12] == ty[12] == tz[12]
-            for u, v, w in zip(tx[8:12], ty[8:12], tz[8:12]):
-                if "NA" in (u, v, w):
-                    assert u == v == w
-                    continue
+            if "NA" in tx[8:12] + ty[8:12] + tz[8:12]:
+                assert tx[8:12] == ty[8:12] == tz[8:12]
+                continue
+            for u, v in zip(tx[8:12], ty[8:12]):
                 assert float(v) == pytest.approx(float(u), rel=1e-6, abs=1e-9)          # the start values do not move the maximisers
-                assert float(v) == pytest.approx(float(w), rel=3e-4, abs=2e-9)          # regenie's own run with --use-null-firth
+            # regenie's own run with --use-null-firth.  Its corrected rows stop at |modified score| < 2.5e-4 (a few times 2.5e-4 * SE^2 from the
+            # root) and take the LRT one iteration before BETA: the bounds of test_cli_step2_bt_approx_firth_rare_variants_against_reference_output
+            beta, se, chisq, logp = (float(t) for t in tz[8:12])
+            assert abs(float(ty[8]) - beta) <= 8e-4 * se * se + 2e-5 * abs(beta) + 5e-6, (y, z)
+            assert float(ty[9]) == pytest.approx(se, rel=2e-4) and float(ty[10]) == pytest.approx(chisq, rel=2e-3, abs=2e-5), (y, z)
+            assert float(ty[11]) == pytest.approx(logp, rel=2e-3, abs=2e-5), (y, z)
         # what Step 2 wrote: the chromosomes it tested, the estimates of its own null Firth fits (= regenie's, to its stopping tolerance)
         got = _read_firth(os.path.join(d, "warm_%d.firth" % k))
         ref2 = _read_firth(os.path.join(REF_OUT, "step2", "bt_firth_rare_usenull_%d.firth.gz" % k))
