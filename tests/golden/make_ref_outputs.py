@@ -63,14 +63,22 @@ CASES = {
     # --step 2 --ct come from a --qt run on the same file: any LOCO prediction is a valid offset of the null Poisson model
     "ct_synth": (["--step", "1", "--bed", "{S}", "--covarFile", "{S}.covar", "--phenoFile", "{S}.pheno", "--bsize", "100", "--qt"],
                  dict(M=300, N=1500, chroms=[1] * 160 + [2] * 140, P=2, seed=23, binary=False, counts=True, missing_pheno=0.03, miss_rate=0.01)),
+    # time-to-event traits (--t2e, Cox ridge at level 1): two traits with tied event times and 3 % missing (time, event) pairs; the
+    # phenotype file {S}.t2e comes from tests/util.py write_t2e_pheno
+    "t2e_kfold_synth": (["--step", "1", "--bed", "{S}", "--covarFile", "{S}.covar", "--phenoFile", "{S}.t2e", "--bsize", "100", "--t2e",
+                         "--phenoColList", "T1,T2", "--eventColList", "E1,E2"],
+                        dict(M=300, N=1200, chroms=[1] * 120 + [2] * 100 + [7] * 80, P=2, seed=31, binary=False, missing_pheno=0.0, miss_rate=0.01,
+                             t2e=dict(ntraits=2, missing=0.03))),
 }
 
 
 def synth(prefix, spec):
-    from tests.util import synth_dosages, write_plink
+    from tests.util import synth_dosages, write_plink, write_t2e_pheno
     g = synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"])
     write_plink(prefix, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"],
                 missing_pheno=spec["missing_pheno"], counts=spec.get("counts", False))
+    if spec.get("t2e"):
+        write_t2e_pheno(prefix + ".t2e", g, seed=spec["seed"], **spec["t2e"])
 
 
 def table_lines(log_text):
@@ -79,7 +87,7 @@ def table_lines(log_text):
     for ln in log_text.splitlines():
         if ln.startswith("phenotype ") and ln.rstrip().endswith(":"):
             on = True
-        if on and (ln.startswith("phenotype ") or ": Rsq = " in ln):
+        if on and (ln.startswith("phenotype ") or ": Rsq = " in ln or ": Deviance = " in ln):
             keep.append(ln.rstrip())
     return keep
 
@@ -214,6 +222,12 @@ def main():
         OUT = os.path.abspath(sys.argv[2])
     if not os.path.exists(REGENIE):
         raise SystemExit("build the reference first: make -C oracle")
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":      # (re)generate the Step-1 cases named after --only, leave the rest alone
+        with tempfile.TemporaryDirectory() as wd:
+            for name in sys.argv[2:]:
+                run_case(name, CASES[name][0], CASES[name][1], wd)
+                print("ok", name)
+        return
     if os.path.isdir(OUT):
         shutil.rmtree(OUT)
     os.makedirs(OUT)

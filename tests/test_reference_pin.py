@@ -157,6 +157,51 @@ def test_qt_kfold_synthetic_missing(tmp_path):
     check_case("qt_kfold_synth_missing", orc.Step1Options(bsize=128), synth=True, tmp_path=tmp_path)
 
 
+def synth_t2e_case(tmp_path, name="t2e_kfold_synth"):
+    """The synthetic time-to-event data set of a fixture: (meta, prefix); phenotype file = prefix + '.t2e'."""
+    from tests.util import synth_dosages, write_plink, write_t2e_pheno
+    meta = json.load(open(os.path.join(REF_OUT, name, "meta.json")))
+    spec = meta["synthetic"]
+    pre = str(tmp_path / "synth")
+    g = synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"])
+    write_plink(pre, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    write_t2e_pheno(pre + ".t2e", g, seed=spec["seed"], **spec["t2e"])
+    return meta, pre
+
+
+T2E_RE = re.compile(r"^\s*(\S+)\s*: Deviance = ([^<]+)(<- min value)?")
+
+
+def test_t2e_cox_ridge_synthetic(tmp_path):
+    """`--step 1 --t2e` (oracle/regenie_step1_t2e.py: null Cox model, Cox ridge paths per fold by cyclic coordinate descent, held-out
+    deviances, out-of-fold predictions) against regenie's own run: two traits with tied event times and missing pairs; the penalties
+    and deviances of the log to its six digits, the same penalty selected, the LOCO files at the text's resolution."""
+    from oracle import regenie_step1_t2e as t2e
+    meta, pre = synth_t2e_case(tmp_path)
+    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".t2e", covar_file=pre + ".covar", bsize=100)
+    res = t2e.run_step1_t2e(opt, {"T1": "E1", "T2": "E2"})
+    ref_lines = [ln for ln in meta["table"]]
+    got_lines = [ln.rstrip() for ln in res["log"]]
+    assert [ln for ln in ref_lines if ln.startswith("phenotype")] == [ln.rstrip() for ln in got_lines if ln.startswith("phenotype")] == \
+        ["phenotype 1 (T1) :", "phenotype 3 (T2) :"]
+    for a, b in zip(ref_lines, got_lines):
+        if a.startswith("phenotype"):
+            continue
+        ma, mb = T2E_RE.match(a), T2E_RE.match(b)
+        assert ma and mb, (a, b)
+        assert float(mb.group(1)) == pytest.approx(float(ma.group(1)), rel=2e-5) and float(mb.group(2)) == pytest.approx(float(ma.group(2)), rel=2e-5)
+        assert bool(ma.group(3)) == bool(mb.group(3)), (a, b)
+    prep = res["prep"]
+    order = [i for i in sorted(range(len(prep.ids)), key=lambda i: prep.ids[i]) if prep.ind_in_analysis[i]]
+    for tn in ("T1", "T2"):
+        ti = prep.pheno_names.index(tn)
+        ids, ref = read_loco_gz(os.path.join(REF_OUT, "t2e_kfold_synth", "out_%d.loco.gz" % (ti + 1)))
+        got = res["traits"][tn]["loco"][order, :].T.copy()
+        got[:, ~prep.mask[order, ti]] = np.nan
+        assert ids == [prep.ids[i] for i in order]
+        assert_text_equal(got, ref, "t2e_kfold_synth %s" % tn)
+
+
 def test_level0_predictors_full_precision():
     """The reference's --run-l0 job files are its level-0 predictors as raw doubles, column-major N x (blocks*R0) per
     phenotype (Step1_Models.cpp:728-734): ridge_level_0 of the oracle against them at fp64 resolution."""

@@ -130,6 +130,30 @@ def write_plink(prefix, g, chroms, P=2, ncov=2, seed=3, h2=0.2, missing_pheno=0.
             fh.write("%d %d " % (i + 1, i + 1) + " ".join(("NA" if miss[i, p] else "%.15g" % Y[i, p]) for p in range(P)) + "\n")
 
 
+def write_t2e_pheno(path, g, ntraits=2, seed=3, missing=0.0, decimals=2):
+    """Time-to-event phenotypes for the samples of write_plink(prefix, g, ...): columns T1 E1 T2 E2 ...; event times exponential with
+    a hazard that carries a polygenic signal, independent exponential censoring, times rounded to `decimals` (tied event times),
+    `missing` of the (time, event) pairs NA."""
+    M, N = g.shape
+    rng = np.random.default_rng(seed + 1000)
+    gs = np.where(g < 0, 0, g).astype(np.float64)
+    gs = (gs - gs.mean(axis=1, keepdims=True)) / (gs.std(axis=1, keepdims=True) + 1e-12)
+    cols = []
+    for p in range(ntraits):
+        idx = rng.choice(M, min(M, 40), replace=False)
+        lp = gs[idx].T @ (rng.standard_normal(idx.size) * np.sqrt(0.3 / idx.size))
+        t_ev = rng.exponential(1.0, N) * np.exp(-lp) * (4.0 + p)
+        t_c = rng.exponential(6.0 + 2 * p, N)
+        tm = np.round(np.minimum(t_ev, t_c), decimals) + 10.0 ** -decimals
+        ev = (t_ev <= t_c).astype(int)
+        miss = rng.random(N) < missing
+        cols.append((tm, ev, miss))
+    with open(path, "w") as fh:
+        fh.write("FID IID " + " ".join("T%d E%d" % (p + 1, p + 1) for p in range(ntraits)) + "\n")
+        for i in range(N):
+            fh.write("%d %d " % (i + 1, i + 1) + " ".join("NA NA" if m[i] else "%.15g %d" % (t[i], e[i]) for t, e, m in cols) + "\n")
+
+
 # ---- any trait mode / CV scheme through the C ABI, and the matching oracle run ---------------------
 def _use_loocv(opt, prep, force_kfold):
     return bool(opt.loocv or (opt.bt and prep.n_analyzed < 5000 and not force_kfold))   # Data.cpp:353-356
