@@ -237,6 +237,29 @@ int rg_l1_bt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, const double* y
              const int32_t* cols_per_chr, double* cumsum_out, int32_t* converged_out,
              int32_t* best_out, double* pred_out);
 
+/* ---- level 1, time-to-event traits (--t2e): Cox ridge, K-fold ------------------------------------
+ * Replaces ridge_cox_level_1 (Step1_Models.cpp:2228-2305) with cox_ridge / cox_ridge_path (cox_ridge.cpp:8-302) and
+ * survival_data::setup (survival_data.cpp:9-150), the penalty grid of check_l0 (Step1_Models.cpp:2105-2113) from
+ * getCoxLambdaMax (:446-450), the deviance selection (Data.cpp:1026-1050) and make_predictions_cox (Data.cpp:1714-1755).
+ * One trait per call: `pheno` is the phenotype of the problem whose level-0 predictors and sample mask belong to the TIME column.
+ *   time, event, offset : N each, sample order: phenodt::phenotypes_raw of the time and the event column (0 / 1; entries of masked
+ *                         samples are not read) and ests::offset_nullreg (the null Cox model's linear predictor)
+ *   opt                 : iteration limits / tolerances (NULL = the reference defaults below)
+ *   tau_out, deviance_out : n_ridge_l1 each: the penalties (largest first) and the held-out deviances summed over the folds
+ *   converged_out       : 0 marks pheno_l1_not_converged (predictions skipped, Data.cpp:1016); best_out: index of the smallest deviance
+ *   pred_out            : nchr x N (or nchrom x N in LOCO output mode) for this trait */
+typedef struct rg_cox_options {
+  int32_t niter_max;                   /* 50    params.niter_max (not used by level 1; kept next to its line-search twin) */
+  int32_t niter_max_line_search;       /* 25    params.niter_max_line_search */
+  int32_t niter_max_ridge;             /* 100   params.niter_max_ridge */
+  int32_t niter_max_line_search_ridge; /* 100   params.niter_max_line_search_ridge */
+  double numtol_cox;                   /* 2.5e-4 params.numtol_cox */
+  double l1_ridge_tol;                 /* 1e-4  params.l1_ridge_tol */
+} rg_cox_options;
+int rg_l1_cox(rg_ctx* ctx, int32_t pheno, int32_t n_ridge_l1, const double* time, const double* event, const double* offset,
+              const rg_cox_options* opt, int32_t nchr, const int32_t* cols_per_chr, double* tau_out, double* deviance_out,
+              int32_t* converged_out, int32_t* best_out, double* pred_out);
+
 /* ---- introspection used by bench.py (timing of the dominant kernels with HIP events) --------- */
 typedef struct rg_timing {
   double ms_prep, ms_xy, ms_gram, ms_assemble, ms_chol, ms_solve, ms_pred, ms_l1_gram, ms_l1_chol,

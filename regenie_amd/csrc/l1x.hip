@@ -1100,3 +1100,408 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
   }
   return RG_OK;
 }
+
+// =========================================================================================================
+// Time-to-event traits: Cox ridge at level 1 (ridge_cox_level_1, Step1_Models.cpp:2228-2305; cox_ridge.cpp; survival_data.cpp)
+// =========================================================================================================
+// The reference fits, per CV fold and penalty, the Cox partial likelihood with ridge penalty by IRLS on the DIAGONAL of the Hessian:
+// an iteration computes the gradient g and diagonal h of the log partial likelihood at eta (cumulative sums over the samples sorted by
+// time), the working response z = (eta - offset) - g / h, and makes ONE cyclic pass over the L coordinates
+//   beta_k <- (r . x_k + beta_k s_k) / (s_k - lambda),  r = h (z - eta + offset) with the eta of the moment,  s_k = sum x_k^2 h
+// (cox_ridge.cpp:116-178).  With the weights w = -h >= 0 that pass is one Gauss-Seidel sweep on (X^T W X + lambda I) beta = X^T W z
+// started at the current beta, so the N-sized work of an iteration is the weighted Gram k_wgram128 already computes for the logistic
+// ridge (2 N L^2 flop on the fp64 matrix cores instead of L dependent passes over N), plus
+//   k_cox_eta   eta = offset + W^T beta on the samples of the chain (training fold, held-out fold, or all)
+//   k_cox_scan  one workgroup: the samples in time order (a permutation the host sorts once per chain) -> mean of eta, the risk-set
+//               sums by chunked scans (1,024 threads, a contiguous chunk each, chunk totals scanned in LDS), g, h, the weights and z
+//               in position order, and the deviance (cox_ridge.cpp:60-114)
+//   k_cox_xtg / k_cox_sweep   X^T g = c - G beta (a row per workgroup), then the sweep by one workgroup with v = c - G beta in LDS,
+//               a rank-one update of v per coordinate, on the symmetrised Gram (k_cox_symm)
+// The host keeps the reference's control flow: step halving against the previous deviance, the two stopping rules, the warm-started
+// path over the penalties (largest first, every fit measured from the FIRST fit's starting deviance, cox_ridge.cpp:254-270), the
+// held-out deviance of every solution, the penalty grid from the score at beta = 0.  Chains (folds) run one after the other: an
+// iteration is dominated by its Gram, there is nothing to gain from interleaving them.
+#define COX_T 1024
+struct CoxChain {                 // one risk-set structure: a training fold, a held-out fold, or all samples
+  const int32_t* order;           // [n] position of the i-th sample in (time asc, event before censored) order
+  const uint8_t* flags;           // [n] bit 0: in the chain's sample set (keep), bit 1: status == 1, bit 2: dd == 1 (first event of its time)
+  const double* ww;               // [n] tie-collapsed event weights (0 unless dd)
+  int n; double w;                // w = 1 / neff
+};
+__global__ __launch_bounds__(256) void k_cox_eta(const double* W, int64_t Np, int L, int P, int p, const double* beta, const double* off,
+                                                 const double* keepv, double* eta) {
+  __shared__ double sB[256];
+  const int64_t pos = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  double acc = 0.0;
+  for (int c0 = 0; c0 < L; c0 += 256) {
+    __syncthreads();
+    sB[threadIdx.x] = (c0 + threadIdx.x < L) ? beta[c0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    if (pos < Np) {
+      const int cn = min(256, L - c0);
+      const double* w = W + ((int64_t)c0 * P + p) * Np + pos;
+      for (int c = 0; c < cn; ++c) acc = fma(w[(int64_t)c * P * Np], sB[c], acc);
+    }
+  }
+  if (pos < Np) eta[pos] = keepv[pos] != 0.0 ? acc + off[pos] : 0.0;     // mask.select(X beta + offset, 0)
+}
+
+__device__ __forceinline__ double cox_block_sum(double v, double* red) {     // COX_T threads; result in every thread
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int i = 0; i < COX_T / 64; ++i) t += red[i];
+  return t;
+}
+// exclusive scan of one value per thread over the workgroup, in thread order (rev = 0) or reverse thread order (rev = 1)
+__device__ __forceinline__ double cox_block_excl(double v, double* buf, int rev) {
+  __syncthreads();
+  buf[threadIdx.x] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {         // 1,024 sequential additions: negligible next to the chunk passes, and a fixed order
+    double run = 0.0;
+    if (!rev) for (int i = 0; i < COX_T; ++i) { const double x = buf[i]; buf[i] = run; run += x; }
+    else for (int i = COX_T - 1; i >= 0; --i) { const double x = buf[i]; buf[i] = run; run += x; }
+  }
+  __syncthreads();
+  return buf[threadIdx.x];
+}
+// out[0] = log partial likelihood part sum_w eta [event] - sum ww log(risk set), out[1] = mean of eta over the chain's samples
+__global__ __launch_bounds__(COX_T) void k_cox_scan(CoxChain ch, const double* eta, const double* off, double* rsk /*[n] scratch*/,
+                                                    double* wv, double* zv, double* gv, int want_grad, double* out) {
+  __shared__ double red[COX_T / 64];
+  __shared__ double buf[COX_T];
+  const int n = ch.n, C = (n + COX_T - 1) / COX_T;
+  const int i0 = min(n, (int)threadIdx.x * C), i1 = min(n, i0 + C);
+  const double w = ch.w;
+  double s = 0.0;
+  for (int i = i0; i < i1; ++i) if (ch.flags[i] & 1) s += eta[ch.order[i]];
+  const double mean = cox_block_sum(s, red) * w;              // sum(eta w_orig) / sum(w_orig), w_orig = 1 / neff on the chain's samples
+  // reverse cumulative sums of w exp(eta - mean) (gradient) and w exp(eta) (likelihood)
+  double se = 0.0, sl = 0.0;
+  for (int i = i0; i < i1; ++i)
+    if (ch.flags[i] & 1) { const double e = eta[ch.order[i]]; se += w * exp(e - mean); sl += w * exp(e); }
+  double run_e = cox_block_excl(se, buf, 1);
+  double run_l = cox_block_excl(sl, buf, 1);
+  double ll = 0.0, sa = 0.0, sb = 0.0;
+  for (int i = i1 - 1; i >= i0; --i) {
+    const uint8_t f = ch.flags[i];
+    const double e = eta[ch.order[i]];
+    if (f & 1) { run_e += w * exp(e - mean); run_l += w * exp(e); }
+    rsk[i] = run_e;
+    if ((f & 1) && (f & 2)) ll += w * e;
+    if ((f & 1) && (f & 4)) {
+      ll -= ch.ww[i] * log(run_l);
+      sa += ch.ww[i] / run_e;
+      sb += ch.ww[i] / (run_e * run_e);
+    }
+  }
+  const double tot = cox_block_sum(ll, red);
+  if (threadIdx.x == 0) { out[0] = tot; out[1] = mean; }
+  if (!want_grad) return;
+  double A = cox_block_excl(sa, buf, 0);
+  double B = cox_block_excl(sb, buf, 0);
+  for (int i = i0; i < i1; ++i) {
+    const uint8_t f = ch.flags[i];
+    const int pos = ch.order[i];
+    if ((f & 1) && (f & 4)) { const double r = rsk[i]; A += ch.ww[i] / r; B += ch.ww[i] / (r * r); }
+    double g = 0.0, h = 0.0;
+    if (f & 1) {
+      const double we = w * exp(eta[pos] - mean);
+      g = w * ((f & 2) ? 1.0 : 0.0) - we * A;
+      h = we * we * B - we * A;
+    }
+    wv[pos] = -h;
+    zv[pos] = (f & 1) ? (eta[pos] - off[pos]) - (h != 0.0 ? g / h : 0.0) : 0.0;
+    gv[pos] = g;
+  }
+}
+// xtw[c] = sum_pos W[c][pos] g[pos]
+__global__ __launch_bounds__(256) void k_cox_xtv(const double* W, int64_t Np, int P, int p, const double* g, double* out) {
+  __shared__ double sred[4];
+  const double* w = W + ((int64_t)blockIdx.x * P + p) * Np;
+  double acc = 0.0;
+  for (int64_t pos = threadIdx.x; pos < Np; pos += 256) acc = fma(w[pos], g[pos], acc);
+  const double s = block_sum_256(acc, sred);
+  if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+// upper triangle <- lower triangle of the n64 x n64 system (32 x 32 tiles)
+__global__ __launch_bounds__(256) void k_cox_symm(double* S, int n64) {
+  __shared__ double t[32][33];
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  for (int r = threadIdx.x >> 5; r < 32; r += 8) t[r][threadIdx.x & 31] = S[(int64_t)(bi * 32 + r) * n64 + bj * 32 + (threadIdx.x & 31)];
+  __syncthreads();
+  for (int r = threadIdx.x >> 5; r < 32; r += 8) {
+    const int row = bj * 32 + r, col = bi * 32 + (threadIdx.x & 31);
+    if (col > row) S[(int64_t)row * n64 + col] = t[threadIdx.x & 31][r];
+  }
+}
+// xtg[k] = c[k] - sum_j G[k][j] beta[j]  (G = system minus lambda on the diagonal; c = row n64 of the system)
+__global__ __launch_bounds__(256) void k_cox_xtg(const double* S, int n64, int L, double lam, const double* beta, double* xtg) {
+  __shared__ double sred[4];
+  const int k = blockIdx.x;
+  const double* row = S + (int64_t)k * n64;
+  double acc = 0.0;
+  for (int j = threadIdx.x; j < L; j += 256) acc = fma(row[j] - (j == k ? lam : 0.0), beta[j], acc);
+  const double s = block_sum_256(acc, sred);
+  if (threadIdx.x == 0) xtg[k] = S[(int64_t)n64 * n64 + k] - s;
+}
+// one cyclic pass: v = c - G beta kept in LDS; coordinate k: beta_k' = (v_k + G_kk beta_k) / (G_kk + lambda), v -= (beta_k' - beta_k) G[k][:]
+__global__ __launch_bounds__(COX_T) void k_cox_sweep(const double* S, int n64, int L, double lam, const double* xtg, double* beta) {
+  extern __shared__ double v[];      // [L]
+  __shared__ double bk[2];
+  for (int j = threadIdx.x; j < L; j += COX_T) v[j] = xtg[j];
+  __syncthreads();
+  for (int k = 0; k < L; ++k) {
+    const double* row = S + (int64_t)k * n64;
+    if (threadIdx.x == 0) {
+      const double skk = row[k], b0 = beta[k];
+      const double b1 = (v[k] + (skk - lam) * b0) / skk;
+      beta[k] = b1;
+      bk[0] = b1 - b0;
+    }
+    __syncthreads();
+    const double d = bk[0];
+    for (int j = threadIdx.x; j < L; j += COX_T) v[j] -= d * (row[j] - (j == k ? lam : 0.0));
+    __syncthreads();
+  }
+}
+
+namespace {
+
+struct CoxHostChain {              // survival_data::setup (survival_data.cpp:9-100) for one sample set
+  std::vector<int32_t> order; std::vector<uint8_t> flags; std::vector<double> ww;
+  double neff = 0, lsat = 0;
+};
+// pos_of[n]: position of compact sample n; in_set[n]: 1 for the chain's samples
+void cox_build_chain(const double* time, const double* event, const std::vector<uint8_t>& in_set, const std::vector<int64_t>& posc, CoxHostChain& c) {
+  const int n = (int)in_set.size();
+  std::vector<int32_t> idx(n);
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  auto st = [&](int i) { return in_set[i] ? event[i] : -999.0; };
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) {      // _getOrder (:104-127): time, then events first
+    if (time[a] != time[b]) return time[a] < time[b];
+    return st(a) > st(b);
+  });
+  c.order.resize(n); c.flags.assign(n, 0); c.ww.assign(n, 0.0);
+  c.neff = 0;
+  for (int i = 0; i < n; ++i) c.neff += in_set[i] ? 1.0 : 0.0;
+  const double w = 1.0 / c.neff;
+  std::vector<int> ev;
+  for (int i = 0; i < n; ++i) {
+    const int s = idx[i];
+    c.order[i] = (int32_t)posc[s];
+    uint8_t f = 0;
+    if (in_set[s]) { f |= 1; if (event[s] == 1.0) { f |= 2 | 4; ev.push_back(i); c.ww[i] = w; } }
+    c.flags[i] = f;
+  }
+  // ties among the event times (_findTies :129-150): the first event of a time carries the weight of all of them
+  std::vector<double> wsub;
+  for (size_t a = 0; a < ev.size();) {
+    size_t b = a + 1;
+    while (b < ev.size() && time[idx[ev[b]]] == time[idx[ev[a]]]) ++b;
+    if (b - a > 1) {
+      for (size_t t = a + 1; t < b; ++t) { c.flags[ev[t]] &= (uint8_t)~4; c.ww[ev[t]] = 0.0; }
+      c.ww[ev[a]] = (double)(b - a) * w;
+    }
+    wsub.push_back((double)(b - a) * w);
+    a = b;
+  }
+  c.lsat = 0;                                                        // _coxDeviance (cox_ridge.cpp:93-114)
+  for (double x : wsub) c.lsat -= x * std::log(x);
+}
+
+struct CoxState {
+  rg_ctx* ctx; L1Common* c; int pw;
+  double *d_eta, *d_off, *d_keep, *d_wv, *d_zv, *d_gv, *d_rsk, *d_beta, *d_xtg, *d_out, *d_sys, *d_tau1;
+  int32_t* d_order; uint8_t* d_flags; double* d_ww; int32_t* d_map;
+  CoxChain dev{};
+  double lsat = 0;
+};
+
+int cox_load_chain(CoxState& s, const CoxHostChain& h, const std::vector<double>& keep_pos) {
+  rg_ctx* ctx = s.ctx;
+  hipStream_t st = s.c->st;
+  const int n = (int)h.order.size();
+  L1X_HIP(hipMemcpyAsync(s.d_order, h.order.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+  L1X_HIP(hipMemcpyAsync(s.d_flags, h.flags.data(), n, hipMemcpyHostToDevice, st));
+  L1X_HIP(hipMemcpyAsync(s.d_ww, h.ww.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
+  L1X_HIP(hipMemcpyAsync(s.d_keep, keep_pos.data(), sizeof(double) * s.c->Np, hipMemcpyHostToDevice, st));
+  L1X_HIP(hipStreamSynchronize(st));
+  s.dev = CoxChain{s.d_order, s.d_flags, s.d_ww, n, 1.0 / h.neff};
+  s.lsat = h.lsat;
+  return RG_OK;
+}
+// eta at beta, then the deviance (and, if asked, gradient / weights / working response) of the loaded chain
+int cox_eval(CoxState& s, const std::vector<double>& beta, bool want_grad, double* deviance) {
+  rg_ctx* ctx = s.ctx;
+  L1Common& c = *s.c;
+  hipStream_t st = c.st;
+  L1X_HIP(hipMemcpyAsync(s.d_beta, beta.data(), sizeof(double) * c.L, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_cox_eta, dim3((unsigned)((c.Np + 255) / 256)), dim3(256), 0, st, c.Wv, c.Np, c.L, c.Pv, s.pw, s.d_beta, s.d_off,
+                     s.d_keep, s.d_eta);
+  hipLaunchKernelGGL(k_cox_scan, dim3(1), dim3(COX_T), 0, st, s.dev, s.d_eta, s.d_off, s.d_rsk, s.d_wv, s.d_zv, s.d_gv, want_grad ? 1 : 0,
+                     s.d_out);
+  double out[2];
+  L1X_HIP(hipMemcpyAsync(out, s.d_out, sizeof(out), hipMemcpyDeviceToHost, st));
+  L1X_HIP(hipStreamSynchronize(st));
+  *deviance = 2.0 * (s.lsat - out[0]);
+  return RG_OK;
+}
+// one IRLS iteration's coordinate pass at the state of the last cox_eval(want_grad): beta in/out, xtg = X^T g out
+int cox_sweep(CoxState& s, double lam, std::vector<double>& beta, std::vector<double>& xtg) {
+  rg_ctx* ctx = s.ctx;
+  L1Common& c = *s.c;
+  hipStream_t st = c.st;
+  const int32_t zero = 0;
+  L1X_HIP(hipMemcpyAsync(s.d_map, &zero, sizeof(int32_t), hipMemcpyHostToDevice, st));
+  L1X_HIP(hipMemcpyAsync(s.d_tau1, &lam, sizeof(double), hipMemcpyHostToDevice, st));
+  L1X_HIP(hipStreamSynchronize(st));
+  WgArgs g{c.Wv, ctx->d_zero, c.Np, c.L, c.Pv, s.pw, c.n64, s.d_wv, s.d_zv, s.d_tau1, s.d_map, 0, s.d_sys, c.msz};
+  { const int rcw = launch_wgram(ctx, st, g, c.T, 1); if (rcw) return rcw; }
+  hipLaunchKernelGGL(k_cox_symm, dim3(c.n64 / 32, c.n64 / 32), dim3(256), 0, st, s.d_sys, c.n64);
+  hipLaunchKernelGGL(k_cox_xtg, dim3(c.L), dim3(256), 0, st, s.d_sys, c.n64, c.L, lam, s.d_beta, s.d_xtg);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k_cox_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * c.L));
+  hipLaunchKernelGGL(k_cox_sweep, dim3(1), dim3(COX_T), sizeof(double) * c.L, st, s.d_sys, c.n64, c.L, lam, s.d_xtg, s.d_beta);
+  L1X_HIP(hipMemcpyAsync(beta.data(), s.d_beta, sizeof(double) * c.L, hipMemcpyDeviceToHost, st));
+  L1X_HIP(hipMemcpyAsync(xtg.data(), s.d_xtg, sizeof(double) * c.L, hipMemcpyDeviceToHost, st));
+  L1X_HIP(hipStreamSynchronize(st));
+  return RG_OK;
+}
+
+}  // namespace
+
+int rg_l1_cox_impl(rg_ctx* ctx, int pheno, int R1, const double* time, const double* event, const double* offset, const rg_cox_options* opt,
+                   int nchr, const int32_t* cols_per_chr, double* tau_out, double* deviance_out, int32_t* converged_out, int32_t* best_out,
+                   double* pred_out) {
+  if (R1 < 2 || R1 > 16) { ctx->err = "rg_l1_cox: n_ridge_l1 must be in [2,16]"; return RG_ERR_ARG; }
+  if (ctx->loocv) { ctx->err = "rg_l1_cox: time-to-event traits use K-fold cross-validation (Regenie.cpp:1199-1201)"; return RG_ERR_STATE; }
+  rg_cox_options o;
+  o.niter_max = 50; o.niter_max_line_search = 25; o.niter_max_ridge = 100; o.niter_max_line_search_ridge = 100;
+  o.numtol_cox = 2.5e-4; o.l1_ridge_tol = 1e-4;
+  if (opt) o = *opt;
+  L1Common c;
+  int rc = l1_common_init(ctx, c, nchr, cols_per_chr, "rg_l1_cox");
+  if (rc) return rc;
+  if (pheno < c.p0v || pheno >= c.p0v + c.P) { ctx->err = "rg_l1_cox: phenotype outside the level-1 view"; return RG_ERR_ARG; }
+  hipStream_t st = c.st;
+  const int L = c.L, n64 = c.n64, K = ctx->K;
+  const int64_t Np = c.Np, N = c.N;
+  const int pw = c.view ? pheno - c.p0v : pheno;
+  if ((size_t)L * sizeof(double) > 150 * 1024) { ctx->err = "rg_l1_cox: more level-0 predictors than the coordinate pass holds in LDS (19,200)"; return RG_ERR_ARG; }
+
+  CoxState s;
+  s.ctx = ctx; s.c = &c; s.pw = pw;
+  L1X_HIP(c.bufs.alloc(&s.d_eta, (size_t)Np)); L1X_HIP(c.bufs.alloc(&s.d_off, (size_t)Np)); L1X_HIP(c.bufs.alloc(&s.d_keep, (size_t)Np));
+  L1X_HIP(c.bufs.alloc(&s.d_wv, (size_t)Np)); L1X_HIP(c.bufs.alloc(&s.d_zv, (size_t)Np)); L1X_HIP(c.bufs.alloc(&s.d_gv, (size_t)Np));
+  L1X_HIP(c.bufs.alloc(&s.d_rsk, (size_t)N)); L1X_HIP(c.bufs.alloc(&s.d_beta, (size_t)n64)); L1X_HIP(c.bufs.alloc(&s.d_xtg, (size_t)n64));
+  L1X_HIP(c.bufs.alloc(&s.d_out, 2)); L1X_HIP(c.bufs.alloc(&s.d_sys, (size_t)c.msz)); L1X_HIP(c.bufs.alloc(&s.d_tau1, 1));
+  L1X_HIP(c.bufs.alloc(&s.d_order, (size_t)N)); L1X_HIP(c.bufs.alloc(&s.d_flags, (size_t)N)); L1X_HIP(c.bufs.alloc(&s.d_ww, (size_t)N));
+  L1X_HIP(c.bufs.alloc(&s.d_map, 1));
+  double* d_betas = nullptr;
+  L1X_HIP(c.bufs.alloc(&d_betas, (size_t)K * R1 * n64));
+  L1X_HIP(hipMemsetAsync(s.d_beta, 0, sizeof(double) * n64, st));
+  L1X_HIP(hipMemsetAsync(s.d_wv, 0, sizeof(double) * Np, st));
+  L1X_HIP(hipMemsetAsync(s.d_zv, 0, sizeof(double) * Np, st));
+  L1X_HIP(hipMemsetAsync(s.d_gv, 0, sizeof(double) * Np, st));
+  std::vector<double> hpos, hmask((size_t)Np);
+  to_pos(ctx, offset, hpos);
+  L1X_HIP(hipMemcpyAsync(s.d_off, hpos.data(), sizeof(double) * Np, hipMemcpyHostToDevice, st));
+  L1X_HIP(hipMemcpyAsync(hmask.data(), ctx->d_maskp + (int64_t)pheno * Np, sizeof(double) * Np, hipMemcpyDeviceToHost, st));
+  L1X_HIP(hipStreamSynchronize(st));
+  std::vector<uint8_t> mask((size_t)N), in_set((size_t)N);
+  std::vector<int> fold((size_t)N, 0);
+  for (int64_t n = 0; n < N; ++n) mask[n] = hmask[(size_t)ctx->h_posc[n]] != 0.0;
+  for (int f = 0; f < K; ++f)
+    for (int64_t n = ctx->fold_cstart[f]; n < ctx->fold_cstart[f + 1]; ++n) fold[n] = f;
+  auto load = [&](int kind, int f) -> int {     // kind 0: all samples, 1: training samples of fold f, 2: held-out samples of fold f
+    for (int64_t n = 0; n < N; ++n) in_set[n] = mask[n] && (kind == 0 || (kind == 1 ? fold[n] != f : fold[n] == f));
+    CoxHostChain h;
+    cox_build_chain(time, event, in_set, ctx->h_posc, h);
+    if (h.neff < 1) { ctx->err = "rg_l1_cox: a fold without samples"; return RG_ERR_ARG; }
+    std::vector<double> kp((size_t)Np, 0.0);
+    for (int64_t n = 0; n < N; ++n) if (in_set[n]) kp[(size_t)ctx->h_posc[n]] = 1.0;
+    return cox_load_chain(s, h, kp);
+  };
+
+  // ---- penalty grid: lambda_max = max |X^T g| / 1e-3 at beta = 0 on all samples (getCoxLambdaMax :446-450), then
+  //      tau_j = lambda_max * 1e-6^(j / (R1 - 1))  (check_l0 :2105-2113) ----
+  std::vector<double> beta((size_t)L, 0.0), xtg((size_t)L, 0.0), tau((size_t)R1);
+  double dev0 = 0;
+  if ((rc = load(0, 0))) return rc;
+  if ((rc = cox_eval(s, beta, true, &dev0))) return rc;
+  hipLaunchKernelGGL(k_cox_xtv, dim3(L), dim3(256), 0, st, c.Wv, Np, c.Pv, pw, s.d_gv, s.d_xtg);
+  L1X_HIP(hipMemcpyAsync(xtg.data(), s.d_xtg, sizeof(double) * L, hipMemcpyDeviceToHost, st));
+  L1X_HIP(hipStreamSynchronize(st));
+  double gmax = 0;
+  for (int k = 0; k < L; ++k) gmax = std::max(gmax, std::fabs(xtg[k]));
+  const double lam_max = gmax / 1e-3;
+  for (int j = 0; j < R1; ++j) tau[j] = std::exp((double)j / (R1 - 1) * std::log(1e-6) + std::log(lam_max));
+  for (int j = 0; j < R1; ++j) { tau_out[j] = tau[j]; deviance_out[j] = 0.0; }
+  *converged_out = 0; *best_out = 0;
+
+  // ---- per fold: the warm-started path, then the held-out deviance of each solution ----
+  std::vector<double> hbetas((size_t)K * R1 * n64, 0.0), beta_old((size_t)L);
+  bool all_conv = true;
+  auto sq = [&](const std::vector<double>& b) { double t = 0; for (int k = 0; k < L; ++k) t += b[k] * b[k]; return t; };
+  for (int f = 0; f < K; ++f) {
+    if ((rc = load(1, f))) return rc;
+    std::fill(beta.begin(), beta.end(), 0.0);
+    double dev_first = 0;
+    for (int j = 0; j < R1; ++j) {                   // cox_ridge_path::fit (cox_ridge.cpp:246-287)
+      const double lam = tau[j];
+      double dev_prev, dev;
+      if ((rc = cox_eval(s, beta, true, &dev))) return rc;     // state at the start values: gradient for the first pass
+      if (j == 0) dev_first = dev;
+      dev_prev = dev_first;                                    // every fit of the path starts its deviance record at the first fit's
+      double obj_prev = dev_prev + lam * sq(beta) / 2;
+      bool conv = false;
+      for (int t = 1; t <= o.niter_max_ridge; ++t) {           // cox_ridge::fit (:116-178)
+        beta_old = beta;
+        if ((rc = cox_sweep(s, lam, beta, xtg))) return rc;
+        if ((rc = cox_eval(s, beta, true, &dev))) return rc;
+        double obj = dev + lam * sq(beta) / 2;
+        if (dev - dev_prev > o.l1_ridge_tol) {                 // step halving towards the previous iterate
+          int ii = 0;
+          bool gave_up = false;
+          while (dev - dev_prev > o.l1_ridge_tol) {
+            if (++ii > o.niter_max_line_search_ridge) { gave_up = true; break; }
+            for (int k = 0; k < L; ++k) beta[k] = (beta[k] + beta_old[k]) / 2;
+            if ((rc = cox_eval(s, beta, true, &dev))) return rc;
+            obj = dev + lam * sq(beta) / 2;
+          }
+          if (gave_up) break;                                  // "cannot correct step size": the fit ends unconverged
+        }
+        double score = 0;
+        for (int k = 0; k < L; ++k) score = std::max(score, std::fabs(xtg[k] - lam * beta[k]));
+        const bool stop = std::fabs(obj - obj_prev) / (0.1 + std::fabs(obj)) < o.l1_ridge_tol || score < o.l1_ridge_tol;
+        dev_prev = dev; obj_prev = obj;
+        if (stop) { conv = true; break; }
+      }
+      all_conv = all_conv && conv;
+      std::memcpy(hbetas.data() + ((size_t)f * R1 + j) * n64, beta.data(), sizeof(double) * L);
+    }
+    if ((rc = load(2, f))) return rc;                           // held-out deviance (Step1_Models.cpp:2293-2297)
+    for (int j = 0; j < R1; ++j) {
+      std::vector<double> b(hbetas.begin() + ((size_t)f * R1 + j) * n64, hbetas.begin() + ((size_t)f * R1 + j) * n64 + L);
+      double dv = 0;
+      if ((rc = cox_eval(s, b, false, &dv))) return rc;
+      deviance_out[j] += dv;
+    }
+  }
+  if (!all_conv) return RG_OK;                                  // pheno_l1_not_converged: predictions are skipped (Data.cpp:1016-1021)
+  *converged_out = 1;
+  int best = 0; double minv = 1e10;
+  for (int j = 0; j < R1; ++j) if (deviance_out[j] < minv) { best = j; minv = deviance_out[j]; }      // no division by Neff (Data.cpp:1031)
+  *best_out = best;
+  L1X_HIP(hipMemcpyAsync(d_betas, hbetas.data(), sizeof(double) * hbetas.size(), hipMemcpyHostToDevice, st));
+  L1X_HIP(hipMemsetAsync(c.d_pred, 0, sizeof(double) * (size_t)nchr * N, st));
+  hipLaunchKernelGGL(k_fold_pred, dim3(ctx->n_c256), dim3(256), sizeof(double) * L, st, c.Wv, Np, L, c.Pv, pw, d_betas + (int64_t)best * n64,
+                     (int64_t)R1 * n64, ctx->d_c256_seg, ctx->d_c256_pos, ctx->d_c256_len, c.d_col0, nchr, ctx->d_cidx, N, c.d_pred);
+  { const int rce = rg_emit_pred(ctx, st, c.d_pred, nchr, 0, pred_out); if (rce) return rce; }
+  L1X_HIP(hipStreamSynchronize(st));
+  return RG_OK;
+}

@@ -730,6 +730,21 @@ int rg_l1_bt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, const double* y
                        best_out, pred_out);
 }
 
+int rg_l1_cox(rg_ctx* ctx, int32_t pheno, int32_t n_ridge_l1, const double* time, const double* event, const double* offset,
+              const rg_cox_options* opt, int32_t nchr, const int32_t* cols_per_chr, double* tau_out, double* deviance_out,
+              int32_t* converged_out, int32_t* best_out, double* pred_out) {
+  if (!ctx) return RG_ERR_ARG;
+  hipSetDevice(ctx->device);
+  if (!time || !event || !offset || nchr < 1 || !cols_per_chr || !tau_out || !deviance_out || !converged_out || !best_out || !pred_out ||
+      pheno < 0 || pheno >= ctx->P) {
+    ctx->err = "rg_l1_cox: bad arguments"; return RG_ERR_ARG;
+  }
+  int rc = rg_sync(ctx);
+  if (rc) return rc;
+  return rg_l1_cox_impl(ctx, pheno, n_ridge_l1, time, event, offset, opt, nchr, cols_per_chr, tau_out, deviance_out, converged_out,
+                        best_out, pred_out);
+}
+
 int rg_set_loco_output(rg_ctx* ctx, int32_t nchrom, const int32_t* chrom_ids, int32_t n_ids) {
   if (!ctx) return RG_ERR_ARG;
   if (nchrom <= 0) { ctx->loco_nchrom = 0; ctx->loco_chrom.clear(); return RG_OK; }

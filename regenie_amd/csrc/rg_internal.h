@@ -323,6 +323,9 @@ int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_
 // l1x.hip
 int rg_l1_qt_loocv_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_t* cols_per_chr,
                         double* cumsum_out, int32_t* best_out, double* pred_out);
+int rg_l1_cox_impl(rg_ctx* ctx, int pheno, int R1, const double* time, const double* event, const double* offset, const rg_cox_options* opt,
+                   int nchr, const int32_t* cols_per_chr, double* tau_out, double* deviance_out, int32_t* converged_out, int32_t* best_out,
+                   double* pred_out);
 int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, const double* offset,
                   const rg_bt_options* opt, int nchr, const int32_t* cols_per_chr, double* cumsum_out,
                   int32_t* converged_out, int32_t* best_out, double* pred_out);

@@ -37,6 +37,11 @@ class RgBtOptions(C.Structure):
                 ("l1_ridge_tol", C.c_double), ("tol", C.c_double)]
 
 
+class RgCoxOptions(C.Structure):
+    _fields_ = [("niter_max", C.c_int32), ("niter_max_line_search", C.c_int32), ("niter_max_ridge", C.c_int32),
+                ("niter_max_line_search_ridge", C.c_int32), ("numtol_cox", C.c_double), ("l1_ridge_tol", C.c_double)]
+
+
 class RgTiming(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("ms_prep", "ms_xy", "ms_gram", "ms_assemble", "ms_chol",
                                           "ms_solve", "ms_pred", "ms_l1_gram", "ms_l1_chol",
@@ -49,7 +54,7 @@ class RgTiming(C.Structure):
 
 EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_set_l0_workspace", "rg_w_rows", "rg_w_bytes",
            "rg_set_w_buffer", "rg_set_block_range", "rg_w_device_ptr", "rg_l0_blocks", "rg_l0_blocks_f64", "rg_sync", "rg_l0_get_w",
-           "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_set_collective", "rg_set_l1_view", "rg_set_loco_output", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
+           "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_l1_cox", "rg_set_collective", "rg_set_l1_view", "rg_set_loco_output", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
            "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak",
            # one node, several GPUs: level-0 hand-off over RCCL / peer copies; streamed ingest helpers (used by the C++ driver)
            "rg_group_create", "rg_group_destroy", "rg_l0_finish", "rg_group_prepare", "rg_group_abort", "rg_l0_batch_blocks", "rg_host_alloc", "rg_host_free",
@@ -102,6 +107,8 @@ def load_library() -> C.CDLL:
     lib.rg_l1_qt_loocv.argtypes = lib.rg_l1_qt.argtypes
     lib.rg_l1_bt.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.rg_l1_cox.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.rg_set_collective.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     lib.rg_set_l1_view.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
     lib.rg_set_loco_output.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
@@ -370,6 +377,25 @@ class Step1Engine:
                                       C.byref(o), nchr, cpc.ctypes.data, cs.ctypes.data, conv.ctypes.data,
                                       best.ctypes.data, pred.ctypes.data))
         return cs, conv.astype(bool), best, [pred[p].T.copy() for p in range(P)]
+
+    def l1_cox(self, pheno: int, time: np.ndarray, event: np.ndarray, offset: np.ndarray, cols_per_chr: Sequence[int], n_ridge_l1: int = 5,
+               niter_max_ridge: int = 100, niter_max_line_search_ridge: int = 100, l1_ridge_tol: float = 1e-4):
+        """Cox ridge level 1 of one time-to-event trait (--t2e; K-fold).  Returns (tau [R1], deviance [R1], converged, best, pred [N,nchr])."""
+        time = np.ascontiguousarray(time, dtype=np.float64)
+        event = np.ascontiguousarray(event, dtype=np.float64)
+        offset = np.ascontiguousarray(offset, dtype=np.float64)
+        assert time.shape == event.shape == offset.shape == (self.N,)
+        cpc = np.ascontiguousarray(cols_per_chr, dtype=np.int32)
+        nchr = cpc.size
+        o = RgCoxOptions(50, 25, niter_max_ridge, niter_max_line_search_ridge, 2.5e-4, l1_ridge_tol)
+        tau = np.zeros(n_ridge_l1)
+        dev = np.zeros(n_ridge_l1)
+        conv = C.c_int32(0)
+        best = C.c_int32(0)
+        pred = np.zeros((self._pred_rows(nchr), self.N))
+        self._check(self.lib.rg_l1_cox(self.h, int(pheno), int(n_ridge_l1), time.ctypes.data, event.ctypes.data, offset.ctypes.data, C.byref(o),
+                                       nchr, cpc.ctypes.data, tau.ctypes.data, dev.ctypes.data, C.byref(conv), C.byref(best), pred.ctypes.data))
+        return tau, dev, bool(conv.value), int(best.value), pred.T.copy()
 
     def set_loco_output(self, chroms: Optional[Sequence[int]], nchrom: int = 23):
         """LOCO output mode: the l1_* calls then return, per phenotype, the (N, nchrom) LOCO predictions (column c-1 leaves
