@@ -71,6 +71,8 @@ struct Params {
   double min_info = 0.0; bool set_min_info = false;             // --minINFO (step 2, dosages)
   bool bt = false, ct = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
        print_prs = false, force_step1 = false, lowmem = false, force_qt = false, cc12 = false, gz = false;
+  bool t2e = false;                        // --t2e: time-to-event traits (step 1: Cox ridge at level 1)
+  std::vector<std::string> event_cols;     // --eventColList, matching --phenoColList (the time columns) in order
   int min_case_count = 10, niter_max = 50, niter_max_line_search = 25, niter_max_ridge = 100;
   // level-0 job split (Data.cpp:232-309, :818-908)
   std::string split_file;              // --split-l0 prefix / --run-l0, --run-l1 master file
@@ -311,13 +313,17 @@ Params parse_args(int argc, char** argv) {
   auto list = [&](std::vector<std::string>& dst, const std::string& v) {
     for (auto& s : split_char(v, ',')) dst.push_back(s);
   };
+  bool saw_pheno_col = false, saw_pheno_collist = false;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     if (a == "--step") p.step = atoi(need(i).c_str());
     else if (a == "--bed") p.bed = need(i);
     else if (a == "--phenoFile" || a == "--p") p.pheno_file = need(i);
     else if (a == "--covarFile" || a == "--c") p.covar_file = need(i);
-    else if (a == "--phenoCol" || a == "--phenoColList") list(p.pheno_cols, need(i));
+    else if (a == "--phenoCol" || a == "--phenoColList") { if (a == "--phenoCol") saw_pheno_col = true; else saw_pheno_collist = true; list(p.pheno_cols, need(i)); }
+    else if (a == "--eventColList") list(p.event_cols, need(i));
+    else if (a == "--t2e") { p.t2e = true; p.bt = p.ct = false; }
+    else if (a == "--t2e-event-l0" || a == "--t2e-l1-pi6") usage_error("option '" + a + "' is not built (the level-0 response of a time-to-event trait is its time column, the penalties come from the score at beta = 0).");
     else if (a == "--covarCol" || a == "--covarColList") list(p.covar_cols, need(i));
     else if (a == "--catCovarList") list(p.cat_covar, need(i));
     else if (a == "--maxCatLevels") p.max_cat_levels = atoi(need(i).c_str());
@@ -337,9 +343,9 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--nauto") p.nchrom = atoi(need(i).c_str()) + 1;
     else if (a == "--device") p.device = atoi(need(i).c_str());
     else if (a == "--lowmem-prefix") { need(i); p.lowmem = true; }
-    else if (a == "--qt") { p.bt = false; p.ct = false; }
-    else if (a == "--bt") { p.bt = true; p.ct = false; }
-    else if (a == "--ct") { p.ct = true; p.bt = false; }
+    else if (a == "--qt") { p.bt = false; p.ct = false; p.t2e = false; }
+    else if (a == "--bt") { p.bt = true; p.ct = false; p.t2e = false; }
+    else if (a == "--ct") { p.ct = true; p.bt = false; p.t2e = false; }
     else if (a == "--loocv") p.loocv = true;
     else if (a == "--strict") p.strict = true;
     else if (a == "--ref-first") p.ref_first = true;
@@ -390,6 +396,15 @@ Params parse_args(int argc, char** argv) {
   }
   if (p.bt) p.rint = false;  // Regenie.cpp:432
   if (p.step != 1 && p.step != 2) usage_error("specify which mode regenie should be running using option --step.");
+  // time-to-event traits (Regenie.cpp:570-587, :1197-1201)
+  if (p.t2e && !p.event_cols.empty() && saw_pheno_col) usage_error("You must specify TTE phenotypes using '--phenoColList' (matching in order with events in '--eventColList').");
+  if (p.t2e && (p.event_cols.empty() || !saw_pheno_collist)) usage_error("You must specify both '--phenoColList' and '--eventColList' (same order) for time-to-event analysis.");
+  if (!p.event_cols.empty() && !p.t2e) usage_error("Option --eventColList must be used with '--t2e' for time-to-event analysis");
+  if (p.t2e && p.event_cols.size() != p.pheno_cols.size()) usage_error("'--phenoColList' and '--eventColList' must name the same number of columns.");
+  if (p.t2e && p.step == 2) usage_error("--step 2 --t2e (the Cox score test) is not built: time-to-event traits are supported in step 1.");
+  if (p.t2e && (p.run_l0 || p.run_l1 || p.split_l0)) usage_error("--t2e with the --split-l0 / --run-l0 / --run-l1 file protocol is not built.");
+  if (p.t2e && p.loocv) { std::cout << "WARNING: option --loocv cannot be used with option --t2e.\n"; p.loocv = false; }
+  if (p.t2e) p.rint = false;
   if (p.step == 2) {
     if (p.pred_list.empty()) usage_error("option '--pred' is required (use the _pred.list file written by step 1).");
     if (p.firth && !p.bt) usage_error("option '--firth' applies to binary traits (--bt).");
@@ -455,6 +470,12 @@ struct Run {
   std::vector<uint8_t> mask;                // col-major N x P
   std::vector<double> Yraw, offset;         // BT: phenotypes_raw (0/1) and offset_nullreg, col-major N x P
   std::vector<uint8_t> pheno_pass;          // BT: null logistic model converged
+  // --t2e: the phenotypes of the run are the TIME columns; Yraw = their raw values, Yevent the matching event columns (0 / 1),
+  // t2e_num[q] = 1-based position of time column q among the selected (time and event) columns of the file: the reference counts
+  // both as phenotypes, and names its outputs by that number (out_<num>.loco)
+  std::vector<double> Yevent;
+  std::vector<int> t2e_num;
+  int outnum(int q) const { return t2e_num.empty() ? q + 1 : t2e_num[q]; }
 };
 
 // ---- binary traits: covariate-only logistic regression (Step1_Models.cpp:54-222) ---------------------------
@@ -582,6 +603,106 @@ double norm_quantile(double p) {
     v = num / den;
   }
   return q < 0 ? -v : v;
+}
+
+// ---- time-to-event traits: the null Cox model of step 1 (fit_null_cox, Step1_Models.cpp:353-440) ------------------------------------------
+// cox_ridge with lambda = 0 on the covariates (cox_ridge.cpp:8-178; survival_data::setup, survival_data.cpp:9-100): IRLS on the diagonal of
+// the Hessian, one cyclic pass over the C coordinates per iteration, step halving on the deviance.  X: col-major N x C.  eta = X beta on
+// the unmasked samples, 0 elsewhere.  (Level 1 -- the same model on the thousands of level-0 predictors -- runs in the library: rg_l1_cox.)
+bool cox_null_fit(const double* time, const double* event, const uint8_t* mask, const double* X, int64_t N, int C, const Params& prm, std::vector<double>& eta) {
+  const int64_t n = N;
+  double neff = 0;
+  for (int64_t i = 0; i < n; ++i) neff += mask[i];
+  const double w = 1.0 / neff;
+  std::vector<int64_t> ord(n);
+  for (int64_t i = 0; i < n; ++i) ord[i] = i;
+  auto st = [&](int64_t i) { return mask[i] ? event[i] : -999.0; };
+  std::stable_sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) { return time[a] != time[b] ? time[a] < time[b] : st(a) > st(b); });
+  std::vector<uint8_t> keep(n), dd(n, 0), ev1(n, 0);
+  std::vector<double> ww(n, 0.0), wsub;
+  std::vector<int64_t> evs;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t s = ord[i];
+    keep[i] = mask[s];
+    if (mask[s] && event[s] == 1.0) { ev1[i] = dd[i] = 1; ww[i] = w; evs.push_back(i); }
+  }
+  for (size_t a = 0; a < evs.size();) {
+    size_t b = a + 1;
+    while (b < evs.size() && time[ord[evs[b]]] == time[ord[evs[a]]]) ++b;
+    if (b - a > 1) { for (size_t t = a + 1; t < b; ++t) { dd[evs[t]] = 0; ww[evs[t]] = 0.0; } ww[evs[a]] = (double)(b - a) * w; }
+    wsub.push_back((double)(b - a) * w);
+    a = b;
+  }
+  double lsat = 0;
+  for (double x : wsub) lsat -= x * std::log(x);
+  std::vector<double> beta(C, 0.0), beta_old(C), g(n), h(n), z(n), rsk(n);
+  eta.assign(n, 0.0);
+  auto deviance = [&]() {
+    double run = 0, ll = 0;
+    for (int64_t i = n - 1; i >= 0; --i) {
+      const double e = eta[ord[i]];
+      if (keep[i]) run += w * std::exp(e);
+      if (keep[i] && ev1[i]) ll += w * e;
+      if (keep[i] && dd[i]) ll -= ww[i] * std::log(run);
+    }
+    return 2.0 * (lsat - ll);
+  };
+  auto grad = [&]() {      // coxGrad (cox_ridge.cpp:60-82): g, h in sample order
+    double mean = 0;
+    for (int64_t i = 0; i < n; ++i) if (mask[i]) mean += eta[i];
+    mean *= w;
+    double run = 0;
+    for (int64_t i = n - 1; i >= 0; --i) { if (keep[i]) run += w * std::exp(eta[ord[i]] - mean); rsk[i] = run; }
+    double A = 0, B = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      if (keep[i] && dd[i]) { A += ww[i] / rsk[i]; B += ww[i] / (rsk[i] * rsk[i]); }
+      const int64_t s = ord[i];
+      if (keep[i]) { const double we = w * std::exp(eta[s] - mean); g[s] = w * (ev1[i] ? 1.0 : 0.0) - we * A; h[s] = we * we * B - we * A; }
+      else { g[s] = 0; h[s] = 0; }
+    }
+  };
+  auto set_eta = [&]() {
+    for (int64_t i = 0; i < n; ++i) {
+      double e = 0;
+      if (mask[i]) for (int c = 0; c < C; ++c) e += X[(size_t)c * N + i] * beta[c];
+      eta[i] = e;
+    }
+  };
+  const double tol = 2.5e-4;        // numtol_cox, Regenie.hpp:221
+  double dev_prev = deviance(), obj_prev = dev_prev;
+  for (int t = 1; t <= prm.niter_max; ++t) {
+    beta_old = beta;
+    grad();
+    for (int64_t i = 0; i < n; ++i) z[i] = (mask[i] ? eta[i] : 0.0) - (h[i] != 0 ? g[i] / h[i] : 0.0);
+    for (int k = 0; k < C; ++k) {
+      const double* xk = X + (size_t)k * N;
+      double rx = 0, s2 = 0;
+      for (int64_t i = 0; i < n; ++i) { rx += h[i] * (z[i] - eta[i]) * xk[i]; s2 += xk[i] * xk[i] * h[i]; }
+      const double b1 = (rx + beta[k] * s2) / s2;                 // lambda = 0
+      for (int64_t i = 0; i < n; ++i) if (mask[i]) eta[i] += xk[i] * (b1 - beta[k]);
+      beta[k] = b1;
+    }
+    double dev = deviance(), obj = dev;
+    if (dev - dev_prev > tol) {
+      int ii = 0;
+      while (dev - dev_prev > tol) {
+        if (++ii > prm.niter_max_line_search) return false;
+        for (int c = 0; c < C; ++c) beta[c] = (beta[c] + beta_old[c]) / 2;
+        set_eta();
+        dev = obj = deviance();
+      }
+    }
+    double score = 0;
+    for (int k = 0; k < C; ++k) {
+      double sx = 0;
+      for (int64_t i = 0; i < n; ++i) sx += g[i] * X[(size_t)k * N + i];
+      score = std::max(score, std::fabs(sx));
+    }
+    const bool stop = std::fabs(obj - obj_prev) / (0.1 + std::fabs(obj)) < tol || score < tol;
+    dev_prev = dev; obj_prev = obj;
+    if (stop) return true;
+  }
+  return false;
 }
 
 // fit_null_poisson + fit_poisson (Step1_Models.cpp:225-345) for one phenotype; offset may be null (zero); eta_out = offset + X beta on
@@ -1024,24 +1145,43 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     if (hdr[0] != "FID" || hdr[1] != "IID") throw std::runtime_error("header of phenotype file must start with: FID IID.");
     std::set<std::string> want(p.pheno_cols.begin(), p.pheno_cols.end());
     std::vector<int> keep_cols;
-    for (size_t j = 2; j < hdr.size(); ++j)
-      if (want.empty() || want.count(hdr[j])) { keep_cols.push_back((int)j); r.pheno_names.push_back(hdr[j]); }
-    r.P = (int)keep_cols.size();
+    if (p.t2e) {   // the TIME columns in file order, then their event columns (files->t2e_map, Regenie.cpp:578-585; Pheno.cpp:230-283)
+      std::vector<std::pair<int, int>> te;          // (header index of the time column, of its event column)
+      std::vector<int> all;
+      for (size_t k = 0; k < p.pheno_cols.size(); ++k) {
+        int tj = -1, ej = -1;
+        for (size_t j = 2; j < hdr.size(); ++j) { if (hdr[j] == p.pheno_cols[k]) tj = (int)j; if (hdr[j] == p.event_cols[k]) ej = (int)j; }
+        if (tj < 0 || ej < 0) throw std::runtime_error("time-to-event column '" + (tj < 0 ? p.pheno_cols[k] : p.event_cols[k]) + "' is not in the phenotype file.");
+        te.emplace_back(tj, ej);
+        all.push_back(tj); all.push_back(ej);
+      }
+      std::sort(te.begin(), te.end());
+      std::sort(all.begin(), all.end());
+      for (auto& x : te) { keep_cols.push_back(x.first); r.pheno_names.push_back(hdr[x.first]); r.t2e_num.push_back((int)(std::lower_bound(all.begin(), all.end(), x.first) - all.begin()) + 1); }
+      for (auto& x : te) keep_cols.push_back(x.second);
+      r.P = (int)te.size();
+    } else {
+      for (size_t j = 2; j < hdr.size(); ++j)
+        if (want.empty() || want.count(hdr[j])) { keep_cols.push_back((int)j); r.pheno_names.push_back(hdr[j]); }
+      r.P = (int)keep_cols.size();
+    }
+    const int NV = (int)keep_cols.size();        // values read per line (--t2e: a time and an event per trait)
     if (r.P < 1) throw std::runtime_error("need at least one phenotype.");
     sout << "n_pheno = " << r.P << "\n";
-    const bool strict = p.strict || r.P == 1;  // Pheno.cpp:198
+    const bool strict = p.strict || (r.P == 1 && !p.t2e);  // Pheno.cpp:198 (with --t2e the reference counts 2 columns per trait)
     if (strict) sout << "   -dropping observations with missing values at any of the phenotypes\n";
     else sout << "   -keeping and mean-imputing missing observations (done for each trait)\n";
     r.Y.assign((size_t)N * r.P, 0.0);
     r.mask.assign((size_t)N * r.P, 1);
-    if (p.bt || p.ct) r.Yraw.assign((size_t)N * r.P, 0.0);
+    if (p.bt || p.ct || p.t2e) r.Yraw.assign((size_t)N * r.P, 0.0);
+    if (p.t2e) r.Yevent.assign((size_t)N * r.P, 0.0);
     // The lines are tokenised, matched to their sample and converted by several threads (at 500,000 samples x 10 phenotypes one thread
     // needs 2 s); the checks and the bookkeeping below then run over the records in file order, exactly as a line-by-line reader would.
     std::vector<std::string> lines;
     while (std::getline(f, line)) lines.push_back(std::move(line));
     struct Rec { int64_t i; int state; };      // state 0: use, 1: blank line, 2: wrong number of columns, 3: a value that is not a number
     std::vector<Rec> recs(lines.size());
-    std::vector<double> vals(lines.size() * (size_t)r.P);
+    std::vector<double> vals(lines.size() * (size_t)NV);
     {
       const int nt = std::max(1, std::min(16, (int)std::thread::hardware_concurrency() - 1));
       const int nchunk = (int)std::min<size_t>(lines.size(), (size_t)nt * 4);
@@ -1055,7 +1195,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
           auto it = idx.find(t[0] + "_" + t[1]);
           if (it == idx.end()) continue;
           rc.i = it->second;
-          try { for (int q = 0; q < r.P; ++q) vals[li * (size_t)r.P + q] = convert_double(t[keep_cols[q]]); }
+          try { for (int q = 0; q < NV; ++q) vals[li * (size_t)NV + q] = convert_double(t[keep_cols[q]]); }
           catch (...) { rc.state = 3; }
         }
       });
@@ -1067,12 +1207,24 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
       const int64_t i = recs[li].i;
       std::vector<std::string> t;                     // the tokens again, for the messages of the rare failing line only
       auto tok = [&]() -> const std::vector<std::string>& { if (t.empty()) t = split_ws(lines[li]); return t; };
-      if (recs[li].state == 3) for (int q = 0; q < r.P; ++q) (void)convert_double(tok()[keep_cols[q]]);     // rethrows the conversion error
+      if (recs[li].state == 3) for (int q = 0; q < NV; ++q) (void)convert_double(tok()[keep_cols[q]]);     // rethrows the conversion error
       if (in_pheno[i]) throw std::runtime_error("individual appears more than once in phenotype file: FID=" + tok()[0] + " IID=" + tok()[1]);
       in_pheno[i] = 1;
       bool all_miss = true;
-      for (int q = 0; q < r.P; ++q) {
-        double v = vals[li * (size_t)r.P + q];
+      for (int q = 0; q < r.P && p.t2e; ++q) {   // Pheno.cpp:262-283
+        const double tv = vals[li * (size_t)NV + q];
+        double ev = vals[li * (size_t)NV + r.P + q];
+        if (p.cc12 && ev != MISSING) ev -= 1;
+        r.Y[(size_t)q * N + i] = r.Yraw[(size_t)q * N + i] = tv;
+        r.Yevent[(size_t)q * N + i] = ev;
+        if (tv < 0 && tv != MISSING) throw std::runtime_error("a phenotype time value is <0 for individual: FID=" + tok()[0] + " IID=" + tok()[1] + " Y=" + tok()[keep_cols[q]]);
+        if (ev != 0 && ev != 1 && ev != MISSING) throw std::runtime_error("a phenotype censor value is invalid for individual: FID=" + tok()[0] + " IID=" + tok()[1] + " Y=" + tok()[keep_cols[r.P + q]]);
+        if (tv != MISSING && ev == MISSING) throw std::runtime_error("a phenotype has missing censor with non-missing time for individual: FID=" + tok()[0] + " IID=" + tok()[1]);
+        if (tv == MISSING) { r.mask[(size_t)q * N + i] = 0; r.Yevent[(size_t)q * N + i] = MISSING; }
+        else all_miss = false;
+      }
+      for (int q = 0; q < r.P && !p.t2e; ++q) {
+        double v = vals[li * (size_t)NV + q];
         if (p.bt) {  // Pheno.cpp:260-283
           if (p.cc12 && v != MISSING) v -= 1;
           r.Yraw[(size_t)q * N + i] = v;
@@ -1222,7 +1374,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     Xraw.assign((size_t)N, 1.0);
   }
   // masks (Pheno.cpp:101, :810-841)
-  const bool strict = p.strict || r.P == 1;
+  const bool strict = p.strict || (r.P == 1 && !p.t2e);
   r.ain.assign(N, 0);
   r.n_analyzed = 0;
   for (int64_t i = 0; i < N; ++i) {
@@ -1239,7 +1391,8 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     for (int64_t i = 0; i < N; ++i) {
       r.mask[(size_t)q * N + i] &= r.ain[i];
       r.Y[(size_t)q * N + i] *= r.ain[i];
-      if (p.bt || p.ct) r.Yraw[(size_t)q * N + i] *= r.ain[i];
+      if (p.bt || p.ct || p.t2e) r.Yraw[(size_t)q * N + i] *= r.ain[i];
+      if (p.t2e) r.Yevent[(size_t)q * N + i] *= r.ain[i];
       r.neff[q] += r.mask[(size_t)q * N + i];
     }
   for (int c = 0; c < ncols; ++c)
@@ -1263,7 +1416,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     }
   }
   // pheno_impute_miss (QT): missing -> mean over analysed non-missing, then mask
-  for (int q = 0; q < r.P && (p.bt || p.ct); ++q) {  // non-QT: mean over the unmasked entries (Pheno.cpp:1921-1930)
+  for (int q = 0; q < r.P && (p.bt || p.ct || p.t2e); ++q) {  // non-QT: mean over the unmasked entries (Pheno.cpp:1921-1930)
     double total = 0.0, ns = 0.0;
     for (int64_t i = 0; i < N; ++i) if (r.mask[(size_t)q * N + i]) { total += r.Y[(size_t)q * N + i]; ns += 1.0; }
     for (int64_t i = 0; i < N; ++i) {
@@ -1272,7 +1425,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
       v *= r.mask[(size_t)q * N + i];
     }
   }
-  for (int q = 0; q < r.P && !(p.bt || p.ct); ++q) {
+  for (int q = 0; q < r.P && !(p.bt || p.ct || p.t2e); ++q) {
     double total = 0.0, ns = 0.0;
     std::set<double> distinct;
     for (int64_t i = 0; i < N; ++i) {
@@ -1286,6 +1439,24 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
       if (v == MISSING) v = total / ns;
       v *= r.mask[(size_t)q * N + i];
     }
+  }
+  if (p.t2e) {   // prep_run (Pheno.cpp:1078-1103) + getBasis with trait_mode 3 (:1663-1667): constant columns (the intercept) are dropped, the
+                 // others centred -- every row, analysed or not, as the reference does -- and scaled by their sd over the analysed samples
+    std::vector<double> X2;
+    int kept = 0;
+    for (int c = 0; c < ncols; ++c) {
+      double mu = 0.0, ss = 0.0;
+      for (int64_t i = 0; i < N; ++i) mu += Xraw[(size_t)c * N + i];
+      mu /= (double)N;
+      for (int64_t i = 0; i < N; ++i) { const double dlt = Xraw[(size_t)c * N + i] - mu; ss += dlt * dlt; }
+      const double sd = std::sqrt(ss) / std::sqrt((double)r.n_analyzed);
+      if (!(sd > 1e-6)) continue;        // const_cov_cox_tol, Regenie.hpp:228
+      for (int64_t i = 0; i < N; ++i) X2.push_back((Xraw[(size_t)c * N + i] - mu) / sd);
+      ++kept;
+    }
+    if (kept == 0) throw std::runtime_error("--t2e without a non-constant covariate is not built (the null Cox model needs one).");
+    Xraw.swap(X2);
+    ncols = kept;
   }
   // getBasis (Pheno.cpp:1660-1681)
   std::vector<double> xtx((size_t)ncols * ncols, 0.0), d, V;
@@ -1320,6 +1491,17 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
       if (!ok) ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, false, eta, nullptr, nullptr, &b0);
       if (!ok) { r.pheno_pass[q] = 0; continue; }
       if (p.write_null_firth) { r.bhat_start.resize((size_t)r.P * nz, 0.0); std::copy(b0.begin(), b0.end(), r.bhat_start.begin() + (size_t)q * nz); }   // Step1_Models.cpp:138
+      for (int64_t i = 0; i < N; ++i) r.offset[(size_t)q * N + i] = eta[i];
+    }
+    sout << "done\n";
+  } else if (p.t2e) {   // fit_null_cox in step 1 (Step1_Models.cpp:353-440): the covariates' linear predictor is the level-1 offset
+    sout << "   -fitting null cox regression on time-to-event phenotypes...";
+    r.offset.assign((size_t)N * r.P, 0.0);
+    for (int q = 0; q < r.P; ++q) {
+      std::vector<double> eta;
+      if (!cox_null_fit(r.Yraw.data() + (size_t)q * N, r.Yevent.data() + (size_t)q * N, r.mask.data() + (size_t)q * N, r.X.data(), N, nz, p, eta))
+        throw std::runtime_error("step1 cox null regression did not converge for phenotype '" + r.pheno_names[q] + "' by coordinate descent (the reference's Newton "
+                                 "fall-back, cox_firth.cpp, is not built).");
       for (int64_t i = 0; i < N; ++i) r.offset[(size_t)q * N + i] = eta[i];
     }
     sout << "done\n";
@@ -2688,7 +2870,7 @@ int run(int argc, char** argv) {
     if (nb > 0) { cols_per_chr.push_back(nb * R0); chroms.push_back(c); }
   }
   const int nchr = (int)chroms.size();
-  const int NCS = (p.bt || p.ct) ? 6 : 5;
+  const int NCS = (p.bt || p.ct || p.t2e) ? 6 : 5;
   std::vector<int64_t> order(N);  // std::map<string,...> iteration order (Data.cpp:1934)
   for (int64_t i = 0; i < N; ++i) order[i] = i;
   std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return r.ids[a] < r.ids[b]; });
@@ -2730,13 +2912,15 @@ int run(int argc, char** argv) {
   // output of one phenotype (Data::output + write_predictions, Data.cpp:956-1129, :1795-1975)
   auto emit_pheno = [&](int q, const double* cs, int bestq, int conv, const double* pq /* [nchr][N] */) {
     std::ostringstream lo;
-    lo << "phenotype " << q + 1 << " (" << r.pheno_names[q] << ") : \n";
+    lo << "phenotype " << r.outnum(q) << " (" << r.pheno_names[q] << ") : \n";
     if (!conv) {  // Data.cpp:1016-1021
       lo << "Level 1 model did not converge. LOCO predictions calculations are skipped.\n\n";
       ph_log[q] = lo.str();
       return;
     }
-    for (int j = 0; j < R1; ++j) {
+    for (int j = 0; j < R1 && p.t2e; ++j)   // Data.cpp:1043-1049: the penalty and the held-out deviance summed over the folds
+      lo << " " << std::right << std::setw(5) << tau[(size_t)q * R1 + j] << " : Deviance = " << cs[5 * R1 + j] << (j == bestq ? "<- min value" : "") << "\n";
+    for (int j = 0; j < R1 && !p.t2e; ++j) {
       const double neff = r.neff[q];
       double num = cs[4 * R1 + j] - cs[0 * R1 + j] * cs[1 * R1 + j] / neff;
       const double rsq = num * num / ((cs[2 * R1 + j] - cs[0 * R1 + j] * cs[0 * R1 + j] / neff) * (cs[3 * R1 + j] - cs[1 * R1 + j] * cs[1 * R1 + j] / neff));
@@ -2753,7 +2937,7 @@ int run(int argc, char** argv) {
       lo << "\n";
     }
     lo << "  * making predictions...writing LOCO predictions...";
-    const std::string loco_fn = p.out + "_" + std::to_string(q + 1) + ".loco" + (p.gz ? ".gz" : "");  // Data.cpp:987
+    const std::string loco_fn = p.out + "_" + std::to_string(r.outnum(q)) + ".loco" + (p.gz ? ".gz" : "");  // Data.cpp:987
     std::vector<double> tot(N, 0.0);
     for (int c = 0; c < nchr; ++c)
       for (int64_t i = 0; i < N; ++i) tot[i] += pq[(size_t)c * N + i];
@@ -2769,7 +2953,7 @@ int run(int argc, char** argv) {
     }
     ph_plist[q] = r.pheno_names[q] + " " + (p.use_rel_path ? loco_fn : get_fullpath(loco_fn)) + "\n";
     if (p.print_prs) {
-      const std::string prs_fn = p.out + "_" + std::to_string(q + 1) + ".prs" + (p.gz ? ".gz" : "");
+      const std::string prs_fn = p.out + "_" + std::to_string(r.outnum(q)) + ".prs" + (p.gz ? ".gz" : "");
       TextOut pf(prs_fn, p.gz);
       pf << header;
       std::vector<std::string> rows;
@@ -2810,7 +2994,17 @@ int run(int argc, char** argv) {
     std::vector<double> cumsum((size_t)nq * NCS * R1), pred((size_t)nq * nchr * N);
     std::vector<int32_t> best(nq), converged(nq, 1);
     const double* tq = tau.data() + (size_t)q0 * R1;
-    if (p.bt || p.ct) {
+    if (p.t2e) {   // one call per trait: the library derives the penalties from the score at beta = 0 and returns them
+      rg_cox_options co;
+      co.niter_max = p.niter_max; co.niter_max_line_search = p.niter_max_line_search; co.niter_max_ridge = p.niter_max_ridge;
+      co.niter_max_line_search_ridge = 100; co.numtol_cox = 2.5e-4; co.l1_ridge_tol = 1e-4;
+      for (int q = 0; q < nq; ++q) {
+        double* cq = cumsum.data() + (size_t)q * NCS * R1;
+        std::fill(cq, cq + (size_t)NCS * R1, 0.0);
+        check(cx, rg_l1_cox(cx, q0 + q, R1, r.Yraw.data() + (size_t)(q0 + q) * N, r.Yevent.data() + (size_t)(q0 + q) * N, r.offset.data() + (size_t)(q0 + q) * N, &co,
+                            nchr, cols_per_chr.data(), tau.data() + (size_t)(q0 + q) * R1, cq + 5 * R1, &converged[q], &best[q], pred.data() + (size_t)q * nchr * N));
+      }
+    } else if (p.bt || p.ct) {
       rg_bt_options bo;  // Regenie.hpp:287-290 defaults; family picks ridge_logistic_level_1* or ridge_poisson_level_1*
       bo.niter_max_ridge = p.niter_max_ridge; bo.niter_max_line_search_ridge = 100; bo.niter_max_line_search = p.niter_max_line_search;
       bo.family = p.ct ? 1 : 0; bo.l1_ridge_tol = 1e-4; bo.tol = 1e-8;
@@ -2835,6 +3029,7 @@ int run(int argc, char** argv) {
     }
     sout << "\n Level 1 ridge...\n";
     if (p.ct) sout << " Level 1 ridge with poisson regression...\n";
+    if (p.t2e) sout << " Level 1 ridge with cox regression...\n";
     tl0 = std::chrono::steady_clock::now();
     level1_range(ctx, 0, P, true);
   } else {
@@ -2843,7 +3038,7 @@ int run(int argc, char** argv) {
     // ridge run on rank 0 alone there)
     std::vector<std::string> rank_log(G);
     std::vector<std::exception_ptr> errs(G, nullptr);
-    const bool shared_l1 = !pheno_sharded && !(p.bt || p.ct) && !use_loocv;
+    const bool shared_l1 = !pheno_sharded && !(p.bt || p.ct || p.t2e) && !use_loocv;
     std::vector<std::thread> th;
     for (int g = 0; g < G; ++g)
       th.emplace_back([&, g]() {

@@ -78,6 +78,43 @@ def test_step2_usage_errors(example_dir, tmp_path):
     assert "minimum MAC must be at least 0.5" in err(["--qt", "--pred", "p.list", "--minMAC", "0.1"])
 
 
+def test_t2e_options_and_phenotype_checks(example_dir, tmp_path):
+    """--t2e: the option rules of the reference (Regenie.cpp:570-587, :1197-1201) and the checks of the (time, event) pairs
+    (Pheno.cpp:262-283) happen before a device is needed; a well-formed run gets as far as the null Cox model and the device."""
+    E = example_dir
+    fam = [ln.split() for ln in open(os.path.join(E, "example_3chr.fam"))]
+
+    def pheno(path, bad=None):
+        with open(path, "w") as fh:
+            fh.write("FID IID T1 E1\n")
+            for i, t in enumerate(fam):
+                tv, ev = "%g" % (1.0 + (i * 37 % 101) / 10.0), str(i % 3 == 0 and 1 or 0)
+                if bad == "neg" and i == 5: tv = "-2"
+                if bad == "censor" and i == 5: ev = "2"
+                if bad == "missing_event" and i == 5: ev = "NA"
+                if i == 7: tv, ev = "NA", "NA"
+                fh.write("%s %s %s %s\n" % (t[0], t[1], tv, ev))
+
+    base = ["--step", "1", "--bed", os.path.join(E, "example_3chr"), "--covarFile", os.path.join(E, "covariates.txt"), "--bsize", "100", "--out", "x"]
+
+    def run(extra, bad=None):
+        pheno(str(tmp_path / "t.txt"), bad)
+        r = subprocess.run([BIN] + base + ["--phenoFile", str(tmp_path / "t.txt")] + extra, cwd=str(tmp_path), capture_output=True, text=True, timeout=60)
+        assert r.returncode != 0
+        return r.stdout + r.stderr
+
+    assert "You must specify both '--phenoColList' and '--eventColList'" in run(["--t2e", "--phenoColList", "T1"])
+    assert "must be used with '--t2e'" in run(["--qt", "--phenoColList", "T1", "--eventColList", "E1"])
+    assert "You must specify TTE phenotypes using '--phenoColList'" in run(["--t2e", "--phenoCol", "T1", "--eventColList", "E1"])
+    assert "is not built" in run(["--t2e", "--phenoColList", "T1", "--eventColList", "E1", "--t2e-event-l0"])
+    ok = ["--t2e", "--phenoColList", "T1", "--eventColList", "E1"]
+    assert "a phenotype time value is <0" in run(ok, "neg")
+    assert "a phenotype censor value is invalid" in run(ok, "censor")
+    assert "missing censor with non-missing time" in run(ok, "missing_event")
+    out = run(ok)
+    assert "n_pheno = 1" in out and "fitting null cox regression on time-to-event phenotypes...done" in out and "no MI355X / HIP device" in out
+
+
 def test_step2_reads_inputs_then_needs_a_gpu(example_dir, tmp_path):
     """Step 2 on the .bgen example up to the device: the LOCO list and files are parsed (check_blup / blup_read), the variant table
     carries positions and alleles, and without a GPU the run ends with the library's error, not a CPU fallback."""

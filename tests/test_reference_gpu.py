@@ -18,7 +18,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 pytest.importorskip("torch")
 
-from tests.test_reference_pin import (EX, REF_OUT, REGENIE, assert_text_equal, parse_table, read_loco_gz)  # noqa: E402
+from tests.test_reference_pin import (EX, REF_OUT, REGENIE, T2E_RE, assert_text_equal, parse_table, read_loco_gz)  # noqa: E402
 from tests.golden.make_ref_outputs import CASES, table_lines  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -62,15 +62,29 @@ def test_driver_reproduces_reference_outputs(name, tmp_path):
     d = str(tmp_path)
     S = os.path.join(d, "synth")
     if spec:
-        from tests.util import synth_dosages, write_plink
+        from tests.util import synth_dosages, write_plink, write_t2e_pheno
         g = synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"])
         write_plink(S, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"],
                     counts=spec.get("counts", False))
+        if spec.get("t2e"):
+            write_t2e_pheno(S + ".t2e", g, seed=spec["seed"], **spec["t2e"])
     r = subprocess.run([BIN] + [a.format(E=EX, S=S) for a in args] + ["--out", "out"], cwd=d, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     meta = json.load(open(os.path.join(REF_OUT, name, "meta.json")))
     assert [ln.split()[0] for ln in open(os.path.join(d, "out_pred.list"))] == meta["pred_list"]
-    _compare_tables(table_lines(open(os.path.join(d, "out.log")).read()), meta["table"], name)
+    if spec and spec.get("t2e"):      # --t2e: penalties and held-out deviances (Data.cpp:1043-1049), files numbered by the time column
+        got_t, ref_t = table_lines(open(os.path.join(d, "out.log")).read()), meta["table"]
+        assert len(got_t) == len(ref_t)
+        for a, b in zip(got_t, ref_t):
+            if b.startswith("phenotype"):
+                assert a.split() == b.split()
+                continue
+            ma, mb = T2E_RE.match(a), T2E_RE.match(b)
+            assert ma and mb, (a, b)
+            assert float(ma.group(1)) == pytest.approx(float(mb.group(1)), rel=2e-5) and float(ma.group(2)) == pytest.approx(float(mb.group(2)), rel=2e-5)
+            assert bool(ma.group(3)) == bool(mb.group(3)), (a, b)
+    else:
+        _compare_tables(table_lines(open(os.path.join(d, "out.log")).read()), meta["table"], name)
     n = 0
     for fn in sorted(os.listdir(os.path.join(REF_OUT, name))):
         if not (fn.endswith(".loco.gz") or fn.endswith(".prs.gz")):
