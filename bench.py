@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N>1: weak scaling of the N=1 workload instead of configs[2]")
     ap.add_argument("--bsize", type=int, default=1000)
     ap.add_argument("--bt", action="store_true", help="binary traits (BASELINE configs[3]'s kind): liability-threshold phenotypes, level 1 = logistic ridge (rg_l1_bt)")
+    ap.add_argument("--t2e", action="store_true", help="time-to-event traits (--t2e): exponential event times whose hazard carries the polygenic signal, independent censoring; "
+                    "level 1 = Cox ridge (rg_l1_cox), one call per trait; the offset of the null Cox model is taken as zero")
     ap.add_argument("--l0-only", action="store_true", help="time level 0 alone (a GPU's share of a run whose W does not fit one device: 50 phenotypes at 500,000 samples)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-blocks", type=int, default=4)
@@ -172,6 +174,12 @@ def main():
                 if np.abs(step).max() < 1e-10:
                     break
             bt_offset[:, q] = X @ b
+    t2e_event = None
+    if args.t2e:    # time = min(event time, censoring time); the time column is also the level-0 response (Pheno.cpp:262-283, Step1_Models.cpp:2259)
+        t_ev = rng.exponential(1.0, (N, P)) * np.exp(-0.5 * (Yraw - Yraw.mean(axis=0)) / Yraw.std(axis=0)) * 4.0
+        t_c = rng.exponential(6.0, (N, P))
+        t2e_event = (t_ev <= t_c).astype(np.float64)
+        Yraw = np.minimum(t_ev, t_c)
     Y, _ = hp.residualize_pheno(Yraw - Yraw.mean(axis=0), X, mask, neff)
     ain = np.ones(N, bool)
     cv_sizes = hp.set_folds(ain, 5)
@@ -250,6 +258,14 @@ def main():
             if args.bt:
                 cs, conv, best, pred = eng.l1_bt(tau, Yraw, bt_offset, cols_per_chr)
                 extra_t["bt_converged"] = [bool(c) for c in conv]
+            elif args.t2e:
+                pred, best, cs, conv, taus = [], [], [], [], []
+                for q in range(P):
+                    tq, dq, cq, bq, pq = eng.l1_cox(q, Yraw[:, q], t2e_event[:, q], np.zeros(N), cols_per_chr)
+                    pred.append(pq); best.append(bq); cs.append(dq); conv.append(cq); taus.append(tq)
+                extra_t["t2e"] = {"converged": [bool(c) for c in conv], "tau": [list(map(float, t)) for t in taus],
+                                  "held_out_deviance": [list(map(float, d)) for d in cs], "best": [int(b) for b in best],
+                                  "events_fraction": float(t2e_event.mean())}
             else:
                 cs, best, pred = eng.l1_qt(tau, cols_per_chr)
             extra_t["level1_wall_ms_last_step"] = (time.perf_counter() - t_l1) * 1e3
@@ -375,7 +391,7 @@ def main():
                           ("BASELINE configs[1]: " if (world == 1 and (N, M, P) == (50000, 100000, 1)) else
                            ("BASELINE configs[2] on ONE GPU: " if (world == 1 and (N, M, P) == (500000, 500000, 10)) else
                             ("" if world == 1 else "weak scaling of BASELINE configs[1]: "))),
-                          N, M, args.snps, P, "BT" if args.bt else "QT", bsize), "samples": N, "snps": M, "phenos": P, "bsize": bsize, "blocks": B,
+                          N, M, args.snps, P, "BT" if args.bt else ("time-to-event" if args.t2e else "QT"), bsize), "samples": N, "snps": M, "phenos": P, "bsize": bsize, "blocks": B,
                        "parallelism": ("blocks sharded x%d, all-to-all of W by phenotype, level 1 phenotype-sharded x%d" if pheno_sharded else
                                        "blocks sharded x%d, all-gather of W, level-1 Gram tiles / ridge systems shared x%d") % (world, world)},
             "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,

@@ -492,6 +492,22 @@ def test_cli_multi_gpu_qt(example_dir, tmp_path):
     assert "GPU 1 : blocks [4..6]" in res["peer2"]["_log"] and "RCCL" in res["rccl1"]["_log"]
 
 
+def test_cli_multi_gpu_t2e(tmp_path):
+    """--t2e on two and three ranks (one device, peer copies): each trait's Cox ridge runs on the rank that owns it (two ranks), or on
+    rank 0 after the all-gather (three ranks for two traits) -- .loco files byte-identical to the single-GPU run, named by the
+    reference's column numbers."""
+    from tests.test_reference_pin import synth_t2e_case
+    _, pre = synth_t2e_case(tmp_path)
+    common = ["--step", "1", "--bed", pre, "--phenoFile", pre + ".t2e", "--covarFile", pre + ".covar", "--bsize", "100", "--t2e",
+              "--phenoColList", "T1,T2", "--eventColList", "E1,E2"]
+    res = _run_pair(None, tmp_path, common, [("peer2", _world(2)), ("peer3", _world(3))])
+    for name in ("peer2", "peer3"):
+        assert sorted(k for k in res[name] if k != "_log") == ["o_1.loco", "o_3.loco"]
+        for fn in ("o_1.loco", "o_3.loco"):
+            assert res[name][fn] == res["plain"][fn], (name, fn)
+    assert "Deviance = " in res["peer2"]["_log"] and "level 1 of phenotypes [2..2]" in res["peer2"]["_log"]
+
+
 @pytest.mark.parametrize("form", ["by_phenotype", "all_gather"])
 def test_cli_multi_gpu_rank_failure_does_not_hang(example_dir, tmp_path, form):
     """A rank whose host side fails (here: the .bed is cut short, so the reader thread of the LAST rank runs out of file) breaks the
