@@ -15,6 +15,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librg_step1_hip.so")
 SOURCES = ["rg_api.hip", "bed_prep.hip", "gram_i8.hip", "gram_fp4.hip", "assemble.hip", "chol.hip", "pred.hip", "l1.hip", "ubench.hip", "loocv.hip", "l1x.hip", "l0_f64.hip", "step2_qt.hip", "step2_bt.hip", "rg_group.hip", "pred_i8.hip", "xy_i8.hip",
            "pgen_api.cpp", "bgen_api.cpp"]  # host-only: .pgen input (include/rg_pgen.h), BGEN v1.2 input (include/rg_bgen.h)
+HOST_SOURCES = ["driver_common.cpp", "driver_models.cpp", "driver_inputs.cpp", "driver_step2.cpp", "driver_step1.cpp", "driver_main.cpp"]  # regenie-amd (host/driver.h)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-Wno-unused-variable", "-Wno-unused-value", "-Wno-unused-result", "-Wno-inline-asm"]
 
@@ -38,7 +39,7 @@ def _digest(paths) -> str:
 
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "host", "rg_step1_main.cpp"),
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "host", f) for f in HOST_SOURCES + ["driver.h"]] + [
                                                       os.path.join(CSRC, "rg_internal.h"),
                                                       os.path.join(CSRC, "step2_internal.h"),
                                                       os.path.join(CSRC, "pgen_reader.h"),
@@ -75,11 +76,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
     # C++ host driver (the reference's host language): `regenie-amd --step 1 ...`
     bindir = os.path.join(HERE, "bin")
     os.makedirs(bindir, exist_ok=True)
-    r = subprocess.run([hipcc, "-O2", "-std=c++17", os.path.join(HERE, "host", "rg_step1_main.cpp"), "-o",
-                        os.path.join(bindir, "regenie-amd"), "-L" + LIBDIR, "-lrg_step1_hip",
-                        "-Wl,-rpath,$ORIGIN/../lib", "-lz"], capture_output=True, text=True)
+    def compile_host(src):
+        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
+        return src, obj, subprocess.run([hipcc, "-x", "c++", "-O2", "-std=c++17", "-c", os.path.join(HERE, "host", src), "-o", obj],
+                                        capture_output=True, text=True)
+
+    hobjs = []
+    with cf.ThreadPoolExecutor(max_workers=len(HOST_SOURCES)) as ex:
+        for src, obj, r in ex.map(compile_host, HOST_SOURCES):
+            if r.returncode != 0:
+                raise RuntimeError("host driver build failed on %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+            hobjs.append(obj)
+    r = subprocess.run([hipcc] + hobjs + ["-o", os.path.join(bindir, "regenie-amd"), "-L" + LIBDIR, "-lrg_step1_hip",
+                        "-Wl,-rpath,$ORIGIN/../lib", "-lz", "-lpthread"], capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("host driver build failed:\n%s\n%s" % (r.stdout, r.stderr))
+        raise RuntimeError("host driver link failed:\n%s\n%s" % (r.stdout, r.stderr))
     with open(stamp, "w") as fh:
         fh.write(dig)
     return LIB

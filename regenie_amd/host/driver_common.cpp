@@ -1,0 +1,275 @@
+// regenie-amd, the C++ host driver (see driver.h): text helpers, the option table, small utilities.
+//
+#include "driver.h"
+
+namespace rgdrv {
+
+
+thread_local std::ostringstream* tl_log = nullptr;
+Log sout;
+std::mutex g_reader_mu;
+
+std::vector<std::string> split_ws(const std::string& s) {     // the tokens `is >> t` would give (a stream per line cost 2 s of a 500,000-sample run)
+  std::vector<std::string> out;
+  const size_t n = s.size();
+  size_t i = 0;
+  while (i < n) {
+    while (i < n && std::isspace((unsigned char)s[i])) ++i;
+    size_t j = i;
+    while (j < n && !std::isspace((unsigned char)s[j])) ++j;
+    if (j > i) out.emplace_back(s, i, j - i);
+    i = j;
+  }
+  return out;
+}
+std::vector<std::string> split_char(const std::string& s, char c) {
+  std::vector<std::string> out;
+  std::string t;
+  std::istringstream is(s);
+  while (std::getline(is, t, c)) if (!t.empty()) out.push_back(t);
+  return out;
+}
+
+int chr_str_to_int(std::string s, int nchrom) {  // Regenie.cpp:1583-1594
+  if (s.compare(0, 3, "chr") == 0) s = s.substr(3);
+  if (!s.empty() && isdigit((unsigned char)s[0])) {
+    int c = atoi(s.c_str());
+    if (c >= 1 && c <= nchrom) return c;
+  } else if (s == "X" || s == "XY" || s == "Y" || s == "PAR1" || s == "PAR2") return nchrom;
+  return -1;
+}
+
+double convert_double(const std::string& v) {  // Regenie.cpp:1663-1675
+  if (v == "NA" || v == "nan" || v == "inf") return MISSING;
+  char* end = nullptr;
+  double d = strtod(v.c_str(), &end);
+  if (end == v.c_str()) throw std::runtime_error("could not convert value to double: '" + v + "'");
+  return d;
+}
+
+std::string cpp_double(double v) {  // default ostream formatting (precision 6)
+  std::ostringstream o;
+  o << v;
+  return o.str();
+}
+
+std::set<std::string> read_id_files(const std::vector<std::string>& files) {  // Geno.cpp:1382-1441
+  std::set<std::string> ids;
+  for (auto& fn : files) {
+    TextIn f(fn);
+    if (!f) throw std::runtime_error("cannot open file : " + fn);
+    std::string line;
+    while (std::getline(f, line)) {
+      auto t = split_ws(line);
+      if (t.size() < 2) throw std::runtime_error("incorrectly formatted file: " + fn);
+      ids.insert(t[0] + "_" + t[1]);
+    }
+  }
+  return ids;
+}
+std::set<std::string> read_snp_files(const std::vector<std::string>& files) {
+  std::set<std::string> ids;
+  for (auto& fn : files) {
+    TextIn f(fn);
+    if (!f) throw std::runtime_error("cannot open file : " + fn);
+    std::string line;
+    while (std::getline(f, line)) {
+      auto t = split_ws(line);
+      if (!t.empty()) ids.insert(t[0]);
+    }
+  }
+  return ids;
+}
+
+// symmetric eigen-decomposition (cyclic Jacobi), ascending eigenvalues; n is the covariate count
+
+void jacobi_eigh(std::vector<double> A, int n, std::vector<double>& d, std::vector<double>& V) {
+  V.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) V[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 100; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) off += A[(size_t)p * n + q] * A[(size_t)p * n + q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[(size_t)p * n + q];
+        if (std::fabs(apq) < 1e-300) continue;
+        const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2.0 * apq);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < n; ++k) {
+          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+          A[(size_t)k * n + p] = c * akp - s * akq;
+          A[(size_t)k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+          A[(size_t)p * n + k] = c * apk - s * aqk;
+          A[(size_t)q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+          V[(size_t)k * n + p] = c * vkp - s * vkq;
+          V[(size_t)k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  d.resize(n);
+  for (int i = 0; i < n; ++i) d[i] = A[(size_t)i * n + i];
+  std::vector<int> idx(n);
+  for (int i = 0; i < n; ++i) idx[i] = i;
+  std::sort(idx.begin(), idx.end(), [&](int a, int b) { return d[a] < d[b]; });
+  std::vector<double> d2(n), V2((size_t)n * n);
+  for (int j = 0; j < n; ++j) {
+    d2[j] = d[idx[j]];
+    for (int k = 0; k < n; ++k) V2[(size_t)k * n + j] = V[(size_t)k * n + idx[j]];
+  }
+  d.swap(d2);
+  V.swap(V2);
+}
+
+[[noreturn]] void usage_error(const std::string& m) { throw std::runtime_error(m); }
+
+Params parse_args(int argc, char** argv) {
+  Params p;
+  auto need = [&](int& i) -> std::string {
+    if (i + 1 >= argc) usage_error(std::string("option '") + argv[i] + "' needs a value");
+    return argv[++i];
+  };
+  auto list = [&](std::vector<std::string>& dst, const std::string& v) {
+    for (auto& s : split_char(v, ',')) dst.push_back(s);
+  };
+  bool saw_pheno_col = false, saw_pheno_collist = false;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    if (a == "--step") p.step = atoi(need(i).c_str());
+    else if (a == "--bed") p.bed = need(i);
+    else if (a == "--phenoFile" || a == "--p") p.pheno_file = need(i);
+    else if (a == "--covarFile" || a == "--c") p.covar_file = need(i);
+    else if (a == "--phenoCol" || a == "--phenoColList") { if (a == "--phenoCol") saw_pheno_col = true; else saw_pheno_collist = true; list(p.pheno_cols, need(i)); }
+    else if (a == "--eventColList") list(p.event_cols, need(i));
+    else if (a == "--t2e") { p.t2e = true; p.bt = p.ct = false; }
+    else if (a == "--t2e-event-l0" || a == "--t2e-l1-pi6") usage_error("option '" + a + "' is not built (the level-0 response of a time-to-event trait is its time column, the penalties come from the score at beta = 0).");
+    else if (a == "--covarCol" || a == "--covarColList") list(p.covar_cols, need(i));
+    else if (a == "--catCovarList") list(p.cat_covar, need(i));
+    else if (a == "--maxCatLevels") p.max_cat_levels = atoi(need(i).c_str());
+    else if (a == "--apply-rint") p.rint = true;
+    else if (a == "--keep") list(p.keep, need(i));
+    else if (a == "--remove") list(p.remove, need(i));
+    else if (a == "--extract") list(p.extract, need(i));
+    else if (a == "--exclude") list(p.exclude, need(i));
+    else if (a == "--bsize" || a == "--b") p.bsize = atoi(need(i).c_str());
+    else if (a == "--cv") p.cv_folds = atoi(need(i).c_str());
+    else if (a == "--l0") p.n_ridge_l0 = atoi(need(i).c_str());
+    else if (a == "--l1") p.n_ridge_l1 = atoi(need(i).c_str());
+    else if (a == "--setl0") { for (auto& s : split_char(need(i), ',')) p.setl0.push_back(atof(s.c_str())); }
+    else if (a == "--setl1") { for (auto& s : split_char(need(i), ',')) p.setl1.push_back(atof(s.c_str())); }
+    else if (a == "--out" || a == "--o") p.out = need(i);
+    else if (a == "--threads") p.threads = atoi(need(i).c_str());
+    else if (a == "--nauto") p.nchrom = atoi(need(i).c_str()) + 1;
+    else if (a == "--device") p.device = atoi(need(i).c_str());
+    else if (a == "--lowmem-prefix") { need(i); p.lowmem = true; }
+    else if (a == "--qt") { p.bt = false; p.ct = false; p.t2e = false; }
+    else if (a == "--bt") { p.bt = true; p.ct = false; p.t2e = false; }
+    else if (a == "--ct") { p.ct = true; p.bt = false; p.t2e = false; }
+    else if (a == "--loocv") p.loocv = true;
+    else if (a == "--strict") p.strict = true;
+    else if (a == "--ref-first") p.ref_first = true;
+    else if (a == "--use-relative-path") p.use_rel_path = true;
+    else if (a == "--print-prs") p.print_prs = true;
+    else if (a == "--force-step1") p.force_step1 = true;
+    else if (a == "--force-qt") p.force_qt = true;
+    else if (a == "--lowmem") p.lowmem = true;
+    else if (a == "--1" || a == "--cc12") p.cc12 = true;
+    else if (a == "--minCaseCount") p.min_case_count = atoi(need(i).c_str());
+    else if (a == "--niter") { p.niter_max = atoi(need(i).c_str()); p.niter_max_ridge = p.niter_max; }  // Regenie.cpp:483
+    else if (a == "--gz") p.gz = true;
+    else if (a == "--pgen") p.pgen = need(i);
+    else if (a == "--bgen") p.bgen = need(i);
+    else if (a == "--sample") p.sample_file = need(i);
+    else if (a == "--split-l0") {
+      auto t = split_char(need(i), ',');
+      if (t.size() != 2) usage_error("must specify number of jobs for --split-l0 (i.e. prefix,njobs).");
+      p.split_l0 = true; p.split_file = t[0]; p.njobs = atoi(t[1].c_str());
+    } else if (a == "--run-l0") {
+      auto t = split_char(need(i), ',');
+      if (t.size() != 2) usage_error("must specify job number for --run-l0 (i.e. master_file,job_number).");
+      p.run_l0 = true; p.split_file = t[0]; p.job_num = atoi(t[1].c_str());
+      if (p.job_num < 1) usage_error("invalid job number for --run-l0 (must be >=1).");
+    } else if (a == "--run-l1") { p.run_l1 = true; p.split_file = need(i); }
+    else if (a == "--keep-l0") p.keep_l0 = true;
+    else if (a == "--gpus") p.gpus = atoi(need(i).c_str());
+    else if (a == "--transport") {
+      const std::string t = need(i);
+      if (t == "rccl") p.transport = RG_TRANSPORT_RCCL;
+      else if (t == "peer") p.transport = RG_TRANSPORT_PEER;
+      else usage_error("--transport must be rccl or peer");
+    }
+    else if (a == "--single-device") p.single_device = true;
+    else if (a == "--force-collectives") p.force_collectives = true;
+    else if (a == "--l1-shared") p.l1_shared = true;
+    else if (a == "--pred") p.pred_list = need(i);
+    else if (a == "--minMAC") p.min_mac = atof(need(i).c_str());
+    else if (a == "--minINFO") { p.min_info = atof(need(i).c_str()); p.set_min_info = true; }
+    else if (a == "--firth") p.firth = true;
+    else if (a == "--approx") p.firth_approx = true;
+    else if (a == "--firth-se") p.firth_se = true;
+    else if (a == "--write-null-firth") p.write_null_firth = true;
+    else if (a == "--use-null-firth") p.use_null_firth = need(i);
+    else if (a == "--pThresh") p.pthresh = atof(need(i).c_str());
+    else if (a == "--spa") p.spa = true;
+    else usage_error("unrecognised option '" + a + "'");
+  }
+  if (p.bt) p.rint = false;  // Regenie.cpp:432
+  if (p.step != 1 && p.step != 2) usage_error("specify which mode regenie should be running using option --step.");
+  // time-to-event traits (Regenie.cpp:570-587, :1197-1201)
+  if (p.t2e && !p.event_cols.empty() && saw_pheno_col) usage_error("You must specify TTE phenotypes using '--phenoColList' (matching in order with events in '--eventColList').");
+  if (p.t2e && (p.event_cols.empty() || !saw_pheno_collist)) usage_error("You must specify both '--phenoColList' and '--eventColList' (same order) for time-to-event analysis.");
+  if (!p.event_cols.empty() && !p.t2e) usage_error("Option --eventColList must be used with '--t2e' for time-to-event analysis");
+  if (p.t2e && p.event_cols.size() != p.pheno_cols.size()) usage_error("'--phenoColList' and '--eventColList' must name the same number of columns.");
+  if (p.t2e && p.step == 2) usage_error("--step 2 --t2e (the Cox score test) is not built: time-to-event traits are supported in step 1.");
+  if (p.t2e && (p.run_l0 || p.run_l1 || p.split_l0)) usage_error("--t2e with the --split-l0 / --run-l0 / --run-l1 file protocol is not built.");
+  if (p.t2e && p.loocv) { std::cout << "WARNING: option --loocv cannot be used with option --t2e.\n"; p.loocv = false; }
+  if (p.t2e) p.rint = false;
+  if (p.step == 2) {
+    if (p.pred_list.empty()) usage_error("option '--pred' is required (use the _pred.list file written by step 1).");
+    if (p.firth && !p.bt) usage_error("option '--firth' applies to binary traits (--bt).");
+    if (p.spa && !p.bt) usage_error("option '--spa' applies to binary traits (--bt).");
+    if (p.spa && p.firth) usage_error("cannot use both '--firth' and '--spa'.");
+    if (p.spa && !(p.pthresh > 0 && p.pthresh < 1)) usage_error("'--pThresh' must be in (0,1).");
+    if (p.firth && !(p.pthresh > 0 && p.pthresh < 1)) usage_error("'--pThresh' must be in (0,1).");
+    if (p.min_mac < 0.5) usage_error("minimum MAC must be at least 0.5.");   // Regenie.cpp:1054
+    if (p.set_min_info && (p.min_info < 0 || p.min_info > 1)) usage_error("minimum info score must be in [0,1].");
+    if (p.force_collectives) usage_error("--force-collectives applies to step 1 (step 2 has no collective: its blocks are independent).");
+  }
+  if (!p.use_null_firth.empty() && !(p.step == 2 && p.firth && p.firth_approx)) usage_error("option --use-null-firth only wors with approximate Firth test.");   // Regenie.cpp:1216-1217
+  if (p.write_null_firth && ((p.step == 2 && !(p.firth && p.firth_approx)) || (p.step == 1 && !p.bt))) {   // Regenie.cpp:1218-1222
+    std::cout << "WARNING: option --write-null-firth only works for BTs with approximate Firth test.\n";
+    p.write_null_firth = false;
+  }
+  if ((int)!p.bed.empty() + (int)!p.pgen.empty() + (int)!p.bgen.empty() != 1) usage_error("must use either --bed,--bgen or --pgen.");  // Regenie.cpp:419-420
+  if (p.pheno_file.empty()) usage_error("option '--phenoFile' is required.");
+  if (p.bsize < 1) usage_error("must specify the block size using '--bsize'.");
+  if (p.cv_folds < 2) usage_error("number of CV folds must be at least 2");
+  if (p.gpus < 1) usage_error("--gpus must be at least 1");
+  if (p.step == 1 && p.single_device && p.gpus > 1 && p.transport != RG_TRANSPORT_PEER) usage_error("--single-device needs --transport peer (RCCL refuses two ranks on one device)");
+  if ((p.gpus > 1 || p.force_collectives) && (p.run_l0 || p.run_l1 || p.split_l0)) usage_error("--gpus / --force-collectives cannot be combined with the --split-l0 / --run-l0 / --run-l1 file protocol");
+  return p;
+}
+
+
+std::string get_fullpath(const std::string& f) {  // Data.cpp:1150-1194
+  char buf[PATH_MAX];
+  if (realpath(f.c_str(), buf)) return buf;
+  if (!f.empty() && f[0] == '/') return f;
+  if (getcwd(buf, sizeof(buf))) return std::string(buf) + "/" + f;
+  return f;
+}
+
+
+void check(rg_ctx* ctx, int rc) {
+  if (rc != 0) throw std::runtime_error(rg_last_error(ctx));
+}
+
+}  // namespace rgdrv

@@ -1,0 +1,705 @@
+// regenie-amd, the C++ host driver (see driver.h): `--step 1` and run().
+#include "driver.h"
+
+namespace rgdrv {
+
+// Ring of host buffers between the .bed / .pgen reader thread and rg_l0_blocks (the block loop of Data.cpp:636-678 with the file
+// read taken off the critical path).  The buffers are page-locked -- copies to the device are then asynchronous and run at the
+// PCIe rate -- on a thread of their own: page-locking costs ~0.2 s per GB, so a run on one GPU starts it while the phenotype and
+// covariate files are still being parsed and the reader takes each buffer as it becomes ready.
+struct IngestRing {
+  static constexpr int NBUF = 3;
+  int per = 1;                       // SNP blocks per buffer
+  bool pinned = true, failed = false;
+  uint8_t* mem[NBUF] = {nullptr, nullptr, nullptr};
+  std::mutex mu; std::condition_variable cv; std::deque<int> free_q;
+  std::thread th;
+  // total_bytes: the rows this ring will carry; blk_bytes: one block; max_per: most blocks per buffer (the library's batch size) or
+  // <= 0 when not known yet; pin: 1 / 0 forces page-locked / pageable buffers, -1 page-locks only when the input is several rings long
+  void start(int64_t total_bytes, int64_t blk_bytes, int max_per, int pin) {
+    int64_t slot = std::max<int64_t>(16LL << 20, std::min<int64_t>(total_bytes / 8, 4LL << 30));
+    if (const char* e = getenv("RG_INGEST_MB")) slot = (int64_t)std::max(1, atoi(e)) << 20;
+    per = (int)std::max<int64_t>(1, slot / std::max<int64_t>(1, blk_bytes));
+    if (max_per > 0) per = std::min(per, max_per);
+    const int64_t bytes = (int64_t)per * blk_bytes;
+    pinned = pin >= 0 ? pin != 0 : total_bytes >= 4 * NBUF * bytes;
+    if (const char* e = getenv("RG_INGEST_PINNED")) pinned = atoi(e) != 0;
+    th = std::thread([this, bytes]() {
+      for (int i = 0; i < NBUF; ++i) {
+        uint8_t* m = pinned ? (uint8_t*)rg_host_alloc(bytes) : (uint8_t*)aligned_alloc(4096, (size_t)(bytes + 4095) / 4096 * 4096);
+        std::lock_guard<std::mutex> lk(mu);
+        if (!m) { failed = true; cv.notify_all(); return; }
+        mem[i] = m;
+        free_q.push_back(i);
+        cv.notify_all();
+      }
+    });
+  }
+  void release() {
+    if (th.joinable()) th.join();
+    for (auto& m : mem) { if (m) { if (pinned) rg_host_free(m); else free(m); } m = nullptr; }
+  }
+  ~IngestRing() { release(); }
+};
+
+int run(int argc, char** argv) {
+  Run r;
+  r.p = parse_args(argc, argv);
+  const Params& p = r.p;
+  sout.f.open(p.out + ".log");
+  auto t_start = std::chrono::steady_clock::now();
+  sout << "              |=============================|\n              |   REGENIE-AMD (step 1, HIP)  |\n              |=============================|\n\n";
+  sout << "Log of output saved in file : " << p.out << ".log\n\nOptions in effect:\n";
+  for (int i = 1; i < argc; ++i) sout << (argv[i][0] == '-' && argv[i][1] == '-' ? "  " : " ") << argv[i] << (i + 1 < argc && argv[i + 1][0] == '-' ? " \\\n" : "");
+  sout << "\n\nFitting null model\n";
+  // The HIP runtime and the device contexts come up on their own threads while this one parses the text files (bringing the
+  // runtime up costs 150 - 200 ms, as much as the parsing)
+  std::vector<std::future<rg_ctx*>> early_ctx;
+  if (p.step == 1 && !p.split_l0)
+    for (int g = 0; g < p.gpus; ++g)
+      early_ctx.push_back(std::async(std::launch::async, [&p, g]() -> rg_ctx* {
+        rg_ctx* c = nullptr;
+        if (rg_create(&c, p.single_device ? p.device : p.device + g, nullptr) != 0) return nullptr;
+        return c;
+      }));
+  if (p.run_l0) prep_parallel_l0(r);
+  read_bim_fam(r);
+  if (p.split_l0) {  // set_parallel_l0 / write_l0_master (Data.cpp:232-309): master + per-job variant lists, then exit
+    std::map<int, int> cn;
+    for (int c : r.snp_chrom) cn[c]++;
+    std::vector<int> bsizes;     // block sizes in traversal order
+    for (int c : r.chr_read) {
+      const int n = cn.count(c) ? cn[c] : 0;
+      const int nbc = (n + p.bsize - 1) / p.bsize;
+      for (int bb = 0; bb < nbc; ++bb) bsizes.push_back(std::min(p.bsize, n - bb * p.bsize));
+    }
+    const int total = (int)bsizes.size();
+    int njobs = p.njobs;
+    sout << " * running level 0 in parallel across " << total << " genotype blocks\n";
+    if (njobs <= 1) throw std::runtime_error("number of jobs must be >1.");
+    if (njobs > total) { sout << "   -WARNING: Number of jobs cannot be greater than number of blocks.\n"; njobs = total; }
+    sout << "   -using " << njobs << " jobs\n   -master file written to [" << p.split_file << ".master]\n";
+    sout << "   -variant list files written to [" << p.split_file << "_job*.snplist]\n";
+    std::ofstream mf(p.split_file + ".master");
+    if (!mf) throw std::runtime_error("cannot write file : " + p.split_file + ".master");
+    mf << r.snp_chrom.size() << " " << p.bsize << std::endl;
+    const int nall = total / njobs, rem = total - nall * njobs;
+    int b = 0; size_t scount = 0;
+    for (int j = 0; j < njobs; ++j) {
+      const int bt = nall + (j < rem ? 1 : 0);
+      int ns = 0;
+      for (int t = 0; t < bt; ++t) ns += bsizes[b++];
+      const std::string fname = p.split_file + "_job" + std::to_string(j + 1);
+      mf << fname << " " << bt << " " << ns << std::endl;
+      std::ofstream sf(fname + ".snplist");
+      if (!sf) throw std::runtime_error("cannot write file : " + fname + ".snplist");
+      for (int t = 0; t < ns; ++t) sf << r.snp_ids[scount + t] << "\n";
+      scount += ns;
+    }
+    sout << "\nEnd of run\n";
+    return 0;
+  }
+  auto since_start = [&]() { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t_start).count(); };
+  sout << "   -genotype metadata read (" << since_start() << "ms since start)\n";
+  const int64_t ingest_blk_bytes = (int64_t)p.bsize * r.bpr;
+  IngestRing pre_ring;
+  IngestRing* pre_ring_ptr = nullptr;
+  if (p.step == 1 && p.gpus == 1 && !p.run_l1 && !r.dosage_mode && r.bpr > 0) {   // one GPU: the ring is page-locked under the parsing below
+    pre_ring.start((int64_t)r.snp_chrom.size() * r.bpr, ingest_blk_bytes, -1, 1);
+    pre_ring_ptr = &pre_ring;
+  }
+  read_pheno_cov(r);
+  sout << "   -phenotypes and covariates ready (" << since_start() << "ms since start)\n";
+  if (p.step == 2) return run_step2_all(r, t_start);
+  const int64_t N = r.N;
+  const int P = r.P;
+
+  // set_blocks (Data.cpp:311-398)
+  std::map<int, int> chr_nsnp;
+  for (int c : r.snp_chrom) chr_nsnp[c]++;
+  struct Blk { int chrom; int64_t start; int bs; };
+  std::vector<Blk> blocks;
+  {
+    int64_t pos = 0;
+    for (int c : r.chr_read) {
+      const int n = chr_nsnp.count(c) ? chr_nsnp[c] : 0;
+      const int nb = (n + p.bsize - 1) / p.bsize;
+      for (int bb = 0; bb < nb; ++bb) blocks.push_back({c, pos + (int64_t)bb * p.bsize, std::min(p.bsize, n - bb * p.bsize)});
+      pos += n;
+    }
+  }
+  const int B = (int)blocks.size();
+  if (B == 0) throw std::runtime_error("total number of blocks must be > 0.");
+  const int64_t M = p.run_l0 ? r.parallel_nGeno : (int64_t)r.snp_chrom.size();   // --run-l0: global count (Data.cpp:607)
+  if (p.run_l0 && (B != r.parallel_nBlocks || (int)r.snp_chrom.size() != r.parallel_nSnps))
+    throw std::runtime_error("number of blocks/variants in the job's snplist doesn't match the master file.");
+  if (p.run_l1) prep_parallel_l1(r, B, (int64_t)r.snp_chrom.size());
+  std::vector<double> h0 = p.setl0, h1 = p.setl1;
+  auto grid = [](int n) {  // set_ridge_params (Regenie.cpp:1497-1508)
+    if (n < 2) throw std::runtime_error("number of ridge parameters must be at least 2 (=" + std::to_string(n) + ")");
+    std::vector<double> v(n);
+    for (int i = 0; i < n; ++i) v[i] = (double)i / (n - 1);
+    v[0] = 0.01; v[n - 1] = 0.99;
+    return v;
+  };
+  if (h0.empty()) h0 = grid(p.n_ridge_l0);
+  if (h1.empty()) h1 = grid(p.n_ridge_l1);
+  const int R0 = (int)h0.size(), R1 = (int)h1.size();
+  std::vector<double> lambda(R0);
+  for (int i = 0; i < R0; ++i) lambda[i] = (double)M * (1 - h0[i]) / h0[i];  // Data.cpp:607
+  sout << std::left << std::setw(20) << " * block size" << ": [" << p.bsize << "]\n";
+  sout << std::left << std::setw(20) << " * # blocks" << ": [" << B << "] for " << M << " variants\n";
+  sout << std::left << std::setw(20) << " * # CV folds" << ": [" << p.cv_folds << "]\n";
+  if (p.loocv) sout << std::left << std::setw(20) << " * LOOCV" << ": [enabled]\n";
+  sout << std::left << std::setw(20) << " * ridge data_l0" << ": [ " << R0 << " : ";
+  for (double h : h0) sout << h << " ";
+  sout << "]\n" << std::left << std::setw(20) << " * ridge data_l1" << ": [ " << R1 << " : ";
+  for (double h : h1) sout << h << " ";
+  sout << "]\n";
+
+  bool use_loocv = p.loocv;
+  if (p.bt && !use_loocv && r.n_analyzed < 5000) {  // Data.cpp:353-356
+    sout << "   -WARNING: Sample size is less than 5,000 so using LOOCV instead of " << p.cv_folds << "-fold CV.\n";
+    use_loocv = true;
+  }
+  // set_folds (Data.cpp:401-426)
+  std::vector<int32_t> cv_sizes(p.cv_folds, 1);
+  if (!use_loocv) {
+    const int64_t target = r.n_analyzed / p.cv_folds;
+    if (target < 1) throw std::runtime_error("not enough samples are present for " + std::to_string(p.cv_folds) + "-fold CV.");
+    int64_t cnt = 0, cum = 0;
+    int cur = 0;
+    for (int64_t i = 0; i < N; ++i) {
+      if (r.ain[i]) cnt++;
+      if (cnt == target) { cv_sizes[cur] = (int32_t)(i - cum + 1); cum += cv_sizes[cur]; cnt = 0; cur++; }
+      else if (cur == p.cv_folds - 1) { cv_sizes[cur] = (int32_t)(N - i); break; }
+    }
+  }
+
+  if (!use_loocv && (p.bt || p.ct)) {  // Data.cpp:436-466: every fold needs both classes / at least one count
+    int64_t start = 0;
+    for (int f = 0; f < p.cv_folds; ++f) {
+      for (int q = 0; q < r.P; ++q) {
+        if (!r.pheno_pass[q]) continue;
+        double sum = 0.0, n = 0.0;
+        for (int64_t i = start; i < start + cv_sizes[f]; ++i)
+          if (r.mask[(size_t)q * N + i]) { sum += r.Yraw[(size_t)q * N + i]; n += 1.0; }
+        if (p.bt && (sum / n) * (1 - sum / n) < NUMTOL)
+          throw std::runtime_error("one of the folds has only cases/controls for phenotype '" + r.pheno_names[q] +
+                                   "'. Either use smaller #folds (option --cv) or use LOOCV (option --loocv).");
+        if (p.ct && sum == 0)
+          throw std::runtime_error("one of the folds has only zero counts for phenotype '" + r.pheno_names[q] +
+                                   "'. Either use smaller #folds (option --cv) or use LOOCV (option --loocv).");
+      }
+      start += cv_sizes[f];
+    }
+  }
+
+  // ---- devices: one context per GPU, one host thread per context ------------------------------------------------------
+  const int G = p.gpus;
+  const bool use_group = G > 1 || p.force_collectives;
+  std::vector<rg_ctx*> ctxs(G, nullptr);
+  rg_problem pr;
+  memset(&pr, 0, sizeof(pr));
+  pr.n_samples = N; pr.n_file = r.n_file; pr.n_pheno = P; pr.n_cov = r.C; pr.cv_folds = use_loocv ? 0 : p.cv_folds;
+  pr.n_ridge_l0 = R0; pr.ref_first = p.ref_first; pr.n_analyzed = r.n_analyzed; pr.cv_sizes = cv_sizes.data();
+  pr.lambda = lambda.data(); pr.X = r.X.data(); pr.Y = r.Y.data(); pr.mask = r.mask.data();
+  pr.ind_in_analysis = r.ain.data(); pr.ind_ignore = (r.N != r.n_file) ? r.ind_ignore.data() : nullptr;
+  pr.neff = r.neff.data(); pr.n_blocks_total = B; pr.max_block_size = p.bsize;
+  for (int g = 0; g < G; ++g) ctxs[g] = early_ctx[g].get();
+  for (int g = 0; g < G; ++g) {
+    if (!ctxs[g])
+      throw std::runtime_error("no MI355X / HIP device available (rg_create failed for device " + std::to_string(p.single_device ? p.device : p.device + g) + ")");
+    // level-0 workspaces in proportion to what this GPU will ingest: a run over a small file asks for small batches (the
+    // bytes a process allocates are set-up time, for it and for the next process on the device), a large one gets the
+    // library's default of 64 GB
+    const int64_t bed_bytes = (int64_t)(B / G + 1) * ingest_blk_bytes;
+    check(ctxs[g], rg_set_l0_workspace(ctxs[g], 0, 0, std::max<int64_t>(6000000000LL, std::min<int64_t>(64000000000LL, 8 * bed_bytes))));
+    check(ctxs[g], rg_set_problem(ctxs[g], &pr));
+  }
+  sout << "   -GPU context" << (G > 1 ? "s" : "") << " ready (" << since_start() << "ms since start)\n";
+  rg_ctx* ctx = ctxs[0];
+  rg_group* grp = nullptr;
+  if (use_group) {
+    if (rg_group_create(&grp, G, ctxs.data(), p.transport) != 0 || !grp) throw std::runtime_error(std::string("cannot set up the GPU group: ") + rg_last_error(ctxs[0]));
+    sout << std::left << std::setw(20) << " * # GPUs" << ": [" << G << "] (" << (p.transport == RG_TRANSPORT_RCCL ? "RCCL" : "peer copies") << ")\n";
+  }
+  // block ranges of the ranks: floor(B/G) blocks each, the first B mod G one more (write_l0_master, Data.cpp:270-302)
+  std::vector<int32_t> bbeg(G + 1, 0), pbeg(G + 1, 0);
+  for (int g = 0; g < G; ++g) bbeg[g + 1] = bbeg[g] + B / G + (g < B % G ? 1 : 0);
+  const bool pheno_sharded = use_group && P >= G && !p.l1_shared;      // all-to-all by phenotype; else all-gather + shared level 1
+  for (int g = 0; g < G; ++g) pbeg[g + 1] = pheno_sharded ? pbeg[g] + P / G + (g < P % G ? 1 : 0) : P;
+  if (!pheno_sharded) pbeg[0] = 0;
+
+  std::mutex io_mu;      // the .pgen / .bgen readers keep per-handle state: one block read at a time
+  // ---- level 0 of blocks [b_lo, b_hi) on one context -------------------------------------------------------------------
+  // get_G + the block loop of level_0_calculations (Data.cpp:636-678) with the file read taken off the critical path: a
+  // reader thread fills page-locked buffers (one pread per block when its variants are contiguous in the file, Geno.cpp:
+  // 1702-1769 reads them one by one), the calling thread hands each buffer to rg_l0_blocks -- asynchronous copies, kernels
+  // queued behind the previous batch on the other pipeline -- and recycles it once its copy has completed (rg_ingest_fence).
+  auto level0_range = [&](rg_ctx* cx, int b_lo, int b_hi, std::ostringstream& lg, IngestRing* pre_ring) {
+    if (b_lo >= b_hi) return;
+    if (r.dosage_mode) {   // a block of dosages is bs x N_file doubles on the host: one block at a time, synchronous
+      std::vector<double> dbuf;
+      for (int b = b_lo; b < b_hi; ++b) {
+        const Blk& bl = blocks[b];
+        auto t0 = std::chrono::steady_clock::now();
+        dbuf.resize((size_t)bl.bs * r.n_file);
+        {
+          std::lock_guard<std::mutex> lk(io_mu);
+          if (r.bgenh) {  // readChunkFromBGENFileToG_fast (Geno.cpp:1574-1699): inflate + probabilities -> dosages
+            if (rg_bgen_read_dosages(r.bgenh, bl.bs, &r.snp_offset[bl.start], p.ref_first ? 1 : 0, dbuf.data(), r.n_file) != RG_BGEN_OK)
+              throw std::runtime_error(rg_bgen_last_error(r.bgenh));
+          } else {        // Read() per kept variant (Geno.cpp:1795-1796): ALT dosages, -3 = missing
+            if (rg_pgen_read_dosage_rows(r.pgen, bl.bs, &r.snp_offset[bl.start], dbuf.data(), r.n_file) != RG_PGEN_OK)
+              throw std::runtime_error(rg_pgen_last_error(r.pgen));
+          }
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        const int32_t id = b, bsv = bl.bs;
+        const double* dp = dbuf.data();
+        check(cx, rg_l0_blocks_f64(cx, 1, &id, &bsv, &dp, r.n_file, RG_MEM_HOST));
+        check(cx, rg_sync(cx));
+        auto t2 = std::chrono::steady_clock::now();
+        lg << " block [" << b + 1 << "] (chromosome " << bl.chrom << ") : " << bl.bs << " snps  (read "
+           << std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() << "ms, level 0 ridge on GPU "
+           << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms)\n";
+      }
+      return;
+    }
+    const int64_t blk_bytes = ingest_blk_bytes;
+    // the ring of host buffers: the one whose page-locking was started while the text files were parsed (one GPU), or a
+    // ring of this rank's own
+    IngestRing own;
+    IngestRing& ring = pre_ring ? *pre_ring : own;
+    if (!pre_ring) own.start((int64_t)(b_hi - b_lo) * blk_bytes, blk_bytes, rg_l0_batch_blocks(cx), -1);
+    const int per = ring.per;
+    const int NBUF = IngestRing::NBUF;
+    struct Slot { int b0 = 0, nb = 0; double read_ms = 0; };
+    std::vector<Slot> slots(NBUF);
+    std::mutex& mu = ring.mu; std::condition_variable& cv = ring.cv;
+    std::deque<int>& free_q = ring.free_q;
+    std::deque<int> ready_q;
+    std::exception_ptr rd_err = nullptr;
+    bool rd_done = false;
+    int rd_threads = 4;    // preads of one buffer in flight (page-cache copies scale with threads; a disk queue likes depth)
+    if (const char* e = getenv("RG_READ_THREADS")) rd_threads = std::max(1, atoi(e));
+    std::thread reader([&]() {
+      int fd = -1;
+      try {
+        if (!r.pgen) {
+          fd = open((p.bed + ".bed").c_str(), O_RDONLY);
+          if (fd < 0) throw std::runtime_error("cannot read bed file");
+        }
+        for (int b0 = b_lo; b0 < b_hi; b0 += per) {
+          int si;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !free_q.empty() || ring.failed; });
+            if (ring.failed) throw std::runtime_error("cannot allocate memory for the genotype buffers");
+            si = free_q.front(); free_q.pop_front();
+          }
+          Slot& sl = slots[si];
+          uint8_t* slmem = ring.mem[si];
+          sl.b0 = b0; sl.nb = std::min(per, b_hi - b0);
+          auto t0 = std::chrono::steady_clock::now();
+          struct Piece { uint8_t* dst; int64_t off, want; };
+          std::vector<Piece> pieces;
+          for (int b = 0; b < sl.nb; ++b) {
+            const Blk& bl = blocks[b0 + b];
+            uint8_t* dst = slmem + (int64_t)b * blk_bytes;
+            if (r.pgen) {  // ReadHardcalls per kept variant (Geno.cpp:1781-1798), as .bed-coded rows
+              std::lock_guard<std::mutex> lk(io_mu);
+              if (rg_pgen_read_bed_rows(r.pgen, bl.bs, &r.snp_offset[bl.start], dst, r.bpr) != RG_PGEN_OK)
+                throw std::runtime_error(rg_pgen_last_error(r.pgen));
+              continue;
+            }
+            int j = 0;
+            while (j < bl.bs) {   // runs of variants that are consecutive in the file: one pread each (jumpto_bed, Geno.cpp:2828-2830)
+              int e = j + 1;
+              while (e < bl.bs && r.snp_offset[bl.start + e] == r.snp_offset[bl.start + e - 1] + 1) ++e;
+              const int64_t want = (int64_t)(e - j) * r.bpr, off = 3 + r.snp_offset[bl.start + j] * r.bpr, chunk = 8 << 20;
+              for (int64_t o = 0; o < want; o += chunk) pieces.push_back({dst + (int64_t)j * r.bpr + o, off + o, std::min(chunk, want - o)});
+              j = e;
+            }
+          }
+          if (!pieces.empty()) {
+            std::atomic<int> bad{0};
+            parallel_for((int)pieces.size(), rd_threads, [&](int t) {
+              const Piece& pc = pieces[t];
+              int64_t got = 0;
+              while (got < pc.want) {
+                const ssize_t k = pread(fd, pc.dst + got, (size_t)(pc.want - got), pc.off + got);
+                if (k <= 0) { bad = 1; return; }
+                got += k;
+              }
+            });
+            if (bad) throw std::runtime_error("cannot read bed file");
+          }
+          sl.read_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            ready_q.push_back(si);
+          }
+          cv.notify_all();
+        }
+      } catch (...) {
+        std::lock_guard<std::mutex> lk(mu);
+        rd_err = std::current_exception();
+      }
+      if (fd >= 0) close(fd);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        rd_done = true;
+      }
+      cv.notify_all();
+    });
+    std::exception_ptr main_err = nullptr;
+    try {
+      for (;;) {
+        int si = -1;
+        {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return !ready_q.empty() || rd_done; });
+          if (!ready_q.empty()) { si = ready_q.front(); ready_q.pop_front(); }
+          else if (rd_err) std::rethrow_exception(rd_err);
+          else break;
+        }
+        Slot& sl = slots[si];
+        std::vector<int32_t> ids(sl.nb), bss(sl.nb);
+        std::vector<const uint8_t*> ptrs(sl.nb);
+        int64_t nsnp = 0;
+        for (int b = 0; b < sl.nb; ++b) {
+          ids[b] = sl.b0 + b; bss[b] = blocks[sl.b0 + b].bs; ptrs[b] = ring.mem[si] + (int64_t)b * blk_bytes;
+          nsnp += bss[b];
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        check(cx, rg_l0_blocks(cx, sl.nb, ids.data(), bss.data(), ptrs.data(), r.bpr, RG_MEM_HOST));
+        check(cx, rg_ingest_fence(cx));     // the rows have crossed PCIe: the buffer goes back to the reader
+        auto t2 = std::chrono::steady_clock::now();
+        lg << " blocks [" << sl.b0 + 1 << ".." << sl.b0 + sl.nb << "] (chromosomes " << blocks[sl.b0].chrom << ".." << blocks[sl.b0 + sl.nb - 1].chrom
+           << ") : " << nsnp << " snps  (read " << (int64_t)sl.read_ms << "ms in the reader thread, queued on the GPU after "
+           << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms)\n";
+        {
+          std::lock_guard<std::mutex> lk(mu);
+          free_q.push_back(si);
+        }
+        cv.notify_all();
+      }
+    } catch (...) {
+      main_err = std::current_exception();
+      {   // let the reader come to its end
+        std::lock_guard<std::mutex> lk(mu);
+        ring.failed = true;
+      }
+      cv.notify_all();
+    }
+    reader.join();
+    if (!main_err) {
+      auto t1 = std::chrono::steady_clock::now();
+      try { check(cx, rg_sync(cx)); } catch (...) { main_err = std::current_exception(); }
+      lg << "   -level 0 ridge of blocks [" << b_lo + 1 << ".." << b_hi << "] complete (" <<
+          std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() << "ms after the last batch was queued)\n";
+    }
+    ring.release();
+    if (main_err) std::rethrow_exception(main_err);
+  };
+
+  if (p.run_l1) {
+    // read_l0 (Step1_Models.cpp:1921-1987): every job file holds N x (blocks_k * R0) raw doubles, column-major,
+    // block-major then ridge index; its columns go to W at block offset bstart_k
+    std::vector<double> slab((size_t)N * R0);
+    for (size_t k = 0; k < r.mprefix.size(); ++k)
+      for (int q = 0; q < P; ++q) {
+        const std::string fn = r.mprefix[k] + "_l0_Y" + std::to_string(q + 1);
+        std::ifstream lf(fn, std::ios::binary | std::ios::ate);
+        if (!lf) throw std::runtime_error("cannot read file : " + fn);
+        const int64_t want = (int64_t)sizeof(double) * N * r.btot[k] * R0;
+        if ((int64_t)lf.tellg() != want) throw std::runtime_error("file " + fn + " is not the right size.");   // Step1_Models.cpp:1962
+        lf.seekg(0);
+        for (int bb = 0; bb < r.btot[k]; ++bb) {
+          lf.read((char*)slab.data(), sizeof(double) * slab.size());
+          if (!lf) throw std::runtime_error("cannot read file : " + fn);
+          check(ctx, rg_l0_set_w(ctx, r.bstart[k] + bb, q, slab.data()));
+        }
+      }
+    sout << "   -level 0 predictors read from the job files\n";
+  }
+  if (p.run_l0) {  // level 0 of this job, then write_l0_file (Step1_Models.cpp:728-734): PFX_job<k>_l0_Y<ph>, and stop (Data.cpp:113-117)
+    std::ostringstream lg;
+    level0_range(ctx, 0, B, lg, pre_ring_ptr);
+    sout << lg.str();
+    std::vector<double> slab((size_t)N * R0);
+    for (int q = 0; q < P; ++q) {
+      const std::string fn = r.job_prefix + "_l0_Y" + std::to_string(q + 1);
+      std::ofstream lf(fn, std::ios::binary);
+      if (!lf) throw std::runtime_error("cannot write file : " + fn);
+      for (int bb = 0; bb < B; ++bb) {
+        check(ctx, rg_l0_get_w(ctx, bb, q, slab.data()));
+        lf.write((const char*)slab.data(), sizeof(double) * slab.size());
+      }
+    }
+    sout << "   -level 0 predictions written to [" << r.job_prefix << "_l0_Y*]\n";
+    rg_destroy(ctx);
+    sout << "\nElapsed time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << "s\nEnd of run\n";
+    return 0;
+  }
+
+  // level-1 inputs shared by the ranks
+  const int L = B * R0;
+  std::vector<double> tau((size_t)P * R1);
+  for (int q = 0; q < P; ++q)
+    for (int j = 0; j < R1; ++j)   // check_l0, Step1_Models.cpp:2115-2117
+      tau[(size_t)q * R1 + j] = (double)L * (1 - h1[j]) / h1[j] * (p.bt ? 3.0 / (M_PI * M_PI) : 1.0);
+  std::vector<double> ct_rate(P, 0.0);
+  if (p.ct)  // Step1_Models.cpp:2101-2104: tau_j = L / log(1 + h_j / (rate (1 - h_j))); rate sums the raw column as it is
+    for (int q = 0; q < P; ++q) {
+      double sum = 0.0;
+      for (int64_t i = 0; i < N; ++i) sum += r.Yraw[(size_t)q * N + i];
+      ct_rate[q] = sum / r.neff[q];
+      for (int j = 0; j < R1; ++j) tau[(size_t)q * R1 + j] = (double)L / std::log(1.0 + h1[j] / (ct_rate[q] * (1 - h1[j])));
+    }
+  std::vector<int32_t> cols_per_chr;
+  std::vector<int> chroms;
+  for (int c : r.chr_read) {
+    int nb = 0;
+    for (auto& bl : blocks) nb += bl.chrom == c;
+    if (nb > 0) { cols_per_chr.push_back(nb * R0); chroms.push_back(c); }
+  }
+  const int nchr = (int)chroms.size();
+  const int NCS = (p.bt || p.ct || p.t2e) ? 6 : 5;
+  std::vector<int64_t> order(N);  // std::map<string,...> iteration order (Data.cpp:1934)
+  for (int64_t i = 0; i < N; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return r.ids[a] < r.ids[b]; });
+  std::string header = "FID_IID ";
+  std::vector<int64_t> kept_order;     // the analysed samples in the writer's order
+  for (int64_t i : order) if (r.ain[i]) { header += r.ids[i] + " "; kept_order.push_back(i); }
+  header += "\n";
+  const int fmt_threads = std::max(1, std::min(32, p.threads > 0 ? p.threads : (int)std::thread::hardware_concurrency() - 1));
+  // one row of a .loco / .prs file (write_chr_row, Data.cpp:1951-1975): `<chr> v1 v2 ... \n`, NA where the phenotype is missing.
+  // The values are formatted by several threads over chunks of samples; the default stream format of a double (%g, six
+  // significant digits) is what std::to_chars(general, 6) produces.
+  auto format_rows = [&](int nrows, const std::function<double(int, int64_t)>& value, const uint8_t* maskq, std::vector<std::string>& rows) {
+    const int NCK = 16;
+    const int64_t nk = (int64_t)kept_order.size();
+    std::vector<std::string> piece((size_t)nrows * NCK);
+    parallel_for(nrows * NCK, fmt_threads, [&](int t) {
+      const int row = t / NCK, ck = t % NCK;
+      std::string& o = piece[t];
+      const int64_t k0 = nk * ck / NCK, k1 = nk * (ck + 1) / NCK;
+      o.reserve((size_t)(k1 - k0) * 12);
+      char buf[48];
+      for (int64_t k = k0; k < k1; ++k) {
+        const int64_t i = kept_order[k];
+        if (maskq[i]) {
+          const auto res = std::to_chars(buf, buf + sizeof(buf), value(row, i), std::chars_format::general, 6);
+          o.append(buf, res.ptr);
+          o.push_back(' ');
+        } else o += "NA ";
+      }
+    });
+    rows.assign(nrows, std::string());
+    for (int row = 0; row < nrows; ++row)
+      for (int ck = 0; ck < NCK; ++ck) rows[row] += piece[(size_t)row * NCK + ck];
+  };
+
+  // per-phenotype results, filled by whichever rank owns the phenotype
+  std::vector<std::string> ph_log(P), ph_plist(P), ph_prslist(P), ph_firthlist(P);
+
+  // output of one phenotype (Data::output + write_predictions, Data.cpp:956-1129, :1795-1975)
+  auto emit_pheno = [&](int q, const double* cs, int bestq, int conv, const double* pq /* [nchr][N] */) {
+    std::ostringstream lo;
+    lo << "phenotype " << r.outnum(q) << " (" << r.pheno_names[q] << ") : \n";
+    if (!conv) {  // Data.cpp:1016-1021
+      lo << "Level 1 model did not converge. LOCO predictions calculations are skipped.\n\n";
+      ph_log[q] = lo.str();
+      return;
+    }
+    for (int j = 0; j < R1 && p.t2e; ++j)   // Data.cpp:1043-1049: the penalty and the held-out deviance summed over the folds
+      lo << " " << std::right << std::setw(5) << tau[(size_t)q * R1 + j] << " : Deviance = " << cs[5 * R1 + j] << (j == bestq ? "<- min value" : "") << "\n";
+    for (int j = 0; j < R1 && !p.t2e; ++j) {
+      const double neff = r.neff[q];
+      double num = cs[4 * R1 + j] - cs[0 * R1 + j] * cs[1 * R1 + j] / neff;
+      const double rsq = num * num / ((cs[2 * R1 + j] - cs[0 * R1 + j] * cs[0 * R1 + j] / neff) * (cs[3 * R1 + j] - cs[1 * R1 + j] * cs[1 * R1 + j] / neff));
+      const double sse = cs[2 * R1 + j] + cs[3 * R1 + j] - 2 * cs[4 * R1 + j];
+      double label = (double)L / (L + (p.bt ? M_PI * M_PI / 3.0 : 1.0) * tau[(size_t)q * R1 + j]);
+      if (p.ct) {  // Data.cpp:1039-1054
+        const double zv = std::exp((double)L / tau[(size_t)q * R1 + j]) - 1;
+        label = ct_rate[q] * zv / (1 + ct_rate[q] * zv);
+      }
+      lo << "  " << std::right << std::setw(5) << label << " : Rsq = " << rsq;
+      if (!p.ct) lo << ", MSE = " << sse / neff;
+      if (p.bt || p.ct) lo << ", -logLik/N = " << cs[5 * R1 + j] / neff;
+      if (j == bestq) lo << "<- min value";
+      lo << "\n";
+    }
+    lo << "  * making predictions...writing LOCO predictions...";
+    const std::string loco_fn = p.out + "_" + std::to_string(r.outnum(q)) + ".loco" + (p.gz ? ".gz" : "");  // Data.cpp:987
+    std::vector<double> tot(N, 0.0);
+    for (int c = 0; c < nchr; ++c)
+      for (int64_t i = 0; i < N; ++i) tot[i] += pq[(size_t)c * N + i];
+    std::vector<const double*> sub(p.nchrom, nullptr);
+    for (int c = 0; c < nchr; ++c) if (chroms[c] >= 1 && chroms[c] <= p.nchrom) sub[chroms[c] - 1] = pq + (size_t)c * N;
+    {
+      TextOut lf(loco_fn, p.gz);
+      if (!lf) throw std::runtime_error("cannot write file : " + loco_fn);
+      lf << header;
+      std::vector<std::string> rows;
+      format_rows(p.nchrom, [&](int row, int64_t i) { return tot[i] - (sub[row] ? sub[row][i] : 0.0); }, r.mask.data() + (size_t)q * N, rows);
+      for (int chr = 1; chr <= p.nchrom; ++chr) lf << std::to_string(chr) << " " << rows[chr - 1] << "\n";
+    }
+    ph_plist[q] = r.pheno_names[q] + " " + (p.use_rel_path ? loco_fn : get_fullpath(loco_fn)) + "\n";
+    if (p.print_prs) {
+      const std::string prs_fn = p.out + "_" + std::to_string(r.outnum(q)) + ".prs" + (p.gz ? ".gz" : "");
+      TextOut pf(prs_fn, p.gz);
+      pf << header;
+      std::vector<std::string> rows;
+      format_rows(1, [&](int, int64_t i) { return tot[i]; }, r.mask.data() + (size_t)q * N, rows);
+      pf << "0 " << rows[0] << "\n";
+      ph_prslist[q] = r.pheno_names[q] + " " + (p.use_rel_path ? prs_fn : get_fullpath(prs_fn)) + "\n";
+    }
+    if (p.write_null_firth) {   // Data.cpp:1873-1902: the null approximate-Firth estimates of every chromosome (offset = its LOCO prediction),
+                                // warm-started along the chromosomes from the null logistic estimates; read back by `--step 2 --use-null-firth`
+      const std::string ffn = p.out + "_" + std::to_string(q + 1) + ".firth" + (p.gz ? ".gz" : "");
+      lo << "writing null approximate Firth estimates...";
+      const int Cn = r.C;
+      std::vector<double> bh(r.bhat_start.begin() + (size_t)q * Cn, r.bhat_start.begin() + (size_t)(q + 1) * Cn), off(N);
+      std::ostringstream body;
+      bool conv = true;
+      for (int chr = 1; chr <= p.nchrom && conv; ++chr) {
+        for (int64_t i = 0; i < N; ++i) off[i] = tot[i] - (sub[chr - 1] ? sub[chr - 1][i] : 0.0);
+        conv = firth_null_fit(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, off.data(), N, Cn, bh);
+        if (!conv) break;
+        body << chr << " ";
+        for (int c = 0; c < Cn; ++c) body << bh[c] << (c + 1 < Cn ? " " : "");
+        body << "\n";
+      }
+      if (!conv) lo << "WARNING: Firth failed to converge";
+      else {
+        TextOut ff(ffn, p.gz);
+        if (!ff) throw std::runtime_error("cannot write file : " + ffn);
+        ff << body.str();
+        ph_firthlist[q] = r.pheno_names[q] + " " + (p.use_rel_path ? ffn : get_fullpath(ffn)) + "\n";
+      }
+    }
+    lo << "done\n\n";
+    ph_log[q] = lo.str();
+  };
+
+  // level 1 of phenotypes [q0, q0 + nq) on one context (its view already set for a phenotype-sharded run)
+  auto level1_range = [&](rg_ctx* cx, int q0, int nq, bool write_out) {
+    std::vector<double> cumsum((size_t)nq * NCS * R1), pred((size_t)nq * nchr * N);
+    std::vector<int32_t> best(nq), converged(nq, 1);
+    const double* tq = tau.data() + (size_t)q0 * R1;
+    if (p.t2e) {   // one call per trait: the library derives the penalties from the score at beta = 0 and returns them
+      rg_cox_options co;
+      co.niter_max = p.niter_max; co.niter_max_line_search = p.niter_max_line_search; co.niter_max_ridge = p.niter_max_ridge;
+      co.niter_max_line_search_ridge = 100; co.numtol_cox = 2.5e-4; co.l1_ridge_tol = 1e-4;
+      for (int q = 0; q < nq; ++q) {
+        double* cq = cumsum.data() + (size_t)q * NCS * R1;
+        std::fill(cq, cq + (size_t)NCS * R1, 0.0);
+        check(cx, rg_l1_cox(cx, q0 + q, R1, r.Yraw.data() + (size_t)(q0 + q) * N, r.Yevent.data() + (size_t)(q0 + q) * N, r.offset.data() + (size_t)(q0 + q) * N, &co,
+                            nchr, cols_per_chr.data(), tau.data() + (size_t)(q0 + q) * R1, cq + 5 * R1, &converged[q], &best[q], pred.data() + (size_t)q * nchr * N));
+      }
+    } else if (p.bt || p.ct) {
+      rg_bt_options bo;  // Regenie.hpp:287-290 defaults; family picks ridge_logistic_level_1* or ridge_poisson_level_1*
+      bo.niter_max_ridge = p.niter_max_ridge; bo.niter_max_line_search_ridge = 100; bo.niter_max_line_search = p.niter_max_line_search;
+      bo.family = p.ct ? 1 : 0; bo.l1_ridge_tol = 1e-4; bo.tol = 1e-8;
+      check(cx, rg_l1_bt(cx, R1, tq, r.Yraw.data() + (size_t)q0 * N, r.offset.data() + (size_t)q0 * N, &bo, nchr, cols_per_chr.data(),
+                         cumsum.data(), converged.data(), best.data(), pred.data()));
+      for (int q = 0; q < nq; ++q) if (!r.pheno_pass[q0 + q]) converged[q] = 0;
+    } else if (use_loocv)
+      check(cx, rg_l1_qt_loocv(cx, R1, tq, nchr, cols_per_chr.data(), cumsum.data(), best.data(), pred.data()));
+    else
+      check(cx, rg_l1_qt(cx, R1, tq, nchr, cols_per_chr.data(), cumsum.data(), best.data(), pred.data()));
+    if (!write_out) return;
+    for (int q = 0; q < nq; ++q)
+      emit_pheno(q0 + q, cumsum.data() + (size_t)q * NCS * R1, best[q], converged[q], pred.data() + (size_t)q * nchr * N);
+  };
+
+  auto tl0 = std::chrono::steady_clock::now();
+  if (!use_group) {
+    if (!p.run_l1) {
+      std::ostringstream lg;
+      level0_range(ctx, 0, B, lg, pre_ring_ptr);
+      sout << lg.str();
+    }
+    sout << "\n Level 1 ridge...\n";
+    if (p.ct) sout << " Level 1 ridge with poisson regression...\n";
+    if (p.t2e) sout << " Level 1 ridge with cox regression...\n";
+    tl0 = std::chrono::steady_clock::now();
+    level1_range(ctx, 0, P, true);
+  } else {
+    // one host thread per GPU: level 0 of the rank's blocks, the exchange, level 1 of the rank's phenotypes (phenotype-
+    // sharded) or of all phenotypes with the heavy steps shared (all-gather form; level-1 models other than the K-fold
+    // ridge run on rank 0 alone there)
+    std::vector<std::string> rank_log(G);
+    std::vector<std::exception_ptr> errs(G, nullptr);
+    const bool shared_l1 = !pheno_sharded && !(p.bt || p.ct || p.t2e) && !use_loocv;
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g)
+      th.emplace_back([&, g]() {
+        try {
+          std::ostringstream lg;
+          // the exchange buffers of this rank (phenotype view, packed send buffer) are allocated before level 0 starts
+          check(ctxs[g], rg_group_prepare(grp, g, bbeg.data(), pheno_sharded ? pbeg.data() : nullptr));
+          level0_range(ctxs[g], bbeg[g], bbeg[g + 1], lg, nullptr);
+          rank_log[g] = lg.str();
+          check(ctxs[g], rg_l0_finish(grp, g, bbeg.data(), pheno_sharded ? pbeg.data() : nullptr));
+          if (pheno_sharded) level1_range(ctxs[g], pbeg[g], pbeg[g + 1] - pbeg[g], true);
+          else if (shared_l1 || g == 0) level1_range(ctxs[g], 0, P, g == 0);
+        } catch (...) {
+          // whatever failed here (reader, file, level 0, level 1): the group is broken, so that the other ranks -- waiting in
+          // the exchange or in a shared level-1 all-reduce, now or later -- fail too instead of waiting for this one
+          errs[g] = std::current_exception();
+          rg_group_abort(grp, g);
+        }
+      });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < G; ++g) {
+      sout << " GPU " << g << " : blocks [" << bbeg[g] + 1 << ".." << bbeg[g + 1] << "]"
+           << (pheno_sharded ? ", level 1 of phenotypes [" + std::to_string(pbeg[g] + 1) + ".." + std::to_string(pbeg[g + 1]) + "]" : std::string()) << "\n" << rank_log[g];
+    }
+    {  // report the rank that failed first-hand, not a peer that only noticed it
+      std::exception_ptr any = nullptr;
+      for (int g = 0; g < G; ++g) {
+        if (!errs[g]) continue;
+        if (!any) any = errs[g];
+        try { std::rethrow_exception(errs[g]); }
+        catch (const std::exception& e) { if (!strstr(e.what(), "another GPU")) std::rethrow_exception(errs[g]); }
+        catch (...) { std::rethrow_exception(errs[g]); }
+      }
+      if (any) std::rethrow_exception(any);
+    }
+    sout << "\n Level 1 ridge...\n";
+  }
+  sout << "   -level 1 for " << P << " phenotype(s) done ("
+       << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tl0).count() << "ms)\n\n";
+
+  sout << "   -predictions written (" << since_start() << "ms since start)\n";
+  // output (Data.cpp:956-1129): the per-phenotype tables and file lists in phenotype order
+  sout << "Output\n------\n";
+  std::ofstream plist(p.out + "_pred.list"), prslist;
+  if (p.print_prs) prslist.open(p.out + "_prs.list");
+  for (int q = 0; q < P; ++q) {
+    sout << ph_log[q];
+    plist << ph_plist[q];
+    if (p.print_prs) prslist << ph_prslist[q];
+  }
+  if (p.run_l1 && !p.keep_l0)   // rm_l0_files (Data.cpp:1131-1147)
+    for (auto& pre : r.mprefix)
+      for (int q = 0; q < P; ++q) std::remove((pre + "_l0_Y" + std::to_string(q + 1)).c_str());
+  sout << "List of blup files written to: [" << p.out << "_pred.list]\n";
+  if (p.write_null_firth) {   // Data.cpp:1102-1121
+    std::ofstream fl(p.out + "_firth.list");
+    for (int q = 0; q < P; ++q) fl << ph_firthlist[q];
+    sout << "List of files with null Firth estimates written to: [" << p.out << "_firth.list]\n";
+  }
+  if (p.print_prs) sout << "List of files with whole genome PRS written to: [" << p.out << "_prs.list]\n";
+  if (grp) rg_group_destroy(grp);
+  for (rg_ctx* cx : ctxs) rg_destroy(cx);
+  sout << "\nElapsed time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << "s\nEnd of run\n";
+  return 0;
+}
+
+}  // namespace rgdrv

@@ -1,0 +1,687 @@
+// regenie-amd, the C++ host driver (see driver.h): `--step 2`.
+#include "driver.h"
+
+namespace rgdrv {
+
+// The per-variant corrections -- fit_firth_logistic_snp_fast (Step2_Models.cpp:1158-1253) and run_SPA_test_snp (:2072-2297) -- run on the
+// device behind the C ABI (rg_s2_bt_correct, regenie_amd/csrc/step2_bt.hip).
+
+// One part of a `--step 2` run: the blocks [blk_lo, blk_hi) of the run's block list (chromosomes in file order, ceil(n_chr / bsize) blocks
+// each) on one device.  A run on G GPUs is G parts on G host threads -- the blocks are independent, there is no exchange -- whose result
+// lines go to part files that are concatenated in block order afterwards (run_step2_all).
+struct S2Part {
+  int part = 0, nparts = 1, device = 0;
+  int blk_lo = 0, blk_hi = INT_MAX;
+  int64_t n_ignored_snps = 0, n_ignored_tests = 0;     // out
+  std::vector<std::string> firth_body;                 // out: --write-null-firth lines per trait
+  std::vector<std::string> files;                      // out: the part's result files, one per trait
+};
+
+int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& part) {
+  const Params& p = r.p;
+  const int64_t N = r.N;
+  const int P = r.P, C = r.C;
+  std::vector<int64_t> an;                      // analysed samples (rows handed to the device), file order
+  for (int64_t i = 0; i < N; ++i) if (r.ain[i]) an.push_back(i);
+  const int64_t n = (int64_t)an.size();
+  bool any_missing = false;                     // filters->has_missing: a sample masked for at least one trait
+  std::vector<uint8_t> has_missing(n, 0);
+  for (int64_t k = 0; k < n; ++k)
+    for (int q = 0; q < P; ++q)
+      if (!r.mask[(size_t)q * N + an[k]]) { has_missing[k] = 1; any_missing = true; }
+  const bool dense_route = getenv("RG_S2_DENSE") != nullptr;     // the fp64 route of the library (rg_s2_qt_block), kept for comparison
+  const bool glm = p.bt || p.ct;                                 // binary / count traits: the score test of a generalised linear null model
+  // compact, sample-fastest copies for the C ABI
+  std::vector<double> Xc((size_t)C * n), Yc((size_t)P * n), resc((size_t)P * n), scf(P);
+  std::vector<uint8_t> Mc((size_t)P * n);
+  for (int c = 0; c < C; ++c) for (int64_t k = 0; k < n; ++k) Xc[(size_t)c * n + k] = r.X[(size_t)c * N + an[k]];
+  for (int q = 0; q < P; ++q)
+    for (int64_t k = 0; k < n; ++k) { Yc[(size_t)q * n + k] = (glm ? r.Yraw : r.Y)[(size_t)q * N + an[k]]; Mc[(size_t)q * n + k] = r.mask[(size_t)q * N + an[k]]; }
+  // binary traits (compute_res_bin, Data.cpp:2439-2445; compute_score_bt, Step2_Models.cpp:471-552): per chromosome the null logistic
+  // model with the LOCO offset gives p^, w = p^ (1 - p^); the score test of a variant needs, per trait, sum w g~^2, X^T W g~ and
+  // g~ . (y - p^) -- contractions of the hard-call row with fixed columns, which rg_s2_contract_packed evaluates on the i8 matrix cores
+  std::vector<double> bt_fit, bt_vstat;
+  std::vector<int32_t> bt_counts;
+  std::vector<uint8_t> bt_pass(P, 1), test_ignored;
+  const bool firth = p.bt && p.firth, spa = p.bt && p.spa, correct = firth || spa;
+  const double z_thr = correct ? norm_quantile(1.0 - 0.5 * p.pthresh) : 0.0;   // sqrt of the chi-square(1) quantile at 1 - pThresh (Data.cpp:2119-2120)
+  std::vector<double> firth_off;                      // [P][n] cov_blup_offset: X beta_nullFirth + LOCO prediction (fit_null_firth, Step2_Models.cpp:1011-1013)
+  if (firth) firth_off.assign((size_t)P * n, 0.0);
+  std::vector<double> firth_bnull((size_t)P * C, 0.0), blup_off;      // exact Firth: the covariate-only estimates (start values), the LOCO offsets
+  std::vector<std::string> null_firth_files, firth_file_body(P);       // --use-null-firth: per-trait files of the list; --write-null-firth: what goes out
+  if (!p.use_null_firth.empty()) {      // check_firth_file / the list reader (Step2_Models.cpp:1871-1934): `<phenotype> <file>` per line
+    sout << " * reading null Firth estimates using file : [" << p.use_null_firth << "]\n";
+    null_firth_files.assign(P, "");
+    TextIn lf(p.use_null_firth);
+    if (!lf) throw std::runtime_error("cannot read file : " + p.use_null_firth);
+    std::string ln;
+    while (std::getline(lf, ln)) {
+      const auto t = split_ws(ln);
+      if (t.empty()) continue;
+      if (t.size() != 2) throw std::runtime_error("incorrectly formatted file specified by --use-null-firth.");
+      for (int q = 0; q < P; ++q) if (r.pheno_names[q] == t[0]) null_firth_files[q] = t[1];
+    }
+  }
+  if (p.write_null_firth) sout << " * writing null Firth estimates to file\n";
+  if (firth && !p.firth_approx) blup_off.assign((size_t)P * n, 0.0);
+  std::vector<double> denum_v;                        // per (variant, trait): the score test's denominator
+  std::vector<uint8_t> corrected, corr_fail;          // per (variant, trait) of a block
+  std::vector<double> corr_beta, corr_se, corr_chisq, corr_logp;
+  if (glm) bt_fit.assign((size_t)P * n, 0.5);
+
+  rg_s2_ctx* s2 = nullptr;
+  if (rg_s2_create(&s2, part.device, n, C, P) != RG_S2_OK || !s2) throw std::runtime_error("no MI355X / HIP device available (rg_s2_create failed)");
+  auto s2check = [&](int rc) { if (rc != RG_S2_OK) throw std::runtime_error(rg_s2_last_error(s2)); };
+  enum class In { Bed, PgenHard, Dosage };
+  const In in = r.dosage_mode ? In::Dosage : (r.pgen ? In::PgenHard : In::Bed);
+  const bool show_info = r.dosage_mode;                 // params.dosage_mode: the INFO column
+  const int flip = (in == In::Bed && p.ref_first) ? 1 : 0;   // .pgen rows always count ALT (PgenReader::Read / ReadHardcalls)
+  // check_sparse_G: params.n_samples, params.prop_zero_thr (Regenie.hpp:311); the .pgen reader counts the observed zeros itself
+  s2check(rg_s2_set_sparse_rule(s2, N, 0.5, r.pgen ? 1 : 0));
+
+  // blocks per chromosome (set_blocks_for_testing: ceil(n_chr / bsize))
+  std::map<int, std::vector<int64_t>> chr_snps;
+  for (size_t j = 0; j < r.snp_chrom.size(); ++j) chr_snps[r.snp_chrom[j]].push_back((int64_t)j);
+  // in_non_par (Geno.cpp:2419, :2251): outside the pseudo-autosomal regions of chromosome X the reference halves the males' calls in the
+  // MAC (and, with the default dosage compensation off, nothing else) -- with no male in the sample file that is the autosomal rule
+  if (chr_snps.count(p.nchrom) && r.has_male)
+    throw std::runtime_error("--step 2 on chromosome " + std::to_string(p.nchrom) + " (X) with male samples: the sex-aware allele counts of the non-PAR region "
+                             "are not built; test the autosomes (or supply a sample file without sex codes of 1).");
+  int total_blocks = 0;
+  for (auto& kv : chr_snps) total_blocks += (int)((kv.second.size() + p.bsize - 1) / p.bsize);
+  sout << std::left << std::setw(20) << " * block size" << ": [" << p.bsize << "]\n";
+  sout << std::left << std::setw(20) << " * # blocks" << ": [" << total_blocks << "]\n";
+  sout << " * approximate memory usage : n/a (genotype blocks are tested on the GPU)\n";
+  sout << " * using minimum MAC of " << p.min_mac << " (variants with lower MAC are ignored)\n";
+
+  // output files, one per phenotype (split_by_pheno is the default; print_header_output_single, Step2_Models.cpp:2386-2398)
+  std::vector<std::unique_ptr<TextOut>> ofs;
+  std::vector<std::string> out_names;
+  const bool multi = part.nparts > 1;        // parts write plain part files; run_step2_all concatenates (and compresses) them
+  for (int q = 0; q < P; ++q) {
+    out_names.push_back(p.out + "_" + r.pheno_names[q] + ".regenie" + (multi ? ".part" + std::to_string(part.part) : (p.gz ? ".gz" : "")));
+    ofs.emplace_back(new TextOut(out_names.back(), multi ? false : p.gz));
+    if (!*ofs.back()) throw std::runtime_error("cannot write file : " + out_names.back());
+    if (part.part == 0) *ofs.back() << "CHROM GENPOS ID ALLELE0 ALLELE1 A1FREQ " << (show_info ? "INFO " : "") << "N TEST BETA SE CHISQ LOG10P EXTRA\n";
+  }
+  part.files = out_names;
+
+  const int fd = in == In::Bed ? open((p.bed + ".bed").c_str(), O_RDONLY) : -1;
+  if (in == In::Bed && fd < 0) throw std::runtime_error("cannot read bed file");
+  std::vector<int64_t> file_idx(n, 0);          // file index of every analysed sample
+  {
+    int64_t kept = 0, k = 0;
+    for (int64_t i = 0; i < r.n_file && k < n; ++i) {
+      if (r.ind_ignore[i]) continue;
+      if (kept == an[k]) file_idx[k++] = i;
+      ++kept;
+    }
+  }
+  int nthreads = p.threads > 0 ? p.threads : std::max(1, (int)std::thread::hardware_concurrency() - 1);   // Regenie.cpp:1104-1106
+  nthreads = std::max(1, std::min(nthreads, 64) / part.nparts);
+  // buildLookupTable (Geno.cpp:2833-2856): 00 -> 2, 01 -> missing (-3), 10 -> 1, 11 -> 0 copies of the first .bim allele
+  static const double lut[4] = {2.0, -3.0, 1.0, 0.0};
+  std::vector<uint8_t> rows, packed;
+  std::vector<double> G, stats, bhat, sfac, mean_v, totp_v, dbuf, ibuf;
+  std::vector<int32_t> ign, nobs_v, nobsp_v;
+  std::vector<int64_t> vidx;
+  std::vector<uint16_t> G16;
+  bool identity = n == r.n_file;                 // every sample of the file is analysed, in file order
+  for (int64_t k = 0; identity && k < n; ++k) identity = file_idx[k] == k;
+  int64_t n_ignored_snps = 0, n_ignored_tests = 0, n_tested = 0;
+  int block = 0;
+  // .bed rows of a block: runs of consecutive variants are cut into pieces read by several threads (the page-cache copy of one pread is a
+  // single core's memcpy), and the NEXT block of the chromosome is read while the current one is tested
+  std::vector<uint8_t> rows_ahead;
+  std::future<void> ahead;
+  auto read_bed = [&](const std::vector<int64_t>& snps, int64_t j0, int bs, std::vector<uint8_t>& buf) {
+    buf.resize((size_t)bs * r.bpr);
+    struct Piece { int64_t file_off, buf_off, len; };
+    std::vector<Piece> pieces;
+    const int64_t chunk = 16 << 20;
+    for (int j = 0; j < bs;) {
+      int e = j + 1;
+      while (e < bs && r.snp_offset[snps[j0 + e]] == r.snp_offset[snps[j0 + e - 1]] + 1) ++e;
+      const int64_t want = (int64_t)(e - j) * r.bpr, off = 3 + r.snp_offset[snps[j0 + j]] * r.bpr;
+      for (int64_t o = 0; o < want; o += chunk) pieces.push_back({off + o, (int64_t)j * r.bpr + o, std::min(chunk, want - o)});
+      j = e;
+    }
+    std::atomic<int> failed(0);
+    parallel_for((int)pieces.size(), std::min(nthreads, 8), [&](int t) {
+      int64_t got = 0;
+      while (got < pieces[t].len) {
+        const ssize_t k = pread(fd, buf.data() + pieces[t].buf_off + got, (size_t)(pieces[t].len - got), pieces[t].file_off + got);
+        if (k <= 0) { failed = 1; return; }
+        got += k;
+      }
+    });
+    if (failed) throw std::runtime_error("cannot read bed file");
+  };
+  for (int chrom : r.chr_read) {
+    if (!chr_snps.count(chrom)) continue;
+    const std::vector<int64_t>& snps = chr_snps[chrom];
+    const int nb_chr = (int)((snps.size() + p.bsize - 1) / p.bsize);
+    if (block + nb_chr <= part.blk_lo || block >= part.blk_hi) { block += nb_chr; continue; }     // none of the chromosome's blocks is this part's
+    sout << "Chromosome " << chrom << " [" << nb_chr << " blocks in total]\n";
+    // blup_read_chr (Step2_Models.cpp:51-140) + compute_res (Data.cpp:2386-2400)
+    sout << (p.bt ? "   -reading loco predictions for the chromosome and fitting null logistic regression on binary phenotypes..."
+                  : p.ct ? "   -reading loco predictions for the chromosome and fitting null poisson regression..." : "   -reading loco predictions for the chromosome...");
+    auto tb = std::chrono::steady_clock::now();
+    for (int q = 0; q < P; ++q) {
+      Run::Blup& bl = r.blups[q];
+      if (chrom < 1 || chrom > (int)bl.line_off.size()) throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' has no line for chromosome " + std::to_string(chrom) + ".");
+      std::string line;
+      if (!bl.lines.empty()) line = bl.lines[chrom - 1];
+      else {
+        std::ifstream f(bl.file, std::ios::binary);
+        f.seekg(bl.line_off[chrom - 1]);
+        std::getline(f, line);
+      }
+      auto t = split_ws(line);
+      if (t.size() != bl.col_sample.size())
+        throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' has different number of entries on line " + std::to_string(chrom + 1) + " compared to the header (=" + std::to_string(t.size()) + " vs " + std::to_string(bl.col_sample.size()) + ").");
+      if (chr_str_to_int(t[0], p.nchrom) != chrom)
+        throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' starts with `" + t[0] + "`instead of chromosome number=" + std::to_string(chrom) + ".");
+      std::vector<double> blup(N, 0.0);
+      for (size_t c = 1; c < t.size(); ++c) {
+        const int64_t i = bl.col_sample[c];
+        if (i < 0 || !r.ain[i] || !r.mask[(size_t)q * N + i]) continue;
+        const double v = convert_double(t[c]);
+        if (v == MISSING) throw std::runtime_error("individual has missing predictions (chr=" + std::to_string(chrom) + ";phenotype=" + r.pheno_names[q] + ").");
+        blup[i] = v;
+      }
+      if (glm) {   // fit_null_logistic / fit_null_poisson, test-mode branch (Step1_Models.cpp:54-140, :225-288): offset = the LOCO prediction of
+                   // the analysed, unmasked samples
+        std::vector<double> off(n), eta, pv;
+        for (int64_t k = 0; k < n; ++k) off[k] = blup[an[k]] * Mc[(size_t)q * n + k];
+        const double* yq = Yc.data() + (size_t)q * n;
+        const uint8_t* mq = Mc.data() + (size_t)q * n;
+        bool ok;
+        std::vector<double> bnull;
+        if (p.ct) ok = fit_poisson(yq, Xc.data(), mq, n, C, p, eta, off.data(), &pv);
+        else {
+          ok = fit_logistic(yq, Xc.data(), mq, n, C, p, true, eta, off.data(), &pv, &bnull);
+          if (!ok) ok = fit_logistic(yq, Xc.data(), mq, n, C, p, false, eta, off.data(), &pv, &bnull);
+        }
+        if (ok && firth) {   // fit_null_firth (Step2_Models.cpp:985-1060): penalised fit of the covariates, start = the unpenalised estimate
+          if (!null_firth_files.empty() && !null_firth_files[q].empty()) {   // --use-null-firth: the stored estimates of this chromosome as start
+            TextIn nf(null_firth_files[q]);                                   // (get_beta_start_firth, Step2_Models.cpp:1936-1981)
+            if (!nf) throw std::runtime_error("cannot read file : " + null_firth_files[q]);
+            std::string ln;
+            while (std::getline(nf, ln)) {
+              const auto t = split_ws(ln);
+              if (t.empty()) throw std::runtime_error("error reading null firth estimates file");
+              if (chr_str_to_int(t[0], p.nchrom) != chrom) continue;
+              if ((int)t.size() - 1 > C) throw std::runtime_error("file has more predictors than included in analysis (=" + std::to_string(t.size()) + " vs " + std::to_string(C) + ")");
+              for (size_t c = 1; c < t.size(); ++c) {
+                const double v = convert_double(t[c]);
+                if (v == MISSING) throw std::runtime_error("no missing values allowed in file");
+                bnull[c - 1] = v;
+              }
+              break;
+            }
+          }
+          ok = firth_null_fit(yq, Xc.data(), mq, off.data(), n, C, bnull);
+          if (ok && p.write_null_firth) {     // (*firth_est_files[i]) << chrom << " " << bvec (Step2_Models.cpp:1019-1020)
+            std::ostringstream ln;
+            ln << chrom << " ";
+            for (int c = 0; c < C; ++c) ln << bnull[c] << (c + 1 < C ? " " : "");
+            firth_file_body[q] += ln.str() + "\n";
+          }
+          if (!ok) sout << "\n     WARNING: null Firth failed for phenotype '" << r.pheno_names[q] << "' (it will be skipped).";
+          for (int64_t k = 0; ok && k < n; ++k) {
+            double e = blup[an[k]];
+            for (int c = 0; c < C; ++c) e += Xc[(size_t)c * n + k] * bnull[c];
+            firth_off[(size_t)q * n + k] = e;
+            if (!p.firth_approx) blup_off[(size_t)q * n + k] = blup[an[k]];
+          }
+          for (int c = 0; ok && c < C; ++c) firth_bnull[(size_t)q * C + c] = bnull[c];
+        }
+        bt_pass[q] = ok ? 1 : 0;
+        if (!ok) { if (!(firth && !bnull.empty())) sout << "\n     WARNING: " << (p.ct ? "poisson" : "logistic") << " regression did not converge for phenotype '" << r.pheno_names[q] << "'."; continue; }
+        // the fitted mean of the null model: the library forms Gamma_sqrt^2, the weighted covariates and (X^T W X)^-1 from it (rg_s2_bt_set_null)
+        for (int64_t k = 0; k < n; ++k) bt_fit[(size_t)q * n + k] = pv[k];
+        continue;
+      }
+      double ss = 0.0;
+      for (int64_t k = 0; k < n; ++k) {
+        const double v = (Yc[(size_t)q * n + k] - blup[an[k]]) * Mc[(size_t)q * n + k];
+        resc[(size_t)q * n + k] = v;
+        ss += v * v;
+      }
+      const double sd = std::sqrt(ss) / std::sqrt(r.neff[q] - C);
+      for (int64_t k = 0; k < n; ++k) resc[(size_t)q * n + k] /= sd;
+      scf[q] = r.scale_Y[q] * sd;
+    }
+    if (glm) {   // compute_res_bin / compute_res_count (Data.cpp:2439-2455): the null models of the chromosome go to the device
+      rg_s2_bt_null nm;
+      memset(&nm, 0, sizeof(nm));
+      nm.family = p.ct ? 1 : 0; nm.X = Xc.data(); nm.y = Yc.data(); nm.mask = Mc.data(); nm.fitted = bt_fit.data();
+      nm.firth_offset = (firth && p.firth_approx) ? firth_off.data() : nullptr; nm.pass = bt_pass.data();
+      s2check(rg_s2_bt_set_null(s2, &nm));
+    } else s2check(rg_s2_set_null(s2, Xc.data(), resc.data(), Mc.data(), scf.data()));
+    sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tb).count() << "ms) \n";
+
+    for (int bb = 0; bb < nb_chr; ++bb, ++block) {
+      if (block < part.blk_lo || block >= part.blk_hi) continue;
+      const int64_t j0 = (int64_t)bb * p.bsize;
+      const int bs = (int)std::min<int64_t>(p.bsize, (int64_t)snps.size() - j0);
+      sout << " block [" << block + 1 << "/" << total_blocks << "] : ";
+      auto t1 = std::chrono::steady_clock::now();
+      vidx.resize(bs);
+      for (int j = 0; j < bs; ++j) vidx[j] = r.snp_offset[snps[j0 + j]];
+      if (in != In::Dosage) rows.resize((size_t)bs * r.bpr);
+      std::unique_lock<std::mutex> rlk(g_reader_mu, std::defer_lock);
+      if (multi && in != In::Bed) rlk.lock();
+      if (in == In::PgenHard) {   // ReadHardcalls per variant (Geno.cpp:2570-2573), as .bed-coded rows (00 = two ALT copies)
+        if (rg_pgen_read_bed_rows(r.pgen, bs, vidx.data(), rows.data(), r.bpr) != RG_PGEN_OK) throw std::runtime_error(rg_pgen_last_error(r.pgen));
+      } else if (in == In::Dosage) {
+        dbuf.resize((size_t)bs * r.n_file);
+        if (r.bgenh) {            // parseSnpfromBGEN (Geno.cpp:2186-2330): dosages and the terms of the IMPUTE info score
+          ibuf.resize((size_t)bs * r.n_file);
+          if (rg_bgen_read_dosages_info(r.bgenh, bs, vidx.data(), p.ref_first ? 1 : 0, dbuf.data(), ibuf.data(), r.n_file) != RG_BGEN_OK)
+            throw std::runtime_error(rg_bgen_last_error(r.bgenh));
+        } else if (rg_pgen_read_dosage_rows(r.pgen, bs, vidx.data(), dbuf.data(), r.n_file) != RG_PGEN_OK)   // Read() (Geno.cpp:2570-2571)
+          throw std::runtime_error(rg_pgen_last_error(r.pgen));
+      }
+      if (rlk.owns_lock()) rlk.unlock();
+      if (in == In::Bed) {   // the block's rows: read ahead by the previous iteration when it could be (same chromosome), else read now
+        if (ahead.valid()) { ahead.get(); rows.swap(rows_ahead); }
+        else read_bed(snps, j0, bs, rows);
+        if (bb + 1 < nb_chr && block + 1 < part.blk_hi) {
+          const int64_t jn = (int64_t)(bb + 1) * p.bsize;
+          const int bn = (int)std::min<int64_t>(p.bsize, (int64_t)snps.size() - jn);
+          ahead = std::async(std::launch::async, [&, jn, bn]() { read_bed(snps, jn, bn, rows_ahead); });
+        }
+      }
+      std::vector<double> total(bs, 0.0);
+      std::vector<int64_t> ns1(bs, 0);
+      std::vector<double> af_t, mac_t, info_num, info_t;   // per trait: only filled when some sample is masked for some trait
+      std::vector<int64_t> ns_t;
+      std::vector<uint8_t> variant_ignored(bs, 0);
+      rg_s2_qt_out o;
+      stats.resize((size_t)bs * P); bhat.resize((size_t)bs * P); sfac.resize(bs); ign.resize(bs);
+      memset(&o, 0, sizeof(o));
+      o.stats = stats.data(); o.bhat = bhat.data(); o.scale_fac = sfac.data(); o.ignored = ign.data();
+      test_ignored.assign((size_t)bs * P, 0);
+      bool integral = false;
+      const int dscale = r.bgenh ? 255 : 16384;
+      if (in == In::Dosage) {
+        // dosages: the analysed samples' doubles, allele totals, the info-score numerator and the per-trait corrections on the host
+        // (parseSnpfromBGEN / readChunkFromPGENFileToG with update_trait_counts, Geno.cpp:2948-2959), the test on the fp64 route
+        G.assign((size_t)bs * n, 0.0);
+        info_num.assign(bs, 0.0);
+        if (any_missing || glm) { af_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0); info_t.assign((size_t)bs * P, 0.0); }
+        parallel_for(bs, nthreads, [&](int j) {
+          const double* d = dbuf.data() + (size_t)j * r.n_file;
+          const double* iv = r.bgenh ? ibuf.data() + (size_t)j * r.n_file : nullptr;
+          double* g = G.data() + (size_t)j * n;
+          double tot = 0.0, inf = 0.0; int64_t ns = 0;
+          for (int64_t k = 0; k < n; ++k) {
+            const int64_t i = file_idx[k];
+            const double v = d[i];
+            g[k] = v;
+            if (v == -3.0) continue;
+            const double e = iv ? iv[i] : v * v;
+            tot += v; inf += e; ++ns;
+            if ((any_missing || glm) && has_missing[k])
+              for (int q = 0; q < P; ++q)
+                if (!Mc[(size_t)q * n + k]) { af_t[(size_t)j * P + q] -= v; ns_t[(size_t)j * P + q] -= 1; info_t[(size_t)j * P + q] -= e; }
+          }
+          total[j] = tot; ns1[j] = ns; info_num[j] = inf;
+          if (std::min(tot, 2.0 * ns - tot) < p.min_mac) variant_ignored[j] = 1;      // compute_mac (Geno.cpp:3077-3108), autosomes
+        });
+        // 8-bit .bgen probabilities and .pgen dosages are integers in units of 1 / 255 and 1 / 16384: as uint16 rows they take the
+        // integer route of the library (digit planes on the i8 matrix cores, 2 B per genotype over PCIe); anything else, or
+        // RG_S2_DENSE=1, the fp64 route
+        integral = !dense_route || glm;
+        if (integral) {
+          G16.resize((size_t)bs * n);
+          std::vector<uint8_t> bad(bs, 0);
+          parallel_for(bs, nthreads, [&](int j) {
+            const double* g = G.data() + (size_t)j * n;
+            uint16_t* q = G16.data() + (size_t)j * n;
+            for (int64_t k = 0; k < n; ++k) {
+              if (g[k] == -3.0) { q[k] = 0xFFFFu; continue; }
+              const double v = g[k] * dscale, rv = std::nearbyint(v);
+              if (std::fabs(v - rv) > 1e-6 || rv < 0 || rv > 2.0 * dscale) { bad[j] = 1; break; }
+              q[k] = (uint16_t)rv;
+            }
+          });
+          for (int j = 0; j < bs; ++j) if (bad[j]) integral = false;
+        }
+      }
+      std::vector<double> af_d; std::vector<int64_t> ns_d;
+      if (glm && in == In::Dosage) { af_d = af_t; ns_d = ns_t; }
+      if (glm) {
+        // the score test of the block through the C ABI (rg_s2_bt_score_*: contractions on the i8 matrix cores, C x C algebra in the library):
+        // hard calls as packed rows, dosages as integer rows
+        bt_counts.resize((size_t)bs * 4); bt_vstat.resize((size_t)bs * 4);
+        denum_v.assign((size_t)bs * P, 0.0);
+        std::vector<double> mu_v(bs, 0.0), totp((size_t)bs * P, 0.0);
+        std::vector<uint8_t> sparse_v(bs, 0);
+        std::vector<int32_t> nobsp((size_t)bs * P, 0);
+        rg_s2_bt_out bo;
+        memset(&bo, 0, sizeof(bo));
+        bo.stats = stats.data(); bo.bhat = bhat.data(); bo.denum = denum_v.data(); bo.test_ignored = test_ignored.data(); bo.mean = mu_v.data();
+        bo.ignored = ign.data(); bo.sparse = sparse_v.data();
+        const uint8_t* src = rows.data();
+        int64_t ld = r.bpr;
+        if (in == In::Dosage) {
+          if (!integral) throw std::runtime_error("--step 2 --bt / --ct on dosages that are not integer multiples of 1/" + std::to_string(dscale) + " is not built.");
+          bo.vstat = bt_vstat.data();
+          s2check(rg_s2_bt_score_int(s2, G16.data(), n, bs, 0, dscale, NUMTOL, &bo));
+        } else {
+          if (!identity) {
+            ld = (n + 3) / 4;
+            packed.assign((size_t)bs * ld, 0);
+            parallel_for(bs, nthreads, [&](int j) {
+              const uint8_t* row = rows.data() + (size_t)j * r.bpr;
+              uint8_t* dst = packed.data() + (size_t)j * ld;
+              for (int64_t k = 0; k < n; ++k) {
+                const int64_t i = file_idx[k];
+                dst[k >> 2] |= (uint8_t)(((row[i >> 2] >> (2 * (i & 3))) & 3) << (2 * (k & 3)));
+              }
+            });
+            src = packed.data();
+          }
+          bo.counts = bt_counts.data(); bo.total_p = totp.data(); bo.n_obs_p = nobsp.data();
+          s2check(rg_s2_bt_score_packed(s2, src, ld, bs, 0, flip, NUMTOL, &bo));
+        }
+        af_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0);
+        for (int j = 0; j < bs; ++j) {
+          if (in != In::Dosage) {     // (dosages: the host loop above has them, summed as the reference sums)
+            const double n1 = bt_counts[(size_t)j * 4], n2 = bt_counts[(size_t)j * 4 + 1], nm = bt_counts[(size_t)j * 4 + 2];
+            ns1[j] = (int64_t)((double)n - nm); total[j] = n1 + 2.0 * n2;
+          }
+          sfac[j] = 1.0;
+          if (std::min(total[j], 2.0 * ns1[j] - total[j]) < p.min_mac) variant_ignored[j] = 1;
+          for (int q = 0; q < P; ++q) {
+            af_t[(size_t)j * P + q] = in != In::Dosage ? totp[(size_t)j * P + q] : af_d[(size_t)j * P + q];      // per-trait allele and sample counts
+            ns_t[(size_t)j * P + q] = in != In::Dosage ? (int64_t)nobsp[(size_t)j * P + q] : ns_d[(size_t)j * P + q];
+          }
+        }
+        if (correct) {
+          // check_pval_snp (Step2_Models.cpp:1987-2029): |z| above the threshold -> run_SPA_test (--spa) or fit_firth_logistic_snp_fast on Gres / Gamma_sqrt
+          // with the null Firth model's covariate effects in the offset.  The flagged (variant, trait) pairs are re-tested on the device, one
+          // workgroup per pair (rg_s2_bt_correct); the exact Firth test (--firth without --approx: a C + 1 parameter fit) stays on the host threads.
+          corrected.assign((size_t)bs * P, 0); corr_fail.assign((size_t)bs * P, 0);
+          corr_beta.assign((size_t)bs * P, 0.0); corr_se.assign((size_t)bs * P, 0.0); corr_chisq.assign((size_t)bs * P, 0.0); corr_logp.assign((size_t)bs * P, -1.0);
+          std::vector<int> todo;
+          for (int j = 0; j < bs; ++j)
+            for (int q = 0; q < P; ++q)
+              if (!variant_ignored[j] && !ign[j] && !test_ignored[(size_t)j * P + q] && std::fabs(stats[(size_t)j * P + q]) > z_thr) todo.push_back(j * P + q);
+          if (spa || p.firth_approx) {
+            std::vector<int32_t> pv_(todo.size()), pt_(todo.size());
+            std::vector<uint8_t> pf_(todo.size());
+            for (size_t t = 0; t < todo.size(); ++t) {
+              const int j = todo[t] / P, q = todo[t] % P;
+              pv_[t] = j; pt_[t] = q;
+              if (spa) pf_[t] = sparse_v[j];                                                            // fastSPA (Step2_Models.cpp:2087-2097)
+              else {
+                const double tq = total[j] + af_t[(size_t)j * P + q];
+                const double nsq = (double)(ns1[j] + ns_t[(size_t)j * P + q]);
+                pf_[t] = sparse_v[j] && std::min(tq, 2.0 * nsq - tq) < 50.0;                            // fit_firth_logistic_snp_fast :1173-1185: carriers only
+              }
+            }
+            std::vector<rg_s2_bt_corr> cr(todo.size());
+            s2check(rg_s2_bt_correct(s2, spa ? RG_S2_BT_SPA : RG_S2_BT_FIRTH_APPROX, (int32_t)todo.size(), pv_.data(), pt_.data(), pf_.data(), p.firth_se ? 1 : 0, cr.data()));
+            for (size_t t = 0; t < todo.size(); ++t) {
+              const size_t e = (size_t)todo[t];
+              corrected[e] = 1;
+              if (cr[t].fail) { corr_fail[e] = 1; continue; }
+              corr_beta[e] = cr[t].beta; corr_se[e] = cr[t].se; corr_chisq[e] = cr[t].chisq; corr_logp[e] = cr[t].logp;
+            }
+          } else
+          parallel_for((int)todo.size(), nthreads, [&](int t) {
+            const int j = todo[t] / P, q = todo[t] % P;
+            const double mu = mu_v[j];
+            std::vector<double> gt(n);                // the mean-imputed genotype of the analysed samples
+            if (in == In::Dosage) { const double* g = G.data() + (size_t)j * n; for (int64_t k = 0; k < n; ++k) gt[k] = g[k] == -3.0 ? mu : g[k]; }
+            else {
+              const uint8_t* row = src + (size_t)j * ld;
+              for (int64_t k = 0; k < n; ++k) {
+                double hc = lut[(row[k >> 2] >> (2 * (k & 3))) & 3];
+                if (flip && hc != -3.0) hc = 2.0 - hc;
+                gt[k] = hc == -3.0 ? mu : hc;
+              }
+            }
+            // the exact test (fit_firth_logistic_snp, Step2_Models.cpp:1062-1156): design [covariates | g~ on its raw scale], offset = the LOCO
+            // prediction; null fit = the variant's coefficient held at 0 under the same penalty, then every coefficient free
+            const uint8_t* mq = Mc.data() + (size_t)q * n;
+            std::vector<const double*> cols(C + 1);
+            for (int c = 0; c < C; ++c) cols[c] = Xc.data() + (size_t)c * n;
+            cols[C] = gt.data();
+            std::vector<double> bf(C + 1, 0.0), inv;
+            for (int c = 0; c < C; ++c) bf[c] = firth_bnull[(size_t)q * C + c];
+            double dev0 = 0.0, dev1 = 0.0;
+            corrected[(size_t)j * P + q] = 1;
+            const bool okx = firth_fit_cols(Yc.data() + (size_t)q * n, cols, mq, blup_off.data() + (size_t)q * n, n, C, 25.0, bf, &dev0) &&
+                             firth_fit_cols(Yc.data() + (size_t)q * n, cols, mq, blup_off.data() + (size_t)q * n, n, C + 1, 5.0, bf, &dev1, &inv);
+            const double lrt = dev0 - dev1;
+            if (!okx || lrt < 0) { corr_fail[(size_t)j * P + q] = 1; return; }
+            corr_beta[(size_t)j * P + q] = bf[C];
+            corr_chisq[(size_t)j * P + q] = lrt;
+            corr_se[(size_t)j * P + q] = (p.firth_se && lrt > 0) ? std::fabs(bf[C]) / std::sqrt(lrt) : std::sqrt(inv[(size_t)C * (C + 1) + C]);
+          });
+        }
+      } else if (in == In::Dosage) {
+        if (integral) s2check(rg_s2_qt_block_int(s2, G16.data(), n, bs, 0, dscale, NUMTOL, &o));
+        else s2check(rg_s2_qt_block(s2, G.data(), n, bs, 0, NUMTOL, &o));
+      } else if (!dense_route) {
+        // hard calls stay packed: the 2-bit codes of the analysed samples go to the device as they are (the rows of the file itself
+        // when no sample was dropped), the library counts the calls and contracts them on the i8 matrix cores
+        const uint8_t* src = rows.data();
+        int64_t ld = r.bpr;
+        if (!identity) {
+          ld = (n + 3) / 4;
+          packed.assign((size_t)bs * ld, 0);
+          parallel_for(bs, nthreads, [&](int j) {
+            const uint8_t* row = rows.data() + (size_t)j * r.bpr;
+            uint8_t* dst = packed.data() + (size_t)j * ld;
+            for (int64_t k = 0; k < n; ++k) {
+              const int64_t i = file_idx[k];
+              dst[k >> 2] |= (uint8_t)(((row[i >> 2] >> (2 * (i & 3))) & 3) << (2 * (k & 3)));
+            }
+          });
+          src = packed.data();
+        }
+        mean_v.resize(bs); nobs_v.resize(bs);
+        o.mean = mean_v.data(); o.n_obs = nobs_v.data();
+        if (any_missing) {
+          totp_v.resize((size_t)bs * P); nobsp_v.resize((size_t)bs * P);
+          o.total_p = totp_v.data(); o.n_obs_p = nobsp_v.data();
+        }
+        s2check(rg_s2_qt_block_packed(s2, src, ld, bs, 0, flip, NUMTOL, &o));
+        if (any_missing) { af_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0); }
+        for (int j = 0; j < bs; ++j) {
+          ns1[j] = nobs_v[j];
+          total[j] = std::nearbyint(mean_v[j] * (double)nobs_v[j]);       // the allele count is an integer: mean = total / n_obs
+          if (std::min(total[j], 2.0 * ns1[j] - total[j]) < p.min_mac) variant_ignored[j] = 1;   // compute_mac (Geno.cpp:3077-3108), autosomes
+          if (any_missing)                                                  // update_trait_counts (Geno.cpp:2948-2959) as differences from the totals
+            for (int q = 0; q < P; ++q) {
+              af_t[(size_t)j * P + q] = std::nearbyint(totp_v[(size_t)j * P + q]) - total[j];
+              ns_t[(size_t)j * P + q] = (int64_t)nobsp_v[(size_t)j * P + q] - ns1[j];
+            }
+        }
+      } else {
+        // parseSnpfromBed: decode the analysed samples, allele counts
+        G.assign((size_t)bs * n, 0.0);
+        if (any_missing) { af_t.assign((size_t)bs * P, 0.0); mac_t.assign((size_t)bs * P, 0.0); ns_t.assign((size_t)bs * P, 0); }
+        parallel_for(bs, nthreads, [&](int j) {
+          const uint8_t* row = rows.data() + (size_t)j * r.bpr;
+          double* g = G.data() + (size_t)j * n;
+          double tot = 0.0; int64_t ns = 0;
+          for (int64_t k = 0; k < n; ++k) {
+            const int64_t i = file_idx[k];
+            double hc = lut[(row[i >> 2] >> (2 * (i & 3))) & 3];
+            if (flip && hc != -3.0) hc = 2.0 - hc;
+            g[k] = hc;
+            if (hc != -3.0) {
+              tot += hc; ++ns;
+              if (any_missing && has_missing[k])   // update_trait_counts (Geno.cpp:2948-2959): subtract from the totals of the traits the sample is masked for
+                for (int q = 0; q < P; ++q)
+                  if (!Mc[(size_t)q * n + k]) { af_t[(size_t)j * P + q] -= hc; mac_t[(size_t)j * P + q] -= hc; ns_t[(size_t)j * P + q] -= 1; }
+            }
+          }
+          total[j] = tot; ns1[j] = ns;
+          // compute_mac (Geno.cpp:3077-3108), autosomes
+          const double mac = std::min(tot, 2.0 * ns - tot);
+          if (mac < p.min_mac) variant_ignored[j] = 1;
+        });
+        s2check(rg_s2_qt_block(s2, G.data(), n, bs, 0, NUMTOL, &o));
+      }
+      // the result lines (compute_score_qt after the statistic, Step2_Models.cpp:440-466; print_sum_stats_single): formatted by the host threads
+      // in contiguous chunks of variants, appended to the files in order
+      const int nchunk = std::max(1, std::min(nthreads, bs / 64));
+      std::vector<std::string> chunk_out((size_t)nchunk * P);
+      std::vector<int64_t> c_snps(nchunk, 0), c_tests(nchunk, 0), c_tested(nchunk, 0);
+      parallel_for(nchunk, nchunk, [&](int t) {
+        for (int j = (int)((int64_t)bs * t / nchunk), je = (int)((int64_t)bs * (t + 1) / nchunk); j < je; ++j) {
+          if (!variant_ignored[j] && show_info && p.set_min_info && ns1[j] > 0) {   // the all-sample info score below --minINFO drops the variant (Geno.cpp:2349-2353)
+            const double af1 = total[j] / (2.0 * ns1[j]);
+            double info1 = 1.0;
+            if (af1 != 0.0 && af1 != 1.0)
+              info1 = r.bgenh ? 1.0 - info_num[j] / (2.0 * ns1[j] * af1 * (1.0 - af1)) : (info_num[j] / ns1[j] - 4.0 * af1 * af1) / (2.0 * af1 * (1.0 - af1));
+            if (info1 < p.min_info) variant_ignored[j] = 1;
+          }
+          if (variant_ignored[j] || ign[j]) { ++c_snps[t]; continue; }
+          const int64_t sj = snps[j0 + j];
+          std::ostringstream head;
+          head << r.snp_chrom[sj] << " " << r.snp_pos[sj] << " " << r.snp_ids[sj] << " " << r.snp_a0[sj] << " " << r.snp_a1[sj] << " ";
+          for (int q = 0; q < P; ++q) {
+            double af = total[j] / (2.0 * ns1[j]);
+            int64_t nsq = ns1[j];
+            double infq = show_info ? info_num[j] : 0.0;
+            if (test_ignored[(size_t)j * P + q]) continue;
+            if (any_missing || glm) {   // compute_mac / compute_aaf_info per trait
+              const double tq = total[j] + af_t[(size_t)j * P + q];
+              nsq = ns1[j] + ns_t[(size_t)j * P + q];
+              const double macq = std::min(tq, 2.0 * nsq - tq);
+              if (macq < p.min_mac) { ++c_tests[t]; continue; }
+              af = tq / (2.0 * nsq);
+              if (show_info) infq += info_t[(size_t)j * P + q];
+            }
+            double info = 1.0;     // compute_aaf_info (Geno.cpp:3132-3141): IMPUTE info for .bgen, MaCH r2 for .pgen dosages
+            if (show_info && af != 0.0 && af != 1.0)
+              info = r.bgenh ? 1.0 - infq / (2.0 * nsq * af * (1.0 - af)) : (infq / nsq - 4.0 * af * af) / (2.0 * af * (1.0 - af));
+            if (show_info && p.set_min_info && info < p.min_info) { ++c_tests[t]; continue; }     // ignored_trait (Geno.cpp:3143-3144)
+            const double st = stats[(size_t)j * P + q];
+            double bh = bhat[(size_t)j * P + q], se = bh / st, chisq = st * st;
+            bool test_fail = false;
+            double logp_spa = -1.0;
+            if (correct && corrected[(size_t)j * P + q]) {
+              if (corr_fail[(size_t)j * P + q]) test_fail = true;                    // get_sumstats(true, ...): the score test's BETA / SE, no p-value
+              else { bh = corr_beta[(size_t)j * P + q]; se = corr_se[(size_t)j * P + q]; chisq = corr_chisq[(size_t)j * P + q]; logp_spa = corr_logp[(size_t)j * P + q]; }
+            }
+            const double logp = logp_spa >= 0 ? logp_spa : get_logp(chisq);       // --spa prints the p-value it computed, the chi-square is derived from it
+            std::ostringstream ln;
+            ln << head.str() << af << " ";
+            if (show_info) ln << info << " ";
+            ln << nsq << " ADD ";
+            if (se >= 0 && !std::isnan(se)) ln << bh << ' ' << se;
+            else ln << "NA NA";
+            if (chisq >= 0 && !std::isnan(logp) && !test_fail) ln << ' ' << chisq << ' ' << logp;
+            else ln << " NA NA";
+            ln << (test_fail ? " TEST_FAIL\n" : " NA\n");
+            chunk_out[(size_t)t * P + q] += ln.str();
+            ++c_tested[t];
+          }
+        }
+      });
+      for (int t = 0; t < nchunk; ++t) {
+        for (int q = 0; q < P; ++q) *ofs[q] << chunk_out[(size_t)t * P + q];
+        n_ignored_snps += c_snps[t]; n_ignored_tests += c_tests[t]; n_tested += c_tested[t];
+      }
+      sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() << "ms) \n";
+    }
+  }
+  if (fd >= 0) close(fd);
+  rg_s2_destroy(s2);
+  part.n_ignored_snps = n_ignored_snps; part.n_ignored_tests = n_ignored_tests;
+  part.firth_body = firth_file_body;
+  return 0;
+}
+
+// `--step 2` on G GPUs (G = 1: the calling thread): contiguous block ranges per GPU, floor(B / G) blocks each and the first B mod G one more
+// (the split of write_l0_master, Data.cpp:270-302), one host thread and one library context per GPU, no collective on the data path.
+int run_step2_all(Run& r, std::chrono::steady_clock::time_point t_start) {
+  const Params& p = r.p;
+  const int P = r.P, G = p.gpus;
+  std::map<int, int64_t> cn;
+  for (int c : r.snp_chrom) cn[c]++;
+  int B = 0;
+  for (auto& kv : cn) B += (int)((kv.second + p.bsize - 1) / p.bsize);
+  std::vector<S2Part> parts(G);
+  int b0 = 0;
+  for (int g = 0; g < G; ++g) {
+    parts[g].part = g; parts[g].nparts = G; parts[g].device = p.single_device ? p.device : p.device + g;
+    parts[g].blk_lo = b0; b0 += B / G + (g < B % G ? 1 : 0); parts[g].blk_hi = b0;
+  }
+  if (G == 1) { parts[0].blk_hi = INT_MAX; run_step2(r, t_start, parts[0]); }
+  else {
+    sout << std::left << std::setw(20) << " * # GPUs" << ": [" << G << "] (blocks [1.." << B << "] in contiguous ranges)\n";
+    std::vector<std::ostringstream> logs(G);
+    std::vector<std::exception_ptr> errs(G, nullptr);
+    std::vector<std::thread> th;
+    for (int g = 0; g < G; ++g)
+      th.emplace_back([&, g]() {
+        tl_log = &logs[g];
+        try { run_step2(r, t_start, parts[g]); } catch (...) { errs[g] = std::current_exception(); }
+        tl_log = nullptr;
+      });
+    for (auto& t : th) t.join();
+    for (int g = 0; g < G; ++g) {
+      sout << " GPU " << g << " : blocks [" << parts[g].blk_lo + 1 << ".." << parts[g].blk_hi << "]\n";
+      if (g == 0) sout << logs[g].str();
+      else {   // the run-wide header lines were logged by part 0
+        const std::string lg = logs[g].str();
+        const size_t at = lg.find("Chromosome ");
+        if (at != std::string::npos) sout << lg.substr(at);
+      }
+    }
+    for (int g = 0; g < G; ++g) if (errs[g]) std::rethrow_exception(errs[g]);
+    // the parts' result files in block order -> PFX_<trait>.regenie[.gz]
+    for (int q = 0; q < P; ++q) {
+      const std::string fn = p.out + "_" + r.pheno_names[q] + ".regenie" + (p.gz ? ".gz" : "");
+      TextOut of(fn, p.gz);
+      if (!of) throw std::runtime_error("cannot write file : " + fn);
+      std::vector<char> buf(8 << 20);
+      for (int g = 0; g < G; ++g) {
+        std::ifstream in(parts[g].files[q], std::ios::binary);
+        while (in) { in.read(buf.data(), (std::streamsize)buf.size()); of.write(buf.data(), in.gcount()); }
+        in.close();
+        std::remove(parts[g].files[q].c_str());
+      }
+      parts[0].files[q] = fn;
+    }
+  }
+  if (p.write_null_firth) {   // print_null_firth_info (Step2_Models.cpp:1871-1900): PFX_<k>.firth per trait + PFX_firth.list
+    std::ofstream fl(p.out + "_firth.list");
+    for (int q = 0; q < P; ++q) {
+      std::string body;
+      std::set<std::string> seen;     // a chromosome that spans two parts was fitted by both: one line
+      for (int g = 0; g < G; ++g) {
+        std::istringstream is(parts[g].firth_body.empty() ? std::string() : parts[g].firth_body[q]);
+        std::string ln;
+        while (std::getline(is, ln)) { const std::string chr = ln.substr(0, ln.find(' ')); if (seen.insert(chr).second) body += ln + "\n"; }
+      }
+      if (body.empty()) continue;
+      const std::string ffn = p.out + "_" + std::to_string(q + 1) + ".firth" + (p.gz ? ".gz" : "");
+      TextOut ff(ffn, p.gz);
+      if (!ff) throw std::runtime_error("cannot write file : " + ffn);
+      ff << body;
+      fl << r.pheno_names[q] << " " << (p.use_rel_path ? ffn : get_fullpath(ffn)) << "\n";
+    }
+    sout << "List of files with null Firth estimates written to: [" << p.out << "_firth.list]\n";
+  }
+  int64_t n_ignored = 0;
+  for (auto& pt : parts) n_ignored += pt.n_ignored_snps * P + pt.n_ignored_tests;
+  sout << "\nAssociation results stored separately for each trait in files : \n";
+  for (auto& fn : parts[0].files) sout << "* [" << fn << "]\n";
+  sout << "\nNumber of ignored tests due to low MAC" << (p.set_min_info ? " or info score" : "") << " : " << n_ignored << "\n";
+  sout << "\nElapsed time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << "s\nEnd of run\n";
+  return 0;
+}
+
+}  // namespace rgdrv
