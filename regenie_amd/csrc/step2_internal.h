@@ -50,6 +50,7 @@ struct rg_s2_ctx {
   int32_t* d_mlist = nullptr;
   int64_t* d_moff = nullptr;    // [P + 1]
   double* d_xl = nullptr;       // [list entries][C]: the listed samples' covariate rows
+  double* d_xq = nullptr;       // [P][C][C]: X^T X over the samples listed for each phenotype
   void* pbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t pcap[6] = {0, 0, 0, 0, 0, 0};
   int32_t hdr[3] = {0, 0, 0};   // staged {total_miss = 0, bs, 0} of the block in flight
