@@ -419,7 +419,7 @@ def measured_traffic(dom, nblocks, n_batches, P):
     except OSError:
         return None, "no build stamp"
     group = {"chol_f64": "chol", "l1_gram_f64": "l1_gram", "gram_fp4": "gram_fp4", "pred": "pred"}[dom]
-    stale = False
+    stale, same_build = False, False
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
         try:
             tj = json.load(open(fn))
@@ -428,12 +428,15 @@ def measured_traffic(dom, nblocks, n_batches, P):
         if tj.get("build_stamp") != stamp:
             stale = True
             continue
+        same_build = True
         g = tj.get("groups", {}).get(group)
         if not g or tj.get("blocks") != nblocks or tj.get("phenos") != P:
             continue
         per = g["hbm_bytes"] / max(1, tj["level0_batches"] if group != "l1_gram" else g.get("lead_launches", P))
         return per, ("FETCH_SIZE x 2 + WRITE_SIZE of the kernel (group) from separate rocprofv3 --pmc passes of this command on this "
                      "build (%s), per launch" % os.path.basename(fn))
+    if same_build:
+        return None, "the PMC traffic file of this build covers another workload (blocks / phenotypes); none was collected for this one"
     return None, ("the committed PMC traffic files were measured on other kernel sources (stale): refused" if stale else
                   "no PMC traffic file for this build / workload (tools/collect_profiles.sh)")
 
