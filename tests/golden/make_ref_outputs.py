@@ -63,6 +63,12 @@ CASES = {
     # --step 2 --ct come from a --qt run on the same file: any LOCO prediction is a valid offset of the null Poisson model
     "ct_synth": (["--step", "1", "--bed", "{S}", "--covarFile", "{S}.covar", "--phenoFile", "{S}.pheno", "--bsize", "100", "--qt"],
                  dict(M=300, N=1500, chroms=[1] * 160 + [2] * 140, P=2, seed=23, binary=False, counts=True, missing_pheno=0.03, miss_rate=0.01)),
+    # time-to-event traits on the example genotypes: time columns out of file order (outputs _1 and _3), tied times, pairs missing for one
+    # trait or for both, --remove / --cv 3 / --ref-first.  example/phenotype_t2e.txt is synthetic (no such file in the reference's example
+    # directory); tests/golden/make_t2e_example_pheno.py writes it
+    "t2e_kfold_3chr_opts": (["--step", "1", "--bed", "{E}/example_3chr", "--covarFile", "{E}/covariates.txt", "--phenoFile", "{E}/phenotype_t2e.txt",
+                             "--remove", "{E}/fid_iid_to_remove.txt", "--bsize", "70", "--cv", "3", "--ref-first", "--t2e",
+                             "--phenoColList", "Relapse_T,Surv", "--eventColList", "Relapse,Died"], None),
     # time-to-event traits (--t2e, Cox ridge at level 1): two traits with tied event times and 3 % missing (time, event) pairs; the
     # phenotype file {S}.t2e comes from tests/util.py write_t2e_pheno
     "t2e_kfold_synth": (["--step", "1", "--bed", "{S}", "--covarFile", "{S}.covar", "--phenoFile", "{S}.t2e", "--bsize", "100", "--t2e",

@@ -72,7 +72,7 @@ def test_driver_reproduces_reference_outputs(name, tmp_path):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     meta = json.load(open(os.path.join(REF_OUT, name, "meta.json")))
     assert [ln.split()[0] for ln in open(os.path.join(d, "out_pred.list"))] == meta["pred_list"]
-    if spec and spec.get("t2e"):      # --t2e: penalties and held-out deviances (Data.cpp:1043-1049), files numbered by the time column
+    if "--t2e" in args:      # --t2e: penalties and held-out deviances (Data.cpp:1043-1049), files numbered by the time column
         got_t, ref_t = table_lines(open(os.path.join(d, "out.log")).read()), meta["table"]
         assert len(got_t) == len(ref_t)
         for a, b in zip(got_t, ref_t):

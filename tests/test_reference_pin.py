@@ -202,6 +202,34 @@ def test_t2e_cox_ridge_synthetic(tmp_path):
         assert_text_equal(got, ref, "t2e_kfold_synth %s" % tn)
 
 
+def test_t2e_cox_ridge_example_with_options():
+    """--t2e on the example genotypes with --remove / --cv 3 / --ref-first: time columns out of file order (regenie numbers its outputs 1 and 3),
+    pairs missing for one trait or both (the covariates are centred over ALL kept samples, analysed or not, Pheno.cpp:1663-1667)."""
+    from oracle import regenie_step1_t2e as t2e
+    meta = json.load(open(os.path.join(REF_OUT, "t2e_kfold_3chr_opts", "meta.json")))
+    opt = orc.Step1Options(bed=E("example_3chr"), pheno_file=E("phenotype_t2e.txt"), covar_file=E("covariates.txt"), remove=[E("fid_iid_to_remove.txt")],
+                           bsize=70, cv_folds=3, ref_first=True)
+    res = t2e.run_step1_t2e(opt, {"Relapse_T": "Relapse", "Surv": "Died"})
+    got_lines = [ln.rstrip() for ln in res["log"]]
+    assert len(got_lines) == len(meta["table"]) and meta["pred_list"] == ["Surv", "Relapse_T"]
+    for a, b in zip(meta["table"], got_lines):
+        if a.startswith("phenotype"):
+            assert a.split() == b.split()
+            continue
+        ma, mb = T2E_RE.match(a), T2E_RE.match(b)
+        assert float(mb.group(1)) == pytest.approx(float(ma.group(1)), rel=2e-5) and float(mb.group(2)) == pytest.approx(float(ma.group(2)), rel=2e-5)
+        assert bool(ma.group(3)) == bool(mb.group(3)), (a, b)
+    prep = res["prep"]
+    order = [i for i in sorted(range(len(prep.ids)), key=lambda i: prep.ids[i]) if prep.ind_in_analysis[i]]
+    for tn in ("Surv", "Relapse_T"):
+        ti = prep.pheno_names.index(tn)
+        ids, ref = read_loco_gz(os.path.join(REF_OUT, "t2e_kfold_3chr_opts", "out_%d.loco.gz" % (ti + 1)))
+        got = res["traits"][tn]["loco"][order, :].T.copy()
+        got[:, ~prep.mask[order, ti]] = np.nan
+        assert ids == [prep.ids[i] for i in order]
+        assert_text_equal(got, ref, "t2e_kfold_3chr_opts %s" % tn)
+
+
 def test_level0_predictors_full_precision():
     """The reference's --run-l0 job files are its level-0 predictors as raw doubles, column-major N x (blocks*R0) per
     phenotype (Step1_Models.cpp:728-734): ridge_level_0 of the oracle against them at fp64 resolution."""
