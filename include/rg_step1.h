@@ -187,6 +187,11 @@ void rg_group_abort(rg_group* g, int32_t rank);
 int32_t rg_l0_batch_blocks(const rg_ctx* ctx); /* SNP blocks the library works on as one batch: the natural size of one rg_l0_blocks call */
 void* rg_host_alloc(int64_t bytes);
 void rg_host_free(void* p);
+/* Page-locks a range the caller owns, so that rows inside it cross PCIe by asynchronous copies without an intermediate buffer.
+ * read_only = 1 for memory the caller may only read -- a file mapping: the pages of the page cache then ARE the source of the copies
+ * (a .bed mapped and registered this way needs neither a read nor a host buffer).  0 on success; rg_host_unregister before unmapping. */
+int rg_host_register(void* ptr, int64_t bytes, int read_only);
+int rg_host_unregister(void* ptr);
 int rg_ingest_fence(rg_ctx* ctx);
 
 /* ---- phenotype-sharded level 1 (optional) ------------------------------------------------------------

@@ -57,7 +57,7 @@ EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_set
            "rg_l0_set_w", "rg_l1_qt", "rg_l1_qt_loocv", "rg_l1_bt", "rg_l1_cox", "rg_set_collective", "rg_set_l1_view", "rg_set_loco_output", "rg_enable_timing", "rg_get_timing", "rg_k_gram_i8", "rg_k_gram_fp4",
            "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak",
            # one node, several GPUs: level-0 hand-off over RCCL / peer copies; streamed ingest helpers (used by the C++ driver)
-           "rg_group_create", "rg_group_destroy", "rg_l0_finish", "rg_group_prepare", "rg_group_abort", "rg_l0_batch_blocks", "rg_host_alloc", "rg_host_free",
+           "rg_group_create", "rg_group_destroy", "rg_l0_finish", "rg_group_prepare", "rg_group_abort", "rg_l0_batch_blocks", "rg_host_alloc", "rg_host_free", "rg_host_register", "rg_host_unregister",
            "rg_ingest_fence",
            # include/rg_pgen.h (host-side .pgen hardcall input; wrapped by regenie_amd/pgen.py)
            "rg_pgen_open", "rg_pgen_close", "rg_pgen_last_error", "rg_pgen_info", "rg_pgen_read_bed_rows",

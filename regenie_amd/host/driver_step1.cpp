@@ -1,5 +1,6 @@
 // regenie-amd, the C++ host driver (see driver.h): `--step 1` and run().
 #include "driver.h"
+#include <sys/mman.h>
 
 namespace rgdrv {
 
@@ -40,6 +41,36 @@ struct IngestRing {
     for (auto& m : mem) { if (m) { if (pinned) rg_host_free(m); else free(m); } m = nullptr; }
   }
   ~IngestRing() { release(); }
+};
+
+// The .bed itself as the source of the host -> device copies: the file is mapped and the mapping registered (read-only) with the runtime on a
+// thread of its own while the text files are parsed; the pages of the page cache are then what the DMA engines read -- no pread, no host
+// buffer, no page-locking of 4 GB slots (which, at 5 GB/s, also slowed the parsing it ran beside).  tools/ingest_probe.cpp: registering an
+// 8 GB mapping takes 0.08 s and copies from it run at 57 GB/s.  Used for one GPU when every block's variants are consecutive in the file
+// (no --extract / --exclude gaps inside a block); RG_INGEST_MAP=0, a mapping or a registration that fails, fall back on the ring.
+struct BedMap {
+  int fd = -1;
+  uint8_t* base = nullptr;
+  size_t bytes = 0;
+  int state = 0;                       // 0 not started / unusable, 1 registering, 2 registered
+  std::thread th;
+  void start(const std::string& path) {
+    fd = open(path.c_str(), O_RDONLY);
+    if (fd < 0) return;
+    const off_t sz = lseek(fd, 0, SEEK_END);
+    if (sz <= 3) return;
+    void* m = mmap(nullptr, (size_t)sz, PROT_READ, MAP_SHARED, fd, 0);
+    if (m == MAP_FAILED) return;
+    base = (uint8_t*)m; bytes = (size_t)sz; state = 1;
+    th = std::thread([this]() { if (rg_host_register(base, (int64_t)bytes, 1) != 0) state = -1; else state = 2; });
+  }
+  bool ready() { if (th.joinable()) th.join(); return state == 2; }
+  ~BedMap() {
+    if (th.joinable()) th.join();
+    if (state == 2) rg_host_unregister(base);
+    if (base) munmap(base, bytes);
+    if (fd >= 0) close(fd);
+  }
 };
 
 int run(int argc, char** argv) {
@@ -104,9 +135,14 @@ int run(int argc, char** argv) {
   const int64_t ingest_blk_bytes = (int64_t)p.bsize * r.bpr;
   IngestRing pre_ring;
   IngestRing* pre_ring_ptr = nullptr;
-  if (p.step == 1 && p.gpus == 1 && !p.run_l1 && !r.dosage_mode && r.bpr > 0) {   // one GPU: the ring is page-locked under the parsing below
-    pre_ring.start((int64_t)r.snp_chrom.size() * r.bpr, ingest_blk_bytes, -1, 1);
-    pre_ring_ptr = &pre_ring;
+  BedMap bed_map;
+  if (p.step == 1 && p.gpus == 1 && !p.run_l1 && !r.dosage_mode && r.bpr > 0) {   // one GPU: the host side of the ingest is set up under the parsing below
+    const char* em = getenv("RG_INGEST_MAP");
+    if (!r.pgen && !(em && atoi(em) == 0)) bed_map.start(p.bed + ".bed");           // the mapped file, registered on its own thread
+    if (bed_map.state == 0) {                                                        // else the ring of page-locked buffers
+      pre_ring.start((int64_t)r.snp_chrom.size() * r.bpr, ingest_blk_bytes, -1, 1);
+      pre_ring_ptr = &pre_ring;
+    }
   }
   read_pheno_cov(r);
   sout << "   -phenotypes and covariates ready (" << since_start() << "ms since start)\n";
@@ -266,6 +302,32 @@ int run(int argc, char** argv) {
            << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms)\n";
       }
       return;
+    }
+    if (!pre_ring && bed_map.state != 0 && p.gpus == 1) {   // the mapped .bed: every block is a range of the file
+      bool consecutive = true;
+      for (int b = b_lo; b < b_hi && consecutive; ++b)
+        for (int j = 1; j < blocks[b].bs; ++j)
+          if (r.snp_offset[blocks[b].start + j] != r.snp_offset[blocks[b].start + j - 1] + 1) { consecutive = false; break; }
+      const int64_t last = r.snp_offset[blocks[b_hi - 1].start + blocks[b_hi - 1].bs - 1];
+      if (consecutive && 3 + (last + 1) * r.bpr <= (int64_t)bed_map.bytes && bed_map.ready()) {
+        const int nb = b_hi - b_lo;
+        std::vector<int32_t> ids(nb), bss(nb);
+        std::vector<const uint8_t*> ptrs(nb);
+        int64_t nsnp = 0;
+        for (int b = 0; b < nb; ++b) {
+          ids[b] = b_lo + b; bss[b] = blocks[b_lo + b].bs; nsnp += bss[b];
+          ptrs[b] = bed_map.base + 3 + r.snp_offset[blocks[b_lo + b].start] * r.bpr;
+        }
+        auto t1 = std::chrono::steady_clock::now();
+        check(cx, rg_l0_blocks(cx, nb, ids.data(), bss.data(), ptrs.data(), r.bpr, RG_MEM_HOST));
+        auto t2 = std::chrono::steady_clock::now();
+        lg << " blocks [" << b_lo + 1 << ".." << b_hi << "] (chromosomes " << blocks[b_lo].chrom << ".." << blocks[b_hi - 1].chrom << ") : " << nsnp
+           << " snps  (copied to the GPU from the mapped file, queued after " << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms)\n";
+        check(cx, rg_sync(cx));
+        lg << "   -level 0 ridge of blocks [" << b_lo + 1 << ".." << b_hi << "] complete (" <<
+            std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t2).count() << "ms after the last batch was queued)\n";
+        return;
+      }
     }
     const int64_t blk_bytes = ingest_blk_bytes;
     // the ring of host buffers: the one whose page-locking was started while the text files were parsed (one GPU), or a
