@@ -136,10 +136,10 @@ int run(int argc, char** argv) {
   IngestRing pre_ring;
   IngestRing* pre_ring_ptr = nullptr;
   BedMap bed_map;
-  if (p.step == 1 && p.gpus == 1 && !p.run_l1 && !r.dosage_mode && r.bpr > 0) {   // one GPU: the host side of the ingest is set up under the parsing below
+  if (p.step == 1 && !p.run_l1 && !r.dosage_mode && r.bpr > 0) {   // the host side of the ingest is set up under the parsing below
     const char* em = getenv("RG_INGEST_MAP");
-    if (!r.pgen && !(em && atoi(em) == 0)) bed_map.start(p.bed + ".bed");           // the mapped file, registered on its own thread
-    if (bed_map.state == 0) {                                                        // else the ring of page-locked buffers
+    if (!r.pgen && !(em && atoi(em) == 0)) bed_map.start(p.bed + ".bed");           // the mapped file, registered on its own thread (shared by the ranks)
+    if (bed_map.state == 0 && p.gpus == 1) {                                         // else, one GPU: the ring of page-locked buffers
       pre_ring.start((int64_t)r.snp_chrom.size() * r.bpr, ingest_blk_bytes, -1, 1);
       pre_ring_ptr = &pre_ring;
     }
@@ -273,6 +273,7 @@ int run(int argc, char** argv) {
   // reader thread fills page-locked buffers (one pread per block when its variants are contiguous in the file, Geno.cpp:
   // 1702-1769 reads them one by one), the calling thread hands each buffer to rg_l0_blocks -- asynchronous copies, kernels
   // queued behind the previous batch on the other pipeline -- and recycles it once its copy has completed (rg_ingest_fence).
+  const bool mapped_ok = bed_map.state != 0 && bed_map.ready();     // joined here, once: the rank threads only read the flag
   auto level0_range = [&](rg_ctx* cx, int b_lo, int b_hi, std::ostringstream& lg, IngestRing* pre_ring) {
     if (b_lo >= b_hi) return;
     if (r.dosage_mode) {   // a block of dosages is bs x N_file doubles on the host: one block at a time, synchronous
@@ -303,13 +304,13 @@ int run(int argc, char** argv) {
       }
       return;
     }
-    if (!pre_ring && bed_map.state != 0 && p.gpus == 1) {   // the mapped .bed: every block is a range of the file
+    if (!pre_ring && mapped_ok) {   // the mapped .bed: every block is a range of the file
       bool consecutive = true;
       for (int b = b_lo; b < b_hi && consecutive; ++b)
         for (int j = 1; j < blocks[b].bs; ++j)
           if (r.snp_offset[blocks[b].start + j] != r.snp_offset[blocks[b].start + j - 1] + 1) { consecutive = false; break; }
       const int64_t last = r.snp_offset[blocks[b_hi - 1].start + blocks[b_hi - 1].bs - 1];
-      if (consecutive && 3 + (last + 1) * r.bpr <= (int64_t)bed_map.bytes && bed_map.ready()) {
+      if (consecutive && 3 + (last + 1) * r.bpr <= (int64_t)bed_map.bytes) {
         const int nb = b_hi - b_lo;
         std::vector<int32_t> ids(nb), bss(nb);
         std::vector<const uint8_t*> ptrs(nb);
