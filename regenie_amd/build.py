@@ -28,18 +28,24 @@ def _hipcc() -> str:
 
 
 def _digest(paths) -> str:
+    """Digest of the sources by content and by their path RELATIVE to the package: the same tree gives the same stamp wherever it is checked
+    out (the GPU box runs a copy under another root; profiles/*traffic*.json are keyed on this stamp)."""
     h = hashlib.sha256()
-    for p in sorted(paths):
-        with open(p, "rb") as fh:
+    for p in sorted(os.path.relpath(os.path.realpath(q), os.path.realpath(HERE)) for q in paths):
+        with open(os.path.join(HERE, p), "rb") as fh:
             h.update(p.encode())
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    os.makedirs(LIBDIR, exist_ok=True)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "host", f) for f in HOST_SOURCES + ["driver.h"]] + [
+def source_digest() -> str:
+    """The stamp build() writes to lib/build.stamp for the current sources."""
+    return _digest(_deps())
+
+
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "host", f) for f in HOST_SOURCES + ["driver.h"]] + [
                                                       os.path.join(CSRC, "rg_internal.h"),
                                                       os.path.join(CSRC, "step2_internal.h"),
                                                       os.path.join(CSRC, "pgen_reader.h"),
@@ -48,8 +54,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
                                                       os.path.join(HERE, "..", "include", "rg_pgen.h"),
                                                       os.path.join(HERE, "..", "include", "rg_step1.h"),
                                                       os.path.join(HERE, "..", "include", "rg_step2.h")]
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "build.stamp")
-    dig = _digest(deps)
+    dig = source_digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         return LIB
     hipcc = _hipcc()

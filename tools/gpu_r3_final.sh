@@ -31,6 +31,11 @@ python tools/trace_seq.py $O/seq $O/${R}_batch_sequence.md > /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats3 -- python bench.py $C3 > $O/stats3.log 2>&1
 python tools/prof_summary.py $O/stats3 $O/${R}_config3_kernel_stats.md > /dev/null
 rm -rf $O/stats $O/seq $O/stats3
+echo "stamp before the tests: $(cat regenie_amd/lib/build.stamp)"
+( time timeout 1500 python -m pytest tests -q -m gpu ) > $O/pytest_gpu.log 2>&1
+tail -3 $O/pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+echo "stamp after tests and smoke (build() must have found the library current): $(cat regenie_amd/lib/build.stamp)"
 ( time python bench.py ) > $O/bench.log 2>&1; grep '^{' $O/bench.log | tail -1 > $O/${R}_bench_line.json
 python - <<PY
 import json
@@ -44,6 +49,3 @@ print("step2", s2.get("error") or {k:(round(v["ms_per_block"],3), round(v["varia
 print("cpu", {k:d["cpu_baseline"].get(k) for k in ("value","unit","cores","kind")})
 PY
 head -14 $O/${R}_kernel_stats.md
-( time timeout 1500 python -m pytest tests -q -m gpu ) > $O/pytest_gpu.log 2>&1
-tail -3 $O/pytest_gpu.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
