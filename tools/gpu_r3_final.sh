@@ -20,7 +20,7 @@ rm -rf $O/fetch $O/write $O/mfma
 RX='k_l1_gram128|k_l1_wty|k_reduce_slices|k_sum_folds'      # restricted to the level-1 kernels: the unrestricted --pmc passes of this size crash inside rocprofv3
 ( RG_PIPELINES=1 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $O/fetch3 -- python bench.py $C3 ) > $O/fetch3.log 2>&1
 ( RG_PIPELINES=1 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $O/write3 -- python bench.py $C3 ) > $O/write3.log 2>&1
-python tools/pmc_traffic.py $O/fetch3 $O/write3 10 $O/${R}_config3_traffic.json 500 10 | cut -c1-300
+python tools/pmc_traffic.py $O/fetch3 $O/write3 10 $O/${R}_config3_traffic.json 512 10 | cut -c1-300
 cp $O/${R}_config3_traffic.json profiles/
 rm -rf $O/fetch3 $O/write3
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python bench.py --steps 4 --warmup 1 --no-cpu --no-disk --no-extra > $O/stats.log 2>&1

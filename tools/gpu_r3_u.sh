@@ -10,6 +10,6 @@ RX='k_l1_gram128|k_l1_wty|k_reduce_slices|k_sum_folds'
 echo "fetch rc $?"
 ( RG_PIPELINES=1 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --kernel-include-regex "$RX" --output-format csv -d $O/write3 -- python bench.py $C3 ) > $O/write3.log 2>&1
 echo "write rc $?"
-python tools/pmc_traffic.py $O/fetch3 $O/write3 10 $O/r3_config3_traffic.json 500 10 | cut -c1-600
+python tools/pmc_traffic.py $O/fetch3 $O/write3 10 $O/r3_config3_traffic.json 512 10 | cut -c1-600
 find $O -name "*.csv" -size +30M -delete; find $O -name "*.db" -delete
 tail -3 $O/fetch3.log | cut -c1-200
