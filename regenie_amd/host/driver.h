@@ -109,6 +109,7 @@ struct Log {  // mstream (Regenie.hpp:120-142): tee to stdout and <out>.log
   Log& operator<<(std::ostream& (*m)(std::ostream&)) { if (tl_log) { *tl_log << m; return *this; } std::cout << m; if (f.is_open()) f << m; return *this; }
 };
 extern Log sout;
+extern bool fast_exit;              // set at the successful end of a run: main() then leaves through _exit once the log is closed
 extern std::mutex g_reader_mu;      // the .pgen / .bgen readers keep per-handle state: one block read at a time (multi-GPU step 2)
 
 // Files (Files.cpp:38-160): a file whose name ends in ".gz" and starts with the gzip magic is read through zlib, anything

@@ -7,6 +7,7 @@ namespace rgdrv {
 
 thread_local std::ostringstream* tl_log = nullptr;
 Log sout;
+bool fast_exit = false;
 std::mutex g_reader_mu;
 
 std::vector<std::string> split_ws(const std::string& s) {     // the tokens `is >> t` would give (a stream per line cost 2 s of a 500,000-sample run)

@@ -67,6 +67,7 @@ struct BedMap {
   bool ready() { if (th.joinable()) th.join(); return state == 2; }
   ~BedMap() {
     if (th.joinable()) th.join();
+    if (fast_exit) return;                 // the process is about to leave through _exit: the mapping goes with it
     if (state == 2) rg_host_unregister(base);
     if (base) munmap(base, bytes);
     if (fd >= 0) close(fd);
@@ -759,8 +760,12 @@ int run(int argc, char** argv) {
     sout << "List of files with null Firth estimates written to: [" << p.out << "_firth.list]\n";
   }
   if (p.print_prs) sout << "List of files with whole genome PRS written to: [" << p.out << "_prs.list]\n";
-  if (grp) rg_group_destroy(grp);
-  for (rg_ctx* cx : ctxs) rg_destroy(cx);
+  // Every output file is written: the contexts' device memory (tens of GB of workspaces and W) and the runtime are left to process exit -- main()
+  // leaves through _exit -- instead of being freed buffer by buffer (80 - 100 ms of a 0.4 s run at BASELINE configs[1]); RG_TEARDOWN=1 frees them.
+  if (getenv("RG_TEARDOWN") && atoi(getenv("RG_TEARDOWN")) != 0) {
+    if (grp) rg_group_destroy(grp);
+    for (rg_ctx* cx : ctxs) rg_destroy(cx);
+  } else fast_exit = true;
   sout << "\nElapsed time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() << "s\nEnd of run\n";
   return 0;
 }
