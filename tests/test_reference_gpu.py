@@ -281,6 +281,62 @@ def test_driver_vs_oracle_at_500k_samples(kind, tmp_path):
     print("%s: LOCO max-rel-err vs the oracle (6-digit text) %.2e" % (kind, worst))
 
 
+def test_driver_t2e_vs_oracle_at_500k_samples(tmp_path):
+    """`--t2e` at 500,000 samples (two traits, two SNP blocks, bsize 1000): event times rounded to 0.001 -- about twenty tied events per
+    distinct time -- and 1 % of the (time, event) pairs missing.  The device's risk-set scans then run over chunks of ~490 samples per
+    thread (tests/test_l1_cox_gpu.py has two), the held-out folds hold 100,000 samples each.  Driver against the oracle
+    (oracle/regenie_step1_t2e.py, pinned to regenie by tests/test_reference_pin.py): penalties, deviances, the selected penalty and
+    the LOCO predictors at the resolution of the 6-digit text."""
+    from oracle import regenie_step1 as orc
+    from oracle import regenie_step1_t2e as t2e
+    from tests.test_reference_pin import T2E_RE
+    d = str(tmp_path)
+    N = 500_000
+    pre = os.path.join(d, "big")
+    _write_big(pre, N, 1100, [4] * 1000 + [11] * 100, 2, False, seed=2027, missing_pheno=0.0)
+    ph = np.loadtxt(pre + ".pheno", skiprows=1, usecols=(2, 3))
+    rng = np.random.default_rng(5)
+    with open(pre + ".t2e", "w") as fh:
+        fh.write("FID IID T1 E1 T2 E2\n")
+        cols = []
+        for q in range(2):
+            lp = 0.4 * (ph[:, q] - ph[:, q].mean()) / ph[:, q].std()
+            t_ev, t_c = rng.exponential(1.0, N) * np.exp(-lp) * (4.0 + q), rng.exponential(7.0, N)
+            tm, ev = np.round(np.minimum(t_ev, t_c), 3) + 0.001, (t_ev <= t_c).astype(int)
+            cols.append((tm, ev, rng.random(N) < 0.01))
+        fh.write("".join("%d %d %s\n" % (i + 1, i + 1, " ".join("NA NA" if m[i] else "%.3f %d" % (t[i], e[i]) for t, e, m in cols)) for i in range(N)))
+    common = ["--step", "1", "--bed", pre, "--covarFile", pre + ".covar", "--phenoFile", pre + ".t2e", "--bsize", "1000", "--t2e",
+              "--phenoColList", "T1,T2", "--eventColList", "E1,E2"]
+    g = subprocess.run([BIN] + common + ["--out", "gpu"], cwd=d, capture_output=True, text=True, timeout=1200)
+    assert g.returncode == 0, g.stdout[-3000:] + g.stderr[-3000:]
+    t0 = time.time()
+    res = t2e.run_step1_t2e(orc.Step1Options(bed=pre, pheno_file=pre + ".t2e", covar_file=pre + ".covar", bsize=1000), {"T1": "E1", "T2": "E2"})
+    print("t2e at 500k: oracle %.1f s" % (time.time() - t0))
+    got_t = table_lines(open(os.path.join(d, "gpu.log")).read())
+    ref_t = [ln.rstrip() for ln in res["log"]]
+    assert len(got_t) == len(ref_t) == 12
+    for a, b in zip(got_t, ref_t):
+        if b.startswith("phenotype"):
+            assert a.split() == b.split()
+            continue
+        ma, mb = T2E_RE.match(a), T2E_RE.match(b)
+        assert float(ma.group(1)) == pytest.approx(float(mb.group(1)), rel=2e-5) and float(ma.group(2)) == pytest.approx(float(mb.group(2)), rel=2e-5), (a, b)
+        assert bool(ma.group(3)) == bool(mb.group(3)), (a, b)
+    prep = res["prep"]
+    order = [i for i in sorted(range(len(prep.ids)), key=lambda i: prep.ids[i]) if prep.ind_in_analysis[i]]
+    for tn, num in (("T1", 1), ("T2", 3)):
+        ti = prep.pheno_names.index(tn)
+        ids_g, got, first = _loco_file_fast(os.path.join(d, "gpu_%d.loco" % num))
+        ref = res["traits"][tn]["loco"][order, :].T.copy()
+        ref[:, ~prep.mask[order, ti]] = np.nan
+        assert ids_g == [prep.ids[i] for i in order] and first == [str(c) for c in range(1, 24)]
+        e, ok = _check_vals(got, ref, ("t2e", tn))
+        mag = np.maximum(np.abs(got[ok]), 1e-300)
+        tol = np.maximum(10.0 ** (np.floor(np.log10(mag)) - 5), 1e-7 * np.max(np.abs(ref[ok])))
+        assert float(np.max(np.abs(got[ok] - ref[ok]) / tol)) <= 1.0, tn
+        assert e < 1e-5
+
+
 needs_ref_binary = pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")
 
 
