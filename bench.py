@@ -311,6 +311,9 @@ def main():
             "l1_chol_f64": P * 5 * R1 * (L ** 3 / 3.0 + 2.0 * L * L),
             # many-row predictions on the i8 matrix cores: 8 digit planes x 2 N bs (P R0) integer operations per block
             "pred_i8": 8 * 2.0 * N * sum(bss) * P * R0 if P * R0 > 16 else 0.0,
+            # the iterative level-1 models (--bt / --t2e): one weighted Gram X^T W X per fold model and IRLS step, the symmetric
+            # product over the positions it contracts, counted as EXECUTED (rg_timing.wgram_positions sums them over the Grams)
+            "wgram_f64": 1.0 * tm["wgram_positions"] * L * (L + 1),
         }
         kernels = {
             "gram_fp4": {"ms": tm["ms_gram"], "achieved_TOPS": flops["gram_fp4"] / (tm["ms_gram"] * 1e-3) / 1e12 if tm["ms_gram"] else None,
@@ -322,7 +325,13 @@ def main():
                             "full_product_TFLOPS_survey_8d": 2.0 * N * L * L * P / (tm["ms_l1_gram"] * 1e-3) / 1e12 if tm["ms_l1_gram"] else None},
             "l1_chol_f64": {"ms": tm["ms_l1_chol"]}, "l1_cv_pred": {"ms": tm["ms_l1_pred"]},
         }
-        cand = ["gram_fp4", "chol_f64", "l1_gram_f64"] + (["pred"] if flops["pred_i8"] else [])
+        if tm["n_wgram"]:
+            kernels["wgram_f64"] = {"ms": tm["ms_wgram"], "achieved_TFLOPS": flops["wgram_f64"] / (tm["ms_wgram"] * 1e-3) / 1e12 if tm["ms_wgram"] else None,
+                                    "chain_grams": tm["n_wgram"], "irls_rounds": tm["n_irls_rounds"], "grams_per_trait": tm["n_wgram"] / P,
+                                    "ms_per_chain_gram": tm["ms_wgram"] / tm["n_wgram"]}
+            kernels["irls_solve"] = {"ms": tm["ms_irls_solve"]}
+            kernels["irls_stream"] = {"ms": tm["ms_irls_stream"]}
+        cand = ["gram_fp4", "chol_f64", "l1_gram_f64"] + (["pred"] if flops["pred_i8"] else []) + (["wgram_f64"] if tm["n_wgram"] and tm["ms_wgram"] else [])
         dom = max(cand, key=lambda k: kernels[k]["ms"])
         kernels["gram_fp4"]["frac_of_fp4_peak"] = kernels["gram_fp4"]["achieved_TOPS"] / PEAK["fp4_mfma_TOPS"]
         traffic, traffic_note = measured_traffic(dom, len(my_blocks), n_batches, P)
@@ -333,17 +342,20 @@ def main():
                     "algorithmic_ops_per_launch": flops["gram_fp4"] / max(1, n_batches), "avg_launch_ms": tm["ms_gram"] / max(1, n_batches)}
         elif dom == "pred":
             a = kernels[dom]["achieved_TOPS_i8_digit_planes"]
-            roof = {"kernel": "k_l0_pred_i8_ring (level-0 predictions, exact digit planes on the i8 matrix cores)", "bound": "mfma", "achieved": a,
+            roof = {"kernel": "k_l0_pred_i8 (level-0 predictions, exact digit planes on the i8 matrix cores)", "bound": "mfma", "achieved": a,
                     "peak": PEAK["i8_mfma_TOPS"], "unit": "TOP/s", "frac": a / PEAK["i8_mfma_TOPS"], "traffic": traffic, "traffic_note": traffic_note,
                     "algorithmic_ops_per_launch": flops["pred_i8"] / max(1, n_batches), "avg_launch_ms": tm["ms_pred"] / max(1, n_batches)}
         else:
             a = kernels[dom]["achieved_TFLOPS"]
+            nlaunch = {"chol_f64": n_batches, "l1_gram_f64": P, "wgram_f64": tm["n_irls_rounds"]}[dom]
             roof = {"kernel": {"chol_f64": "k_chol_update/gfact/gstrip/backsolve (fp64 MFMA batched Cholesky, per level-0 batch of systems)",
-                               "l1_gram_f64": "k_l1_gram128 (fp64 MFMA level-1 fold Gram, one launch per phenotype)"}[dom], "bound": "mfma", "achieved": a,
+                               "l1_gram_f64": "k_l1_gram128 (fp64 MFMA level-1 fold Gram, one launch per phenotype)",
+                               "wgram_f64": "k_wgram128 (fp64 MFMA weighted Gram X^T W X of the logistic / Cox ridge IRLS, one launch per lock-step round "
+                                            "over the unfinished fold models)"}[dom], "bound": "mfma", "achieved": a,
                     "peak": PEAK["f64_mfma_TFLOPS"], "unit": "TFLOP/s", "frac": a / PEAK["f64_mfma_TFLOPS"], "traffic": traffic,
                     "traffic_note": traffic_note,
-                    "algorithmic_flops_per_launch": flops[dom] / max(1, n_batches if dom == "chol_f64" else P),
-                    "avg_launch_ms": kernels[dom]["ms"] / max(1, n_batches if dom == "chol_f64" else P)}
+                    "algorithmic_flops_per_launch": flops[dom] / max(1, nlaunch),
+                    "avg_launch_ms": kernels[dom]["ms"] / max(1, nlaunch)}
 
     # ---- CPU baseline: the oracle (numpy/OpenBLAS restatement of the reference) on a bounded sample ----
     cpu = None
@@ -418,7 +430,7 @@ def measured_traffic(dom, nblocks, n_batches, P):
         stamp = open(os.path.join(ROOT, "regenie_amd", "lib", "build.stamp")).read().strip()
     except OSError:
         return None, "no build stamp"
-    group = {"chol_f64": "chol", "l1_gram_f64": "l1_gram", "gram_fp4": "gram_fp4", "pred": "pred"}[dom]
+    group = {"chol_f64": "chol", "l1_gram_f64": "l1_gram", "gram_fp4": "gram_fp4", "pred": "pred", "wgram_f64": "wgram"}[dom]
     stale, same_build = False, False
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
         try:

@@ -270,6 +270,14 @@ typedef struct rg_timing {
   double ms_prep, ms_xy, ms_gram, ms_assemble, ms_chol, ms_solve, ms_pred, ms_l1_gram, ms_l1_chol,
       ms_l1_pred;
   int64_t n_gram_launches, n_chol_launches;
+  /* the iterative level-1 models (rg_l1_bt, rg_l1_cox): what their time is made of.  The counts are kept whether or not timing is
+   * enabled; the three ms fields need rg_enable_timing (they bracket the launches with events and wait for them). */
+  double ms_wgram;          /* weighted Grams X^T W X (+ slice reduction, + X^T W z row) */
+  double ms_irls_solve;     /* the ridge systems of the IRLS steps (batched Cholesky) / the Cox sweep */
+  double ms_irls_stream;    /* the passes over the predictors that evaluate a state: eta, weights, deviance, score */
+  int64_t n_wgram;          /* chain Grams formed: one per (fold model or LOOCV model, IRLS step) */
+  int64_t n_irls_rounds;    /* lock-step rounds (a round advances every unfinished fold model by one IRLS step) */
+  int64_t wgram_positions;  /* sum over the chain Grams of the sample positions contracted (their flop count is positions * L * (L + 1)) */
 } rg_timing;
 int rg_enable_timing(rg_ctx* ctx, int on); /* wraps kernel groups in hipEvents on the ctx stream */
 int rg_get_timing(rg_ctx* ctx, rg_timing* out);

@@ -630,6 +630,18 @@ struct DevBufs {
     }                                                                                  \
   } while (0)
 
+// brackets the launches of a scope with the context's two events when timing is on (rg_enable_timing) and adds the elapsed time to
+// a slot of rg_timing; a no-op otherwise (the waits would serialise the host with the device)
+struct L1Lap {
+  rg_ctx* c; hipStream_t st; double* slot;
+  L1Lap(rg_ctx* ctx, hipStream_t s, double* sl) : c(ctx), st(s), slot(sl) { if (c->timing) hipEventRecord(c->ev0, st); }
+  ~L1Lap() {
+    if (!c->timing) return;
+    hipEventRecord(c->ev1, st); hipEventSynchronize(c->ev1);
+    float ms = 0.f; hipEventElapsedTime(&ms, c->ev0, c->ev1); *slot += ms;
+  }
+};
+
 struct L1Common {
   rg_ctx* ctx; hipStream_t st;
   int L, P, n64, rtot, T, nchr;   // P: phenotypes of the current view
@@ -785,6 +797,7 @@ struct BtState {
 int bt_eval(BtState& s, const std::vector<double>& hbeta, std::vector<double>& sums /*[nchain][BT_NPART]*/) {
   rg_ctx* ctx = s.ctx;
   hipStream_t st = s.c->st;
+  L1Lap lap(ctx, st, &ctx->tm.ms_irls_stream);
   L1X_HIP(hipMemcpyAsync(s.d_beta, hbeta.data(), sizeof(double) * hbeta.size(), hipMemcpyHostToDevice, st));
   for (int ch0 = 0; ch0 < s.nchain; ch0 += NCH)
     hipLaunchKernelGGL(k_bt_eval, dim3(s.nchunk), dim3(256), 0, st, s.a, ch0, ctx->d_c256_seg, ctx->d_c256_pos,
@@ -801,6 +814,7 @@ int bt_eval(BtState& s, const std::vector<double>& hbeta, std::vector<double>& s
 int bt_score(BtState& s, const std::vector<double>& tauc, std::vector<double>& maxabs) {
   rg_ctx* ctx = s.ctx;
   hipStream_t st = s.c->st;
+  L1Lap lap(ctx, st, &ctx->tm.ms_irls_stream);
   L1X_HIP(hipMemcpyAsync(s.d_tauc, tauc.data(), sizeof(double) * s.nchain, hipMemcpyHostToDevice, st));
   for (int ch0 = 0; ch0 < s.nchain; ch0 += NCH)
     hipLaunchKernelGGL(k_bt_score, dim3(s.c->L), dim3(256), 0, st, s.a, ch0, s.d_tauc, s.d_score);
@@ -824,7 +838,17 @@ int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<doub
   L1X_HIP(hipMemcpyAsync(s.d_tauc, tauc.data(), sizeof(double) * s.nchain, hipMemcpyHostToDevice, st));
   WgArgs g{c.Wv, ctx->d_zero, c.Np, c.L, c.Pv, s.p, c.n64, s.a.wv, rhs_is_score ? nullptr : s.a.zv, s.d_tauc,
            s.d_map, s.a.kfold, s.d_sys, c.msz};
-  { const int rcw = launch_wgram(ctx, st, g, c.T, na); if (rcw) return rcw; }
+  {
+    L1Lap lap(ctx, st, &ctx->tm.ms_wgram);
+    const int rcw = launch_wgram(ctx, st, g, c.T, na); if (rcw) return rcw;
+  }
+  ctx->tm.n_wgram += na;
+  ++ctx->tm.n_irls_rounds;
+  {
+    const int64_t all = ctx->seg.pos_start[ctx->seg.nseg - 1] + ctx->seg.plen[ctx->seg.nseg - 1];
+    for (int i = 0; i < na; ++i) ctx->tm.wgram_positions += all - (s.a.kfold ? ctx->seg.plen[act[i]] : 0);
+  }
+  L1Lap lap2(ctx, st, &ctx->tm.ms_irls_solve);
   if (rhs_is_score)
     for (int i = 0; i < na; ++i)
       L1X_HIP(hipMemcpyAsync(s.d_sys + (int64_t)i * c.msz + (int64_t)c.n64 * c.n64, s.d_score + (int64_t)act[i] * c.n64,
@@ -1340,6 +1364,7 @@ int cox_eval(CoxState& s, const std::vector<double>& beta, bool want_grad, doubl
   rg_ctx* ctx = s.ctx;
   L1Common& c = *s.c;
   hipStream_t st = c.st;
+  L1Lap lap(ctx, st, &ctx->tm.ms_irls_stream);
   L1X_HIP(hipMemcpyAsync(s.d_beta, beta.data(), sizeof(double) * c.L, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_cox_eta, dim3((unsigned)((c.Np + 255) / 256)), dim3(256), 0, st, c.Wv, c.Np, c.L, c.Pv, s.pw, s.d_beta, s.d_off,
                      s.d_keep, s.d_eta);
@@ -1361,7 +1386,13 @@ int cox_sweep(CoxState& s, double lam, std::vector<double>& beta, std::vector<do
   L1X_HIP(hipMemcpyAsync(s.d_tau1, &lam, sizeof(double), hipMemcpyHostToDevice, st));
   L1X_HIP(hipStreamSynchronize(st));
   WgArgs g{c.Wv, ctx->d_zero, c.Np, c.L, c.Pv, s.pw, c.n64, s.d_wv, s.d_zv, s.d_tau1, s.d_map, 0, s.d_sys, c.msz};
-  { const int rcw = launch_wgram(ctx, st, g, c.T, 1); if (rcw) return rcw; }
+  {
+    L1Lap lap(ctx, st, &ctx->tm.ms_wgram);
+    const int rcw = launch_wgram(ctx, st, g, c.T, 1); if (rcw) return rcw;
+  }
+  ++ctx->tm.n_wgram; ++ctx->tm.n_irls_rounds;
+  ctx->tm.wgram_positions += ctx->seg.pos_start[ctx->seg.nseg - 1] + ctx->seg.plen[ctx->seg.nseg - 1];   // held-out samples carry zero weights but are contracted
+  L1Lap lap2(ctx, st, &ctx->tm.ms_irls_solve);
   hipLaunchKernelGGL(k_cox_symm, dim3(c.n64 / 32, c.n64 / 32), dim3(256), 0, st, s.d_sys, c.n64);
   hipLaunchKernelGGL(k_cox_xtg, dim3(c.L), dim3(256), 0, st, s.d_sys, c.n64, c.L, lam, s.d_beta, s.d_xtg);
   hipFuncSetAttribute(reinterpret_cast<const void*>(k_cox_sweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * c.L));

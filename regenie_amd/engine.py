@@ -46,7 +46,9 @@ class RgTiming(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("ms_prep", "ms_xy", "ms_gram", "ms_assemble", "ms_chol",
                                           "ms_solve", "ms_pred", "ms_l1_gram", "ms_l1_chol",
                                           "ms_l1_pred")] + \
-               [("n_gram_launches", C.c_int64), ("n_chol_launches", C.c_int64)]
+               [("n_gram_launches", C.c_int64), ("n_chol_launches", C.c_int64)] + \
+               [("ms_wgram", C.c_double), ("ms_irls_solve", C.c_double), ("ms_irls_stream", C.c_double),
+                ("n_wgram", C.c_int64), ("n_irls_rounds", C.c_int64), ("wgram_positions", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -719,9 +719,18 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     r.offset.assign((size_t)N * r.P, 0.0);
     for (int q = 0; q < r.P; ++q) {
       std::vector<double> eta;
-      if (!cox_null_fit(r.Yraw.data() + (size_t)q * N, r.Yevent.data() + (size_t)q * N, r.mask.data() + (size_t)q * N, r.X.data(), N, nz, p, eta))
-        throw std::runtime_error("step1 cox null regression did not converge for phenotype '" + r.pheno_names[q] + "' by coordinate descent (the reference's Newton "
-                                 "fall-back, cox_firth.cpp, is not built).");
+      const double *tq = r.Yraw.data() + (size_t)q * N, *eq = r.Yevent.data() + (size_t)q * N;
+      const uint8_t* mq = r.mask.data() + (size_t)q * N;
+      // Step1_Models.cpp:415-436: coordinate descent, then the Newton solver with and without its step-halving tolerance; a trait
+      // that none of them fits is dropped with a warning (pheno_pass = false) and the run goes on with the others
+      bool ok = cox_null_fit(tq, eq, mq, r.X.data(), N, nz, p, eta) && !getenv("RG_COX_NULL_FORCE_NEWTON");
+      if (!ok) ok = cox_null_newton(tq, eq, mq, r.X.data(), N, nz, p, 2.5e-4, eta);
+      if (!ok) ok = cox_null_newton(tq, eq, mq, r.X.data(), N, nz, p, 0.0, eta);
+      if (!ok) {
+        r.pheno_pass[q] = 0;
+        sout << "\n     WARNING: step1 cox null regression did not converge for phenotype '" << r.pheno_names[q] << "'.";
+        continue;
+      }
       for (int64_t i = 0; i < N; ++i) r.offset[(size_t)q * N + i] = eta[i];
     }
     sout << "done\n";

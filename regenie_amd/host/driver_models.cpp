@@ -227,6 +227,100 @@ bool cox_null_fit(const double* time, const double* event, const uint8_t* mask, 
   return false;
 }
 
+// The reference's fall-back when the coordinate descent above does not converge (fit_null_cox, Step1_Models.cpp:415-436): the Newton
+// solver of cox_firth.cpp without the Firth term (cox_firth::fit, :137-219, likelihood and derivatives :43-135) from beta = 0 -- full
+// Hessian sum_k ww_k (S2 / S0 - S1 S1^T / S0^2) over the risk sets of the distinct event times, steps clamped to maxstep_null (25), step
+// halving while the log-likelihood drops by more than `stephalf_tol` -- tried with stephalf_tol = numtol_cox_stephalf (2.5e-4) and, if
+// that fails, with 0.  Converged: max |score| < numtol_cox, or a full step that moves no coefficient by 1e-8 (numtol_beta_cox).
+bool cox_null_newton(const double* time, const double* event, const uint8_t* mask, const double* X, int64_t N, int C, const Params& prm, double stephalf_tol,
+                     std::vector<double>& eta) {
+  const int64_t n = N;
+  double neff = 0;
+  for (int64_t i = 0; i < n; ++i) neff += mask[i];
+  const double w = 1.0 / neff;
+  std::vector<int64_t> ord(n);
+  for (int64_t i = 0; i < n; ++i) ord[i] = i;
+  auto stt = [&](int64_t i) { return mask[i] ? event[i] : -999.0; };
+  std::stable_sort(ord.begin(), ord.end(), [&](int64_t a, int64_t b) { return time[a] != time[b] ? time[a] < time[b] : stt(a) > stt(b); });
+  std::vector<double> ww(n, 0.0);       // tie-collapsed event weight at the first event of every distinct event time (survival_data.cpp:40-60)
+  {
+    int64_t a = 0;
+    while (a < n) {
+      int64_t b = a;
+      double cnt = 0;
+      while (b < n && time[ord[b]] == time[ord[a]]) { if (mask[ord[b]] && event[ord[b]] == 1.0) cnt += 1.0; ++b; }
+      if (cnt > 0) ww[a] = cnt * w;      // events sort first inside a time, so position a is an event
+      a = b;
+    }
+  }
+  std::vector<double> beta(C, 0.0), betanew(C, 0.0), score(C), H((size_t)C * C), S1(C), S2((size_t)C * C), we(n), lam0(n), steps;
+  double loglik = 0;
+  auto likelihood = [&](const std::vector<double>& b) {     // eta, loglik, score = X^T residual, H = -second derivative (positive definite)
+    for (int64_t i = 0; i < n; ++i) {
+      double e = 0;
+      if (mask[i]) for (int c = 0; c < C; ++c) e += X[(size_t)c * N + i] * b[c];
+      eta[i] = e;
+    }
+    std::fill(H.begin(), H.end(), 0.0); std::fill(S1.begin(), S1.end(), 0.0); std::fill(S2.begin(), S2.end(), 0.0);
+    double S0 = 0, ll = 0;
+    for (int64_t i = n - 1; i >= 0; --i) {
+      const int64_t s = ord[i];
+      we[i] = mask[s] ? w * std::exp(eta[s]) : 0.0;
+      if (mask[s]) {
+        S0 += we[i];
+        for (int a = 0; a < C; ++a) {
+          const double xa = X[(size_t)a * N + s] * we[i];
+          S1[a] += xa;
+          for (int c2 = 0; c2 <= a; ++c2) S2[(size_t)a * C + c2] += xa * X[(size_t)c2 * N + s];
+        }
+        if (event[s] == 1.0) ll += w * eta[s];
+      }
+      lam0[i] = S0;
+      if (ww[i] > 0) {
+        ll -= ww[i] * std::log(S0);
+        for (int a = 0; a < C; ++a)
+          for (int c2 = 0; c2 <= a; ++c2) H[(size_t)a * C + c2] += ww[i] * (S2[(size_t)a * C + c2] / S0 - S1[a] * S1[c2] / (S0 * S0));
+      }
+    }
+    for (int a = 0; a < C; ++a) for (int c2 = a + 1; c2 < C; ++c2) H[(size_t)a * C + c2] = H[(size_t)c2 * C + a];
+    std::fill(score.begin(), score.end(), 0.0);
+    double A = 0;
+    for (int64_t i = 0; i < n; ++i) {     // cumulative hazard in time order, residual = w (status - mu)
+      if (ww[i] > 0) A += ww[i] / lam0[i];
+      const int64_t s = ord[i];
+      if (!mask[s]) continue;
+      const double res = w * (event[s] == 1.0 ? 1.0 : 0.0) - we[i] * A;
+      for (int a = 0; a < C; ++a) score[a] += X[(size_t)a * N + s] * res;
+    }
+    loglik = ll;
+  };
+  const double tol = 2.5e-4, betatol = 1e-8, maxstep = 25.0;    // numtol_cox, numtol_beta_cox, maxstep_null (Regenie.hpp:221-223, :340)
+  likelihood(beta);
+  double ll_prev = loglik;
+  for (int it = 1; it <= prm.niter_max; ++it) {
+    if (!solve_dense(H, score, C, steps)) return false;
+    for (double& v : steps) if (std::fabs(v) >= maxstep) v = v > 0 ? maxstep : -maxstep;
+    for (int c = 0; c < C; ++c) betanew[c] = beta[c] + steps[c];
+    likelihood(betanew);
+    int ii = 0;
+    while (ll_prev - loglik > stephalf_tol) {
+      if (++ii > prm.niter_max_line_search) {       // "cannot correct step size, add eps" (:186-194)
+        for (int c = 0; c < C; ++c) betanew[c] = beta[c] + steps[c] + 1e-6;
+        likelihood(betanew);
+        break;
+      }
+      for (int c = 0; c < C; ++c) betanew[c] = (beta[c] + betanew[c]) / 2;
+      likelihood(betanew);
+    }
+    double smax = 0, dmax = 0;
+    for (int c = 0; c < C; ++c) { smax = std::max(smax, std::fabs(score[c])); dmax = std::max(dmax, std::fabs(beta[c] - betanew[c])); }
+    beta = betanew;
+    ll_prev = loglik;
+    if (smax < tol || (ii <= 1 && dmax < betatol)) return true;     // eta is the linear predictor at beta
+  }
+  return false;
+}
+
 // fit_null_poisson + fit_poisson (Step1_Models.cpp:225-345) for one phenotype; offset may be null (zero); eta_out = offset + X beta on
 // success, pv_out (optional) the fitted rates
 bool fit_poisson(const double* y, const double* X, const uint8_t* mask, int64_t N, int C, const Params& prm, std::vector<double>& eta,

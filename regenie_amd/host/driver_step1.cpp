@@ -572,6 +572,7 @@ int run(int argc, char** argv) {
 
   // output of one phenotype (Data::output + write_predictions, Data.cpp:956-1129, :1795-1975)
   auto emit_pheno = [&](int q, const double* cs, int bestq, int conv, const double* pq /* [nchr][N] */) {
+    if (!r.pheno_pass[q]) return;   // null model did not converge: the trait is ignored, no table, no file, no list entry (Data.cpp:984)
     std::ostringstream lo;
     lo << "phenotype " << r.outnum(q) << " (" << r.pheno_names[q] << ") : \n";
     if (!conv) {  // Data.cpp:1016-1021
@@ -662,6 +663,7 @@ int run(int argc, char** argv) {
       for (int q = 0; q < nq; ++q) {
         double* cq = cumsum.data() + (size_t)q * NCS * R1;
         std::fill(cq, cq + (size_t)NCS * R1, 0.0);
+        if (!r.pheno_pass[q0 + q]) { converged[q] = 0; best[q] = 0; continue; }   // no offset to fit against: skipped like the other trait modes
         check(cx, rg_l1_cox(cx, q0 + q, R1, r.Yraw.data() + (size_t)(q0 + q) * N, r.Yevent.data() + (size_t)(q0 + q) * N, r.offset.data() + (size_t)(q0 + q) * N, &co,
                             nchr, cols_per_chr.data(), tau.data() + (size_t)(q0 + q) * R1, cq + 5 * R1, &converged[q], &best[q], pred.data() + (size_t)q * nchr * N));
       }
@@ -762,7 +764,14 @@ int run(int argc, char** argv) {
   if (p.print_prs) sout << "List of files with whole genome PRS written to: [" << p.out << "_prs.list]\n";
   // Every output file is written: the contexts' device memory (tens of GB of workspaces and W) and the runtime are left to process exit -- main()
   // leaves through _exit -- instead of being freed buffer by buffer (80 - 100 ms of a 0.4 s run at BASELINE configs[1]); RG_TEARDOWN=1 frees them.
-  if (getenv("RG_TEARDOWN") && atoi(getenv("RG_TEARDOWN")) != 0) {
+  // INVARIANT the fast exit rests on: every output stream of the run (.loco / .prs / .firth / lists) is a local of a scope that has ended by
+  // here, so it is flushed and closed; main() flushes the log and stdout itself.  A tool that finalises at exit (rocprofv3, sanitizers,
+  // coverage) would lose its output, so the fast exit is off whenever one is detected, and RG_TEARDOWN=1 (the test suite sets it) always
+  // takes the full path: contexts, RCCL communicators and the runtime are then torn down in order, which is also what surfaces leaks.
+  const char* td = getenv("RG_TEARDOWN");
+  const bool tooling = getenv("ROCPROFILER_LIBRARY_CTOR") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROF_OUTPUT_PATH") || getenv("LD_PRELOAD") ||
+                       getenv("ASAN_OPTIONS") || getenv("LLVM_PROFILE_FILE");
+  if ((td && atoi(td) != 0) || (tooling && !(td && atoi(td) == 0))) {
     if (grp) rg_group_destroy(grp);
     for (rg_ctx* cx : ctxs) rg_destroy(cx);
   } else fast_exit = true;

@@ -640,7 +640,11 @@ int run_step2_all(Run& r, std::chrono::steady_clock::time_point t_start) {
         if (at != std::string::npos) sout << lg.substr(at);
       }
     }
-    for (int g = 0; g < G; ++g) if (errs[g]) std::rethrow_exception(errs[g]);
+    for (int g = 0; g < G; ++g)
+      if (errs[g]) {   // a part failed: no partial result files are left behind
+        for (int h = 0; h < G; ++h) for (auto& f : parts[h].files) if (!f.empty()) std::remove(f.c_str());
+        std::rethrow_exception(errs[g]);
+      }
     // the parts' result files in block order -> PFX_<trait>.regenie[.gz]
     for (int q = 0; q < P; ++q) {
       const std::string fn = p.out + "_" + r.pheno_names[q] + ".regenie" + (p.gz ? ".gz" : "");
@@ -649,10 +653,14 @@ int run_step2_all(Run& r, std::chrono::steady_clock::time_point t_start) {
       std::vector<char> buf(8 << 20);
       for (int g = 0; g < G; ++g) {
         std::ifstream in(parts[g].files[q], std::ios::binary);
+        if (!in) throw std::runtime_error("cannot read the results of GPU " + std::to_string(g) + " : " + parts[g].files[q]);
         while (in) { in.read(buf.data(), (std::streamsize)buf.size()); of.write(buf.data(), in.gcount()); }
+        if (in.bad() || !of) throw std::runtime_error("error while merging " + parts[g].files[q] + " into " + fn + " (disk full?)");
         in.close();
-        std::remove(parts[g].files[q].c_str());
       }
+      of.flush();
+      if (!of) throw std::runtime_error("error while writing file : " + fn + " (disk full?)");
+      for (int g = 0; g < G; ++g) std::remove(parts[g].files[q].c_str());    // only once the merged file is complete
       parts[0].files[q] = fn;
     }
   }

@@ -11,6 +11,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 EXAMPLE = os.path.join(GOLDEN, "example")
 
 
+# the C++ driver frees its contexts and tears the runtime down in order under the tests (its default is to leave through _exit once
+# every output file is closed): leaks and use-after-free surface here instead of being hidden by the fast exit
+os.environ.setdefault("RG_TEARDOWN", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -508,6 +508,32 @@ def test_cli_multi_gpu_t2e(tmp_path):
     assert "Deviance = " in res["peer2"]["_log"] and "level 1 of phenotypes [2..2]" in res["peer2"]["_log"]
 
 
+def test_cli_t2e_null_model_newton_fallback(tmp_path, monkeypatch):
+    """The null Cox model's fall-back (fit_null_cox, Step1_Models.cpp:415-436: the Newton solver of cox_firth.cpp without the Firth term,
+    used when the coordinate descent does not converge) fits the same model: forced with RG_COX_NULL_FORCE_NEWTON=1 it gives the same
+    penalties, deviances and LOCO predictors as the coordinate descent up to the two solvers' stopping tolerance (score < 2.5e-4)."""
+    from tests.test_reference_pin import synth_t2e_case
+    _, pre = synth_t2e_case(tmp_path)
+    common = ["--step", "1", "--bed", pre, "--phenoFile", pre + ".t2e", "--covarFile", pre + ".covar", "--bsize", "100", "--t2e",
+              "--phenoColList", "T1,T2", "--eventColList", "E1,E2", "--out", "o"]
+    outs = {}
+    for name, env in (("cd", None), ("newton", "1")):
+        d = tmp_path / name
+        d.mkdir()
+        if env:
+            monkeypatch.setenv("RG_COX_NULL_FORCE_NEWTON", env)
+        r = _run(common, str(d))
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        outs[name] = {fn: _parse_loco(str(d / fn))[2] for fn in ("o_1.loco", "o_3.loco")}
+        outs[name]["_log"] = r.stdout
+    for fn in ("o_1.loco", "o_3.loco"):
+        a, b = outs["cd"][fn], outs["newton"][fn]
+        assert np.array_equal(np.isnan(a), np.isnan(b))
+        assert np.nanmax(np.abs(a - b)) <= 2e-3 * np.nanmax(np.abs(a))
+    dev = lambda lg: [float(x.split("Deviance = ")[1].split("<")[0]) for x in lg.splitlines() if "Deviance = " in x]
+    assert dev(outs["newton"]["_log"]) == pytest.approx(dev(outs["cd"]["_log"]), rel=2e-4)
+
+
 @pytest.mark.parametrize("form", ["by_phenotype", "all_gather"])
 def test_cli_multi_gpu_rank_failure_does_not_hang(example_dir, tmp_path, form):
     """A rank whose host side fails (here: the .bed is cut short, so the reader thread of the LAST rank runs out of file) breaks the

@@ -1,0 +1,173 @@
+"""Level 1 at the width of BASELINE configs[2] / [3]: L = 2,560 level-0 predictors (512 blocks x 5 ridge values) per phenotype.
+
+Every other GPU test reaches level 1 with L <= 50 columns, so the code that dominates the target configurations -- the macro-tile table of
+`k_l1_gram128` with its XCD order, K slices and slice reduction (l1.hip), `k_wgram128`'s fold gaps (l1x.hip), the level-1 ridge systems of
+order 2,560 on the per-column Cholesky path (chol.hip) -- was only ever checked by `bench.py --oracle-check`.  Here the predictors are
+injected through `rg_l0_set_w` (the file seam of SURVEY 8b.2: what `--run-l1` reads) at a sample count the oracle finishes in seconds,
+and `rg_l1_qt`, `rg_l1_bt` (K-fold, two traits) and `rg_l1_cox` are held to the oracle's functions for the same rows
+(Step1_Models.cpp:772-872, :966-1156, :2228-2305; Data.cpp:1025-1037, :1196-1266).
+
+The injected predictors have the structure level 0 leaves behind: the five columns of a block are the same block score shrunk by five
+amounts (pairwise correlation 0.9 - 0.99), a small share of the trait in every block, centred and scaled to unit variance over the
+analysed samples, zero for samples outside the analysis."""
+import numpy as np
+import pytest
+
+from oracle import regenie_step1 as orc
+from oracle import regenie_step1_t2e as t2e
+
+pytestmark = pytest.mark.gpu
+
+B_FULL, R0 = 512, 5          # blocks of BASELINE configs[2] (500,000 SNPs / bsize 1000 over 22 chromosomes), ridge values per block
+L_FULL = B_FULL * R0
+
+
+def synth_predictors(N, P, signal, seed, keep=None):
+    """W[ph] (N x L_FULL) shaped like level-0 output, and the liabilities they predict (N x P)."""
+    rng = np.random.default_rng(seed)
+    liab = rng.standard_normal((N, P))
+    keep = np.ones(N, bool) if keep is None else keep
+    W = []
+    for ph in range(P):
+        Z = rng.standard_normal((N, B_FULL)) + signal * liab[:, [ph]]              # block scores: noise + a share of the trait
+        E = rng.standard_normal((N, B_FULL))
+        w = np.empty((N, L_FULL))
+        for r, s in enumerate((0.05, 0.12, 0.2, 0.3, 0.45)):                       # the ridge values of a block: same score, less and less of it
+            w[:, r::R0] = Z + s * E
+        w -= w[keep].mean(axis=0)
+        w /= w[keep].std(axis=0, ddof=1)
+        w[~keep] = 0.0
+        W.append(np.asfortranarray(w))
+    return W, liab
+
+
+def chr_cols():
+    """Columns per chromosome for 512 blocks spread over 22 chromosomes as hg38 lengths would (any split that sums to L exercises k_l1_pred)."""
+    share = np.array([248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 58, 64, 46, 50], float)
+    nb = np.maximum(1, np.floor(share / share.sum() * B_FULL)).astype(int)
+    nb[0] += B_FULL - nb.sum()
+    ctr = np.concatenate([[0], np.cumsum(nb * R0)])
+    return [(c + 1, int(ctr[c]), int(n) * R0) for c, n in enumerate(nb)]
+
+
+def engine_with_w(N, X, Y, mask, keep, cv_sizes, W):
+    from regenie_amd.engine import Step1Engine
+    P = Y.shape[1]
+    eng = Step1Engine(0)
+    eng.set_problem(X=X, Y=Y, mask=mask, ind_in_analysis=keep, cv_sizes=cv_sizes, lam=np.array([1e3, 3e3, 1e4, 3e4, 1e5]),
+                    neff=mask.sum(axis=0).astype(np.float64), n_file=N, n_blocks_total=B_FULL, max_block_size=16)
+    for ph in range(P):
+        for b in range(B_FULL):
+            eng.set_w(b, ph, W[ph][:, b * R0:(b + 1) * R0])
+    return eng
+
+
+def covariates(N, keep, seed):
+    rng = np.random.default_rng(seed)
+    X = np.column_stack([np.ones(N), rng.standard_normal((N, 2))])
+    X[~keep] = 0.0
+    return np.linalg.qr(X)[0] * keep[:, None]
+
+
+def test_qt_kfold_level1_at_L2560():
+    """Two quantitative traits, 20,000 samples (one with 3 % of its values missing), five folds: the five CV sums per ridge value, the
+    selected value, the per-chromosome predictions and the LOCO rows against ridge_level_1 / make_predictions of the oracle."""
+    N, P = 20000, 2
+    rng = np.random.default_rng(11)
+    keep = np.ones(N, bool)
+    W, liab = synth_predictors(N, P, 0.035, seed=5)
+    X = covariates(N, keep, 1)
+    mask = np.ones((N, P), bool)
+    mask[rng.random(N) < 0.03, 1] = False
+    Y = liab - X @ (X.T @ liab)
+    Y = np.where(mask, Y, 0.0)
+    Y /= np.sqrt((Y ** 2).sum(axis=0) / (mask.sum(axis=0) - X.shape[1]))
+    # level 0 leaves values on the rows of samples whose phenotype is missing (Step1_Models.cpp:556-557): W keeps them, y is zero there
+    cv_sizes = orc.set_folds(keep, 5)
+    h1 = orc.set_ridge_params(5)
+    tau = np.stack([orc.tau_from_h(h1, L_FULL, False)] * P)
+    cc = chr_cols()
+    eng = engine_with_w(N, X, Y, mask, keep, cv_sizes, W)
+    cs, best, pred = eng.l1_qt(tau, [nn for (_, _, nn) in cc])
+    eng.close()
+    for ph in range(P):
+        rcs, betas = orc.ridge_level_1(W[ph], Y[:, ph], cv_sizes, tau[ph])
+        rbest = orc.select_tau(rcs, float(mask[:, ph].sum()), False)
+        scale = np.abs(rcs[:5]).max()
+        assert np.abs(cs[ph] - rcs[:5]).max() <= 1e-10 * scale
+        assert int(best[ph]) == rbest
+        rpred = orc.make_predictions(W[ph], betas, rbest, cv_sizes, cc)
+        assert np.abs(pred[ph] - rpred).max() <= 1e-9 * np.abs(rpred).max()
+        rl = orc.loco_from_predictions(rpred, cc, 23)
+        gl = orc.loco_from_predictions(pred[ph], cc, 23)
+        assert np.abs(gl - rl).max() <= 1e-9 * np.abs(rl).max()
+
+
+def test_bt_kfold_level1_at_L2560():
+    """Two binary traits (prevalence 0.3 / 0.12, one with missing values), 6,500 samples, five folds, three ridge values: the K-fold logistic
+    ridge (Step1_Models.cpp:966-1156) runs its IRLS on weighted Grams of order 2,560 -- `k_wgram128` with every chain's held-out fold as a
+    gap -- and the ridge systems on the per-column Cholesky path."""
+    N, P = 6500, 2
+    rng = np.random.default_rng(12)
+    keep = np.ones(N, bool)
+    W, liab = synth_predictors(N, P, 0.04, seed=6)
+    X = covariates(N, keep, 2)
+    mask = np.ones((N, P), bool)
+    mask[rng.random(N) < 0.02, 0] = False
+    yraw = np.column_stack([(liab[:, 0] > np.quantile(liab[:, 0], 0.7)), (liab[:, 1] > np.quantile(liab[:, 1], 0.88))]).astype(np.float64)
+    yraw = np.where(mask, yraw, 0.0)
+    offset = np.empty((N, P))
+    for ph in range(P):                                       # the null model's linear predictor: a constant + a covariate effect
+        prev = yraw[mask[:, ph], ph].mean()
+        offset[:, ph] = np.log(prev / (1 - prev)) + 0.2 * X[:, 1] * np.sqrt(N)
+    Y = np.where(mask, yraw - yraw.mean(axis=0), 0.0)
+    cv_sizes = orc.set_folds(keep, 5)
+    h1 = orc.set_ridge_params(3)
+    tau = np.stack([orc.tau_from_h(h1, L_FULL, True)] * P)
+    cc = chr_cols()
+    opt = orc.Step1Options(bed="", pheno_file="", bt=True)
+    eng = engine_with_w(N, X, Y, mask, keep, cv_sizes, W)
+    cs, conv, best, pred = eng.l1_bt(tau, yraw, offset, [nn for (_, _, nn) in cc], niter_max_ridge=opt.niter_max_ridge,
+                                     niter_max_line_search_ridge=opt.niter_max_line_search_ridge, niter_max_line_search=opt.niter_max_line_search)
+    eng.close()
+    for ph in range(P):
+        rcs, betas, ok = orc.ridge_logistic_level_1(W[ph], yraw[:, ph], offset[:, ph], mask[:, ph], cv_sizes, tau[ph], opt)
+        assert ok and conv[ph]
+        scale = np.abs(rcs).max()
+        assert np.abs(cs[ph] - rcs).max() <= 1e-6 * scale     # both sides stop at max|score| < 1e-4
+        rbest = orc.select_tau(rcs, float(mask[:, ph].sum()), True)
+        assert int(best[ph]) == rbest
+        rpred = orc.make_predictions(W[ph], betas, rbest, cv_sizes, cc)
+        assert np.abs(pred[ph] - rpred).max() <= 1e-6 * np.abs(rpred).max()
+
+
+def test_cox_level1_at_L2560():
+    """One time-to-event trait, 4,000 samples, five folds, three penalties: rg_l1_cox (weighted Gram of order 2,560 per IRLS iteration + one
+    Gauss-Seidel sweep) against the oracle's coordinate passes over the samples (cox_ridge.cpp:116-178)."""
+    N = 4000
+    rng = np.random.default_rng(13)
+    keep = np.ones(N, bool)
+    W, liab = synth_predictors(N, 1, 0.2, seed=7)
+    X = covariates(N, keep, 3)
+    mask = np.ones((N, 1), bool)
+    mask[rng.random(N) < 0.02, 0] = False
+    t_ev = rng.exponential(1.0, N) * np.exp(-0.5 * liab[:, 0]) * 4.0
+    t_c = rng.exponential(6.0, N)
+    time = np.round(np.minimum(t_ev, t_c), 2) + 0.01           # tied event times
+    event = (t_ev <= t_c).astype(np.float64)
+    offset = 0.1 * X[:, 1] * np.sqrt(N)
+    Y = np.where(mask, liab, 0.0)
+    cv_sizes = orc.set_folds(keep, 5)
+    cc = chr_cols()
+    opt = orc.Step1Options(bed="", pheno_file="")
+    rtau, rdev, betas, ok = t2e.ridge_cox_level_1(W[0], time, event, offset, mask[:, 0], cv_sizes, opt, n_ridge_l1=3)
+    eng = engine_with_w(N, X, Y, mask, keep, cv_sizes, W)
+    tau, dev, conv, best, pred = eng.l1_cox(0, time, event, offset, [nn for (_, _, nn) in cc], n_ridge_l1=3)
+    eng.close()
+    assert ok and conv
+    assert tau == pytest.approx(rtau, rel=1e-9)
+    assert dev == pytest.approx(rdev, rel=1e-6)
+    assert best == int(np.argmin(rdev))
+    rpred = orc.make_predictions(W[0], betas, best, cv_sizes, cc)
+    m = mask[:, 0]
+    assert np.abs(pred[m] - rpred[m]).max() <= 1e-6 * np.abs(rpred[m]).max()
