@@ -254,6 +254,7 @@ bool cox_null_newton(const double* time, const double* event, const uint8_t* mas
     }
   }
   std::vector<double> beta(C, 0.0), betanew(C, 0.0), score(C), H((size_t)C * C), S1(C), S2((size_t)C * C), we(n), lam0(n), steps;
+  eta.assign(n, 0.0);
   double loglik = 0;
   auto likelihood = [&](const std::vector<double>& b) {     // eta, loglik, score = X^T residual, H = -second derivative (positive definite)
     for (int64_t i = 0; i < n; ++i) {

@@ -18,7 +18,9 @@ mkdir -p $O
 TMO=${TMO:-1500}
 case $task in
   tests)
-    ( time timeout $TMO python -m pytest tests -q -m gpu "$@" ) > $O/pytest.log 2>&1; tail -15 $O/pytest.log ;;
+    # paths among the arguments select the tests; without any the whole suite runs
+    sel=tests; for a in "$@"; do case $a in tests/*) sel=;; esac; done
+    ( time timeout $TMO python -m pytest $sel -q -m gpu "$@" ) > $O/pytest.log 2>&1; tail -15 $O/pytest.log ;;
   bench)
     ( time timeout $TMO python bench.py "$@" ) > $O/bench.log 2>&1
     grep '^{' $O/bench.log | tail -1 > $O/bench_line.json
