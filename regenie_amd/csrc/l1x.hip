@@ -789,6 +789,7 @@ struct BtState {
   rg_ctx* ctx; L1Common* c; int p, nchain, nchunk;
   BtArgs a;
   double *d_beta, *d_score, *d_tauc, *d_part, *d_sys, *d_dinv;
+  double* d_sw = nullptr;      // [nchain][Np] square roots of the weights (the quasi-Newton Gram of wgram_bf16.hip); null = fp64 Grams only
   int32_t* d_map;
   std::vector<double> h_part, h_score, h_sol;
 };
@@ -828,8 +829,10 @@ int bt_score(BtState& s, const std::vector<double>& tauc, std::vector<double>& m
 
 // (X^T W X + tau I) x = rhs for the chains in `act` (rhs = X^T W z from the extra row, or the score);
 // solutions land in h_sol [nchain][n64].  *bad is set when a system is not positive definite.
+// approx: H~ from the bf16 pair planes (wgram_bf16.hip) instead of the fp64 Gram -- only with rhs_is_score, where the right-hand side is
+// the exact score and the solution a quasi-Newton step (a fixed point of beta + H~^-1 score(beta) has score = 0 whatever H~ is)
 int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<double>& tauc, bool rhs_is_score,
-             bool* bad) {
+             bool* bad, bool approx = false) {
   rg_ctx* ctx = s.ctx;
   L1Common& c = *s.c;
   hipStream_t st = c.st;
@@ -838,7 +841,20 @@ int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<doub
   L1X_HIP(hipMemcpyAsync(s.d_tauc, tauc.data(), sizeof(double) * s.nchain, hipMemcpyHostToDevice, st));
   WgArgs g{c.Wv, ctx->d_zero, c.Np, c.L, c.Pv, s.p, c.n64, s.a.wv, rhs_is_score ? nullptr : s.a.zv, s.d_tauc,
            s.d_map, s.a.kfold, s.d_sys, c.msz};
-  {
+  if (approx && rhs_is_score && s.d_sw) {
+    L1Lap lap(ctx, st, &ctx->tm.ms_wgram);
+    const int MAXSL = 16;
+    double* d_part = (double*)rg_ws(ctx, 14, sizeof(double) * (size_t)MAXSL * na * c.msz);
+    if (!d_part) { ctx->err = "weighted Gram: out of device memory"; return RG_ERR_HIP; }
+    L1X_HIP(hipStreamSynchronize(st));      // `act` (host) must have reached d_map before the table is built from it
+    const int ns = rg_launch_wgram_bf16(ctx, st, c.Wv, c.Np, c.L, c.Pv, s.p, c.n64, s.a.wv, s.d_sw, s.nchain, s.d_map, act.data(), na, s.a.kfold,
+                                        d_part, c.msz, MAXSL);
+    if (ns <= 0) return RG_ERR_HIP;
+    Wg128 g2{g, ns, na, nullptr, d_part};
+    hipLaunchKernelGGL(k_wg_reduce, dim3(c.T * (c.T + 1) / 2, na), dim3(256), 0, st, g2, c.T);
+    L1X_HIP(hipMemset2DAsync(s.d_sys + (int64_t)c.n64 * c.n64, sizeof(double) * c.msz, 0, sizeof(double) * CT * c.n64, na, st));
+    ++ctx->tm.n_wgram_approx_rounds;
+  } else {
     L1Lap lap(ctx, st, &ctx->tm.ms_wgram);
     const int rcw = launch_wgram(ctx, st, g, c.T, na); if (rcw) return rcw;
   }
@@ -970,6 +986,11 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
   L1X_HIP(c.bufs.alloc(&s.d_sys, (size_t)nchain * c.msz));
   L1X_HIP(c.bufs.alloc(&s.d_dinv, rg_chol_ws_doubles((size_t)nchain, c.n64)));
   L1X_HIP(c.bufs.alloc(&s.d_map, (size_t)nchain));
+  // K-fold: the weighted Grams of the IRLS steps as quasi-Newton Hessians on the bf16 matrix cores (wgram_bf16.hip) unless RG_WGRAM_F64=1;
+  // a chain that has not converged after RG_WGRAM_SWITCH steps at one ridge value continues on the fp64 Gram
+  static const bool wg_f64 = getenv("RG_WGRAM_F64") && atoi(getenv("RG_WGRAM_F64")) != 0;
+  static const int wg_switch = getenv("RG_WGRAM_SWITCH") ? atoi(getenv("RG_WGRAM_SWITCH")) : 12;
+  if (!loocv && !wg_f64) L1X_HIP(c.bufs.alloc(&s.d_sw, (size_t)nchain * Np));
   L1X_HIP(hipMemsetAsync(s.d_score, 0, sizeof(double) * (size_t)nchain * n64, st));
   s.h_part.resize((size_t)s.nchunk * nchain * BT_NPART);
   s.h_score.resize((size_t)nchain * n64);
@@ -1049,13 +1070,26 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
         }
         if (!ok) break;
         if (act.empty()) continue;
+        // The IRLS step (Step1_Models.cpp:1059-1064) in its Newton form: beta <- beta + (X^T W X + tau I)^-1 (X^T (y - p) - tau beta),
+        // the same vector as (X^T W X + tau I)^-1 X^T W z.  The score is exact (k_bt_score); the matrix may then be the quasi-Newton
+        // Gram of wgram_bf16.hip.  The score has to be the one at the chain's CURRENT ridge value: a chain that has just moved on to its
+        // next value (or has not been scored yet) gets it recomputed.
+        bool rescore = !any_solved;
+        for (int ch : act) rescore |= (tauc[ch] != taup[std::min(jj[ch], R1 - 1)]);
         for (int ch = 0; ch < K; ++ch) tauc[ch] = taup[std::min(jj[ch], R1 - 1)];
-        bool bad = false;
-        if ((rc = bt_solve(s, act, tauc, false, &bad))) return rc;
-        if (bad) { ok = false; break; }
-        for (int ch : act) {
-          std::memcpy(beta.data() + (size_t)ch * n64, s.h_sol.data() + (size_t)ch * n64, sizeof(double) * L);
-          solved[ch] = 1;
+        if (rescore && (rc = bt_score(s, tauc, maxabs))) return rc;
+        std::vector<int32_t> act_q, act_x;      // quasi-Newton Gram / fp64 Gram (a chain that is slow at this ridge value finishes on the latter)
+        for (int ch : act) ((s.d_sw && niter[ch] <= wg_switch) ? act_q : act_x).push_back(ch);
+        for (int pass = 0; pass < 2 && ok; ++pass) {
+          const std::vector<int32_t>& aa = pass ? act_x : act_q;
+          if (aa.empty()) continue;
+          bool bad = false;
+          if ((rc = bt_solve(s, aa, tauc, true, &bad, pass == 0))) return rc;
+          if (bad) { ok = false; break; }
+          for (int ch : aa) {
+            for (int k = 0; k < L; ++k) beta[(size_t)ch * n64 + k] = betaold[(size_t)ch * n64 + k] + s.h_sol[(size_t)ch * n64 + k];
+            solved[ch] = 1;
+          }
         }
       }
       if (!ok) continue;  // pheno_l1_not_converged: LOCO predictions are skipped (Data.cpp:1016-1021)

@@ -508,6 +508,34 @@ def test_cli_multi_gpu_t2e(tmp_path):
     assert "Deviance = " in res["peer2"]["_log"] and "level 1 of phenotypes [2..2]" in res["peer2"]["_log"]
 
 
+def test_cli_bt_kfold_quasi_newton_gram_equals_fp64_gram(tmp_path, monkeypatch):
+    """The K-fold logistic ridge forms its IRLS Hessians on the bf16 matrix cores (wgram_bf16.hip: bf16 pair planes, exact fp64 score and
+    stopping rule); RG_WGRAM_F64=1 keeps the fp64 Gram of round 3.  Same fixed point, same stopping rule: the selected ridge value is the
+    same, the CV table agrees to its printed digits, the .loco values to the resolution of the text (and most lines are byte-identical)."""
+    from tests.util import synth_dosages, write_plink
+    d = str(tmp_path)
+    S = os.path.join(d, "synth")
+    chroms = [1] * 120 + [2] * 100 + [3] * 80
+    write_plink(S, synth_dosages(300, 5200, miss_rate=0.005, seed=21), chroms, P=3, seed=21, binary=True, missing_pheno=0.02)
+    common = ["--step", "1", "--bed", S, "--covarFile", S + ".covar", "--phenoFile", S + ".pheno", "--bsize", "20", "--bt", "--out", "o"]
+    outs = {}
+    for name in ("quasi", "fp64"):
+        dd = tmp_path / name
+        dd.mkdir()
+        if name == "fp64":
+            monkeypatch.setenv("RG_WGRAM_F64", "1")
+        r = _run(common, str(dd))
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        outs[name] = {k: _parse_loco(str(dd / ("o_%d.loco" % k))) for k in (1, 2, 3)}
+        outs[name]["_log"] = [ln for ln in r.stdout.splitlines() if "-logLik/N" in ln]
+    assert len(outs["quasi"]["_log"]) == 15 and outs["quasi"]["_log"] == outs["fp64"]["_log"]        # 3 traits x 5 ridge values, printed digits
+    for k in (1, 2, 3):
+        a, b = outs["quasi"][k], outs["fp64"][k]
+        assert np.array_equal(np.isnan(a[2]), np.isnan(b[2]))
+        assert np.nanmax(np.abs(a[2] - b[2])) <= 2e-6 * np.nanmax(np.abs(b[2]))
+        assert sum(x == y for x, y in zip(a[3], b[3])) >= 18
+
+
 def test_cli_t2e_null_model_newton_fallback(tmp_path, monkeypatch):
     """The null Cox model's fall-back (fit_null_cox, Step1_Models.cpp:415-436: the Newton solver of cox_firth.cpp without the Firth term,
     used when the coordinate descent does not converge) fits the same model: forced with RG_COX_NULL_FORCE_NEWTON=1 it gives the same
