@@ -1367,6 +1367,119 @@ __global__ __launch_bounds__(256) void k_chol_backsolve(double* mats, int64_t ma
   }
 }
 
+// ---- back substitution for SEVERAL right-hand sides on the matrix cores ---------------------------------------------------------------
+// k_chol_backsolve above walks L once per group of four right-hand sides with VALU dot products: at BASELINE configs[2] (P = 10) that is three
+// passes over every factor and 31 % of the level-0 Cholesky's time with no matrix instruction in it.  Here ONE pass serves sixteen
+// right-hand sides.  One workgroup per system; wave w OWNS the solution tiles j = w, w + 4, w + 8, w + 12 (64 entries x 16 right-hand
+// sides each) and keeps them in registers from the first touch to the last: the only memory traffic is L itself, read once, 32 bytes
+// per lane and K step.  Walking the tile rows upwards, for k = T-1 .. 0:
+//   the owner of k finishes x_k = y_k Linv_kk   (y_k through LDS into A-operand layout; 64 products 16 x 16 x 4)
+//   barrier; every wave subtracts x_k L[k][j] from the tiles j < k it owns (A = -x_k from LDS, B = the tile of L straight from memory)
+// v_mfma_f64_16x16x4: lane (i, q) supplies A[right-hand side i][k = 4 s + q] and B[k = 4 s + q][n = i]; a lane loads FOUR consecutive
+// columns 4 i .. 4 i + 3 of row 4 s + q (one 32-byte load) and feeds component t to the product whose output columns are {4 i' + t}:
+// the four products of a K step then cover the tile's 64 columns, and lane (i, q) owns x[rhs q + 4 r][column 4 i + t] in acc[.][t][r].
+#define BS_PITCH 66
+__global__ __launch_bounds__(256, 2) void k_chol_backsolve_mfma(double* mats, int64_t mat_stride, int n64, int nrhs, int rhs_row0,
+                                                                const double* dinv, FormSrc fs) {
+  __shared__ double xk[2][16][BS_PITCH];
+  __shared__ double ytmp[4][16][BS_PITCH];
+  const int b = blockIdx.x;
+  const int Tfull = n64 / CT;
+  const int T = sys_tiles(fs, b, Tfull);
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = lane & 15, q = lane >> 4;
+  double* M = mats + (int64_t)b * mat_stride;
+  int nsys = n64, yrow0 = rhs_row0;
+  if (fs.embed) {      // embedded right-hand sides: y is row n + p of the system, its entries past column n belong to the factor of the padding
+    const int bb = b + fs.b_offset;
+    nsys = fs.d_n[(bb / (fs.nfold * fs.nshift)) / fs.n_div];
+    yrow0 = nsys;
+  }
+  for (int p0 = 0; p0 < nrhs; p0 += 16) {
+    const int np = nrhs - p0 < 16 ? nrhs - p0 : 16;
+    v4d acc[4][4];      // [owned tile jj][column phase t]: rows (right-hand sides) q + 4 r
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = 4 * jj + w;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pr = q + 4 * r, col = j * CT + 4 * i + t;
+          const bool ok = j < T && pr < np && col < nsys;
+          const int64_t e = ok ? (int64_t)(yrow0 + p0 + pr) * n64 + col : 0;      // clamped address, masked value
+          const double v = M[e];
+          acc[jj][t][r] = ok ? v : 0.0;
+        }
+    }
+    for (int k = T - 1; k >= 0; --k) {
+      const int ow = k & 3, kj = k >> 2;
+      if (w == ow) {     // x_k = y_k Linv_kk
+        double (*yt)[BS_PITCH] = ytmp[w];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+          if (jj == kj) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) yt[q + 4 * r][4 * i + t] = acc[jj][t][r];
+          }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // same wave writes and reads: no barrier needed
+        const double* I = dinv + ((int64_t)b * Tfull + k) * CT * CT + (int64_t)q * CT + 4 * i;
+        v4d out[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) out[t] = (v4d){0, 0, 0, 0};
+#pragma unroll 1
+        for (int s8 = 0; s8 < 4; ++s8) {      // four K steps at a time: the owned tiles and `out` leave room for 32 operand registers
+          double4 bv[4];
+#pragma unroll
+          for (int s = 0; s < 4; ++s) bv[s] = *reinterpret_cast<const double4*>(I + (int64_t)(4 * (4 * s8 + s)) * CT);
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const double a = yt[i][4 * (4 * s8 + s) + q];
+            out[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[s].x, out[0], 0, 0, 0);
+            out[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[s].y, out[1], 0, 0, 0);
+            out[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[s].z, out[2], 0, 0, 0);
+            out[3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[s].w, out[3], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int pr = q + 4 * r, col = 4 * i + t;
+            xk[k & 1][pr][col] = -out[t][r];                     // stored negated: the updates below add A x B
+            if (pr < np) M[(int64_t)(yrow0 + p0 + pr) * n64 + k * CT + col] = out[t][r];
+          }
+      }
+      __syncthreads();
+      if (k == 0) break;
+      const double (*xs)[BS_PITCH] = xk[k & 1];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j = 4 * jj + w;
+        if (j >= k) continue;
+        const double* Lp = M + ((int64_t)k * CT + q) * n64 + j * CT + 4 * i;
+#pragma unroll
+        for (int s8 = 0; s8 < 2; ++s8) {
+          double4 bv[8];
+#pragma unroll
+          for (int s = 0; s < 8; ++s) bv[s] = *reinterpret_cast<const double4*>(Lp + (int64_t)(4 * (8 * s8 + s)) * n64);
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const double a = xs[i][4 * (8 * s8 + s) + q];
+            acc[jj][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[s].x, acc[jj][0], 0, 0, 0);
+            acc[jj][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[s].y, acc[jj][1], 0, 0, 0);
+            acc[jj][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[s].z, acc[jj][2], 0, 0, 0);
+            acc[jj][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[s].w, acc[jj][3], 0, 0, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();      // the next group of right-hand sides reuses xk
+  }
+}
+
 // ---- back substitution for FEW systems: one launch per tile row k, one workgroup per tile column j < k -----------------
 // k_chol_backsolve walks a system with a single workgroup: 2,346 dependent tile steps for order 4,416 (the shared level 1 of an
 // 8-GPU run: 6 ms of the 15 ms its four systems took).  Here launch k applies x_k to every y_j, j < k, in parallel
@@ -1520,7 +1633,13 @@ void rg_launch_chol_solve_src(hipStream_t st, double* mats, int64_t mat_stride, 
     }
   }
   if (nrhs > 0) {
-    hipLaunchKernelGGL(k_chol_backsolve, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, nrhs, dinv, later);
+    // several right-hand sides and at most 16 tile rows: one pass over L on the matrix cores; else the VALU kernel (a single right-hand
+    // side is bound by reading L either way).  RG_BACKSOLVE_VALU=1 keeps the VALU kernel.
+    static const bool valu = getenv("RG_BACKSOLVE_VALU") && atoi(getenv("RG_BACKSOLVE_VALU")) != 0;
+    if (nrhs >= 2 && T <= 16 && !valu)
+      hipLaunchKernelGGL(k_chol_backsolve_mfma, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, nrhs, n64, dinv, later);
+    else
+      hipLaunchKernelGGL(k_chol_backsolve, dim3(batch), dim3(256), 0, st, mats, mat_stride, n64, nrhs, dinv, later);
     ++nl;
   }
   if (n_launch) *n_launch += nl;
