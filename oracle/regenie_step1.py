@@ -48,6 +48,7 @@ class Step1Options:
     covar_file: str = ""
     out: str = "regenie_out"
     bsize: int = 1000
+    n_block: int = 0                 # --nb: total number of blocks (0 = as many as the block size gives)
     bt: bool = False                 # --bt (trait_mode 1); default --qt
     ct: bool = False                 # --ct (trait_mode 2): count phenotypes, Poisson level 1
     cv_folds: int = 5                # --cv
@@ -732,13 +733,18 @@ def set_folds(ind_in_analysis: np.ndarray, cv_folds: int) -> np.ndarray:
     return sizes
 
 
-def chrom_blocks(chrom: np.ndarray, chr_read: List[int], bsize: int) -> List[Tuple[int, int, int]]:
-    """Data.cpp:319-333 + :579-586: list of (chrom, start_index_in_kept_snps, bs)."""
+def chrom_blocks(chrom: np.ndarray, chr_read: List[int], bsize: int, n_block: int = 0) -> List[Tuple[int, int, int]]:
+    """Data.cpp:319-333 + :579-586: list of (chrom, start_index_in_kept_snps, bs).  n_block > 0 (--nb): at most that many blocks in
+    all, taken chromosome by chromosome (set_blocks, Data.cpp:314-329): the variants past them are not analysed."""
     out = []
     pos = 0
+    left = n_block
     for c in chr_read:
         n = int((chrom == c).sum())
         nb = int(math.ceil(n / bsize))
+        if n_block > 0:
+            nb = min(nb, left)
+            left -= nb
         for bb in range(nb):
             bs = bsize if (bb + 1) * bsize <= n else n - bb * bsize
             out.append((c, pos + bb * bsize, bs))
@@ -1363,7 +1369,7 @@ def run_step1(opt: Step1Options, write_files: bool = False, keep_W: bool = True)
     bed, _ = open_bed(opt.bed + ".bed", prep.n_file)
     N, P = prep.Y.shape
     bt = opt.bt
-    blocks = chrom_blocks(chrom, bim.chr_read, opt.bsize)
+    blocks = chrom_blocks(chrom, bim.chr_read, opt.bsize, opt.n_block)
     B = len(blocks)
     use_loocv = opt.loocv
     log: List[str] = []

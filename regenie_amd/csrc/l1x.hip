@@ -1004,9 +1004,15 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
   L1X_HIP(c.bufs.alloc(&s.d_map, (size_t)nchain));
   // K-fold: the weighted Grams of the IRLS steps as quasi-Newton Hessians on the bf16 matrix cores (wgram_bf16.hip) unless RG_WGRAM_F64=1;
   // a chain that has not converged after RG_WGRAM_SWITCH steps at one ridge value continues on the fp64 Gram
-  static const bool wg_f64 = getenv("RG_WGRAM_F64") && atoi(getenv("RG_WGRAM_F64")) != 0;
-  static const int wg_switch = getenv("RG_WGRAM_SWITCH") ? atoi(getenv("RG_WGRAM_SWITCH")) : 12;
-  if (!loocv && !wg_f64) L1X_HIP(c.bufs.alloc(&s.d_sw, (size_t)nchain * Np));
+  // -- where the fp64 Gram costs more than a few milliseconds (RG_WGRAM_QUASI_MIN: flop of one chain Gram from which on the quasi-Newton
+  // Gram is used, default 2e11 = 4 ms of the fp64 kernel; 0 = always).  Below that the fp64 Gram is free and the iterates are those of
+  // the reference's Newton steps digit for digit (small problems are what the reference's own output files pin to the last printed digit;
+  // with the quasi-Newton Gram the last iterate differs from the fp64 one by rho x the last step, up to 1e-5 relative on few samples).
+  const bool wg_f64 = getenv("RG_WGRAM_F64") && atoi(getenv("RG_WGRAM_F64")) != 0;
+  const int wg_switch = getenv("RG_WGRAM_SWITCH") ? atoi(getenv("RG_WGRAM_SWITCH")) : 12;
+  const double wg_min = getenv("RG_WGRAM_QUASI_MIN") ? atof(getenv("RG_WGRAM_QUASI_MIN")) : 2e11;
+  const double gram_flop = (double)(ctx->seg.pos_start[ctx->seg.nseg - 1] + ctx->seg.plen[ctx->seg.nseg - 1]) * (loocv ? 1.0 : (double)(K - 1) / K) * L * (L + 1.0);
+  if (!loocv && !wg_f64 && gram_flop >= wg_min) L1X_HIP(c.bufs.alloc(&s.d_sw, (size_t)nchain * Np));
   L1X_HIP(hipMemsetAsync(s.d_score, 0, sizeof(double) * (size_t)nchain * n64, st));
   s.h_part.resize((size_t)s.nchunk * nchain * BT_NPART);
   s.h_score.resize((size_t)nchain * n64);

@@ -70,6 +70,7 @@ struct Params {
   int max_cat_levels = 10;
   bool rint = false;
   int bsize = 0, cv_folds = 5, n_ridge_l0 = 5, n_ridge_l1 = 5, nchrom = 23, threads = 0;
+  int n_block = 0;                         // --nb: total number of blocks, taken chromosome by chromosome (0: all)
   bool firth = false, firth_approx = false, firth_se = false;   // --firth --approx [--firth-se] (step 2, binary traits)
   bool write_null_firth = false;          // --write-null-firth (step 1 or 2): the null approximate-Firth estimates per chromosome, PFX_<k>.firth + PFX_firth.list
   std::string use_null_firth;             // --use-null-firth LIST (step 2): start values of the null Firth fits

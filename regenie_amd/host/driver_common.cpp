@@ -161,6 +161,7 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--extract") list(p.extract, need(i));
     else if (a == "--exclude") list(p.exclude, need(i));
     else if (a == "--bsize" || a == "--b") p.bsize = atoi(need(i).c_str());
+    else if (a == "--nb") p.n_block = atoi(need(i).c_str());
     else if (a == "--cv") p.cv_folds = atoi(need(i).c_str());
     else if (a == "--l0") p.n_ridge_l0 = atoi(need(i).c_str());
     else if (a == "--l1") p.n_ridge_l1 = atoi(need(i).c_str());
@@ -233,6 +234,12 @@ Params parse_args(int argc, char** argv) {
   if (p.t2e && (p.run_l0 || p.run_l1 || p.split_l0)) usage_error("--t2e with the --split-l0 / --run-l0 / --run-l1 file protocol is not built.");
   if (p.t2e && p.loocv) { std::cout << "WARNING: option --loocv cannot be used with option --t2e.\n"; p.loocv = false; }
   if (p.t2e) p.rint = false;
+  if (p.n_block < 0) usage_error("number of blocks (--nb) must be positive.");
+  if (p.n_block > 0 && (p.run_l0 || p.run_l1 || p.split_l0)) {   // Regenie.cpp:1114-1119
+    std::cout << "WARNING: options --split-l0/--run-l0/--run-l1 cannot be used with --nb.\n";
+    p.run_l0 = p.run_l1 = p.split_l0 = false;
+  }
+  if (p.n_block > 0 && p.step == 2) usage_error("--nb in step 2 is not built (it limits the blocks of a step 1 run here).");
   if (p.step == 2) {
     if (p.pred_list.empty()) usage_error("option '--pred' is required (use the _pred.list file written by step 1).");
     if (p.firth && !p.bt) usage_error("option '--firth' applies to binary traits (--bt).");

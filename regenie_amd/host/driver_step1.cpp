@@ -158,9 +158,11 @@ int run(int argc, char** argv) {
   std::vector<Blk> blocks;
   {
     int64_t pos = 0;
+    int left = p.n_block;      // --nb: at most that many blocks, taken chromosome by chromosome; the variants past them are not analysed
     for (int c : r.chr_read) {
       const int n = chr_nsnp.count(c) ? chr_nsnp[c] : 0;
-      const int nb = (n + p.bsize - 1) / p.bsize;
+      int nb = (n + p.bsize - 1) / p.bsize;
+      if (p.n_block > 0) { nb = std::min(nb, left); left -= nb; }
       for (int bb = 0; bb < nb; ++bb) blocks.push_back({c, pos + (int64_t)bb * p.bsize, std::min(p.bsize, n - bb * p.bsize)});
       pos += n;
     }

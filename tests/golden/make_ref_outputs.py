@@ -36,6 +36,9 @@ CASES = {
                           "--phenoFile", "{E}/phenotype.txt", "--bsize", "100", "--qt"], None),
     "qt_kfold_3chr": (["--step", "1", "--bed", "{E}/example_3chr", "--covarFile", "{E}/covariates.txt",
                        "--phenoFile", "{E}/phenotype.txt", "--bsize", "100", "--qt"], None),
+    # --nb: four blocks in all, taken chromosome by chromosome (set_blocks, Data.cpp:314-329): chromosome 2 keeps three of its four blocks, chromosome 3 none
+    "qt_kfold_3chr_nb": (["--step", "1", "--bed", "{E}/example_3chr", "--covarFile", "{E}/covariates.txt",
+                          "--phenoFile", "{E}/phenotype.txt", "--bsize", "100", "--nb", "4", "--qt"], None),
     "qt_kfold_3chr_opts": (["--step", "1", "--bed", "{E}/example_3chr", "--covarFile", "{E}/covariates.txt",
                             "--phenoFile", "{E}/phenotype.txt", "--remove", "{E}/fid_iid_to_remove.txt",
                             "--bsize", "70", "--cv", "3", "--ref-first", "--qt", "--print-prs"], None),
@@ -63,6 +66,11 @@ CASES = {
     # --step 2 --ct come from a --qt run on the same file: any LOCO prediction is a valid offset of the null Poisson model
     "ct_synth": (["--step", "1", "--bed", "{S}", "--covarFile", "{S}.covar", "--phenoFile", "{S}.pheno", "--bsize", "100", "--qt"],
                  dict(M=300, N=1500, chroms=[1] * 160 + [2] * 140, P=2, seed=23, binary=False, counts=True, missing_pheno=0.03, miss_rate=0.01)),
+    # count traits through Step 1 (round 4): counts drawn from a Poisson distribution whose rate carries the polygenic signal (mean 1.5) --
+    # on these regenie's K-fold Poisson ridge converges (on the floor(exp(.)) counts of ct_synth it does not; its --loocv route crashes
+    # on either).  Complete rows: with partially missing rows the reference's penalty grid is meaningless
+    "ct_kfold_synth": (["--step", "1", "--bed", "{S}", "--covarFile", "{S}.covar", "--phenoFile", "{S}.pheno", "--bsize", "100", "--ct"],
+                       dict(M=300, N=1500, chroms=[1] * 160 + [2] * 140, P=2, seed=23, binary=False, counts="poisson", missing_pheno=0.0, miss_rate=0.01)),
     # time-to-event traits on the example genotypes: time columns out of file order (outputs _1 and _3), tied times, pairs missing for one
     # trait or for both, --remove / --cv 3 / --ref-first.  example/phenotype_t2e.txt is synthetic (no such file in the reference's example
     # directory); tests/golden/make_t2e_example_pheno.py writes it

@@ -519,6 +519,7 @@ def test_cli_bt_kfold_quasi_newton_gram_equals_fp64_gram(tmp_path, monkeypatch):
     write_plink(S, synth_dosages(300, 5200, miss_rate=0.005, seed=21), chroms, P=3, seed=21, binary=True, missing_pheno=0.02)
     common = ["--step", "1", "--bed", S, "--covarFile", S + ".covar", "--phenoFile", S + ".pheno", "--bsize", "20", "--bt", "--out", "o"]
     outs = {}
+    monkeypatch.setenv("RG_WGRAM_QUASI_MIN", "0")            # the quasi-Newton Gram whatever the size (default: from 2e11 flop per Gram on)
     for name in ("quasi", "fp64"):
         dd = tmp_path / name
         dd.mkdir()

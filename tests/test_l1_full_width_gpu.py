@@ -103,10 +103,14 @@ def test_qt_kfold_level1_at_L2560():
         assert np.abs(gl - rl).max() <= 1e-9 * np.abs(rl).max()
 
 
-def test_bt_kfold_level1_at_L2560():
+def test_bt_kfold_level1_at_L2560(monkeypatch):
     """Two binary traits (prevalence 0.3 / 0.12, one with missing values), 6,500 samples, five folds, three ridge values: the K-fold logistic
     ridge (Step1_Models.cpp:966-1156) runs its IRLS on weighted Grams of order 2,560 -- `k_wgram128` with every chain's held-out fold as a
-    gap -- and the ridge systems on the per-column Cholesky path."""
+    gap, and its quasi-Newton replacement on the bf16 matrix cores (`k_wgram_bf16`, forced below) -- and the ridge systems on the
+    per-column Cholesky path."""
+    # the quasi-Newton Gram (wgram_bf16.hip) is the default from 2e11 flop per chain Gram on (500,000 samples); forced here so that the
+    # test covers it at the oracle-friendly sample count
+    monkeypatch.setenv("RG_WGRAM_QUASI_MIN", "0")
     N, P = 6500, 2
     rng = np.random.default_rng(12)
     keep = np.ones(N, bool)

@@ -121,7 +121,9 @@ def write_plink(prefix, g, chroms, P=2, ncov=2, seed=3, h2=0.2, missing_pheno=0.
     Y = np.stack(ys, axis=1)
     if binary:      # liability threshold at prevalence 0.3 -> 0/1 phenotypes
         Y = (Y > np.quantile(Y, 0.7, axis=0, keepdims=True)).astype(np.float64)
-    if counts:      # count phenotypes (--ct): Poisson-like integers with the same genetic signal
+    if counts == "poisson":   # count phenotypes drawn from Poisson(exp(0.25 Y + 0.4)): regenie's own --step 1 --ct converges on these
+        Y = np.random.default_rng(seed + 77).poisson(np.exp(0.25 * Y + 0.4)).astype(np.float64)
+    elif counts:    # count phenotypes (--ct): Poisson-like integers with the same genetic signal (regenie's Step 1 does not converge on these)
         Y = np.floor(np.exp(0.25 * Y + 0.4))
     miss = rng.random((N, P)) < missing_pheno
     with open(prefix + ".pheno", "w") as fh:
