@@ -200,7 +200,8 @@ int rg_ingest_fence(rg_ctx* ctx);
  * of 1/world of the all-gather volume) into a buffer laid out [L][count][Np] (Np = rg_w_rows), and then runs
  * the level-1 entry points on that phenotype range.  tau / yraw / offset inputs and every output of the
  * rg_l1_* calls are then arrays for `pheno_count` phenotypes.  w_dev = NULL with the full range restores the
- * default view (the context's own W, all phenotypes). */
+ * default view (the context's own W, all phenotypes); w_dev = NULL with a sub-range runs level 1 of those phenotypes on the
+ * context's own W (the C++ driver takes the phenotypes one at a time and writes each one's files while the next is computed). */
 int rg_set_l1_view(rg_ctx* ctx, const void* w_dev, int32_t pheno_begin, int32_t pheno_count);
 
 /* ---- LOCO output of the level-1 entry points (optional) ---------------------------------------------------

@@ -774,7 +774,8 @@ int rg_set_loco_output(rg_ctx* ctx, int32_t nchrom, const int32_t* chrom_ids, in
 int rg_set_l1_view(rg_ctx* ctx, const void* w_dev, int32_t pheno_begin, int32_t pheno_count) {
   if (!ctx || !ctx->have_problem) return RG_ERR_STATE;
   if (pheno_begin < 0 || pheno_count < 1 || pheno_begin + pheno_count > ctx->P) { ctx->err = "rg_set_l1_view: phenotype range out of bounds"; return RG_ERR_ARG; }
-  if (!w_dev && (pheno_begin != 0 || pheno_count != ctx->P)) { ctx->err = "rg_set_l1_view: a phenotype subset needs its own predictor buffer"; return RG_ERR_ARG; }
+  // w_dev == NULL with a sub-range: level 1 of those phenotypes on the context's own W (a caller that takes the phenotypes one at a
+  // time to write each one's files while the next is computed)
   ctx->v_W = (const double*)w_dev; ctx->v_p0 = pheno_begin; ctx->v_np = pheno_count;
   return RG_OK;
 }

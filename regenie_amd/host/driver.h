@@ -48,6 +48,7 @@
 #include <string>
 #include <thread>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 #include <charconv>
 #include <climits>
@@ -254,6 +255,32 @@ void parallel_for(int n, int nthreads, F&& fn) {
 }
 
 // ---- driver_common.cpp
+// A whole text file in memory with its line table (the remainder of a TextIn after the header line): the sample files of a 500,000-sample
+// run are tokenised, matched to their samples and converted by several threads from here, without a string per token.
+struct TextLines {
+  std::string buf;
+  std::vector<std::pair<size_t, size_t>> span;      // [begin, end) of every line, '\n' excluded (std::getline's lines)
+  size_t size() const { return span.size(); }
+  const char* begin(size_t l) const { return buf.data() + span[l].first; }
+  const char* end(size_t l) const { return buf.data() + span[l].second; }
+  std::string line(size_t l) const { return buf.substr(span[l].first, span[l].second - span[l].first); }
+};
+void slurp_lines(std::istream& f, TextLines& t);     // everything the stream still holds
+struct Tok { const char* b; const char* e; };
+// whitespace-separated tokens of [b, e) (what `is >> t` would give); returns their number, stores the first `maxtok` of them
+int tokenize(const char* b, const char* e, Tok* out, int maxtok);
+double convert_double_tok(const char* b, const char* e);   // convert_double on a token that is not NUL-terminated
+// "FID_IID" -> sample index without building the key: open addressing over the id strings
+class IdIndex {
+ public:
+  explicit IdIndex(const std::vector<std::string>& ids);
+  int64_t find(const char* fb, const char* fe, const char* ib, const char* ie) const;      // -1: no such sample
+ private:
+  static uint64_t hash(const char* fb, const char* fe, const char* ib, const char* ie);
+  const std::vector<std::string>& ids_;
+  std::vector<int32_t> slot_;
+  uint64_t mask_;
+};
 std::vector<std::string> split_ws(const std::string& s);
 std::vector<std::string> split_char(const std::string& s, char c);
 int chr_str_to_int(std::string s, int nchrom);

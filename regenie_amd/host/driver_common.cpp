@@ -40,6 +40,121 @@ int chr_str_to_int(std::string s, int nchrom) {  // Regenie.cpp:1583-1594
   return -1;
 }
 
+void slurp_lines(std::istream& f, TextLines& t) {
+  t.buf.clear(); t.span.clear();
+  {  // a plain file knows its size: one read into the final buffer (a gzipped one does not seek: chunks)
+    const std::streampos cur = f.tellg();
+    std::streampos endp = -1;
+    if (cur != std::streampos(-1)) { f.seekg(0, std::ios::end); endp = f.tellg(); f.clear(); f.seekg(cur); }
+    if (cur != std::streampos(-1) && endp != std::streampos(-1) && endp >= cur && f) {
+      t.buf.resize((size_t)(endp - cur));
+      f.read(&t.buf[0], (std::streamsize)t.buf.size());
+      t.buf.resize((size_t)f.gcount());
+    } else {
+      f.clear();
+      std::vector<char> chunk(1 << 22);
+      while (f) {
+        f.read(chunk.data(), (std::streamsize)chunk.size());
+        t.buf.append(chunk.data(), (size_t)f.gcount());
+      }
+    }
+  }
+  t.span.reserve(t.buf.size() / 64 + 16);
+  const char* p0 = t.buf.data();
+  const size_t n = t.buf.size();
+  size_t b = 0;
+  while (b < n) {
+    const char* nl = (const char*)memchr(p0 + b, '\n', n - b);
+    const size_t e = nl ? (size_t)(nl - p0) : n;
+    t.span.emplace_back(b, e);
+    b = e + 1;
+  }
+}
+
+int tokenize(const char* b, const char* e, Tok* out, int maxtok) {
+  int n = 0;
+  while (b < e) {
+    while (b < e && std::isspace((unsigned char)*b)) ++b;
+    const char* j = b;
+    while (j < e && !std::isspace((unsigned char)*j)) ++j;
+    if (j > b) { if (n < maxtok) out[n] = Tok{b, j}; ++n; }
+    b = j;
+  }
+  return n;
+}
+
+double convert_double_tok(const char* b, const char* e) {   // same values and the same failures as convert_double(std::string(b, e))
+  const size_t len = (size_t)(e - b);
+  if ((len == 2 && b[0] == 'N' && b[1] == 'A') || (len == 3 && ((b[0] == 'n' && b[1] == 'a' && b[2] == 'n') || (b[0] == 'i' && b[1] == 'n' && b[2] == 'f'))))
+    return MISSING;
+  {  // fast path (Clinger): [-]digits[.digits][e[+-]digits] with at most 15 significant digits and a decimal exponent within +-22 --
+     // mantissa and power of ten are both exact doubles, so ONE multiplication or division gives the correctly rounded value strtod
+     // gives (libstdc++'s from_chars for double goes through strtod under a locale switch: 0.3 us per number)
+    const char* p = b;
+    bool neg = false;
+    if (p < e && *p == '-') { neg = true; ++p; }
+    uint64_t m = 0;
+    int nd = 0, dexp = 0;
+    bool any = false, ok = true;
+    while (p < e && *p >= '0' && *p <= '9') { if (nd < 19) { m = m * 10 + (uint64_t)(*p - '0'); if (m) ++nd; } else ++dexp; any = true; ++p; }
+    if (p < e && *p == '.') {
+      ++p;
+      while (p < e && *p >= '0' && *p <= '9') { if (nd < 19) { m = m * 10 + (uint64_t)(*p - '0'); if (m) ++nd; --dexp; } any = true; ++p; }
+    }
+    if (any && p < e && (*p == 'e' || *p == 'E')) {
+      ++p;
+      bool eneg = false;
+      if (p < e && (*p == '+' || *p == '-')) { eneg = *p == '-'; ++p; }
+      int ex = 0, ned = 0;
+      while (p < e && *p >= '0' && *p <= '9' && ned < 6) { ex = ex * 10 + (*p - '0'); ++ned; ++p; }
+      if (ned == 0) ok = false;
+      dexp += eneg ? -ex : ex;
+    }
+    if (ok && any && p == e && nd <= 15 && dexp >= -22 && dexp <= 22) {
+      static const double P10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+      double d = (double)m;
+      d = dexp < 0 ? d / P10[-dexp] : d * P10[dexp];
+      return neg ? -d : d;
+    }
+  }
+  return convert_double(std::string(b, e));            // anything else (more digits, a leading '+', hex floats, trailing text, ...) as before
+}
+
+IdIndex::IdIndex(const std::vector<std::string>& ids) : ids_(ids) {
+  size_t cap = 16;
+  while (cap < ids.size() * 2 + 2) cap <<= 1;
+  slot_.assign(cap, -1);
+  mask_ = cap - 1;
+  for (size_t i = 0; i < ids.size(); ++i) {
+    const std::string& s = ids[i];
+    // the key is split at its LAST '_' for hashing only (any split gives the same bytes: the hash runs over FID, '_', IID)
+    uint64_t h = hash(s.data(), s.data(), s.data(), s.data() + s.size()) & mask_;
+    for (;;) {
+      if (slot_[h] < 0) { slot_[h] = (int32_t)i; break; }
+      if (ids[(size_t)slot_[h]] == s) break;            // a repeated id keeps its first index (as the map's operator[] overwrote: last) -- ids are unique
+      h = (h + 1) & mask_;
+    }
+  }
+}
+uint64_t IdIndex::hash(const char* fb, const char* fe, const char* ib, const char* ie) {
+  uint64_t h = 1469598103934665603ull;                 // FNV-1a over FID '_' IID; an empty FID part contributes nothing, no separator either
+  for (const char* p = fb; p < fe; ++p) { h ^= (unsigned char)*p; h *= 1099511628211ull; }
+  if (fe > fb) { h ^= (unsigned char)'_'; h *= 1099511628211ull; }
+  for (const char* p = ib; p < ie; ++p) { h ^= (unsigned char)*p; h *= 1099511628211ull; }
+  return h ^ (h >> 29);
+}
+int64_t IdIndex::find(const char* fb, const char* fe, const char* ib, const char* ie) const {
+  const size_t lf = (size_t)(fe - fb), li = (size_t)(ie - ib);
+  uint64_t h = hash(fb, fe, ib, ie) & mask_;
+  for (;;) {
+    const int32_t k = slot_[h];
+    if (k < 0) return -1;
+    const std::string& s = ids_[(size_t)k];
+    if (s.size() == lf + 1 + li && memcmp(s.data(), fb, lf) == 0 && s[lf] == '_' && memcmp(s.data() + lf + 1, ib, li) == 0) return k;
+    h = (h + 1) & mask_;
+  }
+}
+
 double convert_double(const std::string& v) {  // Regenie.cpp:1663-1675
   if (v == "NA" || v == "nan" || v == "inf") return MISSING;
   char* end = nullptr;

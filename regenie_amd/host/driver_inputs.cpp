@@ -98,24 +98,36 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
   const Params& p = r.p;
   if (!p.bgen.empty()) { read_bgen_meta(r); return; }
   const bool pg = !p.pgen.empty();
+  std::future<void> fam_task;     // the .fam file is read on its own thread while this one reads the .bim (two 500,000-line files at BASELINE configs[2])
+  std::string fam_fn;
   if (!pg) {
-    std::string fn = p.bed + ".fam";
-    std::ifstream f(fn);
-    if (!f) throw std::runtime_error("cannot open file : " + fn);
-    sout << std::left << std::setw(20) << " * fam" << ": [" << fn << "] ";
-    std::string line;
-    std::set<std::string> seen;
-    while (std::getline(f, line)) {
-      auto t = split_ws(line);
-      if (t.size() < 6) throw std::runtime_error("incorrectly formatted fam file at line " + std::to_string(r.fam_ids.size() + 1));
-      std::string id = t[0] + "_" + t[1];
-      if (!seen.insert(id).second) throw std::runtime_error("duplicate individual in fam file : FID_IID=" + id);
-      if (t[4] != "0" && t[4] != "1" && t[4] != "2") throw std::runtime_error("unrecognized sex code in file : '" + t[4] + "'");
-      if (t[4] == "1") r.has_male = true;
-      r.fam_ids.push_back(id);
+    fam_fn = p.bed + ".fam";
+    {
+      std::ifstream f(fam_fn);
+      if (!f) throw std::runtime_error("cannot open file : " + fam_fn);
     }
-    r.n_file = (int64_t)r.fam_ids.size();
-    sout << "n_samples = " << r.n_file << "\n";
+    fam_task = std::async(std::launch::async, [&r, fam_fn]() {
+      std::ifstream f(fam_fn);
+      TextLines lines;
+      slurp_lines(f, lines);
+      std::unordered_set<std::string> seen;
+      seen.reserve(lines.size() * 2);
+      r.fam_ids.reserve(lines.size());
+      Tok t[6];
+      for (size_t li = 0; li < lines.size(); ++li) {
+        if (tokenize(lines.begin(li), lines.end(li), t, 6) < 6) throw std::runtime_error("incorrectly formatted fam file at line " + std::to_string(r.fam_ids.size() + 1));
+        std::string id;
+        id.reserve((size_t)(t[0].e - t[0].b) + 1 + (size_t)(t[1].e - t[1].b));
+        id.append(t[0].b, t[0].e).push_back('_');
+        id.append(t[1].b, t[1].e);
+        if (!seen.insert(id).second) throw std::runtime_error("duplicate individual in fam file : FID_IID=" + id);
+        const bool one = t[4].e - t[4].b == 1;
+        if (!one || (*t[4].b != '0' && *t[4].b != '1' && *t[4].b != '2')) throw std::runtime_error("unrecognized sex code in file : '" + std::string(t[4].b, t[4].e) + "'");
+        if (*t[4].b == '1') r.has_male = true;
+        r.fam_ids.push_back(std::move(id));
+      }
+      r.n_file = (int64_t)r.fam_ids.size();
+    });
   } else {  // read_psam (Geno.cpp:941-1004): header line "#FID IID [SEX ...]", any "##" lines before it are skipped
     std::string fn = p.pgen + ".psam";
     if (!file_exists(fn)) fn += ".gz";  // Geno.cpp:952
@@ -166,7 +178,8 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
     if (pg && !file_exists(fn)) fn += ".gz";  // Geno.cpp:783
     TextIn f(fn);
     if (!f) throw std::runtime_error("cannot open file : " + fn);
-    sout << std::left << std::setw(20) << (" * " + kind) << ": [" << fn << "] ";
+    std::ostringstream head;                       // printed once the .fam thread has delivered its own line
+    head << std::left << std::setw(20) << (" * " + kind) << ": [" << fn << "] ";
     std::string line;
     int64_t lineno = 0;
     int minchr = 0;
@@ -220,7 +233,11 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
       ++lineno;
     }
     n_variants_file = lineno;
-    sout << "n_snps = " << lineno << "\n";
+    if (fam_task.valid()) {
+      fam_task.get();                              // rethrows the .fam reader's error
+      sout << std::left << std::setw(20) << " * fam" << ": [" << fam_fn << "] " << "n_samples = " << r.n_file << "\n";
+    }
+    sout << head.str() << "n_snps = " << lineno << "\n";
     if (!extract_files.empty()) sout << "   -keeping variants specified by --extract\n";
     if (!exclude_files.empty()) sout << "   -removing variants specified by --exclude\n";
     if (r.snp_chrom.empty()) throw std::runtime_error("no variant left to include in analysis.");
@@ -350,9 +367,21 @@ void blup_read(Run& r, const std::unordered_map<std::string, int64_t>& idx) {
 void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841, :1903-1935
   const Params& p = r.p;
   const int64_t N = r.N;
-  std::unordered_map<std::string, int64_t> idx;
-  idx.reserve((size_t)N * 2);
-  for (int64_t i = 0; i < N; ++i) idx[r.ids[i]] = i;
+  const bool tmk = getenv("RG_TIMING") != nullptr;
+  auto tm0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char* what) {
+    if (!tmk) return;
+    auto t = std::chrono::steady_clock::now();
+    fprintf(stderr, "[timing] read_pheno_cov %-28s %6lld ms\n", what, (long long)std::chrono::duration_cast<std::chrono::milliseconds>(t - tm0).count());
+    tm0 = t;
+  };
+  std::unordered_map<std::string, int64_t> idx;      // blup_read (step 2) looks samples up by their full id string
+  if (p.step == 2) {
+    idx.reserve((size_t)N * 2);
+    for (int64_t i = 0; i < N; ++i) idx[r.ids[i]] = i;
+  }
+  const IdIndex ids(r.ids);                          // the sample files: FID / IID token pairs -> sample, no key string built
+  const int nt_parse = std::max(1, std::min(32, (int)std::thread::hardware_concurrency() - 1));
   std::vector<uint8_t> in_pheno(N, 0), in_cov(N, p.covar_file.empty() ? 1 : 0);
   {
     TextIn f(p.pheno_file);
@@ -397,36 +426,39 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     if (p.t2e) r.Yevent.assign((size_t)N * r.P, 0.0);
     // The lines are tokenised, matched to their sample and converted by several threads (at 500,000 samples x 10 phenotypes one thread
     // needs 2 s); the checks and the bookkeeping below then run over the records in file order, exactly as a line-by-line reader would.
-    std::vector<std::string> lines;
-    while (std::getline(f, line)) lines.push_back(std::move(line));
+    mark("id index + header");
+    TextLines lines;
+    slurp_lines(f, lines);
+    mark("pheno: file in memory");
     struct Rec { int64_t i; int state; };      // state 0: use, 1: blank line, 2: wrong number of columns, 3: a value that is not a number
     std::vector<Rec> recs(lines.size());
     std::vector<double> vals(lines.size() * (size_t)NV);
     {
-      const int nt = std::max(1, std::min(16, (int)std::thread::hardware_concurrency() - 1));
-      const int nchunk = (int)std::min<size_t>(lines.size(), (size_t)nt * 4);
-      parallel_for(nchunk, nt, [&](int c) {
+      const int ncol = (int)hdr.size();
+      const int nchunk = (int)std::min<size_t>(lines.size(), (size_t)nt_parse * 4);
+      parallel_for(nchunk, nt_parse, [&](int c) {
+        std::vector<Tok> t((size_t)ncol);
         for (size_t li = lines.size() * c / nchunk, le = lines.size() * (c + 1) / nchunk; li < le; ++li) {
-          const auto t = split_ws(lines[li]);
+          const int nt = tokenize(lines.begin(li), lines.end(li), t.data(), ncol);
           Rec& rc = recs[li];
           rc.i = -1; rc.state = 0;
-          if (t.empty()) { rc.state = 1; continue; }
-          if (t.size() != hdr.size()) { rc.state = 2; continue; }
-          auto it = idx.find(t[0] + "_" + t[1]);
-          if (it == idx.end()) continue;
-          rc.i = it->second;
-          try { for (int q = 0; q < NV; ++q) vals[li * (size_t)NV + q] = convert_double(t[keep_cols[q]]); }
+          if (nt == 0) { rc.state = 1; continue; }
+          if (nt != ncol) { rc.state = 2; continue; }
+          rc.i = ids.find(t[0].b, t[0].e, t[1].b, t[1].e);
+          if (rc.i < 0) continue;
+          try { for (int q = 0; q < NV; ++q) vals[li * (size_t)NV + q] = convert_double_tok(t[keep_cols[q]].b, t[keep_cols[q]].e); }
           catch (...) { rc.state = 3; }
         }
       });
     }
+    mark("pheno: parallel parse");
     for (size_t li = 0; li < lines.size(); ++li) {
       if (recs[li].state == 1) continue;
       if (recs[li].state == 2) throw std::runtime_error("incorrectly formatted phenotype file.");
       if (recs[li].i < 0) continue;
       const int64_t i = recs[li].i;
       std::vector<std::string> t;                     // the tokens again, for the messages of the rare failing line only
-      auto tok = [&]() -> const std::vector<std::string>& { if (t.empty()) t = split_ws(lines[li]); return t; };
+      auto tok = [&]() -> const std::vector<std::string>& { if (t.empty()) t = split_ws(lines.line(li)); return t; };
       if (recs[li].state == 3) for (int q = 0; q < NV; ++q) (void)convert_double(tok()[keep_cols[q]]);     // rethrows the conversion error
       if (in_pheno[i]) throw std::runtime_error("individual appears more than once in phenotype file: FID=" + tok()[0] + " IID=" + tok()[1]);
       in_pheno[i] = 1;
@@ -510,6 +542,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
   int ncols = 1;
   std::vector<double> Xraw;  // col-major N x ncols
   if (!p.covar_file.empty()) {
+  mark("pheno: checks in file order");
     TextIn f(p.covar_file);
     if (!f) throw std::runtime_error("cannot open file : " + p.covar_file);
     sout << std::left << std::setw(20) << " * covariates" << ": [" << p.covar_file << "] ";
@@ -540,30 +573,60 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     sout << "n_cov = " << kc.size() << "\n";
     Xraw.assign((size_t)N * ncols, 0.0);
     for (int64_t i = 0; i < N; ++i) Xraw[i] = 1.0;
-    while (std::getline(f, line)) {
-      auto t = split_ws(line);
-      if (t.empty()) continue;
-      if (t.size() != hdr.size()) throw std::runtime_error("incorrectly formatted covariate file.");
-      auto it = idx.find(t[0] + "_" + t[1]);
-      if (it == idx.end()) continue;
-      const int64_t i = it->second;
-      if (in_cov[i]) throw std::runtime_error("individual appears more than once in covariate file: FID=" + t[0] + " IID=" + t[1]);
+    // as the phenotype file: tokenised, matched and converted by several threads; the checks, the categorical levels (numbered in order of
+    // appearance) and the first-missing-value rule then run over the records in file order, exactly as the line-by-line reader did
+    TextLines lines;
+    slurp_lines(f, lines);
+    const int nkc = (int)kc.size(), ncolf = (int)hdr.size();
+    struct CRec { int64_t i; int state; int fail; };   // state 0: use, 1: blank, 2: wrong number of columns; fail: first column whose value is not a number (-1: none)
+    std::vector<CRec> crec(lines.size());
+    std::vector<double> cval(lines.size() * (size_t)std::max(1, nkc));
+    {
+      const int nchunk = (int)std::min<size_t>(lines.size(), (size_t)nt_parse * 4);
+      parallel_for(nchunk, nt_parse, [&](int c) {
+        std::vector<Tok> t((size_t)ncolf);
+        for (size_t li = lines.size() * c / nchunk, le = lines.size() * (c + 1) / nchunk; li < le; ++li) {
+          const int nt = tokenize(lines.begin(li), lines.end(li), t.data(), ncolf);
+          CRec& rc = crec[li];
+          rc.i = -1; rc.state = 0; rc.fail = -1;
+          if (nt == 0) { rc.state = 1; continue; }
+          if (nt != ncolf) { rc.state = 2; continue; }
+          rc.i = ids.find(t[0].b, t[0].e, t[1].b, t[1].e);
+          if (rc.i < 0) continue;
+          for (int cc = 0; cc < nkc; ++cc) {
+            if (is_cat[cc]) continue;                    // levels are assigned in file order below
+            try { cval[li * (size_t)nkc + cc] = convert_double_tok(t[kc[cc]].b, t[kc[cc]].e); }
+            catch (...) { rc.fail = cc; break; }
+          }
+        }
+      });
+    }
+    for (size_t li = 0; li < lines.size(); ++li) {
+      if (crec[li].state == 1) continue;
+      if (crec[li].state == 2) throw std::runtime_error("incorrectly formatted covariate file.");
+      if (crec[li].i < 0) continue;
+      const int64_t i = crec[li].i;
+      std::vector<std::string> t;
+      auto tok = [&]() -> const std::vector<std::string>& { if (t.empty()) t = split_ws(lines.line(li)); return t; };
+      if (in_cov[i]) throw std::runtime_error("individual appears more than once in covariate file: FID=" + tok()[0] + " IID=" + tok()[1]);
       in_cov[i] = 1;
-      for (size_t c = 0; c < kc.size(); ++c) {
+      for (int c = 0; c < nkc; ++c) {
         double v;
         if (is_cat[c]) {
-          const std::string& tok = t[kc[c]];
-          if (tok == "NA" || tok == "nan" || tok == "inf") v = MISSING;
+          const std::string& tk = tok()[kc[c]];
+          if (tk == "NA" || tk == "nan" || tk == "inf") v = MISSING;
           else {
-            auto lv = levels[c].find(tok);
-            if (lv == levels[c].end()) lv = levels[c].emplace(tok, (int)levels[c].size()).first;
+            auto lv = levels[c].find(tk);
+            if (lv == levels[c].end()) lv = levels[c].emplace(tk, (int)levels[c].size()).first;
             v = lv->second;
           }
-        } else v = convert_double(t[kc[c]]);
+        } else if (c == crec[li].fail) v = convert_double(tok()[kc[c]]);     // rethrows the conversion error where the reader would have met it
+        else v = cval[li * (size_t)nkc + c];
         Xraw[(size_t)(1 + c) * N + i] = v;
         if (v == MISSING) { in_cov[i] = 0; break; }
       }
     }
+    mark("covariates: parsed");
     if (std::find(is_cat.begin(), is_cat.end(), (uint8_t)1) != is_cat.end()) {
       // dummy variables (Pheno.cpp:716-783, check_categories :985-1011, get_dummies): level 0 goes to the intercept
       std::vector<double> full(Xraw.begin(), Xraw.begin() + N);
@@ -678,6 +741,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     Xraw.swap(X2);
     ncols = kept;
   }
+  mark("masks / imputation / covariate prep");
   // getBasis (Pheno.cpp:1660-1681)
   std::vector<double> xtx((size_t)ncols * ncols, 0.0), d, V;
   for (int a = 0; a < ncols; ++a)
@@ -748,6 +812,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     }
     sout << "done\n";
   }
+  mark("basis + null models");
   // residualize_phenotypes (Pheno.cpp:1799-1834)
   sout << "   -residualizing and scaling phenotypes...";
   r.scale_Y.assign(r.P, 1.0);
@@ -768,6 +833,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     if (r.scale_Y[q] < 1e-6) throw std::runtime_error("phenotype '" + r.pheno_names[q] + "' has sd=0.");
     for (int64_t i = 0; i < N; ++i) r.Y[(size_t)q * N + i] /= r.scale_Y[q];
   }
+  mark("residualize phenotypes");
   sout << "done\n";
 }
 

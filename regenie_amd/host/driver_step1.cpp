@@ -654,6 +654,57 @@ int run(int argc, char** argv) {
   };
 
   // level 1 of phenotypes [q0, q0 + nq) on one context (its view already set for a phenotype-sharded run)
+  // One context, no exchanged view (the usual single-GPU run): the phenotypes are taken ONE AT A TIME (rg_set_l1_view with a sub-range on
+  // the context's own W) and each one's tables and files are written on a thread of their own while the next phenotype is on the GPU --
+  // at 500,000 samples a .loco file is 115 MB of text, formatting and writing ten of them took as long as level 1 itself.
+  auto level1_pipelined = [&](rg_ctx* cx) {
+    const size_t per = (size_t)nchr * N;
+    // predictions of all phenotypes: page-locked if the runtime grants it (880 MB at BASELINE configs[2]; device -> host at the PCIe rate,
+    // no first-touch faults), uninitialised either way -- every entry is written by the library
+    double* pred = (double*)rg_host_alloc((int64_t)(sizeof(double) * per * P));
+    std::unique_ptr<double[]> pred_own;
+    const bool pinned = pred != nullptr;
+    if (!pinned) { pred_own.reset(new double[per * P]); pred = pred_own.get(); }
+    std::vector<double> cumsum((size_t)P * NCS * R1, 0.0);
+    std::vector<int32_t> best(P, 0), converged(P, 1);
+    std::vector<std::future<void>> writers;
+    std::exception_ptr err = nullptr;
+    try {
+      for (int q = 0; q < P; ++q) {
+        double* cq = cumsum.data() + (size_t)q * NCS * R1;
+        double* pq = pred + (size_t)q * per;
+        if (p.t2e) {
+          rg_cox_options co;
+          co.niter_max = p.niter_max; co.niter_max_line_search = p.niter_max_line_search; co.niter_max_ridge = p.niter_max_ridge;
+          co.niter_max_line_search_ridge = 100; co.numtol_cox = 2.5e-4; co.l1_ridge_tol = 1e-4;
+          if (!r.pheno_pass[q]) { converged[q] = 0; best[q] = 0; }
+          else check(cx, rg_l1_cox(cx, q, R1, r.Yraw.data() + (size_t)q * N, r.Yevent.data() + (size_t)q * N, r.offset.data() + (size_t)q * N, &co,
+                                   nchr, cols_per_chr.data(), tau.data() + (size_t)q * R1, cq + 5 * R1, &converged[q], &best[q], pq));
+        } else {
+          check(cx, rg_set_l1_view(cx, nullptr, q, 1));
+          const double* tq = tau.data() + (size_t)q * R1;
+          if (p.bt || p.ct) {
+            rg_bt_options bo;
+            bo.niter_max_ridge = p.niter_max_ridge; bo.niter_max_line_search_ridge = 100; bo.niter_max_line_search = p.niter_max_line_search;
+            bo.family = p.ct ? 1 : 0; bo.l1_ridge_tol = 1e-4; bo.tol = 1e-8;
+            check(cx, rg_l1_bt(cx, R1, tq, r.Yraw.data() + (size_t)q * N, r.offset.data() + (size_t)q * N, &bo, nchr, cols_per_chr.data(),
+                               cq, &converged[q], &best[q], pq));
+            if (!r.pheno_pass[q]) converged[q] = 0;
+          } else if (use_loocv)
+            check(cx, rg_l1_qt_loocv(cx, R1, tq, nchr, cols_per_chr.data(), cq, &best[q], pq));
+          else
+            check(cx, rg_l1_qt(cx, R1, tq, nchr, cols_per_chr.data(), cq, &best[q], pq));
+        }
+        const int bq = best[q], cv = converged[q];
+        writers.push_back(std::async(std::launch::async, [&, q, cq, bq, cv, pq]() { emit_pheno(q, cq, bq, cv, pq); }));
+      }
+    } catch (...) { err = std::current_exception(); }
+    if (!p.t2e) rg_set_l1_view(cx, nullptr, 0, P);
+    for (auto& w : writers) { try { w.get(); } catch (...) { if (!err) err = std::current_exception(); } }
+    if (pinned) rg_host_free(pred);
+    if (err) std::rethrow_exception(err);
+  };
+
   auto level1_range = [&](rg_ctx* cx, int q0, int nq, bool write_out) {
     std::vector<double> cumsum((size_t)nq * NCS * R1), pred((size_t)nq * nchr * N);
     std::vector<int32_t> best(nq), converged(nq, 1);
@@ -696,7 +747,8 @@ int run(int argc, char** argv) {
     if (p.ct) sout << " Level 1 ridge with poisson regression...\n";
     if (p.t2e) sout << " Level 1 ridge with cox regression...\n";
     tl0 = std::chrono::steady_clock::now();
-    level1_range(ctx, 0, P, true);
+    if (getenv("RG_L1_BATCHED") && atoi(getenv("RG_L1_BATCHED")) != 0) level1_range(ctx, 0, P, true);   // all phenotypes in one call, then the files
+    else level1_pipelined(ctx);
   } else {
     // one host thread per GPU: level 0 of the rank's blocks, the exchange, level 1 of the rank's phenotypes (phenotype-
     // sharded) or of all phenotypes with the heavy steps shared (all-gather form; level-1 models other than the K-fold
