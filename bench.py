@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--oracle-check", action="store_true", help="check the full configuration against the numpy oracle even with --no-cpu "
                     "(level-0 predictors of two blocks, level 1 of phenotype 0 on the full W: CV sums, selected ridge value, LOCO)")
     ap.add_argument("--no-disk", action="store_true", help="skip the end-to-end-from-files leg (the C++ driver on a .bed written to disk)")
+    ap.add_argument("--disk-leg", action="store_true", help="run the end-to-end-from-files leg even with --no-cpu; the engine's device memory is released "
+                    "before the driver starts (BASELINE configs[2] fills the device: 62.5 GB .bed, skipped with a stated reason when the disk is short)")
     ap.add_argument("--no-extra", action="store_true", help="skip the sub-records of the default N=1 run: BASELINE configs[2] in full on this one GPU "
                     "(`config3_single_gpu`) and the Step-2 record at configs[4]'s shape (`step2`)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo only for the "
@@ -381,6 +383,18 @@ def main():
     disk = None
     if rank == 0 and world == 1 and not args.no_cpu and not args.no_disk:
         disk = from_disk_leg(args, torch, packed, blocks, my_blocks, Yraw, cov, M, N, P, res[0])
+    elif rank == 0 and world == 1 and args.disk_leg:      # forced (the configs[2] sub-run of the default line): the device is handed over first
+        loco_ck_forced = float(sum(np.abs(l).sum() for l in res[0]))
+        best_forced = [int(b) for b in res[2]]
+
+        def _free():
+            nonlocal eng, Wt, Wv
+            eng.close()
+            eng = None
+            packed.clear()
+            Wt = Wv = None
+            torch.cuda.empty_cache()
+        disk = from_disk_leg(args, torch, packed, blocks, my_blocks, Yraw, cov, M, N, P, res[0], free_gpu=_free, nruns=2)
 
     # ---- sub-records of the default N=1 run (the engine's memory is released first) ----
     extra = {}
@@ -394,12 +408,23 @@ def main():
         import subprocess
         try:    # BASELINE configs[2] (the north star's target workload) in full on this ONE GPU: 500,000 x 500,000 x 10 QT, resident
             r3 = subprocess.run([sys.executable, os.path.abspath(__file__), "--samples", "500000", "--snps", "500000", "--phenos", "10", "--steps", "1",
-                                 "--warmup", "1", "--no-cpu"], capture_output=True, text=True, timeout=900)
+                                 "--warmup", "1", "--no-cpu"] + ([] if args.no_disk else ["--disk-leg"]), capture_output=True, text=True, timeout=1500)
             l3 = json.loads([ln for ln in r3.stdout.splitlines() if ln.startswith("{")][-1])
             extra["config3_single_gpu"] = {k: l3[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernels", "loco_checksum",
-                                                               "selected_tau_index")}
+                                                               "selected_tau_index", "end_to_end_from_files")}
         except Exception as e:   # noqa: BLE001 - a sub-record must not take the line down
             extra["config3_single_gpu"] = {"error": repr(e)[:500]}
+        try:    # BASELINE configs[3]'s kind (binary traits) at its level-1 shape: 500,000 samples, L = 2,560 level-0 predictors (512 blocks of 100
+                # SNPs -- level 1 does not see the block width), two traits; 98 % of that configuration is this level 1
+            r4 = subprocess.run([sys.executable, os.path.abspath(__file__), "--samples", "500000", "--snps", "51200", "--bsize", "100", "--phenos", "2", "--bt",
+                                 "--steps", "1", "--warmup", "0", "--no-cpu"], capture_output=True, text=True, timeout=900)
+            l4 = json.loads([ln for ln in r4.stdout.splitlines() if ln.startswith("{")][-1])
+            extra["config4_level1_two_binary_traits"] = {
+                "level1_wall_ms": l4["level1"].get("level1_wall_ms_last_step"), "s_per_trait": l4["level1"].get("level1_wall_ms_last_step", 0.0) / 2e3,
+                "converged": l4["level1"].get("bt_converged"), "selected_tau_index": l4["selected_tau_index"], "loco_checksum": l4["loco_checksum"],
+                "roofline": l4["roofline"], "kernels": {k: l4["kernels"].get(k) for k in ("wgram_f64", "irls_solve", "irls_stream")}, "config": l4["config"]}
+        except Exception as e:   # noqa: BLE001
+            extra["config4_level1_two_binary_traits"] = {"error": repr(e)[:500]}
         try:
             from tools.step2_record import step2_record
             extra["step2"] = step2_record(torch=torch)
@@ -472,7 +497,7 @@ def math_sqrt(x):
     return float(np.sqrt(x))
 
 
-def from_disk_leg(args, torch, packed, blocks, my_blocks, Yraw, cov, M, N, P, gpu_loco):
+def from_disk_leg(args, torch, packed, blocks, my_blocks, Yraw, cov, M, N, P, gpu_loco, free_gpu=None, nruns=3):
     """The same workload END TO END through the C++ driver (`regenie-amd --step 1`): the synthetic .bed/.bim/.fam and the
     phenotype / covariate text files are written once to the local disk, then the driver is timed from process start to
     the last .loco byte -- text parsing, context set-up, streamed ingest (reader thread -> page-locked buffers -> PCIe),
@@ -484,6 +509,10 @@ def from_disk_leg(args, torch, packed, blocks, my_blocks, Yraw, cov, M, N, P, gp
     drv = os.path.join(ROOT, "regenie_amd", "bin", "regenie-amd")
     if not os.path.exists(drv):
         return None
+    need = int(sum(blocks[b][2] for b in my_blocks)) * (N // 4) * 1.15 + 2e9
+    free = shutil.disk_usage(tempfile.gettempdir()).free
+    if free < need:
+        return {"skipped": "the from-files leg needs %.0f GB in %s, %.0f GB are free" % (need / 1e9, tempfile.gettempdir(), free / 1e9)}
     d = tempfile.mkdtemp(prefix="rg_from_disk_")
     try:
         pre = os.path.join(d, "g")
@@ -513,26 +542,28 @@ def from_disk_leg(args, torch, packed, blocks, my_blocks, Yraw, cov, M, N, P, gp
             fh.write("FID IID C1 C2\n")
             fh.write("".join("%d %d %.17g %.17g\n" % (i + 1, i + 1, cov[i, 0], cov[i, 1]) for i in range(N)))
         t_write = time.perf_counter() - t0
+        order = sorted(range(N), key=lambda i: "%d_%d" % (i + 1, i + 1))
+        got = np.asarray(gpu_loco[0])[order, :].T.copy()
+        if free_gpu is not None:                # a workload that fills the device: this process lets go of it before the driver starts
+            free_gpu()
         cmd = [drv, "--step", "1", "--bed", pre, "--phenoFile", pre + ".pheno", "--covarFile", pre + ".covar", "--bsize", str(args.bsize),
                "--qt", "--out", os.path.join(d, "o")]
         walls = []
-        for _ in range(3):                      # first run warms the page cache and the driver's code objects
+        for _ in range(nruns):                  # first run warms the page cache and the driver's code objects
             t0 = time.perf_counter()
             r = subprocess.run(cmd, capture_output=True, text=True, cwd=d)
             walls.append(time.perf_counter() - t0)
             if r.returncode != 0:
                 return {"error": (r.stdout + r.stderr)[-1500:]}
-        wall = min(walls[1:])
+        wall = min(walls[1:]) if len(walls) > 1 else walls[0]
         ids, ref = _parse_loco(os.path.join(d, "o_1.loco"))
-        order = sorted(range(N), key=lambda i: "%d_%d" % (i + 1, i + 1))
-        got = np.asarray(gpu_loco[0])[order, :].T
         err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
         stages = [ln.strip() for ln in r.stdout.splitlines() if "level 0 ridge of blocks" in ln or "-level 1 for" in ln or "Elapsed time" in ln
                   or "since start" in ln]
         return {"value": M * N * P / wall, "unit": "SNP*sample*pheno/s", "wall_s": wall, "walls_s": walls, "bed_bytes": nbytes,
                 "bed_GBps": nbytes / wall / 1e9, "driver_log": stages, "setup_write_s": t_write,
                 "loco_text_vs_resident_run_max_rel_err": err,
-                "note": "regenie-amd --step 1 from files on the local disk (page cache warm), process start to exit; best of 2 timed runs"}
+                "note": "regenie-amd --step 1 from files on the local disk (page cache warm), process start to exit; best of the runs after the first (a single run: that run)"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
