@@ -138,8 +138,15 @@ int run(int argc, char** argv) {
   IngestRing* pre_ring_ptr = nullptr;
   BedMap bed_map;
   if (p.step == 1 && !p.run_l1 && !r.dosage_mode && r.bpr > 0) {   // the host side of the ingest is set up under the parsing below
+    // The mapped, registered .bed is the source of the copies for files up to RG_INGEST_MAP_MAX_GB (16): at BASELINE configs[1] (1.25 GB)
+    // it is what makes a run 0.22 s.  For the 62.5 GB file of configs[2] the copies out of a registered file mapping took 7.4 s on the
+    // round-4 boxes (the queueing call itself blocked for 5.8 s) where the ring of page-locked buffers needed 2.4 s -- on the round-3 box
+    // it had been the other way round (1.7 s mapped; profiles/r3_e2e_config3_final.log, profiles/r4_e2e_config3.log).  RG_INGEST_MAP=1
+    // forces the mapping, =0 the ring.
     const char* em = getenv("RG_INGEST_MAP");
-    if (!r.pgen && !(em && atoi(em) == 0)) bed_map.start(p.bed + ".bed");           // the mapped file, registered on its own thread (shared by the ranks)
+    const double map_max = (getenv("RG_INGEST_MAP_MAX_GB") ? atof(getenv("RG_INGEST_MAP_MAX_GB")) : 16.0) * 1e9;
+    const bool want_map = em ? atoi(em) != 0 : (double)r.snp_chrom.size() * (double)r.bpr <= map_max || p.gpus > 1;
+    if (!r.pgen && want_map) bed_map.start(p.bed + ".bed");           // the mapped file, registered on its own thread (shared by the ranks)
     if (bed_map.state == 0 && p.gpus == 1) {                                         // else, one GPU: the ring of page-locked buffers
       pre_ring.start((int64_t)r.snp_chrom.size() * r.bpr, ingest_blk_bytes, -1, 1);
       pre_ring_ptr = &pre_ring;
