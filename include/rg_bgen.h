@@ -7,6 +7,7 @@
  *   rg_bgen_variant         snpinfo[] fields: chromosome, position, rsid, alleles, offset   Geno.cpp:73-128
  *   rg_bgen_read_dosages    readChunkFromBGEN + readChunkFromBGENFileToG_fast               Geno.cpp:2122-2171, :1574-1699
  *   rg_bgen_read_dosages_info   the Step-2 form: parseSnpfromBGEN's dosages and info-score terms   Geno.cpp:2186-2330
+ *   rg_bgen_read_blocks     the inflate half of parseSnpfromBGEN (the caller walks the bytes)  Geno.cpp:2219-2262
  * The rows are ALT-count style dosages in [0, 2] (G = prob1 + 2 prob0, or prob1 + 2 prob2 with ref_first), -3 = missing:
  * the input of rg_l0_blocks_f64 (rg_step1.h), which applies the reference's mean imputation.  Host-only code.
  * Conventions as in rg_pgen.h: 0 on success, <0 on error, rg_bgen_last_error(h); rg_bgen_open always stores a handle.
@@ -49,6 +50,16 @@ int rg_bgen_read_dosages(rg_bgen* h, int64_t n, const int64_t* variant_idx, int3
  * 4 prob0 + prob1 - G^2, or with ref_first 4 prob2 + prob1 - G^2; 0 for a missing sample): info_rows has the layout of rows. */
 int rg_bgen_read_dosages_info(rg_bgen* h, int64_t n, const int64_t* variant_idx, int32_t ref_first, double* rows, double* info_rows,
                               int64_t row_stride);
+/* The inflated, checked probability blocks of n variants, for a caller that walks the bytes itself (the Step-2 driver turns them into
+ * 2-byte integer dosages and the allele / info sums in ONE pass instead of three double rows per variant): block k starts at
+ * blocks + k * block_stride (block_stride >= rg_bgen_block_bytes = 10 + 3 N) and holds, as the file does,
+ *   [0,4) N   [4,6) K = 2   [6] [7] ploidy 2 2   [8, 8+N) ploidy byte per sample, bit 7 = missing   [8+N] phased = 0   [9+N] bits = 8
+ *   [10+N, 10+3N) two probability bytes per sample (prob0, prob1, in units of 1 / 255).
+ * Same checks and messages as rg_bgen_read_dosages; n_threads workers (0: as set by rg_bgen_set_threads), one variant at a time each.
+ * The read calls do not modify the handle: several threads may read through one handle concurrently (rg_bgen_last_error returns the
+ * calling thread's own last message). */
+int rg_bgen_block_bytes(const rg_bgen* h, int64_t* bytes);
+int rg_bgen_read_blocks(rg_bgen* h, int64_t n, const int64_t* variant_idx, uint8_t* blocks, int64_t block_stride, int32_t n_threads);
 
 #ifdef __cplusplus
 }

@@ -62,3 +62,13 @@ class BgenFile:
         rows = np.empty((idx.size, self.n_samples), dtype=np.float64)
         self._check(self.lib.rg_bgen_read_dosages(self.h, idx.size, idx.ctypes.data, 1 if ref_first else 0, rows.ctypes.data, self.n_samples))
         return rows
+
+    def read_blocks(self, variant_idx) -> np.ndarray:
+        """uint8 [len(idx), 10 + 3 n_samples]: the inflated, checked probability blocks (rg_bgen_read_blocks) -- ploidy / missingness bytes
+        at [8, 8 + N), the (prob0, prob1) byte pairs at [10 + N, 10 + 3 N)."""
+        idx = np.ascontiguousarray(variant_idx, dtype=np.int64)
+        nb = C.c_int64()
+        self._check(self.lib.rg_bgen_block_bytes(self.h, C.byref(nb)))
+        blocks = np.empty((idx.size, nb.value), dtype=np.uint8)
+        self._check(self.lib.rg_bgen_read_blocks(self.h, idx.size, idx.ctypes.data, blocks.ctypes.data, nb.value, 0))
+        return blocks

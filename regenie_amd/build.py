@@ -50,6 +50,7 @@ def _deps():
                                                       os.path.join(CSRC, "step2_internal.h"),
                                                       os.path.join(CSRC, "pgen_reader.h"),
                                                       os.path.join(CSRC, "bgen_reader.h"),
+                                                      os.path.join(CSRC, "inflate_fast.h"),
                                                       os.path.join(HERE, "..", "include", "rg_bgen.h"),
                                                       os.path.join(HERE, "..", "include", "rg_pgen.h"),
                                                       os.path.join(HERE, "..", "include", "rg_step1.h"),

@@ -2,6 +2,8 @@
 #include <algorithm>
 #include <new>
 #include <string>
+#include <atomic>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -11,13 +13,23 @@
 struct rg_bgen {
   rgbgen::Reader rd;
   std::string err;
+  std::mutex err_mu;
   bool ok = false;
   int threads = 1;
 };
 
 namespace {
+// The read calls only read the handle (every call has its own buffers), so several host threads -- one per GPU in `--step 2 --gpus N` --
+// may read through one handle at once; a failing call finds ITS message through the calling thread's copy.
+thread_local std::string tl_err;
+thread_local const rg_bgen* tl_err_handle = nullptr;
 int fail(rg_bgen* h, int code, const std::string& msg) {
-  if (h) h->err = msg;
+  if (h) {
+    std::lock_guard<std::mutex> lk(h->err_mu);
+    h->err = msg;
+    tl_err = msg;
+    tl_err_handle = h;
+  }
   return code;
 }
 int classify(const std::string& m) {
@@ -47,7 +59,11 @@ int rg_bgen_open(rg_bgen** out, const char* path) {
 }
 
 void rg_bgen_close(rg_bgen* h) { delete h; }
-const char* rg_bgen_last_error(const rg_bgen* h) { return h ? h->err.c_str() : "null bgen handle"; }
+const char* rg_bgen_last_error(const rg_bgen* h) {
+  if (!h) return "null bgen handle";
+  if (tl_err_handle == h) return tl_err.c_str();
+  return h->err.c_str();
+}
 
 int rg_bgen_info(const rg_bgen* h, int64_t* n_samples, int64_t* n_variants, int32_t* compression, int32_t* has_sample_ids) {
   if (!h || !h->ok) return RG_BGEN_ERR_ARG;
@@ -94,6 +110,45 @@ int rg_bgen_read_dosages_info(rg_bgen* h, int64_t n, const int64_t* variant_idx,
                               int64_t row_stride) {
   if (h && !info_rows) return fail(h, RG_BGEN_ERR_ARG, "rg_bgen_read_dosages_info: bad argument");
   return read_rows(h, n, variant_idx, ref_first, rows, info_rows, row_stride);
+}
+int rg_bgen_block_bytes(const rg_bgen* h, int64_t* bytes) {
+  if (!h || !h->ok || !bytes) return RG_BGEN_ERR_ARG;
+  *bytes = (int64_t)h->rd.block_bytes();
+  return RG_BGEN_OK;
+}
+
+int rg_bgen_read_blocks(rg_bgen* h, int64_t n, const int64_t* variant_idx, uint8_t* blocks, int64_t block_stride, int32_t n_threads) {
+  if (!h) return RG_BGEN_ERR_ARG;
+  if (!h->ok) return fail(h, RG_BGEN_ERR_ARG, "bgen file is not open");
+  if (n < 0 || (n > 0 && (!variant_idx || !blocks)) || block_stride < (int64_t)h->rd.block_bytes())
+    return fail(h, RG_BGEN_ERR_ARG, "rg_bgen_read_blocks: bad argument");
+  for (int64_t k = 0; k < n; ++k)
+    if (variant_idx[k] < 0 || variant_idx[k] >= (int64_t)h->rd.n_variants())
+      return fail(h, RG_BGEN_ERR_ARG, "variant index " + std::to_string(variant_idx[k] + 1) + " is out of range");
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? std::min<int32_t>(n_threads, 256) : h->threads, n));
+  std::vector<std::string> errs((size_t)nt);
+  std::atomic<int64_t> next(0);
+  auto work = [&](int t) {
+    static thread_local std::vector<uint8_t> cbuf, ubuf;      // a caller's worker thread that reads variant after variant keeps its buffers
+    try {
+      for (int64_t k; (k = next.fetch_add(1)) < n;)
+        h->rd.read_block((uint32_t)variant_idx[k], cbuf, ubuf, blocks + k * block_stride, (size_t)block_stride);
+    } catch (const std::exception& e) {
+      errs[(size_t)t] = e.what();
+      if (errs[(size_t)t].empty()) errs[(size_t)t] = "bgen read failed";
+      next = n;
+    }
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+  }
+  for (const auto& e : errs)
+    if (!e.empty()) return fail(h, classify(e), e);
+  return RG_BGEN_OK;
 }
 }  // extern "C"
 

@@ -16,10 +16,13 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
+
+#include "inflate_fast.h"
 
 namespace rgbgen {
 
@@ -148,24 +151,30 @@ class Reader {
     }
   }
 
-  // Dosage row of variant j: n_samples doubles, -3 = missing.
-  void read_dosages(uint32_t j, bool ref_first, double* out, std::vector<uint8_t>& cbuf, std::vector<uint8_t>& ubuf, double* info = nullptr) const {
+  // The inflated, checked probability block of variant j (layout 2: N, K, min / max ploidy, N ploidy-and-missingness bytes, phased flag,
+  // bits, 2 N probability bytes), in `dst` when it is given (capacity `cap` >= block_bytes()) or in `ubuf`; returns its first byte.
+  size_t block_bytes() const { return 10 + 3 * (size_t)n_; }
+  const uint8_t* read_block(uint32_t j, std::vector<uint8_t>& cbuf, std::vector<uint8_t>& ubuf, uint8_t* dst = nullptr, size_t cap = 0) const {
     if (fd_ < 0) throw std::runtime_error("bgen file is closed");
     if (j >= m_) throw std::runtime_error("variant index out of range");
     const Variant& v = vars_[j];
     uint32_t c = 0, d = 0;
     if (!pread_all(&c, 4, v.data)) throw std::runtime_error("cannot read bgen file");
-    const uint8_t* blk;
+    uint8_t* blk;
     size_t blen;
     // a size taken from a corrupt record must not drive the allocations below: the encoding served (layout 2, biallelic,
     // diploid, 8 bits) inflates to 10 + 3 n bytes, and no biallelic diploid block (up to 32 bits) exceeds 10 + 9 n; the
     // exact layout checks (with their own messages) follow after decompression
     const uint64_t most = 64 + 16 * (uint64_t)n_;
+    auto room = [&](uint64_t len) -> uint8_t* {      // a block larger than the caller's row (another encoding, trailing bytes) is inflated aside
+      if (dst && len <= cap) return dst;
+      ubuf.resize(len);
+      return ubuf.data();
+    };
     if (comp_ == 0) {
       if (c > most) throw std::runtime_error("genotype data block of variant " + v.rsid + " is larger than any biallelic diploid block of " + std::to_string(n_) + " samples");
-      ubuf.resize(c);
-      if (c && !pread_all(ubuf.data(), c, v.data + 4)) throw std::runtime_error("cannot read bgen file");
-      blk = ubuf.data();
+      blk = room(c);
+      if (c && !pread_all(blk, c, v.data + 4)) throw std::runtime_error("cannot read bgen file");
       blen = c;
     } else {
       if (c < 4 || !pread_all(&d, 4, v.data + 4)) throw std::runtime_error("failed to decompress genotype data block for variant: " + v.rsid);
@@ -173,19 +182,24 @@ class Reader {
       if ((uint64_t)c > fsize_) throw std::runtime_error("failed to decompress genotype data block for variant: " + v.rsid);
       cbuf.resize(c - 4);
       if (c > 4 && !pread_all(cbuf.data(), c - 4, v.data + 8)) throw std::runtime_error("cannot read bgen file");
-      ubuf.resize(d);
+      blk = room(d);
       bool fail;
       if (comp_ == 1) {
-        uLongf dl = d;
-        fail = uncompress(ubuf.data(), &dl, cbuf.data(), c - 4) != Z_OK || dl != d;
+        // the decoder of inflate_fast.h first (1.7x zlib's rate on these blocks); whatever it does not accept goes through zlib, whose
+        // verdict is the one reported
+        static thread_local rgflate::Tables* tabs = new rgflate::Tables;
+        static const bool zlib_only = getenv("RG_BGEN_ZLIB") != nullptr;
+        fail = zlib_only || !rgflate::inflate_zlib(blk, d, cbuf.data(), c - 4, *tabs);
+        if (fail) {
+          uLongf dl = d;
+          fail = uncompress(blk, &dl, cbuf.data(), c - 4) != Z_OK || dl != d;
+        }
       } else {
-        fail = zstd()(ubuf.data(), d, cbuf.data(), c - 4) != d;
+        fail = zstd()(blk, d, cbuf.data(), c - 4) != d;
       }
       if (fail) throw std::runtime_error("failed to decompress genotype data block for variant: " + v.rsid);  // Geno.cpp:1616-1617
-      blk = ubuf.data();
       blen = d;
     }
-    // probability block (layout 2): N, K, min / max ploidy, N ploidy-and-missingness bytes, phased flag, bits, probabilities
     if (blen < 10ull + n_) throw std::runtime_error("malformed genotype data block for variant: " + v.rsid);
     uint32_t nind;
     uint16_t k;
@@ -195,11 +209,18 @@ class Reader {
     if (nind != n_) throw std::runtime_error("sample count of variant '" + v.rsid + "' does not match the bgen header");
     if (k != 2) throw std::runtime_error("only bi-allelic variants are accepted (variant '" + v.rsid + "').");
     if (pmin != 2 || pmax != 2) throw std::runtime_error("only diploid genotypes are supported (variant '" + v.rsid + "').");
-    const uint8_t* ploidy = blk + 8;
     const uint8_t phased = blk[8 + n_], bits = blk[9 + n_];
     if (phased) throw std::runtime_error("only unphased bgen are supported.");  // Geno.cpp:66-67
     if (bits != 8) throw std::runtime_error("bgen probabilities with " + std::to_string((int)bits) + " bits are not supported (8-bit encoding is) : variant " + v.rsid);
     if (blen < 10ull + n_ + 2ull * n_) throw std::runtime_error("malformed genotype data block for variant: " + v.rsid);
+    if (dst && blk != dst) { std::memcpy(dst, blk, block_bytes()); return dst; }     // trailing bytes after the probabilities: not copied
+    return blk;
+  }
+
+  // Dosage row of variant j: n_samples doubles, -3 = missing.
+  void read_dosages(uint32_t j, bool ref_first, double* out, std::vector<uint8_t>& cbuf, std::vector<uint8_t>& ubuf, double* info = nullptr) const {
+    const uint8_t* blk = read_block(j, cbuf, ubuf);
+    const uint8_t* ploidy = blk + 8;
     const uint8_t* pr = blk + 10 + n_;
     for (uint32_t i = 0; i < n_; ++i) {
       if (ploidy[i] & 0x80) { out[i] = -3.0; if (info) info[i] = 0.0; continue; }

@@ -1235,7 +1235,8 @@ int rg_s2_qt_block_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs
   const uint16_t* dG = G;
   int64_t ldg = ld;
   if (!g_on_device) {
-    S2_HIP(hipMemcpy2DAsync(ctx->buf[B_G], ld8 * sizeof(uint16_t), G, ld * sizeof(uint16_t), n * sizeof(uint16_t), bs, hipMemcpyHostToDevice, ctx->st));
+    if (ld == ld8) S2_HIP(hipMemcpyAsync(ctx->buf[B_G], G, ((size_t)(bs - 1) * ld8 + n) * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->st));     // rows already on the staged pitch: one flat copy
+    else S2_HIP(hipMemcpy2DAsync(ctx->buf[B_G], ld8 * sizeof(uint16_t), G, ld * sizeof(uint16_t), n * sizeof(uint16_t), bs, hipMemcpyHostToDevice, ctx->st));
     dG = (const uint16_t*)ctx->buf[B_G];
     ldg = ld8;
   }
@@ -1414,7 +1415,8 @@ int rg_s2_contract_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs
   const uint16_t* dG = G;
   int64_t ldg = ld;
   if (!g_on_device) {
-    S2_HIP(hipMemcpy2DAsync(ctx->buf[B_G], ld8 * sizeof(uint16_t), G, ld * sizeof(uint16_t), n * sizeof(uint16_t), bs, hipMemcpyHostToDevice, ctx->st));
+    if (ld == ld8) S2_HIP(hipMemcpyAsync(ctx->buf[B_G], G, ((size_t)(bs - 1) * ld8 + n) * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->st));     // rows already on the staged pitch: one flat copy
+    else S2_HIP(hipMemcpy2DAsync(ctx->buf[B_G], ld8 * sizeof(uint16_t), G, ld * sizeof(uint16_t), n * sizeof(uint16_t), bs, hipMemcpyHostToDevice, ctx->st));
     dG = (const uint16_t*)ctx->buf[B_G];
     ldg = ld8;
   }

@@ -321,11 +321,16 @@ void blup_read(Run& r, const std::unordered_map<std::string, int64_t>& idx) {
   }
   sout << " * LOCO predictions : [" << p.pred_list << "]\n";
   r.blups.resize(r.P);
-  for (int q = 0; q < r.P; ++q) {
+  // one host thread per phenotype (each file is ~115 MB at 500,000 samples x 23 rows); messages and errors in phenotype order
+  std::vector<std::string> logs(r.P), errs(r.P);
+  const int nt_files = std::max(1, std::min<int>(r.P, std::min(32u, std::max(1u, std::thread::hardware_concurrency()))));
+  parallel_for(r.P, nt_files, [&](int q) {
+    try {
+    std::ostringstream lg;
     if (!files.count(r.pheno_names[q])) throw std::runtime_error("No step 1 file provided for phenotype '" + r.pheno_names[q] + "'.");
     Run::Blup& bl = r.blups[q];
-    bl.file = files[r.pheno_names[q]];
-    sout << "   -file [" << bl.file << "] for phenotype '" << r.pheno_names[q] << "'\n";
+    bl.file = files.at(r.pheno_names[q]);
+    lg << "   -file [" << bl.file << "] for phenotype '" << r.pheno_names[q] << "'\n";
     // a gzipped file (`--step 1 --gz` writes PFX_<k>.loco.gz and lists it; Files::openForRead inflates it) cannot be revisited by byte
     // offset: its chromosome rows (nChrom lines) are kept in memory instead
     const bool gzf = ends_with_gz(bl.file);
@@ -336,31 +341,44 @@ void blup_read(Run& r, const std::unordered_map<std::string, int64_t>& idx) {
     if (!f) throw std::runtime_error("cannot open file : " + bl.file);
     std::string line;
     std::getline(f, line);
-    auto hdr = split_ws(line);
-    if (hdr.empty() || hdr[0] != "FID_IID") throw std::runtime_error("header of blup file must start with FID_IID (=" + (hdr.empty() ? std::string() : hdr[0]) + ")");
-    bl.col_sample.assign(hdr.size(), -1);
-    for (size_t c = 1; c < hdr.size(); ++c) {
-      auto it = idx.find(hdr[c]);
-      if (it != idx.end()) bl.col_sample[c] = it->second;
+    std::vector<Tok> hdr(line.size() / 2 + 2);
+    const int nh = tokenize(line.data(), line.data() + line.size(), hdr.data(), (int)hdr.size());
+    if (nh == 0 || std::string(hdr[0].b, hdr[0].e) != "FID_IID") throw std::runtime_error("header of blup file must start with FID_IID (=" + (nh == 0 ? std::string() : std::string(hdr[0].b, hdr[0].e)) + ")");
+    bl.col_sample.assign(nh, -1);
+    {
+      std::string key;
+      for (int c = 1; c < nh; ++c) {
+        key.assign(hdr[c].b, hdr[c].e);
+        auto it = idx.find(key);
+        if (it != idx.end()) bl.col_sample[c] = it->second;
+      }
     }
     bl.line_off.push_back(gzf ? 0 : (int64_t)f.tellg());
-    std::getline(f, line);
-    if (gzf) bl.lines.push_back(line);
-    auto l2 = split_ws(line);
-    if (l2.size() != hdr.size()) throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' has different number of entries on line 2 compared to the header.");
+    std::string line2;
+    std::getline(f, line2);
+    if (gzf) bl.lines.push_back(line2);
+    std::vector<Tok> l2(nh + 1);
+    if (tokenize(line2.data(), line2.data() + line2.size(), l2.data(), (int)l2.size()) != nh)
+      throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' has different number of entries on line 2 compared to the header.");
     std::vector<uint8_t> have(N, 0);
-    for (size_t c = 1; c < hdr.size(); ++c)
-      if (bl.col_sample[c] >= 0 && convert_double(l2[c]) != MISSING) have[bl.col_sample[c]] = 1;
+    for (int c = 1; c < nh; ++c)
+      if (bl.col_sample[c] >= 0 && convert_double_tok(l2[c].b, l2[c].e) != MISSING) have[bl.col_sample[c]] = 1;
     int64_t before = 0, after = 0;
     for (int64_t i = 0; i < N; ++i) { before += r.mask[(size_t)q * N + i]; r.mask[(size_t)q * N + i] &= have[i]; after += r.mask[(size_t)q * N + i]; }
     if (after < 1) throw std::runtime_error("all individuals are missing LOCO predictions for phenotype '" + r.pheno_names[q] + "'.");
-    if (after < before) sout << "    + " << before - after << " individuals with missing LOCO predictions will be ignored for the trait\n";
+    if (after < before) lg << "    + " << before - after << " individuals with missing LOCO predictions will be ignored for the trait\n";
     for (;;) {   // offsets of the following lines (one per chromosome)
       const int64_t off = gzf ? 0 : (int64_t)f.tellg();
       if (!std::getline(f, line) || line.empty()) break;
       bl.line_off.push_back(off);
       if (gzf) bl.lines.push_back(line);
     }
+    logs[q] = lg.str();
+    } catch (const std::exception& e) { errs[q] = e.what(); if (errs[q].empty()) errs[q] = "cannot read blup file"; }
+  });
+  for (int q = 0; q < r.P; ++q) {
+    if (!errs[q].empty()) throw std::runtime_error(errs[q]);
+    sout << logs[q];
   }
 }
 

@@ -157,6 +157,117 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     });
     if (failed) throw std::runtime_error("cannot read bed file");
   };
+  // 8-bit .bgen blocks (the UK Biobank encoding): the host threads inflate the NEXT block of this part and walk its bytes once -- 2-byte
+  // integer dosages (units of 1 / 255) into a pinned buffer, the allele / info sums of parseSnpfromBGEN (Geno.cpp:2186-2330) in the
+  // reference's order -- while the device tests the current block and its result lines are formatted.  The three double rows per variant
+  // of the general route (dosage, info term, analysed-sample copy: 12 MB per variant at 500,000 samples) do not exist on this one.
+  struct DosPrep {
+    uint16_t* g16 = nullptr;                 // pinned, bsize rows of ld16 entries
+    std::vector<uint8_t> raw, ignored;
+    std::vector<double> total, info_num, af_t, info_t;
+    std::vector<int64_t> ns1, ns_t;
+    bool integral = false;
+    double ms_inflate = 0, ms_walk = 0, ms_wall = 0;
+    std::string err;
+  };
+  const int64_t ld16 = (n + 7) / 8 * 8;
+  // host threads of the read-ahead: inflate is the bound of this input (about 10 ms per 1.5 MB block and thread with zlib), so it takes
+  // --threads as given, or every hardware thread but two, shared by the parts of a multi-GPU run
+  const int nt_prep = getenv("RG_S2_PREP_THREADS") ? std::max(1, atoi(getenv("RG_S2_PREP_THREADS")))
+                                                    : std::max(1, std::min(p.threads > 0 ? p.threads : std::max(1, (int)std::thread::hardware_concurrency() - 2), 256) / part.nparts);
+  const bool fast_bgen = in == In::Dosage && r.bgenh && (!dense_route || glm) && !(correct && !spa && !p.firth_approx) && !getenv("RG_S2_BGEN_ROWS");
+  DosPrep preps[2];
+  std::future<void> prep_ahead;
+  struct BlkRef { const std::vector<int64_t>* snps; int64_t j0; int bs; };
+  std::vector<BlkRef> my_blocks;             // this part's blocks in the order they are tested
+  size_t my_next = 0;
+  int64_t bgen_block_bytes = 0;
+  double ms_chr = 0, ms_prep_wall = 0, ms_prep_wait = 0, ms_device = 0, ms_format = 0, ms_inflate = 0, ms_walk = 0;
+  if (fast_bgen) {
+    if (rg_bgen_block_bytes(r.bgenh, &bgen_block_bytes) != RG_BGEN_OK) throw std::runtime_error(rg_bgen_last_error(r.bgenh));
+    bgen_block_bytes = (bgen_block_bytes + 63) / 64 * 64;
+    for (auto& d : preps) {
+      d.g16 = (uint16_t*)rg_host_alloc((size_t)p.bsize * ld16 * sizeof(uint16_t));
+      if (!d.g16) throw std::runtime_error("cannot allocate the pinned dosage buffers");
+    }
+    int b = 0;
+    for (int chrom : r.chr_read) {
+      if (!chr_snps.count(chrom)) continue;
+      const std::vector<int64_t>& sn = chr_snps[chrom];
+      const int nbc = (int)((sn.size() + p.bsize - 1) / p.bsize);
+      for (int bb = 0; bb < nbc; ++bb, ++b)
+        if (b >= part.blk_lo && b < part.blk_hi)
+          my_blocks.push_back({&sn, (int64_t)bb * p.bsize, (int)std::min<int64_t>(p.bsize, (int64_t)sn.size() - (int64_t)bb * p.bsize)});
+    }
+  }
+  static const struct T255 { double v[256]; T255() { for (int b = 0; b < 256; ++b) v[b] = b / 255.0; } } t255;   // the reader's prob = byte / 255.0
+  auto prepare = [&](const BlkRef& br, DosPrep& d) {
+    try {
+      const int bs = br.bs;
+      auto ta = std::chrono::steady_clock::now();
+      std::vector<int64_t> vi(bs);
+      for (int j = 0; j < bs; ++j) vi[j] = r.snp_offset[(*br.snps)[br.j0 + j]];
+      d.raw.resize((size_t)nt_prep * bgen_block_bytes);        // one inflated block per worker: walked while it is still in that core's cache
+      d.total.assign(bs, 0.0); d.info_num.assign(bs, 0.0); d.ns1.assign(bs, 0); d.ignored.assign(bs, 0);
+      const bool per_trait = any_missing || glm;
+      if (per_trait) { d.af_t.assign((size_t)bs * P, 0.0); d.ns_t.assign((size_t)bs * P, 0); d.info_t.assign((size_t)bs * P, 0.0); }
+      std::atomic<int> bad(0), next(0);
+      std::vector<std::string> werr(nt_prep);
+      std::vector<double> w_inf(nt_prep, 0.0), w_walk(nt_prep, 0.0);
+      const bool rf = p.ref_first;
+      // (no reader lock: the read call only reads the handle, so the parts of a --gpus N run inflate at the same time)
+      parallel_for(nt_prep, nt_prep, [&](int w) {
+        uint8_t* blk = d.raw.data() + (size_t)w * bgen_block_bytes;
+        for (int j; (j = next.fetch_add(1)) < bs;) {
+          auto t0 = std::chrono::steady_clock::now();
+          if (rg_bgen_read_blocks(r.bgenh, 1, &vi[j], blk, bgen_block_bytes, 1) != RG_BGEN_OK) { werr[w] = rg_bgen_last_error(r.bgenh); next = bs; return; }
+          auto t1 = std::chrono::steady_clock::now();
+          const uint8_t* ploidy = blk + 8;
+          const uint8_t* pr = blk + 10 + r.n_file;
+          uint16_t* q16 = d.g16 + (size_t)j * ld16;
+          double tot = 0.0, inf = 0.0; int64_t ns = 0;
+          unsigned worst = 0;
+          for (int64_t k = 0; k < n; ++k) {
+            const int64_t i = identity ? k : file_idx[k];
+            if (ploidy[i] & 0x80) { q16[k] = 0xFFFFu; continue; }
+            const unsigned b0 = pr[2 * i], b1 = pr[2 * i + 1];
+            const double p0 = t255.v[b0], p1 = t255.v[b1];
+            double v, e;
+            unsigned qi;
+            if (rf) {     // G = prob1 + 2 prob2, prob2 = max(1 - prob0 - prob1, 0) (Geno.cpp:2286-2290)
+              const double p2 = std::max(1.0 - p0 - p1, 0.0);
+              v = p1 + 2.0 * p2; e = (4.0 * p2 + p1) - v * v;
+              qi = b1 + 2u * (b0 + b1 < 255u ? 255u - b0 - b1 : 0u);
+            } else {
+              v = p1 + 2.0 * p0; e = (4.0 * p0 + p1) - v * v;
+              qi = b1 + 2u * b0;
+            }
+            worst = std::max(worst, qi);
+            q16[k] = (uint16_t)qi;
+            tot += v; inf += e; ++ns;
+            if (per_trait && has_missing[k])
+              for (int q = 0; q < P; ++q)
+                if (!Mc[(size_t)q * n + k]) { d.af_t[(size_t)j * P + q] -= v; d.ns_t[(size_t)j * P + q] -= 1; d.info_t[(size_t)j * P + q] -= e; }
+          }
+          for (int64_t k = n; k < ld16; ++k) q16[k] = 0;
+          if (worst > 510u) bad = 1;          // prob0 + prob1 > 1 in the file: not a dosage in [0, 2], the general route reports what the reference would
+          d.total[j] = tot; d.ns1[j] = ns; d.info_num[j] = inf;
+          if (std::min(tot, 2.0 * ns - tot) < p.min_mac) d.ignored[j] = 1;      // compute_mac (Geno.cpp:3077-3108), autosomes
+          auto t2 = std::chrono::steady_clock::now();
+          w_inf[w] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+          w_walk[w] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+        }
+      });
+      for (const auto& e : werr) if (!e.empty()) throw std::runtime_error(e);
+      d.integral = !bad;
+      // thread-milliseconds of the two halves, and the wall time of the block's preparation
+      d.ms_inflate = 0; d.ms_walk = 0;
+      for (int w = 0; w < nt_prep; ++w) { d.ms_inflate += w_inf[w]; d.ms_walk += w_walk[w]; }
+      d.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
+    } catch (const std::exception& e) { d.err = e.what(); if (d.err.empty()) d.err = "bgen read failed"; }
+  };
+  if (fast_bgen && !my_blocks.empty())      // the first block is inflated while the first chromosome's predictions are read
+    prep_ahead = std::async(std::launch::async, [&]() { prepare(my_blocks[0], preps[0]); });
   for (int chrom : r.chr_read) {
     if (!chr_snps.count(chrom)) continue;
     const std::vector<int64_t>& snps = chr_snps[chrom];
@@ -167,9 +278,13 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     sout << (p.bt ? "   -reading loco predictions for the chromosome and fitting null logistic regression on binary phenotypes..."
                   : p.ct ? "   -reading loco predictions for the chromosome and fitting null poisson regression..." : "   -reading loco predictions for the chromosome...");
     auto tb = std::chrono::steady_clock::now();
-    for (int q = 0; q < P; ++q) {
+    // the chromosome's row of every phenotype's .loco file (500,000 numbers each at UK Biobank size): read and converted by one host thread
+    // per phenotype, the checks reported in phenotype order
+    std::vector<std::vector<double>> blup_q(P);
+    std::vector<std::string> blup_err(P);
+    parallel_for(P, nthreads, [&](int q) {
       Run::Blup& bl = r.blups[q];
-      if (chrom < 1 || chrom > (int)bl.line_off.size()) throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' has no line for chromosome " + std::to_string(chrom) + ".");
+      if (chrom < 1 || chrom > (int)bl.line_off.size()) { blup_err[q] = "blup file for phenotype '" + r.pheno_names[q] + "' has no line for chromosome " + std::to_string(chrom) + "."; return; }
       std::string line;
       if (!bl.lines.empty()) line = bl.lines[chrom - 1];
       else {
@@ -177,19 +292,30 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
         f.seekg(bl.line_off[chrom - 1]);
         std::getline(f, line);
       }
-      auto t = split_ws(line);
-      if (t.size() != bl.col_sample.size())
-        throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' has different number of entries on line " + std::to_string(chrom + 1) + " compared to the header (=" + std::to_string(t.size()) + " vs " + std::to_string(bl.col_sample.size()) + ").");
-      if (chr_str_to_int(t[0], p.nchrom) != chrom)
-        throw std::runtime_error("blup file for phenotype '" + r.pheno_names[q] + "' starts with `" + t[0] + "`instead of chromosome number=" + std::to_string(chrom) + ".");
-      std::vector<double> blup(N, 0.0);
-      for (size_t c = 1; c < t.size(); ++c) {
+      std::vector<Tok> t(bl.col_sample.size() + 1);
+      const int nt = tokenize(line.data(), line.data() + line.size(), t.data(), (int)t.size());
+      if ((size_t)nt != bl.col_sample.size()) {
+        blup_err[q] = "blup file for phenotype '" + r.pheno_names[q] + "' has different number of entries on line " + std::to_string(chrom + 1) + " compared to the header (=" + std::to_string(nt) + " vs " + std::to_string(bl.col_sample.size()) + ").";
+        return;
+      }
+      if (chr_str_to_int(std::string(t[0].b, t[0].e), p.nchrom) != chrom) {
+        blup_err[q] = "blup file for phenotype '" + r.pheno_names[q] + "' starts with `" + std::string(t[0].b, t[0].e) + "`instead of chromosome number=" + std::to_string(chrom) + ".";
+        return;
+      }
+      std::vector<double>& blup = blup_q[q];
+      blup.assign(N, 0.0);
+      for (int c = 1; c < nt; ++c) {
         const int64_t i = bl.col_sample[c];
         if (i < 0 || !r.ain[i] || !r.mask[(size_t)q * N + i]) continue;
-        const double v = convert_double(t[c]);
-        if (v == MISSING) throw std::runtime_error("individual has missing predictions (chr=" + std::to_string(chrom) + ";phenotype=" + r.pheno_names[q] + ").");
+        const double v = convert_double_tok(t[c].b, t[c].e);
+        if (v == MISSING) { blup_err[q] = "individual has missing predictions (chr=" + std::to_string(chrom) + ";phenotype=" + r.pheno_names[q] + ")."; return; }
         blup[i] = v;
       }
+    });
+    for (int q = 0; q < P; ++q)
+      if (!blup_err[q].empty()) throw std::runtime_error(blup_err[q]);
+    for (int q = 0; q < P; ++q) {
+      const std::vector<double>& blup = blup_q[q];
       if (glm) {   // fit_null_logistic / fit_null_poisson, test-mode branch (Step1_Models.cpp:54-140, :225-288): offset = the LOCO prediction of
                    // the analysed, unmasked samples
         std::vector<double> off(n), eta, pv;
@@ -261,6 +387,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
       s2check(rg_s2_bt_set_null(s2, &nm));
     } else s2check(rg_s2_set_null(s2, Xc.data(), resc.data(), Mc.data(), scf.data()));
     sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tb).count() << "ms) \n";
+    ms_chr += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
 
     for (int bb = 0; bb < nb_chr; ++bb, ++block) {
       if (block < part.blk_lo || block >= part.blk_hi) continue;
@@ -273,9 +400,24 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
       if (in != In::Dosage) rows.resize((size_t)bs * r.bpr);
       std::unique_lock<std::mutex> rlk(g_reader_mu, std::defer_lock);
       if (multi && in != In::Bed) rlk.lock();
+      DosPrep* dp = nullptr;
+      if (fast_bgen) {
+        if (rlk.owns_lock()) rlk.unlock();      // (the prepared block took the reader's lock itself)
+        auto tw = std::chrono::steady_clock::now();
+        DosPrep& d = preps[my_next & 1];
+        if (prep_ahead.valid()) prep_ahead.get();
+        else prepare(my_blocks[my_next], d);
+        if (my_next + 1 < my_blocks.size())
+          prep_ahead = std::async(std::launch::async, [&, nx = my_next + 1]() { prepare(my_blocks[nx], preps[nx & 1]); });
+        ++my_next;
+        if (!d.err.empty()) { if (prep_ahead.valid()) prep_ahead.wait(); throw std::runtime_error(d.err); }
+        ms_prep_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+        ms_inflate += d.ms_inflate; ms_walk += d.ms_walk; ms_prep_wall += d.ms_wall;
+        if (d.integral) dp = &d;
+      }
       if (in == In::PgenHard) {   // ReadHardcalls per variant (Geno.cpp:2570-2573), as .bed-coded rows (00 = two ALT copies)
         if (rg_pgen_read_bed_rows(r.pgen, bs, vidx.data(), rows.data(), r.bpr) != RG_PGEN_OK) throw std::runtime_error(rg_pgen_last_error(r.pgen));
-      } else if (in == In::Dosage) {
+      } else if (in == In::Dosage && !dp) {
         dbuf.resize((size_t)bs * r.n_file);
         if (r.bgenh) {            // parseSnpfromBGEN (Geno.cpp:2186-2330): dosages and the terms of the IMPUTE info score
           ibuf.resize((size_t)bs * r.n_file);
@@ -294,6 +436,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
           ahead = std::async(std::launch::async, [&, jn, bn]() { read_bed(snps, jn, bn, rows_ahead); });
         }
       }
+      auto t_dev = std::chrono::steady_clock::now();
       std::vector<double> total(bs, 0.0);
       std::vector<int64_t> ns1(bs, 0);
       std::vector<double> af_t, mac_t, info_num, info_t;   // per trait: only filled when some sample is masked for some trait
@@ -306,7 +449,13 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
       test_ignored.assign((size_t)bs * P, 0);
       bool integral = false;
       const int dscale = r.bgenh ? 255 : 16384;
-      if (in == In::Dosage) {
+      const uint16_t* g16p = nullptr;
+      int64_t g16ld = n;
+      if (dp) {      // the block the host threads prepared ahead
+        total.swap(dp->total); ns1.swap(dp->ns1); info_num.swap(dp->info_num); variant_ignored.swap(dp->ignored);
+        if (any_missing || glm) { af_t.swap(dp->af_t); ns_t.swap(dp->ns_t); info_t.swap(dp->info_t); }
+        integral = true; g16p = dp->g16; g16ld = ld16;
+      } else if (in == In::Dosage) {
         // dosages: the analysed samples' doubles, allele totals, the info-score numerator and the per-trait corrections on the host
         // (parseSnpfromBGEN / readChunkFromPGENFileToG with update_trait_counts, Geno.cpp:2948-2959), the test on the fp64 route
         G.assign((size_t)bs * n, 0.0);
@@ -349,6 +498,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
             }
           });
           for (int j = 0; j < bs; ++j) if (bad[j]) integral = false;
+          g16p = G16.data();
         }
       }
       std::vector<double> af_d; std::vector<int64_t> ns_d;
@@ -370,7 +520,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
         if (in == In::Dosage) {
           if (!integral) throw std::runtime_error("--step 2 --bt / --ct on dosages that are not integer multiples of 1/" + std::to_string(dscale) + " is not built.");
           bo.vstat = bt_vstat.data();
-          s2check(rg_s2_bt_score_int(s2, G16.data(), n, bs, 0, dscale, NUMTOL, &bo));
+          s2check(rg_s2_bt_score_int(s2, g16p, g16ld, bs, 0, dscale, NUMTOL, &bo));
         } else {
           if (!identity) {
             ld = (n + 3) / 4;
@@ -466,7 +616,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
           });
         }
       } else if (in == In::Dosage) {
-        if (integral) s2check(rg_s2_qt_block_int(s2, G16.data(), n, bs, 0, dscale, NUMTOL, &o));
+        if (integral) s2check(rg_s2_qt_block_int(s2, g16p, g16ld, bs, 0, dscale, NUMTOL, &o));
         else s2check(rg_s2_qt_block(s2, G.data(), n, bs, 0, NUMTOL, &o));
       } else if (!dense_route) {
         // hard calls stay packed: the 2-bit codes of the analysed samples go to the device as they are (the rows of the file itself
@@ -533,6 +683,8 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
       }
       // the result lines (compute_score_qt after the statistic, Step2_Models.cpp:440-466; print_sum_stats_single): formatted by the host threads
       // in contiguous chunks of variants, appended to the files in order
+      auto t_fmt = std::chrono::steady_clock::now();
+      ms_device += std::chrono::duration<double, std::milli>(t_fmt - t_dev).count();
       const int nchunk = std::max(1, std::min(nthreads, bs / 64));
       std::vector<std::string> chunk_out((size_t)nchunk * P);
       std::vector<int64_t> c_snps(nchunk, 0), c_tests(nchunk, 0), c_tested(nchunk, 0);
@@ -593,9 +745,15 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
         for (int q = 0; q < P; ++q) *ofs[q] << chunk_out[(size_t)t * P + q];
         n_ignored_snps += c_snps[t]; n_ignored_tests += c_tests[t]; n_tested += c_tested[t];
       }
+      ms_format += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_fmt).count();
       sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() << "ms) \n";
     }
   }
+  if (prep_ahead.valid()) prep_ahead.wait();
+  for (auto& d : preps) if (d.g16) rg_host_free(d.g16);
+  if (getenv("RG_TIMING"))
+    fprintf(stderr, "[timing] step 2 part %d: host threads %d (read-ahead %d) | chromosome set-up %.0f ms | waiting for the prepared block %.0f ms (preparing: %.0f ms wall, overlapped; %.0f thread-ms inflate + %.0f thread-ms byte walk) | "
+            "upload + device + results %.0f ms | formatting + writing %.0f ms\n", part.part, nthreads, nt_prep, ms_chr, ms_prep_wait, ms_prep_wall, ms_inflate, ms_walk, ms_device, ms_format);
   if (fd >= 0) close(fd);
   rg_s2_destroy(s2);
   part.n_ignored_snps = n_ignored_snps; part.n_ignored_tests = n_ignored_tests;

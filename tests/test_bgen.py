@@ -63,6 +63,12 @@ def test_synthetic_probabilities_and_missing(tmp_path):
             assert (f.read_dosages(np.arange(m)) == want).all()
             assert (f.read_dosages(np.arange(m), ref_first=True) == want_rf).all()
             assert f.variant(41) == dict(chrom="2", pos=141, rsid="rs41", a0="A", a1="G", offset=o.variants[41]["offset"])
+            blk = f.read_blocks([5, 0, m - 1])                    # rg_bgen_read_blocks: the bytes the Step-2 driver walks itself
+            assert blk.shape == (3, 10 + 3 * n)
+            for k, j in enumerate((5, 0, m - 1)):
+                assert blk[k, :4].view("<u4")[0] == n and tuple(blk[k, 4:8]) == (2, 0, 2, 2) and tuple(blk[k, 8 + n:10 + n]) == (0, 8)
+                assert ((blk[k, 8:8 + n] & 0x80 != 0) == miss[j]).all() and ((blk[k, 8:8 + n] & 0x3f) == 2).all()
+                assert (blk[k, 10 + n:].reshape(n, 2)[~miss[j]] == probs[j][~miss[j]]).all()
 
 
 def test_refusals_and_damage(tmp_path, example_dir):

@@ -100,13 +100,25 @@ def main(N=500000, M=100000, MREF=2000, P=10, C=10):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     print("step 1 (LOCO predictions, %d SNPs): %.1f s" % (ms1, time.time() - t0), flush=True)
     common = ["--step", "2", "--qt", "--sample", D + "/x.sample", "--phenoFile", D + "/x.pheno", "--covarFile", D + "/x.covar", "--pred", D + "/s1_pred.list"]
-    for name, bsz in (("bsize 400", 400), ("bsize 1000", 1000)):
+    print("host: %s hardware threads, cpu.max %s" % (os.cpu_count(), open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "n/a"), flush=True)
+    variants = [("bsize 400", 400, {}), ("bsize 1000", 1000, {})]
+    for extra in os.environ.get("BGEN_E2E_VARIANTS", "").split(";"):          # e.g. "RG_S2_PREP_THREADS=64;RG_BGEN_ZLIB=1"
+        if extra:
+            variants.append(("bsize 400 " + extra, 400, dict(kv.split("=") for kv in extra.split(","))))
+    for name, bsz, env in variants:
         t0 = time.time()
-        r = subprocess.run([exe] + common + ["--bgen", D + "/x.bgen", "--bsize", str(bsz), "--out", D + "/s2"], capture_output=True, text=True)
+        r = subprocess.run([exe] + common + ["--bgen", D + "/x.bgen", "--bsize", str(bsz), "--out", D + "/s2"], capture_output=True, text=True,
+                           env=dict(os.environ, RG_TIMING="1", **env))
         dt = time.time() - t0
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        marks = [ln.strip() for ln in r.stdout.split("\n") if "Elapsed" in ln or "since start" in ln or "shares" in ln or "inflate" in ln]
-        print("regenie-amd --step 2 --bgen, %-10s: wall %.1f s = %.0f variants/s = %.2e variant*sample*pheno/s from the file | %s"
+        marks = [ln.strip() for ln in (r.stdout + r.stderr).split("\n") if "Elapsed" in ln or "since start" in ln or "[timing] step 2" in ln]
+        import re
+        chr_ms = [int(x) for x in re.findall(r"reading loco predictions for the chromosome\.\.\.done \((\d+)ms\)", r.stdout)]
+        blk_ms = [int(x) for x in re.findall(r"block \[\d+/\d+\] : done \((\d+)ms\)", r.stdout)]
+        if chr_ms and blk_ms:
+            marks.append("chromosome set-ups %d x median %d ms (sum %d); blocks %d x median %d ms (sum %d)"
+                         % (len(chr_ms), sorted(chr_ms)[len(chr_ms) // 2], sum(chr_ms), len(blk_ms), sorted(blk_ms)[len(blk_ms) // 2], sum(blk_ms)))
+        print("regenie-amd --step 2 --bgen, %-28s: wall %.1f s = %.0f variants/s = %.2e variant*sample*pheno/s from the file | %s"
               % (name, dt, M / dt, M * N * P / dt, " | ".join(marks)), flush=True)
     # the bounded sample: both programs, line by line
     t0 = time.time()
