@@ -430,6 +430,19 @@ def main():
             extra["step2"] = step2_record(torch=torch)
         except Exception as e:   # noqa: BLE001
             extra["step2"] = {"error": repr(e)[:500]}
+        if not args.no_disk:
+            # Step 2 from configs[4]'s real input format: a BGEN v1.2 file at 500,000 samples written to /tmp, `regenie-amd --step 2 --bgen` from
+            # process start to exit with the shares of its block loop, regenie itself (oracle/_ref) on a bounded sample of the same encoding
+            try:
+                import tempfile
+                with tempfile.TemporaryDirectory() as td:
+                    rb = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bgen_e2e.py"), "--json",
+                                         os.path.join(td, "rec.json"), "500000", "12000", "1000"], capture_output=True, text=True, timeout=900)
+                    if rb.returncode != 0:
+                        raise RuntimeError((rb.stdout + rb.stderr)[-600:])
+                    extra["step2"]["bgen_from_file"] = json.load(open(os.path.join(td, "rec.json")))
+            except Exception as e:   # noqa: BLE001
+                extra.setdefault("step2", {})["bgen_from_file"] = {"error": repr(e)[:600]}
     if rank == 0:
         line = {
             "metric": "Step-1 SNPs x samples x phenos / sec", "value": value, "unit": "SNP*sample*pheno/s",

@@ -266,6 +266,7 @@ struct TextLines {
   std::string line(size_t l) const { return buf.substr(span[l].first, span[l].second - span[l].first); }
 };
 void slurp_lines(std::istream& f, TextLines& t);     // everything the stream still holds
+int usable_cpus();      // hardware threads worth using: affinity mask and cgroup CPU quota taken into account
 struct Tok { const char* b; const char* e; };
 // whitespace-separated tokens of [b, e) (what `is >> t` would give); returns their number, stores the first `maxtok` of them
 int tokenize(const char* b, const char* e, Tok* out, int maxtok);

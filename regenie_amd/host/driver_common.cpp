@@ -1,6 +1,9 @@
 // regenie-amd, the C++ host driver (see driver.h): text helpers, the option table, small utilities.
 //
 #include "driver.h"
+#include <sched.h>
+#include <cmath>
+#include <cstring>
 
 namespace rgdrv {
 
@@ -393,6 +396,32 @@ std::string get_fullpath(const std::string& f) {  // Data.cpp:1150-1194
 
 void check(rg_ctx* ctx, int rc) {
   if (rc != 0) throw std::runtime_error(rg_last_error(ctx));
+}
+
+// Host threads worth starting: the hardware threads this process may run on (its affinity mask), and no more than twice the CPU time a
+// container's cgroup grants it (cpu.max / cfs quota) -- on a 256-thread host with a 16-CPU quota, 254 workers only add scheduling and
+// throttling stalls (measured on `--step 2 --bgen`: 32 workers 5.7 s, 64: 6.1 s, 254: 7.2 s).
+int usable_cpus() {
+  static const int n = []() {
+    int hw = (int)std::thread::hardware_concurrency();
+    if (hw < 1) hw = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int a = CPU_COUNT(&set); if (a > 0) hw = std::min(hw, a); }
+    double quota = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+      char q[64]; long per = 0;
+      if (fscanf(f, "%63s %ld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) quota = atof(q) / (double)per;
+      fclose(f);
+    } else {
+      long q = -1, per = 0;                                                      // cgroup v1
+      if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%ld", &q) != 1) q = -1; fclose(fq); }
+      if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%ld", &per) != 1) per = 0; fclose(fp); }
+      if (q > 0 && per > 0) quota = (double)q / (double)per;
+    }
+    if (quota > 0) hw = std::min(hw, std::max(2, (int)std::ceil(2.0 * quota)));
+    return hw;
+  }();
+  return n;
 }
 
 }  // namespace rgdrv

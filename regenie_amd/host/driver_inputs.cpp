@@ -20,7 +20,7 @@ void read_bgen_meta(Run& r) {
        << (has_ids ? "named" : "anonymous") << " samples and " << nv << " variants with 8-bit encoding.\n";
   {
     int nt = p.threads;
-    if (nt < 1) nt = std::max(1, (int)std::thread::hardware_concurrency() - 1);
+    if (nt < 1) nt = std::max(1, usable_cpus() - 1);
     rg_bgen_set_threads(r.bgenh, std::min(nt, 64));
   }
   std::set<std::string> ext, exc;
@@ -266,7 +266,7 @@ void read_bim_fam(Run& r) {  // bed: Geno.cpp:518-610, :643-690, :1128-1220; pge
     }
     {  // --threads, default = hardware threads - 1 (Regenie.cpp:1104-1106); the decode of a block's variants is spread over them
       int nt = p.threads;
-      if (nt < 1) nt = std::max(1, (int)std::thread::hardware_concurrency() - 1);
+      if (nt < 1) nt = std::max(1, usable_cpus() - 1);
       rg_pgen_set_threads(r.pgen, std::min(nt, 64));
     }
     int64_t ns = 0, nv = 0;
@@ -323,7 +323,7 @@ void blup_read(Run& r, const std::unordered_map<std::string, int64_t>& idx) {
   r.blups.resize(r.P);
   // one host thread per phenotype (each file is ~115 MB at 500,000 samples x 23 rows); messages and errors in phenotype order
   std::vector<std::string> logs(r.P), errs(r.P);
-  const int nt_files = std::max(1, std::min<int>(r.P, std::min(32u, std::max(1u, std::thread::hardware_concurrency()))));
+  const int nt_files = std::max(1, std::min<int>(r.P, std::min(32, usable_cpus())));
   parallel_for(r.P, nt_files, [&](int q) {
     try {
     std::ostringstream lg;
@@ -399,7 +399,7 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     for (int64_t i = 0; i < N; ++i) idx[r.ids[i]] = i;
   }
   const IdIndex ids(r.ids);                          // the sample files: FID / IID token pairs -> sample, no key string built
-  const int nt_parse = std::max(1, std::min(32, (int)std::thread::hardware_concurrency() - 1));
+  const int nt_parse = std::max(1, std::min(32, usable_cpus() - 1));
   std::vector<uint8_t> in_pheno(N, 0), in_cov(N, p.covar_file.empty() ? 1 : 0);
   {
     TextIn f(p.pheno_file);

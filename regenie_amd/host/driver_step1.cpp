@@ -548,7 +548,7 @@ int run(int argc, char** argv) {
   std::vector<int64_t> kept_order;     // the analysed samples in the writer's order
   for (int64_t i : order) if (r.ain[i]) { header += r.ids[i] + " "; kept_order.push_back(i); }
   header += "\n";
-  const int fmt_threads = std::max(1, std::min(32, p.threads > 0 ? p.threads : (int)std::thread::hardware_concurrency() - 1));
+  const int fmt_threads = std::max(1, std::min(32, p.threads > 0 ? p.threads : usable_cpus() - 1));
   // one row of a .loco / .prs file (write_chr_row, Data.cpp:1951-1975): `<chr> v1 v2 ... \n`, NA where the phenotype is missing.
   // The values are formatted by several threads over chunks of samples; the default stream format of a double (%g, six
   // significant digits) is what std::to_chars(general, 6) produces.

@@ -117,7 +117,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
       ++kept;
     }
   }
-  int nthreads = p.threads > 0 ? p.threads : std::max(1, (int)std::thread::hardware_concurrency() - 1);   // Regenie.cpp:1104-1106
+  int nthreads = p.threads > 0 ? p.threads : std::max(1, usable_cpus() - 1);   // Regenie.cpp:1104-1106
   nthreads = std::max(1, std::min(nthreads, 64) / part.nparts);
   // buildLookupTable (Geno.cpp:2833-2856): 00 -> 2, 01 -> missing (-3), 10 -> 1, 11 -> 0 copies of the first .bim allele
   static const double lut[4] = {2.0, -3.0, 1.0, 0.0};
@@ -174,7 +174,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
   // host threads of the read-ahead: inflate is the bound of this input (about 10 ms per 1.5 MB block and thread with zlib), so it takes
   // --threads as given, or every hardware thread but two, shared by the parts of a multi-GPU run
   const int nt_prep = getenv("RG_S2_PREP_THREADS") ? std::max(1, atoi(getenv("RG_S2_PREP_THREADS")))
-                                                    : std::max(1, std::min(p.threads > 0 ? p.threads : std::max(1, (int)std::thread::hardware_concurrency() - 2), 256) / part.nparts);
+                                                    : std::max(1, std::min(p.threads > 0 ? p.threads : usable_cpus(), 256) / part.nparts);
   const bool fast_bgen = in == In::Dosage && r.bgenh && (!dense_route || glm) && !(correct && !spa && !p.firth_approx) && !getenv("RG_S2_BGEN_ROWS");
   DosPrep preps[2];
   std::future<void> prep_ahead;

@@ -6,7 +6,7 @@ next to regenie itself (oracle/_ref/regenie, when present) on a BOUNDED sample o
 `ref_variants` variants, on which both programs run and their result lines are compared.
 
 The LOCO predictions both programs read come from this driver's own step 1 on a small .bed of the same samples.
-Usage (GPU box):  python tools/bgen_e2e.py [N=500000] [M=100000] [ref_variants=2000] [P=10] [C=10]
+Usage (GPU box):  python tools/bgen_e2e.py [--json record.json] [N=500000] [M=100000] [ref_variants=2000] [P=10] [C=10]
 The .bgen is written by a pool of worker processes (one zlib stream per variant; 1.5 MB each at 500,000 samples)."""
 import multiprocessing as mp
 import os
@@ -63,7 +63,12 @@ def write_bgen(path, n, m, chroms, nproc):
     return time.time() - t0
 
 
-def main(N=500000, M=100000, MREF=2000, P=10, C=10):
+def run(N=500000, M=100000, MREF=2000, P=10, C=10, bsizes=(400, 1000), ref_threads=(16, 64), say=print):
+    """Writes the files, runs both programs, returns the record (bench.py's `step2.bgen_from_file`) and prints the lines of the log."""
+    import re
+    import shutil
+    rec = {"samples": N, "variants": M, "phenotypes": P, "covariates": C, "encoding": "BGEN v1.2, layout 2, 8-bit probabilities, zlib", "runs": []}
+    shutil.rmtree(D, ignore_errors=True)
     os.makedirs(D, exist_ok=True)
     nproc = max(1, min(224, (os.cpu_count() or 8) - 8))
     rng = np.random.default_rng(5)
@@ -88,9 +93,10 @@ def main(N=500000, M=100000, MREF=2000, P=10, C=10):
         fh.write("".join("%d %d 0 0 0 -9\n" % (i + 1, i + 1) for i in range(N)))
     chroms = [j * 22 // M + 1 for j in range(M)]
     tw = write_bgen(D + "/x.bgen", N, M, chroms, nproc)
-    print("x.bgen: %d samples x %d variants, %.1f GB, written in %.0f s by %d processes" % (N, M, os.path.getsize(D + "/x.bgen") / 1e9, tw, nproc), flush=True)
+    rec["file_gb"] = round(os.path.getsize(D + "/x.bgen") / 1e9, 2)
+    say("x.bgen: %d samples x %d variants, %.1f GB, written in %.0f s by %d processes" % (N, M, rec["file_gb"], tw, nproc))
     tw = write_bgen(D + "/r.bgen", N, MREF, [j * 22 // MREF + 1 for j in range(MREF)], nproc)
-    print("r.bgen: the reference's bounded sample, %d variants, %.2f GB" % (MREF, os.path.getsize(D + "/r.bgen") / 1e9), flush=True)
+    say("r.bgen: the reference's bounded sample, %d variants, %.2f GB" % (MREF, os.path.getsize(D + "/r.bgen") / 1e9))
     here = os.path.dirname(os.path.abspath(__file__))
     exe = os.path.join(here, "..", "regenie_amd", "bin", "regenie-amd")
     ref = os.path.join(here, "..", "oracle", "_ref", "regenie")
@@ -98,10 +104,12 @@ def main(N=500000, M=100000, MREF=2000, P=10, C=10):
     r = subprocess.run([exe, "--step", "1", "--qt", "--bed", D + "/s", "--phenoFile", D + "/x.pheno", "--covarFile", D + "/x.covar", "--bsize", "100",
                         "--out", D + "/s1"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    print("step 1 (LOCO predictions, %d SNPs): %.1f s" % (ms1, time.time() - t0), flush=True)
+    say("step 1 (LOCO predictions, %d SNPs): %.1f s" % (ms1, time.time() - t0))
     common = ["--step", "2", "--qt", "--sample", D + "/x.sample", "--phenoFile", D + "/x.pheno", "--covarFile", D + "/x.covar", "--pred", D + "/s1_pred.list"]
-    print("host: %s hardware threads, cpu.max %s" % (os.cpu_count(), open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "n/a"), flush=True)
-    variants = [("bsize 400", 400, {}), ("bsize 1000", 1000, {})]
+    cpu_max = open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "n/a"
+    rec["host"] = {"hardware_threads": os.cpu_count(), "cgroup_cpu_max": cpu_max}
+    say("host: %s hardware threads, cpu.max %s" % (os.cpu_count(), cpu_max))
+    variants = [("bsize %d" % b, b, {}) for b in bsizes]
     for extra in os.environ.get("BGEN_E2E_VARIANTS", "").split(";"):          # e.g. "RG_S2_PREP_THREADS=64;RG_BGEN_ZLIB=1"
         if extra:
             variants.append(("bsize 400 " + extra, 400, dict(kv.split("=") for kv in extra.split(","))))
@@ -112,21 +120,29 @@ def main(N=500000, M=100000, MREF=2000, P=10, C=10):
         dt = time.time() - t0
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         marks = [ln.strip() for ln in (r.stdout + r.stderr).split("\n") if "Elapsed" in ln or "since start" in ln or "[timing] step 2" in ln]
-        import re
         chr_ms = [int(x) for x in re.findall(r"reading loco predictions for the chromosome\.\.\.done \((\d+)ms\)", r.stdout)]
         blk_ms = [int(x) for x in re.findall(r"block \[\d+/\d+\] : done \((\d+)ms\)", r.stdout)]
+        run = {"name": name, "bsize": bsz, "wall_s": round(dt, 2), "variants_per_s": round(M / dt, 1), "variant_sample_pheno_per_s": M * N * P / dt}
+        tm = re.search(r"read-ahead (\d+)\) \| chromosome set-up (\d+) ms \| waiting for the prepared block (\d+) ms \(preparing: (\d+) ms wall, overlapped; (\d+) thread-ms inflate "
+                       r"\+ (\d+) thread-ms byte walk\) \| upload \+ device \+ results (\d+) ms \| formatting \+ writing (\d+) ms", r.stderr)
+        if tm:
+            v = [int(x) for x in tm.groups()]
+            run["shares_ms"] = {"host_threads_read_ahead": v[0], "chromosome_setup": v[1], "waiting_for_prepared_block": v[2], "prepare_wall_overlapped": v[3],
+                                "inflate_thread_ms": v[4], "byte_walk_thread_ms": v[5], "upload_device_results": v[6], "format_write": v[7]}
+            run["variants_per_s_block_loop"] = round(M / max(1e-9, (v[2] + v[6] + v[7]) / 1e3), 1)     # what 10 M variants over 22 chromosomes approach
         if chr_ms and blk_ms:
             marks.append("chromosome set-ups %d x median %d ms (sum %d); blocks %d x median %d ms (sum %d)"
                          % (len(chr_ms), sorted(chr_ms)[len(chr_ms) // 2], sum(chr_ms), len(blk_ms), sorted(blk_ms)[len(blk_ms) // 2], sum(blk_ms)))
-        print("regenie-amd --step 2 --bgen, %-28s: wall %.1f s = %.0f variants/s = %.2e variant*sample*pheno/s from the file | %s"
-              % (name, dt, M / dt, M * N * P / dt, " | ".join(marks)), flush=True)
+        rec["runs"].append(run)
+        say("regenie-amd --step 2 --bgen, %-28s: wall %.1f s = %.0f variants/s = %.2e variant*sample*pheno/s from the file | %s"
+            % (name, dt, M / dt, M * N * P / dt, " | ".join(marks)))
     # the bounded sample: both programs, line by line
     t0 = time.time()
     r = subprocess.run([exe] + common + ["--bgen", D + "/r.bgen", "--bsize", "400", "--out", D + "/r_amd"], capture_output=True, text=True)
     t_amd = time.time() - t0
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     if os.path.exists(ref):
-        for thr in (16, 64):
+        for thr in ref_threads:
             t0 = time.time()
             r = subprocess.run([ref] + common + ["--bgen", D + "/r.bgen", "--bsize", "400", "--threads", str(thr), "--out", D + "/r_ref"], capture_output=True, text=True)
             dt = time.time() - t0
@@ -141,9 +157,27 @@ def main(N=500000, M=100000, MREF=2000, P=10, C=10):
                 num = lambda ln: [t for k, t in enumerate(ln.split()) if k in (5, 6, 7, 9, 10, 11, 12)]     # A1FREQ INFO N | BETA SE CHISQ LOG10P
                 close += sum(all(abs(float(u) - float(v)) <= 2e-5 * max(abs(float(v)), 1e-3) for u, v in zip(num(x), num(z)) if u != "NA" and v != "NA")
                              for x, z in zip(a[1:], b[1:]))
-            print("bounded sample (%d variants x %d phenotypes): regenie v4.1.2 (oracle/_ref, --threads %d) %.1f s = %.0f variants/s; regenie-amd %.1f s; "
-                  "%d of %d result lines byte-identical, %d within 2e-5" % (MREF, P, thr, dt, MREF / dt, t_amd, same, tot, close), flush=True)
+            rec.setdefault("cpu_baseline", []).append({"kind": "reference", "program": "regenie v4.1.2 (oracle/_ref)", "threads": thr, "sample": "%d variants of the same encoding" % MREF,
+                                                       "wall_s": round(dt, 1), "variants_per_s": round(MREF / dt, 1), "regenie_amd_wall_s": round(t_amd, 1),
+                                                       "result_lines": tot, "byte_identical": same, "within_2e-5": close})
+            say("bounded sample (%d variants x %d phenotypes): regenie v4.1.2 (oracle/_ref, --threads %d) %.1f s = %.0f variants/s; regenie-amd %.1f s; "
+                "%d of %d result lines byte-identical, %d within 2e-5" % (MREF, P, thr, dt, MREF / dt, t_amd, same, tot, close))
+    shutil.rmtree(D, ignore_errors=True)
+    return rec
+
+
+def main(argv):
+    """[--json PATH] [N M MREF P C]; with --json the record goes to PATH (bench.py's sub-run: one bsize, one reference thread count)."""
+    js = None
+    if argv and argv[0] == "--json":
+        js, argv = argv[1], argv[2:]
+    kw = dict(bsizes=(400,), ref_threads=(16,)) if js else {}
+    rec = run(*[int(a) for a in argv], say=lambda s: print(s, flush=True), **kw)
+    if js:
+        import json
+        with open(js, "w") as fh:
+            json.dump(rec, fh)
 
 
 if __name__ == "__main__":
-    main(*[int(a) for a in sys.argv[1:]])
+    main(sys.argv[1:])

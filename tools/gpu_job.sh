@@ -41,7 +41,11 @@ for k in ("end_to_end_from_files", "cpu_baseline"):
 c = d.get("config3_single_gpu")
 if c: print("config3", {k: c.get(k) for k in ("ms_per_step", "value", "error")}, (c.get("roofline") or {}).get("frac"), {k: v.get("ms") for k, v in (c.get("kernels") or {}).items()})
 s2 = d.get("step2")
-if s2: print("step2", json.dumps(s2)[:600])
+if s2:
+    print("step2", json.dumps({k: v for k, v in s2.items() if k != "bgen_from_file"})[:600])
+    print("step2.bgen_from_file", json.dumps(s2.get("bgen_from_file"))[:1500])
+c4 = d.get("config4_level1_two_binary_traits")
+if c4: print("config4_level1", {k: c4.get(k) for k in ("s_per_trait", "converged", "error")}, (c4.get("roofline") or {}).get("frac"))
 PY
     ;;
   stats)
