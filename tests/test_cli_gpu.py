@@ -684,6 +684,13 @@ def test_cli_step2_multi_gpu(example_dir, tmp_path, mode):
     if mode == "bt_firth":
         for k in (1, 2):
             assert open(str(tmp_path / ("one_%d.firth" % k))).read() == open(str(tmp_path / ("three_%d.firth" % k))).read()
+    if mode == "bt_spa_bgen":
+        # the .bgen blocks reach the device through the read-ahead (inflate + one byte walk into 2-byte rows, driver_step2.cpp `prepare`); the
+        # general route (three double rows per variant, RG_S2_BGEN_ROWS=1) must print the same files
+        rows = subprocess.run([BIN] + cmd + ["--out", "rows"], cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=dict(os.environ, RG_S2_BGEN_ROWS="1"))
+        assert rows.returncode == 0, rows.stdout[-2000:] + rows.stderr[-2000:]
+        for k in (1, 2):
+            assert open(str(tmp_path / ("one_Y%d.regenie" % k)), "rb").read() == open(str(tmp_path / ("rows_Y%d.regenie" % k)), "rb").read()
 
 
 @pytest.mark.parametrize("fmt", ["bed", "bgen", "bgen_rf", "pgen", "pgenhc", "strict", "bgen_mininfo"])
