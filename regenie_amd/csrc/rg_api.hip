@@ -307,7 +307,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if (ctx->d_vsc) { hipFree(ctx->d_vsc); ctx->d_vsc = nullptr; }
   if (ctx->d_xyS) { hipFree(ctx->d_xyS); ctx->d_xyS = nullptr; }
   if (ctx->d_segid) { hipFree(ctx->d_segid); ctx->d_segid = nullptr; }
-  if (Cv * 8 <= 128 && !getenv("RG_XY_F64")) {
+  if (!getenv("RG_XY_F64")) {      // any number of columns: the kernel takes them sixteen at a time
     if ((rc = dev_alloc(ctx, &ctx->d_vd, (size_t)Cv * 8 * Np))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_vsc, (size_t)Cv))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_xyS, (size_t)nb * 2 * nseg * n128 * 128))) return rc;

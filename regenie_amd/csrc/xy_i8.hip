@@ -324,20 +324,21 @@ __global__ __launch_bounds__(256, 4) void k_xy_i8_planes(const int8_t* __restric
       }
 }
 
-// ---- part[blk][fold][row][set][c] = vsc[c] * sum_k 128^k S[.][c*8+k]; grid (ceil(n128*Cv / 256), nseg, nblk) -------------------
+// ---- part[blk][fold][row][set][c0 + c] = vsc[c0 + c] * sum_k 128^k S[.][c*8+k] for the ncg columns of one group of 16;
+// grid (ceil(n128*ncg / 256), nseg, nblk) ------------------------------------------------------------------------------------------
 __global__ void k_xy_combine(const int32_t* __restrict__ S, const double* __restrict__ vsc, const int32_t* __restrict__ nmiss, int n128, int nseg,
-                             int Cv, double* __restrict__ part) {
+                             int Cv, int c0, int ncg, double* __restrict__ part) {
   const int blk = blockIdx.z, f = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n128 * Cv) return;
-  const int j = t / Cv, c = t - j * Cv;
+  if (t >= n128 * ncg) return;
+  const int j = t / ncg, c = t - j * ncg;
   const int nset = nmiss[blk] > 0 ? 2 : 1;
   for (int set = 0; set < nset; ++set) {
     const int32_t* s = S + (((((int64_t)blk * 2 + set) * nseg + f) * n128 + j) * (int64_t)XT) + c * X_NPIECE;
     double v = 0.0, w = 1.0;
 #pragma unroll
     for (int k = 0; k < X_NPIECE; ++k) { v = fma((double)s[k], w, v); w *= 128.0; }
-    part[((((int64_t)blk * nseg + f) * n128 + j) * 2 + set) * Cv + c] = v * vsc[c];
+    part[((((int64_t)blk * nseg + f) * n128 + j) * 2 + set) * Cv + c0 + c] = v * vsc[c0 + c];
   }
 }
 
@@ -372,12 +373,17 @@ void rg_launch_xy_i8_planes(hipStream_t st, const int8_t* aplanes, int64_t a_set
                      (ncols - (ngrp - 1) * 16) * X_NPIECE, S32);
 }
 
-// S32: nblk * 2 * nseg * n128 * 128 int32; part: [nblk][nseg][n128][2][Cv] (rowstats reads it with nchunk = nseg, chunk_seg = identity)
+// S32: nblk * 2 * nseg * n128 * 128 int32; part: [nblk][nseg][n128][2][Cv] (rowstats reads it with nchunk = nseg, chunk_seg = identity).
+// More than 16 columns (many phenotypes: BASELINE configs[3] has 3 + 50): one pass per group of 16 columns, the sums of a group combined
+// into its columns of `part` before the next group reuses S32 (stream order).
 void rg_launch_xy_i8(hipStream_t st, const uint8_t* pk, int64_t pk_ld, int64_t pk_blk_stride, const int32_t* d_bs, const int32_t* nmiss,
                      int nblk, int n128, const SegLayout& seg, const int8_t* vd, const double* vsc, int64_t Np, int Cv, int32_t* S32,
                      double* part) {
-  hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, nblk * 2), dim3(256), 0, st, pk, pk_ld, pk_blk_stride, d_bs, nmiss, n128, seg, vd,
-                     (int64_t)0, 0, Np, Cv * X_NPIECE, -1, RG_XY_LUT_DOSAGE, S32);
-  hipLaunchKernelGGL(k_xy_combine, dim3((n128 * Cv + 255) / 256, seg.nseg, nblk), dim3(256), 0, st, (const int32_t*)S32, vsc, nmiss, n128, seg.nseg,
-                     Cv, part);
+  for (int c0 = 0; c0 < Cv; c0 += 16) {
+    const int ncg = Cv - c0 < 16 ? Cv - c0 : 16;
+    hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, nblk * 2), dim3(256), 0, st, pk, pk_ld, pk_blk_stride, d_bs, nmiss, n128, seg,
+                       vd + (int64_t)c0 * X_NPIECE * Np, (int64_t)0, 0, Np, ncg * X_NPIECE, -1, RG_XY_LUT_DOSAGE, S32);
+    hipLaunchKernelGGL(k_xy_combine, dim3((n128 * ncg + 255) / 256, seg.nseg, nblk), dim3(256), 0, st, (const int32_t*)S32, vsc, nmiss, n128, seg.nseg,
+                       Cv, c0, ncg, part);
+  }
 }

@@ -177,7 +177,6 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
                                                     : std::max(1, std::min(p.threads > 0 ? p.threads : usable_cpus(), 256) / part.nparts);
   const bool fast_bgen = in == In::Dosage && r.bgenh && (!dense_route || glm) && !(correct && !spa && !p.firth_approx) && !getenv("RG_S2_BGEN_ROWS");
   DosPrep preps[2];
-  std::future<void> prep_ahead;
   struct BlkRef { const std::vector<int64_t>* snps; int64_t j0; int bs; };
   std::vector<BlkRef> my_blocks;             // this part's blocks in the order they are tested
   size_t my_next = 0;
@@ -266,6 +265,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
       d.ms_wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta).count();
     } catch (const std::exception& e) { d.err = e.what(); if (d.err.empty()) d.err = "bgen read failed"; }
   };
+  std::future<void> prep_ahead;      // declared after everything `prepare` touches: its destructor waits for the worker before those go away
   if (fast_bgen && !my_blocks.empty())      // the first block is inflated while the first chromosome's predictions are read
     prep_ahead = std::async(std::launch::async, [&]() { prepare(my_blocks[0], preps[0]); });
   for (int chrom : r.chr_read) {
