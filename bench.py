@@ -36,7 +36,7 @@ CHR_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 
 PEAK = {"fp4_mfma_TOPS": 10000.0,    # MX FP4 dense (MI355X_MICROARCH.md: ~10 PF dense, ubench 9099 TF at 32x32x64)
         "i8_mfma_TOPS": 5000.0,      # 2x the bf16 dense peak (MI355X_MICROARCH.md: I8 ~2x bf16 rate; ubench 4404)
         "f64_mfma_TFLOPS": 78.6,     # AMD datasheet FP64 matrix (not listed in the guide)
-        "bf16_mfma_TFLOPS": 2500.0,  # dense bf16 (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 measured)
+        "bf16_mfma_TFLOPS": 2500.0,  # dense bf16 = dense fp16 (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 measured)
         "hbm_GBs": 8000.0}
 
 
@@ -328,14 +328,16 @@ def main():
                             "full_product_TFLOPS_survey_8d": 2.0 * N * L * L * P / (tm["ms_l1_gram"] * 1e-3) / 1e12 if tm["ms_l1_gram"] else None},
             "l1_chol_f64": {"ms": tm["ms_l1_chol"]}, "l1_cv_pred": {"ms": tm["ms_l1_pred"]},
         }
-        wg_bf16 = tm["n_wgram_approx_rounds"] > 0      # the quasi-Newton Grams of wgram_bf16.hip: three bf16 products per operand pair
+        wg_bf16 = tm["n_wgram_approx_rounds"] > 0      # the quasi-Newton Grams of wgram_bf16.hip
+        wg_mult = 3.0 if os.environ.get("RG_WGRAM_FMT") == "bf16x3" else 1.0      # products executed per operand pair: fp16 plane (default) or bf16 hi + lo
         if tm["n_wgram"]:
             kernels["wgram_f64"] = {"ms": tm["ms_wgram"], "achieved_TFLOPS": flops["wgram_f64"] / (tm["ms_wgram"] * 1e-3) / 1e12 if tm["ms_wgram"] else None,
                                     "chain_grams": tm["n_wgram"], "irls_rounds": tm["n_irls_rounds"], "grams_per_trait": tm["n_wgram"] / P,
                                     "ms_per_chain_gram": tm["ms_wgram"] / tm["n_wgram"],
                                     "quasi_newton_bf16_rounds": tm["n_wgram_approx_rounds"],
-                                    "note": ("achieved_TFLOPS counts the fp64-equivalent symmetric product positions x L x (L + 1) per chain Gram; the kernel "
-                                             "executes 3x that in bf16 (hi hi^T + hi lo^T + lo hi^T), conversion and slice reduction included in ms") if wg_bf16 else
+                                    "note": ("achieved_TFLOPS counts the symmetric product positions x L x (L + 1) per chain Gram; the kernel executes "
+                                             + ("3x that in bf16 (hi hi^T + hi lo^T + lo hi^T)" if wg_mult == 3.0 else "exactly that, once, on fp16 operands") +
+                                             "; conversion and slice reduction included in ms") if wg_bf16 else
                                             "fp64 matrix cores (k_wgram128), slice reduction and the X^T W z row included in ms"}
             kernels["irls_solve"] = {"ms": tm["ms_irls_solve"]}
             kernels["irls_stream"] = {"ms": tm["ms_irls_stream"]}
@@ -354,13 +356,14 @@ def main():
                     "peak": PEAK["i8_mfma_TOPS"], "unit": "TOP/s", "frac": a / PEAK["i8_mfma_TOPS"], "traffic": traffic, "traffic_note": traffic_note,
                     "algorithmic_ops_per_launch": flops["pred_i8"] / max(1, n_batches), "avg_launch_ms": tm["ms_pred"] / max(1, n_batches)}
         elif dom == "wgram_f64" and wg_bf16:
-            ex = 3.0 * flops["wgram_f64"] / (tm["ms_wgram"] * 1e-3) / 1e12     # bf16 operations executed per second
-            roof = {"kernel": "k_wsplit + k_wgram_bf16 + k_wg_reduce (quasi-Newton weighted Gram of the logistic ridge IRLS: bf16 pair planes, "
-                              "three products per operand pair, fp32 accumulators flushed into fp64 partial tiles; the score that drives the "
-                              "iteration and its stopping rule stays exact fp64)", "bound": "mfma", "achieved": ex, "peak": PEAK["bf16_mfma_TFLOPS"],
-                    "unit": "TFLOP/s (bf16 executed)", "frac": ex / PEAK["bf16_mfma_TFLOPS"], "traffic": traffic, "traffic_note": traffic_note,
+            ex = wg_mult * flops["wgram_f64"] / (tm["ms_wgram"] * 1e-3) / 1e12     # 16-bit matrix operations executed per second
+            roof = {"kernel": "k_wsplit + k_wgram_mx + k_wg_reduce (quasi-Newton weighted Gram of the logistic ridge IRLS: " +
+                              ("bf16 pair planes, three products per operand pair" if wg_mult == 3.0 else "one fp16 operand plane, one product per operand pair") +
+                              ", fp32 accumulators flushed into fp64 partial tiles; the score that drives the iteration and its stopping rule stays exact fp64)",
+                    "bound": "mfma", "achieved": ex, "peak": PEAK["bf16_mfma_TFLOPS"],
+                    "unit": "TFLOP/s (%s executed)" % ("bf16" if wg_mult == 3.0 else "fp16"), "frac": ex / PEAK["bf16_mfma_TFLOPS"], "traffic": traffic, "traffic_note": traffic_note,
                     "fp64_equivalent_TFLOPS": kernels[dom]["achieved_TFLOPS"],
-                    "algorithmic_flops_per_launch": 3.0 * flops[dom] / max(1, tm["n_irls_rounds"]),
+                    "algorithmic_flops_per_launch": wg_mult * flops[dom] / max(1, tm["n_irls_rounds"]),
                     "avg_launch_ms": kernels[dom]["ms"] / max(1, tm["n_irls_rounds"])}
         else:
             a = kernels[dom]["achieved_TFLOPS"]

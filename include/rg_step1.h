@@ -279,7 +279,7 @@ typedef struct rg_timing {
   int64_t n_wgram;          /* chain Grams formed: one per (fold model or LOOCV model, IRLS step) */
   int64_t n_irls_rounds;    /* lock-step rounds (a round advances every unfinished fold model by one IRLS step) */
   int64_t wgram_positions;  /* sum over the chain Grams of the sample positions contracted (their flop count is positions * L * (L + 1)) */
-  int64_t n_wgram_approx_rounds; /* rounds whose Grams were the quasi-Newton ones (bf16 pair planes, wgram_bf16.hip) rather than fp64 */
+  int64_t n_wgram_approx_rounds; /* rounds whose Grams were the quasi-Newton ones (16-bit operand planes, wgram_bf16.hip) rather than fp64 */
 } rg_timing;
 int rg_enable_timing(rg_ctx* ctx, int on); /* wraps kernel groups in hipEvents on the ctx stream */
 int rg_get_timing(rg_ctx* ctx, rg_timing* out);

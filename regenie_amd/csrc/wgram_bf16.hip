@@ -1,5 +1,5 @@
 // The weighted Gram X^T W X of the logistic / Poisson ridge IRLS (ridge_logistic_level_1, src/Step1_Models.cpp:1041-1101) as a
-// QUASI-NEWTON Hessian on the bf16 matrix cores.
+// QUASI-NEWTON Hessian on the 16-bit matrix cores.
 //
 // BASELINE configs[3] (50 binary traits, 500,000 samples, L = 2,560 level-0 predictors) spends 93 % of its level 1 in that Gram:
 // 57 chain Grams per trait of 0.8 N L (L + 1) flop each, 47 ms apiece at 0.70 of the fp64 matrix peak (profiles/r4_config4_*).  No
@@ -10,33 +10,43 @@
 // has the SAME fixed point for any non-singular H~ -- the penalised maximum-likelihood estimate -- and the same stopping rule (max
 // |score| < 1e-4 on the exact score).  H~ only has to be close enough to H that the step stays a Newton step: with ||H^-1 (H~ - H)|| =
 // rho the error after a step is rho x the error before it plus the usual quadratic term.  Here H~ is formed from the operand
-// V = W sqrt(w) split into two bf16 terms per entry (hi + lo carries 16 significant bits), three products per pair
-// (hi hi^T + hi lo^T + lo hi^T; the diagonal tiles, where sum lo^2 is systematic, also lo lo^T) on v_mfma_f32_32x32x16_bf16 with the
-// fp32 accumulators flushed into fp64 partial tiles every WB_FLUSH stages (4,096 positions: an fp32 running sum of half a million
-// positive terms would otherwise lose its last digits).  Entry errors come out at 1e-8 of the diagonal, rho <= 1e-2 at the smallest
-// ridge value of the default grid, typically 1e-4: the iterates follow the fp64 Newton iterates to that relative distance and stop
-// at the same iteration (tests/test_l1_models_gpu.py, tests/test_l1_full_width_gpu.py hold the results to the oracle at 1e-6).
+// V = W sqrt(w) on the 16-bit matrix cores, fp32 accumulators flushed into fp64 partial tiles every 4,096 positions (an fp32 running sum of
+// half a million positive terms would otherwise lose its last digits).  Two operand formats:
+//   * fp16, ONE plane and ONE product per operand pair (default; v_mfma_f32_32x32x16_f16).  V is standardised predictors times sqrt(w) <= 1/2:
+//     well inside fp16's range, 11 significant bits, rounded to nearest.  The products are exact in fp32, the rounding errors of the two
+//     operands are independent and average over the positions: an entry of H~ is off by about 2^-10.5 / sqrt(N) of the diagonal (1e-6 at
+//     400,000 positions), ||H~ - H|| about 1e-4 of the diagonal, against eigenvalues of H + tau I that are at least tau and in practice 1e-2 of
+//     the diagonal (the five ridge values of a block are correlated 0.9 - 0.99): rho = 1e-2, the IRLS takes the same number of rounds
+//     (measured at 500,000 samples x 2,560 predictors: 24 rounds and 119 chain Grams against 24 and 120) and each Gram costs 5.3 instead of
+//     11.7 ms;
+//   * bf16 hi + lo planes, three products per pair (RG_WGRAM_FMT=bf16x3; hi hi^T + hi lo^T + lo hi^T, on the diagonal tiles also lo lo^T): 16
+//     significant bits, entry errors 1e-8 of the diagonal -- the first form of this kernel, kept for comparison.
+// Either way the results are held to the oracle at 1e-6 (tests/test_l1_models_gpu.py, tests/test_l1_full_width_gpu.py), which is what both
+// sides' stopping rule (max |score| < 1e-4) allows.
 // A chain that needs more than RG_WGRAM_SWITCH (12) steps at one ridge value finishes on the fp64 Gram (k_wgram128); RG_WGRAM_F64=1
 // keeps the fp64 Gram everywhere.  Leave-one-out CV keeps the fp64 Gram (its leverages are read off the matrix itself).
 //
 // Data flow of one lock-step round over the unfinished fold models ("chains"; slot s = s-th active chain):
-//   k_wsplit       V[s][row][chunk] = bf16 pair planes of W[row][pos] * sqrt(w_chain(pos)), 32 positions per 128-byte chunk
-//                  (64 B of hi, 64 B of lo), the chain's held-out fold squeezed out of the position axis; W is read once for all slots
-//   k_wgram_bf16   one workgroup (16 waves, 32 x 128 outputs each) per 256 x 256 tile of the lower triangle, slot and K slice: the
+//   k_wsplit       V[s][row][chunk] = W[row][pos] * sqrt(w_chain(pos)) as fp16, 64 positions per 128-byte chunk (bf16x3: 32 positions,
+//                  64 B of hi, 64 B of lo), the chain's held-out fold squeezed out of the position axis; W is read once for all slots
+//   k_wgram_mx     one workgroup (16 waves, 32 x 128 outputs each) per 256 x 256 tile of the lower triangle, slot and K slice: the
 //                  design of the FP4 fold Gram (gram_fp4.hip) -- 128-byte rows staged by direct global -> LDS copies, two buffers,
-//                  XOR-swizzled 16-byte slots, four waves per SIMD -- with 24 (diagonal tiles: 32) matrix instructions per stage
+//                  XOR-swizzled 16-byte slots, four waves per SIMD -- with 16 matrix instructions per stage and wave (bf16x3: 24, diagonal tiles 32)
 //   k_wg_reduce    (l1x.hip) sums the K slices in a fixed order and puts tau on the diagonal
 #include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <vector>
 #include "rg_internal.h"
 
 #define WB_T 256          // output tile
 #define WB_ROWB 128       // bytes per row and stage: 32 positions, hi then lo
-#define WB_CHUNK 32       // positions per stage
-#define WB_FLUSH 128      // stages between flushes of the fp32 accumulators into the fp64 partial tile
+// positions per stage (= per 128-byte chunk of an operand row) and stages between flushes of the fp32 accumulators into the fp64 partial
+// tile (4,096 positions either way), per operand format: F16 = one fp16 plane (64 positions per chunk), else bf16 hi | lo (32)
+template <bool F16> struct WbFmt { static constexpr int CHUNK = F16 ? 64 : 32, SHIFT = F16 ? 6 : 5, FLUSH = F16 ? 64 : 128; };
 typedef float v16f __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
@@ -56,6 +66,7 @@ struct WSplitArgs {
 
 // block = 4 waves = 4 consecutive predictor rows x the same 512 positions (the weights are shared through the cache);
 // lane i converts positions 8 i .. 8 i + 7 of the range = a quarter of a chunk: 16 bytes of hi, 16 bytes of lo per slot
+template <bool F16>
 __global__ __launch_bounds__(256) void k_wsplit(WSplitArgs a, SegLayout seg) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = blockIdx.y * 4 + wave;
@@ -67,13 +78,15 @@ __global__ __launch_bounds__(256) void k_wsplit(WSplitArgs a, SegLayout seg) {
   double x[8];
 #pragma unroll
   for (int k = 0; k < 8; k += 2) { const double2 t = *reinterpret_cast<const double2*>(w + k); x[k] = t.x; x[k + 1] = t.y; }
-  const int64_t ca = pos >> 5;                       // chunk in position space
-  const int q = (lane & 3) * 16;                     // byte offset of this lane's quarter inside the hi (and the lo) half
+  constexpr int SH = WbFmt<F16>::SHIFT;
+  const int64_t ca = pos >> SH;                      // chunk in position space
+  // byte offset of this lane's 8 positions inside the chunk: an eighth of the fp16 chunk, or a quarter of the hi (and of the lo) half
+  const int q = F16 ? (lane & 7) * 16 : (lane & 3) * 16;
   for (int s = 0; s < a.nslot; ++s) {
     const int chain = a.chainmap[s];
     int64_t cv = ca;
     if (a.excl_own) {
-      const int64_t sk0 = seg.pos_start[chain] >> 5, skn = seg.plen[chain] >> 5;
+      const int64_t sk0 = seg.pos_start[chain] >> SH, skn = seg.plen[chain] >> SH;
       if (ca >= sk0 && ca < sk0 + skn) continue;      // the chain's held-out fold is not part of its operand
       if (ca >= sk0 + skn) cv = ca - skn;
     }
@@ -83,6 +96,12 @@ __global__ __launch_bounds__(256) void k_wsplit(WSplitArgs a, SegLayout seg) {
     for (int k = 0; k < 8; k += 2) {
       const double2 t = *reinterpret_cast<const double2*>(wt + k);
       const float v0 = (float)(x[k] * t.x), v1 = (float)(x[k + 1] * t.y);
+      if (F16) {     // one fp16 value per entry (11 significant bits, round to nearest)
+        const _Float16 f0 = (_Float16)v0, f1 = (_Float16)v1;
+        hi[k >> 1] = (unsigned)__builtin_bit_cast(unsigned short, f0) | ((unsigned)__builtin_bit_cast(unsigned short, f1) << 16);
+        lo[k >> 1] = 0u;
+        continue;
+      }
       const __bf16 h0 = (__bf16)v0, h1 = (__bf16)v1;
       const __bf16 l0 = (__bf16)(v0 - (float)h0), l1 = (__bf16)(v1 - (float)h1);
       hi[k >> 1] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
@@ -90,7 +109,7 @@ __global__ __launch_bounds__(256) void k_wsplit(WSplitArgs a, SegLayout seg) {
     }
     uint8_t* dst = a.V + (int64_t)s * a.v_slot_bytes + (int64_t)row * a.v_row_bytes + cv * WB_ROWB + q;
     *reinterpret_cast<uint4*>(dst) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-    *reinterpret_cast<uint4*>(dst + 64) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+    if (!F16) *reinterpret_cast<uint4*>(dst + 64) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
   }
 }
 
@@ -122,8 +141,9 @@ __device__ __forceinline__ void wb_stage(const uint8_t* abase, int arows, const 
   }
 }
 
-template <bool SAME>
+template <bool SAME, bool F16>
 __device__ __forceinline__ void wb_tile(const WbArgs& g, const WbItem it, int64_t st0, int nstage, uint8_t* smem) {
+  constexpr int WB_FLUSH = WbFmt<F16>::FLUSH;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int l31 = lane & 31, h = lane >> 5;
@@ -183,6 +203,19 @@ __device__ __forceinline__ void wb_tile(const WbArgs& g, const WbItem it, int64_
       if (s + 1 < nstage) wb_stage<SAME>(abase, arows, bbase, brows, g.v_row_bytes, (int64_t)(s + 1) * WB_ROWB, nxt);
       const uint8_t* sa = cur + ra * WB_ROWB;
       const uint8_t* sb = cur + rb * WB_ROWB;
+      if (F16) {
+        // one product: four K = 16 steps over the chunk's 64 positions, 16-byte slot 2 ks + h of the row
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const v4i av = *reinterpret_cast<const v4i*>(sa + (((2 * ks + h) ^ xa) << 4));
+          v4i bv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const v4i*>(sb + j * 32 * WB_ROWB + (((2 * ks + h) ^ xb) << 4));
+          const f16x8 a_f = __builtin_bit_cast(f16x8, av);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_f, __builtin_bit_cast(f16x8, bv[j]), acc[j], 0, 0, 0);
+        }
+      } else {
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         const v4i ah = *reinterpret_cast<const v4i*>(sa + (((2 * ks + h) ^ xa) << 4));
@@ -203,6 +236,7 @@ __device__ __forceinline__ void wb_tile(const WbArgs& g, const WbItem it, int64_
           if (SAME) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_l, b_l, acc[j], 0, 0, 0);
         }
       }
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next stage has landed in LDS
       __syncthreads();
     }
@@ -213,7 +247,9 @@ __device__ __forceinline__ void wb_tile(const WbArgs& g, const WbItem it, int64_
 // Work items come from a host-built table (tile row, tile column, slot, K slice); item w = xcd * ceil(n / 8) + k for workgroup id
 // 8 k + xcd, so that each of the eight XCDs walks a contiguous range of the table -- the tiles of one (slot, slice) -- and streams
 // their common operand panels through its own L2 (as k_gram_fp4_blocks).
-__global__ __launch_bounds__(1024) void k_wgram_bf16(WbArgs g, SegLayout seg) {
+template <bool F16>
+__global__ __launch_bounds__(1024) void k_wgram_mx(WbArgs g, SegLayout seg) {
+  constexpr int WB_CHUNK = WbFmt<F16>::CHUNK;
   __shared__ __attribute__((aligned(16))) uint8_t smem[4 * WB_T * WB_ROWB];
   const int per_xcd = (g.nitem + 7) >> 3;
   const int w = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
@@ -223,8 +259,8 @@ __global__ __launch_bounds__(1024) void k_wgram_bf16(WbArgs g, SegLayout seg) {
   const int64_t all = (seg.pos_start[seg.nseg - 1] + seg.plen[seg.nseg - 1]) / WB_CHUNK;
   const int64_t vs = all - (g.excl_own ? seg.plen[chain] / WB_CHUNK : 0);        // stages of this chain's operand
   const int64_t s0 = vs * it.slice / g.nslice, s1 = vs * (it.slice + 1) / g.nslice;
-  if (it.tr == it.tc) wb_tile<true>(g, it, s0, (int)(s1 - s0), smem);
-  else wb_tile<false>(g, it, s0, (int)(s1 - s0), smem);
+  if (it.tr == it.tc) wb_tile<true, F16>(g, it, s0, (int)(s1 - s0), smem);
+  else wb_tile<false, F16>(g, it, s0, (int)(s1 - s0), smem);
 }
 
 // Forms the partial tiles of the `nslot` chains in `chainmap` into part[slice][slot]; returns the number of K slices (0 on failure).
@@ -233,6 +269,9 @@ int rg_launch_wgram_bf16(rg_ctx* ctx, hipStream_t st, const double* W, int64_t N
                          const int32_t* d_chainmap, const int32_t* h_chainmap, int nslot, int excl_own, double* part, int64_t out_stride,
                          int max_slices) {
   const SegLayout& seg = ctx->seg;
+  // operand format: one fp16 plane and one product per pair (default), or bf16 hi + lo planes and three products (RG_WGRAM_FMT=bf16x3)
+  static const bool F16 = !(getenv("RG_WGRAM_FMT") && std::string(getenv("RG_WGRAM_FMT")) == "bf16x3");
+  const int WB_CHUNK = F16 ? WbFmt<true>::CHUNK : WbFmt<false>::CHUNK, WB_FLUSH = F16 ? WbFmt<true>::FLUSH : WbFmt<false>::FLUSH;
   const int64_t all = seg.pos_start[seg.nseg - 1] + seg.plen[seg.nseg - 1];
   int64_t min_vs = all / WB_CHUNK;
   if (excl_own) for (int s = 0; s < nslot; ++s) min_vs = std::min(min_vs, (all - seg.plen[h_chainmap[s]]) / WB_CHUNK);
@@ -263,8 +302,10 @@ int rg_launch_wgram_bf16(rg_ctx* ctx, hipStream_t st, const double* W, int64_t N
       hipStreamSynchronize(st) != hipSuccess) { ctx->err = "weighted Gram: copy of the work table failed"; return 0; }
   hipLaunchKernelGGL(k_sqrtw, dim3((unsigned)(((int64_t)nchain * Np + 255) / 256)), dim3(256), 0, st, wv, (int64_t)nchain * Np, sw);
   WSplitArgs sa{W, Np, L, P, p, sw, d_chainmap, nslot, excl_own, V, v_row_bytes, v_slot_bytes};
-  hipLaunchKernelGGL(k_wsplit, dim3((unsigned)((all + 511) / 512), (unsigned)((L + 3) / 4)), dim3(256), 0, st, sa, seg);
+  if (F16) hipLaunchKernelGGL(k_wsplit<true>, dim3((unsigned)((all + 511) / 512), (unsigned)((L + 3) / 4)), dim3(256), 0, st, sa, seg);
+  else hipLaunchKernelGGL(k_wsplit<false>, dim3((unsigned)((all + 511) / 512), (unsigned)((L + 3) / 4)), dim3(256), 0, st, sa, seg);
   WbArgs g{V, v_row_bytes, v_slot_bytes, L, n64, nslot, nslice, d_chainmap, excl_own, d_items, (int)items.size(), part, out_stride};
-  hipLaunchKernelGGL(k_wgram_bf16, dim3((unsigned)(((items.size() + 7) / 8) * 8)), dim3(1024), 0, st, g, seg);
+  if (F16) hipLaunchKernelGGL(k_wgram_mx<true>, dim3((unsigned)(((items.size() + 7) / 8) * 8)), dim3(1024), 0, st, g, seg);
+  else hipLaunchKernelGGL(k_wgram_mx<false>, dim3((unsigned)(((items.size() + 7) / 8) * 8)), dim3(1024), 0, st, g, seg);
   return nslice;
 }

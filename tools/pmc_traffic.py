@@ -33,7 +33,7 @@ COUNT = {}
 GROUPS = {"chol": GROUP, "l1_gram": ("k_l1_gram128", "k_l1_gram64", "k_l1_wty", "k_reduce_slices", "k_sum_folds"),
           "gram_fp4": ("k_gram_fp4_blocks",), "pred": ("k_pk_transpose", "k_beta_split", "k_l0_pred_i8", "k_l0_pred", "k_beta_post",
                                                        "k_l0_stats", "k_l0_scale"),
-          "wgram": ("k_wgram_bf16", "k_wsplit", "k_sqrtw", "k_wgram128", "k_wg_reduce", "k_wg_wz", "k_wgram")}
+          "wgram": ("k_wgram_mx", "k_wgram_bf16", "k_wsplit", "k_sqrtw", "k_wgram128", "k_wg_reduce", "k_wg_wz", "k_wgram")}
 
 
 def main(fd, wd, nbatch, out, blocks=None, phenos=None):
