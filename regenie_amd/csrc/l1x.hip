@@ -806,6 +806,10 @@ struct BtState {
   BtArgs a;
   double *d_beta, *d_score, *d_tauc, *d_part, *d_sys, *d_dinv;
   double* d_sw = nullptr;      // [nchain][Np] square roots of the weights (the quasi-Newton Gram of wgram_bf16.hip); null = fp64 Grams only
+  // a chain's last quasi-Newton Hessian, kept for steps that do not form a new one (see "Steps on a Hessian that is already there"):
+  double* d_G = nullptr;       // [nchain][msz] X^T W X + g_tau I as k_wg_reduce left it (right-hand-side rows zero)
+  double* d_fac = nullptr;     // [nchain][msz] its Cholesky factor at fac_tau (lower triangle)
+  double* d_delta = nullptr;   // [nchain] diagonal shifts of a re-factorization
   int32_t* d_map;
   std::vector<double> h_part, h_score, h_sol;
 };
@@ -843,12 +847,122 @@ int bt_score(BtState& s, const std::vector<double>& tauc, std::vector<double>& m
   return RG_OK;
 }
 
+// ---- Steps on a Hessian that is already there ---------------------------------------------------------------------------------
+// beta + H~^-1 score(beta) converges to the same fixed point for any H~ near the Hessian (wgram_bf16.hip), so H~ need not be formed at the
+// current weights either: along the path of ridge values the fitted probabilities move by a few per cent from one value to the next, and
+// X^T W X of a few steps ago is as good a quasi-Newton matrix as a freshly rounded one.  A chain therefore keeps its last Gram G (d_G) and
+// its Cholesky factor (d_fac) and takes
+//   a CHORD step      when the factor is at the current ridge value: two triangular solves (k_tri_solve), no Gram, no factorization;
+//   a REFACTORED step when the ridge value has moved on: G + (tau - g_tau) I factored again, no Gram;
+//   a FRESH step      (Gram at the current weights) when there is nothing to reuse, or when the last reused step shrank max |score| by
+//                     less than RG_WGRAM_REUSE_RATIO (a factor 5), or -- after stepping back -- when it made it larger.
+// The score, the stopping rule (max |score| < 1e-4) and the zero-weight halving are those of every other step.  RG_WGRAM_REUSE=0: fresh only.
+__global__ void k_add_diag(double* mats, int64_t msz, int n64, int L, const double* delta) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < L) mats[(int64_t)blockIdx.y * msz + (int64_t)i * n64 + i] += delta[blockIdx.y];
+}
+
+// x = (F F^T)^-1 b for the factor F that chol.hip leaves in the lower triangle of a row-major n64 x n64 matrix (order L, the padding past it
+// is not touched); one workgroup per system, the vector in LDS.  Forward substitution column tile by column tile (the diagonal tile's 64 pivots
+// on one wave, then every row below takes its 64-term update), backward substitution the same way up the transposed factor (column sums over
+// the rows below, four row groups reduced through LDS).  26 MB of factor per solve at L = 2,560: 0.2 - 0.3 ms.
+__global__ __launch_bounds__(256) void k_tri_solve(const double* __restrict__ fac, int64_t msz, const int32_t* __restrict__ chainmap, int n64, int L,
+                                                   const double* __restrict__ rhs, double* __restrict__ sol) {
+  extern __shared__ double tsm[];
+  double* y = tsm;                         // [n64]
+  double* tile = tsm + n64;                // [64][65]
+  double* red = tile + 64 * 65;            // [4][64]
+  const int tid = threadIdx.x;
+  const int chain = chainmap[blockIdx.x];
+  const double* A = fac + (int64_t)chain * msz;
+  for (int i = tid; i < n64; i += 256) y[i] = i < L ? rhs[(int64_t)chain * n64 + i] : 0.0;
+  const int nt = (L + 63) / 64;
+  auto stage_tile = [&](int k0) {          // lower triangle of the diagonal tile; identity past the order
+    const int nk = L - k0 < 64 ? L - k0 : 64;
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      tile[r * 65 + c] = (r < nk && c <= r) ? A[(int64_t)(k0 + r) * n64 + k0 + c] : (r == c ? 1.0 : 0.0);
+    }
+  };
+  __syncthreads();
+  for (int k = 0; k < nt; ++k) {
+    const int k0 = k * 64;
+    stage_tile(k0);
+    __syncthreads();
+    if (tid < 64) {
+      double v = y[k0 + tid];
+      for (int c = 0; c < 64; ++c) {
+        const double piv = __shfl(v, c) / tile[c * 65 + c];
+        if (tid == c) v = piv;
+        else if (tid > c) v -= tile[tid * 65 + c] * piv;
+      }
+      y[k0 + tid] = v;
+    }
+    __syncthreads();
+    for (int i = k0 + 64 + tid; i < L; i += 256) {
+      const double* row = A + (int64_t)i * n64 + k0;
+      double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+      for (int c = 0; c < 64; c += 2) {
+        const double2 t = *reinterpret_cast<const double2*>(row + c);
+        a0 = fma(t.x, y[k0 + c], a0);
+        a1 = fma(t.y, y[k0 + c + 1], a1);
+      }
+      y[i] -= a0 + a1;
+    }
+    __syncthreads();
+  }
+  const int cc = tid & 63, gg = tid >> 6;
+  for (int k = nt - 1; k >= 0; --k) {
+    const int k0 = k * 64;
+    double acc = 0.0;
+    for (int i = k0 + 64 + gg; i < L; i += 4) acc = fma(A[(int64_t)i * n64 + k0 + cc], y[i], acc);
+    red[gg * 64 + cc] = acc;
+    stage_tile(k0);
+    __syncthreads();
+    if (tid < 64) {
+      double v = y[k0 + tid] - ((red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]));
+      for (int c = 63; c >= 0; --c) {
+        const double piv = __shfl(v, c) / tile[c * 65 + c];
+        if (tid == c) v = piv;
+        else if (tid < c) v -= tile[c * 65 + tid] * piv;
+      }
+      y[k0 + tid] = v;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n64; i += 256) sol[(int64_t)chain * n64 + i] = i < L ? y[i] : 0.0;
+}
+
+static size_t tri_solve_lds(int n64) { return sizeof(double) * ((size_t)n64 + 64 * 65 + 256); }
+
+// chord steps of the chains in `act`: solutions of F F^T x = score with each chain's stored factor, into h_sol
+int bt_chord(BtState& s, const std::vector<int32_t>& act) {
+  rg_ctx* ctx = s.ctx;
+  L1Common& c = *s.c;
+  hipStream_t st = c.st;
+  const int na = (int)act.size();
+  L1Lap lap(ctx, st, &ctx->tm.ms_irls_solve);
+  L1X_HIP(hipMemcpyAsync(s.d_map, act.data(), sizeof(int32_t) * na, hipMemcpyHostToDevice, st));
+  const size_t lds = tri_solve_lds(c.n64);
+  if (lds > 48 * 1024) L1X_HIP(hipFuncSetAttribute((const void*)k_tri_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  double* d_x = s.d_sys;      // [nchain][n64] scratch: the systems' workspace is idle during a chord step
+  hipLaunchKernelGGL(k_tri_solve, dim3(na), dim3(256), lds, st, (const double*)s.d_fac, c.msz, (const int32_t*)s.d_map, c.n64, c.L, (const double*)s.d_score, d_x);
+  for (int i = 0; i < na; ++i)
+    L1X_HIP(hipMemcpyAsync(s.h_sol.data() + (size_t)act[i] * c.n64, d_x + (int64_t)act[i] * c.n64, sizeof(double) * c.n64, hipMemcpyDeviceToHost, st));
+  L1X_HIP(hipStreamSynchronize(st));
+  ++ctx->tm.n_irls_rounds;
+  return RG_OK;
+}
+
 // (X^T W X + tau I) x = rhs for the chains in `act` (rhs = X^T W z from the extra row, or the score);
 // solutions land in h_sol [nchain][n64].  *bad is set when a system is not positive definite.
 // approx: H~ from the bf16 pair planes (wgram_bf16.hip) instead of the fp64 Gram -- only with rhs_is_score, where the right-hand side is
 // the exact score and the solution a quasi-Newton step (a fixed point of beta + H~^-1 score(beta) has score = 0 whatever H~ is)
+// keep: the quasi-Newton Gram and its factor are stored per chain (d_G, d_fac).  g_tau != nullptr: NO Gram is formed -- the stored one is
+// shifted from the ridge value it holds (g_tau[chain]) to tauc[chain] and factored again.
 int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<double>& tauc, bool rhs_is_score,
-             bool* bad, bool approx = false) {
+             bool* bad, bool approx = false, bool keep = false, const std::vector<double>* g_tau = nullptr) {
   rg_ctx* ctx = s.ctx;
   L1Common& c = *s.c;
   hipStream_t st = c.st;
@@ -857,7 +971,16 @@ int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<doub
   L1X_HIP(hipMemcpyAsync(s.d_tauc, tauc.data(), sizeof(double) * s.nchain, hipMemcpyHostToDevice, st));
   WgArgs g{c.Wv, ctx->d_zero, c.Np, c.L, c.Pv, s.p, c.n64, s.a.wv, rhs_is_score ? nullptr : s.a.zv, s.d_tauc,
            s.d_map, s.a.kfold, s.d_sys, c.msz};
-  if (approx && rhs_is_score && s.d_sw) {
+  if (g_tau && s.d_G) {
+    L1Lap lap(ctx, st, &ctx->tm.ms_irls_solve);
+    std::vector<double> delta(na);
+    for (int i = 0; i < na; ++i) {
+      delta[i] = tauc[act[i]] - (*g_tau)[act[i]];
+      L1X_HIP(hipMemcpyAsync(s.d_sys + (int64_t)i * c.msz, s.d_G + (int64_t)act[i] * c.msz, sizeof(double) * c.msz, hipMemcpyDeviceToDevice, st));
+    }
+    L1X_HIP(hipMemcpyAsync(s.d_delta, delta.data(), sizeof(double) * na, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_add_diag, dim3((c.L + 255) / 256, na), dim3(256), 0, st, s.d_sys, c.msz, c.n64, c.L, (const double*)s.d_delta);
+  } else if (approx && rhs_is_score && s.d_sw) {
     L1Lap lap(ctx, st, &ctx->tm.ms_wgram);
     const int MAXSL = 16;
     double* d_part = (double*)rg_ws(ctx, 14, sizeof(double) * (size_t)MAXSL * na * c.msz);
@@ -869,14 +992,17 @@ int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<doub
     Wg128 g2{g, ns, na, nullptr, d_part};
     hipLaunchKernelGGL(k_wg_reduce, dim3(c.T * (c.T + 1) / 2, na), dim3(256), 0, st, g2, c.T);
     L1X_HIP(hipMemset2DAsync(s.d_sys + (int64_t)c.n64 * c.n64, sizeof(double) * c.msz, 0, sizeof(double) * CT * c.n64, na, st));
+    if (keep && s.d_G)
+      for (int i = 0; i < na; ++i)
+        L1X_HIP(hipMemcpyAsync(s.d_G + (int64_t)act[i] * c.msz, s.d_sys + (int64_t)i * c.msz, sizeof(double) * c.msz, hipMemcpyDeviceToDevice, st));
     ++ctx->tm.n_wgram_approx_rounds;
   } else {
     L1Lap lap(ctx, st, &ctx->tm.ms_wgram);
     const int rcw = launch_wgram(ctx, st, g, c.T, na); if (rcw) return rcw;
   }
-  ctx->tm.n_wgram += na;
   ++ctx->tm.n_irls_rounds;
-  {
+  if (!(g_tau && s.d_G)) {
+    ctx->tm.n_wgram += na;
     const int64_t all = ctx->seg.pos_start[ctx->seg.nseg - 1] + ctx->seg.plen[ctx->seg.nseg - 1];
     for (int i = 0; i < na; ++i) ctx->tm.wgram_positions += all - (s.a.kfold ? ctx->seg.plen[act[i]] : 0);
   }
@@ -886,9 +1012,12 @@ int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<doub
       L1X_HIP(hipMemcpyAsync(s.d_sys + (int64_t)i * c.msz + (int64_t)c.n64 * c.n64, s.d_score + (int64_t)act[i] * c.n64,
                              sizeof(double) * c.L, hipMemcpyDeviceToDevice, st));
   rg_launch_chol_solve(st, s.d_sys, c.msz, na, c.n64, CT, 1, s.d_dinv, ctx->d_info + 1, &ctx->tm.n_chol_launches);
-  for (int i = 0; i < na; ++i)
+  for (int i = 0; i < na; ++i) {
     L1X_HIP(hipMemcpyAsync(s.h_sol.data() + (size_t)act[i] * c.n64, s.d_sys + (int64_t)i * c.msz + (int64_t)c.n64 * c.n64,
                            sizeof(double) * c.n64, hipMemcpyDeviceToHost, st));
+    if ((keep || g_tau) && s.d_fac)      // the factor, for chord steps at this ridge value (the square part is enough)
+      L1X_HIP(hipMemcpyAsync(s.d_fac + (int64_t)act[i] * c.msz, s.d_sys + (int64_t)i * c.msz, sizeof(double) * (size_t)c.n64 * c.n64, hipMemcpyDeviceToDevice, st));
+  }
   L1X_HIP(hipStreamSynchronize(st));
   return check_spd(ctx, bad);
 }
@@ -1013,6 +1142,15 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
   const double wg_min = getenv("RG_WGRAM_QUASI_MIN") ? atof(getenv("RG_WGRAM_QUASI_MIN")) : 2e11;
   const double gram_flop = (double)(ctx->seg.pos_start[ctx->seg.nseg - 1] + ctx->seg.plen[ctx->seg.nseg - 1]) * (loocv ? 1.0 : (double)(K - 1) / K) * L * (L + 1.0);
   if (!loocv && !wg_f64 && gram_flop >= wg_min) L1X_HIP(c.bufs.alloc(&s.d_sw, (size_t)nchain * Np));
+  // steps on a stored Hessian (chord / refactored, see k_tri_solve): on with the quasi-Newton Gram unless RG_WGRAM_REUSE=0
+  const bool reuse = s.d_sw && !(getenv("RG_WGRAM_REUSE") && atoi(getenv("RG_WGRAM_REUSE")) == 0) && tri_solve_lds(c.n64) <= 150 * 1024;
+  const double reuse_ratio = getenv("RG_WGRAM_REUSE_RATIO") ? atof(getenv("RG_WGRAM_REUSE_RATIO")) : 0.2;
+  const double reuse_tol = getenv("RG_WGRAM_REUSE_TOL") ? atof(getenv("RG_WGRAM_REUSE_TOL")) : 1e-6;
+  if (reuse) {
+    L1X_HIP(c.bufs.alloc(&s.d_G, (size_t)nchain * c.msz));
+    L1X_HIP(c.bufs.alloc(&s.d_fac, (size_t)nchain * c.msz));
+    L1X_HIP(c.bufs.alloc(&s.d_delta, (size_t)nchain));
+  }
   L1X_HIP(hipMemsetAsync(s.d_score, 0, sizeof(double) * (size_t)nchain * n64, st));
   s.h_part.resize((size_t)s.nchunk * nchain * BT_NPART);
   s.h_score.resize((size_t)nchain * n64);
@@ -1057,7 +1195,10 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
     if (!loocv) {
       // ---- K-fold: the K fold models advance in lockstep launches, each with its own (tau index, iteration) ----
       std::vector<double> beta((size_t)K * n64, 0.0), betaold = beta, sums, maxabs, tauc(K), hbetas((size_t)K * R1 * n64, 0.0);
-      std::vector<int> jj(K, 0), niter(K, 0), solved(K, 0), halv(K, 0);
+      std::vector<int> jj(K, 0), niter(K, 0), solved(K, 0), halv(K, 0), nfresh(K, 0);
+      // stored-Hessian state per chain: has a Gram (at ridge value g_tau), has a factor (at fac_tau), the last step reused one, the next must not
+      std::vector<char> have_g(K, 0), have_f(K, 0), last_reused(K, 0), need_fresh(K, 0);
+      std::vector<double> g_tau(K, 0.0), fac_tau(K, 0.0), prev_abs(K, 0.0);
       int ndone = 0;
       std::vector<char> done(K, 0);
       while (ok && ndone < K) {
@@ -1078,12 +1219,26 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
               continue;  // re-evaluate, no new solve
             }
             halv[ch] = 0;
-            if (maxabs[ch] < o.l1_ridge_tol) {  // converged at tau_j: record beta + held-out sums
+            // A Newton step lands far inside the tolerance it is stopped by (the reference's last step starts from max |score| > 1e-4 and
+            // ends near 1e-8); steps on a stored Hessian converge linearly and would stop just under it, up to 1e-4 / lambda_min further from
+            // the optimum than the reference's iterate.  They are therefore held to a tighter bound (RG_WGRAM_REUSE_TOL, 1e-6).
+            const double tol_ch = last_reused[ch] ? std::min(reuse_tol, o.l1_ridge_tol) : o.l1_ridge_tol;
+            if (last_reused[ch]) {     // how did the step on the stored Hessian do?
+              last_reused[ch] = 0;
+              if (maxabs[ch] > prev_abs[ch] && maxabs[ch] >= tol_ch) {      // worse: step back, form the Gram here
+                std::memcpy(beta.data() + (size_t)ch * n64, betaold.data() + (size_t)ch * n64, sizeof(double) * n64);
+                need_fresh[ch] = 1;
+                solved[ch] = 0;
+                continue;  // re-evaluate at the previous iterate, no new solve this round
+              }
+              if (maxabs[ch] > reuse_ratio * prev_abs[ch]) need_fresh[ch] = 1;
+            }
+            if (maxabs[ch] < tol_ch) {  // converged at tau_j: record beta + held-out sums
               const int j = jj[ch];
               std::memcpy(hbetas.data() + ((size_t)ch * R1 + j) * n64, beta.data() + (size_t)ch * n64, sizeof(double) * n64);
               for (int t = 0; t < 6; ++t) cs[t * R1 + j] += sm[t];
               if (++jj[ch] == R1) { done[ch] = 1; ++ndone; continue; }
-              niter[ch] = 0;
+              niter[ch] = 0; nfresh[ch] = 0;
             }
           } else if (sm[7] != 0.0) { ok = false; break; }
           if (++niter[ch] > o.niter_max_ridge) { ok = false; break; }
@@ -1100,17 +1255,28 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
         for (int ch : act) rescore |= (tauc[ch] != taup[std::min(jj[ch], R1 - 1)]);
         for (int ch = 0; ch < K; ++ch) tauc[ch] = taup[std::min(jj[ch], R1 - 1)];
         if (rescore && (rc = bt_score(s, tauc, maxabs))) return rc;
-        std::vector<int32_t> act_q, act_x;      // quasi-Newton Gram / fp64 Gram (a chain that is slow at this ridge value finishes on the latter)
-        for (int ch : act) ((s.d_sw && niter[ch] <= wg_switch) ? act_q : act_x).push_back(ch);
-        for (int pass = 0; pass < 2 && ok; ++pass) {
-          const std::vector<int32_t>& aa = pass ? act_x : act_q;
+        // quasi-Newton Gram (fresh) / fp64 Gram (a chain that is slow at this ridge value finishes on it) / stored Hessian: chord, refactored
+        std::vector<int32_t> act_q, act_x, act_c, act_r;
+        for (int ch : act) {
+          prev_abs[ch] = maxabs[ch];
+          if (!(s.d_sw && nfresh[ch] <= wg_switch)) act_x.push_back(ch);
+          else if (reuse && have_g[ch] && !need_fresh[ch]) ((have_f[ch] && fac_tau[ch] == tauc[ch]) ? act_c : act_r).push_back(ch);
+          else act_q.push_back(ch);
+        }
+        for (int pass = 0; pass < 4 && ok; ++pass) {
+          const std::vector<int32_t>& aa = pass == 0 ? act_q : pass == 1 ? act_x : pass == 2 ? act_r : act_c;
           if (aa.empty()) continue;
           bool bad = false;
-          if ((rc = bt_solve(s, aa, tauc, true, &bad, pass == 0))) return rc;
+          if (pass == 3) rc = bt_chord(s, aa);
+          else rc = bt_solve(s, aa, tauc, true, &bad, pass == 0, pass == 0 && reuse, pass == 2 ? &g_tau : nullptr);
+          if (rc) return rc;
           if (bad) { ok = false; break; }
           for (int ch : aa) {
             for (int k = 0; k < L; ++k) beta[(size_t)ch * n64 + k] = betaold[(size_t)ch * n64 + k] + s.h_sol[(size_t)ch * n64 + k];
             solved[ch] = 1;
+            if (pass == 0) { ++nfresh[ch]; need_fresh[ch] = 0; if (reuse) { have_g[ch] = have_f[ch] = 1; g_tau[ch] = fac_tau[ch] = tauc[ch]; } }
+            else if (pass == 1) { have_g[ch] = have_f[ch] = 0; }
+            else { last_reused[ch] = 1; if (pass == 2) { have_f[ch] = 1; fac_tau[ch] = tauc[ch]; } }
           }
         }
       }
