@@ -340,8 +340,13 @@ def main():
                                              "; conversion and slice reduction included in ms") if wg_bf16 else
                                             "fp64 matrix cores (k_wgram128), slice reduction and the X^T W z row included in ms"}
             kernels["irls_solve"] = {"ms": tm["ms_irls_solve"]}
-            kernels["irls_stream"] = {"ms": tm["ms_irls_stream"]}
-        cand = ["gram_fp4", "chol_f64", "l1_gram_f64"] + (["pred"] if flops["pred_i8"] else []) + (["wgram_f64"] if tm["n_wgram"] and tm["ms_wgram"] else [])
+            # the streaming half of an IRLS round: eta = X beta over the samples (k_bt_eval) and the exact score X^T (y - p) - tau beta
+            # (k_bt_score), one pass over the phenotype's L x N predictors each (8 L N bytes; the vectors they carry are 1e-3 of that)
+            stream_bytes = 8.0 * L * N * tm.get("n_irls_passes", 0)
+            kernels["irls_stream"] = {"ms": tm["ms_irls_stream"], "passes": tm.get("n_irls_passes", 0),
+                                      "achieved_GBps": stream_bytes / (tm["ms_irls_stream"] * 1e-3) / 1e9 if tm["ms_irls_stream"] else None}
+        cand = (["gram_fp4", "chol_f64", "l1_gram_f64"] + (["pred"] if flops["pred_i8"] else []) + (["wgram_f64"] if tm["n_wgram"] and tm["ms_wgram"] else []) +
+                (["irls_stream"] if tm["n_wgram"] and tm.get("n_irls_passes", 0) else []))
         dom = max(cand, key=lambda k: kernels[k]["ms"])
         kernels["gram_fp4"]["frac_of_fp4_peak"] = kernels["gram_fp4"]["achieved_TOPS"] / PEAK["fp4_mfma_TOPS"]
         traffic, traffic_note = measured_traffic(dom, len(my_blocks), n_batches, P)
@@ -355,6 +360,13 @@ def main():
             roof = {"kernel": "k_l0_pred_i8 (level-0 predictions, exact digit planes on the i8 matrix cores)", "bound": "mfma", "achieved": a,
                     "peak": PEAK["i8_mfma_TOPS"], "unit": "TOP/s", "frac": a / PEAK["i8_mfma_TOPS"], "traffic": traffic, "traffic_note": traffic_note,
                     "algorithmic_ops_per_launch": flops["pred_i8"] / max(1, n_batches), "avg_launch_ms": tm["ms_pred"] / max(1, n_batches)}
+        elif dom == "irls_stream":
+            a = kernels[dom]["achieved_GBps"]
+            roof = {"kernel": "k_bt_eval + k_bt_score (the streaming passes of the logistic-ridge IRLS rounds over the phenotype's predictors; the Hessians are "
+                              "the quasi-Newton Grams of wgram_bf16.hip, reused over several rounds)", "bound": "hbm", "achieved": a, "peak": PEAK["hbm_GBs"],
+                    "unit": "GB/s", "frac": a / PEAK["hbm_GBs"], "traffic": traffic, "traffic_note": traffic_note,
+                    "algorithmic_bytes_per_launch": 8.0 * L * N, "avg_launch_ms": tm["ms_irls_stream"] / max(1, tm["n_irls_passes"]),
+                    "note": "avg_launch_ms includes the small host <-> device copies and the synchronisation each pass ends with"}
         elif dom == "wgram_f64" and wg_bf16:
             ex = wg_mult * flops["wgram_f64"] / (tm["ms_wgram"] * 1e-3) / 1e12     # 16-bit matrix operations executed per second
             roof = {"kernel": "k_wsplit + k_wgram_mx + k_wg_reduce (quasi-Newton weighted Gram of the logistic ridge IRLS: " +
@@ -363,8 +375,10 @@ def main():
                     "bound": "mfma", "achieved": ex, "peak": PEAK["bf16_mfma_TFLOPS"],
                     "unit": "TFLOP/s (%s executed)" % ("bf16" if wg_mult == 3.0 else "fp16"), "frac": ex / PEAK["bf16_mfma_TFLOPS"], "traffic": traffic, "traffic_note": traffic_note,
                     "fp64_equivalent_TFLOPS": kernels[dom]["achieved_TFLOPS"],
-                    "algorithmic_flops_per_launch": wg_mult * flops[dom] / max(1, tm["n_irls_rounds"]),
-                    "avg_launch_ms": kernels[dom]["ms"] / max(1, tm["n_irls_rounds"])}
+                    # a launch = one round in which Grams were formed (k_wsplit + k_wgram_mx + k_wg_reduce over the chains that needed one);
+                    # the other IRLS rounds step on stored Hessians and form none
+                    "algorithmic_flops_per_launch": wg_mult * flops[dom] / max(1, tm["n_wgram_approx_rounds"]),
+                    "avg_launch_ms": kernels[dom]["ms"] / max(1, tm["n_wgram_approx_rounds"])}
         else:
             a = kernels[dom]["achieved_TFLOPS"]
             nlaunch = {"chol_f64": n_batches, "l1_gram_f64": P, "wgram_f64": tm["n_irls_rounds"]}[dom]
@@ -486,7 +500,7 @@ def measured_traffic(dom, nblocks, n_batches, P):
         stamp = open(os.path.join(ROOT, "regenie_amd", "lib", "build.stamp")).read().strip()
     except OSError:
         return None, "no build stamp"
-    group = {"chol_f64": "chol", "l1_gram_f64": "l1_gram", "gram_fp4": "gram_fp4", "pred": "pred", "wgram_f64": "wgram"}[dom]
+    group = {"chol_f64": "chol", "l1_gram_f64": "l1_gram", "gram_fp4": "gram_fp4", "pred": "pred", "wgram_f64": "wgram", "irls_stream": "irls_stream"}[dom]
     stale, same_build = False, False
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
         try:
@@ -500,7 +514,10 @@ def measured_traffic(dom, nblocks, n_batches, P):
         g = tj.get("groups", {}).get(group)
         if not g or tj.get("blocks") != nblocks or tj.get("phenos") != P:
             continue
-        per = g["hbm_bytes"] / max(1, tj["level0_batches"] if group != "l1_gram" else g.get("lead_launches", P))
+        if group == "irls_stream":      # a launch = one streaming pass (k_bt_eval or k_bt_score)
+            per = g["hbm_bytes"] / max(1, g.get("group_launches", 0))
+        else:
+            per = g["hbm_bytes"] / max(1, tj["level0_batches"] if group not in ("l1_gram", "wgram") else g.get("lead_launches", P))
         return per, ("FETCH_SIZE x 2 + WRITE_SIZE of the kernel (group) from separate rocprofv3 --pmc passes of this command on this "
                      "build (%s), per launch" % os.path.basename(fn))
     if same_build:

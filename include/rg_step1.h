@@ -280,6 +280,7 @@ typedef struct rg_timing {
   int64_t n_irls_rounds;    /* lock-step rounds (a round advances every unfinished fold model by one IRLS step) */
   int64_t wgram_positions;  /* sum over the chain Grams of the sample positions contracted (their flop count is positions * L * (L + 1)) */
   int64_t n_wgram_approx_rounds; /* rounds whose Grams were the quasi-Newton ones (16-bit operand planes, wgram_bf16.hip) rather than fp64 */
+  int64_t n_irls_passes;         /* streaming passes over a phenotype's predictors in ms_irls_stream: one per k_bt_eval / k_bt_score launch */
 } rg_timing;
 int rg_enable_timing(rg_ctx* ctx, int on); /* wraps kernel groups in hipEvents on the ctx stream */
 int rg_get_timing(rg_ctx* ctx, rg_timing* out);

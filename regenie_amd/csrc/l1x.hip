@@ -820,9 +820,11 @@ int bt_eval(BtState& s, const std::vector<double>& hbeta, std::vector<double>& s
   hipStream_t st = s.c->st;
   L1Lap lap(ctx, st, &ctx->tm.ms_irls_stream);
   L1X_HIP(hipMemcpyAsync(s.d_beta, hbeta.data(), sizeof(double) * hbeta.size(), hipMemcpyHostToDevice, st));
-  for (int ch0 = 0; ch0 < s.nchain; ch0 += NCH)
+  for (int ch0 = 0; ch0 < s.nchain; ch0 += NCH) {
     hipLaunchKernelGGL(k_bt_eval, dim3(s.nchunk), dim3(256), 0, st, s.a, ch0, ctx->d_c256_seg, ctx->d_c256_pos,
                        ctx->d_c256_len, s.d_part);
+    ++ctx->tm.n_irls_passes;
+  }
   L1X_HIP(hipMemcpyAsync(s.h_part.data(), s.d_part, sizeof(double) * s.h_part.size(), hipMemcpyDeviceToHost, st));
   L1X_HIP(hipStreamSynchronize(st));
   sums.assign((size_t)s.nchain * BT_NPART, 0.0);
@@ -837,8 +839,10 @@ int bt_score(BtState& s, const std::vector<double>& tauc, std::vector<double>& m
   hipStream_t st = s.c->st;
   L1Lap lap(ctx, st, &ctx->tm.ms_irls_stream);
   L1X_HIP(hipMemcpyAsync(s.d_tauc, tauc.data(), sizeof(double) * s.nchain, hipMemcpyHostToDevice, st));
-  for (int ch0 = 0; ch0 < s.nchain; ch0 += NCH)
+  for (int ch0 = 0; ch0 < s.nchain; ch0 += NCH) {
     hipLaunchKernelGGL(k_bt_score, dim3((s.c->L + BT_SROWS - 1) / BT_SROWS), dim3(256), 0, st, s.a, ch0, s.d_tauc, s.d_score);
+    ++ctx->tm.n_irls_passes;
+  }
   L1X_HIP(hipMemcpyAsync(s.h_score.data(), s.d_score, sizeof(double) * s.h_score.size(), hipMemcpyDeviceToHost, st));
   L1X_HIP(hipStreamSynchronize(st));
   maxabs.assign(s.nchain, 0.0);

@@ -48,7 +48,7 @@ class RgTiming(C.Structure):
                                           "ms_l1_pred")] + \
                [("n_gram_launches", C.c_int64), ("n_chol_launches", C.c_int64)] + \
                [("ms_wgram", C.c_double), ("ms_irls_solve", C.c_double), ("ms_irls_stream", C.c_double),
-                ("n_wgram", C.c_int64), ("n_irls_rounds", C.c_int64), ("wgram_positions", C.c_int64), ("n_wgram_approx_rounds", C.c_int64)]
+                ("n_wgram", C.c_int64), ("n_irls_rounds", C.c_int64), ("wgram_positions", C.c_int64), ("n_wgram_approx_rounds", C.c_int64), ("n_irls_passes", C.c_int64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

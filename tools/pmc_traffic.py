@@ -33,6 +33,7 @@ COUNT = {}
 GROUPS = {"chol": GROUP, "l1_gram": ("k_l1_gram128", "k_l1_gram64", "k_l1_wty", "k_reduce_slices", "k_sum_folds"),
           "gram_fp4": ("k_gram_fp4_blocks",), "pred": ("k_pk_transpose", "k_beta_split", "k_l0_pred_i8", "k_l0_pred", "k_beta_post",
                                                        "k_l0_stats", "k_l0_scale"),
+          "irls_stream": ("k_bt_eval", "k_bt_score"),
           "wgram": ("k_wgram_mx", "k_wgram_bf16", "k_wsplit", "k_sqrtw", "k_wgram128", "k_wg_reduce", "k_wg_wz", "k_wgram")}
 
 
@@ -51,7 +52,8 @@ def main(fd, wd, nbatch, out, blocks=None, phenos=None):
         grd = sum(v for k, v in f.items() if k.split("<")[0] in ks) * 1024 * 2
         gwr = sum(v for k, v in w.items() if k.split("<")[0] in ks) * 1024
         lead = next((k for k in ks if ("FETCH_SIZE", k) in COUNT), ks[0])      # dispatches of the group's leading kernel in the read pass
-        groups[gname] = {"read_bytes": grd, "write_bytes": gwr, "hbm_bytes": grd + gwr, "lead_kernel": lead, "lead_launches": COUNT.get(("FETCH_SIZE", lead), 0)}
+        groups[gname] = {"read_bytes": grd, "write_bytes": gwr, "hbm_bytes": grd + gwr, "lead_kernel": lead, "lead_launches": COUNT.get(("FETCH_SIZE", lead), 0),
+                         "group_launches": sum(n for (c, k), n in COUNT.items() if c == "FETCH_SIZE" and k.split("<")[0] in ks)}
     res = {"kernel_group": list(GROUP), "level0_batches": nbatch, "build_stamp": stamp, "groups": groups,
            "blocks": int(blocks) if blocks else None, "phenos": int(phenos) if phenos else None,
            "read_bytes_per_batch": rd / nbatch, "write_bytes_per_batch": wr / nbatch,
