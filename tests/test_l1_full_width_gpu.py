@@ -106,8 +106,8 @@ def test_qt_kfold_level1_at_L2560():
 def test_bt_kfold_level1_at_L2560(monkeypatch):
     """Two binary traits (prevalence 0.3 / 0.12, one with missing values), 6,500 samples, five folds, three ridge values: the K-fold logistic
     ridge (Step1_Models.cpp:966-1156) runs its IRLS on weighted Grams of order 2,560 -- `k_wgram128` with every chain's held-out fold as a
-    gap, and its quasi-Newton replacement on the bf16 matrix cores (`k_wgram_bf16`, forced below) -- and the ridge systems on the
-    per-column Cholesky path."""
+    gap, and its quasi-Newton replacement on the 16-bit matrix cores (`k_wgram_mx`, forced below) with the steps on stored Hessians
+    (`k_tri_solve`) -- and the ridge systems on the per-column Cholesky path."""
     # the quasi-Newton Gram (wgram_bf16.hip) is the default from 2e11 flop per chain Gram on (500,000 samples); forced here so that the
     # test covers it at the oracle-friendly sample count
     monkeypatch.setenv("RG_WGRAM_QUASI_MIN", "0")
@@ -130,19 +130,29 @@ def test_bt_kfold_level1_at_L2560(monkeypatch):
     tau = np.stack([orc.tau_from_h(h1, L_FULL, True)] * P)
     cc = chr_cols()
     opt = orc.Step1Options(bed="", pheno_file="", bt=True)
-    eng = engine_with_w(N, X, Y, mask, keep, cv_sizes, W)
-    cs, conv, best, pred = eng.l1_bt(tau, yraw, offset, [nn for (_, _, nn) in cc], niter_max_ridge=opt.niter_max_ridge,
-                                     niter_max_line_search_ridge=opt.niter_max_line_search_ridge, niter_max_line_search=opt.niter_max_line_search)
-    eng.close()
-    for ph in range(P):
-        rcs, betas, ok = orc.ridge_logistic_level_1(W[ph], yraw[:, ph], offset[:, ph], mask[:, ph], cv_sizes, tau[ph], opt)
-        assert ok and conv[ph]
-        scale = np.abs(rcs).max()
-        assert np.abs(cs[ph] - rcs).max() <= 1e-6 * scale     # both sides stop at max|score| < 1e-4
-        rbest = orc.select_tau(rcs, float(mask[:, ph].sum()), True)
-        assert int(best[ph]) == rbest
-        rpred = orc.make_predictions(W[ph], betas, rbest, cv_sizes, cc)
-        assert np.abs(pred[ph] - rpred).max() <= 1e-6 * np.abs(rpred).max()
+    ref = [orc.ridge_logistic_level_1(W[ph], yraw[:, ph], offset[:, ph], mask[:, ph], cv_sizes, tau[ph], opt) for ph in range(P)]
+    # three policies for the stored Hessians (l1x.hip, "Steps on a Hessian that is already there"): the default (a fresh Gram when a reused
+    # step gains less than a factor 5), never refresh unless a step makes the score WORSE (exercises the step-back), and a fresh Gram every round
+    for policy in ({}, {"RG_WGRAM_REUSE_RATIO": "1e9"}, {"RG_WGRAM_REUSE": "0"}):
+        for k, v in policy.items():
+            monkeypatch.setenv(k, v)
+        eng = engine_with_w(N, X, Y, mask, keep, cv_sizes, W)
+        cs, conv, best, pred = eng.l1_bt(tau, yraw, offset, [nn for (_, _, nn) in cc], niter_max_ridge=opt.niter_max_ridge,
+                                         niter_max_line_search_ridge=opt.niter_max_line_search_ridge, niter_max_line_search=opt.niter_max_line_search)
+        tm = eng.timing()
+        eng.close()
+        for k in policy:
+            monkeypatch.delenv(k)
+        assert tm["n_wgram_approx_rounds"] > 0 and (tm["n_irls_rounds"] > tm["n_wgram_approx_rounds"]) == (policy.get("RG_WGRAM_REUSE") != "0")
+        for ph in range(P):
+            rcs, betas, ok = ref[ph]
+            assert ok and conv[ph], policy
+            scale = np.abs(rcs).max()
+            assert np.abs(cs[ph] - rcs).max() <= 1e-6 * scale, policy     # both sides stop at max|score| < 1e-4
+            rbest = orc.select_tau(rcs, float(mask[:, ph].sum()), True)
+            assert int(best[ph]) == rbest
+            rpred = orc.make_predictions(W[ph], betas, rbest, cv_sizes, cc)
+            assert np.abs(pred[ph] - rpred).max() <= 1e-6 * np.abs(rpred).max(), policy
 
 
 def test_cox_level1_at_L2560():
