@@ -869,7 +869,8 @@ __global__ void k_add_diag(double* mats, int64_t msz, int n64, int L, const doub
 // x = (F F^T)^-1 b for the factor F that chol.hip leaves in the lower triangle of a row-major n64 x n64 matrix (order L, the padding past it
 // is not touched); one workgroup per system, the vector in LDS.  Forward substitution column tile by column tile (the diagonal tile's 64 pivots
 // on one wave, then every row below takes its 64-term update), backward substitution the same way up the transposed factor (column sums over
-// the rows below, four row groups reduced through LDS).  26 MB of factor per solve at L = 2,560: 0.2 - 0.3 ms.
+// the rows below, four row groups reduced through LDS).  Each direction reads the 26 MB of the factor (L = 2,560) once; one workgroup is
+// latency-bound on them: about 4 ms for the chains of a round, which run side by side (a tile-row forward substitution measured slower).
 __global__ __launch_bounds__(256) void k_tri_solve(const double* __restrict__ fac, int64_t msz, const int32_t* __restrict__ chainmap, int n64, int L,
                                                    const double* __restrict__ rhs, double* __restrict__ sol) {
   extern __shared__ double tsm[];
@@ -961,7 +962,7 @@ int bt_chord(BtState& s, const std::vector<int32_t>& act) {
 
 // (X^T W X + tau I) x = rhs for the chains in `act` (rhs = X^T W z from the extra row, or the score);
 // solutions land in h_sol [nchain][n64].  *bad is set when a system is not positive definite.
-// approx: H~ from the bf16 pair planes (wgram_bf16.hip) instead of the fp64 Gram -- only with rhs_is_score, where the right-hand side is
+// approx: H~ from the 16-bit operand planes (wgram_bf16.hip) instead of the fp64 Gram -- only with rhs_is_score, where the right-hand side is
 // the exact score and the solution a quasi-Newton step (a fixed point of beta + H~^-1 score(beta) has score = 0 whatever H~ is)
 // keep: the quasi-Newton Gram and its factor are stored per chain (d_G, d_fac).  g_tau != nullptr: NO Gram is formed -- the stored one is
 // shifted from the ridge value it holds (g_tau[chain]) to tauc[chain] and factored again.
@@ -1135,7 +1136,7 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
   L1X_HIP(c.bufs.alloc(&s.d_sys, (size_t)nchain * c.msz));
   L1X_HIP(c.bufs.alloc(&s.d_dinv, rg_chol_ws_doubles((size_t)nchain, c.n64)));
   L1X_HIP(c.bufs.alloc(&s.d_map, (size_t)nchain));
-  // K-fold: the weighted Grams of the IRLS steps as quasi-Newton Hessians on the bf16 matrix cores (wgram_bf16.hip) unless RG_WGRAM_F64=1;
+  // K-fold: the weighted Grams of the IRLS steps as quasi-Newton Hessians on the 16-bit matrix cores (wgram_bf16.hip) unless RG_WGRAM_F64=1;
   // a chain that has not converged after RG_WGRAM_SWITCH steps at one ridge value continues on the fp64 Gram
   // -- where the fp64 Gram costs more than a few milliseconds (RG_WGRAM_QUASI_MIN: flop of one chain Gram from which on the quasi-Newton
   // Gram is used, default 2e11 = 4 ms of the fp64 kernel; 0 = always).  Below that the fp64 Gram is free and the iterates are those of

@@ -320,7 +320,7 @@ int rg_emit_pred(rg_ctx* ctx, hipStream_t st, const double* d_pred, int nchr, in
 struct L1Args;
 int rg_l1_qt_impl(rg_ctx* ctx, int R1, const double* tau, int nchr, const int32_t* cols_per_chr,
                   double* cumsum_out, int32_t* best_out, double* pred_out);
-// wgram_bf16.hip: partial tiles of the quasi-Newton weighted Gram (bf16 pair planes on the matrix cores); returns the K slices written (0 = failed)
+// wgram_bf16.hip: partial tiles of the quasi-Newton weighted Gram (one fp16 operand plane, or bf16 hi + lo planes, on the matrix cores); returns the K slices written (0 = failed)
 int rg_launch_wgram_bf16(rg_ctx* ctx, hipStream_t st, const double* W, int64_t Np, int L, int P, int p, int n64, const double* wv, double* sw, int nchain,
                          const int32_t* d_chainmap, const int32_t* h_chainmap, int nslot, int excl_own, double* part, int64_t out_stride,
                          int max_slices);
