@@ -870,21 +870,22 @@ __global__ void k_add_diag(double* mats, int64_t msz, int n64, int L, const doub
 // is not touched); one workgroup per system, the vector in LDS.  Forward substitution column tile by column tile (the diagonal tile's 64 pivots
 // on one wave, then every row below takes its 64-term update), backward substitution the same way up the transposed factor (column sums over
 // the rows below, four row groups reduced through LDS).  Each direction reads the 26 MB of the factor (L = 2,560) once; one workgroup is
-// latency-bound on them: about 4 ms for the chains of a round, which run side by side (a tile-row forward substitution measured slower).
-__global__ __launch_bounds__(256) void k_tri_solve(const double* __restrict__ fac, int64_t msz, const int32_t* __restrict__ chainmap, int n64, int L,
+// latency-bound on them (5.2 ms with 256 threads; a tile-row forward substitution measured slower), hence the 1,024 threads.
+#define TS_NT 1024      // threads of a triangular solve: one workgroup per system is latency-bound, so it is as wide as a workgroup gets
+__global__ __launch_bounds__(TS_NT) void k_tri_solve(const double* __restrict__ fac, int64_t msz, const int32_t* __restrict__ chainmap, int n64, int L,
                                                    const double* __restrict__ rhs, double* __restrict__ sol) {
   extern __shared__ double tsm[];
   double* y = tsm;                         // [n64]
   double* tile = tsm + n64;                // [64][65]
-  double* red = tile + 64 * 65;            // [4][64]
+  double* red = tile + 64 * 65;            // [TS_NT / 64][64]
   const int tid = threadIdx.x;
   const int chain = chainmap[blockIdx.x];
   const double* A = fac + (int64_t)chain * msz;
-  for (int i = tid; i < n64; i += 256) y[i] = i < L ? rhs[(int64_t)chain * n64 + i] : 0.0;
+  for (int i = tid; i < n64; i += TS_NT) y[i] = i < L ? rhs[(int64_t)chain * n64 + i] : 0.0;
   const int nt = (L + 63) / 64;
   auto stage_tile = [&](int k0) {          // lower triangle of the diagonal tile; identity past the order
     const int nk = L - k0 < 64 ? L - k0 : 64;
-    for (int e = tid; e < 64 * 64; e += 256) {
+    for (int e = tid; e < 64 * 64; e += TS_NT) {
       const int r = e >> 6, c = e & 63;
       tile[r * 65 + c] = (r < nk && c <= r) ? A[(int64_t)(k0 + r) * n64 + k0 + c] : (r == c ? 1.0 : 0.0);
     }
@@ -904,7 +905,7 @@ __global__ __launch_bounds__(256) void k_tri_solve(const double* __restrict__ fa
       y[k0 + tid] = v;
     }
     __syncthreads();
-    for (int i = k0 + 64 + tid; i < L; i += 256) {
+    for (int i = k0 + 64 + tid; i < L; i += TS_NT) {
       const double* row = A + (int64_t)i * n64 + k0;
       double a0 = 0.0, a1 = 0.0;
 #pragma unroll 8
@@ -921,12 +922,14 @@ __global__ __launch_bounds__(256) void k_tri_solve(const double* __restrict__ fa
   for (int k = nt - 1; k >= 0; --k) {
     const int k0 = k * 64;
     double acc = 0.0;
-    for (int i = k0 + 64 + gg; i < L; i += 4) acc = fma(A[(int64_t)i * n64 + k0 + cc], y[i], acc);
+    for (int i = k0 + 64 + gg; i < L; i += TS_NT / 64) acc = fma(A[(int64_t)i * n64 + k0 + cc], y[i], acc);
     red[gg * 64 + cc] = acc;
     stage_tile(k0);
     __syncthreads();
     if (tid < 64) {
-      double v = y[k0 + tid] - ((red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]));
+      double rs = 0.0;
+      for (int g = 0; g < TS_NT / 64; ++g) rs += red[g * 64 + tid];
+      double v = y[k0 + tid] - rs;
       for (int c = 63; c >= 0; --c) {
         const double piv = __shfl(v, c) / tile[c * 65 + c];
         if (tid == c) v = piv;
@@ -936,10 +939,10 @@ __global__ __launch_bounds__(256) void k_tri_solve(const double* __restrict__ fa
     }
     __syncthreads();
   }
-  for (int i = tid; i < n64; i += 256) sol[(int64_t)chain * n64 + i] = i < L ? y[i] : 0.0;
+  for (int i = tid; i < n64; i += TS_NT) sol[(int64_t)chain * n64 + i] = i < L ? y[i] : 0.0;
 }
 
-static size_t tri_solve_lds(int n64) { return sizeof(double) * ((size_t)n64 + 64 * 65 + 256); }
+static size_t tri_solve_lds(int n64) { return sizeof(double) * ((size_t)n64 + 64 * 65 + TS_NT); }
 
 // chord steps of the chains in `act`: solutions of F F^T x = score with each chain's stored factor, into h_sol
 int bt_chord(BtState& s, const std::vector<int32_t>& act) {
@@ -952,7 +955,7 @@ int bt_chord(BtState& s, const std::vector<int32_t>& act) {
   const size_t lds = tri_solve_lds(c.n64);
   if (lds > 48 * 1024) L1X_HIP(hipFuncSetAttribute((const void*)k_tri_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   double* d_x = s.d_sys;      // [nchain][n64] scratch: the systems' workspace is idle during a chord step
-  hipLaunchKernelGGL(k_tri_solve, dim3(na), dim3(256), lds, st, (const double*)s.d_fac, c.msz, (const int32_t*)s.d_map, c.n64, c.L, (const double*)s.d_score, d_x);
+  hipLaunchKernelGGL(k_tri_solve, dim3(na), dim3(TS_NT), lds, st, (const double*)s.d_fac, c.msz, (const int32_t*)s.d_map, c.n64, c.L, (const double*)s.d_score, d_x);
   for (int i = 0; i < na; ++i)
     L1X_HIP(hipMemcpyAsync(s.h_sol.data() + (size_t)act[i] * c.n64, d_x + (int64_t)act[i] * c.n64, sizeof(double) * c.n64, hipMemcpyDeviceToHost, st));
   L1X_HIP(hipStreamSynchronize(st));
