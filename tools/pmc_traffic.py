@@ -21,7 +21,7 @@ def total(d, counter, level0_only=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            name = r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].replace("void ", "").strip()
             tot[name] = tot.get(name, 0.0) + float(r["Counter_Value"])
             COUNT[(counter, name)] = COUNT.get((counter, name), 0) + 1
     return tot

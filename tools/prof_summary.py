@@ -14,7 +14,7 @@ def main(d, out=None, steps=1):
     rows = list(csv.DictReader(open(f[0])))
     agg = {}
     for r in rows:
-        name = r["Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
+        name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].replace("void ", "").strip()
         if not name.startswith(("k_", "__amd", "Cijk")):
             name = "torch/other"
         a = agg.setdefault(name, [0, 0.0])

@@ -12,7 +12,7 @@ def main(d, out=None):
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     # find the index of the last k_gram_fp4_blocks / k_gram_blocks with a full-size grid, take launches up to k_l0_scale
     def nm(r):
-        return r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "").strip()
+        return r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].split("<")[0].replace("void ", "").strip()
     starts = [i for i, r in enumerate(rows) if nm(r) == "k_bed_prep_rows"]
     # choose the first batch of the last step: batches of a step are consecutive k_bed_prep_rows; pick 4th from the end
     i0 = starts[-4] if len(starts) >= 4 else starts[0]
