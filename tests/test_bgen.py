@@ -103,6 +103,39 @@ def test_refusals_and_damage(tmp_path, example_dir):
         assert f.read_dosages([4]).shape == (1, 500)
         with pytest.raises(RgError):
             f.read_dosages([500])
+        # the block form (rg_bgen_read_blocks: own DEFLATE decoder first, zlib as the arbiter) refuses the same block with the same message,
+        # serves its neighbours, and from several caller threads at once every caller sees its own error
+        with pytest.raises(RgError, match="failed to decompress genotype data block for variant: " + o.variants[5]["rsid"]):
+            f.read_blocks([4, 5, 6])
+        good = f.read_blocks([4, 6])
+        assert good.shape == (2, 10 + 3 * 500) and (f.read_blocks([6])[0] == good[1]).all()
+        with pytest.raises(RgError):
+            f.read_blocks([500])
+        import threading
+        seen = {}
+
+        def worker(k):
+            try:
+                seen[k] = f.read_blocks([5] if k % 2 else [4, 6]).shape
+            except RgError as ex:
+                seen[k] = str(ex)
+        th = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert all(seen[k] == (2, 1510) for k in range(0, 8, 2))
+        assert all("failed to decompress" in seen[k] and o.variants[5]["rsid"] in seen[k] for k in range(1, 8, 2))
+    # every block of the three fixture files through both decoders: RG_BGEN_ZLIB=1 is read at the first inflate of a process, so the
+    # comparison is against the dosage rows, which the oracle pins (test_reference_fixture_pairs)
+    for name in ("example.bgen", "example_3chr.bgen"):
+        with BgenFile(os.path.join(example_dir, name), threads=2) as f:
+            idx = np.arange(f.n_variants)
+            blk = f.read_blocks(idx)
+            n = f.n_samples
+            pr = blk[:, 10 + n:].reshape(len(idx), n, 2).astype(np.float64) / 255.0
+            dos = np.where(blk[:, 8:8 + n] & 0x80, -3.0, pr[:, :, 1] + 2.0 * pr[:, :, 0])
+            assert (dos == f.read_dosages(idx)).all()
 
 
 # ---- the host driver's --bgen / --sample handling (runs before any device is touched) ---------------------------------------
