@@ -73,6 +73,8 @@ class Step1Options:
     min_case_count: int = 10
     cc12: bool = False
     niter_max: int = 50              # logistic null (Regenie.hpp niter_max)
+    t2e_event_l0: bool = False      # --t2e-event-l0: which level-0 FILE --lowmem / --run-l1 read for a time-to-event trait (Step1_Models.cpp:2259-2261); no effect in memory
+    t2e_l1_pi6: bool = False        # --t2e-l1-pi6: level-1 penalties from the heritability grid, L (1 - h) / h x 6 / pi^2 (Step1_Models.cpp:2106-2110)
     niter_max_ridge: int = 100
     niter_max_line_search: int = 25
     niter_max_line_search_ridge: int = 100

@@ -18,7 +18,8 @@ What differs from the quantitative-trait run, with the reference lines each func
     deviance of each fit on the held-out fold is summed and the smallest total wins (ridge_cox_level_1, Step1_Models.cpp:2228-2305;
     cox_ridge_path, cox_ridge.cpp:204-302; survival_data.cpp);
   * predictions: out-of-fold W beta per chromosome, LOCO files as for the other traits (make_predictions_cox, Data.cpp:1714-1755).
-Not restated: --t2e-event-l0, --t2e-l1-pi6, the Newton fall-back of the null model (cox_firth.cpp) when the coordinate descent does not
+Restated too (round 4, pinned against regenie's runs with them): --t2e-l1-pi6, and --t2e-event-l0 as what it is for a run that keeps its
+level-0 predictors in memory: nothing (it only selects the level-0 FILE of the --lowmem / --run-l1 modes).  Not restated: the Newton fall-back of the null model (cox_firth.cpp) when the coordinate descent does not
 converge (the oracle raises instead)."""
 import math
 import os
@@ -275,7 +276,9 @@ def read_t2e(opt: s1.Step1Options, t2e_map: Dict[str, str], fam_ids: List[str]) 
         tot = Y[mask[:, j], j].sum() / mask[:, j].sum()
         Y[:, j] = np.where(mask[:, j], Y[:, j], tot)
     Y = Y * mask
-    pheno_pass = np.array([n in t2e_map for n in names])              # Pheno.cpp:1957-1965
+    # Pheno.cpp:1957-1965: the event columns do not pass unless --t2e-event-l0 keeps them for level 0 (their residuals are then scaled
+    # like any other column's; ridge_cox_level_1 drops them afterwards, Step1_Models.cpp:2255)
+    pheno_pass = np.array([(n in t2e_map) or bool(opt.t2e_event_l0) for n in names])
     return s1.Prepared(ids=prep.ids, n_file=prep.n_file, ind_ignore=prep.ind_ignore, ind_in_analysis=ain, pheno_names=names, Y=Y, Y_raw=Yraw,
                        mask=mask, X=X, Neff=Neff, scale_Y=np.ones(P), ncov=X.shape[1], n_analyzed=int(ain.sum()), pheno_pass=pheno_pass)
 
@@ -317,7 +320,7 @@ def prep_run_t2e(prep: s1.Prepared, t2e_map: Dict[str, str], opt: s1.Step1Option
 # level 1
 # --------------------------------------------------------------------------
 def ridge_cox_level_1(W: np.ndarray, time: np.ndarray, event: np.ndarray, offset: np.ndarray, mask: np.ndarray, cv_sizes: np.ndarray,
-                      opt: s1.Step1Options, n_ridge_l1: int = 5):
+                      opt: s1.Step1Options, n_ridge_l1: int = 5, tau_in: np.ndarray = None):
     """ridge_cox_level_1 for one trait (Step1_Models.cpp:2241-2298).  Returns (tau, summed held-out deviances, per-fold beta matrices,
     converged)."""
     N = W.shape[0]
@@ -327,6 +330,8 @@ def ridge_cox_level_1(W: np.ndarray, time: np.ndarray, event: np.ndarray, offset
     lam_max = np.abs(W.T @ f0.gradient).max() / 1e-3                 # getCoxLambdaMax (:446-450)
     idx = np.linspace(0, n_ridge_l1 - 1, n_ridge_l1)
     tau = np.exp(idx / (n_ridge_l1 - 1) * math.log(1e-6) + math.log(lam_max))      # check_l0 (:2105-2113)
+    if tau_in is not None:                                           # --t2e-l1-pi6: the caller's penalties (:2106-2110)
+        tau = np.asarray(tau_in, np.float64)
     starts = np.concatenate([[0], np.cumsum(cv_sizes)])
     fold_id = np.zeros(N, np.int64)
     for i in range(cv_sizes.size):
@@ -382,9 +387,18 @@ def run_step1_t2e(opt: s1.Step1Options, t2e_map: Dict[str, str], write_files: bo
     out = {"prep": prep, "W": W, "cv_sizes": cv_sizes, "traits": {}, "log": [], "pred_list": []}
     for tn in sorted(t2e_map):                                       # std::map order
         ti, ei = prep.pheno_names.index(tn), prep.pheno_names.index(t2e_map[tn])
-        tau, dev, betas, ok = ridge_cox_level_1(W[ti], prep.Y_raw[:, ti], prep.Y_raw[:, ei], prep.offset[:, ti], prep.mask[:, ti], cv_sizes, opt,
-                                                opt.n_ridge_l1)
-        out["traits"][tn] = {"index": ti, "tau": tau, "deviance": dev, "betas": betas, "converged": ok}
+        # --t2e-event-l0 sets l0_idx = the event column (Step1_Models.cpp:2259), but l0_idx is only the index of the level-0 FILE that
+        # read_l0 loads in the --lowmem / --run-l1 modes (:2260-2261); the in-memory run fits on test_mat_conc[ph_eff] with ph_eff = the
+        # time column whatever the switch says (:2258, :2269-2282) -- regenie's own outputs with and without it are byte-identical here
+        # (tests/golden/ref_outputs/t2e_kfold_synth_event_l0).  This restatement is the in-memory run.
+        li = ti
+        tau_in = None
+        if opt.t2e_l1_pi6:                                           # check_l0 (:2106-2110): L (1 - h) / h x 6 / pi^2 over the level-1 grid of h
+            h1 = np.asarray(opt.setl1, np.float64) if getattr(opt, "setl1", None) is not None else s1.set_ridge_params(opt.n_ridge_l1)
+            tau_in = L * (1 - h1) / h1 * 6.0 / (math.pi * math.pi)
+        tau, dev, betas, ok = ridge_cox_level_1(W[li], prep.Y_raw[:, ti], prep.Y_raw[:, ei], prep.offset[:, ti], prep.mask[:, ti], cv_sizes, opt,
+                                                opt.n_ridge_l1, tau_in)
+        out["traits"][tn] = {"index": ti, "l0_index": li, "tau": tau, "deviance": dev, "betas": betas, "converged": ok}
     for ti, tn in enumerate(prep.pheno_names):                       # Data::output (Data.cpp:966-1110): by column of the run
         if tn not in t2e_map:
             continue
@@ -398,7 +412,7 @@ def run_step1_t2e(opt: s1.Step1Options, t2e_map: Dict[str, str], write_files: bo
         for j in range(opt.n_ridge_l1):
             out["log"].append(" %5s : Deviance = %s%s" % (s1.cpp_double(tr["tau"][j]), s1.cpp_double(tr["deviance"][j]),
                                                          "<- min value" if j == best else ""))
-        pred = s1.make_predictions(W[ti], tr["betas"], best, cv_sizes, chrcols)        # make_predictions_cox (Data.cpp:1714-1755)
+        pred = s1.make_predictions(W[tr["l0_index"]], tr["betas"], best, cv_sizes, chrcols)        # make_predictions_cox (Data.cpp:1714-1755)
         tr["loco"] = s1.loco_from_predictions(pred, chrcols, opt.nchrom)
         if write_files:
             fn = "%s_%d.loco" % (opt.out, ti + 1)

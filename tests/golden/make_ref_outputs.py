@@ -84,6 +84,11 @@ CASES = {
                         dict(M=300, N=1200, chroms=[1] * 120 + [2] * 100 + [7] * 80, P=2, seed=31, binary=False, missing_pheno=0.0, miss_rate=0.01,
                              t2e=dict(ntraits=2, missing=0.03))),
 }
+# the same data with the two undocumented level-1 switches of --t2e (Regenie.cpp:366-367): --t2e-event-l0 (selects the event column's level-0
+# FILE in the --lowmem / --run-l1 modes; this in-memory run comes out byte-identical to the plain one) and --t2e-l1-pi6 (penalties from the
+# heritability grid).  Oracle pins only (the driver refuses both switches with a message).
+for _k, _x in (("t2e_kfold_synth_event_l0", "--t2e-event-l0"), ("t2e_kfold_synth_pi6", "--t2e-l1-pi6")):
+    CASES[_k] = (CASES["t2e_kfold_synth"][0] + [_x], CASES["t2e_kfold_synth"][1])
 
 
 def synth(prefix, spec):

@@ -185,13 +185,17 @@ def synth_t2e_case(tmp_path, name="t2e_kfold_synth"):
 T2E_RE = re.compile(r"^\s*(\S+)\s*: Deviance = ([^<]+)(<- min value)?")
 
 
-def test_t2e_cox_ridge_synthetic(tmp_path):
+@pytest.mark.parametrize("case,extra", [("t2e_kfold_synth", {}), ("t2e_kfold_synth_event_l0", {"t2e_event_l0": True}),
+                                        ("t2e_kfold_synth_pi6", {"t2e_l1_pi6": True})])
+def test_t2e_cox_ridge_synthetic(tmp_path, case, extra):
     """`--step 1 --t2e` (oracle/regenie_step1_t2e.py: null Cox model, Cox ridge paths per fold by cyclic coordinate descent, held-out
     deviances, out-of-fold predictions) against regenie's own run: two traits with tied event times and missing pairs; the penalties
-    and deviances of the log to its six digits, the same penalty selected, the LOCO files at the text's resolution."""
+    and deviances of the log to its six digits, the same penalty selected, the LOCO files at the text's resolution.  Also with the
+    reference's two undocumented level-1 switches, `--t2e-event-l0` (level-0 predictors of the event column) and `--t2e-l1-pi6`
+    (penalties from the heritability grid)."""
     from oracle import regenie_step1_t2e as t2e
-    meta, pre = synth_t2e_case(tmp_path)
-    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".t2e", covar_file=pre + ".covar", bsize=100)
+    meta, pre = synth_t2e_case(tmp_path, case)
+    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".t2e", covar_file=pre + ".covar", bsize=100, **extra)
     res = t2e.run_step1_t2e(opt, {"T1": "E1", "T2": "E2"})
     ref_lines = [ln for ln in meta["table"]]
     got_lines = [ln.rstrip() for ln in res["log"]]
@@ -208,11 +212,11 @@ def test_t2e_cox_ridge_synthetic(tmp_path):
     order = [i for i in sorted(range(len(prep.ids)), key=lambda i: prep.ids[i]) if prep.ind_in_analysis[i]]
     for tn in ("T1", "T2"):
         ti = prep.pheno_names.index(tn)
-        ids, ref = read_loco_gz(os.path.join(REF_OUT, "t2e_kfold_synth", "out_%d.loco.gz" % (ti + 1)))
+        ids, ref = read_loco_gz(os.path.join(REF_OUT, case, "out_%d.loco.gz" % (ti + 1)))
         got = res["traits"][tn]["loco"][order, :].T.copy()
         got[:, ~prep.mask[order, ti]] = np.nan
         assert ids == [prep.ids[i] for i in order]
-        assert_text_equal(got, ref, "t2e_kfold_synth %s" % tn)
+        assert_text_equal(got, ref, "%s %s" % (case, tn))
 
 
 def test_t2e_cox_ridge_example_with_options():
