@@ -261,6 +261,8 @@ typedef struct rg_cox_options {
   int32_t niter_max_line_search_ridge; /* 100   params.niter_max_line_search_ridge */
   double numtol_cox;                   /* 2.5e-4 params.numtol_cox */
   double l1_ridge_tol;                 /* 1e-4  params.l1_ridge_tol */
+  const double* tau;                   /* NULL: the path lambda_max * 1e-6^(j/(R1-1)) from the score at beta = 0 (check_l0, Step1_Models.cpp:2111-2113);
+                                        * else n_ridge_l1 penalties of the caller's, e.g. --t2e-l1-pi6: L (1 - h_j) / h_j * 6 / pi^2 (:2106-2110) */
 } rg_cox_options;
 int rg_l1_cox(rg_ctx* ctx, int32_t pheno, int32_t n_ridge_l1, const double* time, const double* event, const double* offset,
               const rg_cox_options* opt, int32_t nchr, const int32_t* cols_per_chr, double* tau_out, double* deviance_out,

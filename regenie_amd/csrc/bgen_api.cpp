@@ -47,6 +47,7 @@ int rg_bgen_open(rg_bgen** out, const char* path) {
   rg_bgen* h = new (std::nothrow) rg_bgen();
   if (!h) return RG_BGEN_ERR_ARG;
   *out = h;
+  if (tl_err_handle == h) tl_err_handle = nullptr;   // a new handle at a closed handle's address must not inherit its message
   if (!path) return fail(h, RG_BGEN_ERR_ARG, "rg_bgen_open: null path");
   try {
     h->rd.open(path);
@@ -58,11 +59,20 @@ int rg_bgen_open(rg_bgen** out, const char* path) {
   return RG_BGEN_OK;
 }
 
-void rg_bgen_close(rg_bgen* h) { delete h; }
+void rg_bgen_close(rg_bgen* h) {
+  if (tl_err_handle == h) tl_err_handle = nullptr;
+  delete h;
+}
 const char* rg_bgen_last_error(const rg_bgen* h) {
   if (!h) return "null bgen handle";
   if (tl_err_handle == h) return tl_err.c_str();
-  return h->err.c_str();
+  // a failure raised on another thread: copy it under the lock (that thread may be assigning h->err) into this thread's buffer
+  thread_local std::string other;
+  {
+    std::lock_guard<std::mutex> lk(const_cast<rg_bgen*>(h)->err_mu);
+    other = h->err;
+  }
+  return other.c_str();
 }
 
 int rg_bgen_info(const rg_bgen* h, int64_t* n_samples, int64_t* n_variants, int32_t* compression, int32_t* has_sample_ids) {

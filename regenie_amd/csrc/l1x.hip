@@ -942,6 +942,15 @@ __global__ __launch_bounds__(TS_NT) void k_tri_solve(const double* __restrict__ 
   for (int i = tid; i < n64; i += TS_NT) sol[(int64_t)chain * n64 + i] = i < L ? y[i] : 0.0;
 }
 
+// what a workgroup may ask for in dynamic LDS on this device (160 KB on gfx950; asked once)
+static size_t lds_optin_bytes() {
+  static const size_t v = []() -> size_t {
+    int dev = 0, b = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&b, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess || b <= 0) return 64 * 1024;
+    return (size_t)b;
+  }();
+  return v;
+}
 static size_t tri_solve_lds(int n64) { return sizeof(double) * ((size_t)n64 + 64 * 65 + TS_NT); }
 
 // chord steps of the chains in `act`: solutions of F F^T x = score with each chain's stored factor, into h_sol
@@ -956,6 +965,7 @@ int bt_chord(BtState& s, const std::vector<int32_t>& act) {
   if (lds > 48 * 1024) L1X_HIP(hipFuncSetAttribute((const void*)k_tri_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   double* d_x = s.d_sys;      // [nchain][n64] scratch: the systems' workspace is idle during a chord step
   hipLaunchKernelGGL(k_tri_solve, dim3(na), dim3(TS_NT), lds, st, (const double*)s.d_fac, c.msz, (const int32_t*)s.d_map, c.n64, c.L, (const double*)s.d_score, d_x);
+  L1X_HIP(hipGetLastError());   // 62 KB of dynamic LDS at L = 2,560: a refused launch must not pass scratch off as the chord step
   for (int i = 0; i < na; ++i)
     L1X_HIP(hipMemcpyAsync(s.h_sol.data() + (size_t)act[i] * c.n64, d_x + (int64_t)act[i] * c.n64, sizeof(double) * c.n64, hipMemcpyDeviceToHost, st));
   L1X_HIP(hipStreamSynchronize(st));
@@ -988,6 +998,7 @@ int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<doub
     }
     L1X_HIP(hipMemcpyAsync(s.d_delta, delta.data(), sizeof(double) * na, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_add_diag, dim3((c.L + 255) / 256, na), dim3(256), 0, st, s.d_sys, c.msz, c.n64, c.L, (const double*)s.d_delta);
+    L1X_HIP(hipGetLastError());
   } else if (approx && rhs_is_score && s.d_sw) {
     L1Lap lap(ctx, st, &ctx->tm.ms_wgram);
     const int MAXSL = 16;
@@ -996,7 +1007,7 @@ int bt_solve(BtState& s, const std::vector<int32_t>& act, const std::vector<doub
     L1X_HIP(hipStreamSynchronize(st));      // `act` (host) must have reached d_map before the table is built from it
     const int ns = rg_launch_wgram_bf16(ctx, st, c.Wv, c.Np, c.L, c.Pv, s.p, c.n64, s.a.wv, s.d_sw, s.nchain, s.d_map, act.data(), na, s.a.kfold,
                                         d_part, c.msz, MAXSL);
-    if (ns <= 0) return RG_ERR_HIP;
+    if (ns <= 0) { ctx->err = "rg_l1_bt: the quasi-Newton Gram (k_wgram_mx) could not be launched"; return RG_ERR_HIP; }
     Wg128 g2{g, ns, na, nullptr, d_part};
     hipLaunchKernelGGL(k_wg_reduce, dim3(c.T * (c.T + 1) / 2, na), dim3(256), 0, st, g2, c.T);
     L1X_HIP(hipMemset2DAsync(s.d_sys + (int64_t)c.n64 * c.n64, sizeof(double) * c.msz, 0, sizeof(double) * CT * c.n64, na, st));
@@ -1151,7 +1162,7 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
   const double gram_flop = (double)(ctx->seg.pos_start[ctx->seg.nseg - 1] + ctx->seg.plen[ctx->seg.nseg - 1]) * (loocv ? 1.0 : (double)(K - 1) / K) * L * (L + 1.0);
   if (!loocv && !wg_f64 && gram_flop >= wg_min) L1X_HIP(c.bufs.alloc(&s.d_sw, (size_t)nchain * Np));
   // steps on a stored Hessian (chord / refactored, see k_tri_solve): on with the quasi-Newton Gram unless RG_WGRAM_REUSE=0
-  const bool reuse = s.d_sw && !(getenv("RG_WGRAM_REUSE") && atoi(getenv("RG_WGRAM_REUSE")) == 0) && tri_solve_lds(c.n64) <= 150 * 1024;
+  const bool reuse = s.d_sw && !(getenv("RG_WGRAM_REUSE") && atoi(getenv("RG_WGRAM_REUSE")) == 0) && tri_solve_lds(c.n64) <= lds_optin_bytes();
   const double reuse_ratio = getenv("RG_WGRAM_REUSE_RATIO") ? atof(getenv("RG_WGRAM_REUSE_RATIO")) : 0.2;
   const double reuse_tol = getenv("RG_WGRAM_REUSE_TOL") ? atof(getenv("RG_WGRAM_REUSE_TOL")) : 1e-6;
   if (reuse) {
@@ -1642,7 +1653,7 @@ int rg_l1_cox_impl(rg_ctx* ctx, int pheno, int R1, const double* time, const dou
   if (ctx->loocv) { ctx->err = "rg_l1_cox: time-to-event traits use K-fold cross-validation (Regenie.cpp:1199-1201)"; return RG_ERR_STATE; }
   rg_cox_options o;
   o.niter_max = 50; o.niter_max_line_search = 25; o.niter_max_ridge = 100; o.niter_max_line_search_ridge = 100;
-  o.numtol_cox = 2.5e-4; o.l1_ridge_tol = 1e-4;
+  o.numtol_cox = 2.5e-4; o.l1_ridge_tol = 1e-4; o.tau = nullptr;
   if (opt) o = *opt;
   L1Common c;
   int rc = l1_common_init(ctx, c, nchr, cols_per_chr, "rg_l1_cox");
@@ -1701,6 +1712,11 @@ int rg_l1_cox_impl(rg_ctx* ctx, int pheno, int R1, const double* time, const dou
   for (int k = 0; k < L; ++k) gmax = std::max(gmax, std::fabs(xtg[k]));
   const double lam_max = gmax / 1e-3;
   for (int j = 0; j < R1; ++j) tau[j] = std::exp((double)j / (R1 - 1) * std::log(1e-6) + std::log(lam_max));
+  if (o.tau)   // --t2e-l1-pi6: the caller's penalties replace the path from lambda_max (check_l0 :2106-2110)
+    for (int j = 0; j < R1; ++j) {
+      if (!(o.tau[j] > 0)) { ctx->err = "rg_l1_cox: the penalties given in rg_cox_options.tau must be positive"; return RG_ERR_ARG; }
+      tau[j] = o.tau[j];
+    }
   for (int j = 0; j < R1; ++j) { tau_out[j] = tau[j]; deviance_out[j] = 0.0; }
   *converged_out = 0; *best_out = 0;
 

@@ -307,5 +307,6 @@ int rg_launch_wgram_bf16(rg_ctx* ctx, hipStream_t st, const double* W, int64_t N
   WbArgs g{V, v_row_bytes, v_slot_bytes, L, n64, nslot, nslice, d_chainmap, excl_own, d_items, (int)items.size(), part, out_stride};
   if (F16) hipLaunchKernelGGL(k_wgram_mx<true>, dim3((unsigned)(((items.size() + 7) / 8) * 8)), dim3(1024), 0, st, g, seg);
   else hipLaunchKernelGGL(k_wgram_mx<false>, dim3((unsigned)(((items.size() + 7) / 8) * 8)), dim3(1024), 0, st, g, seg);
+  if (hipGetLastError() != hipSuccess) return 0;   // the caller reports "0 slices" as a failure of the Gram
   return nslice;
 }

@@ -39,7 +39,8 @@ class RgBtOptions(C.Structure):
 
 class RgCoxOptions(C.Structure):
     _fields_ = [("niter_max", C.c_int32), ("niter_max_line_search", C.c_int32), ("niter_max_ridge", C.c_int32),
-                ("niter_max_line_search_ridge", C.c_int32), ("numtol_cox", C.c_double), ("l1_ridge_tol", C.c_double)]
+                ("niter_max_line_search_ridge", C.c_int32), ("numtol_cox", C.c_double), ("l1_ridge_tol", C.c_double),
+                ("tau", C.c_void_p)]
 
 
 class RgTiming(C.Structure):
@@ -383,15 +384,19 @@ class Step1Engine:
         return cs, conv.astype(bool), best, [pred[p].T.copy() for p in range(P)]
 
     def l1_cox(self, pheno: int, time: np.ndarray, event: np.ndarray, offset: np.ndarray, cols_per_chr: Sequence[int], n_ridge_l1: int = 5,
-               niter_max_ridge: int = 100, niter_max_line_search_ridge: int = 100, l1_ridge_tol: float = 1e-4):
-        """Cox ridge level 1 of one time-to-event trait (--t2e; K-fold).  Returns (tau [R1], deviance [R1], converged, best, pred [N,nchr])."""
+               niter_max_ridge: int = 100, niter_max_line_search_ridge: int = 100, l1_ridge_tol: float = 1e-4, tau_in: Optional[np.ndarray] = None):
+        """Cox ridge level 1 of one time-to-event trait (--t2e; K-fold).  Returns (tau [R1], deviance [R1], converged, best, pred [N,nchr]).
+        tau_in: the caller's penalties (--t2e-l1-pi6) instead of the path from the score at beta = 0."""
         time = np.ascontiguousarray(time, dtype=np.float64)
         event = np.ascontiguousarray(event, dtype=np.float64)
         offset = np.ascontiguousarray(offset, dtype=np.float64)
         assert time.shape == event.shape == offset.shape == (self.N,)
         cpc = np.ascontiguousarray(cols_per_chr, dtype=np.int32)
         nchr = cpc.size
-        o = RgCoxOptions(50, 25, niter_max_ridge, niter_max_line_search_ridge, 2.5e-4, l1_ridge_tol)
+        if tau_in is not None:
+            tau_in = np.ascontiguousarray(tau_in, dtype=np.float64)
+            assert tau_in.shape == (n_ridge_l1,)
+        o = RgCoxOptions(50, 25, niter_max_ridge, niter_max_line_search_ridge, 2.5e-4, l1_ridge_tol, tau_in.ctypes.data if tau_in is not None else None)
         tau = np.zeros(n_ridge_l1)
         dev = np.zeros(n_ridge_l1)
         conv = C.c_int32(0)

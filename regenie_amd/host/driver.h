@@ -81,6 +81,11 @@ struct Params {
   bool bt = false, ct = false, loocv = false, strict = false, ref_first = false, use_rel_path = false,
        print_prs = false, force_step1 = false, lowmem = false, force_qt = false, cc12 = false, gz = false;
   bool t2e = false;                        // --t2e: time-to-event traits (step 1: Cox ridge at level 1)
+  bool t2e_event_l0 = false;               // --t2e-event-l0: which level-0 FILE a --lowmem / --run-l1 run of the reference reads for a time-to-event trait
+                                           // (l0_idx, Step1_Models.cpp:2259-2261); level 1 itself fits on the time column's predictors either way (:2258,
+                                           // :2269-2282) and this driver keeps them in HBM, so the switch is accepted and changes nothing -- regenie's own
+                                           // in-memory outputs with and without it are byte-identical (tests/golden/ref_outputs/t2e_kfold_synth_event_l0)
+  bool t2e_l1_pi6 = false;                 // --t2e-l1-pi6: level-1 penalties L (1 - h) / h * 6 / pi^2 from the heritability grid (check_l0, :2106-2110)
   std::vector<std::string> event_cols;     // --eventColList, matching --phenoColList (the time columns) in order
   int min_case_count = 10, niter_max = 50, niter_max_line_search = 25, niter_max_ridge = 100;
   // level-0 job split (Data.cpp:232-309, :818-908)

@@ -269,7 +269,8 @@ Params parse_args(int argc, char** argv) {
     else if (a == "--phenoCol" || a == "--phenoColList") { if (a == "--phenoCol") saw_pheno_col = true; else saw_pheno_collist = true; list(p.pheno_cols, need(i)); }
     else if (a == "--eventColList") list(p.event_cols, need(i));
     else if (a == "--t2e") { p.t2e = true; p.bt = p.ct = false; }
-    else if (a == "--t2e-event-l0" || a == "--t2e-l1-pi6") usage_error("option '" + a + "' is not built (the level-0 response of a time-to-event trait is its time column, the penalties come from the score at beta = 0).");
+    else if (a == "--t2e-event-l0") p.t2e_event_l0 = true;   // Regenie.cpp:366, :586
+    else if (a == "--t2e-l1-pi6") p.t2e_l1_pi6 = true;       // Regenie.cpp:367, :587
     else if (a == "--covarCol" || a == "--covarColList") list(p.covar_cols, need(i));
     else if (a == "--catCovarList") list(p.cat_covar, need(i));
     else if (a == "--maxCatLevels") p.max_cat_levels = atoi(need(i).c_str());

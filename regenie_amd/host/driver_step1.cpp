@@ -523,7 +523,7 @@ int run(int argc, char** argv) {
   std::vector<double> tau((size_t)P * R1);
   for (int q = 0; q < P; ++q)
     for (int j = 0; j < R1; ++j)   // check_l0, Step1_Models.cpp:2115-2117
-      tau[(size_t)q * R1 + j] = (double)L * (1 - h1[j]) / h1[j] * (p.bt ? 3.0 / (M_PI * M_PI) : 1.0);
+      tau[(size_t)q * R1 + j] = (double)L * (1 - h1[j]) / h1[j] * (p.bt ? 3.0 / (M_PI * M_PI) : p.t2e && p.t2e_l1_pi6 ? 6.0 / (M_PI * M_PI) : 1.0);
   std::vector<double> ct_rate(P, 0.0);
   if (p.ct)  // Step1_Models.cpp:2101-2104: tau_j = L / log(1 + h_j / (rate (1 - h_j))); rate sums the raw column as it is
     for (int q = 0; q < P; ++q) {
@@ -684,6 +684,7 @@ int run(int argc, char** argv) {
           rg_cox_options co;
           co.niter_max = p.niter_max; co.niter_max_line_search = p.niter_max_line_search; co.niter_max_ridge = p.niter_max_ridge;
           co.niter_max_line_search_ridge = 100; co.numtol_cox = 2.5e-4; co.l1_ridge_tol = 1e-4;
+          co.tau = p.t2e_l1_pi6 ? tau.data() + (size_t)q * R1 : nullptr;
           if (!r.pheno_pass[q]) { converged[q] = 0; best[q] = 0; }
           else check(cx, rg_l1_cox(cx, q, R1, r.Yraw.data() + (size_t)q * N, r.Yevent.data() + (size_t)q * N, r.offset.data() + (size_t)q * N, &co,
                                    nchr, cols_per_chr.data(), tau.data() + (size_t)q * R1, cq + 5 * R1, &converged[q], &best[q], pq));
@@ -703,6 +704,8 @@ int run(int argc, char** argv) {
             check(cx, rg_l1_qt(cx, R1, tq, nchr, cols_per_chr.data(), cq, &best[q], pq));
         }
         const int bq = best[q], cv = converged[q];
+        // at most two writers in flight: each holds its phenotype's text (two copies of ~115 MB at 500,000 samples) and a formatting pool
+        if (q >= 2) writers[q - 2].wait();
         writers.push_back(std::async(std::launch::async, [&, q, cq, bq, cv, pq]() { emit_pheno(q, cq, bq, cv, pq); }));
       }
     } catch (...) { err = std::current_exception(); }
@@ -720,7 +723,9 @@ int run(int argc, char** argv) {
       rg_cox_options co;
       co.niter_max = p.niter_max; co.niter_max_line_search = p.niter_max_line_search; co.niter_max_ridge = p.niter_max_ridge;
       co.niter_max_line_search_ridge = 100; co.numtol_cox = 2.5e-4; co.l1_ridge_tol = 1e-4;
+      std::vector<double> tau_in(tau);   // --t2e-l1-pi6: the grid of the caller's (the call writes the penalties it used back into tau)
       for (int q = 0; q < nq; ++q) {
+        co.tau = p.t2e_l1_pi6 ? tau_in.data() + (size_t)(q0 + q) * R1 : nullptr;
         double* cq = cumsum.data() + (size_t)q * NCS * R1;
         std::fill(cq, cq + (size_t)NCS * R1, 0.0);
         if (!r.pheno_pass[q0 + q]) { converged[q] = 0; best[q] = 0; continue; }   // no offset to fit against: skipped like the other trait modes

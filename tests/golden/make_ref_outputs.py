@@ -86,11 +86,10 @@ CASES = {
 }
 # the same data with the two undocumented level-1 switches of --t2e (Regenie.cpp:366-367): --t2e-event-l0 (selects the event column's level-0
 # FILE in the --lowmem / --run-l1 modes; this in-memory run comes out byte-identical to the plain one) and --t2e-l1-pi6 (penalties from the
-# heritability grid).  Oracle pins only (the driver refuses both switches with a message).
-# They live in a dictionary of their own: tests/test_reference_gpu.py runs the DRIVER on every entry of CASES.
-ORACLE_CASES = {}
+# heritability grid).  Round 5: the driver serves both, so they are entries of CASES (tests/test_reference_gpu.py runs the DRIVER on each).
+ORACLE_CASES = {}   # fixtures only the oracle is held to (none since round 5: the driver serves both switches)
 for _k, _x in (("t2e_kfold_synth_event_l0", "--t2e-event-l0"), ("t2e_kfold_synth_pi6", "--t2e-l1-pi6")):
-    ORACLE_CASES[_k] = (CASES["t2e_kfold_synth"][0] + [_x], CASES["t2e_kfold_synth"][1])
+    CASES[_k] = (CASES["t2e_kfold_synth"][0] + [_x], CASES["t2e_kfold_synth"][1])
 
 
 def synth(prefix, spec):
