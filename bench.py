@@ -40,7 +40,9 @@ PEAK = {"fp4_mfma_TOPS": 10000.0,    # MX FP4 dense (MI355X_MICROARCH.md: ~10 PF
         "hbm_GBs": 8000.0}
 
 
-def snps_per_chrom(M):
+def snps_per_chrom(M, one_chrom=False):
+    if one_chrom:
+        return [M]
     w = np.array(CHR_MB, float)
     n = np.floor(M * w / w.sum()).astype(int)
     n[0] += M - n.sum()
@@ -79,6 +81,12 @@ def main():
     ap.add_argument("--bt", action="store_true", help="binary traits (BASELINE configs[3]'s kind): liability-threshold phenotypes, level 1 = logistic ridge (rg_l1_bt)")
     ap.add_argument("--t2e", action="store_true", help="time-to-event traits (--t2e): exponential event times whose hazard carries the polygenic signal, independent censoring; "
                     "level 1 = Cox ridge (rg_l1_cox), one call per trait; the offset of the null Cox model is taken as zero")
+    ap.add_argument("--loocv", action="store_true", help="leave-one-out cross-validation at both levels (regenie --loocv: ridge_level_0_loocv, ridge_level_1_loocv / "
+                    "the LOO branch of the logistic ridge) instead of 5 folds")
+    ap.add_argument("--prev", default=None, help="--bt: comma-separated case prevalences of the traits (default: 5 %% ... 30 %% evenly spaced, SURVEY 8(d))")
+    ap.add_argument("--oracle-trait", type=int, default=-1, help="--bt --oracle-check: the trait whose first fold chain the numpy oracle refits at full size "
+                    "(default: the one with the lowest prevalence)")
+    ap.add_argument("--one-chrom", action="store_true", help="all SNPs on chromosome 1 (full blocks only: per-block timings of a few blocks)")
     ap.add_argument("--l0-only", action="store_true", help="time level 0 alone (a GPU's share of a run whose W does not fit one device: 50 phenotypes at 500,000 samples)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-blocks", type=int, default=4)
@@ -133,7 +141,7 @@ def main():
     N, P, bsize = args.samples, args.phenos, args.bsize
     assert N % 4 == 0
     M = args.snps * world
-    spc = snps_per_chrom(M)
+    spc = snps_per_chrom(M, args.one_chrom)
     blocks = hp.chrom_blocks(spc, bsize)
     B = len(blocks)
     R0 = R1 = 5
@@ -164,6 +172,9 @@ def main():
     bt_offset = None
     if args.bt:     # cases = liability above its (1 - prevalence) quantile, prevalence 5 - 30 %; the null logistic model on the
         prev = np.linspace(0.05, 0.3, P)          # covariates gives the offset of the level-1 logistic ridge (fit_null_logistic)
+        if args.prev:
+            prev = np.array([float(v) for v in args.prev.split(",")])
+            assert prev.size == P, "--prev needs one value per trait"
         Yraw = np.column_stack([(Yraw[:, q] > np.quantile(Yraw[:, q], 1 - prev[q])).astype(np.float64) for q in range(P)])
         bt_offset = np.zeros((N, P))
         for q in range(P):
@@ -185,7 +196,7 @@ def main():
         Yraw = np.minimum(t_ev, t_c)
     Y, _ = hp.residualize_pheno(Yraw - Yraw.mean(axis=0), X, mask, neff)
     ain = np.ones(N, bool)
-    cv_sizes = hp.set_folds(ain, 5)
+    cv_sizes = None if args.loocv else hp.set_folds(ain, 5)
     lam = M * (1 - hp.set_ridge_params(R0)) / hp.set_ridge_params(R0)
     L = B * R0
     h1 = hp.set_ridge_params(R1)
@@ -259,7 +270,11 @@ def main():
         if rank == 0 or (world > 1 and not solo):           # N>1: level 1 is shared among the ranks
             t_l1 = time.perf_counter()
             if args.bt:
-                cs, conv, best, pred = eng.l1_bt(tau, Yraw, bt_offset, cols_per_chr)
+                if args.oracle_check and not args.loocv:     # the fold models' coefficients come back too (rg_bt_options.beta_out): what the oracle leg compares
+                    cs, conv, best, pred, fold_betas, fold_cs = eng.l1_bt(tau, Yraw, bt_offset, cols_per_chr, fold_detail=True)
+                    extra_t["_fold_detail"] = (fold_betas, fold_cs)
+                else:
+                    cs, conv, best, pred = eng.l1_bt(tau, Yraw, bt_offset, cols_per_chr)
                 extra_t["bt_converged"] = [bool(c) for c in conv]
             elif args.t2e:
                 pred, best, cs, conv, taus = [], [], [], [], []
@@ -269,6 +284,8 @@ def main():
                 extra_t["t2e"] = {"converged": [bool(c) for c in conv], "tau": [list(map(float, t)) for t in taus],
                                   "held_out_deviance": [list(map(float, d)) for d in cs], "best": [int(b) for b in best],
                                   "events_fraction": float(t2e_event.mean())}
+            elif args.loocv:
+                cs, best, pred = eng.l1_qt_loocv(tau, cols_per_chr)
             else:
                 cs, best, pred = eng.l1_qt(tau, cols_per_chr)
             extra_t["level1_wall_ms_last_step"] = (time.perf_counter() - t_l1) * 1e3
@@ -281,6 +298,20 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    import threading
+
+    class _MemPeak(threading.Thread):                       # device memory in use, sampled while the steps run (level-1 buffers live only inside the calls)
+        def __init__(self):
+            super().__init__(daemon=True)
+            self.peak, self.stop = 0, False
+
+        def run(self):
+            while not self.stop:
+                fr, tot = torch.cuda.mem_get_info(dev)
+                self.peak = max(self.peak, tot - fr)
+                time.sleep(0.01)
+    mem = _MemPeak()
+    mem.start()
     for _ in range(args.warmup):
         step()
     fence()
@@ -295,6 +326,9 @@ def main():
         dt = float(tt.item())
     sec_per_step = dt / args.steps
     value = M * N * P / sec_per_step
+    mem.stop = True
+    mem.join()
+    extra_t["device_memory_peak_GB"] = mem.peak / 1e9      # includes the resident synthetic genotypes and W
 
     # ---- per-kernel timing pass (HIP events on the ctx stream) + roofline of the dominant kernel ----
     roof, kernels = None, None
@@ -307,11 +341,13 @@ def main():
         bs_eff = float(np.mean(bss))
         flops = {
             "gram_fp4": 2.0 * N * sum(x * x for x in bss),                       # F_gram = 2 N bs^2 per block
-            "chol_f64": sum((x ** 3 / 3.0 + 2.0 * x * x * P) * 5 * R0 for x in bss),  # K*R0 systems per block
+            # K*R0 systems per block; leave-one-out: R0 systems whose forward substitution carries the N sample rows (loocv.hip)
+            "chol_f64": (sum((x ** 3 / 3.0 + 1.0 * x * x * (N + 2 * P)) * R0 for x in bss) if args.loocv else
+                         sum((x ** 3 / 3.0 + 2.0 * x * x * P) * 5 * R0 for x in bss)),
             # level-1 fold Grams: the symmetric product, lower triangle with the diagonal (what any algorithm must form); SURVEY 8(d)'s
             # 2 N L^2 P counts the full product the reference's W_i^T W_i computes -- twice this, reported next to it
             "l1_gram_f64": 1.0 * N * L * (L + 1) * P,
-            "l1_chol_f64": P * 5 * R1 * (L ** 3 / 3.0 + 2.0 * L * L),
+            "l1_chol_f64": P * (1 if args.loocv else 5) * R1 * (L ** 3 / 3.0 + 2.0 * L * L),
             # many-row predictions on the i8 matrix cores: 8 digit planes x 2 N bs (P R0) integer operations per block
             "pred_i8": 8 * 2.0 * N * sum(bss) * P * R0 if P * R0 > 16 else 0.0,
             # the iterative level-1 models (--bt / --t2e): one weighted Gram X^T W X per fold model and IRLS step, the symmetric
@@ -393,7 +429,25 @@ def main():
 
     # ---- CPU baseline: the oracle (numpy/OpenBLAS restatement of the reference) on a bounded sample ----
     cpu = None
-    if rank == 0 and world == 1 and (not args.no_cpu or args.oracle_check):
+    bt_check = None
+    if rank == 0 and world == 1 and args.bt and args.oracle_check and not args.loocv:
+        # the logistic ridge of ONE fold chain refitted by the numpy oracle at this run's full size.  The device is handed back first (the
+        # default line runs this sub-run next to its other sub-records: RG_GPU_DONE on stderr tells the parent the GPU is free)
+        q = args.oracle_trait if args.oracle_trait >= 0 else int(np.argmin(Yraw.mean(axis=0)))
+        W0 = np.concatenate([eng.get_w(b, q) for b in range(B)], axis=1)
+        fold_betas, fold_cs = extra_t.pop("_fold_detail")
+        eng.close()
+        eng = None
+        packed.clear()
+        Wt = Wv = None
+        torch.cuda.empty_cache()
+        print("RG_GPU_DONE", file=sys.stderr, flush=True)
+        bt_check = bt_oracle_leg(W0, Yraw[:, q], bt_offset[:, q], mask[:, q], cv_sizes, tau[q], q, fold_betas[q, 0], fold_cs[q, 0],
+                                 float(Yraw[:, q].mean()), bool(kernels.get("wgram_f64", {}).get("quasi_newton_bf16_rounds")))
+        del W0
+    elif rank == 0 and world == 1 and args.bt:
+        extra_t.pop("_fold_detail", None)
+    elif rank == 0 and world == 1 and (not args.no_cpu or args.oracle_check) and not args.loocv and not args.t2e:
         cpu = cpu_baseline(args, eng, torch, dev, packed, blocks, my_blocks, X, Y, Yraw, cov, mask, ain, neff, cv_sizes, tau, M, N, P, B, R0,
                            (res[0], res[1], res[2]), with_reference=not (args.no_cpu or args.no_ref))
 
@@ -415,6 +469,7 @@ def main():
 
     # ---- sub-records of the default N=1 run (the engine's memory is released first) ----
     extra = {}
+    p4 = None
     default_n1 = rank == 0 and world == 1 and not args.no_cpu and not args.no_extra and (N, M, P) == (50000, 100000, 1)
     if default_n1:
         loco_ck = float(sum(np.abs(l).sum() for l in res[0]))
@@ -423,25 +478,61 @@ def main():
         del packed, Wt, Wv
         torch.cuda.empty_cache()
         import subprocess
-        try:    # BASELINE configs[2] (the north star's target workload) in full on this ONE GPU: 500,000 x 500,000 x 10 QT, resident
-            r3 = subprocess.run([sys.executable, os.path.abspath(__file__), "--samples", "500000", "--snps", "500000", "--phenos", "10", "--steps", "1",
-                                 "--warmup", "1", "--no-cpu"] + ([] if args.no_disk else ["--disk-leg"]), capture_output=True, text=True, timeout=1500)
-            l3 = json.loads([ln for ln in r3.stdout.splitlines() if ln.startswith("{")][-1])
-            extra["config3_single_gpu"] = {k: l3[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernels", "loco_checksum",
-                                                               "selected_tau_index", "end_to_end_from_files")}
+        me = [sys.executable, os.path.abspath(__file__)]
+        big = ["--samples", "500000", "--steps", "1", "--no-cpu"]
+
+        def sub_line(argv, timeout):
+            r = subprocess.run(me + argv, capture_output=True, text=True, timeout=timeout)
+            js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if not js:
+                raise RuntimeError((r.stdout + r.stderr)[-600:])
+            return json.loads(js[-1])
+        # BASELINE configs[3]'s kind (binary traits) at its level-1 shape: 500,000 samples, L = 2,560 level-0 predictors (512 blocks of 100 SNPs --
+        # level 1 does not see the block width), four traits of prevalence 5 %, 30 %, 1 % and 50 %; 98 % of that configuration is this level 1
+        # (DESIGN.md section 5).  With --oracle-check the sub-run then hands the device back (RG_GPU_DONE on stderr) and has the numpy oracle refit
+        # the first fold chain of the 1 % trait at full size on the host -- minutes of host work that run NEXT TO the sub-records below.
+        p4, err4 = None, []
+        try:
+            p4 = subprocess.Popen(me + big + ["--snps", "51200", "--bsize", "100", "--phenos", "4", "--bt", "--prev", "0.05,0.3,0.01,0.5", "--warmup", "0",
+                                              "--oracle-check", "--oracle-trait", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            gpu_free = threading.Event()
+
+            def _drain():
+                for ln in p4.stderr:
+                    err4.append(ln)
+                    if "RG_GPU_DONE" in ln:
+                        gpu_free.set()
+                gpu_free.set()
+            threading.Thread(target=_drain, daemon=True).start()
+            gpu_free.wait(timeout=900)
         except Exception as e:   # noqa: BLE001 - a sub-record must not take the line down
-            extra["config3_single_gpu"] = {"error": repr(e)[:500]}
-        try:    # BASELINE configs[3]'s kind (binary traits) at its level-1 shape: 500,000 samples, L = 2,560 level-0 predictors (512 blocks of 100
-                # SNPs -- level 1 does not see the block width), two traits; 98 % of that configuration is this level 1
-            r4 = subprocess.run([sys.executable, os.path.abspath(__file__), "--samples", "500000", "--snps", "51200", "--bsize", "100", "--phenos", "2", "--bt",
-                                 "--steps", "1", "--warmup", "0", "--no-cpu"], capture_output=True, text=True, timeout=900)
-            l4 = json.loads([ln for ln in r4.stdout.splitlines() if ln.startswith("{")][-1])
-            extra["config4_level1_two_binary_traits"] = {
-                "level1_wall_ms": l4["level1"].get("level1_wall_ms_last_step"), "s_per_trait": l4["level1"].get("level1_wall_ms_last_step", 0.0) / 2e3,
-                "converged": l4["level1"].get("bt_converged"), "selected_tau_index": l4["selected_tau_index"], "loco_checksum": l4["loco_checksum"],
-                "roofline": l4["roofline"], "kernels": {k: l4["kernels"].get(k) for k in ("wgram_f64", "irls_solve", "irls_stream")}, "config": l4["config"]}
+            extra["config4_level1_binary_traits"] = {"error": repr(e)[:500]}
+        try:    # BASELINE configs[2] (the north star's target workload) in full on this ONE GPU: 500,000 x 500,000 x 10 QT, resident
+            l3 = sub_line(big + ["--snps", "500000", "--phenos", "10", "--warmup", "1"] + ([] if args.no_disk else ["--disk-leg"]), 1500)
+            extra["config3_single_gpu"] = {k: l3[k] for k in ("ms_per_step", "value", "unit", "steps", "warmup", "loco_checksum", "selected_tau_index", "roofline",
+                                                               "kernels", "end_to_end_from_files", "config")}
         except Exception as e:   # noqa: BLE001
-            extra["config4_level1_two_binary_traits"] = {"error": repr(e)[:500]}
+            extra["config3_single_gpu"] = {"error": repr(e)[:500]}
+        # leave-one-out cross-validation (regenie --loocv) at the target sample count: level 0 on eight full blocks of 1,000 SNPs with ten traits,
+        # level 1 at L = 2,560 for two quantitative traits and for one binary trait
+        lo = {}
+        try:
+            l0 = sub_line(big + ["--loocv", "--snps", "8000", "--one-chrom", "--phenos", "10", "--l0-only", "--warmup", "1"], 900)
+            lo["level0_ms_per_block_of_1000_snps"] = l0["ms_per_step"] / 8
+            lo["level0_device_memory_peak_GB"] = l0["level1"].get("device_memory_peak_GB")
+            lo["level0_kernels"] = {k: l0["kernels"][k] for k in ("prep", "gram_fp4", "assemble_form", "chol_f64", "pred")}
+            lq = sub_line(big + ["--loocv", "--snps", "51200", "--bsize", "100", "--phenos", "2", "--warmup", "0"], 900)
+            lo["level1_qt_s_per_trait"] = lq["level1"]["level1_wall_ms_last_step"] / 2e3
+            lo["level1_qt_device_memory_peak_GB"] = lq["level1"].get("device_memory_peak_GB")
+            lo["level1_qt_selected_tau_index"] = lq["selected_tau_index"]
+            lb = sub_line(big + ["--loocv", "--snps", "51200", "--bsize", "100", "--phenos", "1", "--bt", "--prev", "0.1", "--warmup", "0"], 900)
+            lo["level1_bt_s_per_trait"] = lb["level1"]["level1_wall_ms_last_step"] / 1e3
+            lo["level1_bt_converged"] = lb["level1"].get("bt_converged")
+            lo["level1_bt_device_memory_peak_GB"] = lb["level1"].get("device_memory_peak_GB")
+            lo["config"] = "500,000 samples; level 0: 8 blocks x 1,000 SNPs x 10 QT; level 1: 512 blocks x 5 ridge values (bsize 100), 2 QT / 1 BT (prevalence 10 %)"
+        except Exception as e:   # noqa: BLE001
+            lo["error"] = repr(e)[:500]
+        extra["loocv_500k"] = lo
         try:
             from tools.step2_record import step2_record
             extra["step2"] = step2_record(torch=torch)
@@ -460,6 +551,25 @@ def main():
                     extra["step2"]["bgen_from_file"] = json.load(open(os.path.join(td, "rec.json")))
             except Exception as e:   # noqa: BLE001
                 extra.setdefault("step2", {})["bgen_from_file"] = {"error": repr(e)[:600]}
+    if default_n1 and p4 is not None and "config4_level1_binary_traits" not in extra:
+        try:
+            out4, _ = p4.communicate(timeout=1500)
+            js = [ln for ln in out4.splitlines() if ln.startswith("{")]
+            if not js:
+                raise RuntimeError(("".join(err4))[-600:])
+            l4 = json.loads(js[-1])
+            ms4 = l4["level1"].get("level1_wall_ms_last_step", 0.0)
+            extra["config4_level1_binary_traits"] = {
+                "s_per_trait": ms4 / 4e3, "level1_wall_ms": ms4, "traits": 4, "prevalences": [0.05, 0.3, 0.01, 0.5],
+                "converged": l4["level1"].get("bt_converged"), "oracle_check": l4.get("bt_oracle_check"),
+                "selected_tau_index": l4["selected_tau_index"], "loco_checksum": l4["loco_checksum"],
+                "roofline": l4["roofline"], "kernels": {k: l4["kernels"].get(k) for k in ("wgram_f64", "irls_solve", "irls_stream")}, "config": l4["config"]}
+        except Exception as e:   # noqa: BLE001
+            try:
+                p4.kill()
+            except Exception:   # noqa: BLE001
+                pass
+            extra["config4_level1_binary_traits"] = {"error": repr(e)[:500]}
     if rank == 0:
         line = {
             "metric": "Step-1 SNPs x samples x phenos / sec", "value": value, "unit": "SNP*sample*pheno/s",
@@ -476,7 +586,7 @@ def main():
                           N, M, args.snps, P, "BT" if args.bt else ("time-to-event" if args.t2e else "QT"), bsize), "samples": N, "snps": M, "phenos": P, "bsize": bsize, "blocks": B,
                        "parallelism": ("blocks sharded x%d, all-to-all of W by phenotype, level 1 phenotype-sharded x%d" if pheno_sharded else
                                        "blocks sharded x%d, all-gather of W, level-1 Gram tiles / ridge systems shared x%d") % (world, world)},
-            "roofline": roof, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roof, "kernels": kernels, "cpu_baseline": cpu, "bt_oracle_check": bt_check,
             "loco_max_rel_err": cpu.get("loco_max_rel_err") if cpu else None,
             "end_to_end_from_files": disk,
             "loco_checksum": float(res[3]) if len(res) > 3 else (loco_ck if default_n1 else float(sum(np.abs(l).sum() for l in res[0]))),
@@ -489,6 +599,33 @@ def main():
         eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def bt_oracle_leg(W0, yraw, offset, mask, cv_sizes, tau, q, g_beta, g_cs, prevalence, quasi_newton):
+    """`--bt --oracle-check`: oracle/regenie_step1.py's ridge_logistic_level_1 (Step1_Models.cpp:966-1156: Newton steps on the exact fp64 Hessian,
+    every ridge value warm-started from the previous one) for the FIRST fold model of trait q at this run's full sample count, against what the
+    library's default route returned for the same chain (rg_bt_options.beta_out / fold_cumsum_out).  Checker only: nothing here is timed as product."""
+    from oracle import regenie_step1 as orc
+    t0 = time.perf_counter()
+    opt = orc.Step1Options(bed="", pheno_file="", bt=True)
+    cs, betas, ok = orc.ridge_logistic_level_1(W0, yraw, offset, mask, cv_sizes, tau, opt, folds=[0])
+    t_or = time.perf_counter() - t0
+    n0 = int(cv_sizes[0])
+    b_or = betas[0]                                        # L x R1
+    b_gp = np.asarray(g_beta).T                            # [R1][L] -> L x R1
+    eta_or = W0[:n0] @ b_or                                # held-out linear predictors (without the offset), n0 x R1
+    eta_gp = W0[:n0] @ b_gp
+    rel = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))       # noqa: E731
+    return {"trait": q, "prevalence": prevalence, "fold": 0, "samples": int(W0.shape[0]), "predictors": int(W0.shape[1]), "oracle_converged": bool(ok),
+            "route": "default: " + ("quasi-Newton steps on fp16 Hessians, stored and reused (wgram_bf16.hip)" if quasi_newton else "fp64 Hessians (k_wgram128)"),
+            "beta_max_rel_err_per_tau": [rel(b_gp[:, j], b_or[:, j]) for j in range(tau.size)],
+            "beta_max_rel_err": max(rel(b_gp[:, j], b_or[:, j]) for j in range(tau.size)),
+            "held_out_deviance_max_rel_err": float(np.max(np.abs(np.asarray(g_cs)[5] - cs[5]) / np.abs(cs[5]))),
+            "held_out_sums_max_rel_err": float(np.max(np.abs(np.asarray(g_cs) - cs) / np.maximum(np.abs(cs), 1e-300))),
+            "prediction_max_rel_err": max(rel(eta_gp[:, j], eta_or[:, j]) for j in range(tau.size)),
+            "oracle_s": t_or,
+            "note": "max |gpu - oracle| / max |oracle| per ridge value; both sides stop at max |score| < 1e-4 (l1_ridge_tol), so they agree to what that "
+                    "tolerance leaves open, not to rounding"}
 
 
 def measured_traffic(dom, nblocks, n_batches, P):

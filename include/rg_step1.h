@@ -237,6 +237,9 @@ typedef struct rg_bt_options {
                                           Step1_Models.cpp:1429-1758; yraw = counts, offset = null Poisson eta) */
   double l1_ridge_tol;                 /* 1e-4  params.l1_ridge_tol */
   double tol;                          /* 1e-8  params.tol */
+  /* optional outputs of the K-fold route (NULL = not wanted; ignored by LOOCV), the carriers of ridgel1 (Step1_Models.hpp:52-75): */
+  double* beta_out;                    /* [P][K][n_ridge_l1][L]: beta_hat_level_1[ph][fold] -- the coefficients of every fold model at every ridge value */
+  double* fold_cumsum_out;             /* [P][K][6][n_ridge_l1]: each fold's own share of cumsum_out (its held-out Sx, Sy, Sx2, Sy2, Sxy, -logLik) */
 } rg_bt_options;
 int rg_l1_bt(rg_ctx* ctx, int32_t n_ridge_l1, const double* tau, const double* yraw,
              const double* offset, const rg_bt_options* opt, int32_t nchr,

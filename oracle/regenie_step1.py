@@ -985,16 +985,38 @@ def ridge_logistic_level_1_loocv(W, yraw, offset, mask, tau, opt: Step1Options):
     return cs, True
 
 
-def ridge_logistic_level_1(W, yraw, offset, mask, cv_sizes, tau, opt: Step1Options):
+def _xtwx(Xt: np.ndarray, wm: np.ndarray) -> np.ndarray:
+    """X^T diag(w) X.  Small inputs: the one product the reference forms (XtW * X, Step1_Models.cpp:1047-1049).  Above 2e8 entries the same sum
+    is taken over row chunks on a few threads (numpy's elementwise products are single-threaded; at 400,000 x 2,560 the 8 GB temporary of the
+    one-line form costs more than the product itself) -- bench.py's full-size check of the logistic ridge is what needs it."""
+    n, L = Xt.shape
+    if n * L <= 2e8:
+        return (Xt.T * wm[None, :]) @ Xt
+    from concurrent.futures import ThreadPoolExecutor
+    step = 32768
+    parts = [(a, min(n, a + step)) for a in range(0, n, step)]
+
+    def one(ab):
+        a, b = ab
+        Xc = Xt[a:b]
+        return (Xc.T * wm[None, a:b]) @ Xc
+    acc = np.zeros((L, L))
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        for g in ex.map(one, parts):                 # results arrive in chunk order: a fixed summation order
+            acc += g
+    return acc
+
+
+def ridge_logistic_level_1(W, yraw, offset, mask, cv_sizes, tau, opt: Step1Options, folds=None):
     """Step1_Models.cpp:966-1156 (out-of-sample branch) for ONE phenotype.
-    Returns (cumsum[6,R1], betas[K] each L x R1, converged)."""
+    Returns (cumsum[6,R1], betas[K] each L x R1, converged).  folds: restrict the run to these fold models (the sums are then their shares)."""
     N, L = W.shape
     K = cv_sizes.size
     R1 = tau.size
     starts = np.concatenate([[0], np.cumsum(cv_sizes)])
     cs = np.zeros((6, R1))
     betas = [np.zeros((L, R1)) for _ in range(K)]
-    for i in range(K):
+    for i in (range(K) if folds is None else folds):
         tr = np.ones(N, bool)
         tr[starts[i]:starts[i + 1]] = False
         Xt, yt, ot, mt = W[tr], yraw[tr], offset[tr], mask[tr]
@@ -1013,11 +1035,10 @@ def ridge_logistic_level_1(W, yraw, offset, mask, cv_sizes, tau, opt: Step1Optio
                     return cs, betas, False
                 z = np.where(mt, (eta - ot) + (yt - p) / w, 0.0)
                 wm = np.where(mt, w, 0.0)
-                XtW = Xt.T * wm[None, :]
-                XtWX = XtW @ Xt
+                XtWX = _xtwx(Xt, wm)
                 XtWX[np.diag_indices_from(XtWX)] += tau[j]
                 cho = np.linalg.cholesky(XtWX)
-                betanew = np.linalg.solve(cho.T, np.linalg.solve(cho, XtW @ z))
+                betanew = np.linalg.solve(cho.T, np.linalg.solve(cho, Xt.T @ (wm * z)))
                 for _ in range(opt.niter_max_line_search_ridge):
                     p = get_pvec(ot + Xt @ betanew)
                     w, bad = get_wvec(p, mt)

@@ -1120,7 +1120,7 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
   if (R1 < 1 || R1 > 16) { ctx->err = "rg_l1_bt: n_ridge_l1 must be in [1,16]"; return RG_ERR_ARG; }
   rg_bt_options o;
   o.niter_max_ridge = 100; o.niter_max_line_search_ridge = 100; o.niter_max_line_search = 25;
-  o.l1_ridge_tol = 1e-4; o.tol = 1e-8; o.family = 0;
+  o.l1_ridge_tol = 1e-4; o.tol = 1e-8; o.family = 0; o.beta_out = nullptr; o.fold_cumsum_out = nullptr;
   if (opt) o = *opt;
   if (o.family != 0 && o.family != 1) { ctx->err = "rg_l1_bt: family must be 0 (logistic) or 1 (Poisson)"; return RG_ERR_ARG; }
   const bool poisson = o.family == 1;
@@ -1256,6 +1256,8 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
               const int j = jj[ch];
               std::memcpy(hbetas.data() + ((size_t)ch * R1 + j) * n64, beta.data() + (size_t)ch * n64, sizeof(double) * n64);
               for (int t = 0; t < 6; ++t) cs[t * R1 + j] += sm[t];
+              if (o.fold_cumsum_out)
+                for (int t = 0; t < 6; ++t) o.fold_cumsum_out[(((size_t)p * K + ch) * 6 + t) * R1 + j] = sm[t];
               if (++jj[ch] == R1) { done[ch] = 1; ++ndone; continue; }
               niter[ch] = 0; nfresh[ch] = 0;
             }
@@ -1299,6 +1301,10 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
           }
         }
       }
+      if (o.beta_out)
+        for (int ch = 0; ch < K; ++ch)
+          for (int j = 0; j < R1; ++j)
+            std::memcpy(o.beta_out + (((size_t)p * K + ch) * R1 + j) * L, hbetas.data() + ((size_t)ch * R1 + j) * n64, sizeof(double) * L);
       if (!ok) continue;  // pheno_l1_not_converged: LOCO predictions are skipped (Data.cpp:1016-1021)
       converged_out[p] = 1;
       int best = 0; double minv = 1e10;

@@ -34,7 +34,7 @@ class RgProblem(C.Structure):
 class RgBtOptions(C.Structure):
     _fields_ = [("niter_max_ridge", C.c_int32), ("niter_max_line_search_ridge", C.c_int32),
                 ("niter_max_line_search", C.c_int32), ("family", C.c_int32),
-                ("l1_ridge_tol", C.c_double), ("tol", C.c_double)]
+                ("l1_ridge_tol", C.c_double), ("tol", C.c_double), ("beta_out", C.c_void_p), ("fold_cumsum_out", C.c_void_p)]
 
 
 class RgCoxOptions(C.Structure):
@@ -254,6 +254,7 @@ class Step1Engine:
         p.n_blocks_total, p.max_block_size = int(n_blocks_total), int(max_block_size)
         self._check(self.lib.rg_set_problem(self.h, C.byref(p)))
         self.N, self.P, self.R0, self.B = N, P, lam.size, int(n_blocks_total)
+        self.cv_folds = int(cvs.size)
         self.Pv = P                       # phenotypes of the current level-1 view
         self.n_file = int(n_file)
 
@@ -362,9 +363,10 @@ class Step1Engine:
 
     def l1_bt(self, tau: np.ndarray, yraw: np.ndarray, offset: np.ndarray, cols_per_chr: Sequence[int],
               niter_max_ridge: int = 100, niter_max_line_search_ridge: int = 100,
-              niter_max_line_search: int = 25, l1_ridge_tol: float = 1e-4, tol: float = 1e-8, family: int = 0):
+              niter_max_line_search: int = 25, l1_ridge_tol: float = 1e-4, tol: float = 1e-8, family: int = 0, fold_detail: bool = False):
         """Logistic (family 0, --bt) or Poisson (family 1, --ct) ridge level 1, K-fold or LOOCV as the problem was set up.
-        Returns (cumsum [P,6,R1], converged [P] bool, best [P], pred [P][N,nchr])."""
+        Returns (cumsum [P,6,R1], converged [P] bool, best [P], pred [P][N,nchr]); with fold_detail (K-fold) also the fold models'
+        coefficients [P,K,R1,L] and each fold's own held-out sums [P,K,6,R1] (rg_bt_options.beta_out / fold_cumsum_out)."""
         tau = np.ascontiguousarray(tau, dtype=np.float64)
         P, R1 = tau.shape
         assert P == self.Pv
@@ -373,7 +375,13 @@ class Step1Engine:
         assert yraw.shape == (self.N, P) and offset.shape == (self.N, P)
         cpc = np.ascontiguousarray(cols_per_chr, dtype=np.int32)
         nchr = cpc.size
-        o = RgBtOptions(niter_max_ridge, niter_max_line_search_ridge, niter_max_line_search, family, l1_ridge_tol, tol)
+        o = RgBtOptions(niter_max_ridge, niter_max_line_search_ridge, niter_max_line_search, family, l1_ridge_tol, tol, None, None)
+        if fold_detail:
+            K, L = int(self.cv_folds), self.B * self.R0
+            assert K > 0, "fold_detail needs a K-fold problem"
+            betas = np.zeros((P, K, R1, L))
+            fcs = np.zeros((P, K, 6, R1))
+            o.beta_out, o.fold_cumsum_out = betas.ctypes.data, fcs.ctypes.data
         cs = np.zeros((P, 6, R1))
         conv = np.zeros(P, dtype=np.int32)
         best = np.zeros(P, dtype=np.int32)
@@ -381,6 +389,8 @@ class Step1Engine:
         self._check(self.lib.rg_l1_bt(self.h, R1, tau.ctypes.data, yraw.ctypes.data, offset.ctypes.data,
                                       C.byref(o), nchr, cpc.ctypes.data, cs.ctypes.data, conv.ctypes.data,
                                       best.ctypes.data, pred.ctypes.data))
+        if fold_detail:
+            return cs, conv.astype(bool), best, [pred[p].T.copy() for p in range(P)], betas, fcs
         return cs, conv.astype(bool), best, [pred[p].T.copy() for p in range(P)]
 
     def l1_cox(self, pheno: int, time: np.ndarray, event: np.ndarray, offset: np.ndarray, cols_per_chr: Sequence[int], n_ridge_l1: int = 5,

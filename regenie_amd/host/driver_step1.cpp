@@ -681,7 +681,7 @@ int run(int argc, char** argv) {
         double* cq = cumsum.data() + (size_t)q * NCS * R1;
         double* pq = pred + (size_t)q * per;
         if (p.t2e) {
-          rg_cox_options co;
+          rg_cox_options co{};
           co.niter_max = p.niter_max; co.niter_max_line_search = p.niter_max_line_search; co.niter_max_ridge = p.niter_max_ridge;
           co.niter_max_line_search_ridge = 100; co.numtol_cox = 2.5e-4; co.l1_ridge_tol = 1e-4;
           co.tau = p.t2e_l1_pi6 ? tau.data() + (size_t)q * R1 : nullptr;
@@ -692,7 +692,7 @@ int run(int argc, char** argv) {
           check(cx, rg_set_l1_view(cx, nullptr, q, 1));
           const double* tq = tau.data() + (size_t)q * R1;
           if (p.bt || p.ct) {
-            rg_bt_options bo;
+            rg_bt_options bo{};
             bo.niter_max_ridge = p.niter_max_ridge; bo.niter_max_line_search_ridge = 100; bo.niter_max_line_search = p.niter_max_line_search;
             bo.family = p.ct ? 1 : 0; bo.l1_ridge_tol = 1e-4; bo.tol = 1e-8;
             check(cx, rg_l1_bt(cx, R1, tq, r.Yraw.data() + (size_t)q * N, r.offset.data() + (size_t)q * N, &bo, nchr, cols_per_chr.data(),
@@ -720,7 +720,7 @@ int run(int argc, char** argv) {
     std::vector<int32_t> best(nq), converged(nq, 1);
     const double* tq = tau.data() + (size_t)q0 * R1;
     if (p.t2e) {   // one call per trait: the library derives the penalties from the score at beta = 0 and returns them
-      rg_cox_options co;
+      rg_cox_options co{};
       co.niter_max = p.niter_max; co.niter_max_line_search = p.niter_max_line_search; co.niter_max_ridge = p.niter_max_ridge;
       co.niter_max_line_search_ridge = 100; co.numtol_cox = 2.5e-4; co.l1_ridge_tol = 1e-4;
       std::vector<double> tau_in(tau);   // --t2e-l1-pi6: the grid of the caller's (the call writes the penalties it used back into tau)
@@ -733,7 +733,7 @@ int run(int argc, char** argv) {
                             nchr, cols_per_chr.data(), tau.data() + (size_t)(q0 + q) * R1, cq + 5 * R1, &converged[q], &best[q], pred.data() + (size_t)q * nchr * N));
       }
     } else if (p.bt || p.ct) {
-      rg_bt_options bo;  // Regenie.hpp:287-290 defaults; family picks ridge_logistic_level_1* or ridge_poisson_level_1*
+      rg_bt_options bo{};  // Regenie.hpp:287-290 defaults; family picks ridge_logistic_level_1* or ridge_poisson_level_1*
       bo.niter_max_ridge = p.niter_max_ridge; bo.niter_max_line_search_ridge = 100; bo.niter_max_line_search = p.niter_max_line_search;
       bo.family = p.ct ? 1 : 0; bo.l1_ridge_tol = 1e-4; bo.tol = 1e-8;
       check(cx, rg_l1_bt(cx, R1, tq, r.Yraw.data() + (size_t)q0 * N, r.offset.data() + (size_t)q0 * N, &bo, nchr, cols_per_chr.data(),

@@ -137,12 +137,20 @@ def test_bt_kfold_level1_at_L2560(monkeypatch):
         for k, v in policy.items():
             monkeypatch.setenv(k, v)
         eng = engine_with_w(N, X, Y, mask, keep, cv_sizes, W)
-        cs, conv, best, pred = eng.l1_bt(tau, yraw, offset, [nn for (_, _, nn) in cc], niter_max_ridge=opt.niter_max_ridge,
-                                         niter_max_line_search_ridge=opt.niter_max_line_search_ridge, niter_max_line_search=opt.niter_max_line_search)
+        cs, conv, best, pred, fbeta, fcs = eng.l1_bt(tau, yraw, offset, [nn for (_, _, nn) in cc], niter_max_ridge=opt.niter_max_ridge,
+                                                     niter_max_line_search_ridge=opt.niter_max_line_search_ridge,
+                                                     niter_max_line_search=opt.niter_max_line_search, fold_detail=True)
         tm = eng.timing()
         eng.close()
         for k in policy:
             monkeypatch.delenv(k)
+        # the carriers of ridgel1 (rg_bt_options.beta_out / fold_cumsum_out): every fold model's coefficients at every ridge value, and the
+        # folds' shares, which must add up to the sums
+        assert np.abs(fcs.sum(axis=1) - cs).max() <= 1e-12 * np.abs(cs).max()
+        for ph in range(P):
+            for i in range(cv_sizes.size):
+                rb = ref[ph][1][i]                                           # L x R1
+                assert np.abs(fbeta[ph, i].T - rb).max() <= 2e-5 * np.abs(rb).max(), (policy, ph, i, np.abs(fbeta[ph, i].T - rb).max() / np.abs(rb).max())
         assert tm["n_wgram_approx_rounds"] > 0 and (tm["n_irls_rounds"] > tm["n_wgram_approx_rounds"]) == (policy.get("RG_WGRAM_REUSE") != "0")
         for ph in range(P):
             rcs, betas, ok = ref[ph]
@@ -185,3 +193,80 @@ def test_cox_level1_at_L2560():
     rpred = orc.make_predictions(W[0], betas, best, cv_sizes, cc)
     m = mask[:, 0]
     assert np.abs(pred[m] - rpred[m]).max() <= 1e-6 * np.abs(rpred[m]).max()
+
+
+def test_qt_loocv_level1_at_L2560():
+    """Leave-one-out level 1 at full width (Step1_Models.cpp:875-962, Data.cpp:1269-1342): two quantitative traits, 7,000 samples, one with
+    missing values.  `rg_l1_qt_loocv` forms W^T W of order 2,560, its leverages for every ridge value and the refit at the selected one; the
+    CV sums, the selection, the per-chromosome predictions (every sample's own leave-one-out coefficients) and the LOCO rows are held to
+    ridge_level_1_loocv / make_predictions_loocv of the oracle."""
+    N, P = 7000, 2
+    rng = np.random.default_rng(14)
+    keep = np.ones(N, bool)
+    W, liab = synth_predictors(N, P, 0.035, seed=8)
+    X = covariates(N, keep, 4)
+    mask = np.ones((N, P), bool)
+    mask[rng.random(N) < 0.03, 1] = False
+    for ph in range(P):                          # LOOCV level 0 re-masks its predictors (Step1_Models.cpp:693-704): zero rows where the trait is missing
+        W[ph][~mask[:, ph]] = 0.0
+    Y = liab - X @ (X.T @ liab)
+    Y = np.where(mask, Y, 0.0)
+    Y /= np.sqrt((Y ** 2).sum(axis=0) / (mask.sum(axis=0) - X.shape[1]))
+    h1 = orc.set_ridge_params(5)
+    tau = np.stack([orc.tau_from_h(h1, L_FULL, False)] * P)
+    cc = chr_cols()
+    eng = engine_with_w(N, X, Y, mask, keep, None, W)
+    cs, best, pred = eng.l1_qt_loocv(tau, [nn for (_, _, nn) in cc])
+    eng.close()
+    for ph in range(P):
+        neff = float(mask[:, ph].sum())
+        rcs = orc.ridge_level_1_loocv(W[ph], Y[:, ph], tau[ph], neff, X.shape[1])
+        rbest = orc.select_tau(rcs, neff, False)
+        scale = np.abs(rcs[:5]).max()
+        assert np.abs(cs[ph] - rcs[:5]).max() <= 1e-9 * scale
+        assert int(best[ph]) == rbest
+        rpred = orc.make_predictions_loocv(W[ph], Y[:, ph], tau[ph][rbest], cc)
+        assert np.abs(pred[ph] - rpred).max() <= 1e-8 * np.abs(rpred).max()
+        rl = orc.loco_from_predictions(rpred, cc, 23)
+        gl = orc.loco_from_predictions(pred[ph], cc, 23)
+        assert np.abs(gl - rl).max() <= 1e-8 * np.abs(rl).max()
+
+
+def test_bt_loocv_level1_at_L2560():
+    """The leave-one-out logistic ridge at full width (Step1_Models.cpp:1159-1374, Data.cpp:1484-1571): two binary traits (prevalence 0.3 and
+    0.08, one with missing values), 4,500 samples -- below 5,000 regenie takes this route for binary traits by itself (Data.cpp:353) --
+    three ridge values warm-started in the reference's order, the leave-one-out shortcut on the factor of X^T W X + tau I of order 2,560,
+    then the refit at the selected value for the predictions."""
+    N, P = 4500, 2
+    rng = np.random.default_rng(15)
+    keep = np.ones(N, bool)
+    W, liab = synth_predictors(N, P, 0.04, seed=9)
+    X = covariates(N, keep, 5)
+    mask = np.ones((N, P), bool)
+    mask[rng.random(N) < 0.02, 0] = False
+    for ph in range(P):
+        W[ph][~mask[:, ph]] = 0.0
+    yraw = np.column_stack([(liab[:, 0] > np.quantile(liab[:, 0], 0.7)), (liab[:, 1] > np.quantile(liab[:, 1], 0.92))]).astype(np.float64)
+    yraw = np.where(mask, yraw, 0.0)
+    offset = np.empty((N, P))
+    for ph in range(P):
+        prev = yraw[mask[:, ph], ph].mean()
+        offset[:, ph] = np.log(prev / (1 - prev)) + 0.2 * X[:, 1] * np.sqrt(N)
+    Y = np.where(mask, yraw - yraw.mean(axis=0), 0.0)
+    h1 = orc.set_ridge_params(3)
+    tau = np.stack([orc.tau_from_h(h1, L_FULL, True)] * P)
+    cc = chr_cols()
+    opt = orc.Step1Options(bed="", pheno_file="", bt=True)
+    eng = engine_with_w(N, X, Y, mask, keep, None, W)
+    cs, conv, best, pred = eng.l1_bt(tau, yraw, offset, [nn for (_, _, nn) in cc], niter_max_ridge=opt.niter_max_ridge,
+                                     niter_max_line_search_ridge=opt.niter_max_line_search_ridge, niter_max_line_search=opt.niter_max_line_search)
+    eng.close()
+    for ph in range(P):
+        rcs, ok = orc.ridge_logistic_level_1_loocv(W[ph], yraw[:, ph], offset[:, ph], mask[:, ph], tau[ph], opt)
+        assert ok and conv[ph]
+        assert np.abs(cs[ph] - rcs).max() <= 1e-6 * np.abs(rcs).max()        # both sides stop at max|score| < 1e-4
+        rbest = orc.select_tau(rcs, float(mask[:, ph].sum()), True)
+        assert int(best[ph]) == rbest
+        rpred = orc.make_predictions_binary_loocv(W[ph], yraw[:, ph], offset[:, ph], mask[:, ph], tau[ph][rbest], cc, opt)
+        m = mask[:, ph]
+        assert np.abs(pred[ph][m] - rpred[m]).max() <= 1e-6 * np.abs(rpred[m]).max()

@@ -44,8 +44,10 @@ s2 = d.get("step2")
 if s2:
     print("step2", json.dumps({k: v for k, v in s2.items() if k != "bgen_from_file"})[:600])
     print("step2.bgen_from_file", json.dumps(s2.get("bgen_from_file"))[:1500])
-c4 = d.get("config4_level1_two_binary_traits")
-if c4: print("config4_level1", {k: c4.get(k) for k in ("s_per_trait", "converged", "error")}, (c4.get("roofline") or {}).get("frac"))
+c4 = d.get("config4_level1_binary_traits")
+if c4: print("config4_level1", {k: c4.get(k) for k in ("s_per_trait", "converged", "error")}, (c4.get("roofline") or {}).get("frac"), "oracle_check", json.dumps(c4.get("oracle_check"))[:900])
+if d.get("bt_oracle_check"): print("bt_oracle_check", json.dumps(d["bt_oracle_check"])[:900])
+if d.get("loocv_500k"): print("loocv_500k", json.dumps(d["loocv_500k"])[:1200])
 PY
     ;;
   stats)
