@@ -109,9 +109,111 @@ __global__ __launch_bounds__(256) void k_dgemm_nt(const double* A, int64_t lda, 
         C[(r0 + m * 16 + q + 4 * r) * ldc + c0 + n * 16 + i] = acc[m][n][r];
 }
 
+// ---- the same product through LDS: one WORKGROUP per 128 x 128 macro tile (4 waves, 2 x 2 of 64 x 64) ---------------------------------
+// The register-fed kernel above pulls 8 flop per byte through the L2 -> CU fabric and stays near 30 TFLOP/s (29 measured on the 1,024 x
+// 131,072 x 1,024 products of the leave-one-out level 0, profiles/r5_loocv_level0_*).  This is the staging scheme of k_l1_gram128 (l1.hip)
+// with two operand matrices: the 128 rows of A and the 128 rows of B of a macro tile are staged 16 K-positions at a time (32 KB per stage,
+// two stages) by direct global -> LDS copies (global_load_lds, 16 B per lane) and shared by the four waves; the eight 16-byte slots of a row
+// are XOR-swizzled by ((row >> 1) & 7) so that every ds_read_b128 lane group hits 16 distinct bank quads; one barrier per stage.
+// Work order: workgroup id w runs on XCD w % 8; an XCD walks super tiles of SM x SN macro tiles (<= 64 = its resident workgroups), so that
+// the A and B rows a super tile needs are fetched once into that XCD's L2 and shared by its SM * SN products.
+// m, n: multiples of 64 (rows past them are clamped for the loads, wave tiles past them are not stored); K: a multiple of 16.
+struct Gemm128 { const double* A; const double* B; double* C; int64_t lda, ldb, ldc, K; int m, n, MT, NTl, SM, SN, SMcount; };
+__global__ __launch_bounds__(256, 2) void k_dgemm_nt128(Gemm128 g) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[2 * 32768];
+  int mt, nt;
+  {
+    const int w = blockIdx.x, x = w & 7, s = w >> 3;
+    const int per = g.SM * g.SN, u = s / per, within = s % per;
+    const int mi = within % g.SM, ni = within / g.SM;
+    const int sm = u % g.SMcount, snl = u / g.SMcount;
+    mt = sm * g.SM + mi;
+    nt = (snl * 8 + x) * g.SN + ni;
+    if (mt >= g.MT || nt >= g.NTl) return;
+  }
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int i = lane & 15, q = lane >> 4;
+  const int ns = (int)(g.K / 16);
+  const double* src[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int rl = 8 * (wave * 8 + j) + (lane >> 3);
+    const int slot = (lane & 7) ^ ((rl >> 1) & 7);
+    src[j] = (rl < 128 ? g.A + (int64_t)min(mt * 128 + rl, g.m - 1) * g.lda : g.B + (int64_t)min(nt * 128 + rl - 128, g.n - 1) * g.ldb) + 2 * slot;
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+  const uint32_t wdst = __builtin_amdgcn_readfirstlane(lds0 + wave * 8192);
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      glds16p(src[j], wdst + buf * 32768 + j * 1024);
+      src[j] += 16;
+    }
+  };
+  const int row0 = mt * 128 + wr * 64, col0 = nt * 128 + wc * 64;
+  const bool live = row0 < g.m && col0 < g.n;
+  v4d acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = (v4d){0, 0, 0, 0};
+  const int xs = (i >> 1) & 7;
+  const int oa = (wr * 64 + i) * 128 + ((q ^ xs) << 4), ob = 16384 + (wc * 64 + i) * 128 + ((q ^ xs) << 4);
+  const int o4 = (((q + 4) ^ xs) << 4) - ((q ^ xs) << 4);
+  if (ns > 0) issue(0);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int s = 0; s < ns; ++s) {
+    const uint8_t* cur = smem + (s & 1) * 32768;
+    if (s + 1 < ns) issue((s + 1) & 1);
+    if (live) {
+      double2 a[4][2], b[4][2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        a[m][0] = *reinterpret_cast<const double2*>(cur + oa + m * 2048);
+        a[m][1] = *reinterpret_cast<const double2*>(cur + oa + m * 2048 + o4);
+        b[m][0] = *reinterpret_cast<const double2*>(cur + ob + m * 2048);
+        b[m][1] = *reinterpret_cast<const double2*>(cur + ob + m * 2048 + o4);
+      }
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            const double av = kk == 0 ? a[m][0].x : (kk == 1 ? a[m][0].y : (kk == 2 ? a[m][1].x : a[m][1].y));
+            const double bv = kk == 0 ? b[n][0].x : (kk == 1 ? b[n][0].y : (kk == 2 ? b[n][1].x : b[n][1].y));
+            acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[m][n], 0, 0, 0);
+          }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+  if (!live) return;
+  double* O = g.C + (int64_t)row0 * g.ldc + col0;
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) O[(int64_t)(m * 16 + q + 4 * r) * g.ldc + n * 16 + i] = acc[m][n][r];
+}
+
 void rg_launch_dgemm_nt(hipStream_t st, const double* A, int64_t lda, const double* B, int64_t ldb,
                         int m, int n, int64_t k, double* C, int64_t ldc) {
-  hipLaunchKernelGGL(k_dgemm_nt, dim3(n / CT, m / CT), dim3(256), 0, st, A, lda, B, ldb, k, C, ldc);
+  static const bool old = getenv("RG_DGEMM_REG") != nullptr;
+  const bool al = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && lda % 2 == 0 && ldb % 2 == 0;
+  if (old || !al || k % 16 != 0 || (int64_t)m * n < 128 * 128) {
+    hipLaunchKernelGGL(k_dgemm_nt, dim3(n / CT, m / CT), dim3(256), 0, st, A, lda, B, ldb, k, C, ldc);
+    return;
+  }
+  Gemm128 g;
+  g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.K = k; g.m = m; g.n = n;
+  g.MT = (m + 127) / 128; g.NTl = (n + 127) / 128;
+  g.SM = std::min(g.MT, 8); g.SN = std::max(1, std::min(g.NTl, 64 / g.SM));
+  g.SMcount = (g.MT + g.SM - 1) / g.SM;
+  const int nsup = (g.NTl + g.SN - 1) / g.SN;
+  const int64_t per_xcd = (int64_t)g.SMcount * ((nsup + 7) / 8) * g.SM * g.SN;
+  hipLaunchKernelGGL(k_dgemm_nt128, dim3((unsigned)(per_xcd * 8)), dim3(256), 0, st, g);
 }
 
 // ---- XCD-affine work order -----------------------------------------------------------------------

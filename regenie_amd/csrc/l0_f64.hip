@@ -232,13 +232,13 @@ __global__ __launch_bounds__(256) void k_f64_wscale(double* W, int64_t Np, int R
 
 // gt[pos][j] = G[j][pos]: the sample-major standardised genotypes the leave-one-out path appends to its systems as extra
 // right-hand-side rows (loocv.hip); grid (Np / 64, n64 / 64), a 64 x 64 tile through LDS
-__global__ __launch_bounds__(256) void k_f64_transpose(const double* G, int64_t Np, int n64, double* gt) {
+__global__ __launch_bounds__(256) void k_f64_transpose(const double* G, int64_t Np, int n64, double* gt, int64_t pos0) {
   __shared__ double t[64][65];
   const int64_t p0 = (int64_t)blockIdx.x * 64;
   const int j0 = blockIdx.y * 64;
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
     const int jl = e >> 6, pl = e & 63;
-    t[jl][pl] = G[(int64_t)(j0 + jl) * Np + p0 + pl];
+    t[jl][pl] = G[(int64_t)(j0 + jl) * Np + pos0 + p0 + pl];
   }
   __syncthreads();
   for (int e = threadIdx.x; e < 64 * 64; e += 256) {
@@ -339,16 +339,19 @@ int rg_l0_blocks_f64_impl(rg_ctx* ctx, int nblk, const int32_t* block_ids, const
         hipLaunchKernelGGL(k_f64_gxpart, dim3(gpos, nb), dim3(256), 0, st, G, Np, Yp, P, part);
         hipLaunchKernelGGL(k_f64_gysum, dim3((unsigned)(((int64_t)rhs_pad * n64 + 255) / 256)), dim3(256), 0, st, part, (int)gpos, P, nb, n64,
                            rhs_pad, ctx->seg, ctx->d_sum, msz);
-        hipLaunchKernelGGL(k_f64_transpose, dim3((unsigned)(Np / 64), n64 / 64), dim3(256), 0, st, G, Np, n64, ctx->d_gt);
-        rg_launch_chol_solve_formed_x(st, ctx->d_sum, msz, ctx->d_fold, msz, 1, ctx->d_lambda, R0, ctx->d_bs, 0, 1, ctx->d_wk,
-                                      ctx->rtot_wk * n64, n64, (int)(ctx->rtot_wk - n64), 0, ctx->d_dinv, ctx->d_info + 1,
-                                      &ctx->tm.n_chol_launches, 0, ctx->d_gt, (int64_t)Np * n64, rtot, 1, 0, -1, 0);
         LoocvArgs la;
         la.nblk = 1; la.R0 = R0; la.P = P; la.C = C; la.n128 = ctx->n128; la.n64 = n64; la.rtot = (int)ctx->rtot_wk;
         la.row_g0 = rtot; la.Np = Np; la.pk_ld = ctx->pk_ld; la.pk_blk_stride = 0; la.pk = nullptr;
         la.mu = nullptr; la.sc = nullptr; la.Bm = nullptr; la.V = ctx->d_V; la.maskp = ctx->d_maskp;
         la.neff = ctx->d_neff; la.bs = ctx->d_bs; la.blockid = ctx->d_blockid; la.wk = ctx->d_wk; la.gt = ctx->d_gt;
         la.W = rg_w_base(ctx);
+        // one block at a time (nbb == 1): d_bs / d_blockid entry 0 must be THIS block's
+        F64_HIP(hipMemcpyAsync(ctx->d_bs, bs + b, sizeof(int32_t), hipMemcpyHostToDevice, st));
+        F64_HIP(hipMemcpyAsync(ctx->d_blockid, block_ids + b, sizeof(int32_t), hipMemcpyHostToDevice, st));
+        const int rcl = rg_l0_loocv_tri(ctx, st, la, nb, ctx->d_sum, rtot, ctx->d_triws, ctx->d_zt, ctx->loo_chunk, [&](int64_t pos0, int64_t len) {
+          hipLaunchKernelGGL(k_f64_transpose, dim3((unsigned)(len / 64), n64 / 64), dim3(256), 0, st, G, Np, n64, ctx->d_gt, pos0);
+        });
+        if (rcl) return rcl;
         rg_launch_l0_loocv(st, la, ctx->d_lpart, ctx->d_lpart + (size_t)R0 * P * 64, 64);
         continue;
       }

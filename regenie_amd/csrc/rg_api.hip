@@ -29,7 +29,7 @@ void free_all(rg_ctx* c) {
                   c->d_xypart, c->d_chunk_seg, c->d_chunk_pos, c->d_chunk_len, c->d_S, c->d_F, c->d_Bm,
                   c->d_BQ, c->d_GYt, c->d_sc, c->d_fold, c->d_sum, c->d_wk, c->d_dinv, c->d_beta,
                   c->d_cb, c->d_psum, c->d_pstat, c->d_info, c->d_bs, c->d_blockid, (void*)c->d_rawptr, c->d_c1k_seg, c->d_c1k_pos,
-                  c->d_c1k_len, c->d_c256_seg, c->d_c256_pos, c->d_c256_len, c->d_gt, c->d_lpart, c->d_bplanes, c->d_bsc, c->d_pkT, c->d_vd, c->d_vsc, c->d_xyS, c->d_segid};
+                  c->d_c1k_len, c->d_c256_seg, c->d_c256_pos, c->d_c256_len, c->d_gt, c->d_zt, c->d_triws, c->d_lpart, c->d_bplanes, c->d_bsc, c->d_pkT, c->d_vd, c->d_vsc, c->d_xyS, c->d_segid};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (c->own_W && c->d_W) hipFree(c->d_W);
@@ -232,9 +232,10 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   ctx->n128 = (int)rg_round_up(bsm, 128);
   ctx->n64 = (int)rg_round_up(bsm, 64);
   ctx->rtot = ctx->n64 + (int)rg_round_up(P, 64);
-  // LOOCV: every (block, lambda) system carries the Np sample rows as extra right-hand sides
-  ctx->rtot_wk = ctx->loocv ? ctx->rtot + Np : (int64_t)ctx->rtot;
-  ctx->nsys = ctx->loocv ? ctx->R0 : K * ctx->R0;
+  // LOOCV: no ridge systems at level 0 (loocv_tri.hip: one tridiagonal reduction per block serves every ridge value)
+  ctx->rtot_wk = (int64_t)ctx->rtot;
+  ctx->nsys = ctx->loocv ? 1 : K * ctx->R0;
+  ctx->loo_chunk = std::min<int64_t>(Np, 65536);   // sample positions whose transformed genotypes Q^T g~ are resident at a time
   // blocks per batch: more systems per launch hide the Cholesky dependency chain.  (Sizing batches to one round of the
   // block factorization -- one wave per system, 4 per CU: 1024 systems -- was measured: 37.9 ms per step with 3 batches of 37
   // blocks against 36.1 ms with 2 of 55 at BASELINE configs[1]; what the extra batch costs elsewhere outweighs the saved round.)
@@ -265,9 +266,9 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
     const int nbatch = (ctx->B_total + nb - 1) / nb;
     nb = (ctx->B_total + nbatch - 1) / nbatch;
   }
-  if (ctx->loocv) {  // bound the forward-substituted row storage (~24 GB)
-    const double per_blk = 8.0 * ctx->n64 * ((double)ctx->R0 * ctx->rtot_wk + (double)Np);
-    nb = (int)std::max(1.0, std::min((double)nb, 24e9 / per_blk));
+  if (ctx->loocv) {  // bound the chunk buffers of the leave-one-out path (g~ and Q^T g~ of a chunk of samples, fp64: ~16 GB)
+    const double per_blk = 2.0 * 8.0 * ctx->n64 * (double)ctx->loo_chunk;
+    nb = (int)std::max(1.0, std::min((double)nb, 16e9 / per_blk));
   }
   ctx->nblk_cap = nb;
   const int nseg = K, R0 = ctx->R0, n128 = ctx->n128, n64 = ctx->n64, rtot = ctx->rtot;
@@ -296,7 +297,9 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if ((rc = dev_alloc(ctx, &ctx->d_wk, (size_t)nb * ctx->nsys * ctx->rtot_wk * n64))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_dinv, rg_chol_ws_doubles((size_t)nb * ctx->nsys, n64)))) return rc;
   if (ctx->loocv) {
-    if ((rc = dev_alloc(ctx, &ctx->d_gt, (size_t)nb * Np * n64))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_gt, (size_t)nb * ctx->loo_chunk * n64))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_zt, (size_t)nb * ctx->loo_chunk * n64))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->d_triws, rg_loocv_tri_ws_doubles(nb, n64, P, R0)))) return rc;
     if ((rc = dev_alloc(ctx, &ctx->d_lpart, (size_t)2 * nb * R0 * P * 64))) return rc;
   }
   if ((rc = dev_alloc(ctx, &ctx->d_beta, (size_t)nb * nseg * R0 * P * n64))) return rc;
@@ -499,11 +502,11 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     la.W = rg_w_base(ctx);
     {
       StageTimer t(ctx, &ctx->tm.ms_chol);
-      rg_launch_decode_gt(st, la);
-      rg_launch_chol_solve_formed_x(st, ctx->d_sum, msz, ctx->d_fold, msz, 1, ctx->d_lambda, R0, ctx->d_bs, 0, nblk,
-                                    ctx->d_wk, ctx->rtot_wk * n64, n64, (int)(ctx->rtot_wk - n64), 0, ctx->d_dinv,
-                                    ctx->d_info + 1, &ctx->tm.n_chol_launches, 0, ctx->d_gt,
-                                    (int64_t)ctx->Np * n64, rtot, 1, 0, -1, 0);
+      int max_bs = 0;
+      for (int b = 0; b < nblk; ++b) max_bs = std::max(max_bs, (int)bs[b]);
+      const int rcl = rg_l0_loocv_tri(ctx, st, la, max_bs, ctx->d_sum, rtot, ctx->d_triws, ctx->d_zt, ctx->loo_chunk,
+                                      [&](int64_t pos0, int64_t len) { la.gt_pos0 = pos0; la.gt_len = len; rg_launch_decode_gt(st, la); });
+      if (rcl) return rcl;
     }
     {
       StageTimer t(ctx, &ctx->tm.ms_pred);

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -47,7 +48,10 @@ struct rg_ctx {
   bool loocv = false;            // cv_folds == 0: leave-one-out CV, one sample segment
   int64_t rtot_wk = 0;           // rows of one ridge system workspace (LOOCV: + Np appended sample rows)
   int nsys = 0;                  // systems per block: K*R0 (K-fold) or R0 (LOOCV)
-  double* d_gt = nullptr;        // [nblk][Np][n64] standardised genotypes, sample-major (LOOCV)
+  double* d_gt = nullptr;        // [nblk][loo_chunk][n64] standardised genotypes of a chunk of samples, sample-major (LOOCV)
+  double* d_zt = nullptr;        // [nblk][n64][loo_chunk] their transforms Q^T g~ (loocv_tri.hip)
+  double* d_triws = nullptr;     // tridiagonal reductions of a batch: A, Q^T, d, e, step vectors, recurrence tables
+  int64_t loo_chunk = 0;
   double* d_lpart = nullptr;     // LOOCV standardisation partial sums
 
   // problem
@@ -304,7 +308,12 @@ struct LoocvArgs {
   const uint8_t* pk; const double* mu; const double* sc; const double* Bm; const double* V;
   const double* maskp; const double* neff; const int32_t* bs; const int32_t* blockid;
   const double* wk; double* gt; double* W;
+  int64_t gt_pos0 = 0, gt_len = 0;   // the chunk of sample positions k_decode_gt fills (gt: [nblk][gt_len][n64])
 };
+// loocv_tri.hip: the leave-one-out predictors of a batch of assembled blocks through one tridiagonal reduction per block
+size_t rg_loocv_tri_ws_doubles(int nblk, int n64, int P, int R0);
+int rg_l0_loocv_tri(rg_ctx* ctx, hipStream_t st, const LoocvArgs& la, int max_bs, const double* d_sum, int rtot, double* ws, double* zt,
+                    int64_t chunk, const std::function<void(int64_t, int64_t)>& gt_chunk);
 void rg_launch_decode_gt(hipStream_t st, const LoocvArgs& a);
 void rg_launch_l0_loocv(hipStream_t st, const LoocvArgs& a, double* part0, double* part1, int nchunk);
 // l1.hip: fold Grams of a row-major matrix with the level-1 Gram kernel (64x64 tile per wave)

@@ -57,7 +57,10 @@ def test_gram_i8_asymmetric_layout():
     assert np.array_equal(Cd.cpu().numpy(), ga.astype(np.int32) @ gb.astype(np.int32).T)
 
 
-@pytest.mark.parametrize("m,n,k", [(64, 64, 64), (128, 192, 640), (256, 64, 4096)])
+@pytest.mark.parametrize("m,n,k", [(64, 64, 64), (128, 192, 640), (256, 64, 4096),
+                                   # the LDS-staged kernel (k_dgemm_nt128): whole macro tiles, 64-row remainders in both dimensions, many super tiles,
+                                   # more than eight macro-tile rows (two super-tile rows per XCD pass); the entry point takes K in multiples of 64
+                                   (128, 128, 64), (192, 320, 1088), (1024, 8192, 1024), (2688, 1280, 2688), (1152, 4160, 192)])
 def test_dgemm_nt(m, n, k):
     lib = load_library()
     rng = np.random.default_rng(5)
