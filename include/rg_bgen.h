@@ -27,6 +27,7 @@ typedef struct rg_bgen rg_bgen;
 #define RG_BGEN_ERR_ARG (-1)
 #define RG_BGEN_ERR_FORMAT (-2)      /* not a bgen file, malformed or truncated, inflate failure */
 #define RG_BGEN_ERR_UNSUPPORTED (-3) /* layout 1, phased / non-8-bit / multiallelic / non-diploid data */
+#define RG_BGEN_ERR_DEVICE (-4)      /* device path: no MI355X / HIP device, or a HIP call failed */
 
 int rg_bgen_open(rg_bgen** out, const char* path); /* parses the header and scans the variant identifying data */
 void rg_bgen_close(rg_bgen* h);
@@ -60,6 +61,48 @@ int rg_bgen_read_dosages_info(rg_bgen* h, int64_t n, const int64_t* variant_idx,
  * calling thread's own last message). */
 int rg_bgen_block_bytes(const rg_bgen* h, int64_t* bytes);
 int rg_bgen_read_blocks(rg_bgen* h, int64_t n, const int64_t* variant_idx, uint8_t* blocks, int64_t block_stride, int32_t n_threads);
+
+
+/* ---- device path (csrc/bgen_inflate.hip): inflate + walk of parseSnpfromBGEN (Geno.cpp:2186-2330) on the GPU ----------------------------
+ * The host reads the STORED bytes only; the zlib streams of a batch of variants are inflated one per wavefront (k_bgen_inflate), checked
+ * (header fields, Adler-32) and walked into uint16 dosage rows in units of 1 / 255 (0xFFFF = missing) -- the input of rg_s2_qt_block_int /
+ * rg_s2_bt_score_int with g_on_device = 1 -- and the allele / info sums as exact integers.  zlib-compressed files only.
+ *
+ * rg_bgen_compressed_bytes   size of the buffer rg_bgen_read_compressed needs for these variants
+ * rg_bgen_read_compressed    stream k at dst + off[k] (a multiple of 16), clen[k] bytes, inflating to ulen[k] bytes (the file's own field);
+ *                            n_threads workers (0: as set by rg_bgen_set_threads).  The handle is only read. */
+int rg_bgen_compressed_bytes(const rg_bgen* h, int64_t n, const int64_t* variant_idx, int64_t* bytes);
+int rg_bgen_read_compressed(rg_bgen* h, int64_t n, const int64_t* variant_idx, uint8_t* dst, int64_t cap, int64_t* off, int32_t* clen,
+                            int32_t* ulen, int32_t n_threads);
+
+typedef struct rg_bgen_dev rg_bgen_dev;     /* a decoder on one GPU: its own stream, two slots of buffers (a batch can be decoded while the
+                                             * previous one is being tested) */
+int rg_bgen_dev_create(rg_bgen_dev** out, int32_t device);
+void rg_bgen_dev_destroy(rg_bgen_dev* d);
+const char* rg_bgen_dev_last_error(const rg_bgen_dev* d);
+/* The samples of the rows: file_idx[k] = position in the file of analysed sample k (NULL: the n_file samples in file order, n = n_file);
+ * mask: [P][n] bytes, 1 = trait p is observed for sample k (NULL or P = 0: no per-trait sums). */
+int rg_bgen_dev_set_samples(rg_bgen_dev* d, int64_t n_file, int64_t n, const int64_t* file_idx, int32_t P, const uint8_t* mask);
+/* What a batch leaves behind.  The host arrays may be NULL (not wanted); g16 / raw are DEVICE pointers owned by the decoder, valid until the
+ * next call on the same slot.  Sums run over the analysed samples whose genotype is not missing:
+ *   sum_q = sum q_i (q = b1 + 2 b0, or b1 + 2 max(255 - b0 - b1, 0) with ref_first: the dosage x 255);
+ *   sum_info = sum 255 (4 bX + b1) - q^2 (the IMPUTE-info numerator x 65025);  n_obs;  max_q (above 510: prob0 + prob1 > 1 in the file);
+ *   *_t [nvar][P]: the same over the samples MISSING for trait p (what parseSnpfromBGEN's per-trait sums leave out);
+ *   status: 0 = the stream inflated to the stated size, its Adler-32 matches and the block is layout 2 / 2 alleles / ploidy 2 / unphased /
+ *   8 bits; anything else (the values are the decoder's own) marks a variant the caller must read through the host route. */
+typedef struct rg_bgen_dev_out {
+  const uint16_t* g16; int64_t ld16;
+  const uint8_t* raw; int64_t raw_stride;
+  int64_t* sum_q; int64_t* sum_info; int64_t* n_obs; int32_t* max_q;
+  int64_t* sum_q_t; int64_t* sum_info_t; int64_t* n_obs_t;
+  int32_t* status;
+} rg_bgen_dev_out;
+/* comp: host buffer holding the streams (as rg_bgen_read_compressed left them; page-locked memory makes the copy asynchronous);
+ * blocks until the batch is decoded. */
+int rg_bgen_dev_decode(rg_bgen_dev* d, int32_t slot, int32_t nvar, const uint8_t* comp, int64_t comp_bytes, const int64_t* off,
+                       const int32_t* clen, const int32_t* ulen, int32_t ref_first, rg_bgen_dev_out* out);
+/* copies n bytes from a device pointer of rg_bgen_dev_out to the host (tests: the inflated blocks, the dosage rows) */
+int rg_bgen_dev_fetch(rg_bgen_dev* d, const void* device_ptr, void* dst, int64_t n);
 
 #ifdef __cplusplus
 }

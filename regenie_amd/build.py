@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "librg_step1_hip.so")
-SOURCES = ["rg_api.hip", "bed_prep.hip", "gram_i8.hip", "gram_fp4.hip", "assemble.hip", "chol.hip", "pred.hip", "l1.hip", "ubench.hip", "loocv.hip", "loocv_tri.hip", "l1x.hip", "l0_f64.hip", "step2_qt.hip", "step2_bt.hip", "rg_group.hip", "pred_i8.hip", "xy_i8.hip", "wgram_bf16.hip",
+SOURCES = ["rg_api.hip", "bed_prep.hip", "gram_i8.hip", "gram_fp4.hip", "assemble.hip", "chol.hip", "pred.hip", "l1.hip", "ubench.hip", "loocv.hip", "loocv_tri.hip", "l1x.hip", "l0_f64.hip", "step2_qt.hip", "step2_bt.hip", "rg_group.hip", "pred_i8.hip", "xy_i8.hip", "wgram_bf16.hip", "bgen_inflate.hip",
            "pgen_api.cpp", "bgen_api.cpp"]  # host-only: .pgen input (include/rg_pgen.h), BGEN v1.2 input (include/rg_bgen.h)
 HOST_SOURCES = ["driver_common.cpp", "driver_models.cpp", "driver_inputs.cpp", "driver_step2.cpp", "driver_step1.cpp", "driver_main.cpp"]  # regenie-amd (host/driver.h)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -160,6 +160,65 @@ int rg_bgen_read_blocks(rg_bgen* h, int64_t n, const int64_t* variant_idx, uint8
     if (!e.empty()) return fail(h, classify(e), e);
   return RG_BGEN_OK;
 }
+
+// ---- the stored zlib streams of a batch of variants, for the device decoder (bgen_inflate.hip) ----------------------------------
+// Stream k lands at dst + off[k] (16-byte aligned offsets), clen[k] bytes long, inflating to ulen[k] bytes.  Variants that follow each other in
+// the file are fetched as one range per worker (their identifying data, a few dozen bytes each, comes along and is skipped).
+int rg_bgen_compressed_bytes(const rg_bgen* h, int64_t n, const int64_t* variant_idx, int64_t* bytes) {
+  if (!h || !h->ok || n < 0 || (n > 0 && !variant_idx) || !bytes) return RG_BGEN_ERR_ARG;
+  int64_t tot = 0;
+  for (int64_t k = 0; k < n; ++k) {
+    if (variant_idx[k] < 0 || variant_idx[k] >= (int64_t)h->rd.n_variants()) return RG_BGEN_ERR_ARG;
+    tot += ((int64_t)h->rd.variants()[(size_t)variant_idx[k]].csize + 15) / 16 * 16 + 16;
+  }
+  *bytes = tot + 64;
+  return RG_BGEN_OK;
+}
+
+int rg_bgen_read_compressed(rg_bgen* h, int64_t n, const int64_t* variant_idx, uint8_t* dst, int64_t cap, int64_t* off, int32_t* clen,
+                            int32_t* ulen, int32_t n_threads) {
+  if (!h) return RG_BGEN_ERR_ARG;
+  if (!h->ok) return fail(h, RG_BGEN_ERR_ARG, "bgen file is not open");
+  if (n < 0 || (n > 0 && (!variant_idx || !dst || !off || !clen || !ulen))) return fail(h, RG_BGEN_ERR_ARG, "rg_bgen_read_compressed: bad argument");
+  if (h->rd.compression() != 1) return fail(h, RG_BGEN_ERR_UNSUPPORTED, "rg_bgen_read_compressed: the device decoder takes zlib-compressed files (others are not supported here)");
+  int64_t at = 0;
+  for (int64_t k = 0; k < n; ++k) {
+    if (variant_idx[k] < 0 || variant_idx[k] >= (int64_t)h->rd.n_variants())
+      return fail(h, RG_BGEN_ERR_ARG, "variant index " + std::to_string(variant_idx[k] + 1) + " is out of range");
+    const rgbgen::Variant& v = h->rd.variants()[(size_t)variant_idx[k]];
+    if (v.csize < 4 + 6) return fail(h, RG_BGEN_ERR_FORMAT, "failed to decompress genotype data block for variant: " + v.rsid);
+    // the record is placed so that its stream (8 bytes into it: block length, inflated length) starts at a multiple of 16
+    off[k] = at + 16;
+    clen[k] = (int32_t)(v.csize - 4);
+    at = off[k] + ((int64_t)clen[k] + 15) / 16 * 16;
+  }
+  if (at + 64 > cap) return fail(h, RG_BGEN_ERR_ARG, "rg_bgen_read_compressed: the buffer is smaller than rg_bgen_compressed_bytes");
+  const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? std::min<int32_t>(n_threads, 256) : h->threads, n));
+  std::vector<std::string> errs((size_t)nt);
+  std::atomic<int64_t> next(0);
+  auto work = [&](int t) {
+    for (int64_t k; (k = next.fetch_add(1)) < n;) {
+      const rgbgen::Variant& v = h->rd.variants()[(size_t)variant_idx[k]];
+      // [data, data + 4) block length, [data + 4, data + 8) inflated length, then the stream
+      uint8_t* rec = dst + off[k] - 8;
+      if (!h->rd.read_raw(v.data, 4ull + v.csize, rec)) { errs[(size_t)t] = "cannot read bgen file"; next = n; return; }
+      uint32_t d;
+      std::memcpy(&d, rec + 4, 4);
+      if (d > 64 + 16 * (uint64_t)h->rd.n_samples()) { errs[(size_t)t] = "genotype data block of variant " + v.rsid + " is larger than any biallelic diploid block of " + std::to_string(h->rd.n_samples()) + " samples"; next = n; return; }
+      ulen[k] = (int32_t)d;
+    }
+  };
+  if (nt == 1) work(0);
+  else {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+  }
+  for (const auto& e : errs)
+    if (!e.empty()) return fail(h, classify(e), e);
+  return RG_BGEN_OK;
+}
 }  // extern "C"
 
 static int read_rows(rg_bgen* h, int64_t n, const int64_t* variant_idx, int32_t ref_first, double* rows, double* info_rows, int64_t row_stride) {

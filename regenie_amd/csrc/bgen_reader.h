@@ -30,6 +30,7 @@ namespace rgbgen {
 struct Variant {
   uint64_t offset;   // file offset of the variant identifying data (what regenie keeps in snpinfo[].offset)
   uint64_t data;     // file offset of the genotype data block (its 4-byte length field)
+  uint32_t csize;    // that length field: bytes of the block after it (compressed files: 4 bytes of inflated length + the stream)
   uint32_t position;
   std::string id, rsid, chrom, a0, a1;
 };
@@ -146,11 +147,15 @@ class Reader {
       v.data = pos;
       uint32_t c;
       std::memcpy(&c, fetch(pos, 4), 4);
+      v.csize = c;
       pos += 4ull + c;
       if (pos > fsize_) throw std::runtime_error("bgen file ends inside the data of variant '" + v.rsid + "' : " + path);
       vars_.push_back(std::move(v));
     }
   }
+
+  // Bytes [at, at + len) of the file as they are (the device path ships the stored zlib streams: csrc/bgen_inflate.hip)
+  bool read_raw(uint64_t at, uint64_t len, void* dst) const { return fd_ >= 0 && at + len <= fsize_ && pread_all(dst, len, at); }
 
   // The inflated, checked probability block of variant j (layout 2: N, K, min / max ploidy, N ploidy-and-missingness bytes, phased flag,
   // bits, 2 N probability bytes), in `dst` when it is given (capacity `cap` >= block_bytes()) or in `ubuf`; returns its first byte.

@@ -68,6 +68,9 @@ EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_set
            # include/rg_bgen.h (host-side BGEN v1.2 input; wrapped by regenie_amd/bgen.py)
            "rg_bgen_open", "rg_bgen_close", "rg_bgen_last_error", "rg_bgen_info", "rg_bgen_sample_id", "rg_bgen_variant",
            "rg_bgen_set_threads", "rg_bgen_read_dosages", "rg_bgen_read_dosages_info", "rg_bgen_block_bytes", "rg_bgen_read_blocks",
+           # its device path (csrc/bgen_inflate.hip): the stored zlib streams, inflated and walked on the GPU
+           "rg_bgen_compressed_bytes", "rg_bgen_read_compressed", "rg_bgen_dev_create", "rg_bgen_dev_destroy", "rg_bgen_dev_last_error",
+           "rg_bgen_dev_set_samples", "rg_bgen_dev_decode", "rg_bgen_dev_fetch",
            # include/rg_step2.h (Step-2 QT score test; wrapped by regenie_amd/step2.py)
            "rg_s2_create", "rg_s2_destroy", "rg_s2_last_error", "rg_s2_set_null", "rg_s2_qt_block", "rg_s2_qt_block_packed", "rg_s2_qt_block_int", "rg_s2_set_sparse_rule", "rg_s2_set_columns", "rg_s2_contract_packed", "rg_s2_contract_int", "rg_s2_bt_set_null", "rg_s2_bt_score_packed", "rg_s2_bt_score_int", "rg_s2_bt_correct",
            "rg_s2_last_kernel_ms"]
@@ -180,6 +183,16 @@ def load_library() -> C.CDLL:
     lib.rg_bgen_read_dosages_info.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64]
     lib.rg_bgen_block_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.rg_bgen_read_blocks.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]
+    lib.rg_bgen_compressed_bytes.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
+    lib.rg_bgen_read_compressed.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.rg_bgen_dev_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
+    lib.rg_bgen_dev_destroy.argtypes = [C.c_void_p]
+    lib.rg_bgen_dev_destroy.restype = None
+    lib.rg_bgen_dev_last_error.argtypes = [C.c_void_p]
+    lib.rg_bgen_dev_last_error.restype = C.c_char_p
+    lib.rg_bgen_dev_set_samples.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.rg_bgen_dev_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.rg_bgen_dev_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.rg_pgen_read_bed_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64]
     lib.rg_pgen_read_hardcalls.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     lib.rg_pgen_set_threads.argtypes = [C.c_void_p, C.c_int32]

@@ -169,6 +169,11 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     bool integral = false;
     double ms_inflate = 0, ms_walk = 0, ms_wall = 0;
     std::string err;
+    // device route (csrc/bgen_inflate.hip): the stored zlib streams in page-locked memory, the dosage rows left in device memory
+    int64_t g16_rows = 0;                    // rows the pinned buffer holds (the host route's; allocated when that route is first taken)
+    uint8_t* comp = nullptr; int64_t comp_cap = 0;
+    const uint16_t* g16_dev = nullptr; int64_t ld_dev = 0;
+    double ms_read = 0, ms_dev = 0;
   };
   const int64_t ld16 = (n + 7) / 8 * 8;
   // host threads of the read-ahead: inflate is the bound of this input (about 10 ms per 1.5 MB block and thread with zlib), so it takes
@@ -177,6 +182,12 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
                                                     : std::max(1, std::min(p.threads > 0 ? p.threads : usable_cpus(), 256) / part.nparts);
   const bool fast_bgen = in == In::Dosage && r.bgenh && (!dense_route || glm) && !(correct && !spa && !p.firth_approx) && !getenv("RG_S2_BGEN_ROWS");
   DosPrep preps[2];
+  // BGEN inflate + byte walk on the GPU (default for zlib files; RG_S2_BGEN_HOST=1 keeps the host threads' route, which also takes every
+  // block the device decoder flags: a damaged stream, another encoding).  The decoder has its own stream: it works on the next block while
+  // the scoring kernels of the current one run.
+  rg_bgen_dev* bdev = nullptr;
+  int64_t n_dev_blocks = 0, n_host_blocks = 0;
+  double ms_dev_read = 0, ms_dev_decode = 0;
   struct BlkRef { const std::vector<int64_t>* snps; int64_t j0; int bs; };
   std::vector<BlkRef> my_blocks;             // this part's blocks in the order they are tested
   size_t my_next = 0;
@@ -185,9 +196,14 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
   if (fast_bgen) {
     if (rg_bgen_block_bytes(r.bgenh, &bgen_block_bytes) != RG_BGEN_OK) throw std::runtime_error(rg_bgen_last_error(r.bgenh));
     bgen_block_bytes = (bgen_block_bytes + 63) / 64 * 64;
-    for (auto& d : preps) {
-      d.g16 = (uint16_t*)rg_host_alloc((size_t)p.bsize * ld16 * sizeof(uint16_t));
-      if (!d.g16) throw std::runtime_error("cannot allocate the pinned dosage buffers");
+    int32_t bcomp = 0;
+    rg_bgen_info(r.bgenh, nullptr, nullptr, &bcomp, nullptr);
+    if (bcomp == 1 && !getenv("RG_S2_BGEN_HOST") && rg_bgen_dev_create(&bdev, part.device) == RG_BGEN_OK) {
+      const bool per_trait = any_missing || glm;
+      if (rg_bgen_dev_set_samples(bdev, r.n_file, n, identity ? nullptr : file_idx.data(), per_trait ? P : 0, per_trait ? Mc.data() : nullptr) != RG_BGEN_OK) {
+        rg_bgen_dev_destroy(bdev);
+        bdev = nullptr;
+      }
     }
     int b = 0;
     for (int chrom : r.chr_read) {
@@ -199,13 +215,93 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
           my_blocks.push_back({&sn, (int64_t)bb * p.bsize, (int)std::min<int64_t>(p.bsize, (int64_t)sn.size() - (int64_t)bb * p.bsize)});
     }
   }
+  // The device decoder works on one stream per wavefront and needs thousands of them in flight: the blocks of a chromosome are prepared in
+  // groups of >= RG_S2_BGEN_GROUP variants (default 3,072 = the streams the GPU holds at once) whatever --bsize is; the host route keeps
+  // one block per group.  A group is a range of the chromosome's variants, i.e. a BlkRef of its own.
+  struct Group { BlkRef ref; size_t first_block; };
+  std::vector<Group> groups;
+  std::vector<std::pair<size_t, int>> block_group;      // per block of my_blocks: its group, its first row there
+  if (fast_bgen) {
+    const int target = bdev ? std::max(p.bsize, getenv("RG_S2_BGEN_GROUP") ? atoi(getenv("RG_S2_BGEN_GROUP")) : 3072) : p.bsize;
+    for (size_t b = 0; b < my_blocks.size(); ++b) {
+      const BlkRef& br = my_blocks[b];
+      if (!groups.empty()) {
+        Group& g = groups.back();
+        if (g.ref.snps == br.snps && g.ref.j0 + g.ref.bs == br.j0 && g.ref.bs + br.bs <= target) {
+          block_group.push_back({groups.size() - 1, g.ref.bs});
+          g.ref.bs += br.bs;
+          continue;
+        }
+      }
+      groups.push_back({br, b});
+      block_group.push_back({groups.size() - 1, 0});
+    }
+  }
   static const struct T255 { double v[256]; T255() { for (int b = 0; b < 256; ++b) v[b] = b / 255.0; } } t255;   // the reader's prob = byte / 255.0
-  auto prepare = [&](const BlkRef& br, DosPrep& d) {
+  // the device route of a block: false = not taken (no decoder, or a variant the decoder flagged: the host route then gives the reference's verdict)
+  auto prepare_dev = [&](const BlkRef& br, DosPrep& d, int slot, const std::vector<int64_t>& vi) -> bool {
+    if (!bdev) return false;
+    const int bs = br.bs;
+    auto t0 = std::chrono::steady_clock::now();
+    int64_t need = 0;
+    if (rg_bgen_compressed_bytes(r.bgenh, bs, vi.data(), &need) != RG_BGEN_OK) return false;
+    if (d.comp_cap < need) {
+      if (d.comp) rg_host_free(d.comp);
+      d.comp_cap = need + need / 4;
+      d.comp = (uint8_t*)rg_host_alloc((size_t)d.comp_cap);
+      if (!d.comp) { d.comp_cap = 0; return false; }
+    }
+    std::vector<int64_t> off(bs);
+    std::vector<int32_t> clen(bs), ulen(bs), status(bs), maxq(bs);
+    if (rg_bgen_read_compressed(r.bgenh, bs, vi.data(), d.comp, d.comp_cap, off.data(), clen.data(), ulen.data(), std::min(nt_prep, 32)) != RG_BGEN_OK) return false;
+    auto t1 = std::chrono::steady_clock::now();
+    const bool per_trait = any_missing || glm;
+    std::vector<int64_t> sq(bs), si(bs), no(bs), sqt, sit, nt;
+    if (per_trait) { sqt.resize((size_t)bs * P); sit.resize((size_t)bs * P); nt.resize((size_t)bs * P); }
+    rg_bgen_dev_out o;
+    memset(&o, 0, sizeof(o));
+    o.sum_q = sq.data(); o.sum_info = si.data(); o.n_obs = no.data(); o.max_q = maxq.data(); o.status = status.data();
+    if (per_trait) { o.sum_q_t = sqt.data(); o.sum_info_t = sit.data(); o.n_obs_t = nt.data(); }
+    if (rg_bgen_dev_decode(bdev, slot, bs, d.comp, off[bs - 1] + clen[bs - 1], off.data(), clen.data(), ulen.data(), p.ref_first ? 1 : 0, &o) != RG_BGEN_OK) return false;
+    for (int j = 0; j < bs; ++j) if (status[j] != 0) return false;
+    d.total.assign(bs, 0.0); d.info_num.assign(bs, 0.0); d.ns1.assign(bs, 0); d.ignored.assign(bs, 0);
+    if (per_trait) { d.af_t.assign((size_t)bs * P, 0.0); d.ns_t.assign((size_t)bs * P, 0); d.info_t.assign((size_t)bs * P, 0.0); }
+    bool bad = false;
+    for (int j = 0; j < bs; ++j) {
+      // the walk's exact integer sums in the units the host route accumulates as doubles: dosages in 1 / 255, info terms in 1 / 65025
+      d.total[j] = (double)sq[j] / 255.0; d.info_num[j] = (double)si[j] / 65025.0; d.ns1[j] = no[j];
+      if (maxq[j] > 510) bad = true;
+      if (std::min(d.total[j], 2.0 * d.ns1[j] - d.total[j]) < p.min_mac) d.ignored[j] = 1;      // compute_mac (Geno.cpp:3077-3108), autosomes
+      if (per_trait)
+        for (int q = 0; q < P; ++q) {      // the host route SUBTRACTS what the samples missing for trait q contribute
+          d.af_t[(size_t)j * P + q] = -(double)sqt[(size_t)j * P + q] / 255.0;
+          d.ns_t[(size_t)j * P + q] = -nt[(size_t)j * P + q];
+          d.info_t[(size_t)j * P + q] = -(double)sit[(size_t)j * P + q] / 65025.0;
+        }
+    }
+    d.integral = !bad;
+    d.g16_dev = o.g16; d.ld_dev = o.ld16;
+    auto t2 = std::chrono::steady_clock::now();
+    d.ms_read = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    d.ms_dev = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    d.ms_inflate = 0; d.ms_walk = 0;
+    d.ms_wall = d.ms_read + d.ms_dev;
+    return true;
+  };
+  auto prepare = [&](const BlkRef& br, DosPrep& d, int slot) {
     try {
       const int bs = br.bs;
       auto ta = std::chrono::steady_clock::now();
       std::vector<int64_t> vi(bs);
       for (int j = 0; j < bs; ++j) vi[j] = r.snp_offset[(*br.snps)[br.j0 + j]];
+      d.g16_dev = nullptr; d.ms_read = d.ms_dev = 0;
+      if (prepare_dev(br, d, slot, vi)) return;
+      if (d.g16_rows < bs) {
+        if (d.g16) rg_host_free(d.g16);
+        d.g16 = (uint16_t*)rg_host_alloc((size_t)bs * ld16 * sizeof(uint16_t));
+        d.g16_rows = d.g16 ? bs : 0;
+        if (!d.g16) throw std::runtime_error("cannot allocate the pinned dosage buffers");
+      }
       d.raw.resize((size_t)nt_prep * bgen_block_bytes);        // one inflated block per worker: walked while it is still in that core's cache
       d.total.assign(bs, 0.0); d.info_num.assign(bs, 0.0); d.ns1.assign(bs, 0); d.ignored.assign(bs, 0);
       const bool per_trait = any_missing || glm;
@@ -266,8 +362,8 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     } catch (const std::exception& e) { d.err = e.what(); if (d.err.empty()) d.err = "bgen read failed"; }
   };
   std::future<void> prep_ahead;      // declared after everything `prepare` touches: its destructor waits for the worker before those go away
-  if (fast_bgen && !my_blocks.empty())      // the first block is inflated while the first chromosome's predictions are read
-    prep_ahead = std::async(std::launch::async, [&]() { prepare(my_blocks[0], preps[0]); });
+  if (fast_bgen && !groups.empty())      // the first group is inflated while the first chromosome's predictions are read
+    prep_ahead = std::async(std::launch::async, [&]() { prepare(groups[0].ref, preps[0], 0); });
   for (int chrom : r.chr_read) {
     if (!chr_snps.count(chrom)) continue;
     const std::vector<int64_t>& snps = chr_snps[chrom];
@@ -401,18 +497,25 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
       std::unique_lock<std::mutex> rlk(g_reader_mu, std::defer_lock);
       if (multi && in != In::Bed) rlk.lock();
       DosPrep* dp = nullptr;
+      int dp_row0 = 0;                 // the block's first row in its prepared group
       if (fast_bgen) {
         if (rlk.owns_lock()) rlk.unlock();      // (the prepared block took the reader's lock itself)
         auto tw = std::chrono::steady_clock::now();
-        DosPrep& d = preps[my_next & 1];
-        if (prep_ahead.valid()) prep_ahead.get();
-        else prepare(my_blocks[my_next], d);
-        if (my_next + 1 < my_blocks.size())
-          prep_ahead = std::async(std::launch::async, [&, nx = my_next + 1]() { prepare(my_blocks[nx], preps[nx & 1]); });
+        const size_t gi = block_group[my_next].first;
+        dp_row0 = block_group[my_next].second;
+        DosPrep& d = preps[gi & 1];
+        if (groups[gi].first_block == my_next) {      // first block of its group: the group has to be ready, the next one is started
+          if (prep_ahead.valid()) prep_ahead.get();
+          else prepare(groups[gi].ref, d, (int)(gi & 1));
+          if (gi + 1 < groups.size())
+            prep_ahead = std::async(std::launch::async, [&, nx = gi + 1]() { prepare(groups[nx].ref, preps[nx & 1], (int)(nx & 1)); });
+          if (!d.err.empty()) { if (prep_ahead.valid()) prep_ahead.wait(); throw std::runtime_error(d.err); }
+          ms_inflate += d.ms_inflate; ms_walk += d.ms_walk; ms_prep_wall += d.ms_wall;
+          if (d.g16_dev) { ms_dev_read += d.ms_read; ms_dev_decode += d.ms_dev; }
+        }
         ++my_next;
-        if (!d.err.empty()) { if (prep_ahead.valid()) prep_ahead.wait(); throw std::runtime_error(d.err); }
         ms_prep_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
-        ms_inflate += d.ms_inflate; ms_walk += d.ms_walk; ms_prep_wall += d.ms_wall;
+        if (d.g16_dev) ++n_dev_blocks; else ++n_host_blocks;
         if (d.integral) dp = &d;
       }
       if (in == In::PgenHard) {   // ReadHardcalls per variant (Geno.cpp:2570-2573), as .bed-coded rows (00 = two ALT copies)
@@ -451,10 +554,19 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
       const int dscale = r.bgenh ? 255 : 16384;
       const uint16_t* g16p = nullptr;
       int64_t g16ld = n;
+      int g16_on_device = 0;
       if (dp) {      // the block the host threads prepared ahead
-        total.swap(dp->total); ns1.swap(dp->ns1); info_num.swap(dp->info_num); variant_ignored.swap(dp->ignored);
-        if (any_missing || glm) { af_t.swap(dp->af_t); ns_t.swap(dp->ns_t); info_t.swap(dp->info_t); }
-        integral = true; g16p = dp->g16; g16ld = ld16;
+        const size_t r0 = (size_t)dp_row0;
+        total.assign(dp->total.begin() + r0, dp->total.begin() + r0 + bs); ns1.assign(dp->ns1.begin() + r0, dp->ns1.begin() + r0 + bs);
+        info_num.assign(dp->info_num.begin() + r0, dp->info_num.begin() + r0 + bs);
+        variant_ignored.assign(dp->ignored.begin() + r0, dp->ignored.begin() + r0 + bs);
+        if (any_missing || glm) {
+          af_t.assign(dp->af_t.begin() + r0 * P, dp->af_t.begin() + (r0 + bs) * P); ns_t.assign(dp->ns_t.begin() + r0 * P, dp->ns_t.begin() + (r0 + bs) * P);
+          info_t.assign(dp->info_t.begin() + r0 * P, dp->info_t.begin() + (r0 + bs) * P);
+        }
+        integral = true; g16ld = dp->g16_dev ? dp->ld_dev : ld16;
+        g16p = (dp->g16_dev ? dp->g16_dev : dp->g16) + r0 * (size_t)g16ld;
+        g16_on_device = dp->g16_dev ? 1 : 0;
       } else if (in == In::Dosage) {
         // dosages: the analysed samples' doubles, allele totals, the info-score numerator and the per-trait corrections on the host
         // (parseSnpfromBGEN / readChunkFromPGENFileToG with update_trait_counts, Geno.cpp:2948-2959), the test on the fp64 route
@@ -520,7 +632,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
         if (in == In::Dosage) {
           if (!integral) throw std::runtime_error("--step 2 --bt / --ct on dosages that are not integer multiples of 1/" + std::to_string(dscale) + " is not built.");
           bo.vstat = bt_vstat.data();
-          s2check(rg_s2_bt_score_int(s2, g16p, g16ld, bs, 0, dscale, NUMTOL, &bo));
+          s2check(rg_s2_bt_score_int(s2, g16p, g16ld, bs, g16_on_device, dscale, NUMTOL, &bo));
         } else {
           if (!identity) {
             ld = (n + 3) / 4;
@@ -616,7 +728,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
           });
         }
       } else if (in == In::Dosage) {
-        if (integral) s2check(rg_s2_qt_block_int(s2, g16p, g16ld, bs, 0, dscale, NUMTOL, &o));
+        if (integral) s2check(rg_s2_qt_block_int(s2, g16p, g16ld, bs, g16_on_device, dscale, NUMTOL, &o));
         else s2check(rg_s2_qt_block(s2, G.data(), n, bs, 0, NUMTOL, &o));
       } else if (!dense_route) {
         // hard calls stay packed: the 2-bit codes of the analysed samples go to the device as they are (the rows of the file itself
@@ -750,7 +862,14 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     }
   }
   if (prep_ahead.valid()) prep_ahead.wait();
-  for (auto& d : preps) if (d.g16) rg_host_free(d.g16);
+  if (prep_ahead.valid()) prep_ahead.wait();
+  for (auto& d : preps) { if (d.g16) rg_host_free(d.g16); if (d.comp) rg_host_free(d.comp); }
+  if (bdev) {
+    if (getenv("RG_TIMING"))
+      fprintf(stderr, "[timing] step 2 part %d: BGEN on the device: %lld blocks (%lld on the host route) | reading the stored streams %.0f ms | copy + inflate + walk on the GPU %.0f ms (both overlapped with the tests of the previous block)\n",
+              part.part, (long long)n_dev_blocks, (long long)n_host_blocks, ms_dev_read, ms_dev_decode);
+    rg_bgen_dev_destroy(bdev);
+  }
   if (getenv("RG_TIMING"))
     fprintf(stderr, "[timing] step 2 part %d: host threads %d (read-ahead %d) | chromosome set-up %.0f ms | waiting for the prepared block %.0f ms (preparing: %.0f ms wall, overlapped; %.0f thread-ms inflate + %.0f thread-ms byte walk) | "
             "upload + device + results %.0f ms | formatting + writing %.0f ms\n", part.part, nthreads, nt_prep, ms_chr, ms_prep_wait, ms_prep_wall, ms_inflate, ms_walk, ms_device, ms_format);

@@ -220,3 +220,20 @@ def test_short_lived_reader_threads_do_not_leak(example_dir):
             f.read_blocks(idx)
         grown = psutil.Process().memory_info().rss - rss0
     assert grown < 20 << 20, grown
+
+
+def test_read_compressed_hands_out_the_stored_streams(example_dir):
+    """rg_bgen_read_compressed (what the device decoder is fed): every stream sits at a 16-byte aligned offset and zlib inflates it to the block
+    rg_bgen_read_blocks returns; a zstd file is refused (the device decoder takes zlib)."""
+    import zlib
+    with BgenFile(os.path.join(example_dir, "example.bgen"), threads=3) as f:
+        idx = np.array([0, 1, 2, 500, 999, 7])
+        buf, off, clen, ulen = f.read_compressed(idx, threads=3)
+        blk = f.read_blocks(idx)
+        assert (off % 16 == 0).all() and (ulen == blk.shape[1]).all()
+        for k in range(idx.size):
+            assert zlib.decompress(buf[off[k]:off[k] + clen[k]].tobytes()) == blk[k].tobytes()
+    with BgenFile(os.path.join(example_dir, "example_3chr_zstd.bgen")) as f:
+        with pytest.raises(Exception) as e:
+            f.read_compressed([0])
+        assert "zlib" in str(e.value)

@@ -91,11 +91,13 @@ def run(N=500000, M=100000, MREF=2000, P=10, C=10, bsizes=(400, 1000), ref_threa
         fh.write("".join("%d\ts%d\t0\t%d\tA\tG\n" % (j // 100 + 1, j, j + 1) for j in range(ms1)))
     with open(D + "/s.fam", "w") as fh:
         fh.write("".join("%d %d 0 0 0 -9\n" % (i + 1, i + 1) for i in range(N)))
-    chroms = [j * 22 // M + 1 for j in range(M)]
+    nchr = int(os.environ.get("BGEN_E2E_NCHR", "22"))       # chromosomes the variants are spread over (10 M variants over 22: 450,000 each; a bounded
+    chroms = [j * nchr // M + 1 for j in range(M)]           # sample keeps whole blocks per chromosome with fewer of them)
+    rec["chromosomes"] = nchr
     tw = write_bgen(D + "/x.bgen", N, M, chroms, nproc)
     rec["file_gb"] = round(os.path.getsize(D + "/x.bgen") / 1e9, 2)
     say("x.bgen: %d samples x %d variants, %.1f GB, written in %.0f s by %d processes" % (N, M, rec["file_gb"], tw, nproc))
-    tw = write_bgen(D + "/r.bgen", N, MREF, [j * 22 // MREF + 1 for j in range(MREF)], nproc)
+    tw = write_bgen(D + "/r.bgen", N, MREF, [j * nchr // MREF + 1 for j in range(MREF)], nproc)
     say("r.bgen: the reference's bounded sample, %d variants, %.2f GB" % (MREF, os.path.getsize(D + "/r.bgen") / 1e9))
     here = os.path.dirname(os.path.abspath(__file__))
     exe = os.path.join(here, "..", "regenie_amd", "bin", "regenie-amd")
@@ -109,10 +111,12 @@ def run(N=500000, M=100000, MREF=2000, P=10, C=10, bsizes=(400, 1000), ref_threa
     cpu_max = open("/sys/fs/cgroup/cpu.max").read().strip() if os.path.exists("/sys/fs/cgroup/cpu.max") else "n/a"
     rec["host"] = {"hardware_threads": os.cpu_count(), "cgroup_cpu_max": cpu_max}
     say("host: %s hardware threads, cpu.max %s" % (os.cpu_count(), cpu_max))
+    if os.environ.get("BGEN_E2E_BSIZES"):
+        bsizes = tuple(int(b) for b in os.environ["BGEN_E2E_BSIZES"].split(","))
     variants = [("bsize %d" % b, b, {}) for b in bsizes]
-    for extra in os.environ.get("BGEN_E2E_VARIANTS", "").split(";"):          # e.g. "RG_S2_PREP_THREADS=64;RG_BGEN_ZLIB=1"
+    for extra in os.environ.get("BGEN_E2E_VARIANTS", "").split(";"):          # e.g. "RG_S2_BGEN_HOST=1;RG_S2_PREP_THREADS=64,RG_BGEN_ZLIB=1"
         if extra:
-            variants.append(("bsize 400 " + extra, 400, dict(kv.split("=") for kv in extra.split(","))))
+            variants.append(("bsize %d %s" % (bsizes[0], extra), bsizes[0], dict(kv.split("=") for kv in extra.split(","))))
     for name, bsz, env in variants:
         t0 = time.time()
         r = subprocess.run([exe] + common + ["--bgen", D + "/x.bgen", "--bsize", str(bsz), "--out", D + "/s2"], capture_output=True, text=True,
@@ -125,6 +129,10 @@ def run(N=500000, M=100000, MREF=2000, P=10, C=10, bsizes=(400, 1000), ref_threa
         run = {"name": name, "bsize": bsz, "wall_s": round(dt, 2), "variants_per_s": round(M / dt, 1), "variant_sample_pheno_per_s": M * N * P / dt}
         tm = re.search(r"read-ahead (\d+)\) \| chromosome set-up (\d+) ms \| waiting for the prepared block (\d+) ms \(preparing: (\d+) ms wall, overlapped; (\d+) thread-ms inflate "
                        r"\+ (\d+) thread-ms byte walk\) \| upload \+ device \+ results (\d+) ms \| formatting \+ writing (\d+) ms", r.stderr)
+        td = re.search(r"BGEN on the device: (\d+) blocks \((\d+) on the host route\) \| reading the stored streams (\d+) ms \| copy \+ inflate \+ walk on the GPU (\d+) ms", r.stderr)
+        if td:
+            run["bgen_on_device"] = {"blocks": int(td.group(1)), "blocks_on_host_route": int(td.group(2)), "read_streams_ms": int(td.group(3)),
+                                     "copy_inflate_walk_ms": int(td.group(4))}
         if tm:
             v = [int(x) for x in tm.groups()]
             run["shares_ms"] = {"host_threads_read_ahead": v[0], "chromosome_setup": v[1], "waiting_for_prepared_block": v[2], "prepare_wall_overlapped": v[3],
@@ -139,7 +147,7 @@ def run(N=500000, M=100000, MREF=2000, P=10, C=10, bsizes=(400, 1000), ref_threa
             % (name, dt, M / dt, M * N * P / dt, " | ".join(marks)))
     # the bounded sample: both programs, line by line
     t0 = time.time()
-    r = subprocess.run([exe] + common + ["--bgen", D + "/r.bgen", "--bsize", "400", "--out", D + "/r_amd"], capture_output=True, text=True)
+    r = subprocess.run([exe] + common + ["--bgen", D + "/r.bgen", "--bsize", str(bsizes[0]), "--out", D + "/r_amd"], capture_output=True, text=True)
     t_amd = time.time() - t0
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     if os.path.exists(ref):
@@ -172,7 +180,7 @@ def main(argv):
     js = None
     if argv and argv[0] == "--json":
         js, argv = argv[1], argv[2:]
-    kw = dict(bsizes=(400,), ref_threads=(16,)) if js else {}
+    kw = dict(bsizes=(2048,), ref_threads=(16,)) if js else {}
     rec = run(*[int(a) for a in argv], say=lambda s: print(s, flush=True), **kw)
     if js:
         import json
