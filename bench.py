@@ -544,8 +544,11 @@ def main():
             try:
                 import tempfile
                 with tempfile.TemporaryDirectory() as td:
+                    # 18,432 variants on two chromosomes: whole batches of the device decoder (3,072 streams), as the 450,000 variants of a
+                    # chromosome of BASELINE configs[4] give; 1,024 variants for regenie itself
                     rb = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "bgen_e2e.py"), "--json",
-                                         os.path.join(td, "rec.json"), "500000", "12000", "1000"], capture_output=True, text=True, timeout=900)
+                                         os.path.join(td, "rec.json"), "500000", "18432", "1024"], capture_output=True, text=True, timeout=900,
+                                        env=dict(os.environ, BGEN_E2E_NCHR="2"))
                     if rb.returncode != 0:
                         raise RuntimeError((rb.stdout + rb.stderr)[-600:])
                     extra["step2"]["bgen_from_file"] = json.load(open(os.path.join(td, "rec.json")))
@@ -718,6 +721,7 @@ def from_disk_leg(args, torch, packed, blocks, my_blocks, Yraw, cov, M, N, P, gp
             free_gpu()
         cmd = [drv, "--step", "1", "--bed", pre, "--phenoFile", pre + ".pheno", "--covarFile", pre + ".covar", "--bsize", str(args.bsize),
                "--qt", "--out", os.path.join(d, "o")]
+        io = host_io_context(pre + ".bed") if nbytes > (4 << 30) else None      # the large configurations: where the figure is an I/O number
         walls = []
         for _ in range(nruns):                  # first run warms the page cache and the driver's code objects
             t0 = time.perf_counter()
@@ -730,12 +734,109 @@ def from_disk_leg(args, torch, packed, blocks, my_blocks, Yraw, cov, M, N, P, gp
         err = float(np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
         stages = [ln.strip() for ln in r.stdout.splitlines() if "level 0 ridge of blocks" in ln or "-level 1 for" in ln or "Elapsed time" in ln
                   or "since start" in ln]
-        return {"value": M * N * P / wall, "unit": "SNP*sample*pheno/s", "wall_s": wall, "walls_s": walls, "bed_bytes": nbytes,
-                "bed_GBps": nbytes / wall / 1e9, "driver_log": stages, "setup_write_s": t_write,
+        rec_io = None
+        if io:
+            rates = [v for v in list(io["pread_GBps_by_threads"].values()) if v]
+            best = max(rates) if rates else None
+            rec_io = dict(io, read_ceiling_s=(nbytes / 1e9 / best) if best else None, wall_minus_read_ceiling_s=(wall - nbytes / 1e9 / best) if best else None,
+                          page_cache_resident_fraction_after_runs=host_io_context(pre + ".bed", sweep_bytes=0)["page_cache_resident_fraction"])
+        return {"wall_s": wall, "value": M * N * P / wall, "unit": "SNP*sample*pheno/s", "walls_s": walls, "bed_bytes": nbytes,
+                "bed_GBps": nbytes / wall / 1e9, "host_io": rec_io, "driver_log": stages, "setup_write_s": t_write,
                 "loco_text_vs_resident_run_max_rel_err": err,
                 "note": "regenie-amd --step 1 from files on the local disk (page cache warm), process start to exit; best of the runs after the first (a single run: that run)"}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def host_io_context(path, sweep_bytes=8 << 30):
+    """What the from-files figure has to be read against: how much of the file the page cache holds right now (mincore over a mapping), what
+    this box delivers for plain reads of the same file (pread of 16 MB pieces into per-thread buffers, 4 / 8 / 16 threads; through the page
+    cache and with O_DIRECT), and the memory / CPU the container may use.  Bounded: the sweeps stop after `sweep_bytes`."""
+    import ctypes
+    import mmap
+    import threading
+    out = {}
+    size = os.path.getsize(path)
+
+    def resident():
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            m = mmap.mmap(fd, size, access=mmap.ACCESS_COPY)
+            libc = ctypes.CDLL("libc.so.6", use_errno=True)
+            npages = (size + 4095) // 4096
+            vec = (ctypes.c_ubyte * npages)()
+            addr = ctypes.addressof(ctypes.c_char.from_buffer(m))
+            rc = libc.mincore(ctypes.c_void_p(addr), ctypes.c_size_t(size), vec)
+            frac = float((np.frombuffer(vec, dtype=np.uint8) & 1).mean()) if rc == 0 else None
+            del addr
+            m.close()
+            return frac
+        except Exception:   # noqa: BLE001
+            return None
+        finally:
+            os.close(fd)
+
+    def sweep(nthreads, direct):
+        flags = os.O_RDONLY | (os.O_DIRECT if direct else 0)
+        try:
+            fd = os.open(path, flags)
+        except OSError:
+            return None
+        piece = 16 << 20
+        total = min(size, sweep_bytes) // piece * piece
+        if total == 0:
+            os.close(fd)
+            return None
+        nxt = [0]
+        lock = threading.Lock()
+        ok = [True]
+
+        def work():
+            buf = mmap.mmap(-1, piece)          # page-aligned (O_DIRECT needs it)
+            while True:
+                with lock:
+                    off = nxt[0]
+                    nxt[0] += piece
+                if off >= total:
+                    break
+                try:
+                    got = os.preadv(fd, [buf], off)
+                except OSError:
+                    ok[0] = False
+                    break
+                if got != piece:
+                    ok[0] = False
+                    break
+        t0 = time.perf_counter()
+        ths = [threading.Thread(target=work) for _ in range(nthreads)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        dt = time.perf_counter() - t0
+        os.close(fd)
+        return total / dt / 1e9 if ok[0] else None
+    out["page_cache_resident_fraction"] = resident()
+    out["pread_GBps_by_threads"] = {str(n): sweep(n, False) for n in (4, 8, 16)}
+    out["pread_o_direct_GBps_by_threads"] = {str(n): sweep(n, True) for n in (4, 16)}
+    out["page_cache_resident_fraction_after_sweeps"] = resident()
+    mem = {}
+    try:
+        for ln in open("/proc/meminfo"):
+            k, v = ln.split(":")
+            if k in ("MemTotal", "MemAvailable", "Cached"):
+                mem[k + "_GB"] = round(int(v.split()[0]) / 1e6, 1)
+    except OSError:
+        pass
+    for k, f in (("cgroup_memory_max", "/sys/fs/cgroup/memory.max"), ("cgroup_cpu_max", "/sys/fs/cgroup/cpu.max")):
+        try:
+            mem[k] = open(f).read().strip()
+        except OSError:
+            mem[k] = None
+    mem["hardware_threads"] = os.cpu_count()
+    out["host"] = mem
+    out["sweep_bytes"] = int(min(size, sweep_bytes))
+    return out
 
 
 def _parse_loco(path):

@@ -134,42 +134,34 @@ __device__ __forceinline__ unsigned pi8_expand4(unsigned b, unsigned lut) {
 // order -- instead of 160 dependent cross-lane shuffles per lane.  tmp: 8 x 32 x 33 doubles (67.6 KB) of the staging area, free
 // once the contraction is done (the caller has passed a barrier).
 #define PI8_TMP_PITCH 33
-__device__ __forceinline__ void pi8_epilogue(const PredArgs& a, int tile, int nrow, int blk, int s, int p0, int64_t pos, int wave, int c, int kb,
-                                             const double (&out)[16], double (*scb)[16 + 1], const int* srow_w, const int* srow_p,
+#define PI8_CPRE 4      // covariate values of the lane's position held in registers across the contraction (more columns: loaded in the epilogue)
+// Round 5: the epilogue no longer waits for memory.  With one workgroup per CU (132 KB of staged planes) nothing hides a load, and the
+// epilogue of a tile used to pay four exposed round trips -- the rows' covariate products (staged through LDS behind a barrier), the
+// covariate values of the position one after the other, the masks -- about as long as the tile's 512 MFMAs.  Now the covariate products of
+// BOTH tiles are staged once at kernel start (scb), the lane's covariate values (xv) and the masks of its 2 x 16 rows (one bit each) are
+// loaded before the first MFMA and ride along in 18 registers.
+__device__ __forceinline__ void pi8_epilogue(const PredArgs& a, int tile, int64_t pos, int wave, int c, int kb, const double (&out)[16],
+                                             const double (*scb)[PI8_CPRE + 1], const int* srow_w, const double (&xv)[PI8_CPRE], unsigned mkbits,
                                              double* tmp, double (*sred)[PI8_ROWS][2]) {
-  const int R0 = a.R0, nm = a.nseg * R0;
   double corr[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) corr[r] = 0.0;
-  for (int c0 = 0; c0 < a.C; c0 += 16) {            // 16 covariates at a time: their products cb[m][c] through LDS
-    __syncthreads();
-    for (int e = threadIdx.x; e < 32 * 16; e += 512) {
-      const int ml = e >> 4, cc = e & 15, m = tile * 32 + ml;
-      const int mc = m < nrow ? m : 0;
-      const double* cb = a.cb + (((int64_t)blk * nm + s * R0 + mc % R0) * a.P + p0 + mc / R0) * a.C;
-      scb[ml][cc] = (c0 + cc < a.C && m < nrow) ? cb[c0 + cc] : 0.0;
-    }
-    __syncthreads();
-    const int ncc = min(16, a.C - c0);
-    for (int cc = 0; cc < ncc; ++cc) {
-      const double xv = a.V[(int64_t)(c0 + cc) * a.Np + pos];
+  const int npre = min(a.C, PI8_CPRE);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) corr[r] = fma(scb[(r & 3) + 8 * (r >> 2) + 4 * kb][cc], xv, corr[r]);
+  for (int cc = 0; cc < PI8_CPRE; ++cc) {
+    if (cc < npre) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) corr[r] = fma(scb[tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb][cc], xv[cc], corr[r]);
     }
   }
   int wrow[16];
-  double mk[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
-    wrow[r] = srow_w[m];
-    mk[r] = a.maskp[(int64_t)srow_p[m] * a.Np + pos];
-  }
+  for (int r = 0; r < 16; ++r) wrow[r] = srow_w[tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb];
   double* trow = tmp + ((int64_t)wave * 32) * PI8_TMP_PITCH + c;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const bool live = wrow[r] >= 0;
-    const double v = live ? (out[r] - corr[r]) * mk[r] : 0.0;
+    const double v = (live && ((mkbits >> r) & 1u)) ? (out[r] - corr[r]) : 0.0;
     if (live) a.W[(int64_t)wrow[r] * a.Np + pos] = v;
     trow[((r & 3) + 8 * (r >> 2) + 4 * kb) * PI8_TMP_PITCH] = v;
   }
@@ -184,6 +176,20 @@ __device__ __forceinline__ void pi8_epilogue(const PredArgs& a, int tile, int nr
       t += q ? x * x : x;
     }
     sred[w][tile * 32 + ml][q] = t;
+  }
+}
+// covariate columns past PI8_CPRE (rare: more than eight covariates): the remaining products, loaded in the epilogue as before
+__device__ __forceinline__ void pi8_corr_tail(const PredArgs& a, int tile, int nrow, int blk, int s, int p0, int64_t pos, int kb, double (&out)[16]) {
+  const int R0 = a.R0, nm = a.nseg * R0;
+  for (int cc = PI8_CPRE; cc < a.C; ++cc) {
+    const double xvv = a.V[(int64_t)cc * a.Np + pos];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+      const int mc = m < nrow ? m : 0;
+      const double cb = a.cb[(((int64_t)blk * nm + s * R0 + mc % R0) * a.P + p0 + mc / R0) * a.C + cc];
+      out[r] = fma(-(m < nrow ? cb : 0.0), xvv, out[r]);
+    }
   }
 }
 
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
   extern __shared__ __attribute__((aligned(16))) int8_t smem[];
   int8_t* sA = smem;                                                       // [8 planes][32 rows][PI8_PITCH]
   double (*sred)[PI8_ROWS][2] = reinterpret_cast<double (*)[PI8_ROWS][2]>(smem + PI8_NPIECE * PI8_PLANE);   // [8 waves][64][2]
-  __shared__ double scb[PI8_ROWS][16 + 1];             // cb of the group's rows, 16 covariates at a time
+  __shared__ double scb[PI8_ROWS][PI8_CPRE + 1];       // cb of the group's rows (both tiles), the first PI8_CPRE covariates
   __shared__ int srow_w[PI8_ROWS], srow_p[PI8_ROWS];   // W row (col0 + r) * P + p and phenotype of every row m (-1: dead)
   const int blk = blockIdx.z, ch = blockIdx.x, grp = blockIdx.y, p0 = grp * pg;
   const int npg = min(pg, a.P - p0), nrow = npg * a.R0;
@@ -224,92 +230,133 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
     srow_w[m] = live ? (col0 + rr) * a.P + p0 + pl : -1;
     srow_p[m] = p0 + pl;
   }
-#pragma unroll 1
-  for (int tile = 0; tile < 2; ++tile) {
-    if (tile * 32 >= nrow) break;                       // no live row in the second tile
-    double out[16];                                     // rows tile*32 + (reg&3) + 8*(reg>>2) + 4*kb, position pos
+  for (int e = threadIdx.x; e < PI8_ROWS * PI8_CPRE; e += 512) {      // the rows' covariate products, both tiles, once
+    const int m = e / PI8_CPRE, cc = e % PI8_CPRE;
+    const int mc = m < nrow ? m : 0;
+    const double* cb = a.cb + (((int64_t)blk * nm + s * R0 + mc % R0) * a.P + p0 + mc / R0) * a.C;
+    scb[m][cc] = (cc < a.C && m < nrow) ? cb[min(cc, a.C - 1)] : 0.0;
+  }
+  // what the epilogues need from memory, requested before the first MFMA: the position's covariate values and, one bit per row, the masks
+  double xv[PI8_CPRE];
 #pragma unroll
-    for (int set = 0; set < 2; ++set) {                 // unrolled: `out` is not live while the first set is contracted
-      if (set == 1 && !has_miss) break;
-      const unsigned lut = set == 0 ? LUT_DOSAGE : LUT_MISS;
-      double oi[16];                                    // sum_k 128^k S_k over both halves, an integer held in fp64
+  for (int cc = 0; cc < PI8_CPRE; ++cc) xv[cc] = a.V[(int64_t)min(cc, a.C - 1) * a.Np + pos];
+  unsigned mkbits[2] = {0u, 0u};
+  {
+    double mk[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+        const int pl = m < nrow ? m / R0 : 0;
+        mk[t][r] = a.maskp[(int64_t)(p0 + pl) * a.Np + pos];
+      }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mkbits[t] |= (mk[t][r] != 0.0 ? 1u : 0u) << r;
+  }
+  // ---- stages: (tile, set, half) in this order; the operands of stage i + 1 are REQUESTED before the MFMAs of stage i ----
+  // One workgroup per CU (132 KB of staged planes): nothing else hides a load.  Measured with cycle counters per phase (round 5): the
+  // genotype dwords (a load followed at once by its expansion) were 32 % of a workgroup's time, the plane pieces (load -> LDS store)
+  // 20 %, the 128 MFMAs per wave and stage 17 %.  The raw genotype dwords of the next stage (16 registers) now travel while the matrix
+  // cores work: loaded right after the barrier that releases the MFMA loop, expanded at the top of the next stage.  (The 64 registers
+  // of plane pieces do not fit beside them: the compiler parks them in scratch, which waits for the loads before the MFMAs start.)
+  const int ntile = nrow > 32 ? 2 : 1, nset = has_miss ? 2 : 1, nhalf = (n128 + PI8_KHALF - 1) / PI8_KHALF;
+  const int nstage = ntile * nset * nhalf;
+  uint32_t gw[PI8_KHALF / 32];       // raw genotype dwords of the stage about to be expanded
+  auto stage_nst = [&](int half) { return FULL ? PI8_KHALF / 32 : min(PI8_KHALF / 32, nstep - half * (PI8_KHALF / 32)); };
+  auto request = [&](int st) {       // issue the genotype loads of stage st
+    const int half = st % nhalf;
+    const int nst = stage_nst(half);
+#pragma unroll
+    for (int t = 0; t < PI8_KHALF / 32; ++t) {
+      const int tc = half * (PI8_KHALF / 32) + ((FULL || t < nst) ? t : nst - 1);
+      gw[t] = brow[(int64_t)tc * 64];
+    }
+  };
+  request(0);
+  double out[16], oi[16];
+#pragma unroll 1
+  for (int st = 0; st < nstage; ++st) {
+    const int half = st % nhalf, set = (st / nhalf) % nset, tile = st / (nhalf * nset);
+    const int nst = stage_nst(half);
+    const unsigned lut = set == 0 ? LUT_DOSAGE : LUT_MISS;
+    if (half == 0) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) oi[r] = 0.0;
-#pragma unroll 1
-      for (int half = 0; half * PI8_KHALF < n128; ++half) {
-        const int nst = FULL ? PI8_KHALF / 32 : min(PI8_KHALF / 32, nstep - half * (PI8_KHALF / 32));   // K steps of this half
-        __syncthreads();
-        {  // stage 8 planes x 32 rows x (this half's) digits: 16-byte pieces, coalesced along the SNP index.  All loads of a
-           // thread are issued before its first LDS store (a load -> store loop with a run-time trip count is one memory
-           // round trip per iteration: 64 of them per workgroup were ~3/4 of this kernel's time)
-          const int8_t* src = planes + ((grp_idx * 2 + set) * PI8_NPIECE) * (int64_t)PI8_ROWS * n128 + (int64_t)tile * 32 * n128 + half * PI8_KHALF;
-          const int per_row = nst * 2;                  // 16-byte pieces per row; a plane has 32 * per_row, all 8 planes 256 * per_row
-          uint4 v[PI8_KHALF / 32];
-          int dst[PI8_KHALF / 32];
+    }
+    __syncthreads();                 // the previous stage's MFMAs (and a tile's epilogue) are done with the staging area
+    {  // stage 8 planes x 32 rows x (this half's) digits: 16-byte pieces, coalesced along the SNP index; all loads of a thread are
+       // issued before its first LDS store
+      const int8_t* src = planes + ((grp_idx * 2 + set) * PI8_NPIECE) * (int64_t)PI8_ROWS * n128 + (int64_t)tile * 32 * n128 + half * PI8_KHALF;
+      const int per_row = nst * 2;
+      uint4 pv[PI8_KHALF / 32];
 #pragma unroll
-          for (int it = 0; it < PI8_KHALF / 32; ++it) {   // 256 * per_row pieces over 512 threads: per_row / 2 = nst each
-            const int e = threadIdx.x + 512 * it;
-            const int rowk = e / per_row, pc = e - rowk * per_row;       // rowk = k * 32 + row
-            const int k = rowk >> 5, row = rowk & 31;
-            const bool on = FULL || it < nst;
-            v[it] = *reinterpret_cast<const uint4*>(src + (int64_t)(on ? k : 0) * PI8_ROWS * n128 + (int64_t)(on ? row : 0) * n128 + (on ? pc : 0) * 16);
-            dst[it] = on ? k * PI8_PLANE + row * PI8_PITCH + pc * 16 : -1;
-          }
-#pragma unroll
-          for (int it = 0; it < PI8_KHALF / 32; ++it)
-            if (FULL || dst[it] >= 0) *reinterpret_cast<uint4*>(sA + dst[it]) = v[it];
-        }
-        // this lane's genotype operand for the half: SNPs 32 t + 16 kb .. + 15 of its position, sixteen int8 per step
-        v4i bf[PI8_KHALF / 32];
-#pragma unroll
-        for (int t = 0; t < PI8_KHALF / 32; ++t) {
-          const int tc = half * (PI8_KHALF / 32) + ((FULL || t < nst) ? t : nst - 1);   // steps past the width are never multiplied
-          const uint32_t w = brow[(int64_t)tc * 64];
-          bf[t] = (v4i){(int)pi8_expand4(w & 0xFFu, lut), (int)pi8_expand4((w >> 8) & 0xFFu, lut),
-                        (int)pi8_expand4((w >> 16) & 0xFFu, lut), (int)pi8_expand4(w >> 24, lut)};
-        }
-        __syncthreads();
-        // digit planes from the most significant pair down: a pair is combined in int32 (|S_k| <= 64 * 2 * 512 = 2^16 per half, so
-        // 128 S_{k+1} + S_k < 2^24) -- the second chain simply accumulates onto the shifted sums -- and the pairs by Horner in fp64
-        double hr[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) hr[r] = 0.0;
-#pragma unroll 1
-        for (int kp = PI8_NPIECE / 2 - 1; kp >= 0; --kp) {
-          v16i acc;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0;
-#pragma unroll
-          for (int hl = 1; hl >= 0; --hl) {
-            const int8_t* arow = sA + (2 * kp + hl) * PI8_PLANE + c * PI8_PITCH + 16 * kb;
-#pragma unroll
-            for (int t = 0; t < PI8_KHALF / 32; ++t) {
-              if (FULL || t < nst) {
-                const v4i af = *reinterpret_cast<const v4i*>(arow + 32 * t);
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[t], acc, 0, 0, 0);
-              }
-            }
-            if (hl == 1) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) acc[r] *= 128;
-            }
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) hr[r] = fma(hr[r], 16384.0, (double)acc[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oi[r] += hr[r];
+      for (int it = 0; it < PI8_KHALF / 32; ++it) {
+        const int e = threadIdx.x + 512 * it;
+        const int rowk = e / per_row, pc = e - rowk * per_row;
+        const int k = rowk >> 5, row = rowk & 31;
+        const bool on = FULL || it < nst;
+        pv[it] = *reinterpret_cast<const uint4*>(src + (int64_t)(on ? k : 0) * PI8_ROWS * n128 + (int64_t)(on ? row : 0) * n128 + (on ? pc : 0) * 16);
       }
-      // the rows' 2^(e-54): a power of two times an integer -- exact up to the one rounding of the sum above
-      {
-        const double* scrow = psc + (grp_idx * 2 + set) * PI8_ROWS + tile * 32 + 4 * kb;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[r] = set == 0 ? oi[r] * scrow[(r & 3) + 8 * (r >> 2)] : fma(oi[r], scrow[(r & 3) + 8 * (r >> 2)], out[r]);
+      for (int it = 0; it < PI8_KHALF / 32; ++it) {
+        const int e = threadIdx.x + 512 * it;
+        const int rowk = e / per_row, pc = e - rowk * per_row;
+        const int k = rowk >> 5, row = rowk & 31;
+        if (FULL || it < nst) *reinterpret_cast<uint4*>(sA + k * PI8_PLANE + row * PI8_PITCH + pc * 16) = pv[it];
       }
     }
-    // ---- epilogue of the tile (pi8_epilogue): the staged planes are no longer needed, their LDS carries the per-wave sums ----
+    v4i bf[PI8_KHALF / 32];
+#pragma unroll
+    for (int t = 0; t < PI8_KHALF / 32; ++t) {
+      const uint32_t w = gw[t];
+      bf[t] = (v4i){(int)pi8_expand4(w & 0xFFu, lut), (int)pi8_expand4((w >> 8) & 0xFFu, lut),
+                    (int)pi8_expand4((w >> 16) & 0xFFu, lut), (int)pi8_expand4(w >> 24, lut)};
+    }
     __syncthreads();
-    pi8_epilogue(a, tile, nrow, blk, s, p0, pos, wave, c, kb, out, scb, srow_w, srow_p, reinterpret_cast<double*>(sA), sred);
+    if (st + 1 < nstage) request(st + 1);
+    // digit planes from the most significant pair down: a pair is combined in int32 (|S_k| <= 64 * 2 * 512 = 2^16 per half, so
+    // 128 S_{k+1} + S_k < 2^24) -- the second chain simply accumulates onto the shifted sums -- and the pairs by Horner in fp64
+    // (each pair's exact int32 sum enters the fp64 total times its power of two, 16384^kp: every product is exact, the running sum rounds
+    // at 2^-53 of its value -- the Horner form this replaces kept sixteen more doubles alive per lane)
+#pragma unroll 1
+    for (int kp = PI8_NPIECE / 2 - 1; kp >= 0; --kp) {
+      v16i acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0;
+#pragma unroll
+      for (int hl = 1; hl >= 0; --hl) {
+        const int8_t* arow = sA + (2 * kp + hl) * PI8_PLANE + c * PI8_PITCH + 16 * kb;
+#pragma unroll
+        for (int t = 0; t < PI8_KHALF / 32; ++t) {
+          if (FULL || t < nst) {
+            const v4i af = *reinterpret_cast<const v4i*>(arow + 32 * t);
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf[t], acc, 0, 0, 0);
+          }
+        }
+        if (hl == 1) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[r] *= 128;
+        }
+      }
+      const double w14 = kp == 3 ? 4398046511104.0 : (kp == 2 ? 268435456.0 : (kp == 1 ? 16384.0 : 1.0));     // 16384^kp
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oi[r] = fma((double)acc[r], w14, oi[r]);
+    }
+    if (half == nhalf - 1) {
+      // the rows' 2^(e-54): a power of two times an integer -- exact up to the one rounding of the sum above
+      const double* scrow = psc + (grp_idx * 2 + set) * PI8_ROWS + tile * 32 + 4 * kb;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) out[r] = set == 0 ? oi[r] * scrow[(r & 3) + 8 * (r >> 2)] : fma(oi[r], scrow[(r & 3) + 8 * (r >> 2)], out[r]);
+      if (set == nset - 1) {
+        // ---- epilogue of the tile (pi8_epilogue): the staged planes are no longer needed, their LDS carries the per-wave sums ----
+        __syncthreads();
+        if (a.C > PI8_CPRE) pi8_corr_tail(a, tile, nrow, blk, s, p0, pos, kb, out);
+        pi8_epilogue(a, tile, pos, wave, c, kb, out, scb, srow_w, xv, tile == 0 ? mkbits[0] : mkbits[1], reinterpret_cast<double*>(sA), sred);
+      }
+    }
   }
   __syncthreads();
   if (threadIdx.x < nrow * 2) {

@@ -98,6 +98,10 @@ struct rg_group {
   std::vector<std::vector<double>> hstage;   // peer transport: host staging of the all-reduce
   std::vector<const double*> ar_ptr;
   std::vector<int> failed;
+  // one event per rank, recorded on the rank's stream when its part of an exchange is queued.  The exchanges are ordered by events and
+  // stream order only: no host thread waits for the GPU inside rg_l0_finish (round 5; before, each transfer phase ended in a
+  // hipStreamSynchronize).  A transfer that fails on the device surfaces at the rank's next rg_sync, like a kernel fault.
+  std::vector<hipEvent_t> ev;
   Barrier bar;
   std::string err;
   // every rank passes `agree` right before it enters a collective: all ranks alive and willing, or nobody enters
@@ -150,6 +154,19 @@ int group_allreduce(void* user, void* dev_ptr, int64_t n) {
   return 0;
 }
 
+// Peer transport: rank `rank` has queued its pulls on its stream.  Nobody may overwrite its W (a next run) before every peer has pulled:
+// each rank records its event, a host barrier makes sure all events ARE recorded (a wait on an event that has not been recorded yet
+// would pass), then every rank's stream waits for every peer's event.  The host threads never wait for the device here.
+bool chain_after_pulls(rg_group* g, int rank) {
+  rg_ctx* c = g->ctx[rank];
+  if (!g->ev[rank] || hipEventRecord(g->ev[rank], c->stream) != hipSuccess) { g->bar.abort(); return false; }
+  if (!g->bar.wait()) return false;
+  for (int k = 0; k < g->n; ++k)
+    if (k != rank && g->ev[k] && hipStreamWaitEvent(c->stream, g->ev[k], 0) != hipSuccess) { g->bar.abort(); return false; }
+  // the events must not be re-recorded (a next exchange) before every rank has queued its waits
+  return g->bar.wait();
+}
+
 // exchange buffers of one rank for the phenotype-sharded form: the view [L][np_r][Np] and (RCCL) the packed send buffer
 int ensure_exchange_buffers(rg_group* g, int rank, const int32_t* block_begin, const int32_t* pheno_begin) {
   rg_ctx* c = g->ctx[rank];
@@ -194,6 +211,12 @@ int rg_group_create(rg_group** out, int32_t n, rg_ctx* const* ctxs, int transpor
   g->failed.assign(n, 0);
   for (int r = 0; r < n; ++r) g->users[r] = ArUser{g, r};
   g->bar.n = n;
+  g->ev.assign(n, nullptr);
+  for (int r = 0; r < n; ++r) {
+    if (!ctxs[r]) continue;
+    hipSetDevice(ctxs[r]->device);
+    if (hipEventCreateWithFlags(&g->ev[r], hipEventDisableTiming) != hipSuccess) g->ev[r] = nullptr;
+  }
   for (int r = 0; r < n; ++r)
     if (!ctxs[r] || !ctxs[r]->have_problem) { delete g; return RG_ERR_STATE; }
   if (transport == RG_TRANSPORT_RCCL) {
@@ -226,6 +249,7 @@ void rg_group_destroy(rg_group* g) {
     rg_set_collective(g->ctx[r], 1, 0, nullptr, nullptr);
     if (g->wview[r]) hipFree(g->wview[r]);
     if (g->sendbuf[r]) hipFree(g->sendbuf[r]);
+    if (r < (int)g->ev.size() && g->ev[r]) { hipStreamSynchronize(g->ctx[r]->stream); hipEventDestroy(g->ev[r]); }
     if (g->transport == RG_TRANSPORT_RCCL && r < (int)g->comm.size() && g->comm[r]) g_rccl.CommDestroy(g->comm[r]);
   }
   delete g;
@@ -308,9 +332,7 @@ int rg_l0_finish(rg_group* g, int32_t rank, const int32_t* block_begin, const in
                              (size_t)nl, hipMemcpyDeviceToDevice, st) != hipSuccess)
           return broke("rg_l0_finish: peer copy failed");
       }
-      if (hipStreamSynchronize(st) != hipSuccess) return broke("rg_l0_finish: peer copy failed");
-      // nobody may overwrite its W (a next run) before every peer has pulled
-      if (!g->bar.wait()) return rank_error(g, rank, "rg_l0_finish: the exchange failed on another GPU");
+      if (!chain_after_pulls(g, rank)) return rank_error(g, rank, "rg_l0_finish: the exchange failed on another GPU");
     } else {
       // one group of send/recv pairs per rank: a direct exchange in which every pair of GPUs uses its own xGMI link
       ncclResult_t e = g_rccl.GroupStart();
@@ -323,7 +345,7 @@ int rg_l0_finish(rg_group* g, int32_t rank, const int32_t* block_begin, const in
       }
       ncclResult_t e2 = g_rccl.GroupEnd();
       if (e != 0 || e2 != 0) return broke(std::string("RCCL all-to-all: ") + g_rccl.GetErrorString(e ? e : e2));
-      if (hipStreamSynchronize(st) != hipSuccess) return broke("rg_l0_finish: exchange failed");
+      // (stream-ordered: level 1 of this rank queues behind its receives, a next level 0 behind its sends)
     }
     rc = rg_set_l1_view(c, Wv, q0, nq);
     if (rc) return rc;
@@ -338,8 +360,7 @@ int rg_l0_finish(rg_group* g, int32_t rank, const int32_t* block_begin, const in
       if (hipMemcpyAsync(c->d_W + l0 * P * Np, g->ctx[k]->d_W + l0 * P * Np, sizeof(double) * nl * P * Np, hipMemcpyDeviceToDevice, st) != hipSuccess)
         return broke("rg_l0_finish: peer copy failed");
     }
-    if (hipStreamSynchronize(st) != hipSuccess) return broke("rg_l0_finish: peer copy failed");
-    if (!g->bar.wait()) return rank_error(g, rank, "rg_l0_finish: the exchange failed on another GPU");
+    if (!chain_after_pulls(g, rank)) return rank_error(g, rank, "rg_l0_finish: the exchange failed on another GPU");
   } else {
     ncclResult_t e = g_rccl.GroupStart();
     for (int k = 0; k < n && e == 0; ++k) {
@@ -350,7 +371,6 @@ int rg_l0_finish(rg_group* g, int32_t rank, const int32_t* block_begin, const in
     }
     ncclResult_t e2 = g_rccl.GroupEnd();
     if (e != 0 || e2 != 0) return broke(std::string("RCCL all-gather: ") + g_rccl.GetErrorString(e ? e : e2));
-    if (hipStreamSynchronize(st) != hipSuccess) return broke("rg_l0_finish: all-gather failed");
   }
   for (int b = 0; b < c->B_total; ++b) c->block_done[b] = 1;
   rc = rg_set_l1_view(c, nullptr, 0, P);

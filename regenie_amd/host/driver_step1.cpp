@@ -355,7 +355,9 @@ int run(int argc, char** argv) {
     std::deque<int> ready_q;
     std::exception_ptr rd_err = nullptr;
     bool rd_done = false;
-    int rd_threads = 4;    // preads of one buffer in flight (page-cache copies scale with threads; a disk queue likes depth)
+    // preads of one buffer in flight (page-cache copies scale with threads; a disk queue likes depth): half the CPUs this process may use
+    // (affinity mask and cgroup quota), between 4 and 16, shared by the ranks of a multi-GPU run
+    int rd_threads = std::max(4, std::min(16, usable_cpus() / 2 / std::max(1, p.gpus)));
     if (const char* e = getenv("RG_READ_THREADS")) rd_threads = std::max(1, atoi(e));
     std::thread reader([&]() {
       int fd = -1;

@@ -180,7 +180,7 @@ def main(argv):
     js = None
     if argv and argv[0] == "--json":
         js, argv = argv[1], argv[2:]
-    kw = dict(bsizes=(2048,), ref_threads=(16,)) if js else {}
+    kw = dict(bsizes=(400,), ref_threads=(16,)) if js else {}
     rec = run(*[int(a) for a in argv], say=lambda s: print(s, flush=True), **kw)
     if js:
         import json
