@@ -490,7 +490,15 @@ def main():
         # BASELINE configs[3]'s kind (binary traits) at its level-1 shape: 500,000 samples, L = 2,560 level-0 predictors (512 blocks of 100 SNPs --
         # level 1 does not see the block width), four traits of prevalence 5 %, 30 %, 1 % and 50 %; 98 % of that configuration is this level 1
         # (DESIGN.md section 5).  With --oracle-check the sub-run then hands the device back (RG_GPU_DONE on stderr) and has the numpy oracle refit
-        # the first fold chain of the 1 % trait at full size on the host -- minutes of host work that run NEXT TO the sub-records below.
+        # the first fold chain of the 1 % trait at full size on the host -- minutes of host work that run NEXT TO the GPU-bound sub-records
+        # that follow (the leave-one-out runs, the Step-2 kernels); configs[2] above and the BGEN run below (both host-heavy: the job has
+        # 16 CPUs of quota) have the box to themselves.
+        try:    # BASELINE configs[2] (the north star's target workload) in full on this ONE GPU: 500,000 x 500,000 x 10 QT, resident
+            l3 = sub_line(big + ["--snps", "500000", "--phenos", "10", "--warmup", "1"] + ([] if args.no_disk else ["--disk-leg"]), 1500)
+            extra["config3_single_gpu"] = {k: l3[k] for k in ("ms_per_step", "value", "unit", "steps", "warmup", "loco_checksum", "selected_tau_index", "roofline",
+                                                               "kernels", "end_to_end_from_files", "config")}
+        except Exception as e:   # noqa: BLE001
+            extra["config3_single_gpu"] = {"error": repr(e)[:500]}
         p4, err4 = None, []
         try:
             p4 = subprocess.Popen(me + big + ["--snps", "51200", "--bsize", "100", "--phenos", "4", "--bt", "--prev", "0.05,0.3,0.01,0.5", "--warmup", "0",
@@ -507,12 +515,6 @@ def main():
             gpu_free.wait(timeout=900)
         except Exception as e:   # noqa: BLE001 - a sub-record must not take the line down
             extra["config4_level1_binary_traits"] = {"error": repr(e)[:500]}
-        try:    # BASELINE configs[2] (the north star's target workload) in full on this ONE GPU: 500,000 x 500,000 x 10 QT, resident
-            l3 = sub_line(big + ["--snps", "500000", "--phenos", "10", "--warmup", "1"] + ([] if args.no_disk else ["--disk-leg"]), 1500)
-            extra["config3_single_gpu"] = {k: l3[k] for k in ("ms_per_step", "value", "unit", "steps", "warmup", "loco_checksum", "selected_tau_index", "roofline",
-                                                               "kernels", "end_to_end_from_files", "config")}
-        except Exception as e:   # noqa: BLE001
-            extra["config3_single_gpu"] = {"error": repr(e)[:500]}
         # leave-one-out cross-validation (regenie --loocv) at the target sample count: level 0 on eight full blocks of 1,000 SNPs with ten traits,
         # level 1 at L = 2,560 for two quantitative traits and for one binary trait
         lo = {}
@@ -538,6 +540,25 @@ def main():
             extra["step2"] = step2_record(torch=torch)
         except Exception as e:   # noqa: BLE001
             extra["step2"] = {"error": repr(e)[:500]}
+        if p4 is not None and "config4_level1_binary_traits" not in extra:
+            try:
+                out4, _ = p4.communicate(timeout=1500)
+                js = [ln for ln in out4.splitlines() if ln.startswith("{")]
+                if not js:
+                    raise RuntimeError(("".join(err4))[-600:])
+                l4 = json.loads(js[-1])
+                ms4 = l4["level1"].get("level1_wall_ms_last_step", 0.0)
+                extra["config4_level1_binary_traits"] = {
+                    "s_per_trait": ms4 / 4e3, "level1_wall_ms": ms4, "traits": 4, "prevalences": [0.05, 0.3, 0.01, 0.5],
+                    "converged": l4["level1"].get("bt_converged"), "oracle_check": l4.get("bt_oracle_check"),
+                    "selected_tau_index": l4["selected_tau_index"], "loco_checksum": l4["loco_checksum"],
+                    "roofline": l4["roofline"], "kernels": {k: l4["kernels"].get(k) for k in ("wgram_f64", "irls_solve", "irls_stream")}, "config": l4["config"]}
+            except Exception as e:   # noqa: BLE001
+                try:
+                    p4.kill()
+                except Exception:   # noqa: BLE001
+                    pass
+                extra["config4_level1_binary_traits"] = {"error": repr(e)[:500]}
         if not args.no_disk:
             # Step 2 from configs[4]'s real input format: a BGEN v1.2 file at 500,000 samples written to /tmp, `regenie-amd --step 2 --bgen` from
             # process start to exit with the shares of its block loop, regenie itself (oracle/_ref) on a bounded sample of the same encoding
@@ -554,25 +575,6 @@ def main():
                     extra["step2"]["bgen_from_file"] = json.load(open(os.path.join(td, "rec.json")))
             except Exception as e:   # noqa: BLE001
                 extra.setdefault("step2", {})["bgen_from_file"] = {"error": repr(e)[:600]}
-    if default_n1 and p4 is not None and "config4_level1_binary_traits" not in extra:
-        try:
-            out4, _ = p4.communicate(timeout=1500)
-            js = [ln for ln in out4.splitlines() if ln.startswith("{")]
-            if not js:
-                raise RuntimeError(("".join(err4))[-600:])
-            l4 = json.loads(js[-1])
-            ms4 = l4["level1"].get("level1_wall_ms_last_step", 0.0)
-            extra["config4_level1_binary_traits"] = {
-                "s_per_trait": ms4 / 4e3, "level1_wall_ms": ms4, "traits": 4, "prevalences": [0.05, 0.3, 0.01, 0.5],
-                "converged": l4["level1"].get("bt_converged"), "oracle_check": l4.get("bt_oracle_check"),
-                "selected_tau_index": l4["selected_tau_index"], "loco_checksum": l4["loco_checksum"],
-                "roofline": l4["roofline"], "kernels": {k: l4["kernels"].get(k) for k in ("wgram_f64", "irls_solve", "irls_stream")}, "config": l4["config"]}
-        except Exception as e:   # noqa: BLE001
-            try:
-                p4.kill()
-            except Exception:   # noqa: BLE001
-                pass
-            extra["config4_level1_binary_traits"] = {"error": repr(e)[:500]}
     if rank == 0:
         line = {
             "metric": "Step-1 SNPs x samples x phenos / sec", "value": value, "unit": "SNP*sample*pheno/s",

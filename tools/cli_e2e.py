@@ -59,7 +59,9 @@ def main(N=50000, M=100000, P=1, bs=1000):
                 ("RG_PIPELINES=1", {"RG_PIPELINES": "1"}), ("RG_PIPELINES=1", {"RG_PIPELINES": "1"}),
                 ("RG_INGEST_PINNED=1", {"RG_INGEST_PINNED": "1"}), ("sleep 3 s first", {})]
     if N * M > 2e10:      # a large input: the wall is the file read -- the default and more reads in flight
-        variants = [("default (mapped .bed)", {}), ("default (mapped .bed)", {}), ("RG_INGEST_MAP=0 (reader ring)", {"RG_INGEST_MAP": "0"})]
+        variants = [("default (reader ring)", {}), ("default (reader ring)", {}), ("RG_READ_THREADS=4", {"RG_READ_THREADS": "4"}),
+                    ("RG_READ_THREADS=16", {"RG_READ_THREADS": "16"}), ("RG_INGEST_MAP=1 (mapped, registered .bed)", {"RG_INGEST_MAP": "1"}),
+                    ("RG_TIMING=1", {"RG_TIMING": "1"})]
     for name, env in variants:
         if name.startswith("sleep"):
             time.sleep(3)
@@ -68,7 +70,7 @@ def main(N=50000, M=100000, P=1, bs=1000):
                             "--out", d + "/out"], capture_output=True, text=True, env=dict(os.environ, **env))
         dt = time.time() - t0
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        marks = [ln.strip() for ln in r.stdout.split("\n") if "since start" in ln or "level 1 for" in ln or "complete (" in ln or "copied to the GPU" in ln]
+        marks = [ln.strip() for ln in (r.stdout + r.stderr).split("\n") if "since start" in ln or "level 1 for" in ln or "complete (" in ln or "copied to the GPU" in ln or "[timing]" in ln]
         print("%-22s wall %.2f s = %.2e SNP*sample*pheno/s end to end | %s" % (name, dt, M * N * P / dt, " | ".join(marks)), flush=True)
 
 
