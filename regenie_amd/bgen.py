@@ -73,12 +73,13 @@ class BgenFile:
         self._check(self.lib.rg_bgen_read_blocks(self.h, idx.size, idx.ctypes.data, blocks.ctypes.data, nb.value, 0))
         return blocks
 
-    def read_compressed(self, variant_idx, threads: int = 0):
-        """The stored zlib streams of the variants (rg_bgen_read_compressed): (buffer uint8, off int64, clen int32, ulen int32)."""
+    def read_compressed(self, variant_idx, threads: int = 0, alloc=None):
+        """The stored zlib streams of the variants (rg_bgen_read_compressed): (buffer uint8, off int64, clen int32, ulen int32).
+        alloc(nbytes) -> uint8 array: where the bytes go (page-locked memory makes the device decoder's copy asynchronous)."""
         idx = np.ascontiguousarray(variant_idx, dtype=np.int64)
         nb = C.c_int64()
         self._check(self.lib.rg_bgen_compressed_bytes(self.h, idx.size, idx.ctypes.data, C.byref(nb)))
-        buf = np.zeros(nb.value, dtype=np.uint8)
+        buf = np.zeros(nb.value, dtype=np.uint8) if alloc is None else alloc(nb.value)
         off = np.zeros(idx.size, dtype=np.int64)
         clen = np.zeros(idx.size, dtype=np.int32)
         ulen = np.zeros(idx.size, dtype=np.int32)

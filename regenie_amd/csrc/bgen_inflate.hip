@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -230,6 +231,23 @@ __device__ __forceinline__ uint32_t bits_peek(const BitIn& b, uint32_t n) { retu
 __device__ __forceinline__ void bits_drop(BitIn& b, uint32_t n) { b.buf >>= n; b.cnt -= n; }
 __device__ __forceinline__ uint32_t bits_take(BitIn& b, uint32_t n) { const uint32_t v = bits_peek(b, n); bits_drop(b, n); return v; }
 
+// dword `idx` of the stream, out of the two chunk registers (chunk = idx >> 6 is `chunk` or `chunk + 1`); wave-uniform
+__device__ __forceinline__ uint32_t dw_at(uint32_t cur, uint32_t nxt, uint32_t chunk, uint32_t idx) {
+  const uint32_t rel = idx - 64u * chunk;
+  return rel < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(rel & 63u)) : (uint32_t)__builtin_amdgcn_readlane((int)nxt, (int)((rel - 64u) & 63u));
+}
+// the serial reader positioned at absolute bit `bp` (fresh chunk loads: used once per DEFLATE block, after the window decoder)
+__device__ __forceinline__ void bits_seek(BitIn& b, uint32_t bp) {
+  const uint32_t w0 = bp >> 5, chunk = w0 >> 6, lane = (uint32_t)lane_id();
+  b.cur = load_dw(b, 64u * chunk + lane);
+  b.nxt = load_dw(b, 64u * chunk + 64u + lane);
+  const uint32_t d0 = dw_at(b.cur, b.nxt, chunk, w0), d1 = dw_at(b.cur, b.nxt, chunk, w0 + 1u);
+  b.buf = ((uint64_t)d0 | ((uint64_t)d1 << 32)) >> (bp & 31u);
+  b.cnt = 64u - (bp & 31u);
+  b.w = w0 + 2u;
+  if ((b.w >> 6) != chunk) { b.cur = b.nxt; b.nxt = load_dw(b, 64u * (chunk + 2u) + lane); }
+}
+
 enum { ST_OK = 0, ST_HEADER = 1, ST_BTYPE = 2, ST_STORED = 3, ST_TABLE = 4, ST_CODE = 5, ST_DIST = 6, ST_OVERRUN = 7, ST_SHORT = 8, ST_INPUT = 9 };
 
 struct OutState {
@@ -252,6 +270,50 @@ __device__ __forceinline__ void ring_flush(WaveLds& L, OutState& o, uint32_t upt
   o.flushed = done;
 }
 
+// bytes [pos, pos + len) := bytes [pos - dist, pos - dist + len), by all lanes (the caller has checked dist <= pos and pos + len <= cap)
+__device__ __forceinline__ void emit_match(WaveLds& L, OutState& o, uint32_t len, uint32_t dist) {
+  const int lane = lane_id();
+  __builtin_amdgcn_wave_barrier();
+  if (dist <= RING - 64) {
+    // from the ring
+    if (dist >= len || dist >= 64) {
+      // the source lies before the bytes being written (or, dist >= 64, before the 64-byte piece being written): plain offsets
+      for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+        const uint32_t i = c0 + lane;
+        if (i < len) L.ring[(o.pos + i) & (RING - 1)] = L.ring[(o.pos + i - dist) & (RING - 1)];
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+      // an overlapping match of short distance repeats the last `dist` bytes: lane i reads byte i mod dist of them (a float quotient:
+      // i <= 321, dist < 64, exact)
+      for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+        const uint32_t i = c0 + lane;
+        if (i < len) {
+          const uint32_t so = (i - dist * (uint32_t)((float)i / (float)dist)) - dist;
+          L.ring[(o.pos + i) & (RING - 1)] = L.ring[(o.pos + so) & (RING - 1)];
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+  } else {
+    // further back than the ring keeps (one match in ten on zlib level 1 genotype streams): those bytes were flushed to memory at
+    // least RING / 2 - 600 bytes ago (pos - flushed < RING / 2 + 258 + 16).  The wave's own stores have to have reached L2
+    // (s_waitcnt vmcnt(0)), and the loads go past this CU's L1 (agent-scope atomic loads of the aligned words): no cache
+    // maintenance -- a fence here (write-back + invalidate per far match) made the kernel 20x slower
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t c0 = 0; c0 < len; c0 += 64) {
+      const uint32_t i = c0 + lane;
+      if (i < len) {
+        const uintptr_t A = (uintptr_t)(o.out + (o.pos + i - dist));
+        const uint32_t wd = __hip_atomic_load((const uint32_t*)(A & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        L.ring[(o.pos + i) & (RING - 1)] = (uint8_t)(wd >> (8 * (A & 3)));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool PAR>
 __global__ __launch_bounds__(64 * WPB) void k_bgen_inflate(InflateArgs a) {
   __shared__ WaveLds lds[WPB];
   // every quantity of the decode loop is the same in all 64 lanes; uni() (v_readfirstlane) tells the compiler so, and the state then lives in
@@ -342,6 +404,85 @@ __global__ __launch_bounds__(64 * WPB) void k_bgen_inflate(InflateArgs a) {
       if (!build_table(L, 32, (int)hlit, LIT_TB, L.lit, LIT_SLOTS, 0) || !build_table(L, 32 + (int)hlit, (int)hdist, DIST_TB, L.dist, DIST_SLOTS, 1)) { st = ST_TABLE; break; }
     }
     // ---- the block's symbols ----
+    if (PAR) {
+      // Window decoder (round 5, second form): the serial loop below issues ~120 scalar instructions and two or three dependent LDS
+      // round trips per symbol (~1 us).  Here all 64 lanes decode SPECULATIVELY the symbol that would start at each of the next 64
+      // bit positions (lane i: bits bp + i ...: literal / length code, extra bits, distance code, extra bits -- at most 48 bits, taken
+      // from five dwords of the stream by one funnel shift per lane), and the wave then walks the chain of true starts through the
+      // lanes' results (two v_readlane per symbol): the table look-ups of ~2.5 symbols of these streams run in parallel, the serial
+      // part of a symbol is ~25 scalar instructions plus its output.
+      uint32_t bp = b.w * 32u - b.cnt;
+      uint32_t chunk = (bp >> 5) >> 6;
+      uint32_t cur = load_dw(b, 64u * chunk + (uint32_t)lane), nxt = load_dw(b, 64u * chunk + 64u + (uint32_t)lane);
+      bool eob = false;
+      while (st == ST_OK && !eob) {
+        const uint32_t w0 = bp >> 5;
+        if (w0 >= 64u * (chunk + 1u)) { ++chunk; cur = nxt; nxt = load_dw(b, 64u * chunk + 64u + (uint32_t)lane); }
+        if (w0 > b.ndw + 2u) { st = ST_INPUT; break; }
+        const uint32_t d0 = dw_at(cur, nxt, chunk, w0), d1 = dw_at(cur, nxt, chunk, w0 + 1u), d2 = dw_at(cur, nxt, chunk, w0 + 2u),
+                       d3 = dw_at(cur, nxt, chunk, w0 + 3u), d4 = dw_at(cur, nxt, chunk, w0 + 4u);
+        uint32_t A, B = 0;
+        {
+          const uint32_t bb = (bp & 31u) + (uint32_t)lane, q = bb >> 5, sh = bb & 31u;       // q in 0..2
+          const uint32_t lo = q == 0 ? d0 : (q == 1 ? d1 : d2), mid = q == 0 ? d1 : (q == 1 ? d2 : d3), hi = q == 0 ? d2 : (q == 1 ? d3 : d4);
+          const uint32_t r0 = __builtin_amdgcn_alignbit(mid, lo, sh), r1 = __builtin_amdgcn_alignbit(hi, mid, sh);
+          const uint64_t win = ((uint64_t)r1 << 32) | r0;
+          uint32_t e = L.lit[r0 & ((1u << LIT_TB) - 1u)];
+          if (((e >> 8) & K_MASK) == K_SUB) {
+            const uint32_t sb = (e >> 8) & K_XBITS;
+            e = L.lit[(e >> 16) + ((r0 & ((1u << (LIT_TB + sb)) - 1u)) >> LIT_TB)];
+          }
+          const uint32_t kind = (e >> 8) & 0xFFu, nb = e & 0xFFu;
+          A = nb | ((kind & K_MASK) << 8) | (e & 0xFFFF0000u);
+          if ((kind & K_MASK) == K_LEN) {
+            const uint32_t xb = kind & K_XBITS;
+            const uint32_t len = (e >> 16) + ((r0 & ((1u << nb) - 1u)) >> (nb - xb));
+            const uint32_t w2 = (uint32_t)(win >> nb);
+            uint32_t d = L.dist[w2 & ((1u << DIST_TB) - 1u)];
+            if (((d >> 8) & K_MASK) == K_SUB) {
+              const uint32_t sb = (d >> 8) & K_XBITS;
+              d = L.dist[(d >> 16) + ((w2 & ((1u << (DIST_TB + sb)) - 1u)) >> DIST_TB)];
+            }
+            const uint32_t dk = (d >> 8) & 0xFFu, dn = d & 0xFFu;
+            if ((dk & K_MASK) != K_LEN) A = (uint32_t)K_BAD << 8;
+            else {
+              const uint32_t dxb = dk & K_XBITS;
+              const uint32_t dist = (d >> 16) + ((w2 & ((1u << dn) - 1u)) >> (dn - dxb));
+              A = (nb + dn) | ((uint32_t)K_LEN << 8);
+              B = len | (dist << 16);
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t sidx = 0;
+        while (sidx < 64u) {
+          const uint32_t a_ = (uint32_t)__builtin_amdgcn_readlane((int)A, (int)sidx);
+          const uint32_t kd = (a_ >> 8) & K_MASK, adv = a_ & 0xFFu;
+          if (kd == K_LIT) {
+            if (o.pos >= o.cap) { st = ST_OVERRUN; break; }
+            if (lane == 0) L.ring[o.pos & (RING - 1)] = (uint8_t)(a_ >> 16);
+            ++o.pos;
+          } else if (kd == K_LEN) {
+            const uint32_t b_ = (uint32_t)__builtin_amdgcn_readlane((int)B, (int)sidx);
+            const uint32_t len = b_ & 0xFFFFu, dist = b_ >> 16;
+            if (dist > o.pos) { st = ST_DIST; break; }
+            if (o.pos + len > o.cap) { st = ST_OVERRUN; break; }
+            emit_match(L, o, len, dist);
+            o.pos += len;
+          } else if (kd == K_EOB) {
+            sidx += adv;
+            eob = true;
+            break;
+          } else { st = ST_CODE; break; }
+          sidx += adv;
+          if (o.pos - o.flushed >= RING / 2) { __builtin_amdgcn_wave_barrier(); ring_flush(L, o, o.pos & ~15u); }
+        }
+        bp += sidx;
+      }
+      if (st != ST_OK) break;
+      bits_seek(b, bp);
+      continue;
+    }
     while (true) {
       if (b.cnt <= 32 && b.w > b.ndw + 2u) { st = ST_INPUT; break; }           // about to read past the stream (zero bits): not a valid stream
       bits_refill(b);
@@ -373,34 +514,7 @@ __global__ __launch_bounds__(64 * WPB) void k_bgen_inflate(InflateArgs a) {
         bits_drop(b, dn);
         if (dist > o.pos) { st = ST_DIST; break; }
         if (o.pos + len > o.cap) { st = ST_OVERRUN; break; }
-        __builtin_amdgcn_wave_barrier();
-        if (dist <= RING - 64) {
-          // from the ring.  dist >= 64: a 64-byte piece only reads bytes before itself; shorter distances repeat the last `dist` bytes
-          for (uint32_t c0 = 0; c0 < len; c0 += 64) {
-            const uint32_t i = c0 + lane;
-            if (i < len) {
-              // offset from pos of the source byte (wraps: unsigned); i mod dist through a float quotient (i <= 321, dist < 64: exact)
-              const uint32_t so = dist >= 64 ? i - dist : (i - dist * (uint32_t)((float)i / (float)dist)) - dist;
-              L.ring[(o.pos + i) & (RING - 1)] = L.ring[(o.pos + so) & (RING - 1)];
-            }
-            __builtin_amdgcn_wave_barrier();
-          }
-        } else {
-          // further back than the ring keeps (one match in ten on zlib level 1 genotype streams): those bytes were flushed to memory at
-          // least RING / 2 - 600 bytes ago (pos - flushed < RING / 2 + 258 + 16).  The wave's own stores have to have reached L2
-          // (s_waitcnt vmcnt(0)), and the loads go past this CU's L1 (agent-scope atomic loads of the aligned words): no cache
-          // maintenance -- a fence here (write-back + invalidate per far match) made the kernel 20x slower
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          for (uint32_t c0 = 0; c0 < len; c0 += 64) {
-            const uint32_t i = c0 + lane;
-            if (i < len) {
-              const uintptr_t A = (uintptr_t)(o.out + (o.pos + i - dist));
-              const uint32_t wd = __hip_atomic_load((const uint32_t*)(A & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              L.ring[(o.pos + i) & (RING - 1)] = (uint8_t)(wd >> (8 * (A & 3)));
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
-        }
+        emit_match(L, o, len, dist);
         o.pos += len;
       } else if ((kind & K_MASK) == K_EOB) {
         bits_drop(b, nb);
@@ -665,7 +779,9 @@ int rg_bgen_dev_decode(rg_bgen_dev* h, int32_t slot, int32_t nvar, const uint8_t
   BD_HIP(hipMemcpyAsync(d_ulen, ulen, sizeof(int32_t) * nvar, hipMemcpyHostToDevice, st));
   BD_HIP(hipMemsetAsync(s.d_sums, 0, sums_bytes, st));
   InflateArgs ia{s.d_comp, d_off, d_clen, d_ulen, s.d_raw, stride, d_status, nvar};
-  hipLaunchKernelGGL(k_bgen_inflate, dim3((unsigned)((nvar + WPB - 1) / WPB)), dim3(64 * WPB), 0, st, ia);
+  static const bool serial = getenv("RG_BGEN_SERIAL") != nullptr;      // the one-symbol-at-a-time decoder (kept as the cross-check of the window decoder)
+  if (serial) hipLaunchKernelGGL(k_bgen_inflate<false>, dim3((unsigned)((nvar + WPB - 1) / WPB)), dim3(64 * WPB), 0, st, ia);
+  else hipLaunchKernelGGL(k_bgen_inflate<true>, dim3((unsigned)((nvar + WPB - 1) / WPB)), dim3(64 * WPB), 0, st, ia);
   CheckArgs ca{s.d_comp, d_off, d_clen, d_ulen, s.d_raw, stride, h->n_file, d_status, nvar};
   unsigned long long* d_adler = (unsigned long long*)((uint8_t*)s.d_sums + ((nsum * 8 + (size_t)nvar * 4 + 7) / 8) * 8);
   hipLaunchKernelGGL(k_bgen_adler, dim3(ADLER_SEG, (unsigned)nvar), dim3(256), 0, st, ca, d_adler);
