@@ -545,6 +545,8 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
       RG_HIP(hipEventRecord(ctx->ev_join, ctx->st_side));
       RG_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
     } else
+    // (the per-column kernels of level 1 -- k_chol_diag / k_chol_panel -- measured on these 1,375 systems: 17.7 ms per batch against 15.5 ms
+    // for this group-wise path without embedded right-hand sides, 14.5 ms with them)
     rg_launch_chol_solve_formed_x(st, ctx->d_fold, msz, nullptr, 0, 1, ctx->d_lambda, R0, ctx->d_bs, 0, nblk * nseg,
                                   ctx->d_wk, msz, n64, embed ? 0 : rtot - n64, P, ctx->d_dinv, ctx->d_info + 1,
                                   &ctx->tm.n_chol_launches, 0, nullptr, 0, 0, nseg, 0, -1, 0, embed);
