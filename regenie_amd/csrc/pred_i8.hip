@@ -25,6 +25,7 @@
 // genotype operand for 512 SNPs at a time (16 x 16 bytes per lane) in registers across the 8 digit planes; the coefficient
 // digits of one (row tile, plane, half) are staged in LDS per workgroup (32 rows x 512 bytes) and shared by its eight waves.  Epilogue as in pred.hip: covariate term, mask, store, per-row sums in a fixed order.
 #include <algorithm>
+#include <cstdlib>
 #include "rg_internal.h"
 
 #define PI8_NPIECE 8
@@ -369,6 +370,152 @@ __global__ __launch_bounds__(512) void k_l0_pred_i8(PredArgs a, ChunkTab ct, int
   }
 }
 
+// ---- the same contraction with asynchronous staging (round 5) ---------------------------------------------------------------------------
+// Per-phase cycle counters of the kernel above: genotype loads + expansion 32 %, plane staging (global -> registers -> LDS) 20 %, MFMAs 17 %,
+// barriers 15 % -- the phases of the one workgroup a CU holds run back to back.  Here the K loop is outermost: a stage is 128 SNPs of ALL
+// eight digit planes of a 32-row tile (32 KB), copied straight from memory into one of two LDS buffers (global_load_lds, 16 B per lane,
+// issued through inline assembly before the MFMAs of the stage in flight: wave w copies plane w, four instructions of 8 rows x 128 B;
+// the eight 16-byte slots of a row are XOR-swizzled by (row >> 1) & 7 so that a ds_read_b128 lane group falls on 16 distinct bank groups);
+// every plane has its own int32 accumulator (|S_k| <= 64 * 2 * 1,024 = 2^17 over the whole block: no overflow, no pair trick), the genotype
+// dwords of the next stage are requested a stage ahead and expanded right before their four MFMA groups (3.5 vector instructions per MFMA),
+// and the planes meet in fp64 once per tile: out = 2^(e-54) sum_k 128^k S_k (every term exact).  One barrier per stage.
+#define PV2_STAGE 32768        // bytes of one staged K step group: 8 planes x 32 rows x 128 SNPs
+__global__ __launch_bounds__(512) void k_l0_pred_i8v2(PredArgs a, ChunkTab ct, int pg, int ngrp, const int8_t* __restrict__ planes,
+                                                     const double* __restrict__ psc, const uint8_t* __restrict__ pkT) {
+  extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+  int8_t* sA = smem;                                                       // two stage buffers; the epilogue's tmp afterwards
+  double (*sred)[PI8_ROWS][2] = reinterpret_cast<double (*)[PI8_ROWS][2]>(smem + 8 * 32 * PI8_TMP_PITCH * 8);   // [8 waves][64][2], past the tmp area
+  __shared__ double scb[PI8_ROWS][PI8_CPRE + 1];
+  __shared__ int srow_w[PI8_ROWS], srow_p[PI8_ROWS];
+  const int blk = blockIdx.z, ch = blockIdx.x, grp = blockIdx.y, p0 = grp * pg;
+  const int npg = min(pg, a.P - p0), nrow = npg * a.R0;
+  const int s = ct.seg[ch];
+  const int64_t pos0 = ct.pos[ch];
+  const int R0 = a.R0, nm = a.nseg * R0;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = lane & 31, kb = lane >> 5;
+  const int64_t pos = pos0 + wave * 32 + c;
+  const bool has_miss = a.nmiss[blk] > 0;
+  const int n128 = a.n128, nstep = n128 / 32, nstage = n128 / 128;
+  const int64_t grp_idx = ((int64_t)blk * a.nseg + s) * ngrp + grp;
+  const uint32_t* brow = reinterpret_cast<const uint32_t*>(pkT) + (((int64_t)blk * (a.Np >> 5) + (pos >> 5)) * nstep) * 64 + kb * 32 + c;
+  const int col0 = a.blockid[blk] * R0;
+  if (threadIdx.x < PI8_ROWS) {
+    const int m = threadIdx.x;
+    const bool live = m < nrow;
+    const int pl = live ? m / R0 : 0, rr = live ? m % R0 : 0;
+    srow_w[m] = live ? (col0 + rr) * a.P + p0 + pl : -1;
+    srow_p[m] = p0 + pl;
+  }
+  for (int e = threadIdx.x; e < PI8_ROWS * PI8_CPRE; e += 512) {
+    const int m = e / PI8_CPRE, cc = e % PI8_CPRE;
+    const int mc = m < nrow ? m : 0;
+    const double* cb = a.cb + (((int64_t)blk * nm + s * R0 + mc % R0) * a.P + p0 + mc / R0) * a.C;
+    scb[m][cc] = (cc < a.C && m < nrow) ? cb[min(cc, a.C - 1)] : 0.0;
+  }
+  double xv[PI8_CPRE];
+#pragma unroll
+  for (int cc = 0; cc < PI8_CPRE; ++cc) xv[cc] = a.V[(int64_t)min(cc, a.C - 1) * a.Np + pos];
+  unsigned mkbits[2] = {0u, 0u};
+  {
+    double mk[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * kb;
+        const int pl = m < nrow ? m / R0 : 0;
+        mk[t][r] = a.maskp[(int64_t)(p0 + pl) * a.Np + pos];
+      }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mkbits[t] |= (mk[t][r] != 0.0 ? 1u : 0u) << r;
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) int8_t*)smem;
+  const int ntile = nrow > 32 ? 2 : 1, nset = has_miss ? 2 : 1;
+  // this lane's part of a stage copy: plane `wave`, rows 8 j + (lane >> 3), physical slot lane & 7 = logical slot ^ ((row >> 1) & 7)
+  int roff[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int row = 8 * j + (lane >> 3), sl = (lane & 7) ^ ((row >> 1) & 7);
+    roff[j] = row * n128 + sl * 16;
+  }
+  const int xs = (c >> 1) & 7;
+#pragma unroll 1
+  for (int tile = 0; tile < ntile; ++tile) {
+    double out[16];
+#pragma unroll
+    for (int set = 0; set < 2; ++set) {
+      if (set >= nset) break;
+      const unsigned lut = set == 0 ? LUT_DOSAGE : LUT_MISS;
+      const int8_t* psrc = planes + (((grp_idx * 2 + set) * PI8_NPIECE + wave) * (int64_t)PI8_ROWS + (int64_t)tile * 32) * n128;
+      auto issue = [&](int st, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16p(psrc + roff[j] + st * 128, lds0 + buf * PV2_STAGE + (wave * 4 + j) * 1024);
+      };
+      v16i acc[PI8_NPIECE];
+#pragma unroll
+      for (int k = 0; k < PI8_NPIECE; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[k][r] = 0;
+      uint32_t gw[4], gn[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) gw[t] = brow[(int64_t)t * 64];
+      __syncthreads();                           // the previous tile's epilogue is done with the staging area
+      issue(0, 0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll 1
+      for (int st = 0; st < nstage; ++st) {
+        const int8_t* cur = sA + (st & 1) * PV2_STAGE;
+        if (st + 1 < nstage) {
+          issue(st + 1, (st + 1) & 1);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) gn[t] = brow[(int64_t)((st + 1) * 4 + t) * 64];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t w = gw[t];
+          const v4i bf = (v4i){(int)pi8_expand4(w & 0xFFu, lut), (int)pi8_expand4((w >> 8) & 0xFFu, lut),
+                               (int)pi8_expand4((w >> 16) & 0xFFu, lut), (int)pi8_expand4(w >> 24, lut)};
+          const int8_t* arow = cur + c * 128 + (((2 * t + kb) ^ xs) << 4);
+#pragma unroll
+          for (int k = 0; k < PI8_NPIECE; ++k) {
+            const v4i af = *reinterpret_cast<const v4i*>(arow + k * 4096);
+            acc[k] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af, bf, acc[k], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) gw[t] = gn[t];
+        // the next stage has landed and everybody is done with this one
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      // the planes meet: sum_k 128^k S_k (exact terms), times the row's 2^(e-54)
+      {
+        const double* scrow = psc + (grp_idx * 2 + set) * PI8_ROWS + tile * 32 + 4 * kb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          double oi = (double)acc[7][r];
+#pragma unroll
+          for (int k = PI8_NPIECE - 2; k >= 0; --k) oi = fma(oi, 128.0, (double)acc[k][r]);
+          out[r] = set == 0 ? oi * scrow[(r & 3) + 8 * (r >> 2)] : fma(oi, scrow[(r & 3) + 8 * (r >> 2)], out[r]);
+        }
+      }
+    }
+    if (a.C > PI8_CPRE) pi8_corr_tail(a, tile, nrow, blk, s, p0, pos, kb, out);
+    pi8_epilogue(a, tile, pos, wave, c, kb, out, scb, srow_w, xv, tile == 0 ? mkbits[0] : mkbits[1], reinterpret_cast<double*>(sA), sred);
+  }
+  __syncthreads();
+  if (threadIdx.x < nrow * 2) {
+    const int m = threadIdx.x >> 1, q = threadIdx.x & 1;
+    const int pl = m / R0, rr = m % R0;
+    double tsum = 0.0;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) tsum += sred[w][m][q];
+    a.psum[((((int64_t)blk * ct.n + ch) * a.P + p0 + pl) * 8 + rr) * 2 + q] = tsum;
+  }
+}
+
 // planes: nblk * nseg * ngrp * 2 * 8 * 64 * n128 bytes; psc: nblk * nseg * ngrp * 2 * 64 doubles; pkT: nblk * Np * n128 / 4 bytes
 void rg_launch_l0_pred_i8(hipStream_t st, const PredArgs& a, const ChunkTab& c256, int pg, int ngrp, int8_t* planes, double* psc,
                           uint8_t* pkT) {
@@ -376,6 +523,14 @@ void rg_launch_l0_pred_i8(hipStream_t st, const PredArgs& a, const ChunkTab& c25
                      a.n128, a.Np, pkT);
   hipLaunchKernelGGL(k_beta_split, dim3(PI8_ROWS, a.nseg * ngrp, a.nblk), dim3(256), 0, st, a, pg, ngrp, planes, psc);
   const size_t lds = (size_t)PI8_NPIECE * PI8_PLANE + sizeof(double) * 8 * PI8_ROWS * 2;     // 135,168 + 8,192 bytes
+  static const bool v1 = getenv("RG_PRED_V1") != nullptr;     // the register-staged kernel above (round 2 - 4), kept for comparison
+  if (!v1) {
+    const size_t lds2 = (size_t)8 * 32 * PI8_TMP_PITCH * 8 + sizeof(double) * 8 * PI8_ROWS * 2;      // max(two stages, the epilogue's tmp) + sums
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_l0_pred_i8v2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    hipLaunchKernelGGL(k_l0_pred_i8v2, dim3(c256.n, ngrp, a.nblk), dim3(512), lds2, st, a, c256, pg, ngrp, (const int8_t*)planes,
+                       (const double*)psc, (const uint8_t*)pkT);
+    return;
+  }
   // more than 64 KB of dynamic LDS needs the attribute; set per launch (it is per device, and a process may drive several)
   if (a.n128 % PI8_KHALF == 0) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(k_l0_pred_i8<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
