@@ -1060,7 +1060,7 @@ int bt_newton_loocv(BtState& s, double lam, std::vector<double>& beta, const rg_
   while (true) {
     if (++niter > o.niter_max_ridge) break;
     bool bad = false;
-    if ((rc = bt_solve(s, act, tauc, true, &bad))) return rc;
+    if ((rc = bt_solve(s, act, tauc, true, &bad, s.d_sw != nullptr))) return rc;      // Newton step, or the quasi-Newton one at large N
     if (bad) return RG_OK;
     for (int k = 0; k < L; ++k) step[k] = s.h_sol[k];
     for (int ls = 0; ls < o.niter_max_line_search; ++ls) {
@@ -1160,9 +1160,11 @@ int rg_l1_bt_impl(rg_ctx* ctx, int R1, const double* tau, const double* yraw, co
   const int wg_switch = getenv("RG_WGRAM_SWITCH") ? atoi(getenv("RG_WGRAM_SWITCH")) : 12;
   const double wg_min = getenv("RG_WGRAM_QUASI_MIN") ? atof(getenv("RG_WGRAM_QUASI_MIN")) : 2e11;
   const double gram_flop = (double)(ctx->seg.pos_start[ctx->seg.nseg - 1] + ctx->seg.plen[ctx->seg.nseg - 1]) * (loocv ? 1.0 : (double)(K - 1) / K) * L * (L + 1.0);
-  if (!loocv && !wg_f64 && gram_flop >= wg_min) L1X_HIP(c.bufs.alloc(&s.d_sw, (size_t)nchain * Np));
+  // (round 5: the leave-one-out Newton iteration of the logistic ridge takes the same quasi-Newton Hessian -- its line search and its stopping
+  // rule use the exact fp64 deviance and score; the leave-one-out shortcut afterwards forms the exact fp64 Hessian at the converged weights)
+  if (!wg_f64 && gram_flop >= wg_min && !(loocv && poisson)) L1X_HIP(c.bufs.alloc(&s.d_sw, (size_t)nchain * Np));
   // steps on a stored Hessian (chord / refactored, see k_tri_solve): on with the quasi-Newton Gram unless RG_WGRAM_REUSE=0
-  const bool reuse = s.d_sw && !(getenv("RG_WGRAM_REUSE") && atoi(getenv("RG_WGRAM_REUSE")) == 0) && tri_solve_lds(c.n64) <= lds_optin_bytes();
+  const bool reuse = s.d_sw && !loocv && !(getenv("RG_WGRAM_REUSE") && atoi(getenv("RG_WGRAM_REUSE")) == 0) && tri_solve_lds(c.n64) <= lds_optin_bytes();
   const double reuse_ratio = getenv("RG_WGRAM_REUSE_RATIO") ? atof(getenv("RG_WGRAM_REUSE_RATIO")) : 0.2;
   const double reuse_tol = getenv("RG_WGRAM_REUSE_TOL") ? atof(getenv("RG_WGRAM_REUSE_TOL")) : 1e-6;
   if (reuse) {

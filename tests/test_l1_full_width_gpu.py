@@ -232,11 +232,16 @@ def test_qt_loocv_level1_at_L2560():
         assert np.abs(gl - rl).max() <= 1e-8 * np.abs(rl).max()
 
 
-def test_bt_loocv_level1_at_L2560():
-    """The leave-one-out logistic ridge at full width (Step1_Models.cpp:1159-1374, Data.cpp:1484-1571): two binary traits (prevalence 0.3 and
+@pytest.mark.parametrize("quasi", [False, True])
+def test_bt_loocv_level1_at_L2560(monkeypatch, quasi):
+    """quasi: the Newton steps on the fp16 quasi-Newton Hessian (the default from 2e11 flop per Gram on, i.e. at 500,000 samples; forced here) --
+    deviance line search, stopping rule and the leave-one-out shortcut stay exact fp64.
+    The leave-one-out logistic ridge at full width (Step1_Models.cpp:1159-1374, Data.cpp:1484-1571): two binary traits (prevalence 0.3 and
     0.08, one with missing values), 4,500 samples -- below 5,000 regenie takes this route for binary traits by itself (Data.cpp:353) --
     three ridge values warm-started in the reference's order, the leave-one-out shortcut on the factor of X^T W X + tau I of order 2,560,
     then the refit at the selected value for the predictions."""
+    if quasi:
+        monkeypatch.setenv("RG_WGRAM_QUASI_MIN", "0")
     N, P = 4500, 2
     rng = np.random.default_rng(15)
     keep = np.ones(N, bool)
@@ -260,7 +265,9 @@ def test_bt_loocv_level1_at_L2560():
     eng = engine_with_w(N, X, Y, mask, keep, None, W)
     cs, conv, best, pred = eng.l1_bt(tau, yraw, offset, [nn for (_, _, nn) in cc], niter_max_ridge=opt.niter_max_ridge,
                                      niter_max_line_search_ridge=opt.niter_max_line_search_ridge, niter_max_line_search=opt.niter_max_line_search)
+    tm = eng.timing()
     eng.close()
+    assert (tm["n_wgram_approx_rounds"] > 0) == quasi
     for ph in range(P):
         rcs, ok = orc.ridge_logistic_level_1_loocv(W[ph], yraw[:, ph], offset[:, ph], mask[:, ph], tau[ph], opt)
         assert ok and conv[ph]

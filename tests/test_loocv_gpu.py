@@ -59,3 +59,18 @@ def test_level0_loocv_qt_missing(tmp_path):
     eng.close()
     for ph in range(2):
         assert rel_err(W[ph], ref.W[ph]) < 1e-8
+
+
+def test_level0_loocv_more_samples_than_one_chunk(tmp_path):
+    """70,000 samples: the leave-one-out level 0 (loocv_tri.hip) transforms the genotypes 65,536 sample positions at a time (Z = Q^T G~ per chunk,
+    the recurrences per chunk) -- two chunks here, the second a partial one -- with missing calls and a sample filter; blocks of 48 and 16 SNPs
+    (orders that are not multiples of the 64-wide tiles)."""
+    N, M = 70000, 64
+    g = synth_dosages(M, N, miss_rate=0.01, seed=41)
+    pre = str(tmp_path / "big")
+    write_plink(pre, g, np.repeat([1, 2], [48, 16]), P=2, ncov=2, seed=9)
+    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=48, loocv=True)
+    ref, W, eng = _level0_loocv(opt)
+    eng.close()
+    for ph in range(2):
+        assert rel_err(W[ph], ref.W[ph]) < 1e-8
