@@ -1,0 +1,51 @@
+"""bench.py's host-side helpers (no GPU): the I/O context of the from-files record and the oracle leg of `--bt --oracle-check`."""
+import importlib.util
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("rg_bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_host_io_context_reports_residency_and_read_rates(tmp_path):
+    b = _bench()
+    path = str(tmp_path / "f.bin")
+    with open(path, "wb") as fh:
+        fh.write(os.urandom(48 << 20))
+    r = b.host_io_context(path)
+    assert r["page_cache_resident_fraction"] is not None and 0.0 <= r["page_cache_resident_fraction"] <= 1.0
+    assert set(r["pread_GBps_by_threads"]) == {"4", "8", "16"} and all(v is None or v > 0 for v in r["pread_GBps_by_threads"].values())
+    assert r["sweep_bytes"] == 48 << 20 and r["host"]["hardware_threads"] >= 1
+    assert b.host_io_context(path, sweep_bytes=0)["pread_GBps_by_threads"] == {"4": None, "8": None, "16": None}
+
+
+def test_bt_oracle_leg_is_zero_on_the_oracles_own_answer():
+    """The comparison record of `bench.py --bt --oracle-check`: fed the oracle's own coefficients and fold sums it reports zero differences; a
+    perturbed coefficient shows up at its size."""
+    b = _bench()
+    from oracle import regenie_step1 as orc
+    rng = np.random.default_rng(3)
+    N, L = 600, 12
+    W = rng.standard_normal((N, L))
+    liab = W[:, :4].sum(axis=1) * 0.4 + rng.standard_normal(N)
+    y = (liab > np.quantile(liab, 0.8)).astype(np.float64)
+    mask = np.ones(N, bool)
+    off = np.full(N, np.log(0.2 / 0.8))
+    cv = orc.set_folds(mask, 5)
+    tau = orc.tau_from_h(orc.set_ridge_params(3), L, True)
+    opt = orc.Step1Options(bed="", pheno_file="", bt=True)
+    cs, betas, ok = orc.ridge_logistic_level_1(W, y, off, mask, cv, tau, opt, folds=[0])
+    assert ok
+    rec = b.bt_oracle_leg(W, y, off, mask, cv, tau, 0, betas[0].T.copy(), cs, float(y.mean()), False)
+    assert rec["oracle_converged"] and rec["beta_max_rel_err"] == 0.0 and rec["held_out_deviance_max_rel_err"] == 0.0 and rec["prediction_max_rel_err"] == 0.0
+    g = betas[0].T.copy()
+    g[1, 3] *= 1.0 + 1e-3
+    rec = b.bt_oracle_leg(W, y, off, mask, cv, tau, 0, g, cs, float(y.mean()), True)
+    assert 0.0 < rec["beta_max_rel_err"] < 2e-3 and "quasi-Newton" in rec["route"]
