@@ -491,14 +491,28 @@ def main():
         # level 1 does not see the block width), four traits of prevalence 5 %, 30 %, 1 % and 50 %; 98 % of that configuration is this level 1
         # (DESIGN.md section 5).  With --oracle-check the sub-run then hands the device back (RG_GPU_DONE on stderr) and has the numpy oracle refit
         # the first fold chain of the 1 % trait at full size on the host -- minutes of host work that run NEXT TO the GPU-bound sub-records
-        # that follow (the leave-one-out runs, the Step-2 kernels); configs[2] above and the BGEN run below (both host-heavy: the job has
-        # 16 CPUs of quota) have the box to themselves.
+        # that follow (the leave-one-out level 0, the Step-2 kernels); configs[2] and the leave-one-out level 1 above and the BGEN run below
+        # (all host-sensitive: the job has 16 CPUs of quota) have the box to themselves.
         try:    # BASELINE configs[2] (the north star's target workload) in full on this ONE GPU: 500,000 x 500,000 x 10 QT, resident
             l3 = sub_line(big + ["--snps", "500000", "--phenos", "10", "--warmup", "1"] + ([] if args.no_disk else ["--disk-leg"]), 1500)
             extra["config3_single_gpu"] = {k: l3[k] for k in ("ms_per_step", "value", "unit", "steps", "warmup", "loco_checksum", "selected_tau_index", "roofline",
                                                                "kernels", "end_to_end_from_files", "config")}
         except Exception as e:   # noqa: BLE001
             extra["config3_single_gpu"] = {"error": repr(e)[:500]}
+        # leave-one-out cross-validation (regenie --loocv) at the target sample count, level 1 at L = 2,560 for two quantitative traits and for one
+        # binary trait: the level-1 solvers wait on the host between steps, so they too run before the oracle takes the CPUs
+        lo = {}
+        try:
+            lq = sub_line(big + ["--loocv", "--snps", "51200", "--bsize", "100", "--phenos", "2", "--warmup", "0"], 900)
+            lo["level1_qt_s_per_trait"] = lq["level1"]["level1_wall_ms_last_step"] / 2e3
+            lo["level1_qt_device_memory_peak_GB"] = lq["level1"].get("device_memory_peak_GB")
+            lo["level1_qt_selected_tau_index"] = lq["selected_tau_index"]
+            lb = sub_line(big + ["--loocv", "--snps", "51200", "--bsize", "100", "--phenos", "1", "--bt", "--prev", "0.1", "--warmup", "0"], 900)
+            lo["level1_bt_s_per_trait"] = lb["level1"]["level1_wall_ms_last_step"] / 1e3
+            lo["level1_bt_converged"] = lb["level1"].get("bt_converged")
+            lo["level1_bt_device_memory_peak_GB"] = lb["level1"].get("device_memory_peak_GB")
+        except Exception as e:   # noqa: BLE001
+            lo["error_level1"] = repr(e)[:500]
         p4, err4 = None, []
         try:
             p4 = subprocess.Popen(me + big + ["--snps", "51200", "--bsize", "100", "--phenos", "4", "--bt", "--prev", "0.05,0.3,0.01,0.5", "--warmup", "0",
@@ -515,22 +529,12 @@ def main():
             gpu_free.wait(timeout=900)
         except Exception as e:   # noqa: BLE001 - a sub-record must not take the line down
             extra["config4_level1_binary_traits"] = {"error": repr(e)[:500]}
-        # leave-one-out cross-validation (regenie --loocv) at the target sample count: level 0 on eight full blocks of 1,000 SNPs with ten traits,
-        # level 1 at L = 2,560 for two quantitative traits and for one binary trait
-        lo = {}
+        # leave-one-out level 0 on eight full blocks of 1,000 SNPs with ten traits (device time: it does not mind the oracle beside it)
         try:
             l0 = sub_line(big + ["--loocv", "--snps", "8000", "--one-chrom", "--phenos", "10", "--l0-only", "--warmup", "1"], 900)
             lo["level0_ms_per_block_of_1000_snps"] = l0["ms_per_step"] / 8
             lo["level0_device_memory_peak_GB"] = l0["level1"].get("device_memory_peak_GB")
             lo["level0_kernels"] = {k: l0["kernels"][k] for k in ("prep", "gram_fp4", "assemble_form", "chol_f64", "pred")}
-            lq = sub_line(big + ["--loocv", "--snps", "51200", "--bsize", "100", "--phenos", "2", "--warmup", "0"], 900)
-            lo["level1_qt_s_per_trait"] = lq["level1"]["level1_wall_ms_last_step"] / 2e3
-            lo["level1_qt_device_memory_peak_GB"] = lq["level1"].get("device_memory_peak_GB")
-            lo["level1_qt_selected_tau_index"] = lq["selected_tau_index"]
-            lb = sub_line(big + ["--loocv", "--snps", "51200", "--bsize", "100", "--phenos", "1", "--bt", "--prev", "0.1", "--warmup", "0"], 900)
-            lo["level1_bt_s_per_trait"] = lb["level1"]["level1_wall_ms_last_step"] / 1e3
-            lo["level1_bt_converged"] = lb["level1"].get("bt_converged")
-            lo["level1_bt_device_memory_peak_GB"] = lb["level1"].get("device_memory_peak_GB")
             lo["config"] = "500,000 samples; level 0: 8 blocks x 1,000 SNPs x 10 QT; level 1: 512 blocks x 5 ridge values (bsize 100), 2 QT / 1 BT (prevalence 10 %)"
         except Exception as e:   # noqa: BLE001
             lo["error"] = repr(e)[:500]
@@ -635,13 +639,18 @@ def bt_oracle_leg(W0, yraw, offset, mask, cv_sizes, tau, q, g_beta, g_cs, preval
 
 def measured_traffic(dom, nblocks, n_batches, P):
     """HBM bytes per launch (group) of the dominant kernel from the rocprofv3 --pmc passes of THIS build: tools/collect_profiles.sh
-    writes profiles/*traffic*.json with the digest of the kernel sources it was measured on (regenie_amd/lib/build.stamp).  A file
-    measured on other sources is refused (traffic = null) rather than rescaled."""
+    writes profiles/*traffic*.json with the digests of the sources it was measured on (regenie_amd/lib/build.stamp = kernel library + host
+    driver, lib/library.stamp = the kernel library alone).  A file measured on other KERNEL sources is refused (traffic = null) rather than
+    rescaled; a change to the host driver (regenie_amd/host) does not change what a kernel moves and leaves the files valid."""
     import glob
     try:
         stamp = open(os.path.join(ROOT, "regenie_amd", "lib", "build.stamp")).read().strip()
     except OSError:
         return None, "no build stamp"
+    try:
+        lib_stamp = open(os.path.join(ROOT, "regenie_amd", "lib", "library.stamp")).read().strip()
+    except OSError:
+        lib_stamp = None
     group = {"chol_f64": "chol", "l1_gram_f64": "l1_gram", "gram_fp4": "gram_fp4", "pred": "pred", "wgram_f64": "wgram", "irls_stream": "irls_stream"}[dom]
     stale, same_build = False, False
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
@@ -649,7 +658,7 @@ def measured_traffic(dom, nblocks, n_batches, P):
             tj = json.load(open(fn))
         except Exception:   # noqa: BLE001
             continue
-        if tj.get("build_stamp") != stamp:
+        if tj.get("build_stamp") != stamp and (lib_stamp is None or tj.get("library_stamp") != lib_stamp):
             stale = True
             continue
         same_build = True

@@ -44,8 +44,18 @@ def source_digest() -> str:
     return _digest(_deps())
 
 
+def library_digest() -> str:
+    """The digest of what librg_step1_hip.so is built from (the kernels and the C ABI; NOT the host driver above it): build() writes it to
+    lib/library.stamp, and the PMC traffic files under profiles/ are keyed on it -- a change to host/*.cpp does not change what a kernel moves."""
+    return _digest(_lib_deps())
+
+
 def _deps():
-    return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(HERE, "host", f) for f in HOST_SOURCES + ["driver.h"]] + [
+    return _lib_deps() + [os.path.join(HERE, "host", f) for f in HOST_SOURCES + ["driver.h"]]
+
+
+def _lib_deps():
+    return [os.path.join(CSRC, s) for s in SOURCES] + [
                                                       os.path.join(CSRC, "rg_internal.h"),
                                                       os.path.join(CSRC, "step2_internal.h"),
                                                       os.path.join(CSRC, "pgen_reader.h"),
@@ -62,6 +72,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
     stamp = os.path.join(LIBDIR, "build.stamp")
     dig = source_digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
+        with open(os.path.join(LIBDIR, "library.stamp"), "w") as fh:      # (a tree built before this file existed)
+            fh.write(library_digest())
         return LIB
     hipcc = _hipcc()
     objs = []
@@ -102,6 +114,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
                         "-Wl,-rpath,$ORIGIN/../lib", "-lz", "-lpthread"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("host driver link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    with open(os.path.join(LIBDIR, "library.stamp"), "w") as fh:
+        fh.write(library_digest())
     with open(stamp, "w") as fh:
         fh.write(dig)
     return LIB

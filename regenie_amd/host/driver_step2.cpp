@@ -174,6 +174,9 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     uint8_t* comp = nullptr; int64_t comp_cap = 0;
     const uint16_t* g16_dev = nullptr; int64_t ld_dev = 0;
     double ms_read = 0, ms_dev = 0;
+    // the stored streams of the group that will be decoded into this slot NEXT, read while the other slot's group is decoded
+    std::vector<int64_t> rd_off; std::vector<int32_t> rd_clen, rd_ulen;
+    std::future<bool> rd; int64_t rd_group = -1; double rd_ms = 0;
   };
   const int64_t ld16 = (n + 7) / 8 * 8;
   // host threads of the read-ahead: inflate is the bound of this input (about 10 ms per 1.5 MB block and thread with zlib), so it takes
@@ -239,10 +242,12 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
   }
   static const struct T255 { double v[256]; T255() { for (int b = 0; b < 256; ++b) v[b] = b / 255.0; } } t255;   // the reader's prob = byte / 255.0
   // the device route of a block: false = not taken (no decoder, or a variant the decoder flagged: the host route then gives the reference's verdict)
-  auto prepare_dev = [&](const BlkRef& br, DosPrep& d, int slot, const std::vector<int64_t>& vi) -> bool {
-    if (!bdev) return false;
-    const int bs = br.bs;
+  // reads the stored streams of a group into a slot's page-locked buffer (any thread; the handle is only read)
+  auto read_streams = [&](const BlkRef& br, DosPrep& d) -> bool {
     auto t0 = std::chrono::steady_clock::now();
+    const int bs = br.bs;
+    std::vector<int64_t> vi(bs);
+    for (int j = 0; j < bs; ++j) vi[j] = r.snp_offset[(*br.snps)[br.j0 + j]];
     int64_t need = 0;
     if (rg_bgen_compressed_bytes(r.bgenh, bs, vi.data(), &need) != RG_BGEN_OK) return false;
     if (d.comp_cap < need) {
@@ -251,9 +256,31 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
       d.comp = (uint8_t*)rg_host_alloc((size_t)d.comp_cap);
       if (!d.comp) { d.comp_cap = 0; return false; }
     }
-    std::vector<int64_t> off(bs);
-    std::vector<int32_t> clen(bs), ulen(bs), status(bs), maxq(bs);
-    if (rg_bgen_read_compressed(r.bgenh, bs, vi.data(), d.comp, d.comp_cap, off.data(), clen.data(), ulen.data(), std::min(nt_prep, 32)) != RG_BGEN_OK) return false;
+    d.rd_off.resize(bs); d.rd_clen.resize(bs); d.rd_ulen.resize(bs);
+    const bool ok = rg_bgen_read_compressed(r.bgenh, bs, vi.data(), d.comp, d.comp_cap, d.rd_off.data(), d.rd_clen.data(), d.rd_ulen.data(), std::min(nt_prep, 32)) == RG_BGEN_OK;
+    d.rd_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return ok;
+  };
+  auto prepare_dev = [&](const BlkRef& br, DosPrep& d, int slot, const std::vector<int64_t>& vi, int64_t gi) -> bool {
+    if (!bdev) return false;
+    const int bs = br.bs;
+    auto t0 = std::chrono::steady_clock::now();
+    // this group's streams: read ahead (while the previous group was decoded), or now
+    bool have = false;
+    if (d.rd.valid()) { const bool ok = d.rd.get(); have = ok && d.rd_group == gi; }
+    if (!have && !read_streams(br, d)) return false;
+    d.rd_group = -1;
+    // the NEXT group's streams go into the other slot's buffer while this one is decoded (that slot's decode is long done; the main thread
+    // only reads its sums and its device rows)
+    if (gi >= 0 && (size_t)gi + 1 < groups.size()) {
+      DosPrep& dn = preps[(gi + 1) & 1];
+      if (dn.rd.valid()) dn.rd.wait();
+      dn.rd_group = gi + 1;
+      dn.rd = std::async(std::launch::async, [&, gn = gi + 1]() { return read_streams(groups[gn].ref, preps[gn & 1]); });
+    }
+    const std::vector<int64_t>& off = d.rd_off;
+    const std::vector<int32_t>&clen = d.rd_clen, &ulen = d.rd_ulen;
+    std::vector<int32_t> status(bs), maxq(bs);
     auto t1 = std::chrono::steady_clock::now();
     const bool per_trait = any_missing || glm;
     std::vector<int64_t> sq(bs), si(bs), no(bs), sqt, sit, nt;
@@ -282,20 +309,20 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     d.integral = !bad;
     d.g16_dev = o.g16; d.ld_dev = o.ld16;
     auto t2 = std::chrono::steady_clock::now();
-    d.ms_read = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    d.ms_read = have ? 0.0 : d.rd_ms;      // what the read cost THIS group's preparation (read ahead: nothing)
     d.ms_dev = std::chrono::duration<double, std::milli>(t2 - t1).count();
     d.ms_inflate = 0; d.ms_walk = 0;
     d.ms_wall = d.ms_read + d.ms_dev;
     return true;
   };
-  auto prepare = [&](const BlkRef& br, DosPrep& d, int slot) {
+  auto prepare = [&](const BlkRef& br, DosPrep& d, int slot, int64_t gi = -1) {
     try {
       const int bs = br.bs;
       auto ta = std::chrono::steady_clock::now();
       std::vector<int64_t> vi(bs);
       for (int j = 0; j < bs; ++j) vi[j] = r.snp_offset[(*br.snps)[br.j0 + j]];
       d.g16_dev = nullptr; d.ms_read = d.ms_dev = 0;
-      if (prepare_dev(br, d, slot, vi)) return;
+      if (prepare_dev(br, d, slot, vi, gi)) return;
       if (d.g16_rows < bs) {
         if (d.g16) rg_host_free(d.g16);
         d.g16 = (uint16_t*)rg_host_alloc((size_t)bs * ld16 * sizeof(uint16_t));
@@ -363,7 +390,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
   };
   std::future<void> prep_ahead;      // declared after everything `prepare` touches: its destructor waits for the worker before those go away
   if (fast_bgen && !groups.empty())      // the first group is inflated while the first chromosome's predictions are read
-    prep_ahead = std::async(std::launch::async, [&]() { prepare(groups[0].ref, preps[0], 0); });
+    prep_ahead = std::async(std::launch::async, [&]() { prepare(groups[0].ref, preps[0], 0, 0); });
   for (int chrom : r.chr_read) {
     if (!chr_snps.count(chrom)) continue;
     const std::vector<int64_t>& snps = chr_snps[chrom];
@@ -506,9 +533,9 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
         DosPrep& d = preps[gi & 1];
         if (groups[gi].first_block == my_next) {      // first block of its group: the group has to be ready, the next one is started
           if (prep_ahead.valid()) prep_ahead.get();
-          else prepare(groups[gi].ref, d, (int)(gi & 1));
+          else prepare(groups[gi].ref, d, (int)(gi & 1), (int64_t)gi);
           if (gi + 1 < groups.size())
-            prep_ahead = std::async(std::launch::async, [&, nx = gi + 1]() { prepare(groups[nx].ref, preps[nx & 1], (int)(nx & 1)); });
+            prep_ahead = std::async(std::launch::async, [&, nx = gi + 1]() { prepare(groups[nx].ref, preps[nx & 1], (int)(nx & 1), (int64_t)nx); });
           if (!d.err.empty()) { if (prep_ahead.valid()) prep_ahead.wait(); throw std::runtime_error(d.err); }
           ms_inflate += d.ms_inflate; ms_walk += d.ms_walk; ms_prep_wall += d.ms_wall;
           if (d.g16_dev) { ms_dev_read += d.ms_read; ms_dev_decode += d.ms_dev; }
@@ -863,6 +890,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
   }
   if (prep_ahead.valid()) prep_ahead.wait();
   if (prep_ahead.valid()) prep_ahead.wait();
+  for (auto& d : preps) if (d.rd.valid()) d.rd.wait();
   for (auto& d : preps) { if (d.g16) rg_host_free(d.g16); if (d.comp) rg_host_free(d.comp); }
   if (bdev) {
     if (getenv("RG_TIMING"))

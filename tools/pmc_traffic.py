@@ -4,8 +4,8 @@ collected separately: they do not fit one pass, MI355X_MICROARCH.md 'rocprofv3 P
 rocprofv3 reports both in KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads
 (HBM section of the same guide), so read bytes = 2 x FETCH_SIZE; WRITE_SIZE is taken as reported.
 Usage: pmc_traffic.py <fetch_dir> <write_dir> <n_level0_batches_in_the_run> <out.json> [blocks phenos]
-The file records the digest of the kernel sources it was measured on (regenie_amd/lib/build.stamp); bench.py refuses a file whose
-digest is not the current build's."""
+The file records the digests of the sources it was measured on (regenie_amd/lib/build.stamp: everything; lib/library.stamp: the kernel
+library without the host driver); bench.py refuses a file whose library digest is not the current build's."""
 import csv
 import glob
 import json
@@ -47,6 +47,10 @@ def main(fd, wd, nbatch, out, blocks=None, phenos=None):
         stamp = open(os.path.join(here, "..", "regenie_amd", "lib", "build.stamp")).read().strip()
     except OSError:
         stamp = None
+    try:
+        lib_stamp = open(os.path.join(here, "..", "regenie_amd", "lib", "library.stamp")).read().strip()
+    except OSError:
+        lib_stamp = None
     groups = {}
     for gname, ks in GROUPS.items():
         grd = sum(v for k, v in f.items() if k.split("<")[0] in ks) * 1024 * 2
@@ -54,7 +58,7 @@ def main(fd, wd, nbatch, out, blocks=None, phenos=None):
         lead = next((k for k in ks if ("FETCH_SIZE", k) in COUNT), ks[0])      # dispatches of the group's leading kernel in the read pass
         groups[gname] = {"read_bytes": grd, "write_bytes": gwr, "hbm_bytes": grd + gwr, "lead_kernel": lead, "lead_launches": COUNT.get(("FETCH_SIZE", lead), 0),
                          "group_launches": sum(n for (c, k), n in COUNT.items() if c == "FETCH_SIZE" and k.split("<")[0] in ks)}
-    res = {"kernel_group": list(GROUP), "level0_batches": nbatch, "build_stamp": stamp, "groups": groups,
+    res = {"kernel_group": list(GROUP), "level0_batches": nbatch, "build_stamp": stamp, "library_stamp": lib_stamp, "groups": groups,
            "blocks": int(blocks) if blocks else None, "phenos": int(phenos) if phenos else None,
            "read_bytes_per_batch": rd / nbatch, "write_bytes_per_batch": wr / nbatch,
            "hbm_bytes_per_batch": (rd + wr) / nbatch,
