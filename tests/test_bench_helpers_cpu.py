@@ -49,3 +49,30 @@ def test_bt_oracle_leg_is_zero_on_the_oracles_own_answer():
     g[1, 3] *= 1.0 + 1e-3
     rec = b.bt_oracle_leg(W, y, off, mask, cv, tau, 0, g, cs, float(y.mean()), True)
     assert 0.0 < rec["beta_max_rel_err"] < 2e-3 and "quasi-Newton" in rec["route"]
+
+
+def test_traffic_files_are_keyed_on_the_kernel_library_not_on_the_host_driver(tmp_path, monkeypatch):
+    """build.library_digest() covers what librg_step1_hip.so is built from and nothing of regenie_amd/host; measured_traffic() takes a file
+    whose library stamp is the current one even when the full build stamp differs, and refuses one measured on other kernel sources."""
+    import json
+    from regenie_amd import build
+    lib_deps, all_deps = set(map(os.path.realpath, build._lib_deps())), set(map(os.path.realpath, build._deps()))
+    assert lib_deps < all_deps and all(os.sep + "host" + os.sep in d for d in all_deps - lib_deps)
+    assert not any(os.sep + "host" + os.sep in d for d in lib_deps)
+    assert any(d.endswith("chol.hip") for d in lib_deps) and build.library_digest() != build.source_digest()
+    b = _bench()
+    root = tmp_path / "r"
+    (root / "regenie_amd" / "lib").mkdir(parents=True)
+    (root / "profiles").mkdir()
+    (root / "regenie_amd" / "lib" / "build.stamp").write_text("build-now")
+    (root / "regenie_amd" / "lib" / "library.stamp").write_text("lib-now")
+    monkeypatch.setattr(b, "ROOT", str(root))
+    rec = {"build_stamp": "build-then", "library_stamp": "lib-now", "level0_batches": 2, "blocks": 109, "phenos": 1,
+           "groups": {"chol": {"hbm_bytes": 50.0, "lead_launches": 2, "group_launches": 8}}}
+    (root / "profiles" / "x_traffic.json").write_text(json.dumps(rec))
+    per, note = b.measured_traffic("chol_f64", 109, 2, 1)
+    assert per == 25.0 and "x_traffic.json" in note
+    rec["library_stamp"] = "lib-then"
+    (root / "profiles" / "x_traffic.json").write_text(json.dumps(rec))
+    per, note = b.measured_traffic("chol_f64", 109, 2, 1)
+    assert per is None and "stale" in note

@@ -77,8 +77,8 @@ def test_reference_fixture_streams(example_dir, name):
         assert np.abs(res["sum_info"] / 65025.0 - inf).max() <= 1e-12 * max(1.0, np.abs(inf).max())
 
 
-def _write(path, probs, miss, level):
-    """BGEN v1.2 / layout 2 / 8 bits with zlib streams of a chosen level (oracle/bgen.py writes level 6 only)."""
+def _write(path, probs, miss, level, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=15):
+    """BGEN v1.2 / layout 2 / 8 bits with zlib streams of a chosen level, strategy and window (oracle/bgen.py writes level 6 only)."""
     import struct
     m, n = miss.shape
     with open(path, "wb") as fh:
@@ -90,7 +90,8 @@ def _write(path, probs, miss, level):
             fh.write(struct.pack("<H", 0) + struct.pack("<H", len(rs)) + rs + struct.pack("<H", 1) + b"1" + struct.pack("<IH", 100 + j, 2))
             fh.write(struct.pack("<I", 1) + b"A" + struct.pack("<I", 1) + b"G")
             blk = struct.pack("<IHBB", n, 2, 2, 2) + np.where(miss[j], 0x82, 0x02).astype(np.uint8).tobytes() + bytes([0, 8]) + probs[j].tobytes()
-            z = zlib.compress(blk, level)
+            co = zlib.compressobj(level, zlib.DEFLATED, wbits, 8, strategy)
+            z = co.compress(blk) + co.flush()
             fh.write(struct.pack("<II", len(z) + 4, len(blk)) + z)
 
 
@@ -125,6 +126,34 @@ def test_streams_of_every_kind(tmp_path, level):
         assert (res["raw"][:, :blocks.shape[1]] == blocks).all()
         _check(res, _expect(blocks, n, None, False))
         assert res["max_q"][1] > 510 and res["max_q"][0] == 510
+
+
+@pytest.mark.parametrize("strategy,wbits", [(zlib.Z_FIXED, 15), (zlib.Z_RLE, 15), (zlib.Z_HUFFMAN_ONLY, 15), (zlib.Z_FILTERED, 15),
+                                            (zlib.Z_DEFAULT_STRATEGY, 9)])
+def test_streams_of_other_writers(tmp_path, strategy, wbits):
+    """What a writer other than regenie's test data may hold: blocks on the FIXED code (no tables in the stream), run-length matches only
+    (distance 1, overlapping copies), literals only, the filtered strategy, and a 512-byte window (the zlib header's CINFO is not 7)."""
+    rng = np.random.default_rng(77 + strategy + wbits)
+    m, n = 6, 20000
+    g = rng.binomial(2, rng.uniform(0.02, 0.5, m)[:, None], (m, n))
+    p0 = np.where(g == 2, 255, 0); p1 = np.where(g == 1, 255, 0)
+    soft = rng.random((m, n)) < 0.2
+    a = rng.integers(0, 256, (m, n)); b = np.minimum(rng.integers(0, 256, (m, n)), 255 - a)
+    p0 = np.where(soft, a, p0); p1 = np.where(soft, b, p1)
+    p0[0], p1[0] = 0, 255                                             # all heterozygous: one long run
+    probs = np.stack([p0, p1], axis=-1).astype(np.uint8)
+    miss = rng.random((m, n)) < 0.01
+    path = str(tmp_path / "o.bgen")
+    _write(path, probs, miss, 6, strategy, wbits)
+    with BgenFile(path, threads=2) as f, BgenDevice(0) as d:
+        idx = np.arange(m)
+        comp, off, clen, ulen = f.read_compressed(idx)
+        blocks = np.stack([np.frombuffer(zlib.decompress(comp[off[k]:off[k] + clen[k]].tobytes()), dtype=np.uint8) for k in range(m)])
+        d.set_samples(n)
+        res = d.decode(comp, off, clen, ulen, fetch_raw=True)
+        assert (res["status"] == 0).all(), res["status"]
+        assert (res["raw"][:, :blocks.shape[1]] == blocks).all()
+        _check(res, _expect(blocks, n, None, False))
 
 
 def test_damaged_streams_are_flagged_not_decoded(tmp_path, example_dir):
