@@ -173,6 +173,9 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     int64_t g16_rows = 0;                    // rows the pinned buffer holds (the host route's; allocated when that route is first taken)
     uint8_t* comp = nullptr; int64_t comp_cap = 0;
     const uint16_t* g16_dev = nullptr; int64_t ld_dev = 0;
+    int dev_rows = 0;                        // rows [0, dev_rows) of the group are in device memory (g16_dev), the others in g16 from row host_row0 on
+    int host_row0 = 0;
+    bool dev_bad = false;
     double ms_read = 0, ms_dev = 0;
     // the stored streams of the group that will be decoded into this slot NEXT, read while the other slot's group is decoded
     std::vector<int64_t> rd_off; std::vector<int32_t> rd_clen, rd_ulen;
@@ -221,31 +224,51 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
   // The device decoder works on one stream per wavefront and needs thousands of them in flight: the blocks of a chromosome are prepared in
   // groups of >= RG_S2_BGEN_GROUP variants (default 3,072 = the streams the GPU holds at once) whatever --bsize is; the host route keeps
   // one block per group.  A group is a range of the chromosome's variants, i.e. a BlkRef of its own.
-  struct Group { BlkRef ref; size_t first_block; };
+  struct Group { BlkRef ref; size_t first_block; int dev_rows; std::vector<int> starts; };
   std::vector<Group> groups;
   std::vector<std::pair<size_t, int>> block_group;      // per block of my_blocks: its group, its first row there
   if (fast_bgen) {
-    const int target = bdev ? std::max(p.bsize, getenv("RG_S2_BGEN_GROUP") ? atoi(getenv("RG_S2_BGEN_GROUP")) : 3072) : p.bsize;
+    // RG_S2_BGEN_HOST_SHARE=f: the host threads take the share f of every group beside the device (whole blocks from the group's end; their
+    // route gives the same result lines -- both are held to regenie's).  The device's part keeps its size -- a launch takes as long for 2,000
+    // streams as for 3,072, every stream being a chain of its own -- and the host's blocks come on top.  Off by default: on a box that gives
+    // the job 16 CPUs the workers take those from the reads, the chromosome set-ups and the uploads (36,864 variants at 500,000 samples: 4.3 s
+    // without, 4.7 s with f = 0.25, 5.4 s with 0.38, 6.9 s with 0.5); it is for hosts with idle cores.  The share is fixed for a run, so that
+    // the split does not depend on timing.
+    double share = 0.0;
+    if (bdev)
+      if (const char* e = getenv("RG_S2_BGEN_HOST_SHARE")) share = std::min(0.9, std::max(0.0, atof(e)));
+    const int dev_target = std::max(p.bsize, getenv("RG_S2_BGEN_GROUP") ? atoi(getenv("RG_S2_BGEN_GROUP")) : 3072);
+    const int target = bdev ? (int)std::min(65536.0, dev_target / (1.0 - share)) : p.bsize;
     for (size_t b = 0; b < my_blocks.size(); ++b) {
       const BlkRef& br = my_blocks[b];
       if (!groups.empty()) {
         Group& g = groups.back();
         if (g.ref.snps == br.snps && g.ref.j0 + g.ref.bs == br.j0 && g.ref.bs + br.bs <= target) {
           block_group.push_back({groups.size() - 1, g.ref.bs});
+          g.starts.push_back(g.ref.bs);
           g.ref.bs += br.bs;
           continue;
         }
       }
-      groups.push_back({br, b});
+      groups.push_back({br, b, 0, {0}});
       block_group.push_back({groups.size() - 1, 0});
+    }
+    for (Group& g : groups) {
+      g.dev_rows = bdev ? g.ref.bs : 0;
+      if (bdev && share > 0.0) {      // the block boundary nearest to the device's share; a group of one block stays whole
+        const double want = (1.0 - share) * g.ref.bs;
+        int best = g.ref.bs;
+        for (int st : g.starts) if (st > 0 && std::fabs(st - want) < std::fabs(best - want)) best = st;
+        g.dev_rows = best;
+      }
     }
   }
   static const struct T255 { double v[256]; T255() { for (int b = 0; b < 256; ++b) v[b] = b / 255.0; } } t255;   // the reader's prob = byte / 255.0
   // the device route of a block: false = not taken (no decoder, or a variant the decoder flagged: the host route then gives the reference's verdict)
   // reads the stored streams of a group into a slot's page-locked buffer (any thread; the handle is only read)
-  auto read_streams = [&](const BlkRef& br, DosPrep& d) -> bool {
+  auto read_streams = [&](const BlkRef& br, DosPrep& d, int rows) -> bool {
     auto t0 = std::chrono::steady_clock::now();
-    const int bs = br.bs;
+    const int bs = rows;
     std::vector<int64_t> vi(bs);
     for (int j = 0; j < bs; ++j) vi[j] = r.snp_offset[(*br.snps)[br.j0 + j]];
     int64_t need = 0;
@@ -261,22 +284,22 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     d.rd_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return ok;
   };
-  auto prepare_dev = [&](const BlkRef& br, DosPrep& d, int slot, const std::vector<int64_t>& vi, int64_t gi) -> bool {
-    if (!bdev) return false;
-    const int bs = br.bs;
-    auto t0 = std::chrono::steady_clock::now();
+  // the first `rows` variants of a group on the device: their sums into d.total ... (sized by the caller), their dosage rows left in device memory
+  auto prepare_dev = [&](const BlkRef& br, DosPrep& d, int slot, int64_t gi, int rows) -> bool {
+    if (!bdev || rows < 1) return false;
+    const int bs = rows;
     // this group's streams: read ahead (while the previous group was decoded), or now
     bool have = false;
     if (d.rd.valid()) { const bool ok = d.rd.get(); have = ok && d.rd_group == gi; }
-    if (!have && !read_streams(br, d)) return false;
+    if (!have && !read_streams(br, d, rows)) return false;
     d.rd_group = -1;
     // the NEXT group's streams go into the other slot's buffer while this one is decoded (that slot's decode is long done; the main thread
     // only reads its sums and its device rows)
-    if (gi >= 0 && (size_t)gi + 1 < groups.size()) {
+    if (gi >= 0 && (size_t)gi + 1 < groups.size() && groups[gi + 1].dev_rows > 0) {
       DosPrep& dn = preps[(gi + 1) & 1];
       if (dn.rd.valid()) dn.rd.wait();
       dn.rd_group = gi + 1;
-      dn.rd = std::async(std::launch::async, [&, gn = gi + 1]() { return read_streams(groups[gn].ref, preps[gn & 1]); });
+      dn.rd = std::async(std::launch::async, [&, gn = gi + 1]() { return read_streams(groups[gn].ref, preps[gn & 1], groups[gn].dev_rows); });
     }
     const std::vector<int64_t>& off = d.rd_off;
     const std::vector<int32_t>&clen = d.rd_clen, &ulen = d.rd_ulen;
@@ -291,8 +314,6 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     if (per_trait) { o.sum_q_t = sqt.data(); o.sum_info_t = sit.data(); o.n_obs_t = nt.data(); }
     if (rg_bgen_dev_decode(bdev, slot, bs, d.comp, off[bs - 1] + clen[bs - 1], off.data(), clen.data(), ulen.data(), p.ref_first ? 1 : 0, &o) != RG_BGEN_OK) return false;
     for (int j = 0; j < bs; ++j) if (status[j] != 0) return false;
-    d.total.assign(bs, 0.0); d.info_num.assign(bs, 0.0); d.ns1.assign(bs, 0); d.ignored.assign(bs, 0);
-    if (per_trait) { d.af_t.assign((size_t)bs * P, 0.0); d.ns_t.assign((size_t)bs * P, 0); d.info_t.assign((size_t)bs * P, 0.0); }
     bool bad = false;
     for (int j = 0; j < bs; ++j) {
       // the walk's exact integer sums in the units the host route accumulates as doubles: dosages in 1 / 255, info terms in 1 / 65025
@@ -306,82 +327,98 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
           d.info_t[(size_t)j * P + q] = -(double)sit[(size_t)j * P + q] / 65025.0;
         }
     }
-    d.integral = !bad;
+    d.dev_bad = bad;
     d.g16_dev = o.g16; d.ld_dev = o.ld16;
     auto t2 = std::chrono::steady_clock::now();
     d.ms_read = have ? 0.0 : d.rd_ms;      // what the read cost THIS group's preparation (read ahead: nothing)
     d.ms_dev = std::chrono::duration<double, std::milli>(t2 - t1).count();
-    d.ms_inflate = 0; d.ms_walk = 0;
-    d.ms_wall = d.ms_read + d.ms_dev;
     return true;
   };
-  auto prepare = [&](const BlkRef& br, DosPrep& d, int slot, int64_t gi = -1) {
+  auto prepare = [&](const BlkRef& br, DosPrep& d, int slot, int64_t gi) {
     try {
       const int bs = br.bs;
       auto ta = std::chrono::steady_clock::now();
       std::vector<int64_t> vi(bs);
       for (int j = 0; j < bs; ++j) vi[j] = r.snp_offset[(*br.snps)[br.j0 + j]];
-      d.g16_dev = nullptr; d.ms_read = d.ms_dev = 0;
-      if (prepare_dev(br, d, slot, vi, gi)) return;
-      if (d.g16_rows < bs) {
-        if (d.g16) rg_host_free(d.g16);
-        d.g16 = (uint16_t*)rg_host_alloc((size_t)bs * ld16 * sizeof(uint16_t));
-        d.g16_rows = d.g16 ? bs : 0;
-        if (!d.g16) throw std::runtime_error("cannot allocate the pinned dosage buffers");
-      }
-      d.raw.resize((size_t)nt_prep * bgen_block_bytes);        // one inflated block per worker: walked while it is still in that core's cache
-      d.total.assign(bs, 0.0); d.info_num.assign(bs, 0.0); d.ns1.assign(bs, 0); d.ignored.assign(bs, 0);
       const bool per_trait = any_missing || glm;
+      d.g16_dev = nullptr; d.ms_read = d.ms_dev = 0; d.dev_rows = 0; d.host_row0 = 0; d.dev_bad = false;
+      d.total.assign(bs, 0.0); d.info_num.assign(bs, 0.0); d.ns1.assign(bs, 0); d.ignored.assign(bs, 0);
       if (per_trait) { d.af_t.assign((size_t)bs * P, 0.0); d.ns_t.assign((size_t)bs * P, 0); d.info_t.assign((size_t)bs * P, 0.0); }
-      std::atomic<int> bad(0), next(0);
+      std::atomic<int> bad(0);
       std::vector<std::string> werr(nt_prep);
       std::vector<double> w_inf(nt_prep, 0.0), w_walk(nt_prep, 0.0);
       const bool rf = p.ref_first;
-      // (no reader lock: the read call only reads the handle, so the parts of a --gpus N run inflate at the same time)
-      parallel_for(nt_prep, nt_prep, [&](int w) {
-        uint8_t* blk = d.raw.data() + (size_t)w * bgen_block_bytes;
-        for (int j; (j = next.fetch_add(1)) < bs;) {
-          auto t0 = std::chrono::steady_clock::now();
-          if (rg_bgen_read_blocks(r.bgenh, 1, &vi[j], blk, bgen_block_bytes, 1) != RG_BGEN_OK) { werr[w] = rg_bgen_last_error(r.bgenh); next = bs; return; }
-          auto t1 = std::chrono::steady_clock::now();
-          const uint8_t* ploidy = blk + 8;
-          const uint8_t* pr = blk + 10 + r.n_file;
-          uint16_t* q16 = d.g16 + (size_t)j * ld16;
-          double tot = 0.0, inf = 0.0; int64_t ns = 0;
-          unsigned worst = 0;
-          for (int64_t k = 0; k < n; ++k) {
-            const int64_t i = identity ? k : file_idx[k];
-            if (ploidy[i] & 0x80) { q16[k] = 0xFFFFu; continue; }
-            const unsigned b0 = pr[2 * i], b1 = pr[2 * i + 1];
-            const double p0 = t255.v[b0], p1 = t255.v[b1];
-            double v, e;
-            unsigned qi;
-            if (rf) {     // G = prob1 + 2 prob2, prob2 = max(1 - prob0 - prob1, 0) (Geno.cpp:2286-2290)
-              const double p2 = std::max(1.0 - p0 - p1, 0.0);
-              v = p1 + 2.0 * p2; e = (4.0 * p2 + p1) - v * v;
-              qi = b1 + 2u * (b0 + b1 < 255u ? 255u - b0 - b1 : 0u);
-            } else {
-              v = p1 + 2.0 * p0; e = (4.0 * p0 + p1) - v * v;
-              qi = b1 + 2u * b0;
-            }
-            worst = std::max(worst, qi);
-            q16[k] = (uint16_t)qi;
-            tot += v; inf += e; ++ns;
-            if (per_trait && has_missing[k])
-              for (int q = 0; q < P; ++q)
-                if (!Mc[(size_t)q * n + k]) { d.af_t[(size_t)j * P + q] -= v; d.ns_t[(size_t)j * P + q] -= 1; d.info_t[(size_t)j * P + q] -= e; }
-          }
-          for (int64_t k = n; k < ld16; ++k) q16[k] = 0;
-          if (worst > 510u) bad = 1;          // prob0 + prob1 > 1 in the file: not a dosage in [0, 2], the general route reports what the reference would
-          d.total[j] = tot; d.ns1[j] = ns; d.info_num[j] = inf;
-          if (std::min(tot, 2.0 * ns - tot) < p.min_mac) d.ignored[j] = 1;      // compute_mac (Geno.cpp:3077-3108), autosomes
-          auto t2 = std::chrono::steady_clock::now();
-          w_inf[w] += std::chrono::duration<double, std::milli>(t1 - t0).count();
-          w_walk[w] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+      // rows [lo, bs) of the group on the host threads, into the pinned buffer from its first row on
+      auto host_rows = [&](int lo) {
+        if (lo >= bs) return;
+        if (d.g16_rows < bs - lo) {
+          if (d.g16) rg_host_free(d.g16);
+          d.g16 = (uint16_t*)rg_host_alloc((size_t)(bs - lo) * ld16 * sizeof(uint16_t));
+          d.g16_rows = d.g16 ? bs - lo : 0;
+          if (!d.g16) throw std::runtime_error("cannot allocate the pinned dosage buffers");
         }
-      });
-      for (const auto& e : werr) if (!e.empty()) throw std::runtime_error(e);
-      d.integral = !bad;
+        d.host_row0 = lo;
+        d.raw.resize((size_t)nt_prep * bgen_block_bytes);        // one inflated block per worker: walked while it is still in that core's cache
+        std::atomic<int> next(lo);
+        // (no reader lock: the read call only reads the handle, so the parts of a --gpus N run inflate at the same time)
+        parallel_for(nt_prep, nt_prep, [&](int w) {
+          uint8_t* blk = d.raw.data() + (size_t)w * bgen_block_bytes;
+          for (int j; (j = next.fetch_add(1)) < bs;) {
+            auto t0 = std::chrono::steady_clock::now();
+            if (rg_bgen_read_blocks(r.bgenh, 1, &vi[j], blk, bgen_block_bytes, 1) != RG_BGEN_OK) { werr[w] = rg_bgen_last_error(r.bgenh); next = bs; return; }
+            auto t1 = std::chrono::steady_clock::now();
+            const uint8_t* ploidy = blk + 8;
+            const uint8_t* pr = blk + 10 + r.n_file;
+            uint16_t* q16 = d.g16 + (size_t)(j - lo) * ld16;
+            double tot = 0.0, inf = 0.0; int64_t ns = 0;
+            unsigned worst = 0;
+            if (per_trait)
+              for (int q = 0; q < P; ++q) { d.af_t[(size_t)j * P + q] = 0.0; d.ns_t[(size_t)j * P + q] = 0; d.info_t[(size_t)j * P + q] = 0.0; }
+            for (int64_t k = 0; k < n; ++k) {
+              const int64_t i = identity ? k : file_idx[k];
+              if (ploidy[i] & 0x80) { q16[k] = 0xFFFFu; continue; }
+              const unsigned b0 = pr[2 * i], b1 = pr[2 * i + 1];
+              const double p0 = t255.v[b0], p1 = t255.v[b1];
+              double v, e;
+              unsigned qi;
+              if (rf) {     // G = prob1 + 2 prob2, prob2 = max(1 - prob0 - prob1, 0) (Geno.cpp:2286-2290)
+                const double p2 = std::max(1.0 - p0 - p1, 0.0);
+                v = p1 + 2.0 * p2; e = (4.0 * p2 + p1) - v * v;
+                qi = b1 + 2u * (b0 + b1 < 255u ? 255u - b0 - b1 : 0u);
+              } else {
+                v = p1 + 2.0 * p0; e = (4.0 * p0 + p1) - v * v;
+                qi = b1 + 2u * b0;
+              }
+              worst = std::max(worst, qi);
+              q16[k] = (uint16_t)qi;
+              tot += v; inf += e; ++ns;
+              if (per_trait && has_missing[k])
+                for (int q = 0; q < P; ++q)
+                  if (!Mc[(size_t)q * n + k]) { d.af_t[(size_t)j * P + q] -= v; d.ns_t[(size_t)j * P + q] -= 1; d.info_t[(size_t)j * P + q] -= e; }
+            }
+            for (int64_t k = n; k < ld16; ++k) q16[k] = 0;
+            if (worst > 510u) bad = 1;          // prob0 + prob1 > 1 in the file: not a dosage in [0, 2], the general route reports what the reference would
+            d.total[j] = tot; d.ns1[j] = ns; d.info_num[j] = inf;
+            d.ignored[j] = std::min(tot, 2.0 * ns - tot) < p.min_mac ? 1 : 0;      // compute_mac (Geno.cpp:3077-3108), autosomes
+            auto t2 = std::chrono::steady_clock::now();
+            w_inf[w] += std::chrono::duration<double, std::milli>(t1 - t0).count();
+            w_walk[w] += std::chrono::duration<double, std::milli>(t2 - t1).count();
+          }
+        });
+        for (const auto& e : werr) if (!e.empty()) throw std::runtime_error(e);
+      };
+      // the group's first rows on the device and, beside them, its last blocks on the host threads; a group the decoder turns down goes to
+      // the host threads as a whole (a damaged stream, another encoding: their messages are the reference's)
+      const int split = (bdev && gi >= 0) ? groups[gi].dev_rows : 0;
+      bool dev_ok = false;
+      if (split > 0) {
+        std::future<bool> fdev = std::async(std::launch::async, [&]() { return prepare_dev(br, d, slot, gi, split); });
+        try { host_rows(split); } catch (...) { fdev.wait(); throw; }
+        dev_ok = fdev.get();
+      }
+      if (dev_ok) d.dev_rows = split;
+      else { d.g16_dev = nullptr; d.dev_bad = false; host_rows(0); }
+      d.integral = !bad && !d.dev_bad;
       // thread-milliseconds of the two halves, and the wall time of the block's preparation
       d.ms_inflate = 0; d.ms_walk = 0;
       for (int w = 0; w < nt_prep; ++w) { d.ms_inflate += w_inf[w]; d.ms_walk += w_walk[w]; }
@@ -538,11 +575,11 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
             prep_ahead = std::async(std::launch::async, [&, nx = gi + 1]() { prepare(groups[nx].ref, preps[nx & 1], (int)(nx & 1), (int64_t)nx); });
           if (!d.err.empty()) { if (prep_ahead.valid()) prep_ahead.wait(); throw std::runtime_error(d.err); }
           ms_inflate += d.ms_inflate; ms_walk += d.ms_walk; ms_prep_wall += d.ms_wall;
-          if (d.g16_dev) { ms_dev_read += d.ms_read; ms_dev_decode += d.ms_dev; }
+          if (d.dev_rows > 0) { ms_dev_read += d.ms_read; ms_dev_decode += d.ms_dev; }
         }
         ++my_next;
         ms_prep_wait += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
-        if (d.g16_dev) ++n_dev_blocks; else ++n_host_blocks;
+        if (dp_row0 < d.dev_rows) ++n_dev_blocks; else ++n_host_blocks;
         if (d.integral) dp = &d;
       }
       if (in == In::PgenHard) {   // ReadHardcalls per variant (Geno.cpp:2570-2573), as .bed-coded rows (00 = two ALT copies)
@@ -591,9 +628,10 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
           af_t.assign(dp->af_t.begin() + r0 * P, dp->af_t.begin() + (r0 + bs) * P); ns_t.assign(dp->ns_t.begin() + r0 * P, dp->ns_t.begin() + (r0 + bs) * P);
           info_t.assign(dp->info_t.begin() + r0 * P, dp->info_t.begin() + (r0 + bs) * P);
         }
-        integral = true; g16ld = dp->g16_dev ? dp->ld_dev : ld16;
-        g16p = (dp->g16_dev ? dp->g16_dev : dp->g16) + r0 * (size_t)g16ld;
-        g16_on_device = dp->g16_dev ? 1 : 0;
+        const bool on_dev = dp_row0 < dp->dev_rows;      // (a group is split at a block boundary)
+        integral = true; g16ld = on_dev ? dp->ld_dev : ld16;
+        g16p = on_dev ? dp->g16_dev + r0 * (size_t)g16ld : dp->g16 + (r0 - (size_t)dp->host_row0) * (size_t)g16ld;
+        g16_on_device = on_dev ? 1 : 0;
       } else if (in == In::Dosage) {
         // dosages: the analysed samples' doubles, allele totals, the info-score numerator and the per-trait corrections on the host
         // (parseSnpfromBGEN / readChunkFromPGENFileToG with update_trait_counts, Geno.cpp:2948-2959), the test on the fp64 route

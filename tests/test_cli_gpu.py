@@ -769,6 +769,18 @@ def test_cli_step2_qt_masked_phenotypes_against_reference_output(tmp_path, fmt):
             assert ta[:t0] == tb[:t0]
             for x, y in zip(ta[t0:t0 + 4], tb[t0:t0 + 4]):
                 assert float(x) == pytest.approx(float(y), rel=1e-5, abs=1e-9), (la, lb)
+    if fmt != "bgen":
+        return
+    # RG_S2_BGEN_HOST_SHARE: the host threads decode the last blocks of every group beside the device decoder -- the same files, byte for byte
+    import re
+    a3 = list(args)
+    a3[a3.index("--bsize") + 1] = "40"
+    r3 = subprocess.run(a3, cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=dict(env, RG_S2_BGEN_HOST_SHARE="0.5", RG_TIMING="1"))
+    assert r3.returncode == 0, r3.stdout[-3000:] + r3.stderr[-3000:]
+    m = re.search(r"BGEN on the device: (\d+) blocks \((\d+) on the host route\)", r3.stderr)
+    assert m and int(m.group(1)) > 0 and int(m.group(2)) > 0, r3.stderr[-2000:]
+    for k in range(1, spec["P"] + 1):
+        assert open(str(tmp_path / ("s2_Y%d.regenie" % k))).read() == keep[k]
 
 
 def test_cli_step2_bt_score_test_against_reference_output(example_dir, tmp_path):
