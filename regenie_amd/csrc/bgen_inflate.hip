@@ -405,26 +405,44 @@ __global__ __launch_bounds__(64 * WPB) void k_bgen_inflate(InflateArgs a) {
     }
     // ---- the block's symbols ----
     if (PAR) {
-      // Window decoder (round 5, second form): the serial loop below issues ~120 scalar instructions and two or three dependent LDS
-      // round trips per symbol (~1 us).  Here all 64 lanes decode SPECULATIVELY the symbol that would start at each of the next 64
-      // bit positions (lane i: bits bp + i ...: literal / length code, extra bits, distance code, extra bits -- at most 48 bits, taken
-      // from five dwords of the stream by one funnel shift per lane), and the wave then walks the chain of true starts through the
-      // lanes' results (two v_readlane per symbol): the table look-ups of ~2.5 symbols of these streams run in parallel, the serial
-      // part of a symbol is ~25 scalar instructions plus its output.
+      // Window decoder (round 5): the serial loop below issues ~120 scalar instructions and two or three dependent LDS round trips per
+      // symbol (~1 us).  Here all 64 lanes decode SPECULATIVELY the symbol that would start at each of the next 64 bit positions (lane i:
+      // bits bp + i ...: literal / length code, extra bits, distance code, extra bits -- at most 48 bits, out of three dwords of the
+      // stream gathered across the lanes), and the wave then walks the chain of true starts through the lanes' results: ONE v_readlane
+      // per symbol, whose 32 bits hold everything the walk needs --
+      //   bits 0-5 the symbol's length in bits | bit 6 match | bit 7 end of block (bit 8 set) or no code (bit 8 clear)
+      //   literal: bits 8-15 the byte | match: bits 8-16 the length, bits 17-31 the distance - 1.
+      // The scalar unit is what the kernel runs out of (PMC: 114 scalar instructions per symbol in the first form of this loop), so the
+      // walk does as little as it can: a literal is written without a bounds test (the window loop runs while 64 more bytes fit -- a window
+      // holds at most 64 symbols -- and hands the block's tail to the serial loop below), an end-of-block or invalid code takes the
+      // literal's path (its byte lands on a position that is not advanced), and the loop has ONE exit test (a loop with several exits and
+      // lane-dependent code inside is rebuilt by the compiler around exit-selector registers: two dozen scalar moves per symbol).
       uint32_t bp = b.w * 32u - b.cnt;
       uint32_t chunk = (bp >> 5) >> 6;
       uint32_t cur = load_dw(b, 64u * chunk + (uint32_t)lane), nxt = load_dw(b, 64u * chunk + 64u + (uint32_t)lane);
-      bool eob = false;
-      while (st == ST_OK && !eob) {
+      uint32_t stop = 0;                               // 1 = end of block, 2 = the block's tail goes to the serial loop, 16 + ST_* = failure
+      // the window loop runs while a match of any length and the literals of a whole window still fit behind it: one test per match, none per literal
+      const bool win_ok = o.cap >= 322u;
+      const uint32_t lim = o.cap - 322u;
+      while (win_ok && stop == 0u && o.pos <= lim) {
         const uint32_t w0 = bp >> 5;
         if (w0 >= 64u * (chunk + 1u)) { ++chunk; cur = nxt; nxt = load_dw(b, 64u * chunk + 64u + (uint32_t)lane); }
-        if (w0 > b.ndw + 2u) { st = ST_INPUT; break; }
-        const uint32_t d0 = dw_at(cur, nxt, chunk, w0), d1 = dw_at(cur, nxt, chunk, w0 + 1u), d2 = dw_at(cur, nxt, chunk, w0 + 2u),
-                       d3 = dw_at(cur, nxt, chunk, w0 + 3u), d4 = dw_at(cur, nxt, chunk, w0 + 4u);
-        uint32_t A, B = 0;
+        if (w0 > b.ndw + 2u) { stop = 16u + (uint32_t)ST_INPUT; break; }
+        uint32_t A;
         {
-          const uint32_t bb = (bp & 31u) + (uint32_t)lane, q = bb >> 5, sh = bb & 31u;       // q in 0..2
-          const uint32_t lo = q == 0 ? d0 : (q == 1 ? d1 : d2), mid = q == 0 ? d1 : (q == 1 ? d2 : d3), hi = q == 0 ? d2 : (q == 1 ? d3 : d4);
+          // the three dwords the lane's 64 bits span, gathered across the lanes that hold the stream (no scalar work); only a window that
+          // reaches into the next chunk (5 in 64) needs the second register
+          const uint32_t bb = (bp & 31u) + (uint32_t)lane, sh = bb & 31u;
+          const uint32_t base = w0 - 64u * chunk, rel = base + (bb >> 5);      // rel .. rel + 2 <= base + 4 <= 67
+          uint32_t lo, mid, hi;
+          lo = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rel << 2), (int)cur);
+          mid = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rel + 1u) << 2), (int)cur);
+          hi = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rel + 2u) << 2), (int)cur);
+          if (base + 4u >= 64u) {
+            const uint32_t n0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(rel << 2), (int)nxt), n1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rel + 1u) << 2), (int)nxt),
+                           n2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((rel + 2u) << 2), (int)nxt);
+            lo = rel >= 64u ? n0 : lo; mid = rel + 1u >= 64u ? n1 : mid; hi = rel + 2u >= 64u ? n2 : hi;
+          }
           const uint32_t r0 = __builtin_amdgcn_alignbit(mid, lo, sh), r1 = __builtin_amdgcn_alignbit(hi, mid, sh);
           const uint64_t win = ((uint64_t)r1 << 32) | r0;
           uint32_t e = L.lit[r0 & ((1u << LIT_TB) - 1u)];
@@ -433,8 +451,10 @@ __global__ __launch_bounds__(64 * WPB) void k_bgen_inflate(InflateArgs a) {
             e = L.lit[(e >> 16) + ((r0 & ((1u << (LIT_TB + sb)) - 1u)) >> LIT_TB)];
           }
           const uint32_t kind = (e >> 8) & 0xFFu, nb = e & 0xFFu;
-          A = nb | ((kind & K_MASK) << 8) | (e & 0xFFFF0000u);
-          if ((kind & K_MASK) == K_LEN) {
+          A = 0x80u;                                                            // no code
+          if ((kind & K_MASK) == K_LIT) A = nb | ((e >> 8) & 0xFF00u);          // the byte: bits 16-23 of the entry
+          else if ((kind & K_MASK) == K_EOB) A = nb | 0x180u;
+          else if ((kind & K_MASK) == K_LEN) {
             const uint32_t xb = kind & K_XBITS;
             const uint32_t len = (e >> 16) + ((r0 & ((1u << nb) - 1u)) >> (nb - xb));
             const uint32_t w2 = (uint32_t)(win >> nb);
@@ -444,44 +464,47 @@ __global__ __launch_bounds__(64 * WPB) void k_bgen_inflate(InflateArgs a) {
               d = L.dist[(d >> 16) + ((w2 & ((1u << (DIST_TB + sb)) - 1u)) >> DIST_TB)];
             }
             const uint32_t dk = (d >> 8) & 0xFFu, dn = d & 0xFFu;
-            if ((dk & K_MASK) != K_LEN) A = (uint32_t)K_BAD << 8;
-            else {
+            if ((dk & K_MASK) == K_LEN) {
               const uint32_t dxb = dk & K_XBITS;
-              const uint32_t dist = (d >> 16) + ((w2 & ((1u << dn) - 1u)) >> (dn - dxb));
-              A = (nb + dn) | ((uint32_t)K_LEN << 8);
-              B = len | (dist << 16);
+              const uint32_t dist = (d >> 16) + ((w2 & ((1u << dn) - 1u)) >> (dn - dxb));      // 1 .. 32,768
+              // bit 7 of a match: not the common case -- <= 64 bytes out of the ring, none of them written by the match itself -- whose copy is
+              // one masked LDS read + write with nothing to decide
+              const uint32_t slow = (dist > RING - 64u || dist < len || len > 64u) ? 0x80u : 0u;
+              A = (nb + dn) | 0x40u | slow | (len << 8) | ((dist - 1u) << 17);                     // nb + dn <= 48, len <= 258
             }
           }
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t sidx = 0;
-        while (sidx < 64u) {
+        do {
           const uint32_t a_ = (uint32_t)__builtin_amdgcn_readlane((int)A, (int)sidx);
-          const uint32_t kd = (a_ >> 8) & K_MASK, adv = a_ & 0xFFu;
-          if (kd == K_LIT) {
-            if (o.pos >= o.cap) { st = ST_OVERRUN; break; }
-            if (lane == 0) L.ring[o.pos & (RING - 1)] = (uint8_t)(a_ >> 16);
-            ++o.pos;
-          } else if (kd == K_LEN) {
-            const uint32_t b_ = (uint32_t)__builtin_amdgcn_readlane((int)B, (int)sidx);
-            const uint32_t len = b_ & 0xFFFFu, dist = b_ >> 16;
-            if (dist > o.pos) { st = ST_DIST; break; }
-            if (o.pos + len > o.cap) { st = ST_OVERRUN; break; }
-            emit_match(L, o, len, dist);
-            o.pos += len;
-          } else if (kd == K_EOB) {
-            sidx += adv;
-            eob = true;
-            break;
-          } else { st = ST_CODE; break; }
+          uint32_t adv = a_ & 0x3Fu;
+          if (a_ & 0x40u) {
+            const uint32_t len = (a_ >> 8) & 0x1FFu, dist = (a_ >> 17) + 1u;
+            if (dist <= o.pos && o.pos <= lim) {
+              if (a_ & 0x80u) emit_match(L, o, len, dist);
+              else if ((uint32_t)lane < len) L.ring[(o.pos + (uint32_t)lane) & (RING - 1)] = L.ring[(o.pos + (uint32_t)lane - dist) & (RING - 1)];
+              o.pos += len;
+            } else {                                   // not consumed: the serial loop takes the block's tail, and reports a distance before the block
+              stop = o.pos > lim ? 2u : 16u + (uint32_t)ST_DIST;
+              adv = 0;
+            }
+          } else {
+            const uint32_t special = (a_ >> 7) & 1u;
+            if (lane == 0) L.ring[o.pos & (RING - 1)] = (uint8_t)(a_ >> 8);
+            o.pos += special ^ 1u;
+            stop = special ? ((a_ & 0x100u) ? 1u : 16u + (uint32_t)ST_CODE) : 0u;
+          }
           sidx += adv;
           if (o.pos - o.flushed >= RING / 2) { __builtin_amdgcn_wave_barrier(); ring_flush(L, o, o.pos & ~15u); }
-        }
+        } while (sidx < 64u && stop == 0u);
         bp += sidx;
       }
-      if (st != ST_OK) break;
+      if (stop == 0u) stop = 2u;                       // (left at the top: the tail)
+      if (stop > 2u) { st = (int)(stop - 16u); break; }
       bits_seek(b, bp);
-      continue;
+      if (stop == 1u) continue;
+      // (the last bytes of the block: the serial loop, which tests every symbol against the block's size)
     }
     while (true) {
       if (b.cnt <= 32 && b.w > b.ndw + 2u) { st = ST_INPUT; break; }           // about to read past the stream (zero bits): not a valid stream
