@@ -641,7 +641,8 @@ def measured_traffic(dom, nblocks, n_batches, P):
     """HBM bytes per launch (group) of the dominant kernel from the rocprofv3 --pmc passes of THIS build: tools/collect_profiles.sh
     writes profiles/*traffic*.json with the digests of the sources it was measured on (regenie_amd/lib/build.stamp = kernel library + host
     driver, lib/library.stamp = the kernel library alone).  A file measured on other KERNEL sources is refused (traffic = null) rather than
-    rescaled; a change to the host driver (regenie_amd/host) does not change what a kernel moves and leaves the files valid."""
+    rescaled; a change to the host driver (regenie_amd/host) does not change what a kernel moves and leaves the files valid, and so does a
+    change to a source file that neither defines nor launches the group's kernels (`source_digests`: sha256 per file of the library)."""
     import glob
     try:
         stamp = open(os.path.join(ROOT, "regenie_amd", "lib", "build.stamp")).read().strip()
@@ -652,13 +653,25 @@ def measured_traffic(dom, nblocks, n_batches, P):
     except OSError:
         lib_stamp = None
     group = {"chol_f64": "chol", "l1_gram_f64": "l1_gram", "gram_fp4": "gram_fp4", "pred": "pred", "wgram_f64": "wgram", "irls_stream": "irls_stream"}[dom]
+    # the sources that define and launch the group's kernels: a traffic file stays valid for a group while THESE are what it was measured on
+    common = ["csrc/rg_api.hip", "csrc/rg_internal.h", "csrc/bed_prep.hip", "flags"]
+    group_files = {"chol": ["csrc/chol.hip", "csrc/assemble.hip"], "l1_gram": ["csrc/l1.hip"], "gram_fp4": ["csrc/gram_fp4.hip"], "pred": ["csrc/pred.hip", "csrc/pred_i8.hip"],
+                   "wgram": ["csrc/wgram_bf16.hip", "csrc/l1x.hip"], "irls_stream": ["csrc/l1x.hip"]}[group] + common
+    try:
+        now = json.load(open(os.path.join(ROOT, "regenie_amd", "lib", "kernel_files.json")))
+    except (OSError, ValueError):
+        now = None
+
+    def same_group_sources(tj):
+        then = tj.get("source_digests")
+        return bool(now and then) and all(f in now and now.get(f) == then.get(f) for f in group_files)
     stale, same_build = False, False
     for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic*.json")), reverse=True):
         try:
             tj = json.load(open(fn))
         except Exception:   # noqa: BLE001
             continue
-        if tj.get("build_stamp") != stamp and (lib_stamp is None or tj.get("library_stamp") != lib_stamp):
+        if tj.get("build_stamp") != stamp and (lib_stamp is None or tj.get("library_stamp") != lib_stamp) and not same_group_sources(tj):
             stale = True
             continue
         same_build = True
@@ -669,8 +682,8 @@ def measured_traffic(dom, nblocks, n_batches, P):
             per = g["hbm_bytes"] / max(1, g.get("group_launches", 0))
         else:
             per = g["hbm_bytes"] / max(1, tj["level0_batches"] if group not in ("l1_gram", "wgram") else g.get("lead_launches", P))
-        return per, ("FETCH_SIZE x 2 + WRITE_SIZE of the kernel (group) from separate rocprofv3 --pmc passes of this command on this "
-                     "build (%s), per launch" % os.path.basename(fn))
+        return per, ("FETCH_SIZE x 2 + WRITE_SIZE of the kernel (group) from separate rocprofv3 --pmc passes of this command on these "
+                     "kernel sources (%s), per launch" % os.path.basename(fn))
     if same_build:
         return None, "the PMC traffic file of this build covers another workload (blocks / phenotypes); none was collected for this one"
     return None, ("the committed PMC traffic files were measured on other kernel sources (stale): refused" if stale else

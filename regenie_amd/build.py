@@ -50,6 +50,19 @@ def library_digest() -> str:
     return _digest(_lib_deps())
 
 
+def kernel_file_digests() -> dict:
+    """sha256 per source file of the kernel library (path relative to the package) + of the compile flags: the PMC traffic files record
+    them, and bench.py accepts a file for a kernel group as long as the files that define and launch THAT group are unchanged (a change to
+    bgen_inflate.hip does not move what the Cholesky kernels read)."""
+    out = {}
+    for q in _lib_deps():
+        rel = os.path.relpath(os.path.realpath(q), os.path.realpath(HERE))
+        with open(os.path.join(HERE, rel), "rb") as fh:
+            out[rel] = hashlib.sha256(fh.read()).hexdigest()
+    out["flags"] = hashlib.sha256(" ".join(FLAGS).encode()).hexdigest()
+    return out
+
+
 def _deps():
     return _lib_deps() + [os.path.join(HERE, "host", f) for f in HOST_SOURCES + ["driver.h"]]
 
@@ -67,6 +80,12 @@ def _lib_deps():
                                                       os.path.join(HERE, "..", "include", "rg_step2.h")]
 
 
+def _write_file_digests():
+    import json
+    with open(os.path.join(LIBDIR, "kernel_files.json"), "w") as fh:
+        json.dump(kernel_file_digests(), fh, indent=0, sort_keys=True)
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     stamp = os.path.join(LIBDIR, "build.stamp")
@@ -74,6 +93,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == dig:
         with open(os.path.join(LIBDIR, "library.stamp"), "w") as fh:      # (a tree built before this file existed)
             fh.write(library_digest())
+        _write_file_digests()
         return LIB
     hipcc = _hipcc()
     objs = []
@@ -116,6 +136,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         raise RuntimeError("host driver link failed:\n%s\n%s" % (r.stdout, r.stderr))
     with open(os.path.join(LIBDIR, "library.stamp"), "w") as fh:
         fh.write(library_digest())
+    _write_file_digests()
     with open(stamp, "w") as fh:
         fh.write(dig)
     return LIB

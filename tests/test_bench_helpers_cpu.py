@@ -76,3 +76,17 @@ def test_traffic_files_are_keyed_on_the_kernel_library_not_on_the_host_driver(tm
     (root / "profiles" / "x_traffic.json").write_text(json.dumps(rec))
     per, note = b.measured_traffic("chol_f64", 109, 2, 1)
     assert per is None and "stale" in note
+    # another file of the library changed (the BGEN decoder): the Cholesky group's sources are what they were, its traffic stands; a change to
+    # chol.hip itself makes it stale
+    files = {"csrc/rg_api.hip": "a", "csrc/rg_internal.h": "b", "csrc/bed_prep.hip": "c", "flags": "f", "csrc/chol.hip": "d", "csrc/assemble.hip": "e",
+             "csrc/bgen_inflate.hip": "old"}
+    rec["source_digests"] = files
+    (root / "profiles" / "x_traffic.json").write_text(json.dumps(rec))
+    (root / "regenie_amd" / "lib" / "kernel_files.json").write_text(json.dumps(dict(files, **{"csrc/bgen_inflate.hip": "new"})))
+    per, note = b.measured_traffic("chol_f64", 109, 2, 1)
+    assert per == 25.0
+    (root / "regenie_amd" / "lib" / "kernel_files.json").write_text(json.dumps(dict(files, **{"csrc/chol.hip": "new"})))
+    per, note = b.measured_traffic("chol_f64", 109, 2, 1)
+    assert per is None and "stale" in note
+    assert set(build.kernel_file_digests()) >= {"csrc/chol.hip", "csrc/rg_api.hip", "csrc/rg_internal.h", "csrc/bed_prep.hip", "csrc/assemble.hip", "csrc/l1.hip", "csrc/l1x.hip",
+                                                "csrc/gram_fp4.hip", "csrc/pred.hip", "csrc/pred_i8.hip", "csrc/wgram_bf16.hip", "flags"}

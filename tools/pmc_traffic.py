@@ -51,6 +51,10 @@ def main(fd, wd, nbatch, out, blocks=None, phenos=None):
         lib_stamp = open(os.path.join(here, "..", "regenie_amd", "lib", "library.stamp")).read().strip()
     except OSError:
         lib_stamp = None
+    try:
+        file_digests = json.load(open(os.path.join(here, "..", "regenie_amd", "lib", "kernel_files.json")))
+    except (OSError, ValueError):
+        file_digests = None
     groups = {}
     for gname, ks in GROUPS.items():
         grd = sum(v for k, v in f.items() if k.split("<")[0] in ks) * 1024 * 2
@@ -58,7 +62,7 @@ def main(fd, wd, nbatch, out, blocks=None, phenos=None):
         lead = next((k for k in ks if ("FETCH_SIZE", k) in COUNT), ks[0])      # dispatches of the group's leading kernel in the read pass
         groups[gname] = {"read_bytes": grd, "write_bytes": gwr, "hbm_bytes": grd + gwr, "lead_kernel": lead, "lead_launches": COUNT.get(("FETCH_SIZE", lead), 0),
                          "group_launches": sum(n for (c, k), n in COUNT.items() if c == "FETCH_SIZE" and k.split("<")[0] in ks)}
-    res = {"kernel_group": list(GROUP), "level0_batches": nbatch, "build_stamp": stamp, "library_stamp": lib_stamp, "groups": groups,
+    res = {"kernel_group": list(GROUP), "level0_batches": nbatch, "build_stamp": stamp, "library_stamp": lib_stamp, "source_digests": file_digests, "groups": groups,
            "blocks": int(blocks) if blocks else None, "phenos": int(phenos) if phenos else None,
            "read_bytes_per_batch": rd / nbatch, "write_bytes_per_batch": wr / nbatch,
            "hbm_bytes_per_batch": (rd + wr) / nbatch,
