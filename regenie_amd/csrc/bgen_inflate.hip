@@ -9,10 +9,15 @@
 //                    previous code's length, every match on the output so far -- so the parallelism is the batch (400 - 4,000 independent
 //                    streams per launch).  The decode state (bit buffer, positions) is wave-uniform and lives in SGPRs; the Huffman tables
 //                    (two-level, 10 / 9 first-level bits, zlib's ENOUGH bounds) and the last 4 KB of output sit in the wave's slice of
-//                    LDS; the input arrives 256 bytes per global load (one dword per lane, read out with v_readlane), matches are copied
-//                    by all 64 lanes, the ring is flushed to memory in 16-byte pieces per lane; a match that reaches further back than the
-//                    ring reads the flushed output.  Table construction (canonical codes from the code lengths) is lane-parallel
-//                    (ballot / popcount ranks, strided fills).
+//                    LDS; the input arrives 256 bytes per global load (one dword per lane), matches are copied by all 64 lanes, the ring
+//                    is flushed to memory in 16-byte pieces per lane; a match that reaches further back than the ring reads the flushed
+//                    output.  Table construction (canonical codes from the code lengths) is lane-parallel (ballot / popcount ranks,
+//                    strided fills).  The symbols of a block are decoded 64 bit positions at a time: every lane decodes the symbol that
+//                    WOULD start at its bit (table look-ups of all lanes in flight together), the wave then walks the chain of true
+//                    starts with one v_readlane per symbol.  The kernel is bound by scalar issue (one scalar or branch instruction per
+//                    SIMD and four clocks, three waves per SIMD; profiles/r5_bgen_decoder_pmc.md), so that walk is written for
+//                    instruction count: ~50 scalar + branch instructions per symbol on genotype streams (263,000 symbols per 1.5 MB
+//                    block at zlib level 1: four in five are matches of 3 - 8 bytes, one match in four further back than the ring).
 //   k_bgen_check     the block's header fields (N, K = 2, ploidy 2 / 2, unphased, 8 bits: the checks of bgen_reader.h) and the
 //                    Adler-32 of the inflated bytes against the stream's trailer (what zlib's uncompress() verifies)
 //   k_bgen_walk      probabilities -> integer dosages (uint16 rows in units of 1 / 255, the input of the digit-plane kernels of
