@@ -620,8 +620,8 @@ struct WalkArgs {
   const uint8_t* out; int64_t stride; int64_t n_file, n; const int64_t* file_idx;   // file_idx == nullptr: identity
   const int32_t* status; int ref_first;
   uint16_t* g16; int64_t ld16;
-  int P; const uint8_t* mask;          // [P][n], 1 = the trait is observed for the sample; nullptr: no per-trait sums
-  const uint8_t* any_missing;          // [n]: the sample misses at least one trait
+  int P; const unsigned long long* missbits;      // [n][W]: bit p of a sample's words = trait p is MISSING for it; nullptr: no per-trait sums
+  int W;                                          // words per sample = ceil(P / 64)
   long long* sum_q; long long* sum_info; long long* n_obs; int* max_q;      // [nvar]
   long long* sum_q_t; long long* sum_info_t; long long* n_obs_t;            // [nvar][P]: what the samples missing for trait p contribute
 };
@@ -630,10 +630,15 @@ __device__ __forceinline__ long long wave_sum_ll(long long x) {
   return x;
 }
 __global__ __launch_bounds__(256) void k_bgen_walk(WalkArgs a) {
+  extern __shared__ unsigned long long s_trait[];      // [3][P]: what this workgroup's samples contribute to the per-trait corrections
   const int v = blockIdx.y;
   uint16_t* row = a.g16 + (int64_t)v * a.ld16;
   const int64_t k0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
-  if (a.status[v] != ST_OK) return;
+  if (a.status[v] != ST_OK) return;                    // (the same for the whole workgroup)
+  if (a.missbits) {
+    for (int i = threadIdx.x; i < 3 * a.P; i += 256) s_trait[i] = 0ull;
+    __syncthreads();
+  }
   const uint8_t* blk = a.out + (int64_t)v * a.stride;
   const uint8_t* ploidy = blk + 8;
   const uint8_t* pr = blk + 10 + a.n_file;
@@ -654,13 +659,27 @@ __global__ __launch_bounds__(256) void k_bgen_walk(WalkArgs a) {
     const long long inf = 255ll * (long long)(4u * bx + b1) - (long long)q * (long long)q;
     sq += q; si += inf; no += 1;
     mq = max(mq, (int)q);
-    if (a.mask && a.any_missing[k])
-      for (int p = 0; p < a.P; ++p)
-        if (!a.mask[(int64_t)p * a.n + k]) {
-          atomicAdd((unsigned long long*)&a.sum_q_t[(int64_t)v * a.P + p], (unsigned long long)q);
-          atomicAdd((unsigned long long*)&a.sum_info_t[(int64_t)v * a.P + p], (unsigned long long)inf);
-          atomicAdd((unsigned long long*)&a.n_obs_t[(int64_t)v * a.P + p], 1ull);
+    if (a.missbits)
+      for (int w = 0; w < a.W; ++w) {
+        unsigned long long mb = a.missbits[k * a.W + w];        // one load per sample (ten byte loads before): most samples have no bit set
+        while (mb) {       // LDS atomics: three global atomics per missing (sample, trait) would all land on the variant's 3 P words
+          const int p = 64 * w + __ffsll((long long)mb) - 1;
+          mb &= mb - 1ull;
+          atomicAdd(&s_trait[p], (unsigned long long)q);
+          atomicAdd(&s_trait[a.P + p], (unsigned long long)inf);
+          atomicAdd(&s_trait[2 * a.P + p], 1ull);
         }
+      }
+  }
+  if (a.missbits) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * a.P; i += 256) {
+      const unsigned long long x = s_trait[i];
+      if (x == 0ull) continue;
+      const int which = i / a.P, p = i - which * a.P;
+      long long* dst = which == 0 ? a.sum_q_t : (which == 1 ? a.sum_info_t : a.n_obs_t);
+      atomicAdd((unsigned long long*)&dst[(int64_t)v * a.P + p], x);
+    }
   }
   sq = wave_sum_ll(sq); si = wave_sum_ll(si); no = wave_sum_ll(no);
   for (int o = 32; o > 0; o >>= 1) mq = max(mq, __shfl_down(mq, o));
@@ -685,8 +704,7 @@ struct rg_bgen_dev {
   int P = 0;
   bool identity = true;
   int64_t* d_file_idx = nullptr;
-  uint8_t* d_mask = nullptr;
-  uint8_t* d_anymiss = nullptr;
+  unsigned long long* d_missbits = nullptr;      // [n][ceil(P / 64)]: the traits missing per sample
   // per slot: compressed bytes, descriptors, inflated blocks, dosage rows, sums
   struct Slot {
     uint8_t* d_comp = nullptr; size_t comp_cap = 0;
@@ -732,7 +750,7 @@ void rg_bgen_dev_destroy(rg_bgen_dev* h) {
   if (!h) return;
   hipSetDevice(h->device);
   if (h->st) { hipStreamSynchronize(h->st); hipStreamDestroy(h->st); }
-  for (void* p : {(void*)h->d_file_idx, (void*)h->d_mask, (void*)h->d_anymiss}) if (p) hipFree(p);
+  for (void* p : {(void*)h->d_file_idx, (void*)h->d_missbits}) if (p) hipFree(p);
   for (auto& s : h->slot) {
     for (void* p : {(void*)s.d_comp, (void*)s.d_raw, (void*)s.d_g16, s.d_desc, s.d_sums}) if (p) hipFree(p);
     if (s.h_sums) hipHostFree(s.h_sums);
@@ -745,7 +763,7 @@ const char* rg_bgen_dev_last_error(const rg_bgen_dev* h) { return h ? h->err.c_s
 int rg_bgen_dev_set_samples(rg_bgen_dev* h, int64_t n_file, int64_t n, const int64_t* file_idx, int32_t P, const uint8_t* mask) {
   if (!h || n_file < 1 || n < 1 || n > n_file || P < 0) return RG_BGEN_ERR_ARG;
   hipSetDevice(h->device);
-  for (void** p : {(void**)&h->d_file_idx, (void**)&h->d_mask, (void**)&h->d_anymiss}) if (*p) { hipFree(*p); *p = nullptr; }
+  for (void** p : {(void**)&h->d_file_idx, (void**)&h->d_missbits}) if (*p) { hipFree(*p); *p = nullptr; }
   h->n_file = n_file; h->n = n; h->P = mask ? P : 0;
   h->identity = file_idx == nullptr;
   if (file_idx) {
@@ -754,13 +772,12 @@ int rg_bgen_dev_set_samples(rg_bgen_dev* h, int64_t n_file, int64_t n, const int
     BD_HIP(hipMemcpy(h->d_file_idx, file_idx, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice));
   }
   if (mask && P > 0) {
-    std::vector<uint8_t> any((size_t)n, 0);
+    const int W = (P + 63) / 64;
+    std::vector<unsigned long long> bits((size_t)n * W, 0ull);
     for (int p = 0; p < P; ++p)
-      for (int64_t k = 0; k < n; ++k) if (!mask[(size_t)p * n + k]) any[(size_t)k] = 1;
-    BD_HIP(hipMalloc((void**)&h->d_mask, (size_t)P * n));
-    BD_HIP(hipMemcpy(h->d_mask, mask, (size_t)P * n, hipMemcpyHostToDevice));
-    BD_HIP(hipMalloc((void**)&h->d_anymiss, (size_t)n));
-    BD_HIP(hipMemcpy(h->d_anymiss, any.data(), (size_t)n, hipMemcpyHostToDevice));
+      for (int64_t k = 0; k < n; ++k) if (!mask[(size_t)p * n + k]) bits[(size_t)k * W + p / 64] |= 1ull << (p % 64);
+    BD_HIP(hipMalloc((void**)&h->d_missbits, sizeof(unsigned long long) * bits.size()));
+    BD_HIP(hipMemcpy(h->d_missbits, bits.data(), sizeof(unsigned long long) * bits.size(), hipMemcpyHostToDevice));
   }
   return RG_BGEN_OK;
 }
@@ -821,9 +838,9 @@ int rg_bgen_dev_decode(rg_bgen_dev* h, int32_t slot, int32_t nvar, const uint8_t
   long long* d_sit = d_sqt + (size_t)nvar * P;
   long long* d_not = d_sit + (size_t)nvar * P;
   int* d_mq = (int*)(d_not + (size_t)nvar * P);
-  WalkArgs wa{s.d_raw, stride, h->n_file, h->n, h->d_file_idx, d_status, ref_first ? 1 : 0, s.d_g16, ld16, P, h->d_mask, h->d_anymiss,
+  WalkArgs wa{s.d_raw, stride, h->n_file, h->n, h->d_file_idx, d_status, ref_first ? 1 : 0, s.d_g16, ld16, P, h->d_missbits, (P + 63) / 64,
               d_sq, d_si, d_no, d_mq, d_sqt, d_sit, d_not};
-  hipLaunchKernelGGL(k_bgen_walk, dim3((unsigned)((ld16 + 1023) / 1024), (unsigned)nvar), dim3(256), 0, st, wa);
+  hipLaunchKernelGGL(k_bgen_walk, dim3((unsigned)((ld16 + 1023) / 1024), (unsigned)nvar), dim3(256), wa.missbits ? (size_t)(3 * wa.P) * sizeof(unsigned long long) : 0, st, wa);
   BD_HIP(hipGetLastError());
   BD_HIP(hipMemcpyAsync(s.h_sums, s.d_sums, sums_bytes, hipMemcpyDeviceToHost, st));
   BD_HIP(hipMemcpyAsync((uint8_t*)s.h_sums + sums_bytes, d_status, sizeof(int32_t) * nvar, hipMemcpyDeviceToHost, st));

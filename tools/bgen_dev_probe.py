@@ -24,7 +24,13 @@ def main():
     tw = write_bgen(path, N, M, [1] * M, max(1, min(224, (os.cpu_count() or 8) - 8)))
     print("wrote %d variants x %d samples, %.2f GB in %.0f s" % (M, N, os.path.getsize(path) / 1e9, tw), flush=True)
     with BgenFile(path, threads=32) as f, BgenDevice(0) as d:
-        d.set_samples(N)
+        if os.environ.get("BGEN_PROBE_MASK"):       # "P,rate": P traits, each missing for `rate` of the samples (the walk's per-trait corrections)
+            Pm, rate = os.environ["BGEN_PROBE_MASK"].split(",")
+            mask = (np.random.default_rng(3).random((int(Pm), N)) >= float(rate)).astype(np.uint8)
+            d.set_samples(N, mask=mask)
+            print("per-trait masks: %s traits, %.1f %% of the samples missing for each" % (Pm, 100 * float(rate)), flush=True)
+        else:
+            d.set_samples(N)
         pin = {}
 
         def pinned(n):          # page-locked, as the driver's buffers are (rg_host_alloc)
