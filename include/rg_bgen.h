@@ -81,7 +81,8 @@ int rg_bgen_dev_create(rg_bgen_dev** out, int32_t device);
 void rg_bgen_dev_destroy(rg_bgen_dev* d);
 const char* rg_bgen_dev_last_error(const rg_bgen_dev* d);
 /* The samples of the rows: file_idx[k] = position in the file of analysed sample k (NULL: the n_file samples in file order, n = n_file);
- * mask: [P][n] bytes, 1 = trait p is observed for sample k (NULL or P = 0: no per-trait sums). */
+ * mask: [P][n] bytes, 1 = trait p is observed for sample k (NULL or P = 0: no per-trait sums; at most 2,048 traits with masks, RG_BGEN_ERR_ARG beyond:
+ * the caller then keeps the host route). */
 int rg_bgen_dev_set_samples(rg_bgen_dev* d, int64_t n_file, int64_t n, const int64_t* file_idx, int32_t P, const uint8_t* mask);
 /* What a batch leaves behind.  The host arrays may be NULL (not wanted); g16 / raw are DEVICE pointers owned by the decoder, valid until the
  * next call on the same slot.  Sums run over the analysed samples whose genotype is not missing:

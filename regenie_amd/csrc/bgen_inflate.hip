@@ -762,6 +762,7 @@ const char* rg_bgen_dev_last_error(const rg_bgen_dev* h) { return h ? h->err.c_s
 
 int rg_bgen_dev_set_samples(rg_bgen_dev* h, int64_t n_file, int64_t n, const int64_t* file_idx, int32_t P, const uint8_t* mask) {
   if (!h || n_file < 1 || n < 1 || n > n_file || P < 0) return RG_BGEN_ERR_ARG;
+  if (mask && P > 2048) { h->err = "rg_bgen_dev_set_samples: more than 2,048 traits with masks (the walk keeps 3 P sums in LDS)"; return RG_BGEN_ERR_ARG; }
   hipSetDevice(h->device);
   for (void** p : {(void**)&h->d_file_idx, (void**)&h->d_missbits}) if (*p) { hipFree(*p); *p = nullptr; }
   h->n_file = n_file; h->n = n; h->P = mask ? P : 0;
