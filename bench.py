@@ -660,7 +660,11 @@ def measured_traffic(dom, nblocks, n_batches, P):
     try:
         now = json.load(open(os.path.join(ROOT, "regenie_amd", "lib", "kernel_files.json")))
     except (OSError, ValueError):
-        now = None
+        try:      # (a library built before build() wrote the file: the sources beside it are what it was built from, or its stamp would differ)
+            from regenie_amd import build as _b
+            now = _b.kernel_file_digests() if open(os.path.join(ROOT, "regenie_amd", "lib", "library.stamp")).read().strip() == _b.library_digest() else None
+        except Exception:   # noqa: BLE001
+            now = None
 
     def same_group_sources(tj):
         then = tj.get("source_digests")
