@@ -30,6 +30,12 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fin_bgen_raw -- python tools/bgen_dev_probe.py 500000 6144 3072 > gpurun_out/fin_bgen.log 2>&1
 python tools/prof_summary.py gpurun_out/fin_bgen_raw gpurun_out/fin_bgen_stats.md > /dev/null; rm -rf gpurun_out/fin_bgen_raw
 ( grep "rep \|zlib\|wrote" gpurun_out/fin_bgen.log | cut -c1-220; echo; head -8 gpurun_out/fin_bgen_stats.md ) > $P/${R}_bgen_device_decoder.md; cat $P/${R}_bgen_device_decoder.md
+# the decoder's walk when the phenotypes differ in their missing values (ten traits, 5 % each), and its instruction counters
+BGEN_PROBE_MASK=10,0.05 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fin_bgenm_raw -- python tools/bgen_dev_probe.py 500000 3072 3072 > gpurun_out/fin_bgenm.log 2>&1
+python tools/prof_summary.py gpurun_out/fin_bgenm_raw gpurun_out/fin_bgenm_stats.md > /dev/null; rm -rf gpurun_out/fin_bgenm_raw
+( grep "per-trait\|rep 2" gpurun_out/fin_bgenm.log | cut -c1-220; echo; grep "kernel\|---\|k_bgen" gpurun_out/fin_bgenm_stats.md | head -6 ) > gpurun_out/fin_bgen_walk_masks.md; cat gpurun_out/fin_bgen_walk_masks.md
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_VALU SQ_INSTS_LDS --kernel-trace --kernel-include-regex "k_bgen" --output-format csv -d gpurun_out/fin_bgenp_raw -- python tools/bgen_dev_probe.py 500000 3072 3072 > gpurun_out/fin_bgenp.log 2>&1
+python tools/pmc_summary.py gpurun_out/fin_bgenp_raw gpurun_out/fin_bgen_pmc_insts.md > /dev/null; rm -rf gpurun_out/fin_bgenp_raw; head -12 gpurun_out/fin_bgen_pmc_insts.md
 OUT=fin_tests TMO=1700 bash tools/gpu_job.sh tests
 cp gpurun_out/fin_tests/pytest.log $P/${R}_pytest_gpu_final.log
 OUT=fin_smoke bash tools/gpu_job.sh smoke
