@@ -34,7 +34,8 @@ sys.path.insert(0, ROOT)
 CHR_MB = [248, 242, 198, 190, 181, 171, 159, 145, 138, 133, 135, 133, 114, 107, 102, 90, 83, 80, 59, 64, 47, 51]
 
 PEAK = {"fp4_mfma_TOPS": 10000.0,    # MX FP4 dense (MI355X_MICROARCH.md: ~10 PF dense, ubench 9099 TF at 32x32x64)
-        "i8_mfma_TOPS": 5000.0,      # 2x the bf16 dense peak (MI355X_MICROARCH.md: I8 ~2x bf16 rate; ubench 4404)
+        "i8_mfma_TOPS": 5000.0,      # 2x the bf16 dense peak (MI355X_MICROARCH.md: I8 ~2x bf16 rate; the guide's MEASURED ceiling is 3,944, this repo's ubench 4,404:
+                                     # fractions quoted against 5,000 are conservative by 1.14 - 1.27x)
         "f64_mfma_TFLOPS": 78.6,     # AMD datasheet FP64 matrix (not listed in the guide)
         "bf16_mfma_TFLOPS": 2500.0,  # dense bf16 = dense fp16 (MI355X_MICROARCH.md: ~2.5 PF dense, 2495 measured)
         "hbm_GBs": 8000.0}
