@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Randomised pinning of the Step-1 oracle against regenie ITSELF (CPU only; needs oracle/_ref/regenie, i.e. this container).
+
+The committed fixtures (make_ref_outputs.py) pin the oracle on a fixed set of cases.  This script draws cases -- route (QT K-fold, QT
+leave-one-out, BT leave-one-out, BT K-fold at >= 5,000 samples), sample / variant / chromosome / phenotype counts, block size, folds,
+ridge-grid sizes, --ref-first, --strict, missing genotypes and phenotypes -- on the synthetic data of tests/util.py, runs regenie v4.1.2 on
+each, and holds oracle/regenie_step1.py to its .loco files (at the text's resolution), CV tables and selected ridge values with the
+assertions of tests/test_reference_pin.py.  On the quantitative-trait cases regenie's --step 2 --qt then runs on the same files with its own
+LOCO predictions, and oracle/regenie_step2_qt.py (score_qt_block_ref: the sparse / dense choice per variant) is held to every BETA / SE /
+CHISQ / LOG10P of its .regenie files.  Usage:  python tests/golden/fuzz_oracle_vs_reference.py [first_seed=1] [count=40] [log.md]
+A line per case goes to stdout (and to the log file); a mismatch is printed with its arguments and the script exits 1 at the end."""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+import traceback
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import regenie_step1 as orc                                   # noqa: E402
+from tests import test_reference_pin as pin                              # noqa: E402
+from tests.golden.make_ref_outputs import table_lines                    # noqa: E402
+from tests.util import synth_dosages, write_plink                        # noqa: E402
+
+REGENIE = os.path.join(ROOT, "oracle", "_ref", "regenie")
+
+
+def draw(seed):
+    rng = np.random.default_rng(100000 + seed)
+    route = ["qt_kfold", "qt_loocv", "bt_loocv", "qt_kfold", "bt_kfold"][seed % 5]
+    if route == "bt_kfold":
+        N, M = int(rng.integers(5050, 5400)), int(rng.integers(60, 140))
+    else:
+        N, M = int(rng.integers(250, 1100)), int(rng.integers(120, 420))
+    nchr = int(rng.integers(2, 5))
+    cuts = np.sort(rng.choice(np.arange(10, M - 10), nchr - 1, replace=False))
+    chrom_ids = np.sort(rng.choice(np.arange(1, 23), nchr, replace=False))
+    chroms = np.repeat(chrom_ids, np.diff(np.concatenate([[0], cuts, [M]]))).tolist()
+    spec = {"M": M, "N": N, "chroms": chroms, "P": int(rng.integers(1, 4)), "seed": int(1000 + seed), "binary": route.startswith("bt"),
+            "missing_pheno": float(rng.choice([0.0, 0.05])), "miss_rate": float(rng.choice([0.0, 0.02]))}
+    opt = {"bsize": int(rng.choice([37, 64, 100, 150])), "bt": route.startswith("bt"), "loocv": route == "qt_loocv",
+           "cv_folds": int(rng.choice([3, 4, 5, 7])), "n_ridge_l0": int(rng.choice([3, 5, 6])), "n_ridge_l1": int(rng.choice([4, 5, 7])),
+           "ref_first": bool(rng.random() < 0.3), "strict": bool(spec["missing_pheno"] > 0 and rng.random() < 0.3)}
+    return route, spec, opt
+
+
+def run_one(seed, work):
+    route, spec, o = draw(seed)
+    d = os.path.join(work, "c%d" % seed)
+    os.makedirs(d)
+    S = os.path.join(d, "synth")
+    g = synth_dosages(spec["M"], spec["N"], miss_rate=spec["miss_rate"], seed=spec["seed"])
+    write_plink(S, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    args = ["--step", "1", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", str(o["bsize"]), "--cv", str(o["cv_folds"]),
+            "--l0", str(o["n_ridge_l0"]), "--l1", str(o["n_ridge_l1"])]
+    args += ["--bt"] if o["bt"] else []
+    args += ["--loocv"] if o["loocv"] else []
+    args += ["--ref-first"] if o["ref_first"] else []
+    args += ["--strict"] if o["strict"] else []
+    t0 = time.time()
+    r = subprocess.run([REGENIE] + args + ["--out", "out"], cwd=d, capture_output=True, text=True)
+    t_ref = time.time() - t0
+    desc = "seed %d %-8s N %d M %d chr %d P %d bsize %d cv %d l0 %d l1 %d%s%s missG %.2f missY %.2f" % (
+        seed, route, spec["N"], spec["M"], len(set(spec["chroms"])), spec["P"], o["bsize"], o["cv_folds"], o["n_ridge_l0"], o["n_ridge_l1"],
+        " ref-first" if o["ref_first"] else "", " strict" if o["strict"] else "", spec["miss_rate"], spec["missing_pheno"])
+    if r.returncode != 0:
+        return desc + " | regenie itself stopped: " + (r.stdout + r.stderr).strip().splitlines()[-1][:160], None
+    log = open(os.path.join(d, "out.log")).read()
+    t0 = time.time()
+    res = orc.run_step1(orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", **o))
+    t_or = time.time() - t0
+    ref_tab = pin.parse_table(table_lines(log))
+    got_tab = pin.parse_table([l for l in res.log if l.startswith("phenotype ") or ": Rsq = " in l])
+    names = [ln.split()[0] for ln in open(os.path.join(d, "out_pred.list"))]
+    assert len(ref_tab) == len(got_tab) == len(names), (len(ref_tab), len(got_tab), len(names))
+    worst = 0.0
+    for ph, (rt, gt) in enumerate(zip(ref_tab, got_tab)):
+        assert len(rt) == len(gt)
+        for (h, rsq, mse, ll, mn), (h2, rsq2, mse2, ll2, mn2) in zip(rt, gt):
+            assert h == h2 and mn == mn2, ("selected ridge value", ph, h)
+            assert abs(rsq2 - rsq) <= 2e-5 * max(abs(rsq), 1e-12) + 1e-12 and (np.isnan(mse) or abs(mse2 - mse) <= 2e-5 * abs(mse)), ("table", ph, h, rsq, rsq2, mse, mse2)
+            if ll is not None:
+                assert abs(ll2 - ll) <= 2e-5 * abs(ll), ("table logLik", ph, h, ll, ll2)
+        lines = open(os.path.join(d, "out_%d.loco" % (ph + 1))).read().splitlines()
+        ids = lines[0].split()[1:]
+        ref = np.array([[np.nan if t == "NA" else float(t) for t in ln.split()[1:]] for ln in lines[1:]])
+        gids, got = pin.oracle_loco_rows(res, ph)
+        assert ids == gids
+        pin.assert_text_equal(got, ref, "pheno %d" % (ph + 1))
+        ok = ~np.isnan(ref)
+        worst = max(worst, float(np.max(np.abs(got[ok] - ref[ok])) / np.max(np.abs(ref[ok]))))
+    extra = ""
+    if not o["bt"]:
+        extra = ", step 2: %d statistics" % step2_qt_leg(d, S, o)
+    return desc + " | ok: loco max rel err %.1e (%s), regenie %.1f s, oracle %.1f s%s" % (worst, "LOOCV" if res.use_loocv else "K-fold", t_ref, t_or, extra), True
+
+
+def step2_qt_leg(d, S, o):
+    """regenie --step 2 --qt on the case's files with ITS OWN step-1 predictions against the oracle's score test; -> variants x traits compared"""
+    from oracle import regenie_step2_qt as s2
+    args = ["--step", "2", "--qt", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list"]
+    args += ["--ref-first"] if o["ref_first"] else []
+    args += ["--strict"] if o["strict"] else []
+    r = subprocess.run([REGENIE] + args + ["--out", "s2"], cwd=d, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
+    opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, ref_first=o["ref_first"], strict=o["strict"], test_mode=True)
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    bed, _ = orc.open_bed(S + ".bed", prep.n_file)
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    P = prep.Y.shape[1]
+    loco, refs = [], []
+    for ph in range(P):
+        lines = open(os.path.join(d, "out_%d.loco" % (ph + 1))).read().splitlines()
+        pos = {s_: k for k, s_ in enumerate(lines[0].split()[1:])}
+        v = np.array([[np.nan if t == "NA" else float(t) for t in ln.split()[1:]] for ln in lines[1:]])
+        loco.append(np.nan_to_num(v[:, [pos[i] for i in ids]]))
+        refs.append(pin._read_regenie(os.path.join(d, "s2_Y%d.regenie" % (ph + 1))))
+    col = {nm: i for i, nm in enumerate(refs[0][0])}
+    X, Y, mask = prep.X[ia], prep.Y[ia], prep.mask[ia].astype(np.float64)
+    by_id = [{r_[col["ID"]]: r_ for r_ in refs[ph][1]} for ph in range(P)]
+    ncmp = 0
+    for c in sorted(set(chrom.tolist())):
+        blup = np.stack([loco[ph][c - 1] for ph in range(P)], axis=1)
+        res, _, scf = s2.compute_res(Y, blup * mask, mask, prep.Neff, X.shape[1], prep.scale_Y)
+        sel = np.flatnonzero(chrom == c)
+        G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
+        if o["ref_first"]:
+            G = np.where(G < 0, G, 2.0 - G)
+        out = s2.score_qt_block_ref(G, X, res, mask, scf, n_samples=int((~prep.ind_ignore).sum()))
+        for k in range(sel.size):
+            for ph in range(P):
+                r_ = by_id[ph].get(snp_ids[sel[k]])
+                if r_ is None or r_[col["BETA"]] == "NA":       # filtered by regenie (low MAC) / not testable
+                    continue
+                beta, se, chisq, logp = (float(r_[col[nm]]) for nm in ("BETA", "SE", "CHISQ", "LOG10P"))
+                assert abs(out["bhat"][k, ph] - beta) <= 5e-5 * abs(beta) + 2e-6, ("BETA", snp_ids[sel[k]], ph, out["bhat"][k, ph], beta)
+                assert abs(out["se"][k, ph] - se) <= 5e-5 * abs(se), ("SE", snp_ids[sel[k]], ph, out["se"][k, ph], se)
+                assert abs(out["chisq"][k, ph] - chisq) <= 1e-4 * abs(chisq) + 2e-6, ("CHISQ", snp_ids[sel[k]], ph, out["chisq"][k, ph], chisq)
+                assert abs(s2.get_logp(out["chisq"][k, ph]) - logp) <= 1e-4 * abs(logp) + 2e-6, ("LOG10P", snp_ids[sel[k]], ph)
+                ncmp += 1
+    assert ncmp > 0
+    return ncmp
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    count = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    logf = open(sys.argv[3], "a") if len(sys.argv) > 3 else None
+    bad = 0
+    with tempfile.TemporaryDirectory() as work:
+        for seed in range(first, first + count):
+            try:
+                line, ok = run_one(seed, work)
+            except Exception as e:      # noqa: BLE001
+                route, spec, o = draw(seed)
+                line, ok = "seed %d %s MISMATCH %s | spec %s | options %s\n%s" % (seed, route, repr(e)[:300], {k: v for k, v in spec.items() if k != "chroms"}, o,
+                                                                                  traceback.format_exc()[-600:]), False
+            bad += ok is False
+            print(line, flush=True)
+            if logf:
+                logf.write("* " + line.split("\n")[0] + "\n")
+                logf.flush()
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()

@@ -655,3 +655,14 @@ def test_reference_build_reproduces_the_reference_held_golden(tmp_path):
     for ph in (1, 2):
         assert open(os.path.join(d, "fit_bin_out_%d.loco" % ph), "rb").read() == \
             gzip.open(os.path.join(REF_OUT, "bt_loocv_refcmd", "out_%d.loco.gz" % ph), "rb").read()
+
+
+@pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built")
+def test_oracle_against_live_reference_on_drawn_cases(tmp_path):
+    """A few cases of tests/golden/fuzz_oracle_vs_reference.py (routes, sizes, block size, folds, grid sizes, --ref-first / --strict, missing
+    genotypes / phenotypes drawn per seed): regenie runs here and the oracle is held to its .loco files, tables and Step-2 statistics.  The
+    400-case run of the round is tests/golden/fuzz_log.md."""
+    from tests.golden import fuzz_oracle_vs_reference as fz
+    for seed in (1, 2, 3, 4, 6):          # QT leave-one-out, BT leave-one-out, QT K-fold, BT K-fold, --ref-first
+        line, ok = fz.run_one(seed, str(tmp_path))
+        assert ok, line
