@@ -8,7 +8,10 @@ each, and holds oracle/regenie_step1.py to its .loco files (at the text's resolu
 assertions of tests/test_reference_pin.py.  On the quantitative-trait cases regenie's --step 2 --qt then runs on the same files with its own
 LOCO predictions, and oracle/regenie_step2_qt.py (score_qt_block_ref: the sparse / dense choice per variant) is held to every BETA / SE /
 CHISQ / LOG10P of its .regenie files.  Usage:  python tests/golden/fuzz_oracle_vs_reference.py [first_seed=1] [count=40] [log.md]
-A line per case goes to stdout (and to the log file); a mismatch is printed with its arguments and the script exits 1 at the end."""
+A line per case goes to stdout (and to the log file); a mismatch is printed with its arguments and the script exits 1 at the end.
+FUZZ_DRIVER=1 (GPU box): the PRODUCT runs beside them -- `regenie-amd --step 1` and `--step 2 --qt` with the same arguments -- and its .loco
+files and .regenie lines are held to regenie's (values at the text's resolution; the share of byte-identical lines is reported).
+FUZZ_BUDGET_S=t stops drawing new cases after t seconds."""
 import os
 import subprocess
 import sys
@@ -27,6 +30,58 @@ from tests.golden.make_ref_outputs import table_lines                    # noqa:
 from tests.util import synth_dosages, write_plink                        # noqa: E402
 
 REGENIE = os.path.join(ROOT, "oracle", "_ref", "regenie")
+BIN = os.path.join(ROOT, "regenie_amd", "bin", "regenie-amd")
+
+
+def _loco(path):
+    lines = open(path).read().splitlines()
+    return lines[0].split()[1:], np.array([[np.nan if t == "NA" else float(t) for t in ln.split()[1:]] for ln in lines[1:]])
+
+
+def driver_legs(d, args1, o, P):
+    """The product on the case: its .loco files against regenie's (1e-5 of the largest value = BASELINE.json's bar; text ulps reported), and for
+    quantitative traits its --step 2 --qt lines against regenie's."""
+    r = subprocess.run([BIN] + args1 + ["--out", "drv"], cwd=d, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "regenie-amd --step 1: " + (r.stdout + r.stderr)[-500:]
+    assert open(os.path.join(d, "drv_pred.list")).read().replace("drv_", "out_") == open(os.path.join(d, "out_pred.list")).read()
+    worst_ulp, worst_rel, same_files = 0.0, 0.0, 0
+    for ph in range(P):
+        ids_r, ref = _loco(os.path.join(d, "out_%d.loco" % (ph + 1)))
+        ids_g, got = _loco(os.path.join(d, "drv_%d.loco" % (ph + 1)))
+        assert ids_r == ids_g and got.shape == ref.shape and np.array_equal(np.isnan(got), np.isnan(ref)), "driver .loco layout / NA pattern"
+        ok = ~np.isnan(ref)
+        mag = np.maximum(np.abs(ref[ok]), 1e-300)
+        ulp = 10.0 ** (np.floor(np.log10(mag)) - 5)
+        err = np.abs(got[ok] - ref[ok])
+        worst_ulp = max(worst_ulp, float(np.max(err / ulp)))
+        worst_rel = max(worst_rel, float(np.max(err) / np.max(np.abs(ref[ok]))))
+        same_files += open(os.path.join(d, "out_%d.loco" % (ph + 1))).read() == open(os.path.join(d, "drv_%d.loco" % (ph + 1))).read()
+    assert worst_rel < 1e-5, "driver .loco: %.2e of the largest value" % worst_rel
+    out = "driver: loco %.1e (%.1f text ulps, %d/%d files byte-identical)" % (worst_rel, worst_ulp, same_files, P)
+    if not o["bt"]:
+        S = os.path.join(d, "synth")
+        a2 = ["--step", "2", "--qt", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list"]
+        a2 += ["--ref-first"] if o["ref_first"] else []
+        a2 += ["--strict"] if o["strict"] else []
+        r = subprocess.run([BIN] + a2 + ["--out", "d2"], cwd=d, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, "regenie-amd --step 2: " + (r.stdout + r.stderr)[-500:]
+        same = tot = 0
+        for ph in range(P):
+            a = open(os.path.join(d, "d2_Y%d.regenie" % (ph + 1))).read().splitlines()
+            b = open(os.path.join(d, "s2_Y%d.regenie" % (ph + 1))).read().splitlines()
+            assert a[0] == b[0] and len(a) == len(b), "driver .regenie header / line count"
+            for x, y in zip(a[1:], b[1:]):
+                tot += 1
+                if x == y:
+                    same += 1
+                    continue
+                tx, ty = x.split(" "), y.split(" ")
+                assert len(tx) == len(ty) and tx[:5] == ty[:5], (x, y)
+                for u, v in zip(tx[5:], ty[5:]):
+                    assert u == v or (u != "NA" and v != "NA" and abs(float(u) - float(v)) <= 2e-5 * abs(float(v)) + 2e-9), (x, y)
+        out += ", step 2 %d/%d lines byte-identical" % (same, tot)
+    return out
+
 
 
 def draw(seed):
@@ -96,6 +151,8 @@ def run_one(seed, work):
     extra = ""
     if not o["bt"]:
         extra = ", step 2: %d statistics" % step2_qt_leg(d, S, o)
+    if os.environ.get("FUZZ_DRIVER"):
+        extra += " | " + driver_legs(d, args, o, len(names))
     return desc + " | ok: loco max rel err %.1e (%s), regenie %.1f s, oracle %.1f s%s" % (worst, "LOOCV" if res.use_loocv else "K-fold", t_ref, t_or, extra), True
 
 
@@ -153,7 +210,11 @@ def main():
     logf = open(sys.argv[3], "a") if len(sys.argv) > 3 else None
     bad = 0
     with tempfile.TemporaryDirectory() as work:
+        t_start = time.time()
         for seed in range(first, first + count):
+            if os.environ.get("FUZZ_BUDGET_S") and time.time() - t_start > float(os.environ["FUZZ_BUDGET_S"]):
+                print("(time budget reached after %d cases)" % (seed - first), flush=True)
+                break
             try:
                 line, ok = run_one(seed, work)
             except Exception as e:      # noqa: BLE001

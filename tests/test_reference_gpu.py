@@ -360,3 +360,15 @@ def test_driver_vs_live_reference_at_500k_samples(kind, tmp_path):
     print("%s: reference %.1f s, driver %.1f s (wall, from files)" % (kind, t_ref, t_gpu))
     _compare_tables(table_lines(open(os.path.join(d, "gpu.log")).read()), table_lines(open(os.path.join(d, "ref.log")).read()), kind)
     print("%s: LOCO max-rel-err vs regenie %.2e" % (kind, _compare_loco_files(d, P, kind, "ref")))
+
+
+@pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built")
+def test_driver_against_live_reference_on_drawn_cases(tmp_path, monkeypatch):
+    """Cases drawn by tests/golden/fuzz_oracle_vs_reference.py (QT / BT, K-fold / leave-one-out, sizes, block size, folds, grid sizes, --ref-first,
+    --strict, missing genotypes / phenotypes): regenie itself runs beside `regenie-amd --step 1` and `--step 2 --qt` on the same inputs; the
+    driver's files are held to regenie's (1e-5 of the largest value; the round's 80-case run, byte-identical throughout: tests/golden/fuzz_driver_log.md)."""
+    from tests.golden import fuzz_oracle_vs_reference as fz
+    monkeypatch.setenv("FUZZ_DRIVER", "1")
+    for seed in (1, 2, 3, 4, 6):
+        line, ok = fz.run_one(seed, str(tmp_path))
+        assert ok and "driver: loco" in line, line
