@@ -63,6 +63,7 @@ def driver_legs(d, args1, o, P):
         a2 = ["--step", "2", "--qt", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list"]
         a2 += ["--ref-first"] if o["ref_first"] else []
         a2 += ["--strict"] if o["strict"] else []
+        a2 += _prep_args(S, o)
         r = subprocess.run([BIN] + a2 + ["--out", "d2"], cwd=d, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, "regenie-amd --step 2: " + (r.stdout + r.stderr)[-500:]
         same = tot = 0
@@ -103,6 +104,37 @@ def draw(seed):
     return route, spec, opt
 
 
+def draw_prep(seed, route):
+    """Host-preparation options on top of a case (FUZZ_PREP=1): --remove, --exclude, --apply-rint (quantitative traits), a categorical covariate."""
+    rng = np.random.default_rng(700000 + seed)
+    return {"remove": bool(rng.random() < 0.4), "exclude": bool(rng.random() < 0.4), "rint": bool(route.startswith("qt") and rng.random() < 0.4),
+            "cat": bool(rng.random() < 0.4), "levels": int(rng.integers(2, 6)), "seed": int(rng.integers(1, 1 << 30))}
+
+
+def apply_prep(S, spec, pr):
+    """Writes the files the options name; -> (regenie arguments, oracle options)"""
+    rng = np.random.default_rng(pr["seed"])
+    args, kw = [], {}
+    if pr["remove"]:
+        ids = np.sort(rng.choice(spec["N"], max(1, spec["N"] // 20), replace=False)) + 1
+        open(S + ".remove", "w").write("".join("%d %d\n" % (i, i) for i in ids))
+        args += ["--remove", S + ".remove"]; kw["remove"] = [S + ".remove"]
+    if pr["exclude"]:
+        ids = np.sort(rng.choice(spec["M"], max(1, spec["M"] // 15), replace=False))
+        open(S + ".exclude", "w").write("".join("s%d\n" % i for i in ids))
+        args += ["--exclude", S + ".exclude"]; kw["exclude"] = [S + ".exclude"]
+    if pr["rint"]:
+        args += ["--apply-rint"]; kw["apply_rint"] = True
+    if pr["cat"]:
+        lines = open(S + ".covar").read().splitlines()
+        lev = rng.integers(0, pr["levels"], spec["N"])
+        lev[: pr["levels"]] = rng.permutation(pr["levels"])            # every level occurs; the order of first appearance is drawn
+        out = [lines[0] + " CAT"] + [ln + " %d" % (7 * int(v) + 3) for ln, v in zip(lines[1:], lev)]
+        open(S + ".covar", "w").write("\n".join(out) + "\n")
+        args += ["--catCovarList", "CAT"]; kw["cat_covar"] = ["CAT"]
+    return args, kw
+
+
 def run_one(seed, work):
     route, spec, o = draw(seed)
     d = os.path.join(work, "c%d" % seed)
@@ -116,12 +148,19 @@ def run_one(seed, work):
     args += ["--loocv"] if o["loocv"] else []
     args += ["--ref-first"] if o["ref_first"] else []
     args += ["--strict"] if o["strict"] else []
+    prep_desc = ""
+    if os.environ.get("FUZZ_PREP"):
+        pr = draw_prep(seed, route)
+        pa, pk = apply_prep(S, spec, pr)
+        args += pa
+        o = dict(o, **pk)
+        prep_desc = "".join(" " + k for k in ("remove", "exclude", "rint") if pr[k]) + (" cat%d" % pr["levels"] if pr["cat"] else "")
     t0 = time.time()
     r = subprocess.run([REGENIE] + args + ["--out", "out"], cwd=d, capture_output=True, text=True)
     t_ref = time.time() - t0
     desc = "seed %d %-8s N %d M %d chr %d P %d bsize %d cv %d l0 %d l1 %d%s%s missG %.2f missY %.2f" % (
         seed, route, spec["N"], spec["M"], len(set(spec["chroms"])), spec["P"], o["bsize"], o["cv_folds"], o["n_ridge_l0"], o["n_ridge_l1"],
-        " ref-first" if o["ref_first"] else "", " strict" if o["strict"] else "", spec["miss_rate"], spec["missing_pheno"])
+        " ref-first" if o["ref_first"] else "", " strict" if o["strict"] else "", spec["miss_rate"], spec["missing_pheno"]) + prep_desc
     if r.returncode != 0:
         return desc + " | regenie itself stopped: " + (r.stdout + r.stderr).strip().splitlines()[-1][:160], None
     log = open(os.path.join(d, "out.log")).read()
@@ -156,15 +195,27 @@ def run_one(seed, work):
     return desc + " | ok: loco max rel err %.1e (%s), regenie %.1f s, oracle %.1f s%s" % (worst, "LOOCV" if res.use_loocv else "K-fold", t_ref, t_or, extra), True
 
 
+def _prep_args(S, o):
+    a = []
+    for k, flag in (("remove", "--remove"), ("exclude", "--exclude")):
+        for f in o.get(k, ()):
+            a += [flag, f]
+    a += ["--apply-rint"] if o.get("apply_rint") else []
+    a += ["--catCovarList", ",".join(o["cat_covar"])] if o.get("cat_covar") else []
+    return a
+
+
 def step2_qt_leg(d, S, o):
     """regenie --step 2 --qt on the case's files with ITS OWN step-1 predictions against the oracle's score test; -> variants x traits compared"""
     from oracle import regenie_step2_qt as s2
     args = ["--step", "2", "--qt", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list"]
     args += ["--ref-first"] if o["ref_first"] else []
     args += ["--strict"] if o["strict"] else []
+    args += _prep_args(S, o)
     r = subprocess.run([REGENIE] + args + ["--out", "s2"], cwd=d, capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
-    opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, ref_first=o["ref_first"], strict=o["strict"], test_mode=True)
+    opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
+                           **{k: o[k] for k in ("remove", "exclude", "apply_rint", "cat_covar") if k in o})
     bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
     bed, _ = orc.open_bed(S + ".bed", prep.n_file)
     ia = prep.ind_in_analysis
