@@ -190,6 +190,8 @@ def run_one(seed, work):
     extra = ""
     if not o["bt"]:
         extra = ", step 2: %d statistics" % step2_qt_leg(d, S, o)
+    elif os.environ.get("FUZZ_BT_STEP2"):
+        extra = ", step 2 (score test): %d statistics" % step2_bt_leg(d, S, o)
     if os.environ.get("FUZZ_DRIVER"):
         extra += " | " + driver_legs(d, args, o, len(names))
     return desc + " | ok: loco max rel err %.1e (%s), regenie %.1f s, oracle %.1f s%s" % (worst, "LOOCV" if res.use_loocv else "K-fold", t_ref, t_or, extra), True
@@ -250,6 +252,57 @@ def step2_qt_leg(d, S, o):
                 assert abs(out["se"][k, ph] - se) <= 5e-5 * abs(se), ("SE", snp_ids[sel[k]], ph, out["se"][k, ph], se)
                 assert abs(out["chisq"][k, ph] - chisq) <= 1e-4 * abs(chisq) + 2e-6, ("CHISQ", snp_ids[sel[k]], ph, out["chisq"][k, ph], chisq)
                 assert abs(s2.get_logp(out["chisq"][k, ph]) - logp) <= 1e-4 * abs(logp) + 2e-6, ("LOG10P", snp_ids[sel[k]], ph)
+                ncmp += 1
+    assert ncmp > 0
+    return ncmp
+
+
+def step2_bt_leg(d, S, o):
+    """regenie --step 2 --bt (the score test, no Firth / SPA) with ITS OWN step-1 predictions against oracle/regenie_step2_bt.py: the null logistic
+    model with the LOCO offset per chromosome, compute_score_bt, get_sumstats; -> statistics compared"""
+    from oracle import regenie_step2_bt as bt
+    from oracle import regenie_step2_qt as s2
+    args = ["--step", "2", "--bt", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list"]
+    args += ["--ref-first"] if o["ref_first"] else []
+    args += ["--strict"] if o["strict"] else []
+    args += _prep_args(S, o)
+    r = subprocess.run([REGENIE] + args + ["--out", "s2"], cwd=d, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
+    opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, bt=True, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
+                           **{k: o[k] for k in ("remove", "exclude", "cat_covar") if k in o})
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    bed, _ = orc.open_bed(S + ".bed", prep.n_file)
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    P = prep.Y.shape[1]
+    loco, rows, col = [], [], None
+    for ph in range(P):
+        hdr, v = _loco(os.path.join(d, "out_%d.loco" % (ph + 1)))
+        pos = {s_: k for k, s_ in enumerate(hdr)}
+        loco.append(np.nan_to_num(v[:, [pos[i] for i in ids]]))
+        h, body = pin._read_regenie(os.path.join(d, "s2_Y%d.regenie" % (ph + 1)))
+        col = {nm: i for i, nm in enumerate(h)}
+        rows.append({r_[col["ID"]]: r_ for r_ in body})
+    X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
+    ncmp = 0
+    for c in sorted(set(chrom.tolist())):
+        nulls = [bt.null_logistic(Yraw[:, ph], X, mask[:, ph], loco[ph][c - 1], opt) for ph in range(P)]
+        sel = np.flatnonzero(chrom == c)
+        G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
+        if o["ref_first"]:
+            G = np.where(G < 0, G, 2.0 - G)
+        for k in range(sel.size):
+            g, mean, nobs = s2.mean_impute(G[k])
+            for ph in range(P):
+                r_ = rows[ph].get(snp_ids[sel[k]])
+                if r_ is None or r_[col["BETA"]] == "NA" or nulls[ph] is None:
+                    continue
+                out = bt.score_bt(g, X, Yraw[:, ph], mask[:, ph].astype(np.float64), nulls[ph])
+                beta, se, chisq, logp = (float(r_[col[nm]]) for nm in ("BETA", "SE", "CHISQ", "LOG10P"))
+                assert abs(out["bhat"] - beta) <= 5e-5 * abs(beta) + 2e-6, ("BETA", snp_ids[sel[k]], ph, out["bhat"], beta)
+                assert abs(out["se"] - se) <= 5e-5 * abs(se), ("SE", snp_ids[sel[k]], ph, out["se"], se)
+                assert abs(out["chisq"] - chisq) <= 1e-4 * abs(chisq) + 2e-6, ("CHISQ", snp_ids[sel[k]], ph, out["chisq"], chisq)
+                assert abs(s2.get_logp(out["chisq"]) - logp) <= 1e-4 * abs(logp) + 2e-6, ("LOG10P", snp_ids[sel[k]], ph)
                 ncmp += 1
     assert ncmp > 0
     return ncmp
