@@ -903,6 +903,20 @@ def ridge_level_1_loocv(W: np.ndarray, y: np.ndarray, tau: np.ndarray, Neff: flo
     return cs
 
 
+def _llt(A):
+    """Cholesky factor, or None when A is not (numerically) positive definite or not finite.  The reference solves its Newton systems with Eigen's
+    `A.llt().solve(b)` (Step1_Models.cpp:1052, :1325, :1499, :1723), which does not report a failed factorisation: the step is then garbage, the
+    stopping rule is never met, and the trait ends as "did not converge" after --niter rounds.  That happens on count traits whose rows are missing
+    for some traits only: the raw column keeps the missing-value code there, the rate and with it the penalties come out
+    negative or NaN.  The callers below return "not converged" at once (tests/golden/fuzz_oracle_vs_reference.py draws such cases)."""
+    if not np.isfinite(A).all():
+        return None
+    try:
+        return np.linalg.cholesky(A)
+    except np.linalg.LinAlgError:
+        return None
+
+
 def run_log_ridge_loocv(lam: float, beta: np.ndarray, y, X, offset, mask, opt: Step1Options):
     """Step1_Models.cpp:1288-1374.  Returns (ok, beta, p, w)."""
     eta = offset + X @ beta
@@ -922,7 +936,9 @@ def run_log_ridge_loocv(lam: float, beta: np.ndarray, y, X, offset, mask, opt: S
         wm = np.where(mask, w, 0.0)
         XtWX = (X.T * wm[None, :]) @ X
         XtWX[np.diag_indices_from(XtWX)] += lam
-        cho = np.linalg.cholesky(XtWX)
+        cho = _llt(XtWX)
+        if cho is None:
+            return False, beta, p, w
         step = np.linalg.solve(cho.T, np.linalg.solve(cho, score))
         for _ in range(opt.niter_max_line_search):
             betanew = beta + step
@@ -1037,7 +1053,9 @@ def ridge_logistic_level_1(W, yraw, offset, mask, cv_sizes, tau, opt: Step1Optio
                 wm = np.where(mt, w, 0.0)
                 XtWX = _xtwx(Xt, wm)
                 XtWX[np.diag_indices_from(XtWX)] += tau[j]
-                cho = np.linalg.cholesky(XtWX)
+                cho = _llt(XtWX)
+                if cho is None:
+                    return cs, betas, False
                 betanew = np.linalg.solve(cho.T, np.linalg.solve(cho, Xt.T @ (wm * z)))
                 for _ in range(opt.niter_max_line_search_ridge):
                     p = get_pvec(ot + Xt @ betanew)
@@ -1118,7 +1136,9 @@ def ridge_poisson_level_1(W, yraw, offset, mask, cv_sizes, tau, opt: Step1Option
                 XtW = Xt.T * wm[None, :]
                 XtWX = XtW @ Xt
                 XtWX[np.diag_indices_from(XtWX)] += tau[j]
-                cho = np.linalg.cholesky(XtWX)
+                cho = _llt(XtWX)
+                if cho is None:
+                    return cs, betas, False
                 betanew = np.linalg.solve(cho.T, np.linalg.solve(cho, XtW @ z))
                 for _ in range(opt.niter_max_line_search_ridge):
                     _, p = pvec(betanew, Xt, ot)
@@ -1163,7 +1183,9 @@ def run_ct_ridge_loocv(lam: float, beta: np.ndarray, y, X, offset, mask, opt: St
         XtW = X.T * wm[None, :]
         XtWX = XtW @ X
         XtWX[np.diag_indices_from(XtWX)] += lam
-        cho = np.linalg.cholesky(XtWX)
+        cho = _llt(XtWX)
+        if cho is None:
+            return False, betaold, p
         betanew = np.linalg.solve(cho.T, np.linalg.solve(cho, XtW @ z))
         with np.errstate(over="ignore"):
             p = np.exp(offset + X @ betanew)

@@ -585,12 +585,13 @@ int run(int argc, char** argv) {
   auto emit_pheno = [&](int q, const double* cs, int bestq, int conv, const double* pq /* [nchr][N] */) {
     if (!r.pheno_pass[q]) return;   // null model did not converge: the trait is ignored, no table, no file, no list entry (Data.cpp:984)
     std::ostringstream lo;
-    lo << "phenotype " << r.outnum(q) << " (" << r.pheno_names[q] << ") : \n";
-    if (!conv) {  // Data.cpp:1016-1021
+    lo << "phenotype " << r.outnum(q) << " (" << r.pheno_names[q] << ") : ";
+    if (!conv) {  // Data.cpp:1009-1014: on the header's own line
       lo << "Level 1 model did not converge. LOCO predictions calculations are skipped.\n\n";
       ph_log[q] = lo.str();
       return;
     }
+    lo << "\n";
     for (int j = 0; j < R1 && p.t2e; ++j)   // Data.cpp:1043-1049: the penalty and the held-out deviance summed over the folds
       lo << " " << std::right << std::setw(5) << tau[(size_t)q * R1 + j] << " : Deviance = " << cs[5 * R1 + j] << (j == bestq ? "<- min value" : "") << "\n";
     for (int j = 0; j < R1 && !p.t2e; ++j) {

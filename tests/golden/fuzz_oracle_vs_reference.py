@@ -44,6 +44,8 @@ def driver_legs(d, args1, o, P):
     r = subprocess.run([BIN] + args1 + ["--out", "drv"], cwd=d, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "regenie-amd --step 1: " + (r.stdout + r.stderr)[-500:]
     assert open(os.path.join(d, "drv_pred.list")).read().replace("drv_", "out_") == open(os.path.join(d, "out_pred.list")).read()
+    skipped = lambda t: [ln.split(" : ")[0] for ln in t.splitlines() if ln.startswith("phenotype ") and "did not converge" in ln]      # noqa: E731
+    assert skipped(open(os.path.join(d, "drv.log")).read()) == skipped(open(os.path.join(d, "out.log")).read()), "traits reported as not converged"
     worst_ulp, worst_rel, same_files = 0.0, 0.0, 0
     for ph in range(P):
         ids_r, ref = _loco(os.path.join(d, "out_%d.loco" % (ph + 1)))
@@ -58,7 +60,7 @@ def driver_legs(d, args1, o, P):
         same_files += open(os.path.join(d, "out_%d.loco" % (ph + 1))).read() == open(os.path.join(d, "drv_%d.loco" % (ph + 1))).read()
     assert worst_rel < 1e-5, "driver .loco: %.2e of the largest value" % worst_rel
     out = "driver: loco %.1e (%.1f text ulps, %d/%d files byte-identical)" % (worst_rel, worst_ulp, same_files, P)
-    if not o["bt"]:
+    if not o["bt"] and not o.get("ct"):
         S = os.path.join(d, "synth")
         a2 = ["--step", "2", "--qt", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list"]
         a2 += ["--ref-first"] if o["ref_first"] else []
@@ -85,9 +87,21 @@ def driver_legs(d, args1, o, P):
 
 
 
+def ref_table(log_text):
+    """table_lines() that also keeps a trait regenie skipped: `phenotype k (name) : Level 1 model did not converge. ...` is ONE line of its log"""
+    out = []
+    for ln in log_text.splitlines():
+        if ln.startswith("phenotype ") and " : " in ln + " " and "(" in ln:
+            out.append(ln.split(" : ")[0].rstrip().rstrip(":").rstrip() + " :" if "did not converge" in ln else ln.rstrip())
+        elif ": Rsq = " in ln:
+            out.append(ln.rstrip())
+    return out
+
+
 def draw(seed):
     rng = np.random.default_rng(100000 + seed)
-    route = ["qt_kfold", "qt_loocv", "bt_loocv", "qt_kfold", "bt_kfold"][seed % 5]
+    cycle = os.environ["FUZZ_ROUTES"].split(",") if os.environ.get("FUZZ_ROUTES") else ["qt_kfold", "qt_loocv", "bt_loocv", "qt_kfold", "bt_kfold"]
+    route = cycle[seed % len(cycle)]          # FUZZ_ROUTES: also ct_kfold (count traits) and t2e_kfold (time-to-event traits, Cox ridge at level 1)
     if route == "bt_kfold":
         N, M = int(rng.integers(5050, 5400)), int(rng.integers(60, 140))
     else:
@@ -101,6 +115,13 @@ def draw(seed):
     opt = {"bsize": int(rng.choice([37, 64, 100, 150])), "bt": route.startswith("bt"), "loocv": route == "qt_loocv",
            "cv_folds": int(rng.choice([3, 4, 5, 7])), "n_ridge_l0": int(rng.choice([3, 5, 6])), "n_ridge_l1": int(rng.choice([4, 5, 7])),
            "ref_first": bool(rng.random() < 0.3), "strict": bool(spec["missing_pheno"] > 0 and rng.random() < 0.3)}
+    if route == "ct_kfold":
+        spec["counts"] = "poisson"
+        opt["ct"] = True
+    if route == "t2e_kfold":
+        spec["t2e"] = {"ntraits": spec["P"], "missing": spec["missing_pheno"] * 0.6, "decimals": int(rng.choice([1, 2, 3]))}
+        spec["missing_pheno"] = 0.0
+        opt["strict"] = False
     return route, spec, opt
 
 
@@ -141,10 +162,13 @@ def run_one(seed, work):
     os.makedirs(d)
     S = os.path.join(d, "synth")
     g = synth_dosages(spec["M"], spec["N"], miss_rate=spec["miss_rate"], seed=spec["seed"])
-    write_plink(S, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    write_plink(S, g, spec["chroms"], P=spec["P"], seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"], counts=spec.get("counts", False))
+    if route == "t2e_kfold":
+        return run_t2e(seed, d, S, g, spec, o)
     args = ["--step", "1", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", str(o["bsize"]), "--cv", str(o["cv_folds"]),
             "--l0", str(o["n_ridge_l0"]), "--l1", str(o["n_ridge_l1"])]
     args += ["--bt"] if o["bt"] else []
+    args += ["--ct"] if o.get("ct") else []
     args += ["--loocv"] if o["loocv"] else []
     args += ["--ref-first"] if o["ref_first"] else []
     args += ["--strict"] if o["strict"] else []
@@ -167,10 +191,13 @@ def run_one(seed, work):
     t0 = time.time()
     res = orc.run_step1(orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", **o))
     t_or = time.time() - t0
-    ref_tab = pin.parse_table(table_lines(log))
+    ref_tab = pin.parse_table(ref_table(log))
     got_tab = pin.parse_table([l for l in res.log if l.startswith("phenotype ") or ": Rsq = " in l])
     names = [ln.split()[0] for ln in open(os.path.join(d, "out_pred.list"))]
-    assert len(ref_tab) == len(got_tab) == len(names), (len(ref_tab), len(got_tab), len(names))
+    # a trait whose level-1 model did not converge has a line in the table ("... LOCO predictions calculations are skipped") and no file
+    assert len(ref_tab) == len(got_tab), (len(ref_tab), len(got_tab))
+    assert names == [res.prep.pheno_names[ph] for ph in range(len(got_tab)) if res.loco[ph] is not None], ("traits with predictions", names)
+    skipped = len(got_tab) - len(names)
     worst = 0.0
     for ph, (rt, gt) in enumerate(zip(ref_tab, got_tab)):
         assert len(rt) == len(gt)
@@ -179,6 +206,9 @@ def run_one(seed, work):
             assert abs(rsq2 - rsq) <= 2e-5 * max(abs(rsq), 1e-12) + 1e-12 and (np.isnan(mse) or abs(mse2 - mse) <= 2e-5 * abs(mse)), ("table", ph, h, rsq, rsq2, mse, mse2)
             if ll is not None:
                 assert abs(ll2 - ll) <= 2e-5 * abs(ll), ("table logLik", ph, h, ll, ll2)
+        if res.loco[ph] is None:
+            assert not os.path.exists(os.path.join(d, "out_%d.loco" % (ph + 1)))
+            continue
         lines = open(os.path.join(d, "out_%d.loco" % (ph + 1))).read().splitlines()
         ids = lines[0].split()[1:]
         ref = np.array([[np.nan if t == "NA" else float(t) for t in ln.split()[1:]] for ln in lines[1:]])
@@ -188,12 +218,14 @@ def run_one(seed, work):
         ok = ~np.isnan(ref)
         worst = max(worst, float(np.max(np.abs(got[ok] - ref[ok])) / np.max(np.abs(ref[ok]))))
     extra = ""
-    if not o["bt"]:
+    if not o["bt"] and not o.get("ct"):
         extra = ", step 2: %d statistics" % step2_qt_leg(d, S, o)
-    elif os.environ.get("FUZZ_BT_STEP2"):
+    elif o["bt"] and os.environ.get("FUZZ_BT_STEP2"):
         extra = ", step 2 (score test): %d statistics" % step2_bt_leg(d, S, o)
     if os.environ.get("FUZZ_DRIVER"):
         extra += " | " + driver_legs(d, args, o, len(names))
+    if skipped:
+        extra += ", %d trait(s) not converged in both" % skipped
     return desc + " | ok: loco max rel err %.1e (%s), regenie %.1f s, oracle %.1f s%s" % (worst, "LOOCV" if res.use_loocv else "K-fold", t_ref, t_or, extra), True
 
 
@@ -255,6 +287,70 @@ def step2_qt_leg(d, S, o):
                 ncmp += 1
     assert ncmp > 0
     return ncmp
+
+
+def run_t2e(seed, d, S, g, spec, o):
+    """--t2e: (time, event) pairs, Cox ridge at level 1 (oracle/regenie_step1_t2e.py) -- penalties, held-out deviances, selection, .loco files"""
+    from oracle import regenie_step1_t2e as t2e
+    from tests.util import write_t2e_pheno
+    write_t2e_pheno(S + ".t2e", g, seed=spec["seed"], **spec["t2e"])
+    nt = spec["t2e"]["ntraits"]
+    tcols, ecols = ["T%d" % (k + 1) for k in range(nt)], ["E%d" % (k + 1) for k in range(nt)]
+    args = ["--step", "1", "--bed", S, "--phenoFile", S + ".t2e", "--covarFile", S + ".covar", "--bsize", str(o["bsize"]), "--cv", str(o["cv_folds"]),
+            "--l0", str(o["n_ridge_l0"]), "--l1", str(o["n_ridge_l1"]), "--t2e", "--phenoColList", ",".join(tcols), "--eventColList", ",".join(ecols)]
+    args += ["--ref-first"] if o["ref_first"] else []
+    t0 = time.time()
+    r = subprocess.run([REGENIE] + args + ["--out", "out"], cwd=d, capture_output=True, text=True)
+    t_ref = time.time() - t0
+    desc = "seed %d t2e_kfold N %d M %d chr %d traits %d bsize %d cv %d l0 %d l1 %d%s missG %.2f missing pairs %.2f decimals %d" % (
+        seed, spec["N"], spec["M"], len(set(spec["chroms"])), nt, o["bsize"], o["cv_folds"], o["n_ridge_l0"], o["n_ridge_l1"], " ref-first" if o["ref_first"] else "",
+        spec["miss_rate"], spec["t2e"]["missing"], spec["t2e"]["decimals"])
+    if r.returncode != 0:
+        return desc + " | regenie itself stopped: " + (r.stdout + r.stderr).strip().splitlines()[-1][:160], None
+    t0 = time.time()
+    res = t2e.run_step1_t2e(orc.Step1Options(bed=S, pheno_file=S + ".t2e", covar_file=S + ".covar", bsize=o["bsize"], cv_folds=o["cv_folds"], n_ridge_l0=o["n_ridge_l0"],
+                                             n_ridge_l1=o["n_ridge_l1"], ref_first=o["ref_first"]), dict(zip(tcols, ecols)))
+    t_or = time.time() - t0
+    ref_lines = table_lines(open(os.path.join(d, "out.log")).read())
+    got_lines = [ln.rstrip() for ln in res["log"]]
+    assert len(ref_lines) == len(got_lines), (len(ref_lines), len(got_lines))
+    for a, b in zip(ref_lines, got_lines):
+        if a.startswith("phenotype"):
+            assert a.split() == b.split(), (a, b)
+            continue
+        ma, mb = pin.T2E_RE.match(a), pin.T2E_RE.match(b)
+        assert ma and mb, (a, b)
+        assert abs(float(mb.group(1)) - float(ma.group(1))) <= 2e-5 * abs(float(ma.group(1))) and abs(float(mb.group(2)) - float(ma.group(2))) <= 2e-5 * abs(float(ma.group(2))), (a, b)
+        assert bool(ma.group(3)) == bool(mb.group(3)), ("selected penalty", a, b)
+    prep = res["prep"]
+    order = [i for i in sorted(range(len(prep.ids)), key=lambda i: prep.ids[i]) if prep.ind_in_analysis[i]]
+    worst = 0.0
+    for tn in tcols:
+        ti = prep.pheno_names.index(tn)
+        ids, ref = _loco(os.path.join(d, "out_%d.loco" % (ti + 1)))
+        got = res["traits"][tn]["loco"][order, :].T.copy()
+        got[:, ~prep.mask[order, ti]] = np.nan
+        assert ids == [prep.ids[i] for i in order]
+        pin.assert_text_equal(got, ref, tn)
+        ok = ~np.isnan(ref)
+        worst = max(worst, float(np.max(np.abs(got[ok] - ref[ok])) / np.max(np.abs(ref[ok]))))
+    extra = ""
+    if os.environ.get("FUZZ_DRIVER"):
+        r = subprocess.run([BIN] + args + ["--out", "drv"], cwd=d, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, "regenie-amd --step 1 --t2e: " + (r.stdout + r.stderr)[-500:]
+        assert open(os.path.join(d, "drv_pred.list")).read().replace("drv_", "out_") == open(os.path.join(d, "out_pred.list")).read()
+        wd, same = 0.0, 0
+        for tn in tcols:
+            ti = prep.pheno_names.index(tn)
+            ids_r, ref = _loco(os.path.join(d, "out_%d.loco" % (ti + 1)))
+            ids_g, got = _loco(os.path.join(d, "drv_%d.loco" % (ti + 1)))
+            assert ids_r == ids_g and np.array_equal(np.isnan(got), np.isnan(ref))
+            ok = ~np.isnan(ref)
+            wd = max(wd, float(np.max(np.abs(got[ok] - ref[ok])) / np.max(np.abs(ref[ok]))))
+            same += open(os.path.join(d, "out_%d.loco" % (ti + 1))).read() == open(os.path.join(d, "drv_%d.loco" % (ti + 1))).read()
+        assert wd < 1e-5, "driver .loco (t2e): %.2e" % wd
+        extra = " | driver: loco %.1e (%d/%d files byte-identical)" % (wd, same, nt)
+    return desc + " | ok: loco max rel err %.1e, regenie %.1f s, oracle %.1f s%s" % (worst, t_ref, t_or, extra), True
 
 
 def step2_bt_leg(d, S, o):
