@@ -69,9 +69,9 @@ def driver_legs(d, args1, o, P):
         r = subprocess.run([BIN] + a2 + ["--out", "d2"], cwd=d, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, "regenie-amd --step 2: " + (r.stdout + r.stderr)[-500:]
         same = tot = 0
-        for ph in range(P):
-            a = open(os.path.join(d, "d2_Y%d.regenie" % (ph + 1))).read().splitlines()
-            b = open(os.path.join(d, "s2_Y%d.regenie" % (ph + 1))).read().splitlines()
+        for nm in [ln.split()[0] for ln in open(os.path.join(d, "out_pred.list"))]:
+            a = open(os.path.join(d, "d2_%s.regenie" % nm)).read().splitlines()
+            b = open(os.path.join(d, "s2_%s.regenie" % nm)).read().splitlines()
             assert a[0] == b[0] and len(a) == len(b), "driver .regenie header / line count"
             for x, y in zip(a[1:], b[1:]):
                 tot += 1
@@ -115,9 +115,10 @@ def draw(seed):
     opt = {"bsize": int(rng.choice([37, 64, 100, 150])), "bt": route.startswith("bt"), "loocv": route == "qt_loocv",
            "cv_folds": int(rng.choice([3, 4, 5, 7])), "n_ridge_l0": int(rng.choice([3, 5, 6])), "n_ridge_l1": int(rng.choice([4, 5, 7])),
            "ref_first": bool(rng.random() < 0.3), "strict": bool(spec["missing_pheno"] > 0 and rng.random() < 0.3)}
-    if route == "ct_kfold":
+    if route in ("ct_kfold", "ct_loocv"):
         spec["counts"] = "poisson"
         opt["ct"] = True
+        opt["loocv"] = route == "ct_loocv"
     if route == "t2e_kfold":
         spec["t2e"] = {"ntraits": spec["P"], "missing": spec["missing_pheno"] * 0.6, "decimals": int(rng.choice([1, 2, 3]))}
         spec["missing_pheno"] = 0.0
@@ -128,8 +129,12 @@ def draw(seed):
 def draw_prep(seed, route):
     """Host-preparation options on top of a case (FUZZ_PREP=1): --remove, --exclude, --apply-rint (quantitative traits), a categorical covariate."""
     rng = np.random.default_rng(700000 + seed)
-    return {"remove": bool(rng.random() < 0.4), "exclude": bool(rng.random() < 0.4), "rint": bool(route.startswith("qt") and rng.random() < 0.4),
-            "cat": bool(rng.random() < 0.4), "levels": int(rng.integers(2, 6)), "seed": int(rng.integers(1, 1 << 30))}
+    pr = {"remove": bool(rng.random() < 0.4), "exclude": bool(rng.random() < 0.4), "rint": bool(route.startswith("qt") and rng.random() < 0.4),
+          "cat": bool(rng.random() < 0.4), "levels": int(rng.integers(2, 6)), "seed": int(rng.integers(1, 1 << 30))}
+    if os.environ.get("FUZZ_PREP") == "2":      # the complementary lists, a subset of the phenotype columns, --nb
+        pr.update(keep=bool(rng.random() < 0.4), extract=bool(rng.random() < 0.4), phenocol=bool(rng.random() < 0.4), nb=bool(rng.random() < 0.3))
+        pr["keep"] = pr["keep"] and not pr["remove"]          # (regenie takes one of --keep / --remove)
+    return pr
 
 
 def apply_prep(S, spec, pr):
@@ -144,6 +149,20 @@ def apply_prep(S, spec, pr):
         ids = np.sort(rng.choice(spec["M"], max(1, spec["M"] // 15), replace=False))
         open(S + ".exclude", "w").write("".join("s%d\n" % i for i in ids))
         args += ["--exclude", S + ".exclude"]; kw["exclude"] = [S + ".exclude"]
+    if pr.get("keep"):
+        ids = np.sort(rng.choice(spec["N"], spec["N"] - max(1, spec["N"] // 12), replace=False)) + 1
+        open(S + ".keep", "w").write("".join("%d %d\n" % (i, i) for i in ids))
+        args += ["--keep", S + ".keep"]; kw["keep"] = [S + ".keep"]
+    if pr.get("extract"):
+        ids = np.sort(rng.choice(spec["M"], spec["M"] - max(1, spec["M"] // 10), replace=False))
+        open(S + ".extract", "w").write("".join("s%d\n" % i for i in ids))
+        args += ["--extract", S + ".extract"]; kw["extract"] = [S + ".extract"]
+    if pr.get("phenocol") and spec["P"] > 1:
+        cols = ["Y%d" % (k + 1) for k in np.sort(rng.choice(spec["P"], spec["P"] - 1, replace=False))]
+        args += ["--phenoColList", ",".join(cols)]; kw["pheno_cols"] = cols
+    if pr.get("nb"):
+        nb = int(rng.integers(2, 5))
+        args += ["--nb", str(nb)]; kw["n_block"] = nb
     if pr["rint"]:
         args += ["--apply-rint"]; kw["apply_rint"] = True
     if pr["cat"]:
@@ -178,7 +197,7 @@ def run_one(seed, work):
         pa, pk = apply_prep(S, spec, pr)
         args += pa
         o = dict(o, **pk)
-        prep_desc = "".join(" " + k for k in ("remove", "exclude", "rint") if pr[k]) + (" cat%d" % pr["levels"] if pr["cat"] else "")
+        prep_desc = "".join(" " + k for k in ("remove", "exclude", "rint", "keep", "extract", "phenocol", "nb") if pr.get(k)) + (" cat%d" % pr["levels"] if pr["cat"] else "")
     t0 = time.time()
     r = subprocess.run([REGENIE] + args + ["--out", "out"], cwd=d, capture_output=True, text=True)
     t_ref = time.time() - t0
@@ -231,10 +250,11 @@ def run_one(seed, work):
 
 def _prep_args(S, o):
     a = []
-    for k, flag in (("remove", "--remove"), ("exclude", "--exclude")):
+    for k, flag in (("remove", "--remove"), ("exclude", "--exclude"), ("keep", "--keep"), ("extract", "--extract")):
         for f in o.get(k, ()):
             a += [flag, f]
     a += ["--apply-rint"] if o.get("apply_rint") else []
+    a += ["--phenoColList", ",".join(o["pheno_cols"])] if o.get("pheno_cols") else []
     a += ["--catCovarList", ",".join(o["cat_covar"])] if o.get("cat_covar") else []
     return a
 
@@ -249,7 +269,7 @@ def step2_qt_leg(d, S, o):
     r = subprocess.run([REGENIE] + args + ["--out", "s2"], cwd=d, capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
-                           **{k: o[k] for k in ("remove", "exclude", "apply_rint", "cat_covar") if k in o})
+                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "apply_rint", "cat_covar") if k in o})
     bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
     bed, _ = orc.open_bed(S + ".bed", prep.n_file)
     ia = prep.ind_in_analysis
@@ -261,7 +281,7 @@ def step2_qt_leg(d, S, o):
         pos = {s_: k for k, s_ in enumerate(lines[0].split()[1:])}
         v = np.array([[np.nan if t == "NA" else float(t) for t in ln.split()[1:]] for ln in lines[1:]])
         loco.append(np.nan_to_num(v[:, [pos[i] for i in ids]]))
-        refs.append(pin._read_regenie(os.path.join(d, "s2_Y%d.regenie" % (ph + 1))))
+        refs.append(pin._read_regenie(os.path.join(d, "s2_%s.regenie" % prep.pheno_names[ph])))
     col = {nm: i for i, nm in enumerate(refs[0][0])}
     X, Y, mask = prep.X[ia], prep.Y[ia], prep.mask[ia].astype(np.float64)
     by_id = [{r_[col["ID"]]: r_ for r_ in refs[ph][1]} for ph in range(P)]
@@ -365,7 +385,7 @@ def step2_bt_leg(d, S, o):
     r = subprocess.run([REGENIE] + args + ["--out", "s2"], cwd=d, capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, bt=True, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
-                           **{k: o[k] for k in ("remove", "exclude", "cat_covar") if k in o})
+                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "cat_covar") if k in o})
     bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
     bed, _ = orc.open_bed(S + ".bed", prep.n_file)
     ia = prep.ind_in_analysis
@@ -376,7 +396,7 @@ def step2_bt_leg(d, S, o):
         hdr, v = _loco(os.path.join(d, "out_%d.loco" % (ph + 1)))
         pos = {s_: k for k, s_ in enumerate(hdr)}
         loco.append(np.nan_to_num(v[:, [pos[i] for i in ids]]))
-        h, body = pin._read_regenie(os.path.join(d, "s2_Y%d.regenie" % (ph + 1)))
+        h, body = pin._read_regenie(os.path.join(d, "s2_%s.regenie" % prep.pheno_names[ph]))
         col = {nm: i for i, nm in enumerate(h)}
         rows.append({r_[col["ID"]]: r_ for r_ in body})
     X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
