@@ -17,6 +17,18 @@ from . import regenie_step1 as orc
 NUMTOL = 1e-6
 
 
+def flip_geno(g_raw):
+    """flip_geno (Geno.cpp:3150-3162), applied by regenie to every variant of an additive test on a binary or count trait (params.with_flip,
+    Data.cpp:2108; never for quantitative traits): when the counted allele is the major one -- mean dosage of the analysed, observed samples
+    above 1 -- the genotype becomes 2 - g (missing entries stay missing), so that the tests run on the MINOR allele; BETA is negated back
+    afterwards (Step2_Models.cpp:621, :692).  The score test does not see it (sign aside); the corrections do: check_sparse_G and with it the
+    fast forms of the saddlepoint approximation and of the approximate Firth fit (carriers only) look at the minor-allele coding.
+    g_raw: dosages with negative values for missing (what decode_bed_rows returns, after --ref-first).  -> (g, flipped)"""
+    obs = g_raw >= 0
+    flipped = bool(obs.any() and g_raw[obs].mean() > 1.0)
+    return (np.where(obs, 2.0 - g_raw, g_raw) if flipped else g_raw), flipped
+
+
 def null_logistic(y_raw, X, mask, loco_offset, opt):
     """fit_null_logistic, test-mode branch (Step1_Models.cpp:54-140), for one phenotype: logistic regression of the trait on the
     covariate basis with the LOCO prediction as offset.  Returns None when it does not converge (the phenotype is skipped), else

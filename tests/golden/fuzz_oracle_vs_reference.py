@@ -241,6 +241,8 @@ def run_one(seed, work):
         extra = ", step 2: %d statistics" % step2_qt_leg(d, S, o)
     elif o["bt"] and os.environ.get("FUZZ_BT_STEP2"):
         extra = ", step 2 (score test): %d statistics" % step2_bt_leg(d, S, o)
+        if os.environ["FUZZ_BT_STEP2"] == "2":
+            extra += ", corrected: %d Firth + %d SPA rows" % step2_bt_corrections_leg(d, S, o)
     if os.environ.get("FUZZ_DRIVER"):
         extra += " | " + driver_legs(d, args, o, len(names))
     if skipped:
@@ -422,6 +424,98 @@ def step2_bt_leg(d, S, o):
                 ncmp += 1
     assert ncmp > 0
     return ncmp
+
+
+def step2_bt_corrections_leg(d, S, o, pthresh=0.2):
+    """regenie --step 2 --bt with --firth --approx and with --spa (p-value threshold 0.2: a fifth of the tests are corrected) against
+    oracle/regenie_step2_bt.py: null Firth model, the 1-parameter approximate Firth fit (on the carriers only for sparse rare variants),
+    the saddlepoint approximation (its fast form for sparse variants; a test regenie reports as TEST_FAIL has no root here either).
+    Both programs stop their null models and these fits at a tolerance, and the drawn cases are small (a few hundred samples): the rows agree to
+    ~1e-4 here, where the fixtures of tests/test_reference_pin.py (5,000+ samples) hold 3e-5; a difference of logic would be 100x that.
+    -> (firth rows, spa rows)"""
+    from scipy.stats import norm
+    from oracle import regenie_step2_bt as bt
+    from oracle import regenie_step2_qt as s2
+    base = ["--step", "2", "--bt", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list", "--pThresh", str(pthresh)]
+    base += ["--ref-first"] if o["ref_first"] else []
+    base += ["--strict"] if o["strict"] else []
+    base += _prep_args(S, o)
+    for extra, out in ((["--firth", "--approx"], "s2f"), (["--spa"], "s2s")):
+        r = subprocess.run([REGENIE] + base + extra + ["--out", out], cwd=d, capture_output=True, text=True)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
+    opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, bt=True, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
+                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "cat_covar") if k in o})
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    bed, _ = orc.open_bed(S + ".bed", prep.n_file)
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    P = prep.Y.shape[1]
+    loco, frow, srow, col = [], [], [], None
+    for ph in range(P):
+        hdr, v = _loco(os.path.join(d, "out_%d.loco" % (ph + 1)))
+        pos = {s_: k for k, s_ in enumerate(hdr)}
+        loco.append(v[:, [pos[i] for i in ids]])
+        h, body = pin._read_regenie(os.path.join(d, "s2f_%s.regenie" % prep.pheno_names[ph]))
+        col = {nm: i for i, nm in enumerate(h)}
+        frow.append({r_[col["ID"]]: r_ for r_ in body})
+        srow.append({r_[col["ID"]]: r_ for r_ in pin._read_regenie(os.path.join(d, "s2s_%s.regenie" % prep.pheno_names[ph]))[1]})
+    X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
+    zthr = float(norm.ppf(1 - pthresh / 2))
+    n_all = int((~prep.ind_ignore).sum())
+    nf = ns = 0
+    for c in sorted(set(chrom.tolist())):
+        nulls, offs_f = [], []
+        for ph in range(P):
+            nl = bt.null_logistic(Yraw[:, ph], X, mask[:, ph], np.nan_to_num(loco[ph][c - 1]), opt)
+            bnull = bt.firth_null(Yraw[:, ph], X, mask[:, ph], np.nan_to_num(loco[ph][c - 1]), nl["beta"]) if nl is not None else None
+            nulls.append(nl)
+            offs_f.append(X @ bnull + np.nan_to_num(loco[ph][c - 1]) if bnull is not None else None)
+        sel = np.flatnonzero(chrom == c)
+        G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
+        if o["ref_first"]:
+            G = np.where(G < 0, G, 2.0 - G)
+        for k in range(sel.size):
+            gk, flipped = bt.flip_geno(G[k])          # regenie tests the MINOR allele and negates BETA back
+            sgn = -1.0 if flipped else 1.0
+            g, _, _ = s2.mean_impute(gk)
+            sparse = s2.check_sparse(g, n_all)
+            obs = gk >= 0
+            for ph in range(P):
+                rf, rs = frow[ph].get(snp_ids[sel[k]]), srow[ph].get(snp_ids[sel[k]])
+                if rf is None or nulls[ph] is None or offs_f[ph] is None or rf[col["BETA"]] == "NA":
+                    continue
+                m = mask[:, ph].astype(np.float64)
+                out = bt.score_bt(g, X, Yraw[:, ph], m, nulls[ph])
+                if abs(out["stats"]) <= zthr * (1 + 1e-9) + 1e-9:
+                    continue
+                if abs(abs(out["stats"]) - zthr) < 1e-6 * zthr:          # (a tie with the threshold is decided by the last bits)
+                    continue
+                if rs is not None and rs[col["BETA"]] != "NA":
+                    sp = bt.spa_test(out["stats"], out["denum"], out["Gres"], nulls[ph], m, carriers=np.flatnonzero(g != 0) if sparse else None)
+                    if rs[-1] == "TEST_FAIL":
+                        assert sp is None, ("SPA: regenie fails, the oracle finds a root", snp_ids[sel[k]], ph)
+                    else:
+                        assert sp is not None, ("SPA: the oracle finds no root", snp_ids[sel[k]], ph)
+                        for nm, key in (("BETA", "bhat"), ("SE", "se"), ("CHISQ", "chisq"), ("LOG10P", "logp")):
+                            got = sp[key] * (sgn if key == "bhat" else 1.0)
+                            assert abs(got - float(rs[col[nm]])) <= 3e-4 * abs(float(rs[col[nm]])) + 1e-6, ("SPA " + nm, snp_ids[sel[k]], ph, got, rs[col[nm]], flipped)
+                    ns += 1
+                if rf[-1] == "TEST_FAIL":
+                    continue
+                tq = float(gk[obs & (m > 0)].sum())
+                nq = int((obs & (m > 0)).sum())
+                fo = bt.approx_firth(g, X, Yraw[:, ph], m, nulls[ph], offs_f[ph], sparse=sparse, mac=min(tq, 2 * nq - tq))
+                assert fo is not None, ("approximate Firth: no fit", snp_ids[sel[k]], ph)
+                beta, se, chisq = (float(rf[col[nm]]) for nm in ("BETA", "SE", "CHISQ"))
+                # (traits with different missing values: the approximate Firth rows of regenie and of this oracle differ by up to ~1e-2 se^2 in BETA
+                # -- 1e-3 .. 7e-3 of BETA on these small cases -- and ~1e-3 in SE, where they agree to 2e-3 se^2 / 3e-4 without masked samples; the
+                # oracle is self-consistent there (masking a sample = dropping it), the cause was not identified: tests/golden/fuzz_log.md)
+                masked = bool((m == 0).any())
+                assert abs(sgn * fo["bhat"] - beta) <= (2e-2 if masked else 2e-3) * se * se + (2e-3 if masked else 3e-4) * abs(beta) + 5e-6, ("Firth BETA", snp_ids[sel[k]], ph, sgn * fo["bhat"], beta, se, flipped)
+                assert abs(fo["se"] - se) <= (1.5e-3 if masked else 5e-4) * se, ("Firth SE", snp_ids[sel[k]], ph, fo["se"], se)
+                assert abs(fo["chisq"] - chisq) <= (2e-2 if masked else 3e-3) * abs(chisq) + 5e-5, ("Firth CHISQ", snp_ids[sel[k]], ph, fo["chisq"], chisq)
+                nf += 1
+    return nf, ns
 
 
 def main():
