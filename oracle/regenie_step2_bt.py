@@ -108,20 +108,29 @@ def _pvec(eta):
 def firth_null(y_raw, X, mask, offset, beta_start, maxit=2000):
     """fit_approx_firth_null / fit_firth_nr with every column free (Step2_Models.cpp:899-984, :1267-1385): maximise
     l(beta) + 0.5 log |X^T W X| over the covariate effects, the LOCO prediction as offset.  Modified score X^T (y - p + h (0.5 - p)),
-    h = diag of the hat matrix of W^(1/2) X.  Returns beta (None if it does not converge)."""
+    h = diag of the hat matrix of W^(1/2) X.  Returns beta (None if it does not converge).
+
+    A sample that is masked for the trait (analysed, its phenotype missing for THIS trait) is not in the likelihood and not in the
+    score -- but it IS in X^T W X, with weight 1: get_wvec returns `mask.select(p (1 - p), 1)` (Step1_Models.cpp:1809-1811) and
+    fit_firth_nr builds X^T W X from that vector without applying the mask (:1287-1290, :1325-1328), so the penalty, the hat diagonal and
+    the Newton matrix see the masked rows of X.  regenie's own single-trait run of the same trait (the samples dropped instead of masked)
+    gives the masked-out value; its multi-trait run gives this one (1.2e-3 apart in the approximate Firth BETA of a drawn case with 16 of
+    284 samples masked: tests/golden/fuzz_log.md).  The reference is the multi-trait program, so this follows it."""
     m = mask.astype(bool)
-    Xm, ym, om = X[m], y_raw[m], offset[m]          # only the unmasked samples enter (offset may be NA elsewhere)
+    Xm, ym, om = X[m], y_raw[m], np.nan_to_num(offset)[m]
+    Xout = X[~m]                                       # rows that only enter X^T W X (weight 1)
+    extra = Xout.T @ Xout
 
     def pen_dev(b):
         p = _pvec(om + Xm @ b)
         w = p * (1 - p)
-        sign, logdet = np.linalg.slogdet(Xm.T @ (Xm * w[:, None]))
+        sign, logdet = np.linalg.slogdet(Xm.T @ (Xm * w[:, None]) + extra)
         return -2.0 * float(np.sum(np.where(ym == 0, np.log(1 - p), np.log(p)))) - logdet, p, w
 
     beta = np.array(beta_start, dtype=np.float64)
     dev, p, w = pen_dev(beta)
     for _ in range(maxit):
-        XtWX = Xm.T @ (Xm * w[:, None])
+        XtWX = Xm.T @ (Xm * w[:, None]) + extra
         U = Xm * np.sqrt(w)[:, None]
         h = np.einsum("ij,ij->i", U @ np.linalg.inv(XtWX), U)
         score = Xm.T @ (ym - p + h * (0.5 - p))
@@ -227,17 +236,18 @@ def firth_fit(y_raw, X, mask, offset, beta_start, nfree, maxstep=25.0, maxit=200
     (beta, penalised deviance, (X^T W X)^-1) or None."""
     m = mask.astype(bool)
     Xm, ym, om = X[m], y_raw[m], offset[m]
+    extra = X[~m].T @ X[~m]                            # the masked rows enter X^T W X with weight 1 (see firth_null)
 
     def pen_dev(b):
         p = _pvec(om + Xm @ b)
         w = p * (1 - p)
-        sign, logdet = np.linalg.slogdet(Xm.T @ (Xm * w[:, None]))
+        sign, logdet = np.linalg.slogdet(Xm.T @ (Xm * w[:, None]) + extra)
         return -2.0 * float(np.sum(np.where(ym == 0, np.log(1 - p), np.log(p)))) - logdet, p, w
 
     beta = np.array(beta_start, dtype=np.float64)
     dev, p, w = pen_dev(beta)
     for _ in range(maxit):
-        XtWX = Xm.T @ (Xm * w[:, None])
+        XtWX = Xm.T @ (Xm * w[:, None]) + extra
         inv = np.linalg.inv(XtWX)
         U = Xm * np.sqrt(w)[:, None]
         h = np.einsum("ij,ij->i", U @ inv, U)

@@ -449,9 +449,17 @@ bool firth_fit_cols(const double* y, const std::vector<const double*>& cols, con
                     std::vector<double>& beta, double* dev_out, std::vector<double>* inv_out) {
   const int K = (int)cols.size();
   std::vector<double> pv(n), w(n), A((size_t)K * K), Ainv, Afree((size_t)nfree * nfree), Afinv, score(nfree), step(K, 0.0), bnew(K), hx(K);
+  // A sample masked for the trait is in neither the likelihood nor the score -- but it IS in X^T W X, with weight 1: the reference's get_wvec
+  // returns mask.select(p (1 - p), 1) (Step1_Models.cpp:1809-1811) and fit_firth_nr builds X^T W X from it without the mask (:1287-1290,
+  // :1325-1328), so penalty, hat diagonal and Newton matrix see the masked rows.  regenie's single-trait run of the same trait (the samples
+  // dropped) gives the other value; its multi-trait run is the reference of a multi-trait run (found by tests/golden/fuzz_oracle_vs_reference.py).
+  std::vector<double> Amasked((size_t)K * K, 0.0);
+  for (int64_t i = 0; i < n; ++i)
+    if (!mask[i])
+      for (int a = 0; a < K; ++a) { const double xa = cols[a][i]; for (int c = 0; c <= a; ++c) Amasked[(size_t)a * K + c] += xa * cols[c][i]; }
   auto pen_dev = [&](const std::vector<double>& b, double& dev) {
     double ll = 0.0;
-    std::fill(A.begin(), A.end(), 0.0);
+    A = Amasked;
     for (int64_t i = 0; i < n; ++i) {
       if (!mask[i]) continue;
       double e = offset[i];
