@@ -119,7 +119,7 @@ def run(N=500000, M=100000, MREF=2000, P=10, C=10, bsizes=(400, 1000), ref_threa
             variants.append(("bsize %d %s" % (bsizes[0], extra), bsizes[0], dict(kv.split("=") for kv in extra.split(","))))
     for name, bsz, env in variants:
         t0 = time.time()
-        r = subprocess.run([exe] + common + ["--bgen", D + "/x.bgen", "--bsize", str(bsz), "--out", D + "/s2"], capture_output=True, text=True,
+        r = subprocess.run([exe] + common + ["--bgen", D + "/x.bgen", "--bsize", str(bsz), "--out", D + "/s2"] + os.environ.get("BGEN_E2E_ARGS", "").split(), capture_output=True, text=True,
                            env=dict(os.environ, RG_TIMING="1", **env))
         dt = time.time() - t0
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -147,7 +147,8 @@ def run(N=500000, M=100000, MREF=2000, P=10, C=10, bsizes=(400, 1000), ref_threa
             % (name, dt, M / dt, M * N * P / dt, " | ".join(marks)))
     # the bounded sample: both programs, line by line
     t0 = time.time()
-    r = subprocess.run([exe] + common + ["--bgen", D + "/r.bgen", "--bsize", str(bsizes[0]), "--out", D + "/r_amd"], capture_output=True, text=True)
+    r = subprocess.run([exe] + common + ["--bgen", D + "/r.bgen", "--bsize", str(bsizes[0]), "--out", D + "/r_amd"] + os.environ.get("BGEN_E2E_ARGS", "").split(),      # e.g. "--gpus 8"
+                       capture_output=True, text=True)
     t_amd = time.time() - t0
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     if os.path.exists(ref):

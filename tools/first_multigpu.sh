@@ -42,3 +42,17 @@ for n in 1 2 4 $N; do
   else python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus $n --steps 2 --warmup 1 > $O/bench_$n.json 2> $O/bench_$n.err; fi
   tail -1 $O/bench_$n.json | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['n_gpus'], 'GPUs', round(d['ms_per_step'],1), 'ms/step', '%.3e' % d['value'], d['config']['parallelism'])"
 done
+echo "== 4. round 5's entry points on several devices: --step 1 --loocv (the tridiagonal level 0) and --step 2 --bgen (one device decoder per part)"
+python - <<PY 2>&1 | tee $O/round5.log
+import filecmp, os, subprocess
+exe = os.path.abspath("regenie_amd/bin/regenie-amd")
+d = "/tmp/e2e"
+base = [exe, "--step", "1", "--bed", d + "/x", "--phenoFile", d + "/x.pheno", "--covarFile", d + "/x.covar", "--bsize", "1000", "--loocv"]
+subprocess.run(base + ["--out", d + "/loo1"], check=True, capture_output=True)
+for n in (2, $N):
+    r = subprocess.run(base + ["--gpus", str(n), "--out", d + "/loon"], capture_output=True, text=True)
+    print("loocv gpus %d rc %d identical %s" % (n, r.returncode, r.returncode == 0 and filecmp.cmp(d + "/loo1_1.loco", d + "/loon_1.loco", shallow=False)))
+PY
+# the BGEN Step 2 of tools/bgen_e2e.py on N devices (contiguous block ranges per GPU, one decoder each, part files concatenated in block order); its bounded sample
+# is compared line by line with regenie itself
+BGEN_E2E_NCHR=4 BGEN_E2E_ARGS="--gpus $N" python tools/bgen_e2e.py 500000 36864 1024 2>&1 | grep "regenie-amd --step 2\|bounded sample" | cut -c1-300 | tee -a $O/round5.log
