@@ -666,3 +666,40 @@ def test_oracle_against_live_reference_on_drawn_cases(tmp_path):
     for seed in (1, 2, 3, 4, 6):          # QT leave-one-out, BT leave-one-out, QT K-fold, BT K-fold, --ref-first
         line, ok = fz.run_one(seed, str(tmp_path))
         assert ok, line
+
+
+def test_null_firth_estimates_against_reference_files(tmp_path):
+    """--write-null-firth of regenie on the bt_kfold_synth case (tests/golden/ref_outputs/bt_kfold_synth/out_k.firth.gz: per chromosome the covariate
+    estimates of the null Firth model with that chromosome's LOCO prediction as offset; three traits with 100 - 121 of 5,200 samples masked): the
+    oracle's firth_null within 1e-4 -- which it is only with regenie's treatment of the masked samples (weight 1 in X^T W X: get_wvec,
+    Step1_Models.cpp:1809-1811; fit_firth_nr, Step2_Models.cpp:1287-1290); leaving their rows out is 9e-4 away on the second trait."""
+    import json
+    from oracle import regenie_step2_bt as bt
+    from tests.util import synth_dosages, write_plink
+    meta = json.load(open(os.path.join(REF_OUT, "bt_kfold_synth", "meta.json")))
+    spec = meta["synthetic"]
+    S = str(tmp_path / "synth")
+    write_plink(S, synth_dosages(spec["M"], spec["N"], miss_rate=spec.get("miss_rate", 0.0), seed=spec["seed"]), spec["chroms"], P=spec["P"],
+                seed=spec["seed"], binary=spec["binary"], missing_pheno=spec["missing_pheno"])
+    opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=100, bt=True, test_mode=True)
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
+    without = 0.0
+    for ph in range(prep.Y.shape[1]):
+        hdr, v = read_loco_gz(os.path.join(REF_OUT, "bt_kfold_synth", "out_%d.loco.gz" % (ph + 1)))
+        pos = {s: k for k, s in enumerate(hdr)}
+        loco = np.nan_to_num(v[:, [pos[i] for i in ids]])
+        rows = [ln.split() for ln in gzip.open(os.path.join(REF_OUT, "bt_kfold_synth", "out_%d.firth.gz" % (ph + 1)), "rt").read().splitlines()]
+        m = mask[:, ph]
+        assert (~m).sum() >= 100
+        for row in rows[:2]:
+            c, want = int(row[0]), np.array([float(t) for t in row[1:]])
+            nl = bt.null_logistic(Yraw[:, ph], X, m, loco[c - 1], opt)
+            got = bt.firth_null(Yraw[:, ph], X, m, loco[c - 1], nl["beta"])
+            sign = np.sign(got * want)                                  # the basis columns are defined up to sign
+            assert np.max(np.abs(got * sign - want) / np.abs(want)) < 1e-4, (ph, c)
+            alone = bt.firth_null(Yraw[m, ph], X[m], np.ones(int(m.sum()), bool), loco[c - 1][m], nl["beta"])
+            without = max(without, float(np.max(np.abs(alone * np.sign(alone * want) - want) / np.abs(want))))
+    assert without > 5e-4
