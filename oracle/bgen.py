@@ -76,7 +76,7 @@ class BgenOracle:
             self.variants.append(dict(offset=start, data=pos, id=fields[0], rsid=fields[1], chrom=fields[2], pos=bp, a0=al[0], a1=al[1]))
             pos += 4 + c
 
-    def dosages(self, j: int, ref_first: bool = False) -> np.ndarray:
+    def dosages(self, j: int, ref_first: bool = False, want_info: bool = False):
         """readChunkFromBGENFileToG_fast (Geno.cpp:1600-1690): G = prob1 + 2 prob0 (prob1 + 2 prob2 with --ref-first)."""
         d, v = self.data, self.variants[j]
         (c,) = struct.unpack_from("<I", d, v["data"])
@@ -99,6 +99,9 @@ class BgenOracle:
         p0, p1 = pr[:, 0], pr[:, 1]
         p2 = np.maximum(1 - p0 - p1, 0.0)
         g = p1 + 2 * p2 if ref_first else p1 + 2 * p0
+        if want_info:      # the sample's term of the IMPUTE info score's numerator: E[g^2] - E[g]^2 (parseSnpfromBGEN, Geno.cpp:2286-2300)
+            e = (4 * p2 + p1 if ref_first else 4 * p0 + p1) - g * g
+            return np.where(ploidy & 0x80, -3.0, g), np.where(ploidy & 0x80, 0.0, e)
         return np.where(ploidy & 0x80, -3.0, g)
 
 

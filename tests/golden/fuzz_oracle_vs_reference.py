@@ -239,6 +239,8 @@ def run_one(seed, work):
     extra = ""
     if not o["bt"] and not o.get("ct"):
         extra = ", step 2: %d statistics" % step2_qt_leg(d, S, o)
+        if os.environ.get("FUZZ_BGEN"):
+            extra += ", bgen: %d rows" % step2_qt_bgen_leg(d, S, g, spec, o)
     elif o["bt"] and os.environ.get("FUZZ_BT_STEP2"):
         extra = ", step 2 (score test): %d statistics" % step2_bt_leg(d, S, o)
         if os.environ["FUZZ_BT_STEP2"] == "2":
@@ -373,6 +375,71 @@ def run_t2e(seed, d, S, g, spec, o):
         assert wd < 1e-5, "driver .loco (t2e): %.2e" % wd
         extra = " | driver: loco %.1e (%d/%d files byte-identical)" % (wd, same, nt)
     return desc + " | ok: loco max rel err %.1e, regenie %.1f s, oracle %.1f s%s" % (worst, t_ref, t_or, extra), True
+
+
+def step2_qt_bgen_leg(d, S, g, spec, o):
+    """The quantitative cases on BGEN input (8-bit probabilities, 40 % of the calls smeared into genuine probabilities): regenie --step 2 --qt
+    --bgen with its own predictions against the oracle on the dosages -- BETA / SE / CHISQ / LOG10P and the per-trait A1FREQ, INFO (IMPUTE) and N
+    columns (parseSnpfromBGEN, Geno.cpp:2186-2330; update_trait_counts; compute_aaf_info :3110-3146)."""
+    from oracle import bgen as obg
+    from oracle import regenie_step2_qt as s2
+    from tests.util import write_synth_bgen
+    write_synth_bgen(S, g, spec["chroms"], seed=spec["seed"])
+    args = ["--step", "2", "--qt", "--bgen", S + ".bgen", "--sample", S + ".sample", "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list"]
+    args += ["--ref-first"] if o["ref_first"] else []
+    args += ["--strict"] if o["strict"] else []
+    args += _prep_args(S, o)
+    r = subprocess.run([REGENIE] + args + ["--out", "sb"], cwd=d, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
+    opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
+                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "apply_rint", "cat_covar") if k in o})
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    P = prep.Y.shape[1]
+    loco, rows, col = [], [], None
+    for ph in range(P):
+        hdr, v = _loco(os.path.join(d, "out_%d.loco" % (ph + 1)))
+        pos = {s_: k for k, s_ in enumerate(hdr)}
+        loco.append(np.nan_to_num(v[:, [pos[i] for i in ids]]))
+        h, body = pin._read_regenie(os.path.join(d, "sb_%s.regenie" % prep.pheno_names[ph]))
+        col = {nm: i for i, nm in enumerate(h)}
+        rows.append({r_[col["ID"]]: r_ for r_ in body})
+    X, Y, mask = prep.X[ia], prep.Y[ia], prep.mask[ia].astype(np.float64)
+    bg = obg.BgenOracle(S + ".bgen")
+    vidx = {v["rsid"]: k for k, v in enumerate(bg.variants)}
+    keep = ~prep.ind_ignore
+    ncmp = 0
+    for c in sorted(set(chrom.tolist())):
+        blup = np.stack([loco[ph][c - 1] for ph in range(P)], axis=1)
+        res, _, scf = s2.compute_res(Y, blup * mask, mask, prep.Neff, X.shape[1], prep.scale_Y)
+        sel = np.flatnonzero(chrom == c)
+        GI = [bg.dosages(vidx[snp_ids[k]], o["ref_first"], want_info=True) for k in sel]
+        G = np.stack([gi[0][keep][ia] for gi in GI])
+        E = np.stack([gi[1][keep][ia] for gi in GI])
+        out = s2.score_qt_block_ref(G, X, res, mask, scf, n_samples=int(keep.sum()))
+        for k in range(sel.size):
+            obs = G[k] >= 0
+            for ph in range(P):
+                r_ = rows[ph].get(snp_ids[sel[k]])
+                if r_ is None or r_[col["A1FREQ"]] == "NA":      # (a test regenie ignores for the trait, e.g. minimum MAC: the row is all NA)
+                    continue
+                use = obs & (mask[:, ph] > 0)
+                ns, tot = int(use.sum()), float(G[k][use].sum())
+                af = tot / (2 * ns)
+                info = 1.0 if af in (0.0, 1.0) else 1 - float(E[k][use].sum()) / (2 * ns * af * (1 - af))
+                assert int(r_[col["N"]]) == ns, ("N", snp_ids[sel[k]], ph, ns, r_[col["N"]])
+                assert abs(af - float(r_[col["A1FREQ"]])) <= 1e-5 * max(af, 1e-3), ("A1FREQ", snp_ids[sel[k]], ph, af, r_[col["A1FREQ"]])
+                assert abs(info - float(r_[col["INFO"]])) <= 2e-5 * max(abs(info), 1e-2), ("INFO", snp_ids[sel[k]], ph, info, r_[col["INFO"]])
+                if r_[col["BETA"]] == "NA":
+                    continue
+                beta, se, chisq, logp = (float(r_[col[nm]]) for nm in ("BETA", "SE", "CHISQ", "LOG10P"))
+                assert abs(out["bhat"][k, ph] - beta) <= 5e-5 * abs(beta) + 2e-6, ("BETA", snp_ids[sel[k]], ph, out["bhat"][k, ph], beta)
+                assert abs(out["se"][k, ph] - se) <= 5e-5 * abs(se), ("SE", snp_ids[sel[k]], ph, out["se"][k, ph], se)
+                assert abs(out["chisq"][k, ph] - chisq) <= 1e-4 * abs(chisq) + 2e-6, ("CHISQ", snp_ids[sel[k]], ph, out["chisq"][k, ph], chisq)
+                ncmp += 1
+    assert ncmp > 0
+    return ncmp
 
 
 def step2_bt_leg(d, S, o):
