@@ -905,8 +905,9 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
             }
             const double logp = logp_spa >= 0 ? logp_spa : get_logp(chisq);       // --spa prints the p-value it computed, the chi-square is derived from it
             std::ostringstream ln;
-            ln << head.str() << af << " ";
-            if (show_info) ln << info << " ";
+            if (af >= 0) ln << head.str() << af << " ";            // print_sum_stats_single (Step2_Models.cpp:2505-2518): a negative value is "NA"
+            else ln << head.str() << "NA ";
+            if (show_info) { if (info >= 0) ln << info << " "; else ln << "NA "; }      // (the IMPUTE score of very uncertain dosages can be negative)
             ln << nsq << " ADD ";
             if (se >= 0 && !std::isnan(se)) ln << bh << ' ' << se;
             else ln << "NA NA";
