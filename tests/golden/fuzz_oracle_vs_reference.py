@@ -241,6 +241,8 @@ def run_one(seed, work):
         extra = ", step 2: %d statistics" % step2_qt_leg(d, S, o)
         if os.environ.get("FUZZ_BGEN"):
             extra += ", bgen: %d rows" % step2_qt_bgen_leg(d, S, g, spec, o)
+    if os.environ.get("FUZZ_BGEN") == "2" and not o.get("ct"):
+        extra += ", step 1 from bgen: " + step1_bgen_leg(d, S, g, spec, o, args)
     elif o["bt"] and os.environ.get("FUZZ_BT_STEP2"):
         extra = ", step 2 (score test): %d statistics" % step2_bt_leg(d, S, o)
         if os.environ["FUZZ_BT_STEP2"] == "2":
@@ -375,6 +377,37 @@ def run_t2e(seed, d, S, g, spec, o):
         assert wd < 1e-5, "driver .loco (t2e): %.2e" % wd
         extra = " | driver: loco %.1e (%d/%d files byte-identical)" % (wd, same, nt)
     return desc + " | ok: loco max rel err %.1e, regenie %.1f s, oracle %.1f s%s" % (worst, t_ref, t_or, extra), True
+
+
+def step1_bgen_leg(d, S, g, spec, o, args1):
+    """--step 1 on the case's genotypes as BGEN dosages (readChunkFromBGENFileToG, Geno.cpp:1574-1699: level 0 on doubles): regenie's .loco files
+    against the oracle's run with the dosages of oracle/bgen.py as input; -> files compared"""
+    from oracle import bgen as obg
+    from tests.util import write_synth_bgen
+    if not os.path.exists(S + ".bgen"):
+        write_synth_bgen(S, g, spec["chroms"], seed=spec["seed"])
+    a = [x for x in args1]
+    i = a.index("--bed")
+    a[i:i + 2] = ["--bgen", S + ".bgen", "--sample", S + ".sample"]
+    r = subprocess.run([REGENIE] + a + ["--out", "b1"], cwd=d, capture_output=True, text=True)
+    if r.returncode != 0:
+        return "regenie stopped: " + (r.stdout + r.stderr).strip().splitlines()[-1][:120]
+    bg = obg.BgenOracle(S + ".bgen")
+    rf = o["ref_first"]
+    res = orc.run_step1(orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar",
+                                         dosage_provider=lambda offs: np.stack([bg.dosages(int(j), rf) for j in offs]), **o))
+    names = [ln.split()[0] for ln in open(os.path.join(d, "b1_pred.list"))]
+    assert names == [res.prep.pheno_names[ph] for ph in range(len(res.loco)) if res.loco[ph] is not None], ("traits with predictions (bgen)", names)
+    n = 0
+    for ph in range(len(res.loco)):
+        if res.loco[ph] is None:
+            continue
+        ids, ref = _loco(os.path.join(d, "b1_%d.loco" % (ph + 1)))
+        gids, got = pin.oracle_loco_rows(res, ph)
+        assert ids == gids
+        pin.assert_text_equal(got, ref, "bgen step 1, pheno %d" % (ph + 1))
+        n += 1
+    return "%d files" % n
 
 
 def step2_qt_bgen_leg(d, S, g, spec, o):
