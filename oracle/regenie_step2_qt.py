@@ -109,11 +109,14 @@ def score_qt_sparse(g, X, res, masked_indivs, scf_sv, YtX):
     return stats, bhat
 
 
-def score_qt_block_ref(G, X, res, masked_indivs, scf_sv, n_samples=None, numtol=NUMTOL, prop_zero_thr=0.5):
+def score_qt_block_ref(G, X, res, masked_indivs, scf_sv, n_samples=None, numtol=NUMTOL, prop_zero_thr=0.5, zero_count_rule=False):
     """compute_tests_mt over one block as the reference runs it for hard calls (Data.cpp:2476-2555): check_sparse_G decides per
     variant between the sparse branch (no residualisation, scale_fac = 1: Data.cpp:2513-2515) and the dense one.  With every
     mask entry 1 the two branches are the same number; they differ when phenotypes differ in their missing values.
-    Extra output: "sparse" [bs]."""
+    zero_count_rule: check_sparse_G's OTHER form, the one .pgen input takes (readChunkFromPGENFileToG counts the exact zeros among the
+    analysed, observed samples while it parses -- Geno.cpp:2581, :2594; its start value, ind_in_analysis.size() - n_samples, is zero -- then
+    is_sparse = n_zero >= n_samples * prop_zero_thr, :3171): a missing call is not a zero there, where the .bed / .bgen form counts the
+    non-zeros AFTER the mean imputation.  Extra output: "sparse" [bs]."""
     bs, P = G.shape[0], res.shape[1]
     n_samples = X.shape[0] if n_samples is None else n_samples
     YtX = res.T @ X                                                    # Data.cpp:2402
@@ -125,7 +128,8 @@ def score_qt_block_ref(G, X, res, masked_indivs, scf_sv, n_samples=None, numtol=
         if nobs == 0:
             out["ignored"][j], out["scale_fac"][j] = 1, float("nan")
             continue
-        if check_sparse(g, n_samples, prop_zero_thr):
+        sparse = int(np.count_nonzero(G[j] == 0.0)) >= n_samples * prop_zero_thr if zero_count_rule else check_sparse(g, n_samples, prop_zero_thr)
+        if sparse:
             out["sparse"][j], out["scale_fac"][j] = 1, 1.0
             out["stats"][j], out["bhat"][j] = score_qt_sparse(g, X, res, masked_indivs, scf_sv, YtX)
             continue

@@ -241,6 +241,8 @@ def run_one(seed, work):
         extra = ", step 2: %d statistics" % step2_qt_leg(d, S, o)
         if os.environ.get("FUZZ_BGEN"):
             extra += ", bgen: %d rows" % step2_qt_bgen_leg(d, S, g, spec, o)
+    if os.environ.get("FUZZ_PGEN") and not o.get("ct"):
+        extra += ", pgen: " + pgen_legs(d, S, g, spec, o, args)
     if os.environ.get("FUZZ_BGEN") == "2" and not o.get("ct"):
         extra += ", step 1 from bgen: " + step1_bgen_leg(d, S, g, spec, o, args)
     elif o["bt"] and os.environ.get("FUZZ_BT_STEP2"):
@@ -408,6 +410,92 @@ def step1_bgen_leg(d, S, g, spec, o, args1):
         pin.assert_text_equal(got, ref, "bgen step 1, pheno %d" % (ph + 1))
         n += 1
     return "%d files" % n
+
+
+def pgen_legs(d, S, g, spec, o, args1):
+    """The case as a PLINK2 .pgen with a 16-bit dosage track on 40 % of the calls (PgenReader::Read: the ALT dosage, --ref-first does not apply):
+    --step 1 --pgen against the oracle fed by oracle/pgen.py, and for the quantitative cases --step 2 --qt --pgen with its per-trait N, A1FREQ and
+    MaCH-r2 INFO columns (compute_aaf_info, Geno.cpp:3132-3141)."""
+    from oracle import pgen as opg
+    from oracle import regenie_step2_qt as s2
+    from tests.util import write_synth_pgen
+    write_synth_pgen(S + "_p", g, spec["chroms"], seed=spec["seed"], soft=0.4)
+    a = [x for x in args1]
+    i = a.index("--bed")
+    a[i:i + 2] = ["--pgen", S + "_p"]
+    r = subprocess.run([REGENIE] + a + ["--out", "p1"], cwd=d, capture_output=True, text=True)
+    if r.returncode != 0:
+        return "regenie stopped: " + (r.stdout + r.stderr).strip().splitlines()[-1][:120]
+    po = opg.PgenOracle(S + "_p.pgen")
+    res = orc.run_step1(orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar",
+                                         dosage_provider=lambda offs: np.stack([po.dosages(int(j)) for j in offs]), **o))
+    names = [ln.split()[0] for ln in open(os.path.join(d, "p1_pred.list"))]
+    assert names == [res.prep.pheno_names[ph] for ph in range(len(res.loco)) if res.loco[ph] is not None], ("traits with predictions (pgen)", names)
+    nfile = 0
+    for ph in range(len(res.loco)):
+        if res.loco[ph] is None:
+            continue
+        ids, ref = _loco(os.path.join(d, "p1_%d.loco" % (ph + 1)))
+        gids, got = pin.oracle_loco_rows(res, ph)
+        assert ids == gids
+        pin.assert_text_equal(got, ref, "pgen step 1, pheno %d" % (ph + 1))
+        nfile += 1
+    out = "%d files" % nfile
+    if o["bt"] or o.get("ct"):
+        return out
+    args = ["--step", "2", "--qt", "--pgen", S + "_p", "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list"]
+    args += ["--ref-first"] if o["ref_first"] else []
+    args += ["--strict"] if o["strict"] else []
+    args += _prep_args(S, o)
+    r = subprocess.run([REGENIE] + args + ["--out", "sp"], cwd=d, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
+    opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
+                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "apply_rint", "cat_covar") if k in o})
+    bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
+    ia = prep.ind_in_analysis
+    ids = [i for i, k in zip(prep.ids, ia) if k]
+    P = prep.Y.shape[1]
+    loco, rows, col = [], [], None
+    for ph in range(P):
+        hdr, v = _loco(os.path.join(d, "out_%d.loco" % (ph + 1)))
+        pos = {s_: k for k, s_ in enumerate(hdr)}
+        loco.append(np.nan_to_num(v[:, [pos[i] for i in ids]]))
+        h, body = pin._read_regenie(os.path.join(d, "sp_%s.regenie" % prep.pheno_names[ph]))
+        col = {nm: i for i, nm in enumerate(h)}
+        rows.append({r_[col["ID"]]: r_ for r_ in body})
+    X, Y, mask = prep.X[ia], prep.Y[ia], prep.mask[ia].astype(np.float64)
+    keep = ~prep.ind_ignore
+    ncmp = 0
+    for c in sorted(set(chrom.tolist())):
+        blup = np.stack([loco[ph][c - 1] for ph in range(P)], axis=1)
+        res2, _, scf = s2.compute_res(Y, blup * mask, mask, prep.Neff, X.shape[1], prep.scale_Y)
+        sel = np.flatnonzero(chrom == c)
+        G = np.stack([po.dosages(int(offs[k]))[keep][ia] for k in sel])
+        sc = s2.score_qt_block_ref(G, X, res2, mask, scf, n_samples=int(keep.sum()), zero_count_rule=True)
+        for k in range(sel.size):
+            obs = G[k] >= 0
+            for ph in range(P):
+                r_ = rows[ph].get(snp_ids[sel[k]])
+                if r_ is None or r_[col["A1FREQ"]] == "NA":
+                    continue
+                use = obs & (mask[:, ph] > 0)
+                ns, tot = int(use.sum()), float(G[k][use].sum())
+                af = tot / (2 * ns)
+                info = 1.0 if af in (0.0, 1.0) else (float((G[k][use] ** 2).sum()) / ns - 4 * af * af) / (2 * af * (1 - af))
+                assert int(r_[col["N"]]) == ns, ("N (pgen)", snp_ids[sel[k]], ph, ns, r_[col["N"]])
+                assert abs(af - float(r_[col["A1FREQ"]])) <= 1e-5 * max(af, 1e-3), ("A1FREQ (pgen)", snp_ids[sel[k]], ph, af, r_[col["A1FREQ"]])
+                if r_[col["INFO"]] == "NA":
+                    assert info < 0, ("INFO is NA (pgen)", snp_ids[sel[k]], ph, info)
+                else:
+                    assert abs(info - float(r_[col["INFO"]])) <= 2e-5 * max(abs(info), 1e-2), ("INFO (pgen)", snp_ids[sel[k]], ph, info, r_[col["INFO"]])
+                if r_[col["BETA"]] == "NA":
+                    continue
+                beta, se, chisq = (float(r_[col[nm]]) for nm in ("BETA", "SE", "CHISQ"))
+                assert abs(sc["bhat"][k, ph] - beta) <= 5e-5 * abs(beta) + 2e-6, ("BETA (pgen)", snp_ids[sel[k]], ph, sc["bhat"][k, ph], beta)
+                assert abs(sc["se"][k, ph] - se) <= 5e-5 * abs(se), ("SE (pgen)", snp_ids[sel[k]], ph)
+                assert abs(sc["chisq"][k, ph] - chisq) <= 1e-4 * abs(chisq) + 2e-6, ("CHISQ (pgen)", snp_ids[sel[k]], ph)
+                ncmp += 1
+    return out + ", %d step-2 rows" % ncmp
 
 
 def step2_qt_bgen_leg(d, S, g, spec, o):
