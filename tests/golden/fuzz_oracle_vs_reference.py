@@ -10,7 +10,11 @@ LOCO predictions, and oracle/regenie_step2_qt.py (score_qt_block_ref: the sparse
 CHISQ / LOG10P of its .regenie files.  Usage:  python tests/golden/fuzz_oracle_vs_reference.py [first_seed=1] [count=40] [log.md]
 A line per case goes to stdout (and to the log file); a mismatch is printed with its arguments and the script exits 1 at the end.
 FUZZ_DRIVER=1 (GPU box): the PRODUCT runs beside them -- `regenie-amd --step 1` and `--step 2 --qt` with the same arguments -- and its .loco
-files and .regenie lines are held to regenie's (values at the text's resolution; the share of byte-identical lines is reported).
+files and .regenie lines are held to regenie's (values at the text's resolution; the share of byte-identical lines is reported); with FUZZ_BGEN /
+FUZZ_PGEN also on those inputs (driver_same: written in round 5 after the GPU budget was spent -- exercised with regenie standing in for the
+driver, first real run due in the next round:  FUZZ_DRIVER=1 FUZZ_BGEN=2 FUZZ_PGEN=1 FUZZ_PREP=2 python tests/golden/fuzz_oracle_vs_reference.py 1 100).
+Other switches: FUZZ_PREP=1|2 (host-preparation options), FUZZ_ROUTES=ct_kfold,ct_loocv,t2e_kfold,... (routes to cycle through), FUZZ_BT_STEP2=1|2
+(the binary score test / its Firth and saddlepoint corrections), FUZZ_BGEN=1|2, FUZZ_PGEN=1.
 FUZZ_BUDGET_S=t stops drawing new cases after t seconds."""
 import os
 import subprocess
@@ -36,6 +40,44 @@ BIN = os.path.join(ROOT, "regenie_amd", "bin", "regenie-amd")
 def _loco(path):
     lines = open(path).read().splitlines()
     return lines[0].split()[1:], np.array([[np.nan if t == "NA" else float(t) for t in ln.split()[1:]] for ln in lines[1:]])
+
+
+def driver_same(d, args, ref, kind):
+    """FUZZ_DRIVER on another input format: `regenie-amd` with the arguments regenie just ran with (outputs `ref`_*), its files held to regenie's --
+    .loco files within 1e-5 of the largest value (kind "step1"), .regenie lines equal or within 2e-5 per number (kind "step2").  -> text"""
+    if not os.environ.get("FUZZ_DRIVER"):
+        return ""
+    drv = "d" + ref
+    r = subprocess.run([BIN] + args + ["--out", drv], cwd=d, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "regenie-amd (%s): " % ref + (r.stdout + r.stderr)[-500:]
+    names = [ln.split()[0] for ln in open(os.path.join(d, ref + "_pred.list"))] if kind == "step1" else None
+    if kind == "step1":
+        assert [ln.split()[0] for ln in open(os.path.join(d, drv + "_pred.list"))] == names
+        same = 0
+        listed = [os.path.basename(ln.split()[1]) for ln in open(os.path.join(d, ref + "_pred.list"))]
+        for fn in listed:
+            ids_r, a = _loco(os.path.join(d, fn))
+            ids_g, b = _loco(os.path.join(d, "d" + fn))
+            assert ids_r == ids_g and np.array_equal(np.isnan(a), np.isnan(b))
+            ok = ~np.isnan(a)
+            assert float(np.max(np.abs(a[ok] - b[ok])) / np.max(np.abs(a[ok]))) < 1e-5, "driver .loco (%s)" % ref
+            same += open(os.path.join(d, fn)).read() == open(os.path.join(d, "d" + fn)).read()
+        return " [driver: %d/%d files byte-identical]" % (same, len(listed))
+    same = tot = 0
+    for fn in sorted(f for f in os.listdir(d) if f.startswith(ref + "_") and f.endswith(".regenie")):
+        a = open(os.path.join(d, "d" + fn)).read().splitlines()
+        b = open(os.path.join(d, fn)).read().splitlines()
+        assert a[0] == b[0] and len(a) == len(b), "driver .regenie header / line count (%s)" % ref
+        for x, y in zip(a[1:], b[1:]):
+            tot += 1
+            if x == y:
+                same += 1
+                continue
+            tx, ty = x.split(" "), y.split(" ")
+            assert len(tx) == len(ty) and tx[:5] == ty[:5], (x, y)
+            for u, v in zip(tx[5:], ty[5:]):
+                assert u == v or (u != "NA" and v != "NA" and abs(float(u) - float(v)) <= 2e-5 * abs(float(v)) + 2e-9), (x, y)
+    return " [driver: %d/%d lines byte-identical]" % (same, tot)
 
 
 def driver_legs(d, args1, o, P):
@@ -240,7 +282,7 @@ def run_one(seed, work):
     if not o["bt"] and not o.get("ct"):
         extra = ", step 2: %d statistics" % step2_qt_leg(d, S, o)
         if os.environ.get("FUZZ_BGEN"):
-            extra += ", bgen: %d rows" % step2_qt_bgen_leg(d, S, g, spec, o)
+            extra += ", bgen: %s rows" % step2_qt_bgen_leg(d, S, g, spec, o)
     if os.environ.get("FUZZ_PGEN") and not o.get("ct"):
         extra += ", pgen: " + pgen_legs(d, S, g, spec, o, args)
     if os.environ.get("FUZZ_BGEN") == "2" and not o.get("ct"):
@@ -409,7 +451,7 @@ def step1_bgen_leg(d, S, g, spec, o, args1):
         assert ids == gids
         pin.assert_text_equal(got, ref, "bgen step 1, pheno %d" % (ph + 1))
         n += 1
-    return "%d files" % n
+    return "%d files" % n + driver_same(d, a, "b1", "step1")
 
 
 def pgen_legs(d, S, g, spec, o, args1):
@@ -440,7 +482,7 @@ def pgen_legs(d, S, g, spec, o, args1):
         assert ids == gids
         pin.assert_text_equal(got, ref, "pgen step 1, pheno %d" % (ph + 1))
         nfile += 1
-    out = "%d files" % nfile
+    out = "%d files" % nfile + driver_same(d, a, "p1", "step1")
     if o["bt"] or o.get("ct"):
         return out
     args = ["--step", "2", "--qt", "--pgen", S + "_p", "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list"]
@@ -495,7 +537,7 @@ def pgen_legs(d, S, g, spec, o, args1):
                 assert abs(sc["se"][k, ph] - se) <= 5e-5 * abs(se), ("SE (pgen)", snp_ids[sel[k]], ph)
                 assert abs(sc["chisq"][k, ph] - chisq) <= 1e-4 * abs(chisq) + 2e-6, ("CHISQ (pgen)", snp_ids[sel[k]], ph)
                 ncmp += 1
-    return out + ", %d step-2 rows" % ncmp
+    return out + ", %d step-2 rows" % ncmp + driver_same(d, args, "sp", "step2")
 
 
 def step2_qt_bgen_leg(d, S, g, spec, o):
@@ -563,7 +605,7 @@ def step2_qt_bgen_leg(d, S, g, spec, o):
                 assert abs(out["chisq"][k, ph] - chisq) <= 1e-4 * abs(chisq) + 2e-6, ("CHISQ", snp_ids[sel[k]], ph, out["chisq"][k, ph], chisq)
                 ncmp += 1
     assert ncmp > 0
-    return ncmp
+    return str(ncmp) + driver_same(d, args, "sb", "step2")
 
 
 def step2_bt_leg(d, S, o):
