@@ -1421,8 +1421,13 @@ def run_step1(opt: Step1Options, write_files: bool = False, keep_W: bool = True)
     if bt and not use_loocv and prep.n_analyzed < 5000:         # Data.cpp:353-356
         log.append("   -WARNING: Sample size is less than 5,000 so using LOOCV instead of %d-fold CV." % opt.cv_folds)
         use_loocv = True
-    h0 = np.asarray(opt.setl0, np.float64) if opt.setl0 is not None else set_ridge_params(opt.n_ridge_l0)
-    h1 = np.asarray(opt.setl1, np.float64) if opt.setl1 is not None else set_ridge_params(opt.n_ridge_l1)
+    def unit_params(v, name):                                    # get_unit_params (Regenie.cpp:1477-1495): sorted, unique, inside (0, 1)
+        v = np.unique(np.asarray(v, np.float64))
+        if ((v <= 0) | (v >= 1)).any():
+            raise ValueError("must specify values for %s in (0,1)." % name)
+        return v
+    h0 = unit_params(opt.setl0, "--l0") if opt.setl0 is not None else set_ridge_params(opt.n_ridge_l0)
+    h1 = unit_params(opt.setl1, "--l1") if opt.setl1 is not None else set_ridge_params(opt.n_ridge_l1)
     R0 = h0.size
     M = opt.parallel_nGeno if opt.parallel_nGeno is not None else chrom.size
     lam = M * (1 - h0) / h0                                       # Data.cpp:607

@@ -180,7 +180,14 @@ int run(int argc, char** argv) {
   if (p.run_l0 && (B != r.parallel_nBlocks || (int)r.snp_chrom.size() != r.parallel_nSnps))
     throw std::runtime_error("number of blocks/variants in the job's snplist doesn't match the master file.");
   if (p.run_l1) prep_parallel_l1(r, B, (int64_t)r.snp_chrom.size());
-  std::vector<double> h0 = p.setl0, h1 = p.setl1;
+  // --setl0 / --setl1 (get_unit_params, Regenie.cpp:1477-1495): sorted, duplicates removed, every value inside (0, 1)
+  auto unit_params = [](std::vector<double> v, const char* opt) {
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    for (double x : v) if (!(x > 0.0 && x < 1.0)) throw std::runtime_error(std::string("must specify values for ") + opt + " in (0,1).");
+    return v;
+  };
+  std::vector<double> h0 = unit_params(p.setl0, "--l0"), h1 = unit_params(p.setl1, "--l1");
   auto grid = [](int n) {  // set_ridge_params (Regenie.cpp:1497-1508)
     if (n < 2) throw std::runtime_error("number of ridge parameters must be at least 2 (=" + std::to_string(n) + ")");
     std::vector<double> v(n);

@@ -176,6 +176,8 @@ def draw_prep(seed, route):
     if os.environ.get("FUZZ_PREP") == "2":      # the complementary lists, a subset of the phenotype columns, --nb
         pr.update(keep=bool(rng.random() < 0.4), extract=bool(rng.random() < 0.4), phenocol=bool(rng.random() < 0.4), nb=bool(rng.random() < 0.3))
         pr["keep"] = pr["keep"] and not pr["remove"]          # (regenie takes one of --keep / --remove)
+    if os.environ.get("FUZZ_PREP") == "3":      # explicit ridge grids, leave-one-out forced on a binary trait, --print-prs
+        pr.update(setl0=bool(rng.random() < 0.5), setl1=bool(rng.random() < 0.5), force_loocv=bool(route.startswith("bt") and rng.random() < 0.5), prs=bool(rng.random() < 0.4))
     return pr
 
 
@@ -205,6 +207,16 @@ def apply_prep(S, spec, pr):
     if pr.get("nb"):
         nb = int(rng.integers(2, 5))
         args += ["--nb", str(nb)]; kw["n_block"] = nb
+    if pr.get("setl0"):
+        v = np.sort(rng.uniform(0.02, 0.95, int(rng.integers(2, 6))))
+        args += ["--setl0", ",".join("%.4f" % x for x in v)]; kw["setl0"] = [float("%.4f" % x) for x in v]
+    if pr.get("setl1"):
+        v = np.sort(rng.uniform(0.02, 0.95, int(rng.integers(2, 6))))
+        args += ["--setl1", ",".join("%.4f" % x for x in v)]; kw["setl1"] = [float("%.4f" % x) for x in v]
+    if pr.get("force_loocv"):
+        args += ["--loocv"]; kw["loocv"] = True
+    if pr.get("prs"):
+        args += ["--print-prs"]; kw["print_prs"] = True
     if pr["rint"]:
         args += ["--apply-rint"]; kw["apply_rint"] = True
     if pr["cat"]:
@@ -239,7 +251,7 @@ def run_one(seed, work):
         pa, pk = apply_prep(S, spec, pr)
         args += pa
         o = dict(o, **pk)
-        prep_desc = "".join(" " + k for k in ("remove", "exclude", "rint", "keep", "extract", "phenocol", "nb") if pr.get(k)) + (" cat%d" % pr["levels"] if pr["cat"] else "")
+        prep_desc = "".join(" " + k for k in ("remove", "exclude", "rint", "keep", "extract", "phenocol", "nb", "setl0", "setl1", "force_loocv", "prs") if pr.get(k)) + (" cat%d" % pr["levels"] if pr["cat"] else "")
     t0 = time.time()
     r = subprocess.run([REGENIE] + args + ["--out", "out"], cwd=d, capture_output=True, text=True)
     t_ref = time.time() - t0

@@ -138,3 +138,14 @@ def test_step2_reads_inputs_then_needs_a_gpu(example_dir, tmp_path):
     open(str(tmp_path / "bad.list"), "w").write("Y1 %s\nY2 %s\n" % (str(tmp_path / "nope.loco"), str(tmp_path / "ref_2.loco")))
     r = subprocess.run([BIN] + args[:-4] + ["--pred", str(tmp_path / "bad.list"), "--out", "s3"], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "nope.loco" in r.stdout
+
+
+def test_user_ridge_grids_are_checked_like_the_reference(example_dir, tmp_path):
+    """--setl0 / --setl1 (get_unit_params, Regenie.cpp:1477-1495): values outside (0, 1) stop the run with regenie's message before any device is touched.
+    (Sorted and de-duplicated as well: a drawn case with `--setl0 0.2334,0.2334,...` gave other numbers than regenie until round 5,
+    tests/golden/fuzz_log.md; that part needs a GPU to show.)"""
+    E = example_dir
+    for opt, name in (("--setl0", "--l0"), ("--setl1", "--l1")):
+        r = subprocess.run([BIN, "--step", "1", "--bed", os.path.join(E, "example"), "--phenoFile", os.path.join(E, "phenotype.txt"), "--covarFile",
+                            os.path.join(E, "covariates.txt"), "--bsize", "100", opt, "0.5,1.5", "--out", str(tmp_path / "o")], capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and ("ERROR: must specify values for %s in (0,1)." % name) in r.stdout + r.stderr
