@@ -389,7 +389,7 @@ def read_pheno_and_cov(opt: Step1Options, fam_ids: List[str]) -> Prepared:
         raise ValueError("all individuals have missing/invalid values for phenotype '%s'." % names[int(np.argmin(nobs))])
     # rm_phenoCols (Pheno.cpp:528-570): drop BT columns with too few cases
     if trait_mode == 1:
-        ncases = ((Yraw == 1) & mask).sum(axis=0)
+        ncases = (Yraw == 1).sum(axis=0)      # `(phenotypes_raw == 1).colwise().count()`: NOT masked -- a row --strict dropped still counts for the traits read before its first missing value
         keepp = ncases >= opt.min_case_count
         if not keepp.all():
             Y, Yraw, mask = Y[:, keepp], Yraw[:, keepp], mask[:, keepp]
@@ -617,10 +617,8 @@ def fit_null_logistic(prep: Prepared, opt: Step1Options) -> None:
         eta = off + prep.X @ beta0
         p = get_pvec(eta)
         ok, beta, p, eta = fit_logistic(y, prep.X, off, mask, p, eta, beta0, opt, True, NUMTOL)
-        if not ok:
-            eta = off + prep.X @ beta0
-            p = get_pvec(eta)
-            ok, beta, p, eta = fit_logistic(y, prep.X, off, mask, p, eta, beta0, opt, False, NUMTOL)
+        if not ok:      # `fit_logistic(.., true, ..) || fit_logistic(.., false, ..)` on the same pivec / etavec / betaold (:88): the second attempt goes on
+            ok, beta, p, eta = fit_logistic(y, prep.X, off, mask, p, eta, beta, opt, False, NUMTOL)      # from the state the first one left
         if not ok:
             prep.pheno_pass[ph] = False
             continue

@@ -38,8 +38,8 @@ def null_logistic(y_raw, X, mask, loco_offset, opt):
     eta = off + X @ beta0
     p = orc.get_pvec(eta)                                               # :80
     ok, beta, p, eta = orc.fit_logistic(y_raw, X, off, mask, p, eta, beta0, opt, True, NUMTOL)
-    if not ok:
-        ok, beta, p, eta = orc.fit_logistic(y_raw, X, off, mask, p, eta, beta0, opt, False, NUMTOL)
+    if not ok:                                                          # (goes on from the state the first attempt left: the arguments are references)
+        ok, beta, p, eta = orc.fit_logistic(y_raw, X, off, mask, p, eta, beta, opt, False, NUMTOL)
     if not ok:
         return None
     w, _ = orc.get_wvec(p, mask)                                        # :129

@@ -305,8 +305,9 @@ bool solve_dense(std::vector<double> A, std::vector<double> b, int n, std::vecto
 double norm_quantile(double p);
 double get_logp(double t);
 bool spd_logdet_inv(const std::vector<double>& A, int n, double& logdet, std::vector<double>* inv);
+struct LogisticState { std::vector<double> beta, pv, eta; };      // what an attempt of fit_logistic leaves for the next one (the reference's in-place arguments)
 bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t N, int C, const Params& prm, bool check_hs_dev, std::vector<double>& eta,
-                  const double* offset = nullptr, std::vector<double>* pv_out = nullptr, std::vector<double>* beta_out = nullptr);
+                  const double* offset = nullptr, std::vector<double>* pv_out = nullptr, std::vector<double>* beta_out = nullptr, LogisticState* resume = nullptr);
 bool fit_poisson(const double* y, const double* X, const uint8_t* mask, int64_t N, int C, const Params& prm, std::vector<double>& eta,
                  const double* offset = nullptr, std::vector<double>* pv_out = nullptr);
 bool cox_null_fit(const double* time, const double* event, const uint8_t* mask, const double* X, int64_t N, int C, const Params& prm, std::vector<double>& eta);

@@ -529,7 +529,8 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
       std::vector<int> keepq;
       for (int q = 0; q < r.P; ++q) {
         int64_t ncases = 0;
-        for (int64_t i = 0; i < N; ++i) ncases += (r.Yraw[(size_t)q * N + i] == 1 && r.mask[(size_t)q * N + i]);
+        for (int64_t i = 0; i < N; ++i) ncases += r.Yraw[(size_t)q * N + i] == 1;      // `(phenotypes_raw == 1).colwise().count()`: the mask is not looked at -- a row that
+                                                                                          // --strict dropped still counts for the traits read before its first missing value
         if (ncases >= p.min_case_count) keepq.push_back(q);
         else sout << "   -WARNING: phenotype '" << r.pheno_names[q] << "' has fewer than " << p.min_case_count << " cases and is dropped\n";
       }
@@ -789,8 +790,9 @@ void read_pheno_cov(Run& r) {  // Pheno.cpp:50-146, :148-364, :573-808, :810-841
     for (int q = 0; q < r.P; ++q) {
       std::vector<double> eta;
       std::vector<double> b0;
-      bool ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, true, eta, nullptr, nullptr, &b0);
-      if (!ok) ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, false, eta, nullptr, nullptr, &b0);
+      LogisticState lst;      // the second attempt goes on from the first one's state, as the reference's in-place arguments make it
+      bool ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, true, eta, nullptr, nullptr, &b0, &lst);
+      if (!ok) ok = fit_logistic(r.Yraw.data() + (size_t)q * N, r.X.data(), r.mask.data() + (size_t)q * N, N, nz, p, false, eta, nullptr, nullptr, &b0, &lst);
       if (!ok) { r.pheno_pass[q] = 0; continue; }
       if (p.write_null_firth) { r.bhat_start.resize((size_t)r.P * nz, 0.0); std::copy(b0.begin(), b0.end(), r.bhat_start.begin() + (size_t)q * nz); }   // Step1_Models.cpp:138
       for (int64_t i = 0; i < N; ++i) r.offset[(size_t)q * N + i] = eta[i];

@@ -33,16 +33,24 @@ bool solve_dense(std::vector<double> A, std::vector<double> b, int n, std::vecto
 }
 // fit_logistic (Step1_Models.cpp:156-222) for one phenotype; offset may be null (zero); eta_out = offset + X beta on success,
 // pv_out (optional) the fitted probabilities
+// `resume`: the reference calls fit_logistic twice -- with and then without the deviance test of the step halving -- on the SAME pivec / etavec /
+// betavec (Step1_Models.cpp:88: `fit_logistic(.., true, ..) || fit_logistic(.., false, ..)`, all three passed by reference): the second attempt goes
+// on from wherever the first one stopped (with --niter 2 that is four Newton steps; found by tests/golden/fuzz_oracle_vs_reference.py).  resume != nullptr
+// holds that state: empty vectors = start at beta = 0, and in every case the state the attempt leaves, converged or not.
 bool fit_logistic(const double* y, const double* X, const uint8_t* mask, int64_t N, int C, const Params& prm,
-                  bool check_hs_dev, std::vector<double>& eta, const double* offset, std::vector<double>* pv_out, std::vector<double>* beta_out) {
+                  bool check_hs_dev, std::vector<double>& eta, const double* offset, std::vector<double>* pv_out, std::vector<double>* beta_out, LogisticState* resume) {
   std::vector<double> beta(C, 0.0), betanew(C, 0.0), pv(N), w(N);
   auto dev = [&](const std::vector<double>& pp) {
     double t = 0.0;
     for (int64_t i = 0; i < N; ++i) if (mask[i]) t -= (y[i] == 0.0) ? std::log(1.0 - pp[i]) : std::log(pp[i]);
     return 2.0 * t;
   };
-  eta.assign(N, 0.0);
-  for (int64_t i = 0; i < N; ++i) { eta[i] = offset ? offset[i] : 0.0; pv[i] = get_pvec1(eta[i]); }
+  if (resume && (int64_t)resume->pv.size() == N && (int)resume->beta.size() == C) { beta = resume->beta; betanew = beta; pv = resume->pv; eta = resume->eta; }
+  else {
+    eta.assign(N, 0.0);
+    for (int64_t i = 0; i < N; ++i) { eta[i] = offset ? offset[i] : 0.0; pv[i] = get_pvec1(eta[i]); }
+  }
+  struct Leave { LogisticState* st; std::vector<double>&b, &p, &e; ~Leave() { if (st) { st->beta = b; st->pv = p; st->eta = e; } } } leave{resume, beta, pv, eta};
   double dev_old = dev(pv), dev_new = dev_old, diff_dev = 0.0;
   int niter = 0;
   bool small_score = false;

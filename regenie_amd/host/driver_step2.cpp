@@ -486,8 +486,9 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
         std::vector<double> bnull;
         if (p.ct) ok = fit_poisson(yq, Xc.data(), mq, n, C, p, eta, off.data(), &pv);
         else {
-          ok = fit_logistic(yq, Xc.data(), mq, n, C, p, true, eta, off.data(), &pv, &bnull);
-          if (!ok) ok = fit_logistic(yq, Xc.data(), mq, n, C, p, false, eta, off.data(), &pv, &bnull);
+          LogisticState lst;
+          ok = fit_logistic(yq, Xc.data(), mq, n, C, p, true, eta, off.data(), &pv, &bnull, &lst);
+          if (!ok) ok = fit_logistic(yq, Xc.data(), mq, n, C, p, false, eta, off.data(), &pv, &bnull, &lst);
         }
         if (ok && firth) {   // fit_null_firth (Step2_Models.cpp:985-1060): penalised fit of the covariates, start = the unpenalised estimate
           if (!null_firth_files.empty() && !null_firth_files[q].empty()) {   // --use-null-firth: the stored estimates of this chromosome as start

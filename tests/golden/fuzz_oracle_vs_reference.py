@@ -176,6 +176,9 @@ def draw_prep(seed, route):
     if os.environ.get("FUZZ_PREP") == "2":      # the complementary lists, a subset of the phenotype columns, --nb
         pr.update(keep=bool(rng.random() < 0.4), extract=bool(rng.random() < 0.4), phenocol=bool(rng.random() < 0.4), nb=bool(rng.random() < 0.3))
         pr["keep"] = pr["keep"] and not pr["remove"]          # (regenie takes one of --keep / --remove)
+    if os.environ.get("FUZZ_PREP") == "4":      # a subset of the covariate columns, 1 / 2 coding of a binary trait, --minCaseCount, few Newton rounds
+        pr.update(covarcol=bool(rng.random() < 0.5), cc12=bool(route.startswith("bt") and rng.random() < 0.5), mincase=bool(route.startswith("bt") and rng.random() < 0.4),
+                  niter=bool(route.startswith("bt") and rng.random() < 0.3))
     if os.environ.get("FUZZ_PREP") == "3":      # explicit ridge grids, leave-one-out forced on a binary trait, --print-prs
         pr.update(setl0=bool(rng.random() < 0.5), setl1=bool(rng.random() < 0.5), force_loocv=bool(route.startswith("bt") and rng.random() < 0.5), prs=bool(rng.random() < 0.4))
     return pr
@@ -207,6 +210,19 @@ def apply_prep(S, spec, pr):
     if pr.get("nb"):
         nb = int(rng.integers(2, 5))
         args += ["--nb", str(nb)]; kw["n_block"] = nb
+    if pr.get("covarcol"):
+        args += ["--covarColList", "C2"]; kw["covar_cols"] = ["C2"]
+    if pr.get("cc12"):             # control = 1, case = 2 (Pheno.cpp:260-270)
+        lines = open(S + ".pheno").read().splitlines()
+        out = [lines[0]] + [" ".join(t[:2] + [x if x == "NA" else str(int(float(x)) + 1) for x in t[2:]]) for t in (ln.split() for ln in lines[1:])]
+        open(S + ".pheno", "w").write("\n".join(out) + "\n")
+        args += ["--cc12"]; kw["cc12"] = True
+    if pr.get("mincase"):
+        mc = int(rng.choice([50, 200, 400]))
+        args += ["--minCaseCount", str(mc)]; kw["min_case_count"] = mc
+    if pr.get("niter"):
+        ni = int(rng.choice([2, 4, 8]))
+        args += ["--niter", str(ni)]; kw["niter_max"] = ni; kw["niter_max_ridge"] = ni            # (Regenie.cpp:483: both limits)
     if pr.get("setl0"):
         v = np.sort(rng.uniform(0.02, 0.95, int(rng.integers(2, 6))))
         args += ["--setl0", ",".join("%.4f" % x for x in v)]; kw["setl0"] = [float("%.4f" % x) for x in v]
@@ -251,7 +267,7 @@ def run_one(seed, work):
         pa, pk = apply_prep(S, spec, pr)
         args += pa
         o = dict(o, **pk)
-        prep_desc = "".join(" " + k for k in ("remove", "exclude", "rint", "keep", "extract", "phenocol", "nb", "setl0", "setl1", "force_loocv", "prs") if pr.get(k)) + (" cat%d" % pr["levels"] if pr["cat"] else "")
+        prep_desc = "".join(" " + k for k in ("remove", "exclude", "rint", "keep", "extract", "phenocol", "nb", "setl0", "setl1", "force_loocv", "prs", "covarcol", "cc12", "mincase", "niter") if pr.get(k)) + (" cat%d" % pr["levels"] if pr["cat"] else "")
     t0 = time.time()
     r = subprocess.run([REGENIE] + args + ["--out", "out"], cwd=d, capture_output=True, text=True)
     t_ref = time.time() - t0
@@ -291,6 +307,10 @@ def run_one(seed, work):
         ok = ~np.isnan(ref)
         worst = max(worst, float(np.max(np.abs(got[ok] - ref[ok])) / np.max(np.abs(ref[ok]))))
     extra = ""
+    if skipped or len(names) != len(open(S + ".pheno").readline().split()) - 2 - (0 if not o.get("pheno_cols") else 0) and not o.get("pheno_cols"):
+        # (a trait without predictions -- not converged, or dropped by --minCaseCount: regenie's --step 2 would need --phenoColList; the legs below are skipped)
+        return desc + " | ok: loco max rel err %.1e (%s), regenie %.1f s, oracle %.1f s, %d trait(s) not converged in both, %d of the file's traits analysed" % (
+            worst, "LOOCV" if res.use_loocv else "K-fold", t_ref, t_or, skipped, len(names)), True
     if not o["bt"] and not o.get("ct"):
         extra = ", step 2: %d statistics" % step2_qt_leg(d, S, o)
         if os.environ.get("FUZZ_BGEN"):
@@ -317,6 +337,9 @@ def _prep_args(S, o):
             a += [flag, f]
     a += ["--apply-rint"] if o.get("apply_rint") else []
     a += ["--phenoColList", ",".join(o["pheno_cols"])] if o.get("pheno_cols") else []
+    a += ["--covarColList", ",".join(o["covar_cols"])] if o.get("covar_cols") else []
+    a += ["--cc12"] if o.get("cc12") else []
+    a += ["--minCaseCount", str(o["min_case_count"])] if o.get("min_case_count") else []
     a += ["--catCovarList", ",".join(o["cat_covar"])] if o.get("cat_covar") else []
     return a
 
@@ -331,7 +354,7 @@ def step2_qt_leg(d, S, o):
     r = subprocess.run([REGENIE] + args + ["--out", "s2"], cwd=d, capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
-                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "apply_rint", "cat_covar") if k in o})
+                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "covar_cols", "apply_rint", "cat_covar") if k in o})
     bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
     bed, _ = orc.open_bed(S + ".bed", prep.n_file)
     ia = prep.ind_in_analysis
@@ -504,7 +527,7 @@ def pgen_legs(d, S, g, spec, o, args1):
     r = subprocess.run([REGENIE] + args + ["--out", "sp"], cwd=d, capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
-                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "apply_rint", "cat_covar") if k in o})
+                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "covar_cols", "apply_rint", "cat_covar") if k in o})
     bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
     ia = prep.ind_in_analysis
     ids = [i for i, k in zip(prep.ids, ia) if k]
@@ -567,7 +590,7 @@ def step2_qt_bgen_leg(d, S, g, spec, o):
     r = subprocess.run([REGENIE] + args + ["--out", "sb"], cwd=d, capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
-                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "apply_rint", "cat_covar") if k in o})
+                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "covar_cols", "apply_rint", "cat_covar") if k in o})
     bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
     ia = prep.ind_in_analysis
     ids = [i for i, k in zip(prep.ids, ia) if k]
@@ -632,7 +655,7 @@ def step2_bt_leg(d, S, o):
     r = subprocess.run([REGENIE] + args + ["--out", "s2"], cwd=d, capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, bt=True, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
-                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "cat_covar") if k in o})
+                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "covar_cols", "cc12", "min_case_count", "cat_covar") if k in o})
     bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
     bed, _ = orc.open_bed(S + ".bed", prep.n_file)
     ia = prep.ind_in_analysis
@@ -689,7 +712,7 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2):
         r = subprocess.run([REGENIE] + base + extra + ["--out", out], cwd=d, capture_output=True, text=True)
         assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, bt=True, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
-                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "cat_covar") if k in o})
+                           **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "covar_cols", "cc12", "min_case_count", "cat_covar") if k in o})
     bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
     bed, _ = orc.open_bed(S + ".bed", prep.n_file)
     ia = prep.ind_in_analysis
