@@ -587,6 +587,11 @@ def step2_qt_bgen_leg(d, S, g, spec, o):
     args += ["--ref-first"] if o["ref_first"] else []
     args += ["--strict"] if o["strict"] else []
     args += _prep_args(S, o)
+    filt = None
+    if os.environ.get("FUZZ_BGEN_FILTER"):        # --minMAC / --minINFO: which tests regenie leaves out (compute_mac, Geno.cpp:3077-3108; compute_aaf_info :3110-3146)
+        frng = np.random.default_rng(spec["seed"] + 77)
+        filt = (float(frng.choice([5, 20, 60])), float(frng.choice([0.3, 0.6, 0.75])))
+        args += ["--minMAC", "%g" % filt[0], "--minINFO", "%g" % filt[1]]
     r = subprocess.run([REGENIE] + args + ["--out", "sb"], cwd=d, capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
@@ -620,12 +625,20 @@ def step2_qt_bgen_leg(d, S, g, spec, o):
             obs = G[k] >= 0
             for ph in range(P):
                 r_ = rows[ph].get(snp_ids[sel[k]])
-                if r_ is None or r_[col["A1FREQ"]] == "NA":      # (a test regenie ignores for the trait, e.g. minimum MAC: the row is all NA)
-                    continue
                 use = obs & (mask[:, ph] > 0)
                 ns, tot = int(use.sum()), float(G[k][use].sum())
                 af = tot / (2 * ns)
                 info = 1.0 if af in (0.0, 1.0) else 1 - float(E[k][use].sum()) / (2 * ns * af * (1 - af))
+                if filt is not None:               # the variant as a whole (all analysed samples), then the trait's own counts
+                    nsa, tota = int(obs.sum()), float(G[k][obs].sum())
+                    afa = tota / (2 * nsa)
+                    infoa = 1.0 if afa in (0.0, 1.0) else 1 - float(E[k][obs].sum()) / (2 * nsa * afa * (1 - afa))
+                    keep_row = min(tota, 2 * nsa - tota) >= filt[0] and infoa >= filt[1] and min(tot, 2 * ns - tot) >= filt[0] and info >= filt[1]
+                    present = r_ is not None and r_[col["A1FREQ"]] != "NA"
+                    near = min(abs(min(tota, 2 * nsa - tota) - filt[0]), abs(min(tot, 2 * ns - tot) - filt[0])) < 1e-9 or min(abs(infoa - filt[1]), abs(info - filt[1])) < 1e-9
+                    assert present == keep_row or near, ("--minMAC / --minINFO", snp_ids[sel[k]], ph, present, keep_row, tota, nsa, infoa, tot, ns, info)
+                if r_ is None or r_[col["A1FREQ"]] == "NA":      # (a test regenie ignores for the trait, e.g. minimum MAC: the row is all NA)
+                    continue
                 assert int(r_[col["N"]]) == ns, ("N", snp_ids[sel[k]], ph, ns, r_[col["N"]])
                 assert abs(af - float(r_[col["A1FREQ"]])) <= 1e-5 * max(af, 1e-3), ("A1FREQ", snp_ids[sel[k]], ph, af, r_[col["A1FREQ"]])
                 if r_[col["INFO"]] == "NA":                    # print_sum_stats_single (Step2_Models.cpp:2505, :2516): a negative score is printed as NA
@@ -639,8 +652,8 @@ def step2_qt_bgen_leg(d, S, g, spec, o):
                 assert abs(out["se"][k, ph] - se) <= 5e-5 * abs(se), ("SE", snp_ids[sel[k]], ph, out["se"][k, ph], se)
                 assert abs(out["chisq"][k, ph] - chisq) <= 1e-4 * abs(chisq) + 2e-6, ("CHISQ", snp_ids[sel[k]], ph, out["chisq"][k, ph], chisq)
                 ncmp += 1
-    assert ncmp > 0
-    return str(ncmp) + driver_same(d, args, "sb", "step2")
+    assert ncmp > 0 or filt is not None
+    return str(ncmp) + ("" if filt is None else " (--minMAC %g --minINFO %g)" % filt) + driver_same(d, args, "sb", "step2")
 
 
 def step2_bt_leg(d, S, o):
