@@ -404,17 +404,25 @@ def run_t2e(seed, d, S, g, spec, o):
     args = ["--step", "1", "--bed", S, "--phenoFile", S + ".t2e", "--covarFile", S + ".covar", "--bsize", str(o["bsize"]), "--cv", str(o["cv_folds"]),
             "--l0", str(o["n_ridge_l0"]), "--l1", str(o["n_ridge_l1"]), "--t2e", "--phenoColList", ",".join(tcols), "--eventColList", ",".join(ecols)]
     args += ["--ref-first"] if o["ref_first"] else []
+    pk, prep_desc = {}, ""
+    if os.environ.get("FUZZ_PREP"):
+        pr = draw_prep(seed, "t2e_kfold")
+        for k in ("phenocol", "rint", "setl0", "setl1", "nb", "covarcol"):      # (options that do not apply to (time, event) pairs, or are drawn elsewhere)
+            pr[k] = False
+        pa, pk = apply_prep(S, spec, pr)
+        args += pa
+        prep_desc = "".join(" " + k for k in ("remove", "exclude", "keep", "extract") if pr.get(k)) + (" cat%d" % pr["levels"] if pr["cat"] else "")
     t0 = time.time()
     r = subprocess.run([REGENIE] + args + ["--out", "out"], cwd=d, capture_output=True, text=True)
     t_ref = time.time() - t0
     desc = "seed %d t2e_kfold N %d M %d chr %d traits %d bsize %d cv %d l0 %d l1 %d%s missG %.2f missing pairs %.2f decimals %d" % (
         seed, spec["N"], spec["M"], len(set(spec["chroms"])), nt, o["bsize"], o["cv_folds"], o["n_ridge_l0"], o["n_ridge_l1"], " ref-first" if o["ref_first"] else "",
-        spec["miss_rate"], spec["t2e"]["missing"], spec["t2e"]["decimals"])
+        spec["miss_rate"], spec["t2e"]["missing"], spec["t2e"]["decimals"]) + prep_desc
     if r.returncode != 0:
         return desc + " | regenie itself stopped: " + (r.stdout + r.stderr).strip().splitlines()[-1][:160], None
     t0 = time.time()
     res = t2e.run_step1_t2e(orc.Step1Options(bed=S, pheno_file=S + ".t2e", covar_file=S + ".covar", bsize=o["bsize"], cv_folds=o["cv_folds"], n_ridge_l0=o["n_ridge_l0"],
-                                             n_ridge_l1=o["n_ridge_l1"], ref_first=o["ref_first"]), dict(zip(tcols, ecols)))
+                                             n_ridge_l1=o["n_ridge_l1"], ref_first=o["ref_first"], **pk), dict(zip(tcols, ecols)))
     t_or = time.time() - t0
     ref_lines = table_lines(open(os.path.join(d, "out.log")).read())
     got_lines = [ln.rstrip() for ln in res["log"]]
