@@ -127,7 +127,10 @@ int rg_s2_set_sparse_rule(rg_s2_ctx* ctx, int64_t n_samples, double prop_zero_th
  *   rg_s2_bt_correct      check_pval_snp's second look at the tests the caller flags (|z| above its threshold, Step2_Models.cpp:1987-2029):
  *                         RG_S2_BT_FIRTH_APPROX = fit_firth_logistic_snp_fast (:1158-1253), RG_S2_BT_SPA = run_SPA_test_snp (:2072-2297).
  *                         One workgroup per (variant, trait) pair iterates on the device; fast[t] != 0 selects the reference's carriers-only
- *                         form (sparse variants: check_sparse_G's verdict is returned by the score call; Firth adds MAC < 50).
+ *                         form (sparse variants: check_sparse_G's verdict is returned by the score call; Firth adds MAC < 50).  The reference
+ *                         tests the MINOR allele (flip_geno, Geno.cpp:3150-3162: 2 - g when the mean dosage exceeds 1, BETA negated back):
+ *                         the statistics returned are those of the coding given, `sparse` and the carriers of the fast forms those of the
+ *                         coding the reference tests -- the only two things the flip changes.
  * Layouts as above: [P][n] / [C][n] sample-fastest host arrays.  The exact Firth test (--firth without --approx) is not behind this ABI. */
 typedef struct rg_s2_bt_null {
   int32_t family;             /* 0: binary trait (logistic null model), 1: count trait (Poisson; no corrections) */
@@ -148,7 +151,7 @@ typedef struct rg_s2_bt_out {   /* HOST pointers, each may be NULL */
   uint8_t* test_ignored;  /* [bs][P] 1: failed null model, or denum below numtol (Step2_Models.cpp:512-517, :596) */
   double* mean;           /* [bs] mean of the observed entries (the imputed value) */
   int32_t* ignored;       /* [bs] 1: nothing observed */
-  uint8_t* sparse;        /* [bs] check_sparse_G's verdict (rg_s2_set_sparse_rule) */
+  uint8_t* sparse;        /* [bs] check_sparse_G's verdict (rg_s2_set_sparse_rule) on the allele the reference tests (flip_geno) */
   int32_t* counts;        /* [bs][4] hard calls: calls equal to 1, equal to 2, missing, 0 */
   double* vstat;          /* [bs][4] integer dosages: sum (units of 1 / scale), sum of squares, observed, observed non-zero */
   double* total_p;        /* [bs][P] hard calls: the trait's allele count minus the variant's (update_trait_counts, Geno.cpp:2948-2959) */

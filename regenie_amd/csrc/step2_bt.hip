@@ -24,7 +24,8 @@
 #include "step2_internal.h"
 
 struct BtPairDev {
-  int32_t variant, trait, fast, pad;
+  int32_t variant, trait, fast;
+  int32_t flip;                  // the reference tests 2 - g (flip_geno, Geno.cpp:3150-3162: mean dosage > 1): only WHO is a carrier depends on it
   double mu, stats, denum;
   double tc[RG_S2_MAX_COV];      // (X^T W X)^-1 X^T W g~: the covariate coefficients taken out of g~
 };
@@ -42,6 +43,8 @@ struct BtState {
   const uint8_t* d_pk = nullptr; int64_t ldp = 0;
   const uint16_t* d_g16 = nullptr; int64_t ldg = 0;
   std::vector<double> sums, sq, mu, denum, stats;
+  std::vector<uint8_t> flip;                // [bs] flip_geno's verdict: the reference tests the other allele of this variant
+  int32_t* d_two = nullptr; size_t two_cap = 0;      // [bs] observed entries of an integer-dosage row that are exactly 2
   // correction scratch
   double* d_v = nullptr; size_t v_cap = 0;
   void* d_pairs = nullptr; size_t pairs_cap = 0;
@@ -82,11 +85,23 @@ __device__ __forceinline__ double bt_geno(int kind, const uint8_t* pk, const uin
   return v == 0xFFFFu ? mu : (double)v * inv_scale;
 }
 
+// ---- integer dosages: observed entries of a row that are exactly 2 copies (the zeros of the flipped coding 2 - g) -------------------------
+__global__ __launch_bounds__(256) void k_bt_count_two(const uint16_t* __restrict__ g16, int64_t ldg, int64_t n, unsigned two, int32_t* __restrict__ out) {
+  __shared__ int red[4];
+  const uint16_t* g = g16 + (int64_t)blockIdx.x * ldg;
+  int c = 0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) c += (unsigned)g[i] == two;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 // ---- residualised genotype of every flagged pair: v_i = g~_i - sum_c x_ci tc_c on the samples that enter the exact terms, NaN elsewhere ----
 // aux [pair][8] = a_all = sum v p^, lo = sum of the negative v, hi = sum of the positive v (all over the unmasked samples), then over the
 // carriers of a fast (sparse) pair: sum (v Gamma_sqrt)^2, sum v p^; number of samples kept.
 __global__ __launch_bounds__(256) void k_bt_prep(const BtPairDev* __restrict__ pairs, int corr_kind, int kind, const uint8_t* __restrict__ pk, int64_t ldp,
-                                                 const uint16_t* __restrict__ g16, int64_t ldg, double inv_scale, const double* __restrict__ X,
+                                                 const uint16_t* __restrict__ g16, int64_t ldg, double inv_scale, unsigned two, const double* __restrict__ X,
                                                  const uint8_t* __restrict__ M, const double* __restrict__ fit, int64_t n, int C, double* __restrict__ V,
                                                  double* __restrict__ aux) {
   __shared__ double red[6][4];
@@ -109,8 +124,13 @@ __global__ __launch_bounds__(256) void k_bt_prep(const BtPairDev* __restrict__ p
       const double ph = pq[i];
       s[0] += r * ph;
       if (r < 0) s[1] += r; else s[2] += r;
-      // carriers only in the fast forms: fit_firth_logistic_snp_fast drops G <= 1e-4, run_SPA_test_snp's fastSPA the exact zeros
-      const bool keep = !pr.fast || (corr_kind == RG_S2_BT_FIRTH_APPROX ? gt > 1e-4 : gt != 0.0);
+      // carriers only in the fast forms: fit_firth_logistic_snp_fast drops G <= 1e-4, run_SPA_test_snp's fastSPA the exact zeros -- of the
+      // coding the reference tests: 2 - g for a flipped variant (flip_geno).  The residual of 2 - g is -r (the intercept is in the span of X),
+      // the score -stats, and every quantity below is odd or even in that sign as the reference's own BETA = -BETA back-flip needs: the carriers
+      // are all the flip changes.  Integer dosages: the zero of 2 - g is decided on the integers.
+      double gc = gt;
+      if (pr.flip) gc = (kind == 2 && grow[i] != 0xFFFFu) ? (double)((int)two - (int)grow[i]) * inv_scale : 2.0 - gt;
+      const bool keep = !pr.fast || (corr_kind == RG_S2_BT_FIRTH_APPROX ? gc > 1e-4 : gc != 0.0);
       if (keep) {
         out = r;
         s[5] += 1.0;
@@ -333,25 +353,33 @@ int grow(rg_s2_ctx* ctx, void** p, size_t* cap, size_t bytes) {
 }
 
 // the score test of every (variant, trait) of the block from the contraction sums (compute_score_bt / compute_score_ct with get_sumstats)
-int score_from_sums(rg_s2_ctx* ctx, int bs, double numtol, const int32_t* counts, const double* vstat, int scale, const rg_s2_bt_out* out) {
+// n_two [bs]: observed entries equal to 2 (integer dosages; hard calls have it in counts)
+int score_from_sums(rg_s2_ctx* ctx, int bs, double numtol, const int32_t* counts, const double* vstat, const int32_t* n_two, int scale, const rg_s2_bt_out* out) {
   BtState& bt = *ctx->bt;
   const int P = ctx->P, C = ctx->C, ncol = bt.ncol;
   const int64_t n = ctx->n;
   const double Nrule = ctx->rule_n > 0 ? (double)ctx->rule_n : (double)n;
-  bt.mu.assign(bs, 0.0); bt.denum.assign((size_t)bs * P, 0.0); bt.stats.assign((size_t)bs * P, 0.0);
+  bt.mu.assign(bs, 0.0); bt.denum.assign((size_t)bs * P, 0.0); bt.stats.assign((size_t)bs * P, 0.0); bt.flip.assign(bs, 0);
   for (int j = 0; j < bs; ++j) {
-    double nobs, tot, nnz;
-    if (vstat) { nobs = vstat[(size_t)j * 4 + 2]; tot = vstat[(size_t)j * 4] / scale; nnz = vstat[(size_t)j * 4 + 3]; }
+    double nobs, tot, nnz, ntwo;
+    if (vstat) { nobs = vstat[(size_t)j * 4 + 2]; tot = vstat[(size_t)j * 4] / scale; nnz = vstat[(size_t)j * 4 + 3]; ntwo = n_two ? (double)n_two[j] : 0.0; }
     else {
       const double n1 = counts[(size_t)j * 4], n2 = counts[(size_t)j * 4 + 1], nm = counts[(size_t)j * 4 + 2];
-      nobs = (double)n - nm; tot = n1 + 2.0 * n2; nnz = n1 + n2;
+      nobs = (double)n - nm; tot = n1 + 2.0 * n2; nnz = n1 + n2; ntwo = n2;
     }
     const double mu = nobs > 0 ? tot / nobs : 0.0;
     bt.mu[j] = mu;
     if (out->mean) out->mean[j] = mu;
     if (out->ignored) out->ignored[j] = nobs > 0 ? 0 : 1;
+    // flip_geno (Geno.cpp:3150-3162; params.with_flip: additive tests of binary / count traits, Data.cpp:2108): a variant whose mean dosage
+    // exceeds 1 is tested as 2 - g and its BETA negated back.  Nothing printed depends on it but check_sparse_G's verdict (the non-zero
+    // entries of 2 - g: the observed g != 2 and, unless 2 - mean = 0, the imputed ones) and, with it, who the carriers of the fast forms are.
+    // The .pgen form of the rule counts the observed zeros BEFORE the flip (prep_snp_stats, Geno.cpp:2582-2594) and stays as it is.
+    const bool flipped = mu > 1.0;
+    bt.flip[j] = flipped ? 1 : 0;
+    const double nnz_t = flipped ? nobs - ntwo : nnz, mu_t = flipped ? 2.0 - mu : mu;
     if (out->sparse)   // check_sparse_G (Geno.cpp:3165-3177)
-      out->sparse[j] = ctx->rule_zero_count ? (nobs - nnz) >= Nrule * ctx->rule_thr : (nnz + (mu != 0.0 ? (double)n - nobs : 0.0)) <= Nrule * (1.0 - ctx->rule_thr);
+      out->sparse[j] = ctx->rule_zero_count ? (nobs - nnz) >= Nrule * ctx->rule_thr : (nnz_t + (mu_t != 0.0 ? (double)n - nobs : 0.0)) <= Nrule * (1.0 - ctx->rule_thr);
     const double* s0 = bt.sums.data() + (size_t)j * 2 * ncol;
     const double* s1 = s0 + ncol;
     for (int q = 0; q < P; ++q) {
@@ -393,7 +421,7 @@ int score_from_sums(rg_s2_ctx* ctx, int bs, double numtol, const int32_t* counts
 void rg_s2_bt_free(rg_s2_ctx* ctx) {
   if (!ctx || !ctx->bt) return;
   BtState* bt = ctx->bt;
-  for (void* p : {(void*)bt->dX, (void*)bt->dY, (void*)bt->dFit, (void*)bt->dFo, (void*)bt->dM, (void*)bt->d_v, bt->d_pairs, (void*)bt->d_res})
+  for (void* p : {(void*)bt->dX, (void*)bt->dY, (void*)bt->dFit, (void*)bt->dFo, (void*)bt->dM, (void*)bt->d_v, bt->d_pairs, (void*)bt->d_res, (void*)bt->d_two})
     if (p) (void)hipFree(p);
   delete bt;
   ctx->bt = nullptr;
@@ -495,7 +523,7 @@ int rg_s2_bt_score_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   bt.d_pk = (const uint8_t*)ctx->pbuf[RG_S2_Q_PK]; bt.ldp = Np / 4;       // the staged rows (flip applied, padding = 0 copies) stay for the corrections
   bt.d_g16 = nullptr; bt.ldg = 0;
   if (out->counts) memcpy(out->counts, counts.data(), sizeof(int32_t) * counts.size());
-  return score_from_sums(ctx, bs, numtol, counts.data(), nullptr, 1, out);
+  return score_from_sums(ctx, bs, numtol, counts.data(), nullptr, nullptr, 1, out);
 }
 
 int rg_s2_bt_score_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs, int32_t g_on_device, int32_t scale, double numtol,
@@ -516,7 +544,15 @@ int rg_s2_bt_score_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs
   if (g_on_device) { bt.d_g16 = G; bt.ldg = ld; }
   else { bt.d_g16 = (const uint16_t*)ctx->buf[RG_S2_B_G]; bt.ldg = (ctx->n + 7) / 8 * 8; }
   if (out->vstat) memcpy(out->vstat, vstat.data(), sizeof(double) * vstat.size());
-  return score_from_sums(ctx, bs, numtol, nullptr, vstat.data(), scale, out);
+  // the zeros of the flipped coding (flip_geno): entries that are exactly 2 copies, counted on the staged rows
+  std::vector<int32_t> n_two(bs, 0);
+  int rc2;
+  if ((rc2 = grow(ctx, (void**)&bt.d_two, &bt.two_cap, sizeof(int32_t) * (size_t)bs))) return rc2;
+  hipLaunchKernelGGL(k_bt_count_two, dim3(bs), dim3(256), 0, ctx->st, bt.d_g16, bt.ldg, ctx->n, (unsigned)(2 * scale), bt.d_two);
+  S2_HIP(hipGetLastError());
+  S2_HIP(hipMemcpyAsync(n_two.data(), bt.d_two, sizeof(int32_t) * (size_t)bs, hipMemcpyDeviceToHost, ctx->st));
+  S2_HIP(hipStreamSynchronize(ctx->st));
+  return score_from_sums(ctx, bs, numtol, nullptr, vstat.data(), n_two.data(), scale, out);
 }
 
 int rg_s2_bt_correct(rg_s2_ctx* ctx, int32_t kind, int32_t npair, const int32_t* variant, const int32_t* trait, const uint8_t* fast, int32_t firth_se,
@@ -538,7 +574,7 @@ int rg_s2_bt_correct(rg_s2_ctx* ctx, int32_t kind, int32_t npair, const int32_t*
     if (j < 0 || j >= bt.bs || q < 0 || q >= P) return rg_s2_fail(ctx, RG_S2_ERR_ARG, "rg_s2_bt_correct: pair out of range");
     BtPairDev& pd = pairs[t];
     memset(&pd, 0, sizeof(pd));
-    pd.variant = j; pd.trait = q; pd.fast = fast && fast[t] ? 1 : 0;
+    pd.variant = j; pd.trait = q; pd.fast = fast && fast[t] ? 1 : 0; pd.flip = bt.flip[j];
     pd.mu = bt.mu[j]; pd.stats = bt.stats[(size_t)j * P + q]; pd.denum = bt.denum[(size_t)j * P + q];
     const double* s0 = bt.sums.data() + (size_t)j * 2 * ncol;
     const double* s1 = s0 + ncol;
@@ -564,7 +600,7 @@ int rg_s2_bt_correct(rg_s2_ctx* ctx, int32_t kind, int32_t npair, const int32_t*
     S2_HIP(hipMemcpyAsync(bt.d_pairs, pairs.data() + t0, sizeof(BtPairDev) * np, hipMemcpyHostToDevice, ctx->st));
     S2_HIP(hipEventRecord(ctx->e0, ctx->st));
     hipLaunchKernelGGL(k_bt_prep, dim3(np), dim3(256), 0, ctx->st, (const BtPairDev*)bt.d_pairs, kind, bt.kind, bt.d_pk, bt.ldp, bt.d_g16, bt.ldg, inv_scale,
-                       (const double*)bt.dX, (const uint8_t*)bt.dM, (const double*)bt.dFit, n, C, bt.d_v, d_aux);
+                       (unsigned)(2 * std::max(bt.scale, 0)), (const double*)bt.dX, (const uint8_t*)bt.dM, (const double*)bt.dFit, n, C, bt.d_v, d_aux);
     if (kind == RG_S2_BT_FIRTH_APPROX)
       hipLaunchKernelGGL(k_bt_firth1, dim3(np), dim3(256), 0, ctx->st, (const BtPairDev*)bt.d_pairs, (const double*)bt.d_v, (const double*)bt.dY,
                          (const double*)bt.dFo, (const double*)d_aux, n, bt.d_res);

@@ -25,14 +25,18 @@ static std::string g_err;
 extern "C" const char* hp_error() { return g_err.c_str(); }
 extern "C" void* hp_run(int argc, char** argv) {      // the start of rgdrv::run (driver_step1.cpp), up to where the device comes in
   Run* r = new Run;
+  std::cout.flush(); fflush(stdout);
+  const int saved = dup(1), nul = open("/dev/null", O_WRONLY);      // the run's log lines go to <out>.log only
+  dup2(nul, 1); close(nul);
+  auto back = [&]() { std::cout.flush(); fflush(stdout); dup2(saved, 1); close(saved); sout.f.close(); };
   try {
     r->p = parse_args(argc, argv);
     sout.f.open(r->p.out + ".log");
     read_bim_fam(*r);
     read_pheno_cov(*r);
-    sout.f.close();
+    back();
     return r;
-  } catch (const std::exception& e) { g_err = e.what(); sout.f.close(); delete r; return nullptr; }
+  } catch (const std::exception& e) { g_err = e.what(); back(); delete r; return nullptr; }
 }
 extern "C" void hp_free(void* h) { delete (Run*)h; }
 extern "C" void hp_dims(void* h, int64_t* out) { Run* r = (Run*)h; out[0] = r->N; out[1] = r->P; out[2] = r->C; out[3] = r->n_analyzed; out[4] = r->n_file; out[5] = (int64_t)r->snp_ids.size(); }
