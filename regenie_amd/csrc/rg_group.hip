@@ -19,6 +19,7 @@
 // No compute happens here; nothing in this file is a fallback for a kernel.
 #include <dlfcn.h>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include "rg_internal.h"
@@ -42,7 +43,9 @@ struct Rccl {
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool load(std::string& err) {
     if (h) return true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    const char* named = getenv("RG_RCCL_LIB");        // a particular build of RCCL (path or soname); the tests' stand-in, tests/hipcpu/fake_rccl.cpp
+    for (const char* name : {named, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      if (!name || !*name) continue;
       h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (h) break;
     }

@@ -33,6 +33,17 @@ inline hipError_t hipDeviceSynchronize() { return 0; }
 inline hipError_t hipSetDevice(int) { return 0; }
 inline hipError_t hipGetLastError() { return 0; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return 0; }
+constexpr unsigned hipEventDisableTiming = 2;
+constexpr hipError_t hipErrorPeerAccessAlreadyEnabled = 704;
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = reinterpret_cast<hipEvent_t>(malloc(1)); return 0; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { return hipEventCreateWithFlags(e, 0); }
+inline hipError_t hipEventDestroy(hipEvent_t e) { free(e); return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }       // (every operation here has completed when its call returns)
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return 0; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t = nullptr) {
+  for (size_t r = 0; r < height; ++r) memmove((char*)d + r * dpitch, (const char*)s + r * spitch, width);
+  return 0;
+}
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return 0; }
 
 struct dim3 {
@@ -45,7 +56,7 @@ struct dim3 {
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+#define __shared__ static thread_local
 
 namespace hipcpu {
 struct Idx { unsigned x = 0, y = 0, z = 0; };
@@ -60,8 +71,8 @@ struct Block {
   uint64_t slot[1024];
   std::function<void()> body;
 };
-inline Block g_blk;
-inline Idx g_block_idx, g_block_dim, g_grid_dim;
+inline thread_local Block g_blk;      // (per host thread: the rank threads of a multi-device test may launch at the same time)
+inline thread_local Idx g_block_idx, g_block_dim, g_grid_dim;
 constexpr size_t kStack = 256 * 1024;
 
 inline void yield() {
