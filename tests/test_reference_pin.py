@@ -509,7 +509,9 @@ def test_step2_bt_approx_firth_oracle_against_reference_and_golden():
             bnulls.append(bnull)
             offs_f.append(X @ bnull + loco[ph][c - 1])           # cov_blup_offset (Step2_Models.cpp:1011-1013)
         for k in np.flatnonzero(chrom == c):
-            g, _, _ = s2.mean_impute(bg.dosages(int(k))[keep][ia])
+            gk, flipped = bt.flip_geno(bg.dosages(int(k))[keep][ia])      # regenie tests the minor allele and negates BETA back (flip_geno, Geno.cpp:3150-3162)
+            sgn = -1.0 if flipped else 1.0
+            g, _, _ = s2.mean_impute(gk)
             for ph in range(P):
                 r = rows[ph].get(snp_ids[k])
                 if r is None:
@@ -522,19 +524,19 @@ def test_step2_bt_approx_firth_oracle_against_reference_and_golden():
                     re = erow[ph][snp_ids[k]]
                     assert ex is not None
                     for nm in ("BETA", "SE", "CHISQ"):
-                        assert ex[{"BETA": "bhat", "SE": "se", "CHISQ": "chisq"}[nm]] == pytest.approx(float(re[col[nm]]), rel=2e-4), (snp_ids[k], ph, nm)
+                        assert ex[{"BETA": "bhat", "SE": "se", "CHISQ": "chisq"}[nm]] * (sgn if nm == "BETA" else 1.0) == pytest.approx(float(re[col[nm]]), rel=2e-4), (snp_ids[k], ph, nm)
                     sparse = s2.check_sparse(g, int(keep.sum()))                                   # fastSPA = the variant is sparse (Data.cpp:2503; Geno.cpp:3179)
                     sp = bt.spa_test(out["stats"], out["denum"], out["Gres"], nulls[ph], m, carriers=np.flatnonzero(g != 0) if sparse else None)   # --spa
                     rs = srow[ph][snp_ids[k]]
                     assert sp is not None
                     for nm, key in (("BETA", "bhat"), ("SE", "se"), ("CHISQ", "chisq"), ("LOG10P", "logp")):
-                        assert sp[key] == pytest.approx(float(rs[col[nm]]), rel=3e-5), (snp_ids[k], ph, nm)
+                        assert sp[key] * (sgn if key == "bhat" else 1.0) == pytest.approx(float(rs[col[nm]]), rel=3e-5), (snp_ids[k], ph, nm)
                     out = bt.approx_firth(g, X, Yraw[:, ph], m, nulls[ph], offs_f[ph])
                     assert out is not None
                     nfirth += 1
                 for rr, tol in ((r, 5e-5),) + (((grow[snp_ids[k]], 2e-4),) if ph == 0 else ()):
                     beta, se, chisq, logp = (float(rr[col[nm]]) for nm in ("BETA", "SE", "CHISQ", "LOG10P"))
-                    assert out["bhat"] == pytest.approx(beta, rel=tol, abs=2e-6), (snp_ids[k], ph, corrected)
+                    assert sgn * out["bhat"] == pytest.approx(beta, rel=tol, abs=2e-6), (snp_ids[k], ph, corrected)
                     assert out["se"] == pytest.approx(se, rel=tol)
                     assert out["chisq"] == pytest.approx(chisq, rel=2 * tol, abs=2e-6)
                     assert s2.get_logp(out["chisq"]) == pytest.approx(logp, rel=2 * tol, abs=2e-6)
@@ -588,7 +590,9 @@ def test_step2_bt_approx_firth_rare_variants_against_reference(tmp_path):
         G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
         rows = {ph: {r[col["ID"]]: r for r in refs[ph][1]} for ph in range(P)}
         for k in range(sel.size):
-            g, _, _ = s2.mean_impute(G[k])
+            gk, flipped = bt.flip_geno(G[k])                      # the minor allele is what regenie tests (flip_geno), BETA negated back
+            sgn = -1.0 if flipped else 1.0
+            g, _, _ = s2.mean_impute(gk)
             sparse = s2.check_sparse(g, n_all)
             obs = G[k] >= 0
             for ph in range(P):
@@ -602,11 +606,11 @@ def test_step2_bt_approx_firth_rare_variants_against_reference(tmp_path):
                     sp = bt.spa_test(out["stats"], out["denum"], out["Gres"], nulls[ph], m, carriers=np.flatnonzero(g != 0) if sparse else None)
                     rs = srow[ph][snp_ids[sel[k]]]
                     if rs[-1] == "TEST_FAIL":
-                        assert sp is None and out["bhat"] == pytest.approx(float(rs[col["BETA"]]), rel=3e-5)
+                        assert sp is None and sgn * out["bhat"] == pytest.approx(float(rs[col["BETA"]]), rel=3e-5)
                         nspa_fail += 1
                     else:
                         for nm, key in (("BETA", "bhat"), ("SE", "se"), ("CHISQ", "chisq"), ("LOG10P", "logp")):
-                            assert sp[key] == pytest.approx(float(rs[col[nm]]), rel=3e-5), (snp_ids[sel[k]], ph, nm)
+                            assert sp[key] * (sgn if key == "bhat" else 1.0) == pytest.approx(float(rs[col[nm]]), rel=3e-5), (snp_ids[sel[k]], ph, nm)
                     tq = float(G[k][obs & (m > 0)].sum())
                     nq = int((obs & (m > 0)).sum())
                     mac = min(tq, 2 * nq - tq)
@@ -616,7 +620,7 @@ def test_step2_bt_approx_firth_rare_variants_against_reference(tmp_path):
                     nfast += sparse and mac < 50
                 beta, se, chisq = (float(r[col[nm]]) for nm in ("BETA", "SE", "CHISQ"))
                 # regenie stops its 1-parameter fit at |modified score| < 2.5e-4, i.e. within a few times 2.5e-4 * se^2 of the root this oracle finds
-                assert abs(out["bhat"] - beta) <= 8e-4 * se * se + 2e-5 * abs(beta) + 5e-6, (snp_ids[sel[k]], ph)
+                assert abs(sgn * out["bhat"] - beta) <= 8e-4 * se * se + 2e-5 * abs(beta) + 5e-6, (snp_ids[sel[k]], ph)
                 assert out["se"] == pytest.approx(se, rel=2e-4)
                 assert out["chisq"] == pytest.approx(chisq, rel=2e-3, abs=2e-5)      # (its LRT is taken one outer iteration before its BETA)
     assert ncorr > 200 and nfast > 80 and nspa_fail == 1
