@@ -9,6 +9,7 @@ import ctypes as C
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -58,3 +59,83 @@ def test_minor_allele_flip_on_the_emulated_device(gpu_tests, route):
 
 def test_usage_errors_on_the_emulated_device(gpu_tests):
     gpu_tests.test_bt_usage_errors()
+
+
+def _one_shape(t, seed, n, Cc, P, bs, route, miss_y, nrule):
+    from regenie_amd.step2 import BT_FIRTH_APPROX, BT_SPA, Step2QT
+    from oracle import regenie_step2_bt as bt
+    rng = np.random.default_rng(seed)
+    X = np.linalg.qr(np.column_stack([np.ones(n)] + ([rng.normal(size=(n, Cc - 1))] if Cc > 1 else [])))[0]
+    off = 0.3 * rng.normal(size=(n, P))
+    maf = rng.uniform(0.03, 0.5, size=bs)
+    G = rng.binomial(2, maf[:, None], size=(bs, n)).astype(np.float64)
+    G[::3] = 2.0 - G[::3]
+    lin = (X[:, [1]] * 3 if Cc > 1 else 0) + off
+    y = (rng.random((n, P)) < 1 / (1 + np.exp(-(-0.5 + lin)))).astype(np.float64)
+    mask = rng.random((n, P)) > miss_y
+    G[rng.random(G.shape) < 0.02] = np.nan
+    if route == "int":
+        pick = (rng.random(G.shape) < 0.05) & ~np.isnan(G)
+        v = np.clip(np.nan_to_num(G) * 255 + rng.integers(-60, 61, G.shape), 0, 510)
+        G = np.where(pick, v / 255.0, G)
+    nulls, fo = t._nulls(X, off, y, mask)
+    fitted = np.array([nl["p"] for nl in nulls])
+    with Step2QT(n, X.shape[1], P) as s2:
+        s2.set_sparse_rule(nrule, 0.5, False)
+        s2.bt_set_null(X.T, y.T, mask.T, fitted, firth_offset=fo)
+        got = s2.bt_score_packed(t._pack(G)) if route == "packed" else s2.bt_score_int(np.where(np.isnan(G), 0xFFFF, np.rint(np.nan_to_num(G) * 255)).astype(np.uint16), 255)
+        pairs, gi, sg = [], [], []
+        for j in range(bs):
+            gk, flipped = bt.flip_geno(np.where(np.isnan(G[j]), -3.0, G[j]))
+            obs = gk >= 0
+            g = np.where(obs, gk, gk[obs].mean())
+            sgn = -1.0 if flipped else 1.0
+            gi.append(g); sg.append(sgn)
+            sparse = int((g != 0).sum()) <= 0.5 * nrule
+            assert bool(got["sparse"][j]) == sparse, ("sparse", j, flipped)
+            for q in range(P):
+                ref = bt.score_bt(g, X, y[:, q], mask[:, q].astype(float), nulls[q])
+                if ref is None:
+                    assert got["test_ignored"][j, q]; continue
+                assert not got["test_ignored"][j, q]
+                assert got["stats"][j, q] == pytest.approx(sgn * ref["stats"], rel=1e-8, abs=1e-9)
+                assert got["denum"][j, q] == pytest.approx(ref["denum"], rel=1e-8)
+                pairs.append((j, q, ref))
+        var = np.array([p[0] for p in pairs], np.int32); tr = np.array([p[1] for p in pairs], np.int32)
+        fast = np.array([int(got["sparse"][p[0]]) for p in pairs], np.uint8)
+        fc = s2.bt_correct(BT_FIRTH_APPROX, var, tr, fast)
+        sc = s2.bt_correct(BT_SPA, var, tr, fast)
+    nf = ns = 0
+    for tt, (j, q, ref) in enumerate(pairs):
+        g, m, sgn = gi[j], mask[:, q].astype(float), sg[j]
+        is_fast = bool(fast[tt])
+        want = bt.approx_firth(g, X, y[:, q], m, nulls[q], fo[q], sparse=is_fast, mac=0 if is_fast else None)
+        if want is None:
+            assert fc["fail"][tt] == 1, ("firth fail", j, q)
+        else:
+            assert fc["fail"][tt] == 0, ("firth ok", j, q)
+            assert fc["beta"][tt] == pytest.approx(sgn * want["bhat"], rel=1e-5, abs=1e-7), ("firth beta", j, q, is_fast)
+            assert fc["chisq"][tt] == pytest.approx(want["chisq"], rel=1e-5, abs=1e-8)
+            nf += 1
+        if abs(ref["stats"]) < 0.1: continue
+        wsp = bt.spa_test(ref["stats"], ref["denum"], ref["Gres"], nulls[q], m, carriers=np.flatnonzero(g != 0) if is_fast else None)
+        if wsp is None:
+            assert sc["fail"][tt] == 1, ("spa fail", j, q)
+        else:
+            assert sc["fail"][tt] == 0, ("spa ok", j, q)
+            assert sc["logp"][tt] == pytest.approx(wsp["logp"], rel=1e-5, abs=1e-8), ("spa logp", j, q, is_fast, ref["stats"])
+            ns += 1
+    return nf, ns
+
+
+
+@pytest.mark.parametrize("n", [40, 64, 65, 255, 257, 700])
+def test_shapes_the_gpu_tests_do_not_visit(gpu_tests, n):
+    """Sample counts around the wavefront and workgroup sizes, 1 - 5 covariates, one and three traits, masks, both input routes, every third variant
+    counting its major allele, the rule's n_samples above the analysed samples: score test, sparse verdict and both corrections of every pair
+    against the oracle (192 such combinations were run when this was written; a sixth of them stay here)."""
+    k = 0
+    for Cc, P, route, miss_y in ((1, 1, "packed", 0.0), (2, 3, "int", 0.1), (5, 3, "packed", 0.1), (5, 1, "int", 0.0)):
+        k += 1
+        nf, ns = _one_shape(gpu_tests, 2000 + 10 * n + k, n, Cc, P, 9, route, miss_y, n + (k % 3) * 50)
+        assert nf >= 7 * P and ns >= 5 * P
