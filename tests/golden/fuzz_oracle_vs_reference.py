@@ -13,7 +13,7 @@ FUZZ_DRIVER=1 (GPU box): the PRODUCT runs beside them -- `regenie-amd --step 1` 
 files and .regenie lines are held to regenie's (values at the text's resolution; the share of byte-identical lines is reported); with FUZZ_BGEN /
 FUZZ_PGEN also on those inputs (driver_same: written in round 5 after the GPU budget was spent -- exercised with regenie standing in for the
 driver, first real run due in the next round:  FUZZ_DRIVER=1 FUZZ_BGEN=2 FUZZ_PGEN=1 FUZZ_PREP=2 python tests/golden/fuzz_oracle_vs_reference.py 1 100).
-Other switches: FUZZ_PREP=1|2 (host-preparation options), FUZZ_ROUTES=ct_kfold,ct_loocv,t2e_kfold,... (routes to cycle through), FUZZ_BT_STEP2=1|2
+Other switches: FUZZ_PREP=1|2 (host-preparation options), FUZZ_ROUTES=ct_kfold,ct_loocv,t2e_kfold,... (routes to cycle through), FUZZ_BT_STEP2=1|2|3
 (the binary score test / its Firth and saddlepoint corrections), FUZZ_BGEN=1|2, FUZZ_PGEN=1.
 FUZZ_BUDGET_S=t stops drawing new cases after t seconds."""
 import os
@@ -321,8 +321,10 @@ def run_one(seed, work):
         extra += ", step 1 from bgen: " + step1_bgen_leg(d, S, g, spec, o, args)
     elif o["bt"] and os.environ.get("FUZZ_BT_STEP2"):
         extra = ", step 2 (score test): %d statistics" % step2_bt_leg(d, S, o)
-        if os.environ["FUZZ_BT_STEP2"] == "2":
+        if os.environ["FUZZ_BT_STEP2"] in ("2", "3"):
             extra += ", corrected: %d Firth + %d SPA rows" % step2_bt_corrections_leg(d, S, o)
+        if os.environ["FUZZ_BT_STEP2"] == "3":
+            extra += ", from BGEN dosages: %d Firth + %d SPA rows" % step2_bt_corrections_leg(d, S, o, bgen=(g, spec))
     if os.environ.get("FUZZ_DRIVER"):
         extra += " | " + driver_legs(d, args, o, len(names))
     if skipped:
@@ -715,7 +717,7 @@ def step2_bt_leg(d, S, o):
     return ncmp
 
 
-def step2_bt_corrections_leg(d, S, o, pthresh=0.2):
+def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
     """regenie --step 2 --bt with --firth --approx and with --spa (p-value threshold 0.2: a fifth of the tests are corrected) against
     oracle/regenie_step2_bt.py: null Firth model, the 1-parameter approximate Firth fit (on the carriers only for sparse rare variants),
     the saddlepoint approximation (its fast form for sparse variants; a test regenie reports as TEST_FAIL has no root here either).
@@ -725,11 +727,20 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2):
     from scipy.stats import norm
     from oracle import regenie_step2_bt as bt
     from oracle import regenie_step2_qt as s2
-    base = ["--step", "2", "--bt", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list", "--pThresh", str(pthresh)]
+    # bgen = (genotypes, spec): the same case as BGEN dosages (8-bit probabilities, 40 % of the calls smeared): check_sparse_G then counts the
+    # non-zero DOSAGES of the coding regenie tests -- after flip_geno the entries that are not exactly 2
+    src = ["--bed", S] if bgen is None else ["--bgen", S + ".bgen", "--sample", S + ".sample"]
+    tag = "" if bgen is None else "b"
+    if bgen is not None:
+        from oracle import bgen as obg
+        from tests.util import write_synth_bgen
+        if not os.path.exists(S + ".bgen"):
+            write_synth_bgen(S, bgen[0], bgen[1]["chroms"], seed=bgen[1]["seed"])
+    base = ["--step", "2", "--bt"] + src + ["--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list", "--pThresh", str(pthresh)]
     base += ["--ref-first"] if o["ref_first"] else []
     base += ["--strict"] if o["strict"] else []
     base += _prep_args(S, o)
-    for extra, out in ((["--firth", "--approx"], "s2f"), (["--spa"], "s2s")):
+    for extra, out in ((["--firth", "--approx"], "s2f" + tag), (["--spa"], "s2s" + tag)):
         r = subprocess.run([REGENIE] + base + extra + ["--out", out], cwd=d, capture_output=True, text=True)
         assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, bt=True, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
@@ -744,13 +755,16 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2):
         hdr, v = _loco(os.path.join(d, "out_%d.loco" % (ph + 1)))
         pos = {s_: k for k, s_ in enumerate(hdr)}
         loco.append(v[:, [pos[i] for i in ids]])
-        h, body = pin._read_regenie(os.path.join(d, "s2f_%s.regenie" % prep.pheno_names[ph]))
+        h, body = pin._read_regenie(os.path.join(d, "s2f%s_%s.regenie" % (tag, prep.pheno_names[ph])))
         col = {nm: i for i, nm in enumerate(h)}
         frow.append({r_[col["ID"]]: r_ for r_ in body})
-        srow.append({r_[col["ID"]]: r_ for r_ in pin._read_regenie(os.path.join(d, "s2s_%s.regenie" % prep.pheno_names[ph]))[1]})
+        srow.append({r_[col["ID"]]: r_ for r_ in pin._read_regenie(os.path.join(d, "s2s%s_%s.regenie" % (tag, prep.pheno_names[ph])))[1]})
     X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
     zthr = float(norm.ppf(1 - pthresh / 2))
     n_all = int((~prep.ind_ignore).sum())
+    if bgen is not None:
+        bgo = obg.BgenOracle(S + ".bgen")
+        vidx = {v["rsid"]: k for k, v in enumerate(bgo.variants)}
     nf = ns = 0
     for c in sorted(set(chrom.tolist())):
         nulls, offs_f = [], []
@@ -760,9 +774,12 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2):
             nulls.append(nl)
             offs_f.append(X @ bnull + np.nan_to_num(loco[ph][c - 1]) if bnull is not None else None)
         sel = np.flatnonzero(chrom == c)
-        G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
-        if o["ref_first"]:
-            G = np.where(G < 0, G, 2.0 - G)
+        if bgen is None:
+            G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
+            if o["ref_first"]:
+                G = np.where(G < 0, G, 2.0 - G)
+        else:
+            G = np.stack([bgo.dosages(vidx[snp_ids[k]], o["ref_first"])[~prep.ind_ignore][ia] for k in sel])
         for k in range(sel.size):
             gk, flipped = bt.flip_geno(G[k])          # regenie tests the MINOR allele and negates BETA back
             sgn = -1.0 if flipped else 1.0
@@ -803,7 +820,7 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2):
     if os.environ.get("FUZZ_DRIVER"):
         # the product's corrected rows beside regenie's (both stop their fits at a tolerance: the bars of the oracle comparison above).  Variants
         # whose counted allele is the major one are where the carriers of the fast forms are those of 2 - g (flip_geno).
-        for extra, out, ref in ((["--firth", "--approx"], "d2f", "s2f"), (["--spa"], "d2s", "s2s")):
+        for extra, out, ref in ((["--firth", "--approx"], "d2f" + tag, "s2f" + tag), (["--spa"], "d2s" + tag, "s2s" + tag)):
             r = subprocess.run([BIN] + base + extra + ["--out", out], cwd=d, capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, "regenie-amd --step 2 --bt %s: " % extra[0] + (r.stdout + r.stderr)[-500:]
             for ph in range(P):
