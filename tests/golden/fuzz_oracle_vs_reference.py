@@ -319,6 +319,8 @@ def run_one(seed, work):
         extra += ", pgen: " + pgen_legs(d, S, g, spec, o, args)
     if os.environ.get("FUZZ_BGEN") == "2" and not o.get("ct"):
         extra += ", step 1 from bgen: " + step1_bgen_leg(d, S, g, spec, o, args)
+    elif o.get("ct") and os.environ.get("FUZZ_BT_STEP2"):
+        extra = ", step 2 --ct (score test): %d statistics" % step2_bt_leg(d, S, o)
     elif o["bt"] and os.environ.get("FUZZ_BT_STEP2"):
         extra = ", step 2 (score test): %d statistics" % step2_bt_leg(d, S, o)
         if os.environ["FUZZ_BT_STEP2"] in ("2", "3"):
@@ -668,16 +670,18 @@ def step2_qt_bgen_leg(d, S, g, spec, o):
 
 def step2_bt_leg(d, S, o):
     """regenie --step 2 --bt (the score test, no Firth / SPA) with ITS OWN step-1 predictions against oracle/regenie_step2_bt.py: the null logistic
-    model with the LOCO offset per chromosome, compute_score_bt, get_sumstats; -> statistics compared"""
+    model with the LOCO offset per chromosome, compute_score_bt, get_sumstats; -> statistics compared.  Count traits (o["ct"]): --ct, the null
+    Poisson model and compute_score_ct."""
     from oracle import regenie_step2_bt as bt
     from oracle import regenie_step2_qt as s2
-    args = ["--step", "2", "--bt", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list"]
+    ct = bool(o.get("ct"))
+    args = ["--step", "2", "--ct" if ct else "--bt", "--bed", S, "--phenoFile", S + ".pheno", "--covarFile", S + ".covar", "--bsize", "200", "--pred", "out_pred.list"]
     args += ["--ref-first"] if o["ref_first"] else []
     args += ["--strict"] if o["strict"] else []
     args += _prep_args(S, o)
     r = subprocess.run([REGENIE] + args + ["--out", "s2"], cwd=d, capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
-    opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, bt=True, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
+    opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, bt=not ct, ct=ct, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
                            **{k: o[k] for k in ("remove", "exclude", "keep", "extract", "pheno_cols", "covar_cols", "cc12", "min_case_count", "cat_covar") if k in o})
     bim, chrom, offs, snp_ids, prep = orc.load_inputs(opt)
     bed, _ = orc.open_bed(S + ".bed", prep.n_file)
@@ -695,7 +699,7 @@ def step2_bt_leg(d, S, o):
     X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
     ncmp = 0
     for c in sorted(set(chrom.tolist())):
-        nulls = [bt.null_logistic(Yraw[:, ph], X, mask[:, ph], loco[ph][c - 1], opt) for ph in range(P)]
+        nulls = [(bt.null_poisson if ct else bt.null_logistic)(Yraw[:, ph], X, mask[:, ph], loco[ph][c - 1], opt) for ph in range(P)]
         sel = np.flatnonzero(chrom == c)
         G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
         if o["ref_first"]:
@@ -706,7 +710,9 @@ def step2_bt_leg(d, S, o):
                 r_ = rows[ph].get(snp_ids[sel[k]])
                 if r_ is None or r_[col["BETA"]] == "NA" or nulls[ph] is None:
                     continue
-                out = bt.score_bt(g, X, Yraw[:, ph], mask[:, ph].astype(np.float64), nulls[ph])
+                out = (bt.score_ct if ct else bt.score_bt)(g, X, Yraw[:, ph], mask[:, ph].astype(np.float64), nulls[ph])
+                if out is None:
+                    continue
                 beta, se, chisq, logp = (float(r_[col[nm]]) for nm in ("BETA", "SE", "CHISQ", "LOG10P"))
                 assert abs(out["bhat"] - beta) <= 5e-5 * abs(beta) + 2e-6, ("BETA", snp_ids[sel[k]], ph, out["bhat"], beta)
                 assert abs(out["se"] - se) <= 5e-5 * abs(se), ("SE", snp_ids[sel[k]], ph, out["se"], se)
@@ -740,7 +746,8 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
     base += ["--ref-first"] if o["ref_first"] else []
     base += ["--strict"] if o["strict"] else []
     base += _prep_args(S, o)
-    for extra, out in ((["--firth", "--approx"], "s2f" + tag), (["--spa"], "s2s" + tag)):
+    exact = os.environ.get("FUZZ_BT_EXACT") and bgen is None        # also --firth without --approx (a C + 1 parameter fit per flagged test)
+    for extra, out in ((["--firth", "--approx"], "s2f" + tag), (["--spa"], "s2s" + tag)) + (((["--firth"], "s2e"),) if exact else ()):
         r = subprocess.run([REGENIE] + base + extra + ["--out", out], cwd=d, capture_output=True, text=True)
         assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, bt=True, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
@@ -750,8 +757,11 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
     ia = prep.ind_in_analysis
     ids = [i for i, k in zip(prep.ids, ia) if k]
     P = prep.Y.shape[1]
-    loco, frow, srow, col = [], [], [], None
+    loco, frow, srow, erow, col = [], [], [], [], None
+    ne = 0
     for ph in range(P):
+        if exact:
+            erow.append({r_[2]: r_ for r_ in pin._read_regenie(os.path.join(d, "s2e_%s.regenie" % prep.pheno_names[ph]))[1]})
         hdr, v = _loco(os.path.join(d, "out_%d.loco" % (ph + 1)))
         pos = {s_: k for k, s_ in enumerate(hdr)}
         loco.append(v[:, [pos[i] for i in ids]])
@@ -767,11 +777,12 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
         vidx = {v["rsid"]: k for k, v in enumerate(bgo.variants)}
     nf = ns = 0
     for c in sorted(set(chrom.tolist())):
-        nulls, offs_f = [], []
+        nulls, offs_f, bnulls = [], [], []
         for ph in range(P):
             nl = bt.null_logistic(Yraw[:, ph], X, mask[:, ph], np.nan_to_num(loco[ph][c - 1]), opt)
             bnull = bt.firth_null(Yraw[:, ph], X, mask[:, ph], np.nan_to_num(loco[ph][c - 1]), nl["beta"]) if nl is not None else None
             nulls.append(nl)
+            bnulls.append(bnull)
             offs_f.append(X @ bnull + np.nan_to_num(loco[ph][c - 1]) if bnull is not None else None)
         sel = np.flatnonzero(chrom == c)
         if bgen is None:
@@ -806,6 +817,16 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
                             got = sp[key] * (sgn if key == "bhat" else 1.0)
                             assert abs(got - float(rs[col[nm]])) <= 3e-4 * abs(float(rs[col[nm]])) + 1e-6, ("SPA " + nm, snp_ids[sel[k]], ph, got, rs[col[nm]], flipped)
                     ns += 1
+                if exact:           # fit_firth_logistic_snp (Step2_Models.cpp:1062-1156): the design [covariates | g], the LOCO prediction as offset
+                    re_ = erow[ph].get(snp_ids[sel[k]])
+                    if re_ is not None and re_[col["BETA"]] != "NA" and re_[-1] != "TEST_FAIL":
+                        ex = bt.exact_firth(g, X, Yraw[:, ph], m, loco[ph][c - 1], bnulls[ph])
+                        assert ex is not None, ("exact Firth: no fit", snp_ids[sel[k]], ph)
+                        beta, se, chisq = (float(re_[col[nm]]) for nm in ("BETA", "SE", "CHISQ"))
+                        assert abs(sgn * ex["bhat"] - beta) <= 2e-3 * se * se + 5e-4 * abs(beta) + 5e-6, ("exact Firth BETA", snp_ids[sel[k]], ph, sgn * ex["bhat"], beta, se)
+                        assert abs(ex["se"] - se) <= 1e-3 * se, ("exact Firth SE", snp_ids[sel[k]], ph, ex["se"], se)
+                        assert abs(ex["chisq"] - chisq) <= 3e-3 * abs(chisq) + 1e-4, ("exact Firth CHISQ", snp_ids[sel[k]], ph, ex["chisq"], chisq)
+                        ne += 1
                 if rf[-1] == "TEST_FAIL":
                     continue
                 tq = float(gk[obs & (m > 0)].sum())
@@ -836,6 +857,8 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
                             se = float(y[col["SE"]])
                             bar = 2e-3 * se * se + 3e-4 * abs(float(v)) + 5e-6 if nm == "BETA" else 3e-3 * abs(float(v)) + 5e-5
                             assert abs(float(u) - float(v)) <= bar, ("driver " + nm, extra, x, y)
+    if exact:
+        print("      (exact Firth rows compared: %d)" % ne, flush=True)
     return nf, ns
 
 
