@@ -34,7 +34,9 @@ from tests.golden.make_ref_outputs import table_lines                    # noqa:
 from tests.util import synth_dosages, write_plink                        # noqa: E402
 
 REGENIE = os.path.join(ROOT, "oracle", "_ref", "regenie")
-BIN = os.path.join(ROOT, "regenie_amd", "bin", "regenie-amd")
+BIN = os.environ.get("FUZZ_DRIVER_BIN") or os.path.join(ROOT, "regenie_amd", "bin", "regenie-amd")
+# FUZZ_DRIVER_BIN=<tests/hipcpu/emubuild.py's regenie-amd-hostbt> FUZZ_DRIVER_BT_ONLY=1: the driver with the binary-trait Step-2 kernels running on the
+# host stand-in of the HIP runtime (no GPU): only the corrected-rows leg (FUZZ_BT_STEP2=2) has a driver run then
 
 
 def _loco(path):
@@ -327,7 +329,7 @@ def run_one(seed, work):
             extra += ", corrected: %d Firth + %d SPA rows" % step2_bt_corrections_leg(d, S, o)
         if os.environ["FUZZ_BT_STEP2"] == "3":
             extra += ", from BGEN dosages: %d Firth + %d SPA rows" % step2_bt_corrections_leg(d, S, o, bgen=(g, spec))
-    if os.environ.get("FUZZ_DRIVER"):
+    if os.environ.get("FUZZ_DRIVER") and not os.environ.get("FUZZ_DRIVER_BT_ONLY"):
         extra += " | " + driver_legs(d, args, o, len(names))
     if skipped:
         extra += ", %d trait(s) not converged in both" % skipped
@@ -841,7 +843,8 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
     if os.environ.get("FUZZ_DRIVER"):
         # the product's corrected rows beside regenie's (both stop their fits at a tolerance: the bars of the oracle comparison above).  Variants
         # whose counted allele is the major one are where the carriers of the fast forms are those of 2 - g (flip_geno).
-        for extra, out, ref in ((["--firth", "--approx"], "d2f" + tag, "s2f" + tag), (["--spa"], "d2s" + tag, "s2s" + tag)):
+        ndrv = 0
+        for extra, out, ref in ((["--firth", "--approx"], "d2f" + tag, "s2f" + tag), (["--spa"], "d2s" + tag, "s2s" + tag)) + (((["--firth"], "d2e", "s2e"),) if exact else ()):
             r = subprocess.run([BIN] + base + extra + ["--out", out], cwd=d, capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, "regenie-amd --step 2 --bt %s: " % extra[0] + (r.stdout + r.stderr)[-500:]
             for ph in range(P):
@@ -857,6 +860,8 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
                             se = float(y[col["SE"]])
                             bar = 2e-3 * se * se + 3e-4 * abs(float(v)) + 5e-6 if nm == "BETA" else 3e-3 * abs(float(v)) + 5e-5
                             assert abs(float(u) - float(v)) <= bar, ("driver " + nm, extra, x, y)
+                    ndrv += 1
+        print("      (driver rows held to regenie's: %d)" % ndrv, flush=True)
     if exact:
         print("      (exact Firth rows compared: %d)" % ne, flush=True)
     return nf, ns

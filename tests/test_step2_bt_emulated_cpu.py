@@ -139,3 +139,23 @@ def test_shapes_the_gpu_tests_do_not_visit(gpu_tests, n):
         k += 1
         nf, ns = _one_shape(gpu_tests, 2000 + 10 * n + k, n, Cc, P, 9, route, miss_y, n + (k % 3) * 50)
         assert nf >= 7 * P and ns >= 5 * P
+
+
+REGENIE = os.path.join(ROOT, "oracle", "_ref", "regenie")
+
+
+@pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")
+def test_the_driver_on_emulated_kernels_beside_regenie_itself(tmp_path, monkeypatch):
+    """`regenie-amd --step 2 --bt --firth --approx | --spa` -- the driver as shipped, linked with step2_bt.hip on the host stand-in (tests/hipcpu/emubuild.py) --
+    beside regenie on two drawn cases of tests/golden/fuzz_oracle_vs_reference.py, from the .bed and from the same genotypes as BGEN dosages; the second case
+    runs with --ref-first, so every variant counts its major allele and the carriers of the fast forms are those of 2 - g (flip_geno).  The 100-case run of
+    the round is tests/golden/fuzz_driver_log.md."""
+    from tests.golden import fuzz_oracle_vs_reference as fz
+    from tests.hipcpu.emubuild import build_bt_step2_driver
+    monkeypatch.setattr(fz, "BIN", build_bt_step2_driver(str(tmp_path / "build")))
+    for k, v in dict(FUZZ_ROUTES="bt_loocv", FUZZ_BT_STEP2="3", FUZZ_DRIVER="1", FUZZ_DRIVER_BT_ONLY="1", RG_S2_BGEN_ROWS="1").items():
+        monkeypatch.setenv(k, v)
+    for seed in (3, 6):
+        line, ok = fz.run_one(seed, str(tmp_path))
+        assert ok, line
+        assert "from BGEN dosages" in line
