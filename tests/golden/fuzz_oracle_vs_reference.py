@@ -722,6 +722,24 @@ def step2_bt_leg(d, S, o):
                 assert abs(s2.get_logp(out["chisq"]) - logp) <= 1e-4 * abs(logp) + 2e-6, ("LOG10P", snp_ids[sel[k]], ph)
                 ncmp += 1
     assert ncmp > 0
+    if os.environ.get("FUZZ_DRIVER"):          # the product's lines beside regenie's (closed-form score test: byte-identical but for the last digit)
+        r = subprocess.run([BIN] + args + ["--out", "d2"], cwd=d, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, "regenie-amd --step 2 %s: " % ("--ct" if ct else "--bt") + (r.stdout + r.stderr)[-500:]
+        same = tot = 0
+        for ph in range(P):
+            a = open(os.path.join(d, "d2_%s.regenie" % prep.pheno_names[ph])).read().splitlines()
+            b = open(os.path.join(d, "s2_%s.regenie" % prep.pheno_names[ph])).read().splitlines()
+            assert a[0] == b[0] and len(a) == len(b), "driver .regenie header / line count"
+            for x, y in zip(a[1:], b[1:]):
+                tot += 1
+                if x == y:
+                    same += 1
+                    continue
+                tx, ty = x.split(" "), y.split(" ")
+                assert len(tx) == len(ty) and tx[:5] == ty[:5], (x, y)
+                for u, v in zip(tx[5:], ty[5:]):
+                    assert u == v or (u != "NA" and v != "NA" and abs(float(u) - float(v)) <= 5e-5 * abs(float(v)) + 2e-6), (x, y)
+        print("      (driver, score test: %d of %d lines byte-identical to regenie's)" % (same, tot), flush=True)
     return ncmp
 
 
@@ -749,7 +767,10 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
     base += ["--strict"] if o["strict"] else []
     base += _prep_args(S, o)
     exact = os.environ.get("FUZZ_BT_EXACT") and bgen is None        # also --firth without --approx (a C + 1 parameter fit per flagged test)
-    for extra, out in ((["--firth", "--approx"], "s2f" + tag), (["--spa"], "s2s" + tag)) + (((["--firth"], "s2e"),) if exact else ()):
+    # FUZZ_BT_FIRTH_SE: a third of the cases print the Firth SE as |BETA| / sqrt(LRT) (--firth-se, back_correct_se: Step2_Models.cpp:2008-2009)
+    firth_se = bool(os.environ.get("FUZZ_BT_FIRTH_SE")) and sum(map(ord, os.path.basename(d))) % 3 == 0
+    fse = ["--firth-se"] if firth_se else []
+    for extra, out in ((["--firth", "--approx"] + fse, "s2f" + tag), (["--spa"], "s2s" + tag)) + (((["--firth"] + fse, "s2e"),) if exact else ()):
         r = subprocess.run([REGENIE] + base + extra + ["--out", out], cwd=d, capture_output=True, text=True)
         assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, bt=True, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
@@ -826,7 +847,8 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
                         assert ex is not None, ("exact Firth: no fit", snp_ids[sel[k]], ph)
                         beta, se, chisq = (float(re_[col[nm]]) for nm in ("BETA", "SE", "CHISQ"))
                         assert abs(sgn * ex["bhat"] - beta) <= 2e-3 * se * se + 5e-4 * abs(beta) + 5e-6, ("exact Firth BETA", snp_ids[sel[k]], ph, sgn * ex["bhat"], beta, se)
-                        assert abs(ex["se"] - se) <= 1e-3 * se, ("exact Firth SE", snp_ids[sel[k]], ph, ex["se"], se)
+                        want_se = abs(ex["bhat"]) / np.sqrt(ex["chisq"]) if firth_se and ex["chisq"] > 0 else ex["se"]
+                        assert abs(want_se - se) <= (4e-3 if firth_se else 1e-3) * se, ("exact Firth SE", snp_ids[sel[k]], ph, want_se, se)
                         assert abs(ex["chisq"] - chisq) <= 3e-3 * abs(chisq) + 1e-4, ("exact Firth CHISQ", snp_ids[sel[k]], ph, ex["chisq"], chisq)
                         ne += 1
                 if rf[-1] == "TEST_FAIL":
@@ -837,14 +859,15 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
                 assert fo is not None, ("approximate Firth: no fit", snp_ids[sel[k]], ph)
                 beta, se, chisq = (float(rf[col[nm]]) for nm in ("BETA", "SE", "CHISQ"))
                 assert abs(sgn * fo["bhat"] - beta) <= 2e-3 * se * se + 3e-4 * abs(beta) + 5e-6, ("Firth BETA", snp_ids[sel[k]], ph, sgn * fo["bhat"], beta, se, flipped)
-                assert abs(fo["se"] - se) <= 5e-4 * se, ("Firth SE", snp_ids[sel[k]], ph, fo["se"], se)
+                want_se = abs(fo["bhat"]) / np.sqrt(fo["chisq"]) if firth_se and fo["chisq"] > 0 else fo["se"]
+                assert abs(want_se - se) <= (4e-3 if firth_se else 5e-4) * se + 1e-6, ("Firth SE", snp_ids[sel[k]], ph, want_se, se, firth_se)
                 assert abs(fo["chisq"] - chisq) <= 3e-3 * abs(chisq) + 5e-5, ("Firth CHISQ", snp_ids[sel[k]], ph, fo["chisq"], chisq)
                 nf += 1
     if os.environ.get("FUZZ_DRIVER"):
         # the product's corrected rows beside regenie's (both stop their fits at a tolerance: the bars of the oracle comparison above).  Variants
         # whose counted allele is the major one are where the carriers of the fast forms are those of 2 - g (flip_geno).
         ndrv = 0
-        for extra, out, ref in ((["--firth", "--approx"], "d2f" + tag, "s2f" + tag), (["--spa"], "d2s" + tag, "s2s" + tag)) + (((["--firth"], "d2e", "s2e"),) if exact else ()):
+        for extra, out, ref in ((["--firth", "--approx"] + fse, "d2f" + tag, "s2f" + tag), (["--spa"], "d2s" + tag, "s2s" + tag)) + (((["--firth"] + fse, "d2e", "s2e"),) if exact else ()):
             r = subprocess.run([BIN] + base + extra + ["--out", out], cwd=d, capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, "regenie-amd --step 2 --bt %s: " % extra[0] + (r.stdout + r.stderr)[-500:]
             for ph in range(P):
