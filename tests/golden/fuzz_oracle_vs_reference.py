@@ -263,6 +263,7 @@ def run_one(seed, work):
     args += ["--loocv"] if o["loocv"] else []
     args += ["--ref-first"] if o["ref_first"] else []
     args += ["--strict"] if o["strict"] else []
+    args += ["--write-null-firth"] if o["bt"] and os.environ.get("FUZZ_BT_NULLFIRTH") else []       # out_<k>.firth + out_firth.list for --use-null-firth in Step 2
     prep_desc = ""
     if os.environ.get("FUZZ_PREP"):
         pr = draw_prep(seed, route)
@@ -681,6 +682,8 @@ def step2_bt_leg(d, S, o):
     args += ["--ref-first"] if o["ref_first"] else []
     args += ["--strict"] if o["strict"] else []
     args += _prep_args(S, o)
+    if os.environ.get("FUZZ_BT_MINMAC"):       # which tests are left out (compute_mac, Geno.cpp:3077-3108; the trait's own counts where its mask differs): rows of NA in both files
+        args += ["--minMAC", str([10, 40, 120][sum(map(ord, os.path.basename(d))) % 3])]
     r = subprocess.run([REGENIE] + args + ["--out", "s2"], cwd=d, capture_output=True, text=True)
     assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, bt=not ct, ct=ct, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
@@ -769,8 +772,11 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
     exact = os.environ.get("FUZZ_BT_EXACT") and bgen is None        # also --firth without --approx (a C + 1 parameter fit per flagged test)
     # FUZZ_BT_FIRTH_SE: a third of the cases print the Firth SE as |BETA| / sqrt(LRT) (--firth-se, back_correct_se: Step2_Models.cpp:2008-2009)
     firth_se = bool(os.environ.get("FUZZ_BT_FIRTH_SE")) and sum(map(ord, os.path.basename(d))) % 3 == 0
-    fse = ["--firth-se"] if firth_se else []
-    for extra, out in ((["--firth", "--approx"] + fse, "s2f" + tag), (["--spa"], "s2s" + tag)) + (((["--firth"] + fse, "s2e"),) if exact else ()):
+    fse, unf = (["--firth-se"] if firth_se else []), []
+    # FUZZ_BT_NULLFIRTH: every other case starts its null Firth fits from the estimates Step 1 wrote (--use-null-firth, Step2_Models.cpp:899-984)
+    if os.environ.get("FUZZ_BT_NULLFIRTH") and sum(map(ord, os.path.basename(d))) % 2 == 0 and os.path.exists(os.path.join(d, "out_firth.list")):
+        unf = ["--use-null-firth", "out_firth.list"]
+    for extra, out in ((["--firth", "--approx"] + fse + unf, "s2f" + tag), (["--spa"], "s2s" + tag)) + (((["--firth"] + fse, "s2e"),) if exact else ()):
         r = subprocess.run([REGENIE] + base + extra + ["--out", out], cwd=d, capture_output=True, text=True)
         assert r.returncode == 0, (r.stdout + r.stderr)[-600:]
     opt = orc.Step1Options(bed=S, pheno_file=S + ".pheno", covar_file=S + ".covar", bsize=200, bt=True, ref_first=o["ref_first"], strict=o["strict"], test_mode=True,
@@ -867,7 +873,7 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
         # the product's corrected rows beside regenie's (both stop their fits at a tolerance: the bars of the oracle comparison above).  Variants
         # whose counted allele is the major one are where the carriers of the fast forms are those of 2 - g (flip_geno).
         ndrv = 0
-        for extra, out, ref in ((["--firth", "--approx"] + fse, "d2f" + tag, "s2f" + tag), (["--spa"], "d2s" + tag, "s2s" + tag)) + (((["--firth"] + fse, "d2e", "s2e"),) if exact else ()):
+        for extra, out, ref in ((["--firth", "--approx"] + fse + unf, "d2f" + tag, "s2f" + tag), (["--spa"], "d2s" + tag, "s2s" + tag)) + (((["--firth"] + fse, "d2e", "s2e"),) if exact else ()):
             r = subprocess.run([BIN] + base + extra + ["--out", out], cwd=d, capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, "regenie-amd --step 2 --bt %s: " % extra[0] + (r.stdout + r.stderr)[-500:]
             for ph in range(P):
