@@ -326,10 +326,12 @@ def run_one(seed, work):
         extra = ", step 2 --ct (score test): %d statistics" % step2_bt_leg(d, S, o)
     elif o["bt"] and os.environ.get("FUZZ_BT_STEP2"):
         extra = ", step 2 (score test): %d statistics" % step2_bt_leg(d, S, o)
-        if os.environ["FUZZ_BT_STEP2"] in ("2", "3"):
+        if os.environ["FUZZ_BT_STEP2"] in ("2", "3", "4"):
             extra += ", corrected: %d Firth + %d SPA rows" % step2_bt_corrections_leg(d, S, o)
         if os.environ["FUZZ_BT_STEP2"] == "3":
             extra += ", from BGEN dosages: %d Firth + %d SPA rows" % step2_bt_corrections_leg(d, S, o, bgen=(g, spec))
+        if os.environ["FUZZ_BT_STEP2"] == "4":
+            extra += ", from a .pgen with dosages: %d Firth + %d SPA rows" % step2_bt_corrections_leg(d, S, o, pgen=(g, spec))
     if os.environ.get("FUZZ_DRIVER") and not os.environ.get("FUZZ_DRIVER_BT_ONLY"):
         extra += " | " + driver_legs(d, args, o, len(names))
     if skipped:
@@ -746,7 +748,7 @@ def step2_bt_leg(d, S, o):
     return ncmp
 
 
-def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
+def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None, pgen=None):
     """regenie --step 2 --bt with --firth --approx and with --spa (p-value threshold 0.2: a fifth of the tests are corrected) against
     oracle/regenie_step2_bt.py: null Firth model, the 1-parameter approximate Firth fit (on the carriers only for sparse rare variants),
     the saddlepoint approximation (its fast form for sparse variants; a test regenie reports as TEST_FAIL has no root here either).
@@ -760,6 +762,16 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
     # non-zero DOSAGES of the coding regenie tests -- after flip_geno the entries that are not exactly 2
     src = ["--bed", S] if bgen is None else ["--bgen", S + ".bgen", "--sample", S + ".sample"]
     tag = "" if bgen is None else "b"
+    if pgen is not None:
+        # pgen = (genotypes, spec): the case as a .pgen with a dosage track on two fifths of the calls; check_sparse_G then takes the zeros the reader
+        # counted BEFORE flip_geno (prep_snp_stats, Geno.cpp:2582-2594) while the carriers of the fast forms are those of the flipped coding
+        from oracle import pgen as opg
+        from tests.util import write_synth_pgen
+        if not os.path.exists(S + "_p.pgen"):
+            # FUZZ_PGEN_HARD: every other case is a .pgen of hard calls only (the driver then hands the library 2-bit rows, as for a .bed)
+            soft = 0.0 if os.environ.get("FUZZ_PGEN_HARD") and sum(map(ord, os.path.basename(d))) % 2 else 0.4
+            write_synth_pgen(S + "_p", pgen[0], pgen[1]["chroms"], seed=pgen[1]["seed"], soft=soft)
+        src, tag = ["--pgen", S + "_p"], "p"
     if bgen is not None:
         from oracle import bgen as obg
         from tests.util import write_synth_bgen
@@ -769,7 +781,7 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
     base += ["--ref-first"] if o["ref_first"] else []
     base += ["--strict"] if o["strict"] else []
     base += _prep_args(S, o)
-    exact = os.environ.get("FUZZ_BT_EXACT") and bgen is None        # also --firth without --approx (a C + 1 parameter fit per flagged test)
+    exact = os.environ.get("FUZZ_BT_EXACT") and bgen is None and pgen is None        # also --firth without --approx (a C + 1 parameter fit per flagged test)
     # FUZZ_BT_FIRTH_SE: a third of the cases print the Firth SE as |BETA| / sqrt(LRT) (--firth-se, back_correct_se: Step2_Models.cpp:2008-2009)
     firth_se = bool(os.environ.get("FUZZ_BT_FIRTH_SE")) and sum(map(ord, os.path.basename(d))) % 3 == 0
     fse, unf = (["--firth-se"] if firth_se else []), []
@@ -801,7 +813,9 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
     X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
     zthr = float(norm.ppf(1 - pthresh / 2))
     n_all = int((~prep.ind_ignore).sum())
-    if bgen is not None:
+    if pgen is not None:
+        pgo = opg.PgenOracle(S + "_p.pgen")
+    elif bgen is not None:
         bgo = obg.BgenOracle(S + ".bgen")
         vidx = {v["rsid"]: k for k, v in enumerate(bgo.variants)}
     nf = ns = 0
@@ -814,17 +828,19 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None):
             bnulls.append(bnull)
             offs_f.append(X @ bnull + np.nan_to_num(loco[ph][c - 1]) if bnull is not None else None)
         sel = np.flatnonzero(chrom == c)
-        if bgen is None:
+        if bgen is None and pgen is None:
             G = orc.decode_bed_rows(np.asarray(bed[offs[sel]]), prep.n_file)[:, ~prep.ind_ignore][:, ia]
             if o["ref_first"]:
                 G = np.where(G < 0, G, 2.0 - G)
+        elif pgen is not None:
+            G = np.stack([pgo.dosages(int(j))[~prep.ind_ignore][ia] for j in offs[sel]])
         else:
             G = np.stack([bgo.dosages(vidx[snp_ids[k]], o["ref_first"])[~prep.ind_ignore][ia] for k in sel])
         for k in range(sel.size):
             gk, flipped = bt.flip_geno(G[k])          # regenie tests the MINOR allele and negates BETA back
             sgn = -1.0 if flipped else 1.0
             g, _, _ = s2.mean_impute(gk)
-            sparse = s2.check_sparse(g, n_all)
+            sparse = s2.check_sparse(g, n_all) if pgen is None else int(np.count_nonzero(G[k] == 0.0)) >= n_all * 0.5
             obs = gk >= 0
             for ph in range(P):
                 rf, rs = frow[ph].get(snp_ids[sel[k]]), srow[ph].get(snp_ids[sel[k]])

@@ -147,7 +147,7 @@ REGENIE = os.path.join(ROOT, "oracle", "_ref", "regenie")
 @pytest.mark.skipif(not os.path.exists(REGENIE), reason="oracle/_ref/regenie not built (make -C oracle)")
 def test_the_driver_on_emulated_kernels_beside_regenie_itself(tmp_path, monkeypatch):
     """`regenie-amd --step 2 --bt --firth --approx | --spa` -- the driver as shipped, linked with step2_bt.hip on the host stand-in (tests/hipcpu/emubuild.py) --
-    beside regenie on two drawn cases of tests/golden/fuzz_oracle_vs_reference.py, from the .bed and from the same genotypes as BGEN dosages; the second case
+    beside regenie on two drawn cases of tests/golden/fuzz_oracle_vs_reference.py, from the .bed, from the same genotypes as BGEN dosages and (third case) as a .pgen with a dosage track; the second case
     runs with --ref-first, so every variant counts its major allele and the carriers of the fast forms are those of 2 - g (flip_geno).  The 100-case run of
     the round is tests/golden/fuzz_driver_log.md."""
     from tests.golden import fuzz_oracle_vs_reference as fz
@@ -159,3 +159,6 @@ def test_the_driver_on_emulated_kernels_beside_regenie_itself(tmp_path, monkeypa
         line, ok = fz.run_one(seed, str(tmp_path))
         assert ok, line
         assert "from BGEN dosages" in line
+    monkeypatch.setenv("FUZZ_BT_STEP2", "4")             # and from a .pgen with a dosage track: the reader's zero count decides `sparse` (before the flip)
+    line, ok = fz.run_one(5, str(tmp_path))
+    assert ok and "from a .pgen with dosages" in line, line
