@@ -86,6 +86,7 @@ class Reader {
       std::memcpy(&lsi, b, 4);
       std::memcpy(&ns, b + 4, 4);
       if (ns != n_) throw std::runtime_error("bgen sample block does not match the header's sample count : " + path);
+      if ((uint64_t)lsi > fsize_ || 2ull * ns > fsize_) throw std::runtime_error("malformed bgen sample block : " + path);       // (refused before a buffer of that length is allocated)
       std::vector<uint8_t> blk(lsi > 8 ? lsi - 8 : 0);
       if (!blk.empty() && !pread_all(blk.data(), blk.size(), pos + 8)) throw std::runtime_error("cannot read bgen sample block : " + path);
       size_t p = 0;
@@ -101,6 +102,8 @@ class Reader {
     }
     // variant scan: identifying data, then skip the genotype block
     pos = 4ull + offset;
+    // a variant's identifying data and block length take 24 bytes or more: a damaged count is refused before the table is reserved for it
+    if (24ull * m_ > fsize_) throw std::runtime_error("invalid bgen header (more variants than the file can hold) : " + path);
     vars_.reserve(m_);
     // the identifying data of a variant is a few dozen bytes in front of a genotype block that is skipped: one small read
     // per variant (a window that is refilled when a field runs past it) instead of one system call per field
@@ -186,6 +189,8 @@ class Reader {
       if (c < 4 || !pread_all(&d, 4, v.data + 4)) throw std::runtime_error("failed to decompress genotype data block for variant: " + v.rsid);
       if (d > most) throw std::runtime_error("genotype data block of variant " + v.rsid + " is larger than any biallelic diploid block of " + std::to_string(n_) + " samples");
       if ((uint64_t)c > fsize_) throw std::runtime_error("failed to decompress genotype data block for variant: " + v.rsid);
+      // (neither DEFLATE nor zstd's block format expands beyond ~1,030 : 1 / 2^17 per block byte: a length no stream of c bytes can reach is refused before the buffer for it exists)
+      if (comp_ == 1 && (uint64_t)d > 1100ull * c + 64) throw std::runtime_error("failed to decompress genotype data block for variant: " + v.rsid);
       cbuf.resize(c - 4);
       if (c > 4 && !pread_all(cbuf.data(), c - 4, v.data + 8)) throw std::runtime_error("cannot read bgen file");
       blk = room(d);

@@ -113,6 +113,9 @@ class Reader {
     std::memcpy(&n_, h + 7, 4);
     if (m_ == 0 || n_ == 0 || m_ > 0x7ffffffdu || n_ > 0x7ffffffeu)
       throw std::runtime_error("invalid variant or sample count in pgen file : " + path);
+    // every variant owns at least one byte of the file (a fixed-width row, or its record-length byte in the header): a damaged count is
+    // refused here, before the per-variant tables (9 bytes each) are allocated for it
+    if ((uint64_t)m_ > fsize_) throw std::runtime_error("invalid pgen header (more variants than bytes in the file) : " + path);
     const uint8_t ctrl = h[11];
     bpr_ = ((int64_t)n_ + 3) / 4;
     sample_id_bytes_ = (31 - __builtin_clz(n_)) / 8 + 1;

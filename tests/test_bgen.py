@@ -90,6 +90,23 @@ def test_refusals_and_damage(tmp_path, example_dir):
     p = str(tmp_path / "t.bgen")
     open(p, "wb").write(raw[:len(raw) - 100])
     assert err(p).code == -2
+    # a damaged variant count (bytes 8 - 11 of the header) is refused before the variant table is reserved for it
+    big = bytearray(raw)
+    big[11] = 0x70
+    open(p, "wb").write(big)
+    e = err(p)
+    assert e.code == -2 and "more variants than the file can hold" in str(e)
+    # ... and a block whose stated inflated length no stream of its stored length can reach, before the buffer for it exists
+    o0 = obg.BgenOracle(os.path.join(example_dir, "example_3chr.bgen"))
+    far = bytearray(raw)
+    at0 = o0.variants[2]["data"]
+    clen = int.from_bytes(raw[at0:at0 + 4], "little")
+    far[at0 + 4:at0 + 8] = (1100 * clen + 65).to_bytes(4, "little")
+    open(p, "wb").write(far)
+    with BgenFile(p) as f:
+        with pytest.raises(RgError) as e2:
+            f.read_dosages([2])
+        assert e2.value.code == -2
     # a damaged compressed block: the reference's message (Geno.cpp:1616-1617)
     o = obg.BgenOracle(os.path.join(example_dir, "example_3chr.bgen"))
     bad = bytearray(raw)

@@ -4,6 +4,8 @@ and on synthetic files that exercise every record type.  Host-only: runs without
 import ctypes
 import os
 
+import time
+
 import numpy as np
 import pytest
 
@@ -298,6 +300,14 @@ def test_malformed_files_are_errors_not_crashes(tmp_path):
     t = str(tmp_path / "trunc.pgen")
     open(t, "wb").write(raw[:len(raw) - 50])
     assert _open_error(t).code == -2
+    # a damaged variant count (one flipped byte: 40 -> 1.96e9 variants) is refused at once, not after 18 GB of per-variant tables were
+    # allocated for it (found by flipping bytes of small files under AddressSanitizer: the open call took minutes)
+    big = bytearray(raw)
+    big[6] = 117
+    open(t, "wb").write(big)
+    t0 = time.time()
+    e = _open_error(t)
+    assert e.code == -2 and "more variants than bytes" in str(e) and time.time() - t0 < 2.0
     # a difflist whose sample index leaves the file's range
     j = vts.index(4)
     rec0 = int(o.fpos[j])
