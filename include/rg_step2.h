@@ -130,7 +130,9 @@ int rg_s2_set_sparse_rule(rg_s2_ctx* ctx, int64_t n_samples, double prop_zero_th
  *                         form (sparse variants: check_sparse_G's verdict is returned by the score call; Firth adds MAC < 50).  The reference
  *                         tests the MINOR allele (flip_geno, Geno.cpp:3150-3162: 2 - g when the mean dosage exceeds 1, BETA negated back):
  *                         the statistics returned are those of the coding given, `sparse` and the carriers of the fast forms those of the
- *                         coding the reference tests -- the only two things the flip changes.
+ *                         coding the reference tests -- the only two things the flip changes.  The numerator of the statistic is the reference's
+ *                         to the digit: Gres . yres for a dense variant, GW . yres -- the genotype not projected -- for a sparse one
+ *                         (Step2_Models.cpp:517 / :519, :603 / :605; they differ by the null model's score at its stopping point).
  * Layouts as above: [P][n] / [C][n] sample-fastest host arrays.  The exact Firth test (--firth without --approx) is not behind this ABI. */
 typedef struct rg_s2_bt_null {
   int32_t family;             /* 0: binary trait (logistic null model), 1: count trait (Poisson; no corrections) */

@@ -46,10 +46,16 @@ def null_logistic(y_raw, X, mask, loco_offset, opt):
     return dict(p=p, w=w, gamma_sqrt=np.sqrt(w), beta=beta)             # :128-131
 
 
-def score_bt(g, X, y_raw, mask, null, numtol=NUMTOL):
-    """compute_score_bt for one mean-imputed variant and one phenotype (Step2_Models.cpp:486-520, dense form; the sparse form is the
-    same number): GW = g Gamma_sqrt mask, projected off the orthonormal basis of Gamma X (getBasis of X_Gamma, Step1_Models.cpp:132-133),
-    stats = Gres . yres / |Gres| with yres = (y - p) / Gamma_sqrt * mask (Data.cpp:2443-2445); get_sumstats (:2031-2041)."""
+def score_bt(g, X, y_raw, mask, null, numtol=NUMTOL, sparse=False):
+    """compute_score_bt for one mean-imputed variant and one phenotype (Step2_Models.cpp:486-520): GW = g Gamma_sqrt mask, projected off the
+    orthonormal basis of Gamma X (getBasis of X_Gamma, Step1_Models.cpp:132-133), stats = Gres . yres / |Gres| with
+    yres = (y - p) / Gamma_sqrt * mask (Data.cpp:2443-2445; NOT projected); get_sumstats (:2031-2041).
+
+    sparse: check_sparse_G's verdict for the variant.  The sparse form takes GW . yres -- the genotype NOT projected -- as the numerator
+    (:516-517) where the dense one takes Gres . yres (:519).  The two differ by (X^T W g)^T (X^T W X)^-1 X^T (y - p), the null model's
+    score at ITS stopping point times the covariate coefficients of g: regenie stops that model at |score| < 1e-6, so the numbers part in
+    the seventh digit -- which is what kept one line in ten of the product's uncorrected binary-trait rows from being byte-identical to
+    regenie's until this was found (tests/golden/fuzz_driver_log.md; with it, 704 of 704 lines of the case it was found on)."""
     gs_mask = null["gamma_sqrt"] * mask
     XG, _ = orc.get_basis(X * gs_mask[:, None])
     GW = g * gs_mask
@@ -58,7 +64,7 @@ def score_bt(g, X, y_raw, mask, null, numtol=NUMTOL):
     if np.sqrt(denum) < numtol:
         return None
     yres = (y_raw - null["p"]) / null["gamma_sqrt"] * mask
-    stats = float(Gres @ yres) / np.sqrt(denum)
+    stats = float((GW if sparse else Gres) @ yres) / np.sqrt(denum)
     se = 1.0 / np.sqrt(denum)
     return dict(stats=stats, se=se, bhat=stats * se, chisq=stats * stats, denum=denum, Gres=Gres)
 
@@ -78,9 +84,9 @@ def null_poisson(y_raw, X, mask, loco_offset, opt):
     return dict(p=p, w=p, gamma_sqrt=np.sqrt(p), beta=beta)             # :266-268
 
 
-def score_ct(g, X, y_raw, mask, null, numtol=NUMTOL):
+def score_ct(g, X, y_raw, mask, null, numtol=NUMTOL, sparse=False):
     """compute_score_ct (Step2_Models.cpp:559-622): as compute_score_bt with the Poisson weights; the variant is skipped for the trait
-    when denum itself (not its root) is below numtol (:596)."""
+    when denum itself (not its root) is below numtol (:596).  sparse: as in score_bt (the sparse form's numerator is GW . yres, :602-603)."""
     gs_mask = null["gamma_sqrt"] * mask
     XG, _ = orc.get_basis(X * gs_mask[:, None])
     GW = g * gs_mask
@@ -89,7 +95,7 @@ def score_ct(g, X, y_raw, mask, null, numtol=NUMTOL):
     if denum < numtol:
         return None
     yres = (y_raw - null["p"]) / null["gamma_sqrt"] * mask             # compute_res_count, Data.cpp:2457-2465
-    stats = float(Gres @ yres) / np.sqrt(denum)
+    stats = float((GW if sparse else Gres) @ yres) / np.sqrt(denum)
     se = 1.0 / np.sqrt(denum)
     return dict(stats=stats, se=se, bhat=stats * se, chisq=stats * stats)
 

@@ -34,7 +34,7 @@ struct BtState {
   int family = 0;
   bool have_null = false, have_firth = false;
   int ncol = 0;
-  std::vector<double> xwx_inv, msum, xres;     // xres [P][C] = (X^T W X)^-1 X^T ((y - fitted) mask): the null model's residual score, ~0
+  std::vector<double> xwx_inv, msum, xres, rsum;     // xres [P][C] = (X^T W X)^-1 X^T ((y - fitted) mask): the null model's residual score, ~0; rsum [P] = sum of (y - fitted) mask
   std::vector<uint8_t> pass;
   double *dX = nullptr, *dY = nullptr, *dFit = nullptr, *dFo = nullptr;
   uint8_t* dM = nullptr;
@@ -378,8 +378,9 @@ int score_from_sums(rg_s2_ctx* ctx, int bs, double numtol, const int32_t* counts
     const bool flipped = mu > 1.0;
     bt.flip[j] = flipped ? 1 : 0;
     const double nnz_t = flipped ? nobs - ntwo : nnz, mu_t = flipped ? 2.0 - mu : mu;
-    if (out->sparse)   // check_sparse_G (Geno.cpp:3165-3177)
-      out->sparse[j] = ctx->rule_zero_count ? (nobs - nnz) >= Nrule * ctx->rule_thr : (nnz_t + (mu_t != 0.0 ? (double)n - nobs : 0.0)) <= Nrule * (1.0 - ctx->rule_thr);
+    // check_sparse_G (Geno.cpp:3165-3177)
+    const bool sparse_j = ctx->rule_zero_count ? (nobs - nnz) >= Nrule * ctx->rule_thr : (nnz_t + (mu_t != 0.0 ? (double)n - nobs : 0.0)) <= Nrule * (1.0 - ctx->rule_thr);
+    if (out->sparse) out->sparse[j] = sparse_j ? 1 : 0;
     const double* s0 = bt.sums.data() + (size_t)j * 2 * ncol;
     const double* s1 = s0 + ncol;
     for (int q = 0; q < P; ++q) {
@@ -403,7 +404,15 @@ int score_from_sums(rg_s2_ctx* ctx, int bs, double numtol, const int32_t* counts
         denum = sw2 - quad;
         const double sd = std::sqrt(denum);
         if (bt.family == 1 ? !(denum >= numtol) : !(sd >= numtol)) ign = 1;                                    // Step2_Models.cpp:512-517, :596
-        else { st = (s0[cr] + mu * s1[cr] - rcorr) / sd; bh = st / sd; }                                                // get_sumstats (Step2_Models.cpp:2031-2041)
+        else {
+          // The numerator.  Dense form: Gres . yres (Step2_Models.cpp:519, :605) = g~ . r - (X^T W g~)^T (X^T W X)^-1 X^T r with r = (y - p^) mask: yres is not
+          // projected (Data.cpp:2443-2445), Gres is.  SPARSE form: GW . yres (:517, :603) -- the genotype of the coding the reference tests, not projected -- i.e.
+          // g~ . r as it stands, or for a flipped variant (2 - g~) . r, which is -(g~ . r - 2 sum r) in the coding given.  The forms differ by the null model's
+          // score at its stopping point (|score| < 1e-6): the seventh digit of the statistic, and every tenth printed line.
+          const double gr = s0[cr] + mu * s1[cr];
+          const double num = !sparse_j ? gr - rcorr : (flipped ? gr - 2.0 * bt.rsum[q] : gr);
+          st = num / sd; bh = st / sd;                                                                                    // get_sumstats (Step2_Models.cpp:2031-2041)
+        }
       }
       bt.denum[(size_t)j * P + q] = ign ? 0.0 : denum;
       bt.stats[(size_t)j * P + q] = st;
@@ -444,6 +453,7 @@ int rg_s2_bt_set_null(rg_s2_ctx* ctx, const rg_s2_bt_null* nm) {
   bt.pass.assign(P, 1);
   if (nm->pass) bt.pass.assign(nm->pass, nm->pass + P);
   bt.msum.assign(P, 0.0);
+  bt.rsum.assign(P, 0.0);
   bt.xwx_inv.assign((size_t)P * C * C, 0.0);
   bt.xres.assign((size_t)P * C, 0.0);
   // the contraction columns [w_q] (also against g^2) | [w_q x_c] | [y_q - fitted_q] | [mask_q], and (X^T W X)^-1 per trait
@@ -471,6 +481,7 @@ int rg_s2_bt_set_null(rg_s2_ctx* ctx, const rg_s2_bt_null* nm) {
       }
     }
     bt.msum[q] = ms;
+    { double rs = 0.0; for (int64_t k = 0; k < n; ++k) rs += cr[k]; bt.rsum[q] = rs; }
     if (!bt.pass[q]) continue;
     for (int a = 0; a < C; ++a) for (int c = a + 1; c < C; ++c) A[(size_t)a * C + c] = A[(size_t)c * C + a];
     if (!small_inverse(A, C, inv)) return rg_s2_fail(ctx, RG_S2_ERR_ARG, "rg_s2_bt_set_null: X'WX is singular in the null model of trait " + std::to_string(q + 1));

@@ -704,7 +704,7 @@ def step2_bt_leg(d, S, o):
         col = {nm: i for i, nm in enumerate(h)}
         rows.append({r_[col["ID"]]: r_ for r_ in body})
     X, Yraw, mask = prep.X[ia], prep.Y_raw[ia], prep.mask[ia]
-    ncmp = 0
+    ncmp = nline = nexact = 0
     for c in sorted(set(chrom.tolist())):
         nulls = [(bt.null_poisson if ct else bt.null_logistic)(Yraw[:, ph], X, mask[:, ph], loco[ph][c - 1], opt) for ph in range(P)]
         sel = np.flatnonzero(chrom == c)
@@ -712,21 +712,27 @@ def step2_bt_leg(d, S, o):
         if o["ref_first"]:
             G = np.where(G < 0, G, 2.0 - G)
         for k in range(sel.size):
-            g, mean, nobs = s2.mean_impute(G[k])
+            gk, flipped = bt.flip_geno(G[k])           # the minor allele is tested (BETA negated back); the sparse form's numerator is GW . yres
+            g, mean, nobs = s2.mean_impute(gk)
+            sparse = s2.check_sparse(g, int((~prep.ind_ignore).sum()))
             for ph in range(P):
                 r_ = rows[ph].get(snp_ids[sel[k]])
                 if r_ is None or r_[col["BETA"]] == "NA" or nulls[ph] is None:
                     continue
-                out = (bt.score_ct if ct else bt.score_bt)(g, X, Yraw[:, ph], mask[:, ph].astype(np.float64), nulls[ph])
+                out = (bt.score_ct if ct else bt.score_bt)(g, X, Yraw[:, ph], mask[:, ph].astype(np.float64), nulls[ph], sparse=sparse)
                 if out is None:
                     continue
+                out["bhat"] = -out["bhat"] if flipped else out["bhat"]
                 beta, se, chisq, logp = (float(r_[col[nm]]) for nm in ("BETA", "SE", "CHISQ", "LOG10P"))
+                nline += 1
+                nexact += all(("%g" % float("%.6g" % v)) == ("%g" % w) for v, w in ((out["bhat"], beta), (out["se"], se), (out["chisq"], chisq)))
                 assert abs(out["bhat"] - beta) <= 5e-5 * abs(beta) + 2e-6, ("BETA", snp_ids[sel[k]], ph, out["bhat"], beta)
                 assert abs(out["se"] - se) <= 5e-5 * abs(se), ("SE", snp_ids[sel[k]], ph, out["se"], se)
                 assert abs(out["chisq"] - chisq) <= 1e-4 * abs(chisq) + 2e-6, ("CHISQ", snp_ids[sel[k]], ph, out["chisq"], chisq)
                 assert abs(s2.get_logp(out["chisq"]) - logp) <= 1e-4 * abs(logp) + 2e-6, ("LOG10P", snp_ids[sel[k]], ph)
                 ncmp += 1
     assert ncmp > 0
+    print("      (oracle: %d of %d rows round to regenie's printed BETA / SE / CHISQ)" % (nexact, nline), flush=True)
     if os.environ.get("FUZZ_DRIVER"):          # the product's lines beside regenie's (closed-form score test: byte-identical but for the last digit)
         r = subprocess.run([BIN] + args + ["--out", "d2"], cwd=d, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, "regenie-amd --step 2 %s: " % ("--ct" if ct else "--bt") + (r.stdout + r.stderr)[-500:]
@@ -847,7 +853,7 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None, pgen=None):
                 if rf is None or nulls[ph] is None or offs_f[ph] is None or rf[col["BETA"]] == "NA":
                     continue
                 m = mask[:, ph].astype(np.float64)
-                out = bt.score_bt(g, X, Yraw[:, ph], m, nulls[ph])
+                out = bt.score_bt(g, X, Yraw[:, ph], m, nulls[ph], sparse=sparse)
                 if abs(out["stats"]) <= zthr * (1 + 1e-9) + 1e-9:
                     continue
                 if abs(abs(out["stats"]) - zthr) < 1e-6 * zthr:          # (a tie with the threshold is decided by the last bits)

@@ -600,7 +600,7 @@ def test_step2_bt_approx_firth_rare_variants_against_reference(tmp_path):
                 if r is None:
                     continue
                 m = mask[:, ph].astype(np.float64)
-                out = bt.score_bt(g, X, Yraw[:, ph], m, nulls[ph])
+                out = bt.score_bt(g, X, Yraw[:, ph], m, nulls[ph], sparse=sparse)
                 if abs(out["stats"]) > zthr:
                     # --spa on the same data (bt_spa_rare): the fast form for sparse variants, one test regenie reports as TEST_FAIL
                     sp = bt.spa_test(out["stats"], out["denum"], out["Gres"], nulls[ph], m, carriers=np.flatnonzero(g != 0) if sparse else None)

@@ -94,7 +94,7 @@ def _one_shape(t, seed, n, Cc, P, bs, route, miss_y, nrule):
             sparse = int((g != 0).sum()) <= 0.5 * nrule
             assert bool(got["sparse"][j]) == sparse, ("sparse", j, flipped)
             for q in range(P):
-                ref = bt.score_bt(g, X, y[:, q], mask[:, q].astype(float), nulls[q])
+                ref = bt.score_bt(g, X, y[:, q], mask[:, q].astype(float), nulls[q], sparse=sparse)
                 if ref is None:
                     assert got["test_ignored"][j, q]; continue
                 assert not got["test_ignored"][j, q]

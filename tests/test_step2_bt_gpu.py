@@ -72,7 +72,7 @@ def test_bt_score_and_corrections_against_the_oracle(route):
             nnz = int((g != 0).sum())
             assert bool(got["sparse"][j]) == (nnz <= 0.5 * n)
             for q in range(P):
-                ref = bt.score_bt(g, X, y[:, q], mask[:, q].astype(float), nulls[q])
+                ref = bt.score_bt(g, X, y[:, q], mask[:, q].astype(float), nulls[q], sparse=nnz <= 0.5 * n)      # (the sparse form's numerator: GW . yres)
                 assert ref is not None and not got["test_ignored"][j, q]
                 assert got["stats"][j, q] == pytest.approx(ref["stats"], rel=1e-9, abs=1e-10)
                 assert got["bhat"][j, q] == pytest.approx(ref["bhat"], rel=1e-9, abs=1e-12)
@@ -153,7 +153,7 @@ def test_bt_corrections_on_the_allele_the_reference_tests(route):
             nflip += flipped
             nflip_sparse += flipped and sparse
             for q in range(P):
-                ref = bt.score_bt(g, X, y[:, q], mask[:, q].astype(float), nulls[q])
+                ref = bt.score_bt(g, X, y[:, q], mask[:, q].astype(float), nulls[q], sparse=sparse)
                 assert ref is not None and not got["test_ignored"][j, q]
                 assert got["stats"][j, q] == pytest.approx(sgn * ref["stats"], rel=1e-9, abs=1e-10)
                 assert got["bhat"][j, q] == pytest.approx(sgn * ref["bhat"], rel=1e-9, abs=1e-12)
