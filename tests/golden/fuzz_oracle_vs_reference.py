@@ -894,7 +894,7 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None, pgen=None):
     if os.environ.get("FUZZ_DRIVER"):
         # the product's corrected rows beside regenie's (both stop their fits at a tolerance: the bars of the oracle comparison above).  Variants
         # whose counted allele is the major one are where the carriers of the fast forms are those of 2 - g (flip_geno).
-        ndrv = 0
+        ndrv = nsame = 0
         for extra, out, ref in ((["--firth", "--approx"] + fse + unf, "d2f" + tag, "s2f" + tag), (["--spa"], "d2s" + tag, "s2s" + tag)) + (((["--firth"] + fse, "d2e", "s2e"),) if exact else ()):
             r = subprocess.run([BIN] + base + extra + ["--out", out], cwd=d, capture_output=True, text=True, timeout=900)
             assert r.returncode == 0, "regenie-amd --step 2 --bt %s: " % extra[0] + (r.stdout + r.stderr)[-500:]
@@ -903,6 +903,7 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None, pgen=None):
                 h2, b = pin._read_regenie(os.path.join(d, "%s_%s.regenie" % (ref, prep.pheno_names[ph])))
                 assert h == h2 and len(a) == len(b), ("driver rows", extra, ph, len(a), len(b))
                 for x, y in zip(a, b):
+                    nsame += x == y
                     assert x[:5] == y[:5] and x[-1] == y[-1], ("driver row", extra, x, y)
                     for nm in ("BETA", "SE", "CHISQ", "LOG10P"):
                         u, v = x[col[nm]], y[col[nm]]
@@ -912,7 +913,7 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None, pgen=None):
                             bar = 2e-3 * se * se + 3e-4 * abs(float(v)) + 5e-6 if nm == "BETA" else 3e-3 * abs(float(v)) + 5e-5
                             assert abs(float(u) - float(v)) <= bar, ("driver " + nm, extra, x, y)
                     ndrv += 1
-        print("      (driver rows held to regenie's: %d)" % ndrv, flush=True)
+        print("      (driver rows held to regenie's: %d, %d of them identical in every printed digit)" % (ndrv, nsame), flush=True)
     if exact:
         print("      (exact Firth rows compared: %d)" % ne, flush=True)
     return nf, ns
