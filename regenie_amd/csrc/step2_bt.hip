@@ -486,8 +486,9 @@ int rg_s2_bt_set_null(rg_s2_ctx* ctx, const rg_s2_bt_null* nm) {
     for (int a = 0; a < C; ++a) for (int c = a + 1; c < C; ++c) A[(size_t)a * C + c] = A[(size_t)c * C + a];
     if (!small_inverse(A, C, inv)) return rg_s2_fail(ctx, RG_S2_ERR_ARG, "rg_s2_bt_set_null: X'WX is singular in the null model of trait " + std::to_string(q + 1));
     std::copy(inv.begin(), inv.end(), bt.xwx_inv.begin() + (size_t)q * C * C);
-    // the reference projects the covariates out of BOTH factors of Gres . yres (Step2_Models.cpp:503, :528-531): the second projection
-    // contributes (X^T W g~)^T (X^T W X)^-1 X^T (y - p^), which is the null model's score at its stopping point -- tiny, not zero
+    // the dense form's numerator is Gres . yres with Gres = the genotype projected off the covariates and yres NOT projected (Step2_Models.cpp:503, :519;
+    // Data.cpp:2443-2445) = g~ . r - (X^T W g~)^T (X^T W X)^-1 X^T r, r = (y - p^) mask: the second term is the null model's score at its stopping point
+    // (|score| < 1e-6) -- tiny, not zero, and absent from the sparse form (score_from_sums)
     for (int a = 0; a < C; ++a) {
       double t = 0.0;
       for (int c = 0; c < C; ++c) t += inv[(size_t)a * C + c] * xr[c];
