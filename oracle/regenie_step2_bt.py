@@ -157,6 +157,48 @@ def firth_null(y_raw, X, mask, offset, beta_start, maxit=2000):
     return None
 
 
+NITER_FIRTH = 250            # params.niter_max_firth (Regenie.hpp:336)
+TOL_FIRTH = 2.5e-4           # params.numtol_firth (:224)
+
+
+def pseudo_firth(g, y, o, live, p0, x0, dev0, state, niter):
+    """fit_firth_pseudo (Step2_Models.cpp:1548-1665), one parameter, started at 0.  g / y / o: the entries that enter (every sample with the
+    masked ones at g = 0, or the carriers); state(b) -> (p, w, sum g^2 w, penalised deviance).  Returns (beta, se, lrt) or None (fit states 1 - 4)."""
+    beta, beta14 = 0.0, 0.0
+    gl = np.where(live, g, 0.0)
+    for it in range(1, niter + 1):
+        p, w, xtwx, dev = state(beta)
+        h = gl * gl * w / xtwx
+        ystar = y + h * (0.5 - p)
+        score = float(np.sum(gl * (ystar - p)))
+        if abs(score) < TOL_FIRTH and it >= 2:
+            lrt = dev0 - dev
+            return None if lrt < 0 else (beta, float(np.sqrt(1.0 / xtwx)), lrt)
+        if it == 14:
+            beta14 = beta
+        if it == 15 and abs(beta - beta14) > 0.1:
+            return None                                              # state 1: the Newton solver takes over
+        bdiff, betanew = 1e16, beta
+        for _ in range(25):                                          # unpenalised logistic regression on the pseudo-response
+            step = score / xtwx
+            bnew = abs(step)
+            if bnew > bdiff:
+                return None                                          # state 2
+            mx = bnew / 5.0
+            betanew = beta + (step / mx if mx > 1 else step)
+            p = _pvec(o + g * betanew)
+            score = float(np.sum(gl * (ystar - p)))
+            if abs(score) < TOL_FIRTH:
+                break
+            w = np.where(live, p * (1 - p), 0.0)
+            if (np.where(live, w, 1.0) == 0).any():
+                return None                                          # state 3
+            xtwx = float(np.sum(gl * gl * w))
+            beta, bdiff = betanew, bnew
+        beta = betanew
+    return None                                                      # state 1: too slow
+
+
 def firth_snp(y_raw, gvec, mask, offset, carriers=None, maxit=500):
     """fit_firth_logistic_snp_fast with its 1-parameter solvers (Step2_Models.cpp:1158-1253, :1548-1737): the variant's effect with
     the covariate effects of the null Firth model held in the offset; penalty 0.5 log(sum G^2 w), over the carriers only when
@@ -186,6 +228,12 @@ def firth_snp(y_raw, gvec, mask, offset, carriers=None, maxit=500):
 
     # dev0: the deviance of the offset-only model with the penalty of the SAME set of samples (:1206-1218)
     p0, w0, x0, dev0 = state(0.0)
+    # regenie's first solver, to the letter: fit_firth_pseudo (:1548-1665) -- IRLS on the pseudo-response y* = y + h (0.5 - p), stopped at
+    # |modified score| < numtol_firth = 2.5e-4, so its BETA / SE / LRT are those of the iterate it stops at, not of the root; only when it
+    # gives up (slow, a growing step, p = 0, LRT < 0) do the Newton solvers run, which the root finder below stands in for
+    fast = pseudo_firth(g, y, o, live, p0, x0, dev0, state, niter=NITER_FIRTH // 2 if carriers is not None else min(NITER_FIRTH // 2, 50))
+    if fast is not None:
+        return fast
     beta = 0.0
     p, w, xtwx, dev = p0, w0, x0, dev0
     converged = False

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(256) void k_bt_prep(const BtPairDev* __restrict__ p
 __global__ __launch_bounds__(256) void k_bt_firth1(const BtPairDev* __restrict__ pairs, const double* __restrict__ V, const double* __restrict__ Y,
                                                    const double* __restrict__ Fo, const double* __restrict__ aux, int64_t n, double* __restrict__ res) {
   __shared__ double red[2][4];
+  __shared__ double red4[4][4];
   const BtPairDev& pr = pairs[blockIdx.x];
   if (aux[(int64_t)blockIdx.x * 8 + 5] == 0.0) {      // no sample enters the fit
     if (threadIdx.x == 0) { double* r = res + (int64_t)blockIdx.x * 4; r[0] = r[1] = r[2] = 0.0; r[3] = 1.0; }
@@ -184,6 +185,71 @@ __global__ __launch_bounds__(256) void k_bt_firth1(const BtPairDev* __restrict__
   };
   double xtwx, dev, dev0, beta = 0.0;
   state(0.0, xtwx, dev0);
+  // ---- the reference's first solver, to the letter: fit_firth_pseudo (Step2_Models.cpp:1548-1665), one parameter, started at 0 -- IRLS on the pseudo-response
+  // y* = y + h (0.5 - p), stopped at |modified score| < numtol_firth = 2.5e-4: BETA / SE / LRT are those of the iterate it stops at, not of the root.  Every
+  // thread follows the same scalars (the block sums return the same value to all).  Fit states 1 - 4 (too slow, a growing step, p = 0, LRT < 0) leave
+  // `pseudo` at 0 and the root finder below takes over, where the reference runs its Newton solvers.
+  {
+    const int niter = pr.fast ? 125 : 50;            // niter_max_firth / 2, at most 50 unless the fit is on the carriers (:1166, :1186)
+    const double tol = 2.5e-4;
+    auto sums_at = [&](double b, double xt, double bstar, bool want_state, double& o_score, double& o_xtwx, double& o_dev, double& o_zero) {
+      // score = sum g (y* - p(b)) with y* = y + h(bstar) (0.5 - p(bstar)), h = g^2 w / xt; and, when asked, sum g^2 w(b), the deviance and zeros of w at b
+      double t[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const double g = v[i];
+        if (!(g == g)) continue;
+        const double ps = bt_pvec(o[i] + g * bstar);
+        const double ystar = y[i] + g * g * ps * (1.0 - ps) / xt * (0.5 - ps);
+        const double pb = (b == bstar) ? ps : bt_pvec(o[i] + g * b);
+        t[0] += g * (ystar - pb);
+        if (want_state) {
+          const double w = pb * (1.0 - pb);
+          t[1] += g * g * w;
+          t[2] -= (y[i] == 0.0) ? log(1.0 - pb) : log(pb);
+          t[3] += (w == 0.0) ? 1.0 : 0.0;
+        }
+      }
+      bt_block_sum<4>(t, red4);
+      o_score = t[0]; o_xtwx = t[1]; o_dev = 2.0 * t[2]; o_zero = t[3];
+    };
+    int pseudo = 0;           // 1: stopped by its criterion
+    double b = 0.0, b14 = 0.0, xt = xtwx, dv = dev0, se_x = xtwx;
+    for (int itp = 1; itp <= niter && !pseudo; ++itp) {
+      double sc, x_b, d_b, zz;
+      sums_at(b, xt, b, true, sc, x_b, d_b, zz);             // (xt is sum g^2 w at b: kept from the last update, or from state(0))
+      dv = d_b - log(xt);
+      if (fabs(sc) < tol && itp >= 2) { pseudo = 1; se_x = xt; break; }
+      if (itp == 14) b14 = b;
+      if (itp == 15 && fabs(b - b14) > 0.1) break;
+      double bdiff = 1e16, bnew = b, xin = xt;
+      const double bstar = b, xstar = xt;
+      bool bad = false, done = false;
+      for (int il = 0; il < 25; ++il) {
+        const double step = sc / xin, bd = fabs(step);
+        if (bd > bdiff) { bad = true; break; }
+        const double mx = bd / 5.0;
+        bnew = b + (mx > 1.0 ? step / mx : step);
+        double s2, x2, d2, z2;
+        sums_at(bnew, xstar, bstar, true, s2, x2, d2, z2);
+        sc = s2;
+        if (fabs(sc) < tol) { done = true; xin = x2; break; }
+        if (z2 > 0.0) { bad = true; break; }
+        xin = x2; b = bnew; bdiff = bd;
+      }
+      (void)done;
+      if (bad) break;
+      b = bnew;
+      // sum g^2 w at the new b (the inner loop left it in xin when it updated there; after its `break` on the score it belongs to bnew as well)
+      xt = xin;
+    }
+    if (pseudo) {
+      const double lrt = dev0 - dv;
+      if (lrt >= 0) {
+        if (threadIdx.x == 0) { double* r = res + (int64_t)blockIdx.x * 4; r[0] = b; r[1] = sqrt(1.0 / se_x); r[2] = lrt; r[3] = 0.0; }
+        return;
+      }
+    }
+  }
   dev = dev0;
   bool conv = false;
   int it = 0;

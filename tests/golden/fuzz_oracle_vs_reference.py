@@ -824,7 +824,7 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None, pgen=None):
     elif bgen is not None:
         bgo = obg.BgenOracle(S + ".bgen")
         vidx = {v["rsid"]: k for k, v in enumerate(bgo.variants)}
-    nf = ns = 0
+    nf = ns = nfx = 0
     for c in sorted(set(chrom.tolist())):
         nulls, offs_f, bnulls = [], [], []
         for ph in range(P):
@@ -891,6 +891,7 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None, pgen=None):
                 assert abs(want_se - se) <= (4e-3 if firth_se else 5e-4) * se + 1e-6, ("Firth SE", snp_ids[sel[k]], ph, want_se, se, firth_se)
                 assert abs(fo["chisq"] - chisq) <= 3e-3 * abs(chisq) + 5e-5, ("Firth CHISQ", snp_ids[sel[k]], ph, fo["chisq"], chisq)
                 nf += 1
+                nfx += all(("%g" % float("%.6g" % v)) == ("%g" % w_) for v, w_ in ((sgn * fo["bhat"], beta), (want_se, se), (fo["chisq"], chisq)))
     if os.environ.get("FUZZ_DRIVER"):
         # the product's corrected rows beside regenie's (both stop their fits at a tolerance: the bars of the oracle comparison above).  Variants
         # whose counted allele is the major one are where the carriers of the fast forms are those of 2 - g (flip_geno).
@@ -916,6 +917,7 @@ def step2_bt_corrections_leg(d, S, o, pthresh=0.2, bgen=None, pgen=None):
         print("      (driver rows held to regenie's: %d, %d of them identical in every printed digit)" % (ndrv, nsame), flush=True)
     if exact:
         print("      (exact Firth rows compared: %d)" % ne, flush=True)
+    print("      (oracle, approximate Firth: %d of %d rows round to regenie's printed BETA / SE / CHISQ)" % (nfx, nf), flush=True)
     return nf, ns
 
 
