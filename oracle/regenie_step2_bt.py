@@ -105,7 +105,9 @@ def score_ct(g, X, y_raw, mask, null, numtol=NUMTOL, sparse=False):
 # fit_firth_pseudo, step halving, restarts: Step2_Models.cpp:899-984, :1254-1737) that stop at |modified score| < 50 * numtol (null
 # model) or < numtol_firth = 2.5e-4 (per variant).  The penalised likelihood is strictly concave in the range that matters, so its
 # maximiser is unique: this restatement solves the same equations to machine precision with plain Fisher scoring + step halving, and
-# agrees with regenie's printed numbers to its stopping tolerance (~1e-5 relative on BETA, less on CHISQ).
+# agrees with regenie's printed numbers to its stopping tolerance (~1e-5 relative on BETA, less on CHISQ).  The per-variant fit is the
+# exception since round 5: regenie's first solver there (the one-parameter fit_firth_pseudo) is restated to the letter, stopping rule
+# included (pseudo_firth below), so that its rows come out in regenie's digits; the root finder stands in for the solvers behind it.
 
 def _pvec(eta):
     return orc.get_pvec(eta)
