@@ -113,7 +113,7 @@ def _pvec(eta):
     return orc.get_pvec(eta)
 
 
-def firth_null(y_raw, X, mask, offset, beta_start, maxit=2000):
+def firth_null(y_raw, X, mask, offset, beta_start, maxit=2000, stop_tol=50 * NUMTOL):
     """fit_approx_firth_null / fit_firth_nr with every column free (Step2_Models.cpp:899-984, :1267-1385): maximise
     l(beta) + 0.5 log |X^T W X| over the covariate effects, the LOCO prediction as offset.  Modified score X^T (y - p + h (0.5 - p)),
     h = diag of the hat matrix of W^(1/2) X.  Returns beta (None if it does not converge).
@@ -137,11 +137,16 @@ def firth_null(y_raw, X, mask, offset, beta_start, maxit=2000):
 
     beta = np.array(beta_start, dtype=np.float64)
     dev, p, w = pen_dev(beta)
-    for _ in range(maxit):
+    for it in range(1, maxit + 1):
         XtWX = Xm.T @ (Xm * w[:, None]) + extra
         U = Xm * np.sqrt(w)[:, None]
         h = np.einsum("ij,ij->i", U @ np.linalg.inv(XtWX), U)
         score = Xm.T @ (ym - p + h * (0.5 - p))
+        # fit_firth_nr's stopping rule (Step2_Models.cpp:1320-1323) with fit_approx_firth_null's tolerance 50 numtol = 5e-5 (:906): the estimates are those of
+        # the iterate it stops at.  With masked samples in X^T W X the iteration is not Newton's any more and converges linearly, so that iterate lies a
+        # tolerance away from the root -- and every approximate-Firth row of the trait inherits the difference in its last digits.
+        if np.abs(score).max() < stop_tol and it >= 2:
+            return beta
         if np.abs(score).max() < 1e-10:
             return beta
         step = np.linalg.solve(XtWX, score)

@@ -314,7 +314,7 @@ bool cox_null_fit(const double* time, const double* event, const uint8_t* mask, 
 bool cox_null_newton(const double* time, const double* event, const uint8_t* mask, const double* X, int64_t N, int C, const Params& prm, double stephalf_tol,
                      std::vector<double>& eta);   // the reference's Newton fall-back (cox_firth.cpp without the Firth term)
 bool firth_fit_cols(const double* y, const std::vector<const double*>& cols, const uint8_t* mask, const double* offset, int64_t n, int nfree, double maxstep,
-                    std::vector<double>& beta, double* dev_out = nullptr, std::vector<double>* inv_out = nullptr);
+                    std::vector<double>& beta, double* dev_out = nullptr, std::vector<double>* inv_out = nullptr, double stop_tol = 0.0);   // stop_tol > 0: fit_firth_nr's stopping rule
 bool firth_null_fit(const double* y, const double* X, const uint8_t* mask, const double* offset, int64_t n, int C, std::vector<double>& beta);
 // ---- driver_inputs.cpp
 void read_bgen_meta(Run& r);

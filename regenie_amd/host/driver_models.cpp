@@ -454,7 +454,7 @@ bool spd_logdet_inv(const std::vector<double>& A, int n, double& logdet, std::ve
 // others stay where they start); penalty and hat diagonal always use every column.  cols: K column pointers (sample-fastest, n each).
 // beta in: start, out: the maximiser; dev_out: the penalised deviance there; inv_out (optional): (X^T W X)^-1.  false = no convergence.
 bool firth_fit_cols(const double* y, const std::vector<const double*>& cols, const uint8_t* mask, const double* offset, int64_t n, int nfree, double maxstep,
-                    std::vector<double>& beta, double* dev_out, std::vector<double>* inv_out) {
+                    std::vector<double>& beta, double* dev_out, std::vector<double>* inv_out, double stop_tol) {
   const int K = (int)cols.size();
   std::vector<double> pv(n), w(n), A((size_t)K * K), Ainv, Afree((size_t)nfree * nfree), Afinv, score(nfree), step(K, 0.0), bnew(K), hx(K);
   // A sample masked for the trait is in neither the likelihood nor the score -- but it IS in X^T W X, with weight 1: the reference's get_wvec
@@ -503,6 +503,13 @@ bool firth_fit_cols(const double* y, const std::vector<const double*>& cols, con
       if (!spd_logdet_inv(Afree, nfree, ld, &Afinv)) return false;
       Finv = &Afinv;
     }
+    // stop_tol > 0: fit_firth_nr's stopping rule (Step2_Models.cpp:1320-1323) -- |modified score| below the tolerance, from the second iteration on; the
+    // estimates are then those of the iterate the reference stops at (with masked samples in X^T W X the iteration converges linearly: a tolerance off the root)
+    if (stop_tol > 0 && it >= 1) {
+      double smax = 0.0;
+      for (int a = 0; a < nfree; ++a) smax = std::max(smax, std::fabs(score[a]));
+      if (smax < stop_tol) { if (dev_out) *dev_out = dev; if (inv_out) *inv_out = Ainv; return true; }
+    }
     const int F = nfree < K ? nfree : K;
     double mx = 0.0;
     for (int a = 0; a < nfree; ++a) { double t = 0.0; for (int c = 0; c < nfree; ++c) t += (*Finv)[(size_t)a * F + c] * score[c]; step[a] = t; mx = std::max(mx, std::fabs(t)); }
@@ -526,7 +533,7 @@ bool firth_fit_cols(const double* y, const std::vector<const double*>& cols, con
 bool firth_null_fit(const double* y, const double* X, const uint8_t* mask, const double* offset, int64_t n, int C, std::vector<double>& beta) {
   std::vector<const double*> cols(C);
   for (int c = 0; c < C; ++c) cols[c] = X + (size_t)c * n;
-  return firth_fit_cols(y, cols, mask, offset, n, C, 25.0, beta);      // maxstep_null
+  return firth_fit_cols(y, cols, mask, offset, n, C, 25.0, beta, nullptr, nullptr, 50 * NUMTOL);      // maxstep_null; tol = 50 numtol (fit_approx_firth_null, :906)
 }
 
 }  // namespace rgdrv
