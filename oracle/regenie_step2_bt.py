@@ -206,7 +206,7 @@ def pseudo_firth(g, y, o, live, p0, x0, dev0, state, niter):
     return None                                                      # state 1: too slow
 
 
-def firth_snp(y_raw, gvec, mask, offset, carriers=None, maxit=500):
+def firth_snp(y_raw, gvec, mask, offset, carriers=None, maxit=500, root=False):
     """fit_firth_logistic_snp_fast with its 1-parameter solvers (Step2_Models.cpp:1158-1253, :1548-1737): the variant's effect with
     the covariate effects of the null Firth model held in the offset; penalty 0.5 log(sum G^2 w), over the carriers only when
     `carriers` is given (the reference's fast approximation for sparse variants with MAC < 50, where the entries of G off the
@@ -238,8 +238,8 @@ def firth_snp(y_raw, gvec, mask, offset, carriers=None, maxit=500):
     # regenie's first solver, to the letter: fit_firth_pseudo (:1548-1665) -- IRLS on the pseudo-response y* = y + h (0.5 - p), stopped at
     # |modified score| < numtol_firth = 2.5e-4, so its BETA / SE / LRT are those of the iterate it stops at, not of the root; only when it
     # gives up (slow, a growing step, p = 0, LRT < 0) do the Newton solvers run, which the root finder below stands in for
-    fast = pseudo_firth(g, y, o, live, p0, x0, dev0, state, niter=NITER_FIRTH // 2 if carriers is not None else min(NITER_FIRTH // 2, 50))
-    if fast is not None:
+    fast = None if root else pseudo_firth(g, y, o, live, p0, x0, dev0, state, niter=NITER_FIRTH // 2 if carriers is not None else min(NITER_FIRTH // 2, 50))
+    if fast is not None:                                              # (root=True: the maximiser itself, for tests of the equations)
         return fast
     beta = 0.0
     p, w, xtwx, dev = p0, w0, x0, dev0

@@ -112,15 +112,19 @@ def test_firth_fits_maximise_the_penalised_likelihood():
         p = orc.get_pvec(off[m] + gc[m] * b)
         return -2 * np.sum(np.where(y[m] == 0, np.log(1 - p), np.log(p))) - np.log(np.sum(gc[m] ** 2 * p * (1 - p)))
 
-    beta, se, lrt = bt.firth_snp(y, gc, mask.astype(float), off)
+    beta, se, lrt = bt.firth_snp(y, gc, mask.astype(float), off, root=True)
+    # regenie's own answer (its first solver restated to the letter, stopped at |modified score| < 2.5e-4) lies within that tolerance of the maximiser
+    b_reg, se_reg, lrt_reg = bt.firth_snp(y, gc, mask.astype(float), off)
+    assert abs(b_reg - beta) < 2.5e-4 * se * se * 1.01 and abs(lrt_reg - lrt) < 1e-6 and se_reg == pytest.approx(se, rel=1e-4)
     best = minimize_scalar(pen_dev, bracket=(beta - 1, beta + 1), tol=1e-13)
     assert beta == pytest.approx(best.x, abs=1e-7) and lrt == pytest.approx(pen_dev(0.0) - pen_dev(beta), rel=1e-10)
     one = bt.firth_fit(y, gc[:, None], mask.astype(float), off, np.zeros(1), 1, maxstep=5.0)
     assert one[0][0] == pytest.approx(beta, abs=1e-8) and np.sqrt(one[2][0, 0]) == pytest.approx(se, rel=1e-8)
     # the covariate-only model: firth_null and firth_fit with every column free agree; constrained fit has the last coefficient untouched
-    bn = bt.firth_null(y, X, mask, off, np.zeros(X.shape[1]))
+    bn = bt.firth_null(y, X, mask, off, np.zeros(X.shape[1]), stop_tol=0.0)
     ff = bt.firth_fit(y, X, mask.astype(float), off, np.zeros(X.shape[1]), X.shape[1])
     assert np.allclose(bn, ff[0], atol=1e-8)
+    assert np.abs(bt.firth_null(y, X, mask, off, np.zeros(X.shape[1])) - bn).max() < 2e-5 * np.abs(bn).max()       # regenie's stopping rule (50 numtol on the modified score)
     Xg = np.column_stack([X, g])
     nul = bt.firth_fit(y, Xg, mask.astype(float), off, np.concatenate([bn, [0.0]]), X.shape[1])
     full = bt.firth_fit(y, Xg, mask.astype(float), off, nul[0], X.shape[1] + 1, maxstep=5.0)
