@@ -120,7 +120,7 @@ def test_driver_write_and_use_null_firth(tmp_path):
     X^T W X with weight 1 (driver_models.cpp firth_fit_cols; tests/test_firth_null_cpu.py): the oracle with that behaviour is within 7e-5 of these files, 9e-4 without; 3e-3 is still
     what this test allows).  Then
     `--step 2 --firth --approx --use-null-firth LIST --write-null-firth` on the rare variants: the stored estimates are start values only, so every
-    result line equals the run without them, and the estimates Step 2 writes are those of its own null Firth fits."""
+    result line equals the run without them to the stopping tolerance of the null fit, and the estimates Step 2 writes are those of its own null Firth fits."""
     from tests.util import synth_dosages, synth_rare_dosages, write_bed_bim, write_plink
     import shutil
     args, spec = CASES["bt_kfold_synth"]
@@ -159,8 +159,13 @@ def test_driver_write_and_use_null_firth(tmp_path):
             if "NA" in tx[8:12] + ty[8:12] + tz[8:12]:
                 assert tx[8:12] == ty[8:12] == tz[8:12]
                 continue
-            for u, v in zip(tx[8:12], ty[8:12]):
-                assert float(v) == pytest.approx(float(u), rel=1e-6, abs=1e-9)          # the start values do not move the maximisers
+            # the start values do not move the maximisers -- but since round 5 the null Firth fit stops where regenie's stops (|modified score| < 50 numtol from the
+            # second iteration on), so two starts end a tolerance apart and the corrected rows with them: the bars are those of the comparison with regenie below
+            # (twice those bars: each run is within one of them of regenie's)
+            b0, se0 = float(tx[8]), float(tx[9])
+            assert abs(float(ty[8]) - b0) <= 1.6e-3 * se0 * se0 + 4e-5 * abs(b0) + 1e-5, (x, y)
+            assert float(ty[9]) == pytest.approx(se0, rel=4e-4) and float(ty[10]) == pytest.approx(float(tx[10]), rel=4e-3, abs=4e-5), (x, y)
+            assert float(ty[11]) == pytest.approx(float(tx[11]), rel=4e-3, abs=4e-5), (x, y)
             # regenie's own run with --use-null-firth.  Its corrected rows stop at |modified score| < 2.5e-4 (a few times 2.5e-4 * SE^2 from the
             # root) and take the LRT one iteration before BETA: the bounds of test_cli_step2_bt_approx_firth_rare_variants_against_reference_output
             beta, se, chisq, logp = (float(t) for t in tz[8:12])
