@@ -162,3 +162,11 @@ def test_the_driver_on_emulated_kernels_beside_regenie_itself(tmp_path, monkeypa
     monkeypatch.setenv("FUZZ_BT_STEP2", "4")             # and from a .pgen with a dosage track: the reader's zero count decides `sparse` (before the flip)
     line, ok = fz.run_one(5, str(tmp_path))
     assert ok and "from a .pgen with dosages" in line, line
+    # ... and not only within regenie's stopping tolerances: with the sparse form's numerator, regenie's fit_firth_pseudo in the Firth kernel and its stopping rule
+    # in the null Firth model, the driver's files of this case -- uncorrected, saddlepoint and approximate-Firth rows, from the .bed and from the .pgen --
+    # are regenie's files byte for byte (two traits, 5 % of the phenotypes missing, 2 % of the genotypes)
+    d = os.path.join(str(tmp_path), "c5")
+    pairs = [(f, "s" + f[1:]) for f in sorted(os.listdir(d)) if f.startswith("d2") and f.endswith(".regenie")]
+    assert len(pairs) == 10, pairs                      # two traits x (score test, approximate Firth, saddlepoint from the .bed; the two corrections from the .pgen)
+    for mine, theirs in pairs:
+        assert open(os.path.join(d, mine)).read() == open(os.path.join(d, theirs)).read(), (mine, theirs)
