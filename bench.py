@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -343,7 +344,9 @@ def main():
         flops = {
             "gram_fp4": 2.0 * N * sum(x * x for x in bss),                       # F_gram = 2 N bs^2 per block
             # K*R0 systems per block; leave-one-out: R0 systems whose forward substitution carries the N sample rows (loocv.hip)
-            "chol_f64": (sum((x ** 3 / 3.0 + 1.0 * x * x * (N + 2 * P)) * R0 for x in bss) if args.loocv else
+            # leave-one-out (loocv_tri.hip): ONE Householder tridiagonal reduction per block (4/3 bs^3) + the GEMM Z = Q^T G~ (2 N bs^2) serve every
+            # ridge value; the recurrences (N bs R0 (3 + P) multiply-adds) are vector work and not counted here
+            "chol_f64": (sum(4.0 * x ** 3 / 3.0 + 2.0 * N * x * x for x in bss) if args.loocv else
                          sum((x ** 3 / 3.0 + 2.0 * x * x * P) * 5 * R0 for x in bss)),
             # level-1 fold Grams: the symmetric product, lower triangle with the diagonal (what any algorithm must form); SURVEY 8(d)'s
             # 2 N L^2 P counts the full product the reference's W_i^T W_i computes -- twice this, reported next to it
@@ -448,6 +451,26 @@ def main():
         del W0
     elif rank == 0 and world == 1 and args.bt:
         extra_t.pop("_fold_detail", None)
+    elif rank == 0 and world == 1 and args.loocv and args.oracle_check:
+        # the leave-one-out level 0 at THIS run's block order and sample count against the oracle's eigendecomposition route (checker only)
+        from oracle import regenie_step1 as orc
+        prep = orc.Prepared(ids=[], n_file=N, ind_ignore=np.zeros(N, bool), ind_in_analysis=ain, pheno_names=[], Y=Y, Y_raw=None, mask=mask, X=X,
+                            Neff=neff, scale_Y=np.ones(P), ncov=X.shape[1], n_analyzed=N)
+        osel = [my_blocks[0], my_blocks[-1]] if len(my_blocks) > 1 else [my_blocks[0]]
+        werr, t_or = 0.0, 0.0
+        for b in osel:
+            rows = packed[b].cpu().numpy()
+            t0 = time.perf_counter()
+            G = orc.read_chunk_from_bed(rows, N, None, ain)
+            G, _ = orc.residualize_genotypes(G, prep)
+            Wb = orc.ridge_level_0_loocv(G, prep, lam)
+            t_or += time.perf_counter() - t0
+            del G
+            for p in range(P):
+                werr = max(werr, float(np.max(np.abs(eng.get_w(b, p) - Wb[p])) / np.max(np.abs(Wb[p]))))
+            del Wb
+        extra_t["level0_vs_oracle"] = {"W_max_rel_err": werr, "blocks": len(osel), "block_order": [blocks[b][2] for b in osel], "samples": N, "phenos": P,
+                                       "oracle": "oracle.regenie_step1.ridge_level_0_loocv (eigendecomposition route, Step1_Models.cpp:615-726)", "oracle_s": t_or}
     elif rank == 0 and world == 1 and (not args.no_cpu or args.oracle_check) and not args.loocv and not args.t2e:
         cpu = cpu_baseline(args, eng, torch, dev, packed, blocks, my_blocks, X, Y, Yraw, cov, mask, ain, neff, cv_sizes, tau, M, N, P, B, R0,
                            (res[0], res[1], res[2]), with_reference=not (args.no_cpu or args.no_ref))
@@ -532,10 +555,11 @@ def main():
             extra["config4_level1_binary_traits"] = {"error": repr(e)[:500]}
         # leave-one-out level 0 on eight full blocks of 1,000 SNPs with ten traits (device time: it does not mind the oracle beside it)
         try:
-            l0 = sub_line(big + ["--loocv", "--snps", "8000", "--one-chrom", "--phenos", "10", "--l0-only", "--warmup", "1"], 900)
+            l0 = sub_line(big + ["--loocv", "--snps", "8000", "--one-chrom", "--phenos", "10", "--l0-only", "--warmup", "1", "--oracle-check"], 900)
             lo["level0_ms_per_block_of_1000_snps"] = l0["ms_per_step"] / 8
             lo["level0_device_memory_peak_GB"] = l0["level1"].get("device_memory_peak_GB")
             lo["level0_kernels"] = {k: l0["kernels"][k] for k in ("prep", "gram_fp4", "assemble_form", "chol_f64", "pred")}
+            lo["level0_vs_oracle"] = l0["level1"].get("level0_vs_oracle")
             lo["config"] = "500,000 samples; level 0: 8 blocks x 1,000 SNPs x 10 QT; level 1: 512 blocks x 5 ridge values (bsize 100), 2 QT / 1 BT (prevalence 10 %)"
         except Exception as e:   # noqa: BLE001
             lo["error"] = repr(e)[:500]
@@ -604,11 +628,47 @@ def main():
             "setup_s": {"generate": t_gen}, "level1": extra_t,
         }
         line.update(extra)
+        if extra:
+            line["summary"] = summary_of(line)      # last key of the line: a reader that keeps only the line's tail still gets every sub-run's headline
         print(json.dumps(line))
     if eng is not None:
         eng.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def summary_of(line):
+    """Compact digest (< 1,500 characters) of the sub-records, placed LAST in the JSON line."""
+    def g(d, *ks):
+        for k in ks:
+            if not isinstance(d, dict) or d.get(k) is None:
+                return None
+            d = d[k]
+        return round(d, 4 - int(math.floor(math.log10(abs(d)))) - 1) if isinstance(d, float) and d != 0 and math.isfinite(d) else d
+    c3, c4, lo, s2 = (line.get(k) or {} for k in ("config3_single_gpu", "config4_level1_binary_traits", "loocv_500k", "step2"))
+    bg = (s2.get("bgen_from_file") or {})
+    run0 = (bg.get("runs") or [{}])[0] if isinstance(bg.get("runs"), list) else {}
+    cases = s2.get("cases") or {}
+    cb0 = (bg.get("cpu_baseline") or [{}])[0] if isinstance(bg.get("cpu_baseline"), list) else {}
+    out = {
+        "cfg1": {"ms": g(line, "ms_per_step"), "chol_frac": g(line, "roofline", "frac"), "traffic_B": g(line, "roofline", "traffic"),
+                 "files_s": g(line, "end_to_end_from_files", "wall_s"), "loco_err": g(line, "loco_max_rel_err")},
+        "cfg2_1gpu": {"ms": g(c3, "ms_per_step"), "value": g(c3, "value"), "l1_gram_frac": g(c3, "roofline", "frac"), "chol_TF": g(c3, "kernels", "chol_f64", "achieved_TFLOPS"),
+                      "pred_ms": g(c3, "kernels", "pred", "ms"), "files_s": g(c3, "end_to_end_from_files", "wall_s"), "loco_ck": c3.get("loco_checksum")},
+        "cfg3_bt": {"s_per_trait": g(c4, "s_per_trait"), "beta_err": g(c4, "oracle_check", "beta_max_rel_err"), "pred_err": g(c4, "oracle_check", "prediction_max_rel_err"),
+                    "stream_frac": g(c4, "roofline", "frac")},
+        "loocv": {"l0_ms_per_block": g(lo, "level0_ms_per_block_of_1000_snps"), "l0_err": g(lo, "level0_vs_oracle", "W_max_rel_err"),
+                  "l1_qt_s": g(lo, "level1_qt_s_per_trait"), "l1_bt_s": g(lo, "level1_bt_s_per_trait")},
+        "step2": {"hard_Mvar_s": g(cases, "hard_calls", "variants_per_s"), "hard_masked": g(cases, "hard_calls_masked_phenos", "variants_per_s"),
+                  "dos8": g(cases, "dosages_8bit", "variants_per_s"), "dos8_masked": g(cases, "dosages_8bit_masked_phenos", "variants_per_s"),
+                  "bgen_var_s": g(run0, "variants_per_s"), "bgen_block_loop_var_s": g(run0, "variants_per_s_block_loop"),
+                  "bgen_lines_identical": "%s/%s" % (g(cb0, "byte_identical"), g(cb0, "result_lines"))},
+    }
+    errs = [k for k in ("config3_single_gpu", "config4_level1_binary_traits", "loocv_500k", "step2") if isinstance(line.get(k), dict) and
+            any(str(kk).startswith("error") for kk in line[k])]
+    if errs:
+        out["errors_in"] = errs
+    return out
 
 
 def bt_oracle_leg(W0, yraw, offset, mask, cv_sizes, tau, q, g_beta, g_cs, prevalence, quasi_newton):

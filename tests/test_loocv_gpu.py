@@ -74,3 +74,31 @@ def test_level0_loocv_more_samples_than_one_chunk(tmp_path):
     eng.close()
     for ph in range(2):
         assert rel_err(W[ph], ref.W[ph]) < 1e-8
+
+
+def _fast_dosages(M, N, miss_rate, seed):
+    """Binomial(2, maf) hard calls with missing calls as -1 (numpy's generator: synth_dosages' per-element hash takes 20 s at this size)."""
+    rng = np.random.default_rng(seed)
+    maf = rng.uniform(0.05, 0.5, (M, 1))
+    g = rng.binomial(2, maf, (M, N)).astype(np.int8)
+    g[rng.random((M, N)) < miss_rate] = -1
+    return g
+
+
+@pytest.mark.parametrize("binary", [False, True], ids=["qt", "bt"])
+def test_level0_loocv_at_the_block_order_it_is_benchmarked_at(tmp_path, binary):
+    """Block orders 1,024 / 1,000 / 960 (a full last tile, BASELINE's bsize with its padded tile, a tile edge) x 20,000 samples: the tridiagonal
+    leave-one-out level 0 (loocv_tri.hip: up to 1,023 Householder steps per block) against the oracle's eigendecomposition route
+    (ridge_level_0_loocv, Step1_Models.cpp:615-726).  The long reflector chain is what the small-order tests cannot show."""
+    N = 20000
+    g = _fast_dosages(1024 + 1000 + 960, N, 0.01, 51 + binary)
+    pre = str(tmp_path / "lobig")
+    write_plink(pre, g, np.repeat([1, 2, 3], [1024, 1000, 960]), P=2, ncov=2, seed=11, binary=binary)
+    opt = orc.Step1Options(bed=pre, pheno_file=pre + ".pheno", covar_file=pre + ".covar", bsize=1024, loocv=True, bt=binary)
+    ref, W, eng = _level0_loocv(opt)
+    eng.close()
+    assert [b[2] for b in ref.blocks] == [1024, 1000, 960]
+    for ph in range(2):
+        assert rel_err(W[ph], ref.W[ph]) < 1e-8
+        for b in range(3):      # per block too: one bad block must not hide behind the others' scale
+            assert rel_err(W[ph][:, 5 * b:5 * b + 5], ref.W[ph][:, 5 * b:5 * b + 5]) < 1e-8

@@ -55,7 +55,7 @@ def main():
                 t_read += t1 - t0
                 t_dec += t2 - t1
             print("rep %d: batch %d: read %.3f s (%.1f GB/s), copy + decode + walk %.3f s = %.0f variants/s (%.1f GB/s inflated)"
-                  % (rep, batch, t_read, clen.sum() / 1e9 * (M / idx.size) / max(t_read, 1e-9), t_dec, M / t_dec, M * ulen[0] / 1e9 / t_dec), flush=True)
+                  % (rep, batch, t_read, float(clen.sum(dtype=np.float64)) / 1e9 * (M / idx.size) / max(t_read, 1e-9), t_dec, M / t_dec, float(M) * float(ulen[0]) / 1e9 / t_dec), flush=True)
         # check a sample against zlib
         idx = np.arange(0, M, max(1, M // 16))[:16]
         comp, off, clen, ulen = f.read_compressed(idx)
