@@ -70,6 +70,8 @@ def _deps():
 def _lib_deps():
     return [os.path.join(CSRC, s) for s in SOURCES] + [
                                                       os.path.join(CSRC, "rg_internal.h"),
+                                                      os.path.join(CSRC, "chol_common.h"),
+                                                      os.path.join(CSRC, "chol_p128.h"),
                                                       os.path.join(CSRC, "step2_internal.h"),
                                                       os.path.join(CSRC, "pgen_reader.h"),
                                                       os.path.join(CSRC, "bgen_reader.h"),
