@@ -45,9 +45,17 @@
                  "+v"(acc[7][0]), "+v"(acc[7][1])                                                                                       \
                :                                                                                                                        \
                : "memory")
+// (the diagonal block's accumulators: row block w has no columns past block 3)
+#define C128_STAGE_SYNC_ACCD(acc)                                                                                                       \
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier"                                                                            \
+               : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]), \
+                 "+v"(acc[3][1]), "+v"(acc[4][1]), "+v"(acc[5][1]), "+v"(acc[6][1]), "+v"(acc[7][1])                                   \
+               :                                                                                                                        \
+               : "memory")
 #else
 #define C128_LAUNDER(x) ((void)0)
 #define C128_STAGE_SYNC_ACC(acc) C128_STAGE_SYNC()
+#define C128_STAGE_SYNC_ACCD(acc) C128_STAGE_SYNC()
 #endif
 
 #define C128_STAGE 32768
@@ -122,6 +130,10 @@ __device__ __forceinline__ double c128_rows_at(const uint8_t* smem, int rbl, int
   return *reinterpret_cast<const double*>(smem + (16 * rbl + i) * 1024 + (((8 * n + 2 * r + (q >> 1)) ^ i) << 4) + 8 * (q & 1));
 }
 
+// MODE 0: launch j = -1 (diagonal block 0 alone: no tile, no products); 1: j = 0 (tiles of panel 0: no products before the triangular multiply);
+// 2: j >= 1.  Compile-time so that the K loops have no bypass path (with one, hipcc kept a second copy of the 128 accumulator registers
+// alive across the loop and spilled the loop's own operands).
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[C128_LDS];
   const int wave = C128_RFL((int)threadIdx.x >> 6);
@@ -158,32 +170,33 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
     for (int m = 0; m < 2; ++m) acc[n][m] = (v4d){0, 0, 0, 0};
 
   // ======== part 1: tile (it, j) = (X - L[it][0..j-1] L[j][0..j-1]^T) Linv_jj^T ==========================================================
-  if (j >= 0) {
+  if (MODE >= 1) {
     const int rb0 = 32 * wave;                          // this wave's rows of the tile: rb0 + 16 m + i
     {
       // ---- X: acc = -(S - F) from the sources, two row stages per source (rows 0-63 | 64-127); waves 2h, 2h+1 own the rows of stage h
-      int lane = threadIdx.x & 63;
-      C128_LAUNDER(lane);
-      const int i = lane & 15, q = lane >> 4;
 #pragma unroll 1
       for (int src = 0; src < (fx.F ? 2 : 1); ++src) {
         const double* Sx = (src ? fx.F : fx.S) + (int64_t)(128 * it) * n64 + 128 * j;
         const double sgn = src ? 1.0 : -1.0;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+          int lane = threadIdx.x & 63;
+          C128_LAUNDER(lane);       // per stage: the element masks below must not be hoisted out of the stage (they were, as spilled SGPR pairs)
+          const int i = lane & 15, q = lane >> 4;
           c128_issue_rows(Sx + (int64_t)(64 * h) * n64, n64, wave, lane, lds0);
           C128_STAGE_SYNC();
           if ((wave >> 1) == h) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
+              // element (gi, gj) holds data when gj < nb and gi < nrhs: one limit per lane on the column offset e = 16 n + 4 r (+ q)
               const int gi = 128 * it + rb0 + 16 * m + i;
+              const int lim = gi < nrhs ? nb - 128 * j - q : -1;
 #pragma unroll
               for (int n = 0; n < 8; ++n)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                  const int gj = 128 * j + 16 * n + q + 4 * r;
                   double x = c128_rows_at(smem, 2 * (wave & 1) + m, n, r, i, q);
-                  x = (gj < nb && gi < nrhs) ? x : 0.0;
+                  x = (16 * n + 4 * r < lim) ? x : 0.0;
                   acc[n][m][r] = fma(sgn, x, acc[n][m][r]);
                 }
             }
@@ -206,15 +219,16 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
       const double* arows = M + (int64_t)(128 * it) * n64;
       const double* brows = M + (int64_t)(128 * j) * n64;
       const int aoff0 = (rb0 + i) * 128, aoff1 = (rb0 + 16 + i) * 128, boff = 16384 + i * 128;
-      if (ns > 0) {
+      if (MODE >= 2) {
         c128_issue_k(arows, brows, 0, 0, wave, n64, lds0, koff);
         C128_STAGE_SYNC();
-      }
+        int s = 0;
 #pragma unroll 1
-      for (int s = 0; s < ns; ++s) {
-        if (s + 1 < ns) c128_issue_k(arows, brows, s + 1, (s + 1) & 1, wave, n64, lds0, koff);
-        c128_kstage<false, 0>(smem + (s & 1) * C128_STAGE, aoff0, aoff1, boff, s0, s1, acc);
-        C128_STAGE_SYNC_ACC(acc);
+        do {
+          if (s + 1 < ns) c128_issue_k(arows, brows, s + 1, (s + 1) & 1, wave, n64, lds0, koff);
+          c128_kstage<false, 0>(smem + (s & 1) * C128_STAGE, aoff0, aoff1, boff, s0, s1, acc);
+          C128_STAGE_SYNC_ACC(acc);
+        } while (++s < ns);
       }
     }
     {
@@ -274,33 +288,34 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   const int jd = j + 1;
   // row blocks of 16: wave w holds block w (m = 0, columns n <= w) and block 7 - w (m = 1, columns n <= 7 - w)
   {
-    int lane = threadIdx.x & 63;
-    C128_LAUNDER(lane);
-    const int i = lane & 15, q = lane >> 4;
     const double sh = fx.sh;
 #pragma unroll 1
     for (int src = 0; src < (fx.F ? 2 : 1); ++src) {
       const double* Sx = (src ? fx.F : fx.S) + (int64_t)(128 * jd) * n64 + 128 * jd;
 #pragma unroll
       for (int h = 0; h < 2; ++h) {                     // stage h holds row blocks 4h .. 4h + 3: m = h for every wave
+        int lane = threadIdx.x & 63;
+        C128_LAUNDER(lane);
+        const int i = lane & 15, q = lane >> 4;
         c128_issue_rows(Sx + (int64_t)(64 * h) * n64, n64, wave, lane, lds0);
         C128_STAGE_SYNC();
         const int rbk = h == 0 ? wave : 7 - wave;       // this wave's row block of the stage
         const int gi = 128 * jd + 16 * rbk + i;
+        const int lim = gi < nrhs ? nb - 128 * jd - q : -1;        // off the diagonal: data when 16 n + 4 r < lim
+        const int de = 16 * rbk + i - q;                           // the diagonal element sits at 16 n + 4 r == de
+        // on the diagonal: + shift inside the matrix, 2^100 on an embedded right-hand-side row, 1 in the identity padding
+        const double dadd = gi < nb ? sh : (gi < nrhs ? RG_EMBED_DIAG : 1.0), dmul = gi < nb ? 1.0 : 0.0;
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
           if (h == 0 && n > 3) continue;                // row blocks 0-3 have no columns past block 3
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int gj = 128 * jd + 16 * n + q + 4 * r;
             double x = c128_rows_at(smem, rbk - 4 * h, n, r, i, q);
+            x = (16 * n + 4 * r < lim) ? x : 0.0;
             if (src == 0) {
-              const double off = (gj < nb && gi < nrhs) ? x : 0.0;
-              const double dg = gi < nb ? x + sh : (gi < nrhs ? RG_EMBED_DIAG : 1.0);
-              x = gi == gj ? dg : off;
+              x = (16 * n + 4 * r == de) ? fma(x, dmul, dadd) : x;
               acc[n][h][r] = -x;
             } else {
-              x = (gj < nb && gi < nrhs) ? x : 0.0;
               acc[n][h][r] += x;
             }
           }
@@ -321,19 +336,20 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
     const int ns = 8 * jd;
     const double* arows = M + (int64_t)(128 * jd) * n64;
     const int aoff0 = (16 * wave + i) * 128, aoff1 = (16 * (7 - wave) + i) * 128, boff = i * 128;
-    if (ns > 0) {
+    if (MODE >= 1) {
       c128_issue_k(arows, nullptr, 0, 0, wave, n64, lds0, koff);
       C128_STAGE_SYNC();
-    }
+      int s = 0;
 #pragma unroll 1
-    for (int s = 0; s < ns; ++s) {
-      if (s + 1 < ns) c128_issue_k(arows, nullptr, s + 1, (s + 1) & 1, wave, n64, lds0, koff);
-      const uint8_t* cur = smem + (s & 1) * C128_STAGE;
-      if (wave == 0) c128_kstage<true, 0>(cur, aoff0, aoff1, boff, s0, s1, acc);
-      else if (wave == 1) c128_kstage<true, 1>(cur, aoff0, aoff1, boff, s0, s1, acc);
-      else if (wave == 2) c128_kstage<true, 2>(cur, aoff0, aoff1, boff, s0, s1, acc);
-      else c128_kstage<true, 3>(cur, aoff0, aoff1, boff, s0, s1, acc);
-      C128_STAGE_SYNC_ACC(acc);
+      do {
+        if (s + 1 < ns) c128_issue_k(arows, nullptr, s + 1, (s + 1) & 1, wave, n64, lds0, koff);
+        const uint8_t* cur = smem + (s & 1) * C128_STAGE;
+        if (wave == 0) c128_kstage<true, 0>(cur, aoff0, aoff1, boff, s0, s1, acc);
+        else if (wave == 1) c128_kstage<true, 1>(cur, aoff0, aoff1, boff, s0, s1, acc);
+        else if (wave == 2) c128_kstage<true, 2>(cur, aoff0, aoff1, boff, s0, s1, acc);
+        else c128_kstage<true, 3>(cur, aoff0, aoff1, boff, s0, s1, acc);
+        C128_STAGE_SYNC_ACCD(acc);
+      } while (++s < ns);
     }
   }
   // ---- factor the 128 x 128 block as 2 x 2 tiles of 64 (acc = -D: lane (i, q) holds -D[16 rb + i][16 n + q + 4 r]) ------------------------
@@ -465,7 +481,9 @@ static void c128_launch_factor(hipStream_t st, double* mats, int64_t mat_stride,
     a.j = j;
     a.nplain = j < 0 ? 0 : std::max(0, a.Tp - j - 2);
     const unsigned grid = xcd_affine_grid(1, batch, R) + (a.nplain ? xcd_affine_grid(a.nplain, batch, R) : 0u);
-    hipLaunchKernelGGL(k_c128_panel, dim3(grid), dim3(256), 0, st, a);
+    if (j < 0) hipLaunchKernelGGL(k_c128_panel<0>, dim3(grid), dim3(256), 0, st, a);
+    else if (j == 0) hipLaunchKernelGGL(k_c128_panel<1>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_c128_panel<2>, dim3(grid), dim3(256), 0, st, a);
     ++nl;
   }
 }
