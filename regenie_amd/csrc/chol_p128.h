@@ -58,6 +58,28 @@
 #define C128_STAGE_SYNC_ACCD(acc) C128_STAGE_SYNC()
 #endif
 
+// K ring: units of 16 KB = 8 k of the tile's 128 rows (8 KB) | 8 k of the panel's 128 rows (8 KB), four of them, copies issued three units
+// ahead (a stage of 16 k issued ONE ahead left a wave waiting for its copy after every 64 products: the tile's rows come from HBM, 2+ us,
+// against 0.85 us of products -- first device run, profiles/r6_batch_sequence_first_p128.md)
+#define C128_UNIT 16384
+#define C128_NBUF 4
+#define C128_DIST 3
+#ifndef RG_HOST_EMU
+template <int N>
+__device__ __forceinline__ void c128_wait_upto(int n) {   // s_waitcnt vmcnt(4 * min(n, N)), immediate operands only
+  if (N > 0 && n >= N) { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * N) : "memory"); return; }
+  if (N > 0) c128_wait_upto<(N > 0 ? N - 1 : 0)>(n);
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+// unit u has landed (at most `later` units issued after it may still be in flight) and every wave is done with the unit before it
+#define C128_UNIT_SYNC(later)                                          \
+  do {                                                                 \
+    c128_wait_upto<C128_DIST - 1>(later);                              \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    \
+  } while (0)
+#else
+#define C128_UNIT_SYNC(later) __syncthreads()
+#endif
 #define C128_STAGE 32768
 #define C128_LDS (2 * C128_STAGE + 4096)      // the diagonal items alias sA | sB (64 x 66 doubles each) + dv (64) onto the stage buffers
 
@@ -67,56 +89,59 @@ struct C128Args {
   double* dinv;         // [batch][n64 / 64][64 * 64]: tile inverses for the back substitution (k_chol_backsolve*)
   int32_t* info;
   int j, Tp, batch, R, nplain;
+  unsigned long long* dbg;      // RG_C128_DBG=1: per-phase time sums (100 MHz ticks of s_memrealtime, thread 0 of every workgroup); else nullptr
   FormSrc fs;
 };
+#ifndef RG_HOST_EMU
+#define C128_T(k)                                                                        \
+  do {                                                                                   \
+    if (a.dbg && threadIdx.x == 0) {                                                     \
+      const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                    \
+      atomicAdd(&a.dbg[k], t_ - t_prev);                                                 \
+      t_prev = t_;                                                                       \
+    }                                                                                    \
+  } while (0)
+#define C128_T0() (a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull)
+#else
+#define C128_T(k) ((void)0)
+#define C128_T0() 0ull
+#endif
 
-// ---- one K-chunk stage: accT[n][m] += L_j rows(n) x tile rows(m)^T over 16 k ------------------------------------------------------------
-// DIAG: both operands are the panel's own rows (A part of the stage); wave W issues the blocks n <= W (m = 0: row block W) and n <= 7 - W
-// (m = 1: row block 7 - W).
-template <bool DIAG, int W>
-__device__ __forceinline__ void c128_kstage(const uint8_t* cur, int aoff0, int aoff1, int boff, int s0, int s1, v4d (&acc)[8][2]) {
-  double2 a[2][2];
-  a[0][0] = *reinterpret_cast<const double2*>(cur + aoff0 + s0);
-  a[0][1] = *reinterpret_cast<const double2*>(cur + aoff0 + s1);
-  a[1][0] = *reinterpret_cast<const double2*>(cur + aoff1 + s0);
-  a[1][1] = *reinterpret_cast<const double2*>(cur + aoff1 + s1);
+// ---- one ring unit: accT[n][m] += L_j rows(n) x tile rows(m)^T over 8 k -----------------------------------------------------------------
+// rows of 64 bytes, the four 16-byte slots XOR-swizzled by f((row >> 2) & 3), f = (0, 3, 2, 1): every ds_read_b128 lane group then falls on
+// 16 distinct bank quads.  Lane (i, q) takes slot q: k = 2q, 2q + 1.
+// DIAG: both operands are the panel's own rows; wave W issues the blocks n <= W (m = 0: row block W) and n <= 7 - W (m = 1: row block 7 - W).
+template <bool DIAG>
+__device__ __forceinline__ void c128_kunit(const uint8_t* cur, int aoff0, int aoff1, int boff, int sq, v4d (&acc)[8][2], int W) {
+  double2 a[2], b[8];
+  a[0] = *reinterpret_cast<const double2*>(cur + aoff0 + sq);
+  a[1] = *reinterpret_cast<const double2*>(cur + aoff1 + sq);
 #pragma unroll
-  for (int nh = 0; nh < 2; ++nh) {        // the panel's row blocks in two halves: 32 operand registers live instead of 64
-    double2 b[4][2];
+  for (int n = 0; n < 8; ++n) b[n] = *reinterpret_cast<const double2*>(cur + boff + n * 1024 + sq);
 #pragma unroll
-    for (int nl = 0; nl < 4; ++nl) {
-      const int n = 4 * nh + nl;
-      if (DIAG && n > W && n > 7 - W) continue;
-      b[nl][0] = *reinterpret_cast<const double2*>(cur + boff + n * 2048 + s0);
-      b[nl][1] = *reinterpret_cast<const double2*>(cur + boff + n * 2048 + s1);
-    }
+  for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+    for (int n = 0; n < 8; ++n)
 #pragma unroll
-      for (int nl = 0; nl < 4; ++nl)
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const int n = 4 * nh + nl;
-          if (DIAG && n > (m == 0 ? W : 7 - W)) continue;
-          const double av = kk == 0 ? a[m][0].x : (kk == 1 ? a[m][0].y : (kk == 2 ? a[m][1].x : a[m][1].y));
-          const double bv = kk == 0 ? b[nl][0].x : (kk == 1 ? b[nl][0].y : (kk == 2 ? b[nl][1].x : b[nl][1].y));
-          acc[n][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc[n][m], 0, 0, 0);
-        }
-  }
+      for (int m = 0; m < 2; ++m) {
+        if (DIAG && (m == 0 ? n > 3 : false)) continue;                 // row blocks 0-3 have no columns past block 3
+        if (DIAG && n > (m == 0 ? W : 7 - W)) continue;                  // wave-uniform: a scalar branch around the product
+        acc[n][m] = __builtin_amdgcn_mfma_f64_16x16x4f64(kk == 0 ? b[n].x : b[n].y, kk == 0 ? a[m].x : a[m].y, acc[n][m], 0, 0, 0);
+      }
 }
 
 // ---- stage copies (direct global -> LDS, 16 bytes per lane) -------------------------------------------------------------------------------
-// K chunk: piece p of wave w = rows 64 (w & 1) + 8 p .. + 7 of the A part (w < 2: the tile's rows) or the B part (the panel's rows); the slot
-// swizzle (row >> 1) & 7 of row 8 p + (lane >> 3) depends on the parity of p alone: two lane offsets, the rest is scalar
-__device__ __forceinline__ void c128_issue_k(const double* arows, const double* brows, int s, int buf, int wave, int n64, uint32_t lds0,
-                                             const uint32_t (&koff)[2]) {
-  const double* base = (wave < 2 ? arows : brows);      // brows == nullptr: the A part only
-  if (base) {
-    base += 16 * s + (int64_t)(64 * (wave & 1)) * n64;
-    const uint32_t dst = lds0 + buf * C128_STAGE + wave * 8192;
+// ring unit: waves 0, 1 copy the A half (8 k of 128 rows from ap), waves 2, 3 the B half (from bp); piece p of a wave = rows 64 (w & 1) + 16 p .. + 15,
+// lane l -> row + (l >> 2), slot (l & 3); the swizzle f((row >> 2) & 3) = f(l >> 4) is the same for every piece: one lane offset, the rest scalar
+__device__ __forceinline__ void c128_issue_unit(const double* ap, const double* bp, int buf, int wave, int n64, uint32_t lds0, uint32_t uoff) {
+  const double* base = (wave < 2 ? ap : bp) + (int64_t)(64 * (wave & 1)) * n64;
+  const uint32_t dst = lds0 + buf * C128_UNIT + wave * 4096;
 #pragma unroll
-    for (int p = 0; p < 8; ++p) c128_glds16(base + (int64_t)(8 * p) * n64, koff[p & 1], dst + p * 1024);
-  }
+  for (int p = 0; p < 4; ++p) c128_glds16(base + (int64_t)(16 * p) * n64, uoff, dst + p * 1024);
+}
+__device__ __forceinline__ uint32_t c128_unit_off(int lane, int n64) {
+  const int slot = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
+  return (uint32_t)(((int64_t)(lane >> 2) * n64 + 2 * slot) * 8);
 }
 // row stage: 64 rows x 128 doubles (1 KB per row), wave w copies rows 16 w .. 16 w + 15; lane l of row p takes the 16-byte slot l ^ p
 __device__ __forceinline__ void c128_issue_rows(const double* src, int64_t ld, int wave, int lane, uint32_t lds0) {
@@ -124,6 +149,19 @@ __device__ __forceinline__ void c128_issue_rows(const double* src, int64_t ld, i
   const uint32_t dst = lds0 + wave * 16384;
 #pragma unroll
   for (int p = 0; p < 16; ++p) c128_glds16(base + (int64_t)p * ld, (uint32_t)((lane ^ p) << 4), dst + p * 1024);
+}
+// ring unit of 16 rows x 128 doubles (1 KB per row): wave w copies rows 4 w .. 4 w + 3; lane l of row p takes the 16-byte slot l ^ p
+__device__ __forceinline__ void c128_issue_rows16(const double* src, int64_t ld, int buf, int wave, int lane, uint32_t lds0) {
+  const uint32_t dst = lds0 + buf * C128_UNIT + wave * 4096;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int row = 4 * wave + p;
+    c128_glds16(src + (int64_t)row * ld, (uint32_t)((lane ^ row) << 4), dst + p * 1024);
+  }
+}
+// element (row i, column 16 n + q + 4 r) of such a unit
+__device__ __forceinline__ double c128_rows16_at(const uint8_t* cur, int n, int r, int i, int q) {
+  return *reinterpret_cast<const double*>(cur + i * 1024 + (((8 * n + 2 * r + (q >> 1)) ^ i) << 4) + 8 * (q & 1));
 }
 // element (row block rbl of the stage, row i, column 16 n + q + 4 r) of a row stage
 __device__ __forceinline__ double c128_rows_at(const uint8_t* smem, int rbl, int n, int r, int i, int q) {
@@ -162,6 +200,8 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   if (it >= tpb) return;
   double* M = a.mats + (int64_t)b * a.mat_stride;
   const uint32_t lds0 = C128_LDS_ADDR(smem);
+  unsigned long long t_prev = C128_T0();
+  if (a.dbg && threadIdx.x == 0) atomicAdd(&a.dbg[succ ? 17 : 16], 1ull);
 
   v4d acc[8][2];
 #pragma unroll
@@ -170,73 +210,79 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
     for (int m = 0; m < 2; ++m) acc[n][m] = (v4d){0, 0, 0, 0};
 
   // ======== part 1: tile (it, j) = (X - L[it][0..j-1] L[j][0..j-1]^T) Linv_jj^T ==========================================================
+  // ONE ring pipeline per tile, copies three units ahead throughout: 16 j K units, then the tile's 8 row blocks of the source(s) (X: 16 rows x
+  // 128 columns each, consumed by the wave that owns the rows), then the 8 row blocks of Linv (the triangular multiply, block cb of the
+  // result stored under the products of block cb + 1).  (First build: X and Linv as 64 KB stages with nothing in flight behind them --
+  // 17 + 24 us per tile next to 47 us of K units, RG_C128_DBG=1.)
+  const int nsrc = fx.F ? 2 : 1;
   if (MODE >= 1) {
     const int rb0 = 32 * wave;                          // this wave's rows of the tile: rb0 + 16 m + i
+    const int nK = MODE >= 2 ? 16 * j : 0, nX = 8 * nsrc, total = nK + nX + 8;
+    const double* arows = M + (int64_t)(128 * it) * n64;
+    const double* brows = M + (int64_t)(128 * j) * n64;
+    const double* Li = a.linv + ((int64_t)b * a.Tp + j) * (128 * 128);
+    auto issue_xt = [&](int u, int lane) {              // u >= nK: a row block of S / F, then of Linv
+      const int x = u - nK;
+      if (x < nX) c128_issue_rows16((x >= 8 ? fx.F : fx.S) + (int64_t)(128 * it + 16 * (x & 7)) * n64 + 128 * j, n64, u & (C128_NBUF - 1), wave, lane, lds0);
+      else c128_issue_rows16(Li + (int64_t)(16 * (x - nX)) * 128, 128, u & (C128_NBUF - 1), wave, lane, lds0);
+    };
+    int u = 0;
     {
-      // ---- X: acc = -(S - F) from the sources, two row stages per source (rows 0-63 | 64-127); waves 2h, 2h+1 own the rows of stage h
-#pragma unroll 1
-      for (int src = 0; src < (fx.F ? 2 : 1); ++src) {
-        const double* Sx = (src ? fx.F : fx.S) + (int64_t)(128 * it) * n64 + 128 * j;
-        const double sgn = src ? 1.0 : -1.0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          int lane = threadIdx.x & 63;
-          C128_LAUNDER(lane);       // per stage: the element masks below must not be hoisted out of the stage (they were, as spilled SGPR pairs)
-          const int i = lane & 15, q = lane >> 4;
-          c128_issue_rows(Sx + (int64_t)(64 * h) * n64, n64, wave, lane, lds0);
-          C128_STAGE_SYNC();
-          if ((wave >> 1) == h) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              // element (gi, gj) holds data when gj < nb and gi < nrhs: one limit per lane on the column offset e = 16 n + 4 r (+ q)
-              const int gi = 128 * it + rb0 + 16 * m + i;
-              const int lim = gi < nrhs ? nb - 128 * j - q : -1;
-#pragma unroll
-              for (int n = 0; n < 8; ++n)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                  double x = c128_rows_at(smem, 2 * (wave & 1) + m, n, r, i, q);
-                  x = (16 * n + 4 * r < lim) ? x : 0.0;
-                  acc[n][m][r] = fma(sgn, x, acc[n][m][r]);
-                }
-            }
-          }
-          C128_STAGE_SYNC();
-        }
-      }
-    }
-    {
-      // ---- K loop: 8 j stages of 16 k
       int lane = threadIdx.x & 63;
       C128_LAUNDER(lane);
       const int i = lane & 15, q = lane >> 4;
-      const int xs = (i >> 1) & 7;
-      const int s0 = (q ^ xs) << 4, s1 = ((q + 4) ^ xs) << 4;
-      uint32_t koff[2];
+      const int sq = (q ^ ((4 - (i >> 2)) & 3)) << 4;
+      const uint32_t uoff = c128_unit_off(lane, n64);
+      const int aoff0 = (rb0 + i) * 64, aoff1 = (rb0 + 16 + i) * 64, boff = 8192 + i * 64;
+      auto issue_any = [&](int v) {
+        if (v < nK) c128_issue_unit(arows + 8 * v, brows + 8 * v, v & (C128_NBUF - 1), wave, n64, lds0, uoff);
+        else issue_xt(v, lane);
+      };
 #pragma unroll
-      for (int p = 0; p < 2; ++p) koff[p] = (uint32_t)(((int64_t)(lane >> 3) * n64 + 2 * ((lane & 7) ^ (((8 * p + (lane >> 3)) >> 1) & 7))) * 8);
-      const int ns = 8 * j;
-      const double* arows = M + (int64_t)(128 * it) * n64;
-      const double* brows = M + (int64_t)(128 * j) * n64;
-      const int aoff0 = (rb0 + i) * 128, aoff1 = (rb0 + 16 + i) * 128, boff = 16384 + i * 128;
+      for (int p = 0; p < C128_DIST; ++p) issue_any(p);      // total >= 16
       if (MODE >= 2) {
-        c128_issue_k(arows, brows, 0, 0, wave, n64, lds0, koff);
-        C128_STAGE_SYNC();
-        int s = 0;
 #pragma unroll 1
         do {
-          if (s + 1 < ns) c128_issue_k(arows, brows, s + 1, (s + 1) & 1, wave, n64, lds0, koff);
-          c128_kstage<false, 0>(smem + (s & 1) * C128_STAGE, aoff0, aoff1, boff, s0, s1, acc);
-          C128_STAGE_SYNC_ACC(acc);
-        } while (++s < ns);
+          C128_UNIT_SYNC(total - 1 - u);
+          issue_any(u + C128_DIST);                           // (K units are never the last three)
+          c128_kunit<false>(smem + (u & (C128_NBUF - 1)) * C128_UNIT, aoff0, aoff1, boff, sq, acc, 0);
+        } while (++u < nK);
       }
     }
+    C128_T(2);
+#pragma unroll 1
+    for (int src = 0; src < nsrc; ++src) {
+      const double sgn = src ? 1.0 : -1.0;
+#pragma unroll
+      for (int rb = 0; rb < 8; ++rb) {
+        int lane = threadIdx.x & 63;
+        C128_LAUNDER(lane);       // per unit: the element masks below must not be hoisted out (they were, as spilled SGPR pairs)
+        const int i = lane & 15, q = lane >> 4;
+        C128_UNIT_SYNC(total - 1 - u);
+        if (u + C128_DIST < total) issue_xt(u + C128_DIST, lane);
+        if (wave == (rb >> 1)) {
+          const uint8_t* cur = smem + (u & (C128_NBUF - 1)) * C128_UNIT;
+          // element (gi, gj) holds data when gj < nb and gi < nrhs: one limit per lane on the column offset 16 n + 4 r (+ q)
+          const int gi = 128 * it + 16 * rb + i;
+          const int lim = gi < nrhs ? nb - 128 * j - q : -1;
+#pragma unroll
+          for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              double x = c128_rows16_at(cur, n, r, i, q);
+              x = (16 * n + 4 * r < lim) ? x : 0.0;
+              acc[n][rb & 1][r] = fma(sgn, x, acc[n][rb & 1][r]);
+            }
+        }
+        ++u;
+      }
+    }
+    C128_T(1);
     {
-      // ---- T = U Linv^T by row blocks cb of Linv: out[cb] = sum_{n <= cb} U[.][16n..] Linv[16cb..][16n..]^T; two row stages of Linv
+      // ---- T = U Linv^T by row blocks cb of Linv: out[cb] = sum_{n <= cb} U[.][16n..] Linv[16cb..][16n..]^T
       int lane = threadIdx.x & 63;
       C128_LAUNDER(lane);
       const int i = lane & 15, q = lane >> 4;
-      const double* Li = a.linv + ((int64_t)b * a.Tp + j) * (128 * 128);
       double* Trow = M + (int64_t)(128 * it + rb0 + q) * n64 + 128 * j + i;      // element (row rb0 + q, column i) of the tile
       v4d pend[2];                                        // the previous block's results: stored under the next block's products
       int pend_cb = -1;
@@ -247,37 +293,35 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
           for (int r = 0; r < 4; ++r) Trow[(int64_t)(16 * m + 4 * r) * n64 + 16 * pend_cb] = pend[m][r];
       };
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        c128_issue_rows(Li + (int64_t)(64 * h) * 128, 128, wave, lane, lds0);
-        C128_STAGE_SYNC();
+      for (int cb = 0; cb < 8; ++cb) {
+        C128_UNIT_SYNC(total - 1 - u);
+        if (u + C128_DIST < total) issue_xt(u + C128_DIST, lane);
+        const uint8_t* cur = smem + (u & (C128_NBUF - 1)) * C128_UNIT;
+        if (pend_cb >= 0) store_pend();
+        v4d out[2];
+        out[0] = (v4d){0, 0, 0, 0};
+        out[1] = (v4d){0, 0, 0, 0};
 #pragma unroll
-        for (int cl = 0; cl < 4; ++cl) {
-          const int cb = 4 * h + cl;
-          if (pend_cb >= 0) store_pend();
-          v4d out[2];
-          out[0] = (v4d){0, 0, 0, 0};
-          out[1] = (v4d){0, 0, 0, 0};
+        for (int n = 0; n < 8; ++n) {
+          if (n > cb) continue;
 #pragma unroll
-          for (int n = 0; n < 8; ++n) {
-            if (n > cb) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const double lv = c128_rows_at(smem, cl, n, r, i, q);
-              out[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[n][0][r], lv, out[0], 0, 0, 0);
-              out[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[n][1][r], lv, out[1], 0, 0, 0);
-            }
+          for (int r = 0; r < 4; ++r) {
+            const double lv = c128_rows16_at(cur, n, r, i, q);
+            out[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[n][0][r], lv, out[0], 0, 0, 0);
+            out[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-acc[n][1][r], lv, out[1], 0, 0, 0);
           }
-          pend[0] = out[0];
-          pend[1] = out[1];
-          pend_cb = cb;
         }
-        C128_STAGE_SYNC();
+        pend[0] = out[0];
+        pend[1] = out[1];
+        pend_cb = cb;
+        ++u;
       }
       store_pend();
     }
+    C128_T(3);
     if (!succ) return;
-    __threadfence();                                    // the diagonal block below reads this tile back (same workgroup, through L2)
-    C128_STAGE_SYNC();
+    __threadfence_block();                              // the diagonal block below reads this tile back: same workgroup, same L2 (an agent-scope
+    C128_STAGE_SYNC();                                  // fence wrote the XCD's whole L2 back: 25 us per item)
 #pragma unroll
     for (int n = 0; n < 8; ++n)
 #pragma unroll
@@ -285,73 +329,81 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   }
 
   // ======== part 2 (successor item): diagonal block jd = j + 1 ============================================================================
+  // row blocks of 16: wave w holds block w (m = 0, columns n <= w) and block 7 - w (m = 1, columns n <= 7 - w).  The same ring: 8 jd K units
+  // of 16 k (the A half holds 8 k of the panel's rows, the B half the next 8 k of the SAME rows), then the 8 row blocks of the source(s).
   const int jd = j + 1;
-  // row blocks of 16: wave w holds block w (m = 0, columns n <= w) and block 7 - w (m = 1, columns n <= 7 - w)
   {
+    const int nK = MODE >= 1 ? 8 * jd : 0, nX = 8 * nsrc, total = nK + nX;
+    const double* arows = M + (int64_t)(128 * jd) * n64;
+    auto issue_x = [&](int u, int lane) {
+      const int x = u - nK;
+      c128_issue_rows16((x >= 8 ? fx.F : fx.S) + (int64_t)(128 * jd + 16 * (x & 7)) * n64 + 128 * jd, n64, u & (C128_NBUF - 1), wave, lane, lds0);
+    };
+    int u = 0;
+    {
+      int lane = threadIdx.x & 63;
+      C128_LAUNDER(lane);
+      const int i = lane & 15, q = lane >> 4;
+      const int sq = (q ^ ((4 - (i >> 2)) & 3)) << 4;
+      const uint32_t uoff = c128_unit_off(lane, n64);
+      const int aoff0 = (16 * wave + i) * 64, aoff1 = (16 * (7 - wave) + i) * 64, boff = i * 64;
+      auto issue_any = [&](int v) {
+        if (v < nK) c128_issue_unit(arows + 16 * v, arows + 16 * v + 8, v & (C128_NBUF - 1), wave, n64, lds0, uoff);
+        else issue_x(v, lane);
+      };
+#pragma unroll
+      for (int p = 0; p < C128_DIST; ++p) issue_any(p);      // total >= 8
+      if (MODE >= 1) {
+#pragma unroll 1
+        do {
+          C128_UNIT_SYNC(total - 1 - u);
+          issue_any(u + C128_DIST);
+          const uint8_t* cur = smem + (u & (C128_NBUF - 1)) * C128_UNIT;
+          c128_kunit<true>(cur, aoff0, aoff1, boff, sq, acc, wave);
+          c128_kunit<true>(cur + 8192, aoff0, aoff1, boff, sq, acc, wave);
+        } while (++u < nK);
+      }
+    }
+    C128_T(5);
     const double sh = fx.sh;
 #pragma unroll 1
-    for (int src = 0; src < (fx.F ? 2 : 1); ++src) {
-      const double* Sx = (src ? fx.F : fx.S) + (int64_t)(128 * jd) * n64 + 128 * jd;
+    for (int src = 0; src < nsrc; ++src) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {                     // stage h holds row blocks 4h .. 4h + 3: m = h for every wave
+      for (int rb = 0; rb < 8; ++rb) {
         int lane = threadIdx.x & 63;
         C128_LAUNDER(lane);
         const int i = lane & 15, q = lane >> 4;
-        c128_issue_rows(Sx + (int64_t)(64 * h) * n64, n64, wave, lane, lds0);
-        C128_STAGE_SYNC();
-        const int rbk = h == 0 ? wave : 7 - wave;       // this wave's row block of the stage
-        const int gi = 128 * jd + 16 * rbk + i;
-        const int lim = gi < nrhs ? nb - 128 * jd - q : -1;        // off the diagonal: data when 16 n + 4 r < lim
-        const int de = 16 * rbk + i - q;                           // the diagonal element sits at 16 n + 4 r == de
-        // on the diagonal: + shift inside the matrix, 2^100 on an embedded right-hand-side row, 1 in the identity padding
-        const double dadd = gi < nb ? sh : (gi < nrhs ? RG_EMBED_DIAG : 1.0), dmul = gi < nb ? 1.0 : 0.0;
+        C128_UNIT_SYNC(total - 1 - u);
+        if (u + C128_DIST < total) issue_x(u + C128_DIST, lane);
+        if (wave == (rb < 4 ? rb : 7 - rb)) {
+          const uint8_t* cur = smem + (u & (C128_NBUF - 1)) * C128_UNIT;
+          const int gi = 128 * jd + 16 * rb + i;
+          const int lim = gi < nrhs ? nb - 128 * jd - q : -1;        // off the diagonal: data when 16 n + 4 r < lim
+          const int de = 16 * rb + i - q;                            // the diagonal element sits at 16 n + 4 r == de
+          // on the diagonal: + shift inside the matrix, 2^100 on an embedded right-hand-side row, 1 in the identity padding
+          const double dadd = gi < nb ? sh : (gi < nrhs ? RG_EMBED_DIAG : 1.0), dmul = gi < nb ? 1.0 : 0.0;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) {
-          if (h == 0 && n > 3) continue;                // row blocks 0-3 have no columns past block 3
+          for (int n = 0; n < 8; ++n) {
+            if (n > rb) continue;                                    // lower 16-blocks only
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            double x = c128_rows_at(smem, rbk - 4 * h, n, r, i, q);
-            x = (16 * n + 4 * r < lim) ? x : 0.0;
-            if (src == 0) {
-              x = (16 * n + 4 * r == de) ? fma(x, dmul, dadd) : x;
-              acc[n][h][r] = -x;
-            } else {
-              acc[n][h][r] += x;
+            for (int r = 0; r < 4; ++r) {
+              double x = c128_rows16_at(cur, n, r, i, q);
+              x = (16 * n + 4 * r < lim) ? x : 0.0;
+              if (src == 0) {
+                x = (16 * n + 4 * r == de) ? fma(x, dmul, dadd) : x;
+                acc[n][rb < 4 ? 0 : 1][r] -= x;
+              } else {
+                acc[n][rb < 4 ? 0 : 1][r] += x;
+              }
             }
           }
         }
-        C128_STAGE_SYNC();
+        ++u;
       }
     }
+    C128_STAGE_SYNC();
   }
-  {
-    int lane = threadIdx.x & 63;
-    C128_LAUNDER(lane);
-    const int i = lane & 15, q = lane >> 4;
-    const int xs = (i >> 1) & 7;
-    const int s0 = (q ^ xs) << 4, s1 = ((q + 4) ^ xs) << 4;
-    uint32_t koff[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) koff[p] = (uint32_t)(((int64_t)(lane >> 3) * n64 + 2 * ((lane & 7) ^ (((8 * p + (lane >> 3)) >> 1) & 7))) * 8);
-    const int ns = 8 * jd;
-    const double* arows = M + (int64_t)(128 * jd) * n64;
-    const int aoff0 = (16 * wave + i) * 128, aoff1 = (16 * (7 - wave) + i) * 128, boff = i * 128;
-    if (MODE >= 1) {
-      c128_issue_k(arows, nullptr, 0, 0, wave, n64, lds0, koff);
-      C128_STAGE_SYNC();
-      int s = 0;
-#pragma unroll 1
-      do {
-        if (s + 1 < ns) c128_issue_k(arows, nullptr, s + 1, (s + 1) & 1, wave, n64, lds0, koff);
-        const uint8_t* cur = smem + (s & 1) * C128_STAGE;
-        if (wave == 0) c128_kstage<true, 0>(cur, aoff0, aoff1, boff, s0, s1, acc);
-        else if (wave == 1) c128_kstage<true, 1>(cur, aoff0, aoff1, boff, s0, s1, acc);
-        else if (wave == 2) c128_kstage<true, 2>(cur, aoff0, aoff1, boff, s0, s1, acc);
-        else c128_kstage<true, 3>(cur, aoff0, aoff1, boff, s0, s1, acc);
-        C128_STAGE_SYNC_ACCD(acc);
-      } while (++s < ns);
-    }
-  }
+  C128_T(4);
   // ---- factor the 128 x 128 block as 2 x 2 tiles of 64 (acc = -D: lane (i, q) holds -D[16 rb + i][16 n + q + 4 r]) ------------------------
   int tid = threadIdx.x;
   C128_LAUNDER(tid);
@@ -387,7 +439,9 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
       sA[rr][cc] = (cc <= rr) ? -acc[n][0][r] : 0.0;
     }
   __syncthreads();
+  C128_T(6);
   bad |= diag_factor_lds(sA, dv);
+  C128_T(7);
   // L21 = D21 Linv11^T: this wave's row block 7 - w of the block = rows 16 (3 - w) of the lower half
   const int lrb = 3 - wave;
   {
@@ -447,7 +501,9 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
       sA[rr][cc] = (cc <= rr) ? -acc[4 + nn][1][r] : 0.0;
     }
   __syncthreads();
+  C128_T(8);
   bad |= diag_factor_lds(sA, dv);
+  C128_T(9);
   // I21 = -Linv22 M1: wave w takes rows 16 w .. of the lower half
   {
     v4d o[4];
@@ -467,6 +523,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
       for (int r = 0; r < 4; ++r) Lv[(64 + 16 * wave + lq + 4 * r) * 128 + 16 * cb + li] = -o[cb][r];
   }
   save_tile(64, 1);
+  C128_T(10);
   if (bad) atomicMax(a.info, 1);
 }
 
@@ -477,6 +534,9 @@ static void c128_launch_factor(hipStream_t st, double* mats, int64_t mat_stride,
   C128Args a;
   a.mats = mats; a.mat_stride = mat_stride; a.n64 = n64; a.linv = linv; a.dinv = dinv; a.info = info;
   a.Tp = n64 / 128; a.batch = batch; a.R = R; a.fs = first;
+  static const bool dbg = getenv("RG_C128_DBG") && atoi(getenv("RG_C128_DBG")) != 0;
+  a.dbg = nullptr;
+  if (dbg && hipMalloc(&a.dbg, 32 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemsetAsync(a.dbg, 0, 32 * sizeof(unsigned long long), st);
   for (int j = -1; j <= a.Tp - 2; ++j) {
     a.j = j;
     a.nplain = j < 0 ? 0 : std::max(0, a.Tp - j - 2);
@@ -485,5 +545,15 @@ static void c128_launch_factor(hipStream_t st, double* mats, int64_t mat_stride,
     else if (j == 0) hipLaunchKernelGGL(k_c128_panel<1>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(k_c128_panel<2>, dim3(grid), dim3(256), 0, st, a);
     ++nl;
+  }
+  if (a.dbg) {      // diagnostic: per-phase sums over the workgroups, in microseconds of workgroup time (s_memrealtime ticks at 100 MHz)
+    unsigned long long h[32];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(a.dbg);
+    static const char* nm[11] = {"", "X1", "K1", "T1", "X2", "K2", "->sA", "factor11", "L21/M1/D22/save", "factor22", "I21/save"};
+    fprintf(stderr, "c128 phases (batch %d, n64 %d): plain items %llu, successor items %llu; workgroup-us:", batch, n64, h[16], h[17]);
+    for (int k = 1; k <= 10; ++k) fprintf(stderr, " %s %.0f", nm[k], h[k] / 100.0);
+    fprintf(stderr, "\n");
   }
 }

@@ -55,6 +55,7 @@ inline double __hiloint2double(int hi, int lo) { const uint64_t u = ((uint64_t)(
 inline double __builtin_amdgcn_rsq(double x) { return 1.0 / std::sqrt(x); }
 inline int atomicMax(int32_t* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
 inline void __threadfence() {}
+inline void __threadfence_block() {}
 #define C128_LDS_ADDR(p) (emu::lds_base = (uint8_t*)(p), 0u)
 #define C128_STAGE_SYNC() __syncthreads()
 #define C128_RFL(x) (x)
