@@ -89,6 +89,8 @@ struct C128Args {
   double* dinv;         // [batch][n64 / 64][64 * 64]: tile inverses for the back substitution (k_chol_backsolve*)
   int32_t* info;
   int j, Tp, batch, R, nplain;
+  int flags;            // diagnostics (RG_C128_FLAGS): timing only, wrong results: 2 = every source row block is read from
+                        // the system's first 16 rows, 4 = no products in the triangular multiply, 8 = the two tile factorizations skipped
   unsigned long long* dbg;      // RG_C128_DBG=1: per-phase time sums (100 MHz ticks of s_memrealtime, thread 0 of every workgroup); else nullptr
   FormSrc fs;
 };
@@ -106,6 +108,140 @@ struct C128Args {
 #define C128_T(k) ((void)0)
 #define C128_T0() 0ull
 #endif
+
+// ---- blocked (16) factorization + inverse of the 64x64 tile held in LDS (diag_factor_lds of chol_common.h with a straight-line 16 x 16 step) ----
+// On return: lower triangle + diagonal of s = L, strict upper triangle = Linv^T, dv[r] = Linv[r][r].
+// Returns true (in some thread) when a pivot was not positive.
+__device__ __forceinline__ bool c128_factor64(double (&s)[CT][CT + 2], double (&dv)[CT], unsigned long long* dbg = nullptr) {
+#ifndef RG_HOST_EMU
+#define C128_FT(k) do { if (dbg && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&dbg[k], t_ - tf); tf = t_; } } while (0)
+  unsigned long long tf = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#else
+#define C128_FT(k) ((void)0)
+#endif
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lq = lane >> 4;
+  // ---- blocked (16) factorization + inverse, the 16x16x16 block products on the fp64 MFMA ---------------
+  // MFMA 16x16x4: lane (i = lane&15, q = lane>>4) supplies A[i][kk], B[kk][i] and owns D[q + 4r][i], r = 0..3;
+  // a K = 16 block product is 4 instructions with kk(q, s) chosen per product (any permutation of K is fine
+  // as long as A and B use the same one).
+  // element (r, c) of the inverse of a DIAGONAL 16-block at offset o (0 above the diagonal)
+  auto inv_diag = [&](int o, int r, int c) -> double {
+    return (c < r) ? s[o + c][o + r] : ((c == r) ? dv[o + r] : 0.0);
+  };
+  bool bad = false;
+  for (int sb = 0; sb < 4; ++sb) {
+    const int o = sb * 16;
+    const int nb = 3 - sb;   // 16-row blocks below the diagonal block
+    // (i) diagonal block: lanes 0..15 of wave 0 hold one row each in registers; then its inverse, one column each
+    if (tid < 16) {
+      // Straight-line code (round 6): the entries above the diagonal of the 16 x 16 block are don't-cares, so every update runs in all 16
+      // lanes without an exec mask per statement, a bad pivot is flagged without a branch, and the inverse is accumulated right-looking
+      // (16 independent chains instead of one dependent chain of r multiply-adds per entry): 13 instead of 32 us per tile.
+      // Cross-lane values are broadcast with v_readlane (compile-time lane index, no LDS round trip); square root and reciprocal come from
+      // one v_rsq_f64 + two Newton steps (~1 ulp).
+      double a[16], rdv[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = s[o + tid][o + c];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        const double p0 = bcast_lane(a[c], c);
+        const bool ok = p0 > 0.0;
+        bad |= !ok;
+        const double piv = ok ? p0 : 1.0;
+        double r0 = __builtin_amdgcn_rsq(piv);
+        r0 = r0 * fma(-0.5 * piv * r0, r0, 1.5);
+        r0 = r0 * fma(-0.5 * piv * r0, r0, 1.5);
+        double d = piv * r0;
+        d = fma(0.5 * r0, fma(-d, d, piv), d);     // sqrt(piv)
+        const double rd = fma(r0, fma(-d, r0, 1.0), r0);        // 1 / sqrt(piv)
+        rdv[c] = rd;
+        a[c] = tid == c ? d : a[c] * rd;
+#pragma unroll
+        for (int c2 = c + 1; c2 < 16; ++c2) a[c2] = fma(-a[c], bcast_lane(a[c], c2), a[c2]);      // L[c2][c] from lane c2
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c <= tid) s[o + tid][o + c] = a[c];
+      // inverse of the 16x16 triangle, lane = column: x[j] = v[j] / L[j][j], then v[r] -= L[r][j] x[j] for the rows below
+      double v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = (r == tid) ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        v[j] *= rdv[j];
+#pragma unroll
+        for (int r = j + 1; r < 16; ++r) v[r] = fma(-bcast_lane(a[j], r), v[j], v[r]);      // L[r][j] from lane r
+      }
+      dv[o + tid] = v[tid];
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (r > tid) s[o + tid][o + r] = v[r];   // Linv[r][tid], transposed into the upper triangle
+    }
+    C128_FT(11);
+    __syncthreads();
+    C128_FT(14);
+    // (ii) rows below: L21 = A21 * Linv11^T, one 16-row block per wave
+    if (wave < nb) {
+      const int rb = o + 16 + 16 * wave;
+      v4d acc = (v4d){0, 0, 0, 0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s[rb + li][o + 4 * lq + st], inv_diag(o, li, 4 * lq + st), acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[rb + lq + 4 * r][o + li] = acc[r];
+    }
+    __syncthreads();
+    // (iii) trailing update inside the tile: A22 -= L21 L21^T (lower blocks; only the lower triangle of the
+    //       diagonal blocks is written -- their upper triangle will hold the inverse), blocks dealt to the waves
+    {
+      const int nblk2 = nb * (nb + 1) / 2;
+      for (int idx = wave; idx < nblk2; idx += 4) {
+        int bi = 0, rem = idx;
+        while (rem > bi) { rem -= bi + 1; ++bi; }
+        const int bj = rem;
+        const int ri = o + 16 + 16 * bi, rj = o + 16 + 16 * bj;
+        v4d acc = (v4d){0, 0, 0, 0};
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(s[ri + li][o + 4 * lq + st], s[rj + li][o + 4 * lq + st], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (bi != bj || li <= lq + 4 * r) s[ri + lq + 4 * r][rj + li] -= acc[r];
+      }
+    }
+    __syncthreads();
+    C128_FT(12);
+  }
+  C128_FT(12);
+  // off-diagonal blocks of the inverse (i > j), by sub-diagonal distance:
+  //   Linv[i][j] = -Linv[i][i] * sum_{kb=j}^{i-1} L[i][kb] Linv[kb][j]      (Linv[kb][j] at s[16j + .][16kb + .]^T)
+  for (int dist = 1; dist < 4; ++dist) {
+    const int j = wave, ib = wave + dist;
+    if (ib < 4) {
+      v4d m1 = (v4d){0, 0, 0, 0};
+      for (int kb = j; kb < ib; ++kb) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+          const int kk = 4 * lq + st;
+          const double bval = (kb == j) ? inv_diag(16 * j, kk, li) : s[16 * j + li][16 * kb + kk];
+          m1 = __builtin_amdgcn_mfma_f64_16x16x4f64(s[16 * ib + li][16 * kb + kk], bval, m1, 0, 0, 0);
+        }
+      }
+      // second product with kk(q, st) = q + 4 st: the B operand M1[kk][li] is exactly register st of m1
+      v4d acc = (v4d){0, 0, 0, 0};
+#pragma unroll
+      for (int st = 0; st < 4; ++st)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(inv_diag(16 * ib, li, lq + 4 * st), m1[st], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[16 * j + li][16 * ib + lq + 4 * r] = -acc[r];
+    }
+    __syncthreads();
+  }
+  C128_FT(13);
+  return bad;
+}
 
 // ---- one ring unit: accT[n][m] += L_j rows(n) x tile rows(m)^T over 8 k -----------------------------------------------------------------
 // rows of 64 bytes, the four 16-byte slots XOR-swizzled by f((row >> 2) & 3), f = (0, 3, 2, 1): every ds_read_b128 lane group then falls on
@@ -159,6 +295,22 @@ __device__ __forceinline__ void c128_issue_rows16(const double* src, int64_t ld,
     c128_glds16(src + (int64_t)row * ld, (uint32_t)((lane ^ row) << 4), dst + p * 1024);
   }
 }
+// ring unit of 128 rows x 16 doubles (the source's column block of a tile; 128 bytes per row, slots XOR-swizzled by (row >> 1) & 7): wave w
+// copies ITS OWN rows 32 w .. 32 w + 31 (4 pieces of 8 rows); the swizzle of row 8 p + (lane >> 3) depends on the parity of p alone
+__device__ __forceinline__ void c128_issue_cols16(const double* src, int buf, int wave, int n64, uint32_t lds0, const uint32_t (&xoff)[2]) {
+  const double* base = src + (int64_t)(32 * wave) * n64;
+  const uint32_t dst = lds0 + buf * C128_UNIT + wave * 4096;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) c128_glds16(base + (int64_t)(8 * p) * n64, xoff[p & 1], dst + p * 1024);
+}
+__device__ __forceinline__ void c128_cols_off(int lane, int n64, uint32_t (&xoff)[2]) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) xoff[p] = (uint32_t)(((int64_t)(lane >> 3) * n64 + 2 * ((lane & 7) ^ ((4 * p + (lane >> 4)) & 7))) * 8);
+}
+// element (row, column q + 4 r) of such a unit; row = 16 blk + i
+__device__ __forceinline__ double c128_cols16_at(const uint8_t* cur, int row, int r, int i, int q) {
+  return *reinterpret_cast<const double*>(cur + row * 128 + ((((q >> 1) + 2 * r) ^ ((i >> 1) & 7)) << 4) + 8 * (q & 1));
+}
 // element (row i, column 16 n + q + 4 r) of such a unit
 __device__ __forceinline__ double c128_rows16_at(const uint8_t* cur, int n, int r, int i, int q) {
   return *reinterpret_cast<const double*>(cur + i * 1024 + (((8 * n + 2 * r + (q >> 1)) ^ i) << 4) + 8 * (q & 1));
@@ -174,6 +326,7 @@ __device__ __forceinline__ double c128_rows_at(const uint8_t* smem, int rbl, int
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   __shared__ __attribute__((aligned(16))) uint8_t smem[C128_LDS];
+  const unsigned long long t_start = C128_T0();
   const int wave = C128_RFL((int)threadIdx.x >> 6);
   int b, g;
   bool succ;
@@ -201,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   double* M = a.mats + (int64_t)b * a.mat_stride;
   const uint32_t lds0 = C128_LDS_ADDR(smem);
   unsigned long long t_prev = C128_T0();
-  if (a.dbg && threadIdx.x == 0) atomicAdd(&a.dbg[succ ? 17 : 16], 1ull);
+  if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[succ ? 17 : 16], 1ull); atomicAdd(&a.dbg[19], t_prev - t_start); }
 
   v4d acc[8][2];
 #pragma unroll
@@ -218,64 +371,78 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   if (MODE >= 1) {
     const int rb0 = 32 * wave;                          // this wave's rows of the tile: rb0 + 16 m + i
     const int nK = MODE >= 2 ? 16 * j : 0, nX = 8 * nsrc, total = nK + nX + 8;
-    const double* arows = M + (int64_t)(128 * it) * n64;
+    const int kpg = nK / nX;                            // K units in front of every source row block: the X copies (HBM, and slow next to the other
+    const double* arows = M + (int64_t)(128 * it) * n64;   // workgroup's K stream: 2.5 us per unit) land under this tile's own products
     const double* brows = M + (int64_t)(128 * j) * n64;
     const double* Li = a.linv + ((int64_t)b * a.Tp + j) * (128 * 128);
-    auto issue_xt = [&](int u, int lane) {              // u >= nK: a row block of S / F, then of Linv
-      const int x = u - nK;
-      if (x < nX) c128_issue_rows16((x >= 8 ? fx.F : fx.S) + (int64_t)(128 * it + 16 * (x & 7)) * n64 + 128 * j, n64, u & (C128_NBUF - 1), wave, lane, lds0);
-      else c128_issue_rows16(Li + (int64_t)(16 * (x - nX)) * 128, 128, u & (C128_NBUF - 1), wave, lane, lds0);
-    };
-    int u = 0;
-    {
-      int lane = threadIdx.x & 63;
-      C128_LAUNDER(lane);
-      const int i = lane & 15, q = lane >> 4;
-      const int sq = (q ^ ((4 - (i >> 2)) & 3)) << 4;
-      const uint32_t uoff = c128_unit_off(lane, n64);
-      const int aoff0 = (rb0 + i) * 64, aoff1 = (rb0 + 16 + i) * 64, boff = 8192 + i * 64;
-      auto issue_any = [&](int v) {
-        if (v < nK) c128_issue_unit(arows + 8 * v, brows + 8 * v, v & (C128_NBUF - 1), wave, n64, lds0, uoff);
-        else issue_xt(v, lane);
-      };
-#pragma unroll
-      for (int p = 0; p < C128_DIST; ++p) issue_any(p);      // total >= 16
-      if (MODE >= 2) {
-#pragma unroll 1
-        do {
-          C128_UNIT_SYNC(total - 1 - u);
-          issue_any(u + C128_DIST);                           // (K units are never the last three)
-          c128_kunit<false>(smem + (u & (C128_NBUF - 1)) * C128_UNIT, aoff0, aoff1, boff, sq, acc, 0);
-        } while (++u < nK);
+    int lane_k = threadIdx.x & 63;
+    C128_LAUNDER(lane_k);
+    const uint32_t uoff = c128_unit_off(lane_k, n64);
+    uint32_t xoff[2];
+    c128_cols_off(lane_k, n64, xoff);
+    // issue cursor (wave-uniform): kpg K units, one source row block, ... then the remaining K units, then the row blocks of Linv
+    int is_n = 0, is_k = 0, is_x = 0, is_c = 0;
+    auto issue_next = [&]() {
+      if (is_n >= total) return;
+      const int buf = is_n & (C128_NBUF - 1);
+      if (is_x < nX && (is_c == kpg || is_k == nK)) {
+        c128_issue_cols16((is_x >= 8 ? fx.F : fx.S) + ((a.flags & 2) ? 0 : (int64_t)(128 * it) * n64 + 128 * j + 16 * (is_x & 7)), buf, wave, n64, lds0, xoff);
+        ++is_x; is_c = 0;
+      } else if (is_k < nK) {
+        c128_issue_unit(arows + 8 * is_k, brows + 8 * is_k, buf, wave, n64, lds0, uoff);
+        ++is_k; ++is_c;
+      } else {
+        c128_issue_rows16(Li + (int64_t)(16 * (is_n - nK - nX)) * 128, 128, buf, wave, lane_k, lds0);
       }
-    }
-    C128_T(2);
+      ++is_n;
+    };
+    int u = 0, kc = 0;
+    const int ik = lane_k & 15, qk = lane_k >> 4;
+    const int sq = (qk ^ ((4 - (ik >> 2)) & 3)) << 4;
+    const int aoff0 = (rb0 + ik) * 64, aoff1 = (rb0 + 16 + ik) * 64, boff = 8192 + ik * 64;
+    auto k_unit = [&]() {
+      C128_UNIT_SYNC(total - 1 - u);
+      issue_next();
+      c128_kunit<false>(smem + (u & (C128_NBUF - 1)) * C128_UNIT, aoff0, aoff1, boff, sq, acc, 0);
+      ++u; ++kc;
+    };
+#pragma unroll
+    for (int p = 0; p < C128_DIST; ++p) issue_next();      // total >= 16
 #pragma unroll 1
     for (int src = 0; src < nsrc; ++src) {
       const double sgn = src ? 1.0 : -1.0;
 #pragma unroll
       for (int rb = 0; rb < 8; ++rb) {
+        if (MODE >= 2) {
+#pragma unroll 1
+          for (int t = 0; t < kpg; ++t) k_unit();
+        }
         int lane = threadIdx.x & 63;
         C128_LAUNDER(lane);       // per unit: the element masks below must not be hoisted out (they were, as spilled SGPR pairs)
         const int i = lane & 15, q = lane >> 4;
         C128_UNIT_SYNC(total - 1 - u);
-        if (u + C128_DIST < total) issue_xt(u + C128_DIST, lane);
-        if (wave == (rb >> 1)) {
+        issue_next();
+        {   // unit rb = the tile's column block rb (128 rows x 16 columns): every lane takes its two rows' four columns q + 4 r
           const uint8_t* cur = smem + (u & (C128_NBUF - 1)) * C128_UNIT;
-          // element (gi, gj) holds data when gj < nb and gi < nrhs: one limit per lane on the column offset 16 n + 4 r (+ q)
-          const int gi = 128 * it + 16 * rb + i;
-          const int lim = gi < nrhs ? nb - 128 * j - q : -1;
 #pragma unroll
-          for (int n = 0; n < 8; ++n)
+          for (int m = 0; m < 2; ++m) {
+            // element (gi, gj) holds data when gj < nb and gi < nrhs: one limit per lane on the column offset 16 n + 4 r (+ q)
+            const int gi = 128 * it + rb0 + 16 * m + i;
+            const int lim = gi < nrhs ? nb - 128 * j - q : -1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              double x = c128_rows16_at(cur, n, r, i, q);
-              x = (16 * n + 4 * r < lim) ? x : 0.0;
-              acc[n][rb & 1][r] = fma(sgn, x, acc[n][rb & 1][r]);
+              double x = c128_cols16_at(cur, rb0 + 16 * m + i, r, i, q);
+              x = (16 * rb + 4 * r < lim) ? x : 0.0;
+              acc[rb][m][r] = fma(sgn, x, acc[rb][m][r]);
             }
+          }
         }
         ++u;
       }
+    }
+    if (MODE >= 2) {
+#pragma unroll 1
+      while (kc < nK) k_unit();
     }
     C128_T(1);
     {
@@ -295,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
 #pragma unroll
       for (int cb = 0; cb < 8; ++cb) {
         C128_UNIT_SYNC(total - 1 - u);
-        if (u + C128_DIST < total) issue_xt(u + C128_DIST, lane);
+        issue_next();
         const uint8_t* cur = smem + (u & (C128_NBUF - 1)) * C128_UNIT;
         if (pend_cb >= 0) store_pend();
         v4d out[2];
@@ -303,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
         out[1] = (v4d){0, 0, 0, 0};
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
-          if (n > cb) continue;
+          if (n > cb || (a.flags & 4)) continue;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const double lv = c128_rows16_at(cur, n, r, i, q);
@@ -319,7 +486,10 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
       store_pend();
     }
     C128_T(3);
-    if (!succ) return;
+    if (!succ) {
+      if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[18], t_prev - t_start); atomicAdd(&a.dbg[21 + j], t_prev - t_start); }
+      return;
+    }
     __threadfence_block();                              // the diagonal block below reads this tile back: same workgroup, same L2 (an agent-scope
     C128_STAGE_SYNC();                                  // fence wrote the XCD's whole L2 back: 25 us per item)
 #pragma unroll
@@ -334,72 +504,85 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   const int jd = j + 1;
   {
     const int nK = MODE >= 1 ? 8 * jd : 0, nX = 8 * nsrc, total = nK + nX;
+    const int kpg = nK / nX > 0 ? nK / nX : (nK > 0 ? 1 : 0);      // K units (16 k each) in front of every source row block
     const double* arows = M + (int64_t)(128 * jd) * n64;
-    auto issue_x = [&](int u, int lane) {
-      const int x = u - nK;
-      c128_issue_rows16((x >= 8 ? fx.F : fx.S) + (int64_t)(128 * jd + 16 * (x & 7)) * n64 + 128 * jd, n64, u & (C128_NBUF - 1), wave, lane, lds0);
-    };
-    int u = 0;
-    {
-      int lane = threadIdx.x & 63;
-      C128_LAUNDER(lane);
-      const int i = lane & 15, q = lane >> 4;
-      const int sq = (q ^ ((4 - (i >> 2)) & 3)) << 4;
-      const uint32_t uoff = c128_unit_off(lane, n64);
-      const int aoff0 = (16 * wave + i) * 64, aoff1 = (16 * (7 - wave) + i) * 64, boff = i * 64;
-      auto issue_any = [&](int v) {
-        if (v < nK) c128_issue_unit(arows + 16 * v, arows + 16 * v + 8, v & (C128_NBUF - 1), wave, n64, lds0, uoff);
-        else issue_x(v, lane);
-      };
-#pragma unroll
-      for (int p = 0; p < C128_DIST; ++p) issue_any(p);      // total >= 8
-      if (MODE >= 1) {
-#pragma unroll 1
-        do {
-          C128_UNIT_SYNC(total - 1 - u);
-          issue_any(u + C128_DIST);
-          const uint8_t* cur = smem + (u & (C128_NBUF - 1)) * C128_UNIT;
-          c128_kunit<true>(cur, aoff0, aoff1, boff, sq, acc, wave);
-          c128_kunit<true>(cur + 8192, aoff0, aoff1, boff, sq, acc, wave);
-        } while (++u < nK);
+    int lane_k = threadIdx.x & 63;
+    C128_LAUNDER(lane_k);
+    const uint32_t uoff = c128_unit_off(lane_k, n64);
+    uint32_t xoff[2];
+    c128_cols_off(lane_k, n64, xoff);
+    int is_n = 0, is_k = 0, is_x = 0, is_c = 0;
+    auto issue_next = [&]() {
+      if (is_n >= total) return;
+      const int buf = is_n & (C128_NBUF - 1);
+      if (is_x < nX && (is_c == kpg || is_k == nK)) {
+        c128_issue_cols16((is_x >= 8 ? fx.F : fx.S) + ((a.flags & 2) ? 0 : (int64_t)(128 * jd) * n64 + 128 * jd + 16 * (is_x & 7)), buf, wave, n64, lds0, xoff);
+        ++is_x; is_c = 0;
+      } else {
+        c128_issue_unit(arows + 16 * is_k, arows + 16 * is_k + 8, buf, wave, n64, lds0, uoff);
+        ++is_k; ++is_c;
       }
-    }
-    C128_T(5);
+      ++is_n;
+    };
+    int u = 0, kc = 0;
+    const int ik = lane_k & 15, qk = lane_k >> 4;
+    const int sq = (qk ^ ((4 - (ik >> 2)) & 3)) << 4;
+    const int aoff0 = (16 * wave + ik) * 64, aoff1 = (16 * (7 - wave) + ik) * 64, boff = ik * 64;
+    auto k_unit = [&]() {
+      C128_UNIT_SYNC(total - 1 - u);
+      issue_next();
+      const uint8_t* cur = smem + (u & (C128_NBUF - 1)) * C128_UNIT;
+      c128_kunit<true>(cur, aoff0, aoff1, boff, sq, acc, wave);
+      c128_kunit<true>(cur + 8192, aoff0, aoff1, boff, sq, acc, wave);
+      ++u; ++kc;
+    };
+#pragma unroll
+    for (int p = 0; p < C128_DIST; ++p) issue_next();      // total >= 8
     const double sh = fx.sh;
 #pragma unroll 1
     for (int src = 0; src < nsrc; ++src) {
 #pragma unroll
       for (int rb = 0; rb < 8; ++rb) {
+        if (MODE >= 1) {
+#pragma unroll 1
+          for (int t = 0; t < kpg && kc < nK; ++t) k_unit();
+        }
         int lane = threadIdx.x & 63;
         C128_LAUNDER(lane);
         const int i = lane & 15, q = lane >> 4;
         C128_UNIT_SYNC(total - 1 - u);
-        if (u + C128_DIST < total) issue_x(u + C128_DIST, lane);
-        if (wave == (rb < 4 ? rb : 7 - rb)) {
+        issue_next();
+        {   // unit rb = column block rb of the diagonal block: this wave's row blocks w (m = 0) and 7 - w (m = 1) where they lie on or below it
           const uint8_t* cur = smem + (u & (C128_NBUF - 1)) * C128_UNIT;
-          const int gi = 128 * jd + 16 * rb + i;
-          const int lim = gi < nrhs ? nb - 128 * jd - q : -1;        // off the diagonal: data when 16 n + 4 r < lim
-          const int de = 16 * rb + i - q;                            // the diagonal element sits at 16 n + 4 r == de
-          // on the diagonal: + shift inside the matrix, 2^100 on an embedded right-hand-side row, 1 in the identity padding
-          const double dadd = gi < nb ? sh : (gi < nrhs ? RG_EMBED_DIAG : 1.0), dmul = gi < nb ? 1.0 : 0.0;
 #pragma unroll
-          for (int n = 0; n < 8; ++n) {
-            if (n > rb) continue;                                    // lower 16-blocks only
+          for (int m = 0; m < 2; ++m) {
+            if (m == 0 && rb > 3) continue;                            // row blocks 0-3 have no columns past block 3
+            const int rbk = m == 0 ? wave : 7 - wave;
+            if (rb > rbk) continue;                                    // wave-uniform: above the diagonal
+            const int gi = 128 * jd + 16 * rbk + i;
+            const int lim = gi < nrhs ? nb - 128 * jd - q : -1;        // off the diagonal: data when 16 n + 4 r < lim
+            const int de = 16 * rbk + i - q;                           // the diagonal element sits at 16 n + 4 r == de
+            // on the diagonal: + shift inside the matrix, 2^100 on an embedded right-hand-side row, 1 in the identity padding
+            const double dadd = gi < nb ? sh : (gi < nrhs ? RG_EMBED_DIAG : 1.0), dmul = gi < nb ? 1.0 : 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              double x = c128_rows16_at(cur, n, r, i, q);
-              x = (16 * n + 4 * r < lim) ? x : 0.0;
+              double x = c128_cols16_at(cur, 16 * rbk + i, r, i, q);
+              x = (16 * rb + 4 * r < lim) ? x : 0.0;
               if (src == 0) {
-                x = (16 * n + 4 * r == de) ? fma(x, dmul, dadd) : x;
-                acc[n][rb < 4 ? 0 : 1][r] -= x;
+                x = (16 * rb + 4 * r == de) ? fma(x, dmul, dadd) : x;
+                acc[rb][m][r] -= x;
               } else {
-                acc[n][rb < 4 ? 0 : 1][r] += x;
+                acc[rb][m][r] += x;
               }
             }
           }
         }
         ++u;
       }
+    }
+    if (MODE >= 1) {
+#pragma unroll 1
+      while (kc < nK) k_unit();
     }
     C128_STAGE_SYNC();
   }
@@ -440,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
     }
   __syncthreads();
   C128_T(6);
-  bad |= diag_factor_lds(sA, dv);
+  if (!(a.flags & 8)) bad |= c128_factor64(sA, dv, a.dbg);
   C128_T(7);
   // L21 = D21 Linv11^T: this wave's row block 7 - w of the block = rows 16 (3 - w) of the lower half
   const int lrb = 3 - wave;
@@ -502,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
     }
   __syncthreads();
   C128_T(8);
-  bad |= diag_factor_lds(sA, dv);
+  if (!(a.flags & 8)) bad |= c128_factor64(sA, dv, a.dbg);
   C128_T(9);
   // I21 = -Linv22 M1: wave w takes rows 16 w .. of the lower half
   {
@@ -524,7 +707,8 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   }
   save_tile(64, 1);
   C128_T(10);
-  if (bad) atomicMax(a.info, 1);
+  if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[18], t_prev - t_start); atomicAdd(&a.dbg[21 + j], t_prev - t_start); }
+  if (bad && !a.flags) atomicMax(a.info, 1);
 }
 
 // factorization of `batch` systems, all tiles formed from `first` (group-wise path of rg_launch_chol_solve_src); n64 % 128 == 0, no separate
@@ -533,6 +717,9 @@ static void c128_launch_factor(hipStream_t st, double* mats, int64_t mat_stride,
                                int32_t* info, const FormSrc& first, int R, int64_t& nl) {
   C128Args a;
   a.mats = mats; a.mat_stride = mat_stride; a.n64 = n64; a.linv = linv; a.dinv = dinv; a.info = info;
+  static const int flags = getenv("RG_C128_FLAGS") ? atoi(getenv("RG_C128_FLAGS")) : 0;
+  if (flags & 1) R = 1;       // diagnostic: the ridge shifts of a fold matrix are NOT co-located
+  a.flags = flags;
   a.Tp = n64 / 128; a.batch = batch; a.R = R; a.fs = first;
   static const bool dbg = getenv("RG_C128_DBG") && atoi(getenv("RG_C128_DBG")) != 0;
   a.dbg = nullptr;
@@ -554,6 +741,8 @@ static void c128_launch_factor(hipStream_t st, double* mats, int64_t mat_stride,
     static const char* nm[11] = {"", "X1", "K1", "T1", "X2", "K2", "->sA", "factor11", "L21/M1/D22/save", "factor22", "I21/save"};
     fprintf(stderr, "c128 phases (batch %d, n64 %d): plain items %llu, successor items %llu; workgroup-us:", batch, n64, h[16], h[17]);
     for (int k = 1; k <= 10; ++k) fprintf(stderr, " %s %.0f", nm[k], h[k] / 100.0);
-    fprintf(stderr, "\n");
+    fprintf(stderr, " | prologue %.0f, workgroup lifetimes %.0f; per launch j = -1 ..:", h[19] / 100.0, h[18] / 100.0);
+    for (int k = 0; k < a.Tp && k < 11; ++k) fprintf(stderr, " %.0f", h[20 + k] / 100.0);
+    fprintf(stderr, " | inside the tile factorizations: 16x16 steps %.0f, barrier after them %.0f, rows below + trailing update %.0f, inverse blocks %.0f\n", h[11] / 100.0, h[14] / 100.0, h[12] / 100.0, h[13] / 100.0);
   }
 }

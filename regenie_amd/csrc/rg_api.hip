@@ -86,7 +86,10 @@ void rg_destroy(rg_ctx* c) {
   free_all(c);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
-  if (c->st_side) { hipStreamSynchronize(c->st_side); hipStreamDestroy(c->st_side); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
+  if (c->ev_fork) {
+    hipEventDestroy(c->ev_fork);
+    for (int k = 0; k < 3; ++k) { hipStreamSynchronize(c->st_part[k]); hipStreamDestroy(c->st_part[k]); hipEventDestroy(c->ev_part[k]); }
+  }
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -518,35 +521,42 @@ static int l0_batch(rg_ctx* ctx, int nblk, const int32_t* block_ids, const int32
     StageTimer t(ctx, &ctx->tm.ms_chol);
     // d_fold[(blk, f)] holds the training-fold system of fold f (assemble.hip diff_mode): one source matrix per
     // (block, fold), shared by the R0 shifted systems that are co-located on one XCD for their first touch.
-    // Two ranges of systems on two streams (round 5, RG_CHOL_SPLIT=1024; OFF by default): the block factorization (k_chol_gfact) holds
-    // 1,024 systems at a time -- one wave each, 135 KB of LDS per four -- so a batch of 1,375 leaves three quarters of the chip idle for a
-    // second round of every group.  With the systems past the last full round as a range of their own, next to the first range's strip and
-    // update kernels, a batch ALONE takes 13.5 instead of 14.5 ms at BASELINE configs[1] -- but a step (two level-0 pipelines, whose kernels
-    // already fill those idle rounds) takes 36.2 instead of 34.2 ms: the split only adds contention there.  Kept as a switch for one-pipeline runs.
+    // Round 6 (panel-128 kernels, chol_p128.h): a panel launch ends with a tail -- its long items (tile + diagonal block + factorization of a
+    // successor) finish while slots stand empty -- and launch j + 1 of a system only needs launch j of THAT system: ranges of the batch on
+    // streams of their own fill each other's tails: RG_CHOL_PARTS=2 takes a batch ALONE from 11.7 to 11.5 ms (0.429 -> 0.436 of the matrix peak),
+    // but a STEP from 30.2 to 32.1 ms -- the two level-0 pipelines already put another batch's kernels into those tails, more streams only add
+    // contention -- so the default is one range.  (Round 5's RG_CHOL_SPLIT -- the systems past the last full round of k_chol_gfact as a second range -- went with that kernel's
+    // default role.)  The ranges start at multiples of 8 R0 systems: the placement groups of xcd_affine.
     const int nsys_all = nblk * nseg * R0;
-    static const int split_round = getenv("RG_CHOL_SPLIT") ? atoi(getenv("RG_CHOL_SPLIT")) : 0;
-    int n1 = nsys_all;
-    if (split_round > 0 && nsys_all > split_round && nsys_all % split_round != 0 && !ctx->timing_serial)
-      n1 = nsys_all / split_round * split_round / R0 * R0;
-    if (n1 < nsys_all && n1 > 0) {
-      if (!ctx->st_side) {
-        RG_HIP(hipStreamCreateWithFlags(&ctx->st_side, hipStreamNonBlocking));
+    static const int parts_env = getenv("RG_CHOL_PARTS") ? atoi(getenv("RG_CHOL_PARTS")) : 1;
+    int parts = std::max(1, std::min(4, parts_env));
+    while (parts > 1 && nsys_all < parts * 8 * 8 * R0) --parts;
+    if (parts > 1) {
+      const int grp = 8 * R0, ngrp = (nsys_all + grp - 1) / grp;
+      if (!ctx->ev_fork) {
         RG_HIP(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        RG_HIP(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        for (int k = 0; k < 3; ++k) {
+          RG_HIP(hipStreamCreateWithFlags(&ctx->st_part[k], hipStreamNonBlocking));
+          RG_HIP(hipEventCreateWithFlags(&ctx->ev_part[k], hipEventDisableTiming));
+        }
       }
       RG_HIP(hipEventRecord(ctx->ev_fork, st));
-      RG_HIP(hipStreamWaitEvent(ctx->st_side, ctx->ev_fork, 0));
-      rg_launch_chol_solve_formed_x(st, ctx->d_fold, msz, nullptr, 0, 1, ctx->d_lambda, R0, ctx->d_bs, 0, nblk * nseg,
-                                    ctx->d_wk, msz, n64, embed ? 0 : rtot - n64, P, ctx->d_dinv, ctx->d_info + 1,
-                                    &ctx->tm.n_chol_launches, 0, nullptr, 0, 0, nseg, 0, n1, 0, embed);
-      rg_launch_chol_solve_formed_x(ctx->st_side, ctx->d_fold, msz, nullptr, 0, 1, ctx->d_lambda, R0, ctx->d_bs, 0, nblk * nseg,
-                                    ctx->d_wk + (int64_t)n1 * msz, msz, n64, embed ? 0 : rtot - n64, P, ctx->d_dinv + rg_chol_ws_doubles((size_t)n1, n64),
-                                    ctx->d_info + 1, &ctx->tm.n_chol_launches, 0, nullptr, 0, 0, nseg, n1, nsys_all - n1, 0, embed);
-      RG_HIP(hipEventRecord(ctx->ev_join, ctx->st_side));
-      RG_HIP(hipStreamWaitEvent(st, ctx->ev_join, 0));
+      for (int k = 0; k < parts; ++k) {
+        const int s0 = std::min(nsys_all, (ngrp * k / parts) * grp), s1 = std::min(nsys_all, (ngrp * (k + 1) / parts) * grp);
+        if (s1 <= s0) continue;
+        hipStream_t sk = k == 0 ? st : ctx->st_part[k - 1];
+        if (k > 0) RG_HIP(hipStreamWaitEvent(sk, ctx->ev_fork, 0));
+        rg_launch_chol_solve_formed_x(sk, ctx->d_fold, msz, nullptr, 0, 1, ctx->d_lambda, R0, ctx->d_bs, 0, nblk * nseg,
+                                      ctx->d_wk + (int64_t)s0 * msz, msz, n64, embed ? 0 : rtot - n64, P, ctx->d_dinv + rg_chol_ws_doubles((size_t)s0, n64),
+                                      ctx->d_info + 1, &ctx->tm.n_chol_launches, 0, nullptr, 0, 0, nseg, s0, s1 - s0, 0, embed);
+        if (k > 0) {
+          RG_HIP(hipEventRecord(ctx->ev_part[k - 1], sk));
+          RG_HIP(hipStreamWaitEvent(st, ctx->ev_part[k - 1], 0));
+        }
+      }
     } else
     // (the per-column kernels of level 1 -- k_chol_diag / k_chol_panel -- measured on these 1,375 systems: 17.7 ms per batch against 15.5 ms
-    // for this group-wise path without embedded right-hand sides, 14.5 ms with them)
+    // for the group-of-four path without embedded right-hand sides, 14.5 ms with them)
     rg_launch_chol_solve_formed_x(st, ctx->d_fold, msz, nullptr, 0, 1, ctx->d_lambda, R0, ctx->d_bs, 0, nblk * nseg,
                                   ctx->d_wk, msz, n64, embed ? 0 : rtot - n64, P, ctx->d_dinv, ctx->d_info + 1,
                                   &ctx->tm.n_chol_launches, 0, nullptr, 0, 0, nseg, 0, -1, 0, embed);
