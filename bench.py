@@ -422,7 +422,7 @@ def main():
         else:
             a = kernels[dom]["achieved_TFLOPS"]
             nlaunch = {"chol_f64": n_batches, "l1_gram_f64": P, "wgram_f64": tm["n_irls_rounds"]}[dom]
-            roof = {"kernel": {"chol_f64": "k_chol_update/gfact/gstrip/backsolve (fp64 MFMA batched Cholesky, per level-0 batch of systems)",
+            roof = {"kernel": {"chol_f64": "k_c128_panel x (order / 128) + k_chol_backsolve (fp64 MFMA batched Cholesky by panels of 128 columns, chol_p128.h, per level-0 batch of systems)",
                                "l1_gram_f64": "k_l1_gram128 (fp64 MFMA level-1 fold Gram, one launch per phenotype)",
                                "wgram_f64": "k_wgram128 (fp64 MFMA weighted Gram X^T W X of the logistic / Cox ridge IRLS, one launch per lock-step round "
                                             "over the unfinished fold models)"}[dom], "bound": "mfma", "achieved": a,
@@ -716,7 +716,7 @@ def measured_traffic(dom, nblocks, n_batches, P):
     group = {"chol_f64": "chol", "l1_gram_f64": "l1_gram", "gram_fp4": "gram_fp4", "pred": "pred", "wgram_f64": "wgram", "irls_stream": "irls_stream"}[dom]
     # the sources that define and launch the group's kernels: a traffic file stays valid for a group while THESE are what it was measured on
     common = ["csrc/rg_api.hip", "csrc/rg_internal.h", "csrc/bed_prep.hip", "flags"]
-    group_files = {"chol": ["csrc/chol.hip", "csrc/assemble.hip"], "l1_gram": ["csrc/l1.hip"], "gram_fp4": ["csrc/gram_fp4.hip"], "pred": ["csrc/pred.hip", "csrc/pred_i8.hip"],
+    group_files = {"chol": ["csrc/chol.hip", "csrc/chol_p128.h", "csrc/chol_common.h", "csrc/assemble.hip"], "l1_gram": ["csrc/l1.hip"], "gram_fp4": ["csrc/gram_fp4.hip"], "pred": ["csrc/pred.hip", "csrc/pred_i8.hip"],
                    "wgram": ["csrc/wgram_bf16.hip", "csrc/l1x.hip"], "irls_stream": ["csrc/l1x.hip"]}[group] + common
     try:
         now = json.load(open(os.path.join(ROOT, "regenie_amd", "lib", "kernel_files.json")))

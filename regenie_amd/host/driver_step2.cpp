@@ -1,5 +1,6 @@
 // regenie-amd, the C++ host driver (see driver.h): `--step 2`.
 #include "driver.h"
+#include <functional>
 
 namespace rgdrv {
 
@@ -426,6 +427,21 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     } catch (const std::exception& e) { d.err = e.what(); if (d.err.empty()) d.err = "bgen read failed"; }
   };
   std::future<void> prep_ahead;      // declared after everything `prepare` touches: its destructor waits for the worker before those go away
+  // The read-ahead futures of the device route live in `preps` (declared BEFORE `groups`, which their worker dereferences) and the pinned
+  // buffers / the device decoder are freed by hand at the end of the normal path: on an exception (a failed check, a rethrown reader error)
+  // this guard -- declared after all of them, so destroyed first -- joins the workers and releases what they use, in that order.
+  struct S2Cleanup {
+    std::function<void()> f;
+    bool done = false;
+    rg_bgen_dev** dev = nullptr;
+    void run() { if (!done) { done = true; f(); } }
+    ~S2Cleanup() { run(); if (dev && *dev) { rg_bgen_dev_destroy(*dev); *dev = nullptr; } }
+  } cleanup{[&]() {
+    if (prep_ahead.valid()) prep_ahead.wait();
+    for (auto& d : preps) if (d.rd.valid()) d.rd.wait();
+    for (auto& d : preps) { if (d.g16) rg_host_free(d.g16); if (d.comp) rg_host_free(d.comp); d.g16 = nullptr; d.comp = nullptr; }
+  }};
+  cleanup.dev = &bdev;
   if (fast_bgen && !groups.empty())      // the first group is inflated while the first chromosome's predictions are read
     prep_ahead = std::async(std::launch::async, [&]() { prepare(groups[0].ref, preps[0], 0, 0); });
   for (int chrom : r.chr_read) {
@@ -928,15 +944,13 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
       sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t1).count() << "ms) \n";
     }
   }
-  if (prep_ahead.valid()) prep_ahead.wait();
-  if (prep_ahead.valid()) prep_ahead.wait();
-  for (auto& d : preps) if (d.rd.valid()) d.rd.wait();
-  for (auto& d : preps) { if (d.g16) rg_host_free(d.g16); if (d.comp) rg_host_free(d.comp); }
+  cleanup.run();
   if (bdev) {
     if (getenv("RG_TIMING"))
       fprintf(stderr, "[timing] step 2 part %d: BGEN on the device: %lld blocks (%lld on the host route) | reading the stored streams %.0f ms | copy + inflate + walk on the GPU %.0f ms (both overlapped with the tests of the previous block)\n",
               part.part, (long long)n_dev_blocks, (long long)n_host_blocks, ms_dev_read, ms_dev_decode);
     rg_bgen_dev_destroy(bdev);
+    bdev = nullptr;
   }
   if (getenv("RG_TIMING"))
     fprintf(stderr, "[timing] step 2 part %d: host threads %d (read-ahead %d) | chromosome set-up %.0f ms | waiting for the prepared block %.0f ms (preparing: %.0f ms wall, overlapped; %.0f thread-ms inflate + %.0f thread-ms byte walk) | "

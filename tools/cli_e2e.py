@@ -54,6 +54,8 @@ def main(N=50000, M=100000, P=1, bs=1000):
     print("data set written in %.1f s (%.2f GB .bed)" % (time.time() - t0, os.path.getsize(d + "/x.bed") / 1e9), flush=True)
     del dd, code, c, packed
     torch.cuda.empty_cache()
+    if os.environ.get("RG_E2E_WRITE_ONLY"):      # (tools/r6_ingest.py: the data set alone)
+        return
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "regenie_amd", "bin", "regenie-amd")
     variants = [("default", {}), ("default", {}), ("default", {}), ("RG_NBLK=28", {"RG_NBLK": "28"}), ("RG_NBLK=28", {"RG_NBLK": "28"}),
                 ("RG_PIPELINES=1", {"RG_PIPELINES": "1"}), ("RG_PIPELINES=1", {"RG_PIPELINES": "1"}),

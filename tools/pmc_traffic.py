@@ -12,7 +12,7 @@ import json
 import os
 import sys
 
-GROUP = ("k_chol_update", "k_chol_gfact", "k_chol_gstrip", "k_chol_backsolve")
+GROUP = ("k_c128_panel", "k_chol_update", "k_chol_gfact", "k_chol_gstrip", "k_chol_backsolve", "k_chol_backsolve_mfma")      # (k_c128_panel: chol_p128.h, round 6)
 
 
 def total(d, counter, level0_only=True):
