@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include "rg_internal.h"
 
 namespace {
@@ -99,6 +100,13 @@ const char* rg_last_error(const rg_ctx* c) { return c ? c->err.c_str() : "null c
 int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if (!ctx || !p) return RG_ERR_ARG;
   hipSetDevice(ctx->device);
+  // RG_TIMING: where the set-up goes (host layout + uploads | level-0 workspaces | digit planes of V | the other pipelines)
+  static const bool sp_timing = getenv("RG_TIMING") != nullptr;
+  const auto sp_t0 = std::chrono::steady_clock::now();
+  auto sp_mark = [&](const char* what) {
+    if (sp_timing) fprintf(stderr, "[timing] rg_set_problem%s: %s at %.0f ms\n", ctx->is_child ? " (second pipeline)" : "", what,
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - sp_t0).count());
+  };
   // cv_folds == 0 selects leave-one-out CV (params.use_loocv: cv_folds := n_samples, Data.cpp:363)
   if (p->cv_folds != 0 && (p->cv_folds < 2 || p->cv_folds > RG_MAX_SEG)) { ctx->err = "cv_folds must be 0 (LOOCV) or in [2,32]"; return RG_ERR_ARG; }
   ctx->loocv = (p->cv_folds == 0);
@@ -231,6 +239,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if ((rc = dev_alloc(ctx, &ctx->d_info, 4))) return rc;
   RG_HIP(hipMemset(ctx->d_info, 0, sizeof(int32_t) * 4));
 
+  sp_mark("host layout + uploads done");
   // level-0 workspaces
   const int bsm = ctx->bs_max;
   ctx->n128 = (int)rg_round_up(bsm, 128);
@@ -309,6 +318,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   if ((rc = dev_alloc(ctx, &ctx->d_beta, (size_t)nb * nseg * R0 * P * n64))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_cb, (size_t)nb * nseg * R0 * P * C))) return rc;
   if ((rc = dev_alloc(ctx, &ctx->d_psum, (size_t)nb * ctx->n_c256 * P * 8 * 2))) return rc;
+  sp_mark("level-0 workspaces allocated");
   // G~X / G~Y on the i8 matrix cores (xy_i8.hip): digit planes of V = [X | Y], once per problem (RG_XY_F64=1 keeps the fp64 kernel)
   if (ctx->d_vd) { hipFree(ctx->d_vd); ctx->d_vd = nullptr; }
   if (ctx->d_vsc) { hipFree(ctx->d_vsc); ctx->d_vsc = nullptr; }
@@ -348,6 +358,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
   ctx->have_problem = true;
   ctx->join_pending = false; ctx->pipe_rr = 0; ctx->ingest_pending = false;
   memset(&ctx->tm, 0, sizeof(ctx->tm));
+  sp_mark("this pipeline ready");
   // further pipelines (see rg_ctx::twin): a chain of child contexts; RG_PIPELINES=1 keeps a single one
   if (ctx->twin) { rg_destroy(ctx->twin); ctx->twin = nullptr; }
   int npipe = ctx->ws_pipes > 0 ? ctx->ws_pipes : 2;
@@ -368,6 +379,7 @@ int rg_set_problem(rg_ctx* ctx, const rg_problem* p) {
     }
     if (ctx->n_pipe > 1 && !ctx->ev_tw_fork) hipEventCreateWithFlags(&ctx->ev_tw_fork, hipEventDisableTiming);
   }
+  sp_mark("all pipelines ready");
   return RG_OK;
 }
 

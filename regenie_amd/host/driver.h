@@ -116,6 +116,7 @@ struct Log {  // mstream (Regenie.hpp:120-142): tee to stdout and <out>.log
   Log& operator<<(std::ostream& (*m)(std::ostream&)) { if (tl_log) { *tl_log << m; return *this; } std::cout << m; if (f.is_open()) f << m; return *this; }
 };
 extern Log sout;
+bool full_teardown();               // RG_TEARDOWN=1, or a tool that finalises at exit: device memory, page-locked buffers and the runtime are released in order
 extern bool fast_exit;              // set at the successful end of a run: main() then leaves through _exit once the log is closed
 extern std::mutex g_reader_mu;      // the .pgen / .bgen readers keep per-handle state: one block read at a time (multi-GPU step 2)
 

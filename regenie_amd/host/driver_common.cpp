@@ -11,6 +11,15 @@ namespace rgdrv {
 thread_local std::ostringstream* tl_log = nullptr;
 Log sout;
 bool fast_exit = false;
+bool full_teardown() {
+  static const bool v = []() {
+    const char* td = getenv("RG_TEARDOWN");
+    const bool tooling = getenv("ROCPROFILER_LIBRARY_CTOR") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROF_OUTPUT_PATH") || getenv("LD_PRELOAD") ||
+                         getenv("ASAN_OPTIONS") || getenv("LLVM_PROFILE_FILE");
+    return (td && atoi(td) != 0) || (tooling && !(td && atoi(td) == 0));
+  }();
+  return v;
+}
 std::mutex g_reader_mu;
 
 std::vector<std::string> split_ws(const std::string& s) {     // the tokens `is >> t` would give (a stream per line cost 2 s of a 500,000-sample run)

@@ -36,9 +36,12 @@ struct IngestRing {
       }
     });
   }
+  // Un-pinning costs what pinning did (0.1 - 0.15 s per GB: 1.4 s for the three 4.2 GB buffers of BASELINE configs[2], measured between the
+  // end of level 0 and the start of level 1 -- round 6, gpurun_out/r6_ingest): a run that leaves through _exit (the default, see the end of
+  // run_step1) hands the buffers back to the system with the process instead.
   void release() {
     if (th.joinable()) th.join();
-    for (auto& m : mem) { if (m) { if (pinned) rg_host_free(m); else free(m); } m = nullptr; }
+    for (auto& m : mem) { if (m && full_teardown()) { if (pinned) rg_host_free(m); else free(m); } m = nullptr; }
   }
   ~IngestRing() { release(); }
 };
@@ -54,7 +57,7 @@ struct BedMap {
   size_t bytes = 0;
   int state = 0;                       // 0 not started / unusable, 1 registering, 2 registered
   std::thread th;
-  void start(const std::string& path) {
+  void start(const std::string& path, bool want_registered) {
     fd = open(path.c_str(), O_RDONLY);
     if (fd < 0) return;
     const off_t sz = lseek(fd, 0, SEEK_END);
@@ -62,13 +65,17 @@ struct BedMap {
     void* m = mmap(nullptr, (size_t)sz, PROT_READ, MAP_SHARED, fd, 0);
     if (m == MAP_FAILED) return;
     base = (uint8_t*)m; bytes = (size_t)sz; state = 1;
+    // RG_INGEST_MAP=2: the mapping is NOT registered -- the copies then go through the runtime's own staging of pageable memory
+    registered = getenv("RG_INGEST_MAP") ? atoi(getenv("RG_INGEST_MAP")) != 2 : want_registered;
+    if (!registered) { state = 2; return; }
     th = std::thread([this]() { if (rg_host_register(base, (int64_t)bytes, 1) != 0) state = -1; else state = 2; });
   }
+  bool registered = true;
   bool ready() { if (th.joinable()) th.join(); return state == 2; }
   ~BedMap() {
     if (th.joinable()) th.join();
     if (fast_exit) return;                 // the process is about to leave through _exit: the mapping goes with it
-    if (state == 2) rg_host_unregister(base);
+    if (state == 2 && registered) rg_host_unregister(base);
     if (base) munmap(base, bytes);
     if (fd >= 0) close(fd);
   }
@@ -138,15 +145,17 @@ int run(int argc, char** argv) {
   IngestRing* pre_ring_ptr = nullptr;
   BedMap bed_map;
   if (p.step == 1 && !p.run_l1 && !r.dosage_mode && r.bpr > 0) {   // the host side of the ingest is set up under the parsing below
-    // The mapped, registered .bed is the source of the copies for files up to RG_INGEST_MAP_MAX_GB (16): at BASELINE configs[1] (1.25 GB)
-    // it is what makes a run 0.22 s.  For the 62.5 GB file of configs[2] the copies out of a registered file mapping took 7.4 s on the
-    // round-4 boxes (the queueing call itself blocked for 5.8 s) where the ring of page-locked buffers needed 2.4 s -- on the round-3 box
-    // it had been the other way round (1.7 s mapped; profiles/r3_e2e_config3_final.log, profiles/r4_e2e_config3.log).  RG_INGEST_MAP=1
-    // forces the mapping, =0 the ring.
+    // The mapped .bed is the source of the copies (rounds 3 - 5: registered with the runtime, and only for files up to 16 GB -- for the 62.5 GB
+    // file of configs[2] the registered mapping and the ring of page-locked buffers traded places from box to box: DESIGN_HISTORY.md).
+    // Round 6: ONE GPU takes the mapping UNREGISTERED, whatever the file's size -- the copies then go through the runtime's staging of pageable
+    // memory, and nothing is page-locked: at configs[2] the page-locking of the ring (12.6 GB, on a thread beside the parsing) delayed the
+    // runtime's start-up by 1.4 s and cost 1.4 s again when it was released; measured on a device whose memory was clean: ring 5.6 - 6.1 s,
+    // registered mapping 4.4 s, unregistered mapping 3.55 s (level 0 of the 62.5 GB file queued in 1.63 s = 38 GB/s, context ready after
+    // 0.42 s); configs[1]: predictions written after 0.17 - 0.19 s instead of 0.26 - 0.31 s (gpurun_out/r6_ingest, tools/r6_ingest_small.sh).
+    // RG_INGEST_MAP=1 registers the mapping (several GPUs: the ranks share it and their copies are asynchronous), =0 takes the ring.
     const char* em = getenv("RG_INGEST_MAP");
-    const double map_max = (getenv("RG_INGEST_MAP_MAX_GB") ? atof(getenv("RG_INGEST_MAP_MAX_GB")) : 16.0) * 1e9;
-    const bool want_map = em ? atoi(em) != 0 : (double)r.snp_chrom.size() * (double)r.bpr <= map_max || p.gpus > 1;
-    if (!r.pgen && want_map) bed_map.start(p.bed + ".bed");           // the mapped file, registered on its own thread (shared by the ranks)
+    const bool want_map = em ? atoi(em) != 0 : true;
+    if (!r.pgen && want_map) bed_map.start(p.bed + ".bed", p.gpus > 1);           // the mapped file, registered on its own thread (shared by the ranks)
     if (bed_map.state == 0 && p.gpus == 1) {                                         // else, one GPU: the ring of page-locked buffers
       pre_ring.start((int64_t)r.snp_chrom.size() * r.bpr, ingest_blk_bytes, -1, 1);
       pre_ring_ptr = &pre_ring;
@@ -268,7 +277,12 @@ int run(int argc, char** argv) {
     // library's default of 64 GB
     const int64_t bed_bytes = (int64_t)(B / G + 1) * ingest_blk_bytes;
     check(ctxs[g], rg_set_l0_workspace(ctxs[g], 0, 0, std::max<int64_t>(6000000000LL, std::min<int64_t>(64000000000LL, 8 * bed_bytes))));
+    const auto tsp = std::chrono::steady_clock::now();
     check(ctxs[g], rg_set_problem(ctxs[g], &pr));
+    if (getenv("RG_TIMING"))
+      fprintf(stderr, "[timing] rg_set_problem (GPU %d): %.0f ms (entered %lld ms since start)\n", g,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tsp).count(),
+              (long long)std::chrono::duration_cast<std::chrono::milliseconds>(tsp - t_start).count());
   }
   sout << "   -GPU context" << (G > 1 ? "s" : "") << " ready (" << since_start() << "ms since start)\n";
   rg_ctx* ctx = ctxs[0];
@@ -844,10 +858,7 @@ int run(int argc, char** argv) {
   // here, so it is flushed and closed; main() flushes the log and stdout itself.  A tool that finalises at exit (rocprofv3, sanitizers,
   // coverage) would lose its output, so the fast exit is off whenever one is detected, and RG_TEARDOWN=1 (the test suite sets it) always
   // takes the full path: contexts, RCCL communicators and the runtime are then torn down in order, which is also what surfaces leaks.
-  const char* td = getenv("RG_TEARDOWN");
-  const bool tooling = getenv("ROCPROFILER_LIBRARY_CTOR") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROF_OUTPUT_PATH") || getenv("LD_PRELOAD") ||
-                       getenv("ASAN_OPTIONS") || getenv("LLVM_PROFILE_FILE");
-  if ((td && atoi(td) != 0) || (tooling && !(td && atoi(td) == 0))) {
+  if (full_teardown()) {
     if (grp) rg_group_destroy(grp);
     for (rg_ctx* cx : ctxs) rg_destroy(cx);
   } else fast_exit = true;

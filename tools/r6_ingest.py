@@ -26,6 +26,9 @@ def main():
         env = dict(os.environ)
         for kv in [s for s in spec.split(",") if s]:
             a, b = kv.split("=", 1)
+            if a == "SLEEP":            # let the runtime finish scrubbing what the previous process released
+                time.sleep(float(b))
+                continue
             env[a] = b
         t0 = time.time()
         r = subprocess.run([exe, "--step", "1", "--bed", d + "/x", "--phenoFile", d + "/x.pheno", "--covarFile", d + "/x.covar", "--bsize", "1000",
