@@ -136,7 +136,8 @@ int rg_s2_set_sparse_rule(rg_s2_ctx* ctx, int64_t n_samples, double prop_zero_th
  * Layouts as above: [P][n] / [C][n] sample-fastest host arrays.  The exact Firth test (--firth without --approx) is not behind this ABI. */
 typedef struct rg_s2_bt_null {
   int32_t family;             /* 0: binary trait (logistic null model), 1: count trait (Poisson; no corrections) */
-  int32_t reserved;
+  int32_t niter_max;          /* --niter (params->niter_max, Regenie.hpp; 0 = its default of 50): fit_firth_pseudo hands a fit to the
+                                 Newton solvers when one of its logistic steps took more iterations (Step2_Models.cpp:1625) */
   const double* X;            /* [C][n] covariates (new_cov) */
   const double* y;            /* [P][n] raw phenotype */
   const uint8_t* mask;        /* [P][n] masked_indivs */

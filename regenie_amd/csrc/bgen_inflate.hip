@@ -95,18 +95,23 @@ __device__ __noinline__ bool build_table_impl(WaveLds& L, int s0, int n, int tb,
   }
   __builtin_amdgcn_wave_barrier();
   {
-    int left = 1;
+    int left = 1, maxl = 0;
     uint32_t code = 0, prev = 0;
     bool over = false;
     for (int l = 1; l <= 15; ++l) {
       const uint32_t c = uni(L.count[l]);
       left = left * 2 - (int)c;
       if (left < 0) over = true;
+      if (c) maxl = l;
       code = (code + prev) << 1;
       prev = c;
       if (lane == 0) L.next[l] = code;
     }
     if (over) return false;
+    // an INCOMPLETE set is refused like zlib's inflate_table does (inftrees.c: `left > 0 && (type == CODES || max != 1)`): only a
+    // literal / length or distance code that consists of ONE code of one bit may leave slots unreached.  The host route and the reference
+    // then give the verdict on such a stream ('failed to decompress'); before round 6 only the Adler-32 check stood behind it.
+    if (left > 0 && maxl > 0 && (mode == 2 || maxl != 1)) return false;
   }
   __builtin_amdgcn_wave_barrier();
   // codes in symbol order: rank of a symbol among the symbols of its length = popcount of the lanes before it with that length, plus

@@ -32,6 +32,7 @@ struct BtPairDev {
 
 struct BtState {
   int family = 0;
+  int niter_max = 50;                         // --niter (params->niter_max): fit_firth_pseudo gives up on a logistic step that took more iterations
   bool have_null = false, have_firth = false;
   int ncol = 0;
   std::vector<double> xwx_inv, msum, xres, rsum;     // xres [P][C] = (X^T W X)^-1 X^T ((y - fitted) mask): the null model's residual score, ~0; rsum [P] = sum of (y - fitted) mask
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void k_bt_prep(const BtPairDev* __restrict__ p
 // ---- fit_firth_logistic_snp_fast with its one-parameter solver: Fisher scoring with step halving on the penalised deviance ----------------
 // res [pair][4] = beta, se, lrt, fail
 __global__ __launch_bounds__(256) void k_bt_firth1(const BtPairDev* __restrict__ pairs, const double* __restrict__ V, const double* __restrict__ Y,
-                                                   const double* __restrict__ Fo, const double* __restrict__ aux, int64_t n, double* __restrict__ res) {
+                                                   const double* __restrict__ Fo, const double* __restrict__ aux, int64_t n, double* __restrict__ res, int niter_max) {
   __shared__ double red[2][4];
   __shared__ double red4[4][4];
   const BtPairDev& pr = pairs[blockIdx.x];
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(256) void k_bt_firth1(const BtPairDev* __restrict__
       double bdiff = 1e16, bnew = b, xin = xt;
       const double bstar = b, xstar = xt;
       bool bad = false, done = false;
+      int nlog = 26;                                          // the reference's niter_log after its `while (niter_log++ < 25)`: 26 when the loop ran out
       for (int il = 0; il < 25; ++il) {
         const double step = sc / xin, bd = fabs(step);
         if (bd > bdiff) { bad = true; break; }
@@ -232,12 +234,13 @@ __global__ __launch_bounds__(256) void k_bt_firth1(const BtPairDev* __restrict__
         double s2, x2, d2, z2;
         sums_at(bnew, xstar, bstar, true, s2, x2, d2, z2);
         sc = s2;
-        if (fabs(sc) < tol) { done = true; xin = x2; break; }
+        if (fabs(sc) < tol) { done = true; xin = x2; nlog = il + 1; break; }
         if (z2 > 0.0) { bad = true; break; }
         xin = x2; b = bnew; bdiff = bd;
       }
       (void)done;
       if (bad) break;
+      if (nlog > niter_max) break;                            // `if (niter_log > params->niter_max) return 1` (Step2_Models.cpp:1625): only with --niter below 25
       b = bnew;
       // sum g^2 w at the new b (the inner loop left it in xin when it updated there; after its `break` on the score it belongs to bnew as well)
       xt = xin;
@@ -514,6 +517,7 @@ int rg_s2_bt_set_null(rg_s2_ctx* ctx, const rg_s2_bt_null* nm) {
   const int64_t n = ctx->n;
   const int P = ctx->P, C = ctx->C;
   bt.family = nm->family;
+  bt.niter_max = nm->niter_max > 0 ? nm->niter_max : 50;
   bt.ncol = P * (C + 3);
   if (bt.ncol > 4096) return rg_s2_fail(ctx, RG_S2_ERR_ARG, "rg_s2_bt_set_null: phenotypes x (covariates + 3) > 4096 contraction columns");
   bt.pass.assign(P, 1);
@@ -681,7 +685,7 @@ int rg_s2_bt_correct(rg_s2_ctx* ctx, int32_t kind, int32_t npair, const int32_t*
                        (unsigned)(2 * std::max(bt.scale, 0)), (const double*)bt.dX, (const uint8_t*)bt.dM, (const double*)bt.dFit, n, C, bt.d_v, d_aux);
     if (kind == RG_S2_BT_FIRTH_APPROX)
       hipLaunchKernelGGL(k_bt_firth1, dim3(np), dim3(256), 0, ctx->st, (const BtPairDev*)bt.d_pairs, (const double*)bt.d_v, (const double*)bt.dY,
-                         (const double*)bt.dFo, (const double*)d_aux, n, bt.d_res);
+                         (const double*)bt.dFo, (const double*)d_aux, n, bt.d_res, bt.niter_max);
     else
       hipLaunchKernelGGL(k_bt_spa, dim3(np), dim3(256), 0, ctx->st, (const BtPairDev*)bt.d_pairs, (const double*)bt.d_v, (const double*)bt.dFit,
                          (const double*)d_aux, n, bt.d_res);

@@ -559,7 +559,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     if (glm) {   // compute_res_bin / compute_res_count (Data.cpp:2439-2455): the null models of the chromosome go to the device
       rg_s2_bt_null nm;
       memset(&nm, 0, sizeof(nm));
-      nm.family = p.ct ? 1 : 0; nm.X = Xc.data(); nm.y = Yc.data(); nm.mask = Mc.data(); nm.fitted = bt_fit.data();
+      nm.family = p.ct ? 1 : 0; nm.niter_max = p.niter_max; nm.X = Xc.data(); nm.y = Yc.data(); nm.mask = Mc.data(); nm.fitted = bt_fit.data();
       nm.firth_offset = (firth && p.firth_approx) ? firth_off.data() : nullptr; nm.pass = bt_pass.data();
       s2check(rg_s2_bt_set_null(s2, &nm));
     } else s2check(rg_s2_set_null(s2, Xc.data(), resc.data(), Mc.data(), scf.data()));

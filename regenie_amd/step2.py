@@ -22,7 +22,7 @@ class _ContractOut(C.Structure):
 
 
 class _BtNull(C.Structure):
-    _fields_ = [("family", C.c_int32), ("reserved", C.c_int32), ("X", C.c_void_p), ("y", C.c_void_p), ("mask", C.c_void_p),
+    _fields_ = [("family", C.c_int32), ("niter_max", C.c_int32), ("X", C.c_void_p), ("y", C.c_void_p), ("mask", C.c_void_p),
                 ("fitted", C.c_void_p), ("firth_offset", C.c_void_p), ("pass_", C.c_void_p)]
 
 
