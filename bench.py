@@ -537,6 +537,14 @@ def main():
             lo["level1_bt_device_memory_peak_GB"] = lb["level1"].get("device_memory_peak_GB")
         except Exception as e:   # noqa: BLE001
             lo["error_level1"] = repr(e)[:500]
+        # Step-2 kernels (device time between the library's events -- but the missing-call route waits for a 4-byte count on the host between
+        # two kernels: beside the oracle refit below, whose numpy threads exhaust the job's 16-CPU quota, that wait grew from 0.02 to 12 ms
+        # per block in round 6's first line): measured while the box is quiet
+        try:
+            from tools.step2_record import step2_record
+            extra["step2"] = step2_record(torch=torch)
+        except Exception as e:   # noqa: BLE001
+            extra["step2"] = {"error": repr(e)[:500]}
         p4, err4 = None, []
         try:
             p4 = subprocess.Popen(me + big + ["--snps", "51200", "--bsize", "100", "--phenos", "4", "--bt", "--prev", "0.05,0.3,0.01,0.5", "--warmup", "0",
@@ -564,11 +572,6 @@ def main():
         except Exception as e:   # noqa: BLE001
             lo["error"] = repr(e)[:500]
         extra["loocv_500k"] = lo
-        try:
-            from tools.step2_record import step2_record
-            extra["step2"] = step2_record(torch=torch)
-        except Exception as e:   # noqa: BLE001
-            extra["step2"] = {"error": repr(e)[:500]}
         if p4 is not None and "config4_level1_binary_traits" not in extra:
             try:
                 out4, _ = p4.communicate(timeout=1500)

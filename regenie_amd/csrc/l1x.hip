@@ -561,6 +561,9 @@ __global__ __launch_bounds__(256) void k_bt_eval(BtArgs a, int ch0, const int32_
 // (one row per workgroup moved 5 x 4 MB of residuals through L2 for every 4 MB row of W: 8.3 ms per call at 500,000 samples and
 // L = 2,560 -- 1.25 TB/s on the bytes of W; the pass is now bound by W itself).  Fixed summation order: thread t takes positions
 // t, t + 256, ..., then the block reduction.
+// Round 6: 16-byte loads -- thread t takes the position pairs (2t, 2t + 1), (2t + 512, ...), ... (8-byte loads, one position per thread and
+// pass of the loop, kept the kernel at 2.9 ms per pass where k_bt_eval reads the same bytes in 1.9; four rows per workgroup instead of eight
+// measured slower, 3.05 ms).  Still a fixed summation order.
 #define BT_SROWS 8
 __global__ __launch_bounds__(256) void k_bt_score(BtArgs a, int ch0, const double* tauc, double* score) {
   __shared__ double sred[4];
@@ -574,16 +577,16 @@ __global__ __launch_bounds__(256) void k_bt_score(BtArgs a, int ch0, const doubl
   for (int k = 0; k < BT_SROWS; ++k)
 #pragma unroll
     for (int j = 0; j < NCH; ++j) acc[k][j] = 0.0;
-  for (int64_t pos = threadIdx.x; pos < a.Np; pos += 256) {
-    double x[BT_SROWS], r[NCH];
+  for (int64_t pos = 2 * threadIdx.x; pos < a.Np; pos += 512) {      // Np is a multiple of 256: pos + 1 < Np
+    double2 x[BT_SROWS], r[NCH];
 #pragma unroll
-    for (int k = 0; k < BT_SROWS; ++k) x[k] = w[k][pos];
+    for (int k = 0; k < BT_SROWS; ++k) x[k] = *reinterpret_cast<const double2*>(w[k] + pos);
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) r[j] = a.rv[(int64_t)(ch0 + (j < nc ? j : 0)) * a.Np + pos];
+    for (int j = 0; j < NCH; ++j) r[j] = *reinterpret_cast<const double2*>(a.rv + (int64_t)(ch0 + (j < nc ? j : 0)) * a.Np + pos);
 #pragma unroll
     for (int k = 0; k < BT_SROWS; ++k)
 #pragma unroll
-      for (int j = 0; j < NCH; ++j) acc[k][j] = fma(x[k], r[j], acc[k][j]);
+      for (int j = 0; j < NCH; ++j) acc[k][j] = fma(x[k].y, r[j].y, fma(x[k].x, r[j].x, acc[k][j]));
   }
 #pragma unroll
   for (int k = 0; k < BT_SROWS; ++k)
@@ -942,6 +945,136 @@ __global__ __launch_bounds__(TS_NT) void k_tri_solve(const double* __restrict__ 
   for (int i = tid; i < n64; i += TS_NT) sol[(int64_t)chain * n64 + i] = i < L ? y[i] : 0.0;
 }
 
+// ---- the same two substitutions for FEW large systems, one LAUNCH per tile row (round 6) ----------------------------------------------------
+// k_tri_solve walks a system with ONE workgroup: 2 x 40 dependent tile steps at L = 2,560, each a pass of that workgroup over up to 1.3 MB of
+// the factor -- 5.2 ms per call whatever the number of chains (<= 20 workgroups on 256 CUs), 20 % of configs[3]'s level 1
+// (profiles/r4_config4_level1_kernel_stats_stored_hessians.md).  Here a step is a launch and every tile row (column) below (left of) the current
+// one is a workgroup: forward, launch s: y_i -= F[i][s-1] y_(s-1) for every i >= s, and the workgroup of row s then finishes y_s = F_ss^-1 y_s;
+// backward, launch k: y_j -= F[k][j]^T x_k for every j < k, and the workgroup of column k-1 finishes x_(k-1).  2 T launches of a few
+// microseconds each (the scheme of k_chol_backsolve_row, chol.hip, which needs the tile inverses a stored factor does not come with).
+// grid (rows of this step, systems), 256 threads; sol [chain][n64] holds b, then y, then x.
+__global__ __launch_bounds__(256) void k_tri_rows(const double* __restrict__ fac, int64_t msz, const int32_t* __restrict__ chainmap, int n64, int L,
+                                                const double* __restrict__ rhs, double* __restrict__ sol, int step, int backward) {
+  __shared__ double tile[64][65];
+  __shared__ double yv[64];
+  __shared__ double red[4][64];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int chain = chainmap[blockIdx.y];
+  const double* A = fac + (int64_t)chain * msz;
+  double* y = sol + (int64_t)chain * n64;
+  const int T = (L + 63) / 64;
+  auto stage_diag = [&](int k0) {          // lower triangle of the diagonal tile; identity past the order
+    const int nk = L - k0 < 64 ? L - k0 : 64;
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int r = e >> 6, c = e & 63;
+      tile[r][c] = (r < nk && c <= r) ? A[(int64_t)(k0 + r) * n64 + k0 + c] : (r == c ? 1.0 : 0.0);
+    }
+  };
+  if (!backward) {
+    if (step == 0) {                       // b -> sol (the padding past the order: 0), then y_0
+      for (int i = tid; i < n64; i += 256) y[i] = i < L ? rhs[(int64_t)chain * n64 + i] : 0.0;
+      stage_diag(0);
+      __syncthreads();
+      if (tid < 64) {
+        double v = y[tid];
+        const double rd = 1.0 / tile[tid][tid];      // the 64 reciprocals at once: no division inside the chain of 64 dependent steps
+        for (int c = 0; c < 64; ++c) {
+          const double piv = __shfl(v * rd, c);
+          if (tid == c) v = piv;
+          else if (tid > c) v -= tile[tid][c] * piv;
+        }
+        y[tid] = v;
+      }
+      return;
+    }
+    const int i = step + blockIdx.x, k0 = (step - 1) * 64, i0 = i * 64;      // y_i -= F[i][step-1] y_(step-1)
+    if (i >= T) return;
+    if (tid < 64) yv[tid] = y[k0 + tid];
+    __syncthreads();
+    // thread t: row t >> 2 of the tile, columns 16 (t & 3) .. + 15 -- sixteen independent loads (four adjacent lanes cover the row's 512
+    // bytes), then two shuffles (a load per row and six shuffles behind it, row after row, took 24 us per launch: one memory latency per row)
+    {
+      const int r = tid >> 2, q4 = tid & 3, row = i0 + r;
+      const double* ap = A + (int64_t)(row < L ? row : 0) * n64 + k0 + 16 * q4;
+      double4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const double4*>(ap + 4 * u);
+      double p = 0.0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        p += (v[u].x * yv[16 * q4 + 4 * u] + v[u].y * yv[16 * q4 + 4 * u + 1]) + (v[u].z * yv[16 * q4 + 4 * u + 2] + v[u].w * yv[16 * q4 + 4 * u + 3]);
+      p += __shfl_xor(p, 1);
+      p += __shfl_xor(p, 2);
+      if (q4 == 0 && row < L) y[row] -= p;
+    }
+    if (blockIdx.x != 0) return;
+    __threadfence_block();
+    stage_diag(i0);                        // the row of this step: y_s = F_ss^-1 y_s
+    __syncthreads();
+    if (tid < 64) {
+      double v = y[i0 + tid];
+      const double rd = 1.0 / tile[tid][tid];
+      for (int c = 0; c < 64; ++c) {
+        const double piv = __shfl(v * rd, c);
+        if (tid == c) v = piv;
+        else if (tid > c) v -= tile[tid][c] * piv;
+      }
+      y[i0 + tid] = v;
+    }
+    return;
+  }
+  // backward: step = k (T-1 .. 1: the updates with x_k), or T for the first solve x_(T-1)
+  auto solve_t = [&](int j0) {             // x = F_jj^-T y on the tile staged in `tile`
+    if (tid < 64) {
+      double v = y[j0 + tid];
+      const double rd = 1.0 / tile[tid][tid];
+      for (int c = 63; c >= 0; --c) {
+        const double piv = __shfl(v * rd, c);
+        if (tid == c) v = piv;
+        else if (tid < c) v -= tile[c][tid] * piv;
+      }
+      y[j0 + tid] = v;
+    }
+  };
+  if (step == T) {
+    stage_diag((T - 1) * 64);
+    __syncthreads();
+    solve_t((T - 1) * 64);
+    return;
+  }
+  const int k0 = step * 64, j = blockIdx.x, j0 = j * 64;                  // y_j -= F[k][j]^T x_k
+  if (tid < 64) yv[tid] = y[k0 + tid];
+  __syncthreads();
+  double a = 0.0;
+  {
+    double l[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {          // sixteen loads in flight (rows past the order: clamped address, zero weight)
+      const int row = k0 + 16 * w + r;
+      l[r] = A[(int64_t)(row < L ? row : L - 1) * n64 + j0 + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a = fma(l[r], (k0 + 16 * w + r < L) ? yv[16 * w + r] : 0.0, a);
+  }
+  red[w][lane] = a;
+  __syncthreads();
+  if (w == 0) y[j0 + lane] -= (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+  if (j != step - 1) return;
+  __threadfence_block();
+  stage_diag(j0);
+  __syncthreads();
+  solve_t(j0);
+}
+
+static void launch_tri_rows(hipStream_t st, const double* fac, int64_t msz, const int32_t* d_map, int na, int n64, int L, const double* rhs, double* sol) {
+  const int T = (L + 63) / 64;
+  for (int s = 0; s < T; ++s)
+    hipLaunchKernelGGL(k_tri_rows, dim3(s == 0 ? 1 : T - s, na), dim3(256), 0, st, fac, msz, d_map, n64, L, rhs, sol, s, 0);
+  hipLaunchKernelGGL(k_tri_rows, dim3(1, na), dim3(256), 0, st, fac, msz, d_map, n64, L, rhs, sol, T, 1);
+  for (int k = T - 1; k >= 1; --k)
+    hipLaunchKernelGGL(k_tri_rows, dim3(k, na), dim3(256), 0, st, fac, msz, d_map, n64, L, rhs, sol, k, 1);
+}
+
 // what a workgroup may ask for in dynamic LDS on this device (160 KB on gfx950; asked once)
 static size_t lds_optin_bytes() {
   static const size_t v = []() -> size_t {
@@ -964,7 +1097,11 @@ int bt_chord(BtState& s, const std::vector<int32_t>& act) {
   const size_t lds = tri_solve_lds(c.n64);
   if (lds > 48 * 1024) L1X_HIP(hipFuncSetAttribute((const void*)k_tri_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   double* d_x = s.d_sys;      // [nchain][n64] scratch: the systems' workspace is idle during a chord step
-  hipLaunchKernelGGL(k_tri_solve, dim3(na), dim3(TS_NT), lds, st, (const double*)s.d_fac, c.msz, (const int32_t*)s.d_map, c.n64, c.L, (const double*)s.d_score, d_x);
+  static const bool one_wg = getenv("RG_TRI_ONE_WG") && atoi(getenv("RG_TRI_ONE_WG")) != 0;      // the round-4 kernel: one workgroup per system
+  if (one_wg || c.L < 256)
+    hipLaunchKernelGGL(k_tri_solve, dim3(na), dim3(TS_NT), lds, st, (const double*)s.d_fac, c.msz, (const int32_t*)s.d_map, c.n64, c.L, (const double*)s.d_score, d_x);
+  else
+    launch_tri_rows(st, s.d_fac, c.msz, s.d_map, na, c.n64, c.L, s.d_score, d_x);
   L1X_HIP(hipGetLastError());   // 62 KB of dynamic LDS at L = 2,560: a refused launch must not pass scratch off as the chord step
   for (int i = 0; i < na; ++i)
     L1X_HIP(hipMemcpyAsync(s.h_sol.data() + (size_t)act[i] * c.n64, d_x + (int64_t)act[i] * c.n64, sizeof(double) * c.n64, hipMemcpyDeviceToHost, st));
