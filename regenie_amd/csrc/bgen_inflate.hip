@@ -83,7 +83,9 @@ __device__ __forceinline__ void sym_entry(int mode, int s, uint32_t& kind, uint3
 // Canonical Huffman code of the n symbols with lengths L.lens[s0 + s] -> two-level decode table with tb first-level bits.  All 64 lanes of
 // the wave take part; returns false (in every lane) for an over-subscribed code or a table that does not fit.  Slots no code reaches stay
 // K_BAD.  maxlen: 15 (7 for the code-length code).
-__device__ __noinline__ bool build_table_impl(WaveLds& L, int s0, int n, int tb, uint32_t* table, int slots, int mode) {
+__device__ __noinline__ bool build_table_impl(WaveLds& L, int s0, int n, int tb, uint32_t* table, int slots, int mode_in) {
+  const int mode = mode_in & 3;
+  const bool fixed_code = (mode_in & 4) != 0;      // the fixed distance code of RFC 1951 (30 codes of 5 bits) is incomplete by definition: zlib never runs it through inflate_table
   const int lane = lane_id();
   const uint32_t first = 1u << tb;
   if (lane < 16) L.count[lane] = 0;
@@ -111,7 +113,7 @@ __device__ __noinline__ bool build_table_impl(WaveLds& L, int s0, int n, int tb,
     // an INCOMPLETE set is refused like zlib's inflate_table does (inftrees.c: `left > 0 && (type == CODES || max != 1)`): only a
     // literal / length or distance code that consists of ONE code of one bit may leave slots unreached.  The host route and the reference
     // then give the verdict on such a stream ('failed to decompress'); before round 6 only the Adler-32 check stood behind it.
-    if (left > 0 && maxl > 0 && (mode == 2 || maxl != 1)) return false;
+    if (left > 0 && maxl > 0 && !fixed_code && (mode == 2 || maxl != 1)) return false;
   }
   __builtin_amdgcn_wave_barrier();
   // codes in symbol order: rank of a symbol among the symbols of its length = popcount of the lanes before it with that length, plus
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(64 * WPB) void k_bgen_inflate(InflateArgs a) {
       for (int s = lane; s < 288; s += 64) L.lens[s] = (uint8_t)(s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8)));
       if (lane < 32) L.lens[288 + lane] = 5;
       __builtin_amdgcn_wave_barrier();
-      if (!build_table(L, 0, 288, LIT_TB, L.lit, LIT_SLOTS, 0) || !build_table(L, 288, 30, DIST_TB, L.dist, DIST_SLOTS, 1)) { st = ST_TABLE; break; }
+      if (!build_table(L, 0, 288, LIT_TB, L.lit, LIT_SLOTS, 0) || !build_table(L, 288, 30, DIST_TB, L.dist, DIST_SLOTS, 1 | 4)) { st = ST_TABLE; break; }
     } else {
       bits_refill(b);
       const uint32_t hlit = bits_take(b, 5) + 257u, hdist = bits_take(b, 5) + 1u, hclen = bits_take(b, 4) + 4u;

@@ -1197,7 +1197,10 @@ int bt_newton_loocv(BtState& s, double lam, std::vector<double>& beta, const rg_
   while (true) {
     if (++niter > o.niter_max_ridge) break;
     bool bad = false;
-    if ((rc = bt_solve(s, act, tauc, true, &bad, s.d_sw != nullptr))) return rc;      // Newton step, or the quasi-Newton one at large N
+    // Newton step, or the quasi-Newton one at large N -- for at most RG_WGRAM_SWITCH (12) rounds, as in the K-fold chains: a fit the
+    // approximate Hessian has not brought below the tolerance by then finishes on the exact one instead of being reported as not converged
+    static const int qn_rounds = getenv("RG_WGRAM_SWITCH") ? atoi(getenv("RG_WGRAM_SWITCH")) : 12;
+    if ((rc = bt_solve(s, act, tauc, true, &bad, s.d_sw != nullptr && niter <= qn_rounds))) return rc;
     if (bad) return RG_OK;
     for (int k = 0; k < L; ++k) step[k] = s.h_sol[k];
     for (int ls = 0; ls < o.niter_max_line_search; ++ls) {

@@ -3,6 +3,7 @@ import importlib.util
 import os
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -79,7 +80,7 @@ def test_traffic_files_are_keyed_on_the_kernel_library_not_on_the_host_driver(tm
     # another file of the library changed (the BGEN decoder): the Cholesky group's sources are what they were, its traffic stands; a change to
     # chol.hip itself makes it stale
     files = {"csrc/rg_api.hip": "a", "csrc/rg_internal.h": "b", "csrc/bed_prep.hip": "c", "flags": "f", "csrc/chol.hip": "d", "csrc/assemble.hip": "e",
-             "csrc/bgen_inflate.hip": "old"}
+             "csrc/chol_p128.h": "g", "csrc/chol_common.h": "h", "csrc/bgen_inflate.hip": "old"}
     rec["source_digests"] = files
     (root / "profiles" / "x_traffic.json").write_text(json.dumps(rec))
     (root / "regenie_amd" / "lib" / "kernel_files.json").write_text(json.dumps(dict(files, **{"csrc/bgen_inflate.hip": "new"})))
@@ -88,5 +89,26 @@ def test_traffic_files_are_keyed_on_the_kernel_library_not_on_the_host_driver(tm
     (root / "regenie_amd" / "lib" / "kernel_files.json").write_text(json.dumps(dict(files, **{"csrc/chol.hip": "new"})))
     per, note = b.measured_traffic("chol_f64", 109, 2, 1)
     assert per is None and "stale" in note
-    assert set(build.kernel_file_digests()) >= {"csrc/chol.hip", "csrc/rg_api.hip", "csrc/rg_internal.h", "csrc/bed_prep.hip", "csrc/assemble.hip", "csrc/l1.hip", "csrc/l1x.hip",
+    (root / "regenie_amd" / "lib" / "kernel_files.json").write_text(json.dumps(dict(files, **{"csrc/chol_p128.h": "new"})))      # the panel-128 kernels (round 6)
+    per, note = b.measured_traffic("chol_f64", 109, 2, 1)
+    assert per is None and "stale" in note
+    assert set(build.kernel_file_digests()) >= {"csrc/chol.hip", "csrc/chol_p128.h", "csrc/chol_common.h", "csrc/rg_api.hip", "csrc/rg_internal.h", "csrc/bed_prep.hip", "csrc/assemble.hip", "csrc/l1.hip", "csrc/l1x.hip",
                                                 "csrc/gram_fp4.hip", "csrc/pred.hip", "csrc/pred_i8.hip", "csrc/wgram_bf16.hip", "flags"}
+
+
+def test_summary_digest_of_a_recorded_line_fits_the_tail_a_reader_keeps():
+    """bench.py ends its JSON line with `summary` (every sub-run's headline figures): the driver's record keeps the last 2,000 characters of the
+    line, so the digest must stay well below that whatever the sub-records hold, and must carry the figures the review reads first."""
+    import glob
+    import json
+    b = _bench()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[56]_bench_line.json"))):
+        line = json.load(open(fn))
+        s = b.summary_of(line)
+        assert len(json.dumps(s)) < 1500, fn
+        assert s["cfg1"]["ms"] == pytest.approx(line["ms_per_step"], rel=1e-3) and s["cfg1"]["chol_frac"] == pytest.approx(line["roofline"]["frac"], rel=1e-3)
+        assert s["cfg2_1gpu"]["files_s"] is not None and s["cfg2_1gpu"]["loco_ck"] == line["config3_single_gpu"]["loco_checksum"]
+        assert s["cfg3_bt"]["s_per_trait"] is not None and s["step2"]["bgen_lines_identical"].count("/") == 1
+    # a line whose sub-runs failed still gets a digest, with the failures named
+    s = b.summary_of({"ms_per_step": 30.0, "roofline": {"frac": 0.4}, "config3_single_gpu": {"error": "x"}, "step2": {"error": "y"}})
+    assert s["errors_in"] == ["config3_single_gpu", "step2"] and s["cfg2_1gpu"]["ms"] is None
