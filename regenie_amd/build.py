@@ -64,7 +64,7 @@ def kernel_file_digests() -> dict:
 
 
 def _deps():
-    return _lib_deps() + [os.path.join(HERE, "host", f) for f in HOST_SOURCES + ["driver.h"]]
+    return _lib_deps() + [os.path.join(HERE, "host", f) for f in HOST_SOURCES + ["driver.h", "fmt_g6.h"]]
 
 
 def _lib_deps():

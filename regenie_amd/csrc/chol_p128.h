@@ -33,6 +33,9 @@
 #define C128_STAGE_SYNC() asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define c128_glds16 glds16
 #define C128_RFL(x) __builtin_amdgcn_readfirstlane(x)
+// barrier for LDS hazards only: __syncthreads() also waits for every outstanding GLOBAL store of the wave (s_waitcnt vmcnt(0)) -- in the
+// factorization of a diagonal block, which stores L and the inverses between its LDS phases, that was a store round trip per barrier
+#define C128_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // a lane id the compiler cannot connect with the kernel's own: what a phase derives from it cannot be hoisted above the phases before it
 // (hipcc computed the addresses of the LATER phases ahead of the K loop and spilled the K loop's own operands to scratch -- with an
 // s_waitcnt vmcnt in front of every reload, i.e. behind the stage copies just issued)
@@ -54,6 +57,7 @@
                : "memory")
 #else
 #define C128_LAUNDER(x) ((void)0)
+#define C128_LDS_BARRIER() __syncthreads()
 #define C128_STAGE_SYNC_ACC(acc) C128_STAGE_SYNC()
 #define C128_STAGE_SYNC_ACCD(acc) C128_STAGE_SYNC()
 #endif
@@ -90,22 +94,32 @@ struct C128Args {
   int32_t* info;
   int j, Tp, batch, R, nplain;
   int flags;            // diagnostics (RG_C128_FLAGS): timing only, wrong results: 2 = every source row block is read from
-                        // the system's first 16 rows, 4 = no products in the triangular multiply, 8 = the two tile factorizations skipped
+                        // the system's first 16 rows, 4 = no products in the triangular multiply, 8 = the two tile factorizations skipped,
+                        // 16 = every K unit of a tile re-reads the tile's first (is the product loop waiting for memory?)
   unsigned long long* dbg;      // RG_C128_DBG=1: per-phase time sums (100 MHz ticks of s_memrealtime, thread 0 of every workgroup); else nullptr
   FormSrc fs;
 };
 #ifndef RG_HOST_EMU
+// (the sums are kept in the last 1.5 KB of the workgroup's LDS and flushed with the workgroup's last instructions: a global atomic per phase
+// made the NEXT phase wait for it at its first vmcnt(0) and showed up there -- 155 -> 420 thousand workgroup-us in "L21/M1/D22/save")
 #define C128_T(k)                                                                        \
   do {                                                                                   \
     if (a.dbg && threadIdx.x == 0) {                                                     \
       const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                    \
-      atomicAdd(&a.dbg[k], t_ - t_prev);                                                 \
+      tl[k] += t_ - t_prev;                                                              \
       t_prev = t_;                                                                       \
     }                                                                                    \
+  } while (0)
+#define C128_TFLUSH()                                                                    \
+  do {                                                                                   \
+    if (a.dbg && threadIdx.x == 0)                                                       \
+      for (int k_ = 1; k_ < 16; ++k_)                                                    \
+        if (tl[k_]) atomicAdd(&a.dbg[k_], tl[k_]);                                       \
   } while (0)
 #define C128_T0() (a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull)
 #else
 #define C128_T(k) ((void)0)
+#define C128_TFLUSH() ((void)0)
 #define C128_T0() 0ull
 #endif
 
@@ -114,7 +128,7 @@ struct C128Args {
 // Returns true (in some thread) when a pivot was not positive.
 __device__ __forceinline__ bool c128_factor64(double (&s)[CT][CT + 2], double (&dv)[CT], unsigned long long* dbg = nullptr) {
 #ifndef RG_HOST_EMU
-#define C128_FT(k) do { if (dbg && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&dbg[k], t_ - tf); tf = t_; } } while (0)
+#define C128_FT(k) do { if (dbg && threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); dbg[k] += t_ - tf; tf = t_; } } while (0)      // dbg: the workgroup's LDS sums
   unsigned long long tf = dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;
 #else
 #define C128_FT(k) ((void)0)
@@ -180,7 +194,7 @@ __device__ __forceinline__ bool c128_factor64(double (&s)[CT][CT + 2], double (&
         if (r > tid) s[o + tid][o + r] = v[r];   // Linv[r][tid], transposed into the upper triangle
     }
     C128_FT(11);
-    __syncthreads();
+    C128_LDS_BARRIER();
     C128_FT(14);
     // (ii) rows below: L21 = A21 * Linv11^T, one 16-row block per wave
     if (wave < nb) {
@@ -192,7 +206,7 @@ __device__ __forceinline__ bool c128_factor64(double (&s)[CT][CT + 2], double (&
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[rb + lq + 4 * r][o + li] = acc[r];
     }
-    __syncthreads();
+    C128_LDS_BARRIER();
     // (iii) trailing update inside the tile: A22 -= L21 L21^T (lower blocks; only the lower triangle of the
     //       diagonal blocks is written -- their upper triangle will hold the inverse), blocks dealt to the waves
     {
@@ -211,7 +225,7 @@ __device__ __forceinline__ bool c128_factor64(double (&s)[CT][CT + 2], double (&
           if (bi != bj || li <= lq + 4 * r) s[ri + lq + 4 * r][rj + li] -= acc[r];
       }
     }
-    __syncthreads();
+    C128_LDS_BARRIER();
     C128_FT(12);
   }
   C128_FT(12);
@@ -237,7 +251,7 @@ __device__ __forceinline__ bool c128_factor64(double (&s)[CT][CT + 2], double (&
 #pragma unroll
       for (int r = 0; r < 4; ++r) s[16 * j + li][16 * ib + lq + 4 * r] = -acc[r];
     }
-    __syncthreads();
+    C128_LDS_BARRIER();
   }
   C128_FT(13);
   return bad;
@@ -354,7 +368,12 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   double* M = a.mats + (int64_t)b * a.mat_stride;
   const uint32_t lds0 = C128_LDS_ADDR(smem);
   unsigned long long t_prev = C128_T0();
-  if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[succ ? 17 : 16], 1ull); atomicAdd(&a.dbg[19], t_prev - t_start); }
+  unsigned long long* tl = reinterpret_cast<unsigned long long*>(smem + C128_LDS - 1024);      // [16] phase sums of this workgroup (diagnostic)
+  if (a.dbg && threadIdx.x == 0) {
+    for (int k_ = 0; k_ < 16; ++k_) tl[k_] = 0;
+    atomicAdd(&a.dbg[succ ? 17 : 16], 1ull);
+    atomicAdd(&a.dbg[19], t_prev - t_start);
+  }
 
   v4d acc[8][2];
 #pragma unroll
@@ -389,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
         c128_issue_cols16((is_x >= 8 ? fx.F : fx.S) + ((a.flags & 2) ? 0 : (int64_t)(128 * it) * n64 + 128 * j + 16 * (is_x & 7)), buf, wave, n64, lds0, xoff);
         ++is_x; is_c = 0;
       } else if (is_k < nK) {
-        c128_issue_unit(arows + 8 * is_k, brows + 8 * is_k, buf, wave, n64, lds0, uoff);
+        c128_issue_unit(arows + ((a.flags & 16) ? 0 : 8 * is_k), brows + ((a.flags & 16) ? 0 : 8 * is_k), buf, wave, n64, lds0, uoff);
         ++is_k; ++is_c;
       } else {
         c128_issue_rows16(Li + (int64_t)(16 * (is_n - nK - nX)) * 128, 128, buf, wave, lane_k, lds0);
@@ -487,6 +506,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
     }
     C128_T(3);
     if (!succ) {
+      C128_TFLUSH();
       if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[18], t_prev - t_start); atomicAdd(&a.dbg[21 + j], t_prev - t_start); }
       return;
     }
@@ -519,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
         c128_issue_cols16((is_x >= 8 ? fx.F : fx.S) + ((a.flags & 2) ? 0 : (int64_t)(128 * jd) * n64 + 128 * jd + 16 * (is_x & 7)), buf, wave, n64, lds0, xoff);
         ++is_x; is_c = 0;
       } else {
-        c128_issue_unit(arows + 16 * is_k, arows + 16 * is_k + 8, buf, wave, n64, lds0, uoff);
+        c128_issue_unit(arows + ((a.flags & 16) ? 0 : 16 * is_k), arows + ((a.flags & 16) ? 0 : 16 * is_k) + 8, buf, wave, n64, lds0, uoff);
         ++is_k; ++is_c;
       }
       ++is_n;
@@ -621,9 +641,9 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
       const int rr = 16 * wave + i, cc = 16 * n + q + 4 * r;
       sA[rr][cc] = (cc <= rr) ? -acc[n][0][r] : 0.0;
     }
-  __syncthreads();
+  C128_LDS_BARRIER();
   C128_T(6);
-  if (!(a.flags & 8)) bad |= c128_factor64(sA, dv, a.dbg);
+  if (!(a.flags & 8)) bad |= c128_factor64(sA, dv, a.dbg ? tl : nullptr);
   C128_T(7);
   // L21 = D21 Linv11^T: this wave's row block 7 - w of the block = rows 16 (3 - w) of the lower half
   const int lrb = 3 - wave;
@@ -648,7 +668,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
         Dg[(int64_t)(64 + 16 * lrb + lq + 4 * r) * n64 + 16 * cb + li] = out[cb][r];
       }
   }
-  __syncthreads();
+  C128_LDS_BARRIER();
   // D22 -= L21 L21^T (blocks n - 4 <= 3 - w of this wave's row block), and M1 = L21 Linv11 (this wave's 16 rows), both from sA / sB
   v4d m1[4];
   {
@@ -668,9 +688,9 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
       }
     }
   }
-  __syncthreads();
+  C128_LDS_BARRIER();
   save_tile(0, 0);
-  __syncthreads();
+  C128_LDS_BARRIER();
   // M1 -> sB (L21 is no longer needed), D22 -> sA
 #pragma unroll
   for (int cb = 0; cb < 4; ++cb)
@@ -683,9 +703,9 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
       const int rr = 16 * lrb + i, cc = 16 * nn + q + 4 * r;
       sA[rr][cc] = (cc <= rr) ? -acc[4 + nn][1][r] : 0.0;
     }
-  __syncthreads();
+  C128_LDS_BARRIER();
   C128_T(8);
-  if (!(a.flags & 8)) bad |= c128_factor64(sA, dv, a.dbg);
+  if (!(a.flags & 8)) bad |= c128_factor64(sA, dv, a.dbg ? tl : nullptr);
   C128_T(9);
   // I21 = -Linv22 M1: wave w takes rows 16 w .. of the lower half
   {
@@ -707,6 +727,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   }
   save_tile(64, 1);
   C128_T(10);
+  C128_TFLUSH();
   if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[18], t_prev - t_start); atomicAdd(&a.dbg[21 + j], t_prev - t_start); }
   if (bad && !a.flags) atomicMax(a.info, 1);
 }

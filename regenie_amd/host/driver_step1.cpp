@@ -1,5 +1,6 @@
 // regenie-amd, the C++ host driver (see driver.h): `--step 1` and run().
 #include "driver.h"
+#include "fmt_g6.h"
 #include <sys/mman.h>
 
 namespace rgdrv {
@@ -572,31 +573,34 @@ int run(int argc, char** argv) {
   for (int64_t i : order) if (r.ain[i]) { header += r.ids[i] + " "; kept_order.push_back(i); }
   header += "\n";
   const int fmt_threads = std::max(1, std::min(32, p.threads > 0 ? p.threads : usable_cpus() - 1));
+  const bool timing_on = getenv("RG_TIMING") != nullptr;
   // one row of a .loco / .prs file (write_chr_row, Data.cpp:1951-1975): `<chr> v1 v2 ... \n`, NA where the phenotype is missing.
-  // The values are formatted by several threads over chunks of samples; the default stream format of a double (%g, six
-  // significant digits) is what std::to_chars(general, 6) produces.
-  auto format_rows = [&](int nrows, const std::function<double(int, int64_t)>& value, const uint8_t* maskq, std::vector<std::string>& rows) {
-    const int NCK = 16;
+  // The values are formatted by several threads over chunks of samples, in the default stream format of a double (%g, six
+  // significant digits: rgfmt::fmt_g6, a third of the time of std::to_chars(general, 6) and the same text); the pieces go to the
+  // file in order, without being joined first (115 MB per .loco file at 500,000 samples).
+  const int NCK = 16;
+  auto format_rows = [&](int nrows, auto&& value, const uint8_t* maskq, std::vector<std::string>& piece) {
     const int64_t nk = (int64_t)kept_order.size();
-    std::vector<std::string> piece((size_t)nrows * NCK);
+    piece.assign((size_t)nrows * NCK, std::string());
     parallel_for(nrows * NCK, fmt_threads, [&](int t) {
       const int row = t / NCK, ck = t % NCK;
-      std::string& o = piece[t];
       const int64_t k0 = nk * ck / NCK, k1 = nk * (ck + 1) / NCK;
-      o.reserve((size_t)(k1 - k0) * 12);
-      char buf[48];
+      std::string& o = piece[t];
+      o.resize((size_t)(k1 - k0) * 14 + 32);          // a value is at most 13 characters ("-1.23456e-308") and a blank
+      char* w = &o[0];
       for (int64_t k = k0; k < k1; ++k) {
         const int64_t i = kept_order[k];
-        if (maskq[i]) {
-          const auto res = std::to_chars(buf, buf + sizeof(buf), value(row, i), std::chars_format::general, 6);
-          o.append(buf, res.ptr);
-          o.push_back(' ');
-        } else o += "NA ";
+        if (maskq[i]) w = rgfmt::fmt_g6(value(row, i), w);
+        else { w[0] = 'N'; w[1] = 'A'; w += 2; }
+        *w++ = ' ';
       }
+      o.resize((size_t)(w - &o[0]));
     });
-    rows.assign(nrows, std::string());
-    for (int row = 0; row < nrows; ++row)
-      for (int ck = 0; ck < NCK; ++ck) rows[row] += piece[(size_t)row * NCK + ck];
+  };
+  auto write_row = [&](std::ostream& f, const std::string& label, const std::vector<std::string>& piece, int row) {
+    f << label << " ";
+    for (int ck = 0; ck < NCK; ++ck) f.write(piece[(size_t)row * NCK + ck].data(), (std::streamsize)piece[(size_t)row * NCK + ck].size());
+    f << "\n";
   };
 
   // per-phenotype results, filled by whichever rank owns the phenotype
@@ -639,12 +643,19 @@ int run(int argc, char** argv) {
     std::vector<const double*> sub(p.nchrom, nullptr);
     for (int c = 0; c < nchr; ++c) if (chroms[c] >= 1 && chroms[c] <= p.nchrom) sub[chroms[c] - 1] = pq + (size_t)c * N;
     {
+      const auto te0 = std::chrono::steady_clock::now();
       TextOut lf(loco_fn, p.gz);
       if (!lf) throw std::runtime_error("cannot write file : " + loco_fn);
       lf << header;
       std::vector<std::string> rows;
       format_rows(p.nchrom, [&](int row, int64_t i) { return tot[i] - (sub[row] ? sub[row][i] : 0.0); }, r.mask.data() + (size_t)q * N, rows);
-      for (int chr = 1; chr <= p.nchrom; ++chr) lf << std::to_string(chr) << " " << rows[chr - 1] << "\n";
+      const auto te1 = std::chrono::steady_clock::now();
+      for (int chr = 1; chr <= p.nchrom; ++chr) write_row(lf, std::to_string(chr), rows, chr - 1);
+      if (timing_on) {
+        const auto te2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[timing] .loco of phenotype %d: totals + header + formatting %.0f ms, writing %.0f ms (%d formatting threads)\n", q + 1,
+                std::chrono::duration<double, std::milli>(te1 - te0).count(), std::chrono::duration<double, std::milli>(te2 - te1).count(), fmt_threads);
+      }
     }
     ph_plist[q] = r.pheno_names[q] + " " + (p.use_rel_path ? loco_fn : get_fullpath(loco_fn)) + "\n";
     if (p.print_prs) {
@@ -653,7 +664,7 @@ int run(int argc, char** argv) {
       pf << header;
       std::vector<std::string> rows;
       format_rows(1, [&](int, int64_t i) { return tot[i]; }, r.mask.data() + (size_t)q * N, rows);
-      pf << "0 " << rows[0] << "\n";
+      write_row(pf, "0", rows, 0);
       ph_prslist[q] = r.pheno_names[q] + " " + (p.use_rel_path ? prs_fn : get_fullpath(prs_fn)) + "\n";
     }
     if (p.write_null_firth) {   // Data.cpp:1873-1902: the null approximate-Firth estimates of every chromosome (offset = its LOCO prediction),
@@ -688,14 +699,27 @@ int run(int argc, char** argv) {
   // One context, no exchanged view (the usual single-GPU run): the phenotypes are taken ONE AT A TIME (rg_set_l1_view with a sub-range on
   // the context's own W) and each one's tables and files are written on a thread of their own while the next phenotype is on the GPU --
   // at 500,000 samples a .loco file is 115 MB of text, formatting and writing ten of them took as long as level 1 itself.
+  // The predictions of a phenotype ([nchr][N] doubles, 92 MB at BASELINE configs[2]) land in one of three page-locked slots -- the GPU fills one
+  // while the writers of the two phenotypes before it read theirs.  The slots are allocated on a thread of their own while level 0 streams
+  // (l1_slots_start below): page-locking all ten phenotypes' 920 MB at the head of level 1 cost 0.25 s of its 0.96 s (RG_TIMING=1).
+  const int L1_SLOTS = 3;
+  std::future<double*> l1_slots;
+  auto l1_slots_start = [&]() {
+    const int64_t bytes = (int64_t)sizeof(double) * nchr * N * std::min(P, L1_SLOTS);
+    l1_slots = std::async(std::launch::async, [bytes]() { return (double*)rg_host_alloc(bytes); });
+  };
   auto level1_pipelined = [&](rg_ctx* cx) {
     const size_t per = (size_t)nchr * N;
-    // predictions of all phenotypes: page-locked if the runtime grants it (880 MB at BASELINE configs[2]; device -> host at the PCIe rate,
-    // no first-touch faults), uninitialised either way -- every entry is written by the library
-    double* pred = (double*)rg_host_alloc((int64_t)(sizeof(double) * per * P));
-    std::unique_ptr<double[]> pred_own;
+    const int nslot = std::min(P, L1_SLOTS);
+    const auto ta0 = std::chrono::steady_clock::now();
+    if (!l1_slots.valid()) l1_slots_start();
+    double* pred = l1_slots.get();             // page-locked if the runtime grants it (device -> host at the PCIe rate, no first-touch faults),
+    std::unique_ptr<double[]> pred_own;        // uninitialised either way -- every entry is written by the library
     const bool pinned = pred != nullptr;
-    if (!pinned) { pred_own.reset(new double[per * P]); pred = pred_own.get(); }
+    if (!pinned) { pred_own.reset(new double[per * nslot]); pred = pred_own.get(); }
+    if (timing_on)
+      fprintf(stderr, "[timing] level 1: waited %.0f ms for the %d prediction slots (%s)\n",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count(), nslot, pinned ? "page-locked" : "pageable");
     std::vector<double> cumsum((size_t)P * NCS * R1, 0.0);
     std::vector<int32_t> best(P, 0), converged(P, 1);
     std::vector<std::future<void>> writers;
@@ -703,7 +727,10 @@ int run(int argc, char** argv) {
     try {
       for (int q = 0; q < P; ++q) {
         double* cq = cumsum.data() + (size_t)q * NCS * R1;
-        double* pq = pred + (size_t)q * per;
+        double* pq = pred + (size_t)(q % nslot) * per;
+        const auto tw0 = std::chrono::steady_clock::now();
+        if (q >= nslot) writers[q - nslot].wait();      // the slot's previous phenotype is on disk (at most nslot - 1 writers in flight behind the GPU)
+        const auto tq0 = std::chrono::steady_clock::now();
         if (p.t2e) {
           rg_cox_options co{};
           co.niter_max = p.niter_max; co.niter_max_line_search = p.niter_max_line_search; co.niter_max_ridge = p.niter_max_ridge;
@@ -728,8 +755,9 @@ int run(int argc, char** argv) {
             check(cx, rg_l1_qt(cx, R1, tq, nchr, cols_per_chr.data(), cq, &best[q], pq));
         }
         const int bq = best[q], cv = converged[q];
-        // at most two writers in flight: each holds its phenotype's text (two copies of ~115 MB at 500,000 samples) and a formatting pool
-        if (q >= 2) writers[q - 2].wait();
+        if (timing_on)
+          fprintf(stderr, "[timing] level 1 of phenotype %d: waited %.0f ms for its slot, on the GPU %.0f ms\n", q + 1,
+                  std::chrono::duration<double, std::milli>(tq0 - tw0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count());
         writers.push_back(std::async(std::launch::async, [&, q, cq, bq, cv, pq]() { emit_pheno(q, cq, bq, cv, pq); }));
       }
     } catch (...) { err = std::current_exception(); }
@@ -774,6 +802,8 @@ int run(int argc, char** argv) {
 
   auto tl0 = std::chrono::steady_clock::now();
   if (!use_group) {
+    const bool l1_batched = getenv("RG_L1_BATCHED") && atoi(getenv("RG_L1_BATCHED")) != 0;
+    if (!l1_batched) l1_slots_start();
     if (!p.run_l1) {
       std::ostringstream lg;
       level0_range(ctx, 0, B, lg, pre_ring_ptr);
@@ -783,7 +813,7 @@ int run(int argc, char** argv) {
     if (p.ct) sout << " Level 1 ridge with poisson regression...\n";
     if (p.t2e) sout << " Level 1 ridge with cox regression...\n";
     tl0 = std::chrono::steady_clock::now();
-    if (getenv("RG_L1_BATCHED") && atoi(getenv("RG_L1_BATCHED")) != 0) level1_range(ctx, 0, P, true);   // all phenotypes in one call, then the files
+    if (l1_batched) level1_range(ctx, 0, P, true);   // all phenotypes in one call, then the files
     else level1_pipelined(ctx);
   } else {
     // one host thread per GPU: level 0 of the rank's blocks, the exchange, level 1 of the rank's phenotypes (phenotype-
