@@ -194,6 +194,21 @@ int rg_host_register(void* ptr, int64_t bytes, int read_only);
 int rg_host_unregister(void* ptr);
 int rg_ingest_fence(rg_ctx* ctx);
 
+/* ---- the genotype file staged in HBM as a whole (optional; one GPU, the C++ driver's default for a .bed that fits) ----
+ * An MI355X holds 288 GB: the 62.5 GB .bed of BASELINE configs[2] fits beside W and the workspaces, and nothing about its bytes depends
+ * on the phenotypes -- so the driver starts copying the file the moment the runtime is up, while it still parses the text files, and
+ * level 0 reads the rows in place (rg_l0_blocks with RG_MEM_DEVICE, rows at the file's own pitch).  The reference reads a block when
+ * the block loop reaches it (Data.cpp:636-678 -> Geno.cpp:1702-1769).
+ *   rg_stage_alloc : `bytes` of device memory on the context's device, or NULL (also when `bytes` exceeds `max_frac_of_free` of the
+ *                    memory that is free at the time: the caller then streams the file through rg_l0_blocks(RG_MEM_HOST) as before)
+ *   rg_stage_copy  : host -> device copy of `bytes` (pageable or page-locked source) on a stream of its own, from any ONE thread at a
+ *                    time; returns when the bytes have arrived.  Not ordered with the context's streams: hand rows to rg_l0_blocks
+ *                    only after the copy that covers them has returned.
+ *   rg_stage_free  : frees the buffer (after rg_sync). */
+void* rg_stage_alloc(rg_ctx* ctx, int64_t bytes, double max_frac_of_free);
+int rg_stage_copy(rg_ctx* ctx, void* dev_dst, const void* host_src, int64_t bytes);
+void rg_stage_free(rg_ctx* ctx, void* dev_ptr);
+
 /* ---- phenotype-sharded level 1 (optional) ------------------------------------------------------------
  * With P >= world phenotypes the ranks can exchange predictor slabs by phenotype instead of all-gathering W:
  * rank g receives, from every rank, the columns of that rank's blocks for ITS phenotypes only (an all-to-all

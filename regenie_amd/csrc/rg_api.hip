@@ -91,6 +91,7 @@ void rg_destroy(rg_ctx* c) {
     hipEventDestroy(c->ev_fork);
     for (int k = 0; k < 3; ++k) { hipStreamSynchronize(c->st_part[k]); hipStreamDestroy(c->st_part[k]); hipEventDestroy(c->ev_part[k]); }
   }
+  if (c->st_stage) { hipStreamSynchronize(c->st_stage); hipStreamDestroy(c->st_stage); }
   if (c->own_stream) hipStreamDestroy(c->stream);
   delete c;
 }
@@ -690,6 +691,35 @@ int rg_host_register(void* ptr, int64_t bytes, int read_only) {
   return RG_OK;
 }
 int rg_host_unregister(void* ptr) { return (ptr && hipHostUnregister(ptr) == hipSuccess) ? RG_OK : RG_ERR_HIP; }
+
+void* rg_stage_alloc(rg_ctx* ctx, int64_t bytes, double max_frac_of_free) {
+  if (!ctx || bytes <= 0) return nullptr;
+  hipSetDevice(ctx->device);
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (max_frac_of_free > 0 && (double)bytes > max_frac_of_free * (double)fr) return nullptr;
+  void* p = nullptr;
+  if (hipMalloc(&p, (size_t)bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return p;
+}
+int rg_stage_copy(rg_ctx* ctx, void* dev_dst, const void* host_src, int64_t bytes) {
+  if (!ctx || !dev_dst || !host_src || bytes < 0) return RG_ERR_ARG;
+  if (bytes == 0) return RG_OK;
+  hipSetDevice(ctx->device);
+  // a stream that does not synchronise with the null stream or the context's: the copies run beside rg_set_problem's uploads and level 0
+  if (!ctx->st_stage && hipStreamCreateWithFlags(&ctx->st_stage, hipStreamNonBlocking) != hipSuccess) { ctx->err = "rg_stage_copy: no stream"; return RG_ERR_HIP; }
+  if (hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, ctx->st_stage) != hipSuccess ||
+      hipStreamSynchronize(ctx->st_stage) != hipSuccess) {
+    (void)hipGetLastError();
+    return RG_ERR_HIP;
+  }
+  return RG_OK;
+}
+void rg_stage_free(rg_ctx* ctx, void* dev_ptr) {
+  if (!ctx || !dev_ptr) return;
+  hipSetDevice(ctx->device);
+  hipFree(dev_ptr);
+}
 
 int rg_ingest_fence(rg_ctx* ctx) {
   if (!ctx) return RG_ERR_ARG;

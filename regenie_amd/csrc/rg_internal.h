@@ -42,6 +42,7 @@ struct SegLayout {
 struct rg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t st_stage = nullptr;    // rg_stage_copy's own (non-blocking) stream, created on first use
   hipStream_t st_part[3] = {};       // further streams of a level-0 batch's Cholesky (rg_api.hip: ranges of systems side by side)
   hipEvent_t ev_fork = nullptr, ev_part[3] = {};
   bool timing_serial = false;        // RG_CHOL_SPLIT=0 behaviour forced (unused)

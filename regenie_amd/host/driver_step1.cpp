@@ -82,6 +82,108 @@ struct BedMap {
   }
 };
 
+// The whole .bed staged in HBM (rg_stage_*, include/rg_step1.h): from the moment the runtime is up -- under the parsing of the phenotype and
+// covariate files and under rg_set_problem -- the file is copied to the device, and level 0 reads the rows in place.  A few threads pread
+// 32 MB pieces of the file into a small ring of page-locked slots (8 x 32 MB: page-locking them costs 50 ms, not the 1.4 s of the 12.6 GB
+// ring of round 5), one thread sends the pieces in file order (DMA from page-locked memory: the PCIe rate, where the runtime's staging of
+// pageable memory gave 36 - 38 GB/s).  At BASELINE configs[2] (62.5 GB) the copy starts 0.3 s earlier than the first batch of the
+// streamed form did and the level-0 thread queues kernels only.  One GPU, a file of at most a quarter of the free device memory whose kept
+// variants are one range covering at least 80 % of it; RG_INGEST_STAGE=0 streams the file batch by batch as before, =2 copies from the
+// mapping instead of the slots.  A copy that fails leaves the bytes behind `done` unusable: level 0 takes the rest from the mapping.
+struct BedStage {
+  static constexpr int NS = 8;
+  rg_ctx* ctx = nullptr;
+  uint8_t* dev = nullptr;
+  int64_t bytes = 0, piece = 32LL << 20, npieces = 0;
+  std::atomic<int64_t> done{0}, next_piece{0};
+  std::atomic<int> state{0};           // 0 not used, 1 copying, 2 complete, -1 failed / refused
+  std::atomic<bool> stop{false};
+  std::mutex mu;
+  std::condition_variable cv;
+  std::thread th;
+  std::vector<std::thread> fillers;
+  uint8_t* slot[NS] = {};
+  int64_t filled[NS] = {};             // (mu) piece number + 1 held by the slot, 0 = free
+  int64_t sent = 0;                    // (mu) pieces in device memory
+  int fd = -1;
+  int nfill = 0;
+  std::chrono::steady_clock::time_point t_first, t_last;
+  void fail() { { std::lock_guard<std::mutex> lk(mu); state = -1; } cv.notify_all(); }
+  void fill_loop() {
+    for (;;) {
+      const int64_t k = next_piece++;
+      if (k >= npieces) return;
+      const int si = (int)(k % NS);
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return sent + NS > k || state < 0 || stop; });      // piece k - NS has left the slot
+        if (state < 0 || stop) return;
+      }
+      if (!slot[si] && !(slot[si] = (uint8_t*)rg_host_alloc(piece))) return fail();
+      const int64_t off = k * piece, n = std::min(piece, bytes - off);
+      for (int64_t got = 0; got < n;) {
+        const ssize_t rd = pread(fd, slot[si] + got, (size_t)(n - got), (off_t)(off + got));
+        if (rd <= 0) return fail();
+        got += rd;
+      }
+      { std::lock_guard<std::mutex> lk(mu); filled[si] = k + 1; }
+      cv.notify_all();
+    }
+  }
+  void start(std::shared_future<rg_ctx*> fctx, const std::string& path, const uint8_t* mapped, int64_t nbytes, int mode, int threads) {
+    bytes = nbytes;
+    npieces = (bytes + piece - 1) / piece;
+    nfill = threads;
+    state = 1;
+    if (mode != 2) fd = open(path.c_str(), O_RDONLY);
+    const bool from_map = fd < 0;
+    th = std::thread([this, fctx, mapped, from_map]() {
+      ctx = fctx.get();
+      if (!ctx) return fail();
+      dev = (uint8_t*)rg_stage_alloc(ctx, bytes, 0.25);
+      if (!dev) return fail();
+      t_first = std::chrono::steady_clock::now();
+      if (!from_map)
+        for (int t = 0; t < nfill; ++t) fillers.emplace_back([this]() { fill_loop(); });
+      for (int64_t k = 0; k < npieces; ++k) {
+        const int64_t off = k * piece, n = std::min(piece, bytes - off);
+        const int si = (int)(k % NS);
+        const uint8_t* src = mapped + off;
+        if (!from_map) {
+          std::unique_lock<std::mutex> lk(mu);
+          cv.wait(lk, [&] { return filled[si] == k + 1 || state < 0 || stop; });
+          if (filled[si] != k + 1) { lk.unlock(); return fail(); }
+          src = slot[si];
+        }
+        if (stop || rg_stage_copy(ctx, dev + off, src, n) != 0) return fail();
+        { std::lock_guard<std::mutex> lk(mu); filled[si] = 0; sent = k + 1; done = off + n; }
+        cv.notify_all();
+      }
+      t_last = std::chrono::steady_clock::now();
+      { std::lock_guard<std::mutex> lk(mu); state = 2; }
+      cv.notify_all();
+    });
+  }
+  // true once bytes [0, upto) are in device memory; false when the copy failed (or was never started)
+  bool wait(int64_t upto) {
+    if (state == 0) return false;
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return done >= upto || state < 0; });
+    return done >= upto;
+  }
+  ~BedStage() {
+    stop = true;                        // (a run that failed before level 0 was through does not wait for the rest of the file)
+    cv.notify_all();
+    if (th.joinable()) th.join();
+    for (auto& f : fillers) if (f.joinable()) f.join();
+    if (fd >= 0) close(fd);
+    if (full_teardown()) {
+      for (auto& m : slot) if (m) rg_host_free(m);
+      if (dev) rg_stage_free(ctx, dev);
+    }
+  }
+};
+
 int run(int argc, char** argv) {
   Run r;
   r.p = parse_args(argc, argv);
@@ -94,14 +196,14 @@ int run(int argc, char** argv) {
   sout << "\n\nFitting null model\n";
   // The HIP runtime and the device contexts come up on their own threads while this one parses the text files (bringing the
   // runtime up costs 150 - 200 ms, as much as the parsing)
-  std::vector<std::future<rg_ctx*>> early_ctx;
+  std::vector<std::shared_future<rg_ctx*>> early_ctx;
   if (p.step == 1 && !p.split_l0)
     for (int g = 0; g < p.gpus; ++g)
       early_ctx.push_back(std::async(std::launch::async, [&p, g]() -> rg_ctx* {
         rg_ctx* c = nullptr;
         if (rg_create(&c, p.single_device ? p.device : p.device + g, nullptr) != 0) return nullptr;
         return c;
-      }));
+      }).share());
   if (p.run_l0) prep_parallel_l0(r);
   read_bim_fam(r);
   if (p.split_l0) {  // set_parallel_l0 / write_l0_master (Data.cpp:232-309): master + per-job variant lists, then exit
@@ -145,6 +247,7 @@ int run(int argc, char** argv) {
   IngestRing pre_ring;
   IngestRing* pre_ring_ptr = nullptr;
   BedMap bed_map;
+  BedStage bed_stage;                  // declared after bed_map: its thread reads the mapping and is joined first
   if (p.step == 1 && !p.run_l1 && !r.dosage_mode && r.bpr > 0) {   // the host side of the ingest is set up under the parsing below
     // The mapped .bed is the source of the copies (rounds 3 - 5: registered with the runtime, and only for files up to 16 GB -- for the 62.5 GB
     // file of configs[2] the registered mapping and the ring of page-locked buffers traded places from box to box: DESIGN_HISTORY.md).
@@ -157,6 +260,15 @@ int run(int argc, char** argv) {
     const char* em = getenv("RG_INGEST_MAP");
     const bool want_map = em ? atoi(em) != 0 : true;
     if (!r.pgen && want_map) bed_map.start(p.bed + ".bed", p.gpus > 1);           // the mapped file, registered on its own thread (shared by the ranks)
+    {
+      const char* es = getenv("RG_INGEST_STAGE");
+      const int64_t kept_bytes = (int64_t)r.snp_chrom.size() * r.bpr;
+      if (p.gpus == 1 && !p.force_collectives && bed_map.state == 2 && !bed_map.registered && !(es && atoi(es) == 0) && !early_ctx.empty() &&
+          (int64_t)bed_map.bytes > 3 && 5 * kept_bytes >= 4 * ((int64_t)bed_map.bytes - 3) && !r.snp_offset.empty() &&
+          r.snp_offset.back() - r.snp_offset.front() + 1 == (int64_t)r.snp_offset.size())      // the kept variants: one range of the file
+        bed_stage.start(early_ctx[0], p.bed + ".bed", bed_map.base, (int64_t)bed_map.bytes, es ? atoi(es) : 1,
+                        getenv("RG_STAGE_THREADS") ? std::max(1, atoi(getenv("RG_STAGE_THREADS"))) : std::max(2, std::min(6, usable_cpus() / 3)));     // 2 threads fed 24 GB/s, 4 and 8 the 50 GB/s the DMA takes (gpurun_out/r6_ingest)
+    }
     if (bed_map.state == 0 && p.gpus == 1) {                                         // else, one GPU: the ring of page-locked buffers
       pre_ring.start((int64_t)r.snp_chrom.size() * r.bpr, ingest_blk_bytes, -1, 1);
       pre_ring_ptr = &pre_ring;
@@ -352,10 +464,29 @@ int run(int argc, char** argv) {
           ptrs[b] = bed_map.base + 3 + r.snp_offset[blocks[b_lo + b].start] * r.bpr;
         }
         auto t1 = std::chrono::steady_clock::now();
-        check(cx, rg_l0_blocks(cx, nb, ids.data(), bss.data(), ptrs.data(), r.bpr, RG_MEM_HOST));
+        int b_staged = 0;          // blocks taken from the copy of the file in device memory: one library batch at a time, as the copy reaches them
+        if (bed_stage.state != 0) {
+          const int per = std::max(1, (int)rg_l0_batch_blocks(cx));
+          std::vector<const uint8_t*> dptrs(nb);
+          for (int b0 = 0; b0 < nb; b0 += per) {
+            const int n = std::min(per, nb - b0);
+            const int64_t end = (int64_t)(ptrs[b0 + n - 1] - bed_map.base) + (int64_t)bss[b0 + n - 1] * r.bpr;
+            if (!bed_stage.wait(end)) break;
+            for (int b = b0; b < b0 + n; ++b) dptrs[b] = bed_stage.dev + (ptrs[b] - bed_map.base);
+            check(cx, rg_l0_blocks(cx, n, ids.data() + b0, bss.data() + b0, dptrs.data() + b0, r.bpr, RG_MEM_DEVICE));
+            b_staged = b0 + n;
+          }
+        }
+        if (b_staged < nb)
+          check(cx, rg_l0_blocks(cx, nb - b_staged, ids.data() + b_staged, bss.data() + b_staged, ptrs.data() + b_staged, r.bpr, RG_MEM_HOST));
         auto t2 = std::chrono::steady_clock::now();
         lg << " blocks [" << b_lo + 1 << ".." << b_hi << "] (chromosomes " << blocks[b_lo].chrom << ".." << blocks[b_hi - 1].chrom << ") : " << nsnp
-           << " snps  (copied to the GPU from the mapped file, queued after " << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms)\n";
+           << " snps  (" << (b_staged == nb ? "read from the copy of the file in device memory" : b_staged ? "partly read from the copy of the file in device memory" : "copied to the GPU from the mapped file")
+           << ", queued after " << std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count() << "ms)\n";
+        if (b_staged && bed_stage.state == 2 && getenv("RG_TIMING"))
+          fprintf(stderr, "[timing] the .bed in device memory: first piece requested %.0f ms, last piece arrived %.0f ms since start (%.1f GB/s)\n",
+                  std::chrono::duration<double, std::milli>(bed_stage.t_first - t_start).count(), std::chrono::duration<double, std::milli>(bed_stage.t_last - t_start).count(),
+                  bed_stage.bytes / 1e9 / std::max(1e-9, std::chrono::duration<double>(bed_stage.t_last - bed_stage.t_first).count()));
         check(cx, rg_sync(cx));
         lg << "   -level 0 ridge of blocks [" << b_lo + 1 << ".." << b_hi << "] complete (" <<
             std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t2).count() << "ms after the last batch was queued)\n";
