@@ -40,6 +40,21 @@ struct rg_s2_ctx {
   int8_t* dvd = nullptr;        // the digit planes of dV's columns, [col][8][Np]
   double *dvsc = nullptr, *dYtX = nullptr;   // [col] plane scales, [P][C] res_p^T x_c
   double *dQ = nullptr, *dMsum = nullptr;    // [P][C][C] X^T diag(mask_p) X, [P] sum of mask_p
+  // hard-call route, masked problems whose lists of masked samples sum to at most n entries (round 6): the contraction against the mask
+  // columns x_c mask_p / mask_p (C P + P columns over all n samples) is taken as (all samples) - (the samples masked for p), the second
+  // term over a COMPACT sample axis: the masked samples of phenotype 0, padded, then those of phenotype 1, ... -- at 5 % missing values in
+  // each of 10 phenotypes that is n / 2 positions against ONE group of C + 1 columns instead of n positions against 8 groups.
+  bool compact = false;
+  int64_t Ncp = 0;              // compact positions in all (a multiple of 128)
+  int c_spt = 1, c_chunk = 1;   // segments per phenotype, phenotypes per contraction launch (c_spt * c_chunk <= RG_MAX_SEG)
+  std::vector<int64_t> c_off;   // [P + 1] first compact position of a phenotype (its range: a multiple of 128 * c_spt positions)
+  int32_t* d_clist = nullptr;   // [Ncp] analysed-sample index of the position, -1 = padding
+  int32_t* d_cmeta = nullptr;   // [c_K][P][2]: first 32-bit word and words of the (sample chunk, phenotype) range (k_s2_compact_rows)
+  int c_K = 0;                  // sample chunks of S2_CS samples
+  int32_t* d_cw0 = nullptr;     // [P + 1] first 32-bit word of a phenotype's range in the compact row (k_s2_count_traits)
+  double* dVc = nullptr;        // [C padded to 16][Ncp]: x_0 .. x_{C-1} of the listed samples
+  int8_t* dvdc = nullptr;       // their digit planes
+  double* dvscc = nullptr;
   // generic contraction (rg_s2_set_columns / rg_s2_contract_packed): caller-defined columns
   int g_ncol = 0, g_nsq = 0;
   double* gV = nullptr;         // [ncol padded to 16][Np]
@@ -51,8 +66,8 @@ struct rg_s2_ctx {
   int64_t* d_moff = nullptr;    // [P + 1]
   double* d_xl = nullptr;       // [list entries][C]: the listed samples' covariate rows
   double* d_xq = nullptr;       // [P][C][C]: X^T X over the samples listed for each phenotype
-  void* pbuf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t pcap[6] = {0, 0, 0, 0, 0, 0};
+  void* pbuf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t pcap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int32_t hdr[3] = {0, 0, 0};   // staged {total_miss = 0, bs, 0} of the block in flight
   std::string err;
   // ---- binary / count traits behind the ABI (step2_bt.hip): null model per chromosome, the block last scored, correction buffers ----

@@ -469,6 +469,153 @@ __global__ void k_s2_combine(const int32_t* __restrict__ S, const double* __rest
   }
 }
 
+// ---- compact sample axis of a masked problem (hard calls) ----------------------------------------------------------------------------
+// out[row][e] = the 2-bit code of sample clist[e] (code 11 = 0 copies, not missing, for padding).  The compact axis is built chunk-aware
+// (ensure_planes): within a phenotype's range the entries of sample chunk k (S2_CS samples) come first padded to 16, then those of chunk
+// k + 1, ... so that a workgroup = (chunk k, 8 rows) holds the rows' bytes of that chunk in LDS (64 KB), reads every list entry of the chunk
+// ONCE for its 8 rows and writes whole 32-bit words.  The LDS image is byte-transposed -- the 8 rows' bytes of byte position B are the 8
+// bytes at 8 B -- so ONE ds_read_b64 serves an entry for all 8 rows (random byte reads of a row-major image kept the kernel at the LDS's
+// random-access rate: 0.59 ms per 8,192 rows; one workgroup per row with the whole row in LDS and the whole 1 MB list read by every
+// workgroup: 1.34 ms).
+// cmeta [K][P][2]: first 32-bit word of the (chunk, phenotype) range in the compact row, its words.  grid (K, ceil(bs / 8)), S2_CT threads.
+#define S2_CS 32768
+#define S2_CR 8
+#define S2_CT 1024      // threads: a chunk has about one 32-bit word of list entries per thread (256 threads, four words each in turn: latency bound)
+// (Taking k_s2_rows' work -- allele swap, padding codes, call counts -- into this kernel so that the staged rows are read once was built and
+// measured: 1.03 ms against 0.54 + 0.26 ms for the two kernels; the counts' atomics and the write-back sit badly in the chunked grid.)
+__global__ __launch_bounds__(S2_CT) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_s2_compact_rows(const uint8_t* __restrict__ pk, int64_t ldp, const int32_t* __restrict__ clist,
+                                                           const int32_t* __restrict__ cmeta, int P, int bs, uint8_t* __restrict__ out, int64_t ldc) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t srow[];      // [S2_CS / 4 + 1][8]: byte position, row; the last position is 0xFF (padding entries read it)
+  __shared__ int pre[RG_S2_MAX_PHENO + 1];
+  __shared__ int cnt[RG_S2_MAX_PHENO];
+  const int k = blockIdx.x, r0 = blockIdx.y * S2_CR, nr = min(S2_CR, bs - r0), tid = threadIdx.x;
+  constexpr int cb = S2_CS / 4;
+  const int64_t b0 = (int64_t)k * cb;
+  const int nd = (int)(min((int64_t)cb, ldp - b0) / 4);               // dwords of a row in this chunk (ldp is a multiple of 16)
+  for (int o = tid; o < cb / 4; o += S2_CT) {
+    uint32_t d[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) d[r] = (r < nr && o < nd) ? reinterpret_cast<const uint32_t*>(pk + (int64_t)(r0 + r) * ldp + b0)[o] : 0xFFFFFFFFu;
+    // byte transpose: q[b][h] = byte b of rows 4 h .. 4 h + 3
+    uint32_t q[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t t01l = __builtin_amdgcn_perm(d[4 * h + 1], d[4 * h], 0x05010400u), t01h = __builtin_amdgcn_perm(d[4 * h + 1], d[4 * h], 0x07030602u);
+      const uint32_t t23l = __builtin_amdgcn_perm(d[4 * h + 3], d[4 * h + 2], 0x05010400u), t23h = __builtin_amdgcn_perm(d[4 * h + 3], d[4 * h + 2], 0x07030602u);
+      q[0][h] = __builtin_amdgcn_perm(t23l, t01l, 0x05040100u);
+      q[1][h] = __builtin_amdgcn_perm(t23l, t01l, 0x07060302u);
+      q[2][h] = __builtin_amdgcn_perm(t23h, t01h, 0x05040100u);
+      q[3][h] = __builtin_amdgcn_perm(t23h, t01h, 0x07060302u);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(srow + (size_t)o * 32);
+    dst[0] = make_uint4(q[0][0], q[0][1], q[1][0], q[1][1]);
+    dst[1] = make_uint4(q[2][0], q[2][1], q[3][0], q[3][1]);
+  }
+  if (tid == 0) *reinterpret_cast<uint2*>(srow + (size_t)cb * 8) = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+  // word counts of the chunk's P ranges (loaded side by side), then the prefix sums
+  if (tid < P) cnt[tid] = cmeta[((int64_t)k * P + tid) * 2 + 1];
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int p = 0; p < P; ++p) { pre[p] = acc; acc += cnt[p]; }
+    pre[P] = acc;
+  }
+  __syncthreads();
+  const int tot = pre[P], base = k * S2_CS;
+  for (int i = tid; i < tot; i += S2_CT) {
+    int p = 0;
+    while (pre[p + 1] <= i) ++p;
+    const int64_t w = (int64_t)cmeta[((int64_t)k * P + p) * 2] + (i - pre[p]);
+    const int4* ci = reinterpret_cast<const int4*>(clist + w * 16);
+    int ids[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int4 id = ci[q]; ids[4 * q] = id.x; ids[4 * q + 1] = id.y; ids[4 * q + 2] = id.z; ids[4 * q + 3] = id.w; }
+    uint32_t word[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int loc = ids[e] - base;
+      const int ad = ids[e] < 0 ? cb * 8 : (loc >> 2) * 8;
+      const int sh = ids[e] < 0 ? 0 : 2 * (loc & 3);
+      const uint2 v = *reinterpret_cast<const uint2*>(srow + ad);
+      const uint32_t lo = v.x >> sh, hi = v.y >> sh;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        word[r] |= __builtin_amdgcn_ubfe(lo, 8u * r, 2u) << (2 * e);
+        word[4 + r] |= __builtin_amdgcn_ubfe(hi, 8u * r, 2u) << (2 * e);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (r < nr) reinterpret_cast<uint32_t*>(out + (int64_t)(r0 + r) * ldc)[w] = word[r];
+  }
+}
+
+// call counts over a phenotype's range of the compact rows: n1, n2, nmiss [row][p][4] (the column of ones of the compact contraction, both sets,
+// and the squares, without a contraction: sum g = n1 + 2 n2, sum g^2 = n1 + 4 n2, missing = nmiss; padding = code 11 counts nowhere).
+// grid (bs, P), 256 threads; w0 [P + 1] = first 32-bit word of a phenotype's range.
+__global__ __launch_bounds__(256) void k_s2_count_traits(const uint8_t* __restrict__ pkc, int64_t ldc, const int32_t* __restrict__ w0, int32_t* __restrict__ out) {
+  __shared__ int red[3][4];
+  const int p = blockIdx.y, P = gridDim.y;
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(pkc + (int64_t)blockIdx.x * ldc);
+  int c1 = 0, c2 = 0, cm = 0;
+  for (int i = w0[p] + threadIdx.x; i < w0[p + 1]; i += 256) {
+    const uint32_t x = w[i];
+    const uint32_t lo = x & 0x55555555u, hi = (x >> 1) & 0x55555555u;
+    c2 += __popc(~lo & ~hi & 0x55555555u);
+    cm += __popc(lo & ~hi);
+    c1 += __popc(hi & ~lo);
+  }
+  for (int o = 32; o > 0; o >>= 1) { c1 += __shfl_down(c1, o); c2 += __shfl_down(c2, o); cm += __shfl_down(cm, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = c1; red[1][threadIdx.x >> 6] = c2; red[2][threadIdx.x >> 6] = cm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t* o = out + ((int64_t)blockIdx.x * P + p) * 4;
+    o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    o[2] = red[2][0] + red[2][1] + red[2][2] + red[2][3];
+    o[3] = 0;
+  }
+}
+
+// Lc[j][set][p][c] = vsc[c] * sum_k 128^k (sum over phenotype p's segments of S[c >> 4][set][f][j][(c & 15) * 8 + k]), c < C; c = C (the column
+// of ones) and Lq[j][p] (the squares) come from the call counts of k_s2_count_traits.  thread = (j, tt, c <= C);
+// phenotypes t0 .. t0 + nt - 1 of this launch, spt segments each.
+__global__ void k_s2_combine_traits(const int32_t* __restrict__ S, const int32_t* __restrict__ tcnt, const double* __restrict__ vsc,
+                                    const int32_t* __restrict__ total_miss, int bs, int n128, int nseg, int spt, int t0, int nt, int P, int C,
+                                    double* __restrict__ Lc, double* __restrict__ Lq) {
+  const int Cc = C + 1;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)bs * nt * Cc) return;
+  const int c = (int)(t % Cc);
+  const int tt = (int)((t / Cc) % nt);
+  const int j = (int)(t / ((int64_t)Cc * nt));
+  const int p = t0 + tt;
+  if (c == C) {
+    const int32_t* q = tcnt + ((int64_t)j * P + p) * 4;
+    Lc[(((int64_t)j * 2 + 0) * P + p) * Cc + C] = (double)(q[0] + 2 * q[1]);
+    Lc[(((int64_t)j * 2 + 1) * P + p) * Cc + C] = (double)q[2];
+    Lq[(int64_t)j * P + p] = (double)(q[0] + 4 * q[1]);
+    return;
+  }
+  const int grp = c >> 4, cl = c & 15;
+  const int nset = (*total_miss > 0) ? 2 : 1;
+  for (int set = 0; set < 2; ++set) {
+    double v = 0.0;
+    if (set < nset) {
+      long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int f = tt * spt; f < (tt + 1) * spt; ++f) {
+        const int32_t* s = S + (((((int64_t)grp * 2 + set) * nseg + f) * n128 + j) * 128) + cl * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) tk[k] += s[k];
+      }
+#pragma unroll
+      for (int k = 7; k >= 0; --k) v = fma(v, 128.0, (double)tk[k]);
+      v *= vsc[c];
+    }
+    Lc[(((int64_t)j * 2 + set) * P + p) * Cc + c] = v;
+  }
+}
+
 // vstat [bs][4] (doubles, exact integers): sum of the observed entries, sum of their squares (both in the row's integer units), observed
 // count, observed non-zero count.  Hard calls: k_s2_rows fills it from the call counts; integer dosages: k_s2_int_rows.
 struct PackedFinal {
@@ -476,8 +623,10 @@ struct PackedFinal {
   const double* Sq;     // [bs][2][CvB] (hard calls, masked problems) or null
   const double* vstat;  // [bs][4]
   const double* corr;   // [bs][P][C + 2] (integer dosages, masked problems: k_s2_masked_int) or null
+  const double *Lc, *Lq; // masked == 3: [bs][2][P][C + 1] sums over the samples masked for the trait against x_0 .. x_{C-1}, 1; [bs][P] of the squares
   const double *ytx, *Q, *msum, *scf_sv;
-  int bs, C, P, Cvt, cm0, CvB, sqoff, masked;   // masked: 0 none, 1 = mask columns (hard calls), 2 = masked-sample lists (integer dosages)
+  int bs, C, P, Cvt, cm0, CvB, sqoff, masked;   // masked: 0 none, 1 = mask columns (hard calls), 2 = masked-sample lists (integer dosages),
+                                                // 3 = complement over the compact axis (hard calls)
   int64_t n;
   double inv_scale;        // genotype units per integer unit (1 for hard calls, 1 / 255 for 8-bit .bgen probabilities, ...)
   double numtol, nz_max;   // a variant is "sparse" when its non-zero entries number <= nz_max ...
@@ -530,6 +679,29 @@ __global__ void k_s2_packed_final(PackedFinal a) {
     den = g2m - 2.0 * cross + last;
     tot = a0[a.cm0 + p];
     nobs_p = a.msum[p] - a1[a.cm0 + p];
+  } else if (a.masked == 3) {
+    // the mask-column sums of mode 1 as (every sample) - (the samples masked for the trait): sum mask_p g x_c = a[c] - l[c],
+    // sum mask_p g = (sum g) - l[C], sum mask_p [missing] = (missing calls) - l1[C], sum mask_p g^2 = (sum g^2) - Lq
+    const int Cc = C + 1;
+    const double* l0 = a.Lc + (((int64_t)j * 2) * P + p) * Cc;
+    const double* l1 = a.Lc + (((int64_t)j * 2 + 1) * P + p) * Cc;
+    const double m0 = tot_all - l0[C], m1 = nm - l1[C];
+    const double g2m = (sq_all - a.Lq[(int64_t)j * P + p]) + mu * mu * m1;
+    double cross = 0.0;
+    for (int c = 0; c < C; ++c) cross = fma(fma(mu, a1[c] - l1[c], a0[c] - l0[c]), fma(mu, a1[c], a0[c]), cross);
+    double last = b2;
+    if (!sparse) {
+      last = 0.0;
+      const double* q = a.Q + (int64_t)p * C * C;
+      for (int c = 0; c < C; ++c) {
+        double row = 0.0;
+        for (int d = 0; d < C; ++d) row = fma(q[c * C + d], fma(mu, a1[d], a0[d]), row);
+        last = fma(row, fma(mu, a1[c], a0[c]), last);
+      }
+    }
+    den = g2m - 2.0 * cross + last;
+    tot = m0;
+    nobs_p = a.msum[p] - m1;
   } else if (a.masked == 2) {
     // sums over the samples masked for the trait: corr_c = sum g~ x_c, corr2 = sum g~^2, rs2 = sum (g~ - x . beta)^2
     const double* cr = a.corr + ((int64_t)j * P + p) * (C + 2);
@@ -835,8 +1007,18 @@ int ensure_planes(rg_s2_ctx* ctx, bool want_mask_cols) {
   const int C = ctx->C, P = ctx->P;
   const bool mask_cols = want_mask_cols && !ctx->complete;
   if (!ctx->static_ready || ctx->planes_mask_cols != mask_cols) {   // X or the masks changed: column layout, the planes of every column but res, Q_p
-    const int cv1 = !mask_cols ? C + P : C + P + C * P;
-    const int cm0 = !mask_cols ? cv1 : (cv1 + 15) / 16 * 16, cvt = !mask_cols ? cv1 : cm0 + P;
+    // the masked samples as a compact axis (step2_internal.h) when their lists hold at most n entries in all; RG_S2_MASK_COLS=1 keeps the
+    // mask columns of rounds 4 - 5
+    bool compact = false;
+    if (mask_cols && !(getenv("RG_S2_MASK_COLS") && atoi(getenv("RG_S2_MASK_COLS")) != 0)) {
+      int64_t listed = 0;
+      for (size_t e = 0; e < (size_t)P * n; ++e) listed += ctx->hM[e] ? 0 : 1;
+      compact = listed <= n;
+    }
+    ctx->compact = compact;
+    const bool wide = mask_cols && !compact;      // the x_c mask_p / mask_p columns are part of the planes
+    const int cv1 = !wide ? C + P : C + P + C * P;
+    const int cm0 = !wide ? cv1 : (cv1 + 15) / 16 * 16, cvt = !wide ? cv1 : cm0 + P;
     if (cvt > 4096) return fail(ctx, RG_S2_ERR_ARG, "covariates x phenotypes with differing missing values > 4096 columns");
     const int ngrp = (cvt + 15) / 16;
     ctx->Np = (n + 128 * RG_MAX_SEG - 1) / (128 * RG_MAX_SEG) * (128 * RG_MAX_SEG);   // 32 pieces of a multiple of 128 samples
@@ -852,7 +1034,7 @@ int ensure_planes(rg_s2_ctx* ctx, bool want_mask_cols) {
     S2_HIP(hipMemsetAsync(ctx->dV, 0, sizeof(double) * ngrp * 16 * ctx->Np, ctx->st));
     S2_HIP(hipMemcpy2DAsync(ctx->dV, ctx->Np * sizeof(double), ctx->dX, n * sizeof(double), n * sizeof(double), C, hipMemcpyDeviceToDevice, ctx->st));
     if (mask_cols) {
-      hipLaunchKernelGGL(k_s2_mask_cols, dim3((unsigned)((n + 255) / 256), P), dim3(256), 0, ctx->st, ctx->dX, ctx->dM, n, ctx->Np, C, P, cm0, ctx->dV);
+      if (wide) hipLaunchKernelGGL(k_s2_mask_cols, dim3((unsigned)((n + 255) / 256), P), dim3(256), 0, ctx->st, ctx->dX, ctx->dM, n, ctx->Np, C, P, cm0, ctx->dV);
       // Q_p = X^T diag(mask_p) X = I - sum over the samples masked for p of x x^T (X is orthonormal on the analysed samples)
       std::vector<double> Q((size_t)P * C * C, 0.0), msum(P, 0.0), xi(C);
       for (int p = 0; p < P; ++p) {
@@ -871,6 +1053,54 @@ int ensure_planes(rg_s2_ctx* ctx, bool want_mask_cols) {
       S2_HIP(hipMemcpyAsync(ctx->dQ, Q.data(), sizeof(double) * Q.size(), hipMemcpyHostToDevice, ctx->st));
       S2_HIP(hipMemcpyAsync(ctx->dMsum, msum.data(), sizeof(double) * P, hipMemcpyHostToDevice, ctx->st));
       S2_HIP(hipStreamSynchronize(ctx->st));      // Q / msum are locals
+      if (compact) {
+        // compact axis: phenotype p's masked samples at positions c_off[p] ..., padded with -1 to a multiple of 128 * c_spt (c_spt equal
+        // segments per phenotype, as many as RG_MAX_SEG allows for the phenotypes of one launch)
+        ctx->c_chunk = std::min(P, RG_MAX_SEG);
+        ctx->c_spt = RG_MAX_SEG / ctx->c_chunk;
+        const int64_t unit = 128 * (int64_t)ctx->c_spt;
+        const int K = (int)((ctx->Np + S2_CS - 1) / S2_CS);
+        std::vector<int32_t> cl, cmeta((size_t)K * P * 2, 0);
+        ctx->c_off.assign(P + 1, 0);
+        for (int p = 0; p < P; ++p) {
+          const uint8_t* m = ctx->hM.data() + (size_t)p * n;
+          for (int k = 0; k < K; ++k) {      // chunk-aware: the entries of sample chunk k, padded to whole 32-bit words of the compact row
+            const size_t lo = cl.size();
+            for (int64_t i = (int64_t)k * S2_CS; i < std::min<int64_t>(n, (int64_t)(k + 1) * S2_CS); ++i) if (!m[i]) cl.push_back((int32_t)i);
+            cl.resize((cl.size() + 15) / 16 * 16, -1);
+            if (k == K - 1) {                // the phenotype's range: a multiple of 128 * c_spt positions, at least one unit
+              const int64_t len = (int64_t)cl.size() - ctx->c_off[p];
+              cl.resize((size_t)(ctx->c_off[p] + (std::max<int64_t>(len, 1) + unit - 1) / unit * unit), -1);
+            }
+            cmeta[((size_t)k * P + p) * 2] = (int32_t)(lo / 16);
+            cmeta[((size_t)k * P + p) * 2 + 1] = (int32_t)((cl.size() - lo) / 16);
+          }
+          ctx->c_off[p + 1] = (int64_t)cl.size();
+        }
+        ctx->c_K = K;
+        const int64_t Ncp = ctx->Ncp = (int64_t)cl.size();
+        const int ngc = (C + 15) / 16;      // (the column of ones and the squares come from call counts: k_s2_count_traits)
+        std::vector<double> vc((size_t)ngc * 16 * Ncp, 0.0);
+        for (int64_t e = 0; e < Ncp; ++e) {
+          if (cl[e] < 0) continue;
+          for (int c = 0; c < C; ++c) vc[(size_t)c * Ncp + e] = ctx->hX[(size_t)c * n + cl[e]];
+        }
+        std::vector<int32_t> cw0(P + 1);
+        for (int p = 0; p <= P; ++p) cw0[p] = (int32_t)(ctx->c_off[p] / 16);
+        for (void** q : {(void**)&ctx->d_clist, (void**)&ctx->d_cmeta, (void**)&ctx->d_cw0, (void**)&ctx->dVc, (void**)&ctx->dvdc, (void**)&ctx->dvscc})
+          if (*q) { S2_HIP(hipFree(*q)); *q = nullptr; }
+        S2_HIP(hipMalloc((void**)&ctx->d_clist, sizeof(int32_t) * Ncp));
+        S2_HIP(hipMalloc((void**)&ctx->dVc, sizeof(double) * vc.size()));
+        S2_HIP(hipMalloc((void**)&ctx->dvdc, (size_t)ngc * 16 * 8 * Ncp));
+        S2_HIP(hipMalloc((void**)&ctx->dvscc, sizeof(double) * ngc * 16));
+        S2_HIP(hipMemcpy(ctx->d_clist, cl.data(), sizeof(int32_t) * Ncp, hipMemcpyHostToDevice));
+        S2_HIP(hipMalloc((void**)&ctx->d_cw0, sizeof(int32_t) * (P + 1)));
+        S2_HIP(hipMemcpy(ctx->d_cw0, cw0.data(), sizeof(int32_t) * (P + 1), hipMemcpyHostToDevice));
+        S2_HIP(hipMalloc((void**)&ctx->d_cmeta, sizeof(int32_t) * cmeta.size()));
+        S2_HIP(hipMemcpy(ctx->d_cmeta, cmeta.data(), sizeof(int32_t) * cmeta.size(), hipMemcpyHostToDevice));
+        S2_HIP(hipMemcpy(ctx->dVc, vc.data(), sizeof(double) * vc.size(), hipMemcpyHostToDevice));
+        rg_launch_v_split(ctx->st, ctx->dVc, Ncp, ngc * 16, ctx->dvdc, ctx->dvscc);
+      }
     }
     rg_launch_v_split(ctx->st, ctx->dV, ctx->Np, C, ctx->dvd, ctx->dvsc);
     if (cvt > C + P)
@@ -980,6 +1210,12 @@ void rg_s2_destroy(rg_s2_ctx* ctx) {
     if (ctx->gV) (void)hipFree(ctx->gV);
     if (ctx->gvd) (void)hipFree(ctx->gvd);
     if (ctx->gvsc) (void)hipFree(ctx->gvsc);
+    if (ctx->d_clist) (void)hipFree(ctx->d_clist);
+    if (ctx->d_cmeta) (void)hipFree(ctx->d_cmeta);
+    if (ctx->d_cw0) (void)hipFree(ctx->d_cw0);
+    if (ctx->dVc) (void)hipFree(ctx->dVc);
+    if (ctx->dvdc) (void)hipFree(ctx->dvdc);
+    if (ctx->dvscc) (void)hipFree(ctx->dvscc);
     if (ctx->d_mlist) (void)hipFree(ctx->d_mlist);
     if (ctx->d_moff) (void)hipFree(ctx->d_moff);
     if (ctx->d_xl) (void)hipFree(ctx->d_xl);
@@ -1119,19 +1355,26 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   S2_HIP(hipSetDevice(ctx->dev));
   int rc;
   if ((rc = ensure_planes(ctx, true))) return rc;
-  const int Cvt = ctx->Cvt, cm0 = ctx->cm0, ngrp = (Cvt + 15) / 16, masked = ctx->complete ? 0 : 1;
+  const int Cvt = ctx->Cvt, cm0 = ctx->cm0, ngrp = (Cvt + 15) / 16, masked = ctx->complete ? 0 : (ctx->compact ? 3 : 1);
   const int64_t Np = ctx->Np, ldp = Np / 4;
   const int n128 = (int)((bs + 127) / 128 * 128);
-  const int gm0 = cm0 / 16, ngrpB = masked ? ngrp - gm0 : 0, CvB = ngrpB * 16;      // column groups of the g0^2 contraction (the mask columns)
+  const int gm0 = cm0 / 16, ngrpB = masked == 1 ? ngrp - gm0 : 0, CvB = ngrpB * 16;      // column groups of the g0^2 contraction (the mask columns)
+  // masked == 3: the compact axis (step2_internal.h): one contraction launch per c_chunk phenotypes, c_spt segments each
+  const int64_t Ncp = masked == 3 ? ctx->Ncp : 0, ldc = Ncp / 4;
+  const int Cc = C + 1, ngc = (C + 15) / 16, nsegc = masked == 3 ? ctx->c_chunk * ctx->c_spt : 0;
   // enough workgroups to fill the 256 CUs (tiles x segments x column groups >= 768), as few segments as that allows: every segment
   // costs a 64 KB tile of partial sums per workgroup
   SegLayout seg, segB;
   const int nseg = pick_segments(Np, n128 / 128, ngrp, seg), nsegB = pick_segments(Np, n128 / 128, std::max(1, ngrpB), segB);
-  enum { Q_PK, Q_CNT, Q_S, Q_A, Q_VAR, Q_STAT };
-  const size_t s_grp = (size_t)2 * nseg * n128 * 128, s_grpB = (size_t)2 * nsegB * n128 * 128;
+  enum { Q_PK, Q_CNT, Q_S, Q_A, Q_VAR, Q_STAT, Q_PKC, Q_L };
+  const size_t s_grp = (size_t)2 * nseg * n128 * 128, s_grpB = (size_t)2 * nsegB * n128 * 128, s_grpC = (size_t)2 * nsegc * n128 * 128;
   if ((rc = ensure_p(ctx, Q_PK, (size_t)bs * ldp))) return rc;
   if ((rc = ensure_p(ctx, Q_CNT, ((size_t)bs * 4 + 8) * sizeof(int32_t)))) return rc;            // counts | total_miss | bs | 0
-  if ((rc = ensure_p(ctx, Q_S, ((size_t)ngrp * s_grp + (size_t)ngrpB * s_grpB) * sizeof(int32_t)))) return rc;
+  if ((rc = ensure_p(ctx, Q_S, ((size_t)ngrp * s_grp + (size_t)ngrpB * s_grpB + (size_t)(masked == 3 ? ngc : 0) * s_grpC) * sizeof(int32_t)))) return rc;
+  if (masked == 3) {
+    if ((rc = ensure_p(ctx, Q_PKC, (size_t)bs * ldc))) return rc;
+    if ((rc = ensure_p(ctx, Q_L, (size_t)bs * P * ((2 * Cc + 1) * sizeof(double) + 4 * sizeof(int32_t))))) return rc;       // Lc [bs][2][P][Cc] | Lq [bs][P] | call counts [bs][P][4]
+  }
   if ((rc = ensure_p(ctx, Q_A, (size_t)bs * 2 * (Cvt + CvB) * sizeof(double)))) return rc;
   if ((rc = ensure_p(ctx, Q_VAR, (size_t)bs * (6 * sizeof(double) + 2 * sizeof(int32_t))))) return rc;   // scale_fac | mean | vstat[4] | nobs | ignored
   if ((rc = ensure_p(ctx, Q_STAT, (size_t)bs * P * (3 * sizeof(double) + sizeof(int32_t))))) return rc;  // stats | bhat | total_p | nobs_p
@@ -1165,13 +1408,48 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   if (h_miss > 0) rg_launch_xy_i8_both(ctx->st, pk, ldp, d_bs, Cvt, n128, seg, ctx->dvd, Np, RG_XY_LUT_DOSAGE, S);
   else rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, total_miss, Cvt, n128, seg, ctx->dvd, Np, RG_XY_LUT_DOSAGE, S);
   hipLaunchKernelGGL(k_s2_combine, dim3((bs * Cvt + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)S, ctx->dvsc, total_miss, bs, n128, nseg, Cvt, A);
-  if (masked) {   // sum mask_p g0^2: the square LUT against the mask columns only (the missing-indicator set is skipped: d_zero)
+  if (masked == 1) {   // sum mask_p g0^2: the square LUT against the mask columns only (the missing-indicator set is skipped: d_zero)
     rg_launch_xy_i8_sums(ctx->st, pk, ldp, d_bs, d_zero, Cvt - gm0 * 16, n128, segB, ctx->dvd + (size_t)gm0 * 16 * 8 * Np, Np, RG_XY_LUT_SQUARE, S + (size_t)ngrp * s_grp);
     hipLaunchKernelGGL(k_s2_combine, dim3((bs * CvB + 255) / 256), dim3(256), 0, ctx->st, (const int32_t*)(S + (size_t)ngrp * s_grp), ctx->dvsc + gm0 * 16,
                        (const int32_t*)nullptr, bs, n128, nsegB, CvB, Sq);
   }
+  double *Lc = nullptr, *Lq = nullptr;
+  if (masked == 3) {
+    // the rows over the compact axis, then per launch of c_chunk phenotypes: allele counts (and missing indicators) against x_0 .. x_{C-1}, 1
+    // and squared allele counts against the column of ones, summed over each phenotype's own segments
+    uint8_t* pkc = (uint8_t*)ctx->pbuf[Q_PKC];
+    Lc = (double*)ctx->pbuf[Q_L];
+    Lq = Lc + (size_t)bs * 2 * P * Cc;
+    int32_t* Sc = S + (size_t)ngrp * s_grp;
+    int32_t* tcnt = (int32_t*)(Lq + (size_t)bs * P);
+    const size_t lds_c = (size_t)(S2_CS / 4 + 1) * 8;      // (per device, and cheap: set for every block)
+    S2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_s2_compact_rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_c));
+    hipLaunchKernelGGL(k_s2_compact_rows, dim3(ctx->c_K, (bs + S2_CR - 1) / S2_CR), dim3(S2_CT), lds_c, ctx->st, (const uint8_t*)pk, ldp, (const int32_t*)ctx->d_clist,
+                       (const int32_t*)ctx->d_cmeta, P, bs, pkc, ldc);
+    hipLaunchKernelGGL(k_s2_count_traits, dim3(bs, P), dim3(256), 0, ctx->st, (const uint8_t*)pkc, ldc, (const int32_t*)ctx->d_cw0, tcnt);
+    for (int t0 = 0; t0 < P; t0 += ctx->c_chunk) {
+      const int nt = std::min(ctx->c_chunk, P - t0), spt = ctx->c_spt;
+      SegLayout sc;
+      memset(&sc, 0, sizeof(sc));
+      sc.nseg = nt * spt;
+      for (int tt = 0; tt < nt; ++tt) {
+        const int64_t o = ctx->c_off[t0 + tt], len = (ctx->c_off[t0 + tt + 1] - o) / spt;
+        for (int sg = 0; sg < spt; ++sg) {
+          const int f = tt * spt + sg;
+          sc.pos_start[f] = o + sg * len; sc.file_start[f] = sc.pos_start[f]; sc.len[f] = len; sc.plen[f] = len;
+        }
+      }
+      // (the S layout of a launch is [group][set][sc.nseg][n128][128]: a last launch with fewer phenotypes uses the front of the buffer)
+      if (h_miss > 0) rg_launch_xy_i8_both(ctx->st, pkc, ldc, d_bs, C, n128, sc, ctx->dvdc, Ncp, RG_XY_LUT_DOSAGE, Sc);
+      else rg_launch_xy_i8_sums(ctx->st, pkc, ldc, d_bs, total_miss, C, n128, sc, ctx->dvdc, Ncp, RG_XY_LUT_DOSAGE, Sc);
+      const int64_t nthr = (int64_t)bs * nt * Cc;
+      hipLaunchKernelGGL(k_s2_combine_traits, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, ctx->st, (const int32_t*)Sc, (const int32_t*)tcnt,
+                         (const double*)ctx->dvscc, (const int32_t*)total_miss, bs, n128, sc.nseg, spt, t0, nt, P, C, Lc, Lq);
+    }
+  }
   PackedFinal fa;
-  fa.A = A; fa.Sq = masked ? Sq : nullptr; fa.vstat = vstat; fa.corr = nullptr; fa.inv_scale = 1.0;
+  fa.A = A; fa.Sq = masked == 1 ? Sq : nullptr; fa.vstat = vstat; fa.corr = nullptr; fa.inv_scale = 1.0;
+  fa.Lc = Lc; fa.Lq = Lq;
   fa.ytx = ctx->dYtX; fa.Q = ctx->dQ; fa.msum = ctx->dMsum; fa.scf_sv = ctx->dscf;
   fa.bs = bs; fa.C = C; fa.P = P; fa.Cvt = Cvt; fa.cm0 = cm0; fa.CvB = CvB; fa.sqoff = cm0 - gm0 * 16; fa.masked = masked;
   fa.n = n; fa.numtol = numtol; fa.nz_max = (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * (1.0 - ctx->rule_thr);
@@ -1282,6 +1560,7 @@ int rg_s2_qt_block_int(rg_s2_ctx* ctx, const uint16_t* G, int64_t ld, int32_t bs
   }
   PackedFinal fa;
   fa.A = A; fa.Sq = nullptr; fa.vstat = vstat; fa.corr = corr; fa.inv_scale = inv_scale;
+  fa.Lc = nullptr; fa.Lq = nullptr;
   fa.ytx = ctx->dYtX; fa.Q = ctx->dQ; fa.msum = ctx->dMsum; fa.scf_sv = ctx->dscf;
   fa.bs = bs; fa.C = C; fa.P = P; fa.Cvt = Cv; fa.cm0 = Cv; fa.CvB = 0; fa.sqoff = 0; fa.masked = masked;
   fa.n = n; fa.numtol = numtol; fa.nz_max = (double)(ctx->rule_n > 0 ? ctx->rule_n : n) * (1.0 - ctx->rule_thr);
