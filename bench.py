@@ -605,6 +605,11 @@ def main():
                     if rb.returncode != 0:
                         raise RuntimeError((rb.stdout + rb.stderr)[-600:])
                     extra["step2"]["bgen_from_file"] = json.load(open(os.path.join(td, "rec.json")))
+                    br = extra["step2"]["bgen_from_file"].pop("bed_reference", None)
+                    if br:      # regenie itself on a bounded .bed sample at the record's sample count: the record's CPU baseline; the numpy port's stays beside it
+                        extra["step2"]["cpu_baseline_port"] = extra["step2"].get("cpu_baseline")
+                        extra["step2"]["cpu_baseline"] = {"value": br["value"], "unit": br["unit"], "cores": br["threads"], "kind": "reference", "sample": br["sample"],
+                                                          "variants_per_s": br["variants_per_s"], "result_lines_identical": "%d/%d" % (br["byte_identical"], br["result_lines"])}
             except Exception as e:   # noqa: BLE001
                 extra.setdefault("step2", {})["bgen_from_file"] = {"error": repr(e)[:600]}
     if rank == 0:

@@ -320,7 +320,13 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
       // the walk's exact integer sums in the units the host route accumulates as doubles: dosages in 1 / 255, info terms in 1 / 65025
       d.total[j] = (double)sq[j] / 255.0; d.info_num[j] = (double)si[j] / 65025.0; d.ns1[j] = no[j];
       if (maxq[j] > 510) bad = true;
-      if (std::min(d.total[j], 2.0 * d.ns1[j] - d.total[j]) < p.min_mac) d.ignored[j] = 1;      // compute_mac (Geno.cpp:3077-3108), autosomes
+      const double mac = std::min(d.total[j], 2.0 * d.ns1[j] - d.total[j]);
+      // The sum here is the exact integer sum / 255; the host route and regenie add the samples' doubles in order.  A count that lands on
+      // --minMAC to within that summation's rounding could fall on the other side of the `<` there: such a group goes to the host route as a
+      // whole (its verdict is the reference's), so that the filter does not depend on which route a variant took.  (si == 0: every call is a
+      // hard call, the doubles are integers and their sum is exact whatever the order -- the common case of a count that EQUALS --minMAC.)
+      if (si[j] != 0 && std::fabs(mac - p.min_mac) <= 1e-9 * std::max(1.0, mac)) return false;
+      if (mac < p.min_mac) d.ignored[j] = 1;      // compute_mac (Geno.cpp:3077-3108), autosomes
       if (per_trait)
         for (int q = 0; q < P; ++q) {      // the host route SUBTRACTS what the samples missing for trait q contribute
           d.af_t[(size_t)j * P + q] = -(double)sqt[(size_t)j * P + q] / 255.0;
@@ -490,6 +496,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     });
     for (int q = 0; q < P; ++q)
       if (!blup_err[q].empty()) throw std::runtime_error(blup_err[q]);
+    const auto tb1 = std::chrono::steady_clock::now();
     for (int q = 0; q < P; ++q) {
       const std::vector<double>& blup = blup_q[q];
       if (glm) {   // fit_null_logistic / fit_null_poisson, test-mode branch (Step1_Models.cpp:54-140, :225-288): offset = the LOCO prediction of
@@ -556,6 +563,7 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
       for (int64_t k = 0; k < n; ++k) resc[(size_t)q * n + k] /= sd;
       scf[q] = r.scale_Y[q] * sd;
     }
+    const auto tb2 = std::chrono::steady_clock::now();
     if (glm) {   // compute_res_bin / compute_res_count (Data.cpp:2439-2455): the null models of the chromosome go to the device
       rg_s2_bt_null nm;
       memset(&nm, 0, sizeof(nm));
@@ -565,6 +573,10 @@ int run_step2(Run& r, std::chrono::steady_clock::time_point t_start, S2Part& par
     } else s2check(rg_s2_set_null(s2, Xc.data(), resc.data(), Mc.data(), scf.data()));
     sout << "done (" << std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - tb).count() << "ms) \n";
     ms_chr += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
+    if (getenv("RG_TIMING"))
+      fprintf(stderr, "[timing] chromosome %d set-up: predictions read + converted %.0f ms, null models / residuals %.0f ms, to the device %.0f ms\n", chrom,
+              std::chrono::duration<double, std::milli>(tb1 - tb).count(), std::chrono::duration<double, std::milli>(tb2 - tb1).count(),
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb2).count());
 
     for (int bb = 0; bb < nb_chr; ++bb, ++block) {
       if (block < part.blk_lo || block >= part.blk_hi) continue;

@@ -145,6 +145,32 @@ def run(N=500000, M=100000, MREF=2000, P=10, C=10, bsizes=(400, 1000), ref_threa
         rec["runs"].append(run)
         say("regenie-amd --step 2 --bgen, %-28s: wall %.1f s = %.0f variants/s = %.2e variant*sample*pheno/s from the file | %s"
             % (name, dt, M / dt, M * N * P / dt, " | ".join(marks)))
+    # hard calls: both programs on the small .bed itself (2,200 variants x N samples, the LOCO predictions above) -- regenie's rate there is the
+    # `cpu_baseline` of bench.py's Step-2 record (kind "reference")
+    if os.path.exists(ref):
+        bed_args = ["--step", "2", "--qt", "--bed", D + "/s", "--phenoFile", D + "/x.pheno", "--covarFile", D + "/x.covar", "--pred", D + "/s1_pred.list", "--bsize", "400"]
+        t0 = time.time()
+        r = subprocess.run([exe] + bed_args + ["--out", D + "/b_amd"], capture_output=True, text=True)
+        t_amd_bed = time.time() - t0
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        thr = ref_threads[0]
+        t0 = time.time()
+        r = subprocess.run([ref] + bed_args + ["--threads", str(thr), "--out", D + "/b_ref"], capture_output=True, text=True)
+        dt = time.time() - t0
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        same = tot = 0
+        for q in range(P):
+            a = open(D + "/b_amd_Y%d.regenie" % (q + 1)).read().splitlines()
+            b = open(D + "/b_ref_Y%d.regenie" % (q + 1)).read().splitlines()
+            assert len(a) == len(b)
+            tot += len(b) - 1
+            same += sum(x == z for x, z in zip(a[1:], b[1:]))
+        rec["bed_reference"] = {"kind": "reference", "program": "regenie v4.1.2 (oracle/_ref)", "threads": thr, "variants": ms1, "wall_s": round(dt, 2),
+                                "variants_per_s": round(ms1 / dt, 1), "value": ms1 * N * P / dt, "unit": "variant*sample*pheno/s", "regenie_amd_wall_s": round(t_amd_bed, 2),
+                                "result_lines": tot, "byte_identical": same,
+                                "sample": "regenie --step 2 --qt --bed on %d variants x %d samples x %d phenotypes (hard calls, 25 %% of them missing), process start to exit" % (ms1, N, P)}
+        say("hard calls, %d variants x %d phenotypes from a .bed: regenie v4.1.2 (oracle/_ref, --threads %d) %.1f s = %.0f variants/s; regenie-amd %.1f s; %d of %d result lines byte-identical"
+            % (ms1, P, thr, dt, ms1 / dt, t_amd_bed, same, tot))
     # the bounded sample: both programs, line by line
     t0 = time.time()
     r = subprocess.run([exe] + common + ["--bgen", D + "/r.bgen", "--bsize", str(bsizes[0]), "--out", D + "/r_amd"] + os.environ.get("BGEN_E2E_ARGS", "").split(),      # e.g. "--gpus 8"
