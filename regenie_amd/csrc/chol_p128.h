@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
     C128_T(3);
     if (!succ) {
       C128_TFLUSH();
-      if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[18], t_prev - t_start); atomicAdd(&a.dbg[21 + j], t_prev - t_start); }
+      if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[18], t_prev - t_start); atomicAdd(&a.dbg[21 + j], t_prev - t_start); atomicMin(&a.dbg[33 + j], t_start); atomicMax(&a.dbg[45 + j], t_prev); }
       return;
     }
     __threadfence_block();                              // the diagonal block below reads this tile back: same workgroup, same L2 (an agent-scope
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   save_tile(64, 1);
   C128_T(10);
   C128_TFLUSH();
-  if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[18], t_prev - t_start); atomicAdd(&a.dbg[21 + j], t_prev - t_start); }
+  if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[18], t_prev - t_start); atomicAdd(&a.dbg[21 + j], t_prev - t_start); atomicMin(&a.dbg[33 + j], t_start); atomicMax(&a.dbg[45 + j], t_prev); }
   if (bad && !a.flags) atomicMax(a.info, 1);
 }
 
@@ -744,7 +744,10 @@ static void c128_launch_factor(hipStream_t st, double* mats, int64_t mat_stride,
   a.Tp = n64 / 128; a.batch = batch; a.R = R; a.fs = first;
   static const bool dbg = getenv("RG_C128_DBG") && atoi(getenv("RG_C128_DBG")) != 0;
   a.dbg = nullptr;
-  if (dbg && hipMalloc(&a.dbg, 32 * sizeof(unsigned long long)) == hipSuccess) (void)hipMemsetAsync(a.dbg, 0, 32 * sizeof(unsigned long long), st);
+  if (dbg && hipMalloc(&a.dbg, 64 * sizeof(unsigned long long)) == hipSuccess) {
+    (void)hipMemsetAsync(a.dbg, 0, 64 * sizeof(unsigned long long), st);
+    (void)hipMemsetAsync(a.dbg + 32, 0xFF, 12 * sizeof(unsigned long long), st);      // [32 + launch]: earliest workgroup start, [44 + launch]: latest end
+  }
   for (int j = -1; j <= a.Tp - 2; ++j) {
     a.j = j;
     a.nplain = j < 0 ? 0 : std::max(0, a.Tp - j - 2);
@@ -755,7 +758,7 @@ static void c128_launch_factor(hipStream_t st, double* mats, int64_t mat_stride,
     ++nl;
   }
   if (a.dbg) {      // diagnostic: per-phase sums over the workgroups, in microseconds of workgroup time (s_memrealtime ticks at 100 MHz)
-    unsigned long long h[32];
+    unsigned long long h[64];
     (void)hipStreamSynchronize(st);
     (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
     (void)hipFree(a.dbg);
@@ -764,6 +767,13 @@ static void c128_launch_factor(hipStream_t st, double* mats, int64_t mat_stride,
     for (int k = 1; k <= 10; ++k) fprintf(stderr, " %s %.0f", nm[k], h[k] / 100.0);
     fprintf(stderr, " | prologue %.0f, workgroup lifetimes %.0f; per launch j = -1 ..:", h[19] / 100.0, h[18] / 100.0);
     for (int k = 0; k < a.Tp && k < 11; ++k) fprintf(stderr, " %.0f", h[20 + k] / 100.0);
-    fprintf(stderr, " | inside the tile factorizations: 16x16 steps %.0f, barrier after them %.0f, rows below + trailing update %.0f, inverse blocks %.0f\n", h[11] / 100.0, h[14] / 100.0, h[12] / 100.0, h[13] / 100.0);
+    fprintf(stderr, " | inside the tile factorizations: 16x16 steps %.0f, barrier after them %.0f, rows below + trailing update %.0f, inverse blocks %.0f", h[11] / 100.0, h[14] / 100.0, h[12] / 100.0, h[13] / 100.0);
+    // per launch: first start .. last end, and the workgroups in flight on average over that span (512 = every slot of the 256 CUs taken)
+    fprintf(stderr, " | per launch span us (workgroups in flight):");
+    for (int k = 0; k < a.Tp && k < 11; ++k) {
+      const double span = (double)(h[44 + k] - h[32 + k]) / 100.0;
+      fprintf(stderr, " %.0f (%.0f)", span, span > 0 ? h[20 + k] / 100.0 / span : 0.0);
+    }
+    fprintf(stderr, "; first start to last end of the factorization %.0f us\n", (double)(h[44 + a.Tp - 1] - h[32]) / 100.0);
   }
 }
