@@ -373,6 +373,14 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
     for (int k_ = 0; k_ < 16; ++k_) tl[k_] = 0;
     atomicAdd(&a.dbg[succ ? 17 : 16], 1ull);
     atomicAdd(&a.dbg[19], t_prev - t_start);
+#ifndef RG_HOST_EMU
+    // how long a slot of this CU stood empty before this workgroup started: its start against the latest end recorded for the CU
+    // (a.dbg[64 + CU], CU = XCC id : SE : SH : CU of the hardware id registers); gaps above 50 us (launch boundaries) are not counted
+    const unsigned cu = ((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 8) | (((unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xFFu);
+    tl[15] = cu;
+    const unsigned long long le = __hip_atomic_load(&a.dbg[64 + cu], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (le && t_start > le && t_start - le < 5000) { atomicAdd(&a.dbg[56], t_start - le); atomicAdd(&a.dbg[57], 1ull); }
+#endif
   }
 
   v4d acc[8][2];
@@ -507,7 +515,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
     C128_T(3);
     if (!succ) {
       C128_TFLUSH();
-      if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[18], t_prev - t_start); atomicAdd(&a.dbg[21 + j], t_prev - t_start); atomicMin(&a.dbg[33 + j], t_start); atomicMax(&a.dbg[45 + j], t_prev); }
+      if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[18], t_prev - t_start); atomicAdd(&a.dbg[21 + j], t_prev - t_start); atomicMin(&a.dbg[33 + j], t_start); atomicMax(&a.dbg[45 + j], t_prev); atomicMax(&a.dbg[64 + tl[15]], C128_T0()); }
       return;
     }
     __threadfence_block();                              // the diagonal block below reads this tile back: same workgroup, same L2 (an agent-scope
@@ -728,7 +736,7 @@ __global__ __launch_bounds__(256, 2) void k_c128_panel(C128Args a) {
   save_tile(64, 1);
   C128_T(10);
   C128_TFLUSH();
-  if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[18], t_prev - t_start); atomicAdd(&a.dbg[21 + j], t_prev - t_start); atomicMin(&a.dbg[33 + j], t_start); atomicMax(&a.dbg[45 + j], t_prev); }
+  if (a.dbg && threadIdx.x == 0) { atomicAdd(&a.dbg[18], t_prev - t_start); atomicAdd(&a.dbg[21 + j], t_prev - t_start); atomicMin(&a.dbg[33 + j], t_start); atomicMax(&a.dbg[45 + j], t_prev); atomicMax(&a.dbg[64 + tl[15]], C128_T0()); }
   if (bad && !a.flags) atomicMax(a.info, 1);
 }
 
@@ -744,8 +752,8 @@ static void c128_launch_factor(hipStream_t st, double* mats, int64_t mat_stride,
   a.Tp = n64 / 128; a.batch = batch; a.R = R; a.fs = first;
   static const bool dbg = getenv("RG_C128_DBG") && atoi(getenv("RG_C128_DBG")) != 0;
   a.dbg = nullptr;
-  if (dbg && hipMalloc(&a.dbg, 64 * sizeof(unsigned long long)) == hipSuccess) {
-    (void)hipMemsetAsync(a.dbg, 0, 64 * sizeof(unsigned long long), st);
+  if (dbg && hipMalloc(&a.dbg, (64 + 2048) * sizeof(unsigned long long)) == hipSuccess) {
+    (void)hipMemsetAsync(a.dbg, 0, (64 + 2048) * sizeof(unsigned long long), st);
     (void)hipMemsetAsync(a.dbg + 32, 0xFF, 12 * sizeof(unsigned long long), st);      // [32 + launch]: earliest workgroup start, [44 + launch]: latest end
   }
   for (int j = -1; j <= a.Tp - 2; ++j) {
@@ -774,6 +782,7 @@ static void c128_launch_factor(hipStream_t st, double* mats, int64_t mat_stride,
       const double span = (double)(h[44 + k] - h[32 + k]) / 100.0;
       fprintf(stderr, " %.0f (%.0f)", span, span > 0 ? h[20 + k] / 100.0 / span : 0.0);
     }
-    fprintf(stderr, "; first start to last end of the factorization %.0f us\n", (double)(h[44 + a.Tp - 1] - h[32]) / 100.0);
+    fprintf(stderr, "; first start to last end of the factorization %.0f us; a CU's latest workgroup end to the next start on it: %.2f us on average over %llu starts\n",
+            (double)(h[44 + a.Tp - 1] - h[32]) / 100.0, h[57] ? (double)h[56] / 100.0 / (double)h[57] : 0.0, h[57]);
   }
 }

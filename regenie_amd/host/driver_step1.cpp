@@ -87,7 +87,7 @@ struct BedMap {
 // 32 MB pieces of the file into a small ring of page-locked slots (8 x 32 MB: page-locking them costs 50 ms, not the 1.4 s of the 12.6 GB
 // ring of round 5), one thread sends the pieces in file order (DMA from page-locked memory: the PCIe rate, where the runtime's staging of
 // pageable memory gave 36 - 38 GB/s).  At BASELINE configs[2] (62.5 GB) the copy starts 0.3 s earlier than the first batch of the
-// streamed form did and the level-0 thread queues kernels only.  One GPU, a file of at most a quarter of the free device memory whose kept
+// streamed form did and the level-0 thread queues kernels only.  One GPU, a file of at least 4 GB and at most a quarter of the free device memory whose kept
 // variants are one range covering at least 80 % of it; RG_INGEST_STAGE=0 streams the file batch by batch as before, =2 copies from the
 // mapping instead of the slots.  A copy that fails leaves the bytes behind `done` unusable: level 0 takes the rest from the mapping.
 struct BedStage {
@@ -264,7 +264,7 @@ int run(int argc, char** argv) {
       const char* es = getenv("RG_INGEST_STAGE");
       const int64_t kept_bytes = (int64_t)r.snp_chrom.size() * r.bpr;
       if (p.gpus == 1 && !p.force_collectives && bed_map.state == 2 && !bed_map.registered && !(es && atoi(es) == 0) && !early_ctx.empty() &&
-          (int64_t)bed_map.bytes > 3 && 5 * kept_bytes >= 4 * ((int64_t)bed_map.bytes - 3) && !r.snp_offset.empty() &&
+          (int64_t)bed_map.bytes >= ((es && atoi(es) != 0) ? 4 : (4LL << 30)) && 5 * kept_bytes >= 4 * ((int64_t)bed_map.bytes - 3) && !r.snp_offset.empty() &&      // (a file of a few GB is in HBM before the ring's slots are page-locked: configs[1], 1.25 GB, 0.20 s without the stage, 0.24 s with it; RG_INGEST_STAGE=1 forces it)
           r.snp_offset.back() - r.snp_offset.front() + 1 == (int64_t)r.snp_offset.size())      // the kept variants: one range of the file
         bed_stage.start(early_ctx[0], p.bed + ".bed", bed_map.base, (int64_t)bed_map.bytes, es ? atoi(es) : 1,
                         getenv("RG_STAGE_THREADS") ? std::max(1, atoi(getenv("RG_STAGE_THREADS"))) : std::max(2, std::min(6, usable_cpus() / 3)));     // 2 threads fed 24 GB/s, 4 and 8 the 50 GB/s the DMA takes (gpurun_out/r6_ingest)
