@@ -63,6 +63,26 @@ def test_cli_matches_oracle_files(example_dir, tmp_path):
         assert ("MSE = %s<- min value" % orc.cpp_double(mse)) in log
 
 
+@pytest.mark.parametrize("stage", ["1", "2"])
+def test_cli_bed_staged_in_device_memory_equals_streamed(example_dir, tmp_path, stage):
+    """The whole .bed copied to the device up front (BedStage of host/driver_step1.cpp over rg_stage_alloc / rg_stage_copy; the default for
+    files of several GB, forced here: RG_INGEST_STAGE=1 the pread threads + page-locked ring, =2 pageable copies from the mapping) and level
+    0 reading the rows in place must give the files of the batch-by-batch ingest byte for byte."""
+    E = example_dir
+    common = ["--step", "1", "--bed", os.path.join(E, "example_3chr"), "--phenoFile", os.path.join(E, "phenotype.txt"),
+              "--covarFile", os.path.join(E, "covariates.txt"), "--bsize", "100"]
+    outs = {}
+    for name, env in (("streamed", {"RG_INGEST_STAGE": "0"}), ("staged", {"RG_INGEST_STAGE": stage})):
+        r = subprocess.run([BIN] + common + ["--out", str(tmp_path / name)], cwd=str(tmp_path), capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, RG_TEARDOWN="1", **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = r.stdout
+    assert "read from the copy of the file in device memory" in outs["staged"]
+    assert "copied to the GPU from the mapped file" in outs["streamed"]
+    for k in (1, 2):
+        assert open(str(tmp_path / ("staged_%d.loco" % k)), "rb").read() == open(str(tmp_path / ("streamed_%d.loco" % k)), "rb").read()
+
+
 def test_cli_embedded_right_hand_sides_equal_separate_rows(example_dir, tmp_path):
     """Level 0 keeps the right-hand sides of a block's ridge systems in the padding rows of the systems' last tile whenever they fit
     (regenie_amd/csrc/chol.hip, "embedded right-hand sides"); RG_NO_EMBED=1 keeps them in a tile row of their own.  Same predictions to

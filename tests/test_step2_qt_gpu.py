@@ -266,6 +266,40 @@ def test_packed_masked_phenotypes_follow_the_reference_branches(n, C, P, bs, n_s
     assert np.array_equal(again["stats"], got["stats"][5:9], equal_nan=True)
 
 
+@pytest.mark.parametrize("n,C,P,bs,miss_y", [(5003, 5, 3, 64, 0.07), (4097, 12, 7, 40, 0.05), (6001, 3, 40, 33, 0.02), (3001, 17, 6, 20, 0.1), (4000, 4, 5, 30, 0.4)])
+def test_packed_masked_compact_axis_equals_mask_columns(n, C, P, bs, miss_y, monkeypatch):
+    """Round 6: for phenotypes that differ in their missing values the hard-call route takes the sums against the mask columns as
+    (all samples) - (the samples masked for the trait) over a compact sample axis (k_s2_compact_rows / k_s2_count_traits / k_s2_combine_traits)
+    whenever the masked-sample lists hold at most n entries in all; RG_S2_MASK_COLS=1 keeps rounds 4 - 5's C P + P mask columns.  Both against
+    each other and against the oracle: 40 traits need two contraction launches of 32 + 8, 17 covariates two column groups, 40 % missing values in
+    five traits exceed n entries (the library itself falls back on the mask columns: both runs are then the same route)."""
+    X, res, mask, scf, G = _problem(1234 + P, n, C, P, bs, miss_y=miss_y)
+    rng = np.random.default_rng(11)
+    G[rng.random(G.shape) < 0.01] = np.nan
+    G[1, :] = np.nan
+    rows = _pack_bed(G)
+    from regenie_amd.step2 import Step2QT
+    out = {}
+    for name, env in (("compact", None), ("columns", "1")):
+        if env is None:
+            monkeypatch.delenv("RG_S2_MASK_COLS", raising=False)
+        else:
+            monkeypatch.setenv("RG_S2_MASK_COLS", env)
+        with Step2QT(n, C, P) as s2:
+            s2.set_null(X.T, res.T, mask.T, scf)
+            out[name] = s2.score_block_packed(rows)
+            out[name + "_again"] = s2.score_block_packed(rows[3:11])
+    a, b = out["compact"], out["columns"]
+    for k in ("n_obs", "ignored", "n_obs_p", "total_p"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    for k in ("stats", "bhat"):
+        ok = ~np.isnan(b[k])
+        assert np.array_equal(np.isnan(a[k]), np.isnan(b[k])), k
+        assert np.allclose(a[k][ok], b[k][ok], rtol=1e-10, atol=1e-12), (k, np.abs(a[k][ok] - b[k][ok]).max())
+    assert np.array_equal(out["compact_again"]["stats"], a["stats"][3:11], equal_nan=True)
+    _compare(a, s2o.score_qt_block_ref(G, X, res, mask, scf))
+
+
 def test_packed_planes_follow_set_null():
     """A second rg_s2_set_null with other residuals (next chromosome) and then with other masks: the cached digit planes are rebuilt
     for exactly what changed."""

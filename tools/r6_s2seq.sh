@@ -14,6 +14,6 @@ b = i
 while b < len(rows) - 1 and 'k_s2_packed_final' not in rows[b]['Kernel_Name']: b += 1
 t0 = int(rows[a]['Start_Timestamp'])
 for r in rows[a:b + 1]:
-    print('%-28s start %8.1f us  dur %8.1f us' % (r['Kernel_Name'].split('(')[0][:28], (int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
+    print('%-28s start %8.1f us  dur %8.1f us' % ((lambda nm: (nm[nm.find('k_'):] if 'k_' in nm else nm).split('(')[0].split('<')[0][:28])(r['Kernel_Name']), (int(r['Start_Timestamp']) - t0) / 1e3, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
 PY
 rm -rf gpurun_out/s2seq_raw
