@@ -824,7 +824,8 @@ def from_disk_leg(args, torch, packed, blocks, my_blocks, Yraw, cov, M, N, P, gp
         # 100 GB allocate in 0.4 ms on a clean device and in 3.3 - 6.9 s right after 100 GB were freed): a driver that starts right behind
         # this process' engine (or behind its own previous run: 170 GB at configs[2]) waits for that, which no run on an idle device does.
         # The large configuration therefore lets the device settle before every run after the first; the first one is reported as it is.
-        settle_s = 15.0 if nbytes > (4 << 30) else 0.0
+        # (the small configuration too, since round 6: a driver run started right behind the previous one waited 0.3 - 0.4 s for the few GB that one had released)
+        settle_s = 15.0 if nbytes > (4 << 30) else 5.0
         for k in range(nruns):                  # first run warms the page cache and the driver's code objects
             if k > 0 and settle_s:
                 time.sleep(settle_s)
