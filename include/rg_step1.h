@@ -204,10 +204,13 @@ int rg_ingest_fence(rg_ctx* ctx);
  *   rg_stage_copy  : host -> device copy of `bytes` (pageable or page-locked source) on a stream of its own, from any ONE thread at a
  *                    time; returns when the bytes have arrived.  Not ordered with the context's streams: hand rows to rg_l0_blocks
  *                    only after the copy that covers them has returned.
- *   rg_stage_free  : frees the buffer (after rg_sync). */
+ *   rg_stage_free  : frees the buffer (after rg_sync; or when the caller gives the stage up: rg_stage_fits). */
 void* rg_stage_alloc(rg_ctx* ctx, int64_t bytes, double max_frac_of_free);
 int rg_stage_copy(rg_ctx* ctx, void* dev_dst, const void* host_src, int64_t bytes);
 void rg_stage_free(rg_ctx* ctx, void* dev_ptr);
+/* 1 when `bytes` more of device memory are free on the context's device right now (the driver asks once the phenotypes are parsed whether W,
+ * the workspaces and level 1 still fit beside the staged file, and gives the stage up if not), else 0. */
+int rg_stage_fits(rg_ctx* ctx, int64_t bytes);
 
 /* ---- phenotype-sharded level 1 (optional) ------------------------------------------------------------
  * With P >= world phenotypes the ranks can exchange predictor slabs by phenotype instead of all-gathering W:

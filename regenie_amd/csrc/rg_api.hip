@@ -715,6 +715,13 @@ int rg_stage_copy(rg_ctx* ctx, void* dev_dst, const void* host_src, int64_t byte
   }
   return RG_OK;
 }
+int rg_stage_fits(rg_ctx* ctx, int64_t bytes) {
+  if (!ctx) return 0;
+  hipSetDevice(ctx->device);
+  size_t fr = 0, tot = 0;
+  if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return bytes <= (int64_t)fr ? 1 : 0;
+}
 void rg_stage_free(rg_ctx* ctx, void* dev_ptr) {
   if (!ctx || !dev_ptr) return;
   hipSetDevice(ctx->device);

@@ -61,7 +61,7 @@ EXPORTS = ["rg_create", "rg_destroy", "rg_last_error", "rg_set_problem", "rg_set
            "rg_k_chol_solve", "rg_k_dgemm_nt", "rg_k_mfma_peak",
            # one node, several GPUs: level-0 hand-off over RCCL / peer copies; streamed ingest helpers (used by the C++ driver)
            "rg_group_create", "rg_group_destroy", "rg_l0_finish", "rg_group_prepare", "rg_group_abort", "rg_l0_batch_blocks", "rg_host_alloc", "rg_host_free", "rg_host_register", "rg_host_unregister",
-           "rg_ingest_fence", "rg_stage_alloc", "rg_stage_copy", "rg_stage_free",
+           "rg_ingest_fence", "rg_stage_alloc", "rg_stage_copy", "rg_stage_free", "rg_stage_fits",
            # include/rg_pgen.h (host-side .pgen hardcall input; wrapped by regenie_amd/pgen.py)
            "rg_pgen_open", "rg_pgen_close", "rg_pgen_last_error", "rg_pgen_info", "rg_pgen_read_bed_rows",
            "rg_pgen_read_hardcalls", "rg_pgen_set_threads", "rg_pgen_read_dosages", "rg_pgen_read_dosage_rows",
@@ -135,6 +135,7 @@ def load_library() -> C.CDLL:
     lib.rg_stage_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     lib.rg_stage_free.argtypes = [C.c_void_p, C.c_void_p]
     lib.rg_stage_free.restype = None
+    lib.rg_stage_fits.argtypes = [C.c_void_p, C.c_int64]
     lib.rg_enable_timing.argtypes = [C.c_void_p, C.c_int]
     lib.rg_get_timing.argtypes = [C.c_void_p, C.POINTER(RgTiming)]
     lib.rg_k_gram_i8.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64,

@@ -164,6 +164,17 @@ struct BedStage {
       cv.notify_all();
     });
   }
+  // the stage is given up (W, the workspaces and level 1 would not fit beside it): the copy stops, the buffer goes back, level 0 streams the file
+  void cancel() {
+    if (state == 0) return;
+    stop = true;
+    cv.notify_all();
+    if (th.joinable()) th.join();
+    for (auto& f : fillers) if (f.joinable()) f.join();
+    fillers.clear();
+    { std::lock_guard<std::mutex> lk(mu); state = -1; done = 0; }      // (nothing of the buffer counts as arrived any more)
+    if (dev) { rg_stage_free(ctx, dev); dev = nullptr; }
+  }
   // true once bytes [0, upto) are in device memory; false when the copy failed (or was never started)
   bool wait(int64_t upto) {
     if (state == 0) return false;
@@ -390,6 +401,15 @@ int run(int argc, char** argv) {
     // library's default of 64 GB
     const int64_t bed_bytes = (int64_t)(B / G + 1) * ingest_blk_bytes;
     check(ctxs[g], rg_set_l0_workspace(ctxs[g], 0, 0, std::max<int64_t>(6000000000LL, std::min<int64_t>(64000000000LL, 8 * bed_bytes))));
+    if (g == 0 && bed_stage.state != 0) {
+      // W ([B R0][P][Np] doubles), the level-0 workspaces and an allowance for level 1 must still fit beside the staged file -- known only now
+      // that the phenotypes are parsed; if they do not, the stage is given up and the file streams batch by batch
+      const double need = (double)B * R0 * P * (double)(N + 4096) * 8.0 + (double)std::max<int64_t>(6000000000LL, std::min<int64_t>(64000000000LL, 8 * bed_bytes)) + 24e9;
+      if (!rg_stage_fits(ctxs[g], (int64_t)need) || getenv("RG_STAGE_FORCE_CANCEL")) {      // (the switch: for the test of this path)
+        bed_stage.cancel();
+        sout << "   -the genotype file is not kept in device memory (" << (int64_t)(need / 1e9) << " GB of predictors and workspaces take the room)\n";
+      }
+    }
     const auto tsp = std::chrono::steady_clock::now();
     check(ctxs[g], rg_set_problem(ctxs[g], &pr));
     if (getenv("RG_TIMING"))

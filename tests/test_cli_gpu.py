@@ -63,7 +63,7 @@ def test_cli_matches_oracle_files(example_dir, tmp_path):
         assert ("MSE = %s<- min value" % orc.cpp_double(mse)) in log
 
 
-@pytest.mark.parametrize("stage", ["1", "2"])
+@pytest.mark.parametrize("stage", ["1", "2", "given_up"])
 def test_cli_bed_staged_in_device_memory_equals_streamed(example_dir, tmp_path, stage):
     """The whole .bed copied to the device up front (BedStage of host/driver_step1.cpp over rg_stage_alloc / rg_stage_copy; the default for
     files of several GB, forced here: RG_INGEST_STAGE=1 the pread threads + page-locked ring, =2 pageable copies from the mapping) and level
@@ -72,12 +72,17 @@ def test_cli_bed_staged_in_device_memory_equals_streamed(example_dir, tmp_path, 
     common = ["--step", "1", "--bed", os.path.join(E, "example_3chr"), "--phenoFile", os.path.join(E, "phenotype.txt"),
               "--covarFile", os.path.join(E, "covariates.txt"), "--bsize", "100"]
     outs = {}
-    for name, env in (("streamed", {"RG_INGEST_STAGE": "0"}), ("staged", {"RG_INGEST_STAGE": stage})):
+    # "given_up": the stage is started and then cancelled before level 0 (what the driver does when W and the workspaces would not fit beside it)
+    staged_env = {"RG_INGEST_STAGE": "1", "RG_STAGE_FORCE_CANCEL": "1"} if stage == "given_up" else {"RG_INGEST_STAGE": stage}
+    for name, env in (("streamed", {"RG_INGEST_STAGE": "0"}), ("staged", staged_env)):
         r = subprocess.run([BIN] + common + ["--out", str(tmp_path / name)], cwd=str(tmp_path), capture_output=True, text=True, timeout=300,
                            env=dict(os.environ, RG_TEARDOWN="1", **env))
         assert r.returncode == 0, r.stdout + r.stderr
         outs[name] = r.stdout
-    assert "read from the copy of the file in device memory" in outs["staged"]
+    if stage == "given_up":
+        assert "is not kept in device memory" in outs["staged"] and "copied to the GPU from the mapped file" in outs["staged"]
+    else:
+        assert "read from the copy of the file in device memory" in outs["staged"]
     assert "copied to the GPU from the mapped file" in outs["streamed"]
     for k in (1, 2):
         assert open(str(tmp_path / ("staged_%d.loco" % k)), "rb").read() == open(str(tmp_path / ("streamed_%d.loco" % k)), "rb").read()
