@@ -54,6 +54,9 @@ inline int __double2hiint(double x) { int64_t u; memcpy(&u, &x, 8); return (int)
 inline double __hiloint2double(int hi, int lo) { const uint64_t u = ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo; double d; memcpy(&d, &u, 8); return d; }
 inline double __builtin_amdgcn_rsq(double x) { return 1.0 / std::sqrt(x); }
 inline int atomicMax(int32_t* p, int v) { const int o = *p; if (v > o) *p = v; return o; }
+// (the RG_C128_DBG diagnostic's per-launch spans; never executed here -- a.dbg is null on the host)
+inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; if (v < o) *p = v; return o; }
+inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) { const unsigned long long o = *p; if (v > o) *p = v; return o; }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 #define C128_LDS_ADDR(p) (emu::lds_base = (uint8_t*)(p), 0u)
