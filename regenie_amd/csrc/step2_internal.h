@@ -75,6 +75,8 @@ struct rg_s2_ctx {
 };
 
 
+int rg_xy_i8_launch_groups(int ncols);      // xy_i8.hip: groups of workgroups rg_launch_xy_i8_sums / _both launch for that many columns (1 when two groups go in one pass)
+
 static inline int rg_s2_fail(rg_s2_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
   return code;

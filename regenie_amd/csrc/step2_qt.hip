@@ -550,6 +550,8 @@ __global__ __launch_bounds__(S2_CT) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   }
 }
 
+// (Counting inside k_s2_compact_rows, on the words it holds in registers, with one 64-bit LDS atomic per row and word: 0.79 ms for that kernel
+// against 0.49 + 0.14 ms for the two -- the lanes of a wave add to the same (row, phenotype) counter.)
 // call counts over a phenotype's range of the compact rows: n1, n2, nmiss [row][p][4] (the column of ones of the compact contraction, both sets,
 // and the squares, without a contraction: sum g = n1 + 2 n2, sum g^2 = n1 + 4 n2, missing = nmiss; padding = code 11 counts nowhere).
 // grid (bs, P), 256 threads; w0 [P + 1] = first 32-bit word of a phenotype's range.
@@ -1365,7 +1367,7 @@ int rg_s2_qt_block_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   // enough workgroups to fill the 256 CUs (tiles x segments x column groups >= 768), as few segments as that allows: every segment
   // costs a 64 KB tile of partial sums per workgroup
   SegLayout seg, segB;
-  const int nseg = pick_segments(Np, n128 / 128, ngrp, seg), nsegB = pick_segments(Np, n128 / 128, std::max(1, ngrpB), segB);
+  const int nseg = pick_segments(Np, n128 / 128, rg_xy_i8_launch_groups(Cvt), seg), nsegB = pick_segments(Np, n128 / 128, std::max(1, ngrpB), segB);
   enum { Q_PK, Q_CNT, Q_S, Q_A, Q_VAR, Q_STAT, Q_PKC, Q_L };
   const size_t s_grp = (size_t)2 * nseg * n128 * 128, s_grpB = (size_t)2 * nsegB * n128 * 128, s_grpC = (size_t)2 * nsegc * n128 * 128;
   if ((rc = ensure_p(ctx, Q_PK, (size_t)bs * ldp))) return rc;
@@ -1618,7 +1620,7 @@ int rg_s2_contract_packed(rg_s2_ctx* ctx, const uint8_t* rows, int64_t ld, int32
   const int64_t Np = (n + 128 * RG_MAX_SEG - 1) / (128 * RG_MAX_SEG) * (128 * RG_MAX_SEG), ldp = Np / 4;
   const int n128 = (int)((bs + 127) / 128 * 128);
   SegLayout seg, segB;
-  const int nseg = pick_segments(Np, n128 / 128, ngrp, seg), nsegB = pick_segments(Np, n128 / 128, std::max(1, ngrpB), segB);
+  const int nseg = pick_segments(Np, n128 / 128, rg_xy_i8_launch_groups(ncol), seg), nsegB = pick_segments(Np, n128 / 128, std::max(1, ngrpB), segB);
   enum { Q_PK, Q_CNT, Q_S, Q_A };
   const size_t s_grp = (size_t)2 * nseg * n128 * 128, s_grpB = (size_t)2 * nsegB * n128 * 128;
   int rc;

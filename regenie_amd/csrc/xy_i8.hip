@@ -15,6 +15,7 @@
 // idiom of gram_i8.hip).  At 500,000 samples and 13 columns this is 1.3*10^11 integer multiply-adds per block against the
 // 29 ms per 32 blocks of the fp64 VALU kernel.
 #include "rg_internal.h"
+#include <cstdlib>
 
 #define XT 128
 #define X_PITCH 80
@@ -250,6 +251,258 @@ __global__ __launch_bounds__(256, 2) void k_xy_i8_both(const uint8_t* __restrict
   }
 }
 
+// ---- TWO column groups in one pass when the second is narrow (round 6) ---------------------------------------------------------------------
+// BASELINE configs[4]'s Step 2 contracts 10 covariates + 10 residual columns = 160 (column, digit) pairs: one full group of 128 and a second
+// group of 32.  As two passes the second one expanded every packed row again for a quarter of the products (its workgroups are staging- and
+// barrier-bound).  Here the workgroup of group 0 also stages the E <= 2 extra 32-pair blocks of group 1 (sB rows 128 .. 128 + 32 E - 1) and
+// every wave takes a share of their products on the A fragments it holds anyway.  S layout unchanged ([grp][set][seg][row][col]: the
+// extra results land in group 1's columns 0 .. 32 E - 1).
+// both sets: grid (n128 / 128, nseg); wave (wr, wc) takes set wc of the extra blocks for its own 64 rows.
+template <int E>
+__global__ __launch_bounds__(256, 2) void k_xy_i8_both_x(const uint8_t* __restrict__ pk, int64_t pk_ld, const int32_t* __restrict__ d_bs, int n128, SegLayout seg,
+                                                         const int8_t* __restrict__ vd, int64_t Np, int ncol1 /* pairs of group 1 */, unsigned lut0,
+                                                         int32_t* __restrict__ S) {
+  constexpr int PITCH = 144;
+  __shared__ __attribute__((aligned(16))) uint8_t sA[2][XT * PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t sB[(XT + 32 * E) * PITCH];
+  const int f = blockIdx.y, tr = blockIdx.x;
+  const int bs = d_bs[0];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int64_t pos0 = seg.pos_start[f], kbytes = seg.plen[f] / 4;
+  v16i acc[2][2][2], accx[E][2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][i][j][r] = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accx[e][i][r] = 0;
+  const int srow = tid >> 1, half = tid & 1;
+  const int arow = tr * XT + srow;
+  const bool validA = arow < bs;
+  const bool validX = tid < 64 * E && srow < ncol1;                       // threads 0 .. 64 E - 1 also copy a row of group 1
+  const uint8_t* ga = pk + (int64_t)(validA ? arow : 0) * pk_ld + pos0 / 4 + half * 16;
+  const int8_t* gb = vd + (int64_t)srow * Np + pos0 + half * 64;
+  const int8_t* gx = vd + (int64_t)16 * X_NPIECE * Np + (int64_t)(validX ? srow : 0) * Np + pos0 + half * 64;
+  uint8_t* lrowA0 = sA[0] + srow * PITCH + half * 64;
+  uint8_t* lrowA1 = sA[1] + srow * PITCH + half * 64;
+  uint8_t* lrowB = sB + srow * PITCH + half * 64;
+  uint8_t* lrowX = sB + (XT + srow) * PITCH + half * 64;
+  uint4 w = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);   // code 11 -> 0 under both LUTs
+  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0, x0 = v0, x1 = v0, x2 = v0, x3 = v0;
+  if (kbytes > 0) {
+    if (validA) w = *reinterpret_cast<const uint4*>(ga);
+    { const uint4* src = reinterpret_cast<const uint4*>(gb); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
+    if (validX) { const uint4* src = reinterpret_cast<const uint4*>(gx); x0 = src[0]; x1 = src[1]; x2 = src[2]; x3 = src[3]; }
+  }
+  for (int64_t kb = 0; kb < kbytes; kb += 32) {
+    {
+      const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint4 o, m;
+        o.x = x_expand4(ws[d] & 0xFFu, lut0);          m.x = x_expand4(ws[d] & 0xFFu, X_LUT_MISS);
+        o.y = x_expand4((ws[d] >> 8) & 0xFFu, lut0);   m.y = x_expand4((ws[d] >> 8) & 0xFFu, X_LUT_MISS);
+        o.z = x_expand4((ws[d] >> 16) & 0xFFu, lut0);  m.z = x_expand4((ws[d] >> 16) & 0xFFu, X_LUT_MISS);
+        o.w = x_expand4(ws[d] >> 24, lut0);            m.w = x_expand4(ws[d] >> 24, X_LUT_MISS);
+        *reinterpret_cast<uint4*>(lrowA0 + d * 16) = o;
+        *reinterpret_cast<uint4*>(lrowA1 + d * 16) = m;
+      }
+      *reinterpret_cast<uint4*>(lrowB) = v0;
+      *reinterpret_cast<uint4*>(lrowB + 16) = v1;
+      *reinterpret_cast<uint4*>(lrowB + 32) = v2;
+      *reinterpret_cast<uint4*>(lrowB + 48) = v3;
+      if (tid < 64 * E) {
+        *reinterpret_cast<uint4*>(lrowX) = x0;
+        *reinterpret_cast<uint4*>(lrowX + 16) = x1;
+        *reinterpret_cast<uint4*>(lrowX + 32) = x2;
+        *reinterpret_cast<uint4*>(lrowX + 48) = x3;
+      }
+    }
+    __syncthreads();
+    if (kb + 32 < kbytes) {
+      if (validA) w = *reinterpret_cast<const uint4*>(ga + kb + 32);
+      { const uint4* src = reinterpret_cast<const uint4*>(gb + (kb + 32) * 4); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
+      if (validX) { const uint4* src = reinterpret_cast<const uint4*>(gx + (kb + 32) * 4); x0 = src[0]; x1 = src[1]; x2 = src[2]; x3 = src[3]; }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v4i bf[2], bx[E];
+      const int koff = ks * 32 + (lane >> 5) * 16;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sB + (wc * 64 + j * 32 + (lane & 31)) * PITCH + koff);
+#pragma unroll
+      for (int e = 0; e < E; ++e) bx[e] = *reinterpret_cast<const v4i*>(sB + (XT + e * 32 + (lane & 31)) * PITCH + koff);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        v4i af[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sA[q] + (wr * 64 + i * 32 + (lane & 31)) * PITCH + koff);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) acc[q][i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[q][i][j], 0, 0, 0);
+        if (q == wc) {
+#pragma unroll
+          for (int e = 0; e < E; ++e)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) accx[e][i] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bx[e], accx[e][i], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    int32_t* Sf = S + ((((int64_t)0 * 2 + q) * seg.nseg + f) * n128) * (int64_t)XT;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = tr * XT + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int col = wc * 64 + j * 32 + (lane & 31);
+          Sf[(int64_t)row * XT + col] = acc[q][i][j][r];
+        }
+  }
+  {
+    int32_t* Sx = S + ((((int64_t)1 * 2 + wc) * seg.nseg + f) * n128) * (int64_t)XT;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = tr * XT + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          Sx[(int64_t)row * XT + e * 32 + (lane & 31)] = accx[e][i][r];
+        }
+  }
+}
+
+// one set per workgroup (grid (n128 / 128, nseg, 2), set = blockIdx.z; set 1 skipped when *nmiss == 0): wave (wr, wc) takes the extra blocks'
+// rows of its row block 2 wr + wc (its own A fragment af[wc]).
+template <int E>
+__global__ __launch_bounds__(256, 3) void k_xy_i8_sums_x(const uint8_t* __restrict__ pk, int64_t pk_ld, const int32_t* __restrict__ d_bs,
+                                                         const int32_t* __restrict__ nmiss, int n128, SegLayout seg, const int8_t* __restrict__ vd, int64_t Np,
+                                                         int ncol1 /* pairs of group 1 */, unsigned lut0, int32_t* __restrict__ S) {
+  constexpr int PITCH = 144;
+  __shared__ __attribute__((aligned(16))) uint8_t sA[XT * PITCH];
+  __shared__ __attribute__((aligned(16))) uint8_t sB[(XT + 32 * E) * PITCH];
+  const int set = blockIdx.z, f = blockIdx.y, tr = blockIdx.x;
+  if (set == 1 && nmiss[0] == 0) return;
+  const int bs = d_bs[0];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned lut = set ? X_LUT_MISS : lut0;
+  const int64_t pos0 = seg.pos_start[f], kbytes = seg.plen[f] / 4;
+  v16i acc[2][2], accx[E];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accx[e][r] = 0;
+  const int srow = tid >> 1, half = tid & 1;
+  const int arow = tr * XT + srow;
+  const bool validA = arow < bs;
+  const bool validX = tid < 64 * E && srow < ncol1;
+  const uint8_t* ga = pk + (int64_t)(validA ? arow : 0) * pk_ld + pos0 / 4 + half * 16;
+  const int8_t* gb = vd + (int64_t)srow * Np + pos0 + half * 64;
+  const int8_t* gx = vd + (int64_t)16 * X_NPIECE * Np + (int64_t)(validX ? srow : 0) * Np + pos0 + half * 64;
+  uint8_t* lrowA = sA + srow * PITCH + half * 64;
+  uint8_t* lrowB = sB + srow * PITCH + half * 64;
+  uint8_t* lrowX = sB + (XT + srow) * PITCH + half * 64;
+  uint4 w = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+  uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, v2 = v0, v3 = v0, x0 = v0, x1 = v0, x2 = v0, x3 = v0;
+  if (kbytes > 0) {
+    if (validA) w = *reinterpret_cast<const uint4*>(ga);
+    { const uint4* src = reinterpret_cast<const uint4*>(gb); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
+    if (validX) { const uint4* src = reinterpret_cast<const uint4*>(gx); x0 = src[0]; x1 = src[1]; x2 = src[2]; x3 = src[3]; }
+  }
+  for (int64_t kb = 0; kb < kbytes; kb += 32) {
+    {
+      const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint4 o;
+        o.x = x_expand4(ws[d] & 0xFFu, lut);
+        o.y = x_expand4((ws[d] >> 8) & 0xFFu, lut);
+        o.z = x_expand4((ws[d] >> 16) & 0xFFu, lut);
+        o.w = x_expand4(ws[d] >> 24, lut);
+        *reinterpret_cast<uint4*>(lrowA + d * 16) = o;
+      }
+      *reinterpret_cast<uint4*>(lrowB) = v0;
+      *reinterpret_cast<uint4*>(lrowB + 16) = v1;
+      *reinterpret_cast<uint4*>(lrowB + 32) = v2;
+      *reinterpret_cast<uint4*>(lrowB + 48) = v3;
+      if (tid < 64 * E) {
+        *reinterpret_cast<uint4*>(lrowX) = x0;
+        *reinterpret_cast<uint4*>(lrowX + 16) = x1;
+        *reinterpret_cast<uint4*>(lrowX + 32) = x2;
+        *reinterpret_cast<uint4*>(lrowX + 48) = x3;
+      }
+    }
+    __syncthreads();
+    if (kb + 32 < kbytes) {
+      if (validA) w = *reinterpret_cast<const uint4*>(ga + kb + 32);
+      { const uint4* src = reinterpret_cast<const uint4*>(gb + (kb + 32) * 4); v0 = src[0]; v1 = src[1]; v2 = src[2]; v3 = src[3]; }
+      if (validX) { const uint4* src = reinterpret_cast<const uint4*>(gx + (kb + 32) * 4); x0 = src[0]; x1 = src[1]; x2 = src[2]; x3 = src[3]; }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      v4i af[2], bf[2];
+      const int koff = ks * 32 + (lane >> 5) * 16;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const v4i*>(sA + (wr * 64 + i * 32 + (lane & 31)) * PITCH + koff);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const v4i*>(sB + (wc * 64 + j * 32 + (lane & 31)) * PITCH + koff);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bf[j], acc[i][j], 0, 0, 0);
+      const v4i ax = wc ? af[1] : af[0];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const v4i bx = *reinterpret_cast<const v4i*>(sB + (XT + e * 32 + (lane & 31)) * PITCH + koff);
+        accx[e] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ax, bx, accx[e], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  int32_t* Sf = S + ((((int64_t)0 * 2 + set) * seg.nseg + f) * n128) * (int64_t)XT;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tr * XT + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = wc * 64 + j * 32 + (lane & 31);
+        Sf[(int64_t)row * XT + col] = acc[i][j][r];
+      }
+  int32_t* Sx = S + ((((int64_t)1 * 2 + set) * seg.nseg + f) * n128) * (int64_t)XT;
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = tr * XT + wr * 64 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      Sx[(int64_t)row * XT + e * 32 + (lane & 31)] = accx[e][r];
+    }
+}
+
 // ---- the same contraction when the row operand already is int8 (digit planes of integer dosages, step2_qt.hip): A rows are copied like
 // the digit rows.  aplanes [nset][rows][Np]; S[grp][set][seg][row][col]; grid (n128 / 128, nseg, ngrp * nset) --------------------------
 __global__ __launch_bounds__(256, 4) void k_xy_i8_planes(const int8_t* __restrict__ aplanes, int64_t a_set_stride, int nset, const int32_t* __restrict__ d_bs,
@@ -350,9 +603,21 @@ void rg_launch_v_split(hipStream_t st, const double* V, int64_t Np, int Cv, int8
 // in one launch (the group takes the kernel's block index: its planes start at vd + grp * 16 * 8 * Np; the last group's missing columns
 // are neither loaded nor multiplied): S32 [ngrp][2][nseg][n128][128]; lut0 = what set 0 contracts (the allele count, or its square); set 1 is the missing
 // indicator, skipped when *nmiss == 0
+// Two column groups whose second holds at most 32 (column, digit) pairs -- 17 to 20 columns -- go in ONE pass (k_xy_i8_*_x): the caller sizes its segments for that
+// many groups of workgroups (RG_XY_NO_FUSE=1: always one pass per group).
+int rg_xy_i8_launch_groups(int ncols) {
+  static const bool no_fuse = getenv("RG_XY_NO_FUSE") && atoi(getenv("RG_XY_NO_FUSE")) != 0;
+  const int ngrp = (ncols + 15) / 16;
+  return (!no_fuse && ngrp == 2 && (ncols - 16) * X_NPIECE <= 32) ? 1 : ngrp;      // (E = 2, up to 24 columns: the both-sets kernel spills at 256 registers)
+}
 void rg_launch_xy_i8_sums(hipStream_t st, const uint8_t* pk, int64_t pk_ld, const int32_t* d_bs, const int32_t* nmiss, int ncols, int n128,
                           const SegLayout& seg, const int8_t* vd, int64_t Np, unsigned lut0, int32_t* S32) {
   const int ngrp = (ncols + 15) / 16;
+  if (ngrp == 2 && rg_xy_i8_launch_groups(ncols) == 1) {
+    const int n1 = (ncols - 16) * X_NPIECE;
+    hipLaunchKernelGGL(k_xy_i8_sums_x<1>, dim3(n128 / XT, seg.nseg, 2), dim3(256), 0, st, pk, pk_ld, d_bs, nmiss, n128, seg, vd, Np, n1, lut0, S32);
+    return;
+  }
   hipLaunchKernelGGL(k_xy_i8, dim3(n128 / XT, seg.nseg, ngrp * 2), dim3(256), 0, st, pk, pk_ld, (int64_t)0, d_bs, nmiss, n128, seg, vd,
                      (int64_t)16 * X_NPIECE * Np, 1, Np, 16 * X_NPIECE, (ncols - (ngrp - 1) * 16) * X_NPIECE, lut0, S32);
 }
@@ -361,6 +626,11 @@ void rg_launch_xy_i8_sums(hipStream_t st, const uint8_t* pk, int64_t pk_ld, cons
 void rg_launch_xy_i8_both(hipStream_t st, const uint8_t* pk, int64_t pk_ld, const int32_t* d_bs, int ncols, int n128, const SegLayout& seg,
                           const int8_t* vd, int64_t Np, unsigned lut0, int32_t* S32) {
   const int ngrp = (ncols + 15) / 16;
+  if (ngrp == 2 && rg_xy_i8_launch_groups(ncols) == 1) {
+    const int n1 = (ncols - 16) * X_NPIECE;
+    hipLaunchKernelGGL(k_xy_i8_both_x<1>, dim3(n128 / XT, seg.nseg, 1), dim3(256), 0, st, pk, pk_ld, d_bs, n128, seg, vd, Np, n1, lut0, S32);
+    return;
+  }
   hipLaunchKernelGGL(k_xy_i8_both, dim3(n128 / XT, seg.nseg, ngrp), dim3(256), 0, st, pk, pk_ld, d_bs, n128, seg, vd, Np,
                      (ncols - (ngrp - 1) * 16) * X_NPIECE, lut0, S32);
 }
