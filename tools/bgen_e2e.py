@@ -123,7 +123,7 @@ def run(N=500000, M=100000, MREF=2000, P=10, C=10, bsizes=(400, 1000), ref_threa
                            env=dict(os.environ, RG_TIMING="1", **env))
         dt = time.time() - t0
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-        marks = [ln.strip() for ln in (r.stdout + r.stderr).split("\n") if "Elapsed" in ln or "since start" in ln or "[timing] step 2" in ln]
+        marks = [ln.strip() for ln in (r.stdout + r.stderr).split("\n") if "Elapsed" in ln or "since start" in ln or "[timing] step 2" in ln or "[timing] chromosome" in ln]
         chr_ms = [int(x) for x in re.findall(r"reading loco predictions for the chromosome\.\.\.done \((\d+)ms\)", r.stdout)]
         blk_ms = [int(x) for x in re.findall(r"block \[\d+/\d+\] : done \((\d+)ms\)", r.stdout)]
         run = {"name": name, "bsize": bsz, "wall_s": round(dt, 2), "variants_per_s": round(M / dt, 1), "variant_sample_pheno_per_s": M * N * P / dt}
